@@ -1,0 +1,173 @@
+/* sslam_frontend.h — C ABI of the MI355X-native point+line feature front-end.
+ *
+ * This is the drop-in boundary beneath the reference's C++ call surface
+ * (Structure-SLAM-PointLine).  Every entry point names the reference interface it
+ * replaces (paths relative to the reference tree).  Plain pointers and sizes only;
+ * no C++/torch/HIP types in any signature (streams travel as void*).
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = ok, <0 = error (sslam_status_str()).
+ *     Nothing throws across the boundary.
+ *   - "host" entry points take host pointers and are synchronous (H2D, kernels, D2H);
+ *     "_dev" entry points take DEVICE pointers, enqueue on the given HIP stream
+ *     (void* = hipStream_t, NULL = the context's own stream) and return without
+ *     synchronising.
+ *   - The caller owns every output buffer (reference: _keypoints/_descriptors are
+ *     caller containers, src/ORBextractor.cc:1064-1073).
+ *   - The library fails loudly (SSLAM_ERR_NO_DEVICE) when no HIP device is usable:
+ *     there is no CPU fallback.
+ */
+#ifndef SSLAM_FRONTEND_H
+#define SSLAM_FRONTEND_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSLAM_OK 0
+#define SSLAM_ERR_INVALID (-1)     /* bad argument */
+#define SSLAM_ERR_NO_DEVICE (-2)   /* no usable HIP device / HIP runtime error */
+#define SSLAM_ERR_CAPACITY (-3)    /* caller buffer too small */
+#define SSLAM_ERR_HIP (-4)         /* a HIP call failed; see sslam_last_error() */
+#define SSLAM_ERR_UNSUPPORTED (-5)
+
+/* cv::KeyPoint, 28 bytes (opencv2/core/types.hpp): pt.x, pt.y, size, angle,
+ * response, octave, class_id.  Layout consumed verbatim by include/Frame.h:155-160. */
+typedef struct sslam_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} sslam_keypoint;
+
+/* cv::line_descriptor::KeyLine, 68 bytes (opencv2/line_descriptor/descriptor.hpp):
+ * consumed by include/Frame.h:183-189. */
+typedef struct sslam_keyline {
+    float angle;
+    int32_t class_id, octave;
+    float pt_x, pt_y, response, size;
+    float startPointX, startPointY, endPointX, endPointY;
+    float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+    float lineLength;
+    int32_t numOfPixels;
+} sslam_keyline;
+
+typedef struct sslam_ctx sslam_ctx;     /* device context: HIP device, stream, scratch */
+typedef struct sslam_orb sslam_orb;     /* = StructureSLAM::ORBextractor state */
+typedef struct sslam_lines sslam_lines; /* = LSDDetector + BinaryDescriptor state */
+
+const char* sslam_status_str(int status);
+const char* sslam_last_error(void);      /* thread-local text of the last failure */
+int sslam_abi_version(void);
+
+/* ---- context ------------------------------------------------------------- */
+int sslam_ctx_create(int device, sslam_ctx** out);
+int sslam_ctx_destroy(sslam_ctx* ctx);
+int sslam_ctx_synchronize(sslam_ctx* ctx);
+void* sslam_ctx_stream(sslam_ctx* ctx);  /* hipStream_t of the context */
+
+/* ---- ORB  (replaces StructureSLAM::ORBextractor) --------------------------- */
+/* ORBextractor::ORBextractor(int nfeatures,float scaleFactor,int nlevels,int iniThFAST,
+ * int minThFAST), src/ORBextractor.cc:410-470. */
+int sslam_orb_create(sslam_ctx* ctx, int nfeatures, float scaleFactor, int nlevels,
+                     int iniThFAST, int minThFAST, sslam_orb** out);
+int sslam_orb_destroy(sslam_orb* orb);
+
+/* GetLevels/GetScaleFactors/GetInverseScaleFactors/GetScaleSigmaSquares/
+ * GetInverseScaleSigmaSquares, include/ORBextractor.h:63-83.  Each array has
+ * nlevels entries; NULL pointers are skipped. */
+int sslam_orb_get_scales(const sslam_orb* orb, float* scale, float* inv_scale,
+                         float* sigma2, float* inv_sigma2, int32_t* features_per_level);
+
+/* Upper bound on keypoints one frame can return (nfeatures + per-level overshoot,
+ * SURVEY.md D.2 step 5); size kp/desc buffers with it. */
+int sslam_orb_max_keypoints(const sslam_orb* orb);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors),
+ * src/ORBextractor.cc:1043-1105 as called from Frame::ExtractORB (src/Frame.cc:155-161).
+ * gray: host CV_8UC1, stride in bytes.  kp_out[cap], desc_out[cap*32] host.
+ * Empty image (w==0||h==0) -> *n_out = 0, outputs untouched (:1046-1047). */
+int sslam_orb_extract(sslam_orb* orb, const uint8_t* gray, int w, int h, size_t stride,
+                      sslam_keypoint* kp_out, uint8_t* desc_out, int cap, int* n_out);
+
+/* Batch-of-frames mode (north_star): nframes independent images of identical size
+ * resident in HBM.  d_images + i*image_stride is frame i (row pitch `pitch`).
+ * d_kp[nframes*cap], d_desc[nframes*cap*32], d_counts[nframes] are device buffers. */
+int sslam_orb_extract_batch_dev(sslam_orb* orb, const uint8_t* d_images, int w, int h,
+                                size_t pitch, size_t image_stride, int nframes,
+                                sslam_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
+                                int cap, void* stream);
+
+/* Stage taps for stage-by-stage parity tests (not used by the drop-in shim):
+ * copy pyramid level `level` of frame `frame` of the LAST batch to host (unpadded,
+ * contiguous w*h), and the FAST candidate list (x,y,score triplets relative to
+ * minBorder, reference src/ORBextractor.cc:820-825) of that level. */
+int sslam_orb_debug_level(sslam_orb* orb, int frame, int level, uint8_t* out, int* w, int* h);
+int sslam_orb_debug_candidates(sslam_orb* orb, int frame, int level, int32_t* xys_out, int cap, int* n_out);
+
+/* ---- Hamming matching (replaces DescriptorDistance / BFMatcher / Search*) -- */
+/* cv::BFMatcher(NORM_HAMMING,false).knnMatch(q,t,matches,2) as used at
+ * src/LSDmatcher.cpp:150-155,261-266,293-298,336-341,387-392 and
+ * ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1650-1666).
+ * idx/dist are nq x 2 (best, second); missing neighbours (nt<2) are idx=-1,dist=-1.
+ * Ties resolve to the lower train index. */
+int sslam_hamming_knn2(sslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                       int32_t* idx_out, int32_t* dist_out);
+int sslam_hamming_knn2_dev(sslam_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                           int32_t* d_idx, int32_t* d_dist, void* stream);
+/* Dense nq x nt distance matrix (uint16), the input of the windowed Search* variants. */
+int sslam_hamming_matrix(sslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* D);
+
+/* ORBmatcher::SearchForInitialization(F1,F2,vbPrevMatched,vnMatches12,windowSize),
+ * src/ORBmatcher.cc:408-523, with Frame::GetFeaturesInArea (src/Frame.cc:368-421) and
+ * the 64x48 grid (src/Frame.cc:133-148,462-472) evaluated on the device.
+ * kp1/desc1 (n1) = F1.mvKeysUn/mDescriptors, kp2/desc2 (n2) = F2; prev_matched[n1*2]
+ * in/out (vbPrevMatched); matches12[n1] out; bounds = mnMinX,mnMaxX,mnMinY,mnMaxY. */
+int sslam_orb_search_for_initialization(sslam_ctx* ctx,
+        const sslam_keypoint* kp1, const uint8_t* desc1, int n1,
+        const sslam_keypoint* kp2, const uint8_t* desc2, int n2,
+        float* prev_matched, int32_t* matches12, int window_size,
+        float nnratio, int check_orientation, const float bounds[4], int* nmatches_out);
+/* Batch/device form: frame pair p uses kp1 + p*cap etc.; counts n1[p], n2[p] on device. */
+int sslam_orb_search_for_initialization_batch_dev(sslam_ctx* ctx,
+        const sslam_keypoint* d_kp1, const uint8_t* d_desc1, const int32_t* d_n1,
+        const sslam_keypoint* d_kp2, const uint8_t* d_desc2, const int32_t* d_n2,
+        int cap, int npairs, float* d_prev_matched, int32_t* d_matches12, int32_t* d_nmatches,
+        int window_size, float nnratio, int check_orientation, const float bounds[4], void* stream);
+
+/* LSDmatcher::SerachForInitialize(InitialFrame,CurrentFrame,LineMatches),
+ * src/LSDmatcher.cpp:257-284 = knn2 + Frame::lineDescriptorMAD (src/Frame.cc:190-215)
+ * + the `d2-d1 > 0.5*MAD12` gate.  pairs_out[cap*2] (qdx,tdx); gate_scale = 0.5
+ * (0.1 reproduces SearchForTriangulation, src/LSDmatcher.cpp:396).
+ * ratio_mode != 0 uses the `d1/d2 < 1/1.5` gate of SearchByProjection(KF,F)/
+ * SearchByDescriptor (src/LSDmatcher.cpp:158-169,303-314) instead. */
+int sslam_line_match(sslam_ctx* ctx, const uint8_t* ldesc1, int n1, const uint8_t* ldesc2, int n2,
+                     double gate_scale, int ratio_mode, int32_t* pairs_out, int cap, int* npairs_out,
+                     double* nn_mad_out, double* nn12_mad_out);
+int sslam_line_match_batch_dev(sslam_ctx* ctx, const uint8_t* d_ldesc1, const int32_t* d_n1,
+                               const uint8_t* d_ldesc2, const int32_t* d_n2, int cap, int npairs_frames,
+                               double gate_scale, int ratio_mode, int32_t* d_pairs, int32_t* d_npairs,
+                               void* stream);
+
+/* ---- Lines (replaces LineSegment::ExtractLineSegment) --------------------- */
+/* LineSegment::ExtractLineSegment(img,keylines,ldesc,keylineFunctions,scale,numOctaves),
+ * src/ExtractLineSegment.cpp:18-69 = LSDDetector::detect + top-N by response +
+ * BinaryDescriptor::compute + normalised line equations.  max_lines = 40 reproduces
+ * the reference's hard cap (:42); BASELINE configs use 200 / 400. */
+int sslam_lines_create(sslam_ctx* ctx, int max_lines, sslam_lines** out);
+int sslam_lines_destroy(sslam_lines* ln);
+int sslam_lines_extract(sslam_lines* ln, const uint8_t* gray, int w, int h, size_t stride,
+                        sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out /*3 per line*/,
+                        int cap, int* n_out);
+int sslam_lines_extract_batch_dev(sslam_lines* ln, const uint8_t* d_images, int w, int h,
+                                  size_t pitch, size_t image_stride, int nframes,
+                                  sslam_keyline* d_kl, uint8_t* d_ldesc, double* d_linefn,
+                                  int32_t* d_counts, int cap, void* stream);
+/* Stage tap: all LSD segments (x1,y1,x2,y2 float) of frame `frame` of the last batch, before top-N. */
+int sslam_lines_debug_segments(sslam_lines* ln, int frame, float* seg_out, int cap, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSLAM_FRONTEND_H */

@@ -1,0 +1,147 @@
+// Internal declarations shared by the HIP translation units of libsslam_frontend.so.
+// gfx950 (MI355X) only: wave64, no CUDA-compat layer, no dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <mutex>
+#include "../../include/sslam_frontend.h"
+
+namespace sslam {
+
+void set_error(const char* fmt, ...);
+
+#define SSLAM_HIP(expr)                                                                     \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            sslam::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SSLAM_ERR_HIP;                                                           \
+        }                                                                                   \
+    } while (0)
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SSLAM_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        SSLAM_HIP(hipMalloc(&p, want));
+        cap = want;
+        return SSLAM_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct HostPinned {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SSLAM_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        SSLAM_HIP(hipHostMalloc(&p, bytes + 256, hipHostMallocDefault));
+        cap = bytes + 256;
+        return SSLAM_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+}  // namespace sslam
+
+struct sslam_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;                 // host entry points serialise on the context (SURVEY §8b threading)
+    sslam::DevBuf scratch[8];      // matcher staging
+    sslam::HostPinned pinned[4];
+    int num_cus = 0;
+};
+
+// ---- device helpers (wave64) ---------------------------------------------------
+#ifdef __HIPCC__
+namespace sslam {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o, 64);
+        unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o, 64);
+        unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w < v ? w : v;
+    }
+    return v;
+}
+// inclusive prefix sum across the wave
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o, 64);
+        if (l >= o) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+// cv::fastAtan2 (scalar atan_f32) with explicit round-to-nearest fp32 ops, no FMA
+// contraction (oracle decision D4).  Degrees in [0,360).
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// cvRound(float): round half to even
+__device__ __forceinline__ int cv_roundf(float v) { return __float2int_rn(v); }
+
+}  // namespace sslam
+#endif

@@ -1,0 +1,71 @@
+// Context, error reporting and ABI housekeeping of libsslam_frontend.so.
+#include "common.h"
+#include <cstdarg>
+
+namespace sslam {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace sslam
+
+using namespace sslam;
+
+extern "C" const char* sslam_last_error(void) { return g_err; }
+
+extern "C" const char* sslam_status_str(int s) {
+    switch (s) {
+        case SSLAM_OK: return "ok";
+        case SSLAM_ERR_INVALID: return "invalid argument";
+        case SSLAM_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+        case SSLAM_ERR_CAPACITY: return "output buffer too small";
+        case SSLAM_ERR_HIP: return "HIP runtime error";
+        case SSLAM_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int sslam_abi_version(void) { return 1; }
+
+extern "C" int sslam_ctx_create(int device, sslam_ctx** out) {
+    if (!out) return SSLAM_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (%s); libsslam_frontend has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return SSLAM_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { set_error("device %d out of range (have %d)", device, n); return SSLAM_ERR_INVALID; }
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return SSLAM_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error("hipGetDeviceProperties failed"); return SSLAM_ERR_NO_DEVICE; }
+    sslam_ctx* c = new sslam_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; set_error("hipStreamCreate failed"); return SSLAM_ERR_NO_DEVICE; }
+    *out = c;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_ctx_destroy(sslam_ctx* c) {
+    if (!c) return SSLAM_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& b : c->scratch) b.release();
+    for (auto& b : c->pinned) b.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_ctx_synchronize(sslam_ctx* c) {
+    if (!c) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(c->device));
+    SSLAM_HIP(hipStreamSynchronize(c->stream));
+    return SSLAM_OK;
+}
+
+extern "C" void* sslam_ctx_stream(sslam_ctx* c) { return c ? (void*)c->stream : nullptr; }

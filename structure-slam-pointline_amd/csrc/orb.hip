@@ -1,0 +1,943 @@
+// ORB front-end for MI355X (gfx950): pyramid, per-cell FAST-9 + NMS + threshold
+// fallback, quadtree distribution, intensity-centroid orientation, 7x7 blur and
+// 256-bit rBRIEF — the device side of StructureSLAM::ORBextractor
+// (reference src/ORBextractor.cc; behavioural spec in SURVEY.md Appendix D).
+//
+// Design:
+//   * frames are batched: every launch covers all frames (and, where the stage has
+//     no cross-level dependency, all pyramid levels) of the batch;
+//   * pyramid levels are stored UNPADDED (the reference's 19-px reflect border is
+//     never read by any consumer: keypoints live in [19,w-19) and the widest
+//     consumer, rBRIEF, reaches 18 px);
+//   * FAST scores are threshold independent (score = best 9-arc contrast - 1), so
+//     one LDS-staged pass per 30x30-ish cell reproduces "FAST(20) then FAST(7) if
+//     empty" including the cell-local NMS, without a score map in HBM;
+//   * the quadtree is simulated exactly by one wave per (frame, level);
+//   * orientation + blur + rBRIEF run fused, one wave per keypoint, on a 43x43 patch
+//     staged in LDS (no blurred image in HBM).
+#include "common.h"
+#include <cmath>
+#include <algorithm>
+
+using namespace sslam;
+
+namespace {
+
+constexpr int MAX_LEVELS = 16;
+constexpr int EDGE = 19;          // EDGE_THRESHOLD, src/ORBextractor.cc:74
+constexpr int MINB = 16;          // EDGE_THRESHOLD-3, :773
+constexpr int HALF_PATCH = 15;
+
+struct LevelInfo {
+    int w, h, pitch;
+    unsigned off;                 // byte offset of the level inside a frame's pyramid block
+    int cellBeg, nCells;          // range in the frame's cell table
+    int candOff, candCap;         // range in the frame's candidate arrays (u32 units)
+    int nfeat;                    // mnFeaturesPerLevel
+    int selOff, selCap;           // range in the frame's selected-keypoint array
+    int nIni;                     // root nodes of the quadtree
+    float hX;
+    int W, H;                     // maxBorder-minBorder extents
+    float scale;                  // mvScaleFactor
+    float size;                   // float(int(31*scale))
+    int tabX, tabY;               // int16 offsets into the resize tables (3 per entry)
+};
+
+struct Plan {
+    int nlevels;
+    int nCellsFrame, candFrame, selFrame;
+    size_t pyrFrame;              // bytes
+    int maxCellW, maxCellH, maxCellsLevel, maxNodeCap;
+    LevelInfo L[MAX_LEVELS];
+};
+
+struct CellInfo {
+    short level, x0, y0, x1, y1;  // detection rectangle [x0,x1) x [y0,y1) in level coordinates
+    short pad;
+    int candOff;                  // offset inside the frame's candidate array
+};
+
+__device__ const signed char kPat[1024] = {
+#include "orb_pattern.inc"
+};
+__constant__ int kUmax[16];
+__constant__ int kBlurTaps[7];
+
+// ------------------------------------------------------------------ level 0 copy
+__global__ void k_copy_level0(const uint8_t* __restrict__ in, size_t pitch, size_t imageStride,
+                              uint8_t* __restrict__ pyr, size_t pyrFrame, int w, int h, int dpitch) {
+    const int b = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (x >= w) return;
+    const uint8_t* s = in + (size_t)b * imageStride + (size_t)y * pitch + x;
+    uint8_t* d = pyr + (size_t)b * pyrFrame + (size_t)y * dpitch + x;
+    if (x + 16 <= w && (((uintptr_t)s) & 15) == 0) {
+        *(uint4*)d = *(const uint4*)s;
+    } else {
+        int n = min(16, w - x);
+        for (int i = 0; i < n; ++i) d[i] = s[i];
+    }
+}
+
+// ------------------------------------------------------------------ bilinear /1.2
+// cv::resize(INTER_LINEAR) for CV_8UC1: 11-bit fixed-point taps.
+// tabX/tabY entries: {src offset, coef0, coef1} as int16.
+__global__ void k_resize(uint8_t* __restrict__ pyr, size_t pyrFrame, LevelInfo S, LevelInfo D,
+                         const short* __restrict__ tabs) {
+    const int b = blockIdx.z;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (y >= D.h || x4 >= D.w) return;
+    const short* tx = tabs + D.tabX;
+    const short* ty = tabs + D.tabY + y * 3;
+    int sy = ty[0];
+    int b0 = ty[1], b1 = ty[2];
+    int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
+    const uint8_t* s0 = pyr + (size_t)b * pyrFrame + S.off + (size_t)sy0 * S.pitch;
+    const uint8_t* s1 = pyr + (size_t)b * pyrFrame + S.off + (size_t)sy1 * S.pitch;
+    unsigned out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int x = x4 + i;
+        if (x < D.w) {
+            int sx = tx[x * 3], a0 = tx[x * 3 + 1], a1 = tx[x * 3 + 2];
+            int sx1 = min(sx + 1, S.w - 1);
+            int r0 = s0[sx] * a0 + s0[sx1] * a1;
+            int r1 = s1[sx] * a0 + s1[sx1] * a1;
+            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            out |= (unsigned)(v & 255) << (8 * i);
+        }
+    }
+    *(unsigned*)(pyr + (size_t)b * pyrFrame + D.off + (size_t)y * D.pitch + x4) = out;   // pitch%64==0, pad columns are scratch
+}
+
+// ------------------------------------------------------------------ FAST per cell
+// FAST-9/16 score, threshold independent: (max over the 16 nine-pixel arcs of the
+// arc's minimum signed contrast, both polarities) - 1   (cv cornerScore<16>, A.1).
+// Returns 0 when the pixel is not a corner at `minTh`.
+__device__ __forceinline__ int fast_score16(const uint8_t* c, int tp, int minTh) {
+    const int v = c[0];
+    int r[16];
+    r[0] = c[3 * tp];      r[1] = c[3 * tp + 1];   r[2] = c[2 * tp + 2];   r[3] = c[tp + 3];
+    r[4] = c[3];           r[5] = c[-tp + 3];      r[6] = c[-2 * tp + 2];  r[7] = c[-3 * tp + 1];
+    r[8] = c[-3 * tp];     r[9] = c[-3 * tp - 1];  r[10] = c[-2 * tp - 2]; r[11] = c[-tp - 3];
+    r[12] = c[-3];         r[13] = c[tp - 3];      r[14] = c[2 * tp - 2];  r[15] = c[3 * tp - 1];
+    // necessary condition for a 9-arc at minTh: every opposite pair holds one arc member
+    bool cb = true, cd = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        cb = cb && ((r[k] > v + minTh) || (r[k + 8] > v + minTh));
+        cd = cd && ((r[k] < v - minTh) || (r[k + 8] < v - minTh));
+    }
+    if (!(cb || cd)) return 0;
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = v - r[k];
+    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
+    int A = -1000, B = 1000;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        A = max(A, min(mn8[k], d[(k + 8) & 15]));
+        B = min(B, max(mx8[k], d[(k + 8) & 15]));
+    }
+    int s = max(A, -B) - 1;
+    return s >= minTh ? s : 0;
+}
+
+// One wave per (cell, frame).  LDS: image tile with 3-px halo, score tile with a
+// zero rim (NMS neighbours outside the cell's detection rectangle count as 0, D.1),
+// and a keep-code per pixel.  Candidates leave in raster order, packed
+// (score<<24 | y<<12 | x) with x,y relative to minBorder (=16), :820-825.
+__global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrFrame, Plan P,
+                                                   const CellInfo* __restrict__ cells,
+                                                   unsigned* __restrict__ cand, int* __restrict__ cellCount,
+                                                   int iniTh, int minTh, int tileP, int scP) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const int cellId = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x;
+    const CellInfo ci = cells[cellId];
+    const LevelInfo& L = P.L[ci.level];
+    const int cw = ci.x1 - ci.x0, ch = ci.y1 - ci.y0;
+    uint8_t* tile = lds;                                       // (maxCellH+6) x tileP
+    uint8_t* sc = tile + (P.maxCellH + 6) * tileP;             // (maxCellH+2) x scP
+    uint8_t* code = sc + (P.maxCellH + 2) * scP;               // maxCellH x maxCellW
+    const uint8_t* img = pyr + (size_t)b * pyrFrame + L.off;
+    // stage tile rows [y0-3, y1+3) x cols [x0-3, x1+3): always inside the level (x0>=19)
+    const int tw = cw + 6, th = ch + 6;
+    for (int i = lane; i < tw * th; i += 64) {
+        int ry = i / tw, rx = i - ry * tw;
+        tile[ry * tileP + rx] = img[(size_t)(ci.y0 - 3 + ry) * L.pitch + (ci.x0 - 3 + rx)];
+    }
+    for (int i = lane; i < (ch + 2) * scP; i += 64) sc[i] = 0;
+    __syncthreads();
+    const int npx = cw * ch;
+    for (int i = lane; i < npx; i += 64) {
+        int py = i / cw, px = i - py * cw;
+        int s = fast_score16(tile + (py + 3) * tileP + (px + 3), tileP, minTh);
+        sc[(py + 1) * scP + (px + 1)] = (uint8_t)s;
+    }
+    __syncthreads();
+    int cnt20 = 0;
+    for (int i0 = 0; i0 < npx; i0 += 64) {
+        int i = i0 + lane;
+        int cde = 0;
+        if (i < npx) {
+            int py = i / cw, px = i - py * cw;
+            const uint8_t* c = sc + (py + 1) * scP + (px + 1);
+            int s = c[0];
+            if (s > 0 && s > c[-1] && s > c[1] && s > c[-scP - 1] && s > c[-scP] && s > c[-scP + 1] &&
+                s > c[scP - 1] && s > c[scP] && s > c[scP + 1])
+                cde = s >= iniTh ? 2 : 1;
+            code[i] = (uint8_t)cde;
+        }
+        cnt20 += __popcll(__ballot(cde == 2));
+    }
+    __syncthreads();
+    const int need = cnt20 > 0 ? 2 : 1;      // FAST(iniTh) empty -> FAST(minTh), :809-816
+    unsigned* out = cand + (size_t)b * P.candFrame + ci.candOff;
+    int n = 0;
+    for (int i0 = 0; i0 < npx; i0 += 64) {
+        int i = i0 + lane;
+        bool keep = false;
+        int py = 0, px = 0;
+        if (i < npx) { keep = code[i] >= need; py = i / cw; px = i - py * cw; }
+        unsigned long long m = __ballot(keep);
+        if (keep) {
+            int s = sc[(py + 1) * scP + (px + 1)];
+            out[n + mbcnt(m)] = ((unsigned)s << 24) | ((unsigned)(ci.y0 + py - MINB) << 12) | (unsigned)(ci.x0 + px - MINB);
+        }
+        n += __popcll(m);
+    }
+    if (lane == 0) cellCount[(size_t)b * P.nCellsFrame + cellId] = n;
+}
+
+// ------------------------------------------------------------------ quadtree
+// Exact simulation of ORBextractor::DistributeOctTree (src/ORBextractor.cc:539-763,
+// spec SURVEY D.2) by one wave per (level, frame).  Keypoints live in two global
+// ping-pong arrays; a node owns a contiguous segment, and a split is a stable
+// 4-way partition of that segment (ballot + prefix popcount).  The node list is a
+// doubly linked list in LDS; tie-break D1 = creation sequence.
+struct OctLds {
+    int* pre;                 // cell prefix sums            [maxCellsLevel+1]
+    unsigned* box0;           // x0 | x1<<16                 [NC]
+    unsigned* box1;           // y0 | y1<<16
+    unsigned* start;          // segment start, bit31 = lives in buffer B
+    int* count;
+    unsigned* links;          // next | prev<<16 (0xFFFF = nil)
+    unsigned long long* expA; // expandable lists (size<<40 | seq<<16 | node)  [NCp2]
+    unsigned long long* expB;
+};
+
+#define NIL 0xFFFFu
+
+__global__ __launch_bounds__(64) void k_octree(const unsigned* __restrict__ cand, const int* __restrict__ cellCount,
+                                               const CellInfo* __restrict__ cells, unsigned* __restrict__ bufA,
+                                               unsigned* __restrict__ bufB, unsigned* __restrict__ sel,
+                                               int* __restrict__ selCount, Plan P, int NC, int NCp2) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const int level = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const LevelInfo& L = P.L[level];
+    OctLds S;
+    S.expA = (unsigned long long*)lds;
+    S.expB = S.expA + NCp2;
+    S.pre = (int*)(S.expB + NCp2);
+    S.box0 = (unsigned*)(S.pre + P.maxCellsLevel + 1);
+    S.box1 = S.box0 + NC;
+    S.start = S.box1 + NC;
+    S.count = (int*)(S.start + NC);
+    S.links = (unsigned*)(S.count + NC);
+
+    const int nc = L.nCells;
+    const int* cc = cellCount + (size_t)b * P.nCellsFrame + L.cellBeg;
+    int total = 0;
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+        int c = c0 + lane;
+        int cnt = c < nc ? cc[c] : 0;
+        int inc = wave_incl_scan(cnt);
+        if (c < nc) S.pre[c] = total + inc - cnt;
+        total += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) S.pre[nc] = total;
+    __syncthreads();
+    int* selCnt = selCount + (size_t)b * P.nlevels + level;
+    if (total == 0 || L.nIni <= 0 || L.nIni > 8) { if (lane == 0) *selCnt = 0; return; }
+
+    unsigned* A = bufA + (size_t)b * P.candFrame + L.candOff;
+    unsigned* B = bufB + (size_t)b * P.candFrame + L.candOff;
+    const unsigned* cbase = cand + (size_t)b * P.candFrame;
+    // gather the cells' candidates in cell-row-major order (the order FAST emitted them, :789-829)
+    for (int p = lane; p < total; p += 64) {
+        int lo = 0, hi = nc;                       // find c: pre[c] <= p < pre[c+1]
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (S.pre[mid] <= p) lo = mid; else hi = mid; }
+        A[p] = cbase[cells[L.cellBeg + lo].candOff + (p - S.pre[lo])];
+    }
+    __syncthreads();
+
+    // uniform bookkeeping (every lane holds the same values)
+    unsigned head = NIL, tail = NIL;
+    int nNodes = 0, nAlloc = 0, seq = 0;
+
+    auto push_front = [&](unsigned slot) {
+        if (lane == 0) {
+            S.links[slot] = head | (NIL << 16);
+            if (head != NIL) S.links[head] = (S.links[head] & 0xFFFFu) | (slot << 16);
+        }
+        if (head == NIL) tail = slot;
+        head = slot;
+        ++nNodes;
+    };
+    auto push_back = [&](unsigned slot) {
+        if (lane == 0) {
+            S.links[slot] = NIL | (tail << 16);
+            if (tail != NIL) S.links[tail] = (S.links[tail] & 0xFFFF0000u) | slot;
+        }
+        if (tail == NIL) head = slot;
+        tail = slot;
+        ++nNodes;
+    };
+
+    // roots (:545-584): nIni = round(W/H) vertical strips; kp -> strip int(x/hX)
+    {
+        int src_is_B = 0;
+        if (L.nIni > 1) {
+            int o = 0;
+            for (int r = 0; r < L.nIni; ++r) {
+                int begin = o;
+                for (int i0 = 0; i0 < total; i0 += 64) {
+                    int i = i0 + lane;
+                    unsigned v = i < total ? A[i] : 0;
+                    bool mine = i < total && (int)__fdiv_rn((float)(v & 0xFFF), L.hX) == r;
+                    unsigned long long m = __ballot(mine);
+                    if (mine) B[o + mbcnt(m)] = v;
+                    o += __popcll(m);
+                }
+                if (o > begin) {
+                    unsigned slot = nAlloc++;
+                    if (lane == 0) {
+                        S.box0[slot] = (unsigned)(int)__fmul_rn(L.hX, (float)r) | ((unsigned)(int)__fmul_rn(L.hX, (float)(r + 1)) << 16);
+                        S.box1[slot] = 0u | ((unsigned)L.H << 16);
+                        S.start[slot] = (unsigned)begin | 0x80000000u;
+                        S.count[slot] = o - begin;
+                    }
+                    __syncthreads();
+                    push_back(slot);
+                    ++seq;
+                }
+            }
+            src_is_B = 1;
+        } else {
+            unsigned slot = nAlloc++;
+            if (lane == 0) {
+                S.box0[slot] = 0u | ((unsigned)(int)L.hX << 16);
+                S.box1[slot] = 0u | ((unsigned)L.H << 16);
+                S.start[slot] = 0u;
+                S.count[slot] = total;
+            }
+            push_back(slot);
+            ++seq;
+        }
+        (void)src_is_B;
+        __syncthreads();
+    }
+
+    unsigned long long* expCur = S.expA;
+    unsigned long long* expPrev = S.expB;
+    int nExp = 0, nToExpand = 0;
+
+    // DivideNode (:481-537) + child insertion (:615-660): stable partition of the
+    // node's segment into UL, UR, BL, BR; non-empty children pushed to the FRONT in
+    // that order; children with >1 keypoints recorded as expandable.
+    auto split = [&](unsigned it) {
+        const unsigned b0 = S.box0[it], b1 = S.box1[it], st = S.start[it];
+        const int n = S.count[it];
+        const unsigned lk = S.links[it];
+        const int x0 = b0 & 0xFFFF, x1 = b0 >> 16, y0 = b1 & 0xFFFF, y1 = b1 >> 16;
+        const int midx = x0 + ((x1 - x0 + 1) >> 1), midy = y0 + ((y1 - y0 + 1) >> 1);
+        const bool inB = st >> 31;
+        const int s = st & 0x7FFFFFFF;
+        const unsigned* src = (inB ? B : A) + s;
+        unsigned* dst = (inB ? A : B) + s;
+        int c[4] = {0, 0, 0, 0};
+        if (n <= 64) {
+            unsigned v = lane < n ? src[lane] : 0;
+            int cls = lane < n ? (((int)(v & 0xFFF) >= midx) | (((int)((v >> 12) & 0xFFF) >= midy) << 1)) : 4;
+            unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+            c[0] = __popcll(m0); c[1] = __popcll(m1); c[2] = __popcll(m2); c[3] = __popcll(m3);
+            if (cls < 4) {
+                int pos = cls == 0 ? mbcnt(m0) : cls == 1 ? c[0] + mbcnt(m1) : cls == 2 ? c[0] + c[1] + mbcnt(m2) : c[0] + c[1] + c[2] + mbcnt(m3);
+                dst[pos] = v;
+            }
+        } else {
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                int i = i0 + lane;
+                unsigned v = i < n ? src[i] : 0;
+                int cls = i < n ? (((int)(v & 0xFFF) >= midx) | (((int)((v >> 12) & 0xFFF) >= midy) << 1)) : 4;
+                c[0] += __popcll(__ballot(cls == 0)); c[1] += __popcll(__ballot(cls == 1));
+                c[2] += __popcll(__ballot(cls == 2)); c[3] += __popcll(__ballot(cls == 3));
+            }
+            int o[4] = {0, c[0], c[0] + c[1], c[0] + c[1] + c[2]};
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                int i = i0 + lane;
+                unsigned v = i < n ? src[i] : 0;
+                int cls = i < n ? (((int)(v & 0xFFF) >= midx) | (((int)((v >> 12) & 0xFFF) >= midy) << 1)) : 4;
+                unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+                if (cls < 4) {
+                    int pos = cls == 0 ? o[0] + mbcnt(m0) : cls == 1 ? o[1] + mbcnt(m1) : cls == 2 ? o[2] + mbcnt(m2) : o[3] + mbcnt(m3);
+                    dst[pos] = v;
+                }
+                o[0] += __popcll(m0); o[1] += __popcll(m1); o[2] += __popcll(m2); o[3] += __popcll(m3);
+            }
+        }
+        // unlink the parent
+        {
+            unsigned nx = lk & 0xFFFF, pv = lk >> 16;
+            if (lane == 0) {
+                if (pv != NIL) S.links[pv] = (S.links[pv] & 0xFFFF0000u) | nx;
+                if (nx != NIL) S.links[nx] = (S.links[nx] & 0xFFFFu) | (pv << 16);
+            }
+            if (pv == NIL) head = nx;
+            if (nx == NIL) tail = pv;
+            --nNodes;
+        }
+        __syncthreads();
+        const int cx0[4] = {x0, midx, x0, midx}, cx1[4] = {midx, x1, midx, x1};
+        const int cy0[4] = {y0, y0, midy, midy}, cy1[4] = {midy, midy, y1, y1};
+        int off = 0;
+        bool reuse = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c[k] > 0) {
+                unsigned slot = reuse ? it : (unsigned)nAlloc++;
+                reuse = false;
+                if (lane == 0) {
+                    S.box0[slot] = (unsigned)cx0[k] | ((unsigned)cx1[k] << 16);
+                    S.box1[slot] = (unsigned)cy0[k] | ((unsigned)cy1[k] << 16);
+                    S.start[slot] = (unsigned)(s + off) | (inB ? 0u : 0x80000000u);
+                    S.count[slot] = c[k];
+                }
+                __syncthreads();
+                push_front(slot);
+                if (c[k] > 1) {
+                    ++nToExpand;
+                    if (lane == 0) expCur[nExp] = ((unsigned long long)c[k] << 40) | ((unsigned long long)seq << 16) | slot;
+                    ++nExp;
+                }
+                ++seq;
+            }
+            off += c[k];
+        }
+        __syncthreads();
+    };
+
+    const int N = L.nfeat;
+    bool finish = false;
+    while (!finish) {
+        const int prevSize = nNodes;
+        nToExpand = 0; nExp = 0;
+        unsigned it = head;
+        while (it != NIL) {
+            unsigned nx = S.links[it] & 0xFFFF;
+            if (S.count[it] > 1) split(it);
+            it = nx;
+        }
+        if (nNodes >= N || nNodes == prevSize) finish = true;
+        else if (nNodes + nToExpand * 3 > N) {
+            while (!finish) {
+                const int prevSize2 = nNodes;
+                // sort the expandable nodes ascending by (size, creation seq) — :684, tie-break D1
+                int P2 = 1; while (P2 < nExp) P2 <<= 1;
+                for (int i = nExp + lane; i < P2; i += 64) expCur[i] = ~0ull;
+                __syncthreads();
+                for (int k = 2; k <= P2; k <<= 1)
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int i = lane; i < P2; i += 64) {
+                            int ixj = i ^ j;
+                            if (ixj > i) {
+                                unsigned long long a = expCur[i], bb = expCur[ixj];
+                                bool up = (i & k) == 0;
+                                if ((a > bb) == up) { expCur[i] = bb; expCur[ixj] = a; }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                unsigned long long* t = expCur; expCur = expPrev; expPrev = t;
+                const int nPrev = nExp;
+                nExp = 0;
+                for (int j = nPrev - 1; j >= 0; --j) {
+                    split((unsigned)(expPrev[j] & 0xFFFF));
+                    if (nNodes >= N) break;
+                }
+                if (nNodes >= N || nNodes == prevSize2) finish = true;
+            }
+        }
+    }
+
+    // retain the best-response keypoint of each node, list order (:742-760)
+    unsigned* order = (unsigned*)S.expA;
+    if (lane == 0) { int k = 0; for (unsigned it = head; it != NIL; it = S.links[it] & 0xFFFF) order[k++] = it; }
+    __syncthreads();
+    unsigned* out = sel + (size_t)b * P.selFrame + L.selOff;
+    const int nOut = min(nNodes, L.selCap);
+    for (int k = lane; k < nOut; k += 64) {
+        unsigned node = order[k];
+        unsigned st = S.start[node];
+        const unsigned* src = ((st >> 31) ? B : A) + (st & 0x7FFFFFFF);
+        int n = S.count[node];
+        unsigned best = src[0];
+        for (int i = 1; i < n; ++i) { unsigned v = src[i]; if ((v >> 24) > (best >> 24)) best = v; }
+        out[k] = best;
+    }
+    if (lane == 0) *selCnt = nOut;
+}
+
+// ------------------------------------------------------------------ describe
+// One wave per selected keypoint: IC_Angle (:77-104) on the unblurred level,
+// GaussianBlur 7x7 sigma 2 (:1086, fixed-point D6) evaluated only where rBRIEF
+// taps land, computeOrbDescriptor (:108-147), and the KeyPoint record (:837-847,
+// :1095-1101).  The 43x43 source patch is staged in LDS with reflect-101.
+constexpr int PR = 21;               // patch radius: 18 (taps) + 3 (blur)
+constexpr int PW = 2 * PR + 1;       // 43
+constexpr int PP = 44;               // LDS pitch
+constexpr int HW = 37;               // horizontally blurred columns: x-18..x+18
+
+__global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr, size_t pyrFrame, Plan P,
+                                                 const unsigned* __restrict__ sel, const int* __restrict__ selCount,
+                                                 sslam_keypoint* __restrict__ kpOut, uint8_t* __restrict__ descOut,
+                                                 int* __restrict__ counts, int cap) {
+    __shared__ uint8_t patch[PW * PP];
+    __shared__ unsigned short hb[PW * 38];
+    const int b = blockIdx.y, lane = threadIdx.x;
+    int slot = blockIdx.x;
+    // locate (level, index) of this slot
+    int level = 0;
+    while (level < P.nlevels - 1 && slot >= P.L[level].selOff + P.L[level].selCap) ++level;
+    const LevelInfo& L = P.L[level];
+    const int idx = slot - L.selOff;
+    const int* sc = selCount + (size_t)b * P.nlevels;
+    int before = 0, totalKp = 0;
+    for (int l = 0; l < P.nlevels; ++l) { int c = sc[l]; if (l < level) before += c; totalKp += c; }
+    if (slot == 0 && lane == 0) counts[b] = min(totalKp, cap);
+    if (idx >= sc[level]) return;
+    const int outIdx = before + idx;
+    if (outIdx >= cap) return;
+    const unsigned pk = sel[(size_t)b * P.selFrame + slot];
+    const int kx = (int)(pk & 0xFFF) + MINB, ky = (int)((pk >> 12) & 0xFFF) + MINB, score = pk >> 24;
+    const uint8_t* img = pyr + (size_t)b * pyrFrame + L.off;
+    for (int i = lane; i < PW * PW; i += 64) {
+        int r = i / PW, c = i - r * PW;
+        int yy = reflect101(ky - PR + r, L.h), xx = reflect101(kx - PR + c, L.w);
+        patch[r * PP + c] = img[(size_t)yy * L.pitch + xx];
+    }
+    __syncthreads();
+    // intensity centroid over the r=15 disc
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        int r = i / 31, c = i - r * 31;
+        int v = r - HALF_PATCH, u = c - HALF_PATCH;
+        if (abs(u) <= kUmax[abs(v)]) {
+            int I = patch[(PR + v) * PP + (PR + u)];
+            m10 += u * I; m01 += v * I;
+        }
+    }
+    m10 = wave_sum(m10); m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // horizontal blur pass: rows all 43, cols x-18..x+18
+    for (int i = lane; i < PW * HW; i += 64) {
+        int r = i / HW, c = i - r * HW;       // c -> patch col c+3
+        const uint8_t* p = patch + r * PP + c;
+        unsigned acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc += (unsigned)p[k] * (unsigned)kBlurTaps[k];
+        hb[r * 38 + c] = (unsigned short)acc;
+    }
+    __syncthreads();
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float ang = __fmul_rn(angle, factorPI);
+    const float a = (float)cos((double)ang), bsn = (float)sin((double)ang);    // D5
+    unsigned nib = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int t[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const signed char* pp = kPat + ((lane * 4 + k) * 2 + e) * 2;
+            float px = (float)pp[0], py = (float)pp[1];
+            int yy = cv_roundf(__fadd_rn(__fmul_rn(px, bsn), __fmul_rn(py, a)));
+            int xx = cv_roundf(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, bsn)));
+            const unsigned short* h = hb + (PR + yy - 3) * 38 + (18 + xx);
+            unsigned acc = 0;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) acc += (unsigned)h[q * 38] * (unsigned)kBlurTaps[q];
+            t[e] = (int)((acc + 32768u) >> 16);
+        }
+        nib |= (unsigned)(t[0] < t[1]) << k;
+    }
+    unsigned word = nib << (4 * (lane & 7));
+    word |= __shfl_xor((int)word, 1, 64);
+    word |= __shfl_xor((int)word, 2, 64);
+    word |= __shfl_xor((int)word, 4, 64);
+    if ((lane & 7) == 0) ((unsigned*)descOut)[((size_t)b * cap + outIdx) * 8 + (lane >> 3)] = word;
+    if (lane < 7) {
+        float fx = (float)kx, fy = (float)ky;
+        if (level != 0) { fx = __fmul_rn(fx, L.scale); fy = __fmul_rn(fy, L.scale); }
+        unsigned w;
+        switch (lane) {
+            case 0: w = __float_as_uint(fx); break;
+            case 1: w = __float_as_uint(fy); break;
+            case 2: w = __float_as_uint(L.size); break;
+            case 3: w = __float_as_uint(angle); break;
+            case 4: w = __float_as_uint((float)score); break;
+            case 5: w = (unsigned)level; break;
+            default: w = 0xFFFFFFFFu; break;
+        }
+        ((unsigned*)kpOut)[((size_t)b * cap + outIdx) * 7 + lane] = w;
+    }
+}
+
+}  // namespace
+
+// =============================================================== host side
+struct sslam_orb {
+    sslam_ctx* ctx;
+    int nfeatures, nlevels, iniTh, minTh;
+    float scaleFactorF;
+    double scaleFactor;
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> perLevel;
+    int umax[16];
+    int planW = 0, planH = 0;
+    Plan plan;
+    std::vector<CellInfo> cells;
+    std::vector<short> tabs;
+    DevBuf dCells, dTabs, dPyr, dCellCount, dCand, dBufA, dBufB, dSel, dSelCount;
+    DevBuf dImg, dKp, dDesc, dCounts;       // single-frame host path staging
+    HostPinned hImg, hOut;
+    int wsFrames = 0;
+    int lastFrames = 0;
+    bool constsUploaded = false;
+};
+
+static inline int cvRoundF(float v) { return (int)lrintf(v); }
+
+static std::vector<int> blur_taps_q8(int n, double sigma) {
+    // bit-exact 8.8 Gaussian taps with error diffusion, sum == 256 (decision D6)
+    std::vector<double> k(n);
+    double sum = 0, s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; ++i) { double x = i - (n - 1) * 0.5; k[i] = std::exp(s2 * x * x); sum += k[i]; }
+    std::vector<int> t(n);
+    double err = 0; long isum = 0;
+    for (int i = 0; i < n / 2; ++i) {
+        double adj = k[i] / sum * 256.0 + err;
+        int v = (int)lrint(adj);
+        err = adj - v; t[i] = t[n - 1 - i] = v; isum += v;
+    }
+    t[n / 2] = (int)(256 - 2 * isum);
+    return t;
+}
+
+static int build_plan(sslam_orb* o, int w, int h) {
+    Plan& P = o->plan;
+    memset(&P, 0, sizeof(P));
+    P.nlevels = o->nlevels;
+    o->cells.clear(); o->tabs.clear();
+    size_t off = 0;
+    int candOff = 0, selOff = 0;
+    for (int l = 0; l < o->nlevels; ++l) {
+        LevelInfo& L = P.L[l];
+        float s = o->invScale[l];
+        L.w = cvRoundF((float)w * s); L.h = cvRoundF((float)h * s);     // ComputePyramid :1112
+        if (L.w < 1 || L.h < 1 || L.w > 4095 + MINB || L.h > 4095 + MINB) { set_error("image size %dx%d unsupported at level %d", w, h, l); return SSLAM_ERR_UNSUPPORTED; }
+        L.pitch = (L.w + 63) & ~63;
+        L.off = (unsigned)off;
+        off += (size_t)L.pitch * L.h;
+        off = (off + 255) & ~(size_t)255;
+        L.scale = o->scale[l];
+        L.size = (float)(int)(31 * o->scale[l]);                          // :835
+        L.nfeat = o->perLevel[l];
+        // FAST cell grid, :771-829 / SURVEY D.1
+        const int maxBX = L.w - EDGE + 3, maxBY = L.h - EDGE + 3;
+        const float width = (float)(maxBX - MINB), height = (float)(maxBY - MINB);
+        L.W = maxBX - MINB; L.H = maxBY - MINB;
+        L.cellBeg = (int)o->cells.size();
+        L.candOff = candOff;
+        const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+        if (nCols > 0 && nRows > 0 && L.W > 0 && L.H > 0) {
+            const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+            for (int i = 0; i < nRows; ++i) {
+                const float iniY = (float)(MINB + i * hCell);
+                float maxY = iniY + hCell + 6;
+                if (iniY >= maxBY - 3) continue;
+                if (maxY > maxBY) maxY = (float)maxBY;
+                for (int j = 0; j < nCols; ++j) {
+                    const float iniX = (float)(MINB + j * wCell);
+                    float maxX = iniX + wCell + 6;
+                    if (iniX >= maxBX - 6) continue;
+                    if (maxX > maxBX) maxX = (float)maxBX;
+                    CellInfo c;
+                    c.level = (short)l; c.pad = 0;
+                    c.x0 = (short)((int)iniX + 3); c.x1 = (short)((int)maxX - 3);
+                    c.y0 = (short)((int)iniY + 3); c.y1 = (short)((int)maxY - 3);
+                    if (c.x1 <= c.x0 || c.y1 <= c.y0) continue;       // view narrower than 7: FAST finds nothing
+                    c.candOff = candOff;
+                    int cw = c.x1 - c.x0, chh = c.y1 - c.y0;
+                    candOff += ((cw + 1) / 2) * ((chh + 1) / 2);      // strict 3x3 NMS keeps <= 1 per 2x2
+                    P.maxCellW = std::max(P.maxCellW, cw); P.maxCellH = std::max(P.maxCellH, chh);
+                    o->cells.push_back(c);
+                }
+            }
+        }
+        L.nCells = (int)o->cells.size() - L.cellBeg;
+        L.candCap = candOff - L.candOff;
+        P.maxCellsLevel = std::max(P.maxCellsLevel, L.nCells);
+        // quadtree roots, :543-545
+        if (L.W > 0 && L.H > 0) {
+            L.nIni = (int)std::round((float)L.W / (float)L.H);
+            L.hX = L.nIni > 0 ? (float)L.W / (float)L.nIni : 0.f;
+        } else { L.nIni = 0; L.hX = 0; }
+        L.selOff = selOff;
+        L.selCap = std::max(L.nfeat + 3, 4 * std::max(L.nIni, 1) + 1);
+        selOff += L.selCap;
+        P.maxNodeCap = std::max(P.maxNodeCap, L.selCap + 2);
+        // resize tables (level l from level l-1), cv::resize INTER_LINEAR 8u, A.5
+        if (l > 0) {
+            const LevelInfo& S = P.L[l - 1];
+            const double inv_sx = (double)L.w / S.w, inv_sy = (double)L.h / S.h;
+            const double sx_ = 1. / inv_sx, sy_ = 1. / inv_sy;
+            L.tabX = (int)o->tabs.size();
+            for (int dx = 0; dx < L.w; ++dx) {
+                float fx = (float)((dx + 0.5) * sx_ - 0.5);
+                int sx = (int)std::floor(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
+                o->tabs.push_back((short)sx);
+                o->tabs.push_back((short)cvRoundF((1.f - fx) * 2048));
+                o->tabs.push_back((short)cvRoundF(fx * 2048));
+            }
+            L.tabY = (int)o->tabs.size();
+            for (int dy = 0; dy < L.h; ++dy) {
+                float fy = (float)((dy + 0.5) * sy_ - 0.5);
+                int sy = (int)std::floor(fy);
+                fy -= sy;
+                o->tabs.push_back((short)sy);
+                o->tabs.push_back((short)cvRoundF((1.f - fy) * 2048));
+                o->tabs.push_back((short)cvRoundF(fy * 2048));
+            }
+        }
+    }
+    P.pyrFrame = (off + 255) & ~(size_t)255;
+    P.nCellsFrame = (int)o->cells.size();
+    P.candFrame = std::max(candOff, 1);
+    P.selFrame = selOff;
+    if (o->dCells.ensure(std::max<size_t>(o->cells.size(), 1) * sizeof(CellInfo)) != SSLAM_OK) return SSLAM_ERR_HIP;
+    if (o->dTabs.ensure(std::max<size_t>(o->tabs.size(), 1) * sizeof(short)) != SSLAM_OK) return SSLAM_ERR_HIP;
+    if (!o->cells.empty()) SSLAM_HIP(hipMemcpy(o->dCells.p, o->cells.data(), o->cells.size() * sizeof(CellInfo), hipMemcpyHostToDevice));
+    if (!o->tabs.empty()) SSLAM_HIP(hipMemcpy(o->dTabs.p, o->tabs.data(), o->tabs.size() * sizeof(short), hipMemcpyHostToDevice));
+    o->planW = w; o->planH = h;
+    o->wsFrames = 0;
+    return SSLAM_OK;
+}
+
+static int ensure_workspace(sslam_orb* o, int nframes) {
+    if (nframes <= o->wsFrames) return SSLAM_OK;
+    const Plan& P = o->plan;
+    int rc;
+    if ((rc = o->dPyr.ensure(P.pyrFrame * nframes))) return rc;
+    if ((rc = o->dCellCount.ensure(sizeof(int) * (size_t)std::max(P.nCellsFrame, 1) * nframes))) return rc;
+    if ((rc = o->dCand.ensure(sizeof(unsigned) * (size_t)P.candFrame * nframes))) return rc;
+    if ((rc = o->dBufA.ensure(sizeof(unsigned) * (size_t)P.candFrame * nframes))) return rc;
+    if ((rc = o->dBufB.ensure(sizeof(unsigned) * (size_t)P.candFrame * nframes))) return rc;
+    if ((rc = o->dSel.ensure(sizeof(unsigned) * (size_t)P.selFrame * nframes))) return rc;
+    if ((rc = o->dSelCount.ensure(sizeof(int) * (size_t)P.nlevels * nframes))) return rc;
+    o->wsFrames = nframes;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_create(sslam_ctx* ctx, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, sslam_orb** out) {
+    if (!ctx || !out || nlevels < 1 || nlevels > MAX_LEVELS || nfeatures < 0 || !(scaleFactor > 1.0f) || minTh < 1 || iniTh < minTh || iniTh > 255) {
+        set_error("sslam_orb_create: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    sslam_orb* o = new sslam_orb();
+    o->ctx = ctx; o->nfeatures = nfeatures; o->nlevels = nlevels; o->iniTh = iniTh; o->minTh = minTh;
+    o->scaleFactorF = scaleFactor; o->scaleFactor = (double)scaleFactor;     // member is a double holding the float, include/ORBextractor.h:97
+    // src/ORBextractor.cc:415-446
+    o->scale.resize(nlevels); o->sigma2.resize(nlevels); o->invScale.resize(nlevels); o->invSigma2.resize(nlevels);
+    o->scale[0] = 1.0f; o->sigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; ++i) { o->scale[i] = (float)(o->scale[i - 1] * o->scaleFactor); o->sigma2[i] = o->scale[i] * o->scale[i]; }
+    for (int i = 0; i < nlevels; ++i) { o->invScale[i] = 1.0f / o->scale[i]; o->invSigma2[i] = 1.0f / o->sigma2[i]; }
+    o->perLevel.resize(nlevels);
+    float factor = (float)(1.0f / o->scaleFactor);
+    float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; ++l) { o->perLevel[l] = cvRoundF(nDesired); sum += o->perLevel[l]; nDesired *= factor; }
+    o->perLevel[nlevels - 1] = std::max(nfeatures - sum, 0);
+    // umax, :454-469
+    {
+        int v, v0, vmax = (int)std::floor(HALF_PATCH * std::sqrt(2.f) / 2 + 1);
+        int vmin = (int)std::ceil(HALF_PATCH * std::sqrt(2.f) / 2);
+        const double hp2 = HALF_PATCH * HALF_PATCH;
+        for (v = 0; v <= vmax; ++v) o->umax[v] = (int)lrint(std::sqrt(hp2 - v * v));
+        for (v = HALF_PATCH, v0 = 0; v >= vmin; --v) { while (o->umax[v0] == o->umax[v0 + 1]) ++v0; o->umax[v] = v0; ++v0; }
+    }
+    *out = o;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_destroy(sslam_orb* o) {
+    if (!o) return SSLAM_OK;
+    (void)hipSetDevice(o->ctx->device);
+    (void)hipStreamSynchronize(o->ctx->stream);
+    DevBuf* bufs[] = {&o->dCells, &o->dTabs, &o->dPyr, &o->dCellCount, &o->dCand, &o->dBufA, &o->dBufB, &o->dSel, &o->dSelCount, &o->dImg, &o->dKp, &o->dDesc, &o->dCounts};
+    for (DevBuf* b : bufs) b->release();
+    o->hImg.release(); o->hOut.release();
+    delete o;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_get_scales(const sslam_orb* o, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int32_t* per_level) {
+    if (!o) return SSLAM_ERR_INVALID;
+    for (int i = 0; i < o->nlevels; ++i) {
+        if (scale) scale[i] = o->scale[i];
+        if (inv_scale) inv_scale[i] = o->invScale[i];
+        if (sigma2) sigma2[i] = o->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = o->invSigma2[i];
+        if (per_level) per_level[i] = o->perLevel[i];
+    }
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_max_keypoints(const sslam_orb* o) {
+    if (!o) return SSLAM_ERR_INVALID;
+    int n = 0;
+    for (int l = 0; l < o->nlevels; ++l) n += std::max(o->perLevel[l] + 3, 4 * 8 + 1);
+    return n;
+}
+
+extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images, int w, int h, size_t pitch, size_t image_stride,
+                                           int nframes, sslam_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts, int cap, void* stream_) {
+    if (!o || !d_images || !d_kp || !d_desc || !d_counts || w <= 0 || h <= 0 || nframes <= 0 || cap <= 0 || pitch < (size_t)w) {
+        set_error("sslam_orb_extract_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    SSLAM_HIP(hipSetDevice(o->ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : o->ctx->stream;
+    int rc;
+    if (w != o->planW || h != o->planH) {
+        SSLAM_HIP(hipStreamSynchronize(st));
+        if ((rc = build_plan(o, w, h))) return rc;
+    }
+    if (!o->constsUploaded) {
+        std::vector<int> taps = blur_taps_q8(7, 2.0);
+        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kUmax), o->umax, sizeof(int) * 16));
+        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kBlurTaps), taps.data(), sizeof(int) * 7));
+        o->constsUploaded = true;
+    }
+    if (nframes > o->wsFrames) { SSLAM_HIP(hipStreamSynchronize(st)); }
+    if ((rc = ensure_workspace(o, nframes))) return rc;
+    const Plan& P = o->plan;
+    uint8_t* pyr = o->dPyr.as<uint8_t>();
+    {
+        dim3 blk(64), grd((w + 64 * 16 - 1) / (64 * 16), h, nframes);
+        hipLaunchKernelGGL(k_copy_level0, grd, blk, 0, st, d_images, pitch, image_stride, pyr, P.pyrFrame, w, h, P.L[0].pitch);
+    }
+    for (int l = 1; l < P.nlevels; ++l) {
+        dim3 blk(64, 4), grd((P.L[l].w + 255) / 256, (P.L[l].h + 3) / 4, nframes);
+        hipLaunchKernelGGL(k_resize, grd, blk, 0, st, pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short>());
+    }
+    if (P.nCellsFrame > 0) {
+        int tileP = (P.maxCellW + 6 + 3) & ~3, scP = P.maxCellW + 2;
+        size_t lds = (size_t)(P.maxCellH + 6) * tileP + (size_t)(P.maxCellH + 2) * scP + (size_t)P.maxCellH * P.maxCellW;
+        dim3 grd(P.nCellsFrame, nframes);
+        hipLaunchKernelGGL(k_fast_cells, grd, dim3(64), lds, st, pyr, P.pyrFrame, P, o->dCells.as<CellInfo>(), o->dCand.as<unsigned>(),
+                           o->dCellCount.as<int>(), o->iniTh, o->minTh, tileP, scP);
+    }
+    {
+        int NC = P.maxNodeCap + 2, NCp2 = 1;
+        while (NCp2 < NC) NCp2 <<= 1;
+        size_t lds = sizeof(unsigned long long) * 2 * NCp2 + sizeof(int) * (P.maxCellsLevel + 1) + sizeof(unsigned) * 5 * (size_t)NC;
+        dim3 grd(P.nlevels, nframes);
+        hipLaunchKernelGGL(k_octree, grd, dim3(64), lds, st, o->dCand.as<unsigned>(), o->dCellCount.as<int>(), o->dCells.as<CellInfo>(),
+                           o->dBufA.as<unsigned>(), o->dBufB.as<unsigned>(), o->dSel.as<unsigned>(), o->dSelCount.as<int>(), P, NC, NCp2);
+    }
+    {
+        dim3 grd(P.selFrame, nframes);
+        hipLaunchKernelGGL(k_describe, grd, dim3(64), 0, st, pyr, P.pyrFrame, P, o->dSel.as<unsigned>(), o->dSelCount.as<int>(),
+                           d_kp, d_desc, d_counts, cap);
+    }
+    SSLAM_HIP(hipGetLastError());
+    o->lastFrames = nframes;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_extract(sslam_orb* o, const uint8_t* gray, int w, int h, size_t stride,
+                                 sslam_keypoint* kp_out, uint8_t* desc_out, int cap, int* n_out) {
+    if (!o || !n_out) { set_error("sslam_orb_extract: null handle"); return SSLAM_ERR_INVALID; }
+    if (w == 0 || h == 0 || !gray) { *n_out = 0; return SSLAM_OK; }      // empty image: return, outputs untouched (:1046-1047)
+    if (w < 0 || h < 0 || stride < (size_t)w || !kp_out || !desc_out) { set_error("sslam_orb_extract: invalid arguments"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(o->ctx->mu);
+    SSLAM_HIP(hipSetDevice(o->ctx->device));
+    hipStream_t st = o->ctx->stream;
+    const int icap = sslam_orb_max_keypoints(o);
+    int rc;
+    const size_t dpitch = ((size_t)w + 63) & ~(size_t)63;
+    if ((rc = o->dImg.ensure(dpitch * h))) return rc;
+    if ((rc = o->dKp.ensure(sizeof(sslam_keypoint) * (size_t)icap))) return rc;
+    if ((rc = o->dDesc.ensure(32 * (size_t)icap))) return rc;
+    if ((rc = o->dCounts.ensure(sizeof(int) * 4))) return rc;
+    if ((rc = o->hOut.ensure((sizeof(sslam_keypoint) + 32) * (size_t)icap + 64))) return rc;
+    SSLAM_HIP(hipMemcpy2DAsync(o->dImg.p, dpitch, gray, stride, w, h, hipMemcpyHostToDevice, st));
+    if ((rc = sslam_orb_extract_batch_dev(o, o->dImg.as<uint8_t>(), w, h, dpitch, dpitch * h, 1, o->dKp.as<sslam_keypoint>(),
+                                          o->dDesc.as<uint8_t>(), o->dCounts.as<int>(), icap, st))) return rc;
+    uint8_t* hp = o->hOut.as<uint8_t>();
+    SSLAM_HIP(hipMemcpyAsync(hp, o->dCounts.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(hp + 64, o->dKp.p, sizeof(sslam_keypoint) * (size_t)icap, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(hp + 64 + sizeof(sslam_keypoint) * (size_t)icap, o->dDesc.p, 32 * (size_t)icap, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    int n = *(int*)hp;
+    *n_out = n;
+    if (n > cap) { set_error("sslam_orb_extract: %d keypoints exceed caller capacity %d", n, cap); return SSLAM_ERR_CAPACITY; }
+    memcpy(kp_out, hp + 64, sizeof(sslam_keypoint) * (size_t)n);
+    memcpy(desc_out, hp + 64 + sizeof(sslam_keypoint) * (size_t)icap, 32 * (size_t)n);
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_debug_level(sslam_orb* o, int frame, int level, uint8_t* out, int* w, int* h) {
+    if (!o || frame < 0 || frame >= o->lastFrames || level < 0 || level >= o->nlevels) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(o->ctx->device));
+    SSLAM_HIP(hipStreamSynchronize(o->ctx->stream));
+    const LevelInfo& L = o->plan.L[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (out) SSLAM_HIP(hipMemcpy2D(out, L.w, o->dPyr.as<uint8_t>() + (size_t)frame * o->plan.pyrFrame + L.off, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_debug_candidates(sslam_orb* o, int frame, int level, int32_t* xys, int cap, int* n_out) {
+    if (!o || frame < 0 || frame >= o->lastFrames || level < 0 || level >= o->nlevels || !n_out) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(o->ctx->device));
+    SSLAM_HIP(hipStreamSynchronize(o->ctx->stream));
+    const Plan& P = o->plan;
+    const LevelInfo& L = P.L[level];
+    std::vector<int> counts(std::max(L.nCells, 1));
+    std::vector<unsigned> cand(std::max(L.candCap, 1));
+    if (L.nCells) SSLAM_HIP(hipMemcpy(counts.data(), o->dCellCount.as<int>() + (size_t)frame * P.nCellsFrame + L.cellBeg, sizeof(int) * L.nCells, hipMemcpyDeviceToHost));
+    if (L.candCap) SSLAM_HIP(hipMemcpy(cand.data(), o->dCand.as<unsigned>() + (size_t)frame * P.candFrame + L.candOff, sizeof(unsigned) * L.candCap, hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int c = 0; c < L.nCells; ++c) {
+        const CellInfo& ci = o->cells[L.cellBeg + c];
+        for (int k = 0; k < counts[c]; ++k, ++n) {
+            if (n < cap) {
+                unsigned v = cand[ci.candOff - L.candOff + k];
+                xys[n * 3] = v & 0xFFF; xys[n * 3 + 1] = (v >> 12) & 0xFFF; xys[n * 3 + 2] = v >> 24;
+            }
+        }
+    }
+    *n_out = n;
+    return SSLAM_OK;
+}

@@ -1,0 +1,192 @@
+"""ctypes binding of libsslam_frontend.so (include/sslam_frontend.h) for the tests
+and bench.py.  The product is the C-ABI library + the C++ shim in shim/; this module
+is the harness-side view of the same entry points.  It never falls back to a CPU
+path: loading fails loudly if the HIP library is missing, and every call raises on
+a non-zero status."""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsslam_frontend.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+KL_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"),
+                     ("pt_x", "<f4"), ("pt_y", "<f4"), ("response", "<f4"), ("size", "<f4"),
+                     ("startPointX", "<f4"), ("startPointY", "<f4"), ("endPointX", "<f4"), ("endPointY", "<f4"),
+                     ("sPointInOctaveX", "<f4"), ("sPointInOctaveY", "<f4"),
+                     ("ePointInOctaveX", "<f4"), ("ePointInOctaveY", "<f4"),
+                     ("lineLength", "<f4"), ("numOfPixels", "<i4")])
+assert KP_DTYPE.itemsize == 28 and KL_DTYPE.itemsize == 68
+
+_lib = None
+
+
+class SslamError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SslamError("HIP library %s not built (run __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.sslam_status_str.restype = C.c_char_p
+        _lib.sslam_last_error.restype = C.c_char_p
+        _lib.sslam_ctx_stream.restype = C.c_void_p
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        L = lib()
+        raise SslamError("%s: %s" % (L.sslam_status_str(rc).decode(), L.sslam_last_error().decode()))
+
+
+def _p(a):
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):          # torch tensor (device or host)
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))
+
+
+class Context:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().sslam_ctx_create(int(device), C.byref(self.h)))
+
+    def synchronize(self):
+        _chk(lib().sslam_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return lib().sslam_ctx_stream(self.h)
+
+    def close(self):
+        if self.h:
+            lib().sslam_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    # ---- Hamming ------------------------------------------------------------
+    def hamming_knn2(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+        nq, nt = q.shape[0], t.shape[0]
+        idx = np.full((nq, 2), -1, np.int32); dist = np.full((nq, 2), -1, np.int32)
+        _chk(lib().sslam_hamming_knn2(self.h, _p(q), nq, _p(t), nt, _p(idx), _p(dist)))
+        return idx, dist
+
+    def hamming_matrix(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+        D = np.zeros((q.shape[0], t.shape[0]), np.uint16)
+        _chk(lib().sslam_hamming_matrix(self.h, _p(q), q.shape[0], _p(t), t.shape[0], _p(D)))
+        return D
+
+    def search_for_initialization(self, kp1, d1, kp2, d2, prev_matched, window=100, nnratio=0.9,
+                                  check_orientation=True, bounds=(0.0, 640.0, 0.0, 480.0)):
+        kp1 = np.ascontiguousarray(kp1); kp2 = np.ascontiguousarray(kp2)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+        m12 = np.full(len(kp1), -1, np.int32)
+        n = C.c_int(0)
+        b = (C.c_float * 4)(*bounds)
+        _chk(lib().sslam_orb_search_for_initialization(self.h, _p(kp1), _p(d1), len(kp1), _p(kp2), _p(d2), len(kp2),
+                                                       _p(pm), _p(m12), int(window), C.c_float(nnratio),
+                                                       int(bool(check_orientation)), b, C.byref(n)))
+        return m12, pm, n.value
+
+    def line_match(self, l1, l2, gate_scale=0.5, ratio_mode=False):
+        l1 = np.ascontiguousarray(l1, np.uint8); l2 = np.ascontiguousarray(l2, np.uint8)
+        cap = max(len(l1), 1)
+        pairs = np.zeros((cap, 2), np.int32)
+        n = C.c_int(0); mad = C.c_double(0); mad12 = C.c_double(0)
+        _chk(lib().sslam_line_match(self.h, _p(l1), len(l1), _p(l2), len(l2), C.c_double(gate_scale), int(bool(ratio_mode)),
+                                    _p(pairs), cap, C.byref(n), C.byref(mad), C.byref(mad12)))
+        return pairs[:n.value].copy(), mad.value, mad12.value
+
+
+class OrbExtractor:
+    """Harness-side mirror of StructureSLAM::ORBextractor (include/ORBextractor.h:45-111)."""
+
+    def __init__(self, ctx, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.ctx = ctx
+        self.nlevels = nlevels
+        self.h = C.c_void_p()
+        _chk(lib().sslam_orb_create(ctx.h, int(nfeatures), C.c_float(scale_factor), int(nlevels), int(ini_th), int(min_th), C.byref(self.h)))
+        self.cap = lib().sslam_orb_max_keypoints(self.h)
+
+    def scales(self):
+        n = self.nlevels
+        s = np.zeros(n, np.float32); i = np.zeros(n, np.float32); g = np.zeros(n, np.float32); ig = np.zeros(n, np.float32)
+        f = np.zeros(n, np.int32)
+        _chk(lib().sslam_orb_get_scales(self.h, _p(s), _p(i), _p(g), _p(ig), _p(f)))
+        return s, i, g, ig, f
+
+    def __call__(self, gray):
+        """operator()(image, mask, keypoints, descriptors) on a host image."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape if gray.ndim == 2 else (0, 0)
+        kp = np.zeros(self.cap, KP_DTYPE); desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int(0)
+        _chk(lib().sslam_orb_extract(self.h, _p(gray), w, h, C.c_size_t(gray.strides[0] if gray.ndim == 2 and h else 0),
+                                     _p(kp), _p(desc), self.cap, C.byref(n)))
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch_dev(self, d_images, w, h, pitch, image_stride, nframes, d_kp, d_desc, d_counts, cap, stream=None):
+        _chk(lib().sslam_orb_extract_batch_dev(self.h, _p(d_images), int(w), int(h), C.c_size_t(pitch), C.c_size_t(image_stride),
+                                               int(nframes), _p(d_kp), _p(d_desc), _p(d_counts), int(cap), C.c_void_p(stream or 0)))
+
+    def debug_level(self, frame, level):
+        w = C.c_int(0); h = C.c_int(0)
+        _chk(lib().sslam_orb_debug_level(self.h, frame, level, C.c_void_p(0), C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _chk(lib().sslam_orb_debug_level(self.h, frame, level, _p(out), C.byref(w), C.byref(h)))
+        return out
+
+    def debug_candidates(self, frame, level, cap=400000):
+        out = np.zeros((cap, 3), np.int32); n = C.c_int(0)
+        _chk(lib().sslam_orb_debug_candidates(self.h, frame, level, _p(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def close(self):
+        if self.h:
+            lib().sslam_orb_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class LineExtractor:
+    """Harness-side mirror of LineSegment::ExtractLineSegment (src/ExtractLineSegment.cpp:18-69)."""
+
+    def __init__(self, ctx, max_lines=40):
+        self.ctx = ctx
+        self.max_lines = max_lines
+        self.h = C.c_void_p()
+        _chk(lib().sslam_lines_create(ctx.h, int(max_lines), C.byref(self.h)))
+
+    def __call__(self, gray, cap=None):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        cap = cap or 8192
+        kl = np.zeros(cap, KL_DTYPE); ld = np.zeros((cap, 32), np.uint8); fn = np.zeros((cap, 3), np.float64)
+        n = C.c_int(0)
+        _chk(lib().sslam_lines_extract(self.h, _p(gray), w, h, C.c_size_t(gray.strides[0]), _p(kl), _p(ld), _p(fn), cap, C.byref(n)))
+        return kl[:n.value].copy(), ld[:n.value].copy(), fn[:n.value].copy()
+
+    def extract_batch_dev(self, d_images, w, h, pitch, image_stride, nframes, d_kl, d_ldesc, d_linefn, d_counts, cap, stream=None):
+        _chk(lib().sslam_lines_extract_batch_dev(self.h, _p(d_images), int(w), int(h), C.c_size_t(pitch), C.c_size_t(image_stride),
+                                                 int(nframes), _p(d_kl), _p(d_ldesc), _p(d_linefn), _p(d_counts), int(cap),
+                                                 C.c_void_p(stream or 0)))
+
+    def debug_segments(self, frame, cap=20000):
+        out = np.zeros((cap, 4), np.float32); n = C.c_int(0)
+        _chk(lib().sslam_lines_debug_segments(self.h, frame, _p(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def close(self):
+        if self.h:
+            lib().sslam_lines_destroy(self.h)
+            self.h = C.c_void_p()
