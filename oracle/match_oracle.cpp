@@ -1,0 +1,218 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see cvleaf.h header).  PARITY UNPINNED.
+//
+// CPU restatement of the reference's Hamming matchers on the hot path:
+//   ORBmatcher::DescriptorDistance      src/ORBmatcher.cc:1650-1666
+//   ORBmatcher::SearchForInitialization src/ORBmatcher.cc:408-523
+//   ORBmatcher::ComputeThreeMaxima      src/ORBmatcher.cc:1604-1645
+//   Frame::AssignFeaturesToGrid/PosInGrid/GetFeaturesInArea  src/Frame.cc:133-148,462-472,368-421
+//   cv::BFMatcher(NORM_HAMMING,false).knnMatch(q,t,m,2)      (OpenCV batch_distance.cpp, A.10)
+//   Frame::lineDescriptorMAD            src/Frame.cc:190-215
+//   LSDmatcher::SerachForInitialize / SearchByProjection(KF,F) / SearchForTriangulation gates
+//                                       src/LSDmatcher.cpp:143-183,257-284,382-415
+#include "oracle.h"
+#include <vector>
+#include <cmath>
+#include <climits>
+#include <algorithm>
+#include <cstring>
+
+namespace orc {
+
+static const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;      // src/ORBmatcher.cc:37-39
+static const int GRID_COLS = 64, GRID_ROWS = 48;                      // include/Frame.h:45-46
+
+struct KPm { float x, y, size, angle, response; int octave, class_id; };
+
+static int descriptor_distance(const uint8_t* a, const uint8_t* b) {
+    const int32_t* pa = (const int32_t*)a; const int32_t* pb = (const int32_t*)b;
+    int dist = 0;
+    for (int i = 0; i < 8; ++i, ++pa, ++pb) {
+        unsigned v = *pa ^ *pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+// knnMatch(..., 2): ascending distance, ties -> lower train index
+static void knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist) {
+    for (int i = 0; i < nq; ++i) {
+        int bd[2] = {INT_MAX, INT_MAX}, bi[2] = {-1, -1};
+        for (int j = 0; j < nt; ++j) {
+            int d = descriptor_distance(q + (size_t)i * 32, t + (size_t)j * 32);
+            if (d < bd[1]) {
+                int k = 0;
+                if (d < bd[0]) { bd[1] = bd[0]; bi[1] = bi[0]; k = 0; } else k = 1;
+                bd[k] = d; bi[k] = j;
+            }
+        }
+        for (int k = 0; k < 2; ++k) { idx[i * 2 + k] = bi[k]; dist[i * 2 + k] = bi[k] >= 0 ? bd[k] : -1; }
+    }
+}
+
+struct FrameGrid {
+    float minX, maxX, minY, maxY, invW, invH;
+    std::vector<int> cells[GRID_COLS][GRID_ROWS];
+    const KPm* kps; int n;
+    void build(const KPm* k, int n_, const float b[4]) {
+        kps = k; n = n_;
+        minX = b[0]; maxX = b[1]; minY = b[2]; maxY = b[3];
+        invW = (float)GRID_COLS / (maxX - minX);               // src/Frame.cc:108-109
+        invH = (float)GRID_ROWS / (maxY - minY);
+        for (int i = 0; i < n; ++i) {
+            int px = (int)std::round((k[i].x - minX) * invW), py = (int)std::round((k[i].y - minY) * invH);
+            if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
+            cells[px][py].push_back(i);
+        }
+    }
+    std::vector<int> in_area(float x, float y, float r, int minLevel, int maxLevel) const {
+        std::vector<int> out;
+        const int nMinCellX = std::max(0, (int)std::floor((x - minX - r) * invW));
+        if (nMinCellX >= GRID_COLS) return out;
+        const int nMaxCellX = std::min(GRID_COLS - 1, (int)std::ceil((x - minX + r) * invW));
+        if (nMaxCellX < 0) return out;
+        const int nMinCellY = std::max(0, (int)std::floor((y - minY - r) * invH));
+        if (nMinCellY >= GRID_ROWS) return out;
+        const int nMaxCellY = std::min(GRID_ROWS - 1, (int)std::ceil((y - minY + r) * invH));
+        if (nMaxCellY < 0) return out;
+        const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
+            for (int iy = nMinCellY; iy <= nMaxCellY; ++iy)
+                for (int j : cells[ix][iy]) {
+                    const KPm& kp = kps[j];
+                    if (checkLevels) {
+                        if (kp.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                    }
+                    const float dx = kp.x - x, dy = kp.y - y;
+                    if (std::fabs(dx) < r && std::fabs(dy) < r) out.push_back(j);
+                }
+        return out;
+    }
+};
+
+static void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; ++i) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) ind3 = -1;
+}
+
+static int search_for_initialization(const KPm* kp1, const uint8_t* d1, int n1, const KPm* kp2, const uint8_t* d2, int n2,
+                                     float* prevMatched, int32_t* m12, int windowSize, float nnratio, bool checkOri,
+                                     const float bounds[4]) {
+    int nmatches = 0;
+    for (int i = 0; i < n1; ++i) m12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> matchedDist(n2, INT_MAX), m21(n2, -1);
+    FrameGrid* g = new FrameGrid();
+    g->build(kp2, n2, bounds);
+    for (int i1 = 0; i1 < n1; ++i1) {
+        const KPm& k1 = kp1[i1];
+        int level1 = k1.octave;
+        if (level1 > 0) continue;
+        std::vector<int> ind2 = g->in_area(prevMatched[i1 * 2], prevMatched[i1 * 2 + 1], (float)windowSize, level1, level1);
+        if (ind2.empty()) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int i2 : ind2) {
+            int dist = descriptor_distance(d1 + (size_t)i1 * 32, d2 + (size_t)i2 * 32);
+            if (matchedDist[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (m21[bestIdx2] >= 0) { m12[m21[bestIdx2]] = -1; nmatches--; }
+                m12[i1] = bestIdx2; m21[bestIdx2] = i1; matchedDist[bestIdx2] = bestDist; nmatches++;
+                if (checkOri) {
+                    float rot = kp1[i1].angle - kp2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i]) if (m12[idx1] >= 0) { m12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; ++i1)
+        if (m12[i1] >= 0) { prevMatched[i1 * 2] = kp2[m12[i1]].x; prevMatched[i1 * 2 + 1] = kp2[m12[i1]].y; }
+    delete g;
+    return nmatches;
+}
+
+// Frame::lineDescriptorMAD on knn-2 results (only medians are consumed, so std::sort's
+// instability is harmless)
+static void line_descriptor_mad(const int32_t* dist, int n, double& nn_mad, double& nn12_mad) {
+    std::vector<float> a(n);
+    for (int i = 0; i < n; ++i) a[i] = (float)dist[i * 2];
+    std::sort(a.begin(), a.end());
+    double med = a[n / 2];
+    for (int i = 0; i < n; ++i) a[i] = fabsf((float)(a[i] - med));
+    std::sort(a.begin(), a.end());
+    nn_mad = 1.4826 * a[n / 2];
+    std::vector<float> g(n);
+    for (int i = 0; i < n; ++i) g[i] = (float)dist[i * 2 + 1] - (float)dist[i * 2];
+    std::sort(g.begin(), g.end(), [](float x, float y) { return x > y; });
+    double med12 = g[n / 2];
+    for (int i = 0; i < n; ++i) g[i] = fabsf((float)(g[i] - med12));
+    std::sort(g.begin(), g.end());
+    nn12_mad = 1.4826 * g[n / 2];
+}
+
+}  // namespace orc
+
+using namespace orc;
+
+extern "C" {
+
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
+
+int orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist) { knn2(q, nq, t, nt, idx, dist); return 0; }
+
+int orc_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* D) {
+    for (int i = 0; i < nq; ++i) for (int j = 0; j < nt; ++j) D[(size_t)i * nt + j] = (uint16_t)descriptor_distance(q + (size_t)i * 32, t + (size_t)j * 32);
+    return 0;
+}
+
+int orc_search_for_initialization(const void* kp1, const uint8_t* d1, int n1, const void* kp2, const uint8_t* d2, int n2,
+                                  float* prev_matched, int32_t* m12, int window, float nnratio, int check_ori, const float* bounds) {
+    return search_for_initialization((const KPm*)kp1, d1, n1, (const KPm*)kp2, d2, n2, prev_matched, m12, window, nnratio, check_ori != 0, bounds);
+}
+
+// LSDmatcher gates.  Degenerate inputs (n1==0 or n2<2) are UB in the reference
+// (src/LSDmatcher.cpp:167); defined here (and in the HIP library) as "0 matches".
+int orc_line_match(const uint8_t* l1, int n1, const uint8_t* l2, int n2, double gate_scale, int ratio_mode,
+                   int32_t* pairs, int cap, double* nn_mad, double* nn12_mad) {
+    *nn_mad = 0; *nn12_mad = 0;
+    if (n1 <= 0 || n2 < 2) return 0;
+    std::vector<int32_t> idx(n1 * 2), dist(n1 * 2);
+    knn2(l1, n1, l2, n2, idx.data(), dist.data());
+    line_descriptor_mad(dist.data(), n1, *nn_mad, *nn12_mad);
+    double th = *nn12_mad * gate_scale;
+    const float minRatio = 1.0f / 1.5f;
+    int n = 0;
+    for (int i = 0; i < n1; ++i) {
+        bool ok;
+        if (ratio_mode) { double r = (float)dist[i * 2] / (float)dist[i * 2 + 1]; ok = r < minRatio; }
+        else { double g = (float)dist[i * 2 + 1] - (float)dist[i * 2]; ok = g > th; }
+        if (ok) { if (n < cap) { pairs[n * 2] = i; pairs[n * 2 + 1] = idx[i * 2]; } ++n; }
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,437 @@
+// Hamming matchers for MI355X (gfx950): brute-force knn-2 (BFMatcher semantics),
+// dense distance matrix, ORBmatcher::SearchForInitialization and the LSDmatcher
+// knn2+MAD gates — device side of reference src/ORBmatcher.cc:408-523,1604-1666,
+// src/LSDmatcher.cpp:143-183,257-284,364-415, src/Frame.cc:133-148,190-215,368-472.
+//
+// The path is integer/bitwise: v_bcnt popcounts on 8x u32 XORs, wave-wide min
+// reductions with the tie-break order carried in the key; no MFMA.
+#include "common.h"
+#include <algorithm>
+
+using namespace sslam;
+
+namespace {
+
+constexpr int TH_LOW = 50;
+constexpr int HISTO_LENGTH = 30;
+constexpr int GRID_COLS = 64, GRID_ROWS = 48;
+
+__device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// one wave per query; lanes stride the train set (coalesced 32 B per lane).
+// key = dist<<32 | idx so the minimum resolves ties to the lower train index (A.10).
+__device__ __forceinline__ void wave_knn2(const uint8_t* __restrict__ qd, const uint8_t* __restrict__ t, int nt,
+                                          unsigned long long& best, unsigned long long& second) {
+    const int lane = threadIdx.x & 63;
+    const uint4 q0 = ((const uint4*)qd)[0], q1 = ((const uint4*)qd)[1];
+    unsigned long long b = ~0ull, s = ~0ull;
+    for (int j = lane; j < nt; j += 64) {
+        const uint4* tp = (const uint4*)(t + (size_t)j * 32);
+        unsigned long long k = ((unsigned long long)hamming256(q0, q1, tp[0], tp[1]) << 32) | (unsigned)j;
+        if (k < b) { s = b; b = k; } else if (k < s) s = k;
+    }
+    best = wave_min_u64(b);
+    unsigned long long c = (b == best) ? s : b;
+    second = wave_min_u64(c);
+}
+
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                              int* __restrict__ idx, int* __restrict__ dist) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave >= nq) return;
+    unsigned long long b, s;
+    wave_knn2(q + (size_t)wave * 32, t, nt, b, s);
+    if ((threadIdx.x & 63) == 0) {
+        idx[wave * 2] = b == ~0ull ? -1 : (int)(unsigned)b;
+        dist[wave * 2] = b == ~0ull ? -1 : (int)(b >> 32);
+        idx[wave * 2 + 1] = s == ~0ull ? -1 : (int)(unsigned)s;
+        dist[wave * 2 + 1] = s == ~0ull ? -1 : (int)(s >> 32);
+    }
+}
+
+__global__ void k_hamming_matrix(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt, unsigned short* __restrict__ D) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= nt || i >= nq) return;
+    const uint4* qp = (const uint4*)(q + (size_t)i * 32);
+    const uint4* tp = (const uint4*)(t + (size_t)j * 32);
+    D[(size_t)i * nt + j] = (unsigned short)hamming256(qp[0], qp[1], tp[0], tp[1]);
+}
+
+// ---------------------------------------------------------------- SearchForInitialization
+// One wave per frame pair.  The i1 loop is sequential (vMatchedDistance / un-match
+// semantics); the candidate scan of each step is wave-parallel.  The
+// GetFeaturesInArea order (grid cell x-major, then y, then index — D.4) is carried in
+// the reduction key so "first strictly smaller distance wins" is reproduced.
+struct SfiArgs {
+    const sslam_keypoint* kp1; const uint8_t* d1; const int* n1;
+    const sslam_keypoint* kp2; const uint8_t* d2; const int* n2;
+    int cap, n1s, n2s;             // n1s/n2s used when n1/n2 pointers are null
+    float* prevMatched; int* m12; int* nmatches;
+    int* scratch;                  // per pair: matchedDist[cap], m21[cap], cand[cap], key[cap], bin[cap]
+    int window; float nnratio; int checkOri;
+    float minX, maxX, minY, maxY;
+};
+
+__global__ __launch_bounds__(64) void k_search_init(SfiArgs A) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int n1 = A.n1 ? A.n1[p] : A.n1s, n2 = A.n2 ? A.n2[p] : A.n2s;
+    const sslam_keypoint* kp1 = A.kp1 + (size_t)p * A.cap;
+    const sslam_keypoint* kp2 = A.kp2 + (size_t)p * A.cap;
+    const uint8_t* d1 = A.d1 + (size_t)p * A.cap * 32;
+    const uint8_t* d2 = A.d2 + (size_t)p * A.cap * 32;
+    float* pm = A.prevMatched + (size_t)p * A.cap * 2;
+    int* m12 = A.m12 + (size_t)p * A.cap;
+    int* matchedDist = A.scratch + (size_t)p * A.cap * 5;
+    int* m21 = matchedDist + A.cap;
+    int* cand = m21 + A.cap;       // compact list of F2 level-0, in-grid keypoints
+    int* ckey = cand + A.cap;      // their GetFeaturesInArea order key
+    int* binOf = ckey + A.cap;     // rotation bin of i1 (or -1)
+    __shared__ int hist[HISTO_LENGTH];
+
+    const float invW = __fdiv_rn((float)GRID_COLS, __fsub_rn(A.maxX, A.minX));
+    const float invH = __fdiv_rn((float)GRID_ROWS, __fsub_rn(A.maxY, A.minY));
+    for (int i = lane; i < n1; i += 64) { m12[i] = -1; binOf[i] = -1; }
+    for (int i = lane; i < n2; i += 64) { matchedDist[i] = 0x7FFFFFFF; m21[i] = -1; }
+    if (lane < HISTO_LENGTH) hist[lane] = 0;
+    // candidates of level 0 that sit in the 64x48 grid (PosInGrid, src/Frame.cc:462-472)
+    int nc = 0;
+    for (int j0 = 0; j0 < n2; j0 += 64) {
+        int j = j0 + lane;
+        bool ok = false; int key = 0;
+        if (j < n2) {
+            const sslam_keypoint k = kp2[j];
+            int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, A.minX), invW));
+            int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, A.minY), invH));
+            ok = k.octave == 0 && px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS;     // level1 == 0 -> minLevel=maxLevel=0
+            key = ((px * GRID_ROWS + py) << 19) | j;
+        }
+        unsigned long long m = __ballot(ok);
+        if (ok) { int o = nc + mbcnt(m); cand[o] = j; ckey[o] = key; }
+        nc += __popcll(m);
+    }
+    __syncthreads();
+    int nmatches = 0;
+    const float r = (float)A.window;
+    for (int i1 = 0; i1 < n1; ++i1) {
+        const int level1 = kp1[i1].octave;
+        if (level1 > 0) continue;
+        const float cx = pm[i1 * 2], cy = pm[i1 * 2 + 1];
+        const uint4 q0 = ((const uint4*)(d1 + (size_t)i1 * 32))[0], q1 = ((const uint4*)(d1 + (size_t)i1 * 32))[1];
+        unsigned long long b = ~0ull; unsigned s2 = 0x7FFFFFFFu;    // best key (dist<<32|orderkey), second-best distance
+        for (int c = lane; c < nc; c += 64) {
+            const int j = cand[c];
+            const float dx = __fsub_rn(kp2[j].x, cx), dy = __fsub_rn(kp2[j].y, cy);
+            if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+            const uint4* tp = (const uint4*)(d2 + (size_t)j * 32);
+            const int dist = hamming256(q0, q1, tp[0], tp[1]);
+            if (matchedDist[j] <= dist) continue;
+            unsigned long long k = ((unsigned long long)dist << 32) | (unsigned)ckey[c];
+            if (k < b) { if (b != ~0ull) s2 = min(s2, (unsigned)(b >> 32)); b = k; }
+            else s2 = min(s2, (unsigned)dist);
+        }
+        const unsigned long long best = wave_min_u64(b);
+        if (best == ~0ull) continue;                   // vIndices2 empty, or every candidate suppressed: bestDist stays INT_MAX
+        unsigned other = (b == best) ? s2 : min(s2, (unsigned)(b >> 32));
+        if (b == ~0ull) other = 0x7FFFFFFFu;
+        const unsigned second = wave_min_u32(other);
+        const int bestDist = (int)(best >> 32);
+        const int bestIdx2 = (int)(best & 0x7FFFF);
+        if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn((float)(int)second, A.nnratio)) {
+            const int prev = m21[bestIdx2];
+            if (prev >= 0) { if (lane == 0) m12[prev] = -1; nmatches--; }
+            if (lane == 0) { m12[i1] = bestIdx2; m21[bestIdx2] = i1; matchedDist[bestIdx2] = bestDist; }
+            nmatches++;
+            if (A.checkOri) {
+                float rot = __fsub_rn(kp1[i1].angle, kp2[bestIdx2].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (lane == 0) { binOf[i1] = bin; hist[bin]++; }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (A.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;      // ComputeThreeMaxima
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+        int removed = 0;
+        for (int i0 = 0; i0 < n1; i0 += 64) {
+            int i = i0 + lane;
+            bool rm = false;
+            if (i < n1) {
+                int bn = binOf[i];
+                rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3 && m12[i] >= 0;
+                if (rm) m12[i] = -1;
+            }
+            removed += __popcll(__ballot(rm));
+        }
+        nmatches -= removed;
+    }
+    __syncthreads();
+    for (int i = lane; i < n1; i += 64) {
+        int m = m12[i];
+        if (m >= 0) { pm[i * 2] = kp2[m].x; pm[i * 2 + 1] = kp2[m].y; }
+    }
+    if (lane == 0) A.nmatches[p] = nmatches;
+}
+
+// ---------------------------------------------------------------- line matching
+// One 256-thread workgroup per frame pair: knn-2 of n1 query LBD descriptors against
+// n2 train descriptors, Frame::lineDescriptorMAD (medians via LDS bitonic sorts), then
+// the MAD-gap or ratio gate, pairs emitted in query order.
+constexpr int LM_MAX = 1024;
+
+__device__ void lds_sort_asc(float* a, int P2) {
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P2; i += blockDim.x) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    float x = a[i], y = a[ixj];
+                    bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(256) void k_line_match(const uint8_t* __restrict__ l1, const int* __restrict__ n1p, int n1s,
+                                                    const uint8_t* __restrict__ l2, const int* __restrict__ n2p, int n2s, int cap,
+                                                    double gateScale, int ratioMode, int* __restrict__ pairs, int* __restrict__ npairs,
+                                                    double* __restrict__ madOut) {
+    __shared__ int bd[LM_MAX], sd[LM_MAX], bi[LM_MAX];
+    __shared__ float srt[LM_MAX];
+    __shared__ int wcount[4];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n1 = n1p ? n1p[p] : n1s, n2 = n2p ? n2p[p] : n2s;
+    const uint8_t* q = l1 + (size_t)p * cap * 32;
+    const uint8_t* t = l2 + (size_t)p * cap * 32;
+    int* out = pairs + (size_t)p * cap * 2;
+    if (n1 <= 0 || n2 < 2 || n1 > LM_MAX) {      // degenerate (UB in the reference, src/LSDmatcher.cpp:167): defined as 0 matches
+        if (tid == 0) { npairs[p] = 0; if (madOut) { madOut[p * 2] = 0; madOut[p * 2 + 1] = 0; } }
+        return;
+    }
+    for (int i = wv; i < n1; i += 4) {
+        unsigned long long b, s;
+        wave_knn2(q + (size_t)i * 32, t, n2, b, s);
+        if (lane == 0) { bd[i] = (int)(b >> 32); bi[i] = (int)(unsigned)b; sd[i] = (int)(s >> 32); }
+    }
+    __syncthreads();
+    int P2 = 1; while (P2 < n1) P2 <<= 1;
+    const float INF = 3.0e38f;
+    // NN distance MAD
+    for (int i = tid; i < P2; i += 256) srt[i] = i < n1 ? (float)bd[i] : INF;
+    __syncthreads();
+    lds_sort_asc(srt, P2);
+    const double med = srt[n1 / 2];
+    __syncthreads();
+    for (int i = tid; i < P2; i += 256) srt[i] = i < n1 ? fabsf((float)((double)(float)bd[i] - med)) : INF;
+    __syncthreads();
+    lds_sort_asc(srt, P2);
+    const double nnMad = 1.4826 * (double)srt[n1 / 2];
+    __syncthreads();
+    // NN12 gap MAD: median of the gaps sorted DESCENDING = ascending element n1-1-n1/2
+    for (int i = tid; i < P2; i += 256) srt[i] = i < n1 ? __fsub_rn((float)sd[i], (float)bd[i]) : INF;
+    __syncthreads();
+    lds_sort_asc(srt, P2);
+    const double med12 = srt[n1 - 1 - n1 / 2];
+    __syncthreads();
+    for (int i = tid; i < P2; i += 256) srt[i] = i < n1 ? fabsf((float)((double)__fsub_rn((float)sd[i], (float)bd[i]) - med12)) : INF;
+    __syncthreads();
+    lds_sort_asc(srt, P2);
+    const double nn12Mad = 1.4826 * (double)srt[n1 / 2];
+    const double th = nn12Mad * gateScale;
+    const float minRatio = 1.0f / 1.5f;
+    __syncthreads();
+    // gate + ordered compaction
+    int base = 0;
+    for (int i0 = 0; i0 < n1; i0 += 256) {
+        int i = i0 + tid;
+        bool ok = false;
+        if (i < n1) {
+            if (ratioMode) ok = (double)__fdiv_rn((float)bd[i], (float)sd[i]) < (double)minRatio;
+            else ok = (double)__fsub_rn((float)sd[i], (float)bd[i]) > th;
+        }
+        unsigned long long m = __ballot(ok);
+        if (lane == 0) wcount[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; ++w) off += wcount[w];
+        if (ok) { int o = off + mbcnt(m); if (o < cap) { out[o * 2] = i; out[o * 2 + 1] = bi[i]; } }
+        base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    if (tid == 0) { npairs[p] = base; if (madOut) { madOut[p * 2] = nnMad; madOut[p * 2 + 1] = nn12Mad; } }
+}
+
+}  // namespace
+
+// =============================================================== host side
+static hipStream_t pick(sslam_ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
+
+extern "C" int sslam_hamming_knn2_dev(sslam_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx, int32_t* d_dist, void* stream) {
+    if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_idx || !d_dist))) { set_error("sslam_hamming_knn2_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
+    if (nq == 0) return SSLAM_OK;
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, pick(ctx, stream), d_q, nq, d_t, nt, d_idx, d_dist);
+    SSLAM_HIP(hipGetLastError());
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_hamming_knn2(sslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist) {
+    if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t)) { set_error("sslam_hamming_knn2: invalid arguments"); return SSLAM_ERR_INVALID; }
+    if (nq == 0) return SSLAM_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ctx->scratch[0].ensure((size_t)nq * 32))) return rc;
+    if ((rc = ctx->scratch[1].ensure((size_t)std::max(nt, 1) * 32))) return rc;
+    if ((rc = ctx->scratch[2].ensure((size_t)nq * 16))) return rc;
+    hipStream_t st = ctx->stream;
+    SSLAM_HIP(hipMemcpyAsync(ctx->scratch[0].p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    if (nt) SSLAM_HIP(hipMemcpyAsync(ctx->scratch[1].p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+    int* di = ctx->scratch[2].as<int>();
+    if ((rc = sslam_hamming_knn2_dev(ctx, ctx->scratch[0].as<uint8_t>(), nq, ctx->scratch[1].as<uint8_t>(), nt, di, di + (size_t)nq * 2, st))) return rc;
+    SSLAM_HIP(hipMemcpyAsync(idx, di, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(dist, di + (size_t)nq * 2, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_hamming_matrix(sslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* D) {
+    if (!ctx || nq < 0 || nt < 0 || ((nq > 0 && nt > 0) && (!q || !t || !D))) { set_error("sslam_hamming_matrix: invalid arguments"); return SSLAM_ERR_INVALID; }
+    if (nq == 0 || nt == 0) return SSLAM_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ctx->scratch[0].ensure((size_t)nq * 32))) return rc;
+    if ((rc = ctx->scratch[1].ensure((size_t)nt * 32))) return rc;
+    if ((rc = ctx->scratch[2].ensure((size_t)nq * nt * 2))) return rc;
+    hipStream_t st = ctx->stream;
+    SSLAM_HIP(hipMemcpyAsync(ctx->scratch[0].p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(ctx->scratch[1].p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_hamming_matrix, dim3((nt + 255) / 256, nq), dim3(256), 0, st, ctx->scratch[0].as<uint8_t>(), nq,
+                       ctx->scratch[1].as<uint8_t>(), nt, ctx->scratch[2].as<unsigned short>());
+    SSLAM_HIP(hipGetLastError());
+    SSLAM_HIP(hipMemcpyAsync(D, ctx->scratch[2].p, (size_t)nq * nt * 2, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_search_for_initialization_batch_dev(sslam_ctx* ctx,
+        const sslam_keypoint* d_kp1, const uint8_t* d_desc1, const int32_t* d_n1,
+        const sslam_keypoint* d_kp2, const uint8_t* d_desc2, const int32_t* d_n2,
+        int cap, int npairs, float* d_prev, int32_t* d_m12, int32_t* d_nm,
+        int window, float nnratio, int checkOri, const float bounds[4], void* stream) {
+    if (!ctx || !d_kp1 || !d_desc1 || !d_kp2 || !d_desc2 || !d_n1 || !d_n2 || !d_prev || !d_m12 || !d_nm || cap <= 0 || cap >= (1 << 19) || npairs <= 0 || !bounds) {
+        set_error("sslam_orb_search_for_initialization_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ctx->scratch[3].ensure(sizeof(int) * 5 * (size_t)cap * npairs))) return rc;
+    SfiArgs A;
+    A.kp1 = d_kp1; A.d1 = d_desc1; A.n1 = d_n1; A.kp2 = d_kp2; A.d2 = d_desc2; A.n2 = d_n2;
+    A.cap = cap; A.n1s = 0; A.n2s = 0; A.prevMatched = d_prev; A.m12 = d_m12; A.nmatches = d_nm;
+    A.scratch = ctx->scratch[3].as<int>(); A.window = window; A.nnratio = nnratio; A.checkOri = checkOri;
+    A.minX = bounds[0]; A.maxX = bounds[1]; A.minY = bounds[2]; A.maxY = bounds[3];
+    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(64), 0, pick(ctx, stream), A);
+    SSLAM_HIP(hipGetLastError());
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_search_for_initialization(sslam_ctx* ctx,
+        const sslam_keypoint* kp1, const uint8_t* desc1, int n1, const sslam_keypoint* kp2, const uint8_t* desc2, int n2,
+        float* prev_matched, int32_t* matches12, int window, float nnratio, int checkOri, const float bounds[4], int* nmatches_out) {
+    if (!ctx || n1 < 0 || n2 < 0 || !nmatches_out || !bounds || (n1 > 0 && (!kp1 || !desc1 || !prev_matched || !matches12)) || (n2 > 0 && (!kp2 || !desc2))) {
+        set_error("sslam_orb_search_for_initialization: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    *nmatches_out = 0;
+    if (n1 == 0) return SSLAM_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    const int cap = std::max(std::max(n1, n2), 1);
+    if (cap >= (1 << 19)) { set_error("too many keypoints"); return SSLAM_ERR_UNSUPPORTED; }
+    hipStream_t st = ctx->stream;
+    const size_t kb = sizeof(sslam_keypoint) * (size_t)cap, db = 32 * (size_t)cap;
+    int rc;
+    // layout: kp1 | kp2 | d1 | d2 | prev | m12 | n1,n2,nm
+    size_t total = 2 * kb + 2 * db + 8 * (size_t)cap + 4 * (size_t)cap + 64;
+    if ((rc = ctx->scratch[4].ensure(total))) return rc;
+    uint8_t* base = ctx->scratch[4].as<uint8_t>();
+    sslam_keypoint* dk1 = (sslam_keypoint*)base; sslam_keypoint* dk2 = (sslam_keypoint*)(base + kb);
+    uint8_t* dd1 = base + 2 * kb; uint8_t* dd2 = dd1 + db;
+    float* dpm = (float*)(dd2 + db); int* dm12 = (int*)((uint8_t*)dpm + 8 * (size_t)cap); int* dn = dm12 + cap;
+    int hn[3] = {n1, n2, 0};
+    SSLAM_HIP(hipMemcpyAsync(dk1, kp1, sizeof(sslam_keypoint) * (size_t)n1, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(dd1, desc1, 32 * (size_t)n1, hipMemcpyHostToDevice, st));
+    if (n2) {
+        SSLAM_HIP(hipMemcpyAsync(dk2, kp2, sizeof(sslam_keypoint) * (size_t)n2, hipMemcpyHostToDevice, st));
+        SSLAM_HIP(hipMemcpyAsync(dd2, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, st));
+    }
+    SSLAM_HIP(hipMemcpyAsync(dpm, prev_matched, 8 * (size_t)n1, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(dn, hn, sizeof(hn), hipMemcpyHostToDevice, st));
+    if ((rc = sslam_orb_search_for_initialization_batch_dev(ctx, dk1, dd1, dn, dk2, dd2, dn + 1, cap, 1, dpm, dm12, dn + 2, window, nnratio, checkOri, bounds, st))) return rc;
+    SSLAM_HIP(hipMemcpyAsync(prev_matched, dpm, 8 * (size_t)n1, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(matches12, dm12, 4 * (size_t)n1, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(hn, dn, sizeof(hn), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    *nmatches_out = hn[2];
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_line_match_batch_dev(sslam_ctx* ctx, const uint8_t* d_l1, const int32_t* d_n1, const uint8_t* d_l2, const int32_t* d_n2,
+                                          int cap, int npf, double gate_scale, int ratio_mode, int32_t* d_pairs, int32_t* d_npairs, void* stream) {
+    if (!ctx || !d_l1 || !d_l2 || !d_n1 || !d_n2 || !d_pairs || !d_npairs || cap <= 0 || npf <= 0) { set_error("sslam_line_match_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_line_match, dim3(npf), dim3(256), 0, pick(ctx, stream), d_l1, d_n1, 0, d_l2, d_n2, 0, cap, gate_scale, ratio_mode, d_pairs, d_npairs, (double*)nullptr);
+    SSLAM_HIP(hipGetLastError());
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_line_match(sslam_ctx* ctx, const uint8_t* l1, int n1, const uint8_t* l2, int n2, double gate_scale, int ratio_mode,
+                                int32_t* pairs_out, int cap, int* npairs_out, double* nn_mad_out, double* nn12_mad_out) {
+    if (!ctx || n1 < 0 || n2 < 0 || !npairs_out || (n1 > 0 && (!l1 || !pairs_out)) || (n2 > 0 && !l2)) { set_error("sslam_line_match: invalid arguments"); return SSLAM_ERR_INVALID; }
+    *npairs_out = 0;
+    if (nn_mad_out) *nn_mad_out = 0;
+    if (nn12_mad_out) *nn12_mad_out = 0;
+    if (n1 == 0 || n2 < 2) return SSLAM_OK;       // degenerate: defined as no matches
+    if (n1 > LM_MAX) { set_error("sslam_line_match: n1=%d exceeds %d", n1, LM_MAX); return SSLAM_ERR_UNSUPPORTED; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int c = std::max(n1, n2);
+    int rc;
+    size_t total = 64 * (size_t)c + 8 * (size_t)c + 64;
+    if ((rc = ctx->scratch[5].ensure(total))) return rc;
+    uint8_t* base = ctx->scratch[5].as<uint8_t>();
+    uint8_t* d1 = base; uint8_t* d2 = base + 32 * (size_t)c;
+    int* dp = (int*)(d2 + 32 * (size_t)c); int* dn = dp + 2 * (size_t)c; double* dm = (double*)(dn + 4);
+    SSLAM_HIP(hipMemcpyAsync(d1, l1, 32 * (size_t)n1, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(d2, l2, 32 * (size_t)n2, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_line_match, dim3(1), dim3(256), 0, st, d1, (const int*)nullptr, n1, d2, (const int*)nullptr, n2, c, gate_scale, ratio_mode, dp, dn, dm);
+    SSLAM_HIP(hipGetLastError());
+    int np = 0; double mads[2] = {0, 0};
+    std::vector<int> hp(2 * (size_t)c);
+    SSLAM_HIP(hipMemcpyAsync(&np, dn, sizeof(int), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(mads, dm, sizeof(mads), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(hp.data(), dp, 8 * (size_t)c, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    *npairs_out = np;
+    if (nn_mad_out) *nn_mad_out = mads[0];
+    if (nn12_mad_out) *nn12_mad_out = mads[1];
+    if (np > cap) { set_error("sslam_line_match: %d pairs exceed capacity %d", np, cap); return SSLAM_ERR_CAPACITY; }
+    memcpy(pairs_out, hp.data(), 8 * (size_t)np);
+    return SSLAM_OK;
+}

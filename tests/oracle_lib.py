@@ -76,3 +76,47 @@ class Oracle:
     def fast_score(self, patch7):
         patch7 = np.ascontiguousarray(patch7, np.uint8)
         return int(self.L.orc_fast_score(_p(patch7)))
+
+
+def _orc_match_methods():
+    def descriptor_distance(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+        return int(self.L.orc_descriptor_distance(_p(a), _p(b)))
+
+    def knn2(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+        idx = np.zeros((len(q), 2), np.int32); dist = np.zeros((len(q), 2), np.int32)
+        self.L.orc_knn2(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+        return idx, dist
+
+    def hamming_matrix(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+        D = np.zeros((len(q), len(t)), np.uint16)
+        self.L.orc_hamming_matrix(_p(q), len(q), _p(t), len(t), _p(D))
+        return D
+
+    def search_for_initialization(self, kp1, d1, kp2, d2, prev_matched, window=100, nnratio=0.9, check_orientation=True,
+                                  bounds=(0.0, 640.0, 0.0, 480.0)):
+        kp1 = np.ascontiguousarray(kp1); kp2 = np.ascontiguousarray(kp2)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+        m12 = np.full(len(kp1), -1, np.int32)
+        b = np.array(bounds, np.float32)
+        n = self.L.orc_search_for_initialization(_p(kp1), _p(d1), len(kp1), _p(kp2), _p(d2), len(kp2), _p(pm), _p(m12),
+                                                 int(window), C.c_float(nnratio), int(bool(check_orientation)), _p(b))
+        return m12, pm, n
+
+    def line_match(self, l1, l2, gate_scale=0.5, ratio_mode=False):
+        l1 = np.ascontiguousarray(l1, np.uint8); l2 = np.ascontiguousarray(l2, np.uint8)
+        cap = max(len(l1), 1)
+        pairs = np.zeros((cap, 2), np.int32)
+        mad = C.c_double(0); mad12 = C.c_double(0)
+        n = self.L.orc_line_match(_p(l1), len(l1), _p(l2), len(l2), C.c_double(gate_scale), int(bool(ratio_mode)), _p(pairs), cap,
+                                  C.byref(mad), C.byref(mad12))
+        return pairs[:n].copy(), mad.value, mad12.value
+
+    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match):
+        setattr(Oracle, f.__name__, f)
+
+
+_orc_match_methods()
