@@ -284,12 +284,11 @@ struct Lsd {
         double left_x = min_y->x, right_x = min_y->x;
         int min_iter = min_y->y, max_iter = max_y->y;
         for (int y = min_iter; y <= max_iter; ++y) {
-            if (y >= 0 && y < h) {
-                for (int x = int(left_x); x <= int(right_x); ++x) {
-                    if (x < 0 || x >= w) continue;
-                    ++total_pts;
-                    if (isAligned(x, y, rec.theta, rec.prec)) ++alg_pts;
-                }
+            if (y < 0 || y >= h) continue;          // NB: also skips the edge stepping below (as upstream)
+            for (int x = int(left_x); x <= int(right_x); ++x) {
+                if (x < 0 || x >= w) continue;
+                ++total_pts;
+                if (isAligned(x, y, rec.theta, rec.prec)) ++alg_pts;
             }
             if (y >= leftmost->y) lstep = slstep;
             if (y >= rightmost->y) rstep = srstep;

@@ -1,0 +1,1061 @@
+// Line front-end for MI355X (gfx950): LSD detector (REFINE_ADV) + KeyLine fill +
+// top-N by response + LBD band descriptor + line equations — the device side of
+// LineSegment::ExtractLineSegment (reference src/ExtractLineSegment.cpp:18-69), whose
+// arithmetic lives in un-vendored OpenCV 3.4 (imgproc/lsd.cpp, contrib
+// line_descriptor LSDDetector.cpp / binary_descriptor.cpp).
+//
+// Design:
+//   * data-parallel stages (blur, 0.8x rescale, gradient/level-line angle, 1024-bin
+//     stable counting sort of the seeds, Sobel, LBD) are ordinary batched launches;
+//   * region growing is sequential by definition (seed order + a global `used` map
+//     + a region angle that changes with every accepted pixel).  It runs as one
+//     persistent 256-thread workgroup per frame: wave 0 replays the exact sequential
+//     order, the `used` bitmap lives in LDS, and the whole workgroup shares the
+//     data-parallel parts (seed scan, un-marking, NFA rectangle counting).  Frames of
+//     a batch run concurrently, one workgroup each;
+//   * all order-dependent fp64 sums are accumulated in the reference's order so the
+//     segments match the CPU oracle bit-for-bit.
+#include "common.h"
+#include <cmath>
+#include <cfloat>
+#include <algorithm>
+
+using namespace sslam;
+
+namespace {
+
+constexpr double kPI = 3.14159265358979323846;
+constexpr double DEG2RAD = kPI / 180;
+constexpr double M_3_2_PI_ = (3 * kPI) / 2, M_2PI_ = 2 * kPI;
+constexpr float NOTDEF_F = -1024.0f;
+constexpr int N_BINS = 1024;
+constexpr int TILE_PX = 8192;           // raster tile of the counting sort
+constexpr int MAX_SEG = 8192;           // segments per frame (LSD output capacity)
+constexpr int NUM_BANDS = 9, BAND_W = 7, LSP_H = 63;
+
+struct LsdPlan {
+    int w, h;                 // source image
+    int sw, sh, spitch;       // scaled image (0.8x)
+    int npx;                  // sw*sh
+    int nTiles;
+    size_t frameBytes;        // per-frame workspace
+    size_t offScaled, offBlur, offAng, offS, offOrder, offTileHist, offReg, offSeg, offMisc, offDx, offDy, offBlur5, offKl, offSortIdx;
+    int blurTaps[7];          // sigma 0.75, 7 taps (q8)
+    int blur5Taps[5];         // sigma 1, 5 taps (q8)
+    int tabX, tabY;           // offsets into the resize table (int: ofs, c1)
+    double rho, prec, p, logNT;
+    int minRegSize;
+};
+
+struct Misc {                 // per-frame scalars
+    int maxS;                 // max gx^2+gy^2 over defined pixels
+    int nDefined;
+    int nSeg;
+    int nKl;
+    int overflow;
+};
+
+// ------------------------------------------------------------------ separable blur (q8 taps, D6)
+template <int R>
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ src, size_t spitch, size_t sframe,
+                                              uint8_t* __restrict__ dst, size_t dpitch, size_t dframe, int w, int h,
+                                              const int* __restrict__ tapsArr) {
+    constexpr int TW = 64, TH = 16;
+    __shared__ uint8_t tile[(TH + 2 * R) * (TW + 2 * R + 2)];
+    __shared__ unsigned short hb[(TH + 2 * R) * TW];
+    const int b = blockIdx.z, bx = blockIdx.x * TW, by = blockIdx.y * TH;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const uint8_t* s = src + (size_t)b * sframe;
+    int taps[2 * R + 1];
+#pragma unroll
+    for (int k = 0; k < 2 * R + 1; ++k) taps[k] = tapsArr[k];
+    constexpr int LW = TW + 2 * R, LH = TH + 2 * R, LP = TW + 2 * R + 2;
+    for (int i = tid; i < LW * LH; i += 256) {
+        int r = i / LW, c = i - r * LW;
+        int yy = reflect101(min(by - R + r, h + R - 1), h), xx = reflect101(min(bx - R + c, w + R - 1), w);
+        yy = min(max(yy, 0), h - 1); xx = min(max(xx, 0), w - 1);
+        tile[r * LP + c] = s[(size_t)yy * spitch + xx];
+    }
+    __syncthreads();
+    for (int i = tid; i < LH * TW; i += 256) {
+        int r = i / TW, c = i - r * TW;
+        unsigned acc = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * R + 1; ++k) acc += (unsigned)tile[r * LP + c + k] * (unsigned)taps[k];
+        hb[r * TW + c] = (unsigned short)acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < TH * TW; i += 256) {
+        int r = i / TW, c = i - r * TW;
+        int x = bx + c, y = by + r;
+        if (x < w && y < h) {
+            unsigned acc = 0;
+#pragma unroll
+            for (int k = 0; k < 2 * R + 1; ++k) acc += (unsigned)hb[(r + k) * TW + c] * (unsigned)taps[k];
+            dst[(size_t)b * dframe + (size_t)y * dpitch + x] = (uint8_t)((acc + 32768u) >> 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ INTER_LINEAR_EXACT 0.8x (D7)
+__global__ void k_resize_exact(const uint8_t* __restrict__ src, size_t spitch, size_t sframe, int w, int h,
+                               uint8_t* __restrict__ dst, size_t dpitch, size_t dframe, int dw, int dh,
+                               const int* __restrict__ tx, const int* __restrict__ ty) {
+    const int b = blockIdx.z, x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const int sx = tx[x * 2], cx = tx[x * 2 + 1], sy = ty[y * 2], cy = ty[y * 2 + 1];
+    const int sx1 = min(sx + 1, w - 1), sy1 = min(sy + 1, h - 1);
+    const uint8_t* s0 = src + (size_t)b * sframe + (size_t)sy * spitch;
+    const uint8_t* s1 = src + (size_t)b * sframe + (size_t)sy1 * spitch;
+    unsigned r0 = s0[sx] * (256 - cx) + s0[sx1] * cx, r1 = s1[sx] * (256 - cx) + s1[sx1] * cx;
+    unsigned v = r0 * (256 - cy) + r1 * cy;
+    dst[(size_t)b * dframe + (size_t)y * dpitch + x] = (uint8_t)((v + 32768u) >> 16);
+}
+
+// ------------------------------------------------------------------ gradient / level-line angle (ll_angle)
+__global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws, LsdPlan P) {
+    const int b = blockIdx.y;
+    const uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const uint8_t* img = base + P.offScaled;
+    float* ang = (float*)(base + P.offAng);
+    int* S = (int*)(base + P.offS);
+    Misc* misc = (Misc*)(base + P.offMisc);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int smax = 0;
+    if (i < P.npx) {
+        const int y = i / P.sw, x = i - y * P.sw;
+        float a = NOTDEF_F; int s = 0;
+        if (x < P.sw - 1 && y < P.sh - 1) {
+            const uint8_t* r0 = img + (size_t)y * P.spitch + x;
+            const uint8_t* r1 = r0 + P.spitch;
+            int DA = (int)r1[1] - (int)r0[0], BC = (int)r0[1] - (int)r1[0];
+            int gx = DA + BC, gy = DA - BC;
+            s = gx * gx + gy * gy;
+            double norm = sqrt((double)s / 4.0);
+            if (norm > P.rho) { a = fast_atan2_deg((float)gx, (float)(-gy)); smax = s; }
+        }
+        ang[i] = a; S[i] = s;
+    }
+    smax = wave_max(smax);
+    if ((threadIdx.x & 63) == 0 && smax > 0) atomicMax(&misc->maxS, smax);
+}
+
+__device__ __forceinline__ int lsd_bin(int s, double binCoef) {
+    int i = (int)(sqrt((double)s / 4.0) * binCoef);
+    return min(max(i, 0), N_BINS - 1);
+}
+__device__ __forceinline__ double lsd_bin_coef(int maxS) {
+    return maxS > 0 ? (double)(N_BINS - 1) / sqrt((double)maxS / 4.0) : 0.0;
+}
+
+// stable counting sort of the DEFINED pixels by descending bin, raster order inside a bin (D2):
+// per-tile histograms -> scan -> stable scatter.
+__global__ __launch_bounds__(64) void k_lsd_hist(uint8_t* __restrict__ ws, LsdPlan P) {
+    __shared__ int hist[N_BINS];
+    const int tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const float* ang = (const float*)(base + P.offAng);
+    const int* S = (const int*)(base + P.offS);
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    int* th = (int*)(base + P.offTileHist) + (size_t)tile * N_BINS;
+    for (int i = lane; i < N_BINS; i += 64) hist[i] = 0;
+    __syncthreads();
+    const double bc = lsd_bin_coef(misc->maxS);
+    const int beg = tile * TILE_PX, end = min(beg + TILE_PX, P.npx);
+    for (int i = beg + lane; i < end; i += 64)
+        if (ang[i] != NOTDEF_F) atomicAdd(&hist[lsd_bin(S[i], bc)], 1);
+    __syncthreads();
+    for (int i = lane; i < N_BINS; i += 64) th[i] = hist[i];
+}
+
+__global__ __launch_bounds__(1024) void k_lsd_scan(uint8_t* __restrict__ ws, LsdPlan P) {
+    __shared__ int part[1024];
+    const int b = blockIdx.x, t = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    int* th = (int*)(base + P.offTileHist);
+    Misc* misc = (Misc*)(base + P.offMisc);
+    const int bin = N_BINS - 1 - t;           // thread t owns the t-th bin in descending order
+    int tot = 0;
+    for (int k = 0; k < P.nTiles; ++k) tot += th[(size_t)k * N_BINS + bin];
+    part[t] = tot;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {      // inclusive Hillis-Steele scan
+        int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int basePos = part[t] - tot;
+    for (int k = 0; k < P.nTiles; ++k) {
+        int c = th[(size_t)k * N_BINS + bin];
+        th[(size_t)k * N_BINS + bin] = basePos;
+        basePos += c;
+    }
+    if (t == 1023) misc->nDefined = part[1023];
+}
+
+__global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, LsdPlan P) {
+    __shared__ int cursor[N_BINS];
+    const int tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const float* ang = (const float*)(base + P.offAng);
+    const int* S = (const int*)(base + P.offS);
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int* th = (const int*)(base + P.offTileHist) + (size_t)tile * N_BINS;
+    unsigned* order = (unsigned*)(base + P.offOrder);
+    for (int i = lane; i < N_BINS; i += 64) cursor[i] = th[i];
+    __syncthreads();
+    const double bc = lsd_bin_coef(misc->maxS);
+    const int beg = tile * TILE_PX, end = min(beg + TILE_PX, P.npx);
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const bool def = i < end && ang[i] != NOTDEF_F;
+        const int bin = def ? lsd_bin(S[i], bc) : -1;
+        unsigned long long todo = __ballot(def);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int bsel = __shfl(bin, leader, 64);
+            const unsigned long long m = __ballot(def && bin == bsel);
+            if (def && bin == bsel) order[cursor[bsel] + mbcnt(m)] = (unsigned)i;
+            __syncthreads();
+            if (lane == leader) cursor[bsel] += __popcll(m);
+            __syncthreads();
+            todo &= ~m;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ the sequential core
+struct RectD { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
+
+__device__ __forceinline__ double angle_diff_signed(double a, double b) {
+    double diff = a - b;
+    while (diff <= -kPI) diff += M_2PI_;
+    while (diff > kPI) diff -= M_2PI_;
+    return diff;
+}
+__device__ __forceinline__ bool is_aligned_val(float aDeg, double theta, double prec) {
+    if (aDeg == NOTDEF_F) return false;
+    double n_theta = theta - (double)aDeg * DEG2RAD;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > M_3_2_PI_) { n_theta -= M_2PI_; if (n_theta < 0) n_theta = -n_theta; }
+    return n_theta <= prec;
+}
+__device__ double log_gamma_d(double x) {
+    if (x > 15) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
+    const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+    double a = (x + 0.5) * log(x + 5.5) - (x + 5.5), bq = 0;
+    for (int n = 0; n < 7; ++n) { a -= log(x + (double)n); bq += q[n] * pow(x, (double)n); }
+    return a + log(bq);
+}
+__device__ double nfa_d(int n, int k, double p, double logNT) {
+    if (n == 0 || k == 0) return -logNT;
+    if (n == k) return -logNT - (double)n * log10(p);
+    double p_term = p / (1 - p);
+    double log1term = log_gamma_d((double)n + 1) - log_gamma_d((double)k + 1) - log_gamma_d((double)(n - k) + 1) +
+                      (double)k * log(p) + (double)(n - k) * log(1.0 - p);
+    double term = exp(log1term);
+    if (term == 0.0) {      // double_equal(term, 0) holds only for an exact zero
+        if ((double)k > (double)n * p) return -log1term / 2.30258509299404568402 - logNT;
+        return -logNT;
+    }
+    double bin_tail = term, tolerance = 0.1;
+    for (int i = k + 1; i <= n; ++i) {
+        double bin_term = (double)(n - i + 1) / (double)i;
+        double mult_term = bin_term * p_term;
+        term *= mult_term;
+        bin_tail += term;
+        if (bin_term < 1) {
+            double err = term * ((1 - pow(mult_term, (double)(n - i + 1))) / (1 - mult_term) - 1);
+            if (err < tolerance * fabs(-log10(bin_tail) - logNT) * bin_tail) break;
+        }
+    }
+    return -log10(bin_tail) - logNT;
+}
+
+struct Shared {
+    // broadcast scalars of the workgroup
+    int seedFirst[4];
+    int regCount;
+    int total, alg;
+    double regAngle;
+    double logNfa;
+    RectD rec;
+    int flag;
+};
+
+// wave 0 only: LineSegmentDetectorImpl::region_grow.  `used` bitmap in LDS.
+__device__ void region_grow_w0(int seed, int sw, int sh, const float* __restrict__ ang, unsigned* usedBits,
+                               unsigned* __restrict__ reg, double prec, int& nOut, double& regAngleOut) {
+    const int lane = threadIdx.x & 63;
+    int n = 1;
+    double regAngle = (double)ang[seed] * DEG2RAD;
+    float sumdx = (float)cos(regAngle), sumdy = (float)sin(regAngle);
+    if (lane == 0) { reg[0] = (unsigned)seed; atomicOr(&usedBits[seed >> 5], 1u << (seed & 31)); }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const int k = lane;                         // neighbour slot 0..8 (row-major 3x3)
+    const int dy = k / 3 - 1, dx = k - (k / 3) * 3 - 1;
+    for (int i = 0; i < n; ++i) {
+        const int pidx = (int)reg[i];
+        const int py = pidx / sw, px = pidx - py * sw;
+        const int yy = py + dy, xx = px + dx;
+        bool cand = k < 9 && k != 4 && xx >= 0 && yy >= 0 && xx < sw && yy < sh;
+        int nidx = 0; float a = NOTDEF_F; float cs = 0.f, sn = 0.f;
+        if (cand) {
+            nidx = yy * sw + xx;
+            cand = ((usedBits[nidx >> 5] >> (nidx & 31)) & 1u) == 0;
+            if (cand) { a = ang[nidx]; cand = a != NOTDEF_F; }
+            if (cand) { float af = (float)((double)a * DEG2RAD); cs = (float)cos((double)af); sn = (float)sin((double)af); }
+        }
+        while (true) {
+            const bool al = cand && is_aligned_val(a, regAngle, prec);
+            const unsigned long long m = __ballot(al);
+            if (!m) break;
+            const int sel = __ffsll((long long)m) - 1;
+            if (lane == sel) { atomicOr(&usedBits[nidx >> 5], 1u << (nidx & 31)); reg[n] = (unsigned)nidx; }
+            ++n;
+            sumdx = __fadd_rn(sumdx, __shfl(cs, sel, 64));
+            sumdy = __fadd_rn(sumdy, __shfl(sn, sel, 64));
+            regAngle = (double)fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
+            cand = cand && lane > sel;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    nOut = n; regAngleOut = regAngle;
+}
+
+// wave 0 only (all lanes redundantly): region2rect + get_theta, sums in region order.
+__device__ void region2rect_w0(const unsigned* __restrict__ reg, int n, int sw, const float* __restrict__ ang, const int* __restrict__ S,
+                               double regAngle, double prec, double p, RectD& rec) {
+    double x = 0, y = 0, sum = 0;
+    for (int i = 0; i < n; ++i) {
+        const int idx = (int)reg[i];
+        const int py = idx / sw, px = idx - py * sw;
+        const double wgt = sqrt((double)S[idx] / 4.0);
+        x = x + (double)px * wgt; y = y + (double)py * wgt; sum = sum + wgt;
+    }
+    x /= sum; y /= sum;
+    double Ixx = 0, Iyy = 0, Ixy = 0;
+    for (int i = 0; i < n; ++i) {
+        const int idx = (int)reg[i];
+        const int py = idx / sw, px = idx - py * sw;
+        const double wgt = sqrt((double)S[idx] / 4.0);
+        const double ddx = (double)px - x, ddy = (double)py - y;
+        Ixx = Ixx + ddy * ddy * wgt; Iyy = Iyy + ddx * ddx * wgt; Ixy = Ixy - ddx * ddy * wgt;
+    }
+    const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
+                                           : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
+    theta *= DEG2RAD;
+    if (fabs(angle_diff_signed(theta, regAngle)) > prec) theta += kPI;
+    const double dx = cos(theta), dy = sin(theta);
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+    for (int i = 0; i < n; ++i) {
+        const int idx = (int)reg[i];
+        const int py = idx / sw, px = idx - py * sw;
+        const double rdx = (double)px - x, rdy = (double)py - y;
+        const double l = rdx * dx + rdy * dy, ww = -rdx * dy + rdy * dx;
+        if (l > l_max) l_max = l; else if (l < l_min) l_min = l;
+        if (ww > w_max) w_max = ww; else if (ww < w_min) w_min = ww;
+    }
+    rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy; rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
+    rec.width = w_max - w_min; rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy; rec.prec = prec; rec.p = p;
+    if (rec.width < 1.0) rec.width = 1.0;
+}
+
+__device__ __forceinline__ double dist_d(double x1, double y1, double x2, double y2) {
+    return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1));
+}
+
+// whole workgroup: LineSegmentDetectorImpl::rect_nfa (upstream's integer edge stepping included).
+__device__ double rect_nfa_wg(const RectD& rec, int sw, int sh, const float* __restrict__ ang, double logNT, Shared* sh_) {
+    const int tid = threadIdx.x;
+    const double half_width = rec.width / 2.0;
+    const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
+    int ex[4], ey[4];
+    ex[0] = (int)(rec.x1 - dyhw); ey[0] = (int)(rec.y1 + dxhw);
+    ex[1] = (int)(rec.x2 - dyhw); ey[1] = (int)(rec.y2 + dxhw);
+    ex[2] = (int)(rec.x2 + dyhw); ey[2] = (int)(rec.y2 - dxhw);
+    ex[3] = (int)(rec.x1 + dyhw); ey[3] = (int)(rec.y1 - dxhw);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {           // insertion sort by (x, y)
+        int vx = ex[i], vy = ey[i], j = i - 1;
+        while (j >= 0 && (ex[j] > vx || (ex[j] == vx && ey[j] > vy))) { ex[j + 1] = ex[j]; ey[j + 1] = ey[j]; --j; }
+        ex[j + 1] = vx; ey[j + 1] = vy;
+    }
+    int imin = 0, imax = 0;
+    for (int i = 1; i < 4; ++i) { if (ey[imin] > ey[i]) imin = i; if (ey[imax] < ey[i]) imax = i; }
+    bool taken[4] = {false, false, false, false};
+    taken[imin] = true;
+    int il = -1; for (int i = 0; i < 4; ++i) if (!taken[i]) { if (il < 0) il = i; else if (ex[il] > ex[i]) il = i; }
+    taken[il] = true;
+    int ir = -1; for (int i = 0; i < 4; ++i) if (!taken[i]) { if (ir < 0) ir = i; else if (ex[ir] < ex[i]) ir = i; }
+    taken[ir] = true;
+    int it = -1; for (int i = 0; i < 4; ++i) if (!taken[i]) { if (it < 0) it = i; else if (ex[it] > ex[i]) it = i; }
+    const int mx = ex[imin], my = ey[imin], lx = ex[il], ly = ey[il], rx = ex[ir], ry = ey[ir], tx = ex[it];
+    const int flstep = (my != ly) ? (mx - lx) / (my - ly) : 0;
+    const int slstep = (ly != tx) ? (lx - tx) / (ly - tx) : 0;
+    const int frstep = (my != ry) ? (mx - rx) / (my - ry) : 0;
+    const int srstep = (ry != tx) ? (rx - tx) / (ry - tx) : 0;
+    const int maxy = ey[imax];
+    // rows outside the image are skipped WITHOUT stepping the edges (upstream `continue`)
+    const int y0 = max(my, 0), y1 = min(maxy, sh - 1);
+    if (tid == 0) { sh_->total = 0; sh_->alg = 0; }
+    __syncthreads();
+    int total = 0, alg = 0;
+    if (my < sh) {
+        // a row y (y0 <= y <= y1) has seen (y - y0) steps; a step taken after row t uses the second slope iff t >= ly (t >= ry)
+        const int wv = tid >> 6, lane = tid & 63;
+        for (int y = y0 + wv; y <= y1; y += 4) {
+            const long long steps = y - y0;
+            long long nl2 = 0, nr2 = 0;        // steps with the second slope: rows t in [y0, y-1] with t >= ly
+            if (steps > 0) {
+                long long f = max((long long)ly, (long long)y0); nl2 = max(0LL, (long long)y - f);
+                long long g = max((long long)ry, (long long)y0); nr2 = max(0LL, (long long)y - g);
+            }
+            const long long lft = (long long)mx + (steps - nl2) * flstep + nl2 * slstep;
+            const long long rgt = (long long)mx + (steps - nr2) * frstep + nr2 * srstep;
+            const long long xa = max(lft, 0LL), xb = min(rgt, (long long)sw - 1);
+            if (xb >= xa) {
+                if (lane == 0) total += (int)(xb - xa + 1);
+                const float* row = ang + (size_t)y * sw;
+                for (long long x = xa + lane; x <= xb; x += 64) alg += is_aligned_val(row[x], rec.theta, rec.prec) ? 1 : 0;
+            }
+        }
+    }
+    total = wave_sum(total); alg = wave_sum(alg);
+    if ((tid & 63) == 0) { atomicAdd(&sh_->total, total); atomicAdd(&sh_->alg, alg); }
+    __syncthreads();
+    const int T = sh_->total, A = sh_->alg;
+    __syncthreads();
+    return nfa_d(T, A, rec.p, logNT);
+}
+
+__device__ double rect_improve_wg(RectD& rec, int sw, int sh, const float* ang, double logNT, Shared* S_) {
+    const double delta = 0.5, delta_2 = delta / 2.0, LOG_EPS = 0.0;
+    double log_nfa = rect_nfa_wg(rec, sw, sh, ang, logNT, S_);
+    if (log_nfa > LOG_EPS) return log_nfa;
+    RectD r = rec;
+    for (int n = 0; n < 5; ++n) {
+        r.p /= 2; r.prec = r.p * kPI;
+        double v = rect_nfa_wg(r, sw, sh, ang, logNT, S_);
+        if (v > log_nfa) { log_nfa = v; rec = r; }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.width -= delta;
+            double v = rect_nfa_wg(r, sw, sh, ang, logNT, S_);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+            r.width -= delta;
+            double v = rect_nfa_wg(r, sw, sh, ang, logNT, S_);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+            r.width -= delta;
+            double v = rect_nfa_wg(r, sw, sh, ang, logNT, S_);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.p /= 2; r.prec = r.p * kPI;
+            double v = rect_nfa_wg(r, sw, sh, ang, logNT, S_);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    return log_nfa;
+}
+
+// One persistent workgroup per frame: the flsd() main loop.
+__global__ __launch_bounds__(256) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P) {
+    extern __shared__ __align__(16) unsigned usedBits[];         // npx bits
+    __shared__ Shared sh;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const float* ang = (const float*)(base + P.offAng);
+    const int* S = (const int*)(base + P.offS);
+    const unsigned* order = (const unsigned*)(base + P.offOrder);
+    unsigned* reg = (unsigned*)(base + P.offReg);
+    float4* seg = (float4*)(base + P.offSeg);
+    Misc* misc = (Misc*)(base + P.offMisc);
+    const int sw = P.sw, sh_ = P.sh;
+    const int nWords = (P.npx + 31) >> 5;
+    for (int i = tid; i < nWords; i += 256) usedBits[i] = 0;
+    __syncthreads();
+    const int nOrd = misc->nDefined;
+    const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
+    int nSeg = 0;
+    int pos = 0;
+    while (pos < nOrd) {
+        // next unused seed among order[pos .. pos+256)
+        const int q = pos + tid;
+        bool un = false;
+        int idx = 0;
+        if (q < nOrd) { idx = (int)order[q]; un = ((usedBits[idx >> 5] >> (idx & 31)) & 1u) == 0; }
+        const unsigned long long m = __ballot(un);
+        if (lane == 0) sh.seedFirst[wv] = m ? wv * 64 + (__ffsll((long long)m) - 1) : -1;
+        __syncthreads();
+        int first = -1;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) if (sh.seedFirst[k] >= 0) first = sh.seedFirst[k];
+        __syncthreads();
+        if (first < 0) { pos += 256; continue; }
+        const int seed = (int)order[pos + first];
+        pos = pos + first + 1;
+        // ---- region_grow
+        if (wv == 0) {
+            int n; double ra;
+            region_grow_w0(seed, sw, sh_, ang, usedBits, reg, prec, n, ra);
+            if (lane == 0) { sh.regCount = n; sh.regAngle = ra; }
+        }
+        __syncthreads();
+        int n = sh.regCount;
+        double regAngle = sh.regAngle;
+        if (n < P.minRegSize) { __syncthreads(); continue; }
+        // ---- region2rect
+        if (wv == 0) {
+            RectD rec;
+            region2rect_w0(reg, n, sw, ang, S, regAngle, prec, p, rec);
+            if (lane == 0) sh.rec = rec;
+        }
+        __syncthreads();
+        RectD rec = sh.rec;
+        __syncthreads();
+        // ---- refine (LSD_REFINE_STD part)
+        bool ok = true;
+        double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+        if (density < DENSITY_TH) {
+            // un-mark the region; angle statistics near the seed in region order
+            for (int i = tid; i < n; i += 256) { int id = (int)reg[i]; atomicAnd(&usedBits[id >> 5], ~(1u << (id & 31))); }
+            __syncthreads();
+            if (wv == 0) {
+                const int id0 = (int)reg[0];
+                const double xc = (double)(id0 % sw), yc = (double)(id0 / sw);
+                const double ang_c = (double)ang[id0] * DEG2RAD;
+                double sum = 0, s_sum = 0; int cnt = 0;
+                for (int i = 0; i < n; ++i) {
+                    const int id = (int)reg[i];
+                    const int py = id / sw, px = id - py * sw;
+                    if (dist_d(xc, yc, (double)px, (double)py) < rec.width) {
+                        const double ang_d = angle_diff_signed((double)ang[id] * DEG2RAD, ang_c);
+                        sum = sum + ang_d; s_sum = s_sum + ang_d * ang_d; ++cnt;
+                    }
+                }
+                const double mean_angle = sum / (double)cnt;
+                const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
+                int n2; double ra2;
+                region_grow_w0(id0, sw, sh_, ang, usedBits, reg, tau, n2, ra2);
+                if (lane == 0) { sh.regCount = n2; sh.regAngle = ra2; }
+                if (n2 >= 2) {
+                    RectD r2;
+                    region2rect_w0(reg, n2, sw, ang, S, ra2, prec, p, r2);
+                    if (lane == 0) sh.rec = r2;
+                }
+            }
+            __syncthreads();
+            n = sh.regCount; regAngle = sh.regAngle;
+            if (n < 2) ok = false;
+            else {
+                rec = sh.rec;
+                density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+                if (density < DENSITY_TH) {
+                    // reduce_region_radius: sequential swap-with-last removal (order matters for later sums)
+                    __syncthreads();          // everyone has read sh.* before wave 0 rewrites it
+                    if (wv == 0) {
+                        const int id0 = (int)reg[0];
+                        const double xc = (double)(id0 % sw), yc = (double)(id0 / sw);
+                        const double r1 = (rec.x1 - xc) * (rec.x1 - xc) + (rec.y1 - yc) * (rec.y1 - yc);
+                        const double r2 = (rec.x2 - xc) * (rec.x2 - xc) + (rec.y2 - yc) * (rec.y2 - yc);
+                        double radSq = r1 > r2 ? r1 : r2;
+                        int nn = n; bool good = true; RectD rr = rec; double dens = density;
+                        while (dens < DENSITY_TH) {
+                            radSq *= 0.75 * 0.75;
+                            for (int i = 0; i < nn; ++i) {
+                                const int id = (int)reg[i];
+                                const int py = id / sw, px = id - py * sw;
+                                const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
+                                if (d2 > radSq) {
+                                    if (lane == 0) { atomicAnd(&usedBits[id >> 5], ~(1u << (id & 31))); unsigned last = reg[nn - 1]; reg[nn - 1] = (unsigned)id; reg[i] = last; }
+                                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                                    --nn; --i;
+                                }
+                            }
+                            if (nn < 2) { good = false; break; }
+                            region2rect_w0(reg, nn, sw, ang, S, regAngle, prec, p, rr);
+                            dens = (double)nn / (dist_d(rr.x1, rr.y1, rr.x2, rr.y2) * rr.width);
+                        }
+                        if (lane == 0) { sh.regCount = nn; sh.rec = rr; sh.flag = good ? 1 : 0; }
+                    }
+                    __syncthreads();
+                    n = sh.regCount; rec = sh.rec; ok = sh.flag != 0;
+                }
+            }
+            __syncthreads();
+        }
+        if (!ok) continue;
+        // ---- rect_improve (LSD_REFINE_ADV part) + NFA gate
+        const double logNfa = rect_improve_wg(rec, sw, sh_, ang, P.logNT, &sh);
+        if (!(logNfa > 0.0)) continue;
+        if (nSeg < MAX_SEG) {
+            if (tid == 0) {
+                const double SCALE = 0.8;
+                double x1 = (rec.x1 + 0.5) / SCALE, y1 = (rec.y1 + 0.5) / SCALE, x2 = (rec.x2 + 0.5) / SCALE, y2 = (rec.y2 + 0.5) / SCALE;
+                seg[nSeg] = make_float4((float)x1, (float)y1, (float)x2, (float)y2);
+            }
+        }
+        ++nSeg;
+    }
+    if (tid == 0) { misc->nSeg = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1; }
+}
+
+// ------------------------------------------------------------------ KeyLine fill + top-N (LSDDetector::detectImpl, ExtractLineSegment :42-51)
+__global__ __launch_bounds__(256) void k_keylines(uint8_t* __restrict__ ws, LsdPlan P, int maxLines,
+                                                  sslam_keyline* __restrict__ klOut, double* __restrict__ fnOut,
+                                                  int* __restrict__ counts, int cap) {
+    __shared__ unsigned long long keys[MAX_SEG];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const float4* seg = (const float4*)(base + P.offSeg);
+    Misc* misc = (Misc*)(base + P.offMisc);
+    sslam_keyline* klw = (sslam_keyline*)(base + P.offKl);
+    const int n = misc->nSeg;
+    for (int i = tid; i < n; i += 256) {
+        float4 s = seg[i];
+        float e0 = s.x, e1 = s.y, e2 = s.z, e3 = s.w;
+        const float W = (float)P.w, H = (float)P.h;           // checkLineExtremes
+        if (e0 < 0) e0 = 0; if (e0 >= W) e0 = W - 1.0f;
+        if (e2 < 0) e2 = 0; if (e2 >= W) e2 = W - 1.0f;
+        if (e1 < 0) e1 = 0; if (e1 >= H) e1 = H - 1.0f;
+        if (e3 < 0) e3 = 0; if (e3 >= H) e3 = H - 1.0f;
+        sslam_keyline k;
+        k.startPointX = e0; k.startPointY = e1; k.endPointX = e2; k.endPointY = e3;
+        k.sPointInOctaveX = e0; k.sPointInOctaveY = e1; k.ePointInOctaveX = e2; k.ePointInOctaveY = e3;
+        const double ddx = (double)__fsub_rn(e0, e2), ddy = (double)__fsub_rn(e1, e3);
+        k.lineLength = (float)sqrt(ddx * ddx + ddy * ddy);
+        const int ax = cv_roundf(e0), ay = cv_roundf(e1), bx = cv_roundf(e2), by = cv_roundf(e3);
+        k.numOfPixels = max(abs(bx - ax), abs(by - ay)) + 1;
+        k.angle = (float)atan2((double)__fsub_rn(e3, e1), (double)__fsub_rn(e2, e0));     // D5
+        k.class_id = i; k.octave = 0;
+        k.size = __fmul_rn(__fsub_rn(e2, e0), __fsub_rn(e3, e1));
+        k.response = __fdiv_rn(k.lineLength, (float)max(P.w, P.h));
+        k.pt_x = __fdiv_rn(__fadd_rn(e2, e0), 2.f); k.pt_y = __fdiv_rn(__fadd_rn(e3, e1), 2.f);
+        klw[i] = k;
+        keys[i] = ((unsigned long long)(~__float_as_uint(k.response)) << 32) | (unsigned)i;   // response >= 0: descending response, ascending index (D3 stable)
+    }
+    __syncthreads();
+    int nOut = n;
+    const bool doSort = n > maxLines;
+    if (doSort) {
+        int P2 = 1; while (P2 < n) P2 <<= 1;
+        for (int i = n + tid; i < P2; i += 256) keys[i] = ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= P2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < P2; i += 256) {
+                    int ixj = i ^ j;
+                    if (ixj > i) {
+                        unsigned long long a = keys[i], c = keys[ixj];
+                        bool up = (i & k) == 0;
+                        if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        nOut = maxLines;
+    }
+    nOut = min(nOut, cap);
+    for (int i = tid; i < nOut; i += 256) {
+        const int src = doSort ? (int)(unsigned)keys[i] : i;
+        sslam_keyline k = klw[src];
+        if (doSort) k.class_id = i;
+        klOut[(size_t)b * cap + i] = k;
+        // line equation sp x ep, normalised by its first two components (ExtractLineSegment :56-68), fp64
+        const double sx = k.startPointX, sy = k.startPointY, ex = k.endPointX, ey = k.endPointY;
+        const double l0 = __dsub_rn(sy, ey), l1 = __dsub_rn(ex, sx), l2 = __dsub_rn(__dmul_rn(sx, ey), __dmul_rn(sy, ex));
+        const double nrm = sqrt(__dadd_rn(__dmul_rn(l0, l0), __dmul_rn(l1, l1)));
+        double* f = fnOut + ((size_t)b * cap + i) * 3;
+        f[0] = l0 / nrm; f[1] = l1 / nrm; f[2] = l2 / nrm;
+    }
+    if (tid == 0) { counts[b] = nOut; misc->nKl = nOut; }
+}
+
+// ------------------------------------------------------------------ Sobel 3x3 -> s16 (reflect-101)
+__global__ __launch_bounds__(256) void k_sobel(const uint8_t* __restrict__ src, size_t spitch, size_t sframe, int w, int h,
+                                               short* __restrict__ dxo, short* __restrict__ dyo, size_t dframeBytes) {
+    const int b = blockIdx.z, x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const uint8_t* s = src + (size_t)b * sframe;
+    const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h), xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+    const uint8_t *r0 = s + (size_t)ym * spitch, *r1 = s + (size_t)y * spitch, *r2 = s + (size_t)yp * spitch;
+    const int gx = ((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]);
+    const int gy = ((int)r2[xm] - (int)r0[xm]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xp] - (int)r0[xp]);
+    short* dxp = (short*)((uint8_t*)dxo + (size_t)b * dframeBytes);
+    short* dyp = (short*)((uint8_t*)dyo + (size_t)b * dframeBytes);
+    dxp[(size_t)y * w + x] = (short)gx; dyp[(size_t)y * w + x] = (short)gy;
+}
+
+// ------------------------------------------------------------------ LBD (BinaryDescriptor::computeLBD)
+// One wave per line: lane = row of the 63-row line-support region, walking its row in
+// the reference's order so every fp32 accumulation matches bit for bit; then 9 lanes
+// fold rows into bands (again in row order), and the 72-float vector is normalised,
+// clipped and binarised by lane 0..31.
+__constant__ float kGaussL[21];
+__constant__ float kGaussG[63];
+__constant__ signed char kComb[64];
+
+__global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdPlan P, const sslam_keyline* __restrict__ kls,
+                                            const int* __restrict__ counts, uint8_t* __restrict__ descOut, int cap) {
+    __shared__ float rows[8][64];       // pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 per row
+    __shared__ float band[8][NUM_BANDS];
+    __shared__ float des[72];
+    const int li = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    if (li >= counts[b]) return;
+    const uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const short* dxImg = (const short*)(base + P.offDx);
+    const short* dyImg = (const short*)(base + P.offDy);
+    const sslam_keyline kl = kls[(size_t)b * cap + li];
+    const int lengthOfLSP = (short)kl.numOfPixels;
+    const int halfWidth = (lengthOfLSP - 1) / 2, halfHeight = (LSP_H - 1) / 2;
+    const float midX = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveX, kl.ePointInOctaveX));
+    const float midY = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveY, kl.ePointInOctaveY));
+    const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);      // D5
+    const float dO0 = -dL1, dO1 = dL0;
+    const int realWidth = P.w, imageWidth = P.w - 1, imageHeight = P.h - 1;
+    if (lane < LSP_H) {
+        // row start: sCor0 after `lane` steps of (sCorX0 -= dL1, sCorY0 += dL0), sequential float ops
+        float sx0 = __fadd_rn(__fadd_rn(__fmul_rn(-dL0, (float)halfWidth), __fmul_rn(dL1, (float)halfHeight)), midX);
+        float sy0 = __fadd_rn(__fsub_rn(__fmul_rn(-dL1, (float)halfWidth), __fmul_rn(dL0, (float)halfHeight)), midY);
+        for (int r = 0; r < lane; ++r) { sx0 = __fsub_rn(sx0, dL1); sy0 = __fadd_rn(sy0, dL0); }
+        float sx = sx0, sy = sy0;
+        float pL = 0, nL = 0, pO = 0, nO = 0;
+        for (int wID = 0; wID < lengthOfLSP; ++wID) {
+            int tc = (int)(short)(int)roundf(sx);
+            const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
+            tc = (int)(short)(int)roundf(sy);
+            const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
+            const float dx = (float)dxImg[(size_t)yCor * realWidth + xCor], dy = (float)dyImg[(size_t)yCor * realWidth + xCor];
+            const float gDL = __fadd_rn(__fmul_rn(dx, dL0), __fmul_rn(dy, dL1));
+            const float gDO = __fadd_rn(__fmul_rn(dx, dO0), __fmul_rn(dy, dO1));
+            if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
+            if (gDO > 0) pO = __fadd_rn(pO, gDO); else nO = __fsub_rn(nO, gDO);
+            sx = __fadd_rn(sx, dL0); sy = __fadd_rn(sy, dL1);
+        }
+        const float cg = kGaussG[lane];
+        pL = __fmul_rn(cg, pL); nL = __fmul_rn(cg, nL); pO = __fmul_rn(cg, pO); nO = __fmul_rn(cg, nO);
+        rows[0][lane] = pL; rows[1][lane] = nL; rows[2][lane] = __fmul_rn(pL, pL); rows[3][lane] = __fmul_rn(nL, nL);
+        rows[4][lane] = pO; rows[5][lane] = nO; rows[6][lane] = __fmul_rn(pO, pO); rows[7][lane] = __fmul_rn(nO, nO);
+    }
+    __syncthreads();
+    // band sums: lane -> (quantity q = lane/9, band = lane%9); rows visited in increasing hID so the
+    // accumulation order equals the reference's (own band, band above, band below contributions interleave by row)
+    for (int t = lane; t < 8 * NUM_BANDS; t += 64) {
+        const int q = t / NUM_BANDS, bd = t - q * NUM_BANDS;
+        const bool sq = (q == 2 || q == 3 || q == 6 || q == 7);
+        float acc = 0;
+        const int h0 = max(0, (bd - 1) * BAND_W), h1 = min(LSP_H, (bd + 2) * BAND_W);
+        for (int hID = h0; hID < h1; ++hID) {
+            const int own = hID / BAND_W, m = hID - own * BAND_W;
+            float c;
+            if (own == bd) c = kGaussL[m + BAND_W];
+            else if (own == bd + 1) c = kGaussL[m + 2 * BAND_W];     // row of the band below contributes "upward"
+            else c = kGaussL[m];                                       // row of the band above contributes "downward"
+            const float v = rows[q][hID];
+            acc = sq ? __fadd_rn(acc, __fmul_rn(__fmul_rn(c, c), v)) : __fadd_rn(acc, __fmul_rn(c, v));
+        }
+        band[q][bd] = acc;
+    }
+    __syncthreads();
+    if (lane < NUM_BANDS) {
+        const int bd = lane;
+        const float invN = (bd == 0 || bd == NUM_BANDS - 1) ? (float)(1.0 / (BAND_W * 2.0)) : (float)(1.0 / (BAND_W * 3.0));
+        float t;
+        t = __fmul_rn(band[0][bd], invN); des[bd * 8 + 0] = t; des[bd * 8 + 4] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[2][bd], invN), __fmul_rn(t, t)));
+        t = __fmul_rn(band[1][bd], invN); des[bd * 8 + 1] = t; des[bd * 8 + 5] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[3][bd], invN), __fmul_rn(t, t)));
+        t = __fmul_rn(band[4][bd], invN); des[bd * 8 + 2] = t; des[bd * 8 + 6] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[6][bd], invN), __fmul_rn(t, t)));
+        t = __fmul_rn(band[5][bd], invN); des[bd * 8 + 3] = t; des[bd * 8 + 7] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[7][bd], invN), __fmul_rn(t, t)));
+    }
+    __syncthreads();
+    // normalise means / stds separately, clip at 0.4, renormalise: sequential sums (every lane redundantly)
+    float tempM = 0, tempS = 0;
+    for (int bd = 0; bd < NUM_BANDS; ++bd) {
+        const float* d = des + bd * 8;
+        tempM = __fadd_rn(tempM, __fmul_rn(d[0], d[0])); tempM = __fadd_rn(tempM, __fmul_rn(d[1], d[1]));
+        tempM = __fadd_rn(tempM, __fmul_rn(d[2], d[2])); tempM = __fadd_rn(tempM, __fmul_rn(d[3], d[3]));
+        tempS = __fadd_rn(tempS, __fmul_rn(d[4], d[4])); tempS = __fadd_rn(tempS, __fmul_rn(d[5], d[5]));
+        tempS = __fadd_rn(tempS, __fmul_rn(d[6], d[6])); tempS = __fadd_rn(tempS, __fmul_rn(d[7], d[7]));
+    }
+    tempM = __fdiv_rn(1.f, __fsqrt_rn(tempM)); tempS = __fdiv_rn(1.f, __fsqrt_rn(tempS));
+    __syncthreads();
+    for (int i = lane; i < 72; i += 64) {
+        float v = des[i];
+        v = ((i & 7) < 4) ? __fmul_rn(v, tempM) : __fmul_rn(v, tempS);
+        if (v > 0.4f) v = 0.4f;
+        des[i] = v;
+    }
+    __syncthreads();
+    float temp = 0;
+    for (int i = 0; i < 72; ++i) temp = __fadd_rn(temp, __fmul_rn(des[i], des[i]));
+    temp = __fdiv_rn(1.f, __fsqrt_rn(temp));
+    __syncthreads();
+    for (int i = lane; i < 72; i += 64) des[i] = __fmul_rn(des[i], temp);
+    __syncthreads();
+    if (lane < 32) {
+        const float* f1 = des + 8 * kComb[lane * 2];
+        const float* f2 = des + 8 * kComb[lane * 2 + 1];
+        unsigned r = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (f1[i] > f2[i]) r += 1u << i;
+        descOut[((size_t)b * cap + li) * 32 + lane] = (uint8_t)r;
+    }
+}
+
+__global__ void k_zero_misc(uint8_t* ws, LsdPlan P) {
+    Misc* m = (Misc*)(ws + (size_t)blockIdx.x * P.frameBytes + P.offMisc);
+    if (threadIdx.x == 0) { m->maxS = 0; m->nDefined = 0; m->nSeg = 0; m->nKl = 0; m->overflow = 0; }
+}
+
+}  // namespace
+
+// =============================================================== host side
+struct sslam_lines {
+    sslam_ctx* ctx;
+    int maxLines;
+    int planW = 0, planH = 0;
+    LsdPlan plan;
+    DevBuf dWs, dTabs, dTaps;
+    int wsFrames = 0, lastFrames = 0;
+    DevBuf dImg, dKl, dDesc, dFn, dCounts;
+    HostPinned hOut;
+    bool constsUploaded = false;
+};
+
+static std::vector<int> taps_q8(int n, double sigma) {
+    std::vector<double> k(n);
+    double sum = 0, s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; ++i) { double x = i - (n - 1) * 0.5; k[i] = std::exp(s2 * x * x); sum += k[i]; }
+    std::vector<int> t(n);
+    double err = 0; long isum = 0;
+    for (int i = 0; i < n / 2; ++i) {
+        double adj = k[i] / sum * 256.0 + err;
+        int v = (int)lrint(adj);
+        err = adj - v; t[i] = t[n - 1 - i] = v; isum += v;
+    }
+    t[n / 2] = (int)(256 - 2 * isum);
+    return t;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int lines_build_plan(sslam_lines* L, int w, int h) {
+    LsdPlan& P = L->plan;
+    memset(&P, 0, sizeof(P));
+    P.w = w; P.h = h;
+    const double SCALE = 0.8;
+    P.sw = (int)lrint(w * SCALE); P.sh = (int)lrint(h * SCALE);
+    if (P.sw < 8 || P.sh < 8) { set_error("image %dx%d too small for LSD", w, h); return SSLAM_ERR_UNSUPPORTED; }
+    P.spitch = (P.sw + 63) & ~63;
+    P.npx = P.sw * P.sh;
+    if ((size_t)(P.npx + 31) / 32 * 4 > 150 * 1024) { set_error("image %dx%d exceeds the LDS used-map capacity", w, h); return SSLAM_ERR_UNSUPPORTED; }
+    P.nTiles = (P.npx + TILE_PX - 1) / TILE_PX;
+    const double ANG_TH = 22.5, QUANT = 2.0, SIGMA_SCALE = 0.6;
+    P.prec = kPI * ANG_TH / 180; P.p = ANG_TH / 180;
+    P.rho = QUANT / std::sin(P.prec);
+    P.logNT = 5 * (std::log10((double)P.sw) + std::log10((double)P.sh)) / 2 + std::log10(11.0);
+    P.minRegSize = (int)(size_t)(-P.logNT / std::log10(P.p));
+    const double sigma = SIGMA_SCALE / SCALE;
+    const unsigned hk = (unsigned)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
+    if (hk != 3) { set_error("unexpected LSD kernel size"); return SSLAM_ERR_UNSUPPORTED; }
+    std::vector<int> t7 = taps_q8(7, sigma), t5 = taps_q8(5, 1.0);
+    for (int i = 0; i < 7; ++i) P.blurTaps[i] = t7[i];
+    for (int i = 0; i < 5; ++i) P.blur5Taps[i] = t5[i];
+    // INTER_LINEAR_EXACT tables (D7)
+    std::vector<int> tabs;
+    auto coeffs = [&](double inv_scale, int ssz, int dsz) {
+        double scale = 1.0 / inv_scale;
+        for (int v = 0; v < dsz; ++v) {
+            double fv = scale * ((double)v + 0.5) - 0.5;
+            int iv = (int)std::floor(fv);
+            int ofs = 0, c1 = 0;
+            if (iv >= 0 && ssz > 1) { if (iv < ssz - 1) { ofs = iv; c1 = (int)lrint((fv - iv) * 256.0); } else { ofs = ssz - 1; c1 = 0; } }
+            tabs.push_back(ofs); tabs.push_back(c1);
+        }
+    };
+    P.tabX = 0; coeffs(SCALE, w, P.sw);
+    P.tabY = (int)tabs.size(); coeffs(SCALE, h, P.sh);
+    int rc;
+    if ((rc = L->dTabs.ensure(tabs.size() * sizeof(int)))) return rc;
+    SSLAM_HIP(hipMemcpy(L->dTabs.p, tabs.data(), tabs.size() * sizeof(int), hipMemcpyHostToDevice));
+    int taps[16] = {0};
+    for (int i = 0; i < 7; ++i) taps[i] = t7[i];
+    for (int i = 0; i < 5; ++i) taps[8 + i] = t5[i];
+    if ((rc = L->dTaps.ensure(sizeof(taps)))) return rc;
+    SSLAM_HIP(hipMemcpy(L->dTaps.p, taps, sizeof(taps), hipMemcpyHostToDevice));
+    // per-frame workspace layout
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t bpitch = ((size_t)w + 63) & ~(size_t)63;
+    P.offBlur = take(bpitch * h);                         // sigma-0.75 blur of the source (LSD)
+    P.offScaled = take((size_t)P.spitch * P.sh);
+    P.offAng = take(sizeof(float) * (size_t)P.npx);
+    P.offS = take(sizeof(int) * (size_t)P.npx);
+    P.offOrder = take(sizeof(unsigned) * (size_t)P.npx);
+    P.offTileHist = take(sizeof(int) * (size_t)P.nTiles * N_BINS);
+    P.offReg = take(sizeof(unsigned) * (size_t)P.npx);
+    P.offSeg = take(sizeof(float4) * MAX_SEG);
+    P.offMisc = take(sizeof(Misc));
+    P.offBlur5 = take(bpitch * h);                        // sigma-1 blur of the source (LBD)
+    P.offDx = take(sizeof(short) * (size_t)w * h);
+    P.offDy = take(sizeof(short) * (size_t)w * h);
+    P.offKl = take(sizeof(sslam_keyline) * MAX_SEG);
+    P.frameBytes = align_up(off, 4096);
+    L->planW = w; L->planH = h; L->wsFrames = 0;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_lines_create(sslam_ctx* ctx, int max_lines, sslam_lines** out) {
+    if (!ctx || !out || max_lines <= 0 || max_lines > MAX_SEG) { set_error("sslam_lines_create: invalid arguments"); return SSLAM_ERR_INVALID; }
+    sslam_lines* L = new sslam_lines();
+    L->ctx = ctx; L->maxLines = max_lines;
+    *out = L;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_lines_destroy(sslam_lines* L) {
+    if (!L) return SSLAM_OK;
+    (void)hipSetDevice(L->ctx->device);
+    (void)hipStreamSynchronize(L->ctx->stream);
+    DevBuf* bufs[] = {&L->dWs, &L->dTabs, &L->dTaps, &L->dImg, &L->dKl, &L->dDesc, &L->dFn, &L->dCounts};
+    for (DevBuf* b : bufs) b->release();
+    L->hOut.release();
+    delete L;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_images, int w, int h, size_t pitch, size_t image_stride,
+                                             int nframes, sslam_keyline* d_kl, uint8_t* d_ldesc, double* d_linefn, int32_t* d_counts,
+                                             int cap, void* stream_) {
+    if (!L || !d_images || !d_kl || !d_ldesc || !d_linefn || !d_counts || w <= 0 || h <= 0 || nframes <= 0 || cap <= 0 || pitch < (size_t)w) {
+        set_error("sslam_lines_extract_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    SSLAM_HIP(hipSetDevice(L->ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : L->ctx->stream;
+    int rc;
+    if (w != L->planW || h != L->planH) { SSLAM_HIP(hipStreamSynchronize(st)); if ((rc = lines_build_plan(L, w, h))) return rc; }
+    if (!L->constsUploaded) {
+        float gl[21], gg[63];
+        {   // BinaryDescriptor ctor weights (integer divisions are the library's)
+            double u = (BAND_W * 3 - 1) / 2, sigma = (BAND_W * 2 + 1) / 2, inv = -1 / (2 * sigma * sigma);
+            for (int i = 0; i < 21; ++i) { double d = i - u; gl[i] = (float)std::exp(d * d * inv); }
+            u = (NUM_BANDS * BAND_W - 1) / 2; sigma = u; inv = -1 / (2 * sigma * sigma);
+            for (int i = 0; i < 63; ++i) { double d = i - u; gg[i] = (float)std::exp(d * d * inv); }
+        }
+        static const signed char comb[64] = {0, 1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 1, 2, 1, 3, 1, 4, 1, 5, 1, 6, 2, 3, 2, 4, 2, 5, 2, 6, 2, 7,
+                                             2, 8, 3, 4, 3, 5, 3, 6, 3, 7, 3, 8, 4, 5, 4, 6, 4, 7, 4, 8, 5, 6, 5, 7, 5, 8, 6, 7, 6, 8, 7, 8};
+        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kGaussL), gl, sizeof(gl)));
+        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kGaussG), gg, sizeof(gg)));
+        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kComb), comb, sizeof(comb)));
+        L->constsUploaded = true;
+    }
+    const LsdPlan& P = L->plan;
+    if (nframes > L->wsFrames) {
+        SSLAM_HIP(hipStreamSynchronize(st));
+        if ((rc = L->dWs.ensure(P.frameBytes * (size_t)nframes))) return rc;
+        L->wsFrames = nframes;
+    }
+    uint8_t* ws = L->dWs.as<uint8_t>();
+    const size_t bpitch = ((size_t)w + 63) & ~(size_t)63;
+    const int* taps = L->dTaps.as<int>();
+    hipLaunchKernelGGL(k_zero_misc, dim3(nframes), dim3(64), 0, st, ws, P);
+    // LSD: blur(7, 0.75) -> 0.8x -> gradient
+    hipLaunchKernelGGL(k_blur<3>, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride,
+                       ws + P.offBlur, bpitch, P.frameBytes, w, h, taps);
+    hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 63) / 64, (P.sh + 3) / 4, nframes), dim3(64, 4), 0, st, ws + P.offBlur, bpitch, P.frameBytes, w, h,
+                       ws + P.offScaled, (size_t)P.spitch, P.frameBytes, P.sw, P.sh, L->dTabs.as<int>() + P.tabX, L->dTabs.as<int>() + P.tabY);
+    hipLaunchKernelGGL(k_lsd_grad, dim3((P.npx + 255) / 256, nframes), dim3(256), 0, st, ws, P);
+    hipLaunchKernelGGL(k_lsd_hist, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P);
+    hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P);
+    hipLaunchKernelGGL(k_lsd_scatter, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P);
+    {
+        size_t lds = (size_t)((P.npx + 31) / 32) * 4;
+        if (lds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_lsd_regions, dim3(nframes), dim3(256), lds, st, ws, P);
+    }
+    hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap);
+    // LBD: blur(5, 1) -> Sobel -> bands
+    hipLaunchKernelGGL(k_blur<2>, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride,
+                       ws + P.offBlur5, bpitch, P.frameBytes, w, h, taps + 8);
+    hipLaunchKernelGGL(k_sobel, dim3((w + 63) / 64, (h + 3) / 4, nframes), dim3(64, 4), 0, st, ws + P.offBlur5, bpitch, P.frameBytes, w, h,
+                       (short*)(ws + P.offDx), (short*)(ws + P.offDy), P.frameBytes);
+    hipLaunchKernelGGL(k_lbd, dim3(std::min(L->maxLines, cap), nframes), dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap);
+    SSLAM_HIP(hipGetLastError());
+    L->lastFrames = nframes;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_lines_extract(sslam_lines* L, const uint8_t* gray, int w, int h, size_t stride, sslam_keyline* kl_out, uint8_t* ldesc_out,
+                                   double* linefn_out, int cap, int* n_out) {
+    if (!L || !n_out) { set_error("sslam_lines_extract: null handle"); return SSLAM_ERR_INVALID; }
+    *n_out = 0;
+    if (w == 0 || h == 0 || !gray) return SSLAM_OK;
+    if (w < 0 || h < 0 || stride < (size_t)w || !kl_out || !ldesc_out || !linefn_out || cap <= 0) { set_error("sslam_lines_extract: invalid arguments"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(L->ctx->mu);
+    SSLAM_HIP(hipSetDevice(L->ctx->device));
+    hipStream_t st = L->ctx->stream;
+    const int icap = L->maxLines;
+    int rc;
+    const size_t dpitch = ((size_t)w + 63) & ~(size_t)63;
+    if ((rc = L->dImg.ensure(dpitch * h))) return rc;
+    if ((rc = L->dKl.ensure(sizeof(sslam_keyline) * (size_t)icap))) return rc;
+    if ((rc = L->dDesc.ensure(32 * (size_t)icap))) return rc;
+    if ((rc = L->dFn.ensure(24 * (size_t)icap))) return rc;
+    if ((rc = L->dCounts.ensure(16))) return rc;
+    const size_t total = 64 + (sizeof(sslam_keyline) + 32 + 24) * (size_t)icap;
+    if ((rc = L->hOut.ensure(total))) return rc;
+    SSLAM_HIP(hipMemcpy2DAsync(L->dImg.p, dpitch, gray, stride, w, h, hipMemcpyHostToDevice, st));
+    if ((rc = sslam_lines_extract_batch_dev(L, L->dImg.as<uint8_t>(), w, h, dpitch, dpitch * h, 1, L->dKl.as<sslam_keyline>(), L->dDesc.as<uint8_t>(),
+                                            L->dFn.as<double>(), L->dCounts.as<int>(), icap, st))) return rc;
+    uint8_t* hp = L->hOut.as<uint8_t>();
+    uint8_t* hk = hp + 64; uint8_t* hd = hk + sizeof(sslam_keyline) * (size_t)icap; uint8_t* hf = hd + 32 * (size_t)icap;
+    SSLAM_HIP(hipMemcpyAsync(hp, L->dCounts.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(hk, L->dKl.p, sizeof(sslam_keyline) * (size_t)icap, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(hd, L->dDesc.p, 32 * (size_t)icap, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(hf, L->dFn.p, 24 * (size_t)icap, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    const int n = *(int*)hp;
+    *n_out = n;
+    if (n > cap) { set_error("sslam_lines_extract: %d lines exceed caller capacity %d", n, cap); return SSLAM_ERR_CAPACITY; }
+    memcpy(kl_out, hk, sizeof(sslam_keyline) * (size_t)n);
+    memcpy(ldesc_out, hd, 32 * (size_t)n);
+    memcpy(linefn_out, hf, 24 * (size_t)n);
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_lines_debug_segments(sslam_lines* L, int frame, float* seg_out, int cap, int* n_out) {
+    if (!L || frame < 0 || frame >= L->lastFrames || !n_out) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(L->ctx->device));
+    SSLAM_HIP(hipStreamSynchronize(L->ctx->stream));
+    const LsdPlan& P = L->plan;
+    const uint8_t* base = L->dWs.as<uint8_t>() + (size_t)frame * P.frameBytes;
+    Misc m;
+    SSLAM_HIP(hipMemcpy(&m, base + P.offMisc, sizeof(m), hipMemcpyDeviceToHost));
+    *n_out = m.nSeg;
+    int n = std::min(m.nSeg, cap);
+    if (n > 0 && seg_out) SSLAM_HIP(hipMemcpy(seg_out, base + P.offSeg, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return SSLAM_OK;
+}

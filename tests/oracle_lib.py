@@ -120,3 +120,40 @@ def _orc_match_methods():
 
 
 _orc_match_methods()
+
+KL_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"),
+                     ("pt_x", "<f4"), ("pt_y", "<f4"), ("response", "<f4"), ("size", "<f4"),
+                     ("startPointX", "<f4"), ("startPointY", "<f4"), ("endPointX", "<f4"), ("endPointY", "<f4"),
+                     ("sPointInOctaveX", "<f4"), ("sPointInOctaveY", "<f4"),
+                     ("ePointInOctaveX", "<f4"), ("ePointInOctaveY", "<f4"),
+                     ("lineLength", "<f4"), ("numOfPixels", "<i4")])
+
+
+def _orc_line_methods():
+    def lines_extract(self, gray, max_lines=40, want_float=False):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        cap = 20000
+        kl = np.zeros(cap, KL_DTYPE); ld = np.zeros((cap, 32), np.uint8); fn = np.zeros((cap, 3), np.float64)
+        raw = np.zeros((cap, 4), np.float32); rn = C.c_int(0)
+        fd = np.zeros((cap, 72), np.float32) if want_float else None
+        n = self.L.orc_lines_extract(_p(gray), w, h, gray.strides[0], int(max_lines), _p(kl), _p(ld), _p(fn), cap, _p(raw), cap,
+                                     C.byref(rn), _p(fd))
+        n = min(n, cap)
+        out = (kl[:n].copy(), ld[:n].copy(), fn[:n].copy(), raw[:rn.value].copy())
+        return out + (fd[:n].copy(),) if want_float else out
+
+    def lsd_scaled(self, gray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        ow = C.c_int(0); oh = C.c_int(0)
+        self.L.orc_lsd_scaled(_p(gray), w, h, gray.strides[0], C.c_void_p(0), C.byref(ow), C.byref(oh))
+        out = np.zeros((oh.value, ow.value), np.uint8)
+        self.L.orc_lsd_scaled(_p(gray), w, h, gray.strides[0], _p(out), C.byref(ow), C.byref(oh))
+        return out
+
+    for f in (lines_extract, lsd_scaled):
+        setattr(Oracle, f.__name__, f)
+
+
+_orc_line_methods()
