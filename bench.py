@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — front-end frames/sec (ORB + LSD/LBD extract + match) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+A "step" is one pass of the hot path over one batch of B synthetic 640x480 frames that
+are already resident in HBM: ORB extract (1000 kp, 8 levels), LSD+LBD extract (<=200
+lines), and matching against the previous frame's features (SearchForInitialization +
+dense knn-2 for ORB, knn-2 + MAD gate for lines)  == BASELINE.json configs[2].
+With --gpus N (launched under torch.distributed.run, one rank per GPU) every rank processes
+its own B frames (weak scaling, frames are independent units) and the per-frame results are
+gathered to rank 0 over RCCL once per step; no other collective exists on the path.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel,
+algorithmic bytes from SURVEY.md §8(d) / DESIGN.md over the HIP-event launch duration) and
+`cpu_baseline` (the CPU oracle = restatement of the reference path, 1 core, bounded sample).
+"""
+import argparse, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H = 640, 480
+NFEAT, NLINES = 1000, 200
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def alg_bytes_per_frame(w, h, nkp, nln):
+    """Algorithmic HBM bytes per frame per kernel (SURVEY.md §8(d) + Appendix B byte model,
+    split per kernel in DESIGN.md §roofline).  P = pyramid level pixels."""
+    import numpy as np
+    P = []
+    sc = np.float32(1.0)
+    for l in range(8):
+        isc = np.float32(1.0) / sc
+        P.append(int(np.rint(np.float32(w) * isc)) * int(np.rint(np.float32(h) * isc)))
+        sc = np.float32(sc * np.float32(1.2))
+    sP = sum(P)
+    s08 = int(round(w * 0.8)) * int(round(h * 0.8))
+    return {
+        "k_copy_level0": w * h + P[0],                      # input read + level-0 write
+        "k_resize": sum(P[:-1]) + sum(P[1:]),               # resize reads of level l-1 + writes of level l
+        "k_fast_cells": sP,                                 # FAST read of every level
+        "k_octree": 0,                                      # candidate lists only (latency-bound, no image traffic)
+        "k_describe": 2 * sP + nkp * (2 * 961 + 32 + 28),   # blur r/w folded into the per-keypoint patch stage + patch reads + outputs
+        "k_blur<3>": 2 * w * h,                             # LSD pre-blur r/w
+        "k_resize_exact": w * h + s08,
+        "k_lsd_grad": s08 + 8 * s08,                        # gradient read, fp32 angle + int magnitude write
+        "k_lsd_hist": 8 * s08, "k_lsd_scan": 0, "k_lsd_scatter": 4 * s08,    # ordered-list build
+        "k_lsd_regions": 5 * s08,                           # region-grow reads (angle + magnitude + used)
+        "k_keylines": nln * (16 + 68 + 24),
+        "k_blur<2>": 2 * w * h, "k_sobel": w * h + 4 * w * h,
+        "k_lbd": nln * 63 * 100 * 4 + nln * 100,            # band reads at a nominal 100-px line + descriptor
+        "k_search_init": 2 * 32 * nkp + 8 * nkp, "k_knn2_batch": 2 * 32 * nkp + 16 * nkp,
+        "k_line_match": 2 * 32 * nln + 16 * nln,
+        "k_zero_misc": 0,
+    }
+
+
+def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=64):
+    """The CPU oracle (a restatement of the reference's CPU path; kind "port") timed on this box's
+    host cores, single thread like the reference's front-end (src/Frame.cc:86-87)."""
+    import numpy as np
+    import oracle_lib
+    orc = oracle_lib.Oracle()
+    t0 = time.perf_counter()
+    n = 0
+    prev_feat = None
+    # prime "previous" features outside the timed loop
+    pk, pd = orc.orb_extract(frames_prev[0], NFEAT)
+    pl = orc.lines_extract(frames_prev[0], NLINES)
+    t0 = time.perf_counter()
+    while n < max_frames and (time.perf_counter() - t0) < budget_s:
+        cur = frames_cur[n % len(frames_cur)]
+        kp, d = orc.orb_extract(cur, NFEAT)
+        kl, ld, fn, raw = orc.lines_extract(cur, NLINES)
+        pm = np.stack([pk["x"], pk["y"]], axis=1).astype(np.float32)
+        orc.search_for_initialization(pk, pd, kp, d, pm, 100, 0.9, True, (0.0, float(W), 0.0, float(H)))
+        orc.knn2(pd, d)
+        orc.line_match(pl[1], ld, 0.5, False)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same 640x480 workload (ORB 1000 + LSD/LBD 200 + matches), %.1f s, single thread" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing (used for rocprofv3 runs)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import pkg
+    from synth import synth_frame, warp_prev
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" % (args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; this framework has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    fe = pkg.frontend()
+    pipeline = pkg._load("sslam_pipeline", os.path.join(pkg.PKG_DIR, "pipeline.py"))
+    ctx = fe.Context(local_rank)
+    B = args.batch
+    # synthetic frames: `unique` distinct scenes per rank (seeds 2000+), each with its warped previous frame
+    U = max(1, min(args.unique, B))
+    cur_np = [synth_frame(2000 + rank * 64 + i, W, H) for i in range(U)]
+    prev_np = [warp_prev(f) for f in cur_np]
+    reps = (B + U - 1) // U
+    cur = torch.from_numpy(np.stack(cur_np)).to(dev).repeat(reps, 1, 1)[:B].contiguous()
+    prev = torch.from_numpy(np.stack(prev_np)).to(dev).repeat(reps, 1, 1)[:B].contiguous()
+
+    pipe = pipeline.FrontendBatch(fe, ctx, W, H, B, NFEAT, NLINES, dev)
+    # previous-frame features: extracted once, resident (the stream's t-1 state)
+    pipe.extract(prev, "prev")
+    torch.cuda.synchronize()
+
+    gather_buf = None
+    def one_step():
+        pipe.step(cur)
+        if dist is not None:
+            rec = pipe.packed_results()
+            nonlocal gather_buf
+            if rank == 0:
+                if gather_buf is None:
+                    gather_buf = [torch.empty_like(rec) for _ in range(world)]
+                dist.gather(rec, gather_buf, dst=0)
+            else:
+                dist.gather(rec, None, dst=0)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_profile:
+        fe.lib().sslam_profile_enable(ctx.h, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fe.lib().sslam_profile_enable(ctx.h, 0)
+    prof = pipeline.profile_drain(fe, ctx) if not args.no_profile else {}
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        counts = pipe.feat["cur"]["n"].cpu().numpy(); lcounts = pipe.feat["cur"]["nl"].cpu().numpy()
+        nm = pipe.nmatch.cpu().numpy(); nlp = pipe.nlpairs.cpu().numpy()
+        total_frames = B * world * args.steps
+        fps = total_frames / dt
+        out = {
+            "metric": "front-end frames/sec (ORB+LSD extract+match) 640x480 @1000kp/200ln",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 640x480 ORB(1000kp,8 levels)+LSD/LBD(<=200 lines) extract + Hamming match vs previous frame, inputs resident in HBM",
+                       "batch_per_gpu": B, "global_batch": B * world, "unique_frames": U,
+                       "mean_keypoints": float(counts.mean()), "mean_lines": float(lcounts.mean()),
+                       "mean_orb_matches": float(nm.mean()), "mean_line_matches": float(nlp.mean()),
+                       "parallelism": "frames sharded %d/GPU, RCCL gather of results to rank 0 per step" % B if world > 1 else "single GPU"},
+        }
+        if prof:
+            ab = alg_bytes_per_frame(W, H, NFEAT, NLINES)
+            dom = max(prof.items(), key=lambda kv: kv[1][0])
+            name, (ms, launches) = dom
+            avg_s = ms / launches * 1e-3
+            bytes_per_launch = ab.get(name, 0) * B
+            ach = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+            out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": None, "avg_launch_ms": ms / launches, "launches": launches,
+                               "alg_bytes_per_launch": bytes_per_launch,
+                               "whole_pipeline": {"alg_bytes_per_frame": sum(ab.values()), "achieved": sum(ab.values()) * fps / world / 1e9,
+                                                  "frac": sum(ab.values()) * fps / world / 1e9 / HBM_PEAK_GBS},
+                               "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cur_np, prev_np)
+        print(json.dumps(out))
+    pipe.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,12 @@ int sslam_ctx_destroy(sslam_ctx* ctx);
 int sslam_ctx_synchronize(sslam_ctx* ctx);
 void* sslam_ctx_stream(sslam_ctx* ctx);  /* hipStream_t of the context */
 
+/* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline
+ * leg; no reference counterpart).  drain() synchronises, returns the number of distinct
+ * kernels and fills name / total ms / launch count per kernel. */
+int sslam_profile_enable(sslam_ctx* ctx, int on);
+int sslam_profile_drain(sslam_ctx* ctx, const char** names_out, double* ms_out, int* launches_out, int cap);
+
 /* ---- ORB  (replaces StructureSLAM::ORBextractor) --------------------------- */
 /* ORBextractor::ORBextractor(int nfeatures,float scaleFactor,int nlevels,int iniThFAST,
  * int minThFAST), src/ORBextractor.cc:410-470. */
@@ -116,6 +122,10 @@ int sslam_hamming_knn2(sslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* 
                        int32_t* idx_out, int32_t* dist_out);
 int sslam_hamming_knn2_dev(sslam_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
                            int32_t* d_idx, int32_t* d_dist, void* stream);
+/* Batch form: frame f = rows [f*cap, f*cap+nq[f]) of d_q against rows [f*cap, f*cap+nt[f]) of d_t;
+ * d_idx/d_dist are nframes*cap x 2. */
+int sslam_hamming_knn2_batch_dev(sslam_ctx* ctx, const uint8_t* d_q, const int32_t* d_nq, const uint8_t* d_t,
+                                 const int32_t* d_nt, int cap, int nframes, int32_t* d_idx, int32_t* d_dist, void* stream);
 /* Dense nq x nt distance matrix (uint16), the input of the windowed Search* variants. */
 int sslam_hamming_matrix(sslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* D);
 

@@ -55,14 +55,32 @@ struct HostPinned {
 
 }  // namespace sslam
 
+struct sslam_prof_rec { const char* name; hipEvent_t a, b; };
+
 struct sslam_ctx {
     int device = 0;
+    bool profEnabled = false;              // per-kernel HIP-event timing (sslam_profile_*)
+    std::vector<sslam_prof_rec> prof;
     hipStream_t stream = nullptr;
     std::mutex mu;                 // host entry points serialise on the context (SURVEY §8b threading)
     sslam::DevBuf scratch[8];      // matcher staging
     sslam::HostPinned pinned[4];
     int num_cus = 0;
 };
+
+namespace sslam {
+// RAII stage timer: records a HIP event pair on the launch stream around one kernel launch.
+struct ProfScope {
+    sslam_ctx* c; hipStream_t st; sslam_prof_rec r; bool on;
+    ProfScope(sslam_ctx* ctx, const char* name, hipStream_t s) : c(ctx), st(s), on(ctx->profEnabled) {
+        if (!on) return;
+        r.name = name;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); c->prof.push_back(r); } }
+};
+}  // namespace sslam
 
 // ---- device helpers (wave64) ---------------------------------------------------
 #ifdef __HIPCC__

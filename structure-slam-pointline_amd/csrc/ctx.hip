@@ -69,3 +69,32 @@ extern "C" int sslam_ctx_synchronize(sslam_ctx* c) {
 }
 
 extern "C" void* sslam_ctx_stream(sslam_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---- per-kernel profiling (HIP events on the launch stream) -------------------
+#include <map>
+extern "C" int sslam_profile_enable(sslam_ctx* c, int on) {
+    if (!c) return SSLAM_ERR_INVALID;
+    c->profEnabled = on != 0;
+    return SSLAM_OK;
+}
+
+// Drains the recorded event pairs: per distinct kernel name, total milliseconds and launch count.
+// names_out receives pointers to static strings.  Returns the number of distinct kernels (<= cap).
+extern "C" int sslam_profile_drain(sslam_ctx* c, const char** names_out, double* ms_out, int* launches_out, int cap) {
+    if (!c) return SSLAM_ERR_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return SSLAM_ERR_HIP;
+    std::map<std::string, std::pair<double, int>> agg;
+    std::map<std::string, const char*> nm;
+    for (auto& r : c->prof) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { auto& e = agg[r.name]; e.first += ms; e.second += 1; nm[r.name] = r.name; }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    c->prof.clear();
+    int n = 0;
+    for (auto& kv : agg) {
+        if (n < cap) { if (names_out) names_out[n] = nm[kv.first]; if (ms_out) ms_out[n] = kv.second.first; if (launches_out) launches_out[n] = kv.second.second; }
+        ++n;
+    }
+    return n;
+}

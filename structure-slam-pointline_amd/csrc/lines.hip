@@ -39,7 +39,7 @@ struct LsdPlan {
     int npx;                  // sw*sh
     int nTiles;
     size_t frameBytes;        // per-frame workspace
-    size_t offScaled, offBlur, offAng, offS, offOrder, offTileHist, offReg, offSeg, offMisc, offDx, offDy, offBlur5, offKl, offSortIdx;
+    size_t offScaled, offBlur, offAng, offS, offPix, offOrder, offTileHist, offReg, offSeg, offMisc, offDx, offDy, offBlur5, offKl, offSortIdx;
     int blurTaps[7];          // sigma 0.75, 7 taps (q8)
     int blur5Taps[5];         // sigma 1, 5 taps (q8)
     int tabX, tabY;           // offsets into the resize table (int: ofs, c1)
@@ -53,6 +53,7 @@ struct Misc {                 // per-frame scalars
     int nSeg;
     int nKl;
     int overflow;
+    long long cyc[8];         // master-wave cycle breakdown (debug): grow, rect, refine, nfa count, nfa math, seed scan
 };
 
 // ------------------------------------------------------------------ separable blur (q8 taps, D6)
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
     const uint8_t* img = base + P.offScaled;
     float* ang = (float*)(base + P.offAng);
     int* S = (int*)(base + P.offS);
+    float4* pix = (float4*)(base + P.offPix);
     Misc* misc = (Misc*)(base + P.offMisc);
     const int i = blockIdx.x * 256 + threadIdx.x;
     int smax = 0;
@@ -135,6 +137,10 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
             if (norm > P.rho) { a = fast_atan2_deg((float)gx, (float)(-gy)); smax = s; }
         }
         ang[i] = a; S[i] = s;
+        // per-pixel record for region growing: angle, cosf/sinf of the (float) angle in radians (D5), magnitude^2
+        float cs = 0.f, sn = 0.f;
+        if (a != NOTDEF_F) { const float af = (float)((double)a * DEG2RAD); cs = (float)cos((double)af); sn = (float)sin((double)af); }
+        pix[i] = make_float4(a, cs, sn, __int_as_float(s));
     }
     smax = wave_max(smax);
     if ((threadIdx.x & 63) == 0 && smax > 0) atomicMax(&misc->maxS, smax);
@@ -228,6 +234,9 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, Ls
 // ------------------------------------------------------------------ the sequential core
 struct RectD { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 
+constexpr int QCAP = 2048;          // region points kept in LDS; longer regions continue in global memory
+constexpr int MAXC = 5;             // rectangle candidates evaluated per NFA job
+
 __device__ __forceinline__ double angle_diff_signed(double a, double b) {
     double diff = a - b;
     while (diff <= -kPI) diff += M_2PI_;
@@ -248,12 +257,16 @@ __device__ double log_gamma_d(double x) {
     for (int n = 0; n < 7; ++n) { a -= log(x + (double)n); bq += q[n] * pow(x, (double)n); }
     return a + log(bq);
 }
-__device__ double nfa_d(int n, int k, double p, double logNT) {
+// lgam[j] = log_gamma(j) for integer j >= 1 (every argument nfa() uses is an integer + 1)
+__global__ void k_lgamma_table(double* __restrict__ lgam, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) lgam[j] = j >= 1 ? log_gamma_d((double)j) : 0.0;
+}
+__device__ double nfa_d(int n, int k, double p, double logNT, const double* __restrict__ lgam) {
     if (n == 0 || k == 0) return -logNT;
     if (n == k) return -logNT - (double)n * log10(p);
     double p_term = p / (1 - p);
-    double log1term = log_gamma_d((double)n + 1) - log_gamma_d((double)k + 1) - log_gamma_d((double)(n - k) + 1) +
-                      (double)k * log(p) + (double)(n - k) * log(1.0 - p);
+    double log1term = lgam[n + 1] - lgam[k + 1] - lgam[n - k + 1] + (double)k * log(p) + (double)(n - k) * log(1.0 - p);
     double term = exp(log1term);
     if (term == 0.0) {      // double_equal(term, 0) holds only for an exact zero
         if ((double)k > (double)n * p) return -log1term / 2.30258509299404568402 - logNT;
@@ -273,75 +286,102 @@ __device__ double nfa_d(int n, int k, double p, double logNT) {
     return -log10(bin_tail) - logNT;
 }
 
-struct Shared {
-    // broadcast scalars of the workgroup
-    int seedFirst[4];
-    int regCount;
-    int total, alg;
-    double regAngle;
-    double logNfa;
-    RectD rec;
-    int flag;
+// region point list: first QCAP entries in LDS, the rest in global memory.  entry = x | y<<16
+struct RegQ {
+    unsigned* lds; unsigned* glb;
+    __device__ __forceinline__ unsigned get(int i) const { return i < QCAP ? lds[i] : glb[i]; }
+    __device__ __forceinline__ void set(int i, unsigned v) const { if (i < QCAP) lds[i] = v; else glb[i] = v; }
 };
+__device__ __forceinline__ void rq_fence(int n) { if (n > QCAP) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-// wave 0 only: LineSegmentDetectorImpl::region_grow.  `used` bitmap in LDS.
-__device__ void region_grow_w0(int seed, int sw, int sh, const float* __restrict__ ang, unsigned* usedBits,
-                               unsigned* __restrict__ reg, double prec, int& nOut, double& regAngleOut) {
+__device__ __forceinline__ bool used_get(const unsigned* ub, int idx) { return (ub[idx >> 5] >> (idx & 31)) & 1u; }
+
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// LineSegmentDetectorImpl::region_grow by one wave.  Seven queue entries are staged at a time (9
+// lanes each: the 3x3 neighbourhood in row-major order), so one global-load round trip serves up
+// to seven points.  Lane order == the reference's visiting order, and the region angle only
+// changes when a pixel is accepted, so ONE ballot over all staged lanes finds the next accepted
+// pixel exactly as the sequential scan would; lanes before it are consumed, lanes after it are
+// re-tested against the updated angle.
+__device__ int region_grow_m(int seedX, int seedY, int sw, int sh, const float4* __restrict__ pix, unsigned* ub, const RegQ& rq,
+                             double prec, double& regAngleOut) {
     const int lane = threadIdx.x & 63;
+    const int seed = seedY * sw + seedX;
     int n = 1;
-    double regAngle = (double)ang[seed] * DEG2RAD;
+    double regAngle = (double)pix[seed].x * DEG2RAD;
     float sumdx = (float)cos(regAngle), sumdy = (float)sin(regAngle);
-    if (lane == 0) { reg[0] = (unsigned)seed; atomicOr(&usedBits[seed >> 5], 1u << (seed & 31)); }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    const int k = lane;                         // neighbour slot 0..8 (row-major 3x3)
+    if (lane == 0) { rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16)); atomicOr(&ub[seed >> 5], 1u << (seed & 31)); }
+    const int g = lane / 9, k = lane - g * 9;           // group (queue slot) and neighbour slot
     const int dy = k / 3 - 1, dx = k - (k / 3) * 3 - 1;
-    for (int i = 0; i < n; ++i) {
-        const int pidx = (int)reg[i];
-        const int py = pidx / sw, px = pidx - py * sw;
-        const int yy = py + dy, xx = px + dx;
-        bool cand = k < 9 && k != 4 && xx >= 0 && yy >= 0 && xx < sw && yy < sh;
-        int nidx = 0; float a = NOTDEF_F; float cs = 0.f, sn = 0.f;
-        if (cand) {
-            nidx = yy * sw + xx;
-            cand = ((usedBits[nidx >> 5] >> (nidx & 31)) & 1u) == 0;
-            if (cand) { a = ang[nidx]; cand = a != NOTDEF_F; }
-            if (cand) { float af = (float)((double)a * DEG2RAD); cs = (float)cos((double)af); sn = (float)sin((double)af); }
+    int i = 0;
+    while (i < n) {
+        const int np = min(7, n - i);
+        bool cand = false; int nidx = -1, xx = 0, yy = 0; float4 px4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
+        if (g < np && k != 4) {
+            const unsigned e = rq.get(i + g);
+            xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
+            if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
+                nidx = yy * sw + xx;
+                if (!used_get(ub, nidx)) { px4 = pix[nidx]; cand = px4.x != NOTDEF_F; }
+            }
         }
+        int lastSel = -1;
         while (true) {
-            const bool al = cand && is_aligned_val(a, regAngle, prec);
+            const bool al = cand && lane > lastSel && is_aligned_val(px4.x, regAngle, prec);
             const unsigned long long m = __ballot(al);
             if (!m) break;
             const int sel = __ffsll((long long)m) - 1;
-            if (lane == sel) { atomicOr(&usedBits[nidx >> 5], 1u << (nidx & 31)); reg[n] = (unsigned)nidx; }
+            const int selIdx = __shfl(nidx, sel, 64);
+            if (lane == sel) { atomicOr(&ub[nidx >> 5], 1u << (nidx & 31)); rq.set(n, (unsigned)xx | ((unsigned)yy << 16)); }
             ++n;
-            sumdx = __fadd_rn(sumdx, __shfl(cs, sel, 64));
-            sumdy = __fadd_rn(sumdy, __shfl(sn, sel, 64));
+            sumdx = __fadd_rn(sumdx, __shfl(px4.y, sel, 64));
+            sumdy = __fadd_rn(sumdy, __shfl(px4.z, sel, 64));
             regAngle = (double)fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
-            cand = cand && lane > sel;
+            if (nidx == selIdx) cand = false;              // the accepted pixel is now USED for every later visitor
+            lastSel = sel;
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        i += np;
+        rq_fence(n);
     }
-    nOut = n; regAngleOut = regAngle;
+    regAngleOut = regAngle;
+    return n;
 }
 
-// wave 0 only (all lanes redundantly): region2rect + get_theta, sums in region order.
-__device__ void region2rect_w0(const unsigned* __restrict__ reg, int n, int sw, const float* __restrict__ ang, const int* __restrict__ S,
-                               double regAngle, double prec, double p, RectD& rec) {
+// one wave: region2rect + get_theta.  Loads and per-point products run lane-parallel; the
+// fp64 sums are then folded strictly in region order (readlane walk), extents by min/max.
+__device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __restrict__ pix, double regAngle, double prec, double p, RectD& rec) {
+    const int lane = threadIdx.x & 63;
     double x = 0, y = 0, sum = 0;
-    for (int i = 0; i < n; ++i) {
-        const int idx = (int)reg[i];
-        const int py = idx / sw, px = idx - py * sw;
-        const double wgt = sqrt((double)S[idx] / 4.0);
-        x = x + (double)px * wgt; y = y + (double)py * wgt; sum = sum + wgt;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        double fx = 0, fy = 0, wgt = 0;
+        if (i < n) {
+            const unsigned e = rq.get(i);
+            const int px = e & 0xFFFF, py = e >> 16;
+            wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
+            fx = (double)px * wgt; fy = (double)py * wgt;
+        }
+        const int cnt = min(64, n - base);
+        for (int j = 0; j < cnt; ++j) { x = x + readlane_d(fx, j); y = y + readlane_d(fy, j); sum = sum + readlane_d(wgt, j); }
     }
     x /= sum; y /= sum;
     double Ixx = 0, Iyy = 0, Ixy = 0;
-    for (int i = 0; i < n; ++i) {
-        const int idx = (int)reg[i];
-        const int py = idx / sw, px = idx - py * sw;
-        const double wgt = sqrt((double)S[idx] / 4.0);
-        const double ddx = (double)px - x, ddy = (double)py - y;
-        Ixx = Ixx + ddy * ddy * wgt; Iyy = Iyy + ddx * ddx * wgt; Ixy = Ixy - ddx * ddy * wgt;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        double a = 0, b = 0, c = 0;
+        if (i < n) {
+            const unsigned e = rq.get(i);
+            const int px = e & 0xFFFF, py = e >> 16;
+            const double wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
+            const double ddx = (double)px - x, ddy = (double)py - y;
+            a = ddy * ddy * wgt; b = ddx * ddx * wgt; c = ddx * ddy * wgt;
+        }
+        const int cnt = min(64, n - base);
+        for (int j = 0; j < cnt; ++j) { Ixx = Ixx + readlane_d(a, j); Iyy = Iyy + readlane_d(b, j); Ixy = Ixy - readlane_d(c, j); }
     }
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
     double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
@@ -349,14 +389,17 @@ __device__ void region2rect_w0(const unsigned* __restrict__ reg, int n, int sw, 
     theta *= DEG2RAD;
     if (fabs(angle_diff_signed(theta, regAngle)) > prec) theta += kPI;
     const double dx = cos(theta), dy = sin(theta);
-    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
-    for (int i = 0; i < n; ++i) {
-        const int idx = (int)reg[i];
-        const int py = idx / sw, px = idx - py * sw;
-        const double rdx = (double)px - x, rdy = (double)py - y;
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;       // running min/max from 0: order independent
+    for (int i = lane; i < n; i += 64) {
+        const unsigned e = rq.get(i);
+        const double rdx = (double)(e & 0xFFFF) - x, rdy = (double)(e >> 16) - y;
         const double l = rdx * dx + rdy * dy, ww = -rdx * dy + rdy * dx;
-        if (l > l_max) l_max = l; else if (l < l_min) l_min = l;
-        if (ww > w_max) w_max = ww; else if (ww < w_min) w_min = ww;
+        l_max = fmax(l_max, l); l_min = fmin(l_min, l); w_max = fmax(w_max, ww); w_min = fmin(w_min, ww);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        l_max = fmax(l_max, __shfl_xor(l_max, o, 64)); l_min = fmin(l_min, __shfl_xor(l_min, o, 64));
+        w_max = fmax(w_max, __shfl_xor(w_max, o, 64)); w_min = fmin(w_min, __shfl_xor(w_min, o, 64));
     }
     rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy; rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
     rec.width = w_max - w_min; rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy; rec.prec = prec; rec.p = p;
@@ -367,261 +410,290 @@ __device__ __forceinline__ double dist_d(double x1, double y1, double x2, double
     return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1));
 }
 
-// whole workgroup: LineSegmentDetectorImpl::rect_nfa (upstream's integer edge stepping included).
-__device__ double rect_nfa_wg(const RectD& rec, int sw, int sh, const float* __restrict__ ang, double logNT, Shared* sh_) {
-    const int tid = threadIdx.x;
+enum { NFA_MAXROWS = 64 };
+struct NfaGeom { int mx, y0, y1, ly, ry, fl, sl, fr, sr; };
+
+__device__ __forceinline__ int sel4(int i, int a, int b, int c, int d) { return i == 0 ? a : i == 1 ? b : i == 2 ? c : d; }
+
+// rect_nfa's corner bookkeeping (upstream's integer edge stepping and p.y-vs-p.x comparisons
+// included), in registers only.
+__device__ NfaGeom nfa_geom(const RectD& rec, int sh) {
     const double half_width = rec.width / 2.0;
     const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
-    int ex[4], ey[4];
-    ex[0] = (int)(rec.x1 - dyhw); ey[0] = (int)(rec.y1 + dxhw);
-    ex[1] = (int)(rec.x2 - dyhw); ey[1] = (int)(rec.y2 + dxhw);
-    ex[2] = (int)(rec.x2 + dyhw); ey[2] = (int)(rec.y2 - dxhw);
-    ex[3] = (int)(rec.x1 + dyhw); ey[3] = (int)(rec.y1 - dxhw);
-#pragma unroll
-    for (int i = 1; i < 4; ++i) {           // insertion sort by (x, y)
-        int vx = ex[i], vy = ey[i], j = i - 1;
-        while (j >= 0 && (ex[j] > vx || (ex[j] == vx && ey[j] > vy))) { ex[j + 1] = ex[j]; ey[j + 1] = ey[j]; --j; }
-        ex[j + 1] = vx; ey[j + 1] = vy;
-    }
+    long long k0 = ((long long)((int)(rec.x1 - dyhw) + (1 << 30)) << 32) | (unsigned)((int)(rec.y1 + dxhw) + (1 << 30));
+    long long k1 = ((long long)((int)(rec.x2 - dyhw) + (1 << 30)) << 32) | (unsigned)((int)(rec.y2 + dxhw) + (1 << 30));
+    long long k2 = ((long long)((int)(rec.x2 + dyhw) + (1 << 30)) << 32) | (unsigned)((int)(rec.y2 - dxhw) + (1 << 30));
+    long long k3 = ((long long)((int)(rec.x1 + dyhw) + (1 << 30)) << 32) | (unsigned)((int)(rec.y1 - dxhw) + (1 << 30));
+#define CSWAP(a, b) { long long lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; }
+    CSWAP(k0, k1) CSWAP(k2, k3) CSWAP(k0, k2) CSWAP(k1, k3) CSWAP(k1, k2)      // ascending by (x, y)
+#undef CSWAP
+    const int x0 = (int)(k0 >> 32) - (1 << 30), x1 = (int)(k1 >> 32) - (1 << 30), x2 = (int)(k2 >> 32) - (1 << 30), x3 = (int)(k3 >> 32) - (1 << 30);
+    const int y0 = (int)(unsigned)k0 - (1 << 30), y1 = (int)(unsigned)k1 - (1 << 30), y2 = (int)(unsigned)k2 - (1 << 30), y3 = (int)(unsigned)k3 - (1 << 30);
     int imin = 0, imax = 0;
-    for (int i = 1; i < 4; ++i) { if (ey[imin] > ey[i]) imin = i; if (ey[imax] < ey[i]) imax = i; }
-    bool taken[4] = {false, false, false, false};
-    taken[imin] = true;
-    int il = -1; for (int i = 0; i < 4; ++i) if (!taken[i]) { if (il < 0) il = i; else if (ex[il] > ex[i]) il = i; }
-    taken[il] = true;
-    int ir = -1; for (int i = 0; i < 4; ++i) if (!taken[i]) { if (ir < 0) ir = i; else if (ex[ir] < ex[i]) ir = i; }
-    taken[ir] = true;
-    int it = -1; for (int i = 0; i < 4; ++i) if (!taken[i]) { if (it < 0) it = i; else if (ex[it] > ex[i]) it = i; }
-    const int mx = ex[imin], my = ey[imin], lx = ex[il], ly = ey[il], rx = ex[ir], ry = ey[ir], tx = ex[it];
-    const int flstep = (my != ly) ? (mx - lx) / (my - ly) : 0;
-    const int slstep = (ly != tx) ? (lx - tx) / (ly - tx) : 0;
-    const int frstep = (my != ry) ? (mx - rx) / (my - ry) : 0;
-    const int srstep = (ry != tx) ? (rx - tx) / (ry - tx) : 0;
-    const int maxy = ey[imax];
+    if (sel4(imin, y0, y1, y2, y3) > y1) imin = 1;
+    if (sel4(imax, y0, y1, y2, y3) < y1) imax = 1;
+    if (sel4(imin, y0, y1, y2, y3) > y2) imin = 2;
+    if (sel4(imax, y0, y1, y2, y3) < y2) imax = 2;
+    if (sel4(imin, y0, y1, y2, y3) > y3) imin = 3;
+    if (sel4(imax, y0, y1, y2, y3) < y3) imax = 3;
+    // leftmost = first untaken with the smallest x (strict compare keeps the earliest)
+    int il = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i != imin) { if (il < 0) il = i; else if (sel4(il, x0, x1, x2, x3) > sel4(i, x0, x1, x2, x3)) il = i; }
+    int ir = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i != imin && i != il) { if (ir < 0) ir = i; else if (sel4(ir, x0, x1, x2, x3) < sel4(i, x0, x1, x2, x3)) ir = i; }
+    int it = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i != imin && i != il && i != ir) it = i;
+    NfaGeom g;
+    const int mx = sel4(imin, x0, x1, x2, x3), my = sel4(imin, y0, y1, y2, y3);
+    const int lx = sel4(il, x0, x1, x2, x3), ly = sel4(il, y0, y1, y2, y3);
+    const int rx = sel4(ir, x0, x1, x2, x3), ry = sel4(ir, y0, y1, y2, y3);
+    const int tx = sel4(it, x0, x1, x2, x3);
+    g.mx = mx; g.ly = ly; g.ry = ry;
+    g.fl = (my != ly) ? (mx - lx) / (my - ly) : 0;
+    g.sl = (ly != tx) ? (lx - tx) / (ly - tx) : 0;
+    g.fr = (my != ry) ? (mx - rx) / (my - ry) : 0;
+    g.sr = (ry != tx) ? (rx - tx) / (ry - tx) : 0;
     // rows outside the image are skipped WITHOUT stepping the edges (upstream `continue`)
-    const int y0 = max(my, 0), y1 = min(maxy, sh - 1);
-    if (tid == 0) { sh_->total = 0; sh_->alg = 0; }
-    __syncthreads();
-    int total = 0, alg = 0;
-    if (my < sh) {
-        // a row y (y0 <= y <= y1) has seen (y - y0) steps; a step taken after row t uses the second slope iff t >= ly (t >= ry)
-        const int wv = tid >> 6, lane = tid & 63;
-        for (int y = y0 + wv; y <= y1; y += 4) {
-            const long long steps = y - y0;
-            long long nl2 = 0, nr2 = 0;        // steps with the second slope: rows t in [y0, y-1] with t >= ly
-            if (steps > 0) {
-                long long f = max((long long)ly, (long long)y0); nl2 = max(0LL, (long long)y - f);
-                long long g = max((long long)ry, (long long)y0); nr2 = max(0LL, (long long)y - g);
-            }
-            const long long lft = (long long)mx + (steps - nl2) * flstep + nl2 * slstep;
-            const long long rgt = (long long)mx + (steps - nr2) * frstep + nr2 * srstep;
-            const long long xa = max(lft, 0LL), xb = min(rgt, (long long)sw - 1);
-            if (xb >= xa) {
-                if (lane == 0) total += (int)(xb - xa + 1);
-                const float* row = ang + (size_t)y * sw;
-                for (long long x = xa + lane; x <= xb; x += 64) alg += is_aligned_val(row[x], rec.theta, rec.prec) ? 1 : 0;
-            }
-        }
-    }
-    total = wave_sum(total); alg = wave_sum(alg);
-    if ((tid & 63) == 0) { atomicAdd(&sh_->total, total); atomicAdd(&sh_->alg, alg); }
-    __syncthreads();
-    const int T = sh_->total, A = sh_->alg;
-    __syncthreads();
-    return nfa_d(T, A, rec.p, logNT);
+    g.y0 = max(my, 0); g.y1 = min(sel4(imax, y0, y1, y2, y3), sh - 1);
+    return g;
 }
 
-__device__ double rect_improve_wg(RectD& rec, int sw, int sh, const float* ang, double logNT, Shared* S_) {
+// x-range of row y (clipped to the image); a row has seen (y - y0) edge steps, the step taken after
+// row t uses the second slope iff t >= ly (resp. ry).
+__device__ __forceinline__ void nfa_row_range(const NfaGeom& g, int y, int sw, int& xa, int& xb) {
+    const long long steps = y - g.y0;
+    long long nl2 = 0, nr2 = 0;
+    if (steps > 0) {
+        nl2 = max(0LL, (long long)y - max((long long)g.ly, (long long)g.y0));
+        nr2 = max(0LL, (long long)y - max((long long)g.ry, (long long)g.y0));
+    }
+    const long long lft = (long long)g.mx + (steps - nl2) * g.fl + nl2 * g.sl;
+    const long long rgt = (long long)g.mx + (steps - nr2) * g.fr + nr2 * g.sr;
+    xa = (int)max(lft, 0LL); xb = (int)min(rgt, (long long)sw - 1);
+}
+
+// one wave: total / aligned point counts of rect_nfa for one rectangle.
+__device__ void nfa_count_w(const RectD& rec, int sw, int sh, const float* __restrict__ ang, int& totalOut, int& algOut) {
+    const int lane = threadIdx.x & 63;
+    const NfaGeom g = nfa_geom(rec, sh);
+    int total = 0, alg = 0;
+    const int nrows = g.y1 - g.y0 + 1;
+    // pass 1: row widths (lane per row) to pick the mapping
+    int wmax = 0;
+    for (int r0 = 0; r0 < nrows; r0 += 64) {
+        const int r = r0 + lane;
+        if (r < nrows) { int xa, xb; nfa_row_range(g, g.y0 + r, sw, xa, xb); if (xb >= xa) { total += xb - xa + 1; wmax = max(wmax, xb - xa + 1); } }
+    }
+    total = wave_sum(total); wmax = wave_max(wmax);
+    if (total > 0) {
+        if (wmax <= 24) {
+            // narrow rows: lane per row, four independent loads in flight per lane
+            for (int r0 = 0; r0 < nrows; r0 += 64) {
+                const int r = r0 + lane;
+                int xa = 0, xb = -1;
+                if (r < nrows) nfa_row_range(g, g.y0 + r, sw, xa, xb);
+                const float* row = ang + (size_t)(g.y0 + min(r, nrows - 1)) * sw;
+                for (int x = xa; x <= xb; x += 4) {
+                    const float a0 = row[x], a1 = x + 1 <= xb ? row[x + 1] : NOTDEF_F, a2 = x + 2 <= xb ? row[x + 2] : NOTDEF_F, a3 = x + 3 <= xb ? row[x + 3] : NOTDEF_F;
+                    alg += (int)is_aligned_val(a0, rec.theta, rec.prec) + (int)is_aligned_val(a1, rec.theta, rec.prec) +
+                           (int)is_aligned_val(a2, rec.theta, rec.prec) + (int)is_aligned_val(a3, rec.theta, rec.prec);
+                }
+            }
+        } else {
+            // wide rows: the wave sweeps each row, two rows in flight
+            for (int y = g.y0; y <= g.y1; y += 2) {
+                int xa0, xb0, xa1 = 0, xb1 = -1;
+                nfa_row_range(g, y, sw, xa0, xb0);
+                if (y + 1 <= g.y1) nfa_row_range(g, y + 1, sw, xa1, xb1);
+                const float* row0 = ang + (size_t)y * sw;
+                const float* row1 = row0 + sw;
+                const int span = max(xb0 - xa0, xb1 - xa1) + 1;
+                for (int o = lane; o < span; o += 64) {
+                    const float a0 = xa0 + o <= xb0 ? row0[xa0 + o] : NOTDEF_F;
+                    const float a1 = xa1 + o <= xb1 ? row1[xa1 + o] : NOTDEF_F;
+                    alg += (int)is_aligned_val(a0, rec.theta, rec.prec) + (int)is_aligned_val(a1, rec.theta, rec.prec);
+                }
+            }
+        }
+        alg = wave_sum(alg);
+    }
+    totalOut = total; algOut = alg;
+}
+
+// rect_improve.  Inside one refinement stage the candidate rectangles do not depend on which of
+// them gets accepted, so a stage's (up to five) NFAs are evaluated together: counts one after the
+// other (wave-wide), the five binomial-tail evaluations lane-parallel.
+struct ImproveLds { RectD cand[MAXC]; double val[MAXC]; int total[MAXC], alg[MAXC]; long long cycCount, cycMath; };
+
+__device__ void nfa_eval_w(ImproveLds* L, int nc, int sw, int sh, const float* __restrict__ ang, double logNT, const double* __restrict__ lgam) {
+    const int lane = threadIdx.x & 63;
+    const long long tc0 = __builtin_readcyclecounter();
+    for (int c = 0; c < nc; ++c) {
+        int t, a;
+        nfa_count_w(L->cand[c], sw, sh, ang, t, a);
+        if (lane == 0) { L->total[c] = t; L->alg[c] = a; }
+    }
+    __syncthreads();
+    const long long tc1 = __builtin_readcyclecounter();
+    if (lane < nc) L->val[lane] = nfa_d(L->total[lane], L->alg[lane], L->cand[lane].p, logNT, lgam);
+    __syncthreads();
+    if (lane == 0) { L->cycCount += tc1 - tc0; L->cycMath += __builtin_readcyclecounter() - tc1; }
+}
+
+__device__ double rect_improve_w(RectD& rec, ImproveLds* L, int sw, int sh, const float* ang, double logNT, const double* lgam) {
+    const int lane = threadIdx.x & 63;
     const double delta = 0.5, delta_2 = delta / 2.0, LOG_EPS = 0.0;
-    double log_nfa = rect_nfa_wg(rec, sw, sh, ang, logNT, S_);
+    if (lane == 0) L->cand[0] = rec;
+    __syncthreads();
+    nfa_eval_w(L, 1, sw, sh, ang, logNT, lgam);
+    double log_nfa = L->val[0];
     if (log_nfa > LOG_EPS) return log_nfa;
-    RectD r = rec;
-    for (int n = 0; n < 5; ++n) {
-        r.p /= 2; r.prec = r.p * kPI;
-        double v = rect_nfa_wg(r, sw, sh, ang, logNT, S_);
-        if (v > log_nfa) { log_nfa = v; rec = r; }
-    }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.width -= delta;
-            double v = rect_nfa_wg(r, sw, sh, ang, logNT, S_);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
+    for (int stage = 0; stage < 5; ++stage) {
+        RectD r = rec;
+        int nc = 0;
+        for (int n = 0; n < 5; ++n) {
+            if (stage == 0 || stage == 4) {
+                if (stage == 4 && !((r.width - delta) >= 0.5)) continue;
+                r.p /= 2; r.prec = r.p * kPI;
+            } else {
+                if (!((r.width - delta) >= 0.5)) continue;
+                if (stage == 2) { r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; }
+                if (stage == 3) { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
+                r.width -= delta;
+            }
+            if (lane == 0) L->cand[nc] = r;
+            ++nc;
         }
-    }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
-            r.width -= delta;
-            double v = rect_nfa_wg(r, sw, sh, ang, logNT, S_);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
+        __syncthreads();
+        if (nc > 0) {
+            nfa_eval_w(L, nc, sw, sh, ang, logNT, lgam);
+            for (int j = 0; j < nc; ++j) { const double v = L->val[j]; if (v > log_nfa) { log_nfa = v; rec = L->cand[j]; } }
         }
-    }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
-            r.width -= delta;
-            double v = rect_nfa_wg(r, sw, sh, ang, logNT, S_);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
-        }
-    }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.p /= 2; r.prec = r.p * kPI;
-            double v = rect_nfa_wg(r, sw, sh, ang, logNT, S_);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
-        }
+        __syncthreads();
+        if (stage < 4 && log_nfa > LOG_EPS) return log_nfa;
     }
     return log_nfa;
 }
 
-// One persistent workgroup per frame: the flsd() main loop.
-__global__ __launch_bounds__(256) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P) {
-    extern __shared__ __align__(16) unsigned usedBits[];         // npx bits
-    __shared__ Shared sh;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// One persistent single-wave workgroup per frame: the flsd() main loop replayed in order.
+__global__ __launch_bounds__(64) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
+    extern __shared__ __align__(16) unsigned dynLds[];           // used bitmap (npx bits) then the region queue
+    __shared__ ImproveLds imp;
+    const int b = blockIdx.x, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     const float* ang = (const float*)(base + P.offAng);
-    const int* S = (const int*)(base + P.offS);
+    const float4* pix = (const float4*)(base + P.offPix);
     const unsigned* order = (const unsigned*)(base + P.offOrder);
-    unsigned* reg = (unsigned*)(base + P.offReg);
     float4* seg = (float4*)(base + P.offSeg);
     Misc* misc = (Misc*)(base + P.offMisc);
-    const int sw = P.sw, sh_ = P.sh;
+    const int sw = P.sw, sh = P.sh;
     const int nWords = (P.npx + 31) >> 5;
-    for (int i = tid; i < nWords; i += 256) usedBits[i] = 0;
+    unsigned* ub = dynLds;
+    RegQ rq; rq.lds = dynLds + nWords; rq.glb = (unsigned*)(base + P.offReg);
+    for (int i = lane; i < nWords; i += 64) ub[i] = 0;
+    if (lane == 0) { imp.cycCount = 0; imp.cycMath = 0; }
     __syncthreads();
     const int nOrd = misc->nDefined;
     const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
     int nSeg = 0;
-    int pos = 0;
-    while (pos < nOrd) {
-        // next unused seed among order[pos .. pos+256)
-        const int q = pos + tid;
-        bool un = false;
-        int idx = 0;
-        if (q < nOrd) { idx = (int)order[q]; un = ((usedBits[idx >> 5] >> (idx & 31)) & 1u) == 0; }
-        const unsigned long long m = __ballot(un);
-        if (lane == 0) sh.seedFirst[wv] = m ? wv * 64 + (__ffsll((long long)m) - 1) : -1;
-        __syncthreads();
-        int first = -1;
-#pragma unroll
-        for (int k = 3; k >= 0; --k) if (sh.seedFirst[k] >= 0) first = sh.seedFirst[k];
-        __syncthreads();
-        if (first < 0) { pos += 256; continue; }
-        const int seed = (int)order[pos + first];
-        pos = pos + first + 1;
-        // ---- region_grow
-        if (wv == 0) {
-            int n; double ra;
-            region_grow_w0(seed, sw, sh_, ang, usedBits, reg, prec, n, ra);
-            if (lane == 0) { sh.regCount = n; sh.regAngle = ra; }
-        }
-        __syncthreads();
-        int n = sh.regCount;
-        double regAngle = sh.regAngle;
-        if (n < P.minRegSize) { __syncthreads(); continue; }
-        // ---- region2rect
-        if (wv == 0) {
+    long long cyc0 = 0, cyc1 = 0, cyc2 = 0, cyc3 = 0;
+    const long long tStart = __builtin_readcyclecounter();
+    for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
+        const int q = pos0 + lane;
+        const int idx = q < nOrd ? (int)order[q] : -1;
+        int after = -1;                                    // lanes <= after are consumed
+        while (true) {
+            const bool un = idx >= 0 && lane > after && !used_get(ub, idx);
+            const unsigned long long m = __ballot(un);
+            if (!m) break;
+            const int first = __ffsll((long long)m) - 1;
+            after = first;
+            const int seed = __shfl(idx, first, 64);
+            const int sy = seed / sw, sx = seed - sy * sw;
+            double regAngle;
+            long long t0 = __builtin_readcyclecounter();
+            int n = region_grow_m(sx, sy, sw, sh, pix, ub, rq, prec, regAngle);
+            long long t1 = __builtin_readcyclecounter(); cyc0 += t1 - t0;
+            if (n < P.minRegSize) continue;
             RectD rec;
-            region2rect_w0(reg, n, sw, ang, S, regAngle, prec, p, rec);
-            if (lane == 0) sh.rec = rec;
-        }
-        __syncthreads();
-        RectD rec = sh.rec;
-        __syncthreads();
-        // ---- refine (LSD_REFINE_STD part)
-        bool ok = true;
-        double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
-        if (density < DENSITY_TH) {
-            // un-mark the region; angle statistics near the seed in region order
-            for (int i = tid; i < n; i += 256) { int id = (int)reg[i]; atomicAnd(&usedBits[id >> 5], ~(1u << (id & 31))); }
-            __syncthreads();
-            if (wv == 0) {
-                const int id0 = (int)reg[0];
-                const double xc = (double)(id0 % sw), yc = (double)(id0 / sw);
-                const double ang_c = (double)ang[id0] * DEG2RAD;
+            region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec);
+            long long t2 = __builtin_readcyclecounter(); cyc1 += t2 - t1;
+            // ---- refine (LSD_REFINE_STD part)
+            double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+            if (density < DENSITY_TH) {
+                const unsigned e0 = rq.get(0);
+                const int x0 = e0 & 0xFFFF, y0 = e0 >> 16;
+                const double xc = (double)x0, yc = (double)y0;
+                const double ang_c = (double)pix[y0 * sw + x0].x * DEG2RAD;
                 double sum = 0, s_sum = 0; int cnt = 0;
-                for (int i = 0; i < n; ++i) {
-                    const int id = (int)reg[i];
-                    const int py = id / sw, px = id - py * sw;
-                    if (dist_d(xc, yc, (double)px, (double)py) < rec.width) {
-                        const double ang_d = angle_diff_signed((double)ang[id] * DEG2RAD, ang_c);
-                        sum = sum + ang_d; s_sum = s_sum + ang_d * ang_d; ++cnt;
+                for (int bs = 0; bs < n; bs += 64) {
+                    const int i = bs + lane;
+                    double ad = 0; bool in = false;
+                    if (i < n) {
+                        const unsigned e = rq.get(i);
+                        const int px = e & 0xFFFF, py = e >> 16, id = py * sw + px;
+                        atomicAnd(&ub[id >> 5], ~(1u << (id & 31)));
+                        if (dist_d(xc, yc, (double)px, (double)py) < rec.width) { in = true; ad = angle_diff_signed((double)pix[id].x * DEG2RAD, ang_c); }
                     }
+                    const unsigned long long mi = __ballot(in);
+                    const int c2 = min(64, n - bs);
+                    for (int j = 0; j < c2; ++j)
+                        if ((mi >> j) & 1ull) { const double a = readlane_d(ad, j); sum = sum + a; s_sum = s_sum + a * a; ++cnt; }
                 }
                 const double mean_angle = sum / (double)cnt;
                 const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-                int n2; double ra2;
-                region_grow_w0(id0, sw, sh_, ang, usedBits, reg, tau, n2, ra2);
-                if (lane == 0) { sh.regCount = n2; sh.regAngle = ra2; }
-                if (n2 >= 2) {
-                    RectD r2;
-                    region2rect_w0(reg, n2, sw, ang, S, ra2, prec, p, r2);
-                    if (lane == 0) sh.rec = r2;
-                }
-            }
-            __syncthreads();
-            n = sh.regCount; regAngle = sh.regAngle;
-            if (n < 2) ok = false;
-            else {
-                rec = sh.rec;
+                n = region_grow_m(x0, y0, sw, sh, pix, ub, rq, tau, regAngle);
+                if (n < 2) continue;
+                region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec);
                 density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
                 if (density < DENSITY_TH) {
-                    // reduce_region_radius: sequential swap-with-last removal (order matters for later sums)
-                    __syncthreads();          // everyone has read sh.* before wave 0 rewrites it
-                    if (wv == 0) {
-                        const int id0 = (int)reg[0];
-                        const double xc = (double)(id0 % sw), yc = (double)(id0 / sw);
-                        const double r1 = (rec.x1 - xc) * (rec.x1 - xc) + (rec.y1 - yc) * (rec.y1 - yc);
-                        const double r2 = (rec.x2 - xc) * (rec.x2 - xc) + (rec.y2 - yc) * (rec.y2 - yc);
-                        double radSq = r1 > r2 ? r1 : r2;
-                        int nn = n; bool good = true; RectD rr = rec; double dens = density;
-                        while (dens < DENSITY_TH) {
-                            radSq *= 0.75 * 0.75;
-                            for (int i = 0; i < nn; ++i) {
-                                const int id = (int)reg[i];
-                                const int py = id / sw, px = id - py * sw;
-                                const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
-                                if (d2 > radSq) {
-                                    if (lane == 0) { atomicAnd(&usedBits[id >> 5], ~(1u << (id & 31))); unsigned last = reg[nn - 1]; reg[nn - 1] = (unsigned)id; reg[i] = last; }
-                                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                                    --nn; --i;
-                                }
+                    // reduce_region_radius: sequential swap-with-last removal (the order feeds later sums)
+                    const double r1 = (rec.x1 - xc) * (rec.x1 - xc) + (rec.y1 - yc) * (rec.y1 - yc);
+                    const double r2 = (rec.x2 - xc) * (rec.x2 - xc) + (rec.y2 - yc) * (rec.y2 - yc);
+                    double radSq = r1 > r2 ? r1 : r2;
+                    bool good = true;
+                    while (density < DENSITY_TH) {
+                        radSq *= 0.75 * 0.75;
+                        for (int i = 0; i < n; ++i) {
+                            const unsigned e = rq.get(i);
+                            const int px = e & 0xFFFF, py = e >> 16;
+                            const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
+                            if (d2 > radSq) {
+                                const int id = py * sw + px;
+                                const unsigned last = rq.get(n - 1);
+                                if (lane == 0) { atomicAnd(&ub[id >> 5], ~(1u << (id & 31))); rq.set(i, last); }
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                                --n; --i;
                             }
-                            if (nn < 2) { good = false; break; }
-                            region2rect_w0(reg, nn, sw, ang, S, regAngle, prec, p, rr);
-                            dens = (double)nn / (dist_d(rr.x1, rr.y1, rr.x2, rr.y2) * rr.width);
                         }
-                        if (lane == 0) { sh.regCount = nn; sh.rec = rr; sh.flag = good ? 1 : 0; }
+                        if (n < 2) { good = false; break; }
+                        region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec);
+                        density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
                     }
-                    __syncthreads();
-                    n = sh.regCount; rec = sh.rec; ok = sh.flag != 0;
+                    if (!good) continue;
                 }
             }
-            __syncthreads();
-        }
-        if (!ok) continue;
-        // ---- rect_improve (LSD_REFINE_ADV part) + NFA gate
-        const double logNfa = rect_improve_wg(rec, sw, sh_, ang, P.logNT, &sh);
-        if (!(logNfa > 0.0)) continue;
-        if (nSeg < MAX_SEG) {
-            if (tid == 0) {
+            // ---- rect_improve (LSD_REFINE_ADV part) + NFA gate
+            long long t3 = __builtin_readcyclecounter(); cyc2 += t3 - t2;
+            const double logNfa = rect_improve_w(rec, &imp, sw, sh, ang, P.logNT, lgam);
+            cyc3 += __builtin_readcyclecounter() - t3;
+            if (!(logNfa > 0.0)) continue;
+            if (nSeg < MAX_SEG && lane == 0) {
                 const double SCALE = 0.8;
-                double x1 = (rec.x1 + 0.5) / SCALE, y1 = (rec.y1 + 0.5) / SCALE, x2 = (rec.x2 + 0.5) / SCALE, y2 = (rec.y2 + 0.5) / SCALE;
-                seg[nSeg] = make_float4((float)x1, (float)y1, (float)x2, (float)y2);
+                seg[nSeg] = make_float4((float)((rec.x1 + 0.5) / SCALE), (float)((rec.y1 + 0.5) / SCALE),
+                                        (float)((rec.x2 + 0.5) / SCALE), (float)((rec.y2 + 0.5) / SCALE));
             }
+            ++nSeg;
         }
-        ++nSeg;
     }
-    if (tid == 0) { misc->nSeg = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1; }
+    if (lane == 0) {
+        misc->nSeg = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
+        misc->cyc[0] = cyc0; misc->cyc[1] = cyc1; misc->cyc[2] = cyc2; misc->cyc[3] = cyc3; misc->cyc[4] = __builtin_readcyclecounter() - tStart;
+        misc->cyc[5] = imp.cycCount; misc->cyc[6] = imp.cycMath;
+    }
 }
 
 // ------------------------------------------------------------------ KeyLine fill + top-N (LSDDetector::detectImpl, ExtractLineSegment :42-51)
@@ -838,7 +910,7 @@ struct sslam_lines {
     int maxLines;
     int planW = 0, planH = 0;
     LsdPlan plan;
-    DevBuf dWs, dTabs, dTaps;
+    DevBuf dWs, dTabs, dTaps, dLgam;
     int wsFrames = 0, lastFrames = 0;
     DevBuf dImg, dKl, dDesc, dFn, dCounts;
     HostPinned hOut;
@@ -871,7 +943,7 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     if (P.sw < 8 || P.sh < 8) { set_error("image %dx%d too small for LSD", w, h); return SSLAM_ERR_UNSUPPORTED; }
     P.spitch = (P.sw + 63) & ~63;
     P.npx = P.sw * P.sh;
-    if ((size_t)(P.npx + 31) / 32 * 4 > 150 * 1024) { set_error("image %dx%d exceeds the LDS used-map capacity", w, h); return SSLAM_ERR_UNSUPPORTED; }
+    if ((size_t)(P.npx + 31) / 32 * 4 + 4 * QCAP > 150 * 1024) { set_error("image %dx%d exceeds the LDS used-map capacity", w, h); return SSLAM_ERR_UNSUPPORTED; }
     P.nTiles = (P.npx + TILE_PX - 1) / TILE_PX;
     const double ANG_TH = 22.5, QUANT = 2.0, SIGMA_SCALE = 0.6;
     P.prec = kPI * ANG_TH / 180; P.p = ANG_TH / 180;
@@ -914,6 +986,7 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offScaled = take((size_t)P.spitch * P.sh);
     P.offAng = take(sizeof(float) * (size_t)P.npx);
     P.offS = take(sizeof(int) * (size_t)P.npx);
+    P.offPix = take(sizeof(float4) * (size_t)P.npx);
     P.offOrder = take(sizeof(unsigned) * (size_t)P.npx);
     P.offTileHist = take(sizeof(int) * (size_t)P.nTiles * N_BINS);
     P.offReg = take(sizeof(unsigned) * (size_t)P.npx);
@@ -924,6 +997,12 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offDy = take(sizeof(short) * (size_t)w * h);
     P.offKl = take(sizeof(sslam_keyline) * MAX_SEG);
     P.frameBytes = align_up(off, 4096);
+    {   // log-gamma table for nfa(): arguments are integers in [1, npx+2]
+        const int nl = P.npx + 4;
+        if ((rc = L->dLgam.ensure(sizeof(double) * (size_t)nl))) return rc;
+        hipLaunchKernelGGL(k_lgamma_table, dim3((nl + 255) / 256), dim3(256), 0, L->ctx->stream, L->dLgam.as<double>(), nl);
+        SSLAM_HIP(hipStreamSynchronize(L->ctx->stream));
+    }
     L->planW = w; L->planH = h; L->wsFrames = 0;
     return SSLAM_OK;
 }
@@ -940,7 +1019,7 @@ extern "C" int sslam_lines_destroy(sslam_lines* L) {
     if (!L) return SSLAM_OK;
     (void)hipSetDevice(L->ctx->device);
     (void)hipStreamSynchronize(L->ctx->stream);
-    DevBuf* bufs[] = {&L->dWs, &L->dTabs, &L->dTaps, &L->dImg, &L->dKl, &L->dDesc, &L->dFn, &L->dCounts};
+    DevBuf* bufs[] = {&L->dWs, &L->dTabs, &L->dTaps, &L->dLgam, &L->dImg, &L->dKl, &L->dDesc, &L->dFn, &L->dCounts};
     for (DevBuf* b : bufs) b->release();
     L->hOut.release();
     delete L;
@@ -981,28 +1060,28 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     uint8_t* ws = L->dWs.as<uint8_t>();
     const size_t bpitch = ((size_t)w + 63) & ~(size_t)63;
     const int* taps = L->dTaps.as<int>();
-    hipLaunchKernelGGL(k_zero_misc, dim3(nframes), dim3(64), 0, st, ws, P);
+    { sslam::ProfScope _ps(L->ctx, "k_zero_misc", st); hipLaunchKernelGGL(k_zero_misc, dim3(nframes), dim3(64), 0, st, ws, P); }
     // LSD: blur(7, 0.75) -> 0.8x -> gradient
-    hipLaunchKernelGGL(k_blur<3>, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride,
-                       ws + P.offBlur, bpitch, P.frameBytes, w, h, taps);
-    hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 63) / 64, (P.sh + 3) / 4, nframes), dim3(64, 4), 0, st, ws + P.offBlur, bpitch, P.frameBytes, w, h,
-                       ws + P.offScaled, (size_t)P.spitch, P.frameBytes, P.sw, P.sh, L->dTabs.as<int>() + P.tabX, L->dTabs.as<int>() + P.tabY);
-    hipLaunchKernelGGL(k_lsd_grad, dim3((P.npx + 255) / 256, nframes), dim3(256), 0, st, ws, P);
-    hipLaunchKernelGGL(k_lsd_hist, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P);
-    hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P);
-    hipLaunchKernelGGL(k_lsd_scatter, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P);
+    { sslam::ProfScope _ps(L->ctx, "k_blur<3>", st); hipLaunchKernelGGL(k_blur<3>, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride,
+                       ws + P.offBlur, bpitch, P.frameBytes, w, h, taps); }
+    { sslam::ProfScope _ps(L->ctx, "k_resize_exact", st); hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 63) / 64, (P.sh + 3) / 4, nframes), dim3(64, 4), 0, st, ws + P.offBlur, bpitch, P.frameBytes, w, h,
+                       ws + P.offScaled, (size_t)P.spitch, P.frameBytes, P.sw, P.sh, L->dTabs.as<int>() + P.tabX, L->dTabs.as<int>() + P.tabY); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st); hipLaunchKernelGGL(k_lsd_grad, dim3((P.npx + 255) / 256, nframes), dim3(256), 0, st, ws, P); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_hist", st); hipLaunchKernelGGL(k_lsd_hist, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_scan", st); hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }
     {
-        size_t lds = (size_t)((P.npx + 31) / 32) * 4;
+        size_t lds = (size_t)((P.npx + 31) / 32) * 4 + sizeof(unsigned) * QCAP;
         if (lds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_lsd_regions, dim3(nframes), dim3(256), lds, st, ws, P);
+        { sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st); hipLaunchKernelGGL(k_lsd_regions, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>()); }
     }
-    hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap);
+    { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
     // LBD: blur(5, 1) -> Sobel -> bands
-    hipLaunchKernelGGL(k_blur<2>, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride,
-                       ws + P.offBlur5, bpitch, P.frameBytes, w, h, taps + 8);
-    hipLaunchKernelGGL(k_sobel, dim3((w + 63) / 64, (h + 3) / 4, nframes), dim3(64, 4), 0, st, ws + P.offBlur5, bpitch, P.frameBytes, w, h,
-                       (short*)(ws + P.offDx), (short*)(ws + P.offDy), P.frameBytes);
-    hipLaunchKernelGGL(k_lbd, dim3(std::min(L->maxLines, cap), nframes), dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap);
+    { sslam::ProfScope _ps(L->ctx, "k_blur<2>", st); hipLaunchKernelGGL(k_blur<2>, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride,
+                       ws + P.offBlur5, bpitch, P.frameBytes, w, h, taps + 8); }
+    { sslam::ProfScope _ps(L->ctx, "k_sobel", st); hipLaunchKernelGGL(k_sobel, dim3((w + 63) / 64, (h + 3) / 4, nframes), dim3(64, 4), 0, st, ws + P.offBlur5, bpitch, P.frameBytes, w, h,
+                       (short*)(ws + P.offDx), (short*)(ws + P.offDy), P.frameBytes); }
+    { sslam::ProfScope _ps(L->ctx, "k_lbd", st); hipLaunchKernelGGL(k_lbd, dim3(std::min(L->maxLines, cap), nframes), dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap); }
     SSLAM_HIP(hipGetLastError());
     L->lastFrames = nframes;
     return SSLAM_OK;
@@ -1057,5 +1136,16 @@ extern "C" int sslam_lines_debug_segments(sslam_lines* L, int frame, float* seg_
     *n_out = m.nSeg;
     int n = std::min(m.nSeg, cap);
     if (n > 0 && seg_out) SSLAM_HIP(hipMemcpy(seg_out, base + P.offSeg, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_lines_debug_cycles(sslam_lines* L, int frame, long long* out8) {
+    if (!L || frame < 0 || frame >= L->lastFrames || !out8) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(L->ctx->device));
+    SSLAM_HIP(hipDeviceSynchronize());
+    const LsdPlan& P = L->plan;
+    Misc m;
+    SSLAM_HIP(hipMemcpy(&m, L->dWs.as<uint8_t>() + (size_t)frame * P.frameBytes + P.offMisc, sizeof(m), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out8[i] = m.cyc[i];
     return SSLAM_OK;
 }

@@ -52,6 +52,23 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
     }
 }
 
+// batch form: frame f uses q + f*cap*32 (nq[f] rows) against t + f*cap*32 (nt[f] rows)
+__global__ __launch_bounds__(256) void k_knn2_batch(const uint8_t* __restrict__ q, const int* __restrict__ nq, const uint8_t* __restrict__ t,
+                                                    const int* __restrict__ nt, int cap, int* __restrict__ idx, int* __restrict__ dist) {
+    const int f = blockIdx.y;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave >= nq[f]) return;
+    unsigned long long b, s;
+    wave_knn2(q + ((size_t)f * cap + wave) * 32, t + (size_t)f * cap * 32, nt[f], b, s);
+    if ((threadIdx.x & 63) == 0) {
+        const size_t o = ((size_t)f * cap + wave) * 2;
+        idx[o] = b == ~0ull ? -1 : (int)(unsigned)b;
+        dist[o] = b == ~0ull ? -1 : (int)(b >> 32);
+        idx[o + 1] = s == ~0ull ? -1 : (int)(unsigned)s;
+        dist[o + 1] = s == ~0ull ? -1 : (int)(s >> 32);
+    }
+}
+
 __global__ void k_hamming_matrix(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt, unsigned short* __restrict__ D) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (j >= nt || i >= nq) return;
@@ -285,7 +302,17 @@ extern "C" int sslam_hamming_knn2_dev(sslam_ctx* ctx, const uint8_t* d_q, int nq
     if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_idx || !d_dist))) { set_error("sslam_hamming_knn2_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
     if (nq == 0) return SSLAM_OK;
     SSLAM_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, pick(ctx, stream), d_q, nq, d_t, nt, d_idx, d_dist);
+    { sslam::ProfScope _ps(ctx, "k_knn2", pick(ctx, stream)); hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, pick(ctx, stream), d_q, nq, d_t, nt, d_idx, d_dist); }
+    SSLAM_HIP(hipGetLastError());
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_hamming_knn2_batch_dev(sslam_ctx* ctx, const uint8_t* d_q, const int32_t* d_nq, const uint8_t* d_t, const int32_t* d_nt,
+                                            int cap, int nframes, int32_t* d_idx, int32_t* d_dist, void* stream) {
+    if (!ctx || !d_q || !d_nq || !d_t || !d_nt || !d_idx || !d_dist || cap <= 0 || nframes <= 0) { set_error("sslam_hamming_knn2_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    { sslam::ProfScope _ps(ctx, "k_knn2_batch", st); hipLaunchKernelGGL(k_knn2_batch, dim3((cap + 3) / 4, nframes), dim3(256), 0, st, d_q, d_nq, d_t, d_nt, cap, d_idx, d_dist); }
     SSLAM_HIP(hipGetLastError());
     return SSLAM_OK;
 }
@@ -322,8 +349,8 @@ extern "C" int sslam_hamming_matrix(sslam_ctx* ctx, const uint8_t* q, int nq, co
     hipStream_t st = ctx->stream;
     SSLAM_HIP(hipMemcpyAsync(ctx->scratch[0].p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
     SSLAM_HIP(hipMemcpyAsync(ctx->scratch[1].p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_hamming_matrix, dim3((nt + 255) / 256, nq), dim3(256), 0, st, ctx->scratch[0].as<uint8_t>(), nq,
-                       ctx->scratch[1].as<uint8_t>(), nt, ctx->scratch[2].as<unsigned short>());
+    { sslam::ProfScope _ps(ctx, "k_hamming_matrix", st); hipLaunchKernelGGL(k_hamming_matrix, dim3((nt + 255) / 256, nq), dim3(256), 0, st, ctx->scratch[0].as<uint8_t>(), nq,
+                       ctx->scratch[1].as<uint8_t>(), nt, ctx->scratch[2].as<unsigned short>()); }
     SSLAM_HIP(hipGetLastError());
     SSLAM_HIP(hipMemcpyAsync(D, ctx->scratch[2].p, (size_t)nq * nt * 2, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
@@ -346,7 +373,7 @@ extern "C" int sslam_orb_search_for_initialization_batch_dev(sslam_ctx* ctx,
     A.cap = cap; A.n1s = 0; A.n2s = 0; A.prevMatched = d_prev; A.m12 = d_m12; A.nmatches = d_nm;
     A.scratch = ctx->scratch[3].as<int>(); A.window = window; A.nnratio = nnratio; A.checkOri = checkOri;
     A.minX = bounds[0]; A.maxX = bounds[1]; A.minY = bounds[2]; A.maxY = bounds[3];
-    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(64), 0, pick(ctx, stream), A);
+    { sslam::ProfScope _ps(ctx, "k_search_init", pick(ctx, stream)); hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(64), 0, pick(ctx, stream), A); }
     SSLAM_HIP(hipGetLastError());
     return SSLAM_OK;
 }
@@ -395,7 +422,7 @@ extern "C" int sslam_line_match_batch_dev(sslam_ctx* ctx, const uint8_t* d_l1, c
                                           int cap, int npf, double gate_scale, int ratio_mode, int32_t* d_pairs, int32_t* d_npairs, void* stream) {
     if (!ctx || !d_l1 || !d_l2 || !d_n1 || !d_n2 || !d_pairs || !d_npairs || cap <= 0 || npf <= 0) { set_error("sslam_line_match_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
     SSLAM_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_line_match, dim3(npf), dim3(256), 0, pick(ctx, stream), d_l1, d_n1, 0, d_l2, d_n2, 0, cap, gate_scale, ratio_mode, d_pairs, d_npairs, (double*)nullptr);
+    { sslam::ProfScope _ps(ctx, "k_line_match", pick(ctx, stream)); hipLaunchKernelGGL(k_line_match, dim3(npf), dim3(256), 0, pick(ctx, stream), d_l1, d_n1, 0, d_l2, d_n2, 0, cap, gate_scale, ratio_mode, d_pairs, d_npairs, (double*)nullptr); }
     SSLAM_HIP(hipGetLastError());
     return SSLAM_OK;
 }
@@ -420,7 +447,7 @@ extern "C" int sslam_line_match(sslam_ctx* ctx, const uint8_t* l1, int n1, const
     int* dp = (int*)(d2 + 32 * (size_t)c); int* dn = dp + 2 * (size_t)c; double* dm = (double*)(dn + 4);
     SSLAM_HIP(hipMemcpyAsync(d1, l1, 32 * (size_t)n1, hipMemcpyHostToDevice, st));
     SSLAM_HIP(hipMemcpyAsync(d2, l2, 32 * (size_t)n2, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_line_match, dim3(1), dim3(256), 0, st, d1, (const int*)nullptr, n1, d2, (const int*)nullptr, n2, c, gate_scale, ratio_mode, dp, dn, dm);
+    { sslam::ProfScope _ps(ctx, "k_line_match", st); hipLaunchKernelGGL(k_line_match, dim3(1), dim3(256), 0, st, d1, (const int*)nullptr, n1, d2, (const int*)nullptr, n2, c, gate_scale, ratio_mode, dp, dn, dm); }
     SSLAM_HIP(hipGetLastError());
     int np = 0; double mads[2] = {0, 0};
     std::vector<int> hp(2 * (size_t)c);

@@ -844,31 +844,31 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
     uint8_t* pyr = o->dPyr.as<uint8_t>();
     {
         dim3 blk(64), grd((w + 64 * 16 - 1) / (64 * 16), h, nframes);
-        hipLaunchKernelGGL(k_copy_level0, grd, blk, 0, st, d_images, pitch, image_stride, pyr, P.pyrFrame, w, h, P.L[0].pitch);
+        { sslam::ProfScope _ps(o->ctx, "k_copy_level0", st); hipLaunchKernelGGL(k_copy_level0, grd, blk, 0, st, d_images, pitch, image_stride, pyr, P.pyrFrame, w, h, P.L[0].pitch); }
     }
     for (int l = 1; l < P.nlevels; ++l) {
         dim3 blk(64, 4), grd((P.L[l].w + 255) / 256, (P.L[l].h + 3) / 4, nframes);
-        hipLaunchKernelGGL(k_resize, grd, blk, 0, st, pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short>());
+        { sslam::ProfScope _ps(o->ctx, "k_resize", st); hipLaunchKernelGGL(k_resize, grd, blk, 0, st, pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short>()); }
     }
     if (P.nCellsFrame > 0) {
         int tileP = (P.maxCellW + 6 + 3) & ~3, scP = P.maxCellW + 2;
         size_t lds = (size_t)(P.maxCellH + 6) * tileP + (size_t)(P.maxCellH + 2) * scP + (size_t)P.maxCellH * P.maxCellW;
         dim3 grd(P.nCellsFrame, nframes);
-        hipLaunchKernelGGL(k_fast_cells, grd, dim3(64), lds, st, pyr, P.pyrFrame, P, o->dCells.as<CellInfo>(), o->dCand.as<unsigned>(),
-                           o->dCellCount.as<int>(), o->iniTh, o->minTh, tileP, scP);
+        { sslam::ProfScope _ps(o->ctx, "k_fast_cells", st); hipLaunchKernelGGL(k_fast_cells, grd, dim3(64), lds, st, pyr, P.pyrFrame, P, o->dCells.as<CellInfo>(), o->dCand.as<unsigned>(),
+                           o->dCellCount.as<int>(), o->iniTh, o->minTh, tileP, scP); }
     }
     {
         int NC = P.maxNodeCap + 2, NCp2 = 1;
         while (NCp2 < NC) NCp2 <<= 1;
         size_t lds = sizeof(unsigned long long) * 2 * NCp2 + sizeof(int) * (P.maxCellsLevel + 1) + sizeof(unsigned) * 5 * (size_t)NC;
         dim3 grd(P.nlevels, nframes);
-        hipLaunchKernelGGL(k_octree, grd, dim3(64), lds, st, o->dCand.as<unsigned>(), o->dCellCount.as<int>(), o->dCells.as<CellInfo>(),
-                           o->dBufA.as<unsigned>(), o->dBufB.as<unsigned>(), o->dSel.as<unsigned>(), o->dSelCount.as<int>(), P, NC, NCp2);
+        { sslam::ProfScope _ps(o->ctx, "k_octree", st); hipLaunchKernelGGL(k_octree, grd, dim3(64), lds, st, o->dCand.as<unsigned>(), o->dCellCount.as<int>(), o->dCells.as<CellInfo>(),
+                           o->dBufA.as<unsigned>(), o->dBufB.as<unsigned>(), o->dSel.as<unsigned>(), o->dSelCount.as<int>(), P, NC, NCp2); }
     }
     {
         dim3 grd(P.selFrame, nframes);
-        hipLaunchKernelGGL(k_describe, grd, dim3(64), 0, st, pyr, P.pyrFrame, P, o->dSel.as<unsigned>(), o->dSelCount.as<int>(),
-                           d_kp, d_desc, d_counts, cap);
+        { sslam::ProfScope _ps(o->ctx, "k_describe", st); hipLaunchKernelGGL(k_describe, grd, dim3(64), 0, st, pyr, P.pyrFrame, P, o->dSel.as<unsigned>(), o->dSelCount.as<int>(),
+                           d_kp, d_desc, d_counts, cap); }
     }
     SSLAM_HIP(hipGetLastError());
     o->lastFrames = nframes;

@@ -1,0 +1,97 @@
+"""Batch-of-frames front-end pipeline over the C ABI (harness side, used by bench.py and
+the batch/multi-GPU tests).  One instance per GPU/process.  All device memory is held in
+torch tensors (plumbing); every computation is a libsslam_frontend.so kernel launched on
+torch's current stream through the *_dev entry points.
+
+Workload = BASELINE config 3: per frame ORB extract (1000 kp) + LSD/LBD extract (<=200
+lines) + match against the previous frame's features: ORBmatcher::SearchForInitialization
+(window 100, level 0) + dense knn-2 over all ORB descriptors, and the LSD knn-2 + MAD gate.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+
+class FrontendBatch:
+    def __init__(self, fe, ctx, w, h, batch, nfeatures=1000, max_lines=200, device="cuda:0", with_lines=True, with_match=True):
+        self.fe, self.ctx = fe, ctx
+        self.w, self.h, self.B = w, h, batch
+        self.dev = torch.device(device)
+        self.with_lines, self.with_match = with_lines, with_match
+        self.orb = fe.OrbExtractor(ctx, nfeatures, 1.2, 8, 20, 7)
+        self.lines = fe.LineExtractor(ctx, max_lines) if with_lines else None
+        self.cap, self.lcap = self.orb.cap, max_lines
+        B, cap, lcap = batch, self.cap, self.lcap
+        z = lambda *s, dt=torch.uint8: torch.zeros(*s, dtype=dt, device=self.dev)
+        self.feat = {}
+        for tag in ("cur", "prev"):
+            self.feat[tag] = dict(kp=z(B, cap, 7, dt=torch.float32), desc=z(B, cap, 32), n=z(B, dt=torch.int32),
+                                  kl=z(B, lcap, 17, dt=torch.float32), ldesc=z(B, lcap, 32),
+                                  linefn=z(B, lcap, 3, dt=torch.float64), nl=z(B, dt=torch.int32))
+        self.pm = z(B, cap, 2, dt=torch.float32)
+        self.m12 = z(B, cap, dt=torch.int32)
+        self.nmatch = z(B, dt=torch.int32)
+        self.knn_idx = z(B, cap, 2, dt=torch.int32)
+        self.knn_dist = z(B, cap, 2, dt=torch.int32)
+        self.lpairs = z(B, lcap, 2, dt=torch.int32)
+        self.nlpairs = z(B, dt=torch.int32)
+        self.bounds = (C.c_float * 4)(0.0, float(w), 0.0, float(h))
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def extract(self, images, tag="cur"):
+        """images: uint8 device tensor [B, h, w] (contiguous)."""
+        assert images.is_cuda and images.dtype == torch.uint8 and images.shape == (self.B, self.h, self.w) and images.is_contiguous()
+        f = self.feat[tag]
+        st = self._stream()
+        self.orb.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kp"], f["desc"], f["n"], self.cap, st)
+        if self.with_lines:
+            self.lines.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kl"], f["ldesc"], f["linefn"],
+                                         f["nl"], self.lcap, st)
+
+    def match(self):
+        """cur (F2 / train) against prev (F1 / query)."""
+        L = self.fe.lib()
+        p, c = self.feat["prev"], self.feat["cur"]
+        st = C.c_void_p(self._stream())
+        _p = lambda t: C.c_void_p(t.data_ptr())
+        self.pm.copy_(p["kp"][:, :, :2])          # vbPrevMatched starts at F1's keypoint positions (Tracking.cc:340-342)
+        rc = L.sslam_orb_search_for_initialization_batch_dev(self.ctx.h, _p(p["kp"]), _p(p["desc"]), _p(p["n"]), _p(c["kp"]), _p(c["desc"]),
+                                                             _p(c["n"]), self.cap, self.B, _p(self.pm), _p(self.m12), _p(self.nmatch), 100,
+                                                             C.c_float(0.9), 1, self.bounds, st)
+        assert rc == 0, L.sslam_last_error()
+        rc = L.sslam_hamming_knn2_batch_dev(self.ctx.h, _p(p["desc"]), _p(p["n"]), _p(c["desc"]), _p(c["n"]), self.cap, self.B,
+                                            _p(self.knn_idx), _p(self.knn_dist), st)
+        assert rc == 0, L.sslam_last_error()
+        if self.with_lines:
+            rc = L.sslam_line_match_batch_dev(self.ctx.h, _p(p["ldesc"]), _p(p["nl"]), _p(c["ldesc"]), _p(c["nl"]), self.lcap, self.B,
+                                              C.c_double(0.5), 0, _p(self.lpairs), _p(self.nlpairs), st)
+            assert rc == 0, L.sslam_last_error()
+
+    def step(self, images):
+        self.extract(images, "cur")
+        if self.with_match:
+            self.match()
+
+    def packed_results(self):
+        """Fixed-capacity record per frame for the final gather: counts, keypoints,
+        descriptors, keylines, line descriptors as one uint8 tensor [B, rec_bytes]."""
+        c = self.feat["cur"]
+        parts = [c["n"].view(torch.uint8).reshape(self.B, -1), c["nl"].view(torch.uint8).reshape(self.B, -1),
+                 c["kp"].view(torch.uint8).reshape(self.B, -1), c["desc"].reshape(self.B, -1),
+                 c["kl"].view(torch.uint8).reshape(self.B, -1), c["ldesc"].reshape(self.B, -1)]
+        return torch.cat(parts, dim=1)
+
+    def close(self):
+        self.orb.close()
+        if self.lines:
+            self.lines.close()
+
+
+def profile_drain(fe, ctx, cap=64):
+    L = fe.lib()
+    names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); cnt = (C.c_int * cap)()
+    n = L.sslam_profile_drain(ctx.h, names, ms, cnt, cap)
+    assert n >= 0
+    return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n, cap))}
