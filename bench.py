@@ -89,8 +89,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=3072)
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
+    ap.add_argument("--no-overlap", action="store_true", help="run the point and line branches on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing (used for rocprofv3 runs)")
     args = ap.parse_args()
@@ -135,18 +136,12 @@ def main():
     pipe.extract(prev, "prev")
     torch.cuda.synchronize()
 
-    gather_buf = None
+    sharding = pkg._load("sslam_sharding", os.path.join(pkg.PKG_DIR, "sharding.py"))
+
     def one_step():
-        pipe.step(cur)
-        if dist is not None:
-            rec = pipe.packed_results()
-            nonlocal gather_buf
-            if rank == 0:
-                if gather_buf is None:
-                    gather_buf = [torch.empty_like(rec) for _ in range(world)]
-                dist.gather(rec, gather_buf, dst=0)
-            else:
-                dist.gather(rec, None, dst=0)
+        pipe.step(cur, overlap=not args.no_overlap)
+        if dist is not None:      # the one exchange step of the path: per-frame records to rank 0 over RCCL
+            sharding.gather_to_root(dist, pipe.packed_results(), world, rank)
 
     for _ in range(args.warmup):
         one_step()

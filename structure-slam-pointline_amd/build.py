@@ -11,7 +11,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsslam_frontend.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("SSLAM_EXTRA_FLAGS", "").split()
 
 
 def sources():

@@ -28,6 +28,7 @@ constexpr double kPI = 3.14159265358979323846;
 constexpr double DEG2RAD = kPI / 180;
 constexpr double M_3_2_PI_ = (3 * kPI) / 2, M_2PI_ = 2 * kPI;
 constexpr float NOTDEF_F = -1024.0f;
+constexpr float USED_F = -2048.0f;       // written over pix[].x while a pixel belongs to a region (the `used` map)
 constexpr int N_BINS = 1024;
 constexpr int TILE_PX = 8192;           // raster tile of the counting sort
 constexpr int MAX_SEG = 8192;           // segments per frame (LSD output capacity)
@@ -272,15 +273,27 @@ __device__ double nfa_d(int n, int k, double p, double logNT, const double* __re
         if ((double)k > (double)n * p) return -log1term / 2.30258509299404568402 - logNT;
         return -logNT;
     }
-    double bin_tail = term, tolerance = 0.1;
-    for (int i = k + 1; i <= n; ++i) {
-        double bin_term = (double)(n - i + 1) / (double)i;
-        double mult_term = bin_term * p_term;
-        term *= mult_term;
-        bin_tail += term;
-        if (bin_term < 1) {
-            double err = term * ((1 - pow(mult_term, (double)(n - i + 1))) / (1 - mult_term) - 1);
-            if (err < tolerance * fabs(-log10(bin_tail) - logNT) * bin_tail) break;
+    double bin_tail = term;
+    const double tolerance = 0.1;
+    bool done = false;
+    for (int i0 = k + 1; i0 <= n && !done; i0 += 8) {
+        double mt[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {           // independent divisions: issue back to back
+            const int i = min(i0 + j, n);
+            mt[j] = ((double)(n - i + 1) / (double)i) * p_term;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j;
+            if (i <= n && !done) {
+                term *= mt[j];
+                bin_tail += term;
+                if (n - i + 1 < i) {             // bin_term < 1
+                    const double err = term * ((1 - pow(mt[j], (double)(n - i + 1))) / (1 - mt[j]) - 1);
+                    if (err < tolerance * fabs(-log10(bin_tail) - logNT) * bin_tail) done = true;
+                }
+            }
         }
     }
     return -log10(bin_tail) - logNT;
@@ -307,14 +320,14 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // changes when a pixel is accepted, so ONE ballot over all staged lanes finds the next accepted
 // pixel exactly as the sequential scan would; lanes before it are consumed, lanes after it are
 // re-tested against the updated angle.
-__device__ int region_grow_m(int seedX, int seedY, int sw, int sh, const float4* __restrict__ pix, unsigned* ub, const RegQ& rq,
+__device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __restrict__ pix, const float* __restrict__ ang, const RegQ& rq,
                              double prec, double& regAngleOut) {
     const int lane = threadIdx.x & 63;
     const int seed = seedY * sw + seedX;
     int n = 1;
-    double regAngle = (double)pix[seed].x * DEG2RAD;
+    double regAngle = (double)ang[seed] * DEG2RAD;
     float sumdx = (float)cos(regAngle), sumdy = (float)sin(regAngle);
-    if (lane == 0) { rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16)); atomicOr(&ub[seed >> 5], 1u << (seed & 31)); }
+    if (lane == 0) { rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16)); pix[seed].x = USED_F; }
     const int g = lane / 9, k = lane - g * 9;           // group (queue slot) and neighbour slot
     const int dy = k / 3 - 1, dx = k - (k / 3) * 3 - 1;
     int i = 0;
@@ -326,7 +339,8 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, const float4*
             xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
             if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
                 nidx = yy * sw + xx;
-                if (!used_get(ub, nidx)) { px4 = pix[nidx]; cand = px4.x != NOTDEF_F; }
+                px4 = pix[nidx];                 // .x < 0: NOTDEF or already USED
+                cand = px4.x >= 0.f;
             }
         }
         int lastSel = -1;
@@ -336,7 +350,7 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, const float4*
             if (!m) break;
             const int sel = __ffsll((long long)m) - 1;
             const int selIdx = __shfl(nidx, sel, 64);
-            if (lane == sel) { atomicOr(&ub[nidx >> 5], 1u << (nidx & 31)); rq.set(n, (unsigned)xx | ((unsigned)yy << 16)); }
+            if (lane == sel) { pix[nidx].x = USED_F; rq.set(n, (unsigned)xx | ((unsigned)yy << 16)); }
             ++n;
             sumdx = __fadd_rn(sumdx, __shfl(px4.y, sel, 64));
             sumdy = __fadd_rn(sumdy, __shfl(px4.z, sel, 64));
@@ -345,7 +359,6 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, const float4*
             lastSel = sel;
         }
         i += np;
-        rq_fence(n);
     }
     regAngleOut = regAngle;
     return n;
@@ -475,66 +488,66 @@ __device__ __forceinline__ void nfa_row_range(const NfaGeom& g, int y, int sw, i
     xa = (int)max(lft, 0LL); xb = (int)min(rgt, (long long)sw - 1);
 }
 
-// one wave: total / aligned point counts of rect_nfa for one rectangle.
-__device__ void nfa_count_w(const RectD& rec, int sw, int sh, const float* __restrict__ ang, int& totalOut, int& algOut) {
-    const int lane = threadIdx.x & 63;
-    const NfaGeom g = nfa_geom(rec, sh);
-    int total = 0, alg = 0;
-    const int nrows = g.y1 - g.y0 + 1;
-    // pass 1: row widths (lane per row) to pick the mapping
-    int wmax = 0;
-    for (int r0 = 0; r0 < nrows; r0 += 64) {
-        const int r = r0 + lane;
-        if (r < nrows) { int xa, xb; nfa_row_range(g, g.y0 + r, sw, xa, xb); if (xb >= xa) { total += xb - xa + 1; wmax = max(wmax, xb - xa + 1); } }
-    }
-    total = wave_sum(total); wmax = wave_max(wmax);
-    if (total > 0) {
-        if (wmax <= 24) {
-            // narrow rows: lane per row, four independent loads in flight per lane
-            for (int r0 = 0; r0 < nrows; r0 += 64) {
-                const int r = r0 + lane;
-                int xa = 0, xb = -1;
-                if (r < nrows) nfa_row_range(g, g.y0 + r, sw, xa, xb);
-                const float* row = ang + (size_t)(g.y0 + min(r, nrows - 1)) * sw;
-                for (int x = xa; x <= xb; x += 4) {
-                    const float a0 = row[x], a1 = x + 1 <= xb ? row[x + 1] : NOTDEF_F, a2 = x + 2 <= xb ? row[x + 2] : NOTDEF_F, a3 = x + 3 <= xb ? row[x + 3] : NOTDEF_F;
-                    alg += (int)is_aligned_val(a0, rec.theta, rec.prec) + (int)is_aligned_val(a1, rec.theta, rec.prec) +
-                           (int)is_aligned_val(a2, rec.theta, rec.prec) + (int)is_aligned_val(a3, rec.theta, rec.prec);
-                }
-            }
-        } else {
-            // wide rows: the wave sweeps each row, two rows in flight
-            for (int y = g.y0; y <= g.y1; y += 2) {
-                int xa0, xb0, xa1 = 0, xb1 = -1;
-                nfa_row_range(g, y, sw, xa0, xb0);
-                if (y + 1 <= g.y1) nfa_row_range(g, y + 1, sw, xa1, xb1);
-                const float* row0 = ang + (size_t)y * sw;
-                const float* row1 = row0 + sw;
-                const int span = max(xb0 - xa0, xb1 - xa1) + 1;
-                for (int o = lane; o < span; o += 64) {
-                    const float a0 = xa0 + o <= xb0 ? row0[xa0 + o] : NOTDEF_F;
-                    const float a1 = xa1 + o <= xb1 ? row1[xa1 + o] : NOTDEF_F;
-                    alg += (int)is_aligned_val(a0, rec.theta, rec.prec) + (int)is_aligned_val(a1, rec.theta, rec.prec);
-                }
-            }
-        }
-        alg = wave_sum(alg);
-    }
-    totalOut = total; algOut = alg;
-}
-
-// rect_improve.  Inside one refinement stage the candidate rectangles do not depend on which of
-// them gets accepted, so a stage's (up to five) NFAs are evaluated together: counts one after the
-// other (wave-wide), the five binomial-tail evaluations lane-parallel.
-struct ImproveLds { RectD cand[MAXC]; double val[MAXC]; int total[MAXC], alg[MAXC]; long long cycCount, cycMath; };
+// rect_improve support.  Inside one refinement stage the candidate rectangles do not depend on
+// which of them gets accepted, so a stage's (up to five) NFAs are evaluated together: all rows of
+// all candidates are spread over the wave (two lanes per row, twelve independent loads per lane,
+// wide rows swept by the whole wave), then the binomial tails run lane-parallel.
+struct ImproveLds { RectD cand[MAXC]; double val[MAXC]; NfaGeom geom[MAXC]; int total[MAXC], alg[MAXC]; long long cycCount, cycMath; };
 
 __device__ void nfa_eval_w(ImproveLds* L, int nc, int sw, int sh, const float* __restrict__ ang, double logNT, const double* __restrict__ lgam) {
     const int lane = threadIdx.x & 63;
     const long long tc0 = __builtin_readcyclecounter();
-    for (int c = 0; c < nc; ++c) {
-        int t, a;
-        nfa_count_w(L->cand[c], sw, sh, ang, t, a);
-        if (lane == 0) { L->total[c] = t; L->alg[c] = a; }
+    if (lane < nc) { L->geom[lane] = nfa_geom(L->cand[lane], sh); L->total[lane] = 0; L->alg[lane] = 0; }
+    __syncthreads();
+    int rb[MAXC + 1];
+    rb[0] = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) rb[c + 1] = rb[c] + (c < nc ? max(0, L->geom[c].y1 - L->geom[c].y0 + 1) : 0);
+    const int R = rb[MAXC];
+    const int half = lane & 1;
+    for (int t0 = 0; t0 < R; t0 += 32) {
+        const int t = t0 + (lane >> 1);
+        int c = 0, y = 0, xa = 0, xb = -1;
+        double theta = 0, prec = 0;
+        if (t < R) {
+#pragma unroll
+            for (int q = 1; q < MAXC; ++q) c += (t >= rb[q]) ? 1 : 0;
+            const NfaGeom g = L->geom[c];
+            const int rbc = c == 0 ? rb[0] : c == 1 ? rb[1] : c == 2 ? rb[2] : c == 3 ? rb[3] : rb[4];
+            y = g.y0 + (t - rbc);
+            nfa_row_range(g, y, sw, xa, xb);
+            theta = L->cand[c].theta; prec = L->cand[c].prec;
+        }
+        const int width = xb - xa + 1;
+        if (width > 0 && half == 0) atomicAdd(&L->total[c], width);
+        const bool wide = width > 24;
+        if (width > 0 && !wide) {
+            const float* row = ang + (size_t)y * sw;
+            const int xs = xa + half * 12;
+            float a[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) a[j] = (xs + j <= xb) ? row[xs + j] : NOTDEF_F;
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) cnt += (int)is_aligned_val(a[j], theta, prec);
+            if (cnt) atomicAdd(&L->alg[c], cnt);
+        }
+        // wide rows: whole wave sweeps them one by one
+        unsigned long long wm = __ballot(wide && half == 0);
+        while (wm) {
+            const int src = __ffsll((long long)wm) - 1;
+            wm &= wm - 1;
+            const int wc = __shfl(c, src, 64), wy = __shfl(y, src, 64), wxa = __shfl(xa, src, 64), wxb = __shfl(xb, src, 64);
+            const double wth = L->cand[wc].theta, wpr = L->cand[wc].prec;
+            const float* row = ang + (size_t)wy * sw;
+            int cnt = 0;
+            for (int x = wxa + lane; x <= wxb; x += 128) {
+                const float a0 = row[x], a1 = x + 64 <= wxb ? row[x + 64] : NOTDEF_F;
+                cnt += (int)is_aligned_val(a0, wth, wpr) + (int)is_aligned_val(a1, wth, wpr);
+            }
+            cnt = wave_sum(cnt);
+            if (lane == 0 && cnt) atomicAdd(&L->alg[wc], cnt);
+        }
     }
     __syncthreads();
     const long long tc1 = __builtin_readcyclecounter();
@@ -579,21 +592,21 @@ __device__ double rect_improve_w(RectD& rec, ImproveLds* L, int sw, int sh, cons
 }
 
 // One persistent single-wave workgroup per frame: the flsd() main loop replayed in order.
-__global__ __launch_bounds__(64) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
-    extern __shared__ __align__(16) unsigned dynLds[];           // used bitmap (npx bits) then the region queue
+#ifndef SSLAM_LSD_MINWAVES
+#define SSLAM_LSD_MINWAVES 3          // waves/SIMD the register allocator must leave room for
+#endif
+__global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
+    extern __shared__ __align__(16) unsigned dynLds[];           // region queue (first QCAP points)
     __shared__ ImproveLds imp;
     const int b = blockIdx.x, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     const float* ang = (const float*)(base + P.offAng);
-    const float4* pix = (const float4*)(base + P.offPix);
+    float4* pix = (float4*)(base + P.offPix);
     const unsigned* order = (const unsigned*)(base + P.offOrder);
     float4* seg = (float4*)(base + P.offSeg);
     Misc* misc = (Misc*)(base + P.offMisc);
     const int sw = P.sw, sh = P.sh;
-    const int nWords = (P.npx + 31) >> 5;
-    unsigned* ub = dynLds;
-    RegQ rq; rq.lds = dynLds + nWords; rq.glb = (unsigned*)(base + P.offReg);
-    for (int i = lane; i < nWords; i += 64) ub[i] = 0;
+    RegQ rq; rq.lds = dynLds; rq.glb = (unsigned*)(base + P.offReg);
     if (lane == 0) { imp.cycCount = 0; imp.cycMath = 0; }
     __syncthreads();
     const int nOrd = misc->nDefined;
@@ -606,7 +619,7 @@ __global__ __launch_bounds__(64) void k_lsd_regions(uint8_t* __restrict__ ws, Ls
         const int idx = q < nOrd ? (int)order[q] : -1;
         int after = -1;                                    // lanes <= after are consumed
         while (true) {
-            const bool un = idx >= 0 && lane > after && !used_get(ub, idx);
+            const bool un = idx >= 0 && lane > after && pix[idx].x >= 0.f;
             const unsigned long long m = __ballot(un);
             if (!m) break;
             const int first = __ffsll((long long)m) - 1;
@@ -615,7 +628,7 @@ __global__ __launch_bounds__(64) void k_lsd_regions(uint8_t* __restrict__ ws, Ls
             const int sy = seed / sw, sx = seed - sy * sw;
             double regAngle;
             long long t0 = __builtin_readcyclecounter();
-            int n = region_grow_m(sx, sy, sw, sh, pix, ub, rq, prec, regAngle);
+            int n = region_grow_m(sx, sy, sw, sh, pix, ang, rq, prec, regAngle);
             long long t1 = __builtin_readcyclecounter(); cyc0 += t1 - t0;
             if (n < P.minRegSize) continue;
             RectD rec;
@@ -627,7 +640,7 @@ __global__ __launch_bounds__(64) void k_lsd_regions(uint8_t* __restrict__ ws, Ls
                 const unsigned e0 = rq.get(0);
                 const int x0 = e0 & 0xFFFF, y0 = e0 >> 16;
                 const double xc = (double)x0, yc = (double)y0;
-                const double ang_c = (double)pix[y0 * sw + x0].x * DEG2RAD;
+                const double ang_c = (double)ang[y0 * sw + x0] * DEG2RAD;
                 double sum = 0, s_sum = 0; int cnt = 0;
                 for (int bs = 0; bs < n; bs += 64) {
                     const int i = bs + lane;
@@ -635,8 +648,9 @@ __global__ __launch_bounds__(64) void k_lsd_regions(uint8_t* __restrict__ ws, Ls
                     if (i < n) {
                         const unsigned e = rq.get(i);
                         const int px = e & 0xFFFF, py = e >> 16, id = py * sw + px;
-                        atomicAnd(&ub[id >> 5], ~(1u << (id & 31)));
-                        if (dist_d(xc, yc, (double)px, (double)py) < rec.width) { in = true; ad = angle_diff_signed((double)pix[id].x * DEG2RAD, ang_c); }
+                        const float aOrig = ang[id];
+                        pix[id].x = aOrig;                 // NOTUSED again
+                        if (dist_d(xc, yc, (double)px, (double)py) < rec.width) { in = true; ad = angle_diff_signed((double)aOrig * DEG2RAD, ang_c); }
                     }
                     const unsigned long long mi = __ballot(in);
                     const int c2 = min(64, n - bs);
@@ -645,7 +659,7 @@ __global__ __launch_bounds__(64) void k_lsd_regions(uint8_t* __restrict__ ws, Ls
                 }
                 const double mean_angle = sum / (double)cnt;
                 const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-                n = region_grow_m(x0, y0, sw, sh, pix, ub, rq, tau, regAngle);
+                n = region_grow_m(x0, y0, sw, sh, pix, ang, rq, tau, regAngle);
                 if (n < 2) continue;
                 region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec);
                 density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
@@ -664,7 +678,7 @@ __global__ __launch_bounds__(64) void k_lsd_regions(uint8_t* __restrict__ ws, Ls
                             if (d2 > radSq) {
                                 const int id = py * sw + px;
                                 const unsigned last = rq.get(n - 1);
-                                if (lane == 0) { atomicAnd(&ub[id >> 5], ~(1u << (id & 31))); rq.set(i, last); }
+                                if (lane == 0) { pix[id].x = ang[id]; rq.set(i, last); }
                                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                                 --n; --i;
                             }
@@ -943,7 +957,7 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     if (P.sw < 8 || P.sh < 8) { set_error("image %dx%d too small for LSD", w, h); return SSLAM_ERR_UNSUPPORTED; }
     P.spitch = (P.sw + 63) & ~63;
     P.npx = P.sw * P.sh;
-    if ((size_t)(P.npx + 31) / 32 * 4 + 4 * QCAP > 150 * 1024) { set_error("image %dx%d exceeds the LDS used-map capacity", w, h); return SSLAM_ERR_UNSUPPORTED; }
+    if (P.sw > 65535 || P.sh > 65535) { set_error("image %dx%d too large", w, h); return SSLAM_ERR_UNSUPPORTED; }
     P.nTiles = (P.npx + TILE_PX - 1) / TILE_PX;
     const double ANG_TH = 22.5, QUANT = 2.0, SIGMA_SCALE = 0.6;
     P.prec = kPI * ANG_TH / 180; P.p = ANG_TH / 180;
@@ -1071,7 +1085,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scan", st); hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }
     {
-        size_t lds = (size_t)((P.npx + 31) / 32) * 4 + sizeof(unsigned) * QCAP;
+        size_t lds = sizeof(unsigned) * QCAP;
         if (lds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         { sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st); hipLaunchKernelGGL(k_lsd_regions, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>()); }
     }

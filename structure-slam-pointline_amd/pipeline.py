@@ -52,6 +52,11 @@ class FrontendBatch:
 
     def match(self):
         """cur (F2 / train) against prev (F1 / query)."""
+        self._match_points()
+        if self.with_lines:
+            self._match_lines()
+
+    def _match_points(self):
         L = self.fe.lib()
         p, c = self.feat["prev"], self.feat["cur"]
         st = C.c_void_p(self._stream())
@@ -64,24 +69,50 @@ class FrontendBatch:
         rc = L.sslam_hamming_knn2_batch_dev(self.ctx.h, _p(p["desc"]), _p(p["n"]), _p(c["desc"]), _p(c["n"]), self.cap, self.B,
                                             _p(self.knn_idx), _p(self.knn_dist), st)
         assert rc == 0, L.sslam_last_error()
-        if self.with_lines:
+
+    def _match_lines(self):
+        L = self.fe.lib()
+        p, c = self.feat["prev"], self.feat["cur"]
+        st = C.c_void_p(self._stream())
+        _p = lambda t: C.c_void_p(t.data_ptr())
+        if True:
             rc = L.sslam_line_match_batch_dev(self.ctx.h, _p(p["ldesc"]), _p(p["nl"]), _p(c["ldesc"]), _p(c["nl"]), self.lcap, self.B,
                                               C.c_double(0.5), 0, _p(self.lpairs), _p(self.nlpairs), st)
             assert rc == 0, L.sslam_last_error()
 
-    def step(self, images):
-        self.extract(images, "cur")
-        if self.with_match:
-            self.match()
+    def step(self, images, overlap=False):
+        """One pass of the hot path.  overlap=True runs the point branch (ORB extract + ORB matching)
+        and the line branch (LSD/LBD extract + line matching) on two HIP streams: the line branch is
+        latency-bound (one persistent wave per frame), the point branch fills the idle issue slots."""
+        if not (overlap and self.with_lines):
+            self.extract(images, "cur")
+            if self.with_match:
+                self.match()
+            return
+        if not hasattr(self, "_s1"):
+            self._s1, self._s2 = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        cur = torch.cuda.current_stream(self.dev)
+        self._s1.wait_stream(cur); self._s2.wait_stream(cur)
+        f = self.feat["cur"]
+        with torch.cuda.stream(self._s2):
+            self.lines.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kl"], f["ldesc"], f["linefn"],
+                                         f["nl"], self.lcap, self._stream())
+            if self.with_match:
+                self._match_lines()
+        with torch.cuda.stream(self._s1):
+            self.orb.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kp"], f["desc"], f["n"], self.cap, self._stream())
+            if self.with_match:
+                self._match_points()
+        cur.wait_stream(self._s1); cur.wait_stream(self._s2)
 
     def packed_results(self):
-        """Fixed-capacity record per frame for the final gather: counts, keypoints,
-        descriptors, keylines, line descriptors as one uint8 tensor [B, rec_bytes]."""
+        """Fixed-capacity record per frame for the final gather, see sharding.record_layout."""
+        import importlib.util, os, sys
+        if "sslam_sharding" not in sys.modules:
+            spec = importlib.util.spec_from_file_location("sslam_sharding", os.path.join(os.path.dirname(os.path.abspath(__file__)), "sharding.py"))
+            m = importlib.util.module_from_spec(spec); sys.modules["sslam_sharding"] = m; spec.loader.exec_module(m)
         c = self.feat["cur"]
-        parts = [c["n"].view(torch.uint8).reshape(self.B, -1), c["nl"].view(torch.uint8).reshape(self.B, -1),
-                 c["kp"].view(torch.uint8).reshape(self.B, -1), c["desc"].reshape(self.B, -1),
-                 c["kl"].view(torch.uint8).reshape(self.B, -1), c["ldesc"].reshape(self.B, -1)]
-        return torch.cat(parts, dim=1)
+        return sys.modules["sslam_sharding"].pack_records(c["n"], c["nl"], c["kp"], c["desc"], c["kl"], c["ldesc"])
 
     def close(self):
         self.orb.close()

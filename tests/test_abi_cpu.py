@@ -1,0 +1,47 @@
+"""CPU suite: the C-ABI library is built, loads, exports every symbol include/sslam_frontend.h
+declares, and refuses to run without a GPU (no CPU fallback)."""
+import ctypes, os, re
+import pytest
+import pkg
+
+ROOT = pkg.ROOT
+
+
+def _declared_functions():
+    txt = open(os.path.join(ROOT, "include", "sslam_frontend.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sslam_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib_path = pkg.builder().build(force=False, verbose=False)
+    L = ctypes.CDLL(lib_path)
+    names = _declared_functions()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.sslam_abi_version() == 1
+
+
+def test_struct_layouts_match_opencv():
+    fe = pkg.frontend()
+    assert fe.KP_DTYPE.itemsize == 28          # cv::KeyPoint
+    assert fe.KL_DTYPE.itemsize == 68          # cv::line_descriptor::KeyLine
+    assert fe.KL_DTYPE.names[:3] == ("angle", "class_id", "octave") and fe.KL_DTYPE.names[-1] == "numOfPixels"
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    fe = pkg.frontend()
+    with pytest.raises(fe.SslamError) as e:
+        fe.Context(0)
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_graft_entry_build():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(ROOT, "__graft_entry__.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    m.build()

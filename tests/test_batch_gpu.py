@@ -1,0 +1,85 @@
+"""GPU: the batch-of-frames device API equals per-frame extraction, frame by frame, and full-size
+size-independent properties of the hot path (BASELINE configs at their full sizes)."""
+import os
+import numpy as np
+import pytest
+import torch
+import pkg
+from synth import synth_frame, warp_prev, noise_frame, const_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_equals_single_and_oracle(fe, ctx, oracle):
+    pipeline = pkg._load("sslam_pipeline", os.path.join(pkg.PKG_DIR, "pipeline.py"))
+    sh = pkg._load("sslam_sharding", os.path.join(pkg.PKG_DIR, "sharding.py"))
+    frames = [synth_frame(2000), noise_frame(9), const_frame(), synth_frame(2001), warp_prev(synth_frame(2000))]
+    B = len(frames)
+    pipe = pipeline.FrontendBatch(fe, ctx, 640, 480, B, 1000, 200, "cuda:0")
+    imgs = torch.from_numpy(np.stack(frames)).cuda()
+    prev = torch.from_numpy(np.stack([warp_prev(f) for f in frames])).cuda()
+    pipe.extract(prev, "prev")
+    pipe.step(imgs, overlap=True)
+    torch.cuda.synchronize()
+    rec = pipe.packed_results().cpu().numpy()
+    ox = fe.OrbExtractor(ctx, 1000); lx = fe.LineExtractor(ctx, 200)
+    for i, f in enumerate(frames):
+        r = sh.unpack_record(rec[i], pipe.cap, pipe.lcap)
+        kp, desc = ox(f); kl, ld, fn = lx(f)
+        assert r["n"] == len(kp) and r["nl"] == len(kl)
+        np.testing.assert_array_equal(r["kp"], kp.view(np.uint8).reshape(len(kp), 28))
+        np.testing.assert_array_equal(r["desc"], desc)
+        np.testing.assert_array_equal(r["kl"], kl.view(np.uint8).reshape(len(kl), 68))
+        np.testing.assert_array_equal(r["ldesc"], ld)
+    # matching of the batch == host API == oracle (frame 0 and 3)
+    m12 = pipe.m12.cpu().numpy(); nm = pipe.nmatch.cpu().numpy()
+    kidx = pipe.knn_idx.cpu().numpy(); lp = pipe.lpairs.cpu().numpy(); nlp = pipe.nlpairs.cpu().numpy()
+    for i in (0, 3):
+        kp1, d1 = oracle.orb_extract(warp_prev(frames[i]), 1000); kp2, d2 = oracle.orb_extract(frames[i], 1000)
+        pm = np.stack([kp1["x"], kp1["y"]], axis=1).astype(np.float32)
+        om12, _, on = oracle.search_for_initialization(kp1, d1, kp2, d2, pm, 100, 0.9, True)
+        assert nm[i] == on
+        np.testing.assert_array_equal(m12[i][:len(kp1)], om12)
+        oi, od = oracle.knn2(d1, d2)
+        np.testing.assert_array_equal(kidx[i][:len(kp1)], oi)
+        l1 = oracle.lines_extract(warp_prev(frames[i]), 200); l2 = oracle.lines_extract(frames[i], 200)
+        opairs, _, _ = oracle.line_match(l1[1], l2[1], 0.5, False)
+        assert nlp[i] == len(opairs)
+        np.testing.assert_array_equal(lp[i][:nlp[i]], opairs)
+    assert nm[2] == 0 and rec[2][:8].view(np.int32).tolist() == [0, 0]          # constant frame: nothing, no error
+    ox.close(); lx.close(); pipe.close()
+
+
+def test_fullsize_properties_1280(fe, ctx):
+    """BASELINE configs[3] size: properties that do not need the (slow) oracle."""
+    img = synth_frame(1235, w=1280, h=960)
+    ox = fe.OrbExtractor(ctx, 2000); lx = fe.LineExtractor(ctx, 400)
+    kp, desc = ox(img); kp2, desc2 = ox(img)
+    np.testing.assert_array_equal(kp.view(np.uint8), kp2.view(np.uint8))       # idempotent / deterministic
+    np.testing.assert_array_equal(desc, desc2)
+    assert 1900 <= len(kp) <= 2016 and (np.diff(kp["octave"]) >= 0).all()
+    per = np.bincount(kp["octave"], minlength=8)
+    assert (per <= np.array([434, 362, 302, 251, 209, 175, 145, 122]) + 2).all()   # quota + quadtree overshoot (D.2)
+    D = ctx.hamming_matrix(desc, desc)
+    assert (np.diag(D) == 0).all() and (D == D.T).all()                           # Hamming metric properties
+    idx, dist = ctx.hamming_knn2(desc, desc)
+    assert (dist[:, 0] == 0).all() and (dist[:, 1] >= 0).all()
+    assert (D[np.arange(len(D)), idx[:, 0]] == 0).all()
+    srt = np.sort(D, axis=1)
+    assert (srt[:, 0] == dist[:, 0]).all() and (srt[:, 1] == dist[:, 1]).all()    # knn2 distances == two smallest of the dense matrix
+    kl, ld, fn = lx(img)
+    assert len(kl) == 400 and (np.diff(kl["response"]) <= 0).all()
+    assert np.allclose(np.hypot(fn[:, 0], fn[:, 1]), 1.0)
+    ends = np.stack([kl["startPointX"], kl["startPointY"], np.ones(len(kl))], 1)
+    assert np.abs((fn * ends).sum(1)).max() < 1e-6                                 # endpoints lie on their line
+    ox.close(); lx.close()
+
+
+def test_empty_and_tiny_inputs(fe, ctx):
+    ox = fe.OrbExtractor(ctx, 1000)
+    kp, desc = ox(np.zeros((0, 0), np.uint8))
+    assert len(kp) == 0
+    kp, desc = ox(synth_frame(5, w=64, h=48))          # most levels smaller than a FAST cell
+    assert desc.shape == (len(kp), 32)
+    ox.close()
+    assert ctx.hamming_knn2(np.zeros((0, 32), np.uint8), np.zeros((4, 32), np.uint8))[0].shape == (0, 2)

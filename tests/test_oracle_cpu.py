@@ -1,0 +1,158 @@
+"""CPU suite (no GPU): known-answer tests of the oracle's leaf math, the oracle against the
+committed golden fixtures, and host-side helpers.  The reference ships no tests of its own
+(SURVEY.md §4), so the KATs are the hand-derivable ones listed there."""
+import os
+import numpy as np
+import pytest
+from synth import synth_frame, warp_prev, const_frame
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_popcount_distance(oracle):
+    z = np.zeros(32, np.uint8); o = np.full(32, 255, np.uint8)
+    assert oracle.descriptor_distance(z, o) == 256          # src/ORBmatcher.cc:1650-1666
+    assert oracle.descriptor_distance(z, z) == 0
+    a = np.zeros(32, np.uint8); a[5] = 0b10110001
+    assert oracle.descriptor_distance(a, z) == 4
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (50, 32), dtype=np.uint8); y = rng.integers(0, 256, (50, 32), dtype=np.uint8)
+    ref = np.unpackbits(x ^ y, axis=1).sum(axis=1)
+    assert [oracle.descriptor_distance(x[i], y[i]) for i in range(50)] == list(ref)
+
+
+def test_orb_constructor_tables(oracle):
+    scale, per_level, umax = oracle.orb_params(1000, 1.2, 8)
+    assert list(umax) == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]       # src/ORBextractor.cc:454-469
+    assert list(per_level) == [217, 181, 151, 126, 105, 87, 73, 60]                         # :436-446
+    np.testing.assert_allclose(scale, 1.2 ** np.arange(8), rtol=1e-6)
+    _, per_level2, _ = oracle.orb_params(2000, 1.2, 8)
+    assert list(per_level2) == [434, 362, 302, 251, 209, 175, 145, 122]
+
+
+def test_rbrief_pattern_table():
+    inc = os.path.join(os.path.dirname(GOLD), "..", "oracle", "orb_pattern.inc")
+    txt = open(inc).read().split("*/", 1)[1]
+    nums = np.array([int(t) for t in txt.replace("\n", "").split(",") if t.strip()])
+    assert nums.size == 1024                                      # 512 points, src/ORBextractor.cc:150-408
+    assert list(nums[:4]) == [8, -3, 9, 5] and list(nums[-4:]) == [-1, -6, 0, -11]
+    assert nums.min() == -13 and nums.max() == 13 or (nums.min() >= -13 and nums.max() <= 13)
+    r = np.sqrt((nums.reshape(-1, 2) ** 2).sum(axis=1)).max()
+    assert r < 19                                                 # taps stay inside EDGE_THRESHOLD
+    prod = os.path.join(os.path.dirname(GOLD), "..", "structure-slam-pointline_amd", "csrc", "orb_pattern.inc")
+    assert open(prod).read() == open(inc).read()
+
+
+def test_fast_atan2_axes(oracle):
+    assert oracle.fast_atan2(0, 1) == 0.0
+    assert abs(oracle.fast_atan2(1, 0) - 90.0) < 1e-4
+    assert abs(oracle.fast_atan2(0, -1) - 180.0) < 1e-4
+    assert abs(oracle.fast_atan2(-1, 0) - 270.0) < 1e-4
+    assert abs(oracle.fast_atan2(1, 1) - 45.0) < 0.02
+    for y, x in [(3, 4), (-2, 7), (5, -1), (-9, -9)]:
+        assert abs(oracle.fast_atan2(y, x) - (np.degrees(np.arctan2(y, x)) % 360)) < 0.05     # accuracy ~0.3 deg worst case
+
+
+def test_reflect101(oracle):
+    L = oracle.L
+    assert [L.orc_reflect101(i, 5) for i in (-2, -1, 0, 4, 5, 6)] == [2, 1, 0, 4, 3, 2]
+
+
+def test_gauss_taps(oracle):
+    assert list(oracle.gauss_taps(7, 2.0)) == [18, 34, 48, 56, 48, 34, 18]      # 8.8 fixed point, sum == 256 (decision D6)
+    assert sum(oracle.gauss_taps(7, 0.75)) == 256 and sum(oracle.gauss_taps(5, 1.0)) == 256
+
+
+def test_blur_constant_and_impulse(oracle):
+    c = np.full((20, 30), 77, np.uint8)
+    np.testing.assert_array_equal(oracle.blur7(c), c)             # taps sum to exactly 1.0
+    imp = np.zeros((21, 21), np.uint8); imp[10, 10] = 255
+    b = oracle.blur7(imp)
+    t = np.array([18, 34, 48, 56, 48, 34, 18])
+    exp = ((np.outer(t, t) * 255 + 32768) >> 16).astype(np.uint8)
+    np.testing.assert_array_equal(b[7:14, 7:14], exp)
+
+
+def test_fast_score_bright_arc(oracle):
+    p = np.full((7, 7), 100, np.uint8)
+    assert oracle.fast_score(p) <= 0                               # flat patch: no corner
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    q = p.copy()
+    for k in range(9):                                             # 9 contiguous ring pixels brighter by 50
+        dx, dy = ring[k]; q[3 + dy, 3 + dx] = 150
+    assert oracle.fast_score(q) == 49                              # score = arc contrast - 1
+    q2 = p.copy()
+    for k in range(8):
+        dx, dy = ring[k]; q2[3 + dy, 3 + dx] = 150
+    assert oracle.fast_score(q2) <= 0                              # 8 contiguous is not FAST-9
+
+
+def test_oracle_against_golden():
+    import oracle_lib
+    orc = oracle_lib.Oracle()
+    g = np.load(os.path.join(GOLD, "oracle_golden.npz"))
+    icl = np.load(os.path.join(GOLD, "icl_input_gray.npz"))["gray"]
+    frames = {"icl": (icl, 1000, 40), "synth1234": (synth_frame(1234), 1000, 200), "synth_small": (synth_frame(4321, w=320, h=240), 500, 200)}
+    import hashlib
+    for name, (img, nfeat, nln) in frames.items():
+        assert hashlib.sha256(img.tobytes()).digest() == g[name + "_sha"].tobytes(), "fixture image bytes changed: " + name
+        kp, desc = orc.orb_extract(img, nfeat)
+        np.testing.assert_array_equal(kp.view(np.uint8).reshape(len(kp), 28), g[name + "_kp"])
+        np.testing.assert_array_equal(desc, g[name + "_desc"])
+        kl, ld, fn, raw = orc.lines_extract(img, nln)
+        np.testing.assert_array_equal(raw, g[name + "_segs"])
+        np.testing.assert_array_equal(kl.view(np.uint8).reshape(len(kl), 68), g[name + "_kl"])
+        np.testing.assert_array_equal(ld, g[name + "_ldesc"])
+        np.testing.assert_array_equal(fn, g[name + "_linefn"])
+
+
+def test_oracle_match_golden(oracle):
+    g = np.load(os.path.join(GOLD, "oracle_golden.npz"))
+    cur = synth_frame(1234); prev = warp_prev(cur)
+    kp1, d1 = oracle.orb_extract(prev, 1000); kp2, d2 = oracle.orb_extract(cur, 1000)
+    pm = np.stack([kp1["x"], kp1["y"]], axis=1).astype(np.float32)
+    m12, pmo, n = oracle.search_for_initialization(kp1, d1, kp2, d2, pm, 100, 0.9, True)
+    np.testing.assert_array_equal(m12, g["match_m12"]); assert n == int(g["match_n"][0]) and n > 50
+    assert n == int((m12 >= 0).sum())
+    # every surviving match respects TH_LOW and the window
+    for i in np.nonzero(m12 >= 0)[0]:
+        assert oracle.descriptor_distance(d1[i], d2[m12[i]]) <= 50
+        assert abs(kp2["x"][m12[i]] - kp1["x"][i]) < 100 and abs(kp2["y"][m12[i]] - kp1["y"][i]) < 100
+    l1 = oracle.lines_extract(prev, 200); l2 = oracle.lines_extract(cur, 200)
+    pairs, mad, mad12 = oracle.line_match(l1[1], l2[1], 0.5, False)
+    np.testing.assert_array_equal(pairs, g["lmatch_pairs"])
+    assert [mad, mad12] == list(g["lmatch_mad"])
+
+
+def test_orb_structure_properties(oracle):
+    img = synth_frame(55)
+    kp, desc = oracle.orb_extract(img, 1000)
+    assert 900 <= len(kp) <= 1016 and desc.shape == (len(kp), 32)
+    assert (np.diff(kp["octave"]) >= 0).all()                      # levels concatenated 0..7 (:1075-1103)
+    sizes = {0: 31, 1: 37, 2: 44, 3: 53, 4: 64, 5: 77, 6: 92, 7: 111}
+    assert all(kp["size"][i] == sizes[int(kp["octave"][i])] for i in range(len(kp)))
+    assert ((kp["angle"] >= 0) & (kp["angle"] < 360)).all() and (kp["class_id"] == -1).all()
+    l0 = kp[kp["octave"] == 0]
+    assert (l0["x"] >= 19).all() and (l0["x"] < 640 - 19).all() and (l0["y"] >= 19).all() and (l0["y"] < 480 - 19).all()
+    assert (l0["x"] == np.round(l0["x"])).all()
+    kc, dc = oracle.orb_extract(const_frame(), 1000)
+    assert len(kc) == 0
+
+
+def test_knn2_degenerate(oracle):
+    q = np.zeros((3, 32), np.uint8); t = np.zeros((1, 32), np.uint8)
+    idx, dist = oracle.knn2(q, t)
+    assert (idx[:, 0] == 0).all() and (idx[:, 1] == -1).all() and (dist[:, 1] == -1).all()
+    pairs, mad, mad12 = oracle.line_match(q, t)                    # <2 train rows: defined as no matches
+    assert len(pairs) == 0
+
+
+def test_line_equations_and_keylines(oracle):
+    kl, ld, fn, raw = oracle.lines_extract(synth_frame(1234), 40)
+    assert len(kl) == 40 and (np.diff(kl["response"]) <= 0).all() and list(kl["class_id"]) == list(range(40))
+    for i in range(len(kl)):
+        sx, sy, ex, ey = [float(kl[f][i]) for f in ("startPointX", "startPointY", "endPointX", "endPointY")]
+        l = np.cross([sx, sy, 1.0], [ex, ey, 1.0]); l = l / np.hypot(l[0], l[1])
+        np.testing.assert_allclose(fn[i], l, rtol=1e-12, atol=1e-12)
+        assert abs(fn[i] @ np.array([sx, sy, 1.0])) < 1e-6 and abs(np.hypot(fn[i][0], fn[i][1]) - 1) < 1e-12
+        assert kl["numOfPixels"][i] == max(abs(round(ex) - round(sx)), abs(round(ey) - round(sy))) + 1
