@@ -38,23 +38,41 @@ class FrontendBatch:
         self.bounds = (C.c_float * 4)(0.0, float(w), 0.0, float(h))
 
     def _stream(self):
-        return torch.cuda.current_stream(self.dev).cuda_stream
+        h = torch.cuda.current_stream(self.dev).cuda_stream
+        assert h != 0, "pipeline work must run on an explicit (non-default) stream: handle 0 means 'context stream' in the C ABI"
+        return h
+
+    def _streams(self):
+        if not hasattr(self, "_s1"):
+            self._s1, self._s2 = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        return self._s1, self._s2
 
     def extract(self, images, tag="cur"):
-        """images: uint8 device tensor [B, h, w] (contiguous)."""
+        """images: uint8 device tensor [B, h, w] (contiguous).  Runs on the pipeline's point stream; the
+        caller's current stream is ordered before and after."""
         assert images.is_cuda and images.dtype == torch.uint8 and images.shape == (self.B, self.h, self.w) and images.is_contiguous()
         f = self.feat[tag]
-        st = self._stream()
-        self.orb.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kp"], f["desc"], f["n"], self.cap, st)
-        if self.with_lines:
-            self.lines.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kl"], f["ldesc"], f["linefn"],
-                                         f["nl"], self.lcap, st)
+        s1, _ = self._streams()
+        cur = torch.cuda.current_stream(self.dev)
+        s1.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            st = self._stream()
+            self.orb.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kp"], f["desc"], f["n"], self.cap, st)
+            if self.with_lines:
+                self.lines.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kl"], f["ldesc"], f["linefn"],
+                                             f["nl"], self.lcap, st)
+        cur.wait_stream(s1)
 
     def match(self):
         """cur (F2 / train) against prev (F1 / query)."""
-        self._match_points()
-        if self.with_lines:
-            self._match_lines()
+        s1, _ = self._streams()
+        cur = torch.cuda.current_stream(self.dev)
+        s1.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            self._match_points()
+            if self.with_lines:
+                self._match_lines()
+        cur.wait_stream(s1)
 
     def _match_points(self):
         L = self.fe.lib()
@@ -89,8 +107,7 @@ class FrontendBatch:
             if self.with_match:
                 self.match()
             return
-        if not hasattr(self, "_s1"):
-            self._s1, self._s2 = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        self._streams()
         cur = torch.cuda.current_stream(self.dev)
         self._s1.wait_stream(cur); self._s2.wait_stream(cur)
         f = self.feat["cur"]
