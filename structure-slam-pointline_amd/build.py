@@ -52,5 +52,30 @@ def build(force=False, verbose=True):
     return LIB
 
 
+SHIM = os.path.join(HERE, "shim")
+SHIM_LIB = os.path.join(LIBDIR, "libsslam_shim.so")
+SHIM_TEST = os.path.join(LIBDIR, "shim_test")
+
+
+def build_shim(force=False, verbose=True):
+    """The C++ host side (reference class surfaces over the C ABI): plain g++, links the HIP library."""
+    build(force=False, verbose=verbose)
+    srcs = [os.path.join(SHIM, f) for f in ("shim.cc", "shim_test.cpp", "cv_min.h", "ORBextractor.h", "ExtractLineSegment.h", "FrontendMatchers.h")]
+    if not force and os.path.exists(SHIM_TEST) and os.path.exists(SHIM_LIB) and \
+            all(os.path.getmtime(x) < os.path.getmtime(SHIM_TEST) for x in srcs + [LIB]):
+        return SHIM_TEST
+    cxx = os.environ.get("CXX", "g++")
+    cmds = [[cxx, "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared", os.path.join(SHIM, "shim.cc"), "-L" + LIBDIR, "-lsslam_frontend",
+             "-Wl,-rpath,$ORIGIN", "-o", SHIM_LIB],
+            [cxx, "-O2", "-std=c++17", "-Wall", os.path.join(SHIM, "shim_test.cpp"), "-L" + LIBDIR, "-lsslam_shim", "-lsslam_frontend",
+             "-Wl,-rpath,$ORIGIN", "-o", SHIM_TEST]]
+    for c in cmds:
+        if verbose:
+            print(" ".join(c), flush=True)
+        subprocess.check_call(c)
+    return SHIM_TEST
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_shim(force="--force" in sys.argv))

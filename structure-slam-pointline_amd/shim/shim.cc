@@ -1,0 +1,138 @@
+// Host side of the drop-in: the reference's class surfaces implemented over the C ABI.
+// Plain C++ (g++), links libsslam_frontend.so; no HIP types.
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <stdexcept>
+#include "../../include/sslam_frontend.h"
+#include "ORBextractor.h"
+#include "ExtractLineSegment.h"
+#include "FrontendMatchers.h"
+
+namespace {
+struct Global {
+    std::mutex mu;
+    sslam_ctx* ctx = nullptr;
+    sslam_lines* lines = nullptr;
+    int maxLines = 40;                       // reference cap, src/ExtractLineSegment.cpp:42
+    sslam_ctx* get() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!ctx) {
+            const char* d = std::getenv("SSLAM_DEVICE");
+            int rc = sslam_ctx_create(d ? std::atoi(d) : 0, &ctx);
+            if (rc != SSLAM_OK) { std::fprintf(stderr, "sslam front-end: %s (%s)\n", sslam_status_str(rc), sslam_last_error()); throw std::runtime_error("sslam front-end: no usable GPU (no CPU fallback)"); }
+        }
+        return ctx;
+    }
+    sslam_lines* getLines() {
+        sslam_ctx* c = get();
+        std::lock_guard<std::mutex> lk(mu);
+        if (!lines && sslam_lines_create(c, maxLines, &lines) != SSLAM_OK) throw std::runtime_error(sslam_last_error());
+        return lines;
+    }
+} G;
+void check(int rc) { if (rc != SSLAM_OK) throw std::runtime_error(std::string(sslam_status_str(rc)) + ": " + sslam_last_error()); }
+}  // namespace
+
+namespace StructureSLAM
+{
+ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
+    : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST), mHandle(nullptr)
+{
+    check(sslam_orb_create(G.get(), nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, &mHandle));
+    mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+    check(sslam_orb_get_scales(mHandle, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(), nullptr));
+    mvImagePyramid.resize(nlevels);
+}
+ORBextractor::~ORBextractor() { sslam_orb_destroy(mHandle); }
+
+void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors)
+{
+#ifdef SSLAM_HAVE_OPENCV
+    if (_image.empty()) return;
+    cv::Mat image = _image.getMat();
+#else
+    const cv::Mat& image = _image;
+    if (image.empty()) return;                       // outputs untouched, src/ORBextractor.cc:1046-1047
+#endif
+    const int cap = sslam_orb_max_keypoints(mHandle);
+    mStageKeys.resize(cap);
+    std::vector<uint8_t> desc((size_t)cap * 32);
+    int n = 0;
+    check(sslam_orb_extract(mHandle, image.data, image.cols, image.rows, (size_t)image.step, (sslam_keypoint*)mStageKeys.data(), desc.data(), cap, &n));
+    _keypoints.assign(mStageKeys.begin(), mStageKeys.begin() + n);
+    if (n == 0) { _descriptors.release(); return; }  // :1064-1065
+    _descriptors.create(n, 32, CV_8U);               // :1068
+#ifdef SSLAM_HAVE_OPENCV
+    cv::Mat d = _descriptors.getMat();
+#else
+    cv::Mat& d = _descriptors;
+#endif
+    for (int i = 0; i < n; ++i) std::memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
+}
+
+LineSegment::LineSegment() {}
+void LineSegment::SetMaxLines(int n) {
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (n != G.maxLines && G.lines) { sslam_lines_destroy(G.lines); G.lines = nullptr; }
+    G.maxLines = n;
+}
+void LineSegment::ExtractLineSegment(const cv::Mat &img, std::vector<cv::line_descriptor::KeyLine> &keylines, cv::Mat &ldesc,
+                                     std::vector<sslam_shim::Vector3d> &keylineFunctions, int, int)
+{
+    sslam_lines* L = G.getLines();
+    const int cap = G.maxLines;
+    keylines.resize(cap);
+    std::vector<uint8_t> d((size_t)cap * 32);
+    std::vector<double> fn((size_t)cap * 3);
+    int n = 0;
+    int rc = sslam_lines_extract(L, img.data, img.cols, img.rows, (size_t)img.step, (sslam_keyline*)keylines.data(), d.data(), fn.data(), cap, &n);
+    if (rc != SSLAM_OK) n = 0;                       // reference: OpenCV would throw; the shim returns 0 lines
+    keylines.resize(n);
+    if (n > 0) { ldesc.create(n, 32, CV_8U); for (int i = 0; i < n; ++i) std::memcpy(ldesc.ptr(i), &d[(size_t)i * 32], 32); }
+    for (int i = 0; i < n; ++i) { sslam_shim::Vector3d v; v(0) = fn[i * 3]; v(1) = fn[i * 3 + 1]; v(2) = fn[i * 3 + 2]; keylineFunctions.push_back(v); }
+}
+}  // namespace StructureSLAM
+
+namespace sslam_shim
+{
+static std::vector<uint8_t> rows32(const cv::Mat& m) {
+    std::vector<uint8_t> out((size_t)m.rows * 32);
+    for (int i = 0; i < m.rows; ++i) std::memcpy(&out[(size_t)i * 32], m.ptr(i), 32);
+    return out;
+}
+int DescriptorDistance(const cv::Mat &a, const cv::Mat &b) {
+    const uint32_t* pa = (const uint32_t*)a.ptr(0); const uint32_t* pb = (const uint32_t*)b.ptr(0);
+    int dist = 0;
+    for (int i = 0; i < 8; ++i) dist += __builtin_popcount(pa[i] ^ pb[i]);
+    return dist;
+}
+int SearchForInitialization(const std::vector<cv::KeyPoint> &k1, const cv::Mat &d1, const std::vector<cv::KeyPoint> &k2, const cv::Mat &d2,
+                            const float bounds[4], std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12,
+                            int windowSize, float nnratio, bool checkOri) {
+    vnMatches12.assign(k1.size(), -1);
+    if (k1.empty()) return 0;
+    std::vector<uint8_t> a = rows32(d1), b = rows32(d2);
+    int n = 0;
+    check(sslam_orb_search_for_initialization(G.get(), (const sslam_keypoint*)k1.data(), a.data(), (int)k1.size(), (const sslam_keypoint*)k2.data(),
+                                              b.data(), (int)k2.size(), (float*)vbPrevMatched.data(), vnMatches12.data(), windowSize, nnratio,
+                                              checkOri ? 1 : 0, bounds, &n));
+    return n;
+}
+void KnnMatch2(const cv::Mat &q, const cv::Mat &t, std::vector<int> &idx, std::vector<int> &dist) {
+    idx.assign((size_t)q.rows * 2, -1); dist.assign((size_t)q.rows * 2, -1);
+    if (q.rows == 0) return;
+    std::vector<uint8_t> a = rows32(q), b = rows32(t);
+    check(sslam_hamming_knn2(G.get(), a.data(), q.rows, b.data(), t.rows, idx.data(), dist.data()));
+}
+int LineMatch(const cv::Mat &l1, const cv::Mat &l2, double gateScale, bool ratioMode, std::vector<std::pair<int,int> > &matches) {
+    matches.clear();
+    if (l1.rows == 0 || l2.rows < 2) return 0;       // UB in the reference (src/LSDmatcher.cpp:167); defined as no matches
+    std::vector<uint8_t> a = rows32(l1), b = rows32(l2);
+    std::vector<int> pairs((size_t)l1.rows * 2);
+    int n = 0;
+    check(sslam_line_match(G.get(), a.data(), l1.rows, b.data(), l2.rows, gateScale, ratioMode ? 1 : 0, pairs.data(), l1.rows, &n, nullptr, nullptr));
+    for (int i = 0; i < n; ++i) matches.push_back(std::make_pair(pairs[i * 2], pairs[i * 2 + 1]));
+    return n;
+}
+}  // namespace sslam_shim

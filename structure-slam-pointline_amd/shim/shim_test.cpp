@@ -1,0 +1,60 @@
+// Exercises the drop-in C++ surface exactly as Frame.cc / Tracking.cc do and dumps the results for
+// tests/test_shim_gpu.py to compare against the oracle.
+//   shim_test <gray.raw> <w> <h> <prev.raw> <outprefix> <nfeatures> <maxlines>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include "ORBextractor.h"
+#include "ExtractLineSegment.h"
+#include "FrontendMatchers.h"
+
+static std::vector<uint8_t> readAll(const char* p) { std::ifstream f(p, std::ios::binary); return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()); }
+template <class T> static void dump(const std::string& p, const T* d, size_t n) { std::ofstream f(p, std::ios::binary); f.write((const char*)d, sizeof(T) * n); }
+
+int main(int argc, char** argv) {
+    if (argc < 8) return 2;
+    const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+    std::vector<uint8_t> cur = readAll(argv[1]), prev = readAll(argv[4]);
+    const std::string out = argv[5];
+    cv::Mat imCur(h, w, CV_8UC1, cur.data()), imPrev(h, w, CV_8UC1, prev.data());
+    StructureSLAM::ORBextractor* ext = new StructureSLAM::ORBextractor(std::atoi(argv[6]), 1.2f, 8, 20, 7);   // Tracking.cc:118
+    StructureSLAM::LineSegment::SetMaxLines(std::atoi(argv[7]));
+    StructureSLAM::LineSegment* seg = nullptr;            // deliberately NOT constructed: Frame::mpLineSegment is never initialised in the reference
+    alignas(8) char fake[sizeof(StructureSLAM::LineSegment)];
+    seg = reinterpret_cast<StructureSLAM::LineSegment*>(fake);
+
+    std::vector<cv::KeyPoint> k1, k2; cv::Mat d1, d2;
+    (*ext)(imPrev, cv::Mat(), k1, d1);                    // Frame::ExtractORB, src/Frame.cc:158
+    (*ext)(imCur, cv::Mat(), k2, d2);
+    std::vector<cv::line_descriptor::KeyLine> l1, l2; cv::Mat ld1, ld2; std::vector<sslam_shim::Vector3d> f1, f2;
+    seg->ExtractLineSegment(imPrev, l1, ld1, f1);         // Frame::ExtractLSD, src/Frame.cc:152
+    seg->ExtractLineSegment(imCur, l2, ld2, f2);
+    std::vector<cv::Point2f> prevMatched(k1.size());
+    for (size_t i = 0; i < k1.size(); ++i) prevMatched[i] = k1[i].pt;      // Tracking.cc:340-342
+    std::vector<int> m12;
+    const float bounds[4] = {0.f, (float)w, 0.f, (float)h};
+    int nm = sslam_shim::SearchForInitialization(k1, d1, k2, d2, bounds, prevMatched, m12, 100, 0.9f, true);   // Tracking.cc:365-366
+    std::vector<std::pair<int,int> > lm;
+    int nlm = sslam_shim::LineMatch(ld1, ld2, 0.5, false, lm);             // Tracking.cc:367-368
+    std::vector<int> kidx, kdist;
+    sslam_shim::KnnMatch2(ld1, ld2, kidx, kdist);
+    // empty image: outputs untouched
+    std::vector<cv::KeyPoint> ke(3); cv::Mat de; (*ext)(cv::Mat(), cv::Mat(), ke, de);
+    const int emptyOk = ke.size() == 3 ? 1 : 0;
+
+    dump(out + "_kp.bin", k2.data(), k2.size());
+    std::vector<uint8_t> dd((size_t)d2.rows * 32); for (int i = 0; i < d2.rows; ++i) memcpy(&dd[(size_t)i * 32], d2.ptr(i), 32);
+    dump(out + "_desc.bin", dd.data(), dd.size());
+    dump(out + "_kl.bin", l2.data(), l2.size());
+    std::vector<uint8_t> ll((size_t)ld2.rows * 32); for (int i = 0; i < ld2.rows; ++i) memcpy(&ll[(size_t)i * 32], ld2.ptr(i), 32);
+    dump(out + "_ldesc.bin", ll.data(), ll.size());
+    dump(out + "_fn.bin", f2.data(), f2.size());
+    dump(out + "_m12.bin", m12.data(), m12.size());
+    std::vector<int> lmf; for (auto& p : lm) { lmf.push_back(p.first); lmf.push_back(p.second); }
+    dump(out + "_lm.bin", lmf.data(), lmf.size());
+    int meta[6] = {(int)k2.size(), (int)l2.size(), nm, nlm, emptyOk, ext->GetLevels()};
+    dump(out + "_meta.bin", meta, 6);
+    std::printf("shim_test: %zu keypoints, %zu lines, %d ORB matches, %d line matches\n", k2.size(), l2.size(), nm, nlm);
+    delete ext;
+    return 0;
+}
