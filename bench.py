@@ -189,8 +189,14 @@ def main():
             avg_s = ms / launches * 1e-3
             bytes_per_launch = ab.get(name, 0) * B
             ach = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+            traffic = None
+            try:      # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), scaled to this batch
+                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"][name]
+                traffic = (pt["fetch_bytes_per_frame"] + pt["write_bytes_per_frame"]) * B
+            except Exception:
+                pass
             out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": None, "avg_launch_ms": ms / launches, "launches": launches,
+                               "traffic": traffic, "avg_launch_ms": ms / launches, "launches": launches,
                                "alg_bytes_per_launch": bytes_per_launch,
                                "whole_pipeline": {"alg_bytes_per_frame": sum(ab.values()), "achieved": sum(ab.values()) * fps / world / 1e9,
                                                   "frac": sum(ab.values()) * fps / world / 1e9 / HBM_PEAK_GBS},

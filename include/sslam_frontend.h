@@ -146,6 +146,33 @@ int sslam_orb_search_for_initialization_batch_dev(sslam_ctx* ctx,
         int cap, int npairs, float* d_prev_matched, int32_t* d_matches12, int32_t* d_nmatches,
         int window_size, float nnratio, int check_orientation, const float bounds[4], void* stream);
 
+/* The projection-window matcher family.  The tracker keeps the projection / visibility logic (poses, map
+ * points: host state) and hands over one query per map point or map line; the device replays the
+ * window search, the best/second-best Hamming selection, the level-consistent ratio test, the
+ * "keypoint already taken" rule and the rotation-histogram pruning of:
+ *   kind 0, mode 0  ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)   src/ORBmatcher.cc:45-129
+ *   kind 0, mode 1  ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)        src/ORBmatcher.cc:1331-1473
+ *   kind 1, mode 0  LSDmatcher::SearchByProjection(Frame&, const vector<MapLine*>&, th)    src/LSDmatcher.cpp:185-255
+ *                   LSDmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)        src/LSDmatcher.cpp:22-141
+ * feats = F.mvKeysUn (sslam_keypoint) or F.mvKeylinesUn (sslam_keyline), desc = F.mDescriptors / F.mLdesc,
+ * uright = F.mvuRight or NULL (monocular), occupied[i] = F.mvpMapPoints[i] has Observations()>0 (or NULL).
+ * assigned_out[i] = index of the query now owning feature i (-> F.mvpMapPoints[i] = that pMP) or -1. */
+typedef struct sslam_proj_query {
+    float u, v;            /* window centre (mTrackProjX/Y or projected u,v); lines: first projected endpoint */
+    float u2, v2;          /* lines: second projected endpoint */
+    float radius;          /* r * mvScaleFactors[level] resp. th * mvScaleFactors[octave] */
+    int32_t min_level, max_level;   /* the GetFeaturesInArea / GetLinesInArea level arguments */
+    float angle;           /* mode 1: LastFrame.mvKeysUn[i].angle (rotation histogram) */
+    float ur;              /* stereo: mTrackProjXR resp. u - mbf*invzc; ignored when uright == NULL */
+    int32_t valid;         /* 0: skipped (not in view, bad, outlier, behind the camera, outside the image) */
+    int32_t obs_positive;  /* the map point / line has Observations() > 0 */
+} sslam_proj_query;
+int sslam_search_by_projection(sslam_ctx* ctx, int kind, int mode, const void* feats, const uint8_t* desc, int n,
+                               const float bounds[4], const float* uright, const uint8_t* occupied,
+                               const sslam_proj_query* queries, const uint8_t* qdesc, int nq,
+                               float nnratio, int th_dist, int check_orientation,
+                               int32_t* assigned_out, int* nmatches_out);
+
 /* LSDmatcher::SerachForInitialize(InitialFrame,CurrentFrame,LineMatches),
  * src/LSDmatcher.cpp:257-284 = knn2 + Frame::lineDescriptorMAD (src/Frame.cc:190-215)
  * + the `d2-d1 > 0.5*MAD12` gate.  pairs_out[cap*2] (qdx,tdx); gate_scale = 0.5

@@ -174,6 +174,87 @@ static void line_descriptor_mad(const int32_t* dist, int n, double& nn_mad, doub
     nn12_mad = 1.4826 * g[n / 2];
 }
 
+// Frame::GetLinesInArea, src/Frame.cc:423-460 (linear scan, index order)
+struct KLm { float angle; int class_id, octave; float pt_x, pt_y, response, size, sx, sy, ex, ey, sxo, syo, exo, eyo, len; int npix; };
+static std::vector<int> lines_in_area(const KLm* kl, int n, float x1, float y1, float x2, float y2, float r, int minLevel, int maxLevel) {
+    std::vector<int> out;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel > 0);
+    for (int i = 0; i < n; ++i) {
+        const KLm& k = kl[i];
+        float distance = (float)((0.5 * (x1 + x2) - k.pt_x) * (0.5 * (x1 + x2) - k.pt_x) + (0.5 * (y1 + y2) - k.pt_y) * (0.5 * (y1 + y2) - k.pt_y));
+        if (distance > r * r) continue;
+        float slope = (y1 - y2) / (x1 - x2) - k.angle;
+        if (slope > r * 0.01) continue;
+        if (bCheckLevels) {
+            if (k.octave < minLevel) continue;
+            if (maxLevel >= 0 && k.octave > maxLevel) continue;
+        }
+        out.push_back(i);
+    }
+    return out;
+}
+
+struct ProjQuery { float u, v, u2, v2, radius; int minLevel, maxLevel; float angle, ur; int valid, obsPositive; };
+
+// The window/projection matcher family, restated once:
+//   kind 0, mode 0: ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)      src/ORBmatcher.cc:45-129
+//   kind 0, mode 1: ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)      src/ORBmatcher.cc:1331-1473
+//   kind 1, mode 0: LSDmatcher::SearchByProjection(Frame&, vector<MapLine*>&, th)        src/LSDmatcher.cpp:185-255
+//                   LSDmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)      src/LSDmatcher.cpp:22-141
+// The projection / visibility tests (tracker state) stay with the caller, which passes one ProjQuery per
+// map point / line: window centre (or projected endpoints), radius, level range, validity.
+static int search_by_projection(int kind, int mode, const void* feats, const uint8_t* desc, int n, const float bounds[4],
+                                const float* uright, const uint8_t* occupiedIn, const ProjQuery* q, const uint8_t* qdesc, int nq,
+                                float nnratio, int thDist, bool checkOri, int32_t* assigned) {
+    int nmatches = 0;
+    std::vector<uint8_t> occ(occupiedIn, occupiedIn + n);
+    for (int i = 0; i < n; ++i) assigned[i] = -1;
+    const KPm* kps = (const KPm*)feats; const KLm* kls = (const KLm*)feats;
+    FrameGrid* g = nullptr;
+    if (kind == 0) { g = new FrameGrid(); g->build(kps, n, bounds); }
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int iq = 0; iq < nq; ++iq) {
+        const ProjQuery& Q = q[iq];
+        if (!Q.valid) continue;
+        std::vector<int> ind = kind == 0 ? g->in_area(Q.u, Q.v, Q.radius, Q.minLevel, Q.maxLevel)
+                                         : lines_in_area(kls, n, Q.u, Q.v, Q.u2, Q.v2, Q.radius, Q.minLevel, Q.maxLevel);
+        if (ind.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : ind) {
+            if (occ[idx]) continue;
+            if (kind == 0 && uright && uright[idx] > 0) {
+                const float er = std::fabs(Q.ur - uright[idx]);
+                if (er > Q.radius) continue;
+            }
+            const int dist = descriptor_distance(qdesc + (size_t)iq * 32, desc + (size_t)idx * 32);
+            const int oct = kind == 0 ? kps[idx].octave : kls[idx].octave;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = oct; bestIdx = idx; }
+            else if (mode == 0 && dist < bestDist2) { bestLevel2 = oct; bestDist2 = dist; }
+        }
+        if (bestDist <= thDist) {
+            if (mode == 0 && bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            assigned[bestIdx] = iq; occ[bestIdx] = Q.obsPositive ? 1 : 0; nmatches++;
+            if (mode == 1 && checkOri) {
+                float rot = Q.angle - kps[bestIdx].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx);
+            }
+        }
+    }
+    if (mode == 1 && checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { assigned[idx] = -1; nmatches--; }
+    }
+    delete g;
+    return nmatches;
+}
+
 }  // namespace orc
 
 using namespace orc;
@@ -192,6 +273,12 @@ int orc_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, uint1
 int orc_search_for_initialization(const void* kp1, const uint8_t* d1, int n1, const void* kp2, const uint8_t* d2, int n2,
                                   float* prev_matched, int32_t* m12, int window, float nnratio, int check_ori, const float* bounds) {
     return search_for_initialization((const KPm*)kp1, d1, n1, (const KPm*)kp2, d2, n2, prev_matched, m12, window, nnratio, check_ori != 0, bounds);
+}
+
+int orc_search_by_projection(int kind, int mode, const void* feats, const uint8_t* desc, int n, const float* bounds, const float* uright,
+                             const uint8_t* occupied, const void* q, const uint8_t* qdesc, int nq, float nnratio, int th_dist, int check_ori,
+                             int32_t* assigned) {
+    return search_by_projection(kind, mode, feats, desc, n, bounds, uright, occupied, (const ProjQuery*)q, qdesc, nq, nnratio, th_dist, check_ori != 0, assigned);
 }
 
 // LSDmatcher gates.  Degenerate inputs (n1==0 or n2<2) are UB in the reference

@@ -203,6 +203,141 @@ __global__ __launch_bounds__(64) void k_search_init(SfiArgs A) {
     if (lane == 0) A.nmatches[p] = nmatches;
 }
 
+
+// ---------------------------------------------------------------- projection-window matchers
+// ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)  src/ORBmatcher.cc:45-129   (kind 0, mode 0)
+// ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)  src/ORBmatcher.cc:1331-1473 (kind 0, mode 1)
+// LSDmatcher::SearchByProjection(Frame&, vector<MapLine*>&, th) / (Frame&, const Frame&, ...) src/LSDmatcher.cpp:185-255,22-141 (kind 1, mode 0)
+// One wave per problem.  Queries are consumed sequentially (an accepted match occupies its keypoint for
+// the later queries); the candidate scan of each query is wave-parallel, with the reference's candidate
+// order (GetFeaturesInArea cell order / GetLinesInArea index order) carried in the reduction key.
+struct ProjArgs {
+    int kind, mode;
+    const void* feats; const uint8_t* desc; int n;
+    float minX, maxX, minY, maxY;
+    const float* uright; const uint8_t* occIn;
+    const sslam_proj_query* q; const uint8_t* qdesc; int nq;
+    float nnratio; int thDist, checkOri;
+    int* assigned; int* nmatches;
+    int* scratch;          // occ[n], key[n], qbin[nq], qidx[nq]
+};
+
+__global__ __launch_bounds__(64) void k_search_proj(ProjArgs A) {
+    const int lane = threadIdx.x;
+    const int n = A.n, nq = A.nq;
+    int* occ = A.scratch; int* key = occ + n; int* qbin = key + n; int* qidx = qbin + nq;
+    const sslam_keypoint* kps = (const sslam_keypoint*)A.feats;
+    const sslam_keyline* kls = (const sslam_keyline*)A.feats;
+    __shared__ int hist[HISTO_LENGTH];
+    if (lane < HISTO_LENGTH) hist[lane] = 0;
+    const float invW = __fdiv_rn((float)GRID_COLS, __fsub_rn(A.maxX, A.minX));
+    const float invH = __fdiv_rn((float)GRID_ROWS, __fsub_rn(A.maxY, A.minY));
+    for (int i = lane; i < n; i += 64) {
+        occ[i] = A.occIn ? (int)A.occIn[i] : 0;
+        A.assigned[i] = -1;
+        int k = i;                                  // lines: GetLinesInArea scans in index order
+        if (A.kind == 0) {
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(kps[i].x, A.minX), invW));
+            const int py = (int)roundf(__fmul_rn(__fsub_rn(kps[i].y, A.minY), invH));
+            k = (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) ? (((px * GRID_ROWS + py) << 19) | i) : -1;
+        }
+        key[i] = k;
+    }
+    for (int i = lane; i < nq; i += 64) qbin[i] = -1;
+    __syncthreads();
+    int nmatches = 0;
+    for (int iq = 0; iq < nq; ++iq) {
+        const sslam_proj_query Q = A.q[iq];
+        if (!Q.valid) continue;
+        const uint4 q0 = ((const uint4*)(A.qdesc + (size_t)iq * 32))[0], q1 = ((const uint4*)(A.qdesc + (size_t)iq * 32))[1];
+        unsigned long long b = ~0ull, s = ~0ull;
+        bool any = false;
+        for (int i = lane; i < n; i += 64) {
+            const int k = key[i];
+            if (k < 0) continue;
+            int oct;
+            if (A.kind == 0) {
+                const sslam_keypoint kp = kps[i];
+                oct = kp.octave;
+                if (Q.min_level > 0 || Q.max_level >= 0) {
+                    if (oct < Q.min_level) continue;
+                    if (Q.max_level >= 0 && oct > Q.max_level) continue;
+                }
+                const float dx = __fsub_rn(kp.x, Q.u), dy = __fsub_rn(kp.y, Q.v);
+                if (!(fabsf(dx) < Q.radius && fabsf(dy) < Q.radius)) continue;
+            } else {
+                const sslam_keyline kl = kls[i];
+                oct = kl.octave;
+                const double mxp = 0.5 * (double)__fadd_rn(Q.u, Q.u2) - (double)kl.pt_x, myp = 0.5 * (double)__fadd_rn(Q.v, Q.v2) - (double)kl.pt_y;
+                const float distance = (float)(mxp * mxp + myp * myp);
+                if (distance > __fmul_rn(Q.radius, Q.radius)) continue;
+                const float slope = __fsub_rn(__fdiv_rn(__fsub_rn(Q.v, Q.v2), __fsub_rn(Q.u, Q.u2)), kl.angle);
+                if ((double)slope > (double)Q.radius * 0.01) continue;
+                if (Q.min_level > 0 || Q.max_level > 0) {
+                    if (oct < Q.min_level) continue;
+                    if (Q.max_level >= 0 && oct > Q.max_level) continue;
+                }
+            }
+            any = true;                              // vIndices non-empty
+            if (occ[i]) continue;
+            if (A.kind == 0 && A.uright) {
+                const float ur = A.uright[i];
+                if (ur > 0 && fabsf(__fsub_rn(Q.ur, ur)) > Q.radius) continue;
+            }
+            const uint4* tp = (const uint4*)(A.desc + (size_t)i * 32);
+            const unsigned long long kk = ((unsigned long long)hamming256(q0, q1, tp[0], tp[1]) << 32) | (unsigned)k;
+            if (kk < b) { s = b; b = kk; } else if (kk < s) s = kk;
+        }
+        if (!__ballot(any)) continue;
+        const unsigned long long best = wave_min_u64(b);
+        const unsigned long long second = wave_min_u64(b == best ? s : b);
+        int bestDist = 256, bestLevel = -1, bestIdx = -1, bestDist2 = 256, bestLevel2 = -1;
+        if (best != ~0ull && (int)(best >> 32) < 256) {
+            bestDist = (int)(best >> 32); bestIdx = (int)(best & 0x7FFFF);
+            bestLevel = A.kind == 0 ? kps[bestIdx].octave : kls[bestIdx].octave;
+        }
+        if (A.mode == 0 && second != ~0ull && (int)(second >> 32) < 256) {
+            bestDist2 = (int)(second >> 32);
+            const int i2 = (int)(second & 0x7FFFF);
+            bestLevel2 = A.kind == 0 ? kps[i2].octave : kls[i2].octave;
+        }
+        if (bestDist <= A.thDist && bestIdx >= 0) {
+            if (A.mode == 0 && bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(A.nnratio, (float)bestDist2)) continue;
+            ++nmatches;
+            if (lane == 0) { A.assigned[bestIdx] = iq; occ[bestIdx] = Q.obs_positive ? 1 : 0; }
+            if (A.mode == 1 && A.checkOri) {
+                float rot = __fsub_rn(Q.angle, kps[bestIdx].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (lane == 0) { qbin[iq] = bin; qidx[iq] = bestIdx; hist[bin]++; }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (A.mode == 1 && A.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            const int c = hist[i];
+            if (c > max1) { max3 = max2; max2 = max1; max1 = c; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (c > max2) { max3 = max2; max2 = c; ind3 = ind2; ind2 = i; }
+            else if (c > max3) { max3 = c; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+        int removed = 0;
+        for (int i0 = 0; i0 < nq; i0 += 64) {
+            const int i = i0 + lane;
+            bool rm = false;
+            if (i < nq) { const int bn = qbin[i]; rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3; if (rm) A.assigned[qidx[i]] = -1; }
+            removed += __popcll(__ballot(rm));
+        }
+        nmatches -= removed;
+    }
+    if (lane == 0) *A.nmatches = nmatches;
+}
+
 // ---------------------------------------------------------------- line matching
 // One 256-thread workgroup per frame pair: knn-2 of n1 query LBD descriptors against
 // n2 train descriptors, Frame::lineDescriptorMAD (medians via LDS bitonic sorts), then
@@ -460,5 +595,46 @@ extern "C" int sslam_line_match(sslam_ctx* ctx, const uint8_t* l1, int n1, const
     if (nn12_mad_out) *nn12_mad_out = mads[1];
     if (np > cap) { set_error("sslam_line_match: %d pairs exceed capacity %d", np, cap); return SSLAM_ERR_CAPACITY; }
     memcpy(pairs_out, hp.data(), 8 * (size_t)np);
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_search_by_projection(sslam_ctx* ctx, int kind, int mode, const void* feats, const uint8_t* desc, int n, const float bounds[4],
+                                          const float* uright, const uint8_t* occupied, const sslam_proj_query* queries, const uint8_t* qdesc, int nq,
+                                          float nnratio, int th_dist, int check_orientation, int32_t* assigned_out, int* nmatches_out) {
+    if (!ctx || (kind != 0 && kind != 1) || (mode != 0 && mode != 1) || (kind == 1 && mode == 1) || n < 0 || nq < 0 || !nmatches_out || !bounds ||
+        (n > 0 && (!feats || !desc || !assigned_out)) || (nq > 0 && (!queries || !qdesc)) || n >= (1 << 19)) {
+        set_error("sslam_search_by_projection: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    *nmatches_out = 0;
+    for (int i = 0; i < n; ++i) assigned_out[i] = -1;
+    if (n == 0 || nq == 0) return SSLAM_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t fsz = kind == 0 ? sizeof(sslam_keypoint) : sizeof(sslam_keyline);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t oF = 0, oD = oF + al(fsz * n), oU = oD + al(32 * (size_t)n), oO = oU + al(4 * (size_t)n), oQ = oO + al((size_t)n),
+           oQD = oQ + al(sizeof(sslam_proj_query) * (size_t)nq), oA = oQD + al(32 * (size_t)nq), oN = oA + al(4 * (size_t)n),
+           oS = oN + 256, total = oS + al(4 * (2 * (size_t)n + 2 * (size_t)nq));
+    int rc;
+    if ((rc = ctx->scratch[6].ensure(total))) return rc;
+    uint8_t* B = ctx->scratch[6].as<uint8_t>();
+    SSLAM_HIP(hipMemcpyAsync(B + oF, feats, fsz * n, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oD, desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
+    if (uright) SSLAM_HIP(hipMemcpyAsync(B + oU, uright, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    if (occupied) SSLAM_HIP(hipMemcpyAsync(B + oO, occupied, (size_t)n, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oQ, queries, sizeof(sslam_proj_query) * (size_t)nq, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oQD, qdesc, 32 * (size_t)nq, hipMemcpyHostToDevice, st));
+    ProjArgs A;
+    A.kind = kind; A.mode = mode; A.feats = B + oF; A.desc = B + oD; A.n = n;
+    A.minX = bounds[0]; A.maxX = bounds[1]; A.minY = bounds[2]; A.maxY = bounds[3];
+    A.uright = uright ? (const float*)(B + oU) : nullptr; A.occIn = occupied ? B + oO : nullptr;
+    A.q = (const sslam_proj_query*)(B + oQ); A.qdesc = B + oQD; A.nq = nq; A.nnratio = nnratio; A.thDist = th_dist; A.checkOri = check_orientation;
+    A.assigned = (int*)(B + oA); A.nmatches = (int*)(B + oN); A.scratch = (int*)(B + oS);
+    { sslam::ProfScope _ps(ctx, "k_search_proj", st); hipLaunchKernelGGL(k_search_proj, dim3(1), dim3(64), 0, st, A); }
+    SSLAM_HIP(hipGetLastError());
+    SSLAM_HIP(hipMemcpyAsync(assigned_out, B + oA, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + oN, sizeof(int), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
     return SSLAM_OK;
 }

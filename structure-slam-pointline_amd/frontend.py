@@ -20,6 +20,10 @@ KL_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"),
                      ("lineLength", "<f4"), ("numOfPixels", "<i4")])
 assert KP_DTYPE.itemsize == 28 and KL_DTYPE.itemsize == 68
 
+PQ_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("u2", "<f4"), ("v2", "<f4"), ("radius", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                     ("angle", "<f4"), ("ur", "<f4"), ("valid", "<i4"), ("obs_positive", "<i4")])
+assert PQ_DTYPE.itemsize == 44
+
 _lib = None
 
 
@@ -98,6 +102,19 @@ class Context:
                                                        _p(pm), _p(m12), int(window), C.c_float(nnratio),
                                                        int(bool(check_orientation)), b, C.byref(n)))
         return m12, pm, n.value
+
+    def search_by_projection(self, kind, mode, feats, desc, queries, qdesc, occupied=None, uright=None, nnratio=0.8, th_dist=100,
+                             check_orientation=True, bounds=(0.0, 640.0, 0.0, 480.0)):
+        feats = np.ascontiguousarray(feats); desc = np.ascontiguousarray(desc, np.uint8)
+        queries = np.ascontiguousarray(queries, PQ_DTYPE); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        n = len(feats)
+        assigned = np.full(n, -1, np.int32); nm = C.c_int(0)
+        b = (C.c_float * 4)(*bounds)
+        occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        _chk(lib().sslam_search_by_projection(self.h, int(kind), int(mode), _p(feats), _p(desc), n, b, _p(ur), _p(occ), _p(queries), _p(qdesc),
+                                              len(queries), C.c_float(nnratio), int(th_dist), int(bool(check_orientation)), _p(assigned), C.byref(nm)))
+        return assigned, nm.value
 
     def line_match(self, l1, l2, gate_scale=0.5, ratio_mode=False):
         l1 = np.ascontiguousarray(l1, np.uint8); l2 = np.ascontiguousarray(l2, np.uint8)

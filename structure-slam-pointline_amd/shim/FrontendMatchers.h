@@ -18,6 +18,20 @@ int SearchForInitialization(const std::vector<cv::KeyPoint> &keysUn1, const cv::
                             std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12,
                             int windowSize, float nnratio, bool checkOri);
 
+// The projection-window family: ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (src/ORBmatcher.cc:45-129, mode 0),
+// ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (:1331-1473, mode 1) and, with keylines,
+// LSDmatcher::SearchByProjection(Frame&, vector<MapLine*>&, th) / (Frame&, const Frame&, ...) (src/LSDmatcher.cpp:185-255, 22-141).
+// The caller keeps the projection / visibility loop and fills one sslam_proj_query per map point (include/sslam_frontend.h);
+// assigned[i] >= 0 means F.mvpMapPoints[i] = map point of query assigned[i].
+struct ProjQuery { float u, v, u2, v2, radius; int min_level, max_level; float angle, ur; int valid, obs_positive; };
+int SearchByProjection(int mode, const std::vector<cv::KeyPoint> &keysUn, const cv::Mat &desc, const float bounds[4],
+                       const std::vector<float> *uRight, const std::vector<unsigned char> &occupied,
+                       const std::vector<ProjQuery> &queries, const cv::Mat &queryDesc, float nnratio, int thDist, bool checkOri,
+                       std::vector<int> &assigned);
+int SearchLinesByProjection(const std::vector<cv::line_descriptor::KeyLine> &keylinesUn, const cv::Mat &ldesc,
+                            const std::vector<unsigned char> &occupied, const std::vector<ProjQuery> &queries, const cv::Mat &queryDesc,
+                            float nnratio, int thDist, std::vector<int> &assigned);
+
 // cv::BFMatcher(NORM_HAMMING,false).knnMatch(q,t,m,2) as used by every LSDmatcher entry point.
 void KnnMatch2(const cv::Mat &query, const cv::Mat &train, std::vector<int> &idx /*nq*2*/, std::vector<int> &dist /*nq*2*/);
 

@@ -119,6 +119,30 @@ int SearchForInitialization(const std::vector<cv::KeyPoint> &k1, const cv::Mat &
                                               checkOri ? 1 : 0, bounds, &n));
     return n;
 }
+static_assert(sizeof(ProjQuery) == sizeof(sslam_proj_query), "ProjQuery layout");
+int SearchByProjection(int mode, const std::vector<cv::KeyPoint> &k, const cv::Mat &desc, const float bounds[4], const std::vector<float> *uRight,
+                       const std::vector<unsigned char> &occupied, const std::vector<ProjQuery> &queries, const cv::Mat &qd, float nnratio,
+                       int thDist, bool checkOri, std::vector<int> &assigned) {
+    assigned.assign(k.size(), -1);
+    if (k.empty() || queries.empty()) return 0;
+    std::vector<uint8_t> a = rows32(desc), b = rows32(qd);
+    int n = 0;
+    check(sslam_search_by_projection(G.get(), 0, mode, k.data(), a.data(), (int)k.size(), bounds, uRight ? uRight->data() : nullptr,
+                                     occupied.empty() ? nullptr : occupied.data(), (const sslam_proj_query*)queries.data(), b.data(),
+                                     (int)queries.size(), nnratio, thDist, checkOri ? 1 : 0, assigned.data(), &n));
+    return n;
+}
+int SearchLinesByProjection(const std::vector<cv::line_descriptor::KeyLine> &kl, const cv::Mat &ldesc, const std::vector<unsigned char> &occupied,
+                            const std::vector<ProjQuery> &queries, const cv::Mat &qd, float nnratio, int thDist, std::vector<int> &assigned) {
+    assigned.assign(kl.size(), -1);
+    if (kl.empty() || queries.empty()) return 0;
+    std::vector<uint8_t> a = rows32(ldesc), b = rows32(qd);
+    const float bounds[4] = {0.f, 1.f, 0.f, 1.f};
+    int n = 0;
+    check(sslam_search_by_projection(G.get(), 1, 0, kl.data(), a.data(), (int)kl.size(), bounds, nullptr, occupied.empty() ? nullptr : occupied.data(),
+                                     (const sslam_proj_query*)queries.data(), b.data(), (int)queries.size(), nnratio, thDist, 0, assigned.data(), &n));
+    return n;
+}
 void KnnMatch2(const cv::Mat &q, const cv::Mat &t, std::vector<int> &idx, std::vector<int> &dist) {
     idx.assign((size_t)q.rows * 2, -1); dist.assign((size_t)q.rows * 2, -1);
     if (q.rows == 0) return;

@@ -115,7 +115,20 @@ def _orc_match_methods():
                                   C.byref(mad), C.byref(mad12))
         return pairs[:n].copy(), mad.value, mad12.value
 
-    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match):
+    def search_by_projection(self, kind, mode, feats, desc, queries, qdesc, occupied=None, uright=None, nnratio=0.8, th_dist=100,
+                             check_orientation=True, bounds=(0.0, 640.0, 0.0, 480.0)):
+        feats = np.ascontiguousarray(feats); desc = np.ascontiguousarray(desc, np.uint8)
+        queries = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        n = len(feats)
+        assigned = np.full(n, -1, np.int32)
+        b = np.array(bounds, np.float32)
+        occ = np.zeros(n, np.uint8) if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        nm = self.L.orc_search_by_projection(int(kind), int(mode), _p(feats), _p(desc), n, _p(b), _p(ur), _p(occ), _p(queries), _p(qdesc),
+                                             len(queries), C.c_float(nnratio), int(th_dist), int(bool(check_orientation)), _p(assigned))
+        return assigned, nm
+
+    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection):
         setattr(Oracle, f.__name__, f)
 
 

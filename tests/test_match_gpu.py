@@ -66,3 +66,55 @@ def test_line_match(ctx, oracle, n1, n2, ratio):
     opairs, omad, omad12 = oracle.line_match(q, t, 0.5, ratio)
     np.testing.assert_array_equal(pairs, opairs)
     assert mad == omad and mad12 == omad12
+
+
+def _proj_queries(fe, rng, feats1, kind, mode, scales):
+    n = len(feats1)
+    q = np.zeros(n, fe.PQ_DTYPE)
+    if kind == 0:
+        q["u"] = feats1["x"] + 3 + rng.normal(0, 1.5, n); q["v"] = feats1["y"] - 2 + rng.normal(0, 1.5, n)
+        o = feats1["octave"]
+        if mode == 1:      # TrackWithMotionModel: th 15, levels [o-1, o+1]  (Tracking.cc:1227)
+            q["radius"] = 15 * scales[o]; q["min_level"] = o - 1; q["max_level"] = o + 1
+            third = rng.integers(0, 3, n)                      # exercise the forward / backward level windows too
+            q["max_level"] = np.where(third == 1, -1, q["max_level"]); q["min_level"] = np.where(third == 1, o, q["min_level"])
+            q["min_level"] = np.where(third == 2, 0, q["min_level"]); q["max_level"] = np.where(third == 2, o, q["max_level"])
+        else:              # SearchLocalPoints: r = 4 (or 2.5) * scale, levels [p-1, p]  (ORBmatcher.cc:66-71)
+            q["radius"] = np.where(rng.random(n) < 0.3, 2.5, 4.0) * 3 * scales[o]; q["min_level"] = o - 1; q["max_level"] = o
+        q["angle"] = feats1["angle"]
+    else:
+        q["u"] = feats1["startPointX"] + 3; q["v"] = feats1["startPointY"] - 2
+        q["u2"] = feats1["endPointX"] + 3; q["v2"] = feats1["endPointY"] - 2
+        q["radius"] = np.where(rng.random(n) < 0.5, 5.0, 8.0) * 3; q["min_level"] = -1; q["max_level"] = 0
+    q["valid"] = rng.random(n) < 0.95
+    q["obs_positive"] = rng.random(n) < 0.9
+    return q
+
+
+@pytest.mark.parametrize("mode,seed", [(0, 1234), (1, 1234), (0, 2003), (1, 2003)])
+def test_orb_search_by_projection(fe, ctx, oracle, mode, seed):
+    rng = np.random.default_rng(seed + mode)
+    cur = synth_frame(seed); prev = warp_prev(cur)
+    kp1, d1 = oracle.orb_extract(prev, 1000); kp2, d2 = oracle.orb_extract(cur, 1000)
+    scales = oracle.orb_params()[0]
+    q = _proj_queries(fe, rng, kp1, 0, mode, scales)
+    occ = (rng.random(len(kp2)) < 0.05).astype(np.uint8)
+    for uright in (None, np.where(rng.random(len(kp2)) < 0.3, kp2["x"] - rng.uniform(0, 40, len(kp2)), -1).astype(np.float32)):
+        if uright is not None:
+            q["ur"] = q["u"] - rng.uniform(0, 40, len(q))
+        a, n = ctx.search_by_projection(0, mode, kp2, d2, q, d1, occ, uright, 0.8 if mode == 0 else 0.9, 100, True)
+        oa, on = oracle.search_by_projection(0, mode, kp2, d2, q, d1, occ, uright, 0.8 if mode == 0 else 0.9, 100, True)
+        assert on > 50 and n == on
+        np.testing.assert_array_equal(a, oa)
+
+
+def test_line_search_by_projection(fe, ctx, oracle):
+    rng = np.random.default_rng(5)
+    cur = synth_frame(2000); prev = warp_prev(cur)
+    kl1, ld1, _, _ = oracle.lines_extract(prev, 200); kl2, ld2, _, _ = oracle.lines_extract(cur, 200)
+    q = _proj_queries(fe, rng, kl1, 1, 0, None)
+    occ = (rng.random(len(kl2)) < 0.05).astype(np.uint8)
+    a, n = ctx.search_by_projection(1, 0, kl2, ld2, q, ld1, occ, None, 0.6, 100, True)
+    oa, on = oracle.search_by_projection(1, 0, kl2, ld2, q, ld1, occ, None, 0.6, 100, True)
+    assert on > 10 and n == on
+    np.testing.assert_array_equal(a, oa)
