@@ -173,6 +173,17 @@ int sslam_search_by_projection(sslam_ctx* ctx, int kind, int mode, const void* f
                                float nnratio, int th_dist, int check_orientation,
                                int32_t* assigned_out, int* nmatches_out);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches), src/ORBmatcher.cc:159-291.
+ * The DBoW2 vocabulary transform stays on the host (the vocabulary file is not part of the reference tree); the
+ * matcher takes the two FeatureVectors as CSR lists over the nodes BOTH frames contain, ascending node id:
+ * node k owns keyframe features kf_idx[node_kf_ptr[k]..node_kf_ptr[k+1]) and frame features f_idx[node_f_ptr[k]..).
+ * kf_valid[i] = vpMapPointsKF[i] && !isBad().  assigned_out[j] = keyframe feature matched to frame feature j, or -1. */
+int sslam_orb_search_by_bow(sslam_ctx* ctx, const sslam_keypoint* kf_kp, const uint8_t* kf_desc, const uint8_t* kf_valid, int nkf,
+                            const sslam_keypoint* f_kp, const uint8_t* f_desc, int nf,
+                            const int32_t* node_kf_ptr, const int32_t* node_f_ptr, int nnodes,
+                            const int32_t* kf_idx, const int32_t* f_idx, float nnratio, int check_orientation,
+                            int32_t* assigned_out, int* nmatches_out);
+
 /* LSDmatcher::SerachForInitialize(InitialFrame,CurrentFrame,LineMatches),
  * src/LSDmatcher.cpp:257-284 = knn2 + Frame::lineDescriptorMAD (src/Frame.cc:190-215)
  * + the `d2-d1 > 0.5*MAD12` gate.  pairs_out[cap*2] (qdx,tdx); gate_scale = 0.5

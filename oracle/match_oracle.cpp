@@ -255,6 +255,52 @@ static int search_by_projection(int kind, int mode, const void* feats, const uin
     return nmatches;
 }
 
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), src/ORBmatcher.cc:159-291.  The DBoW2 vocabulary
+// (an LFS pointer in the reference tree) only decides WHICH features share a node; the matcher consumes the two
+// FeatureVectors, passed here as CSR lists over the shared nodes in ascending node id (the merge walk of :188-253).
+static int search_by_bow(const KPm* kpKF, const uint8_t* dKF, const uint8_t* validKF, const KPm* kpF, const uint8_t* dF, int nF,
+                         const int32_t* ptrKF, const int32_t* ptrF, int nnodes, const int32_t* idxKF, const int32_t* idxF,
+                         float nnratio, bool checkOri, int32_t* assigned) {
+    int nmatches = 0;
+    for (int i = 0; i < nF; ++i) assigned[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int nd = 0; nd < nnodes; ++nd) {
+        for (int a = ptrKF[nd]; a < ptrKF[nd + 1]; ++a) {
+            const int realIdxKF = idxKF[a];
+            if (!validKF[realIdxKF]) continue;                         // !pMP || pMP->isBad()
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            for (int b = ptrF[nd]; b < ptrF[nd + 1]; ++b) {
+                const int realIdxF = idxF[b];
+                if (assigned[realIdxF] >= 0) continue;
+                const int dist = descriptor_distance(dKF + (size_t)realIdxKF * 32, dF + (size_t)realIdxF * 32);
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+                assigned[bestIdxF] = realIdxKF;
+                if (checkOri) {
+                    float rot = kpKF[realIdxKF].angle - kpF[bestIdxF].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(bestIdxF);
+                }
+                nmatches++;
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { assigned[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 }  // namespace orc
 
 using namespace orc;
@@ -279,6 +325,12 @@ int orc_search_by_projection(int kind, int mode, const void* feats, const uint8_
                              const uint8_t* occupied, const void* q, const uint8_t* qdesc, int nq, float nnratio, int th_dist, int check_ori,
                              int32_t* assigned) {
     return search_by_projection(kind, mode, feats, desc, n, bounds, uright, occupied, (const ProjQuery*)q, qdesc, nq, nnratio, th_dist, check_ori != 0, assigned);
+}
+
+int orc_search_by_bow(const void* kpKF, const uint8_t* dKF, const uint8_t* validKF, const void* kpF, const uint8_t* dF, int nF,
+                      const int32_t* ptrKF, const int32_t* ptrF, int nnodes, const int32_t* idxKF, const int32_t* idxF, float nnratio, int check_ori,
+                      int32_t* assigned) {
+    return search_by_bow((const KPm*)kpKF, dKF, validKF, (const KPm*)kpF, dF, nF, ptrKF, ptrF, nnodes, idxKF, idxF, nnratio, check_ori != 0, assigned);
 }
 
 // LSDmatcher gates.  Degenerate inputs (n1==0 or n2<2) are UB in the reference

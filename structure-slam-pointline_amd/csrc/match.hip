@@ -338,6 +338,79 @@ __global__ __launch_bounds__(64) void k_search_proj(ProjArgs A) {
     if (lane == 0) *A.nmatches = nmatches;
 }
 
+
+// ---------------------------------------------------------------- SearchByBoW(KeyFrame*, Frame&)
+// src/ORBmatcher.cc:159-291.  One wave: the shared vocabulary nodes are walked in ascending id, the keyframe features
+// of a node sequentially (a matched frame feature is skipped by the later ones), the node's frame features lane-parallel
+// with the list position in the reduction key (first strictly smaller distance wins).
+struct BowArgs {
+    const sslam_keypoint* kpKF; const uint8_t* dKF; const uint8_t* validKF;
+    const sslam_keypoint* kpF; const uint8_t* dF; int nF;
+    const int* ptrKF; const int* ptrF; int nnodes; const int* idxKF; const int* idxF;
+    float nnratio; int checkOri; int* assigned; int* nmatches; int* qbin;   // qbin[nF]: rotation bin recorded for a frame feature
+};
+
+__global__ __launch_bounds__(64) void k_search_bow(BowArgs A) {
+    const int lane = threadIdx.x;
+    __shared__ int hist[HISTO_LENGTH];
+    if (lane < HISTO_LENGTH) hist[lane] = 0;
+    for (int i = lane; i < A.nF; i += 64) { A.assigned[i] = -1; A.qbin[i] = -1; }
+    __syncthreads();
+    int nmatches = 0, removed = 0;
+    for (int nd = 0; nd < A.nnodes; ++nd) {
+        const int f0 = A.ptrF[nd], f1 = A.ptrF[nd + 1];
+        for (int a = A.ptrKF[nd]; a < A.ptrKF[nd + 1]; ++a) {
+            const int ik = A.idxKF[a];
+            if (!A.validKF[ik]) continue;
+            const uint4 q0 = ((const uint4*)(A.dKF + (size_t)ik * 32))[0], q1 = ((const uint4*)(A.dKF + (size_t)ik * 32))[1];
+            unsigned long long b = ~0ull, s = ~0ull;
+            for (int p = f0 + lane; p < f1; p += 64) {
+                const int jf = A.idxF[p];
+                if (A.assigned[jf] >= 0) continue;
+                const uint4* tp = (const uint4*)(A.dF + (size_t)jf * 32);
+                const unsigned long long kk = ((unsigned long long)hamming256(q0, q1, tp[0], tp[1]) << 32) | (unsigned)(p - f0);
+                if (kk < b) { s = b; b = kk; } else if (kk < s) s = kk;
+            }
+            const unsigned long long best = wave_min_u64(b);
+            const unsigned long long second = wave_min_u64(b == best ? s : b);
+            int bestDist1 = 256, bestDist2 = 256, bestIdxF = -1;
+            if (best != ~0ull && (int)(best >> 32) < 256) { bestDist1 = (int)(best >> 32); bestIdxF = A.idxF[f0 + (int)(unsigned)best]; }
+            if (second != ~0ull && (int)(second >> 32) < 256) bestDist2 = (int)(second >> 32);
+            if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(A.nnratio, (float)bestDist2)) {
+                if (A.checkOri) {
+                    float rot = __fsub_rn(A.kpKF[ik].angle, A.kpF[bestIdxF].angle);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    if (lane == 0) { A.qbin[bestIdxF] = bin; hist[bin]++; }
+                }
+                if (lane == 0) A.assigned[bestIdxF] = ik;
+                ++nmatches;
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    if (A.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            const int c = hist[i];
+            if (c > max1) { max3 = max2; max2 = max1; max1 = c; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (c > max2) { max3 = max2; max2 = c; ind3 = ind2; ind2 = i; }
+            else if (c > max3) { max3 = c; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+        for (int i0 = 0; i0 < A.nF; i0 += 64) {      // a frame feature is matched at most once, so entries == features
+            const int i = i0 + lane;
+            bool rm = false;
+            if (i < A.nF) { const int bn = A.qbin[i]; rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3; if (rm) A.assigned[i] = -1; }
+            removed += __popcll(__ballot(rm));
+        }
+    }
+    if (lane == 0) *A.nmatches = nmatches - removed;
+}
+
 // ---------------------------------------------------------------- line matching
 // One 256-thread workgroup per frame pair: knn-2 of n1 query LBD descriptors against
 // n2 train descriptors, Frame::lineDescriptorMAD (medians via LDS bitonic sorts), then
@@ -635,6 +708,46 @@ extern "C" int sslam_search_by_projection(sslam_ctx* ctx, int kind, int mode, co
     SSLAM_HIP(hipGetLastError());
     SSLAM_HIP(hipMemcpyAsync(assigned_out, B + oA, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + oN, sizeof(int), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_search_by_bow(sslam_ctx* ctx, const sslam_keypoint* kf_kp, const uint8_t* kf_desc, const uint8_t* kf_valid, int nkf,
+                                       const sslam_keypoint* f_kp, const uint8_t* f_desc, int nf, const int32_t* node_kf_ptr, const int32_t* node_f_ptr,
+                                       int nnodes, const int32_t* kf_idx, const int32_t* f_idx, float nnratio, int check_orientation,
+                                       int32_t* assigned_out, int* nmatches_out) {
+    if (!ctx || nkf < 0 || nf < 0 || nnodes < 0 || !nmatches_out || (nf > 0 && !assigned_out) ||
+        (nnodes > 0 && (!node_kf_ptr || !node_f_ptr || !kf_idx || !f_idx || !kf_kp || !kf_desc || !kf_valid || !f_kp || !f_desc))) {
+        set_error("sslam_orb_search_by_bow: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    *nmatches_out = 0;
+    for (int i = 0; i < nf; ++i) assigned_out[i] = -1;
+    if (nnodes == 0 || nf == 0 || nkf == 0) return SSLAM_OK;
+    const int nk = node_kf_ptr[nnodes], nfi = node_f_ptr[nnodes];
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t ks = sizeof(sslam_keypoint);
+    size_t o[16]; size_t off = 0; int k = 0;
+    auto take = [&](size_t b) { o[k++] = off; off += al(b); };
+    take(ks * nkf); take(32 * (size_t)nkf); take((size_t)nkf); take(ks * nf); take(32 * (size_t)nf);
+    take(4 * (size_t)(nnodes + 1)); take(4 * (size_t)(nnodes + 1)); take(4 * (size_t)std::max(nk, 1)); take(4 * (size_t)std::max(nfi, 1));
+    take(4 * (size_t)nf); take(256); take(4 * (size_t)nf);
+    int rc;
+    if ((rc = ctx->scratch[7].ensure(off))) return rc;
+    uint8_t* B = ctx->scratch[7].as<uint8_t>();
+    const void* src[9] = {kf_kp, kf_desc, kf_valid, f_kp, f_desc, node_kf_ptr, node_f_ptr, kf_idx, f_idx};
+    const size_t len[9] = {ks * nkf, 32 * (size_t)nkf, (size_t)nkf, ks * nf, 32 * (size_t)nf, 4 * (size_t)(nnodes + 1), 4 * (size_t)(nnodes + 1), 4 * (size_t)nk, 4 * (size_t)nfi};
+    for (int i = 0; i < 9; ++i) if (len[i]) SSLAM_HIP(hipMemcpyAsync(B + o[i], src[i], len[i], hipMemcpyHostToDevice, st));
+    BowArgs A;
+    A.kpKF = (const sslam_keypoint*)(B + o[0]); A.dKF = B + o[1]; A.validKF = B + o[2]; A.kpF = (const sslam_keypoint*)(B + o[3]); A.dF = B + o[4]; A.nF = nf;
+    A.ptrKF = (const int*)(B + o[5]); A.ptrF = (const int*)(B + o[6]); A.nnodes = nnodes; A.idxKF = (const int*)(B + o[7]); A.idxF = (const int*)(B + o[8]);
+    A.nnratio = nnratio; A.checkOri = check_orientation; A.assigned = (int*)(B + o[9]); A.nmatches = (int*)(B + o[10]); A.qbin = (int*)(B + o[11]);
+    { sslam::ProfScope _ps(ctx, "k_search_bow", st); hipLaunchKernelGGL(k_search_bow, dim3(1), dim3(64), 0, st, A); }
+    SSLAM_HIP(hipGetLastError());
+    SSLAM_HIP(hipMemcpyAsync(assigned_out, B + o[9], 4 * (size_t)nf, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + o[10], sizeof(int), hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
     return SSLAM_OK;
 }

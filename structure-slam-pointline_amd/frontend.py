@@ -116,6 +116,18 @@ class Context:
                                               len(queries), C.c_float(nnratio), int(th_dist), int(bool(check_orientation)), _p(assigned), C.byref(nm)))
         return assigned, nm.value
 
+    def search_by_bow(self, kf_kp, kf_desc, kf_valid, f_kp, f_desc, ptr_kf, ptr_f, idx_kf, idx_f, nnratio=0.9, check_orientation=True):
+        kf_kp = np.ascontiguousarray(kf_kp); f_kp = np.ascontiguousarray(f_kp)
+        kf_desc = np.ascontiguousarray(kf_desc, np.uint8); f_desc = np.ascontiguousarray(f_desc, np.uint8)
+        kf_valid = np.ascontiguousarray(kf_valid, np.uint8)
+        ptr_kf = np.ascontiguousarray(ptr_kf, np.int32); ptr_f = np.ascontiguousarray(ptr_f, np.int32)
+        idx_kf = np.ascontiguousarray(idx_kf, np.int32); idx_f = np.ascontiguousarray(idx_f, np.int32)
+        assigned = np.full(len(f_kp), -1, np.int32); nm = C.c_int(0)
+        _chk(lib().sslam_orb_search_by_bow(self.h, _p(kf_kp), _p(kf_desc), _p(kf_valid), len(kf_kp), _p(f_kp), _p(f_desc), len(f_kp), _p(ptr_kf),
+                                           _p(ptr_f), len(ptr_kf) - 1, _p(idx_kf), _p(idx_f), C.c_float(nnratio), int(bool(check_orientation)),
+                                           _p(assigned), C.byref(nm)))
+        return assigned, nm.value
+
     def line_match(self, l1, l2, gate_scale=0.5, ratio_mode=False):
         l1 = np.ascontiguousarray(l1, np.uint8); l2 = np.ascontiguousarray(l2, np.uint8)
         cap = max(len(l1), 1)

@@ -128,7 +128,18 @@ def _orc_match_methods():
                                              len(queries), C.c_float(nnratio), int(th_dist), int(bool(check_orientation)), _p(assigned))
         return assigned, nm
 
-    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection):
+    def search_by_bow(self, kf_kp, kf_desc, kf_valid, f_kp, f_desc, ptr_kf, ptr_f, idx_kf, idx_f, nnratio=0.9, check_orientation=True):
+        kf_kp = np.ascontiguousarray(kf_kp); f_kp = np.ascontiguousarray(f_kp)
+        kf_desc = np.ascontiguousarray(kf_desc, np.uint8); f_desc = np.ascontiguousarray(f_desc, np.uint8)
+        kf_valid = np.ascontiguousarray(kf_valid, np.uint8)
+        ptr_kf = np.ascontiguousarray(ptr_kf, np.int32); ptr_f = np.ascontiguousarray(ptr_f, np.int32)
+        idx_kf = np.ascontiguousarray(idx_kf, np.int32); idx_f = np.ascontiguousarray(idx_f, np.int32)
+        assigned = np.full(len(f_kp), -1, np.int32)
+        nm = self.L.orc_search_by_bow(_p(kf_kp), _p(kf_desc), _p(kf_valid), _p(f_kp), _p(f_desc), len(f_kp), _p(ptr_kf), _p(ptr_f),
+                                      len(ptr_kf) - 1, _p(idx_kf), _p(idx_f), C.c_float(nnratio), int(bool(check_orientation)), _p(assigned))
+        return assigned, nm
+
+    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow):
         setattr(Oracle, f.__name__, f)
 
 

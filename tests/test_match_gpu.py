@@ -118,3 +118,30 @@ def test_line_search_by_projection(fe, ctx, oracle):
     oa, on = oracle.search_by_projection(1, 0, kl2, ld2, q, ld1, occ, None, 0.6, 100, True)
     assert on > 10 and n == on
     np.testing.assert_array_equal(a, oa)
+
+
+def _pseudo_feature_vectors(d1, d2, nbits=5):
+    """Stand-in for DBoW2's FeatureVector (the vocabulary file is not in the reference tree): node id = a few
+    descriptor bits, so related descriptors mostly share a node.  Returns CSR lists over the shared nodes."""
+    def node(d):
+        return (d[:, 0].astype(np.int32) >> (8 - nbits)) | ((d[:, 7].astype(np.int32) >> 6) << nbits)
+    n1, n2 = node(d1), node(d2)
+    shared = sorted(set(n1.tolist()) & set(n2.tolist()))
+    pk, pf, ik, jf = [0], [0], [], []
+    for nd in shared:
+        a = np.nonzero(n1 == nd)[0]; b = np.nonzero(n2 == nd)[0]      # ascending feature index, as DBoW2 fills them
+        ik += a.tolist(); jf += b.tolist(); pk.append(len(ik)); pf.append(len(jf))
+    return np.array(pk, np.int32), np.array(pf, np.int32), np.array(ik, np.int32), np.array(jf, np.int32)
+
+
+@pytest.mark.parametrize("seed,ori,ratio", [(1234, True, 0.9), (2003, False, 0.75), (2004, True, 0.7)])
+def test_search_by_bow(fe, ctx, oracle, seed, ori, ratio):
+    rng = np.random.default_rng(seed)
+    cur = synth_frame(seed); prev = warp_prev(cur)
+    kp1, d1 = oracle.orb_extract(prev, 1000); kp2, d2 = oracle.orb_extract(cur, 1000)
+    pk, pf, ik, jf = _pseudo_feature_vectors(d1, d2)
+    valid = (rng.random(len(kp1)) < 0.9).astype(np.uint8)
+    a, n = ctx.search_by_bow(kp1, d1, valid, kp2, d2, pk, pf, ik, jf, ratio, ori)
+    oa, on = oracle.search_by_bow(kp1, d1, valid, kp2, d2, pk, pf, ik, jf, ratio, ori)
+    assert on > 30 and n == on
+    np.testing.assert_array_equal(a, oa)
