@@ -138,13 +138,16 @@ def main():
 
     sharding = pkg._load("sslam_sharding", os.path.join(pkg.PKG_DIR, "sharding.py"))
 
+    gather = sharding.AsyncGather(dist, world, rank)
+
     def one_step():
         pipe.step(cur, overlap=not args.no_overlap)
-        if dist is not None:      # the one exchange step of the path: per-frame records to rank 0 over RCCL
-            sharding.gather_to_root(dist, pipe.packed_results(), world, rank)
+        if dist is not None:      # the one exchange step of the path: per-frame records to rank 0 over RCCL,
+            gather.submit(pipe.packed_results())      # overlapped with the next step's kernels
 
     for _ in range(args.warmup):
         one_step()
+    gather.wait()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -154,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    gather.wait()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -285,6 +285,17 @@ static inline void fast9_view(const Img8& img, int x0, int y0, int x1, int y1,
         for (int j = 3; j < cols - 3; ++j) {
             const uint8_t* p = img.d.data() + (size_t)(y0 + i) * stride + (x0 + j);
             int v = p[0];
+            // fast.cpp's early rejection: a 9-arc needs one of every opposite ring pair on its side of the threshold
+            {
+                const int lo = v - threshold, hi = v + threshold;
+                auto cls = [&](int k) { int x = p[kFastRing[k][0] + kFastRing[k][1] * stride]; return (x < lo ? 1 : 0) | (x > hi ? 2 : 0); };
+                int d = cls(0) | cls(8);
+                if (d == 0) continue;
+                d &= cls(2) | cls(10); d &= cls(4) | cls(12); d &= cls(6) | cls(14);
+                if (d == 0) continue;
+                d &= cls(1) | cls(9); d &= cls(3) | cls(11); d &= cls(5) | cls(13); d &= cls(7) | cls(15);
+                if (d == 0) continue;
+            }
             int cb = 0, cd = 0;
             bool corner = false;
             for (int k = 0; k < 25 && !corner; ++k) {

@@ -263,11 +263,15 @@ __global__ void k_lgamma_table(double* __restrict__ lgam, int n) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) lgam[j] = j >= 1 ? log_gamma_d((double)j) : 0.0;
 }
-__device__ double nfa_d(int n, int k, double p, double logNT, const double* __restrict__ lgam) {
+// plog[h] = {log(p), log(1-p), log10(p)} for p = 0.125 * 2^-h: every precision rect_improve can reach
+struct PLog { double lp, l1mp, l10p; };
+__device__ double nfa_d(int n, int k, double p, double logNT, const double* __restrict__ lgam, const PLog* plog) {
     if (n == 0 || k == 0) return -logNT;
-    if (n == k) return -logNT - (double)n * log10(p);
+    const int h = 1020 - ((__double2hiint(p) >> 20) & 0x7FF);        // p is an exact power of two
+    const bool tab = h >= 0 && h < 16 && p == ldexp(0.125, -h);
+    if (n == k) return -logNT - (double)n * (tab ? plog[h].l10p : log10(p));
     double p_term = p / (1 - p);
-    double log1term = lgam[n + 1] - lgam[k + 1] - lgam[n - k + 1] + (double)k * log(p) + (double)(n - k) * log(1.0 - p);
+    double log1term = lgam[n + 1] - lgam[k + 1] - lgam[n - k + 1] + (double)k * (tab ? plog[h].lp : log(p)) + (double)(n - k) * (tab ? plog[h].l1mp : log(1.0 - p));
     double term = exp(log1term);
     if (term == 0.0) {      // double_equal(term, 0) holds only for an exact zero
         if ((double)k > (double)n * p) return -log1term / 2.30258509299404568402 - logNT;
@@ -492,7 +496,7 @@ __device__ __forceinline__ void nfa_row_range(const NfaGeom& g, int y, int sw, i
 // which of them gets accepted, so a stage's (up to five) NFAs are evaluated together: all rows of
 // all candidates are spread over the wave (two lanes per row, twelve independent loads per lane,
 // wide rows swept by the whole wave), then the binomial tails run lane-parallel.
-struct ImproveLds { RectD cand[MAXC]; double val[MAXC]; NfaGeom geom[MAXC]; int total[MAXC], alg[MAXC]; long long cycCount, cycMath; };
+struct ImproveLds { RectD cand[MAXC]; double val[MAXC]; NfaGeom geom[MAXC]; int total[MAXC], alg[MAXC]; long long cycCount, cycMath; PLog plog[16]; };
 
 __device__ void nfa_eval_w(ImproveLds* L, int nc, int sw, int sh, const float* __restrict__ ang, double logNT, const double* __restrict__ lgam) {
     const int lane = threadIdx.x & 63;
@@ -551,7 +555,7 @@ __device__ void nfa_eval_w(ImproveLds* L, int nc, int sw, int sh, const float* _
     }
     __syncthreads();
     const long long tc1 = __builtin_readcyclecounter();
-    if (lane < nc) L->val[lane] = nfa_d(L->total[lane], L->alg[lane], L->cand[lane].p, logNT, lgam);
+    if (lane < nc) L->val[lane] = nfa_d(L->total[lane], L->alg[lane], L->cand[lane].p, logNT, lgam, L->plog);
     __syncthreads();
     if (lane == 0) { L->cycCount += tc1 - tc0; L->cycMath += __builtin_readcyclecounter() - tc1; }
 }
@@ -608,6 +612,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
     const int sw = P.sw, sh = P.sh;
     RegQ rq; rq.lds = dynLds; rq.glb = (unsigned*)(base + P.offReg);
     if (lane == 0) { imp.cycCount = 0; imp.cycMath = 0; }
+    if (lane < 16) { const double pp = ldexp(0.125, -lane); imp.plog[lane].lp = log(pp); imp.plog[lane].l1mp = log(1.0 - pp); imp.plog[lane].l10p = log10(pp); }
     __syncthreads();
     const int nOrd = misc->nDefined;
     const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;

@@ -52,3 +52,35 @@ def gather_to_root(dist, rec, world, rank):
         return None
     stacked = torch.stack(bufs, dim=1)            # [B_local, world, size] -> global index = local*world + rank
     return stacked.reshape(-1, rec.shape[1])
+
+
+class AsyncGather:
+    """The one exchange step, overlapped with the next step's compute: gather(step k) runs on RCCL's stream
+    while the kernels of step k+1 execute; at most one gather is in flight."""
+    def __init__(self, dist, world, rank):
+        self.dist, self.world, self.rank = dist, world, rank
+        self.work = None; self.bufs = None; self.rec = None
+
+    def submit(self, rec):
+        self.wait()
+        if self.world == 1:
+            self.rec = rec
+            return
+        if self.rank == 0 and (self.bufs is None or self.bufs[0].shape != rec.shape):
+            self.bufs = [torch.empty_like(rec) for _ in range(self.world)]
+        self.rec = rec                     # keep the source alive until the collective has consumed it
+        self.work = self.dist.gather(rec, self.bufs if self.rank == 0 else None, dst=0, async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+    def result(self):
+        """records in global frame order on rank 0 (None elsewhere)"""
+        self.wait()
+        if self.world == 1:
+            return self.rec
+        if self.rank != 0:
+            return None
+        return torch.stack(self.bufs, dim=1).reshape(-1, self.rec.shape[1])

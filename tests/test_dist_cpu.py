@@ -47,7 +47,11 @@ def _worker(rank, world, port, q):
     sh = pkg._load("sslam_sharding", os.path.join(pkg.PKG_DIR, "sharding.py"))
     rec = _pack(sh, sh.shard_indices(NFRAMES, world, rank))
     out = sh.gather_to_root(dist, rec, world, rank)
+    ag = sh.AsyncGather(dist, world, rank)             # the overlapped form used by bench.py: two steps back to back
+    ag.submit(rec.clone()); ag.submit(rec)
+    out2 = ag.result()
     if rank == 0:
+        assert torch.equal(out, out2)
         q.put(out.numpy())
     dist.barrier()
     dist.destroy_process_group()
