@@ -17,6 +17,7 @@
 //     segments match the CPU oracle bit-for-bit.
 #include "common.h"
 #include <cmath>
+#include <cstdlib>
 #include <cfloat>
 #include <algorithm>
 
@@ -63,38 +64,69 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ src, s
                                               uint8_t* __restrict__ dst, size_t dpitch, size_t dframe, int w, int h,
                                               const int* __restrict__ tapsArr) {
     constexpr int TW = 64, TH = 16;
-    __shared__ uint8_t tile[(TH + 2 * R) * (TW + 2 * R + 2)];
-    __shared__ unsigned short hb[(TH + 2 * R) * TW];
+    constexpr int LW = TW + 2 * R, LH = TH + 2 * R, LP = 80;       // LDS row: up to 3 alignment bytes + 70 pixels, dword multiple
+    __shared__ __align__(16) uint8_t tile[LH * LP];
+    __shared__ __align__(16) unsigned short hb[LH * TW];
     const int b = blockIdx.z, bx = blockIdx.x * TW, by = blockIdx.y * TH;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const uint8_t* s = src + (size_t)b * sframe;
     int taps[2 * R + 1];
 #pragma unroll
     for (int k = 0; k < 2 * R + 1; ++k) taps[k] = tapsArr[k];
-    constexpr int LW = TW + 2 * R, LH = TH + 2 * R, LP = TW + 2 * R + 2;
-    for (int i = tid; i < LW * LH; i += 256) {
-        int r = i / LW, c = i - r * LW;
-        int yy = reflect101(min(by - R + r, h + R - 1), h), xx = reflect101(min(bx - R + c, w + R - 1), w);
-        yy = min(max(yy, 0), h - 1); xx = min(max(xx, 0), w - 1);
-        tile[r * LP + c] = s[(size_t)yy * spitch + xx];
+    // interior tiles: aligned dword loads (the tile then starts at byte `off` of each LDS row); border tiles: reflect-101 bytes
+    const int ax = (bx - R) & ~3;
+    const bool interior = bx - R >= 0 && by - R >= 0 && bx + TW + R <= w && by + TH + R <= h && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
+    const int off = interior ? (bx - R) - ax : 0;
+    if (interior) {
+        constexpr int NDW = (3 + LW + 3) / 4;
+        for (int i = tid; i < LH * NDW; i += 256) {
+            const int r = i / NDW, q = i - r * NDW;
+            ((unsigned*)(tile + r * LP))[q] = ((const unsigned*)(s + (size_t)(by - R + r) * spitch + ax))[q];
+        }
+    } else {
+        for (int i = tid; i < LW * LH; i += 256) {
+            int r = i / LW, c = i - r * LW;
+            int yy = reflect101(min(by - R + r, h + R - 1), h), xx = reflect101(min(bx - R + c, w + R - 1), w);
+            yy = min(max(yy, 0), h - 1); xx = min(max(xx, 0), w - 1);
+            tile[r * LP + c] = s[(size_t)yy * spitch + xx];
+        }
     }
     __syncthreads();
-    for (int i = tid; i < LH * TW; i += 256) {
-        int r = i / TW, c = i - r * TW;
-        unsigned acc = 0;
+    // horizontal pass: four outputs from 4 + 2R bytes
+    for (int i = tid; i < LH * (TW / 4); i += 256) {
+        const int r = i / (TW / 4), c4 = (i - r * (TW / 4)) * 4;
+        const uint8_t* p = tile + r * LP + off + c4;
+        unsigned v[4 + 2 * R];
 #pragma unroll
-        for (int k = 0; k < 2 * R + 1; ++k) acc += (unsigned)tile[r * LP + c + k] * (unsigned)taps[k];
-        hb[r * TW + c] = (unsigned short)acc;
-    }
-    __syncthreads();
-    for (int i = tid; i < TH * TW; i += 256) {
-        int r = i / TW, c = i - r * TW;
-        int x = bx + c, y = by + r;
-        if (x < w && y < h) {
+        for (int k = 0; k < 4 + 2 * R; ++k) v[k] = p[k];
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
             unsigned acc = 0;
 #pragma unroll
-            for (int k = 0; k < 2 * R + 1; ++k) acc += (unsigned)hb[(r + k) * TW + c] * (unsigned)taps[k];
-            dst[(size_t)b * dframe + (size_t)y * dpitch + x] = (uint8_t)((acc + 32768u) >> 16);
+            for (int k = 0; k < 2 * R + 1; ++k) acc += v[j + k] * (unsigned)taps[k];
+            o[j] = acc;
+        }
+        uint2 w2; w2.x = o[0] | (o[1] << 16); w2.y = o[2] | (o[3] << 16);
+        *(uint2*)(hb + r * TW + c4) = w2;
+    }
+    __syncthreads();
+    // vertical pass: one thread = four horizontally adjacent outputs, one aligned 4-byte store
+    {
+        const int r = tid >> 4, c4 = (tid & 15) * 4;
+        const int x = bx + c4, y = by + r;
+        unsigned acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 2 * R + 1; ++k) {
+            const uint2 q = *(const uint2*)(hb + (r + k) * TW + c4);
+            acc[0] += (q.x & 0xFFFF) * (unsigned)taps[k]; acc[1] += (q.x >> 16) * (unsigned)taps[k];
+            acc[2] += (q.y & 0xFFFF) * (unsigned)taps[k]; acc[3] += (q.y >> 16) * (unsigned)taps[k];
+        }
+        if (y < h && x < w) {
+            uint8_t* d = dst + (size_t)b * dframe + (size_t)y * dpitch + x;
+            const unsigned o0 = (acc[0] + 32768u) >> 16, o1 = (acc[1] + 32768u) >> 16, o2 = (acc[2] + 32768u) >> 16, o3 = (acc[3] + 32768u) >> 16;
+            if (x + 3 < w) *(unsigned*)d = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);      // dpitch % 64 == 0, x % 4 == 0
+            else { d[0] = (uint8_t)o0; if (x + 1 < w) d[1] = (uint8_t)o1; if (x + 2 < w) d[2] = (uint8_t)o2; }
         }
     }
 }
@@ -115,7 +147,24 @@ __global__ void k_resize_exact(const uint8_t* __restrict__ src, size_t spitch, s
 }
 
 // ------------------------------------------------------------------ gradient / level-line angle (ll_angle)
-__global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws, LsdPlan P) {
+// The 2x2 gradient of an 8-bit image takes only 1021 x 1021 values, so angle (exact fastAtan2), the defined test
+// (|g|/2 > rho) and the D5 cos/sin of the angle are tabulated once per process; the per-frame kernel is then a gather.
+constexpr int GT = 1021;          // gx, gy in [-510, 510]
+__global__ void k_grad_table(float4* __restrict__ tab, double rho) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= GT * GT) return;
+    const int gy = i / GT - 510, gx = i - (i / GT) * GT - 510;
+    const int s = gx * gx + gy * gy;
+    float a = NOTDEF_F, cs = 0.f, sn = 0.f;
+    if (sqrt((double)s / 4.0) > rho) {
+        a = fast_atan2_deg((float)gx, (float)(-gy));
+        const float af = (float)((double)a * DEG2RAD);
+        cs = (float)cos((double)af); sn = (float)sin((double)af);
+    }
+    tab[i] = make_float4(a, cs, sn, __int_as_float(s));
+}
+
+__global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws, LsdPlan P, const float4* __restrict__ gtab) {
     const int b = blockIdx.y;
     const uint8_t* base = ws + (size_t)b * P.frameBytes;
     const uint8_t* img = base + P.offScaled;
@@ -127,21 +176,17 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
     int smax = 0;
     if (i < P.npx) {
         const int y = i / P.sw, x = i - y * P.sw;
-        float a = NOTDEF_F; int s = 0;
+        float4 rec = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
         if (x < P.sw - 1 && y < P.sh - 1) {
             const uint8_t* r0 = img + (size_t)y * P.spitch + x;
             const uint8_t* r1 = r0 + P.spitch;
-            int DA = (int)r1[1] - (int)r0[0], BC = (int)r0[1] - (int)r1[0];
-            int gx = DA + BC, gy = DA - BC;
-            s = gx * gx + gy * gy;
-            double norm = sqrt((double)s / 4.0);
-            if (norm > P.rho) { a = fast_atan2_deg((float)gx, (float)(-gy)); smax = s; }
+            const int DA = (int)r1[1] - (int)r0[0], BC = (int)r0[1] - (int)r1[0];
+            const int gx = DA + BC, gy = DA - BC;
+            rec = gtab[(gy + 510) * GT + (gx + 510)];
+            if (rec.x != NOTDEF_F) smax = __float_as_int(rec.w);
         }
-        ang[i] = a; S[i] = s;
-        // per-pixel record for region growing: angle, cosf/sinf of the (float) angle in radians (D5), magnitude^2
-        float cs = 0.f, sn = 0.f;
-        if (a != NOTDEF_F) { const float af = (float)((double)a * DEG2RAD); cs = (float)cos((double)af); sn = (float)sin((double)af); }
-        pix[i] = make_float4(a, cs, sn, __int_as_float(s));
+        ang[i] = rec.x; S[i] = __float_as_int(rec.w);
+        pix[i] = rec;          // per-pixel record for region growing: angle, cosf/sinf (D5), |g|^2
     }
     smax = wave_max(smax);
     if ((threadIdx.x & 63) == 0 && smax > 0) atomicMax(&misc->maxS, smax);
@@ -293,7 +338,11 @@ __device__ double nfa_d(int n, int k, double p, double logNT, const double* __re
             if (i <= n && !done) {
                 term *= mt[j];
                 bin_tail += term;
-                if (n - i + 1 < i) {             // bin_term < 1
+                // exact shortcut: past the mode (ratio < 1, and the ratio only shrinks with i) every later term is smaller than
+                // this one; once a term is below half an ulp of the sum, no later addition can change bin_tail, and bin_tail is
+                // all the function returns from here on.
+                if (mt[j] < 1.0 && term < bin_tail * 0x1p-54) done = true;
+                if (!done && n - i + 1 < i) {             // bin_term < 1
                     const double err = term * ((1 - pow(mt[j], (double)(n - i + 1))) / (1 - mt[j]) - 1);
                     if (err < tolerance * fabs(-log10(bin_tail) - logNT) * bin_tail) done = true;
                 }
@@ -481,14 +530,15 @@ __device__ NfaGeom nfa_geom(const RectD& rec, int sh) {
 // x-range of row y (clipped to the image); a row has seen (y - y0) edge steps, the step taken after
 // row t uses the second slope iff t >= ly (resp. ry).
 __device__ __forceinline__ void nfa_row_range(const NfaGeom& g, int y, int sw, int& xa, int& xb) {
-    const long long steps = y - g.y0;
-    long long nl2 = 0, nr2 = 0;
+    // |slope| <= image width, steps <= image height: every product fits 32 bits for images up to 32k x 32k / 2
+    const int steps = y - g.y0;
+    int nl2 = 0, nr2 = 0;
     if (steps > 0) {
-        nl2 = max(0LL, (long long)y - max((long long)g.ly, (long long)g.y0));
-        nr2 = max(0LL, (long long)y - max((long long)g.ry, (long long)g.y0));
+        nl2 = max(0, y - max(g.ly, g.y0));
+        nr2 = max(0, y - max(g.ry, g.y0));
     }
-    const long long lft = (long long)g.mx + (steps - nl2) * g.fl + nl2 * g.sl;
-    const long long rgt = (long long)g.mx + (steps - nr2) * g.fr + nr2 * g.sr;
+    const long long lft = (long long)g.mx + (long long)(steps - nl2) * g.fl + (long long)nl2 * g.sl;
+    const long long rgt = (long long)g.mx + (long long)(steps - nr2) * g.fr + (long long)nr2 * g.sr;
     xa = (int)max(lft, 0LL); xb = (int)min(rgt, (long long)sw - 1);
 }
 
@@ -835,17 +885,31 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
         for (int r = 0; r < lane; ++r) { sx0 = __fsub_rn(sx0, dL1); sy0 = __fadd_rn(sy0, dL0); }
         float sx = sx0, sy = sy0;
         float pL = 0, nL = 0, pO = 0, nO = 0;
-        for (int wID = 0; wID < lengthOfLSP; ++wID) {
-            int tc = (int)(short)(int)roundf(sx);
-            const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
-            tc = (int)(short)(int)roundf(sy);
-            const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
-            const float dx = (float)dxImg[(size_t)yCor * realWidth + xCor], dy = (float)dyImg[(size_t)yCor * realWidth + xCor];
-            const float gDL = __fadd_rn(__fmul_rn(dx, dL0), __fmul_rn(dy, dL1));
-            const float gDO = __fadd_rn(__fmul_rn(dx, dO0), __fmul_rn(dy, dO1));
-            if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
-            if (gDO > 0) pO = __fadd_rn(pO, gDO); else nO = __fsub_rn(nO, gDO);
-            sx = __fadd_rn(sx, dL0); sy = __fadd_rn(sy, dL1);
+        for (int w0 = 0; w0 < lengthOfLSP; w0 += 4) {
+            // coordinates of four consecutive steps (the float walk itself stays sequential), then the eight gathers together
+            int idx4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int tc = (int)(short)(int)roundf(sx);
+                const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
+                tc = (int)(short)(int)roundf(sy);
+                const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
+                idx4[u] = yCor * realWidth + xCor;
+                sx = __fadd_rn(sx, dL0); sy = __fadd_rn(sy, dL1);
+            }
+            short dxs[4], dys[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { dxs[u] = dxImg[idx4[u]]; dys[u] = dyImg[idx4[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (w0 + u < lengthOfLSP) {
+                    const float dx = (float)dxs[u], dy = (float)dys[u];
+                    const float gDL = __fadd_rn(__fmul_rn(dx, dL0), __fmul_rn(dy, dL1));
+                    const float gDO = __fadd_rn(__fmul_rn(dx, dO0), __fmul_rn(dy, dO1));
+                    if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
+                    if (gDO > 0) pO = __fadd_rn(pO, gDO); else nO = __fsub_rn(nO, gDO);
+                }
+            }
         }
         const float cg = kGaussG[lane];
         pL = __fmul_rn(cg, pL); nL = __fmul_rn(cg, nL); pO = __fmul_rn(cg, pO); nO = __fmul_rn(cg, nO);
@@ -929,7 +993,7 @@ struct sslam_lines {
     int maxLines;
     int planW = 0, planH = 0;
     LsdPlan plan;
-    DevBuf dWs, dTabs, dTaps, dLgam;
+    DevBuf dWs, dTabs, dTaps, dLgam, dGtab;
     int wsFrames = 0, lastFrames = 0;
     DevBuf dImg, dKl, dDesc, dFn, dCounts;
     HostPinned hOut;
@@ -1016,6 +1080,11 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offDy = take(sizeof(short) * (size_t)w * h);
     P.offKl = take(sizeof(sslam_keyline) * MAX_SEG);
     P.frameBytes = align_up(off, 4096);
+    if (!L->dGtab.p) {   // gradient -> {angle, cos, sin, |g|^2} table (rho depends only on LSD constants)
+        if ((rc = L->dGtab.ensure(sizeof(float4) * (size_t)GT * GT))) return rc;
+        hipLaunchKernelGGL(k_grad_table, dim3((GT * GT + 255) / 256), dim3(256), 0, L->ctx->stream, L->dGtab.as<float4>(), P.rho);
+        SSLAM_HIP(hipStreamSynchronize(L->ctx->stream));
+    }
     {   // log-gamma table for nfa(): arguments are integers in [1, npx+2]
         const int nl = P.npx + 4;
         if ((rc = L->dLgam.ensure(sizeof(double) * (size_t)nl))) return rc;
@@ -1038,7 +1107,7 @@ extern "C" int sslam_lines_destroy(sslam_lines* L) {
     if (!L) return SSLAM_OK;
     (void)hipSetDevice(L->ctx->device);
     (void)hipStreamSynchronize(L->ctx->stream);
-    DevBuf* bufs[] = {&L->dWs, &L->dTabs, &L->dTaps, &L->dLgam, &L->dImg, &L->dKl, &L->dDesc, &L->dFn, &L->dCounts};
+    DevBuf* bufs[] = {&L->dWs, &L->dTabs, &L->dTaps, &L->dLgam, &L->dGtab, &L->dImg, &L->dKl, &L->dDesc, &L->dFn, &L->dCounts};
     for (DevBuf* b : bufs) b->release();
     L->hOut.release();
     delete L;
@@ -1085,12 +1154,13 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
                        ws + P.offBlur, bpitch, P.frameBytes, w, h, taps); }
     { sslam::ProfScope _ps(L->ctx, "k_resize_exact", st); hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 63) / 64, (P.sh + 3) / 4, nframes), dim3(64, 4), 0, st, ws + P.offBlur, bpitch, P.frameBytes, w, h,
                        ws + P.offScaled, (size_t)P.spitch, P.frameBytes, P.sw, P.sh, L->dTabs.as<int>() + P.tabX, L->dTabs.as<int>() + P.tabY); }
-    { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st); hipLaunchKernelGGL(k_lsd_grad, dim3((P.npx + 255) / 256, nframes), dim3(256), 0, st, ws, P); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st); hipLaunchKernelGGL(k_lsd_grad, dim3((P.npx + 255) / 256, nframes), dim3(256), 0, st, ws, P, L->dGtab.as<float4>()); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_hist", st); hipLaunchKernelGGL(k_lsd_hist, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scan", st); hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }
     {
         size_t lds = sizeof(unsigned) * QCAP;
+        if (const char* e = getenv("SSLAM_LSD_LDS_PAD")) lds = std::max(lds, (size_t)atoi(e));      // experiment knob: cap resident region workgroups per CU
         if (lds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         { sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st); hipLaunchKernelGGL(k_lsd_regions, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>()); }
     }

@@ -52,20 +52,43 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
     }
 }
 
-// batch form: frame f uses q + f*cap*32 (nq[f] rows) against t + f*cap*32 (nt[f] rows)
+// batch form: frame f uses q + f*cap*32 (nq[f] rows) against t + f*cap*32 (nt[f] rows).  The kernel is bound by L2
+// traffic on the train rows, so each wave scores FOUR queries against every train row it loads.
 __global__ __launch_bounds__(256) void k_knn2_batch(const uint8_t* __restrict__ q, const int* __restrict__ nq, const uint8_t* __restrict__ t,
                                                     const int* __restrict__ nt, int cap, int* __restrict__ idx, int* __restrict__ dist) {
-    const int f = blockIdx.y;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (wave >= nq[f]) return;
-    unsigned long long b, s;
-    wave_knn2(q + ((size_t)f * cap + wave) * 32, t + (size_t)f * cap * 32, nt[f], b, s);
-    if ((threadIdx.x & 63) == 0) {
-        const size_t o = ((size_t)f * cap + wave) * 2;
-        idx[o] = b == ~0ull ? -1 : (int)(unsigned)b;
-        dist[o] = b == ~0ull ? -1 : (int)(b >> 32);
-        idx[o + 1] = s == ~0ull ? -1 : (int)(unsigned)s;
-        dist[o + 1] = s == ~0ull ? -1 : (int)(s >> 32);
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int q0i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4;
+    const int nqf = nq[f], ntf = nt[f];
+    if (q0i >= nqf) return;
+    const uint8_t* qb = q + (size_t)f * cap * 32;
+    const uint8_t* tb = t + (size_t)f * cap * 32;
+    uint4 qa[4], qc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int qi = min(q0i + k, nqf - 1);
+        qa[k] = ((const uint4*)(qb + (size_t)qi * 32))[0]; qc[k] = ((const uint4*)(qb + (size_t)qi * 32))[1];
+    }
+    unsigned long long b[4] = {~0ull, ~0ull, ~0ull, ~0ull}, s[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    for (int j = lane; j < ntf; j += 64) {
+        const uint4* tp = (const uint4*)(tb + (size_t)j * 32);
+        const uint4 t0 = tp[0], t1 = tp[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long kk = ((unsigned long long)hamming256(qa[k], qc[k], t0, t1) << 32) | (unsigned)j;
+            if (kk < b[k]) { s[k] = b[k]; b[k] = kk; } else if (kk < s[k]) s[k] = kk;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long best = wave_min_u64(b[k]);
+        const unsigned long long second = wave_min_u64(b[k] == best ? s[k] : b[k]);
+        if (lane == 0 && q0i + k < nqf) {
+            const size_t o = ((size_t)f * cap + q0i + k) * 2;
+            idx[o] = best == ~0ull ? -1 : (int)(unsigned)best;
+            dist[o] = best == ~0ull ? -1 : (int)(best >> 32);
+            idx[o + 1] = second == ~0ull ? -1 : (int)(unsigned)second;
+            dist[o + 1] = second == ~0ull ? -1 : (int)(second >> 32);
+        }
     }
 }
 
@@ -520,7 +543,7 @@ extern "C" int sslam_hamming_knn2_batch_dev(sslam_ctx* ctx, const uint8_t* d_q, 
     if (!ctx || !d_q || !d_nq || !d_t || !d_nt || !d_idx || !d_dist || cap <= 0 || nframes <= 0) { set_error("sslam_hamming_knn2_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
-    { sslam::ProfScope _ps(ctx, "k_knn2_batch", st); hipLaunchKernelGGL(k_knn2_batch, dim3((cap + 3) / 4, nframes), dim3(256), 0, st, d_q, d_nq, d_t, d_nt, cap, d_idx, d_dist); }
+    { sslam::ProfScope _ps(ctx, "k_knn2_batch", st); hipLaunchKernelGGL(k_knn2_batch, dim3((cap + 15) / 16, nframes), dim3(256), 0, st, d_q, d_nq, d_t, d_nt, cap, d_idx, d_dist); }
     SSLAM_HIP(hipGetLastError());
     return SSLAM_OK;
 }

@@ -151,10 +151,10 @@ __device__ __forceinline__ int fast_score16(const uint8_t* c, int tp, int minTh)
     return s >= minTh ? s : 0;
 }
 
-// One wave per (cell, frame).  LDS: image tile with 3-px halo, score tile with a
-// zero rim (NMS neighbours outside the cell's detection rectangle count as 0, D.1),
-// and a keep-code per pixel.  Candidates leave in raster order, packed
-// (score<<24 | y<<12 | x) with x,y relative to minBorder (=16), :820-825.
+// One wave per (cell, frame).  LDS: image tile with 3-px halo (staged with aligned dword loads), score
+// tile with a zero rim (NMS neighbours outside the cell's detection rectangle count as 0, D.1), and a
+// keep-code per pixel.  Candidates leave in raster order, packed (score<<24 | y<<12 | x) with x,y
+// relative to minBorder (=16), :820-825.  i -> (row, col) uses an exact magic-multiply division.
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrFrame, Plan P,
                                                    const CellInfo* __restrict__ cells,
                                                    unsigned* __restrict__ cand, int* __restrict__ cellCount,
@@ -165,23 +165,38 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     const CellInfo ci = cells[cellId];
     const LevelInfo& L = P.L[ci.level];
     const int cw = ci.x1 - ci.x0, ch = ci.y1 - ci.y0;
-    uint8_t* tile = lds;                                       // (maxCellH+6) x tileP
+    uint8_t* tile = lds;                                       // (maxCellH+6) x tileP, tileP % 4 == 0
     uint8_t* sc = tile + (P.maxCellH + 6) * tileP;             // (maxCellH+2) x scP
     uint8_t* code = sc + (P.maxCellH + 2) * scP;               // maxCellH x maxCellW
     const uint8_t* img = pyr + (size_t)b * pyrFrame + L.off;
-    // stage tile rows [y0-3, y1+3) x cols [x0-3, x1+3): always inside the level (x0>=19)
-    const int tw = cw + 6, th = ch + 6;
-    for (int i = lane; i < tw * th; i += 64) {
-        int ry = i / tw, rx = i - ry * tw;
-        tile[ry * tileP + rx] = img[(size_t)(ci.y0 - 3 + ry) * L.pitch + (ci.x0 - 3 + rx)];
+    // stage rows [y0-3, y1+3) from the 4-byte aligned column ax <= x0-3; cells are interior (x0 >= 19) and the
+    // row pitch is a multiple of 64, so the aligned dwords stay inside the row
+    const int ax = (ci.x0 - 3) & ~3, off = (ci.x0 - 3) - ax;
+    const int ndw = (off + cw + 6 + 3) >> 2, th = ch + 6;
+    for (int ry = lane >> 4; ry < th; ry += 4) {
+        const uint8_t* srow = img + (size_t)(ci.y0 - 3 + ry) * L.pitch + ax;
+        for (int q = lane & 15; q < ndw; q += 16) ((unsigned*)(tile + ry * tileP))[q] = ((const unsigned*)srow)[q];
     }
-    for (int i = lane; i < (ch + 2) * scP; i += 64) sc[i] = 0;
+    for (int i = lane; i < (((ch + 2) * scP + 3) >> 2); i += 64) ((unsigned*)sc)[i] = 0;
     __syncthreads();
     const int npx = cw * ch;
-    for (int i = lane; i < npx; i += 64) {
-        int py = i / cw, px = i - py * cw;
-        int s = fast_score16(tile + (py + 3) * tileP + (px + 3), tileP, minTh);
-        sc[(py + 1) * scP + (px + 1)] = (uint8_t)s;
+    const unsigned magic = (1u << 20) / (unsigned)cw + 1;      // floor(i/cw) == (i*magic)>>20 for i < 4400, cw <= 64
+    for (int i0 = 0; i0 < npx; i0 += 64) {
+        const int i = i0 + lane;
+        int py = 0, px = 0; bool maybe = false;
+        const uint8_t* c = tile;
+        if (i < npx) {
+            py = (int)(((unsigned long long)(unsigned)i * magic) >> 20); px = i - py * cw;
+            c = tile + (py + 3) * tileP + (off + px + 3);
+            // a 9-arc contains one pixel of every opposite ring pair: if the vertical pair is within +-minTh the pixel
+            // cannot be a corner.  Whole wave chunks of flat image skip the ring evaluation.
+            const int v = c[0], r0 = c[3 * tileP], r8 = c[-3 * tileP];
+            maybe = abs(r0 - v) > minTh || abs(r8 - v) > minTh;
+        }
+        if (__ballot(maybe)) {
+            const int s = maybe ? fast_score16(c, tileP, minTh) : 0;
+            if (i < npx && s) sc[(py + 1) * scP + (px + 1)] = (uint8_t)s;        // sc is pre-zeroed
+        }
     }
     __syncthreads();
     int cnt20 = 0;
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
         int i = i0 + lane;
         int cde = 0;
         if (i < npx) {
-            int py = i / cw, px = i - py * cw;
+            const int py = (int)(((unsigned long long)(unsigned)i * magic) >> 20), px = i - py * cw;
             const uint8_t* c = sc + (py + 1) * scP + (px + 1);
             int s = c[0];
             if (s > 0 && s > c[-1] && s > c[1] && s > c[-scP - 1] && s > c[-scP] && s > c[-scP + 1] &&
@@ -206,10 +221,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     for (int i0 = 0; i0 < npx; i0 += 64) {
         int i = i0 + lane;
         bool keep = false;
-        int py = 0, px = 0;
-        if (i < npx) { keep = code[i] >= need; py = i / cw; px = i - py * cw; }
+        if (i < npx) keep = code[i] >= need;
         unsigned long long m = __ballot(keep);
         if (keep) {
+            const int py = (int)(((unsigned long long)(unsigned)i * magic) >> 20), px = i - py * cw;
             int s = sc[(py + 1) * scP + (px + 1)];
             out[n + mbcnt(m)] = ((unsigned)s << 24) | ((unsigned)(ci.y0 + py - MINB) << 12) | (unsigned)(ci.x0 + px - MINB);
         }
@@ -504,15 +519,15 @@ __global__ __launch_bounds__(64) void k_octree(const unsigned* __restrict__ cand
 // :1095-1101).  The 43x43 source patch is staged in LDS with reflect-101.
 constexpr int PR = 21;               // patch radius: 18 (taps) + 3 (blur)
 constexpr int PW = 2 * PR + 1;       // 43
-constexpr int PP = 44;               // LDS pitch
+constexpr int PP = 48;               // LDS pitch: 12 aligned dwords per row
 constexpr int HW = 37;               // horizontally blurred columns: x-18..x+18
 
 __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr, size_t pyrFrame, Plan P,
                                                  const unsigned* __restrict__ sel, const int* __restrict__ selCount,
                                                  sslam_keypoint* __restrict__ kpOut, uint8_t* __restrict__ descOut,
                                                  int* __restrict__ counts, int cap) {
-    __shared__ uint8_t patch[PW * PP];
-    __shared__ unsigned short hb[PW * 38];
+    __shared__ __align__(16) uint8_t patch[PW * PP + 16];
+    __shared__ __align__(16) unsigned short hb[PW * 40];
     const int b = blockIdx.y, lane = threadIdx.x;
     int slot = blockIdx.x;
     // locate (level, index) of this slot
@@ -530,10 +545,23 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
     const unsigned pk = sel[(size_t)b * P.selFrame + slot];
     const int kx = (int)(pk & 0xFFF) + MINB, ky = (int)((pk >> 12) & 0xFFF) + MINB, score = pk >> 24;
     const uint8_t* img = pyr + (size_t)b * pyrFrame + L.off;
-    for (int i = lane; i < PW * PW; i += 64) {
-        int r = i / PW, c = i - r * PW;
-        int yy = reflect101(ky - PR + r, L.h), xx = reflect101(kx - PR + c, L.w);
-        patch[r * PP + c] = img[(size_t)yy * L.pitch + xx];
+    // stage the 43x43 patch.  Interior keypoints (almost all): 12 aligned dwords per row, the patch then starts at
+    // byte `off` of each LDS row.  Keypoints within 21 px of the level border: byte loads with reflect-101.
+    const int ax = (kx - PR) & ~3;
+    const bool interior = kx - PR >= 0 && ky - PR >= 0 && ky + PR < L.h && kx + PR < L.w && ax + 48 <= L.pitch;
+    const int off = interior ? (kx - PR) - ax : 0;
+    if (interior) {
+        const uint8_t* src = img + (size_t)(ky - PR) * L.pitch + ax;
+        for (int i = lane; i < PW * 12; i += 64) {
+            const int r = i / 12, q = i - r * 12;
+            ((unsigned*)(patch + r * PP))[q] = ((const unsigned*)(src + (size_t)r * L.pitch))[q];
+        }
+    } else {
+        for (int i = lane; i < PW * PW; i += 64) {
+            int r = i / PW, c = i - r * PW;
+            int yy = reflect101(ky - PR + r, L.h), xx = reflect101(kx - PR + c, L.w);
+            patch[r * PP + c] = img[(size_t)yy * L.pitch + xx];
+        }
     }
     __syncthreads();
     // intensity centroid over the r=15 disc
@@ -542,20 +570,29 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
         int r = i / 31, c = i - r * 31;
         int v = r - HALF_PATCH, u = c - HALF_PATCH;
         if (abs(u) <= kUmax[abs(v)]) {
-            int I = patch[(PR + v) * PP + (PR + u)];
+            int I = patch[(PR + v) * PP + off + (PR + u)];
             m10 += u * I; m01 += v * I;
         }
     }
     m10 = wave_sum(m10); m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // horizontal blur pass: rows all 43, cols x-18..x+18
-    for (int i = lane; i < PW * HW; i += 64) {
-        int r = i / HW, c = i - r * HW;       // c -> patch col c+3
-        const uint8_t* p = patch + r * PP + c;
-        unsigned acc = 0;
+    // horizontal blur pass: all 43 rows, columns x-18..x+21 in groups of four outputs from ten bytes
+    for (int i = lane; i < PW * 10; i += 64) {
+        const int r = i / 10, g4 = i - r * 10;
+        const uint8_t* p = patch + r * PP + off + g4 * 4;
+        unsigned v[10];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) acc += (unsigned)p[k] * (unsigned)kBlurTaps[k];
-        hb[r * 38 + c] = (unsigned short)acc;
+        for (int k = 0; k < 10; ++k) v[k] = p[k];
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned acc = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) acc += v[j + k] * (unsigned)kBlurTaps[k];
+            o[j] = acc;
+        }
+        uint2 w2; w2.x = o[0] | (o[1] << 16); w2.y = o[2] | (o[3] << 16);
+        *(uint2*)(hb + r * 40 + g4 * 4) = w2;
     }
     __syncthreads();
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
@@ -571,10 +608,10 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
             float px = (float)pp[0], py = (float)pp[1];
             int yy = cv_roundf(__fadd_rn(__fmul_rn(px, bsn), __fmul_rn(py, a)));
             int xx = cv_roundf(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, bsn)));
-            const unsigned short* h = hb + (PR + yy - 3) * 38 + (18 + xx);
+            const unsigned short* h = hb + (PR + yy - 3) * 40 + (18 + xx);
             unsigned acc = 0;
 #pragma unroll
-            for (int q = 0; q < 7; ++q) acc += (unsigned)h[q * 38] * (unsigned)kBlurTaps[q];
+            for (int q = 0; q < 7; ++q) acc += (unsigned)h[q * 40] * (unsigned)kBlurTaps[q];
             t[e] = (int)((acc + 32768u) >> 16);
         }
         nib |= (unsigned)(t[0] < t[1]) << k;
@@ -851,8 +888,8 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
         { sslam::ProfScope _ps(o->ctx, "k_resize", st); hipLaunchKernelGGL(k_resize, grd, blk, 0, st, pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short>()); }
     }
     if (P.nCellsFrame > 0) {
-        int tileP = (P.maxCellW + 6 + 3) & ~3, scP = P.maxCellW + 2;
-        size_t lds = (size_t)(P.maxCellH + 6) * tileP + (size_t)(P.maxCellH + 2) * scP + (size_t)P.maxCellH * P.maxCellW;
+        int tileP = (P.maxCellW + 6 + 3 + 7) & ~3, scP = P.maxCellW + 2;
+        size_t lds = (size_t)(P.maxCellH + 6) * tileP + (((size_t)(P.maxCellH + 2) * scP + 3) & ~(size_t)3) + (size_t)P.maxCellH * P.maxCellW + 16;
         dim3 grd(P.nCellsFrame, nframes);
         { sslam::ProfScope _ps(o->ctx, "k_fast_cells", st); hipLaunchKernelGGL(k_fast_cells, grd, dim3(64), lds, st, pyr, P.pyrFrame, P, o->dCells.as<CellInfo>(), o->dCand.as<unsigned>(),
                            o->dCellCount.as<int>(), o->iniTh, o->minTh, tileP, scP); }
