@@ -49,7 +49,7 @@ def alg_bytes_per_frame(w, h, nkp, nln):
         "k_lsd_hist": 8 * s08, "k_lsd_scan": 0, "k_lsd_scatter": 4 * s08,    # ordered-list build
         "k_lsd_regions": 5 * s08,                           # region-grow reads (angle + magnitude + used)
         "k_keylines": nln * (16 + 68 + 24),
-        "k_blur<2>": 2 * w * h, "k_sobel": w * h + 4 * w * h,
+        "k_blur_sobel": w * h + 4 * w * h,                  # fused LBD pre-blur + Sobel: source read, 2 x s16 write
         "k_lbd": nln * 63 * 100 * 4 + nln * 100,            # band reads at a nominal 100-px line + descriptor
         "k_search_init": 2 * 32 * nkp + 8 * nkp, "k_knn2_batch": 2 * 32 * nkp + 16 * nkp,
         "k_line_match": 2 * 32 * nln + 16 * nln,

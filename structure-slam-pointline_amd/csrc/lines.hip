@@ -836,19 +836,82 @@ __global__ __launch_bounds__(256) void k_keylines(uint8_t* __restrict__ ws, LsdP
     if (tid == 0) { counts[b] = nOut; misc->nKl = nOut; }
 }
 
-// ------------------------------------------------------------------ Sobel 3x3 -> s16 (reflect-101)
-__global__ __launch_bounds__(256) void k_sobel(const uint8_t* __restrict__ src, size_t spitch, size_t sframe, int w, int h,
-                                               short* __restrict__ dxo, short* __restrict__ dyo, size_t dframeBytes) {
-    const int b = blockIdx.z, x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= w || y >= h) return;
+// ------------------------------------------------------------------ LBD front: 5x5 sigma-1 blur + Sobel 3x3 -> s16, fused
+// BinaryDescriptor::computeGaussianPyramid (GaussianBlur 5x5, sigma 1) + cv::Sobel(CV_16S, ksize 3), both BORDER_REFLECT_101.
+// The blurred image never reaches HBM: a 70x22 source tile (reflect-101) -> 66x22 horizontal pass -> 66x18 blurred tile in
+// LDS -> 64x16 dx/dy.  (A symmetric kernel with reflect-101 borders commutes with the reflection, so evaluating the blur at the
+// one-pixel Sobel halo outside the image from the reflected source IS the blurred value at the reflected pixel.)
+__global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ src, size_t spitch, size_t sframe, int w, int h,
+                                                    short* __restrict__ dxo, short* __restrict__ dyo, size_t dframeBytes,
+                                                    const int* __restrict__ tapsArr) {
+    constexpr int TW = 64, TH = 16, R = 3;                 // blur radius 2 + Sobel radius 1
+    constexpr int LW = TW + 2 * R, LH = TH + 2 * R, LP = 80, BW = TW + 2, BH = TH + 2, HP = 68;
+    __shared__ __align__(16) uint8_t tile[LH * LP];
+    __shared__ __align__(16) unsigned short hb[LH * HP];
+    __shared__ __align__(16) uint8_t bl[BH * HP];
+    const int b = blockIdx.z, bx = blockIdx.x * TW, by = blockIdx.y * TH;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
     const uint8_t* s = src + (size_t)b * sframe;
-    const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h), xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
-    const uint8_t *r0 = s + (size_t)ym * spitch, *r1 = s + (size_t)y * spitch, *r2 = s + (size_t)yp * spitch;
-    const int gx = ((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]);
-    const int gy = ((int)r2[xm] - (int)r0[xm]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xp] - (int)r0[xp]);
-    short* dxp = (short*)((uint8_t*)dxo + (size_t)b * dframeBytes);
-    short* dyp = (short*)((uint8_t*)dyo + (size_t)b * dframeBytes);
-    dxp[(size_t)y * w + x] = (short)gx; dyp[(size_t)y * w + x] = (short)gy;
+    int taps[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) taps[k] = tapsArr[k];
+    const int ax = (bx - R) & ~3;
+    const bool interior = bx - R >= 0 && by - R >= 0 && bx + TW + R <= w && by + TH + R <= h && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
+    const int off = interior ? (bx - R) - ax : 0;
+    if (interior) {
+        constexpr int NDW = (3 + LW + 3) / 4;
+        for (int i = tid; i < LH * NDW; i += 256) {
+            const int r = i / NDW, q = i - r * NDW;
+            ((unsigned*)(tile + r * LP))[q] = ((const unsigned*)(s + (size_t)(by - R + r) * spitch + ax))[q];
+        }
+    } else {
+        for (int i = tid; i < LW * LH; i += 256) {
+            int r = i / LW, c = i - r * LW;
+            int yy = reflect101(min(by - R + r, h + R - 1), h), xx = reflect101(min(bx - R + c, w + R - 1), w);
+            yy = min(max(yy, 0), h - 1); xx = min(max(xx, 0), w - 1);
+            tile[r * LP + c] = s[(size_t)yy * spitch + xx];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < LH * BW; i += 256) {            // horizontal 5 taps at x = bx-1+c
+        const int r = i / BW, c = i - r * BW;
+        const uint8_t* p = tile + r * LP + off + c;
+        unsigned acc = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc += (unsigned)p[k] * (unsigned)taps[k];
+        hb[r * HP + c] = (unsigned short)acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < BH * BW; i += 256) {            // vertical 5 taps at y = by-1+r
+        const int r = i / BW, c = i - r * BW;
+        unsigned acc = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc += (unsigned)hb[(r + k) * HP + c] * (unsigned)taps[k];
+        bl[r * HP + c] = (uint8_t)((acc + 32768u) >> 16);
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 4, c4 = (tid & 15) * 4;
+        const int x = bx + c4, y = by + r;
+        if (y < h && x < w) {
+            short gx[4], gy[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint8_t* q = bl + r * HP + c4 + j;          // q[0] = blurred(y-1, x+j-1)
+                const int a0 = q[0], a1 = q[1], a2 = q[2], m0 = q[HP], m2 = q[HP + 2], c0 = q[2 * HP], c1 = q[2 * HP + 1], c2 = q[2 * HP + 2];
+                gx[j] = (short)((a2 - a0) + 2 * (m2 - m0) + (c2 - c0));
+                gy[j] = (short)((c0 - a0) + 2 * (c1 - a1) + (c2 - a2));
+            }
+            short* dxp = (short*)((uint8_t*)dxo + (size_t)b * dframeBytes) + (size_t)y * w + x;
+            short* dyp = (short*)((uint8_t*)dyo + (size_t)b * dframeBytes) + (size_t)y * w + x;
+            if (x + 3 < w && ((w & 3) == 0) && ((dframeBytes & 7) == 0)) {
+                *(short4*)dxp = make_short4(gx[0], gx[1], gx[2], gx[3]);
+                *(short4*)dyp = make_short4(gy[0], gy[1], gy[2], gy[3]);
+            } else {
+                for (int j = 0; j < 4 && x + j < w; ++j) { dxp[j] = gx[j]; dyp[j] = gy[j]; }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ LBD (BinaryDescriptor::computeLBD)
@@ -1165,11 +1228,9 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         { sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st); hipLaunchKernelGGL(k_lsd_regions, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>()); }
     }
     { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
-    // LBD: blur(5, 1) -> Sobel -> bands
-    { sslam::ProfScope _ps(L->ctx, "k_blur<2>", st); hipLaunchKernelGGL(k_blur<2>, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride,
-                       ws + P.offBlur5, bpitch, P.frameBytes, w, h, taps + 8); }
-    { sslam::ProfScope _ps(L->ctx, "k_sobel", st); hipLaunchKernelGGL(k_sobel, dim3((w + 63) / 64, (h + 3) / 4, nframes), dim3(64, 4), 0, st, ws + P.offBlur5, bpitch, P.frameBytes, w, h,
-                       (short*)(ws + P.offDx), (short*)(ws + P.offDy), P.frameBytes); }
+    // LBD: blur(5, 1) + Sobel fused -> bands
+    { sslam::ProfScope _ps(L->ctx, "k_blur_sobel", st); hipLaunchKernelGGL(k_blur_sobel, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride, w, h,
+                       (short*)(ws + P.offDx), (short*)(ws + P.offDy), P.frameBytes, taps + 8); }
     { sslam::ProfScope _ps(L->ctx, "k_lbd", st); hipLaunchKernelGGL(k_lbd, dim3(std::min(L->maxLines, cap), nframes), dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap); }
     SSLAM_HIP(hipGetLastError());
     L->lastFrames = nframes;

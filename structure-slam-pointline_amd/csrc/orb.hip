@@ -83,32 +83,61 @@ __global__ void k_copy_level0(const uint8_t* __restrict__ in, size_t pitch, size
 // ------------------------------------------------------------------ bilinear /1.2
 // cv::resize(INTER_LINEAR) for CV_8UC1: 11-bit fixed-point taps.
 // tabX/tabY entries: {src offset, coef0, coef1} as int16.
-__global__ void k_resize(uint8_t* __restrict__ pyr, size_t pyrFrame, LevelInfo S, LevelInfo D,
-                         const short* __restrict__ tabs) {
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_t pyrFrame, LevelInfo S, LevelInfo D,
+                                                const short* __restrict__ tabs) {
+    // block = 256 x 4 output pixels; the (at most 8) source rows it touches are staged in LDS with aligned dword loads
+    constexpr int SROWS = 8, SP = 336;                 // 256 * 1.2 + slack, dword multiple
+    __shared__ __align__(16) uint8_t src[SROWS * SP];
     const int b = blockIdx.z;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (y >= D.h || x4 >= D.w) return;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int y0 = blockIdx.y * 4, xb = blockIdx.x * 256;
     const short* tx = tabs + D.tabX;
-    const short* ty = tabs + D.tabY + y * 3;
-    int sy = ty[0];
-    int b0 = ty[1], b1 = ty[2];
-    int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
-    const uint8_t* s0 = pyr + (size_t)b * pyrFrame + S.off + (size_t)sy0 * S.pitch;
-    const uint8_t* s1 = pyr + (size_t)b * pyrFrame + S.off + (size_t)sy1 * S.pitch;
-    unsigned out = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int x = x4 + i;
-        if (x < D.w) {
-            int sx = tx[x * 3], a0 = tx[x * 3 + 1], a1 = tx[x * 3 + 2];
-            int sx1 = min(sx + 1, S.w - 1);
-            int r0 = s0[sx] * a0 + s0[sx1] * a1;
-            int r1 = s1[sx] * a0 + s1[sx1] * a1;
-            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            out |= (unsigned)(v & 255) << (8 * i);
+    const short* tyb = tabs + D.tabY;
+    const int ylast = min(y0 + 3, D.h - 1);
+    const int rb = min(max((int)tyb[y0 * 3], 0), S.h - 1);
+    const int re = min(max((int)tyb[ylast * 3] + 1, 0), S.h - 1);
+    const int xl = min(xb + 255, D.w - 1);
+    const int sxa = (int)tx[xb * 3] & ~3;
+    const int sxe = min((int)tx[xl * 3] + 1, S.w - 1);
+    const int ndw = ((sxe - sxa) >> 2) + 1, nrows = re - rb + 1;
+    const uint8_t* sbase = pyr + (size_t)b * pyrFrame + S.off;
+    const bool staged = nrows <= SROWS && ndw * 4 <= SP;
+    if (staged) {
+        for (int i = tid; i < nrows * ndw; i += 256) {
+            const int r = i / ndw, q = i - r * ndw;
+            ((unsigned*)(src + r * SP))[q] = ((const unsigned*)(sbase + (size_t)(rb + r) * S.pitch + sxa))[q];   // pitch % 64 == 0: in-row, pad bytes unused
         }
     }
+    __syncthreads();
+    const int y = y0 + threadIdx.y;
+    const int x4 = xb + threadIdx.x * 4;
+    if (y >= D.h || x4 >= D.w) return;
+    const short* ty = tyb + y * 3;
+    const int sy = ty[0], b0 = ty[1], b1 = ty[2];
+    const int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
+    unsigned out = 0;
+#define RESIZE_BODY(S0, S1, XOFF)                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+        int x = x4 + i;                                                                       \
+        if (x < D.w) {                                                                        \
+            int sx = tx[x * 3], a0 = tx[x * 3 + 1], a1 = tx[x * 3 + 2];                       \
+            int sx1 = min(sx + 1, S.w - 1);                                                   \
+            int r0 = S0[sx - XOFF] * a0 + S0[sx1 - XOFF] * a1;                                \
+            int r1 = S1[sx - XOFF] * a0 + S1[sx1 - XOFF] * a1;                                \
+            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;           \
+            out |= (unsigned)(v & 255) << (8 * i);                                            \
+        }                                                                                     \
+    }
+    if (staged) {
+        const uint8_t* l0 = src + (sy0 - rb) * SP;
+        const uint8_t* l1 = src + (sy1 - rb) * SP;
+        RESIZE_BODY(l0, l1, sxa)
+    } else {
+        const uint8_t* g0 = sbase + (size_t)sy0 * S.pitch;
+        const uint8_t* g1 = sbase + (size_t)sy1 * S.pitch;
+        RESIZE_BODY(g0, g1, 0)
+    }
+#undef RESIZE_BODY
     *(unsigned*)(pyr + (size_t)b * pyrFrame + D.off + (size_t)y * D.pitch + x4) = out;   // pitch%64==0, pad columns are scratch
 }
 
@@ -181,36 +210,46 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     __syncthreads();
     const int npx = cw * ch;
     const unsigned magic = (1u << 20) / (unsigned)cw + 1;      // floor(i/cw) == (i*magic)>>20 for i < 4400, cw <= 64
+    // pass A: cheap pretest on every pixel (a 9-arc contains one pixel of every opposite ring pair: if the vertical pair is
+    // within +-minTh of the centre the pixel cannot be a corner); survivors are compacted so that the expensive ring
+    // evaluation of pass B runs with full lanes on the few pixels that can matter.
+    unsigned short* clist = (unsigned short*)(lds + (((P.maxCellH + 6) * tileP + (P.maxCellH + 2) * scP + P.maxCellH * P.maxCellW + 7) & ~3));
+    int ncl = 0;
     for (int i0 = 0; i0 < npx; i0 += 64) {
         const int i = i0 + lane;
-        int py = 0, px = 0; bool maybe = false;
-        const uint8_t* c = tile;
+        bool maybe = false;
         if (i < npx) {
-            py = (int)(((unsigned long long)(unsigned)i * magic) >> 20); px = i - py * cw;
-            c = tile + (py + 3) * tileP + (off + px + 3);
-            // a 9-arc contains one pixel of every opposite ring pair: if the vertical pair is within +-minTh the pixel
-            // cannot be a corner.  Whole wave chunks of flat image skip the ring evaluation.
+            const int py = (int)(((unsigned long long)(unsigned)i * magic) >> 20), px = i - py * cw;
+            const uint8_t* c = tile + (py + 3) * tileP + (off + px + 3);
             const int v = c[0], r0 = c[3 * tileP], r8 = c[-3 * tileP];
             maybe = abs(r0 - v) > minTh || abs(r8 - v) > minTh;
         }
-        if (__ballot(maybe)) {
-            const int s = maybe ? fast_score16(c, tileP, minTh) : 0;
-            if (i < npx && s) sc[(py + 1) * scP + (px + 1)] = (uint8_t)s;        // sc is pre-zeroed
-        }
+        const unsigned long long m = __ballot(maybe);
+        if (maybe) clist[ncl + mbcnt(m)] = (unsigned short)i;
+        ncl += __popcll(m);
     }
     __syncthreads();
+    for (int j = lane; j < ncl; j += 64) {
+        const int i = clist[j];
+        const int py = (int)(((unsigned long long)(unsigned)i * magic) >> 20), px = i - py * cw;
+        const int s = fast_score16(tile + (py + 3) * tileP + (off + px + 3), tileP, minTh);
+        if (s) sc[(py + 1) * scP + (px + 1)] = (uint8_t)s;        // sc is pre-zeroed
+    }
+    __syncthreads();
+    // NMS + thresholds + emission only visit the compacted list (it is in raster order, and so is what it emits)
     int cnt20 = 0;
-    for (int i0 = 0; i0 < npx; i0 += 64) {
-        int i = i0 + lane;
+    for (int j0 = 0; j0 < ncl; j0 += 64) {
+        const int j = j0 + lane;
         int cde = 0;
-        if (i < npx) {
+        if (j < ncl) {
+            const int i = clist[j];
             const int py = (int)(((unsigned long long)(unsigned)i * magic) >> 20), px = i - py * cw;
             const uint8_t* c = sc + (py + 1) * scP + (px + 1);
             int s = c[0];
             if (s > 0 && s > c[-1] && s > c[1] && s > c[-scP - 1] && s > c[-scP] && s > c[-scP + 1] &&
                 s > c[scP - 1] && s > c[scP] && s > c[scP + 1])
                 cde = s >= iniTh ? 2 : 1;
-            code[i] = (uint8_t)cde;
+            code[j] = (uint8_t)cde;
         }
         cnt20 += __popcll(__ballot(cde == 2));
     }
@@ -218,12 +257,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     const int need = cnt20 > 0 ? 2 : 1;      // FAST(iniTh) empty -> FAST(minTh), :809-816
     unsigned* out = cand + (size_t)b * P.candFrame + ci.candOff;
     int n = 0;
-    for (int i0 = 0; i0 < npx; i0 += 64) {
-        int i = i0 + lane;
+    for (int j0 = 0; j0 < ncl; j0 += 64) {
+        const int j = j0 + lane;
         bool keep = false;
-        if (i < npx) keep = code[i] >= need;
+        if (j < ncl) keep = code[j] >= need;
         unsigned long long m = __ballot(keep);
         if (keep) {
+            const int i = clist[j];
             const int py = (int)(((unsigned long long)(unsigned)i * magic) >> 20), px = i - py * cw;
             int s = sc[(py + 1) * scP + (px + 1)];
             out[n + mbcnt(m)] = ((unsigned)s << 24) | ((unsigned)(ci.y0 + py - MINB) << 12) | (unsigned)(ci.x0 + px - MINB);
@@ -889,7 +929,7 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
     }
     if (P.nCellsFrame > 0) {
         int tileP = (P.maxCellW + 6 + 3 + 7) & ~3, scP = P.maxCellW + 2;
-        size_t lds = (size_t)(P.maxCellH + 6) * tileP + (((size_t)(P.maxCellH + 2) * scP + 3) & ~(size_t)3) + (size_t)P.maxCellH * P.maxCellW + 16;
+        size_t lds = (size_t)(P.maxCellH + 6) * tileP + (((size_t)(P.maxCellH + 2) * scP + 3) & ~(size_t)3) + 3 * (size_t)P.maxCellH * P.maxCellW + 32;
         dim3 grd(P.nCellsFrame, nframes);
         { sslam::ProfScope _ps(o->ctx, "k_fast_cells", st); hipLaunchKernelGGL(k_fast_cells, grd, dim3(64), lds, st, pyr, P.pyrFrame, P, o->dCells.as<CellInfo>(), o->dCand.as<unsigned>(),
                            o->dCellCount.as<int>(), o->iniTh, o->minTh, tileP, scP); }
