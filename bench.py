@@ -57,7 +57,7 @@ def alg_bytes_per_frame(w, h, nkp, nln):
     }
 
 
-def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=64):
+def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=600):
     """The CPU oracle (a restatement of the reference's CPU path; kind "port") timed on this box's
     host cores, single thread like the reference's front-end (src/Frame.cc:86-87)."""
     import numpy as np
@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=3072)
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
-    ap.add_argument("--no-overlap", action="store_true", help="run the point and line branches on one stream")
+    ap.add_argument("--overlap", action="store_true", help="run the point and line branches on two streams (off by default: the persistent LSD kernel wants every wave slot, sharing them costs a second round)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing (used for rocprofv3 runs)")
     args = ap.parse_args()
@@ -141,7 +141,7 @@ def main():
     gather = sharding.AsyncGather(dist, world, rank)
 
     def one_step():
-        pipe.step(cur, overlap=not args.no_overlap)
+        pipe.step(cur, overlap=args.overlap)
         if dist is not None:      # the one exchange step of the path: per-frame records to rank 0 over RCCL,
             gather.submit(pipe.packed_results())      # overlapped with the next step's kernels
 
