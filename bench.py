@@ -22,6 +22,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H = 640, 480
 NFEAT, NLINES = 1000, 200
+WORKLOADS = {     # BASELINE.json configs; c3 (configs[2]) is the one the metric is quoted on and the default
+    "c2": dict(w=640, h=480, nfeat=1000, nlines=0, match=False, batch=3072, name="BASELINE configs[1]: single synthetic 640x480 frame stream, ORB-only (1000 kp, 8 levels)"),
+    "c3": dict(w=640, h=480, nfeat=1000, nlines=200, match=True, batch=3072, name="BASELINE configs[2]: 640x480 ORB(1000kp,8 levels)+LSD/LBD(<=200 lines) extract + Hamming match vs previous frame, inputs resident in HBM"),
+    "c4": dict(w=1280, h=960, nfeat=2000, nlines=400, match=True, batch=768, name="BASELINE configs[3]: 1280x960 ORB(2000kp)+LSD/LBD(<=400 lines) extract + match, inputs resident in HBM"),
+}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -57,7 +62,7 @@ def alg_bytes_per_frame(w, h, nkp, nln):
     }
 
 
-def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=600):
+def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=600, with_lines=True, with_match=True):
     """The CPU oracle (a restatement of the reference's CPU path; kind "port") timed on this box's
     host cores, single thread like the reference's front-end (src/Frame.cc:86-87)."""
     import numpy as np
@@ -68,20 +73,23 @@ def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=600):
     prev_feat = None
     # prime "previous" features outside the timed loop
     pk, pd = orc.orb_extract(frames_prev[0], NFEAT)
-    pl = orc.lines_extract(frames_prev[0], NLINES)
+    pl = orc.lines_extract(frames_prev[0], NLINES) if with_lines else None
     t0 = time.perf_counter()
     while n < max_frames and (time.perf_counter() - t0) < budget_s:
         cur = frames_cur[n % len(frames_cur)]
         kp, d = orc.orb_extract(cur, NFEAT)
-        kl, ld, fn, raw = orc.lines_extract(cur, NLINES)
-        pm = np.stack([pk["x"], pk["y"]], axis=1).astype(np.float32)
-        orc.search_for_initialization(pk, pd, kp, d, pm, 100, 0.9, True, (0.0, float(W), 0.0, float(H)))
-        orc.knn2(pd, d)
-        orc.line_match(pl[1], ld, 0.5, False)
+        if with_lines:
+            kl, ld, fn, raw = orc.lines_extract(cur, NLINES)
+        if with_match:
+            pm = np.stack([pk["x"], pk["y"]], axis=1).astype(np.float32)
+            orc.search_for_initialization(pk, pd, kp, d, pm, 100, 0.9, True, (0.0, float(W), 0.0, float(H)))
+            orc.knn2(pd, d)
+            if with_lines:
+                orc.line_match(pl[1], ld, 0.5, False)
         n += 1
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same 640x480 workload (ORB 1000 + LSD/LBD 200 + matches), %.1f s, single thread" % (n, dt)}
+            "sample": "%d frames of the same %dx%d workload (ORB %d%s%s), %.1f s, single thread" % (n, W, H, NFEAT, " + LSD/LBD %d" % NLINES if with_lines else "", " + matches" if with_match else "", dt)}
 
 
 def main():
@@ -89,7 +97,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=3072)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: the workload's)")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--overlap", action="store_true", help="run the point and line branches on two streams (off by default: the persistent LSD kernel wants every wave slot, sharing them costs a second round)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,6 +109,11 @@ def main():
     import torch
     import pkg
     from synth import synth_frame, warp_prev
+    global W, H, NFEAT, NLINES
+    wl = WORKLOADS[args.workload]
+    W, H, NFEAT, NLINES = wl["w"], wl["h"], wl["nfeat"], max(wl["nlines"], 1)
+    if args.batch <= 0:
+        args.batch = wl["batch"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -131,7 +145,7 @@ def main():
     cur = torch.from_numpy(np.stack(cur_np)).to(dev).repeat(reps, 1, 1)[:B].contiguous()
     prev = torch.from_numpy(np.stack(prev_np)).to(dev).repeat(reps, 1, 1)[:B].contiguous()
 
-    pipe = pipeline.FrontendBatch(fe, ctx, W, H, B, NFEAT, NLINES, dev)
+    pipe = pipeline.FrontendBatch(fe, ctx, W, H, B, NFEAT, NLINES, dev, with_lines=wl["nlines"] > 0, with_match=wl["match"])
     # previous-frame features: extracted once, resident (the stream's t-1 state)
     pipe.extract(prev, "prev")
     torch.cuda.synchronize()
@@ -176,11 +190,11 @@ def main():
         total_frames = B * world * args.steps
         fps = total_frames / dt
         out = {
-            "metric": "front-end frames/sec (ORB+LSD extract+match) 640x480 @1000kp/200ln",
+            "metric": "front-end frames/sec (ORB+LSD extract+match) 640x480 @1000kp/200ln" if args.workload == "c3" else "front-end frames/sec, workload " + args.workload,
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 640x480 ORB(1000kp,8 levels)+LSD/LBD(<=200 lines) extract + Hamming match vs previous frame, inputs resident in HBM",
+            "config": {"workload": wl["name"],
                        "batch_per_gpu": B, "global_batch": B * world, "unique_frames": U,
                        "mean_keypoints": float(counts.mean()), "mean_lines": float(lcounts.mean()),
                        "mean_orb_matches": float(nm.mean()), "mean_line_matches": float(nlp.mean()),
@@ -206,7 +220,7 @@ def main():
                                                   "frac": sum(ab.values()) * fps / world / 1e9 / HBM_PEAK_GBS},
                                "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cur_np, prev_np)
+            out["cpu_baseline"] = cpu_baseline(cur_np, prev_np, with_lines=wl["nlines"] > 0, with_match=wl["match"])
         print(json.dumps(out))
     pipe.close()
     ctx.close()
