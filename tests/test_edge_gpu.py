@@ -1,0 +1,113 @@
+"""GPU: parameter and shape edge cases of the drop-in surface, each compared bit-exactly with the oracle."""
+import numpy as np
+import pytest
+from synth import synth_frame, noise_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _orb_eq(fe, ctx, oracle, img, nfeat, scale, nlevels, ini=20, mn=7):
+    ex = fe.OrbExtractor(ctx, nfeat, scale, nlevels, ini, mn)
+    try:
+        kp, desc = ex(img)
+        okp, odesc = oracle.orb_extract(img, nfeat, scale, nlevels, ini, mn)
+        assert len(kp) == len(okp)
+        np.testing.assert_array_equal(kp.view(np.uint8), okp.view(np.uint8))
+        np.testing.assert_array_equal(desc, odesc)
+        return len(kp)
+    finally:
+        ex.close()
+
+
+@pytest.mark.parametrize("nfeat,scale,nlevels,ini,mn", [
+    (1000, 1.2, 1, 20, 7),        # single level
+    (300, 1.5, 5, 20, 7),         # coarse pyramid
+    (5000, 1.2, 8, 20, 7),        # more features than most levels can supply
+    (50, 1.2, 8, 20, 7),          # tiny quotas (quadtree stops after the first passes)
+    (1000, 1.2, 8, 40, 12),       # other FAST thresholds
+    (800, 1.1, 12, 20, 7),        # fine pyramid, 12 levels
+    (0, 1.2, 8, 20, 7),           # nfeatures = 0: the quadtree still returns its first split
+])
+def test_orb_parameter_grid(fe, ctx, oracle, nfeat, scale, nlevels, ini, mn):
+    _orb_eq(fe, ctx, oracle, synth_frame(4000 + nfeat + nlevels), nfeat, scale, nlevels, ini, mn)
+
+
+@pytest.mark.parametrize("w,h", [(641, 479), (97, 81), (64, 48), (1023, 257), (255, 700)])
+def test_orb_ragged_sizes(fe, ctx, oracle, w, h):
+    _orb_eq(fe, ctx, oracle, synth_frame(5000 + w, w=w, h=h), 600, 1.2, 8)
+
+
+def test_orb_strided_input(fe, ctx, oracle):
+    big = synth_frame(6001, w=800, h=500)
+    view = big[7:487, 33:673]                       # 480 x 640 window, row stride 800
+    assert view.strides[0] == 800 and not view.flags["C_CONTIGUOUS"]
+    ex = fe.OrbExtractor(ctx, 1000)
+    import ctypes as C
+    kp = np.zeros(ex.cap, fe.KP_DTYPE); desc = np.zeros((ex.cap, 32), np.uint8); n = C.c_int(0)
+    rc = fe.lib().sslam_orb_extract(ex.h, C.c_void_p(view.ctypes.data), 640, 480, C.c_size_t(800), C.c_void_p(kp.ctypes.data),
+                                    C.c_void_p(desc.ctypes.data), ex.cap, C.byref(n))
+    assert rc == 0
+    okp, odesc = oracle.orb_extract(np.ascontiguousarray(view), 1000)
+    np.testing.assert_array_equal(kp[:n.value].view(np.uint8), okp.view(np.uint8))
+    np.testing.assert_array_equal(desc[:n.value], odesc)
+    ex.close()
+
+
+@pytest.mark.parametrize("w,h,cap", [(641, 479, 200), (200, 150, 200), (640, 480, 1), (640, 480, 3000)])
+def test_lines_ragged_and_caps(fe, ctx, oracle, w, h, cap):
+    img = synth_frame(7000 + w + cap, w=w, h=h)
+    ex = fe.LineExtractor(ctx, cap)
+    kl, ld, fn = ex(img)
+    okl, old, ofn, oraw = oracle.lines_extract(img, cap)
+    np.testing.assert_array_equal(ex.debug_segments(0), oraw)
+    assert len(kl) == len(okl) == min(cap, len(oraw))
+    a = kl.copy(); b = okl.copy(); a["angle"] = 0; b["angle"] = 0
+    np.testing.assert_array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert np.unpackbits(ld ^ old, axis=1).sum(axis=1).max(initial=0) <= 8
+    np.testing.assert_array_equal(fn, ofn)
+    ex.close()
+
+
+def test_capacity_and_argument_errors(fe, ctx):
+    import ctypes as C
+    L = fe.lib()
+    ex = fe.OrbExtractor(ctx, 1000)
+    img = synth_frame(1)
+    kp = np.zeros(10, fe.KP_DTYPE); desc = np.zeros((10, 32), np.uint8); n = C.c_int(0)
+    rc = L.sslam_orb_extract(ex.h, C.c_void_p(img.ctypes.data), 640, 480, C.c_size_t(640), C.c_void_p(kp.ctypes.data), C.c_void_p(desc.ctypes.data), 10, C.byref(n))
+    assert rc == -3 and n.value > 10                    # SSLAM_ERR_CAPACITY reports the true count
+    rc = L.sslam_orb_extract(ex.h, C.c_void_p(img.ctypes.data), 640, 480, C.c_size_t(100), C.c_void_p(kp.ctypes.data), C.c_void_p(desc.ctypes.data), 10, C.byref(n))
+    assert rc == -1                                     # stride < width
+    h = C.c_void_p()
+    assert L.sslam_orb_create(ctx.h, 1000, C.c_float(1.0), 8, 20, 7, C.byref(h)) == -1       # scaleFactor must be > 1
+    assert L.sslam_orb_create(ctx.h, 1000, C.c_float(1.2), 99, 20, 7, C.byref(h)) == -1
+    assert L.sslam_lines_create(ctx.h, 0, C.byref(h)) == -1
+    assert b"invalid" in L.sslam_last_error()
+    ex.close()
+
+
+def test_two_extractors_interleaved_and_threads(fe, ctx, oracle):
+    """Tracking keeps two extractors (ini 2*nFeatures + regular, src/Tracking.cc:118-120) and the matchers run on
+    helper threads (src/Tracking.cc:1323-1326): interleaved use and concurrent calls on one context stay exact."""
+    import threading
+    a = fe.OrbExtractor(ctx, 2000); b = fe.OrbExtractor(ctx, 1000)
+    img1, img2 = synth_frame(8001), synth_frame(8002, w=320, h=240)
+    r1 = a(img1); r2 = b(img2); r3 = a(img2); r4 = b(img1)
+    o = oracle
+    for got, (im, nf) in zip((r1, r2, r3, r4), ((img1, 2000), (img2, 1000), (img2, 2000), (img1, 1000))):
+        okp, od = o.orb_extract(im, nf)
+        np.testing.assert_array_equal(got[0].view(np.uint8), okp.view(np.uint8)); np.testing.assert_array_equal(got[1], od)
+    d1, d2 = r4[1], r1[1]
+    want = oracle.knn2(d1, d2)
+    errs = []
+    def work():
+        try:
+            for _ in range(5):
+                idx, dist = ctx.hamming_knn2(d1, d2)
+                assert (idx == want[0]).all() and (dist == want[1]).all()
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=work) for _ in range(4)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs
+    a.close(); b.close()
