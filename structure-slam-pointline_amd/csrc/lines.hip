@@ -41,7 +41,7 @@ struct LsdPlan {
     int npx;                  // sw*sh
     int nTiles;
     size_t frameBytes;        // per-frame workspace
-    size_t offScaled, offBlur, offAng, offS, offPix, offOrder, offTileHist, offReg, offSeg, offMisc, offDx, offDy, offBlur5, offKl, offSortIdx;
+    size_t offScaled, offBlur, offAng, offS, offPix, offCand, offFlag, offOrder, offTileHist, offReg, offSeg, offMisc, offDx, offDy, offBlur5, offKl, offSortIdx;
     int blurTaps[7];          // sigma 0.75, 7 taps (q8)
     int blur5Taps[5];         // sigma 1, 5 taps (q8)
     int tabX, tabY;           // offsets into the resize table (int: ofs, c1)
@@ -53,6 +53,7 @@ struct Misc {                 // per-frame scalars
     int maxS;                 // max gx^2+gy^2 over defined pixels
     int nDefined;
     int nSeg;
+    int nCand;                // rectangles handed from the sequential core to the NFA stage
     int nKl;
     int overflow;
     long long cyc[8];         // master-wave cycle breakdown (debug): grow, rect, refine, nfa count, nfa math, seed scan
@@ -280,7 +281,10 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, Ls
 // ------------------------------------------------------------------ the sequential core
 struct RectD { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 
-constexpr int QCAP = 2048;          // region points kept in LDS; longer regions continue in global memory
+#ifndef SSLAM_LSD_QCAP
+#define SSLAM_LSD_QCAP 2048
+#endif
+constexpr int QCAP = SSLAM_LSD_QCAP;  // region points kept in LDS; longer regions continue in global memory
 constexpr int MAXC = 5;             // rectangle candidates evaluated per NFA job
 
 __device__ __forceinline__ double angle_diff_signed(double a, double b) {
@@ -651,18 +655,15 @@ __device__ double rect_improve_w(RectD& rec, ImproveLds* L, int sw, int sh, cons
 #endif
 __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
     extern __shared__ __align__(16) unsigned dynLds[];           // region queue (first QCAP points)
-    __shared__ ImproveLds imp;
     const int b = blockIdx.x, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     const float* ang = (const float*)(base + P.offAng);
     float4* pix = (float4*)(base + P.offPix);
     const unsigned* order = (const unsigned*)(base + P.offOrder);
-    float4* seg = (float4*)(base + P.offSeg);
+    double* candOut = (double*)(base + P.offCand);
     Misc* misc = (Misc*)(base + P.offMisc);
     const int sw = P.sw, sh = P.sh;
     RegQ rq; rq.lds = dynLds; rq.glb = (unsigned*)(base + P.offReg);
-    if (lane == 0) { imp.cycCount = 0; imp.cycMath = 0; }
-    if (lane < 16) { const double pp = ldexp(0.125, -lane); imp.plog[lane].lp = log(pp); imp.plog[lane].l1mp = log(1.0 - pp); imp.plog[lane].l10p = log10(pp); }
     __syncthreads();
     const int nOrd = misc->nDefined;
     const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
@@ -745,23 +746,56 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                     if (!good) continue;
                 }
             }
-            // ---- rect_improve (LSD_REFINE_ADV part) + NFA gate
+            // ---- hand the rectangle to the NFA stage (rect_improve reads only the static angle map and never touches
+            // `used`, so it is not part of the sequential dependency chain: k_lsd_nfa evaluates all candidates in parallel)
             long long t3 = __builtin_readcyclecounter(); cyc2 += t3 - t2;
-            const double logNfa = rect_improve_w(rec, &imp, sw, sh, ang, P.logNT, lgam);
-            cyc3 += __builtin_readcyclecounter() - t3;
-            if (!(logNfa > 0.0)) continue;
             if (nSeg < MAX_SEG && lane == 0) {
-                const double SCALE = 0.8;
-                seg[nSeg] = make_float4((float)((rec.x1 + 0.5) / SCALE), (float)((rec.y1 + 0.5) / SCALE),
-                                        (float)((rec.x2 + 0.5) / SCALE), (float)((rec.y2 + 0.5) / SCALE));
+                double* o = candOut + (size_t)nSeg * 12;
+                o[0] = rec.x1; o[1] = rec.y1; o[2] = rec.x2; o[3] = rec.y2; o[4] = rec.width; o[5] = rec.x; o[6] = rec.y;
+                o[7] = rec.theta; o[8] = rec.dx; o[9] = rec.dy; o[10] = rec.prec; o[11] = rec.p;
             }
             ++nSeg;
         }
     }
     if (lane == 0) {
-        misc->nSeg = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
+        misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
         misc->cyc[0] = cyc0; misc->cyc[1] = cyc1; misc->cyc[2] = cyc2; misc->cyc[3] = cyc3; misc->cyc[4] = __builtin_readcyclecounter() - tStart;
-        misc->cyc[5] = imp.cycCount; misc->cyc[6] = imp.cycMath;
+    }
+}
+
+// rect_improve + the NFA gate for every candidate rectangle, one wave each (LSD_REFINE_ADV part of flsd()).
+__global__ __launch_bounds__(64) void k_lsd_nfa(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
+    __shared__ ImproveLds imp;
+    const int b = blockIdx.y, lane = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int nCand = misc->nCand;
+    if ((int)blockIdx.x >= nCand) return;
+    const float* ang = (const float*)(base + P.offAng);
+    const double* cand = (const double*)(base + P.offCand);
+    float4* seg = (float4*)(base + P.offSeg);
+    int* flag = (int*)(base + P.offFlag);
+    if (lane == 0) { imp.cycCount = 0; imp.cycMath = 0; }
+    if (lane < 16) { const double pp = ldexp(0.125, -lane); imp.plog[lane].lp = log(pp); imp.plog[lane].l1mp = log(1.0 - pp); imp.plog[lane].l10p = log10(pp); }
+    __syncthreads();
+    for (int c = blockIdx.x; c < nCand; c += gridDim.x) {
+        RectD rec;
+        {
+            const double* o = cand + (size_t)c * 12;
+            rec.x1 = o[0]; rec.y1 = o[1]; rec.x2 = o[2]; rec.y2 = o[3]; rec.width = o[4]; rec.x = o[5]; rec.y = o[6];
+            rec.theta = o[7]; rec.dx = o[8]; rec.dy = o[9]; rec.prec = o[10]; rec.p = o[11];
+        }
+        const double logNfa = rect_improve_w(rec, &imp, P.sw, P.sh, ang, P.logNT, lgam);
+        if (lane == 0) {
+            const bool ok = logNfa > 0.0;
+            flag[c] = ok ? 1 : 0;
+            if (ok) {
+                const double SCALE = 0.8;
+                seg[c] = make_float4((float)((rec.x1 + 0.5) / SCALE), (float)((rec.y1 + 0.5) / SCALE),
+                                     (float)((rec.x2 + 0.5) / SCALE), (float)((rec.y2 + 0.5) / SCALE));
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -772,10 +806,34 @@ __global__ __launch_bounds__(256) void k_keylines(uint8_t* __restrict__ ws, LsdP
     __shared__ unsigned long long keys[MAX_SEG];
     const int b = blockIdx.x, tid = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
-    const float4* seg = (const float4*)(base + P.offSeg);
+    float4* seg = (float4*)(base + P.offSeg);
     Misc* misc = (Misc*)(base + P.offMisc);
     sslam_keyline* klw = (sslam_keyline*)(base + P.offKl);
-    const int n = misc->nSeg;
+    // ordered compaction of the candidates the NFA stage accepted (seed order == the reference's emission order)
+    __shared__ int wcnt[4];
+    __shared__ int nAcc;
+    {
+        const int* flag = (const int*)(base + P.offFlag);
+        const int nCand = misc->nCand;
+        const int lane = tid & 63, wv = tid >> 6;
+        int basePos = 0;
+        for (int i0 = 0; i0 < nCand; i0 += 256) {
+            const int i = i0 + tid;
+            const bool ok = i < nCand && flag[i] != 0;
+            const float4 v = ok ? seg[i] : make_float4(0, 0, 0, 0);
+            const unsigned long long m = __ballot(ok);
+            if (lane == 0) wcnt[wv] = __popcll(m);
+            __syncthreads();                       // also orders the reads of seg[i0..i0+256) before the writes below (dst <= src)
+            int off = basePos;
+            for (int q = 0; q < wv; ++q) off += wcnt[q];
+            if (ok) seg[off + mbcnt(m)] = v;
+            basePos += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+        }
+        if (tid == 0) { nAcc = basePos; misc->nSeg = basePos; }
+        __syncthreads();
+    }
+    const int n = nAcc;
     for (int i = tid; i < n; i += 256) {
         float4 s = seg[i];
         float e0 = s.x, e1 = s.y, e2 = s.z, e3 = s.w;
@@ -1045,7 +1103,7 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
 
 __global__ void k_zero_misc(uint8_t* ws, LsdPlan P) {
     Misc* m = (Misc*)(ws + (size_t)blockIdx.x * P.frameBytes + P.offMisc);
-    if (threadIdx.x == 0) { m->maxS = 0; m->nDefined = 0; m->nSeg = 0; m->nKl = 0; m->overflow = 0; }
+    if (threadIdx.x == 0) { m->maxS = 0; m->nDefined = 0; m->nSeg = 0; m->nCand = 0; m->nKl = 0; m->overflow = 0; }
 }
 
 }  // namespace
@@ -1137,6 +1195,8 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offTileHist = take(sizeof(int) * (size_t)P.nTiles * N_BINS);
     P.offReg = take(sizeof(unsigned) * (size_t)P.npx);
     P.offSeg = take(sizeof(float4) * MAX_SEG);
+    P.offCand = take(sizeof(double) * 12 * MAX_SEG);      // candidate rectangles (RectD) awaiting the NFA stage, seed order
+    P.offFlag = take(sizeof(int) * MAX_SEG);
     P.offMisc = take(sizeof(Misc));
     P.offBlur5 = take(bpitch * h);                        // sigma-1 blur of the source (LBD)
     P.offDx = take(sizeof(short) * (size_t)w * h);
@@ -1227,6 +1287,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         if (lds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         { sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st); hipLaunchKernelGGL(k_lsd_regions, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>()); }
     }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_nfa", st); hipLaunchKernelGGL(k_lsd_nfa, dim3(1024, nframes), dim3(64), 0, st, ws, P, L->dLgam.as<double>()); }
     { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
     // LBD: blur(5, 1) + Sobel fused -> bands
     { sslam::ProfScope _ps(L->ctx, "k_blur_sobel", st); hipLaunchKernelGGL(k_blur_sobel, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride, w, h,
