@@ -212,6 +212,9 @@ int sslam_lines_extract_batch_dev(sslam_lines* ln, const uint8_t* d_images, int 
                                   size_t pitch, size_t image_stride, int nframes,
                                   sslam_keyline* d_kl, uint8_t* d_ldesc, double* d_linefn,
                                   int32_t* d_counts, int cap, void* stream);
+/* Self-test of the table-based exact integer division of the NFA binomial tail against the hardware IEEE division:
+ * `pairs` random quotients a/b with 1 <= a,b < n; *mismatches_out must come back 0. */
+int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, long long* mismatches_out);
 /* Stage tap: all LSD segments (x1,y1,x2,y2 float) of frame `frame` of the last batch, before top-N. */
 int sslam_lines_debug_segments(sslam_lines* ln, int frame, float* seg_out, int cap, int* n_out);
 

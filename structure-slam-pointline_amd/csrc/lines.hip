@@ -41,7 +41,7 @@ struct LsdPlan {
     int npx;                  // sw*sh
     int nTiles;
     size_t frameBytes;        // per-frame workspace
-    size_t offScaled, offBlur, offAng, offS, offPix, offCand, offFlag, offOrder, offTileHist, offReg, offSeg, offMisc, offDx, offDy, offBlur5, offKl, offSortIdx;
+    size_t offScaled, offBlur, offAng, offS, offPix, offCand, offFlag, offNfa, offOrder, offTileHist, offReg, offSeg, offMisc, offDx, offDy, offBlur5, offKl, offSortIdx;
     int blurTaps[7];          // sigma 0.75, 7 taps (q8)
     int blur5Taps[5];         // sigma 1, 5 taps (q8)
     int tabX, tabY;           // offsets into the resize table (int: ofs, c1)
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, Ls
 struct RectD { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 
 #ifndef SSLAM_LSD_QCAP
-#define SSLAM_LSD_QCAP 2048
+#define SSLAM_LSD_QCAP 1024
 #endif
 constexpr int QCAP = SSLAM_LSD_QCAP;  // region points kept in LDS; longer regions continue in global memory
 constexpr int MAXC = 5;             // rectangle candidates evaluated per NFA job
@@ -308,13 +308,37 @@ __device__ double log_gamma_d(double x) {
     return a + log(bq);
 }
 // lgam[j] = log_gamma(j) for integer j >= 1 (every argument nfa() uses is an integer + 1)
+// ... followed by plog[h] = {log p, log(1-p), log10 p} for p = 0.125 * 2^-h, h < 16
 __global__ void k_lgamma_table(double* __restrict__ lgam, int n) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) lgam[j] = j >= 1 ? log_gamma_d((double)j) : 0.0;
+    if (j < 16) { const double pp = ldexp(0.125, -j); lgam[n + 3 * j] = log(pp); lgam[n + 3 * j + 1] = log(1.0 - pp); lgam[n + 3 * j + 2] = log10(pp); }
+    if (j < n) lgam[n + 48 + j] = j >= 1 ? 1.0 / (double)j : 0.0;          // correctly rounded reciprocals for exact_div()
+}
+
+// a / b for small positive integers, bit-identical to the IEEE quotient: with y = RN(1/b) from the table, q0 = RN(a*y),
+// the FMA residual r = a - b*q0 is exact and q0 + r*y rounds to RN(a/b) (Markstein's division theorem; checked against the
+// hardware division by sslam_selftest_exact_div).
+__device__ __forceinline__ double exact_div(double a, double b, double y) {
+    const double q0 = a * y;
+    const double r = fma(-b, q0, a);
+    return fma(r, y, q0);
+}
+__global__ void k_selftest_div(const double* __restrict__ rcp, int n, unsigned long long seed, int iters, unsigned long long* __restrict__ bad) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned long long nb = 0;
+    for (int it = 0; it < iters; ++it) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const int b = 1 + (int)((x >> 8) % (unsigned long long)(n - 1));
+        const int a = 1 + (int)((x >> 36) % (unsigned long long)(n - 1));
+        const double q = exact_div((double)a, (double)b, rcp[b]), ref = (double)a / (double)b;
+        nb += (__double_as_longlong(q) != __double_as_longlong(ref)) ? 1 : 0;
+    }
+    if (nb) atomicAdd(bad, nb);
 }
 // plog[h] = {log(p), log(1-p), log10(p)} for p = 0.125 * 2^-h: every precision rect_improve can reach
 struct PLog { double lp, l1mp, l10p; };
-__device__ double nfa_d(int n, int k, double p, double logNT, const double* __restrict__ lgam, const PLog* plog) {
+__device__ double nfa_d(int n, int k, double p, double logNT, const double* __restrict__ lgam, const PLog* plog, const double* __restrict__ rcp) {
     if (n == 0 || k == 0) return -logNT;
     const int h = 1020 - ((__double2hiint(p) >> 20) & 0x7FF);        // p is an exact power of two
     const bool tab = h >= 0 && h < 16 && p == ldexp(0.125, -h);
@@ -334,7 +358,7 @@ __device__ double nfa_d(int n, int k, double p, double logNT, const double* __re
 #pragma unroll
         for (int j = 0; j < 8; ++j) {           // independent divisions: issue back to back
             const int i = min(i0 + j, n);
-            mt[j] = ((double)(n - i + 1) / (double)i) * p_term;
+            mt[j] = exact_div((double)(n - i + 1), (double)i, rcp[i]) * p_term;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -546,112 +570,254 @@ __device__ __forceinline__ void nfa_row_range(const NfaGeom& g, int y, int sw, i
     xa = (int)max(lft, 0LL); xb = (int)min(rgt, (long long)sw - 1);
 }
 
-// rect_improve support.  Inside one refinement stage the candidate rectangles do not depend on
-// which of them gets accepted, so a stage's (up to five) NFAs are evaluated together: all rows of
-// all candidates are spread over the wave (two lanes per row, twelve independent loads per lane,
-// wide rows swept by the whole wave), then the binomial tails run lane-parallel.
-struct ImproveLds { RectD cand[MAXC]; double val[MAXC]; NfaGeom geom[MAXC]; int total[MAXC], alg[MAXC]; long long cycCount, cycMath; PLog plog[16]; };
+// ------------------------------------------------------------------ rect_improve as staged, fully parallel kernels
+// rect_improve (LSD_REFINE_ADV) evaluates the rectangle, then five refinement stages of up to five candidate rectangles
+// each; inside a stage the candidates do not depend on which of them is accepted.  Per stage two launches cover every
+// candidate of every frame: k_nfa_count (one wave per rectangle: aligned-point counts of the stage's candidates) and
+// k_nfa_math (8 lanes per rectangle: the binomial-tail NFAs lane-parallel, then the reference's sequential acceptance).
+struct NfaState { double logNfa; int done, nc; int cnt[6][2]; };      // per rectangle; cnt[k] = {total, aligned}
 
-__device__ void nfa_eval_w(ImproveLds* L, int nc, int sw, int sh, const float* __restrict__ ang, double logNT, const double* __restrict__ lgam) {
-    const int lane = threadIdx.x & 63;
-    const long long tc0 = __builtin_readcyclecounter();
-    if (lane < nc) { L->geom[lane] = nfa_geom(L->cand[lane], sh); L->total[lane] = 0; L->alg[lane] = 0; }
-    __syncthreads();
-    int rb[MAXC + 1];
-    rb[0] = 0;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) rb[c + 1] = rb[c] + (c < nc ? max(0, L->geom[c].y1 - L->geom[c].y0 + 1) : 0);
-    const int R = rb[MAXC];
-    const int half = lane & 1;
-    for (int t0 = 0; t0 < R; t0 += 32) {
-        const int t = t0 + (lane >> 1);
-        int c = 0, y = 0, xa = 0, xb = -1;
-        double theta = 0, prec = 0;
-        if (t < R) {
-#pragma unroll
-            for (int q = 1; q < MAXC; ++q) c += (t >= rb[q]) ? 1 : 0;
-            const NfaGeom g = L->geom[c];
-            const int rbc = c == 0 ? rb[0] : c == 1 ? rb[1] : c == 2 ? rb[2] : c == 3 ? rb[3] : rb[4];
-            y = g.y0 + (t - rbc);
-            nfa_row_range(g, y, sw, xa, xb);
-            theta = L->cand[c].theta; prec = L->cand[c].prec;
-        }
-        const int width = xb - xa + 1;
-        if (width > 0 && half == 0) atomicAdd(&L->total[c], width);
-        const bool wide = width > 24;
-        if (width > 0 && !wide) {
-            const float* row = ang + (size_t)y * sw;
-            const int xs = xa + half * 12;
-            float a[12];
-#pragma unroll
-            for (int j = 0; j < 12; ++j) a[j] = (xs + j <= xb) ? row[xs + j] : NOTDEF_F;
-            int cnt = 0;
-#pragma unroll
-            for (int j = 0; j < 12; ++j) cnt += (int)is_aligned_val(a[j], theta, prec);
-            if (cnt) atomicAdd(&L->alg[c], cnt);
-        }
-        // wide rows: whole wave sweeps them one by one
-        unsigned long long wm = __ballot(wide && half == 0);
-        while (wm) {
-            const int src = __ffsll((long long)wm) - 1;
-            wm &= wm - 1;
-            const int wc = __shfl(c, src, 64), wy = __shfl(y, src, 64), wxa = __shfl(xa, src, 64), wxb = __shfl(xb, src, 64);
-            const double wth = L->cand[wc].theta, wpr = L->cand[wc].prec;
-            const float* row = ang + (size_t)wy * sw;
-            int cnt = 0;
-            for (int x = wxa + lane; x <= wxb; x += 128) {
-                const float a0 = row[x], a1 = x + 64 <= wxb ? row[x + 64] : NOTDEF_F;
-                cnt += (int)is_aligned_val(a0, wth, wpr) + (int)is_aligned_val(a1, wth, wpr);
-            }
-            cnt = wave_sum(cnt);
-            if (lane == 0 && cnt) atomicAdd(&L->alg[wc], cnt);
+// candidate j of stage `stage` (0..4) grown from the stage's starting rectangle exactly like rect_improve's loops;
+// false when iteration j is skipped (width floor) — then every later iteration is skipped too.
+__device__ bool stage_cand(const RectD& rec, int stage, int j, RectD& r) {
+    const double delta = 0.5, delta_2 = delta / 2.0;
+    r = rec;
+    for (int n = 0; n <= j; ++n) {
+        if (stage == 0 || stage == 4) {
+            if (stage == 4 && !((r.width - delta) >= 0.5)) return false;
+            r.p /= 2; r.prec = r.p * kPI;
+        } else {
+            if (!((r.width - delta) >= 0.5)) return false;
+            if (stage == 2) { r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; }
+            if (stage == 3) { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
+            r.width -= delta;
         }
     }
-    __syncthreads();
-    const long long tc1 = __builtin_readcyclecounter();
-    if (lane < nc) L->val[lane] = nfa_d(L->total[lane], L->alg[lane], L->cand[lane].p, logNT, lgam, L->plog);
-    __syncthreads();
-    if (lane == 0) { L->cycCount += tc1 - tc0; L->cycMath += __builtin_readcyclecounter() - tc1; }
+    return true;
 }
 
-__device__ double rect_improve_w(RectD& rec, ImproveLds* L, int sw, int sh, const float* ang, double logNT, const double* lgam) {
-    const int lane = threadIdx.x & 63;
-    const double delta = 0.5, delta_2 = delta / 2.0, LOG_EPS = 0.0;
-    if (lane == 0) L->cand[0] = rec;
-    __syncthreads();
-    nfa_eval_w(L, 1, sw, sh, ang, logNT, lgam);
-    double log_nfa = L->val[0];
-    if (log_nfa > LOG_EPS) return log_nfa;
-    for (int stage = 0; stage < 5; ++stage) {
-        RectD r = rec;
-        int nc = 0;
-        for (int n = 0; n < 5; ++n) {
-            if (stage == 0 || stage == 4) {
-                if (stage == 4 && !((r.width - delta) >= 0.5)) continue;
-                r.p /= 2; r.prec = r.p * kPI;
-            } else {
-                if (!((r.width - delta) >= 0.5)) continue;
-                if (stage == 2) { r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; }
-                if (stage == 3) { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
-                r.width -= delta;
+__device__ __forceinline__ void load_rect(const double* o, RectD& rec) {
+    rec.x1 = o[0]; rec.y1 = o[1]; rec.x2 = o[2]; rec.y2 = o[3]; rec.width = o[4]; rec.x = o[5]; rec.y = o[6];
+    rec.theta = o[7]; rec.dx = o[8]; rec.dy = o[9]; rec.prec = o[10]; rec.p = o[11];
+}
+__device__ __forceinline__ void store_rect(double* o, const RectD& rec) {
+    o[0] = rec.x1; o[1] = rec.y1; o[2] = rec.x2; o[3] = rec.y2; o[4] = rec.width; o[5] = rec.x; o[6] = rec.y;
+    o[7] = rec.theta; o[8] = rec.dx; o[9] = rec.dy; o[10] = rec.prec; o[11] = rec.p;
+}
+
+// angular distance used by isAligned (NOTDEF -> +inf)
+__device__ __forceinline__ double align_dist(float aDeg, double theta) {
+    if (aDeg == NOTDEF_F) return 1e300;
+    double n_theta = theta - (double)aDeg * DEG2RAD;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > M_3_2_PI_) { n_theta -= M_2PI_; if (n_theta < 0) n_theta = -n_theta; }
+    return n_theta;
+}
+
+struct CountLds { RectD cand[MAXC]; NfaGeom geom[MAXC]; int total[MAXC], alg[MAXC]; };
+
+// stage 0 is merged with the initial evaluation: same rectangle, six precisions (p, p/2 .. p/32); stage 4 likewise has one
+// geometry and five precisions.  Stages 1-3 change the rectangle itself.
+__global__ __launch_bounds__(64) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
+    __shared__ CountLds L;
+    const int b = blockIdx.y, lane = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int nCand = misc->nCand;
+    const float* ang = (const float*)(base + P.offAng);
+    const double* rects = (const double*)(base + P.offCand);
+    NfaState* st = (NfaState*)(base + P.offNfa);
+    const int sw = P.sw, sh = P.sh;
+    for (int c = blockIdx.x; c < nCand; c += gridDim.x) {
+        if (stage > 0 && st[c].done) continue;
+        RectD rec; load_rect(rects + (size_t)c * 12, rec);
+        if (stage == 0 || stage == 4) {
+            // one geometry, K nested precisions: prec_k = (p / 2^k) * pi (k from 0 for the merged initial evaluation)
+            const int K = stage == 0 ? 6 : 5;
+            const bool live = stage == 0 || (rec.width - 0.5) >= 0.5;
+            int algk[6] = {0, 0, 0, 0, 0, 0};
+            int total = 0;
+            if (live) {
+                double prec[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) prec[k] = stage == 0 ? (k == 0 ? rec.prec : ldexp(rec.p, -k) * kPI) : ldexp(rec.p, -(k + 1)) * kPI;
+                const NfaGeom g = nfa_geom(rec, sh);
+                const int nrows = g.y1 - g.y0 + 1;
+                const int half = lane & 1;
+                for (int t0 = 0; t0 < nrows; t0 += 32) {
+                    const int t = t0 + (lane >> 1);
+                    int xa = 0, xb = -1; const int y = g.y0 + t;
+                    if (t < nrows) nfa_row_range(g, y, sw, xa, xb);
+                    const int width = xb - xa + 1;
+                    if (width > 0 && half == 0) total += width;
+                    const bool wide = width > 24;
+                    if (width > 0 && !wide) {
+                        const float* row = ang + (size_t)y * sw;
+                        const int xs = xa + half * 12;
+                        float a[12];
+#pragma unroll
+                        for (int j = 0; j < 12; ++j) a[j] = (xs + j <= xb) ? row[xs + j] : NOTDEF_F;
+#pragma unroll
+                        for (int j = 0; j < 12; ++j) {
+                            const double d = align_dist(a[j], rec.theta);
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) algk[k] += (k < K && d <= prec[k]) ? 1 : 0;
+                        }
+                    }
+                    unsigned long long wm = __ballot(wide && half == 0);
+                    while (wm) {
+                        const int src = __ffsll((long long)wm) - 1;
+                        wm &= wm - 1;
+                        const int wy = __shfl(y, src, 64), wxa = __shfl(xa, src, 64), wxb = __shfl(xb, src, 64);
+                        const float* row = ang + (size_t)wy * sw;
+                        for (int x = wxa + lane; x <= wxb; x += 64) {
+                            const double d = align_dist(row[x], rec.theta);
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) algk[k] += (k < K && d <= prec[k]) ? 1 : 0;
+                        }
+                    }
+                }
             }
-            if (lane == 0) L->cand[nc] = r;
-            ++nc;
+            total = wave_sum(total);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) algk[k] = wave_sum(algk[k]);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { st[c].cnt[k][0] = total; st[c].cnt[k][1] = algk[k]; }
+                st[c].nc = live ? K : 0;
+            }
+        } else {
+            // distinct rectangles: all rows of all candidates spread over the wave
+            RectD r;
+            const bool valid = lane < MAXC && stage_cand(rec, stage, lane, r);
+            const int nc = __popcll(__ballot(valid));
+            if (valid) { L.cand[lane] = r; L.geom[lane] = nfa_geom(r, sh); L.total[lane] = 0; L.alg[lane] = 0; }
+            __syncthreads();
+            int rb[MAXC + 1];
+            rb[0] = 0;
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q) rb[q + 1] = rb[q] + (q < nc ? max(0, L.geom[q].y1 - L.geom[q].y0 + 1) : 0);
+            const int R = rb[MAXC];
+            const int half = lane & 1;
+            for (int t0 = 0; t0 < R; t0 += 32) {
+                const int t = t0 + (lane >> 1);
+                int cc = 0, y = 0, xa = 0, xb = -1;
+                double theta = 0, prec = 0;
+                if (t < R) {
+#pragma unroll
+                    for (int q = 1; q < MAXC; ++q) cc += (t >= rb[q]) ? 1 : 0;
+                    const NfaGeom g = L.geom[cc];
+                    const int rbc = cc == 0 ? rb[0] : cc == 1 ? rb[1] : cc == 2 ? rb[2] : cc == 3 ? rb[3] : rb[4];
+                    y = g.y0 + (t - rbc);
+                    nfa_row_range(g, y, sw, xa, xb);
+                    theta = L.cand[cc].theta; prec = L.cand[cc].prec;
+                }
+                const int width = xb - xa + 1;
+                if (width > 0 && half == 0) atomicAdd(&L.total[cc], width);
+                const bool wide = width > 24;
+                if (width > 0 && !wide) {
+                    const float* row = ang + (size_t)y * sw;
+                    const int xs = xa + half * 12;
+                    float a[12];
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) a[j] = (xs + j <= xb) ? row[xs + j] : NOTDEF_F;
+                    int cnt = 0;
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) cnt += (int)is_aligned_val(a[j], theta, prec);
+                    if (cnt) atomicAdd(&L.alg[cc], cnt);
+                }
+                unsigned long long wm = __ballot(wide && half == 0);
+                while (wm) {
+                    const int src = __ffsll((long long)wm) - 1;
+                    wm &= wm - 1;
+                    const int wc = __shfl(cc, src, 64), wy = __shfl(y, src, 64), wxa = __shfl(xa, src, 64), wxb = __shfl(xb, src, 64);
+                    const double wth = L.cand[wc].theta, wpr = L.cand[wc].prec;
+                    const float* row = ang + (size_t)wy * sw;
+                    int cnt = 0;
+                    for (int x = wxa + lane; x <= wxb; x += 128) {
+                        const float a0 = row[x], a1 = x + 64 <= wxb ? row[x + 64] : NOTDEF_F;
+                        cnt += (int)is_aligned_val(a0, wth, wpr) + (int)is_aligned_val(a1, wth, wpr);
+                    }
+                    cnt = wave_sum(cnt);
+                    if (lane == 0 && cnt) atomicAdd(&L.alg[wc], cnt);
+                }
+            }
+            __syncthreads();
+            if (lane < MAXC) { st[c].cnt[lane][0] = lane < nc ? L.total[lane] : 0; st[c].cnt[lane][1] = lane < nc ? L.alg[lane] : 0; }
+            if (lane == 0) st[c].nc = nc;
+            __syncthreads();
         }
-        __syncthreads();
-        if (nc > 0) {
-            nfa_eval_w(L, nc, sw, sh, ang, logNT, lgam);
-            for (int j = 0; j < nc; ++j) { const double v = L->val[j]; if (v > log_nfa) { log_nfa = v; rec = L->cand[j]; } }
-        }
-        __syncthreads();
-        if (stage < 4 && log_nfa > LOG_EPS) return log_nfa;
     }
-    return log_nfa;
+}
+
+// stage -1: the initial evaluation (cnt[0]); stage 0: cnt[1..5]; stages 1-4: cnt[0..nc).
+__global__ __launch_bounds__(256) void k_nfa_math(uint8_t* __restrict__ ws, LsdPlan P, int stage, const double* __restrict__ lgam) {
+    const int b = blockIdx.y;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int nCand = misc->nCand;
+    double* rects = (double*)(base + P.offCand);
+    NfaState* st = (NfaState*)(base + P.offNfa);
+    const PLog* plog = (const PLog*)(lgam + P.npx + 4);
+    const int j = threadIdx.x & 7;
+    for (int c0 = blockIdx.x * 32; c0 < nCand; c0 += gridDim.x * 32) {
+        const int c = c0 + (threadIdx.x >> 3);
+        const bool act = c < nCand && !(stage >= 0 && st[c].done);
+        RectD rec, r;
+        int nc = 0, kofs = 0;
+        double v = 0;
+        if (act) {
+            load_rect(rects + (size_t)c * 12, rec);
+            if (stage < 0) nc = 1;
+            else if (stage == 0) { nc = 5; kofs = 1; }
+            else nc = stage == 4 ? (st[c].nc > 0 ? 5 : 0) : st[c].nc;
+            if (j < nc) {
+                double p = rec.p;
+                if (stage >= 0) { stage_cand(rec, stage, j, r); p = r.p; }
+                v = nfa_d(st[c].cnt[j + kofs][0], st[c].cnt[j + kofs][1], p, P.logNT, lgam, plog, lgam + P.npx + 4 + 48);
+            }
+        }
+        // acceptance in order by the group's lane 0 (values gathered from its 8-lane group)
+        double vs[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) vs[q] = __shfl(v, ((threadIdx.x & 63) & ~7) + q, 64);
+        if (act && j == 0) {
+            if (stage < 0) { st[c].logNfa = vs[0]; st[c].done = vs[0] > 0.0 ? 1 : 0; }
+            else {
+                double log_nfa = st[c].logNfa;
+                bool changed = false;
+                for (int q = 0; q < nc; ++q)
+                    if (vs[q] > log_nfa) { log_nfa = vs[q]; stage_cand(rec, stage, q, r); changed = true; }
+                if (changed) { store_rect(rects + (size_t)c * 12, r); st[c].logNfa = log_nfa; }
+                if (stage < 4 && log_nfa > 0.0) st[c].done = 1;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nfa_finish(uint8_t* __restrict__ ws, LsdPlan P) {
+    const int b = blockIdx.y;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int nCand = misc->nCand;
+    const double* rects = (const double*)(base + P.offCand);
+    const NfaState* st = (const NfaState*)(base + P.offNfa);
+    float4* seg = (float4*)(base + P.offSeg);
+    int* flag = (int*)(base + P.offFlag);
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < nCand; c += gridDim.x * 256) {
+        const bool ok = st[c].logNfa > 0.0;
+        flag[c] = ok ? 1 : 0;
+        if (ok) {
+            const double* o = rects + (size_t)c * 12;
+            const double SCALE = 0.8;
+            seg[c] = make_float4((float)((o[0] + 0.5) / SCALE), (float)((o[1] + 0.5) / SCALE), (float)((o[2] + 0.5) / SCALE), (float)((o[3] + 0.5) / SCALE));
+        }
+    }
 }
 
 // One persistent single-wave workgroup per frame: the flsd() main loop replayed in order.
 #ifndef SSLAM_LSD_MINWAVES
-#define SSLAM_LSD_MINWAVES 3          // waves/SIMD the register allocator must leave room for
+#define SSLAM_LSD_MINWAVES 6          // waves/SIMD the register allocator must leave room for (6 x 4 SIMDs = 24 frames per CU, LDS allows 32)
 #endif
 __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
     extern __shared__ __align__(16) unsigned dynLds[];           // region queue (first QCAP points)
@@ -760,42 +926,6 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
     if (lane == 0) {
         misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
         misc->cyc[0] = cyc0; misc->cyc[1] = cyc1; misc->cyc[2] = cyc2; misc->cyc[3] = cyc3; misc->cyc[4] = __builtin_readcyclecounter() - tStart;
-    }
-}
-
-// rect_improve + the NFA gate for every candidate rectangle, one wave each (LSD_REFINE_ADV part of flsd()).
-__global__ __launch_bounds__(64) void k_lsd_nfa(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
-    __shared__ ImproveLds imp;
-    const int b = blockIdx.y, lane = threadIdx.x;
-    uint8_t* base = ws + (size_t)b * P.frameBytes;
-    const Misc* misc = (const Misc*)(base + P.offMisc);
-    const int nCand = misc->nCand;
-    if ((int)blockIdx.x >= nCand) return;
-    const float* ang = (const float*)(base + P.offAng);
-    const double* cand = (const double*)(base + P.offCand);
-    float4* seg = (float4*)(base + P.offSeg);
-    int* flag = (int*)(base + P.offFlag);
-    if (lane == 0) { imp.cycCount = 0; imp.cycMath = 0; }
-    if (lane < 16) { const double pp = ldexp(0.125, -lane); imp.plog[lane].lp = log(pp); imp.plog[lane].l1mp = log(1.0 - pp); imp.plog[lane].l10p = log10(pp); }
-    __syncthreads();
-    for (int c = blockIdx.x; c < nCand; c += gridDim.x) {
-        RectD rec;
-        {
-            const double* o = cand + (size_t)c * 12;
-            rec.x1 = o[0]; rec.y1 = o[1]; rec.x2 = o[2]; rec.y2 = o[3]; rec.width = o[4]; rec.x = o[5]; rec.y = o[6];
-            rec.theta = o[7]; rec.dx = o[8]; rec.dy = o[9]; rec.prec = o[10]; rec.p = o[11];
-        }
-        const double logNfa = rect_improve_w(rec, &imp, P.sw, P.sh, ang, P.logNT, lgam);
-        if (lane == 0) {
-            const bool ok = logNfa > 0.0;
-            flag[c] = ok ? 1 : 0;
-            if (ok) {
-                const double SCALE = 0.8;
-                seg[c] = make_float4((float)((rec.x1 + 0.5) / SCALE), (float)((rec.y1 + 0.5) / SCALE),
-                                     (float)((rec.x2 + 0.5) / SCALE), (float)((rec.y2 + 0.5) / SCALE));
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -1197,6 +1327,7 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offSeg = take(sizeof(float4) * MAX_SEG);
     P.offCand = take(sizeof(double) * 12 * MAX_SEG);      // candidate rectangles (RectD) awaiting the NFA stage, seed order
     P.offFlag = take(sizeof(int) * MAX_SEG);
+    P.offNfa = take(sizeof(NfaState) * MAX_SEG);
     P.offMisc = take(sizeof(Misc));
     P.offBlur5 = take(bpitch * h);                        // sigma-1 blur of the source (LBD)
     P.offDx = take(sizeof(short) * (size_t)w * h);
@@ -1210,7 +1341,7 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     }
     {   // log-gamma table for nfa(): arguments are integers in [1, npx+2]
         const int nl = P.npx + 4;
-        if ((rc = L->dLgam.ensure(sizeof(double) * (size_t)nl))) return rc;
+        if ((rc = L->dLgam.ensure(sizeof(double) * (2 * (size_t)nl + 48)))) return rc;
         hipLaunchKernelGGL(k_lgamma_table, dim3((nl + 255) / 256), dim3(256), 0, L->ctx->stream, L->dLgam.as<double>(), nl);
         SSLAM_HIP(hipStreamSynchronize(L->ctx->stream));
     }
@@ -1287,7 +1418,12 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         if (lds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         { sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st); hipLaunchKernelGGL(k_lsd_regions, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>()); }
     }
-    { sslam::ProfScope _ps(L->ctx, "k_lsd_nfa", st); hipLaunchKernelGGL(k_lsd_nfa, dim3(1024, nframes), dim3(64), 0, st, ws, P, L->dLgam.as<double>()); }
+    for (int stage = 0; stage <= 4; ++stage) {
+        { sslam::ProfScope _ps(L->ctx, "k_nfa_count", st); hipLaunchKernelGGL(k_nfa_count, dim3(512, nframes), dim3(64), 0, st, ws, P, stage); }
+        if (stage == 0) { sslam::ProfScope _ps(L->ctx, "k_nfa_math", st); hipLaunchKernelGGL(k_nfa_math, dim3(16, nframes), dim3(256), 0, st, ws, P, -1, L->dLgam.as<double>()); }
+        { sslam::ProfScope _ps(L->ctx, "k_nfa_math", st); hipLaunchKernelGGL(k_nfa_math, dim3(16, nframes), dim3(256), 0, st, ws, P, stage, L->dLgam.as<double>()); }
+    }
+    { sslam::ProfScope _ps(L->ctx, "k_nfa_finish", st); hipLaunchKernelGGL(k_nfa_finish, dim3(4, nframes), dim3(256), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
     // LBD: blur(5, 1) + Sobel fused -> bands
     { sslam::ProfScope _ps(L->ctx, "k_blur_sobel", st); hipLaunchKernelGGL(k_blur_sobel, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride, w, h,
@@ -1358,5 +1494,25 @@ extern "C" int sslam_lines_debug_cycles(sslam_lines* L, int frame, long long* ou
     Misc m;
     SSLAM_HIP(hipMemcpy(&m, L->dWs.as<uint8_t>() + (size_t)frame * P.frameBytes + P.offMisc, sizeof(m), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) out8[i] = m.cyc[i];
+    return SSLAM_OK;
+}
+
+// Self-test of the table-based exact division used in the NFA tail (tests/test_lines_gpu.py): returns the number of
+// random (a, b) pairs, 1 <= a, b < n, whose quotient differs from the hardware IEEE division (must be 0).
+extern "C" int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, long long* mismatches_out) {
+    if (!ctx || n < 3 || pairs <= 0 || !mismatches_out) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    double* tab = nullptr; unsigned long long* bad = nullptr;
+    SSLAM_HIP(hipMalloc(&tab, sizeof(double) * (2 * (size_t)n + 48)));
+    SSLAM_HIP(hipMalloc(&bad, sizeof(unsigned long long)));
+    SSLAM_HIP(hipMemset(bad, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_lgamma_table, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, tab, n);
+    const int threads = 256 * 1024, iters = (int)((pairs + threads - 1) / threads);
+    hipLaunchKernelGGL(k_selftest_div, dim3(1024), dim3(256), 0, ctx->stream, tab + n + 48, n, 0x1234567ull, iters, bad);
+    unsigned long long h = 0;
+    SSLAM_HIP(hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SSLAM_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(tab); (void)hipFree(bad);
+    *mismatches_out = (long long)h;
     return SSLAM_OK;
 }

@@ -70,3 +70,11 @@ def test_lines_constant(fe, ctx, oracle):
     kl, ld, fn = ex(const_frame())
     assert len(kl) == 0
     ex.close()
+
+
+def test_exact_division_selftest(fe, ctx):
+    """the NFA tail divides small integers through a reciprocal table + two FMAs; it must equal the IEEE division bit for bit"""
+    import ctypes as C
+    bad = C.c_longlong(-1)
+    rc = fe.lib().sslam_selftest_exact_div(ctx.h, 1024 * 768 + 4, C.c_longlong(2_000_000_000), C.byref(bad))
+    assert rc == 0 and bad.value == 0, bad.value
