@@ -1462,7 +1462,10 @@ extern "C" int sslam_lines_extract(sslam_lines* L, const uint8_t* gray, int w, i
     SSLAM_HIP(hipMemcpyAsync(hk, L->dKl.p, sizeof(sslam_keyline) * (size_t)icap, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipMemcpyAsync(hd, L->dDesc.p, 32 * (size_t)icap, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipMemcpyAsync(hf, L->dFn.p, 24 * (size_t)icap, hipMemcpyDeviceToHost, st));
+    Misc hm;
+    SSLAM_HIP(hipMemcpyAsync(&hm, L->dWs.as<uint8_t>() + L->plan.offMisc, sizeof(hm), hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
+    if (hm.overflow) { set_error("sslam_lines_extract: more than %d candidate rectangles in one frame", MAX_SEG); return SSLAM_ERR_UNSUPPORTED; }
     const int n = *(int*)hp;
     *n_out = n;
     if (n > cap) { set_error("sslam_lines_extract: %d lines exceed caller capacity %d", n, cap); return SSLAM_ERR_CAPACITY; }

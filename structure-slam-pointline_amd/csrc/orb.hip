@@ -560,7 +560,6 @@ __global__ __launch_bounds__(64) void k_octree(const unsigned* __restrict__ cand
 constexpr int PR = 21;               // patch radius: 18 (taps) + 3 (blur)
 constexpr int PW = 2 * PR + 1;       // 43
 constexpr int PP = 48;               // LDS pitch: 12 aligned dwords per row
-constexpr int HW = 37;               // horizontally blurred columns: x-18..x+18
 
 __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr, size_t pyrFrame, Plan P,
                                                  const unsigned* __restrict__ sel, const int* __restrict__ selCount,

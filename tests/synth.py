@@ -77,3 +77,12 @@ def noise_frame(seed=7, w=640, h=480):
 
 def const_frame(val=128, w=640, h=480):
     return np.full((h, w), val, dtype=np.uint8)
+
+
+def ramp_frame(seed=3, w=640, h=480):
+    """Two thick smooth edges: LSD regions of several thousand pixels (exercises the region-list spill past the LDS queue)."""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = 60 + 120 / (1 + np.exp(-((xx * 0.02 + yy) - 0.42 * h) / 2.5)) + 50 / (1 + np.exp(-((xx - 0.05 * yy) - 0.62 * w) / 3.0))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    img = img + rng.normal(0, 1.0, img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)

@@ -6,7 +6,7 @@ ZERO for everything except quantities that pass through libm-vs-ocml transcenden
 <= 1 ulp on floats (checked below as exact-or-1ulp) and identical segment SETS."""
 import numpy as np
 import pytest
-from synth import synth_frame, noise_frame, const_frame
+from synth import synth_frame, noise_frame, const_frame, ramp_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -78,3 +78,9 @@ def test_exact_division_selftest(fe, ctx):
     bad = C.c_longlong(-1)
     rc = fe.lib().sslam_selftest_exact_div(ctx.h, 1024 * 768 + 4, C.c_longlong(2_000_000_000), C.byref(bad))
     assert rc == 0 and bad.value == 0, bad.value
+
+
+def test_lines_huge_regions(fe, ctx, oracle):
+    """regions far larger than the 1024-point LDS queue continue in global memory"""
+    n, bad = _cmp_lines(fe, ctx, oracle, ramp_frame(), 200)
+    assert n >= 1
