@@ -395,9 +395,9 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// LineSegmentDetectorImpl::region_grow by one wave.  Seven queue entries are staged at a time (9
-// lanes each: the 3x3 neighbourhood in row-major order), so one global-load round trip serves up
-// to seven points.  Lane order == the reference's visiting order, and the region angle only
+// LineSegmentDetectorImpl::region_grow by one wave.  Eight queue entries are staged at a time (8
+// lanes each: the 3x3 neighbourhood in row-major order without its centre), so one global-load round
+// trip serves up to eight points.  Lane order == the reference's visiting order, and the region angle only
 // changes when a pixel is accepted, so ONE ballot over all staged lanes finds the next accepted
 // pixel exactly as the sequential scan would; lanes before it are consumed, lanes after it are
 // re-tested against the updated angle.
@@ -409,13 +409,14 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __res
     double regAngle = (double)ang[seed] * DEG2RAD;
     float sumdx = (float)cos(regAngle), sumdy = (float)sin(regAngle);
     if (lane == 0) { rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16)); pix[seed].x = USED_F; }
-    const int g = lane / 9, k = lane - g * 9;           // group (queue slot) and neighbour slot
+    const int g = lane >> 3, k8 = lane & 7;             // group (queue slot) and neighbour slot (centre skipped)
+    const int k = k8 + (k8 >= 4 ? 1 : 0);                // row-major 3x3 position 0..8 without 4
     const int dy = k / 3 - 1, dx = k - (k / 3) * 3 - 1;
     int i = 0;
     while (i < n) {
-        const int np = min(7, n - i);
+        const int np = min(8, n - i);
         bool cand = false; int nidx = -1, xx = 0, yy = 0; float4 px4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
-        if (g < np && k != 4) {
+        if (g < np) {
             const unsigned e = rq.get(i + g);
             xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
             if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
