@@ -60,91 +60,128 @@ struct Misc {                 // per-frame scalars
 };
 
 // ------------------------------------------------------------------ separable blur (q8 taps, D6)
-template <int R>
-__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ src, size_t spitch, size_t sframe,
-                                              uint8_t* __restrict__ dst, size_t dpitch, size_t dframe, int w, int h,
-                                              const int* __restrict__ tapsArr) {
-    constexpr int TW = 64, TH = 16;
-    constexpr int LW = TW + 2 * R, LH = TH + 2 * R, LP = 80;       // LDS row: up to 3 alignment bytes + 70 pixels, dword multiple
-    __shared__ __align__(16) uint8_t tile[LH * LP];
-    __shared__ __align__(16) unsigned short hb[LH * TW];
-    const int b = blockIdx.z, bx = blockIdx.x * TW, by = blockIdx.y * TH;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const uint8_t* s = src + (size_t)b * sframe;
-    int taps[2 * R + 1];
-#pragma unroll
-    for (int k = 0; k < 2 * R + 1; ++k) taps[k] = tapsArr[k];
-    // interior tiles: aligned dword loads (the tile then starts at byte `off` of each LDS row); border tiles: reflect-101 bytes
-    const int ax = (bx - R) & ~3;
-    const bool interior = bx - R >= 0 && by - R >= 0 && bx + TW + R <= w && by + TH + R <= h && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
-    const int off = interior ? (bx - R) - ax : 0;
-    if (interior) {
-        constexpr int NDW = (3 + LW + 3) / 4;
-        for (int i = tid; i < LH * NDW; i += 256) {
-            const int r = i / NDW, q = i - r * NDW;
-            ((unsigned*)(tile + r * LP))[q] = ((const unsigned*)(s + (size_t)(by - R + r) * spitch + ax))[q];
-        }
+// Stencil kernels here are register sliding windows: one thread owns four adjacent columns of a strip of STRIP rows, reads
+// each source row once as three aligned dwords (columns x-4 .. x+7), keeps the horizontally filtered rows it still needs
+// in registers and emits one packed store per output row.  No LDS, no barriers, and the unrolled row loop keeps many
+// loads in flight (these kernels are latency-bound, not byte-bound).
+constexpr int STRIP = 32;
+
+// source columns x4-4 .. x4+7 of row yy (BORDER_REFLECT_101 in x for the threads that touch the border)
+__device__ __forceinline__ void load_row12(const uint8_t* __restrict__ s, size_t spitch, int yy, int x4, int w, bool fast, unsigned px[12]) {
+    const uint8_t* row = s + (size_t)yy * spitch;
+    if (fast) {
+        const unsigned* q = (const unsigned*)(row + x4 - 4);
+        const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
+        px[0] = d0 & 255; px[1] = (d0 >> 8) & 255; px[2] = (d0 >> 16) & 255; px[3] = d0 >> 24;
+        px[4] = d1 & 255; px[5] = (d1 >> 8) & 255; px[6] = (d1 >> 16) & 255; px[7] = d1 >> 24;
+        px[8] = d2 & 255; px[9] = (d2 >> 8) & 255; px[10] = (d2 >> 16) & 255; px[11] = d2 >> 24;
     } else {
-        for (int i = tid; i < LW * LH; i += 256) {
-            int r = i / LW, c = i - r * LW;
-            int yy = reflect101(min(by - R + r, h + R - 1), h), xx = reflect101(min(bx - R + c, w + R - 1), w);
-            yy = min(max(yy, 0), h - 1); xx = min(max(xx, 0), w - 1);
-            tile[r * LP + c] = s[(size_t)yy * spitch + xx];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            int xx = reflect101(min(x4 - 4 + i, w + 2), w);
+            xx = min(max(xx, 0), w - 1);
+            px[i] = row[xx];
         }
     }
-    __syncthreads();
-    // horizontal pass: four outputs from 4 + 2R bytes
-    for (int i = tid; i < LH * (TW / 4); i += 256) {
-        const int r = i / (TW / 4), c4 = (i - r * (TW / 4)) * 4;
-        const uint8_t* p = tile + r * LP + off + c4;
-        unsigned v[4 + 2 * R];
+}
+__device__ __forceinline__ int reflect_row(int y, int h, int R) {
+    const int yy = reflect101(min(y, h + R - 1), h);
+    return min(max(yy, 0), h - 1);
+}
+
+// 7x7 Gaussian (LSD's sigma = 0.6/0.8 pre-blur), 16.16 accumulation as in D6
+__global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, size_t spitch, size_t sframe,
+                                               uint8_t* __restrict__ dst, size_t dpitch, size_t dframe, int w, int h,
+                                               const int* __restrict__ tapsArr) {
+    constexpr int R = 3;
+    const int ngroups = (w + 3) >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int strip = t / ngroups, x4 = (t - strip * ngroups) * 4, y0 = strip * STRIP;
+    if (y0 >= h) return;
+    const int b = blockIdx.y;
+    const uint8_t* s = src + (size_t)b * sframe;
+    uint8_t* d = dst + (size_t)b * dframe;
+    unsigned taps[7];
 #pragma unroll
-        for (int k = 0; k < 4 + 2 * R; ++k) v[k] = p[k];
-        unsigned o[4];
+    for (int k = 0; k < 7; ++k) taps[k] = (unsigned)tapsArr[k];
+    const bool fast = x4 >= 4 && x4 + 8 <= w && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
+    unsigned win[7][4];
+#pragma unroll
+    for (int r = 0; r < STRIP + 2 * R; ++r) {
+        if (r >= 2 * R && y0 + r - 2 * R >= h) break;
+        unsigned px[12];
+        load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, px);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned acc = 0;
 #pragma unroll
-            for (int k = 0; k < 2 * R + 1; ++k) acc += v[j + k] * (unsigned)taps[k];
-            o[j] = acc;
+            for (int k = 0; k < 7; ++k) acc += px[j + 1 + k] * taps[k];
+            win[r % 7][j] = acc;
         }
-        uint2 w2; w2.x = o[0] | (o[1] << 16); w2.y = o[2] | (o[3] << 16);
-        *(uint2*)(hb + r * TW + c4) = w2;
-    }
-    __syncthreads();
-    // vertical pass: one thread = four horizontally adjacent outputs, one aligned 4-byte store
-    {
-        const int r = tid >> 4, c4 = (tid & 15) * 4;
-        const int x = bx + c4, y = by + r;
-        unsigned acc[4] = {0, 0, 0, 0};
+        if (r >= 2 * R) {
+            const int y = y0 + r - 2 * R;
+            unsigned o[4];
 #pragma unroll
-        for (int k = 0; k < 2 * R + 1; ++k) {
-            const uint2 q = *(const uint2*)(hb + (r + k) * TW + c4);
-            acc[0] += (q.x & 0xFFFF) * (unsigned)taps[k]; acc[1] += (q.x >> 16) * (unsigned)taps[k];
-            acc[2] += (q.y & 0xFFFF) * (unsigned)taps[k]; acc[3] += (q.y >> 16) * (unsigned)taps[k];
-        }
-        if (y < h && x < w) {
-            uint8_t* d = dst + (size_t)b * dframe + (size_t)y * dpitch + x;
-            const unsigned o0 = (acc[0] + 32768u) >> 16, o1 = (acc[1] + 32768u) >> 16, o2 = (acc[2] + 32768u) >> 16, o3 = (acc[3] + 32768u) >> 16;
-            if (x + 3 < w) *(unsigned*)d = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);      // dpitch % 64 == 0, x % 4 == 0
-            else { d[0] = (uint8_t)o0; if (x + 1 < w) d[1] = (uint8_t)o1; if (x + 2 < w) d[2] = (uint8_t)o2; }
+            for (int j = 0; j < 4; ++j) {
+                unsigned acc = 0;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) acc += win[(r - 2 * R + k) % 7][j] * taps[k];
+                o[j] = (acc + 32768u) >> 16;
+            }
+            uint8_t* dp = d + (size_t)y * dpitch + x4;
+            if (x4 + 3 < w) *(unsigned*)dp = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);      // dpitch % 64 == 0, x4 % 4 == 0
+            else { dp[0] = (uint8_t)o[0]; if (x4 + 1 < w) dp[1] = (uint8_t)o[1]; if (x4 + 2 < w) dp[2] = (uint8_t)o[2]; }
         }
     }
 }
 
 // ------------------------------------------------------------------ INTER_LINEAR_EXACT 0.8x (D7)
-__global__ void k_resize_exact(const uint8_t* __restrict__ src, size_t spitch, size_t sframe, int w, int h,
-                               uint8_t* __restrict__ dst, size_t dpitch, size_t dframe, int dw, int dh,
-                               const int* __restrict__ tx, const int* __restrict__ ty) {
-    const int b = blockIdx.z, x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= dw || y >= dh) return;
-    const int sx = tx[x * 2], cx = tx[x * 2 + 1], sy = ty[y * 2], cy = ty[y * 2 + 1];
-    const int sx1 = min(sx + 1, w - 1), sy1 = min(sy + 1, h - 1);
+// tx/ty entries: {source offset, coefficient of the second tap (q8)}.  One thread = four adjacent outputs, source rows read
+// as three aligned dwords.
+__device__ __forceinline__ unsigned pick2(unsigned d0, unsigned d1, unsigned d2, int o) {      // bytes o, o+1 of d0:d1:d2 (o <= 10)
+    const unsigned long long w01 = (unsigned long long)d0 | ((unsigned long long)d1 << 32);
+    const unsigned long long w12 = (unsigned long long)d1 | ((unsigned long long)d2 << 32);
+    return (unsigned)((o < 4 ? w01 : w12) >> (8 * (o < 4 ? o : o - 4)));
+}
+__global__ __launch_bounds__(256) void k_resize_exact(const uint8_t* __restrict__ src, size_t spitch, size_t sframe, int w, int h,
+                                                      uint8_t* __restrict__ dst, size_t dpitch, size_t dframe, int dw, int dh,
+                                                      const int* __restrict__ tx, const int* __restrict__ ty) {
+    const int b = blockIdx.z, x4 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (x4 >= dw || y >= dh) return;
+    const int2 tyv = ((const int2*)ty)[y];
+    int2 txv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) txv[j] = ((const int2*)tx)[min(x4 + j, dw - 1)];
+    const int sy = tyv.x, cy = tyv.y, sy1 = min(sy + 1, h - 1);
     const uint8_t* s0 = src + (size_t)b * sframe + (size_t)sy * spitch;
     const uint8_t* s1 = src + (size_t)b * sframe + (size_t)sy1 * spitch;
-    unsigned r0 = s0[sx] * (256 - cx) + s0[sx1] * cx, r1 = s1[sx] * (256 - cx) + s1[sx1] * cx;
-    unsigned v = r0 * (256 - cy) + r1 * cy;
-    dst[(size_t)b * dframe + (size_t)y * dpitch + x] = (uint8_t)((v + 32768u) >> 16);
+    unsigned p00[4], p01[4], p10[4], p11[4];
+    const int a = txv[0].x & ~3;
+    if (txv[3].x - a <= 10) {                       // spitch % 64 == 0 and another buffer follows the last row: whole dwords are readable
+        const unsigned* q0 = (const unsigned*)(s0 + a);
+        const unsigned* q1 = (const unsigned*)(s1 + a);
+        const unsigned u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned e0 = pick2(u0, u1, u2, txv[j].x - a), e1 = pick2(v0, v1, v2, txv[j].x - a);
+            p00[j] = e0 & 255; p01[j] = (e0 >> 8) & 255; p10[j] = e1 & 255; p11[j] = (e1 >> 8) & 255;   // second tap has weight 0 at the last column
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sx = txv[j].x, sx1 = min(sx + 1, w - 1);
+            p00[j] = s0[sx]; p01[j] = s0[sx1]; p10[j] = s1[sx]; p11[j] = s1[sx1];
+        }
+    }
+    unsigned out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned cx = (unsigned)txv[j].y;
+        const unsigned r0 = p00[j] * (256 - cx) + p01[j] * cx, r1 = p10[j] * (256 - cx) + p11[j] * cx;
+        const unsigned v = r0 * (256 - (unsigned)cy) + r1 * (unsigned)cy;
+        out |= ((v + 32768u) >> 16) << (8 * j);
+    }
+    *(unsigned*)(dst + (size_t)b * dframe + (size_t)y * dpitch + x4) = out;      // dpitch % 64 == 0: pad columns are scratch
 }
 
 // ------------------------------------------------------------------ gradient / level-line angle (ll_angle)
@@ -165,32 +202,56 @@ __global__ void k_grad_table(float4* __restrict__ tab, double rho) {
     tab[i] = make_float4(a, cs, sn, __int_as_float(s));
 }
 
+// One thread = four horizontally adjacent pixels: the 2x5 source bytes come from two dword + two byte loads, the four
+// table gathers are in flight together, and angle / key / record leave as 16-byte stores when the row length allows.
+// S[i] = |g|^2 for DEFINED pixels and -1 otherwise, so the counting sort reads one array.
 __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws, LsdPlan P, const float4* __restrict__ gtab) {
-    const int b = blockIdx.y;
+    const int b = blockIdx.z;
     const uint8_t* base = ws + (size_t)b * P.frameBytes;
     const uint8_t* img = base + P.offScaled;
     float* ang = (float*)(base + P.offAng);
     int* S = (int*)(base + P.offS);
     float4* pix = (float4*)(base + P.offPix);
     Misc* misc = (Misc*)(base + P.offMisc);
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y, x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     int smax = 0;
-    if (i < P.npx) {
-        const int y = i / P.sw, x = i - y * P.sw;
-        float4 rec = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
-        if (x < P.sw - 1 && y < P.sh - 1) {
-            const uint8_t* r0 = img + (size_t)y * P.spitch + x;
-            const uint8_t* r1 = r0 + P.spitch;
-            const int DA = (int)r1[1] - (int)r0[0], BC = (int)r0[1] - (int)r1[0];
+    if (y < P.sh && x4 < P.sw) {
+        const uint8_t* r0 = img + (size_t)y * P.spitch + x4;               // spitch % 64 == 0: aligned dwords, pad bytes readable
+        const bool lastRow = y >= P.sh - 1;
+        const uint8_t* r1 = lastRow ? r0 : r0 + P.spitch;
+        const unsigned d0 = *(const unsigned*)r0, d1 = *(const unsigned*)r1;
+        const bool more = x4 + 4 < P.sw;
+        const unsigned e0 = more ? r0[4] : 0u, e1 = more ? r1[4] : 0u;
+        int p0[5] = {(int)(d0 & 255), (int)((d0 >> 8) & 255), (int)((d0 >> 16) & 255), (int)(d0 >> 24), (int)e0};
+        int p1[5] = {(int)(d1 & 255), (int)((d1 >> 8) & 255), (int)((d1 >> 16) & 255), (int)(d1 >> 24), (int)e1};
+        float4 rec[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int DA = p1[j + 1] - p0[j], BC = p0[j + 1] - p1[j];
             const int gx = DA + BC, gy = DA - BC;
-            rec = gtab[(gy + 510) * GT + (gx + 510)];
-            if (rec.x != NOTDEF_F) smax = __float_as_int(rec.w);
+            const bool in = !lastRow && x4 + j < P.sw - 1;
+            rec[j] = in ? gtab[(gy + 510) * GT + (gx + 510)] : make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
         }
-        ang[i] = rec.x; S[i] = __float_as_int(rec.w);
-        pix[i] = rec;          // per-pixel record for region growing: angle, cosf/sinf (D5), |g|^2
+        int sv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool def = rec[j].x != NOTDEF_F;
+            sv[j] = def ? __float_as_int(rec[j].w) : -1;
+            smax = max(smax, sv[j]);
+        }
+        const size_t i = (size_t)y * P.sw + x4;
+        if ((P.sw & 3) == 0) {
+            *(float4*)(ang + i) = make_float4(rec[0].x, rec[1].x, rec[2].x, rec[3].x);
+            *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) { ang[i + j] = rec[j].x; S[i + j] = sv[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) pix[i + j] = rec[j];      // per-pixel record for region growing: angle, cosf/sinf (D5), |g|^2
     }
     smax = wave_max(smax);
-    if ((threadIdx.x & 63) == 0 && smax > 0) atomicMax(&misc->maxS, smax);
+    if (threadIdx.x == 0 && smax > 0) atomicMax(&misc->maxS, smax);
 }
 
 __device__ __forceinline__ int lsd_bin(int s, double binCoef) {
@@ -207,7 +268,6 @@ __global__ __launch_bounds__(64) void k_lsd_hist(uint8_t* __restrict__ ws, LsdPl
     __shared__ int hist[N_BINS];
     const int tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
-    const float* ang = (const float*)(base + P.offAng);
     const int* S = (const int*)(base + P.offS);
     const Misc* misc = (const Misc*)(base + P.offMisc);
     int* th = (int*)(base + P.offTileHist) + (size_t)tile * N_BINS;
@@ -215,8 +275,13 @@ __global__ __launch_bounds__(64) void k_lsd_hist(uint8_t* __restrict__ ws, LsdPl
     __syncthreads();
     const double bc = lsd_bin_coef(misc->maxS);
     const int beg = tile * TILE_PX, end = min(beg + TILE_PX, P.npx);
-    for (int i = beg + lane; i < end; i += 64)
-        if (ang[i] != NOTDEF_F) atomicAdd(&hist[lsd_bin(S[i], bc)], 1);
+    for (int i0 = beg; i0 < end; i0 += 512) {            // eight coalesced loads in flight per lane (order is irrelevant here)
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = i0 + k * 64 + lane; v[k] = i < end ? S[i] : -1; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (v[k] >= 0) atomicAdd(&hist[lsd_bin(v[k], bc)], 1);
+    }
     __syncthreads();
     for (int i = lane; i < N_BINS; i += 64) th[i] = hist[i];
 }
@@ -247,11 +312,13 @@ __global__ __launch_bounds__(1024) void k_lsd_scan(uint8_t* __restrict__ ws, Lsd
     if (t == 1023) misc->nDefined = part[1023];
 }
 
+// One wave per tile walks its pixels in raster order, 64 at a time (four such groups are loaded ahead).  Inside a group
+// the rank of a pixel among the lanes of the same bin comes from ballots; the wave's LDS accesses execute in program order,
+// so the cursor read / write-back needs no barrier.
 __global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, LsdPlan P) {
     __shared__ int cursor[N_BINS];
     const int tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
-    const float* ang = (const float*)(base + P.offAng);
     const int* S = (const int*)(base + P.offS);
     const Misc* misc = (const Misc*)(base + P.offMisc);
     const int* th = (const int*)(base + P.offTileHist) + (size_t)tile * N_BINS;
@@ -260,20 +327,28 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, Ls
     __syncthreads();
     const double bc = lsd_bin_coef(misc->maxS);
     const int beg = tile * TILE_PX, end = min(beg + TILE_PX, P.npx);
-    for (int i0 = beg; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        const bool def = i < end && ang[i] != NOTDEF_F;
-        const int bin = def ? lsd_bin(S[i], bc) : -1;
-        unsigned long long todo = __ballot(def);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int bsel = __shfl(bin, leader, 64);
-            const unsigned long long m = __ballot(def && bin == bsel);
-            if (def && bin == bsel) order[cursor[bsel] + mbcnt(m)] = (unsigned)i;
-            __syncthreads();
-            if (lane == leader) cursor[bsel] += __popcll(m);
-            __syncthreads();
-            todo &= ~m;
+    for (int i0 = beg; i0 < end; i0 += 256) {
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = i0 + k * 64 + lane; v[k] = i < end ? S[i] : -1; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool def = v[k] >= 0;
+            const int bin = def ? lsd_bin(v[k], bc) : -1;
+            unsigned long long todo = __ballot(def);
+            int rank = 0, total = 0;
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int bsel = __builtin_amdgcn_readlane(bin, leader);
+                const unsigned long long m = __ballot(bin == bsel);
+                if (bin == bsel) { rank = mbcnt(m); total = __popcll(m); }
+                todo &= ~m;
+            }
+            if (def) {
+                const int pos = cursor[bin] + rank;
+                order[pos] = (unsigned)(i0 + k * 64 + lane);
+                if (rank == total - 1) cursor[bin] = pos + 1;
+            }
         }
     }
 }
@@ -1033,71 +1108,63 @@ __global__ __launch_bounds__(256) void k_keylines(uint8_t* __restrict__ ws, LsdP
 __global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ src, size_t spitch, size_t sframe, int w, int h,
                                                     short* __restrict__ dxo, short* __restrict__ dyo, size_t dframeBytes,
                                                     const int* __restrict__ tapsArr) {
-    constexpr int TW = 64, TH = 16, R = 3;                 // blur radius 2 + Sobel radius 1
-    constexpr int LW = TW + 2 * R, LH = TH + 2 * R, LP = 80, BW = TW + 2, BH = TH + 2, HP = 68;
-    __shared__ __align__(16) uint8_t tile[LH * LP];
-    __shared__ __align__(16) unsigned short hb[LH * HP];
-    __shared__ __align__(16) uint8_t bl[BH * HP];
-    const int b = blockIdx.z, bx = blockIdx.x * TW, by = blockIdx.y * TH;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
+    // register sliding window (see k_blur7): 5x5 blur rows -> 3-row Sobel window.  Blurring the reflect-extended source with
+    // symmetric taps equals reflect-extending the blurred image, which is what Sobel's BORDER_REFLECT_101 reads.
+    constexpr int R = 3;                                   // blur radius 2 + Sobel radius 1
+    const int ngroups = (w + 3) >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int strip = t / ngroups, x4 = (t - strip * ngroups) * 4, y0 = strip * STRIP;
+    if (y0 >= h) return;
+    const int b = blockIdx.y;
     const uint8_t* s = src + (size_t)b * sframe;
-    int taps[5];
+    unsigned taps[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) taps[k] = tapsArr[k];
-    const int ax = (bx - R) & ~3;
-    const bool interior = bx - R >= 0 && by - R >= 0 && bx + TW + R <= w && by + TH + R <= h && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
-    const int off = interior ? (bx - R) - ax : 0;
-    if (interior) {
-        constexpr int NDW = (3 + LW + 3) / 4;
-        for (int i = tid; i < LH * NDW; i += 256) {
-            const int r = i / NDW, q = i - r * NDW;
-            ((unsigned*)(tile + r * LP))[q] = ((const unsigned*)(s + (size_t)(by - R + r) * spitch + ax))[q];
+    for (int k = 0; k < 5; ++k) taps[k] = (unsigned)tapsArr[k];
+    const bool fast = x4 >= 4 && x4 + 8 <= w && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
+    const bool vec = ((w & 3) == 0) && ((dframeBytes & 7) == 0);
+    unsigned hb[5][6];                                     // horizontally blurred rows, columns x4-1 .. x4+4
+    int bl[3][6];                                          // blurred rows
+#pragma unroll
+    for (int r = 0; r < STRIP + 2 * R; ++r) {
+        if (r >= 2 * R && y0 + r - 2 * R >= h) break;
+        unsigned px[12];
+        load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, px);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            unsigned acc = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc += px[c + 1 + k] * taps[k];
+            hb[r % 5][c] = acc & 0xFFFFu;                   // the staged sums are 16-bit (taps sum to 256)
         }
-    } else {
-        for (int i = tid; i < LW * LH; i += 256) {
-            int r = i / LW, c = i - r * LW;
-            int yy = reflect101(min(by - R + r, h + R - 1), h), xx = reflect101(min(bx - R + c, w + R - 1), w);
-            yy = min(max(yy, 0), h - 1); xx = min(max(xx, 0), w - 1);
-            tile[r * LP + c] = s[(size_t)yy * spitch + xx];
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < LH * BW; i += 256) {            // horizontal 5 taps at x = bx-1+c
-        const int r = i / BW, c = i - r * BW;
-        const uint8_t* p = tile + r * LP + off + c;
-        unsigned acc = 0;
+        if (r >= 4) {
+            const int q = r - 4;                           // blurred row y0 - 1 + q
 #pragma unroll
-        for (int k = 0; k < 5; ++k) acc += (unsigned)p[k] * (unsigned)taps[k];
-        hb[r * HP + c] = (unsigned short)acc;
-    }
-    __syncthreads();
-    for (int i = tid; i < BH * BW; i += 256) {            // vertical 5 taps at y = by-1+r
-        const int r = i / BW, c = i - r * BW;
-        unsigned acc = 0;
+            for (int c = 0; c < 6; ++c) {
+                unsigned acc = 0;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) acc += (unsigned)hb[(r + k) * HP + c] * (unsigned)taps[k];
-        bl[r * HP + c] = (uint8_t)((acc + 32768u) >> 16);
-    }
-    __syncthreads();
-    {
-        const int r = tid >> 4, c4 = (tid & 15) * 4;
-        const int x = bx + c4, y = by + r;
-        if (y < h && x < w) {
-            short gx[4], gy[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint8_t* q = bl + r * HP + c4 + j;          // q[0] = blurred(y-1, x+j-1)
-                const int a0 = q[0], a1 = q[1], a2 = q[2], m0 = q[HP], m2 = q[HP + 2], c0 = q[2 * HP], c1 = q[2 * HP + 1], c2 = q[2 * HP + 2];
-                gx[j] = (short)((a2 - a0) + 2 * (m2 - m0) + (c2 - c0));
-                gy[j] = (short)((c0 - a0) + 2 * (c1 - a1) + (c2 - a2));
+                for (int k = 0; k < 5; ++k) acc += hb[(q + k) % 5][c] * taps[k];
+                bl[q % 3][c] = (int)(((acc + 32768u) >> 16) & 255u);
             }
-            short* dxp = (short*)((uint8_t*)dxo + (size_t)b * dframeBytes) + (size_t)y * w + x;
-            short* dyp = (short*)((uint8_t*)dyo + (size_t)b * dframeBytes) + (size_t)y * w + x;
-            if (x + 3 < w && ((w & 3) == 0) && ((dframeBytes & 7) == 0)) {
-                *(short4*)dxp = make_short4(gx[0], gx[1], gx[2], gx[3]);
-                *(short4*)dyp = make_short4(gy[0], gy[1], gy[2], gy[3]);
-            } else {
-                for (int j = 0; j < 4 && x + j < w; ++j) { dxp[j] = gx[j]; dyp[j] = gy[j]; }
+            if (q >= 2) {
+                const int y = y0 + q - 2;
+                const int* A = bl[(q - 2) % 3];
+                const int* M = bl[(q - 1) % 3];
+                const int* C = bl[q % 3];
+                short gx[4], gy[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    gx[j] = (short)((A[j + 2] - A[j]) + 2 * (M[j + 2] - M[j]) + (C[j + 2] - C[j]));
+                    gy[j] = (short)((C[j] - A[j]) + 2 * (C[j + 1] - A[j + 1]) + (C[j + 2] - A[j + 2]));
+                }
+                short* dxp = (short*)((uint8_t*)dxo + (size_t)b * dframeBytes) + (size_t)y * w + x4;
+                short* dyp = (short*)((uint8_t*)dyo + (size_t)b * dframeBytes) + (size_t)y * w + x4;
+                if (x4 + 3 < w && vec) {
+                    *(short4*)dxp = make_short4(gx[0], gx[1], gx[2], gx[3]);
+                    *(short4*)dyp = make_short4(gy[0], gy[1], gy[2], gy[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (x4 + j < w) { dxp[j] = gx[j]; dyp[j] = gy[j]; }
+                }
             }
         }
     }
@@ -1405,11 +1472,11 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     const int* taps = L->dTaps.as<int>();
     { sslam::ProfScope _ps(L->ctx, "k_zero_misc", st); hipLaunchKernelGGL(k_zero_misc, dim3(nframes), dim3(64), 0, st, ws, P); }
     // LSD: blur(7, 0.75) -> 0.8x -> gradient
-    { sslam::ProfScope _ps(L->ctx, "k_blur<3>", st); hipLaunchKernelGGL(k_blur<3>, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride,
+    { sslam::ProfScope _ps(L->ctx, "k_blur7", st); hipLaunchKernelGGL(k_blur7, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride,
                        ws + P.offBlur, bpitch, P.frameBytes, w, h, taps); }
-    { sslam::ProfScope _ps(L->ctx, "k_resize_exact", st); hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 63) / 64, (P.sh + 3) / 4, nframes), dim3(64, 4), 0, st, ws + P.offBlur, bpitch, P.frameBytes, w, h,
+    { sslam::ProfScope _ps(L->ctx, "k_resize_exact", st); hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, nframes), dim3(64, 4), 0, st, ws + P.offBlur, bpitch, P.frameBytes, w, h,
                        ws + P.offScaled, (size_t)P.spitch, P.frameBytes, P.sw, P.sh, L->dTabs.as<int>() + P.tabX, L->dTabs.as<int>() + P.tabY); }
-    { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st); hipLaunchKernelGGL(k_lsd_grad, dim3((P.npx + 255) / 256, nframes), dim3(256), 0, st, ws, P, L->dGtab.as<float4>()); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st); hipLaunchKernelGGL(k_lsd_grad, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, nframes), dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>()); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_hist", st); hipLaunchKernelGGL(k_lsd_hist, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scan", st); hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }
@@ -1427,7 +1494,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     { sslam::ProfScope _ps(L->ctx, "k_nfa_finish", st); hipLaunchKernelGGL(k_nfa_finish, dim3(4, nframes), dim3(256), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
     // LBD: blur(5, 1) + Sobel fused -> bands
-    { sslam::ProfScope _ps(L->ctx, "k_blur_sobel", st); hipLaunchKernelGGL(k_blur_sobel, dim3((w + 63) / 64, (h + 15) / 16, nframes), dim3(64, 4), 0, st, d_images, pitch, image_stride, w, h,
+    { sslam::ProfScope _ps(L->ctx, "k_blur_sobel", st); hipLaunchKernelGGL(k_blur_sobel, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride, w, h,
                        (short*)(ws + P.offDx), (short*)(ws + P.offDy), P.frameBytes, taps + 8); }
     { sslam::ProfScope _ps(L->ctx, "k_lbd", st); hipLaunchKernelGGL(k_lbd, dim3(std::min(L->maxLines, cap), nframes), dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap); }
     SSLAM_HIP(hipGetLastError());

@@ -40,7 +40,7 @@ struct LevelInfo {
     int W, H;                     // maxBorder-minBorder extents
     float scale;                  // mvScaleFactor
     float size;                   // float(int(31*scale))
-    int tabX, tabY;               // int16 offsets into the resize tables (3 per entry)
+    int tabX, tabY;               // entry (int16x4) offsets into the resize tables
 };
 
 struct Plan {
@@ -82,62 +82,59 @@ __global__ void k_copy_level0(const uint8_t* __restrict__ in, size_t pitch, size
 
 // ------------------------------------------------------------------ bilinear /1.2
 // cv::resize(INTER_LINEAR) for CV_8UC1: 11-bit fixed-point taps.
-// tabX/tabY entries: {src offset, coef0, coef1} as int16.
+// tabX/tabY entries: {src offset, coef0, coef1, 0} as int16x4 (tabX padded to a multiple of 4 entries).
+// One thread = 4 horizontally adjacent output pixels: two 16-byte table loads, then the two source rows as three aligned
+// dwords each (sub-dword global loads cost the texture path four times a dword load), bytes picked with 64-bit shifts,
+// one dword store.  A group whose taps span more than the 12 loaded bytes (scale factors above ~2) takes byte loads.
+__device__ __forceinline__ unsigned pick2(unsigned d0, unsigned d1, unsigned d2, int o) {      // bytes o, o+1 of d0:d1:d2 (o <= 10)
+    const unsigned long long w01 = (unsigned long long)d0 | ((unsigned long long)d1 << 32);
+    const unsigned long long w12 = (unsigned long long)d1 | ((unsigned long long)d2 << 32);
+    return (unsigned)((o < 4 ? w01 : w12) >> (8 * (o < 4 ? o : o - 4)));
+}
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_t pyrFrame, LevelInfo S, LevelInfo D,
-                                                const short* __restrict__ tabs) {
-    // block = 256 x 4 output pixels; the (at most 8) source rows it touches are staged in LDS with aligned dword loads
-    constexpr int SROWS = 8, SP = 336;                 // 256 * 1.2 + slack, dword multiple
-    __shared__ __align__(16) uint8_t src[SROWS * SP];
+                                                const short4* __restrict__ tabs) {
     const int b = blockIdx.z;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int y0 = blockIdx.y * 4, xb = blockIdx.x * 256;
-    const short* tx = tabs + D.tabX;
-    const short* tyb = tabs + D.tabY;
-    const int ylast = min(y0 + 3, D.h - 1);
-    const int rb = min(max((int)tyb[y0 * 3], 0), S.h - 1);
-    const int re = min(max((int)tyb[ylast * 3] + 1, 0), S.h - 1);
-    const int xl = min(xb + 255, D.w - 1);
-    const int sxa = (int)tx[xb * 3] & ~3;
-    const int sxe = min((int)tx[xl * 3] + 1, S.w - 1);
-    const int ndw = ((sxe - sxa) >> 2) + 1, nrows = re - rb + 1;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (y >= D.h || x4 >= D.w) return;
+    const short4 ty = tabs[D.tabY + y];
+    const uint4 ta = *(const uint4*)(tabs + D.tabX + x4), tb = *(const uint4*)(tabs + D.tabX + x4 + 2);
+    const int sy0 = min(max((int)ty.x, 0), S.h - 1), sy1 = min(max((int)ty.x + 1, 0), S.h - 1);
     const uint8_t* sbase = pyr + (size_t)b * pyrFrame + S.off;
-    const bool staged = nrows <= SROWS && ndw * 4 <= SP;
-    if (staged) {
-        for (int i = tid; i < nrows * ndw; i += 256) {
-            const int r = i / ndw, q = i - r * ndw;
-            ((unsigned*)(src + r * SP))[q] = ((const unsigned*)(sbase + (size_t)(rb + r) * S.pitch + sxa))[q];   // pitch % 64 == 0: in-row, pad bytes unused
+    const uint8_t* g0 = sbase + (size_t)sy0 * S.pitch;
+    const uint8_t* g1 = sbase + (size_t)sy1 * S.pitch;
+    const unsigned tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+    int sx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sx[i] = (short)(tw[2 * i] & 0xFFFF);
+    const int a = sx[0] & ~3;
+    int p00[4], p01[4], p10[4], p11[4];
+    if (sx[3] - a <= 10) {                          // pitch % 64 == 0 and the frame block has 16 spare bytes: the dwords are readable
+        const unsigned* q0 = (const unsigned*)(g0 + a);
+        const unsigned* q1 = (const unsigned*)(g1 + a);
+        const unsigned u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned e0 = pick2(u0, u1, u2, sx[i] - a), e1 = pick2(v0, v1, v2, sx[i] - a);
+            p00[i] = e0 & 255; p01[i] = (e0 >> 8) & 255; p10[i] = e1 & 255; p11[i] = (e1 >> 8) & 255;   // right tap has weight 0 at the last column
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sx1 = min(sx[i] + 1, S.w - 1);
+            p00[i] = g0[sx[i]]; p01[i] = g0[sx1]; p10[i] = g1[sx[i]]; p11[i] = g1[sx1];
         }
     }
-    __syncthreads();
-    const int y = y0 + threadIdx.y;
-    const int x4 = xb + threadIdx.x * 4;
-    if (y >= D.h || x4 >= D.w) return;
-    const short* ty = tyb + y * 3;
-    const int sy = ty[0], b0 = ty[1], b1 = ty[2];
-    const int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
+    const int b0 = ty.y, b1 = ty.z;
     unsigned out = 0;
-#define RESIZE_BODY(S0, S1, XOFF)                                                             \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-        int x = x4 + i;                                                                       \
-        if (x < D.w) {                                                                        \
-            int sx = tx[x * 3], a0 = tx[x * 3 + 1], a1 = tx[x * 3 + 2];                       \
-            int sx1 = min(sx + 1, S.w - 1);                                                   \
-            int r0 = S0[sx - XOFF] * a0 + S0[sx1 - XOFF] * a1;                                \
-            int r1 = S1[sx - XOFF] * a0 + S1[sx1 - XOFF] * a1;                                \
-            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;           \
-            out |= (unsigned)(v & 255) << (8 * i);                                            \
-        }                                                                                     \
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int a0 = (short)(tw[2 * i] >> 16), a1 = (short)(tw[2 * i + 1] & 0xFFFF);
+        const int r0 = p00[i] * a0 + p01[i] * a1;
+        const int r1 = p10[i] * a0 + p11[i] * a1;
+        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        out |= (unsigned)(v & 255) << (8 * i);
     }
-    if (staged) {
-        const uint8_t* l0 = src + (sy0 - rb) * SP;
-        const uint8_t* l1 = src + (sy1 - rb) * SP;
-        RESIZE_BODY(l0, l1, sxa)
-    } else {
-        const uint8_t* g0 = sbase + (size_t)sy0 * S.pitch;
-        const uint8_t* g1 = sbase + (size_t)sy1 * S.pitch;
-        RESIZE_BODY(g0, g1, 0)
-    }
-#undef RESIZE_BODY
     *(unsigned*)(pyr + (size_t)b * pyrFrame + D.off + (size_t)y * D.pitch + x4) = out;   // pitch%64==0, pad columns are scratch
 }
 
@@ -786,9 +783,10 @@ static int build_plan(sslam_orb* o, int w, int h) {
             const LevelInfo& S = P.L[l - 1];
             const double inv_sx = (double)L.w / S.w, inv_sy = (double)L.h / S.h;
             const double sx_ = 1. / inv_sx, sy_ = 1. / inv_sy;
-            L.tabX = (int)o->tabs.size();
-            for (int dx = 0; dx < L.w; ++dx) {
-                float fx = (float)((dx + 0.5) * sx_ - 0.5);
+            L.tabX = (int)o->tabs.size() / 4;
+            for (int dx = 0; dx < ((L.w + 3) & ~3); ++dx) {      // padded entries repeat the last column (never stored past pitch)
+                const int dxe = std::min(dx, L.w - 1);
+                float fx = (float)((dxe + 0.5) * sx_ - 0.5);
                 int sx = (int)std::floor(fx);
                 fx -= sx;
                 if (sx < 0) { fx = 0; sx = 0; }
@@ -796,8 +794,9 @@ static int build_plan(sslam_orb* o, int w, int h) {
                 o->tabs.push_back((short)sx);
                 o->tabs.push_back((short)cvRoundF((1.f - fx) * 2048));
                 o->tabs.push_back((short)cvRoundF(fx * 2048));
+                o->tabs.push_back(0);
             }
-            L.tabY = (int)o->tabs.size();
+            L.tabY = (int)o->tabs.size() / 4;
             for (int dy = 0; dy < L.h; ++dy) {
                 float fy = (float)((dy + 0.5) * sy_ - 0.5);
                 int sy = (int)std::floor(fy);
@@ -805,10 +804,12 @@ static int build_plan(sslam_orb* o, int w, int h) {
                 o->tabs.push_back((short)sy);
                 o->tabs.push_back((short)cvRoundF((1.f - fy) * 2048));
                 o->tabs.push_back((short)cvRoundF(fy * 2048));
+                o->tabs.push_back(0);
             }
+            while ((o->tabs.size() / 4) % 4) o->tabs.insert(o->tabs.end(), 4, (short)0);      // keep every tabX 32-byte aligned
         }
     }
-    P.pyrFrame = (off + 255) & ~(size_t)255;
+    P.pyrFrame = (off + 16 + 255) & ~(size_t)255;      // 16 spare bytes: k_resize reads whole dwords past a row's last pixel
     P.nCellsFrame = (int)o->cells.size();
     P.candFrame = std::max(candOff, 1);
     P.selFrame = selOff;
@@ -924,7 +925,7 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
     }
     for (int l = 1; l < P.nlevels; ++l) {
         dim3 blk(64, 4), grd((P.L[l].w + 255) / 256, (P.L[l].h + 3) / 4, nframes);
-        { sslam::ProfScope _ps(o->ctx, "k_resize", st); hipLaunchKernelGGL(k_resize, grd, blk, 0, st, pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short>()); }
+        { sslam::ProfScope _ps(o->ctx, "k_resize", st); hipLaunchKernelGGL(k_resize, grd, blk, 0, st, pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short4>()); }
     }
     if (P.nCellsFrame > 0) {
         int tileP = (P.maxCellW + 6 + 3 + 7) & ~3, scP = P.maxCellW + 2;
