@@ -413,46 +413,90 @@ __global__ void k_selftest_div(const double* __restrict__ rcp, int n, unsigned l
 }
 // plog[h] = {log(p), log(1-p), log10(p)} for p = 0.125 * 2^-h: every precision rect_improve can reach
 struct PLog { double lp, l1mp, l10p; };
-__device__ double nfa_d(int n, int k, double p, double logNT, const double* __restrict__ lgam, const PLog* plog, const double* __restrict__ rcp) {
-    if (n == 0 || k == 0) return -logNT;
+
+// nfa()'s early-exit test `err < tolerance * |-log10(bin_tail) - logNT| * bin_tail` with
+// err = term * ((1 - m^q) / (1 - m) - 1), decided from fp32 log2/exp2 estimates inside rigorous guard bands:
+// returns 1 (test holds) / 0 (test fails) when the estimate cannot disagree with the fp64 expression, -1 when it might.
+// Here 0 < m < 1/7 (bin_term < 1 and p <= 1/8), so B = m + m^2 + .. + m^(q-1) lies in [m, 1.17 m] for q >= 2 and is exactly 0
+// for q == 1 (fl((1-m)/(1-m)) - 1).  v_log_f32 / v_exp_f32 are 1-ulp: the estimate of m^q is within 1e-5 relative for
+// |q log2 m| <= 60 (and m^q < 1e-18 otherwise), the fp64 evaluation of B is within 6e-16 absolute, log10(bin_tail) from the
+// split exponent + fp32 mantissa log is within 1e-7 absolute; the bands below are several times wider than that.
+__device__ __forceinline__ int tail_test_cheap(double term, double m, int q, double bin_tail, double logNT) {
+    if (!(m > 0.0 && m < 0.15)) return -1;
+    double B = 0.0;
+    if (q >= 2) {
+        double mq = 0.0;
+        if (m > 1e-30) {
+            const float x = (float)q * __builtin_amdgcn_logf((float)m);
+            if (x > -60.f) mq = (double)__builtin_amdgcn_exp2f(x);
+        }
+        B = (1.0 - mq) / (1.0 - m) - 1.0;
+    }
+    const double errHi = term * (B * (1.0 + 1e-5) + 4e-15), errLo = term * (B * (1.0 - 1e-5) - 4e-15);
+    int e;
+    const double f = frexp(bin_tail, &e);                                 // bin_tail = f * 2^e, f in [0.5, 1)
+    const double l10 = ((double)e + (double)__builtin_amdgcn_logf((float)f)) * 0.30102999566398120;
+    const double A = fabs(-l10 - logNT);
+    const double rhsHi = 0.1 * (A + 2e-6) * bin_tail * (1.0 + 1e-14), rhsLo = 0.1 * fmax(A - 2e-6, 0.0) * bin_tail * (1.0 - 1e-14);
+    if (errHi < rhsLo) return 1;
+    if (errLo >= rhsHi) return 0;
+    return -1;
+}
+// LineSegmentDetectorImpl::nfa() split for lane-dynamic scheduling: nfa_setup() covers everything before the binomial-tail
+// loop, tail_block() advances the loop by up to eight terms, and the caller finishes with -log10(bin_tail) - logNT.
+struct TailState { double term, bin_tail, p_term; int n, i; };           // i = next term index (k+1 .. n)
+
+// returns true when the tail loop has to run; otherwise v is the function value
+__device__ __forceinline__ bool nfa_setup(int n, int k, double p, double logNT, const double* __restrict__ lgam, const PLog* __restrict__ plog, TailState& S, double& v) {
+    if (n == 0 || k == 0) { v = -logNT; return false; }
     const int h = 1020 - ((__double2hiint(p) >> 20) & 0x7FF);        // p is an exact power of two
     const bool tab = h >= 0 && h < 16 && p == ldexp(0.125, -h);
-    if (n == k) return -logNT - (double)n * (tab ? plog[h].l10p : log10(p));
-    double p_term = p / (1 - p);
-    double log1term = lgam[n + 1] - lgam[k + 1] - lgam[n - k + 1] + (double)k * (tab ? plog[h].lp : log(p)) + (double)(n - k) * (tab ? plog[h].l1mp : log(1.0 - p));
-    double term = exp(log1term);
+    if (n == k) { v = -logNT - (double)n * (tab ? plog[h].l10p : log10(p)); return false; }
+    const double p_term = p / (1 - p);
+    const double log1term = lgam[n + 1] - lgam[k + 1] - lgam[n - k + 1] + (double)k * (tab ? plog[h].lp : log(p)) + (double)(n - k) * (tab ? plog[h].l1mp : log(1.0 - p));
+    const double term = exp(log1term);
     if (term == 0.0) {      // double_equal(term, 0) holds only for an exact zero
-        if ((double)k > (double)n * p) return -log1term / 2.30258509299404568402 - logNT;
-        return -logNT;
+        v = ((double)k > (double)n * p) ? -log1term / 2.30258509299404568402 - logNT : -logNT;
+        return false;
     }
-    double bin_tail = term;
+    S.term = term; S.bin_tail = term; S.p_term = p_term; S.n = n; S.i = k + 1;
+    return true;
+}
+
+// up to eight terms of the tail loop; true when the loop is over (early exit or i > n)
+__device__ __forceinline__ bool tail_block(TailState& S, double logNT, const double* __restrict__ rcp) {
     const double tolerance = 0.1;
+    const int n = S.n, i0 = S.i;
+    double term = S.term, bin_tail = S.bin_tail;
+    double mt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {           // independent divisions: issue back to back
+        const int i = min(i0 + j, n);
+        mt[j] = exact_div((double)(n - i + 1), (double)i, rcp[i]) * S.p_term;
+    }
     bool done = false;
-    for (int i0 = k + 1; i0 <= n && !done; i0 += 8) {
-        double mt[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {           // independent divisions: issue back to back
-            const int i = min(i0 + j, n);
-            mt[j] = exact_div((double)(n - i + 1), (double)i, rcp[i]) * p_term;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i = i0 + j;
-            if (i <= n && !done) {
-                term *= mt[j];
-                bin_tail += term;
-                // exact shortcut: past the mode (ratio < 1, and the ratio only shrinks with i) every later term is smaller than
-                // this one; once a term is below half an ulp of the sum, no later addition can change bin_tail, and bin_tail is
-                // all the function returns from here on.
-                if (mt[j] < 1.0 && term < bin_tail * 0x1p-54) done = true;
-                if (!done && n - i + 1 < i) {             // bin_term < 1
+    for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j;
+        if (i <= n && !done) {
+            term *= mt[j];
+            bin_tail += term;
+            // exact shortcut: past the mode (ratio < 1, and the ratio only shrinks with i) every later term is smaller than
+            // this one; once a term is below half an ulp of the sum, no later addition can change bin_tail, and bin_tail is
+            // all the function returns from here on.
+            if (mt[j] < 1.0 && term < bin_tail * 0x1p-54) done = true;
+            if (!done && n - i + 1 < i) {             // bin_term < 1
+                const int dec = tail_test_cheap(term, mt[j], n - i + 1, bin_tail, logNT);
+                if (dec > 0) done = true;
+                else if (dec < 0) {                    // the guard bands overlap (rare): evaluate the reference's expression itself
                     const double err = term * ((1 - pow(mt[j], (double)(n - i + 1))) / (1 - mt[j]) - 1);
                     if (err < tolerance * fabs(-log10(bin_tail) - logNT) * bin_tail) done = true;
                 }
             }
         }
     }
-    return -log10(bin_tail) - logNT;
+    S.term = term; S.bin_tail = bin_tail; S.i = i0 + 8;
+    return done || S.i > n;
 }
 
 // region point list: first QCAP entries in LDS, the rest in global memory.  entry = x | y<<16
@@ -650,8 +694,8 @@ __device__ __forceinline__ void nfa_row_range(const NfaGeom& g, int y, int sw, i
 // rect_improve (LSD_REFINE_ADV) evaluates the rectangle, then five refinement stages of up to five candidate rectangles
 // each; inside a stage the candidates do not depend on which of them is accepted.  Per stage two launches cover every
 // candidate of every frame: k_nfa_count (one wave per rectangle: aligned-point counts of the stage's candidates) and
-// k_nfa_math (8 lanes per rectangle: the binomial-tail NFAs lane-parallel, then the reference's sequential acceptance).
-struct NfaState { double logNfa; int done, nc; int cnt[6][2]; };      // per rectangle; cnt[k] = {total, aligned}
+// k_nfa_eval (the binomial-tail NFAs of all candidates, lanes scheduled dynamically) + k_nfa_accept (the reference's sequential acceptance).
+struct NfaState { double logNfa; int done, nc; int cnt[6][2]; double val[6]; };      // per rectangle; cnt[k] = {total, aligned}, val[j] = NFA of candidate j
 
 // candidate j of stage `stage` (0..4) grown from the stage's starting rectangle exactly like rect_improve's loops;
 // false when iteration j is skipped (width floor) — then every later iteration is skipped too.
@@ -827,47 +871,121 @@ __global__ __launch_bounds__(64) void k_nfa_count(uint8_t* __restrict__ ws, LsdP
 }
 
 // stage -1: the initial evaluation (cnt[0]); stage 0: cnt[1..5]; stages 1-4: cnt[0..nc).
-__global__ __launch_bounds__(256) void k_nfa_math(uint8_t* __restrict__ ws, LsdPlan P, int stage, const double* __restrict__ lgam) {
+// One wave walks a frame's (rectangle, candidate) evaluations with lane-level dynamic scheduling: the tail loop's trip count
+// varies from 1 to thousands, so lanes that finish pick up the next evaluation instead of idling until the slowest lane of a
+// fixed assignment is done.  Setup (log-gamma terms, exp) and the final log10 run only when at least EVAL_REFILL lanes need
+// them.  Results land in NfaState::val; k_nfa_accept applies the reference's in-order acceptance.
+constexpr int EVAL_CH = 1024;          // rectangles per item-list chunk
+constexpr int EVAL_REFILL = 16;
+__device__ __forceinline__ int stage_ncand(const NfaState& s, int stage) {
+    if (stage < 0) return 1;
+    if (s.done) return 0;
+    return stage == 0 ? 5 : stage == 4 ? (s.nc > 0 ? 5 : 0) : s.nc;
+}
+__global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPlan P, int stage, const double* __restrict__ lgam) {
+    __shared__ unsigned short items[EVAL_CH * 5];            // (rect - chunk) << 3 | candidate
+    const int b = blockIdx.y, lane = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    Misc* misc = (Misc*)(base + P.offMisc);
+    const int nCand = misc->nCand;
+    const double* rects = (const double*)(base + P.offCand);
+    NfaState* st = (NfaState*)(base + P.offNfa);
+    const PLog* plog = (const PLog*)(lgam + P.npx + 4);
+    const double* rcp = lgam + P.npx + 4 + 48;
+    const int per = (nCand + gridDim.x - 1) / gridDim.x;
+    const int c0 = blockIdx.x * per, c1 = min(c0 + per, nCand);
+#ifdef SSLAM_LSD_STATS
+    long long useful = 0, executed = 0, evals = 0;
+#endif
+    for (int chunk = c0; chunk < c1; chunk += EVAL_CH) {
+        const int cend = min(chunk + EVAL_CH, c1);
+        int nItems = 0;
+        for (int cb = chunk; cb < cend; cb += 64) {
+            const int c = cb + lane;
+            const int cnt = c < cend ? stage_ncand(st[c], stage) : 0;
+            const int incl = wave_incl_scan(cnt);
+            const int ex = nItems + incl - cnt;
+            for (int j = 0; j < cnt; ++j) items[ex + j] = (unsigned short)(((c - chunk) << 3) | j);
+            nItems += __builtin_amdgcn_readlane(incl, 63);
+        }
+        __syncthreads();
+        int pos = 0, myc = 0, myj = 0;
+        bool active = false, pending = false, needLog = false;
+        TailState S; S.term = 0; S.bin_tail = 1; S.p_term = 0; S.n = 0; S.i = 1;
+        double v = 0;
+        while (true) {
+            const unsigned long long am = __ballot(active);
+            const int nIdle = 64 - __popcll(am);
+            const bool more = pos < nItems;
+            if ((more && nIdle >= EVAL_REFILL) || am == 0) {
+                if (!active && pending) {                      // finish and publish what the idle lanes hold
+                    if (needLog) v = -log10(S.bin_tail) - P.logNT;
+                    st[myc].val[myj] = v;
+                    pending = false;
+                }
+                if (!more) { if (am == 0) break; }
+                else {
+                    if (!active) {
+                        const int my = pos + mbcnt(~am);
+                        if (my < nItems) {
+                            const unsigned it = items[my];
+                            myc = chunk + (int)(it >> 3); myj = (int)(it & 7);
+                            const int kofs = stage == 0 ? 1 : 0;
+                            const int n = st[myc].cnt[myj + kofs][0], k = st[myc].cnt[myj + kofs][1];
+                            double p = rects[(size_t)myc * 12 + 11];
+                            if (stage == 0 || stage == 4) p = ldexp(p, -(myj + 1));       // stage_cand halves p once per step
+                            needLog = nfa_setup(n, k, p, P.logNT, lgam, plog, S, v);
+                            active = needLog; pending = true;
+#ifdef SSLAM_LSD_STATS
+                            ++evals;
+#endif
+                        }
+                    }
+                    pos += nIdle;
+                    continue;
+                }
+            }
+            if (active) {
+#ifdef SSLAM_LSD_STATS
+                useful += min(8, S.n - S.i + 1);
+#endif
+                if (tail_block(S, P.logNT, rcp)) active = false;
+            }
+#ifdef SSLAM_LSD_STATS
+            executed += 8;
+#endif
+        }
+        __syncthreads();
+    }
+#ifdef SSLAM_LSD_STATS
+    // cyc[5] = useful tail iterations (upper bound: whole blocks), cyc[6] = lane-iterations the wave executed, cyc[7] = evaluations
+    atomicAdd((unsigned long long*)&misc->cyc[5], (unsigned long long)useful); atomicAdd((unsigned long long*)&misc->cyc[6], (unsigned long long)executed);
+    atomicAdd((unsigned long long*)&misc->cyc[7], (unsigned long long)evals);
+#endif
+}
+
+// rect_improve's acceptance, in candidate order, one lane per rectangle (the candidates of a stage do not depend on which of
+// them is accepted, so they were all evaluated up front).
+__global__ __launch_bounds__(256) void k_nfa_accept(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
     const int b = blockIdx.y;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     const Misc* misc = (const Misc*)(base + P.offMisc);
     const int nCand = misc->nCand;
     double* rects = (double*)(base + P.offCand);
     NfaState* st = (NfaState*)(base + P.offNfa);
-    const PLog* plog = (const PLog*)(lgam + P.npx + 4);
-    const int j = threadIdx.x & 7;
-    for (int c0 = blockIdx.x * 32; c0 < nCand; c0 += gridDim.x * 32) {
-        const int c = c0 + (threadIdx.x >> 3);
-        const bool act = c < nCand && !(stage >= 0 && st[c].done);
-        RectD rec, r;
-        int nc = 0, kofs = 0;
-        double v = 0;
-        if (act) {
-            load_rect(rects + (size_t)c * 12, rec);
-            if (stage < 0) nc = 1;
-            else if (stage == 0) { nc = 5; kofs = 1; }
-            else nc = stage == 4 ? (st[c].nc > 0 ? 5 : 0) : st[c].nc;
-            if (j < nc) {
-                double p = rec.p;
-                if (stage >= 0) { stage_cand(rec, stage, j, r); p = r.p; }
-                v = nfa_d(st[c].cnt[j + kofs][0], st[c].cnt[j + kofs][1], p, P.logNT, lgam, plog, lgam + P.npx + 4 + 48);
-            }
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < nCand; c += gridDim.x * 256) {
+        if (stage < 0) { const double v0 = st[c].val[0]; st[c].logNfa = v0; st[c].done = v0 > 0.0 ? 1 : 0; continue; }
+        const int nc = stage_ncand(st[c], stage);
+        if (st[c].done) continue;
+        double log_nfa = st[c].logNfa;
+        int best = -1;
+        for (int q = 0; q < nc; ++q) { const double vq = st[c].val[q]; if (vq > log_nfa) { log_nfa = vq; best = q; } }
+        if (best >= 0) {
+            RectD rec, r; load_rect(rects + (size_t)c * 12, rec);
+            stage_cand(rec, stage, best, r);
+            store_rect(rects + (size_t)c * 12, r); st[c].logNfa = log_nfa;
         }
-        // acceptance in order by the group's lane 0 (values gathered from its 8-lane group)
-        double vs[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) vs[q] = __shfl(v, ((threadIdx.x & 63) & ~7) + q, 64);
-        if (act && j == 0) {
-            if (stage < 0) { st[c].logNfa = vs[0]; st[c].done = vs[0] > 0.0 ? 1 : 0; }
-            else {
-                double log_nfa = st[c].logNfa;
-                bool changed = false;
-                for (int q = 0; q < nc; ++q)
-                    if (vs[q] > log_nfa) { log_nfa = vs[q]; stage_cand(rec, stage, q, r); changed = true; }
-                if (changed) { store_rect(rects + (size_t)c * 12, r); st[c].logNfa = log_nfa; }
-                if (stage < 4 && log_nfa > 0.0) st[c].done = 1;
-            }
-        }
+        if (stage < 4 && log_nfa > 0.0) st[c].done = 1;
     }
 }
 
@@ -1486,10 +1604,15 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         if (lds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         { sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st); hipLaunchKernelGGL(k_lsd_regions, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>()); }
     }
+    const int evalWaves = nframes >= 1024 ? 1 : nframes >= 64 ? 4 : 16;      // waves per frame walking the NFA evaluations
     for (int stage = 0; stage <= 4; ++stage) {
         { sslam::ProfScope _ps(L->ctx, "k_nfa_count", st); hipLaunchKernelGGL(k_nfa_count, dim3(512, nframes), dim3(64), 0, st, ws, P, stage); }
-        if (stage == 0) { sslam::ProfScope _ps(L->ctx, "k_nfa_math", st); hipLaunchKernelGGL(k_nfa_math, dim3(16, nframes), dim3(256), 0, st, ws, P, -1, L->dLgam.as<double>()); }
-        { sslam::ProfScope _ps(L->ctx, "k_nfa_math", st); hipLaunchKernelGGL(k_nfa_math, dim3(16, nframes), dim3(256), 0, st, ws, P, stage, L->dLgam.as<double>()); }
+        if (stage == 0) {
+            { sslam::ProfScope _ps(L->ctx, "k_nfa_eval", st); hipLaunchKernelGGL(k_nfa_eval, dim3(evalWaves, nframes), dim3(64), 0, st, ws, P, -1, L->dLgam.as<double>()); }
+            { sslam::ProfScope _ps(L->ctx, "k_nfa_accept", st); hipLaunchKernelGGL(k_nfa_accept, dim3(4, nframes), dim3(256), 0, st, ws, P, -1); }
+        }
+        { sslam::ProfScope _ps(L->ctx, "k_nfa_eval", st); hipLaunchKernelGGL(k_nfa_eval, dim3(evalWaves, nframes), dim3(64), 0, st, ws, P, stage, L->dLgam.as<double>()); }
+        { sslam::ProfScope _ps(L->ctx, "k_nfa_accept", st); hipLaunchKernelGGL(k_nfa_accept, dim3(4, nframes), dim3(256), 0, st, ws, P, stage); }
     }
     { sslam::ProfScope _ps(L->ctx, "k_nfa_finish", st); hipLaunchKernelGGL(k_nfa_finish, dim3(4, nframes), dim3(256), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
