@@ -734,12 +734,80 @@ __device__ __forceinline__ double align_dist(float aDeg, double theta) {
     return n_theta;
 }
 
-struct CountLds { RectD cand[MAXC]; NfaGeom geom[MAXC]; int total[MAXC], alg[MAXC]; };
+// k_nfa_count: one wave walks a frame's rectangles.  The corner bookkeeping of rect_nfa (nfa_geom: sorting, slopes, integer
+// divisions) is the same few hundred instructions whether one lane or sixty-four execute it, so it runs lane-parallel for a
+// batch of up to 64 (rectangle, candidate) items whose results are parked in LDS; the wave then counts the items one after
+// the other with all lanes on the pixels.  Counters are wave-uniform (ballot + popcount), so nothing is reduced at the end.
+constexpr int EVAL_CH = 1024;          // rectangles per item-list chunk (k_nfa_count, k_nfa_eval)
+constexpr int EVAL_REFILL = 16;
+struct CntItem { NfaGeom g; int c, j, pad; double theta, prec, p; };
+
+// aligned-point counts of one rectangle for K nested precisions (K = 1: a single tolerance); total = pixels visited
+template <int K>
+__device__ __forceinline__ void count_item(const NfaGeom& g, double theta, const double (&prec)[6], const float* __restrict__ ang, int sw,
+                                           int lane, int& totalOut, int (&alg)[6]) {
+    const int nrows = g.y1 - g.y0 + 1;
+    const int half = lane & 1;
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) alg[k] = 0;
+    for (int t0 = 0; t0 < nrows; t0 += 32) {
+        const int t = t0 + (lane >> 1);
+        int xa = 0, xb = -1; const int y = g.y0 + t;
+        if (t < nrows) nfa_row_range(g, y, sw, xa, xb);
+        const int width = xb - xa + 1;
+        if (width > 0 && half == 0) total += width;
+        const bool wide = width > 24;
+        // narrow rows: the two lanes of a row split it evenly; the wave steps through the longest share
+        const int h0 = (width + 1) >> 1;
+        const int xs = xa + half * h0, xe = half ? xb : xa + h0 - 1;
+        const int mine = (width > 0 && !wide) ? xe - xs + 1 : 0;
+        const int mw = wave_max(mine);
+        if (mw > 0) {
+            const float* row = ang + (size_t)y * sw + xs;
+            float a[12];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = j < mine ? row[j] : NOTDEF_F;
+            if (mw > 4) {
+#pragma unroll
+                for (int j = 4; j < 8; ++j) a[j] = j < mine ? row[j] : NOTDEF_F;
+            }
+            if (mw > 8) {
+#pragma unroll
+                for (int j = 8; j < 12; ++j) a[j] = j < mine ? row[j] : NOTDEF_F;
+            }
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                if (j < mw) {
+                    const double d = j < mine ? align_dist(a[j], theta) : 1e300;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) alg[k] += __popcll(__ballot(d <= prec[k]));
+                }
+            }
+        }
+        unsigned long long wm = __ballot(wide && half == 0);
+        while (wm) {
+            const int src = __ffsll((long long)wm) - 1;
+            wm &= wm - 1;
+            const int wy = __builtin_amdgcn_readlane(y, src), wxa = __builtin_amdgcn_readlane(xa, src), wxb = __builtin_amdgcn_readlane(xb, src);
+            const float* row = ang + (size_t)wy * sw;
+            for (int x0 = wxa; x0 <= wxb; x0 += 128) {
+                const int x = x0 + lane;
+                const float a0 = x <= wxb ? row[x] : NOTDEF_F, a1 = x + 64 <= wxb ? row[x + 64] : NOTDEF_F;
+                const double d0 = align_dist(a0, theta), d1 = align_dist(a1, theta);
+#pragma unroll
+                for (int k = 0; k < K; ++k) alg[k] += __popcll(__ballot(d0 <= prec[k])) + __popcll(__ballot(d1 <= prec[k]));
+            }
+        }
+    }
+    totalOut = wave_sum(total);
+}
 
 // stage 0 is merged with the initial evaluation: same rectangle, six precisions (p, p/2 .. p/32); stage 4 likewise has one
-// geometry and five precisions.  Stages 1-3 change the rectangle itself.
+// geometry and five precisions.  Stages 1-3 change the rectangle itself: up to five candidates per rectangle, each an item.
 __global__ __launch_bounds__(64) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
-    __shared__ CountLds L;
+    __shared__ CntItem its[64];
+    __shared__ unsigned short act[EVAL_CH];
     const int b = blockIdx.y, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     const Misc* misc = (const Misc*)(base + P.offMisc);
@@ -748,123 +816,66 @@ __global__ __launch_bounds__(64) void k_nfa_count(uint8_t* __restrict__ ws, LsdP
     const double* rects = (const double*)(base + P.offCand);
     NfaState* st = (NfaState*)(base + P.offNfa);
     const int sw = P.sw, sh = P.sh;
-    for (int c = blockIdx.x; c < nCand; c += gridDim.x) {
-        if (stage > 0 && st[c].done) continue;
-        RectD rec; load_rect(rects + (size_t)c * 12, rec);
-        if (stage == 0 || stage == 4) {
-            // one geometry, K nested precisions: prec_k = (p / 2^k) * pi (k from 0 for the merged initial evaluation)
-            const int K = stage == 0 ? 6 : 5;
-            const bool live = stage == 0 || (rec.width - 0.5) >= 0.5;
-            int algk[6] = {0, 0, 0, 0, 0, 0};
-            int total = 0;
-            if (live) {
+    const int per = (nCand + gridDim.x - 1) / gridDim.x;
+    const int c0 = blockIdx.x * per, c1 = min(c0 + per, nCand);
+    const bool nested = stage == 0 || stage == 4;
+    const int rpb = nested ? 64 : 12;                              // rectangles per batch (stages 1-3: five lanes each)
+    for (int chunk = c0; chunk < c1; chunk += EVAL_CH) {
+        const int cend = min(chunk + EVAL_CH, c1);
+        int nAct = 0;
+        for (int cb = chunk; cb < cend; cb += 64) {               // rectangles still being refined
+            const int c = cb + lane;
+            const bool on = c < cend && (stage == 0 || !st[c].done);
+            const unsigned long long m = __ballot(on);
+            if (on) act[nAct + mbcnt(m)] = (unsigned short)(c - chunk);
+            nAct += __popcll(m);
+        }
+        __syncthreads();
+        for (int a0 = 0; a0 < nAct; a0 += rpb) {
+            const int nr = min(rpb, nAct - a0);
+            const int nIt = nested ? nr : nr * MAXC;
+            {
+                const int ri = nested ? lane : lane / MAXC, j = nested ? 0 : lane - ri * MAXC;
+                bool valid = false;
+                int c = 0;
+                if (lane < nIt) {
+                    c = chunk + act[a0 + ri];
+                    RectD rec, r; load_rect(rects + (size_t)c * 12, rec);
+                    if (nested) { r = rec; valid = stage == 0 || (rec.width - 0.5) >= 0.5; }
+                    else valid = stage_cand(rec, stage, j, r);
+                    CntItem& I = its[lane];
+                    I.c = c; I.j = valid ? j : -1;
+                    if (valid) { I.g = nfa_geom(r, sh); I.theta = r.theta; I.prec = r.prec; I.p = r.p; }
+                }
+                const unsigned long long vm = __ballot(valid);
+                if (lane < nIt) {
+                    if (nested) { if (!valid) st[c].nc = 0; }
+                    else if (j == 0) st[c].nc = __popcll((vm >> lane) & 31ull);
+                }
+            }
+            __syncthreads();
+            for (int it = 0; it < nIt; ++it) {
+                const int j = its[it].j;
+                if (j < 0) continue;
+                const NfaGeom g = its[it].g;
+                const double theta = its[it].theta, p = its[it].p;
+                const int c = its[it].c;
                 double prec[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) prec[k] = stage == 0 ? (k == 0 ? rec.prec : ldexp(rec.p, -k) * kPI) : ldexp(rec.p, -(k + 1)) * kPI;
-                const NfaGeom g = nfa_geom(rec, sh);
-                const int nrows = g.y1 - g.y0 + 1;
-                const int half = lane & 1;
-                for (int t0 = 0; t0 < nrows; t0 += 32) {
-                    const int t = t0 + (lane >> 1);
-                    int xa = 0, xb = -1; const int y = g.y0 + t;
-                    if (t < nrows) nfa_row_range(g, y, sw, xa, xb);
-                    const int width = xb - xa + 1;
-                    if (width > 0 && half == 0) total += width;
-                    const bool wide = width > 24;
-                    if (width > 0 && !wide) {
-                        const float* row = ang + (size_t)y * sw;
-                        const int xs = xa + half * 12;
-                        float a[12];
+                for (int k = 0; k < 6; ++k) prec[k] = stage == 0 ? (k == 0 ? its[it].prec : ldexp(p, -k) * kPI) : stage == 4 ? ldexp(p, -(k + 1)) * kPI : its[it].prec;
+                int total, alg[6];
+                if (stage == 0) count_item<6>(g, theta, prec, ang, sw, lane, total, alg);
+                else if (stage == 4) count_item<5>(g, theta, prec, ang, sw, lane, total, alg);
+                else count_item<1>(g, theta, prec, ang, sw, lane, total, alg);
+                if (lane == 0) {
+                    if (nested) {
+                        const int K = stage == 0 ? 6 : 5;
 #pragma unroll
-                        for (int j = 0; j < 12; ++j) a[j] = (xs + j <= xb) ? row[xs + j] : NOTDEF_F;
-#pragma unroll
-                        for (int j = 0; j < 12; ++j) {
-                            const double d = align_dist(a[j], rec.theta);
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) algk[k] += (k < K && d <= prec[k]) ? 1 : 0;
-                        }
-                    }
-                    unsigned long long wm = __ballot(wide && half == 0);
-                    while (wm) {
-                        const int src = __ffsll((long long)wm) - 1;
-                        wm &= wm - 1;
-                        const int wy = __shfl(y, src, 64), wxa = __shfl(xa, src, 64), wxb = __shfl(xb, src, 64);
-                        const float* row = ang + (size_t)wy * sw;
-                        for (int x = wxa + lane; x <= wxb; x += 64) {
-                            const double d = align_dist(row[x], rec.theta);
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) algk[k] += (k < K && d <= prec[k]) ? 1 : 0;
-                        }
-                    }
+                        for (int k = 0; k < 6; ++k) if (k < K) { st[c].cnt[k][0] = total; st[c].cnt[k][1] = alg[k]; }
+                        st[c].nc = K;
+                    } else { st[c].cnt[j][0] = total; st[c].cnt[j][1] = alg[0]; }
                 }
             }
-            total = wave_sum(total);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) algk[k] = wave_sum(algk[k]);
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { st[c].cnt[k][0] = total; st[c].cnt[k][1] = algk[k]; }
-                st[c].nc = live ? K : 0;
-            }
-        } else {
-            // distinct rectangles: all rows of all candidates spread over the wave
-            RectD r;
-            const bool valid = lane < MAXC && stage_cand(rec, stage, lane, r);
-            const int nc = __popcll(__ballot(valid));
-            if (valid) { L.cand[lane] = r; L.geom[lane] = nfa_geom(r, sh); L.total[lane] = 0; L.alg[lane] = 0; }
-            __syncthreads();
-            int rb[MAXC + 1];
-            rb[0] = 0;
-#pragma unroll
-            for (int q = 0; q < MAXC; ++q) rb[q + 1] = rb[q] + (q < nc ? max(0, L.geom[q].y1 - L.geom[q].y0 + 1) : 0);
-            const int R = rb[MAXC];
-            const int half = lane & 1;
-            for (int t0 = 0; t0 < R; t0 += 32) {
-                const int t = t0 + (lane >> 1);
-                int cc = 0, y = 0, xa = 0, xb = -1;
-                double theta = 0, prec = 0;
-                if (t < R) {
-#pragma unroll
-                    for (int q = 1; q < MAXC; ++q) cc += (t >= rb[q]) ? 1 : 0;
-                    const NfaGeom g = L.geom[cc];
-                    const int rbc = cc == 0 ? rb[0] : cc == 1 ? rb[1] : cc == 2 ? rb[2] : cc == 3 ? rb[3] : rb[4];
-                    y = g.y0 + (t - rbc);
-                    nfa_row_range(g, y, sw, xa, xb);
-                    theta = L.cand[cc].theta; prec = L.cand[cc].prec;
-                }
-                const int width = xb - xa + 1;
-                if (width > 0 && half == 0) atomicAdd(&L.total[cc], width);
-                const bool wide = width > 24;
-                if (width > 0 && !wide) {
-                    const float* row = ang + (size_t)y * sw;
-                    const int xs = xa + half * 12;
-                    float a[12];
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) a[j] = (xs + j <= xb) ? row[xs + j] : NOTDEF_F;
-                    int cnt = 0;
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) cnt += (int)is_aligned_val(a[j], theta, prec);
-                    if (cnt) atomicAdd(&L.alg[cc], cnt);
-                }
-                unsigned long long wm = __ballot(wide && half == 0);
-                while (wm) {
-                    const int src = __ffsll((long long)wm) - 1;
-                    wm &= wm - 1;
-                    const int wc = __shfl(cc, src, 64), wy = __shfl(y, src, 64), wxa = __shfl(xa, src, 64), wxb = __shfl(xb, src, 64);
-                    const double wth = L.cand[wc].theta, wpr = L.cand[wc].prec;
-                    const float* row = ang + (size_t)wy * sw;
-                    int cnt = 0;
-                    for (int x = wxa + lane; x <= wxb; x += 128) {
-                        const float a0 = row[x], a1 = x + 64 <= wxb ? row[x + 64] : NOTDEF_F;
-                        cnt += (int)is_aligned_val(a0, wth, wpr) + (int)is_aligned_val(a1, wth, wpr);
-                    }
-                    cnt = wave_sum(cnt);
-                    if (lane == 0 && cnt) atomicAdd(&L.alg[wc], cnt);
-                }
-            }
-            __syncthreads();
-            if (lane < MAXC) { st[c].cnt[lane][0] = lane < nc ? L.total[lane] : 0; st[c].cnt[lane][1] = lane < nc ? L.alg[lane] : 0; }
-            if (lane == 0) st[c].nc = nc;
             __syncthreads();
         }
     }
@@ -875,8 +886,6 @@ __global__ __launch_bounds__(64) void k_nfa_count(uint8_t* __restrict__ ws, LsdP
 // varies from 1 to thousands, so lanes that finish pick up the next evaluation instead of idling until the slowest lane of a
 // fixed assignment is done.  Setup (log-gamma terms, exp) and the final log10 run only when at least EVAL_REFILL lanes need
 // them.  Results land in NfaState::val; k_nfa_accept applies the reference's in-order acceptance.
-constexpr int EVAL_CH = 1024;          // rectangles per item-list chunk
-constexpr int EVAL_REFILL = 16;
 __device__ __forceinline__ int stage_ncand(const NfaState& s, int stage) {
     if (stage < 0) return 1;
     if (s.done) return 0;
@@ -1605,8 +1614,9 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         { sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st); hipLaunchKernelGGL(k_lsd_regions, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>()); }
     }
     const int evalWaves = nframes >= 1024 ? 1 : nframes >= 64 ? 4 : 16;      // waves per frame walking the NFA evaluations
+    const int countWaves = nframes >= 2048 ? 2 : nframes >= 128 ? 8 : 64;    // waves per frame walking the rectangle counts
     for (int stage = 0; stage <= 4; ++stage) {
-        { sslam::ProfScope _ps(L->ctx, "k_nfa_count", st); hipLaunchKernelGGL(k_nfa_count, dim3(512, nframes), dim3(64), 0, st, ws, P, stage); }
+        { sslam::ProfScope _ps(L->ctx, "k_nfa_count", st); hipLaunchKernelGGL(k_nfa_count, dim3(countWaves, nframes), dim3(64), 0, st, ws, P, stage); }
         if (stage == 0) {
             { sslam::ProfScope _ps(L->ctx, "k_nfa_eval", st); hipLaunchKernelGGL(k_nfa_eval, dim3(evalWaves, nframes), dim3(64), 0, st, ws, P, -1, L->dLgam.as<double>()); }
             { sslam::ProfScope _ps(L->ctx, "k_nfa_accept", st); hipLaunchKernelGGL(k_nfa_accept, dim3(4, nframes), dim3(256), 0, st, ws, P, -1); }
