@@ -41,7 +41,7 @@ struct LsdPlan {
     int npx;                  // sw*sh
     int nTiles;
     size_t frameBytes;        // per-frame workspace
-    size_t offScaled, offBlur, offAng, offS, offPix, offCand, offFlag, offNfa, offOrder, offTileHist, offReg, offSeg, offMisc, offDx, offDy, offBlur5, offKl, offSortIdx;
+    size_t offScaled, offBlur, offAng, offS, offPix, offCand, offFlag, offNfa, offOrder, offTileHist, offReg, offSeg, offMisc, offDxy, offKl, offSortIdx;
     int blurTaps[7];          // sigma 0.75, 7 taps (q8)
     int blur5Taps[5];         // sigma 1, 5 taps (q8)
     int tabX, tabY;           // offsets into the resize table (int: ofs, c1)
@@ -520,6 +520,9 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // changes when a pixel is accepted, so ONE ballot over all staged lanes finds the next accepted
 // pixel exactly as the sequential scan would; lanes before it are consumed, lanes after it are
 // re-tested against the updated angle.
+// LAT selects the accept-chain flavour: v_readlane + pre-converted operands shorten the dependent chain of a lone wave
+// (single-frame latency, -11 %), while with six waves per SIMD the LDS-permute form issues fewer wait states (throughput).
+template <bool LAT>
 __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __restrict__ pix, const float* __restrict__ ang, const RegQ& rq,
                              double prec, double& regAngleOut) {
     const int lane = threadIdx.x & 63;
@@ -545,16 +548,23 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __res
             }
         }
         int lastSel = -1;
+        const double candRad = LAT ? (double)px4.x * DEG2RAD : 0.0;     // isAligned's operand, converted once per staging
         while (true) {
-            const bool al = cand && lane > lastSel && is_aligned_val(px4.x, regAngle, prec);
+            bool al;
+            if (LAT) {
+                double nt = regAngle - candRad;              // is_aligned_val(px4.x, regAngle, prec), same operations
+                if (nt < 0) nt = -nt;
+                if (nt > M_3_2_PI_) { nt -= M_2PI_; if (nt < 0) nt = -nt; }
+                al = cand && lane > lastSel && nt <= prec;
+            } else al = cand && lane > lastSel && is_aligned_val(px4.x, regAngle, prec);
             const unsigned long long m = __ballot(al);
             if (!m) break;
-            const int sel = __ffsll((long long)m) - 1;
-            const int selIdx = __shfl(nidx, sel, 64);
+            const int sel = __ffsll((long long)m) - 1;       // wave-uniform: the lane reads below are v_readlane, not LDS permutes
+            const int selIdx = LAT ? __builtin_amdgcn_readlane(nidx, sel) : __shfl(nidx, sel, 64);
             if (lane == sel) { pix[nidx].x = USED_F; rq.set(n, (unsigned)xx | ((unsigned)yy << 16)); }
             ++n;
-            sumdx = __fadd_rn(sumdx, __shfl(px4.y, sel, 64));
-            sumdy = __fadd_rn(sumdy, __shfl(px4.z, sel, 64));
+            sumdx = __fadd_rn(sumdx, LAT ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px4.y), sel)) : __shfl(px4.y, sel, 64));
+            sumdy = __fadd_rn(sumdy, LAT ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px4.z), sel)) : __shfl(px4.z, sel, 64));
             regAngle = (double)fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
             if (nidx == selIdx) cand = false;              // the accepted pixel is now USED for every later visitor
             lastSel = sel;
@@ -1022,6 +1032,7 @@ __global__ __launch_bounds__(256) void k_nfa_finish(uint8_t* __restrict__ ws, Ls
 #ifndef SSLAM_LSD_MINWAVES
 #define SSLAM_LSD_MINWAVES 6          // waves/SIMD the register allocator must leave room for (6 x 4 SIMDs = 24 frames per CU, LDS allows 32)
 #endif
+template <bool LAT>
 __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
     extern __shared__ __align__(16) unsigned dynLds[];           // region queue (first QCAP points)
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -1049,11 +1060,11 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
             if (!m) break;
             const int first = __ffsll((long long)m) - 1;
             after = first;
-            const int seed = __shfl(idx, first, 64);
+            const int seed = LAT ? __builtin_amdgcn_readlane(idx, first) : __shfl(idx, first, 64);
             const int sy = seed / sw, sx = seed - sy * sw;
             double regAngle;
             long long t0 = __builtin_readcyclecounter();
-            int n = region_grow_m(sx, sy, sw, sh, pix, ang, rq, prec, regAngle);
+            int n = region_grow_m<LAT>(sx, sy, sw, sh, pix, ang, rq, prec, regAngle);
             long long t1 = __builtin_readcyclecounter(); cyc0 += t1 - t0;
             if (n < P.minRegSize) continue;
             RectD rec;
@@ -1084,7 +1095,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                 }
                 const double mean_angle = sum / (double)cnt;
                 const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-                n = region_grow_m(x0, y0, sw, sh, pix, ang, rq, tau, regAngle);
+                n = region_grow_m<LAT>(x0, y0, sw, sh, pix, ang, rq, tau, regAngle);
                 if (n < 2) continue;
                 region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec);
                 density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
@@ -1233,7 +1244,7 @@ __global__ __launch_bounds__(256) void k_keylines(uint8_t* __restrict__ ws, LsdP
 // LDS -> 64x16 dx/dy.  (A symmetric kernel with reflect-101 borders commutes with the reflection, so evaluating the blur at the
 // one-pixel Sobel halo outside the image from the reflected source IS the blurred value at the reflected pixel.)
 __global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ src, size_t spitch, size_t sframe, int w, int h,
-                                                    short* __restrict__ dxo, short* __restrict__ dyo, size_t dframeBytes,
+                                                    unsigned* __restrict__ dxyo, size_t dframeBytes,
                                                     const int* __restrict__ tapsArr) {
     // register sliding window (see k_blur7): 5x5 blur rows -> 3-row Sobel window.  Blurring the reflect-extended source with
     // symmetric taps equals reflect-extending the blurred image, which is what Sobel's BORDER_REFLECT_101 reads.
@@ -1248,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 5; ++k) taps[k] = (unsigned)tapsArr[k];
     const bool fast = x4 >= 4 && x4 + 8 <= w && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
-    const bool vec = ((w & 3) == 0) && ((dframeBytes & 7) == 0);
+    const bool vec = ((w & 3) == 0) && ((dframeBytes & 15) == 0);
     unsigned hb[5][6];                                     // horizontally blurred rows, columns x4-1 .. x4+4
     int bl[3][6];                                          // blurred rows
 #pragma unroll
@@ -1283,14 +1294,15 @@ __global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ 
                     gx[j] = (short)((A[j + 2] - A[j]) + 2 * (M[j + 2] - M[j]) + (C[j + 2] - C[j]));
                     gy[j] = (short)((C[j] - A[j]) + 2 * (C[j + 1] - A[j + 1]) + (C[j + 2] - A[j + 2]));
                 }
-                short* dxp = (short*)((uint8_t*)dxo + (size_t)b * dframeBytes) + (size_t)y * w + x4;
-                short* dyp = (short*)((uint8_t*)dyo + (size_t)b * dframeBytes) + (size_t)y * w + x4;
-                if (x4 + 3 < w && vec) {
-                    *(short4*)dxp = make_short4(gx[0], gx[1], gx[2], gx[3]);
-                    *(short4*)dyp = make_short4(gy[0], gy[1], gy[2], gy[3]);
-                } else {
+                // interleaved {dx, dy} int16 pairs: the LBD walk fetches both with one dword gather
+                unsigned* op = (unsigned*)((uint8_t*)dxyo + (size_t)b * dframeBytes) + (size_t)y * w + x4;
+                unsigned pk[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (x4 + j < w) { dxp[j] = gx[j]; dyp[j] = gy[j]; }
+                for (int j = 0; j < 4; ++j) pk[j] = ((unsigned)(unsigned short)gx[j]) | ((unsigned)(unsigned short)gy[j] << 16);
+                if (x4 + 3 < w && vec) *(uint4*)op = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (x4 + j < w) op[j] = pk[j];
                 }
             }
         }
@@ -1314,8 +1326,7 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
     const int li = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     if (li >= counts[b]) return;
     const uint8_t* base = ws + (size_t)b * P.frameBytes;
-    const short* dxImg = (const short*)(base + P.offDx);
-    const short* dyImg = (const short*)(base + P.offDy);
+    const unsigned* dxyImg = (const unsigned*)(base + P.offDxy);      // {dx, dy} int16 pairs
     const sslam_keyline kl = kls[(size_t)b * cap + li];
     const int lengthOfLSP = (short)kl.numOfPixels;
     const int halfWidth = (lengthOfLSP - 1) / 2, halfHeight = (LSP_H - 1) / 2;
@@ -1331,25 +1342,25 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
         for (int r = 0; r < lane; ++r) { sx0 = __fsub_rn(sx0, dL1); sy0 = __fadd_rn(sy0, dL0); }
         float sx = sx0, sy = sy0;
         float pL = 0, nL = 0, pO = 0, nO = 0;
-        for (int w0 = 0; w0 < lengthOfLSP; w0 += 4) {
-            // coordinates of four consecutive steps (the float walk itself stays sequential), then the eight gathers together
-            int idx4[4];
+        for (int w0 = 0; w0 < lengthOfLSP; w0 += 8) {
+            // coordinates of eight consecutive steps (the float walk itself stays sequential), then the eight gathers together
+            int idx8[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 int tc = (int)(short)(int)roundf(sx);
                 const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
                 tc = (int)(short)(int)roundf(sy);
                 const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
-                idx4[u] = yCor * realWidth + xCor;
+                idx8[u] = yCor * realWidth + xCor;
                 sx = __fadd_rn(sx, dL0); sy = __fadd_rn(sy, dL1);
             }
-            short dxs[4], dys[4];
+            unsigned g[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { dxs[u] = dxImg[idx4[u]]; dys[u] = dyImg[idx4[u]]; }
+            for (int u = 0; u < 8; ++u) g[u] = dxyImg[idx8[u]];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 if (w0 + u < lengthOfLSP) {
-                    const float dx = (float)dxs[u], dy = (float)dys[u];
+                    const float dx = (float)(short)(g[u] & 0xFFFFu), dy = (float)(short)(g[u] >> 16);
                     const float gDL = __fadd_rn(__fmul_rn(dx, dL0), __fmul_rn(dy, dL1));
                     const float gDO = __fadd_rn(__fmul_rn(dx, dO0), __fmul_rn(dy, dO1));
                     if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
@@ -1524,9 +1535,7 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offFlag = take(sizeof(int) * MAX_SEG);
     P.offNfa = take(sizeof(NfaState) * MAX_SEG);
     P.offMisc = take(sizeof(Misc));
-    P.offBlur5 = take(bpitch * h);                        // sigma-1 blur of the source (LBD)
-    P.offDx = take(sizeof(short) * (size_t)w * h);
-    P.offDy = take(sizeof(short) * (size_t)w * h);
+    P.offDxy = take(sizeof(unsigned) * (size_t)w * h);       // Sobel {dx, dy} of the sigma-1 blur, int16 pairs
     P.offKl = take(sizeof(sslam_keyline) * MAX_SEG);
     P.frameBytes = align_up(off, 4096);
     if (!L->dGtab.p) {   // gradient -> {angle, cos, sin, |g|^2} table (rho depends only on LSD constants)
@@ -1610,8 +1619,13 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     {
         size_t lds = sizeof(unsigned) * QCAP;
         if (const char* e = getenv("SSLAM_LSD_LDS_PAD")) lds = std::max(lds, (size_t)atoi(e));      // experiment knob: cap resident region workgroups per CU
-        if (lds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        { sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st); hipLaunchKernelGGL(k_lsd_regions, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>()); }
+        if (lds > 48 * 1024) {
+            SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st);
+        if (nframes < 1024) hipLaunchKernelGGL(k_lsd_regions<true>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());      // lone waves: shortest chain
+        else hipLaunchKernelGGL(k_lsd_regions<false>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());
     }
     const int evalWaves = nframes >= 1024 ? 1 : nframes >= 64 ? 4 : 16;      // waves per frame walking the NFA evaluations
     const int countWaves = nframes >= 2048 ? 2 : nframes >= 128 ? 8 : 64;    // waves per frame walking the rectangle counts
@@ -1628,7 +1642,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
     // LBD: blur(5, 1) + Sobel fused -> bands
     { sslam::ProfScope _ps(L->ctx, "k_blur_sobel", st); hipLaunchKernelGGL(k_blur_sobel, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride, w, h,
-                       (short*)(ws + P.offDx), (short*)(ws + P.offDy), P.frameBytes, taps + 8); }
+                       (unsigned*)(ws + P.offDxy), P.frameBytes, taps + 8); }
     { sslam::ProfScope _ps(L->ctx, "k_lbd", st); hipLaunchKernelGGL(k_lbd, dim3(std::min(L->maxLines, cap), nframes), dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap); }
     SSLAM_HIP(hipGetLastError());
     L->lastFrames = nframes;

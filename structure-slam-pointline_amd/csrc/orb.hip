@@ -93,10 +93,11 @@ __device__ __forceinline__ unsigned pick2(unsigned d0, unsigned d1, unsigned d2,
 }
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_t pyrFrame, LevelInfo S, LevelInfo D,
                                                 const short4* __restrict__ tabs) {
-    const int b = blockIdx.z;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (y >= D.h || x4 >= D.w) return;
+    const int b = blockIdx.y;
+    const int ngroups = (D.w + 3) >> 2;                 // flattened (row, 4-pixel group) index: full waves whatever the level width
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int y = t / ngroups, x4 = (t - y * ngroups) * 4;
+    if (y >= D.h) return;
     const short4 ty = tabs[D.tabY + y];
     const uint4 ta = *(const uint4*)(tabs + D.tabX + x4), tb = *(const uint4*)(tabs + D.tabX + x4 + 2);
     const int sy0 = min(max((int)ty.x, 0), S.h - 1), sy1 = min(max((int)ty.x + 1, 0), S.h - 1);
@@ -924,7 +925,7 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
         { sslam::ProfScope _ps(o->ctx, "k_copy_level0", st); hipLaunchKernelGGL(k_copy_level0, grd, blk, 0, st, d_images, pitch, image_stride, pyr, P.pyrFrame, w, h, P.L[0].pitch); }
     }
     for (int l = 1; l < P.nlevels; ++l) {
-        dim3 blk(64, 4), grd((P.L[l].w + 255) / 256, (P.L[l].h + 3) / 4, nframes);
+        dim3 blk(256), grd((((P.L[l].w + 3) / 4) * P.L[l].h + 255) / 256, nframes);
         { sslam::ProfScope _ps(o->ctx, "k_resize", st); hipLaunchKernelGGL(k_resize, grd, blk, 0, st, pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short4>()); }
     }
     if (P.nCellsFrame > 0) {
