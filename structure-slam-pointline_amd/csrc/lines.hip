@@ -687,17 +687,41 @@ __device__ NfaGeom nfa_geom(const RectD& rec, int sh) {
 
 // x-range of row y (clipped to the image); a row has seen (y - y0) edge steps, the step taken after
 // row t uses the second slope iff t >= ly (resp. ry).
-__device__ __forceinline__ void nfa_row_range(const NfaGeom& g, int y, int sw, int& xa, int& xb) {
-    // |slope| <= image width, steps <= image height: every product fits 32 bits for images up to 32k x 32k / 2
+template <bool SMALL>
+__device__ __forceinline__ void nfa_row_edges(const NfaGeom& g, int y, long long& lft, long long& rgt) {
     const int steps = y - g.y0;
     int nl2 = 0, nr2 = 0;
     if (steps > 0) {
         nl2 = max(0, y - max(g.ly, g.y0));
         nr2 = max(0, y - max(g.ry, g.y0));
     }
-    const long long lft = (long long)g.mx + (long long)(steps - nl2) * g.fl + (long long)nl2 * g.sl;
-    const long long rgt = (long long)g.mx + (long long)(steps - nr2) * g.fr + (long long)nr2 * g.sr;
+    if (SMALL) {      // images below 32768 x 32768: |slope| < 2^15 and steps < 2^15, every product and sum fits 32 bits
+        lft = g.mx + (steps - nl2) * g.fl + nl2 * g.sl;
+        rgt = g.mx + (steps - nr2) * g.fr + nr2 * g.sr;
+    } else {
+        lft = (long long)g.mx + (long long)(steps - nl2) * g.fl + (long long)nl2 * g.sl;
+        rgt = (long long)g.mx + (long long)(steps - nr2) * g.fr + (long long)nr2 * g.sr;
+    }
+}
+template <bool SMALL>
+__device__ __forceinline__ void nfa_row_range(const NfaGeom& g, int y, int sw, int& xa, int& xb) {
+    long long lft, rgt;
+    nfa_row_edges<SMALL>(g, y, lft, rgt);
     xa = (int)max(lft, 0LL); xb = (int)min(rgt, (long long)sw - 1);
+}
+// upper bound of the (unclipped) row width of a rectangle: the edges are linear in y between the corner rows, so the
+// maximum sits at one of them.  Only used to pick how many lanes share a row.
+__device__ int nfa_max_width(const NfaGeom& g) {
+    int best = 1;
+    const int ys[8] = {g.y0, g.y1, g.ly - 1, g.ly, g.ly + 1, g.ry - 1, g.ry, g.ry + 1};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int y = min(max(ys[i], g.y0), g.y1);
+        long long lft, rgt;
+        nfa_row_edges<false>(g, y, lft, rgt);
+        best = max(best, (int)min(rgt - lft + 1, 1LL << 20));
+    }
+    return best;
 }
 
 // ------------------------------------------------------------------ rect_improve as staged, fully parallel kernels
@@ -750,71 +774,126 @@ __device__ __forceinline__ double align_dist(float aDeg, double theta) {
 // the other with all lanes on the pixels.  Counters are wave-uniform (ballot + popcount), so nothing is reduced at the end.
 constexpr int EVAL_CH = 1024;          // rectangles per item-list chunk (k_nfa_count, k_nfa_eval)
 constexpr int EVAL_REFILL = 16;
-struct CntItem { NfaGeom g; int c, j, pad; double theta, prec, p; };
+struct CntItem { NfaGeom g; int c, j, lg; double theta, prec, p; };      // lg: log2 of the lanes sharing a row
 
-// aligned-point counts of one rectangle for K nested precisions (K = 1: a single tolerance); total = pixels visited
-template <int K>
-__device__ __forceinline__ void count_item(const NfaGeom& g, double theta, const double (&prec)[6], const float* __restrict__ ang, int sw,
+// Pixel walk shared by the two counters below.  A row is shared by 2^lg lanes (lg picked per rectangle from its widest
+// row: tall thin rectangles put 32 rows in flight, flat ones spread one row over the whole wave); each lane owns a
+// contiguous run of the row and the wave steps through the runs twelve pixels at a time.  Every step starts with
+// ballot(pixel exists), which both ends the loop early and counts the rectangle's pixels.
+
+// aligned-point counts of one rectangle for K nested precisions; total = pixels visited
+template <int K, bool SMALL>
+__device__ __forceinline__ void count_item(const NfaGeom& g, int lg, double theta, const double (&prec)[6], const float* __restrict__ ang, int sw,
                                            int lane, int& totalOut, int (&alg)[6]) {
     const int nrows = g.y1 - g.y0 + 1;
-    const int half = lane & 1;
+    const int rowsPer = 64 >> lg, r = lane >> lg, sub = lane & ((1 << lg) - 1);
     int total = 0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) alg[k] = 0;
-    for (int t0 = 0; t0 < nrows; t0 += 32) {
-        const int t = t0 + (lane >> 1);
+    for (int t0 = 0; t0 < nrows; t0 += rowsPer) {
+        const int t = t0 + r;
         int xa = 0, xb = -1; const int y = g.y0 + t;
-        if (t < nrows) nfa_row_range(g, y, sw, xa, xb);
-        const int width = xb - xa + 1;
-        if (width > 0 && half == 0) total += width;
-        const bool wide = width > 24;
-        // narrow rows: the two lanes of a row split it evenly; the wave steps through the longest share
-        const int h0 = (width + 1) >> 1;
-        const int xs = xa + half * h0, xe = half ? xb : xa + h0 - 1;
-        const int mine = (width > 0 && !wide) ? xe - xs + 1 : 0;
-        const int mw = wave_max(mine);
-        if (mw > 0) {
-            const float* row = ang + (size_t)y * sw + xs;
+        if (t < nrows) nfa_row_range<SMALL>(g, y, sw, xa, xb);
+        const int width = max(xb - xa + 1, 0);
+        const int share = (width + (1 << lg) - 1) >> lg;
+        const int xs = xa + sub * share;
+        const int mine = max(min(share, xb - xs + 1), 0);
+        const float* row = ang + (size_t)y * sw + xs;
+        for (int c0 = 0; __ballot(c0 < mine) != 0; c0 += 12) {
             float a[12];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = j < mine ? row[j] : NOTDEF_F;
-            if (mw > 4) {
+            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            if (__ballot(c0 + 4 < mine)) {
 #pragma unroll
-                for (int j = 4; j < 8; ++j) a[j] = j < mine ? row[j] : NOTDEF_F;
+                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
             }
-            if (mw > 8) {
+            if (__ballot(c0 + 8 < mine)) {
 #pragma unroll
-                for (int j = 8; j < 12; ++j) a[j] = j < mine ? row[j] : NOTDEF_F;
+                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
             }
 #pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                if (j < mw) {
-                    const double d = j < mine ? align_dist(a[j], theta) : 1e300;
+            for (int q = 0; q < 12; ++q) {
+                const unsigned long long have = __ballot(c0 + q < mine);
+                if (!have) break;
+                total += __popcll(have);
+                const double d = c0 + q < mine ? align_dist(a[q], theta) : 1e300;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) alg[k] += __popcll(__ballot(d <= prec[k]));
-                }
-            }
-        }
-        unsigned long long wm = __ballot(wide && half == 0);
-        while (wm) {
-            const int src = __ffsll((long long)wm) - 1;
-            wm &= wm - 1;
-            const int wy = __builtin_amdgcn_readlane(y, src), wxa = __builtin_amdgcn_readlane(xa, src), wxb = __builtin_amdgcn_readlane(xb, src);
-            const float* row = ang + (size_t)wy * sw;
-            for (int x0 = wxa; x0 <= wxb; x0 += 128) {
-                const int x = x0 + lane;
-                const float a0 = x <= wxb ? row[x] : NOTDEF_F, a1 = x + 64 <= wxb ? row[x + 64] : NOTDEF_F;
-                const double d0 = align_dist(a0, theta), d1 = align_dist(a1, theta);
-#pragma unroll
-                for (int k = 0; k < K; ++k) alg[k] += __popcll(__ballot(d0 <= prec[k])) + __popcll(__ballot(d1 <= prec[k]));
+                for (int k = 0; k < K; ++k) alg[k] += __popcll(__ballot(d <= prec[k]));
             }
         }
     }
-    totalOut = wave_sum(total);
+    totalOut = total;
+}
+
+// Stages 1-3: the (up to five) candidates of a rectangle differ by half-pixel width / offset steps and share theta and the
+// tolerance, so they are counted in ONE pass over the union of their rows: the angle test runs once per pixel, membership in
+// candidate j is two integer compares against that candidate's own row range (rect_nfa's edge stepping, per candidate).
+template <bool SMALL>
+__device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int nc, int lg, const float* __restrict__ ang, int sw, int lane,
+                                            int (&total)[MAXC], int (&alg)[MAXC]) {
+    const double theta = it5[0].theta, prec = it5[0].prec;
+    NfaGeom g[MAXC];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) g[j] = it5[j < nc ? j : 0].g;
+    int y0u = g[0].y0, y1u = g[0].y1;
+#pragma unroll
+    for (int j = 1; j < MAXC; ++j) if (j < nc) { y0u = min(y0u, g[j].y0); y1u = max(y1u, g[j].y1); }
+    const int nrows = y1u - y0u + 1;
+    const int rowsPer = 64 >> lg, r = lane >> lg, sub = lane & ((1 << lg) - 1);
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) { total[j] = 0; alg[j] = 0; }
+    for (int t0 = 0; t0 < nrows; t0 += rowsPer) {
+        const int t = t0 + r;
+        const int y = y0u + t;
+        int xaj[MAXC], xbj[MAXC];
+        int xa = 0x7fffffff, xb = -1;
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) {
+            xaj[j] = 1; xbj[j] = 0;
+            if (j < nc && t < nrows && y >= g[j].y0 && y <= g[j].y1) {
+                nfa_row_range<SMALL>(g[j], y, sw, xaj[j], xbj[j]);
+                if (xbj[j] >= xaj[j]) { xa = min(xa, xaj[j]); xb = max(xb, xbj[j]); }
+                else { xaj[j] = 1; xbj[j] = 0; }
+            }
+        }
+        const int width = xb >= xa ? xb - xa + 1 : 0;
+        const int share = (width + (1 << lg) - 1) >> lg;
+        const int xs = xa + sub * share;
+        const int mine = width > 0 ? max(min(share, xb - xs + 1), 0) : 0;
+        const float* row = ang + (size_t)y * sw + xs;
+        for (int c0 = 0; __ballot(c0 < mine) != 0; c0 += 12) {
+            float a[12];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            if (__ballot(c0 + 4 < mine)) {
+#pragma unroll
+                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            }
+            if (__ballot(c0 + 8 < mine)) {
+#pragma unroll
+                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            }
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const bool have = c0 + q < mine;
+                if (!__ballot(have)) break;
+                const bool al = have && align_dist(a[q], theta) <= prec;
+                const int x = xs + c0 + q;
+#pragma unroll
+                for (int j = 0; j < MAXC; ++j) {
+                    if (j < nc) {
+                        const bool in = have && x >= xaj[j] && x <= xbj[j];
+                        total[j] += __popcll(__ballot(in));
+                        alg[j] += __popcll(__ballot(in && al));
+                    }
+                }
+            }
+        }
+    }
 }
 
 // stage 0 is merged with the initial evaluation: same rectangle, six precisions (p, p/2 .. p/32); stage 4 likewise has one
-// geometry and five precisions.  Stages 1-3 change the rectangle itself: up to five candidates per rectangle, each an item.
+// geometry and five precisions.  Stages 1-3 change the rectangle itself: up to five candidates per rectangle.
 __global__ __launch_bounds__(64) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
     __shared__ CntItem its[64];
     __shared__ unsigned short act[EVAL_CH];
@@ -829,6 +908,7 @@ __global__ __launch_bounds__(64) void k_nfa_count(uint8_t* __restrict__ ws, LsdP
     const int per = (nCand + gridDim.x - 1) / gridDim.x;
     const int c0 = blockIdx.x * per, c1 = min(c0 + per, nCand);
     const bool nested = stage == 0 || stage == 4;
+    const bool small = sw < 32768 && sh < 32768;
     const int rpb = nested ? 64 : 12;                              // rectangles per batch (stages 1-3: five lanes each)
     for (int chunk = c0; chunk < c1; chunk += EVAL_CH) {
         const int cend = min(chunk + EVAL_CH, c1);
@@ -855,7 +935,12 @@ __global__ __launch_bounds__(64) void k_nfa_count(uint8_t* __restrict__ ws, LsdP
                     else valid = stage_cand(rec, stage, j, r);
                     CntItem& I = its[lane];
                     I.c = c; I.j = valid ? j : -1;
-                    if (valid) { I.g = nfa_geom(r, sh); I.theta = r.theta; I.prec = r.prec; I.p = r.p; }
+                    if (valid) {
+                        I.g = nfa_geom(r, sh); I.theta = r.theta; I.prec = r.prec; I.p = r.p;
+                        const int need = (nfa_max_width(I.g) + (nested ? 0 : 3) + 11) / 12;       // lanes per row so that a run is <= 12 pixels
+                        int lg = 1; while ((1 << lg) < need && lg < 6) ++lg;
+                        I.lg = lg;
+                    }
                 }
                 const unsigned long long vm = __ballot(valid);
                 if (lane < nIt) {
@@ -864,6 +949,24 @@ __global__ __launch_bounds__(64) void k_nfa_count(uint8_t* __restrict__ ws, LsdP
                 }
             }
             __syncthreads();
+            if (!nested) {
+                for (int ri = 0; ri < nr; ++ri) {
+                    const CntItem* it5 = its + ri * MAXC;
+                    int nc = 0;
+#pragma unroll
+                    for (int j = 0; j < MAXC; ++j) nc += it5[j].j >= 0 ? 1 : 0;           // valid candidates form a prefix
+                    if (nc == 0) continue;
+                    int total[MAXC], alg[MAXC];
+                    if (small) count_rect5<true>(it5, nc, it5[0].lg, ang, sw, lane, total, alg);
+                    else count_rect5<false>(it5, nc, it5[0].lg, ang, sw, lane, total, alg);
+                    const int c = it5[0].c;
+                    if (lane < nc) {
+                        const int tj = lane == 0 ? total[0] : lane == 1 ? total[1] : lane == 2 ? total[2] : lane == 3 ? total[3] : total[4];
+                        const int aj = lane == 0 ? alg[0] : lane == 1 ? alg[1] : lane == 2 ? alg[2] : lane == 3 ? alg[3] : alg[4];
+                        st[c].cnt[lane][0] = tj; st[c].cnt[lane][1] = aj;
+                    }
+                }
+            } else
             for (int it = 0; it < nIt; ++it) {
                 const int j = its[it].j;
                 if (j < 0) continue;
@@ -872,18 +975,16 @@ __global__ __launch_bounds__(64) void k_nfa_count(uint8_t* __restrict__ ws, LsdP
                 const int c = its[it].c;
                 double prec[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) prec[k] = stage == 0 ? (k == 0 ? its[it].prec : ldexp(p, -k) * kPI) : stage == 4 ? ldexp(p, -(k + 1)) * kPI : its[it].prec;
+                for (int k = 0; k < 6; ++k) prec[k] = stage == 0 ? (k == 0 ? its[it].prec : ldexp(p, -k) * kPI) : ldexp(p, -(k + 1)) * kPI;
                 int total, alg[6];
-                if (stage == 0) count_item<6>(g, theta, prec, ang, sw, lane, total, alg);
-                else if (stage == 4) count_item<5>(g, theta, prec, ang, sw, lane, total, alg);
-                else count_item<1>(g, theta, prec, ang, sw, lane, total, alg);
+                const int lg = its[it].lg;
+                if (stage == 0) { if (small) count_item<6, true>(g, lg, theta, prec, ang, sw, lane, total, alg); else count_item<6, false>(g, lg, theta, prec, ang, sw, lane, total, alg); }
+                else { if (small) count_item<5, true>(g, lg, theta, prec, ang, sw, lane, total, alg); else count_item<5, false>(g, lg, theta, prec, ang, sw, lane, total, alg); }
                 if (lane == 0) {
-                    if (nested) {
-                        const int K = stage == 0 ? 6 : 5;
+                    const int K = stage == 0 ? 6 : 5;
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) if (k < K) { st[c].cnt[k][0] = total; st[c].cnt[k][1] = alg[k]; }
-                        st[c].nc = K;
-                    } else { st[c].cnt[j][0] = total; st[c].cnt[j][1] = alg[0]; }
+                    for (int k = 0; k < 6; ++k) if (k < K) { st[c].cnt[k][0] = total; st[c].cnt[k][1] = alg[k]; }
+                    st[c].nc = K;
                 }
             }
             __syncthreads();
@@ -1627,10 +1728,13 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         if (nframes < 1024) hipLaunchKernelGGL(k_lsd_regions<true>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());      // lone waves: shortest chain
         else hipLaunchKernelGGL(k_lsd_regions<false>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());
     }
-    const int evalWaves = nframes >= 1024 ? 1 : nframes >= 64 ? 4 : 16;      // waves per frame walking the NFA evaluations
-    const int countWaves = nframes >= 2048 ? 2 : nframes >= 128 ? 8 : 64;    // waves per frame walking the rectangle counts
+    int evalWaves = nframes >= 1024 ? 1 : nframes >= 64 ? 4 : 16;      // waves per frame walking the NFA evaluations
+    int countWaves = nframes >= 2048 ? 1 : nframes >= 128 ? 8 : 64;    // waves per frame walking the rectangle counts
+    if (const char* e = getenv("SSLAM_COUNT_WAVES")) countWaves = std::max(1, atoi(e));
+    if (const char* e = getenv("SSLAM_EVAL_WAVES")) evalWaves = std::max(1, atoi(e));
     for (int stage = 0; stage <= 4; ++stage) {
-        { sslam::ProfScope _ps(L->ctx, "k_nfa_count", st); hipLaunchKernelGGL(k_nfa_count, dim3(countWaves, nframes), dim3(64), 0, st, ws, P, stage); }
+        { static const char* kCountNames[5] = {"k_nfa_count", "k_nfa_count/s1", "k_nfa_count/s2", "k_nfa_count/s3", "k_nfa_count/s4"};
+          sslam::ProfScope _ps(L->ctx, getenv("SSLAM_PROF_STAGES") ? kCountNames[stage] : "k_nfa_count", st); hipLaunchKernelGGL(k_nfa_count, dim3(countWaves, nframes), dim3(64), 0, st, ws, P, stage); }
         if (stage == 0) {
             { sslam::ProfScope _ps(L->ctx, "k_nfa_eval", st); hipLaunchKernelGGL(k_nfa_eval, dim3(evalWaves, nframes), dim3(64), 0, st, ws, P, -1, L->dLgam.as<double>()); }
             { sslam::ProfScope _ps(L->ctx, "k_nfa_accept", st); hipLaunchKernelGGL(k_nfa_accept, dim3(4, nframes), dim3(256), 0, st, ws, P, -1); }
