@@ -575,11 +575,32 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __res
     return n;
 }
 
+// Three fp64 running sums that must be folded strictly in region order (the reference adds point after point).  The wave
+// computes the 64 addends of each sum lane-parallel and parks them in LDS; then lanes 0..2 each walk ONE of the three
+// arrays, so a step of all three chains is one ds_read_b64 + one v_add_f64 (a readlane walk costs nine instructions).
+// acc is live in lanes 0..2 only; ordered_sums_get() broadcasts the results.
+struct OrdSum { double acc; };
+__device__ __forceinline__ void ordered_sums_add(OrdSum& S, double* __restrict__ red, double v0, double v1, double v2, int cnt, int lane) {
+    red[lane] = v0; red[64 + lane] = v1; red[128 + lane] = v2;
+    if (lane < 3) {
+        const double* src = red + lane * 64;
+        double acc = S.acc;
+        int j = 0;
+        for (; j + 4 <= cnt; j += 4) {
+            const double a0 = src[j], a1 = src[j + 1], a2 = src[j + 2], a3 = src[j + 3];
+            acc = acc + a0; acc = acc + a1; acc = acc + a2; acc = acc + a3;
+        }
+        for (; j < cnt; ++j) acc = acc + src[j];
+        S.acc = acc;
+    }
+}
+__device__ __forceinline__ double ordered_sums_get(const OrdSum& S, int which) { return readlane_d(S.acc, which); }
+
 // one wave: region2rect + get_theta.  Loads and per-point products run lane-parallel; the
-// fp64 sums are then folded strictly in region order (readlane walk), extents by min/max.
-__device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __restrict__ pix, double regAngle, double prec, double p, RectD& rec) {
+// fp64 sums are then folded strictly in region order (ordered_sums_add), extents by min/max.
+__device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __restrict__ pix, double regAngle, double prec, double p, RectD& rec, double* __restrict__ red) {
     const int lane = threadIdx.x & 63;
-    double x = 0, y = 0, sum = 0;
+    OrdSum S1; S1.acc = 0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         double fx = 0, fy = 0, wgt = 0;
@@ -589,11 +610,12 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
             wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
             fx = (double)px * wgt; fy = (double)py * wgt;
         }
-        const int cnt = min(64, n - base);
-        for (int j = 0; j < cnt; ++j) { x = x + readlane_d(fx, j); y = y + readlane_d(fy, j); sum = sum + readlane_d(wgt, j); }
+        ordered_sums_add(S1, red, fx, fy, wgt, min(64, n - base), lane);
     }
+    double x = ordered_sums_get(S1, 0), y = ordered_sums_get(S1, 1);
+    const double sum = ordered_sums_get(S1, 2);
     x /= sum; y /= sum;
-    double Ixx = 0, Iyy = 0, Ixy = 0;
+    OrdSum S2; S2.acc = 0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         double a = 0, b = 0, c = 0;
@@ -604,9 +626,9 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
             const double ddx = (double)px - x, ddy = (double)py - y;
             a = ddy * ddy * wgt; b = ddx * ddx * wgt; c = ddx * ddy * wgt;
         }
-        const int cnt = min(64, n - base);
-        for (int j = 0; j < cnt; ++j) { Ixx = Ixx + readlane_d(a, j); Iyy = Iyy + readlane_d(b, j); Ixy = Ixy - readlane_d(c, j); }
+        ordered_sums_add(S2, red, a, b, -c, min(64, n - base), lane);      // Ixy -= c  ==  Ixy += (-c), exactly
     }
+    const double Ixx = ordered_sums_get(S2, 0), Iyy = ordered_sums_get(S2, 1), Ixy = ordered_sums_get(S2, 2);
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
     double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
                                            : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
@@ -1145,6 +1167,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
     Misc* misc = (Misc*)(base + P.offMisc);
     const int sw = P.sw, sh = P.sh;
     RegQ rq; rq.lds = dynLds; rq.glb = (unsigned*)(base + P.offReg);
+    __shared__ double red[3 * 64];                                 // addends of the ordered fp64 sums
     __syncthreads();
     const int nOrd = misc->nDefined;
     const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
@@ -1169,7 +1192,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
             long long t1 = __builtin_readcyclecounter(); cyc0 += t1 - t0;
             if (n < P.minRegSize) continue;
             RectD rec;
-            region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec);
+            region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
             long long t2 = __builtin_readcyclecounter(); cyc1 += t2 - t1;
             // ---- refine (LSD_REFINE_STD part)
             double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
@@ -1178,7 +1201,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                 const int x0 = e0 & 0xFFFF, y0 = e0 >> 16;
                 const double xc = (double)x0, yc = (double)y0;
                 const double ang_c = (double)ang[y0 * sw + x0] * DEG2RAD;
-                double sum = 0, s_sum = 0; int cnt = 0;
+                OrdSum SR; SR.acc = 0; int cnt = 0;
                 for (int bs = 0; bs < n; bs += 64) {
                     const int i = bs + lane;
                     double ad = 0; bool in = false;
@@ -1189,16 +1212,17 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                         pix[id].x = aOrig;                 // NOTUSED again
                         if (dist_d(xc, yc, (double)px, (double)py) < rec.width) { in = true; ad = angle_diff_signed((double)aOrig * DEG2RAD, ang_c); }
                     }
+                    // points outside the radius contribute an exact +0.0 (the sums start at +0 and can never be -0)
                     const unsigned long long mi = __ballot(in);
-                    const int c2 = min(64, n - bs);
-                    for (int j = 0; j < c2; ++j)
-                        if ((mi >> j) & 1ull) { const double a = readlane_d(ad, j); sum = sum + a; s_sum = s_sum + a * a; ++cnt; }
+                    ordered_sums_add(SR, red, in ? ad : 0.0, in ? ad * ad : 0.0, 0.0, min(64, n - bs), lane);
+                    cnt += __popcll(mi);
                 }
+                const double sum = ordered_sums_get(SR, 0), s_sum = ordered_sums_get(SR, 1);
                 const double mean_angle = sum / (double)cnt;
                 const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
                 n = region_grow_m<LAT>(x0, y0, sw, sh, pix, ang, rq, tau, regAngle);
                 if (n < 2) continue;
-                region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec);
+                region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
                 density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
                 if (density < DENSITY_TH) {
                     // reduce_region_radius: sequential swap-with-last removal (the order feeds later sums)
@@ -1221,7 +1245,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                             }
                         }
                         if (n < 2) { good = false; break; }
-                        region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec);
+                        region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
                         density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
                     }
                     if (!good) continue;
