@@ -548,6 +548,8 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __res
             }
         }
         int lastSel = -1;
+        const int nBefore = n;
+        unsigned long long accMask = 0;                    // lanes accepted from this staging, in lane (= acceptance) order
         const double candRad = LAT ? (double)px4.x * DEG2RAD : 0.0;     // isAligned's operand, converted once per staging
         while (true) {
             bool al;
@@ -561,7 +563,8 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __res
             if (!m) break;
             const int sel = __ffsll((long long)m) - 1;       // wave-uniform: the lane reads below are v_readlane, not LDS permutes
             const int selIdx = LAT ? __builtin_amdgcn_readlane(nidx, sel) : __shfl(nidx, sel, 64);
-            if (lane == sel) { pix[nidx].x = USED_F; rq.set(n, (unsigned)xx | ((unsigned)yy << 16)); }
+            if (LAT) accMask |= 1ull << sel;               // lone wave: the used-map / queue stores follow the loop, all lanes at once
+            else if (lane == sel) { pix[nidx].x = USED_F; rq.set(n, (unsigned)xx | ((unsigned)yy << 16)); }
             ++n;
             sumdx = __fadd_rn(sumdx, LAT ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px4.y), sel)) : __shfl(px4.y, sel, 64));
             sumdy = __fadd_rn(sumdy, LAT ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px4.z), sel)) : __shfl(px4.z, sel, 64));
@@ -569,6 +572,7 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __res
             if (nidx == selIdx) cand = false;              // the accepted pixel is now USED for every later visitor
             lastSel = sel;
         }
+        if (LAT && accMask != 0 && ((accMask >> lane) & 1ull)) { pix[nidx].x = USED_F; rq.set(nBefore + mbcnt(accMask), (unsigned)xx | ((unsigned)yy << 16)); }
         i += np;
     }
     regAngleOut = regAngle;
@@ -1225,6 +1229,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                 region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
                 density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
                 if (density < DENSITY_TH) {
+                    const long long tr0 = __builtin_readcyclecounter();
                     // reduce_region_radius: sequential swap-with-last removal (the order feeds later sums)
                     const double r1 = (rec.x1 - xc) * (rec.x1 - xc) + (rec.y1 - yc) * (rec.y1 - yc);
                     const double r2 = (rec.x2 - xc) * (rec.x2 - xc) + (rec.y2 - yc) * (rec.y2 - yc);
@@ -1248,6 +1253,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                         region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
                         density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
                     }
+                    cyc3 += __builtin_readcyclecounter() - tr0;
                     if (!good) continue;
                 }
             }

@@ -9,7 +9,7 @@ for rep in range(2):
 out = (C.c_longlong*8)()
 fe.lib().sslam_lines_debug_cycles(ex.h, 0, out)
 tot = out[4]
-print('nfa count %.1f%% math %.1f%%' % (100*out[5]/tot, 100*out[6]/tot)); print('lines', len(kl), 'cycles: grow %.1f%% rect %.1f%% refine %.1f%% improve %.1f%% total %d (%.2f ms @2.4GHz?)' % (100*out[0]/tot, 100*out[1]/tot, 100*out[2]/tot, 100*out[3]/tot, tot, tot/2.4e6))
+print('nfa count %.1f%% math %.1f%%' % (100*out[5]/tot, 100*out[6]/tot)); print('lines', len(kl), 'cycles: grow %.1f%% rect %.1f%% refine %.1f%% (of which reduce_region_radius %.1f%%) total %d (%.2f ms @2.4GHz?)' % (100*out[0]/tot, 100*out[1]/tot, 100*out[2]/tot, 100*out[3]/tot, tot, tot/2.4e6))
 import time
 t=time.time(); 
 for _ in range(5): ex(img)
