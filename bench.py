@@ -48,13 +48,14 @@ def alg_bytes_per_frame(w, h, nkp, nln):
         "k_fast_cells": sP,                                 # FAST read of every level
         "k_octree": 0,                                      # candidate lists only (latency-bound, no image traffic)
         "k_describe": 2 * sP + nkp * (2 * 961 + 32 + 28),   # blur r/w folded into the per-keypoint patch stage + patch reads + outputs
-        "k_blur<3>": 2 * w * h,                             # LSD pre-blur r/w
+        "k_blur7": 2 * w * h,                               # LSD pre-blur r/w
         "k_resize_exact": w * h + s08,
         "k_lsd_grad": s08 + 8 * s08,                        # gradient read, fp32 angle + int magnitude write
         "k_lsd_hist": 8 * s08, "k_lsd_scan": 0, "k_lsd_scatter": 4 * s08,    # ordered-list build
         "k_lsd_regions": 5 * s08,                           # region-grow reads (angle + magnitude + used)
+        "k_nfa_count": 0, "k_nfa_eval": 0, "k_nfa_accept": 0, "k_nfa_finish": 0,      # rectangle validation: angle-map rows under ~400 rectangles, cache resident
         "k_keylines": nln * (16 + 68 + 24),
-        "k_blur_sobel": w * h + 4 * w * h,                  # fused LBD pre-blur + Sobel: source read, 2 x s16 write
+        "k_blur_sobel": w * h + 4 * w * h,                  # fused LBD pre-blur + Sobel: source read, {dx,dy} s16 pair write
         "k_lbd": nln * 63 * 100 * 4 + nln * 100,            # band reads at a nominal 100-px line + descriptor
         "k_search_init": 2 * 32 * nkp + 8 * nkp, "k_knn2_batch": 2 * 32 * nkp + 16 * nkp,
         "k_line_match": 2 * 32 * nln + 16 * nln,
@@ -209,8 +210,9 @@ def main():
             ach = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
             traffic = None
             try:      # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), scaled to this batch
-                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"][name]
-                traffic = (pt["fetch_bytes_per_frame"] + pt["write_bytes_per_frame"]) * B
+                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                pt = pj["kernels"][name]      # fetch side x2: gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, calibrated in profiles/)
+                traffic = (pt["fetch_bytes_per_frame"] * pj.get("fetch_correction", 1.0) + pt["write_bytes_per_frame"]) * B
             except Exception:
                 pass
             out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

@@ -215,6 +215,14 @@ int sslam_lines_extract_batch_dev(sslam_lines* ln, const uint8_t* d_images, int 
 /* Self-test of the table-based exact integer division of the NFA binomial tail against the hardware IEEE division:
  * `pairs` random quotients a/b with 1 <= a,b < n; *mismatches_out must come back 0. */
 int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, long long* mismatches_out);
+/* Self-test of the guarded fp32 early-exit test used in the NFA tail loop (the reference's `err < tolerance * ...` test,
+ * opencv lsd.cpp nfa(), reached from src/ExtractLineSegment.cpp:38-43): random inputs, half on the decision boundary.
+ * disagree_out must be 0; ambiguous_out = cases that fall back to the fp64 expression. */
+int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long long* disagree_out, long long* ambiguous_out);
+/* Profiling aid (no reference counterpart): reads a known number of bytes in one of the library's two dominant access
+ * patterns (mode 0: 16 B/lane coalesced stream, mode 1: scattered 16-B gathers) so that rocprofv3's FETCH_SIZE can be
+ * calibrated on this device (tools/fetch_probe.py, profiles/README.md). */
+int sslam_selftest_fetch_probe(sslam_ctx* ctx, size_t bytes, int mode, long long* bytes_requested_out);
 /* Stage tap: all LSD segments (x1,y1,x2,y2 float) of frame `frame` of the last batch, before top-N. */
 int sslam_lines_debug_segments(sslam_lines* ln, int frame, float* seg_out, int cap, int* n_out);
 

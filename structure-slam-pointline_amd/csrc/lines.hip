@@ -442,6 +442,51 @@ __device__ __forceinline__ int tail_test_cheap(double term, double m, int q, dou
     if (errLo >= rhsHi) return 0;
     return -1;
 }
+
+// Self-test of tail_test_cheap (sslam_selftest_tail_test): random (term, m, q, bin_tail), half of them steered onto the
+// decision boundary err ~ rhs, counted as disagreeing when the cheap verdict differs from the fp64 expression.
+__global__ void k_selftest_tail(unsigned long long seed, int iters, double logNT, unsigned long long* __restrict__ out) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned long long bad = 0, amb = 0;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (double)(x >> 11) * 0x1p-53; };
+    for (int it = 0; it < iters; ++it) {
+        const double m = exp2(-(2.81 + rnd() * rnd() * 38.0));
+        const double u = rnd();
+        const int q = 1 + (int)(u * u * u * 200000.0);
+        const double term = exp2(-rnd() * 1000.0);
+        double bin_tail = term * (1.0 + exp2(rnd() * 30.0 - 10.0));
+        if (it & 1) {       // onto the boundary: err = 0.1 * A * bin_tail, +- up to 1e-3 relative
+            const double err = term * ((1 - pow(m, (double)q)) / (1 - m) - 1);
+            if (err > 0) {
+                const double bt0 = err / (0.1 * 13.0), A0 = fabs(-log10(bt0) - logNT);
+                if (A0 > 0) bin_tail = err / (0.1 * A0) * (1.0 + (rnd() - 0.5) * 2e-3 * rnd());
+            }
+        }
+        const int dec = tail_test_cheap(term, m, q, bin_tail, logNT);
+        const double err = term * ((1 - pow(m, (double)q)) / (1 - m) - 1);
+        const bool ref = err < 0.1 * fabs(-log10(bin_tail) - logNT) * bin_tail;
+        if (dec < 0) ++amb; else if ((dec > 0) != ref) ++bad;
+    }
+    if (bad) atomicAdd(out, bad);
+    if (amb) atomicAdd(out + 1, amb);
+}
+
+// FETCH_SIZE calibration probes (tools/fetch_probe.py under rocprofv3 --pmc FETCH_SIZE): a known number of bytes read
+// in the two access patterns this library uses most, 16 B/lane coalesced streams and scattered 16-B gathers.
+__global__ void k_probe_stream16(const float4* __restrict__ buf, size_t nElem, float* __restrict__ sink) {
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nElem; i += (size_t)gridDim.x * blockDim.x) acc += buf[i].x;
+    if (acc == 12345.678f) *sink = acc;
+}
+__global__ void k_probe_gather16(const float4* __restrict__ buf, size_t nElem, int iters, float* __restrict__ sink) {
+    unsigned long long x = 0x9E3779B97F4A7C15ull * (1 + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x);
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        acc += buf[(size_t)(x >> 8) % nElem].x;
+    }
+    if (acc == 12345.678f) *sink = acc;
+}
 // LineSegmentDetectorImpl::nfa() split for lane-dynamic scheduling: nfa_setup() covers everything before the binomial-tail
 // loop, tail_block() advances the loop by up to eight terms, and the caller finishes with -log10(bin_tail) - logNT.
 struct TailState { double term, bin_tail, p_term; int n, i; };           // i = next term index (k+1 .. n)
@@ -1866,5 +1911,48 @@ extern "C" int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, 
     SSLAM_HIP(hipStreamSynchronize(ctx->stream));
     (void)hipFree(tab); (void)hipFree(bad);
     *mismatches_out = (long long)h;
+    return SSLAM_OK;
+}
+
+// Self-test of the guarded fp32 early-exit test of the NFA tail (tests/test_lines_gpu.py): `samples` random inputs, half
+// of them on the decision boundary.  disagree_out = decided cases whose verdict differs from the fp64 expression (must be
+// 0); ambiguous_out = cases handed to the fp64 expression.
+extern "C" int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long long* disagree_out, long long* ambiguous_out) {
+    if (!ctx || samples <= 0 || !disagree_out || !ambiguous_out) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    unsigned long long* d = nullptr;
+    SSLAM_HIP(hipMalloc(&d, 2 * sizeof(unsigned long long)));
+    SSLAM_HIP(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+    const int threads = 256 * 1024, iters = (int)((samples + threads - 1) / threads);
+    const double logNT = 5 * (std::log10(512.0) + std::log10(384.0)) / 2 + std::log10(11.0);
+    hipLaunchKernelGGL(k_selftest_tail, dim3(1024), dim3(256), 0, ctx->stream, 0xABCDEF12345ull, iters, logNT, d);
+    unsigned long long h[2] = {0, 0};
+    SSLAM_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SSLAM_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d);
+    *disagree_out = (long long)h[0]; *ambiguous_out = (long long)h[1];
+    return SSLAM_OK;
+}
+
+// FETCH_SIZE calibration: reads `bytes` of a freshly allocated buffer once with 16 B/lane coalesced loads (mode 0) or
+// issues bytes/16 scattered 16-B gathers over it (mode 1).  bytes_requested_out = 16 x loads issued.
+extern "C" int sslam_selftest_fetch_probe(sslam_ctx* ctx, size_t bytes, int mode, long long* bytes_requested_out) {
+    if (!ctx || bytes < (1u << 20) || (mode != 0 && mode != 1) || !bytes_requested_out) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    float4* buf = nullptr; float* sink = nullptr;
+    SSLAM_HIP(hipMalloc(&buf, bytes));
+    SSLAM_HIP(hipMalloc(&sink, sizeof(float)));
+    SSLAM_HIP(hipMemsetAsync(buf, 0, bytes, ctx->stream));
+    const size_t nElem = bytes / sizeof(float4);
+    if (mode == 0) {
+        hipLaunchKernelGGL(k_probe_stream16, dim3(8192), dim3(256), 0, ctx->stream, buf, nElem, sink);
+        *bytes_requested_out = (long long)(nElem * 16);
+    } else {
+        const int threads = 8192 * 256, iters = (int)std::max<size_t>(1, nElem / threads);
+        hipLaunchKernelGGL(k_probe_gather16, dim3(8192), dim3(256), 0, ctx->stream, buf, nElem, iters, sink);
+        *bytes_requested_out = (long long)threads * iters * 16;
+    }
+    SSLAM_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(buf); (void)hipFree(sink);
     return SSLAM_OK;
 }

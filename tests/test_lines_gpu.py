@@ -80,6 +80,17 @@ def test_exact_division_selftest(fe, ctx):
     assert rc == 0 and bad.value == 0, bad.value
 
 
+def test_tail_test_selftest(fe, ctx):
+    """the NFA tail's early-exit test is decided from fp32 estimates inside guard bands; a decided case must never
+    differ from the fp64 expression, and undecided cases (which re-run that expression) must stay rare"""
+    import ctypes as C
+    bad, amb = C.c_longlong(-1), C.c_longlong(-1)
+    n = 500_000_000
+    rc = fe.lib().sslam_selftest_tail_test(ctx.h, C.c_longlong(n), C.byref(bad), C.byref(amb))
+    assert rc == 0 and bad.value == 0, (bad.value, amb.value)
+    assert 0 < amb.value < 0.2 * n, amb.value        # half of the samples sit within 1e-3 of the boundary
+
+
 def test_lines_huge_regions(fe, ctx, oracle):
     """regions far larger than the 1024-point LDS queue continue in global memory"""
     n, bad = _cmp_lines(fe, ctx, oracle, ramp_frame(), 200)
