@@ -173,6 +173,33 @@ int sslam_search_by_projection(sslam_ctx* ctx, int kind, int mode, const void* f
                                float nnratio, int th_dist, int check_orientation,
                                int32_t* assigned_out, int* nmatches_out);
 
+/* ---- device-resident frames (no single reference function: replaces the re-upload of
+ * Frame::mvKeysUn / mDescriptors / mvKeylinesUn / mLdesc (include/Frame.h:155-189) around every matcher call) -------------
+ * A frame handle owns device copies of one Frame's features (kind 0: sslam_keypoint rows, 1: sslam_keyline rows), their
+ * 32-byte descriptors, optionally mvuRight, and the image bounds {mnMinX, mnMaxX, mnMinY, mnMaxY}. */
+typedef struct sslam_frame sslam_frame;
+int sslam_frame_upload(sslam_ctx* ctx, int kind, const void* feats, const uint8_t* desc, int n, const float* uright, const float bounds[4],
+                       sslam_frame** out);
+/* Snapshot (device to device) of what the last sslam_orb_extract / sslam_lines_extract call on this handle produced:
+ * Frame::ExtractORB / ExtractLSD (src/Frame.cc:150-161) followed by the matchers without any upload. */
+int sslam_frame_from_orb(sslam_orb* orb, const float bounds[4], sslam_frame** out);
+int sslam_frame_from_lines(sslam_lines* lines, const float bounds[4], sslam_frame** out);
+void sslam_frame_destroy(sslam_frame* frame);
+int sslam_frame_count(const sslam_frame* frame);
+/* sslam_search_by_projection with the frame's features taken from the handle (same kernels, same results). */
+int sslam_search_by_projection_frame(sslam_ctx* ctx, const sslam_frame* frame, int mode, const uint8_t* occupied,
+                                     const sslam_proj_query* queries, const uint8_t* qdesc, int nq,
+                                     float nnratio, int th_dist, int check_orientation, int32_t* assigned_out, int* nmatches_out);
+/* sslam_hamming_knn2 between the descriptors of two frame handles (cv::BFMatcher::knnMatch(d1, d2, m, 2),
+ * src/LSDmatcher.cpp:150,261,293,336,387). */
+int sslam_hamming_knn2_frames(sslam_ctx* ctx, const sslam_frame* query, const sslam_frame* train, int32_t* idx, int32_t* dist);
+
+/* MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:247-312, and MapLine::ComputeDistinctiveDescriptors,
+ * src/MapLine.cpp:246-317, for nsets observation sets at once: set s owns rows ptr[s]..ptr[s+1]
+ * of desc (ptr[0] = 0).  best_out[s] = index inside the set of the descriptor with the least median Hamming distance to
+ * the rest (median = sorted[int(0.5*(N-1))], first row wins ties), -1 for an empty set.  Sets are limited to 1024 rows. */
+int sslam_distinctive_descriptors(sslam_ctx* ctx, const uint8_t* desc, const int32_t* ptr, int nsets, int32_t* best_out);
+
 /* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches), src/ORBmatcher.cc:159-291.
  * The DBoW2 vocabulary transform stays on the host (the vocabulary file is not part of the reference tree); the
  * matcher takes the two FeatureVectors as CSR lists over the nodes BOTH frames contain, ascending node id:

@@ -307,6 +307,27 @@ using namespace orc;
 
 extern "C" {
 
+// MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:276-306 (MapLine: src/MapLine.cpp:280-311): N x N Hamming
+// distances, per row sort and take sorted[0.5*(N-1)] (index truncated to int), first row with the smallest median.
+// The MapLine variant fills the matrix with cv::norm(NORM_HAMMING), the same popcount distance.
+static int distinctive_index(const uint8_t* d, int n) {
+    if (n <= 0) return -1;
+    std::vector<std::vector<int>> D(n, std::vector<int>(n, 0));
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) { const int v = descriptor_distance(d + (size_t)i * 32, d + (size_t)j * 32); D[i][j] = v; D[j][i] = v; }
+    int bestMedian = INT_MAX, bestIdx = 0;
+    for (int i = 0; i < n; ++i) {
+        std::vector<int> v(D[i]);
+        std::sort(v.begin(), v.end());
+        const int median = v[(size_t)(0.5 * (n - 1))];
+        if (median < bestMedian) { bestMedian = median; bestIdx = i; }
+    }
+    return bestIdx;
+}
+int orc_distinctive(const uint8_t* desc, const int32_t* ptr, int nsets, int32_t* best) {
+    for (int s = 0; s < nsets; ++s) best[s] = distinctive_index(desc + (size_t)ptr[s] * 32, ptr[s + 1] - ptr[s]);
+    return 0;
+}
+
 int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
 
 int orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist) { knn2(q, nq, t, nt, idx, dist); return 0; }

@@ -68,6 +68,16 @@ struct sslam_ctx {
     int num_cus = 0;
 };
 
+// device-resident copy of one Frame's features: keypoints or keylines, 32-byte descriptors, optional
+// mvuRight, image bounds.  Matchers that take a frame handle skip the per-call upload.
+struct sslam_frame {
+    sslam_ctx* ctx = nullptr;
+    int kind = 0, n = 0;           // kind 0: sslam_keypoint rows, 1: sslam_keyline rows
+    float bounds[4] = {0, 0, 0, 0};
+    bool hasUright = false;
+    sslam::DevBuf feats, desc, uright;
+};
+
 namespace sslam {
 // RAII stage timer: records a HIP event pair on the launch stream around one kernel launch.
 struct ProfScope {

@@ -1628,6 +1628,7 @@ struct sslam_lines {
     LsdPlan plan;
     DevBuf dWs, dTabs, dTaps, dLgam, dGtab;
     int wsFrames = 0, lastFrames = 0;
+    int lastN = -1;                 // lines of the last sslam_lines_extract (still resident in dKl/dDesc)
     DevBuf dImg, dKl, dDesc, dFn, dCounts;
     HostPinned hOut;
     bool constsUploaded = false;
@@ -1862,6 +1863,7 @@ extern "C" int sslam_lines_extract(sslam_lines* L, const uint8_t* gray, int w, i
     if (hm.overflow) { set_error("sslam_lines_extract: more than %d candidate rectangles in one frame", MAX_SEG); return SSLAM_ERR_UNSUPPORTED; }
     const int n = *(int*)hp;
     *n_out = n;
+    L->lastN = n;
     if (n > cap) { set_error("sslam_lines_extract: %d lines exceed caller capacity %d", n, cap); return SSLAM_ERR_CAPACITY; }
     memcpy(kl_out, hk, sizeof(sslam_keyline) * (size_t)n);
     memcpy(ldesc_out, hd, 32 * (size_t)n);
@@ -1955,4 +1957,13 @@ extern "C" int sslam_selftest_fetch_probe(sslam_ctx* ctx, size_t bytes, int mode
     SSLAM_HIP(hipStreamSynchronize(ctx->stream));
     (void)hipFree(buf); (void)hipFree(sink);
     return SSLAM_OK;
+}
+
+// Device-resident frame handle of the last sslam_lines_extract call (keylines + LBD descriptors), see sslam_frame_from_orb.
+int sslam_frame_from_device(sslam_ctx* ctx, int kind, const void* d_feats, const uint8_t* d_desc, int n, const float bounds[4], sslam_frame** out);
+extern "C" int sslam_frame_from_lines(sslam_lines* L, const float bounds[4], sslam_frame** out) {
+    if (!L || !bounds || !out) { set_error("sslam_frame_from_lines: invalid arguments"); return SSLAM_ERR_INVALID; }
+    if (L->lastN < 0) { set_error("sslam_frame_from_lines: no sslam_lines_extract call to snapshot"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(L->ctx->mu);
+    return sslam_frame_from_device(L->ctx, 1, L->dKl.p, L->dDesc.as<uint8_t>(), L->lastN, bounds, out);
 }

@@ -529,6 +529,51 @@ __global__ __launch_bounds__(256) void k_line_match(const uint8_t* __restrict__ 
 // =============================================================== host side
 static hipStream_t pick(sslam_ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
 
+// ------------------------------------------------------------------ distinctive descriptor of an observation set
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312) == MapLine::ComputeDistinctiveDescriptors
+// (src/MapLine.cpp:246-317): all-pairs Hamming distances of the N observed descriptors, per row the median
+// `sorted[int(0.5*(N-1))]`, and the FIRST row with the smallest median wins.  One wave per set: the descriptors sit in LDS,
+// lane i owns row i (rows i+64, ... in turn); the k-th smallest of a row is found by bisection on the value
+// (distances are integers in [0,256]: nine counting passes) instead of sorting.
+constexpr int DISTINCT_MAXN = 1024;
+__global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ ptr, int nsets, int32_t* __restrict__ best) {
+    __shared__ __align__(16) unsigned d[DISTINCT_MAXN * 8];
+    const int lane = threadIdx.x;
+    for (int sIdx = blockIdx.x; sIdx < nsets; sIdx += gridDim.x) {
+        const int beg = ptr[sIdx], n = ptr[sIdx + 1] - beg;
+        if (n <= 0) { if (lane == 0) best[sIdx] = -1; continue; }
+        __syncthreads();
+        for (int i = lane; i < n * 8; i += 64) d[i] = ((const unsigned*)(desc + (size_t)beg * 32))[i];
+        __syncthreads();
+        const int k = (int)(0.5 * (double)(n - 1));              // index of the median in the sorted row
+        unsigned long long bestKey = ~0ull;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            int lo = 0, hi = 256;                                  // smallest v with #{j : dist(i,j) <= v} >= k+1
+            if (i < n) {
+                unsigned a[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) a[w] = d[i * 8 + w];
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    int cnt = 0;
+                    for (int j = 0; j < n; ++j) {
+                        int dist = 0;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) dist += __popc(a[w] ^ d[j * 8 + w]);
+                        cnt += dist <= mid ? 1 : 0;
+                    }
+                    if (cnt >= k + 1) hi = mid; else lo = mid + 1;
+                }
+                const unsigned long long key = ((unsigned long long)(unsigned)lo << 32) | (unsigned)i;
+                bestKey = key < bestKey ? key : bestKey;
+            }
+        }
+        bestKey = wave_min_u64(bestKey);
+        if (lane == 0) best[sIdx] = (int)(unsigned)bestKey;
+    }
+}
+
 extern "C" int sslam_hamming_knn2_dev(sslam_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx, int32_t* d_dist, void* stream) {
     if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_idx || !d_dist))) { set_error("sslam_hamming_knn2_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
     if (nq == 0) return SSLAM_OK;
@@ -694,6 +739,34 @@ extern "C" int sslam_line_match(sslam_ctx* ctx, const uint8_t* l1, int n1, const
     return SSLAM_OK;
 }
 
+// shared body of the projection matchers: features already on the device (d_feats / d_desc / d_uright), per-call inputs staged here
+static int search_proj_core(sslam_ctx* ctx, int kind, int mode, const void* d_feats, const uint8_t* d_desc, int n, const float bounds[4],
+                            const float* d_uright, const uint8_t* occupied, const sslam_proj_query* queries, const uint8_t* qdesc, int nq,
+                            float nnratio, int th_dist, int check_orientation, int32_t* assigned_out, int* nmatches_out) {
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t oO = 0, oQ = oO + al((size_t)n), oQD = oQ + al(sizeof(sslam_proj_query) * (size_t)nq), oA = oQD + al(32 * (size_t)nq), oN = oA + al(4 * (size_t)n),
+           oS = oN + 256, total = oS + al(4 * (2 * (size_t)n + 2 * (size_t)nq));
+    int rc;
+    if ((rc = ctx->scratch[6].ensure(total))) return rc;
+    uint8_t* B = ctx->scratch[6].as<uint8_t>();
+    if (occupied) SSLAM_HIP(hipMemcpyAsync(B + oO, occupied, (size_t)n, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oQ, queries, sizeof(sslam_proj_query) * (size_t)nq, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oQD, qdesc, 32 * (size_t)nq, hipMemcpyHostToDevice, st));
+    ProjArgs A;
+    A.kind = kind; A.mode = mode; A.feats = (const uint8_t*)d_feats; A.desc = d_desc; A.n = n;
+    A.minX = bounds[0]; A.maxX = bounds[1]; A.minY = bounds[2]; A.maxY = bounds[3];
+    A.uright = d_uright; A.occIn = occupied ? B + oO : nullptr;
+    A.q = (const sslam_proj_query*)(B + oQ); A.qdesc = B + oQD; A.nq = nq; A.nnratio = nnratio; A.thDist = th_dist; A.checkOri = check_orientation;
+    A.assigned = (int*)(B + oA); A.nmatches = (int*)(B + oN); A.scratch = (int*)(B + oS);
+    { sslam::ProfScope _ps(ctx, "k_search_proj", st); hipLaunchKernelGGL(k_search_proj, dim3(1), dim3(64), 0, st, A); }
+    SSLAM_HIP(hipGetLastError());
+    SSLAM_HIP(hipMemcpyAsync(assigned_out, B + oA, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + oN, sizeof(int), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    return SSLAM_OK;
+}
+
 extern "C" int sslam_search_by_projection(sslam_ctx* ctx, int kind, int mode, const void* feats, const uint8_t* desc, int n, const float bounds[4],
                                           const float* uright, const uint8_t* occupied, const sslam_proj_query* queries, const uint8_t* qdesc, int nq,
                                           float nnratio, int th_dist, int check_orientation, int32_t* assigned_out, int* nmatches_out) {
@@ -709,28 +782,99 @@ extern "C" int sslam_search_by_projection(sslam_ctx* ctx, int kind, int mode, co
     hipStream_t st = ctx->stream;
     const size_t fsz = kind == 0 ? sizeof(sslam_keypoint) : sizeof(sslam_keyline);
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    size_t oF = 0, oD = oF + al(fsz * n), oU = oD + al(32 * (size_t)n), oO = oU + al(4 * (size_t)n), oQ = oO + al((size_t)n),
-           oQD = oQ + al(sizeof(sslam_proj_query) * (size_t)nq), oA = oQD + al(32 * (size_t)nq), oN = oA + al(4 * (size_t)n),
-           oS = oN + 256, total = oS + al(4 * (2 * (size_t)n + 2 * (size_t)nq));
+    const size_t oF = 0, oD = oF + al(fsz * n), oU = oD + al(32 * (size_t)n), total = oU + al(4 * (size_t)n);
     int rc;
-    if ((rc = ctx->scratch[6].ensure(total))) return rc;
-    uint8_t* B = ctx->scratch[6].as<uint8_t>();
+    if ((rc = ctx->scratch[7].ensure(total))) return rc;
+    uint8_t* B = ctx->scratch[7].as<uint8_t>();
     SSLAM_HIP(hipMemcpyAsync(B + oF, feats, fsz * n, hipMemcpyHostToDevice, st));
     SSLAM_HIP(hipMemcpyAsync(B + oD, desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
     if (uright) SSLAM_HIP(hipMemcpyAsync(B + oU, uright, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-    if (occupied) SSLAM_HIP(hipMemcpyAsync(B + oO, occupied, (size_t)n, hipMemcpyHostToDevice, st));
-    SSLAM_HIP(hipMemcpyAsync(B + oQ, queries, sizeof(sslam_proj_query) * (size_t)nq, hipMemcpyHostToDevice, st));
-    SSLAM_HIP(hipMemcpyAsync(B + oQD, qdesc, 32 * (size_t)nq, hipMemcpyHostToDevice, st));
-    ProjArgs A;
-    A.kind = kind; A.mode = mode; A.feats = B + oF; A.desc = B + oD; A.n = n;
-    A.minX = bounds[0]; A.maxX = bounds[1]; A.minY = bounds[2]; A.maxY = bounds[3];
-    A.uright = uright ? (const float*)(B + oU) : nullptr; A.occIn = occupied ? B + oO : nullptr;
-    A.q = (const sslam_proj_query*)(B + oQ); A.qdesc = B + oQD; A.nq = nq; A.nnratio = nnratio; A.thDist = th_dist; A.checkOri = check_orientation;
-    A.assigned = (int*)(B + oA); A.nmatches = (int*)(B + oN); A.scratch = (int*)(B + oS);
-    { sslam::ProfScope _ps(ctx, "k_search_proj", st); hipLaunchKernelGGL(k_search_proj, dim3(1), dim3(64), 0, st, A); }
-    SSLAM_HIP(hipGetLastError());
-    SSLAM_HIP(hipMemcpyAsync(assigned_out, B + oA, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-    SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + oN, sizeof(int), hipMemcpyDeviceToHost, st));
+    return search_proj_core(ctx, kind, mode, B + oF, B + oD, n, bounds, uright ? (const float*)(B + oU) : nullptr, occupied, queries, qdesc, nq,
+                            nnratio, th_dist, check_orientation, assigned_out, nmatches_out);
+}
+
+// ---- device-resident frames
+extern "C" int sslam_frame_upload(sslam_ctx* ctx, int kind, const void* feats, const uint8_t* desc, int n, const float* uright, const float bounds[4],
+                                  sslam_frame** out) {
+    if (!ctx || !out || (kind != 0 && kind != 1) || n < 0 || n >= (1 << 19) || !bounds || (n > 0 && (!feats || !desc))) {
+        set_error("sslam_frame_upload: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    sslam_frame* f = new sslam_frame();
+    f->ctx = ctx; f->kind = kind; f->n = n; f->hasUright = uright != nullptr;
+    for (int i = 0; i < 4; ++i) f->bounds[i] = bounds[i];
+    const size_t fsz = kind == 0 ? sizeof(sslam_keypoint) : sizeof(sslam_keyline);
+    int rc = SSLAM_OK;
+    if ((rc = f->feats.ensure(std::max<size_t>(fsz * n, 256))) || (rc = f->desc.ensure(std::max<size_t>(32 * (size_t)n, 256))) ||
+        (uright && (rc = f->uright.ensure(std::max<size_t>(4 * (size_t)n, 256))))) { sslam_frame_destroy(f); return rc; }
+    if (n > 0) {
+        SSLAM_HIP(hipMemcpyAsync(f->feats.p, feats, fsz * n, hipMemcpyHostToDevice, ctx->stream));
+        SSLAM_HIP(hipMemcpyAsync(f->desc.p, desc, 32 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        if (uright) SSLAM_HIP(hipMemcpyAsync(f->uright.p, uright, 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        SSLAM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *out = f;
+    return SSLAM_OK;
+}
+
+// adopt device buffers the extractors already hold (sslam_frame_from_orb / sslam_frame_from_lines): device-to-device snapshot
+int sslam_frame_from_device(sslam_ctx* ctx, int kind, const void* d_feats, const uint8_t* d_desc, int n, const float bounds[4], sslam_frame** out) {
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    sslam_frame* f = new sslam_frame();
+    f->ctx = ctx; f->kind = kind; f->n = n;
+    for (int i = 0; i < 4; ++i) f->bounds[i] = bounds[i];
+    const size_t fsz = kind == 0 ? sizeof(sslam_keypoint) : sizeof(sslam_keyline);
+    int rc;
+    if ((rc = f->feats.ensure(std::max<size_t>(fsz * n, 256))) || (rc = f->desc.ensure(std::max<size_t>(32 * (size_t)n, 256)))) { sslam_frame_destroy(f); return rc; }
+    if (n > 0) {
+        SSLAM_HIP(hipMemcpyAsync(f->feats.p, d_feats, fsz * n, hipMemcpyDeviceToDevice, ctx->stream));
+        SSLAM_HIP(hipMemcpyAsync(f->desc.p, d_desc, 32 * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+        SSLAM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *out = f;
+    return SSLAM_OK;
+}
+
+extern "C" void sslam_frame_destroy(sslam_frame* f) {
+    if (!f) return;
+    if (f->ctx) (void)hipSetDevice(f->ctx->device);
+    f->feats.release(); f->desc.release(); f->uright.release();
+    delete f;
+}
+
+extern "C" int sslam_frame_count(const sslam_frame* f) { return f ? f->n : 0; }
+
+extern "C" int sslam_search_by_projection_frame(sslam_ctx* ctx, const sslam_frame* frame, int mode, const uint8_t* occupied,
+                                                const sslam_proj_query* queries, const uint8_t* qdesc, int nq,
+                                                float nnratio, int th_dist, int check_orientation, int32_t* assigned_out, int* nmatches_out) {
+    if (!ctx || !frame || frame->ctx != ctx || (mode != 0 && mode != 1) || (frame->kind == 1 && mode == 1) || nq < 0 || !nmatches_out ||
+        (frame->n > 0 && !assigned_out) || (nq > 0 && (!queries || !qdesc))) {
+        set_error("sslam_search_by_projection_frame: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    *nmatches_out = 0;
+    for (int i = 0; i < frame->n; ++i) assigned_out[i] = -1;
+    if (frame->n == 0 || nq == 0) return SSLAM_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    return search_proj_core(ctx, frame->kind, mode, frame->feats.p, frame->desc.as<uint8_t>(), frame->n, frame->bounds,
+                            frame->hasUright ? frame->uright.as<float>() : nullptr, occupied, queries, qdesc, nq, nnratio, th_dist, check_orientation,
+                            assigned_out, nmatches_out);
+}
+
+extern "C" int sslam_hamming_knn2_frames(sslam_ctx* ctx, const sslam_frame* q, const sslam_frame* t, int32_t* idx, int32_t* dist) {
+    if (!ctx || !q || !t || q->ctx != ctx || t->ctx != ctx || (q->n > 0 && (!idx || !dist))) { set_error("sslam_hamming_knn2_frames: invalid arguments"); return SSLAM_ERR_INVALID; }
+    if (q->n == 0) return SSLAM_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc;
+    if ((rc = ctx->scratch[6].ensure(16 * (size_t)q->n))) return rc;
+    int32_t* dI = ctx->scratch[6].as<int32_t>();
+    int32_t* dD = dI + 2 * (size_t)q->n;
+    if ((rc = sslam_hamming_knn2_dev(ctx, q->desc.as<uint8_t>(), q->n, t->desc.as<uint8_t>(), t->n, dI, dD, (void*)st))) return rc;
+    SSLAM_HIP(hipMemcpyAsync(idx, dI, 8 * (size_t)q->n, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(dist, dD, 8 * (size_t)q->n, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
     return SSLAM_OK;
 }
@@ -771,6 +915,37 @@ extern "C" int sslam_orb_search_by_bow(sslam_ctx* ctx, const sslam_keypoint* kf_
     SSLAM_HIP(hipGetLastError());
     SSLAM_HIP(hipMemcpyAsync(assigned_out, B + o[9], 4 * (size_t)nf, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + o[10], sizeof(int), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    return SSLAM_OK;
+}
+
+
+// MapPoint / MapLine ::ComputeDistinctiveDescriptors for `nsets` observation sets at once: set s owns descriptor rows
+// ptr[s] .. ptr[s+1] of `desc`; best_out[s] = index (inside the set) of the descriptor with the least median distance to
+// the rest, first such row on ties, -1 for an empty set.
+extern "C" int sslam_distinctive_descriptors(sslam_ctx* ctx, const uint8_t* desc, const int32_t* ptr, int nsets, int32_t* best_out) {
+    if (!ctx || nsets < 0 || (nsets > 0 && (!ptr || !best_out))) { set_error("sslam_distinctive_descriptors: invalid arguments"); return SSLAM_ERR_INVALID; }
+    if (nsets == 0) return SSLAM_OK;
+    const int total = ptr[nsets];
+    if (ptr[0] != 0 || total < 0 || (total > 0 && !desc)) { set_error("sslam_distinctive_descriptors: invalid set offsets"); return SSLAM_ERR_INVALID; }
+    for (int s2 = 0; s2 < nsets; ++s2) {
+        const int n = ptr[s2 + 1] - ptr[s2];
+        if (n < 0) { set_error("sslam_distinctive_descriptors: offsets must be non-decreasing"); return SSLAM_ERR_INVALID; }
+        if (n > DISTINCT_MAXN) { set_error("sslam_distinctive_descriptors: a set of %d descriptors exceeds the supported %d", n, DISTINCT_MAXN); return SSLAM_ERR_UNSUPPORTED; }
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t oD = 0, oP = oD + al(32 * (size_t)std::max(total, 1)), oB = oP + al(4 * (size_t)(nsets + 1)), tot = oB + al(4 * (size_t)nsets);
+    int rc;
+    if ((rc = ctx->scratch[6].ensure(tot))) return rc;
+    uint8_t* B = ctx->scratch[6].as<uint8_t>();
+    if (total > 0) SSLAM_HIP(hipMemcpyAsync(B + oD, desc, 32 * (size_t)total, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oP, ptr, 4 * (size_t)(nsets + 1), hipMemcpyHostToDevice, st));
+    { sslam::ProfScope _ps(ctx, "k_distinctive", st); hipLaunchKernelGGL(k_distinctive, dim3(std::min(nsets, 4096)), dim3(64), 0, st, B + oD, (const int32_t*)(B + oP), nsets, (int32_t*)(B + oB)); }
+    SSLAM_HIP(hipGetLastError());
+    SSLAM_HIP(hipMemcpyAsync(best_out, B + oB, 4 * (size_t)nsets, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
     return SSLAM_OK;
 }

@@ -695,6 +695,7 @@ struct sslam_orb {
     HostPinned hImg, hOut;
     int wsFrames = 0;
     int lastFrames = 0;
+    int lastN = -1;                 // keypoints of the last sslam_orb_extract (still resident in dKp/dDesc)
     bool constsUploaded = false;
 };
 
@@ -979,6 +980,7 @@ extern "C" int sslam_orb_extract(sslam_orb* o, const uint8_t* gray, int w, int h
     SSLAM_HIP(hipStreamSynchronize(st));
     int n = *(int*)hp;
     *n_out = n;
+    o->lastN = n;
     if (n > cap) { set_error("sslam_orb_extract: %d keypoints exceed caller capacity %d", n, cap); return SSLAM_ERR_CAPACITY; }
     memcpy(kp_out, hp + 64, sizeof(sslam_keypoint) * (size_t)n);
     memcpy(desc_out, hp + 64 + sizeof(sslam_keypoint) * (size_t)icap, 32 * (size_t)n);
@@ -1018,4 +1020,15 @@ extern "C" int sslam_orb_debug_candidates(sslam_orb* o, int frame, int level, in
     }
     *n_out = n;
     return SSLAM_OK;
+}
+
+// Keep the features of the last sslam_orb_extract call on the device as a frame handle (device-to-device snapshot of the
+// keypoints + descriptors the extractor still holds): the Frame that ExtractORB just filled never has to be uploaded
+// again for SearchByProjection / knn matching.
+int sslam_frame_from_device(sslam_ctx* ctx, int kind, const void* d_feats, const uint8_t* d_desc, int n, const float bounds[4], sslam_frame** out);
+extern "C" int sslam_frame_from_orb(sslam_orb* o, const float bounds[4], sslam_frame** out) {
+    if (!o || !bounds || !out) { set_error("sslam_frame_from_orb: invalid arguments"); return SSLAM_ERR_INVALID; }
+    if (o->lastN < 0) { set_error("sslam_frame_from_orb: no sslam_orb_extract call to snapshot"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(o->ctx->mu);
+    return sslam_frame_from_device(o->ctx, 0, o->dKp.p, o->dDesc.as<uint8_t>(), o->lastN, bounds, out);
 }

@@ -128,6 +128,16 @@ class Context:
                                            _p(assigned), C.byref(nm)))
         return assigned, nm.value
 
+    def distinctive_descriptors(self, desc, ptr):
+        """MapPoint/MapLine::ComputeDistinctiveDescriptors for every set ptr[s]..ptr[s+1] (src/MapPoint.cc:247-312)."""
+        desc = np.ascontiguousarray(desc, np.uint8); ptr = np.ascontiguousarray(ptr, np.int32)
+        best = np.full(len(ptr) - 1, -2, np.int32)
+        _chk(lib().sslam_distinctive_descriptors(self.h, _p(desc), _p(ptr), len(ptr) - 1, _p(best)))
+        return best
+
+    def frame_upload(self, kind, feats, desc, uright=None, bounds=(0.0, 640.0, 0.0, 480.0)):
+        return Frame(self, kind=kind, feats=feats, desc=desc, uright=uright, bounds=bounds)
+
     def line_match(self, l1, l2, gate_scale=0.5, ratio_mode=False):
         l1 = np.ascontiguousarray(l1, np.uint8); l2 = np.ascontiguousarray(l2, np.uint8)
         cap = max(len(l1), 1)
@@ -136,6 +146,45 @@ class Context:
         _chk(lib().sslam_line_match(self.h, _p(l1), len(l1), _p(l2), len(l2), C.c_double(gate_scale), int(bool(ratio_mode)),
                                     _p(pairs), cap, C.byref(n), C.byref(mad), C.byref(mad12)))
         return pairs[:n.value].copy(), mad.value, mad12.value
+
+
+class Frame:
+    """Device-resident features of one Frame (sslam_frame_*): upload once, or snapshot what an extractor just produced."""
+
+    def __init__(self, ctx, kind=0, feats=None, desc=None, uright=None, bounds=(0.0, 640.0, 0.0, 480.0), orb=None, lines=None):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        b = (C.c_float * 4)(*bounds)
+        if orb is not None:
+            _chk(lib().sslam_frame_from_orb(orb.h, b, C.byref(self.h)))
+        elif lines is not None:
+            _chk(lib().sslam_frame_from_lines(lines.h, b, C.byref(self.h)))
+        else:
+            feats = np.ascontiguousarray(feats); desc = np.ascontiguousarray(desc, np.uint8)
+            ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+            _chk(lib().sslam_frame_upload(ctx.h, int(kind), _p(feats), _p(desc), len(feats), _p(ur), b, C.byref(self.h)))
+
+    def __len__(self):
+        return int(lib().sslam_frame_count(self.h))
+
+    def search_by_projection(self, mode, queries, qdesc, occupied=None, nnratio=0.8, th_dist=100, check_orientation=True):
+        queries = np.ascontiguousarray(queries, PQ_DTYPE); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        n = len(self)
+        assigned = np.full(n, -1, np.int32); nm = C.c_int(0)
+        occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        _chk(lib().sslam_search_by_projection_frame(self.ctx.h, self.h, int(mode), _p(occ), _p(queries), _p(qdesc), len(queries),
+                                                    C.c_float(nnratio), int(th_dist), int(bool(check_orientation)), _p(assigned), C.byref(nm)))
+        return assigned, nm.value
+
+    def knn2(self, train):
+        n = len(self)
+        idx = np.full((n, 2), -1, np.int32); dist = np.full((n, 2), -1, np.int32)
+        _chk(lib().sslam_hamming_knn2_frames(self.ctx.h, self.h, train.h, _p(idx), _p(dist)))
+        return idx, dist
+
+    def close(self):
+        if self.h:
+            lib().sslam_frame_destroy(self.h); self.h = C.c_void_p()
 
 
 class OrbExtractor:

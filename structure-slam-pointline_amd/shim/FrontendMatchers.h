@@ -35,6 +35,11 @@ int SearchLinesByProjection(const std::vector<cv::line_descriptor::KeyLine> &key
 // cv::BFMatcher(NORM_HAMMING,false).knnMatch(q,t,m,2) as used by every LSDmatcher entry point.
 void KnnMatch2(const cv::Mat &query, const cv::Mat &train, std::vector<int> &idx /*nq*2*/, std::vector<int> &dist /*nq*2*/);
 
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:276-306) / MapLine::ComputeDistinctiveDescriptors
+// (src/MapLine.cpp:280-311): index of the observed descriptor with the least median Hamming distance to the others
+// (replaces the N x N loop + per-row sort; `BestIdx = sslam_shim::DistinctiveIndex(vDescriptors);`).
+int DistinctiveIndex(const std::vector<cv::Mat> &vDescriptors);
+
 // LSDmatcher::SerachForInitialize / SearchForTriangulation (gate_scale 0.5 / 0.1) and, with ratioMode,
 // SearchByProjection(KF,F) / SearchByDescriptor (src/LSDmatcher.cpp:143-183,257-362,382-415).
 int LineMatch(const cv::Mat &ldesc1, const cv::Mat &ldesc2, double gateScale, bool ratioMode, std::vector<std::pair<int,int> > &matches);

@@ -149,6 +149,16 @@ void KnnMatch2(const cv::Mat &q, const cv::Mat &t, std::vector<int> &idx, std::v
     std::vector<uint8_t> a = rows32(q), b = rows32(t);
     check(sslam_hamming_knn2(G.get(), a.data(), q.rows, b.data(), t.rows, idx.data(), dist.data()));
 }
+int DistinctiveIndex(const std::vector<cv::Mat> &vDescriptors) {
+    const int n = (int)vDescriptors.size();
+    if (n == 0) return 0;                                   // the reference returns before reaching the loop
+    std::vector<uint8_t> d((size_t)n * 32);
+    for (int i = 0; i < n; ++i) memcpy(&d[(size_t)i * 32], vDescriptors[i].ptr(0), 32);
+    const int32_t ptr[2] = {0, n};
+    int32_t best = 0;
+    check(sslam_distinctive_descriptors(G.get(), d.data(), ptr, 1, &best));
+    return best;
+}
 int LineMatch(const cv::Mat &l1, const cv::Mat &l2, double gateScale, bool ratioMode, std::vector<std::pair<int,int> > &matches) {
     matches.clear();
     if (l1.rows == 0 || l2.rows < 2) return 0;       // UB in the reference (src/LSDmatcher.cpp:167); defined as no matches

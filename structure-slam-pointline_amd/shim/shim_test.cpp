@@ -52,8 +52,11 @@ int main(int argc, char** argv) {
     dump(out + "_m12.bin", m12.data(), m12.size());
     std::vector<int> lmf; for (auto& p : lm) { lmf.push_back(p.first); lmf.push_back(p.second); }
     dump(out + "_lm.bin", lmf.data(), lmf.size());
-    int meta[6] = {(int)k2.size(), (int)l2.size(), nm, nlm, emptyOk, ext->GetLevels()};
-    dump(out + "_meta.bin", meta, 6);
+    // MapPoint::ComputeDistinctiveDescriptors over the first rows of the ORB descriptors (src/MapPoint.cc:276-306)
+    std::vector<cv::Mat> obs; for (int i = 0; i < std::min(d2.rows, 37); ++i) obs.push_back(d2.row(i));
+    const int bestIdx = sslam_shim::DistinctiveIndex(obs);
+    int meta[7] = {(int)k2.size(), (int)l2.size(), nm, nlm, emptyOk, ext->GetLevels(), bestIdx};
+    dump(out + "_meta.bin", meta, 7);
     std::printf("shim_test: %zu keypoints, %zu lines, %d ORB matches, %d line matches\n", k2.size(), l2.size(), nm, nlm);
     delete ext;
     return 0;

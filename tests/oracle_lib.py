@@ -139,7 +139,13 @@ def _orc_match_methods():
                                       len(ptr_kf) - 1, _p(idx_kf), _p(idx_f), C.c_float(nnratio), int(bool(check_orientation)), _p(assigned))
         return assigned, nm
 
-    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow):
+    def distinctive(self, desc, ptr):
+        desc = np.ascontiguousarray(desc, np.uint8); ptr = np.ascontiguousarray(ptr, np.int32)
+        best = np.zeros(len(ptr) - 1, np.int32)
+        self.L.orc_distinctive(_p(desc), _p(ptr), len(ptr) - 1, _p(best))
+        return best
+
+    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, distinctive):
         setattr(Oracle, f.__name__, f)
 
 

@@ -145,3 +145,74 @@ def test_search_by_bow(fe, ctx, oracle, seed, ori, ratio):
     oa, on = oracle.search_by_bow(kp1, d1, valid, kp2, d2, pk, pf, ik, jf, ratio, ori)
     assert on > 30 and n == on
     np.testing.assert_array_equal(a, oa)
+
+
+# ---- device-resident frames: same matchers, features uploaded once or never
+@pytest.mark.parametrize("mode", [0, 1])
+def test_frame_handle_search_by_projection(fe, ctx, oracle, mode):
+    rng = np.random.default_rng(77 + mode)
+    cur = synth_frame(2003); prev = warp_prev(cur)
+    kp1, d1 = oracle.orb_extract(prev, 1000)
+    scales = oracle.orb_params()[0]
+    ex = fe.OrbExtractor(ctx, 1000)
+    kp2, d2 = ex(cur)                                   # ExtractORB ...
+    fr = fe.Frame(ctx, orb=ex)                          # ... its features stay on the device
+    up = ctx.frame_upload(0, kp2, d2)                   # the same features uploaded once from the host
+    assert len(fr) == len(kp2) == len(up)
+    q = _proj_queries(fe, rng, kp1, 0, mode, scales)
+    occ = (rng.random(len(kp2)) < 0.05).astype(np.uint8)
+    oa, on = oracle.search_by_projection(0, mode, kp2, d2, q, d1, occ, None, 0.8, 100, True)
+    for f in (fr, up):
+        a, n = f.search_by_projection(mode, q, d1, occ, 0.8, 100, True)
+        assert on > 50 and n == on
+        np.testing.assert_array_equal(a, oa)
+    ex(prev)                                            # a later extraction must not disturb the snapshot
+    a, n = fr.search_by_projection(mode, q, d1, occ, 0.8, 100, True)
+    np.testing.assert_array_equal(a, oa)
+    fr.close(); up.close(); ex.close()
+
+
+def test_frame_handle_lines_and_knn2(fe, ctx, oracle):
+    rng = np.random.default_rng(9)
+    cur = synth_frame(2000); prev = warp_prev(cur)
+    lx = fe.LineExtractor(ctx, 200)
+    kl1, ld1, _ = lx(prev); f1 = fe.Frame(ctx, lines=lx)
+    kl2, ld2, _ = lx(cur); f2 = fe.Frame(ctx, lines=lx)
+    assert len(f1) == len(kl1) and len(f2) == len(kl2)
+    idx, dist = f1.knn2(f2)                             # BFMatcher::knnMatch(d1, d2, m, 2) on resident descriptors
+    oi, od = oracle.knn2(ld1, ld2)
+    np.testing.assert_array_equal(idx, oi); np.testing.assert_array_equal(dist, od)
+    q = _proj_queries(fe, rng, kl1, 1, 0, None)
+    occ = (rng.random(len(kl2)) < 0.05).astype(np.uint8)
+    a, n = f2.search_by_projection(0, q, ld1, occ, 0.6, 100, True)
+    oa, on = oracle.search_by_projection(1, 0, kl2, ld2, q, ld1, occ, None, 0.6, 100, True)
+    assert on > 10 and n == on
+    np.testing.assert_array_equal(a, oa)
+    f1.close(); f2.close(); lx.close()
+
+
+# ---- MapPoint / MapLine ::ComputeDistinctiveDescriptors
+def test_distinctive_descriptors(ctx, oracle):
+    rng = np.random.default_rng(31)
+    sizes = [1, 2, 3, 4, 5, 17, 64, 65, 130, 0, 257, 2, 1024]
+    sets = []
+    for n in sizes:
+        base = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+        d = np.repeat(base, n, axis=0)
+        if n:
+            flips = rng.random((n, 256)) < rng.uniform(0.02, 0.3, (n, 1))      # observations of one point: noisy copies
+            d = d ^ np.packbits(flips, axis=1)
+        sets.append(d)
+    sets.append(np.repeat(rng.integers(0, 256, (1, 32), dtype=np.uint8), 9, axis=0))     # all equal: first row wins
+    desc = np.concatenate(sets); ptr = np.concatenate([[0], np.cumsum([len(x) for x in sets])]).astype(np.int32)
+    got = ctx.distinctive_descriptors(desc, ptr)
+    want = oracle.distinctive(desc, ptr)
+    np.testing.assert_array_equal(got, want)
+    assert got[sizes.index(0)] == -1 and got[-1] == 0
+
+
+def test_distinctive_descriptors_limits(fe, ctx):
+    import ctypes as C
+    d = np.zeros((1025, 32), np.uint8); ptr = np.array([0, 1025], np.int32); best = np.zeros(1, np.int32)
+    rc = fe.lib().sslam_distinctive_descriptors(ctx.h, d.ctypes.data_as(C.c_void_p), ptr.ctypes.data_as(C.c_void_p), 1, best.ctypes.data_as(C.c_void_p))
+    assert rc != 0 and b"1024" in fe.lib().sslam_last_error()

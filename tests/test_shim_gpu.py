@@ -41,3 +41,5 @@ def test_cpp_shim_end_to_end(oracle):
     opairs, _, _ = oracle.line_match(l1[1], old, 0.5, False)
     assert meta[3] == len(opairs)
     np.testing.assert_array_equal(lm, opairs)
+    nobs = min(len(odesc), 37)                                   # MapPoint::ComputeDistinctiveDescriptors through the shim
+    assert meta[6] == oracle.distinctive(odesc[:nobs], np.array([0, nobs], np.int32))[0]
