@@ -194,6 +194,18 @@ int sslam_search_by_projection_frame(sslam_ctx* ctx, const sslam_frame* frame, i
  * src/LSDmatcher.cpp:150,261,293,336,387). */
 int sslam_hamming_knn2_frames(sslam_ctx* ctx, const sslam_frame* query, const sslam_frame* train, int32_t* idx, int32_t* dist);
 
+/* The candidate search of the Fuse family on a device-resident keyframe:
+ *   ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th)            src/ORBmatcher.cc:828-960   chi2_mode 1 (stereo 7.8 / mono 5.99 gates, :913-936)
+ *   ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, th, vpReplacePoint) :962-1103 chi2_mode 0
+ *   LSDmatcher::Fuse(KeyFrame*, const vector<MapLine*>&, th)             src/LSDmatcher.cpp:417-548  chi2_mode 0, keyline frame
+ * One sslam_proj_query per projected map point / line: u,v (and u2,v2 for lines), radius = th*mvScaleFactors[pred], ur,
+ * min_level = pred-1, max_level = pred, valid.  best_idx_out[q] = the feature with the smallest descriptor distance in the
+ * window (first in KeyFrame::GetFeaturesInArea / GetLinesInArea order on ties, src/KeyFrame.cc:610-683), -1 if none;
+ * best_dist_out[q] = that distance (INT_MAX if none).  inv_level_sigma2 = KeyFrame::mvInvLevelSigma2 (chi2_mode 1 only).
+ * The `bestDist <= TH_LOW` test and the Replace / AddObservation bookkeeping stay with the caller, in query order. */
+int sslam_fuse_search(sslam_ctx* ctx, const sslam_frame* keyframe, int chi2_mode, const float* inv_level_sigma2, int nlevels,
+                      const sslam_proj_query* queries, const uint8_t* qdesc, int nq, int32_t* best_idx_out, int32_t* best_dist_out);
+
 /* MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:247-312, and MapLine::ComputeDistinctiveDescriptors,
  * src/MapLine.cpp:246-317, for nsets observation sets at once: set s owns rows ptr[s]..ptr[s+1]
  * of desc (ptr[0] = 0).  best_out[s] = index inside the set of the descriptor with the least median Hamming distance to

@@ -255,6 +255,46 @@ static int search_by_projection(int kind, int mode, const void* feats, const uin
     return nmatches;
 }
 
+// The candidate search inside the Fuse family, one independent best-match per projected map point / line:
+//   kind 0, chi2 1: ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th)          src/ORBmatcher.cc:828-960  (:897-948)
+//   kind 0, chi2 0: ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, ..., th, vpReplacePoint)  src/ORBmatcher.cc:962-1103 (:1055-1080)
+//   kind 1        : LSDmatcher::Fuse(KeyFrame*, const vector<MapLine*>&, th)           src/LSDmatcher.cpp:417-548 (:497-523)
+// KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:610-649) has no level filter; the level test [pred-1, pred] is Fuse's own.
+// The projection / visibility tests and the Replace / AddObservation bookkeeping on (bestIdx, bestDist) stay with the caller.
+static void fuse_search(int kind, int chi2, const void* feats, const uint8_t* desc, int n, const float bounds[4], const float* uright,
+                        const float* invLevelSigma2, const ProjQuery* q, const uint8_t* qdesc, int nq, int32_t* bestIdxOut, int32_t* bestDistOut) {
+    const KPm* kps = (const KPm*)feats; const KLm* kls = (const KLm*)feats;
+    FrameGrid* g = nullptr;
+    if (kind == 0) { g = new FrameGrid(); g->build(kps, n, bounds); }
+    for (int iq = 0; iq < nq; ++iq) {
+        const ProjQuery& Q = q[iq];
+        bestIdxOut[iq] = -1; bestDistOut[iq] = INT_MAX;
+        if (!Q.valid) continue;
+        std::vector<int> ind = kind == 0 ? g->in_area(Q.u, Q.v, Q.radius, -1, -1) : lines_in_area(kls, n, Q.u, Q.v, Q.u2, Q.v2, Q.radius, -1, -1);
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int idx : ind) {
+            const int lvl = kind == 0 ? kps[idx].octave : kls[idx].octave;
+            if (lvl < Q.minLevel || lvl > Q.maxLevel) continue;
+            if (kind == 0 && chi2) {
+                const float kpx = kps[idx].x, kpy = kps[idx].y;
+                const float ex = Q.u - kpx, ey = Q.v - kpy;
+                if (uright && uright[idx] >= 0) {
+                    const float er = Q.ur - uright[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * invLevelSigma2[lvl] > 7.8) continue;
+                } else {
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * invLevelSigma2[lvl] > 5.99) continue;
+                }
+            }
+            const int dist = descriptor_distance(qdesc + (size_t)iq * 32, desc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        bestIdxOut[iq] = bestIdx; bestDistOut[iq] = bestDist;
+    }
+    delete g;
+}
+
 // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), src/ORBmatcher.cc:159-291.  The DBoW2 vocabulary
 // (an LFS pointer in the reference tree) only decides WHICH features share a node; the matcher consumes the two
 // FeatureVectors, passed here as CSR lists over the shared nodes in ascending node id (the merge walk of :188-253).
@@ -346,6 +386,12 @@ int orc_search_by_projection(int kind, int mode, const void* feats, const uint8_
                              const uint8_t* occupied, const void* q, const uint8_t* qdesc, int nq, float nnratio, int th_dist, int check_ori,
                              int32_t* assigned) {
     return search_by_projection(kind, mode, feats, desc, n, bounds, uright, occupied, (const ProjQuery*)q, qdesc, nq, nnratio, th_dist, check_ori != 0, assigned);
+}
+
+int orc_fuse_search(int kind, int chi2, const void* feats, const uint8_t* desc, int n, const float* bounds, const float* uright,
+                    const float* inv_level_sigma2, const void* q, const uint8_t* qdesc, int nq, int32_t* best_idx, int32_t* best_dist) {
+    fuse_search(kind, chi2, feats, desc, n, bounds, uright, inv_level_sigma2, (const ProjQuery*)q, qdesc, nq, best_idx, best_dist);
+    return 0;
 }
 
 int orc_search_by_bow(const void* kpKF, const uint8_t* dKF, const uint8_t* validKF, const void* kpF, const uint8_t* dF, int nF,

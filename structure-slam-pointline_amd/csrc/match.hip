@@ -529,6 +529,78 @@ __global__ __launch_bounds__(256) void k_line_match(const uint8_t* __restrict__ 
 // =============================================================== host side
 static hipStream_t pick(sslam_ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
 
+// ------------------------------------------------------------------ Fuse: independent best match per projected point / line
+// ORBmatcher::Fuse (src/ORBmatcher.cc:897-948 with the chi-square gates, :1055-1080 without) and LSDmatcher::Fuse
+// (src/LSDmatcher.cpp:497-523): every query keeps the candidate with the smallest Hamming distance, the first one in
+// KeyFrame::GetFeaturesInArea / GetLinesInArea order on ties.  Queries do not interact, so one wave takes one query and scans
+// the keyframe's features lane-parallel; the candidate order travels in the low bits of the min-reduction key.
+struct FuseArgs {
+    int kind, chi2;
+    const void* feats; const uint8_t* desc; int n;
+    float minX, maxX, minY, maxY;
+    const float* uright; const float* invSigma2; int nlevels;
+    const sslam_proj_query* q; const uint8_t* qdesc; int nq;
+    int* bestIdx; int* bestDist;
+};
+__global__ __launch_bounds__(64) void k_fuse_search(FuseArgs A) {
+    const int lane = threadIdx.x;
+    const sslam_keypoint* kps = (const sslam_keypoint*)A.feats;
+    const sslam_keyline* kls = (const sslam_keyline*)A.feats;
+    const float invW = __fdiv_rn((float)GRID_COLS, __fsub_rn(A.maxX, A.minX));
+    const float invH = __fdiv_rn((float)GRID_ROWS, __fsub_rn(A.maxY, A.minY));
+    for (int iq = blockIdx.x; iq < A.nq; iq += gridDim.x) {
+        const sslam_proj_query Q = A.q[iq];
+        unsigned long long b = ~0ull;
+        if (Q.valid) {
+            const uint4 q0 = ((const uint4*)(A.qdesc + (size_t)iq * 32))[0], q1 = ((const uint4*)(A.qdesc + (size_t)iq * 32))[1];
+            for (int i = lane; i < A.n; i += 64) {
+                int key = i, lvl;
+                if (A.kind == 0) {
+                    const sslam_keypoint kp = kps[i];
+                    const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, A.minX), invW));
+                    const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, A.minY), invH));
+                    if (!(px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS)) continue;      // not in the grid at all
+                    key = ((px * GRID_ROWS + py) << 19) | i;
+                    const float dx = __fsub_rn(kp.x, Q.u), dy = __fsub_rn(kp.y, Q.v);
+                    if (!(fabsf(dx) < Q.radius && fabsf(dy) < Q.radius)) continue;
+                    lvl = kp.octave;
+                    if (lvl < Q.min_level || lvl > Q.max_level) continue;
+                    if (A.chi2) {
+                        const float ex = __fsub_rn(Q.u, kp.x), ey = __fsub_rn(Q.v, kp.y);
+                        const float inv = (lvl >= 0 && lvl < A.nlevels) ? A.invSigma2[lvl] : 0.f;
+                        const float ur = A.uright ? A.uright[i] : -1.f;
+                        if (ur >= 0) {
+                            const float er = __fsub_rn(Q.ur, ur);
+                            const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                            if ((double)__fmul_rn(e2, inv) > 7.8) continue;
+                        } else {
+                            const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                            if ((double)__fmul_rn(e2, inv) > 5.99) continue;
+                        }
+                    }
+                } else {
+                    const sslam_keyline kl = kls[i];
+                    const double mxp = 0.5 * (double)__fadd_rn(Q.u, Q.u2) - (double)kl.pt_x, myp = 0.5 * (double)__fadd_rn(Q.v, Q.v2) - (double)kl.pt_y;
+                    const float distance = (float)(mxp * mxp + myp * myp);
+                    if (distance > __fmul_rn(Q.radius, Q.radius)) continue;
+                    const float slope = __fsub_rn(__fdiv_rn(__fsub_rn(Q.v, Q.v2), __fsub_rn(Q.u, Q.u2)), kl.angle);
+                    if ((double)slope > (double)Q.radius * 0.01) continue;
+                    lvl = kl.octave;
+                    if (lvl < Q.min_level || lvl > Q.max_level) continue;
+                }
+                const uint4* tp = (const uint4*)(A.desc + (size_t)i * 32);
+                const unsigned long long kk = ((unsigned long long)hamming256(q0, q1, tp[0], tp[1]) << 32) | (unsigned)key;
+                b = kk < b ? kk : b;
+            }
+        }
+        b = wave_min_u64(b);
+        if (lane == 0) {
+            A.bestIdx[iq] = b == ~0ull ? -1 : (int)(b & 0x7FFFF);
+            A.bestDist[iq] = b == ~0ull ? 0x7fffffff : (int)(b >> 32);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ distinctive descriptor of an observation set
 // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312) == MapLine::ComputeDistinctiveDescriptors
 // (src/MapLine.cpp:246-317): all-pairs Hamming distances of the N observed descriptors, per row the median
@@ -946,6 +1018,43 @@ extern "C" int sslam_distinctive_descriptors(sslam_ctx* ctx, const uint8_t* desc
     { sslam::ProfScope _ps(ctx, "k_distinctive", st); hipLaunchKernelGGL(k_distinctive, dim3(std::min(nsets, 4096)), dim3(64), 0, st, B + oD, (const int32_t*)(B + oP), nsets, (int32_t*)(B + oB)); }
     SSLAM_HIP(hipGetLastError());
     SSLAM_HIP(hipMemcpyAsync(best_out, B + oB, 4 * (size_t)nsets, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    return SSLAM_OK;
+}
+
+// The candidate search of ORBmatcher::Fuse (both overloads) and LSDmatcher::Fuse on a device-resident keyframe: per query the
+// feature with the smallest descriptor distance inside the window (first in GetFeaturesInArea / GetLinesInArea order on ties),
+// -1 / INT_MAX when the window holds no admissible feature.  The caller applies `bestDist <= TH_LOW` and the Replace /
+// AddObservation bookkeeping in query order, exactly as the reference does after its inner loop.
+extern "C" int sslam_fuse_search(sslam_ctx* ctx, const sslam_frame* kf, int chi2_mode, const float* inv_level_sigma2, int nlevels,
+                                 const sslam_proj_query* queries, const uint8_t* qdesc, int nq, int32_t* best_idx_out, int32_t* best_dist_out) {
+    if (!ctx || !kf || kf->ctx != ctx || (chi2_mode != 0 && chi2_mode != 1) || nq < 0 || (nq > 0 && (!queries || !qdesc || !best_idx_out || !best_dist_out)) ||
+        (chi2_mode == 1 && (kf->kind != 0 || !inv_level_sigma2 || nlevels <= 0 || nlevels > 64))) {
+        set_error("sslam_fuse_search: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    for (int i = 0; i < nq; ++i) { best_idx_out[i] = -1; best_dist_out[i] = 0x7fffffff; }
+    if (nq == 0 || kf->n == 0) return SSLAM_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t oQ = 0, oQD = oQ + al(sizeof(sslam_proj_query) * (size_t)nq), oS = oQD + al(32 * (size_t)nq), oI = oS + 256, oD = oI + al(4 * (size_t)nq),
+                 total = oD + al(4 * (size_t)nq);
+    int rc;
+    if ((rc = ctx->scratch[6].ensure(total))) return rc;
+    uint8_t* B = ctx->scratch[6].as<uint8_t>();
+    SSLAM_HIP(hipMemcpyAsync(B + oQ, queries, sizeof(sslam_proj_query) * (size_t)nq, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oQD, qdesc, 32 * (size_t)nq, hipMemcpyHostToDevice, st));
+    if (chi2_mode) SSLAM_HIP(hipMemcpyAsync(B + oS, inv_level_sigma2, sizeof(float) * (size_t)nlevels, hipMemcpyHostToDevice, st));
+    FuseArgs A;
+    A.kind = kf->kind; A.chi2 = chi2_mode; A.feats = kf->feats.p; A.desc = kf->desc.as<uint8_t>(); A.n = kf->n;
+    A.minX = kf->bounds[0]; A.maxX = kf->bounds[1]; A.minY = kf->bounds[2]; A.maxY = kf->bounds[3];
+    A.uright = kf->hasUright ? kf->uright.as<float>() : nullptr; A.invSigma2 = (const float*)(B + oS); A.nlevels = nlevels;
+    A.q = (const sslam_proj_query*)(B + oQ); A.qdesc = B + oQD; A.nq = nq; A.bestIdx = (int*)(B + oI); A.bestDist = (int*)(B + oD);
+    { sslam::ProfScope _ps(ctx, "k_fuse_search", st); hipLaunchKernelGGL(k_fuse_search, dim3(std::min(nq, 8192)), dim3(64), 0, st, A); }
+    SSLAM_HIP(hipGetLastError());
+    SSLAM_HIP(hipMemcpyAsync(best_idx_out, B + oI, 4 * (size_t)nq, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(best_dist_out, B + oD, 4 * (size_t)nq, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
     return SSLAM_OK;
 }

@@ -176,6 +176,14 @@ class Frame:
                                                     C.c_float(nnratio), int(th_dist), int(bool(check_orientation)), _p(assigned), C.byref(nm)))
         return assigned, nm.value
 
+    def fuse_search(self, queries, qdesc, chi2_mode=0, inv_level_sigma2=None):
+        """candidate search of ORBmatcher::Fuse / LSDmatcher::Fuse on this (key)frame: (best_idx, best_dist) per query"""
+        queries = np.ascontiguousarray(queries, PQ_DTYPE); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        sg = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        bi = np.zeros(len(queries), np.int32); bd = np.zeros(len(queries), np.int32)
+        _chk(lib().sslam_fuse_search(self.ctx.h, self.h, int(chi2_mode), _p(sg), 0 if sg is None else len(sg), _p(queries), _p(qdesc), len(queries), _p(bi), _p(bd)))
+        return bi, bd
+
     def knn2(self, train):
         n = len(self)
         idx = np.full((n, 2), -1, np.int32); dist = np.full((n, 2), -1, np.int32)

@@ -139,13 +139,23 @@ def _orc_match_methods():
                                       len(ptr_kf) - 1, _p(idx_kf), _p(idx_f), C.c_float(nnratio), int(bool(check_orientation)), _p(assigned))
         return assigned, nm
 
+    def fuse_search(self, kind, chi2, feats, desc, queries, qdesc, uright=None, inv_level_sigma2=None, bounds=(0.0, 640.0, 0.0, 480.0)):
+        feats = np.ascontiguousarray(feats); desc = np.ascontiguousarray(desc, np.uint8)
+        queries = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        sg = np.ones(8, np.float32) if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        bi = np.zeros(len(queries), np.int32); bd = np.zeros(len(queries), np.int32)
+        self.L.orc_fuse_search(int(kind), int(chi2), _p(feats), _p(desc), len(feats), _p(b), _p(ur), _p(sg), _p(queries), _p(qdesc), len(queries), _p(bi), _p(bd))
+        return bi, bd
+
     def distinctive(self, desc, ptr):
         desc = np.ascontiguousarray(desc, np.uint8); ptr = np.ascontiguousarray(ptr, np.int32)
         best = np.zeros(len(ptr) - 1, np.int32)
         self.L.orc_distinctive(_p(desc), _p(ptr), len(ptr) - 1, _p(best))
         return best
 
-    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, distinctive):
+    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, distinctive, fuse_search):
         setattr(Oracle, f.__name__, f)
 
 

@@ -216,3 +216,37 @@ def test_distinctive_descriptors_limits(fe, ctx):
     d = np.zeros((1025, 32), np.uint8); ptr = np.array([0, 1025], np.int32); best = np.zeros(1, np.int32)
     rc = fe.lib().sslam_distinctive_descriptors(ctx.h, d.ctypes.data_as(C.c_void_p), ptr.ctypes.data_as(C.c_void_p), 1, best.ctypes.data_as(C.c_void_p))
     assert rc != 0 and b"1024" in fe.lib().sslam_last_error()
+
+
+# ---- Fuse candidate search: ORBmatcher::Fuse x2, LSDmatcher::Fuse
+@pytest.mark.parametrize("chi2,seed", [(1, 1234), (0, 1234), (1, 2003)])
+def test_orb_fuse_search(fe, ctx, oracle, chi2, seed):
+    rng = np.random.default_rng(seed + chi2)
+    cur = synth_frame(seed); prev = warp_prev(cur)
+    kp1, d1 = oracle.orb_extract(prev, 1000); kp2, d2 = oracle.orb_extract(cur, 1000)
+    scales, _, _, inv_sigma2 = oracle.orb_params()[0], None, None, None
+    sc = oracle.orb_params()[0].astype(np.float32)
+    inv_sigma2 = (1.0 / (sc * sc)).astype(np.float32)           # KeyFrame::mvInvLevelSigma2
+    q = _proj_queries(fe, rng, kp1, 0, 0, sc)
+    q["radius"] = 3.0 * sc[kp1["octave"]]                        # Fuse: th = 3 (LocalMapping::SearchInNeighbors)
+    q["ur"] = q["u"] - rng.uniform(0, 40, len(q))
+    uright = np.where(rng.random(len(kp2)) < 0.4, kp2["x"] - rng.uniform(0, 40, len(kp2)), -1).astype(np.float32)
+    kf = ctx.frame_upload(0, kp2, d2, uright)
+    bi, bd = kf.fuse_search(q, d1, chi2, inv_sigma2 if chi2 else None)
+    oi, od = oracle.fuse_search(0, chi2, kp2, d2, q, d1, uright, inv_sigma2)
+    assert (oi >= 0).sum() > 100
+    np.testing.assert_array_equal(bi, oi); np.testing.assert_array_equal(bd, od)
+    kf.close()
+
+
+def test_line_fuse_search(fe, ctx, oracle):
+    rng = np.random.default_rng(11)
+    cur = synth_frame(2000); prev = warp_prev(cur)
+    kl1, ld1, _, _ = oracle.lines_extract(prev, 200); kl2, ld2, _, _ = oracle.lines_extract(cur, 200)
+    q = _proj_queries(fe, rng, kl1, 1, 0, None)
+    kf = ctx.frame_upload(1, kl2, ld2)
+    bi, bd = kf.fuse_search(q, ld1, 0)
+    oi, od = oracle.fuse_search(1, 0, kl2, ld2, q, ld1)
+    assert (oi >= 0).sum() > 20
+    np.testing.assert_array_equal(bi, oi); np.testing.assert_array_equal(bd, od)
+    kf.close()
