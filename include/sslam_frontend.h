@@ -202,9 +202,22 @@ int sslam_hamming_knn2_frames(sslam_ctx* ctx, const sslam_frame* query, const ss
  * min_level = pred-1, max_level = pred, valid.  best_idx_out[q] = the feature with the smallest descriptor distance in the
  * window (first in KeyFrame::GetFeaturesInArea / GetLinesInArea order on ties, src/KeyFrame.cc:610-683), -1 if none;
  * best_dist_out[q] = that distance (INT_MAX if none).  inv_level_sigma2 = KeyFrame::mvInvLevelSigma2 (chi2_mode 1 only).
- * The `bestDist <= TH_LOW` test and the Replace / AddObservation bookkeeping stay with the caller, in query order. */
+ * The `bestDist <= TH_LOW` test and the Replace / AddObservation bookkeeping stay with the caller, in query order.
+ * The same inner loop (chi2_mode 0) is the candidate search of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1196-1227, :1276-1307,
+ * gate TH_HIGH) and of the loop-closing ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, ...) (:293-406). */
 int sslam_fuse_search(sslam_ctx* ctx, const sslam_frame* keyframe, int chi2_mode, const float* inv_level_sigma2, int nlevels,
                       const sslam_proj_query* queries, const uint8_t* qdesc, int nq, int32_t* best_idx_out, int32_t* best_dist_out);
+
+/* ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, vector<pair<size_t,size_t>>&, bOnlyStereo),
+ * src/ORBmatcher.cc:660-826 (epipolar test CheckDistEpipolarLine :140-157), on two device-resident keyframes (their
+ * mvuRight are in the handles).  free1[i] / free2[i] = !GetMapPoint(i); the two FeatureVectors as CSR lists over the shared
+ * vocabulary nodes in ascending node id (see sslam_orb_search_by_bow); F12 row-major (F12.at<float>(r,c) = F12[3r+c]);
+ * (ex, ey) = epipole in image 2 (:667-673); scale_factors2 = pKF2->mvScaleFactors, level_sigma2_2 = pKF2->mvLevelSigma2.
+ * matches12_out[i1] = matched keyframe-2 feature or -1 (the reference's vMatches12 after the rotation-histogram pruning). */
+int sslam_orb_search_for_triangulation(sslam_ctx* ctx, const sslam_frame* kf1, const sslam_frame* kf2, const uint8_t* free1, const uint8_t* free2,
+                                       const int32_t* node_kf1_ptr, const int32_t* node_kf2_ptr, int nnodes, const int32_t* kf1_idx, const int32_t* kf2_idx,
+                                       const float F12[9], float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int nlevels,
+                                       int only_stereo, int check_orientation, int32_t* matches12_out, int* nmatches_out);
 
 /* MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:247-312, and MapLine::ComputeDistinctiveDescriptors,
  * src/MapLine.cpp:246-317, for nsets observation sets at once: set s owns rows ptr[s]..ptr[s+1]

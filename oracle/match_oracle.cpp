@@ -388,6 +388,80 @@ int orc_search_by_projection(int kind, int mode, const void* feats, const uint8_
     return search_by_projection(kind, mode, feats, desc, n, bounds, uright, occupied, (const ProjQuery*)q, qdesc, nq, nnratio, th_dist, check_ori != 0, assigned);
 }
 
+// ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bOnlyStereo),
+// src/ORBmatcher.cc:660-826, with CheckDistEpipolarLine :140-157.  FeatureVectors as CSR lists over the shared nodes
+// (ascending node id), free1/free2 = "no MapPoint yet" (:704-708, :725-729).  The reference never sets vbMatched2, so the
+// idx1 queries are independent; `dist>bestDist` lets a later candidate with an EQUAL distance replace the current one.
+static int search_for_triangulation(const KPm* kp1, const uint8_t* d1, const float* ur1, const uint8_t* free1, int n1,
+                                    const KPm* kp2, const uint8_t* d2, const float* ur2, const uint8_t* free2, int n2,
+                                    const int32_t* ptr1, const int32_t* ptr2, int nnodes, const int32_t* idx1v, const int32_t* idx2v,
+                                    const float* F12, float ex, float ey, const float* scaleFactors2, const float* levelSigma2_2,
+                                    bool onlyStereo, bool checkOri, int32_t* m12) {
+    int nmatches = 0;
+    for (int i = 0; i < n1; ++i) m12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int nd = 0; nd < nnodes; ++nd) {
+        for (int a = ptr1[nd]; a < ptr1[nd + 1]; ++a) {
+            const int i1 = idx1v[a];
+            if (!free1[i1]) continue;
+            const bool bStereo1 = ur1 && ur1[i1] >= 0;
+            if (onlyStereo && !bStereo1) continue;
+            const KPm& k1 = kp1[i1];
+            int bestDist = TH_LOW, bestIdx2 = -1;
+            for (int b = ptr2[nd]; b < ptr2[nd + 1]; ++b) {
+                const int i2 = idx2v[b];
+                if (!free2[i2]) continue;
+                const bool bStereo2 = ur2 && ur2[i2] >= 0;
+                if (onlyStereo && !bStereo2) continue;
+                const int dist = descriptor_distance(d1 + (size_t)i1 * 32, d2 + (size_t)i2 * 32);
+                if (dist > TH_LOW || dist > bestDist) continue;
+                const KPm& k2 = kp2[i2];
+                if (!bStereo1 && !bStereo2) {
+                    const float distex = ex - k2.x, distey = ey - k2.y;
+                    if (distex * distex + distey * distey < 100 * scaleFactors2[k2.octave]) continue;
+                }
+                // CheckDistEpipolarLine
+                const float la = k1.x * F12[0] + k1.y * F12[3] + F12[6];
+                const float lb = k1.x * F12[1] + k1.y * F12[4] + F12[7];
+                const float lc = k1.x * F12[2] + k1.y * F12[5] + F12[8];
+                const float num = la * k2.x + lb * k2.y + lc;
+                const float den = la * la + lb * lb;
+                if (den == 0) continue;
+                const float dsqr = num * num / den;
+                if (dsqr < 3.84 * levelSigma2_2[k2.octave]) { bestIdx2 = i2; bestDist = dist; }
+            }
+            if (bestIdx2 >= 0) {
+                m12[i1] = bestIdx2; nmatches++;
+                if (checkOri) {
+                    float rot = k1.angle - kp2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int i1 : rotHist[i]) { m12[i1] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+int orc_search_for_triangulation(const void* kp1, const uint8_t* d1, const float* ur1, const uint8_t* free1, int n1,
+                                 const void* kp2, const uint8_t* d2, const float* ur2, const uint8_t* free2, int n2,
+                                 const int32_t* ptr1, const int32_t* ptr2, int nnodes, const int32_t* idx1, const int32_t* idx2,
+                                 const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                 int only_stereo, int check_ori, int32_t* m12) {
+    return search_for_triangulation((const KPm*)kp1, d1, ur1, free1, n1, (const KPm*)kp2, d2, ur2, free2, n2, ptr1, ptr2, nnodes, idx1, idx2,
+                                    F12, ex, ey, scale_factors2, level_sigma2_2, only_stereo != 0, check_ori != 0, m12);
+}
+
 int orc_fuse_search(int kind, int chi2, const void* feats, const uint8_t* desc, int n, const float* bounds, const float* uright,
                     const float* inv_level_sigma2, const void* q, const uint8_t* qdesc, int nq, int32_t* best_idx, int32_t* best_dist) {
     fuse_search(kind, chi2, feats, desc, n, bounds, uright, inv_level_sigma2, (const ProjQuery*)q, qdesc, nq, best_idx, best_dist);

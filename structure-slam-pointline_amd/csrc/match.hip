@@ -601,6 +601,106 @@ __global__ __launch_bounds__(64) void k_fuse_search(FuseArgs A) {
     }
 }
 
+// ------------------------------------------------------------------ ORBmatcher::SearchForTriangulation
+// src/ORBmatcher.cc:660-826 (+ CheckDistEpipolarLine :140-157).  The reference never sets vbMatched2, so every keyframe-1
+// feature is an independent query over the keyframe-2 features of its vocabulary node: one wave per query, candidates
+// lane-parallel.  `dist > bestDist` (not >=) lets a later candidate with an equal distance win, hence the inverted position
+// in the min-reduction key.  k_tri_finish applies the rotation-histogram pruning and counts.
+struct TriArgs {
+    const sslam_keypoint* kp1; const uint8_t* d1; const float* ur1; const uint8_t* free1; int n1;
+    const sslam_keypoint* kp2; const uint8_t* d2; const float* ur2; const uint8_t* free2;
+    const int* ptr1; const int* ptr2; int nnodes; const int* idx1; const int* idx2; const int* nodeOf; int total1;
+    float F[9]; float ex, ey; const float* scale2; const float* sigma2_2; int nlevels;
+    int onlyStereo, checkOri;
+    int* m12; int* qbin; int* nmatches;
+};
+__global__ __launch_bounds__(64) void k_tri_search(TriArgs A) {
+    const int lane = threadIdx.x;
+    for (int a = blockIdx.x; a < A.total1; a += gridDim.x) {
+        const int i1 = A.idx1[a];
+        if (!A.free1[i1]) continue;
+        const bool st1 = A.ur1 && A.ur1[i1] >= 0;
+        if (A.onlyStereo && !st1) continue;
+        const int nd = A.nodeOf[a];
+        const int f0 = A.ptr2[nd], f1 = A.ptr2[nd + 1];
+        const sslam_keypoint k1 = A.kp1[i1];
+        const uint4 q0 = ((const uint4*)(A.d1 + (size_t)i1 * 32))[0], q1 = ((const uint4*)(A.d1 + (size_t)i1 * 32))[1];
+        const float la = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, A.F[0]), __fmul_rn(k1.y, A.F[3])), A.F[6]);
+        const float lb = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, A.F[1]), __fmul_rn(k1.y, A.F[4])), A.F[7]);
+        const float lc = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, A.F[2]), __fmul_rn(k1.y, A.F[5])), A.F[8]);
+        const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+        unsigned long long b = ~0ull;
+        for (int p = f0 + lane; p < f1; p += 64) {
+            const int i2 = A.idx2[p];
+            if (!A.free2[i2]) continue;
+            const bool st2 = A.ur2 && A.ur2[i2] >= 0;
+            if (A.onlyStereo && !st2) continue;
+            const uint4* tp = (const uint4*)(A.d2 + (size_t)i2 * 32);
+            const int dist = hamming256(q0, q1, tp[0], tp[1]);
+            if (dist > TH_LOW) continue;
+            const sslam_keypoint k2 = A.kp2[i2];
+            const int oct = min(max(k2.octave, 0), A.nlevels - 1);
+            if (!st1 && !st2) {
+                const float dx = __fsub_rn(A.ex, k2.x), dy = __fsub_rn(A.ey, k2.y);
+                if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.f, A.scale2[oct])) continue;
+            }
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, k2.x), __fmul_rn(lb, k2.y)), lc);
+            if (den == 0.f) continue;
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if (!((double)dsqr < 3.84 * (double)A.sigma2_2[oct])) continue;
+            const unsigned long long kk = ((unsigned long long)dist << 32) | (unsigned)(0x7FFFFFFF - (p - f0));
+            b = kk < b ? kk : b;
+        }
+        b = wave_min_u64(b);
+        if (b != ~0ull && lane == 0) {
+            const int i2 = A.idx2[f0 + (0x7FFFFFFF - (int)(unsigned)b)];
+            A.m12[i1] = i2;
+            if (A.checkOri) {
+                float rot = __fsub_rn(k1.angle, A.kp2[i2].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                A.qbin[i1] = bin;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_tri_finish(int* __restrict__ m12, const int* __restrict__ qbin, int n1, int checkOri, int* __restrict__ nmatches) {
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int keep[3];
+    __shared__ int total;
+    const int t = threadIdx.x;
+    if (t < HISTO_LENGTH) hist[t] = 0;
+    if (t == 0) total = 0;
+    __syncthreads();
+    if (checkOri) {
+        for (int i = t; i < n1; i += 256) if (m12[i] >= 0) atomicAdd(&hist[qbin[i]], 1);
+        __syncthreads();
+        if (t == 0) {
+            int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+            for (int i = 0; i < HISTO_LENGTH; ++i) {
+                const int c = hist[i];
+                if (c > max1) { max3 = max2; max2 = max1; max1 = c; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (c > max2) { max3 = max2; max2 = c; ind3 = ind2; ind2 = i; }
+                else if (c > max3) { max3 = c; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+            keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
+        }
+        __syncthreads();
+    }
+    int cnt = 0;
+    for (int i = t; i < n1; i += 256) {
+        if (m12[i] < 0) continue;
+        if (checkOri) { const int bn = qbin[i]; if (bn != keep[0] && bn != keep[1] && bn != keep[2]) { m12[i] = -1; continue; } }
+        ++cnt;
+    }
+    atomicAdd(&total, cnt);
+    __syncthreads();
+    if (t == 0) *nmatches = total;
+}
+
 // ------------------------------------------------------------------ distinctive descriptor of an observation set
 // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312) == MapLine::ComputeDistinctiveDescriptors
 // (src/MapLine.cpp:246-317): all-pairs Hamming distances of the N observed descriptors, per row the median
@@ -1055,6 +1155,67 @@ extern "C" int sslam_fuse_search(sslam_ctx* ctx, const sslam_frame* kf, int chi2
     SSLAM_HIP(hipGetLastError());
     SSLAM_HIP(hipMemcpyAsync(best_idx_out, B + oI, 4 * (size_t)nq, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipMemcpyAsync(best_dist_out, B + oD, 4 * (size_t)nq, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    return SSLAM_OK;
+}
+
+// ORBmatcher::SearchForTriangulation on two device-resident keyframes (their mvuRight travel with the handles).
+extern "C" int sslam_orb_search_for_triangulation(sslam_ctx* ctx, const sslam_frame* kf1, const sslam_frame* kf2, const uint8_t* free1, const uint8_t* free2,
+                                                  const int32_t* node_kf1_ptr, const int32_t* node_kf2_ptr, int nnodes, const int32_t* kf1_idx, const int32_t* kf2_idx,
+                                                  const float F12[9], float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int nlevels,
+                                                  int only_stereo, int check_orientation, int32_t* matches12_out, int* nmatches_out) {
+    if (!ctx || !kf1 || !kf2 || kf1->ctx != ctx || kf2->ctx != ctx || kf1->kind != 0 || kf2->kind != 0 || nnodes < 0 || !nmatches_out || !F12 ||
+        !scale_factors2 || !level_sigma2_2 || nlevels <= 0 || nlevels > 64 || (kf1->n > 0 && (!free1 || !matches12_out)) || (kf2->n > 0 && !free2) ||
+        (nnodes > 0 && (!node_kf1_ptr || !node_kf2_ptr || !kf1_idx || !kf2_idx))) {
+        set_error("sslam_orb_search_for_triangulation: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    *nmatches_out = 0;
+    const int n1 = kf1->n, n2 = kf2->n;
+    for (int i = 0; i < n1; ++i) matches12_out[i] = -1;
+    if (n1 == 0 || n2 == 0 || nnodes == 0) return SSLAM_OK;
+    const int total1 = node_kf1_ptr[nnodes], total2 = node_kf2_ptr[nnodes];
+    if (node_kf1_ptr[0] != 0 || node_kf2_ptr[0] != 0 || total1 < 0 || total2 < 0) { set_error("sslam_orb_search_for_triangulation: invalid node offsets"); return SSLAM_ERR_INVALID; }
+    for (int i = 0; i < total1; ++i) if (kf1_idx[i] < 0 || kf1_idx[i] >= n1) { set_error("sslam_orb_search_for_triangulation: keyframe-1 index out of range"); return SSLAM_ERR_INVALID; }
+    for (int i = 0; i < total2; ++i) if (kf2_idx[i] < 0 || kf2_idx[i] >= n2) { set_error("sslam_orb_search_for_triangulation: keyframe-2 index out of range"); return SSLAM_ERR_INVALID; }
+    if (total1 == 0 || total2 == 0) return SSLAM_OK;
+    std::vector<int32_t> nodeOf((size_t)total1);
+    for (int nd = 0; nd < nnodes; ++nd) for (int a = node_kf1_ptr[nd]; a < node_kf1_ptr[nd + 1]; ++a) nodeOf[a] = nd;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
+    const size_t oF1 = take(n1), oF2 = take(n2), oP1 = take(4 * (size_t)(nnodes + 1)), oP2 = take(4 * (size_t)(nnodes + 1)), oI1 = take(4 * (size_t)total1),
+                 oI2 = take(4 * (size_t)total2), oNO = take(4 * (size_t)total1), oSF = take(4 * (size_t)nlevels), oSG = take(4 * (size_t)nlevels),
+                 oM = take(4 * (size_t)n1), oQB = take(4 * (size_t)n1), oN = take(4);
+    int rc;
+    if ((rc = ctx->scratch[6].ensure(off))) return rc;
+    uint8_t* B = ctx->scratch[6].as<uint8_t>();
+    SSLAM_HIP(hipMemcpyAsync(B + oF1, free1, n1, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oF2, free2, n2, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oP1, node_kf1_ptr, 4 * (size_t)(nnodes + 1), hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oP2, node_kf2_ptr, 4 * (size_t)(nnodes + 1), hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oI1, kf1_idx, 4 * (size_t)total1, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oI2, kf2_idx, 4 * (size_t)total2, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oNO, nodeOf.data(), 4 * (size_t)total1, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oSF, scale_factors2, 4 * (size_t)nlevels, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(B + oSG, level_sigma2_2, 4 * (size_t)nlevels, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemsetAsync(B + oM, 0xFF, 4 * (size_t)n1, st));
+    TriArgs A;
+    A.kp1 = kf1->feats.as<sslam_keypoint>(); A.d1 = kf1->desc.as<uint8_t>(); A.ur1 = kf1->hasUright ? kf1->uright.as<float>() : nullptr; A.free1 = B + oF1; A.n1 = n1;
+    A.kp2 = kf2->feats.as<sslam_keypoint>(); A.d2 = kf2->desc.as<uint8_t>(); A.ur2 = kf2->hasUright ? kf2->uright.as<float>() : nullptr; A.free2 = B + oF2;
+    A.ptr1 = (const int*)(B + oP1); A.ptr2 = (const int*)(B + oP2); A.nnodes = nnodes; A.idx1 = (const int*)(B + oI1); A.idx2 = (const int*)(B + oI2);
+    A.nodeOf = (const int*)(B + oNO); A.total1 = total1;
+    for (int i = 0; i < 9; ++i) A.F[i] = F12[i];
+    A.ex = ex; A.ey = ey; A.scale2 = (const float*)(B + oSF); A.sigma2_2 = (const float*)(B + oSG); A.nlevels = nlevels;
+    A.onlyStereo = only_stereo; A.checkOri = check_orientation;
+    A.m12 = (int*)(B + oM); A.qbin = (int*)(B + oQB); A.nmatches = (int*)(B + oN);
+    { sslam::ProfScope _ps(ctx, "k_tri_search", st); hipLaunchKernelGGL(k_tri_search, dim3(std::min(total1, 8192)), dim3(64), 0, st, A); }
+    { sslam::ProfScope _ps(ctx, "k_tri_finish", st); hipLaunchKernelGGL(k_tri_finish, dim3(1), dim3(256), 0, st, A.m12, A.qbin, n1, check_orientation, A.nmatches); }
+    SSLAM_HIP(hipGetLastError());
+    SSLAM_HIP(hipMemcpyAsync(matches12_out, B + oM, 4 * (size_t)n1, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + oN, sizeof(int), hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
     return SSLAM_OK;
 }

@@ -184,6 +184,20 @@ class Frame:
         _chk(lib().sslam_fuse_search(self.ctx.h, self.h, int(chi2_mode), _p(sg), 0 if sg is None else len(sg), _p(queries), _p(qdesc), len(queries), _p(bi), _p(bd)))
         return bi, bd
 
+    def search_for_triangulation(self, kf2, free1, free2, ptr1, ptr2, idx1, idx2, F12, ex, ey, scale_factors2, level_sigma2_2,
+                                 only_stereo=False, check_orientation=True):
+        """ORBmatcher::SearchForTriangulation(this, kf2, F12, ...) -> (vMatches12, nmatches)"""
+        f1 = np.ascontiguousarray(free1, np.uint8); f2 = np.ascontiguousarray(free2, np.uint8)
+        ptr1 = np.ascontiguousarray(ptr1, np.int32); ptr2 = np.ascontiguousarray(ptr2, np.int32)
+        idx1 = np.ascontiguousarray(idx1, np.int32); idx2 = np.ascontiguousarray(idx2, np.int32)
+        F = (C.c_float * 9)(*np.asarray(F12, np.float32).reshape(9).tolist())
+        sf = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2_2, np.float32)
+        m12 = np.full(len(self), -2, np.int32); nm = C.c_int(0)
+        _chk(lib().sslam_orb_search_for_triangulation(self.ctx.h, self.h, kf2.h, _p(f1), _p(f2), _p(ptr1), _p(ptr2), len(ptr1) - 1, _p(idx1), _p(idx2),
+                                                      F, C.c_float(ex), C.c_float(ey), _p(sf), _p(sg), len(sf), int(bool(only_stereo)),
+                                                      int(bool(check_orientation)), _p(m12), C.byref(nm)))
+        return m12, nm.value
+
     def knn2(self, train):
         n = len(self)
         idx = np.full((n, 2), -1, np.int32); dist = np.full((n, 2), -1, np.int32)

@@ -149,13 +149,30 @@ def _orc_match_methods():
         self.L.orc_fuse_search(int(kind), int(chi2), _p(feats), _p(desc), len(feats), _p(b), _p(ur), _p(sg), _p(queries), _p(qdesc), len(queries), _p(bi), _p(bd))
         return bi, bd
 
+    def search_for_triangulation(self, kp1, d1, ur1, free1, kp2, d2, ur2, free2, ptr1, ptr2, idx1, idx2, F12, ex, ey, scale_factors2,
+                                 level_sigma2_2, only_stereo=False, check_orientation=True):
+        kp1 = np.ascontiguousarray(kp1); kp2 = np.ascontiguousarray(kp2)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        u1 = None if ur1 is None else np.ascontiguousarray(ur1, np.float32); u2 = None if ur2 is None else np.ascontiguousarray(ur2, np.float32)
+        f1 = np.ascontiguousarray(free1, np.uint8); f2 = np.ascontiguousarray(free2, np.uint8)
+        ptr1 = np.ascontiguousarray(ptr1, np.int32); ptr2 = np.ascontiguousarray(ptr2, np.int32)
+        idx1 = np.ascontiguousarray(idx1, np.int32); idx2 = np.ascontiguousarray(idx2, np.int32)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sf = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2_2, np.float32)
+        m12 = np.zeros(len(kp1), np.int32)
+        self.L.orc_search_for_triangulation.argtypes = None
+        n = self.L.orc_search_for_triangulation(_p(kp1), _p(d1), _p(u1), _p(f1), len(kp1), _p(kp2), _p(d2), _p(u2), _p(f2), len(kp2), _p(ptr1), _p(ptr2),
+                                                len(ptr1) - 1, _p(idx1), _p(idx2), _p(F), C.c_float(ex), C.c_float(ey), _p(sf), _p(sg),
+                                                int(bool(only_stereo)), int(bool(check_orientation)), _p(m12))
+        return m12, n
+
     def distinctive(self, desc, ptr):
         desc = np.ascontiguousarray(desc, np.uint8); ptr = np.ascontiguousarray(ptr, np.int32)
         best = np.zeros(len(ptr) - 1, np.int32)
         self.L.orc_distinctive(_p(desc), _p(ptr), len(ptr) - 1, _p(best))
         return best
 
-    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, distinctive, fuse_search):
+    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, distinctive, fuse_search, search_for_triangulation):
         setattr(Oracle, f.__name__, f)
 
 

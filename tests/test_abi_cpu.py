@@ -31,13 +31,14 @@ def test_struct_layouts_match_opencv():
 
 
 def test_fails_loudly_without_gpu():
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("GPU present")
     fe = pkg.frontend()
-    with pytest.raises(fe.SslamError) as e:
-        fe.Context(0)
-    assert "no CPU fallback" in str(e.value)
+    try:
+        ctx = fe.Context(0)
+    except fe.SslamError as e:
+        assert "no CPU fallback" in str(e)
+        return
+    ctx.close()
+    pytest.skip("GPU present")
 
 
 def test_graft_entry_build():

@@ -250,3 +250,31 @@ def test_line_fuse_search(fe, ctx, oracle):
     assert (oi >= 0).sum() > 20
     np.testing.assert_array_equal(bi, oi); np.testing.assert_array_equal(bd, od)
     kf.close()
+
+
+# ---- ORBmatcher::SearchForTriangulation
+@pytest.mark.parametrize("seed,only_stereo,ori", [(1234, False, True), (2003, False, False), (2004, True, True)])
+def test_search_for_triangulation(fe, ctx, oracle, seed, only_stereo, ori):
+    rng = np.random.default_rng(seed)
+    cur = synth_frame(seed); prev = warp_prev(cur)
+    kp1, d1 = oracle.orb_extract(prev, 1000); kp2, d2 = oracle.orb_extract(cur, 1000)
+    # the warp prev -> cur is a rigid image motion H; F12 = ([e2]x H)^T makes the epipolar line of kp1 pass through H kp1
+    a = np.deg2rad(1.5); cx, cy = 319.5, 239.5
+    H = np.array([[np.cos(a), np.sin(a), cx - 3.0 - cx * np.cos(a) - cy * np.sin(a)],
+                  [-np.sin(a), np.cos(a), cy + 2.0 + cx * np.sin(a) - cy * np.cos(a)], [0, 0, 1.0]])
+    ex, ey = -2000.0, 300.0
+    E = np.array([[0, -1.0, ey], [1.0, 0, -ex], [-ey, ex, 0]])
+    F12 = (E @ H).T
+    F12 = (F12 / np.abs(F12).max()).astype(np.float32)
+    sc = oracle.orb_params()[0].astype(np.float32); sg = (sc * sc).astype(np.float32)
+    pk, pf, ik, jf = _pseudo_feature_vectors(d1, d2)
+    free1 = (rng.random(len(kp1)) < 0.9).astype(np.uint8); free2 = (rng.random(len(kp2)) < 0.9).astype(np.uint8)
+    p_st = 0.7 if only_stereo else 0.3
+    ur1 = np.where(rng.random(len(kp1)) < p_st, kp1["x"] - 5, -1).astype(np.float32)
+    ur2 = np.where(rng.random(len(kp2)) < p_st, kp2["x"] - 5, -1).astype(np.float32)
+    f1 = ctx.frame_upload(0, kp1, d1, ur1); f2 = ctx.frame_upload(0, kp2, d2, ur2)
+    m, n = f1.search_for_triangulation(f2, free1, free2, pk, pf, ik, jf, F12, ex, ey, sc, sg, only_stereo, ori)
+    om, on = oracle.search_for_triangulation(kp1, d1, ur1, free1, kp2, d2, ur2, free2, pk, pf, ik, jf, F12, ex, ey, sc, sg, only_stereo, ori)
+    assert on > 30 and n == on, (n, on)
+    np.testing.assert_array_equal(m, om)
+    f1.close(); f2.close()
