@@ -219,6 +219,24 @@ int sslam_orb_search_for_triangulation(sslam_ctx* ctx, const sslam_frame* kf1, c
                                        const float F12[9], float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int nlevels,
                                        int only_stereo, int check_orientation, int32_t* matches12_out, int* nmatches_out);
 
+/* ---- DBoW2 vocabulary descent: Frame::ComputeBoW, src/Frame.cc:474-481 ->
+ * ORBVocabulary::transform(vCurrentDesc, mBowVec, mFeatVec, 4), whose per-feature work is
+ * TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup), Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1216-1259.
+ * The vocabulary is handed over as arrays in DBoW2's node numbering (node 0 = root): children of node i are
+ * children[child_ptr[i] .. child_ptr[i+1]) in m_nodes[i].children order (a node without children is a leaf), node_desc =
+ * 32-byte descriptor per node, word_id / weight per node (meaningful for leaves), levels = m_L.  The ORBvoc.txt loader stays
+ * on the host (the file is an LFS pointer in the reference tree).  Outputs per feature: the word, its weight (0 = stopped
+ * word) and the node passed at level m_L - levelsup; BowVector / FeatureVector are std::maps the caller fills from them
+ * in feature order (v.addWeight(id, w); fv.addFeature(nid, i); then the L1 normalisation, TemplatedVocabulary.h:1147-1199). */
+typedef struct sslam_vocab sslam_vocab;
+int sslam_vocab_create(sslam_ctx* ctx, int nnodes, int levels, const int32_t* child_ptr, const int32_t* children, const uint8_t* node_desc,
+                       const int32_t* word_id, const double* weight, sslam_vocab** out);
+void sslam_vocab_destroy(sslam_vocab* vocab);
+int sslam_bow_transform(sslam_ctx* ctx, const sslam_vocab* vocab, const uint8_t* desc, int n, int levelsup,
+                        int32_t* word_out, double* weight_out, int32_t* node_out);
+int sslam_bow_transform_frame(sslam_ctx* ctx, const sslam_vocab* vocab, const sslam_frame* frame, int levelsup,
+                              int32_t* word_out, double* weight_out, int32_t* node_out);
+
 /* MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:247-312, and MapLine::ComputeDistinctiveDescriptors,
  * src/MapLine.cpp:246-317, for nsets observation sets at once: set s owns rows ptr[s]..ptr[s+1]
  * of desc (ptr[0] = 0).  best_out[s] = index inside the set of the descriptor with the least median Hamming distance to

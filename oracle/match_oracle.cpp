@@ -462,6 +462,32 @@ int orc_search_for_triangulation(const void* kp1, const uint8_t* d1, const float
                                     F12, ex, ey, scale_factors2, level_sigma2_2, only_stereo != 0, check_ori != 0, m12);
 }
 
+// TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup), Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1216-1259
+// (FORB::distance = Hamming), on a vocabulary given as CSR children lists in DBoW2's node numbering.
+int orc_bow_transform(int nnodes, int levels, const int32_t* childPtr, const int32_t* children, const uint8_t* nodeDesc, const int32_t* wordId,
+                      const double* weight, const uint8_t* feat, int n, int levelsup, int32_t* wordOut, double* weightOut, int32_t* nodeOut) {
+    (void)nnodes;
+    for (int i = 0; i < n; ++i) {
+        const int nid_level = levels - levelsup;
+        int nid = 0;                       // root when nid_level <= 0 (:1227)
+        int final_id = 0, current_level = 0;
+        do {
+            ++current_level;
+            const int c0 = childPtr[final_id], c1 = childPtr[final_id + 1];
+            final_id = children[c0];
+            double best_d = (double)descriptor_distance(feat + (size_t)i * 32, nodeDesc + (size_t)final_id * 32);
+            for (int c = c0 + 1; c < c1; ++c) {
+                const int id = children[c];
+                const double d = (double)descriptor_distance(feat + (size_t)i * 32, nodeDesc + (size_t)id * 32);
+                if (d < best_d) { best_d = d; final_id = id; }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (childPtr[final_id + 1] > childPtr[final_id]);
+        wordOut[i] = wordId[final_id]; weightOut[i] = weight[final_id]; nodeOut[i] = nid;
+    }
+    return 0;
+}
+
 int orc_fuse_search(int kind, int chi2, const void* feats, const uint8_t* desc, int n, const float* bounds, const float* uright,
                     const float* inv_level_sigma2, const void* q, const uint8_t* qdesc, int nq, int32_t* best_idx, int32_t* best_dist) {
     fuse_search(kind, chi2, feats, desc, n, bounds, uright, inv_level_sigma2, (const ProjQuery*)q, qdesc, nq, best_idx, best_dist);

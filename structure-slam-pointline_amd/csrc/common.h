@@ -78,6 +78,14 @@ struct sslam_frame {
     sslam::DevBuf feats, desc, uright;
 };
 
+// device-resident DBoW2 vocabulary tree: CSR children lists, 32-byte node descriptors, word id
+// and weight per node (leaves).
+struct sslam_vocab {
+    sslam_ctx* ctx = nullptr;
+    int nnodes = 0, levels = 0;
+    sslam::DevBuf childPtr, children, desc, wordId, weight;
+};
+
 namespace sslam {
 // RAII stage timer: records a HIP event pair on the launch stream around one kernel launch.
 struct ProfScope {

@@ -701,6 +701,35 @@ __global__ __launch_bounds__(256) void k_tri_finish(int* __restrict__ m12, const
     if (t == 0) *nmatches = total;
 }
 
+// ------------------------------------------------------------------ DBoW2 vocabulary descent (Frame::ComputeBoW)
+// TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup), Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1216-1259:
+// from the root, move to the child with the smallest Hamming distance (the FIRST such child: `d < best_d`) until a leaf;
+// remember the node passed at level L - levelsup.  Features are independent: one lane per feature.
+__global__ __launch_bounds__(256) void k_bow_transform(const uint8_t* __restrict__ feat, int n, const int* __restrict__ childPtr, const int* __restrict__ children,
+                                                       const uint8_t* __restrict__ nodeDesc, const int* __restrict__ wordId, const double* __restrict__ weight,
+                                                       int nidLevel, int* __restrict__ wordOut, double* __restrict__ weightOut, int* __restrict__ nodeOut) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 q0 = ((const uint4*)(feat + (size_t)i * 32))[0], q1 = ((const uint4*)(feat + (size_t)i * 32))[1];
+    int node = 0, level = 0, nid = 0;
+    while (childPtr[node + 1] > childPtr[node]) {
+        ++level;
+        const int c0 = childPtr[node], c1 = childPtr[node + 1];
+        int best = children[c0];
+        const uint4* bp = (const uint4*)(nodeDesc + (size_t)best * 32);
+        int bestD = hamming256(q0, q1, bp[0], bp[1]);
+        for (int c = c0 + 1; c < c1; ++c) {
+            const int id = children[c];
+            const uint4* tp = (const uint4*)(nodeDesc + (size_t)id * 32);
+            const int d = hamming256(q0, q1, tp[0], tp[1]);
+            if (d < bestD) { bestD = d; best = id; }
+        }
+        node = best;
+        if (level == nidLevel) nid = node;
+    }
+    wordOut[i] = wordId[node]; weightOut[i] = weight[node]; nodeOut[i] = nid;
+}
+
 // ------------------------------------------------------------------ distinctive descriptor of an observation set
 // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312) == MapLine::ComputeDistinctiveDescriptors
 // (src/MapLine.cpp:246-317): all-pairs Hamming distances of the N observed descriptors, per row the median
@@ -1218,4 +1247,80 @@ extern "C" int sslam_orb_search_for_triangulation(sslam_ctx* ctx, const sslam_fr
     SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + oN, sizeof(int), hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
     return SSLAM_OK;
+}
+
+// ---- DBoW2 vocabulary
+extern "C" int sslam_vocab_create(sslam_ctx* ctx, int nnodes, int levels, const int32_t* child_ptr, const int32_t* children, const uint8_t* node_desc,
+                                  const int32_t* word_id, const double* weight, sslam_vocab** out) {
+    if (!ctx || !out || nnodes < 1 || levels < 1 || !child_ptr || !node_desc || !word_id || !weight) { set_error("sslam_vocab_create: invalid arguments"); return SSLAM_ERR_INVALID; }
+    const int nch = child_ptr[nnodes];
+    if (child_ptr[0] != 0 || nch < 0 || (nch > 0 && !children)) { set_error("sslam_vocab_create: invalid child offsets"); return SSLAM_ERR_INVALID; }
+    for (int i = 0; i < nnodes; ++i) if (child_ptr[i + 1] < child_ptr[i]) { set_error("sslam_vocab_create: child offsets must be non-decreasing"); return SSLAM_ERR_INVALID; }
+    for (int i = 0; i < nch; ++i) if (children[i] <= 0 || children[i] >= nnodes) { set_error("sslam_vocab_create: child id out of range"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    sslam_vocab* v = new sslam_vocab();
+    v->ctx = ctx; v->nnodes = nnodes; v->levels = levels;
+    int rc;
+    if ((rc = v->childPtr.ensure(4 * (size_t)(nnodes + 1))) || (rc = v->children.ensure(std::max<size_t>(4 * (size_t)nch, 256))) || (rc = v->desc.ensure(32 * (size_t)nnodes)) ||
+        (rc = v->wordId.ensure(4 * (size_t)nnodes)) || (rc = v->weight.ensure(8 * (size_t)nnodes))) { sslam_vocab_destroy(v); return rc; }
+    hipStream_t st = ctx->stream;
+    SSLAM_HIP(hipMemcpyAsync(v->childPtr.p, child_ptr, 4 * (size_t)(nnodes + 1), hipMemcpyHostToDevice, st));
+    if (nch > 0) SSLAM_HIP(hipMemcpyAsync(v->children.p, children, 4 * (size_t)nch, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(v->desc.p, node_desc, 32 * (size_t)nnodes, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(v->wordId.p, word_id, 4 * (size_t)nnodes, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(v->weight.p, weight, 8 * (size_t)nnodes, hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    *out = v;
+    return SSLAM_OK;
+}
+
+extern "C" void sslam_vocab_destroy(sslam_vocab* v) {
+    if (!v) return;
+    if (v->ctx) (void)hipSetDevice(v->ctx->device);
+    v->childPtr.release(); v->children.release(); v->desc.release(); v->wordId.release(); v->weight.release();
+    delete v;
+}
+
+static int bow_core(sslam_ctx* ctx, const sslam_vocab* v, const uint8_t* d_desc, int n, int levelsup, int32_t* word_out, double* weight_out, int32_t* node_out) {
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t oW = 0, oV = oW + al(4 * (size_t)n), oN = oV + al(8 * (size_t)n), total = oN + al(4 * (size_t)n);
+    int rc;
+    if ((rc = ctx->scratch[6].ensure(total))) return rc;
+    uint8_t* B = ctx->scratch[6].as<uint8_t>();
+    { sslam::ProfScope _ps(ctx, "k_bow_transform", st);
+      hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, st, d_desc, n, v->childPtr.as<int>(), v->children.as<int>(), v->desc.as<uint8_t>(),
+                         v->wordId.as<int>(), v->weight.as<double>(), v->levels - levelsup, (int*)(B + oW), (double*)(B + oV), (int*)(B + oN)); }
+    SSLAM_HIP(hipGetLastError());
+    SSLAM_HIP(hipMemcpyAsync(word_out, B + oW, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(weight_out, B + oV, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(node_out, B + oN, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_bow_transform_frame(sslam_ctx* ctx, const sslam_vocab* vocab, const sslam_frame* frame, int levelsup,
+                                         int32_t* word_out, double* weight_out, int32_t* node_out) {
+    if (!ctx || !vocab || !frame || vocab->ctx != ctx || frame->ctx != ctx || levelsup < 0 || (frame->n > 0 && (!word_out || !weight_out || !node_out))) {
+        set_error("sslam_bow_transform_frame: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    if (frame->n == 0) return SSLAM_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    return bow_core(ctx, vocab, frame->desc.as<uint8_t>(), frame->n, levelsup, word_out, weight_out, node_out);
+}
+
+extern "C" int sslam_bow_transform(sslam_ctx* ctx, const sslam_vocab* vocab, const uint8_t* desc, int n, int levelsup,
+                                   int32_t* word_out, double* weight_out, int32_t* node_out) {
+    if (!ctx || !vocab || vocab->ctx != ctx || n < 0 || levelsup < 0 || (n > 0 && (!desc || !word_out || !weight_out || !node_out))) {
+        set_error("sslam_bow_transform: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    if (n == 0) return SSLAM_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ctx->scratch[7].ensure(32 * (size_t)n))) return rc;
+    SSLAM_HIP(hipMemcpyAsync(ctx->scratch[7].p, desc, 32 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    return bow_core(ctx, vocab, ctx->scratch[7].as<uint8_t>(), n, levelsup, word_out, weight_out, node_out);
 }

@@ -148,6 +148,35 @@ class Context:
         return pairs[:n.value].copy(), mad.value, mad12.value
 
 
+class Vocabulary:
+    """Device-resident DBoW2 vocabulary tree (sslam_vocab_*): CSR children lists in DBoW2's node numbering."""
+
+    def __init__(self, ctx, levels, child_ptr, children, node_desc, word_id, weight):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        child_ptr = np.ascontiguousarray(child_ptr, np.int32); children = np.ascontiguousarray(children, np.int32)
+        node_desc = np.ascontiguousarray(node_desc, np.uint8); word_id = np.ascontiguousarray(word_id, np.int32)
+        weight = np.ascontiguousarray(weight, np.float64)
+        _chk(lib().sslam_vocab_create(ctx.h, len(child_ptr) - 1, int(levels), _p(child_ptr), _p(children), _p(node_desc), _p(word_id), _p(weight), C.byref(self.h)))
+
+    def transform(self, desc, levelsup=4):
+        """per feature: (word id, word weight, node at level L - levelsup) -- Frame::ComputeBoW's device part"""
+        if isinstance(desc, Frame):
+            n = len(desc)
+            w = np.zeros(n, np.int32); v = np.zeros(n, np.float64); nd = np.zeros(n, np.int32)
+            _chk(lib().sslam_bow_transform_frame(self.ctx.h, self.h, desc.h, int(levelsup), _p(w), _p(v), _p(nd)))
+            return w, v, nd
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        w = np.zeros(n, np.int32); v = np.zeros(n, np.float64); nd = np.zeros(n, np.int32)
+        _chk(lib().sslam_bow_transform(self.ctx.h, self.h, _p(desc), n, int(levelsup), _p(w), _p(v), _p(nd)))
+        return w, v, nd
+
+    def close(self):
+        if self.h:
+            lib().sslam_vocab_destroy(self.h); self.h = C.c_void_p()
+
+
 class Frame:
     """Device-resident features of one Frame (sslam_frame_*): upload once, or snapshot what an extractor just produced."""
 

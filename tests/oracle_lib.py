@@ -166,13 +166,23 @@ def _orc_match_methods():
                                                 int(bool(only_stereo)), int(bool(check_orientation)), _p(m12))
         return m12, n
 
+    def bow_transform(self, levels, child_ptr, children, node_desc, word_id, weight, feat, levelsup=4):
+        child_ptr = np.ascontiguousarray(child_ptr, np.int32); children = np.ascontiguousarray(children, np.int32)
+        node_desc = np.ascontiguousarray(node_desc, np.uint8); word_id = np.ascontiguousarray(word_id, np.int32)
+        weight = np.ascontiguousarray(weight, np.float64); feat = np.ascontiguousarray(feat, np.uint8)
+        n = len(feat)
+        w = np.zeros(n, np.int32); v = np.zeros(n, np.float64); nd = np.zeros(n, np.int32)
+        self.L.orc_bow_transform(len(child_ptr) - 1, int(levels), _p(child_ptr), _p(children), _p(node_desc), _p(word_id), _p(weight), _p(feat), n,
+                                 int(levelsup), _p(w), _p(v), _p(nd))
+        return w, v, nd
+
     def distinctive(self, desc, ptr):
         desc = np.ascontiguousarray(desc, np.uint8); ptr = np.ascontiguousarray(ptr, np.int32)
         best = np.zeros(len(ptr) - 1, np.int32)
         self.L.orc_distinctive(_p(desc), _p(ptr), len(ptr) - 1, _p(best))
         return best
 
-    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, distinctive, fuse_search, search_for_triangulation):
+    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, distinctive, fuse_search, search_for_triangulation, bow_transform):
         setattr(Oracle, f.__name__, f)
 
 

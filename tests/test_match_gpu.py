@@ -278,3 +278,51 @@ def test_search_for_triangulation(fe, ctx, oracle, seed, only_stereo, ori):
     assert on > 30 and n == on, (n, on)
     np.testing.assert_array_equal(m, om)
     f1.close(); f2.close()
+
+
+# ---- DBoW2 vocabulary descent, Frame::ComputeBoW.  The ORBvoc file is an LFS pointer in the reference
+# tree, so the tree here is synthetic: k-ary, L levels, clustered node descriptors, a few stopped words (weight 0) and a ragged branch.
+def _synthetic_vocab(rng, k=10, L=4):
+    ptr = [0]; children = []; desc = [np.zeros(32, np.uint8)]; level_of = [0]
+    parent_desc = {0: rng.integers(0, 256, 32, dtype=np.uint8)}
+    frontier = [0]; nid = 1
+    child_lists = {}
+    for lvl in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            kk = k if not (lvl == L and p % 7 == 3) else 0           # some level L-1 nodes stay leaves (ragged tree)
+            ids = list(range(nid, nid + kk)); nid += kk
+            child_lists[p] = ids
+            for c in ids:
+                flips = rng.random(256) < 0.5 / lvl
+                parent_desc[c] = parent_desc[p] ^ np.packbits(flips)
+                level_of.append(lvl)
+            nxt += ids
+        frontier = nxt
+    n = nid
+    ptr = np.zeros(n + 1, np.int32); ch = []
+    for i in range(n):
+        ids = child_lists.get(i, [])
+        ch += ids; ptr[i + 1] = len(ch)
+    desc = np.stack([parent_desc[i] for i in range(n)])
+    leaf = np.array([len(child_lists.get(i, [])) == 0 for i in range(n)])
+    word = np.full(n, -1, np.int32); word[leaf] = np.arange(leaf.sum(), dtype=np.int32)
+    weight = np.zeros(n, np.float64); weight[leaf] = np.where(rng.random(leaf.sum()) < 0.05, 0.0, rng.uniform(0.1, 9.0, leaf.sum()))
+    return L, ptr, np.array(ch, np.int32), desc, word, weight
+
+
+@pytest.mark.parametrize("levelsup", [4, 2, 0, 6])
+def test_bow_transform(fe, ctx, oracle, levelsup):
+    rng = np.random.default_rng(5)
+    L, ptr, ch, nd, word, weight = _synthetic_vocab(rng)
+    kp, d = oracle.orb_extract(synth_frame(1234), 1000)
+    feat = np.concatenate([d, nd[rng.integers(1, len(nd), 200)]])        # real descriptors + exact node descriptors (distance-0 ties)
+    voc = fe.Vocabulary(ctx, L, ptr, ch, nd, word, weight)
+    w, v, n = voc.transform(feat, levelsup)
+    ow, ov, on = oracle.bow_transform(L, ptr, ch, nd, word, weight, feat, levelsup)
+    np.testing.assert_array_equal(w, ow); np.testing.assert_array_equal(v, ov); np.testing.assert_array_equal(n, on)
+    assert (w >= 0).all() and len(np.unique(w)) > 300
+    fr = ctx.frame_upload(0, kp, d)
+    w2, v2, n2 = voc.transform(fr, levelsup)                               # Frame::ComputeBoW on a resident frame
+    np.testing.assert_array_equal(w2, ow[:len(d)]); np.testing.assert_array_equal(n2, on[:len(d)])
+    fr.close(); voc.close()
