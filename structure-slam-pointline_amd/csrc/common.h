@@ -126,12 +126,25 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o, 64));
     return v;
 }
+// lane permutations inside a row of 16 run on the DPP path (no LDS round trip): quad swaps, then row rotations by 4 and 8;
+// only the two cross-row steps go through ds_bpermute
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)v, CTRL, 0xF, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    unsigned long long w;
+    w = dpp_u64<0xB1>(v); v = w < v ? w : v;          // quad_perm [1,0,3,2]
+    w = dpp_u64<0x4E>(v); v = w < v ? w : v;          // quad_perm [2,3,0,1]
+    w = dpp_u64<0x124>(v); v = w < v ? w : v;         // row_ror:4
+    w = dpp_u64<0x128>(v); v = w < v ? w : v;         // row_ror:8
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 16; o <= 32; o <<= 1) {
         unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o, 64);
         unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o, 64);
-        unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        w = ((unsigned long long)hi << 32) | lo;
         v = w < v ? w : v;
     }
     return v;

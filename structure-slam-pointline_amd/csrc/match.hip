@@ -529,6 +529,248 @@ __global__ __launch_bounds__(256) void k_line_match(const uint8_t* __restrict__ 
 // =============================================================== host side
 static hipStream_t pick(sslam_ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
 
+// ------------------------------------------------------------------ projection matchers, low-latency form
+// Same semantics as k_search_proj, built for the single-frame call.  The frame's features are sorted by their
+// GetFeaturesInArea order (grid column, row, index: one bitonic sort in LDS) and staged in LDS in that order (position,
+// level, angle, occupancy, descriptors), so a query only scans the sorted range of the grid columns its window touches.
+// Sixteen waves evaluate sixteen consecutive queries speculatively against the occupancy at the start of the round, each
+// wave also taking its own accept / reject decision; wave 0 then commits them in query order and re-evaluates a query only
+// if an earlier query of the same round occupied its best or second-best feature (removing any other candidate cannot
+// change best / second, so the check is exact).  Global memory is touched once per round (the next round's queries are
+// prefetched); the one-wave kernel above spends ~7 us per query on dependent global loads.
+constexpr int PROJ_WAVES = 16;
+constexpr int PROJ_MAXN = 2048;            // features that fit: 64 B each in sorted order + the sort keys
+struct ProjLds { float* px; float* py; float* ang; int* oct; float* ur; int* occ; unsigned* ord; uint4* desc; int* colStart; };
+struct ProjDecision { int acc, bestP, secondP, bin; };
+
+// best / second-best candidate of one query (keys: dist | sorted position | level; the position is unique, so the level bits
+// below it never take part in a comparison)
+__device__ __forceinline__ void proj_scan(const ProjArgs& A, const ProjLds& S, const sslam_proj_query& Q, const uint4& q0, const uint4& q1, int lane,
+                                          float invW, unsigned long long& best, unsigned long long& second, bool& anyOut) {
+    unsigned long long b = ~0ull, s = ~0ull;
+    bool any = false;
+    int p0 = 0, p1 = A.n;
+    if (A.kind == 0) {        // grid columns the window can touch (KeyFrame/Frame::GetFeaturesInArea's own cell range)
+        const int c0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.u, A.minX), Q.radius), invW)));
+        const int c1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.u, A.minX), Q.radius), invW)));
+        if (c0 >= GRID_COLS || c1 < 0) { p0 = p1 = 0; }
+        else { p0 = S.colStart[c0]; p1 = S.colStart[c1 + 1]; }
+    }
+    for (int p = p0 + lane; p < p1; p += 64) {
+        const int oct = S.oct[p];
+        if (A.kind == 0) {
+            if (Q.min_level > 0 || Q.max_level >= 0) {
+                if (oct < Q.min_level) continue;
+                if (Q.max_level >= 0 && oct > Q.max_level) continue;
+            }
+            const float dx = __fsub_rn(S.px[p], Q.u), dy = __fsub_rn(S.py[p], Q.v);
+            if (!(fabsf(dx) < Q.radius && fabsf(dy) < Q.radius)) continue;
+        } else {
+            const double mxp = 0.5 * (double)__fadd_rn(Q.u, Q.u2) - (double)S.px[p], myp = 0.5 * (double)__fadd_rn(Q.v, Q.v2) - (double)S.py[p];
+            const float distance = (float)(mxp * mxp + myp * myp);
+            if (distance > __fmul_rn(Q.radius, Q.radius)) continue;
+            const float slope = __fsub_rn(__fdiv_rn(__fsub_rn(Q.v, Q.v2), __fsub_rn(Q.u, Q.u2)), S.ang[p]);
+            if ((double)slope > (double)Q.radius * 0.01) continue;
+            if (Q.min_level > 0 || Q.max_level > 0) {
+                if (oct < Q.min_level) continue;
+                if (Q.max_level >= 0 && oct > Q.max_level) continue;
+            }
+        }
+        any = true;                              // vIndices non-empty
+        if (S.occ[p]) continue;
+        if (A.kind == 0 && A.uright) {
+            const float ur = S.ur[p];
+            if (ur > 0 && fabsf(__fsub_rn(Q.ur, ur)) > Q.radius) continue;
+        }
+        const unsigned long long kk = ((unsigned long long)hamming256(q0, q1, S.desc[2 * p], S.desc[2 * p + 1]) << 35) | ((unsigned long long)(unsigned)p << 4) | (unsigned)(oct & 15);
+        if (kk < b) { s = b; b = kk; } else if (kk < s) s = kk;
+    }
+    anyOut = __ballot(any) != 0;
+    best = wave_min_u64(b);
+    second = wave_min_u64(b == best ? s : b);
+}
+
+// the reference's accept / reject logic on (best, second): thresholds, same-level ratio test (mode 0), rotation bin (mode 1)
+__device__ __forceinline__ ProjDecision proj_decide(const ProjArgs& A, const ProjLds& S, float qAngle, unsigned long long b, unsigned long long s2) {
+    ProjDecision D; D.acc = 0; D.bestP = -1; D.secondP = -2; D.bin = -1;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1;
+    if (b != ~0ull) D.bestP = (int)((b >> 4) & 0x7FFFFFFF);
+    if (s2 != ~0ull) D.secondP = (int)((s2 >> 4) & 0x7FFFFFFF);
+    if (b != ~0ull && (int)(b >> 35) < 256) { bestDist = (int)(b >> 35); bestLevel = (int)(b & 15); }
+    if (A.mode == 0 && s2 != ~0ull && (int)(s2 >> 35) < 256) { bestDist2 = (int)(s2 >> 35); bestLevel2 = (int)(s2 & 15); }
+    if (bestDist <= A.thDist && b != ~0ull && (int)(b >> 35) < 256) {
+        if (A.mode == 0 && bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(A.nnratio, (float)bestDist2)) return D;
+        D.acc = 1;
+        if (A.mode == 1 && A.checkOri) {
+            float rot = __fsub_rn(qAngle, S.ang[D.bestP]);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+            if (bin == HISTO_LENGTH) bin = 0;
+            D.bin = bin;
+        }
+    }
+    return D;
+}
+
+__global__ __launch_bounds__(PROJ_WAVES * 64) void k_search_proj_lds(ProjArgs A) {
+    extern __shared__ __align__(16) uint8_t dyn[];
+    constexpr int NT = PROJ_WAVES * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = A.n, nq = A.nq;
+    int* key2 = A.scratch + n; int* qbin = key2 + n; int* qidx = qbin + nq;      // same scratch layout as k_search_proj
+    int N2 = 64; while (N2 < n) N2 <<= 1;
+    ProjLds S;
+    S.desc = (uint4*)dyn;
+    S.px = (float*)(S.desc + 2 * (size_t)n); S.py = S.px + n; S.ang = S.py + n; S.ur = S.ang + n;
+    S.oct = (int*)(S.ur + n); S.occ = S.oct + n; S.ord = (unsigned*)(S.occ + n); S.colStart = (int*)(S.ord + N2);
+    __shared__ int rAcc[PROJ_WAVES], rBestP[PROJ_WAVES], rSecondP[PROJ_WAVES], rBin[PROJ_WAVES], rObs[PROJ_WAVES];
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int sh_nmatches;
+    const sslam_keypoint* kps = (const sslam_keypoint*)A.feats;
+    const sslam_keyline* kls = (const sslam_keyline*)A.feats;
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) sh_nmatches = 0;
+    const float invW = __fdiv_rn((float)GRID_COLS, __fsub_rn(A.maxX, A.minX));
+    const float invH = __fdiv_rn((float)GRID_ROWS, __fsub_rn(A.maxY, A.minY));
+    // sort keys: (grid column * ROWS + grid row) << 19 | index; features outside the grid (and the padding) sort last
+    for (int i = tid; i < N2; i += NT) {
+        unsigned k = 0xFFFFFFFFu;
+        if (i < n) {
+            A.assigned[i] = -1;
+            if (A.kind == 0) {
+                const int gx = (int)roundf(__fmul_rn(__fsub_rn(kps[i].x, A.minX), invW));
+                const int gy = (int)roundf(__fmul_rn(__fsub_rn(kps[i].y, A.minY), invH));
+                if (gx >= 0 && gx < GRID_COLS && gy >= 0 && gy < GRID_ROWS) k = ((unsigned)(gx * GRID_ROWS + gy) << 19) | (unsigned)i;
+            } else k = (unsigned)i;                 // lines: GetLinesInArea scans in index order
+        }
+        S.ord[i] = k;
+    }
+    for (int i = tid; i < nq; i += NT) qbin[i] = -1;
+    __syncthreads();
+    if (A.kind == 0) {
+        for (int k = 2; k <= N2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < N2; i += NT) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned a = S.ord[i], b2 = S.ord[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > b2) == up) { S.ord[i] = b2; S.ord[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+    }
+    // stage the features in sorted order; A.n shrinks to the features that are in the grid (the rest can never be a candidate)
+    int nIn = n;
+    if (A.kind == 0) {
+        int c = 0;
+        for (int i = tid; i < n; i += NT) c += S.ord[i] != 0xFFFFFFFFu ? 1 : 0;
+        c = wave_sum(c);
+        if (lane == 0) atomicAdd(&sh_nmatches, c);
+        __syncthreads();
+        nIn = sh_nmatches;
+        __syncthreads();
+        if (tid == 0) sh_nmatches = 0;
+    }
+    for (int p = tid; p < nIn; p += NT) {
+        const int i = (int)(S.ord[p] & 0x7FFFFu);
+        if (A.kind == 0) { const sslam_keypoint kp = kps[i]; S.px[p] = kp.x; S.py[p] = kp.y; S.ang[p] = kp.angle; S.oct[p] = kp.octave; }
+        else { const sslam_keyline kl = kls[i]; S.px[p] = kl.pt_x; S.py[p] = kl.pt_y; S.ang[p] = kl.angle; S.oct[p] = kl.octave; }
+        S.occ[p] = A.occIn ? (int)A.occIn[i] : 0;
+        S.ur[p] = A.uright ? A.uright[i] : -1.f;
+        S.desc[2 * p] = ((const uint4*)A.desc)[2 * i]; S.desc[2 * p + 1] = ((const uint4*)A.desc)[2 * i + 1];
+    }
+    if (A.kind == 0) {        // colStart[c] = first sorted position whose grid column is >= c
+        for (int p = tid; p <= nIn; p += NT) {
+            const int colPrev = p == 0 ? -1 : (int)(S.ord[p - 1] >> 19) / GRID_ROWS;
+            const int colCur = p == nIn ? GRID_COLS : (int)(S.ord[p] >> 19) / GRID_ROWS;
+            for (int c = colPrev + 1; c <= colCur; ++c) S.colStart[c] = p;
+        }
+    }
+    __syncthreads();
+    ProjArgs B = A; B.n = nIn;
+    // this wave's query of the first round
+    sslam_proj_query Q; uint4 q0, q1;
+    Q.valid = 0; Q.obs_positive = 0; Q.angle = 0.f;
+    q0 = q1 = make_uint4(0, 0, 0, 0);
+    if (wave < nq) { Q = A.q[wave]; q0 = ((const uint4*)(A.qdesc + (size_t)wave * 32))[0]; q1 = ((const uint4*)(A.qdesc + (size_t)wave * 32))[1]; }
+    for (int base = 0; base < nq; base += PROJ_WAVES) {
+        const int iq = base + wave;
+        // prefetch the next round's query while this one is evaluated
+        sslam_proj_query Qn; uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+        Qn.valid = 0; Qn.obs_positive = 0; Qn.angle = 0.f;
+        const int iqn = iq + PROJ_WAVES;
+        if (iqn < nq) { Qn = A.q[iqn]; n0 = ((const uint4*)(A.qdesc + (size_t)iqn * 32))[0]; n1 = ((const uint4*)(A.qdesc + (size_t)iqn * 32))[1]; }
+        ProjDecision D; D.acc = 0; D.bestP = -1; D.secondP = -2; D.bin = -1;
+        if (iq < nq && Q.valid) {
+            unsigned long long best, second; bool any;
+            proj_scan(B, S, Q, q0, q1, lane, invW, best, second, any);
+            if (any) D = proj_decide(B, S, Q.angle, best, second);
+        }
+        if (lane == 0) { rAcc[wave] = D.acc; rBestP[wave] = D.bestP; rSecondP[wave] = D.secondP; rBin[wave] = D.bin; rObs[wave] = Q.obs_positive; }
+        __syncthreads();
+        if (wave == 0) {
+            // lane w holds what wave w decided; the serial loop broadcasts with v_readlane, and lane t remembers the t-th
+            // feature occupied during this round
+            const int cnt = min(PROJ_WAVES, nq - base);
+            const int myAcc = lane < cnt ? rAcc[lane] : 0, myBP = lane < cnt ? rBestP[lane] : -1, mySP = lane < cnt ? rSecondP[lane] : -2;
+            const int myBin = lane < cnt ? rBin[lane] : -1, myObs = lane < cnt ? rObs[lane] : 0;
+            int myTaken = -3, nTaken = 0, accepted = 0;
+            for (int w = 0; w < cnt; ++w) {
+                int acc = __builtin_amdgcn_readlane(myAcc, w), bP = __builtin_amdgcn_readlane(myBP, w), bin = __builtin_amdgcn_readlane(myBin, w);
+                const int sP = __builtin_amdgcn_readlane(mySP, w);
+                const int jq = base + w;
+                if (nTaken > 0 && __ballot(lane < nTaken && (myTaken == bP || myTaken == sP))) {      // rare: re-evaluate against the updated occupancy
+                    const sslam_proj_query Qw = A.q[jq];
+                    const uint4 w0 = ((const uint4*)(A.qdesc + (size_t)jq * 32))[0], w1 = ((const uint4*)(A.qdesc + (size_t)jq * 32))[1];
+                    unsigned long long b, s2; bool any2;
+                    proj_scan(B, S, Qw, w0, w1, lane, invW, b, s2, any2);
+                    ProjDecision R; R.acc = 0; R.bestP = -1; R.bin = -1;
+                    if (any2) R = proj_decide(B, S, Qw.angle, b, s2);
+                    acc = R.acc; bP = R.bestP; bin = R.bin;
+                }
+                if (!acc) continue;
+                ++accepted;
+                const int obsPositive = __builtin_amdgcn_readlane(myObs, w);
+                if (lane == 0) {
+                    const int fi = (int)(S.ord[bP] & 0x7FFFFu);
+                    A.assigned[fi] = jq;
+                    if (obsPositive) S.occ[bP] = 1;
+                    if (A.mode == 1 && A.checkOri) { qbin[jq] = bin; qidx[jq] = fi; hist[bin]++; }
+                }
+                if (obsPositive) { if (lane == nTaken) myTaken = bP; ++nTaken; }
+            }
+            if (lane == 0) sh_nmatches += accepted;
+        }
+        __syncthreads();
+        Q = Qn; q0 = n0; q1 = n1;
+    }
+    if (wave == 0) {
+        int nmatches = sh_nmatches;
+        if (A.mode == 1 && A.checkOri) {
+            int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+            for (int i = 0; i < HISTO_LENGTH; ++i) {
+                const int c = hist[i];
+                if (c > max1) { max3 = max2; max2 = max1; max1 = c; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (c > max2) { max3 = max2; max2 = c; ind3 = ind2; ind2 = i; }
+                else if (c > max3) { max3 = c; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+            int removed = 0;
+            for (int i0 = 0; i0 < nq; i0 += 64) {
+                const int i = i0 + lane;
+                bool rm = false;
+                if (i < nq) { const int bn = qbin[i]; rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3; if (rm) A.assigned[qidx[i]] = -1; }
+                removed += __popcll(__ballot(rm));
+            }
+            nmatches -= removed;
+        }
+        if (lane == 0) *A.nmatches = nmatches;
+    }
+}
+
 // ------------------------------------------------------------------ Fuse: independent best match per projected point / line
 // ORBmatcher::Fuse (src/ORBmatcher.cc:897-948 with the chi-square gates, :1055-1080 without) and LSDmatcher::Fuse
 // (src/LSDmatcher.cpp:497-523): every query keeps the candidate with the smallest Hamming distance, the first one in
@@ -960,7 +1202,13 @@ static int search_proj_core(sslam_ctx* ctx, int kind, int mode, const void* d_fe
     A.uright = d_uright; A.occIn = occupied ? B + oO : nullptr;
     A.q = (const sslam_proj_query*)(B + oQ); A.qdesc = B + oQD; A.nq = nq; A.nnratio = nnratio; A.thDist = th_dist; A.checkOri = check_orientation;
     A.assigned = (int*)(B + oA); A.nmatches = (int*)(B + oN); A.scratch = (int*)(B + oS);
-    { sslam::ProfScope _ps(ctx, "k_search_proj", st); hipLaunchKernelGGL(k_search_proj, dim3(1), dim3(64), 0, st, A); }
+    if (n <= PROJ_MAXN) {       // the frame fits in LDS: sixteen speculative queries per round
+        int n2 = 64; while (n2 < n) n2 <<= 1;
+        const size_t lds = (size_t)n * (32 + 6 * 4) + (size_t)n2 * 4 + (GRID_COLS + 2) * 4 + 64;
+        if (lds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_search_proj_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        sslam::ProfScope _ps(ctx, "k_search_proj_lds", st);
+        hipLaunchKernelGGL(k_search_proj_lds, dim3(1), dim3(PROJ_WAVES * 64), lds, st, A);
+    } else { sslam::ProfScope _ps(ctx, "k_search_proj", st); hipLaunchKernelGGL(k_search_proj, dim3(1), dim3(64), 0, st, A); }
     SSLAM_HIP(hipGetLastError());
     SSLAM_HIP(hipMemcpyAsync(assigned_out, B + oA, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + oN, sizeof(int), hipMemcpyDeviceToHost, st));
