@@ -62,6 +62,8 @@ __device__ const signed char kPat[1024] = {
 };
 __constant__ int kUmax[16];
 __constant__ int kBlurTaps[7];
+__constant__ unsigned kBlurPack[2];      // taps 0-3 and 4-6 as bytes, for v_dot4_u32_u8
+__constant__ unsigned kDiscMask[31 * 8];  // byte masks of the r=15 disc: row v, dword m covers u = 4m-15 .. 4m-12
 
 // ------------------------------------------------------------------ level 0 copy
 __global__ void k_copy_level0(const uint8_t* __restrict__ in, size_t pitch, size_t imageStride,
@@ -582,59 +584,74 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
     const unsigned pk = sel[(size_t)b * P.selFrame + slot];
     const int kx = (int)(pk & 0xFFF) + MINB, ky = (int)((pk >> 12) & 0xFFF) + MINB, score = pk >> 24;
     const uint8_t* img = pyr + (size_t)b * pyrFrame + L.off;
-    // stage the 43x43 patch.  Interior keypoints (almost all): 12 aligned dwords per row, the patch then starts at
-    // byte `off` of each LDS row.  Keypoints within 21 px of the level border: byte loads with reflect-101.
+    // stage the 43x43 patch so that patch column c sits at LDS byte c + 2 of its row: the disc of IC_Angle (columns 6..36)
+    // and the four-output groups of the horizontal blur then start on dword boundaries and can be consumed as whole dwords
+    // (v_dot4_u32_u8 does four multiply-adds per instruction).  Interior keypoints (almost all): 12 aligned global dwords per
+    // row, shifted into place with v_alignbyte against the neighbouring lane's dword (DPP); five rows per pass so that a row
+    // never straddles the wave.  Keypoints within 21 px of the level border: byte loads with reflect-101.
+    constexpr int SH = 2;
     const int ax = (kx - PR) & ~3;
     const bool interior = kx - PR >= 0 && ky - PR >= 0 && ky + PR < L.h && kx + PR < L.w && ax + 48 <= L.pitch;
-    const int off = interior ? (kx - PR) - ax : 0;
     if (interior) {
+        const int delta = (kx - PR) - ax - SH;                     // LDS byte b of a row = global byte ax + delta + b
         const uint8_t* src = img + (size_t)(ky - PR) * L.pitch + ax;
-        for (int i = lane; i < PW * 12; i += 64) {
-            const int r = i / 12, q = i - r * 12;
-            ((unsigned*)(patch + r * PP))[q] = ((const unsigned*)(src + (size_t)r * L.pitch))[q];
+        const int rr = lane / 12, q = lane - rr * 12;
+        for (int r0 = 0; r0 < PW; r0 += 5) {
+            const int r = r0 + rr;
+            const bool on = lane < 60 && r < PW;
+            const unsigned g = on ? ((const unsigned*)(src + (size_t)r * L.pitch))[q] : 0u;
+            const unsigned nxt = (unsigned)__builtin_amdgcn_mov_dpp((int)g, 0x130, 0xF, 0xF, false);      // wave_shl:1 = lane + 1
+            const unsigned prv = (unsigned)__builtin_amdgcn_mov_dpp((int)g, 0x138, 0xF, 0xF, false);      // wave_shr:1 = lane - 1
+            unsigned word;
+            if (delta >= 0) word = __builtin_amdgcn_alignbyte(q < 11 ? nxt : 0u, g, (unsigned)delta);
+            else word = __builtin_amdgcn_alignbyte(g, q > 0 ? prv : 0u, (unsigned)(delta + 4));
+            if (on) ((unsigned*)(patch + r * PP))[q] = word;
         }
     } else {
         for (int i = lane; i < PW * PW; i += 64) {
             int r = i / PW, c = i - r * PW;
             int yy = reflect101(ky - PR + r, L.h), xx = reflect101(kx - PR + c, L.w);
-            patch[r * PP + c] = img[(size_t)yy * L.pitch + xx];
+            patch[r * PP + SH + c] = img[(size_t)yy * L.pitch + xx];
         }
     }
     __syncthreads();
-    // intensity centroid over the r=15 disc
+    // intensity centroid over the r=15 disc: lane = (row v, dword m); weights u + 16 keep the dot product unsigned
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-        int r = i / 31, c = i - r * 31;
-        int v = r - HALF_PATCH, u = c - HALF_PATCH;
-        if (abs(u) <= kUmax[abs(v)]) {
-            int I = patch[(PR + v) * PP + off + (PR + u)];
-            m10 += u * I; m01 += v * I;
-        }
+    for (int i = lane; i < 31 * 8; i += 64) {
+        const int r = i >> 3, m = i & 7;
+        const unsigned I4 = ((const unsigned*)(patch + (PR - HALF_PATCH + r) * PP + 8))[m] & kDiscMask[i];
+        const unsigned w0 = (unsigned)(4 * m + 1);
+        const unsigned W4 = w0 | ((w0 + 1) << 8) | ((w0 + 2) << 16) | ((w0 + 3) << 24);
+        const int sum = (int)__builtin_amdgcn_udot4(I4, 0x01010101u, 0u, false);
+        m10 += (int)__builtin_amdgcn_udot4(I4, W4, 0u, false) - 16 * sum;
+        m01 += (r - HALF_PATCH) * sum;
     }
     m10 = wave_sum(m10); m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // horizontal blur pass: all 43 rows, columns x-18..x+21 in groups of four outputs from ten bytes
+    // horizontal blur pass: all 43 rows, columns x-18..x+21 in groups of four outputs from three dwords
+    const unsigned T0 = kBlurPack[0], T1 = kBlurPack[1];
     for (int i = lane; i < PW * 10; i += 64) {
         const int r = i / 10, g4 = i - r * 10;
-        const uint8_t* p = patch + r * PP + off + g4 * 4;
-        unsigned v[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) v[k] = p[k];
-        unsigned o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned acc = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) acc += v[j + k] * (unsigned)kBlurTaps[k];
-            o[j] = acc;
-        }
-        uint2 w2; w2.x = o[0] | (o[1] << 16); w2.y = o[2] | (o[3] << 16);
+        const unsigned* p = (const unsigned*)(patch + r * PP) + g4;
+        const unsigned d0 = p[0], d1 = p[1], d2 = p[2];
+        // output j uses LDS bytes 4*g4 + 2 + j .. + 8 + j
+        const unsigned lo0 = __builtin_amdgcn_alignbyte(d1, d0, 2), hi0 = __builtin_amdgcn_alignbyte(d2, d1, 2);
+        const unsigned lo1 = __builtin_amdgcn_alignbyte(d1, d0, 3), hi1 = __builtin_amdgcn_alignbyte(d2, d1, 3);
+        const unsigned lo2 = d1, hi2 = d2;
+        const unsigned lo3 = __builtin_amdgcn_alignbyte(d2, d1, 1), hi3 = d2 >> 8;     // the fourth byte of hi has tap weight 0
+        const unsigned o0 = __builtin_amdgcn_udot4(lo0, T0, __builtin_amdgcn_udot4(hi0, T1, 0u, false), false);
+        const unsigned o1 = __builtin_amdgcn_udot4(lo1, T0, __builtin_amdgcn_udot4(hi1, T1, 0u, false), false);
+        const unsigned o2 = __builtin_amdgcn_udot4(lo2, T0, __builtin_amdgcn_udot4(hi2, T1, 0u, false), false);
+        const unsigned o3 = __builtin_amdgcn_udot4(lo3, T0, __builtin_amdgcn_udot4(hi3, T1, 0u, false), false);
+        uint2 w2; w2.x = o0 | (o1 << 16); w2.y = o2 | (o3 << 16);
         *(uint2*)(hb + r * 40 + g4 * 4) = w2;
     }
     __syncthreads();
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
-    const float a = (float)cos((double)ang), bsn = (float)sin((double)ang);    // D5
+    double snD, csD;
+    sincos((double)ang, &snD, &csD);                                           // D5: one argument reduction for both
+    const float a = (float)csD, bsn = (float)snD;
     unsigned nib = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -915,6 +932,18 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
         std::vector<int> taps = blur_taps_q8(7, 2.0);
         SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kUmax), o->umax, sizeof(int) * 16));
         SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kBlurTaps), taps.data(), sizeof(int) * 7));
+        for (int t : taps) if (t < 0 || t > 255) { set_error("blur taps do not fit a byte"); return SSLAM_ERR_UNSUPPORTED; }
+        const unsigned pack[2] = {(unsigned)taps[0] | ((unsigned)taps[1] << 8) | ((unsigned)taps[2] << 16) | ((unsigned)taps[3] << 24),
+                                  (unsigned)taps[4] | ((unsigned)taps[5] << 8) | ((unsigned)taps[6] << 16)};
+        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kBlurPack), pack, sizeof(pack)));
+        unsigned mask[31 * 8];
+        for (int r = 0; r < 31; ++r)
+            for (int m = 0; m < 8; ++m) {
+                unsigned w = 0;
+                for (int k = 0; k < 4; ++k) { const int u = 4 * m + k - 15; if (std::abs(u) <= o->umax[std::abs(r - 15)]) w |= 0xFFu << (8 * k); }
+                mask[r * 8 + m] = w;
+            }
+        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kDiscMask), mask, sizeof(mask)));
         o->constsUploaded = true;
     }
     if (nframes > o->wsFrames) { SSLAM_HIP(hipStreamSynchronize(st)); }
