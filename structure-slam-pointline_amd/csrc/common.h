@@ -149,15 +149,16 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     }
     return v;
 }
-// inclusive prefix sum across the wave
+// inclusive prefix sum across the wave: four DPP row_shr steps inside each row of 16 (zero fill at the row start), then the
+// three row totals are added with v_readlane; no LDS round trip
 __device__ __forceinline__ int wave_incl_scan(int v) {
-    int l = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o, 64);
-        if (l >= o) v += t;
-    }
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane_id() >> 4;
+    return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
 }
 
 __device__ __forceinline__ int reflect101(int i, int n) {

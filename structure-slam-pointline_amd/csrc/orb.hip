@@ -61,6 +61,9 @@ __device__ const signed char kPat[1024] = {
 #include "orb_pattern.inc"
 };
 __constant__ int kUmax[16];
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(unsigned v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ unsigned as_u32(s16x2 v) { return __builtin_bit_cast(unsigned, v); }
 __constant__ int kBlurTaps[7];
 __constant__ unsigned kBlurPack[2];      // taps 0-3 and 4-6 as bytes, for v_dot4_u32_u8
 __constant__ unsigned kDiscMask[31 * 8];  // byte masks of the r=15 disc: row v, dword m covers u = 4m-15 .. 4m-12
@@ -210,23 +213,58 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     __syncthreads();
     const int npx = cw * ch;
     const unsigned magic = (1u << 20) / (unsigned)cw + 1;      // floor(i/cw) == (i*magic)>>20 for i < 4400, cw <= 64
-    // pass A: cheap pretest on every pixel (a 9-arc contains one pixel of every opposite ring pair: if the vertical pair is
-    // within +-minTh of the centre the pixel cannot be a corner); survivors are compacted so that the expensive ring
-    // evaluation of pass B runs with full lanes on the few pixels that can matter.
+    // pass A: necessary condition for a 9-arc at minTh, four pixels per lane on whole dwords.  Nine contiguous ring positions
+    // always contain two ADJACENT compass points (ring 0/4/8/12 = S/E/N/W at distance 3), i.e. one vertical and one
+    // horizontal one, and both must lie on the arc's side of the threshold:
+    //   ((S|N brighter) & (E|W brighter)) | ((S|N darker) & (E|W darker)).
+    // Bytes are widened to two 16-bit halves per dword and compared with packed i16 arithmetic (sign bit of th -/+ (r - v)).
+    // Survivors are compacted in raster order so that the expensive ring evaluation of pass B runs with full lanes on the few
+    // pixels that can matter.
     unsigned short* clist = (unsigned short*)(lds + (((P.maxCellH + 6) * tileP + (P.maxCellH + 2) * scP + P.maxCellH * P.maxCellW + 7) & ~3));
     int ncl = 0;
-    for (int i0 = 0; i0 < npx; i0 += 64) {
-        const int i = i0 + lane;
-        bool maybe = false;
-        if (i < npx) {
-            const int py = (int)(((unsigned long long)(unsigned)i * magic) >> 20), px = i - py * cw;
-            const uint8_t* c = tile + (py + 3) * tileP + (off + px + 3);
-            const int v = c[0], r0 = c[3 * tileP], r8 = c[-3 * tileP];
-            maybe = abs(r0 - v) > minTh || abs(r8 - v) > minTh;
+    {
+        const int T0 = off + 3;                                    // tile column of pixel 0
+        const int gmin = T0 >> 2, ng = ((T0 + cw - 1) >> 2) - gmin + 1;
+        const unsigned gmagic = (1u << 20) / (unsigned)ng + 1;     // ng <= 17, items < 4400
+        const int nitems = ch * ng;
+        const s16x2 th2 = {(short)minTh, (short)minTh};
+        for (int it0 = 0; it0 < nitems; it0 += 64) {
+            const int it = it0 + lane;
+            unsigned flags = 0;
+            int py = 0, g = 0;
+            if (it < nitems) {
+                py = (int)(((unsigned long long)(unsigned)it * gmagic) >> 20);
+                g = gmin + (it - py * ng);
+                const unsigned* rc = (const unsigned*)(tile + (py + 3) * tileP) + g;
+                const unsigned c1 = rc[0], c0 = rc[-1], c2 = rc[1];
+                const unsigned n4 = ((const unsigned*)(tile + py * tileP))[g], s4 = ((const unsigned*)(tile + (py + 6) * tileP))[g];
+                const unsigned e4 = __builtin_amdgcn_alignbyte(c2, c1, 3), w4 = __builtin_amdgcn_alignbyte(c1, c0, 1);
+                unsigned res = 0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                      // h = 0: bytes 0,2   h = 1: bytes 1,3
+                    const unsigned sh = 8 * h;
+                    const s16x2 v = as_s16x2((c1 >> sh) & 0x00FF00FFu);
+                    const s16x2 dn = as_s16x2((n4 >> sh) & 0x00FF00FFu) - v, ds = as_s16x2((s4 >> sh) & 0x00FF00FFu) - v;
+                    const s16x2 de = as_s16x2((e4 >> sh) & 0x00FF00FFu) - v, dw = as_s16x2((w4 >> sh) & 0x00FF00FFu) - v;
+                    // sign(th - d) <=> d > th (brighter), sign(th + d) <=> d < -th (darker)
+                    const unsigned bV = as_u32(th2 - dn) | as_u32(th2 - ds), bH = as_u32(th2 - de) | as_u32(th2 - dw);
+                    const unsigned dV = as_u32(th2 + dn) | as_u32(th2 + ds), dH = as_u32(th2 + de) | as_u32(th2 + dw);
+                    const unsigned m = ((bV & bH) | (dV & dH)) & 0x80008000u;
+                    res |= m >> (15 - h);                          // bit 0+h from byte h, bit 16+h from byte 2+h
+                }
+                // res bits: 0 -> byte 0, 1 -> byte 1, 16 -> byte 2, 17 -> byte 3
+                flags = (res & 3u) | ((res >> 14) & 12u);
+                const int px0 = 4 * g - T0;                        // pixel of byte 0
+                flags &= (0xFu << max(0, -px0)) & (0xFu >> max(0, px0 + 4 - cw));      // bytes that are pixels of this cell
+            }
+            const int cntf = __popc(flags);
+            const int incl = wave_incl_scan(cntf);
+            int pos = ncl + incl - cntf;
+            const int ibase = py * cw + 4 * g - T0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (flags & (1u << k)) clist[pos++] = (unsigned short)(ibase + k);
+            ncl += __builtin_amdgcn_readlane(incl, 63);
         }
-        const unsigned long long m = __ballot(maybe);
-        if (maybe) clist[ncl + mbcnt(m)] = (unsigned short)i;
-        ncl += __popcll(m);
     }
     __syncthreads();
     for (int j = lane; j < ncl; j += 64) {
