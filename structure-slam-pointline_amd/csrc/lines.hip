@@ -66,23 +66,31 @@ struct Misc {                 // per-frame scalars
 // loads in flight (these kernels are latency-bound, not byte-bound).
 constexpr int STRIP = 32;
 
-// source columns x4-4 .. x4+7 of row yy (BORDER_REFLECT_101 in x for the threads that touch the border)
-__device__ __forceinline__ void load_row12(const uint8_t* __restrict__ s, size_t spitch, int yy, int x4, int w, bool fast, unsigned px[12]) {
+// source columns x4-4 .. x4+7 of row yy as three dwords (BORDER_REFLECT_101 in x for the threads that touch the border)
+__device__ __forceinline__ void load_row12(const uint8_t* __restrict__ s, size_t spitch, int yy, int x4, int w, bool fast, unsigned& d0, unsigned& d1, unsigned& d2) {
     const uint8_t* row = s + (size_t)yy * spitch;
     if (fast) {
         const unsigned* q = (const unsigned*)(row + x4 - 4);
-        const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
-        px[0] = d0 & 255; px[1] = (d0 >> 8) & 255; px[2] = (d0 >> 16) & 255; px[3] = d0 >> 24;
-        px[4] = d1 & 255; px[5] = (d1 >> 8) & 255; px[6] = (d1 >> 16) & 255; px[7] = d1 >> 24;
-        px[8] = d2 & 255; px[9] = (d2 >> 8) & 255; px[10] = (d2 >> 16) & 255; px[11] = d2 >> 24;
+        d0 = q[0]; d1 = q[1]; d2 = q[2];
     } else {
+        unsigned px[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             int xx = reflect101(min(x4 - 4 + i, w + 2), w);
             xx = min(max(xx, 0), w - 1);
             px[i] = row[xx];
         }
+        d0 = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        d1 = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+        d2 = px[8] | (px[9] << 8) | (px[10] << 16) | (px[11] << 24);
     }
+}
+// sum over k of tap[k] * byte[s + k] of the 12 bytes d0:d1:d2, taps packed four to a dword (v_dot4_u32_u8); s = 1 .. 6,
+// the taps beyond the kernel length are 0 so the bytes they meet do not matter
+__device__ __forceinline__ unsigned hdot(unsigned d0, unsigned d1, unsigned d2, int s, unsigned T0, unsigned T1) {
+    const unsigned lo = s < 4 ? __builtin_amdgcn_alignbyte(d1, d0, (unsigned)s) : __builtin_amdgcn_alignbyte(d2, d1, (unsigned)(s - 4));
+    const unsigned hi = s < 4 ? __builtin_amdgcn_alignbyte(d2, d1, (unsigned)s) : (d2 >> (8 * (s - 4)));
+    return __builtin_amdgcn_udot4(lo, T0, __builtin_amdgcn_udot4(hi, T1, 0u, false), false);
 }
 __device__ __forceinline__ int reflect_row(int y, int h, int R) {
     const int yy = reflect101(min(y, h + R - 1), h);
@@ -104,20 +112,16 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, 
     unsigned taps[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) taps[k] = (unsigned)tapsArr[k];
+    const unsigned T0 = taps[0] | (taps[1] << 8) | (taps[2] << 16) | (taps[3] << 24), T1 = taps[4] | (taps[5] << 8) | (taps[6] << 16);   // q8 taps < 256
     const bool fast = x4 >= 4 && x4 + 8 <= w && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
     unsigned win[7][4];
 #pragma unroll
     for (int r = 0; r < STRIP + 2 * R; ++r) {
         if (r >= 2 * R && y0 + r - 2 * R >= h) break;
-        unsigned px[12];
-        load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, px);
+        unsigned d0, d1, d2;
+        load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, d0, d1, d2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned acc = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) acc += px[j + 1 + k] * taps[k];
-            win[r % 7][j] = acc;
-        }
+        for (int j = 0; j < 4; ++j) win[r % 7][j] = hdot(d0, d1, d2, j + 1, T0, T1);      // columns x4+j-3 .. x4+j+3
         if (r >= 2 * R) {
             const int y = y0 + r - 2 * R;
             unsigned o[4];
@@ -1434,6 +1438,7 @@ __global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ 
     unsigned taps[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) taps[k] = (unsigned)tapsArr[k];
+    const unsigned T0 = taps[0] | (taps[1] << 8) | (taps[2] << 16) | (taps[3] << 24), T1 = taps[4];       // q8 taps < 256
     const bool fast = x4 >= 4 && x4 + 8 <= w && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
     const bool vec = ((w & 3) == 0) && ((dframeBytes & 15) == 0);
     unsigned hb[5][6];                                     // horizontally blurred rows, columns x4-1 .. x4+4
@@ -1441,15 +1446,10 @@ __global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ 
 #pragma unroll
     for (int r = 0; r < STRIP + 2 * R; ++r) {
         if (r >= 2 * R && y0 + r - 2 * R >= h) break;
-        unsigned px[12];
-        load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, px);
+        unsigned d0, d1, d2;
+        load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, d0, d1, d2);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            unsigned acc = 0;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) acc += px[c + 1 + k] * taps[k];
-            hb[r % 5][c] = acc & 0xFFFFu;                   // the staged sums are 16-bit (taps sum to 256)
-        }
+        for (int c = 0; c < 6; ++c) hb[r % 5][c] = hdot(d0, d1, d2, c + 1, T0, T1);      // columns x4+c-3 .. x4+c+1 (sums fit 16 bits: taps sum to 256)
         if (r >= 4) {
             const int q = r - 4;                           // blurred row y0 - 1 + q
 #pragma unroll

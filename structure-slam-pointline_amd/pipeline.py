@@ -93,10 +93,9 @@ class FrontendBatch:
         p, c = self.feat["prev"], self.feat["cur"]
         st = C.c_void_p(self._stream())
         _p = lambda t: C.c_void_p(t.data_ptr())
-        if True:
-            rc = L.sslam_line_match_batch_dev(self.ctx.h, _p(p["ldesc"]), _p(p["nl"]), _p(c["ldesc"]), _p(c["nl"]), self.lcap, self.B,
-                                              C.c_double(0.5), 0, _p(self.lpairs), _p(self.nlpairs), st)
-            assert rc == 0, L.sslam_last_error()
+        rc = L.sslam_line_match_batch_dev(self.ctx.h, _p(p["ldesc"]), _p(p["nl"]), _p(c["ldesc"]), _p(c["nl"]), self.lcap, self.B,
+                                          C.c_double(0.5), 0, _p(self.lpairs), _p(self.nlpairs), st)
+        assert rc == 0, L.sslam_last_error()
 
     def step(self, images, overlap=False):
         """One pass of the hot path.  overlap=True runs the point branch (ORB extract + ORB matching)
