@@ -49,8 +49,7 @@ def alg_bytes_per_frame(w, h, nkp, nln):
         "k_octree": 0,                                      # candidate lists only (latency-bound, no image traffic)
         "k_describe": 2 * sP + nkp * (2 * 961 + 32 + 28),   # blur r/w folded into the per-keypoint patch stage + patch reads + outputs
         "k_blur7": 2 * w * h,                               # LSD pre-blur r/w
-        "k_resize_exact": w * h + s08,
-        "k_lsd_grad": s08 + 8 * s08,                        # gradient read, fp32 angle + int magnitude write
+        "k_lsd_grad": (w * h + s08) + s08 + 8 * s08,        # 0.8x resample (fused: blurred read, scaled image) + gradient read, fp32 angle + int magnitude write
         "k_lsd_hist": 8 * s08, "k_lsd_scan": 0, "k_lsd_scatter": 4 * s08,    # ordered-list build
         "k_lsd_regions": 5 * s08,                           # region-grow reads (angle + magnitude + used)
         "k_nfa_count": 0, "k_nfa_eval": 0, "k_nfa_accept": 0, "k_nfa_finish": 0,      # rectangle validation: angle-map rows under ~400 rectangles, cache resident

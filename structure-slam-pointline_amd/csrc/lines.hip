@@ -41,7 +41,7 @@ struct LsdPlan {
     int npx;                  // sw*sh
     int nTiles;
     size_t frameBytes;        // per-frame workspace
-    size_t offScaled, offBlur, offAng, offS, offPix, offCand, offFlag, offNfa, offOrder, offTileHist, offReg, offSeg, offMisc, offDxy, offKl, offSortIdx;
+    size_t offBlur, offAng, offS, offPix, offCand, offFlag, offNfa, offOrder, offTileHist, offReg, offSeg, offMisc, offDxy, offKl, offSortIdx;
     int blurTaps[7];          // sigma 0.75, 7 taps (q8)
     int blur5Taps[5];         // sigma 1, 5 taps (q8)
     int tabX, tabY;           // offsets into the resize table (int: ofs, c1)
@@ -139,55 +139,13 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, 
     }
 }
 
-// ------------------------------------------------------------------ INTER_LINEAR_EXACT 0.8x (D7)
-// tx/ty entries: {source offset, coefficient of the second tap (q8)}.  One thread = four adjacent outputs, source rows read
-// as three aligned dwords.
+// ------------------------------------------------------------------ INTER_LINEAR_EXACT 0.8x (D7), consumed inside k_lsd_grad
+// tx/ty entries: {source offset, coefficient of the second tap (q8)}; source rows are read as three aligned dwords.
 __device__ __forceinline__ unsigned pick2(unsigned d0, unsigned d1, unsigned d2, int o) {      // bytes o, o+1 of d0:d1:d2 (o <= 10)
     const unsigned long long w01 = (unsigned long long)d0 | ((unsigned long long)d1 << 32);
     const unsigned long long w12 = (unsigned long long)d1 | ((unsigned long long)d2 << 32);
     return (unsigned)((o < 4 ? w01 : w12) >> (8 * (o < 4 ? o : o - 4)));
 }
-__global__ __launch_bounds__(256) void k_resize_exact(const uint8_t* __restrict__ src, size_t spitch, size_t sframe, int w, int h,
-                                                      uint8_t* __restrict__ dst, size_t dpitch, size_t dframe, int dw, int dh,
-                                                      const int* __restrict__ tx, const int* __restrict__ ty) {
-    const int b = blockIdx.z, x4 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
-    if (x4 >= dw || y >= dh) return;
-    const int2 tyv = ((const int2*)ty)[y];
-    int2 txv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) txv[j] = ((const int2*)tx)[min(x4 + j, dw - 1)];
-    const int sy = tyv.x, cy = tyv.y, sy1 = min(sy + 1, h - 1);
-    const uint8_t* s0 = src + (size_t)b * sframe + (size_t)sy * spitch;
-    const uint8_t* s1 = src + (size_t)b * sframe + (size_t)sy1 * spitch;
-    unsigned p00[4], p01[4], p10[4], p11[4];
-    const int a = txv[0].x & ~3;
-    if (txv[3].x - a <= 10) {                       // spitch % 64 == 0 and another buffer follows the last row: whole dwords are readable
-        const unsigned* q0 = (const unsigned*)(s0 + a);
-        const unsigned* q1 = (const unsigned*)(s1 + a);
-        const unsigned u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned e0 = pick2(u0, u1, u2, txv[j].x - a), e1 = pick2(v0, v1, v2, txv[j].x - a);
-            p00[j] = e0 & 255; p01[j] = (e0 >> 8) & 255; p10[j] = e1 & 255; p11[j] = (e1 >> 8) & 255;   // second tap has weight 0 at the last column
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int sx = txv[j].x, sx1 = min(sx + 1, w - 1);
-            p00[j] = s0[sx]; p01[j] = s0[sx1]; p10[j] = s1[sx]; p11[j] = s1[sx1];
-        }
-    }
-    unsigned out = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned cx = (unsigned)txv[j].y;
-        const unsigned r0 = p00[j] * (256 - cx) + p01[j] * cx, r1 = p10[j] * (256 - cx) + p11[j] * cx;
-        const unsigned v = r0 * (256 - (unsigned)cy) + r1 * (unsigned)cy;
-        out |= ((v + 32768u) >> 16) << (8 * j);
-    }
-    *(unsigned*)(dst + (size_t)b * dframe + (size_t)y * dpitch + x4) = out;      // dpitch % 64 == 0: pad columns are scratch
-}
-
 // ------------------------------------------------------------------ gradient / level-line angle (ll_angle)
 // The 2x2 gradient of an 8-bit image takes only 1021 x 1021 values, so angle (exact fastAtan2), the defined test
 // (|g|/2 > rho) and the D5 cos/sin of the angle are tabulated once per process; the per-frame kernel is then a gather.
@@ -209,10 +167,17 @@ __global__ void k_grad_table(float4* __restrict__ tab, double rho) {
 // One thread = four horizontally adjacent pixels: the 2x5 source bytes come from two dword + two byte loads, the four
 // table gathers are in flight together, and angle / key / record leave as 16-byte stores when the row length allows.
 // S[i] = |g|^2 for DEFINED pixels and -1 otherwise, so the counting sort reads one array.
-__global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws, LsdPlan P, const float4* __restrict__ gtab) {
+// The 0.8x INTER_LINEAR_EXACT image (D7) is never stored: this kernel is bound by its 24 B/pixel of writes, so the 2 x 5
+// scaled pixels a thread needs are recomputed here from the blurred source (four source rows as three aligned dwords each).
+__device__ __forceinline__ int scaled_px(unsigned e0, unsigned e1, unsigned cx, unsigned cy) {      // e = {p0, p1} bytes of the two source rows
+    const unsigned r0 = (e0 & 255u) * (256u - cx) + ((e0 >> 8) & 255u) * cx, r1 = (e1 & 255u) * (256u - cx) + ((e1 >> 8) & 255u) * cx;
+    return (int)((r0 * (256u - cy) + r1 * cy + 32768u) >> 16);
+}
+__global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws, LsdPlan P, const float4* __restrict__ gtab, size_t bpitch,
+                                                  const int* __restrict__ tx, const int* __restrict__ ty) {
     const int b = blockIdx.z;
     const uint8_t* base = ws + (size_t)b * P.frameBytes;
-    const uint8_t* img = base + P.offScaled;
+    const uint8_t* src = base + P.offBlur;
     float* ang = (float*)(base + P.offAng);
     int* S = (int*)(base + P.offS);
     float4* pix = (float4*)(base + P.offPix);
@@ -220,14 +185,33 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
     const int y = blockIdx.y * 4 + threadIdx.y, x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     int smax = 0;
     if (y < P.sh && x4 < P.sw) {
-        const uint8_t* r0 = img + (size_t)y * P.spitch + x4;               // spitch % 64 == 0: aligned dwords, pad bytes readable
         const bool lastRow = y >= P.sh - 1;
-        const uint8_t* r1 = lastRow ? r0 : r0 + P.spitch;
-        const unsigned d0 = *(const unsigned*)r0, d1 = *(const unsigned*)r1;
-        const bool more = x4 + 4 < P.sw;
-        const unsigned e0 = more ? r0[4] : 0u, e1 = more ? r1[4] : 0u;
-        int p0[5] = {(int)(d0 & 255), (int)((d0 >> 8) & 255), (int)((d0 >> 16) & 255), (int)(d0 >> 24), (int)e0};
-        int p1[5] = {(int)(d1 & 255), (int)((d1 >> 8) & 255), (int)((d1 >> 16) & 255), (int)(d1 >> 24), (int)e1};
+        const int2 ty0 = ((const int2*)ty)[y], ty1 = ((const int2*)ty)[min(y + 1, P.sh - 1)];
+        int2 txv[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) txv[j] = ((const int2*)tx)[min(x4 + j, P.sw - 1)];
+        const uint8_t* rw[4] = {src + (size_t)ty0.x * bpitch, src + (size_t)min(ty0.x + 1, P.h - 1) * bpitch,
+                                src + (size_t)ty1.x * bpitch, src + (size_t)min(ty1.x + 1, P.h - 1) * bpitch};
+        int p0[5], p1[5];
+        const int a = txv[0].x & ~3;
+        if (txv[4].x - a <= 10) {                       // bpitch % 64 == 0 and another buffer follows the last row: whole dwords are readable
+            unsigned d[4][3];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const unsigned* q = (const unsigned*)(rw[r] + a); d[r][0] = q[0]; d[r][1] = q[1]; d[r][2] = q[2]; }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int o = txv[j].x - a;                                    // second tap has weight 0 at the last column
+                p0[j] = scaled_px(pick2(d[0][0], d[0][1], d[0][2], o), pick2(d[1][0], d[1][1], d[1][2], o), (unsigned)txv[j].y, (unsigned)ty0.y);
+                p1[j] = scaled_px(pick2(d[2][0], d[2][1], d[2][2], o), pick2(d[3][0], d[3][1], d[3][2], o), (unsigned)txv[j].y, (unsigned)ty1.y);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int sx = txv[j].x, sx1 = min(sx + 1, P.w - 1);
+                p0[j] = scaled_px(rw[0][sx] | ((unsigned)rw[0][sx1] << 8), rw[1][sx] | ((unsigned)rw[1][sx1] << 8), (unsigned)txv[j].y, (unsigned)ty0.y);
+                p1[j] = scaled_px(rw[2][sx] | ((unsigned)rw[2][sx1] << 8), rw[3][sx] | ((unsigned)rw[3][sx1] << 8), (unsigned)txv[j].y, (unsigned)ty1.y);
+            }
+        }
         float4 rec[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1700,7 +1684,6 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t bpitch = ((size_t)w + 63) & ~(size_t)63;
     P.offBlur = take(bpitch * h);                         // sigma-0.75 blur of the source (LSD)
-    P.offScaled = take((size_t)P.spitch * P.sh);
     P.offAng = take(sizeof(float) * (size_t)P.npx);
     P.offS = take(sizeof(int) * (size_t)P.npx);
     P.offPix = take(sizeof(float4) * (size_t)P.npx);
@@ -1787,9 +1770,8 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     // LSD: blur(7, 0.75) -> 0.8x -> gradient
     { sslam::ProfScope _ps(L->ctx, "k_blur7", st); hipLaunchKernelGGL(k_blur7, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride,
                        ws + P.offBlur, bpitch, P.frameBytes, w, h, taps); }
-    { sslam::ProfScope _ps(L->ctx, "k_resize_exact", st); hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, nframes), dim3(64, 4), 0, st, ws + P.offBlur, bpitch, P.frameBytes, w, h,
-                       ws + P.offScaled, (size_t)P.spitch, P.frameBytes, P.sw, P.sh, L->dTabs.as<int>() + P.tabX, L->dTabs.as<int>() + P.tabY); }
-    { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st); hipLaunchKernelGGL(k_lsd_grad, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, nframes), dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>()); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st); hipLaunchKernelGGL(k_lsd_grad, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, nframes), dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>(), bpitch,
+                                                                        L->dTabs.as<int>() + P.tabX, L->dTabs.as<int>() + P.tabY); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_hist", st); hipLaunchKernelGGL(k_lsd_hist, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scan", st); hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }

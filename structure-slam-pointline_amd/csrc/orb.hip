@@ -211,7 +211,6 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     }
     for (int i = lane; i < (((ch + 2) * scP + 3) >> 2); i += 64) ((unsigned*)sc)[i] = 0;
     __syncthreads();
-    const int npx = cw * ch;
     const unsigned magic = (1u << 20) / (unsigned)cw + 1;      // floor(i/cw) == (i*magic)>>20 for i < 4400, cw <= 64
     // pass A: necessary condition for a 9-arc at minTh, four pixels per lane on whole dwords.  Nine contiguous ring positions
     // always contain two ADJACENT compass points (ring 0/4/8/12 = S/E/N/W at distance 3), i.e. one vertical and one
