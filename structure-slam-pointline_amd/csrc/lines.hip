@@ -953,7 +953,10 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
 
 // stage 0 is merged with the initial evaluation: same rectangle, six precisions (p, p/2 .. p/32); stage 4 likewise has one
 // geometry and five precisions.  Stages 1-3 change the rectangle itself: up to five candidates per rectangle.
-__global__ __launch_bounds__(64) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
+#ifndef SSLAM_COUNT_MINWAVES
+#define SSLAM_COUNT_MINWAVES 4
+#endif
+__global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
     __shared__ CntItem its[64];
     __shared__ unsigned short act[EVAL_CH];
     const int b = blockIdx.y, lane = threadIdx.x;
