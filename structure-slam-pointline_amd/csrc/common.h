@@ -169,21 +169,32 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 
 // cv::fastAtan2 (scalar atan_f32) with explicit round-to-nearest fp32 ops, no FMA
 // contraction (oracle decision D4).  Degrees in [0,360).
+template <bool BRANCHY = false>
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
     const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
     const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
     const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
     const float eps = (float)2.2204460492503131e-16;
-    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    // both branches of the reference divide the smaller magnitude by the larger one.  Default: one branch-free instance (fewer
+    // instructions, what a SIMD shared by several waves wants); BRANCHY keeps the two-sided form, whose wave-uniform branch
+    // is the shorter dependent chain for a lone wave.
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool steep = !(ax >= ay);
+    float a;
+    if (BRANCHY) {
+        if (!steep) {
+            const float c = __fdiv_rn(ay, __fadd_rn(ax, eps)), c2 = __fmul_rn(c, c);
+            a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+        } else {
+            const float c = __fdiv_rn(ax, __fadd_rn(ay, eps)), c2 = __fmul_rn(c, c);
+            a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+        }
     } else {
-        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+        const float c = __fdiv_rn(steep ? ax : ay, __fadd_rn(steep ? ay : ax, eps));
+        const float c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+        if (steep) a = __fsub_rn(90.f, a);
     }
     if (x < 0) a = __fsub_rn(180.f, a);
     if (y < 0) a = __fsub_rn(360.f, a);

@@ -357,11 +357,11 @@ __device__ __forceinline__ double angle_diff_signed(double a, double b) {
     return diff;
 }
 __device__ __forceinline__ bool is_aligned_val(float aDeg, double theta, double prec) {
-    if (aDeg == NOTDEF_F) return false;
-    double n_theta = theta - (double)aDeg * DEG2RAD;
-    if (n_theta < 0) n_theta = -n_theta;
-    if (n_theta > M_3_2_PI_) { n_theta -= M_2PI_; if (n_theta < 0) n_theta = -n_theta; }
-    return n_theta <= prec;
+    // isAligned: |theta - a|, folded once around the circle (fabs == the reference's conditional negations; +-0 compare alike)
+    double n_theta = fabs(theta - (double)aDeg * DEG2RAD);
+    const double wrapped = fabs(n_theta - M_2PI_);
+    n_theta = n_theta > M_3_2_PI_ ? wrapped : n_theta;
+    return aDeg != NOTDEF_F && n_theta <= prec;
 }
 __device__ double log_gamma_d(double x) {
     if (x > 15) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
@@ -591,7 +591,7 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __res
                 if (nt < 0) nt = -nt;
                 if (nt > M_3_2_PI_) { nt -= M_2PI_; if (nt < 0) nt = -nt; }
                 al = cand && lane > lastSel && nt <= prec;
-            } else al = cand && lane > lastSel && is_aligned_val(px4.x, regAngle, prec);
+            } else { const bool ok = is_aligned_val(px4.x, regAngle, prec); al = cand && lane > lastSel && ok; }      // straight-line: no exec-masked region around the test
             const unsigned long long m = __ballot(al);
             if (!m) break;
             const int sel = __ffsll((long long)m) - 1;       // wave-uniform: the lane reads below are v_readlane, not LDS permutes
@@ -601,7 +601,7 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __res
             ++n;
             sumdx = __fadd_rn(sumdx, LAT ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px4.y), sel)) : __shfl(px4.y, sel, 64));
             sumdy = __fadd_rn(sumdy, LAT ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px4.z), sel)) : __shfl(px4.z, sel, 64));
-            regAngle = (double)fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
+            regAngle = (double)fast_atan2_deg<LAT>(sumdy, sumdx) * DEG2RAD;
             if (nidx == selIdx) cand = false;              // the accepted pixel is now USED for every later visitor
             lastSel = sel;
         }
