@@ -820,11 +820,9 @@ __device__ __forceinline__ void store_rect(double* o, const RectD& rec) {
 
 // angular distance used by isAligned (NOTDEF -> +inf)
 __device__ __forceinline__ double align_dist(float aDeg, double theta) {
-    if (aDeg == NOTDEF_F) return 1e300;
-    double n_theta = theta - (double)aDeg * DEG2RAD;
-    if (n_theta < 0) n_theta = -n_theta;
-    if (n_theta > M_3_2_PI_) { n_theta -= M_2PI_; if (n_theta < 0) n_theta = -n_theta; }
-    return n_theta;
+    const double n_theta = fabs(theta - (double)aDeg * DEG2RAD);          // fabs == the reference's conditional negations
+    const double wrapped = fabs(n_theta - M_2PI_);
+    return aDeg == NOTDEF_F ? 1e300 : (n_theta > M_3_2_PI_ ? wrapped : n_theta);
 }
 
 // k_nfa_count: one wave walks a frame's rectangles.  The corner bookkeeping of rect_nfa (nfa_geom: sorting, slopes, integer
