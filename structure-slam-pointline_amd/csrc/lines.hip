@@ -363,20 +363,26 @@ __device__ __forceinline__ bool is_aligned_val(float aDeg, double theta, double 
     n_theta = n_theta > M_3_2_PI_ ? wrapped : n_theta;
     return aDeg != NOTDEF_F && n_theta <= prec;
 }
-__device__ double log_gamma_d(double x) {
-    if (x > 15) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
-    const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
-    double a = (x + 0.5) * log(x + 5.5) - (x + 5.5), bq = 0;
-    for (int n = 0; n < 7; ++n) { a -= log(x + (double)n); bq += q[n] * pow(x, (double)n); }
-    return a + log(bq);
+// Tables of nfa(): lgam[j] = log_gamma(j) for integer j >= 1 (every argument nfa() uses is an integer + 1), then
+// plog[h] = {log(p), log(1-p), log10(p)} for p = 0.125 * 2^-h (every precision rect_improve can reach), then 1/j for
+// exact_div().  They are evaluated on the HOST with the same libm calls, in the same order, as the reference's
+// log_gamma_windschitl / log_gamma_lanczos (opencv lsd.cpp): when the binomial tail is ~1 the NFA is -logNT + O(1e-15),
+// and rect_improve's strict `v > log_nfa` comparisons between such values depend on the last bit of every term.
+static double host_log_gamma(double x) {
+    if (x > 15) return 0.918938533204673 + (x - 0.5) * std::log(x) - x + 0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0)));
+    static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+    double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5), bq = 0;
+    for (int n = 0; n < 7; ++n) { a -= std::log(x + (double)n); bq += q[n] * std::pow(x, (double)n); }
+    return a + std::log(bq);
 }
-// lgam[j] = log_gamma(j) for integer j >= 1 (every argument nfa() uses is an integer + 1)
-// ... followed by plog[h] = {log p, log(1-p), log10 p} for p = 0.125 * 2^-h, h < 16
-__global__ void k_lgamma_table(double* __restrict__ lgam, int n) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) lgam[j] = j >= 1 ? log_gamma_d((double)j) : 0.0;
-    if (j < 16) { const double pp = ldexp(0.125, -j); lgam[n + 3 * j] = log(pp); lgam[n + 3 * j + 1] = log(1.0 - pp); lgam[n + 3 * j + 2] = log10(pp); }
-    if (j < n) lgam[n + 48 + j] = j >= 1 ? 1.0 / (double)j : 0.0;          // correctly rounded reciprocals for exact_div()
+static int upload_nfa_tables(double* d_tab, int n, hipStream_t st) {
+    std::vector<double> t(2 * (size_t)n + 48);
+    for (int j = 0; j < n; ++j) t[j] = j >= 1 ? host_log_gamma((double)j) : 0.0;
+    for (int j = 0; j < 16; ++j) { const double pp = std::ldexp(0.125, -j); t[n + 3 * j] = std::log(pp); t[n + 3 * j + 1] = std::log(1.0 - pp); t[n + 3 * j + 2] = std::log10(pp); }
+    for (int j = 0; j < n; ++j) t[(size_t)n + 48 + j] = j >= 1 ? 1.0 / (double)j : 0.0;          // correctly rounded reciprocals for exact_div()
+    SSLAM_HIP(hipMemcpyAsync(d_tab, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    return SSLAM_OK;
 }
 
 // a / b for small positive integers, bit-identical to the IEEE quotient: with y = RN(1/b) from the table, q0 = RN(a*y),
@@ -1554,14 +1560,15 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
         band[q][bd] = acc;
     }
     __syncthreads();
+    // sqrtf, not __fsqrt_rn: HIP maps the latter to the native (1-ulp) v_sqrt_f32, the former is correctly rounded
     if (lane < NUM_BANDS) {
         const int bd = lane;
         const float invN = (bd == 0 || bd == NUM_BANDS - 1) ? (float)(1.0 / (BAND_W * 2.0)) : (float)(1.0 / (BAND_W * 3.0));
         float t;
-        t = __fmul_rn(band[0][bd], invN); des[bd * 8 + 0] = t; des[bd * 8 + 4] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[2][bd], invN), __fmul_rn(t, t)));
-        t = __fmul_rn(band[1][bd], invN); des[bd * 8 + 1] = t; des[bd * 8 + 5] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[3][bd], invN), __fmul_rn(t, t)));
-        t = __fmul_rn(band[4][bd], invN); des[bd * 8 + 2] = t; des[bd * 8 + 6] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[6][bd], invN), __fmul_rn(t, t)));
-        t = __fmul_rn(band[5][bd], invN); des[bd * 8 + 3] = t; des[bd * 8 + 7] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[7][bd], invN), __fmul_rn(t, t)));
+        t = __fmul_rn(band[0][bd], invN); des[bd * 8 + 0] = t; des[bd * 8 + 4] = sqrtf(__fsub_rn(__fmul_rn(band[2][bd], invN), __fmul_rn(t, t)));
+        t = __fmul_rn(band[1][bd], invN); des[bd * 8 + 1] = t; des[bd * 8 + 5] = sqrtf(__fsub_rn(__fmul_rn(band[3][bd], invN), __fmul_rn(t, t)));
+        t = __fmul_rn(band[4][bd], invN); des[bd * 8 + 2] = t; des[bd * 8 + 6] = sqrtf(__fsub_rn(__fmul_rn(band[6][bd], invN), __fmul_rn(t, t)));
+        t = __fmul_rn(band[5][bd], invN); des[bd * 8 + 3] = t; des[bd * 8 + 7] = sqrtf(__fsub_rn(__fmul_rn(band[7][bd], invN), __fmul_rn(t, t)));
     }
     __syncthreads();
     // normalise means / stds separately, clip at 0.4, renormalise: sequential sums (every lane redundantly)
@@ -1573,7 +1580,7 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
         tempS = __fadd_rn(tempS, __fmul_rn(d[4], d[4])); tempS = __fadd_rn(tempS, __fmul_rn(d[5], d[5]));
         tempS = __fadd_rn(tempS, __fmul_rn(d[6], d[6])); tempS = __fadd_rn(tempS, __fmul_rn(d[7], d[7]));
     }
-    tempM = __fdiv_rn(1.f, __fsqrt_rn(tempM)); tempS = __fdiv_rn(1.f, __fsqrt_rn(tempS));
+    tempM = __fdiv_rn(1.f, sqrtf(tempM)); tempS = __fdiv_rn(1.f, sqrtf(tempS));
     __syncthreads();
     for (int i = lane; i < 72; i += 64) {
         float v = des[i];
@@ -1584,10 +1591,13 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
     __syncthreads();
     float temp = 0;
     for (int i = 0; i < 72; ++i) temp = __fadd_rn(temp, __fmul_rn(des[i], des[i]));
-    temp = __fdiv_rn(1.f, __fsqrt_rn(temp));
+    temp = __fdiv_rn(1.f, sqrtf(temp));
     __syncthreads();
     for (int i = lane; i < 72; i += 64) des[i] = __fmul_rn(des[i], temp);
     __syncthreads();
+#ifdef SSLAM_LBD_DEBUG
+    for (int i = lane; i < 72; i += 64) ((float*)(const_cast<uint8_t*>(base) + P.offCand))[li * 72 + i] = des[i];      // normalised 72-float vector (candidate buffer is free here)
+#endif
     if (lane < 32) {
         const float* f1 = des + 8 * kComb[lane * 2];
         const float* f2 = des + 8 * kComb[lane * 2 + 1];
@@ -1707,8 +1717,7 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     {   // log-gamma table for nfa(): arguments are integers in [1, npx+2]
         const int nl = P.npx + 4;
         if ((rc = L->dLgam.ensure(sizeof(double) * (2 * (size_t)nl + 48)))) return rc;
-        hipLaunchKernelGGL(k_lgamma_table, dim3((nl + 255) / 256), dim3(256), 0, L->ctx->stream, L->dLgam.as<double>(), nl);
-        SSLAM_HIP(hipStreamSynchronize(L->ctx->stream));
+        if ((rc = upload_nfa_tables(L->dLgam.as<double>(), nl, L->ctx->stream))) return rc;
     }
     L->planW = w; L->planH = h; L->wsFrames = 0;
     return SSLAM_OK;
@@ -1888,7 +1897,7 @@ extern "C" int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, 
     SSLAM_HIP(hipMalloc(&tab, sizeof(double) * (2 * (size_t)n + 48)));
     SSLAM_HIP(hipMalloc(&bad, sizeof(unsigned long long)));
     SSLAM_HIP(hipMemset(bad, 0, sizeof(unsigned long long)));
-    hipLaunchKernelGGL(k_lgamma_table, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, tab, n);
+    { const int rc = upload_nfa_tables(tab, n, ctx->stream); if (rc) return rc; }
     const int threads = 256 * 1024, iters = (int)((pairs + threads - 1) / threads);
     hipLaunchKernelGGL(k_selftest_div, dim3(1024), dim3(256), 0, ctx->stream, tab + n + 48, n, 0x1234567ull, iters, bad);
     unsigned long long h = 0;
@@ -1950,3 +1959,32 @@ extern "C" int sslam_frame_from_lines(sslam_lines* L, const float bounds[4], ssl
     std::lock_guard<std::mutex> lk(L->ctx->mu);
     return sslam_frame_from_device(L->ctx, 1, L->dKl.p, L->dDesc.as<uint8_t>(), L->lastN, bounds, out);
 }
+
+#if defined(SSLAM_LBD_DEBUG) || defined(SSLAM_NFA_DEBUG)
+// development aid: candidate rectangles (12 doubles) and their NfaState after the last stage (SSLAM_NFA_DEBUG: the LBD dump of
+// SSLAM_LBD_DEBUG reuses the candidate buffer)
+extern "C" int sslam_lines_debug_nfa(sslam_lines* L, int frame, double* rects_out, void* state_out, int cap, int* n_out, int* state_size) {
+    if (!L || frame < 0 || frame >= L->lastFrames) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(L->ctx->device));
+    SSLAM_HIP(hipStreamSynchronize(L->ctx->stream));
+    const LsdPlan& P = L->plan;
+    const uint8_t* base = L->dWs.as<uint8_t>() + (size_t)frame * P.frameBytes;
+    Misc m; SSLAM_HIP(hipMemcpy(&m, base + P.offMisc, sizeof(m), hipMemcpyDeviceToHost));
+    const int n = std::min(m.nCand, cap);
+    *n_out = n; *state_size = (int)sizeof(NfaState);
+    SSLAM_HIP(hipMemcpy(rects_out, base + P.offCand, sizeof(double) * 12 * (size_t)n, hipMemcpyDeviceToHost));
+    SSLAM_HIP(hipMemcpy(state_out, base + P.offNfa, sizeof(NfaState) * (size_t)n, hipMemcpyDeviceToHost));
+    return SSLAM_OK;
+}
+#endif
+#ifdef SSLAM_LBD_DEBUG
+// development aid: the normalised 72-float LBD vectors of the last extraction (k_lbd parks them in the candidate buffer)
+extern "C" int sslam_lines_debug_lbd_floats(sslam_lines* L, int frame, float* out, int nlines) {
+    if (!L || frame < 0 || frame >= L->lastFrames || !out) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(L->ctx->device));
+    SSLAM_HIP(hipStreamSynchronize(L->ctx->stream));
+    const LsdPlan& P = L->plan;
+    SSLAM_HIP(hipMemcpy(out, L->dWs.as<uint8_t>() + (size_t)frame * P.frameBytes + P.offCand, sizeof(float) * 72 * (size_t)nlines, hipMemcpyDeviceToHost));
+    return SSLAM_OK;
+}
+#endif

@@ -24,6 +24,7 @@ using namespace sslam;
 namespace {
 
 constexpr int MAX_LEVELS = 16;
+constexpr int MAX_ROOTS = 64;            // quadtree root strips = round(W/H) of a level (src/ORBextractor.cc:543)
 constexpr int EDGE = 19;          // EDGE_THRESHOLD, src/ORBextractor.cc:74
 constexpr int MINB = 16;          // EDGE_THRESHOLD-3, :773
 constexpr int HALF_PATCH = 15;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(64) void k_octree(const unsigned* __restrict__ cand
     if (lane == 0) S.pre[nc] = total;
     __syncthreads();
     int* selCnt = selCount + (size_t)b * P.nlevels + level;
-    if (total == 0 || L.nIni <= 0 || L.nIni > 8) { if (lane == 0) *selCnt = 0; return; }
+    if (total == 0 || L.nIni <= 0) { if (lane == 0) *selCnt = 0; return; }      // build_plan rejects aspect ratios beyond MAX_ROOTS
 
     unsigned* A = bufA + (size_t)b * P.candFrame + L.candOff;
     unsigned* B = bufB + (size_t)b * P.candFrame + L.candOff;
@@ -828,6 +829,8 @@ static int build_plan(sslam_orb* o, int w, int h) {
         // quadtree roots, :543-545
         if (L.W > 0 && L.H > 0) {
             L.nIni = (int)std::round((float)L.W / (float)L.H);
+            if (L.nCells == 0) L.nIni = 0;            // no FAST cell fits: the level yields no keypoints whatever its aspect ratio
+            if (L.nIni > MAX_ROOTS) { set_error("image %dx%d: level %d would start the quadtree with %d root nodes (limit %d)", w, h, l, L.nIni, MAX_ROOTS); return SSLAM_ERR_UNSUPPORTED; }
             L.hX = L.nIni > 0 ? (float)L.W / (float)L.nIni : 0.f;
         } else { L.nIni = 0; L.hX = 0; }
         L.selOff = selOff;

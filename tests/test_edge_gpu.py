@@ -111,3 +111,43 @@ def test_two_extractors_interleaved_and_threads(fe, ctx, oracle):
     [t.start() for t in ts]; [t.join() for t in ts]
     assert not errs
     a.close(); b.close()
+
+
+def test_randomised_parity_sweep(fe, ctx, oracle):
+    """tools/fuzz_parity.py in small: random sizes (incl. extreme aspect ratios), densities, noise levels and extractor
+    parameters; every output compared with the oracle.  (The long sweep found the three defects this guards against: levels
+    dropped on wide images, a 1-ulp native sqrt in LBD, device-evaluated log-gamma tables in the NFA.)"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from fuzz_parity import cases
+    rng = np.random.default_rng(777)
+    n = 0
+    for it, img, nfeat, nlev, sf, ini, mn, cap in cases(80, rng):
+        if it % 2 and it != 75:          # every other case, plus the frame whose NFA hinged on the last bit of log-gamma
+            continue
+        ox = fe.OrbExtractor(ctx, nfeat, sf, nlev, ini, mn)
+        kp, d = ox(img); okp, od = oracle.orb_extract(img, nfeat, sf, nlev, ini, mn); ox.close()
+        assert len(kp) == len(okp), (it, img.shape)
+        np.testing.assert_array_equal(kp.view(np.uint8), okp.view(np.uint8)); np.testing.assert_array_equal(d, od)
+        lx = fe.LineExtractor(ctx, cap)
+        kl, ld, fn = lx(img); raw = lx.debug_segments(0); lx.close()
+        okl, old, ofn, oraw = oracle.lines_extract(img, cap)
+        np.testing.assert_array_equal(raw, oraw, err_msg="LSD segments, case %d %s" % (it, img.shape))
+        for f in kl.dtype.names:
+            if f != "angle":
+                np.testing.assert_array_equal(kl[f], okl[f], err_msg=f)
+        same = kl["angle"].view(np.uint32) == okl["angle"].view(np.uint32)
+        np.testing.assert_array_equal(ld[same], old[same]); np.testing.assert_array_equal(fn, ofn)
+        n += 1
+    assert n >= 40
+
+
+def test_orb_extreme_aspect_ratio(fe, ctx, oracle):
+    """a level whose border-less area is wider than 8.5 x its height starts the quadtree with more than eight root nodes;
+    degenerate upper levels (no FAST cell fits) yield no keypoints without failing the extraction"""
+    for w, h in ((800, 104), (848, 87), (900, 96)):
+        img = synth_frame(5, w=w, h=h)
+        ox = fe.OrbExtractor(ctx, 1000, 1.2, 8)
+        kp, d = ox(img); okp, od = oracle.orb_extract(img, 1000, 1.2, 8); ox.close()
+        assert len(okp) > 50 and len(kp) == len(okp)
+        np.testing.assert_array_equal(kp.view(np.uint8), okp.view(np.uint8)); np.testing.assert_array_equal(d, od)
