@@ -75,11 +75,14 @@ def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=600, with_li
     pk, pd = orc.orb_extract(frames_prev[0], NFEAT)
     pl = orc.lines_extract(frames_prev[0], NLINES) if with_lines else None
     t0 = time.perf_counter()
+    ref = []        # the oracle's outputs for the first pass over the distinct frames: compared with the GPU batch after the timing
     while n < max_frames and (time.perf_counter() - t0) < budget_s:
         cur = frames_cur[n % len(frames_cur)]
         kp, d = orc.orb_extract(cur, NFEAT)
         if with_lines:
             kl, ld, fn, raw = orc.lines_extract(cur, NLINES)
+        if n < len(frames_cur):
+            ref.append((kp, d, kl if with_lines else None, ld if with_lines else None))
         if with_match:
             pm = np.stack([pk["x"], pk["y"]], axis=1).astype(np.float32)
             orc.search_for_initialization(pk, pd, kp, d, pm, 100, 0.9, True, (0.0, float(W), 0.0, float(H)))
@@ -89,7 +92,23 @@ def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=600, with_li
         n += 1
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same %dx%d workload (ORB %d%s%s), %.1f s, single thread" % (n, W, H, NFEAT, " + LSD/LBD %d" % NLINES if with_lines else "", " + matches" if with_match else "", dt)}
+            "sample": "%d frames of the same %dx%d workload (ORB %d%s%s), %.1f s, single thread" % (n, W, H, NFEAT, " + LSD/LBD %d" % NLINES if with_lines else "", " + matches" if with_match else "", dt)}, ref
+
+
+def parity_vs_gpu(ref, feat, with_lines):
+    """The oracle outputs of the baseline leg against what the timed GPU batch holds for the same frames (batch slot i = distinct
+    frame i): keypoints + descriptors byte for byte, keylines byte for byte except KeyLine.angle (<= 1 ulp), LBD bytes."""
+    import numpy as np
+    res = {"frames": len(ref), "orb_equal": 0, "lines_equal": 0 if with_lines else None}
+    n = feat["n"][:len(ref)].cpu().numpy(); nl = feat["nl"][:len(ref)].cpu().numpy()
+    for i, (kp, d, kl, ld) in enumerate(ref):
+        gk = feat["kp"][i, :n[i]].cpu().numpy().view(np.uint8).reshape(-1, 28); gd = feat["desc"][i, :n[i]].cpu().numpy()
+        res["orb_equal"] += int(n[i] == len(kp) and np.array_equal(gk, kp.view(np.uint8).reshape(-1, 28)) and np.array_equal(gd, d))
+        if with_lines:
+            gl = feat["kl"][i, :nl[i]].cpu().numpy().view(np.uint8).reshape(-1, 68).copy(); ol = kl.view(np.uint8).reshape(-1, 68).copy()
+            gl[:, 0:4] = 0; ol[:, 0:4] = 0
+            res["lines_equal"] += int(nl[i] == len(kl) and np.array_equal(gl, ol) and np.array_equal(feat["ldesc"][i, :nl[i]].cpu().numpy(), ld))
+    return res
 
 
 def main():
@@ -221,7 +240,8 @@ def main():
                                                   "frac": sum(ab.values()) * fps / world / 1e9 / HBM_PEAK_GBS},
                                "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cur_np, prev_np, with_lines=wl["nlines"] > 0, with_match=wl["match"])
+            out["cpu_baseline"], ref = cpu_baseline(cur_np, prev_np, with_lines=wl["nlines"] > 0, with_match=wl["match"])
+            out["cpu_baseline"]["parity_vs_gpu"] = parity_vs_gpu(ref, pipe.feat["cur"], wl["nlines"] > 0)
         print(json.dumps(out))
     pipe.close()
     ctx.close()
