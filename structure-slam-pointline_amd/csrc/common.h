@@ -106,6 +106,17 @@ namespace sslam {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Workgroups are handed to the eight XCDs round-robin (linear id % 8).  With one workgroup per frame a batch whose content
+// repeats with a period of 8 (or drifts slowly) would give every XCD the same kind of frame and the kernel would last as long
+// as the heaviest kind.  Rotating the assignment inside each group of eight frames by a digit sum of the group index gives every
+// XCD (and every CU / SIMD behind it) one frame of every group and a mix of residue classes; the map is a bijection on [0, n)
+// (the tail group is left alone).
+__device__ __forceinline__ int xcd_mix_frame(int id, int n) {
+    const int g = id >> 3;
+    const int rot = g + (g >> 3) + (g >> 6) + (g >> 9);       // no power-of-two period: CUs and SIMDs are dealt out round-robin as well
+    return ((g << 3) + 8 <= n) ? ((g << 3) | ((id + rot) & 7)) : id;
+}
+
 // number of set bits of `mask` strictly below this lane
 __device__ __forceinline__ int mbcnt(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));

@@ -963,7 +963,7 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
 __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
     __shared__ CntItem its[64];
     __shared__ unsigned short act[EVAL_CH];
-    const int b = blockIdx.y, lane = threadIdx.x;
+    const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     const Misc* misc = (const Misc*)(base + P.offMisc);
     const int nCand = misc->nCand;
@@ -1070,7 +1070,7 @@ __device__ __forceinline__ int stage_ncand(const NfaState& s, int stage) {
 }
 __global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPlan P, int stage, const double* __restrict__ lgam) {
     __shared__ unsigned short items[EVAL_CH * 5];            // (rect - chunk) << 3 | candidate
-    const int b = blockIdx.y, lane = threadIdx.x;
+    const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     Misc* misc = (Misc*)(base + P.offMisc);
     const int nCand = misc->nCand;
@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(256) void k_nfa_finish(uint8_t* __restrict__ ws, Ls
 template <bool LAT>
 __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
     extern __shared__ __align__(16) unsigned dynLds[];           // region queue (first QCAP points)
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = xcd_mix_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     const float* ang = (const float*)(base + P.offAng);
     float4* pix = (float4*)(base + P.offPix);

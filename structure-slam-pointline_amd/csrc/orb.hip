@@ -335,7 +335,9 @@ __global__ __launch_bounds__(64) void k_octree(const unsigned* __restrict__ cand
                                                unsigned* __restrict__ bufB, unsigned* __restrict__ sel,
                                                int* __restrict__ selCount, Plan P, int NC, int NCp2) {
     extern __shared__ __align__(16) uint8_t lds[];
-    const int level = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    // linear workgroup id = frame * nlevels + x: with eight levels the XCD would be the level; rotate by the frame instead
+    // (digit-sum rotation: XCDs, CUs and SIMDs are all dealt out round-robin, a plain +frame would still be periodic per CU)
+    const int b = blockIdx.y, level = (int)((blockIdx.x + b + (b >> 3) + (b >> 6) + (b >> 9)) % gridDim.x), lane = threadIdx.x;
     const LevelInfo& L = P.L[level];
     OctLds S;
     S.expA = (unsigned long long*)lds;
