@@ -116,7 +116,7 @@ struct SfiArgs {
 };
 
 __global__ __launch_bounds__(64) void k_search_init(SfiArgs A) {
-    const int p = blockIdx.x, lane = threadIdx.x;
+    const int p = xcd_mix_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;      // one wave per frame pair: see xcd_mix_frame
     const int n1 = A.n1 ? A.n1[p] : A.n1s, n2 = A.n2 ? A.n2[p] : A.n2s;
     const sslam_keypoint* kp1 = A.kp1 + (size_t)p * A.cap;
     const sslam_keypoint* kp2 = A.kp2 + (size_t)p * A.cap;
