@@ -83,3 +83,37 @@ def test_empty_and_tiny_inputs(fe, ctx):
     assert desc.shape == (len(kp), 32)
     ox.close()
     assert ctx.hamming_knn2(np.zeros((0, 32), np.uint8), np.zeros((4, 32), np.uint8))[0].shape == (0, 2)
+
+
+def test_batch_of_19_distinct_frames(fe, ctx, oracle):
+    """two full groups of eight plus a tail: the XCD-aware frame mapping (xcd_mix_frame) permutes which workgroup handles which
+    frame; every slot must still hold ITS frame's results"""
+    pipeline = pkg._load("sslam_pipeline", os.path.join(pkg.PKG_DIR, "pipeline.py"))
+    w, h, B = 320, 240, 19
+    frames = [synth_frame(4000 + i, w, h, nshapes=10 + 7 * i, nstrokes=3 * i, noise=float(i % 4)) for i in range(B)]
+    pipe = pipeline.FrontendBatch(fe, ctx, w, h, B, 500, 100, "cuda:0")
+    imgs = torch.from_numpy(np.stack(frames)).cuda()
+    prev = torch.from_numpy(np.stack([warp_prev(f) for f in frames])).cuda()
+    pipe.extract(prev, "prev")
+    pipe.step(imgs)
+    torch.cuda.synchronize()
+    c = pipe.feat["cur"]
+    n = c["n"].cpu().numpy(); nl = c["nl"].cpu().numpy()
+    m12 = pipe.m12.cpu().numpy(); nm = pipe.nmatch.cpu().numpy(); lp = pipe.lpairs.cpu().numpy(); nlp = pipe.nlpairs.cpu().numpy()
+    for i, f in enumerate(frames):
+        okp, od = oracle.orb_extract(f, 500); okl, old, ofn, _ = oracle.lines_extract(f, 100)
+        assert n[i] == len(okp) and nl[i] == len(okl), i
+        np.testing.assert_array_equal(c["kp"][i, :n[i]].cpu().numpy().view(np.uint8).reshape(-1, 28), okp.view(np.uint8).reshape(-1, 28))
+        np.testing.assert_array_equal(c["desc"][i, :n[i]].cpu().numpy(), od)
+        np.testing.assert_array_equal(c["ldesc"][i, :nl[i]].cpu().numpy(), old)
+        np.testing.assert_array_equal(c["linefn"][i, :nl[i]].cpu().numpy(), ofn)
+        kp1, d1 = oracle.orb_extract(warp_prev(f), 500)
+        pm = np.stack([kp1["x"], kp1["y"]], axis=1).astype(np.float32)
+        om12, _, on = oracle.search_for_initialization(kp1, d1, okp, od, pm, 100, 0.9, True, (0.0, float(w), 0.0, float(h)))
+        assert nm[i] == on, i
+        np.testing.assert_array_equal(m12[i][:len(kp1)], om12)
+        l1 = oracle.lines_extract(warp_prev(f), 100)
+        opairs, _, _ = oracle.line_match(l1[1], old, 0.5, False)
+        assert nlp[i] == len(opairs)
+        np.testing.assert_array_equal(lp[i][:nlp[i]], opairs)
+    pipe.close()
