@@ -373,14 +373,13 @@ struct BowArgs {
     float nnratio; int checkOri; int* assigned; int* nmatches; int* qbin;   // qbin[nF]: rotation bin recorded for a frame feature
 };
 
+// A frame feature belongs to one vocabulary node, so the only order dependence of SearchByBoW -- a frame feature that is
+// already matched is skipped (:216-217) -- stays inside a node: one wave per node walks that node's keyframe features in order
+// (grid = 1 replays all nodes in order, used when a caller's lists share a feature between nodes).  The rotation histogram
+// only needs counts; k_bow_finish builds it, prunes and counts.  assigned / qbin arrive as -1, *nmatches as 0.
 __global__ __launch_bounds__(64) void k_search_bow(BowArgs A) {
     const int lane = threadIdx.x;
-    __shared__ int hist[HISTO_LENGTH];
-    if (lane < HISTO_LENGTH) hist[lane] = 0;
-    for (int i = lane; i < A.nF; i += 64) { A.assigned[i] = -1; A.qbin[i] = -1; }
-    __syncthreads();
-    int nmatches = 0, removed = 0;
-    for (int nd = 0; nd < A.nnodes; ++nd) {
+    for (int nd = blockIdx.x; nd < A.nnodes; nd += gridDim.x) {
         const int f0 = A.ptrF[nd], f1 = A.ptrF[nd + 1];
         for (int a = A.ptrKF[nd]; a < A.ptrKF[nd + 1]; ++a) {
             const int ik = A.idxKF[a];
@@ -400,38 +399,55 @@ __global__ __launch_bounds__(64) void k_search_bow(BowArgs A) {
             if (best != ~0ull && (int)(best >> 32) < 256) { bestDist1 = (int)(best >> 32); bestIdxF = A.idxF[f0 + (int)(unsigned)best]; }
             if (second != ~0ull && (int)(second >> 32) < 256) bestDist2 = (int)(second >> 32);
             if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(A.nnratio, (float)bestDist2)) {
-                if (A.checkOri) {
-                    float rot = __fsub_rn(A.kpKF[ik].angle, A.kpF[bestIdxF].angle);
-                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                    int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
-                    if (bin == HISTO_LENGTH) bin = 0;
-                    if (lane == 0) { A.qbin[bestIdxF] = bin; hist[bin]++; }
+                if (lane == 0) {
+                    if (A.checkOri) {
+                        float rot = __fsub_rn(A.kpKF[ik].angle, A.kpF[bestIdxF].angle);
+                        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                        int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        A.qbin[bestIdxF] = bin;
+                    }
+                    A.assigned[bestIdxF] = ik;
                 }
-                if (lane == 0) A.assigned[bestIdxF] = ik;
-                ++nmatches;
-                __syncthreads();
+                __syncthreads();          // the next keyframe feature of this node must see the assignment
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void k_bow_finish(int* __restrict__ assigned, const int* __restrict__ qbin, int nF, int checkOri, int* __restrict__ nmatches) {
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int keep[3];
+    __shared__ int total;
+    const int t = threadIdx.x;
+    if (t < HISTO_LENGTH) hist[t] = 0;
+    if (t == 0) total = 0;
     __syncthreads();
-    if (A.checkOri) {
-        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
-        for (int i = 0; i < HISTO_LENGTH; ++i) {
-            const int c = hist[i];
-            if (c > max1) { max3 = max2; max2 = max1; max1 = c; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (c > max2) { max3 = max2; max2 = c; ind3 = ind2; ind2 = i; }
-            else if (c > max3) { max3 = c; ind3 = i; }
+    if (checkOri) {
+        for (int i = t; i < nF; i += 256) if (assigned[i] >= 0) atomicAdd(&hist[qbin[i]], 1);
+        __syncthreads();
+        if (t == 0) {
+            int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+            for (int i = 0; i < HISTO_LENGTH; ++i) {
+                const int c = hist[i];
+                if (c > max1) { max3 = max2; max2 = max1; max1 = c; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (c > max2) { max3 = max2; max2 = c; ind3 = ind2; ind2 = i; }
+                else if (c > max3) { max3 = c; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+            keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
         }
-        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
-        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
-        for (int i0 = 0; i0 < A.nF; i0 += 64) {      // a frame feature is matched at most once, so entries == features
-            const int i = i0 + lane;
-            bool rm = false;
-            if (i < A.nF) { const int bn = A.qbin[i]; rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3; if (rm) A.assigned[i] = -1; }
-            removed += __popcll(__ballot(rm));
-        }
+        __syncthreads();
     }
-    if (lane == 0) *A.nmatches = nmatches - removed;
+    int cnt = 0;
+    for (int i = t; i < nF; i += 256) {
+        if (assigned[i] < 0) continue;
+        if (checkOri) { const int bn = qbin[i]; if (bn != keep[0] && bn != keep[1] && bn != keep[2]) { assigned[i] = -1; continue; } }
+        ++cnt;
+    }
+    atomicAdd(&total, cnt);
+    __syncthreads();
+    if (t == 0) *nmatches = total;
 }
 
 // ---------------------------------------------------------------- line matching
@@ -1340,6 +1356,9 @@ extern "C" int sslam_orb_search_by_bow(sslam_ctx* ctx, const sslam_keypoint* kf_
     for (int i = 0; i < nf; ++i) assigned_out[i] = -1;
     if (nnodes == 0 || nf == 0 || nkf == 0) return SSLAM_OK;
     const int nk = node_kf_ptr[nnodes], nfi = node_f_ptr[nnodes];
+    if (node_kf_ptr[0] != 0 || node_f_ptr[0] != 0 || nk < 0 || nfi < 0) { set_error("sslam_orb_search_by_bow: invalid node offsets"); return SSLAM_ERR_INVALID; }
+    for (int i = 0; i < nk; ++i) if (kf_idx[i] < 0 || kf_idx[i] >= nkf) { set_error("sslam_orb_search_by_bow: keyframe feature index out of range"); return SSLAM_ERR_INVALID; }
+    for (int i = 0; i < nfi; ++i) if (f_idx[i] < 0 || f_idx[i] >= nf) { set_error("sslam_orb_search_by_bow: frame feature index out of range"); return SSLAM_ERR_INVALID; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -1360,7 +1379,15 @@ extern "C" int sslam_orb_search_by_bow(sslam_ctx* ctx, const sslam_keypoint* kf_
     A.kpKF = (const sslam_keypoint*)(B + o[0]); A.dKF = B + o[1]; A.validKF = B + o[2]; A.kpF = (const sslam_keypoint*)(B + o[3]); A.dF = B + o[4]; A.nF = nf;
     A.ptrKF = (const int*)(B + o[5]); A.ptrF = (const int*)(B + o[6]); A.nnodes = nnodes; A.idxKF = (const int*)(B + o[7]); A.idxF = (const int*)(B + o[8]);
     A.nnratio = nnratio; A.checkOri = check_orientation; A.assigned = (int*)(B + o[9]); A.nmatches = (int*)(B + o[10]); A.qbin = (int*)(B + o[11]);
-    { sslam::ProfScope _ps(ctx, "k_search_bow", st); hipLaunchKernelGGL(k_search_bow, dim3(1), dim3(64), 0, st, A); }
+    SSLAM_HIP(hipMemsetAsync(A.assigned, 0xFF, 4 * (size_t)nf, st));
+    SSLAM_HIP(hipMemsetAsync(A.qbin, 0xFF, 4 * (size_t)nf, st));
+    bool disjoint = true;                     // DBoW2 puts a feature under exactly one node; if a caller's lists do not, replay in order
+    {
+        std::vector<uint8_t> seen((size_t)nf, 0);
+        for (int i = 0; i < nfi && disjoint; ++i) { if (seen[f_idx[i]]) disjoint = false; seen[f_idx[i]] = 1; }
+    }
+    { sslam::ProfScope _ps(ctx, "k_search_bow", st); hipLaunchKernelGGL(k_search_bow, dim3(disjoint ? std::min(nnodes, 4096) : 1), dim3(64), 0, st, A); }
+    { sslam::ProfScope _ps(ctx, "k_bow_finish", st); hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, st, A.assigned, A.qbin, nf, check_orientation, A.nmatches); }
     SSLAM_HIP(hipGetLastError());
     SSLAM_HIP(hipMemcpyAsync(assigned_out, B + o[9], 4 * (size_t)nf, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + o[10], sizeof(int), hipMemcpyDeviceToHost, st));

@@ -326,3 +326,24 @@ def test_bow_transform(fe, ctx, oracle, levelsup):
     w2, v2, n2 = voc.transform(fr, levelsup)                               # Frame::ComputeBoW on a resident frame
     np.testing.assert_array_equal(w2, ow[:len(d)]); np.testing.assert_array_equal(n2, on[:len(d)])
     fr.close(); voc.close()
+
+
+def test_search_by_bow_overlapping_nodes(fe, ctx, oracle):
+    """DBoW2 files a feature under exactly one node; lists that share a frame feature between nodes make the order of the
+    nodes matter, and the matcher then replays them in order (one workgroup) instead of one workgroup per node"""
+    rng = np.random.default_rng(3)
+    cur = synth_frame(2003); prev = warp_prev(cur)
+    kp1, d1 = oracle.orb_extract(prev, 1000); kp2, d2 = oracle.orb_extract(cur, 1000)
+    pk, pf, ik, jf = _pseudo_feature_vectors(d1, d2, nbits=4)
+    # append to every node a few frame features of the NEXT node (so they are candidates twice)
+    nf = []; npf = [0]
+    for k in range(len(pf) - 1):
+        own = jf[pf[k]:pf[k + 1]].tolist()
+        nxt = jf[pf[k + 1]:pf[k + 2]][:3].tolist() if k + 2 < len(pf) else []
+        nf += own + nxt; npf.append(len(nf))
+    jf2 = np.array(nf, np.int32); pf2 = np.array(npf, np.int32)
+    valid = (rng.random(len(kp1)) < 0.9).astype(np.uint8)
+    a, n = ctx.search_by_bow(kp1, d1, valid, kp2, d2, pk, pf2, ik, jf2, 0.8, True)
+    oa, on = oracle.search_by_bow(kp1, d1, valid, kp2, d2, pk, pf2, ik, jf2, 0.8, True)
+    assert on > 30 and n == on
+    np.testing.assert_array_equal(a, oa)

@@ -48,6 +48,9 @@ F12 = np.array([[0, -1e-3, 0.3], [1e-3, 0, 2.0], [-0.3, -2.0, 1.0]], np.float32)
 kf1 = ctx.frame_upload(0, kp1, d1); sg = (sc * sc).astype(np.float32)
 row("SearchForTriangulation 1000x1000", lambda: kf1.search_for_triangulation(kf, free1, free2, pk, pf, ik, jf, F12, -2000.0, 300.0, sc, sg, False, True),
     lambda: orc.search_for_triangulation(kp1, d1, None, free1, kp2, d2, None, free2, pk, pf, ik, jf, F12, -2000.0, 300.0, sc, sg, False, True))
+valid = np.ones(len(kp1), np.uint8)
+row("SearchByBoW 1000x1000 (32-node pseudo vocabulary level)", lambda: ctx.search_by_bow(kp1, d1, valid, kp2, d2, pk, pf, ik, jf, 0.7, True),
+    lambda: orc.search_by_bow(kp1, d1, valid, kp2, d2, pk, pf, ik, jf, 0.7, True))
 sizes = rng.integers(3, 15, 2000); ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
 dd = rng.integers(0, 256, (ptr[-1], 32), dtype=np.uint8)
 row("ComputeDistinctiveDescriptors, 2000 map points x 3..14 observations", lambda: ctx.distinctive_descriptors(dd, ptr), lambda: orc.distinctive(dd, ptr))

@@ -66,6 +66,11 @@ def main():
         om, onm = orc.search_for_triangulation(kp1, d1, ur1, free1, kp2, d2, ur, free2, pk, pf, ik, jf, F12, ex, ey, sc, (sc * sc).astype(np.float32), onlyst, ori)
         if nm != onm or not np.array_equal(m, om): bad.append("tri it %d %d/%d" % (it, nm, onm))
         f1.close(); kf.close()
+        # ---- SearchByBoW over the same pseudo vocabulary nodes
+        validk = (rng.random(len(kp1)) < 0.9).astype(np.uint8); rb = float(rng.choice([0.6, 0.75, 0.9]))
+        ab, nb = ctx.search_by_bow(kp1, d1, validk, kp2, d2, pk, pf, ik, jf, rb, ori)
+        ob, onb = orc.search_by_bow(kp1, d1, validk, kp2, d2, pk, pf, ik, jf, rb, ori)
+        if nb != onb or not np.array_equal(ab, ob): bad.append("bow it %d %d/%d" % (it, nb, onb))
         # ---- lines: projection + knn + MAD gate
         if len(kl1) > 2 and len(kl2) > 2:
             ql = np.zeros(len(kl1), fe.PQ_DTYPE)
