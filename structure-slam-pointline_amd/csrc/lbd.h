@@ -1,0 +1,298 @@
+// KeyLine fill + top-N, LBD pre-blur + Sobel (fused register sliding window), LBD band descriptor.
+// Part of lines.hip (included there, inside its anonymous namespace: one translation unit, so device helpers are shared
+// without relocatable device code).  Not a standalone header.
+#pragma once
+
+// ------------------------------------------------------------------ KeyLine fill + top-N (LSDDetector::detectImpl, ExtractLineSegment :42-51)
+__global__ __launch_bounds__(256) void k_keylines(uint8_t* __restrict__ ws, LsdPlan P, int maxLines,
+                                                  sslam_keyline* __restrict__ klOut, double* __restrict__ fnOut,
+                                                  int* __restrict__ counts, int cap) {
+    __shared__ unsigned long long keys[MAX_SEG];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    float4* seg = (float4*)(base + P.offSeg);
+    Misc* misc = (Misc*)(base + P.offMisc);
+    sslam_keyline* klw = (sslam_keyline*)(base + P.offKl);
+    // ordered compaction of the candidates the NFA stage accepted (seed order == the reference's emission order)
+    __shared__ int wcnt[4];
+    __shared__ int nAcc;
+    {
+        const int* flag = (const int*)(base + P.offFlag);
+        const int nCand = misc->nCand;
+        const int lane = tid & 63, wv = tid >> 6;
+        int basePos = 0;
+        for (int i0 = 0; i0 < nCand; i0 += 256) {
+            const int i = i0 + tid;
+            const bool ok = i < nCand && flag[i] != 0;
+            const float4 v = ok ? seg[i] : make_float4(0, 0, 0, 0);
+            const unsigned long long m = __ballot(ok);
+            if (lane == 0) wcnt[wv] = __popcll(m);
+            __syncthreads();                       // also orders the reads of seg[i0..i0+256) before the writes below (dst <= src)
+            int off = basePos;
+            for (int q = 0; q < wv; ++q) off += wcnt[q];
+            if (ok) seg[off + mbcnt(m)] = v;
+            basePos += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+        }
+        if (tid == 0) { nAcc = basePos; misc->nSeg = basePos; }
+        __syncthreads();
+    }
+    const int n = nAcc;
+    for (int i = tid; i < n; i += 256) {
+        float4 s = seg[i];
+        float e0 = s.x, e1 = s.y, e2 = s.z, e3 = s.w;
+        const float W = (float)P.w, H = (float)P.h;           // checkLineExtremes
+        if (e0 < 0) e0 = 0; if (e0 >= W) e0 = W - 1.0f;
+        if (e2 < 0) e2 = 0; if (e2 >= W) e2 = W - 1.0f;
+        if (e1 < 0) e1 = 0; if (e1 >= H) e1 = H - 1.0f;
+        if (e3 < 0) e3 = 0; if (e3 >= H) e3 = H - 1.0f;
+        sslam_keyline k;
+        k.startPointX = e0; k.startPointY = e1; k.endPointX = e2; k.endPointY = e3;
+        k.sPointInOctaveX = e0; k.sPointInOctaveY = e1; k.ePointInOctaveX = e2; k.ePointInOctaveY = e3;
+        const double ddx = (double)__fsub_rn(e0, e2), ddy = (double)__fsub_rn(e1, e3);
+        k.lineLength = (float)sqrt(ddx * ddx + ddy * ddy);
+        const int ax = cv_roundf(e0), ay = cv_roundf(e1), bx = cv_roundf(e2), by = cv_roundf(e3);
+        k.numOfPixels = max(abs(bx - ax), abs(by - ay)) + 1;
+        k.angle = (float)atan2((double)__fsub_rn(e3, e1), (double)__fsub_rn(e2, e0));     // D5
+        k.class_id = i; k.octave = 0;
+        k.size = __fmul_rn(__fsub_rn(e2, e0), __fsub_rn(e3, e1));
+        k.response = __fdiv_rn(k.lineLength, (float)max(P.w, P.h));
+        k.pt_x = __fdiv_rn(__fadd_rn(e2, e0), 2.f); k.pt_y = __fdiv_rn(__fadd_rn(e3, e1), 2.f);
+        klw[i] = k;
+        keys[i] = ((unsigned long long)(~__float_as_uint(k.response)) << 32) | (unsigned)i;   // response >= 0: descending response, ascending index (D3 stable)
+    }
+    __syncthreads();
+    int nOut = n;
+    const bool doSort = n > maxLines;
+    if (doSort) {
+        int P2 = 1; while (P2 < n) P2 <<= 1;
+        for (int i = n + tid; i < P2; i += 256) keys[i] = ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= P2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < P2; i += 256) {
+                    int ixj = i ^ j;
+                    if (ixj > i) {
+                        unsigned long long a = keys[i], c = keys[ixj];
+                        bool up = (i & k) == 0;
+                        if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        nOut = maxLines;
+    }
+    nOut = min(nOut, cap);
+    for (int i = tid; i < nOut; i += 256) {
+        const int src = doSort ? (int)(unsigned)keys[i] : i;
+        sslam_keyline k = klw[src];
+        if (doSort) k.class_id = i;
+        klOut[(size_t)b * cap + i] = k;
+        // line equation sp x ep, normalised by its first two components (ExtractLineSegment :56-68), fp64
+        const double sx = k.startPointX, sy = k.startPointY, ex = k.endPointX, ey = k.endPointY;
+        const double l0 = __dsub_rn(sy, ey), l1 = __dsub_rn(ex, sx), l2 = __dsub_rn(__dmul_rn(sx, ey), __dmul_rn(sy, ex));
+        const double nrm = sqrt(__dadd_rn(__dmul_rn(l0, l0), __dmul_rn(l1, l1)));
+        double* f = fnOut + ((size_t)b * cap + i) * 3;
+        f[0] = l0 / nrm; f[1] = l1 / nrm; f[2] = l2 / nrm;
+    }
+    if (tid == 0) { counts[b] = nOut; misc->nKl = nOut; }
+}
+
+// ------------------------------------------------------------------ LBD front: 5x5 sigma-1 blur + Sobel 3x3 -> s16, fused
+// BinaryDescriptor::computeGaussianPyramid (GaussianBlur 5x5, sigma 1) + cv::Sobel(CV_16S, ksize 3), both BORDER_REFLECT_101.
+// The blurred image never reaches HBM: a 70x22 source tile (reflect-101) -> 66x22 horizontal pass -> 66x18 blurred tile in
+// LDS -> 64x16 dx/dy.  (A symmetric kernel with reflect-101 borders commutes with the reflection, so evaluating the blur at the
+// one-pixel Sobel halo outside the image from the reflected source IS the blurred value at the reflected pixel.)
+__global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ src, size_t spitch, size_t sframe, int w, int h,
+                                                    unsigned* __restrict__ dxyo, size_t dframeBytes,
+                                                    const int* __restrict__ tapsArr) {
+    // register sliding window (see k_blur7): 5x5 blur rows -> 3-row Sobel window.  Blurring the reflect-extended source with
+    // symmetric taps equals reflect-extending the blurred image, which is what Sobel's BORDER_REFLECT_101 reads.
+    constexpr int R = 3;                                   // blur radius 2 + Sobel radius 1
+    const int ngroups = (w + 3) >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int strip = t / ngroups, x4 = (t - strip * ngroups) * 4, y0 = strip * STRIP;
+    if (y0 >= h) return;
+    const int b = blockIdx.y;
+    const uint8_t* s = src + (size_t)b * sframe;
+    unsigned taps[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) taps[k] = (unsigned)tapsArr[k];
+    const unsigned T0 = taps[0] | (taps[1] << 8) | (taps[2] << 16) | (taps[3] << 24), T1 = taps[4];       // q8 taps < 256
+    const bool fast = x4 >= 4 && x4 + 8 <= w && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
+    const bool vec = ((w & 3) == 0) && ((dframeBytes & 15) == 0);
+    unsigned hb[5][6];                                     // horizontally blurred rows, columns x4-1 .. x4+4
+    int bl[3][6];                                          // blurred rows
+#pragma unroll
+    for (int r = 0; r < STRIP + 2 * R; ++r) {
+        if (r >= 2 * R && y0 + r - 2 * R >= h) break;
+        unsigned d0, d1, d2;
+        load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, d0, d1, d2);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) hb[r % 5][c] = hdot(d0, d1, d2, c + 1, T0, T1);      // columns x4+c-3 .. x4+c+1 (sums fit 16 bits: taps sum to 256)
+        if (r >= 4) {
+            const int q = r - 4;                           // blurred row y0 - 1 + q
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                unsigned acc = 0;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) acc += hb[(q + k) % 5][c] * taps[k];
+                bl[q % 3][c] = (int)(((acc + 32768u) >> 16) & 255u);
+            }
+            if (q >= 2) {
+                const int y = y0 + q - 2;
+                const int* A = bl[(q - 2) % 3];
+                const int* M = bl[(q - 1) % 3];
+                const int* C = bl[q % 3];
+                short gx[4], gy[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    gx[j] = (short)((A[j + 2] - A[j]) + 2 * (M[j + 2] - M[j]) + (C[j + 2] - C[j]));
+                    gy[j] = (short)((C[j] - A[j]) + 2 * (C[j + 1] - A[j + 1]) + (C[j + 2] - A[j + 2]));
+                }
+                // interleaved {dx, dy} int16 pairs: the LBD walk fetches both with one dword gather
+                unsigned* op = (unsigned*)((uint8_t*)dxyo + (size_t)b * dframeBytes) + (size_t)y * w + x4;
+                unsigned pk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[j] = ((unsigned)(unsigned short)gx[j]) | ((unsigned)(unsigned short)gy[j] << 16);
+                if (x4 + 3 < w && vec) *(uint4*)op = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (x4 + j < w) op[j] = pk[j];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LBD (BinaryDescriptor::computeLBD)
+// One wave per line: lane = row of the 63-row line-support region, walking its row in
+// the reference's order so every fp32 accumulation matches bit for bit; then 9 lanes
+// fold rows into bands (again in row order), and the 72-float vector is normalised,
+// clipped and binarised by lane 0..31.
+__constant__ float kGaussL[21];
+__constant__ float kGaussG[63];
+__constant__ signed char kComb[64];
+
+__global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdPlan P, const sslam_keyline* __restrict__ kls,
+                                            const int* __restrict__ counts, uint8_t* __restrict__ descOut, int cap) {
+    __shared__ float rows[8][64];       // pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 per row
+    __shared__ float band[8][NUM_BANDS];
+    __shared__ float des[72];
+    const int li = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    if (li >= counts[b]) return;
+    const uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const unsigned* dxyImg = (const unsigned*)(base + P.offDxy);      // {dx, dy} int16 pairs
+    const sslam_keyline kl = kls[(size_t)b * cap + li];
+    const int lengthOfLSP = (short)kl.numOfPixels;
+    const int halfWidth = (lengthOfLSP - 1) / 2, halfHeight = (LSP_H - 1) / 2;
+    const float midX = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveX, kl.ePointInOctaveX));
+    const float midY = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveY, kl.ePointInOctaveY));
+    const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);      // D5
+    const float dO0 = -dL1, dO1 = dL0;
+    const int realWidth = P.w, imageWidth = P.w - 1, imageHeight = P.h - 1;
+    if (lane < LSP_H) {
+        // row start: sCor0 after `lane` steps of (sCorX0 -= dL1, sCorY0 += dL0), sequential float ops
+        float sx0 = __fadd_rn(__fadd_rn(__fmul_rn(-dL0, (float)halfWidth), __fmul_rn(dL1, (float)halfHeight)), midX);
+        float sy0 = __fadd_rn(__fsub_rn(__fmul_rn(-dL1, (float)halfWidth), __fmul_rn(dL0, (float)halfHeight)), midY);
+        for (int r = 0; r < lane; ++r) { sx0 = __fsub_rn(sx0, dL1); sy0 = __fadd_rn(sy0, dL0); }
+        float sx = sx0, sy = sy0;
+        float pL = 0, nL = 0, pO = 0, nO = 0;
+        for (int w0 = 0; w0 < lengthOfLSP; w0 += 8) {
+            // coordinates of eight consecutive steps (the float walk itself stays sequential), then the eight gathers together
+            int idx8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int tc = (int)(short)(int)roundf(sx);
+                const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
+                tc = (int)(short)(int)roundf(sy);
+                const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
+                idx8[u] = yCor * realWidth + xCor;
+                sx = __fadd_rn(sx, dL0); sy = __fadd_rn(sy, dL1);
+            }
+            unsigned g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[u] = dxyImg[idx8[u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (w0 + u < lengthOfLSP) {
+                    const float dx = (float)(short)(g[u] & 0xFFFFu), dy = (float)(short)(g[u] >> 16);
+                    const float gDL = __fadd_rn(__fmul_rn(dx, dL0), __fmul_rn(dy, dL1));
+                    const float gDO = __fadd_rn(__fmul_rn(dx, dO0), __fmul_rn(dy, dO1));
+                    if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
+                    if (gDO > 0) pO = __fadd_rn(pO, gDO); else nO = __fsub_rn(nO, gDO);
+                }
+            }
+        }
+        const float cg = kGaussG[lane];
+        pL = __fmul_rn(cg, pL); nL = __fmul_rn(cg, nL); pO = __fmul_rn(cg, pO); nO = __fmul_rn(cg, nO);
+        rows[0][lane] = pL; rows[1][lane] = nL; rows[2][lane] = __fmul_rn(pL, pL); rows[3][lane] = __fmul_rn(nL, nL);
+        rows[4][lane] = pO; rows[5][lane] = nO; rows[6][lane] = __fmul_rn(pO, pO); rows[7][lane] = __fmul_rn(nO, nO);
+    }
+    __syncthreads();
+    // band sums: lane -> (quantity q = lane/9, band = lane%9); rows visited in increasing hID so the
+    // accumulation order equals the reference's (own band, band above, band below contributions interleave by row)
+    for (int t = lane; t < 8 * NUM_BANDS; t += 64) {
+        const int q = t / NUM_BANDS, bd = t - q * NUM_BANDS;
+        const bool sq = (q == 2 || q == 3 || q == 6 || q == 7);
+        float acc = 0;
+        const int h0 = max(0, (bd - 1) * BAND_W), h1 = min(LSP_H, (bd + 2) * BAND_W);
+        for (int hID = h0; hID < h1; ++hID) {
+            const int own = hID / BAND_W, m = hID - own * BAND_W;
+            float c;
+            if (own == bd) c = kGaussL[m + BAND_W];
+            else if (own == bd + 1) c = kGaussL[m + 2 * BAND_W];     // row of the band below contributes "upward"
+            else c = kGaussL[m];                                       // row of the band above contributes "downward"
+            const float v = rows[q][hID];
+            acc = sq ? __fadd_rn(acc, __fmul_rn(__fmul_rn(c, c), v)) : __fadd_rn(acc, __fmul_rn(c, v));
+        }
+        band[q][bd] = acc;
+    }
+    __syncthreads();
+    // sqrtf, not __fsqrt_rn: HIP maps the latter to the native (1-ulp) v_sqrt_f32, the former is correctly rounded
+    if (lane < NUM_BANDS) {
+        const int bd = lane;
+        const float invN = (bd == 0 || bd == NUM_BANDS - 1) ? (float)(1.0 / (BAND_W * 2.0)) : (float)(1.0 / (BAND_W * 3.0));
+        float t;
+        t = __fmul_rn(band[0][bd], invN); des[bd * 8 + 0] = t; des[bd * 8 + 4] = sqrtf(__fsub_rn(__fmul_rn(band[2][bd], invN), __fmul_rn(t, t)));
+        t = __fmul_rn(band[1][bd], invN); des[bd * 8 + 1] = t; des[bd * 8 + 5] = sqrtf(__fsub_rn(__fmul_rn(band[3][bd], invN), __fmul_rn(t, t)));
+        t = __fmul_rn(band[4][bd], invN); des[bd * 8 + 2] = t; des[bd * 8 + 6] = sqrtf(__fsub_rn(__fmul_rn(band[6][bd], invN), __fmul_rn(t, t)));
+        t = __fmul_rn(band[5][bd], invN); des[bd * 8 + 3] = t; des[bd * 8 + 7] = sqrtf(__fsub_rn(__fmul_rn(band[7][bd], invN), __fmul_rn(t, t)));
+    }
+    __syncthreads();
+    // normalise means / stds separately, clip at 0.4, renormalise: sequential sums (every lane redundantly)
+    float tempM = 0, tempS = 0;
+    for (int bd = 0; bd < NUM_BANDS; ++bd) {
+        const float* d = des + bd * 8;
+        tempM = __fadd_rn(tempM, __fmul_rn(d[0], d[0])); tempM = __fadd_rn(tempM, __fmul_rn(d[1], d[1]));
+        tempM = __fadd_rn(tempM, __fmul_rn(d[2], d[2])); tempM = __fadd_rn(tempM, __fmul_rn(d[3], d[3]));
+        tempS = __fadd_rn(tempS, __fmul_rn(d[4], d[4])); tempS = __fadd_rn(tempS, __fmul_rn(d[5], d[5]));
+        tempS = __fadd_rn(tempS, __fmul_rn(d[6], d[6])); tempS = __fadd_rn(tempS, __fmul_rn(d[7], d[7]));
+    }
+    tempM = __fdiv_rn(1.f, sqrtf(tempM)); tempS = __fdiv_rn(1.f, sqrtf(tempS));
+    __syncthreads();
+    for (int i = lane; i < 72; i += 64) {
+        float v = des[i];
+        v = ((i & 7) < 4) ? __fmul_rn(v, tempM) : __fmul_rn(v, tempS);
+        if (v > 0.4f) v = 0.4f;
+        des[i] = v;
+    }
+    __syncthreads();
+    float temp = 0;
+    for (int i = 0; i < 72; ++i) temp = __fadd_rn(temp, __fmul_rn(des[i], des[i]));
+    temp = __fdiv_rn(1.f, sqrtf(temp));
+    __syncthreads();
+    for (int i = lane; i < 72; i += 64) des[i] = __fmul_rn(des[i], temp);
+    __syncthreads();
+#ifdef SSLAM_LBD_DEBUG
+    for (int i = lane; i < 72; i += 64) ((float*)(const_cast<uint8_t*>(base) + P.offCand))[li * 72 + i] = des[i];      // normalised 72-float vector (candidate buffer is free here)
+#endif
+    if (lane < 32) {
+        const float* f1 = des + 8 * kComb[lane * 2];
+        const float* f2 = des + 8 * kComb[lane * 2 + 1];
+        unsigned r = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (f1[i] > f2[i]) r += 1u << i;
+        descOut[((size_t)b * cap + li) * 32 + lane] = (uint8_t)r;
+    }
+}

@@ -1,0 +1,286 @@
+// LSD front: 7x7 pre-blur (register sliding window), exact 0.8x resample + gradient / level-line angle, stable counting sort of the seeds.
+// Part of lines.hip (included there, inside its anonymous namespace: one translation unit, so device helpers are shared
+// without relocatable device code).  Not a standalone header.
+#pragma once
+
+// ------------------------------------------------------------------ separable blur (q8 taps, D6)
+// Stencil kernels here are register sliding windows: one thread owns four adjacent columns of a strip of STRIP rows, reads
+// each source row once as three aligned dwords (columns x-4 .. x+7), keeps the horizontally filtered rows it still needs
+// in registers and emits one packed store per output row.  No LDS, no barriers, and the unrolled row loop keeps many
+// loads in flight (these kernels are latency-bound, not byte-bound).
+constexpr int STRIP = 32;
+
+// source columns x4-4 .. x4+7 of row yy as three dwords (BORDER_REFLECT_101 in x for the threads that touch the border)
+__device__ __forceinline__ void load_row12(const uint8_t* __restrict__ s, size_t spitch, int yy, int x4, int w, bool fast, unsigned& d0, unsigned& d1, unsigned& d2) {
+    const uint8_t* row = s + (size_t)yy * spitch;
+    if (fast) {
+        const unsigned* q = (const unsigned*)(row + x4 - 4);
+        d0 = q[0]; d1 = q[1]; d2 = q[2];
+    } else {
+        unsigned px[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            int xx = reflect101(min(x4 - 4 + i, w + 2), w);
+            xx = min(max(xx, 0), w - 1);
+            px[i] = row[xx];
+        }
+        d0 = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        d1 = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+        d2 = px[8] | (px[9] << 8) | (px[10] << 16) | (px[11] << 24);
+    }
+}
+// sum over k of tap[k] * byte[s + k] of the 12 bytes d0:d1:d2, taps packed four to a dword (v_dot4_u32_u8); s = 1 .. 6,
+// the taps beyond the kernel length are 0 so the bytes they meet do not matter
+__device__ __forceinline__ unsigned hdot(unsigned d0, unsigned d1, unsigned d2, int s, unsigned T0, unsigned T1) {
+    const unsigned lo = s < 4 ? __builtin_amdgcn_alignbyte(d1, d0, (unsigned)s) : __builtin_amdgcn_alignbyte(d2, d1, (unsigned)(s - 4));
+    const unsigned hi = s < 4 ? __builtin_amdgcn_alignbyte(d2, d1, (unsigned)s) : (d2 >> (8 * (s - 4)));
+    return __builtin_amdgcn_udot4(lo, T0, __builtin_amdgcn_udot4(hi, T1, 0u, false), false);
+}
+__device__ __forceinline__ int reflect_row(int y, int h, int R) {
+    const int yy = reflect101(min(y, h + R - 1), h);
+    return min(max(yy, 0), h - 1);
+}
+
+// 7x7 Gaussian (LSD's sigma = 0.6/0.8 pre-blur), 16.16 accumulation as in D6
+__global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, size_t spitch, size_t sframe,
+                                               uint8_t* __restrict__ dst, size_t dpitch, size_t dframe, int w, int h,
+                                               const int* __restrict__ tapsArr) {
+    constexpr int R = 3;
+    const int ngroups = (w + 3) >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int strip = t / ngroups, x4 = (t - strip * ngroups) * 4, y0 = strip * STRIP;
+    if (y0 >= h) return;
+    const int b = blockIdx.y;
+    const uint8_t* s = src + (size_t)b * sframe;
+    uint8_t* d = dst + (size_t)b * dframe;
+    unsigned taps[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) taps[k] = (unsigned)tapsArr[k];
+    const unsigned T0 = taps[0] | (taps[1] << 8) | (taps[2] << 16) | (taps[3] << 24), T1 = taps[4] | (taps[5] << 8) | (taps[6] << 16);   // q8 taps < 256
+    const bool fast = x4 >= 4 && x4 + 8 <= w && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
+    unsigned win[7][4];
+#pragma unroll
+    for (int r = 0; r < STRIP + 2 * R; ++r) {
+        if (r >= 2 * R && y0 + r - 2 * R >= h) break;
+        unsigned d0, d1, d2;
+        load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, d0, d1, d2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) win[r % 7][j] = hdot(d0, d1, d2, j + 1, T0, T1);      // columns x4+j-3 .. x4+j+3
+        if (r >= 2 * R) {
+            const int y = y0 + r - 2 * R;
+            unsigned o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned acc = 0;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) acc += win[(r - 2 * R + k) % 7][j] * taps[k];
+                o[j] = (acc + 32768u) >> 16;
+            }
+            uint8_t* dp = d + (size_t)y * dpitch + x4;
+            if (x4 + 3 < w) *(unsigned*)dp = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);      // dpitch % 64 == 0, x4 % 4 == 0
+            else { dp[0] = (uint8_t)o[0]; if (x4 + 1 < w) dp[1] = (uint8_t)o[1]; if (x4 + 2 < w) dp[2] = (uint8_t)o[2]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ INTER_LINEAR_EXACT 0.8x (D7), consumed inside k_lsd_grad
+// tx/ty entries: {source offset, coefficient of the second tap (q8)}; source rows are read as three aligned dwords.
+__device__ __forceinline__ unsigned pick2(unsigned d0, unsigned d1, unsigned d2, int o) {      // bytes o, o+1 of d0:d1:d2 (o <= 10)
+    const unsigned long long w01 = (unsigned long long)d0 | ((unsigned long long)d1 << 32);
+    const unsigned long long w12 = (unsigned long long)d1 | ((unsigned long long)d2 << 32);
+    return (unsigned)((o < 4 ? w01 : w12) >> (8 * (o < 4 ? o : o - 4)));
+}
+// ------------------------------------------------------------------ gradient / level-line angle (ll_angle)
+// The 2x2 gradient of an 8-bit image takes only 1021 x 1021 values, so angle (exact fastAtan2), the defined test
+// (|g|/2 > rho) and the D5 cos/sin of the angle are tabulated once per process; the per-frame kernel is then a gather.
+constexpr int GT = 1021;          // gx, gy in [-510, 510]
+__global__ void k_grad_table(float4* __restrict__ tab, double rho) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= GT * GT) return;
+    const int gy = i / GT - 510, gx = i - (i / GT) * GT - 510;
+    const int s = gx * gx + gy * gy;
+    float a = NOTDEF_F, cs = 0.f, sn = 0.f;
+    if (sqrt((double)s / 4.0) > rho) {
+        a = fast_atan2_deg((float)gx, (float)(-gy));
+        const float af = (float)((double)a * DEG2RAD);
+        cs = (float)cos((double)af); sn = (float)sin((double)af);
+    }
+    tab[i] = make_float4(a, cs, sn, __int_as_float(s));
+}
+
+// One thread = four horizontally adjacent pixels: the 2x5 source bytes come from two dword + two byte loads, the four
+// table gathers are in flight together, and angle / key / record leave as 16-byte stores when the row length allows.
+// S[i] = |g|^2 for DEFINED pixels and -1 otherwise, so the counting sort reads one array.
+// The 0.8x INTER_LINEAR_EXACT image (D7) is never stored: this kernel is bound by its 24 B/pixel of writes, so the 2 x 5
+// scaled pixels a thread needs are recomputed here from the blurred source (four source rows as three aligned dwords each).
+__device__ __forceinline__ int scaled_px(unsigned e0, unsigned e1, unsigned cx, unsigned cy) {      // e = {p0, p1} bytes of the two source rows
+    const unsigned r0 = (e0 & 255u) * (256u - cx) + ((e0 >> 8) & 255u) * cx, r1 = (e1 & 255u) * (256u - cx) + ((e1 >> 8) & 255u) * cx;
+    return (int)((r0 * (256u - cy) + r1 * cy + 32768u) >> 16);
+}
+__global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws, LsdPlan P, const float4* __restrict__ gtab, size_t bpitch,
+                                                  const int* __restrict__ tx, const int* __restrict__ ty) {
+    const int b = blockIdx.z;
+    const uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const uint8_t* src = base + P.offBlur;
+    float* ang = (float*)(base + P.offAng);
+    int* S = (int*)(base + P.offS);
+    float4* pix = (float4*)(base + P.offPix);
+    Misc* misc = (Misc*)(base + P.offMisc);
+    const int y = blockIdx.y * 4 + threadIdx.y, x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    int smax = 0;
+    if (y < P.sh && x4 < P.sw) {
+        const bool lastRow = y >= P.sh - 1;
+        const int2 ty0 = ((const int2*)ty)[y], ty1 = ((const int2*)ty)[min(y + 1, P.sh - 1)];
+        int2 txv[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) txv[j] = ((const int2*)tx)[min(x4 + j, P.sw - 1)];
+        const uint8_t* rw[4] = {src + (size_t)ty0.x * bpitch, src + (size_t)min(ty0.x + 1, P.h - 1) * bpitch,
+                                src + (size_t)ty1.x * bpitch, src + (size_t)min(ty1.x + 1, P.h - 1) * bpitch};
+        int p0[5], p1[5];
+        const int a = txv[0].x & ~3;
+        if (txv[4].x - a <= 10) {                       // bpitch % 64 == 0 and another buffer follows the last row: whole dwords are readable
+            unsigned d[4][3];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const unsigned* q = (const unsigned*)(rw[r] + a); d[r][0] = q[0]; d[r][1] = q[1]; d[r][2] = q[2]; }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int o = txv[j].x - a;                                    // second tap has weight 0 at the last column
+                p0[j] = scaled_px(pick2(d[0][0], d[0][1], d[0][2], o), pick2(d[1][0], d[1][1], d[1][2], o), (unsigned)txv[j].y, (unsigned)ty0.y);
+                p1[j] = scaled_px(pick2(d[2][0], d[2][1], d[2][2], o), pick2(d[3][0], d[3][1], d[3][2], o), (unsigned)txv[j].y, (unsigned)ty1.y);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int sx = txv[j].x, sx1 = min(sx + 1, P.w - 1);
+                p0[j] = scaled_px(rw[0][sx] | ((unsigned)rw[0][sx1] << 8), rw[1][sx] | ((unsigned)rw[1][sx1] << 8), (unsigned)txv[j].y, (unsigned)ty0.y);
+                p1[j] = scaled_px(rw[2][sx] | ((unsigned)rw[2][sx1] << 8), rw[3][sx] | ((unsigned)rw[3][sx1] << 8), (unsigned)txv[j].y, (unsigned)ty1.y);
+            }
+        }
+        float4 rec[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int DA = p1[j + 1] - p0[j], BC = p0[j + 1] - p1[j];
+            const int gx = DA + BC, gy = DA - BC;
+            const bool in = !lastRow && x4 + j < P.sw - 1;
+            rec[j] = in ? gtab[(gy + 510) * GT + (gx + 510)] : make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
+        }
+        int sv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool def = rec[j].x != NOTDEF_F;
+            sv[j] = def ? __float_as_int(rec[j].w) : -1;
+            smax = max(smax, sv[j]);
+        }
+        const size_t i = (size_t)y * P.sw + x4;
+        if ((P.sw & 3) == 0) {
+            *(float4*)(ang + i) = make_float4(rec[0].x, rec[1].x, rec[2].x, rec[3].x);
+            *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) { ang[i + j] = rec[j].x; S[i + j] = sv[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) pix[i + j] = rec[j];      // per-pixel record for region growing: angle, cosf/sinf (D5), |g|^2
+    }
+    smax = wave_max(smax);
+    if (threadIdx.x == 0 && smax > 0) atomicMax(&misc->maxS, smax);
+}
+
+__device__ __forceinline__ int lsd_bin(int s, double binCoef) {
+    int i = (int)(sqrt((double)s / 4.0) * binCoef);
+    return min(max(i, 0), N_BINS - 1);
+}
+__device__ __forceinline__ double lsd_bin_coef(int maxS) {
+    return maxS > 0 ? (double)(N_BINS - 1) / sqrt((double)maxS / 4.0) : 0.0;
+}
+
+// stable counting sort of the DEFINED pixels by descending bin, raster order inside a bin (D2):
+// per-tile histograms -> scan -> stable scatter.
+__global__ __launch_bounds__(64) void k_lsd_hist(uint8_t* __restrict__ ws, LsdPlan P) {
+    __shared__ int hist[N_BINS];
+    const int tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const int* S = (const int*)(base + P.offS);
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    int* th = (int*)(base + P.offTileHist) + (size_t)tile * N_BINS;
+    for (int i = lane; i < N_BINS; i += 64) hist[i] = 0;
+    __syncthreads();
+    const double bc = lsd_bin_coef(misc->maxS);
+    const int beg = tile * TILE_PX, end = min(beg + TILE_PX, P.npx);
+    for (int i0 = beg; i0 < end; i0 += 512) {            // eight coalesced loads in flight per lane (order is irrelevant here)
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = i0 + k * 64 + lane; v[k] = i < end ? S[i] : -1; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (v[k] >= 0) atomicAdd(&hist[lsd_bin(v[k], bc)], 1);
+    }
+    __syncthreads();
+    for (int i = lane; i < N_BINS; i += 64) th[i] = hist[i];
+}
+
+__global__ __launch_bounds__(1024) void k_lsd_scan(uint8_t* __restrict__ ws, LsdPlan P) {
+    __shared__ int part[1024];
+    const int b = blockIdx.x, t = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    int* th = (int*)(base + P.offTileHist);
+    Misc* misc = (Misc*)(base + P.offMisc);
+    const int bin = N_BINS - 1 - t;           // thread t owns the t-th bin in descending order
+    int tot = 0;
+    for (int k = 0; k < P.nTiles; ++k) tot += th[(size_t)k * N_BINS + bin];
+    part[t] = tot;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {      // inclusive Hillis-Steele scan
+        int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int basePos = part[t] - tot;
+    for (int k = 0; k < P.nTiles; ++k) {
+        int c = th[(size_t)k * N_BINS + bin];
+        th[(size_t)k * N_BINS + bin] = basePos;
+        basePos += c;
+    }
+    if (t == 1023) misc->nDefined = part[1023];
+}
+
+// One wave per tile walks its pixels in raster order, 64 at a time (four such groups are loaded ahead).  Inside a group
+// the rank of a pixel among the lanes of the same bin comes from ballots; the wave's LDS accesses execute in program order,
+// so the cursor read / write-back needs no barrier.
+__global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, LsdPlan P) {
+    __shared__ int cursor[N_BINS];
+    const int tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const int* S = (const int*)(base + P.offS);
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int* th = (const int*)(base + P.offTileHist) + (size_t)tile * N_BINS;
+    unsigned* order = (unsigned*)(base + P.offOrder);
+    for (int i = lane; i < N_BINS; i += 64) cursor[i] = th[i];
+    __syncthreads();
+    const double bc = lsd_bin_coef(misc->maxS);
+    const int beg = tile * TILE_PX, end = min(beg + TILE_PX, P.npx);
+    for (int i0 = beg; i0 < end; i0 += 256) {
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = i0 + k * 64 + lane; v[k] = i < end ? S[i] : -1; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool def = v[k] >= 0;
+            const int bin = def ? lsd_bin(v[k], bc) : -1;
+            unsigned long long todo = __ballot(def);
+            int rank = 0, total = 0;
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int bsel = __builtin_amdgcn_readlane(bin, leader);
+                const unsigned long long m = __ballot(bin == bsel);
+                if (bin == bsel) { rank = mbcnt(m); total = __popcll(m); }
+                todo &= ~m;
+            }
+            if (def) {
+                const int pos = cursor[bin] + rank;
+                order[pos] = (unsigned)(i0 + k * 64 + lane);
+                if (rank == total - 1) cursor[bin] = pos + 1;
+            }
+        }
+    }
+}

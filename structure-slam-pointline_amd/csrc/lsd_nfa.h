@@ -1,0 +1,676 @@
+// LSD rectangle validation (rect_improve / rect_nfa / nfa): host-evaluated tables, exact division, guarded early-exit test,
+// aligned-point counting, lane-dynamic NFA evaluation, in-order acceptance; self-test and calibration kernels.
+// Part of lines.hip (included there, inside its anonymous namespace: one translation unit, so device helpers are shared
+// without relocatable device code).  Not a standalone header.
+#pragma once
+
+// Tables of nfa(): lgam[j] = log_gamma(j) for integer j >= 1 (every argument nfa() uses is an integer + 1), then
+// plog[h] = {log(p), log(1-p), log10(p)} for p = 0.125 * 2^-h (every precision rect_improve can reach), then 1/j for
+// exact_div().  They are evaluated on the HOST with the same libm calls, in the same order, as the reference's
+// log_gamma_windschitl / log_gamma_lanczos (opencv lsd.cpp): when the binomial tail is ~1 the NFA is -logNT + O(1e-15),
+// and rect_improve's strict `v > log_nfa` comparisons between such values depend on the last bit of every term.
+static double host_log_gamma(double x) {
+    if (x > 15) return 0.918938533204673 + (x - 0.5) * std::log(x) - x + 0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0)));
+    static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+    double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5), bq = 0;
+    for (int n = 0; n < 7; ++n) { a -= std::log(x + (double)n); bq += q[n] * std::pow(x, (double)n); }
+    return a + std::log(bq);
+}
+static int upload_nfa_tables(double* d_tab, int n, hipStream_t st) {
+    std::vector<double> t(2 * (size_t)n + 48);
+    for (int j = 0; j < n; ++j) t[j] = j >= 1 ? host_log_gamma((double)j) : 0.0;
+    for (int j = 0; j < 16; ++j) { const double pp = std::ldexp(0.125, -j); t[n + 3 * j] = std::log(pp); t[n + 3 * j + 1] = std::log(1.0 - pp); t[n + 3 * j + 2] = std::log10(pp); }
+    for (int j = 0; j < n; ++j) t[(size_t)n + 48 + j] = j >= 1 ? 1.0 / (double)j : 0.0;          // correctly rounded reciprocals for exact_div()
+    SSLAM_HIP(hipMemcpyAsync(d_tab, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    return SSLAM_OK;
+}
+
+// a / b for small positive integers, bit-identical to the IEEE quotient: with y = RN(1/b) from the table, q0 = RN(a*y),
+// the FMA residual r = a - b*q0 is exact and q0 + r*y rounds to RN(a/b) (Markstein's division theorem; checked against the
+// hardware division by sslam_selftest_exact_div).
+__device__ __forceinline__ double exact_div(double a, double b, double y) {
+    const double q0 = a * y;
+    const double r = fma(-b, q0, a);
+    return fma(r, y, q0);
+}
+__global__ void k_selftest_div(const double* __restrict__ rcp, int n, unsigned long long seed, int iters, unsigned long long* __restrict__ bad) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned long long nb = 0;
+    for (int it = 0; it < iters; ++it) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const int b = 1 + (int)((x >> 8) % (unsigned long long)(n - 1));
+        const int a = 1 + (int)((x >> 36) % (unsigned long long)(n - 1));
+        const double q = exact_div((double)a, (double)b, rcp[b]), ref = (double)a / (double)b;
+        nb += (__double_as_longlong(q) != __double_as_longlong(ref)) ? 1 : 0;
+    }
+    if (nb) atomicAdd(bad, nb);
+}
+// plog[h] = {log(p), log(1-p), log10(p)} for p = 0.125 * 2^-h: every precision rect_improve can reach
+struct PLog { double lp, l1mp, l10p; };
+
+// nfa()'s early-exit test `err < tolerance * |-log10(bin_tail) - logNT| * bin_tail` with
+// err = term * ((1 - m^q) / (1 - m) - 1), decided from fp32 log2/exp2 estimates inside rigorous guard bands:
+// returns 1 (test holds) / 0 (test fails) when the estimate cannot disagree with the fp64 expression, -1 when it might.
+// Here 0 < m < 1/7 (bin_term < 1 and p <= 1/8), so B = m + m^2 + .. + m^(q-1) lies in [m, 1.17 m] for q >= 2 and is exactly 0
+// for q == 1 (fl((1-m)/(1-m)) - 1).  v_log_f32 / v_exp_f32 are 1-ulp: the estimate of m^q is within 1e-5 relative for
+// |q log2 m| <= 60 (and m^q < 1e-18 otherwise), the fp64 evaluation of B is within 6e-16 absolute, log10(bin_tail) from the
+// split exponent + fp32 mantissa log is within 1e-7 absolute; the bands below are several times wider than that.
+__device__ __forceinline__ int tail_test_cheap(double term, double m, int q, double bin_tail, double logNT) {
+    if (!(m > 0.0 && m < 0.15)) return -1;
+    double B = 0.0;
+    if (q >= 2) {
+        double mq = 0.0;
+        if (m > 1e-30) {
+            const float x = (float)q * __builtin_amdgcn_logf((float)m);
+            if (x > -60.f) mq = (double)__builtin_amdgcn_exp2f(x);
+        }
+        B = (1.0 - mq) / (1.0 - m) - 1.0;
+    }
+    const double errHi = term * (B * (1.0 + 1e-5) + 4e-15), errLo = term * (B * (1.0 - 1e-5) - 4e-15);
+    int e;
+    const double f = frexp(bin_tail, &e);                                 // bin_tail = f * 2^e, f in [0.5, 1)
+    const double l10 = ((double)e + (double)__builtin_amdgcn_logf((float)f)) * 0.30102999566398120;
+    const double A = fabs(-l10 - logNT);
+    const double rhsHi = 0.1 * (A + 2e-6) * bin_tail * (1.0 + 1e-14), rhsLo = 0.1 * fmax(A - 2e-6, 0.0) * bin_tail * (1.0 - 1e-14);
+    if (errHi < rhsLo) return 1;
+    if (errLo >= rhsHi) return 0;
+    return -1;
+}
+
+// Self-test of tail_test_cheap (sslam_selftest_tail_test): random (term, m, q, bin_tail), half of them steered onto the
+// decision boundary err ~ rhs, counted as disagreeing when the cheap verdict differs from the fp64 expression.
+__global__ void k_selftest_tail(unsigned long long seed, int iters, double logNT, unsigned long long* __restrict__ out) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    unsigned long long bad = 0, amb = 0;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (double)(x >> 11) * 0x1p-53; };
+    for (int it = 0; it < iters; ++it) {
+        const double m = exp2(-(2.81 + rnd() * rnd() * 38.0));
+        const double u = rnd();
+        const int q = 1 + (int)(u * u * u * 200000.0);
+        const double term = exp2(-rnd() * 1000.0);
+        double bin_tail = term * (1.0 + exp2(rnd() * 30.0 - 10.0));
+        if (it & 1) {       // onto the boundary: err = 0.1 * A * bin_tail, +- up to 1e-3 relative
+            const double err = term * ((1 - pow(m, (double)q)) / (1 - m) - 1);
+            if (err > 0) {
+                const double bt0 = err / (0.1 * 13.0), A0 = fabs(-log10(bt0) - logNT);
+                if (A0 > 0) bin_tail = err / (0.1 * A0) * (1.0 + (rnd() - 0.5) * 2e-3 * rnd());
+            }
+        }
+        const int dec = tail_test_cheap(term, m, q, bin_tail, logNT);
+        const double err = term * ((1 - pow(m, (double)q)) / (1 - m) - 1);
+        const bool ref = err < 0.1 * fabs(-log10(bin_tail) - logNT) * bin_tail;
+        if (dec < 0) ++amb; else if ((dec > 0) != ref) ++bad;
+    }
+    if (bad) atomicAdd(out, bad);
+    if (amb) atomicAdd(out + 1, amb);
+}
+
+// FETCH_SIZE calibration probes (tools/fetch_probe.py under rocprofv3 --pmc FETCH_SIZE): a known number of bytes read
+// in the two access patterns this library uses most, 16 B/lane coalesced streams and scattered 16-B gathers.
+__global__ void k_probe_stream16(const float4* __restrict__ buf, size_t nElem, float* __restrict__ sink) {
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nElem; i += (size_t)gridDim.x * blockDim.x) acc += buf[i].x;
+    if (acc == 12345.678f) *sink = acc;
+}
+__global__ void k_probe_gather16(const float4* __restrict__ buf, size_t nElem, int iters, float* __restrict__ sink) {
+    unsigned long long x = 0x9E3779B97F4A7C15ull * (1 + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x);
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        acc += buf[(size_t)(x >> 8) % nElem].x;
+    }
+    if (acc == 12345.678f) *sink = acc;
+}
+// LineSegmentDetectorImpl::nfa() split for lane-dynamic scheduling: nfa_setup() covers everything before the binomial-tail
+// loop, tail_block() advances the loop by up to eight terms, and the caller finishes with -log10(bin_tail) - logNT.
+struct TailState { double term, bin_tail, p_term; int n, i; };           // i = next term index (k+1 .. n)
+
+// returns true when the tail loop has to run; otherwise v is the function value
+__device__ __forceinline__ bool nfa_setup(int n, int k, double p, double logNT, const double* __restrict__ lgam, const PLog* __restrict__ plog, TailState& S, double& v) {
+    if (n == 0 || k == 0) { v = -logNT; return false; }
+    const int h = 1020 - ((__double2hiint(p) >> 20) & 0x7FF);        // p is an exact power of two
+    const bool tab = h >= 0 && h < 16 && p == ldexp(0.125, -h);
+    if (n == k) { v = -logNT - (double)n * (tab ? plog[h].l10p : log10(p)); return false; }
+    const double p_term = p / (1 - p);
+    const double log1term = lgam[n + 1] - lgam[k + 1] - lgam[n - k + 1] + (double)k * (tab ? plog[h].lp : log(p)) + (double)(n - k) * (tab ? plog[h].l1mp : log(1.0 - p));
+    const double term = exp(log1term);
+    if (term == 0.0) {      // double_equal(term, 0) holds only for an exact zero
+        v = ((double)k > (double)n * p) ? -log1term / 2.30258509299404568402 - logNT : -logNT;
+        return false;
+    }
+    S.term = term; S.bin_tail = term; S.p_term = p_term; S.n = n; S.i = k + 1;
+    return true;
+}
+
+// up to eight terms of the tail loop; true when the loop is over (early exit or i > n)
+__device__ __forceinline__ bool tail_block(TailState& S, double logNT, const double* __restrict__ rcp) {
+    const double tolerance = 0.1;
+    const int n = S.n, i0 = S.i;
+    double term = S.term, bin_tail = S.bin_tail;
+    double mt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {           // independent divisions: issue back to back
+        const int i = min(i0 + j, n);
+        mt[j] = exact_div((double)(n - i + 1), (double)i, rcp[i]) * S.p_term;
+    }
+    bool done = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j;
+        if (i <= n && !done) {
+            term *= mt[j];
+            bin_tail += term;
+            // exact shortcut: past the mode (ratio < 1, and the ratio only shrinks with i) every later term is smaller than
+            // this one; once a term is below half an ulp of the sum, no later addition can change bin_tail, and bin_tail is
+            // all the function returns from here on.
+            if (mt[j] < 1.0 && term < bin_tail * 0x1p-54) done = true;
+            if (!done && n - i + 1 < i) {             // bin_term < 1
+                const int dec = tail_test_cheap(term, mt[j], n - i + 1, bin_tail, logNT);
+                if (dec > 0) done = true;
+                else if (dec < 0) {                    // the guard bands overlap (rare): evaluate the reference's expression itself
+                    const double err = term * ((1 - pow(mt[j], (double)(n - i + 1))) / (1 - mt[j]) - 1);
+                    if (err < tolerance * fabs(-log10(bin_tail) - logNT) * bin_tail) done = true;
+                }
+            }
+        }
+    }
+    S.term = term; S.bin_tail = bin_tail; S.i = i0 + 8;
+    return done || S.i > n;
+}
+
+enum { NFA_MAXROWS = 64 };
+struct NfaGeom { int mx, y0, y1, ly, ry, fl, sl, fr, sr; };
+
+__device__ __forceinline__ int sel4(int i, int a, int b, int c, int d) { return i == 0 ? a : i == 1 ? b : i == 2 ? c : d; }
+
+// rect_nfa's corner bookkeeping (upstream's integer edge stepping and p.y-vs-p.x comparisons
+// included), in registers only.
+__device__ NfaGeom nfa_geom(const RectD& rec, int sh) {
+    const double half_width = rec.width / 2.0;
+    const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
+    long long k0 = ((long long)((int)(rec.x1 - dyhw) + (1 << 30)) << 32) | (unsigned)((int)(rec.y1 + dxhw) + (1 << 30));
+    long long k1 = ((long long)((int)(rec.x2 - dyhw) + (1 << 30)) << 32) | (unsigned)((int)(rec.y2 + dxhw) + (1 << 30));
+    long long k2 = ((long long)((int)(rec.x2 + dyhw) + (1 << 30)) << 32) | (unsigned)((int)(rec.y2 - dxhw) + (1 << 30));
+    long long k3 = ((long long)((int)(rec.x1 + dyhw) + (1 << 30)) << 32) | (unsigned)((int)(rec.y1 - dxhw) + (1 << 30));
+#define CSWAP(a, b) { long long lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; }
+    CSWAP(k0, k1) CSWAP(k2, k3) CSWAP(k0, k2) CSWAP(k1, k3) CSWAP(k1, k2)      // ascending by (x, y)
+#undef CSWAP
+    const int x0 = (int)(k0 >> 32) - (1 << 30), x1 = (int)(k1 >> 32) - (1 << 30), x2 = (int)(k2 >> 32) - (1 << 30), x3 = (int)(k3 >> 32) - (1 << 30);
+    const int y0 = (int)(unsigned)k0 - (1 << 30), y1 = (int)(unsigned)k1 - (1 << 30), y2 = (int)(unsigned)k2 - (1 << 30), y3 = (int)(unsigned)k3 - (1 << 30);
+    int imin = 0, imax = 0;
+    if (sel4(imin, y0, y1, y2, y3) > y1) imin = 1;
+    if (sel4(imax, y0, y1, y2, y3) < y1) imax = 1;
+    if (sel4(imin, y0, y1, y2, y3) > y2) imin = 2;
+    if (sel4(imax, y0, y1, y2, y3) < y2) imax = 2;
+    if (sel4(imin, y0, y1, y2, y3) > y3) imin = 3;
+    if (sel4(imax, y0, y1, y2, y3) < y3) imax = 3;
+    // leftmost = first untaken with the smallest x (strict compare keeps the earliest)
+    int il = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i != imin) { if (il < 0) il = i; else if (sel4(il, x0, x1, x2, x3) > sel4(i, x0, x1, x2, x3)) il = i; }
+    int ir = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i != imin && i != il) { if (ir < 0) ir = i; else if (sel4(ir, x0, x1, x2, x3) < sel4(i, x0, x1, x2, x3)) ir = i; }
+    int it = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i != imin && i != il && i != ir) it = i;
+    NfaGeom g;
+    const int mx = sel4(imin, x0, x1, x2, x3), my = sel4(imin, y0, y1, y2, y3);
+    const int lx = sel4(il, x0, x1, x2, x3), ly = sel4(il, y0, y1, y2, y3);
+    const int rx = sel4(ir, x0, x1, x2, x3), ry = sel4(ir, y0, y1, y2, y3);
+    const int tx = sel4(it, x0, x1, x2, x3);
+    g.mx = mx; g.ly = ly; g.ry = ry;
+    g.fl = (my != ly) ? (mx - lx) / (my - ly) : 0;
+    g.sl = (ly != tx) ? (lx - tx) / (ly - tx) : 0;
+    g.fr = (my != ry) ? (mx - rx) / (my - ry) : 0;
+    g.sr = (ry != tx) ? (rx - tx) / (ry - tx) : 0;
+    // rows outside the image are skipped WITHOUT stepping the edges (upstream `continue`)
+    g.y0 = max(my, 0); g.y1 = min(sel4(imax, y0, y1, y2, y3), sh - 1);
+    return g;
+}
+
+// x-range of row y (clipped to the image); a row has seen (y - y0) edge steps, the step taken after
+// row t uses the second slope iff t >= ly (resp. ry).
+template <bool SMALL>
+__device__ __forceinline__ void nfa_row_edges(const NfaGeom& g, int y, long long& lft, long long& rgt) {
+    const int steps = y - g.y0;
+    int nl2 = 0, nr2 = 0;
+    if (steps > 0) {
+        nl2 = max(0, y - max(g.ly, g.y0));
+        nr2 = max(0, y - max(g.ry, g.y0));
+    }
+    if (SMALL) {      // images below 32768 x 32768: |slope| < 2^15 and steps < 2^15, every product and sum fits 32 bits
+        lft = g.mx + (steps - nl2) * g.fl + nl2 * g.sl;
+        rgt = g.mx + (steps - nr2) * g.fr + nr2 * g.sr;
+    } else {
+        lft = (long long)g.mx + (long long)(steps - nl2) * g.fl + (long long)nl2 * g.sl;
+        rgt = (long long)g.mx + (long long)(steps - nr2) * g.fr + (long long)nr2 * g.sr;
+    }
+}
+template <bool SMALL>
+__device__ __forceinline__ void nfa_row_range(const NfaGeom& g, int y, int sw, int& xa, int& xb) {
+    long long lft, rgt;
+    nfa_row_edges<SMALL>(g, y, lft, rgt);
+    xa = (int)max(lft, 0LL); xb = (int)min(rgt, (long long)sw - 1);
+}
+// upper bound of the (unclipped) row width of a rectangle: the edges are linear in y between the corner rows, so the
+// maximum sits at one of them.  Only used to pick how many lanes share a row.
+__device__ int nfa_max_width(const NfaGeom& g) {
+    int best = 1;
+    const int ys[8] = {g.y0, g.y1, g.ly - 1, g.ly, g.ly + 1, g.ry - 1, g.ry, g.ry + 1};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int y = min(max(ys[i], g.y0), g.y1);
+        long long lft, rgt;
+        nfa_row_edges<false>(g, y, lft, rgt);
+        best = max(best, (int)min(rgt - lft + 1, 1LL << 20));
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------ rect_improve as staged, fully parallel kernels
+// rect_improve (LSD_REFINE_ADV) evaluates the rectangle, then five refinement stages of up to five candidate rectangles
+// each; inside a stage the candidates do not depend on which of them is accepted.  Per stage two launches cover every
+// candidate of every frame: k_nfa_count (one wave per rectangle: aligned-point counts of the stage's candidates) and
+// k_nfa_eval (the binomial-tail NFAs of all candidates, lanes scheduled dynamically) + k_nfa_accept (the reference's sequential acceptance).
+struct NfaState { double logNfa; int done, nc; int cnt[6][2]; double val[6]; };      // per rectangle; cnt[k] = {total, aligned}, val[j] = NFA of candidate j
+
+// candidate j of stage `stage` (0..4) grown from the stage's starting rectangle exactly like rect_improve's loops;
+// false when iteration j is skipped (width floor) — then every later iteration is skipped too.
+__device__ bool stage_cand(const RectD& rec, int stage, int j, RectD& r) {
+    const double delta = 0.5, delta_2 = delta / 2.0;
+    r = rec;
+    for (int n = 0; n <= j; ++n) {
+        if (stage == 0 || stage == 4) {
+            if (stage == 4 && !((r.width - delta) >= 0.5)) return false;
+            r.p /= 2; r.prec = r.p * kPI;
+        } else {
+            if (!((r.width - delta) >= 0.5)) return false;
+            if (stage == 2) { r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; }
+            if (stage == 3) { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
+            r.width -= delta;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ void load_rect(const double* o, RectD& rec) {
+    rec.x1 = o[0]; rec.y1 = o[1]; rec.x2 = o[2]; rec.y2 = o[3]; rec.width = o[4]; rec.x = o[5]; rec.y = o[6];
+    rec.theta = o[7]; rec.dx = o[8]; rec.dy = o[9]; rec.prec = o[10]; rec.p = o[11];
+}
+__device__ __forceinline__ void store_rect(double* o, const RectD& rec) {
+    o[0] = rec.x1; o[1] = rec.y1; o[2] = rec.x2; o[3] = rec.y2; o[4] = rec.width; o[5] = rec.x; o[6] = rec.y;
+    o[7] = rec.theta; o[8] = rec.dx; o[9] = rec.dy; o[10] = rec.prec; o[11] = rec.p;
+}
+
+// angular distance used by isAligned (NOTDEF -> +inf)
+__device__ __forceinline__ double align_dist(float aDeg, double theta) {
+    const double n_theta = fabs(theta - (double)aDeg * DEG2RAD);          // fabs == the reference's conditional negations
+    const double wrapped = fabs(n_theta - M_2PI_);
+    return aDeg == NOTDEF_F ? 1e300 : (n_theta > M_3_2_PI_ ? wrapped : n_theta);
+}
+
+// k_nfa_count: one wave walks a frame's rectangles.  The corner bookkeeping of rect_nfa (nfa_geom: sorting, slopes, integer
+// divisions) is the same few hundred instructions whether one lane or sixty-four execute it, so it runs lane-parallel for a
+// batch of up to 64 (rectangle, candidate) items whose results are parked in LDS; the wave then counts the items one after
+// the other with all lanes on the pixels.  Counters are wave-uniform (ballot + popcount), so nothing is reduced at the end.
+constexpr int EVAL_CH = 1024;          // rectangles per item-list chunk (k_nfa_count, k_nfa_eval)
+constexpr int EVAL_REFILL = 16;
+struct CntItem { NfaGeom g; int c, j, lg; double theta, prec, p; };      // lg: log2 of the lanes sharing a row
+
+// Pixel walk shared by the two counters below.  A row is shared by 2^lg lanes (lg picked per rectangle from its widest
+// row: tall thin rectangles put 32 rows in flight, flat ones spread one row over the whole wave); each lane owns a
+// contiguous run of the row and the wave steps through the runs twelve pixels at a time.  Every step starts with
+// ballot(pixel exists), which both ends the loop early and counts the rectangle's pixels.
+
+// aligned-point counts of one rectangle for K nested precisions; total = pixels visited
+template <int K, bool SMALL>
+__device__ __forceinline__ void count_item(const NfaGeom& g, int lg, double theta, const double (&prec)[6], const float* __restrict__ ang, int sw,
+                                           int lane, int& totalOut, int (&alg)[6]) {
+    const int nrows = g.y1 - g.y0 + 1;
+    const int rowsPer = 64 >> lg, r = lane >> lg, sub = lane & ((1 << lg) - 1);
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) alg[k] = 0;
+    for (int t0 = 0; t0 < nrows; t0 += rowsPer) {
+        const int t = t0 + r;
+        int xa = 0, xb = -1; const int y = g.y0 + t;
+        if (t < nrows) nfa_row_range<SMALL>(g, y, sw, xa, xb);
+        const int width = max(xb - xa + 1, 0);
+        const int share = (width + (1 << lg) - 1) >> lg;
+        const int xs = xa + sub * share;
+        const int mine = max(min(share, xb - xs + 1), 0);
+        const float* row = ang + (size_t)y * sw + xs;
+        for (int c0 = 0; __ballot(c0 < mine) != 0; c0 += 12) {
+            float a[12];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            if (__ballot(c0 + 4 < mine)) {
+#pragma unroll
+                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            }
+            if (__ballot(c0 + 8 < mine)) {
+#pragma unroll
+                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            }
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const unsigned long long have = __ballot(c0 + q < mine);
+                if (!have) break;
+                total += __popcll(have);
+                const double d = c0 + q < mine ? align_dist(a[q], theta) : 1e300;
+#pragma unroll
+                for (int k = 0; k < K; ++k) alg[k] += __popcll(__ballot(d <= prec[k]));
+            }
+        }
+    }
+    totalOut = total;
+}
+
+// Stages 1-3: the (up to five) candidates of a rectangle differ by half-pixel width / offset steps and share theta and the
+// tolerance, so they are counted in ONE pass over the union of their rows: the angle test runs once per pixel, membership in
+// candidate j is two integer compares against that candidate's own row range (rect_nfa's edge stepping, per candidate).
+template <bool SMALL>
+__device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int nc, int lg, const float* __restrict__ ang, int sw, int lane,
+                                            int (&total)[MAXC], int (&alg)[MAXC]) {
+    const double theta = it5[0].theta, prec = it5[0].prec;
+    NfaGeom g[MAXC];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) g[j] = it5[j < nc ? j : 0].g;
+    int y0u = g[0].y0, y1u = g[0].y1;
+#pragma unroll
+    for (int j = 1; j < MAXC; ++j) if (j < nc) { y0u = min(y0u, g[j].y0); y1u = max(y1u, g[j].y1); }
+    const int nrows = y1u - y0u + 1;
+    const int rowsPer = 64 >> lg, r = lane >> lg, sub = lane & ((1 << lg) - 1);
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) { total[j] = 0; alg[j] = 0; }
+    for (int t0 = 0; t0 < nrows; t0 += rowsPer) {
+        const int t = t0 + r;
+        const int y = y0u + t;
+        int xaj[MAXC], xbj[MAXC];
+        int xa = 0x7fffffff, xb = -1;
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) {
+            xaj[j] = 1; xbj[j] = 0;
+            if (j < nc && t < nrows && y >= g[j].y0 && y <= g[j].y1) {
+                nfa_row_range<SMALL>(g[j], y, sw, xaj[j], xbj[j]);
+                if (xbj[j] >= xaj[j]) { xa = min(xa, xaj[j]); xb = max(xb, xbj[j]); }
+                else { xaj[j] = 1; xbj[j] = 0; }
+            }
+        }
+        const int width = xb >= xa ? xb - xa + 1 : 0;
+        const int share = (width + (1 << lg) - 1) >> lg;
+        const int xs = xa + sub * share;
+        const int mine = width > 0 ? max(min(share, xb - xs + 1), 0) : 0;
+        const float* row = ang + (size_t)y * sw + xs;
+        for (int c0 = 0; __ballot(c0 < mine) != 0; c0 += 12) {
+            float a[12];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            if (__ballot(c0 + 4 < mine)) {
+#pragma unroll
+                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            }
+            if (__ballot(c0 + 8 < mine)) {
+#pragma unroll
+                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            }
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const bool have = c0 + q < mine;
+                if (!__ballot(have)) break;
+                const bool al = have && align_dist(a[q], theta) <= prec;
+                const int x = xs + c0 + q;
+#pragma unroll
+                for (int j = 0; j < MAXC; ++j) {
+                    if (j < nc) {
+                        const bool in = have && x >= xaj[j] && x <= xbj[j];
+                        total[j] += __popcll(__ballot(in));
+                        alg[j] += __popcll(__ballot(in && al));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// stage 0 is merged with the initial evaluation: same rectangle, six precisions (p, p/2 .. p/32); stage 4 likewise has one
+// geometry and five precisions.  Stages 1-3 change the rectangle itself: up to five candidates per rectangle.
+#ifndef SSLAM_COUNT_MINWAVES
+#define SSLAM_COUNT_MINWAVES 4
+#endif
+__global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
+    __shared__ CntItem its[64];
+    __shared__ unsigned short act[EVAL_CH];
+    const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y, lane = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int nCand = misc->nCand;
+    const float* ang = (const float*)(base + P.offAng);
+    const double* rects = (const double*)(base + P.offCand);
+    NfaState* st = (NfaState*)(base + P.offNfa);
+    const int sw = P.sw, sh = P.sh;
+    const int per = (nCand + gridDim.x - 1) / gridDim.x;
+    const int c0 = blockIdx.x * per, c1 = min(c0 + per, nCand);
+    const bool nested = stage == 0 || stage == 4;
+    const bool small = sw < 32768 && sh < 32768;
+    const int rpb = nested ? 64 : 12;                              // rectangles per batch (stages 1-3: five lanes each)
+    for (int chunk = c0; chunk < c1; chunk += EVAL_CH) {
+        const int cend = min(chunk + EVAL_CH, c1);
+        int nAct = 0;
+        for (int cb = chunk; cb < cend; cb += 64) {               // rectangles still being refined
+            const int c = cb + lane;
+            const bool on = c < cend && (stage == 0 || !st[c].done);
+            const unsigned long long m = __ballot(on);
+            if (on) act[nAct + mbcnt(m)] = (unsigned short)(c - chunk);
+            nAct += __popcll(m);
+        }
+        __syncthreads();
+        for (int a0 = 0; a0 < nAct; a0 += rpb) {
+            const int nr = min(rpb, nAct - a0);
+            const int nIt = nested ? nr : nr * MAXC;
+            {
+                const int ri = nested ? lane : lane / MAXC, j = nested ? 0 : lane - ri * MAXC;
+                bool valid = false;
+                int c = 0;
+                if (lane < nIt) {
+                    c = chunk + act[a0 + ri];
+                    RectD rec, r; load_rect(rects + (size_t)c * 12, rec);
+                    if (nested) { r = rec; valid = stage == 0 || (rec.width - 0.5) >= 0.5; }
+                    else valid = stage_cand(rec, stage, j, r);
+                    CntItem& I = its[lane];
+                    I.c = c; I.j = valid ? j : -1;
+                    if (valid) {
+                        I.g = nfa_geom(r, sh); I.theta = r.theta; I.prec = r.prec; I.p = r.p;
+                        const int need = (nfa_max_width(I.g) + (nested ? 0 : 3) + 11) / 12;       // lanes per row so that a run is <= 12 pixels
+                        int lg = 1; while ((1 << lg) < need && lg < 6) ++lg;
+                        I.lg = lg;
+                    }
+                }
+                const unsigned long long vm = __ballot(valid);
+                if (lane < nIt) {
+                    if (nested) { if (!valid) st[c].nc = 0; }
+                    else if (j == 0) st[c].nc = __popcll((vm >> lane) & 31ull);
+                }
+            }
+            __syncthreads();
+            if (!nested) {
+                for (int ri = 0; ri < nr; ++ri) {
+                    const CntItem* it5 = its + ri * MAXC;
+                    int nc = 0;
+#pragma unroll
+                    for (int j = 0; j < MAXC; ++j) nc += it5[j].j >= 0 ? 1 : 0;           // valid candidates form a prefix
+                    if (nc == 0) continue;
+                    int total[MAXC], alg[MAXC];
+                    if (small) count_rect5<true>(it5, nc, it5[0].lg, ang, sw, lane, total, alg);
+                    else count_rect5<false>(it5, nc, it5[0].lg, ang, sw, lane, total, alg);
+                    const int c = it5[0].c;
+                    if (lane < nc) {
+                        const int tj = lane == 0 ? total[0] : lane == 1 ? total[1] : lane == 2 ? total[2] : lane == 3 ? total[3] : total[4];
+                        const int aj = lane == 0 ? alg[0] : lane == 1 ? alg[1] : lane == 2 ? alg[2] : lane == 3 ? alg[3] : alg[4];
+                        st[c].cnt[lane][0] = tj; st[c].cnt[lane][1] = aj;
+                    }
+                }
+            } else
+            for (int it = 0; it < nIt; ++it) {
+                const int j = its[it].j;
+                if (j < 0) continue;
+                const NfaGeom g = its[it].g;
+                const double theta = its[it].theta, p = its[it].p;
+                const int c = its[it].c;
+                double prec[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) prec[k] = stage == 0 ? (k == 0 ? its[it].prec : ldexp(p, -k) * kPI) : ldexp(p, -(k + 1)) * kPI;
+                int total, alg[6];
+                const int lg = its[it].lg;
+                if (stage == 0) { if (small) count_item<6, true>(g, lg, theta, prec, ang, sw, lane, total, alg); else count_item<6, false>(g, lg, theta, prec, ang, sw, lane, total, alg); }
+                else { if (small) count_item<5, true>(g, lg, theta, prec, ang, sw, lane, total, alg); else count_item<5, false>(g, lg, theta, prec, ang, sw, lane, total, alg); }
+                if (lane == 0) {
+                    const int K = stage == 0 ? 6 : 5;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) if (k < K) { st[c].cnt[k][0] = total; st[c].cnt[k][1] = alg[k]; }
+                    st[c].nc = K;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// stage -1: the initial evaluation (cnt[0]); stage 0: cnt[1..5]; stages 1-4: cnt[0..nc).
+// One wave walks a frame's (rectangle, candidate) evaluations with lane-level dynamic scheduling: the tail loop's trip count
+// varies from 1 to thousands, so lanes that finish pick up the next evaluation instead of idling until the slowest lane of a
+// fixed assignment is done.  Setup (log-gamma terms, exp) and the final log10 run only when at least EVAL_REFILL lanes need
+// them.  Results land in NfaState::val; k_nfa_accept applies the reference's in-order acceptance.
+__device__ __forceinline__ int stage_ncand(const NfaState& s, int stage) {
+    if (stage < 0) return 1;
+    if (s.done) return 0;
+    return stage == 0 ? 5 : stage == 4 ? (s.nc > 0 ? 5 : 0) : s.nc;
+}
+__global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPlan P, int stage, const double* __restrict__ lgam) {
+    __shared__ unsigned short items[EVAL_CH * 5];            // (rect - chunk) << 3 | candidate
+    const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y, lane = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    Misc* misc = (Misc*)(base + P.offMisc);
+    const int nCand = misc->nCand;
+    const double* rects = (const double*)(base + P.offCand);
+    NfaState* st = (NfaState*)(base + P.offNfa);
+    const PLog* plog = (const PLog*)(lgam + P.npx + 4);
+    const double* rcp = lgam + P.npx + 4 + 48;
+    const int per = (nCand + gridDim.x - 1) / gridDim.x;
+    const int c0 = blockIdx.x * per, c1 = min(c0 + per, nCand);
+#ifdef SSLAM_LSD_STATS
+    long long useful = 0, executed = 0, evals = 0;
+#endif
+    for (int chunk = c0; chunk < c1; chunk += EVAL_CH) {
+        const int cend = min(chunk + EVAL_CH, c1);
+        int nItems = 0;
+        for (int cb = chunk; cb < cend; cb += 64) {
+            const int c = cb + lane;
+            const int cnt = c < cend ? stage_ncand(st[c], stage) : 0;
+            const int incl = wave_incl_scan(cnt);
+            const int ex = nItems + incl - cnt;
+            for (int j = 0; j < cnt; ++j) items[ex + j] = (unsigned short)(((c - chunk) << 3) | j);
+            nItems += __builtin_amdgcn_readlane(incl, 63);
+        }
+        __syncthreads();
+        int pos = 0, myc = 0, myj = 0;
+        bool active = false, pending = false, needLog = false;
+        TailState S; S.term = 0; S.bin_tail = 1; S.p_term = 0; S.n = 0; S.i = 1;
+        double v = 0;
+        while (true) {
+            const unsigned long long am = __ballot(active);
+            const int nIdle = 64 - __popcll(am);
+            const bool more = pos < nItems;
+            if ((more && nIdle >= EVAL_REFILL) || am == 0) {
+                if (!active && pending) {                      // finish and publish what the idle lanes hold
+                    if (needLog) v = -log10(S.bin_tail) - P.logNT;
+                    st[myc].val[myj] = v;
+                    pending = false;
+                }
+                if (!more) { if (am == 0) break; }
+                else {
+                    if (!active) {
+                        const int my = pos + mbcnt(~am);
+                        if (my < nItems) {
+                            const unsigned it = items[my];
+                            myc = chunk + (int)(it >> 3); myj = (int)(it & 7);
+                            const int kofs = stage == 0 ? 1 : 0;
+                            const int n = st[myc].cnt[myj + kofs][0], k = st[myc].cnt[myj + kofs][1];
+                            double p = rects[(size_t)myc * 12 + 11];
+                            if (stage == 0 || stage == 4) p = ldexp(p, -(myj + 1));       // stage_cand halves p once per step
+                            needLog = nfa_setup(n, k, p, P.logNT, lgam, plog, S, v);
+                            active = needLog; pending = true;
+#ifdef SSLAM_LSD_STATS
+                            ++evals;
+#endif
+                        }
+                    }
+                    pos += nIdle;
+                    continue;
+                }
+            }
+            if (active) {
+#ifdef SSLAM_LSD_STATS
+                useful += min(8, S.n - S.i + 1);
+#endif
+                if (tail_block(S, P.logNT, rcp)) active = false;
+            }
+#ifdef SSLAM_LSD_STATS
+            executed += 8;
+#endif
+        }
+        __syncthreads();
+    }
+#ifdef SSLAM_LSD_STATS
+    // cyc[5] = useful tail iterations (upper bound: whole blocks), cyc[6] = lane-iterations the wave executed, cyc[7] = evaluations
+    atomicAdd((unsigned long long*)&misc->cyc[5], (unsigned long long)useful); atomicAdd((unsigned long long*)&misc->cyc[6], (unsigned long long)executed);
+    atomicAdd((unsigned long long*)&misc->cyc[7], (unsigned long long)evals);
+#endif
+}
+
+// rect_improve's acceptance, in candidate order, one lane per rectangle (the candidates of a stage do not depend on which of
+// them is accepted, so they were all evaluated up front).
+__global__ __launch_bounds__(256) void k_nfa_accept(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
+    const int b = blockIdx.y;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int nCand = misc->nCand;
+    double* rects = (double*)(base + P.offCand);
+    NfaState* st = (NfaState*)(base + P.offNfa);
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < nCand; c += gridDim.x * 256) {
+        if (stage < 0) { const double v0 = st[c].val[0]; st[c].logNfa = v0; st[c].done = v0 > 0.0 ? 1 : 0; continue; }
+        const int nc = stage_ncand(st[c], stage);
+        if (st[c].done) continue;
+        double log_nfa = st[c].logNfa;
+        int best = -1;
+        for (int q = 0; q < nc; ++q) { const double vq = st[c].val[q]; if (vq > log_nfa) { log_nfa = vq; best = q; } }
+        if (best >= 0) {
+            RectD rec, r; load_rect(rects + (size_t)c * 12, rec);
+            stage_cand(rec, stage, best, r);
+            store_rect(rects + (size_t)c * 12, r); st[c].logNfa = log_nfa;
+        }
+        if (stage < 4 && log_nfa > 0.0) st[c].done = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nfa_finish(uint8_t* __restrict__ ws, LsdPlan P) {
+    const int b = blockIdx.y;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int nCand = misc->nCand;
+    const double* rects = (const double*)(base + P.offCand);
+    const NfaState* st = (const NfaState*)(base + P.offNfa);
+    float4* seg = (float4*)(base + P.offSeg);
+    int* flag = (int*)(base + P.offFlag);
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < nCand; c += gridDim.x * 256) {
+        const bool ok = st[c].logNfa > 0.0;
+        flag[c] = ok ? 1 : 0;
+        if (ok) {
+            const double* o = rects + (size_t)c * 12;
+            const double SCALE = 0.8;
+            seg[c] = make_float4((float)((o[0] + 0.5) / SCALE), (float)((o[1] + 0.5) / SCALE), (float)((o[2] + 0.5) / SCALE), (float)((o[3] + 0.5) / SCALE));
+        }
+    }
+}

@@ -1,0 +1,284 @@
+// LSD sequential core: region growing, region2rect, refine / reduce_region_radius, one persistent single-wave workgroup per frame.
+// Part of lines.hip (included there, inside its anonymous namespace: one translation unit, so device helpers are shared
+// without relocatable device code).  Not a standalone header.
+#pragma once
+
+// region point list: first QCAP entries in LDS, the rest in global memory.  entry = x | y<<16
+struct RegQ {
+    unsigned* lds; unsigned* glb;
+    __device__ __forceinline__ unsigned get(int i) const { return i < QCAP ? lds[i] : glb[i]; }
+    __device__ __forceinline__ void set(int i, unsigned v) const { if (i < QCAP) lds[i] = v; else glb[i] = v; }
+};
+__device__ __forceinline__ void rq_fence(int n) { if (n > QCAP) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+__device__ __forceinline__ bool used_get(const unsigned* ub, int idx) { return (ub[idx >> 5] >> (idx & 31)) & 1u; }
+
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// LineSegmentDetectorImpl::region_grow by one wave.  Eight queue entries are staged at a time (8
+// lanes each: the 3x3 neighbourhood in row-major order without its centre), so one global-load round
+// trip serves up to eight points.  Lane order == the reference's visiting order, and the region angle only
+// changes when a pixel is accepted, so ONE ballot over all staged lanes finds the next accepted
+// pixel exactly as the sequential scan would; lanes before it are consumed, lanes after it are
+// re-tested against the updated angle.
+// LAT selects the accept-chain flavour: v_readlane + pre-converted operands shorten the dependent chain of a lone wave
+// (single-frame latency, -11 %), while with six waves per SIMD the LDS-permute form issues fewer wait states (throughput).
+template <bool LAT>
+__device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __restrict__ pix, const float* __restrict__ ang, const RegQ& rq,
+                             double prec, double& regAngleOut) {
+    const int lane = threadIdx.x & 63;
+    const int seed = seedY * sw + seedX;
+    int n = 1;
+    double regAngle = (double)ang[seed] * DEG2RAD;
+    float sumdx = (float)cos(regAngle), sumdy = (float)sin(regAngle);
+    if (lane == 0) { rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16)); pix[seed].x = USED_F; }
+    const int g = lane >> 3, k8 = lane & 7;             // group (queue slot) and neighbour slot (centre skipped)
+    const int k = k8 + (k8 >= 4 ? 1 : 0);                // row-major 3x3 position 0..8 without 4
+    const int dy = k / 3 - 1, dx = k - (k / 3) * 3 - 1;
+    int i = 0;
+    while (i < n) {
+        const int np = min(8, n - i);
+        bool cand = false; int nidx = -1, xx = 0, yy = 0; float4 px4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
+        if (g < np) {
+            const unsigned e = rq.get(i + g);
+            xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
+            if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
+                nidx = yy * sw + xx;
+                px4 = pix[nidx];                 // .x < 0: NOTDEF or already USED
+                cand = px4.x >= 0.f;
+            }
+        }
+        int lastSel = -1;
+        const int nBefore = n;
+        unsigned long long accMask = 0;                    // lanes accepted from this staging, in lane (= acceptance) order
+        const double candRad = LAT ? (double)px4.x * DEG2RAD : 0.0;     // isAligned's operand, converted once per staging
+        while (true) {
+            bool al;
+            if (LAT) {
+                double nt = regAngle - candRad;              // is_aligned_val(px4.x, regAngle, prec), same operations
+                if (nt < 0) nt = -nt;
+                if (nt > M_3_2_PI_) { nt -= M_2PI_; if (nt < 0) nt = -nt; }
+                al = cand && lane > lastSel && nt <= prec;
+            } else { const bool ok = is_aligned_val(px4.x, regAngle, prec); al = cand && lane > lastSel && ok; }      // straight-line: no exec-masked region around the test
+            const unsigned long long m = __ballot(al);
+            if (!m) break;
+            const int sel = __ffsll((long long)m) - 1;       // wave-uniform: the lane reads below are v_readlane, not LDS permutes
+            const int selIdx = LAT ? __builtin_amdgcn_readlane(nidx, sel) : __shfl(nidx, sel, 64);
+            if (LAT) accMask |= 1ull << sel;               // lone wave: the used-map / queue stores follow the loop, all lanes at once
+            else if (lane == sel) { pix[nidx].x = USED_F; rq.set(n, (unsigned)xx | ((unsigned)yy << 16)); }
+            ++n;
+            sumdx = __fadd_rn(sumdx, LAT ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px4.y), sel)) : __shfl(px4.y, sel, 64));
+            sumdy = __fadd_rn(sumdy, LAT ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px4.z), sel)) : __shfl(px4.z, sel, 64));
+            regAngle = (double)fast_atan2_deg<LAT>(sumdy, sumdx) * DEG2RAD;
+            if (nidx == selIdx) cand = false;              // the accepted pixel is now USED for every later visitor
+            lastSel = sel;
+        }
+        if (LAT && accMask != 0 && ((accMask >> lane) & 1ull)) { pix[nidx].x = USED_F; rq.set(nBefore + mbcnt(accMask), (unsigned)xx | ((unsigned)yy << 16)); }
+        i += np;
+    }
+    regAngleOut = regAngle;
+    return n;
+}
+
+// Three fp64 running sums that must be folded strictly in region order (the reference adds point after point).  The wave
+// computes the 64 addends of each sum lane-parallel and parks them in LDS; then lanes 0..2 each walk ONE of the three
+// arrays, so a step of all three chains is one ds_read_b64 + one v_add_f64 (a readlane walk costs nine instructions).
+// acc is live in lanes 0..2 only; ordered_sums_get() broadcasts the results.
+struct OrdSum { double acc; };
+__device__ __forceinline__ void ordered_sums_add(OrdSum& S, double* __restrict__ red, double v0, double v1, double v2, int cnt, int lane) {
+    red[lane] = v0; red[64 + lane] = v1; red[128 + lane] = v2;
+    if (lane < 3) {
+        const double* src = red + lane * 64;
+        double acc = S.acc;
+        int j = 0;
+        for (; j + 4 <= cnt; j += 4) {
+            const double a0 = src[j], a1 = src[j + 1], a2 = src[j + 2], a3 = src[j + 3];
+            acc = acc + a0; acc = acc + a1; acc = acc + a2; acc = acc + a3;
+        }
+        for (; j < cnt; ++j) acc = acc + src[j];
+        S.acc = acc;
+    }
+}
+__device__ __forceinline__ double ordered_sums_get(const OrdSum& S, int which) { return readlane_d(S.acc, which); }
+
+// one wave: region2rect + get_theta.  Loads and per-point products run lane-parallel; the
+// fp64 sums are then folded strictly in region order (ordered_sums_add), extents by min/max.
+__device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __restrict__ pix, double regAngle, double prec, double p, RectD& rec, double* __restrict__ red) {
+    const int lane = threadIdx.x & 63;
+    OrdSum S1; S1.acc = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        double fx = 0, fy = 0, wgt = 0;
+        if (i < n) {
+            const unsigned e = rq.get(i);
+            const int px = e & 0xFFFF, py = e >> 16;
+            wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
+            fx = (double)px * wgt; fy = (double)py * wgt;
+        }
+        ordered_sums_add(S1, red, fx, fy, wgt, min(64, n - base), lane);
+    }
+    double x = ordered_sums_get(S1, 0), y = ordered_sums_get(S1, 1);
+    const double sum = ordered_sums_get(S1, 2);
+    x /= sum; y /= sum;
+    OrdSum S2; S2.acc = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        double a = 0, b = 0, c = 0;
+        if (i < n) {
+            const unsigned e = rq.get(i);
+            const int px = e & 0xFFFF, py = e >> 16;
+            const double wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
+            const double ddx = (double)px - x, ddy = (double)py - y;
+            a = ddy * ddy * wgt; b = ddx * ddx * wgt; c = ddx * ddy * wgt;
+        }
+        ordered_sums_add(S2, red, a, b, -c, min(64, n - base), lane);      // Ixy -= c  ==  Ixy += (-c), exactly
+    }
+    const double Ixx = ordered_sums_get(S2, 0), Iyy = ordered_sums_get(S2, 1), Ixy = ordered_sums_get(S2, 2);
+    const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
+                                           : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
+    theta *= DEG2RAD;
+    if (fabs(angle_diff_signed(theta, regAngle)) > prec) theta += kPI;
+    const double dx = cos(theta), dy = sin(theta);
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;       // running min/max from 0: order independent
+    for (int i = lane; i < n; i += 64) {
+        const unsigned e = rq.get(i);
+        const double rdx = (double)(e & 0xFFFF) - x, rdy = (double)(e >> 16) - y;
+        const double l = rdx * dx + rdy * dy, ww = -rdx * dy + rdy * dx;
+        l_max = fmax(l_max, l); l_min = fmin(l_min, l); w_max = fmax(w_max, ww); w_min = fmin(w_min, ww);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        l_max = fmax(l_max, __shfl_xor(l_max, o, 64)); l_min = fmin(l_min, __shfl_xor(l_min, o, 64));
+        w_max = fmax(w_max, __shfl_xor(w_max, o, 64)); w_min = fmin(w_min, __shfl_xor(w_min, o, 64));
+    }
+    rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy; rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
+    rec.width = w_max - w_min; rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy; rec.prec = prec; rec.p = p;
+    if (rec.width < 1.0) rec.width = 1.0;
+}
+
+__device__ __forceinline__ double dist_d(double x1, double y1, double x2, double y2) {
+    return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1));
+}
+
+// One persistent single-wave workgroup per frame: the flsd() main loop replayed in order.
+#ifndef SSLAM_LSD_MINWAVES
+#define SSLAM_LSD_MINWAVES 6          // waves/SIMD the register allocator must leave room for (6 x 4 SIMDs = 24 frames per CU, LDS allows 32)
+#endif
+template <bool LAT>
+__global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
+    extern __shared__ __align__(16) unsigned dynLds[];           // region queue (first QCAP points)
+    const int b = xcd_mix_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const float* ang = (const float*)(base + P.offAng);
+    float4* pix = (float4*)(base + P.offPix);
+    const unsigned* order = (const unsigned*)(base + P.offOrder);
+    double* candOut = (double*)(base + P.offCand);
+    Misc* misc = (Misc*)(base + P.offMisc);
+    const int sw = P.sw, sh = P.sh;
+    RegQ rq; rq.lds = dynLds; rq.glb = (unsigned*)(base + P.offReg);
+    __shared__ double red[3 * 64];                                 // addends of the ordered fp64 sums
+    __syncthreads();
+    const int nOrd = misc->nDefined;
+    const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
+    int nSeg = 0;
+    long long cyc0 = 0, cyc1 = 0, cyc2 = 0, cyc3 = 0;
+    const long long tStart = __builtin_readcyclecounter();
+    for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
+        const int q = pos0 + lane;
+        const int idx = q < nOrd ? (int)order[q] : -1;
+        int after = -1;                                    // lanes <= after are consumed
+        while (true) {
+            const bool un = idx >= 0 && lane > after && pix[idx].x >= 0.f;
+            const unsigned long long m = __ballot(un);
+            if (!m) break;
+            const int first = __ffsll((long long)m) - 1;
+            after = first;
+            const int seed = LAT ? __builtin_amdgcn_readlane(idx, first) : __shfl(idx, first, 64);
+            const int sy = seed / sw, sx = seed - sy * sw;
+            double regAngle;
+            long long t0 = __builtin_readcyclecounter();
+            int n = region_grow_m<LAT>(sx, sy, sw, sh, pix, ang, rq, prec, regAngle);
+            long long t1 = __builtin_readcyclecounter(); cyc0 += t1 - t0;
+            if (n < P.minRegSize) continue;
+            RectD rec;
+            region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
+            long long t2 = __builtin_readcyclecounter(); cyc1 += t2 - t1;
+            // ---- refine (LSD_REFINE_STD part)
+            double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+            if (density < DENSITY_TH) {
+                const unsigned e0 = rq.get(0);
+                const int x0 = e0 & 0xFFFF, y0 = e0 >> 16;
+                const double xc = (double)x0, yc = (double)y0;
+                const double ang_c = (double)ang[y0 * sw + x0] * DEG2RAD;
+                OrdSum SR; SR.acc = 0; int cnt = 0;
+                for (int bs = 0; bs < n; bs += 64) {
+                    const int i = bs + lane;
+                    double ad = 0; bool in = false;
+                    if (i < n) {
+                        const unsigned e = rq.get(i);
+                        const int px = e & 0xFFFF, py = e >> 16, id = py * sw + px;
+                        const float aOrig = ang[id];
+                        pix[id].x = aOrig;                 // NOTUSED again
+                        if (dist_d(xc, yc, (double)px, (double)py) < rec.width) { in = true; ad = angle_diff_signed((double)aOrig * DEG2RAD, ang_c); }
+                    }
+                    // points outside the radius contribute an exact +0.0 (the sums start at +0 and can never be -0)
+                    const unsigned long long mi = __ballot(in);
+                    ordered_sums_add(SR, red, in ? ad : 0.0, in ? ad * ad : 0.0, 0.0, min(64, n - bs), lane);
+                    cnt += __popcll(mi);
+                }
+                const double sum = ordered_sums_get(SR, 0), s_sum = ordered_sums_get(SR, 1);
+                const double mean_angle = sum / (double)cnt;
+                const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
+                n = region_grow_m<LAT>(x0, y0, sw, sh, pix, ang, rq, tau, regAngle);
+                if (n < 2) continue;
+                region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
+                density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+                if (density < DENSITY_TH) {
+                    const long long tr0 = __builtin_readcyclecounter();
+                    // reduce_region_radius: sequential swap-with-last removal (the order feeds later sums)
+                    const double r1 = (rec.x1 - xc) * (rec.x1 - xc) + (rec.y1 - yc) * (rec.y1 - yc);
+                    const double r2 = (rec.x2 - xc) * (rec.x2 - xc) + (rec.y2 - yc) * (rec.y2 - yc);
+                    double radSq = r1 > r2 ? r1 : r2;
+                    bool good = true;
+                    while (density < DENSITY_TH) {
+                        radSq *= 0.75 * 0.75;
+                        for (int i = 0; i < n; ++i) {
+                            const unsigned e = rq.get(i);
+                            const int px = e & 0xFFFF, py = e >> 16;
+                            const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
+                            if (d2 > radSq) {
+                                const int id = py * sw + px;
+                                const unsigned last = rq.get(n - 1);
+                                if (lane == 0) { pix[id].x = ang[id]; rq.set(i, last); }
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                                --n; --i;
+                            }
+                        }
+                        if (n < 2) { good = false; break; }
+                        region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
+                        density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+                    }
+                    cyc3 += __builtin_readcyclecounter() - tr0;
+                    if (!good) continue;
+                }
+            }
+            // ---- hand the rectangle to the NFA stage (rect_improve reads only the static angle map and never touches
+            // `used`, so it is not part of the sequential dependency chain: k_lsd_nfa evaluates all candidates in parallel)
+            long long t3 = __builtin_readcyclecounter(); cyc2 += t3 - t2;
+            if (nSeg < MAX_SEG && lane == 0) {
+                double* o = candOut + (size_t)nSeg * 12;
+                o[0] = rec.x1; o[1] = rec.y1; o[2] = rec.x2; o[3] = rec.y2; o[4] = rec.width; o[5] = rec.x; o[6] = rec.y;
+                o[7] = rec.theta; o[8] = rec.dx; o[9] = rec.dy; o[10] = rec.prec; o[11] = rec.p;
+            }
+            ++nSeg;
+        }
+    }
+    if (lane == 0) {
+        misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
+        misc->cyc[0] = cyc0; misc->cyc[1] = cyc1; misc->cyc[2] = cyc2; misc->cyc[3] = cyc3; misc->cyc[4] = __builtin_readcyclecounter() - tStart;
+    }
+}

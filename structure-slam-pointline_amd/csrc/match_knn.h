@@ -1,0 +1,182 @@
+// Brute-force Hamming kernels: constants, 256-bit popcount distance, knn-2 (BFMatcher semantics), distance matrix,
+// knn-2 + MAD gates for lines.
+// Part of match.hip (included there, inside its anonymous namespace: one translation unit).  Not a standalone header.
+#pragma once
+
+constexpr int TH_LOW = 50;
+constexpr int HISTO_LENGTH = 30;
+constexpr int GRID_COLS = 64, GRID_ROWS = 48;
+
+__device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// one wave per query; lanes stride the train set (coalesced 32 B per lane).
+// key = dist<<32 | idx so the minimum resolves ties to the lower train index (A.10).
+__device__ __forceinline__ void wave_knn2(const uint8_t* __restrict__ qd, const uint8_t* __restrict__ t, int nt,
+                                          unsigned long long& best, unsigned long long& second) {
+    const int lane = threadIdx.x & 63;
+    const uint4 q0 = ((const uint4*)qd)[0], q1 = ((const uint4*)qd)[1];
+    unsigned long long b = ~0ull, s = ~0ull;
+    for (int j = lane; j < nt; j += 64) {
+        const uint4* tp = (const uint4*)(t + (size_t)j * 32);
+        unsigned long long k = ((unsigned long long)hamming256(q0, q1, tp[0], tp[1]) << 32) | (unsigned)j;
+        if (k < b) { s = b; b = k; } else if (k < s) s = k;
+    }
+    best = wave_min_u64(b);
+    unsigned long long c = (b == best) ? s : b;
+    second = wave_min_u64(c);
+}
+
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                              int* __restrict__ idx, int* __restrict__ dist) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave >= nq) return;
+    unsigned long long b, s;
+    wave_knn2(q + (size_t)wave * 32, t, nt, b, s);
+    if ((threadIdx.x & 63) == 0) {
+        idx[wave * 2] = b == ~0ull ? -1 : (int)(unsigned)b;
+        dist[wave * 2] = b == ~0ull ? -1 : (int)(b >> 32);
+        idx[wave * 2 + 1] = s == ~0ull ? -1 : (int)(unsigned)s;
+        dist[wave * 2 + 1] = s == ~0ull ? -1 : (int)(s >> 32);
+    }
+}
+
+// batch form: frame f uses q + f*cap*32 (nq[f] rows) against t + f*cap*32 (nt[f] rows).  The kernel is bound by L2
+// traffic on the train rows, so each wave scores FOUR queries against every train row it loads.
+__global__ __launch_bounds__(256) void k_knn2_batch(const uint8_t* __restrict__ q, const int* __restrict__ nq, const uint8_t* __restrict__ t,
+                                                    const int* __restrict__ nt, int cap, int* __restrict__ idx, int* __restrict__ dist) {
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int q0i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4;
+    const int nqf = nq[f], ntf = nt[f];
+    if (q0i >= nqf) return;
+    const uint8_t* qb = q + (size_t)f * cap * 32;
+    const uint8_t* tb = t + (size_t)f * cap * 32;
+    uint4 qa[4], qc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int qi = min(q0i + k, nqf - 1);
+        qa[k] = ((const uint4*)(qb + (size_t)qi * 32))[0]; qc[k] = ((const uint4*)(qb + (size_t)qi * 32))[1];
+    }
+    unsigned long long b[4] = {~0ull, ~0ull, ~0ull, ~0ull}, s[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    for (int j = lane; j < ntf; j += 64) {
+        const uint4* tp = (const uint4*)(tb + (size_t)j * 32);
+        const uint4 t0 = tp[0], t1 = tp[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long kk = ((unsigned long long)hamming256(qa[k], qc[k], t0, t1) << 32) | (unsigned)j;
+            if (kk < b[k]) { s[k] = b[k]; b[k] = kk; } else if (kk < s[k]) s[k] = kk;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long best = wave_min_u64(b[k]);
+        const unsigned long long second = wave_min_u64(b[k] == best ? s[k] : b[k]);
+        if (lane == 0 && q0i + k < nqf) {
+            const size_t o = ((size_t)f * cap + q0i + k) * 2;
+            idx[o] = best == ~0ull ? -1 : (int)(unsigned)best;
+            dist[o] = best == ~0ull ? -1 : (int)(best >> 32);
+            idx[o + 1] = second == ~0ull ? -1 : (int)(unsigned)second;
+            dist[o + 1] = second == ~0ull ? -1 : (int)(second >> 32);
+        }
+    }
+}
+
+__global__ void k_hamming_matrix(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt, unsigned short* __restrict__ D) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= nt || i >= nq) return;
+    const uint4* qp = (const uint4*)(q + (size_t)i * 32);
+    const uint4* tp = (const uint4*)(t + (size_t)j * 32);
+    D[(size_t)i * nt + j] = (unsigned short)hamming256(qp[0], qp[1], tp[0], tp[1]);
+}
+
+// ---------------------------------------------------------------- line matching
+// One 256-thread workgroup per frame pair: knn-2 of n1 query LBD descriptors against
+// n2 train descriptors, Frame::lineDescriptorMAD (medians via LDS bitonic sorts), then
+// the MAD-gap or ratio gate, pairs emitted in query order.
+constexpr int LM_MAX = 1024;
+
+__device__ void lds_sort_asc(float* a, int P2) {
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P2; i += blockDim.x) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    float x = a[i], y = a[ixj];
+                    bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(256) void k_line_match(const uint8_t* __restrict__ l1, const int* __restrict__ n1p, int n1s,
+                                                    const uint8_t* __restrict__ l2, const int* __restrict__ n2p, int n2s, int cap,
+                                                    double gateScale, int ratioMode, int* __restrict__ pairs, int* __restrict__ npairs,
+                                                    double* __restrict__ madOut) {
+    __shared__ int bd[LM_MAX], sd[LM_MAX], bi[LM_MAX];
+    __shared__ float srt[LM_MAX];
+    __shared__ int wcount[4];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n1 = n1p ? n1p[p] : n1s, n2 = n2p ? n2p[p] : n2s;
+    const uint8_t* q = l1 + (size_t)p * cap * 32;
+    const uint8_t* t = l2 + (size_t)p * cap * 32;
+    int* out = pairs + (size_t)p * cap * 2;
+    if (n1 <= 0 || n2 < 2 || n1 > LM_MAX) {      // degenerate (UB in the reference, src/LSDmatcher.cpp:167): defined as 0 matches
+        if (tid == 0) { npairs[p] = 0; if (madOut) { madOut[p * 2] = 0; madOut[p * 2 + 1] = 0; } }
+        return;
+    }
+    for (int i = wv; i < n1; i += 4) {
+        unsigned long long b, s;
+        wave_knn2(q + (size_t)i * 32, t, n2, b, s);
+        if (lane == 0) { bd[i] = (int)(b >> 32); bi[i] = (int)(unsigned)b; sd[i] = (int)(s >> 32); }
+    }
+    __syncthreads();
+    int P2 = 1; while (P2 < n1) P2 <<= 1;
+    const float INF = 3.0e38f;
+    // NN distance MAD
+    for (int i = tid; i < P2; i += 256) srt[i] = i < n1 ? (float)bd[i] : INF;
+    __syncthreads();
+    lds_sort_asc(srt, P2);
+    const double med = srt[n1 / 2];
+    __syncthreads();
+    for (int i = tid; i < P2; i += 256) srt[i] = i < n1 ? fabsf((float)((double)(float)bd[i] - med)) : INF;
+    __syncthreads();
+    lds_sort_asc(srt, P2);
+    const double nnMad = 1.4826 * (double)srt[n1 / 2];
+    __syncthreads();
+    // NN12 gap MAD: median of the gaps sorted DESCENDING = ascending element n1-1-n1/2
+    for (int i = tid; i < P2; i += 256) srt[i] = i < n1 ? __fsub_rn((float)sd[i], (float)bd[i]) : INF;
+    __syncthreads();
+    lds_sort_asc(srt, P2);
+    const double med12 = srt[n1 - 1 - n1 / 2];
+    __syncthreads();
+    for (int i = tid; i < P2; i += 256) srt[i] = i < n1 ? fabsf((float)((double)__fsub_rn((float)sd[i], (float)bd[i]) - med12)) : INF;
+    __syncthreads();
+    lds_sort_asc(srt, P2);
+    const double nn12Mad = 1.4826 * (double)srt[n1 / 2];
+    const double th = nn12Mad * gateScale;
+    const float minRatio = 1.0f / 1.5f;
+    __syncthreads();
+    // gate + ordered compaction
+    int base = 0;
+    for (int i0 = 0; i0 < n1; i0 += 256) {
+        int i = i0 + tid;
+        bool ok = false;
+        if (i < n1) {
+            if (ratioMode) ok = (double)__fdiv_rn((float)bd[i], (float)sd[i]) < (double)minRatio;
+            else ok = (double)__fsub_rn((float)sd[i], (float)bd[i]) > th;
+        }
+        unsigned long long m = __ballot(ok);
+        if (lane == 0) wcount[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; ++w) off += wcount[w];
+        if (ok) { int o = off + mbcnt(m); if (o < cap) { out[o * 2] = i; out[o * 2 + 1] = bi[i]; } }
+        base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    if (tid == 0) { npairs[p] = base; if (madOut) { madOut[p * 2] = nnMad; madOut[p * 2 + 1] = nn12Mad; } }
+}
