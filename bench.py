@@ -146,7 +146,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
-    if world > 1:
+    # SSLAM_FORCE_COLLECTIVE=1 (tests): run the RCCL exchange step even with a single rank, so the collective path is exercised on a 1-GPU box
+    force_collective = os.environ.get("SSLAM_FORCE_COLLECTIVE") == "1" and "RANK" in os.environ
+    if world > 1 or force_collective:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -171,7 +173,7 @@ def main():
 
     sharding = pkg._load("sslam_sharding", os.path.join(pkg.PKG_DIR, "sharding.py"))
 
-    gather = sharding.AsyncGather(dist, world, rank)
+    gather = sharding.AsyncGather(dist, world, rank, always_collective=force_collective)
 
     def one_step():
         pipe.step(cur, overlap=args.overlap)
@@ -203,6 +205,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    if rank == 0 and dist is not None:
+        # the gathered records of the last step must be this rank's own packed results at every slot it owns (global frame i = local i // world on rank i % world)
+        got = gather.result()
+        mine = pipe.packed_results()
+        assert got.shape[0] == B * world and torch.equal(got[0::world], mine), "RCCL gather returned records that differ from rank 0's own"
     if rank == 0:
         counts = pipe.feat["cur"]["n"].cpu().numpy(); lcounts = pipe.feat["cur"]["nl"].cpu().numpy()
         nm = pipe.nmatch.cpu().numpy(); nlp = pipe.nlpairs.cpu().numpy()

@@ -57,13 +57,14 @@ def gather_to_root(dist, rec, world, rank):
 class AsyncGather:
     """The one exchange step, overlapped with the next step's compute: gather(step k) runs on RCCL's stream
     while the kernels of step k+1 execute; at most one gather is in flight."""
-    def __init__(self, dist, world, rank):
+    def __init__(self, dist, world, rank, always_collective=False):
         self.dist, self.world, self.rank = dist, world, rank
+        self.local_only = world == 1 and not (always_collective and dist is not None)
         self.work = None; self.bufs = None; self.rec = None
 
     def submit(self, rec):
         self.wait()
-        if self.world == 1:
+        if self.local_only:
             self.rec = rec
             return
         if self.rank == 0 and (self.bufs is None or self.bufs[0].shape != rec.shape):
@@ -79,7 +80,7 @@ class AsyncGather:
     def result(self):
         """records in global frame order on rank 0 (None elsewhere)"""
         self.wait()
-        if self.world == 1:
+        if self.local_only:
             return self.rec
         if self.rank != 0:
             return None
