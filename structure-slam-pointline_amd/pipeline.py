@@ -47,7 +47,7 @@ class FrontendBatch:
             self._s1, self._s2 = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
         return self._s1, self._s2
 
-    def extract(self, images, tag="cur"):
+    def extract(self, images, tag="cur", lines_first=False):
         """images: uint8 device tensor [B, h, w] (contiguous).  Runs on the pipeline's point stream; the
         caller's current stream is ordered before and after."""
         assert images.is_cuda and images.dtype == torch.uint8 and images.shape == (self.B, self.h, self.w) and images.is_contiguous()
@@ -57,10 +57,16 @@ class FrontendBatch:
         s1.wait_stream(cur)
         with torch.cuda.stream(s1):
             st = self._stream()
-            self.orb.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kp"], f["desc"], f["n"], self.cap, st)
-            if self.with_lines:
-                self.lines.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kl"], f["ldesc"], f["linefn"],
-                                             f["nl"], self.lcap, st)
+
+            def _orb():
+                self.orb.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kp"], f["desc"], f["n"], self.cap, st)
+
+            def _lines():
+                if self.with_lines:
+                    self.lines.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kl"], f["ldesc"], f["linefn"],
+                                                 f["nl"], self.lcap, st)
+            for fn in ((_lines, _orb) if lines_first else (_orb, _lines)):
+                fn()
         cur.wait_stream(s1)
 
     def match(self):
@@ -97,12 +103,12 @@ class FrontendBatch:
                                           C.c_double(0.5), 0, _p(self.lpairs), _p(self.nlpairs), st)
         assert rc == 0, L.sslam_last_error()
 
-    def step(self, images, overlap=False):
+    def step(self, images, overlap=False, lines_first=False):
         """One pass of the hot path.  overlap=True runs the point branch (ORB extract + ORB matching)
         and the line branch (LSD/LBD extract + line matching) on two HIP streams: the line branch is
         latency-bound (one persistent wave per frame), the point branch fills the idle issue slots."""
         if not (overlap and self.with_lines):
-            self.extract(images, "cur")
+            self.extract(images, "cur", lines_first=lines_first)
             if self.with_match:
                 self.match()
             return
