@@ -224,8 +224,8 @@ int sslam_orb_search_for_triangulation(sslam_ctx* ctx, const sslam_frame* kf1, c
  * TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup), Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1216-1259.
  * The vocabulary is handed over as arrays in DBoW2's node numbering (node 0 = root): children of node i are
  * children[child_ptr[i] .. child_ptr[i+1]) in m_nodes[i].children order (a node without children is a leaf), node_desc =
- * 32-byte descriptor per node, word_id / weight per node (meaningful for leaves), levels = m_L.  The ORBvoc.txt loader stays
- * on the host (the file is an LFS pointer in the reference tree).  Outputs per feature: the word, its weight (0 = stopped
+ * 32-byte descriptor per node, word_id / weight per node (meaningful for leaves), levels = m_L (sslam_vocab_load_text below builds
+ * exactly these arrays from an ORBvoc.txt-format file).  Outputs per feature: the word, its weight (0 = stopped
  * word) and the node passed at level m_L - levelsup; BowVector / FeatureVector are std::maps the caller fills from them
  * in feature order (v.addWeight(id, w); fv.addFeature(nid, i); then the L1 normalisation, TemplatedVocabulary.h:1147-1199). */
 typedef struct sslam_vocab sslam_vocab;
@@ -236,6 +236,27 @@ int sslam_bow_transform(sslam_ctx* ctx, const sslam_vocab* vocab, const uint8_t*
                         int32_t* word_out, double* weight_out, int32_t* node_out);
 int sslam_bow_transform_frame(sslam_ctx* ctx, const sslam_vocab* vocab, const sslam_frame* frame, int levelsup,
                               int32_t* word_out, double* weight_out, int32_t* node_out);
+
+/* ORBVocabulary::loadFromTextFile (src/System.cc:64-73 -> TemplatedVocabulary.h:1338-1423): first line "k L scoring weighting"
+ * (rejected outside 0<=k<=20, 1<=L<=10, 0<=scoring<=5, 0<=weighting<=3, as the reference does), then one line per node in id order
+ * starting at 1: "parent isLeaf d0 .. d31 weight"; children keep file order, word ids count the leaves in file order.  Blank lines
+ * are skipped (the reference's getline loop appends a node from uninitialised values after the final newline: undefined behaviour,
+ * not reproduced).  sslam_vocab_set_types overrides what sslam_vocab_create assumes (TF_IDF = 0, L1_NORM = 0, the enums of
+ * Thirdparty/DBoW2/DBoW2/BowVector.h:36-53). */
+int sslam_vocab_load_text(sslam_ctx* ctx, const char* path, sslam_vocab** out);
+int sslam_vocab_set_types(sslam_vocab* vocab, int weighting, int scoring);
+int sslam_vocab_info(const sslam_vocab* vocab, int* k, int* levels, int* scoring, int* weighting, int* nnodes, int* nwords);
+
+/* Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:474-481, src/KeyFrame.cc:74-84) complete:
+ * TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup), TemplatedVocabulary.h:1126-1208, with
+ * BowVector::addWeight / addIfNotExist / normalize (BowVector.cpp:34-85) and FeatureVector::addFeature (FeatureVector.cpp:30-44).
+ * The descent runs on the device, the two std::maps are assembled on the host in feature order and returned flattened in key
+ * order: BowVector = (bow_word[i], bow_value[i]) for i < *nbow; FeatureVector = node fv_node[j] owns the feature indices
+ * fv_feat[fv_ptr[j] .. fv_ptr[j+1]) for j < *nfv.  Capacities: n entries each, n + 1 for fv_ptr. */
+int sslam_compute_bow(sslam_ctx* ctx, const sslam_vocab* vocab, const uint8_t* desc, int n, int levelsup,
+                      int32_t* bow_word, double* bow_value, int* nbow, int32_t* fv_node, int32_t* fv_ptr, int32_t* fv_feat, int* nfv);
+int sslam_compute_bow_frame(sslam_ctx* ctx, const sslam_vocab* vocab, const sslam_frame* frame, int levelsup,
+                            int32_t* bow_word, double* bow_value, int* nbow, int32_t* fv_node, int32_t* fv_ptr, int32_t* fv_feat, int* nfv);
 
 /* MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:247-312, and MapLine::ComputeDistinctiveDescriptors,
  * src/MapLine.cpp:246-317, for nsets observation sets at once: set s owns rows ptr[s]..ptr[s+1]

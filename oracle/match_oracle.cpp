@@ -15,6 +15,10 @@
 #include <climits>
 #include <algorithm>
 #include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <map>
 
 namespace orc {
 
@@ -485,6 +489,91 @@ int orc_bow_transform(int nnodes, int levels, const int32_t* childPtr, const int
         } while (childPtr[final_id + 1] > childPtr[final_id]);
         wordOut[i] = wordId[final_id]; weightOut[i] = weight[final_id]; nodeOut[i] = nid;
     }
+    return 0;
+}
+
+// ---- DBoW2 vocabulary text file + BowVector / FeatureVector (test infrastructure like the rest of this file)
+// TemplatedVocabulary::loadFromTextFile, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1423, read with the same stream
+// operations.  One decision where the reference is undefined: its `while(!f.eof())` loop runs once more on the empty string after the
+// final newline and appends a node from uninitialised locals; here an empty line ends nothing and adds nothing.
+namespace {
+struct OrcVocab { int k = 0, L = 0, scoring = 0, weighting = 0; std::vector<int32_t> parent, wordId; std::vector<std::vector<int32_t>> children; std::vector<uint8_t> desc; std::vector<double> weight; };
+OrcVocab g_vocab;
+}
+int orc_vocab_load_text(const char* path, int* k, int* L, int* scoring, int* weighting, int* nnodes, int* nwords) {
+    std::ifstream f(path);
+    if (!f.is_open()) return -1;
+    OrcVocab v;
+    std::string s;
+    std::getline(f, s);
+    std::stringstream ss; ss << s;
+    int n1 = -1, n2 = -1; v.k = -1; v.L = -1;
+    ss >> v.k; ss >> v.L; ss >> n1; ss >> n2;
+    if (v.k < 0 || v.k > 20 || v.L < 1 || v.L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) return -2;
+    v.scoring = n1; v.weighting = n2;
+    v.parent.assign(1, -1); v.wordId.assign(1, 0); v.children.resize(1); v.desc.assign(32, 0); v.weight.assign(1, 0.0);
+    int words = 0;
+    while (!f.eof()) {
+        std::string snode;
+        std::getline(f, snode);
+        std::stringstream ssnode; ssnode << snode;
+        int pid;
+        if (!(ssnode >> pid)) continue;
+        const int nid = (int)v.parent.size();
+        if (pid < 0 || pid >= nid) return -3;
+        v.parent.push_back(pid); v.children.resize(nid + 1); v.children[pid].push_back(nid);
+        int nIsLeaf = 0; ssnode >> nIsLeaf;
+        v.desc.resize(v.desc.size() + 32, 0);
+        for (int i = 0; i < 32; ++i) { int n; ssnode >> n; if (!ssnode.fail()) v.desc[(size_t)nid * 32 + i] = (unsigned char)n; }      // FORB::fromString, FORB.cpp:120-135
+        double w = 0; ssnode >> w; v.weight.push_back(w);
+        if (nIsLeaf > 0) v.wordId.push_back(words++); else v.wordId.push_back(0);
+    }
+    g_vocab = v;
+    *k = v.k; *L = v.L; *scoring = v.scoring; *weighting = v.weighting; *nnodes = (int)v.parent.size(); *nwords = words;
+    return 0;
+}
+// the loaded tree as the CSR arrays orc_bow_transform / sslam_vocab_create take
+int orc_vocab_arrays(int32_t* childPtr, int32_t* children, uint8_t* nodeDesc, int32_t* wordId, double* weight) {
+    const OrcVocab& v = g_vocab; const int n = (int)v.parent.size();
+    int c = 0; childPtr[0] = 0;
+    for (int i = 0; i < n; ++i) { for (int ch : v.children[i]) children[c++] = ch; childPtr[i + 1] = c; }
+    std::memcpy(nodeDesc, v.desc.data(), v.desc.size()); std::memcpy(wordId, v.wordId.data(), 4 * (size_t)n); std::memcpy(weight, v.weight.data(), 8 * (size_t)n);
+    return 0;
+}
+// TemplatedVocabulary::transform(features, v, fv, levelsup), TemplatedVocabulary.h:1126-1208 with BowVector.cpp:34-85 and
+// FeatureVector.cpp:30-44; the two maps come back flattened in key order.
+int orc_compute_bow(int nnodes, int levels, const int32_t* childPtr, const int32_t* children, const uint8_t* nodeDesc, const int32_t* wordId, const double* weight,
+                    int weighting, int scoring, const uint8_t* feat, int n, int levelsup,
+                    int32_t* bowWord, double* bowValue, int32_t* nbow, int32_t* fvNode, int32_t* fvPtr, int32_t* fvFeat, int32_t* nfv) {
+    std::vector<int32_t> w(n), nd(n); std::vector<double> wt(n);
+    orc_bow_transform(nnodes, levels, childPtr, children, nodeDesc, wordId, weight, feat, n, levelsup, w.data(), wt.data(), nd.data());
+    std::map<int32_t, double> v; std::map<int32_t, std::vector<unsigned>> fv;
+    const bool must = scoring != 5, l2 = scoring == 1;          // ScoringObject.h:74-89
+    if (weighting == 0 || weighting == 1) {                      // TF_IDF, TF
+        for (int i = 0; i < n; ++i) if (wt[i] > 0) {
+            auto vit = v.lower_bound(w[i]);
+            if (vit != v.end() && !(v.key_comp()(w[i], vit->first))) vit->second += wt[i]; else v.insert(vit, std::make_pair(w[i], wt[i]));
+            fv[nd[i]].push_back((unsigned)i);
+        }
+        if (!v.empty() && !must) { const double ndv = (double)v.size(); for (auto& kv : v) kv.second /= ndv; }
+    } else {                                                      // IDF, BINARY
+        for (int i = 0; i < n; ++i) if (wt[i] > 0) {
+            auto vit = v.lower_bound(w[i]);
+            if (vit == v.end() || v.key_comp()(w[i], vit->first)) v.insert(vit, std::make_pair(w[i], wt[i]));
+            fv[nd[i]].push_back((unsigned)i);
+        }
+    }
+    if (must) {
+        double norm = 0.0;
+        if (!l2) { for (auto& kv : v) norm += std::fabs(kv.second); }
+        else { for (auto& kv : v) norm += kv.second * kv.second; norm = std::sqrt(norm); }
+        if (norm > 0.0) for (auto& kv : v) kv.second /= norm;
+    }
+    int j = 0; for (auto& kv : v) { bowWord[j] = kv.first; bowValue[j] = kv.second; ++j; }
+    *nbow = j;
+    int a = 0, c = 0; fvPtr[0] = 0;
+    for (auto& kv : fv) { fvNode[a] = kv.first; for (unsigned idx : kv.second) fvFeat[c++] = (int32_t)idx; fvPtr[++a] = c; }
+    *nfv = a;
     return 0;
 }
 

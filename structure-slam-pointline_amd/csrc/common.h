@@ -83,6 +83,7 @@ struct sslam_frame {
 struct sslam_vocab {
     sslam_ctx* ctx = nullptr;
     int nnodes = 0, levels = 0;
+    int k = 0, nwords = 0, scoring = 0 /* L1_NORM */, weighting = 0 /* TF_IDF */;      // DBoW2 BowVector.h:36-53
     sslam::DevBuf childPtr, children, desc, wordId, weight;
 };
 

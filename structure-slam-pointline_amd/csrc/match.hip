@@ -524,6 +524,7 @@ extern "C" int sslam_vocab_create(sslam_ctx* ctx, int nnodes, int levels, const 
     SSLAM_HIP(hipSetDevice(ctx->device));
     sslam_vocab* v = new sslam_vocab();
     v->ctx = ctx; v->nnodes = nnodes; v->levels = levels;
+    for (int i = 1; i < nnodes; ++i) v->nwords += child_ptr[i + 1] == child_ptr[i];
     int rc;
     if ((rc = v->childPtr.ensure(4 * (size_t)(nnodes + 1))) || (rc = v->children.ensure(std::max<size_t>(4 * (size_t)nch, 256))) || (rc = v->desc.ensure(32 * (size_t)nnodes)) ||
         (rc = v->wordId.ensure(4 * (size_t)nnodes)) || (rc = v->weight.ensure(8 * (size_t)nnodes))) { sslam_vocab_destroy(v); return rc; }

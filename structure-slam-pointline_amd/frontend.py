@@ -159,6 +159,40 @@ class Vocabulary:
         weight = np.ascontiguousarray(weight, np.float64)
         _chk(lib().sslam_vocab_create(ctx.h, len(child_ptr) - 1, int(levels), _p(child_ptr), _p(children), _p(node_desc), _p(word_id), _p(weight), C.byref(self.h)))
 
+    @classmethod
+    def from_text_file(cls, ctx, path):
+        """ORBVocabulary::loadFromTextFile (src/System.cc:64-73): an ORBvoc.txt-format file -> device-resident tree"""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        _chk(lib().sslam_vocab_load_text(ctx.h, str(path).encode(), C.byref(self.h)))
+        return self
+
+    def info(self):
+        v = [C.c_int() for _ in range(6)]
+        _chk(lib().sslam_vocab_info(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("k", "levels", "scoring", "weighting", "nnodes", "nwords"), (x.value for x in v)))
+
+    def set_types(self, weighting=0, scoring=0):
+        _chk(lib().sslam_vocab_set_types(self.h, int(weighting), int(scoring)))
+
+    def compute_bow(self, desc, levelsup=4):
+        """Frame::ComputeBoW (src/Frame.cc:474-481): -> (BowVector as {word: value}, FeatureVector as {node: [feature indices]}), both in key order"""
+        if isinstance(desc, Frame):
+            n = len(desc)
+        else:
+            desc = np.ascontiguousarray(desc, np.uint8); n = len(desc)
+        m = max(n, 1)
+        bw = np.zeros(m, np.int32); bv = np.zeros(m, np.float64); fn = np.zeros(m, np.int32); fp = np.zeros(n + 1, np.int32); ff = np.zeros(m, np.int32)
+        nb, nf = C.c_int(), C.c_int()
+        if isinstance(desc, Frame):
+            _chk(lib().sslam_compute_bow_frame(self.ctx.h, self.h, desc.h, int(levelsup), _p(bw), _p(bv), C.byref(nb), _p(fn), _p(fp), _p(ff), C.byref(nf)))
+        else:
+            _chk(lib().sslam_compute_bow(self.ctx.h, self.h, _p(desc), n, int(levelsup), _p(bw), _p(bv), C.byref(nb), _p(fn), _p(fp), _p(ff), C.byref(nf)))
+        bow = {int(bw[i]): float(bv[i]) for i in range(nb.value)}
+        fv = {int(fn[j]): ff[fp[j]:fp[j + 1]].tolist() for j in range(nf.value)}
+        return bow, fv
+
     def transform(self, desc, levelsup=4):
         """per feature: (word id, word weight, node at level L - levelsup) -- Frame::ComputeBoW's device part"""
         if isinstance(desc, Frame):

@@ -3,6 +3,8 @@
 // the members that method reads, so the body of the reference method becomes one call
 // (INTEGRATION.md shows the patch).
 #pragma once
+#include <map>
+#include <string>
 #include <utility>
 #include <vector>
 #include "cv_min.h"
@@ -39,6 +41,27 @@ void KnnMatch2(const cv::Mat &query, const cv::Mat &train, std::vector<int> &idx
 // (src/MapLine.cpp:280-311): index of the observed descriptor with the least median Hamming distance to the others
 // (replaces the N x N loop + per-row sort; `BestIdx = sslam_shim::DistinctiveIndex(vDescriptors);`).
 int DistinctiveIndex(const std::vector<cv::Mat> &vDescriptors);
+
+// ORBVocabulary (include/ORBVocabulary.h:31-32 = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>): the two members the
+// reference calls on the hot path -- loadFromTextFile (src/System.cc:64-73) and transform(features, BowVector&, FeatureVector&,
+// levelsup) (Frame::ComputeBoW src/Frame.cc:474-481, KeyFrame::ComputeBoW src/KeyFrame.cc:71-80).  BowVector / FeatureVector keep
+// DBoW2's container types (std::map<WordId, WordValue>, std::map<NodeId, std::vector<unsigned> >), so
+// `mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4);` compiles unchanged against this class.
+typedef std::map<unsigned int, double> BowVector;
+typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;
+class ORBVocabulary
+{
+public:
+    ORBVocabulary();
+    ~ORBVocabulary();
+    bool loadFromTextFile(const std::string &filename);
+    bool empty() const;
+    unsigned int size() const;                  // number of words
+    void transform(const std::vector<cv::Mat> &features, BowVector &v, FeatureVector &fv, int levelsup) const;
+private:
+    ORBVocabulary(const ORBVocabulary &); ORBVocabulary &operator=(const ORBVocabulary &);
+    void *mHandle;
+};
 
 // LSDmatcher::SerachForInitialize / SearchForTriangulation (gate_scale 0.5 / 0.1) and, with ratioMode,
 // SearchByProjection(KF,F) / SearchByDescriptor (src/LSDmatcher.cpp:143-183,257-362,382-415).

@@ -159,6 +159,33 @@ int DistinctiveIndex(const std::vector<cv::Mat> &vDescriptors) {
     check(sslam_distinctive_descriptors(G.get(), d.data(), ptr, 1, &best));
     return best;
 }
+ORBVocabulary::ORBVocabulary() : mHandle(nullptr) {}
+ORBVocabulary::~ORBVocabulary() { if (mHandle) sslam_vocab_destroy((sslam_vocab*)mHandle); }
+bool ORBVocabulary::loadFromTextFile(const std::string &filename) {
+    sslam_vocab* v = nullptr;
+    if (sslam_vocab_load_text(G.get(), filename.c_str(), &v) != SSLAM_OK) return false;      // the reference returns false on a bad file (TemplatedVocabulary.h:1359-1363)
+    if (mHandle) sslam_vocab_destroy((sslam_vocab*)mHandle);
+    mHandle = v;
+    return true;
+}
+bool ORBVocabulary::empty() const { return mHandle == nullptr || size() == 0; }
+unsigned int ORBVocabulary::size() const {
+    int nwords = 0;
+    if (mHandle) check(sslam_vocab_info((const sslam_vocab*)mHandle, nullptr, nullptr, nullptr, nullptr, nullptr, &nwords));
+    return (unsigned int)nwords;
+}
+void ORBVocabulary::transform(const std::vector<cv::Mat> &features, BowVector &v, FeatureVector &fv, int levelsup) const {
+    v.clear(); fv.clear();
+    const int n = (int)features.size();
+    if (empty() || n == 0) return;                          // TemplatedVocabulary.h:1131-1137
+    std::vector<uint8_t> d((size_t)n * 32);
+    for (int i = 0; i < n; ++i) memcpy(&d[(size_t)i * 32], features[i].ptr(0), 32);
+    std::vector<int32_t> bw(n), fn(n), fp(n + 1), ff(n); std::vector<double> bv(n);
+    int nb = 0, nf = 0;
+    check(sslam_compute_bow(G.get(), (const sslam_vocab*)mHandle, d.data(), n, levelsup, bw.data(), bv.data(), &nb, fn.data(), fp.data(), ff.data(), &nf));
+    for (int i = 0; i < nb; ++i) v.insert(v.end(), std::make_pair((unsigned int)bw[i], bv[i]));
+    for (int j = 0; j < nf; ++j) fv.insert(fv.end(), std::make_pair((unsigned int)fn[j], std::vector<unsigned int>(ff.begin() + fp[j], ff.begin() + fp[j + 1])));
+}
 int LineMatch(const cv::Mat &l1, const cv::Mat &l2, double gateScale, bool ratioMode, std::vector<std::pair<int,int> > &matches) {
     matches.clear();
     if (l1.rows == 0 || l2.rows < 2) return 0;       // UB in the reference (src/LSDmatcher.cpp:167); defined as no matches

@@ -55,8 +55,24 @@ int main(int argc, char** argv) {
     // MapPoint::ComputeDistinctiveDescriptors over the first rows of the ORB descriptors (src/MapPoint.cc:276-306)
     std::vector<cv::Mat> obs; for (int i = 0; i < std::min(d2.rows, 37); ++i) obs.push_back(d2.row(i));
     const int bestIdx = sslam_shim::DistinctiveIndex(obs);
-    int meta[7] = {(int)k2.size(), (int)l2.size(), nm, nlm, emptyOk, ext->GetLevels(), bestIdx};
-    dump(out + "_meta.bin", meta, 7);
+    // Frame::ComputeBoW (src/Frame.cc:474-481) with a vocabulary loaded the way System.cc:64-73 does
+    int nWords = -1;
+    if (argc > 8) {
+        sslam_shim::ORBVocabulary voc;
+        if (!voc.loadFromTextFile(argv[8])) return 3;
+        nWords = (int)voc.size();
+        std::vector<cv::Mat> vCurrentDesc; for (int j = 0; j < d2.rows; ++j) vCurrentDesc.push_back(d2.row(j));      // Converter::toDescriptorVector
+        sslam_shim::BowVector bowVec; sslam_shim::FeatureVector featVec;
+        voc.transform(vCurrentDesc, bowVec, featVec, 2);
+        std::vector<double> bow; for (auto& kv : bowVec) { bow.push_back((double)kv.first); bow.push_back(kv.second); }
+        std::vector<int> fv; for (auto& kv : featVec) { fv.push_back((int)kv.first); fv.push_back((int)kv.second.size()); for (unsigned f : kv.second) fv.push_back((int)f); }
+        dump(out + "_bow.bin", bow.data(), bow.size());
+        dump(out + "_fv.bin", fv.data(), fv.size());
+        sslam_shim::ORBVocabulary bad;
+        if (bad.loadFromTextFile(std::string(argv[8]) + ".missing") || !bad.empty()) return 4;
+    }
+    int meta[8] = {(int)k2.size(), (int)l2.size(), nm, nlm, emptyOk, ext->GetLevels(), bestIdx, nWords};
+    dump(out + "_meta.bin", meta, 8);
     std::printf("shim_test: %zu keypoints, %zu lines, %d ORB matches, %d line matches\n", k2.size(), l2.size(), nm, nlm);
     delete ext;
     return 0;

@@ -176,13 +176,38 @@ def _orc_match_methods():
                                  int(levelsup), _p(w), _p(v), _p(nd))
         return w, v, nd
 
+    def vocab_load_text(self, path):
+        """-> dict(k, levels, scoring, weighting, nwords, child_ptr, children, node_desc, word_id, weight)"""
+        import ctypes as C
+        k, L, sc, wg, nn, nw = (C.c_int() for _ in range(6))
+        rc = self.L.orc_vocab_load_text(str(path).encode(), C.byref(k), C.byref(L), C.byref(sc), C.byref(wg), C.byref(nn), C.byref(nw))
+        if rc != 0:
+            raise ValueError("orc_vocab_load_text failed: %d" % rc)
+        n = nn.value
+        cp = np.zeros(n + 1, np.int32); ch = np.zeros(max(n - 1, 1), np.int32); nd = np.zeros((n, 32), np.uint8); wi = np.zeros(n, np.int32); wt = np.zeros(n, np.float64)
+        self.L.orc_vocab_arrays(_p(cp), _p(ch), _p(nd), _p(wi), _p(wt))
+        return dict(k=k.value, levels=L.value, scoring=sc.value, weighting=wg.value, nwords=nw.value, child_ptr=cp, children=ch[:n - 1], node_desc=nd, word_id=wi, weight=wt)
+
+    def compute_bow(self, levels, child_ptr, children, node_desc, word_id, weight, feat, levelsup=4, weighting=0, scoring=0):
+        """-> (bow_word, bow_value, fv_node, fv_ptr, fv_feat): BowVector and FeatureVector flattened in key order"""
+        import ctypes as C
+        child_ptr = np.ascontiguousarray(child_ptr, np.int32); children = np.ascontiguousarray(children, np.int32)
+        node_desc = np.ascontiguousarray(node_desc, np.uint8); word_id = np.ascontiguousarray(word_id, np.int32)
+        weight = np.ascontiguousarray(weight, np.float64); feat = np.ascontiguousarray(feat, np.uint8)
+        n = len(feat)
+        bw = np.zeros(max(n, 1), np.int32); bv = np.zeros(max(n, 1), np.float64); fn = np.zeros(max(n, 1), np.int32); fp = np.zeros(n + 1, np.int32); ff = np.zeros(max(n, 1), np.int32)
+        nb, nf = C.c_int32(), C.c_int32()
+        self.L.orc_compute_bow(len(child_ptr) - 1, int(levels), _p(child_ptr), _p(children), _p(node_desc), _p(word_id), _p(weight), int(weighting), int(scoring),
+                               _p(feat), n, int(levelsup), _p(bw), _p(bv), C.byref(nb), _p(fn), _p(fp), _p(ff), C.byref(nf))
+        return bw[:nb.value], bv[:nb.value], fn[:nf.value], fp[:nf.value + 1], ff[:fp[nf.value]]
+
     def distinctive(self, desc, ptr):
         desc = np.ascontiguousarray(desc, np.uint8); ptr = np.ascontiguousarray(ptr, np.int32)
         best = np.zeros(len(ptr) - 1, np.int32)
         self.L.orc_distinctive(_p(desc), _p(ptr), len(ptr) - 1, _p(best))
         return best
 
-    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, distinctive, fuse_search, search_for_triangulation, bow_transform):
+    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, distinctive, fuse_search, search_for_triangulation, bow_transform, vocab_load_text, compute_bow):
         setattr(Oracle, f.__name__, f)
 
 

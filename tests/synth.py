@@ -86,3 +86,48 @@ def ramp_frame(seed=3, w=640, h=480):
     rng = np.random.Generator(np.random.PCG64(seed))
     img = img + rng.normal(0, 1.0, img.shape)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def synthetic_vocab(rng, k=10, L=4):
+    """a ragged DBoW2-style tree in DBoW2's node numbering (root 0, parent id < child id): (L, child_ptr, children, node_desc, word_id, weight)"""
+    ptr = [0]; children = []; desc = [np.zeros(32, np.uint8)]; level_of = [0]
+    parent_desc = {0: rng.integers(0, 256, 32, dtype=np.uint8)}
+    frontier = [0]; nid = 1
+    child_lists = {}
+    for lvl in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            kk = k if not (lvl == L and p % 7 == 3) else 0           # some level L-1 nodes stay leaves (ragged tree)
+            ids = list(range(nid, nid + kk)); nid += kk
+            child_lists[p] = ids
+            for c in ids:
+                flips = rng.random(256) < 0.5 / lvl
+                parent_desc[c] = parent_desc[p] ^ np.packbits(flips)
+                level_of.append(lvl)
+            nxt += ids
+        frontier = nxt
+    n = nid
+    ptr = np.zeros(n + 1, np.int32); ch = []
+    for i in range(n):
+        ids = child_lists.get(i, [])
+        ch += ids; ptr[i + 1] = len(ch)
+    desc = np.stack([parent_desc[i] for i in range(n)])
+    leaf = np.array([len(child_lists.get(i, [])) == 0 for i in range(n)])
+    word = np.full(n, -1, np.int32); word[leaf] = np.arange(leaf.sum(), dtype=np.int32)
+    weight = np.zeros(n, np.float64); weight[leaf] = np.where(rng.random(leaf.sum()) < 0.05, 0.0, rng.uniform(0.1, 9.0, leaf.sum()))
+    return L, ptr, np.array(ch, np.int32), desc, word, weight
+
+
+def write_vocab_text(path, k, L, ptr, children, desc, weight, scoring=0, weighting=0, weight_fmt="%r", trailing_newline=True):
+    """the file TemplatedVocabulary::saveToTextFile writes (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1428-1455): header
+    "k L  scoring weighting", then "parent isLeaf d0 .. d31 weight" per node from id 1"""
+    n = len(ptr) - 1
+    parent = np.zeros(n, np.int64)
+    for p in range(n):
+        parent[children[ptr[p]:ptr[p + 1]]] = p
+    lines = ["%d %d  %d %d" % (k, L, scoring, weighting)]
+    for i in range(1, n):
+        leaf = int(ptr[i + 1] == ptr[i])
+        lines.append("%d %d %s %s" % (parent[i], leaf, " ".join(str(int(b)) for b in desc[i]), weight_fmt % float(weight[i])))
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + ("\n" if trailing_newline else ""))

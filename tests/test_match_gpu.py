@@ -1,7 +1,7 @@
 """GPU parity: Hamming matchers vs the oracle (bit-exact indices, distances, match arrays)."""
 import numpy as np
 import pytest
-from synth import synth_frame, warp_prev
+from synth import synth_frame, warp_prev, synthetic_vocab, write_vocab_text
 
 pytestmark = pytest.mark.gpu
 
@@ -282,39 +282,10 @@ def test_search_for_triangulation(fe, ctx, oracle, seed, only_stereo, ori):
 
 # ---- DBoW2 vocabulary descent, Frame::ComputeBoW.  The ORBvoc file is an LFS pointer in the reference
 # tree, so the tree here is synthetic: k-ary, L levels, clustered node descriptors, a few stopped words (weight 0) and a ragged branch.
-def _synthetic_vocab(rng, k=10, L=4):
-    ptr = [0]; children = []; desc = [np.zeros(32, np.uint8)]; level_of = [0]
-    parent_desc = {0: rng.integers(0, 256, 32, dtype=np.uint8)}
-    frontier = [0]; nid = 1
-    child_lists = {}
-    for lvl in range(1, L + 1):
-        nxt = []
-        for p in frontier:
-            kk = k if not (lvl == L and p % 7 == 3) else 0           # some level L-1 nodes stay leaves (ragged tree)
-            ids = list(range(nid, nid + kk)); nid += kk
-            child_lists[p] = ids
-            for c in ids:
-                flips = rng.random(256) < 0.5 / lvl
-                parent_desc[c] = parent_desc[p] ^ np.packbits(flips)
-                level_of.append(lvl)
-            nxt += ids
-        frontier = nxt
-    n = nid
-    ptr = np.zeros(n + 1, np.int32); ch = []
-    for i in range(n):
-        ids = child_lists.get(i, [])
-        ch += ids; ptr[i + 1] = len(ch)
-    desc = np.stack([parent_desc[i] for i in range(n)])
-    leaf = np.array([len(child_lists.get(i, [])) == 0 for i in range(n)])
-    word = np.full(n, -1, np.int32); word[leaf] = np.arange(leaf.sum(), dtype=np.int32)
-    weight = np.zeros(n, np.float64); weight[leaf] = np.where(rng.random(leaf.sum()) < 0.05, 0.0, rng.uniform(0.1, 9.0, leaf.sum()))
-    return L, ptr, np.array(ch, np.int32), desc, word, weight
-
-
 @pytest.mark.parametrize("levelsup", [4, 2, 0, 6])
 def test_bow_transform(fe, ctx, oracle, levelsup):
     rng = np.random.default_rng(5)
-    L, ptr, ch, nd, word, weight = _synthetic_vocab(rng)
+    L, ptr, ch, nd, word, weight = synthetic_vocab(rng)
     kp, d = oracle.orb_extract(synth_frame(1234), 1000)
     feat = np.concatenate([d, nd[rng.integers(1, len(nd), 200)]])        # real descriptors + exact node descriptors (distance-0 ties)
     voc = fe.Vocabulary(ctx, L, ptr, ch, nd, word, weight)
@@ -347,3 +318,49 @@ def test_search_by_bow_overlapping_nodes(fe, ctx, oracle):
     oa, on = oracle.search_by_bow(kp1, d1, valid, kp2, d2, pk, pf2, ik, jf2, 0.8, True)
     assert on > 30 and n == on
     np.testing.assert_array_equal(a, oa)
+
+
+def _bow_sets(bw, bv, fn, fp, ff):
+    return {int(w): float(v) for w, v in zip(bw, bv)}, {int(fn[j]): ff[fp[j]:fp[j + 1]].tolist() for j in range(len(fn))}
+
+
+@pytest.mark.parametrize("weighting,scoring", [(0, 0), (1, 5), (2, 1), (3, 0)])
+def test_vocabulary_text_file_and_compute_bow(fe, ctx, oracle, tmp_path, weighting, scoring):
+    """System.cc:64-73 + Frame::ComputeBoW end to end: ORBvoc.txt-format file -> device tree -> BowVector / FeatureVector"""
+    rng = np.random.default_rng(11)
+    L, ptr, ch, nd, word, weight = synthetic_vocab(rng, k=9, L=3)
+    path = tmp_path / "voc.txt"
+    write_vocab_text(path, 9, L, ptr, ch, nd, weight, scoring=scoring, weighting=weighting, weight_fmt="%.6g")
+    ov = oracle.vocab_load_text(path)
+    voc = fe.Vocabulary.from_text_file(ctx, path)
+    info = voc.info()
+    assert info == dict(k=9, levels=L, scoring=scoring, weighting=weighting, nnodes=len(ptr) - 1, nwords=ov["nwords"])
+    kp, d = oracle.orb_extract(synth_frame(1234), 1000)
+    feat = np.concatenate([d, nd[rng.integers(1, len(nd), 100)]])
+    w, v, n = voc.transform(feat, 2)
+    ow, ovv, on = oracle.bow_transform(ov["levels"], ov["child_ptr"], ov["children"], ov["node_desc"], ov["word_id"], ov["weight"], feat, 2)
+    np.testing.assert_array_equal(w, ow); np.testing.assert_array_equal(v, ovv); np.testing.assert_array_equal(n, on)
+    bow, fv = voc.compute_bow(feat, 2)
+    obow, ofv = _bow_sets(*oracle.compute_bow(ov["levels"], ov["child_ptr"], ov["children"], ov["node_desc"], ov["word_id"], ov["weight"], feat, 2, weighting, scoring))
+    assert list(bow.keys()) == list(obow.keys()) and list(bow.values()) == list(obow.values())        # bit-equal doubles, same key order
+    assert fv == ofv and len(bow) > 100 and len(fv) > 5
+    assert sorted(sum(fv.values(), [])) == [i for i in range(len(feat)) if ovv[i] > 0]                 # stopped words drop their features
+    if scoring != 5:
+        norm = sum(abs(x) for x in bow.values()) if scoring != 1 else sum(x * x for x in bow.values()) ** 0.5
+        assert abs(norm - 1.0) < 1e-12
+    fr = ctx.frame_upload(0, kp, d)
+    bow2, fv2 = voc.compute_bow(fr, 2)
+    obow2, ofv2 = _bow_sets(*oracle.compute_bow(ov["levels"], ov["child_ptr"], ov["children"], ov["node_desc"], ov["word_id"], ov["weight"], d, 2, weighting, scoring))
+    assert bow2 == obow2 and fv2 == ofv2
+    e_bow, e_fv = voc.compute_bow(np.zeros((0, 32), np.uint8))
+    assert e_bow == {} and e_fv == {}
+    fr.close(); voc.close()
+
+
+def test_vocabulary_text_file_rejects_garbage(fe, ctx, tmp_path):
+    for name, text in (("hdr", "25 6 0 0\n0 1 " + "0 " * 32 + "1.0\n"), ("short", "10 3 0 0\n0 1 1 2 3 0.5\n"), ("parent", "10 3 0 0\n5 1 " + "0 " * 32 + "1.0\n")):
+        p = tmp_path / (name + ".txt"); p.write_text(text)
+        with pytest.raises(Exception):
+            fe.Vocabulary.from_text_file(ctx, p)
+    with pytest.raises(Exception):
+        fe.Vocabulary.from_text_file(ctx, tmp_path / "missing.txt")

@@ -156,3 +156,44 @@ def test_line_equations_and_keylines(oracle):
         np.testing.assert_allclose(fn[i], l, rtol=1e-12, atol=1e-12)
         assert abs(fn[i] @ np.array([sx, sy, 1.0])) < 1e-6 and abs(np.hypot(fn[i][0], fn[i][1]) - 1) < 1e-12
         assert kl["numOfPixels"][i] == max(abs(round(ex) - round(sx)), abs(round(ey) - round(sy))) + 1
+
+
+def test_vocabulary_text_loader_and_bow_vector(oracle, tmp_path):
+    """oracle side of ORBVocabulary::loadFromTextFile + transform(features, BowVector, FeatureVector, levelsup) against a
+    brute-force numpy restatement on a small ragged tree"""
+    from synth import synthetic_vocab, write_vocab_text
+    rng = np.random.default_rng(2)
+    L, ptr, ch, nd, word, weight = synthetic_vocab(rng, k=5, L=3)
+    for fmt, nl in (("%r", True), ("%.6g", False)):
+        path = tmp_path / "voc.txt"
+        write_vocab_text(path, 5, L, ptr, ch, nd, weight, weight_fmt=fmt, trailing_newline=nl)
+        v = oracle.vocab_load_text(path)
+        assert (v["k"], v["levels"], v["scoring"], v["weighting"]) == (5, L, 0, 0)
+        np.testing.assert_array_equal(v["child_ptr"], ptr); np.testing.assert_array_equal(v["children"], ch); np.testing.assert_array_equal(v["node_desc"][1:], nd[1:])      # the root is not in the file
+        leaf = ptr[1:] == ptr[:-1]
+        np.testing.assert_array_equal(v["word_id"][leaf], word[leaf]); assert v["nwords"] == leaf.sum()
+        np.testing.assert_array_equal(v["weight"][1:], np.array([float(fmt % float(x)) for x in weight[1:]]))
+    feat = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    w = v["weight"]
+    # brute force: descend by minimum Hamming distance, first child wins ties
+    words, nodes, wts = [], [], []
+    for f in feat:
+        cur, lvl, nid = 0, 0, 0
+        while ptr[cur + 1] > ptr[cur]:
+            kids = ch[ptr[cur]:ptr[cur + 1]]
+            dist = np.unpackbits(nd[kids] ^ f, axis=1).sum(axis=1)
+            cur = int(kids[int(np.argmin(dist))]); lvl += 1
+            if lvl == L - 1:
+                nid = cur
+        words.append(int(v["word_id"][cur])); nodes.append(nid); wts.append(float(w[cur]))
+    bow, fv = {}, {}
+    for i, (wd, nn, wt) in enumerate(zip(words, nodes, wts)):
+        if wt > 0:
+            bow[wd] = bow.get(wd, 0.0) + wt if wd in bow else wt
+            fv.setdefault(nn, []).append(i)
+    keys = sorted(bow); norm = 0.0
+    for kk in keys:
+        norm += abs(bow[kk])
+    bw, bv, fn, fp, ff = oracle.compute_bow(L, ptr, ch, nd, v["word_id"], w, feat, levelsup=1)
+    assert bw.tolist() == keys and bv.tolist() == [bow[kk] / norm for kk in keys]
+    assert fn.tolist() == sorted(fv) and [ff[fp[j]:fp[j + 1]].tolist() for j in range(len(fn))] == [fv[kk] for kk in sorted(fv)]
