@@ -275,6 +275,16 @@ int sslam_orb_search_by_bow(sslam_ctx* ctx, const sslam_keypoint* kf_kp, const u
                             const int32_t* kf_idx, const int32_t* f_idx, float nnratio, int check_orientation,
                             int32_t* assigned_out, int* nmatches_out);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12), src/ORBmatcher.cc:525-658 (loop closing,
+ * src/LoopClosing.cc:271): same node walk; kfX_valid[i] = vpMapPointsX[i] && !isBad(); a candidate of the second keyframe is skipped
+ * when it is already matched or has no good map point (:576-580); the gate is `bestDist1 < TH_LOW` (strict, :600).
+ * matches12_out[i] = feature of the second keyframe whose map point goes into vpMatches12[i], or -1. */
+int sslam_orb_search_by_bow_keyframes(sslam_ctx* ctx, const sslam_keypoint* kf1_kp, const uint8_t* kf1_desc, const uint8_t* kf1_valid, int n1,
+                                      const sslam_keypoint* kf2_kp, const uint8_t* kf2_desc, const uint8_t* kf2_valid, int n2,
+                                      const int32_t* node_kf1_ptr, const int32_t* node_kf2_ptr, int nnodes,
+                                      const int32_t* kf1_idx, const int32_t* kf2_idx, float nnratio, int check_orientation,
+                                      int32_t* matches12_out, int* nmatches_out);
+
 /* LSDmatcher::SerachForInitialize(InitialFrame,CurrentFrame,LineMatches),
  * src/LSDmatcher.cpp:257-284 = knn2 + Frame::lineDescriptorMAD (src/Frame.cc:190-215)
  * + the `d2-d1 > 0.5*MAD12` gate.  pairs_out[cap*2] (qdx,tdx); gate_scale = 0.5

@@ -583,6 +583,55 @@ int orc_fuse_search(int kind, int chi2, const void* feats, const uint8_t* desc, 
     return 0;
 }
 
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12), src/ORBmatcher.cc:525-658.
+// matches12[idx1] = idx2 stands for vpMatches12[idx1] = vpMapPoints2[idx2].
+int orc_search_by_bow_keyframes(const void* kp1v, const uint8_t* d1, const uint8_t* valid1, int n1, const void* kp2v, const uint8_t* d2, const uint8_t* valid2, int n2,
+                                const int32_t* ptr1, const int32_t* ptr2, int nnodes, const int32_t* idx1s, const int32_t* idx2s, float nnratio, int check_ori,
+                                int32_t* matches12) {
+    const KPm* kp1 = (const KPm*)kp1v; const KPm* kp2 = (const KPm*)kp2v;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    std::vector<char> vbMatched2((size_t)n2, 0);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int nd = 0; nd < nnodes; ++nd) {
+        for (int a = ptr1[nd]; a < ptr1[nd + 1]; ++a) {
+            const int idx1 = idx1s[a];
+            if (!valid1[idx1]) continue;                                    // :561-566
+            int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+            for (int b = ptr2[nd]; b < ptr2[nd + 1]; ++b) {
+                const int idx2 = idx2s[b];
+                if (vbMatched2[idx2] || !valid2[idx2]) continue;            // :576-580
+                const int dist = descriptor_distance(d1 + (size_t)idx1 * 32, d2 + (size_t)idx2 * 32);
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 < TH_LOW) {
+                if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                    matches12[idx1] = bestIdx2; vbMatched2[bestIdx2] = 1;
+                    if (check_ori) {
+                        float rot = kp1[idx1].angle - kp2[bestIdx2].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(idx1);
+                    }
+                    nmatches++;
+                }
+            }
+        }
+    }
+    if (check_ori) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { matches12[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 int orc_search_by_bow(const void* kpKF, const uint8_t* dKF, const uint8_t* validKF, const void* kpF, const uint8_t* dF, int nF,
                       const int32_t* ptrKF, const int32_t* ptrF, int nnodes, const int32_t* idxKF, const int32_t* idxF, float nnratio, int check_ori,
                       int32_t* assigned) {

@@ -332,10 +332,10 @@ extern "C" int sslam_hamming_knn2_frames(sslam_ctx* ctx, const sslam_frame* q, c
     return SSLAM_OK;
 }
 
-extern "C" int sslam_orb_search_by_bow(sslam_ctx* ctx, const sslam_keypoint* kf_kp, const uint8_t* kf_desc, const uint8_t* kf_valid, int nkf,
-                                       const sslam_keypoint* f_kp, const uint8_t* f_desc, int nf, const int32_t* node_kf_ptr, const int32_t* node_f_ptr,
-                                       int nnodes, const int32_t* kf_idx, const int32_t* f_idx, float nnratio, int check_orientation,
-                                       int32_t* assigned_out, int* nmatches_out) {
+static int search_by_bow_core(sslam_ctx* ctx, const sslam_keypoint* kf_kp, const uint8_t* kf_desc, const uint8_t* kf_valid, int nkf,
+                              const sslam_keypoint* f_kp, const uint8_t* f_desc, const uint8_t* f_valid, int nf, const int32_t* node_kf_ptr, const int32_t* node_f_ptr,
+                              int nnodes, const int32_t* kf_idx, const int32_t* f_idx, float nnratio, int check_orientation, int strict_th,
+                              int32_t* assigned_out, int* nmatches_out) {
     if (!ctx || nkf < 0 || nf < 0 || nnodes < 0 || !nmatches_out || (nf > 0 && !assigned_out) ||
         (nnodes > 0 && (!node_kf_ptr || !node_f_ptr || !kf_idx || !f_idx || !kf_kp || !kf_desc || !kf_valid || !f_kp || !f_desc))) {
         set_error("sslam_orb_search_by_bow: invalid arguments"); return SSLAM_ERR_INVALID;
@@ -356,14 +356,16 @@ extern "C" int sslam_orb_search_by_bow(sslam_ctx* ctx, const sslam_keypoint* kf_
     auto take = [&](size_t b) { o[k++] = off; off += al(b); };
     take(ks * nkf); take(32 * (size_t)nkf); take((size_t)nkf); take(ks * nf); take(32 * (size_t)nf);
     take(4 * (size_t)(nnodes + 1)); take(4 * (size_t)(nnodes + 1)); take(4 * (size_t)std::max(nk, 1)); take(4 * (size_t)std::max(nfi, 1));
-    take(4 * (size_t)nf); take(256); take(4 * (size_t)nf);
+    take(4 * (size_t)nf); take(256); take(4 * (size_t)nf); take((size_t)nf);
     int rc;
     if ((rc = ctx->scratch[7].ensure(off))) return rc;
     uint8_t* B = ctx->scratch[7].as<uint8_t>();
     const void* src[9] = {kf_kp, kf_desc, kf_valid, f_kp, f_desc, node_kf_ptr, node_f_ptr, kf_idx, f_idx};
     const size_t len[9] = {ks * nkf, 32 * (size_t)nkf, (size_t)nkf, ks * nf, 32 * (size_t)nf, 4 * (size_t)(nnodes + 1), 4 * (size_t)(nnodes + 1), 4 * (size_t)nk, 4 * (size_t)nfi};
     for (int i = 0; i < 9; ++i) if (len[i]) SSLAM_HIP(hipMemcpyAsync(B + o[i], src[i], len[i], hipMemcpyHostToDevice, st));
+    if (f_valid) SSLAM_HIP(hipMemcpyAsync(B + o[12], f_valid, (size_t)nf, hipMemcpyHostToDevice, st));
     BowArgs A;
+    A.validF = f_valid ? B + o[12] : nullptr; A.strictTh = strict_th;
     A.kpKF = (const sslam_keypoint*)(B + o[0]); A.dKF = B + o[1]; A.validKF = B + o[2]; A.kpF = (const sslam_keypoint*)(B + o[3]); A.dF = B + o[4]; A.nF = nf;
     A.ptrKF = (const int*)(B + o[5]); A.ptrF = (const int*)(B + o[6]); A.nnodes = nnodes; A.idxKF = (const int*)(B + o[7]); A.idxF = (const int*)(B + o[8]);
     A.nnratio = nnratio; A.checkOri = check_orientation; A.assigned = (int*)(B + o[9]); A.nmatches = (int*)(B + o[10]); A.qbin = (int*)(B + o[11]);
@@ -380,6 +382,31 @@ extern "C" int sslam_orb_search_by_bow(sslam_ctx* ctx, const sslam_keypoint* kf_
     SSLAM_HIP(hipMemcpyAsync(assigned_out, B + o[9], 4 * (size_t)nf, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + o[10], sizeof(int), hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_search_by_bow(sslam_ctx* ctx, const sslam_keypoint* kf_kp, const uint8_t* kf_desc, const uint8_t* kf_valid, int nkf,
+                                       const sslam_keypoint* f_kp, const uint8_t* f_desc, int nf, const int32_t* node_kf_ptr, const int32_t* node_f_ptr,
+                                       int nnodes, const int32_t* kf_idx, const int32_t* f_idx, float nnratio, int check_orientation,
+                                       int32_t* assigned_out, int* nmatches_out) {
+    return search_by_bow_core(ctx, kf_kp, kf_desc, kf_valid, nkf, f_kp, f_desc, nullptr, nf, node_kf_ptr, node_f_ptr, nnodes, kf_idx, f_idx, nnratio, check_orientation, 0,
+                              assigned_out, nmatches_out);
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12), src/ORBmatcher.cc:525-658: the same walk with the
+// second keyframe in the frame's role, candidates limited to features that own a good map point, `dist < TH_LOW`, and the result indexed by
+// the first keyframe's features (every feature sits in one node and a taken candidate is skipped, so the map is one-to-one).
+extern "C" int sslam_orb_search_by_bow_keyframes(sslam_ctx* ctx, const sslam_keypoint* kf1_kp, const uint8_t* kf1_desc, const uint8_t* kf1_valid, int n1,
+                                                 const sslam_keypoint* kf2_kp, const uint8_t* kf2_desc, const uint8_t* kf2_valid, int n2,
+                                                 const int32_t* node_kf1_ptr, const int32_t* node_kf2_ptr, int nnodes, const int32_t* kf1_idx, const int32_t* kf2_idx,
+                                                 float nnratio, int check_orientation, int32_t* matches12_out, int* nmatches_out) {
+    if (n1 < 0 || (n1 > 0 && !matches12_out) || (n2 > 0 && nnodes > 0 && !kf2_valid)) { set_error("sslam_orb_search_by_bow_keyframes: invalid arguments"); return SSLAM_ERR_INVALID; }
+    for (int i = 0; i < n1; ++i) matches12_out[i] = -1;
+    std::vector<int32_t> assigned((size_t)std::max(n2, 1), -1);
+    const int rc = search_by_bow_core(ctx, kf1_kp, kf1_desc, kf1_valid, n1, kf2_kp, kf2_desc, kf2_valid, n2, node_kf1_ptr, node_kf2_ptr, nnodes, kf1_idx, kf2_idx, nnratio,
+                                      check_orientation, 1, assigned.data(), nmatches_out);
+    if (rc) return rc;
+    for (int j = 0; j < n2; ++j) if (assigned[j] >= 0) matches12_out[assigned[j]] = j;
     return SSLAM_OK;
 }
 

@@ -274,6 +274,7 @@ struct BowArgs {
     const sslam_keypoint* kpF; const uint8_t* dF; int nF;
     const int* ptrKF; const int* ptrF; int nnodes; const int* idxKF; const int* idxF;
     float nnratio; int checkOri; int* assigned; int* nmatches; int* qbin;   // qbin[nF]: rotation bin recorded for a frame feature
+    const uint8_t* validF; int strictTh;     // KeyFrame-KeyFrame form (:525-658): candidates need a good map point of their own, and the gate is dist < TH_LOW
 };
 
 // A frame feature belongs to one vocabulary node, so the only order dependence of SearchByBoW -- a frame feature that is
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(64) void k_search_bow(BowArgs A) {
             unsigned long long b = ~0ull, s = ~0ull;
             for (int p = f0 + lane; p < f1; p += 64) {
                 const int jf = A.idxF[p];
-                if (A.assigned[jf] >= 0) continue;
+                if (A.assigned[jf] >= 0 || (A.validF && !A.validF[jf])) continue;
                 const uint4* tp = (const uint4*)(A.dF + (size_t)jf * 32);
                 const unsigned long long kk = ((unsigned long long)hamming256(q0, q1, tp[0], tp[1]) << 32) | (unsigned)(p - f0);
                 if (kk < b) { s = b; b = kk; } else if (kk < s) s = kk;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(64) void k_search_bow(BowArgs A) {
             int bestDist1 = 256, bestDist2 = 256, bestIdxF = -1;
             if (best != ~0ull && (int)(best >> 32) < 256) { bestDist1 = (int)(best >> 32); bestIdxF = A.idxF[f0 + (int)(unsigned)best]; }
             if (second != ~0ull && (int)(second >> 32) < 256) bestDist2 = (int)(second >> 32);
-            if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(A.nnratio, (float)bestDist2)) {
+            if ((A.strictTh ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW) && (float)bestDist1 < __fmul_rn(A.nnratio, (float)bestDist2)) {
                 if (lane == 0) {
                     if (A.checkOri) {
                         float rot = __fsub_rn(A.kpKF[ik].angle, A.kpF[bestIdxF].angle);

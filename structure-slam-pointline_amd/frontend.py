@@ -128,6 +128,18 @@ class Context:
                                            _p(assigned), C.byref(nm)))
         return assigned, nm.value
 
+    def search_by_bow_keyframes(self, kp1, d1, valid1, kp2, d2, valid2, ptr1, ptr2, idx1, idx2, nnratio=0.8, check_orientation=True):
+        """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (src/ORBmatcher.cc:525-658): -> (matches12, nmatches)"""
+        kp1 = np.ascontiguousarray(kp1); kp2 = np.ascontiguousarray(kp2)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        valid1 = np.ascontiguousarray(valid1, np.uint8); valid2 = np.ascontiguousarray(valid2, np.uint8)
+        ptr1 = np.ascontiguousarray(ptr1, np.int32); ptr2 = np.ascontiguousarray(ptr2, np.int32)
+        idx1 = np.ascontiguousarray(idx1, np.int32); idx2 = np.ascontiguousarray(idx2, np.int32)
+        m12 = np.full(max(len(kp1), 1), -1, np.int32); nm = C.c_int(0)
+        _chk(lib().sslam_orb_search_by_bow_keyframes(self.h, _p(kp1), _p(d1), _p(valid1), len(kp1), _p(kp2), _p(d2), _p(valid2), len(kp2), _p(ptr1), _p(ptr2),
+                                                     len(ptr1) - 1, _p(idx1), _p(idx2), C.c_float(nnratio), int(bool(check_orientation)), _p(m12), C.byref(nm)))
+        return m12[:len(kp1)], nm.value
+
     def distinctive_descriptors(self, desc, ptr):
         """MapPoint/MapLine::ComputeDistinctiveDescriptors for every set ptr[s]..ptr[s+1] (src/MapPoint.cc:247-312)."""
         desc = np.ascontiguousarray(desc, np.uint8); ptr = np.ascontiguousarray(ptr, np.int32)

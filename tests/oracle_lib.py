@@ -139,6 +139,17 @@ def _orc_match_methods():
                                       len(ptr_kf) - 1, _p(idx_kf), _p(idx_f), C.c_float(nnratio), int(bool(check_orientation)), _p(assigned))
         return assigned, nm
 
+    def search_by_bow_keyframes(self, kp1, d1, valid1, kp2, d2, valid2, ptr1, ptr2, idx1, idx2, nnratio=0.8, check_orientation=True):
+        kp1 = np.ascontiguousarray(kp1); kp2 = np.ascontiguousarray(kp2)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        valid1 = np.ascontiguousarray(valid1, np.uint8); valid2 = np.ascontiguousarray(valid2, np.uint8)
+        ptr1 = np.ascontiguousarray(ptr1, np.int32); ptr2 = np.ascontiguousarray(ptr2, np.int32)
+        idx1 = np.ascontiguousarray(idx1, np.int32); idx2 = np.ascontiguousarray(idx2, np.int32)
+        m12 = np.full(len(kp1), -1, np.int32)
+        nm = self.L.orc_search_by_bow_keyframes(_p(kp1), _p(d1), _p(valid1), len(kp1), _p(kp2), _p(d2), _p(valid2), len(kp2), _p(ptr1), _p(ptr2),
+                                                len(ptr1) - 1, _p(idx1), _p(idx2), C.c_float(nnratio), int(bool(check_orientation)), _p(m12))
+        return m12, nm
+
     def fuse_search(self, kind, chi2, feats, desc, queries, qdesc, uright=None, inv_level_sigma2=None, bounds=(0.0, 640.0, 0.0, 480.0)):
         feats = np.ascontiguousarray(feats); desc = np.ascontiguousarray(desc, np.uint8)
         queries = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
@@ -207,7 +218,7 @@ def _orc_match_methods():
         self.L.orc_distinctive(_p(desc), _p(ptr), len(ptr) - 1, _p(best))
         return best
 
-    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, distinctive, fuse_search, search_for_triangulation, bow_transform, vocab_load_text, compute_bow):
+    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, search_by_bow_keyframes, distinctive, fuse_search, search_for_triangulation, bow_transform, vocab_load_text, compute_bow):
         setattr(Oracle, f.__name__, f)
 
 

@@ -147,6 +147,28 @@ def test_search_by_bow(fe, ctx, oracle, seed, ori, ratio):
     np.testing.assert_array_equal(a, oa)
 
 
+@pytest.mark.parametrize("seed,ori,ratio", [(1234, True, 0.8), (2003, False, 0.75), (2005, True, 0.9)])
+def test_search_by_bow_keyframes(fe, ctx, oracle, seed, ori, ratio):
+    """ORBmatcher::SearchByBoW(KF1, KF2, vpMatches12), src/ORBmatcher.cc:525-658 (loop closing): map-point masks on both sides, strict TH_LOW"""
+    rng = np.random.default_rng(seed)
+    cur = synth_frame(seed); prev = warp_prev(cur)
+    kp1, d1 = oracle.orb_extract(prev, 1000); kp2, d2 = oracle.orb_extract(cur, 1000)
+    d2 = d2.copy()
+    near = np.argmin(np.unpackbits(d1[:200, None, :] ^ d2[None, :, :], axis=2).sum(axis=2), axis=1)
+    for i in range(0, 200, 7):                                             # plant matches at exactly TH_LOW = 50 bits (accepted by `<=`, rejected by `<`)
+        row = d1[i].copy(); bits = np.unpackbits(row); flip = rng.choice(256, 50, replace=False); bits[flip] ^= 1; d2[near[i]] = np.packbits(bits)
+    pk, pf, ik, jf = _pseudo_feature_vectors(d1, d2, nbits=3)
+    v1 = (rng.random(len(kp1)) < 0.85).astype(np.uint8); v2 = (rng.random(len(kp2)) < 0.8).astype(np.uint8)
+    m, n = ctx.search_by_bow_keyframes(kp1, d1, v1, kp2, d2, v2, pk, pf, ik, jf, ratio, ori)
+    om, on = oracle.search_by_bow_keyframes(kp1, d1, v1, kp2, d2, v2, pk, pf, ik, jf, ratio, ori)
+    assert on > 30 and n == on, (n, on)
+    np.testing.assert_array_equal(m, om)
+    got = m[m >= 0]
+    assert (v2[got] == 1).all() and len(np.unique(got)) == len(got) and (v1[m >= 0] == 1).all()
+    e, en = ctx.search_by_bow_keyframes(kp1[:0], d1[:0], v1[:0], kp2, d2, v2, np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert en == 0 and len(e) == 0
+
+
 # ---- device-resident frames (SURVEY.md §8(f) rank 1): same matchers, features uploaded once or never
 @pytest.mark.parametrize("mode", [0, 1])
 def test_frame_handle_search_by_projection(fe, ctx, oracle, mode):
