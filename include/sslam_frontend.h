@@ -154,6 +154,16 @@ int sslam_orb_search_for_initialization_batch_dev(sslam_ctx* ctx,
  *   kind 0, mode 1  ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)        src/ORBmatcher.cc:1331-1473
  *   kind 1, mode 0  LSDmatcher::SearchByProjection(Frame&, const vector<MapLine*>&, th)    src/LSDmatcher.cpp:185-255
  *                   LSDmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)        src/LSDmatcher.cpp:22-141
+ * Mode 1 is the "best candidate only, a feature that already holds a map point is skipped" rule; three more overloads are the same
+ * rule under other arguments (each checked against its own line-by-line restatement, tests/test_match_gpu.py):
+ *   kind 0, mode 1  ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)  src/ORBmatcher.cc:1475-1602 (relocalisation):
+ *                   occupied[i] = CurrentFrame.mvpMapPoints[i] != NULL, obs_positive = 1, uright = NULL, th_dist = ORBdist,
+ *                   min/max_level = pred-1 / pred+1, angle = pKF->mvKeysUn[i].angle
+ *   kind 0, mode 1  ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)        src/ORBmatcher.cc:293-406 (loop closing):
+ *                   occupied[i] = vpMatched[i] != NULL, obs_positive = 1, uright = NULL, th_dist = TH_LOW, check_orientation = 0,
+ *                   min/max_level = pred-1 / pred (KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:610-649, scans like Frame's)
+ *   kind 1, mode 1  LSDmatcher::SearchByProjection(KeyFrame*, Scw, vpLines, vpMatched, th)         src/LSDmatcher.cpp:558-683: as the line above
+ *                   with both projected endpoints (kind 1 accepts mode 1 only with check_orientation = 0)
  * feats = F.mvKeysUn (sslam_keypoint) or F.mvKeylinesUn (sslam_keyline), desc = F.mDescriptors / F.mLdesc,
  * uright = F.mvuRight or NULL (monocular), occupied[i] = F.mvpMapPoints[i] has Observations()>0 (or NULL).
  * assigned_out[i] = index of the query now owning feature i (-> F.mvpMapPoints[i] = that pMP) or -1. */
@@ -204,7 +214,9 @@ int sslam_hamming_knn2_frames(sslam_ctx* ctx, const sslam_frame* query, const ss
  * best_dist_out[q] = that distance (INT_MAX if none).  inv_level_sigma2 = KeyFrame::mvInvLevelSigma2 (chi2_mode 1 only).
  * The `bestDist <= TH_LOW` test and the Replace / AddObservation bookkeeping stay with the caller, in query order.
  * The same inner loop (chi2_mode 0) is the candidate search of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1196-1227, :1276-1307,
- * gate TH_HIGH) and of the loop-closing ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, ...) (:293-406). */
+ * gate TH_HIGH), LSDmatcher::SearchBySim3 (src/LSDmatcher.cpp:685-929) and LSDmatcher::Fuse(KeyFrame*, Scw, ...) (:931-1063).  The
+ * loop-closing SearchByProjection(KeyFrame*, Scw, ...) overloads skip features that are already matched, which makes their queries
+ * order dependent: they are sslam_search_by_projection mode 1 (above), not this function. */
 int sslam_fuse_search(sslam_ctx* ctx, const sslam_frame* keyframe, int chi2_mode, const float* inv_level_sigma2, int nlevels,
                       const sslam_proj_query* queries, const uint8_t* qdesc, int nq, int32_t* best_idx_out, int32_t* best_dist_out);
 

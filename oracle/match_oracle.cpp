@@ -386,6 +386,81 @@ int orc_search_for_initialization(const void* kp1, const uint8_t* d1, int n1, co
     return search_for_initialization((const KPm*)kp1, d1, n1, (const KPm*)kp2, d2, n2, prev_matched, m12, window, nnratio, check_ori != 0, bounds);
 }
 
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist),
+// src/ORBmatcher.cc:1475-1602 (relocalisation), restated on its own: q[i] carries what the projection block (:1499-1530) produces for
+// pKF's i-th map point (u, v, radius = th*scale[pred], maxLevel = pred, angle = pKF->mvKeysUn[i].angle, valid = passed every `continue`).
+// hasMapPoint[i2] = CurrentFrame.mvpMapPoints[i2] != NULL on entry.  assigned[i2] = i as elsewhere.
+int orc_search_by_projection_reloc(const void* feats, const uint8_t* desc, int n, const float* bounds, const uint8_t* hasMapPoint, const void* qv,
+                                   const uint8_t* qdesc, int nq, int ORBdist, int check_ori, int32_t* assigned) {
+    const KPm* kps = (const KPm*)feats; const ProjQuery* q = (const ProjQuery*)qv;
+    FrameGrid g; g.build(kps, n, bounds);
+    std::vector<char> mvpMapPoints(hasMapPoint, hasMapPoint + n);
+    for (int i = 0; i < n; ++i) assigned[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < nq; ++i) {
+        if (!q[i].valid) continue;
+        const int nPredictedLevel = q[i].maxLevel;
+        const std::vector<int> vIndices2 = g.in_area(q[i].u, q[i].v, q[i].radius, nPredictedLevel - 1, nPredictedLevel + 1);
+        if (vIndices2.empty()) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (mvpMapPoints[i2]) continue;
+            const int dist = descriptor_distance(qdesc + (size_t)i * 32, desc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {
+            mvpMapPoints[bestIdx2] = 1; assigned[bestIdx2] = i; nmatches++;
+            if (check_ori) {
+                float rot = q[i].angle - kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_ori) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { assigned[idx] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:293-406 (kind 0), and
+// LSDmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpLines, vpMatched, th), src/LSDmatcher.cpp:558-683 (kind 1): the loop-closing
+// window search.  q[i]: u, v (lines: both projected endpoints), radius, maxLevel = nPredictedLevel, valid.  matchedIn[idx] = vpMatched[idx] != NULL
+// on entry; assigned[idx] = i stands for vpMatched[idx] = vpPoints[i].
+int orc_search_by_projection_sim3(int kind, const void* feats, const uint8_t* desc, int n, const float* bounds, const uint8_t* matchedIn, const void* qv,
+                                  const uint8_t* qdesc, int nq, int32_t* assigned) {
+    const KPm* kps = (const KPm*)feats; const KLm* kls = (const KLm*)feats; const ProjQuery* q = (const ProjQuery*)qv;
+    FrameGrid g; if (kind == 0) g.build(kps, n, bounds);
+    std::vector<char> vpMatched(matchedIn, matchedIn + n);
+    for (int i = 0; i < n; ++i) assigned[i] = -1;
+    int nmatches = 0;
+    for (int i = 0; i < nq; ++i) {
+        if (!q[i].valid) continue;
+        const int nPredictedLevel = q[i].maxLevel;
+        const std::vector<int> vIndices = kind == 0 ? g.in_area(q[i].u, q[i].v, q[i].radius, -1, -1)
+                                                    : lines_in_area(kls, n, q[i].u, q[i].v, q[i].u2, q[i].v2, q[i].radius, -1, -1);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : vIndices) {
+            if (vpMatched[idx]) continue;
+            const int level = kind == 0 ? kps[idx].octave : kls[idx].octave;
+            if (level < nPredictedLevel - 1 || level > nPredictedLevel) continue;
+            const int dist = descriptor_distance(qdesc + (size_t)i * 32, desc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { vpMatched[bestIdx] = 1; assigned[bestIdx] = i; nmatches++; }
+    }
+    return nmatches;
+}
+
 int orc_search_by_projection(int kind, int mode, const void* feats, const uint8_t* desc, int n, const float* bounds, const float* uright,
                              const uint8_t* occupied, const void* q, const uint8_t* qdesc, int nq, float nnratio, int th_dist, int check_ori,
                              int32_t* assigned) {

@@ -223,7 +223,7 @@ static int search_proj_core(sslam_ctx* ctx, int kind, int mode, const void* d_fe
 extern "C" int sslam_search_by_projection(sslam_ctx* ctx, int kind, int mode, const void* feats, const uint8_t* desc, int n, const float bounds[4],
                                           const float* uright, const uint8_t* occupied, const sslam_proj_query* queries, const uint8_t* qdesc, int nq,
                                           float nnratio, int th_dist, int check_orientation, int32_t* assigned_out, int* nmatches_out) {
-    if (!ctx || (kind != 0 && kind != 1) || (mode != 0 && mode != 1) || (kind == 1 && mode == 1) || n < 0 || nq < 0 || !nmatches_out || !bounds ||
+    if (!ctx || (kind != 0 && kind != 1) || (mode != 0 && mode != 1) || (kind == 1 && mode == 1 && check_orientation) || n < 0 || nq < 0 || !nmatches_out || !bounds ||
         (n > 0 && (!feats || !desc || !assigned_out)) || (nq > 0 && (!queries || !qdesc)) || n >= (1 << 19)) {
         set_error("sslam_search_by_projection: invalid arguments"); return SSLAM_ERR_INVALID;
     }
@@ -301,7 +301,7 @@ extern "C" int sslam_frame_count(const sslam_frame* f) { return f ? f->n : 0; }
 extern "C" int sslam_search_by_projection_frame(sslam_ctx* ctx, const sslam_frame* frame, int mode, const uint8_t* occupied,
                                                 const sslam_proj_query* queries, const uint8_t* qdesc, int nq,
                                                 float nnratio, int th_dist, int check_orientation, int32_t* assigned_out, int* nmatches_out) {
-    if (!ctx || !frame || frame->ctx != ctx || (mode != 0 && mode != 1) || (frame->kind == 1 && mode == 1) || nq < 0 || !nmatches_out ||
+    if (!ctx || !frame || frame->ctx != ctx || (mode != 0 && mode != 1) || (frame->kind == 1 && mode == 1 && check_orientation) || nq < 0 || !nmatches_out ||
         (frame->n > 0 && !assigned_out) || (nq > 0 && (!queries || !qdesc))) {
         set_error("sslam_search_by_projection_frame: invalid arguments"); return SSLAM_ERR_INVALID;
     }

@@ -32,7 +32,10 @@ int SearchByProjection(int mode, const std::vector<cv::KeyPoint> &keysUn, const 
                        std::vector<int> &assigned);
 int SearchLinesByProjection(const std::vector<cv::line_descriptor::KeyLine> &keylinesUn, const cv::Mat &ldesc,
                             const std::vector<unsigned char> &occupied, const std::vector<ProjQuery> &queries, const cv::Mat &queryDesc,
-                            float nnratio, int thDist, std::vector<int> &assigned);
+                            float nnratio, int thDist, std::vector<int> &assigned, int mode = 0);
+// mode 1 (both functions): best candidate only and a feature that already holds a map point / line is skipped -- with the argument
+// mapping of include/sslam_frontend.h this is also ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)
+// (src/ORBmatcher.cc:1475-1602) and the loop-closing SearchByProjection(KeyFrame*, Scw, ...) overloads (:293-406, src/LSDmatcher.cpp:558-683).
 
 // cv::BFMatcher(NORM_HAMMING,false).knnMatch(q,t,m,2) as used by every LSDmatcher entry point.
 void KnnMatch2(const cv::Mat &query, const cv::Mat &train, std::vector<int> &idx /*nq*2*/, std::vector<int> &dist /*nq*2*/);

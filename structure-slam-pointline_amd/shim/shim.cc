@@ -133,13 +133,13 @@ int SearchByProjection(int mode, const std::vector<cv::KeyPoint> &k, const cv::M
     return n;
 }
 int SearchLinesByProjection(const std::vector<cv::line_descriptor::KeyLine> &kl, const cv::Mat &ldesc, const std::vector<unsigned char> &occupied,
-                            const std::vector<ProjQuery> &queries, const cv::Mat &qd, float nnratio, int thDist, std::vector<int> &assigned) {
+                            const std::vector<ProjQuery> &queries, const cv::Mat &qd, float nnratio, int thDist, std::vector<int> &assigned, int mode) {
     assigned.assign(kl.size(), -1);
     if (kl.empty() || queries.empty()) return 0;
     std::vector<uint8_t> a = rows32(ldesc), b = rows32(qd);
     const float bounds[4] = {0.f, 1.f, 0.f, 1.f};
     int n = 0;
-    check(sslam_search_by_projection(G.get(), 1, 0, kl.data(), a.data(), (int)kl.size(), bounds, nullptr, occupied.empty() ? nullptr : occupied.data(),
+    check(sslam_search_by_projection(G.get(), 1, mode, kl.data(), a.data(), (int)kl.size(), bounds, nullptr, occupied.empty() ? nullptr : occupied.data(),
                                      (const sslam_proj_query*)queries.data(), b.data(), (int)queries.size(), nnratio, thDist, 0, assigned.data(), &n));
     return n;
 }

@@ -128,6 +128,25 @@ def _orc_match_methods():
                                              len(queries), C.c_float(nnratio), int(th_dist), int(bool(check_orientation)), _p(assigned))
         return assigned, nm
 
+    def search_by_projection_reloc(self, feats, desc, queries, qdesc, has_map_point, orb_dist=100, check_orientation=True, bounds=(0.0, 640.0, 0.0, 480.0)):
+        """direct restatement of ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1475-1602"""
+        feats = np.ascontiguousarray(feats); desc = np.ascontiguousarray(desc, np.uint8)
+        queries = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        n = len(feats); assigned = np.full(n, -1, np.int32); b = np.array(bounds, np.float32)
+        hm = np.ascontiguousarray(has_map_point, np.uint8)
+        nm = self.L.orc_search_by_projection_reloc(_p(feats), _p(desc), n, _p(b), _p(hm), _p(queries), _p(qdesc), len(queries), int(orb_dist),
+                                                   int(bool(check_orientation)), _p(assigned))
+        return assigned, nm
+
+    def search_by_projection_sim3(self, kind, feats, desc, queries, qdesc, matched, bounds=(0.0, 640.0, 0.0, 480.0)):
+        """direct restatement of the loop-closing SearchByProjection(KeyFrame*, Scw, ...): src/ORBmatcher.cc:293-406, src/LSDmatcher.cpp:558-683"""
+        feats = np.ascontiguousarray(feats); desc = np.ascontiguousarray(desc, np.uint8)
+        queries = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        n = len(feats); assigned = np.full(n, -1, np.int32); b = np.array(bounds, np.float32)
+        mt = np.ascontiguousarray(matched, np.uint8)
+        nm = self.L.orc_search_by_projection_sim3(int(kind), _p(feats), _p(desc), n, _p(b), _p(mt), _p(queries), _p(qdesc), len(queries), _p(assigned))
+        return assigned, nm
+
     def search_by_bow(self, kf_kp, kf_desc, kf_valid, f_kp, f_desc, ptr_kf, ptr_f, idx_kf, idx_f, nnratio=0.9, check_orientation=True):
         kf_kp = np.ascontiguousarray(kf_kp); f_kp = np.ascontiguousarray(f_kp)
         kf_desc = np.ascontiguousarray(kf_desc, np.uint8); f_desc = np.ascontiguousarray(f_desc, np.uint8)
@@ -218,7 +237,7 @@ def _orc_match_methods():
         self.L.orc_distinctive(_p(desc), _p(ptr), len(ptr) - 1, _p(best))
         return best
 
-    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_bow, search_by_bow_keyframes, distinctive, fuse_search, search_for_triangulation, bow_transform, vocab_load_text, compute_bow):
+    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_projection_reloc, search_by_projection_sim3, search_by_bow, search_by_bow_keyframes, distinctive, fuse_search, search_for_triangulation, bow_transform, vocab_load_text, compute_bow):
         setattr(Oracle, f.__name__, f)
 
 

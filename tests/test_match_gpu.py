@@ -147,6 +147,55 @@ def test_search_by_bow(fe, ctx, oracle, seed, ori, ratio):
     np.testing.assert_array_equal(a, oa)
 
 
+# ---- the remaining SearchByProjection overloads are parameterisations of the ordered window matcher (mode 1: best only, a feature that
+# holds a map point is skipped); each is checked against its own line-by-line restatement in the oracle
+@pytest.mark.parametrize("seed,ori,orb_dist", [(1234, True, 100), (2003, False, 64), (2004, True, 50)])
+def test_search_by_projection_relocalisation(fe, ctx, oracle, seed, ori, orb_dist):
+    """ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1475-1602 (Tracking::Relocalization)"""
+    rng = np.random.default_rng(seed)
+    cur = synth_frame(seed); prev = warp_prev(cur)
+    kp1, d1 = oracle.orb_extract(prev, 1000); kp2, d2 = oracle.orb_extract(cur, 1000)
+    scales = oracle.orb_params()[0]
+    q = np.zeros(len(kp1), fe.PQ_DTYPE)
+    q["u"] = kp1["x"] + 3 + rng.normal(0, 2.0, len(kp1)); q["v"] = kp1["y"] - 2 + rng.normal(0, 2.0, len(kp1))
+    pred = np.clip(kp1["octave"] + rng.integers(-1, 2, len(kp1)), 0, 7)
+    q["radius"] = 10 * scales[pred]; q["min_level"] = pred - 1; q["max_level"] = pred + 1        # th = 10 (Tracking.cc Relocalization), GetFeaturesInArea(u, v, radius, pred-1, pred+1)
+    q["angle"] = kp1["angle"]; q["valid"] = rng.random(len(kp1)) < 0.9; q["obs_positive"] = 1      # a matched feature always blocks later queries (:1545-1546)
+    has_mp = (rng.random(len(kp2)) < 0.3).astype(np.uint8)                                         # CurrentFrame.mvpMapPoints[i2] != NULL
+    qd = q.copy(); qd["max_level"] = pred                                                           # the restatement takes the predicted level
+    oa, on = oracle.search_by_projection_reloc(kp2, d2, qd, d1, has_mp, orb_dist, ori)
+    a, n = ctx.search_by_projection(0, 1, kp2, d2, q, d1, has_mp, None, 0.0, orb_dist, ori)
+    assert on > 50 and n == on, (n, on)
+    np.testing.assert_array_equal(a, oa)
+    assert (has_mp[a >= 0] == 0).all()
+
+
+@pytest.mark.parametrize("kind,seed", [(0, 1234), (0, 2003), (1, 1234), (1, 2003)])
+def test_search_by_projection_loop_closing(fe, ctx, oracle, kind, seed):
+    """ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:293-406, and the line twin src/LSDmatcher.cpp:558-683"""
+    rng = np.random.default_rng(seed + kind)
+    cur = synth_frame(seed); prev = warp_prev(cur)
+    if kind == 0:
+        f1, d1 = oracle.orb_extract(prev, 1000); f2, d2 = oracle.orb_extract(cur, 1000)
+        scales = oracle.orb_params()[0]
+        q = np.zeros(len(f1), fe.PQ_DTYPE)
+        q["u"] = f1["x"] + 3 + rng.normal(0, 2.0, len(f1)); q["v"] = f1["y"] - 2 + rng.normal(0, 2.0, len(f1))
+        pred = np.clip(f1["octave"] + rng.integers(0, 2, len(f1)), 0, 7)
+        q["radius"] = 10 * scales[pred]
+    else:
+        f1, d1, _, _ = oracle.lines_extract(prev, 200); f2, d2, _, _ = oracle.lines_extract(cur, 200)
+        q = np.zeros(len(f1), fe.PQ_DTYPE)
+        q["u"] = f1["startPointX"] + 3; q["v"] = f1["startPointY"] - 2; q["u2"] = f1["endPointX"] + 3; q["v2"] = f1["endPointY"] - 2
+        pred = rng.integers(0, 3, len(f1))                                                          # level 2 leaves no octave-0 keyline in [pred-1, pred]
+        q["radius"] = 10 * 1.2 ** pred
+    q["min_level"] = pred - 1; q["max_level"] = pred; q["valid"] = rng.random(len(f1)) < 0.9; q["obs_positive"] = 1
+    matched = (rng.random(len(f2)) < 0.25).astype(np.uint8)                                         # vpMatched[idx] != NULL on entry
+    oa, on = oracle.search_by_projection_sim3(kind, f2, d2, q, d1, matched)
+    a, n = ctx.search_by_projection(kind, 1, f2, d2, q, d1, matched, None, 0.0, 50, False)          # TH_LOW, no rotation check
+    assert on > (50 if kind == 0 else 10) and n == on, (n, on)
+    np.testing.assert_array_equal(a, oa)
+
+
 @pytest.mark.parametrize("seed,ori,ratio", [(1234, True, 0.8), (2003, False, 0.75), (2005, True, 0.9)])
 def test_search_by_bow_keyframes(fe, ctx, oracle, seed, ori, ratio):
     """ORBmatcher::SearchByBoW(KF1, KF2, vpMatches12), src/ORBmatcher.cc:525-658 (loop closing): map-point masks on both sides, strict TH_LOW"""

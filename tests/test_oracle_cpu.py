@@ -197,3 +197,32 @@ def test_vocabulary_text_loader_and_bow_vector(oracle, tmp_path):
     bw, bv, fn, fp, ff = oracle.compute_bow(L, ptr, ch, nd, v["word_id"], w, feat, levelsup=1)
     assert bw.tolist() == keys and bv.tolist() == [bow[kk] / norm for kk in keys]
     assert fn.tolist() == sorted(fv) and [ff[fp[j]:fp[j + 1]].tolist() for j in range(len(fn))] == [fv[kk] for kk in sorted(fv)]
+
+
+def test_projection_overloads_are_parameterisations_of_the_ordered_matcher(oracle):
+    """oracle vs oracle: the relocalisation (src/ORBmatcher.cc:1475-1602) and loop-closing (:293-406, src/LSDmatcher.cpp:558-683) overloads, restated
+    line by line, equal the generic ordered window matcher (mode 1) under the argument mapping INTEGRATION.md gives"""
+    import pkg
+    from synth import synth_frame, warp_prev
+    PQ = pkg.frontend().PQ_DTYPE
+    rng = np.random.default_rng(9)
+    cur = synth_frame(77, w=320, h=240); prev = warp_prev(cur)
+    kp1, d1 = oracle.orb_extract(prev, 500); kp2, d2 = oracle.orb_extract(cur, 500)
+    scales = oracle.orb_params()[0]
+    b = (0.0, 320.0, 0.0, 240.0)
+    q = np.zeros(len(kp1), PQ)
+    q["u"] = kp1["x"] + 3; q["v"] = kp1["y"] - 2
+    pred = np.clip(kp1["octave"] + rng.integers(-1, 2, len(kp1)), 0, 7)
+    q["radius"] = 10 * scales[pred]; q["angle"] = kp1["angle"]; q["valid"] = rng.random(len(kp1)) < 0.9; q["obs_positive"] = 1
+    occ = (rng.random(len(kp2)) < 0.3).astype(np.uint8)
+    qr = q.copy(); qr["min_level"] = pred - 1; qr["max_level"] = pred + 1
+    qd = q.copy(); qd["max_level"] = pred
+    a0, n0 = oracle.search_by_projection_reloc(kp2, d2, qd, d1, occ, 80, True, bounds=b)
+    a1, n1 = oracle.search_by_projection(0, 1, kp2, d2, qr, d1, occ, None, 0.0, 80, True, bounds=b)
+    assert n0 == n1 and n0 > 20
+    np.testing.assert_array_equal(a0, a1)
+    qs = q.copy(); qs["min_level"] = pred - 1; qs["max_level"] = pred
+    a2, n2 = oracle.search_by_projection_sim3(0, kp2, d2, qd, d1, occ, bounds=b)
+    a3, n3 = oracle.search_by_projection(0, 1, kp2, d2, qs, d1, occ, None, 0.0, 50, False, bounds=b)
+    assert n2 == n3 and n2 > 20
+    np.testing.assert_array_equal(a2, a3)
