@@ -9,7 +9,12 @@
 // modules/core/src/mathfuncs_core.simd.hpp) as restated from their published
 // source.  PARITY UNPINNED: the reference ships no tests/golden vectors and the
 // real library cannot be run here; this file *defines* the behaviour the HIP
-// path must match bit-for-bit.  Call sites in the reference:
+// path must match bit-for-bit.  What could be checked against an independent
+// implementation offline IS checked (tests/test_oracle_cpu.py): the FAST-9/16 corner set,
+// cornerScore (= largest passing threshold) and the intensity-centroid orientation against
+// scikit-image 0.18.3 (fixtures in tests/golden/skimage_fast_orient.npz), Sobel 3x3 and the
+// LSD NFA against scipy.  Resize, GaussianBlur, NMS, LSD region logic and LBD have no such
+// counterpart here and stay unpinned.  Call sites in the reference:
 //   src/ORBextractor.cc:81,103 (cvRound, fastAtan2), :809,814 (FAST),
 //   :1086 (GaussianBlur), :1120 (resize), :1122,1127 (copyMakeBorder).
 //
@@ -275,7 +280,7 @@ static inline int fast_corner_score16(const uint8_t* p, int stride, int threshol
 // cv::FAST(view, kps, threshold, nonmaxSuppression=true), TYPE_9_16, on the view
 // [x0,x1) x [y0,y1) of img.  Emits view-relative coordinates in raster order. A.1
 static inline void fast9_view(const Img8& img, int x0, int y0, int x1, int y1,
-                              int threshold, std::vector<FastKp>& out) {
+                              int threshold, std::vector<FastKp>& out, std::vector<uint8_t>* score_map_out = nullptr) {
     const int cols = x1 - x0, rows = y1 - y0, stride = img.w;
     out.clear();
     if (cols < 7 || rows < 7) return;
@@ -307,6 +312,7 @@ static inline void fast9_view(const Img8& img, int x0, int y0, int x1, int y1,
             if (corner) sc[(size_t)i * cols + j] = (uint8_t)fast_corner_score16(p, stride, threshold);
         }
     }
+    if (score_map_out) *score_map_out = sc;              // test tap: the score of every pixel that passed the segment test, before NMS
     // A pixel that passed the segment test always has score >= threshold; with
     // threshold >= 1 a stored 0 therefore means "not a corner".
     for (int i = 3; i < rows - 3; ++i)

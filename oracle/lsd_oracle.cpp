@@ -422,6 +422,19 @@ void lsd_detect_keylines(const Img8& image, std::vector<KeyLine>& keylines, std:
     }
 }
 
+// test taps: the NFA of (n, k, p) for an image of w x h pixels, and cv::Sobel 3x3 as the LBD stage calls it
+extern "C" double orc_lsd_nfa(int w, int h, int n, int k, double p) {
+    Lsd lsd; lsd.w = w; lsd.h = h;
+    lsd.LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
+    return lsd.nfa(n, k, p);
+}
+extern "C" int orc_sobel3(const uint8_t* src, int w, int h, int16_t* gx, int16_t* gy) {
+    Img8 im(w, h); std::memcpy(im.d.data(), src, (size_t)w * h);
+    std::vector<int16_t> x, y; sobel3_s16(im, x, y);
+    std::memcpy(gx, x.data(), 2 * (size_t)w * h); std::memcpy(gy, y.data(), 2 * (size_t)w * h);
+    return 0;
+}
+
 // stage taps used by the parity tests
 void lsd_debug_scaled(const Img8& image, Img8& scaled_out) {
     Lsd lsd;

@@ -383,6 +383,19 @@ int orc_gauss_taps(int n, double sigma, int* out) {
 float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 int orc_reflect101(int i, int n) { return reflect101(i, n); }
 
+// cv::FAST on the whole image as one view: score_map_out[w*h] = cornerScore of every pixel that passes the 9-of-16 segment test at
+// `threshold` (0 elsewhere), before non-maximum suppression; returns the number of keypoints after NMS (xys_out: x, y, score).
+int orc_fast_image(const uint8_t* gray, int w, int h, int stride, int threshold, uint8_t* score_map_out, int32_t* xys_out, int cap) {
+    Img8 im(w, h);
+    for (int y = 0; y < h; ++y) std::memcpy(im.row(y), gray + (size_t)y * stride, w);
+    std::vector<FastKp> kps; std::vector<uint8_t> sc;
+    fast9_view(im, 0, 0, w, h, threshold, kps, &sc);
+    if (score_map_out) { if (sc.empty()) std::memset(score_map_out, 0, (size_t)w * h); else std::memcpy(score_map_out, sc.data(), (size_t)w * h); }
+    const int n = std::min((int)kps.size(), cap);
+    for (int i = 0; i < n && xys_out; ++i) { xys_out[i * 3] = kps[i].x; xys_out[i * 3 + 1] = kps[i].y; xys_out[i * 3 + 2] = kps[i].score; }
+    return (int)kps.size();
+}
+
 int orc_fast_score(const uint8_t* patch7x7) {   // score of the centre of a 7x7 patch (threshold-independent form): cornerScore with t=0
     return fast_corner_score16(patch7x7 + 3 * 7 + 3, 7, 0);
 }

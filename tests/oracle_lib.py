@@ -206,6 +206,13 @@ def _orc_match_methods():
                                  int(levelsup), _p(w), _p(v), _p(nd))
         return w, v, nd
 
+    def fast_image(self, img, threshold):
+        """cv::FAST(img, threshold, nms=True) on the whole image: (score map before NMS, keypoints (x, y, score) after NMS)"""
+        img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+        sc = np.zeros((h, w), np.uint8); cap = w * h // 4; xys = np.zeros((cap, 3), np.int32)
+        n = self.L.orc_fast_image(_p(img), w, h, w, int(threshold), _p(sc), _p(xys), cap)
+        return sc, xys[:n].copy()
+
     def vocab_load_text(self, path):
         """-> dict(k, levels, scoring, weighting, nwords, child_ptr, children, node_desc, word_id, weight)"""
         import ctypes as C
@@ -237,7 +244,7 @@ def _orc_match_methods():
         self.L.orc_distinctive(_p(desc), _p(ptr), len(ptr) - 1, _p(best))
         return best
 
-    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_projection_reloc, search_by_projection_sim3, search_by_bow, search_by_bow_keyframes, distinctive, fuse_search, search_for_triangulation, bow_transform, vocab_load_text, compute_bow):
+    for f in (descriptor_distance, knn2, hamming_matrix, search_for_initialization, line_match, search_by_projection, search_by_projection_reloc, search_by_projection_sim3, search_by_bow, search_by_bow_keyframes, distinctive, fuse_search, search_for_triangulation, bow_transform, vocab_load_text, compute_bow, fast_image):
         setattr(Oracle, f.__name__, f)
 
 

@@ -226,3 +226,66 @@ def test_projection_overloads_are_parameterisations_of_the_ordered_matcher(oracl
     a3, n3 = oracle.search_by_projection(0, 1, kp2, d2, qs, d1, occ, None, 0.0, 50, False, bounds=b)
     assert n2 == n3 and n2 > 20
     np.testing.assert_array_equal(a2, a3)
+
+
+def test_fast_and_orientation_against_scikit_image(oracle):
+    """The one independent implementation available offline (scikit-image 0.18.3 in the build container, fixtures from
+    tests/golden/make_skimage_fixtures.py): the FAST-9/16 corner SET at thresholds 20 and 7, OpenCV's cornerScore (= the largest
+    threshold at which a pixel is still a corner, by definition) and the intensity-centroid orientation (exact atan2 vs fastAtan2's
+    documented 0.3 degrees).  NMS, the cell logic and everything downstream have no independent counterpart."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "skimage_fast_orient.npz"))
+    ncorner = nkp = 0
+    for name in ("synth11", "synth12", "noise5"):
+        img = g[name + "_img"]; h, w = img.shape
+        maxth = g[name + "_fast_maxth"]
+        for t in (7, 20):
+            sc, kps = oracle.fast_image(img, t)
+            mask = np.unpackbits(g["%s_fast_mask_t%d" % (name, t)])[:w * h].reshape(h, w).astype(bool)
+            np.testing.assert_array_equal(sc > 0, mask, err_msg="%s: FAST corner set at threshold %d" % (name, t))
+            np.testing.assert_array_equal(sc[mask], maxth[mask], err_msg="%s: cornerScore vs largest passing threshold" % name)
+            assert (maxth[mask] >= t).all()
+            ncorner += int(mask.sum())
+            # what NMS keeps is a subset of the corner set, with the scores of the map
+            assert all(mask[y, x] and sc[y, x] == s for x, y, s in kps)
+        # orientation of the level-0 keypoints (their coordinates are image pixels)
+        ref = {(int(x), int(y)): float(a) for (x, y), a in zip(g[name + "_orient_xy"], g[name + "_orient_deg"])}
+        kp, _ = oracle.orb_extract(img, 500)
+        for k in kp[kp["octave"] == 0]:
+            key = (int(k["x"]), int(k["y"]))
+            assert key in ref, key                                  # every level-0 ORB keypoint is a FAST corner at threshold 7
+            d = abs(float(k["angle"]) - ref[key]) % 360.0
+            assert min(d, 360.0 - d) < 0.35, (key, float(k["angle"]), ref[key])
+            nkp += 1
+    assert ncorner > 5000 and nkp > 150, (ncorner, nkp)
+
+
+def test_sobel_and_nfa_against_scipy(oracle):
+    """two more leaves with an independent implementation at hand: cv::Sobel 3x3 / BORDER_REFLECT_101 (scipy.ndimage.correlate, mode
+    'mirror', exact integers) and the LSD number of false alarms (exact binomial tail from scipy.stats; the restated algorithm truncates
+    the tail once the remainder is below 10 % of |NFA| x tail, so it may only err upwards and by a bounded amount)"""
+    import ctypes as C
+    from scipy import ndimage, stats
+    img = synth_frame(5, w=200, h=120)
+    gx = np.zeros(img.shape, np.int16); gy = np.zeros(img.shape, np.int16)
+    oracle.L.orc_sobel3(img.ctypes.data_as(C.c_void_p), img.shape[1], img.shape[0], gx.ctypes.data_as(C.c_void_p), gy.ctypes.data_as(C.c_void_p))
+    k = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]])
+    np.testing.assert_array_equal(gx, ndimage.correlate(img.astype(np.int32), k, mode="mirror"))
+    np.testing.assert_array_equal(gy, ndimage.correlate(img.astype(np.int32), k.T, mode="mirror"))
+    oracle.L.orc_lsd_nfa.restype = C.c_double
+    w, h = 512, 384
+    log_nt = 5 * (np.log10(w) + np.log10(h)) / 2 + np.log10(11.0)
+    rng = np.random.default_rng(3)
+    checked = 0
+    for _ in range(3000):
+        n = int(rng.integers(2, 600)); p = float(rng.choice([0.125, 0.0625, 0.03125]))
+        kk = int(rng.integers(max(1, int(n * p)), n + 1))
+        got = oracle.L.orc_lsd_nfa(w, h, n, kk, C.c_double(p))
+        ref = -stats.binom.logsf(kk - 1, n, p) / np.log(10.0) - log_nt
+        if ref > 250:                                     # first term below ~1e-260: the prescribed algorithm runs on denormals there (few significant bits)
+            continue
+        lg = 5e-5 * (1.0 + abs(ref))                      # the Windschitl / Lanczos log-gamma approximations the algorithm prescribes
+        slack = np.log10(1.0 + 0.1 * abs(got)) + lg
+        assert -lg <= got - ref <= slack, (n, kk, p, got, ref)
+        checked += 1
+    assert checked > 2500
+    assert oracle.L.orc_lsd_nfa(w, h, 0, 0, C.c_double(0.125)) == -log_nt                    # n == 0 or k == 0: -logNT
