@@ -289,3 +289,39 @@ def test_sobel_and_nfa_against_scipy(oracle):
         checked += 1
     assert checked > 2500
     assert oracle.L.orc_lsd_nfa(w, h, 0, 0, C.c_double(0.125)) == -log_nt                    # n == 0 or k == 0: -logNT
+
+
+def test_fixed_point_leaves_track_their_real_valued_definitions(oracle):
+    """The 8-bit resize, Gaussian blur and fastAtan2 are fixed-point / polynomial forms of plain real-valued operators; scipy / numpy
+    evaluate those operators in floating point with the same sampling conventions (pixel-centre mapping, edge clamp, reflect-101).  The
+    oracle must stay within the rounding those forms allow: this pins geometry, taps and borders, not the last bit."""
+    from scipy import ndimage
+    img = synth_frame(6)                                             # 640x480
+    # cv::resize INTER_LINEAR, level 1 of the ORB pyramid = level 0 / 1.2 (src/ORBextractor.cc:1107-1132)
+    lvl1 = oracle.pyramid_level(img, 1)
+    oh, ow = lvl1.shape
+    assert (ow, oh) == (533, 400)
+    ref = ndimage.zoom(img.astype(np.float64), (oh / img.shape[0], ow / img.shape[1]), order=1, mode="nearest", grid_mode=True)
+    assert ref.shape == lvl1.shape
+    d = np.abs(lvl1.astype(np.float64) - ref)
+    assert d.max() <= 1.0 and d.mean() < 0.3, (d.max(), d.mean())
+    # the LSD 0.8x stage: 7x7 sigma 0.75 blur, then INTER_LINEAR_EXACT to 512x384
+    sc = oracle.lsd_scaled(img)
+    assert sc.shape == (384, 512)
+    # cv::GaussianBlur 7x7 sigma 2, BORDER_REFLECT_101 (src/ORBextractor.cc:1086)
+    x = np.arange(-3, 4, dtype=np.float64); k = np.exp(-x * x / (2 * 2.0 * 2.0)); k /= k.sum()
+    refb = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    db = np.abs(oracle.blur7(img).astype(np.float64) - refb)
+    assert db.max() <= 1.5 and db.mean() < 0.3, (db.max(), db.mean())      # taps quantised to 1/256 + two roundings
+    k2 = np.exp(-x * x / (2 * 0.75 * 0.75)); k2 /= k2.sum()
+    blur = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k2, axis=1, mode="mirror"), k2, axis=0, mode="mirror")
+    refs = ndimage.zoom(blur, (384 / 480, 512 / 640), order=1, mode="nearest", grid_mode=True)
+    ds = np.abs(sc.astype(np.float64) - refs)
+    assert ds.max() <= 1.5 and ds.mean() < 0.35, (ds.max(), ds.mean())
+    # cv::fastAtan2: documented accuracy ~0.3 degrees, range [0, 360)
+    rng = np.random.default_rng(8)
+    ys = rng.integers(-40000, 40000, 20000).astype(np.float32); xs = rng.integers(-40000, 40000, 20000).astype(np.float32)
+    got = np.array([oracle.fast_atan2(float(y), float(x)) for y, x in zip(ys, xs)])
+    want = np.degrees(np.arctan2(ys.astype(np.float64), xs.astype(np.float64))) % 360.0
+    dd = np.abs(got - want); dd = np.minimum(dd, 360.0 - dd)
+    assert dd.max() < 0.3 and (got >= 0).all() and (got < 360.0 + 1e-4).all(), dd.max()
