@@ -21,7 +21,7 @@ def main():
         kp1, d1 = orc.orb_extract(prev, nf); kp2, d2 = orc.orb_extract(cur, nf)
         kl1, ld1, _, _ = orc.lines_extract(prev, 200); kl2, ld2, _, _ = orc.lines_extract(cur, 200)
         pairs.append((w, h, kp1, d1, kp2, d2, kl1, ld1, kl2, ld2))
-    bad = []; nchk = 0
+    bad = []; nchk = 0; voc = [None, None, None]
     t0 = time.time()
     for it in range(n_iter):
         w, h, kp1, d1, kp2, d2, kl1, ld1, kl2, ld2 = pairs[int(rng.integers(0, len(pairs)))]
@@ -71,6 +71,38 @@ def main():
         ab, nb = ctx.search_by_bow(kp1, d1, validk, kp2, d2, pk, pf, ik, jf, rb, ori)
         ob, onb = orc.search_by_bow(kp1, d1, validk, kp2, d2, pk, pf, ik, jf, rb, ori)
         if nb != onb or not np.array_equal(ab, ob): bad.append("bow it %d %d/%d" % (it, nb, onb))
+        # ---- SearchByBoW(KF, KF): map-point masks on both sides, strict TH_LOW
+        valid2 = (rng.random(len(kp2)) < float(rng.choice([0.5, 0.9, 1.0]))).astype(np.uint8)
+        mk, nk = ctx.search_by_bow_keyframes(kp1, d1, validk, kp2, d2, valid2, pk, pf, ik, jf, rb, ori)
+        omk, onk = orc.search_by_bow_keyframes(kp1, d1, validk, kp2, d2, valid2, pk, pf, ik, jf, rb, ori)
+        if nk != onk or not np.array_equal(mk, omk): bad.append("bow kf-kf it %d %d/%d" % (it, nk, onk))
+        # ---- relocalisation / loop-closing overloads of SearchByProjection against their own restatements
+        pred = np.clip(o + rng.integers(-1, 2, len(sel)), 0, 7)
+        qr = q.copy(); qr["radius"] = rs * sc[pred]; qr["min_level"] = pred - 1; qr["max_level"] = pred + 1; qr["obs_positive"] = 1
+        qdm = qr.copy(); qdm["max_level"] = pred
+        od_ = int(rng.choice([50, 64, 100]))
+        a, n = ctx.search_by_projection(0, 1, kp2, d2, qr, qd, occ, None, 0.0, od_, ori, bounds)
+        oa, on = orc.search_by_projection_reloc(kp2, d2, qdm, qd, occ, od_, ori, bounds)
+        if n != on or not np.array_equal(a, oa): bad.append("reloc it %d %d/%d" % (it, n, on))
+        qs = qr.copy(); qs["max_level"] = pred
+        a, n = ctx.search_by_projection(0, 1, kp2, d2, qs, qd, occ, None, 0.0, 50, False, bounds)
+        oa, on = orc.search_by_projection_sim3(0, kp2, d2, qdm, qd, occ, bounds)
+        if n != on or not np.array_equal(a, oa): bad.append("sim3 proj it %d %d/%d" % (it, n, on))
+        # ---- Frame::ComputeBoW through a text vocabulary (rebuilt now and then)
+        if it % 25 == 0:
+            import tempfile, os
+            from synth import synthetic_vocab, write_vocab_text
+            if voc[0] is not None: voc[0].close()
+            L, ptr_, ch_, nd_, word_, weight_ = synthetic_vocab(rng, k=int(rng.integers(3, 11)), L=int(rng.integers(2, 5)))
+            wg, scg = int(rng.integers(0, 4)), int(rng.integers(0, 6))
+            with tempfile.TemporaryDirectory() as td:
+                vp = os.path.join(td, "v.txt"); write_vocab_text(vp, 10, L, ptr_, ch_, nd_, weight_, scoring=scg, weighting=wg, weight_fmt="%.6g")
+                voc[0] = fe.Vocabulary.from_text_file(ctx, vp); voc[1] = orc.vocab_load_text(vp); voc[2] = (wg, scg)
+        ov = voc[1]; lu = int(rng.integers(0, 6))
+        bow, fv = voc[0].compute_bow(d2, lu)
+        bw, bv, fn, fp, ff = orc.compute_bow(ov["levels"], ov["child_ptr"], ov["children"], ov["node_desc"], ov["word_id"], ov["weight"], d2, lu, voc[2][0], voc[2][1])
+        if list(bow.keys()) != bw.tolist() or list(bow.values()) != bv.tolist() or list(fv.keys()) != fn.tolist() or \
+                any(fv[int(fn[j])] != ff[fp[j]:fp[j + 1]].tolist() for j in range(len(fn))): bad.append("compute_bow it %d" % it)
         # ---- lines: projection + knn + MAD gate
         if len(kl1) > 2 and len(kl2) > 2:
             ql = np.zeros(len(kl1), fe.PQ_DTYPE)
@@ -81,6 +113,10 @@ def main():
             a, n = ctx.search_by_projection(1, 0, kl2, ld2, ql, ld1, occl, None, 0.6, 100, True, bounds)
             oa, on = orc.search_by_projection(1, 0, kl2, ld2, ql, ld1, occl, None, 0.6, 100, True, bounds)
             if n != on or not np.array_equal(a, oa): bad.append("line proj it %d" % it)
+            predl = rng.integers(0, 3, len(kl1)); qm = ql.copy(); qm["min_level"] = predl - 1; qm["max_level"] = predl; qm["obs_positive"] = 1
+            a, n = ctx.search_by_projection(1, 1, kl2, ld2, qm, ld1, occl, None, 0.0, 50, False, bounds)
+            oa, on = orc.search_by_projection_sim3(1, kl2, ld2, qm, ld1, occl, bounds)
+            if n != on or not np.array_equal(a, oa): bad.append("line sim3 proj it %d %d/%d" % (it, n, on))
             gs = float(rng.choice([0.5, 0.1])); rm = bool(rng.integers(0, 2))
             p1, _, _ = ctx.line_match(ld1, ld2, gs, rm); p2, _, _ = orc.line_match(ld1, ld2, gs, rm)
             if not np.array_equal(p1, p2): bad.append("line match it %d" % it)
