@@ -332,6 +332,12 @@ int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, long long* 
  * opencv lsd.cpp nfa(), reached from src/ExtractLineSegment.cpp:38-43): random inputs, half on the decision boundary.
  * disagree_out must be 0; ambiguous_out = cases that fall back to the fp64 expression. */
 int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long long* disagree_out, long long* ambiguous_out);
+/* The region-growing core replaces the IEEE division inside cv::fastAtan2 by the hardware's refinement sequence without its
+ * scaling / special-case steps (identity on the value range of a region's direction sums) and the quadrant compares by sign-bit
+ * arithmetic: `samples` random and adversarial sums, bit-compared with the `/` operator and the straight form.
+ * mismatches_out[0] = divisions that differ, mismatches_out[1] = angles that differ. */
+int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long long mismatches_out[2]);
+
 /* Profiling aid (no reference counterpart): reads a known number of bytes in one of the library's two dominant access
  * patterns (mode 0: 16 B/lane coalesced stream, mode 1: scattered 16-B gathers) so that rocprofv3's FETCH_SIZE can be
  * calibrated on this device (tools/fetch_probe.py, profiles/README.md). */

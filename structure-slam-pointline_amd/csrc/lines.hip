@@ -208,7 +208,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scan", st); hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }
     {
-        size_t lds = sizeof(unsigned) * QCAP;
+        size_t lds = sizeof(unsigned) * (QCAP + 4);      // + the sink slot behind the queue (region_grow_w)
         if (const char* e = getenv("SSLAM_LSD_LDS_PAD")) lds = std::max(lds, (size_t)atoi(e));      // experiment knob: cap resident region workgroups per CU
         if (lds > 48 * 1024) {
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -347,6 +347,22 @@ extern "C" int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long 
     SSLAM_HIP(hipStreamSynchronize(ctx->stream));
     (void)hipFree(d);
     *disagree_out = (long long)h[0]; *ambiguous_out = (long long)h[1];
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long long* mismatches_out) {
+    if (!ctx || samples <= 0 || !mismatches_out) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    unsigned long long* d = nullptr;
+    SSLAM_HIP(hipMalloc(&d, 2 * sizeof(unsigned long long)));
+    SSLAM_HIP(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+    const int threads = 256 * 1024, iters = (int)((samples + threads - 1) / threads);
+    hipLaunchKernelGGL(k_selftest_region_div, dim3(1024), dim3(256), 0, ctx->stream, 0x5EEDF00D1234ull, iters, d);
+    unsigned long long h[2] = {0, 0};
+    SSLAM_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SSLAM_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d);
+    mismatches_out[0] = (long long)h[0]; mismatches_out[1] = (long long)h[1];      // division, atan2
     return SSLAM_OK;
 }
 

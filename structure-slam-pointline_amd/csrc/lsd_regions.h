@@ -26,9 +26,70 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // re-tested against the updated angle.
 // LAT selects the accept-chain flavour: v_readlane + pre-converted operands shorten the dependent chain of a lone wave
 // (single-frame latency, -11 %), while with six waves per SIMD the LDS-permute form issues fewer wait states (throughput).
-template <bool LAT>
-__device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __restrict__ pix, const float* __restrict__ ang, const RegQ& rq,
+// a / b for 0 <= a <= b, b in [2^-60, 2^60], a == 0 or a >= 2^-80 b: the hardware's IEEE division sequence (v_div_scale, v_rcp, three
+// fused refinement steps, v_div_fmas, v_div_fixup) without the scaling and the special-case fix-up, which are the identity on this domain
+// -- the same rcp and the same fused operations, hence the same correctly rounded quotient (sslam_selftest_region_div compares it with
+// the `/` operator bit for bit).  The direction sums of a region are sums of float cos/sin values: |component| >= 6e-17 or exactly 0.
+__device__ __forceinline__ float div_unit_range(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+    float q = a * r;
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+
+// cv::fastAtan2 as in common.h (branch-free form), with the division above
+__device__ __forceinline__ float fast_atan2_deg_unit(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float c = div_unit_range(fminf(ax, ay), __fadd_rn(fmaxf(ax, ay), eps));      // the smaller magnitude over the larger one, either way
+    const float c2 = __fmul_rn(c, c);
+    float a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    if (ax < ay) a = __fsub_rn(90.f, a);
+    // "if (x < 0) a = 180 - a; if (y < 0) a = 360 - a" without compares: (sign ? K : 0) - a is K - a or -a, and K - a >= 0.  The sums are
+    // never -0 (they start at a nonzero cos or a +0 sin and x + (-x) rounds to +0), so the sign bit is exactly "x < 0".
+    a = fabsf(__fsub_rn(__int_as_float((__float_as_int(x) >> 31) & 0x43340000), a));
+    a = fabsf(__fsub_rn(__int_as_float((__float_as_int(y) >> 31) & 0x43b40000), a));
+    return a;
+}
+
+// selftest: the trimmed division and the branch-free atan2 against the `/` operator and fast_atan2_deg on direction sums of every magnitude
+// a region can produce (components from 6e-17 -- cos of 90.0 degrees in float -- up to 2^20 pixels, exact zeros, equal components)
+__global__ void k_selftest_region_div(unsigned long long seed, int iters, unsigned long long* __restrict__ out) {
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (float)((double)(x >> 11) * 0x1p-53); };
+    unsigned long long bad = 0, bad2 = 0;
+    for (int it = 0; it < iters; ++it) {
+        const float ex = exp2f(-54.f + 74.f * rnd()), ey = exp2f(-54.f + 74.f * rnd());
+        float sx = (1.f + rnd()) * ex, sy = (1.f + rnd()) * ey;
+        const int mode = (int)(rnd() * 16.f);
+        if (mode == 0) sy = 0.f; else if (mode == 1) sx = sy; else if (mode == 2) sx = 6.123234e-17f * (float)(1 + (int)(rnd() * 4000.f));
+        else if (mode == 3) { sx = (float)(int)(rnd() * 100000.f); sy = (float)(int)(rnd() * 100000.f); if (sx == 0.f && sy == 0.f) sx = 1.f; }
+        if ((x & 1) && sx != 0.f) sx = -sx;           // no -0: a region's sums cannot produce one (see fast_atan2_deg_unit)
+        if ((x & 2) && sy != 0.f) sy = -sy;
+        if (sx == 0.f && sy == 0.f) continue;
+        const float eps = (float)2.2204460492503131e-16;
+        const float ax = fabsf(sx), ay = fabsf(sy), mn = fminf(ax, ay), mx = __fadd_rn(fmaxf(ax, ay), eps);
+        if (__float_as_int(div_unit_range(mn, mx)) != __float_as_int(__fdiv_rn(mn, mx))) ++bad;
+        if (__float_as_int(fast_atan2_deg_unit(sy, sx)) != __float_as_int(fast_atan2_deg<false>(sy, sx))) ++bad2;
+    }
+    if (bad) atomicAdd(out, bad);
+    if (bad2) atomicAdd(out + 1, bad2);
+}
+
+// WIDE = false needs prec < pi/2: then "fold at 3pi/2, compare" is "|d| <= prec or ||d| - 2pi| <= prec" on the very same doubles (for
+// |d| in (pi, 3pi/2] both forms say no, above 3pi/2 the first clause cannot hold) -- two compares instead of compare + select + compare.
+template <bool LAT, bool WIDE>
+__device__ int region_grow_w(int seedX, int seedY, int sw, int sh, float4* __restrict__ pix, const float* __restrict__ ang, const RegQ& rq,
                              double prec, double& regAngleOut) {
+#ifndef SSLAM_LSD_READLANE
+#define SSLAM_LSD_READLANE 0
+#endif
+    constexpr bool RL = LAT || SSLAM_LSD_READLANE;      // broadcasts of the accepted lane: v_readlane for the lone wave, LDS permutes with six waves per SIMD (measured: 35.4 vs 37.2 ms)
     const int lane = threadIdx.x & 63;
     const int seed = seedY * sw + seedX;
     int n = 1;
@@ -51,36 +112,46 @@ __device__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __res
                 cand = px4.x >= 0.f;
             }
         }
-        int lastSel = -1;
         const int nBefore = n;
         unsigned long long accMask = 0;                    // lanes accepted from this staging, in lane (= acceptance) order
-        const double candRad = LAT ? (double)px4.x * DEG2RAD : 0.0;     // isAligned's operand, converted once per staging
-        while (true) {
-            bool al;
-            if (LAT) {
-                double nt = regAngle - candRad;              // is_aligned_val(px4.x, regAngle, prec), same operations
-                if (nt < 0) nt = -nt;
-                if (nt > M_3_2_PI_) { nt -= M_2PI_; if (nt < 0) nt = -nt; }
-                al = cand && lane > lastSel && nt <= prec;
-            } else { const bool ok = is_aligned_val(px4.x, regAngle, prec); al = cand && lane > lastSel && ok; }      // straight-line: no exec-masked region around the test
-            const unsigned long long m = __ballot(al);
-            if (!m) break;
-            const int sel = __ffsll((long long)m) - 1;       // wave-uniform: the lane reads below are v_readlane, not LDS permutes
-            const int selIdx = LAT ? __builtin_amdgcn_readlane(nidx, sel) : __shfl(nidx, sel, 64);
+        // the live candidates and "lanes after the last accepted one" are wave-uniform 64-bit masks: scalar updates, no VALU
+        unsigned long long candM = __builtin_amdgcn_ballot_w64(cand);
+        const double candRad = (double)px4.x * DEG2RAD;     // isAligned's operand, converted once per staging
+        auto aligned_mask = [&]() -> unsigned long long {
+            if (WIDE) return __builtin_amdgcn_ballot_w64(is_aligned_val(px4.x, regAngle, prec));
+            const double d = fabs(regAngle - candRad);
+            return __builtin_amdgcn_ballot_w64(d <= prec) | __builtin_amdgcn_ballot_w64(fabs(d - M_2PI_) <= prec);
+        };
+        unsigned long long m = aligned_mask() & candM;
+        while (m) {                                          // bottom-tested: the next mask is computed right after the angle update
+            const int sel = __ffsll((long long)m) - 1;       // wave-uniform
+            const int selIdx = RL ? __builtin_amdgcn_readlane(nidx, sel) : __builtin_amdgcn_ds_bpermute(sel << 2, nidx);
             if (LAT) accMask |= 1ull << sel;               // lone wave: the used-map / queue stores follow the loop, all lanes at once
-            else if (lane == sel) { pix[nidx].x = USED_F; rq.set(n, (unsigned)xx | ((unsigned)yy << 16)); }
+            else if (lane == sel) {                        // LDS slot QCAP is a sink, so the common case has no branch around the store
+                const unsigned v = (unsigned)xx | ((unsigned)yy << 16);
+                pix[nidx].x = USED_F; rq.lds[min(n, QCAP)] = v;
+                if (n >= QCAP) rq.glb[n] = v;
+            }
             ++n;
-            sumdx = __fadd_rn(sumdx, LAT ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px4.y), sel)) : __shfl(px4.y, sel, 64));
-            sumdy = __fadd_rn(sumdy, LAT ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px4.z), sel)) : __shfl(px4.z, sel, 64));
-            regAngle = (double)fast_atan2_deg<LAT>(sumdy, sumdx) * DEG2RAD;
-            if (nidx == selIdx) cand = false;              // the accepted pixel is now USED for every later visitor
-            lastSel = sel;
+            sumdx = __fadd_rn(sumdx, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.y), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.y))));
+            sumdy = __fadd_rn(sumdy, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.z), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.z))));
+            regAngle = (double)fast_atan2_deg_unit(sumdy, sumdx) * DEG2RAD;
+            candM &= ~__builtin_amdgcn_ballot_w64(nidx == selIdx);      // the accepted pixel is now USED for every later visitor
+            m = aligned_mask() & candM & (~1ull << sel);                // only lanes above sel
         }
         if (LAT && accMask != 0 && ((accMask >> lane) & 1ull)) { pix[nidx].x = USED_F; rq.set(nBefore + mbcnt(accMask), (unsigned)xx | ((unsigned)yy << 16)); }
         i += np;
     }
     regAngleOut = regAngle;
     return n;
+}
+
+template <bool LAT>
+__device__ __forceinline__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __restrict__ pix, const float* __restrict__ ang, const RegQ& rq,
+                                             double prec, double& regAngleOut) {
+    // the first growth runs at 22.5 degrees; refine()'s tolerance (two standard deviations of the angles) is normally smaller still
+    if (prec < 1.5) return region_grow_w<LAT, false>(seedX, seedY, sw, sh, pix, ang, rq, prec, regAngleOut);
+    return region_grow_w<LAT, true>(seedX, seedY, sw, sh, pix, ang, rq, prec, regAngleOut);
 }
 
 // Three fp64 running sums that must be folded strictly in region order (the reference adds point after point).  The wave

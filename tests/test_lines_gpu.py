@@ -91,6 +91,14 @@ def test_tail_test_selftest(fe, ctx):
     assert 0 < amb.value < 0.2 * n, amb.value        # half of the samples sit within 1e-3 of the boundary
 
 
+def test_region_division_selftest(fe, ctx):
+    """the accept chain's division / atan2 shortcuts must equal the plain forms bit for bit over every magnitude a region can produce"""
+    import ctypes as C
+    bad = (C.c_longlong * 2)(-1, -1)
+    rc = fe.lib().sslam_selftest_region_div(ctx.h, C.c_longlong(2_000_000_000), bad)
+    assert rc == 0 and bad[0] == 0 and bad[1] == 0, (bad[0], bad[1])
+
+
 def test_lines_huge_regions(fe, ctx, oracle):
     """regions far larger than the 1024-point LDS queue continue in global memory"""
     n, bad = _cmp_lines(fe, ctx, oracle, ramp_frame(), 200)
