@@ -311,6 +311,17 @@ __device__ __forceinline__ double align_dist(float aDeg, double theta) {
     return aDeg == NOTDEF_F ? 1e300 : (n_theta > M_3_2_PI_ ? wrapped : n_theta);
 }
 
+// The same two doubles, folded with a minimum: for a tolerance below pi/2 "fold at 3pi/2, then compare" and "min(n, |n - 2pi|) <= prec"
+// decide alike (n in (pi, 3pi/2] fails both, above 3pi/2 the wrapped value is the smaller one).  rect_nfa's tolerances are pi/8 and below.
+// NOTDEF is not handled here: callers AND the compare mask with ballot(a != NOTDEF).
+__device__ __forceinline__ double align_dist_min(float aDeg, double theta) {
+    const double n_theta = fabs(theta - (double)aDeg * DEG2RAD);
+    return fmin(n_theta, fabs(n_theta - M_2PI_));
+}
+// wave-wide vote on ONE comparison: the compare writes the lane mask itself.  (HIP's __ballot takes an int, and a vote on a conjunction
+// makes the compiler rebuild a 0/1 vector from the scalar masks -- v_cndmask + v_cmp per vote; conjunctions are done on the masks instead.)
+__device__ __forceinline__ unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // k_nfa_count: one wave walks a frame's rectangles.  The corner bookkeeping of rect_nfa (nfa_geom: sorting, slopes, integer
 // divisions) is the same few hundred instructions whether one lane or sixty-four execute it, so it runs lane-parallel for a
 // batch of up to 64 (rectangle, candidate) items whose results are parked in LDS; the wave then counts the items one after
@@ -342,26 +353,27 @@ __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, double thet
         const int xs = xa + sub * share;
         const int mine = max(min(share, xb - xs + 1), 0);
         const float* row = ang + (size_t)y * sw + xs;
-        for (int c0 = 0; __ballot(c0 < mine) != 0; c0 += 12) {
+        for (int c0 = 0; vote(c0 < mine) != 0; c0 += 12) {
             float a[12];
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
-            if (__ballot(c0 + 4 < mine)) {
+            if (vote(c0 + 4 < mine)) {
 #pragma unroll
                 for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
             }
-            if (__ballot(c0 + 8 < mine)) {
+            if (vote(c0 + 8 < mine)) {
 #pragma unroll
                 for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
             }
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
-                const unsigned long long have = __ballot(c0 + q < mine);
+                const unsigned long long have = vote(c0 + q < mine);
                 if (!have) break;
                 total += __popcll(have);
-                const double d = c0 + q < mine ? align_dist(a[q], theta) : 1e300;
+                const double d = align_dist_min(a[q], theta);
+                const unsigned long long def = vote(a[q] != NOTDEF_F);       // lanes without a pixel hold NOTDEF too
 #pragma unroll
-                for (int k = 0; k < K; ++k) alg[k] += __popcll(__ballot(d <= prec[k]));
+                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(d <= prec[k]) & def);
             }
         }
     }
@@ -404,30 +416,30 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
         const int xs = xa + sub * share;
         const int mine = width > 0 ? max(min(share, xb - xs + 1), 0) : 0;
         const float* row = ang + (size_t)y * sw + xs;
-        for (int c0 = 0; __ballot(c0 < mine) != 0; c0 += 12) {
+        for (int c0 = 0; vote(c0 < mine) != 0; c0 += 12) {
             float a[12];
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
-            if (__ballot(c0 + 4 < mine)) {
+            if (vote(c0 + 4 < mine)) {
 #pragma unroll
                 for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
             }
-            if (__ballot(c0 + 8 < mine)) {
+            if (vote(c0 + 8 < mine)) {
 #pragma unroll
                 for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
             }
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
-                const bool have = c0 + q < mine;
-                if (!__ballot(have)) break;
-                const bool al = have && align_dist(a[q], theta) <= prec;
+                const unsigned long long have = vote(c0 + q < mine);
+                if (!have) break;
+                const unsigned long long al = vote(align_dist_min(a[q], theta) <= prec) & vote(a[q] != NOTDEF_F);      // subset of have
                 const int x = xs + c0 + q;
 #pragma unroll
                 for (int j = 0; j < MAXC; ++j) {
                     if (j < nc) {
-                        const bool in = have && x >= xaj[j] && x <= xbj[j];
-                        total[j] += __popcll(__ballot(in));
-                        alg[j] += __popcll(__ballot(in && al));
+                        const unsigned long long in = vote(x >= xaj[j]) & vote(x <= xbj[j]) & have;
+                        total[j] += __popcll(in);
+                        alg[j] += __popcll(in & al);
                     }
                 }
             }
