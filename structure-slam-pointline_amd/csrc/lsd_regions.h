@@ -180,6 +180,7 @@ __device__ __forceinline__ double ordered_sums_get(const OrdSum& S, int which) {
 __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __restrict__ pix, double regAngle, double prec, double p, RectD& rec, double* __restrict__ red) {
     const int lane = threadIdx.x & 63;
     OrdSum S1; S1.acc = 0;
+    double wgt0 = 0; int px0 = 0, py0 = 0;                  // the first 64 points stay in registers for the second pass (most regions are that short)
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         double fx = 0, fy = 0, wgt = 0;
@@ -188,6 +189,7 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
             const int px = e & 0xFFFF, py = e >> 16;
             wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
             fx = (double)px * wgt; fy = (double)py * wgt;
+            if (base == 0) { wgt0 = wgt; px0 = px; py0 = py; }
         }
         ordered_sums_add(S1, red, fx, fy, wgt, min(64, n - base), lane);
     }
@@ -199,9 +201,12 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
         const int i = base + lane;
         double a = 0, b = 0, c = 0;
         if (i < n) {
-            const unsigned e = rq.get(i);
-            const int px = e & 0xFFFF, py = e >> 16;
-            const double wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
+            int px = px0, py = py0; double wgt = wgt0;
+            if (base != 0) {
+                const unsigned e = rq.get(i);
+                px = e & 0xFFFF; py = e >> 16;
+                wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
+            }
             const double ddx = (double)px - x, ddy = (double)py - y;
             a = ddy * ddy * wgt; b = ddx * ddx * wgt; c = ddx * ddy * wgt;
         }
