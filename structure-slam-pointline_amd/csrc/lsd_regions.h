@@ -236,6 +236,51 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
     if (rec.width < 1.0) rec.width = 1.0;
 }
 
+// reduce_region_radius's removal pass for a point list that lives in LDS (n <= QCAP).  The reference walks the list once, overwrites a
+// far point with the LAST point and tests that one again; that walk is a two-pointer partition: with K points kept, the holes below K
+// receive -- in ascending order -- the kept points above K in descending order (checked against the sequential walk on 2*10^5 random
+// keep patterns before it was written down here, and by the parity tests since).  n/64 wave steps instead of n.
+// scratch: 1536 bytes of LDS (keep masks of <= 16 chunks, then the hole positions as u16: holes <= min(K, n - K) <= 512).
+__device__ int remove_far_points_lds(unsigned* __restrict__ q, int n, double xc, double yc, double radSq, int sw, float4* __restrict__ pix,
+                                     const float* __restrict__ ang, void* scratch) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long* km = (unsigned long long*)scratch;
+    unsigned short* holeIdx = (unsigned short*)(km + 16);
+    const int nch = (n + 63) >> 6;
+    int K = 0;
+    for (int c = 0; c < nch; ++c) {
+        const int i = c * 64 + lane;
+        bool keep = false;
+        if (i < n) {
+            const unsigned e = q[i];
+            const int px = e & 0xFFFF, py = e >> 16;
+            const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
+            keep = !(d2 > radSq);
+            if (!keep) { const int id = py * sw + px; pix[id].x = ang[id]; }      // NOTUSED again
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (lane == 0) km[c] = m;
+        K += __popcll(m);
+    }
+    int run = 0;
+    for (int c = 0; c * 64 < K; ++c) {
+        const int i = c * 64 + lane;
+        const bool hole = i < K && !((km[c] >> lane) & 1ull);
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(hole);
+        if (hole) holeIdx[run + mbcnt(hm)] = (unsigned short)i;
+        run += __popcll(hm);
+    }
+    int runB = 0;
+    for (int c = nch - 1; c >= 0 && c * 64 + 63 >= K; --c) {
+        const int j = c * 64 + lane;
+        const bool bk = j >= K && ((km[c] >> lane) & 1ull);                        // bits beyond n are clear
+        const unsigned long long bm = __builtin_amdgcn_ballot_w64(bk);
+        if (bk) q[holeIdx[runB + __popcll((bm >> lane) >> 1)]] = q[j];            // rank counted from the back
+        runB += __popcll(bm);
+    }
+    return K;
+}
+
 __device__ __forceinline__ double dist_d(double x1, double y1, double x2, double y2) {
     return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1));
 }
@@ -322,7 +367,8 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                     bool good = true;
                     while (density < DENSITY_TH) {
                         radSq *= 0.75 * 0.75;
-                        for (int i = 0; i < n; ++i) {
+                        if (n <= QCAP) n = remove_far_points_lds(rq.lds, n, xc, yc, radSq, sw, pix, ang, red);
+                        else for (int i = 0; i < n; ++i) {
                             const unsigned e = rq.get(i);
                             const int px = e & 0xFFFF, py = e >> 16;
                             const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
