@@ -7,6 +7,12 @@
 struct RegQ {
     unsigned* lds; unsigned* glb;
     __device__ __forceinline__ unsigned get(int i) const { return i < QCAP ? lds[i] : glb[i]; }
+    // n = current list length (wave-uniform): a list that fits in LDS is read with ds_read under a scalar branch; the per-lane select of
+    // get() makes the compiler build a generic pointer and issue a flat load, which takes the vector-memory path even for LDS addresses
+    __device__ __forceinline__ unsigned get_n(int i, int n) const {
+        if (n <= QCAP) { unsigned v = lds[i]; asm volatile("" : "+v"(v)); return v; }      // the empty asm keeps the two loads from being merged into one flat load
+        return get(i);
+    }
     __device__ __forceinline__ void set(int i, unsigned v) const { if (i < QCAP) lds[i] = v; else glb[i] = v; }
 };
 __device__ __forceinline__ void rq_fence(int n) { if (n > QCAP) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
@@ -104,7 +110,7 @@ __device__ int region_grow_w(int seedX, int seedY, int sw, int sh, float4* __res
         const int np = min(8, n - i);
         bool cand = false; int nidx = -1, xx = 0, yy = 0; float4 px4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
         if (g < np) {
-            const unsigned e = rq.get(i + g);
+            const unsigned e = rq.get_n(i + g, n);
             xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
             if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
                 nidx = yy * sw + xx;
@@ -185,7 +191,7 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
         const int i = base + lane;
         double fx = 0, fy = 0, wgt = 0;
         if (i < n) {
-            const unsigned e = rq.get(i);
+            const unsigned e = rq.get_n(i, n);
             const int px = e & 0xFFFF, py = e >> 16;
             wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
             fx = (double)px * wgt; fy = (double)py * wgt;
@@ -203,7 +209,7 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
         if (i < n) {
             int px = px0, py = py0; double wgt = wgt0;
             if (base != 0) {
-                const unsigned e = rq.get(i);
+                const unsigned e = rq.get_n(i, n);
                 px = e & 0xFFFF; py = e >> 16;
                 wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
             }
@@ -221,7 +227,7 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
     const double dx = cos(theta), dy = sin(theta);
     double l_min = 0, l_max = 0, w_min = 0, w_max = 0;       // running min/max from 0: order independent
     for (int i = lane; i < n; i += 64) {
-        const unsigned e = rq.get(i);
+        const unsigned e = rq.get_n(i, n);
         const double rdx = (double)(e & 0xFFFF) - x, rdy = (double)(e >> 16) - y;
         const double l = rdx * dx + rdy * dy, ww = -rdx * dy + rdy * dx;
         l_max = fmax(l_max, l); l_min = fmin(l_min, l); w_max = fmax(w_max, ww); w_min = fmin(w_min, ww);
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                     const int i = bs + lane;
                     double ad = 0; bool in = false;
                     if (i < n) {
-                        const unsigned e = rq.get(i);
+                        const unsigned e = rq.get_n(i, n);
                         const int px = e & 0xFFFF, py = e >> 16, id = py * sw + px;
                         const float aOrig = ang[id];
                         pix[id].x = aOrig;                 // NOTUSED again
