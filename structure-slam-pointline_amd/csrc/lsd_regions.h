@@ -108,20 +108,35 @@ __device__ int region_grow_w(int seedX, int seedY, int sw, int sh, float4* __res
     int i = 0;
     while (i < n) {
         const int np = min(8, n - i);
-        bool cand = false; int nidx = -1, xx = 0, yy = 0; float4 px4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
-        if (g < np) {
-            const unsigned e = rq.get_n(i + g, n);
+        // Lone wave: straight-line staging -- every lane loads (slots past the staged entries re-read the last entry, coordinates are
+        // clamped into the image) and the three conditions (slot staged, neighbour inside the image, pixel neither NOTDEF nor USED) meet as
+        // lane masks: fewer instructions and no branches on the one wave's path (14.2 -> 13.5 ms per frame).  With six waves per SIMD the
+        // extra gather lanes cost more than the branches save (32.3 -> 32.8 ms per 6144 frames), so that flavour keeps the masked loads.
+        int nidx = -1, xx = 0, yy = 0; float4 px4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
+        unsigned long long candM;
+        if (LAT) {
+            const unsigned e = rq.get_n(min(i + g, n - 1), n);
             xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
-            if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
-                nidx = yy * sw + xx;
-                px4 = pix[nidx];                 // .x < 0: NOTDEF or already USED
-                cand = px4.x >= 0.f;
+            nidx = min(max(yy, 0), sh - 1) * sw + min(max(xx, 0), sw - 1);
+            px4 = pix[nidx];                             // .x < 0: NOTDEF or already USED
+            candM = __builtin_amdgcn_ballot_w64(px4.x >= 0.f) & __builtin_amdgcn_ballot_w64((unsigned)xx < (unsigned)sw) &
+                    __builtin_amdgcn_ballot_w64((unsigned)yy < (unsigned)sh) & (np == 8 ? ~0ull : ((1ull << (np * 8)) - 1));
+        } else {
+            bool cand = false;
+            if (g < np) {
+                const unsigned e = rq.get_n(i + g, n);
+                xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
+                if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
+                    nidx = yy * sw + xx;
+                    px4 = pix[nidx];
+                    cand = px4.x >= 0.f;
+                }
             }
+            candM = __builtin_amdgcn_ballot_w64(cand);
         }
         const int nBefore = n;
         unsigned long long accMask = 0;                    // lanes accepted from this staging, in lane (= acceptance) order
         // the live candidates and "lanes after the last accepted one" are wave-uniform 64-bit masks: scalar updates, no VALU
-        unsigned long long candM = __builtin_amdgcn_ballot_w64(cand);
         const double candRad = (double)px4.x * DEG2RAD;     // isAligned's operand, converted once per staging
         auto aligned_mask = [&]() -> unsigned long long {
             if (WIDE) return __builtin_amdgcn_ballot_w64(is_aligned_val(px4.x, regAngle, prec));
