@@ -117,3 +117,39 @@ def test_batch_of_19_distinct_frames(fe, ctx, oracle):
         assert nlp[i] == len(opairs)
         np.testing.assert_array_equal(lp[i][:nlp[i]], opairs)
     pipe.close()
+
+
+def test_batch_of_2176_frames_throughput_kernels(fe, ctx, oracle):
+    """from 1024 frames on the LSD core runs its six-waves-per-SIMD flavour (k_lsd_regions<false>) and the NFA stages one wave per frame
+    (from 2048 on also the rectangle counter): the kernels the benchmark times.  2176 = 17 * 128 small frames, 17 distinct ones tiled, so
+    every distinct frame lands on many different workgroups / XCDs; a sample of slots is compared with the oracle and all copies of a
+    frame must agree with each other byte for byte."""
+    pipeline = pkg._load("sslam_pipeline", os.path.join(pkg.PKG_DIR, "pipeline.py"))
+    w, h, U, REP = 192, 144, 17, 128
+    B = U * REP
+    frames = [synth_frame(5000 + i, w, h, nshapes=8 + 3 * i, nstrokes=2 * i, noise=float(i % 3)) for i in range(U)]
+    pipe = pipeline.FrontendBatch(fe, ctx, w, h, B, 300, 60, "cuda:0", with_match=False)
+    imgs = torch.from_numpy(np.stack(frames)).cuda().repeat(REP, 1, 1).contiguous()          # slot s holds frame s % 17
+    pipe.step(imgs)
+    torch.cuda.synchronize()
+    c = pipe.feat["cur"]
+    n = c["n"].cpu().numpy(); nl = c["nl"].cpu().numpy()
+    kp = c["kp"].cpu().numpy(); desc = c["desc"].cpu().numpy(); kl = c["kl"].cpu().numpy(); ld = c["ldesc"].cpu().numpy(); fn = c["linefn"].cpu().numpy()
+    total_lines = 0
+    for i, f in enumerate(frames):
+        okp, od = oracle.orb_extract(f, 300); okl, old, ofn, _ = oracle.lines_extract(f, 60)
+        total_lines += len(okl)
+        slots = np.arange(i, B, U)
+        assert (n[slots] == len(okp)).all() and (nl[slots] == len(okl)).all(), i
+        for s in (slots[0], slots[37], slots[-1]):
+            np.testing.assert_array_equal(kp[s, :n[s]].view(np.uint8).reshape(-1, 28), okp.view(np.uint8).reshape(-1, 28))
+            np.testing.assert_array_equal(desc[s, :n[s]], od)
+            a = kl[s, :nl[s]].view(np.uint8).reshape(-1, 68).copy(); b = okl.view(np.uint8).reshape(-1, 68).copy()
+            a[:, 0:4] = 0; b[:, 0:4] = 0                                # KeyLine.angle: atan2, <= 1 ulp (test_lines_gpu)
+            np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(ld[s, :nl[s]], old); np.testing.assert_array_equal(fn[s, :nl[s]], ofn)
+        ref = slots[0]
+        for arr, cnt in ((kp, n[ref]), (desc, n[ref]), (kl, nl[ref]), (ld, nl[ref]), (fn, nl[ref])):
+            assert (arr[slots, :cnt].view(np.uint8) == arr[ref, :cnt].view(np.uint8)).all(), i          # every copy identical, wherever it ran (rows past the count are unspecified)
+    assert total_lines > 100
+    pipe.close()
