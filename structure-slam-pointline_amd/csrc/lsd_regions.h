@@ -327,8 +327,14 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
     const int nOrd = misc->nDefined;
     const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
     int nSeg = 0;
+    // stage clocks for tools/lsd_cycles.py: compiled in with -DSSLAM_LSD_CYCLES only (an s_memtime + wait per read sits on the one wave's path)
+#ifdef SSLAM_LSD_CYCLES
+#define SSLAM_CLK() __builtin_readcyclecounter()
+#else
+#define SSLAM_CLK() 0ll
+#endif
     long long cyc0 = 0, cyc1 = 0, cyc2 = 0, cyc3 = 0;
-    const long long tStart = __builtin_readcyclecounter();
+    const long long tStart = SSLAM_CLK();
     for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
         const int q = pos0 + lane;
         const int idx = q < nOrd ? (int)order[q] : -1;
@@ -342,13 +348,13 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
             const int seed = LAT ? __builtin_amdgcn_readlane(idx, first) : __shfl(idx, first, 64);
             const int sy = seed / sw, sx = seed - sy * sw;
             double regAngle;
-            long long t0 = __builtin_readcyclecounter();
+            long long t0 = SSLAM_CLK();
             int n = region_grow_m<LAT>(sx, sy, sw, sh, pix, ang, rq, prec, regAngle);
-            long long t1 = __builtin_readcyclecounter(); cyc0 += t1 - t0;
+            long long t1 = SSLAM_CLK(); cyc0 += t1 - t0;
             if (n < P.minRegSize) continue;
             RectD rec;
             region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
-            long long t2 = __builtin_readcyclecounter(); cyc1 += t2 - t1;
+            long long t2 = SSLAM_CLK(); cyc1 += t2 - t1;
             // ---- refine (LSD_REFINE_STD part)
             double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
             if (density < DENSITY_TH) {
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                 region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
                 density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
                 if (density < DENSITY_TH) {
-                    const long long tr0 = __builtin_readcyclecounter();
+                    const long long tr0 = SSLAM_CLK();
                     // reduce_region_radius: sequential swap-with-last removal (the order feeds later sums)
                     const double r1 = (rec.x1 - xc) * (rec.x1 - xc) + (rec.y1 - yc) * (rec.y1 - yc);
                     const double r2 = (rec.x2 - xc) * (rec.x2 - xc) + (rec.y2 - yc) * (rec.y2 - yc);
@@ -405,13 +411,13 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                         region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
                         density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
                     }
-                    cyc3 += __builtin_readcyclecounter() - tr0;
+                    cyc3 += SSLAM_CLK() - tr0;
                     if (!good) continue;
                 }
             }
             // ---- hand the rectangle to the NFA stage (rect_improve reads only the static angle map and never touches
             // `used`, so it is not part of the sequential dependency chain: k_lsd_nfa evaluates all candidates in parallel)
-            long long t3 = __builtin_readcyclecounter(); cyc2 += t3 - t2;
+            long long t3 = SSLAM_CLK(); cyc2 += t3 - t2;
             if (nSeg < MAX_SEG && lane == 0) {
                 double* o = candOut + (size_t)nSeg * 12;
                 o[0] = rec.x1; o[1] = rec.y1; o[2] = rec.x2; o[3] = rec.y2; o[4] = rec.width; o[5] = rec.x; o[6] = rec.y;
@@ -422,6 +428,6 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
     }
     if (lane == 0) {
         misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
-        misc->cyc[0] = cyc0; misc->cyc[1] = cyc1; misc->cyc[2] = cyc2; misc->cyc[3] = cyc3; misc->cyc[4] = __builtin_readcyclecounter() - tStart;
+        misc->cyc[0] = cyc0; misc->cyc[1] = cyc1; misc->cyc[2] = cyc2; misc->cyc[3] = cyc3; misc->cyc[4] = SSLAM_CLK() - tStart;
     }
 }
