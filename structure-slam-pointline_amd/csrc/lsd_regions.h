@@ -24,14 +24,6 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// LineSegmentDetectorImpl::region_grow by one wave.  Eight queue entries are staged at a time (8
-// lanes each: the 3x3 neighbourhood in row-major order without its centre), so one global-load round
-// trip serves up to eight points.  Lane order == the reference's visiting order, and the region angle only
-// changes when a pixel is accepted, so ONE ballot over all staged lanes finds the next accepted
-// pixel exactly as the sequential scan would; lanes before it are consumed, lanes after it are
-// re-tested against the updated angle.
-// LAT selects the accept-chain flavour: v_readlane + pre-converted operands shorten the dependent chain of a lone wave
-// (single-frame latency, -11 %), while with six waves per SIMD the LDS-permute form issues fewer wait states (throughput).
 // a / b for 0 <= a <= b, b in [2^-60, 2^60], a == 0 or a >= 2^-80 b: the hardware's IEEE division sequence (v_div_scale, v_rcp, three
 // fused refinement steps, v_div_fmas, v_div_fixup) without the scaling and the special-case fix-up, which are the identity on this domain
 // -- the same rcp and the same fused operations, hence the same correctly rounded quotient (sslam_selftest_region_div compares it with
@@ -87,6 +79,14 @@ __global__ void k_selftest_region_div(unsigned long long seed, int iters, unsign
     if (bad2) atomicAdd(out + 1, bad2);
 }
 
+// LineSegmentDetectorImpl::region_grow by one wave.  Eight queue entries are staged at a time (8
+// lanes each: the 3x3 neighbourhood in row-major order without its centre), so one global-load round
+// trip serves up to eight points.  Lane order == the reference's visiting order, and the region angle only
+// changes when a pixel is accepted, so ONE ballot over all staged lanes finds the next accepted
+// pixel exactly as the sequential scan would; lanes before it are consumed, lanes after it are
+// re-tested against the updated angle.
+// LAT selects the flavour: v_readlane broadcasts, deferred stores and straight-line staging for a lone wave (single-frame latency),
+// LDS permutes, immediate stores and masked staging loads with six waves per SIMD (throughput); each choice measured both ways.
 // WIDE = false needs prec < pi/2: then "fold at 3pi/2, compare" is "|d| <= prec or ||d| - 2pi| <= prec" on the very same doubles (for
 // |d| in (pi, 3pi/2] both forms say no, above 3pi/2 the first clause cannot hold) -- two compares instead of compare + select + compare.
 template <bool LAT, bool WIDE>
