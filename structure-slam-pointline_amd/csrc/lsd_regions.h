@@ -15,10 +15,6 @@ struct RegQ {
     }
     __device__ __forceinline__ void set(int i, unsigned v) const { if (i < QCAP) lds[i] = v; else glb[i] = v; }
 };
-__device__ __forceinline__ void rq_fence(int n) { if (n > QCAP) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
-
-__device__ __forceinline__ bool used_get(const unsigned* ub, int idx) { return (ub[idx >> 5] >> (idx & 31)) & 1u; }
-
 __device__ __forceinline__ double readlane_d(double v, int l) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
