@@ -40,5 +40,9 @@ for name, img in frames.items():
     ang = corner_orientations(f, corners, OFAST_MASK)             # radians, atan2(m01, m10)
     out[name + "_orient_xy"] = corners[:, ::-1].astype(np.int16)
     out[name + "_orient_deg"] = (np.degrees(ang) % 360.0).astype(np.float32)
+# the 256 rBRIEF test pairs as scikit-image ships them (its copy of OpenCV's bit_pattern_31_: an independent transcription of the table at
+# src/ORBextractor.cc:150-408)
+import skimage.feature
+out["orb_positions"] = np.loadtxt(os.path.join(os.path.dirname(skimage.feature.__file__), "orb_descriptor_positions.txt")).astype(np.int8)
 np.savez_compressed(os.path.join(HERE, "skimage_fast_orient.npz"), **out)
 print({k: (v.shape, v.dtype) for k, v in out.items()})

@@ -41,6 +41,9 @@ def test_rbrief_pattern_table():
     assert r < 19                                                 # taps stay inside EDGE_THRESHOLD
     prod = os.path.join(os.path.dirname(GOLD), "..", "structure-slam-pointline_amd", "csrc", "orb_pattern.inc")
     assert open(prod).read() == open(inc).read()
+    # scikit-image carries its own transcription of the same OpenCV table (fixture from tests/golden/make_skimage_fixtures.py)
+    sk = np.load(os.path.join(GOLD, "skimage_fast_orient.npz"))["orb_positions"]
+    assert sk.shape == (256, 4) and (sk.astype(np.int64).reshape(-1) == nums).all()
 
 
 def test_fast_atan2_axes(oracle):
