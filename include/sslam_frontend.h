@@ -325,6 +325,17 @@ int sslam_lines_extract_batch_dev(sslam_lines* ln, const uint8_t* d_images, int 
                                   size_t pitch, size_t image_stride, int nframes,
                                   sslam_keyline* d_kl, uint8_t* d_ldesc, double* d_linefn,
                                   int32_t* d_counts, int cap, void* stream);
+/* Host-buffer batch (SURVEY.md §8(b) `sslam_frontend_batch`): n frames of one size in host memory through Frame::ExtractORB and, when
+ * `lines` is not NULL, Frame::ExtractLSD (src/Frame.cc:150-161); frame i starts at images + i*image_stride (row pitch `stride`).
+ * Per-frame results in the caller's arrays: kp_out[n*cap], desc_out[n*cap*32], nkp_out[n], kl_out[n*lcap], ldesc_out[n*lcap*32],
+ * linefn_out[n*lcap*3], nl_out[n]; rows past a frame's count are unspecified.  Frames are processed in chunks of `chunk` (0 = 512): the
+ * upload of chunk k+1 and the download of chunk k-1 overlap the kernels of chunk k (two copy streams; pinned caller memory -- hipHostMalloc /
+ * hipHostRegister -- is copied directly, pageable memory through pinned staging buffers).  This is the
+ * PCIe-inclusive form of the batch mode; callers that already hold their frames in HBM use the *_batch_dev entry points directly. */
+int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride, int chunk,
+                         sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
+                         sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap);
+
 /* Self-test of the table-based exact integer division of the NFA binomial tail against the hardware IEEE division:
  * `pairs` random quotients a/b with 1 <= a,b < n; *mismatches_out must come back 0. */
 int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, long long* mismatches_out);

@@ -1,0 +1,131 @@
+// Host-buffer batch mode: the `sslam_frontend_batch` of SURVEY.md §8(b) -- n frames of one size in host memory go through
+// Frame::ExtractORB + Frame::ExtractLSD (src/Frame.cc:150-161) and come back as per-frame host records.  Pure host orchestration over the
+// *_batch_dev entry points: chunks of frames are staged through pinned buffers, the H2D copy of chunk k+1 and the D2H copy of chunk k-1
+// run on two copy streams while chunk k computes (two slots of device / pinned buffers, HIP events between the streams).
+#include "common.h"
+#include <algorithm>
+#include <cstring>
+
+using namespace sslam;
+
+namespace {
+struct Slot {
+    DevBuf dIn, dKp, dDesc, dN, dKl, dLd, dFn, dNl;
+    HostPinned hIn, hOut;
+    hipEvent_t evIn = nullptr, evDone = nullptr, evOut = nullptr;
+    int first = 0, count = 0;            // frames of the chunk in flight
+    void release() {
+        dIn.release(); dKp.release(); dDesc.release(); dN.release(); dKl.release(); dLd.release(); dFn.release(); dNl.release(); hIn.release(); hOut.release();
+        if (evIn) (void)hipEventDestroy(evIn);
+        if (evDone) (void)hipEventDestroy(evDone);
+        if (evOut) (void)hipEventDestroy(evOut);
+        evIn = evDone = evOut = nullptr;
+    }
+};
+}  // namespace
+
+extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride, int chunk,
+                                    sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
+                                    sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap) {
+    sslam_ctx* ctx = orb ? sslam_orb_context(orb) : nullptr;
+    if (!orb || !ctx || n < 0 || w <= 0 || h <= 0 || stride < (size_t)w || cap <= 0 || (n > 0 && (!images || !kp_out || !desc_out || !nkp_out)) ||
+        (lines && (sslam_lines_context(lines) != ctx || lcap <= 0 || (n > 0 && (!kl_out || !ldesc_out || !linefn_out || !nl_out)))) || (n > 1 && image_stride < stride * (size_t)(h - 1) + (size_t)w)) {
+        set_error("sslam_frontend_batch: invalid arguments"); return SSLAM_ERR_INVALID;
+    }
+    if (n == 0) return SSLAM_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    const int C = std::min(n, chunk > 0 ? chunk : 512);
+    const size_t fpx = (size_t)w * h;
+    const size_t oKp = 0, oDesc = oKp + sizeof(sslam_keypoint) * (size_t)C * cap, oN = oDesc + 32 * (size_t)C * cap, oKl = oN + 256 + 4 * (size_t)C,
+                 oLd = oKl + (lines ? sizeof(sslam_keyline) * (size_t)C * lcap : 0), oFn = oLd + (lines ? 32 * (size_t)C * lcap : 0),
+                 oNl = oFn + (lines ? 24 * (size_t)C * lcap : 0), outBytes = oNl + 256 + 4 * (size_t)C;
+    // pinned (hipHostMalloc / hipHostRegister) caller memory is copied from / to directly; pageable memory goes through the pinned staging
+    auto is_pinned = [](const void* q) {
+        hipPointerAttribute_t a;
+        if (!q || hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    const bool inDirect = stride == (size_t)w && (n == 1 || image_stride == fpx) && is_pinned(images);
+    const bool outDirect = is_pinned(kp_out) && is_pinned(desc_out) && is_pinned(nkp_out) &&
+                           (!lines || (is_pinned(kl_out) && is_pinned(ldesc_out) && is_pinned(linefn_out) && is_pinned(nl_out)));
+    Slot slot[2];
+    hipStream_t cp = nullptr, cpOut = nullptr;          // H2D and D2H on separate streams: the next chunk's upload must not queue behind this chunk's download
+    int rc = SSLAM_OK;
+    auto fail = [&](int code) { for (auto& s : slot) s.release(); if (cp) (void)hipStreamDestroy(cp); if (cpOut) (void)hipStreamDestroy(cpOut); return code; };
+    if (hipStreamCreateWithFlags(&cp, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&cpOut, hipStreamNonBlocking) != hipSuccess) { set_error("sslam_frontend_batch: hipStreamCreate failed"); return fail(SSLAM_ERR_HIP); }
+    for (auto& s : slot) {
+        if ((rc = s.dIn.ensure(fpx * C)) || (rc = s.dKp.ensure(sizeof(sslam_keypoint) * (size_t)C * cap)) || (rc = s.dDesc.ensure(32 * (size_t)C * cap)) ||
+            (rc = s.dN.ensure(4 * (size_t)C)) || (!inDirect && (rc = s.hIn.ensure(fpx * C))) || (!outDirect && (rc = s.hOut.ensure(outBytes)))) return fail(rc);
+        if (lines && ((rc = s.dKl.ensure(sizeof(sslam_keyline) * (size_t)C * lcap)) || (rc = s.dLd.ensure(32 * (size_t)C * lcap)) ||
+                      (rc = s.dFn.ensure(24 * (size_t)C * lcap)) || (rc = s.dNl.ensure(4 * (size_t)C)))) return fail(rc);
+        if (hipEventCreateWithFlags(&s.evIn, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.evDone, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.evOut, hipEventDisableTiming) != hipSuccess) { set_error("sslam_frontend_batch: hipEventCreate failed"); return fail(SSLAM_ERR_HIP); }
+    }
+    // results of a finished chunk: pinned staging -> the caller's arrays
+    auto drain = [&](Slot& s) -> int {
+        if (s.count == 0) return SSLAM_OK;
+        if (hipEventSynchronize(s.evOut) != hipSuccess) { set_error("sslam_frontend_batch: D2H failed"); return SSLAM_ERR_HIP; }
+        if (outDirect) { s.count = 0; return SSLAM_OK; }
+        const uint8_t* H = s.hOut.as<uint8_t>();
+        const size_t f0 = (size_t)s.first, c = (size_t)s.count;
+        std::memcpy(kp_out + f0 * cap, H + oKp, sizeof(sslam_keypoint) * c * cap);
+        std::memcpy(desc_out + 32 * f0 * cap, H + oDesc, 32 * c * cap);
+        std::memcpy(nkp_out + f0, H + oN, 4 * c);
+        if (lines) {
+            std::memcpy(kl_out + f0 * lcap, H + oKl, sizeof(sslam_keyline) * c * lcap);
+            std::memcpy(ldesc_out + 32 * f0 * lcap, H + oLd, 32 * c * lcap);
+            std::memcpy(linefn_out + 3 * f0 * lcap, H + oFn, 24 * c * lcap);
+            std::memcpy(nl_out + f0, H + oNl, 4 * c);
+        }
+        s.count = 0;
+        return SSLAM_OK;
+    };
+    hipStream_t st = ctx->stream;
+    int k = 0;
+    for (int f0 = 0; f0 < n && rc == SSLAM_OK; f0 += C, ++k) {
+        Slot& s = slot[k & 1];
+        if ((rc = drain(s))) break;                                         // the slot's previous chunk (k-2) has to be out before it is reused
+        const int c = std::min(C, n - f0);
+        const uint8_t* hin = images + (size_t)f0 * fpx;
+        if (!inDirect) {
+            uint8_t* stage = s.hIn.as<uint8_t>();
+            for (int i = 0; i < c; ++i) {                                   // tight rows in the staging buffer
+                const uint8_t* src = images + (size_t)(f0 + i) * image_stride;
+                if (stride == (size_t)w) std::memcpy(stage + i * fpx, src, fpx);
+                else for (int y = 0; y < h; ++y) std::memcpy(stage + i * fpx + (size_t)y * w, src + (size_t)y * stride, w);
+            }
+            hin = stage;
+        }
+        if (hipMemcpyAsync(s.dIn.p, hin, fpx * c, hipMemcpyHostToDevice, cp) != hipSuccess || hipEventRecord(s.evIn, cp) != hipSuccess ||
+            hipStreamWaitEvent(st, s.evIn, 0) != hipSuccess) { set_error("sslam_frontend_batch: H2D failed"); rc = SSLAM_ERR_HIP; break; }
+        if ((rc = sslam_orb_extract_batch_dev(orb, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, s.dKp.as<sslam_keypoint>(), s.dDesc.as<uint8_t>(), s.dN.as<int32_t>(), cap, st))) break;
+        if (lines && (rc = sslam_lines_extract_batch_dev(lines, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, s.dKl.as<sslam_keyline>(), s.dLd.as<uint8_t>(), s.dFn.as<double>(),
+                                                         s.dNl.as<int32_t>(), lcap, st))) break;
+        if (hipEventRecord(s.evDone, st) != hipSuccess || hipStreamWaitEvent(cpOut, s.evDone, 0) != hipSuccess) { set_error("sslam_frontend_batch: event failed"); rc = SSLAM_ERR_HIP; break; }
+        uint8_t* H = outDirect ? nullptr : s.hOut.as<uint8_t>();
+        const size_t g = (size_t)f0;
+        void* tKp = outDirect ? (void*)(kp_out + g * cap) : (void*)(H + oKp);
+        void* tDesc = outDirect ? (void*)(desc_out + 32 * g * cap) : (void*)(H + oDesc);
+        void* tN = outDirect ? (void*)(nkp_out + g) : (void*)(H + oN);
+        bool ok = hipMemcpyAsync(tKp, s.dKp.p, sizeof(sslam_keypoint) * (size_t)c * cap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
+                  hipMemcpyAsync(tDesc, s.dDesc.p, 32 * (size_t)c * cap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
+                  hipMemcpyAsync(tN, s.dN.p, 4 * (size_t)c, hipMemcpyDeviceToHost, cpOut) == hipSuccess;
+        if (ok && lines) {
+            void* tKl = outDirect ? (void*)(kl_out + g * lcap) : (void*)(H + oKl);
+            void* tLd = outDirect ? (void*)(ldesc_out + 32 * g * lcap) : (void*)(H + oLd);
+            void* tFn = outDirect ? (void*)(linefn_out + 3 * g * lcap) : (void*)(H + oFn);
+            void* tNl = outDirect ? (void*)(nl_out + g) : (void*)(H + oNl);
+            ok = hipMemcpyAsync(tKl, s.dKl.p, sizeof(sslam_keyline) * (size_t)c * lcap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
+                 hipMemcpyAsync(tLd, s.dLd.p, 32 * (size_t)c * lcap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
+                 hipMemcpyAsync(tFn, s.dFn.p, 24 * (size_t)c * lcap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
+                 hipMemcpyAsync(tNl, s.dNl.p, 4 * (size_t)c, hipMemcpyDeviceToHost, cpOut) == hipSuccess;
+        }
+        if (!ok || hipEventRecord(s.evOut, cpOut) != hipSuccess) { set_error("sslam_frontend_batch: D2H failed"); rc = SSLAM_ERR_HIP; break; }
+        s.first = f0; s.count = c;
+    }
+    if (rc == SSLAM_OK) rc = drain(slot[k & 1]);          // older chunk first
+    if (rc == SSLAM_OK) rc = drain(slot[(k + 1) & 1]);
+    (void)hipStreamSynchronize(cp); (void)hipStreamSynchronize(cpOut); (void)hipStreamSynchronize(st);
+    return fail(rc);
+}

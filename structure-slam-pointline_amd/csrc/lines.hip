@@ -426,3 +426,5 @@ extern "C" int sslam_lines_debug_lbd_floats(sslam_lines* L, int frame, float* ou
     return SSLAM_OK;
 }
 #endif
+
+extern "C" sslam_ctx* sslam_lines_context(sslam_lines* L) { return L ? L->ctx : nullptr; }

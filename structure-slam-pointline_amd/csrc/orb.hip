@@ -1103,3 +1103,5 @@ extern "C" int sslam_frame_from_orb(sslam_orb* o, const float bounds[4], sslam_f
     std::lock_guard<std::mutex> lk(o->ctx->mu);
     return sslam_frame_from_device(o->ctx, 0, o->dKp.p, o->dDesc.as<uint8_t>(), o->lastN, bounds, out);
 }
+
+extern "C" sslam_ctx* sslam_orb_context(sslam_orb* o) { return o ? o->ctx : nullptr; }

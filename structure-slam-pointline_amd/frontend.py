@@ -284,6 +284,30 @@ class Frame:
             lib().sslam_frame_destroy(self.h); self.h = C.c_void_p()
 
 
+def frontend_batch(orb, lines, images, chunk=0, max_lines=None, pinned=False):
+    """sslam_frontend_batch: images = uint8 array [n, h, w] in HOST memory -> per-frame (keypoints, descriptors, keylines, line descriptors,
+    line functions) lists; `lines` may be None (ORB only).  pinned=True allocates the result arrays in pinned memory (torch), so that the
+    library copies straight into them; pass a pinned `images` array for the same on the way in."""
+    images = np.ascontiguousarray(images, np.uint8)
+    n, h, w = images.shape
+    cap = orb.cap
+    lcap = int(max_lines if max_lines is not None else (lines.max_lines if lines is not None else 1))
+
+    def alloc(shape, dt):
+        if not pinned:
+            return np.zeros(shape, dt)
+        import torch
+        nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+        return torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True).numpy()[:nbytes].view(dt).reshape(shape)
+    kp = alloc((n, cap), KP_DTYPE); desc = alloc((n, cap, 32), np.uint8); nk = alloc((n,), np.int32)
+    kl = alloc((n, lcap), KL_DTYPE); ld = alloc((n, lcap, 32), np.uint8); fn = alloc((n, lcap, 3), np.float64); nl = alloc((n,), np.int32)
+    _chk(lib().sslam_frontend_batch(orb.h, lines.h if lines is not None else None, _p(images), n, w, h, C.c_size_t(w), C.c_size_t(w * h), int(chunk),
+                                    _p(kp), _p(desc), _p(nk), cap, _p(kl), _p(ld), _p(fn), _p(nl), lcap))
+    if lines is None:
+        nl = np.zeros(n, np.int32)
+    return [(kp[i, :nk[i]], desc[i, :nk[i]], kl[i, :nl[i]], ld[i, :nl[i]], fn[i, :nl[i]]) for i in range(n)]
+
+
 class OrbExtractor:
     """Harness-side mirror of StructureSLAM::ORBextractor (include/ORBextractor.h:45-111)."""
 

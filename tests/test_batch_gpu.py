@@ -153,3 +153,29 @@ def test_batch_of_2176_frames_throughput_kernels(fe, ctx, oracle):
             assert (arr[slots, :cnt].view(np.uint8) == arr[ref, :cnt].view(np.uint8)).all(), i          # every copy identical, wherever it ran (rows past the count are unspecified)
     assert total_lines > 100
     pipe.close()
+
+
+def test_frontend_batch_host_buffers(fe, ctx, oracle):
+    """sslam_frontend_batch: host images in, host records out, chunked with copy/compute overlap.  37 frames in chunks of 8
+    (five chunks, the last one short, both buffer slots reused) must equal the per-frame host entry points frame by frame."""
+    w, h, n = 256, 192, 37
+    frames = np.stack([synth_frame(6000 + i, w, h, nshapes=10 + i, nstrokes=i % 7, noise=float(i % 3)) for i in range(n)])
+    orb = fe.OrbExtractor(ctx, 400); lines = fe.LineExtractor(ctx, 80)
+    out = fe.frontend_batch(orb, lines, frames, chunk=8)
+    assert len(out) == n
+    for i in (0, 7, 8, 15, 16, 31, 32, 36):
+        kp, d = orb(frames[i]); kl, ld, fn = lines(frames[i])
+        bkp, bd, bkl, bld, bfn = out[i]
+        assert len(bkp) == len(kp) and len(bkl) == len(kl), i
+        np.testing.assert_array_equal(bkp.view(np.uint8), kp.view(np.uint8)); np.testing.assert_array_equal(bd, d)
+        np.testing.assert_array_equal(bkl.view(np.uint8), kl.view(np.uint8)); np.testing.assert_array_equal(bld, ld); np.testing.assert_array_equal(bfn, fn)
+    okp, od = oracle.orb_extract(frames[20], 400)
+    np.testing.assert_array_equal(out[20][0].view(np.uint8).reshape(-1, 28), okp.view(np.uint8).reshape(-1, 28)); np.testing.assert_array_equal(out[20][1], od)
+    pin = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True); pin.numpy()[:] = frames
+    direct = fe.frontend_batch(orb, lines, pin.numpy(), chunk=16, pinned=True)          # pinned memory in and out: no staging copies
+    for i in (0, 15, 16, 36):
+        for a, b in zip(direct[i], out[i]):
+            np.testing.assert_array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+    only = fe.frontend_batch(orb, None, frames[:5])                       # ORB only, one chunk
+    np.testing.assert_array_equal(only[3][1], out[3][1]); assert len(only[3][2]) == 0
+    orb.close(); lines.close()
