@@ -355,6 +355,9 @@ int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long long misma
 int sslam_selftest_fetch_probe(sslam_ctx* ctx, size_t bytes, int mode, long long* bytes_requested_out);
 /* Stage tap: all LSD segments (x1,y1,x2,y2 float) of frame `frame` of the last batch, before top-N. */
 int sslam_lines_debug_segments(sslam_lines* ln, int frame, float* seg_out, int cap, int* n_out);
+/* Stage clocks of the sequential LSD core for frame `frame` of the last call (grow, rect, refine, radius reduction, total, ...): zeros unless
+ * the library was built with -DSSLAM_LSD_CYCLES (tools/lsd_cycles.py). */
+int sslam_lines_debug_cycles(sslam_lines* ln, int frame, long long* out8);
 
 #ifdef __cplusplus
 }

@@ -88,8 +88,8 @@ struct sslam_vocab {
 };
 
 // owner context of an extractor handle (the handle types are private to their translation units)
-extern "C" sslam_ctx* sslam_orb_context(sslam_orb* orb);
-extern "C" sslam_ctx* sslam_lines_context(sslam_lines* lines);
+extern "C" __attribute__((visibility("hidden"))) sslam_ctx* sslam_orb_context(sslam_orb* orb);
+extern "C" __attribute__((visibility("hidden"))) sslam_ctx* sslam_lines_context(sslam_lines* lines);
 
 namespace sslam {
 // RAII stage timer: records a HIP event pair on the launch stream around one kernel launch.
