@@ -5,7 +5,7 @@
 //   pixel state (atomic int): NOTDEF = INT_MIN, unused = 0, claimed by the seed at order position s = s - 2^30 (older seed = smaller value)
 //   claim = atomic min, un-claim = CAS(own tag -> 0); a reader treats a tag above its own (a younger seed's claim) as unused.
 // build: g++ -O2 -std=c++17 -ffp-contract=off -pthread -Ioracle tools/lsd_spec_proto.cpp -o /tmp/lsd_spec_proto
-// run:   /tmp/lsd_spec_proto <frame.raw 640x480> <threads> <repeats> [chaos: yield once in N pixel reads] [0 = no stamp validation]
+// run:   /tmp/lsd_spec_proto <frame.raw 640x480> <threads> <repeats> [chaos: yield once in N pixel reads] [0 = no stamp validation] [1 = FIFO hand-out as in the draft kernel]
 #include "../oracle/lsd_oracle.cpp"
 #include <atomic>
 #include <climits>
@@ -123,11 +123,61 @@ struct Spec : Lsd {
         region2rect(c.reg, reg_angle, prec, p, rec);
         return refine_t(c, reg_angle, rec);
     }
+    // ---- hand-out exactly as in the draft HIP kernel (branch wip/lsd-spec): a FIFO of seeds refilled under a lock by whoever finds it empty,
+    // 64 order entries per scan step, the commit counter sampled once per refill, the "claimed by a region in flight" flag taken at scan time
+    bool fifoMode = false;
+    static const int FIFO = 32, PUSH_CAP = 16;
+    std::atomic<int> fifoHead{0}, fifoTail{0}, exhausted{0};
+    int fifoPos[FIFO], fifoSeq[FIFO], fifoWait[FIFO];
+    bool take_fifo(int& ticket, int& pos, int& startSeq, bool& wait) {
+        while (true) {
+            const int head = fifoHead.load(std::memory_order_acquire), tail = fifoTail.load(std::memory_order_acquire);
+            if (head < tail) {
+                const int sl = head % FIFO;
+                pos = fifoPos[sl]; startSeq = fifoSeq[sl]; wait = fifoWait[sl] != 0;
+                int expect = head;
+                if (fifoHead.compare_exchange_strong(expect, head + 1, std::memory_order_acq_rel)) { ticket = head; return true; }
+                continue;
+            }
+            if (exhausted.load(std::memory_order_acquire)) return false;
+            if (!pickMu.try_lock()) { std::this_thread::yield(); continue; }
+            const int seq0 = commitSeq.load(std::memory_order_acquire);
+            const int c0 = commitTicket.load(std::memory_order_acquire);
+            int tl = fifoTail.load(std::memory_order_acquire);
+            const int oldestTag = c0 == tl ? INT_MAX : TAG0 + ringPos[c0 % RING];
+            size_t p0 = pickPos; int pushed = 0;
+            while (p0 < order.size() && pushed < PUSH_CAP) {
+                const int room = FIFO - (tl - fifoHead.load(std::memory_order_acquire));
+                if (room <= 0) break;
+                int have = 0, took = 0; size_t resume = p0 + 64;
+                for (size_t q = p0; q < std::min(p0 + 64, order.size()); ++q) {
+                    const int v = tag[order[q]].load(std::memory_order_acquire);
+                    const bool cand = v >= 0 || (is_tag(v) && v >= oldestTag);
+                    if (!cand) continue;
+                    if (have < room) { const int t = tl + have; fifoPos[t % FIFO] = (int)q; fifoSeq[t % FIFO] = seq0; fifoWait[t % FIFO] = v < 0; ringPos[t % RING] = (int)q; ++took; }
+                    else if (have == room) resume = q;                     // first candidate that did not fit
+                    ++have;
+                }
+                tl += took; pushed += took;
+                if (took < have) { p0 = resume; break; }
+                p0 += 64;
+            }
+            pickPos = std::min(p0, order.size());
+            if (p0 >= order.size() && pushed == 0) exhausted.store(1, std::memory_order_release);
+            fifoTail.store(tl, std::memory_order_release);
+            pickMu.unlock();
+        }
+    }
     void worker() {
         Ctx c; c.rd.assign(ntiles, 0); c.wr.assign(ntiles, 0); c.rng += (unsigned long long)(size_t)&c;
         while (true) {
             int ticket, pos = -1, startSeq; bool wait = false;
-            {
+            if (fifoMode) {
+                if (!take_fifo(ticket, pos, startSeq, wait)) return;
+                c.T = TAG0 + pos;
+                const int v0 = tag[order[pos]].load(std::memory_order_acquire);
+                if (!wait && !(v0 >= 0 || (is_tag(v0) && v0 > c.T))) wait = true;      // the kernel re-reads the seed before it speculates
+            } else {
                 std::lock_guard<std::mutex> lk(pickMu);
                 // BEFORE the scan: the scan's "this pixel is unused" is the first read of the speculative run, and a region that commits
                 // between the scan and a later read of commitSeq would escape the stamp test (found by this prototype: a seed grown from a
@@ -181,7 +231,7 @@ struct Spec : Lsd {
         tag = std::vector<std::atomic<int>>((size_t)w * h); tileStamp = std::vector<std::atomic<int>>(ntiles);
         for (size_t i = 0; i < tag.size(); ++i) tag[i].store(angles[i] == NOTDEF ? NOTDEF_T : 0);
         for (auto& t : tileStamp) t.store(0);
-        commitSeq = 0; commitTicket = 0; pickPos = 0; tickets = 0; emitted.clear(); seedLog.clear(); nSpecOk = nRedo = nWait = 0;
+        commitSeq = 0; commitTicket = 0; pickPos = 0; tickets = 0; emitted.clear(); seedLog.clear(); nSpecOk = nRedo = nWait = 0; fifoHead = 0; fifoTail = 0; exhausted = 0;
         std::vector<std::thread> th;
         for (int i = 0; i < nthreads; ++i) th.emplace_back([this] { worker(); });
         for (auto& t : th) t.join();
@@ -200,6 +250,7 @@ int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: lsd_spec_proto frame.raw [threads] [repeats]\n"); return 2; }
     const int nth = argc > 2 ? atoi(argv[2]) : 8, reps = argc > 3 ? atoi(argv[3]) : 5, chaos = argc > 4 ? atoi(argv[4]) : 0;
     const bool validate = !(argc > 5 && atoi(argv[5]) == 0);
+    const bool fifo = argc > 6 && atoi(argv[6]) != 0;
     FILE* f = fopen(argv[1], "rb"); if (!f) return 2;
     Img8 im(640, 480); if (fread(im.d.data(), 1, im.d.size(), f) != im.d.size()) return 2; fclose(f);
     Lsd ref; std::vector<Seg4f> want; ref.detect(im, want);
@@ -211,7 +262,7 @@ int main(int argc, char** argv) {
     printf("1 thread: %zu segments (%zu expected) %s, %zu rectangles, %zu seeds ran\n", seq.size(), want.size(), okSeq ? "EQUAL" : "MISMATCH", one.emitted.size(), one.seedLog.size());
     int bad = !okSeq;
     for (int r = 0; r < reps; ++r) {
-        Spec s; s.chaos = chaos; s.validate = validate; std::vector<Seg4f> got; s.run(im, nth, got);
+        Spec s; s.chaos = chaos; s.validate = validate; s.fifoMode = fifo; std::vector<Seg4f> got; s.run(im, nth, got);
         bool same = got.size() == want.size();
         for (size_t i = 0; same && i < got.size(); ++i) same = memcmp(&got[i], &want[i], sizeof(Seg4f)) == 0;
         bool rects = s.emitted.size() == one.emitted.size();
