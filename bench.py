@@ -91,8 +91,19 @@ def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=600, with_li
                 orc.line_match(pl[1], ld, 0.5, False)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same %dx%d workload (ORB %d%s%s), %.1f s, single thread" % (n, W, H, NFEAT, " + LSD/LBD %d" % NLINES if with_lines else "", " + matches" if with_match else "", dt)}, ref
+    out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of the same %dx%d workload (ORB %d%s%s), %.1f s, single thread" % (n, W, H, NFEAT, " + LSD/LBD %d" % NLINES if with_lines else "", " + matches" if with_match else "", dt)}
+    # the same oracle as N independent single-threaded processes, one pinned per host core (informational; `value` stays the
+    # single-thread figure, the reference's front-end being single-threaded).  A separate interpreter without torch; any failure just omits it.
+    try:
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_allcores.py"), str(W), str(H), str(NFEAT), str(NLINES if with_lines else 0), "6", "256"],
+                           capture_output=True, text=True, timeout=120)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        out["all_cores"] = json.loads(line[-1]) if r.returncode == 0 and line else None
+    except Exception:
+        out["all_cores"] = None
+    return out, ref
 
 
 def parity_vs_gpu(ref, feat, with_lines):
