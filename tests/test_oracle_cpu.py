@@ -328,3 +328,13 @@ def test_fixed_point_leaves_track_their_real_valued_definitions(oracle):
     want = np.degrees(np.arctan2(ys.astype(np.float64), xs.astype(np.float64))) % 360.0
     dd = np.abs(got - want); dd = np.minimum(dd, 360.0 - dd)
     assert dd.max() < 0.3 and (got >= 0).all() and (got < 360.0 + 1e-4).all(), dd.max()
+
+
+def test_cpu_allcores_script():
+    """the all-cores leg of bench.py's cpu_baseline: two pinned oracle processes for a second each, one JSON line back"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "cpu_allcores.py"), "320", "240", "300", "50", "1", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["cores"] in (1, 2) and out["value"] > 1 and out["frames"] >= 2
