@@ -217,11 +217,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    gather_ok = None
     if rank == 0 and dist is not None:
-        # the gathered records of the last step must be this rank's own packed results at every slot it owns (global frame i = local i // world on rank i % world)
-        got = gather.result()
-        mine = pipe.packed_results()
-        assert got.shape[0] == B * world and torch.equal(got[0::world], mine), "RCCL gather returned records that differ from rank 0's own"
+        # the gathered records of the last step must be this rank's own packed results at every slot it owns (global frame i = local i // world on rank i % world);
+        # reported in the JSON line (config.gather_check), never fatal for the measurement
+        try:
+            got = gather.result()
+            mine = pipe.packed_results()
+            gather_ok = bool(got.shape[0] == B * world and torch.equal(got[0::world], mine))
+            del got, mine
+        except Exception as e:
+            gather_ok = "error: %s" % (str(e)[:200],)
     if rank == 0:
         counts = pipe.feat["cur"]["n"].cpu().numpy(); lcounts = pipe.feat["cur"]["nl"].cpu().numpy()
         nm = pipe.nmatch.cpu().numpy(); nlp = pipe.nlpairs.cpu().numpy()
@@ -236,7 +242,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "unique_frames": U,
                        "mean_keypoints": float(counts.mean()), "mean_lines": float(lcounts.mean()),
                        "mean_orb_matches": float(nm.mean()), "mean_line_matches": float(nlp.mean()),
-                       "parallelism": "frames sharded %d/GPU, RCCL gather of results to rank 0 per step" % B if world > 1 else "single GPU"},
+                       "parallelism": "frames sharded %d/GPU, RCCL gather of results to rank 0 per step" % B if world > 1 else "single GPU",
+                       "gather_check": gather_ok},
         }
         if prof:
             ab = alg_bytes_per_frame(W, H, NFEAT, NLINES)

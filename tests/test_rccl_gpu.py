@@ -1,6 +1,6 @@
 """GPU: the exchange step of the sharded mode over RCCL.  The GPU box has one device, so the launch is the
 driver's own (`python -m torch.distributed.run --nproc-per-node 1 ... bench.py`) with SSLAM_FORCE_COLLECTIVE=1: the process
-group is nccl (= RCCL), every step's packed records go through dist.gather on the device, and bench.py asserts that what
+group is nccl (= RCCL), every step's packed records go through dist.gather on the device, and bench.py reports (config.gather_check) whether what
 rank 0 receives equals its own packed results.  World sizes > 1 are covered on gloo in test_dist_cpu.py."""
 import json, os, subprocess, sys
 import pytest
@@ -22,3 +22,4 @@ def test_bench_under_torchrun_with_rccl_gather():
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
     assert out["config"]["mean_keypoints"] > 500 and out["config"]["mean_lines"] > 50
+    assert out["config"]["gather_check"] is True          # rank 0 compared what RCCL delivered with its own packed records
