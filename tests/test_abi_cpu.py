@@ -46,3 +46,14 @@ def test_graft_entry_build():
     spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(ROOT, "__graft_entry__.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     m.build()
+
+
+def test_documents_name_only_declared_entry_points():
+    """every sslam_* name in the documents is declared in include/sslam_frontend.h (prefixes like `sslam_vocab_*` and the C++ shim namespace aside)"""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = set(re.findall(r"\b(sslam_[a-z0-9_]+)\b", open(os.path.join(root, "include", "sslam_frontend.h")).read()))
+    for doc in ("INTEGRATION.md", "DESIGN.md", "README.md", os.path.join("profiles", "README.md"), os.path.join("tools", "README.md")):
+        names = set(re.findall(r"\b(sslam_[a-z0-9_]+)\b", open(os.path.join(root, doc)).read()))
+        unknown = sorted(n for n in names if n not in declared and not n.startswith("sslam_shim") and not n.endswith("_"))
+        assert not unknown, (doc, unknown)
