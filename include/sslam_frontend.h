@@ -105,12 +105,25 @@ int sslam_orb_extract_batch_dev(sslam_orb* orb, const uint8_t* d_images, int w, 
                                 sslam_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
                                 int cap, void* stream);
 
+/* Batch status.  The batch kernels clamp a frame's rows to `cap` (d_counts[i] <= cap) and cannot return a status from the device, so a
+ * batch caller asks afterwards: frames of the LAST batch on this handle whose keypoint total exceeded `cap` -- the condition for which the
+ * single-frame call returns SSLAM_ERR_CAPACITY.  The host form synchronises the stream and returns SSLAM_ERR_CAPACITY when there is one
+ * (first_frame_out = its index, -1 if none); the _dev form enqueues the check and writes d_status4 = {frames over capacity, first such frame
+ * (INT_MAX if none), 0, INT_MAX}.  sslam_frontend_batch performs both checks per chunk itself. */
+int sslam_orb_batch_status(sslam_orb* orb, int cap, void* stream, int* truncated_frames_out, int* first_frame_out);
+int sslam_orb_batch_status_dev(sslam_orb* orb, int cap, int32_t* d_status4, void* stream);
+
 /* Stage taps for stage-by-stage parity tests (not used by the drop-in shim):
  * copy pyramid level `level` of frame `frame` of the LAST batch to host (unpadded,
  * contiguous w*h), and the FAST candidate list (x,y,score triplets relative to
  * minBorder, reference src/ORBextractor.cc:820-825) of that level. */
 int sslam_orb_debug_level(sslam_orb* orb, int frame, int level, uint8_t* out, int* w, int* h);
 int sslam_orb_debug_candidates(sslam_orb* orb, int frame, int level, int32_t* xys_out, int cap, int* n_out);
+/* Stage tap of GaussianBlur(7x7, sigma 2) on the level clones (src/ORBextractor.cc:1085-1086): the blurred levels are never stored
+ * (the blur is fused into the descriptor kernel), so the tap re-runs that kernel's two blur passes over the selection of frame
+ * `frame` of the LAST batch and returns, per keypoint in output order, its KeyPoint record and the blurred 37x37 window
+ * (|dx|,|dy| <= 18, row-major, in level coordinates) around it: kp_out[cap], patches_out[cap*37*37]. */
+int sslam_orb_debug_blur_patches(sslam_orb* orb, int frame, sslam_keypoint* kp_out, uint8_t* patches_out, int cap, int* n_out);
 
 /* ---- Hamming matching (replaces DescriptorDistance / BFMatcher / Search*) -- */
 /* cv::BFMatcher(NORM_HAMMING,false).knnMatch(q,t,matches,2) as used at
@@ -325,10 +338,17 @@ int sslam_lines_extract_batch_dev(sslam_lines* ln, const uint8_t* d_images, int 
                                   size_t pitch, size_t image_stride, int nframes,
                                   sslam_keyline* d_kl, uint8_t* d_ldesc, double* d_linefn,
                                   int32_t* d_counts, int cap, void* stream);
+/* Batch status of the line extractor (see sslam_orb_batch_status): frames of the last batch holding more lines than `cap`
+ * (SSLAM_ERR_CAPACITY) and frames whose LSD stage overflowed its 8192 candidate rectangles (SSLAM_ERR_UNSUPPORTED, as the single-frame call
+ * reports it).  d_status4 = {frames over capacity, first of them, frames over the LSD limit, first of them}. */
+int sslam_lines_batch_status(sslam_lines* ln, int cap, void* stream, int* truncated_frames_out, int* unsupported_frames_out, int* first_frame_out);
+int sslam_lines_batch_status_dev(sslam_lines* ln, int cap, int32_t* d_status4, void* stream);
 /* Host-buffer batch (SURVEY.md §8(b) `sslam_frontend_batch`): n frames of one size in host memory through Frame::ExtractORB and, when
  * `lines` is not NULL, Frame::ExtractLSD (src/Frame.cc:150-161); frame i starts at images + i*image_stride (row pitch `stride`).
  * Per-frame results in the caller's arrays: kp_out[n*cap], desc_out[n*cap*32], nkp_out[n], kl_out[n*lcap], ldesc_out[n*lcap*32],
- * linefn_out[n*lcap*3], nl_out[n]; rows past a frame's count are unspecified.  Frames are processed in chunks of `chunk` (0 = 512): the
+ * linefn_out[n*lcap*3], nl_out[n]; rows past a frame's count are unspecified.  A frame with more keypoints than `cap` / more lines than
+ * `lcap` makes the call return SSLAM_ERR_CAPACITY, an LSD overflow SSLAM_ERR_UNSUPPORTED (as the single-frame entry points do; the arrays
+ * then hold the truncated rows).  Frames are processed in chunks of `chunk` (0 = 512): the
  * upload of chunk k+1 and the download of chunk k-1 overlap the kernels of chunk k (two copy streams; pinned caller memory -- hipHostMalloc /
  * hipHostRegister -- is copied directly, pageable memory through pinned staging buffers).  This is the
  * PCIe-inclusive form of the batch mode; callers that already hold their frames in HBM use the *_batch_dev entry points directly. */

@@ -8,14 +8,17 @@
 
 using namespace sslam;
 
+extern "C" int sslam_orb_batch_status_dev(sslam_orb* orb, int cap, int32_t* d_status4, void* stream);
+extern "C" int sslam_lines_batch_status_dev(sslam_lines* lines, int cap, int32_t* d_status4, void* stream);
+
 namespace {
 struct Slot {
-    DevBuf dIn, dKp, dDesc, dN, dKl, dLd, dFn, dNl;
-    HostPinned hIn, hOut;
+    DevBuf dIn, dKp, dDesc, dN, dKl, dLd, dFn, dNl, dStatus;
+    HostPinned hIn, hOut, hStatus;
     hipEvent_t evIn = nullptr, evDone = nullptr, evOut = nullptr;
     int first = 0, count = 0;            // frames of the chunk in flight
     void release() {
-        dIn.release(); dKp.release(); dDesc.release(); dN.release(); dKl.release(); dLd.release(); dFn.release(); dNl.release(); hIn.release(); hOut.release();
+        dIn.release(); dKp.release(); dDesc.release(); dN.release(); dKl.release(); dLd.release(); dFn.release(); dNl.release(); dStatus.release(); hIn.release(); hOut.release(); hStatus.release();
         if (evIn) (void)hipEventDestroy(evIn);
         if (evDone) (void)hipEventDestroy(evDone);
         if (evOut) (void)hipEventDestroy(evOut);
@@ -56,16 +59,24 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
     if (hipStreamCreateWithFlags(&cp, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&cpOut, hipStreamNonBlocking) != hipSuccess) { set_error("sslam_frontend_batch: hipStreamCreate failed"); return fail(SSLAM_ERR_HIP); }
     for (auto& s : slot) {
         if ((rc = s.dIn.ensure(fpx * C)) || (rc = s.dKp.ensure(sizeof(sslam_keypoint) * (size_t)C * cap)) || (rc = s.dDesc.ensure(32 * (size_t)C * cap)) ||
-            (rc = s.dN.ensure(4 * (size_t)C)) || (!inDirect && (rc = s.hIn.ensure(fpx * C))) || (!outDirect && (rc = s.hOut.ensure(outBytes)))) return fail(rc);
+            (rc = s.dN.ensure(4 * (size_t)C)) || (rc = s.dStatus.ensure(32)) || (rc = s.hStatus.ensure(32)) || (!inDirect && (rc = s.hIn.ensure(fpx * C))) || (!outDirect && (rc = s.hOut.ensure(outBytes)))) return fail(rc);
         if (lines && ((rc = s.dKl.ensure(sizeof(sslam_keyline) * (size_t)C * lcap)) || (rc = s.dLd.ensure(32 * (size_t)C * lcap)) ||
                       (rc = s.dFn.ensure(24 * (size_t)C * lcap)) || (rc = s.dNl.ensure(4 * (size_t)C)))) return fail(rc);
         if (hipEventCreateWithFlags(&s.evIn, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.evDone, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.evOut, hipEventDisableTiming) != hipSuccess) { set_error("sslam_frontend_batch: hipEventCreate failed"); return fail(SSLAM_ERR_HIP); }
     }
+    int firstStatus = SSLAM_OK;                        // a truncated / unsupported frame does not stop the batch; it is reported at the end
     // results of a finished chunk: pinned staging -> the caller's arrays
     auto drain = [&](Slot& s) -> int {
         if (s.count == 0) return SSLAM_OK;
         if (hipEventSynchronize(s.evOut) != hipSuccess) { set_error("sslam_frontend_batch: D2H failed"); return SSLAM_ERR_HIP; }
+        // per-chunk status words (sslam_orb_batch_status_dev / sslam_lines_batch_status_dev): the conditions the single-frame calls report
+        const int* S = s.hStatus.as<int>();
+        int status = SSLAM_OK;
+        if (lines && S[6]) { set_error("sslam_frontend_batch: frame %d produced more than 8192 LSD candidate rectangles", s.first + S[7]); status = SSLAM_ERR_UNSUPPORTED; }
+        else if (S[0]) { set_error("sslam_frontend_batch: %d frame(s) of chunk %d.. hold more keypoints than cap %d (first: frame %d)", S[0], s.first, cap, s.first + S[1]); status = SSLAM_ERR_CAPACITY; }
+        else if (lines && S[4]) { set_error("sslam_frontend_batch: %d frame(s) of chunk %d.. hold more lines than lcap %d (first: frame %d)", S[4], s.first, lcap, s.first + S[5]); status = SSLAM_ERR_CAPACITY; }
+        if (status != SSLAM_OK && firstStatus == SSLAM_OK) firstStatus = status;
         if (outDirect) { s.count = 0; return SSLAM_OK; }
         const uint8_t* H = s.hOut.as<uint8_t>();
         const size_t f0 = (size_t)s.first, c = (size_t)s.count;
@@ -102,6 +113,8 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
         if ((rc = sslam_orb_extract_batch_dev(orb, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, s.dKp.as<sslam_keypoint>(), s.dDesc.as<uint8_t>(), s.dN.as<int32_t>(), cap, st))) break;
         if (lines && (rc = sslam_lines_extract_batch_dev(lines, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, s.dKl.as<sslam_keyline>(), s.dLd.as<uint8_t>(), s.dFn.as<double>(),
                                                          s.dNl.as<int32_t>(), lcap, st))) break;
+        if ((rc = sslam_orb_batch_status_dev(orb, cap, s.dStatus.as<int32_t>(), st))) break;
+        if (lines && (rc = sslam_lines_batch_status_dev(lines, lcap, s.dStatus.as<int32_t>() + 4, st))) break;
         if (hipEventRecord(s.evDone, st) != hipSuccess || hipStreamWaitEvent(cpOut, s.evDone, 0) != hipSuccess) { set_error("sslam_frontend_batch: event failed"); rc = SSLAM_ERR_HIP; break; }
         uint8_t* H = outDirect ? nullptr : s.hOut.as<uint8_t>();
         const size_t g = (size_t)f0;
@@ -110,7 +123,8 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
         void* tN = outDirect ? (void*)(nkp_out + g) : (void*)(H + oN);
         bool ok = hipMemcpyAsync(tKp, s.dKp.p, sizeof(sslam_keypoint) * (size_t)c * cap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
                   hipMemcpyAsync(tDesc, s.dDesc.p, 32 * (size_t)c * cap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
-                  hipMemcpyAsync(tN, s.dN.p, 4 * (size_t)c, hipMemcpyDeviceToHost, cpOut) == hipSuccess;
+                  hipMemcpyAsync(tN, s.dN.p, 4 * (size_t)c, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
+                  hipMemcpyAsync(s.hStatus.p, s.dStatus.p, 32, hipMemcpyDeviceToHost, cpOut) == hipSuccess;
         if (ok && lines) {
             void* tKl = outDirect ? (void*)(kl_out + g * lcap) : (void*)(H + oKl);
             void* tLd = outDirect ? (void*)(ldesc_out + 32 * g * lcap) : (void*)(H + oLd);
@@ -127,5 +141,5 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
     if (rc == SSLAM_OK) rc = drain(slot[k & 1]);          // older chunk first
     if (rc == SSLAM_OK) rc = drain(slot[(k + 1) & 1]);
     (void)hipStreamSynchronize(cp); (void)hipStreamSynchronize(cpOut); (void)hipStreamSynchronize(st);
-    return fail(rc);
+    return fail(rc != SSLAM_OK ? rc : firstStatus);
 }

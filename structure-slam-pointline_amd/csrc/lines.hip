@@ -35,6 +35,22 @@ __global__ void k_zero_misc(uint8_t* ws, LsdPlan P) {
     if (threadIdx.x == 0) { m->maxS = 0; m->nDefined = 0; m->nSeg = 0; m->nCand = 0; m->nKl = 0; m->overflow = 0; }
 }
 
+// batch status (one workgroup): status[0] = frames holding more lines than the caller's capacity (k_keylines drops the rows past
+// it), status[1] = the first of them, status[2] = frames whose LSD produced more than MAX_SEG candidate rectangles (results
+// incomplete), status[3] = the first of those; "first" is INT_MAX when there is none
+__global__ __launch_bounds__(256) void k_lines_status(const uint8_t* __restrict__ ws, LsdPlan P, int nframes, int maxLines, int cap, int* __restrict__ status) {
+    __shared__ int cnt[2], first[2];
+    if (threadIdx.x < 2) { cnt[threadIdx.x] = 0; first[threadIdx.x] = 0x7FFFFFFF; }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nframes; b += 256) {
+        const Misc* m = (const Misc*)(ws + (size_t)b * P.frameBytes + P.offMisc);
+        if (min(m->nSeg, maxLines) > cap) { atomicAdd(&cnt[0], 1); atomicMin(&first[0], b); }
+        if (m->overflow) { atomicAdd(&cnt[1], 1); atomicMin(&first[1], b); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { status[0] = cnt[0]; status[1] = first[0]; status[2] = cnt[1]; status[3] = first[1]; }
+}
+
 }  // namespace
 
 // =============================================================== host side
@@ -282,6 +298,33 @@ extern "C" int sslam_lines_extract(sslam_lines* L, const uint8_t* gray, int w, i
     memcpy(kl_out, hk, sizeof(sslam_keyline) * (size_t)n);
     memcpy(ldesc_out, hd, 32 * (size_t)n);
     memcpy(linefn_out, hf, 24 * (size_t)n);
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_lines_batch_status_dev(sslam_lines* L, int cap, int32_t* d_status4, void* stream_) {
+    if (!L || !d_status4 || cap <= 0 || L->lastFrames <= 0) { set_error("sslam_lines_batch_status_dev: invalid arguments (or no batch yet)"); return SSLAM_ERR_INVALID; }
+    SSLAM_HIP(hipSetDevice(L->ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : L->ctx->stream;
+    hipLaunchKernelGGL(k_lines_status, dim3(1), dim3(256), 0, st, L->dWs.as<uint8_t>(), L->plan, L->lastFrames, L->maxLines, cap, d_status4);
+    SSLAM_HIP(hipGetLastError());
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_lines_batch_status(sslam_lines* L, int cap, void* stream_, int* truncated_frames_out, int* unsupported_frames_out, int* first_frame_out) {
+    if (!L) { set_error("sslam_lines_batch_status: null handle"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(L->ctx->mu);
+    int rc;
+    if ((rc = L->dCounts.ensure(16))) return rc;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : L->ctx->stream;
+    if ((rc = sslam_lines_batch_status_dev(L, cap, L->dCounts.as<int32_t>(), st))) return rc;
+    int h[4] = {0, 0, 0, 0};
+    SSLAM_HIP(hipMemcpyAsync(h, L->dCounts.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    if (truncated_frames_out) *truncated_frames_out = h[0];
+    if (unsupported_frames_out) *unsupported_frames_out = h[2];
+    if (first_frame_out) *first_frame_out = h[2] ? h[3] : h[0] ? h[1] : -1;
+    if (h[2]) { set_error("sslam_lines_batch_status: %d frame(s) with more than %d candidate rectangles (first: frame %d)", h[2], MAX_SEG, h[3]); return SSLAM_ERR_UNSUPPORTED; }
+    if (h[0]) { set_error("sslam_lines_batch_status: %d frame(s) hold more lines than the capacity %d (first: frame %d)", h[0], cap, h[1]); return SSLAM_ERR_CAPACITY; }
     return SSLAM_OK;
 }
 

@@ -601,6 +601,10 @@ constexpr int PR = 21;               // patch radius: 18 (taps) + 3 (blur)
 constexpr int PW = 2 * PR + 1;       // 43
 constexpr int PP = 48;               // LDS pitch: 12 aligned dwords per row
 
+// TAP = true is the stage tap of the blur (a7, sslam_orb_debug_blur_patches): the same staging and the same two blur passes, but instead
+// of the 512 rBRIEF taps every position of the 37x37 window |dx|,|dy| <= 18 is evaluated and written to descOut (1369 bytes per keypoint).
+constexpr int TAPW = 37;
+template <bool TAP>
 __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr, size_t pyrFrame, Plan P,
                                                  const unsigned* __restrict__ sel, const int* __restrict__ selCount,
                                                  sslam_keypoint* __restrict__ kpOut, uint8_t* __restrict__ descOut,
@@ -687,6 +691,16 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
         *(uint2*)(hb + r * 40 + g4 * 4) = w2;
     }
     __syncthreads();
+    if (TAP) {
+        for (int i = lane; i < TAPW * TAPW; i += 64) {
+            const int yy = i / TAPW - 18, xx = i - (i / TAPW) * TAPW - 18;
+            const unsigned short* h = hb + (PR + yy - 3) * 40 + (18 + xx);
+            unsigned acc = 0;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) acc += (unsigned)h[q * 40] * (unsigned)kBlurTaps[q];
+            descOut[((size_t)b * cap + outIdx) * (TAPW * TAPW) + i] = (uint8_t)((acc + 32768u) >> 16);
+        }
+    }
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
     double snD, csD;
@@ -714,7 +728,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
     word |= __shfl_xor((int)word, 1, 64);
     word |= __shfl_xor((int)word, 2, 64);
     word |= __shfl_xor((int)word, 4, 64);
-    if ((lane & 7) == 0) ((unsigned*)descOut)[((size_t)b * cap + outIdx) * 8 + (lane >> 3)] = word;
+    if (!TAP && (lane & 7) == 0) ((unsigned*)descOut)[((size_t)b * cap + outIdx) * 8 + (lane >> 3)] = word;
     if (lane < 7) {
         float fx = (float)kx, fy = (float)ky;
         if (level != 0) { fx = __fmul_rn(fx, L.scale); fy = __fmul_rn(fy, L.scale); }
@@ -730,6 +744,21 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
         }
         ((unsigned*)kpOut)[((size_t)b * cap + outIdx) * 7 + lane] = w;
     }
+}
+
+// batch status: frames whose keypoint total exceeds the caller's capacity (k_describe drops the rows past it).  One workgroup.
+// status[0] = number of such frames, status[1] = the first one (INT_MAX if none), status[2..3] = 0 (the line extractor's words)
+__global__ __launch_bounds__(256) void k_orb_status(const int* __restrict__ selCount, int nlevels, int nframes, int cap, int* __restrict__ status) {
+    __shared__ int cnt, first;
+    if (threadIdx.x == 0) { cnt = 0; first = 0x7FFFFFFF; }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nframes; b += 256) {
+        int t = 0;
+        for (int l = 0; l < nlevels; ++l) t += selCount[(size_t)b * nlevels + l];
+        if (t > cap) { atomicAdd(&cnt, 1); atomicMin(&first, b); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { status[0] = cnt; status[1] = first; status[2] = 0; status[3] = 0x7FFFFFFF; }
 }
 
 }  // namespace
@@ -1017,7 +1046,7 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
     }
     {
         dim3 grd(P.selFrame, nframes);
-        { sslam::ProfScope _ps(o->ctx, "k_describe", st); hipLaunchKernelGGL(k_describe, grd, dim3(64), 0, st, pyr, P.pyrFrame, P, o->dSel.as<unsigned>(), o->dSelCount.as<int>(),
+        { sslam::ProfScope _ps(o->ctx, "k_describe", st); hipLaunchKernelGGL(k_describe<false>, grd, dim3(64), 0, st, pyr, P.pyrFrame, P, o->dSel.as<unsigned>(), o->dSelCount.as<int>(),
                            d_kp, d_desc, d_counts, cap); }
     }
     SSLAM_HIP(hipGetLastError());
@@ -1058,6 +1087,31 @@ extern "C" int sslam_orb_extract(sslam_orb* o, const uint8_t* gray, int w, int h
     return SSLAM_OK;
 }
 
+extern "C" int sslam_orb_batch_status_dev(sslam_orb* o, int cap, int32_t* d_status4, void* stream_) {
+    if (!o || !d_status4 || cap <= 0 || o->lastFrames <= 0) { set_error("sslam_orb_batch_status_dev: invalid arguments (or no batch yet)"); return SSLAM_ERR_INVALID; }
+    SSLAM_HIP(hipSetDevice(o->ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : o->ctx->stream;
+    hipLaunchKernelGGL(k_orb_status, dim3(1), dim3(256), 0, st, o->dSelCount.as<int>(), o->plan.nlevels, o->lastFrames, cap, d_status4);
+    SSLAM_HIP(hipGetLastError());
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_batch_status(sslam_orb* o, int cap, void* stream_, int* truncated_frames_out, int* first_frame_out) {
+    if (!o) { set_error("sslam_orb_batch_status: null handle"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(o->ctx->mu);
+    int rc;
+    if ((rc = o->dCounts.ensure(sizeof(int) * 4))) return rc;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : o->ctx->stream;
+    if ((rc = sslam_orb_batch_status_dev(o, cap, o->dCounts.as<int32_t>(), st))) return rc;
+    int h[4] = {0, 0, 0, 0};
+    SSLAM_HIP(hipMemcpyAsync(h, o->dCounts.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    if (truncated_frames_out) *truncated_frames_out = h[0];
+    if (first_frame_out) *first_frame_out = h[0] ? h[1] : -1;
+    if (h[0]) { set_error("sslam_orb_batch_status: %d frame(s) hold more keypoints than the capacity %d (first: frame %d)", h[0], cap, h[1]); return SSLAM_ERR_CAPACITY; }
+    return SSLAM_OK;
+}
+
 extern "C" int sslam_orb_debug_level(sslam_orb* o, int frame, int level, uint8_t* out, int* w, int* h) {
     if (!o || frame < 0 || frame >= o->lastFrames || level < 0 || level >= o->nlevels) return SSLAM_ERR_INVALID;
     SSLAM_HIP(hipSetDevice(o->ctx->device));
@@ -1090,6 +1144,37 @@ extern "C" int sslam_orb_debug_candidates(sslam_orb* o, int frame, int level, in
         }
     }
     *n_out = n;
+    return SSLAM_OK;
+}
+
+// Stage tap for a7 (GaussianBlur 7x7 sigma 2 on each level, src/ORBextractor.cc:1085-1086): the blurred image never exists in memory
+// (the blur is evaluated inside k_describe where rBRIEF taps land), so the tap re-runs k_describe<true> over the selection of the last
+// batch and returns, per keypoint in output order, the blurred 37x37 window around it plus its KeyPoint record.
+extern "C" int sslam_orb_debug_blur_patches(sslam_orb* o, int frame, sslam_keypoint* kp_out, uint8_t* patches_out, int cap, int* n_out) {
+    if (!o || frame < 0 || frame >= o->lastFrames || !kp_out || !patches_out || !n_out || cap <= 0) return SSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(o->ctx->mu);
+    SSLAM_HIP(hipSetDevice(o->ctx->device));
+    hipStream_t st = o->ctx->stream;
+    SSLAM_HIP(hipStreamSynchronize(st));
+    const Plan& P = o->plan;
+    const int icap = sslam_orb_max_keypoints(o);
+    DevBuf dk, dp, dc;
+    int rc;
+    if ((rc = dk.ensure(sizeof(sslam_keypoint) * (size_t)icap)) || (rc = dp.ensure((size_t)icap * TAPW * TAPW)) || (rc = dc.ensure(sizeof(int) * 4))) { dk.release(); dp.release(); dc.release(); return rc; }
+    hipLaunchKernelGGL(k_describe<true>, dim3(P.selFrame, 1), dim3(64), 0, st, o->dPyr.as<uint8_t>() + (size_t)frame * P.pyrFrame, P.pyrFrame, P,
+                       o->dSel.as<unsigned>() + (size_t)frame * P.selFrame, o->dSelCount.as<int>() + (size_t)frame * P.nlevels,
+                       dk.as<sslam_keypoint>(), dp.as<uint8_t>(), dc.as<int>(), icap);
+    int n = 0;
+    hipError_t e = hipMemcpyAsync(&n, dc.p, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && n <= cap) {
+        e = hipMemcpy(kp_out, dk.p, sizeof(sslam_keypoint) * (size_t)n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(patches_out, dp.p, (size_t)n * TAPW * TAPW, hipMemcpyDeviceToHost);
+    }
+    dk.release(); dp.release(); dc.release();
+    if (e != hipSuccess) { set_error("sslam_orb_debug_blur_patches: %s", hipGetErrorString(e)); return SSLAM_ERR_HIP; }
+    *n_out = n;
+    if (n > cap) { set_error("sslam_orb_debug_blur_patches: %d keypoints exceed capacity %d", n, cap); return SSLAM_ERR_CAPACITY; }
     return SSLAM_OK;
 }
 

@@ -346,6 +346,12 @@ class OrbExtractor:
         _chk(lib().sslam_orb_debug_level(self.h, frame, level, _p(out), C.byref(w), C.byref(h)))
         return out
 
+    def debug_blur_patches(self, frame=0):
+        """a7 stage tap: (keypoints, blurred 37x37 windows around them) of frame `frame` of the last call, in output order."""
+        kp = np.zeros(self.cap, KP_DTYPE); pat = np.zeros((self.cap, 37, 37), np.uint8); n = C.c_int(0)
+        _chk(lib().sslam_orb_debug_blur_patches(self.h, frame, _p(kp), _p(pat), self.cap, C.byref(n)))
+        return kp[:n.value].copy(), pat[:n.value].copy()
+
     def debug_candidates(self, frame, level, cap=400000):
         out = np.zeros((cap, 3), np.int32); n = C.c_int(0)
         _chk(lib().sslam_orb_debug_candidates(self.h, frame, level, _p(out), cap, C.byref(n)))
