@@ -32,7 +32,12 @@ namespace {
 
 __global__ void k_zero_misc(uint8_t* ws, LsdPlan P) {
     Misc* m = (Misc*)(ws + (size_t)blockIdx.x * P.frameBytes + P.offMisc);
-    if (threadIdx.x == 0) { m->maxS = 0; m->nDefined = 0; m->nSeg = 0; m->nCand = 0; m->nKl = 0; m->overflow = 0; }
+    if (threadIdx.x == 0) {
+        m->maxS = 0; m->nDefined = 0; m->nSeg = 0; m->nCand = 0; m->nKl = 0; m->overflow = 0;
+#if defined(SSLAM_LSD_DRIFT_VERIFY) || defined(SSLAM_LSD_CYCLES)
+        m->cyc[5] = 0; m->cyc[6] = 0; m->cyc[7] = 0;      // shortcut decisions that disagree with the exact test; (shortcuts << 32) + decisions
+#endif
+    }
 }
 
 // batch status (one workgroup): status[0] = frames holding more lines than the caller's capacity (k_keylines drops the rows past
@@ -231,7 +236,9 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st);
-        if (nframes < 1024) hipLaunchKernelGGL(k_lsd_regions<true>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());      // lone waves: shortest chain
+        bool lone = nframes < 1024;
+        if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) lone = e[0] == 'l';      // experiment knob: "lat" / "thr"
+        if (lone) hipLaunchKernelGGL(k_lsd_regions<true>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());      // lone waves: shortest chain
         else hipLaunchKernelGGL(k_lsd_regions<false>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());
     }
     int evalWaves = nframes >= 1024 ? 1 : nframes >= 64 ? 4 : 16;      // waves per frame walking the NFA evaluations

@@ -41,7 +41,7 @@ struct Misc {                 // per-frame scalars
 struct RectD { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 
 #ifndef SSLAM_LSD_QCAP
-#define SSLAM_LSD_QCAP 1024
+#define SSLAM_LSD_QCAP 768
 #endif
 constexpr int QCAP = SSLAM_LSD_QCAP;  // region points kept in LDS; longer regions continue in global memory
 constexpr int MAXC = 5;             // rectangle candidates evaluated per NFA job

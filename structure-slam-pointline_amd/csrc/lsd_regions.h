@@ -85,23 +85,49 @@ __global__ void k_selftest_region_div(unsigned long long seed, int iters, unsign
 // LDS permutes, immediate stores and masked staging loads with six waves per SIMD (throughput); each choice measured both ways.
 // WIDE = false needs prec < pi/2: then "fold at 3pi/2, compare" is "|d| <= prec or ||d| - 2pi| <= prec" on the very same doubles (for
 // |d| in (pi, 3pi/2] both forms say no, above 3pi/2 the first clause cannot hold) -- two compares instead of compare + select + compare.
+//
+// Drift-bounded decisions (SSLAM_LSD_DRIFT, tolerances up to 0.45 rad): the reference recomputes reg_angle = fastAtan2(sumdy, sumdx) after
+// EVERY accepted pixel, 27 dependent instructions that one whole wave executes for one pixel.  The angle is a pure function of the two
+// sums, so it only has to exist when a decision needs it.  Between two evaluations the wave keeps thetaRef (the last exact angle) and eps,
+// a rigorous bound on how far the true direction of the sums can have turned since: adding a unit vector u that makes the angle alpha with
+// S turns S by asin(|u| sin(alpha) / |S + u|) <= 1.006 alpha / max(|S'x|, |S'y|) (alpha <= 22.6 degrees because u was just accepted, and
+// |S'| >= 2.5 is required), and alpha <= dc(u) + eps + E, E = 0.0096 degrees being the largest error of the fastAtan2 polynomial (measured
+// over every float in [0, 1]).  A candidate whose circular distance dc to thetaRef is <= prec - eps - slack is accepted by the reference
+// whatever the exact angle is, one with dc >= prec + eps + slack is rejected; only a candidate inside that band forces the exact angle
+// (and resets eps).  The sums themselves are still added pixel by pixel in the reference's order, so the exact angle, whenever it is
+// evaluated, is bit-identical to the reference's.  -DSSLAM_LSD_DRIFT_VERIFY cross-checks every shortcut decision against the exact test
+// and counts disagreements in Misc::cyc[6] (cyc[7] = shortcuts << 32 | decisions; tools/lsd_drift_verify.py).
+#ifndef SSLAM_LSD_DRIFT
+#define SSLAM_LSD_DRIFT 1
+#endif
 template <bool LAT, bool WIDE>
-__device__ int region_grow_w(int seedX, int seedY, int sw, int sh, float4* __restrict__ pix, const float* __restrict__ ang, const RegQ& rq,
-                             double prec, double& regAngleOut) {
+__device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos, float seedSin, int sw, int sh, float4* __restrict__ pix, const RegQ& rq,
+                             double prec, double& regAngleOut, long long* __restrict__ verifyCnt) {
 #ifndef SSLAM_LSD_READLANE
 #define SSLAM_LSD_READLANE 0
 #endif
     constexpr bool RL = LAT || SSLAM_LSD_READLANE;      // broadcasts of the accepted lane: v_readlane for the lone wave, LDS permutes with six waves per SIMD (measured: 35.4 vs 37.2 ms)
+    constexpr bool DRIFT = !WIDE && SSLAM_LSD_DRIFT;
     const int lane = threadIdx.x & 63;
     const int seed = seedY * sw + seedX;
     int n = 1;
-    double regAngle = (double)ang[seed] * DEG2RAD;
-    float sumdx = (float)cos(regAngle), sumdy = (float)sin(regAngle);
+    double regAngle = (double)seedDeg * DEG2RAD;          // the seed's level-line angle, cos / sin: evaluated lane-parallel for a whole chunk of seed candidates (k_lsd_regions)
+    float sumdx = seedCos, sumdy = seedSin;
     if (lane == 0) { rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16)); pix[seed].x = USED_F; }
     const int g = lane >> 3, k8 = lane & 7;             // group (queue slot) and neighbour slot (centre skipped)
     const int k = k8 + (k8 >= 4 ? 1 : 0);                // row-major 3x3 position 0..8 without 4
     const int dy = k / 3 - 1, dx = k - (k / 3) * 3 - 1;
+    // drift state (degrees): thetaRef = the last exact angle, band = eps + slack with eps the bound on the turn of the sums since thetaRef,
+    // fresh = regAngle is the exact angle of the current sums
+    const float precDeg = (float)(prec * (180.0 / kPI));
+    const float minM = prec <= 0.45 ? 2.5f : 3.0e38f;    // wider tolerances (refine() can ask for them) always take the exact path
+    constexpr float DRIFT_K = 1.007f, DRIFT_E = 0.011f, DRIFT_ADD = 2e-5f, DRIFT_SLACK = 0.05f;
+    float thetaRef = seedDeg, band = DRIFT_SLACK;
+    bool fresh = true;
     int i = 0;
+#ifdef SSLAM_LSD_CYCLES
+    long long* cycStage = verifyCnt - 1;      // Misc::cyc[5..]: staging wait, accept loops, stagings (the NFA statistics of SSLAM_LSD_STATS use the same slots)
+#endif
     while (i < n) {
         const int np = min(8, n - i);
         // Lone wave: straight-line staging -- every lane loads (slots past the staged entries re-read the last entry, coordinates are
@@ -110,6 +136,9 @@ __device__ int region_grow_w(int seedX, int seedY, int sw, int sh, float4* __res
         // extra gather lanes cost more than the branches save (32.3 -> 32.8 ms per 6144 frames), so that flavour keeps the masked loads.
         int nidx = -1, xx = 0, yy = 0; float4 px4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
         unsigned long long candM;
+#ifdef SSLAM_LSD_CYCLES
+        const long long tS0 = __builtin_readcyclecounter();
+#endif
         if (LAT) {
             const unsigned e = rq.get_n(min(i + g, n - 1), n);
             xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
@@ -130,45 +159,111 @@ __device__ int region_grow_w(int seedX, int seedY, int sw, int sh, float4* __res
             }
             candM = __builtin_amdgcn_ballot_w64(cand);
         }
+#ifdef SSLAM_LSD_CYCLES
+        const long long tS1 = __builtin_readcyclecounter();
+#endif
         const int nBefore = n;
         unsigned long long accMask = 0;                    // lanes accepted from this staging, in lane (= acceptance) order
         // the live candidates and "lanes after the last accepted one" are wave-uniform 64-bit masks: scalar updates, no VALU
-        const double candRad = (double)px4.x * DEG2RAD;     // isAligned's operand, converted once per staging
         auto aligned_mask = [&]() -> unsigned long long {
             if (WIDE) return __builtin_amdgcn_ballot_w64(is_aligned_val(px4.x, regAngle, prec));
-            const double d = fabs(regAngle - candRad);
+            const double d = fabs(regAngle - (double)px4.x * DEG2RAD);
             return __builtin_amdgcn_ballot_w64(d <= prec) | __builtin_amdgcn_ballot_w64(fabs(d - M_2PI_) <= prec);
         };
-        unsigned long long m = aligned_mask() & candM;
-        while (m) {                                          // bottom-tested: the next mask is computed right after the angle update
-            const int sel = __ffsll((long long)m) - 1;       // wave-uniform
-            const int selIdx = RL ? __builtin_amdgcn_readlane(nidx, sel) : __builtin_amdgcn_ds_bpermute(sel << 2, nidx);
-            if (LAT) accMask |= 1ull << sel;               // lone wave: the used-map / queue stores follow the loop, all lanes at once
-            else if (lane == sel) {                        // LDS slot QCAP is a sink, so the common case has no branch around the store
-                const unsigned v = (unsigned)xx | ((unsigned)yy << 16);
-                pix[nidx].x = USED_F; rq.lds[min(n, QCAP)] = v;
-                if (n >= QCAP) rq.glb[n] = v;
+        unsigned long long live = candM;                      // candidates that are still to be decided: the lanes above the last accepted one
+        if (!DRIFT) {
+            unsigned long long m = aligned_mask() & live;
+            while (m) {                                          // bottom-tested: the next mask is computed right after the angle update
+                const int sel = __ffsll((long long)m) - 1;       // wave-uniform
+                const int selIdx = RL ? __builtin_amdgcn_readlane(nidx, sel) : __builtin_amdgcn_ds_bpermute(sel << 2, nidx);
+                if (LAT) accMask |= 1ull << sel;               // lone wave: the used-map / queue stores follow the loop, all lanes at once
+                else if (lane == sel) {                        // LDS slot QCAP is a sink, so the common case has no branch around the store
+                    const unsigned v = (unsigned)xx | ((unsigned)yy << 16);
+                    pix[nidx].x = USED_F; rq.lds[min(n, QCAP)] = v;
+                    if (n >= QCAP) rq.glb[n] = v;
+                }
+                ++n;
+                sumdx = __fadd_rn(sumdx, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.y), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.y))));
+                sumdy = __fadd_rn(sumdy, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.z), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.z))));
+                regAngle = (double)fast_atan2_deg_unit(sumdy, sumdx) * DEG2RAD;
+                candM &= ~__builtin_amdgcn_ballot_w64(nidx == selIdx);      // the accepted pixel is now USED for every later visitor
+                m = aligned_mask() & candM & (~1ull << sel);                // only lanes above sel
             }
-            ++n;
-            sumdx = __fadd_rn(sumdx, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.y), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.y))));
-            sumdy = __fadd_rn(sumdy, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.z), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.z))));
-            regAngle = (double)fast_atan2_deg_unit(sumdy, sumdx) * DEG2RAD;
-            candM &= ~__builtin_amdgcn_ballot_w64(nidx == selIdx);      // the accepted pixel is now USED for every later visitor
-            m = aligned_mask() & candM & (~1ull << sel);                // only lanes above sel
+        } else {
+            // per lane and per reference angle: which side of the tolerance the candidate is on, and how far from it
+            float dc, u; unsigned long long side;
+            auto classify = [&]() {
+                const float d = fabsf(__fsub_rn(thetaRef, px4.x));
+                dc = fminf(d, __fsub_rn(360.f, d));                          // circular distance of the lane's level-line angle to thetaRef
+                u = fabsf(__fsub_rn(dc, precDeg));
+                side = __builtin_amdgcn_ballot_w64(dc <= precDeg);
+            };
+            classify();
+            while (live) {
+                const unsigned long long unc = __builtin_amdgcn_ballot_w64(u < band);       // the exact angle could decide these either way
+                const unsigned long long cm = (side | unc) & live;                          // everything that is not certainly rejected
+#ifdef SSLAM_LSD_DRIFT_VERIFY
+                {
+                    const double ra = (double)fast_atan2_deg_unit(sumdy, sumdx) * DEG2RAD;
+                    const double d = fabs(ra - (double)px4.x * DEG2RAD);
+                    const unsigned long long mx = (__builtin_amdgcn_ballot_w64(d <= prec) | __builtin_amdgcn_ballot_w64(fabs(d - M_2PI_) <= prec)) & live;
+                    const int selX = mx ? __ffsll((long long)mx) - 1 : -1, selC = cm ? __ffsll((long long)cm) - 1 : -1;
+                    const bool decided = selC < 0 || !((unc >> selC) & 1ull);
+                    if (decided && selC != selX && lane == 0 && verifyCnt) atomicAdd((unsigned long long*)verifyCnt, 1ull);
+                    if (lane == 0 && verifyCnt) atomicAdd((unsigned long long*)verifyCnt + 1, decided ? 0x100000001ull : 1ull);   // lo: decisions, hi: shortcuts
+                }
+#endif
+                if (!cm) break;
+                int sel = __ffsll((long long)cm) - 1;             // wave-uniform
+                if ((unc >> sel) & 1ull) {                       // inside the band: this decision needs the exact angle of the current sums
+                    if (!fresh) {
+                        const float a = fast_atan2_deg_unit(sumdy, sumdx);
+                        regAngle = (double)a * DEG2RAD; thetaRef = a; band = DRIFT_SLACK; fresh = true;
+                        classify();
+                    }
+                    const unsigned long long m = aligned_mask() & live;
+                    if (!m) break;
+                    sel = __ffsll((long long)m) - 1;
+                }
+                const int selIdx = RL ? __builtin_amdgcn_readlane(nidx, sel) : __builtin_amdgcn_ds_bpermute(sel << 2, nidx);
+                if (LAT) accMask |= 1ull << sel;
+                else if (lane == sel) {
+                    const unsigned v = (unsigned)xx | ((unsigned)yy << 16);
+                    pix[nidx].x = USED_F; rq.lds[min(n, QCAP)] = v;
+                    if (n >= QCAP) rq.glb[n] = v;
+                }
+                ++n;
+                sumdx = __fadd_rn(sumdx, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.y), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.y))));
+                sumdy = __fadd_rn(sumdy, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.z), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.z))));
+                {   // the sums turned by at most K (dc(sel) + eps + E) / max(|S'x|, |S'y|) + ADD degrees (eps + E = band - slack + E)
+                    const float dcs = __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(dc), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(dc)));
+                    const float M = fmaxf(fabsf(sumdx), fabsf(sumdy));
+                    const float aK = __builtin_fmaf(__fadd_rn(dcs, band), DRIFT_K, (DRIFT_E - DRIFT_SLACK) * DRIFT_K);
+                    const float r = M < minM ? 1.0e9f : __builtin_amdgcn_rcpf(M);
+                    band = __fadd_rn(__builtin_fmaf(aK, r, band), DRIFT_ADD);
+                    fresh = false;
+                }
+                candM &= ~__builtin_amdgcn_ballot_w64(nidx == selIdx);      // the accepted pixel is now USED for every later visitor
+                live = candM & (~1ull << sel);                              // only lanes above sel
+            }
         }
         if (LAT && accMask != 0 && ((accMask >> lane) & 1ull)) { pix[nidx].x = USED_F; rq.set(nBefore + mbcnt(accMask), (unsigned)xx | ((unsigned)yy << 16)); }
+#ifdef SSLAM_LSD_CYCLES
+        if (verifyCnt) { const long long tS2 = __builtin_readcyclecounter(); cycStage[0] += tS1 - tS0; cycStage[1] += tS2 - tS1; cycStage[2] += 1; }
+#endif
         i += np;
     }
+    if (DRIFT && !fresh) regAngle = (double)fast_atan2_deg_unit(sumdy, sumdx) * DEG2RAD;
     regAngleOut = regAngle;
     return n;
 }
 
 template <bool LAT>
-__device__ __forceinline__ int region_grow_m(int seedX, int seedY, int sw, int sh, float4* __restrict__ pix, const float* __restrict__ ang, const RegQ& rq,
-                                             double prec, double& regAngleOut) {
+__device__ __forceinline__ int region_grow_m(int seedX, int seedY, float seedDeg, float seedCos, float seedSin, int sw, int sh, float4* __restrict__ pix, const RegQ& rq,
+                                             double prec, double& regAngleOut, long long* __restrict__ verifyCnt) {
     // the first growth runs at 22.5 degrees; refine()'s tolerance (two standard deviations of the angles) is normally smaller still
-    if (prec < 1.5) return region_grow_w<LAT, false>(seedX, seedY, sw, sh, pix, ang, rq, prec, regAngleOut);
-    return region_grow_w<LAT, true>(seedX, seedY, sw, sh, pix, ang, rq, prec, regAngleOut);
+    if (prec < 1.5) return region_grow_w<LAT, false>(seedX, seedY, seedDeg, seedCos, seedSin, sw, sh, pix, rq, prec, regAngleOut, verifyCnt);
+    return region_grow_w<LAT, true>(seedX, seedY, seedDeg, seedCos, seedSin, sw, sh, pix, rq, prec, regAngleOut, verifyCnt);
 }
 
 // Three fp64 running sums that must be folded strictly in region order (the reference adds point after point).  The wave
@@ -319,6 +414,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
     const int sw = P.sw, sh = P.sh;
     RegQ rq; rq.lds = dynLds; rq.glb = (unsigned*)(base + P.offReg);
     __shared__ double red[3 * 64];                                 // addends of the ordered fp64 sums
+    __shared__ float4 seedStash[64];                               // per seed candidate of the current chunk: angle, cos, sin, x | y << 16
     __syncthreads();
     const int nOrd = misc->nDefined;
     const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
@@ -334,30 +430,48 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
     for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
         const int q = pos0 + lane;
         const int idx = q < nOrd ? (int)order[q] : -1;
-        int after = -1;                                    // lanes <= after are consumed
-        while (true) {
-            const bool un = idx >= 0 && lane > after && pix[idx].x >= 0.f;
-            const unsigned long long m = __ballot(un);
-            if (!m) break;
-            const int first = __ffsll((long long)m) - 1;
-            after = first;
-            const int seed = LAT ? __builtin_amdgcn_readlane(idx, first) : __shfl(idx, first, 64);
-            const int sy = seed / sw, sx = seed - sy * sw;
+        // One gather per chunk of 64 seed candidates: pix.x is the candidate's level-line angle while it is unused.  What a region start
+        // needs from its seed -- coordinates, the angle, cos and sin of it (two fp64 evaluations that the whole wave used to execute for ONE
+        // seed, after a dependent load of the angle) -- is computed here for all 64 candidates at once and parked in LDS.
+        const float a0 = idx >= 0 ? pix[idx].x : -1.f;
+        unsigned long long unM = __ballot(a0 >= 0.f);         // candidates of this chunk that are still unused (wave-uniform, kept up to date below)
+        if (!unM) continue;
+        {
+            const int cy = idx / sw, cx = idx - cy * sw;
+            const double ar = (double)a0 * DEG2RAD;
+            seedStash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
+        }
+        while (unM) {
+            const int first = __ffsll((long long)unM) - 1;
+            unM &= unM - 1;                                   // the seed itself is consumed whatever happens
+            const float4 sd = seedStash[first];               // wave-uniform address: one broadcast read
+            const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
             double regAngle;
             long long t0 = SSLAM_CLK();
-            int n = region_grow_m<LAT>(sx, sy, sw, sh, pix, ang, rq, prec, regAngle);
+            int n = region_grow_m<LAT>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, prec, regAngle, &misc->cyc[6]);
             long long t1 = SSLAM_CLK(); cyc0 += t1 - t0;
-            if (n < P.minRegSize) continue;
+            if (n < P.minRegSize) {
+                // too small: rejected, its pixels stay used.  Which candidates of this chunk did it take?  Compare them with the (few) points of
+                // the region instead of gathering 64 pixel records again.
+                for (int k = 1; k < n; ++k) {
+                    const unsigned e = rq.lds[k];             // minRegSize < QCAP
+                    unM &= ~__ballot(idx == (int)(e >> 16) * sw + (int)(e & 0xFFFF));
+                }
+                continue;
+            }
             RectD rec;
+            bool emit = false;
+            long long t2 = t1;
+            do {
             region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
-            long long t2 = SSLAM_CLK(); cyc1 += t2 - t1;
+            t2 = SSLAM_CLK(); cyc1 += t2 - t1;
             // ---- refine (LSD_REFINE_STD part)
             double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
             if (density < DENSITY_TH) {
                 const unsigned e0 = rq.get(0);
                 const int x0 = e0 & 0xFFFF, y0 = e0 >> 16;
                 const double xc = (double)x0, yc = (double)y0;
-                const double ang_c = (double)ang[y0 * sw + x0] * DEG2RAD;
+                const double ang_c = (double)sd.x * DEG2RAD;      // reg[0] is the seed
                 OrdSum SR; SR.acc = 0; int cnt = 0;
                 for (int bs = 0; bs < n; bs += 64) {
                     const int i = bs + lane;
@@ -377,8 +491,8 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                 const double sum = ordered_sums_get(SR, 0), s_sum = ordered_sums_get(SR, 1);
                 const double mean_angle = sum / (double)cnt;
                 const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-                n = region_grow_m<LAT>(x0, y0, sw, sh, pix, ang, rq, tau, regAngle);
-                if (n < 2) continue;
+                n = region_grow_m<LAT>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pix, rq, tau, regAngle, &misc->cyc[6]);
+                if (n < 2) break;
                 region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
                 density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
                 if (density < DENSITY_TH) {
@@ -408,12 +522,18 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                         density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
                     }
                     cyc3 += SSLAM_CLK() - tr0;
-                    if (!good) continue;
+                    if (!good) break;
                 }
             }
+            emit = true;
+            } while (false);
             // ---- hand the rectangle to the NFA stage (rect_improve reads only the static angle map and never touches
             // `used`, so it is not part of the sequential dependency chain: k_lsd_nfa evaluates all candidates in parallel)
             long long t3 = SSLAM_CLK(); cyc2 += t3 - t2;
+            // a region of this size -- kept or not, refine() may have released pixels again -- can have changed any candidate of the chunk:
+            // gather their state once more (candidates before the seed are never revisited, as in the reference's forward loop)
+            unM = __ballot(idx >= 0 && lane > first && pix[idx].x >= 0.f);
+            if (!emit) continue;
             if (nSeg < MAX_SEG && lane == 0) {
                 double* o = candOut + (size_t)nSeg * 12;
                 o[0] = rec.x1; o[1] = rec.y1; o[2] = rec.x2; o[3] = rec.y2; o[4] = rec.width; o[5] = rec.x; o[6] = rec.y;

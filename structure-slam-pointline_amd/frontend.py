@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsslam_frontend.so")
+LIB_PATH = os.environ.get("SSLAM_LIB") or os.path.join(HERE, "lib", "libsslam_frontend.so")      # SSLAM_LIB: kernel-variant experiments (tools/build_variant.sh)
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
