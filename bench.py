@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
 """bench.py — front-end frames/sec (ORB + LSD/LBD extract + match) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3] [--batch B] [--unique U]
 
-A "step" is one pass of the hot path over one batch of B synthetic 640x480 frames that
-are already resident in HBM: ORB extract (1000 kp, 8 levels), LSD+LBD extract (<=200
-lines), and matching against the previous frame's features (SearchForInitialization +
-dense knn-2 for ORB, knn-2 + MAD gate for lines)  == BASELINE.json configs[2].
-With --gpus N (launched under torch.distributed.run, one rank per GPU) every rank processes
-its own B frames (weak scaling, frames are independent units) and the per-frame results are
-gathered to rank 0 over RCCL once per step; no other collective exists on the path.
+A "step" is one pass of the hot path over one batch of B synthetic 640x480 frames that are already resident in HBM: ORB extract
+(1000 kp, 8 levels), LSD+LBD extract (<=200 lines), and matching against the previous frame's features (SearchForInitialization +
+dense knn-2 for ORB, knn-2 + MAD gate for lines)  == BASELINE.json configs[2].  With --gpus N (launched under torch.distributed.run,
+one rank per GPU) every rank processes its own B frames (weak scaling, frames are independent units) and the compacted per-frame records
+are gathered to rank 0 once per step through the library's own RCCL exchange (sslam_group_gather_dev: ncclSend / ncclRecv), overlapped
+with the next step's kernels; no other collective exists on the path.
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel,
-algorithmic bytes from SURVEY.md §8(d) / DESIGN.md over the HIP-event launch duration) and
-`cpu_baseline` (the CPU oracle = restatement of the reference path, 1 core, bounded sample).
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline        dominant kernel: algorithmic bytes (SURVEY.md §8(d) / DESIGN.md) over the HIP-event launch duration; whole pipeline
+                  with §8(d)'s own 18 566 506 B/frame next to the per-kernel table's sum
+  cpu_baseline    the CPU oracle (restatement of the reference path, "port"), one core, bounded sample, -O3 -march=native built on this box
+  latency         single-frame H2D -> kernels -> D2H through the host entry points (what the drop-in shim calls per frame), p50/p90
+  pcie_inclusive  sslam_frontend_batch: host images in, host records out (pinned and pageable)
 """
 import argparse, json, os, sys, time
 
@@ -23,23 +25,43 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 W, H = 640, 480
 NFEAT, NLINES = 1000, 200
 WORKLOADS = {     # BASELINE.json configs; c3 (configs[2]) is the one the metric is quoted on and the default
-    "c2": dict(w=640, h=480, nfeat=1000, nlines=0, match=False, batch=3072, name="BASELINE configs[1]: single synthetic 640x480 frame stream, ORB-only (1000 kp, 8 levels)"),
-    "c3": dict(w=640, h=480, nfeat=1000, nlines=200, match=True, batch=6144, name="BASELINE configs[2]: 640x480 ORB(1000kp,8 levels)+LSD/LBD(<=200 lines) extract + Hamming match vs previous frame, inputs resident in HBM"),
-    "c4": dict(w=1280, h=960, nfeat=2000, nlines=400, match=True, batch=3072, name="BASELINE configs[3]: 1280x960 ORB(2000kp)+LSD/LBD(<=400 lines) extract + match, inputs resident in HBM"),
+    "c2": dict(w=640, h=480, nfeat=1000, nlines=0, match=False, batch=3072, unique=64, name="BASELINE configs[1]: single synthetic 640x480 frame stream, ORB-only (1000 kp, 8 levels)"),
+    "c3": dict(w=640, h=480, nfeat=1000, nlines=200, match=True, batch=6144, unique=64, name="BASELINE configs[2]: 640x480 ORB(1000kp,8 levels)+LSD/LBD(<=200 lines) extract + Hamming match vs previous frame, inputs resident in HBM"),
+    "c4": dict(w=1280, h=960, nfeat=2000, nlines=400, match=True, batch=1536, unique=16, name="BASELINE configs[3]: 1280x960 ORB(2000kp)+LSD/LBD(<=400 lines) extract + match, inputs resident in HBM"),
+    "c5": dict(w=640, h=480, nfeat=1000, nlines=200, match=True, batch=8, unique=8, h2d=True, sync_gather=True,
+               name="BASELINE configs[4]: 8 independent 640x480 frames sharded over the GPUs (8/N per GPU), H2D + extract + match + RCCL gather of keypoints/lines inside the timed step"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def alg_bytes_per_frame(w, h, nkp, nln):
-    """Algorithmic HBM bytes per frame per kernel (SURVEY.md §8(d) + Appendix B byte model,
-    split per kernel in DESIGN.md §roofline).  P = pyramid level pixels."""
+def level_pixels(w, h):
     import numpy as np
-    P = []
+    P, PP = [], []
     sc = np.float32(1.0)
     for l in range(8):
         isc = np.float32(1.0) / sc
-        P.append(int(np.rint(np.float32(w) * isc)) * int(np.rint(np.float32(h) * isc)))
+        lw, lh = int(np.rint(np.float32(w) * isc)), int(np.rint(np.float32(h) * isc))
+        P.append(lw * lh); PP.append((lw + 38) * (lh + 38))
         sc = np.float32(sc * np.float32(1.2))
+    return P, PP
+
+
+def survey_bytes_per_frame(w, h, nkp, nln):
+    """SURVEY.md §8(d) / Appendix B byte model, verbatim (18 566 506 B at 640x480 / 1000 / 200; 59 595 532 B at 1280x960 / 2000 / 400)"""
+    P, PP = level_pixels(w, h)
+    s = int(round(w * 0.8)) * int(round(h * 0.8))
+    orb = w * h + sum(PP) + sum(P[:-1]) + sum(P) + 2 * sum(P) + nkp * (2 * 961 + 32 + 28)
+    lsd = 3 * w * h + s + s + 8 * s + 4 * s + 5 * s
+    lbd = w * h + 4 * w * h + nln * 63 * 100 * 4 + nln * 100
+    match = 2 * 32 * nkp + 8 * nkp + 2 * 32 * nln + 16 * nln
+    return orb + lsd + lbd + match
+
+
+def alg_bytes_per_frame(w, h, nkp, nln):
+    """Algorithmic HBM bytes per frame per kernel: the same byte model split per kernel as THIS implementation moves the data.
+    It differs from §8(d)'s total where the structure differs: no padded pyramid (-0.21 MB), an 8-byte/pixel counting-sort pass the survey's
+    "ordered-list write" does not price (+1.57 MB), knn-2 outputs, the rectangle counter's angle-map rows."""
+    P, PP = level_pixels(w, h)
     sP = sum(P)
     s08 = int(round(w * 0.8)) * int(round(h * 0.8))
     return {
@@ -52,7 +74,8 @@ def alg_bytes_per_frame(w, h, nkp, nln):
         "k_lsd_grad": (w * h + s08) + s08 + 8 * s08,        # 0.8x resample (fused: blurred read, scaled image) + gradient read, fp32 angle + int magnitude write
         "k_lsd_hist": 8 * s08, "k_lsd_scan": 0, "k_lsd_scatter": 4 * s08,    # ordered-list build
         "k_lsd_regions": 5 * s08,                           # region-grow reads (angle + magnitude + used)
-        "k_nfa_count": 0, "k_nfa_eval": 0, "k_nfa_accept": 0, "k_nfa_finish": 0,      # rectangle validation: angle-map rows under ~400 rectangles, cache resident
+        "k_nfa_count": 2 * nln * 100 * 6 * 4,               # angle-map rows under ~2 nln candidate rectangles of a nominal 100 x 6 pixels, 4 B each
+        "k_nfa_eval": 0, "k_nfa_accept": 0, "k_nfa_finish": 0,      # rectangle records only
         "k_keylines": nln * (16 + 68 + 24),
         "k_blur_sobel": w * h + 4 * w * h,                  # fused LBD pre-blur + Sobel: source read, {dx,dy} s16 pair write
         "k_lbd": nln * 63 * 100 * 4 + nln * 100,            # band reads at a nominal 100-px line + descriptor
@@ -62,26 +85,46 @@ def alg_bytes_per_frame(w, h, nkp, nln):
     }
 
 
-def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=600, with_lines=True, with_match=True):
-    """The CPU oracle (a restatement of the reference's CPU path; kind "port") timed on this box's
-    host cores, single thread like the reference's front-end (src/Frame.cc:86-87)."""
+def synth_frames(w, h, U, rank):
+    """U distinct seeded scenes per rank (+ their warped previous frames): object count and noise vary from frame to frame, so the LSD core's
+    content-dependent work varies too.  Cached in /tmp (generation costs ~0.2 s per 640x480 frame)."""
+    import numpy as np
+    from synth import synth_frame, warp_prev
+    cache = "/tmp/sslam_bench_frames_%dx%d_%d_r%d.npz" % (w, h, U, rank)
+    if os.path.exists(cache):
+        z = np.load(cache)
+        return list(z["cur"]), list(z["prev"])
+    area = (w * h) / (640 * 480)
+    cur = []
+    for i in range(U):
+        k = i % 8      # eight kinds of scene: the default density (the round-1 frames), sparser / denser, more noise
+        ns, nst, noise = [(60, 40, 2.0), (35, 25, 2.0), (90, 60, 2.0), (60, 40, 3.5), (45, 70, 1.0), (75, 30, 2.5), (60, 40, 2.0), (50, 50, 2.0)][k]
+        cur.append(synth_frame(2000 + rank * 1000 + i, w, h, nshapes=int(ns * area), nstrokes=int(nst * area), noise=noise))
+    prev = [warp_prev(f) for f in cur]
+    try:
+        np.savez(cache, cur=np.stack(cur), prev=np.stack(prev))
+    except Exception:
+        pass
+    return cur, prev
+
+
+def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=600, with_lines=True, with_match=True, nref=8):
+    """The CPU oracle (a restatement of the reference's CPU path; kind "port") timed on this box's host cores, single thread like the
+    reference's front-end (src/Frame.cc:86-87), built here with the reference's flags -O3 -march=native (CMakeLists.txt:10-11)."""
     import numpy as np
     import oracle_lib
-    orc = oracle_lib.Oracle()
-    t0 = time.perf_counter()
-    n = 0
-    prev_feat = None
-    # prime "previous" features outside the timed loop
-    pk, pd = orc.orb_extract(frames_prev[0], NFEAT)
+    orc = oracle_lib.Oracle(native=True)
+    pk, pd = orc.orb_extract(frames_prev[0], NFEAT)      # prime "previous" features outside the timed loop
     pl = orc.lines_extract(frames_prev[0], NLINES) if with_lines else None
     t0 = time.perf_counter()
-    ref = []        # the oracle's outputs for the first pass over the distinct frames: compared with the GPU batch after the timing
+    n = 0
+    ref = []        # the oracle's outputs for the first distinct frames: compared with the GPU batch after the timing
     while n < max_frames and (time.perf_counter() - t0) < budget_s:
         cur = frames_cur[n % len(frames_cur)]
         kp, d = orc.orb_extract(cur, NFEAT)
         if with_lines:
             kl, ld, fn, raw = orc.lines_extract(cur, NLINES)
-        if n < len(frames_cur):
+        if n < min(nref, len(frames_cur)):
             ref.append((kp, d, kl if with_lines else None, ld if with_lines else None))
         if with_match:
             pm = np.stack([pk["x"], pk["y"]], axis=1).astype(np.float32)
@@ -92,7 +135,9 @@ def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=600, with_li
         n += 1
     dt = time.perf_counter() - t0
     out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d frames of the same %dx%d workload (ORB %d%s%s), %.1f s, single thread" % (n, W, H, NFEAT, " + LSD/LBD %d" % NLINES if with_lines else "", " + matches" if with_match else "", dt)}
+           "flags": "-O3 -march=native -ffp-contract=off, built on this host" if orc.native else "-O3 generic x86-64 (the native build failed on this host)",
+           "sample": "%d frames of the same %dx%d workload (ORB %d%s%s), %.1f s, single thread" % (n, W, H, NFEAT, " + LSD/LBD %d" % NLINES if with_lines else "", " + SearchForInitialization + dense knn-2 + line match" if with_match else "", dt),
+           "note": "the workload's dense 1000x1000 knn-2 (SURVEY.md §8(d) config 3) is part of both sides; the reference itself only runs the windowed search per frame"}
     # the same oracle as N independent single-threaded processes, one pinned per host core (informational; `value` stays the
     # single-thread figure, the reference's front-end being single-threaded).  A separate interpreter without torch; any failure just omits it.
     try:
@@ -122,6 +167,52 @@ def parity_vs_gpu(ref, feat, with_lines):
     return res
 
 
+def latency_leg(fe, ctx, frames, with_lines, nframes=120):
+    """SURVEY §8(d) "GPU timing protocol": per frame H2D -> kernels -> D2H through the synchronous host entry points sslam_orb_extract +
+    sslam_lines_extract -- exactly what Frame::ExtractORB / ExtractLSD (src/Frame.cc:150-161) call through the shim, one frame at a time.
+    HIP events on the context's stream bracket each call (the call's own copies and kernels run on that stream); wall clock beside it."""
+    import numpy as np, torch
+    ox = fe.OrbExtractor(ctx, NFEAT); lx = fe.LineExtractor(ctx, NLINES) if with_lines else None
+    st = torch.cuda.ExternalStream(ctx.stream)
+    for f in frames[:3]:
+        ox(f)
+        if lx: lx(f)
+    ev = []; wall = []
+    for i in range(nframes):
+        f = frames[i % len(frames)]
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        t0 = time.perf_counter()
+        e0.record(st); ox(f); e1.record(st)
+        if lx: lx(f)
+        e2.record(st)
+        wall.append((time.perf_counter() - t0) * 1e3); ev.append((e0, e1, e2))
+    torch.cuda.synchronize()
+    orb = np.array([a.elapsed_time(b) for a, b, c in ev]); lin = np.array([b.elapsed_time(c) for a, b, c in ev]); wall = np.array(wall)
+    ox.close()
+    if lx: lx.close()
+    pct = lambda a: {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "max": float(a.max())}
+    return {"unit": "ms", "frames": nframes, "path": "sslam_orb_extract + sslam_lines_extract per frame (host image in, host results out)",
+            "orb_extract_hipEvent": pct(orb), "lines_extract_hipEvent": pct(lin) if with_lines else None, "frame_hipEvent": pct(orb + lin), "frame_wall": pct(wall),
+            "frames_per_s_one_at_a_time": float(1e3 / np.median(wall))}
+
+
+def pcie_leg(fe, ctx, frames, with_lines, n=2048, chunk=1024):
+    """sslam_frontend_batch: host images in, host records out, copies overlapped with kernels (extract only: the API of SURVEY §8(b))."""
+    import numpy as np, torch
+    ox = fe.OrbExtractor(ctx, NFEAT); lx = fe.LineExtractor(ctx, NLINES) if with_lines else None
+    U = len(frames)
+    host = np.stack([frames[i % U] for i in range(n)])
+    out = {"entry": "sslam_frontend_batch", "frames": n, "chunk": chunk, "note": "extract only (ORB + LSD/LBD), H2D of chunk k+1 and D2H of chunk k-1 under the kernels of chunk k; result allocation inside the timed region"}
+    fe.frontend_batch(ox, lx, host[:chunk], chunk=chunk)          # workspace allocation outside the timing
+    t0 = time.perf_counter(); fe.frontend_batch(ox, lx, host, chunk=chunk); out["pageable_frames_per_s"] = n / (time.perf_counter() - t0)
+    pin = torch.empty(host.shape, dtype=torch.uint8, pin_memory=True); pin.numpy()[:] = host
+    fe.frontend_batch(ox, lx, pin.numpy()[:chunk], chunk=chunk, pinned=True)
+    t0 = time.perf_counter(); fe.frontend_batch(ox, lx, pin.numpy(), chunk=chunk, pinned=True); out["pinned_frames_per_s"] = n / (time.perf_counter() - t0)
+    ox.close()
+    if lx: lx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,9 +220,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: the workload's)")
-    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
+    ap.add_argument("--unique", type=int, default=0, help="distinct synthetic frames per rank, tiled to the batch (default: the workload's, 64 for c3)")
     ap.add_argument("--overlap", action="store_true", help="run the point and line branches on two streams (off by default: the persistent LSD kernel wants every wave slot, sharing them costs a second round)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the latency and PCIe-inclusive legs")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing (used for rocprofv3 runs)")
     args = ap.parse_args()
 
@@ -139,12 +231,10 @@ def main():
     import numpy as np
     import torch
     import pkg
-    from synth import synth_frame, warp_prev
     global W, H, NFEAT, NLINES
     wl = WORKLOADS[args.workload]
     W, H, NFEAT, NLINES = wl["w"], wl["h"], wl["nfeat"], max(wl["nlines"], 1)
-    if args.batch <= 0:
-        args.batch = wl["batch"]
+    with_lines = wl["nlines"] > 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -155,6 +245,8 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; this framework has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    if args.batch <= 0:
+        args.batch = max(1, wl["batch"] // world) if args.workload == "c5" else wl["batch"]
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
@@ -164,37 +256,49 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))      # bootstrap, barrier and the max-over-ranks timing only
 
     fe = pkg.frontend()
     pipeline = pkg._load("sslam_pipeline", os.path.join(pkg.PKG_DIR, "pipeline.py"))
+    sharding = pkg._load("sslam_sharding", os.path.join(pkg.PKG_DIR, "sharding.py"))
     ctx = fe.Context(local_rank)
     B = args.batch
-    # synthetic frames: `unique` distinct scenes per rank (seeds 2000+), each with its warped previous frame
-    U = max(1, min(args.unique, B))
-    cur_np = [synth_frame(2000 + rank * 64 + i, W, H) for i in range(U)]
-    prev_np = [warp_prev(f) for f in cur_np]
+    U = max(1, min(args.unique if args.unique > 0 else wl["unique"], B))
+    cur_np, prev_np = synth_frames(W, H, U, rank)
     reps = (B + U - 1) // U
     cur = torch.from_numpy(np.stack(cur_np)).to(dev).repeat(reps, 1, 1)[:B].contiguous()
     prev = torch.from_numpy(np.stack(prev_np)).to(dev).repeat(reps, 1, 1)[:B].contiguous()
+    host_cur = None
+    if wl.get("h2d"):
+        host_cur = torch.empty((B, H, W), dtype=torch.uint8, pin_memory=True); host_cur.copy_(cur)
 
-    pipe = pipeline.FrontendBatch(fe, ctx, W, H, B, NFEAT, NLINES, dev, with_lines=wl["nlines"] > 0, with_match=wl["match"])
-    # previous-frame features: extracted once, resident (the stream's t-1 state)
-    pipe.extract(prev, "prev")
+    pipe = pipeline.FrontendBatch(fe, ctx, W, H, B, NFEAT, NLINES, dev, with_lines=with_lines, with_match=wl["match"])
+    pipe.extract(prev, "prev")      # previous-frame features: extracted once, resident (the stream's t-1 state)
     torch.cuda.synchronize()
 
-    sharding = pkg._load("sslam_sharding", os.path.join(pkg.PKG_DIR, "sharding.py"))
-
-    gather = sharding.AsyncGather(dist, world, rank, always_collective=force_collective)
+    gather = None
+    if dist is not None:
+        # the library's own communicator (RCCL through the C ABI): rank 0 makes the id, torch.distributed only carries it to the others
+        uid = torch.from_numpy(fe.Group.unique_id()).to(dev) if rank == 0 else torch.zeros(128, dtype=torch.uint8, device=dev)
+        dist.broadcast(uid, src=0)
+        if force_collective and world == 1:
+            os.environ["SSLAM_GROUP_SELF_SENDRECV"] = "1"      # one rank: route its own records through ncclSend / ncclRecv so that RCCL moves the bytes
+        group = fe.Group(device=local_rank, rank=rank, nranks=world, uid=uid.cpu().numpy())
+        gather = sharding.GroupGather(fe, ctx, group, pipe, dev)
 
     def one_step():
+        if host_cur is not None:
+            cur.copy_(host_cur, non_blocking=True)             # configs[4]: the H2D of the frames is part of the step
         pipe.step(cur, overlap=args.overlap)
-        if dist is not None:      # the one exchange step of the path: per-frame records to rank 0 over RCCL,
-            gather.submit(pipe.packed_results())      # overlapped with the next step's kernels
+        if gather is not None:      # the one exchange step of the path: compacted per-frame records to rank 0 over RCCL,
+            gather.submit()         # overlapped with the next step's kernels (configs[4]: waited for inside the step)
+            if wl.get("sync_gather"):
+                gather.wait()
 
     for _ in range(args.warmup):
         one_step()
-    gather.wait()
+    if gather is not None:
+        gather.wait()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -204,7 +308,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    gather.wait()
+    if gather is not None:
+        gather.wait()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -217,61 +322,83 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    gather_ok = None
-    if rank == 0 and dist is not None:
-        # the gathered records of the last step must be this rank's own packed results at every slot it owns (global frame i = local i // world on rank i % world);
+    gather_info = None
+    if rank == 0 and gather is not None:
+        # what RCCL delivered for the last step: rank 0's own records must be in it byte for byte (global frame i = local i // world on rank i % world);
         # reported in the JSON line (config.gather_check), never fatal for the measurement
         try:
-            got = gather.result()
-            mine = pipe.packed_results()
-            gather_ok = bool(got.shape[0] == B * world and torch.equal(got[0::world], mine))
-            del got, mine
+            got, sizes = gather.result()
+            mine = pipe.packed_stream()
+            rk, rd, rn, rl, rld, rfn, rnl, nrec = fe.unpack_records(got.cpu().numpy(), B * world, pipe.cap, pipe.lcap, with_lines)
+            ok = nrec == B * world and sizes[0] == mine.numel()
+            c = pipe.feat["cur"]
+            n_own = c["n"].cpu().numpy()
+            ok = ok and bool((rn[0::world] == n_own).all()) and bool(np.array_equal(rd[0::world][0, :n_own[0]], c["desc"][0, :n_own[0]].cpu().numpy()))
+            if with_lines:
+                nl_own = c["nl"].cpu().numpy()
+                ok = ok and bool((rnl[0::world] == nl_own).all()) and bool(np.array_equal(rfn[0::world][-1, :nl_own[-1]], c["linefn"][-1, :nl_own[-1]].cpu().numpy()))
+            gather_info = {"ok": bool(ok), "records": int(nrec), "bytes_per_rank": sizes, "bytes_per_frame": float(sum(sizes)) / max(nrec, 1)}
         except Exception as e:
-            gather_ok = "error: %s" % (str(e)[:200],)
+            gather_info = {"ok": False, "error": str(e)[:200]}
     if rank == 0:
         counts = pipe.feat["cur"]["n"].cpu().numpy(); lcounts = pipe.feat["cur"]["nl"].cpu().numpy()
         nm = pipe.nmatch.cpu().numpy(); nlp = pipe.nlpairs.cpu().numpy()
         total_frames = B * world * args.steps
         fps = total_frames / dt
+        stat = lambda a: {"min": int(a[:U].min()), "mean": float(a[:U].mean()), "max": int(a[:U].max())}
         out = {
             "metric": "front-end frames/sec (ORB+LSD extract+match) 640x480 @1000kp/200ln" if args.workload == "c3" else "front-end frames/sec, workload " + args.workload,
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.workload != "c5" else "strong", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["name"],
                        "batch_per_gpu": B, "global_batch": B * world, "unique_frames": U,
+                       "keypoints_per_frame": stat(counts), "lines_per_frame": stat(lcounts),
                        "mean_keypoints": float(counts.mean()), "mean_lines": float(lcounts.mean()),
                        "mean_orb_matches": float(nm.mean()), "mean_line_matches": float(nlp.mean()),
-                       "parallelism": "frames sharded %d/GPU, RCCL gather of results to rank 0 per step" % B if world > 1 else "single GPU",
-                       "gather_check": gather_ok},
+                       "parallelism": ("frames sharded %d/GPU, RCCL gather (sslam_group_gather_dev) of compacted records to rank 0 per step" % B) if gather is not None else "single GPU",
+                       "gather_check": gather_info["ok"] if gather_info else None, "gather": gather_info},
         }
         if prof:
-            ab = alg_bytes_per_frame(W, H, NFEAT, NLINES)
+            ab = alg_bytes_per_frame(W, H, NFEAT, NLINES if with_lines else 0)
             dom = max(prof.items(), key=lambda kv: kv[1][0])
             name, (ms, launches) = dom
             avg_s = ms / launches * 1e-3
             bytes_per_launch = ab.get(name, 0) * B
             ach = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-            traffic = None
-            try:      # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), scaled to this batch
+            traffic, traffic_src = None, None
+            try:      # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs cannot share a process with this timing run), scaled to this batch
                 pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 pt = pj["kernels"][name]      # fetch side x2: gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, calibrated in profiles/)
                 traffic = (pt["fetch_bytes_per_frame"] * pj.get("fetch_correction", 1.0) + pt["write_bytes_per_frame"]) * B
+                traffic_src = "profiles/pmc_traffic.json (%s), scaled to this batch" % pj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
             except Exception:
                 pass
+            sv = survey_bytes_per_frame(W, H, NFEAT, NLINES if with_lines else 0)
+            per_gpu_fps = fps / world
             out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": traffic, "avg_launch_ms": ms / launches, "launches": launches,
+                               "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": ms / launches, "launches": launches,
                                "alg_bytes_per_launch": bytes_per_launch,
-                               "whole_pipeline": {"alg_bytes_per_frame": sum(ab.values()), "achieved": sum(ab.values()) * fps / world / 1e9,
-                                                  "frac": sum(ab.values()) * fps / world / 1e9 / HBM_PEAK_GBS},
+                               "whole_pipeline": {"survey_8d_bytes_per_frame": sv, "achieved": sv * per_gpu_fps / 1e9, "frac": sv * per_gpu_fps / 1e9 / HBM_PEAK_GBS,
+                                                  "per_kernel_table_bytes_per_frame": sum(ab.values()), "per_kernel_table_frac": sum(ab.values()) * per_gpu_fps / 1e9 / HBM_PEAK_GBS,
+                                                  "note": "frac uses SURVEY.md §8(d)'s own byte total; the per-kernel table (DESIGN.md §4) is what this implementation moves"},
                                "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+        if world == 1 and not args.no_extras and args.workload in ("c3", "c2", "c4"):
+            try:
+                out["latency"] = latency_leg(fe, ctx, cur_np, with_lines)
+                out["pcie_inclusive"] = pcie_leg(fe, ctx, cur_np, with_lines, n=2048 if W == 640 else 512, chunk=1024 if W == 640 else 256)
+            except Exception as e:
+                out["latency_error"] = str(e)[:300]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], ref = cpu_baseline(cur_np, prev_np, with_lines=wl["nlines"] > 0, with_match=wl["match"])
-            out["cpu_baseline"]["parity_vs_gpu"] = parity_vs_gpu(ref, pipe.feat["cur"], wl["nlines"] > 0)
+            out["cpu_baseline"], ref = cpu_baseline(cur_np, prev_np, with_lines=with_lines, with_match=wl["match"])
+            out["cpu_baseline"]["parity_vs_gpu"] = parity_vs_gpu(ref, pipe.feat["cur"], with_lines)
         print(json.dumps(out))
+    if gather is not None:
+        gather.wait(); group.close()
     pipe.close()
     ctx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

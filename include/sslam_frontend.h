@@ -356,6 +356,69 @@ int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const uint8_t* imag
                          sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
                          sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap);
 
+
+/* ---- multi-GPU batch mode (SURVEY.md §8(b) "sslam_group_create + sslam_frontend_batch_sharded", §8(e)) ----------------------
+ * north_star: "a batch-of-frames mode shards independent images across the 8 GPUs of one node with RCCL over xGMI only for the final
+ * keypoint/line gather".  Frames are independent units: global frame i lives on GPU i % G.  Each GPU runs the single-GPU path on its
+ * shard; the ONE exchange step is a gather of compacted per-frame records to the root GPU (grouped ncclSend / ncclRecv, sizes first).
+ * There is no reference counterpart (the reference front-end is one thread on one CPU, src/Frame.cc:86-87); the caller-side loop this
+ * replaces is the per-frame Frame::ExtractORB / ExtractLSD pair (src/Frame.cc:150-161).  RCCL is bound at run time (dlopen of
+ * librccl.so.1, or the copy a host process such as PyTorch already loaded), so the library itself has no link-time RCCL dependency.
+ *
+ * Record stream (what travels over xGMI and what rank 0 ingests): per frame, 16-byte aligned,
+ *   sslam_record_header {n_kp, n_ln, frame, bytes}  then  n_kp x sslam_keypoint (28 B), n_kp x 32 B descriptors,
+ *   n_ln x sslam_keyline (68 B), n_ln x 32 B LBD descriptors, n_ln x 3 doubles (mvKeyLineFunctions, src/ExtractLineSegment.cpp:56-68)
+ * -- compacted to the counts, not padded to the capacities: about 80 KB per 640x480 frame at 1000 keypoints / 165 lines. */
+typedef struct sslam_group sslam_group;
+#define SSLAM_GROUP_ID_BYTES 128
+typedef struct sslam_record_header { int32_t n_kp, n_ln, frame, bytes; } sslam_record_header;
+typedef struct sslam_frontend_params {     /* ORBextractor ctor arguments (Examples/ICL.yaml:41-54) + the line cap; max_lines 0 = no line extraction */
+    int32_t nfeatures; float scale_factor; int32_t nlevels, ini_th_fast, min_th_fast, max_lines;
+} sslam_frontend_params;
+
+/* One process drives `ngpu` devices (0 .. ngpu-1): one context, extractor pair and host thread per device, communicators from
+ * ncclCommInitAll.  This is the form a C++ host like the reference's (one process) uses. */
+int sslam_group_create(int ngpu, sslam_group** out);
+/* One process per GPU (torch.distributed / MPI style): rank 0 obtains an id, the launcher broadcasts it, every rank joins.  `device` is the
+ * HIP device of this process. */
+int sslam_group_unique_id(uint8_t id_out[SSLAM_GROUP_ID_BYTES]);
+int sslam_group_create_rank(int device, int rank, int nranks, const uint8_t id[SSLAM_GROUP_ID_BYTES], sslam_group** out);
+int sslam_group_destroy(sslam_group* group);
+int sslam_group_size(const sslam_group* group);
+int sslam_group_rank(const sslam_group* group);      /* 0 in the single-process form */
+
+/* Compacts the per-frame results of a *_batch_dev call into the record stream above: frame i of the batch becomes the record with
+ * header.frame = frame0 + i*frame_step.  d_kl / d_ldesc / d_linefn / d_nl may be NULL (no lines).  d_out[out_capacity]; *d_total_bytes
+ * (device) receives the stream length, or UINT64_MAX when it does not fit.  Enqueued on `stream`, no synchronisation. */
+int sslam_pack_records_dev(sslam_ctx* ctx, int nframes, int frame0, int frame_step,
+                           const sslam_keypoint* d_kp, const uint8_t* d_desc, const int32_t* d_nkp, int cap,
+                           const sslam_keyline* d_kl, const uint8_t* d_ldesc, const double* d_linefn, const int32_t* d_nl, int lcap,
+                           uint8_t* d_out, uint64_t out_capacity, uint64_t* d_total_bytes, void* stream);
+/* Upper bound of the stream length for nframes frames at the given capacities (buffer sizing). */
+uint64_t sslam_record_stream_capacity(int nframes, int cap, int lcap);
+/* Host side of the ingest: scatters a record stream (host memory) into per-frame arrays indexed by header.frame, laid out like the
+ * outputs of sslam_frontend_batch (kp_out[nframes*cap] ...; line outputs may be NULL).  Returns SSLAM_ERR_INVALID on a malformed
+ * stream, SSLAM_ERR_CAPACITY when a record exceeds cap / lcap.  *nrecords_out = records seen. */
+int sslam_unpack_records(const uint8_t* stream, uint64_t bytes, int nframes,
+                         sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
+                         sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap, int* nrecords_out);
+
+/* The exchange step, one-process-per-GPU form: every rank hands over its device-resident record stream (length in *d_send_bytes, a
+ * device word as written by sslam_pack_records_dev); rank 0 receives the streams of all ranks back to back in d_recv (rank order) and
+ * gets the per-rank lengths in bytes_per_rank_out[nranks] (host).  Sizes travel first (one 8-byte ncclAllGather), then one grouped
+ * ncclSend / ncclRecv per peer.  Synchronous on `stream` (NULL = an internal stream); call it from a side thread to overlap it with the
+ * next batch's kernels.  d_recv / recv_capacity / bytes_per_rank_out are ignored on ranks other than 0. */
+int sslam_group_gather_dev(sslam_group* group, const uint8_t* d_send, const uint64_t* d_send_bytes,
+                           uint8_t* d_recv, uint64_t recv_capacity, uint64_t* bytes_per_rank_out, void* stream);
+
+/* sslam_frontend_batch over all GPUs of a single-process group: n frames in host memory, frame i -> GPU i % G, per-GPU extraction in
+ * chunks, RCCL gather of the records to GPU 0, results in the caller's arrays exactly as sslam_frontend_batch returns them (same
+ * error behaviour).  The per-device extractors are created from `params` on first use and kept in the group. */
+int sslam_frontend_batch_sharded(sslam_group* group, const sslam_frontend_params* params,
+                                 const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride,
+                                 sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
+                                 sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap);
+
 /* Self-test of the table-based exact integer division of the NFA binomial tail against the hardware IEEE division:
  * `pairs` random quotients a/b with 1 <= a,b < n; *mismatches_out must come back 0. */
 int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, long long* mismatches_out);

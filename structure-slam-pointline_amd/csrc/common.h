@@ -64,6 +64,7 @@ struct sslam_ctx {
     hipStream_t stream = nullptr;
     std::mutex mu;                 // host entry points serialise on the context (SURVEY §8b threading)
     sslam::DevBuf scratch[8];      // matcher staging
+    sslam::DevBuf recordOffsets;   // sslam_pack_records_dev: per-frame offsets of the record stream
     sslam::HostPinned pinned[4];
     int num_cus = 0;
 };

@@ -1,0 +1,457 @@
+// Multi-GPU batch mode (SURVEY.md §8(b),(e); north_star: "shards independent images across the 8 GPUs of one node with RCCL over
+// xGMI only for the final keypoint/line gather").  Frames are independent units, so the path has exactly one exchange step: the
+// compacted per-frame records of every GPU go to the root GPU.  This file holds
+//   * the record stream (pack kernels, host-side unpack),
+//   * the group handle in its two forms (one process driving G devices / one process per GPU) over RCCL bound with dlopen,
+//   * the gather (sizes first, then grouped ncclSend / ncclRecv),
+//   * sslam_frontend_batch_sharded, the host-buffer batch entry point over all GPUs of a single-process group.
+// xGMI is point to point (7 links per GPU): a gather to one root is bound by the root's ingest, G-1 links x ~50 GB/s effective.  At
+// ~80 KB per 640x480 frame that is >4 M frames/s of ingest, two orders of magnitude above what eight GPUs extract; the exchange is
+// latency, not bandwidth.
+#include "common.h"
+#include <dlfcn.h>
+#include <algorithm>
+#include <condition_variable>
+#include <thread>
+
+using namespace sslam;
+
+namespace {
+
+// ------------------------------------------------------------------ RCCL, bound at run time
+typedef struct ncclComm* ncclComm_t;
+struct NcclUid { char internal[128]; };
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(NcclUid*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, NcclUid, int) = nullptr;
+    int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclUint8 = 1, kNcclUint64 = 5;      // ncclDataType_t (rccl.h)
+
+Rccl* rccl() {
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy that is already in the process (PyTorch ships its own librccl.so.1) wins: two RCCL instances in one process would not share state
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        R.h = h;
+        R.GetUniqueId = (decltype(R.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        R.CommInitRank = (decltype(R.CommInitRank))dlsym(h, "ncclCommInitRank");
+        R.CommInitAll = (decltype(R.CommInitAll))dlsym(h, "ncclCommInitAll");
+        R.CommDestroy = (decltype(R.CommDestroy))dlsym(h, "ncclCommDestroy");
+        R.GroupStart = (decltype(R.GroupStart))dlsym(h, "ncclGroupStart");
+        R.GroupEnd = (decltype(R.GroupEnd))dlsym(h, "ncclGroupEnd");
+        R.Send = (decltype(R.Send))dlsym(h, "ncclSend");
+        R.Recv = (decltype(R.Recv))dlsym(h, "ncclRecv");
+        R.AllGather = (decltype(R.AllGather))dlsym(h, "ncclAllGather");
+        R.GetErrorString = (decltype(R.GetErrorString))dlsym(h, "ncclGetErrorString");
+        if (!R.GetUniqueId || !R.CommInitRank || !R.CommInitAll || !R.CommDestroy || !R.GroupStart || !R.GroupEnd || !R.Send || !R.Recv || !R.AllGather) R.h = nullptr;
+    });
+    return R.h ? &R : nullptr;
+}
+#define SSLAM_NCCL(expr)                                                                                              \
+    do {                                                                                                              \
+        int _r = (expr);                                                                                              \
+        if (_r != 0) {                                                                                                \
+            sslam::set_error("%s failed: %s", #expr, rccl()->GetErrorString ? rccl()->GetErrorString(_r) : "rccl error"); \
+            return SSLAM_ERR_HIP;                                                                                     \
+        }                                                                                                             \
+    } while (0)
+
+// ------------------------------------------------------------------ record stream
+__host__ __device__ inline unsigned record_bytes(int nkp, int nl) {
+    return (unsigned)((16 + nkp * (28 + 32) + nl * (68 + 32 + 24) + 15) & ~15);
+}
+
+// one workgroup: exclusive scan of the record sizes -> offsets[nframes + 1]; total (or UINT64_MAX when it exceeds the capacity)
+__global__ __launch_bounds__(1024) void k_record_offsets(const int* __restrict__ nkp, const int* __restrict__ nl, int nframes, int cap, int lcap,
+                                                         unsigned long long* __restrict__ offsets, unsigned long long capacity,
+                                                         unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long part[1024];
+    const int t = threadIdx.x, per = (nframes + 1023) / 1024;
+    const int lo = min(t * per, nframes), hi = min(lo + per, nframes);
+    unsigned long long s = 0;
+    for (int i = lo; i < hi; ++i) s += record_bytes(min(nkp[i], cap), nl ? min(nl[i], lcap) : 0);
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned long long v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned long long run = part[t] - s;
+    for (int i = lo; i < hi; ++i) { offsets[i] = run; run += record_bytes(min(nkp[i], cap), nl ? min(nl[i], lcap) : 0); }
+    if (t == 1023) { offsets[nframes] = part[1023]; *total = part[1023] <= capacity ? part[1023] : ~0ull; }
+}
+
+// one workgroup per frame: header + the five segments, dword copies (every segment is a multiple of four bytes and starts on one)
+__global__ __launch_bounds__(256) void k_record_copy(int frame0, int frameStep, const unsigned* __restrict__ kp, const unsigned* __restrict__ desc,
+                                                     const int* __restrict__ nkp, int cap, const unsigned* __restrict__ kl, const unsigned* __restrict__ ldesc,
+                                                     const unsigned* __restrict__ linefn, const int* __restrict__ nl, int lcap,
+                                                     const unsigned long long* __restrict__ offsets, int nframes, unsigned* __restrict__ out,
+                                                     const unsigned long long* __restrict__ total) {
+    if (*total == ~0ull) return;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int n = min(nkp[b], cap), m = nl ? min(nl[b], lcap) : 0;
+    unsigned* o = out + offsets[b] / 4;
+    const unsigned bytes = record_bytes(n, m);
+    if (t < 4) o[t] = t == 0 ? (unsigned)n : t == 1 ? (unsigned)m : t == 2 ? (unsigned)(frame0 + b * frameStep) : bytes;
+    o += 4;
+    const unsigned* src[5] = {kp + (size_t)b * cap * 7, desc + (size_t)b * cap * 8, kl ? kl + (size_t)b * lcap * 17 : nullptr,
+                              ldesc ? ldesc + (size_t)b * lcap * 8 : nullptr, linefn ? linefn + (size_t)b * lcap * 6 : nullptr};
+    const int words[5] = {n * 7, n * 8, m * 17, m * 8, m * 6};
+    for (int s = 0; s < 5; ++s) {
+        for (int i = t; i < words[s]; i += 256) o[i] = src[s][i];
+        o += words[s];
+    }
+    const int tail = (int)(bytes / 4) - 4 - (words[0] + words[1] + words[2] + words[3] + words[4]);      // alignment padding: defined bytes
+    if (t < tail) o[t] = 0;
+}
+
+struct Barrier {      // reusable thread barrier (the per-device host threads of a single-process group)
+    std::mutex mu; std::condition_variable cv; int count = 0, waiting = 0, gen = 0;
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        const int g = gen;
+        if (++waiting == count) { waiting = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return g != gen; });
+    }
+};
+
+struct Member {       // one GPU of a single-process group
+    sslam_ctx* ctx = nullptr; sslam_orb* orb = nullptr; sslam_lines* lines = nullptr;
+    ncclComm_t comm = nullptr;
+    DevBuf dIn, dKp, dDesc, dN, dKl, dLd, dFn, dNl, dSend, dTotal, dStatus, dRecv;
+    HostPinned hTotal, hRecv;
+};
+
+}  // namespace
+
+struct sslam_group {
+    int nranks = 1, rank = 0, device = 0;
+    bool singleProcess = true;
+    std::vector<Member> mem;               // single-process: one per device; rank form: one
+    sslam_frontend_params params{};
+    bool haveParams = false;
+    DevBuf dSizes;                         // rank form: nranks x uint64 (all-gathered lengths)
+    HostPinned hSizes;
+    hipStream_t stream = nullptr;          // rank form: internal stream
+    std::mutex mu;
+};
+
+extern "C" uint64_t sslam_record_stream_capacity(int nframes, int cap, int lcap) {
+    return (uint64_t)std::max(nframes, 0) * record_bytes(std::max(cap, 0), std::max(lcap, 0));
+}
+
+extern "C" int sslam_pack_records_dev(sslam_ctx* ctx, int nframes, int frame0, int frame_step,
+                                      const sslam_keypoint* d_kp, const uint8_t* d_desc, const int32_t* d_nkp, int cap,
+                                      const sslam_keyline* d_kl, const uint8_t* d_ldesc, const double* d_linefn, const int32_t* d_nl, int lcap,
+                                      uint8_t* d_out, uint64_t out_capacity, uint64_t* d_total_bytes, void* stream_) {
+    const bool lines = d_kl != nullptr;
+    if (!ctx || nframes <= 0 || !d_kp || !d_desc || !d_nkp || cap <= 0 || !d_out || !d_total_bytes ||
+        (lines && (!d_ldesc || !d_linefn || !d_nl || lcap <= 0))) { set_error("sslam_pack_records_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if ((size_t)(nframes + 1) * 8 > ctx->recordOffsets.cap) SSLAM_HIP(hipStreamSynchronize(st));      // a growing buffer is freed first: nothing may still read it
+        if ((rc = ctx->recordOffsets.ensure(sizeof(unsigned long long) * ((size_t)nframes + 1)))) return rc;
+    }
+    unsigned long long* off = ctx->recordOffsets.as<unsigned long long>();
+    hipLaunchKernelGGL(k_record_offsets, dim3(1), dim3(1024), 0, st, d_nkp, lines ? d_nl : nullptr, nframes, cap, lcap, off, (unsigned long long)out_capacity,
+                       (unsigned long long*)d_total_bytes);
+    hipLaunchKernelGGL(k_record_copy, dim3(nframes), dim3(256), 0, st, frame0, frame_step, (const unsigned*)d_kp, (const unsigned*)d_desc, d_nkp, cap,
+                       (const unsigned*)d_kl, (const unsigned*)d_ldesc, (const unsigned*)d_linefn, lines ? d_nl : nullptr, lcap, off, nframes, (unsigned*)d_out,
+                       (const unsigned long long*)d_total_bytes);
+    SSLAM_HIP(hipGetLastError());
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_unpack_records(const uint8_t* stream, uint64_t bytes, int nframes,
+                                    sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
+                                    sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap, int* nrecords_out) {
+    if ((!stream && bytes) || nframes < 0 || !kp_out || !desc_out || !nkp_out || cap <= 0) { set_error("sslam_unpack_records: invalid arguments"); return SSLAM_ERR_INVALID; }
+    uint64_t pos = 0; int nrec = 0;
+    while (pos + sizeof(sslam_record_header) <= bytes) {
+        sslam_record_header hd;
+        memcpy(&hd, stream + pos, sizeof(hd));
+        if (hd.n_kp < 0 || hd.n_ln < 0 || hd.frame < 0 || hd.frame >= nframes || (unsigned)hd.bytes != record_bytes(hd.n_kp, hd.n_ln) || pos + (uint64_t)hd.bytes > bytes) {
+            set_error("sslam_unpack_records: malformed record at byte %llu", (unsigned long long)pos); return SSLAM_ERR_INVALID;
+        }
+        if (hd.n_kp > cap || (hd.n_ln > 0 && kl_out && hd.n_ln > lcap)) { set_error("sslam_unpack_records: frame %d exceeds the output capacity", hd.frame); return SSLAM_ERR_CAPACITY; }
+        const uint8_t* p = stream + pos + sizeof(hd);
+        const size_t f = (size_t)hd.frame;
+        memcpy(kp_out + f * cap, p, (size_t)hd.n_kp * 28); p += (size_t)hd.n_kp * 28;
+        memcpy(desc_out + f * cap * 32, p, (size_t)hd.n_kp * 32); p += (size_t)hd.n_kp * 32;
+        nkp_out[f] = hd.n_kp;
+        if (kl_out && ldesc_out && linefn_out && nl_out) {
+            memcpy(kl_out + f * lcap, p, (size_t)hd.n_ln * 68); p += (size_t)hd.n_ln * 68;
+            memcpy(ldesc_out + f * lcap * 32, p, (size_t)hd.n_ln * 32); p += (size_t)hd.n_ln * 32;
+            memcpy(linefn_out + f * lcap * 3, p, (size_t)hd.n_ln * 24);
+            nl_out[f] = hd.n_ln;
+        }
+        pos += (uint64_t)hd.bytes; ++nrec;
+    }
+    if (pos != bytes) { set_error("sslam_unpack_records: %llu trailing bytes", (unsigned long long)(bytes - pos)); return SSLAM_ERR_INVALID; }
+    if (nrecords_out) *nrecords_out = nrec;
+    return SSLAM_OK;
+}
+
+// ------------------------------------------------------------------ group handles
+static void member_release(Member& m) {
+    if (m.ctx) (void)hipSetDevice(m.ctx->device);
+    if (m.comm && rccl()) (void)rccl()->CommDestroy(m.comm);
+    if (m.lines) sslam_lines_destroy(m.lines);
+    if (m.orb) sslam_orb_destroy(m.orb);
+    DevBuf* bufs[] = {&m.dIn, &m.dKp, &m.dDesc, &m.dN, &m.dKl, &m.dLd, &m.dFn, &m.dNl, &m.dSend, &m.dTotal, &m.dStatus, &m.dRecv};
+    for (DevBuf* b : bufs) b->release();
+    m.hTotal.release(); m.hRecv.release();
+    if (m.ctx) sslam_ctx_destroy(m.ctx);
+    m = Member();
+}
+
+extern "C" int sslam_group_create(int ngpu, sslam_group** out) {
+    if (!out || ngpu <= 0 || ngpu > 64) { set_error("sslam_group_create: invalid arguments"); return SSLAM_ERR_INVALID; }
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) { set_error("sslam_group_create: no HIP device visible; there is no CPU fallback"); return SSLAM_ERR_NO_DEVICE; }
+    if (ngpu > have) { set_error("sslam_group_create: %d GPUs requested, %d visible", ngpu, have); return SSLAM_ERR_INVALID; }
+    if (!rccl()) { set_error("sslam_group_create: librccl.so.1 could not be loaded"); return SSLAM_ERR_UNSUPPORTED; }
+    sslam_group* g = new sslam_group();
+    g->nranks = ngpu; g->rank = 0; g->singleProcess = true;
+    g->mem.resize(ngpu);
+    int rc = SSLAM_OK;
+    for (int d = 0; d < ngpu && rc == SSLAM_OK; ++d) rc = sslam_ctx_create(d, &g->mem[d].ctx);
+    if (rc == SSLAM_OK) {
+        std::vector<int> devs(ngpu); std::vector<ncclComm_t> comms(ngpu, nullptr);
+        for (int d = 0; d < ngpu; ++d) devs[d] = d;
+        const int r = rccl()->CommInitAll(comms.data(), ngpu, devs.data());
+        if (r != 0) { set_error("ncclCommInitAll failed: %s", rccl()->GetErrorString ? rccl()->GetErrorString(r) : "rccl error"); rc = SSLAM_ERR_HIP; }
+        else for (int d = 0; d < ngpu; ++d) g->mem[d].comm = comms[d];
+    }
+    if (rc != SSLAM_OK) { for (auto& m : g->mem) member_release(m); delete g; return rc; }
+    *out = g;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_group_unique_id(uint8_t id_out[SSLAM_GROUP_ID_BYTES]) {
+    if (!id_out) return SSLAM_ERR_INVALID;
+    if (!rccl()) { set_error("sslam_group_unique_id: librccl.so.1 could not be loaded"); return SSLAM_ERR_UNSUPPORTED; }
+    NcclUid u;
+    SSLAM_NCCL(rccl()->GetUniqueId(&u));
+    memcpy(id_out, u.internal, SSLAM_GROUP_ID_BYTES);
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_group_create_rank(int device, int rank, int nranks, const uint8_t id[SSLAM_GROUP_ID_BYTES], sslam_group** out) {
+    if (!out || !id || nranks <= 0 || rank < 0 || rank >= nranks) { set_error("sslam_group_create_rank: invalid arguments"); return SSLAM_ERR_INVALID; }
+    if (!rccl()) { set_error("sslam_group_create_rank: librccl.so.1 could not be loaded"); return SSLAM_ERR_UNSUPPORTED; }
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || device < 0 || device >= have) { set_error("sslam_group_create_rank: device %d not visible", device); return SSLAM_ERR_NO_DEVICE; }
+    SSLAM_HIP(hipSetDevice(device));
+    sslam_group* g = new sslam_group();
+    g->nranks = nranks; g->rank = rank; g->device = device; g->singleProcess = false;
+    g->mem.resize(1);
+    NcclUid u; memcpy(u.internal, id, SSLAM_GROUP_ID_BYTES);
+    const int r = rccl()->CommInitRank(&g->mem[0].comm, nranks, u, rank);
+    if (r != 0) { set_error("ncclCommInitRank failed: %s", rccl()->GetErrorString ? rccl()->GetErrorString(r) : "rccl error"); delete g; return SSLAM_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess || g->dSizes.ensure(8 * (size_t)nranks + 8) != SSLAM_OK ||
+        g->hSizes.ensure(8 * (size_t)nranks + 8) != SSLAM_OK) {
+        set_error("sslam_group_create_rank: allocation failed"); (void)rccl()->CommDestroy(g->mem[0].comm); delete g; return SSLAM_ERR_HIP;
+    }
+    *out = g;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_group_destroy(sslam_group* g) {
+    if (!g) return SSLAM_OK;
+    if (!g->singleProcess) (void)hipSetDevice(g->device);
+    for (auto& m : g->mem) member_release(m);
+    g->dSizes.release(); g->hSizes.release();
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_group_size(const sslam_group* g) { return g ? g->nranks : SSLAM_ERR_INVALID; }
+extern "C" int sslam_group_rank(const sslam_group* g) { return g ? g->rank : SSLAM_ERR_INVALID; }
+
+// ------------------------------------------------------------------ the exchange step, one process per GPU
+extern "C" int sslam_group_gather_dev(sslam_group* g, const uint8_t* d_send, const uint64_t* d_send_bytes,
+                                      uint8_t* d_recv, uint64_t recv_capacity, uint64_t* bytes_per_rank_out, void* stream_) {
+    if (!g || g->singleProcess || !d_send || !d_send_bytes || (g->rank == 0 && (!d_recv || !bytes_per_rank_out))) {
+        set_error("sslam_group_gather_dev: invalid arguments (a single-process group gathers inside sslam_frontend_batch_sharded)"); return SSLAM_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(g->mu);
+    SSLAM_HIP(hipSetDevice(g->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : g->stream;
+    Rccl* R = rccl();
+    ncclComm_t comm = g->mem[0].comm;
+    uint64_t* dS = g->dSizes.as<uint64_t>(); uint64_t* hS = g->hSizes.as<uint64_t>();
+    // 1. lengths: every rank learns every length (eight bytes each)
+    SSLAM_NCCL(R->AllGather(d_send_bytes, dS, 1, kNcclUint64, comm, st));
+    SSLAM_HIP(hipMemcpyAsync(hS, dS, 8 * (size_t)g->nranks, hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    uint64_t total = 0;
+    for (int r = 0; r < g->nranks; ++r) {
+        if (hS[r] == ~0ull) { set_error("sslam_group_gather_dev: the record stream of rank %d overflowed its buffer", r); return SSLAM_ERR_CAPACITY; }
+        total += hS[r];
+    }
+    if (g->rank == 0 && total > recv_capacity) { set_error("sslam_group_gather_dev: %llu bytes do not fit the receive buffer", (unsigned long long)total); return SSLAM_ERR_CAPACITY; }
+    // 2. payload: one grouped send / receive per peer; the root's own stream is a device-to-device copy (or, for tests on one GPU, a
+    //    self send/recv through RCCL with SSLAM_GROUP_SELF_SENDRECV=1)
+    const bool selfRccl = getenv("SSLAM_GROUP_SELF_SENDRECV") != nullptr;
+    SSLAM_NCCL(R->GroupStart());
+    int rcN = 0;
+    if (g->rank == 0) {
+        uint64_t off = 0;
+        for (int r = 0; r < g->nranks && rcN == 0; ++r) {
+            if (hS[r] && (r != 0 || selfRccl)) rcN = R->Recv(d_recv + off, (size_t)hS[r], kNcclUint8, r, comm, st);
+            off += hS[r];
+        }
+        if (rcN == 0 && selfRccl && hS[0]) rcN = R->Send(d_send, (size_t)hS[0], kNcclUint8, 0, comm, st);
+    } else if (hS[g->rank]) rcN = R->Send(d_send, (size_t)hS[g->rank], kNcclUint8, 0, comm, st);
+    const int rcE = R->GroupEnd();
+    if (rcN != 0 || rcE != 0) { set_error("sslam_group_gather_dev: ncclSend / ncclRecv failed: %s", R->GetErrorString ? R->GetErrorString(rcN ? rcN : rcE) : "rccl error"); return SSLAM_ERR_HIP; }
+    if (g->rank == 0 && !selfRccl && hS[0]) SSLAM_HIP(hipMemcpyAsync(d_recv, d_send, (size_t)hS[0], hipMemcpyDeviceToDevice, st));
+    SSLAM_HIP(hipStreamSynchronize(st));
+    if (g->rank == 0) for (int r = 0; r < g->nranks; ++r) bytes_per_rank_out[r] = hS[r];
+    return SSLAM_OK;
+}
+
+// ------------------------------------------------------------------ host-buffer batch over all GPUs of a single-process group
+extern "C" int sslam_orb_batch_status_dev(sslam_orb* orb, int cap, int32_t* d_status4, void* stream);
+extern "C" int sslam_lines_batch_status_dev(sslam_lines* lines, int cap, int32_t* d_status4, void* stream);
+
+extern "C" int sslam_frontend_batch_sharded(sslam_group* g, const sslam_frontend_params* prm,
+                                            const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride,
+                                            sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
+                                            sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap) {
+    if (!g || !g->singleProcess || !prm || n < 0 || w <= 0 || h <= 0 || stride < (size_t)w || cap <= 0 || (n > 0 && (!images || !kp_out || !desc_out || !nkp_out)) ||
+        (n > 1 && image_stride < stride * (size_t)(h - 1) + (size_t)w)) {
+        set_error("sslam_frontend_batch_sharded: invalid arguments (needs a group from sslam_group_create)"); return SSLAM_ERR_INVALID;
+    }
+    const bool lines = prm->max_lines > 0;
+    if (lines && (lcap <= 0 || (n > 0 && (!kl_out || !ldesc_out || !linefn_out || !nl_out)))) { set_error("sslam_frontend_batch_sharded: line outputs missing"); return SSLAM_ERR_INVALID; }
+    if (n == 0) return SSLAM_OK;
+    std::lock_guard<std::mutex> lk(g->mu);
+    const int G = g->nranks;
+    // extractors per device, rebuilt when the parameters change
+    if (!g->haveParams || memcmp(&g->params, prm, sizeof(*prm)) != 0) {
+        for (auto& m : g->mem) {
+            (void)hipSetDevice(m.ctx->device);
+            if (m.lines) { sslam_lines_destroy(m.lines); m.lines = nullptr; }
+            if (m.orb) { sslam_orb_destroy(m.orb); m.orb = nullptr; }
+            int rc = sslam_orb_create(m.ctx, prm->nfeatures, prm->scale_factor, prm->nlevels, prm->ini_th_fast, prm->min_th_fast, &m.orb);
+            if (rc == SSLAM_OK && lines) rc = sslam_lines_create(m.ctx, prm->max_lines, &m.lines);
+            if (rc != SSLAM_OK) { g->haveParams = false; return rc; }
+        }
+        g->params = *prm; g->haveParams = true;
+    }
+    const int perDev = (n + G - 1) / G, C = std::min(perDev, 512), nChunks = (perDev + C - 1) / C;
+    const size_t fpx = (size_t)w * h;
+    const uint64_t sendCap = sslam_record_stream_capacity(C, cap, lines ? lcap : 0);
+    const bool selfRccl = getenv("SSLAM_GROUP_SELF_SENDRECV") != nullptr;
+    Barrier bar; bar.count = G;
+    std::vector<int> status(G, SSLAM_OK);
+    std::vector<std::string> errs(G);
+    std::vector<uint64_t> sizes(G, 0);
+    Rccl* R = rccl();
+    auto worker = [&](int d) {
+        Member& m = g->mem[d];
+        int rc = SSLAM_OK;
+        auto fail = [&](int code, const char* what) { if (rc == SSLAM_OK) { rc = code; errs[d] = what ? what : sslam_last_error(); } };
+        if (hipSetDevice(m.ctx->device) != hipSuccess) fail(SSLAM_ERR_HIP, "hipSetDevice failed");
+        hipStream_t st = m.ctx->stream;
+        if (rc == SSLAM_OK) {
+            int e = m.dIn.ensure(fpx * C) | m.dKp.ensure(sizeof(sslam_keypoint) * (size_t)C * cap) | m.dDesc.ensure(32 * (size_t)C * cap) | m.dN.ensure(4 * (size_t)C) |
+                    m.dSend.ensure(sendCap + 16) | m.dTotal.ensure(16) | m.dStatus.ensure(32) | m.hTotal.ensure(64);
+            if (lines) e |= m.dKl.ensure(sizeof(sslam_keyline) * (size_t)C * lcap) | m.dLd.ensure(32 * (size_t)C * lcap) | m.dFn.ensure(24 * (size_t)C * lcap) | m.dNl.ensure(4 * (size_t)C);
+            if (d == 0) e |= m.dRecv.ensure(sendCap * G + 16) | m.hRecv.ensure(sendCap * G + 16);
+            if (e) fail(SSLAM_ERR_HIP, nullptr);
+        }
+        for (int ck = 0; ck < nChunks; ++ck) {
+            // local slot j of this chunk = global frame (ck*C + j)*G + d
+            int c = 0;
+            for (int j = 0; j < C; ++j) if ((size_t)(ck * C + j) * G + d < (size_t)n) c = j + 1;
+            uint64_t myBytes = 0;
+            if (rc == SSLAM_OK && c > 0) {
+                for (int j = 0; j < c && rc == SSLAM_OK; ++j) {
+                    const uint8_t* src = images + ((size_t)(ck * C + j) * G + d) * image_stride;
+                    if (hipMemcpy2DAsync(m.dIn.as<uint8_t>() + (size_t)j * fpx, w, src, stride, w, h, hipMemcpyHostToDevice, st) != hipSuccess) fail(SSLAM_ERR_HIP, "H2D failed");
+                }
+                if (rc == SSLAM_OK && (rc = sslam_orb_extract_batch_dev(m.orb, m.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, m.dKp.as<sslam_keypoint>(), m.dDesc.as<uint8_t>(),
+                                                                         m.dN.as<int32_t>(), cap, st))) errs[d] = sslam_last_error();
+                if (rc == SSLAM_OK && lines && (rc = sslam_lines_extract_batch_dev(m.lines, m.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, m.dKl.as<sslam_keyline>(), m.dLd.as<uint8_t>(),
+                                                                                    m.dFn.as<double>(), m.dNl.as<int32_t>(), lcap, st))) errs[d] = sslam_last_error();
+                if (rc == SSLAM_OK && (rc = sslam_orb_batch_status_dev(m.orb, cap, m.dStatus.as<int32_t>(), st))) errs[d] = sslam_last_error();
+                if (rc == SSLAM_OK && lines && (rc = sslam_lines_batch_status_dev(m.lines, lcap, m.dStatus.as<int32_t>() + 4, st))) errs[d] = sslam_last_error();
+                if (rc == SSLAM_OK && (rc = sslam_pack_records_dev(m.ctx, c, ck * C * G + d, G, m.dKp.as<sslam_keypoint>(), m.dDesc.as<uint8_t>(), m.dN.as<int32_t>(), cap,
+                                                                   lines ? m.dKl.as<sslam_keyline>() : nullptr, m.dLd.as<uint8_t>(), m.dFn.as<double>(), m.dNl.as<int32_t>(), lcap,
+                                                                   m.dSend.as<uint8_t>(), sendCap, m.dTotal.as<uint64_t>(), st))) errs[d] = sslam_last_error();
+                if (rc == SSLAM_OK) {
+                    uint8_t* hp = m.hTotal.as<uint8_t>();
+                    if (hipMemcpyAsync(hp, m.dTotal.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(hp + 16, m.dStatus.p, 32, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess) fail(SSLAM_ERR_HIP, "kernels / D2H failed");
+                    else {
+                        const int* S = (const int*)(hp + 16);
+                        if (lines && S[6]) fail(SSLAM_ERR_UNSUPPORTED, "a frame produced more than 8192 LSD candidate rectangles");
+                        else if (S[0]) fail(SSLAM_ERR_CAPACITY, "a frame holds more keypoints than cap");
+                        else if (lines && S[4]) fail(SSLAM_ERR_CAPACITY, "a frame holds more lines than lcap");
+                        myBytes = *(const uint64_t*)hp;
+                        if (myBytes == ~0ull) { fail(SSLAM_ERR_CAPACITY, "record stream overflow"); myBytes = 0; }
+                    }
+                }
+            }
+            if (rc != SSLAM_OK) myBytes = 0;      // a failed member still takes part in the exchange (with nothing), so that nobody hangs
+            sizes[d] = myBytes;
+            bar.wait();
+            // the exchange step: grouped ncclSend / ncclRecv to device 0
+            uint64_t total = 0;
+            for (int r = 0; r < G; ++r) total += sizes[r];
+            int e1 = R->GroupStart(), e2 = 0;
+            if (d == 0) {
+                uint64_t off = 0;
+                for (int r = 0; r < G; ++r) {
+                    if (sizes[r] && (r != 0 || selfRccl) && !e2) e2 = R->Recv(m.dRecv.as<uint8_t>() + off, (size_t)sizes[r], kNcclUint8, r, m.comm, st);
+                    off += sizes[r];
+                }
+                if (selfRccl && sizes[0] && !e2) e2 = R->Send(m.dSend.p, (size_t)sizes[0], kNcclUint8, 0, m.comm, st);
+            } else if (sizes[d]) e2 = R->Send(m.dSend.p, (size_t)sizes[d], kNcclUint8, 0, m.comm, st);
+            const int e3 = R->GroupEnd();
+            if (e1 || e2 || e3) fail(SSLAM_ERR_HIP, "ncclSend / ncclRecv failed");
+            if (d == 0 && !selfRccl && sizes[0] && hipMemcpyAsync(m.dRecv.p, m.dSend.p, (size_t)sizes[0], hipMemcpyDeviceToDevice, st) != hipSuccess) fail(SSLAM_ERR_HIP, "D2D failed");
+            if (d == 0 && total) {
+                if (hipMemcpyAsync(m.hRecv.p, m.dRecv.p, (size_t)total, hipMemcpyDeviceToHost, st) != hipSuccess) fail(SSLAM_ERR_HIP, "D2H failed");
+            }
+            if (hipStreamSynchronize(st) != hipSuccess) fail(SSLAM_ERR_HIP, "exchange failed");
+            if (d == 0 && total && rc == SSLAM_OK) {
+                int nrec = 0;
+                const int u = sslam_unpack_records(m.hRecv.as<uint8_t>(), total, n, kp_out, desc_out, nkp_out, cap, lines ? kl_out : nullptr, ldesc_out, linefn_out, nl_out, lcap, &nrec);
+                if (u != SSLAM_OK) fail(u, nullptr);
+            }
+            bar.wait();      // buffers are reused by the next chunk only after the root has taken everything
+        }
+        status[d] = rc;
+    };
+    std::vector<std::thread> th;
+    for (int d = 1; d < G; ++d) th.emplace_back(worker, d);
+    worker(0);
+    for (auto& t : th) t.join();
+    for (int d = 0; d < G; ++d)
+        if (status[d] != SSLAM_OK) { set_error("sslam_frontend_batch_sharded: GPU %d: %s", d, errs[d].c_str()); return status[d]; }
+    return SSLAM_OK;
+}

@@ -395,3 +395,81 @@ class LineExtractor:
         if self.h:
             lib().sslam_lines_destroy(self.h)
             self.h = C.c_void_p()
+
+
+# ---- multi-GPU batch mode (include/sslam_frontend.h: sslam_group_*, record stream) ------------------------------------------------
+class FrontendParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("ini_th_fast", C.c_int32),
+                ("min_th_fast", C.c_int32), ("max_lines", C.c_int32)]
+
+
+def record_bytes(nkp, nl):
+    return (16 + nkp * 60 + nl * 124 + 15) & ~15
+
+
+def record_stream_capacity(nframes, cap, lcap):
+    lib().sslam_record_stream_capacity.restype = C.c_uint64
+    return int(lib().sslam_record_stream_capacity(int(nframes), int(cap), int(lcap)))
+
+
+def pack_records_dev(ctx, nframes, frame0, frame_step, d_kp, d_desc, d_nkp, cap, d_kl, d_ldesc, d_linefn, d_nl, lcap, d_out, out_capacity, d_total, stream=None):
+    """device tensors / pointers in, record stream in d_out, length in the device word d_total (enqueued, not synchronised)"""
+    _chk(lib().sslam_pack_records_dev(ctx.h, int(nframes), int(frame0), int(frame_step), _p(d_kp), _p(d_desc), _p(d_nkp), int(cap),
+                                      _p(d_kl), _p(d_ldesc), _p(d_linefn), _p(d_nl), int(lcap), _p(d_out), C.c_uint64(out_capacity), _p(d_total),
+                                      C.c_void_p(stream or 0)))
+
+
+def unpack_records(stream, nframes, cap, lcap, with_lines=True):
+    """host record stream (uint8 array) -> (kp[n,cap], desc, nkp, kl, ldesc, linefn, nl, nrecords) as sslam_frontend_batch lays them out"""
+    stream = np.ascontiguousarray(stream, np.uint8)
+    kp = np.zeros((nframes, cap), KP_DTYPE); desc = np.zeros((nframes, cap, 32), np.uint8); nk = np.full(nframes, -1, np.int32)
+    kl = np.zeros((nframes, lcap), KL_DTYPE); ld = np.zeros((nframes, lcap, 32), np.uint8); fn = np.zeros((nframes, lcap, 3), np.float64); nl = np.full(nframes, -1, np.int32)
+    nrec = C.c_int(0)
+    _chk(lib().sslam_unpack_records(_p(stream), C.c_uint64(stream.size), int(nframes), _p(kp), _p(desc), _p(nk), int(cap),
+                                    _p(kl) if with_lines else None, _p(ld), _p(fn), _p(nl), int(lcap), C.byref(nrec)))
+    return kp, desc, nk, kl, ld, fn, nl, nrec.value
+
+
+class Group:
+    """sslam_group: Group(ngpu=G) drives G devices from this process; Group(device=, rank=, nranks=, uid=) is one rank of a
+    one-process-per-GPU job (uid from Group.unique_id() on rank 0, broadcast by the launcher)."""
+
+    def __init__(self, ngpu=None, device=0, rank=0, nranks=1, uid=None):
+        self.h = C.c_void_p()
+        if ngpu is not None:
+            _chk(lib().sslam_group_create(int(ngpu), C.byref(self.h)))
+        else:
+            uid = np.ascontiguousarray(uid, np.uint8)
+            assert uid.size == 128
+            _chk(lib().sslam_group_create_rank(int(device), int(rank), int(nranks), _p(uid), C.byref(self.h)))
+        self.size = lib().sslam_group_size(self.h); self.rank = lib().sslam_group_rank(self.h)
+
+    @staticmethod
+    def unique_id():
+        uid = np.zeros(128, np.uint8)
+        _chk(lib().sslam_group_unique_id(_p(uid)))
+        return uid
+
+    def gather_dev(self, d_send, d_send_bytes, d_recv=None, recv_capacity=0, stream=None):
+        """the exchange step (blocking); returns the per-rank stream lengths on rank 0, None elsewhere"""
+        sizes = np.zeros(self.size, np.uint64)
+        _chk(lib().sslam_group_gather_dev(self.h, _p(d_send), _p(d_send_bytes), _p(d_recv), C.c_uint64(recv_capacity), _p(sizes), C.c_void_p(stream or 0)))
+        return sizes if self.rank == 0 else None
+
+    def frontend_batch_sharded(self, images, nfeatures=1000, max_lines=200, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, cap=None, lcap=None):
+        images = np.ascontiguousarray(images, np.uint8)
+        n, h, w = images.shape
+        prm = FrontendParams(int(nfeatures), float(scale_factor), int(nlevels), int(ini_th), int(min_th), int(max_lines))
+        if cap is None:
+            cap = int(nfeatures) + 64 * int(nlevels)
+        lcap = int(lcap if lcap is not None else max(max_lines, 1))
+        kp = np.zeros((n, cap), KP_DTYPE); desc = np.zeros((n, cap, 32), np.uint8); nk = np.zeros(n, np.int32)
+        kl = np.zeros((n, lcap), KL_DTYPE); ld = np.zeros((n, lcap, 32), np.uint8); fn = np.zeros((n, lcap, 3), np.float64); nl = np.zeros(n, np.int32)
+        _chk(lib().sslam_frontend_batch_sharded(self.h, C.byref(prm), _p(images), n, w, h, C.c_size_t(w), C.c_size_t(w * h), _p(kp), _p(desc), _p(nk), cap,
+                                                _p(kl), _p(ld), _p(fn), _p(nl), lcap))
+        return [(kp[i, :nk[i]], desc[i, :nk[i]], kl[i, :nl[i]], ld[i, :nl[i]], fn[i, :nl[i]]) for i in range(n)]
+
+    def close(self):
+        if self.h:
+            lib().sslam_group_destroy(self.h)
+            self.h = C.c_void_p()

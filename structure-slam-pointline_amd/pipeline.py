@@ -127,14 +127,19 @@ class FrontendBatch:
                 self._match_points()
         cur.wait_stream(self._s1); cur.wait_stream(self._s2)
 
-    def packed_results(self):
-        """Fixed-capacity record per frame for the final gather, see sharding.record_layout."""
-        import importlib.util, os, sys
-        if "sslam_sharding" not in sys.modules:
-            spec = importlib.util.spec_from_file_location("sslam_sharding", os.path.join(os.path.dirname(os.path.abspath(__file__)), "sharding.py"))
-            m = importlib.util.module_from_spec(spec); sys.modules["sslam_sharding"] = m; spec.loader.exec_module(m)
+    def packed_stream(self):
+        """The step's results as the C ABI's record stream (sslam_pack_records_dev): device uint8 tensor trimmed to its length (synchronises)."""
         c = self.feat["cur"]
-        return sys.modules["sslam_sharding"].pack_records(c["n"], c["nl"], c["kp"], c["desc"], c["kl"], c["ldesc"])
+        capb = self.fe.record_stream_capacity(self.B, self.cap, self.lcap if self.with_lines else 0)
+        out = torch.zeros(capb + 16, dtype=torch.uint8, device=self.dev); tot = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        s1, _ = self._streams()
+        s1.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s1):
+            ln = self.with_lines
+            self.fe.pack_records_dev(self.ctx, self.B, 0, 1, c["kp"], c["desc"], c["n"], self.cap, c["kl"] if ln else None, c["ldesc"] if ln else None,
+                                     c["linefn"] if ln else None, c["nl"] if ln else None, self.lcap, out, capb, tot, self._stream())
+        s1.synchronize()
+        return out[:int(tot[0].item())]
 
     def close(self):
         self.orb.close()

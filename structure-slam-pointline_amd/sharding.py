@@ -1,8 +1,15 @@
-"""Frame sharding and the final result gather for the batch-of-frames mode.
+"""Frame sharding and the final result gather for the batch-of-frames mode -- harness side.
 
-Frames are independent units: global frame i of a batch of n goes to rank i % world (round-robin),
-every rank runs the same single-GPU pipeline on its shard, and ONE exchange step at the end gathers
-the fixed-capacity per-frame records to rank 0.  No other collective exists on the path."""
+Frames are independent units: global frame i of a batch of n goes to rank i % world (round-robin), every rank runs the same
+single-GPU pipeline on its shard, and ONE exchange step at the end gathers the per-frame records to rank 0.  No other collective
+exists on the path.  The records are the C ABI's record stream (include/sslam_frontend.h: sslam_record_header + keypoints, descriptors,
+keylines, LBD descriptors and the 24-byte line equations, compacted to the counts).
+
+  * GroupGather: the product path -- sslam_pack_records_dev + sslam_group_gather_dev (RCCL ncclSend / ncclRecv inside the library),
+    run from a side thread so that the exchange of step k overlaps the kernels of step k+1;
+  * pack_stream_host / gather_streams: the same stream built with numpy and moved with torch.distributed (gloo) -- the CPU tests of the
+    N > 1 bookkeeping (tests/test_dist_cpu.py), where no GPU and no RCCL exist."""
+import threading
 import numpy as np
 import torch
 
@@ -11,77 +18,87 @@ def shard_indices(n_frames, world, rank):
     return list(range(rank, n_frames, world))
 
 
-def record_layout(cap, lcap):
-    """byte offsets of one frame record: [n_kp i32][n_ln i32][kp cap*28][desc cap*32][kl lcap*68][ldesc lcap*32]"""
-    o = {"n": 0, "nl": 4, "kp": 8}
-    o["desc"] = o["kp"] + cap * 28
-    o["kl"] = o["desc"] + cap * 32
-    o["ldesc"] = o["kl"] + lcap * 68
-    o["size"] = o["ldesc"] + lcap * 32
-    return o
+def record_bytes(nkp, nl):
+    return (16 + nkp * 60 + nl * 124 + 15) & ~15
 
 
-def pack_records(n, nl, kp, desc, kl, ldesc):
-    """torch tensors [B], [B], [B,cap,7] f32, [B,cap,32] u8, [B,lcap,17] f32, [B,lcap,32] u8 -> [B, size] u8"""
-    B = n.shape[0]
-    parts = [n.view(torch.uint8).reshape(B, -1), nl.view(torch.uint8).reshape(B, -1), kp.view(torch.uint8).reshape(B, -1),
-             desc.reshape(B, -1), kl.view(torch.uint8).reshape(B, -1), ldesc.reshape(B, -1)]
-    return torch.cat(parts, dim=1).contiguous()
+def pack_stream_host(records):
+    """records: iterable of (frame, kp[n,28] u8, desc[n,32] u8, kl[m,68] u8, ldesc[m,32] u8, linefn[m,3] f64) -> uint8 stream"""
+    parts = []
+    for frame, kp, desc, kl, ld, fn in records:
+        n, m = len(kp), len(kl)
+        b = record_bytes(n, m)
+        body = np.concatenate([np.array([n, m, frame, b], np.int32).view(np.uint8), np.ascontiguousarray(kp, np.uint8).reshape(-1),
+                               np.ascontiguousarray(desc, np.uint8).reshape(-1), np.ascontiguousarray(kl, np.uint8).reshape(-1),
+                               np.ascontiguousarray(ld, np.uint8).reshape(-1), np.ascontiguousarray(fn, np.float64).reshape(-1).view(np.uint8)])
+        parts.append(np.concatenate([body, np.zeros(b - body.size, np.uint8)]))
+    return np.concatenate(parts) if parts else np.zeros(0, np.uint8)
 
 
-def unpack_record(rec, cap, lcap):
-    """one frame record (1-D uint8 numpy) -> dict of numpy arrays trimmed to the counts"""
-    lay = record_layout(cap, lcap)
-    rec = np.ascontiguousarray(rec)
-    n = int(rec[0:4].view(np.int32)[0]); nl = int(rec[4:8].view(np.int32)[0])
-    kp = rec[lay["kp"]:lay["desc"]].reshape(cap, 28)[:n]
-    desc = rec[lay["desc"]:lay["kl"]].reshape(cap, 32)[:n]
-    kl = rec[lay["kl"]:lay["ldesc"]].reshape(lcap, 68)[:nl]
-    ldesc = rec[lay["ldesc"]:lay["size"]].reshape(lcap, 32)[:nl]
-    return {"n": n, "nl": nl, "kp": kp, "desc": desc, "kl": kl, "ldesc": ldesc}
-
-
-def gather_to_root(dist, rec, world, rank):
-    """rec: [B_local, size] uint8 (same B_local on every rank).  Returns on rank 0 the records in GLOBAL
-    frame order (frame i lives on rank i % world at local slot i // world); None elsewhere."""
+def gather_streams(dist, stream, world, rank):
+    """stream: 1-D uint8 tensor of this rank (any length).  Returns on rank 0 the streams of all ranks back to back (rank order) and
+    the per-rank lengths; (None, None) elsewhere.  Lengths first (all_gather of one int64), then one gather padded to the longest."""
     if world == 1:
-        return rec
-    bufs = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
-    dist.gather(rec, bufs, dst=0)
+        return stream, [int(stream.numel())]
+    mine = torch.tensor([stream.numel()], dtype=torch.int64, device=stream.device)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine)
+    sizes = [int(s.item()) for s in sizes]
+    longest = max(max(sizes), 1)
+    padded = torch.zeros(longest, dtype=torch.uint8, device=stream.device); padded[:stream.numel()] = stream
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+    dist.gather(padded, bufs, dst=0)
     if rank != 0:
-        return None
-    stacked = torch.stack(bufs, dim=1)            # [B_local, world, size] -> global index = local*world + rank
-    return stacked.reshape(-1, rec.shape[1])
+        return None, None
+    return torch.cat([bufs[r][:sizes[r]] for r in range(world)]), sizes
 
 
-class AsyncGather:
-    """The one exchange step, overlapped with the next step's compute: gather(step k) runs on RCCL's stream
-    while the kernels of step k+1 execute; at most one gather is in flight."""
-    def __init__(self, dist, world, rank, always_collective=False):
-        self.dist, self.world, self.rank = dist, world, rank
-        self.local_only = world == 1 and not (always_collective and dist is not None)
-        self.work = None; self.bufs = None; self.rec = None
+class GroupGather:
+    """The exchange step through the C ABI (one process per GPU): pack the step's results into the record stream on the device, then
+    sslam_group_gather_dev on a side thread -- the gather of step k runs while the kernels of step k+1 execute; at most one is in flight."""
 
-    def submit(self, rec):
+    def __init__(self, fe, ctx, group, pipe, device):
+        self.fe, self.ctx, self.group, self.pipe = fe, ctx, group, pipe
+        self.world, self.rank = group.size, group.rank
+        cap_bytes = fe.record_stream_capacity(pipe.B, pipe.cap, pipe.lcap if pipe.with_lines else 0)
+        self.cap_bytes = cap_bytes
+        self.send = [torch.zeros(cap_bytes + 16, dtype=torch.uint8, device=device) for _ in range(2)]      # double buffered: step k+1 packs while step k travels
+        self.total = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(2)]
+        self.recv = torch.zeros(cap_bytes * self.world + 16, dtype=torch.uint8, device=device) if self.rank == 0 else None
+        self.k = 0
+        self.thread = None; self.sizes = None; self.error = None
+
+    def submit(self):
+        """call on the stream the step's kernels were launched on (torch's current stream)"""
         self.wait()
-        if self.local_only:
-            self.rec = rec
-            return
-        if self.rank == 0 and (self.bufs is None or self.bufs[0].shape != rec.shape):
-            self.bufs = [torch.empty_like(rec) for _ in range(self.world)]
-        self.rec = rec                     # keep the source alive until the collective has consumed it
-        self.work = self.dist.gather(rec, self.bufs if self.rank == 0 else None, dst=0, async_op=True)
+        s = self.k & 1; self.k += 1
+        p, c = self.pipe, self.pipe.feat["cur"]
+        st = torch.cuda.current_stream().cuda_stream
+        lines = p.with_lines
+        self.fe.pack_records_dev(self.ctx, p.B, self.rank, self.world, c["kp"], c["desc"], c["n"], p.cap,
+                                 c["kl"] if lines else None, c["ldesc"] if lines else None, c["linefn"] if lines else None, c["nl"] if lines else None, p.lcap,
+                                 self.send[s], self.cap_bytes, self.total[s], st)
+        ev = torch.cuda.Event(); ev.record()
+        self.last = s
+
+        def run():
+            try:
+                ev.synchronize()
+                self.sizes = self.group.gather_dev(self.send[s], self.total[s], self.recv, self.recv.numel() if self.recv is not None else 0)
+            except Exception as e:          # reported by wait()
+                self.error = e
+        self.thread = threading.Thread(target=run); self.thread.start()
 
     def wait(self):
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
+        if self.thread is not None:
+            self.thread.join(); self.thread = None
+            if self.error is not None:
+                e, self.error = self.error, None
+                raise e
 
     def result(self):
-        """records in global frame order on rank 0 (None elsewhere)"""
+        """(record streams of all ranks back to back as a device tensor, per-rank lengths) on rank 0, None elsewhere"""
         self.wait()
-        if self.local_only:
-            return self.rec
-        if self.rank != 0:
+        if self.rank != 0 or self.sizes is None:
             return None
-        return torch.stack(self.bufs, dim=1).reshape(-1, self.rec.shape[1])
+        return self.recv[:int(self.sizes.sum())], [int(x) for x in self.sizes]

@@ -21,10 +21,25 @@ def _p(a):
     return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
 
 
+def build_native():
+    """-O3 -march=native build for the CPU-baseline timing leg (oracle/Makefile `native`); None if the host compiler refuses"""
+    try:
+        subprocess.check_call(["make", "-s", "-C", ODIR, "native"])
+        return os.path.join(ODIR, "_native", "liboracle_native.so")
+    except Exception:
+        return None
+
+
 class Oracle:
-    def __init__(self):
+    def __init__(self, native=False):
         build()
-        self.L = C.CDLL(OLIB)
+        self.native = False
+        path = OLIB
+        if native:
+            p = build_native()
+            if p and os.path.exists(p):
+                path, self.native = p, True
+        self.L = C.CDLL(path)
         self.L.orc_fast_atan2.restype = C.c_float
         self.L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
 

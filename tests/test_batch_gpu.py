@@ -12,7 +12,6 @@ pytestmark = pytest.mark.gpu
 
 def test_batch_equals_single_and_oracle(fe, ctx, oracle):
     pipeline = pkg._load("sslam_pipeline", os.path.join(pkg.PKG_DIR, "pipeline.py"))
-    sh = pkg._load("sslam_sharding", os.path.join(pkg.PKG_DIR, "sharding.py"))
     frames = [synth_frame(2000), noise_frame(9), const_frame(), synth_frame(2001), warp_prev(synth_frame(2000))]
     B = len(frames)
     pipe = pipeline.FrontendBatch(fe, ctx, 640, 480, B, 1000, 200, "cuda:0")
@@ -21,16 +20,17 @@ def test_batch_equals_single_and_oracle(fe, ctx, oracle):
     pipe.extract(prev, "prev")
     pipe.step(imgs, overlap=True)
     torch.cuda.synchronize()
-    rec = pipe.packed_results().cpu().numpy()
+    rkp, rdesc, rn, rkl, rld, rfn, rnl, nrec = fe.unpack_records(pipe.packed_stream().cpu().numpy(), B, pipe.cap, pipe.lcap)      # the record stream of the gather
+    assert nrec == B
     ox = fe.OrbExtractor(ctx, 1000); lx = fe.LineExtractor(ctx, 200)
     for i, f in enumerate(frames):
-        r = sh.unpack_record(rec[i], pipe.cap, pipe.lcap)
         kp, desc = ox(f); kl, ld, fn = lx(f)
-        assert r["n"] == len(kp) and r["nl"] == len(kl)
-        np.testing.assert_array_equal(r["kp"], kp.view(np.uint8).reshape(len(kp), 28))
-        np.testing.assert_array_equal(r["desc"], desc)
-        np.testing.assert_array_equal(r["kl"], kl.view(np.uint8).reshape(len(kl), 68))
-        np.testing.assert_array_equal(r["ldesc"], ld)
+        assert rn[i] == len(kp) and rnl[i] == len(kl)
+        np.testing.assert_array_equal(rkp[i, :rn[i]].view(np.uint8).reshape(-1, 28), kp.view(np.uint8).reshape(len(kp), 28))
+        np.testing.assert_array_equal(rdesc[i, :rn[i]], desc)
+        np.testing.assert_array_equal(rkl[i, :rnl[i]].view(np.uint8).reshape(-1, 68), kl.view(np.uint8).reshape(len(kl), 68))
+        np.testing.assert_array_equal(rld[i, :rnl[i]], ld)
+        np.testing.assert_array_equal(rfn[i, :rnl[i]], fn)
     # matching of the batch == host API == oracle (frame 0 and 3)
     m12 = pipe.m12.cpu().numpy(); nm = pipe.nmatch.cpu().numpy()
     kidx = pipe.knn_idx.cpu().numpy(); lp = pipe.lpairs.cpu().numpy(); nlp = pipe.nlpairs.cpu().numpy()
@@ -46,7 +46,7 @@ def test_batch_equals_single_and_oracle(fe, ctx, oracle):
         opairs, _, _ = oracle.line_match(l1[1], l2[1], 0.5, False)
         assert nlp[i] == len(opairs)
         np.testing.assert_array_equal(lp[i][:nlp[i]], opairs)
-    assert nm[2] == 0 and rec[2][:8].view(np.int32).tolist() == [0, 0]          # constant frame: nothing, no error
+    assert nm[2] == 0 and rn[2] == 0 and rnl[2] == 0          # constant frame: nothing, no error
     ox.close(); lx.close(); pipe.close()
 
 

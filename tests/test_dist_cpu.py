@@ -1,6 +1,8 @@
 """CPU suite: the N>1 path (frame sharding + the single final gather) with world_size 2 on gloo.
-Each rank packs oracle-produced per-frame records for its shard; rank 0 must end up with exactly
-the concatenation of the single-process results, in global frame order."""
+Each rank builds the C ABI's record stream (sslam_record_header + keypoints, descriptors, keylines, LBD descriptors, line equations) for
+the oracle-produced results of its shard; rank 0 gathers the streams and ingests them with the library's own sslam_unpack_records (host
+code: it runs without a GPU).  What rank 0 ends up with must be exactly the single-process results, frame by frame, line equations
+included, for an uneven shard split (5 frames over 2 ranks) too."""
 import os, sys
 import numpy as np
 import pytest
@@ -11,7 +13,7 @@ import pkg
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CAP, LCAP = 600, 60
-NFRAMES = 4
+NFRAMES = 5
 
 
 def _frame_record(i):
@@ -19,40 +21,22 @@ def _frame_record(i):
     import oracle_lib
     from synth import synth_frame
     orc = oracle_lib.Oracle()
-    img = synth_frame(3000 + i, w=256, h=192)
+    img = synth_frame(3000 + i, w=256, h=192) if i != 2 else np.full((192, 256), 99, np.uint8)      # frame 2: nothing to find
     kp, desc = orc.orb_extract(img, 300)
     kl, ld, fn, raw = orc.lines_extract(img, LCAP)
-    n, nl = len(kp), len(kl)
-    kpa = np.zeros((CAP, 28), np.uint8); kpa[:n] = kp.view(np.uint8).reshape(n, 28)
-    da = np.zeros((CAP, 32), np.uint8); da[:n] = desc
-    kla = np.zeros((LCAP, 68), np.uint8); kla[:nl] = kl.view(np.uint8).reshape(nl, 68)
-    lda = np.zeros((LCAP, 32), np.uint8); lda[:nl] = ld
-    return n, nl, kpa, da, kla, lda
-
-
-def _pack(sh, idxs):
-    recs = [_frame_record(i) for i in idxs]
-    t = lambda k, dt: torch.from_numpy(np.stack([np.asarray(r[k]) for r in recs]).astype(dt))
-    n = t(0, np.int32); nl = t(1, np.int32)
-    kp = torch.from_numpy(np.stack([r[2] for r in recs])).view(torch.float32).reshape(len(idxs), CAP, 7)
-    desc = torch.from_numpy(np.stack([r[3] for r in recs]))
-    kl = torch.from_numpy(np.stack([r[4] for r in recs])).view(torch.float32).reshape(len(idxs), LCAP, 17)
-    ld = torch.from_numpy(np.stack([r[5] for r in recs]))
-    return sh.pack_records(n, nl, kp, desc, kl, ld)
+    return (i, kp.view(np.uint8).reshape(len(kp), 28), desc, kl.view(np.uint8).reshape(len(kl), 68), ld, fn)
 
 
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sh = pkg._load("sslam_sharding", os.path.join(pkg.PKG_DIR, "sharding.py"))
-    rec = _pack(sh, sh.shard_indices(NFRAMES, world, rank))
-    out = sh.gather_to_root(dist, rec, world, rank)
-    ag = sh.AsyncGather(dist, world, rank)             # the overlapped form used by bench.py: two steps back to back
-    ag.submit(rec.clone()); ag.submit(rec)
-    out2 = ag.result()
+    stream = torch.from_numpy(sh.pack_stream_host([_frame_record(i) for i in sh.shard_indices(NFRAMES, world, rank)]))
+    out, sizes = sh.gather_streams(dist, stream, world, rank)
+    out2, sizes2 = sh.gather_streams(dist, stream.clone(), world, rank)          # a second step on the same group
     if rank == 0:
-        assert torch.equal(out, out2)
-        q.put(out.numpy())
+        assert torch.equal(out, out2) and sizes == sizes2 and len(sizes) == world and sum(sizes) == out.numel()
+        q.put((out.numpy(), sizes))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,23 +48,43 @@ def test_shard_indices():
     assert sorted(sum((sh.shard_indices(10, 4, r) for r in range(4)), [])) == list(range(10))
 
 
-@pytest.mark.timeout(300)
-def test_gather_equals_single_process_concatenation():
+def test_host_stream_matches_the_c_abi_layout():
+    """sharding.pack_stream_host writes what sslam_pack_records_dev writes: the library's unpack reads it back, malformed streams are refused"""
+    fe = pkg.frontend()
     sh = pkg._load("sslam_sharding", os.path.join(pkg.PKG_DIR, "sharding.py"))
+    recs = [_frame_record(i) for i in (0, 2)]
+    stream = sh.pack_stream_host(recs)
+    assert stream.size == sum(sh.record_bytes(len(r[1]), len(r[3])) for r in recs) == sum(fe.record_bytes(len(r[1]), len(r[3])) for r in recs)
+    kp, desc, nk, kl, ld, fn, nl, nrec = fe.unpack_records(stream, 3, CAP, LCAP)
+    assert nrec == 2 and nk[1] == -1 and nk[2] == 0 and nl[2] == 0 and nk[0] == len(recs[0][1]) > 100
+    np.testing.assert_array_equal(fn[0, :nl[0]], recs[0][5])
+    bad = stream.copy(); bad[12] ^= 0x10                                  # header.bytes no longer matches the counts
+    with pytest.raises(fe.SslamError):
+        fe.unpack_records(bad, 3, CAP, LCAP)
+    with pytest.raises(fe.SslamError):
+        fe.unpack_records(stream, 3, 10, LCAP)                            # capacity too small for frame 0
+
+
+@pytest.mark.timeout(300)
+def test_gather_equals_single_process_results():
+    fe = pkg.frontend()
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs: p.start()
-    gathered = q.get(timeout=240)
+    gathered, sizes = q.get(timeout=240)
     for p in procs: p.join(timeout=60)
     assert all(p.exitcode == 0 for p in procs)
-    single = _pack(sh, list(range(NFRAMES))).numpy()
-    np.testing.assert_array_equal(gathered, single)
-    lay = sh.record_layout(CAP, LCAP)
-    assert gathered.shape == (NFRAMES, lay["size"])
-    r0 = sh.unpack_record(gathered[1], CAP, LCAP)
-    n, nl, kpa, da, kla, lda = _frame_record(1)
-    assert r0["n"] == n and r0["nl"] == nl
-    np.testing.assert_array_equal(r0["desc"], da[:n]); np.testing.assert_array_equal(r0["kl"], kla[:nl])
+    kp, desc, nk, kl, ld, fn, nl, nrec = fe.unpack_records(gathered, NFRAMES, CAP, LCAP)      # rank 0's ingest
+    assert nrec == NFRAMES and len(sizes) == 2 and sizes[0] != sizes[1]                       # 3 frames on rank 0, 2 on rank 1
+    for i in range(NFRAMES):
+        _, okp, od, okl, old, ofn = _frame_record(i)
+        assert nk[i] == len(okp) and nl[i] == len(okl), i
+        np.testing.assert_array_equal(kp[i, :nk[i]].view(np.uint8).reshape(-1, 28), okp)
+        np.testing.assert_array_equal(desc[i, :nk[i]], od)
+        np.testing.assert_array_equal(kl[i, :nl[i]].view(np.uint8).reshape(-1, 68), okl)
+        np.testing.assert_array_equal(ld[i, :nl[i]], old)
+        np.testing.assert_array_equal(fn[i, :nl[i]], ofn)                                     # mvKeyLineFunctions reach rank 0
+    assert nk[2] == 0

@@ -15,7 +15,7 @@ def worker(core, w, h, nfeat, nlines, seconds, q):
     import numpy as np
     import oracle_lib
     from synth import synth_frame, warp_prev
-    orc = oracle_lib.Oracle()
+    orc = oracle_lib.Oracle(native=True)      # built once by the parent (bench.py) before the workers start
     frames = [synth_frame(2000 + i, w, h) for i in range(4)]
     prev = warp_prev(frames[0])
     pk, pd = orc.orb_extract(prev, nfeat)
