@@ -60,7 +60,7 @@ SHIM_TEST = os.path.join(LIBDIR, "shim_test")
 def build_shim(force=False, verbose=True):
     """The C++ host side (reference class surfaces over the C ABI): plain g++, links the HIP library."""
     build(force=False, verbose=verbose)
-    srcs = [os.path.join(SHIM, f) for f in ("shim.cc", "shim_test.cpp", "cv_min.h", "ORBextractor.h", "ExtractLineSegment.h", "FrontendMatchers.h")]
+    srcs = [os.path.join(SHIM, f) for f in ("shim.cc", "shim_test.cpp", "cv_min.h", "ORBextractor.h", "ExtractLineSegment.h", "FrontendMatchers.h", "ORBmatcher.h", "LSDmatcher.h")]
     if not force and os.path.exists(SHIM_TEST) and os.path.exists(SHIM_LIB) and \
             all(os.path.getmtime(x) < os.path.getmtime(SHIM_TEST) for x in srcs + [LIB]):
         return SHIM_TEST

@@ -11,7 +11,7 @@
 
 namespace {
 struct Global {
-    std::mutex mu;
+    std::mutex mu, linesMu;                  // linesMu: held for the duration of a line extraction and by SetMaxLines
     sslam_ctx* ctx = nullptr;
     sslam_lines* lines = nullptr;
     int maxLines = 40;                       // reference cap, src/ExtractLineSegment.cpp:42
@@ -73,6 +73,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector
 
 LineSegment::LineSegment() {}
 void LineSegment::SetMaxLines(int n) {
+    std::lock_guard<std::mutex> lk2(G.linesMu);
     std::lock_guard<std::mutex> lk(G.mu);
     if (n != G.maxLines && G.lines) { sslam_lines_destroy(G.lines); G.lines = nullptr; }
     G.maxLines = n;
@@ -80,6 +81,9 @@ void LineSegment::SetMaxLines(int n) {
 void LineSegment::ExtractLineSegment(const cv::Mat &img, std::vector<cv::line_descriptor::KeyLine> &keylines, cv::Mat &ldesc,
                                      std::vector<sslam_shim::Vector3d> &keylineFunctions, int, int)
 {
+    // the handle is shared by every (never constructed) LineSegment; an extraction holds the lock that SetMaxLines needs to replace it
+    G.getLines();
+    std::lock_guard<std::mutex> lk(G.linesMu);
     sslam_lines* L = G.getLines();
     const int cap = G.maxLines;
     keylines.resize(cap);
@@ -87,7 +91,13 @@ void LineSegment::ExtractLineSegment(const cv::Mat &img, std::vector<cv::line_de
     std::vector<double> fn((size_t)cap * 3);
     int n = 0;
     int rc = sslam_lines_extract(L, img.data, img.cols, img.rows, (size_t)img.step, (sslam_keyline*)keylines.data(), d.data(), fn.data(), cap, &n);
-    if (rc != SSLAM_OK) n = 0;                       // reference: OpenCV would throw; the shim returns 0 lines
+    if (rc == SSLAM_ERR_UNSUPPORTED) {               // an image LSD cannot take (smaller than 10x10, > 8192 rectangles): the reference's OpenCV would throw; 0 lines, said aloud
+        std::fprintf(stderr, "sslam front-end: ExtractLineSegment: %s -- returning no lines\n", sslam_last_error());
+        n = 0;
+    } else if (rc != SSLAM_OK) {                     // a GPU fault must not degrade tracking silently: same behaviour as the ORB path
+        keylines.clear();
+        check(rc);
+    }
     keylines.resize(n);
     if (n > 0) { ldesc.create(n, 32, CV_8U); for (int i = 0; i < n; ++i) std::memcpy(ldesc.ptr(i), &d[(size_t)i * 32], 32); }
     for (int i = 0; i < n; ++i) { sslam_shim::Vector3d v; v(0) = fn[i * 3]; v(1) = fn[i * 3 + 1]; v(2) = fn[i * 3 + 2]; keylineFunctions.push_back(v); }

@@ -7,6 +7,36 @@
 #include "ORBextractor.h"
 #include "ExtractLineSegment.h"
 #include "FrontendMatchers.h"
+#include "ORBmatcher.h"
+#include "LSDmatcher.h"
+
+// Minimal stand-ins for the reference's Frame / KeyFrame / MapPoint / MapLine with exactly the members the matcher bodies read
+// (include/Frame.h:150-200, include/MapPoint.h, include/MapLine.h, include/KeyFrame.h): the class drop-ins are member templates, so the
+// reference's own types bind the same way at its call sites.
+struct TMapPoint {
+    bool mbTrackInView = true, bad = false; int mnTrackScaleLevel = 0, nObs = 1; float mTrackViewCos = 1.f, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = -1;
+    cv::Mat desc;
+    bool isBad() const { return bad; }
+    cv::Mat GetDescriptor() const { return desc; }
+    int Observations() const { return nObs; }
+};
+struct TMapLine {
+    bool mbTrackInView = true, bad = false; int mnTrackScaleLevel = 0, nObs = 1; float mTrackViewCos = 1.f, mTrackProjX1 = 0, mTrackProjY1 = 0, mTrackProjX2 = 0, mTrackProjY2 = 0;
+    cv::Mat desc;
+    bool isBad() const { return bad; }
+    cv::Mat GetDescriptor() const { return desc; }
+    int Observations() const { return nObs; }
+};
+struct TFrame {
+    std::vector<cv::KeyPoint> mvKeysUn; cv::Mat mDescriptors; std::vector<float> mvuRight, mvScaleFactors; std::vector<TMapPoint*> mvpMapPoints;
+    std::vector<cv::line_descriptor::KeyLine> mvKeylinesUn; cv::Mat mLdesc; std::vector<TMapLine*> mvpMapLines; int NL = 0;
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
+};
+struct TKeyFrame {
+    cv::Mat mLineDescriptors; std::vector<TMapLine*> lines;
+    std::vector<TMapLine*> GetMapLineMatches() const { return lines; }
+    TMapLine* GetMapLine(size_t i) const { return lines[i]; }
+};
 
 static std::vector<uint8_t> readAll(const char* p) { std::ifstream f(p, std::ios::binary); return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()); }
 template <class T> static void dump(const std::string& p, const T* d, size_t n) { std::ofstream f(p, std::ios::binary); f.write((const char*)d, sizeof(T) * n); }
@@ -38,6 +68,57 @@ int main(int argc, char** argv) {
     int nlm = sslam_shim::LineMatch(ld1, ld2, 0.5, false, lm);             // Tracking.cc:367-368
     std::vector<int> kidx, kdist;
     sslam_shim::KnnMatch2(ld1, ld2, kidx, kdist);
+    // ---- the matcher CLASS drop-ins (shim/ORBmatcher.h, shim/LSDmatcher.h) with the call syntax of Tracking.cc / LocalMapping.cc
+    {
+        TFrame F1, F2;
+        F1.mvKeysUn = k1; F1.mDescriptors = d1; F2.mvKeysUn = k2; F2.mDescriptors = d2;
+        F1.mnMaxX = F2.mnMaxX = (float)w; F1.mnMaxY = F2.mnMaxY = (float)h;
+        F1.mLdesc = ld1; F2.mLdesc = ld2; F1.mvKeylinesUn = l1; F2.mvKeylinesUn = l2; F1.NL = (int)l1.size(); F2.NL = (int)l2.size();
+        for (int i = 0; i < 8; ++i) F2.mvScaleFactors.push_back(ext->GetScaleFactors()[i]);
+        std::vector<cv::Point2f> pm2(k1.size()); for (size_t i = 0; i < k1.size(); ++i) pm2[i] = k1[i].pt;
+        std::vector<int> m12c;
+        StructureSLAM::ORBmatcher matcher(0.9, true);                          // Tracking.cc:365
+        const int nmc = matcher.SearchForInitialization(F1, F2, pm2, m12c, 100);
+        std::vector<std::pair<int,int> > lmc;
+        StructureSLAM::LSDmatcher lmatcher;                                     // Tracking.cc:367
+        const int nlmc = lmatcher.SerachForInitialize(F1, F2, lmc);
+        if (nmc != nm || m12c != m12 || nlmc != nlm || lmc != lm) { std::fprintf(stderr, "class drop-ins differ from the free functions\n"); return 5; }
+        // Tracking::SearchLocalPoints (src/Tracking.cc:1729-1736): map points = the previous frame's keypoints "projected" to where they were
+        std::vector<TMapPoint> mps(k1.size());
+        for (size_t i = 0; i < k1.size(); ++i) {
+            TMapPoint& m = mps[i];
+            m.desc = d1.row((int)i); m.mTrackProjX = k1[i].pt.x + 2.5f; m.mTrackProjY = k1[i].pt.y - 1.5f; m.mnTrackScaleLevel = k1[i].octave;
+            m.mTrackViewCos = (i % 2) ? 0.9995f : 0.9f; m.mbTrackInView = (i % 3) != 0; m.bad = (i % 7) == 0;
+        }
+        std::vector<TMapPoint*> vp; for (auto& m : mps) vp.push_back(&m);
+        TMapPoint held; held.nObs = 1; TMapPoint ghost; ghost.nObs = 0;
+        F2.mvpMapPoints.assign(k2.size(), nullptr); F2.mvuRight.assign(k2.size(), -1.f);
+        for (size_t i = 0; i < k2.size(); ++i) if (i % 5 == 0) F2.mvpMapPoints[i] = (i % 10 == 0) ? &held : &ghost;      // observed points block a keypoint, unobserved ones do not
+        StructureSLAM::ORBmatcher local(0.8);                                  // Tracking.cc:1729
+        const int nloc = local.SearchByProjection(F2, vp, 3);
+        std::vector<int> own(k2.size(), -1);
+        for (size_t i = 0; i < k2.size(); ++i) { TMapPoint* q = F2.mvpMapPoints[i]; own[i] = q == nullptr ? -1 : q == &held ? -2 : q == &ghost ? -3 : (int)(q - mps.data()); }
+        own.push_back(nloc);
+        dump(out + "_cls_local.bin", own.data(), own.size());
+        // LSDmatcher on keyframes: LocalMapping.cc:920 (triangulation, gate 0.1) and Tracking.cc:1024 (keyframe -> frame, ratio gate)
+        std::vector<TMapLine> mls(l1.size() + l2.size());
+        TKeyFrame KF1, KF2; KF1.mLineDescriptors = ld1; KF2.mLineDescriptors = ld2;
+        for (size_t i = 0; i < l1.size(); ++i) KF1.lines.push_back(i % 4 == 0 ? &mls[i] : nullptr);
+        for (size_t i = 0; i < l2.size(); ++i) KF2.lines.push_back(i % 6 == 1 ? &mls[l1.size() + i] : nullptr);
+        std::vector<std::pair<size_t, size_t> > tri;
+        lmatcher.SearchForTriangulation(&KF1, &KF2, tri);
+        std::vector<int> trif; for (auto& pr : tri) { trif.push_back((int)pr.first); trif.push_back((int)pr.second); }
+        dump(out + "_cls_tri.bin", trif.data(), trif.size());
+        std::vector<TMapLine*> k2f;
+        const int nk2f = lmatcher.SearchByProjection(&KF1, F2, k2f);
+        std::vector<int> k2fi; for (TMapLine* q : k2f) k2fi.push_back(q ? (int)(q - mls.data()) : -1);
+        k2fi.push_back(nk2f);
+        dump(out + "_cls_kf2f.bin", k2fi.data(), k2fi.size());
+        std::vector<TMapLine*> kk;
+        lmatcher.SearchByDescriptor(&KF1, &KF2, kk);
+        std::vector<int> kki; for (TMapLine* q : kk) kki.push_back(q ? (int)(q - mls.data()) : -1);
+        dump(out + "_cls_kf2kf.bin", kki.data(), kki.size());
+    }
     // empty image: outputs untouched
     std::vector<cv::KeyPoint> ke(3); cv::Mat de; (*ext)(cv::Mat(), cv::Mat(), ke, de);
     const int emptyOk = ke.size() == 3 ? 1 : 0;

@@ -57,3 +57,48 @@ def test_cpp_shim_end_to_end(oracle):
     for j in range(len(fn_)):
         exp += [int(fn_[j]), int(fp[j + 1] - fp[j])] + ff[fp[j]:fp[j + 1]].tolist()
     assert fvflat.tolist() == exp and len(bw) > 100
+
+
+def test_matcher_class_dropins(oracle, fe):
+    """shim/ORBmatcher.h / shim/LSDmatcher.h: the reference's class names and call syntax (member templates over the frame types) --
+    ORBmatcher::SearchByProjection(F, vpMapPoints, th) as Tracking::SearchLocalPoints calls it, LSDmatcher::SearchForTriangulation,
+    SearchByProjection(KF, F, ...) and SearchByDescriptor(KF, KF, ...) -- against the oracle's restatements of the reference bodies.
+    (SearchForInitialization / SerachForInitialize through the classes are asserted equal to the free functions inside shim_test.)"""
+    exe = pkg.builder().build_shim(force=False, verbose=False)
+    cur = synth_frame(1234); prev = warp_prev(cur)
+    with tempfile.TemporaryDirectory() as d:
+        cur.tofile(os.path.join(d, "cur.raw")); prev.tofile(os.path.join(d, "prev.raw"))
+        out = os.path.join(d, "o")
+        r = subprocess.run([exe, os.path.join(d, "cur.raw"), "640", "480", os.path.join(d, "prev.raw"), out, "1000", "40"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rd = lambda n: np.fromfile(out + "_" + n + ".bin", dtype=np.int32)
+        own, tri, kf2f, kf2kf = rd("cls_local"), rd("cls_tri").reshape(-1, 2), rd("cls_kf2f"), rd("cls_kf2kf")
+    kp1, d1 = oracle.orb_extract(prev, 1000); kp2, d2 = oracle.orb_extract(cur, 1000)
+    scale = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    sc = [np.float32(1.0)]
+    for _ in range(7): sc.append(np.float32(sc[-1] * np.float32(1.2)))
+    # the queries Tracking::SearchLocalPoints' loop forms (src/ORBmatcher.cc:51-70) for the stand-in map points of shim_test
+    idx = [i for i in range(len(kp1)) if i % 3 != 0 and i % 7 != 0]
+    q = np.zeros(len(idx), fe.PQ_DTYPE)
+    for j, i in enumerate(idx):
+        lvl = int(kp1["octave"][i]); r0 = np.float32(2.5) if i % 2 else np.float32(4.0)
+        q[j] = (np.float32(kp1["x"][i]) + np.float32(2.5), np.float32(kp1["y"][i]) - np.float32(1.5), 0, 0, np.float32(np.float32(r0 * np.float32(3.0)) * sc[lvl]), lvl - 1, lvl, 0.0, -1.0, 1, 1)
+    occupied = np.array([1 if i % 10 == 0 else 0 for i in range(len(kp2))], np.uint8)
+    res = oracle.search_by_projection(0, 0, kp2, d2, q, d1[idx], occupied=occupied, uright=np.full(len(kp2), -1, np.float32), nnratio=0.8, th_dist=100, check_orientation=False)
+    assigned, n = res[0], res[1]
+    exp = np.array([idx[a] if a >= 0 else (-2 if i % 10 == 0 else -3 if i % 5 == 0 else -1) for i, a in enumerate(assigned)], np.int32)
+    assert own[-1] == n and n > 100
+    np.testing.assert_array_equal(own[:-1], exp)
+    l1 = oracle.lines_extract(prev, 40); l2 = oracle.lines_extract(cur, 40)
+    p01, _, _ = oracle.line_match(l1[1], l2[1], 0.1, False)
+    np.testing.assert_array_equal(tri, np.array([p for p in p01 if not (p[0] % 4 == 0 or p[1] % 6 == 1)], np.int32).reshape(-1, 2))
+    pr, _, _ = oracle.line_match(l1[1], l2[1], 0.5, True)                       # keyframe -> frame: ratio gate, keyframe lines 0, 4, 8, ... hold map lines
+    e = np.full(len(l2[0]), -1, np.int32)
+    for a, b in pr:
+        if a % 4 == 0: e[b] = a
+    np.testing.assert_array_equal(kf2f[:-1], e); assert kf2f[-1] == sum(1 for a, b in pr if a % 4 == 0)
+    p05, _, _ = oracle.line_match(l1[1], l2[1], 0.5, False)                     # keyframe -> keyframe: MAD gate, the SECOND keyframe's map lines
+    e2 = np.full(len(l1[0]), -1, np.int32)
+    for a, b in p05:
+        if b % 6 == 1: e2[a] = len(l1[0]) + b
+    np.testing.assert_array_equal(kf2kf, e2)
