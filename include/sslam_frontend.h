@@ -422,6 +422,10 @@ int sslam_frontend_batch_sharded(sslam_group* group, const sslam_frontend_params
 /* Self-test of the table-based exact integer division of the NFA binomial tail against the hardware IEEE division:
  * `pairs` random quotients a/b with 1 <= a,b < n; *mismatches_out must come back 0. */
 int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, long long* mismatches_out);
+/* The log-gamma / log(p) / reciprocal tables of the NFA stage as the library evaluates them on the host with the reference's own libm
+ * expressions (opencv lsd.cpp log_gamma_windschitl / log_gamma_lanczos, reached from src/ExtractLineSegment.cpp:38-40): out[2n + 48].
+ * Host-only; lets a test pin the table bits (a libm that rounds differently would otherwise go unnoticed until a rectangle flips). */
+int sslam_debug_nfa_tables(int n, double* out);
 /* Self-test of the guarded fp32 early-exit test used in the NFA tail loop (the reference's `err < tolerance * ...` test,
  * opencv lsd.cpp nfa(), reached from src/ExtractLineSegment.cpp:38-43): random inputs, half on the decision boundary.
  * disagree_out must be 0; ambiguous_out = cases that fall back to the fp64 expression. */

@@ -428,6 +428,7 @@ extern "C" double orc_lsd_nfa(int w, int h, int n, int k, double p) {
     lsd.LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
     return lsd.nfa(n, k, p);
 }
+extern "C" double orc_log_gamma(double x) { return log_gamma(x); }
 extern "C" int orc_sobel3(const uint8_t* src, int w, int h, int16_t* gx, int16_t* gy) {
     Img8 im(w, h); std::memcpy(im.d.data(), src, (size_t)w * h);
     std::vector<int16_t> x, y; sobel3_s16(im, x, y);

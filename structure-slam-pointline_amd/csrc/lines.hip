@@ -478,3 +478,14 @@ extern "C" int sslam_lines_debug_lbd_floats(sslam_lines* L, int frame, float* ou
 #endif
 
 extern "C" sslam_ctx* sslam_lines_context(sslam_lines* L) { return L ? L->ctx : nullptr; }
+
+// The host-evaluated nfa() tables exactly as upload_nfa_tables() sends them to the device (decision D8): lgam[0..n), then 16 x {log p,
+// log(1-p), log10 p}, then 1/j.  Pure host code (no GPU needed): tests/test_oracle_cpu.py pins the bits against committed goldens, so a
+// host libm that rounds log / sinh / pow differently is noticed before it can flip a borderline rectangle.
+extern "C" int sslam_debug_nfa_tables(int n, double* out) {
+    if (n < 2 || !out) return SSLAM_ERR_INVALID;
+    for (int j = 0; j < n; ++j) out[j] = j >= 1 ? host_log_gamma((double)j) : 0.0;
+    for (int j = 0; j < 16; ++j) { const double pp = std::ldexp(0.125, -j); out[n + 3 * j] = std::log(pp); out[n + 3 * j + 1] = std::log(1.0 - pp); out[n + 3 * j + 2] = std::log10(pp); }
+    for (int j = 0; j < n; ++j) out[(size_t)n + 48 + j] = j >= 1 ? 1.0 / (double)j : 0.0;
+    return SSLAM_OK;
+}

@@ -338,3 +338,23 @@ def test_cpu_allcores_script():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["cores"] in (1, 2) and out["value"] > 1 and out["frames"] >= 2
+
+
+def test_nfa_tables_are_pinned(oracle):
+    """decision D8: the NFA stage's log-gamma / log(p) tables are evaluated on the HOST (the reference's own libm expressions), so their bits
+    depend on the libm of the box that runs the library.  Goldens generated in the build container (glibc 2.35): the library's table, the
+    oracle's log_gamma and the goldens must agree bit for bit wherever the suite runs."""
+    import ctypes as C
+    import pkg
+    g = np.load(os.path.join(GOLD, "nfa_tables.npz"))
+    L = C.CDLL(pkg.builder().build(force=False, verbose=False))
+    n = int(g["j"].max()) + 4
+    tab = np.zeros(2 * n + 48)
+    assert L.sslam_debug_nfa_tables(n, C.c_void_p(tab.ctypes.data)) == 0
+    np.testing.assert_array_equal(tab[g["j"]].view(np.uint64), g["lgam_bits"])
+    np.testing.assert_array_equal(tab[n:n + 48].view(np.uint64), g["plog_bits"])
+    oracle.L.orc_log_gamma.restype = C.c_double; oracle.L.orc_log_gamma.argtypes = [C.c_double]
+    some = g["j"][::37]
+    assert [np.float64(oracle.L.orc_log_gamma(float(j))).view(np.uint64) for j in some] == list(g["lgam_bits"][::37])
+    assert tab[1] == tab[2] == 0.0 or abs(tab[1]) < 1e-12                    # log Gamma(1) = log Gamma(2) = 0 up to the approximation
+    assert (tab[n + 48 + 1:n + 48 + 5] == [1.0, 0.5, 1.0 / 3.0, 0.25]).all()
