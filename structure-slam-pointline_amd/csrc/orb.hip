@@ -164,23 +164,32 @@ __device__ __forceinline__ int fast_score16(const uint8_t* c, int tp, int minTh)
         cd = cd && ((r[k] < v - minTh) || (r[k + 8] < v - minTh));
     }
     if (!(cb || cd)) return 0;
-    int d[16];
+    // One polarity per evaluation.  A 9-arc whose pixels are all darker than v - t and one whose pixels are all brighter than v + t would
+    // have to share two ring positions, so at most one polarity can reach a score >= minTh >= 1: the lane picks the polarity its pair
+    // test left open (d = v - r for a darker ring, r - v for a brighter one) and runs ONE max-of-arc-minimum network instead of the two
+    // of cv::cornerScore; the rare pixel that passed both pair tests runs the network a second time with the other sign.
+    int best = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool on = pass == 0 ? true : (cb && cd);
+        if (__builtin_amdgcn_ballot_w64(on) == 0) break;
+        const bool dark = pass == 0 ? cd : false;               // pass 0: darker ring if that test passed, else brighter; pass 1: the brighter one
+        int d[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = v - r[k];
-    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+        for (int k = 0; k < 16; ++k) d[k] = dark ? v - r[k] : r[k] - v;
+        int mn2[16], mn4[16], mn8[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+        for (int k = 0; k < 16; ++k) mn2[k] = min(d[k], d[(k + 1) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+        for (int k = 0; k < 16; ++k) mn4[k] = min(mn2[k], mn2[(k + 2) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
-    int A = -1000, B = 1000;
+        for (int k = 0; k < 16; ++k) mn8[k] = min(mn4[k], mn4[(k + 4) & 15]);
+        int A = -1000;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        A = max(A, min(mn8[k], d[(k + 8) & 15]));
-        B = min(B, max(mx8[k], d[(k + 8) & 15]));
+        for (int k = 0; k < 16; ++k) A = max(A, min(mn8[k], d[(k + 8) & 15]));
+        if (on) best = max(best, A);
     }
-    int s = max(A, -B) - 1;
+    int s = best - 1;
     return s >= minTh ? s : 0;
 }
 
