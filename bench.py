@@ -221,7 +221,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: the workload's)")
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic frames per rank, tiled to the batch (default: the workload's, 64 for c3)")
-    ap.add_argument("--overlap", action="store_true", help="run the point and line branches on two streams (off by default: the persistent LSD kernel wants every wave slot, sharing them costs a second round)")
+    ap.add_argument("--no-overlap", action="store_true", help="run the point branch (ORB extract + match) and the line branch (LSD/LBD extract + match) one after the other on one stream instead of on two HIP streams (default: two streams -- the sequential LSD core is latency-bound and leaves issue slots that the VALU-bound ORB kernels fill)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the latency and PCIe-inclusive legs")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing (used for rocprofv3 runs)")
@@ -289,7 +289,7 @@ def main():
     def one_step():
         if host_cur is not None:
             cur.copy_(host_cur, non_blocking=True)             # configs[4]: the H2D of the frames is part of the step
-        pipe.step(cur, overlap=args.overlap)
+        pipe.step(cur, overlap=not args.no_overlap)
         if gather is not None:      # the one exchange step of the path: compacted per-frame records to rank 0 over RCCL,
             gather.submit()         # overlapped with the next step's kernels (configs[4]: waited for inside the step)
             if wl.get("sync_gather"):
@@ -356,6 +356,7 @@ def main():
                        "keypoints_per_frame": stat(counts), "lines_per_frame": stat(lcounts),
                        "mean_keypoints": float(counts.mean()), "mean_lines": float(lcounts.mean()),
                        "mean_orb_matches": float(nm.mean()), "mean_line_matches": float(nlp.mean()),
+                       "streams": "point branch and line branch on two HIP streams" if not args.no_overlap else "one stream",
                        "parallelism": ("frames sharded %d/GPU, RCCL gather (sslam_group_gather_dev) of compacted records to rank 0 per step" % B) if gather is not None else "single GPU",
                        "gather_check": gather_info["ok"] if gather_info else None, "gather": gather_info},
         }
@@ -382,7 +383,8 @@ def main():
                                "whole_pipeline": {"survey_8d_bytes_per_frame": sv, "achieved": sv * per_gpu_fps / 1e9, "frac": sv * per_gpu_fps / 1e9 / HBM_PEAK_GBS,
                                                   "per_kernel_table_bytes_per_frame": sum(ab.values()), "per_kernel_table_frac": sum(ab.values()) * per_gpu_fps / 1e9 / HBM_PEAK_GBS,
                                                   "note": "frac uses SURVEY.md §8(d)'s own byte total; the per-kernel table (DESIGN.md §4) is what this implementation moves"},
-                               "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+                               "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+                               "kernels_note": "HIP-event durations per kernel; with the two branches on two streams kernels of different branches overlap, so the durations include the sharing and their sum exceeds ms_per_step (run with --no-overlap for isolated durations)" if not args.no_overlap else "kernels run back to back on one stream"}
         if world == 1 and not args.no_extras and args.workload in ("c3", "c2", "c4"):
             try:
                 out["latency"] = latency_leg(fe, ctx, cur_np, with_lines)

@@ -59,6 +59,34 @@ __global__ __launch_bounds__(256) void k_knn2_batch(const uint8_t* __restrict__ 
         const int qi = min(q0i + k, nqf - 1);
         qa[k] = ((const uint4*)(qb + (size_t)qi * 32))[0]; qc[k] = ((const uint4*)(qb + (size_t)qi * 32))[1];
     }
+    if (ntf <= 65536) {
+        // 32-bit keys (dist << 16 | train index; all keys of a query are distinct): best and second-best are three integer min / max per
+        // pair -- b' = min(b, k), s' = min(s, max(b, k)) -- instead of 64-bit compares and selects
+        unsigned b[4] = {~0u, ~0u, ~0u, ~0u}, s[4] = {~0u, ~0u, ~0u, ~0u};
+        for (int j = lane; j < ntf; j += 64) {
+            const uint4* tp = (const uint4*)(tb + (size_t)j * 32);
+            const uint4 t0 = tp[0], t1 = tp[1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned kk = ((unsigned)hamming256(qa[k], qc[k], t0, t1) << 16) | (unsigned)j;
+                s[k] = min(s[k], max(b[k], kk));
+                b[k] = min(b[k], kk);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned best = wave_min_u32(b[k]);
+            const unsigned second = wave_min_u32(b[k] == best ? s[k] : b[k]);
+            if (lane == 0 && q0i + k < nqf) {
+                const size_t o = ((size_t)f * cap + q0i + k) * 2;
+                idx[o] = best == ~0u ? -1 : (int)(best & 0xFFFFu);
+                dist[o] = best == ~0u ? -1 : (int)(best >> 16);
+                idx[o + 1] = second == ~0u ? -1 : (int)(second & 0xFFFFu);
+                dist[o + 1] = second == ~0u ? -1 : (int)(second >> 16);
+            }
+        }
+        return;
+    }
     unsigned long long b[4] = {~0ull, ~0ull, ~0ull, ~0ull}, s[4] = {~0ull, ~0ull, ~0ull, ~0ull};
     for (int j = lane; j < ntf; j += 64) {
         const uint4* tp = (const uint4*)(tb + (size_t)j * 32);

@@ -44,7 +44,9 @@ class FrontendBatch:
 
     def _streams(self):
         if not hasattr(self, "_s1"):
-            self._s1, self._s2 = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+            import os
+            pr = int(os.environ.get("SSLAM_LINE_STREAM_PRIORITY", "0"))      # experiment knob: -1 = the line branch (critical path) on a high-priority stream
+            self._s1, self._s2 = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev, priority=pr)
         return self._s1, self._s2
 
     def extract(self, images, tag="cur", lines_first=False):
@@ -103,7 +105,7 @@ class FrontendBatch:
                                           C.c_double(0.5), 0, _p(self.lpairs), _p(self.nlpairs), st)
         assert rc == 0, L.sslam_last_error()
 
-    def step(self, images, overlap=False, lines_first=False):
+    def step(self, images, overlap=False, lines_first=False, join=True):
         """One pass of the hot path.  overlap=True runs the point branch (ORB extract + ORB matching)
         and the line branch (LSD/LBD extract + line matching) on two HIP streams: the line branch is
         latency-bound (one persistent wave per frame), the point branch fills the idle issue slots."""
@@ -125,7 +127,8 @@ class FrontendBatch:
             self.orb.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kp"], f["desc"], f["n"], self.cap, self._stream())
             if self.with_match:
                 self._match_points()
-        cur.wait_stream(self._s1); cur.wait_stream(self._s2)
+        if join:      # join=False: the two branches may drift apart across steps (the point branch of step k+1 under the line branch of step k);
+            cur.wait_stream(self._s1); cur.wait_stream(self._s2)      # the caller synchronises both streams (or the device) before it reads results
 
     def packed_stream(self):
         """The step's results as the C ABI's record stream (sslam_pack_records_dev): device uint8 tensor trimmed to its length (synchronises)."""
