@@ -369,7 +369,7 @@ def main():
             ach = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
             traffic, traffic_src = None, None
             try:      # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs cannot share a process with this timing run), scaled to this batch
-                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_c4.json" if args.workload == "c4" else "pmc_traffic.json")))
                 pt = pj["kernels"][name]      # fetch side x2: gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, calibrated in profiles/)
                 traffic = (pt["fetch_bytes_per_frame"] * pj.get("fetch_correction", 1.0) + pt["write_bytes_per_frame"]) * B
                 traffic_src = "profiles/pmc_traffic.json (%s), scaled to this batch" % pj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")

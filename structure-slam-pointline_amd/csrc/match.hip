@@ -96,6 +96,13 @@ extern "C" int sslam_orb_search_for_initialization_batch_dev(sslam_ctx* ctx,
     A.cap = cap; A.n1s = 0; A.n2s = 0; A.prevMatched = d_prev; A.m12 = d_m12; A.nmatches = d_nm;
     A.scratch = ctx->scratch[3].as<int>(); A.window = window; A.nnratio = nnratio; A.checkOri = checkOri;
     A.minX = bounds[0]; A.maxX = bounds[1]; A.minY = bounds[2]; A.maxY = bounds[3];
+    // a handful of pairs (the single call of Tracking::MonocularInitialization): the LDS-resident kernel, as long as a pair fits the CU's LDS
+    const size_t ldsNeed = 64 + (size_t)cap * 14 * 4 + (size_t)cap * 2 * 4;      // per candidate 14 words, per F1 keypoint 2
+    if (npairs <= 8 && ldsNeed <= 150 * 1024 && !getenv("SSLAM_SFI_GLOBAL")) {
+        if (ldsNeed > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_search_init_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsNeed));
+        sslam::ProfScope _ps(ctx, "k_search_init", pick(ctx, stream));
+        hipLaunchKernelGGL(k_search_init_lds, dim3(npairs), dim3(64), ldsNeed, pick(ctx, stream), A);
+    } else
     { sslam::ProfScope _ps(ctx, "k_search_init", pick(ctx, stream)); hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(64), 0, pick(ctx, stream), A); }
     SSLAM_HIP(hipGetLastError());
     return SSLAM_OK;
@@ -116,27 +123,31 @@ extern "C" int sslam_orb_search_for_initialization(sslam_ctx* ctx,
     hipStream_t st = ctx->stream;
     const size_t kb = sizeof(sslam_keypoint) * (size_t)cap, db = 32 * (size_t)cap;
     int rc;
-    // layout: kp1 | kp2 | d1 | d2 | prev | m12 | n1,n2,nm
-    size_t total = 2 * kb + 2 * db + 8 * (size_t)cap + 4 * (size_t)cap + 64;
+    // device layout: kp1 | kp2 | d1 | d2 | prev | n1,n2,nm (16 B) | m12 -- everything that goes in is one contiguous range, so is everything
+    // that comes back (prev .. m12): ONE staged H2D and ONE D2H through pinned memory instead of six + three pageable copies (a pageable
+    // hipMemcpyAsync costs 10-20 us of host time each, more than the kernel of a single call)
+    const size_t oPrev = 2 * kb + 2 * db, oN = oPrev + 8 * (size_t)cap, oM = oN + 16, total = oM + 4 * (size_t)cap + 64;
     if ((rc = ctx->scratch[4].ensure(total))) return rc;
+    if ((rc = ctx->pinned[2].ensure(total))) return rc;
     uint8_t* base = ctx->scratch[4].as<uint8_t>();
+    uint8_t* H = ctx->pinned[2].as<uint8_t>();
     sslam_keypoint* dk1 = (sslam_keypoint*)base; sslam_keypoint* dk2 = (sslam_keypoint*)(base + kb);
     uint8_t* dd1 = base + 2 * kb; uint8_t* dd2 = dd1 + db;
-    float* dpm = (float*)(dd2 + db); int* dm12 = (int*)((uint8_t*)dpm + 8 * (size_t)cap); int* dn = dm12 + cap;
-    int hn[3] = {n1, n2, 0};
-    SSLAM_HIP(hipMemcpyAsync(dk1, kp1, sizeof(sslam_keypoint) * (size_t)n1, hipMemcpyHostToDevice, st));
-    SSLAM_HIP(hipMemcpyAsync(dd1, desc1, 32 * (size_t)n1, hipMemcpyHostToDevice, st));
-    if (n2) {
-        SSLAM_HIP(hipMemcpyAsync(dk2, kp2, sizeof(sslam_keypoint) * (size_t)n2, hipMemcpyHostToDevice, st));
-        SSLAM_HIP(hipMemcpyAsync(dd2, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, st));
-    }
-    SSLAM_HIP(hipMemcpyAsync(dpm, prev_matched, 8 * (size_t)n1, hipMemcpyHostToDevice, st));
-    SSLAM_HIP(hipMemcpyAsync(dn, hn, sizeof(hn), hipMemcpyHostToDevice, st));
+    float* dpm = (float*)(base + oPrev); int* dn = (int*)(base + oN); int* dm12 = (int*)(base + oM);
+    memcpy(H, kp1, sizeof(sslam_keypoint) * (size_t)n1);
+    if (n2) memcpy(H + kb, kp2, sizeof(sslam_keypoint) * (size_t)n2);
+    memcpy(H + 2 * kb, desc1, 32 * (size_t)n1);
+    if (n2) memcpy(H + 2 * kb + db, desc2, 32 * (size_t)n2);
+    memcpy(H + oPrev, prev_matched, 8 * (size_t)n1);
+    int hn[4] = {n1, n2, 0, 0};
+    memcpy(H + oN, hn, sizeof(hn));
+    SSLAM_HIP(hipMemcpyAsync(base, H, oM, hipMemcpyHostToDevice, st));
     if ((rc = sslam_orb_search_for_initialization_batch_dev(ctx, dk1, dd1, dn, dk2, dd2, dn + 1, cap, 1, dpm, dm12, dn + 2, window, nnratio, checkOri, bounds, st))) return rc;
-    SSLAM_HIP(hipMemcpyAsync(prev_matched, dpm, 8 * (size_t)n1, hipMemcpyDeviceToHost, st));
-    SSLAM_HIP(hipMemcpyAsync(matches12, dm12, 4 * (size_t)n1, hipMemcpyDeviceToHost, st));
-    SSLAM_HIP(hipMemcpyAsync(hn, dn, sizeof(hn), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(H + oPrev, base + oPrev, oM + 4 * (size_t)n1 - oPrev, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
+    memcpy(prev_matched, H + oPrev, 8 * (size_t)n1);
+    memcpy(matches12, H + oM, 4 * (size_t)n1);
+    memcpy(hn, H + oN, sizeof(hn));
     *nmatches_out = hn[2];
     return SSLAM_OK;
 }
@@ -197,9 +208,14 @@ static int search_proj_core(sslam_ctx* ctx, int kind, int mode, const void* d_fe
     int rc;
     if ((rc = ctx->scratch[6].ensure(total))) return rc;
     uint8_t* B = ctx->scratch[6].as<uint8_t>();
-    if (occupied) SSLAM_HIP(hipMemcpyAsync(B + oO, occupied, (size_t)n, hipMemcpyHostToDevice, st));
-    SSLAM_HIP(hipMemcpyAsync(B + oQ, queries, sizeof(sslam_proj_query) * (size_t)nq, hipMemcpyHostToDevice, st));
-    SSLAM_HIP(hipMemcpyAsync(B + oQD, qdesc, 32 * (size_t)nq, hipMemcpyHostToDevice, st));
+    // occupancy, queries and query descriptors sit back to back in B: one staged H2D through pinned memory (each pageable copy costs more
+    // host time than it moves data); the results (assigned, count) come back the same way
+    if ((rc = ctx->pinned[3].ensure(oN + 256))) return rc;
+    uint8_t* H = ctx->pinned[3].as<uint8_t>();
+    if (occupied) memcpy(H + oO, occupied, (size_t)n);
+    memcpy(H + oQ, queries, sizeof(sslam_proj_query) * (size_t)nq);
+    memcpy(H + oQD, qdesc, 32 * (size_t)nq);
+    SSLAM_HIP(hipMemcpyAsync(B + oO, H + oO, oA, hipMemcpyHostToDevice, st));
     ProjArgs A;
     A.kind = kind; A.mode = mode; A.feats = (const uint8_t*)d_feats; A.desc = d_desc; A.n = n;
     A.minX = bounds[0]; A.maxX = bounds[1]; A.minY = bounds[2]; A.maxY = bounds[3];
@@ -214,9 +230,10 @@ static int search_proj_core(sslam_ctx* ctx, int kind, int mode, const void* d_fe
         hipLaunchKernelGGL(k_search_proj_lds, dim3(1), dim3(PROJ_WAVES * 64), lds, st, A);
     } else { sslam::ProfScope _ps(ctx, "k_search_proj", st); hipLaunchKernelGGL(k_search_proj, dim3(1), dim3(64), 0, st, A); }
     SSLAM_HIP(hipGetLastError());
-    SSLAM_HIP(hipMemcpyAsync(assigned_out, B + oA, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-    SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + oN, sizeof(int), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(H + oA, B + oA, oN + 4 - oA, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
+    memcpy(assigned_out, H + oA, 4 * (size_t)n);
+    memcpy(nmatches_out, H + oN, sizeof(int));
     return SSLAM_OK;
 }
 

@@ -130,6 +130,138 @@ __global__ __launch_bounds__(64) void k_search_init(SfiArgs A) {
 }
 
 
+// Low-latency form for the single call (Tracking::MonocularInitialization hands over ONE frame pair and waits): the same sequential i1
+// loop, but everything an iteration touches lives in LDS -- the level-0 keypoints of F1 as a compact list, and per candidate of F2 its
+// position, GetFeaturesInArea order key, descriptor, matched distance and owner -- so a step is LDS reads plus one prefetched query
+// descriptor instead of a chain of dependent global loads (~1 us each with one wave on the chip).  Semantics identical to k_search_init:
+// candidates are compacted in ascending index, so (cell, slot) orders like (cell, index).
+// dynamic LDS: per candidate 14 words (x, y, key, index, matchedDist, owner, 8 descriptor words) + per F1 keypoint 2 words (level-0 list, bin)
+__global__ __launch_bounds__(64) void k_search_init_lds(SfiArgs A) {
+    extern __shared__ __align__(16) unsigned sfi[];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int n1 = A.n1 ? A.n1[p] : A.n1s, n2 = A.n2 ? A.n2[p] : A.n2s;
+    const sslam_keypoint* kp1 = A.kp1 + (size_t)p * A.cap;
+    const sslam_keypoint* kp2 = A.kp2 + (size_t)p * A.cap;
+    const uint8_t* d1 = A.d1 + (size_t)p * A.cap * 32;
+    const uint8_t* d2 = A.d2 + (size_t)p * A.cap * 32;
+    float* pm = A.prevMatched + (size_t)p * A.cap * 2;
+    int* m12 = A.m12 + (size_t)p * A.cap;
+    uint4* cdesc = (uint4*)sfi;                              // [2 * n2]
+    float* cxs = (float*)(cdesc + 2 * (size_t)n2);            // [n2]
+    float* cys = cxs + n2;
+    int* ckey = (int*)(cys + n2);
+    int* cj = ckey + n2;
+    int* md = cj + n2;                                       // matched distance per candidate slot
+    int* owner = md + n2;                                    // m21 per candidate slot
+    int* list1 = owner + n2;                                 // level-0 keypoints of F1, ascending  [n1]
+    int* binOf = list1 + n1;                                 // rotation bin per F1 keypoint, -1   [n1]
+    __shared__ int hist[HISTO_LENGTH];
+    const float invW = __fdiv_rn((float)GRID_COLS, __fsub_rn(A.maxX, A.minX));
+    const float invH = __fdiv_rn((float)GRID_ROWS, __fsub_rn(A.maxY, A.minY));
+    if (lane < HISTO_LENGTH) hist[lane] = 0;
+    int nl = 0;
+    for (int i0 = 0; i0 < n1; i0 += 64) {
+        const int i = i0 + lane;
+        const bool l0 = i < n1 && kp1[i].octave == 0;
+        if (i < n1) { m12[i] = -1; binOf[i] = -1; }
+        const unsigned long long m = __ballot(l0);
+        if (l0) list1[nl + mbcnt(m)] = i;
+        nl += __popcll(m);
+    }
+    int nc = 0;
+    for (int j0 = 0; j0 < n2; j0 += 64) {
+        const int j = j0 + lane;
+        bool ok = false; int cell = 0; float x = 0, y = 0;
+        if (j < n2) {
+            const sslam_keypoint k = kp2[j];
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, A.minX), invW));
+            const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, A.minY), invH));
+            ok = k.octave == 0 && px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS;
+            cell = px * GRID_ROWS + py; x = k.x; y = k.y;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (ok) {
+            const int o = nc + mbcnt(m);
+            cxs[o] = x; cys[o] = y; ckey[o] = (cell << 19) | o; cj[o] = j; md[o] = 0x7FFFFFFF; owner[o] = -1;
+            const uint4* tp = (const uint4*)(d2 + (size_t)j * 32);
+            cdesc[2 * o] = tp[0]; cdesc[2 * o + 1] = tp[1];
+        }
+        nc += __popcll(m);
+    }
+    __syncthreads();
+    int nmatches = 0;
+    const float r = (float)A.window;
+    uint4 q0n = make_uint4(0, 0, 0, 0), q1n = q0n; float cxn = 0, cyn = 0;
+    if (nl > 0) { const int i = list1[0]; q0n = ((const uint4*)(d1 + (size_t)i * 32))[0]; q1n = ((const uint4*)(d1 + (size_t)i * 32))[1]; cxn = pm[i * 2]; cyn = pm[i * 2 + 1]; }
+    for (int t = 0; t < nl; ++t) {
+        const int i1 = list1[t];
+        const uint4 q0 = q0n, q1 = q1n; const float cx = cxn, cy = cyn;
+        if (t + 1 < nl) { const int i = list1[t + 1]; q0n = ((const uint4*)(d1 + (size_t)i * 32))[0]; q1n = ((const uint4*)(d1 + (size_t)i * 32))[1]; cxn = pm[i * 2]; cyn = pm[i * 2 + 1]; }
+        unsigned long long b = ~0ull; unsigned s2 = 0x7FFFFFFFu;
+        for (int c = lane; c < nc; c += 64) {
+            const float dx = __fsub_rn(cxs[c], cx), dy = __fsub_rn(cys[c], cy);
+            if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+            const int dist = hamming256(q0, q1, cdesc[2 * c], cdesc[2 * c + 1]);
+            if (md[c] <= dist) continue;
+            const unsigned long long k = ((unsigned long long)dist << 32) | (unsigned)ckey[c];
+            if (k < b) { if (b != ~0ull) s2 = min(s2, (unsigned)(b >> 32)); b = k; }
+            else s2 = min(s2, (unsigned)dist);
+        }
+        const unsigned long long best = wave_min_u64(b);
+        if (best == ~0ull) continue;
+        unsigned other = (b == best) ? s2 : min(s2, (unsigned)(b >> 32));
+        if (b == ~0ull) other = 0x7FFFFFFFu;
+        const unsigned second = wave_min_u32(other);
+        const int bestDist = (int)(best >> 32);
+        const int slot = (int)(best & 0x7FFFF);
+        if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn((float)(int)second, A.nnratio)) {
+            const int bestIdx2 = cj[slot];
+            const int prev = owner[slot];
+            if (prev >= 0) { if (lane == 0) m12[prev] = -1; nmatches--; }
+            if (lane == 0) { m12[i1] = bestIdx2; owner[slot] = i1; md[slot] = bestDist; }
+            nmatches++;
+            if (A.checkOri) {
+                float rot = __fsub_rn(kp1[i1].angle, kp2[bestIdx2].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (lane == 0) { binOf[i1] = bin; hist[bin]++; }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (A.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;      // ComputeThreeMaxima
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            const int sh = hist[i];
+            if (sh > max1) { max3 = max2; max2 = max1; max1 = sh; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sh > max2) { max3 = max2; max2 = sh; ind3 = ind2; ind2 = i; }
+            else if (sh > max3) { max3 = sh; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+        int removed = 0;
+        for (int i0 = 0; i0 < n1; i0 += 64) {
+            const int i = i0 + lane;
+            bool rm = false;
+            if (i < n1) {
+                const int bn = binOf[i];
+                rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3 && m12[i] >= 0;
+                if (rm) m12[i] = -1;
+            }
+            removed += __popcll(__ballot(rm));
+        }
+        nmatches -= removed;
+    }
+    __syncthreads();
+    for (int i = lane; i < n1; i += 64) {
+        const int m = m12[i];
+        if (m >= 0) { pm[i * 2] = kp2[m].x; pm[i * 2 + 1] = kp2[m].y; }
+    }
+    if (lane == 0) A.nmatches[p] = nmatches;
+}
+
 // ---------------------------------------------------------------- projection-window matchers
 // ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)  src/ORBmatcher.cc:45-129   (kind 0, mode 0)
 // ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)  src/ORBmatcher.cc:1331-1473 (kind 0, mode 1)

@@ -4,7 +4,8 @@ import sys, time; sys.path.insert(0, 'tests')
 import numpy as np
 import pkg, oracle_lib
 from synth import synth_frame, warp_prev
-from test_match_gpu import _proj_queries, _pseudo_feature_vectors, _synthetic_vocab
+from test_match_gpu import _proj_queries, _pseudo_feature_vectors
+from synth import synthetic_vocab as _synthetic_vocab
 
 fe = pkg.frontend(); ctx = fe.Context(0); orc = oracle_lib.Oracle()
 rng = np.random.default_rng(1)
