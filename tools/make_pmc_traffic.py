@@ -17,7 +17,7 @@ def totals(path):
         c = sqlite3.connect(db)
         for name, cname, val in c.execute("select name, counter_name, counter_value from pmc_events"):
             short = name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-            short = short.split('<')[0] if short.startswith('k_lsd_regions') else short
+            short = short.split('<')[0]
             agg[short] = agg.get(short, 0.0) + val
     return agg
 
