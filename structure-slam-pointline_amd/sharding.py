@@ -73,12 +73,18 @@ class GroupGather:
         self.wait()
         s = self.k & 1; self.k += 1
         p, c = self.pipe, self.pipe.feat["cur"]
-        st = torch.cuda.current_stream().cuda_stream
         lines = p.with_lines
-        self.fe.pack_records_dev(self.ctx, p.B, self.rank, self.world, c["kp"], c["desc"], c["n"], p.cap,
-                                 c["kl"] if lines else None, c["ldesc"] if lines else None, c["linefn"] if lines else None, c["nl"] if lines else None, p.lcap,
-                                 self.send[s], self.cap_bytes, self.total[s], st)
-        ev = torch.cuda.Event(); ev.record()
+        # the pack runs on the pipeline's own (non-default) stream, ordered after this step's kernels of both branches and before the next
+        # step's (stream handle 0 would mean "the context's stream" in the C ABI, which is not ordered with the pipeline at all)
+        s1, _ = p._streams()
+        cur = torch.cuda.current_stream(p.dev)
+        s1.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            self.fe.pack_records_dev(self.ctx, p.B, self.rank, self.world, c["kp"], c["desc"], c["n"], p.cap,
+                                     c["kl"] if lines else None, c["ldesc"] if lines else None, c["linefn"] if lines else None, c["nl"] if lines else None, p.lcap,
+                                     self.send[s], self.cap_bytes, self.total[s], p._stream())
+            ev = torch.cuda.Event(); ev.record(s1)
+        cur.wait_stream(s1)
         self.last = s
 
         def run():
