@@ -115,32 +115,51 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
 #pragma unroll
     for (int i = 0; i < 4; ++i) sx[i] = (short)(tw[2 * i] & 0xFFFF);
     const int a = sx[0] & ~3;
-    int p00[4], p01[4], p10[4], p11[4];
-    if (sx[3] - a <= 10) {                          // pitch % 64 == 0 and the frame block has 16 spare bytes: the dwords are readable
+    unsigned out = 0;
+    const int b0 = ty.y, b1 = ty.z;
+    if (sx[3] - a <= 10 && sx[1] - sx[0] <= 2 && sx[3] - sx[2] <= 2) {      // pitch % 64 == 0 and the frame block has 16 spare bytes: the dwords are readable
+        // Two outputs at a time: their four source bytes per row lie inside one 8-byte window of the three loaded dwords (window start =
+        // dword 0 or 1), so ONE v_perm per row fetches [left_i, right_i, left_i+1, right_i+1]; a second v_perm widens a pair to 16-bit
+        // lanes for v_dot2_i32_i16 with the (a0, a1) coefficient pair taken from the table words with one v_alignbit.
         const unsigned* q0 = (const unsigned*)(g0 + a);
         const unsigned* q1 = (const unsigned*)(g1 + a);
         const unsigned u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
+        const int b0s = b0 << 16, b1s = b1 << 16;            // (b * x) >> 16 == mulhi(b << 16, x) for the 11-bit taps
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned e0 = pick2(u0, u1, u2, sx[i] - a), e1 = pick2(v0, v1, v2, sx[i] - a);
-            p00[i] = e0 & 255; p01[i] = (e0 >> 8) & 255; p10[i] = e1 & 255; p11[i] = (e1 >> 8) & 255;   // right tap has weight 0 at the last column
+        for (int pr = 0; pr < 2; ++pr) {
+            const int oA = sx[2 * pr] - a, oB = sx[2 * pr + 1] - a;
+            const bool hi = oA >= 4;
+            const int base = hi ? 4 : 0;
+            const unsigned w = (unsigned)(oA - base) | ((unsigned)(oB - base) << 16);
+            const unsigned sel = w * 0x0101u + 0x01000100u;                                  // bytes q, q+1 for both outputs
+            const unsigned r0 = __builtin_amdgcn_perm(hi ? u2 : u1, hi ? u1 : u0, sel);
+            const unsigned r1 = __builtin_amdgcn_perm(hi ? v2 : v1, hi ? v1 : v0, sel);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = 2 * pr + e;
+                const unsigned wsel = e == 0 ? 0x0c010c00u : 0x0c030c02u;                    // (byte, 0, byte + 1, 0): two zero-extended 16-bit lanes
+                const s16x2 p0 = as_s16x2(__builtin_amdgcn_perm(0u, r0, wsel)), p1 = as_s16x2(__builtin_amdgcn_perm(0u, r1, wsel));
+                const s16x2 cf = as_s16x2(__builtin_amdgcn_alignbit(tw[2 * i + 1], tw[2 * i], 16));      // (a0, a1)
+                const int h0 = __builtin_amdgcn_sdot2(p0, cf, 0, false), h1 = __builtin_amdgcn_sdot2(p1, cf, 0, false);
+                const int v = (__mulhi(b0s, h0 >> 4) + __mulhi(b1s, h1 >> 4) + 2) >> 2;
+                out |= (unsigned)(v & 255) << (8 * i);
+            }
         }
     } else {
+        int p00[4], p01[4], p10[4], p11[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int sx1 = min(sx[i] + 1, S.w - 1);
             p00[i] = g0[sx[i]]; p01[i] = g0[sx1]; p10[i] = g1[sx[i]]; p11[i] = g1[sx1];
         }
-    }
-    const int b0 = ty.y, b1 = ty.z;
-    unsigned out = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int a0 = (short)(tw[2 * i] >> 16), a1 = (short)(tw[2 * i + 1] & 0xFFFF);
-        const int r0 = p00[i] * a0 + p01[i] * a1;
-        const int r1 = p10[i] * a0 + p11[i] * a1;
-        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        out |= (unsigned)(v & 255) << (8 * i);
+        for (int i = 0; i < 4; ++i) {
+            const int a0 = (short)(tw[2 * i] >> 16), a1 = (short)(tw[2 * i + 1] & 0xFFFF);
+            const int r0 = p00[i] * a0 + p01[i] * a1;
+            const int r1 = p10[i] * a0 + p11[i] * a1;
+            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            out |= (unsigned)(v & 255) << (8 * i);
+        }
     }
     *(unsigned*)(pyr + (size_t)b * pyrFrame + D.off + (size_t)y * D.pitch + x4) = out;   // pitch%64==0, pad columns are scratch
 }
