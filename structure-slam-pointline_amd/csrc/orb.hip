@@ -270,14 +270,19 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                 unsigned res = 0;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {                      // h = 0: bytes 0,2   h = 1: bytes 1,3
-                    const unsigned sh = 8 * h;
-                    const s16x2 v = as_s16x2((c1 >> sh) & 0x00FF00FFu);
-                    const s16x2 dn = as_s16x2((n4 >> sh) & 0x00FF00FFu) - v, ds = as_s16x2((s4 >> sh) & 0x00FF00FFu) - v;
-                    const s16x2 de = as_s16x2((e4 >> sh) & 0x00FF00FFu) - v, dw = as_s16x2((w4 >> sh) & 0x00FF00FFu) - v;
-                    // sign(th - d) <=> d > th (brighter), sign(th + d) <=> d < -th (darker)
-                    const unsigned bV = as_u32(th2 - dn) | as_u32(th2 - ds), bH = as_u32(th2 - de) | as_u32(th2 - dw);
-                    const unsigned dV = as_u32(th2 + dn) | as_u32(th2 + ds), dH = as_u32(th2 + de) | as_u32(th2 + dw);
-                    const unsigned m = ((bV & bH) | (dV & dH)) & 0x80008000u;
+                    // bytes h and h + 2 of a dword as two zero-extended 16-bit lanes: one v_perm each
+                    const unsigned wsel = h == 0 ? 0x0c020c00u : 0x0c030c01u;
+                    const s16x2 v = as_s16x2(__builtin_amdgcn_perm(0u, c1, wsel));
+                    const s16x2 rn = as_s16x2(__builtin_amdgcn_perm(0u, n4, wsel)), rs = as_s16x2(__builtin_amdgcn_perm(0u, s4, wsel));
+                    const s16x2 re = as_s16x2(__builtin_amdgcn_perm(0u, e4, wsel)), rw = as_s16x2(__builtin_amdgcn_perm(0u, w4, wsel));
+                    // (N or S brighter than v + t) == max(N, S) > v + t, (N or S darker) == min(N, S) < v - t: packed max / min, then one
+                    // packed subtraction per test whose sign bit is the answer
+                    const s16x2 vp = v + th2, vm = v - th2;
+                    const s16x2 mxV = __builtin_elementwise_max(rn, rs), mnV = __builtin_elementwise_min(rn, rs);
+                    const s16x2 mxH = __builtin_elementwise_max(re, rw), mnH = __builtin_elementwise_min(re, rw);
+                    const unsigned bright = as_u32(vp - mxV) & as_u32(vp - mxH);      // sign set <=> max > v + t on both axes
+                    const unsigned dark = as_u32(mnV - vm) & as_u32(mnH - vm);        // sign set <=> min < v - t on both axes
+                    const unsigned m = (bright | dark) & 0x80008000u;
                     res |= m >> (15 - h);                          // bit 0+h from byte h, bit 16+h from byte 2+h
                 }
                 // res bits: 0 -> byte 0, 1 -> byte 1, 16 -> byte 2, 17 -> byte 3
