@@ -193,19 +193,22 @@ __device__ __forceinline__ int fast_score16(const uint8_t* c, int tp, int minTh)
         const bool on = pass == 0 ? true : (cb && cd);
         if (__builtin_amdgcn_ballot_w64(on) == 0) break;
         const bool dark = pass == 0 ? cd : false;               // pass 0: darker ring if that test passed, else brighter; pass 1: the brighter one
+        // d = signed contrast in the chosen polarity; the minimum over a 9-arc is a min3 of three min3's (v_min3_i32), the maximum over the
+        // sixteen arcs a max3 tree: 40 instructions instead of the 80 of a doubling network
+        const int sg = dark ? -1 : 1;
         int d[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = dark ? v - r[k] : r[k] - v;
-        int mn2[16], mn4[16], mn8[16];
+        for (int k = 0; k < 16; ++k) d[k] = (r[k] - v) * sg;
+        int m3[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) mn2[k] = min(d[k], d[(k + 1) & 15]);
+        for (int k = 0; k < 16; ++k) m3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        int m9[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) mn4[k] = min(mn2[k], mn2[(k + 2) & 15]);
+        for (int k = 0; k < 16; ++k) m9[k] = min(min(m3[k], m3[(k + 3) & 15]), m3[(k + 6) & 15]);
+        int A = max(max(m9[0], m9[1]), m9[2]);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) mn8[k] = min(mn4[k], mn4[(k + 4) & 15]);
-        int A = -1000;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) A = max(A, min(mn8[k], d[(k + 8) & 15]));
+        for (int k = 3; k < 15; k += 2) A = max(max(A, m9[k]), m9[k + 1]);
+        A = max(A, m9[15]);
         if (on) best = max(best, A);
     }
     int s = best - 1;
