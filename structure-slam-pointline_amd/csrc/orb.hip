@@ -195,10 +195,12 @@ __device__ __forceinline__ int fast_score16(const uint8_t* c, int tp, int minTh)
         const bool dark = pass == 0 ? cd : false;               // pass 0: darker ring if that test passed, else brighter; pass 1: the brighter one
         // d = signed contrast in the chosen polarity; the minimum over a 9-arc is a min3 of three min3's (v_min3_i32), the maximum over the
         // sixteen arcs a max3 tree: 40 instructions instead of the 80 of a doubling network
-        const int sg = dark ? -1 : 1;
+        // brighter ring: d = r - v.  Darker ring: ~(r - v) = (v - r) - 1 -- a bitwise NOT reverses the order like a negation does, costs one
+        // xor per element instead of a negate + select, and the constant 1 comes back after the network
+        const int sg = dark ? -1 : 0;
         int d[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = (r[k] - v) * sg;
+        for (int k = 0; k < 16; ++k) d[k] = (r[k] - v) ^ sg;
         int m3[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) m3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
@@ -209,7 +211,7 @@ __device__ __forceinline__ int fast_score16(const uint8_t* c, int tp, int minTh)
 #pragma unroll
         for (int k = 3; k < 15; k += 2) A = max(max(A, m9[k]), m9[k + 1]);
         A = max(A, m9[15]);
-        if (on) best = max(best, A);
+        if (on) best = max(best, A - sg);      // + 1 for the darker polarity (see above)
     }
     int s = best - 1;
     return s >= minTh ? s : 0;
