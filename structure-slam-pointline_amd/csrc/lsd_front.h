@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
     float4* pix = (float4*)(base + P.offPix);
     Misc* misc = (Misc*)(base + P.offMisc);
     const int y = blockIdx.y * 4 + threadIdx.y, x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    __shared__ float4 trs[4][4 * 66];
     int smax = 0;
     if (y < P.sh && x4 < P.sw) {
         const bool lastRow = y >= P.sh - 1;
@@ -179,8 +180,24 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) { ang[i + j] = rec[j].x; S[i + j] = sv[j]; }
         }
+        if ((P.sw & 255) == 0) {
+            // the 16-byte records of a lane's four pixels are 64 bytes apart from the next lane's: stored directly, every store instruction
+            // would be 64 partial (16 of 64 bytes) L2 writes.  Transposed through LDS (the wave's own 4 KB, in-order DS, no workgroup
+            // barrier) each instruction writes 1 KB contiguous.  Row pitch 66 records: conflict-free for both the writes and the reads.
+            float4* t = trs[threadIdx.y];
+            const int lane = threadIdx.x;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) pix[i + j] = rec[j];      // per-pixel record for region growing: angle, cosf/sinf (D5), |g|^2
+            for (int j = 0; j < 4; ++j) t[j * 66 + lane] = rec[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            float4* row = pix + (size_t)y * P.sw + blockIdx.x * 256;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) row[k * 64 + lane] = t[(lane & 3) * 66 + k * 16 + (lane >> 2)];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) pix[i + j] = rec[j];      // per-pixel record for region growing: angle, cosf/sinf (D5), |g|^2
+        }
     }
     smax = wave_max(smax);
     if (threadIdx.x == 0 && smax > 0) atomicMax(&misc->maxS, smax);
