@@ -100,9 +100,11 @@ __global__ void k_selftest_region_div(unsigned long long seed, int iters, unsign
 #ifndef SSLAM_LSD_DRIFT
 #define SSLAM_LSD_DRIFT 1
 #endif
-template <bool LAT, bool WIDE>
+// SPEC (multi-wave form, lsd_regions_mw.h): a helper wave grows a region AHEAD of the frame's main wave.  It never writes the pixel map: the
+// pixels it takes are marked in its own bitmap `bm` (LDS), and it gives up (returns -n) when the list would outgrow `capN` points.
+template <bool LAT, bool WIDE, bool SPEC = false>
 __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos, float seedSin, int sw, int sh, float4* __restrict__ pix, const RegQ& rq,
-                             double prec, double& regAngleOut, long long* __restrict__ verifyCnt) {
+                             double prec, double& regAngleOut, long long* __restrict__ verifyCnt, unsigned* __restrict__ bm = nullptr, int capN = 0) {
 #ifndef SSLAM_LSD_READLANE
 #define SSLAM_LSD_READLANE 0
 #endif
@@ -113,7 +115,10 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
     int n = 1;
     double regAngle = (double)seedDeg * DEG2RAD;          // the seed's level-line angle, cos / sin: evaluated lane-parallel for a whole chunk of seed candidates (k_lsd_regions)
     float sumdx = seedCos, sumdy = seedSin;
-    if (lane == 0) { rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16)); pix[seed].x = USED_F; }
+    if (lane == 0) {
+        rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16));
+        if (SPEC) atomicOr(&bm[seed >> 5], 1u << (seed & 31)); else pix[seed].x = USED_F;
+    }
     const int g = lane >> 3, k8 = lane & 7;             // group (queue slot) and neighbour slot (centre skipped)
     const int k = k8 + (k8 >= 4 ? 1 : 0);                // row-major 3x3 position 0..8 without 4
     const int dy = k / 3 - 1, dx = k - (k / 3) * 3 - 1;
@@ -129,6 +134,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
     long long* cycStage = verifyCnt - 1;      // Misc::cyc[5..]: staging wait, accept loops, stagings (the NFA statistics of SSLAM_LSD_STATS use the same slots)
 #endif
     while (i < n) {
+        if (SPEC && n + 64 > capN) return -n;
         const int np = min(8, n - i);
         // Lone wave: straight-line staging -- every lane loads (slots past the staged entries re-read the last entry, coordinates are
         // clamped into the image) and the three conditions (slot staged, neighbour inside the image, pixel neither NOTDEF nor USED) meet as
@@ -146,6 +152,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
             px4 = pix[nidx];                             // .x < 0: NOTDEF or already USED
             candM = __builtin_amdgcn_ballot_w64(px4.x >= 0.f) & __builtin_amdgcn_ballot_w64((unsigned)xx < (unsigned)sw) &
                     __builtin_amdgcn_ballot_w64((unsigned)yy < (unsigned)sh) & (np == 8 ? ~0ull : ((1ull << (np * 8)) - 1));
+            if (SPEC) candM &= ~__builtin_amdgcn_ballot_w64((bm[nidx >> 5] >> (nidx & 31)) & 1u);      // taken by this helper itself
         } else {
             bool cand = false;
             if (g < np) {
@@ -247,7 +254,10 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
                 live = candM & (~1ull << sel);                              // only lanes above sel
             }
         }
-        if (LAT && accMask != 0 && ((accMask >> lane) & 1ull)) { pix[nidx].x = USED_F; rq.set(nBefore + mbcnt(accMask), (unsigned)xx | ((unsigned)yy << 16)); }
+        if (LAT && accMask != 0 && ((accMask >> lane) & 1ull)) {
+            if (SPEC) atomicOr(&bm[nidx >> 5], 1u << (nidx & 31)); else pix[nidx].x = USED_F;
+            rq.set(nBefore + mbcnt(accMask), (unsigned)xx | ((unsigned)yy << 16));
+        }
 #ifdef SSLAM_LSD_CYCLES
         if (verifyCnt) { const long long tS2 = __builtin_readcyclecounter(); cycStage[0] += tS1 - tS0; cycStage[1] += tS2 - tS1; cycStage[2] += 1; }
 #endif
@@ -397,14 +407,63 @@ __device__ __forceinline__ double dist_d(double x1, double y1, double x2, double
     return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1));
 }
 
+// ------------------------------------------------------------------ multi-wave form (one frame at a time): shared state
+// A frame that has a CU to itself gets one MAIN wave, which replays flsd() in seed order exactly like the single-wave kernel, and up to
+// MW_HMAX HELPER waves that run region_grow AHEAD of it -- 68 % of the lone wave's time.  Only the main wave ever writes the pixel map.
+//   * helpers claim chunks of 64 order positions (CAS on MwCtl::cursor) and grow the unused seeds of their chunk, EACH ON ITS OWN, on a
+//     READ-ONLY view of the pixel map (plus a private bitmap of the pixels of the region being grown).  Per seed they publish the point list
+//     (LDS arena), its length, the final region angle, the bounding box and the un-mark sequence number sampled before the first pixel was read;
+//   * the main wave, at a seed whose chunk a helper owns, takes the helper's region instead of growing it when the region is what its own
+//     growth would produce NOW:
+//       (b) every point of the region is unused now (one parallel gather; region_grow's dependency chain is gone);
+//       (c) no pixel the helper can have seen as USED has been released since: pixels are released only by refine(), each refine logs the
+//           bounding box of everything it touched with a new sequence number AFTER its last store, and a region whose box (grown by one
+//           pixel: the tested neighbourhood) meets a box logged after the region's sample is not taken.
+//     A pixel the helper saw unused and rejected by angle stays rejected whatever its state is now; a pixel it saw used and that is still
+//     used blocks growth the same way; so (b) and (c) make the helper's list, in its order, the list the sequential growth yields -- and the
+//     region angle with it, since it is a function of the list.  Anything else falls back to the main wave's own region_grow.
+//   * regions published but not yet taken are recorded in a coarse shared map (2 x 2 pixel cells) that only steers the helpers' choice of
+//     seeds -- a seed inside somebody's speculative region will most likely be taken by then -- and never enters a region's growth.
+// Stale or torn views only ever cost a fallback: the checks read the main wave's own stores.
+constexpr int MW_HMAX = 4;          // helper waves (LDS: one bitmap of the scaled frame each)
+constexpr int MW_ARENA = 2048;      // region points a helper can publish per chunk
+constexpr int MW_RES = 24;          // regions a helper can publish per chunk
+constexpr int MW_EV = 16;           // refine events kept
+struct MwRes { int lane, n, off, startSeq, lo, hi, angLo, angHi; };       // lo = x0 | y0 << 16, hi = x1 | y1 << 16
+struct MwSlot { int chunkPos, nres, doneLane, abortPos; MwRes res[MW_RES]; };
+struct MwCtl { int cursor, finished, unmarkSeq, mainPos; int evLo[MW_EV], evHi[MW_EV]; };
+struct MwShared { MwCtl* ctl; MwSlot* slots; unsigned* arena; unsigned* specMap; int specW; int nHelpers; };
+__device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lds_cas_uniform(int* p, int expect, int want, int lane) {      // one CAS per wave, result broadcast
+    int got = expect;
+    if (lane == 0) got = atomicCAS(p, expect, want);
+    return __builtin_amdgcn_readfirstlane(got);
+}
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) { typedef unsigned short u16x2 __attribute__((ext_vector_type(2))); return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) { typedef unsigned short u16x2 __attribute__((ext_vector_type(2))); return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+// bounding box of a point list (entries x | y << 16 are already packed u16 pairs)
+__device__ __forceinline__ void list_bbox(const unsigned* __restrict__ lst, int n, int lane, unsigned& lo, unsigned& hi) {
+    unsigned mn = 0xFFFFFFFFu, mx = 0u;
+    for (int i = lane; i < n; i += 64) { const unsigned e = lst[i]; mn = pk_min_u16(mn, e); mx = pk_max_u16(mx, e); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = pk_min_u16(mn, (unsigned)__shfl_xor((int)mn, o, 64)); mx = pk_max_u16(mx, (unsigned)__shfl_xor((int)mx, o, 64)); }
+    lo = mn; hi = mx;
+}
+__device__ __forceinline__ bool boxes_meet(unsigned lo, unsigned hi, unsigned elo, unsigned ehi, int grow) {
+    const int x0 = (int)(lo & 0xFFFF) - grow, y0 = (int)(lo >> 16) - grow, x1 = (int)(hi & 0xFFFF) + grow, y1 = (int)(hi >> 16) + grow;
+    const int ex0 = elo & 0xFFFF, ey0 = elo >> 16, ex1 = ehi & 0xFFFF, ey1 = ehi >> 16;
+    return !(x1 < ex0 || ex1 < x0 || y1 < ey0 || ey1 < y0);
+}
+
 // One persistent single-wave workgroup per frame: the flsd() main loop replayed in order.
 #ifndef SSLAM_LSD_MINWAVES
 #define SSLAM_LSD_MINWAVES 6          // waves/SIMD the register allocator must leave room for (6 x 4 SIMDs = 24 frames per CU, LDS allows 32)
 #endif
-template <bool LAT>
-__global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
-    extern __shared__ __align__(16) unsigned dynLds[];           // region queue (first QCAP points)
-    const int b = xcd_mix_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
+template <bool LAT, bool MW>
+__device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsigned* __restrict__ dynLds, double* __restrict__ red, float4* __restrict__ seedStash,
+                                                 const MwShared& mw) {
+    const int lane = threadIdx.x & 63;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     const float* ang = (const float*)(base + P.offAng);
     float4* pix = (float4*)(base + P.offPix);
@@ -413,10 +472,15 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
     Misc* misc = (Misc*)(base + P.offMisc);
     const int sw = P.sw, sh = P.sh;
     RegQ rq; rq.lds = dynLds; rq.glb = (unsigned*)(base + P.offReg);
-    __shared__ double red[3 * 64];                                 // addends of the ordered fp64 sums
-    __shared__ float4 seedStash[64];                               // per seed candidate of the current chunk: angle, cos, sin, x | y << 16
-    __syncthreads();
     const int nOrd = misc->nDefined;
+    int unmarkSeq = 0;                                             // MW: refine events logged so far (the main wave is the only writer)
+    long long mwTaken = 0, mwOwn = 0, mwBadChunks = 0;             // MW statistics (Misc::cyc[5..7])
+#ifdef SSLAM_MW_STATS
+    long long mwCause[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // why the main wave grew a region itself (count | points << 32): tools/mw_debug.py
+#define SSLAM_MW_CAUSE(c) cause = (c)
+#else
+#define SSLAM_MW_CAUSE(c)
+#endif
     const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
     int nSeg = 0;
     // stage clocks for tools/lsd_cycles.py: compiled in with -DSSLAM_LSD_CYCLES only (an s_memtime + wait per read sits on the one wave's path)
@@ -428,6 +492,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
     long long cyc0 = 0, cyc1 = 0, cyc2 = 0, cyc3 = 0;
     const long long tStart = SSLAM_CLK();
     for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
+        if (MW) lds_st(&mw.ctl->mainPos, pos0);                   // every chunk below pos0 is finished: its helper may move on
         const int q = pos0 + lane;
         const int idx = q < nOrd ? (int)order[q] : -1;
         // One gather per chunk of 64 seed candidates: pix.x is the candidate's level-line angle while it is unused.  What a region start
@@ -441,6 +506,19 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
             const double ar = (double)a0 * DEG2RAD;
             seedStash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
         }
+        // MW: whose chunk is this?  Below the cursor: a helper claimed it; otherwise the main wave takes it (and everything the cursor skipped)
+        int owner = -1, rp = 0;
+        if (MW) {
+            for (;;) {
+                const int c = lds_ld(&mw.ctl->cursor);
+                if (c > pos0) { owner = -2; break; }
+                if (lds_cas_uniform(&mw.ctl->cursor, c, pos0 + 64, lane) == c) break;
+            }
+            while (owner == -2) {                             // the claimant publishes its slot right after the CAS
+                for (int h = 0; h < mw.nHelpers; ++h) if (lds_ld(&mw.slots[h].chunkPos) == pos0) owner = h;
+                if (owner == -2) __builtin_amdgcn_s_sleep(1);
+            }
+        }
         while (unM) {
             const int first = __ffsll((long long)unM) - 1;
             unM &= unM - 1;                                   // the seed itself is consumed whatever happens
@@ -448,7 +526,49 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
             const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
             double regAngle;
             long long t0 = SSLAM_CLK();
-            int n = region_grow_m<LAT>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, prec, regAngle, &misc->cyc[6]);
+            int n = -1;
+#ifdef SSLAM_MW_STATS
+            int cause = 7;                                      // 7: the main wave's own chunk
+#endif
+            if (MW && owner >= 0) {
+                MwSlot* S = &mw.slots[owner];
+                while (lds_ld(&S->doneLane) <= first) __builtin_amdgcn_s_sleep(1);
+                const int nres = lds_ld(&S->nres);
+                while (rp < nres && S->res[rp].lane < first) ++rp;                 // regions grown from seeds that were taken by the time their turn came
+                SSLAM_MW_CAUSE(1);
+                if (rp < nres && S->res[rp].lane == first) {
+                    const MwRes r = S->res[rp]; ++rp;
+                    const unsigned* lst = mw.arena + (size_t)owner * MW_ARENA + r.off;
+                    bool ok = r.n > 0 && unmarkSeq - r.startSeq <= MW_EV;
+                    if (!ok) SSLAM_MW_CAUSE(r.n > 0 ? 4 : 5);
+                    for (int sq = r.startSeq + 1; ok && sq <= unmarkSeq; ++sq) {
+                        ok = !boxes_meet((unsigned)r.lo, (unsigned)r.hi, (unsigned)mw.ctl->evLo[sq & (MW_EV - 1)], (unsigned)mw.ctl->evHi[sq & (MW_EV - 1)], 1);
+                        if (!ok) SSLAM_MW_CAUSE(4);
+                    }
+                    for (int bs = 0; ok && bs < r.n; bs += 64) {
+                        const int i = bs + lane;
+                        bool usedNow = false;
+                        if (i < r.n) { const unsigned e = lst[i]; usedNow = pix[(int)(e >> 16) * sw + (int)(e & 0xFFFF)].x < 0.f; }
+                        ok = __ballot(usedNow) == 0;
+                        if (!ok) SSLAM_MW_CAUSE(3);
+                    }
+                    if (ok) {
+                        for (int bs = 0; bs < r.n; bs += 64) {
+                            const int i = bs + lane;
+                            if (i < r.n) { const unsigned e = lst[i]; pix[(int)(e >> 16) * sw + (int)(e & 0xFFFF)].x = USED_F; rq.lds[i] = e; }
+                        }
+                        n = r.n; regAngle = __hiloint2double(r.angHi, r.angLo);
+                        mwTaken += 1 + ((long long)n << 32);
+                    }
+                }
+            }
+            if (n < 0) {
+                n = region_grow_m<LAT>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, prec, regAngle, &misc->cyc[6]);
+                mwOwn += 1 + ((long long)n << 32);
+#ifdef SSLAM_MW_STATS
+                mwCause[cause] += 1 + ((long long)n << 32);
+#endif
+            }
             long long t1 = SSLAM_CLK(); cyc0 += t1 - t0;
             if (n < P.minRegSize) {
                 // too small: rejected, its pixels stay used.  Which candidates of this chunk did it take?  Compare them with the (few) points of
@@ -462,12 +582,17 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
             RectD rec;
             bool emit = false;
             long long t2 = t1;
+            bool refined = false; unsigned evLo = 0xFFFFFFFFu, evHi = 0u;      // MW: everything refine() may have released lies inside this box
             do {
             region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
             t2 = SSLAM_CLK(); cyc1 += t2 - t1;
             // ---- refine (LSD_REFINE_STD part)
             double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
             if (density < DENSITY_TH) {
+                if (MW) {
+                    refined = true;
+                    if (n <= QCAP) list_bbox(rq.lds, n, lane, evLo, evHi); else { evLo = 0u; evHi = 0xFFFFFFFFu; }
+                }
                 const unsigned e0 = rq.get(0);
                 const int x0 = e0 & 0xFFFF, y0 = e0 >> 16;
                 const double xc = (double)x0, yc = (double)y0;
@@ -492,6 +617,10 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
                 const double mean_angle = sum / (double)cnt;
                 const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
                 n = region_grow_m<LAT>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pix, rq, tau, regAngle, &misc->cyc[6]);
+                if (MW) {                                     // the re-grown region can reach outside the first one, and reduce_region_radius releases from it
+                    unsigned l2, h2;
+                    if (n <= QCAP) { list_bbox(rq.lds, n, lane, l2, h2); evLo = pk_min_u16(evLo, l2); evHi = pk_max_u16(evHi, h2); } else { evLo = 0u; evHi = 0xFFFFFFFFu; }
+                }
                 if (n < 2) break;
                 region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
                 density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
@@ -527,6 +656,12 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
             }
             emit = true;
             } while (false);
+            if (MW && refined) {                              // log the event once the last store of this refine has left
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                ++unmarkSeq;
+                if (lane == 0) { mw.ctl->evLo[unmarkSeq & (MW_EV - 1)] = (int)evLo; mw.ctl->evHi[unmarkSeq & (MW_EV - 1)] = (int)evHi; }
+                lds_st(&mw.ctl->unmarkSeq, unmarkSeq);
+            }
             // ---- hand the rectangle to the NFA stage (rect_improve reads only the static angle map and never touches
             // `used`, so it is not part of the sequential dependency chain: k_lsd_nfa evaluates all candidates in parallel)
             long long t3 = SSLAM_CLK(); cyc2 += t3 - t2;
@@ -542,8 +677,124 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
             ++nSeg;
         }
     }
+    if (MW) lds_st(&mw.ctl->finished, 1);
     if (lane == 0) {
         misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
         misc->cyc[0] = cyc0; misc->cyc[1] = cyc1; misc->cyc[2] = cyc2; misc->cyc[3] = cyc3; misc->cyc[4] = SSLAM_CLK() - tStart;
+        if (MW) { misc->cyc[5] = mwTaken; misc->cyc[6] = mwOwn; misc->cyc[7] = mwBadChunks; }
+#ifdef SSLAM_MW_STATS
+        if (MW) { misc->cyc[0] = mwTaken; for (int c = 1; c < 8; ++c) misc->cyc[c] = mwCause[c]; }
+#endif
     }
+}
+
+template <bool LAT>
+__global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
+    extern __shared__ __align__(16) unsigned dynLds[];           // region queue (first QCAP points)
+    __shared__ double red[3 * 64];                                 // addends of the ordered fp64 sums
+    __shared__ float4 seedStash[64];                               // per seed candidate of the current chunk: angle, cos, sin, x | y << 16
+    __syncthreads();
+    lsd_regions_body<LAT, false>(ws, P, xcd_mix_frame(blockIdx.x, gridDim.x), dynLds, red, seedStash, MwShared{});
+}
+
+// ------------------------------------------------------------------ multi-wave form: the helper wave and the kernel
+// One helper: claim a chunk, grow its unused seeds in order on the read-only view + own bitmap, publish, wait until the main wave has passed.
+__device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int b, const MwShared& mw, unsigned* __restrict__ bm, int bmWords, float4* __restrict__ stash) {
+    const int lane = threadIdx.x & 63;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    float4* pix = (float4*)(base + P.offPix);
+    const unsigned* order = (const unsigned*)(base + P.offOrder);
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int sw = P.sw, sh = P.sh, nOrd = misc->nDefined;
+    MwCtl* ctl = mw.ctl; MwSlot* S = &mw.slots[h];
+    unsigned* arena = mw.arena + (size_t)h * MW_ARENA;
+    for (int i = lane; i < bmWords; i += 64) bm[i] = 0u;
+    for (;;) {
+        // ---- claim the next chunk nobody has
+        int c;
+        for (;;) {
+            if (lds_ld(&ctl->finished)) return;
+            c = lds_ld(&ctl->cursor);
+            const int mp = lds_ld(&ctl->mainPos);
+            if (c >= nOrd) return;
+            if (c < mp) { lds_cas_uniform(&ctl->cursor, c, mp, lane); continue; }      // the main wave is already past it
+            if (lds_cas_uniform(&ctl->cursor, c, c + 64, lane) == c) break;
+        }
+        if (lane == 0) { S->nres = 0; S->doneLane = 0; }
+        lds_st(&S->chunkPos, c);
+        // ---- the chunk's seed candidates as this wave sees them now
+        const int q = c + lane;
+        const int idx = q < nOrd ? (int)order[q] : -1;
+        const float a0 = idx >= 0 ? pix[idx].x : -1.f;
+        const int cy = max(idx, 0) / sw, cx = max(idx, 0) - cy * sw;
+        const int cell = (cy >> 1) * mw.specW + (cx >> 1);
+        unsigned long long unM = __ballot(a0 >= 0.f && !((mw.specMap[cell >> 5] >> (cell & 31)) & 1u));
+        if (unM) {
+            const double ar = (double)a0 * DEG2RAD;
+            stash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
+        }
+        int off = 0, k = 0;
+        while (unM) {
+            if (lds_ld(&ctl->mainPos) > c || lds_ld(&S->abortPos) == c || lds_ld(&ctl->finished)) break;
+            const int first = __ffsll((long long)unM) - 1;
+            unM &= unM - 1;
+            const float4 sd = stash[first];
+            const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
+            const int startSeq = lds_ld(&ctl->unmarkSeq);      // sampled BEFORE the first pixel of this region is read
+            if (pix[sy * sw + sx].x < 0.f) continue;           // taken since the chunk was scanned (a region in front of it, committed meanwhile)
+            { const int sc = (sy >> 1) * mw.specW + (sx >> 1); if ((mw.specMap[sc >> 5] >> (sc & 31)) & 1u) continue; }      // ... or about to be
+            RegQ rq; rq.lds = arena + off; rq.glb = nullptr;
+            const int capN = min(QCAP, MW_ARENA - off);
+            double regAngle = 0;
+            if (k >= MW_RES || capN <= 64) break;                // no room left: the main wave grows the rest of the chunk itself
+            int n = region_grow_w<true, false, true>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, P.prec, regAngle, nullptr, bm, capN);
+            if (n < 0) {                                        // too long for a helper: release its marks, the main wave grows this one
+                for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int id = (int)(e >> 16) * sw + (int)(e & 0xFFFF); atomicAnd(&bm[id >> 5], ~(1u << (id & 31))); }
+                continue;
+            }
+            unsigned lo, hi;
+            list_bbox(rq.lds, n, lane, lo, hi);
+            if (lane == 0) {
+                MwRes& r = S->res[k];
+                r.lane = first; r.n = n; r.off = off; r.startSeq = startSeq; r.lo = (int)lo; r.hi = (int)hi;
+                r.angLo = __double2loint(regAngle); r.angHi = __double2hiint(regAngle);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            ++k; off += n;
+            lds_st(&S->nres, k);
+            lds_st(&S->doneLane, first + 1);
+            // candidates of this chunk that the region took; then the private marks go (the next region is grown on its own) and the region
+            // enters the shared map that steers seed choice
+            if (n > 1) unM &= ~__ballot(idx >= 0 && ((bm[max(idx, 0) >> 5] >> (max(idx, 0) & 31)) & 1u));
+            for (int i = lane; i < n; i += 64) {
+                const unsigned e = rq.lds[i]; const int px = e & 0xFFFF, py = e >> 16, id = py * sw + px, cl = (py >> 1) * mw.specW + (px >> 1);
+                atomicAnd(&bm[id >> 5], ~(1u << (id & 31)));
+                atomicOr(&mw.specMap[cl >> 5], 1u << (cl & 31));
+            }
+        }
+        lds_st(&S->doneLane, 64);
+        while (lds_ld(&ctl->mainPos) <= c && !lds_ld(&ctl->finished)) __builtin_amdgcn_s_sleep(2);
+        // ---- the main wave is past the chunk: its regions leave the shared map
+        for (int i = lane; i < off; i += 64) { const unsigned e = arena[i]; const int cl = (int)(e >> 17) * mw.specW + (int)((e & 0xFFFF) >> 1); atomicAnd(&mw.specMap[cl >> 5], ~(1u << (cl & 31))); }
+    }
+}
+
+// dynamic LDS: [main queue QCAP + 4][arena nHelpers x MW_ARENA][bitmaps nHelpers x bmWords][shared coarse map specWords]
+__global__ __launch_bounds__(64 * (1 + MW_HMAX)) void k_lsd_regions_mw(uint8_t* __restrict__ ws, LsdPlan P, int nHelpers, int bmWords, int specWords) {
+    extern __shared__ __align__(16) unsigned dynLds[];
+    __shared__ double red[3 * 64];
+    __shared__ float4 seedStash[64];
+    __shared__ float4 helperStash[MW_HMAX][64];
+    __shared__ MwCtl ctl;
+    __shared__ MwSlot slots[MW_HMAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; }
+    if (threadIdx.x < MW_HMAX) { slots[threadIdx.x].chunkPos = -1; slots[threadIdx.x].nres = 0; slots[threadIdx.x].doneLane = 0; slots[threadIdx.x].abortPos = -1; }
+    MwShared mw; mw.ctl = &ctl; mw.slots = slots; mw.arena = dynLds + QCAP + 4; mw.nHelpers = nHelpers;
+    mw.specMap = mw.arena + (size_t)nHelpers * (MW_ARENA + bmWords); mw.specW = (P.sw + 1) >> 1;
+    for (int i = threadIdx.x; i < specWords; i += blockDim.x) mw.specMap[i] = 0u;
+    __syncthreads();
+    const int b = blockIdx.x;
+    if (wave == 0) lsd_regions_body<true, true>(ws, P, b, dynLds, red, seedStash, mw);
+    else if (wave <= nHelpers) mw_helper(wave - 1, ws, P, b, mw, dynLds + QCAP + 4 + (size_t)nHelpers * MW_ARENA + (size_t)(wave - 1) * bmWords, bmWords, helperStash[wave - 1]);
 }
