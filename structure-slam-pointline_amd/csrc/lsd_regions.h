@@ -15,6 +15,10 @@ struct RegQ {
     }
     __device__ __forceinline__ void set(int i, unsigned v) const { if (i < QCAP) lds[i] = v; else glb[i] = v; }
 };
+// multi-wave form (below): a helper's private marks: a 256 x 256 bit TORUS (8 KB of LDS whatever the frame size).  A region that stays within +-126 pixels of its seed
+// (tested neighbours: +-127) cannot alias on it; a helper abandons a region that reaches further and the main wave grows that one itself.
+constexpr int MW_BM_WORDS = 256 * 256 / 32, MW_REACH = 126;
+__device__ __forceinline__ int mw_bit(int x, int y) { return ((y & 255) << 8) | (x & 255); }
 __device__ __forceinline__ double readlane_d(double v, int l) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
@@ -117,7 +121,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
     float sumdx = seedCos, sumdy = seedSin;
     if (lane == 0) {
         rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16));
-        if (SPEC) atomicOr(&bm[seed >> 5], 1u << (seed & 31)); else pix[seed].x = USED_F;
+        if (SPEC) { const int bi = mw_bit(seedX, seedY); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pix[seed].x = USED_F;
     }
     const int g = lane >> 3, k8 = lane & 7;             // group (queue slot) and neighbour slot (centre skipped)
     const int k = k8 + (k8 >= 4 ? 1 : 0);                // row-major 3x3 position 0..8 without 4
@@ -152,7 +156,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
             px4 = pix[nidx];                             // .x < 0: NOTDEF or already USED
             candM = __builtin_amdgcn_ballot_w64(px4.x >= 0.f) & __builtin_amdgcn_ballot_w64((unsigned)xx < (unsigned)sw) &
                     __builtin_amdgcn_ballot_w64((unsigned)yy < (unsigned)sh) & (np == 8 ? ~0ull : ((1ull << (np * 8)) - 1));
-            if (SPEC) candM &= ~__builtin_amdgcn_ballot_w64((bm[nidx >> 5] >> (nidx & 31)) & 1u);      // taken by this helper itself
+            if (SPEC) { const int bi = mw_bit(xx, yy); candM &= ~__builtin_amdgcn_ballot_w64((bm[bi >> 5] >> (bi & 31)) & 1u); }      // taken by this helper itself
         } else {
             bool cand = false;
             if (g < np) {
@@ -255,9 +259,10 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
             }
         }
         if (LAT && accMask != 0 && ((accMask >> lane) & 1ull)) {
-            if (SPEC) atomicOr(&bm[nidx >> 5], 1u << (nidx & 31)); else pix[nidx].x = USED_F;
+            if (SPEC) { const int bi = mw_bit(xx, yy); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pix[nidx].x = USED_F;
             rq.set(nBefore + mbcnt(accMask), (unsigned)xx | ((unsigned)yy << 16));
         }
+        if (SPEC && __builtin_amdgcn_ballot_w64(((accMask >> lane) & 1ull) && (abs(xx - seedX) > MW_REACH || abs(yy - seedY) > MW_REACH))) return -n;      // leaves the torus
 #ifdef SSLAM_LSD_CYCLES
         if (verifyCnt) { const long long tS2 = __builtin_readcyclecounter(); cycStage[0] += tS1 - tS0; cycStage[1] += tS2 - tS1; cycStage[2] += 1; }
 #endif
@@ -363,8 +368,9 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
 // receive -- in ascending order -- the kept points above K in descending order (checked against the sequential walk on 2*10^5 random
 // keep patterns before it was written down here, and by the parity tests since).  n/64 wave steps instead of n.
 // scratch: 1536 bytes of LDS (keep masks of <= 16 chunks, then the hole positions as u16: holes <= min(K, n - K) <= 512).
+template <bool SPEC = false>
 __device__ int remove_far_points_lds(unsigned* __restrict__ q, int n, double xc, double yc, double radSq, int sw, float4* __restrict__ pix,
-                                     const float* __restrict__ ang, void* scratch) {
+                                     const float* __restrict__ ang, void* scratch, unsigned* __restrict__ bm = nullptr) {
     const int lane = threadIdx.x & 63;
     unsigned long long* km = (unsigned long long*)scratch;
     unsigned short* holeIdx = (unsigned short*)(km + 16);
@@ -378,7 +384,10 @@ __device__ int remove_far_points_lds(unsigned* __restrict__ q, int n, double xc,
             const int px = e & 0xFFFF, py = e >> 16;
             const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
             keep = !(d2 > radSq);
-            if (!keep) { const int id = py * sw + px; pix[id].x = ang[id]; }      // NOTUSED again
+            if (!keep) {                                                          // NOTUSED again
+                if (SPEC) { const int bi = mw_bit(px, py); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
+                else { const int id = py * sw + px; pix[id].x = ang[id]; }
+            }
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         if (lane == 0) km[c] = m;
@@ -425,14 +434,28 @@ __device__ __forceinline__ double dist_d(double x1, double y1, double x2, double
 //   * regions published but not yet taken are recorded in a coarse shared map (2 x 2 pixel cells) that only steers the helpers' choice of
 //     seeds -- a seed inside somebody's speculative region will most likely be taken by then -- and never enters a region's growth.
 // Stale or torn views only ever cost a fallback: the checks read the main wave's own stores.
-constexpr int MW_HMAX = 4;          // helper waves (LDS: one bitmap of the scaled frame each)
-constexpr int MW_ARENA = 2048;      // region points a helper can publish per chunk
-constexpr int MW_RES = 24;          // regions a helper can publish per chunk
+constexpr int MW_HMAX = 6;          // helper waves
+
+constexpr int MW_NSLOT = 2;         // chunks a helper can have published and not yet passed by the main wave
+#ifndef SSLAM_MW_ARENA
+#define SSLAM_MW_ARENA 1536
+#endif
+constexpr int MW_ARENA = SSLAM_MW_ARENA;      // list words per chunk slot (points of every list + 24 words per rectangle)
+constexpr int MW_RES = 16;          // regions a helper can publish per chunk
 constexpr int MW_EV = 16;           // refine events kept
-struct MwRes { int lane, n, off, startSeq, lo, hi, angLo, angHi; };       // lo = x0 | y0 << 16, hi = x1 | y1 << 16
-struct MwSlot { int chunkPos, nres, doneLane, abortPos; MwRes res[MW_RES]; };
-struct MwCtl { int cursor, finished, unmarkSeq, mainPos; int evLo[MW_EV], evHi[MW_EV]; };
-struct MwShared { MwCtl* ctl; MwSlot* slots; unsigned* arena; unsigned* specMap; int specW; int nHelpers; };
+// A published seed.  Lists in the helper's arena from `off`: A = the region as first grown (nA points); if refine() ran, B = the region
+// re-grown at the refined tolerance (nB), and if reduce_region_radius ran, F = what it left of B (nF).  The pixels that end up USED are the
+// last list's; A and B are what the helper accepted on the way, i.e. what must still be unused for the result to stand.
+constexpr int MW_REFINED = 1, MW_REDUCED = 2, MW_EMIT = 4;
+struct MwRes { int lane, off, nA, nB, nF, flags, startSeq, lo, hi, pad; };       // lo = x0 | y0 << 16, hi = x1 | y1 << 16: box of A and B; the rectangle (MW_EMIT) follows the lists
+struct MwSlot { int chunkPos, nres, doneLane, used; MwRes res[MW_RES]; };
+struct MwCtl { int cursor, finished, unmarkSeq, mainPos; int evLo[MW_EV], evHi[MW_EV]; unsigned long long helperIdle, helperBusy; int why[8]; };
+struct MwShared {
+    MwCtl* ctl; MwSlot* slots; unsigned* arena; unsigned* specMap; int specW, specShift; int nHelpers;      // specShift: log2 of the shared map's cell edge, < 0: no map
+    __device__ __forceinline__ int cell(int x, int y) const { return (y >> specShift) * specW + (x >> specShift); }
+    __device__ __forceinline__ bool spec(int x, int y) const { if (specShift < 0) return false; const int c = cell(x, y); return (specMap[c >> 5] >> (c & 31)) & 1u; }
+};
+struct SpecLists { unsigned* bm; unsigned* free; int cap; int nB; bool reduced, gaveUp; };      // helper side of rect_refine
 __device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int lds_cas_uniform(int* p, int expect, int want, int lane) {      // one CAS per wave, result broadcast
@@ -454,6 +477,115 @@ __device__ __forceinline__ bool boxes_meet(unsigned lo, unsigned hi, unsigned el
     const int x0 = (int)(lo & 0xFFFF) - grow, y0 = (int)(lo >> 16) - grow, x1 = (int)(hi & 0xFFFF) + grow, y1 = (int)(hi >> 16) + grow;
     const int ex0 = elo & 0xFFFF, ey0 = elo >> 16, ex1 = ehi & 0xFFFF, ey1 = ehi >> 16;
     return !(x1 < ex0 || ex1 < x0 || y1 < ey0 || ey1 < y0);
+}
+
+// stage clocks for tools/lsd_cycles.py: compiled in with -DSSLAM_LSD_CYCLES only (an s_memtime + wait per read sits on the one wave's path)
+#ifdef SSLAM_LSD_CYCLES
+#define SSLAM_CLK() __builtin_readcyclecounter()
+#else
+#define SSLAM_CLK() 0ll
+#endif
+
+// region2rect + refine() (LSD_REFINE_STD) of one grown region: returns whether a rectangle goes to the NFA stage.  n / rq hold the region on
+// entry and what is left USED on exit.  Main-wave form: releases and re-marks pixels in the pixel map (WANTBOX: the box of everything touched,
+// for the multi-wave event log).  SPEC form (helper wave): marks live in the private bitmap, the re-grown list goes BEHIND the first one in the
+// arena and reduce_region_radius works on a copy, so that everything the helper ever accepted can be validated later.
+template <bool LAT, bool SPEC, bool WANTBOX>
+__device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& regAngle, RegQ& rq, float4* __restrict__ pix, const float* __restrict__ ang, double* __restrict__ red,
+                            RectD& rec, bool& refined, unsigned& evLo, unsigned& evHi, long long* cycs, SpecLists* sl, long long* verifyCnt) {
+    const int lane = threadIdx.x & 63;
+    const int sw = P.sw, sh = P.sh;
+    const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
+    const long long tA = SSLAM_CLK();
+    region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
+    cycs[0] = SSLAM_CLK() - tA;
+    // ---- refine (LSD_REFINE_STD part)
+    double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+    if (density >= DENSITY_TH) return true;
+    refined = true;
+    if (WANTBOX) { if (n <= QCAP) list_bbox(rq.lds, n, lane, evLo, evHi); else { evLo = 0u; evHi = 0xFFFFFFFFu; } }
+    const unsigned e0 = rq.get(0);
+    const int x0 = e0 & 0xFFFF, y0 = e0 >> 16;
+    const double xc = (double)x0, yc = (double)y0;
+    const double ang_c = (double)sd.x * DEG2RAD;      // reg[0] is the seed
+    OrdSum SR; SR.acc = 0; int cnt = 0;
+    for (int bs = 0; bs < n; bs += 64) {
+        const int i = bs + lane;
+        double ad = 0; bool in = false;
+        if (i < n) {
+            const unsigned e = rq.get_n(i, n);
+            const int px = e & 0xFFFF, py = e >> 16, id = py * sw + px;
+            const float aOrig = ang[id];
+            if (SPEC) { const int bi = mw_bit(px, py); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
+            else pix[id].x = aOrig;                 // NOTUSED again
+            if (dist_d(xc, yc, (double)px, (double)py) < rec.width) { in = true; ad = angle_diff_signed((double)aOrig * DEG2RAD, ang_c); }
+        }
+        // points outside the radius contribute an exact +0.0 (the sums start at +0 and can never be -0)
+        const unsigned long long mi = __ballot(in);
+        ordered_sums_add(SR, red, in ? ad : 0.0, in ? ad * ad : 0.0, 0.0, min(64, n - bs), lane);
+        cnt += __popcll(mi);
+    }
+    const double sum = ordered_sums_get(SR, 0), s_sum = ordered_sums_get(SR, 1);
+    const double mean_angle = sum / (double)cnt;
+    const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
+    if (SPEC) {
+        const int capN = min(QCAP, sl->cap);
+        if (capN <= 64) { sl->gaveUp = true; return false; }
+        rq.lds = sl->free;
+        n = tau < 1.5 ? region_grow_w<true, false, true>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pix, rq, tau, regAngle, nullptr, sl->bm, capN)
+                      : region_grow_w<true, true, true>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pix, rq, tau, regAngle, nullptr, sl->bm, capN);
+        if (n < 0) {
+            for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
+            sl->gaveUp = true; return false;
+        }
+        sl->nB = n; sl->free += n; sl->cap -= n;
+    } else n = region_grow_m<LAT>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pix, rq, tau, regAngle, verifyCnt);
+    if (WANTBOX) {                                // the re-grown region can reach outside the first one, and reduce_region_radius releases from it
+        unsigned l2, h2;
+        if (n <= QCAP) { list_bbox(rq.lds, n, lane, l2, h2); evLo = pk_min_u16(evLo, l2); evHi = pk_max_u16(evHi, h2); } else { evLo = 0u; evHi = 0xFFFFFFFFu; }
+    }
+    if (n < 2) return false;
+    region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
+    density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+    if (density < DENSITY_TH) {
+        const long long tr0 = SSLAM_CLK();
+        if (SPEC) {                               // work on a copy: list B stays as grown
+            if (sl->cap < n) {
+                for (int i = lane; i < n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
+                sl->gaveUp = true; return false;
+            }
+            for (int i = lane; i < n; i += 64) sl->free[i] = rq.lds[i];
+            rq.lds = sl->free; sl->reduced = true;
+        }
+        // reduce_region_radius: sequential swap-with-last removal (the order feeds later sums)
+        const double r1 = (rec.x1 - xc) * (rec.x1 - xc) + (rec.y1 - yc) * (rec.y1 - yc);
+        const double r2 = (rec.x2 - xc) * (rec.x2 - xc) + (rec.y2 - yc) * (rec.y2 - yc);
+        double radSq = r1 > r2 ? r1 : r2;
+        bool good = true;
+        while (density < DENSITY_TH) {
+            radSq *= 0.75 * 0.75;
+            if (SPEC) n = remove_far_points_lds<true>(rq.lds, n, xc, yc, radSq, sw, pix, ang, red, sl->bm);
+            else if (n <= QCAP) n = remove_far_points_lds<false>(rq.lds, n, xc, yc, radSq, sw, pix, ang, red);
+            else for (int i = 0; i < n; ++i) {
+                const unsigned e = rq.get(i);
+                const int px = e & 0xFFFF, py = e >> 16;
+                const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
+                if (d2 > radSq) {
+                    const int id = py * sw + px;
+                    const unsigned last = rq.get(n - 1);
+                    if (lane == 0) { pix[id].x = ang[id]; rq.set(i, last); }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    --n; --i;
+                }
+            }
+            if (n < 2) { good = false; break; }
+            region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
+            density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+        }
+        cycs[2] = SSLAM_CLK() - tr0;
+        if (!good) return false;
+    }
+    return true;
 }
 
 // One persistent single-wave workgroup per frame: the flsd() main loop replayed in order.
@@ -483,14 +615,12 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
 #endif
     const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
     int nSeg = 0;
-    // stage clocks for tools/lsd_cycles.py: compiled in with -DSSLAM_LSD_CYCLES only (an s_memtime + wait per read sits on the one wave's path)
-#ifdef SSLAM_LSD_CYCLES
-#define SSLAM_CLK() __builtin_readcyclecounter()
-#else
-#define SSLAM_CLK() 0ll
-#endif
-    long long cyc0 = 0, cyc1 = 0, cyc2 = 0, cyc3 = 0;
+    long long cyc0 = 0, cyc1 = 0, cyc2 = 0, cyc3 = 0, cycWait = 0, cycTake = 0, cycOwn = 0;
     const long long tStart = SSLAM_CLK();
+#ifdef SSLAM_MW_STATS
+#define SSLAM_CLK2() __builtin_readcyclecounter()
+    const long long tStart2 = SSLAM_CLK2();
+#endif
     for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
         if (MW) lds_st(&mw.ctl->mainPos, pos0);                   // every chunk below pos0 is finished: its helper may move on
         const int q = pos0 + lane;
@@ -507,7 +637,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             seedStash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
         }
         // MW: whose chunk is this?  Below the cursor: a helper claimed it; otherwise the main wave takes it (and everything the cursor skipped)
-        int owner = -1, rp = 0;
+        int owner = -1;
         if (MW) {
             for (;;) {
                 const int c = lds_ld(&mw.ctl->cursor);
@@ -515,7 +645,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                 if (lds_cas_uniform(&mw.ctl->cursor, c, pos0 + 64, lane) == c) break;
             }
             while (owner == -2) {                             // the claimant publishes its slot right after the CAS
-                for (int h = 0; h < mw.nHelpers; ++h) if (lds_ld(&mw.slots[h].chunkPos) == pos0) owner = h;
+                for (int h = 0; h < mw.nHelpers * MW_NSLOT; ++h) if (lds_ld(&mw.slots[h].chunkPos) == pos0) owner = h;
                 if (owner == -2) __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -527,43 +657,57 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             double regAngle;
             long long t0 = SSLAM_CLK();
             int n = -1;
+            bool took = false, tookEmit = false; RectD tookRec; const unsigned* smallList = rq.lds;
 #ifdef SSLAM_MW_STATS
             int cause = 7;                                      // 7: the main wave's own chunk
 #endif
             if (MW && owner >= 0) {
                 MwSlot* S = &mw.slots[owner];
                 while (lds_ld(&S->doneLane) <= first) __builtin_amdgcn_s_sleep(1);
+                const long long tw = SSLAM_CLK(); cycWait += tw - t0;
                 const int nres = lds_ld(&S->nres);
-                while (rp < nres && S->res[rp].lane < first) ++rp;                 // regions grown from seeds that were taken by the time their turn came
+                // the helper's regions are in no particular order (it may have looked at the chunk more than once)
+                const unsigned long long hit = __ballot(lane < nres && S->res[min(lane, MW_RES - 1)].lane == first);
                 SSLAM_MW_CAUSE(1);
-                if (rp < nres && S->res[rp].lane == first) {
-                    const MwRes r = S->res[rp]; ++rp;
-                    const unsigned* lst = mw.arena + (size_t)owner * MW_ARENA + r.off;
-                    bool ok = r.n > 0 && unmarkSeq - r.startSeq <= MW_EV;
-                    if (!ok) SSLAM_MW_CAUSE(r.n > 0 ? 4 : 5);
-                    for (int sq = r.startSeq + 1; ok && sq <= unmarkSeq; ++sq) {
-                        ok = !boxes_meet((unsigned)r.lo, (unsigned)r.hi, (unsigned)mw.ctl->evLo[sq & (MW_EV - 1)], (unsigned)mw.ctl->evHi[sq & (MW_EV - 1)], 1);
+                if (hit) {
+                    const MwRes* r = &S->res[__ffsll((long long)hit) - 1];
+                    const int nA = r->nA, nB = r->nB, nF = r->nF, flags = r->flags, startSeq = r->startSeq;
+                    const unsigned* lstA = mw.arena + (size_t)owner * MW_ARENA + r->off;
+                    const unsigned* lstB = lstA + nA;
+                    const unsigned* lstF = (flags & MW_REDUCED) ? lstB + nB : (flags & MW_REFINED) ? lstB : lstA;
+                    bool ok = unmarkSeq - startSeq <= MW_EV;
+                    if (!ok) SSLAM_MW_CAUSE(4);
+                    for (int sq = startSeq + 1; ok && sq <= unmarkSeq; ++sq) {
+                        ok = !boxes_meet((unsigned)r->lo, (unsigned)r->hi, (unsigned)mw.ctl->evLo[sq & (MW_EV - 1)], (unsigned)mw.ctl->evHi[sq & (MW_EV - 1)], 1);
                         if (!ok) SSLAM_MW_CAUSE(4);
                     }
-                    for (int bs = 0; ok && bs < r.n; bs += 64) {
+                    // everything the helper accepted on the way (A, and B when refine() ran) must be unused now
+                    for (int bs = 0; ok && bs < nA + nB; bs += 64) {
                         const int i = bs + lane;
                         bool usedNow = false;
-                        if (i < r.n) { const unsigned e = lst[i]; usedNow = pix[(int)(e >> 16) * sw + (int)(e & 0xFFFF)].x < 0.f; }
+                        if (i < nA + nB) { const unsigned e = lstA[i]; usedNow = pix[(int)(e >> 16) * sw + (int)(e & 0xFFFF)].x < 0.f; }
                         ok = __ballot(usedNow) == 0;
                         if (!ok) SSLAM_MW_CAUSE(3);
                     }
                     if (ok) {
-                        for (int bs = 0; bs < r.n; bs += 64) {
-                            const int i = bs + lane;
-                            if (i < r.n) { const unsigned e = lst[i]; pix[(int)(e >> 16) * sw + (int)(e & 0xFFFF)].x = USED_F; rq.lds[i] = e; }
+                        for (int i = lane; i < nF; i += 64) { const unsigned e = lstF[i]; pix[(int)(e >> 16) * sw + (int)(e & 0xFFFF)].x = USED_F; }
+                        took = true; n = nA; smallList = lstA;
+                        tookEmit = (flags & MW_EMIT) != 0;
+                        if (tookEmit) {
+                            const int* rw = (const int*)(lstB + nB + ((flags & MW_REDUCED) ? nF : 0));
+                            double* rd = (double*)&tookRec;
+#pragma unroll
+                            for (int j = 0; j < 12; ++j) rd[j] = __hiloint2double(rw[2 * j + 1], rw[2 * j]);
                         }
-                        n = r.n; regAngle = __hiloint2double(r.angHi, r.angLo);
                         mwTaken += 1 + ((long long)n << 32);
                     }
                 }
+                cycTake += SSLAM_CLK() - tw;
             }
             if (n < 0) {
+                const long long to = SSLAM_CLK();
                 n = region_grow_m<LAT>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, prec, regAngle, &misc->cyc[6]);
+                cycOwn += SSLAM_CLK() - to;
                 mwOwn += 1 + ((long long)n << 32);
 #ifdef SSLAM_MW_STATS
                 mwCause[cause] += 1 + ((long long)n << 32);
@@ -574,7 +718,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                 // too small: rejected, its pixels stay used.  Which candidates of this chunk did it take?  Compare them with the (few) points of
                 // the region instead of gathering 64 pixel records again.
                 for (int k = 1; k < n; ++k) {
-                    const unsigned e = rq.lds[k];             // minRegSize < QCAP
+                    const unsigned e = smallList[k];          // minRegSize < QCAP
                     unM &= ~__ballot(idx == (int)(e >> 16) * sw + (int)(e & 0xFFFF));
                 }
                 continue;
@@ -582,85 +726,18 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             RectD rec;
             bool emit = false;
             long long t2 = t1;
-            bool refined = false; unsigned evLo = 0xFFFFFFFFu, evHi = 0u;      // MW: everything refine() may have released lies inside this box
-            do {
-            region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
-            t2 = SSLAM_CLK(); cyc1 += t2 - t1;
-            // ---- refine (LSD_REFINE_STD part)
-            double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
-            if (density < DENSITY_TH) {
-                if (MW) {
-                    refined = true;
-                    if (n <= QCAP) list_bbox(rq.lds, n, lane, evLo, evHi); else { evLo = 0u; evHi = 0xFFFFFFFFu; }
+            if (took) { emit = tookEmit; rec = tookRec; }
+            else {
+                bool refined = false; unsigned evLo = 0xFFFFFFFFu, evHi = 0u;      // MW: everything refine() may have released lies inside this box
+                long long cycs[3] = {0, 0, 0};
+                emit = rect_refine<LAT, false, MW>(P, sd, n, regAngle, rq, pix, ang, red, rec, refined, evLo, evHi, cycs, nullptr, &misc->cyc[6]);
+                cyc1 += cycs[0]; t2 = t1 + cycs[0]; cyc3 += cycs[2];
+                if (MW && refined) {                              // log the event once the last store of this refine has left
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    ++unmarkSeq;
+                    if (lane == 0) { mw.ctl->evLo[unmarkSeq & (MW_EV - 1)] = (int)evLo; mw.ctl->evHi[unmarkSeq & (MW_EV - 1)] = (int)evHi; }
+                    lds_st(&mw.ctl->unmarkSeq, unmarkSeq);
                 }
-                const unsigned e0 = rq.get(0);
-                const int x0 = e0 & 0xFFFF, y0 = e0 >> 16;
-                const double xc = (double)x0, yc = (double)y0;
-                const double ang_c = (double)sd.x * DEG2RAD;      // reg[0] is the seed
-                OrdSum SR; SR.acc = 0; int cnt = 0;
-                for (int bs = 0; bs < n; bs += 64) {
-                    const int i = bs + lane;
-                    double ad = 0; bool in = false;
-                    if (i < n) {
-                        const unsigned e = rq.get_n(i, n);
-                        const int px = e & 0xFFFF, py = e >> 16, id = py * sw + px;
-                        const float aOrig = ang[id];
-                        pix[id].x = aOrig;                 // NOTUSED again
-                        if (dist_d(xc, yc, (double)px, (double)py) < rec.width) { in = true; ad = angle_diff_signed((double)aOrig * DEG2RAD, ang_c); }
-                    }
-                    // points outside the radius contribute an exact +0.0 (the sums start at +0 and can never be -0)
-                    const unsigned long long mi = __ballot(in);
-                    ordered_sums_add(SR, red, in ? ad : 0.0, in ? ad * ad : 0.0, 0.0, min(64, n - bs), lane);
-                    cnt += __popcll(mi);
-                }
-                const double sum = ordered_sums_get(SR, 0), s_sum = ordered_sums_get(SR, 1);
-                const double mean_angle = sum / (double)cnt;
-                const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-                n = region_grow_m<LAT>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pix, rq, tau, regAngle, &misc->cyc[6]);
-                if (MW) {                                     // the re-grown region can reach outside the first one, and reduce_region_radius releases from it
-                    unsigned l2, h2;
-                    if (n <= QCAP) { list_bbox(rq.lds, n, lane, l2, h2); evLo = pk_min_u16(evLo, l2); evHi = pk_max_u16(evHi, h2); } else { evLo = 0u; evHi = 0xFFFFFFFFu; }
-                }
-                if (n < 2) break;
-                region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
-                density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
-                if (density < DENSITY_TH) {
-                    const long long tr0 = SSLAM_CLK();
-                    // reduce_region_radius: sequential swap-with-last removal (the order feeds later sums)
-                    const double r1 = (rec.x1 - xc) * (rec.x1 - xc) + (rec.y1 - yc) * (rec.y1 - yc);
-                    const double r2 = (rec.x2 - xc) * (rec.x2 - xc) + (rec.y2 - yc) * (rec.y2 - yc);
-                    double radSq = r1 > r2 ? r1 : r2;
-                    bool good = true;
-                    while (density < DENSITY_TH) {
-                        radSq *= 0.75 * 0.75;
-                        if (n <= QCAP) n = remove_far_points_lds(rq.lds, n, xc, yc, radSq, sw, pix, ang, red);
-                        else for (int i = 0; i < n; ++i) {
-                            const unsigned e = rq.get(i);
-                            const int px = e & 0xFFFF, py = e >> 16;
-                            const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
-                            if (d2 > radSq) {
-                                const int id = py * sw + px;
-                                const unsigned last = rq.get(n - 1);
-                                if (lane == 0) { pix[id].x = ang[id]; rq.set(i, last); }
-                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                                --n; --i;
-                            }
-                        }
-                        if (n < 2) { good = false; break; }
-                        region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
-                        density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
-                    }
-                    cyc3 += SSLAM_CLK() - tr0;
-                    if (!good) break;
-                }
-            }
-            emit = true;
-            } while (false);
-            if (MW && refined) {                              // log the event once the last store of this refine has left
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                ++unmarkSeq;
-                if (lane == 0) { mw.ctl->evLo[unmarkSeq & (MW_EV - 1)] = (int)evLo; mw.ctl->evHi[unmarkSeq & (MW_EV - 1)] = (int)evHi; }
-                lds_st(&mw.ctl->unmarkSeq, unmarkSeq);
             }
             // ---- hand the rectangle to the NFA stage (rect_improve reads only the static angle map and never touches
             // `used`, so it is not part of the sequential dependency chain: k_lsd_nfa evaluates all candidates in parallel)
@@ -682,8 +759,12 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
         misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
         misc->cyc[0] = cyc0; misc->cyc[1] = cyc1; misc->cyc[2] = cyc2; misc->cyc[3] = cyc3; misc->cyc[4] = SSLAM_CLK() - tStart;
         if (MW) { misc->cyc[5] = mwTaken; misc->cyc[6] = mwOwn; misc->cyc[7] = mwBadChunks; }
+#ifdef SSLAM_LSD_CYCLES
+        if (MW) { misc->cyc[5] = cycWait; misc->cyc[6] = cycTake; misc->cyc[7] = cycOwn; }
+#endif
 #ifdef SSLAM_MW_STATS
-        if (MW) { misc->cyc[0] = mwTaken; for (int c = 1; c < 8; ++c) misc->cyc[c] = mwCause[c]; }
+        if (MW) { misc->cyc[0] = mwTaken; for (int c = 1; c < 8; ++c) misc->cyc[c] = mwCause[c]; misc->cyc[5] = (long long)mw.ctl->helperBusy; misc->cyc[6] = (long long)mw.ctl->helperIdle; misc->cyc[2] = SSLAM_CLK2() - tStart2;
+                  long long w0 = 0, w1 = 0; for (int c = 0; c < 4; ++c) { w0 |= (long long)(mw.ctl->why[c] & 0xFFFF) << (16 * c); w1 |= (long long)(mw.ctl->why[4 + c] & 0xFFFF) << (16 * c); } misc->cyc[3] = w0; misc->cyc[4] = w1; }
 #endif
     }
 }
@@ -699,17 +780,33 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
 
 // ------------------------------------------------------------------ multi-wave form: the helper wave and the kernel
 // One helper: claim a chunk, grow its unused seeds in order on the read-only view + own bitmap, publish, wait until the main wave has passed.
-__device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int b, const MwShared& mw, unsigned* __restrict__ bm, int bmWords, float4* __restrict__ stash) {
+__device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int b, const MwShared& mw, unsigned* __restrict__ bm, float4* __restrict__ stash, double* __restrict__ red) {
     const int lane = threadIdx.x & 63;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     float4* pix = (float4*)(base + P.offPix);
+    const float* ang = (const float*)(base + P.offAng);
     const unsigned* order = (const unsigned*)(base + P.offOrder);
     const Misc* misc = (const Misc*)(base + P.offMisc);
     const int sw = P.sw, sh = P.sh, nOrd = misc->nDefined;
-    MwCtl* ctl = mw.ctl; MwSlot* S = &mw.slots[h];
-    unsigned* arena = mw.arena + (size_t)h * MW_ARENA;
-    for (int i = lane; i < bmWords; i += 64) bm[i] = 0u;
-    for (;;) {
+    MwCtl* ctl = mw.ctl;
+    for (int i = lane; i < MW_BM_WORDS; i += 64) bm[i] = 0u;
+    for (int turn = 0;; turn = (turn + 1) % MW_NSLOT) {
+        // ---- the older of this helper's slots: free once the main wave has passed its chunk; its regions then leave the shared map
+        MwSlot* S = &mw.slots[h * MW_NSLOT + turn];
+        unsigned* arena = mw.arena + (size_t)(h * MW_NSLOT + turn) * MW_ARENA;
+#ifdef SSLAM_MW_STATS
+        const long long tIdle0 = __builtin_readcyclecounter();
+#endif
+        while (S->chunkPos >= 0 && lds_ld(&ctl->mainPos) <= S->chunkPos && !lds_ld(&ctl->finished)) __builtin_amdgcn_s_sleep(2);
+#ifdef SSLAM_MW_STATS
+        if (lane == 0) atomicAdd(&ctl->helperIdle, (unsigned long long)(__builtin_readcyclecounter() - tIdle0));
+#endif
+        if (S->chunkPos >= 0 && mw.specShift >= 0)
+            for (int kk = 0; kk < S->nres; ++kk) {
+                const MwRes* r = &S->res[kk];
+                const unsigned* lstF = arena + r->off + ((r->flags & MW_REDUCED) ? r->nA + r->nB : (r->flags & MW_REFINED) ? r->nA : 0);
+                for (int i = lane; i < r->nF; i += 64) { const unsigned e = lstF[i]; const int cl = mw.cell((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&mw.specMap[cl >> 5], ~(1u << (cl & 31))); }
+            }
         // ---- claim the next chunk nobody has
         int c;
         for (;;) {
@@ -720,81 +817,126 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
             if (c < mp) { lds_cas_uniform(&ctl->cursor, c, mp, lane); continue; }      // the main wave is already past it
             if (lds_cas_uniform(&ctl->cursor, c, c + 64, lane) == c) break;
         }
-        if (lane == 0) { S->nres = 0; S->doneLane = 0; }
+#ifdef SSLAM_MW_STATS
+        const long long tClaim = __builtin_readcyclecounter();
+#endif
+        if (lane == 0) { S->nres = 0; S->doneLane = 0; S->used = 0; }
         lds_st(&S->chunkPos, c);
         // ---- the chunk's seed candidates as this wave sees them now
         const int q = c + lane;
         const int idx = q < nOrd ? (int)order[q] : -1;
-        const float a0 = idx >= 0 ? pix[idx].x : -1.f;
         const int cy = max(idx, 0) / sw, cx = max(idx, 0) - cy * sw;
-        const int cell = (cy >> 1) * mw.specW + (cx >> 1);
-        unsigned long long unM = __ballot(a0 >= 0.f && !((mw.specMap[cell >> 5] >> (cell & 31)) & 1u));
+#ifdef SSLAM_MW_STATS
+#define SSLAM_MW_WHY(i, v) do { if (lane == 0) atomicAdd(&ctl->why[i], (v)); } while (0)
+#else
+#define SSLAM_MW_WHY(i, v)
+#endif
+        // Pass 0 grows the seeds that are unused and outside every speculative region, in order.  While the main wave is still in front of
+        // the chunk and this helper has nowhere else to go (its other slot not passed yet), it keeps looking again: whatever is unused by
+        // then and still has no region -- seeds the shared map had talked it out of, pixels a refine() released -- is grown as well, so
+        // that the main wave finds a region for (nearly) every seed instead of growing those itself.
+        const MwSlot* other = &mw.slots[h * MW_NSLOT + (turn + 1) % MW_NSLOT];
+        unsigned long long haveRes = 0;
+        int off = 0, k = 0; bool room = true;
+        for (int pass = 0; room; ++pass) {
+        if (pass > 0) {
+            const int oc = other->chunkPos, mp = lds_ld(&ctl->mainPos);
+            if (mp >= c || lds_ld(&ctl->finished) || oc < 0 || mp > oc) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        const float a0 = idx >= 0 ? pix[idx].x : -1.f;
+        unsigned long long unM = __ballot(a0 >= 0.f && (pass > 0 || !mw.spec(cx, cy))) & ~haveRes;
+        if (pass == 0) SSLAM_MW_WHY(0, __popcll(__ballot(a0 >= 0.f && mw.spec(cx, cy))));
         if (unM) {
             const double ar = (double)a0 * DEG2RAD;
             stash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
         }
-        int off = 0, k = 0;
         while (unM) {
-            if (lds_ld(&ctl->mainPos) > c || lds_ld(&S->abortPos) == c || lds_ld(&ctl->finished)) break;
+            if (lds_ld(&ctl->mainPos) > c || lds_ld(&ctl->finished)) { SSLAM_MW_WHY(7, 1 + __popcll(unM)); break; }
             const int first = __ffsll((long long)unM) - 1;
             unM &= unM - 1;
             const float4 sd = stash[first];
             const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
             const int startSeq = lds_ld(&ctl->unmarkSeq);      // sampled BEFORE the first pixel of this region is read
-            if (pix[sy * sw + sx].x < 0.f) continue;           // taken since the chunk was scanned (a region in front of it, committed meanwhile)
-            { const int sc = (sy >> 1) * mw.specW + (sx >> 1); if ((mw.specMap[sc >> 5] >> (sc & 31)) & 1u) continue; }      // ... or about to be
+            if (pix[sy * sw + sx].x < 0.f) { SSLAM_MW_WHY(1, 1); continue; }           // taken since the chunk was scanned (a region in front of it, committed meanwhile)
+            if (pass == 0 && mw.spec(sx, sy)) { SSLAM_MW_WHY(2, 1); continue; }         // ... or about to be
             RegQ rq; rq.lds = arena + off; rq.glb = nullptr;
-            const int capN = min(QCAP, MW_ARENA - off);
+            const int capN = min(QCAP, MW_ARENA - 24 - off);
             double regAngle = 0;
-            if (k >= MW_RES || capN <= 64) break;                // no room left: the main wave grows the rest of the chunk itself
+            if (k >= MW_RES || capN <= 64) { SSLAM_MW_WHY(k >= MW_RES ? 3 : 4, 1 + __popcll(unM)); room = false; break; }                // no room left: the main wave grows the rest of the chunk itself
             int n = region_grow_w<true, false, true>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, P.prec, regAngle, nullptr, bm, capN);
             if (n < 0) {                                        // too long for a helper: release its marks, the main wave grows this one
-                for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int id = (int)(e >> 16) * sw + (int)(e & 0xFFFF); atomicAnd(&bm[id >> 5], ~(1u << (id & 31))); }
+                for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
+                SSLAM_MW_WHY(5, 1);
                 continue;
             }
+            // ---- the rest of flsd()'s per-seed body on the private marks: region2rect, refine()
+            const int nA = n;
+            unsigned* lstA = rq.lds;
+            SpecLists sl; sl.bm = bm; sl.free = lstA + nA; sl.cap = MW_ARENA - 24 - off - nA; sl.nB = 0; sl.reduced = false; sl.gaveUp = false;
+            bool emit = false, refined = false; unsigned dLo = 0, dHi = 0; long long cycs[3];
+            RectD rec;
+            if (n >= P.minRegSize) {
+                emit = rect_refine<true, true, false>(P, sd, n, regAngle, rq, pix, ang, red, rec, refined, dLo, dHi, cycs, &sl, nullptr);
+                if (sl.gaveUp) { SSLAM_MW_WHY(6, 1); continue; }                        // its marks are released; the main wave handles this seed
+            }
+            // marks still set: the final list (rq.lds[0..n)).  They go -- the next region is grown on its own.
+            for (int i = lane; i < n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
+            const int nAB = nA + sl.nB;
+            int total = nAB + (sl.reduced ? n : 0);
+            if (emit) {                                         // the rectangle follows the lists
+                if (lane == 0) {
+                    int* rw = (int*)(lstA + total); const double* rd = (const double*)&rec;
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) { rw[2 * j] = __double2loint(rd[j]); rw[2 * j + 1] = __double2hiint(rd[j]); }
+                }
+                total += 24;
+            }
             unsigned lo, hi;
-            list_bbox(rq.lds, n, lane, lo, hi);
+            list_bbox(lstA, nAB, lane, lo, hi);
             if (lane == 0) {
                 MwRes& r = S->res[k];
-                r.lane = first; r.n = n; r.off = off; r.startSeq = startSeq; r.lo = (int)lo; r.hi = (int)hi;
-                r.angLo = __double2loint(regAngle); r.angHi = __double2hiint(regAngle);
+                r.lane = first; r.off = off; r.nA = nA; r.nB = sl.nB; r.nF = n; r.startSeq = startSeq; r.lo = (int)lo; r.hi = (int)hi;
+                r.flags = (refined ? MW_REFINED : 0) | (sl.reduced ? MW_REDUCED : 0) | (emit ? MW_EMIT : 0);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            ++k; off += n;
+            ++k; off += total; haveRes |= 1ull << first;
             lds_st(&S->nres, k);
-            lds_st(&S->doneLane, first + 1);
-            // candidates of this chunk that the region took; then the private marks go (the next region is grown on its own) and the region
-            // enters the shared map that steers seed choice
-            if (n > 1) unM &= ~__ballot(idx >= 0 && ((bm[max(idx, 0) >> 5] >> (max(idx, 0) & 31)) & 1u));
+            if (pass == 0) lds_st(&S->doneLane, first + 1);
+            // what the region leaves USED enters the shared map that steers seed choice; candidates of this chunk inside it are dropped
             for (int i = lane; i < n; i += 64) {
-                const unsigned e = rq.lds[i]; const int px = e & 0xFFFF, py = e >> 16, id = py * sw + px, cl = (py >> 1) * mw.specW + (px >> 1);
-                atomicAnd(&bm[id >> 5], ~(1u << (id & 31)));
+                if (mw.specShift < 0) break;
+                const unsigned e = rq.lds[i]; const int cl = mw.cell((int)(e & 0xFFFF), (int)(e >> 16));
                 atomicOr(&mw.specMap[cl >> 5], 1u << (cl & 31));
             }
+            if (n > 1 && pass == 0) unM &= ~__ballot(idx >= 0 && mw.spec(cx, cy));
         }
-        lds_st(&S->doneLane, 64);
-        while (lds_ld(&ctl->mainPos) <= c && !lds_ld(&ctl->finished)) __builtin_amdgcn_s_sleep(2);
-        // ---- the main wave is past the chunk: its regions leave the shared map
-        for (int i = lane; i < off; i += 64) { const unsigned e = arena[i]; const int cl = (int)(e >> 17) * mw.specW + (int)((e & 0xFFFF) >> 1); atomicAnd(&mw.specMap[cl >> 5], ~(1u << (cl & 31))); }
+        if (pass == 0) lds_st(&S->doneLane, 64);
+        }
+        if (lane == 0) S->used = off;
+#ifdef SSLAM_MW_STATS
+        if (lane == 0) atomicAdd(&ctl->helperBusy, (unsigned long long)(__builtin_readcyclecounter() - tClaim));
+#endif
     }
 }
 
-// dynamic LDS: [main queue QCAP + 4][arena nHelpers x MW_ARENA][bitmaps nHelpers x bmWords][shared coarse map specWords]
-__global__ __launch_bounds__(64 * (1 + MW_HMAX)) void k_lsd_regions_mw(uint8_t* __restrict__ ws, LsdPlan P, int nHelpers, int bmWords, int specWords) {
+// dynamic LDS: [main queue QCAP + 4][arena nHelpers x MW_NSLOT x MW_ARENA][bitmaps nHelpers x MW_BM_WORDS][shared coarse map specWords]
+__global__ __launch_bounds__(64 * (1 + MW_HMAX)) void k_lsd_regions_mw(uint8_t* __restrict__ ws, LsdPlan P, int nHelpers, int specWords, int specShift) {
     extern __shared__ __align__(16) unsigned dynLds[];
     __shared__ double red[3 * 64];
     __shared__ float4 seedStash[64];
     __shared__ float4 helperStash[MW_HMAX][64];
+    __shared__ double helperRed[MW_HMAX][3 * 64];
     __shared__ MwCtl ctl;
-    __shared__ MwSlot slots[MW_HMAX];
+    __shared__ MwSlot slots[MW_HMAX * MW_NSLOT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; }
-    if (threadIdx.x < MW_HMAX) { slots[threadIdx.x].chunkPos = -1; slots[threadIdx.x].nres = 0; slots[threadIdx.x].doneLane = 0; slots[threadIdx.x].abortPos = -1; }
+    if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; ctl.helperIdle = 0; ctl.helperBusy = 0; for (int c = 0; c < 8; ++c) ctl.why[c] = 0; }
+    if (threadIdx.x < MW_HMAX * MW_NSLOT) { slots[threadIdx.x].chunkPos = -1; slots[threadIdx.x].nres = 0; slots[threadIdx.x].doneLane = 0; slots[threadIdx.x].used = 0; }
     MwShared mw; mw.ctl = &ctl; mw.slots = slots; mw.arena = dynLds + QCAP + 4; mw.nHelpers = nHelpers;
-    mw.specMap = mw.arena + (size_t)nHelpers * (MW_ARENA + bmWords); mw.specW = (P.sw + 1) >> 1;
+    mw.specMap = mw.arena + (size_t)nHelpers * (MW_NSLOT * MW_ARENA + MW_BM_WORDS); mw.specShift = specShift; mw.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
     for (int i = threadIdx.x; i < specWords; i += blockDim.x) mw.specMap[i] = 0u;
     __syncthreads();
     const int b = blockIdx.x;
     if (wave == 0) lsd_regions_body<true, true>(ws, P, b, dynLds, red, seedStash, mw);
-    else if (wave <= nHelpers) mw_helper(wave - 1, ws, P, b, mw, dynLds + QCAP + 4 + (size_t)nHelpers * MW_ARENA + (size_t)(wave - 1) * bmWords, bmWords, helperStash[wave - 1]);
+    else if (wave <= nHelpers) mw_helper(wave - 1, ws, P, b, mw, dynLds + QCAP + 4 + (size_t)nHelpers * MW_NSLOT * MW_ARENA + (size_t)(wave - 1) * MW_BM_WORDS, helperStash[wave - 1], helperRed[wave - 1]);
 }

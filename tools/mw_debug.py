@@ -20,8 +20,10 @@ for it, img, nfeat, nlev, sf, ini, mn, cap in cases(n, rng):
         same = raw.shape == oraw.shape and np.array_equal(raw, oraw)
         nbad += not same
         if os.environ.get("MW_STATS"):
-            names = ["taken", "no result", "bogus before", "point used", "refine event", "gave up", "chunk abandoned", "own chunk"]
-            print("   " + "  ".join("%s %d/%dpx" % (names[c], out[c] & 0xFFFFFFFF, out[c] >> 32) for c in range(8)))
+            names = ["taken", "no result", "", "point used", "refine event", "", "", "own chunk"]
+            why = [(out[3 + c // 4] >> (16 * (c % 4))) & 0xFFFF for c in range(8)]
+            print("   helper skips: in map at scan %d, used at turn %d, in map at turn %d, results full %d, arena full %d, growth gave up %d, refine gave up %d, main passed %d" % tuple(why))
+            print("   " + "  ".join("%s %d/%dpx" % (names[c], out[c] & 0xFFFFFFFF, out[c] >> 32) for c in (0, 1, 7)) + "   main %.2f Mcyc, helpers busy %.2f idle %.2f Mcyc" % (out[2] / 1e6, out[5] / 1e6, out[6] / 1e6))
         print("it %d %s rep %d: %s  segs %d/%d  taken %d (%d px) own %d (%d px) badChunks %d" % (it, img.shape, rep, "ok" if same else "DIFF", len(raw), len(oraw), out[5] & 0xFFFFFFFF, out[5] >> 32, out[6] & 0xFFFFFFFF, out[6] >> 32, out[7]))
         if not same and raw.shape == oraw.shape:
             d = np.nonzero((raw != oraw).any(axis=1))[0]; print("   first differing segments", d[:6], raw[d[:2]], oraw[d[:2]])
