@@ -631,11 +631,15 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
         const float a0 = idx >= 0 ? pix[idx].x : -1.f;
         unsigned long long unM = __ballot(a0 >= 0.f);         // candidates of this chunk that are still unused (wave-uniform, kept up to date below)
         if (!unM) continue;
-        {
+        // (multi-wave form: only the seeds the main wave grows itself need this -- evaluated at the first one of the chunk)
+        bool stashReady = false;
+        auto fill_stash = [&]() {
             const int cy = idx / sw, cx = idx - cy * sw;
             const double ar = (double)a0 * DEG2RAD;
             seedStash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
-        }
+            stashReady = true;
+        };
+        if (!MW) fill_stash();
         // MW: whose chunk is this?  Below the cursor: a helper claimed it; otherwise the main wave takes it (and everything the cursor skipped)
         int owner = -1;
         if (MW) {
@@ -652,8 +656,8 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
         while (unM) {
             const int first = __ffsll((long long)unM) - 1;
             unM &= unM - 1;                                   // the seed itself is consumed whatever happens
-            const float4 sd = seedStash[first];               // wave-uniform address: one broadcast read
-            const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
+            float4 sd = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!MW) sd = seedStash[first];                   // wave-uniform address: one broadcast read
             double regAngle;
             long long t0 = SSLAM_CLK();
             int n = -1;
@@ -706,6 +710,8 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             }
             if (n < 0) {
                 const long long to = SSLAM_CLK();
+                if (MW) { if (!stashReady) fill_stash(); sd = seedStash[first]; }
+                const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
                 n = region_grow_m<LAT>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, prec, regAngle, &misc->cyc[6]);
                 cycOwn += SSLAM_CLK() - to;
                 mwOwn += 1 + ((long long)n << 32);
