@@ -608,7 +608,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
     int unmarkSeq = 0;                                             // MW: refine events logged so far (the main wave is the only writer)
     long long mwTaken = 0, mwOwn = 0, mwBadChunks = 0;             // MW statistics (Misc::cyc[5..7])
 #ifdef SSLAM_MW_STATS
-    long long mwCause[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // why the main wave grew a region itself (count | points << 32): tools/mw_debug.py
+    long long mwCause[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mwBig = 0, mwTiny = 0;                // why the main wave grew a region itself (count | points << 32): tools/mw_debug.py
 #define SSLAM_MW_CAUSE(c) cause = (c)
 #else
 #define SSLAM_MW_CAUSE(c)
@@ -717,6 +717,8 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                 mwOwn += 1 + ((long long)n << 32);
 #ifdef SSLAM_MW_STATS
                 mwCause[cause] += 1 + ((long long)n << 32);
+                if (n >= 100) mwBig += 1 + ((long long)n << 32);
+                if (n <= 2) mwTiny += 1 + ((long long)n << 32);
 #endif
             }
             long long t1 = SSLAM_CLK(); cyc0 += t1 - t0;
@@ -769,7 +771,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
         if (MW) { misc->cyc[5] = cycWait; misc->cyc[6] = cycTake; misc->cyc[7] = cycOwn; }
 #endif
 #ifdef SSLAM_MW_STATS
-        if (MW) { misc->cyc[0] = mwTaken; for (int c = 1; c < 8; ++c) misc->cyc[c] = mwCause[c]; misc->cyc[5] = (long long)mw.ctl->helperBusy; misc->cyc[6] = (long long)mw.ctl->helperIdle; misc->cyc[2] = SSLAM_CLK2() - tStart2;
+        if (MW) { misc->cyc[0] = mwTaken; for (int c = 1; c < 8; ++c) misc->cyc[c] = mwCause[c]; misc->cyc[5] = (long long)mw.ctl->helperBusy; misc->cyc[6] = (long long)mw.ctl->helperIdle; misc->cyc[2] = SSLAM_CLK2() - tStart2; misc->cyc[7] = mwBig; misc->cyc[1] = mwCause[1] + mwCause[3] + mwCause[4];
                   long long w0 = 0, w1 = 0; for (int c = 0; c < 4; ++c) { w0 |= (long long)(mw.ctl->why[c] & 0xFFFF) << (16 * c); w1 |= (long long)(mw.ctl->why[4 + c] & 0xFFFF) << (16 * c); } misc->cyc[3] = w0; misc->cyc[4] = w1; }
 #endif
     }
@@ -842,7 +844,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
         // then and still has no region -- seeds the shared map had talked it out of, pixels a refine() released -- is grown as well, so
         // that the main wave finds a region for (nearly) every seed instead of growing those itself.
         const MwSlot* other = &mw.slots[h * MW_NSLOT + (turn + 1) % MW_NSLOT];
-        unsigned long long haveRes = 0;
+        unsigned long long haveRes = 0;      // seeds with a region, or that this helper gave up on
         int off = 0, k = 0; bool room = true;
         for (int pass = 0; room; ++pass) {
         if (pass > 0) {
@@ -873,7 +875,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
             int n = region_grow_w<true, false, true>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, P.prec, regAngle, nullptr, bm, capN);
             if (n < 0) {                                        // too long for a helper: release its marks, the main wave grows this one
                 for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
-                SSLAM_MW_WHY(5, 1);
+                SSLAM_MW_WHY(5, 1); haveRes |= 1ull << first;
                 continue;
             }
             // ---- the rest of flsd()'s per-seed body on the private marks: region2rect, refine()
@@ -884,7 +886,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
             RectD rec;
             if (n >= P.minRegSize) {
                 emit = rect_refine<true, true, false>(P, sd, n, regAngle, rq, pix, ang, red, rec, refined, dLo, dHi, cycs, &sl, nullptr);
-                if (sl.gaveUp) { SSLAM_MW_WHY(6, 1); continue; }                        // its marks are released; the main wave handles this seed
+                if (sl.gaveUp) { SSLAM_MW_WHY(6, 1); haveRes |= 1ull << first; continue; }                        // its marks are released; the main wave handles this seed
             }
             // marks still set: the final list (rq.lds[0..n)).  They go -- the next region is grown on its own.
             for (int i = lane; i < n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }

@@ -6,6 +6,7 @@ ZERO for everything except quantities that pass through libm-vs-ocml transcenden
 <= 1 ulp on floats (checked below as exact-or-1ulp) and identical segment SETS."""
 import numpy as np
 import pytest
+import torch
 from synth import synth_frame, noise_frame, const_frame, ramp_frame
 
 pytestmark = pytest.mark.gpu
@@ -103,3 +104,52 @@ def test_lines_huge_regions(fe, ctx, oracle):
     """regions far larger than the 1024-point LDS queue continue in global memory"""
     n, bad = _cmp_lines(fe, ctx, oracle, ramp_frame(), 200)
     assert n >= 1
+
+
+@pytest.mark.parametrize("flavour", ["mw", "lat", "thr"])
+def test_lsd_core_flavours(fe, ctx, oracle, flavour, monkeypatch):
+    """The sequential core has three launch forms (lsd_regions.h): multi-wave (main wave + helper waves running the per-seed body ahead of it;
+    what a single frame gets), the lone wave and the six-waves-per-SIMD throughput form.  Each is forced here over frames that stress the
+    multi-wave protocol in different ways: long lines (helpers give up beyond their reach), 1280x960 (coarser shared map), noise (hundreds of
+    one-pixel regions per chunk: result slots run out), a ramp (regions beyond every helper limit) and an odd size."""
+    import ctypes as C
+    monkeypatch.setenv("SSLAM_LSD_FLAVOUR", flavour)
+    frames = [(synth_frame(2000), 200), (synth_frame(1235, w=1280, h=960), 400), (synth_frame(91, w=333, h=251), 200),
+              (noise_frame(3, w=320, h=240), 200), (ramp_frame(), 200)]
+    taken = 0
+    for img, cap in frames:
+        _cmp_lines(fe, ctx, oracle, img, cap)
+        if flavour == "mw":
+            ex = fe.LineExtractor(ctx, cap); ex(img)
+            out = (C.c_longlong * 8)(); fe.lib().sslam_lines_debug_cycles(ex.h, 0, out); ex.close()
+            taken += out[5] & 0xFFFFFFFF
+    if flavour == "mw":
+        assert taken > 1000, "the multi-wave form took almost no region from its helpers: %d" % taken
+
+
+@pytest.mark.parametrize("knobs", [{"SSLAM_LSD_HELPERS": "1"}, {"SSLAM_LSD_HELPERS": "3", "SSLAM_MW_SMAP": "-1"}, {"SSLAM_MW_SMAP": "0"}, {"SSLAM_MW_SMAP": "2"}])
+def test_lsd_multiwave_configurations(fe, ctx, oracle, knobs, monkeypatch):
+    """fewer helpers, no / exact / coarser shared map: the schedule changes completely, the output must not"""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("SSLAM_LSD_FLAVOUR", "mw")
+    for img, cap in [(synth_frame(2000), 200), (synth_frame(77, w=800, h=600), 300)]:
+        _cmp_lines(fe, ctx, oracle, img, cap)
+
+
+def test_lsd_multiwave_batch(fe, ctx, oracle):
+    """up to 256 frames per call take the multi-wave form, one workgroup per frame: results per frame as for single calls"""
+    frames = [synth_frame(3000 + i) for i in range(12)]
+    ex = fe.LineExtractor(ctx, 200)
+    try:
+        dev = torch.from_numpy(np.stack(frames)).cuda()
+        nf, cap = len(frames), 256
+        d_kl = torch.zeros(nf * cap * 68, dtype=torch.uint8, device="cuda"); d_ld = torch.zeros(nf * cap * 32, dtype=torch.uint8, device="cuda")
+        d_fn = torch.zeros(nf * cap * 3, dtype=torch.float64, device="cuda"); d_n = torch.zeros(nf, dtype=torch.int32, device="cuda")
+        ex.extract_batch_dev(dev, 640, 480, 640, 640 * 480, nf, d_kl, d_ld, d_fn, d_n, cap)
+        torch.cuda.synchronize()
+        for i, f in enumerate(frames):
+            okl, old, ofn, oraw = oracle.lines_extract(f, 200)
+            np.testing.assert_array_equal(ex.debug_segments(i), oraw, err_msg="frame %d" % i)
+    finally:
+        ex.close()

@@ -20,7 +20,7 @@ for it, img, nfeat, nlev, sf, ini, mn, cap in cases(n, rng):
         same = raw.shape == oraw.shape and np.array_equal(raw, oraw)
         nbad += not same
         if os.environ.get("MW_STATS"):
-            names = ["taken", "no result", "", "point used", "refine event", "", "", "own chunk"]
+            names = ["taken", "own (no region or not valid)", "", "", "", "", "", "own >= 100 points"]
             why = [(out[3 + c // 4] >> (16 * (c % 4))) & 0xFFFF for c in range(8)]
             print("   helper skips: in map at scan %d, used at turn %d, in map at turn %d, results full %d, arena full %d, growth gave up %d, refine gave up %d, main passed %d" % tuple(why))
             print("   " + "  ".join("%s %d/%dpx" % (names[c], out[c] & 0xFFFFFFFF, out[c] >> 32) for c in (0, 1, 7)) + "   main %.2f Mcyc, helpers busy %.2f idle %.2f Mcyc" % (out[2] / 1e6, out[5] / 1e6, out[6] / 1e6))
