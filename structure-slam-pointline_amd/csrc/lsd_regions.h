@@ -437,18 +437,19 @@ __device__ __forceinline__ double dist_d(double x1, double y1, double x2, double
 constexpr int MW_HMAX = 6;          // helper waves
 
 constexpr int MW_NSLOT = 2;         // chunks a helper can have published and not yet passed by the main wave
-#ifndef SSLAM_MW_ARENA
-#define SSLAM_MW_ARENA 1536
+#ifndef SSLAM_MW_RING
+#define SSLAM_MW_RING 3072
 #endif
-constexpr int MW_ARENA = SSLAM_MW_ARENA;      // list words per chunk slot (points of every list + 24 words per rectangle)
+constexpr int MW_RING = SSLAM_MW_RING;        // list words per helper, shared by its chunks (points of every list + 24 words per rectangle)
 constexpr int MW_RES = 16;          // regions a helper can publish per chunk
+constexpr int MW_WANT = QCAP / 2 + 24;      // ring space a helper waits for before it starts a region (while older chunks can still retire)
 constexpr int MW_EV = 16;           // refine events kept
 // A published seed.  Lists in the helper's arena from `off`: A = the region as first grown (nA points); if refine() ran, B = the region
 // re-grown at the refined tolerance (nB), and if reduce_region_radius ran, F = what it left of B (nF).  The pixels that end up USED are the
 // last list's; A and B are what the helper accepted on the way, i.e. what must still be unused for the result to stand.
 constexpr int MW_REFINED = 1, MW_REDUCED = 2, MW_EMIT = 4;
 struct MwRes { int lane, off, nA, nB, nF, flags, startSeq, lo, hi, pad; };       // lo = x0 | y0 << 16, hi = x1 | y1 << 16: box of A and B; the rectangle (MW_EMIT) follows the lists
-struct MwSlot { int chunkPos, nres, doneLane, used; MwRes res[MW_RES]; };
+struct MwSlot { int chunkPos, nres, doneLane, begin; MwRes res[MW_RES]; };      // begin: where the chunk's lists start in the helper's ring
 struct MwCtl { int cursor, finished, unmarkSeq, mainPos; int evLo[MW_EV], evHi[MW_EV]; unsigned long long helperIdle, helperBusy; int why[8]; };
 struct MwShared {
     MwCtl* ctl; MwSlot* slots; unsigned* arena; unsigned* specMap; int specW, specShift; int nHelpers;      // specShift: log2 of the shared map's cell edge, < 0: no map
@@ -676,7 +677,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                 if (hit) {
                     const MwRes* r = &S->res[__ffsll((long long)hit) - 1];
                     const int nA = r->nA, nB = r->nB, nF = r->nF, flags = r->flags, startSeq = r->startSeq;
-                    const unsigned* lstA = mw.arena + (size_t)owner * MW_ARENA + r->off;
+                    const unsigned* lstA = mw.arena + (size_t)(owner / MW_NSLOT) * MW_RING + r->off;
                     const unsigned* lstB = lstA + nA;
                     const unsigned* lstF = (flags & MW_REDUCED) ? lstB + nB : (flags & MW_REFINED) ? lstB : lstA;
                     bool ok = unmarkSeq - startSeq <= MW_EV;
@@ -717,7 +718,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                 mwOwn += 1 + ((long long)n << 32);
 #ifdef SSLAM_MW_STATS
                 mwCause[cause] += 1 + ((long long)n << 32);
-                if (n >= 100) mwBig += 1 + ((long long)n << 32);
+                if (n >= 100) mwBig += 1ll << (cause == 1 ? 0 : cause == 3 ? 16 : cause == 4 ? 32 : 48);
                 if (n <= 2) mwTiny += 1 + ((long long)n << 32);
 #endif
             }
@@ -797,24 +798,64 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
     const Misc* misc = (const Misc*)(base + P.offMisc);
     const int sw = P.sw, sh = P.sh, nOrd = misc->nDefined;
     MwCtl* ctl = mw.ctl;
+    MwSlot* slots = &mw.slots[h * MW_NSLOT];
+    unsigned* ring = mw.arena + (size_t)h * MW_RING;
+#ifdef SSLAM_MW_STATS
+#define SSLAM_MW_WHY(i, v) do { if (lane == 0) atomicAdd(&ctl->why[i], (v)); } while (0)
+#else
+#define SSLAM_MW_WHY(i, v)
+#endif
     for (int i = lane; i < MW_BM_WORDS; i += 64) bm[i] = 0u;
-    for (int turn = 0;; turn = (turn + 1) % MW_NSLOT) {
-        // ---- the older of this helper's slots: free once the main wave has passed its chunk; its regions then leave the shared map
-        MwSlot* S = &mw.slots[h * MW_NSLOT + turn];
-        unsigned* arena = mw.arena + (size_t)(h * MW_NSLOT + turn) * MW_ARENA;
+    // The lists of this helper's chunks live in ONE ring of MW_RING words, allocated front to back: the chunks the main wave has not passed
+    // occupy the band [tail, head).  reap() retires the chunks it has passed (their regions leave the shared map, the slot is free again)
+    // and returns the band's tail, or -1 when nothing is outstanding.
+    int head = 0;
+    const MwSlot* cur = nullptr;           // the slot being filled is never retired from inside its own loop
+    auto reap = [&]() -> int {
+        const int mp = lds_ld(&ctl->mainPos);
+        int tailChunk = 0x7FFFFFFF, tail = -1;
+        for (int j = 0; j < MW_NSLOT; ++j) {
+            MwSlot* T = &slots[j];
+            const int cp = T->chunkPos;
+            if (cp < 0) continue;
+            if (mp > cp && T != cur) {
+                if (mw.specShift >= 0)
+                    for (int kk = 0; kk < T->nres; ++kk) {
+                        const MwRes* r = &T->res[kk];
+                        const unsigned* lstF = ring + r->off + ((r->flags & MW_REDUCED) ? r->nA + r->nB : (r->flags & MW_REFINED) ? r->nA : 0);
+                        for (int i = lane; i < r->nF; i += 64) { const unsigned e = lstF[i]; const int cl = mw.cell((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&mw.specMap[cl >> 5], ~(1u << (cl & 31))); }
+                    }
+                lds_st(&T->chunkPos, -1);
+            } else if (cp < tailChunk) { tailChunk = cp; tail = T->begin; }
+        }
+        return tail;
+    };
+    // words that can be written at `head` in one piece without touching the band (one word stays free so that head == tail means empty);
+    // moves head to the front of the ring when the piece there is the larger one
+    auto contiguous = [&](int tail) -> int {
+        if (tail < 0) { head = 0; return MW_RING; }
+        if (head < tail) return tail - head - 1;
+        int cap = MW_RING - head;
+        if (tail - 1 > cap) { head = 0; cap = tail - 1; }
+        return cap;
+    };
+    for (;;) {
+        // ---- a free slot
+        MwSlot* S = nullptr;
+        cur = nullptr;
 #ifdef SSLAM_MW_STATS
         const long long tIdle0 = __builtin_readcyclecounter();
 #endif
-        while (S->chunkPos >= 0 && lds_ld(&ctl->mainPos) <= S->chunkPos && !lds_ld(&ctl->finished)) __builtin_amdgcn_s_sleep(2);
+        for (;;) {
+            if (lds_ld(&ctl->finished)) return;
+            reap();
+            for (int j = 0; j < MW_NSLOT; ++j) if (slots[j].chunkPos < 0) S = &slots[j];
+            if (S) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
 #ifdef SSLAM_MW_STATS
         if (lane == 0) atomicAdd(&ctl->helperIdle, (unsigned long long)(__builtin_readcyclecounter() - tIdle0));
 #endif
-        if (S->chunkPos >= 0 && mw.specShift >= 0)
-            for (int kk = 0; kk < S->nres; ++kk) {
-                const MwRes* r = &S->res[kk];
-                const unsigned* lstF = arena + r->off + ((r->flags & MW_REDUCED) ? r->nA + r->nB : (r->flags & MW_REFINED) ? r->nA : 0);
-                for (int i = lane; i < r->nF; i += 64) { const unsigned e = lstF[i]; const int cl = mw.cell((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&mw.specMap[cl >> 5], ~(1u << (cl & 31))); }
-            }
         // ---- claim the next chunk nobody has
         int c;
         for (;;) {
@@ -828,107 +869,112 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
 #ifdef SSLAM_MW_STATS
         const long long tClaim = __builtin_readcyclecounter();
 #endif
-        if (lane == 0) { S->nres = 0; S->doneLane = 0; S->used = 0; }
+        contiguous(reap());                                    // (resets head when nothing is outstanding)
+        if (lane == 0) { S->nres = 0; S->doneLane = 0; S->begin = head; }
         lds_st(&S->chunkPos, c);
+        cur = S;
         // ---- the chunk's seed candidates as this wave sees them now
         const int q = c + lane;
         const int idx = q < nOrd ? (int)order[q] : -1;
         const int cy = max(idx, 0) / sw, cx = max(idx, 0) - cy * sw;
-#ifdef SSLAM_MW_STATS
-#define SSLAM_MW_WHY(i, v) do { if (lane == 0) atomicAdd(&ctl->why[i], (v)); } while (0)
-#else
-#define SSLAM_MW_WHY(i, v)
-#endif
         // Pass 0 grows the seeds that are unused and outside every speculative region, in order.  While the main wave is still in front of
-        // the chunk and this helper has nowhere else to go (its other slot not passed yet), it keeps looking again: whatever is unused by
-        // then and still has no region -- seeds the shared map had talked it out of, pixels a refine() released -- is grown as well, so
-        // that the main wave finds a region for (nearly) every seed instead of growing those itself.
-        const MwSlot* other = &mw.slots[h * MW_NSLOT + (turn + 1) % MW_NSLOT];
+        // the chunk and this helper has nowhere else to go (no free slot), it keeps looking again: whatever is unused by then and still has
+        // no region -- seeds the shared map had talked it out of, pixels a refine() released -- is grown as well, so that the main wave
+        // finds a region for (nearly) every seed instead of growing those itself.
         unsigned long long haveRes = 0;      // seeds with a region, or that this helper gave up on
-        int off = 0, k = 0; bool room = true;
+        int k = 0; bool room = true;
         for (int pass = 0; room; ++pass) {
-        if (pass > 0) {
-            const int oc = other->chunkPos, mp = lds_ld(&ctl->mainPos);
-            if (mp >= c || lds_ld(&ctl->finished) || oc < 0 || mp > oc) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-        const float a0 = idx >= 0 ? pix[idx].x : -1.f;
-        unsigned long long unM = __ballot(a0 >= 0.f && (pass > 0 || !mw.spec(cx, cy))) & ~haveRes;
-        if (pass == 0) SSLAM_MW_WHY(0, __popcll(__ballot(a0 >= 0.f && mw.spec(cx, cy))));
-        if (unM) {
-            const double ar = (double)a0 * DEG2RAD;
-            stash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
-        }
-        while (unM) {
-            if (lds_ld(&ctl->mainPos) > c || lds_ld(&ctl->finished)) { SSLAM_MW_WHY(7, 1 + __popcll(unM)); break; }
-            const int first = __ffsll((long long)unM) - 1;
-            unM &= unM - 1;
-            const float4 sd = stash[first];
-            const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
-            const int startSeq = lds_ld(&ctl->unmarkSeq);      // sampled BEFORE the first pixel of this region is read
-            if (pix[sy * sw + sx].x < 0.f) { SSLAM_MW_WHY(1, 1); continue; }           // taken since the chunk was scanned (a region in front of it, committed meanwhile)
-            if (pass == 0 && mw.spec(sx, sy)) { SSLAM_MW_WHY(2, 1); continue; }         // ... or about to be
-            RegQ rq; rq.lds = arena + off; rq.glb = nullptr;
-            const int capN = min(QCAP, MW_ARENA - 24 - off);
-            double regAngle = 0;
-            if (k >= MW_RES || capN <= 64) { SSLAM_MW_WHY(k >= MW_RES ? 3 : 4, 1 + __popcll(unM)); room = false; break; }                // no room left: the main wave grows the rest of the chunk itself
-            int n = region_grow_w<true, false, true>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, P.prec, regAngle, nullptr, bm, capN);
-            if (n < 0) {                                        // too long for a helper: release its marks, the main wave grows this one
-                for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
-                SSLAM_MW_WHY(5, 1); haveRes |= 1ull << first;
-                continue;
+            if (pass > 0) {
+                reap();
+                bool freeSlot = false;
+                for (int j = 0; j < MW_NSLOT; ++j) freeSlot |= slots[j].chunkPos < 0;
+                if (freeSlot || lds_ld(&ctl->mainPos) >= c || lds_ld(&ctl->finished)) break;
+                __builtin_amdgcn_s_sleep(8);
             }
-            // ---- the rest of flsd()'s per-seed body on the private marks: region2rect, refine()
-            const int nA = n;
-            unsigned* lstA = rq.lds;
-            SpecLists sl; sl.bm = bm; sl.free = lstA + nA; sl.cap = MW_ARENA - 24 - off - nA; sl.nB = 0; sl.reduced = false; sl.gaveUp = false;
-            bool emit = false, refined = false; unsigned dLo = 0, dHi = 0; long long cycs[3];
-            RectD rec;
-            if (n >= P.minRegSize) {
-                emit = rect_refine<true, true, false>(P, sd, n, regAngle, rq, pix, ang, red, rec, refined, dLo, dHi, cycs, &sl, nullptr);
-                if (sl.gaveUp) { SSLAM_MW_WHY(6, 1); haveRes |= 1ull << first; continue; }                        // its marks are released; the main wave handles this seed
+            const float a0 = idx >= 0 ? pix[idx].x : -1.f;
+            unsigned long long unM = __ballot(a0 >= 0.f && (pass > 0 || !mw.spec(cx, cy))) & ~haveRes;
+            if (pass == 0) SSLAM_MW_WHY(0, __popcll(__ballot(a0 >= 0.f && mw.spec(cx, cy))));
+            if (unM) {
+                const double ar = (double)a0 * DEG2RAD;
+                stash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
             }
-            // marks still set: the final list (rq.lds[0..n)).  They go -- the next region is grown on its own.
-            for (int i = lane; i < n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
-            const int nAB = nA + sl.nB;
-            int total = nAB + (sl.reduced ? n : 0);
-            if (emit) {                                         // the rectangle follows the lists
-                if (lane == 0) {
-                    int* rw = (int*)(lstA + total); const double* rd = (const double*)&rec;
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) { rw[2 * j] = __double2loint(rd[j]); rw[2 * j + 1] = __double2hiint(rd[j]); }
+            while (unM) {
+                if (lds_ld(&ctl->mainPos) > c || lds_ld(&ctl->finished)) { SSLAM_MW_WHY(7, 1 + __popcll(unM)); room = false; break; }
+                const int first = __ffsll((long long)unM) - 1;
+                unM &= unM - 1;
+                const float4 sd = stash[first];
+                const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
+                const int startSeq = lds_ld(&ctl->unmarkSeq);      // sampled BEFORE the first pixel of this region is read
+                if (pix[sy * sw + sx].x < 0.f) { SSLAM_MW_WHY(1, 1); continue; }           // taken since the chunk was scanned (a region in front of it, committed meanwhile)
+                if (pass == 0 && mw.spec(sx, sy)) { SSLAM_MW_WHY(2, 1); continue; }         // ... or about to be
+                // room for a region of some size, or as much as there will ever be: older chunks of this helper still in the ring are
+                // retired as the main wave passes them -- waiting for that beats abandoning a seed (the main wave would grow it itself)
+                int tail = reap(), space = contiguous(tail);          // may move head
+                while (space < MW_WANT && tail >= 0 && tail != S->begin && !lds_ld(&ctl->finished) && lds_ld(&ctl->mainPos) <= c) {
+                    __builtin_amdgcn_s_sleep(4);
+                    tail = reap(); space = contiguous(tail);
                 }
-                total += 24;
+                const int capN = min(QCAP, space - 24);
+                if (k >= MW_RES || capN <= 64) { SSLAM_MW_WHY(k >= MW_RES ? 3 : 4, 1 + __popcll(unM)); room = false; break; }      // no room left: the main wave grows the rest itself
+                RegQ rq; rq.lds = ring + head; rq.glb = nullptr;
+                double regAngle = 0;
+                int n = region_grow_w<true, false, true>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, P.prec, regAngle, nullptr, bm, capN);
+                if (n < 0) {                                        // too long for a helper: release its marks, the main wave grows this one
+                    for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
+                    SSLAM_MW_WHY(5, 1); haveRes |= 1ull << first;
+                    continue;
+                }
+                // ---- the rest of flsd()'s per-seed body on the private marks: region2rect, refine()
+                const int nA = n;
+                unsigned* lstA = rq.lds;
+                SpecLists sl; sl.bm = bm; sl.free = lstA + nA; sl.cap = space - 24 - nA; sl.nB = 0; sl.reduced = false; sl.gaveUp = false;
+                bool emit = false, refined = false; unsigned dLo = 0, dHi = 0; long long cycs[3];
+                RectD rec;
+                if (n >= P.minRegSize) {
+                    emit = rect_refine<true, true, false>(P, sd, n, regAngle, rq, pix, ang, red, rec, refined, dLo, dHi, cycs, &sl, nullptr);
+                    if (sl.gaveUp) { SSLAM_MW_WHY(6, 1); haveRes |= 1ull << first; continue; }      // its marks are released; the main wave handles this seed
+                }
+                // marks still set: the final list (rq.lds[0..n)).  They go -- the next region is grown on its own.
+                for (int i = lane; i < n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
+                const int nAB = nA + sl.nB;
+                int total = nAB + (sl.reduced ? n : 0);
+                if (emit) {                                         // the rectangle follows the lists
+                    if (lane == 0) {
+                        int* rw = (int*)(lstA + total); const double* rd = (const double*)&rec;
+#pragma unroll
+                        for (int j = 0; j < 12; ++j) { rw[2 * j] = __double2loint(rd[j]); rw[2 * j + 1] = __double2hiint(rd[j]); }
+                    }
+                    total += 24;
+                }
+                unsigned lo, hi;
+                list_bbox(lstA, nAB, lane, lo, hi);
+                if (lane == 0) {
+                    MwRes& r = S->res[k];
+                    r.lane = first; r.off = head; r.nA = nA; r.nB = sl.nB; r.nF = n; r.startSeq = startSeq; r.lo = (int)lo; r.hi = (int)hi;
+                    r.flags = (refined ? MW_REFINED : 0) | (sl.reduced ? MW_REDUCED : 0) | (emit ? MW_EMIT : 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                ++k; head += total; haveRes |= 1ull << first;
+                lds_st(&S->nres, k);
+                if (pass == 0) lds_st(&S->doneLane, first + 1);
+                // what the region leaves USED enters the shared map that steers seed choice; candidates of this chunk inside it are dropped
+                for (int i = lane; i < n; i += 64) {
+                    if (mw.specShift < 0) break;
+                    const unsigned e = rq.lds[i]; const int cl = mw.cell((int)(e & 0xFFFF), (int)(e >> 16));
+                    atomicOr(&mw.specMap[cl >> 5], 1u << (cl & 31));
+                }
+                if (n > 1 && pass == 0) unM &= ~__ballot(idx >= 0 && mw.spec(cx, cy));
             }
-            unsigned lo, hi;
-            list_bbox(lstA, nAB, lane, lo, hi);
-            if (lane == 0) {
-                MwRes& r = S->res[k];
-                r.lane = first; r.off = off; r.nA = nA; r.nB = sl.nB; r.nF = n; r.startSeq = startSeq; r.lo = (int)lo; r.hi = (int)hi;
-                r.flags = (refined ? MW_REFINED : 0) | (sl.reduced ? MW_REDUCED : 0) | (emit ? MW_EMIT : 0);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            ++k; off += total; haveRes |= 1ull << first;
-            lds_st(&S->nres, k);
-            if (pass == 0) lds_st(&S->doneLane, first + 1);
-            // what the region leaves USED enters the shared map that steers seed choice; candidates of this chunk inside it are dropped
-            for (int i = lane; i < n; i += 64) {
-                if (mw.specShift < 0) break;
-                const unsigned e = rq.lds[i]; const int cl = mw.cell((int)(e & 0xFFFF), (int)(e >> 16));
-                atomicOr(&mw.specMap[cl >> 5], 1u << (cl & 31));
-            }
-            if (n > 1 && pass == 0) unM &= ~__ballot(idx >= 0 && mw.spec(cx, cy));
+            if (pass == 0) lds_st(&S->doneLane, 64);
         }
-        if (pass == 0) lds_st(&S->doneLane, 64);
-        }
-        if (lane == 0) S->used = off;
+        lds_st(&S->doneLane, 64);
 #ifdef SSLAM_MW_STATS
         if (lane == 0) atomicAdd(&ctl->helperBusy, (unsigned long long)(__builtin_readcyclecounter() - tClaim));
 #endif
     }
 }
 
-// dynamic LDS: [main queue QCAP + 4][arena nHelpers x MW_NSLOT x MW_ARENA][bitmaps nHelpers x MW_BM_WORDS][shared coarse map specWords]
+// dynamic LDS: [main queue QCAP + 4][rings nHelpers x MW_RING][bitmaps nHelpers x MW_BM_WORDS][shared coarse map specWords]
 __global__ __launch_bounds__(64 * (1 + MW_HMAX)) void k_lsd_regions_mw(uint8_t* __restrict__ ws, LsdPlan P, int nHelpers, int specWords, int specShift) {
     extern __shared__ __align__(16) unsigned dynLds[];
     __shared__ double red[3 * 64];
@@ -939,12 +985,12 @@ __global__ __launch_bounds__(64 * (1 + MW_HMAX)) void k_lsd_regions_mw(uint8_t* 
     __shared__ MwSlot slots[MW_HMAX * MW_NSLOT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; ctl.helperIdle = 0; ctl.helperBusy = 0; for (int c = 0; c < 8; ++c) ctl.why[c] = 0; }
-    if (threadIdx.x < MW_HMAX * MW_NSLOT) { slots[threadIdx.x].chunkPos = -1; slots[threadIdx.x].nres = 0; slots[threadIdx.x].doneLane = 0; slots[threadIdx.x].used = 0; }
+    if (threadIdx.x < MW_HMAX * MW_NSLOT) { slots[threadIdx.x].chunkPos = -1; slots[threadIdx.x].nres = 0; slots[threadIdx.x].doneLane = 0; slots[threadIdx.x].begin = 0; }
     MwShared mw; mw.ctl = &ctl; mw.slots = slots; mw.arena = dynLds + QCAP + 4; mw.nHelpers = nHelpers;
-    mw.specMap = mw.arena + (size_t)nHelpers * (MW_NSLOT * MW_ARENA + MW_BM_WORDS); mw.specShift = specShift; mw.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
+    mw.specMap = mw.arena + (size_t)nHelpers * (MW_RING + MW_BM_WORDS); mw.specShift = specShift; mw.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
     for (int i = threadIdx.x; i < specWords; i += blockDim.x) mw.specMap[i] = 0u;
     __syncthreads();
     const int b = blockIdx.x;
     if (wave == 0) lsd_regions_body<true, true>(ws, P, b, dynLds, red, seedStash, mw);
-    else if (wave <= nHelpers) mw_helper(wave - 1, ws, P, b, mw, dynLds + QCAP + 4 + (size_t)nHelpers * MW_NSLOT * MW_ARENA + (size_t)(wave - 1) * MW_BM_WORDS, helperStash[wave - 1], helperRed[wave - 1]);
+    else if (wave <= nHelpers) mw_helper(wave - 1, ws, P, b, mw, dynLds + QCAP + 4 + (size_t)nHelpers * MW_RING + (size_t)(wave - 1) * MW_BM_WORDS, helperStash[wave - 1], helperRed[wave - 1]);
 }
