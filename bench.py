@@ -191,9 +191,25 @@ def latency_leg(fe, ctx, frames, with_lines, nframes=120):
     ox.close()
     if lx: lx.close()
     pct = lambda a: {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "max": float(a.max())}
-    return {"unit": "ms", "frames": nframes, "path": "sslam_orb_extract + sslam_lines_extract per frame (host image in, host results out)",
-            "orb_extract_hipEvent": pct(orb), "lines_extract_hipEvent": pct(lin) if with_lines else None, "frame_hipEvent": pct(orb + lin), "frame_wall": pct(wall),
-            "frames_per_s_one_at_a_time": float(1e3 / np.median(wall))}
+    out = {"unit": "ms", "frames": nframes, "path": "sslam_orb_extract + sslam_lines_extract per frame (host image in, host results out)",
+           "lsd_core": "multi-wave (one main wave + helper waves per frame)",
+           "orb_extract_hipEvent": pct(orb), "lines_extract_hipEvent": pct(lin) if with_lines else None, "frame_hipEvent": pct(orb + lin), "frame_wall": pct(wall),
+           "frames_per_s_one_at_a_time": float(1e3 / np.median(wall))}
+    if with_lines and not os.environ.get("SSLAM_LSD_FLAVOUR"):
+        # the same call with the sequential core forced to its lone-wave form (what a single frame got before the multi-wave form existed)
+        os.environ["SSLAM_LSD_FLAVOUR"] = "lat"
+        try:
+            lx = fe.LineExtractor(ctx, NLINES); lone = []
+            for i in range(3 + min(nframes, 48)):
+                f = frames[i % len(frames)]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st); lx(f); e1.record(st); torch.cuda.synchronize()
+                if i >= 3: lone.append(e0.elapsed_time(e1))
+            lx.close()
+            out["lines_extract_lone_wave_hipEvent"] = pct(np.array(lone))
+        finally:
+            del os.environ["SSLAM_LSD_FLAVOUR"]
+    return out
 
 
 def pcie_leg(fe, ctx, frames, with_lines, n=2048, chunk=1024):

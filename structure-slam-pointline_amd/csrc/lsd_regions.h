@@ -444,6 +444,7 @@ constexpr int MW_RING = SSLAM_MW_RING;        // list words per helper, shared b
 constexpr int MW_RES = 16;          // regions a helper can publish per chunk
 constexpr int MW_WANT = QCAP / 2 + 24;      // ring space a helper waits for before it starts a region (while older chunks can still retire)
 constexpr int MW_EV = 16;           // refine events kept
+constexpr int MW_SPIN_LIMIT = 1 << 21;      // polls (tens of milliseconds) before the main wave stops waiting for a helper
 // A published seed.  Lists in the helper's arena from `off`: A = the region as first grown (nA points); if refine() ran, B = the region
 // re-grown at the refined tolerance (nB), and if reduce_region_radius ran, F = what it left of B (nF).  The pixels that end up USED are the
 // last list's; A and B are what the helper accepted on the way, i.e. what must still be unused for the result to stand.
@@ -649,9 +650,11 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                 if (c > pos0) { owner = -2; break; }
                 if (lds_cas_uniform(&mw.ctl->cursor, c, pos0 + 64, lane) == c) break;
             }
-            while (owner == -2) {                             // the claimant publishes its slot right after the CAS
+            // the claimant publishes its slot right after the CAS.  Every wait of the main wave is bounded: if a helper ever failed to show up
+            // the main wave would go on alone (Misc::cyc[7] counts it; the tests require zero)
+            for (int spin = 0; owner == -2; ++spin) {
                 for (int h = 0; h < mw.nHelpers * MW_NSLOT; ++h) if (lds_ld(&mw.slots[h].chunkPos) == pos0) owner = h;
-                if (owner == -2) __builtin_amdgcn_s_sleep(1);
+                if (owner == -2) { if (spin > MW_SPIN_LIMIT) { owner = -1; ++mwBadChunks; } else __builtin_amdgcn_s_sleep(1); }
             }
         }
         while (unM) {
@@ -668,9 +671,11 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
 #endif
             if (MW && owner >= 0) {
                 MwSlot* S = &mw.slots[owner];
-                while (lds_ld(&S->doneLane) <= first) __builtin_amdgcn_s_sleep(1);
+                int spin = 0;
+                while (lds_ld(&S->doneLane) <= first && spin <= MW_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); ++spin; }
+                if (spin > MW_SPIN_LIMIT) { owner = -1; ++mwBadChunks; }
                 const long long tw = SSLAM_CLK(); cycWait += tw - t0;
-                const int nres = lds_ld(&S->nres);
+                const int nres = owner >= 0 ? lds_ld(&S->nres) : 0;
                 // the helper's regions are in no particular order (it may have looked at the chunk more than once)
                 const unsigned long long hit = __ballot(lane < nres && S->res[min(lane, MW_RES - 1)].lane == first);
                 SSLAM_MW_CAUSE(1);

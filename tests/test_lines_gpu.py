@@ -123,6 +123,7 @@ def test_lsd_core_flavours(fe, ctx, oracle, flavour, monkeypatch):
             ex = fe.LineExtractor(ctx, cap); ex(img)
             out = (C.c_longlong * 8)(); fe.lib().sslam_lines_debug_cycles(ex.h, 0, out); ex.close()
             taken += out[5] & 0xFFFFFFFF
+            assert out[7] == 0, "the main wave gave up waiting for a helper"
     if flavour == "mw":
         assert taken > 1000, "the multi-wave form took almost no region from its helpers: %d" % taken
 
