@@ -240,7 +240,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         // a frame that gets a CU to itself: one main wave + helper waves running flsd()'s per-seed body ahead of it (lsd_regions.h, multi-wave form).
         // LDS: the kernel's static arrays + main queue, per helper its chunk slots and its private torus, and the shared map that steers the
         // helpers' seed choice (per 2 x 2 cell by default; SSLAM_MW_SMAP: -1 none, 0 one bit per pixel, 1 / 2 coarser)
-        const size_t mwBase = lds + 28 * 1024, perHelper = sizeof(unsigned) * ((size_t)MW_RING + MW_BM_WORDS);
+        const size_t mwBase = lds + sizeof(MwSlot) * MW_HMAX * MW_NSLOT + 20 * 1024, perHelper = sizeof(unsigned) * ((size_t)MW_RING + MW_BM_WORDS);
         int specShift = 1, specWords = 0, nHelpers = 0;
         if (const char* e = getenv("SSLAM_MW_SMAP")) specShift = atoi(e);
         for (; specShift <= 3; ++specShift) {

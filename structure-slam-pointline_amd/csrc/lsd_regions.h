@@ -434,14 +434,25 @@ __device__ __forceinline__ double dist_d(double x1, double y1, double x2, double
 //   * regions published but not yet taken are recorded in a coarse shared map (2 x 2 pixel cells) that only steers the helpers' choice of
 //     seeds -- a seed inside somebody's speculative region will most likely be taken by then -- and never enters a region's growth.
 // Stale or torn views only ever cost a fallback: the checks read the main wave's own stores.
-constexpr int MW_HMAX = 6;          // helper waves
+#ifndef SSLAM_MW_HMAX
+#define SSLAM_MW_HMAX 6
+#endif
+constexpr int MW_HMAX = SSLAM_MW_HMAX;          // helper waves
 
-constexpr int MW_NSLOT = 2;         // chunks a helper can have published and not yet passed by the main wave
+#ifndef SSLAM_MW_SUB
+#define SSLAM_MW_SUB 64
+#endif
+#ifndef SSLAM_MW_NSLOT
+#define SSLAM_MW_NSLOT 2
+#endif
+constexpr int MW_SUB = SSLAM_MW_SUB;          // order positions a helper claims at a time: 64 = the main wave's chunk (16 and 32 spread dense stretches of the
+                                    // seed list over several helpers -- half as many regions left to the main wave -- but the claims cost the helpers more than that returns: 9.1 / 8.6 / 8.4 ms)
+constexpr int MW_NSLOT = SSLAM_MW_NSLOT;         // claims a helper can have published and not yet passed by the main wave
 #ifndef SSLAM_MW_RING
 #define SSLAM_MW_RING 3072
 #endif
 constexpr int MW_RING = SSLAM_MW_RING;        // list words per helper, shared by its chunks (points of every list + 24 words per rectangle)
-constexpr int MW_RES = 16;          // regions a helper can publish per chunk
+constexpr int MW_RES = MW_SUB < 24 ? MW_SUB : 24;      // regions per claim
 constexpr int MW_WANT = QCAP / 2 + 24;      // ring space a helper waits for before it starts a region (while older chunks can still retire)
 constexpr int MW_EV = 16;           // refine events kept
 constexpr int MW_SPIN_LIMIT = 1 << 21;      // polls (tens of milliseconds) before the main wave stops waiting for a helper
@@ -449,9 +460,18 @@ constexpr int MW_SPIN_LIMIT = 1 << 21;      // polls (tens of milliseconds) befo
 // re-grown at the refined tolerance (nB), and if reduce_region_radius ran, F = what it left of B (nF).  The pixels that end up USED are the
 // last list's; A and B are what the helper accepted on the way, i.e. what must still be unused for the result to stand.
 constexpr int MW_REFINED = 1, MW_REDUCED = 2, MW_EMIT = 4;
-struct MwRes { int lane, off, nA, nB, nF, flags, startSeq, lo, hi, pad; };       // lo = x0 | y0 << 16, hi = x1 | y1 << 16: box of A and B; the rectangle (MW_EMIT) follows the lists
+struct MwRes {                      // 20 bytes; lo = x0 | y0 << 16, hi = x1 | y1 << 16: box of A and B; the rectangle (MW_EMIT) follows the lists
+    unsigned w0, w1, w2, lo, hi;    // lane | flags << 8 | (startSeq & 0xFFFF) << 16,  off | nA << 16,  nB | nF << 16
+    __device__ __forceinline__ int lane() const { return w0 & 0xFF; }
+    __device__ __forceinline__ int flags() const { return (w0 >> 8) & 0xFF; }
+    __device__ __forceinline__ int startSeq() const { return w0 >> 16; }
+    __device__ __forceinline__ int off() const { return w1 & 0xFFFF; }
+    __device__ __forceinline__ int nA() const { return w1 >> 16; }
+    __device__ __forceinline__ int nB() const { return w2 & 0xFFFF; }
+    __device__ __forceinline__ int nF() const { return w2 >> 16; }
+};
 struct MwSlot { int chunkPos, nres, doneLane, begin; MwRes res[MW_RES]; };      // begin: where the chunk's lists start in the helper's ring
-struct MwCtl { int cursor, finished, unmarkSeq, mainPos; int evLo[MW_EV], evHi[MW_EV]; unsigned long long helperIdle, helperBusy; int why[8]; };
+struct MwCtl { int cursor, finished, unmarkSeq, mainPos; int evLo[MW_EV], evHi[MW_EV]; unsigned long long helperIdle, helperBusy; int why[8]; unsigned long long hcyc[8]; };
 struct MwShared {
     MwCtl* ctl; MwSlot* slots; unsigned* arena; unsigned* specMap; int specW, specShift; int nHelpers;      // specShift: log2 of the shared map's cell edge, < 0: no map
     __device__ __forceinline__ int cell(int x, int y) const { return (y >> specShift) * specW + (x >> specShift); }
@@ -642,20 +662,15 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             stashReady = true;
         };
         if (!MW) fill_stash();
-        // MW: whose chunk is this?  Below the cursor: a helper claimed it; otherwise the main wave takes it (and everything the cursor skipped)
-        int owner = -1;
-        if (MW) {
-            for (;;) {
-                const int c = lds_ld(&mw.ctl->cursor);
-                if (c > pos0) { owner = -2; break; }
-                if (lds_cas_uniform(&mw.ctl->cursor, c, pos0 + 64, lane) == c) break;
-            }
-            // the claimant publishes its slot right after the CAS.  Every wait of the main wave is bounded: if a helper ever failed to show up
-            // the main wave would go on alone (Misc::cyc[7] counts it; the tests require zero)
-            for (int spin = 0; owner == -2; ++spin) {
-                for (int h = 0; h < mw.nHelpers * MW_NSLOT; ++h) if (lds_ld(&mw.slots[h].chunkPos) == pos0) owner = h;
-                if (owner == -2) { if (spin > MW_SPIN_LIMIT) { owner = -1; ++mwBadChunks; } else __builtin_amdgcn_s_sleep(1); }
-            }
+        // MW: whose positions are these?  Helpers claim MW_SUB positions at a time from the cursor; what is still unclaimed of this chunk (and
+        // everything the cursor skipped) becomes the main wave's own.
+        unsigned mineMask = 0;                                // bit j: positions [pos0 + j * MW_SUB, + MW_SUB) are the main wave's
+        int owner = -1, ownerSub = -1;
+        if (MW) for (;;) {
+            const int c = lds_ld(&mw.ctl->cursor);
+            if (c >= pos0 + 64) break;
+            const int cc = max(c, pos0);
+            if (lds_cas_uniform(&mw.ctl->cursor, c, cc + MW_SUB, lane) == c) mineMask |= 1u << ((cc - pos0) / MW_SUB);
         }
         while (unM) {
             const int first = __ffsll((long long)unM) - 1;
@@ -669,6 +684,16 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
 #ifdef SSLAM_MW_STATS
             int cause = 7;                                      // 7: the main wave's own chunk
 #endif
+            if (MW && first / MW_SUB != ownerSub) {
+                // the claimant publishes its slot right after the CAS.  Every wait of the main wave is bounded: if a helper ever failed to show
+                // up the main wave would go on alone (Misc::cyc[7] counts it; the tests require zero)
+                ownerSub = first / MW_SUB;
+                owner = ((mineMask >> ownerSub) & 1u) ? -1 : -2;
+                for (int spin = 0; owner == -2; ++spin) {
+                    for (int h = 0; h < mw.nHelpers * MW_NSLOT; ++h) if (lds_ld(&mw.slots[h].chunkPos) == pos0 + ownerSub * MW_SUB) owner = h;
+                    if (owner == -2) { if (spin > MW_SPIN_LIMIT) { owner = -1; ++mwBadChunks; } else __builtin_amdgcn_s_sleep(1); }
+                }
+            }
             if (MW && owner >= 0) {
                 MwSlot* S = &mw.slots[owner];
                 int spin = 0;
@@ -677,18 +702,19 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                 const long long tw = SSLAM_CLK(); cycWait += tw - t0;
                 const int nres = owner >= 0 ? lds_ld(&S->nres) : 0;
                 // the helper's regions are in no particular order (it may have looked at the chunk more than once)
-                const unsigned long long hit = __ballot(lane < nres && S->res[min(lane, MW_RES - 1)].lane == first);
+                const unsigned long long hit = __ballot(lane < nres && S->res[min(lane, MW_RES - 1)].lane() == first);
                 SSLAM_MW_CAUSE(1);
                 if (hit) {
                     const MwRes* r = &S->res[__ffsll((long long)hit) - 1];
-                    const int nA = r->nA, nB = r->nB, nF = r->nF, flags = r->flags, startSeq = r->startSeq;
-                    const unsigned* lstA = mw.arena + (size_t)(owner / MW_NSLOT) * MW_RING + r->off;
+                    const int nA = r->nA(), nB = r->nB(), nF = r->nF(), flags = r->flags();
+                    const int startSeq = unmarkSeq - ((unmarkSeq - r->startSeq()) & 0xFFFF);      // the sample, 16 bits of it published
+                    const unsigned* lstA = mw.arena + (size_t)(owner / MW_NSLOT) * MW_RING + r->off();
                     const unsigned* lstB = lstA + nA;
                     const unsigned* lstF = (flags & MW_REDUCED) ? lstB + nB : (flags & MW_REFINED) ? lstB : lstA;
                     bool ok = unmarkSeq - startSeq <= MW_EV;
                     if (!ok) SSLAM_MW_CAUSE(4);
                     for (int sq = startSeq + 1; ok && sq <= unmarkSeq; ++sq) {
-                        ok = !boxes_meet((unsigned)r->lo, (unsigned)r->hi, (unsigned)mw.ctl->evLo[sq & (MW_EV - 1)], (unsigned)mw.ctl->evHi[sq & (MW_EV - 1)], 1);
+                        ok = !boxes_meet(r->lo, r->hi, (unsigned)mw.ctl->evLo[sq & (MW_EV - 1)], (unsigned)mw.ctl->evHi[sq & (MW_EV - 1)], 1);
                         if (!ok) SSLAM_MW_CAUSE(4);
                     }
                     // everything the helper accepted on the way (A, and B when refine() ran) must be unused now
@@ -776,7 +802,9 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
 #ifdef SSLAM_LSD_CYCLES
         if (MW) { misc->cyc[5] = cycWait; misc->cyc[6] = cycTake; misc->cyc[7] = cycOwn; }
 #endif
-#ifdef SSLAM_MW_STATS
+#ifdef SSLAM_MW_HCYC
+        if (MW) for (int c = 0; c < 8; ++c) misc->cyc[c] = (long long)mw.ctl->hcyc[c];
+#elif defined(SSLAM_MW_STATS)
         if (MW) { misc->cyc[0] = mwTaken; for (int c = 1; c < 8; ++c) misc->cyc[c] = mwCause[c]; misc->cyc[5] = (long long)mw.ctl->helperBusy; misc->cyc[6] = (long long)mw.ctl->helperIdle; misc->cyc[2] = SSLAM_CLK2() - tStart2; misc->cyc[7] = mwBig; misc->cyc[1] = mwCause[1] + mwCause[3] + mwCause[4];
                   long long w0 = 0, w1 = 0; for (int c = 0; c < 4; ++c) { w0 |= (long long)(mw.ctl->why[c] & 0xFFFF) << (16 * c); w1 |= (long long)(mw.ctl->why[4 + c] & 0xFFFF) << (16 * c); } misc->cyc[3] = w0; misc->cyc[4] = w1; }
 #endif
@@ -807,8 +835,11 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
     unsigned* ring = mw.arena + (size_t)h * MW_RING;
 #ifdef SSLAM_MW_STATS
 #define SSLAM_MW_WHY(i, v) do { if (lane == 0) atomicAdd(&ctl->why[i], (v)); } while (0)
+#define SSLAM_MW_T(i) do { const long long tn_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&ctl->hcyc[i], (unsigned long long)(tn_ - tPrev)); tPrev = tn_; } while (0)
+    long long tPrev = __builtin_readcyclecounter();
 #else
 #define SSLAM_MW_WHY(i, v)
+#define SSLAM_MW_T(i)
 #endif
     for (int i = lane; i < MW_BM_WORDS; i += 64) bm[i] = 0u;
     // The lists of this helper's chunks live in ONE ring of MW_RING words, allocated front to back: the chunks the main wave has not passed
@@ -827,8 +858,8 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 if (mw.specShift >= 0)
                     for (int kk = 0; kk < T->nres; ++kk) {
                         const MwRes* r = &T->res[kk];
-                        const unsigned* lstF = ring + r->off + ((r->flags & MW_REDUCED) ? r->nA + r->nB : (r->flags & MW_REFINED) ? r->nA : 0);
-                        for (int i = lane; i < r->nF; i += 64) { const unsigned e = lstF[i]; const int cl = mw.cell((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&mw.specMap[cl >> 5], ~(1u << (cl & 31))); }
+                        const unsigned* lstF = ring + r->off() + ((r->flags() & MW_REDUCED) ? r->nA() + r->nB() : (r->flags() & MW_REFINED) ? r->nA() : 0);
+                        for (int i = lane; i < r->nF(); i += 64) { const unsigned e = lstF[i]; const int cl = mw.cell((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&mw.specMap[cl >> 5], ~(1u << (cl & 31))); }
                     }
                 lds_st(&T->chunkPos, -1);
             } else if (cp < tailChunk) { tailChunk = cp; tail = T->begin; }
@@ -861,6 +892,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
 #ifdef SSLAM_MW_STATS
         if (lane == 0) atomicAdd(&ctl->helperIdle, (unsigned long long)(__builtin_readcyclecounter() - tIdle0));
 #endif
+        SSLAM_MW_T(0);
         // ---- claim the next chunk nobody has
         int c;
         for (;;) {
@@ -869,7 +901,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
             const int mp = lds_ld(&ctl->mainPos);
             if (c >= nOrd) return;
             if (c < mp) { lds_cas_uniform(&ctl->cursor, c, mp, lane); continue; }      // the main wave is already past it
-            if (lds_cas_uniform(&ctl->cursor, c, c + 64, lane) == c) break;
+            if (lds_cas_uniform(&ctl->cursor, c, c + MW_SUB, lane) == c) break;
         }
 #ifdef SSLAM_MW_STATS
         const long long tClaim = __builtin_readcyclecounter();
@@ -879,8 +911,8 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
         lds_st(&S->chunkPos, c);
         cur = S;
         // ---- the chunk's seed candidates as this wave sees them now
-        const int q = c + lane;
-        const int idx = q < nOrd ? (int)order[q] : -1;
+        const int q = c + lane, laneBase = c & 63;            // lanes are numbered as in the main wave's chunk of 64
+        const int idx = lane < MW_SUB && q < nOrd ? (int)order[q] : -1;
         const int cy = max(idx, 0) / sw, cx = max(idx, 0) - cy * sw;
         // Pass 0 grows the seeds that are unused and outside every speculative region, in order.  While the main wave is still in front of
         // the chunk and this helper has nowhere else to go (no free slot), it keeps looking again: whatever is unused by then and still has
@@ -890,11 +922,13 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
         int k = 0; bool room = true;
         for (int pass = 0; room; ++pass) {
             if (pass > 0) {
+                SSLAM_MW_T(7);
                 reap();
                 bool freeSlot = false;
                 for (int j = 0; j < MW_NSLOT; ++j) freeSlot |= slots[j].chunkPos < 0;
-                if (freeSlot || lds_ld(&ctl->mainPos) >= c || lds_ld(&ctl->finished)) break;
+                if (freeSlot || lds_ld(&ctl->mainPos) >= (c & ~63) || lds_ld(&ctl->finished)) break;
                 __builtin_amdgcn_s_sleep(8);
+                SSLAM_MW_T(6);
             }
             const float a0 = idx >= 0 ? pix[idx].x : -1.f;
             unsigned long long unM = __ballot(a0 >= 0.f && (pass > 0 || !mw.spec(cx, cy))) & ~haveRes;
@@ -903,6 +937,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 const double ar = (double)a0 * DEG2RAD;
                 stash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
             }
+            SSLAM_MW_T(1);
             while (unM) {
                 if (lds_ld(&ctl->mainPos) > c || lds_ld(&ctl->finished)) { SSLAM_MW_WHY(7, 1 + __popcll(unM)); room = false; break; }
                 const int first = __ffsll((long long)unM) - 1;
@@ -915,10 +950,11 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 // room for a region of some size, or as much as there will ever be: older chunks of this helper still in the ring are
                 // retired as the main wave passes them -- waiting for that beats abandoning a seed (the main wave would grow it itself)
                 int tail = reap(), space = contiguous(tail);          // may move head
-                while (space < MW_WANT && tail >= 0 && tail != S->begin && !lds_ld(&ctl->finished) && lds_ld(&ctl->mainPos) <= c) {
+                while (space < MW_WANT && tail >= 0 && tail != S->begin && !lds_ld(&ctl->finished) && lds_ld(&ctl->mainPos) < (c & ~63)) {      // (never once the main wave is AT this chunk: it may be waiting for us)
                     __builtin_amdgcn_s_sleep(4);
                     tail = reap(); space = contiguous(tail);
                 }
+                SSLAM_MW_T(2);
                 const int capN = min(QCAP, space - 24);
                 if (k >= MW_RES || capN <= 64) { SSLAM_MW_WHY(k >= MW_RES ? 3 : 4, 1 + __popcll(unM)); room = false; break; }      // no room left: the main wave grows the rest itself
                 RegQ rq; rq.lds = ring + head; rq.glb = nullptr;
@@ -929,6 +965,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                     SSLAM_MW_WHY(5, 1); haveRes |= 1ull << first;
                     continue;
                 }
+                SSLAM_MW_T(3);
                 // ---- the rest of flsd()'s per-seed body on the private marks: region2rect, refine()
                 const int nA = n;
                 unsigned* lstA = rq.lds;
@@ -939,6 +976,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                     emit = rect_refine<true, true, false>(P, sd, n, regAngle, rq, pix, ang, red, rec, refined, dLo, dHi, cycs, &sl, nullptr);
                     if (sl.gaveUp) { SSLAM_MW_WHY(6, 1); haveRes |= 1ull << first; continue; }      // its marks are released; the main wave handles this seed
                 }
+                SSLAM_MW_T(4);
                 // marks still set: the final list (rq.lds[0..n)).  They go -- the next region is grown on its own.
                 for (int i = lane; i < n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
                 const int nAB = nA + sl.nB;
@@ -955,13 +993,14 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 list_bbox(lstA, nAB, lane, lo, hi);
                 if (lane == 0) {
                     MwRes& r = S->res[k];
-                    r.lane = first; r.off = head; r.nA = nA; r.nB = sl.nB; r.nF = n; r.startSeq = startSeq; r.lo = (int)lo; r.hi = (int)hi;
-                    r.flags = (refined ? MW_REFINED : 0) | (sl.reduced ? MW_REDUCED : 0) | (emit ? MW_EMIT : 0);
+                    const unsigned flags = (refined ? MW_REFINED : 0) | (sl.reduced ? MW_REDUCED : 0) | (emit ? MW_EMIT : 0);
+                    r.w0 = (unsigned)(laneBase + first) | (flags << 8) | ((unsigned)(startSeq & 0xFFFF) << 16);
+                    r.w1 = (unsigned)head | ((unsigned)nA << 16); r.w2 = (unsigned)sl.nB | ((unsigned)n << 16); r.lo = lo; r.hi = hi;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 ++k; head += total; haveRes |= 1ull << first;
                 lds_st(&S->nres, k);
-                if (pass == 0) lds_st(&S->doneLane, first + 1);
+                if (pass == 0) lds_st(&S->doneLane, laneBase + first + 1);
                 // what the region leaves USED enters the shared map that steers seed choice; candidates of this chunk inside it are dropped
                 for (int i = lane; i < n; i += 64) {
                     if (mw.specShift < 0) break;
@@ -969,10 +1008,10 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                     atomicOr(&mw.specMap[cl >> 5], 1u << (cl & 31));
                 }
                 if (n > 1 && pass == 0) unM &= ~__ballot(idx >= 0 && mw.spec(cx, cy));
+                SSLAM_MW_T(5);
             }
             if (pass == 0) lds_st(&S->doneLane, 64);
         }
-        lds_st(&S->doneLane, 64);
 #ifdef SSLAM_MW_STATS
         if (lane == 0) atomicAdd(&ctl->helperBusy, (unsigned long long)(__builtin_readcyclecounter() - tClaim));
 #endif
@@ -989,7 +1028,7 @@ __global__ __launch_bounds__(64 * (1 + MW_HMAX)) void k_lsd_regions_mw(uint8_t* 
     __shared__ MwCtl ctl;
     __shared__ MwSlot slots[MW_HMAX * MW_NSLOT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; ctl.helperIdle = 0; ctl.helperBusy = 0; for (int c = 0; c < 8; ++c) ctl.why[c] = 0; }
+    if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; ctl.helperIdle = 0; ctl.helperBusy = 0; for (int c = 0; c < 8; ++c) { ctl.why[c] = 0; ctl.hcyc[c] = 0; } }
     if (threadIdx.x < MW_HMAX * MW_NSLOT) { slots[threadIdx.x].chunkPos = -1; slots[threadIdx.x].nres = 0; slots[threadIdx.x].doneLane = 0; slots[threadIdx.x].begin = 0; }
     MwShared mw; mw.ctl = &ctl; mw.slots = slots; mw.arena = dynLds + QCAP + 4; mw.nHelpers = nHelpers;
     mw.specMap = mw.arena + (size_t)nHelpers * (MW_RING + MW_BM_WORDS); mw.specShift = specShift; mw.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
