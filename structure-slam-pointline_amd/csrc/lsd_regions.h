@@ -471,7 +471,7 @@ struct MwRes {                      // 20 bytes; lo = x0 | y0 << 16, hi = x1 | y
     __device__ __forceinline__ int nF() const { return w2 >> 16; }
 };
 struct MwSlot { int chunkPos, nres, doneLane, begin; MwRes res[MW_RES]; };      // begin: where the chunk's lists start in the helper's ring
-struct MwCtl { int cursor, finished, unmarkSeq, mainPos; int evLo[MW_EV], evHi[MW_EV]; unsigned long long helperIdle, helperBusy; int why[8]; unsigned long long hcyc[8]; };
+struct MwCtl { int cursor, finished, unmarkSeq, mainPos; int evLo[MW_EV], evHi[MW_EV]; unsigned long long helperIdle, helperBusy; int why[8]; unsigned long long hcyc[8], published; };
 struct MwShared {
     MwCtl* ctl; MwSlot* slots; unsigned* arena; unsigned* specMap; int specW, specShift; int nHelpers;      // specShift: log2 of the shared map's cell edge, < 0: no map
     __device__ __forceinline__ int cell(int x, int y) const { return (y >> specShift) * specW + (x >> specShift); }
@@ -803,7 +803,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
         if (MW) { misc->cyc[5] = cycWait; misc->cyc[6] = cycTake; misc->cyc[7] = cycOwn; }
 #endif
 #ifdef SSLAM_MW_HCYC
-        if (MW) for (int c = 0; c < 8; ++c) misc->cyc[c] = (long long)mw.ctl->hcyc[c];
+        if (MW) { for (int c = 0; c < 8; ++c) misc->cyc[c] = (long long)mw.ctl->hcyc[c]; misc->cyc[7] = (long long)mw.ctl->published; }
 #elif defined(SSLAM_MW_STATS)
         if (MW) { misc->cyc[0] = mwTaken; for (int c = 1; c < 8; ++c) misc->cyc[c] = mwCause[c]; misc->cyc[5] = (long long)mw.ctl->helperBusy; misc->cyc[6] = (long long)mw.ctl->helperIdle; misc->cyc[2] = SSLAM_CLK2() - tStart2; misc->cyc[7] = mwBig; misc->cyc[1] = mwCause[1] + mwCause[3] + mwCause[4];
                   long long w0 = 0, w1 = 0; for (int c = 0; c < 4; ++c) { w0 |= (long long)(mw.ctl->why[c] & 0xFFFF) << (16 * c); w1 |= (long long)(mw.ctl->why[4 + c] & 0xFFFF) << (16 * c); } misc->cyc[3] = w0; misc->cyc[4] = w1; }
@@ -999,6 +999,9 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 ++k; head += total; haveRes |= 1ull << first;
+#ifdef SSLAM_MW_STATS
+                if (lane == 0) atomicAdd(&ctl->published, 1ull + ((unsigned long long)(nA + sl.nB) << 32));
+#endif
                 lds_st(&S->nres, k);
                 if (pass == 0) lds_st(&S->doneLane, laneBase + first + 1);
                 // what the region leaves USED enters the shared map that steers seed choice; candidates of this chunk inside it are dropped
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(64 * (1 + MW_HMAX)) void k_lsd_regions_mw(uint8_t* 
     __shared__ MwCtl ctl;
     __shared__ MwSlot slots[MW_HMAX * MW_NSLOT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; ctl.helperIdle = 0; ctl.helperBusy = 0; for (int c = 0; c < 8; ++c) { ctl.why[c] = 0; ctl.hcyc[c] = 0; } }
+    if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; ctl.helperIdle = 0; ctl.helperBusy = 0; for (int c = 0; c < 8; ++c) { ctl.why[c] = 0; ctl.hcyc[c] = 0; } ctl.published = 0; }
     if (threadIdx.x < MW_HMAX * MW_NSLOT) { slots[threadIdx.x].chunkPos = -1; slots[threadIdx.x].nres = 0; slots[threadIdx.x].doneLane = 0; slots[threadIdx.x].begin = 0; }
     MwShared mw; mw.ctl = &ctl; mw.slots = slots; mw.arena = dynLds + QCAP + 4; mw.nHelpers = nHelpers;
     mw.specMap = mw.arena + (size_t)nHelpers * (MW_RING + MW_BM_WORDS); mw.specShift = specShift; mw.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
