@@ -343,6 +343,12 @@ int sslam_lines_extract_batch_dev(sslam_lines* ln, const uint8_t* d_images, int 
  * reports it).  d_status4 = {frames over capacity, first of them, frames over the LSD limit, first of them}. */
 int sslam_lines_batch_status(sslam_lines* ln, int cap, void* stream, int* truncated_frames_out, int* unsupported_frames_out, int* first_frame_out);
 int sslam_lines_batch_status_dev(sslam_lines* ln, int cap, int32_t* d_status4, void* stream);
+/* Scheduling hint for a caller that keeps a second stream busy while a batch of line extractions is in flight (bench.py's two-stream mode;
+ * the reference has no batch mode and no counterpart).  `hip_event` (a hipEvent_t; NULL clears it) is recorded on the stream of every
+ * following sslam_lines_extract_batch_dev call immediately BEFORE the sequential core (k_lsd_regions) is launched.  The core is latency-bound
+ * and leaves issue slots free, the kernels in front of it are bandwidth-bound and do not: a second stream that waits for the event overlaps
+ * the core instead of the prologue.  The event stays the caller's. */
+int sslam_lines_set_core_event(sslam_lines* ln, void* hip_event);
 /* Host-buffer batch (SURVEY.md §8(b) `sslam_frontend_batch`): n frames of one size in host memory through Frame::ExtractORB and, when
  * `lines` is not NULL, Frame::ExtractLSD (src/Frame.cc:150-161); frame i starts at images + i*image_stride (row pitch `stride`).
  * Per-frame results in the caller's arrays: kp_out[n*cap], desc_out[n*cap*32], nkp_out[n], kl_out[n*lcap], ldesc_out[n*lcap*32],

@@ -66,6 +66,7 @@ struct sslam_lines {
     LsdPlan plan;
     DevBuf dWs, dTabs, dTaps, dLgam, dGtab;
     int wsFrames = 0, lastFrames = 0;
+    hipEvent_t coreEvent = nullptr;          // sslam_lines_set_core_event
     int lastN = -1;                 // lines of the last sslam_lines_extract (still resident in dKl/dDesc)
     DevBuf dImg, dKl, dDesc, dFn, dCounts;
     HostPinned hOut;
@@ -235,6 +236,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
+        if (L->coreEvent) SSLAM_HIP(hipEventRecord(L->coreEvent, st));
         sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st);
         bool lone = nframes < 1024;
         // a frame that gets a CU to itself: one main wave + helper waves running flsd()'s per-seed body ahead of it (lsd_regions.h, multi-wave form).
@@ -364,6 +366,12 @@ extern "C" int sslam_lines_debug_segments(sslam_lines* L, int frame, float* seg_
     *n_out = m.nSeg;
     int n = std::min(m.nSeg, cap);
     if (n > 0 && seg_out) SSLAM_HIP(hipMemcpy(seg_out, base + P.offSeg, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_lines_set_core_event(sslam_lines* L, void* hip_event) {
+    if (!L) return SSLAM_ERR_INVALID;
+    L->coreEvent = (hipEvent_t)hip_event;
     return SSLAM_OK;
 }
 

@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) { ang[i + j] = rec[j].x; S[i + j] = sv[j]; }
         }
-        if ((P.sw & 255) == 0) {
+#ifndef SSLAM_GRAD_TRANSPOSE
+#define SSLAM_GRAD_TRANSPOSE 1
+#endif
+        if (SSLAM_GRAD_TRANSPOSE && (P.sw & 255) == 0) {
             // the 16-byte records of a lane's four pixels are 64 bytes apart from the next lane's: stored directly, every store instruction
             // would be 64 partial (16 of 64 bytes) L2 writes.  Transposed through LDS (the wave's own 4 KB, in-order DS, no workgroup
             // barrier) each instruction writes 1 KB contiguous.  Row pitch 66 records: conflict-free for both the writes and the reads.

@@ -386,6 +386,10 @@ class LineExtractor:
                                                  int(nframes), _p(d_kl), _p(d_ldesc), _p(d_linefn), _p(d_counts), int(cap),
                                                  C.c_void_p(stream or 0)))
 
+    def set_core_event(self, hip_event):
+        """hipEvent_t handle (int) recorded right before the sequential LSD core of every following batch call; 0 / None clears it"""
+        _chk(lib().sslam_lines_set_core_event(self.h, C.c_void_p(int(hip_event or 0))))
+
     def debug_segments(self, frame, cap=20000):
         out = np.zeros((cap, 4), np.float32); n = C.c_int(0)
         _chk(lib().sslam_lines_debug_segments(self.h, frame, _p(out), cap, C.byref(n)))

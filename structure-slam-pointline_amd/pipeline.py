@@ -115,6 +115,16 @@ class FrontendBatch:
                 self.match()
             return
         self._streams()
+        if not hasattr(self, "_core_event"):
+            # The kernels in front of the sequential core (blur, gradient, counting sort: ~33 ms of 12 288 frames) are bandwidth-bound; the core
+            # itself is latency-bound and leaves issue slots free.  The library records this event right before the core, and the point branch
+            # waits for it: it then runs under the core instead of competing with the prologue (SSLAM_POINTS_AT_CORE=0: both start together).
+            import os
+            self._core_event = None
+            if os.environ.get("SSLAM_POINTS_AT_CORE", "1") != "0":
+                ev = torch.cuda.Event(); ev.record(self._s2)          # (recording creates the hipEvent_t)
+                self._core_event = ev
+                self.lines.set_core_event(ev.cuda_event)
         cur = torch.cuda.current_stream(self.dev)
         self._s1.wait_stream(cur); self._s2.wait_stream(cur)
         f = self.feat["cur"]
@@ -124,6 +134,8 @@ class FrontendBatch:
             if self.with_match:
                 self._match_lines()
         with torch.cuda.stream(self._s1):
+            if self._core_event is not None:      # the point branch starts when the sequential LSD core does (sslam_lines_set_core_event)
+                self._s1.wait_event(self._core_event)
             self.orb.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kp"], f["desc"], f["n"], self.cap, self._stream())
             if self.with_match:
                 self._match_points()

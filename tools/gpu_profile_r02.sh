@@ -16,7 +16,9 @@ for wl in c3 c4; do
     rm -rf $O/pmc_${wl}_$c && timeout 600 rocprofv3 --pmc $c -d $O/pmc_${wl}_$c -- python $R/bench.py --workload $wl --batch $b --steps 1 --warmup 1 --no-overlap --no-cpu-baseline --no-extras --no-profile > $O/pmc_${wl}_$c.log 2>&1
   done
 done
+rm -rf $O/lat && cd $R && timeout 300 rocprofv3 --kernel-trace --stats -d $O/lat -- python tools/latency_probe.py > $O/lat.log 2>&1      # one frame per call: the multi-wave core
 cd $R
+python tools/rocpd_summary.py $O/lat $O/kernel_trace_single_frame.txt > /dev/null; rm -rf $O/lat
 python tools/rocpd_summary.py $O/kt $O/kernel_trace_two_streams.txt > /dev/null
 python tools/rocpd_summary.py $O/kt1 $O/kernel_trace_one_stream.txt > /dev/null
 for wl in c3 c4; do
