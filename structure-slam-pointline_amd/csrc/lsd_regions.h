@@ -417,23 +417,28 @@ __device__ __forceinline__ double dist_d(double x1, double y1, double x2, double
 }
 
 // ------------------------------------------------------------------ multi-wave form (one frame at a time): shared state
-// A frame that has a CU to itself gets one MAIN wave, which replays flsd() in seed order exactly like the single-wave kernel, and up to
-// MW_HMAX HELPER waves that run region_grow AHEAD of it -- 68 % of the lone wave's time.  Only the main wave ever writes the pixel map.
-//   * helpers claim chunks of 64 order positions (CAS on MwCtl::cursor) and grow the unused seeds of their chunk, EACH ON ITS OWN, on a
-//     READ-ONLY view of the pixel map (plus a private bitmap of the pixels of the region being grown).  Per seed they publish the point list
-//     (LDS arena), its length, the final region angle, the bounding box and the un-mark sequence number sampled before the first pixel was read;
-//   * the main wave, at a seed whose chunk a helper owns, takes the helper's region instead of growing it when the region is what its own
-//     growth would produce NOW:
-//       (b) every point of the region is unused now (one parallel gather; region_grow's dependency chain is gone);
-//       (c) no pixel the helper can have seen as USED has been released since: pixels are released only by refine(), each refine logs the
-//           bounding box of everything it touched with a new sequence number AFTER its last store, and a region whose box (grown by one
-//           pixel: the tested neighbourhood) meets a box logged after the region's sample is not taken.
+//   A frame that has a CU to itself -- the reference calls LineSegment::ExtractLineSegment once per frame,
+// src/Frame.cc:157-161 -- gets one MAIN wave, which replays flsd()'s seed loop in order exactly like the single-wave kernel, and up to MW_HMAX
+// HELPER waves that run the loop's per-seed body (region_grow, region2rect, refine with its re-growth and reduce_region_radius) AHEAD of it.
+// Only the main wave ever writes the pixel map.
+//   * helpers claim MW_SUB order positions at a time (CAS on MwCtl::cursor) and process the unused seeds of their claim, EACH SEED ON ITS
+//     OWN, on a READ-ONLY view of the pixel map; the pixels a region takes -- and releases again in refine() -- live in the helper's private
+//     bitmap.  Per seed they publish (MwRes + the helper's ring in LDS): list A = the region as first grown, list B = the region re-grown at
+//     refine's tolerance (if refine ran), list F = what reduce_region_radius left (if it ran), the rectangle, the bounding box of A and B
+//     and the release sequence number sampled before the first pixel was read;
+//   * the main wave, at a seed whose claim a helper owns, TAKES the helper's result (marks the last list USED, emits the rectangle) instead
+//     of running the body when the result is what the body would produce NOW:
+//       (b) every point of A and B is unused now (one parallel gather; region_grow's dependency chain is gone);
+//       (c) no pixel the helper can have seen as USED has been released since: pixels are released only by a refine() the main wave runs
+//           itself, each logs the bounding box of everything it touched with a new sequence number AFTER its last store, and a result whose
+//           box (grown by one pixel: the tested neighbourhood) meets a box logged after the result's sample is not taken.
 //     A pixel the helper saw unused and rejected by angle stays rejected whatever its state is now; a pixel it saw used and that is still
-//     used blocks growth the same way; so (b) and (c) make the helper's list, in its order, the list the sequential growth yields -- and the
-//     region angle with it, since it is a function of the list.  Anything else falls back to the main wave's own region_grow.
-//   * regions published but not yet taken are recorded in a coarse shared map (2 x 2 pixel cells) that only steers the helpers' choice of
-//     seeds -- a seed inside somebody's speculative region will most likely be taken by then -- and never enters a region's growth.
-// Stale or torn views only ever cost a fallback: the checks read the main wave's own stores.
+//     used blocks growth the same way; accepted pixels are in A or B.  So (b) and (c) make the helper's lists, in their order, the lists the
+//     sequential body yields, and rectangle and refine outcome are functions of the lists.  Anything else: the main wave runs the body itself.
+//   * what published-but-not-yet-taken results would mark is recorded in a coarse shared map (2 x 2 pixel cells) that only steers the
+//     helpers' choice of seeds -- a seed inside somebody's speculative region will most likely be used by its turn -- and never enters a
+//     region's growth.
+// Stale or torn views only ever cost a fallback: the checks read the main wave's own stores.  Every wait of the main wave is bounded.
 #ifndef SSLAM_MW_HMAX
 #define SSLAM_MW_HMAX 6
 #endif
@@ -456,7 +461,7 @@ constexpr int MW_RES = MW_SUB < 24 ? MW_SUB : 24;      // regions per claim
 constexpr int MW_WANT = QCAP / 2 + 24;      // ring space a helper waits for before it starts a region (while older chunks can still retire)
 constexpr int MW_EV = 16;           // refine events kept
 constexpr int MW_SPIN_LIMIT = 1 << 21;      // polls (tens of milliseconds) before the main wave stops waiting for a helper
-// A published seed.  Lists in the helper's arena from `off`: A = the region as first grown (nA points); if refine() ran, B = the region
+// A published seed.  Lists in the helper's ring from `off`: A = the region as first grown (nA points); if refine() ran, B = the region
 // re-grown at the refined tolerance (nB), and if reduce_region_radius ran, F = what it left of B (nF).  The pixels that end up USED are the
 // last list's; A and B are what the helper accepted on the way, i.e. what must still be unused for the result to stand.
 constexpr int MW_REFINED = 1, MW_REDUCED = 2, MW_EMIT = 4;
