@@ -476,7 +476,8 @@ struct MwRes {                      // 20 bytes; lo = x0 | y0 << 16, hi = x1 | y
     __device__ __forceinline__ int nF() const { return w2 >> 16; }
 };
 struct MwSlot { int chunkPos, nres, doneLane, begin; MwRes res[MW_RES]; };      // begin: where the chunk's lists start in the helper's ring
-struct MwCtl { int cursor, finished, unmarkSeq, mainPos; int evLo[MW_EV], evHi[MW_EV]; unsigned long long helperIdle, helperBusy; int why[8]; unsigned long long hcyc[8], published; };
+struct MwCtl { int cursor, finished, unmarkSeq, mainPos; int evLo[MW_EV], evHi[MW_EV]; unsigned long long helperIdle, helperBusy; int why[8]; unsigned long long hcyc[8], published;
+               int flPos[MW_HMAX]; float flX[MW_HMAX], flY[MW_HMAX], flCos[MW_HMAX], flSin[MW_HMAX], flAng[MW_HMAX]; };      // fl*: the seed each helper is growing right now
 struct MwShared {
     MwCtl* ctl; MwSlot* slots; unsigned* arena; unsigned* specMap; int specW, specShift; int nHelpers;      // specShift: log2 of the shared map's cell edge, < 0: no map
     __device__ __forceinline__ int cell(int x, int y) const { return (y >> specShift) * specW + (x >> specShift); }
@@ -924,6 +925,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
         // no region -- seeds the shared map had talked it out of, pixels a refine() released -- is grown as well, so that the main wave
         // finds a region for (nearly) every seed instead of growing those itself.
         unsigned long long haveRes = 0;      // seeds with a region, or that this helper gave up on
+        unsigned long long deferred = 0;     // seeds put off in pass 0 because an earlier seed of (most likely) the same edge is being grown elsewhere
         int k = 0; bool room = true;
         for (int pass = 0; room; ++pass) {
             if (pass > 0) {
@@ -931,7 +933,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 reap();
                 bool freeSlot = false;
                 for (int j = 0; j < MW_NSLOT; ++j) freeSlot |= slots[j].chunkPos < 0;
-                if (freeSlot || lds_ld(&ctl->mainPos) >= (c & ~63) || lds_ld(&ctl->finished)) break;
+                if ((freeSlot && !(pass == 1 && (deferred & ~haveRes))) || lds_ld(&ctl->mainPos) >= (c & ~63) || lds_ld(&ctl->finished)) break;
                 __builtin_amdgcn_s_sleep(8);
                 SSLAM_MW_T(6);
             }
@@ -951,7 +953,32 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
                 const int startSeq = lds_ld(&ctl->unmarkSeq);      // sampled BEFORE the first pixel of this region is read
                 if (pix[sy * sw + sx].x < 0.f) { SSLAM_MW_WHY(1, 1); continue; }           // taken since the chunk was scanned (a region in front of it, committed meanwhile)
-                if (pass == 0 && mw.spec(sx, sy)) { SSLAM_MW_WHY(2, 1); continue; }         // ... or about to be
+                if ((pass == 0 || ((deferred >> first) & 1ull)) && mw.spec(sx, sy)) { SSLAM_MW_WHY(2, 1); continue; }         // ... or about to be
+                // Consecutive positions of the top bins are pixels of the same long edges: helpers that start them together each grow the whole
+                // edge and only the earliest seed's region is ever taken.  So: if another helper is growing an EARLIER seed whose level line
+                // passes within 3 pixels of this seed at a similar angle, this seed is put off (pass 0) / waits for that region (later passes)
+                // and is looked at again once it is settled -- by then it is usually covered.  A guess about what to grow, nothing more.
+                {
+                    const int myP = c + first;
+                    auto blocked = [&]() -> bool {
+                        bool b = false;
+                        for (int j = 0; j < mw.nHelpers; ++j) {
+                            if (j == h || lds_ld(&ctl->flPos[j]) >= myP) continue;
+                            const float da = fabsf(sd.x - ctl->flAng[j]), dd = fminf(da, 360.f - da);
+                            const float perp = fabsf(((float)sx - ctl->flX[j]) * ctl->flSin[j] - ((float)sy - ctl->flY[j]) * ctl->flCos[j]);
+                            b |= dd < 22.5f && perp < 3.f;
+                        }
+                        return b;
+                    };
+                    if (blocked()) {
+                        if (pass == 0) { deferred |= 1ull << first; SSLAM_MW_WHY(3, 1); continue; }
+                        while (blocked() && lds_ld(&ctl->mainPos) < (c & ~63) && !lds_ld(&ctl->finished)) __builtin_amdgcn_s_sleep(8);
+                        if (pix[sy * sw + sx].x < 0.f || mw.spec(sx, sy)) continue;
+                    }
+                }
+                if (lane == 0) { ctl->flX[h] = (float)sx; ctl->flY[h] = (float)sy; ctl->flCos[h] = sd.y; ctl->flSin[h] = sd.z; ctl->flAng[h] = sd.x; }
+                lds_st(&ctl->flPos[h], c + first);
+                struct FlGuard { int* p; __device__ ~FlGuard() { lds_st(p, 0x7FFFFFFF); } } flGuard{&ctl->flPos[h]};      // cleared however the body is left
                 // room for a region of some size, or as much as there will ever be: older chunks of this helper still in the ring are
                 // retired as the main wave passes them -- waiting for that beats abandoning a seed (the main wave would grow it itself)
                 int tail = reap(), space = contiguous(tail);          // may move head
@@ -1036,7 +1063,7 @@ __global__ __launch_bounds__(64 * (1 + MW_HMAX)) void k_lsd_regions_mw(uint8_t* 
     __shared__ MwCtl ctl;
     __shared__ MwSlot slots[MW_HMAX * MW_NSLOT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; ctl.helperIdle = 0; ctl.helperBusy = 0; for (int c = 0; c < 8; ++c) { ctl.why[c] = 0; ctl.hcyc[c] = 0; } ctl.published = 0; }
+    if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; ctl.helperIdle = 0; ctl.helperBusy = 0; for (int c = 0; c < 8; ++c) { ctl.why[c] = 0; ctl.hcyc[c] = 0; } ctl.published = 0; for (int c = 0; c < MW_HMAX; ++c) ctl.flPos[c] = 0x7FFFFFFF; }
     if (threadIdx.x < MW_HMAX * MW_NSLOT) { slots[threadIdx.x].chunkPos = -1; slots[threadIdx.x].nres = 0; slots[threadIdx.x].doneLane = 0; slots[threadIdx.x].begin = 0; }
     MwShared mw; mw.ctl = &ctl; mw.slots = slots; mw.arena = dynLds + QCAP + 4; mw.nHelpers = nHelpers;
     mw.specMap = mw.arena + (size_t)nHelpers * (MW_RING + MW_BM_WORDS); mw.specShift = specShift; mw.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
