@@ -299,8 +299,23 @@ def main():
         dist.broadcast(uid, src=0)
         if force_collective and world == 1:
             os.environ["SSLAM_GROUP_SELF_SENDRECV"] = "1"      # one rank: route its own records through ncclSend / ncclRecv so that RCCL moves the bytes
-        group = fe.Group(device=local_rank, rank=rank, nranks=world, uid=uid.cpu().numpy())
-        gather = sharding.GroupGather(fe, ctx, group, pipe, dev)
+        # every rank must end up on the same exchange path: the library's communicator if ALL ranks got one and one trial gather went
+        # through everywhere, else torch.distributed (also RCCL) -- a measurement run must not die on the communicator bootstrap
+        group = None; gather_impl = "sslam_group_gather_dev"; why = ""
+        try:
+            if os.environ.get("SSLAM_BENCH_FAIL_GROUP"):      # test knob: exercise the fallback
+                raise RuntimeError("SSLAM_BENCH_FAIL_GROUP")
+            group = fe.Group(device=local_rank, rank=rank, nranks=world, uid=uid.cpu().numpy())
+            gather = sharding.GroupGather(fe, ctx, group, pipe, dev)
+            pipe.step(cur, overlap=not args.no_overlap); gather.submit(); gather.wait()
+            ok = 1
+        except Exception as e:      # noqa: BLE001
+            ok = 0; why = str(e)[:160]
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            print("bench.py: rank %d falls back to torch.distributed for the gather (%s)" % (rank, why or "another rank failed"), file=sys.stderr)
+            gather = sharding.TorchGather(fe, ctx, dist, pipe, dev, world, rank); group = None
+            gather_impl = "torch.distributed gather (backend nccl = RCCL); library communicator unavailable: " + (why or "on another rank")
 
     def one_step():
         if host_cur is not None:
@@ -364,7 +379,7 @@ def main():
             if with_lines:
                 nl_own = c["nl"].cpu().numpy()
                 ok = ok and bool((rnl[0::world] == nl_own).all()) and bool(np.array_equal(rfn[0::world][-1, :nl_own[-1]], c["linefn"][-1, :nl_own[-1]].cpu().numpy()))
-            gather_info = {"ok": bool(ok), "records": int(nrec), "bytes_per_rank": sizes, "bytes_per_frame": float(sum(sizes)) / max(nrec, 1)}
+            gather_info = {"ok": bool(ok), "impl": gather_impl, "records": int(nrec), "bytes_per_rank": sizes, "bytes_per_frame": float(sum(sizes)) / max(nrec, 1)}
         except Exception as e:
             gather_info = {"ok": False, "error": str(e)[:200]}
     if rank == 0:
@@ -425,7 +440,9 @@ def main():
             out["cpu_baseline"]["parity_vs_gpu"] = parity_vs_gpu(ref, pipe.feat["cur"], with_lines)
         print(json.dumps(out))
     if gather is not None:
-        gather.wait(); group.close()
+        gather.wait()
+        if group is not None:
+            group.close()
     pipe.close()
     ctx.close()
     if dist is not None:

@@ -108,3 +108,36 @@ class GroupGather:
         if self.rank != 0 or self.sizes is None:
             return None
         return self.recv[:int(self.sizes.sum())], [int(x) for x in self.sizes]
+
+
+class TorchGather:
+    """The same exchange step through torch.distributed (backend "nccl" = RCCL): what bench.py falls back to when the library's own
+    communicator cannot be created on some rank (the records are still packed by sslam_pack_records_dev).  Synchronous."""
+
+    def __init__(self, fe, ctx, dist, pipe, device, world, rank):
+        self.fe, self.ctx, self.dist, self.pipe, self.world, self.rank = fe, ctx, dist, pipe, world, rank
+        self.cap_bytes = fe.record_stream_capacity(pipe.B, pipe.cap, pipe.lcap if pipe.with_lines else 0)
+        self.send = torch.zeros(self.cap_bytes + 16, dtype=torch.uint8, device=device)
+        self.total = torch.zeros(2, dtype=torch.int64, device=device)
+        self.out = None
+
+    def submit(self):
+        p, c = self.pipe, self.pipe.feat["cur"]
+        lines = p.with_lines
+        s1, _ = p._streams()
+        cur = torch.cuda.current_stream(p.dev)
+        s1.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            self.fe.pack_records_dev(self.ctx, p.B, self.rank, self.world, c["kp"], c["desc"], c["n"], p.cap,
+                                     c["kl"] if lines else None, c["ldesc"] if lines else None, c["linefn"] if lines else None, c["nl"] if lines else None, p.lcap,
+                                     self.send, self.cap_bytes, self.total, p._stream())
+        cur.wait_stream(s1)
+        n = int(self.total[0].item())
+        got, sizes = gather_streams(self.dist, self.send[:n], self.world, self.rank)
+        self.out = (got, sizes) if self.rank == 0 else None
+
+    def wait(self):
+        pass
+
+    def result(self):
+        return self.out
