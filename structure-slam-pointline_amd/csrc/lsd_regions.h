@@ -724,7 +724,8 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                         if (!ok) SSLAM_MW_CAUSE(4);
                     }
                     // everything the helper accepted on the way (A, and B when refine() ran) must be unused now
-                    for (int bs = 0; ok && bs < nA + nB; bs += 64) {
+                    // (a region of one point is its seed, which the main wave knows to be unused: no gather -- 45 % of the takes)
+                    for (int bs = 0; ok && nA + nB > 1 && bs < nA + nB; bs += 64) {
                         const int i = bs + lane;
                         bool usedNow = false;
                         if (i < nA + nB) { const unsigned e = lstA[i]; usedNow = pix[(int)(e >> 16) * sw + (int)(e & 0xFFFF)].x < 0.f; }
