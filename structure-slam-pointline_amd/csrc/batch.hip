@@ -36,7 +36,7 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
         set_error("sslam_frontend_batch: invalid arguments"); return SSLAM_ERR_INVALID;
     }
     if (n == 0) return SSLAM_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     const int C = std::min(n, chunk > 0 ? chunk : 512);
     const size_t fpx = (size_t)w * h;

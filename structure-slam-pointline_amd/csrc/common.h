@@ -62,7 +62,7 @@ struct sslam_ctx {
     bool profEnabled = false;              // per-kernel HIP-event timing (sslam_profile_*)
     std::vector<sslam_prof_rec> prof;
     hipStream_t stream = nullptr;
-    std::mutex mu;                 // host entry points serialise on the context (SURVEY §8b threading)
+    std::recursive_mutex mu;       // every entry point serialises on the context (SURVEY §8b threading); recursive: the host forms call the *_batch_dev forms
     sslam::DevBuf scratch[8];      // matcher staging
     sslam::DevBuf recordOffsets;   // sslam_pack_records_dev: per-frame offsets of the record stream
     sslam::HostPinned pinned[4];

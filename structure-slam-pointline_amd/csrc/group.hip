@@ -167,7 +167,7 @@ extern "C" int sslam_pack_records_dev(sslam_ctx* ctx, int nframes, int frame0, i
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     int rc;
     {
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         if ((size_t)(nframes + 1) * 8 > ctx->recordOffsets.cap) SSLAM_HIP(hipStreamSynchronize(st));      // a growing buffer is freed first: nothing may still read it
         if ((rc = ctx->recordOffsets.ensure(sizeof(unsigned long long) * ((size_t)nframes + 1)))) return rc;
     }

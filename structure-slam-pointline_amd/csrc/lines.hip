@@ -192,6 +192,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     if (!L || !d_images || !d_kl || !d_ldesc || !d_linefn || !d_counts || w <= 0 || h <= 0 || nframes <= 0 || cap <= 0 || pitch < (size_t)w) {
         set_error("sslam_lines_extract_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID;
     }
+    std::lock_guard<std::recursive_mutex> lk(L->ctx->mu);      // plan, workspace and profile records are shared state
     SSLAM_HIP(hipSetDevice(L->ctx->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : L->ctx->stream;
     int rc;
@@ -292,7 +293,7 @@ extern "C" int sslam_lines_extract(sslam_lines* L, const uint8_t* gray, int w, i
     *n_out = 0;
     if (w == 0 || h == 0 || !gray) return SSLAM_OK;
     if (w < 0 || h < 0 || stride < (size_t)w || !kl_out || !ldesc_out || !linefn_out || cap <= 0) { set_error("sslam_lines_extract: invalid arguments"); return SSLAM_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(L->ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(L->ctx->mu);
     SSLAM_HIP(hipSetDevice(L->ctx->device));
     hipStream_t st = L->ctx->stream;
     const int icap = L->maxLines;
@@ -339,7 +340,7 @@ extern "C" int sslam_lines_batch_status_dev(sslam_lines* L, int cap, int32_t* d_
 
 extern "C" int sslam_lines_batch_status(sslam_lines* L, int cap, void* stream_, int* truncated_frames_out, int* unsupported_frames_out, int* first_frame_out) {
     if (!L) { set_error("sslam_lines_batch_status: null handle"); return SSLAM_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(L->ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(L->ctx->mu);
     int rc;
     if ((rc = L->dCounts.ensure(16))) return rc;
     hipStream_t st = stream_ ? (hipStream_t)stream_ : L->ctx->stream;
@@ -388,12 +389,20 @@ extern "C" int sslam_lines_debug_cycles(sslam_lines* L, int frame, long long* ou
 
 // Self-test of the table-based exact division used in the NFA tail (tests/test_lines_gpu.py): returns the number of
 // random (a, b) pairs, 1 <= a, b < n, whose quotient differs from the hardware IEEE division (must be 0).
+namespace {
+struct ScopedDev {            // device scratch of a self-test: freed on every return path
+    void* p = nullptr;
+    ~ScopedDev() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
 extern "C" int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, long long* mismatches_out) {
     if (!ctx || n < 3 || pairs <= 0 || !mismatches_out) return SSLAM_ERR_INVALID;
     SSLAM_HIP(hipSetDevice(ctx->device));
-    double* tab = nullptr; unsigned long long* bad = nullptr;
-    SSLAM_HIP(hipMalloc(&tab, sizeof(double) * (2 * (size_t)n + 48)));
-    SSLAM_HIP(hipMalloc(&bad, sizeof(unsigned long long)));
+    ScopedDev tabMem, badMem;
+    SSLAM_HIP(hipMalloc(&tabMem.p, sizeof(double) * (2 * (size_t)n + 48)));
+    SSLAM_HIP(hipMalloc(&badMem.p, sizeof(unsigned long long)));
+    double* tab = (double*)tabMem.p; unsigned long long* bad = (unsigned long long*)badMem.p;
     SSLAM_HIP(hipMemset(bad, 0, sizeof(unsigned long long)));
     { const int rc = upload_nfa_tables(tab, n, ctx->stream); if (rc) return rc; }
     const int threads = 256 * 1024, iters = (int)((pairs + threads - 1) / threads);
@@ -401,7 +410,6 @@ extern "C" int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, 
     unsigned long long h = 0;
     SSLAM_HIP(hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     SSLAM_HIP(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(tab); (void)hipFree(bad);
     *mismatches_out = (long long)h;
     return SSLAM_OK;
 }
@@ -412,8 +420,9 @@ extern "C" int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, 
 extern "C" int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long long* disagree_out, long long* ambiguous_out) {
     if (!ctx || samples <= 0 || !disagree_out || !ambiguous_out) return SSLAM_ERR_INVALID;
     SSLAM_HIP(hipSetDevice(ctx->device));
-    unsigned long long* d = nullptr;
-    SSLAM_HIP(hipMalloc(&d, 2 * sizeof(unsigned long long)));
+    ScopedDev dMem;
+    SSLAM_HIP(hipMalloc(&dMem.p, 2 * sizeof(unsigned long long)));
+    unsigned long long* d = (unsigned long long*)dMem.p;
     SSLAM_HIP(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
     const int threads = 256 * 1024, iters = (int)((samples + threads - 1) / threads);
     const double logNT = 5 * (std::log10(512.0) + std::log10(384.0)) / 2 + std::log10(11.0);
@@ -421,7 +430,6 @@ extern "C" int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long 
     unsigned long long h[2] = {0, 0};
     SSLAM_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     SSLAM_HIP(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d);
     *disagree_out = (long long)h[0]; *ambiguous_out = (long long)h[1];
     return SSLAM_OK;
 }
@@ -429,15 +437,15 @@ extern "C" int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long 
 extern "C" int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long long* mismatches_out) {
     if (!ctx || samples <= 0 || !mismatches_out) return SSLAM_ERR_INVALID;
     SSLAM_HIP(hipSetDevice(ctx->device));
-    unsigned long long* d = nullptr;
-    SSLAM_HIP(hipMalloc(&d, 2 * sizeof(unsigned long long)));
+    ScopedDev dMem;
+    SSLAM_HIP(hipMalloc(&dMem.p, 2 * sizeof(unsigned long long)));
+    unsigned long long* d = (unsigned long long*)dMem.p;
     SSLAM_HIP(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
     const int threads = 256 * 1024, iters = (int)((samples + threads - 1) / threads);
     hipLaunchKernelGGL(k_selftest_region_div, dim3(1024), dim3(256), 0, ctx->stream, 0x5EEDF00D1234ull, iters, d);
     unsigned long long h[2] = {0, 0};
     SSLAM_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     SSLAM_HIP(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d);
     mismatches_out[0] = (long long)h[0]; mismatches_out[1] = (long long)h[1];      // division, atan2
     return SSLAM_OK;
 }
@@ -447,9 +455,10 @@ extern "C" int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long
 extern "C" int sslam_selftest_fetch_probe(sslam_ctx* ctx, size_t bytes, int mode, long long* bytes_requested_out) {
     if (!ctx || bytes < (1u << 20) || (mode != 0 && mode != 1) || !bytes_requested_out) return SSLAM_ERR_INVALID;
     SSLAM_HIP(hipSetDevice(ctx->device));
-    float4* buf = nullptr; float* sink = nullptr;
-    SSLAM_HIP(hipMalloc(&buf, bytes));
-    SSLAM_HIP(hipMalloc(&sink, sizeof(float)));
+    ScopedDev bufMem, sinkMem;
+    SSLAM_HIP(hipMalloc(&bufMem.p, bytes));
+    SSLAM_HIP(hipMalloc(&sinkMem.p, sizeof(float)));
+    float4* buf = (float4*)bufMem.p; float* sink = (float*)sinkMem.p;
     SSLAM_HIP(hipMemsetAsync(buf, 0, bytes, ctx->stream));
     const size_t nElem = bytes / sizeof(float4);
     if (mode == 0) {
@@ -461,7 +470,6 @@ extern "C" int sslam_selftest_fetch_probe(sslam_ctx* ctx, size_t bytes, int mode
         *bytes_requested_out = (long long)threads * iters * 16;
     }
     SSLAM_HIP(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(buf); (void)hipFree(sink);
     return SSLAM_OK;
 }
 
@@ -470,7 +478,7 @@ int sslam_frame_from_device(sslam_ctx* ctx, int kind, const void* d_feats, const
 extern "C" int sslam_frame_from_lines(sslam_lines* L, const float bounds[4], sslam_frame** out) {
     if (!L || !bounds || !out) { set_error("sslam_frame_from_lines: invalid arguments"); return SSLAM_ERR_INVALID; }
     if (L->lastN < 0) { set_error("sslam_frame_from_lines: no sslam_lines_extract call to snapshot"); return SSLAM_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(L->ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(L->ctx->mu);
     return sslam_frame_from_device(L->ctx, 1, L->dKl.p, L->dDesc.as<uint8_t>(), L->lastN, bounds, out);
 }
 

@@ -23,6 +23,7 @@ static hipStream_t pick(sslam_ctx* c, void* s) { return s ? (hipStream_t)s : c->
 
 extern "C" int sslam_hamming_knn2_dev(sslam_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx, int32_t* d_dist, void* stream) {
     if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_idx || !d_dist))) { set_error("sslam_hamming_knn2_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (nq == 0) return SSLAM_OK;
     SSLAM_HIP(hipSetDevice(ctx->device));
     { sslam::ProfScope _ps(ctx, "k_knn2", pick(ctx, stream)); hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, pick(ctx, stream), d_q, nq, d_t, nt, d_idx, d_dist); }
@@ -33,6 +34,7 @@ extern "C" int sslam_hamming_knn2_dev(sslam_ctx* ctx, const uint8_t* d_q, int nq
 extern "C" int sslam_hamming_knn2_batch_dev(sslam_ctx* ctx, const uint8_t* d_q, const int32_t* d_nq, const uint8_t* d_t, const int32_t* d_nt,
                                             int cap, int nframes, int32_t* d_idx, int32_t* d_dist, void* stream) {
     if (!ctx || !d_q || !d_nq || !d_t || !d_nt || !d_idx || !d_dist || cap <= 0 || nframes <= 0) { set_error("sslam_hamming_knn2_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
     { sslam::ProfScope _ps(ctx, "k_knn2_batch", st); hipLaunchKernelGGL(k_knn2_batch, dim3((cap + 15) / 16, nframes), dim3(256), 0, st, d_q, d_nq, d_t, d_nt, cap, d_idx, d_dist); }
@@ -43,7 +45,7 @@ extern "C" int sslam_hamming_knn2_batch_dev(sslam_ctx* ctx, const uint8_t* d_q, 
 extern "C" int sslam_hamming_knn2(sslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist) {
     if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t)) { set_error("sslam_hamming_knn2: invalid arguments"); return SSLAM_ERR_INVALID; }
     if (nq == 0) return SSLAM_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     int rc;
     if ((rc = ctx->scratch[0].ensure((size_t)nq * 32))) return rc;
@@ -63,7 +65,7 @@ extern "C" int sslam_hamming_knn2(sslam_ctx* ctx, const uint8_t* q, int nq, cons
 extern "C" int sslam_hamming_matrix(sslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* D) {
     if (!ctx || nq < 0 || nt < 0 || ((nq > 0 && nt > 0) && (!q || !t || !D))) { set_error("sslam_hamming_matrix: invalid arguments"); return SSLAM_ERR_INVALID; }
     if (nq == 0 || nt == 0) return SSLAM_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     int rc;
     if ((rc = ctx->scratch[0].ensure((size_t)nq * 32))) return rc;
@@ -88,6 +90,7 @@ extern "C" int sslam_orb_search_for_initialization_batch_dev(sslam_ctx* ctx,
     if (!ctx || !d_kp1 || !d_desc1 || !d_kp2 || !d_desc2 || !d_n1 || !d_n2 || !d_prev || !d_m12 || !d_nm || cap <= 0 || cap >= (1 << 19) || npairs <= 0 || !bounds) {
         set_error("sslam_orb_search_for_initialization_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID;
     }
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);      // scratch buffers and profile records are shared state
     SSLAM_HIP(hipSetDevice(ctx->device));
     int rc;
     if ((rc = ctx->scratch[3].ensure(sizeof(int) * 5 * (size_t)cap * npairs))) return rc;
@@ -116,7 +119,7 @@ extern "C" int sslam_orb_search_for_initialization(sslam_ctx* ctx,
     }
     *nmatches_out = 0;
     if (n1 == 0) return SSLAM_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     const int cap = std::max(std::max(n1, n2), 1);
     if (cap >= (1 << 19)) { set_error("too many keypoints"); return SSLAM_ERR_UNSUPPORTED; }
@@ -155,6 +158,7 @@ extern "C" int sslam_orb_search_for_initialization(sslam_ctx* ctx,
 extern "C" int sslam_line_match_batch_dev(sslam_ctx* ctx, const uint8_t* d_l1, const int32_t* d_n1, const uint8_t* d_l2, const int32_t* d_n2,
                                           int cap, int npf, double gate_scale, int ratio_mode, int32_t* d_pairs, int32_t* d_npairs, void* stream) {
     if (!ctx || !d_l1 || !d_l2 || !d_n1 || !d_n2 || !d_pairs || !d_npairs || cap <= 0 || npf <= 0) { set_error("sslam_line_match_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     { sslam::ProfScope _ps(ctx, "k_line_match", pick(ctx, stream)); hipLaunchKernelGGL(k_line_match, dim3(npf), dim3(256), 0, pick(ctx, stream), d_l1, d_n1, 0, d_l2, d_n2, 0, cap, gate_scale, ratio_mode, d_pairs, d_npairs, (double*)nullptr); }
     SSLAM_HIP(hipGetLastError());
@@ -169,7 +173,7 @@ extern "C" int sslam_line_match(sslam_ctx* ctx, const uint8_t* l1, int n1, const
     if (nn12_mad_out) *nn12_mad_out = 0;
     if (n1 == 0 || n2 < 2) return SSLAM_OK;       // degenerate: defined as no matches
     if (n1 > LM_MAX) { set_error("sslam_line_match: n1=%d exceeds %d", n1, LM_MAX); return SSLAM_ERR_UNSUPPORTED; }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int c = std::max(n1, n2);
@@ -247,7 +251,7 @@ extern "C" int sslam_search_by_projection(sslam_ctx* ctx, int kind, int mode, co
     *nmatches_out = 0;
     for (int i = 0; i < n; ++i) assigned_out[i] = -1;
     if (n == 0 || nq == 0) return SSLAM_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const size_t fsz = kind == 0 ? sizeof(sslam_keypoint) : sizeof(sslam_keyline);
@@ -264,27 +268,39 @@ extern "C" int sslam_search_by_projection(sslam_ctx* ctx, int kind, int mode, co
 }
 
 // ---- device-resident frames
+extern "C" void sslam_frame_destroy(sslam_frame* f);
+extern "C" void sslam_vocab_destroy(sslam_vocab* v);
+namespace {
+// a handle under construction: destroyed on every early return (the SSLAM_HIP error paths included), handed over with release()
+template <class T, void (*Destroy)(T*)> struct HandleGuard {
+    T* p; explicit HandleGuard(T* q) : p(q) {}
+    ~HandleGuard() { if (p) Destroy(p); }
+    T* release() { T* q = p; p = nullptr; return q; }
+};
+}  // namespace
+
 extern "C" int sslam_frame_upload(sslam_ctx* ctx, int kind, const void* feats, const uint8_t* desc, int n, const float* uright, const float bounds[4],
                                   sslam_frame** out) {
     if (!ctx || !out || (kind != 0 && kind != 1) || n < 0 || n >= (1 << 19) || !bounds || (n > 0 && (!feats || !desc))) {
         set_error("sslam_frame_upload: invalid arguments"); return SSLAM_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     sslam_frame* f = new sslam_frame();
+    HandleGuard<sslam_frame, sslam_frame_destroy> guard(f);
     f->ctx = ctx; f->kind = kind; f->n = n; f->hasUright = uright != nullptr;
     for (int i = 0; i < 4; ++i) f->bounds[i] = bounds[i];
     const size_t fsz = kind == 0 ? sizeof(sslam_keypoint) : sizeof(sslam_keyline);
     int rc = SSLAM_OK;
     if ((rc = f->feats.ensure(std::max<size_t>(fsz * n, 256))) || (rc = f->desc.ensure(std::max<size_t>(32 * (size_t)n, 256))) ||
-        (uright && (rc = f->uright.ensure(std::max<size_t>(4 * (size_t)n, 256))))) { sslam_frame_destroy(f); return rc; }
+        (uright && (rc = f->uright.ensure(std::max<size_t>(4 * (size_t)n, 256))))) return rc;
     if (n > 0) {
         SSLAM_HIP(hipMemcpyAsync(f->feats.p, feats, fsz * n, hipMemcpyHostToDevice, ctx->stream));
         SSLAM_HIP(hipMemcpyAsync(f->desc.p, desc, 32 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
         if (uright) SSLAM_HIP(hipMemcpyAsync(f->uright.p, uright, 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
         SSLAM_HIP(hipStreamSynchronize(ctx->stream));
     }
-    *out = f;
+    *out = guard.release();
     return SSLAM_OK;
 }
 
@@ -292,17 +308,18 @@ extern "C" int sslam_frame_upload(sslam_ctx* ctx, int kind, const void* feats, c
 int sslam_frame_from_device(sslam_ctx* ctx, int kind, const void* d_feats, const uint8_t* d_desc, int n, const float bounds[4], sslam_frame** out) {
     SSLAM_HIP(hipSetDevice(ctx->device));
     sslam_frame* f = new sslam_frame();
+    HandleGuard<sslam_frame, sslam_frame_destroy> guard(f);
     f->ctx = ctx; f->kind = kind; f->n = n;
     for (int i = 0; i < 4; ++i) f->bounds[i] = bounds[i];
     const size_t fsz = kind == 0 ? sizeof(sslam_keypoint) : sizeof(sslam_keyline);
     int rc;
-    if ((rc = f->feats.ensure(std::max<size_t>(fsz * n, 256))) || (rc = f->desc.ensure(std::max<size_t>(32 * (size_t)n, 256)))) { sslam_frame_destroy(f); return rc; }
+    if ((rc = f->feats.ensure(std::max<size_t>(fsz * n, 256))) || (rc = f->desc.ensure(std::max<size_t>(32 * (size_t)n, 256)))) return rc;
     if (n > 0) {
         SSLAM_HIP(hipMemcpyAsync(f->feats.p, d_feats, fsz * n, hipMemcpyDeviceToDevice, ctx->stream));
         SSLAM_HIP(hipMemcpyAsync(f->desc.p, d_desc, 32 * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
         SSLAM_HIP(hipStreamSynchronize(ctx->stream));
     }
-    *out = f;
+    *out = guard.release();
     return SSLAM_OK;
 }
 
@@ -325,7 +342,7 @@ extern "C" int sslam_search_by_projection_frame(sslam_ctx* ctx, const sslam_fram
     *nmatches_out = 0;
     for (int i = 0; i < frame->n; ++i) assigned_out[i] = -1;
     if (frame->n == 0 || nq == 0) return SSLAM_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     return search_proj_core(ctx, frame->kind, mode, frame->feats.p, frame->desc.as<uint8_t>(), frame->n, frame->bounds,
                             frame->hasUright ? frame->uright.as<float>() : nullptr, occupied, queries, qdesc, nq, nnratio, th_dist, check_orientation,
@@ -335,7 +352,7 @@ extern "C" int sslam_search_by_projection_frame(sslam_ctx* ctx, const sslam_fram
 extern "C" int sslam_hamming_knn2_frames(sslam_ctx* ctx, const sslam_frame* q, const sslam_frame* t, int32_t* idx, int32_t* dist) {
     if (!ctx || !q || !t || q->ctx != ctx || t->ctx != ctx || (q->n > 0 && (!idx || !dist))) { set_error("sslam_hamming_knn2_frames: invalid arguments"); return SSLAM_ERR_INVALID; }
     if (q->n == 0) return SSLAM_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     int rc;
@@ -364,7 +381,7 @@ static int search_by_bow_core(sslam_ctx* ctx, const sslam_keypoint* kf_kp, const
     if (node_kf_ptr[0] != 0 || node_f_ptr[0] != 0 || nk < 0 || nfi < 0) { set_error("sslam_orb_search_by_bow: invalid node offsets"); return SSLAM_ERR_INVALID; }
     for (int i = 0; i < nk; ++i) if (kf_idx[i] < 0 || kf_idx[i] >= nkf) { set_error("sslam_orb_search_by_bow: keyframe feature index out of range"); return SSLAM_ERR_INVALID; }
     for (int i = 0; i < nfi; ++i) if (f_idx[i] < 0 || f_idx[i] >= nf) { set_error("sslam_orb_search_by_bow: frame feature index out of range"); return SSLAM_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -441,7 +458,7 @@ extern "C" int sslam_distinctive_descriptors(sslam_ctx* ctx, const uint8_t* desc
         if (n < 0) { set_error("sslam_distinctive_descriptors: offsets must be non-decreasing"); return SSLAM_ERR_INVALID; }
         if (n > DISTINCT_MAXN) { set_error("sslam_distinctive_descriptors: a set of %d descriptors exceeds the supported %d", n, DISTINCT_MAXN); return SSLAM_ERR_UNSUPPORTED; }
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -470,7 +487,7 @@ extern "C" int sslam_fuse_search(sslam_ctx* ctx, const sslam_frame* kf, int chi2
     }
     for (int i = 0; i < nq; ++i) { best_idx_out[i] = -1; best_dist_out[i] = 0x7fffffff; }
     if (nq == 0 || kf->n == 0) return SSLAM_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -516,7 +533,7 @@ extern "C" int sslam_orb_search_for_triangulation(sslam_ctx* ctx, const sslam_fr
     if (total1 == 0 || total2 == 0) return SSLAM_OK;
     std::vector<int32_t> nodeOf((size_t)total1);
     for (int nd = 0; nd < nnodes; ++nd) for (int a = node_kf1_ptr[nd]; a < node_kf1_ptr[nd + 1]; ++a) nodeOf[a] = nd;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -564,14 +581,15 @@ extern "C" int sslam_vocab_create(sslam_ctx* ctx, int nnodes, int levels, const 
     if (child_ptr[0] != 0 || nch < 0 || (nch > 0 && !children)) { set_error("sslam_vocab_create: invalid child offsets"); return SSLAM_ERR_INVALID; }
     for (int i = 0; i < nnodes; ++i) if (child_ptr[i + 1] < child_ptr[i]) { set_error("sslam_vocab_create: child offsets must be non-decreasing"); return SSLAM_ERR_INVALID; }
     for (int i = 0; i < nch; ++i) if (children[i] <= 0 || children[i] >= nnodes) { set_error("sslam_vocab_create: child id out of range"); return SSLAM_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     sslam_vocab* v = new sslam_vocab();
+    HandleGuard<sslam_vocab, sslam_vocab_destroy> guard(v);
     v->ctx = ctx; v->nnodes = nnodes; v->levels = levels;
     for (int i = 1; i < nnodes; ++i) v->nwords += child_ptr[i + 1] == child_ptr[i];
     int rc;
     if ((rc = v->childPtr.ensure(4 * (size_t)(nnodes + 1))) || (rc = v->children.ensure(std::max<size_t>(4 * (size_t)nch, 256))) || (rc = v->desc.ensure(32 * (size_t)nnodes)) ||
-        (rc = v->wordId.ensure(4 * (size_t)nnodes)) || (rc = v->weight.ensure(8 * (size_t)nnodes))) { sslam_vocab_destroy(v); return rc; }
+        (rc = v->wordId.ensure(4 * (size_t)nnodes)) || (rc = v->weight.ensure(8 * (size_t)nnodes))) return rc;
     hipStream_t st = ctx->stream;
     SSLAM_HIP(hipMemcpyAsync(v->childPtr.p, child_ptr, 4 * (size_t)(nnodes + 1), hipMemcpyHostToDevice, st));
     if (nch > 0) SSLAM_HIP(hipMemcpyAsync(v->children.p, children, 4 * (size_t)nch, hipMemcpyHostToDevice, st));
@@ -579,7 +597,7 @@ extern "C" int sslam_vocab_create(sslam_ctx* ctx, int nnodes, int levels, const 
     SSLAM_HIP(hipMemcpyAsync(v->wordId.p, word_id, 4 * (size_t)nnodes, hipMemcpyHostToDevice, st));
     SSLAM_HIP(hipMemcpyAsync(v->weight.p, weight, 8 * (size_t)nnodes, hipMemcpyHostToDevice, st));
     SSLAM_HIP(hipStreamSynchronize(st));
-    *out = v;
+    *out = guard.release();
     return SSLAM_OK;
 }
 
@@ -614,7 +632,7 @@ extern "C" int sslam_bow_transform_frame(sslam_ctx* ctx, const sslam_vocab* voca
         set_error("sslam_bow_transform_frame: invalid arguments"); return SSLAM_ERR_INVALID;
     }
     if (frame->n == 0) return SSLAM_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     return bow_core(ctx, vocab, frame->desc.as<uint8_t>(), frame->n, levelsup, word_out, weight_out, node_out);
 }
@@ -625,7 +643,7 @@ extern "C" int sslam_bow_transform(sslam_ctx* ctx, const sslam_vocab* vocab, con
         set_error("sslam_bow_transform: invalid arguments"); return SSLAM_ERR_INVALID;
     }
     if (n == 0) return SSLAM_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     int rc;
     if ((rc = ctx->scratch[7].ensure(32 * (size_t)n))) return rc;

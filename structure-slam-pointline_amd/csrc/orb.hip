@@ -1030,6 +1030,7 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
     if (!o || !d_images || !d_kp || !d_desc || !d_counts || w <= 0 || h <= 0 || nframes <= 0 || cap <= 0 || pitch < (size_t)w) {
         set_error("sslam_orb_extract_batch_dev: invalid arguments"); return SSLAM_ERR_INVALID;
     }
+    std::lock_guard<std::recursive_mutex> lk(o->ctx->mu);      // plan, workspace and profile records are shared state
     SSLAM_HIP(hipSetDevice(o->ctx->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : o->ctx->stream;
     int rc;
@@ -1097,7 +1098,7 @@ extern "C" int sslam_orb_extract(sslam_orb* o, const uint8_t* gray, int w, int h
     if (!o || !n_out) { set_error("sslam_orb_extract: null handle"); return SSLAM_ERR_INVALID; }
     if (w == 0 || h == 0 || !gray) { *n_out = 0; return SSLAM_OK; }      // empty image: return, outputs untouched (:1046-1047)
     if (w < 0 || h < 0 || stride < (size_t)w || !kp_out || !desc_out) { set_error("sslam_orb_extract: invalid arguments"); return SSLAM_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(o->ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(o->ctx->mu);
     SSLAM_HIP(hipSetDevice(o->ctx->device));
     hipStream_t st = o->ctx->stream;
     const int icap = sslam_orb_max_keypoints(o);
@@ -1136,7 +1137,7 @@ extern "C" int sslam_orb_batch_status_dev(sslam_orb* o, int cap, int32_t* d_stat
 
 extern "C" int sslam_orb_batch_status(sslam_orb* o, int cap, void* stream_, int* truncated_frames_out, int* first_frame_out) {
     if (!o) { set_error("sslam_orb_batch_status: null handle"); return SSLAM_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(o->ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(o->ctx->mu);
     int rc;
     if ((rc = o->dCounts.ensure(sizeof(int) * 4))) return rc;
     hipStream_t st = stream_ ? (hipStream_t)stream_ : o->ctx->stream;
@@ -1190,7 +1191,7 @@ extern "C" int sslam_orb_debug_candidates(sslam_orb* o, int frame, int level, in
 // batch and returns, per keypoint in output order, the blurred 37x37 window around it plus its KeyPoint record.
 extern "C" int sslam_orb_debug_blur_patches(sslam_orb* o, int frame, sslam_keypoint* kp_out, uint8_t* patches_out, int cap, int* n_out) {
     if (!o || frame < 0 || frame >= o->lastFrames || !kp_out || !patches_out || !n_out || cap <= 0) return SSLAM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(o->ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(o->ctx->mu);
     SSLAM_HIP(hipSetDevice(o->ctx->device));
     hipStream_t st = o->ctx->stream;
     SSLAM_HIP(hipStreamSynchronize(st));
@@ -1223,7 +1224,7 @@ int sslam_frame_from_device(sslam_ctx* ctx, int kind, const void* d_feats, const
 extern "C" int sslam_frame_from_orb(sslam_orb* o, const float bounds[4], sslam_frame** out) {
     if (!o || !bounds || !out) { set_error("sslam_frame_from_orb: invalid arguments"); return SSLAM_ERR_INVALID; }
     if (o->lastN < 0) { set_error("sslam_frame_from_orb: no sslam_orb_extract call to snapshot"); return SSLAM_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(o->ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(o->ctx->mu);
     return sslam_frame_from_device(o->ctx, 0, o->dKp.p, o->dDesc.as<uint8_t>(), o->lastN, bounds, out);
 }
 
