@@ -47,6 +47,10 @@ def test_multiwave_protocol_checks_are_necessary(proto):
     exe, frames = proto
     bad_none = sum(_run(exe, f, 6, 4, 10, 0, 0)[0] for f in frames)
     bad_only_c = sum(_run(exe, f, 6, 4, 10, 2, 0)[0] for f in frames)
-    bad_only_b = sum(_run(exe, f, 6, 10, 10, 1, 40)[0] for f in frames)
     assert bad_none > 0 and bad_only_c > 0, (bad_none, bad_only_c)
-    assert bad_only_b > 0, "check (c) never mattered in %d runs: the model does not exercise releases" % (10 * len(frames))
+    bad_only_b = 0; runs = 0
+    for attempt in range(4):            # (c) matters only when a release races a helper's view: scheduling-dependent, so a few rounds
+        bad_only_b += sum(_run(exe, f, 6, 10, 10, 1, 40)[0] for f in frames); runs += 10 * len(frames)
+        if bad_only_b:
+            break
+    assert bad_only_b > 0, "check (c) never mattered in %d runs: the model does not exercise releases" % runs
