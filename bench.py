@@ -302,17 +302,25 @@ def main():
         # every rank must end up on the same exchange path: the library's communicator if ALL ranks got one and one trial gather went
         # through everywhere, else torch.distributed (also RCCL) -- a measurement run must not die on the communicator bootstrap
         group = None; gather_impl = "sslam_group_gather_dev"; why = ""
+        def agreed(ok):      # every rank learns whether ALL ranks succeeded
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+        ok = True
         try:
             if os.environ.get("SSLAM_BENCH_FAIL_GROUP"):      # test knob: exercise the fallback
                 raise RuntimeError("SSLAM_BENCH_FAIL_GROUP")
             group = fe.Group(device=local_rank, rank=rank, nranks=world, uid=uid.cpu().numpy())
             gather = sharding.GroupGather(fe, ctx, group, pipe, dev)
-            pipe.step(cur, overlap=not args.no_overlap); gather.submit(); gather.wait()
-            ok = 1
         except Exception as e:      # noqa: BLE001
-            ok = 0; why = str(e)[:160]
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+            ok = False; why = str(e)[:160]
+        ok = agreed(ok)
+        if ok:                       # one trial exchange, agreed upon again, before anything is timed
+            try:
+                pipe.step(cur, overlap=not args.no_overlap); gather.submit(); gather.wait()
+            except Exception as e:      # noqa: BLE001
+                ok = False; why = str(e)[:160]
+            ok = agreed(ok)
+        if not ok:
             print("bench.py: rank %d falls back to torch.distributed for the gather (%s)" % (rank, why or "another rank failed"), file=sys.stderr)
             gather = sharding.TorchGather(fe, ctx, dist, pipe, dev, world, rank); group = None
             gather_impl = "torch.distributed gather (backend nccl = RCCL); library communicator unavailable: " + (why or "on another rank")
