@@ -442,6 +442,12 @@ int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long long* disag
  * mismatches_out[0] = divisions that differ, mismatches_out[1] = angles that differ. */
 int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long long mismatches_out[2]);
 
+/* The rectangle counter tests a pixel's level-line angle against (theta, tolerance) with integer compares: the set the reference's
+ * isAligned accepts (opencv lsd.cpp, restated at oracle/lsd_oracle.cpp:68-76; reached from src/ExtractLineSegment.cpp:38-40) is at most
+ * two intervals of fp32 bit patterns whose end points are found with the fp64 expression itself (csrc/lsd_align_win.h).  `cases` random and
+ * adversarial (theta, tolerance) pairs, each compared with the reference predicate on every angle the gradient table can hold, the
+ * neighbours of every end point and random patterns.  out3 = {disagreements (must be 0), tests, cases with three windows (must be 0)}. */
+int sslam_selftest_align_windows(sslam_ctx* ctx, int cases, long long out3[3]);
 /* Profiling aid (no reference counterpart): reads a known number of bytes in one of the library's two dominant access
  * patterns (mode 0: 16 B/lane coalesced stream, mode 1: scattered 16-B gathers) so that rocprofv3's FETCH_SIZE can be
  * calibrated on this device (tools/fetch_probe.py, profiles/README.md). */

@@ -25,6 +25,7 @@ using namespace sslam;
 namespace {
 
 #include "lsd_plan.h"
+#include "lsd_align_win.h"
 #include "lsd_front.h"
 #include "lsd_regions.h"
 #include "lsd_nfa.h"
@@ -139,9 +140,13 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t bpitch = ((size_t)w + 63) & ~(size_t)63;
     P.offBlur = take(bpitch * h);                         // sigma-0.75 blur of the source (LSD)
-    P.offAng = take(sizeof(float) * (size_t)P.npx);
+    // tiled planes, padded to whole k_lsd_grad blocks (256 x 4 pixels): see lsd_plan.h
+    P.tW = ((P.sw + 255) / 256) * 32; P.cW = P.tW * 2;
+    const size_t tileRows = ((size_t)P.sh + 3) / 4;
+    if ((size_t)P.tW * 32 * tileRows >= ((size_t)1 << 30)) { set_error("image %dx%d too large", w, h); return SSLAM_ERR_UNSUPPORTED; }      // plane elements are indexed with int
+    P.offT = take(sizeof(float) * 32 * (size_t)P.tW * tileRows);
     P.offS = take(sizeof(int) * (size_t)P.npx);
-    P.offPix = take(sizeof(float4) * (size_t)P.npx);
+    P.offCs = take(sizeof(float2) * 16 * (size_t)P.cW * tileRows);
     P.offOrder = take(sizeof(unsigned) * (size_t)P.npx);
     P.offTileHist = take(sizeof(int) * (size_t)P.nTiles * N_BINS);
     P.offReg = take(sizeof(unsigned) * (size_t)P.npx);
@@ -447,6 +452,22 @@ extern "C" int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long
     SSLAM_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     SSLAM_HIP(hipStreamSynchronize(ctx->stream));
     mismatches_out[0] = (long long)h[0]; mismatches_out[1] = (long long)h[1];      // division, atan2
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_selftest_align_windows(sslam_ctx* ctx, int cases, long long out3[3]) {
+    if (!ctx || cases <= 0 || !out3) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    ScopedDev dMem;
+    SSLAM_HIP(hipMalloc(&dMem.p, 3 * sizeof(unsigned long long)));
+    unsigned long long* d = (unsigned long long*)dMem.p;
+    SSLAM_HIP(hipMemset(d, 0, 3 * sizeof(unsigned long long)));
+    const int blocks = 512, rounds = (cases + blocks - 1) / blocks;
+    hipLaunchKernelGGL(k_selftest_align, dim3(blocks), dim3(256), 0, ctx->stream, 0xA11D0C5ull, rounds, d);
+    unsigned long long h[3] = {0, 0, 0};
+    SSLAM_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SSLAM_HIP(hipStreamSynchronize(ctx->stream));
+    out3[0] = (long long)h[0]; out3[1] = (long long)h[1]; out3[2] = (long long)h[2];
     return SSLAM_OK;
 }
 

@@ -109,9 +109,9 @@ __global__ void k_grad_table(float4* __restrict__ tab, double rho) {
 }
 
 // One thread = four horizontally adjacent pixels: the 2x5 source bytes come from two dword + two byte loads, the four
-// table gathers are in flight together, and angle / key / record leave as 16-byte stores when the row length allows.
-// S[i] = |g|^2 for DEFINED pixels and -1 otherwise, so the counting sort reads one array.
-// The 0.8x INTER_LINEAR_EXACT image (D7) is never stored: this kernel is bound by its 24 B/pixel of writes, so the 2 x 5
+// table gathers are in flight together.  Outputs (16 B per pixel; 24 in rounds 1-2): the tiled T plane (angle, NOTDEF), the tiled
+// Cs plane (cos, sin) and the row-major sort key S[i] = |g|^2 for DEFINED pixels and -1 otherwise (lsd_plan.h).
+// The 0.8x INTER_LINEAR_EXACT image (D7) is never stored: this kernel is bound by its writes, so the 2 x 5
 // scaled pixels a thread needs are recomputed here from the blurred source (four source rows as three aligned dwords each).
 __device__ __forceinline__ int scaled_px(unsigned e0, unsigned e1, unsigned cx, unsigned cy) {      // e = {p0, p1} bytes of the two source rows
     const unsigned r0 = (e0 & 255u) * (256u - cx) + ((e0 >> 8) & 255u) * cx, r1 = (e1 & 255u) * (256u - cx) + ((e1 >> 8) & 255u) * cx;
@@ -122,12 +122,20 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
     const int b = blockIdx.z;
     const uint8_t* base = ws + (size_t)b * P.frameBytes;
     const uint8_t* src = base + P.offBlur;
-    float* ang = (float*)(base + P.offAng);
+    float* T = (float*)(base + P.offT);
+    float2* Cs = (float2*)(base + P.offCs);
     int* S = (int*)(base + P.offS);
-    float4* pix = (float4*)(base + P.offPix);
     Misc* misc = (Misc*)(base + P.offMisc);
-    const int y = blockIdx.y * 4 + threadIdx.y, x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    __shared__ float4 trs[4][4 * 66];
+    const int lane = threadIdx.x, tyy = threadIdx.y;
+    const int y = blockIdx.y * 4 + tyy, x4 = (blockIdx.x * 64 + lane) * 4;
+    // A workgroup covers 256 x 4 pixels = 32 T tiles + 64 Cs tiles, contiguous in memory (tiles of one tile row follow each other).
+    // A thread's four pixels are half a T tile row and one Cs tile row: stored directly a store instruction would write 64 pieces of
+    // 16 / 32 bytes.  Staged through LDS (tile pitch padded: conflict-free b128 stores) the block leaves as 4 KB + 8 KB contiguous.
+    __shared__ float4 stT[32 * 10];
+    __shared__ float4 stC[64 * 9];
+    float4 rec[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rec[j] = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
     int smax = 0;
     if (y < P.sh && x4 < P.sw) {
         const bool lastRow = y >= P.sh - 1;
@@ -157,13 +165,12 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
                 p1[j] = scaled_px(rw[2][sx] | ((unsigned)rw[2][sx1] << 8), rw[3][sx] | ((unsigned)rw[3][sx1] << 8), (unsigned)txv[j].y, (unsigned)ty1.y);
             }
         }
-        float4 rec[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int DA = p1[j + 1] - p0[j], BC = p0[j + 1] - p1[j];
             const int gx = DA + BC, gy = DA - BC;
             const bool in = !lastRow && x4 + j < P.sw - 1;
-            rec[j] = in ? gtab[(gy + 510) * GT + (gx + 510)] : make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
+            if (in) rec[j] = gtab[(gy + 510) * GT + (gx + 510)];
         }
         int sv[4];
 #pragma unroll
@@ -173,37 +180,24 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
             smax = max(smax, sv[j]);
         }
         const size_t i = (size_t)y * P.sw + x4;
-        if ((P.sw & 3) == 0) {
-            *(float4*)(ang + i) = make_float4(rec[0].x, rec[1].x, rec[2].x, rec[3].x);
-            *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
-        } else {
+        if ((P.sw & 3) == 0) *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
+        else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) { ang[i + j] = rec[j].x; S[i + j] = sv[j]; }
-        }
-#ifndef SSLAM_GRAD_TRANSPOSE
-#define SSLAM_GRAD_TRANSPOSE 1
-#endif
-        if (SSLAM_GRAD_TRANSPOSE && (P.sw & 255) == 0) {
-            // the 16-byte records of a lane's four pixels are 64 bytes apart from the next lane's: stored directly, every store instruction
-            // would be 64 partial (16 of 64 bytes) L2 writes.  Transposed through LDS (the wave's own 4 KB, in-order DS, no workgroup
-            // barrier) each instruction writes 1 KB contiguous.  Row pitch 66 records: conflict-free for both the writes and the reads.
-            float4* t = trs[threadIdx.y];
-            const int lane = threadIdx.x;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t[j * 66 + lane] = rec[j];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            float4* row = pix + (size_t)y * P.sw + blockIdx.x * 256;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) row[k * 64 + lane] = t[(lane & 3) * 66 + k * 16 + (lane >> 2)];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) pix[i + j] = rec[j];      // per-pixel record for region growing: angle, cosf/sinf (D5), |g|^2
+            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) S[i + j] = sv[j];
         }
     }
+    stT[(lane >> 1) * 10 + tyy * 2 + (lane & 1)] = make_float4(rec[0].x, rec[1].x, rec[2].x, rec[3].x);
+    stC[lane * 9 + tyy * 2] = make_float4(rec[0].y, rec[0].z, rec[1].y, rec[1].z);
+    stC[lane * 9 + tyy * 2 + 1] = make_float4(rec[2].y, rec[2].z, rec[3].y, rec[3].z);
+    __syncthreads();
+    const int tid = tyy * 64 + lane;
+    float4* Tg = (float4*)(T + ((size_t)blockIdx.y * P.tW + (size_t)blockIdx.x * 32) * 32);
+    float4* Cg = (float4*)(Cs + ((size_t)blockIdx.y * P.cW + (size_t)blockIdx.x * 64) * 16);
+    Tg[tid] = stT[tid + 2 * (tid >> 3)];
+    Cg[tid] = stC[tid + (tid >> 3)];
+    Cg[tid + 256] = stC[tid + 256 + ((tid + 256) >> 3)];
     smax = wave_max(smax);
-    if (threadIdx.x == 0 && smax > 0) atomicMax(&misc->maxS, smax);
+    if (lane == 0 && smax > 0) atomicMax(&misc->maxS, smax);
 }
 
 __device__ __forceinline__ int lsd_bin(int s, double binCoef) {
@@ -279,6 +273,8 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, Ls
     __syncthreads();
     const double bc = lsd_bin_coef(misc->maxS);
     const int beg = tile * TILE_PX, end = min(beg + TILE_PX, P.npx);
+    const int y0 = beg / P.sw, x0 = beg - y0 * P.sw;
+    const float rsw = 1.0f / (float)P.sw;
     for (int i0 = beg; i0 < end; i0 += 256) {
         int v[4];
 #pragma unroll
@@ -298,7 +294,12 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, Ls
             }
             if (def) {
                 const int pos = cursor[bin] + rank;
-                order[pos] = (unsigned)(i0 + k * 64 + lane);
+                // x | y << 16 (the packing of the region lists): v = column of the tile's first pixel + offset < 2^24, so the float
+                // quotient is off by at most one
+                const int vo = x0 + (i0 - beg) + k * 64 + lane;
+                int qy = (int)((float)vo * rsw), rx = vo - qy * P.sw;
+                if (rx < 0) { --qy; rx += P.sw; } else if (rx >= P.sw) { ++qy; rx -= P.sw; }
+                order[pos] = (unsigned)rx | ((unsigned)(y0 + qy) << 16);
                 if (rank == total - 1) cursor[bin] = pos + 1;
             }
         }

@@ -304,89 +304,89 @@ __device__ __forceinline__ void store_rect(double* o, const RectD& rec) {
     o[7] = rec.theta; o[8] = rec.dx; o[9] = rec.dy; o[10] = rec.prec; o[11] = rec.p;
 }
 
-// angular distance used by isAligned (NOTDEF -> +inf)
-__device__ __forceinline__ double align_dist(float aDeg, double theta) {
-    const double n_theta = fabs(theta - (double)aDeg * DEG2RAD);          // fabs == the reference's conditional negations
-    const double wrapped = fabs(n_theta - M_2PI_);
-    return aDeg == NOTDEF_F ? 1e300 : (n_theta > M_3_2_PI_ ? wrapped : n_theta);
-}
-
-// The same two doubles, folded with a minimum: for a tolerance below pi/2 "fold at 3pi/2, then compare" and "min(n, |n - 2pi|) <= prec"
-// decide alike (n in (pi, 3pi/2] fails both, above 3pi/2 the wrapped value is the smaller one).  rect_nfa's tolerances are pi/8 and below.
-// NOTDEF is not handled here: callers AND the compare mask with ballot(a != NOTDEF).
-__device__ __forceinline__ double align_dist_min(float aDeg, double theta) {
-    const double n_theta = fabs(theta - (double)aDeg * DEG2RAD);
-    return fmin(n_theta, fabs(n_theta - M_2PI_));
-}
 // wave-wide vote on ONE comparison: the compare writes the lane mask itself.  (HIP's __ballot takes an int, and a vote on a conjunction
 // makes the compiler rebuild a 0/1 vector from the scalar masks -- v_cndmask + v_cmp per vote; conjunctions are done on the masks instead.)
 __device__ __forceinline__ unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // k_nfa_count: one wave walks a frame's rectangles.  The corner bookkeeping of rect_nfa (nfa_geom: sorting, slopes, integer
 // divisions) is the same few hundred instructions whether one lane or sixty-four execute it, so it runs lane-parallel for a
-// batch of up to 64 (rectangle, candidate) items whose results are parked in LDS; the wave then counts the items one after
+// batch of (rectangle, candidate) items whose results are parked in LDS; the wave then counts the items one after
 // the other with all lanes on the pixels.  Counters are wave-uniform (ballot + popcount), so nothing is reduced at the end.
+//
+// Round 3: the alignment test is integer.  theta and the tolerance are fixed per item, and isAligned is monotone in the stored fp32
+// angle, so the aligned set is at most two intervals of angle bit patterns (lsd_align_win.h: end points found with the fp64 expression
+// itself in the lane-parallel setup).  Per pixel: |T| (the used bit is the sign, NOTDEF becomes 1024 > every interval) and two
+// compares per interval -- "in [lo, hi]" is counted as #(b >= lo) - #(b > hi), which also makes lanes without a pixel (sentinel above
+// every hi) cancel without a `have` mask.  The pixels a candidate covers are no longer counted by votes either: that total is the
+// sum of its row widths, accumulated by the first lane of every row.
 constexpr int EVAL_CH = 1024;          // rectangles per item-list chunk (k_nfa_count, k_nfa_eval)
 constexpr int EVAL_REFILL = 16;
-struct CntItem { NfaGeom g; int c, j, lg; double theta, prec, p; };      // lg: log2 of the lanes sharing a row
+constexpr int CNT_NEST = 32;           // items per batch in the nested stages (their windows need 6 x 2 intervals each)
+constexpr unsigned PIX_NONE = 0x7FFFFFFFu;      // what a lane without a pixel holds: above every interval
+struct CntItem { NfaGeom g; int c, j, lg, nWin; int lo[2], hi[2]; };      // lg: log2 of the lanes sharing a row; [lo, hi]: aligned angle bit patterns
 
 // Pixel walk shared by the two counters below.  A row is shared by 2^lg lanes (lg picked per rectangle from its widest
 // row: tall thin rectangles put 32 rows in flight, flat ones spread one row over the whole wave); each lane owns a
-// contiguous run of the row and the wave steps through the runs twelve pixels at a time.  Every step starts with
-// ballot(pixel exists), which both ends the loop early and counts the rectangle's pixels.
+// contiguous run of the row and the wave steps through the runs twelve pixels at a time.
+// element of pixel (x, y) in the T plane given yb = tix(0, y): x + 24 * (x >> 3) steps over the other three rows of each tile
+__device__ __forceinline__ unsigned t_abs(const unsigned* __restrict__ Tb, int yb, int x) { return Tb[yb + x + (x >> 3) * 24] & 0x7FFFFFFFu; }
 
-// aligned-point counts of one rectangle for K nested precisions; total = pixels visited
+// aligned-point counts of one rectangle for K nested precisions; total = pixels visited.  win: [k][window] {lo, hi} in LDS
 template <int K, bool SMALL>
-__device__ __forceinline__ void count_item(const NfaGeom& g, int lg, double theta, const double (&prec)[6], const float* __restrict__ ang, int sw,
+__device__ __forceinline__ void count_item(const NfaGeom& g, int lg, int nWin, const int* __restrict__ win, const unsigned* __restrict__ Tb, int tW, int sw,
                                            int lane, int& totalOut, int (&alg)[6]) {
     const int nrows = g.y1 - g.y0 + 1;
     const int rowsPer = 64 >> lg, r = lane >> lg, sub = lane & ((1 << lg) - 1);
     int total = 0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) alg[k] = 0;
+    int lo0[K], hi0[K];                            // the second window (angles around the 0 / 360 seam) is rare: read from LDS where it is needed
+#pragma unroll
+    for (int k = 0; k < K; ++k) { lo0[k] = win[k * 4]; hi0[k] = win[k * 4 + 1]; }
     for (int t0 = 0; t0 < nrows; t0 += rowsPer) {
         const int t = t0 + r;
         int xa = 0, xb = -1; const int y = g.y0 + t;
         if (t < nrows) nfa_row_range<SMALL>(g, y, sw, xa, xb);
         const int width = max(xb - xa + 1, 0);
+        total += sub == 0 ? width : 0;
         const int share = (width + (1 << lg) - 1) >> lg;
         const int xs = xa + sub * share;
         const int mine = max(min(share, xb - xs + 1), 0);
-        const float* row = ang + (size_t)y * sw + xs;
+        const int yb = tix(0, max(y, 0), tW);
         for (int c0 = 0; vote(c0 < mine) != 0; c0 += 12) {
-            float a[12];
+            unsigned a[12];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
             if (vote(c0 + 4 < mine)) {
 #pragma unroll
-                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
             }
             if (vote(c0 + 8 < mine)) {
 #pragma unroll
-                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
             }
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
-                const unsigned long long have = vote(c0 + q < mine);
-                if (!have) break;
-                total += __popcll(have);
-                const double d = align_dist_min(a[q], theta);
-                const unsigned long long def = vote(a[q] != NOTDEF_F);       // lanes without a pixel hold NOTDEF too
+                if (!vote(c0 + q < mine)) break;
 #pragma unroll
-                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(d <= prec[k]) & def);
+                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote((int)a[q] >= lo0[k])) - __popcll(vote((int)a[q] > hi0[k]));
+                if (nWin > 1) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) alg[k] += __popcll(vote((int)a[q] >= win[k * 4 + 2])) - __popcll(vote((int)a[q] > win[k * 4 + 3]));
+                }
             }
         }
     }
-    totalOut = total;
+    totalOut = wave_sum(total);
 }
 
 // Stages 1-3: the (up to five) candidates of a rectangle differ by half-pixel width / offset steps and share theta and the
 // tolerance, so they are counted in ONE pass over the union of their rows: the angle test runs once per pixel, membership in
 // candidate j is two integer compares against that candidate's own row range (rect_nfa's edge stepping, per candidate).
 template <bool SMALL>
-__device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int nc, int lg, const float* __restrict__ ang, int sw, int lane,
+__device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int nc, int lg, const unsigned* __restrict__ Tb, int tW, int sw, int lane,
                                             int (&total)[MAXC], int (&alg)[MAXC]) {
-    const double theta = it5[0].theta, prec = it5[0].prec;
+    const int nWin = it5[0].nWin, lo0 = it5[0].lo[0], hi0 = it5[0].hi[0], lo1 = it5[0].lo[1], hi1 = it5[0].hi[1];
     NfaGeom g[MAXC];
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) g[j] = it5[j < nc ? j : 0].g;
@@ -410,41 +410,93 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
                 if (xbj[j] >= xaj[j]) { xa = min(xa, xaj[j]); xb = max(xb, xbj[j]); }
                 else { xaj[j] = 1; xbj[j] = 0; }
             }
+            total[j] += sub == 0 ? xbj[j] - xaj[j] + 1 : 0;             // the candidate's pixels in this row (0 for an empty row: xaj = 1, xbj = 0)
         }
         const int width = xb >= xa ? xb - xa + 1 : 0;
         const int share = (width + (1 << lg) - 1) >> lg;
         const int xs = xa + sub * share;
         const int mine = width > 0 ? max(min(share, xb - xs + 1), 0) : 0;
-        const float* row = ang + (size_t)y * sw + xs;
+        const int yb = tix(0, max(y, 0), tW);
         for (int c0 = 0; vote(c0 < mine) != 0; c0 += 12) {
-            float a[12];
+            unsigned a[12];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
             if (vote(c0 + 4 < mine)) {
 #pragma unroll
-                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
             }
             if (vote(c0 + 8 < mine)) {
 #pragma unroll
-                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? row[c0 + q] : NOTDEF_F;
+                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
             }
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
-                const unsigned long long have = vote(c0 + q < mine);
-                if (!have) break;
-                const unsigned long long al = vote(align_dist_min(a[q], theta) <= prec) & vote(a[q] != NOTDEF_F);      // subset of have
+                if (!vote(c0 + q < mine)) break;
+                unsigned long long al = vote((int)a[q] >= lo0) & ~vote((int)a[q] > hi0);       // lanes without a pixel hold PIX_NONE: above every hi
+                if (nWin > 1) al |= vote((int)a[q] >= lo1) & ~vote((int)a[q] > hi1);
+                if (!al) continue;
                 const int x = xs + c0 + q;
 #pragma unroll
                 for (int j = 0; j < MAXC; ++j) {
-                    if (j < nc) {
-                        const unsigned long long in = vote(x >= xaj[j]) & vote(x <= xbj[j]) & have;
-                        total[j] += __popcll(in);
-                        alg[j] += __popcll(in & al);
-                    }
+                    if (j < nc) alg[j] += __popcll(vote(x >= xaj[j]) & vote(x <= xbj[j]) & al);
                 }
             }
         }
     }
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) total[j] = wave_sum(total[j]);
+}
+
+// Self-test of lsd_align_win.h on the device (sslam_selftest_align_windows): one (theta, tolerance) case per block round -- theta anywhere
+// region2rect can put it ([0, 3pi)), negative, glued to the 0 / 2pi seams or to the pruning edges; tolerances pi/8 * 2^-h and arbitrary
+// ones below pi/2 -- whose windows are compared with the reference predicate (is_aligned_val, lsd_plan.h) on EVERY angle the gradient
+// table holds, on the +-3 neighbours of every end point and on random bit patterns.  out[0] = disagreements, out[1] = tests,
+// out[2] = cases with three non-empty windows (excluded by construction).
+__global__ __launch_bounds__(256) void k_selftest_align(unsigned long long seed, int rounds, unsigned long long* __restrict__ out) {
+    __shared__ int w[6];
+    __shared__ double tp[2];
+    unsigned long long bad = 0, tests = 0;
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x + 1) * 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (double)(x >> 11) * 0x1p-53; };
+    for (int rd = 0; rd < rounds; ++rd) {
+        if (threadIdx.x == 0) {
+            const int mode = (int)(rnd() * 8);
+            double theta = -kPI + rnd() * 4 * kPI;
+            if (mode == 0) theta = (rnd() - 0.5) * 0.9;
+            else if (mode == 1) theta = 2 * kPI + (rnd() - 0.5) * 0.9;
+            else if (mode == 2) theta = (double)fast_atan2_deg((float)((int)(rnd() * 1021) - 510), (float)((int)(rnd() * 1021) - 510) + 0.5f) * DEG2RAD;
+            else if (mode == 3) theta = -kPI + rnd() * 0.5;
+            double prec = kPI * (22.5 / 180.0);
+            const int h = (int)(rnd() * 7);
+            for (int i = 0; i < h; ++i) prec /= 2;
+            if (mode == 5) prec = rnd() * 1.5;
+            if (mode == 6) theta = prec * (rnd() < 0.5 ? 1 : -1) + (rnd() - 0.5) * 1e-9 + (rnd() < 0.5 ? 0 : 2 * kPI);
+            int n, lo[2], hi[2];
+            const bool ok = alnwin::windows(theta, prec, n, lo, hi);
+            w[0] = n; w[1] = lo[0]; w[2] = hi[0]; w[3] = lo[1]; w[4] = hi[1]; w[5] = ok ? 0 : 1;
+            tp[0] = theta; tp[1] = prec;
+        }
+        __syncthreads();
+        const double theta = tp[0], prec = tp[1];
+        const int n = w[0], lo0 = w[1], hi0 = w[2], lo1 = w[3], hi1 = w[4];
+        auto check = [&](int b) {
+            if (b < 0 || b > alnwin::BMAX) return;
+            const bool inw = (n > 0 && b >= lo0 && b <= hi0) || (n > 1 && b >= lo1 && b <= hi1);
+            ++tests;
+            if (is_aligned_val(__int_as_float(b), theta, prec) != inw) ++bad;
+        };
+        for (int i = threadIdx.x; i < GT * GT; i += blockDim.x) {
+            const int gy = i / GT - 510, gx = i - (i / GT) * GT - 510;
+            if (gx == 0 && gy == 0) continue;
+            check(__float_as_int(fast_atan2_deg((float)gx, (float)(-gy))));
+        }
+        if (threadIdx.x < 14) { const int d = (int)threadIdx.x % 7 - 3; check((threadIdx.x < 7 ? lo0 : hi0) + d); check((threadIdx.x < 7 ? lo1 : hi1) + d); }
+        for (int i = 0; i < 16; ++i) check((int)(rnd() * (alnwin::BMAX + 1.0)));
+        if (threadIdx.x == 0 && w[5]) atomicAdd(out + 2, 1ull);
+        __syncthreads();
+    }
+    if (bad) atomicAdd(out, bad);
+    atomicAdd(out + 1, tests);
 }
 
 // stage 0 is merged with the initial evaluation: same rectangle, six precisions (p, p/2 .. p/32); stage 4 likewise has one
@@ -454,20 +506,21 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
 #endif
 __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
     __shared__ CntItem its[64];
+    __shared__ int nestWin[CNT_NEST][6][4];                          // nested stages: {lo0, hi0, lo1, hi1} per precision
     __shared__ unsigned short act[EVAL_CH];
     const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
-    const Misc* misc = (const Misc*)(base + P.offMisc);
+    Misc* misc = (Misc*)(base + P.offMisc);
     const int nCand = misc->nCand;
-    const float* ang = (const float*)(base + P.offAng);
+    const unsigned* Tb = (const unsigned*)(base + P.offT);
     const double* rects = (const double*)(base + P.offCand);
     NfaState* st = (NfaState*)(base + P.offNfa);
-    const int sw = P.sw, sh = P.sh;
+    const int sw = P.sw, sh = P.sh, tW = P.tW;
     const int per = (nCand + gridDim.x - 1) / gridDim.x;
     const int c0 = blockIdx.x * per, c1 = min(c0 + per, nCand);
     const bool nested = stage == 0 || stage == 4;
     const bool small = sw < 32768 && sh < 32768;
-    const int rpb = nested ? 64 : 12;                              // rectangles per batch (stages 1-3: five lanes each)
+    const int rpb = nested ? CNT_NEST : 12;                        // rectangles per batch (stages 1-3: five lanes each)
     for (int chunk = c0; chunk < c1; chunk += EVAL_CH) {
         const int cend = min(chunk + EVAL_CH, c1);
         int nAct = 0;
@@ -484,7 +537,7 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
             const int nIt = nested ? nr : nr * MAXC;
             {
                 const int ri = nested ? lane : lane / MAXC, j = nested ? 0 : lane - ri * MAXC;
-                bool valid = false;
+                bool valid = false, winOk = true;
                 int c = 0;
                 if (lane < nIt) {
                     c = chunk + act[a0 + ri];
@@ -494,12 +547,30 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
                     CntItem& I = its[lane];
                     I.c = c; I.j = valid ? j : -1;
                     if (valid) {
-                        I.g = nfa_geom(r, sh); I.theta = r.theta; I.prec = r.prec; I.p = r.p;
+                        I.g = nfa_geom(r, sh);
                         const int need = (nfa_max_width(I.g) + (nested ? 0 : 3) + 11) / 12;       // lanes per row so that a run is <= 12 pixels
                         int lg = 1; while ((1 << lg) < need && lg < 6) ++lg;
                         I.lg = lg;
+                        if (nested) {                                // six (stage 0) / five (stage 4) tolerances around one theta
+                            int nw = 0;
+#pragma unroll 1
+                            for (int k = 0; k < (stage == 0 ? 6 : 5); ++k) {
+                                const double pk = stage == 0 ? (k == 0 ? r.prec : ldexp(r.p, -k) * kPI) : ldexp(r.p, -(k + 1)) * kPI;
+                                int n, lo[2], hi[2];
+                                winOk &= alnwin::windows(r.theta, pk, n, lo, hi);
+                                // (which window lands in which slot may differ between tolerances: the counter adds both slots, empty ones count nothing)
+                                nestWin[lane][k][0] = lo[0]; nestWin[lane][k][1] = hi[0]; nestWin[lane][k][2] = lo[1]; nestWin[lane][k][3] = hi[1];
+                                nw = max(nw, n);
+                            }
+                            I.nWin = nw;
+                        } else if (j == 0) {                         // the candidates of a rectangle share theta and the tolerance: the first one's windows serve all
+                            int n;
+                            winOk = alnwin::windows(r.theta, r.prec, n, I.lo, I.hi);
+                            I.nWin = n;
+                        }
                     }
                 }
+                if (__ballot(!winOk) && lane == 0) misc->overflow = 1;      // three non-empty windows: excluded by construction (lsd_align_win.h); never count wrong silently
                 const unsigned long long vm = __ballot(valid);
                 if (lane < nIt) {
                     if (nested) { if (!valid) st[c].nc = 0; }
@@ -515,8 +586,8 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
                     for (int j = 0; j < MAXC; ++j) nc += it5[j].j >= 0 ? 1 : 0;           // valid candidates form a prefix
                     if (nc == 0) continue;
                     int total[MAXC], alg[MAXC];
-                    if (small) count_rect5<true>(it5, nc, it5[0].lg, ang, sw, lane, total, alg);
-                    else count_rect5<false>(it5, nc, it5[0].lg, ang, sw, lane, total, alg);
+                    if (small) count_rect5<true>(it5, nc, it5[0].lg, Tb, tW, sw, lane, total, alg);
+                    else count_rect5<false>(it5, nc, it5[0].lg, Tb, tW, sw, lane, total, alg);
                     const int c = it5[0].c;
                     if (lane < nc) {
                         const int tj = lane == 0 ? total[0] : lane == 1 ? total[1] : lane == 2 ? total[2] : lane == 3 ? total[3] : total[4];
@@ -529,15 +600,12 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
                 const int j = its[it].j;
                 if (j < 0) continue;
                 const NfaGeom g = its[it].g;
-                const double theta = its[it].theta, p = its[it].p;
                 const int c = its[it].c;
-                double prec[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) prec[k] = stage == 0 ? (k == 0 ? its[it].prec : ldexp(p, -k) * kPI) : ldexp(p, -(k + 1)) * kPI;
                 int total, alg[6];
-                const int lg = its[it].lg;
-                if (stage == 0) { if (small) count_item<6, true>(g, lg, theta, prec, ang, sw, lane, total, alg); else count_item<6, false>(g, lg, theta, prec, ang, sw, lane, total, alg); }
-                else { if (small) count_item<5, true>(g, lg, theta, prec, ang, sw, lane, total, alg); else count_item<5, false>(g, lg, theta, prec, ang, sw, lane, total, alg); }
+                const int lg = its[it].lg, nWin = its[it].nWin;
+                const int* win = &nestWin[it][0][0];
+                if (stage == 0) { if (small) count_item<6, true>(g, lg, nWin, win, Tb, tW, sw, lane, total, alg); else count_item<6, false>(g, lg, nWin, win, Tb, tW, sw, lane, total, alg); }
+                else { if (small) count_item<5, true>(g, lg, nWin, win, Tb, tW, sw, lane, total, alg); else count_item<5, false>(g, lg, nWin, win, Tb, tW, sw, lane, total, alg); }
                 if (lane == 0) {
                     const int K = stage == 0 ? 6 : 5;
 #pragma unroll

@@ -15,6 +15,15 @@ struct RegQ {
     }
     __device__ __forceinline__ void set(int i, unsigned v) const { if (i < QCAP) lds[i] = v; else glb[i] = v; }
 };
+// the per-pixel planes of one frame (lsd_plan.h): T = angle | used in the sign bit (8 x 4 tiles), Cs = {cos, sin} (4 x 4 tiles), S = |g|^2 (row-major)
+struct Planes {
+    float* T; const float2* Cs; const int* S; int tW, cW;
+    __device__ __forceinline__ unsigned* Tb() const { return (unsigned*)T; }
+    __device__ __forceinline__ int ti(int x, int y) const { return tix(x, y, tW); }
+    __device__ __forceinline__ int ti(unsigned e) const { return tix((int)(e & 0xFFFF), (int)(e >> 16), tW); }
+};
+__device__ __forceinline__ bool t_free(float t) { return __float_as_int(t) >= 0; }      // defined and not part of a region
+__device__ __forceinline__ float t_used(float t) { return __int_as_float(__float_as_int(t) | (int)USED_BIT); }
 // multi-wave form (below): a helper's private marks: a 256 x 256 bit TORUS (8 KB of LDS whatever the frame size).  A region that stays within +-126 pixels of its seed
 // (tested neighbours: +-127) cannot alias on it; a helper abandons a region that reaches further and the main wave grows that one itself.
 constexpr int MW_BM_WORDS = 256 * 256 / 32, MW_REACH = 126;
@@ -107,7 +116,7 @@ __global__ void k_selftest_region_div(unsigned long long seed, int iters, unsign
 // SPEC (multi-wave form, lsd_regions_mw.h): a helper wave grows a region AHEAD of the frame's main wave.  It never writes the pixel map: the
 // pixels it takes are marked in its own bitmap `bm` (LDS), and it gives up (returns -n) when the list would outgrow `capN` points.
 template <bool LAT, bool WIDE, bool SPEC = false>
-__device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos, float seedSin, int sw, int sh, float4* __restrict__ pix, const RegQ& rq,
+__device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos, float seedSin, int sw, int sh, const Planes& pl, const RegQ& rq,
                              double prec, double& regAngleOut, long long* __restrict__ verifyCnt, unsigned* __restrict__ bm = nullptr, int capN = 0) {
 #ifndef SSLAM_LSD_READLANE
 #define SSLAM_LSD_READLANE 0
@@ -115,13 +124,12 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
     constexpr bool RL = LAT || SSLAM_LSD_READLANE;      // broadcasts of the accepted lane: v_readlane for the lone wave, LDS permutes with six waves per SIMD (measured: 35.4 vs 37.2 ms)
     constexpr bool DRIFT = !WIDE && SSLAM_LSD_DRIFT;
     const int lane = threadIdx.x & 63;
-    const int seed = seedY * sw + seedX;
     int n = 1;
     double regAngle = (double)seedDeg * DEG2RAD;          // the seed's level-line angle, cos / sin: evaluated lane-parallel for a whole chunk of seed candidates (k_lsd_regions)
     float sumdx = seedCos, sumdy = seedSin;
     if (lane == 0) {
         rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16));
-        if (SPEC) { const int bi = mw_bit(seedX, seedY); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pix[seed].x = USED_F;
+        if (SPEC) { const int bi = mw_bit(seedX, seedY); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pl.T[pl.ti(seedX, seedY)] = t_used(seedDeg);
     }
     const int g = lane >> 3, k8 = lane & 7;             // group (queue slot) and neighbour slot (centre skipped)
     const int k = k8 + (k8 >= 4 ? 1 : 0);                // row-major 3x3 position 0..8 without 4
@@ -144,7 +152,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
         // clamped into the image) and the three conditions (slot staged, neighbour inside the image, pixel neither NOTDEF nor USED) meet as
         // lane masks: fewer instructions and no branches on the one wave's path (14.2 -> 13.5 ms per frame).  With six waves per SIMD the
         // extra gather lanes cost more than the branches save (32.3 -> 32.8 ms per 6144 frames), so that flavour keeps the masked loads.
-        int nidx = -1, xx = 0, yy = 0; float4 px4 = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
+        int nidx = -1, xx = 0, yy = 0; float tv = NOTDEF_F; float2 cs = make_float2(0.f, 0.f);      // nidx: the pixel's element in the T plane (its identity)
         unsigned long long candM;
 #ifdef SSLAM_LSD_CYCLES
         const long long tS0 = __builtin_readcyclecounter();
@@ -152,9 +160,11 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
         if (LAT) {
             const unsigned e = rq.get_n(min(i + g, n - 1), n);
             xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
-            nidx = min(max(yy, 0), sh - 1) * sw + min(max(xx, 0), sw - 1);
-            px4 = pix[nidx];                             // .x < 0: NOTDEF or already USED
-            candM = __builtin_amdgcn_ballot_w64(px4.x >= 0.f) & __builtin_amdgcn_ballot_w64((unsigned)xx < (unsigned)sw) &
+            const int cx = min(max(xx, 0), sw - 1), cy = min(max(yy, 0), sh - 1);
+            nidx = pl.ti(cx, cy);
+            tv = pl.T[nidx];                             // sign bit set: NOTDEF or already USED
+            cs = pl.Cs[cix(cx, cy, pl.cW)];
+            candM = __builtin_amdgcn_ballot_w64(t_free(tv)) & __builtin_amdgcn_ballot_w64((unsigned)xx < (unsigned)sw) &
                     __builtin_amdgcn_ballot_w64((unsigned)yy < (unsigned)sh) & (np == 8 ? ~0ull : ((1ull << (np * 8)) - 1));
             if (SPEC) { const int bi = mw_bit(xx, yy); candM &= ~__builtin_amdgcn_ballot_w64((bm[bi >> 5] >> (bi & 31)) & 1u); }      // taken by this helper itself
         } else {
@@ -163,9 +173,10 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
                 const unsigned e = rq.get_n(i + g, n);
                 xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
                 if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
-                    nidx = yy * sw + xx;
-                    px4 = pix[nidx];
-                    cand = px4.x >= 0.f;
+                    nidx = pl.ti(xx, yy);
+                    tv = pl.T[nidx];
+                    cs = pl.Cs[cix(xx, yy, pl.cW)];
+                    cand = t_free(tv);
                 }
             }
             candM = __builtin_amdgcn_ballot_w64(cand);
@@ -177,8 +188,8 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
         unsigned long long accMask = 0;                    // lanes accepted from this staging, in lane (= acceptance) order
         // the live candidates and "lanes after the last accepted one" are wave-uniform 64-bit masks: scalar updates, no VALU
         auto aligned_mask = [&]() -> unsigned long long {
-            if (WIDE) return __builtin_amdgcn_ballot_w64(is_aligned_val(px4.x, regAngle, prec));
-            const double d = fabs(regAngle - (double)px4.x * DEG2RAD);
+            if (WIDE) return __builtin_amdgcn_ballot_w64(is_aligned_val(tv, regAngle, prec));
+            const double d = fabs(regAngle - (double)tv * DEG2RAD);
             return __builtin_amdgcn_ballot_w64(d <= prec) | __builtin_amdgcn_ballot_w64(fabs(d - M_2PI_) <= prec);
         };
         unsigned long long live = candM;                      // candidates that are still to be decided: the lanes above the last accepted one
@@ -190,12 +201,12 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
                 if (LAT) accMask |= 1ull << sel;               // lone wave: the used-map / queue stores follow the loop, all lanes at once
                 else if (lane == sel) {                        // LDS slot QCAP is a sink, so the common case has no branch around the store
                     const unsigned v = (unsigned)xx | ((unsigned)yy << 16);
-                    pix[nidx].x = USED_F; rq.lds[min(n, QCAP)] = v;
+                    pl.T[nidx] = t_used(tv); rq.lds[min(n, QCAP)] = v;
                     if (n >= QCAP) rq.glb[n] = v;
                 }
                 ++n;
-                sumdx = __fadd_rn(sumdx, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.y), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.y))));
-                sumdy = __fadd_rn(sumdy, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.z), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.z))));
+                sumdx = __fadd_rn(sumdx, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(cs.x), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(cs.x))));
+                sumdy = __fadd_rn(sumdy, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(cs.y), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(cs.y))));
                 regAngle = (double)fast_atan2_deg_unit(sumdy, sumdx) * DEG2RAD;
                 candM &= ~__builtin_amdgcn_ballot_w64(nidx == selIdx);      // the accepted pixel is now USED for every later visitor
                 m = aligned_mask() & candM & (~1ull << sel);                // only lanes above sel
@@ -204,7 +215,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
             // per lane and per reference angle: which side of the tolerance the candidate is on, and how far from it
             float dc, u; unsigned long long side;
             auto classify = [&]() {
-                const float d = fabsf(__fsub_rn(thetaRef, px4.x));
+                const float d = fabsf(__fsub_rn(thetaRef, tv));
                 dc = fminf(d, __fsub_rn(360.f, d));                          // circular distance of the lane's level-line angle to thetaRef
                 u = fabsf(__fsub_rn(dc, precDeg));
                 side = __builtin_amdgcn_ballot_w64(dc <= precDeg);
@@ -216,7 +227,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
 #ifdef SSLAM_LSD_DRIFT_VERIFY
                 {
                     const double ra = (double)fast_atan2_deg_unit(sumdy, sumdx) * DEG2RAD;
-                    const double d = fabs(ra - (double)px4.x * DEG2RAD);
+                    const double d = fabs(ra - (double)tv * DEG2RAD);
                     const unsigned long long mx = (__builtin_amdgcn_ballot_w64(d <= prec) | __builtin_amdgcn_ballot_w64(fabs(d - M_2PI_) <= prec)) & live;
                     const int selX = mx ? __ffsll((long long)mx) - 1 : -1, selC = cm ? __ffsll((long long)cm) - 1 : -1;
                     const bool decided = selC < 0 || !((unc >> selC) & 1ull);
@@ -240,12 +251,12 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
                 if (LAT) accMask |= 1ull << sel;
                 else if (lane == sel) {
                     const unsigned v = (unsigned)xx | ((unsigned)yy << 16);
-                    pix[nidx].x = USED_F; rq.lds[min(n, QCAP)] = v;
+                    pl.T[nidx] = t_used(tv); rq.lds[min(n, QCAP)] = v;
                     if (n >= QCAP) rq.glb[n] = v;
                 }
                 ++n;
-                sumdx = __fadd_rn(sumdx, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.y), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.y))));
-                sumdy = __fadd_rn(sumdy, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(px4.z), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(px4.z))));
+                sumdx = __fadd_rn(sumdx, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(cs.x), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(cs.x))));
+                sumdy = __fadd_rn(sumdy, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(cs.y), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(cs.y))));
                 {   // the sums turned by at most K (dc(sel) + eps + E) / max(|S'x|, |S'y|) + ADD degrees (eps + E = band - slack + E)
                     const float dcs = __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(dc), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(dc)));
                     const float M = fmaxf(fabsf(sumdx), fabsf(sumdy));
@@ -259,7 +270,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
             }
         }
         if (LAT && accMask != 0 && ((accMask >> lane) & 1ull)) {
-            if (SPEC) { const int bi = mw_bit(xx, yy); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pix[nidx].x = USED_F;
+            if (SPEC) { const int bi = mw_bit(xx, yy); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pl.T[nidx] = t_used(tv);
             rq.set(nBefore + mbcnt(accMask), (unsigned)xx | ((unsigned)yy << 16));
         }
         if (SPEC && __builtin_amdgcn_ballot_w64(((accMask >> lane) & 1ull) && (abs(xx - seedX) > MW_REACH || abs(yy - seedY) > MW_REACH))) return -n;      // leaves the torus
@@ -274,11 +285,11 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
 }
 
 template <bool LAT>
-__device__ __forceinline__ int region_grow_m(int seedX, int seedY, float seedDeg, float seedCos, float seedSin, int sw, int sh, float4* __restrict__ pix, const RegQ& rq,
+__device__ __forceinline__ int region_grow_m(int seedX, int seedY, float seedDeg, float seedCos, float seedSin, int sw, int sh, const Planes& pl, const RegQ& rq,
                                              double prec, double& regAngleOut, long long* __restrict__ verifyCnt) {
     // the first growth runs at 22.5 degrees; refine()'s tolerance (two standard deviations of the angles) is normally smaller still
-    if (prec < 1.5) return region_grow_w<LAT, false>(seedX, seedY, seedDeg, seedCos, seedSin, sw, sh, pix, rq, prec, regAngleOut, verifyCnt);
-    return region_grow_w<LAT, true>(seedX, seedY, seedDeg, seedCos, seedSin, sw, sh, pix, rq, prec, regAngleOut, verifyCnt);
+    if (prec < 1.5) return region_grow_w<LAT, false>(seedX, seedY, seedDeg, seedCos, seedSin, sw, sh, pl, rq, prec, regAngleOut, verifyCnt);
+    return region_grow_w<LAT, true>(seedX, seedY, seedDeg, seedCos, seedSin, sw, sh, pl, rq, prec, regAngleOut, verifyCnt);
 }
 
 // Three fp64 running sums that must be folded strictly in region order (the reference adds point after point).  The wave
@@ -304,7 +315,7 @@ __device__ __forceinline__ double ordered_sums_get(const OrdSum& S, int which) {
 
 // one wave: region2rect + get_theta.  Loads and per-point products run lane-parallel; the
 // fp64 sums are then folded strictly in region order (ordered_sums_add), extents by min/max.
-__device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __restrict__ pix, double regAngle, double prec, double p, RectD& rec, double* __restrict__ red) {
+__device__ void region2rect_m(const RegQ& rq, int n, int sw, const int* __restrict__ S, double regAngle, double prec, double p, RectD& rec, double* __restrict__ red) {
     const int lane = threadIdx.x & 63;
     OrdSum S1; S1.acc = 0;
     double wgt0 = 0; int px0 = 0, py0 = 0;                  // the first 64 points stay in registers for the second pass (most regions are that short)
@@ -314,7 +325,7 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
         if (i < n) {
             const unsigned e = rq.get_n(i, n);
             const int px = e & 0xFFFF, py = e >> 16;
-            wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
+            wgt = sqrt((double)S[py * sw + px] / 4.0);
             fx = (double)px * wgt; fy = (double)py * wgt;
             if (base == 0) { wgt0 = wgt; px0 = px; py0 = py; }
         }
@@ -332,7 +343,7 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
             if (base != 0) {
                 const unsigned e = rq.get_n(i, n);
                 px = e & 0xFFFF; py = e >> 16;
-                wgt = sqrt((double)__float_as_int(pix[py * sw + px].w) / 4.0);
+                wgt = sqrt((double)S[py * sw + px] / 4.0);
             }
             const double ddx = (double)px - x, ddy = (double)py - y;
             a = ddy * ddy * wgt; b = ddx * ddx * wgt; c = ddx * ddy * wgt;
@@ -369,8 +380,8 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const float4* __res
 // keep patterns before it was written down here, and by the parity tests since).  n/64 wave steps instead of n.
 // scratch: 1536 bytes of LDS (keep masks of <= 16 chunks, then the hole positions as u16: holes <= min(K, n - K) <= 512).
 template <bool SPEC = false>
-__device__ int remove_far_points_lds(unsigned* __restrict__ q, int n, double xc, double yc, double radSq, int sw, float4* __restrict__ pix,
-                                     const float* __restrict__ ang, void* scratch, unsigned* __restrict__ bm = nullptr) {
+__device__ int remove_far_points_lds(unsigned* __restrict__ q, int n, double xc, double yc, double radSq, const Planes& pl,
+                                     void* scratch, unsigned* __restrict__ bm = nullptr) {
     const int lane = threadIdx.x & 63;
     unsigned long long* km = (unsigned long long*)scratch;
     unsigned short* holeIdx = (unsigned short*)(km + 16);
@@ -386,7 +397,7 @@ __device__ int remove_far_points_lds(unsigned* __restrict__ q, int n, double xc,
             keep = !(d2 > radSq);
             if (!keep) {                                                          // NOTUSED again
                 if (SPEC) { const int bi = mw_bit(px, py); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
-                else { const int id = py * sw + px; pix[id].x = ang[id]; }
+                else { unsigned* t = pl.Tb() + pl.ti(px, py); *t &= ~USED_BIT; }
             }
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
@@ -519,13 +530,13 @@ __device__ __forceinline__ bool boxes_meet(unsigned lo, unsigned hi, unsigned el
 // for the multi-wave event log).  SPEC form (helper wave): marks live in the private bitmap, the re-grown list goes BEHIND the first one in the
 // arena and reduce_region_radius works on a copy, so that everything the helper ever accepted can be validated later.
 template <bool LAT, bool SPEC, bool WANTBOX>
-__device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& regAngle, RegQ& rq, float4* __restrict__ pix, const float* __restrict__ ang, double* __restrict__ red,
+__device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& regAngle, RegQ& rq, const Planes& pl, double* __restrict__ red,
                             RectD& rec, bool& refined, unsigned& evLo, unsigned& evHi, long long* cycs, SpecLists* sl, long long* verifyCnt) {
     const int lane = threadIdx.x & 63;
     const int sw = P.sw, sh = P.sh;
     const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
     const long long tA = SSLAM_CLK();
-    region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
+    region2rect_m(rq, n, sw, pl.S, regAngle, prec, p, rec, red);
     cycs[0] = SSLAM_CLK() - tA;
     // ---- refine (LSD_REFINE_STD part)
     double density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
@@ -542,10 +553,10 @@ __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& r
         double ad = 0; bool in = false;
         if (i < n) {
             const unsigned e = rq.get_n(i, n);
-            const int px = e & 0xFFFF, py = e >> 16, id = py * sw + px;
-            const float aOrig = ang[id];
+            const int px = e & 0xFFFF, py = e >> 16, id = pl.ti(px, py);
+            const float aOrig = fabsf(pl.T[id]);      // the angle whatever the used bit says (a helper's view may be racing the main wave's marks)
             if (SPEC) { const int bi = mw_bit(px, py); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
-            else pix[id].x = aOrig;                 // NOTUSED again
+            else pl.T[id] = aOrig;                  // NOTUSED again
             if (dist_d(xc, yc, (double)px, (double)py) < rec.width) { in = true; ad = angle_diff_signed((double)aOrig * DEG2RAD, ang_c); }
         }
         // points outside the radius contribute an exact +0.0 (the sums start at +0 and can never be -0)
@@ -560,20 +571,20 @@ __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& r
         const int capN = min(QCAP, sl->cap);
         if (capN <= 64) { sl->gaveUp = true; return false; }
         rq.lds = sl->free;
-        n = tau < 1.5 ? region_grow_w<true, false, true>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pix, rq, tau, regAngle, nullptr, sl->bm, capN)
-                      : region_grow_w<true, true, true>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pix, rq, tau, regAngle, nullptr, sl->bm, capN);
+        n = tau < 1.5 ? region_grow_w<true, false, true>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pl, rq, tau, regAngle, nullptr, sl->bm, capN)
+                      : region_grow_w<true, true, true>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pl, rq, tau, regAngle, nullptr, sl->bm, capN);
         if (n < 0) {
             for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
             sl->gaveUp = true; return false;
         }
         sl->nB = n; sl->free += n; sl->cap -= n;
-    } else n = region_grow_m<LAT>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pix, rq, tau, regAngle, verifyCnt);
+    } else n = region_grow_m<LAT>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pl, rq, tau, regAngle, verifyCnt);
     if (WANTBOX) {                                // the re-grown region can reach outside the first one, and reduce_region_radius releases from it
         unsigned l2, h2;
         if (n <= QCAP) { list_bbox(rq.lds, n, lane, l2, h2); evLo = pk_min_u16(evLo, l2); evHi = pk_max_u16(evHi, h2); } else { evLo = 0u; evHi = 0xFFFFFFFFu; }
     }
     if (n < 2) return false;
-    region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
+    region2rect_m(rq, n, sw, pl.S, regAngle, prec, p, rec, red);
     density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     if (density < DENSITY_TH) {
         const long long tr0 = SSLAM_CLK();
@@ -592,22 +603,21 @@ __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& r
         bool good = true;
         while (density < DENSITY_TH) {
             radSq *= 0.75 * 0.75;
-            if (SPEC) n = remove_far_points_lds<true>(rq.lds, n, xc, yc, radSq, sw, pix, ang, red, sl->bm);
-            else if (n <= QCAP) n = remove_far_points_lds<false>(rq.lds, n, xc, yc, radSq, sw, pix, ang, red);
+            if (SPEC) n = remove_far_points_lds<true>(rq.lds, n, xc, yc, radSq, pl, red, sl->bm);
+            else if (n <= QCAP) n = remove_far_points_lds<false>(rq.lds, n, xc, yc, radSq, pl, red);
             else for (int i = 0; i < n; ++i) {
                 const unsigned e = rq.get(i);
                 const int px = e & 0xFFFF, py = e >> 16;
                 const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
                 if (d2 > radSq) {
-                    const int id = py * sw + px;
                     const unsigned last = rq.get(n - 1);
-                    if (lane == 0) { pix[id].x = ang[id]; rq.set(i, last); }
+                    if (lane == 0) { unsigned* t = pl.Tb() + pl.ti(px, py); *t &= ~USED_BIT; rq.set(i, last); }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     --n; --i;
                 }
             }
             if (n < 2) { good = false; break; }
-            region2rect_m(rq, n, sw, pix, regAngle, prec, p, rec, red);
+            region2rect_m(rq, n, sw, pl.S, regAngle, prec, p, rec, red);
             density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
         }
         cycs[2] = SSLAM_CLK() - tr0;
@@ -625,9 +635,8 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                                                  const MwShared& mw) {
     const int lane = threadIdx.x & 63;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
-    const float* ang = (const float*)(base + P.offAng);
-    float4* pix = (float4*)(base + P.offPix);
-    const unsigned* order = (const unsigned*)(base + P.offOrder);
+    Planes pl; pl.T = (float*)(base + P.offT); pl.Cs = (const float2*)(base + P.offCs); pl.S = (const int*)(base + P.offS); pl.tW = P.tW; pl.cW = P.cW;
+    const unsigned* order = (const unsigned*)(base + P.offOrder);          // seed candidates in LSD's order, x | y << 16
     double* candOut = (double*)(base + P.offCand);
     Misc* misc = (Misc*)(base + P.offMisc);
     const int sw = P.sw, sh = P.sh;
@@ -652,19 +661,20 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
     for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
         if (MW) lds_st(&mw.ctl->mainPos, pos0);                   // every chunk below pos0 is finished: its helper may move on
         const int q = pos0 + lane;
-        const int idx = q < nOrd ? (int)order[q] : -1;
-        // One gather per chunk of 64 seed candidates: pix.x is the candidate's level-line angle while it is unused.  What a region start
+        const bool have = q < nOrd;
+        const unsigned idx = have ? order[q] : 0xFFFFFFFFu;
+        const int tiSeed = have ? pl.ti(idx) : 0;
+        // One gather per chunk of 64 seed candidates: T is the candidate's level-line angle while it is unused.  What a region start
         // needs from its seed -- coordinates, the angle, cos and sin of it (two fp64 evaluations that the whole wave used to execute for ONE
         // seed, after a dependent load of the angle) -- is computed here for all 64 candidates at once and parked in LDS.
-        const float a0 = idx >= 0 ? pix[idx].x : -1.f;
-        unsigned long long unM = __ballot(a0 >= 0.f);         // candidates of this chunk that are still unused (wave-uniform, kept up to date below)
+        const float a0 = have ? pl.T[tiSeed] : NOTDEF_F;
+        unsigned long long unM = __ballot(t_free(a0));        // candidates of this chunk that are still unused (wave-uniform, kept up to date below)
         if (!unM) continue;
         // (multi-wave form: only the seeds the main wave grows itself need this -- evaluated at the first one of the chunk)
         bool stashReady = false;
         auto fill_stash = [&]() {
-            const int cy = idx / sw, cx = idx - cy * sw;
             const double ar = (double)a0 * DEG2RAD;
-            seedStash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
+            seedStash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float((int)idx));
             stashReady = true;
         };
         if (!MW) fill_stash();
@@ -725,15 +735,20 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                     }
                     // everything the helper accepted on the way (A, and B when refine() ran) must be unused now
                     // (a region of one point is its seed, which the main wave knows to be unused: no gather -- 45 % of the takes)
+                    float v0 = 0.f; int ti0 = 0;                 // first 64 points: value and element kept for the marking below
                     for (int bs = 0; ok && nA + nB > 1 && bs < nA + nB; bs += 64) {
                         const int i = bs + lane;
                         bool usedNow = false;
-                        if (i < nA + nB) { const unsigned e = lstA[i]; usedNow = pix[(int)(e >> 16) * sw + (int)(e & 0xFFFF)].x < 0.f; }
+                        if (i < nA + nB) { const int ti = pl.ti(lstA[i]); const float v = pl.T[ti]; usedNow = !t_free(v); if (bs == 0) { v0 = v; ti0 = ti; } }
                         ok = __ballot(usedNow) == 0;
                         if (!ok) SSLAM_MW_CAUSE(3);
                     }
                     if (ok) {
-                        for (int i = lane; i < nF; i += 64) { const unsigned e = lstF[i]; pix[(int)(e >> 16) * sw + (int)(e & 0xFFFF)].x = USED_F; }
+                        // mark list F used (the used bit joins the angle, so a mark needs the pixel's value): a one-point region is the seed,
+                        // whose value lane `first` read with the chunk; an unrefined region of up to 64 points is list A, just gathered
+                        if (nA + nB == 1) { if (lane == first) pl.T[tiSeed] = t_used(a0); }
+                        else if (!(flags & MW_REFINED) && nF <= 64) { if (lane < nF) pl.T[ti0] = t_used(v0); }
+                        else for (int i = lane; i < nF; i += 64) { unsigned* t = pl.Tb() + pl.ti(lstF[i]); *t |= USED_BIT; }
                         took = true; n = nA; smallList = lstA;
                         tookEmit = (flags & MW_EMIT) != 0;
                         if (tookEmit) {
@@ -751,7 +766,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                 const long long to = SSLAM_CLK();
                 if (MW) { if (!stashReady) fill_stash(); sd = seedStash[first]; }
                 const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
-                n = region_grow_m<LAT>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, prec, regAngle, &misc->cyc[6]);
+                n = region_grow_m<LAT>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pl, rq, prec, regAngle, &misc->cyc[6]);
                 cycOwn += SSLAM_CLK() - to;
                 mwOwn += 1 + ((long long)n << 32);
 #ifdef SSLAM_MW_STATS
@@ -766,7 +781,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                 // the region instead of gathering 64 pixel records again.
                 for (int k = 1; k < n; ++k) {
                     const unsigned e = smallList[k];          // minRegSize < QCAP
-                    unM &= ~__ballot(idx == (int)(e >> 16) * sw + (int)(e & 0xFFFF));
+                    unM &= ~__ballot(idx == e);
                 }
                 continue;
             }
@@ -777,7 +792,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             else {
                 bool refined = false; unsigned evLo = 0xFFFFFFFFu, evHi = 0u;      // MW: everything refine() may have released lies inside this box
                 long long cycs[3] = {0, 0, 0};
-                emit = rect_refine<LAT, false, MW>(P, sd, n, regAngle, rq, pix, ang, red, rec, refined, evLo, evHi, cycs, nullptr, &misc->cyc[6]);
+                emit = rect_refine<LAT, false, MW>(P, sd, n, regAngle, rq, pl, red, rec, refined, evLo, evHi, cycs, nullptr, &misc->cyc[6]);
                 cyc1 += cycs[0]; t2 = t1 + cycs[0]; cyc3 += cycs[2];
                 if (MW && refined) {                              // log the event once the last store of this refine has left
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -791,7 +806,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             long long t3 = SSLAM_CLK(); cyc2 += t3 - t2;
             // a region of this size -- kept or not, refine() may have released pixels again -- can have changed any candidate of the chunk:
             // gather their state once more (candidates before the seed are never revisited, as in the reference's forward loop)
-            unM = __ballot(idx >= 0 && lane > first && pix[idx].x >= 0.f);
+            unM = __ballot(have && lane > first && t_free(pl.T[tiSeed]));
             if (!emit) continue;
             if (nSeg < MAX_SEG && lane == 0) {
                 double* o = candOut + (size_t)nSeg * 12;
@@ -832,8 +847,7 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
 __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int b, const MwShared& mw, unsigned* __restrict__ bm, float4* __restrict__ stash, double* __restrict__ red) {
     const int lane = threadIdx.x & 63;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
-    float4* pix = (float4*)(base + P.offPix);
-    const float* ang = (const float*)(base + P.offAng);
+    Planes pl; pl.T = (float*)(base + P.offT); pl.Cs = (const float2*)(base + P.offCs); pl.S = (const int*)(base + P.offS); pl.tW = P.tW; pl.cW = P.cW;
     const unsigned* order = (const unsigned*)(base + P.offOrder);
     const Misc* misc = (const Misc*)(base + P.offMisc);
     const int sw = P.sw, sh = P.sh, nOrd = misc->nDefined;
@@ -919,8 +933,9 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
         cur = S;
         // ---- the chunk's seed candidates as this wave sees them now
         const int q = c + lane, laneBase = c & 63;            // lanes are numbered as in the main wave's chunk of 64
-        const int idx = lane < MW_SUB && q < nOrd ? (int)order[q] : -1;
-        const int cy = max(idx, 0) / sw, cx = max(idx, 0) - cy * sw;
+        const bool have = lane < MW_SUB && q < nOrd;
+        const unsigned idx = have ? order[q] : 0u;
+        const int cy = idx >> 16, cx = idx & 0xFFFF, tiSeed = pl.ti(idx);
         // Pass 0 grows the seeds that are unused and outside every speculative region, in order.  While the main wave is still in front of
         // the chunk and this helper has nowhere else to go (no free slot), it keeps looking again: whatever is unused by then and still has
         // no region -- seeds the shared map had talked it out of, pixels a refine() released -- is grown as well, so that the main wave
@@ -938,9 +953,9 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 __builtin_amdgcn_s_sleep(8);
                 SSLAM_MW_T(6);
             }
-            const float a0 = idx >= 0 ? pix[idx].x : -1.f;
-            unsigned long long unM = __ballot(a0 >= 0.f && (pass > 0 || !mw.spec(cx, cy))) & ~haveRes;
-            if (pass == 0) SSLAM_MW_WHY(0, __popcll(__ballot(a0 >= 0.f && mw.spec(cx, cy))));
+            const float a0 = have ? pl.T[tiSeed] : NOTDEF_F;
+            unsigned long long unM = __ballot(t_free(a0) && (pass > 0 || !mw.spec(cx, cy))) & ~haveRes;
+            if (pass == 0) SSLAM_MW_WHY(0, __popcll(__ballot(t_free(a0) && mw.spec(cx, cy))));
             if (unM) {
                 const double ar = (double)a0 * DEG2RAD;
                 stash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
@@ -953,7 +968,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 const float4 sd = stash[first];
                 const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
                 const int startSeq = lds_ld(&ctl->unmarkSeq);      // sampled BEFORE the first pixel of this region is read
-                if (pix[sy * sw + sx].x < 0.f) { SSLAM_MW_WHY(1, 1); continue; }           // taken since the chunk was scanned (a region in front of it, committed meanwhile)
+                if (!t_free(pl.T[pl.ti(sx, sy)])) { SSLAM_MW_WHY(1, 1); continue; }           // taken since the chunk was scanned (a region in front of it, committed meanwhile)
                 if ((pass == 0 || ((deferred >> first) & 1ull)) && mw.spec(sx, sy)) { SSLAM_MW_WHY(2, 1); continue; }         // ... or about to be
                 // Consecutive positions of the top bins are pixels of the same long edges: helpers that start them together each grow the whole
                 // edge and only the earliest seed's region is ever taken.  So: if another helper is growing an EARLIER seed whose level line
@@ -974,7 +989,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                     if (blocked()) {
                         if (pass == 0) { deferred |= 1ull << first; SSLAM_MW_WHY(3, 1); continue; }
                         while (blocked() && lds_ld(&ctl->mainPos) < (c & ~63) && !lds_ld(&ctl->finished)) __builtin_amdgcn_s_sleep(8);
-                        if (pix[sy * sw + sx].x < 0.f || mw.spec(sx, sy)) continue;
+                        if (!t_free(pl.T[pl.ti(sx, sy)]) || mw.spec(sx, sy)) continue;
                     }
                 }
                 if (lane == 0) { ctl->flX[h] = (float)sx; ctl->flY[h] = (float)sy; ctl->flCos[h] = sd.y; ctl->flSin[h] = sd.z; ctl->flAng[h] = sd.x; }
@@ -992,7 +1007,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 if (k >= MW_RES || capN <= 64) { SSLAM_MW_WHY(k >= MW_RES ? 3 : 4, 1 + __popcll(unM)); room = false; break; }      // no room left: the main wave grows the rest itself
                 RegQ rq; rq.lds = ring + head; rq.glb = nullptr;
                 double regAngle = 0;
-                int n = region_grow_w<true, false, true>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pix, rq, P.prec, regAngle, nullptr, bm, capN);
+                int n = region_grow_w<true, false, true>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pl, rq, P.prec, regAngle, nullptr, bm, capN);
                 if (n < 0) {                                        // too long for a helper: release its marks, the main wave grows this one
                     for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
                     SSLAM_MW_WHY(5, 1); haveRes |= 1ull << first;
@@ -1006,7 +1021,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 bool emit = false, refined = false; unsigned dLo = 0, dHi = 0; long long cycs[3];
                 RectD rec;
                 if (n >= P.minRegSize) {
-                    emit = rect_refine<true, true, false>(P, sd, n, regAngle, rq, pix, ang, red, rec, refined, dLo, dHi, cycs, &sl, nullptr);
+                    emit = rect_refine<true, true, false>(P, sd, n, regAngle, rq, pl, red, rec, refined, dLo, dHi, cycs, &sl, nullptr);
                     if (sl.gaveUp) { SSLAM_MW_WHY(6, 1); haveRes |= 1ull << first; continue; }      // its marks are released; the main wave handles this seed
                 }
                 SSLAM_MW_T(4);
@@ -1043,7 +1058,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                     const unsigned e = rq.lds[i]; const int cl = mw.cell((int)(e & 0xFFFF), (int)(e >> 16));
                     atomicOr(&mw.specMap[cl >> 5], 1u << (cl & 31));
                 }
-                if (n > 1 && pass == 0) unM &= ~__ballot(idx >= 0 && mw.spec(cx, cy));
+                if (n > 1 && pass == 0) unM &= ~__ballot(have && mw.spec(cx, cy));
                 SSLAM_MW_T(5);
             }
             if (pass == 0) lds_st(&S->doneLane, 64);

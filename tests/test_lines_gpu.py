@@ -100,6 +100,15 @@ def test_region_division_selftest(fe, ctx):
     assert rc == 0 and bad[0] == 0 and bad[1] == 0, (bad[0], bad[1])
 
 
+def test_align_windows_selftest(fe, ctx):
+    """k_nfa_count's integer form of isAligned: the windows of (theta, tolerance) must be exactly the set the reference predicate accepts,
+    on every angle the gradient table can hold (1021^2 gradients per case), end-point neighbours and random patterns"""
+    import ctypes as C
+    out = (C.c_longlong * 3)(-1, -1, -1)
+    rc = fe.lib().sslam_selftest_align_windows(ctx.h, 4096, out)
+    assert rc == 0 and out[0] == 0 and out[2] == 0 and out[1] > 4_000_000_000, (out[0], out[1], out[2])
+
+
 def test_lines_huge_regions(fe, ctx, oracle):
     """regions far larger than the 1024-point LDS queue continue in global memory"""
     n, bad = _cmp_lines(fe, ctx, oracle, ramp_frame(), 200)

@@ -25,5 +25,5 @@ with torch.cuda.stream(torch.cuda.Stream()):
     torch.cuda.synchronize()
 prof = pipeline.profile_drain(fe, ctx)
 nl = f["nl"].cpu().numpy()
-print(os.environ.get("SSLAM_LIB", "product")[-40:], "B", B, "lines/frame %.1f" % nl.mean(), {k: round(v[0] / R, 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:4]},
+print(os.environ.get("SSLAM_LIB", "product")[-40:], "B", B, "lines/frame %.1f" % nl.mean(), {k: round(v[0] / R, 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("LSD_ONLY_TOP", "4"))]},
       "sum %.2f" % (sum(v[0] for v in prof.values()) / R), "cksum", int(f["ldesc"].to(torch.int64).sum().item()))
