@@ -421,8 +421,13 @@ def main():
             try:      # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs cannot share a process with this timing run), scaled to this batch
                 pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_c4.json" if args.workload == "c4" else "pmc_traffic.json")))
                 pt = pj["kernels"][name]      # fetch side x2: gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, calibrated in profiles/)
-                traffic = (pt["fetch_bytes_per_frame"] * pj.get("fetch_correction", 1.0) + pt["write_bytes_per_frame"]) * B
-                traffic_src = "profiles/pmc_traffic.json (%s), scaled to this batch" % pj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
+                core_now = "k_lsd_regions_mw" if B <= 256 else "k_lsd_regions<true>" if B < 1024 else "k_lsd_regions<false>"
+                if "fetch_correction" not in pj or pj.get("lsd_core") != core_now:
+                    # the counted kernel must be the instantiation this run times, and the gfx950 fetch correction must be on record in the file
+                    traffic_src = "refused: the PMC file counted %s at batch %s (fetch_correction %s), this run times %s" % (pj.get("lsd_core"), pj.get("batch"), pj.get("fetch_correction"), core_now)
+                else:
+                    traffic = (pt["fetch_bytes_per_frame"] * pj["fetch_correction"] + pt["write_bytes_per_frame"]) * B
+                    traffic_src = "profiles/%s: fetch x %.1f + write per frame x this batch (%s)" % ("pmc_traffic_c4.json" if args.workload == "c4" else "pmc_traffic.json", pj["fetch_correction"], pj.get("source", ""))
             except Exception:
                 pass
             sv = survey_bytes_per_frame(W, H, NFEAT, NLINES if with_lines else 0)

@@ -179,7 +179,9 @@ int sslam_orb_search_for_initialization_batch_dev(sslam_ctx* ctx,
  *                   with both projected endpoints (kind 1 accepts mode 1 only with check_orientation = 0)
  * feats = F.mvKeysUn (sslam_keypoint) or F.mvKeylinesUn (sslam_keyline), desc = F.mDescriptors / F.mLdesc,
  * uright = F.mvuRight or NULL (monocular), occupied[i] = F.mvpMapPoints[i] has Observations()>0 (or NULL).
- * assigned_out[i] = index of the query now owning feature i (-> F.mvpMapPoints[i] = that pMP) or -1. */
+ * assigned_out[i] = index of the query now owning feature i (-> F.mvpMapPoints[i] = that pMP), -1 if no query touched it (the pointer
+ * keeps its value), or -2 (mode 1 with check_orientation only) if it was matched and then removed by the rotation-consistency check
+ * (the reference writes NULL there, src/ORBmatcher.cc:1465, :1596). */
 typedef struct sslam_proj_query {
     float u, v;            /* window centre (mTrackProjX/Y or projected u,v); lines: first projected endpoint */
     float u2, v2;          /* lines: second projected endpoint */
@@ -424,6 +426,15 @@ int sslam_frontend_batch_sharded(sslam_group* group, const sslam_frontend_params
                                  const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride,
                                  sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
                                  sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap);
+/* How sslam_frontend_batch_sharded deals a batch over the GPUs (host-only bookkeeping, callable without a device): global frame i lives on
+ * GPU i mod ngpu, every GPU walks its frames in chunks of *chunk_slots_out slots.  sslam_shard_frame = the global frame in slot `slot` of
+ * chunk `chunk` on GPU `gpu` (-1: the slot is empty -- uneven tails); sslam_shard_chunk_count = how many leading slots of that chunk hold
+ * a frame.  On any error of sslam_frontend_batch_sharded the outputs hold what arrived: nkp_out[i] (and nl_out[i]) = -1 marks a frame whose
+ * records never reached the root (a HIP / RCCL failure on its GPU); truncated rows (SSLAM_ERR_CAPACITY) and LSD overflow
+ * (SSLAM_ERR_UNSUPPORTED) are deferred statuses as in sslam_frontend_batch -- every frame is still delivered, clamped. */
+int sslam_shard_layout(int n, int ngpu, int* chunk_slots_out, int* nchunks_out);
+int sslam_shard_frame(int n, int ngpu, int chunk, int gpu, int slot);
+int sslam_shard_chunk_count(int n, int ngpu, int chunk, int gpu);
 
 /* Self-test of the table-based exact integer division of the NFA binomial tail against the hardware IEEE division:
  * `pairs` random quotients a/b with 1 <= a,b < n; *mismatches_out must come back 0. */

@@ -253,7 +253,7 @@ static int search_by_projection(int kind, int mode, const void* feats, const uin
         three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
         for (int i = 0; i < HISTO_LENGTH; ++i)
             if (i != ind1 && i != ind2 && i != ind3)
-                for (int idx : rotHist[i]) { assigned[idx] = -1; nmatches--; }
+                for (int idx : rotHist[i]) { assigned[idx] = -2; nmatches--; }      // CurrentFrame.mvpMapPoints[rotHist[i][j]] = NULL (src/ORBmatcher.cc:1465, :1596): matched and removed, not "untouched"
     }
     delete g;
     return nmatches;
@@ -426,7 +426,7 @@ int orc_search_by_projection_reloc(const void* feats, const uint8_t* desc, int n
         three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
         for (int i = 0; i < HISTO_LENGTH; ++i)
             if (i != ind1 && i != ind2 && i != ind3)
-                for (int idx : rotHist[i]) { assigned[idx] = -1; nmatches--; }
+                for (int idx : rotHist[i]) { assigned[idx] = -2; nmatches--; }      // CurrentFrame.mvpMapPoints[rotHist[i][j]] = NULL (src/ORBmatcher.cc:1465, :1596): matched and removed, not "untouched"
     }
     return nmatches;
 }

@@ -64,7 +64,8 @@ struct sslam_ctx {
     hipStream_t stream = nullptr;
     std::recursive_mutex mu;       // every entry point serialises on the context (SURVEY §8b threading); recursive: the host forms call the *_batch_dev forms
     sslam::DevBuf scratch[8];      // matcher staging
-    sslam::DevBuf recordOffsets;   // sslam_pack_records_dev: per-frame offsets of the record stream
+    sslam::DevBuf recordOffsets[4];   // sslam_pack_records_dev: per-frame offsets of the record stream, one buffer per stream that packs
+    void* recordOffsetsStream[4] = {nullptr, nullptr, nullptr, nullptr};
     sslam::HostPinned pinned[4];
     int num_cus = 0;
 };
@@ -132,6 +133,15 @@ __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+// sum over the wave as a wave-uniform value without an LDS round trip: four DPP row_shr steps leave each row's total in its last lane,
+// the four totals are read with v_readlane (wave_sum's six __shfl_xor steps are six dependent ds_bpermute round trips)
+__device__ __forceinline__ int wave_sum_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+    return __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) + __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll

@@ -55,7 +55,7 @@ extern "C" int sslam_ctx_destroy(sslam_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->scratch) b.release();
-    c->recordOffsets.release();
+    for (auto& b : c->recordOffsets) b.release();
     for (auto& b : c->pinned) b.release();
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -163,15 +163,26 @@ extern "C" int sslam_pack_records_dev(sslam_ctx* ctx, int nframes, int frame0, i
     const bool lines = d_kl != nullptr;
     if (!ctx || nframes <= 0 || !d_kp || !d_desc || !d_nkp || cap <= 0 || !d_out || !d_total_bytes ||
         (lines && (!d_ldesc || !d_linefn || !d_nl || lcap <= 0))) { set_error("sslam_pack_records_dev: invalid arguments"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);      // the whole call: launches included (every entry point serialises on the context)
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     int rc;
-    {
-        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-        if ((size_t)(nframes + 1) * 8 > ctx->recordOffsets.cap) SSLAM_HIP(hipStreamSynchronize(st));      // a growing buffer is freed first: nothing may still read it
-        if ((rc = ctx->recordOffsets.ensure(sizeof(unsigned long long) * ((size_t)nframes + 1)))) return rc;
+    // the per-frame offsets live in a buffer that belongs to the STREAM of the call (a small ring of them per context): packs on different
+    // streams never share one, and a buffer is only ever freed (to grow) after its own stream has drained
+    DevBuf* offBuf = nullptr;
+    for (int i = 0; i < 4 && !offBuf; ++i) if (ctx->recordOffsetsStream[i] == (void*)st && ctx->recordOffsets[i].p) offBuf = &ctx->recordOffsets[i];
+    if (!offBuf) {
+        int slot = -1;
+        for (int i = 0; i < 4 && slot < 0; ++i) if (!ctx->recordOffsets[i].p) slot = i;
+        if (slot < 0) {                                      // more than four streams: recycle slot 0 once its stream is idle
+            slot = 0;
+            SSLAM_HIP(hipStreamSynchronize((hipStream_t)ctx->recordOffsetsStream[0]));
+        }
+        ctx->recordOffsetsStream[slot] = (void*)st; offBuf = &ctx->recordOffsets[slot];
     }
-    unsigned long long* off = ctx->recordOffsets.as<unsigned long long>();
+    if ((size_t)(nframes + 1) * 8 > offBuf->cap) SSLAM_HIP(hipStreamSynchronize(st));      // a growing buffer is freed first: nothing may still read it
+    if ((rc = offBuf->ensure(sizeof(unsigned long long) * ((size_t)nframes + 1)))) return rc;
+    unsigned long long* off = offBuf->as<unsigned long long>();
     hipLaunchKernelGGL(k_record_offsets, dim3(1), dim3(1024), 0, st, d_nkp, lines ? d_nl : nullptr, nframes, cap, lcap, off, (unsigned long long)out_capacity,
                        (unsigned long long*)d_total_bytes);
     hipLaunchKernelGGL(k_record_copy, dim3(nframes), dim3(256), 0, st, frame0, frame_step, (const unsigned*)d_kp, (const unsigned*)d_desc, d_nkp, cap,
@@ -268,8 +279,8 @@ extern "C" int sslam_group_create_rank(int device, int rank, int nranks, const u
     NcclUid u; memcpy(u.internal, id, SSLAM_GROUP_ID_BYTES);
     const int r = rccl()->CommInitRank(&g->mem[0].comm, nranks, u, rank);
     if (r != 0) { set_error("ncclCommInitRank failed: %s", rccl()->GetErrorString ? rccl()->GetErrorString(r) : "rccl error"); delete g; return SSLAM_ERR_HIP; }
-    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess || g->dSizes.ensure(8 * (size_t)nranks + 8) != SSLAM_OK ||
-        g->hSizes.ensure(8 * (size_t)nranks + 8) != SSLAM_OK) {
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess || g->dSizes.ensure(16 * (size_t)nranks + 16) != SSLAM_OK ||
+        g->hSizes.ensure(16 * (size_t)nranks + 16) != SSLAM_OK) {
         set_error("sslam_group_create_rank: allocation failed"); (void)rccl()->CommDestroy(g->mem[0].comm); delete g; return SSLAM_ERR_HIP;
     }
     *out = g;
@@ -300,17 +311,28 @@ extern "C" int sslam_group_gather_dev(sslam_group* g, const uint8_t* d_send, con
     hipStream_t st = stream_ ? (hipStream_t)stream_ : g->stream;
     Rccl* R = rccl();
     ncclComm_t comm = g->mem[0].comm;
-    uint64_t* dS = g->dSizes.as<uint64_t>(); uint64_t* hS = g->hSizes.as<uint64_t>();
-    // 1. lengths: every rank learns every length (eight bytes each)
-    SSLAM_NCCL(R->AllGather(d_send_bytes, dS, 1, kNcclUint64, comm, st));
-    SSLAM_HIP(hipMemcpyAsync(hS, dS, 8 * (size_t)g->nranks, hipMemcpyDeviceToHost, st));
+    // 1. lengths: every rank learns every length AND the root's receive capacity (a pair of words per rank), so that the decision to go
+    //    on is the same everywhere: a rank that returned before posting its side of the exchange would leave the others blocked in theirs
+    uint64_t* dPair = g->dSizes.as<uint64_t>(); uint64_t* dAll = dPair + 2;
+    uint64_t* hPair = g->hSizes.as<uint64_t>(); uint64_t* hAll = hPair + 2;
+    hPair[1] = g->rank == 0 ? recv_capacity : 0;
+    SSLAM_HIP(hipMemcpyAsync(dPair, d_send_bytes, 8, hipMemcpyDeviceToDevice, st));
+    SSLAM_HIP(hipMemcpyAsync(dPair + 1, hPair + 1, 8, hipMemcpyHostToDevice, st));
+    SSLAM_NCCL(R->AllGather(dPair, dAll, 2, kNcclUint64, comm, st));
+    SSLAM_HIP(hipMemcpyAsync(hAll, dAll, 16 * (size_t)g->nranks, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
+    std::vector<uint64_t> hSv((size_t)g->nranks);
+    uint64_t* hS = hSv.data();
     uint64_t total = 0;
     for (int r = 0; r < g->nranks; ++r) {
-        if (hS[r] == ~0ull) { set_error("sslam_group_gather_dev: the record stream of rank %d overflowed its buffer", r); return SSLAM_ERR_CAPACITY; }
+        hS[r] = hAll[2 * r];
+        if (hS[r] == ~0ull) { set_error("sslam_group_gather_dev: the record stream of rank %d overflowed its buffer", r); return SSLAM_ERR_CAPACITY; }      // (seen by every rank alike)
         total += hS[r];
     }
-    if (g->rank == 0 && total > recv_capacity) { set_error("sslam_group_gather_dev: %llu bytes do not fit the receive buffer", (unsigned long long)total); return SSLAM_ERR_CAPACITY; }
+    if (total > hAll[1]) {                                       // hAll[1]: rank 0's capacity -- every rank takes the same exit
+        set_error("sslam_group_gather_dev: %llu bytes do not fit the root's receive buffer of %llu", (unsigned long long)total, (unsigned long long)hAll[1]);
+        return SSLAM_ERR_CAPACITY;
+    }
     // 2. payload: one grouped send / receive per peer; the root's own stream is a device-to-device copy (or, for tests on one GPU, a
     //    self send/recv through RCCL with SSLAM_GROUP_SELF_SENDRECV=1)
     const bool selfRccl = getenv("SSLAM_GROUP_SELF_SENDRECV") != nullptr;
@@ -330,6 +352,31 @@ extern "C" int sslam_group_gather_dev(sslam_group* g, const uint8_t* d_send, con
     SSLAM_HIP(hipStreamSynchronize(st));
     if (g->rank == 0) for (int r = 0; r < g->nranks; ++r) bytes_per_rank_out[r] = hS[r];
     return SSLAM_OK;
+}
+
+// ------------------------------------------------------------------ how a batch is dealt over the GPUs (host-only: no HIP, no RCCL)
+// Global frame i lives on GPU i mod G; every GPU walks its frames in chunks of C = min(ceil(n / G), 512) slots, so slot j of
+// chunk ck on GPU d is global frame (ck * C + j) * G + d.  The tail is uneven: the last chunk of a GPU may hold fewer frames than the same
+// chunk elsewhere, or none (that GPU then takes part in the exchange with zero bytes).
+extern "C" int sslam_shard_layout(int n, int ngpu, int* chunk_slots_out, int* nchunks_out) {
+    if (n < 0 || ngpu <= 0) return SSLAM_ERR_INVALID;
+    const int perDev = (n + ngpu - 1) / ngpu, C = std::max(1, std::min(perDev, 512));
+    if (chunk_slots_out) *chunk_slots_out = C;
+    if (nchunks_out) *nchunks_out = (perDev + C - 1) / C;
+    return SSLAM_OK;
+}
+extern "C" int sslam_shard_frame(int n, int ngpu, int chunk, int gpu, int slot) {
+    int C = 0, nChunks = 0;
+    if (sslam_shard_layout(n, ngpu, &C, &nChunks) != SSLAM_OK || chunk < 0 || chunk >= nChunks || gpu < 0 || gpu >= ngpu || slot < 0 || slot >= C) return -1;
+    const long long f = ((long long)chunk * C + slot) * ngpu + gpu;
+    return f < n ? (int)f : -1;
+}
+extern "C" int sslam_shard_chunk_count(int n, int ngpu, int chunk, int gpu) {      // frames GPU `gpu` holds in chunk `chunk` (its slots 0 .. count-1)
+    int C = 0, nChunks = 0;
+    if (sslam_shard_layout(n, ngpu, &C, &nChunks) != SSLAM_OK || chunk < 0 || chunk >= nChunks || gpu < 0 || gpu >= ngpu) return 0;
+    int c = 0;
+    for (int j = 0; j < C; ++j) if (sslam_shard_frame(n, ngpu, chunk, gpu, j) >= 0) c = j + 1;
+    return c;
 }
 
 // ------------------------------------------------------------------ host-buffer batch over all GPUs of a single-process group
@@ -361,19 +408,26 @@ extern "C" int sslam_frontend_batch_sharded(sslam_group* g, const sslam_frontend
         }
         g->params = *prm; g->haveParams = true;
     }
-    const int perDev = (n + G - 1) / G, C = std::min(perDev, 512), nChunks = (perDev + C - 1) / C;
+    int C = 0, nChunks = 0;
+    (void)sslam_shard_layout(n, G, &C, &nChunks);
     const size_t fpx = (size_t)w * h;
     const uint64_t sendCap = sslam_record_stream_capacity(C, cap, lines ? lcap : 0);
     const bool selfRccl = getenv("SSLAM_GROUP_SELF_SENDRECV") != nullptr;
     Barrier bar; bar.count = G;
-    std::vector<int> status(G, SSLAM_OK);
-    std::vector<std::string> errs(G);
+    std::vector<int> status(G, SSLAM_OK), soft(G, SSLAM_OK), allocOk(G, 1);
+    std::vector<std::string> errs(G), softErrs(G);
+    // a frame whose records never arrive (a real HIP / RCCL failure on its GPU) keeps -1 here; every other frame is delivered, clamped to
+    // the capacities, exactly as sslam_frontend_batch delivers it
+    for (int i = 0; i < n; ++i) { nkp_out[i] = -1; if (lines) nl_out[i] = -1; }
     std::vector<uint64_t> sizes(G, 0);
     Rccl* R = rccl();
     auto worker = [&](int d) {
         Member& m = g->mem[d];
         int rc = SSLAM_OK;
         auto fail = [&](int code, const char* what) { if (rc == SSLAM_OK) { rc = code; errs[d] = what ? what : sslam_last_error(); } };
+        // truncated rows (SSLAM_ERR_CAPACITY) and frames with too many LSD candidates (SSLAM_ERR_UNSUPPORTED) are a DEFERRED status, like
+        // firstStatus in sslam_frontend_batch: the clamped records still travel, the first such status is returned at the end
+        auto defer = [&](int code, const char* what) { if (soft[d] == SSLAM_OK) { soft[d] = code; softErrs[d] = what; } };
         if (hipSetDevice(m.ctx->device) != hipSuccess) fail(SSLAM_ERR_HIP, "hipSetDevice failed");
         hipStream_t st = m.ctx->stream;
         if (rc == SSLAM_OK) {
@@ -383,14 +437,18 @@ extern "C" int sslam_frontend_batch_sharded(sslam_group* g, const sslam_frontend
             if (d == 0) e |= m.dRecv.ensure(sendCap * G + 16) | m.hRecv.ensure(sendCap * G + 16);
             if (e) fail(SSLAM_ERR_HIP, nullptr);
         }
+        // whether the exchange can run at all is decided together: with the root's receive buffers missing nobody may send
+        allocOk[d] = rc == SSLAM_OK ? 1 : 0;
+        bar.wait();
+        bool everyoneReady = true;
+        for (int r = 0; r < G; ++r) everyoneReady = everyoneReady && allocOk[r] != 0;
+        if (!everyoneReady) { if (rc == SSLAM_OK) { rc = SSLAM_ERR_HIP; errs[d] = "another GPU of the group could not allocate its buffers"; } status[d] = rc; return; }
         for (int ck = 0; ck < nChunks; ++ck) {
-            // local slot j of this chunk = global frame (ck*C + j)*G + d
-            int c = 0;
-            for (int j = 0; j < C; ++j) if ((size_t)(ck * C + j) * G + d < (size_t)n) c = j + 1;
+            const int c = sslam_shard_chunk_count(n, G, ck, d);      // local slot j of this chunk = global frame sslam_shard_frame(n, G, ck, d, j)
             uint64_t myBytes = 0;
             if (rc == SSLAM_OK && c > 0) {
                 for (int j = 0; j < c && rc == SSLAM_OK; ++j) {
-                    const uint8_t* src = images + ((size_t)(ck * C + j) * G + d) * image_stride;
+                    const uint8_t* src = images + (size_t)sslam_shard_frame(n, G, ck, d, j) * image_stride;
                     if (hipMemcpy2DAsync(m.dIn.as<uint8_t>() + (size_t)j * fpx, w, src, stride, w, h, hipMemcpyHostToDevice, st) != hipSuccess) fail(SSLAM_ERR_HIP, "H2D failed");
                 }
                 if (rc == SSLAM_OK && (rc = sslam_orb_extract_batch_dev(m.orb, m.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, m.dKp.as<sslam_keypoint>(), m.dDesc.as<uint8_t>(),
@@ -399,7 +457,7 @@ extern "C" int sslam_frontend_batch_sharded(sslam_group* g, const sslam_frontend
                                                                                     m.dFn.as<double>(), m.dNl.as<int32_t>(), lcap, st))) errs[d] = sslam_last_error();
                 if (rc == SSLAM_OK && (rc = sslam_orb_batch_status_dev(m.orb, cap, m.dStatus.as<int32_t>(), st))) errs[d] = sslam_last_error();
                 if (rc == SSLAM_OK && lines && (rc = sslam_lines_batch_status_dev(m.lines, lcap, m.dStatus.as<int32_t>() + 4, st))) errs[d] = sslam_last_error();
-                if (rc == SSLAM_OK && (rc = sslam_pack_records_dev(m.ctx, c, ck * C * G + d, G, m.dKp.as<sslam_keypoint>(), m.dDesc.as<uint8_t>(), m.dN.as<int32_t>(), cap,
+                if (rc == SSLAM_OK && (rc = sslam_pack_records_dev(m.ctx, c, sslam_shard_frame(n, G, ck, d, 0), G, m.dKp.as<sslam_keypoint>(), m.dDesc.as<uint8_t>(), m.dN.as<int32_t>(), cap,
                                                                    lines ? m.dKl.as<sslam_keyline>() : nullptr, m.dLd.as<uint8_t>(), m.dFn.as<double>(), m.dNl.as<int32_t>(), lcap,
                                                                    m.dSend.as<uint8_t>(), sendCap, m.dTotal.as<uint64_t>(), st))) errs[d] = sslam_last_error();
                 if (rc == SSLAM_OK) {
@@ -408,15 +466,15 @@ extern "C" int sslam_frontend_batch_sharded(sslam_group* g, const sslam_frontend
                         hipStreamSynchronize(st) != hipSuccess) fail(SSLAM_ERR_HIP, "kernels / D2H failed");
                     else {
                         const int* S = (const int*)(hp + 16);
-                        if (lines && S[6]) fail(SSLAM_ERR_UNSUPPORTED, "a frame produced more than 8192 LSD candidate rectangles");
-                        else if (S[0]) fail(SSLAM_ERR_CAPACITY, "a frame holds more keypoints than cap");
-                        else if (lines && S[4]) fail(SSLAM_ERR_CAPACITY, "a frame holds more lines than lcap");
+                        if (lines && S[6]) defer(SSLAM_ERR_UNSUPPORTED, "a frame produced more than 8192 LSD candidate rectangles");
+                        else if (S[0]) defer(SSLAM_ERR_CAPACITY, "a frame holds more keypoints than cap (rows truncated)");
+                        else if (lines && S[4]) defer(SSLAM_ERR_CAPACITY, "a frame holds more lines than lcap (rows truncated)");
                         myBytes = *(const uint64_t*)hp;
                         if (myBytes == ~0ull) { fail(SSLAM_ERR_CAPACITY, "record stream overflow"); myBytes = 0; }
                     }
                 }
             }
-            if (rc != SSLAM_OK) myBytes = 0;      // a failed member still takes part in the exchange (with nothing), so that nobody hangs
+            if (rc != SSLAM_OK) myBytes = 0;      // a member with a real failure still takes part in the exchange (with nothing), so that nobody hangs
             sizes[d] = myBytes;
             bar.wait();
             // the exchange step: grouped ncclSend / ncclRecv to device 0
@@ -438,7 +496,7 @@ extern "C" int sslam_frontend_batch_sharded(sslam_group* g, const sslam_frontend
                 if (hipMemcpyAsync(m.hRecv.p, m.dRecv.p, (size_t)total, hipMemcpyDeviceToHost, st) != hipSuccess) fail(SSLAM_ERR_HIP, "D2H failed");
             }
             if (hipStreamSynchronize(st) != hipSuccess) fail(SSLAM_ERR_HIP, "exchange failed");
-            if (d == 0 && total && rc == SSLAM_OK) {
+            if (d == 0 && total) {                // whatever arrived is delivered, also after a failure of the root's own extraction
                 int nrec = 0;
                 const int u = sslam_unpack_records(m.hRecv.as<uint8_t>(), total, n, kp_out, desc_out, nkp_out, cap, lines ? kl_out : nullptr, ldesc_out, linefn_out, nl_out, lcap, &nrec);
                 if (u != SSLAM_OK) fail(u, nullptr);
@@ -453,5 +511,7 @@ extern "C" int sslam_frontend_batch_sharded(sslam_group* g, const sslam_frontend
     for (auto& t : th) t.join();
     for (int d = 0; d < G; ++d)
         if (status[d] != SSLAM_OK) { set_error("sslam_frontend_batch_sharded: GPU %d: %s", d, errs[d].c_str()); return status[d]; }
+    for (int d = 0; d < G; ++d)
+        if (soft[d] != SSLAM_OK) { set_error("sslam_frontend_batch_sharded: GPU %d: %s", d, softErrs[d].c_str()); return soft[d]; }
     return SSLAM_OK;
 }

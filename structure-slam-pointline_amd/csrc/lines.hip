@@ -140,13 +140,10 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t bpitch = ((size_t)w + 63) & ~(size_t)63;
     P.offBlur = take(bpitch * h);                         // sigma-0.75 blur of the source (LSD)
-    // tiled planes, padded to whole k_lsd_grad blocks (256 x 4 pixels): see lsd_plan.h
-    P.tW = ((P.sw + 255) / 256) * 32; P.cW = P.tW * 2;
-    const size_t tileRows = ((size_t)P.sh + 3) / 4;
-    if ((size_t)P.tW * 32 * tileRows >= ((size_t)1 << 30)) { set_error("image %dx%d too large", w, h); return SSLAM_ERR_UNSUPPORTED; }      // plane elements are indexed with int
-    P.offT = take(sizeof(float) * 32 * (size_t)P.tW * tileRows);
+    P.tW = P.sw; P.cW = P.sw;
+    P.offT = take(sizeof(float) * (size_t)P.npx);
     P.offS = take(sizeof(int) * (size_t)P.npx);
-    P.offCs = take(sizeof(float2) * 16 * (size_t)P.cW * tileRows);
+    P.offCs = take(sizeof(float2) * (size_t)P.npx);
     P.offOrder = take(sizeof(unsigned) * (size_t)P.npx);
     P.offTileHist = take(sizeof(int) * (size_t)P.nTiles * N_BINS);
     P.offReg = take(sizeof(unsigned) * (size_t)P.npx);

@@ -16,10 +16,12 @@
 #pragma once
 #ifdef __HIPCC__
 #define SSLAM_HD __host__ __device__ __forceinline__
+#define SSLAM_HD_OUTLINE __host__ __device__ __attribute__((noinline))
 #else
 #include <cmath>
 #include <cstring>
 #define SSLAM_HD inline
+#define SSLAM_HD_OUTLINE inline
 #endif
 
 namespace alnwin {
@@ -88,16 +90,18 @@ SSLAM_HD int first_true(double theta, double prec, double estDeg) {
     return hi;
 }
 
-// The aligned set of (theta, prec), prec < pi/2, as up to two closed intervals [lo[i], hi[i]] of bit patterns (n = how many are non-empty).
-// Returns false if all three windows came out non-empty, which the argument above excludes (callers flag the frame instead of counting wrong).
-SSLAM_HD bool windows(double theta, double prec, int& n, int (&lo)[2], int (&hi)[2]) {
-    n = 0; lo[0] = lo[1] = BMAX + 1; hi[0] = hi[1] = BMAX;      // empty: lo = hi + 1
-    bool ok = true;
+// The aligned set of (theta, prec), prec < pi/2, as up to two closed intervals [lo0, hi0], [lo1, hi1] of bit patterns (n = how many are
+// non-empty; an empty one is lo = hi + 1 above every angle).  ok = false if all three windows came out non-empty, which the argument above
+// excludes (callers flag the frame instead of counting wrong).
+// (Six searches inlined per call site: k_nfa_count calls it from ONE place, a loop over the tolerances -- two call sites doubled its code.)
+struct Win { int n, lo0, hi0, lo1, hi1, ok; };
+SSLAM_HD Win windows(double theta, double prec) {
+    Win w; w.n = 0; w.lo0 = w.lo1 = BMAX + 1; w.hi0 = w.hi1 = BMAX; w.ok = 1;
     const double slack = 1e-6;                                // g lies in [theta - 2pi(1 + 1e-15), theta]: a window that g cannot reach is skipped without evaluating
-    auto put = [&](int l, int h1) {                          // (no dynamic indexing: the arrays stay in registers)
+    auto put = [&](int l, int h1) {
         if (l >= h1) return;
-        if (n == 0) { lo[0] = l; hi[0] = h1 - 1; } else if (n == 1) { lo[1] = l; hi[1] = h1 - 1; } else ok = false;
-        ++n;
+        if (w.n == 0) { w.lo0 = l; w.hi0 = h1 - 1; } else if (w.n == 1) { w.lo1 = l; w.hi1 = h1 - 1; } else w.ok = 0;
+        ++w.n;
     };
     if (theta >= -prec - slack && theta - A_2PI <= prec + slack)
         put(first_true<0>(theta, prec, (theta - prec) / A_D2R), first_true<1>(theta, prec, (theta + prec) / A_D2R));
@@ -105,8 +109,13 @@ SSLAM_HD bool windows(double theta, double prec, int& n, int (&lo)[2], int (&hi)
         put(first_true<2>(theta, prec, (theta - A_2PI - prec) / A_D2R), first_true<3>(theta, prec, (theta - A_2PI + prec) / A_D2R));
     if (theta <= prec + slack)
         put(first_true<4>(theta, prec, (theta + A_2PI - prec) / A_D2R), first_true<5>(theta, prec, (theta + A_2PI + prec) / A_D2R));
-    if (n > 2) n = 2;
-    return ok;
+    if (w.n > 2) w.n = 2;
+    return w;
+}
+SSLAM_HD bool windows(double theta, double prec, int& n, int (&lo)[2], int (&hi)[2]) {
+    const Win w = windows(theta, prec);
+    n = w.n; lo[0] = w.lo0; hi[0] = w.hi0; lo[1] = w.lo1; hi[1] = w.hi1;
+    return w.ok != 0;
 }
 
 }  // namespace alnwin

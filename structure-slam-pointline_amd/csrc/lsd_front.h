@@ -109,8 +109,8 @@ __global__ void k_grad_table(float4* __restrict__ tab, double rho) {
 }
 
 // One thread = four horizontally adjacent pixels: the 2x5 source bytes come from two dword + two byte loads, the four
-// table gathers are in flight together.  Outputs (16 B per pixel; 24 in rounds 1-2): the tiled T plane (angle, NOTDEF), the tiled
-// Cs plane (cos, sin) and the row-major sort key S[i] = |g|^2 for DEFINED pixels and -1 otherwise (lsd_plan.h).
+// table gathers are in flight together.  Outputs (16 B per pixel; 24 in rounds 1-2): the T plane (angle, NOTDEF), the Cs plane
+// (cos, sin) and the sort key S[i] = |g|^2 for DEFINED pixels and -1 otherwise (lsd_plan.h).
 // The 0.8x INTER_LINEAR_EXACT image (D7) is never stored: this kernel is bound by its writes, so the 2 x 5
 // scaled pixels a thread needs are recomputed here from the blurred source (four source rows as three aligned dwords each).
 __device__ __forceinline__ int scaled_px(unsigned e0, unsigned e1, unsigned cx, unsigned cy) {      // e = {p0, p1} bytes of the two source rows
@@ -128,11 +128,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
     Misc* misc = (Misc*)(base + P.offMisc);
     const int lane = threadIdx.x, tyy = threadIdx.y;
     const int y = blockIdx.y * 4 + tyy, x4 = (blockIdx.x * 64 + lane) * 4;
-    // A workgroup covers 256 x 4 pixels = 32 T tiles + 64 Cs tiles, contiguous in memory (tiles of one tile row follow each other).
-    // A thread's four pixels are half a T tile row and one Cs tile row: stored directly a store instruction would write 64 pieces of
-    // 16 / 32 bytes.  Staged through LDS (tile pitch padded: conflict-free b128 stores) the block leaves as 4 KB + 8 KB contiguous.
-    __shared__ float4 stT[32 * 10];
-    __shared__ float4 stC[64 * 9];
+    __shared__ float4 stC[4][2 * 64];      // per wave: the {cos, sin} pairs of its 256 pixels, transposed for contiguous stores (below)
     float4 rec[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rec[j] = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
@@ -186,16 +182,27 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
             for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) S[i + j] = sv[j];
         }
     }
-    stT[(lane >> 1) * 10 + tyy * 2 + (lane & 1)] = make_float4(rec[0].x, rec[1].x, rec[2].x, rec[3].x);
-    stC[lane * 9 + tyy * 2] = make_float4(rec[0].y, rec[0].z, rec[1].y, rec[1].z);
-    stC[lane * 9 + tyy * 2 + 1] = make_float4(rec[2].y, rec[2].z, rec[3].y, rec[3].z);
-    __syncthreads();
-    const int tid = tyy * 64 + lane;
-    float4* Tg = (float4*)(T + ((size_t)blockIdx.y * P.tW + (size_t)blockIdx.x * 32) * 32);
-    float4* Cg = (float4*)(Cs + ((size_t)blockIdx.y * P.cW + (size_t)blockIdx.x * 64) * 16);
-    Tg[tid] = stT[tid + 2 * (tid >> 3)];
-    Cg[tid] = stC[tid + (tid >> 3)];
-    Cg[tid + 256] = stC[tid + 256 + ((tid + 256) >> 3)];
+    if (y < P.sh) {
+        const size_t i = (size_t)y * P.sw + x4;
+        if ((P.sw & 255) == 0) {
+            // T: one 16-byte store per lane, 1 KB contiguous per instruction.  Cs: a lane's four pairs are 32 bytes -- stored directly,
+            // each of the two store instructions would write 16 of every 32 bytes; through the wave's own 2 KB of LDS (in-order DS, no
+            // workgroup barrier) each instruction writes 1 KB contiguous
+            *(float4*)(T + i) = make_float4(rec[0].x, rec[1].x, rec[2].x, rec[3].x);
+            float4* t = stC[tyy];
+            t[lane] = make_float4(rec[0].y, rec[0].z, rec[1].y, rec[1].z);
+            t[64 + lane] = make_float4(rec[2].y, rec[2].z, rec[3].y, rec[3].z);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            float4* row = (float4*)(Cs + (size_t)y * P.sw + (size_t)blockIdx.x * 256);      // 128 float4 per wave: element e = pixels 2e, 2e + 1
+            row[lane] = t[(lane & 1) * 64 + (lane >> 1)];
+            row[64 + lane] = t[(lane & 1) * 64 + 32 + (lane >> 1)];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) { T[i + j] = rec[j].x; Cs[i + j] = make_float2(rec[j].y, rec[j].z); }
+        }
+    }
     smax = wave_max(smax);
     if (lane == 0 && smax > 0) atomicMax(&misc->maxS, smax);
 }

@@ -254,6 +254,15 @@ __device__ __forceinline__ void nfa_row_range(const NfaGeom& g, int y, int sw, i
     nfa_row_edges<SMALL>(g, y, lft, rgt);
     xa = (int)max(lft, 0LL); xb = (int)min(rgt, (long long)sw - 1);
 }
+// `small` as a run-time (wave-uniform) flag: one instance of the counters instead of two
+__device__ __forceinline__ void nfa_row_range(const NfaGeom& g, int y, int sw, bool small, int& xa, int& xb) {
+    if (small) {
+        const int steps = y - g.y0;
+        int nl2 = 0, nr2 = 0;
+        if (steps > 0) { nl2 = max(0, y - max(g.ly, g.y0)); nr2 = max(0, y - max(g.ry, g.y0)); }
+        xa = max(g.mx + (steps - nl2) * g.fl + nl2 * g.sl, 0); xb = min(g.mx + (steps - nr2) * g.fr + nr2 * g.sr, sw - 1);
+    } else nfa_row_range<false>(g, y, sw, xa, xb);
+}
 // upper bound of the (unclipped) row width of a rectangle: the edges are linear in y between the corner rows, so the
 // maximum sits at one of them.  Only used to pick how many lanes share a row.
 __device__ int nfa_max_width(const NfaGeom& g) {
@@ -323,30 +332,40 @@ constexpr int EVAL_CH = 1024;          // rectangles per item-list chunk (k_nfa_
 constexpr int EVAL_REFILL = 16;
 constexpr int CNT_NEST = 32;           // items per batch in the nested stages (their windows need 6 x 2 intervals each)
 constexpr unsigned PIX_NONE = 0x7FFFFFFFu;      // what a lane without a pixel holds: above every interval
-struct CntItem { NfaGeom g; int c, j, lg, nWin; int lo[2], hi[2]; };      // lg: log2 of the lanes sharing a row; [lo, hi]: aligned angle bit patterns
+struct CntItem { NfaGeom g; int c, j, lg, nWin; int lo[2], hi[2];      // lg: log2 of the lanes sharing a row; [lo, hi]: aligned angle bit patterns
+#ifdef SSLAM_NFA_F64               // A/B knob: the per-pixel fp64 predicate of rounds 1-2 on the new planes
+                 double theta, prec, p;
+#endif
+};
+#ifdef SSLAM_NFA_F64
+__device__ __forceinline__ double align_dist_min(float aDeg, double theta) {
+    const double n_theta = fabs(theta - (double)aDeg * DEG2RAD);
+    return fmin(n_theta, fabs(n_theta - M_2PI_));
+}
+#endif
 
 // Pixel walk shared by the two counters below.  A row is shared by 2^lg lanes (lg picked per rectangle from its widest
 // row: tall thin rectangles put 32 rows in flight, flat ones spread one row over the whole wave); each lane owns a
 // contiguous run of the row and the wave steps through the runs twelve pixels at a time.
-// element of pixel (x, y) in the T plane given yb = tix(0, y): x + 24 * (x >> 3) steps over the other three rows of each tile
-__device__ __forceinline__ unsigned t_abs(const unsigned* __restrict__ Tb, int yb, int x) { return Tb[yb + x + (x >> 3) * 24] & 0x7FFFFFFFu; }
+// |T| of pixel x of the row that starts at element yb: the angle whatever the used bit says, 1024 for NOTDEF
+__device__ __forceinline__ unsigned t_abs(const unsigned* __restrict__ Tb, int yb, int x) { return Tb[yb + x] & 0x7FFFFFFFu; }
 
-// aligned-point counts of one rectangle for K nested precisions; total = pixels visited.  win: [k][window] {lo, hi} in LDS
-template <int K, bool SMALL>
-__device__ __forceinline__ void count_item(const NfaGeom& g, int lg, int nWin, const int* __restrict__ win, const unsigned* __restrict__ Tb, int tW, int sw,
-                                           int lane, int& totalOut, int (&alg)[6]) {
+// aligned-point counts of one rectangle for six nested tolerances; total = pixels visited.  win: [k] {lo, hi} of ONE window per tolerance
+// (an item whose angles straddle the 0 / 360 seam has a second window: the caller runs a second pass for it -- the windows are disjoint,
+// so the counts add -- instead of every pixel step carrying a second set of compares).
+__device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const int* __restrict__ win, const unsigned* __restrict__ Tb, int tW, int sw, bool small,
+                                           int lane, int& totalOut, int (&alg)[6], double theta = 0, const double* precs = nullptr) {
+    constexpr int K = 6;
     const int nrows = g.y1 - g.y0 + 1;
     const int rowsPer = 64 >> lg, r = lane >> lg, sub = lane & ((1 << lg) - 1);
     int total = 0;
+    int lo[K], hi[K];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) alg[k] = 0;
-    int lo0[K], hi0[K];                            // the second window (angles around the 0 / 360 seam) is rare: read from LDS where it is needed
-#pragma unroll
-    for (int k = 0; k < K; ++k) { lo0[k] = win[k * 4]; hi0[k] = win[k * 4 + 1]; }
+    for (int k = 0; k < K; ++k) { lo[k] = win[k * 4]; hi[k] = win[k * 4 + 1]; }
     for (int t0 = 0; t0 < nrows; t0 += rowsPer) {
         const int t = t0 + r;
         int xa = 0, xb = -1; const int y = g.y0 + t;
-        if (t < nrows) nfa_row_range<SMALL>(g, y, sw, xa, xb);
+        if (t < nrows) nfa_row_range(g, y, sw, small, xa, xb);
         const int width = max(xb - xa + 1, 0);
         total += sub == 0 ? width : 0;
         const int share = (width + (1 << lg) - 1) >> lg;
@@ -368,25 +387,31 @@ __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, int nWin, c
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 if (!vote(c0 + q < mine)) break;
+#ifdef SSLAM_NFA_F64
+                const float af = __uint_as_float(a[q]);
+                const double dd = align_dist_min(af, theta);
+                const unsigned long long def = vote(af < 1000.f);       // NOTDEF is 1024 here, lanes without a pixel hold a NaN pattern
 #pragma unroll
-                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote((int)a[q] >= lo0[k])) - __popcll(vote((int)a[q] > hi0[k]));
-                if (nWin > 1) {
+                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(dd <= precs[k]) & def);
+#else
 #pragma unroll
-                    for (int k = 0; k < K; ++k) alg[k] += __popcll(vote((int)a[q] >= win[k * 4 + 2])) - __popcll(vote((int)a[q] > win[k * 4 + 3]));
-                }
+                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote((int)a[q] >= lo[k]) & ~vote((int)a[q] > hi[k]));      // lanes without a pixel: above every hi
+#endif
             }
         }
     }
-    totalOut = wave_sum(total);
+    totalOut = wave_sum_dpp(total);
 }
 
 // Stages 1-3: the (up to five) candidates of a rectangle differ by half-pixel width / offset steps and share theta and the
 // tolerance, so they are counted in ONE pass over the union of their rows: the angle test runs once per pixel, membership in
 // candidate j is two integer compares against that candidate's own row range (rect_nfa's edge stepping, per candidate).
-template <bool SMALL>
-__device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int nc, int lg, const unsigned* __restrict__ Tb, int tW, int sw, int lane,
+// [lo, hi]: one window of aligned angle patterns (second pass for a second window, as above; totals from the first pass).
+__device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int nc, int lg, int lo, int hi, const unsigned* __restrict__ Tb, int tW, int sw, bool small, int lane,
                                             int (&total)[MAXC], int (&alg)[MAXC]) {
-    const int nWin = it5[0].nWin, lo0 = it5[0].lo[0], hi0 = it5[0].hi[0], lo1 = it5[0].lo[1], hi1 = it5[0].hi[1];
+#ifdef SSLAM_NFA_F64
+    const double theta = it5[0].theta, prec = it5[0].prec;
+#endif
     NfaGeom g[MAXC];
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) g[j] = it5[j < nc ? j : 0].g;
@@ -396,7 +421,7 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
     const int nrows = y1u - y0u + 1;
     const int rowsPer = 64 >> lg, r = lane >> lg, sub = lane & ((1 << lg) - 1);
 #pragma unroll
-    for (int j = 0; j < MAXC; ++j) { total[j] = 0; alg[j] = 0; }
+    for (int j = 0; j < MAXC; ++j) total[j] = 0;
     for (int t0 = 0; t0 < nrows; t0 += rowsPer) {
         const int t = t0 + r;
         const int y = y0u + t;
@@ -406,7 +431,7 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
         for (int j = 0; j < MAXC; ++j) {
             xaj[j] = 1; xbj[j] = 0;
             if (j < nc && t < nrows && y >= g[j].y0 && y <= g[j].y1) {
-                nfa_row_range<SMALL>(g[j], y, sw, xaj[j], xbj[j]);
+                nfa_row_range(g[j], y, sw, small, xaj[j], xbj[j]);
                 if (xbj[j] >= xaj[j]) { xa = min(xa, xaj[j]); xb = max(xb, xbj[j]); }
                 else { xaj[j] = 1; xbj[j] = 0; }
             }
@@ -432,9 +457,12 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 if (!vote(c0 + q < mine)) break;
-                unsigned long long al = vote((int)a[q] >= lo0) & ~vote((int)a[q] > hi0);       // lanes without a pixel hold PIX_NONE: above every hi
-                if (nWin > 1) al |= vote((int)a[q] >= lo1) & ~vote((int)a[q] > hi1);
-                if (!al) continue;
+#ifdef SSLAM_NFA_F64
+                const float af = __uint_as_float(a[q]);
+                const unsigned long long al = vote(align_dist_min(af, theta) <= prec) & vote(af < 1000.f);
+#else
+                const unsigned long long al = vote((int)a[q] >= lo) & ~vote((int)a[q] > hi);       // lanes without a pixel hold PIX_NONE: above every hi
+#endif
                 const int x = xs + c0 + q;
 #pragma unroll
                 for (int j = 0; j < MAXC; ++j) {
@@ -444,7 +472,7 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
         }
     }
 #pragma unroll
-    for (int j = 0; j < MAXC; ++j) total[j] = wave_sum(total[j]);
+    for (int j = 0; j < MAXC; ++j) total[j] = wave_sum_dpp(total[j]);
 }
 
 // Self-test of lsd_align_win.h on the device (sslam_selftest_align_windows): one (theta, tolerance) case per block round -- theta anywhere
@@ -551,23 +579,24 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
                         const int need = (nfa_max_width(I.g) + (nested ? 0 : 3) + 11) / 12;       // lanes per row so that a run is <= 12 pixels
                         int lg = 1; while ((1 << lg) < need && lg < 6) ++lg;
                         I.lg = lg;
-                        if (nested) {                                // six (stage 0) / five (stage 4) tolerances around one theta
-                            int nw = 0;
+#ifdef SSLAM_NFA_F64
+                        I.theta = r.theta; I.prec = r.prec; I.p = r.p;
+#endif
+                        // aligned-angle windows (lsd_align_win.h): six tolerances around one theta in the nested stages (stage 4 uses five of
+                        // them), one for the first candidate of a rectangle in stages 1-3 (its candidates share theta and the tolerance)
+                        const int nK = nested ? 6 : j == 0 ? 1 : 0;
+                        int nw = 0;
 #pragma unroll 1
-                            for (int k = 0; k < (stage == 0 ? 6 : 5); ++k) {
-                                const double pk = stage == 0 ? (k == 0 ? r.prec : ldexp(r.p, -k) * kPI) : ldexp(r.p, -(k + 1)) * kPI;
-                                int n, lo[2], hi[2];
-                                winOk &= alnwin::windows(r.theta, pk, n, lo, hi);
-                                // (which window lands in which slot may differ between tolerances: the counter adds both slots, empty ones count nothing)
-                                nestWin[lane][k][0] = lo[0]; nestWin[lane][k][1] = hi[0]; nestWin[lane][k][2] = lo[1]; nestWin[lane][k][3] = hi[1];
-                                nw = max(nw, n);
-                            }
-                            I.nWin = nw;
-                        } else if (j == 0) {                         // the candidates of a rectangle share theta and the tolerance: the first one's windows serve all
-                            int n;
-                            winOk = alnwin::windows(r.theta, r.prec, n, I.lo, I.hi);
-                            I.nWin = n;
+                        for (int k = 0; k < nK; ++k) {
+                            const double pk = !nested ? r.prec : stage == 0 ? (k == 0 ? r.prec : ldexp(r.p, -k) * kPI) : ldexp(r.p, -(k + 1)) * kPI;
+                            const alnwin::Win w = alnwin::windows(r.theta, pk);
+                            winOk &= w.ok != 0;
+                            // (which window lands in which slot may differ between tolerances: the counter adds both slots, empty ones count nothing)
+                            if (nested) { nestWin[lane][k][0] = w.lo0; nestWin[lane][k][1] = w.hi0; nestWin[lane][k][2] = w.lo1; nestWin[lane][k][3] = w.hi1; }
+                            else { I.lo[0] = w.lo0; I.hi[0] = w.hi0; I.lo[1] = w.lo1; I.hi[1] = w.hi1; }
+                            nw = max(nw, w.n);
                         }
+                        I.nWin = nw;
                     }
                 }
                 if (__ballot(!winOk) && lane == 0) misc->overflow = 1;      // three non-empty windows: excluded by construction (lsd_align_win.h); never count wrong silently
@@ -585,9 +614,13 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
 #pragma unroll
                     for (int j = 0; j < MAXC; ++j) nc += it5[j].j >= 0 ? 1 : 0;           // valid candidates form a prefix
                     if (nc == 0) continue;
-                    int total[MAXC], alg[MAXC];
-                    if (small) count_rect5<true>(it5, nc, it5[0].lg, Tb, tW, sw, lane, total, alg);
-                    else count_rect5<false>(it5, nc, it5[0].lg, Tb, tW, sw, lane, total, alg);
+                    int total[MAXC], alg[MAXC], tot2[MAXC];
+#pragma unroll
+                    for (int j = 0; j < MAXC; ++j) alg[j] = 0;
+                    count_rect5(it5, nc, it5[0].lg, it5[0].lo[0], it5[0].hi[0], Tb, tW, sw, small, lane, total, alg);
+#ifndef SSLAM_NFA_F64
+                    if (it5[0].nWin > 1) count_rect5(it5, nc, it5[0].lg, it5[0].lo[1], it5[0].hi[1], Tb, tW, sw, small, lane, tot2, alg);      // the 0 / 360 seam: a second, disjoint window
+#endif
                     const int c = it5[0].c;
                     if (lane < nc) {
                         const int tj = lane == 0 ? total[0] : lane == 1 ? total[1] : lane == 2 ? total[2] : lane == 3 ? total[3] : total[4];
@@ -601,11 +634,17 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
                 if (j < 0) continue;
                 const NfaGeom g = its[it].g;
                 const int c = its[it].c;
-                int total, alg[6];
+                int total, tot2, alg[6] = {0, 0, 0, 0, 0, 0};
                 const int lg = its[it].lg, nWin = its[it].nWin;
                 const int* win = &nestWin[it][0][0];
-                if (stage == 0) { if (small) count_item<6, true>(g, lg, nWin, win, Tb, tW, sw, lane, total, alg); else count_item<6, false>(g, lg, nWin, win, Tb, tW, sw, lane, total, alg); }
-                else { if (small) count_item<5, true>(g, lg, nWin, win, Tb, tW, sw, lane, total, alg); else count_item<5, false>(g, lg, nWin, win, Tb, tW, sw, lane, total, alg); }
+#ifdef SSLAM_NFA_F64
+                double precs[6];
+                for (int k = 0; k < 6; ++k) precs[k] = stage == 0 ? (k == 0 ? its[it].prec : ldexp(its[it].p, -k) * kPI) : ldexp(its[it].p, -(k + 1)) * kPI;
+                count_item(g, lg, win, Tb, tW, sw, small, lane, total, alg, its[it].theta, precs); (void)nWin; (void)tot2;
+#else
+                count_item(g, lg, win, Tb, tW, sw, small, lane, total, alg);
+                if (nWin > 1) count_item(g, lg, win + 2, Tb, tW, sw, small, lane, tot2, alg);      // the 0 / 360 seam: second windows, disjoint from the first
+#endif
                 if (lane == 0) {
                     const int K = stage == 0 ? 6 : 5;
 #pragma unroll

@@ -7,16 +7,16 @@ constexpr double kPI = 3.14159265358979323846;
 constexpr double DEG2RAD = kPI / 180;
 constexpr double M_3_2_PI_ = (3 * kPI) / 2, M_2PI_ = 2 * kPI;
 constexpr float NOTDEF_F = -1024.0f;
-// Per-pixel planes of the scaled image (round 3: the 16-byte {angle, cos, sin, |g|^2} record and the row-major angle map are gone):
+// Per-pixel planes of the scaled image, all row-major (round 3: the 16-byte {angle, cos, sin, |g|^2} record and the separate angle map are gone):
 //   T   4 B  level-line angle in degrees (fastAtan2: [0, 360), never -0) for DEFINED pixels, NOTDEF_F otherwise.  The SIGN BIT is the
 //            `used` map of region growing: a pixel that belongs to a region holds -angle, so "unused and defined" is one integer
 //            compare (bits >= 0), releasing a pixel clears the bit again, and the angle survives for the rectangle counter
-//            (|T|; NOTDEF becomes 1024, above every angle).  Stored in tiles of 8 x 4 pixels = one 128-byte line: a 3 x 3
-//            neighbourhood touches 1.9 lines on average instead of 3.75 with 16-byte row-major records, and a region's
-//            footprint shrinks by 2.5-4x (what the per-wave share of L1 / L2 can actually hold at 24 frames per CU).
-//   Cs  8 B  {cosf, sinf} of the angle (decision D5), tiles of 4 x 4 pixels = one line; read for accepted pixels' direction sums.
-//   S   4 B  gx^2 + gy^2 (-1: undefined), row-major: the counting sort streams it, region2rect gathers its weights from it.
-// Both tiled planes are padded to whole workgroup blocks of k_lsd_grad (256 x 4 pixels), so every block is written complete.
+//            (|T|; NOTDEF becomes 1024, above every angle).
+//   Cs  8 B  {cosf, sinf} of the angle (decision D5); read with T by region growing for the accepted pixels' direction sums.
+//   S   4 B  gx^2 + gy^2 (-1: undefined): the counting sort streams it, region2rect gathers its weights from it.
+// 16 bytes per pixel written by k_lsd_grad instead of 24.  (A tiled form of T / Cs -- 8 x 4 and 4 x 4 pixels per 128-byte line -- was built
+// and measured first: L1 misses of the sequential core -12 %, its time unchanged, the rectangle counter +40 % for the address
+// arithmetic; profiles/README.md, round 3.)
 constexpr unsigned USED_BIT = 0x80000000u;
 constexpr int N_BINS = 1024;
 constexpr int TILE_PX = 8192;           // raster tile of the counting sort
@@ -29,7 +29,7 @@ struct LsdPlan {
     int npx;                  // sw*sh
     int nTiles;
     size_t frameBytes;        // per-frame workspace
-    int tW, cW;               // tiles per tile row of the T plane (8-pixel tiles) and of the Cs plane (4-pixel tiles); tile rows: ceil(sh / 4)
+    int tW, cW;               // row pitch (elements) of the T and Cs planes (= sw)
     size_t offBlur, offT, offS, offCs, offCand, offFlag, offNfa, offOrder, offTileHist, offReg, offSeg, offMisc, offDxy, offKl, offSortIdx;
     int blurTaps[7];          // sigma 0.75, 7 taps (q8)
     int blur5Taps[5];         // sigma 1, 5 taps (q8)
@@ -48,9 +48,9 @@ struct Misc {                 // per-frame scalars
     long long cyc[8];         // master-wave cycle breakdown (debug): grow, rect, refine, nfa count, nfa math, seed scan
 };
 
-// element index of pixel (x, y) in the tiled planes
-__device__ __forceinline__ int tix(int x, int y, int tW) { return ((((y >> 2) * tW) + (x >> 3)) << 5) | ((y & 3) << 3) | (x & 7); }
-__device__ __forceinline__ int cix(int x, int y, int cW) { return ((((y >> 2) * cW) + (x >> 2)) << 4) | ((y & 3) << 2) | (x & 3); }
+// element index of pixel (x, y) in the T / Cs planes
+__device__ __forceinline__ int tix(int x, int y, int tW) { return y * tW + x; }
+__device__ __forceinline__ int cix(int x, int y, int cW) { return y * cW + x; }
 
 // ------------------------------------------------------------------ the sequential core
 struct RectD { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };

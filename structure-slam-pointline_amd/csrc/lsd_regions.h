@@ -650,7 +650,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
 #else
 #define SSLAM_MW_CAUSE(c)
 #endif
-    const double prec = P.prec, p = P.p, DENSITY_TH = 0.7;
+    const double prec = P.prec;
     int nSeg = 0;
     long long cyc0 = 0, cyc1 = 0, cyc2 = 0, cyc3 = 0, cycWait = 0, cycTake = 0, cycOwn = 0;
     const long long tStart = SSLAM_CLK();
@@ -697,6 +697,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             long long t0 = SSLAM_CLK();
             int n = -1;
             bool took = false, tookEmit = false; RectD tookRec; const unsigned* smallList = rq.lds;
+            unsigned bxLo = 0u, bxHi = 0xFFFFFFFFu;              // box (packed x | y << 16 minima / maxima) of every pixel this seed's body touched
 #ifdef SSLAM_MW_STATS
             int cause = 7;                                      // 7: the main wave's own chunk
 #endif
@@ -749,7 +750,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
                         if (nA + nB == 1) { if (lane == first) pl.T[tiSeed] = t_used(a0); }
                         else if (!(flags & MW_REFINED) && nF <= 64) { if (lane < nF) pl.T[ti0] = t_used(v0); }
                         else for (int i = lane; i < nF; i += 64) { unsigned* t = pl.Tb() + pl.ti(lstF[i]); *t |= USED_BIT; }
-                        took = true; n = nA; smallList = lstA;
+                        took = true; n = nA; smallList = lstA; bxLo = r->lo; bxHi = r->hi;
                         tookEmit = (flags & MW_EMIT) != 0;
                         if (tookEmit) {
                             const int* rw = (const int*)(lstB + nB + ((flags & MW_REDUCED) ? nF : 0));
@@ -792,8 +793,11 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             else {
                 bool refined = false; unsigned evLo = 0xFFFFFFFFu, evHi = 0u;      // MW: everything refine() may have released lies inside this box
                 long long cycs[3] = {0, 0, 0};
-                emit = rect_refine<LAT, false, MW>(P, sd, n, regAngle, rq, pl, red, rec, refined, evLo, evHi, cycs, nullptr, &misc->cyc[6]);
+                const int nGrown = n;
+                emit = rect_refine<LAT, false, true>(P, sd, n, regAngle, rq, pl, red, rec, refined, evLo, evHi, cycs, nullptr, &misc->cyc[6]);
                 cyc1 += cycs[0]; t2 = t1 + cycs[0]; cyc3 += cycs[2];
+                if (!refined) { if (nGrown <= QCAP) list_bbox(rq.lds, nGrown, lane, evLo, evHi); else { evLo = 0u; evHi = 0xFFFFFFFFu; } }      // the list is the region as grown
+                bxLo = evLo; bxHi = evHi;
                 if (MW && refined) {                              // log the event once the last store of this refine has left
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     ++unmarkSeq;
@@ -804,9 +808,19 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             // ---- hand the rectangle to the NFA stage (rect_improve reads only the static angle map and never touches
             // `used`, so it is not part of the sequential dependency chain: k_lsd_nfa evaluates all candidates in parallel)
             long long t3 = SSLAM_CLK(); cyc2 += t3 - t2;
-            // a region of this size -- kept or not, refine() may have released pixels again -- can have changed any candidate of the chunk:
-            // gather their state once more (candidates before the seed are never revisited, as in the reference's forward loop)
-            unM = __ballot(have && lane > first && t_free(pl.T[tiSeed]));
+            // a region of this size -- kept or not, refine() may have released pixels again -- can have changed the candidates of the chunk that
+            // lie inside the box of what it touched (everything it marked or released is inside; pixels of other regions are never released):
+            // only those are gathered again.  (Rounds 1-2 gathered all 64: 27 k scattered lines per frame, a quarter of the core's L1 misses.)
+            {
+                const int ix = (int)(idx & 0xFFFF), iy = (int)(idx >> 16);
+#ifdef SSLAM_LSD_NO_BOXFILTER      // A/B knob: the round-2 behaviour
+                bxLo = 0u; bxHi = 0xFFFFFFFFu;
+#endif
+                const bool chk = have && ((unM >> lane) & 1ull) && ix >= (int)(bxLo & 0xFFFF) && ix <= (int)(bxHi & 0xFFFF) && iy >= (int)(bxLo >> 16) && iy <= (int)(bxHi >> 16);
+                bool usedNow = false;
+                if (chk) usedNow = !t_free(pl.T[tiSeed]);
+                unM &= ~__ballot(usedNow);
+            }
             if (!emit) continue;
             if (nSeg < MAX_SEG && lane == 0) {
                 double* o = candOut + (size_t)nSeg * 12;
@@ -1078,7 +1092,7 @@ __global__ __launch_bounds__(64 * (1 + MW_HMAX)) void k_lsd_regions_mw(uint8_t* 
     __shared__ double helperRed[MW_HMAX][3 * 64];
     __shared__ MwCtl ctl;
     __shared__ MwSlot slots[MW_HMAX * MW_NSLOT];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; ctl.helperIdle = 0; ctl.helperBusy = 0; for (int c = 0; c < 8; ++c) { ctl.why[c] = 0; ctl.hcyc[c] = 0; } ctl.published = 0; for (int c = 0; c < MW_HMAX; ++c) ctl.flPos[c] = 0x7FFFFFFF; }
     if (threadIdx.x < MW_HMAX * MW_NSLOT) { slots[threadIdx.x].chunkPos = -1; slots[threadIdx.x].nres = 0; slots[threadIdx.x].doneLane = 0; slots[threadIdx.x].begin = 0; }
     MwShared mw; mw.ctl = &ctl; mw.slots = slots; mw.arena = dynLds + QCAP + 4; mw.nHelpers = nHelpers;

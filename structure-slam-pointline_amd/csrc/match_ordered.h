@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64) void k_search_proj(ProjArgs A) {
         for (int i0 = 0; i0 < nq; i0 += 64) {
             const int i = i0 + lane;
             bool rm = false;
-            if (i < nq) { const int bn = qbin[i]; rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3; if (rm) A.assigned[qidx[i]] = -1; }
+            if (i < nq) { const int bn = qbin[i]; rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3; if (rm) A.assigned[qidx[i]] = -2; }      // matched, then removed by the rotation check: the reference NULLs the pointer (src/ORBmatcher.cc:1465)
             removed += __popcll(__ballot(rm));
         }
         nmatches -= removed;
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(PROJ_WAVES * 64) void k_search_proj_lds(ProjArgs A)
             for (int i0 = 0; i0 < nq; i0 += 64) {
                 const int i = i0 + lane;
                 bool rm = false;
-                if (i < nq) { const int bn = qbin[i]; rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3; if (rm) A.assigned[qidx[i]] = -1; }
+                if (i < nq) { const int bn = qbin[i]; rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3; if (rm) A.assigned[qidx[i]] = -2; }      // matched, then removed by the rotation check: the reference NULLs the pointer (src/ORBmatcher.cc:1465)
                 removed += __popcll(__ballot(rm));
             }
             nmatches -= removed;

@@ -133,6 +133,8 @@ class TorchGather:
                                      self.send, self.cap_bytes, self.total, p._stream())
         cur.wait_stream(s1)
         n = int(self.total[0].item())
+        if n < 0 or n > self.cap_bytes:      # the pack kernel's overflow sentinel is UINT64_MAX, which reads as -1 here: never slice with it
+            raise RuntimeError("record stream overflow: the packed results of rank %d do not fit %d bytes" % (self.rank, self.cap_bytes))
         got, sizes = gather_streams(self.dist, self.send[:n], self.world, self.rank)
         self.out = (got, sizes) if self.rank == 0 else None
 

@@ -11,6 +11,35 @@
 
 namespace sslam_shim
 {
+// The pose algebra of the two per-frame tracking calls (ORBmatcher / LSDmatcher ::SearchByProjection(Frame&, const Frame&, th, bMono),
+// src/ORBmatcher.cc:1340-1349,1363-1364, src/LSDmatcher.cpp:25-34,50-59): 3x3 * 3x1 products on CV_32F matrices.  With OpenCV present these
+// are the reference's own cv::Mat expressions (same gemm, same roundings); with the stand-in Mat (cv_min.h) plain float arithmetic in
+// row order -- OpenCV's small-matrix path accumulates a 3-term row in float as well, but that is upstream behaviour this build cannot pin.
+struct Rt { float R[9], t[3]; };
+inline Rt PoseRt(const cv::Mat &Tcw) {          // Rcw = Tcw.rowRange(0,3).colRange(0,3), tcw = Tcw.rowRange(0,3).col(3)
+    Rt p;
+    for (int r = 0; r < 3; ++r) { const float *row = Tcw.ptr<float>(r); p.R[3 * r] = row[0]; p.R[3 * r + 1] = row[1]; p.R[3 * r + 2] = row[2]; p.t[r] = row[3]; }
+    return p;
+}
+inline void RxPlusT(const Rt &p, const float x[3], float out[3]) {      // R * x + t
+#ifdef SSLAM_HAVE_OPENCV
+    const cv::Mat R(3, 3, CV_32F, (void *)p.R), t(3, 1, CV_32F, (void *)p.t), xv(3, 1, CV_32F, (void *)x);
+    const cv::Mat o = R * xv + t;
+    for (int r = 0; r < 3; ++r) out[r] = o.at<float>(r);
+#else
+    for (int r = 0; r < 3; ++r) out[r] = ((p.R[3 * r] * x[0] + p.R[3 * r + 1] * x[1]) + p.R[3 * r + 2] * x[2]) + p.t[r];
+#endif
+}
+inline void MinusRtT(const Rt &p, float out[3]) {                      // -R.t() * t
+#ifdef SSLAM_HAVE_OPENCV
+    const cv::Mat R(3, 3, CV_32F, (void *)p.R), t(3, 1, CV_32F, (void *)p.t);
+    const cv::Mat o = -R.t() * t;
+    for (int r = 0; r < 3; ++r) out[r] = o.at<float>(r);
+#else
+    for (int r = 0; r < 3; ++r) out[r] = ((-p.R[r]) * p.t[0] + (-p.R[3 + r]) * p.t[1]) + (-p.R[6 + r]) * p.t[2];
+#endif
+}
+
 // ORBmatcher::DescriptorDistance / LSDmatcher::DescriptorDistance (src/ORBmatcher.cc:1650-1666): host popcount, unchanged semantics.
 int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
 

@@ -5,10 +5,11 @@
 //
 // Provided here (src/LSDmatcher.cpp bodies to delete): DescriptorDistance :364-380, SearchByProjection(KeyFrame*, Frame&, ...) :143-183,
 // SearchByProjection(Frame&, vector<MapLine*>&, th) :185-255 with RadiusByViewingCos :550-556, SerachForInitialize :257-284,
-// SearchByDescriptor x2 :286-362, SearchForTriangulation :382-415.
-// Left in the reference source (pose algebra on cv::Mat stays on the host; INTEGRATION.md §3 has their one-call bodies):
-// SearchByProjection(Frame&, const Frame&, ...) :22-141, SearchByProjection(KeyFrame*, Scw, ...) :558-683, SearchBySim3 :685-929, Fuse x2.
+// SearchByDescriptor x2 :286-362, SearchForTriangulation :382-415, SearchByProjection(Frame&, const Frame&, th, bMono) :22-141 (round 3).
+// Left in the reference source (Sim3 algebra on cv::Mat stays on the host; INTEGRATION.md §3 has their one-call bodies):
+// SearchByProjection(KeyFrame*, Scw, ...) :558-683, SearchBySim3 :685-929, Fuse x2.
 #pragma once
+#include <type_traits>
 #include <utility>
 #include <vector>
 #include "FrontendMatchers.h"
@@ -62,7 +63,8 @@ public:
             if (bFactor) r *= th;
             sslam_shim::ProjQuery e{};
             e.u = pML->mTrackProjX1; e.v = pML->mTrackProjY1; e.u2 = pML->mTrackProjX2; e.v2 = pML->mTrackProjY2;
-            e.radius = r * F.mvScaleFactors[nPredictLevel]; e.min_level = nPredictLevel - 1; e.max_level = nPredictLevel; e.valid = 1; e.obs_positive = 1;
+            e.radius = r * F.mvScaleFactors[nPredictLevel]; e.min_level = nPredictLevel - 1; e.max_level = nPredictLevel; e.valid = 1;
+            e.obs_positive = pML->Observations() > 0;      // re-read by later queries for a line this one takes (src/LSDmatcher.cpp:221-223)
             const cv::Mat d = pML->GetDescriptor();
             qd.insert(qd.end(), d.ptr(0), d.ptr(0) + 32);
             q.push_back(e); owner.push_back(pML);
@@ -74,6 +76,61 @@ public:
         std::vector<int> assigned;
         const int n = sslam_shim::SearchLinesByProjection(F.mvKeylinesUn, F.mLdesc, occupied, q, qdesc, mfNNratio, TH_HIGH, assigned, 0);
         for (size_t i = 0; i < assigned.size(); ++i) if (assigned[i] >= 0) F.mvpMapLines[i] = owner[assigned[i]];
+        return n;
+    }
+
+    // last frame's map lines projected into the current frame (the line twin of ORBmatcher::SearchByProjection(Frame&, const Frame&, ...)):
+    // src/LSDmatcher.cpp:22-141.  Projection loop here, GetLinesInArea + best / second-best + the same-level ratio test + "already holds an
+    // observed line" on the device (kind 1, mode 0).  `LastFrame.mvKeys[i].octave` (the POINT list indexed by a line index, :80) is the
+    // reference's own expression and is kept.
+    template <class FrameT>
+    int SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame, const float th, const bool bMono)
+    {
+        typedef typename std::remove_pointer<typename std::decay<decltype(CurrentFrame.mvpMapLines[0])>::type>::type MapLineT;
+        const sslam_shim::Rt cw = sslam_shim::PoseRt(CurrentFrame.mTcw), lw = sslam_shim::PoseRt(LastFrame.mTcw);
+        float twc[3], tlc[3];
+        sslam_shim::MinusRtT(cw, twc);
+        sslam_shim::RxPlusT(lw, twc, tlc);
+        const bool bForward = tlc[2] > CurrentFrame.mb && !bMono;
+        const bool bBackward = -tlc[2] > CurrentFrame.mb && !bMono;
+        std::vector<sslam_shim::ProjQuery> q; std::vector<MapLineT *> owner; std::vector<unsigned char> qd;
+        for (int i = 0; i < LastFrame.NL; i++) {
+            MapLineT *pML = LastFrame.mvpMapLines[i];
+            if (!pML || pML->isBad() || LastFrame.mvbLineOutlier[i]) continue;
+            const auto P = pML->GetWorldPos();             // Vector6d
+            const float SP[3] = {(float)P(0), (float)P(1), (float)P(2)}, EP[3] = {(float)P(3), (float)P(4), (float)P(5)};
+            float SPc[3], EPc[3];
+            sslam_shim::RxPlusT(cw, SP, SPc);
+            sslam_shim::RxPlusT(cw, EP, EPc);
+            if (SPc[2] < 0.0f || EPc[2] < 0.0f) continue;
+            const float invz1 = 1.0f / SPc[2];
+            const float u1 = CurrentFrame.fx * SPc[0] * invz1 + CurrentFrame.cx;
+            const float v1 = CurrentFrame.fy * SPc[1] * invz1 + CurrentFrame.cy;
+            if (u1 < CurrentFrame.mnMinX || u1 > CurrentFrame.mnMaxX) continue;
+            if (v1 < CurrentFrame.mnMinY || v1 > CurrentFrame.mnMaxY) continue;
+            const float invz2 = 1.0f / EPc[2];
+            const float u2 = CurrentFrame.fx * EPc[0] * invz2 + CurrentFrame.cx;
+            const float v2 = CurrentFrame.fy * EPc[1] * invz2 + CurrentFrame.cy;
+            if (u2 < CurrentFrame.mnMinX || u2 > CurrentFrame.mnMaxX) continue;
+            if (v2 < CurrentFrame.mnMinY || v2 > CurrentFrame.mnMaxY) continue;
+            const int nLastOctave = LastFrame.mvKeys[i].octave;
+            sslam_shim::ProjQuery e{};
+            e.u = u1; e.v = v1; e.u2 = u2; e.v2 = v2; e.radius = th * CurrentFrame.mvScaleFactors[nLastOctave];
+            if (bForward) { e.min_level = nLastOctave; e.max_level = -1; }
+            else if (bBackward) { e.min_level = 0; e.max_level = nLastOctave; }
+            else { e.min_level = nLastOctave - 1; e.max_level = nLastOctave + 1; }
+            e.valid = 1; e.obs_positive = pML->Observations() > 0;
+            const cv::Mat d = pML->GetDescriptor();
+            qd.insert(qd.end(), d.ptr(0), d.ptr(0) + 32);
+            q.push_back(e); owner.push_back(pML);
+        }
+        if (q.empty()) return 0;
+        std::vector<unsigned char> occupied(CurrentFrame.mvKeylinesUn.size(), 0);
+        for (size_t i = 0; i < occupied.size(); ++i) occupied[i] = CurrentFrame.mvpMapLines[i] && CurrentFrame.mvpMapLines[i]->Observations() > 0;
+        cv::Mat qdesc((int)q.size(), 32, CV_8U, qd.data());
+        std::vector<int> assigned;
+        const int n = sslam_shim::SearchLinesByProjection(CurrentFrame.mvKeylinesUn, CurrentFrame.mLdesc, occupied, q, qdesc, mfNNratio, TH_HIGH, assigned, 0);
+        for (size_t i = 0; i < assigned.size(); ++i) if (assigned[i] >= 0) CurrentFrame.mvpMapLines[i] = owner[assigned[i]];
         return n;
     }
 
@@ -99,7 +156,6 @@ public:
     }
 
 #ifdef SSLAM_REFERENCE_TYPES      // bodies stay in the reference's src/LSDmatcher.cpp
-    int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
     int SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapLine *> &vpLines, std::vector<MapLine *> &vpMatched, int th);
     int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapLine *> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th);
     int Fuse(KeyFrame *pKF, const std::vector<MapLine *> &vpMapLines, const float th = 3.0);

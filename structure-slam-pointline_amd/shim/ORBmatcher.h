@@ -6,14 +6,16 @@
 // mbTrackInView, isBad(), mnTrackScaleLevel, mTrackViewCos, mTrackProjX/Y/XR, GetDescriptor(), Observations().
 //
 // Provided here (src/ORBmatcher.cc bodies to delete): DescriptorDistance :1650-1666, SearchForInitialization :408-523,
-// SearchByProjection(Frame&, vector<MapPoint*>&, th) :45-129 with RadiusByViewingCos :131-137.
-// Left in the reference source (they need cv::Mat pose algebra / DBoW2 FeatureVector walks that stay on the host; INTEGRATION.md §3 shows
-// the one-call bodies over sslam_shim::SearchByProjection / sslam_orb_search_by_bow / sslam_fuse_search): SearchByProjection(Frame&, const
-// Frame&, ...) :1331-1473, SearchByProjection(Frame&, KeyFrame*, ...) :1475-1602, SearchByProjection(KeyFrame*, Scw, ...) :293-406,
+// SearchByProjection(Frame&, vector<MapPoint*>&, th) :45-129 with RadiusByViewingCos :131-137, SearchByProjection(Frame&, const Frame&, th,
+// bMono) :1331-1473 (the per-frame tracking call; round 3).
+// Left in the reference source (relocalisation / mapping / loop-closing calls: DBoW2 FeatureVector walks and Sim3 algebra that stay on the
+// host; INTEGRATION.md §3 shows the one-call bodies over sslam_shim::SearchByProjection / sslam_orb_search_by_bow / sslam_fuse_search):
+// SearchByProjection(Frame&, KeyFrame*, ...) :1475-1602, SearchByProjection(KeyFrame*, Scw, ...) :293-406,
 // SearchByBoW x2, SearchForTriangulation, SearchBySim3, Fuse x2.  Those stay declared exactly as in the reference header when the reference's
 // own types are in scope (SSLAM_REFERENCE_TYPES, defined by including this file after Frame.h / KeyFrame.h / MapPoint.h).
 #pragma once
 #include <set>
+#include <type_traits>
 #include <utility>
 #include <vector>
 #include "FrontendMatchers.h"
@@ -46,7 +48,8 @@ public:
             if (bFactor) r *= th;
             sslam_shim::ProjQuery e{};
             e.u = pMP->mTrackProjX; e.v = pMP->mTrackProjY; e.radius = r * F.mvScaleFactors[nPredictedLevel];
-            e.min_level = nPredictedLevel - 1; e.max_level = nPredictedLevel; e.ur = pMP->mTrackProjXR; e.valid = 1; e.obs_positive = 1;
+            e.min_level = nPredictedLevel - 1; e.max_level = nPredictedLevel; e.ur = pMP->mTrackProjXR; e.valid = 1;
+            e.obs_positive = pMP->Observations() > 0;      // re-read by later queries for a keypoint this one takes (src/ORBmatcher.cc:86-88)
             const cv::Mat d = pMP->GetDescriptor();
             qd.insert(qd.end(), d.ptr(0), d.ptr(0) + 32);
             q.push_back(e); owner.push_back(pMP);
@@ -62,6 +65,62 @@ public:
         return n;
     }
 
+    // Project MapPoints tracked in the last frame into the current frame and search matches (Tracking::TrackWithMotionModel,
+    // src/Tracking.cc:1227, retried with 2*th at :1243): src/ORBmatcher.cc:1331-1473.  The projection loop stays here (poses, map points:
+    // tracker state); GetFeaturesInArea, the best-candidate selection, the "keypoint already holds an observed point" rule, the stereo
+    // gate and the rotation histogram run on the device (mode 1).  The second parameter is `const FrameT&`, which is what distinguishes this
+    // overload from the map-point one above (a vector) exactly as in the reference header (include/ORBmatcher.h:54,58).
+    template <class FrameT>
+    int SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame, const float th, const bool bMono)
+    {
+        typedef typename std::remove_pointer<typename std::decay<decltype(CurrentFrame.mvpMapPoints[0])>::type>::type MapPointT;
+        const sslam_shim::Rt cw = sslam_shim::PoseRt(CurrentFrame.mTcw), lw = sslam_shim::PoseRt(LastFrame.mTcw);
+        float twc[3], tlc[3];
+        sslam_shim::MinusRtT(cw, twc);                 // twc = -Rcw.t()*tcw
+        sslam_shim::RxPlusT(lw, twc, tlc);             // tlc = Rlw*twc+tlw
+        const bool bForward = tlc[2] > CurrentFrame.mb && !bMono;
+        const bool bBackward = -tlc[2] > CurrentFrame.mb && !bMono;
+        std::vector<sslam_shim::ProjQuery> q; std::vector<MapPointT *> owner; std::vector<unsigned char> qd;
+        for (int i = 0; i < LastFrame.N; i++) {
+            MapPointT *pMP = LastFrame.mvpMapPoints[i];
+            if (!pMP || LastFrame.mvbOutlier[i]) continue;
+            const cv::Mat x3Dw = pMP->GetWorldPos();
+            const float xw[3] = {x3Dw.template at<float>(0), x3Dw.template at<float>(1), x3Dw.template at<float>(2)};
+            float x3Dc[3];
+            sslam_shim::RxPlusT(cw, xw, x3Dc);         // x3Dc = Rcw*x3Dw+tcw
+            const float xc = x3Dc[0], yc = x3Dc[1];
+            const float invzc = 1.0 / x3Dc[2];
+            if (invzc < 0) continue;
+            const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+            const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+            if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+            if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+            const int nLastOctave = LastFrame.mvKeys[i].octave;
+            sslam_shim::ProjQuery e{};
+            e.u = u; e.v = v; e.radius = th * CurrentFrame.mvScaleFactors[nLastOctave];
+            if (bForward) { e.min_level = nLastOctave; e.max_level = -1; }                 // GetFeaturesInArea(u, v, radius, nLastOctave)
+            else if (bBackward) { e.min_level = 0; e.max_level = nLastOctave; }
+            else { e.min_level = nLastOctave - 1; e.max_level = nLastOctave + 1; }
+            e.angle = LastFrame.mvKeysUn[i].angle; e.ur = u - CurrentFrame.mbf * invzc; e.valid = 1; e.obs_positive = pMP->Observations() > 0;
+            const cv::Mat d = pMP->GetDescriptor();
+            qd.insert(qd.end(), d.ptr(0), d.ptr(0) + 32);
+            q.push_back(e); owner.push_back(pMP);
+        }
+        if (q.empty()) return 0;
+        std::vector<unsigned char> occupied(CurrentFrame.mvKeysUn.size(), 0);
+        for (size_t i = 0; i < occupied.size(); ++i) occupied[i] = CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations() > 0;
+        const float bounds[4] = {(float)CurrentFrame.mnMinX, (float)CurrentFrame.mnMaxX, (float)CurrentFrame.mnMinY, (float)CurrentFrame.mnMaxY};
+        cv::Mat qdesc((int)q.size(), 32, CV_8U, qd.data());
+        std::vector<int> assigned;
+        const int n = sslam_shim::SearchByProjection(1, CurrentFrame.mvKeysUn, CurrentFrame.mDescriptors, bounds, &CurrentFrame.mvuRight, occupied, q, qdesc, mfNNratio, TH_HIGH,
+                                                     mbCheckOrientation, assigned);
+        for (size_t i = 0; i < assigned.size(); ++i) {
+            if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = owner[assigned[i]];
+            else if (assigned[i] == -2) CurrentFrame.mvpMapPoints[i] = static_cast<MapPointT *>(NULL);      // matched, then removed by the rotation check (:1465)
+        }
+        return n;
+    }
+
     // Matching for the Map Initialization (src/Tracking.cc:365-366)
     template <class FrameT>
     int SearchForInitialization(FrameT &F1, FrameT &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize = 10)
@@ -72,7 +131,6 @@ public:
     }
 
 #ifdef SSLAM_REFERENCE_TYPES      // declarations of the methods whose bodies stay in the reference's src/ORBmatcher.cc
-    int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
     int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist);
     int SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched, int th);
     int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);

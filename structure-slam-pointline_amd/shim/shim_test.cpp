@@ -15,14 +15,17 @@
 // reference's own types bind the same way at its call sites.
 struct TMapPoint {
     bool mbTrackInView = true, bad = false; int mnTrackScaleLevel = 0, nObs = 1; float mTrackViewCos = 1.f, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = -1;
-    cv::Mat desc;
+    cv::Mat desc, worldPos;                    // worldPos: 3 x 1 CV_32F (MapPoint::GetWorldPos)
+    cv::Mat GetWorldPos() const { return worldPos; }
     bool isBad() const { return bad; }
     cv::Mat GetDescriptor() const { return desc; }
     int Observations() const { return nObs; }
 };
+struct TVector6d { double v[6]; double operator()(int i) const { return v[i]; } };      // Eigen Vector6d (MapLine::GetWorldPos)
 struct TMapLine {
     bool mbTrackInView = true, bad = false; int mnTrackScaleLevel = 0, nObs = 1; float mTrackViewCos = 1.f, mTrackProjX1 = 0, mTrackProjY1 = 0, mTrackProjX2 = 0, mTrackProjY2 = 0;
-    cv::Mat desc;
+    cv::Mat desc; TVector6d worldPos{};
+    TVector6d GetWorldPos() const { return worldPos; }
     bool isBad() const { return bad; }
     cv::Mat GetDescriptor() const { return desc; }
     int Observations() const { return nObs; }
@@ -31,6 +34,9 @@ struct TFrame {
     std::vector<cv::KeyPoint> mvKeysUn; cv::Mat mDescriptors; std::vector<float> mvuRight, mvScaleFactors; std::vector<TMapPoint*> mvpMapPoints;
     std::vector<cv::line_descriptor::KeyLine> mvKeylinesUn; cv::Mat mLdesc; std::vector<TMapLine*> mvpMapLines; int NL = 0;
     float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
+    // what the two per-frame tracking calls read on top of that (include/Frame.h:96-200)
+    cv::Mat mTcw; float fx = 0, fy = 0, cx = 0, cy = 0, mb = 0, mbf = 0; int N = 0;
+    std::vector<cv::KeyPoint> mvKeys; std::vector<bool> mvbOutlier, mvbLineOutlier;
 };
 struct TKeyFrame {
     cv::Mat mLineDescriptors; std::vector<TMapLine*> lines;
@@ -118,6 +124,66 @@ int main(int argc, char** argv) {
         lmatcher.SearchByDescriptor(&KF1, &KF2, kk);
         std::vector<int> kki; for (TMapLine* q : kk) kki.push_back(q ? (int)(q - mls.data()) : -1);
         dump(out + "_cls_kf2kf.bin", kki.data(), kki.size());
+    }
+    // ---- the per-frame tracking calls (Tracking::TrackWithMotionModel, src/Tracking.cc:1227-1243): ORBmatcher / LSDmatcher ::SearchByProjection(
+    // CurrentFrame, LastFrame, th, bMono) through stand-in frames with poses, intrinsics and map points / lines at known world positions.
+    // Poses, world positions and flags are dumped; tests/test_shim_gpu.py forms the same queries in float32 and asks the oracle.
+    {
+        TFrame Last, Cur;
+        Last.mvKeysUn = k1; Last.mvKeys = k1; Last.N = (int)k1.size(); Last.NL = (int)l1.size(); Last.mvKeylinesUn = l1;
+        Cur.mvKeysUn = k2; Cur.mvKeys = k2; Cur.mDescriptors = d2; Cur.N = (int)k2.size(); Cur.mvKeylinesUn = l2; Cur.mLdesc = ld2; Cur.NL = (int)l2.size();
+        Cur.mnMaxX = (float)w; Cur.mnMaxY = (float)h;
+        for (int i = 0; i < 8; ++i) Cur.mvScaleFactors.push_back(ext->GetScaleFactors()[i]);
+        Cur.fx = 520.9f; Cur.fy = 521.0f; Cur.cx = 325.1f; Cur.cy = 249.7f; Cur.mbf = 40.f;
+        Last.mTcw = cv::Mat(4, 4, CV_32F); Cur.mTcw = cv::Mat(4, 4, CV_32F);
+        const float cz = 0.99995f, sz = 0.0099998f;                     // ~0.573 degrees about the optical axis + a small translation
+        const float TL[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        const float TC[16] = {cz, -sz, 0, 0.012f, sz, cz, 0, -0.007f, 0, 0, 1, -0.05f, 0, 0, 0, 1};
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { Last.mTcw.at<float>(r, c) = TL[4 * r + c]; Cur.mTcw.at<float>(r, c) = TC[4 * r + c]; }
+        std::vector<TMapPoint> mps(k1.size()); std::vector<float> wp(3 * k1.size());
+        Last.mvpMapPoints.assign(k1.size(), nullptr); Last.mvbOutlier.assign(k1.size(), false);
+        for (size_t i = 0; i < k1.size(); ++i) {
+            const float z = 2.0f + 0.35f * (float)(i % 7);
+            wp[3 * i] = (k1[i].pt.x - Cur.cx) / Cur.fx * z; wp[3 * i + 1] = (k1[i].pt.y - Cur.cy) / Cur.fy * z; wp[3 * i + 2] = (i % 61 == 0) ? -z : z;      // a few behind the camera
+            mps[i].worldPos = cv::Mat(3, 1, CV_32F, &wp[3 * i]); mps[i].desc = d1.row((int)i); mps[i].nObs = (i % 11 == 0) ? 0 : 2;
+            if (i % 4 != 0) Last.mvpMapPoints[i] = &mps[i];
+            Last.mvbOutlier[i] = (i % 9 == 0);
+        }
+        std::vector<TMapLine> mls(l1.size()); std::vector<double> wl(6 * l1.size());
+        Last.mvpMapLines.assign(l1.size(), nullptr); Last.mvbLineOutlier.assign(l1.size(), false);
+        for (size_t i = 0; i < l1.size(); ++i) {
+            const double z = 2.5 + 0.4 * (double)(i % 5);
+            const double e[4] = {l1[i].startPointX, l1[i].startPointY, l1[i].endPointX, l1[i].endPointY};
+            for (int k = 0; k < 2; ++k) { mls[i].worldPos.v[3 * k] = (e[2 * k] - Cur.cx) / Cur.fx * z; mls[i].worldPos.v[3 * k + 1] = (e[2 * k + 1] - Cur.cy) / Cur.fy * z; mls[i].worldPos.v[3 * k + 2] = z; }
+            for (int k = 0; k < 6; ++k) wl[6 * i + k] = mls[i].worldPos.v[k];
+            mls[i].desc = ld1.row((int)i); mls[i].bad = (i % 13 == 5); mls[i].nObs = (i % 6 == 0) ? 0 : 1;
+            if (i % 3 != 1) Last.mvpMapLines[i] = &mls[i];
+            Last.mvbLineOutlier[i] = (i % 8 == 7);
+        }
+        TMapPoint held; held.nObs = 1; TMapPoint ghost; ghost.nObs = 0; TMapLine lheld; lheld.nObs = 1; TMapLine lghost; lghost.nObs = 0;
+        std::vector<int> res;
+        for (int pass = 0; pass < 2; ++pass) {          // pass 0: monocular (levels [oct-1, oct+1]); pass 1: "stereo", moving forward (levels >= oct)
+            const bool bMono = pass == 0;
+            Cur.mb = 0.01f;                              // tlc.z = 0.05 > mb: bForward when !bMono
+            Cur.mvpMapPoints.assign(k2.size(), nullptr); Cur.mvuRight.assign(k2.size(), -1.f);
+            for (size_t i = 0; i < k2.size(); ++i) if (i % 5 == 0) Cur.mvpMapPoints[i] = (i % 10 == 0) ? &held : &ghost;
+            Cur.mvpMapLines.assign(l2.size(), nullptr);
+            for (size_t i = 0; i < l2.size(); ++i) if (i % 4 == 0) Cur.mvpMapLines[i] = (i % 8 == 0) ? &lheld : &lghost;
+            StructureSLAM::ORBmatcher matcher(0.9, true);                      // Tracking.cc:1216
+            const int np = matcher.SearchByProjection(Cur, Last, 15.f, bMono); // Tracking.cc:1227 (th = 15 for monocular)
+            StructureSLAM::LSDmatcher lmatcher;
+            const int nl = lmatcher.SearchByProjection(Cur, Last, 15.f, bMono);
+            for (size_t i = 0; i < k2.size(); ++i) { TMapPoint* q = Cur.mvpMapPoints[i]; res.push_back(q == nullptr ? -1 : q == &held ? -2 : q == &ghost ? -3 : (int)(q - mps.data())); }
+            res.push_back(np);
+            for (size_t i = 0; i < l2.size(); ++i) { TMapLine* q = Cur.mvpMapLines[i]; res.push_back(q == nullptr ? -1 : q == &lheld ? -2 : q == &lghost ? -3 : (int)(q - mls.data())); }
+            res.push_back(nl);
+        }
+        dump(out + "_trk.bin", res.data(), res.size());
+        dump(out + "_trk_wp.bin", wp.data(), wp.size());
+        dump(out + "_trk_wl.bin", wl.data(), wl.size());
+        std::vector<float> cam = {Cur.fx, Cur.fy, Cur.cx, Cur.cy, Cur.mbf, Cur.mb};
+        cam.insert(cam.end(), TL, TL + 16); cam.insert(cam.end(), TC, TC + 16);
+        dump(out + "_trk_cam.bin", cam.data(), cam.size());
     }
     // empty image: outputs untouched
     std::vector<cv::KeyPoint> ke(3); cv::Mat de; (*ext)(cv::Mat(), cv::Mat(), ke, de);

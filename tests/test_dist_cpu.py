@@ -88,3 +88,32 @@ def test_gather_equals_single_process_results():
         np.testing.assert_array_equal(ld[i, :nl[i]], old)
         np.testing.assert_array_equal(fn[i, :nl[i]], ofn)                                     # mvKeyLineFunctions reach rank 0
     assert nk[2] == 0
+
+
+def test_sharded_batch_bookkeeping_without_devices():
+    """sslam_frontend_batch_sharded's dealing of frames over GPUs (csrc/group.hip: sslam_shard_layout / _frame / _chunk_count, the very functions
+    its worker threads call): every frame lands in exactly one (GPU, chunk, slot), on GPU frame % G, slots of a chunk are filled front to back
+    (the worker processes slots 0 .. count-1), a GPU's frame numbers advance by G (the record header's frame0 + b * step), and uneven tails
+    leave some GPUs with a short or empty last chunk.  No device needed: this is the part of the N > 1 path that can run here."""
+    import ctypes as C
+    L = C.CDLL(pkg.builder().build(force=False, verbose=False))
+    for n in (0, 1, 7, 8, 9, 64, 1000, 4095, 4096, 4097, 8 * 512 + 3, 12288):
+        for G in (1, 2, 3, 4, 8):
+            slots, chunks = C.c_int(-1), C.c_int(-1)
+            assert L.sslam_shard_layout(n, G, C.byref(slots), C.byref(chunks)) == 0
+            Cs, K = slots.value, chunks.value
+            assert 1 <= Cs <= 512 and K * Cs * G >= n and (K == 0) == (n == 0)
+            seen = np.zeros(n, np.int32)
+            for d in range(G):
+                for ck in range(K):
+                    c = L.sslam_shard_chunk_count(n, G, ck, d)
+                    fr = [L.sslam_shard_frame(n, G, ck, d, j) for j in range(Cs)]
+                    assert all(f >= 0 for f in fr[:c]) and all(f < 0 for f in fr[c:])          # a prefix of the slots
+                    for j in range(c):
+                        assert fr[j] % G == d and fr[j] == fr[0] + j * G                       # what sslam_pack_records_dev stamps: frame0 + b * step
+                        seen[fr[j]] += 1
+            assert (seen == 1).all()
+            if n and n % G:        # uneven tail: the GPUs past the remainder hold one frame fewer in total
+                per = [sum(L.sslam_shard_chunk_count(n, G, ck, d) for ck in range(K)) for d in range(G)]
+                assert max(per) - min(per) == 1 and sum(per) == n
+    assert L.sslam_shard_frame(10, 2, 0, 2, 0) == -1 and L.sslam_shard_frame(10, 2, 5, 0, 0) == -1 and L.sslam_shard_layout(-1, 2, None, None) != 0

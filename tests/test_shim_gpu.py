@@ -102,3 +102,83 @@ def test_matcher_class_dropins(oracle, fe):
     for a, b in p05:
         if b % 6 == 1: e2[a] = len(l1[0]) + b
     np.testing.assert_array_equal(kf2kf, e2)
+
+
+def test_tracking_call_class_dropins(oracle, fe):
+    """shim/ORBmatcher.h / LSDmatcher.h: SearchByProjection(CurrentFrame, LastFrame, th, bMono) -- the call Tracking::TrackWithMotionModel makes for
+    every tracked frame (src/Tracking.cc:1227, :1243; bodies src/ORBmatcher.cc:1331-1473, src/LSDmatcher.cpp:22-141) -- through stand-in frames
+    with poses, intrinsics and map points / lines at known world positions.  The test forms the reference's queries itself (the projection loop
+    in float32, same operation order) and asks the oracle's restatement of the window search; the frame's pointer arrays after the call must
+    agree, including keypoints that were matched and then removed by the rotation check (NULL, not "unchanged")."""
+    exe = pkg.builder().build_shim(force=False, verbose=False)
+    cur = synth_frame(1234); prev = warp_prev(cur)
+    with tempfile.TemporaryDirectory() as d:
+        cur.tofile(os.path.join(d, "cur.raw")); prev.tofile(os.path.join(d, "prev.raw"))
+        out = os.path.join(d, "o")
+        r = subprocess.run([exe, os.path.join(d, "cur.raw"), "640", "480", os.path.join(d, "prev.raw"), out, "1000", "40"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        trk = np.fromfile(out + "_trk.bin", dtype=np.int32); wp = np.fromfile(out + "_trk_wp.bin", dtype=np.float32).reshape(-1, 3)
+        wl = np.fromfile(out + "_trk_wl.bin", dtype=np.float64).reshape(-1, 6); cam = np.fromfile(out + "_trk_cam.bin", dtype=np.float32)
+    f32 = np.float32
+    fx, fy, cx, cy, mbf, mb = (f32(v) for v in cam[:6]); TL = cam[6:22].reshape(4, 4); TC = cam[22:38].reshape(4, 4)
+    kp1, d1 = oracle.orb_extract(prev, 1000); kp2, d2 = oracle.orb_extract(cur, 1000)
+    kl1, ld1 = oracle.lines_extract(prev, 40)[:2]; kl2, ld2 = oracle.lines_extract(cur, 40)[:2]
+    sc = [f32(1.0)]
+    for _ in range(7): sc.append(f32(sc[-1] * f32(1.2)))
+
+    def rx_plus_t(T, x):          # gemm's row order in float32 (shim/FrontendMatchers.h RxPlusT, the stand-in path)
+        return [f32(f32(f32(f32(T[r, 0] * x[0]) + f32(T[r, 1] * x[1])) + f32(T[r, 2] * x[2])) + T[r, 3]) for r in range(3)]
+    twc = [f32(f32(f32(f32(-TC[0, r]) * TC[0, 3]) + f32(f32(-TC[1, r]) * TC[1, 3])) + f32(f32(-TC[2, r]) * TC[2, 3])) for r in range(3)]
+    tlc = rx_plus_t(TL, twc)
+    W, H, th = f32(640), f32(480), f32(15.0)
+    pos = 0; pruned_seen = False
+    for bMono in (True, False):
+        fwd = (tlc[2] > mb) and not bMono; bwd = (-tlc[2] > mb) and not bMono
+        assert fwd == (not bMono) and not bwd
+        def levels(o):
+            return (o, -1) if fwd else (0, o) if bwd else (o - 1, o + 1)
+        # ---- points
+        q = []; qd = []; owner = []
+        for i in range(len(kp1)):
+            if i % 4 == 0 or i % 9 == 0: continue                          # no map point / outlier
+            xc, yc, zc = rx_plus_t(TC, wp[i])
+            invzc = f32(1.0 / np.float64(zc))
+            if invzc < 0: continue
+            u = f32(f32(f32(fx * xc) * invzc) + cx); v = f32(f32(f32(fy * yc) * invzc) + cy)
+            if u < 0 or u > W or v < 0 or v > H: continue
+            o = int(kp1["octave"][i]); lo, hi = levels(o)
+            q.append((u, v, 0, 0, f32(th * sc[o]), lo, hi, f32(kp1["angle"][i]), f32(u - f32(mbf * invzc)), 1, 0 if i % 11 == 0 else 1)); qd.append(d1[i]); owner.append(i)
+        qa = np.array(q, fe.PQ_DTYPE)
+        occupied = np.array([1 if i % 10 == 0 else 0 for i in range(len(kp2))], np.uint8)
+        assigned, n = oracle.search_by_projection(0, 1, kp2, d2, qa, np.stack(qd), occupied=occupied, uright=np.full(len(kp2), -1, np.float32), nnratio=0.9, th_dist=100, check_orientation=True)[:2]
+        exp = np.array([owner[a] if a >= 0 else -1 if a == -2 else (-2 if i % 10 == 0 else -3 if i % 5 == 0 else -1) for i, a in enumerate(assigned)], np.int32)
+        got = trk[pos:pos + len(kp2)]; pos += len(kp2)
+        np.testing.assert_array_equal(got, exp)
+        assert trk[pos] == n and n > 50, (trk[pos], n); pos += 1
+        pruned_seen = pruned_seen or bool((assigned == -2).any())
+        # ---- lines
+        q = []; qd = []; owner = []
+        for i in range(len(kl1)):
+            if i % 3 == 1 or i % 13 == 5 or i % 8 == 7: continue           # no map line / bad / outlier
+            sp = [f32(wl[i, k]) for k in range(3)]; ep = [f32(wl[i, 3 + k]) for k in range(3)]
+            s3 = rx_plus_t(TC, sp); e3 = rx_plus_t(TC, ep)
+            if s3[2] < 0 or e3[2] < 0: continue
+            iz1 = f32(f32(1.0) / s3[2]); u1 = f32(f32(f32(fx * s3[0]) * iz1) + cx); v1 = f32(f32(f32(fy * s3[1]) * iz1) + cy)
+            if u1 < 0 or u1 > W or v1 < 0 or v1 > H: continue
+            iz2 = f32(f32(1.0) / e3[2]); u2 = f32(f32(f32(fx * e3[0]) * iz2) + cx); v2 = f32(f32(f32(fy * e3[1]) * iz2) + cy)
+            if u2 < 0 or u2 > W or v2 < 0 or v2 > H: continue
+            o = int(kp1["octave"][i]); lo, hi = levels(o)                   # LastFrame.mvKeys[i].octave: the reference's own expression (src/LSDmatcher.cpp:80)
+            q.append((u1, v1, u2, v2, f32(th * sc[o]), lo, hi, 0.0, 0.0, 1, 0 if i % 6 == 0 else 1)); qd.append(ld1[i]); owner.append(i)
+        got = trk[pos:pos + len(kl2)]; pos += len(kl2)
+        init = np.array([(-2 if i % 8 == 0 else -3 if i % 4 == 0 else -1) for i in range(len(kl2))], np.int32)
+        if q:
+            qa = np.array(q, fe.PQ_DTYPE)
+            occ = np.array([1 if i % 8 == 0 else 0 for i in range(len(kl2))], np.uint8)
+            assigned, n = oracle.search_by_projection(1, 0, kl2, ld2, qa, np.stack(qd), occupied=occ, uright=None, nnratio=0.6, th_dist=100, check_orientation=False)[:2]
+            exp = np.array([owner[a] if a >= 0 else init[i] for i, a in enumerate(assigned)], np.int32)
+        else:
+            exp, n = init, 0
+        np.testing.assert_array_equal(got, exp)
+        assert trk[pos] == n; pos += 1
+    assert pos == len(trk)
+    assert pruned_seen, "no keypoint was matched and then removed by the rotation check: the NULL-vs-unchanged distinction went untested"

@@ -9,6 +9,13 @@ values (KB) converted to bytes per frame; see profiles/README.md for the gfx950 
 import sqlite3, sys, glob, os, json
 
 MATCH = {"k_knn2_batch", "k_search_init", "k_line_match"}
+FETCH_CORRECTION = 2.0      # gfx950 tallies 128-byte read requests at 64 B (MI355X_MICROARCH.md, HBM section; calibrated in profiles/README.md on this library's own access patterns)
+
+
+def lsd_core(batch):
+    """which launch form of the sequential LSD core a batch of this size runs (lines.hip: sslam_lines_extract_batch_dev)"""
+    return "k_lsd_regions_mw" if batch <= 256 else "k_lsd_regions<true>" if batch < 1024 else "k_lsd_regions<false>"
+
 ONCE = {"k_grad_table", "k_lgamma_table", "k_probe_stream16", "k_probe_gather16"}
 
 def totals(path):
@@ -31,7 +38,10 @@ def main():
         frames = B * (mp if k in MATCH else ep)
         ker[k] = {"fetch_bytes_per_frame": f.get(k, 0.0) * 1024.0 / frames, "write_bytes_per_frame": w.get(k, 0.0) * 1024.0 / frames}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --batch %d (%d extraction passes, %d matching passes); raw counter values, "
-                         "multi-launch kernels summed; see profiles/README.md for the gfx950 calibration" % (B, ep, mp), "kernels": ker}, open(out, 'w'), indent=1)
+                         "multi-launch kernels summed; see profiles/README.md for the gfx950 calibration" % (B, ep, mp),
+               "batch": B, "lsd_core": lsd_core(B), "fetch_correction": FETCH_CORRECTION,
+               "fetch_correction_note": "multiply fetch_bytes_per_frame by this before comparing with a byte count (write side raw)",
+               "kernels": ker}, open(out, 'w'), indent=1)
     for k, v in sorted(ker.items(), key=lambda kv: -(kv[1]["fetch_bytes_per_frame"] + kv[1]["write_bytes_per_frame"])):
         print("%-20s fetch %10.0f B/frame  write %10.0f B/frame" % (k, v["fetch_bytes_per_frame"], v["write_bytes_per_frame"]))
 
