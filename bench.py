@@ -212,18 +212,27 @@ def latency_leg(fe, ctx, frames, with_lines, nframes=120):
     return out
 
 
-def pcie_leg(fe, ctx, frames, with_lines, n=2048, chunk=1024):
-    """sslam_frontend_batch: host images in, host records out, copies overlapped with kernels (extract only: the API of SURVEY §8(b))."""
+def pcie_leg(fe, ctx, frames, with_lines, n=18432, chunk=0):
+    """sslam_frontend_batch: host images in, host records out (extract only: the API of SURVEY §8(b)).  n covers three chunks of the default
+    size (6144 frames = every wave slot of the sequential LSD core), so that uploads, kernels and downloads of neighbouring chunks overlap;
+    the result arrays exist before the timed call (a caller streams into its own buffers)."""
     import numpy as np, torch
     ox = fe.OrbExtractor(ctx, NFEAT); lx = fe.LineExtractor(ctx, NLINES) if with_lines else None
     U = len(frames)
-    host = np.stack([frames[i % U] for i in range(n)])
-    out = {"entry": "sslam_frontend_batch", "frames": n, "chunk": chunk, "note": "extract only (ORB + LSD/LBD), H2D of chunk k+1 and D2H of chunk k-1 under the kernels of chunk k; result allocation inside the timed region"}
-    fe.frontend_batch(ox, lx, host[:chunk], chunk=chunk)          # workspace allocation outside the timing
-    t0 = time.perf_counter(); fe.frontend_batch(ox, lx, host, chunk=chunk); out["pageable_frames_per_s"] = n / (time.perf_counter() - t0)
+    host = np.stack([frames[i % U] for i in range(min(n, 4 * U))])
+    host = np.ascontiguousarray(np.tile(host, ((n + len(host) - 1) // len(host), 1, 1))[:n])
+    out = {"entry": "sslam_frontend_batch", "frames": n, "chunk": chunk or "default (6144)",
+           "note": "extract only (ORB + LSD/LBD); H2D of chunk k+1 and D2H of chunk k-1 under the kernels of chunk k, point and line branch on two streams inside the library; result arrays allocated before the timed call"}
+    lcap = NLINES
+    warm = min(n, 6144)
+    res_pg = fe.frontend_batch_alloc(n, ox.cap, lcap, pinned=False)
+    fe.frontend_batch_raw(ox, lx, host[:warm], tuple(a[:warm] for a in res_pg), chunk=chunk)          # workspace / staging allocation outside the timing
+    t0 = time.perf_counter(); fe.frontend_batch_raw(ox, lx, host, res_pg, chunk=chunk); out["pageable_frames_per_s"] = n / (time.perf_counter() - t0)
     pin = torch.empty(host.shape, dtype=torch.uint8, pin_memory=True); pin.numpy()[:] = host
-    fe.frontend_batch(ox, lx, pin.numpy()[:chunk], chunk=chunk, pinned=True)
-    t0 = time.perf_counter(); fe.frontend_batch(ox, lx, pin.numpy(), chunk=chunk, pinned=True); out["pinned_frames_per_s"] = n / (time.perf_counter() - t0)
+    res_pin = fe.frontend_batch_alloc(n, ox.cap, lcap, pinned=True)
+    fe.frontend_batch_raw(ox, lx, pin.numpy()[:warm], tuple(a[:warm] for a in res_pin), chunk=chunk)
+    t0 = time.perf_counter(); fe.frontend_batch_raw(ox, lx, pin.numpy(), res_pin, chunk=chunk); out["pinned_frames_per_s"] = n / (time.perf_counter() - t0)
+    out["results_equal"] = bool(np.array_equal(res_pg[2], res_pin[2]) and np.array_equal(res_pg[6], res_pin[6]))
     ox.close()
     if lx: lx.close()
     return out
@@ -344,6 +353,8 @@ def main():
     torch.cuda.synchronize()
     if not args.no_profile:
         fe.lib().sslam_profile_enable(ctx.h, 1)
+    if gather is not None:
+        gather.wait_s = 0.0; gather.waits = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -356,7 +367,15 @@ def main():
     dt = time.perf_counter() - t0
     fe.lib().sslam_profile_enable(ctx.h, 0)
     prof = pipeline.profile_drain(fe, ctx) if not args.no_profile else {}
+    per_rank = None
     if dist is not None:
+        # every rank's own wall time and how long it stood still for the exchange: rank 0 prints them (a slow rank or an exchange that is
+        # not hidden behind the next step shows here, not in the max-over-ranks figure)
+        mine = torch.tensor([dt, gather.wait_s if gather is not None else 0.0], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "wall_s": float(a[0].item()), "frames_per_s": B * args.steps / float(a[0].item()), "gather_wait_ms_per_step": float(a[1].item()) * 1e3 / max(args.steps, 1)}
+                    for r, a in enumerate(allr)]
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -387,9 +406,10 @@ def main():
             if with_lines:
                 nl_own = c["nl"].cpu().numpy()
                 ok = ok and bool((rnl[0::world] == nl_own).all()) and bool(np.array_equal(rfn[0::world][-1, :nl_own[-1]], c["linefn"][-1, :nl_own[-1]].cpu().numpy()))
-            gather_info = {"ok": bool(ok), "impl": gather_impl, "records": int(nrec), "bytes_per_rank": sizes, "bytes_per_frame": float(sum(sizes)) / max(nrec, 1)}
+            gather_info = {"ok": bool(ok), "impl": gather_impl, "records": int(nrec), "bytes_per_rank": sizes, "bytes_per_frame": float(sum(sizes)) / max(nrec, 1),
+                           "per_rank": per_rank, "note": "gather_wait_ms_per_step = time the pipeline waited for the previous step's exchange (0: hidden behind the kernels)"}
         except Exception as e:
-            gather_info = {"ok": False, "error": str(e)[:200]}
+            gather_info = {"ok": False, "impl": gather_impl, "error": str(e)[:200], "per_rank": per_rank}
     if rank == 0:
         counts = pipe.feat["cur"]["n"].cpu().numpy(); lcounts = pipe.feat["cur"]["nl"].cpu().numpy()
         nm = pipe.nmatch.cpu().numpy(); nlp = pipe.nlpairs.cpu().numpy()
@@ -442,21 +462,26 @@ def main():
                                                   "note": "frac uses SURVEY.md §8(d)'s own byte total; the per-kernel table (DESIGN.md §4) is what this implementation moves"},
                                "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
                                "kernels_note": "HIP-event durations per kernel; with the two branches on two streams kernels of different branches overlap, so the durations include the sharing and their sum exceeds ms_per_step (run with --no-overlap for isolated durations)" if not args.no_overlap else "kernels run back to back on one stream"}
-        if world == 1 and not args.no_extras and args.workload in ("c3", "c2", "c4"):
-            try:
-                out["latency"] = latency_leg(fe, ctx, cur_np, with_lines)
-                out["pcie_inclusive"] = pcie_leg(fe, ctx, cur_np, with_lines, n=2048 if W == 640 else 512, chunk=1024 if W == 640 else 256)
-            except Exception as e:
-                out["latency_error"] = str(e)[:300]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], ref = cpu_baseline(cur_np, prev_np, with_lines=with_lines, with_match=wl["match"])
             out["cpu_baseline"]["parity_vs_gpu"] = parity_vs_gpu(ref, pipe.feat["cur"], with_lines)
+        if world == 1 and not args.no_extras and args.workload in ("c3", "c2", "c4"):
+            # the extra legs build their own extractors: the resident batch (175 GB at the default size) is released first
+            pipe.close(); pipe = None
+            del cur, prev
+            torch.cuda.empty_cache()
+            try:
+                out["latency"] = latency_leg(fe, ctx, cur_np, with_lines)
+                out["pcie_inclusive"] = pcie_leg(fe, ctx, cur_np, with_lines, n=18432 if W == 640 else 3072, chunk=0 if W == 640 else 1024)
+            except Exception as e:
+                out["latency_error"] = str(e)[:300]
         print(json.dumps(out))
     if gather is not None:
         gather.wait()
         if group is not None:
             group.close()
-    pipe.close()
+    if pipe is not None:
+        pipe.close()
     ctx.close()
     if dist is not None:
         dist.barrier()

@@ -356,13 +356,17 @@ int sslam_lines_set_core_event(sslam_lines* ln, void* hip_event);
  * Per-frame results in the caller's arrays: kp_out[n*cap], desc_out[n*cap*32], nkp_out[n], kl_out[n*lcap], ldesc_out[n*lcap*32],
  * linefn_out[n*lcap*3], nl_out[n]; rows past a frame's count are unspecified.  A frame with more keypoints than `cap` / more lines than
  * `lcap` makes the call return SSLAM_ERR_CAPACITY, an LSD overflow SSLAM_ERR_UNSUPPORTED (as the single-frame entry points do; the arrays
- * then hold the truncated rows).  Frames are processed in chunks of `chunk` (0 = 512): the
- * upload of chunk k+1 and the download of chunk k-1 overlap the kernels of chunk k (two copy streams; pinned caller memory -- hipHostMalloc /
- * hipHostRegister -- is copied directly, pageable memory through pinned staging buffers).  This is the
- * PCIe-inclusive form of the batch mode; callers that already hold their frames in HBM use the *_batch_dev entry points directly. */
+ * then hold the truncated rows).  Frames are processed in chunks of `chunk` (0 = as many as fill every wave slot of the sequential LSD core,
+ * 6144, bounded by a third of the free device memory): the upload of chunk k+1 and the download of chunk k-1 overlap the kernels of chunk
+ * k (two copy streams; pinned caller memory -- hipHostMalloc / hipHostRegister -- is copied directly, pageable memory through pinned staging
+ * buffers filled by a few host threads, SSLAM_BATCH_THREADS); the point branch and the line branch of a chunk run on two HIP streams, the point
+ * branch released when the sequential core starts (sslam_lines_set_core_event).  Staging buffers, streams and events are kept per context
+ * between calls (sslam_frontend_batch_release frees them early).  This is the PCIe-inclusive form of the batch mode; callers that already
+ * hold their frames in HBM use the *_batch_dev entry points directly. */
 int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride, int chunk,
                          sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
                          sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap);
+int sslam_frontend_batch_release(sslam_ctx* ctx);
 
 
 /* ---- multi-GPU batch mode (SURVEY.md §8(b) "sslam_group_create + sslam_frontend_batch_sharded", §8(e)) ----------------------
@@ -459,6 +463,10 @@ int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long long misma
  * adversarial (theta, tolerance) pairs, each compared with the reference predicate on every angle the gradient table can hold, the
  * neighbours of every end point and random patterns.  out3 = {disagreements (must be 0), tests, cases with three windows (must be 0)}. */
 int sslam_selftest_align_windows(sslam_ctx* ctx, int cases, long long out3[3]);
+/* Profiling aid (no reference counterpart): the chip's issue rate for one kind of vector instruction (0: v_add_u32, 1: v_fma_f32,
+ * 2: v_add_f64, 3: v_bcnt_u32_b32), 16 independent instructions per lane and round with 8 waves per SIMD resident: wave-instructions per
+ * second in units of 1e9.  What the SQ utilisation figures of profiles/README.md are priced against. */
+int sslam_selftest_valu_rate(sslam_ctx* ctx, int kind, double* ginst_per_s_out);
 /* Profiling aid (no reference counterpart): reads a known number of bytes in one of the library's two dominant access
  * patterns (mode 0: 16 B/lane coalesced stream, mode 1: scattered 16-B gathers) so that rocprofv3's FETCH_SIZE can be
  * calibrated on this device (tools/fetch_probe.py, profiles/README.md). */

@@ -1,30 +1,70 @@
 // Host-buffer batch mode: the `sslam_frontend_batch` of SURVEY.md §8(b) -- n frames of one size in host memory go through
 // Frame::ExtractORB + Frame::ExtractLSD (src/Frame.cc:150-161) and come back as per-frame host records.  Pure host orchestration over the
-// *_batch_dev entry points: chunks of frames are staged through pinned buffers, the H2D copy of chunk k+1 and the D2H copy of chunk k-1
-// run on two copy streams while chunk k computes (two slots of device / pinned buffers, HIP events between the streams).
+// *_batch_dev entry points.
+//
+// Round 3 (the entry ran at 17 k frames/s against 60 k for resident frames):
+//   * a chunk is as large as the sequential LSD core wants its launches -- 6144 frames fill every wave slot of the chip (24 single-wave
+//     workgroups per CU); chunks of 1024 ran the core at one wave per SIMD.  Default chunk = min(n, 6144), bounded by free device memory;
+//   * the point branch and the line branch of a chunk run on two HIP streams, the point branch released by the event the library records
+//     right before the sequential core (sslam_lines_set_core_event) -- the alignment pipeline.py uses for resident batches, now inside the
+//     library;
+//   * pageable caller memory is staged through pinned buffers by a few host threads (one memcpy thread moves ~10 GB/s: 32 k frames/s of
+//     307 KB frames at best); the buffers, streams and events live in a per-context cache instead of being allocated per call;
+//   * uploads, kernels and downloads of neighbouring chunks overlap as before (two slots).
 #include "common.h"
 #include <algorithm>
 #include <cstring>
+#include <thread>
 
 using namespace sslam;
 
 extern "C" int sslam_orb_batch_status_dev(sslam_orb* orb, int cap, int32_t* d_status4, void* stream);
 extern "C" int sslam_lines_batch_status_dev(sslam_lines* lines, int cap, int32_t* d_status4, void* stream);
+extern "C" int sslam_lines_set_core_event(sslam_lines* lines, void* hip_event);
 
 namespace {
 struct Slot {
     DevBuf dIn, dKp, dDesc, dN, dKl, dLd, dFn, dNl, dStatus;
     HostPinned hIn, hOut, hStatus;
-    hipEvent_t evIn = nullptr, evDone = nullptr, evOut = nullptr;
+    hipEvent_t evIn = nullptr, evPoint = nullptr, evLines = nullptr, evOut = nullptr;
     int first = 0, count = 0;            // frames of the chunk in flight
     void release() {
         dIn.release(); dKp.release(); dDesc.release(); dN.release(); dKl.release(); dLd.release(); dFn.release(); dNl.release(); dStatus.release(); hIn.release(); hOut.release(); hStatus.release();
-        if (evIn) (void)hipEventDestroy(evIn);
-        if (evDone) (void)hipEventDestroy(evDone);
-        if (evOut) (void)hipEventDestroy(evOut);
-        evIn = evDone = evOut = nullptr;
+        for (hipEvent_t* e : {&evIn, &evPoint, &evLines, &evOut}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
     }
 };
+// what a context keeps between calls: staging / device buffers of the two slots, the copy and branch streams, the core event
+struct BatchCache {
+    Slot slot[2];
+    hipStream_t cp = nullptr, cpOut = nullptr, stLines = nullptr;
+    hipEvent_t evCore = nullptr;
+    ~BatchCache() {
+        for (auto& s : slot) s.release();
+        for (hipStream_t* st : {&cp, &cpOut, &stLines}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
+        if (evCore) (void)hipEventDestroy(evCore);
+    }
+};
+void free_batch_cache(void* p) { delete (BatchCache*)p; }
+
+// n bytes (or `rows` strided rows) copied by up to `threads` host threads: a single memcpy stream is the bottleneck of the pageable path
+template <class F>
+void parallel_for(int items, int threads, F f) {
+    threads = std::max(1, std::min(threads, items));
+    if (threads == 1) { f(0, items); return; }
+    std::vector<std::thread> th;
+    const int per = (items + threads - 1) / threads;
+    for (int t = 1; t < threads; ++t) { const int a = t * per, b = std::min(items, a + per); if (a < b) th.emplace_back([=] { f(a, b); }); }
+    f(0, std::min(items, per));
+    for (auto& t : th) t.join();
+}
+int copy_threads() {
+    static const int n = [] {
+        if (const char* e = getenv("SSLAM_BATCH_THREADS")) return std::max(1, atoi(e));
+        const unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(8u, hc ? hc / 2 : 4u));
+    }();
+    return n;
+}
 }  // namespace
 
 extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride, int chunk,
@@ -38,8 +78,16 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
     if (n == 0) return SSLAM_OK;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
-    const int C = std::min(n, chunk > 0 ? chunk : 512);
     const size_t fpx = (size_t)w * h;
+    int C = std::min(n, chunk > 0 ? chunk : 6144);
+    if (chunk <= 0) {      // the default follows the core's wave slots, but never asks for more than a third of the free device memory
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+            const size_t perFrame = 24 * fpx + 8 * fpx + (size_t)cap * 60 * 3 + (lines ? (size_t)lcap * 124 * 3 : 0) + 65536;      // extractor workspaces + the two slots, generously
+            const size_t fit = freeB / 3 / std::max<size_t>(perFrame, 1);
+            if (fit >= 256 && (size_t)C > fit) C = (int)fit;
+        }
+    }
     const size_t oKp = 0, oDesc = oKp + sizeof(sslam_keypoint) * (size_t)C * cap, oN = oDesc + 32 * (size_t)C * cap, oKl = oN + 256 + 4 * (size_t)C,
                  oLd = oKl + (lines ? sizeof(sslam_keyline) * (size_t)C * lcap : 0), oFn = oLd + (lines ? 32 * (size_t)C * lcap : 0),
                  oNl = oFn + (lines ? 24 * (size_t)C * lcap : 0), outBytes = oNl + 256 + 4 * (size_t)C;
@@ -52,19 +100,27 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
     const bool inDirect = stride == (size_t)w && (n == 1 || image_stride == fpx) && is_pinned(images);
     const bool outDirect = is_pinned(kp_out) && is_pinned(desc_out) && is_pinned(nkp_out) &&
                            (!lines || (is_pinned(kl_out) && is_pinned(ldesc_out) && is_pinned(linefn_out) && is_pinned(nl_out)));
-    Slot slot[2];
-    hipStream_t cp = nullptr, cpOut = nullptr;          // H2D and D2H on separate streams: the next chunk's upload must not queue behind this chunk's download
+    if (!ctx->batchCache) { ctx->batchCache = new BatchCache(); ctx->batchCacheFree = free_batch_cache; }
+    BatchCache& B = *(BatchCache*)ctx->batchCache;
+    Slot* slot = B.slot;
     int rc = SSLAM_OK;
-    auto fail = [&](int code) { for (auto& s : slot) s.release(); if (cp) (void)hipStreamDestroy(cp); if (cpOut) (void)hipStreamDestroy(cpOut); return code; };
-    if (hipStreamCreateWithFlags(&cp, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&cpOut, hipStreamNonBlocking) != hipSuccess) { set_error("sslam_frontend_batch: hipStreamCreate failed"); return fail(SSLAM_ERR_HIP); }
-    for (auto& s : slot) {
-        if ((rc = s.dIn.ensure(fpx * C)) || (rc = s.dKp.ensure(sizeof(sslam_keypoint) * (size_t)C * cap)) || (rc = s.dDesc.ensure(32 * (size_t)C * cap)) ||
-            (rc = s.dN.ensure(4 * (size_t)C)) || (rc = s.dStatus.ensure(32)) || (rc = s.hStatus.ensure(32)) || (!inDirect && (rc = s.hIn.ensure(fpx * C))) || (!outDirect && (rc = s.hOut.ensure(outBytes)))) return fail(rc);
-        if (lines && ((rc = s.dKl.ensure(sizeof(sslam_keyline) * (size_t)C * lcap)) || (rc = s.dLd.ensure(32 * (size_t)C * lcap)) ||
-                      (rc = s.dFn.ensure(24 * (size_t)C * lcap)) || (rc = s.dNl.ensure(4 * (size_t)C)))) return fail(rc);
-        if (hipEventCreateWithFlags(&s.evIn, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.evDone, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.evOut, hipEventDisableTiming) != hipSuccess) { set_error("sslam_frontend_batch: hipEventCreate failed"); return fail(SSLAM_ERR_HIP); }
+    if ((!B.cp && hipStreamCreateWithFlags(&B.cp, hipStreamNonBlocking) != hipSuccess) || (!B.cpOut && hipStreamCreateWithFlags(&B.cpOut, hipStreamNonBlocking) != hipSuccess) ||
+        (!B.stLines && hipStreamCreateWithFlags(&B.stLines, hipStreamNonBlocking) != hipSuccess) || (!B.evCore && hipEventCreateWithFlags(&B.evCore, hipEventDisableTiming) != hipSuccess)) {
+        set_error("sslam_frontend_batch: stream / event creation failed"); return SSLAM_ERR_HIP;
     }
+    hipStream_t cp = B.cp, cpOut = B.cpOut, stP = ctx->stream, stL = B.stLines;      // H2D and D2H on separate streams: the next chunk's upload must not queue behind this chunk's download
+    for (int i = 0; i < 2; ++i) {
+        Slot& s = slot[i];
+        s.count = 0;
+        if ((rc = s.dIn.ensure(fpx * C)) || (rc = s.dKp.ensure(sizeof(sslam_keypoint) * (size_t)C * cap)) || (rc = s.dDesc.ensure(32 * (size_t)C * cap)) ||
+            (rc = s.dN.ensure(4 * (size_t)C)) || (rc = s.dStatus.ensure(32)) || (rc = s.hStatus.ensure(32)) || (!inDirect && (rc = s.hIn.ensure(fpx * C))) || (!outDirect && (rc = s.hOut.ensure(outBytes)))) return rc;
+        if (lines && ((rc = s.dKl.ensure(sizeof(sslam_keyline) * (size_t)C * lcap)) || (rc = s.dLd.ensure(32 * (size_t)C * lcap)) ||
+                      (rc = s.dFn.ensure(24 * (size_t)C * lcap)) || (rc = s.dNl.ensure(4 * (size_t)C)))) return rc;
+        for (hipEvent_t* e : {&s.evIn, &s.evPoint, &s.evLines, &s.evOut})
+            if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { set_error("sslam_frontend_batch: hipEventCreate failed"); return SSLAM_ERR_HIP; }
+        if (n <= C) break;                 // one chunk: the second slot is never used
+    }
+    const int T = copy_threads();
     int firstStatus = SSLAM_OK;                        // a truncated / unsupported frame does not stop the batch; it is reported at the end
     // results of a finished chunk: pinned staging -> the caller's arrays
     auto drain = [&](Slot& s) -> int {
@@ -79,20 +135,24 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
         if (status != SSLAM_OK && firstStatus == SSLAM_OK) firstStatus = status;
         if (outDirect) { s.count = 0; return SSLAM_OK; }
         const uint8_t* H = s.hOut.as<uint8_t>();
-        const size_t f0 = (size_t)s.first, c = (size_t)s.count;
-        std::memcpy(kp_out + f0 * cap, H + oKp, sizeof(sslam_keypoint) * c * cap);
-        std::memcpy(desc_out + 32 * f0 * cap, H + oDesc, 32 * c * cap);
-        std::memcpy(nkp_out + f0, H + oN, 4 * c);
-        if (lines) {
-            std::memcpy(kl_out + f0 * lcap, H + oKl, sizeof(sslam_keyline) * c * lcap);
-            std::memcpy(ldesc_out + 32 * f0 * lcap, H + oLd, 32 * c * lcap);
-            std::memcpy(linefn_out + 3 * f0 * lcap, H + oFn, 24 * c * lcap);
-            std::memcpy(nl_out + f0, H + oNl, 4 * c);
-        }
+        const size_t f0 = (size_t)s.first;
+        parallel_for(s.count, T, [&](int a, int b) {      // frames [a, b) of the chunk
+            const size_t c = (size_t)(b - a), g = f0 + a;
+            std::memcpy(kp_out + g * cap, H + oKp + sizeof(sslam_keypoint) * (size_t)a * cap, sizeof(sslam_keypoint) * c * cap);
+            std::memcpy(desc_out + 32 * g * cap, H + oDesc + 32 * (size_t)a * cap, 32 * c * cap);
+            std::memcpy(nkp_out + g, H + oN + 4 * (size_t)a, 4 * c);
+            if (lines) {
+                std::memcpy(kl_out + g * lcap, H + oKl + sizeof(sslam_keyline) * (size_t)a * lcap, sizeof(sslam_keyline) * c * lcap);
+                std::memcpy(ldesc_out + 32 * g * lcap, H + oLd + 32 * (size_t)a * lcap, 32 * c * lcap);
+                std::memcpy(linefn_out + 3 * g * lcap, H + oFn + 24 * (size_t)a * lcap, 24 * c * lcap);
+                std::memcpy(nl_out + g, H + oNl + 4 * (size_t)a, 4 * c);
+            }
+        });
         s.count = 0;
         return SSLAM_OK;
     };
-    hipStream_t st = ctx->stream;
+    const bool twoStreams = lines != nullptr && getenv("SSLAM_BATCH_ONE_STREAM") == nullptr;
+    if (lines) (void)sslam_lines_set_core_event(lines, twoStreams ? (void*)B.evCore : nullptr);
     int k = 0;
     for (int f0 = 0; f0 < n && rc == SSLAM_OK; f0 += C, ++k) {
         Slot& s = slot[k & 1];
@@ -101,21 +161,28 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
         const uint8_t* hin = images + (size_t)f0 * fpx;
         if (!inDirect) {
             uint8_t* stage = s.hIn.as<uint8_t>();
-            for (int i = 0; i < c; ++i) {                                   // tight rows in the staging buffer
-                const uint8_t* src = images + (size_t)(f0 + i) * image_stride;
-                if (stride == (size_t)w) std::memcpy(stage + i * fpx, src, fpx);
-                else for (int y = 0; y < h; ++y) std::memcpy(stage + i * fpx + (size_t)y * w, src + (size_t)y * stride, w);
-            }
+            parallel_for(c, T, [&](int a, int b) {                          // tight rows in the staging buffer
+                for (int i = a; i < b; ++i) {
+                    const uint8_t* src = images + (size_t)(f0 + i) * image_stride;
+                    if (stride == (size_t)w) std::memcpy(stage + i * fpx, src, fpx);
+                    else for (int y = 0; y < h; ++y) std::memcpy(stage + i * fpx + (size_t)y * w, src + (size_t)y * stride, w);
+                }
+            });
             hin = stage;
         }
+        hipStream_t stLn = twoStreams ? stL : stP;
         if (hipMemcpyAsync(s.dIn.p, hin, fpx * c, hipMemcpyHostToDevice, cp) != hipSuccess || hipEventRecord(s.evIn, cp) != hipSuccess ||
-            hipStreamWaitEvent(st, s.evIn, 0) != hipSuccess) { set_error("sslam_frontend_batch: H2D failed"); rc = SSLAM_ERR_HIP; break; }
-        if ((rc = sslam_orb_extract_batch_dev(orb, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, s.dKp.as<sslam_keypoint>(), s.dDesc.as<uint8_t>(), s.dN.as<int32_t>(), cap, st))) break;
+            hipStreamWaitEvent(stP, s.evIn, 0) != hipSuccess || (twoStreams && hipStreamWaitEvent(stL, s.evIn, 0) != hipSuccess)) { set_error("sslam_frontend_batch: H2D failed"); rc = SSLAM_ERR_HIP; break; }
+        // line branch first: its call records the core event; the point branch then waits for that event and runs under the latency-bound core
         if (lines && (rc = sslam_lines_extract_batch_dev(lines, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, s.dKl.as<sslam_keyline>(), s.dLd.as<uint8_t>(), s.dFn.as<double>(),
-                                                         s.dNl.as<int32_t>(), lcap, st))) break;
-        if ((rc = sslam_orb_batch_status_dev(orb, cap, s.dStatus.as<int32_t>(), st))) break;
-        if (lines && (rc = sslam_lines_batch_status_dev(lines, lcap, s.dStatus.as<int32_t>() + 4, st))) break;
-        if (hipEventRecord(s.evDone, st) != hipSuccess || hipStreamWaitEvent(cpOut, s.evDone, 0) != hipSuccess) { set_error("sslam_frontend_batch: event failed"); rc = SSLAM_ERR_HIP; break; }
+                                                         s.dNl.as<int32_t>(), lcap, stLn))) break;
+        if (lines && (rc = sslam_lines_batch_status_dev(lines, lcap, s.dStatus.as<int32_t>() + 4, stLn))) break;
+        if (twoStreams && (hipEventRecord(s.evLines, stL) != hipSuccess || hipStreamWaitEvent(stP, B.evCore, 0) != hipSuccess)) { set_error("sslam_frontend_batch: event failed"); rc = SSLAM_ERR_HIP; break; }
+        if ((rc = sslam_orb_extract_batch_dev(orb, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, s.dKp.as<sslam_keypoint>(), s.dDesc.as<uint8_t>(), s.dN.as<int32_t>(), cap, stP))) break;
+        if ((rc = sslam_orb_batch_status_dev(orb, cap, s.dStatus.as<int32_t>(), stP))) break;
+        if (hipEventRecord(s.evPoint, stP) != hipSuccess || hipStreamWaitEvent(cpOut, s.evPoint, 0) != hipSuccess ||
+            (twoStreams && hipStreamWaitEvent(cpOut, s.evLines, 0) != hipSuccess)) { set_error("sslam_frontend_batch: event failed"); rc = SSLAM_ERR_HIP; break; }
+        // the next chunk's upload into the OTHER slot may start at once; this slot's input is overwritten only two chunks later, after drain()
         uint8_t* H = outDirect ? nullptr : s.hOut.as<uint8_t>();
         const size_t g = (size_t)f0;
         void* tKp = outDirect ? (void*)(kp_out + g * cap) : (void*)(H + oKp);
@@ -140,6 +207,18 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
     }
     if (rc == SSLAM_OK) rc = drain(slot[k & 1]);          // older chunk first
     if (rc == SSLAM_OK) rc = drain(slot[(k + 1) & 1]);
-    (void)hipStreamSynchronize(cp); (void)hipStreamSynchronize(cpOut); (void)hipStreamSynchronize(st);
-    return fail(rc != SSLAM_OK ? rc : firstStatus);
+    (void)hipStreamSynchronize(cp); (void)hipStreamSynchronize(cpOut); (void)hipStreamSynchronize(stL); (void)hipStreamSynchronize(stP);
+    if (lines) (void)sslam_lines_set_core_event(lines, nullptr);
+    for (int i = 0; i < 2; ++i) slot[i].count = 0;
+    return rc != SSLAM_OK ? rc : firstStatus;
+}
+
+// Releases the staging buffers, streams and events sslam_frontend_batch keeps per context between calls (they are also released with the context).
+extern "C" int sslam_frontend_batch_release(sslam_ctx* ctx) {
+    if (!ctx) return SSLAM_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    if (ctx->batchCache && ctx->batchCacheFree) ctx->batchCacheFree(ctx->batchCache);
+    ctx->batchCache = nullptr;
+    return SSLAM_OK;
 }

@@ -68,6 +68,8 @@ struct sslam_ctx {
     void* recordOffsetsStream[4] = {nullptr, nullptr, nullptr, nullptr};
     sslam::HostPinned pinned[4];
     int num_cus = 0;
+    void* batchCache = nullptr;                  // sslam_frontend_batch: staging buffers, streams, events kept between calls (batch.hip)
+    void (*batchCacheFree)(void*) = nullptr;
 };
 
 // device-resident copy of one Frame's features: keypoints or keylines, 32-byte descriptors, optional

@@ -54,6 +54,7 @@ extern "C" int sslam_ctx_destroy(sslam_ctx* c) {
     if (!c) return SSLAM_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->batchCache && c->batchCacheFree) { c->batchCacheFree(c->batchCache); c->batchCache = nullptr; }
     for (auto& b : c->scratch) b.release();
     for (auto& b : c->recordOffsets) b.release();
     for (auto& b : c->pinned) b.release();

@@ -468,6 +468,54 @@ extern "C" int sslam_selftest_align_windows(sslam_ctx* ctx, int cases, long long
     return SSLAM_OK;
 }
 
+// Issue-rate probe (profiles/README.md, round 3): every lane runs `iters` rounds of 16 independent VALU instructions of one kind
+// (0: v_add_u32, 1: v_fma_f32, 2: v_add_f64, 3: v_bcnt_u32_b32) with 8 waves per SIMD resident, so that the rate is the pipe's, not a
+// dependency chain's.  *ginst_per_s_out = wave-instructions per second over the whole chip (divide by SIMDs x clock for cycles per instruction).
+namespace {
+template <int KIND>
+__global__ __launch_bounds__(256) void k_probe_valu(int iters, unsigned* __restrict__ sink) {
+    unsigned a[16]; double d[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a[i] = threadIdx.x + i; d[i] = (double)(threadIdx.x + i); }
+    const unsigned b = blockIdx.x | 1u; const float fb = 1.0000001f; const double db = 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (KIND == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            else if (KIND == 1) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(fb));
+            else if (KIND == 2) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"(db));
+            else asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+        }
+    }
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += a[i] + (unsigned)d[i];
+    if (acc == 0x12345u) *sink = acc;
+}
+}  // namespace
+extern "C" int sslam_selftest_valu_rate(sslam_ctx* ctx, int kind, double* ginst_per_s_out) {
+    if (!ctx || kind < 0 || kind > 3 || !ginst_per_s_out) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    ScopedDev sinkMem;
+    SSLAM_HIP(hipMalloc(&sinkMem.p, 4));
+    const int blocks = ctx->num_cus * 8, iters = 20000;      // 8 workgroups of 4 waves per CU = 8 waves per SIMD
+    hipEvent_t e0, e1;
+    SSLAM_HIP(hipEventCreate(&e0)); SSLAM_HIP(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {          // the first launch warms the clocks up
+        (void)hipEventRecord(e0, ctx->stream);
+        if (kind == 0) hipLaunchKernelGGL(k_probe_valu<0>, dim3(blocks), dim3(256), 0, ctx->stream, iters, (unsigned*)sinkMem.p);
+        else if (kind == 1) hipLaunchKernelGGL(k_probe_valu<1>, dim3(blocks), dim3(256), 0, ctx->stream, iters, (unsigned*)sinkMem.p);
+        else if (kind == 2) hipLaunchKernelGGL(k_probe_valu<2>, dim3(blocks), dim3(256), 0, ctx->stream, iters, (unsigned*)sinkMem.p);
+        else hipLaunchKernelGGL(k_probe_valu<3>, dim3(blocks), dim3(256), 0, ctx->stream, iters, (unsigned*)sinkMem.p);
+        (void)hipEventRecord(e1, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); set_error("sslam_selftest_valu_rate: kernel failed"); return SSLAM_ERR_HIP; }
+    }
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ginst_per_s_out = (double)blocks * 4.0 * iters * 16.0 / (ms * 1e-3) / 1e9;
+    return SSLAM_OK;
+}
+
 // FETCH_SIZE calibration: reads `bytes` of a freshly allocated buffer once with 16 B/lane coalesced loads (mode 0) or
 // issues bytes/16 scattered 16-B gathers over it (mode 1).  bytes_requested_out = 16 x loads issued.
 extern "C" int sslam_selftest_fetch_probe(sslam_ctx* ctx, size_t bytes, int mode, long long* bytes_requested_out) {

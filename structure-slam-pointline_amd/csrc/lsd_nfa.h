@@ -322,22 +322,30 @@ __device__ __forceinline__ unsigned long long vote(bool p) { return __builtin_am
 // batch of (rectangle, candidate) items whose results are parked in LDS; the wave then counts the items one after
 // the other with all lanes on the pixels.  Counters are wave-uniform (ballot + popcount), so nothing is reduced at the end.
 //
-// Round 3: the alignment test is integer.  theta and the tolerance are fixed per item, and isAligned is monotone in the stored fp32
-// angle, so the aligned set is at most two intervals of angle bit patterns (lsd_align_win.h: end points found with the fp64 expression
-// itself in the lane-parallel setup).  Per pixel: |T| (the used bit is the sign, NOTDEF becomes 1024 > every interval) and two
-// compares per interval -- "in [lo, hi]" is counted as #(b >= lo) - #(b > hi), which also makes lanes without a pixel (sentinel above
-// every hi) cancel without a `have` mask.  The pixels a candidate covers are no longer counted by votes either: that total is the
-// sum of its row widths, accumulated by the first lane of every row.
+// Round 3: the pixels a candidate covers are no longer counted by votes -- that total is the sum of its row widths, accumulated by the
+// first lane of every row -- and the angle plane is T (|T|: the used bit is the sign; NOTDEF becomes 1024).
+// The alignment test has an INTEGER form as well (-DSSLAM_NFA_INT): theta and the tolerance are fixed per item and isAligned is monotone
+// in the stored fp32 angle, so the aligned set is at most two intervals of angle bit patterns (lsd_align_win.h: end points found with the
+// fp64 expression itself in the lane-parallel setup; "in [lo, hi]" = two integer compares, a second pass for the rare second window).
+// It is exact (CPU test over every table angle, sslam_selftest_align_windows, the whole GPU suite and the fuzz sweeps ran with it) and it
+// removes the eight fp64 instructions per pixel slot -- and the kernel does not get faster: 21.2 ms per 12 288 frames against 20.3 ms with
+// the fp64 predicate on the same planes (19.9 ms in round 2).  The counter is bound by its row-range bookkeeping and its dependent
+// loads, not by the predicate; the fp64 form stays the default.  (What DID cost 33 %: masking the used bit inside the conditional load,
+// which made the compiler wait for every load before issuing the next -- see t_raw.)
 constexpr int EVAL_CH = 1024;          // rectangles per item-list chunk (k_nfa_count, k_nfa_eval)
 constexpr int EVAL_REFILL = 16;
+#ifdef SSLAM_NFA_INT
 constexpr int CNT_NEST = 32;           // items per batch in the nested stages (their windows need 6 x 2 intervals each)
+#else
+constexpr int CNT_NEST = 64;
+#endif
 constexpr unsigned PIX_NONE = 0x7FFFFFFFu;      // what a lane without a pixel holds: above every interval
 struct CntItem { NfaGeom g; int c, j, lg, nWin; int lo[2], hi[2];      // lg: log2 of the lanes sharing a row; [lo, hi]: aligned angle bit patterns
-#ifdef SSLAM_NFA_F64               // A/B knob: the per-pixel fp64 predicate of rounds 1-2 on the new planes
+#ifndef SSLAM_NFA_INT               // default: the per-pixel fp64 predicate (-DSSLAM_NFA_INT: the integer windows of lsd_align_win.h -- exact, measured 4 % slower)
                  double theta, prec, p;
 #endif
 };
-#ifdef SSLAM_NFA_F64
+#ifndef SSLAM_NFA_INT
 __device__ __forceinline__ double align_dist_min(float aDeg, double theta) {
     const double n_theta = fabs(theta - (double)aDeg * DEG2RAD);
     return fmin(n_theta, fabs(n_theta - M_2PI_));
@@ -347,8 +355,14 @@ __device__ __forceinline__ double align_dist_min(float aDeg, double theta) {
 // Pixel walk shared by the two counters below.  A row is shared by 2^lg lanes (lg picked per rectangle from its widest
 // row: tall thin rectangles put 32 rows in flight, flat ones spread one row over the whole wave); each lane owns a
 // contiguous run of the row and the wave steps through the runs twelve pixels at a time.
-// |T| of pixel x of the row that starts at element yb: the angle whatever the used bit says, 1024 for NOTDEF
-__device__ __forceinline__ unsigned t_abs(const unsigned* __restrict__ Tb, int yb, int x) { return Tb[yb + x] & 0x7FFFFFFFu; }
+// T of pixel x of the row that starts at element yb, RAW: the used bit is masked off where the value is consumed (T_ABS), not here --
+// inside the conditional load the mask needs the loaded value, so the compiler waits for every load before it issues the next one
+// (measured: the counter 33 % slower, twelve dependent round trips per run instead of twelve loads in flight)
+__device__ __forceinline__ unsigned t_raw(const unsigned* __restrict__ Tb, int yb, int x) { return Tb[yb + x]; }
+// the angle whatever the used bit says; 1024 for NOTDEF, PIX_NONE stays above every hi.  The empty asm pins the raw value in a register at
+// the point of use: without it the compiler sinks the mask back into the conditional load
+__device__ __forceinline__ unsigned t_abs_u(unsigned v) { asm volatile("" : "+v"(v)); return v & 0x7FFFFFFFu; }
+#define T_ABS(v) ((int)t_abs_u(v))
 
 // aligned-point counts of one rectangle for six nested tolerances; total = pixels visited.  win: [k] {lo, hi} of ONE window per tolerance
 // (an item whose angles straddle the 0 / 360 seam has a second window: the caller runs a second pass for it -- the windows are disjoint,
@@ -359,9 +373,11 @@ __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const int* 
     const int nrows = g.y1 - g.y0 + 1;
     const int rowsPer = 64 >> lg, r = lane >> lg, sub = lane & ((1 << lg) - 1);
     int total = 0;
+#ifdef SSLAM_NFA_INT
     int lo[K], hi[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { lo[k] = win[k * 4]; hi[k] = win[k * 4 + 1]; }
+#endif
     for (int t0 = 0; t0 < nrows; t0 += rowsPer) {
         const int t = t0 + r;
         int xa = 0, xb = -1; const int y = g.y0 + t;
@@ -375,27 +391,28 @@ __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const int* 
         for (int c0 = 0; vote(c0 < mine) != 0; c0 += 12) {
             unsigned a[12];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
+            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
             if (vote(c0 + 4 < mine)) {
 #pragma unroll
-                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
+                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
             }
             if (vote(c0 + 8 < mine)) {
 #pragma unroll
-                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
+                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
             }
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 if (!vote(c0 + q < mine)) break;
-#ifdef SSLAM_NFA_F64
-                const float af = __uint_as_float(a[q]);
+#ifndef SSLAM_NFA_INT
+                const float af = __uint_as_float(t_abs_u(a[q]));
                 const double dd = align_dist_min(af, theta);
                 const unsigned long long def = vote(af < 1000.f);       // NOTDEF is 1024 here, lanes without a pixel hold a NaN pattern
 #pragma unroll
                 for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(dd <= precs[k]) & def);
 #else
+                const int ab = T_ABS(a[q]);
 #pragma unroll
-                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote((int)a[q] >= lo[k]) & ~vote((int)a[q] > hi[k]));      // lanes without a pixel: above every hi
+                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(ab >= lo[k]) & ~vote(ab > hi[k]));      // lanes without a pixel: above every hi
 #endif
             }
         }
@@ -409,7 +426,7 @@ __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const int* 
 // [lo, hi]: one window of aligned angle patterns (second pass for a second window, as above; totals from the first pass).
 __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int nc, int lg, int lo, int hi, const unsigned* __restrict__ Tb, int tW, int sw, bool small, int lane,
                                             int (&total)[MAXC], int (&alg)[MAXC]) {
-#ifdef SSLAM_NFA_F64
+#ifndef SSLAM_NFA_INT
     const double theta = it5[0].theta, prec = it5[0].prec;
 #endif
     NfaGeom g[MAXC];
@@ -445,23 +462,24 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
         for (int c0 = 0; vote(c0 < mine) != 0; c0 += 12) {
             unsigned a[12];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
+            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
             if (vote(c0 + 4 < mine)) {
 #pragma unroll
-                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
+                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
             }
             if (vote(c0 + 8 < mine)) {
 #pragma unroll
-                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? t_abs(Tb, yb, xs + c0 + q) : PIX_NONE;
+                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
             }
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 if (!vote(c0 + q < mine)) break;
-#ifdef SSLAM_NFA_F64
-                const float af = __uint_as_float(a[q]);
+#ifndef SSLAM_NFA_INT
+                const float af = __uint_as_float(t_abs_u(a[q]));
                 const unsigned long long al = vote(align_dist_min(af, theta) <= prec) & vote(af < 1000.f);
 #else
-                const unsigned long long al = vote((int)a[q] >= lo) & ~vote((int)a[q] > hi);       // lanes without a pixel hold PIX_NONE: above every hi
+                const int ab = T_ABS(a[q]);
+                const unsigned long long al = vote(ab >= lo) & ~vote(ab > hi);       // lanes without a pixel hold PIX_NONE: above every hi
 #endif
                 const int x = xs + c0 + q;
 #pragma unroll
@@ -534,7 +552,9 @@ __global__ __launch_bounds__(256) void k_selftest_align(unsigned long long seed,
 #endif
 __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
     __shared__ CntItem its[64];
+#ifdef SSLAM_NFA_INT
     __shared__ int nestWin[CNT_NEST][6][4];                          // nested stages: {lo0, hi0, lo1, hi1} per precision
+#endif
     __shared__ unsigned short act[EVAL_CH];
     const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
@@ -579,9 +599,10 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
                         const int need = (nfa_max_width(I.g) + (nested ? 0 : 3) + 11) / 12;       // lanes per row so that a run is <= 12 pixels
                         int lg = 1; while ((1 << lg) < need && lg < 6) ++lg;
                         I.lg = lg;
-#ifdef SSLAM_NFA_F64
+#ifndef SSLAM_NFA_INT
                         I.theta = r.theta; I.prec = r.prec; I.p = r.p;
 #endif
+#ifdef SSLAM_NFA_INT
                         // aligned-angle windows (lsd_align_win.h): six tolerances around one theta in the nested stages (stage 4 uses five of
                         // them), one for the first candidate of a rectangle in stages 1-3 (its candidates share theta and the tolerance)
                         const int nK = nested ? 6 : j == 0 ? 1 : 0;
@@ -597,6 +618,9 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
                             nw = max(nw, w.n);
                         }
                         I.nWin = nw;
+#else
+                        I.nWin = 1;
+#endif
                     }
                 }
                 if (__ballot(!winOk) && lane == 0) misc->overflow = 1;      // three non-empty windows: excluded by construction (lsd_align_win.h); never count wrong silently
@@ -618,7 +642,7 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
 #pragma unroll
                     for (int j = 0; j < MAXC; ++j) alg[j] = 0;
                     count_rect5(it5, nc, it5[0].lg, it5[0].lo[0], it5[0].hi[0], Tb, tW, sw, small, lane, total, alg);
-#ifndef SSLAM_NFA_F64
+#ifdef SSLAM_NFA_INT
                     if (it5[0].nWin > 1) count_rect5(it5, nc, it5[0].lg, it5[0].lo[1], it5[0].hi[1], Tb, tW, sw, small, lane, tot2, alg);      // the 0 / 360 seam: a second, disjoint window
 #endif
                     const int c = it5[0].c;
@@ -636,8 +660,12 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
                 const int c = its[it].c;
                 int total, tot2, alg[6] = {0, 0, 0, 0, 0, 0};
                 const int lg = its[it].lg, nWin = its[it].nWin;
+#ifdef SSLAM_NFA_INT
                 const int* win = &nestWin[it][0][0];
-#ifdef SSLAM_NFA_F64
+#else
+                const int* win = nullptr;
+#endif
+#ifndef SSLAM_NFA_INT
                 double precs[6];
                 for (int k = 0; k < 6; ++k) precs[k] = stage == 0 ? (k == 0 ? its[it].prec : ldexp(its[it].p, -k) * kPI) : ldexp(its[it].p, -(k + 1)) * kPI;
                 count_item(g, lg, win, Tb, tW, sw, small, lane, total, alg, its[it].theta, precs); (void)nWin; (void)tot2;

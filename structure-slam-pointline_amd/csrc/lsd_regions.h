@@ -163,7 +163,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
             const int cx = min(max(xx, 0), sw - 1), cy = min(max(yy, 0), sh - 1);
             nidx = pl.ti(cx, cy);
             tv = pl.T[nidx];                             // sign bit set: NOTDEF or already USED
-            cs = pl.Cs[cix(cx, cy, pl.cW)];
+            cs = pl.Cs[nidx];                            // (same row pitch: one index serves both planes)
             candM = __builtin_amdgcn_ballot_w64(t_free(tv)) & __builtin_amdgcn_ballot_w64((unsigned)xx < (unsigned)sw) &
                     __builtin_amdgcn_ballot_w64((unsigned)yy < (unsigned)sh) & (np == 8 ? ~0ull : ((1ull << (np * 8)) - 1));
             if (SPEC) { const int bi = mw_bit(xx, yy); candM &= ~__builtin_amdgcn_ballot_w64((bm[bi >> 5] >> (bi & 31)) & 1u); }      // taken by this helper itself
@@ -175,7 +175,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
                 if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
                     nidx = pl.ti(xx, yy);
                     tv = pl.T[nidx];
-                    cs = pl.Cs[cix(xx, yy, pl.cW)];
+                    cs = pl.Cs[nidx];
                     cand = t_free(tv);
                 }
             }

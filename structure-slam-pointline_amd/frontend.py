@@ -284,6 +284,30 @@ class Frame:
             lib().sslam_frame_destroy(self.h); self.h = C.c_void_p()
 
 
+def frontend_batch_alloc(n, cap, lcap, pinned=False):
+    """result arrays of sslam_frontend_batch for n frames (pinned=True: in pinned memory, so that the library copies straight into them);
+    pageable arrays are touched once so that a timed call does not pay their first page faults"""
+    def alloc(shape, dt):
+        if not pinned:
+            a = np.empty(shape, dt); a.view(np.uint8).reshape(-1)[::4096] = 0
+            return a
+        import torch
+        nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+        return torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True).numpy()[:nbytes].view(dt).reshape(shape)
+    return (alloc((n, cap), KP_DTYPE), alloc((n, cap, 32), np.uint8), alloc((n,), np.int32),
+            alloc((n, lcap), KL_DTYPE), alloc((n, lcap, 32), np.uint8), alloc((n, lcap, 3), np.float64), alloc((n,), np.int32))
+
+
+def frontend_batch_raw(orb, lines, images, out, chunk=0, lcap=None):
+    """sslam_frontend_batch into arrays from frontend_batch_alloc: the bare library call (what the PCIe-inclusive measurements time)"""
+    n, h, w = images.shape
+    kp, desc, nk, kl, ld, fn, nl = out
+    lcap = int(lcap if lcap is not None else kl.shape[1])
+    _chk(lib().sslam_frontend_batch(orb.h, lines.h if lines is not None else None, _p(images), n, w, h, C.c_size_t(w), C.c_size_t(w * h), int(chunk),
+                                    _p(kp), _p(desc), _p(nk), orb.cap, _p(kl), _p(ld), _p(fn), _p(nl), lcap))
+    return out
+
+
 def frontend_batch(orb, lines, images, chunk=0, max_lines=None, pinned=False):
     """sslam_frontend_batch: images = uint8 array [n, h, w] in HOST memory -> per-frame (keypoints, descriptors, keylines, line descriptors,
     line functions) lists; `lines` may be None (ORB only).  pinned=True allocates the result arrays in pinned memory (torch), so that the

@@ -67,6 +67,7 @@ class GroupGather:
         self.recv = torch.zeros(cap_bytes * self.world + 16, dtype=torch.uint8, device=device) if self.rank == 0 else None
         self.k = 0
         self.thread = None; self.sizes = None; self.error = None
+        self.wait_s = 0.0; self.waits = 0
 
     def submit(self):
         """call on the stream the step's kernels were launched on (torch's current stream)"""
@@ -97,7 +98,10 @@ class GroupGather:
 
     def wait(self):
         if self.thread is not None:
+            import time
+            t0 = time.perf_counter()
             self.thread.join(); self.thread = None
+            self.wait_s += time.perf_counter() - t0; self.waits += 1      # how long the pipeline stood still for the exchange (0 = fully hidden)
             if self.error is not None:
                 e, self.error = self.error, None
                 raise e
@@ -120,6 +124,7 @@ class TorchGather:
         self.send = torch.zeros(self.cap_bytes + 16, dtype=torch.uint8, device=device)
         self.total = torch.zeros(2, dtype=torch.int64, device=device)
         self.out = None
+        self.wait_s = 0.0; self.waits = 0
 
     def submit(self):
         p, c = self.pipe, self.pipe.feat["cur"]
