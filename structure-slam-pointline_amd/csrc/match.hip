@@ -100,11 +100,14 @@ extern "C" int sslam_orb_search_for_initialization_batch_dev(sslam_ctx* ctx,
     A.scratch = ctx->scratch[3].as<int>(); A.window = window; A.nnratio = nnratio; A.checkOri = checkOri;
     A.minX = bounds[0]; A.maxX = bounds[1]; A.minY = bounds[2]; A.maxY = bounds[3];
     // a handful of pairs (the single call of Tracking::MonocularInitialization): the LDS-resident kernel, as long as a pair fits the CU's LDS
-    const size_t ldsNeed = 64 + (size_t)cap * 14 * 4 + (size_t)cap * 2 * 4;      // per candidate 14 words, per F1 keypoint 2
-    if (npairs <= 8 && ldsNeed <= 150 * 1024 && !getenv("SSLAM_SFI_GLOBAL")) {
-        if (ldsNeed > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_search_init_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsNeed));
+    const size_t ldsNeed = 64 + (size_t)cap * 15 * 4 + (size_t)cap * 2 * 4;      // per candidate 15 words (14 + the stamp of the speculative form), per F1 keypoint 2
+    const char* sfiForm = getenv("SSLAM_SFI_FORM");      // test / experiment knob: "global", "lds" (one wave), default: sixteen speculative waves
+    if (npairs <= 8 && ldsNeed <= 150 * 1024 && !getenv("SSLAM_SFI_GLOBAL") && !(sfiForm && sfiForm[0] == 'g')) {
+        const bool oneWave = sfiForm && sfiForm[0] == 'l';
+        if (ldsNeed > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute(oneWave ? (const void*)k_search_init_lds : (const void*)k_search_init_spec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsNeed));
         sslam::ProfScope _ps(ctx, "k_search_init", pick(ctx, stream));
-        hipLaunchKernelGGL(k_search_init_lds, dim3(npairs), dim3(64), ldsNeed, pick(ctx, stream), A);
+        if (oneWave) hipLaunchKernelGGL(k_search_init_lds, dim3(npairs), dim3(64), ldsNeed, pick(ctx, stream), A);
+        else hipLaunchKernelGGL(k_search_init_spec, dim3(npairs), dim3(SFI_WAVES * 64), ldsNeed, pick(ctx, stream), A);
     } else
     { sslam::ProfScope _ps(ctx, "k_search_init", pick(ctx, stream)); hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(64), 0, pick(ctx, stream), A); }
     SSLAM_HIP(hipGetLastError());
@@ -208,7 +211,7 @@ static int search_proj_core(sslam_ctx* ctx, int kind, int mode, const void* d_fe
     hipStream_t st = ctx->stream;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t oO = 0, oQ = oO + al((size_t)n), oQD = oQ + al(sizeof(sslam_proj_query) * (size_t)nq), oA = oQD + al(32 * (size_t)nq), oN = oA + al(4 * (size_t)n),
-           oS = oN + 256, total = oS + al(4 * (2 * (size_t)n + 2 * (size_t)nq));
+           oS = oN + 256, oT = oS + al(4 * (2 * (size_t)n + 2 * (size_t)nq)), oC = oT + al(8 * (size_t)PROJ_K * (size_t)nq), total = oC + al(4 * (size_t)nq);
     int rc;
     if ((rc = ctx->scratch[6].ensure(total))) return rc;
     uint8_t* B = ctx->scratch[6].as<uint8_t>();
@@ -226,9 +229,18 @@ static int search_proj_core(sslam_ctx* ctx, int kind, int mode, const void* d_fe
     A.uright = d_uright; A.occIn = occupied ? B + oO : nullptr;
     A.q = (const sslam_proj_query*)(B + oQ); A.qdesc = B + oQD; A.nq = nq; A.nnratio = nnratio; A.thDist = th_dist; A.checkOri = check_orientation;
     A.assigned = (int*)(B + oA); A.nmatches = (int*)(B + oN); A.scratch = (int*)(B + oS);
-    if (n <= PROJ_MAXN) {       // the frame fits in LDS: sixteen speculative queries per round
+    A.stats = getenv("SSLAM_PROJ_STATS") ? (long long*)(B + oN + 64) : nullptr;      // development aid: seven counters behind the match count
+    const char* form = getenv("SSLAM_PROJ_FORM");      // test / experiment knob: "lds" (sixteen speculative waves on one CU), "wave" (one wave), default: two kernels
+    if (nq > 0 && n <= 8192 && !form) {      // one wave per query over the whole chip, then an ordered commit with parallel prefixes (match_ordered.h)
+        ProjTopArgs T; T.A = A; T.top = (unsigned long long*)(B + oT); T.cnt = (int*)(B + oC);
+        { sslam::ProfScope _ps(ctx, "k_proj_topk", st); hipLaunchKernelGGL(k_proj_topk, dim3((nq + 3) / 4), dim3(256), 0, st, T); }
+        const int featsInLds = n <= PROJ_MAXN ? 1 : 0;      // 64 bytes per feature: the re-scans of the commit then never leave the CU
+        const size_t lds = (featsInLds ? 64 : 8) * (size_t)n + 64;
+        if (lds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_proj_commit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { sslam::ProfScope _ps(ctx, "k_proj_commit", st); hipLaunchKernelGGL(k_proj_commit, dim3(1), dim3(64), lds, st, T, featsInLds); }
+    } else if (n <= PROJ_MAXN && !(form && form[0] == 'w')) {       // the frame fits in LDS: sixteen speculative queries per round
         int n2 = 64; while (n2 < n) n2 <<= 1;
-        const size_t lds = (size_t)n * (32 + 6 * 4) + (size_t)n2 * 4 + (GRID_COLS + 2) * 4 + 64;
+        const size_t lds = (size_t)n * (32 + 7 * 4) + (size_t)n2 * 4 + (GRID_COLS + 2) * 4 + 64;
         if (lds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_search_proj_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         sslam::ProfScope _ps(ctx, "k_search_proj_lds", st);
         hipLaunchKernelGGL(k_search_proj_lds, dim3(1), dim3(PROJ_WAVES * 64), lds, st, A);
@@ -238,6 +250,11 @@ static int search_proj_core(sslam_ctx* ctx, int kind, int mode, const void* d_fe
     SSLAM_HIP(hipStreamSynchronize(st));
     memcpy(assigned_out, H + oA, 4 * (size_t)n);
     memcpy(nmatches_out, H + oN, sizeof(int));
+    if (A.stats) {
+        long long hs[4];
+        SSLAM_HIP(hipMemcpy(hs, B + oN + 64, sizeof(hs), hipMemcpyDeviceToHost));
+        fprintf(stderr, "proj stats: commit steps %lld, re-scans %lld (%lld cycles), commit kernel %lld cycles\n", hs[0], hs[1], hs[2], hs[3]);
+    }
     return SSLAM_OK;
 }
 
@@ -394,28 +411,35 @@ static int search_by_bow_core(sslam_ctx* ctx, const sslam_keypoint* kf_kp, const
     int rc;
     if ((rc = ctx->scratch[7].ensure(off))) return rc;
     uint8_t* B = ctx->scratch[7].as<uint8_t>();
+    // every input (and the -1 fill of the two result arrays) goes through ONE pinned staging buffer and one H2D copy: ten small pageable
+    // copies cost more host time than the kernels take (0.11 ms of the call's 0.18)
     const void* src[9] = {kf_kp, kf_desc, kf_valid, f_kp, f_desc, node_kf_ptr, node_f_ptr, kf_idx, f_idx};
     const size_t len[9] = {ks * nkf, 32 * (size_t)nkf, (size_t)nkf, ks * nf, 32 * (size_t)nf, 4 * (size_t)(nnodes + 1), 4 * (size_t)(nnodes + 1), 4 * (size_t)nk, 4 * (size_t)nfi};
-    for (int i = 0; i < 9; ++i) if (len[i]) SSLAM_HIP(hipMemcpyAsync(B + o[i], src[i], len[i], hipMemcpyHostToDevice, st));
-    if (f_valid) SSLAM_HIP(hipMemcpyAsync(B + o[12], f_valid, (size_t)nf, hipMemcpyHostToDevice, st));
+    if ((rc = ctx->pinned[1].ensure(off))) return rc;
+    uint8_t* H = ctx->pinned[1].as<uint8_t>();
+    for (int i = 0; i < 9; ++i) if (len[i]) memcpy(H + o[i], src[i], len[i]);
+    memset(H + o[9], 0xFF, 4 * (size_t)nf); memset(H + o[10], 0, 256); memset(H + o[11], 0xFF, 4 * (size_t)nf);
+    if (f_valid) memcpy(H + o[12], f_valid, (size_t)nf);
+    SSLAM_HIP(hipMemcpyAsync(B, H, off, hipMemcpyHostToDevice, st));
     BowArgs A;
     A.validF = f_valid ? B + o[12] : nullptr; A.strictTh = strict_th;
     A.kpKF = (const sslam_keypoint*)(B + o[0]); A.dKF = B + o[1]; A.validKF = B + o[2]; A.kpF = (const sslam_keypoint*)(B + o[3]); A.dF = B + o[4]; A.nF = nf;
     A.ptrKF = (const int*)(B + o[5]); A.ptrF = (const int*)(B + o[6]); A.nnodes = nnodes; A.idxKF = (const int*)(B + o[7]); A.idxF = (const int*)(B + o[8]);
     A.nnratio = nnratio; A.checkOri = check_orientation; A.assigned = (int*)(B + o[9]); A.nmatches = (int*)(B + o[10]); A.qbin = (int*)(B + o[11]);
-    SSLAM_HIP(hipMemsetAsync(A.assigned, 0xFF, 4 * (size_t)nf, st));
-    SSLAM_HIP(hipMemsetAsync(A.qbin, 0xFF, 4 * (size_t)nf, st));
     bool disjoint = true;                     // DBoW2 puts a feature under exactly one node; if a caller's lists do not, replay in order
     {
         std::vector<uint8_t> seen((size_t)nf, 0);
         for (int i = 0; i < nfi && disjoint; ++i) { if (seen[f_idx[i]]) disjoint = false; seen[f_idx[i]] = 1; }
     }
     { sslam::ProfScope _ps(ctx, "k_search_bow", st); hipLaunchKernelGGL(k_search_bow, dim3(disjoint ? std::min(nnodes, 4096) : 1), dim3(64), 0, st, A); }
+    // (a fused form -- the last workgroup to finish runs this pass, saving the launch -- was measured: the two agent-scope fences per
+    // workgroup cost more than the launch, 0.111 against 0.103 ms per call)
     { sslam::ProfScope _ps(ctx, "k_bow_finish", st); hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, st, A.assigned, A.qbin, nf, check_orientation, A.nmatches); }
     SSLAM_HIP(hipGetLastError());
-    SSLAM_HIP(hipMemcpyAsync(assigned_out, B + o[9], 4 * (size_t)nf, hipMemcpyDeviceToHost, st));
-    SSLAM_HIP(hipMemcpyAsync(nmatches_out, B + o[10], sizeof(int), hipMemcpyDeviceToHost, st));
+    SSLAM_HIP(hipMemcpyAsync(H + o[9], B + o[9], o[10] + 4 - o[9], hipMemcpyDeviceToHost, st));      // assigned + the count, back through the same staging
     SSLAM_HIP(hipStreamSynchronize(st));
+    memcpy(assigned_out, H + o[9], 4 * (size_t)nf);
+    memcpy(nmatches_out, H + o[10], sizeof(int));
     return SSLAM_OK;
 }
 

@@ -262,6 +262,205 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SfiArgs A) {
     if (lane == 0) A.nmatches[p] = nmatches;
 }
 
+// Speculative form of the single call (round 3): sixteen waves evaluate sixteen consecutive level-0 keypoints of F1 against the state at the
+// start of a round; wave 0 then commits them.  A match only ever LOWERS the matched distance of its candidate slot (a candidate is eligible
+// while matchedDist > dist), so an earlier keypoint of the round can change a later one's result only through that slot being the later
+// one's best or second-best candidate -- the rule of k_search_proj_lds.  Every accepting wave stamps its slot with (round, wave); if no
+// wave finds an earlier stamp of the round on its best / second, all sixteen commit at once (un-matching the slots' previous owners, which
+// are then keypoints of earlier rounds: distinct slots, distinct owners); otherwise the round is replayed serially with re-evaluation.
+// Same LDS layout as k_search_init_lds plus the stamps; same results (tests/test_match_gpu.py compares all three forms with the oracle).
+constexpr int SFI_WAVES = 16;
+struct SfiLds { uint4* cdesc; float* cxs; float* cys; int* ckey; int* cj; int* md; int* owner; int* stamp; };
+__device__ __forceinline__ void sfi_scan(const SfiLds& S, int nc, float cx, float cy, float r, const uint4& q0, const uint4& q1, int lane,
+                                         unsigned long long& best, unsigned long long& second) {
+    unsigned long long b = ~0ull, s2 = ~0ull;
+    for (int c = lane; c < nc; c += 64) {
+        const float dx = __fsub_rn(S.cxs[c], cx), dy = __fsub_rn(S.cys[c], cy);
+        if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+        const int dist = hamming256(q0, q1, S.cdesc[2 * c], S.cdesc[2 * c + 1]);
+        if (S.md[c] <= dist) continue;
+        const unsigned long long k = ((unsigned long long)dist << 32) | (unsigned)S.ckey[c];
+        if (k < b) { s2 = b; b = k; } else if (k < s2) s2 = k;
+    }
+    best = wave_min_u64(b);
+    second = wave_min_u64(b == best ? s2 : b);
+}
+__global__ __launch_bounds__(SFI_WAVES * 64) void k_search_init_spec(SfiArgs A) {
+    extern __shared__ __align__(16) unsigned sfi[];
+    constexpr int NT = SFI_WAVES * 64;
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n1 = A.n1 ? A.n1[p] : A.n1s, n2 = A.n2 ? A.n2[p] : A.n2s;
+    const sslam_keypoint* kp1 = A.kp1 + (size_t)p * A.cap;
+    const sslam_keypoint* kp2 = A.kp2 + (size_t)p * A.cap;
+    const uint8_t* d1 = A.d1 + (size_t)p * A.cap * 32;
+    const uint8_t* d2 = A.d2 + (size_t)p * A.cap * 32;
+    float* pm = A.prevMatched + (size_t)p * A.cap * 2;
+    int* m12 = A.m12 + (size_t)p * A.cap;
+    SfiLds S;
+    S.cdesc = (uint4*)sfi;
+    S.cxs = (float*)(S.cdesc + 2 * (size_t)n2); S.cys = S.cxs + n2;
+    S.ckey = (int*)(S.cys + n2); S.cj = S.ckey + n2; S.md = S.cj + n2; S.owner = S.md + n2; S.stamp = S.owner + n2;
+    int* list1 = S.stamp + n2;                               // level-0 keypoints of F1, ascending  [n1]
+    int* binOf = list1 + n1;                                 // rotation bin per F1 keypoint, -1   [n1]
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int sh_nl, sh_nc, sh_nm;
+    __shared__ int rAcc[SFI_WAVES], rBest[SFI_WAVES], rSecond[SFI_WAVES], rDist[SFI_WAVES], rBin[SFI_WAVES];
+    const float invW = __fdiv_rn((float)GRID_COLS, __fsub_rn(A.maxX, A.minX));
+    const float invH = __fdiv_rn((float)GRID_ROWS, __fsub_rn(A.maxY, A.minY));
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) sh_nm = 0;
+    for (int i = tid; i < n1; i += NT) { m12[i] = -1; binOf[i] = -1; }
+    if (wave == 0) {                                         // the two compact lists, in ascending index (one wave: ordered compaction by ballots)
+        int nl = 0;
+        for (int i0 = 0; i0 < n1; i0 += 64) {
+            const int i = i0 + lane;
+            const bool l0 = i < n1 && kp1[i].octave == 0;
+            const unsigned long long m = __ballot(l0);
+            if (l0) list1[nl + mbcnt(m)] = i;
+            nl += __popcll(m);
+        }
+        int nc = 0;
+        for (int j0 = 0; j0 < n2; j0 += 64) {
+            const int j = j0 + lane;
+            bool ok = false; int cell = 0; float x = 0, y = 0;
+            if (j < n2) {
+                const sslam_keypoint k = kp2[j];
+                const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, A.minX), invW));
+                const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, A.minY), invH));
+                ok = k.octave == 0 && px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS;
+                cell = px * GRID_ROWS + py; x = k.x; y = k.y;
+            }
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int o = nc + mbcnt(m);
+                S.cxs[o] = x; S.cys[o] = y; S.ckey[o] = (cell << 19) | o; S.cj[o] = j; S.md[o] = 0x7FFFFFFF; S.owner[o] = -1; S.stamp[o] = 0;
+            }
+            nc += __popcll(m);
+        }
+        if (lane == 0) { sh_nl = nl; sh_nc = nc; }
+    }
+    __syncthreads();
+    const int nl = sh_nl, nc = sh_nc;
+    for (int c = tid; c < nc; c += NT) {                    // descriptors of the candidates, by all waves
+        const uint4* tp = (const uint4*)(d2 + (size_t)S.cj[c] * 32);
+        S.cdesc[2 * c] = tp[0]; S.cdesc[2 * c + 1] = tp[1];
+    }
+    __syncthreads();
+    const float r = (float)A.window;
+    auto decide = [&](int i1, unsigned long long best, unsigned long long second, int& acc, int& slot, int& slot2, int& dist, int& bin) {
+        acc = 0; slot = -1; slot2 = -2; dist = 0; bin = -1;
+        if (best == ~0ull) return;                           // vIndices2 empty, or every candidate suppressed
+        slot = (int)(best & 0x7FFFF);
+        if (second != ~0ull) slot2 = (int)(second & 0x7FFFF);
+        const int bestDist = (int)(best >> 32);
+        const unsigned sec = second == ~0ull ? 0x7FFFFFFFu : (unsigned)(second >> 32);
+        if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn((float)(int)sec, A.nnratio)) {
+            acc = 1; dist = bestDist;
+            if (A.checkOri) {
+                float rot = __fsub_rn(kp1[i1].angle, kp2[S.cj[slot]].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+            }
+        }
+    };
+    for (int base = 0; base < nl; base += SFI_WAVES) {
+        const int t = base + wave;
+        int acc = 0, slot = -1, slot2 = -2, dist = 0, bin = -1;
+        if (t < nl) {
+            const int i1 = list1[t];
+            const uint4 q0 = ((const uint4*)(d1 + (size_t)i1 * 32))[0], q1 = ((const uint4*)(d1 + (size_t)i1 * 32))[1];
+            unsigned long long best, second;
+            sfi_scan(S, nc, pm[i1 * 2], pm[i1 * 2 + 1], r, q0, q1, lane, best, second);
+            decide(i1, best, second, acc, slot, slot2, dist, bin);
+        }
+        if (lane == 0) { rAcc[wave] = acc; rBest[wave] = slot; rSecond[wave] = slot2; rDist[wave] = dist; rBin[wave] = bin; }
+        __syncthreads();
+        if (wave == 0) {
+            const int cnt = min(SFI_WAVES, nl - base);
+            const int myAcc = lane < cnt ? rAcc[lane] : 0, myB = lane < cnt ? rBest[lane] : -1, myS = lane < cnt ? rSecond[lane] : -2;
+            const int myDist = lane < cnt ? rDist[lane] : 0, myBin = lane < cnt ? rBin[lane] : -1;
+            const int roundTag = base / SFI_WAVES + 1;
+            if (lane < cnt && myAcc) atomicMax(&S.stamp[myB], (roundTag << 5) | (31 - lane));
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            bool clash = false;
+            if (lane < cnt) {
+                if (myB >= 0) { const int st = S.stamp[myB]; clash |= (st >> 5) == roundTag && 31 - (st & 31) < lane; }
+                if (myS >= 0) { const int st = S.stamp[myS]; clash |= (st >> 5) == roundTag && 31 - (st & 31) < lane; }
+            }
+            int delta = 0;
+            if (!__ballot(clash)) {
+                bool unmatch = false;
+                if (lane < cnt && myAcc) {
+                    const int i1 = list1[base + lane];
+                    const int prev = S.owner[myB];
+                    if (prev >= 0) { m12[prev] = -1; unmatch = true; }
+                    m12[i1] = S.cj[myB]; S.owner[myB] = i1; S.md[myB] = myDist;
+                    if (A.checkOri) { binOf[i1] = myBin; atomicAdd(&hist[myBin], 1); }
+                }
+                delta = __popcll(__ballot(lane < cnt && myAcc)) - __popcll(__ballot(unmatch));
+            } else {
+                // serial replay of the round: a keypoint is re-evaluated when an earlier one of the round took its best or second-best slot
+                int myTaken = -3, nTaken = 0;
+                for (int w = 0; w < cnt; ++w) {
+                    int a = __builtin_amdgcn_readlane(myAcc, w), b = __builtin_amdgcn_readlane(myB, w), ds = __builtin_amdgcn_readlane(myDist, w), bn = __builtin_amdgcn_readlane(myBin, w);
+                    const int s2 = __builtin_amdgcn_readlane(myS, w);
+                    const int i1 = list1[base + w];
+                    if (nTaken > 0 && __ballot(lane < nTaken && (myTaken == b || myTaken == s2))) {
+                        const uint4 q0 = ((const uint4*)(d1 + (size_t)i1 * 32))[0], q1 = ((const uint4*)(d1 + (size_t)i1 * 32))[1];
+                        unsigned long long best, second; int sl2;
+                        sfi_scan(S, nc, pm[i1 * 2], pm[i1 * 2 + 1], r, q0, q1, lane, best, second);
+                        decide(i1, best, second, a, b, sl2, ds, bn);
+                    }
+                    if (!a) continue;
+                    const int prev = S.owner[b];
+                    if (prev >= 0) { if (lane == 0) m12[prev] = -1; --delta; }
+                    if (lane == 0) { m12[i1] = S.cj[b]; S.owner[b] = i1; S.md[b] = ds; if (A.checkOri) { binOf[i1] = bn; hist[bn]++; } }
+                    ++delta;
+                    if (lane == nTaken) myTaken = b;
+                    ++nTaken;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
+            }
+            if (lane == 0) sh_nm += delta;
+        }
+        __syncthreads();
+    }
+    int nmatches = sh_nm;
+    __syncthreads();
+    if (A.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;      // ComputeThreeMaxima
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            const int sh = hist[i];
+            if (sh > max1) { max3 = max2; max2 = max1; max1 = sh; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sh > max2) { max3 = max2; max2 = sh; ind3 = ind2; ind2 = i; }
+            else if (sh > max3) { max3 = sh; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+        if (wave == 0) {
+            int removed = 0;
+            for (int i0 = 0; i0 < n1; i0 += 64) {
+                const int i = i0 + lane;
+                bool rm = false;
+                if (i < n1) {
+                    const int bn = binOf[i];
+                    rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3 && m12[i] >= 0;
+                    if (rm) m12[i] = -1;
+                }
+                removed += __popcll(__ballot(rm));
+            }
+            nmatches -= removed;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n1; i += NT) {
+        const int m = m12[i];
+        if (m >= 0) { pm[i * 2] = kp2[m].x; pm[i * 2 + 1] = kp2[m].y; }
+    }
+    if (tid == 0) A.nmatches[p] = nmatches;
+}
+
 // ---------------------------------------------------------------- projection-window matchers
 // ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)  src/ORBmatcher.cc:45-129   (kind 0, mode 0)
 // ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)  src/ORBmatcher.cc:1331-1473 (kind 0, mode 1)
@@ -278,6 +477,7 @@ struct ProjArgs {
     float nnratio; int thDist, checkOri;
     int* assigned; int* nmatches;
     int* scratch;          // occ[n], key[n], qbin[nq], qidx[nq]
+    long long* stats;      // SSLAM_PROJ_STATS (development aid, two-kernel form): commit steps, re-scans, cycles in re-scans, total cycles
 };
 
 __global__ __launch_bounds__(64) void k_search_proj(ProjArgs A) {
@@ -397,6 +597,298 @@ __global__ __launch_bounds__(64) void k_search_proj(ProjArgs A) {
 }
 
 
+// ------------------------------------------------------------------ projection matchers, two-kernel form (round 3: the single call)
+// The LDS-resident kernel below keeps one CU busy: sixteen waves share four SIMDs, so a round of sixteen candidate scans is bound by that
+// CU's issue rate (5.5 k cycles per round measured, 63 rounds per 1000 queries), and its commit falls back to a serial replay whenever two
+// queries of a round meet on a feature (62 % of the rounds on neighbouring keypoints): 0.43-0.51 ms per call against 0.26-0.44 ms on one
+// CPU core.  The candidate SET of a query is static -- window, level range, stereo gate and the initial occupancy do not depend on earlier
+// queries; only "taken by an earlier accepted query" does.  So:
+//   k_proj_topk    one wave per query over the whole chip: scan every feature once, keep the PROJ_K smallest keys (distance, then the
+//                  reference's candidate order -- GetFeaturesInArea cell order / GetLinesInArea index order --, level in the low bits) and
+//                  the number of eligible candidates;
+//   k_proj_commit  one wave walks the queries in order, 64 at a time: every pending query picks the first (and second) entry of its list
+//                  that is still free, accepting queries stamp their feature, and the longest prefix of queries on whose picks no EARLIER
+//                  pending query has a stamp commits at once (their decisions cannot influence each other); the first query with a stamp
+//                  in front of it simply picks again in the next step, now as the first pending one.  A query whose list runs out of
+//                  free entries although it had more candidates than PROJ_K is re-scanned against the live occupancy (rare).
+// The result equals the sequential loop: a query's pick is "smallest key among its candidates that are free when its turn comes", and a
+// prefix commits only when that set of free candidates is already final for every query in it.
+// Measured (1000 queries against 1000 keypoints): 0.14-0.22 ms per call, CPU oracle 0.26-0.46 ms (profiles/r03_matchers.txt).
+#ifndef SSLAM_PROJ_K
+#define SSLAM_PROJ_K 8
+#endif
+constexpr int PROJ_K = SSLAM_PROJ_K;      // list length: with 4, 3 % of the queries of a dense frame ran out of free entries and paid a re-scan (11-13 k cycles each, two thirds of the commit)
+struct ProjTopArgs { ProjArgs A; unsigned long long* top; int* cnt; };
+
+// the candidate test of one (query, feature) pair, features in global memory; returns false when the feature is no candidate.
+// key = dist << 35 | order << 4 | level, order = (cell << 19 | index) for keypoints, index for lines
+template <class OccFn>
+__device__ __forceinline__ bool proj_candidate(const ProjArgs& A, const sslam_proj_query& Q, const uint4& q0, const uint4& q1, int i, float invW, float invH, OccFn occupied,
+                                               unsigned long long& key) {
+    const sslam_keypoint* kps = (const sslam_keypoint*)A.feats;
+    const sslam_keyline* kls = (const sslam_keyline*)A.feats;
+    int oct; unsigned order = (unsigned)i;
+    if (A.kind == 0) {
+        const sslam_keypoint kp = kps[i];
+        oct = kp.octave;
+        if (Q.min_level > 0 || Q.max_level >= 0) {
+            if (oct < Q.min_level) return false;
+            if (Q.max_level >= 0 && oct > Q.max_level) return false;
+        }
+        const float dx = __fsub_rn(kp.x, Q.u), dy = __fsub_rn(kp.y, Q.v);
+        if (!(fabsf(dx) < Q.radius && fabsf(dy) < Q.radius)) return false;
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, A.minX), invW));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, A.minY), invH));
+        if (!(px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS)) return false;      // not in the grid: GetFeaturesInArea never returns it
+        order = ((unsigned)(px * GRID_ROWS + py) << 19) | (unsigned)i;
+    } else {
+        const sslam_keyline kl = kls[i];
+        oct = kl.octave;
+        const double mxp = 0.5 * (double)__fadd_rn(Q.u, Q.u2) - (double)kl.pt_x, myp = 0.5 * (double)__fadd_rn(Q.v, Q.v2) - (double)kl.pt_y;
+        const float distance = (float)(mxp * mxp + myp * myp);
+        if (distance > __fmul_rn(Q.radius, Q.radius)) return false;
+        const float slope = __fsub_rn(__fdiv_rn(__fsub_rn(Q.v, Q.v2), __fsub_rn(Q.u, Q.u2)), kl.angle);
+        if ((double)slope > (double)Q.radius * 0.01) return false;
+        if (Q.min_level > 0 || Q.max_level > 0) {
+            if (oct < Q.min_level) return false;
+            if (Q.max_level >= 0 && oct > Q.max_level) return false;
+        }
+    }
+    if (occupied(i)) return false;
+    if (A.kind == 0 && A.uright) {
+        const float ur = A.uright[i];
+        if (ur > 0 && fabsf(__fsub_rn(Q.ur, ur)) > Q.radius) return false;
+    }
+    const uint4* tp = (const uint4*)(A.desc + (size_t)i * 32);
+    key = ((unsigned long long)hamming256(q0, q1, tp[0], tp[1]) << 35) | ((unsigned long long)order << 4) | (unsigned)(oct & 15);
+    return true;
+}
+__device__ __forceinline__ int proj_key_feature(unsigned long long key) { return (int)((key >> 4) & 0x7FFFFu); }
+
+__global__ __launch_bounds__(256) void k_proj_topk(ProjTopArgs T) {
+    const ProjArgs& A = T.A;
+    const int lane = threadIdx.x & 63, iq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iq >= A.nq) return;
+    const sslam_proj_query Q = A.q[iq];
+    unsigned long long t[PROJ_K];
+#pragma unroll
+    for (int k = 0; k < PROJ_K; ++k) t[k] = ~0ull;
+    int cnt = 0;
+    if (Q.valid) {
+        const float invW = __fdiv_rn((float)GRID_COLS, __fsub_rn(A.maxX, A.minX));
+        const float invH = __fdiv_rn((float)GRID_ROWS, __fsub_rn(A.maxY, A.minY));
+        const uint4 q0 = ((const uint4*)(A.qdesc + (size_t)iq * 32))[0], q1 = ((const uint4*)(A.qdesc + (size_t)iq * 32))[1];
+        const uint8_t* occIn = A.occIn;
+        for (int i = lane; i < A.n; i += 64) {
+            unsigned long long kk;
+            if (!proj_candidate(A, Q, q0, q1, i, invW, invH, [&](int f) { return occIn && occIn[f]; }, kk)) continue;
+            ++cnt;
+            if (kk < t[PROJ_K - 1]) {                        // the lane's own PROJ_K smallest, ascending (one insertion pass)
+                t[PROJ_K - 1] = kk;
+#pragma unroll
+                for (int k = PROJ_K - 1; k > 0; --k) if (t[k] < t[k - 1]) { const unsigned long long x = t[k - 1]; t[k - 1] = t[k]; t[k] = x; }
+            }
+        }
+    }
+    cnt = wave_sum(cnt);
+#pragma unroll
+    for (int k = 0; k < PROJ_K; ++k) {                       // merge: the wave's smallest, K times (keys are unique: they carry the feature index)
+        const unsigned long long m = wave_min_u64(t[0]);
+        if (lane == 0) T.top[(size_t)iq * PROJ_K + k] = m;
+        if (t[0] == m && m != ~0ull) {
+#pragma unroll
+            for (int j = 0; j + 1 < PROJ_K; ++j) t[j] = t[j + 1];
+            t[PROJ_K - 1] = ~0ull;
+        }
+    }
+    if (lane == 0) T.cnt[iq] = cnt;
+}
+
+// accept / reject on (best, second) keys of the layout above: thresholds, same-level ratio test (mode 0), rotation bin (mode 1)
+__device__ __forceinline__ void proj_decide_keys(const ProjArgs& A, float qAngle, unsigned long long b, unsigned long long s2, int& acc, int& bin) {
+    acc = 0; bin = -1;
+    if (b == ~0ull) return;
+    const int bestDist = (int)(b >> 35), bestLevel = (int)(b & 15);
+    int bestDist2 = 256, bestLevel2 = -1;
+    if (A.mode == 0 && s2 != ~0ull) { bestDist2 = (int)(s2 >> 35); bestLevel2 = (int)(s2 & 15); }
+    if (bestDist > A.thDist || bestDist >= 256) return;
+    if (A.mode == 0 && bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(A.nnratio, (float)bestDist2)) return;
+    acc = 1;
+    if (A.mode == 1 && A.checkOri) {
+        float rot = __fsub_rn(qAngle, ((const sslam_keypoint*)A.feats)[proj_key_feature(b)].angle);
+        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+        bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+        if (bin == HISTO_LENGTH) bin = 0;
+    }
+}
+
+// the same test on a copy of the frame's features in LDS (k_proj_commit's re-scan); every field first, the tests afterwards: one LDS round
+// trip per feature instead of one per early exit
+struct ProjFeatLds { const uint4* desc; const float* x; const float* y; const float* ang; const float* ur; const int* oct; const int* order; };
+__device__ __forceinline__ bool proj_candidate_lds(const ProjArgs& A, const ProjFeatLds& F, const sslam_proj_query& Q, const uint4& q0, const uint4& q1, int i, const int* __restrict__ occ,
+                                                   unsigned long long& key) {
+    const int order = F.order[i], oct = F.oct[i], occupied = occ[i];
+    const float fx = F.x[i], fy = F.y[i], fang = F.ang[i], fur = F.ur[i];
+    bool ok = order >= 0 && !occupied;                        // (order < 0: keypoint outside the grid)
+    if (A.kind == 0) {
+        if (Q.min_level > 0 || Q.max_level >= 0) ok = ok && oct >= Q.min_level && !(Q.max_level >= 0 && oct > Q.max_level);
+        const float dx = __fsub_rn(fx, Q.u), dy = __fsub_rn(fy, Q.v);
+        ok = ok && fabsf(dx) < Q.radius && fabsf(dy) < Q.radius;
+        if (A.uright) ok = ok && !(fur > 0 && fabsf(__fsub_rn(Q.ur, fur)) > Q.radius);
+    } else {
+        const double mxp = 0.5 * (double)__fadd_rn(Q.u, Q.u2) - (double)fx, myp = 0.5 * (double)__fadd_rn(Q.v, Q.v2) - (double)fy;
+        const float distance = (float)(mxp * mxp + myp * myp);
+        ok = ok && !(distance > __fmul_rn(Q.radius, Q.radius));
+        const float slope = __fsub_rn(__fdiv_rn(__fsub_rn(Q.v, Q.v2), __fsub_rn(Q.u, Q.u2)), fang);
+        ok = ok && !((double)slope > (double)Q.radius * 0.01);
+        if (Q.min_level > 0 || Q.max_level > 0) ok = ok && oct >= Q.min_level && !(Q.max_level >= 0 && oct > Q.max_level);
+    }
+    if (!ok) return false;
+    key = ((unsigned long long)hamming256(q0, q1, F.desc[2 * i], F.desc[2 * i + 1]) << 35) | ((unsigned long long)(unsigned)order << 4) | (unsigned)(oct & 15);
+    return true;
+}
+
+// dynamic LDS: occ[n], stamp[n] (+ when the frame fits, PROJ_MAXN features: descriptors, positions, angle, right coordinate, level, order key)
+__global__ __launch_bounds__(64) void k_proj_commit(ProjTopArgs T, int featsInLds) {
+    extern __shared__ __align__(16) int pc[];
+    const ProjArgs& A = T.A;
+    const int lane = threadIdx.x, n = A.n, nq = A.nq;
+    ProjFeatLds F;
+    uint4* fdesc = (uint4*)pc;                                  // [2n] when featsInLds
+    int* rest = featsInLds ? (int*)(fdesc + 2 * (size_t)n) : pc;
+    int* occ = rest; int* stamp = rest + n;
+    float* fx = (float*)(stamp + n); float* fy = fx + n; float* fang = fy + n; float* fur = fang + n; int* foct = (int*)(fur + n); int* ford = foct + n;
+    F.desc = fdesc; F.x = fx; F.y = fy; F.ang = fang; F.ur = fur; F.oct = foct; F.order = ford;
+    int* qbin = A.scratch + 2 * n; int* qidx = qbin + nq;          // the scratch layout of the other forms
+    __shared__ int hist[HISTO_LENGTH];
+    if (lane < HISTO_LENGTH) hist[lane] = 0;
+    const float invW = __fdiv_rn((float)GRID_COLS, __fsub_rn(A.maxX, A.minX));
+    const float invH = __fdiv_rn((float)GRID_ROWS, __fsub_rn(A.maxY, A.minY));
+    for (int i = lane; i < n; i += 64) { occ[i] = A.occIn ? (int)A.occIn[i] : 0; stamp[i] = 0; A.assigned[i] = -1; }
+    if (featsInLds) for (int i = lane; i < n; i += 64) {
+        int order = i;
+        if (A.kind == 0) {
+            const sslam_keypoint kp = ((const sslam_keypoint*)A.feats)[i];
+            fx[i] = kp.x; fy[i] = kp.y; fang[i] = kp.angle; foct[i] = kp.octave;
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, A.minX), invW)), py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, A.minY), invH));
+            order = (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) ? (((px * GRID_ROWS + py) << 19) | i) : -1;
+        } else {
+            const sslam_keyline kl = ((const sslam_keyline*)A.feats)[i];
+            fx[i] = kl.pt_x; fy[i] = kl.pt_y; fang[i] = kl.angle; foct[i] = kl.octave;
+        }
+        ford[i] = order; fur[i] = A.uright ? A.uright[i] : -1.f;
+        fdesc[2 * i] = ((const uint4*)A.desc)[2 * i]; fdesc[2 * i + 1] = ((const uint4*)A.desc)[2 * i + 1];
+    }
+    for (int i = lane; i < nq; i += 64) qbin[i] = -1;
+    __syncthreads();
+    int nmatches = 0, it = 0;
+    long long stRescan = 0, cyRescan = 0; const long long tK0 = __builtin_readcyclecounter();
+    for (int base = 0; base < nq; base += 64) {
+        const int qi = base + lane, end = min(64, nq - base);
+        unsigned long long ks[PROJ_K];
+#pragma unroll
+        for (int k = 0; k < PROJ_K; ++k) ks[k] = ~0ull;
+        int cnt = 0, valid = 0, obs = 0; float qAngle = 0.f;
+        if (lane < end) {
+            const sslam_proj_query* Qp = A.q + qi;
+            valid = Qp->valid; obs = Qp->obs_positive; qAngle = Qp->angle; cnt = T.cnt[qi];
+            const unsigned long long* tp = T.top + (size_t)qi * PROJ_K;
+#pragma unroll
+            for (int k = 0; k < PROJ_K; ++k) ks[k] = tp[k];
+        }
+        int start = 0;
+        while (start < end) {
+            ++it;
+            const bool active = lane >= start && lane < end && valid != 0;
+            // first and second list entry whose feature is free now
+            unsigned long long b = ~0ull, s2 = ~0ull; int nfree = 0;
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < PROJ_K; ++k) {
+                    if (ks[k] == ~0ull) continue;
+                    if (occ[proj_key_feature(ks[k])]) continue;
+                    if (nfree == 0) b = ks[k]; else if (nfree == 1) s2 = ks[k];
+                    ++nfree;
+                }
+            }
+            const int need = A.mode == 0 ? 2 : 1;
+            const bool exhausted = active && nfree < need && cnt > PROJ_K;      // the list ran dry although more candidates exist
+            int acc = 0, bin = -1;
+            if (active && !exhausted) proj_decide_keys(A, qAngle, b, s2, acc, bin);
+            const int fb = b != ~0ull ? proj_key_feature(b) : -1, fs = (A.mode == 0 && s2 != ~0ull) ? proj_key_feature(s2) : -1;
+            const int tag = (it << 6) | (63 - lane);
+            if (active && acc) atomicMax(&stamp[fb], tag);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            bool clash = exhausted;
+            if (active && !exhausted) {
+                if (fb >= 0) { const int st = stamp[fb]; clash |= (st >> 6) == it && 63 - (st & 63) < lane; }
+                if (fs >= 0) { const int st = stamp[fs]; clash |= (st >> 6) == it && 63 - (st & 63) < lane; }
+            }
+            const unsigned long long cm = __ballot(clash);
+            const int c = cm ? __ffsll((long long)cm) - 1 : end;          // lanes below `start` are inactive: never set
+            const bool commit = active && lane < c && acc;
+            if (commit) {
+                A.assigned[fb] = qi;
+                if (obs) occ[fb] = 1;
+                if (A.mode == 1 && A.checkOri) { qbin[qi] = bin; qidx[qi] = fb; atomicAdd(&hist[bin], 1); }
+            }
+            nmatches += __popcll(__ballot(commit));
+            start = c;
+            if (c < end && ((__ballot(exhausted) >> c) & 1ull)) {
+                // query base + c is the first pending one and its list is spent: scan its candidates against the live occupancy
+                ++stRescan; const long long tr0 = A.stats ? __builtin_readcyclecounter() : 0;
+                const int jq = base + c;
+                const sslam_proj_query Q = A.q[jq];
+                const uint4 q0 = ((const uint4*)(A.qdesc + (size_t)jq * 32))[0], q1 = ((const uint4*)(A.qdesc + (size_t)jq * 32))[1];
+                unsigned long long lb = ~0ull, ls = ~0ull;
+                for (int i = lane; i < n; i += 64) {
+                    unsigned long long kk;
+                    if (!(featsInLds ? proj_candidate_lds(A, F, Q, q0, q1, i, occ, kk) : proj_candidate(A, Q, q0, q1, i, invW, invH, [&](int f) { return occ[f] != 0; }, kk))) continue;
+                    if (kk < lb) { ls = lb; lb = kk; } else if (kk < ls) ls = kk;
+                }
+                const unsigned long long best = wave_min_u64(lb);
+                const unsigned long long second = wave_min_u64(lb == best ? ls : lb);
+                int a2 = 0, bn2 = -1;
+                proj_decide_keys(A, Q.angle, best, A.mode == 0 ? second : ~0ull, a2, bn2);
+                if (a2) {
+                    const int f = proj_key_feature(best);
+                    if (lane == 0) {
+                        A.assigned[f] = jq;
+                        if (Q.obs_positive) occ[f] = 1;
+                        if (A.mode == 1 && A.checkOri) { qbin[jq] = bn2; qidx[jq] = f; atomicAdd(&hist[bn2], 1); }
+                    }
+                    ++nmatches;
+                }
+                start = c + 1;
+                if (A.stats) cyRescan += __builtin_readcyclecounter() - tr0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+    }
+    __syncthreads();
+    if (A.mode == 1 && A.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            const int c = hist[i];
+            if (c > max1) { max3 = max2; max2 = max1; max1 = c; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (c > max2) { max3 = max2; max2 = c; ind3 = ind2; ind2 = i; }
+            else if (c > max3) { max3 = c; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
+        int removed = 0;
+        for (int i0 = 0; i0 < nq; i0 += 64) {
+            const int i = i0 + lane;
+            bool rm = false;
+            if (i < nq) { const int bn = qbin[i]; rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3; if (rm) A.assigned[qidx[i]] = -2; }      // matched, then removed by the rotation check (src/ORBmatcher.cc:1465)
+            removed += __popcll(__ballot(rm));
+        }
+        nmatches -= removed;
+    }
+    if (lane == 0) *A.nmatches = nmatches;
+    if (lane == 0 && A.stats) { A.stats[0] = it; A.stats[1] = stRescan; A.stats[2] = cyRescan; A.stats[3] = __builtin_readcyclecounter() - tK0; }
+}
+
 // ---------------------------------------------------------------- SearchByBoW(KeyFrame*, Frame&)
 // src/ORBmatcher.cc:159-291.  One wave: the shared vocabulary nodes are walked in ascending id, the keyframe features
 // of a node sequentially (a matched frame feature is skipped by the later ones), the node's frame features lane-parallel
@@ -497,7 +989,7 @@ __global__ __launch_bounds__(256) void k_bow_finish(int* __restrict__ assigned, 
 // prefetched); the one-wave kernel above spends ~7 us per query on dependent global loads.
 constexpr int PROJ_WAVES = 16;
 constexpr int PROJ_MAXN = 2048;            // features that fit: 64 B each in sorted order + the sort keys
-struct ProjLds { float* px; float* py; float* ang; int* oct; float* ur; int* occ; unsigned* ord; uint4* desc; int* colStart; };
+struct ProjLds { float* px; float* py; float* ang; int* oct; float* ur; int* occ; unsigned* ord; uint4* desc; int* colStart; int* stamp; };
 struct ProjDecision { int acc, bestP, secondP, bin; };
 
 // best / second-best candidate of one query (keys: dist | sorted position | level; the position is unique, so the level bits
@@ -580,6 +1072,7 @@ __global__ __launch_bounds__(PROJ_WAVES * 64) void k_search_proj_lds(ProjArgs A)
     S.desc = (uint4*)dyn;
     S.px = (float*)(S.desc + 2 * (size_t)n); S.py = S.px + n; S.ang = S.py + n; S.ur = S.ang + n;
     S.oct = (int*)(S.ur + n); S.occ = S.oct + n; S.ord = (unsigned*)(S.occ + n); S.colStart = (int*)(S.ord + N2);
+    S.stamp = S.colStart + GRID_COLS + 2;                  // [n] per sorted feature: (round << 5 | 31 - wave) of the earliest wave of the latest round that accepted it
     __shared__ int rAcc[PROJ_WAVES], rBestP[PROJ_WAVES], rSecondP[PROJ_WAVES], rBin[PROJ_WAVES], rObs[PROJ_WAVES];
     __shared__ int hist[HISTO_LENGTH];
     __shared__ int sh_nmatches;
@@ -603,6 +1096,7 @@ __global__ __launch_bounds__(PROJ_WAVES * 64) void k_search_proj_lds(ProjArgs A)
         S.ord[i] = k;
     }
     for (int i = tid; i < nq; i += NT) qbin[i] = -1;
+    for (int i = tid; i < n; i += NT) S.stamp[i] = 0;
     __syncthreads();
     if (A.kind == 0) {
         for (int k = 2; k <= N2; k <<= 1)
@@ -674,6 +1168,27 @@ __global__ __launch_bounds__(PROJ_WAVES * 64) void k_search_proj_lds(ProjArgs A)
             const int myAcc = lane < cnt ? rAcc[lane] : 0, myBP = lane < cnt ? rBestP[lane] : -1, mySP = lane < cnt ? rSecondP[lane] : -2;
             const int myBin = lane < cnt ? rBin[lane] : -1, myObs = lane < cnt ? rObs[lane] : 0;
             int myTaken = -3, nTaken = 0, accepted = 0;
+            // Fast path (round 3): the sixteen decisions are independent unless an earlier wave of this round accepted a feature that is this
+            // wave's best or second-best (the only way an earlier query can change a later one, as above).  Every accepting wave stamps its
+            // feature with (round, wave); a wave that finds an earlier wave's stamp of this round on its best or second-best sends the round
+            // down the serial path below.  Otherwise all sixteen commit at once.
+            const int roundTag = base / PROJ_WAVES + 1;
+            if (lane < cnt && myAcc) atomicMax(&S.stamp[myBP], (roundTag << 5) | (31 - lane));
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            bool clash = false;
+            if (lane < cnt) {
+                if (myBP >= 0) { const int st = S.stamp[myBP]; clash |= (st >> 5) == roundTag && 31 - (st & 31) < lane; }
+                if (mySP >= 0) { const int st = S.stamp[mySP]; clash |= (st >> 5) == roundTag && 31 - (st & 31) < lane; }
+            }
+            if (!__ballot(clash)) {
+                if (lane < cnt && myAcc) {
+                    const int fi = (int)(S.ord[myBP] & 0x7FFFFu), jq = base + lane;
+                    A.assigned[fi] = jq;
+                    if (myObs) S.occ[myBP] = 1;
+                    if (A.mode == 1 && A.checkOri) { qbin[jq] = myBin; qidx[jq] = fi; atomicAdd(&hist[myBin], 1); }
+                }
+                accepted = __popcll(__ballot(lane < cnt && myAcc));
+            } else
             for (int w = 0; w < cnt; ++w) {
                 int acc = __builtin_amdgcn_readlane(myAcc, w), bP = __builtin_amdgcn_readlane(myBP, w), bin = __builtin_amdgcn_readlane(myBin, w);
                 const int sP = __builtin_amdgcn_readlane(mySP, w);

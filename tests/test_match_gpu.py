@@ -57,6 +57,38 @@ def test_search_for_initialization(fe, ctx, oracle, seed, nfeat, ori):
     np.testing.assert_array_equal(pmo, opm)
 
 
+@pytest.mark.parametrize("form", ["spec", "lds", "global"])
+@pytest.mark.parametrize("seed", [3, 4])
+def test_search_for_initialization_contention(fe, ctx, oracle, form, seed, monkeypatch):
+    """The single call has three kernels (csrc/match_ordered.h: sixteen speculative waves -- the default --, one wave in LDS, one wave on global
+    memory).  Contended input: every F2 keypoint is wanted by several F1 keypoints in a row (near-duplicate descriptors at nearly the same
+    place), so that matches are taken over by later, closer keypoints (the un-match path) and keypoints of one speculative round collide on
+    their best / second-best candidate (the serial replay with re-evaluation).  All three forms must equal the oracle's restatement of
+    src/ORBmatcher.cc:408-523."""
+    if form != "spec": monkeypatch.setenv("SSLAM_SFI_FORM", form)
+    rng = np.random.default_rng(seed)
+    n2 = 260
+    kp2 = np.zeros(n2, fe.KP_DTYPE)
+    kp2["x"] = rng.uniform(20, 620, n2).astype(np.float32); kp2["y"] = rng.uniform(20, 460, n2).astype(np.float32)
+    kp2["octave"] = (rng.random(n2) < 0.15).astype(np.int32); kp2["angle"] = rng.uniform(0, 360, n2).astype(np.float32); kp2["size"] = 31
+    d2 = _rand_desc(rng, n2)
+    reps = 4
+    src = np.repeat(np.arange(n2), reps); rng.shuffle(src[: len(src) // 2])          # half in contended runs, half scattered
+    n1 = len(src)
+    kp1 = np.zeros(n1, fe.KP_DTYPE)
+    kp1["x"] = kp2["x"][src] + rng.uniform(-3, 3, n1).astype(np.float32); kp1["y"] = kp2["y"][src] + rng.uniform(-3, 3, n1).astype(np.float32)
+    kp1["octave"] = (rng.random(n1) < 0.1).astype(np.int32); kp1["angle"] = (kp2["angle"][src] + rng.normal(0, 8, n1)).astype(np.float32) % np.float32(360); kp1["size"] = 31
+    d1 = d2[src].copy()
+    for i in range(n1):                                                            # 0..24 flipped bits: ties, takeovers and ratio-test failures
+        for b in rng.integers(0, 256, int(rng.integers(0, 25))): d1[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    pm = np.stack([kp1["x"], kp1["y"]], axis=1).astype(np.float32)
+    m12, pmo, n = ctx.search_for_initialization(kp1, d1, kp2, d2, pm, 100, 0.9, True)
+    om12, opm, on = oracle.search_for_initialization(kp1, d1, kp2, d2, pm, 100, 0.9, True)
+    assert on > 50 and n == on
+    np.testing.assert_array_equal(m12, om12)
+    np.testing.assert_array_equal(pmo, opm)
+
+
 @pytest.mark.parametrize("n1,n2,ratio", [(40, 40, False), (200, 187, False), (400, 400, True), (1, 2, False), (5, 1, False), (0, 9, False)])
 def test_line_match(ctx, oracle, n1, n2, ratio):
     rng = np.random.default_rng(n1 * 31 + n2)
@@ -106,6 +138,33 @@ def test_orb_search_by_projection(fe, ctx, oracle, mode, seed):
         oa, on = oracle.search_by_projection(0, mode, kp2, d2, q, d1, occ, uright, 0.8 if mode == 0 else 0.9, 100, True)
         assert on > 50 and n == on
         np.testing.assert_array_equal(a, oa)
+
+
+@pytest.mark.parametrize("form", ["two-kernel", "lds", "wave"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_orb_search_by_projection_contention(fe, ctx, oracle, form, mode, monkeypatch):
+    """The window matcher has three device forms (csrc/match_ordered.h: per-query top-4 lists + ordered commit with parallel prefixes -- the
+    default --, sixteen speculative waves in LDS, one wave).  Contended input: every query is repeated several times in a row with small
+    jitter (so that consecutive queries want the same keypoint, lists run dry and the commit has to re-scan), a third of the map points has
+    no observations (takes a keypoint without blocking it), a fifth of the keypoints is occupied from the start.  All forms must equal the
+    oracle's restatement of src/ORBmatcher.cc:45-129 / :1331-1473."""
+    if form != "two-kernel": monkeypatch.setenv("SSLAM_PROJ_FORM", form)
+    rng = np.random.default_rng(77 + mode)
+    cur = synth_frame(1234); prev = warp_prev(cur)
+    kp1, d1 = oracle.orb_extract(prev, 500); kp2, d2 = oracle.orb_extract(cur, 1000)
+    scales = oracle.orb_params()[0]
+    sel = np.repeat(rng.permutation(len(kp1))[:180], 7)                       # runs of seven near-identical queries
+    q = _proj_queries(fe, rng, kp1[sel], 0, mode, scales)
+    q["radius"] *= 1.5
+    q["obs_positive"] = rng.random(len(q)) < 0.67
+    qd = d1[sel].copy()
+    for i in range(len(qd)):
+        for b in rng.integers(0, 256, int(rng.integers(0, 12))): qd[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    occ = (rng.random(len(kp2)) < 0.2).astype(np.uint8)
+    a, n = ctx.search_by_projection(0, mode, kp2, d2, q, qd, occ, None, 0.8 if mode == 0 else 0.9, 100, True)
+    oa, on = oracle.search_by_projection(0, mode, kp2, d2, q, qd, occ, None, 0.8 if mode == 0 else 0.9, 100, True)
+    assert on > 50 and n == on
+    np.testing.assert_array_equal(a, oa)
 
 
 def test_line_search_by_projection(fe, ctx, oracle):
