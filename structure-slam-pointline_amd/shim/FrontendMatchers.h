@@ -58,7 +58,11 @@ struct ProjQuery { float u, v, u2, v2, radius; int min_level, max_level; float a
 int SearchByProjection(int mode, const std::vector<cv::KeyPoint> &keysUn, const cv::Mat &desc, const float bounds[4],
                        const std::vector<float> *uRight, const std::vector<unsigned char> &occupied,
                        const std::vector<ProjQuery> &queries, const cv::Mat &queryDesc, float nnratio, int thDist, bool checkOri,
-                       std::vector<int> &assigned);
+                       std::vector<int> &assigned, long frameId = -1);
+// frameId >= 0 (Frame::mnId, include/Frame.h:128): the frame's features stay on the device between calls (a small cache in the shim), so the
+// retry of TrackWithMotionModel (src/Tracking.cc:1243) and SearchLocalPoints (:1736) on the same frame upload nothing but their queries.
+template <class T> auto FrameId(const T &f, int) -> decltype((long)f.mnId) { return (long)f.mnId; }
+template <class T> long FrameId(const T &, ...) { return -1; }
 int SearchLinesByProjection(const std::vector<cv::line_descriptor::KeyLine> &keylinesUn, const cv::Mat &ldesc,
                             const std::vector<unsigned char> &occupied, const std::vector<ProjQuery> &queries, const cv::Mat &queryDesc,
                             float nnratio, int thDist, std::vector<int> &assigned, int mode = 0);

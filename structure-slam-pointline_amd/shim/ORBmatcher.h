@@ -60,7 +60,8 @@ public:
         const float bounds[4] = {(float)F.mnMinX, (float)F.mnMaxX, (float)F.mnMinY, (float)F.mnMaxY};
         cv::Mat qdesc((int)q.size(), 32, CV_8U, qd.data());
         std::vector<int> assigned;
-        const int n = sslam_shim::SearchByProjection(0, F.mvKeysUn, F.mDescriptors, bounds, &F.mvuRight, occupied, q, qdesc, mfNNratio, TH_HIGH, false, assigned);
+        const int n = sslam_shim::SearchByProjection(0, F.mvKeysUn, F.mDescriptors, bounds, &F.mvuRight, occupied, q, qdesc, mfNNratio, TH_HIGH, false, assigned,
+                                                     sslam_shim::FrameId(F, 0));
         for (size_t i = 0; i < assigned.size(); ++i) if (assigned[i] >= 0) F.mvpMapPoints[i] = owner[assigned[i]];
         return n;
     }
@@ -113,7 +114,7 @@ public:
         cv::Mat qdesc((int)q.size(), 32, CV_8U, qd.data());
         std::vector<int> assigned;
         const int n = sslam_shim::SearchByProjection(1, CurrentFrame.mvKeysUn, CurrentFrame.mDescriptors, bounds, &CurrentFrame.mvuRight, occupied, q, qdesc, mfNNratio, TH_HIGH,
-                                                     mbCheckOrientation, assigned);
+                                                     mbCheckOrientation, assigned, sslam_shim::FrameId(CurrentFrame, 0));
         for (size_t i = 0; i < assigned.size(); ++i) {
             if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = owner[assigned[i]];
             else if (assigned[i] == -2) CurrentFrame.mvpMapPoints[i] = static_cast<MapPointT *>(NULL);      // matched, then removed by the rotation check (:1465)

@@ -130,13 +130,50 @@ int SearchForInitialization(const std::vector<cv::KeyPoint> &k1, const cv::Mat &
     return n;
 }
 static_assert(sizeof(ProjQuery) == sizeof(sslam_proj_query), "ProjQuery layout");
+// Device-resident copies of the frames the tracker keeps matching against: a Frame's mvKeysUn / mDescriptors /
+// mvuRight never change after its constructor (src/Frame.cc:69-131), and Frame::mnId (include/Frame.h:128) names it -- copies made by
+// `mLastFrame = Frame(mCurrentFrame)` share the id and the features.  The last few frames stay on the device, so the second and later
+// matcher calls on a frame (Tracking.cc:1227 and its retry :1243, :1736) skip the upload of ~60 KB of features.
+namespace {
+struct ResidentFrame { long id = -1; int kind = 0, n = 0; sslam_frame* h = nullptr; unsigned long stamp = 0; };
+ResidentFrame g_resident[4];
+unsigned long g_residentClock = 0;
+std::mutex g_residentMu;
+sslam_frame* resident_frame(long id, int kind, const void* feats, const uint8_t* desc, int n, const float* uright, const float bounds[4]) {
+    std::lock_guard<std::mutex> lk(g_residentMu);
+    ResidentFrame* victim = &g_resident[0];
+    for (auto& r : g_resident) {
+        if (r.h && r.id == id && r.kind == kind && r.n == n) { r.stamp = ++g_residentClock; return r.h; }
+        if (r.stamp < victim->stamp) victim = &r;
+    }
+    if (victim->h) { sslam_frame_destroy(victim->h); victim->h = nullptr; }
+    sslam_frame* h = nullptr;
+    check(sslam_frame_upload(G.get(), kind, feats, desc, n, uright, bounds, &h));
+    victim->id = id; victim->kind = kind; victim->n = n; victim->h = h; victim->stamp = ++g_residentClock;
+    return h;
+}
+}  // namespace
 int SearchByProjection(int mode, const std::vector<cv::KeyPoint> &k, const cv::Mat &desc, const float bounds[4], const std::vector<float> *uRight,
                        const std::vector<unsigned char> &occupied, const std::vector<ProjQuery> &queries, const cv::Mat &qd, float nnratio,
-                       int thDist, bool checkOri, std::vector<int> &assigned) {
+                       int thDist, bool checkOri, std::vector<int> &assigned, long frameId) {
     assigned.assign(k.size(), -1);
     if (k.empty() || queries.empty()) return 0;
-    std::vector<uint8_t> a = rows32(desc), b = rows32(qd);
+    std::vector<uint8_t> b = rows32(qd);
     int n = 0;
+    if (frameId >= 0) {
+        sslam_frame* fr = nullptr;
+        {
+            std::vector<uint8_t> a;      // only built when the frame is not resident yet: resident_frame() uploads at most once per frame
+            bool have = false;
+            { std::lock_guard<std::mutex> lk(g_residentMu); for (auto& r : g_resident) have = have || (r.h && r.id == frameId && r.kind == 0 && r.n == (int)k.size()); }
+            if (!have) a = rows32(desc);
+            fr = resident_frame(frameId, 0, k.data(), a.data(), (int)k.size(), uRight ? uRight->data() : nullptr, bounds);
+        }
+        check(sslam_search_by_projection_frame(G.get(), fr, mode, occupied.empty() ? nullptr : occupied.data(), (const sslam_proj_query*)queries.data(), b.data(),
+                                               (int)queries.size(), nnratio, thDist, checkOri ? 1 : 0, assigned.data(), &n));
+        return n;
+    }
+    std::vector<uint8_t> a = rows32(desc);
     check(sslam_search_by_projection(G.get(), 0, mode, k.data(), a.data(), (int)k.size(), bounds, uRight ? uRight->data() : nullptr,
                                      occupied.empty() ? nullptr : occupied.data(), (const sslam_proj_query*)queries.data(), b.data(),
                                      (int)queries.size(), nnratio, thDist, checkOri ? 1 : 0, assigned.data(), &n));

@@ -36,6 +36,7 @@ struct TFrame {
     float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0;
     // what the two per-frame tracking calls read on top of that (include/Frame.h:96-200)
     cv::Mat mTcw; float fx = 0, fy = 0, cx = 0, cy = 0, mb = 0, mbf = 0; int N = 0;
+    long unsigned int mnId = 0;                  // Frame::mnId: makes the shim keep this frame's features on the device between calls
     std::vector<cv::KeyPoint> mvKeys; std::vector<bool> mvbOutlier, mvbLineOutlier;
 };
 struct TKeyFrame {
@@ -130,6 +131,7 @@ int main(int argc, char** argv) {
     // Poses, world positions and flags are dumped; tests/test_shim_gpu.py forms the same queries in float32 and asks the oracle.
     {
         TFrame Last, Cur;
+        Last.mnId = 41; Cur.mnId = 42;          // pass 1 below finds Cur's features resident (uploaded by pass 0)
         Last.mvKeysUn = k1; Last.mvKeys = k1; Last.N = (int)k1.size(); Last.NL = (int)l1.size(); Last.mvKeylinesUn = l1;
         Cur.mvKeysUn = k2; Cur.mvKeys = k2; Cur.mDescriptors = d2; Cur.N = (int)k2.size(); Cur.mvKeylinesUn = l2; Cur.mLdesc = ld2; Cur.NL = (int)l2.size();
         Cur.mnMaxX = (float)w; Cur.mnMaxY = (float)h;
