@@ -233,6 +233,17 @@ def pcie_leg(fe, ctx, frames, with_lines, n=18432, chunk=0):
     fe.frontend_batch_raw(ox, lx, pin.numpy()[:warm], tuple(a[:warm] for a in res_pin), chunk=chunk)
     t0 = time.perf_counter(); fe.frontend_batch_raw(ox, lx, pin.numpy(), res_pin, chunk=chunk); out["pinned_frames_per_s"] = n / (time.perf_counter() - t0)
     out["results_equal"] = bool(np.array_equal(res_pg[2], res_pin[2]) and np.array_equal(res_pg[6], res_pin[6]))
+    # the same with the match stage (sslam_frontend_batch_match: frame i against frame i-1 -- SearchForInitialization + dense 2-NN + line matcher,
+    # the three matchers of the resident-frame step), i.e. BASELINE configs[2] end to end through host buffers
+    m_pg = fe.frontend_batch_match_alloc(n, ox.cap, lcap, pinned=False)
+    fe.frontend_batch_match_raw(ox, lx, host[:warm], tuple(a[:warm] for a in res_pg), tuple(a[:warm] for a in m_pg), chunk=chunk)
+    t0 = time.perf_counter(); fe.frontend_batch_match_raw(ox, lx, host, res_pg, m_pg, chunk=chunk); out["pageable_with_match_frames_per_s"] = n / (time.perf_counter() - t0)
+    m_pin = fe.frontend_batch_match_alloc(n, ox.cap, lcap, pinned=True)
+    fe.frontend_batch_match_raw(ox, lx, pin.numpy()[:warm], tuple(a[:warm] for a in res_pin), tuple(a[:warm] for a in m_pin), chunk=chunk)
+    t0 = time.perf_counter(); fe.frontend_batch_match_raw(ox, lx, pin.numpy(), res_pin, m_pin, chunk=chunk); out["pinned_with_match_frames_per_s"] = n / (time.perf_counter() - t0)
+    out["match_results_equal"] = bool(np.array_equal(m_pg[1], m_pin[1]) and np.array_equal(m_pg[5], m_pin[5]))
+    out["match_entry"] = "sslam_frontend_batch_match (SearchForInitialization window 100 + dense Hamming 2-NN + LSD line matcher against the previous frame of the sequence)"
+    out["matches_per_frame"] = float(m_pin[1][1:].mean())
     ox.close()
     if lx: lx.close()
     return out

@@ -367,6 +367,31 @@ int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const uint8_t* imag
                          sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
                          sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap);
 int sslam_frontend_batch_release(sslam_ctx* ctx);
+/* sslam_frontend_batch plus the match stage of BASELINE configs[2] ("extract + Hamming match vs previous frame"): the batch is a SEQUENCE,
+ * frame i is matched against frame i-1 of the same call with the three matchers the resident-frame pipeline times
+ *   ORBmatcher::SearchForInitialization(F1 = frame i-1, F2 = frame i, vbPrevMatched = F1's keypoint positions, window_size)
+ *                                                       src/ORBmatcher.cc:408-523 as called at src/Tracking.cc:330-345,
+ *   the dense Hamming 2-NN of F1's descriptors in F2's (cv::BFMatcher::knnMatch, the reduction under every Search*; optional),
+ *   LSDmatcher::SerachForInitialize(F1, F2) on the LBD descriptors (src/LSDmatcher.cpp:257-284; only with `lines`),
+ * on the device, behind the chunk's extraction (point matchers on the point stream, the line matcher on the line stream).  Rows of frame i
+ * describe the pair (i-1, i) and are indexed by F1's features: init_matches12[i*cap + j] = keypoint of frame i matched to keypoint j of
+ * frame i-1 or -1 (j < nkp_out[i-1]), init_nmatches[i]; knn_idx / knn_dist[(i*cap + j)*2 + {0,1}]; line_pairs[(i*lcap + p)*2 + {0,1}] =
+ * (line of frame i-1, line of frame i) for p < line_npairs[i].  Frame 0 has no predecessor: its counts are 0 and its rows unspecified.
+ * Chunking, staging, streams and error behaviour are those of sslam_frontend_batch (chunk boundaries do not show: the last frame of a
+ * chunk stays on the device as the next chunk's predecessor); the match arrays follow the same pinned-or-staged rule as the others. */
+typedef struct sslam_batch_match {
+    int32_t window_size; float nnratio; int32_t check_orientation; float bounds[4];      /* SearchForInitialization: windowSize (100), mfNNratio (0.9), mbCheckOrientation, mnMinX/MaxX/MinY/MaxY */
+    double line_gate_scale; int32_t line_ratio_mode;                                    /* sslam_line_match arguments (0.5, 0) */
+    int32_t* init_matches12;      /* [n*cap] */
+    int32_t* init_nmatches;       /* [n] */
+    int32_t* knn_idx;             /* [n*cap*2] or NULL (then knn_dist is NULL as well) */
+    int32_t* knn_dist;            /* [n*cap*2] */
+    int32_t* line_pairs;          /* [n*lcap*2]; ignored without `lines` */
+    int32_t* line_npairs;         /* [n] */
+} sslam_batch_match;
+int sslam_frontend_batch_match(sslam_orb* orb, sslam_lines* lines, const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride, int chunk,
+                               sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
+                               sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap, const sslam_batch_match* match);
 
 
 /* ---- multi-GPU batch mode (SURVEY.md §8(b) "sslam_group_create + sslam_frontend_batch_sharded", §8(e)) ----------------------

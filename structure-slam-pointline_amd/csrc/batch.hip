@@ -10,7 +10,11 @@
 //     library;
 //   * pageable caller memory is staged through pinned buffers by a few host threads (one memcpy thread moves ~10 GB/s: 32 k frames/s of
 //     307 KB frames at best); the buffers, streams and events live in a per-context cache instead of being allocated per call;
-//   * uploads, kernels and downloads of neighbouring chunks overlap as before (two slots).
+//   * uploads, kernels and downloads of neighbouring chunks overlap as before (two slots);
+//   * sslam_frontend_batch_match adds the match stage of BASELINE configs[2] ("extract + Hamming match vs previous frame"): frame i is
+//     matched against frame i-1 of the call -- ORBmatcher::SearchForInitialization, the dense Hamming 2-NN and the LSD line matcher, the
+//     three launches pipeline.py times for resident frames.  The device arrays of a chunk carry one extra frame in front (the last frame
+//     of the chunk before it), so "previous" and "current" are the same arrays one frame apart and the *_batch_dev matchers run unchanged.
 #include "common.h"
 #include <algorithm>
 #include <cstring>
@@ -22,14 +26,21 @@ extern "C" int sslam_orb_batch_status_dev(sslam_orb* orb, int cap, int32_t* d_st
 extern "C" int sslam_lines_batch_status_dev(sslam_lines* lines, int cap, int32_t* d_status4, void* stream);
 extern "C" int sslam_lines_set_core_event(sslam_lines* lines, void* hip_event);
 
+// vbPrevMatched of SearchForInitialization starts at F1's keypoint positions (src/Tracking.cc:340-342): the first two floats of each record
+__global__ __launch_bounds__(256) void k_prev_matched_init(const sslam_keypoint* __restrict__ kp, size_t rows, float2* __restrict__ pm) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) { const float* k = (const float*)(kp + i); pm[i] = make_float2(k[0], k[1]); }
+}
+
 namespace {
 struct Slot {
     DevBuf dIn, dKp, dDesc, dN, dKl, dLd, dFn, dNl, dStatus;
+    DevBuf dPm, dM12, dNm, dKnnI, dKnnD, dLp, dNlp;      // match stage: vbPrevMatched, vnMatches12, counts, 2-NN, line pairs
     HostPinned hIn, hOut, hStatus;
     hipEvent_t evIn = nullptr, evPoint = nullptr, evLines = nullptr, evOut = nullptr;
     int first = 0, count = 0;            // frames of the chunk in flight
     void release() {
-        dIn.release(); dKp.release(); dDesc.release(); dN.release(); dKl.release(); dLd.release(); dFn.release(); dNl.release(); dStatus.release(); hIn.release(); hOut.release(); hStatus.release();
+        dIn.release(); dKp.release(); dDesc.release(); dN.release(); dKl.release(); dLd.release(); dFn.release(); dNl.release(); dStatus.release(); dPm.release(); dM12.release(); dNm.release(); dKnnI.release(); dKnnD.release(); dLp.release(); dNlp.release(); hIn.release(); hOut.release(); hStatus.release();
         for (hipEvent_t* e : {&evIn, &evPoint, &evLines, &evOut}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
     }
 };
@@ -67,30 +78,38 @@ int copy_threads() {
 }
 }  // namespace
 
-extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride, int chunk,
-                                    sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
-                                    sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap) {
+namespace {
+int batch_impl(const char* fn, sslam_orb* orb, sslam_lines* lines, const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride, int chunk,
+               sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
+               sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap, const sslam_batch_match* M) {
     sslam_ctx* ctx = orb ? sslam_orb_context(orb) : nullptr;
     if (!orb || !ctx || n < 0 || w <= 0 || h <= 0 || stride < (size_t)w || cap <= 0 || (n > 0 && (!images || !kp_out || !desc_out || !nkp_out)) ||
-        (lines && (sslam_lines_context(lines) != ctx || lcap <= 0 || (n > 0 && (!kl_out || !ldesc_out || !linefn_out || !nl_out)))) || (n > 1 && image_stride < stride * (size_t)(h - 1) + (size_t)w)) {
-        set_error("sslam_frontend_batch: invalid arguments"); return SSLAM_ERR_INVALID;
+        (lines && (sslam_lines_context(lines) != ctx || lcap <= 0 || (n > 0 && (!kl_out || !ldesc_out || !linefn_out || !nl_out)))) || (n > 1 && image_stride < stride * (size_t)(h - 1) + (size_t)w) ||
+        (M && n > 0 && (!M->init_matches12 || !M->init_nmatches || (M->knn_idx == nullptr) != (M->knn_dist == nullptr) || (lines && (!M->line_pairs || !M->line_npairs))))) {
+        set_error("%s: invalid arguments", fn); return SSLAM_ERR_INVALID;
     }
     if (n == 0) return SSLAM_OK;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     const size_t fpx = (size_t)w * h;
+    const bool knn = M && M->knn_idx, lmatch = M && lines;
     int C = std::min(n, chunk > 0 ? chunk : 6144);
     if (chunk <= 0) {      // the default follows the core's wave slots, but never asks for more than a third of the free device memory
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-            const size_t perFrame = 24 * fpx + 8 * fpx + (size_t)cap * 60 * 3 + (lines ? (size_t)lcap * 124 * 3 : 0) + 65536;      // extractor workspaces + the two slots, generously
+            const size_t perFrame = 24 * fpx + 8 * fpx + (size_t)cap * (60 * 3 + (M ? 12 + 20 + (knn ? 32 : 0) : 0)) + (lines ? (size_t)lcap * 124 * 3 : 0) + 65536;      // extractor workspaces + the two slots, generously
             const size_t fit = freeB / 3 / std::max<size_t>(perFrame, 1);
             if (fit >= 256 && (size_t)C > fit) C = (int)fit;
         }
     }
-    const size_t oKp = 0, oDesc = oKp + sizeof(sslam_keypoint) * (size_t)C * cap, oN = oDesc + 32 * (size_t)C * cap, oKl = oN + 256 + 4 * (size_t)C,
-                 oLd = oKl + (lines ? sizeof(sslam_keyline) * (size_t)C * lcap : 0), oFn = oLd + (lines ? 32 * (size_t)C * lcap : 0),
-                 oNl = oFn + (lines ? 24 * (size_t)C * lcap : 0), outBytes = oNl + 256 + 4 * (size_t)C;
+    // host staging layout of one chunk's results (pageable callers)
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t oKp = take(sizeof(sslam_keypoint) * (size_t)C * cap), oDesc = take(32 * (size_t)C * cap), oN = take(4 * (size_t)C),
+                 oKl = take(lines ? sizeof(sslam_keyline) * (size_t)C * lcap : 0), oLd = take(lines ? 32 * (size_t)C * lcap : 0), oFn = take(lines ? 24 * (size_t)C * lcap : 0),
+                 oNl = take(lines ? 4 * (size_t)C : 0), oM12 = take(M ? 4 * (size_t)C * cap : 0), oNm = take(M ? 4 * (size_t)C : 0),
+                 oKi = take(knn ? 8 * (size_t)C * cap : 0), oKd = take(knn ? 8 * (size_t)C * cap : 0), oLp = take(lmatch ? 8 * (size_t)C * lcap : 0), oNlp = take(lmatch ? 4 * (size_t)C : 0);
+    const size_t outBytes = o;
     // pinned (hipHostMalloc / hipHostRegister) caller memory is copied from / to directly; pageable memory goes through the pinned staging
     auto is_pinned = [](const void* q) {
         hipPointerAttribute_t a;
@@ -99,25 +118,33 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
     };
     const bool inDirect = stride == (size_t)w && (n == 1 || image_stride == fpx) && is_pinned(images);
     const bool outDirect = is_pinned(kp_out) && is_pinned(desc_out) && is_pinned(nkp_out) &&
-                           (!lines || (is_pinned(kl_out) && is_pinned(ldesc_out) && is_pinned(linefn_out) && is_pinned(nl_out)));
+                           (!lines || (is_pinned(kl_out) && is_pinned(ldesc_out) && is_pinned(linefn_out) && is_pinned(nl_out))) &&
+                           (!M || (is_pinned(M->init_matches12) && is_pinned(M->init_nmatches) && (!knn || (is_pinned(M->knn_idx) && is_pinned(M->knn_dist))) &&
+                                   (!lmatch || (is_pinned(M->line_pairs) && is_pinned(M->line_npairs)))));
     if (!ctx->batchCache) { ctx->batchCache = new BatchCache(); ctx->batchCacheFree = free_batch_cache; }
     BatchCache& B = *(BatchCache*)ctx->batchCache;
     Slot* slot = B.slot;
     int rc = SSLAM_OK;
     if ((!B.cp && hipStreamCreateWithFlags(&B.cp, hipStreamNonBlocking) != hipSuccess) || (!B.cpOut && hipStreamCreateWithFlags(&B.cpOut, hipStreamNonBlocking) != hipSuccess) ||
         (!B.stLines && hipStreamCreateWithFlags(&B.stLines, hipStreamNonBlocking) != hipSuccess) || (!B.evCore && hipEventCreateWithFlags(&B.evCore, hipEventDisableTiming) != hipSuccess)) {
-        set_error("sslam_frontend_batch: stream / event creation failed"); return SSLAM_ERR_HIP;
+        set_error("%s: stream / event creation failed", fn); return SSLAM_ERR_HIP;
     }
     hipStream_t cp = B.cp, cpOut = B.cpOut, stP = ctx->stream, stL = B.stLines;      // H2D and D2H on separate streams: the next chunk's upload must not queue behind this chunk's download
+    // Feature arrays hold C + 1 frames: slot 0 is the frame in front of the chunk (the match stage's "previous frame" of the chunk's first
+    // frame), the chunk's own frames follow.  Without the match stage the extra frame is simply never read.
+    const size_t F1 = (size_t)C + 1;
     for (int i = 0; i < 2; ++i) {
         Slot& s = slot[i];
         s.count = 0;
-        if ((rc = s.dIn.ensure(fpx * C)) || (rc = s.dKp.ensure(sizeof(sslam_keypoint) * (size_t)C * cap)) || (rc = s.dDesc.ensure(32 * (size_t)C * cap)) ||
-            (rc = s.dN.ensure(4 * (size_t)C)) || (rc = s.dStatus.ensure(32)) || (rc = s.hStatus.ensure(32)) || (!inDirect && (rc = s.hIn.ensure(fpx * C))) || (!outDirect && (rc = s.hOut.ensure(outBytes)))) return rc;
-        if (lines && ((rc = s.dKl.ensure(sizeof(sslam_keyline) * (size_t)C * lcap)) || (rc = s.dLd.ensure(32 * (size_t)C * lcap)) ||
-                      (rc = s.dFn.ensure(24 * (size_t)C * lcap)) || (rc = s.dNl.ensure(4 * (size_t)C)))) return rc;
+        if ((rc = s.dIn.ensure(fpx * C)) || (rc = s.dKp.ensure(sizeof(sslam_keypoint) * F1 * cap)) || (rc = s.dDesc.ensure(32 * F1 * cap)) ||
+            (rc = s.dN.ensure(4 * F1)) || (rc = s.dStatus.ensure(32)) || (rc = s.hStatus.ensure(32)) || (!inDirect && (rc = s.hIn.ensure(fpx * C))) || (!outDirect && (rc = s.hOut.ensure(outBytes)))) return rc;
+        if (lines && ((rc = s.dKl.ensure(sizeof(sslam_keyline) * (size_t)C * lcap)) || (rc = s.dLd.ensure(32 * F1 * lcap)) ||
+                      (rc = s.dFn.ensure(24 * (size_t)C * lcap)) || (rc = s.dNl.ensure(4 * F1)))) return rc;
+        if (M && ((rc = s.dPm.ensure(8 * (size_t)C * cap)) || (rc = s.dM12.ensure(4 * (size_t)C * cap)) || (rc = s.dNm.ensure(4 * (size_t)C)) ||
+                  (knn && ((rc = s.dKnnI.ensure(8 * (size_t)C * cap)) || (rc = s.dKnnD.ensure(8 * (size_t)C * cap)))) ||
+                  (lmatch && ((rc = s.dLp.ensure(8 * (size_t)C * lcap)) || (rc = s.dNlp.ensure(4 * (size_t)C)))))) return rc;
         for (hipEvent_t* e : {&s.evIn, &s.evPoint, &s.evLines, &s.evOut})
-            if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { set_error("sslam_frontend_batch: hipEventCreate failed"); return SSLAM_ERR_HIP; }
+            if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { set_error("%s: hipEventCreate failed", fn); return SSLAM_ERR_HIP; }
         if (n <= C) break;                 // one chunk: the second slot is never used
     }
     const int T = copy_threads();
@@ -125,13 +152,13 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
     // results of a finished chunk: pinned staging -> the caller's arrays
     auto drain = [&](Slot& s) -> int {
         if (s.count == 0) return SSLAM_OK;
-        if (hipEventSynchronize(s.evOut) != hipSuccess) { set_error("sslam_frontend_batch: D2H failed"); return SSLAM_ERR_HIP; }
+        if (hipEventSynchronize(s.evOut) != hipSuccess) { set_error("%s: D2H failed", fn); return SSLAM_ERR_HIP; }
         // per-chunk status words (sslam_orb_batch_status_dev / sslam_lines_batch_status_dev): the conditions the single-frame calls report
         const int* S = s.hStatus.as<int>();
         int status = SSLAM_OK;
-        if (lines && S[6]) { set_error("sslam_frontend_batch: frame %d produced more than 8192 LSD candidate rectangles", s.first + S[7]); status = SSLAM_ERR_UNSUPPORTED; }
-        else if (S[0]) { set_error("sslam_frontend_batch: %d frame(s) of chunk %d.. hold more keypoints than cap %d (first: frame %d)", S[0], s.first, cap, s.first + S[1]); status = SSLAM_ERR_CAPACITY; }
-        else if (lines && S[4]) { set_error("sslam_frontend_batch: %d frame(s) of chunk %d.. hold more lines than lcap %d (first: frame %d)", S[4], s.first, lcap, s.first + S[5]); status = SSLAM_ERR_CAPACITY; }
+        if (lines && S[6]) { set_error("%s: frame %d produced more than 8192 LSD candidate rectangles", fn, s.first + S[7]); status = SSLAM_ERR_UNSUPPORTED; }
+        else if (S[0]) { set_error("%s: %d frame(s) of chunk %d.. hold more keypoints than cap %d (first: frame %d)", fn, S[0], s.first, cap, s.first + S[1]); status = SSLAM_ERR_CAPACITY; }
+        else if (lines && S[4]) { set_error("%s: %d frame(s) of chunk %d.. hold more lines than lcap %d (first: frame %d)", fn, S[4], s.first, lcap, s.first + S[5]); status = SSLAM_ERR_CAPACITY; }
         if (status != SSLAM_OK && firstStatus == SSLAM_OK) firstStatus = status;
         if (outDirect) { s.count = 0; return SSLAM_OK; }
         const uint8_t* H = s.hOut.as<uint8_t>();
@@ -146,6 +173,12 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
                 std::memcpy(ldesc_out + 32 * g * lcap, H + oLd + 32 * (size_t)a * lcap, 32 * c * lcap);
                 std::memcpy(linefn_out + 3 * g * lcap, H + oFn + 24 * (size_t)a * lcap, 24 * c * lcap);
                 std::memcpy(nl_out + g, H + oNl + 4 * (size_t)a, 4 * c);
+            }
+            if (M) {
+                std::memcpy(M->init_matches12 + g * cap, H + oM12 + 4 * (size_t)a * cap, 4 * c * cap);
+                std::memcpy(M->init_nmatches + g, H + oNm + 4 * (size_t)a, 4 * c);
+                if (knn) { std::memcpy(M->knn_idx + 2 * g * cap, H + oKi + 8 * (size_t)a * cap, 8 * c * cap); std::memcpy(M->knn_dist + 2 * g * cap, H + oKd + 8 * (size_t)a * cap, 8 * c * cap); }
+                if (lmatch) { std::memcpy(M->line_pairs + 2 * g * lcap, H + oLp + 8 * (size_t)a * lcap, 8 * c * lcap); std::memcpy(M->line_npairs + g, H + oNlp + 4 * (size_t)a, 4 * c); }
             }
         });
         s.count = 0;
@@ -172,37 +205,68 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
         }
         hipStream_t stLn = twoStreams ? stL : stP;
         if (hipMemcpyAsync(s.dIn.p, hin, fpx * c, hipMemcpyHostToDevice, cp) != hipSuccess || hipEventRecord(s.evIn, cp) != hipSuccess ||
-            hipStreamWaitEvent(stP, s.evIn, 0) != hipSuccess || (twoStreams && hipStreamWaitEvent(stL, s.evIn, 0) != hipSuccess)) { set_error("sslam_frontend_batch: H2D failed"); rc = SSLAM_ERR_HIP; break; }
+            hipStreamWaitEvent(stP, s.evIn, 0) != hipSuccess || (twoStreams && hipStreamWaitEvent(stL, s.evIn, 0) != hipSuccess)) { set_error("%s: H2D failed", fn); rc = SSLAM_ERR_HIP; break; }
+        // the chunk's frames start one frame into the feature arrays
+        sslam_keypoint* dKp = s.dKp.as<sslam_keypoint>() + cap; uint8_t* dDesc = s.dDesc.as<uint8_t>() + 32 * (size_t)cap; int32_t* dN = s.dN.as<int32_t>() + 1;
+        uint8_t* dLd = lines ? s.dLd.as<uint8_t>() + 32 * (size_t)lcap : nullptr; int32_t* dNl = lines ? s.dNl.as<int32_t>() + 1 : nullptr;
+        if (M) {
+            // frame 0 of the array = the frame in front of this chunk: the last frame of the chunk before (the other slot, same streams: ordered
+            // behind its extraction), or no frame at all for the first chunk of the call (count 0: nothing matches)
+            bool ok = true;
+            if (k == 0) {
+                ok = hipMemsetAsync(s.dN.p, 0, 4, stP) == hipSuccess && (!lines || hipMemsetAsync(s.dNl.p, 0, 4, stLn) == hipSuccess);
+            } else {
+                const Slot& q = slot[(k + 1) & 1]; const size_t last = (size_t)C;      // every chunk but the last one is full
+                ok = hipMemcpyAsync(s.dKp.p, q.dKp.as<sslam_keypoint>() + last * cap, sizeof(sslam_keypoint) * (size_t)cap, hipMemcpyDeviceToDevice, stP) == hipSuccess &&
+                     hipMemcpyAsync(s.dDesc.p, q.dDesc.as<uint8_t>() + 32 * last * cap, 32 * (size_t)cap, hipMemcpyDeviceToDevice, stP) == hipSuccess &&
+                     hipMemcpyAsync(s.dN.p, q.dN.as<int32_t>() + last, 4, hipMemcpyDeviceToDevice, stP) == hipSuccess;
+                if (ok && lines) ok = hipMemcpyAsync(s.dLd.p, q.dLd.as<uint8_t>() + 32 * last * lcap, 32 * (size_t)lcap, hipMemcpyDeviceToDevice, stLn) == hipSuccess &&
+                                      hipMemcpyAsync(s.dNl.p, q.dNl.as<int32_t>() + last, 4, hipMemcpyDeviceToDevice, stLn) == hipSuccess;
+            }
+            if (!ok) { set_error("%s: carrying the previous frame failed", fn); rc = SSLAM_ERR_HIP; break; }
+        }
         // line branch first: its call records the core event; the point branch then waits for that event and runs under the latency-bound core
-        if (lines && (rc = sslam_lines_extract_batch_dev(lines, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, s.dKl.as<sslam_keyline>(), s.dLd.as<uint8_t>(), s.dFn.as<double>(),
-                                                         s.dNl.as<int32_t>(), lcap, stLn))) break;
+        if (lines && (rc = sslam_lines_extract_batch_dev(lines, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, s.dKl.as<sslam_keyline>(), dLd, s.dFn.as<double>(), dNl, lcap, stLn))) break;
         if (lines && (rc = sslam_lines_batch_status_dev(lines, lcap, s.dStatus.as<int32_t>() + 4, stLn))) break;
-        if (twoStreams && (hipEventRecord(s.evLines, stL) != hipSuccess || hipStreamWaitEvent(stP, B.evCore, 0) != hipSuccess)) { set_error("sslam_frontend_batch: event failed"); rc = SSLAM_ERR_HIP; break; }
-        if ((rc = sslam_orb_extract_batch_dev(orb, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, s.dKp.as<sslam_keypoint>(), s.dDesc.as<uint8_t>(), s.dN.as<int32_t>(), cap, stP))) break;
+        if (lmatch && (rc = sslam_line_match_batch_dev(ctx, s.dLd.as<uint8_t>(), s.dNl.as<int32_t>(), dLd, dNl, lcap, c, M->line_gate_scale, M->line_ratio_mode,
+                                                       s.dLp.as<int32_t>(), s.dNlp.as<int32_t>(), stLn))) break;
+        if (twoStreams && (hipEventRecord(s.evLines, stL) != hipSuccess || hipStreamWaitEvent(stP, B.evCore, 0) != hipSuccess)) { set_error("%s: event failed", fn); rc = SSLAM_ERR_HIP; break; }
+        if ((rc = sslam_orb_extract_batch_dev(orb, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, dKp, dDesc, dN, cap, stP))) break;
         if ((rc = sslam_orb_batch_status_dev(orb, cap, s.dStatus.as<int32_t>(), stP))) break;
+        if (M) {      // previous frame = F1 (query), current frame = F2 (train), as Tracking::MonocularInitialization calls it (src/Tracking.cc:330-345)
+            const size_t rows = (size_t)c * cap;
+            hipLaunchKernelGGL(k_prev_matched_init, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stP, s.dKp.as<sslam_keypoint>(), rows, s.dPm.as<float2>());
+            if (hipGetLastError() != hipSuccess) { set_error("%s: launch failed", fn); rc = SSLAM_ERR_HIP; break; }
+            if ((rc = sslam_orb_search_for_initialization_batch_dev(ctx, s.dKp.as<sslam_keypoint>(), s.dDesc.as<uint8_t>(), s.dN.as<int32_t>(), dKp, dDesc, dN, cap, c, s.dPm.as<float>(),
+                                                                    s.dM12.as<int32_t>(), s.dNm.as<int32_t>(), M->window_size, M->nnratio, M->check_orientation, M->bounds, stP))) break;
+            if (knn && (rc = sslam_hamming_knn2_batch_dev(ctx, s.dDesc.as<uint8_t>(), s.dN.as<int32_t>(), dDesc, dN, cap, c, s.dKnnI.as<int32_t>(), s.dKnnD.as<int32_t>(), stP))) break;
+        }
         if (hipEventRecord(s.evPoint, stP) != hipSuccess || hipStreamWaitEvent(cpOut, s.evPoint, 0) != hipSuccess ||
-            (twoStreams && hipStreamWaitEvent(cpOut, s.evLines, 0) != hipSuccess)) { set_error("sslam_frontend_batch: event failed"); rc = SSLAM_ERR_HIP; break; }
+            (twoStreams && hipStreamWaitEvent(cpOut, s.evLines, 0) != hipSuccess)) { set_error("%s: event failed", fn); rc = SSLAM_ERR_HIP; break; }
         // the next chunk's upload into the OTHER slot may start at once; this slot's input is overwritten only two chunks later, after drain()
         uint8_t* H = outDirect ? nullptr : s.hOut.as<uint8_t>();
         const size_t g = (size_t)f0;
-        void* tKp = outDirect ? (void*)(kp_out + g * cap) : (void*)(H + oKp);
-        void* tDesc = outDirect ? (void*)(desc_out + 32 * g * cap) : (void*)(H + oDesc);
-        void* tN = outDirect ? (void*)(nkp_out + g) : (void*)(H + oN);
-        bool ok = hipMemcpyAsync(tKp, s.dKp.p, sizeof(sslam_keypoint) * (size_t)c * cap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
-                  hipMemcpyAsync(tDesc, s.dDesc.p, 32 * (size_t)c * cap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
-                  hipMemcpyAsync(tN, s.dN.p, 4 * (size_t)c, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
-                  hipMemcpyAsync(s.hStatus.p, s.dStatus.p, 32, hipMemcpyDeviceToHost, cpOut) == hipSuccess;
-        if (ok && lines) {
-            void* tKl = outDirect ? (void*)(kl_out + g * lcap) : (void*)(H + oKl);
-            void* tLd = outDirect ? (void*)(ldesc_out + 32 * g * lcap) : (void*)(H + oLd);
-            void* tFn = outDirect ? (void*)(linefn_out + 3 * g * lcap) : (void*)(H + oFn);
-            void* tNl = outDirect ? (void*)(nl_out + g) : (void*)(H + oNl);
-            ok = hipMemcpyAsync(tKl, s.dKl.p, sizeof(sslam_keyline) * (size_t)c * lcap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
-                 hipMemcpyAsync(tLd, s.dLd.p, 32 * (size_t)c * lcap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
-                 hipMemcpyAsync(tFn, s.dFn.p, 24 * (size_t)c * lcap, hipMemcpyDeviceToHost, cpOut) == hipSuccess &&
-                 hipMemcpyAsync(tNl, s.dNl.p, 4 * (size_t)c, hipMemcpyDeviceToHost, cpOut) == hipSuccess;
+        bool ok = true;
+        auto down = [&](void* direct, size_t stageOff, const void* dev, size_t bytes) {
+            if (ok && bytes) ok = hipMemcpyAsync(outDirect ? direct : (void*)(H + stageOff), dev, bytes, hipMemcpyDeviceToHost, cpOut) == hipSuccess;
+        };
+        down(kp_out + g * cap, oKp, dKp, sizeof(sslam_keypoint) * (size_t)c * cap);
+        down(desc_out + 32 * g * cap, oDesc, dDesc, 32 * (size_t)c * cap);
+        down(nkp_out + g, oN, dN, 4 * (size_t)c);
+        if (ok) ok = hipMemcpyAsync(s.hStatus.p, s.dStatus.p, 32, hipMemcpyDeviceToHost, cpOut) == hipSuccess;
+        if (lines) {
+            down(kl_out + g * lcap, oKl, s.dKl.p, sizeof(sslam_keyline) * (size_t)c * lcap);
+            down(ldesc_out + 32 * g * lcap, oLd, dLd, 32 * (size_t)c * lcap);
+            down(linefn_out + 3 * g * lcap, oFn, s.dFn.p, 24 * (size_t)c * lcap);
+            down(nl_out + g, oNl, dNl, 4 * (size_t)c);
         }
-        if (!ok || hipEventRecord(s.evOut, cpOut) != hipSuccess) { set_error("sslam_frontend_batch: D2H failed"); rc = SSLAM_ERR_HIP; break; }
+        if (M) {
+            down(M->init_matches12 + g * cap, oM12, s.dM12.p, 4 * (size_t)c * cap);
+            down(M->init_nmatches + g, oNm, s.dNm.p, 4 * (size_t)c);
+            if (knn) { down(M->knn_idx + 2 * g * cap, oKi, s.dKnnI.p, 8 * (size_t)c * cap); down(M->knn_dist + 2 * g * cap, oKd, s.dKnnD.p, 8 * (size_t)c * cap); }
+            if (lmatch) { down(M->line_pairs + 2 * g * lcap, oLp, s.dLp.p, 8 * (size_t)c * lcap); down(M->line_npairs + g, oNlp, s.dNlp.p, 4 * (size_t)c); }
+        }
+        if (!ok || hipEventRecord(s.evOut, cpOut) != hipSuccess) { set_error("%s: D2H failed", fn); rc = SSLAM_ERR_HIP; break; }
         s.first = f0; s.count = c;
     }
     if (rc == SSLAM_OK) rc = drain(slot[k & 1]);          // older chunk first
@@ -211,6 +275,20 @@ extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const ui
     if (lines) (void)sslam_lines_set_core_event(lines, nullptr);
     for (int i = 0; i < 2; ++i) slot[i].count = 0;
     return rc != SSLAM_OK ? rc : firstStatus;
+}
+}  // namespace
+
+extern "C" int sslam_frontend_batch(sslam_orb* orb, sslam_lines* lines, const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride, int chunk,
+                                    sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
+                                    sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap) {
+    return batch_impl("sslam_frontend_batch", orb, lines, images, n, w, h, stride, image_stride, chunk, kp_out, desc_out, nkp_out, cap, kl_out, ldesc_out, linefn_out, nl_out, lcap, nullptr);
+}
+
+extern "C" int sslam_frontend_batch_match(sslam_orb* orb, sslam_lines* lines, const uint8_t* images, int n, int w, int h, size_t stride, size_t image_stride, int chunk,
+                                          sslam_keypoint* kp_out, uint8_t* desc_out, int32_t* nkp_out, int cap,
+                                          sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out, int32_t* nl_out, int lcap, const sslam_batch_match* match) {
+    if (!match) { set_error("sslam_frontend_batch_match: invalid arguments"); return SSLAM_ERR_INVALID; }
+    return batch_impl("sslam_frontend_batch_match", orb, lines, images, n, w, h, stride, image_stride, chunk, kp_out, desc_out, nkp_out, cap, kl_out, ldesc_out, linefn_out, nl_out, lcap, match);
 }
 
 // Releases the staging buffers, streams and events sslam_frontend_batch keeps per context between calls (they are also released with the context).

@@ -308,6 +308,43 @@ def frontend_batch_raw(orb, lines, images, out, chunk=0, lcap=None):
     return out
 
 
+class BatchMatch(C.Structure):
+    """sslam_batch_match (include/sslam_frontend.h)"""
+    _fields_ = [("window_size", C.c_int32), ("nnratio", C.c_float), ("check_orientation", C.c_int32), ("bounds", C.c_float * 4),
+                ("line_gate_scale", C.c_double), ("line_ratio_mode", C.c_int32),
+                ("init_matches12", C.c_void_p), ("init_nmatches", C.c_void_p), ("knn_idx", C.c_void_p), ("knn_dist", C.c_void_p),
+                ("line_pairs", C.c_void_p), ("line_npairs", C.c_void_p)]
+
+
+def frontend_batch_match_alloc(n, cap, lcap, pinned=False, knn=True):
+    """the match-stage arrays of sslam_frontend_batch_match: (init_matches12, init_nmatches, knn_idx, knn_dist, line_pairs, line_npairs)"""
+    def alloc(shape, dt):
+        if not pinned:
+            a = np.empty(shape, dt); a.view(np.uint8).reshape(-1)[::4096] = 0
+            return a
+        import torch
+        nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+        return torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True).numpy()[:nbytes].view(dt).reshape(shape)
+    return (alloc((n, cap), np.int32), alloc((n,), np.int32), alloc((n, cap, 2), np.int32) if knn else None, alloc((n, cap, 2), np.int32) if knn else None,
+            alloc((n, lcap, 2), np.int32), alloc((n,), np.int32))
+
+
+def frontend_batch_match_raw(orb, lines, images, out, mout, chunk=0, window=100, nnratio=0.9, check_orientation=True, bounds=None, line_gate_scale=0.5, line_ratio_mode=False):
+    """sslam_frontend_batch_match into arrays from frontend_batch_alloc / frontend_batch_match_alloc: frame i is matched against frame i-1"""
+    n, h, w = images.shape
+    kp, desc, nk, kl, ld, fn, nl = out
+    m12, nm, ki, kd, lp, nlp = mout
+    M = BatchMatch()
+    M.window_size = int(window); M.nnratio = float(nnratio); M.check_orientation = int(bool(check_orientation))
+    M.bounds = (C.c_float * 4)(*(bounds if bounds is not None else (0.0, float(w), 0.0, float(h))))
+    M.line_gate_scale = float(line_gate_scale); M.line_ratio_mode = int(bool(line_ratio_mode))
+    vp = lambda a: a.ctypes.data if a is not None else None
+    M.init_matches12 = vp(m12); M.init_nmatches = vp(nm); M.knn_idx = vp(ki); M.knn_dist = vp(kd); M.line_pairs = vp(lp); M.line_npairs = vp(nlp)
+    _chk(lib().sslam_frontend_batch_match(orb.h, lines.h if lines is not None else None, _p(images), n, w, h, C.c_size_t(w), C.c_size_t(w * h), int(chunk),
+                                          _p(kp), _p(desc), _p(nk), orb.cap, _p(kl), _p(ld), _p(fn), _p(nl), int(kl.shape[1]), C.byref(M)))
+    return out, mout
+
+
 def frontend_batch(orb, lines, images, chunk=0, max_lines=None, pinned=False):
     """sslam_frontend_batch: images = uint8 array [n, h, w] in HOST memory -> per-frame (keypoints, descriptors, keylines, line descriptors,
     line functions) lists; `lines` may be None (ORB only).  pinned=True allocates the result arrays in pinned memory (torch), so that the

@@ -179,3 +179,49 @@ def test_frontend_batch_host_buffers(fe, ctx, oracle):
     only = fe.frontend_batch(orb, None, frames[:5])                       # ORB only, one chunk
     np.testing.assert_array_equal(only[3][1], out[3][1]); assert len(only[3][2]) == 0
     orb.close(); lines.close()
+
+
+def test_frontend_batch_match_stage(fe, ctx, oracle):
+    """sslam_frontend_batch_match (BASELINE configs[2] through host buffers): frame i against frame i-1 of the call -- SearchForInitialization,
+    the dense 2-NN and the line matcher behind the chunked extraction.  23 frames in chunks of 6 (the predecessor of a chunk's first frame
+    comes from the chunk before): every pair must equal the single-call host matchers on the per-frame results, two pairs are checked
+    against the oracle directly, and the extraction half must equal sslam_frontend_batch."""
+    w, h, n = 256, 192, 23
+    base = synth_frame(7100, w, h, nshapes=18, nstrokes=5, noise=1.0)
+    frames = np.stack([np.roll(base, (i // 3, i), axis=(0, 1)) if i % 5 else synth_frame(7200 + i, w, h, nshapes=12 + i, nstrokes=i % 4, noise=1.0) for i in range(n)])
+    orb = fe.OrbExtractor(ctx, 400); lines = fe.LineExtractor(ctx, 80)
+    ref = fe.frontend_batch(orb, lines, frames, chunk=6)
+    for pinned in (False, True):
+        out = fe.frontend_batch_alloc(n, orb.cap, 80, pinned=pinned); mout = fe.frontend_batch_match_alloc(n, orb.cap, 80, pinned=pinned)
+        src = frames
+        if pinned:
+            pin = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True); pin.numpy()[:] = frames; src = pin.numpy()
+        fe.frontend_batch_match_raw(orb, lines, src, out, mout, chunk=6, bounds=(0.0, float(w), 0.0, float(h)))
+        kp, desc, nk, kl, ld, fn, nl = out
+        m12, nm, ki, kd, lp, nlp = mout
+        assert nm[0] == 0 and nlp[0] == 0
+        total = 0
+        for i in range(n):
+            np.testing.assert_array_equal(kp[i, :nk[i]].view(np.uint8), ref[i][0].view(np.uint8)); np.testing.assert_array_equal(desc[i, :nk[i]], ref[i][1])
+            np.testing.assert_array_equal(ld[i, :nl[i]], ref[i][3])
+            if i == 0:
+                continue
+            k1, d1, l1 = ref[i - 1][0], ref[i - 1][1], ref[i - 1][3]
+            k2, d2, l2 = ref[i][0], ref[i][1], ref[i][3]
+            pm = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+            em12, _, enm = ctx.search_for_initialization(k1, d1, k2, d2, pm, 100, 0.9, True, (0.0, float(w), 0.0, float(h)))
+            np.testing.assert_array_equal(m12[i, :len(k1)], em12); assert nm[i] == enm, i
+            eidx, edist = ctx.hamming_knn2(d1, d2)
+            np.testing.assert_array_equal(ki[i, :len(k1)], eidx); np.testing.assert_array_equal(kd[i, :len(k1)], edist)
+            ep, _, _ = ctx.line_match(l1, l2, 0.5, False)
+            assert nlp[i] == len(ep), i
+            np.testing.assert_array_equal(lp[i, :nlp[i]], ep)
+            total += enm
+            if i in (6, 13):      # chunk boundaries (6 | 12 | 18): the pair straddles two chunks for i = 6; against the oracle itself
+                om12, _, onm = oracle.search_for_initialization(k1, d1, k2, d2, pm, 100, 0.9, True, (0.0, float(w), 0.0, float(h)))
+                np.testing.assert_array_equal(m12[i, :len(k1)], om12); assert nm[i] == onm
+        assert total > 200
+    only = fe.frontend_batch_alloc(5, orb.cap, 1); monly = fe.frontend_batch_match_alloc(5, orb.cap, 1, knn=False)          # ORB only, no 2-NN, one chunk
+    fe.frontend_batch_match_raw(orb, None, frames[:5], only, monly)
+    np.testing.assert_array_equal(monly[0][3, :len(ref[2][0])], m12[3, :len(ref[2][0])])
+    orb.close(); lines.close()
