@@ -501,6 +501,9 @@ int sslam_lines_debug_segments(sslam_lines* ln, int frame, float* seg_out, int c
 /* Stage clocks of the sequential LSD core for frame `frame` of the last call (grow, rect, refine, radius reduction, total, ...): zeros unless
  * the library was built with -DSSLAM_LSD_CYCLES (tools/lsd_cycles.py). */
 int sslam_lines_debug_cycles(sslam_lines* ln, int frame, long long* out8);
+/* counters of the cluster form of the sequential core (one frame at a time, helper waves on several compute units) for frame `frame` of
+ * the last call; meaningful in builds with -DSSLAM_CL_CYCLES only (tools/cl_probe.py). */
+int sslam_lines_debug_cluster(sslam_lines* ln, int frame, long long* out8);
 
 #ifdef __cplusplus
 }

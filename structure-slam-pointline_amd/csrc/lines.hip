@@ -28,6 +28,7 @@ namespace {
 #include "lsd_align_win.h"
 #include "lsd_front.h"
 #include "lsd_regions.h"
+#include "lsd_cluster.h"
 #include "lsd_nfa.h"
 #include "lbd.h"
 
@@ -66,6 +67,8 @@ struct sslam_lines {
     int planW = 0, planH = 0;
     LsdPlan plan;
     DevBuf dWs, dTabs, dTaps, dLgam, dGtab;
+    size_t clFrame = 0;
+    DevBuf dCl;                     // cluster form of the sequential core (lsd_cluster.h): chunk headers, shared map and list arenas of up to 8 frames
     int wsFrames = 0, lastFrames = 0;
     hipEvent_t coreEvent = nullptr;          // sslam_lines_set_core_event
     int lastN = -1;                 // lines of the last sslam_lines_extract (still resident in dKl/dDesc)
@@ -181,7 +184,7 @@ extern "C" int sslam_lines_destroy(sslam_lines* L) {
     if (!L) return SSLAM_OK;
     (void)hipSetDevice(L->ctx->device);
     (void)hipStreamSynchronize(L->ctx->stream);
-    DevBuf* bufs[] = {&L->dWs, &L->dTabs, &L->dTaps, &L->dLgam, &L->dGtab, &L->dImg, &L->dKl, &L->dDesc, &L->dFn, &L->dCounts};
+    DevBuf* bufs[] = {&L->dWs, &L->dCl, &L->dTabs, &L->dTaps, &L->dLgam, &L->dGtab, &L->dImg, &L->dKl, &L->dDesc, &L->dFn, &L->dCounts};
     for (DevBuf* b : bufs) b->release();
     L->hOut.release();
     delete L;
@@ -257,7 +260,27 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         bool mw = nframes <= 256 && nHelpers >= 1;
         if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) { lone = e[0] == 'l' || e[0] == 'm'; mw = e[0] == 'm' && nHelpers >= 1; }      // experiment knob: "mw" / "lat" / "thr"
         if (const char* e = getenv("SSLAM_LSD_HELPERS")) nHelpers = std::max(1, std::min(nHelpers, atoi(e)));
-        if (mw) {
+        // Up to 8 frames (one per XCD) whose frame-wide bitmap fits the main wave's LDS: the cluster form -- helper waves on several compute
+        // units, results through global memory, monotonic pixel map (lsd_cluster.h).  SSLAM_LSD_CLUSTER=0 keeps the multi-wave form,
+        // SSLAM_CL_WGS = workgroups per frame (4 waves each), SSLAM_CL_WINDOW = how many chunks the helpers may run ahead.
+        bool cluster = nframes <= 8 && P.sw <= TorusFrame::XMASK + 1 && P.sh <= TorusFrame::YMASK + 1 && mw;
+        if (const char* e = getenv("SSLAM_LSD_CLUSTER")) cluster = cluster && atoi(e) != 0; else cluster = false;
+        if (cluster) {
+            int nWG = 8, window = 0, clShift = 1;
+            if (const char* e = getenv("SSLAM_CL_WGS")) nWG = std::max(1, std::min(CL_MAXWG, atoi(e)));
+            if (const char* e = getenv("SSLAM_CL_WINDOW")) window = std::max(-1, atoi(e)); else window = 48;      // in sub-chunks of 16 positions; -1: no helpers at all (the main wave alone)
+            if (const char* e = getenv("SSLAM_CL_SMAP")) clShift = atoi(e);
+            const int clSpecWords = clShift < 0 ? 0 : (((P.sw + (1 << clShift) - 1) >> clShift) * ((P.sh + (1 << clShift) - 1) >> clShift) + 31) / 32;
+            const size_t maxSubs = ((size_t)P.npx + CL_SUB - 1) / CL_SUB;
+            const size_t zeroBytes = 512 + ((maxSubs * sizeof(ClHdr) + 511) & ~(size_t)511) + 4 * (size_t)((clSpecWords + 127) & ~127);
+            const size_t clFrame = align_up(zeroBytes + 4 * (size_t)CL_ARENA * (CL_MAXWG * CL_WAVES), 4096);
+            L->clFrame = clFrame;
+            if (L->dCl.cap < clFrame * 8) { SSLAM_HIP(hipStreamSynchronize(st)); if ((rc = L->dCl.ensure(clFrame * 8))) return rc; }
+            for (int f = 0; f < nframes; ++f) SSLAM_HIP(hipMemsetAsync(L->dCl.as<uint8_t>() + (size_t)f * clFrame, 0, zeroBytes, st));
+            const size_t clLds = sizeof(unsigned) * ((size_t)QCAP + 4 + TorusFrame::WORDS + CL_SCAN + (size_t)CL_WAVES * (CL_LIST + MW_BM_WORDS));
+            SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
+            hipLaunchKernelGGL(k_lsd_regions_cl, dim3(8 * nWG), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
+        } else if (mw) {
             const size_t mwLds = lds + sizeof(unsigned) * ((size_t)nHelpers * ((size_t)MW_RING + MW_BM_WORDS) + specWords);
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_mw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mwLds));
             hipLaunchKernelGGL(k_lsd_regions_mw, dim3(nframes), dim3(64 * (1 + MW_HMAX)), mwLds, st, ws, P, nHelpers, specWords, specShift);
@@ -386,6 +409,17 @@ extern "C" int sslam_lines_debug_cycles(sslam_lines* L, int frame, long long* ou
     Misc m;
     SSLAM_HIP(hipMemcpy(&m, L->dWs.as<uint8_t>() + (size_t)frame * P.frameBytes + P.offMisc, sizeof(m), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) out8[i] = m.cyc[i];
+    return SSLAM_OK;
+}
+
+// counters of the cluster form's helpers for frame `frame` of the last call (lsd_cluster.h, ClCtl::stat; filled by builds with -DSSLAM_CL_CYCLES)
+extern "C" int sslam_lines_debug_cluster(sslam_lines* L, int frame, long long* out8) {
+    if (!L || frame < 0 || frame >= 8 || !out8 || !L->dCl.p || !L->clFrame) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(L->ctx->device));
+    SSLAM_HIP(hipDeviceSynchronize());
+    ClCtl c;
+    SSLAM_HIP(hipMemcpy(&c, L->dCl.as<uint8_t>() + (size_t)frame * L->clFrame, sizeof(c), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out8[i] = c.stat[i];
     return SSLAM_OK;
 }
 

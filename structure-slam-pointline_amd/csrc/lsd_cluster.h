@@ -1,0 +1,490 @@
+// LSD sequential core, CLUSTER form: one frame at a time with helper waves on SEVERAL compute units.  Part of lines.hip (included after
+// lsd_regions.h, same anonymous namespace).  Not a standalone header.
+//
+// The multi-wave form (lsd_regions.h) keeps everything in one workgroup's LDS and is bound by what six helper waves next to
+// the main wave can grow (they are busy 99 % of the frame; the main wave waits for them a quarter of its time and grows what they could
+// not provide -- results full, ring full, reach of the 256 x 256 torus -- itself).  This form takes the helpers out of the main wave's
+// workgroup: a frame owns the workgroups  blockIdx % 8 == frame  (observed dispatch rule: those share an XCD and its L2; nothing below
+// depends on it for correctness), four waves each, wave 0 of the first one is the MAIN wave, every other wave a helper.  Shared state
+// lives in global memory.
+//
+// Protocol (what is different from the multi-wave form):
+//   * THE PIXEL MAP IS MONOTONIC.  The main wave never releases a pixel in it: a seed it has to grow itself is grown on a private bitmap
+//     that covers the whole frame (MARK_PRIV), refine() / reduce_region_radius release and re-mark there, and only the pixels that end up
+//     USED are committed to the map.  A taken result commits its last list, as before.
+//   * Therefore a helper's view may be arbitrarily stale (its L1, another XCD's L2): a pixel it saw USED is used now; a pixel it saw unused
+//     and rejected by angle is rejected by the sequential run whatever its state; a pixel it accepted is in list A or B.  Check (b) of the
+//     multi-wave form -- every point of A and B is unused NOW, read by the main wave from its own map -- is the whole validation; there are
+//     no release events and no check (c).
+//   * Results travel through global memory with L1-bypassing (sc1) stores and loads on both sides: per chunk of 64 seed positions a header
+//     (state, flag = doneLane | nres << 8, up to CL_RES results) and per helper a bump-allocated arena for the lists (never reused within a
+//     frame: no ring, no waiting for space, unbounded run-ahead inside the window).  Publication order: lists, result record,
+//     s_waitcnt vmcnt(0), flag.  The main wave reads flag, then records, then lists.
+//   * Chunks are claimed in order by the helpers (global cursor, at most `window` chunks ahead of the main wave); a claim is a CAS on the
+//     header's state, and the main wave, arriving at a chunk nobody has started, CASes it for itself -- it never waits for a helper that is
+//     not there.  Every wait of the main wave is bounded.
+#pragma once
+
+constexpr int CL_SUB = 16, CL_NSUB = 64 / CL_SUB;      // helpers claim sub-chunks of 16 seed positions (four helpers share a chunk of the main wave: the dense head of the seed list is where it waits)
+constexpr int CL_RES = CL_SUB;             // results per sub-chunk header: one per position
+constexpr int CL_ARENA = 1 << 16;          // list words per helper per frame (MwRes::off is 16 bits)
+constexpr int CL_LIST = 3072;              // LDS words per helper for the region in progress (lists A, B, F and the rectangle)
+constexpr int CL_WAVES = 4;                // waves per workgroup (one per SIMD)
+constexpr int CL_MAXWG = 16;               // workgroups per frame at most
+constexpr int CL_SCAN = 2 * 64 * 4;          // LDS words of the main wave's look-ahead over the seed list (order entries + map values of one group of chunks)
+constexpr int CL_SPIN_LIMIT = 1 << 18;     // polls before the main wave stops waiting for a helper (each poll is an L2 round trip)
+struct alignas(16) ClHdr { int state, flag, pad[2]; MwRes res[CL_RES]; };      // per sub-chunk; state: 0 free, 1 the main wave's, 2 + h helper h's; flag = doneLane (0..16) | nres << 8
+static_assert(sizeof(ClHdr) == 16 + 20 * CL_RES, "sub-chunk header layout");
+struct ClCtl { int mainPos, finished, cursor, pad; long long stat[8]; };
+struct ClShared {
+    ClCtl* ctl; ClHdr* hdr; unsigned* arena; unsigned* specMap; int specW, specShift, nHelpers, window;
+    __device__ __forceinline__ int cell(int x, int y) const { return (y >> specShift) * specW + (x >> specShift); }
+};
+// L1-bypassing accesses (global_load / global_store ... sc1): served by the L2 / memory, which is where the other compute units' stores are
+__device__ __forceinline__ int g_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned g_ldu(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void g_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifdef SSLAM_CL_PLAIN_STORES      // measurement knob: result stores stay in the XCD's L2 (only correct while helpers and main wave share an XCD)
+__device__ __forceinline__ void g_stu(unsigned* p, unsigned v) { *(volatile unsigned*)p = v; }
+#else
+__device__ __forceinline__ void g_stu(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+__device__ __forceinline__ void cl_compiler_fence() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void cl_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ bool cl_spec(const ClShared& cl, int x, int y) {
+    if (cl.specShift < 0) return false;
+    const int c = cl.cell(x, y);
+    return (g_ldu(&cl.specMap[c >> 5]) >> (c & 31)) & 1u;
+}
+
+// stage clocks of the main wave (tools/cl_probe.py --cycles): compiled in with -DSSLAM_CL_CYCLES only
+#ifdef SSLAM_CL_CYCLES
+#define CL_CLK() __builtin_readcyclecounter()
+#define CL_STAT(i, v) do { if (lane == 0) atomicAdd((unsigned long long*)&ctl->stat[i], (unsigned long long)(v)); } while (0)
+#else
+#define CL_CLK() 0ll
+#define CL_STAT(i, v)
+#endif
+// ------------------------------------------------------------------ the main wave
+__device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsigned* __restrict__ qLds, unsigned* __restrict__ bmMain, unsigned* __restrict__ scanBuf,
+                        double* __restrict__ red, float4* __restrict__ seedStash, const ClShared& cl) {
+    typedef TorusFrame G;
+    const int lane = threadIdx.x & 63;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    Planes pl; pl.T = (float*)(base + P.offT); pl.Cs = (const float2*)(base + P.offCs); pl.S = (const int*)(base + P.offS); pl.tW = P.tW; pl.cW = P.cW;
+    const unsigned* order = (const unsigned*)(base + P.offOrder);
+    double* candOut = (double*)(base + P.offCand);
+    Misc* misc = (Misc*)(base + P.offMisc);
+    const int sw = P.sw, sh = P.sh;
+    RegQ rq; rq.lds = qLds; rq.glb = (unsigned*)(base + P.offReg);
+    const int nOrd = misc->nDefined;
+    const double prec = P.prec;
+    int nSeg = 0;
+    long long clTaken = 0, clOwn = 0, clBad = 0, clWait = 0, clOwnChunks = 0, clRefused = 0;
+    long long cWait = 0, cTake = 0, cOwn = 0, cRect = 0, clOwnRefused = 0;
+    const long long cStart = CL_CLK();
+    // The seed list is scanned CL_GROUP chunks at a time, one group ahead: order entries and their map values of group g + 1 are loaded
+    // while group g is processed (two dependent round trips per chunk were a fifth of the main wave's time -- most chunks hold no unused
+    // seed at all).  A value loaded early can be out of date; everything marked since its load lies inside the union of the boxes of
+    // the commits since (accCur), and only the candidates inside that box are read again.
+    constexpr int CL_GROUP = 4;
+    unsigned* scanIdx = scanBuf; float* scanT = (float*)(scanBuf + 64 * CL_GROUP);
+    unsigned nIdx[CL_GROUP]; float nT[CL_GROUP];
+    auto load_group = [&](int p0) {
+#pragma unroll
+        for (int j = 0; j < CL_GROUP; ++j) { const int q = p0 + 64 * j + lane; nIdx[j] = q < nOrd ? order[q] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int j = 0; j < CL_GROUP; ++j) nT[j] = nIdx[j] != 0xFFFFFFFFu ? pl.T[pl.ti(nIdx[j])] : NOTDEF_F;
+    };
+    load_group(0);
+    unsigned accCurLo = 0xFFFFFFFFu, accCurHi = 0u, accNextLo = 0xFFFFFFFFu, accNextHi = 0u;      // packed x | y << 16 minima / maxima; Lo > Hi: empty
+    bool accCurAny = false, accNextAny = false;
+    for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
+        const int gj = (pos0 >> 6) & (CL_GROUP - 1);
+        if (gj == 0) {
+#pragma unroll
+            for (int j = 0; j < CL_GROUP; ++j) { scanIdx[64 * j + lane] = nIdx[j]; scanT[64 * j + lane] = nT[j]; }      // (every lane reads back its own entries only)
+            accCurLo = accNextLo; accCurHi = accNextHi; accCurAny = accNextAny;
+            accNextLo = 0xFFFFFFFFu; accNextHi = 0u; accNextAny = false;
+            if (pos0 + 64 * CL_GROUP < nOrd) load_group(pos0 + 64 * CL_GROUP);
+        }
+        if (lane == 0) g_st(&cl.ctl->mainPos, pos0);
+        const unsigned idx = scanIdx[64 * gj + lane];
+        const bool have = idx != 0xFFFFFFFFu;
+        const int tiSeed = have ? pl.ti(idx) : 0;
+        float a0 = scanT[64 * gj + lane];
+        if (accCurAny) {
+            const int ix = (int)(idx & 0xFFFF), iy = (int)(idx >> 16);
+            if (have && t_free(a0) && ix >= (int)(accCurLo & 0xFFFF) && ix <= (int)(accCurHi & 0xFFFF) && iy >= (int)(accCurLo >> 16) && iy <= (int)(accCurHi >> 16)) a0 = pl.T[tiSeed];
+        }
+        unsigned long long unM = __ballot(t_free(a0));
+        if (!unM) continue;
+        bool stashReady = false;
+        auto fill_stash = [&]() {
+            const double ar = (double)a0 * DEG2RAD;
+            seedStash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float((int)idx));
+            stashReady = true;
+        };
+        // whose sub-chunks?  A helper that has started one owns it; the main wave claims the others (with unused seeds) for itself.  Lanes
+        // 0..3 fetch state and flag of the four headers in one round trip; lane l then holds record (l & 15) of sub-chunk (l >> 4).
+        ClHdr* H4 = &cl.hdr[(pos0 >> 6) * CL_NSUB];
+        const int mySub = lane >> 4, myK = lane & 15;
+        int stv = 1, flv = 0, nsv = 0;               // per sub-chunk, in lane s: state, last flag read, records loaded
+        {
+            const bool need = lane < CL_NSUB && ((unM >> (16 * lane)) & 0xFFFFull) != 0;
+            if (need) {
+                stv = g_ld(&H4[lane].state); flv = g_ld(&H4[lane].flag);
+                if (stv == 0) { stv = atomicCAS(&H4[lane].state, 0, 1); if (stv == 0) stv = 1; }
+                if (stv < 2) { flv = 0; ++clOwnChunks; }
+            }
+        }
+        cl_compiler_fence();
+        MwRes myRes; myRes.w0 = myRes.w1 = myRes.w2 = myRes.lo = myRes.hi = 0u;
+        auto load_records = [&](int s, int nres) {      // records [nsv_s, nres) of sub-chunk s (a record is complete before the flag counts it)
+            if (mySub == s && myK < nres) {
+                const unsigned* r = (const unsigned*)&H4[s].res[myK];
+                myRes.w0 = g_ldu(r); myRes.w1 = g_ldu(r + 1); myRes.w2 = g_ldu(r + 2); myRes.lo = g_ldu(r + 3); myRes.hi = g_ldu(r + 4);
+            }
+            if (lane == s) nsv = nres;
+        };
+        {   // what is published already, all four sub-chunks at once
+            const int f0 = __builtin_amdgcn_readlane(flv, 0), f1 = __builtin_amdgcn_readlane(flv, 1), f2 = __builtin_amdgcn_readlane(flv, 2), f3 = __builtin_amdgcn_readlane(flv, 3);
+            const int myFlag = mySub == 0 ? f0 : mySub == 1 ? f1 : mySub == 2 ? f2 : f3;
+            const int myN = min(myFlag >> 8, CL_RES);
+            if (myK < myN) {
+                const unsigned* r = (const unsigned*)&H4[mySub].res[myK];
+                myRes.w0 = g_ldu(r); myRes.w1 = g_ldu(r + 1); myRes.w2 = g_ldu(r + 2); myRes.lo = g_ldu(r + 3); myRes.hi = g_ldu(r + 4);
+            }
+            if (lane < CL_NSUB) nsv = min(flv >> 8, CL_RES);
+        }
+        while (unM) {
+            const int first = __ffsll((long long)unM) - 1;
+            unM &= unM - 1;
+            const int s = first >> 4, f16 = first & 15;
+            ClHdr* H = &H4[s];
+            const int stS = __builtin_amdgcn_readlane(stv, s);
+            int owner = stS >= 2 ? stS - 2 : -1;
+            int flag = __builtin_amdgcn_readlane(flv, s);
+            float4 sd = make_float4(0.f, 0.f, 0.f, 0.f);
+            double regAngle = 0;
+            int n = -1;
+            bool took = false, tookEmit = false; RectD tookRec;
+            unsigned e0 = 0u;                            // lane i: point i of a taken region's first list (i < 64)
+            bool wasRefused = false;
+            unsigned bxLo = 0u, bxHi = 0xFFFFFFFFu;
+            const long long c0 = CL_CLK();
+            if (owner >= 0) {
+                int spin = 0;
+                while ((flag & 0xFF) <= f16) {
+                    flag = __builtin_amdgcn_readfirstlane(g_ld(&H->flag));
+                    if ((flag & 0xFF) > f16) break;
+                    if (++spin > CL_SPIN_LIMIT) { owner = -1; ++clBad; if (lane == s) stv = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                clWait += spin;
+                if (lane == s) flv = flag;
+            }
+            const long long c1 = CL_CLK(); cWait += c1 - c0;
+            if (owner >= 0) {
+                cl_compiler_fence();
+                int nres = min(flag >> 8, CL_RES);
+                if (nres > __builtin_amdgcn_readlane(nsv, s)) load_records(s, nres);
+                unsigned long long hit = __ballot(mySub == s && myK < nres && myRes.lane() == first);
+                if (!hit && nres < CL_RES) {                // nothing for this seed: a second look of the helper may have added it since the flag was read
+                    flag = __builtin_amdgcn_readfirstlane(g_ld(&H->flag));
+                    if (lane == s) flv = flag;
+                    cl_compiler_fence();
+                    nres = min(flag >> 8, CL_RES);
+                    if (nres > __builtin_amdgcn_readlane(nsv, s)) {
+                        load_records(s, nres);
+                        hit = __ballot(mySub == s && myK < nres && myRes.lane() == first);
+                    }
+                }
+                if (hit) {
+                    const int hl = __ffsll((long long)hit) - 1;
+                    MwRes r;
+                    r.w0 = (unsigned)__builtin_amdgcn_readlane((int)myRes.w0, hl); r.w1 = (unsigned)__builtin_amdgcn_readlane((int)myRes.w1, hl);
+                    r.w2 = (unsigned)__builtin_amdgcn_readlane((int)myRes.w2, hl); r.lo = (unsigned)__builtin_amdgcn_readlane((int)myRes.lo, hl);
+                    r.hi = (unsigned)__builtin_amdgcn_readlane((int)myRes.hi, hl);
+                    const int nA = r.nA(), nB = r.nB(), nF = r.nF(), flags = r.flags();
+                    const unsigned* lstA = cl.arena + (size_t)owner * CL_ARENA + r.off();
+                    const unsigned* lstB = lstA + nA;
+                    const unsigned* lstF = (flags & MW_REDUCED) ? lstB + nB : (flags & MW_REFINED) ? lstB : lstA;
+                    bool ok = true;
+                    float v0 = 0.f; int ti0 = 0;
+                    // the rectangle's 24 words travel with the first list load (one round trip instead of two)
+                    const unsigned* rw = lstB + nB + ((flags & MW_REDUCED) ? nF : 0);
+                    const unsigned wv = ((flags & MW_EMIT) && lane < 24) ? g_ldu(rw + lane) : 0u;
+                    for (int bs = 0; ok && nA + nB > 1 && bs < nA + nB; bs += 64) {      // (b): everything the helper accepted on the way is unused now
+                        const int i = bs + lane;
+                        bool usedNow = false;
+                        if (i < nA + nB) { const unsigned e = g_ldu(lstA + i); const int ti = pl.ti(e); const float v = pl.T[ti]; usedNow = !t_free(v); if (bs == 0) { v0 = v; ti0 = ti; e0 = e; } }
+                        ok = __ballot(usedNow) == 0;
+                    }
+                    if (ok) {
+                        if (nA + nB == 1) { if (lane == first) pl.T[tiSeed] = t_used(a0); }
+                        else if (!(flags & MW_REFINED) && nF <= 64) { if (lane < nF) pl.T[ti0] = t_used(v0); }
+                        else for (int i = lane; i < nF; i += 64) { unsigned* t = pl.Tb() + pl.ti(g_ldu(lstF + i)); *t |= USED_BIT; }
+                        took = true; n = nA; bxLo = r.lo; bxHi = r.hi;
+                        tookEmit = (flags & MW_EMIT) != 0;
+                        if (tookEmit) {
+                            double* rd = (double*)&tookRec;
+#pragma unroll
+                            for (int j = 0; j < 12; ++j) rd[j] = __hiloint2double(__builtin_amdgcn_readlane((int)wv, 2 * j + 1), __builtin_amdgcn_readlane((int)wv, 2 * j));
+                        }
+                        clTaken += 1 + ((long long)n << 32);
+                    } else { ++clRefused; wasRefused = true; }
+                }
+            }
+            const long long c2 = CL_CLK(); cTake += c2 - c1;
+            if (n < 0) {      // the main wave's own growth: private marks, the map is written at commit time only
+                if (!stashReady) fill_stash();
+                sd = seedStash[first];
+                const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
+                n = region_grow_m<true, MARK_PRIV, G>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pl, rq, prec, regAngle, nullptr, bmMain);
+                clOwn += 1 + ((long long)n << 32);
+                if (wasRefused) clOwnRefused += 1 + ((long long)n << 32);
+            }
+            const long long c3 = CL_CLK(); cOwn += c3 - c2;
+            RectD rec;
+            bool emit = false;
+            const bool tooSmall = n < P.minRegSize;       // (of the region as first grown: refine() may shrink a kept region below the minimum)
+            if (took) {
+                if (!tooSmall) { emit = tookEmit; rec = tookRec; }
+            } else {
+                if (!tooSmall) {
+                    bool refined = false; unsigned evLo = 0xFFFFFFFFu, evHi = 0u;
+                    long long cycs[3] = {0, 0, 0};
+                    SpecLists sl; sl.bm = bmMain; sl.free = nullptr; sl.cap = 0; sl.nB = 0; sl.reduced = false; sl.gaveUp = false;
+                    emit = rect_refine<true, MARK_PRIV, false, G>(P, sd, n, regAngle, rq, pl, red, rec, refined, evLo, evHi, cycs, &sl, nullptr);
+                }
+                // commit: what is left in the list stays USED (a region below the minimum size, a region refine() gave up on: all of it)
+                for (int i = lane; i < n; i += 64) {
+                    const unsigned e = rq.get_n(i, n);
+                    const int px = (int)(e & 0xFFFF), py = (int)(e >> 16);
+                    unsigned* t = pl.Tb() + pl.ti(px, py); *t |= USED_BIT;
+                    const int bi = bm_bit<G>(px, py); atomicAnd(&bmMain[bi >> 5], ~(1u << (bi & 31)));
+                }
+                if (n <= QCAP) list_bbox(rq.lds, n, lane, bxLo, bxHi); else { bxLo = 0u; bxHi = 0xFFFFFFFFu; }
+            }
+            if (!took) cRect += CL_CLK() - c3;
+            accCurLo = pk_min_u16(accCurLo, bxLo); accCurHi = pk_max_u16(accCurHi, bxHi); accNextLo = pk_min_u16(accNextLo, bxLo); accNextHi = pk_max_u16(accNextHi, bxHi);
+            accCurAny = accNextAny = true;
+            if (tooSmall) {
+                // too small: rejected, its pixels stay used.  Which candidates of this chunk did it take?
+                for (int k = 1; k < n; ++k) {
+                    const unsigned e = took ? (unsigned)__builtin_amdgcn_readlane((int)e0, k) : rq.lds[k];      // (minRegSize < 64)
+                    unM &= ~__ballot(idx == e);
+                }
+                continue;
+            }
+            {   // candidates of this chunk inside the box of what was just marked: are they still unused?
+                const int ix = (int)(idx & 0xFFFF), iy = (int)(idx >> 16);
+                const bool chk = have && ((unM >> lane) & 1ull) && ix >= (int)(bxLo & 0xFFFF) && ix <= (int)(bxHi & 0xFFFF) && iy >= (int)(bxLo >> 16) && iy <= (int)(bxHi >> 16);
+                bool usedNow = false;
+                if (chk) usedNow = !t_free(pl.T[tiSeed]);
+                unM &= ~__ballot(usedNow);
+            }
+            if (!emit) continue;
+            if (nSeg < MAX_SEG && lane == 0) {
+                double* o = candOut + (size_t)nSeg * 12;
+                o[0] = rec.x1; o[1] = rec.y1; o[2] = rec.x2; o[3] = rec.y2; o[4] = rec.width; o[5] = rec.x; o[6] = rec.y;
+                o[7] = rec.theta; o[8] = rec.dx; o[9] = rec.dy; o[10] = rec.prec; o[11] = rec.p;
+            }
+            ++nSeg;
+        }
+    }
+    if (lane == 0) {
+        g_st(&cl.ctl->finished, 1);
+        misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
+        misc->cyc[0] = clWait; misc->cyc[1] = clOwnChunks; misc->cyc[2] = clRefused; misc->cyc[3] = 0; misc->cyc[4] = 0;
+#ifdef SSLAM_CL_CYCLES
+        misc->cyc[0] = cWait; misc->cyc[1] = cTake; misc->cyc[2] = cOwn; misc->cyc[3] = cRect; misc->cyc[4] = CL_CLK() - cStart;
+        cl.ctl->stat[4] = clOwnRefused; cl.ctl->stat[5] = clOwn;
+#endif
+        misc->cyc[5] = clTaken; misc->cyc[6] = clOwn; misc->cyc[7] = clBad;
+    }
+}
+
+// ------------------------------------------------------------------ a helper wave
+// Claims a chunk, grows its unused seeds in order (each seed on its own, on its view of the pixel map + private marks), publishes.  While
+// it cannot claim another chunk (window) and the main wave is still in front of this one it looks at the chunk again: whatever is unused by
+// then and has no result -- seeds the shared map had talked it out of, seeds it gave up on -- is grown as well.  What its results would mark
+// stays in the shared map until the main wave has passed the chunk (reap).
+constexpr int CL_FIFO = 16;                // chunks a helper can have published and not yet retired from the shared map
+__device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int b, const ClShared& cl, unsigned* __restrict__ listBuf, unsigned* __restrict__ bm,
+                          float4* __restrict__ stash, double* __restrict__ red) {
+    typedef TorusHelper G;
+    const int lane = threadIdx.x & 63;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    Planes pl; pl.T = (float*)(base + P.offT); pl.Cs = (const float2*)(base + P.offCs); pl.S = (const int*)(base + P.offS); pl.tW = P.tW; pl.cW = P.cW;
+    const unsigned* order = (const unsigned*)(base + P.offOrder);
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int sw = P.sw, sh = P.sh, nOrd = misc->nDefined, nSubs = (nOrd + CL_SUB - 1) / CL_SUB;
+    ClCtl* ctl = cl.ctl;
+    unsigned* arena = cl.arena + (size_t)h * CL_ARENA;
+    int ah = 0;                                                   // arena words used
+    if (cl.window < 0) return;                                    // (test knob: the main wave alone)
+    constexpr int LISTCAP = CL_LIST - CL_FIFO;                    // the tail of the list buffer holds the FIFO of published chunks: chunk << 8 | results
+    unsigned* fifo = listBuf + LISTCAP;
+    int fHead = 0, fTail = 0;                                     // [fTail, fHead) outstanding
+    // retire the chunks the main wave has passed: their regions leave the shared map
+    auto reap = [&]() {
+        if (cl.specShift < 0) { fTail = fHead; return; }
+        const int mc = g_ld(&ctl->mainPos) >> 6;
+        while (fTail < fHead) {
+            const unsigned ent = fifo[fTail & (CL_FIFO - 1)];
+            const int sc = (int)(ent >> 8), k = (int)(ent & 0xFF);
+            if (sc / CL_NSUB >= mc && !g_ld(&ctl->finished)) break;
+            const ClHdr* H = &cl.hdr[sc];
+            for (int kk = 0; kk < k; ++kk) {
+                const unsigned* r = (const unsigned*)&H->res[kk];
+                MwRes R; R.w0 = g_ldu(r); R.w1 = g_ldu(r + 1); R.w2 = g_ldu(r + 2); R.lo = 0; R.hi = 0;
+                const unsigned* lstF = arena + R.off() + ((R.flags() & MW_REDUCED) ? R.nA() + R.nB() : (R.flags() & MW_REFINED) ? R.nA() : 0);
+                for (int i = lane; i < R.nF(); i += 64) { const unsigned e = g_ldu(lstF + i); const int clc = cl.cell((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&cl.specMap[clc >> 5], ~(1u << (clc & 31))); }
+            }
+            ++fTail;
+        }
+    };
+    for (;;) {
+        // ---- the next chunk nobody has, not further than `window` chunks in front of the main wave
+        int sc = 0;                                               // the sub-chunk; c = the main wave's chunk it belongs to
+        if (lane == 0) sc = atomicAdd(&ctl->cursor, 1);
+        sc = __builtin_amdgcn_readfirstlane(sc);
+        const int c = sc / CL_NSUB;
+        if (sc >= nSubs) { for (int spin = 0; fTail < fHead && spin < (1 << 20) && !g_ld(&ctl->finished); ++spin) { reap(); __builtin_amdgcn_s_sleep(16); } return; }
+        bool gone = false;
+        for (int spin = 0;; ++spin) {
+            if (g_ld(&ctl->finished)) return;
+            reap();
+            const int mc = g_ld(&ctl->mainPos) >> 6;
+            if (c < mc) { gone = true; if (lane == 0) atomicMax(&ctl->cursor, mc * CL_NSUB); break; }      // the main wave is already past it: the cursor jumps to where it is
+            if (sc <= mc * CL_NSUB + cl.window && fHead - fTail < CL_FIFO) break;
+            if (spin > (1 << 22)) return;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (gone) continue;
+        ClHdr* H = &cl.hdr[sc];
+        int got = 0;
+        if (lane == 0) got = atomicCAS(&H->state, 0, 2 + h);
+        if (__builtin_amdgcn_readfirstlane(got) != 0) continue;  // the main wave took it
+        // ---- the sub-chunk's seed candidates (lanes 0..15)
+        const int q = sc * CL_SUB + lane, laneBase = (sc % CL_NSUB) * CL_SUB;      // results are numbered by the lane of the main wave's chunk
+        const bool have = lane < CL_SUB && q < nOrd;
+        const unsigned idx = have ? order[q] : 0u;
+        const int cy = idx >> 16, cx = idx & 0xFFFF, tiSeed = pl.ti(idx);
+        unsigned long long haveRes = 0;      // seeds with a result, or that this helper gave up on
+        int k = 0; bool room = true;
+        for (int pass = 0; room; ++pass) {
+            if (pass > 0) {
+                // another look only while there is nothing else to do (the next chunk is outside the window) and the main wave is still in front
+                reap();
+                const int mp = g_ld(&ctl->mainPos);
+                if (mp >= c * 64 || g_ld(&ctl->finished)) break;
+                if (g_ld(&ctl->cursor) <= (mp >> 6) * CL_NSUB + cl.window && fHead - fTail < CL_FIFO - 1) break;
+                __builtin_amdgcn_s_sleep(8);
+                asm volatile("buffer_inv sc1" ::: "memory");
+            }
+            const float a0 = have ? pl.T[tiSeed] : NOTDEF_F;
+            unsigned long long unM = __ballot(t_free(a0) && (pass > 0 || !cl_spec(cl, cx, cy))) & ~haveRes;
+            if (unM) {
+                const double ar = (double)a0 * DEG2RAD;
+                stash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
+            }
+            while (unM) {
+                if (g_ld(&ctl->mainPos) > c * 64 || g_ld(&ctl->finished)) { CL_STAT(3, 1 + __popcll(unM)); room = false; break; }      // the main wave has passed this chunk
+                const int first = __ffsll((long long)unM) - 1;
+                unM &= unM - 1;
+                const float4 sd = stash[first];
+                const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
+                asm volatile("buffer_inv sc1" ::: "memory");      // this compute unit's L1 may hold lines from before the main wave's latest marks: start from the L2's view
+                if (!t_free(pl.T[pl.ti(sx, sy)])) continue;       // taken since the chunk was scanned
+                if (pass == 0 && cl_spec(cl, sx, sy)) continue;   // ... or about to be
+                if (k >= CL_RES || ah + 3 * QCAP + 24 > CL_ARENA) { CL_STAT(0, 1 + __popcll(unM)); room = false; break; }      // no room left: the main wave grows the rest itself
+                RegQ rq; rq.lds = listBuf; rq.glb = nullptr;
+                double regAngle = 0;
+                const int capN = min(QCAP, LISTCAP - 24);
+                int n = region_grow_w<true, false, MARK_SPEC, G>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pl, rq, P.prec, regAngle, nullptr, bm, capN);
+                if (n < 0) {                                      // too long for a helper: release its marks, the main wave grows this one
+                    for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int bi = bm_bit<G>((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
+                    haveRes |= 1ull << first; CL_STAT(1, 1 + ((long long)(-n) << 32));
+                    continue;
+                }
+                const int nA = n;
+                unsigned* lstA = rq.lds;
+                SpecLists sl; sl.bm = bm; sl.free = lstA + nA; sl.cap = LISTCAP - 24 - nA; sl.nB = 0; sl.reduced = false; sl.gaveUp = false;
+                bool emit = false, refined = false; unsigned dLo = 0, dHi = 0; long long cycs[3];
+                RectD rec;
+                if (n >= P.minRegSize) {
+                    emit = rect_refine<true, MARK_SPEC, false, G>(P, sd, n, regAngle, rq, pl, red, rec, refined, dLo, dHi, cycs, &sl, nullptr);
+                    if (sl.gaveUp) { haveRes |= 1ull << first; CL_STAT(2, 1); continue; }      // its marks are released; the main wave handles this seed
+                }
+                // marks still set: the final list (rq.lds[0..n)).  They go -- the next region is grown on its own.
+                for (int i = lane; i < n; i += 64) { const unsigned e = rq.lds[i]; const int bi = bm_bit<G>((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
+                const int nAB = nA + sl.nB;
+                int total = nAB + (sl.reduced ? n : 0);
+                if (emit) {
+                    if (lane == 0) {
+                        int* rw = (int*)(lstA + total); const double* rd = (const double*)&rec;
+#pragma unroll
+                        for (int j = 0; j < 12; ++j) { rw[2 * j] = __double2loint(rd[j]); rw[2 * j + 1] = __double2hiint(rd[j]); }
+                    }
+                    total += 24;
+                }
+                unsigned lo, hi;
+                list_bbox(lstA, nAB, lane, lo, hi);
+                // ---- publish: lists, record, (stores complete), flag
+                for (int i = lane; i < total; i += 64) g_stu(arena + ah + i, lstA[i]);
+                if (lane == 0) {
+                    const unsigned flags = (refined ? MW_REFINED : 0) | (sl.reduced ? MW_REDUCED : 0) | (emit ? MW_EMIT : 0);
+                    unsigned* r = (unsigned*)&H->res[k];
+                    g_stu(r, (unsigned)(laneBase + first) | (flags << 8)); g_stu(r + 1, (unsigned)ah | ((unsigned)nA << 16)); g_stu(r + 2, (unsigned)sl.nB | ((unsigned)n << 16));
+                    g_stu(r + 3, lo); g_stu(r + 4, hi);
+                }
+                cl_stores_done();
+                ++k; ah += total; haveRes |= 1ull << first;
+                if (lane == 0) g_st(&H->flag, (pass == 0 ? first + 1 : CL_SUB) | (k << 8));
+                // what the region leaves USED enters the shared map that steers seed choice; candidates of this chunk inside it are dropped
+                if (cl.specShift >= 0) {
+                    for (int i = lane; i < n; i += 64) {
+                        const unsigned e = rq.lds[i]; const int clc = cl.cell((int)(e & 0xFFFF), (int)(e >> 16));
+                        atomicOr(&cl.specMap[clc >> 5], 1u << (clc & 31));
+                    }
+                    if (n > 1 && pass == 0) {
+                        cl_stores_done();
+                        unM &= ~__ballot(have && cl_spec(cl, cx, cy));
+                    }
+                }
+            }
+            if (pass == 0 && lane == 0) g_st(&H->flag, CL_SUB | (k << 8));
+        }
+        if (k > 0 && cl.specShift >= 0) { if (lane == 0) fifo[fHead & (CL_FIFO - 1)] = ((unsigned)sc << 8) | (unsigned)k; ++fHead; }
+    }
+}
+
+// One frame = the workgroups with blockIdx % 8 == frame (role = blockIdx / 8); dynamic LDS: per wave a list buffer of CL_LIST words and a
+// 256 x 256-bit torus, in front of them (role 0 only) the main wave's region queue and its frame-wide bitmap.
+__global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl(uint8_t* __restrict__ ws, LsdPlan P, uint8_t* __restrict__ clArea, size_t clFrameBytes, int nframes, int nWG,
+                                                                 int specWords, int specShift, int window) {
+    extern __shared__ __align__(16) unsigned dynLds[];
+    __shared__ double red[CL_WAVES][3 * 64];
+    __shared__ float4 stashes[CL_WAVES][64];
+    const int b = blockIdx.x & 7, role = blockIdx.x >> 3, wave = threadIdx.x >> 6;
+    if (b >= nframes) return;
+    uint8_t* area = clArea + (size_t)b * clFrameBytes;
+    ClShared cl;
+    cl.ctl = (ClCtl*)area;
+    const size_t maxSubs = ((size_t)P.npx + CL_SUB - 1) / CL_SUB;
+    cl.hdr = (ClHdr*)(area + 512);
+    cl.specMap = (unsigned*)(area + 512 + ((maxSubs * sizeof(ClHdr) + 511) & ~(size_t)511));
+    cl.arena = cl.specMap + ((specWords + 127) & ~127);
+    cl.specShift = specShift; cl.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
+    cl.nHelpers = nWG * CL_WAVES - 1; cl.window = window;
+    const int mainWords = role == 0 ? QCAP + 4 + TorusFrame::WORDS + CL_SCAN : 0;
+    unsigned* mine = dynLds + mainWords + (size_t)wave * (CL_LIST + MW_BM_WORDS);
+    for (int i = threadIdx.x & 63; i < MW_BM_WORDS; i += 64) mine[CL_LIST + i] = 0u;
+    if (role == 0) for (int i = threadIdx.x; i < TorusFrame::WORDS; i += blockDim.x) dynLds[QCAP + 4 + i] = 0u;
+    __syncthreads();
+    if (role == 0 && wave == 0) cl_main(ws, P, b, dynLds, dynLds + QCAP + 4, dynLds + QCAP + 4 + TorusFrame::WORDS, red[0], stashes[0], cl);
+    else cl_helper(role * CL_WAVES + wave - 1, ws, P, b, cl, mine, mine + CL_LIST, stashes[wave], red[wave]);
+}

@@ -28,6 +28,17 @@ __device__ __forceinline__ float t_used(float t) { return __int_as_float(__float
 // (tested neighbours: +-127) cannot alias on it; a helper abandons a region that reaches further and the main wave grows that one itself.
 constexpr int MW_BM_WORDS = 256 * 256 / 32, MW_REACH = 126;
 __device__ __forceinline__ int mw_bit(int x, int y) { return ((y & 255) << 8) | (x & 255); }
+// Where a growing region's marks live (template argument of region_grow_w / rect_refine / remove_far_points_lds):
+//   MARK_MAP   the pixel map itself (single-wave kernel, main wave of the multi-wave form);
+//   MARK_SPEC  a helper's private bitmap: lists A / B / F are all kept for the later validation, growth gives up beyond capN points or
+//              outside the bitmap's reach;
+//   MARK_PRIV  a private bitmap that covers the whole frame (main wave of the cluster form): lists are handled as with MARK_MAP, the pixel
+//              map is written once, when the outcome of the seed is committed -- pixels are never released in it.
+// G = the bitmap's geometry (a torus of XMASK+1 x YMASK+1 bits; REACH = how far from its seed a region may go before bits could alias).
+enum { MARK_MAP = 0, MARK_SPEC = 1, MARK_PRIV = 2 };
+struct TorusHelper { static constexpr int XMASK = 255, YMASK = 255, YSHIFT = 8, REACH = MW_REACH, WORDS = MW_BM_WORDS; };
+struct TorusFrame { static constexpr int XMASK = 1023, YMASK = 511, YSHIFT = 10, REACH = 1 << 20, WORDS = 1024 * 512 / 32; };      // no aliasing for frames up to 1024 x 512
+template <class G> __device__ __forceinline__ int bm_bit(int x, int y) { return ((y & G::YMASK) << G::YSHIFT) | (x & G::XMASK); }
 __device__ __forceinline__ double readlane_d(double v, int l) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
@@ -115,12 +126,13 @@ __global__ void k_selftest_region_div(unsigned long long seed, int iters, unsign
 #endif
 // SPEC (multi-wave form, lsd_regions_mw.h): a helper wave grows a region AHEAD of the frame's main wave.  It never writes the pixel map: the
 // pixels it takes are marked in its own bitmap `bm` (LDS), and it gives up (returns -n) when the list would outgrow `capN` points.
-template <bool LAT, bool WIDE, bool SPEC = false>
+template <bool LAT, bool WIDE, int MARK = MARK_MAP, class G = TorusHelper>
 __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos, float seedSin, int sw, int sh, const Planes& pl, const RegQ& rq,
                              double prec, double& regAngleOut, long long* __restrict__ verifyCnt, unsigned* __restrict__ bm = nullptr, int capN = 0) {
 #ifndef SSLAM_LSD_READLANE
 #define SSLAM_LSD_READLANE 0
 #endif
+    static_assert(MARK == MARK_MAP || LAT, "private marks are written by the lone-wave flavour only");
     constexpr bool RL = LAT || SSLAM_LSD_READLANE;      // broadcasts of the accepted lane: v_readlane for the lone wave, LDS permutes with six waves per SIMD (measured: 35.4 vs 37.2 ms)
     constexpr bool DRIFT = !WIDE && SSLAM_LSD_DRIFT;
     const int lane = threadIdx.x & 63;
@@ -129,7 +141,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
     float sumdx = seedCos, sumdy = seedSin;
     if (lane == 0) {
         rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16));
-        if (SPEC) { const int bi = mw_bit(seedX, seedY); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pl.T[pl.ti(seedX, seedY)] = t_used(seedDeg);
+        if (MARK) { const int bi = bm_bit<G>(seedX, seedY); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pl.T[pl.ti(seedX, seedY)] = t_used(seedDeg);
     }
     const int g = lane >> 3, k8 = lane & 7;             // group (queue slot) and neighbour slot (centre skipped)
     const int k = k8 + (k8 >= 4 ? 1 : 0);                // row-major 3x3 position 0..8 without 4
@@ -146,7 +158,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
     long long* cycStage = verifyCnt - 1;      // Misc::cyc[5..]: staging wait, accept loops, stagings (the NFA statistics of SSLAM_LSD_STATS use the same slots)
 #endif
     while (i < n) {
-        if (SPEC && n + 64 > capN) return -n;
+        if (MARK == MARK_SPEC && n + 64 > capN) return -n;
         const int np = min(8, n - i);
         // Lone wave: straight-line staging -- every lane loads (slots past the staged entries re-read the last entry, coordinates are
         // clamped into the image) and the three conditions (slot staged, neighbour inside the image, pixel neither NOTDEF nor USED) meet as
@@ -166,7 +178,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
             cs = pl.Cs[nidx];                            // (same row pitch: one index serves both planes)
             candM = __builtin_amdgcn_ballot_w64(t_free(tv)) & __builtin_amdgcn_ballot_w64((unsigned)xx < (unsigned)sw) &
                     __builtin_amdgcn_ballot_w64((unsigned)yy < (unsigned)sh) & (np == 8 ? ~0ull : ((1ull << (np * 8)) - 1));
-            if (SPEC) { const int bi = mw_bit(xx, yy); candM &= ~__builtin_amdgcn_ballot_w64((bm[bi >> 5] >> (bi & 31)) & 1u); }      // taken by this helper itself
+            if (MARK) { const int bi = bm_bit<G>(xx, yy); candM &= ~__builtin_amdgcn_ballot_w64((bm[bi >> 5] >> (bi & 31)) & 1u); }      // taken by this wave itself
         } else {
             bool cand = false;
             if (g < np) {
@@ -270,10 +282,10 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
             }
         }
         if (LAT && accMask != 0 && ((accMask >> lane) & 1ull)) {
-            if (SPEC) { const int bi = mw_bit(xx, yy); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pl.T[nidx] = t_used(tv);
+            if (MARK) { const int bi = bm_bit<G>(xx, yy); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pl.T[nidx] = t_used(tv);
             rq.set(nBefore + mbcnt(accMask), (unsigned)xx | ((unsigned)yy << 16));
         }
-        if (SPEC && __builtin_amdgcn_ballot_w64(((accMask >> lane) & 1ull) && (abs(xx - seedX) > MW_REACH || abs(yy - seedY) > MW_REACH))) return -n;      // leaves the torus
+        if (MARK == MARK_SPEC && __builtin_amdgcn_ballot_w64(((accMask >> lane) & 1ull) && (abs(xx - seedX) > G::REACH || abs(yy - seedY) > G::REACH))) return -n;      // leaves the torus
 #ifdef SSLAM_LSD_CYCLES
         if (verifyCnt) { const long long tS2 = __builtin_readcyclecounter(); cycStage[0] += tS1 - tS0; cycStage[1] += tS2 - tS1; cycStage[2] += 1; }
 #endif
@@ -284,12 +296,12 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
     return n;
 }
 
-template <bool LAT>
+template <bool LAT, int MARK = MARK_MAP, class G = TorusHelper>
 __device__ __forceinline__ int region_grow_m(int seedX, int seedY, float seedDeg, float seedCos, float seedSin, int sw, int sh, const Planes& pl, const RegQ& rq,
-                                             double prec, double& regAngleOut, long long* __restrict__ verifyCnt) {
+                                             double prec, double& regAngleOut, long long* __restrict__ verifyCnt, unsigned* __restrict__ bm = nullptr) {
     // the first growth runs at 22.5 degrees; refine()'s tolerance (two standard deviations of the angles) is normally smaller still
-    if (prec < 1.5) return region_grow_w<LAT, false>(seedX, seedY, seedDeg, seedCos, seedSin, sw, sh, pl, rq, prec, regAngleOut, verifyCnt);
-    return region_grow_w<LAT, true>(seedX, seedY, seedDeg, seedCos, seedSin, sw, sh, pl, rq, prec, regAngleOut, verifyCnt);
+    if (prec < 1.5) return region_grow_w<LAT, false, MARK, G>(seedX, seedY, seedDeg, seedCos, seedSin, sw, sh, pl, rq, prec, regAngleOut, verifyCnt, bm, 0);
+    return region_grow_w<LAT, true, MARK, G>(seedX, seedY, seedDeg, seedCos, seedSin, sw, sh, pl, rq, prec, regAngleOut, verifyCnt, bm, 0);
 }
 
 // Three fp64 running sums that must be folded strictly in region order (the reference adds point after point).  The wave
@@ -379,7 +391,7 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const int* __restri
 // receive -- in ascending order -- the kept points above K in descending order (checked against the sequential walk on 2*10^5 random
 // keep patterns before it was written down here, and by the parity tests since).  n/64 wave steps instead of n.
 // scratch: 1536 bytes of LDS (keep masks of <= 16 chunks, then the hole positions as u16: holes <= min(K, n - K) <= 512).
-template <bool SPEC = false>
+template <int MARK = MARK_MAP, class G = TorusHelper>
 __device__ int remove_far_points_lds(unsigned* __restrict__ q, int n, double xc, double yc, double radSq, const Planes& pl,
                                      void* scratch, unsigned* __restrict__ bm = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -396,7 +408,7 @@ __device__ int remove_far_points_lds(unsigned* __restrict__ q, int n, double xc,
             const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
             keep = !(d2 > radSq);
             if (!keep) {                                                          // NOTUSED again
-                if (SPEC) { const int bi = mw_bit(px, py); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
+                if (MARK) { const int bi = bm_bit<G>(px, py); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
                 else { unsigned* t = pl.Tb() + pl.ti(px, py); *t &= ~USED_BIT; }
             }
         }
@@ -529,7 +541,7 @@ __device__ __forceinline__ bool boxes_meet(unsigned lo, unsigned hi, unsigned el
 // entry and what is left USED on exit.  Main-wave form: releases and re-marks pixels in the pixel map (WANTBOX: the box of everything touched,
 // for the multi-wave event log).  SPEC form (helper wave): marks live in the private bitmap, the re-grown list goes BEHIND the first one in the
 // arena and reduce_region_radius works on a copy, so that everything the helper ever accepted can be validated later.
-template <bool LAT, bool SPEC, bool WANTBOX>
+template <bool LAT, int MARK, bool WANTBOX, class G = TorusHelper>
 __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& regAngle, RegQ& rq, const Planes& pl, double* __restrict__ red,
                             RectD& rec, bool& refined, unsigned& evLo, unsigned& evHi, long long* cycs, SpecLists* sl, long long* verifyCnt) {
     const int lane = threadIdx.x & 63;
@@ -555,7 +567,7 @@ __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& r
             const unsigned e = rq.get_n(i, n);
             const int px = e & 0xFFFF, py = e >> 16, id = pl.ti(px, py);
             const float aOrig = fabsf(pl.T[id]);      // the angle whatever the used bit says (a helper's view may be racing the main wave's marks)
-            if (SPEC) { const int bi = mw_bit(px, py); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
+            if (MARK) { const int bi = bm_bit<G>(px, py); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
             else pl.T[id] = aOrig;                  // NOTUSED again
             if (dist_d(xc, yc, (double)px, (double)py) < rec.width) { in = true; ad = angle_diff_signed((double)aOrig * DEG2RAD, ang_c); }
         }
@@ -567,18 +579,18 @@ __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& r
     const double sum = ordered_sums_get(SR, 0), s_sum = ordered_sums_get(SR, 1);
     const double mean_angle = sum / (double)cnt;
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)cnt + mean_angle * mean_angle);
-    if (SPEC) {
+    if (MARK == MARK_SPEC) {
         const int capN = min(QCAP, sl->cap);
         if (capN <= 64) { sl->gaveUp = true; return false; }
         rq.lds = sl->free;
-        n = tau < 1.5 ? region_grow_w<true, false, true>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pl, rq, tau, regAngle, nullptr, sl->bm, capN)
-                      : region_grow_w<true, true, true>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pl, rq, tau, regAngle, nullptr, sl->bm, capN);
+        n = tau < 1.5 ? region_grow_w<true, false, MARK_SPEC, G>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pl, rq, tau, regAngle, nullptr, sl->bm, capN)
+                      : region_grow_w<true, true, MARK_SPEC, G>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pl, rq, tau, regAngle, nullptr, sl->bm, capN);
         if (n < 0) {
-            for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
+            for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int bi = bm_bit<G>((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
             sl->gaveUp = true; return false;
         }
         sl->nB = n; sl->free += n; sl->cap -= n;
-    } else n = region_grow_m<LAT>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pl, rq, tau, regAngle, verifyCnt);
+    } else n = region_grow_m<LAT, MARK, G>(x0, y0, sd.x, sd.y, sd.z, sw, sh, pl, rq, tau, regAngle, verifyCnt, MARK ? sl->bm : nullptr);
     if (WANTBOX) {                                // the re-grown region can reach outside the first one, and reduce_region_radius releases from it
         unsigned l2, h2;
         if (n <= QCAP) { list_bbox(rq.lds, n, lane, l2, h2); evLo = pk_min_u16(evLo, l2); evHi = pk_max_u16(evHi, h2); } else { evLo = 0u; evHi = 0xFFFFFFFFu; }
@@ -588,9 +600,9 @@ __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& r
     density = (double)n / (dist_d(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     if (density < DENSITY_TH) {
         const long long tr0 = SSLAM_CLK();
-        if (SPEC) {                               // work on a copy: list B stays as grown
+        if (MARK == MARK_SPEC) {                  // work on a copy: list B stays as grown
             if (sl->cap < n) {
-                for (int i = lane; i < n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
+                for (int i = lane; i < n; i += 64) { const unsigned e = rq.lds[i]; const int bi = bm_bit<G>((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
                 sl->gaveUp = true; return false;
             }
             for (int i = lane; i < n; i += 64) sl->free[i] = rq.lds[i];
@@ -603,15 +615,19 @@ __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& r
         bool good = true;
         while (density < DENSITY_TH) {
             radSq *= 0.75 * 0.75;
-            if (SPEC) n = remove_far_points_lds<true>(rq.lds, n, xc, yc, radSq, pl, red, sl->bm);
-            else if (n <= QCAP) n = remove_far_points_lds<false>(rq.lds, n, xc, yc, radSq, pl, red);
+            if (MARK == MARK_SPEC) n = remove_far_points_lds<MARK_SPEC, G>(rq.lds, n, xc, yc, radSq, pl, red, sl->bm);
+            else if (n <= QCAP) n = remove_far_points_lds<MARK, G>(rq.lds, n, xc, yc, radSq, pl, red, MARK ? sl->bm : nullptr);
             else for (int i = 0; i < n; ++i) {
                 const unsigned e = rq.get(i);
                 const int px = e & 0xFFFF, py = e >> 16;
                 const double d2 = ((double)px - xc) * ((double)px - xc) + ((double)py - yc) * ((double)py - yc);
                 if (d2 > radSq) {
                     const unsigned last = rq.get(n - 1);
-                    if (lane == 0) { unsigned* t = pl.Tb() + pl.ti(px, py); *t &= ~USED_BIT; rq.set(i, last); }
+                    if (lane == 0) {
+                        if (MARK) { const int bi = bm_bit<G>(px, py); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
+                        else { unsigned* t = pl.Tb() + pl.ti(px, py); *t &= ~USED_BIT; }
+                        rq.set(i, last);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     --n; --i;
                 }
