@@ -258,22 +258,24 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             if (nHelpers >= std::min(MW_HMAX, 5) || specShift < 0) break;      // a coarser map rather than fewer helpers (large frames)
         }
         bool mw = nframes <= 256 && nHelpers >= 1;
-        if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) { lone = e[0] == 'l' || e[0] == 'm'; mw = e[0] == 'm' && nHelpers >= 1; }      // experiment knob: "mw" / "lat" / "thr"
+        if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) { lone = e[0] == 'l' || e[0] == 'm' || e[0] == 'c'; mw = (e[0] == 'm' || e[0] == 'c') && nHelpers >= 1; }      // experiment knob: "cl" / "mw" / "lat" / "thr"
         if (const char* e = getenv("SSLAM_LSD_HELPERS")) nHelpers = std::max(1, std::min(nHelpers, atoi(e)));
         // Up to 8 frames (one per XCD) whose frame-wide bitmap fits the main wave's LDS: the cluster form -- helper waves on several compute
-        // units, results through global memory, monotonic pixel map (lsd_cluster.h).  SSLAM_LSD_CLUSTER=0 keeps the multi-wave form,
-        // SSLAM_CL_WGS = workgroups per frame (4 waves each), SSLAM_CL_WINDOW = how many chunks the helpers may run ahead.
-        bool cluster = nframes <= 8 && P.sw <= TorusFrame::XMASK + 1 && P.sh <= TorusFrame::YMASK + 1 && mw;
-        if (const char* e = getenv("SSLAM_LSD_CLUSTER")) cluster = cluster && atoi(e) != 0; else cluster = false;
+        // units, results through global memory, monotonic pixel map (lsd_cluster.h).  SSLAM_LSD_CLUSTER=0 (or SSLAM_LSD_FLAVOUR=mw) keeps the
+        // multi-wave form; SSLAM_CL_WGS = workgroups per frame (4 waves each), SSLAM_CL_WINDOW = how many sub-chunks of 16 seed positions the
+        // helpers may run ahead, SSLAM_CL_SMAP = cell size (log2) of the shared map that steers their seed choice (-1: none).
+        bool cluster = nframes <= 8 && P.sw <= TorusFrame::XMASK + 1 && P.sh <= TorusFrame::YMASK + 1;
+        if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) cluster = cluster && e[0] == 'c';      // "cl" / "mw" / "lat" / "thr"
+        if (const char* e = getenv("SSLAM_LSD_CLUSTER")) cluster = cluster && atoi(e) != 0;
         if (cluster) {
-            int nWG = 8, window = 0, clShift = 1;
+            int nWG = 6, window = 0, clShift = 0;
             if (const char* e = getenv("SSLAM_CL_WGS")) nWG = std::max(1, std::min(CL_MAXWG, atoi(e)));
-            if (const char* e = getenv("SSLAM_CL_WINDOW")) window = std::max(-1, atoi(e)); else window = 48;      // in sub-chunks of 16 positions; -1: no helpers at all (the main wave alone)
+            if (const char* e = getenv("SSLAM_CL_WINDOW")) window = std::max(-1, atoi(e)); else window = 40;      // in sub-chunks of 16 positions; -1: no helpers at all (the main wave alone)
             if (const char* e = getenv("SSLAM_CL_SMAP")) clShift = atoi(e);
             const int clSpecWords = clShift < 0 ? 0 : (((P.sw + (1 << clShift) - 1) >> clShift) * ((P.sh + (1 << clShift) - 1) >> clShift) + 31) / 32;
             const size_t maxSubs = ((size_t)P.npx + CL_SUB - 1) / CL_SUB;
-            const size_t zeroBytes = 512 + ((maxSubs * sizeof(ClHdr) + 511) & ~(size_t)511) + 4 * (size_t)((clSpecWords + 127) & ~127);
-            const size_t clFrame = align_up(zeroBytes + 4 * (size_t)CL_ARENA * (CL_MAXWG * CL_WAVES), 4096);
+            const size_t zeroBytes = 512 + ((maxSubs * sizeof(ClSub) + 511) & ~(size_t)511) + 4 * (size_t)((clSpecWords + 127) & ~127);      // control block, sub-chunk states / flags, shared map
+            const size_t clFrame = align_up(zeroBytes + maxSubs * CL_RES * sizeof(ClRec) + 4 * (size_t)CL_ARENA * (CL_MAXWG * CL_WAVES), 4096);
             L->clFrame = clFrame;
             if (L->dCl.cap < clFrame * 8) { SSLAM_HIP(hipStreamSynchronize(st)); if ((rc = L->dCl.ensure(clFrame * 8))) return rc; }
             for (int f = 0; f < nframes; ++f) SSLAM_HIP(hipMemsetAsync(L->dCl.as<uint8_t>() + (size_t)f * clFrame, 0, zeroBytes, st));

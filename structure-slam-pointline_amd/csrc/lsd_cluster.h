@@ -33,11 +33,14 @@ constexpr int CL_WAVES = 4;                // waves per workgroup (one per SIMD)
 constexpr int CL_MAXWG = 16;               // workgroups per frame at most
 constexpr int CL_SCAN = 2 * 64 * 4;          // LDS words of the main wave's look-ahead over the seed list (order entries + map values of one group of chunks)
 constexpr int CL_SPIN_LIMIT = 1 << 18;     // polls before the main wave stops waiting for a helper (each poll is an L2 round trip)
-struct alignas(16) ClHdr { int state, flag, pad[2]; MwRes res[CL_RES]; };      // per sub-chunk; state: 0 free, 1 the main wave's, 2 + h helper h's; flag = doneLane (0..16) | nres << 8
-static_assert(sizeof(ClHdr) == 16 + 20 * CL_RES, "sub-chunk header layout");
+constexpr int CL_INL = 11;                 // points a result record carries itself: a region this small (and below the minimum region size: no rectangle, no refine) needs no list in the arena
+constexpr int MW_INLINE = 8;               // MwRes flag: the record's own points are the whole result
+struct ClSub { int state, flag; };         // per sub-chunk, zeroed per launch; state: 0 free, 1 the main wave's, 2 + h helper h's; flag = doneLane (0..16) | nres << 8
+struct alignas(16) ClRec { MwRes m; unsigned pts[CL_INL]; };      // 64 bytes; records of sub-chunk sc: rec[sc * CL_RES ..)
+static_assert(sizeof(ClRec) == 64, "result record layout");
 struct ClCtl { int mainPos, finished, cursor, pad; long long stat[8]; };
 struct ClShared {
-    ClCtl* ctl; ClHdr* hdr; unsigned* arena; unsigned* specMap; int specW, specShift, nHelpers, window;
+    ClCtl* ctl; ClSub* sub; ClRec* rec; unsigned* arena; unsigned* specMap; int specW, specShift, nHelpers, window;
     __device__ __forceinline__ int cell(int x, int y) const { return (y >> specShift) * specW + (x >> specShift); }
 };
 // L1-bypassing accesses (global_load / global_store ... sc1): served by the L2 / memory, which is where the other compute units' stores are
@@ -126,42 +129,64 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             stashReady = true;
         };
         // whose sub-chunks?  A helper that has started one owns it; the main wave claims the others (with unused seeds) for itself.  Lanes
-        // 0..3 fetch state and flag of the four headers in one round trip; lane l then holds record (l & 15) of sub-chunk (l >> 4).
-        ClHdr* H4 = &cl.hdr[(pos0 >> 6) * CL_NSUB];
+        // 0..3 fetch state and flag of the four headers in one round trip; lane l then holds record (l & 15) of sub-chunk (l >> 4) -- and,
+        // when the record carries its points itself (a small region: most of them), validates it ON ITS OWN: every lane gathers the map
+        // values of its record's points, all records of the chunk in one round trip, instead of one list load + one gather per take.
+        const int sc0 = (pos0 >> 6) * CL_NSUB;
+        ClSub* S4 = &cl.sub[sc0];
         const int mySub = lane >> 4, myK = lane & 15;
+        const ClRec* myRecPtr = &cl.rec[(size_t)(sc0 + mySub) * CL_RES + myK];
         int stv = 1, flv = 0, nsv = 0;               // per sub-chunk, in lane s: state, last flag read, records loaded
         {
             const bool need = lane < CL_NSUB && ((unM >> (16 * lane)) & 0xFFFFull) != 0;
             if (need) {
-                stv = g_ld(&H4[lane].state); flv = g_ld(&H4[lane].flag);
-                if (stv == 0) { stv = atomicCAS(&H4[lane].state, 0, 1); if (stv == 0) stv = 1; }
+                stv = g_ld(&S4[lane].state); flv = g_ld(&S4[lane].flag);
+                if (stv == 0) { stv = atomicCAS(&S4[lane].state, 0, 1); if (stv == 0) stv = 1; }
                 if (stv < 2) { flv = 0; ++clOwnChunks; }
             }
         }
         cl_compiler_fence();
         MwRes myRes; myRes.w0 = myRes.w1 = myRes.w2 = myRes.lo = myRes.hi = 0u;
-        auto load_records = [&](int s, int nres) {      // records [nsv_s, nres) of sub-chunk s (a record is complete before the flag counts it)
-            if (mySub == s && myK < nres) {
-                const unsigned* r = (const unsigned*)&H4[s].res[myK];
+        unsigned myP[CL_INL]; float myV[CL_INL];      // an inline record's points and their map values as last gathered
+#pragma unroll
+        for (int i = 0; i < CL_INL; ++i) { myP[i] = 0u; myV[i] = 0.f; }
+        int myOk = 0, myDirty = 0;                   // inline record: every point was unused at the last gather / a commit since may have touched it
+        auto gather_mine = [&]() {                   // (the calling lanes hold an inline record)
+            const int nA = (int)(myRes.w1 >> 16);
+            bool allFree = true;
+#pragma unroll
+            for (int i = 0; i < CL_INL; ++i) if (i < nA) myV[i] = pl.T[pl.ti(myP[i])];
+#pragma unroll
+            for (int i = 0; i < CL_INL; ++i) if (i < nA) allFree = allFree && t_free(myV[i]);
+            myOk = allFree ? 1 : 0; myDirty = 0;
+        };
+        auto fetch_records = [&](bool mine) {        // the calling lanes load their record (a record is complete before the flag counts it)
+            if (mine) {
+                const unsigned* r = (const unsigned*)myRecPtr;
                 myRes.w0 = g_ldu(r); myRes.w1 = g_ldu(r + 1); myRes.w2 = g_ldu(r + 2); myRes.lo = g_ldu(r + 3); myRes.hi = g_ldu(r + 4);
+#ifdef SSLAM_CL_INLINE
+#pragma unroll
+                for (int i = 0; i < CL_INL; ++i) myP[i] = g_ldu(r + 5 + i);
+                if (myRes.flags() & MW_INLINE) gather_mine();
+#endif
             }
-            if (lane == s) nsv = nres;
         };
         {   // what is published already, all four sub-chunks at once
             const int f0 = __builtin_amdgcn_readlane(flv, 0), f1 = __builtin_amdgcn_readlane(flv, 1), f2 = __builtin_amdgcn_readlane(flv, 2), f3 = __builtin_amdgcn_readlane(flv, 3);
             const int myFlag = mySub == 0 ? f0 : mySub == 1 ? f1 : mySub == 2 ? f2 : f3;
-            const int myN = min(myFlag >> 8, CL_RES);
-            if (myK < myN) {
-                const unsigned* r = (const unsigned*)&H4[mySub].res[myK];
-                myRes.w0 = g_ldu(r); myRes.w1 = g_ldu(r + 1); myRes.w2 = g_ldu(r + 2); myRes.lo = g_ldu(r + 3); myRes.hi = g_ldu(r + 4);
-            }
+            fetch_records(myK < min(myFlag >> 8, CL_RES));
             if (lane < CL_NSUB) nsv = min(flv >> 8, CL_RES);
         }
+        auto load_records = [&](int s, int nres) {      // records [nsv_s, nres) of sub-chunk s
+            const int had = __builtin_amdgcn_readlane(nsv, s);
+            fetch_records(mySub == s && myK >= had && myK < nres);
+            if (lane == s) nsv = nres;
+        };
         while (unM) {
             const int first = __ffsll((long long)unM) - 1;
             unM &= unM - 1;
             const int s = first >> 4, f16 = first & 15;
-            ClHdr* H = &H4[s];
+            ClSub* H = &S4[s];
             const int stS = __builtin_amdgcn_readlane(stv, s);
             int owner = stS >= 2 ? stS - 2 : -1;
             int flag = __builtin_amdgcn_readlane(flv, s);
@@ -170,7 +195,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             int n = -1;
             bool took = false, tookEmit = false; RectD tookRec;
             unsigned e0 = 0u;                            // lane i: point i of a taken region's first list (i < 64)
-            bool wasRefused = false;
+            bool wasRefused = false, tookInline = false; int tookLane = 0;
             unsigned bxLo = 0u, bxHi = 0xFFFFFFFFu;
             const long long c0 = CL_CLK();
             if (owner >= 0) {
@@ -207,6 +232,20 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                     r.w2 = (unsigned)__builtin_amdgcn_readlane((int)myRes.w2, hl); r.lo = (unsigned)__builtin_amdgcn_readlane((int)myRes.lo, hl);
                     r.hi = (unsigned)__builtin_amdgcn_readlane((int)myRes.hi, hl);
                     const int nA = r.nA(), nB = r.nB(), nF = r.nF(), flags = r.flags();
+                    if (flags & MW_INLINE) {
+                        // the holder lane has validated the record on its own; a commit since then that could have touched it set myDirty
+                        if (nA > 1 && __builtin_amdgcn_readlane(myDirty, hl)) { if (lane == hl) gather_mine(); }
+                        const bool ok = nA == 1 || __builtin_amdgcn_readlane(myOk, hl) != 0;      // (a region of one point is its seed, known to be unused)
+                        if (ok) {
+                            if (nA == 1) { if (lane == first) pl.T[tiSeed] = t_used(a0); }
+                            else if (lane == hl) {
+#pragma unroll
+                                for (int i = 0; i < CL_INL; ++i) if (i < nA) pl.T[pl.ti(myP[i])] = t_used(myV[i]);
+                            }
+                            took = true; tookInline = true; tookLane = hl; n = nA; bxLo = r.lo; bxHi = r.hi;
+                            clTaken += 1 + ((long long)n << 32);
+                        } else { ++clRefused; wasRefused = true; }
+                    } else {
                     const unsigned* lstA = cl.arena + (size_t)owner * CL_ARENA + r.off();
                     const unsigned* lstB = lstA + nA;
                     const unsigned* lstF = (flags & MW_REDUCED) ? lstB + nB : (flags & MW_REFINED) ? lstB : lstA;
@@ -234,6 +273,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                         }
                         clTaken += 1 + ((long long)n << 32);
                     } else { ++clRefused; wasRefused = true; }
+                    }
                 }
             }
             const long long c2 = CL_CLK(); cTake += c2 - c1;
@@ -270,9 +310,14 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             if (!took) cRect += CL_CLK() - c3;
             accCurLo = pk_min_u16(accCurLo, bxLo); accCurHi = pk_max_u16(accCurHi, bxHi); accNextLo = pk_min_u16(accNextLo, bxLo); accNextHi = pk_max_u16(accNextHi, bxHi);
             accCurAny = accNextAny = true;
+            // inline records waiting in the lanes: whatever this commit marked lies inside its box
+            if ((myRes.flags() & MW_INLINE) && boxes_meet(myRes.lo, myRes.hi, bxLo, bxHi, 0)) myDirty = 1;
             if (tooSmall) {
                 // too small: rejected, its pixels stay used.  Which candidates of this chunk did it take?
-                for (int k = 1; k < n; ++k) {
+                if (tookInline) {
+#pragma unroll
+                    for (int i = 1; i < CL_INL; ++i) if (i < n) unM &= ~__ballot(idx == (unsigned)__builtin_amdgcn_readlane((int)myP[i], tookLane));
+                } else for (int k = 1; k < n; ++k) {
                     const unsigned e = took ? (unsigned)__builtin_amdgcn_readlane((int)e0, k) : rq.lds[k];      // (minRegSize < 64)
                     unM &= ~__ballot(idx == e);
                 }
@@ -336,11 +381,10 @@ __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
             const unsigned ent = fifo[fTail & (CL_FIFO - 1)];
             const int sc = (int)(ent >> 8), k = (int)(ent & 0xFF);
             if (sc / CL_NSUB >= mc && !g_ld(&ctl->finished)) break;
-            const ClHdr* H = &cl.hdr[sc];
             for (int kk = 0; kk < k; ++kk) {
-                const unsigned* r = (const unsigned*)&H->res[kk];
+                const unsigned* r = (const unsigned*)&cl.rec[(size_t)sc * CL_RES + kk];
                 MwRes R; R.w0 = g_ldu(r); R.w1 = g_ldu(r + 1); R.w2 = g_ldu(r + 2); R.lo = 0; R.hi = 0;
-                const unsigned* lstF = arena + R.off() + ((R.flags() & MW_REDUCED) ? R.nA() + R.nB() : (R.flags() & MW_REFINED) ? R.nA() : 0);
+                const unsigned* lstF = (R.flags() & MW_INLINE) ? r + 5 : arena + R.off() + ((R.flags() & MW_REDUCED) ? R.nA() + R.nB() : (R.flags() & MW_REFINED) ? R.nA() : 0);
                 for (int i = lane; i < R.nF(); i += 64) { const unsigned e = g_ldu(lstF + i); const int clc = cl.cell((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&cl.specMap[clc >> 5], ~(1u << (clc & 31))); }
             }
             ++fTail;
@@ -364,7 +408,7 @@ __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
             __builtin_amdgcn_s_sleep(8);
         }
         if (gone) continue;
-        ClHdr* H = &cl.hdr[sc];
+        ClSub* H = &cl.sub[sc];
         int got = 0;
         if (lane == 0) got = atomicCAS(&H->state, 0, 2 + h);
         if (__builtin_amdgcn_readfirstlane(got) != 0) continue;  // the main wave took it
@@ -433,16 +477,31 @@ __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 }
                 unsigned lo, hi;
                 list_bbox(lstA, nAB, lane, lo, hi);
-                // ---- publish: lists, record, (stores complete), flag
-                for (int i = lane; i < total; i += 64) g_stu(arena + ah + i, lstA[i]);
-                if (lane == 0) {
-                    const unsigned flags = (refined ? MW_REFINED : 0) | (sl.reduced ? MW_REDUCED : 0) | (emit ? MW_EMIT : 0);
-                    unsigned* r = (unsigned*)&H->res[k];
-                    g_stu(r, (unsigned)(laneBase + first) | (flags << 8)); g_stu(r + 1, (unsigned)ah | ((unsigned)nA << 16)); g_stu(r + 2, (unsigned)sl.nB | ((unsigned)n << 16));
-                    g_stu(r + 3, lo); g_stu(r + 4, hi);
+                // ---- publish: lists (a small rejected region travels inside its record), record, (stores complete), flag
+                // -DSSLAM_CL_INLINE: a small rejected region travels inside its record and the main wave's lanes validate such records on their own,
+                // a whole chunk in one gather.  Measured and left off: the take path loses a round trip per small region (4.9 -> 4.1 M cycles per
+                // frame) but every chunk with unused seeds pays the sixteen-word record fetch and the gather up front (3.5 -> 5.3 M): 7.7 ms per
+                // frame against 7.4 without.  Kept because it is what a fully prefetched main wave would build on.
+#ifdef SSLAM_CL_INLINE
+                const bool inl = nA < P.minRegSize && nA <= CL_INL;      // (below the minimum size: no rectangle, no refine, the last list is the first)
+#else
+                const bool inl = false;
+#endif
+                if (!inl) for (int i = lane; i < total; i += 64) g_stu(arena + ah + i, lstA[i]);
+                {
+                    const unsigned flags = (refined ? MW_REFINED : 0) | (sl.reduced ? MW_REDUCED : 0) | (emit ? MW_EMIT : 0) | (inl ? MW_INLINE : 0);
+                    unsigned* r = (unsigned*)&cl.rec[(size_t)sc * CL_RES + k];
+                    unsigned w = 0u;
+                    if (lane == 0) w = (unsigned)(laneBase + first) | (flags << 8);
+                    else if (lane == 1) w = (unsigned)(inl ? 0 : ah) | ((unsigned)nA << 16);
+                    else if (lane == 2) w = (unsigned)sl.nB | ((unsigned)n << 16);
+                    else if (lane == 3) w = lo;
+                    else if (lane == 4) w = hi;
+                    else if (lane < 5 + CL_INL && inl && lane - 5 < nA) w = lstA[lane - 5];
+                    if (lane < 5 + CL_INL) g_stu(r + lane, w);
                 }
                 cl_stores_done();
-                ++k; ah += total; haveRes |= 1ull << first;
+                ++k; if (!inl) ah += total; haveRes |= 1ull << first;
                 if (lane == 0) g_st(&H->flag, (pass == 0 ? first + 1 : CL_SUB) | (k << 8));
                 // what the region leaves USED enters the shared map that steers seed choice; candidates of this chunk inside it are dropped
                 if (cl.specShift >= 0) {
@@ -475,9 +534,10 @@ __global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl(uint8_t* __res
     ClShared cl;
     cl.ctl = (ClCtl*)area;
     const size_t maxSubs = ((size_t)P.npx + CL_SUB - 1) / CL_SUB;
-    cl.hdr = (ClHdr*)(area + 512);
-    cl.specMap = (unsigned*)(area + 512 + ((maxSubs * sizeof(ClHdr) + 511) & ~(size_t)511));
-    cl.arena = cl.specMap + ((specWords + 127) & ~127);
+    cl.sub = (ClSub*)(area + 512);
+    cl.specMap = (unsigned*)(area + 512 + ((maxSubs * sizeof(ClSub) + 511) & ~(size_t)511));
+    cl.rec = (ClRec*)(cl.specMap + ((specWords + 127) & ~127));
+    cl.arena = (unsigned*)(cl.rec + maxSubs * CL_RES);
     cl.specShift = specShift; cl.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
     cl.nHelpers = nWG * CL_WAVES - 1; cl.window = window;
     const int mainWords = role == 0 ? QCAP + 4 + TorusFrame::WORDS + CL_SCAN : 0;

@@ -115,12 +115,14 @@ def test_lines_huge_regions(fe, ctx, oracle):
     assert n >= 1
 
 
-@pytest.mark.parametrize("flavour", ["mw", "lat", "thr"])
+@pytest.mark.parametrize("flavour", ["cl", "mw", "lat", "thr"])
 def test_lsd_core_flavours(fe, ctx, oracle, flavour, monkeypatch):
-    """The sequential core has three launch forms (lsd_regions.h): multi-wave (main wave + helper waves running the per-seed body ahead of it;
-    what a single frame gets), the lone wave and the six-waves-per-SIMD throughput form.  Each is forced here over frames that stress the
-    multi-wave protocol in different ways: long lines (helpers give up beyond their reach), 1280x960 (coarser shared map), noise (hundreds of
-    one-pixel regions per chunk: result slots run out), a ramp (regions beyond every helper limit) and an odd size."""
+    """The sequential core has four launch forms (lsd_regions.h, lsd_cluster.h): cluster (main wave + helper waves on several compute units,
+    results through global memory, monotonic pixel map: what a single frame gets when its bitmap fits the main wave's LDS), multi-wave (main
+    wave + helper waves in one workgroup), the lone wave and the six-waves-per-SIMD throughput form.  Each is forced here over frames that
+    stress the helper protocols in different ways: long lines (helpers give up beyond their reach), 1280x960 (coarser shared map; too large
+    for the cluster form, which hands over to the multi-wave form), noise (hundreds of one-pixel regions per chunk: result slots run out), a
+    ramp (regions beyond every helper limit) and an odd size."""
     import ctypes as C
     monkeypatch.setenv("SSLAM_LSD_FLAVOUR", flavour)
     frames = [(synth_frame(2000), 200), (synth_frame(1235, w=1280, h=960), 400), (synth_frame(91, w=333, h=251), 200),
@@ -128,13 +130,46 @@ def test_lsd_core_flavours(fe, ctx, oracle, flavour, monkeypatch):
     taken = 0
     for img, cap in frames:
         _cmp_lines(fe, ctx, oracle, img, cap)
-        if flavour == "mw":
+        if flavour in ("mw", "cl"):
             ex = fe.LineExtractor(ctx, cap); ex(img)
             out = (C.c_longlong * 8)(); fe.lib().sslam_lines_debug_cycles(ex.h, 0, out); ex.close()
             taken += out[5] & 0xFFFFFFFF
             assert out[7] == 0, "the main wave gave up waiting for a helper"
-    if flavour == "mw":
-        assert taken > 1000, "the multi-wave form took almost no region from its helpers: %d" % taken
+    if flavour in ("mw", "cl"):
+        assert taken > 1000, "the %s form took almost no region from its helpers: %d" % (flavour, taken)
+
+
+@pytest.mark.parametrize("knobs", [{"SSLAM_CL_WGS": "1"}, {"SSLAM_CL_WGS": "16", "SSLAM_CL_WINDOW": "400"}, {"SSLAM_CL_WINDOW": "-1"}, {"SSLAM_CL_WINDOW": "3"},
+                                   {"SSLAM_CL_SMAP": "-1"}, {"SSLAM_CL_SMAP": "2", "SSLAM_CL_WGS": "3"}])
+def test_lsd_cluster_configurations(fe, ctx, oracle, knobs, monkeypatch):
+    """three helpers .. sixty-three, helpers far ahead of the main wave (stale views, refused results) or barely ahead, no helpers at all (every
+    seed through the main wave's private growth + commit), no / coarser shared map: the schedule changes completely, the output must not"""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("SSLAM_LSD_FLAVOUR", "cl")
+    for img, cap in [(synth_frame(2000), 200), (synth_frame(77, w=800, h=600), 300), (noise_frame(5, w=320, h=240), 200)]:
+        _cmp_lines(fe, ctx, oracle, img, cap)
+
+
+def test_lsd_cluster_batch(fe, ctx, oracle):
+    """up to 8 frames per call take the cluster form, one XCD's worth of workgroups per frame: results per frame as for single calls"""
+    frames = [synth_frame(3100 + i) for i in range(7)]
+    ex = fe.LineExtractor(ctx, 200)
+    try:
+        dev = torch.from_numpy(np.stack(frames)).cuda()
+        nf, cap = len(frames), 256
+        d_kl = torch.zeros(nf * cap * 68, dtype=torch.uint8, device="cuda"); d_ld = torch.zeros(nf * cap * 32, dtype=torch.uint8, device="cuda")
+        d_fn = torch.zeros(nf * cap * 3, dtype=torch.float64, device="cuda"); d_n = torch.zeros(nf, dtype=torch.int32, device="cuda")
+        ex.extract_batch_dev(dev, 640, 480, 640, 640 * 480, nf, d_kl, d_ld, d_fn, d_n, cap)
+        torch.cuda.synchronize()
+        import ctypes as C
+        for i, f in enumerate(frames):
+            okl, old, ofn, oraw = oracle.lines_extract(f, 200)
+            np.testing.assert_array_equal(ex.debug_segments(i), oraw, err_msg="frame %d" % i)
+            out = (C.c_longlong * 8)(); fe.lib().sslam_lines_debug_cycles(ex.h, i, out)
+            assert out[7] == 0 and (out[5] & 0xFFFFFFFF) > 200, (i, out[5] & 0xFFFFFFFF, out[7])
+    finally:
+        ex.close()
 
 
 @pytest.mark.parametrize("knobs", [{"SSLAM_LSD_HELPERS": "1"}, {"SSLAM_LSD_HELPERS": "3", "SSLAM_MW_SMAP": "-1"}, {"SSLAM_MW_SMAP": "0"}, {"SSLAM_MW_SMAP": "2"}])
