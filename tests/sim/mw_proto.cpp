@@ -9,9 +9,18 @@
 // the rectangle's twelve doubles) and the final `used` map -- bit for bit.  `chaos` makes threads yield at random pixel reads so that views go
 // stale at every possible point; with check (b) or (c) switched off the comparison must (and does) fail, which shows the test can see a broken
 // protocol.  Built and run by tests/test_mw_proto_cpu.py.
-//   usage: mw_proto <frame.raw> <w> <h> <helpers> <repeats> <chaos: yield once in N reads, 0 = never> [checks: 3 = both (default), 1 = only (b), 2 = only (c), 0 = none] [percentage of seeds the main thread does itself regardless]
+//
+// CLUSTER protocol (csrc/lsd_cluster.h; mode 1): the helpers sit on other compute units, so their view of the map can be
+// ARBITRARILY STALE -- modelled here by a per-helper cache of 64-pixel lines that is refreshed from the map only once in `stale` accesses
+// (lines of different age side by side, never going back in time).  The main thread therefore never releases a pixel in the map: a seed it
+// runs itself is grown on private marks (the very body the helpers run) and only what ends up USED is committed; a taken result commits
+// its last list.  With the map monotonic, check (b) alone is the validation -- and the negative controls show both halves: without (b) the
+// runs differ, and the multi-wave protocol (releases in the map, checks (b) + (c)) on stale views differs as well, which is why the
+// cluster form needs the monotonic map.
+//   usage: mw_proto <frame.raw> <w> <h> <helpers> <repeats> <chaos: yield once in N reads, 0 = never> [checks: 3 = both (default), 1 = only (b), 2 = only (c), 0 = none] [percentage of seeds the main thread does itself regardless] [mode: 0 multi-wave, 1 cluster] [stale: a cached line is refreshed once in N reads, 0 = views are always fresh]
 #include "../../oracle/lsd_oracle.cpp"
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -36,6 +45,7 @@ struct Chunk {
 
 struct Mw : Lsd {
     double prec = 0, p = 0; size_t min_reg_size = 0;
+    int mode = 0, stale = 0;                // mode 1: cluster protocol (monotonic map, private growth of the main thread, check (b) only); stale: see above
     int H = 4, chaos = 0, checks = 3, ownPct = 0;      // ownPct: the main thread ignores the helper's result for this share of the seeds (more refines of its own -> more releases)
     std::vector<Chunk> chunks;              // one per chunk of the order list (the kernel recycles a few slots; storage is not what is tested)
     std::atomic<int> cursor{0}, mainPos{0}, finished{0}, unmarkSeq{0};
@@ -73,10 +83,19 @@ struct Mw : Lsd {
         }
     }
     // ---------------------------------------------------------------- helper side: the body on a read-only view + private marks
-    struct HCtx { std::vector<uint8_t> mine; unsigned long long rng; };
+    struct HCtx { std::vector<uint8_t> mine; unsigned long long rng; int stale = 0; std::vector<uint8_t> cache, have; };
     void jitter(unsigned long long& rng) { if (chaos) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; if (rng % (unsigned)chaos == 0) std::this_thread::yield(); } }
     bool view_unused(HCtx& c, int idx) {
         jitter(c.rng);
+        if (c.stale) {                          // a cache of 64-pixel lines: a line is fetched on first use and refreshed only now and then
+            const size_t line = (size_t)idx / 64, n = used.size();
+            c.rng ^= c.rng << 13; c.rng ^= c.rng >> 7; c.rng ^= c.rng << 17;
+            if (!c.have[line] || c.rng % (unsigned)c.stale == 0) {
+                for (size_t i = line * 64; i < std::min(n, line * 64 + 64); ++i) c.cache[i] = reinterpret_cast<volatile uint8_t*>(used.data())[i];
+                c.have[line] = 1;
+            }
+            return c.cache[idx] == 0 && !c.mine[idx];
+        }
         return reinterpret_cast<volatile uint8_t*>(used.data())[idx] == 0 && !c.mine[idx];
     }
     void grow_private(HCtx& c, int sx, int sy, std::vector<RegionPoint>& reg, double& reg_angle, double prc) {
@@ -156,6 +175,7 @@ struct Mw : Lsd {
     }
     void helper_thread(int hid) {
         HCtx c; c.mine.assign((size_t)w * h, 0); c.rng = 88172645463325252ull + 7919ull * hid;
+        c.stale = stale; if (stale) { c.cache.assign((size_t)w * h, 0); c.have.assign(((size_t)w * h + 63) / 64, 0); }
         const int nOrd = (int)order.size();
         for (;;) {
             if (finished.load()) return;
@@ -188,6 +208,7 @@ struct Mw : Lsd {
         for (int i = 0; i < H; ++i) th.emplace_back([this, i] { helper_thread(i); });
         unsigned long long rng = 1234567;
         std::vector<RegionPoint> reg;
+        HCtx own; own.mine.assign((size_t)w * h, 0); own.rng = 99;          // cluster protocol: the main thread's private marks (its view is the map itself)
         for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
             mainPos.store(pos0, std::memory_order_release);
             // whose chunk: below the cursor a helper claimed it, otherwise the main thread takes it
@@ -208,7 +229,7 @@ struct Mw : Lsd {
                     { std::lock_guard<std::mutex> g(K.mu); for (auto& r : K.res) if (r.lane == lane) { Rcopy = r; R = &Rcopy; } }
                     if (R) {
                         bool ok = true;
-                        if (checks & 2) {                                   // (c) no release near the result since its sample
+                        if ((checks & 2) && mode == 0) {                    // (c) no release near the result since its sample (the cluster protocol has no releases)
                             std::lock_guard<std::mutex> g(evMu);
                             for (int sq = R->startSeq; ok && sq < (int)events.size(); ++sq) {
                                 const Ev& e = events[sq];
@@ -222,7 +243,12 @@ struct Mw : Lsd {
                         } else ++nRefused;
                     }
                 }
-                if (!took) {                                                // the body by the main thread itself, on the map
+                if (!took && mode == 1) {                                   // cluster protocol: the body on private marks, then ONE commit -- the map never loses a pixel
+                    Result R; ++nOwn;
+                    helper_body(own, idx % w, idx / w, R);
+                    for (int id : R.F) used[id] = 1;
+                    s.size = (int)R.F.size(); s.emit = R.emit; s.rec = R.rec;
+                } else if (!took) {                                         // the body by the main thread itself, on the map
                     double reg_angle; ++nOwn;
                     region_grow(idx % w, idx / w, reg, reg_angle, prec);
                     s.size = (int)reg.size();
@@ -235,6 +261,9 @@ struct Mw : Lsd {
                         bool ok = true;
                         if (density < DENSITY_TH) {
                             grow_box(reg);
+                            // (stale views: an adversarial schedule -- the region stays marked for a while before refine() releases it, long enough
+                            // for helpers to cache lines that show it USED)
+                            if (stale) std::this_thread::sleep_for(std::chrono::microseconds(400));
                             double xc = double(reg[0].x), yc = double(reg[0].y); const double ang_c = reg[0].angle;
                             double sum = 0, s_sum = 0; int n = 0;
                             for (size_t i = 0; i < reg.size(); ++i) {
@@ -274,6 +303,7 @@ int main(int argc, char** argv) {
     FILE* f = std::fopen(argv[1], "rb"); if (!f || std::fread(img.d.data(), 1, img.d.size(), f) != img.d.size()) { std::fprintf(stderr, "cannot read frame\n"); return 2; }
     std::fclose(f);
     Mw M; M.H = std::atoi(argv[4]); const int reps = std::atoi(argv[5]); M.chaos = std::atoi(argv[6]); M.checks = argc > 7 ? std::atoi(argv[7]) : 3; M.ownPct = argc > 8 ? std::atoi(argv[8]) : 0;
+    M.mode = argc > 9 ? std::atoi(argv[9]) : 0; M.stale = argc > 10 ? std::atoi(argv[10]) : 0;
     M.prepare(img);
     std::vector<SeedLog> ref; M.run_sequential(ref);
     const std::vector<uint8_t> usedRef = M.used;

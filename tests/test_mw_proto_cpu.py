@@ -27,9 +27,9 @@ def proto(tmp_path_factory):
     return exe, frames
 
 
-def _run(exe, frame, helpers, reps, chaos, checks=3, own=0):
+def _run(exe, frame, helpers, reps, chaos, checks=3, own=0, mode=0, stale=0):
     p, w, h = frame
-    r = subprocess.run([exe, p, str(w), str(h), str(helpers), str(reps), str(chaos), str(checks), str(own)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, p, str(w), str(h), str(helpers), str(reps), str(chaos), str(checks), str(own), str(mode), str(stale)], capture_output=True, text=True, timeout=600)
     last = r.stdout.strip().splitlines()[-1]          # "different runs: X of N"
     return int(last.split()[2]), r.stdout
 
@@ -54,3 +54,27 @@ def test_multiwave_protocol_checks_are_necessary(proto):
         if bad_only_b:
             break
     assert bad_only_b > 0, "check (c) never mattered in %d runs: the model does not exercise releases" % runs
+
+
+# ---- the cluster form (csrc/lsd_cluster.h): helpers on other compute units see the map through caches of any age; the main
+# ---- thread never releases a pixel in the map (private growth + one commit), and check (b) alone validates a result
+@pytest.mark.parametrize("helpers,chaos,own,stale", [(4, 0, 0, 50), (6, 10, 30, 400), (12, 3, 60, 100000), (3, 50, 20, 7), (6, 10, 0, 0)])
+def test_cluster_protocol_equals_sequential(proto, helpers, chaos, own, stale):
+    exe, frames = proto
+    for f in frames:
+        bad, out = _run(exe, f, helpers, 6, chaos, 3, own, 1, stale)
+        assert bad == 0, out
+
+
+def test_cluster_protocol_needs_check_b_and_the_monotonic_map(proto):
+    """negative controls: (1) without check (b) the cluster protocol differs from the sequential run; (2) the multi-wave protocol -- releases in
+    the map, checks (b) + (c) -- differs on stale views (a helper that cached a line while a region of the main thread was marked keeps seeing
+    it USED after refine() released it, and no release event after its sample tells): the reason the cluster form keeps the map monotonic"""
+    exe, frames = proto
+    assert sum(_run(exe, f, 6, 4, 10, 0, 30, 1, 50)[0] for f in frames) > 0
+    bad = 0; runs = 0
+    for attempt in range(16):           # scheduling-dependent (about two rounds in three show it): a few rounds
+        bad += _run(exe, frames[0], 12, 10, 3, 3, 80, 0, 100000)[0]; runs += 10
+        if bad:
+            break
+    assert bad > 0, "the multi-wave protocol never differed on stale views in %d runs" % runs
