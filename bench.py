@@ -192,7 +192,7 @@ def latency_leg(fe, ctx, frames, with_lines, nframes=120):
     if lx: lx.close()
     pct = lambda a: {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "max": float(a.max())}
     out = {"unit": "ms", "frames": nframes, "path": "sslam_orb_extract + sslam_lines_extract per frame (host image in, host results out)",
-           "lsd_core": "multi-wave (one main wave + helper waves per frame)",
+           "lsd_core": "cluster form (one main wave + helper waves on several compute units; lsd_cluster.h)" if (W * 0.8 <= 1024 and H * 0.8 <= 512 and os.environ.get("SSLAM_LSD_CLUSTER", "1") != "0" and os.environ.get("SSLAM_LSD_FLAVOUR", "c")[0] == "c") else "multi-wave (one main wave + helper waves per frame; lsd_regions.h)",
            "orb_extract_hipEvent": pct(orb), "lines_extract_hipEvent": pct(lin) if with_lines else None, "frame_hipEvent": pct(orb + lin), "frame_wall": pct(wall),
            "frames_per_s_one_at_a_time": float(1e3 / np.median(wall))}
     if with_lines and not os.environ.get("SSLAM_LSD_FLAVOUR"):
@@ -212,14 +212,17 @@ def latency_leg(fe, ctx, frames, with_lines, nframes=120):
     return out
 
 
-def pcie_leg(fe, ctx, frames, with_lines, n=18432, chunk=0):
+def pcie_leg(fe, ctx, frames, with_lines, n=18432, chunk=0, prev_frames=None):
     """sslam_frontend_batch: host images in, host records out (extract only: the API of SURVEY §8(b)).  n covers three chunks of the default
     size (6144 frames = every wave slot of the sequential LSD core), so that uploads, kernels and downloads of neighbouring chunks overlap;
     the result arrays exist before the timed call (a caller streams into its own buffers)."""
     import numpy as np, torch
     ox = fe.OrbExtractor(ctx, NFEAT); lx = fe.LineExtractor(ctx, NLINES) if with_lines else None
     U = len(frames)
-    host = np.stack([frames[i % U] for i in range(min(n, 4 * U))])
+    if prev_frames is not None:      # a sequence: previous frame, current frame, previous frame, ... so that the match stage has something to match
+        host = np.stack([(prev_frames if i % 2 == 0 else frames)[(i // 2) % U] for i in range(min(n, 4 * U))])
+    else:
+        host = np.stack([frames[i % U] for i in range(min(n, 4 * U))])
     host = np.ascontiguousarray(np.tile(host, ((n + len(host) - 1) // len(host), 1, 1))[:n])
     out = {"entry": "sslam_frontend_batch", "frames": n, "chunk": chunk or "default (6144)",
            "note": "extract only (ORB + LSD/LBD); H2D of chunk k+1 and D2H of chunk k-1 under the kernels of chunk k, point and line branch on two streams inside the library; result arrays allocated before the timed call"}
@@ -243,7 +246,7 @@ def pcie_leg(fe, ctx, frames, with_lines, n=18432, chunk=0):
     t0 = time.perf_counter(); fe.frontend_batch_match_raw(ox, lx, pin.numpy(), res_pin, m_pin, chunk=chunk); out["pinned_with_match_frames_per_s"] = n / (time.perf_counter() - t0)
     out["match_results_equal"] = bool(np.array_equal(m_pg[1], m_pin[1]) and np.array_equal(m_pg[5], m_pin[5]))
     out["match_entry"] = "sslam_frontend_batch_match (SearchForInitialization window 100 + dense Hamming 2-NN + LSD line matcher against the previous frame of the sequence)"
-    out["matches_per_frame"] = float(m_pin[1][1:].mean())
+    out["matches_per_frame"] = float(m_pin[1][1::2].mean()) if prev_frames is not None else float(m_pin[1][1:].mean())      # (odd frames: a frame against its own predecessor)
     ox.close()
     if lx: lx.close()
     return out
@@ -483,7 +486,7 @@ def main():
             torch.cuda.empty_cache()
             try:
                 out["latency"] = latency_leg(fe, ctx, cur_np, with_lines)
-                out["pcie_inclusive"] = pcie_leg(fe, ctx, cur_np, with_lines, n=18432 if W == 640 else 3072, chunk=0 if W == 640 else 1024)
+                out["pcie_inclusive"] = pcie_leg(fe, ctx, cur_np, with_lines, n=18432 if W == 640 else 3072, chunk=0 if W == 640 else 1024, prev_frames=prev_np)
             except Exception as e:
                 out["latency_error"] = str(e)[:300]
         print(json.dumps(out))

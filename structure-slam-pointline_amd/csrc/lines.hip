@@ -268,10 +268,11 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) cluster = cluster && e[0] == 'c';      // "cl" / "mw" / "lat" / "thr"
         if (const char* e = getenv("SSLAM_LSD_CLUSTER")) cluster = cluster && atoi(e) != 0;
         if (cluster) {
-            int nWG = 6, window = 0, clShift = 0;
+            int nWG = 8, window = 0, clShift = 0;
             if (const char* e = getenv("SSLAM_CL_WGS")) nWG = std::max(1, std::min(CL_MAXWG, atoi(e)));
             if (const char* e = getenv("SSLAM_CL_WINDOW")) window = std::max(-1, atoi(e)); else window = 40;      // in sub-chunks of 16 positions; -1: no helpers at all (the main wave alone)
             if (const char* e = getenv("SSLAM_CL_SMAP")) clShift = atoi(e);
+            if (getenv("SSLAM_CL_NO_FEEDER") && window >= 0) window |= 1 << 20;      // experiment knob: the main wave fetches everything itself
             const int clSpecWords = clShift < 0 ? 0 : (((P.sw + (1 << clShift) - 1) >> clShift) * ((P.sh + (1 << clShift) - 1) >> clShift) + 31) / 32;
             const size_t maxSubs = ((size_t)P.npx + CL_SUB - 1) / CL_SUB;
             const size_t zeroBytes = 512 + ((maxSubs * sizeof(ClSub) + 511) & ~(size_t)511) + 4 * (size_t)((clSpecWords + 127) & ~127);      // control block, sub-chunk states / flags, shared map
@@ -279,7 +280,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             L->clFrame = clFrame;
             if (L->dCl.cap < clFrame * 8) { SSLAM_HIP(hipStreamSynchronize(st)); if ((rc = L->dCl.ensure(clFrame * 8))) return rc; }
             for (int f = 0; f < nframes; ++f) SSLAM_HIP(hipMemsetAsync(L->dCl.as<uint8_t>() + (size_t)f * clFrame, 0, zeroBytes, st));
-            const size_t clLds = sizeof(unsigned) * ((size_t)QCAP + 4 + TorusFrame::WORDS + CL_SCAN + (size_t)CL_WAVES * (CL_LIST + MW_BM_WORDS));
+            const size_t clLds = sizeof(unsigned) * std::max((size_t)QCAP + 4 + TorusFrame::WORDS + CL_SCAN + CL_RING_WORDS, (size_t)CL_HPW * (CL_LIST + ClTorus::WORDS));      // the main wave's workgroup / a helper workgroup
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
             hipLaunchKernelGGL(k_lsd_regions_cl, dim3(8 * nWG), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
         } else if (mw) {

@@ -30,15 +30,37 @@ constexpr int CL_RES = CL_SUB;             // results per sub-chunk header: one 
 constexpr int CL_ARENA = 1 << 16;          // list words per helper per frame (MwRes::off is 16 bits)
 constexpr int CL_LIST = 3072;              // LDS words per helper for the region in progress (lists A, B, F and the rectangle)
 constexpr int CL_WAVES = 4;                // waves per workgroup (one per SIMD)
+#ifndef SSLAM_CL_HELPERS_PER_WG
+#define SSLAM_CL_HELPERS_PER_WG 3
+#endif
+constexpr int CL_HPW = SSLAM_CL_HELPERS_PER_WG;      // helper waves per helper workgroup: 3 with a 512 x 512 torus each (reach 254 pixels: the regions helpers used to give up on were a fifth of what the main wave grew itself), 4 with 256 x 256
+typedef std::conditional<CL_HPW == 4, TorusHelper, TorusWide>::type ClTorus;
 constexpr int CL_MAXWG = 16;               // workgroups per frame at most
 constexpr int CL_SCAN = 2 * 64 * 4;          // LDS words of the main wave's look-ahead over the seed list (order entries + map values of one group of chunks)
 constexpr int CL_SPIN_LIMIT = 1 << 18;     // polls before the main wave stops waiting for a helper (each poll is an L2 round trip)
-constexpr int CL_INL = 11;                 // points a result record carries itself: a region this small (and below the minimum region size: no rectangle, no refine) needs no list in the arena
-constexpr int MW_INLINE = 8;               // MwRes flag: the record's own points are the whole result
 struct ClSub { int state, flag; };         // per sub-chunk, zeroed per launch; state: 0 free, 1 the main wave's, 2 + h helper h's; flag = doneLane (0..16) | nres << 8
-struct alignas(16) ClRec { MwRes m; unsigned pts[CL_INL]; };      // 64 bytes; records of sub-chunk sc: rec[sc * CL_RES ..)
-static_assert(sizeof(ClRec) == 64, "result record layout");
+struct alignas(16) ClRec { MwRes m; unsigned pad[3]; };           // 32 bytes; records of sub-chunk sc: rec[sc * CL_RES ..)
+static_assert(sizeof(ClRec) == 32, "result record layout");
 struct ClCtl { int mainPos, finished, cursor, pad; long long stat[8]; };
+// The main wave's workgroup runs ONE more wave, the FEEDER: it walks the seed list a few chunks ahead of the main wave and stages in LDS what
+// the main wave would otherwise fetch from global memory with one dependent round trip after the other -- states and flags of the chunk's
+// sub-chunks, the result records, and for every result of up to CL_STG points its list and the map values of its points (LDS-DMA loads,
+// all of a chunk in flight at once).  A staged map value can be out of date: the main wave counts its commits, keeps the boxes of the last
+// 64 in its lanes, the feeder notes the counter BEFORE it gathers, and a result whose box meets a commit younger than its gather is
+// gathered again (same compute unit, same L1: a gather issued after the counter was read sees every store issued before the counter was
+// written).  The main wave never waits for the feeder: a chunk that is not staged when it arrives takes the global path.
+constexpr int CL_RING = 3;                 // chunks staged ahead
+constexpr int CL_STG = 32;                 // list entries (A then B) staged per result; longer results take the global path
+struct ClSlot {
+    int chunk, ready, pad0, pad1;
+    int st[CL_NSUB], fl[CL_NSUB];          // state / flag of the sub-chunks as staged (st 1: no result expected)
+    MwRes rec[64];                         // record (l & 15) of sub-chunk (l >> 4)
+    int gseq[64];                          // the main wave's commit counter before the record's points were gathered; -1: not staged
+    unsigned e[64][CL_STG];
+    float v[64][CL_STG];
+};
+struct ClLocal { int mainChunk, commitSeq, finished, pad; };      // LDS: main wave -> feeder
+constexpr int CL_RING_WORDS = (int)((sizeof(ClSlot) * CL_RING + sizeof(ClLocal) + 3) / 4);
 struct ClShared {
     ClCtl* ctl; ClSub* sub; ClRec* rec; unsigned* arena; unsigned* specMap; int specW, specShift, nHelpers, window;
     __device__ __forceinline__ int cell(int x, int y) const { return (y >> specShift) * specW + (x >> specShift); }
@@ -70,7 +92,7 @@ __device__ __forceinline__ bool cl_spec(const ClShared& cl, int x, int y) {
 #endif
 // ------------------------------------------------------------------ the main wave
 __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsigned* __restrict__ qLds, unsigned* __restrict__ bmMain, unsigned* __restrict__ scanBuf,
-                        double* __restrict__ red, float4* __restrict__ seedStash, const ClShared& cl) {
+                        double* __restrict__ red, float4* __restrict__ seedStash, const ClShared& cl, ClSlot* __restrict__ ring, ClLocal* __restrict__ loc) {
     typedef TorusFrame G;
     const int lane = threadIdx.x & 63;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
@@ -102,6 +124,8 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
     load_group(0);
     unsigned accCurLo = 0xFFFFFFFFu, accCurHi = 0u, accNextLo = 0xFFFFFFFFu, accNextHi = 0u;      // packed x | y << 16 minima / maxima; Lo > Hi: empty
     bool accCurAny = false, accNextAny = false;
+    int commitSeq = 0, logSeq = -1; unsigned logLo = 0u, logHi = 0u;      // lane (seq & 63) keeps the box of commit seq
+    long long clStagedChunks = 0, clStagedTakes = 0, clRegather = 0;
     for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
         const int gj = (pos0 >> 6) & (CL_GROUP - 1);
         if (gj == 0) {
@@ -112,6 +136,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             if (pos0 + 64 * CL_GROUP < nOrd) load_group(pos0 + 64 * CL_GROUP);
         }
         if (lane == 0) g_st(&cl.ctl->mainPos, pos0);
+        lds_st(&loc->mainChunk, pos0 >> 6);
         const unsigned idx = scanIdx[64 * gj + lane];
         const bool have = idx != 0xFFFFFFFFu;
         const int tiSeed = have ? pl.ti(idx) : 0;
@@ -137,7 +162,11 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
         const int mySub = lane >> 4, myK = lane & 15;
         const ClRec* myRecPtr = &cl.rec[(size_t)(sc0 + mySub) * CL_RES + myK];
         int stv = 1, flv = 0, nsv = 0;               // per sub-chunk, in lane s: state, last flag read, records loaded
-        {
+        ClSlot* SL = &ring[(pos0 >> 6) % CL_RING];
+        const bool staged = lds_ld(&SL->chunk) == (pos0 >> 6) && lds_ld(&SL->ready) == 1;      // the feeder has this chunk in LDS
+        int myGseq = -1;                             // staged: the commit counter at the gather of my record's points (-1: not staged)
+        if (staged) ++clStagedChunks;
+        if (!staged) {
             const bool need = lane < CL_NSUB && ((unM >> (16 * lane)) & 0xFFFFull) != 0;
             if (need) {
                 stv = g_ld(&S4[lane].state); flv = g_ld(&S4[lane].flag);
@@ -147,31 +176,16 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
         }
         cl_compiler_fence();
         MwRes myRes; myRes.w0 = myRes.w1 = myRes.w2 = myRes.lo = myRes.hi = 0u;
-        unsigned myP[CL_INL]; float myV[CL_INL];      // an inline record's points and their map values as last gathered
-#pragma unroll
-        for (int i = 0; i < CL_INL; ++i) { myP[i] = 0u; myV[i] = 0.f; }
-        int myOk = 0, myDirty = 0;                   // inline record: every point was unused at the last gather / a commit since may have touched it
-        auto gather_mine = [&]() {                   // (the calling lanes hold an inline record)
-            const int nA = (int)(myRes.w1 >> 16);
-            bool allFree = true;
-#pragma unroll
-            for (int i = 0; i < CL_INL; ++i) if (i < nA) myV[i] = pl.T[pl.ti(myP[i])];
-#pragma unroll
-            for (int i = 0; i < CL_INL; ++i) if (i < nA) allFree = allFree && t_free(myV[i]);
-            myOk = allFree ? 1 : 0; myDirty = 0;
-        };
         auto fetch_records = [&](bool mine) {        // the calling lanes load their record (a record is complete before the flag counts it)
             if (mine) {
                 const unsigned* r = (const unsigned*)myRecPtr;
                 myRes.w0 = g_ldu(r); myRes.w1 = g_ldu(r + 1); myRes.w2 = g_ldu(r + 2); myRes.lo = g_ldu(r + 3); myRes.hi = g_ldu(r + 4);
-#ifdef SSLAM_CL_INLINE
-#pragma unroll
-                for (int i = 0; i < CL_INL; ++i) myP[i] = g_ldu(r + 5 + i);
-                if (myRes.flags() & MW_INLINE) gather_mine();
-#endif
             }
         };
-        {   // what is published already, all four sub-chunks at once
+        if (staged) {   // everything the global path fetches below, from LDS
+            if (lane < CL_NSUB) { stv = SL->st[lane]; flv = SL->fl[lane]; nsv = min(flv >> 8, CL_RES); }
+            myRes = SL->rec[lane]; myGseq = SL->gseq[lane];
+        } else {   // what is published already, all four sub-chunks at once
             const int f0 = __builtin_amdgcn_readlane(flv, 0), f1 = __builtin_amdgcn_readlane(flv, 1), f2 = __builtin_amdgcn_readlane(flv, 2), f3 = __builtin_amdgcn_readlane(flv, 3);
             const int myFlag = mySub == 0 ? f0 : mySub == 1 ? f1 : mySub == 2 ? f2 : f3;
             fetch_records(myK < min(myFlag >> 8, CL_RES));
@@ -179,6 +193,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
         }
         auto load_records = [&](int s, int nres) {      // records [nsv_s, nres) of sub-chunk s
             const int had = __builtin_amdgcn_readlane(nsv, s);
+            if (mySub == s && myK >= had && myK < nres) myGseq = -1;
             fetch_records(mySub == s && myK >= had && myK < nres);
             if (lane == s) nsv = nres;
         };
@@ -195,7 +210,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             int n = -1;
             bool took = false, tookEmit = false; RectD tookRec;
             unsigned e0 = 0u;                            // lane i: point i of a taken region's first list (i < 64)
-            bool wasRefused = false, tookInline = false; int tookLane = 0;
+            bool wasRefused = false;
             unsigned bxLo = 0u, bxHi = 0xFFFFFFFFu;
             const long long c0 = CL_CLK();
             if (owner >= 0) {
@@ -232,20 +247,6 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                     r.w2 = (unsigned)__builtin_amdgcn_readlane((int)myRes.w2, hl); r.lo = (unsigned)__builtin_amdgcn_readlane((int)myRes.lo, hl);
                     r.hi = (unsigned)__builtin_amdgcn_readlane((int)myRes.hi, hl);
                     const int nA = r.nA(), nB = r.nB(), nF = r.nF(), flags = r.flags();
-                    if (flags & MW_INLINE) {
-                        // the holder lane has validated the record on its own; a commit since then that could have touched it set myDirty
-                        if (nA > 1 && __builtin_amdgcn_readlane(myDirty, hl)) { if (lane == hl) gather_mine(); }
-                        const bool ok = nA == 1 || __builtin_amdgcn_readlane(myOk, hl) != 0;      // (a region of one point is its seed, known to be unused)
-                        if (ok) {
-                            if (nA == 1) { if (lane == first) pl.T[tiSeed] = t_used(a0); }
-                            else if (lane == hl) {
-#pragma unroll
-                                for (int i = 0; i < CL_INL; ++i) if (i < nA) pl.T[pl.ti(myP[i])] = t_used(myV[i]);
-                            }
-                            took = true; tookInline = true; tookLane = hl; n = nA; bxLo = r.lo; bxHi = r.hi;
-                            clTaken += 1 + ((long long)n << 32);
-                        } else { ++clRefused; wasRefused = true; }
-                    } else {
                     const unsigned* lstA = cl.arena + (size_t)owner * CL_ARENA + r.off();
                     const unsigned* lstB = lstA + nA;
                     const unsigned* lstF = (flags & MW_REDUCED) ? lstB + nB : (flags & MW_REFINED) ? lstB : lstA;
@@ -254,7 +255,24 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                     // the rectangle's 24 words travel with the first list load (one round trip instead of two)
                     const unsigned* rw = lstB + nB + ((flags & MW_REDUCED) ? nF : 0);
                     const unsigned wv = ((flags & MW_EMIT) && lane < 24) ? g_ldu(rw + lane) : 0u;
-                    for (int bs = 0; ok && nA + nB > 1 && bs < nA + nB; bs += 64) {      // (b): everything the helper accepted on the way is unused now
+                    const int gs = __builtin_amdgcn_readlane(myGseq, hl);
+                    bool viaStage = false;
+                    if (gs >= 0 && nA + nB > 1) {
+                        // staged result: list and map values are in LDS.  Values gathered before commit gs + 1 .. commitSeq can be out of date
+                        // only inside those commits' boxes
+                        const bool young = logSeq > gs && boxes_meet(logLo, logHi, r.lo, r.hi, 0);
+                        const bool dirty = commitSeq - gs > 64 || __ballot(young) != 0;
+                        const int i = lane;
+                        bool usedNow = false;
+                        if (i < nA + nB) {
+                            const unsigned e = SL->e[hl][i]; const int ti = pl.ti(e);
+                            const float v = dirty ? pl.T[ti] : SL->v[hl][i];
+                            usedNow = !t_free(v); v0 = v; ti0 = ti; e0 = e;
+                        }
+                        ok = __ballot(usedNow) == 0;
+                        viaStage = true; ++clStagedTakes; if (dirty) ++clRegather;
+                    }
+                    for (int bs = 0; !viaStage && ok && nA + nB > 1 && bs < nA + nB; bs += 64) {      // (b): everything the helper accepted on the way is unused now
                         const int i = bs + lane;
                         bool usedNow = false;
                         if (i < nA + nB) { const unsigned e = g_ldu(lstA + i); const int ti = pl.ti(e); const float v = pl.T[ti]; usedNow = !t_free(v); if (bs == 0) { v0 = v; ti0 = ti; e0 = e; } }
@@ -273,7 +291,6 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                         }
                         clTaken += 1 + ((long long)n << 32);
                     } else { ++clRefused; wasRefused = true; }
-                    }
                 }
             }
             const long long c2 = CL_CLK(); cTake += c2 - c1;
@@ -310,14 +327,12 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             if (!took) cRect += CL_CLK() - c3;
             accCurLo = pk_min_u16(accCurLo, bxLo); accCurHi = pk_max_u16(accCurHi, bxHi); accNextLo = pk_min_u16(accNextLo, bxLo); accNextHi = pk_max_u16(accNextHi, bxHi);
             accCurAny = accNextAny = true;
-            // inline records waiting in the lanes: whatever this commit marked lies inside its box
-            if ((myRes.flags() & MW_INLINE) && boxes_meet(myRes.lo, myRes.hi, bxLo, bxHi, 0)) myDirty = 1;
+            ++commitSeq;                                  // (after the commit's stores were issued: the feeder reads the counter before it gathers)
+            if (lane == (commitSeq & 63)) { logLo = bxLo; logHi = bxHi; logSeq = commitSeq; }
+            lds_st(&loc->commitSeq, commitSeq);
             if (tooSmall) {
                 // too small: rejected, its pixels stay used.  Which candidates of this chunk did it take?
-                if (tookInline) {
-#pragma unroll
-                    for (int i = 1; i < CL_INL; ++i) if (i < n) unM &= ~__ballot(idx == (unsigned)__builtin_amdgcn_readlane((int)myP[i], tookLane));
-                } else for (int k = 1; k < n; ++k) {
+                for (int k = 1; k < n; ++k) {
                     const unsigned e = took ? (unsigned)__builtin_amdgcn_readlane((int)e0, k) : rq.lds[k];      // (minRegSize < 64)
                     unM &= ~__ballot(idx == e);
                 }
@@ -339,15 +354,96 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             ++nSeg;
         }
     }
+    lds_st(&loc->finished, 1);
     if (lane == 0) {
         g_st(&cl.ctl->finished, 1);
         misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
-        misc->cyc[0] = clWait; misc->cyc[1] = clOwnChunks; misc->cyc[2] = clRefused; misc->cyc[3] = 0; misc->cyc[4] = 0;
+        misc->cyc[0] = clWait; misc->cyc[1] = clOwnChunks; misc->cyc[2] = clRefused; misc->cyc[3] = clStagedChunks | (clRegather << 32); misc->cyc[4] = clStagedTakes;
 #ifdef SSLAM_CL_CYCLES
         misc->cyc[0] = cWait; misc->cyc[1] = cTake; misc->cyc[2] = cOwn; misc->cyc[3] = cRect; misc->cyc[4] = CL_CLK() - cStart;
         cl.ctl->stat[4] = clOwnRefused; cl.ctl->stat[5] = clOwn;
 #endif
         misc->cyc[5] = clTaken; misc->cyc[6] = clOwn; misc->cyc[7] = clBad;
+    }
+}
+
+// ------------------------------------------------------------------ the feeder wave (second wave of the main wave's workgroup)
+__device__ void cl_feeder(uint8_t* __restrict__ ws, const LsdPlan& P, int b, const ClShared& cl, ClSlot* __restrict__ ring, ClLocal* __restrict__ loc) {
+    const int lane = threadIdx.x & 63;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    Planes pl; pl.T = (float*)(base + P.offT); pl.Cs = (const float2*)(base + P.offCs); pl.S = (const int*)(base + P.offS); pl.tW = P.tW; pl.cW = P.cW;
+    const unsigned* order = (const unsigned*)(base + P.offOrder);
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const int nOrd = misc->nDefined, nChunks = (nOrd + 63) >> 6;
+    const int mySub = lane >> 4, myK = lane & 15;
+    if (cl.window < 0) return;
+    for (int c = 1; c < nChunks; ++c) {
+        // the slot of chunk c is free once the main wave is past chunk c - CL_RING
+        int mc = 0;
+        for (int spin = 0;; ++spin) {
+            if (lds_ld(&loc->finished) || spin > (1 << 24)) return;
+            mc = lds_ld(&loc->mainChunk);
+            if (c < mc + CL_RING) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (c <= mc) continue;                                   // the main wave is there already: it takes the global path
+        const int q = c * 64 + lane;
+        const unsigned idx = q < nOrd ? order[q] : 0xFFFFFFFFu;
+        const float a0 = idx != 0xFFFFFFFFu ? pl.T[pl.ti(idx)] : NOTDEF_F;
+        const unsigned long long unM = __ballot(t_free(a0));
+        if (!unM) continue;
+        ClSlot* S = &ring[c % CL_RING];
+        if (lane == 0) { S->ready = 0; S->chunk = c; }
+        // states and flags of the sub-chunks with unused seeds; a helper still in its first pass is waited for until the main wave gets here
+        const ClSub* S4 = &cl.sub[c * CL_NSUB];
+        const bool need = lane < CL_NSUB && ((unM >> (16 * lane)) & 0xFFFFull) != 0;
+        int stv = 1, flv = 0;
+        bool pending = true;
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+            if (need) { stv = g_ld(&S4[lane].state); flv = g_ld(&S4[lane].flag); }
+            pending = __ballot(need && (stv < 2 || (flv & 0xFF) < CL_SUB)) != 0;      // nobody has started it, or its helper is still in pass 0
+            if (!pending || lds_ld(&loc->mainChunk) >= c || lds_ld(&loc->finished)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (pending) continue;                                   // not staged: the main wave sorts it out itself
+        cl_compiler_fence();
+        if (lane < CL_NSUB) { S->st[lane] = need ? stv : 1; S->fl[lane] = need ? flv : 0; }
+        const int f0 = __builtin_amdgcn_readlane(flv, 0), f1 = __builtin_amdgcn_readlane(flv, 1), f2 = __builtin_amdgcn_readlane(flv, 2), f3 = __builtin_amdgcn_readlane(flv, 3);
+        const int s0 = __builtin_amdgcn_readlane(stv, 0), s1 = __builtin_amdgcn_readlane(stv, 1), s2 = __builtin_amdgcn_readlane(stv, 2), s3 = __builtin_amdgcn_readlane(stv, 3);
+        const int myFlag = mySub == 0 ? f0 : mySub == 1 ? f1 : mySub == 2 ? f2 : f3;
+        const int myOwner = (mySub == 0 ? s0 : mySub == 1 ? s1 : mySub == 2 ? s2 : s3) - 2;
+        MwRes R; R.w0 = R.w1 = R.w2 = R.lo = R.hi = 0u;
+        const bool valid = myK < min(myFlag >> 8, CL_RES);
+        if (valid) {
+            const unsigned* r = (const unsigned*)&cl.rec[(size_t)(c * CL_NSUB + mySub) * CL_RES + myK];
+            R.w0 = g_ldu(r); R.w1 = g_ldu(r + 1); R.w2 = g_ldu(r + 2); R.lo = g_ldu(r + 3); R.hi = g_ldu(r + 4);
+        }
+        S->rec[lane] = R; S->gseq[lane] = -1;
+        const int cnt = valid ? R.nA() + R.nB() : 0;
+        const bool stageable = cnt > 1 && cnt <= CL_STG;
+        const unsigned long long stM = __ballot(stageable);
+        const unsigned* myList = cl.arena + (size_t)max(myOwner, 0) * CL_ARENA + R.off();
+        // the lists: LDS-DMA, every result of the chunk in flight at once
+        for (unsigned long long m = stM; m; m &= m - 1) {
+            const int r = __ffsll((long long)m) - 1;
+            const int cr = __builtin_amdgcn_readlane(cnt, r);
+            const unsigned long long lp = (unsigned long long)(size_t)myList;
+            const unsigned* lst = (const unsigned*)(size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(lp >> 32), r) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lp, r));
+            if (lane < cr) __builtin_amdgcn_global_load_lds(lst + lane, &S->e[r][0], 4, 0, 16);
+        }
+        cl_stores_done();
+        // the map values of their points; the main wave's commit counter first
+        const int seq = lds_ld(&loc->commitSeq);
+        cl_compiler_fence();
+        for (unsigned long long m = stM; m; m &= m - 1) {
+            const int r = __ffsll((long long)m) - 1;
+            const int cr = __builtin_amdgcn_readlane(cnt, r);
+            if (lane < cr) { const unsigned e = ((volatile unsigned*)&S->e[r][0])[lane]; __builtin_amdgcn_global_load_lds(pl.T + pl.ti(e), &S->v[r][0], 4, 0, 0); }
+        }
+        cl_stores_done();
+        if (stageable) S->gseq[lane] = seq;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lds_st(&S->ready, 1);
     }
 }
 
@@ -359,7 +455,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
 constexpr int CL_FIFO = 16;                // chunks a helper can have published and not yet retired from the shared map
 __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int b, const ClShared& cl, unsigned* __restrict__ listBuf, unsigned* __restrict__ bm,
                           float4* __restrict__ stash, double* __restrict__ red) {
-    typedef TorusHelper G;
+    typedef ClTorus G;
     const int lane = threadIdx.x & 63;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     Planes pl; pl.T = (float*)(base + P.offT); pl.Cs = (const float2*)(base + P.offCs); pl.S = (const int*)(base + P.offS); pl.tW = P.tW; pl.cW = P.cW;
@@ -384,7 +480,7 @@ __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
             for (int kk = 0; kk < k; ++kk) {
                 const unsigned* r = (const unsigned*)&cl.rec[(size_t)sc * CL_RES + kk];
                 MwRes R; R.w0 = g_ldu(r); R.w1 = g_ldu(r + 1); R.w2 = g_ldu(r + 2); R.lo = 0; R.hi = 0;
-                const unsigned* lstF = (R.flags() & MW_INLINE) ? r + 5 : arena + R.off() + ((R.flags() & MW_REDUCED) ? R.nA() + R.nB() : (R.flags() & MW_REFINED) ? R.nA() : 0);
+                const unsigned* lstF = arena + R.off() + ((R.flags() & MW_REDUCED) ? R.nA() + R.nB() : (R.flags() & MW_REFINED) ? R.nA() : 0);
                 for (int i = lane; i < R.nF(); i += 64) { const unsigned e = g_ldu(lstF + i); const int clc = cl.cell((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&cl.specMap[clc >> 5], ~(1u << (clc & 31))); }
             }
             ++fTail;
@@ -477,31 +573,21 @@ __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 }
                 unsigned lo, hi;
                 list_bbox(lstA, nAB, lane, lo, hi);
-                // ---- publish: lists (a small rejected region travels inside its record), record, (stores complete), flag
-                // -DSSLAM_CL_INLINE: a small rejected region travels inside its record and the main wave's lanes validate such records on their own,
-                // a whole chunk in one gather.  Measured and left off: the take path loses a round trip per small region (4.9 -> 4.1 M cycles per
-                // frame) but every chunk with unused seeds pays the sixteen-word record fetch and the gather up front (3.5 -> 5.3 M): 7.7 ms per
-                // frame against 7.4 without.  Kept because it is what a fully prefetched main wave would build on.
-#ifdef SSLAM_CL_INLINE
-                const bool inl = nA < P.minRegSize && nA <= CL_INL;      // (below the minimum size: no rectangle, no refine, the last list is the first)
-#else
-                const bool inl = false;
-#endif
-                if (!inl) for (int i = lane; i < total; i += 64) g_stu(arena + ah + i, lstA[i]);
+                // ---- publish: lists, record, (stores complete), flag
+                for (int i = lane; i < total; i += 64) g_stu(arena + ah + i, lstA[i]);
                 {
-                    const unsigned flags = (refined ? MW_REFINED : 0) | (sl.reduced ? MW_REDUCED : 0) | (emit ? MW_EMIT : 0) | (inl ? MW_INLINE : 0);
+                    const unsigned flags = (refined ? MW_REFINED : 0) | (sl.reduced ? MW_REDUCED : 0) | (emit ? MW_EMIT : 0);
                     unsigned* r = (unsigned*)&cl.rec[(size_t)sc * CL_RES + k];
                     unsigned w = 0u;
                     if (lane == 0) w = (unsigned)(laneBase + first) | (flags << 8);
-                    else if (lane == 1) w = (unsigned)(inl ? 0 : ah) | ((unsigned)nA << 16);
+                    else if (lane == 1) w = (unsigned)ah | ((unsigned)nA << 16);
                     else if (lane == 2) w = (unsigned)sl.nB | ((unsigned)n << 16);
                     else if (lane == 3) w = lo;
                     else if (lane == 4) w = hi;
-                    else if (lane < 5 + CL_INL && inl && lane - 5 < nA) w = lstA[lane - 5];
-                    if (lane < 5 + CL_INL) g_stu(r + lane, w);
+                    if (lane < 5) g_stu(r + lane, w);
                 }
                 cl_stores_done();
-                ++k; if (!inl) ah += total; haveRes |= 1ull << first;
+                ++k; ah += total; haveRes |= 1ull << first;
                 if (lane == 0) g_st(&H->flag, (pass == 0 ? first + 1 : CL_SUB) | (k << 8));
                 // what the region leaves USED enters the shared map that steers seed choice; candidates of this chunk inside it are dropped
                 if (cl.specShift >= 0) {
@@ -529,6 +615,8 @@ __global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl(uint8_t* __res
     __shared__ double red[CL_WAVES][3 * 64];
     __shared__ float4 stashes[CL_WAVES][64];
     const int b = blockIdx.x & 7, role = blockIdx.x >> 3, wave = threadIdx.x >> 6;
+    const bool nofeed = (window & (1 << 20)) != 0;      // (experiment knob: no feeder wave)
+    if (window >= 0) window &= (1 << 20) - 1;
     if (b >= nframes) return;
     uint8_t* area = clArea + (size_t)b * clFrameBytes;
     ClShared cl;
@@ -539,12 +627,23 @@ __global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl(uint8_t* __res
     cl.rec = (ClRec*)(cl.specMap + ((specWords + 127) & ~127));
     cl.arena = (unsigned*)(cl.rec + maxSubs * CL_RES);
     cl.specShift = specShift; cl.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
-    cl.nHelpers = nWG * CL_WAVES - 1; cl.window = window;
-    const int mainWords = role == 0 ? QCAP + 4 + TorusFrame::WORDS + CL_SCAN : 0;
-    unsigned* mine = dynLds + mainWords + (size_t)wave * (CL_LIST + MW_BM_WORDS);
-    for (int i = threadIdx.x & 63; i < MW_BM_WORDS; i += 64) mine[CL_LIST + i] = 0u;
-    if (role == 0) for (int i = threadIdx.x; i < TorusFrame::WORDS; i += blockDim.x) dynLds[QCAP + 4 + i] = 0u;
+    cl.nHelpers = (nWG - 1) * CL_HPW; cl.window = window;
+    unsigned* mine = dynLds + (size_t)wave * (CL_LIST + ClTorus::WORDS);      // (helper workgroups)
+    if (role != 0 && wave < CL_HPW) for (int i = threadIdx.x & 63; i < ClTorus::WORDS; i += 64) mine[CL_LIST + i] = 0u;
+    if (role == 0) {
+        for (int i = threadIdx.x; i < TorusFrame::WORDS; i += blockDim.x) dynLds[QCAP + 4 + i] = 0u;
+        ClSlot* ring = (ClSlot*)(dynLds + QCAP + 4 + TorusFrame::WORDS + CL_SCAN);
+        if (threadIdx.x < CL_RING) { ring[threadIdx.x].chunk = -1; ring[threadIdx.x].ready = 0; }
+        if (threadIdx.x == 0) { ClLocal* loc = (ClLocal*)(ring + CL_RING); loc->mainChunk = 0; loc->commitSeq = 0; loc->finished = 0; }
+    }
     __syncthreads();
-    if (role == 0 && wave == 0) cl_main(ws, P, b, dynLds, dynLds + QCAP + 4, dynLds + QCAP + 4 + TorusFrame::WORDS, red[0], stashes[0], cl);
-    else cl_helper(role * CL_WAVES + wave - 1, ws, P, b, cl, mine, mine + CL_LIST, stashes[wave], red[wave]);
+    if (role == 0) {
+        // the main wave's workgroup: main wave + feeder.  No helpers here: their L1 invalidations cost the main wave 4 % (7.21 -> 6.89 ms)
+        ClSlot* ring = (ClSlot*)(dynLds + QCAP + 4 + TorusFrame::WORDS + CL_SCAN);
+        ClLocal* loc = (ClLocal*)(ring + CL_RING);
+        if (wave == 0) cl_main(ws, P, b, dynLds, dynLds + QCAP + 4, dynLds + QCAP + 4 + TorusFrame::WORDS, red[0], stashes[0], cl, ring, loc);
+        else if (wave == 1 && !nofeed) cl_feeder(ws, P, b, cl, ring, loc);
+        return;
+    }
+    else if (wave < CL_HPW) cl_helper((role - 1) * CL_HPW + wave, ws, P, b, cl, mine, mine + CL_LIST, stashes[wave], red[wave]);
 }

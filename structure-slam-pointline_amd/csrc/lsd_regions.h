@@ -37,6 +37,7 @@ __device__ __forceinline__ int mw_bit(int x, int y) { return ((y & 255) << 8) | 
 // G = the bitmap's geometry (a torus of XMASK+1 x YMASK+1 bits; REACH = how far from its seed a region may go before bits could alias).
 enum { MARK_MAP = 0, MARK_SPEC = 1, MARK_PRIV = 2 };
 struct TorusHelper { static constexpr int XMASK = 255, YMASK = 255, YSHIFT = 8, REACH = MW_REACH, WORDS = MW_BM_WORDS; };
+struct TorusWide { static constexpr int XMASK = 511, YMASK = 511, YSHIFT = 9, REACH = 254, WORDS = 512 * 512 / 32; };      // cluster form helpers: three per workgroup, 32 KB each
 struct TorusFrame { static constexpr int XMASK = 1023, YMASK = 511, YSHIFT = 10, REACH = 1 << 20, WORDS = 1024 * 512 / 32; };      // no aliasing for frames up to 1024 x 512
 template <class G> __device__ __forceinline__ int bm_bit(int x, int y) { return ((y & G::YMASK) << G::YSHIFT) | (x & G::XMASK); }
 __device__ __forceinline__ double readlane_d(double v, int l) {

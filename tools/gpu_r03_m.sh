@@ -1,12 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R
-run() { echo "== $*"; env SSLAM_LSD_CLUSTER=1 "$@" timeout 200 python tools/latency_probe.py 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-110; }
-run SSLAM_CL_WINDOW=40 SSLAM_CL_WGS=6
-run SSLAM_CL_WINDOW=32 SSLAM_CL_WGS=5
-run SSLAM_CL_WINDOW=40 SSLAM_CL_WGS=5
-run SSLAM_CL_WINDOW=48 SSLAM_CL_WGS=6
-run SSLAM_CL_WINDOW=56 SSLAM_CL_WGS=7
-run SSLAM_CL_WINDOW=40 SSLAM_CL_WGS=4
-run SSLAM_CL_WINDOW=24 SSLAM_CL_WGS=4
-run SSLAM_CL_WINDOW=40 SSLAM_CL_WGS=6 SSLAM_CL_SMAP=0
-run SSLAM_CL_WINDOW=40 SSLAM_CL_WGS=6 SSLAM_CL_SMAP=2
+echo "== check"; timeout 300 python tools/cl_probe.py 64 2>&1 | grep -v amdgpu.ids | tail -4
+run() { echo "== $*"; env "$@" timeout 200 python tools/latency_probe.py 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-110; }
+run A=1
+run SSLAM_CL_WINDOW=48 SSLAM_CL_WGS=10
+run SSLAM_CL_WINDOW=32 SSLAM_CL_WGS=7
+run SSLAM_CL_WINDOW=40 SSLAM_CL_WGS=12
