@@ -268,9 +268,9 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) cluster = cluster && e[0] == 'c';      // "cl" / "mw" / "lat" / "thr"
         if (const char* e = getenv("SSLAM_LSD_CLUSTER")) cluster = cluster && atoi(e) != 0;
         if (cluster) {
-            int nWG = 8, window = 0, clShift = 0;
+            int nWG = 10, window = 0, clShift = 0;
             if (const char* e = getenv("SSLAM_CL_WGS")) nWG = std::max(1, std::min(CL_MAXWG, atoi(e)));
-            if (const char* e = getenv("SSLAM_CL_WINDOW")) window = std::max(-1, atoi(e)); else window = 40;      // in sub-chunks of 16 positions; -1: no helpers at all (the main wave alone)
+            if (const char* e = getenv("SSLAM_CL_WINDOW")) window = std::max(-1, atoi(e)); else window = 640 / CL_SUB;      // in sub-chunks (640 seed positions); -1: no helpers at all (the main wave alone)
             if (const char* e = getenv("SSLAM_CL_SMAP")) clShift = atoi(e);
             if (getenv("SSLAM_CL_NO_FEEDER") && window >= 0) window |= 1 << 20;      // experiment knob: the main wave fetches everything itself
             const int clSpecWords = clShift < 0 ? 0 : (((P.sw + (1 << clShift) - 1) >> clShift) * ((P.sh + (1 << clShift) - 1) >> clShift) + 31) / 32;

@@ -25,7 +25,11 @@
 //     not there.  Every wait of the main wave is bounded.
 #pragma once
 
-constexpr int CL_SUB = 16, CL_NSUB = 64 / CL_SUB;      // helpers claim sub-chunks of 16 seed positions (four helpers share a chunk of the main wave: the dense head of the seed list is where it waits)
+#ifndef SSLAM_CL_SUB_SHIFT
+#define SSLAM_CL_SUB_SHIFT 2          // sub-chunks of 16 / 8 / 4 / 2 positions: 6.69 / 6.49 / 6.29 / 6.90 ms per frame (2: the claims cost more than the finer dealing returns)
+#endif
+constexpr int CL_SUB_SHIFT = SSLAM_CL_SUB_SHIFT;
+constexpr int CL_SUB = 1 << CL_SUB_SHIFT, CL_NSUB = 64 / CL_SUB;      // helpers claim sub-chunks of 16 seed positions (four helpers share a chunk of the main wave: the dense head of the seed list is where it waits)
 constexpr int CL_RES = CL_SUB;             // results per sub-chunk header: one per position
 constexpr int CL_ARENA = 1 << 16;          // list words per helper per frame (MwRes::off is 16 bits)
 constexpr int CL_LIST = 3072;              // LDS words per helper for the region in progress (lists A, B, F and the rectangle)
@@ -54,7 +58,7 @@ constexpr int CL_STG = 32;                 // list entries (A then B) staged per
 struct ClSlot {
     int chunk, ready, pad0, pad1;
     int st[CL_NSUB], fl[CL_NSUB];          // state / flag of the sub-chunks as staged (st 1: no result expected)
-    MwRes rec[64];                         // record (l & 15) of sub-chunk (l >> 4)
+    MwRes rec[64];                         // record (l & (CL_SUB - 1)) of sub-chunk (l >> CL_SUB_SHIFT)
     int gseq[64];                          // the main wave's commit counter before the record's points were gathered; -1: not staged
     unsigned e[64][CL_STG];
     float v[64][CL_STG];
@@ -154,12 +158,12 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             stashReady = true;
         };
         // whose sub-chunks?  A helper that has started one owns it; the main wave claims the others (with unused seeds) for itself.  Lanes
-        // 0..3 fetch state and flag of the four headers in one round trip; lane l then holds record (l & 15) of sub-chunk (l >> 4) -- and,
+        // 0..CL_NSUB-1 fetch state and flag of the chunk's headers in one round trip; lane l then holds record (l % CL_SUB) of sub-chunk (l / CL_SUB) -- and,
         // when the record carries its points itself (a small region: most of them), validates it ON ITS OWN: every lane gathers the map
         // values of its record's points, all records of the chunk in one round trip, instead of one list load + one gather per take.
         const int sc0 = (pos0 >> 6) * CL_NSUB;
         ClSub* S4 = &cl.sub[sc0];
-        const int mySub = lane >> 4, myK = lane & 15;
+        const int mySub = lane >> CL_SUB_SHIFT, myK = lane & (CL_SUB - 1);
         const ClRec* myRecPtr = &cl.rec[(size_t)(sc0 + mySub) * CL_RES + myK];
         int stv = 1, flv = 0, nsv = 0;               // per sub-chunk, in lane s: state, last flag read, records loaded
         ClSlot* SL = &ring[(pos0 >> 6) % CL_RING];
@@ -167,7 +171,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
         int myGseq = -1;                             // staged: the commit counter at the gather of my record's points (-1: not staged)
         if (staged) ++clStagedChunks;
         if (!staged) {
-            const bool need = lane < CL_NSUB && ((unM >> (16 * lane)) & 0xFFFFull) != 0;
+            const bool need = lane < CL_NSUB && ((unM >> (CL_SUB * lane)) & ((1ull << CL_SUB) - 1)) != 0;
             if (need) {
                 stv = g_ld(&S4[lane].state); flv = g_ld(&S4[lane].flag);
                 if (stv == 0) { stv = atomicCAS(&S4[lane].state, 0, 1); if (stv == 0) stv = 1; }
@@ -186,8 +190,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             if (lane < CL_NSUB) { stv = SL->st[lane]; flv = SL->fl[lane]; nsv = min(flv >> 8, CL_RES); }
             myRes = SL->rec[lane]; myGseq = SL->gseq[lane];
         } else {   // what is published already, all four sub-chunks at once
-            const int f0 = __builtin_amdgcn_readlane(flv, 0), f1 = __builtin_amdgcn_readlane(flv, 1), f2 = __builtin_amdgcn_readlane(flv, 2), f3 = __builtin_amdgcn_readlane(flv, 3);
-            const int myFlag = mySub == 0 ? f0 : mySub == 1 ? f1 : mySub == 2 ? f2 : f3;
+            const int myFlag = __builtin_amdgcn_ds_bpermute(mySub << 2, flv);      // the flag lane mySub holds
             fetch_records(myK < min(myFlag >> 8, CL_RES));
             if (lane < CL_NSUB) nsv = min(flv >> 8, CL_RES);
         }
@@ -200,7 +203,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
         while (unM) {
             const int first = __ffsll((long long)unM) - 1;
             unM &= unM - 1;
-            const int s = first >> 4, f16 = first & 15;
+            const int s = first >> CL_SUB_SHIFT, f16 = first & (CL_SUB - 1);
             ClSub* H = &S4[s];
             const int stS = __builtin_amdgcn_readlane(stv, s);
             int owner = stS >= 2 ? stS - 2 : -1;
@@ -375,7 +378,7 @@ __device__ void cl_feeder(uint8_t* __restrict__ ws, const LsdPlan& P, int b, con
     const unsigned* order = (const unsigned*)(base + P.offOrder);
     const Misc* misc = (const Misc*)(base + P.offMisc);
     const int nOrd = misc->nDefined, nChunks = (nOrd + 63) >> 6;
-    const int mySub = lane >> 4, myK = lane & 15;
+    const int mySub = lane >> CL_SUB_SHIFT, myK = lane & (CL_SUB - 1);
     if (cl.window < 0) return;
     for (int c = 1; c < nChunks; ++c) {
         // the slot of chunk c is free once the main wave is past chunk c - CL_RING
@@ -396,7 +399,7 @@ __device__ void cl_feeder(uint8_t* __restrict__ ws, const LsdPlan& P, int b, con
         if (lane == 0) { S->ready = 0; S->chunk = c; }
         // states and flags of the sub-chunks with unused seeds; a helper still in its first pass is waited for until the main wave gets here
         const ClSub* S4 = &cl.sub[c * CL_NSUB];
-        const bool need = lane < CL_NSUB && ((unM >> (16 * lane)) & 0xFFFFull) != 0;
+        const bool need = lane < CL_NSUB && ((unM >> (CL_SUB * lane)) & ((1ull << CL_SUB) - 1)) != 0;
         int stv = 1, flv = 0;
         bool pending = true;
         for (int spin = 0; spin < (1 << 22); ++spin) {
@@ -408,10 +411,8 @@ __device__ void cl_feeder(uint8_t* __restrict__ ws, const LsdPlan& P, int b, con
         if (pending) continue;                                   // not staged: the main wave sorts it out itself
         cl_compiler_fence();
         if (lane < CL_NSUB) { S->st[lane] = need ? stv : 1; S->fl[lane] = need ? flv : 0; }
-        const int f0 = __builtin_amdgcn_readlane(flv, 0), f1 = __builtin_amdgcn_readlane(flv, 1), f2 = __builtin_amdgcn_readlane(flv, 2), f3 = __builtin_amdgcn_readlane(flv, 3);
-        const int s0 = __builtin_amdgcn_readlane(stv, 0), s1 = __builtin_amdgcn_readlane(stv, 1), s2 = __builtin_amdgcn_readlane(stv, 2), s3 = __builtin_amdgcn_readlane(stv, 3);
-        const int myFlag = mySub == 0 ? f0 : mySub == 1 ? f1 : mySub == 2 ? f2 : f3;
-        const int myOwner = (mySub == 0 ? s0 : mySub == 1 ? s1 : mySub == 2 ? s2 : s3) - 2;
+        const int myFlag = __builtin_amdgcn_ds_bpermute(mySub << 2, flv);
+        const int myOwner = __builtin_amdgcn_ds_bpermute(mySub << 2, stv) - 2;
         MwRes R; R.w0 = R.w1 = R.w2 = R.lo = R.hi = 0u;
         const bool valid = myK < min(myFlag >> 8, CL_RES);
         if (valid) {
@@ -452,7 +453,7 @@ __device__ void cl_feeder(uint8_t* __restrict__ ws, const LsdPlan& P, int b, con
 // it cannot claim another chunk (window) and the main wave is still in front of this one it looks at the chunk again: whatever is unused by
 // then and has no result -- seeds the shared map had talked it out of, seeds it gave up on -- is grown as well.  What its results would mark
 // stays in the shared map until the main wave has passed the chunk (reap).
-constexpr int CL_FIFO = 16;                // chunks a helper can have published and not yet retired from the shared map
+constexpr int CL_FIFO = 64;                // sub-chunks a helper can have published and not yet retired from the shared map
 __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int b, const ClShared& cl, unsigned* __restrict__ listBuf, unsigned* __restrict__ bm,
                           float4* __restrict__ stash, double* __restrict__ red) {
     typedef ClTorus G;
