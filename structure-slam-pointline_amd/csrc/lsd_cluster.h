@@ -30,7 +30,8 @@
 #endif
 constexpr int CL_SUB_SHIFT = SSLAM_CL_SUB_SHIFT;
 constexpr int CL_SUB = 1 << CL_SUB_SHIFT, CL_NSUB = 64 / CL_SUB;      // helpers claim sub-chunks of 16 seed positions (four helpers share a chunk of the main wave: the dense head of the seed list is where it waits)
-constexpr int CL_RES = CL_SUB;             // results per sub-chunk header: one per position
+constexpr int CL_RES = 2 * CL_SUB;         // result records per sub-chunk: one per position (the main wave's lanes hold the first CL_SUB) + as many for results a helper publishes AGAIN
+                                           // after finding its first version overtaken by a commit (records are written once, never rewritten)
 constexpr int CL_ARENA = 1 << 16;          // list words per helper per frame (MwRes::off is 16 bits)
 constexpr int CL_LIST = 3072;              // LDS words per helper for the region in progress (lists A, B, F and the rectangle)
 constexpr int CL_WAVES = 4;                // waves per workgroup (one per SIMD)
@@ -129,7 +130,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
     unsigned accCurLo = 0xFFFFFFFFu, accCurHi = 0u, accNextLo = 0xFFFFFFFFu, accNextHi = 0u;      // packed x | y << 16 minima / maxima; Lo > Hi: empty
     bool accCurAny = false, accNextAny = false;
     int commitSeq = 0, logSeq = -1; unsigned logLo = 0u, logHi = 0u;      // lane (seq & 63) keeps the box of commit seq
-    long long clStagedChunks = 0, clStagedTakes = 0, clRegather = 0;
+    long long clStagedChunks = 0, clStagedTakes = 0, clRegather = 0, clLate = 0;
     for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
         const int gj = (pos0 >> 6) & (CL_GROUP - 1);
         if (gj == 0) {
@@ -187,12 +188,12 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             }
         };
         if (staged) {   // everything the global path fetches below, from LDS
-            if (lane < CL_NSUB) { stv = SL->st[lane]; flv = SL->fl[lane]; nsv = min(flv >> 8, CL_RES); }
+            if (lane < CL_NSUB) { stv = SL->st[lane]; flv = SL->fl[lane]; nsv = min(flv >> 8, CL_SUB); }
             myRes = SL->rec[lane]; myGseq = SL->gseq[lane];
         } else {   // what is published already, all four sub-chunks at once
             const int myFlag = __builtin_amdgcn_ds_bpermute(mySub << 2, flv);      // the flag lane mySub holds
-            fetch_records(myK < min(myFlag >> 8, CL_RES));
-            if (lane < CL_NSUB) nsv = min(flv >> 8, CL_RES);
+            fetch_records(myK < min(myFlag >> 8, CL_SUB));
+            if (lane < CL_NSUB) nsv = min(flv >> 8, CL_SUB);
         }
         auto load_records = [&](int s, int nres) {      // records [nsv_s, nres) of sub-chunk s
             const int had = __builtin_amdgcn_readlane(nsv, s);
@@ -228,72 +229,94 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                 if (lane == s) flv = flag;
             }
             const long long c1 = CL_CLK(); cWait += c1 - c0;
+            // validate + commit one published result.  gs / hl: the feeder's staging of it (gs < 0: not staged); returns whether it was taken
+            auto try_take = [&](const MwRes& r, int gs, int hl) -> bool {
+                const int nA = r.nA(), nB = r.nB(), nF = r.nF(), flags = r.flags();
+                const unsigned* lstA = cl.arena + (size_t)owner * CL_ARENA + r.off();
+                const unsigned* lstB = lstA + nA;
+                const unsigned* lstF = (flags & MW_REDUCED) ? lstB + nB : (flags & MW_REFINED) ? lstB : lstA;
+                bool ok = true;
+                float v0 = 0.f; int ti0 = 0;
+                // the rectangle's 24 words travel with the first list load (one round trip instead of two)
+                const unsigned* rw = lstB + nB + ((flags & MW_REDUCED) ? nF : 0);
+                const unsigned wv = ((flags & MW_EMIT) && lane < 24) ? g_ldu(rw + lane) : 0u;
+                bool viaStage = false;
+                if (gs >= 0 && nA + nB > 1) {
+                    // staged result: list and map values are in LDS.  Values gathered before commit gs + 1 .. commitSeq can be out of date
+                    // only inside those commits' boxes
+                    const bool young = logSeq > gs && boxes_meet(logLo, logHi, r.lo, r.hi, 0);
+                    const bool dirty = commitSeq - gs > 64 || __ballot(young) != 0;
+                    const int i = lane;
+                    bool usedNow = false;
+                    if (i < nA + nB) {
+                        const unsigned e = SL->e[hl][i]; const int ti = pl.ti(e);
+                        const float v = dirty ? pl.T[ti] : SL->v[hl][i];
+                        usedNow = !t_free(v); v0 = v; ti0 = ti; e0 = e;
+                    }
+                    ok = __ballot(usedNow) == 0;
+                    viaStage = true; ++clStagedTakes; if (dirty) ++clRegather;
+                }
+                for (int bs = 0; !viaStage && ok && nA + nB > 1 && bs < nA + nB; bs += 64) {      // (b): everything the helper accepted on the way is unused now
+                    const int i = bs + lane;
+                    bool usedNow = false;
+                    if (i < nA + nB) { const unsigned e = g_ldu(lstA + i); const int ti = pl.ti(e); const float v = pl.T[ti]; usedNow = !t_free(v); if (bs == 0) { v0 = v; ti0 = ti; e0 = e; } }
+                    ok = __ballot(usedNow) == 0;
+                }
+                if (!ok) return false;
+                if (nA + nB == 1) { if (lane == first) pl.T[tiSeed] = t_used(a0); }
+                else if (!(flags & MW_REFINED) && nF <= 64) { if (lane < nF) pl.T[ti0] = t_used(v0); }
+                else for (int i = lane; i < nF; i += 64) { unsigned* t = pl.Tb() + pl.ti(g_ldu(lstF + i)); *t |= USED_BIT; }
+                took = true; n = nA; bxLo = r.lo; bxHi = r.hi;
+                tookEmit = (flags & MW_EMIT) != 0;
+                if (tookEmit) {
+                    double* rd = (double*)&tookRec;
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) rd[j] = __hiloint2double(__builtin_amdgcn_readlane((int)wv, 2 * j + 1), __builtin_amdgcn_readlane((int)wv, 2 * j));
+                }
+                clTaken += 1 + ((long long)n << 32);
+                return true;
+            };
             if (owner >= 0) {
                 cl_compiler_fence();
                 int nres = min(flag >> 8, CL_RES);
-                if (nres > __builtin_amdgcn_readlane(nsv, s)) load_records(s, nres);
-                unsigned long long hit = __ballot(mySub == s && myK < nres && myRes.lane() == first);
-                if (!hit && nres < CL_RES) {                // nothing for this seed: a second look of the helper may have added it since the flag was read
-                    flag = __builtin_amdgcn_readfirstlane(g_ld(&H->flag));
-                    if (lane == s) flv = flag;
-                    cl_compiler_fence();
-                    nres = min(flag >> 8, CL_RES);
-                    if (nres > __builtin_amdgcn_readlane(nsv, s)) {
-                        load_records(s, nres);
-                        hit = __ballot(mySub == s && myK < nres && myRes.lane() == first);
-                    }
-                }
+                if (min(nres, CL_SUB) > __builtin_amdgcn_readlane(nsv, s)) load_records(s, min(nres, CL_SUB));
+                // the lanes hold records 0 .. CL_SUB-1 of the sub-chunk; a seed can have two of them (the helper published again): the later one counts
+                const unsigned long long hit = __ballot(mySub == s && myK < min(nres, CL_SUB) && myRes.lane() == first);
+                int triedK = -1;
+                bool done = false;
                 if (hit) {
-                    const int hl = __ffsll((long long)hit) - 1;
+                    const int hl = 63 - __clzll((long long)hit);
                     MwRes r;
                     r.w0 = (unsigned)__builtin_amdgcn_readlane((int)myRes.w0, hl); r.w1 = (unsigned)__builtin_amdgcn_readlane((int)myRes.w1, hl);
                     r.w2 = (unsigned)__builtin_amdgcn_readlane((int)myRes.w2, hl); r.lo = (unsigned)__builtin_amdgcn_readlane((int)myRes.lo, hl);
                     r.hi = (unsigned)__builtin_amdgcn_readlane((int)myRes.hi, hl);
-                    const int nA = r.nA(), nB = r.nB(), nF = r.nF(), flags = r.flags();
-                    const unsigned* lstA = cl.arena + (size_t)owner * CL_ARENA + r.off();
-                    const unsigned* lstB = lstA + nA;
-                    const unsigned* lstF = (flags & MW_REDUCED) ? lstB + nB : (flags & MW_REFINED) ? lstB : lstA;
-                    bool ok = true;
-                    float v0 = 0.f; int ti0 = 0;
-                    // the rectangle's 24 words travel with the first list load (one round trip instead of two)
-                    const unsigned* rw = lstB + nB + ((flags & MW_REDUCED) ? nF : 0);
-                    const unsigned wv = ((flags & MW_EMIT) && lane < 24) ? g_ldu(rw + lane) : 0u;
-                    const int gs = __builtin_amdgcn_readlane(myGseq, hl);
-                    bool viaStage = false;
-                    if (gs >= 0 && nA + nB > 1) {
-                        // staged result: list and map values are in LDS.  Values gathered before commit gs + 1 .. commitSeq can be out of date
-                        // only inside those commits' boxes
-                        const bool young = logSeq > gs && boxes_meet(logLo, logHi, r.lo, r.hi, 0);
-                        const bool dirty = commitSeq - gs > 64 || __ballot(young) != 0;
-                        const int i = lane;
-                        bool usedNow = false;
-                        if (i < nA + nB) {
-                            const unsigned e = SL->e[hl][i]; const int ti = pl.ti(e);
-                            const float v = dirty ? pl.T[ti] : SL->v[hl][i];
-                            usedNow = !t_free(v); v0 = v; ti0 = ti; e0 = e;
-                        }
-                        ok = __ballot(usedNow) == 0;
-                        viaStage = true; ++clStagedTakes; if (dirty) ++clRegather;
-                    }
-                    for (int bs = 0; !viaStage && ok && nA + nB > 1 && bs < nA + nB; bs += 64) {      // (b): everything the helper accepted on the way is unused now
-                        const int i = bs + lane;
-                        bool usedNow = false;
-                        if (i < nA + nB) { const unsigned e = g_ldu(lstA + i); const int ti = pl.ti(e); const float v = pl.T[ti]; usedNow = !t_free(v); if (bs == 0) { v0 = v; ti0 = ti; e0 = e; } }
-                        ok = __ballot(usedNow) == 0;
-                    }
-                    if (ok) {
-                        if (nA + nB == 1) { if (lane == first) pl.T[tiSeed] = t_used(a0); }
-                        else if (!(flags & MW_REFINED) && nF <= 64) { if (lane < nF) pl.T[ti0] = t_used(v0); }
-                        else for (int i = lane; i < nF; i += 64) { unsigned* t = pl.Tb() + pl.ti(g_ldu(lstF + i)); *t |= USED_BIT; }
-                        took = true; n = nA; bxLo = r.lo; bxHi = r.hi;
-                        tookEmit = (flags & MW_EMIT) != 0;
-                        if (tookEmit) {
-                            double* rd = (double*)&tookRec;
+                    triedK = hl & (CL_SUB - 1);
+                    done = try_take(r, __builtin_amdgcn_readlane(myGseq, hl), hl);
+                    if (!done) { ++clRefused; wasRefused = true; }
+                }
+                if (!done) {
+                    // nothing for this seed, or what there was has been overtaken by a commit: the helper may have published (again) since the
+                    // flag was read -- a second look, a re-validation.  One poll, then every record of the sub-chunk behind the one tried
+                    flag = __builtin_amdgcn_readfirstlane(g_ld(&H->flag));
+                    if (lane == s) flv = flag;
+                    cl_compiler_fence();
+                    nres = min(flag >> 8, CL_RES);
+                    if (nres > triedK + 1) {
+                        const unsigned* rb = (const unsigned*)&cl.rec[(size_t)(sc0 + s) * CL_RES];
+                        MwRes best; best.w0 = best.w1 = best.w2 = best.lo = best.hi = 0u; int bestK = -1;
 #pragma unroll
-                            for (int j = 0; j < 12; ++j) rd[j] = __hiloint2double(__builtin_amdgcn_readlane((int)wv, 2 * j + 1), __builtin_amdgcn_readlane((int)wv, 2 * j));
+                        for (int kk = 0; kk < CL_RES; ++kk) {
+                            if (kk > triedK && kk < nres) {
+                                const unsigned* q = rb + kk * (sizeof(ClRec) / 4);
+                                MwRes c; c.w0 = g_ldu(q); c.w1 = g_ldu(q + 1); c.w2 = g_ldu(q + 2); c.lo = g_ldu(q + 3); c.hi = g_ldu(q + 4);
+                                if (c.lane() == first) { best = c; bestK = kk; }
+                            }
                         }
-                        clTaken += 1 + ((long long)n << 32);
-                    } else { ++clRefused; wasRefused = true; }
+                        if (bestK >= 0) {
+                            done = try_take(best, -1, 0);
+                            if (done) { ++clLate; wasRefused = false; } else if (!wasRefused) { ++clRefused; wasRefused = true; }
+                        }
+                    }
                 }
             }
             const long long c2 = CL_CLK(); cTake += c2 - c1;
@@ -361,7 +384,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
     if (lane == 0) {
         g_st(&cl.ctl->finished, 1);
         misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
-        misc->cyc[0] = clWait; misc->cyc[1] = clOwnChunks; misc->cyc[2] = clRefused; misc->cyc[3] = clStagedChunks | (clRegather << 32); misc->cyc[4] = clStagedTakes;
+        misc->cyc[0] = clWait; misc->cyc[1] = clOwnChunks; misc->cyc[2] = clRefused; misc->cyc[3] = clStagedChunks | (clRegather << 32); misc->cyc[4] = clStagedTakes | (clLate << 32);
 #ifdef SSLAM_CL_CYCLES
         misc->cyc[0] = cWait; misc->cyc[1] = cTake; misc->cyc[2] = cOwn; misc->cyc[3] = cRect; misc->cyc[4] = CL_CLK() - cStart;
         cl.ctl->stat[4] = clOwnRefused; cl.ctl->stat[5] = clOwn;
@@ -414,7 +437,7 @@ __device__ void cl_feeder(uint8_t* __restrict__ ws, const LsdPlan& P, int b, con
         const int myFlag = __builtin_amdgcn_ds_bpermute(mySub << 2, flv);
         const int myOwner = __builtin_amdgcn_ds_bpermute(mySub << 2, stv) - 2;
         MwRes R; R.w0 = R.w1 = R.w2 = R.lo = R.hi = 0u;
-        const bool valid = myK < min(myFlag >> 8, CL_RES);
+        const bool valid = myK < min(myFlag >> 8, CL_SUB);
         if (valid) {
             const unsigned* r = (const unsigned*)&cl.rec[(size_t)(c * CL_NSUB + mySub) * CL_RES + myK];
             R.w0 = g_ldu(r); R.w1 = g_ldu(r + 1); R.w2 = g_ldu(r + 2); R.lo = g_ldu(r + 3); R.hi = g_ldu(r + 4);
@@ -516,6 +539,10 @@ __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
         const int cy = idx >> 16, cx = idx & 0xFFFF, tiSeed = pl.ti(idx);
         unsigned long long haveRes = 0;      // seeds with a result, or that this helper gave up on
         int k = 0; bool room = true;
+        // what this helper has published for the sub-chunk (for the re-validation of later passes): seed lane, list offset, points of A and B
+        int pubLane[CL_RES], pubOff[CL_RES], pubCnt[CL_RES]; unsigned pubLive = 0u;
+#pragma unroll
+        for (int j = 0; j < CL_RES; ++j) { pubLane[j] = 0; pubOff[j] = 0; pubCnt[j] = 0; }
         for (int pass = 0; room; ++pass) {
             if (pass > 0) {
                 // another look only while there is nothing else to do (the next chunk is outside the window) and the main wave is still in front
@@ -525,6 +552,22 @@ __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 if (g_ld(&ctl->cursor) <= (mp >> 6) * CL_NSUB + cl.window && fHead - fTail < CL_FIFO - 1) break;
                 __builtin_amdgcn_s_sleep(8);
                 asm volatile("buffer_inv sc1" ::: "memory");
+                // Re-validation: a published result that a commit has overtaken since (one of its points is used now) would be refused by
+                // the main wave, which then grows the seed itself.  While this helper has nothing else to do it checks its results the way
+                // the main wave will, and a seed whose result died is grown again below and published as a NEW record (the later one counts).
+#pragma unroll
+                for (int j = 0; j < CL_RES; ++j) {
+                    if (j < k && ((pubLive >> j) & 1u) && pubCnt[j] > 1) {
+                        bool usedAny = false;
+                        for (int bs = 0; bs < pubCnt[j]; bs += 64) {
+                            const int i = bs + lane;
+                            bool u = false;
+                            if (i < pubCnt[j]) u = !t_free(pl.T[pl.ti(g_ldu(arena + pubOff[j] + i))]);
+                            usedAny = usedAny || __ballot(u) != 0;
+                        }
+                        if (usedAny) { pubLive &= ~(1u << j); haveRes &= ~(1ull << pubLane[j]); CL_STAT(6, 1); }
+                    }
+                }
             }
             const float a0 = have ? pl.T[tiSeed] : NOTDEF_F;
             unsigned long long unM = __ballot(t_free(a0) && (pass > 0 || !cl_spec(cl, cx, cy))) & ~haveRes;
@@ -588,6 +631,9 @@ __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                     if (lane < 5) g_stu(r + lane, w);
                 }
                 cl_stores_done();
+#pragma unroll
+                for (int j = 0; j < CL_RES; ++j) if (j == k) { pubLane[j] = first; pubOff[j] = ah; pubCnt[j] = nAB; }
+                pubLive |= 1u << k;
                 ++k; ah += total; haveRes |= 1ull << first;
                 if (lane == 0) g_st(&H->flag, (pass == 0 ? first + 1 : CL_SUB) | (k << 8));
                 // what the region leaves USED enters the shared map that steers seed choice; candidates of this chunk inside it are dropped

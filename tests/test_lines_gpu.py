@@ -139,11 +139,12 @@ def test_lsd_core_flavours(fe, ctx, oracle, flavour, monkeypatch):
         assert taken > 1000, "the %s form took almost no region from its helpers: %d" % (flavour, taken)
 
 
-@pytest.mark.parametrize("knobs", [{"SSLAM_CL_WGS": "1"}, {"SSLAM_CL_WGS": "16", "SSLAM_CL_WINDOW": "400"}, {"SSLAM_CL_WINDOW": "-1"}, {"SSLAM_CL_WINDOW": "3"},
-                                   {"SSLAM_CL_SMAP": "-1"}, {"SSLAM_CL_SMAP": "2", "SSLAM_CL_WGS": "3"}])
+@pytest.mark.parametrize("knobs", [{"SSLAM_CL_WGS": "2"}, {"SSLAM_CL_WGS": "16", "SSLAM_CL_WINDOW": "1600"}, {"SSLAM_CL_WINDOW": "-1"}, {"SSLAM_CL_WINDOW": "6"},
+                                   {"SSLAM_CL_SMAP": "-1"}, {"SSLAM_CL_SMAP": "2", "SSLAM_CL_WGS": "3"}, {"SSLAM_CL_NO_FEEDER": "1"}])
 def test_lsd_cluster_configurations(fe, ctx, oracle, knobs, monkeypatch):
-    """three helpers .. sixty-three, helpers far ahead of the main wave (stale views, refused results) or barely ahead, no helpers at all (every
-    seed through the main wave's private growth + commit), no / coarser shared map: the schedule changes completely, the output must not"""
+    """three helpers .. forty-five, helpers far ahead of the main wave (stale views, refused results, second publications) or barely ahead, no
+    helpers at all (every seed through the main wave's private growth + commit), no / coarser shared map, no feeder wave (every take through
+    the global path): the schedule changes completely, the output must not"""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     monkeypatch.setenv("SSLAM_LSD_FLAVOUR", "cl")

@@ -10,7 +10,7 @@ fe = pkg.frontend(); ctx = fe.Context(0)
 cur, prev = bench.synth_frames(640, 480, 64, 0)
 lx = fe.LineExtractor(ctx, 200)
 orc = None if "--nocheck" in sys.argv else oracle_lib.Oracle()
-bad = 0; ts = []; acc = np.zeros(8); cyc = np.zeros(5); hst = np.zeros(8, np.int64); stg = np.zeros(3)
+bad = 0; ts = []; acc = np.zeros(8); cyc = np.zeros(5); hst = np.zeros(8, np.int64); stg = np.zeros(4)
 for i, f in enumerate(cur[:n]):
     lx(f)
     t0 = time.perf_counter(); kl, ld, fn = lx(f); ts.append((time.perf_counter() - t0) * 1e3)
@@ -18,7 +18,7 @@ for i, f in enumerate(cur[:n]):
     cyc += np.array(o[:5], float)
     if "--cycles" in sys.argv:
         o2 = (C.c_longlong * 8)(); fe.lib().sslam_lines_debug_cluster(lx.h, 0, o2); hst += np.array([int(x) for x in o2], np.int64)
-    stg += np.array([o[3] & 0xFFFFFFFF, o[3] >> 32, o[4]], float)
+    stg += np.array([o[3] & 0xFFFFFFFF, o[3] >> 32, o[4] & 0xFFFFFFFF, o[4] >> 32], float)
     acc += np.array([o[5] & 0xFFFFFFFF, o[5] >> 32, o[6] & 0xFFFFFFFF, o[6] >> 32, o[2], o[1], o[0], o[7]], float)
     if orc is not None:
         okl, old, ofn, oraw = orc.lines_extract(f, 200)
@@ -27,7 +27,7 @@ for i, f in enumerate(cur[:n]):
         if not same: print("frame", i, "DIFFERS: segments", len(lx.debug_segments(0)), "oracle", len(oraw))
 ts = np.array(ts)
 if "--cycles" not in sys.argv:
-    print("feeder: chunks staged %.0f, takes validated from LDS %.0f (gathered again after a nearby commit: %.0f) per frame" % (stg[0] / n, stg[2] / n, stg[1] / n))
+    print("feeder: chunks staged %.0f, takes validated from LDS %.0f (gathered again after a nearby commit: %.0f); results taken from a helper's second publication %.1f per frame" % (stg[0] / n, stg[2] / n, stg[1] / n, stg[3] / n))
 if "--cycles" in sys.argv:      # library built with -DSSLAM_CL_CYCLES: cyc[0..4] = wait, validate + take, own growth, own rect / refine / commit, total
     tot = cyc[4]
     print("main wave %.2f Mcycles/frame: wait %.1f%%  validate+take %.1f%%  own growth %.1f%%  own rect/refine/commit %.1f%%  seed scans and the rest %.1f%%" % (
