@@ -351,6 +351,12 @@ int sslam_lines_batch_status_dev(sslam_lines* ln, int cap, int32_t* d_status4, v
  * and leaves issue slots free, the kernels in front of it are bandwidth-bound and do not: a second stream that waits for the event overlaps
  * the core instead of the prologue.  The event stays the caller's. */
 int sslam_lines_set_core_event(sslam_lines* ln, void* hip_event);
+/* Two extractors that take turns (a batch processed as two half batches, each on its own streams): the sequential core wants every wave slot
+ * of the chip, so two cores must not overlap -- but one half's kernels BEHIND its core (NFA stages, LBD: VALU-bound) overlap well with the
+ * other half's kernels IN FRONT of its core (blur, gradient, counting sort: bandwidth-bound).  Every following sslam_lines_extract_batch_dev
+ * of `ln` makes its stream wait for `wait_event` right before the core (NULL: no wait; an event that was never recorded does not block) and
+ * records `done_event` right behind it (NULL: nothing).  The events stay the caller's. */
+int sslam_lines_set_core_gate(sslam_lines* ln, void* wait_event, void* done_event);
 /* Host-buffer batch (SURVEY.md §8(b) `sslam_frontend_batch`): n frames of one size in host memory through Frame::ExtractORB and, when
  * `lines` is not NULL, Frame::ExtractLSD (src/Frame.cc:150-161); frame i starts at images + i*image_stride (row pitch `stride`).
  * Per-frame results in the caller's arrays: kp_out[n*cap], desc_out[n*cap*32], nkp_out[n], kl_out[n*lcap], ldesc_out[n*lcap*32],

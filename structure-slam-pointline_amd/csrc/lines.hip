@@ -71,6 +71,7 @@ struct sslam_lines {
     DevBuf dCl;                     // cluster form of the sequential core (lsd_cluster.h): chunk headers, shared map and list arenas of up to 8 frames
     int wsFrames = 0, lastFrames = 0;
     hipEvent_t coreEvent = nullptr;          // sslam_lines_set_core_event
+    hipEvent_t coreWait = nullptr, coreDone = nullptr;      // sslam_lines_set_core_gate
     int lastN = -1;                 // lines of the last sslam_lines_extract (still resident in dKl/dDesc)
     DevBuf dImg, dKl, dDesc, dFn, dCounts;
     HostPinned hOut;
@@ -242,6 +243,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
+        if (L->coreWait) SSLAM_HIP(hipStreamWaitEvent(st, L->coreWait, 0));      // (sslam_lines_set_core_gate: another extractor's core has the wave slots until then)
         if (L->coreEvent) SSLAM_HIP(hipEventRecord(L->coreEvent, st));
         sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st);
         bool lone = nframes < 1024;
@@ -290,6 +292,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         } else if (lone) hipLaunchKernelGGL(k_lsd_regions<true>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());      // lone waves: shortest chain
         else hipLaunchKernelGGL(k_lsd_regions<false>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());
     }
+    if (L->coreDone) SSLAM_HIP(hipEventRecord(L->coreDone, st));
     int evalWaves = nframes >= 1024 ? 1 : nframes >= 64 ? 4 : 16;      // waves per frame walking the NFA evaluations
     int countWaves = nframes >= 2048 ? 1 : nframes >= 128 ? 8 : 64;    // waves per frame walking the rectangle counts
     if (const char* e = getenv("SSLAM_COUNT_WAVES")) countWaves = std::max(1, atoi(e));
@@ -401,6 +404,12 @@ extern "C" int sslam_lines_debug_segments(sslam_lines* L, int frame, float* seg_
 extern "C" int sslam_lines_set_core_event(sslam_lines* L, void* hip_event) {
     if (!L) return SSLAM_ERR_INVALID;
     L->coreEvent = (hipEvent_t)hip_event;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_lines_set_core_gate(sslam_lines* L, void* wait_event, void* done_event) {
+    if (!L) return SSLAM_ERR_INVALID;
+    L->coreWait = (hipEvent_t)wait_event; L->coreDone = (hipEvent_t)done_event;
     return SSLAM_OK;
 }
 

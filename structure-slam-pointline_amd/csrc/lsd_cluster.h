@@ -41,7 +41,10 @@ constexpr int CL_WAVES = 4;                // waves per workgroup (one per SIMD)
 constexpr int CL_HPW = SSLAM_CL_HELPERS_PER_WG;      // helper waves per helper workgroup: 3 with a 512 x 512 torus each (reach 254 pixels: the regions helpers used to give up on were a fifth of what the main wave grew itself), 4 with 256 x 256
 typedef std::conditional<CL_HPW == 4, TorusHelper, TorusWide>::type ClTorus;
 constexpr int CL_MAXWG = 16;               // workgroups per frame at most
-constexpr int CL_SCAN = 2 * 64 * 4;          // LDS words of the main wave's look-ahead over the seed list (order entries + map values of one group of chunks)
+#ifndef SSLAM_CL_GROUP
+#define SSLAM_CL_GROUP 4
+#endif
+constexpr int CL_SCAN = 2 * 64 * SSLAM_CL_GROUP;          // LDS words of the main wave's look-ahead over the seed list (order entries + map values of one group of chunks)
 constexpr int CL_SPIN_LIMIT = 1 << 18;     // polls before the main wave stops waiting for a helper (each poll is an L2 round trip)
 struct ClSub { int state, flag; };         // per sub-chunk, zeroed per launch; state: 0 free, 1 the main wave's, 2 + h helper h's; flag = doneLane (0..16) | nres << 8
 struct alignas(16) ClRec { MwRes m; unsigned pad[3]; };           // 32 bytes; records of sub-chunk sc: rec[sc * CL_RES ..)
@@ -117,7 +120,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
     // while group g is processed (two dependent round trips per chunk were a fifth of the main wave's time -- most chunks hold no unused
     // seed at all).  A value loaded early can be out of date; everything marked since its load lies inside the union of the boxes of
     // the commits since (accCur), and only the candidates inside that box are read again.
-    constexpr int CL_GROUP = 4;
+    constexpr int CL_GROUP = SSLAM_CL_GROUP;
     unsigned* scanIdx = scanBuf; float* scanT = (float*)(scanBuf + 64 * CL_GROUP);
     unsigned nIdx[CL_GROUP]; float nT[CL_GROUP];
     auto load_group = [&](int p0) {

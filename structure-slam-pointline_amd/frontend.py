@@ -451,6 +451,10 @@ class LineExtractor:
         """hipEvent_t handle (int) recorded right before the sequential LSD core of every following batch call; 0 / None clears it"""
         _chk(lib().sslam_lines_set_core_event(self.h, C.c_void_p(int(hip_event or 0))))
 
+    def set_core_gate(self, wait_event, done_event):
+        """sslam_lines_set_core_gate: hipEvent_t handles (int; 0 / None: none) waited for right before / recorded right behind the sequential core"""
+        _chk(lib().sslam_lines_set_core_gate(self.h, C.c_void_p(int(wait_event or 0)), C.c_void_p(int(done_event or 0))))
+
     def debug_segments(self, frame, cap=20000):
         out = np.zeros((cap, 4), np.float32); n = C.c_int(0)
         _chk(lib().sslam_lines_debug_segments(self.h, frame, _p(out), cap, C.byref(n)))
