@@ -149,7 +149,7 @@ int orc_lines_extract(const uint8_t* gray, int w, int h, int stride, int max_lin
     std::vector<KeyLine> kls; std::vector<Seg4f> raw;
     lsd_detect_keylines(im, kls, &raw);
     if (raw_n) *raw_n = (int)raw.size();
-    if (raw_segments) std::memcpy(raw_segments, raw.data(), sizeof(Seg4f) * std::min<size_t>(raw.size(), raw_cap));
+    if (raw_segments && !raw.empty()) std::memcpy(raw_segments, raw.data(), sizeof(Seg4f) * std::min<size_t>(raw.size(), raw_cap));
     if ((int)kls.size() > max_lines) {
         std::stable_sort(kls.begin(), kls.end(), [](const KeyLine& a, const KeyLine& b) { return a.response > b.response; });   // D3
         kls.resize(max_lines);
@@ -158,9 +158,11 @@ int orc_lines_extract(const uint8_t* gray, int w, int h, int stride, int max_lin
     std::vector<uint8_t> desc; std::vector<float> fdesc;
     lbd_compute(im, kls, desc, float_desc_out ? &fdesc : nullptr);
     int n = std::min((int)kls.size(), cap);
-    std::memcpy(kl_out, kls.data(), sizeof(KeyLine) * n);
-    std::memcpy(ldesc_out, desc.data(), (size_t)n * 32);
-    if (float_desc_out) std::memcpy(float_desc_out, fdesc.data(), sizeof(float) * 72 * n);
+    if (n > 0) {      // (memcpy from an empty vector's null data() is undefined even for 0 bytes: tests/test_sanitize_cpu.py)
+        std::memcpy(kl_out, kls.data(), sizeof(KeyLine) * n);
+        std::memcpy(ldesc_out, desc.data(), (size_t)n * 32);
+        if (float_desc_out) std::memcpy(float_desc_out, fdesc.data(), sizeof(float) * 72 * n);
+    }
     for (int i = 0; i < n; ++i) {          // :56-68, Eigen Vector3d cross product in double
         double sx = kls[i].startPointX, sy = kls[i].startPointY, ex = kls[i].endPointX, ey = kls[i].endPointY;
         double l0 = sy * 1.0 - 1.0 * ey, l1 = 1.0 * ex - sx * 1.0, l2 = sx * ey - sy * ex;

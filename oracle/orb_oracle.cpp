@@ -337,8 +337,10 @@ int orc_orb_extract(const uint8_t* gray, int w, int h, int stride, int nfeatures
     std::vector<KP> kps; std::vector<uint8_t> desc;
     orb_extract(P, im, kps, desc, nullptr);
     int n = std::min((int)kps.size(), cap);
-    std::memcpy(kp_out, kps.data(), (size_t)n * sizeof(KP));
-    std::memcpy(desc_out, desc.data(), (size_t)n * 32);
+    if (n > 0) {      // (memcpy from an empty vector's null data() is undefined even for 0 bytes: tests/test_sanitize_cpu.py)
+        std::memcpy(kp_out, kps.data(), (size_t)n * sizeof(KP));
+        std::memcpy(desc_out, desc.data(), (size_t)n * 32);
+    }
     return (int)kps.size();
 }
 

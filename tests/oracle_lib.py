@@ -39,6 +39,7 @@ class Oracle:
             p = build_native()
             if p and os.path.exists(p):
                 path, self.native = p, True
+        path = os.environ.get("SSLAM_ORACLE_LIB", path)      # (tests/test_sanitize_cpu.py: the same sources built with ASan + UBSan)
         self.L = C.CDLL(path)
         self.L.orc_fast_atan2.restype = C.c_float
         self.L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
