@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <mutex>
@@ -96,16 +97,23 @@ extern "C" __attribute__((visibility("hidden"))) sslam_ctx* sslam_orb_context(ss
 extern "C" __attribute__((visibility("hidden"))) sslam_ctx* sslam_lines_context(sslam_lines* lines);
 
 namespace sslam {
+// roctx ranges (the reference has no tracing; this is the hook the survey proposed): with SSLAM_ROCTX=1 every stage
+// scope below also pushes / pops a roctx range named after the kernel, so that `rocprofv3 --marker-trace` shows the host-side launch
+// sequence of a call next to the kernel trace.  libroctx64 is bound at run time (dlopen): no link-time dependency, no cost when unset.
+void roctx_push(const char* name);      // ctx.hip
+void roctx_pop();
 // RAII stage timer: records a HIP event pair on the launch stream around one kernel launch.
 struct ProfScope {
-    sslam_ctx* c; hipStream_t st; sslam_prof_rec r; bool on;
-    ProfScope(sslam_ctx* ctx, const char* name, hipStream_t s) : c(ctx), st(s), on(ctx->profEnabled) {
+    sslam_ctx* c; hipStream_t st; sslam_prof_rec r; bool on; bool marked;
+    ProfScope(sslam_ctx* ctx, const char* name, hipStream_t s) : c(ctx), st(s), on(ctx->profEnabled), marked(false) {
+        static const bool kRoctx = getenv("SSLAM_ROCTX") != nullptr;
+        if (kRoctx) { roctx_push(name); marked = true; }
         if (!on) return;
         r.name = name;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(r.a, st);
     }
-    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); c->prof.push_back(r); } }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); c->prof.push_back(r); } if (marked) roctx_pop(); }
 };
 }  // namespace sslam
 

@@ -1,8 +1,27 @@
 // Context, error reporting and ABI housekeeping of libsslam_frontend.so.
 #include "common.h"
 #include <cstdarg>
+#include <dlfcn.h>
 
 namespace sslam {
+// roctx, bound at run time (SSLAM_ROCTX=1): roctxRangePushA / roctxRangePop of libroctx64 (or the rocprofiler-sdk build of it)
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Roctx() {
+        void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void roctx_push(const char* name) { Roctx& r = roctx(); if (r.push) (void)r.push(name); }
+void roctx_pop() { Roctx& r = roctx(); if (r.pop) (void)r.pop(); }
+
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
     va_list ap;
