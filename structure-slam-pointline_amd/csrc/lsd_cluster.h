@@ -468,7 +468,9 @@ __device__ void cl_feeder(uint8_t* __restrict__ ws, const LsdPlan& P, int b, con
             if (lane < cr) { const unsigned e = ((volatile unsigned*)&S->e[r][0])[lane]; __builtin_amdgcn_global_load_lds(pl.T + pl.ti(e), &S->v[r][0], 4, 0, 0); }
         }
         cl_stores_done();
-        if (stageable) S->gseq[lane] = seq;
+        // (two commits of margin: the counter is an LDS store, the commit's marks are vector stores issued before it -- the gather was issued
+        // after the counter was read and follows them through the compute unit's one vector-memory pipe, but nothing is lost by not relying on it)
+        if (stageable) S->gseq[lane] = max(seq - 2, 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         lds_st(&S->ready, 1);
     }
