@@ -144,7 +144,11 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             if (pos0 + 64 * CL_GROUP < nOrd) load_group(pos0 + 64 * CL_GROUP);
         }
         if (lane == 0) g_st(&cl.ctl->mainPos, pos0);
+#if defined(SSLAM_CL_RELAXED_SEQ)
+        __hip_atomic_store(&loc->mainChunk, pos0 >> 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
         lds_st(&loc->mainChunk, pos0 >> 6);
+#endif
         const unsigned idx = scanIdx[64 * gj + lane];
         const bool have = idx != 0xFFFFFFFFu;
         const int tiSeed = have ? pl.ti(idx) : 0;
@@ -358,7 +362,11 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             accCurAny = accNextAny = true;
             ++commitSeq;                                  // (after the commit's stores were issued: the feeder reads the counter before it gathers)
             if (lane == (commitSeq & 63)) { logLo = bxLo; logHi = bxHi; logSeq = commitSeq; }
+#if defined(SSLAM_CL_RELAXED_SEQ)      // measurement knob: how much the release (a wait for the commit's stores) costs
+            __hip_atomic_store(&loc->commitSeq, commitSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
             lds_st(&loc->commitSeq, commitSeq);
+#endif
             if (tooSmall) {
                 // too small: rejected, its pixels stay used.  Which candidates of this chunk did it take?
                 for (int k = 1; k < n; ++k) {
@@ -554,7 +562,11 @@ __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 reap();
                 const int mp = g_ld(&ctl->mainPos);
                 if (mp >= c * 64 || g_ld(&ctl->finished)) break;
+#ifdef SSLAM_CL_EAGER_SECOND_LOOK
+                if (pass > 1 && g_ld(&ctl->cursor) <= (mp >> 6) * CL_NSUB + cl.window && fHead - fTail < CL_FIFO - 1) break;
+#else
                 if (g_ld(&ctl->cursor) <= (mp >> 6) * CL_NSUB + cl.window && fHead - fTail < CL_FIFO - 1) break;
+#endif
                 __builtin_amdgcn_s_sleep(8);
                 asm volatile("buffer_inv sc1" ::: "memory");
                 // Re-validation: a published result that a commit has overtaken since (one of its points is used now) would be refused by
