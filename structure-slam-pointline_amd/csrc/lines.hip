@@ -262,11 +262,14 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         bool mw = nframes <= 256 && nHelpers >= 1;
         if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) { lone = e[0] == 'l' || e[0] == 'm' || e[0] == 'c'; mw = (e[0] == 'm' || e[0] == 'c') && nHelpers >= 1; }      // experiment knob: "cl" / "mw" / "lat" / "thr"
         if (const char* e = getenv("SSLAM_LSD_HELPERS")) nHelpers = std::max(1, std::min(nHelpers, atoi(e)));
-        // Up to 8 frames (one per XCD) whose frame-wide bitmap fits the main wave's LDS: the cluster form -- helper waves on several compute
+        // Up to 64 frames (one to eight per XCD) whose frame-wide bitmap fits the main wave's LDS: the cluster form -- helper waves on several compute
         // units, results through global memory, monotonic pixel map (lsd_cluster.h).  SSLAM_LSD_CLUSTER=0 (or SSLAM_LSD_FLAVOUR=mw) keeps the
         // multi-wave form; SSLAM_CL_WGS = workgroups per frame (4 waves each), SSLAM_CL_WINDOW = how many sub-chunks of 16 seed positions the
         // helpers may run ahead, SSLAM_CL_SMAP = cell size (log2) of the shared map that steers their seed choice (-1: none).
-        bool cluster = nframes <= 8 && P.sw <= TorusFrame::XMASK + 1 && P.sh <= TorusFrame::YMASK + 1;
+        int CL_MAXFRAMES = 64;      // up to eight frames per XCD, four workgroups each.  Per call, cluster against multi-wave form (tools/small_batch_probe.py):
+                                    // 1 frame 5.9 / 7.9 ms, 8: 8.5 / 11.2, 16: 9.0 / 11.9, 24: 9.4 / 12.6, 32: 10.3 / 13.1, 64: 13.5 / 15.7, 96: 21.6 / 15.9
+        if (const char* e = getenv("SSLAM_CL_MAXFRAMES")) CL_MAXFRAMES = std::max(1, std::min(128, atoi(e)));      // experiment knob
+        bool cluster = nframes <= CL_MAXFRAMES && P.sw <= TorusFrame::XMASK + 1 && P.sh <= TorusFrame::YMASK + 1;
         if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) cluster = cluster && e[0] == 'c';      // "cl" / "mw" / "lat" / "thr"
         if (const char* e = getenv("SSLAM_LSD_CLUSTER")) cluster = cluster && atoi(e) != 0;
         if (cluster) {
@@ -280,11 +283,13 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             const size_t zeroBytes = 512 + ((maxSubs * sizeof(ClSub) + 511) & ~(size_t)511) + 4 * (size_t)((clSpecWords + 127) & ~127);      // control block, sub-chunk states / flags, shared map
             const size_t clFrame = align_up(zeroBytes + maxSubs * CL_RES * sizeof(ClRec) + 4 * (size_t)CL_ARENA * (CL_MAXWG * CL_WAVES), 4096);
             L->clFrame = clFrame;
-            if (L->dCl.cap < clFrame * 8) { SSLAM_HIP(hipStreamSynchronize(st)); if ((rc = L->dCl.ensure(clFrame * 8))) return rc; }
+            const size_t clSlots = (size_t)((nframes + 7) / 8) * 8;
+            if (nframes > 8) nWG = std::max(2, std::min(nWG, 32 / ((nframes + 7) / 8)));      // the frames of an XCD share its 32 compute units
+            if (L->dCl.cap < clFrame * clSlots) { SSLAM_HIP(hipStreamSynchronize(st)); if ((rc = L->dCl.ensure(clFrame * clSlots))) return rc; }
             for (int f = 0; f < nframes; ++f) SSLAM_HIP(hipMemsetAsync(L->dCl.as<uint8_t>() + (size_t)f * clFrame, 0, zeroBytes, st));
             const size_t clLds = sizeof(unsigned) * std::max((size_t)QCAP + 4 + TorusFrame::WORDS + CL_SCAN + CL_RING_WORDS, (size_t)CL_HPW * (CL_LIST + ClTorus::WORDS));      // the main wave's workgroup / a helper workgroup
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
-            hipLaunchKernelGGL(k_lsd_regions_cl, dim3(8 * nWG), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
+            hipLaunchKernelGGL(k_lsd_regions_cl, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
         } else if (mw) {
             const size_t mwLds = lds + sizeof(unsigned) * ((size_t)nHelpers * ((size_t)MW_RING + MW_BM_WORDS) + specWords);
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_mw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mwLds));
@@ -426,7 +431,7 @@ extern "C" int sslam_lines_debug_cycles(sslam_lines* L, int frame, long long* ou
 
 // counters of the cluster form's helpers for frame `frame` of the last call (lsd_cluster.h, ClCtl::stat; filled by builds with -DSSLAM_CL_CYCLES)
 extern "C" int sslam_lines_debug_cluster(sslam_lines* L, int frame, long long* out8) {
-    if (!L || frame < 0 || frame >= 8 || !out8 || !L->dCl.p || !L->clFrame) return SSLAM_ERR_INVALID;
+    if (!L || frame < 0 || frame >= 128 || !out8 || !L->dCl.p || !L->clFrame) return SSLAM_ERR_INVALID;
     SSLAM_HIP(hipSetDevice(L->ctx->device));
     SSLAM_HIP(hipDeviceSynchronize());
     ClCtl c;

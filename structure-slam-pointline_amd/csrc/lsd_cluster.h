@@ -671,14 +671,15 @@ __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
     }
 }
 
-// One frame = the workgroups with blockIdx % 8 == frame (role = blockIdx / 8); dynamic LDS: per wave a list buffer of CL_LIST words and a
+// One frame = nWG workgroups of one XCD (blockIdx % 8 == frame % 8; role = (blockIdx / 8) % nWG; up to eight frames per XCD); dynamic LDS: per wave a list buffer of CL_LIST words and a
 // 256 x 256-bit torus, in front of them (role 0 only) the main wave's region queue and its frame-wide bitmap.
 __global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl(uint8_t* __restrict__ ws, LsdPlan P, uint8_t* __restrict__ clArea, size_t clFrameBytes, int nframes, int nWG,
                                                                  int specWords, int specShift, int window) {
     extern __shared__ __align__(16) unsigned dynLds[];
     __shared__ double red[CL_WAVES][3 * 64];
     __shared__ float4 stashes[CL_WAVES][64];
-    const int b = blockIdx.x & 7, role = blockIdx.x >> 3, wave = threadIdx.x >> 6;
+    // blocks with the same (blockIdx % 8) share an XCD; an XCD hosts frames xcd, xcd + 8, xcd + 16, ... (nWG workgroups each)
+    const int j = blockIdx.x >> 3, b = (blockIdx.x & 7) + 8 * (j / nWG), role = j % nWG, wave = threadIdx.x >> 6;
     const bool nofeed = (window & (1 << 20)) != 0;      // (experiment knob: no feeder wave)
     if (window >= 0) window &= (1 << 20) - 1;
     if (b >= nframes) return;

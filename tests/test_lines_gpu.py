@@ -152,9 +152,11 @@ def test_lsd_cluster_configurations(fe, ctx, oracle, knobs, monkeypatch):
         _cmp_lines(fe, ctx, oracle, img, cap)
 
 
-def test_lsd_cluster_batch(fe, ctx, oracle):
-    """up to 8 frames per call take the cluster form, one XCD's worth of workgroups per frame: results per frame as for single calls"""
-    frames = [synth_frame(3100 + i) for i in range(7)]
+@pytest.mark.parametrize("nf", [7, 19, 41])
+def test_lsd_cluster_batch(fe, ctx, oracle, nf):
+    """up to 64 frames per call take the cluster form, one to eight frames per XCD (fewer helper workgroups per frame as they share its
+    compute units): results per frame as for single calls"""
+    frames = [synth_frame(3100 + i) for i in range(nf)]
     ex = fe.LineExtractor(ctx, 200)
     try:
         dev = torch.from_numpy(np.stack(frames)).cuda()
@@ -183,8 +185,10 @@ def test_lsd_multiwave_configurations(fe, ctx, oracle, knobs, monkeypatch):
         _cmp_lines(fe, ctx, oracle, img, cap)
 
 
-def test_lsd_multiwave_batch(fe, ctx, oracle):
-    """up to 256 frames per call take the multi-wave form, one workgroup per frame: results per frame as for single calls"""
+def test_lsd_multiwave_batch(fe, ctx, oracle, monkeypatch):
+    """65 .. 256 frames per call (and frames too large for the cluster form) take the multi-wave form, one workgroup per frame: results per
+    frame as for single calls"""
+    monkeypatch.setenv("SSLAM_LSD_FLAVOUR", "mw")
     frames = [synth_frame(3000 + i) for i in range(12)]
     ex = fe.LineExtractor(ctx, 200)
     try:
