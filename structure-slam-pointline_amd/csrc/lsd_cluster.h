@@ -1,12 +1,12 @@
-// LSD sequential core, CLUSTER form: one frame at a time with helper waves on SEVERAL compute units.  Part of lines.hip (included after
-// lsd_regions.h, same anonymous namespace).  Not a standalone header.
+// LSD sequential core, CLUSTER form: up to 64 frames per call, each with helper waves on SEVERAL compute units.  Part of lines.hip (included
+// after lsd_regions.h, same anonymous namespace).  Not a standalone header.  DESIGN.md 5e has the measurements.
 //
 // The multi-wave form (lsd_regions.h) keeps everything in one workgroup's LDS and is bound by what six helper waves next to
 // the main wave can grow (they are busy 99 % of the frame; the main wave waits for them a quarter of its time and grows what they could
 // not provide -- results full, ring full, reach of the 256 x 256 torus -- itself).  This form takes the helpers out of the main wave's
-// workgroup: a frame owns the workgroups  blockIdx % 8 == frame  (observed dispatch rule: those share an XCD and its L2; nothing below
-// depends on it for correctness), four waves each, wave 0 of the first one is the MAIN wave, every other wave a helper.  Shared state
-// lives in global memory.
+// workgroup: a frame owns nWG workgroups of one XCD (blockIdx % 8 == frame % 8: the observed dispatch rule, those share an L2; nothing
+// below depends on it for correctness).  Workgroup 0 of a frame runs the MAIN wave and a FEEDER wave, the others three HELPER waves each.
+// Shared state lives in global memory.
 //
 // Protocol (what is different from the multi-wave form):
 //   * THE PIXEL MAP IS MONOTONIC.  The main wave never releases a pixel in it: a seed it has to grow itself is grown on a private bitmap
@@ -15,14 +15,18 @@
 //   * Therefore a helper's view may be arbitrarily stale (its L1, another XCD's L2): a pixel it saw USED is used now; a pixel it saw unused
 //     and rejected by angle is rejected by the sequential run whatever its state; a pixel it accepted is in list A or B.  Check (b) of the
 //     multi-wave form -- every point of A and B is unused NOW, read by the main wave from its own map -- is the whole validation; there are
-//     no release events and no check (c).
-//   * Results travel through global memory with L1-bypassing (sc1) stores and loads on both sides: per chunk of 64 seed positions a header
-//     (state, flag = doneLane | nres << 8, up to CL_RES results) and per helper a bump-allocated arena for the lists (never reused within a
-//     frame: no ring, no waiting for space, unbounded run-ahead inside the window).  Publication order: lists, result record,
-//     s_waitcnt vmcnt(0), flag.  The main wave reads flag, then records, then lists.
-//   * Chunks are claimed in order by the helpers (global cursor, at most `window` chunks ahead of the main wave); a claim is a CAS on the
-//     header's state, and the main wave, arriving at a chunk nobody has started, CASes it for itself -- it never waits for a helper that is
-//     not there.  Every wait of the main wave is bounded.
+//     no release events and no check (c).  (tests/sim/mw_proto.cpp, mode 1, is this protocol with real threads and stale views.)
+//   * Results travel through global memory with L1-bypassing (sc1) stores and loads on both sides: per SUB-CHUNK of CL_SUB seed positions
+//     {state, flag = doneLane | nres << 8} and up to CL_RES write-once result records, per helper a bump-allocated arena for the lists
+//     (never reused within a frame: no ring, no waiting for space).  Publication order: lists, result record, s_waitcnt vmcnt(0), flag.
+//     The main wave reads flag, then records, then lists.
+//   * Sub-chunks are claimed in order by the helpers (global cursor, at most `window` sub-chunks ahead of the main wave); a claim is a CAS
+//     on the state, and the main wave, arriving at a sub-chunk nobody has started, CASes it for itself -- it never waits for a helper that
+//     is not there.  Every wait of the main wave is bounded.
+//   * A helper with nothing to claim looks at its sub-chunk again (seeds without a result by now) and re-validates what it published; a
+//     seed whose result has been overtaken by a commit is grown again and published as a second record (the later one counts).
+//   * The feeder wave stages chunk states, records, lists and map values in LDS ahead of the main wave (ClSlot); the main wave numbers its
+//     commits so that a staged value that may be out of date is read again.
 #pragma once
 
 #ifndef SSLAM_CL_SUB_SHIFT

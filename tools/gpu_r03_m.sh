@@ -1,3 +1,4 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R
-timeout 900 python -m pytest tests/test_lines_gpu.py tests/test_batch_gpu.py tests/test_configs_gpu.py tests/test_edge_gpu.py -x -q -m gpu 2>&1 | tail -2
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
