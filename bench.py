@@ -192,7 +192,7 @@ def latency_leg(fe, ctx, frames, with_lines, nframes=120):
     if lx: lx.close()
     pct = lambda a: {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "max": float(a.max())}
     out = {"unit": "ms", "frames": nframes, "path": "sslam_orb_extract + sslam_lines_extract per frame (host image in, host results out)",
-           "lsd_core": "cluster form (one main wave + helper waves on several compute units; lsd_cluster.h)" if (W * 0.8 <= 1024 and H * 0.8 <= 512 and os.environ.get("SSLAM_LSD_CLUSTER", "1") != "0" and os.environ.get("SSLAM_LSD_FLAVOUR", "c")[0] == "c") else "multi-wave (one main wave + helper waves per frame; lsd_regions.h)",
+           "lsd_core": "cluster form (one main wave + helper waves on several compute units; lsd_cluster.h)" if (W * 0.8 <= 2048 and H * 0.8 <= 1024 and os.environ.get("SSLAM_LSD_CLUSTER", "1") != "0" and os.environ.get("SSLAM_LSD_FLAVOUR", "c")[0] == "c") else "multi-wave (one main wave + helper waves per frame; lsd_regions.h)",
            "orb_extract_hipEvent": pct(orb), "lines_extract_hipEvent": pct(lin) if with_lines else None, "frame_hipEvent": pct(orb + lin), "frame_wall": pct(wall),
            "frames_per_s_one_at_a_time": float(1e3 / np.median(wall))}
     if with_lines and not os.environ.get("SSLAM_LSD_FLAVOUR"):

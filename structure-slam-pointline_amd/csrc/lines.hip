@@ -269,7 +269,8 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         int CL_MAXFRAMES = 64;      // up to eight frames per XCD, four workgroups each.  Per call, cluster against multi-wave form (tools/small_batch_probe.py):
                                     // 1 frame 5.9 / 7.9 ms, 8: 8.5 / 11.2, 16: 9.0 / 11.9, 24: 9.4 / 12.6, 32: 10.3 / 13.1, 64: 13.5 / 15.7, 96: 21.6 / 15.9
         if (const char* e = getenv("SSLAM_CL_MAXFRAMES")) CL_MAXFRAMES = std::max(1, std::min(128, atoi(e)));      // experiment knob
-        bool cluster = nframes <= CL_MAXFRAMES && P.sw <= TorusFrame::XMASK + 1 && P.sh <= TorusFrame::YMASK + 1;
+        const bool bigFrame = P.sw > TorusFrame::XMASK + 1 || P.sh > TorusFrame::YMASK + 1;      // the main wave's bitmap in global memory instead of LDS
+        bool cluster = nframes <= CL_MAXFRAMES && P.sw <= TorusGlobal::XMASK + 1 && P.sh <= TorusGlobal::YMASK + 1;
         if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) cluster = cluster && e[0] == 'c';      // "cl" / "mw" / "lat" / "thr"
         if (const char* e = getenv("SSLAM_LSD_CLUSTER")) cluster = cluster && atoi(e) != 0;
         if (cluster) {
@@ -280,14 +281,14 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             if (getenv("SSLAM_CL_NO_FEEDER") && window >= 0) window |= 1 << 20;      // experiment knob: the main wave fetches everything itself
             const int clSpecWords = clShift < 0 ? 0 : (((P.sw + (1 << clShift) - 1) >> clShift) * ((P.sh + (1 << clShift) - 1) >> clShift) + 31) / 32;
             const size_t maxSubs = ((size_t)P.npx + CL_SUB - 1) / CL_SUB;
-            const size_t zeroBytes = 512 + ((maxSubs * sizeof(ClSub) + 511) & ~(size_t)511) + 4 * (size_t)((clSpecWords + 127) & ~127);      // control block, sub-chunk states / flags, shared map
+            const size_t zeroBytes = 512 + ((maxSubs * sizeof(ClSub) + 511) & ~(size_t)511) + 4 * (size_t)((clSpecWords + 127) & ~127) + (bigFrame ? 4 * (size_t)TorusGlobal::WORDS : 0);      // control block, sub-chunk states / flags, shared map (+ the main wave's bitmap)
             const size_t clFrame = align_up(zeroBytes + maxSubs * CL_RES * sizeof(ClRec) + 4 * (size_t)CL_ARENA * (CL_MAXWG * CL_WAVES), 4096);
             L->clFrame = clFrame;
             const size_t clSlots = (size_t)((nframes + 7) / 8) * 8;
             if (nframes > 8) nWG = std::max(2, std::min(nWG, 32 / ((nframes + 7) / 8)));      // the frames of an XCD share its 32 compute units
             if (L->dCl.cap < clFrame * clSlots) { SSLAM_HIP(hipStreamSynchronize(st)); if ((rc = L->dCl.ensure(clFrame * clSlots))) return rc; }
             for (int f = 0; f < nframes; ++f) SSLAM_HIP(hipMemsetAsync(L->dCl.as<uint8_t>() + (size_t)f * clFrame, 0, zeroBytes, st));
-            const size_t clLds = sizeof(unsigned) * std::max((size_t)QCAP + 4 + TorusFrame::WORDS + CL_SCAN + CL_RING_WORDS, (size_t)CL_HPW * (CL_LIST + ClTorus::WORDS));      // the main wave's workgroup / a helper workgroup
+            const size_t clLds = sizeof(unsigned) * std::max((size_t)QCAP + 4 + (bigFrame ? 0 : TorusFrame::WORDS) + CL_SCAN + CL_RING_WORDS, (size_t)CL_HPW * (CL_LIST + ClTorus::WORDS));      // the main wave's workgroup / a helper workgroup
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
             hipLaunchKernelGGL(k_lsd_regions_cl, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
         } else if (mw) {

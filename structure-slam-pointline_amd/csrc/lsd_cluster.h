@@ -74,7 +74,7 @@ struct ClSlot {
 struct ClLocal { int mainChunk, commitSeq, finished, pad; };      // LDS: main wave -> feeder
 constexpr int CL_RING_WORDS = (int)((sizeof(ClSlot) * CL_RING + sizeof(ClLocal) + 3) / 4);
 struct ClShared {
-    ClCtl* ctl; ClSub* sub; ClRec* rec; unsigned* arena; unsigned* specMap; int specW, specShift, nHelpers, window;
+    ClCtl* ctl; ClSub* sub; ClRec* rec; unsigned* arena; unsigned* specMap; unsigned* bigBm; int specW, specShift, nHelpers, window;
     __device__ __forceinline__ int cell(int x, int y) const { return (y >> specShift) * specW + (x >> specShift); }
 };
 // L1-bypassing accesses (global_load / global_store ... sc1): served by the L2 / memory, which is where the other compute units' stores are
@@ -103,9 +103,9 @@ __device__ __forceinline__ bool cl_spec(const ClShared& cl, int x, int y) {
 #define CL_STAT(i, v)
 #endif
 // ------------------------------------------------------------------ the main wave
+template <class G>      // the main wave's private bitmap: TorusFrame (LDS) or TorusGlobal (larger frames)
 __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsigned* __restrict__ qLds, unsigned* __restrict__ bmMain, unsigned* __restrict__ scanBuf,
                         double* __restrict__ red, float4* __restrict__ seedStash, const ClShared& cl, ClSlot* __restrict__ ring, ClLocal* __restrict__ loc) {
-    typedef TorusFrame G;
     const int lane = threadIdx.x & 63;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     Planes pl; pl.T = (float*)(base + P.offT); pl.Cs = (const float2*)(base + P.offCs); pl.S = (const int*)(base + P.offS); pl.tW = P.tW; pl.cW = P.cW;
@@ -693,24 +693,30 @@ __global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl(uint8_t* __res
     const size_t maxSubs = ((size_t)P.npx + CL_SUB - 1) / CL_SUB;
     cl.sub = (ClSub*)(area + 512);
     cl.specMap = (unsigned*)(area + 512 + ((maxSubs * sizeof(ClSub) + 511) & ~(size_t)511));
-    cl.rec = (ClRec*)(cl.specMap + ((specWords + 127) & ~127));
+    cl.bigBm = cl.specMap + ((specWords + 127) & ~127);      // (zeroed with the shared map when the frame is too large for the LDS bitmap; empty otherwise)
+    cl.rec = (ClRec*)(cl.bigBm + ((P.sw > TorusFrame::XMASK + 1 || P.sh > TorusFrame::YMASK + 1) ? TorusGlobal::WORDS : 0));
     cl.arena = (unsigned*)(cl.rec + maxSubs * CL_RES);
     cl.specShift = specShift; cl.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
     cl.nHelpers = (nWG - 1) * CL_HPW; cl.window = window;
     unsigned* mine = dynLds + (size_t)wave * (CL_LIST + ClTorus::WORDS);      // (helper workgroups)
     if (role != 0 && wave < CL_HPW) for (int i = threadIdx.x & 63; i < ClTorus::WORDS; i += 64) mine[CL_LIST + i] = 0u;
+    const bool bigFrame = P.sw > TorusFrame::XMASK + 1 || P.sh > TorusFrame::YMASK + 1;      // the main wave's bitmap lives in global memory (zeroed by the host)
+    const int bmWords = bigFrame ? 0 : TorusFrame::WORDS;
     if (role == 0) {
-        for (int i = threadIdx.x; i < TorusFrame::WORDS; i += blockDim.x) dynLds[QCAP + 4 + i] = 0u;
-        ClSlot* ring = (ClSlot*)(dynLds + QCAP + 4 + TorusFrame::WORDS + CL_SCAN);
+        for (int i = threadIdx.x; i < bmWords; i += blockDim.x) dynLds[QCAP + 4 + i] = 0u;
+        ClSlot* ring = (ClSlot*)(dynLds + QCAP + 4 + bmWords + CL_SCAN);
         if (threadIdx.x < CL_RING) { ring[threadIdx.x].chunk = -1; ring[threadIdx.x].ready = 0; }
         if (threadIdx.x == 0) { ClLocal* loc = (ClLocal*)(ring + CL_RING); loc->mainChunk = 0; loc->commitSeq = 0; loc->finished = 0; }
     }
     __syncthreads();
     if (role == 0) {
         // the main wave's workgroup: main wave + feeder.  No helpers here: their L1 invalidations cost the main wave 4 % (7.21 -> 6.89 ms)
-        ClSlot* ring = (ClSlot*)(dynLds + QCAP + 4 + TorusFrame::WORDS + CL_SCAN);
+        ClSlot* ring = (ClSlot*)(dynLds + QCAP + 4 + bmWords + CL_SCAN);
         ClLocal* loc = (ClLocal*)(ring + CL_RING);
-        if (wave == 0) cl_main(ws, P, b, dynLds, dynLds + QCAP + 4, dynLds + QCAP + 4 + TorusFrame::WORDS, red[0], stashes[0], cl, ring, loc);
+        if (wave == 0) {
+            if (bigFrame) cl_main<TorusGlobal>(ws, P, b, dynLds, cl.bigBm, dynLds + QCAP + 4, red[0], stashes[0], cl, ring, loc);
+            else cl_main<TorusFrame>(ws, P, b, dynLds, dynLds + QCAP + 4, dynLds + QCAP + 4 + TorusFrame::WORDS, red[0], stashes[0], cl, ring, loc);
+        }
         else if (wave == 1 && !nofeed) cl_feeder(ws, P, b, cl, ring, loc);
         return;
     }

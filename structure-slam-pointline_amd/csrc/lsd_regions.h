@@ -39,6 +39,15 @@ enum { MARK_MAP = 0, MARK_SPEC = 1, MARK_PRIV = 2 };
 struct TorusHelper { static constexpr int XMASK = 255, YMASK = 255, YSHIFT = 8, REACH = MW_REACH, WORDS = MW_BM_WORDS; };
 struct TorusWide { static constexpr int XMASK = 511, YMASK = 511, YSHIFT = 9, REACH = 254, WORDS = 512 * 512 / 32; };      // cluster form helpers: three per workgroup, 32 KB each
 struct TorusFrame { static constexpr int XMASK = 1023, YMASK = 511, YSHIFT = 10, REACH = 1 << 20, WORDS = 1024 * 512 / 32; };      // no aliasing for frames up to 1024 x 512
+// the same for frames up to 2048 x 1024 (the scaled 1280 x 960 of BASELINE configs[3]): 256 KB, kept in GLOBAL memory -- the marks are set and
+// cleared with atomics (executed in the L2), so they are read with L1-bypassing loads
+struct TorusGlobal { static constexpr int XMASK = 2047, YMASK = 1023, YSHIFT = 11, REACH = 1 << 20, WORDS = 2048 * 1024 / 32; static constexpr bool GLOBAL = true; };
+template <class G, class = void> struct bm_is_global { static constexpr bool value = false; };
+template <class G> struct bm_is_global<G, decltype((void)G::GLOBAL)> { static constexpr bool value = G::GLOBAL; };
+template <class G> __device__ __forceinline__ unsigned bm_word(const unsigned* bm, int w) {
+    if (bm_is_global<G>::value) return __hip_atomic_load(bm + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return bm[w];
+}
 template <class G> __device__ __forceinline__ int bm_bit(int x, int y) { return ((y & G::YMASK) << G::YSHIFT) | (x & G::XMASK); }
 __device__ __forceinline__ double readlane_d(double v, int l) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -179,7 +188,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
             cs = pl.Cs[nidx];                            // (same row pitch: one index serves both planes)
             candM = __builtin_amdgcn_ballot_w64(t_free(tv)) & __builtin_amdgcn_ballot_w64((unsigned)xx < (unsigned)sw) &
                     __builtin_amdgcn_ballot_w64((unsigned)yy < (unsigned)sh) & (np == 8 ? ~0ull : ((1ull << (np * 8)) - 1));
-            if (MARK) { const int bi = bm_bit<G>(xx, yy); candM &= ~__builtin_amdgcn_ballot_w64((bm[bi >> 5] >> (bi & 31)) & 1u); }      // taken by this wave itself
+            if (MARK) { const int bi = bm_bit<G>(xx, yy); candM &= ~__builtin_amdgcn_ballot_w64((bm_word<G>(bm, bi >> 5) >> (bi & 31)) & 1u); }      // taken by this wave itself
         } else {
             bool cand = false;
             if (g < np) {

@@ -118,10 +118,10 @@ def test_lines_huge_regions(fe, ctx, oracle):
 @pytest.mark.parametrize("flavour", ["cl", "mw", "lat", "thr"])
 def test_lsd_core_flavours(fe, ctx, oracle, flavour, monkeypatch):
     """The sequential core has four launch forms (lsd_regions.h, lsd_cluster.h): cluster (main wave + helper waves on several compute units,
-    results through global memory, monotonic pixel map: what a single frame gets when its bitmap fits the main wave's LDS), multi-wave (main
+    results through global memory, monotonic pixel map: what a single frame gets), multi-wave (main
     wave + helper waves in one workgroup), the lone wave and the six-waves-per-SIMD throughput form.  Each is forced here over frames that
-    stress the helper protocols in different ways: long lines (helpers give up beyond their reach), 1280x960 (coarser shared map; too large
-    for the cluster form, which hands over to the multi-wave form), noise (hundreds of one-pixel regions per chunk: result slots run out), a
+    stress the helper protocols in different ways: long lines (helpers give up beyond their reach), 1280x960 (coarser shared map in the
+    multi-wave form; the cluster form's main wave keeps its private bitmap in global memory), noise (hundreds of one-pixel regions per chunk: result slots run out), a
     ramp (regions beyond every helper limit) and an odd size."""
     import ctypes as C
     monkeypatch.setenv("SSLAM_LSD_FLAVOUR", flavour)
