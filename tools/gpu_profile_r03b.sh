@@ -18,3 +18,8 @@ head -8 $O/kernel_trace_single_frame.txt
 python -c "
 import json
 d=json.load(open('$O/bench_r03.json')); print(round(d['value']), d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic']); print(d['latency']['lines_extract_hipEvent'], d['latency']['lsd_core']); print({k: v for k, v in d['pcie_inclusive'].items() if 'per_s' in k or 'matches' in k})"
+cd $R && timeout 600 python bench.py --workload c4 --no-cpu-baseline > $O/bench_r03_c4.json 2>/dev/null
+python -c "
+import json
+d=json.load(open('$O/bench_r03_c4.json')); print('c4', round(d['value']), d['ms_per_step'], d['latency']['lines_extract_hipEvent'], d['latency']['lsd_core'][:40])"
+timeout 300 python tools/small_batch_probe.py > $O/small_batches.txt 2>&1; SSLAM_LSD_FLAVOUR=mw timeout 300 python tools/small_batch_probe.py > $O/small_batches_mw.txt 2>&1; tail -3 $O/small_batches.txt

@@ -7,7 +7,7 @@ import numpy as np, torch, pkg, bench
 torch.cuda.set_device(0)
 fe = pkg.frontend(); ctx = fe.Context(0)
 cur, prev = bench.synth_frames(640, 480, 64, 0)
-for nf in (64, 96, 128):
+for nf in (1, 2, 4, 8, 16, 32, 64, 96):
     ex = fe.LineExtractor(ctx, 200)
     cap = 256
     d_kl = torch.zeros(nf * cap * 68, dtype=torch.uint8, device="cuda"); d_ld = torch.zeros(nf * cap * 32, dtype=torch.uint8, device="cuda")
