@@ -50,7 +50,7 @@ struct Mw : Lsd {
     std::vector<Chunk> chunks;              // one per chunk of the order list (the kernel recycles a few slots; storage is not what is tested)
     std::atomic<int> cursor{0}, mainPos{0}, finished{0}, unmarkSeq{0};
     struct Ev { int x0, y0, x1, y1; }; std::vector<Ev> events; std::mutex evMu;
-    long nTaken = 0, nOwn = 0, nRefused = 0;
+    long nTaken = 0, nOwn = 0, nRefused = 0; std::atomic<long> nRepublished{0}, nLate{0};
 
     void prepare(const Img8& image) {       // Lsd::detect up to the seed loop
         prec = M_PI * ANG_TH / 180; p = ANG_TH / 180;
@@ -196,6 +196,27 @@ struct Mw : Lsd {
                 K.done.store(lane + 1, std::memory_order_release);
             }
             K.done.store(64, std::memory_order_release);
+            // cluster protocol: while the main thread is still in front of the chunk the helper checks what it published the way the main
+            // thread will (every accepted point unused -- in ITS view) and publishes a seed whose result died again, as a NEW result (results
+            // are never rewritten; the later one of a seed counts)
+            for (int round = 0; mode == 1 && round < 3 && mainPos.load() < cpos && !finished.load(); ++round) {
+                size_t nres; { std::lock_guard<std::mutex> g(K.mu); nres = K.res.size(); }
+                for (size_t ri = 0; ri < nres && mainPos.load() < cpos; ++ri) {
+                    Result old; { std::lock_guard<std::mutex> g(K.mu); old = K.res[ri]; }
+                    bool superseded = false;
+                    { std::lock_guard<std::mutex> g(K.mu); for (size_t rj = ri + 1; rj < K.res.size(); ++rj) superseded = superseded || K.res[rj].lane == old.lane; }
+                    if (superseded) continue;
+                    bool dead = false;
+                    for (const std::vector<int>* l : {&old.A, &old.B}) for (int id : *l) dead = dead || !view_unused(c, id);
+                    const int idx = order[cpos + old.lane];
+                    if (!dead || !view_unused(c, idx)) continue;
+                    Result R; R.lane = old.lane;
+                    helper_body(c, idx % w, idx / w, R);
+                    { std::lock_guard<std::mutex> g(K.mu); K.res.push_back(std::move(R)); }
+                    ++nRepublished;
+                }
+                std::this_thread::yield();
+            }
         }
     }
     // ---------------------------------------------------------------- main side
@@ -203,7 +224,7 @@ struct Mw : Lsd {
         used.assign((size_t)w * h, 0);
         const int nOrd = (int)order.size();
         chunks = std::vector<Chunk>((nOrd + 63) / 64 + 1);
-        cursor = 0; mainPos = 0; finished = 0; unmarkSeq = 0; events.clear(); nTaken = nOwn = nRefused = 0;
+        cursor = 0; mainPos = 0; finished = 0; unmarkSeq = 0; events.clear(); nTaken = nOwn = nRefused = 0; nRepublished = 0; nLate = 0;
         std::vector<std::thread> th;
         for (int i = 0; i < H; ++i) th.emplace_back([this, i] { helper_thread(i); });
         unsigned long long rng = 1234567;
@@ -226,8 +247,17 @@ struct Mw : Lsd {
                     while (K.pos.load(std::memory_order_acquire) != pos0) std::this_thread::yield();
                     while (K.done.load(std::memory_order_acquire) <= lane) std::this_thread::yield();
                     Result Rcopy; Result* R = nullptr;      // (a copy: the helper may append to the list, and move it, while the main thread looks at this one)
-                    { std::lock_guard<std::mutex> g(K.mu); for (auto& r : K.res) if (r.lane == lane) { Rcopy = r; R = &Rcopy; } }
-                    if (R) {
+                    int tried = -1;
+                    { std::lock_guard<std::mutex> g(K.mu); for (size_t ri = 0; ri < K.res.size(); ++ri) if (K.res[ri].lane == lane) { Rcopy = K.res[ri]; R = &Rcopy; tried = (int)ri; } }
+                    for (int attempt = 0; attempt < 2 && R && !took; ++attempt) {
+                        if (attempt == 1) {         // cluster protocol: after a refusal, one more look for a result the helper published since
+                            R = nullptr;
+                            if (mode != 1) break;
+                            std::lock_guard<std::mutex> g(K.mu);
+                            for (size_t ri = tried + 1; ri < K.res.size(); ++ri) if (K.res[ri].lane == lane) { Rcopy = K.res[ri]; R = &Rcopy; }
+                            if (!R) break;
+                            ++nLate;
+                        }
                         bool ok = true;
                         if ((checks & 2) && mode == 0) {                    // (c) no release near the result since its sample (the cluster protocol has no releases)
                             std::lock_guard<std::mutex> g(evMu);
@@ -312,7 +342,7 @@ int main(int argc, char** argv) {
         std::vector<SeedLog> log; M.run_multi(log);
         const bool same = same_log(ref, log) && usedRef == M.used;
         bad += !same;
-        std::printf("run %d: %s  seeds %zu  taken %ld  own %ld  refused %ld  refine events %zu\n", r, same ? "identical" : "DIFFERENT", log.size(), M.nTaken, M.nOwn, M.nRefused, M.events.size());
+        std::printf("run %d: %s  seeds %zu  taken %ld  own %ld  refused %ld  refine events %zu  published again %ld  taken from a later result %ld\n", r, same ? "identical" : "DIFFERENT", log.size(), M.nTaken, M.nOwn, M.nRefused, M.events.size(), M.nRepublished.load(), M.nLate.load());
     }
     std::printf("different runs: %d of %d\n", bad, reps);
     return bad ? 1 : 0;
