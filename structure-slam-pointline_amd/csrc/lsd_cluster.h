@@ -61,8 +61,14 @@ struct ClCtl { int mainPos, finished, cursor, pad; long long stat[8]; };
 // 64 in its lanes, the feeder notes the counter BEFORE it gathers, and a result whose box meets a commit younger than its gather is
 // gathered again (same compute unit, same L1: a gather issued after the counter was read sees every store issued before the counter was
 // written).  The main wave never waits for the feeder: a chunk that is not staged when it arrives takes the global path.
-constexpr int CL_RING = 3;                 // chunks staged ahead
-constexpr int CL_STG = 32;                 // list entries (A then B) staged per result; longer results take the global path
+#ifndef SSLAM_CL_RING
+#define SSLAM_CL_RING 3
+#endif
+#ifndef SSLAM_CL_STG
+#define SSLAM_CL_STG 32
+#endif
+constexpr int CL_RING = SSLAM_CL_RING;     // chunks staged ahead
+constexpr int CL_STG = SSLAM_CL_STG;       // list entries (A then B) staged per result; longer results take the global path
 struct ClSlot {
     int chunk, ready, pad0, pad1;
     int st[CL_NSUB], fl[CL_NSUB];          // state / flag of the sub-chunks as staged (st 1: no result expected)

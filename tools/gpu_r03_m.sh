@@ -1,4 +1,8 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; cd $R; O=$R/gpurun_out/r03; mkdir -p $O
-timeout 600 python tools/cl_stress.py 300 6 > $O/cl_stress.txt 2>&1; tail -3 $O/cl_stress.txt
-timeout 900 python tools/fuzz_parity.py 600 4242 > $O/fuzz_parity_600_4242.txt 2>&1; tail -1 $O/fuzz_parity_600_4242.txt
+R=$GRAFT_REPO_ROOT; cd $R
+V=$R/structure-slam-pointline_amd/lib/variants
+echo "== stg64 ring2"; SSLAM_LIB=$V/clstg64.so timeout 300 python tools/cl_probe.py 64 2>&1 | grep -v amdgpu.ids | tail -2
+run() { echo "== $*"; env "$@" timeout 200 python tools/latency_probe.py 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-110; }
+run A=1
+run SSLAM_LIB=$V/clstg64.so
+run SSLAM_LIB=$V/clring4.so
