@@ -185,7 +185,10 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
         const ClRec* myRecPtr = &cl.rec[(size_t)(sc0 + mySub) * CL_RES + myK];
         int stv = 1, flv = 0, nsv = 0;               // per sub-chunk, in lane s: state, last flag read, records loaded
         ClSlot* SL = &ring[(pos0 >> 6) % CL_RING];
-        const bool staged = lds_ld(&SL->chunk) == (pos0 >> 6) && lds_ld(&SL->ready) == 1;      // the feeder has this chunk in LDS
+        // (LDS and vector loads at wave-uniform addresses still land in vector registers: without the readfirstlane the compiler treats what
+        // depends on them -- here every branch on `staged`, further down the record of a late result and with it n, took and the loop's own
+        // mask of unused seeds -- as divergent and wraps the whole seed loop in exec-mask bookkeeping)
+        const bool staged = __builtin_amdgcn_readfirstlane(lds_ld(&SL->chunk)) == (pos0 >> 6) && __builtin_amdgcn_readfirstlane(lds_ld(&SL->ready)) == 1;      // the feeder has this chunk in LDS
         int myGseq = -1;                             // staged: the commit counter at the gather of my record's points (-1: not staged)
         if (staged) ++clStagedChunks;
         if (!staged) {
@@ -219,6 +222,9 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             if (lane == s) nsv = nres;
         };
         while (unM) {
+            // (wave-uniform by construction -- ballots -- but carried through branches the compiler cannot prove uniform: pin it to scalar
+            // registers, or the whole seed loop runs under exec-mask bookkeeping)
+            unM = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unM >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)unM);
             const int first = __ffsll((long long)unM) - 1;
             unM &= unM - 1;
             const int s = first >> CL_SUB_SHIFT, f16 = first & (CL_SUB - 1);
@@ -325,7 +331,10 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                         for (int kk = 0; kk < CL_RES; ++kk) {
                             if (kk > triedK && kk < nres) {
                                 const unsigned* q = rb + kk * (sizeof(ClRec) / 4);
-                                MwRes c; c.w0 = g_ldu(q); c.w1 = g_ldu(q + 1); c.w2 = g_ldu(q + 2); c.lo = g_ldu(q + 3); c.hi = g_ldu(q + 4);
+                                MwRes c;
+                                c.w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)g_ldu(q)); c.w1 = (unsigned)__builtin_amdgcn_readfirstlane((int)g_ldu(q + 1));
+                                c.w2 = (unsigned)__builtin_amdgcn_readfirstlane((int)g_ldu(q + 2)); c.lo = (unsigned)__builtin_amdgcn_readfirstlane((int)g_ldu(q + 3));
+                                c.hi = (unsigned)__builtin_amdgcn_readfirstlane((int)g_ldu(q + 4));
                                 if (c.lane() == first) { best = c; bestK = kk; }
                             }
                         }
@@ -337,6 +346,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                 }
             }
             const long long c2 = CL_CLK(); cTake += c2 - c1;
+            n = __builtin_amdgcn_readfirstlane(n); took = __builtin_amdgcn_readfirstlane((int)took) != 0; tookEmit = __builtin_amdgcn_readfirstlane((int)tookEmit) != 0;
             if (n < 0) {      // the main wave's own growth: private marks, the map is written at commit time only
                 if (!stashReady) fill_stash();
                 sd = seedStash[first];
@@ -346,6 +356,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                 if (wasRefused) clOwnRefused += 1 + ((long long)n << 32);
             }
             const long long c3 = CL_CLK(); cOwn += c3 - c2;
+            n = __builtin_amdgcn_readfirstlane(n);
             RectD rec;
             bool emit = false;
             const bool tooSmall = n < P.minRegSize;       // (of the region as first grown: refine() may shrink a kept region below the minimum)
@@ -367,6 +378,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                 }
                 if (n <= QCAP) list_bbox(rq.lds, n, lane, bxLo, bxHi); else { bxLo = 0u; bxHi = 0xFFFFFFFFu; }
             }
+            n = __builtin_amdgcn_readfirstlane(n); emit = __builtin_amdgcn_readfirstlane((int)emit) != 0;
             if (!took) cRect += CL_CLK() - c3;
             accCurLo = pk_min_u16(accCurLo, bxLo); accCurHi = pk_max_u16(accCurHi, bxHi); accNextLo = pk_min_u16(accNextLo, bxLo); accNextHi = pk_max_u16(accNextHi, bxHi);
             accCurAny = accNextAny = true;

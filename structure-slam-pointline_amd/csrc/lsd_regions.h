@@ -715,6 +715,9 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             if (lds_cas_uniform(&mw.ctl->cursor, c, cc + MW_SUB, lane) == c) mineMask |= 1u << ((cc - pos0) / MW_SUB);
         }
         while (unM) {
+            // (multi-wave form: the mask is wave-uniform by construction but carried through branches on LDS loads, which the compiler
+            // cannot prove uniform -- pinned to scalar registers, or the whole seed loop runs under exec-mask bookkeeping)
+            if (MW) unM = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unM >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)unM);
             const int first = __ffsll((long long)unM) - 1;
             unM &= unM - 1;                                   // the seed itself is consumed whatever happens
             float4 sd = make_float4(0.f, 0.f, 0.f, 0.f);
