@@ -1,7 +1,8 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; cd $R; O=$R/gpurun_out/r03; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-rm -rf $O/lat && cd $R && timeout 300 rocprofv3 --kernel-trace --stats -d $O/lat -- python tools/latency_probe.py > $O/lat.log 2>&1
-python tools/rocpd_summary.py $O/lat $O/kernel_trace_single_frame.txt > /dev/null; rm -rf $O/lat
-head -4 $O/kernel_trace_single_frame.txt
-timeout 300 python tools/cl_probe.py 64 > $O/cl_probe.txt 2>&1; tail -2 $O/cl_probe.txt
+R=$GRAFT_REPO_ROOT; cd $R
+run() { name=$1; shift; env "$@" timeout 300 python bench.py --no-cpu-baseline --no-extras --no-profile 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', round(d['value']), round(d['ms_per_step'],1))"; }
+run default A=1
+run defer SSLAM_DEFER_POINT_MATCH=1
+run default2 A=1
+run defer2 SSLAM_DEFER_POINT_MATCH=1
