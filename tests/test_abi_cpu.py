@@ -30,6 +30,31 @@ def test_struct_layouts_match_opencv():
     assert fe.KL_DTYPE.names[:3] == ("angle", "class_id", "octave") and fe.KL_DTYPE.names[-1] == "numOfPixels"
 
 
+def test_parameter_structs_match_the_header(tmp_path):
+    """the ctypes mirrors of the C ABI's parameter structs (sslam_batch_match, sslam_frontend_params, sslam_record_header) have the layout the
+    C compiler gives the header's declarations"""
+    import subprocess
+    fe = pkg.frontend()
+    src = tmp_path / "layout.c"
+    src.write_text("""#include <stdio.h>
+#include <stddef.h>
+#include "sslam_frontend.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sslam_batch_match), offsetof(sslam_batch_match, nnratio), offsetof(sslam_batch_match, bounds),
+           offsetof(sslam_batch_match, line_gate_scale), offsetof(sslam_batch_match, line_ratio_mode), offsetof(sslam_batch_match, init_matches12),
+           offsetof(sslam_batch_match, line_npairs), sizeof(sslam_frontend_params), sizeof(sslam_record_header));
+    return 0;
+}
+""")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    B = fe.BatchMatch
+    want = [ctypes.sizeof(B), B.nnratio.offset, B.bounds.offset, B.line_gate_scale.offset, B.line_ratio_mode.offset, B.init_matches12.offset, B.line_npairs.offset,
+            ctypes.sizeof(fe.FrontendParams), 16]
+    assert got == want, (got, want)
+
+
 def test_fails_loudly_without_gpu():
     fe = pkg.frontend()
     try:
