@@ -433,7 +433,8 @@ static int search_by_bow_core(sslam_ctx* ctx, const sslam_keypoint* kf_kp, const
     }
     { sslam::ProfScope _ps(ctx, "k_search_bow", st); hipLaunchKernelGGL(k_search_bow, dim3(disjoint ? std::min(nnodes, 4096) : 1), dim3(64), 0, st, A); }
     // (a fused form -- the last workgroup to finish runs this pass, saving the launch -- was measured: the two agent-scope fences per
-    // workgroup cost more than the launch, 0.111 against 0.103 ms per call)
+    // workgroup cost more than the launch, 0.111 against 0.103 ms per call; both passes in ONE workgroup of sixteen waves, no fences at
+    // all: 0.235 ms -- two nodes per wave in series instead of one workgroup per node)
     { sslam::ProfScope _ps(ctx, "k_bow_finish", st); hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, st, A.assigned, A.qbin, nf, check_orientation, A.nmatches); }
     SSLAM_HIP(hipGetLastError());
     SSLAM_HIP(hipMemcpyAsync(H + o[9], B + o[9], o[10] + 4 - o[9], hipMemcpyDeviceToHost, st));      // assigned + the count, back through the same staging
