@@ -7,9 +7,11 @@
 // of opencv 3.4.x (modules/features2d/src/fast.cpp, fast_score.cpp,
 // modules/imgproc/src/resize.cpp, smooth.cpp, deriv.cpp, copy.cpp,
 // modules/core/src/mathfuncs_core.simd.hpp) as restated from their published
-// source.  PARITY UNPINNED: the reference ships no tests/golden vectors and the
+// source.  PARITY UNPINNED FOR THIS FILE: the reference ships no tests/golden vectors and the
 // real library cannot be run here; this file *defines* the behaviour the HIP
-// path must match bit-for-bit.  What could be checked against an independent
+// path must match bit-for-bit.  (The reference's OWN code around these leaves is pinned since round 4:
+// oracle/ref_pin compiles src/ORBextractor.cc unmodified against a stub cv:: layer that forwards to
+// this header, and the result equals orb_oracle.cpp byte for byte.)  What could be checked against an independent
 // implementation offline IS checked (tests/test_oracle_cpu.py): the FAST-9/16 corner set,
 // cornerScore (= largest passing threshold) and the intensity-centroid orientation against
 // scikit-image 0.18.3 (fixtures in tests/golden/skimage_fast_orient.npz), Sobel 3x3 and the

@@ -1,4 +1,9 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see cvleaf.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see cvleaf.h header).
+// PINNED (round 4, `make -C oracle/ref_pin pin-stub`, oracle/ref_pin/compare_slices.py): the reference's own bodies of DescriptorDistance,
+// ComputeThreeMaxima, SearchForInitialization, AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea / GetLinesInArea, lineDescriptorMAD and
+// LSDmatcher::SerachForInitialize -- cut by line range and compiled here -- return what this file's restatements return on the same arrays.
+// The projection / BoW / Fuse / Sim3 / triangulation restatements below are NOT pinned that way (their reference bodies need MapPoint /
+// KeyFrame / DBoW2), nor is cv::BFMatcher::knnMatch's tie-break (OpenCV leaf).
 //
 // CPU restatement of the reference's Hamming matchers on the hot path:
 //   ORBmatcher::DescriptorDistance      src/ORBmatcher.cc:1650-1666
@@ -711,6 +716,19 @@ int orc_search_by_bow(const void* kpKF, const uint8_t* dKF, const uint8_t* valid
                       const int32_t* ptrKF, const int32_t* ptrF, int nnodes, const int32_t* idxKF, const int32_t* idxF, float nnratio, int check_ori,
                       int32_t* assigned) {
     return search_by_bow((const KPm*)kpKF, dKF, validKF, (const KPm*)kpF, dF, nF, ptrKF, ptrF, nnodes, idxKF, idxF, nnratio, check_ori != 0, assigned);
+}
+
+// Frame::GetFeaturesInArea / GetLinesInArea on their own (src/Frame.cc:368-421, 423-460): what oracle/ref_pin's slices are compared with
+int orc_features_in_area(const void* kps, int n, const float* bounds, float x, float y, float r, int minLevel, int maxLevel, int32_t* out) {
+    FrameGrid* g = new FrameGrid(); g->build((const KPm*)kps, n, bounds);
+    std::vector<int> v = g->in_area(x, y, r, minLevel, maxLevel);
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    delete g; return (int)v.size();
+}
+int orc_lines_in_area(const void* kls, int n, float x1, float y1, float x2, float y2, float r, int minLevel, int maxLevel, int32_t* out) {
+    std::vector<int> v = lines_in_area((const KLm*)kls, n, x1, y1, x2, y2, r, minLevel, maxLevel);
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return (int)v.size();
 }
 
 // LSDmatcher gates.  Degenerate inputs (n1==0 or n2<2) are UB in the reference

@@ -1,8 +1,14 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see cvleaf.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see cvleaf.h header).
 //
 // CPU restatement of StructureSLAM::ORBextractor (reference src/ORBextractor.cc,
 // include/ORBextractor.h) with the OpenCV leaves from cvleaf.h.
 // Each function cites the reference lines it follows.
+//
+// PINNED (round 4) for everything that is the reference's own code: `make -C oracle/ref_pin pin-stub`
+// compiles /root/reference/src/ORBextractor.cc unmodified against a stub cv:: layer whose leaves are
+// cvleaf.h, and its keypoints + descriptors equal this file's byte for byte on 16 fixtures (the reference's
+// real frame, synthetic frames up to 1280x960, non-default scale / level / threshold settings):
+// oracle/ref_pin/pin_report_stub.json, tests/test_pin_cpu.py.  The OpenCV leaves themselves stay UNPINNED.
 //
 // Determinism decision D1: the reference breaks ties in the
 // careful-split ordering by heap pointer value (src/ORBextractor.cc:684); here a

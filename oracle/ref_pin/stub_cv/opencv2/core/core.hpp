@@ -1,0 +1,3 @@
+// ORACLE ref_pin stub (test infrastructure): stands in for <opencv2/core/core.hpp>
+#pragma once
+#include "../../stub_cv.hpp"

@@ -1,0 +1,3 @@
+// ORACLE ref_pin stub (test infrastructure): stands in for <opencv2/highgui/highgui.hpp>
+#pragma once
+#include "../../stub_cv.hpp"
