@@ -76,6 +76,7 @@ def alg_bytes_per_frame(w, h, nkp, nln):
         "k_lsd_regions": 5 * s08,                           # region-grow reads (angle + magnitude + used)
         "k_nfa_count": 2 * nln * 100 * 6 * 4,               # angle-map rows under ~2 nln candidate rectangles of a nominal 100 x 6 pixels, 4 B each
         "k_nfa_eval": 0, "k_nfa_accept": 0, "k_nfa_finish": 0,      # rectangle records only
+        "k_nfa_all": 0,                                     # round 4: the same stage as one launch in the batch form (its bytes are k_nfa_count's row above; never both in one run)
         "k_keylines": nln * (16 + 68 + 24),
         "k_blur_sobel": w * h + 4 * w * h,                  # fused LBD pre-blur + Sobel: source read, {dx,dy} s16 pair write
         "k_lbd": nln * 63 * 100 * 4 + nln * 100,            # band reads at a nominal 100-px line + descriptor

@@ -4,10 +4,32 @@
 #pragma once
 
 // ------------------------------------------------------------------ KeyLine fill + top-N (LSDDetector::detectImpl, ExtractLineSegment :42-51)
+// bitonic sort of P2 (a power of two) 64-bit keys by the 256 threads of the workgroup, ascending
+template <class KeyPtr>
+__device__ __forceinline__ void keyline_sort(KeyPtr keys, int P2, int tid) {
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P2; i += 256) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = keys[i], c = keys[ixj];
+                    bool up = (i & k) == 0;
+                    if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// The sort keys of up to KL_LDS accepted segments live in LDS (8 KB); a frame with more of them -- MAX_SEG is the hard limit -- sorts in
+// the frame's workspace instead (the NFA states are dead by now).  Rounds 1-3 declared `__shared__ keys[MAX_SEG]`, 64 KB per workgroup:
+// with the point branch's workgroups holding LDS on every CU, the line stream's 12 288 workgroups of this kernel could only trickle in
+// (0.45 ms alone, 18.6 ms under the point branch).
+constexpr int KL_LDS = 1024;
 __global__ __launch_bounds__(256) void k_keylines(uint8_t* __restrict__ ws, LsdPlan P, int maxLines,
                                                   sslam_keyline* __restrict__ klOut, double* __restrict__ fnOut,
                                                   int* __restrict__ counts, int cap) {
-    __shared__ unsigned long long keys[MAX_SEG];
+    __shared__ unsigned long long keysL[KL_LDS];
     const int b = blockIdx.x, tid = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     float4* seg = (float4*)(base + P.offSeg);
@@ -38,6 +60,9 @@ __global__ __launch_bounds__(256) void k_keylines(uint8_t* __restrict__ ws, LsdP
         __syncthreads();
     }
     const int n = nAcc;
+    static_assert(sizeof(NfaState) >= sizeof(unsigned long long), "the overflow sort buffer reuses the NFA states");
+    unsigned long long* keysG = (unsigned long long*)(base + P.offNfa);      // MAX_SEG keys fit: sizeof(NfaState) >= 8
+    const bool inLds = n <= KL_LDS;
     for (int i = tid; i < n; i += 256) {
         float4 s = seg[i];
         float e0 = s.x, e1 = s.y, e2 = s.z, e3 = s.w;
@@ -59,32 +84,28 @@ __global__ __launch_bounds__(256) void k_keylines(uint8_t* __restrict__ ws, LsdP
         k.response = __fdiv_rn(k.lineLength, (float)max(P.w, P.h));
         k.pt_x = __fdiv_rn(__fadd_rn(e2, e0), 2.f); k.pt_y = __fdiv_rn(__fadd_rn(e3, e1), 2.f);
         klw[i] = k;
-        keys[i] = ((unsigned long long)(~__float_as_uint(k.response)) << 32) | (unsigned)i;   // response >= 0: descending response, ascending index (D3 stable)
+        const unsigned long long key = ((unsigned long long)(~__float_as_uint(k.response)) << 32) | (unsigned)i;   // response >= 0: descending response, ascending index (D3 stable)
+        if (inLds) keysL[i] = key; else keysG[i] = key;
     }
     __syncthreads();
     int nOut = n;
     const bool doSort = n > maxLines;
     if (doSort) {
         int P2 = 1; while (P2 < n) P2 <<= 1;
-        for (int i = n + tid; i < P2; i += 256) keys[i] = ~0ull;
-        __syncthreads();
-        for (int k = 2; k <= P2; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < P2; i += 256) {
-                    int ixj = i ^ j;
-                    if (ixj > i) {
-                        unsigned long long a = keys[i], c = keys[ixj];
-                        bool up = (i & k) == 0;
-                        if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
-                    }
-                }
-                __syncthreads();
-            }
+        if (inLds) {
+            for (int i = n + tid; i < P2; i += 256) keysL[i] = ~0ull;
+            __syncthreads();
+            keyline_sort(keysL, P2, tid);
+        } else {
+            for (int i = n + tid; i < P2; i += 256) keysG[i] = ~0ull;
+            __syncthreads();
+            keyline_sort(keysG, P2, tid);
+        }
         nOut = maxLines;
     }
     nOut = min(nOut, cap);
     for (int i = tid; i < nOut; i += 256) {
-        const int src = doSort ? (int)(unsigned)keys[i] : i;
+        const int src = doSort ? (int)(unsigned)(inLds ? keysL[i] : keysG[i]) : i;
         sslam_keyline k = klw[src];
         if (doSort) k.class_id = i;
         klOut[(size_t)b * cap + i] = k;

@@ -550,22 +550,40 @@ __global__ __launch_bounds__(256) void k_selftest_align(unsigned long long seed,
 #ifndef SSLAM_COUNT_MINWAVES
 #define SSLAM_COUNT_MINWAVES 4
 #endif
-__global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
-    __shared__ CntItem its[64];
+// LDS of one wave of the NFA stage: the counter's item batch + active list, or the evaluator's item list (never both at once)
+struct NfaCountLds {
+    CntItem its[64];
 #ifdef SSLAM_NFA_INT
-    __shared__ int nestWin[CNT_NEST][6][4];                          // nested stages: {lo0, hi0, lo1, hi1} per precision
+    int nestWin[CNT_NEST][6][4];                                     // nested stages: {lo0, hi0, lo1, hi1} per precision
 #endif
-    __shared__ unsigned short act[EVAL_CH];
-    const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y, lane = threadIdx.x;
-    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    unsigned short act[EVAL_CH];
+};
+union NfaLds { NfaCountLds c; unsigned short items[EVAL_CH * 5]; };      // items: (rect - chunk) << 3 | candidate
+
+// the inner synchronisation of the per-wave stage bodies: only the wave's own LDS arrays are at stake.  A single-wave workgroup may use
+// the workgroup barrier; waves of a larger workgroup run the bodies with different trip counts and must not meet at one.
+template <bool WG1>
+__device__ __forceinline__ void nfa_wave_sync() {
+    if (WG1) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+}
+
+// aligned-point counts of the stage's candidates for the rectangles [part * per, ...) of one frame: the body of one wave
+template <bool WG1>
+__device__ __forceinline__ void nfa_count_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int part, int nparts, int lane, NfaCountLds& L) {
+    CntItem* its = L.its;
+#ifdef SSLAM_NFA_INT
+    int (*nestWin)[6][4] = L.nestWin;
+#endif
+    unsigned short* act = L.act;
     Misc* misc = (Misc*)(base + P.offMisc);
     const int nCand = misc->nCand;
     const unsigned* Tb = (const unsigned*)(base + P.offT);
     const double* rects = (const double*)(base + P.offCand);
     NfaState* st = (NfaState*)(base + P.offNfa);
     const int sw = P.sw, sh = P.sh, tW = P.tW;
-    const int per = (nCand + gridDim.x - 1) / gridDim.x;
-    const int c0 = blockIdx.x * per, c1 = min(c0 + per, nCand);
+    const int per = (nCand + nparts - 1) / nparts;
+    const int c0 = part * per, c1 = min(c0 + per, nCand);
     const bool nested = stage == 0 || stage == 4;
     const bool small = sw < 32768 && sh < 32768;
     const int rpb = nested ? CNT_NEST : 12;                        // rectangles per batch (stages 1-3: five lanes each)
@@ -579,7 +597,7 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
             if (on) act[nAct + mbcnt(m)] = (unsigned short)(c - chunk);
             nAct += __popcll(m);
         }
-        __syncthreads();
+        nfa_wave_sync<WG1>();
         for (int a0 = 0; a0 < nAct; a0 += rpb) {
             const int nr = min(rpb, nAct - a0);
             const int nIt = nested ? nr : nr * MAXC;
@@ -630,7 +648,7 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
                     else if (j == 0) st[c].nc = __popcll((vm >> lane) & 31ull);
                 }
             }
-            __syncthreads();
+            nfa_wave_sync<WG1>();
             if (!nested) {
                 for (int ri = 0; ri < nr; ++ri) {
                     const CntItem* it5 = its + ri * MAXC;
@@ -680,9 +698,15 @@ __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t*
                     st[c].nc = K;
                 }
             }
-            __syncthreads();
+            nfa_wave_sync<WG1>();
         }
     }
+}
+
+__global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
+    __shared__ NfaCountLds L;
+    const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y;
+    nfa_count_body<true>(ws + (size_t)b * P.frameBytes, P, stage, blockIdx.x, gridDim.x, threadIdx.x, L);
 }
 
 // stage -1: the initial evaluation (cnt[0]); stage 0: cnt[1..5]; stages 1-4: cnt[0..nc).
@@ -695,18 +719,17 @@ __device__ __forceinline__ int stage_ncand(const NfaState& s, int stage) {
     if (s.done) return 0;
     return stage == 0 ? 5 : stage == 4 ? (s.nc > 0 ? 5 : 0) : s.nc;
 }
-__global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPlan P, int stage, const double* __restrict__ lgam) {
-    __shared__ unsigned short items[EVAL_CH * 5];            // (rect - chunk) << 3 | candidate
-    const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y, lane = threadIdx.x;
-    uint8_t* base = ws + (size_t)b * P.frameBytes;
+template <bool WG1>
+__device__ __forceinline__ void nfa_eval_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, const double* __restrict__ lgam, int part, int nparts, int lane,
+                                               unsigned short* __restrict__ items) {
     Misc* misc = (Misc*)(base + P.offMisc);
     const int nCand = misc->nCand;
     const double* rects = (const double*)(base + P.offCand);
     NfaState* st = (NfaState*)(base + P.offNfa);
     const PLog* plog = (const PLog*)(lgam + P.npx + 4);
     const double* rcp = lgam + P.npx + 4 + 48;
-    const int per = (nCand + gridDim.x - 1) / gridDim.x;
-    const int c0 = blockIdx.x * per, c1 = min(c0 + per, nCand);
+    const int per = (nCand + nparts - 1) / nparts;
+    const int c0 = part * per, c1 = min(c0 + per, nCand);
 #ifdef SSLAM_LSD_STATS
     long long useful = 0, executed = 0, evals = 0;
 #endif
@@ -721,7 +744,7 @@ __global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPl
             for (int j = 0; j < cnt; ++j) items[ex + j] = (unsigned short)(((c - chunk) << 3) | j);
             nItems += __builtin_amdgcn_readlane(incl, 63);
         }
-        __syncthreads();
+        nfa_wave_sync<WG1>();
         int pos = 0, myc = 0, myj = 0;
         bool active = false, pending = false, needLog = false;
         TailState S; S.term = 0; S.bin_tail = 1; S.p_term = 0; S.n = 0; S.i = 1;
@@ -768,7 +791,7 @@ __global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPl
             executed += 8;
 #endif
         }
-        __syncthreads();
+        nfa_wave_sync<WG1>();
     }
 #ifdef SSLAM_LSD_STATS
     // cyc[5] = useful tail iterations (upper bound: whole blocks), cyc[6] = lane-iterations the wave executed, cyc[7] = evaluations
@@ -777,16 +800,20 @@ __global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPl
 #endif
 }
 
+__global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPlan P, int stage, const double* __restrict__ lgam) {
+    __shared__ unsigned short items[EVAL_CH * 5];
+    const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y;
+    nfa_eval_body<true>(ws + (size_t)b * P.frameBytes, P, stage, lgam, blockIdx.x, gridDim.x, threadIdx.x, items);
+}
+
 // rect_improve's acceptance, in candidate order, one lane per rectangle (the candidates of a stage do not depend on which of
 // them is accepted, so they were all evaluated up front).
-__global__ __launch_bounds__(256) void k_nfa_accept(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
-    const int b = blockIdx.y;
-    uint8_t* base = ws + (size_t)b * P.frameBytes;
+__device__ __forceinline__ void nfa_accept_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int tid, int nthreads) {
     const Misc* misc = (const Misc*)(base + P.offMisc);
     const int nCand = misc->nCand;
     double* rects = (double*)(base + P.offCand);
     NfaState* st = (NfaState*)(base + P.offNfa);
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < nCand; c += gridDim.x * 256) {
+    for (int c = tid; c < nCand; c += nthreads) {
         if (stage < 0) { const double v0 = st[c].val[0]; st[c].logNfa = v0; st[c].done = v0 > 0.0 ? 1 : 0; continue; }
         const int nc = stage_ncand(st[c], stage);
         if (st[c].done) continue;
@@ -802,16 +829,18 @@ __global__ __launch_bounds__(256) void k_nfa_accept(uint8_t* __restrict__ ws, Ls
     }
 }
 
-__global__ __launch_bounds__(256) void k_nfa_finish(uint8_t* __restrict__ ws, LsdPlan P) {
-    const int b = blockIdx.y;
-    uint8_t* base = ws + (size_t)b * P.frameBytes;
+__global__ __launch_bounds__(256) void k_nfa_accept(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
+    nfa_accept_body(ws + (size_t)blockIdx.y * P.frameBytes, P, stage, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+__device__ __forceinline__ void nfa_finish_body(uint8_t* __restrict__ base, const LsdPlan& P, int tid, int nthreads) {
     const Misc* misc = (const Misc*)(base + P.offMisc);
     const int nCand = misc->nCand;
     const double* rects = (const double*)(base + P.offCand);
     const NfaState* st = (const NfaState*)(base + P.offNfa);
     float4* seg = (float4*)(base + P.offSeg);
     int* flag = (int*)(base + P.offFlag);
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < nCand; c += gridDim.x * 256) {
+    for (int c = tid; c < nCand; c += nthreads) {
         const bool ok = st[c].logNfa > 0.0;
         flag[c] = ok ? 1 : 0;
         if (ok) {
@@ -820,4 +849,46 @@ __global__ __launch_bounds__(256) void k_nfa_finish(uint8_t* __restrict__ ws, Ls
             seg[c] = make_float4((float)((o[0] + 0.5) / SCALE), (float)((o[1] + 0.5) / SCALE), (float)((o[2] + 0.5) / SCALE), (float)((o[3] + 0.5) / SCALE));
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_nfa_finish(uint8_t* __restrict__ ws, LsdPlan P) {
+    nfa_finish_body(ws + (size_t)blockIdx.y * P.frameBytes, P, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+// The whole NFA stage of one frame in ONE launch (round 4).  count -> evaluate -> accept are frame-local, so a frame's stages need no
+// launch boundary between them: W waves of one workgroup (W = blockDim.x / 64; 1 in the batch form, where the frames themselves fill the
+// chip) walk the frame's rectangles stage after stage with a workgroup barrier in between.  18 dependent launches became one: the line
+// stream queues once behind the point branch's grids instead of 18 times, and a frame no longer waits at every stage for the slowest
+// frame of the batch -- only the kernel's one tail is left.  Results are those of the separate launches (same bodies, same order).
+template <bool WG1>
+__device__ __forceinline__ void nfa_all_body(uint8_t* __restrict__ base, const LsdPlan& P, const double* __restrict__ lgam, int wave, int nwaves, int lane, NfaLds& L) {
+    const int nthreads = nwaves * 64;
+#pragma unroll 1
+    for (int it = -1; it <= 4; ++it) {
+        // Every body derives its addresses from (base, lgam, lane).  Made opaque per use, none of that is loop invariant any more: hoisted out of
+        // this loop the bodies' address arithmetic was live across all of them (131 spilled SGPRs, 14 spilled VGPRs, 60 bytes of scratch).
+#define NFA_OPAQUE() asm volatile("" : "+s"(base), "+s"(lgam), "+v"(lane))
+        NFA_OPAQUE();
+        if (it != 0) {                                   // stage 0's counts came with the initial evaluation's (nested tolerances, one pass)
+            nfa_count_body<WG1>(base, P, it < 0 ? 0 : it, wave, nwaves, lane, L.c);
+            __syncthreads();
+        }
+        NFA_OPAQUE();
+        nfa_eval_body<WG1>(base, P, it, lgam, wave, nwaves, lane, L.items);
+        __syncthreads();
+        NFA_OPAQUE();
+        nfa_accept_body(base, P, it, wave * 64 + lane, nthreads);
+        __syncthreads();
+    }
+    nfa_finish_body(base, P, wave * 64 + lane, nthreads);
+#undef NFA_OPAQUE
+}
+
+#ifndef SSLAM_NFA_ALL_MINWAVES
+#define SSLAM_NFA_ALL_MINWAVES 4
+#endif
+__global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_all(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
+    __shared__ NfaLds L;
+    const int b = xcd_mix_frame(blockIdx.x, gridDim.x);
+    nfa_all_body<true>(ws + (size_t)b * P.frameBytes, P, lgam, 0, 1, threadIdx.x, L);
 }
