@@ -265,6 +265,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the latency and PCIe-inclusive legs")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing (used for rocprofv3 runs)")
+    ap.add_argument("--no-pcie", action="store_true", help="latency leg only (no PCIe-inclusive host-batch leg)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="the default run appends a short pass of BASELINE configs[3] (1280x960 / 2000 kp / 400 lines) as other_workloads.c4; this skips it")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver (already exported on the GPU boxes)
@@ -487,9 +489,26 @@ def main():
             torch.cuda.empty_cache()
             try:
                 out["latency"] = latency_leg(fe, ctx, cur_np, with_lines)
-                out["pcie_inclusive"] = pcie_leg(fe, ctx, cur_np, with_lines, n=18432 if W == 640 else 3072, chunk=0 if W == 640 else 1024, prev_frames=prev_np)
+                if not args.no_pcie:
+                    out["pcie_inclusive"] = pcie_leg(fe, ctx, cur_np, with_lines, n=18432 if W == 640 else 3072, chunk=0 if W == 640 else 1024, prev_frames=prev_np)
             except Exception as e:
                 out["latency_error"] = str(e)[:300]
+        if world == 1 and args.workload == "c3" and not args.no_extras and not args.no_other_workloads:
+            # BASELINE configs[3] (1280x960, 2000 kp, 400 lines: the "rocprof HBM-GB/s run") in the driver's own bench run: a short pass of the
+            # same harness in a child process (this process holds no batch any more), its headline numbers appended to this line
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pcie"],
+                                   capture_output=True, text=True, timeout=900)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                c4 = json.loads(line[-1])
+                out["other_workloads"] = {"c4": {"workload": c4["config"]["workload"], "value": c4["value"], "unit": c4["unit"], "ms_per_step": c4["ms_per_step"], "steps": c4["steps"],
+                                                 "batch": c4["config"].get("batch_per_gpu"), "mean_keypoints": c4["config"].get("mean_keypoints"), "mean_lines": c4["config"].get("mean_lines"),
+                                                 "roofline": {k: c4["roofline"].get(k) for k in ("kernel", "frac", "achieved", "avg_launch_ms", "traffic")} if "roofline" in c4 else None,
+                                                 "whole_pipeline_frac": c4.get("roofline", {}).get("whole_pipeline", {}).get("frac"),
+                                                 "latency": {k: c4.get("latency", {}).get(k) for k in ("orb_extract_hipEvent", "lines_extract_hipEvent", "frames_per_s_one_at_a_time")}}}
+            except Exception as e:
+                out["other_workloads"] = {"c4": {"error": str(e)[:300]}}
         print(json.dumps(out))
     if gather is not None:
         gather.wait()

@@ -67,6 +67,7 @@ struct sslam_ctx {
     sslam::DevBuf scratch[8];      // matcher staging
     sslam::DevBuf recordOffsets[4];   // sslam_pack_records_dev: per-frame offsets of the record stream, one buffer per stream that packs
     void* recordOffsetsStream[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long recordOffsetsUse[4] = {0, 0, 0, 0}, recordOffsetsClock = 0;      // least-recently-used recycling of the four slots
     sslam::HostPinned pinned[4];
     int num_cus = 0;
     void* batchCache = nullptr;                  // sslam_frontend_batch: staging buffers, streams, events kept between calls (batch.hip)

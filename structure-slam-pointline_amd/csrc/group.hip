@@ -11,6 +11,7 @@
 #include "common.h"
 #include <dlfcn.h>
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <thread>
 
@@ -36,7 +37,7 @@ struct Rccl {
 };
 constexpr int kNcclUint8 = 1, kNcclUint64 = 5;      // ncclDataType_t (rccl.h)
 
-Rccl* rccl() {
+Rccl* rccl_real() {
     static Rccl R;
     static std::once_flag once;
     std::call_once(once, [] {
@@ -61,11 +62,144 @@ Rccl* rccl() {
     });
     return R.h ? &R : nullptr;
 }
+
+// ------------------------------------------------------------------ SSLAM_GROUP_FAKE_RCCL=1: an in-process stand-in for the RCCL entry points
+// N > 1 has never run on hardware here (one GPU per box), so the group code's multi-member paths -- a host thread per device, uneven tails,
+// the collective error agreement, grouped send / receive to the root -- had no execution at all.  With this table selected at group creation
+// the "devices" of a group are contexts (streams) of whatever GPUs are visible, dealt round-robin, and the collectives are host-mediated
+// device-to-device copies with NCCL's matching rules: a send to p pairs with p's receive from the sender in posting order, calls between
+// GroupStart / GroupEnd are issued together, an all-gather is a rendezvous of all ranks.  Same process only (ranks are threads).  It moves
+// real bytes between real device buffers through the same code paths; it says nothing about xGMI -- the scaling run stays the driver's.
+struct FakeWorld {
+    int nranks = 0, refs = 0;
+    std::mutex mu; std::condition_variable cv;
+    struct Msg { unsigned long id; int src, dst; const void* ptr; size_t bytes; bool taken; };
+    std::vector<Msg> box;                           // posted sends, in posting order (entries are named by id: the vector shifts when a sender clears its own)
+    unsigned long nextId = 1;
+    std::vector<const void*> agPtr; int agArrived = 0, agLeft = 0, agGen = 0;
+};
+struct FakeComm { FakeWorld* w; int rank; };
+struct FakeOp { int kind; const void* sptr; void* rptr; size_t bytes; int peer; FakeComm* c; hipStream_t st; unsigned long id; };      // 0 send, 1 recv
+// every wait of the stand-in is bounded: a protocol error of the group code must fail a test, not hang the suite
+constexpr std::chrono::seconds kFakeWait(60);
+thread_local int tFakeDepth = 0;
+thread_local std::vector<FakeOp> tFakeOps;
+std::mutex gFakeMu;
+std::vector<std::pair<NcclUid, FakeWorld*>> gFakeWorlds;      // worlds being assembled by ncclCommInitRank, keyed by unique id
+int gFakeIdCounter = 0;
+
+size_t fake_dtype_bytes(int dt) { return dt == kNcclUint64 ? 8 : 1; }
+int fake_flush() {
+    std::vector<FakeOp> ops; ops.swap(tFakeOps);
+    // sends first: publish (the data must be final: drain the sender's stream), then receives (wait for the partner's publication, copy,
+    // acknowledge), then wait until every own send was taken -- a rank that posts both directions in one group cannot block itself
+    for (FakeOp& o : ops) if (o.kind == 0) {
+        if (hipStreamSynchronize(o.st) != hipSuccess) return 1;
+        std::lock_guard<std::mutex> lk(o.c->w->mu);
+        o.id = o.c->w->nextId++;
+        o.c->w->box.push_back({o.id, o.c->rank, o.peer, o.sptr, o.bytes, false});
+        o.c->w->cv.notify_all();
+    }
+    auto find = [](FakeWorld* w, unsigned long id) -> FakeWorld::Msg* { for (auto& m : w->box) if (m.id == id) return &m; return nullptr; };
+    for (FakeOp& o : ops) if (o.kind == 1) {
+        FakeWorld* w = o.c->w; const void* src = nullptr; unsigned long id = 0; size_t bytes = 0;
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            // the oldest untaken send of that peer to this rank (receives of one rank are issued by one thread, one after the other)
+            if (!w->cv.wait_for(lk, kFakeWait, [&] { for (auto& m : w->box) if (!m.taken && m.src == o.peer && m.dst == o.c->rank) { id = m.id; return true; } return false; })) return 4;
+            FakeWorld::Msg* m = find(w, id);
+            src = m->ptr; bytes = m->bytes;
+        }
+        if (bytes != o.bytes) return 2;               // NCCL would hang or corrupt on mismatched sizes: here it is an error
+        // stream-ordered on the receiver's stream like the real receive, then drained: the sender may reuse its buffer once this returns
+        if (o.bytes && hipMemcpyAsync(o.rptr, src, o.bytes, hipMemcpyDeviceToDevice, o.st) != hipSuccess) return 1;
+        if (hipStreamSynchronize(o.st) != hipSuccess) return 1;
+        std::lock_guard<std::mutex> lk(w->mu);
+        if (FakeWorld::Msg* m = find(w, id)) m->taken = true;
+        w->cv.notify_all();
+    }
+    for (FakeOp& o : ops) if (o.kind == 0) {
+        FakeWorld* w = o.c->w;
+        std::unique_lock<std::mutex> lk(w->mu);
+        if (!w->cv.wait_for(lk, kFakeWait, [&] { FakeWorld::Msg* m = find(w, o.id); return !m || m->taken; })) return 4;
+        for (size_t i = 0; i < w->box.size(); ++i) if (w->box[i].id == o.id) { w->box.erase(w->box.begin() + i); break; }
+    }
+    return 0;
+}
+int fakeGetUniqueId(NcclUid* u) { std::lock_guard<std::mutex> lk(gFakeMu); memset(u, 0, sizeof(*u)); snprintf(u->internal, sizeof(u->internal), "sslam-fake-rccl-%d", ++gFakeIdCounter); return 0; }
+int fakeCommInitAll(ncclComm_t* comms, int n, const int*) {
+    FakeWorld* w = new FakeWorld(); w->nranks = n; w->refs = n; w->agPtr.assign(n, nullptr);
+    for (int r = 0; r < n; ++r) comms[r] = (ncclComm_t) new FakeComm{w, r};
+    return 0;
+}
+int fakeCommInitRank(ncclComm_t* comm, int n, NcclUid id, int rank) {
+    std::lock_guard<std::mutex> lk(gFakeMu);
+    FakeWorld* w = nullptr;
+    for (auto& e : gFakeWorlds) if (memcmp(e.first.internal, id.internal, sizeof(id.internal)) == 0) w = e.second;
+    if (!w) { w = new FakeWorld(); w->nranks = n; w->agPtr.assign(n, nullptr); gFakeWorlds.push_back({id, w}); }
+    if (w->nranks != n || rank < 0 || rank >= n) return 3;
+    ++w->refs;
+    *comm = (ncclComm_t) new FakeComm{w, rank};
+    return 0;
+}
+int fakeCommDestroy(ncclComm_t c_) {
+    FakeComm* c = (FakeComm*)c_; if (!c) return 0;
+    std::lock_guard<std::mutex> lk(gFakeMu);
+    if (--c->w->refs == 0) {
+        for (size_t i = 0; i < gFakeWorlds.size(); ++i) if (gFakeWorlds[i].second == c->w) { gFakeWorlds.erase(gFakeWorlds.begin() + i); break; }
+        delete c->w;
+    }
+    delete c; return 0;
+}
+int fakeGroupStart() { ++tFakeDepth; return 0; }
+int fakeGroupEnd() { if (--tFakeDepth > 0) return 0; tFakeDepth = 0; return fake_flush(); }
+int fakeSend(const void* p, size_t count, int dt, int peer, ncclComm_t c, hipStream_t st) {
+    tFakeOps.push_back({0, p, nullptr, count * fake_dtype_bytes(dt), peer, (FakeComm*)c, st, 0});
+    return tFakeDepth ? 0 : fake_flush();
+}
+int fakeRecv(void* p, size_t count, int dt, int peer, ncclComm_t c, hipStream_t st) {
+    tFakeOps.push_back({1, nullptr, p, count * fake_dtype_bytes(dt), peer, (FakeComm*)c, st, 0});
+    return tFakeDepth ? 0 : fake_flush();
+}
+int fakeAllGather(const void* sp, void* rp, size_t count, int dt, ncclComm_t c_, hipStream_t st) {
+    FakeComm* c = (FakeComm*)c_; FakeWorld* w = c->w; const size_t bytes = count * fake_dtype_bytes(dt);
+    if (hipStreamSynchronize(st) != hipSuccess) return 1;
+    std::vector<const void*> ptrs;
+    {
+        std::unique_lock<std::mutex> lk(w->mu);
+        if (!w->cv.wait_for(lk, kFakeWait, [&] { return w->agLeft == 0; })) return 4;              // the previous round has been left by everybody
+        const int gen = w->agGen;
+        w->agPtr[c->rank] = sp;
+        if (++w->agArrived == w->nranks) { w->agLeft = w->nranks; w->agArrived = 0; ++w->agGen; w->cv.notify_all(); }
+        else if (!w->cv.wait_for(lk, kFakeWait, [&] { return w->agGen != gen; })) return 4;
+        ptrs = w->agPtr;
+    }
+    int rc = 0;
+    for (int r = 0; r < w->nranks && !rc; ++r) if (bytes && hipMemcpyAsync((char*)rp + (size_t)r * bytes, ptrs[r], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = 1;
+    if (hipStreamSynchronize(st) != hipSuccess) rc = 1;
+    std::unique_lock<std::mutex> lk(w->mu);
+    if (--w->agLeft == 0) w->cv.notify_all();
+    if (!w->cv.wait_for(lk, kFakeWait, [&] { return w->agLeft == 0; })) return 4;                  // nobody's send buffer is reused before everybody has copied it
+    return rc;
+}
+const char* fakeGetErrorString(int e) { return e == 4 ? "fake rccl: a peer did not show up within 60 s" : e == 2 ? "fake rccl: send / receive sizes differ" : e == 3 ? "fake rccl: inconsistent communicator arguments" : "fake rccl: HIP error"; }
+Rccl* rccl_fake() {
+    static Rccl F;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        F.h = (void*)&F; F.GetUniqueId = fakeGetUniqueId; F.CommInitRank = fakeCommInitRank; F.CommInitAll = fakeCommInitAll; F.CommDestroy = fakeCommDestroy;
+        F.GroupStart = fakeGroupStart; F.GroupEnd = fakeGroupEnd; F.Send = fakeSend; F.Recv = fakeRecv; F.AllGather = fakeAllGather; F.GetErrorString = fakeGetErrorString;
+    });
+    return &F;
+}
+bool fake_rccl_requested() { const char* e = getenv("SSLAM_GROUP_FAKE_RCCL"); return e && atoi(e) != 0; }
+// the table a NEW group binds (kept in the group: a process may hold real and stand-in groups side by side)
+Rccl* rccl() { return fake_rccl_requested() ? rccl_fake() : rccl_real(); }
 #define SSLAM_NCCL(expr)                                                                                              \
     do {                                                                                                              \
         int _r = (expr);                                                                                              \
         if (_r != 0) {                                                                                                \
-            sslam::set_error("%s failed: %s", #expr, rccl()->GetErrorString ? rccl()->GetErrorString(_r) : "rccl error"); \
+            sslam::set_error("%s failed (rccl status %d)", #expr, _r);                                               \
             return SSLAM_ERR_HIP;                                                                                     \
         }                                                                                                             \
     } while (0)
@@ -134,6 +268,7 @@ struct Barrier {      // reusable thread barrier (the per-device host threads of
 struct Member {       // one GPU of a single-process group
     sslam_ctx* ctx = nullptr; sslam_orb* orb = nullptr; sslam_lines* lines = nullptr;
     ncclComm_t comm = nullptr;
+    Rccl* api = nullptr;                    // the table the communicator was made with (real RCCL or the in-process stand-in)
     DevBuf dIn, dKp, dDesc, dN, dKl, dLd, dFn, dNl, dSend, dTotal, dStatus, dRecv;
     HostPinned hTotal, hRecv;
 };
@@ -143,6 +278,7 @@ struct Member {       // one GPU of a single-process group
 struct sslam_group {
     int nranks = 1, rank = 0, device = 0;
     bool singleProcess = true;
+    Rccl* api = nullptr;                   // real RCCL, or the in-process stand-in (SSLAM_GROUP_FAKE_RCCL=1 when the group was created)
     std::vector<Member> mem;               // single-process: one per device; rank form: one
     sslam_frontend_params params{};
     bool haveParams = false;
@@ -174,12 +310,16 @@ extern "C" int sslam_pack_records_dev(sslam_ctx* ctx, int nframes, int frame0, i
     if (!offBuf) {
         int slot = -1;
         for (int i = 0; i < 4 && slot < 0; ++i) if (!ctx->recordOffsets[i].p) slot = i;
-        if (slot < 0) {                                      // more than four streams: recycle slot 0 once its stream is idle
+        if (slot < 0) {                                      // more than four streams: recycle the least recently used slot once its work is done
             slot = 0;
-            SSLAM_HIP(hipStreamSynchronize((hipStream_t)ctx->recordOffsetsStream[0]));
+            for (int i = 1; i < 4; ++i) if (ctx->recordOffsetsUse[i] < ctx->recordOffsetsUse[slot]) slot = i;
+            // the remembered handle may belong to a stream the caller has destroyed since (or to a new stream that reuses the handle): a failed
+            // synchronise is not an error of this call -- drain the device instead, after which nothing can still read the buffer
+            if (hipStreamSynchronize((hipStream_t)ctx->recordOffsetsStream[slot]) != hipSuccess) { (void)hipGetLastError(); SSLAM_HIP(hipDeviceSynchronize()); }
         }
         ctx->recordOffsetsStream[slot] = (void*)st; offBuf = &ctx->recordOffsets[slot];
     }
+    ctx->recordOffsetsUse[offBuf - ctx->recordOffsets] = ++ctx->recordOffsetsClock;
     if ((size_t)(nframes + 1) * 8 > offBuf->cap) SSLAM_HIP(hipStreamSynchronize(st));      // a growing buffer is freed first: nothing may still read it
     if ((rc = offBuf->ensure(sizeof(unsigned long long) * ((size_t)nframes + 1)))) return rc;
     unsigned long long* off = offBuf->as<unsigned long long>();
@@ -225,7 +365,7 @@ extern "C" int sslam_unpack_records(const uint8_t* stream, uint64_t bytes, int n
 // ------------------------------------------------------------------ group handles
 static void member_release(Member& m) {
     if (m.ctx) (void)hipSetDevice(m.ctx->device);
-    if (m.comm && rccl()) (void)rccl()->CommDestroy(m.comm);
+    if (m.comm && m.api) (void)m.api->CommDestroy(m.comm);
     if (m.lines) sslam_lines_destroy(m.lines);
     if (m.orb) sslam_orb_destroy(m.orb);
     DevBuf* bufs[] = {&m.dIn, &m.dKp, &m.dDesc, &m.dN, &m.dKl, &m.dLd, &m.dFn, &m.dNl, &m.dSend, &m.dTotal, &m.dStatus, &m.dRecv};
@@ -239,19 +379,21 @@ extern "C" int sslam_group_create(int ngpu, sslam_group** out) {
     if (!out || ngpu <= 0 || ngpu > 64) { set_error("sslam_group_create: invalid arguments"); return SSLAM_ERR_INVALID; }
     int have = 0;
     if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) { set_error("sslam_group_create: no HIP device visible; there is no CPU fallback"); return SSLAM_ERR_NO_DEVICE; }
-    if (ngpu > have) { set_error("sslam_group_create: %d GPUs requested, %d visible", ngpu, have); return SSLAM_ERR_INVALID; }
-    if (!rccl()) { set_error("sslam_group_create: librccl.so.1 could not be loaded"); return SSLAM_ERR_UNSUPPORTED; }
+    const bool fake = fake_rccl_requested();      // the stand-in deals its members over the visible GPUs round-robin (several contexts per GPU)
+    if (ngpu > have && !fake) { set_error("sslam_group_create: %d GPUs requested, %d visible", ngpu, have); return SSLAM_ERR_INVALID; }
+    Rccl* R = rccl();
+    if (!R) { set_error("sslam_group_create: librccl.so.1 could not be loaded"); return SSLAM_ERR_UNSUPPORTED; }
     sslam_group* g = new sslam_group();
-    g->nranks = ngpu; g->rank = 0; g->singleProcess = true;
+    g->nranks = ngpu; g->rank = 0; g->singleProcess = true; g->api = R;
     g->mem.resize(ngpu);
     int rc = SSLAM_OK;
-    for (int d = 0; d < ngpu && rc == SSLAM_OK; ++d) rc = sslam_ctx_create(d, &g->mem[d].ctx);
+    for (int d = 0; d < ngpu && rc == SSLAM_OK; ++d) rc = sslam_ctx_create(d % have, &g->mem[d].ctx);
     if (rc == SSLAM_OK) {
         std::vector<int> devs(ngpu); std::vector<ncclComm_t> comms(ngpu, nullptr);
-        for (int d = 0; d < ngpu; ++d) devs[d] = d;
-        const int r = rccl()->CommInitAll(comms.data(), ngpu, devs.data());
-        if (r != 0) { set_error("ncclCommInitAll failed: %s", rccl()->GetErrorString ? rccl()->GetErrorString(r) : "rccl error"); rc = SSLAM_ERR_HIP; }
-        else for (int d = 0; d < ngpu; ++d) g->mem[d].comm = comms[d];
+        for (int d = 0; d < ngpu; ++d) devs[d] = d % have;
+        const int r = R->CommInitAll(comms.data(), ngpu, devs.data());
+        if (r != 0) { set_error("ncclCommInitAll failed: %s", R->GetErrorString ? R->GetErrorString(r) : "rccl error"); rc = SSLAM_ERR_HIP; }
+        else for (int d = 0; d < ngpu; ++d) { g->mem[d].comm = comms[d]; g->mem[d].api = R; }
     }
     if (rc != SSLAM_OK) { for (auto& m : g->mem) member_release(m); delete g; return rc; }
     *out = g;
@@ -274,14 +416,15 @@ extern "C" int sslam_group_create_rank(int device, int rank, int nranks, const u
     if (hipGetDeviceCount(&have) != hipSuccess || device < 0 || device >= have) { set_error("sslam_group_create_rank: device %d not visible", device); return SSLAM_ERR_NO_DEVICE; }
     SSLAM_HIP(hipSetDevice(device));
     sslam_group* g = new sslam_group();
-    g->nranks = nranks; g->rank = rank; g->device = device; g->singleProcess = false;
+    g->nranks = nranks; g->rank = rank; g->device = device; g->singleProcess = false; g->api = rccl();
     g->mem.resize(1);
     NcclUid u; memcpy(u.internal, id, SSLAM_GROUP_ID_BYTES);
-    const int r = rccl()->CommInitRank(&g->mem[0].comm, nranks, u, rank);
-    if (r != 0) { set_error("ncclCommInitRank failed: %s", rccl()->GetErrorString ? rccl()->GetErrorString(r) : "rccl error"); delete g; return SSLAM_ERR_HIP; }
+    const int r = g->api->CommInitRank(&g->mem[0].comm, nranks, u, rank);
+    if (r != 0) { set_error("ncclCommInitRank failed: %s", g->api->GetErrorString ? g->api->GetErrorString(r) : "rccl error"); delete g; return SSLAM_ERR_HIP; }
+    g->mem[0].api = g->api;
     if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess || g->dSizes.ensure(16 * (size_t)nranks + 16) != SSLAM_OK ||
         g->hSizes.ensure(16 * (size_t)nranks + 16) != SSLAM_OK) {
-        set_error("sslam_group_create_rank: allocation failed"); (void)rccl()->CommDestroy(g->mem[0].comm); delete g; return SSLAM_ERR_HIP;
+        set_error("sslam_group_create_rank: allocation failed"); (void)g->api->CommDestroy(g->mem[0].comm); g->mem[0].comm = nullptr; delete g; return SSLAM_ERR_HIP;
     }
     *out = g;
     return SSLAM_OK;
@@ -309,7 +452,7 @@ extern "C" int sslam_group_gather_dev(sslam_group* g, const uint8_t* d_send, con
     std::lock_guard<std::mutex> lk(g->mu);
     SSLAM_HIP(hipSetDevice(g->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : g->stream;
-    Rccl* R = rccl();
+    Rccl* R = g->api;
     ncclComm_t comm = g->mem[0].comm;
     // 1. lengths: every rank learns every length AND the root's receive capacity (a pair of words per rank), so that the decision to go
     //    on is the same everywhere: a rank that returned before posting its side of the exchange would leave the others blocked in theirs
@@ -420,7 +563,7 @@ extern "C" int sslam_frontend_batch_sharded(sslam_group* g, const sslam_frontend
     // the capacities, exactly as sslam_frontend_batch delivers it
     for (int i = 0; i < n; ++i) { nkp_out[i] = -1; if (lines) nl_out[i] = -1; }
     std::vector<uint64_t> sizes(G, 0);
-    Rccl* R = rccl();
+    Rccl* R = g->api;
     auto worker = [&](int d) {
         Member& m = g->mem[d];
         int rc = SSLAM_OK;

@@ -67,7 +67,7 @@ struct sslam_lines {
     int planW = 0, planH = 0;
     LsdPlan plan;
     DevBuf dWs, dTabs, dTaps, dLgam, dGtab;
-    size_t clFrame = 0;
+    size_t clFrame = 0; int clSlots = 0;      // layout of the last cluster-form launch (sslam_lines_debug_cluster reads it back)
     DevBuf dCl;                     // cluster form of the sequential core (lsd_cluster.h): chunk headers, shared map and list arenas of up to 8 frames
     int wsFrames = 0, lastFrames = 0;
     hipEvent_t coreEvent = nullptr;          // sslam_lines_set_core_event
@@ -282,10 +282,13 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             const int clSpecWords = clShift < 0 ? 0 : (((P.sw + (1 << clShift) - 1) >> clShift) * ((P.sh + (1 << clShift) - 1) >> clShift) + 31) / 32;
             const size_t maxSubs = ((size_t)P.npx + CL_SUB - 1) / CL_SUB;
             const size_t zeroBytes = 512 + ((maxSubs * sizeof(ClSub) + 511) & ~(size_t)511) + 4 * (size_t)((clSpecWords + 127) & ~127) + (bigFrame ? 4 * (size_t)TorusGlobal::WORDS : 0);      // control block, sub-chunk states / flags, shared map (+ the main wave's bitmap)
-            const size_t clFrame = align_up(zeroBytes + maxSubs * CL_RES * sizeof(ClRec) + 4 * (size_t)CL_ARENA * (CL_MAXWG * CL_WAVES), 4096);
-            L->clFrame = clFrame;
-            const size_t clSlots = (size_t)((nframes + 7) / 8) * 8;
             if (nframes > 8) nWG = std::max(2, std::min(nWG, 32 / ((nframes + 7) / 8)));      // the frames of an XCD share its 32 compute units
+            // per frame: the zeroed head, two result records per seed position, one 256 KB list arena per HELPER THAT EXISTS ((nWG - 1) x CL_HPW: 27 by default;
+            // rounds 1-3 sized it for 64).  One slot per frame of the call: blocks with b >= nframes return at once, so the XCD-aligned grid needs no padding slots
+            // (a single 640x480 frame held 8 slots of 30 MB before).
+            const size_t clFrame = align_up(zeroBytes + maxSubs * CL_RES * sizeof(ClRec) + 4 * (size_t)CL_ARENA * (size_t)std::max(1, (nWG - 1) * CL_HPW), 4096);
+            L->clFrame = clFrame; L->clSlots = nframes;
+            const size_t clSlots = (size_t)nframes;
             if (L->dCl.cap < clFrame * clSlots) { SSLAM_HIP(hipStreamSynchronize(st)); if ((rc = L->dCl.ensure(clFrame * clSlots))) return rc; }
             for (int f = 0; f < nframes; ++f) SSLAM_HIP(hipMemsetAsync(L->dCl.as<uint8_t>() + (size_t)f * clFrame, 0, zeroBytes, st));
             const size_t clLds = sizeof(unsigned) * std::max((size_t)QCAP + 4 + (bigFrame ? 0 : TorusFrame::WORDS) + CL_SCAN + CL_RING_WORDS, (size_t)CL_HPW * (CL_LIST + ClTorus::WORDS));      // the main wave's workgroup / a helper workgroup
@@ -299,16 +302,33 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         else hipLaunchKernelGGL(k_lsd_regions<false>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());
     }
     if (L->coreDone) SSLAM_HIP(hipEventRecord(L->coreDone, st));
-    int evalWaves = nframes >= 1024 ? 1 : nframes >= 64 ? 4 : 16;      // waves per frame walking the NFA evaluations
-    int countWaves = nframes >= 2048 ? 1 : nframes >= 128 ? 8 : 64;    // waves per frame walking the rectangle counts
+    int evalWaves = nframes >= 1024 ? 1 : nframes >= 64 ? 4 : nframes >= 16 ? 16 : 32;      // waves per frame walking the NFA evaluations
+    int countWaves = nframes >= 2048 ? 1 : nframes >= 128 ? 8 : nframes >= 16 ? 64 : 128;   // waves per frame walking the rectangle counts (round 4: 128 / 32 for a handful of frames, 6.25 -> 6.09 ms per frame)
     if (const char* e = getenv("SSLAM_COUNT_WAVES")) countWaves = std::max(1, atoi(e));
     if (const char* e = getenv("SSLAM_EVAL_WAVES")) evalWaves = std::max(1, atoi(e));
-    // one wave per frame in the batch form: the whole NFA stage as ONE launch (lsd_nfa.h, k_nfa_all).  SSLAM_NFA_FUSED=0 keeps the 18 launches.
-    bool nfaFused = countWaves == 1 && evalWaves == 1;
-    if (const char* e = getenv("SSLAM_NFA_FUSED")) nfaFused = atoi(e) == 2 || (nfaFused && atoi(e) != 0);      // 2: whatever the batch size (tests)
-    if (nfaFused) {
+    // The whole NFA stage as ONE launch (lsd_nfa.h): one wave per frame when the frames themselves fill the chip (k_nfa_all, calls of >= 2048 frames).
+    // Below that the 18 launches stay: a single frame's stage is bound by the work of each wave, not by launch boundaries (kernel durations add up
+    // to the stage's 0.6 ms), and the one-workgroup form (k_nfa_all_wg, sixteen waves) has a quarter of the counting waves: measured 6.42 / 7.70 ms
+    // p50 / p90 per frame against 6.25 / 7.40 (eight waves: 6.66).  What helped instead: 128 counting and 32 evaluating waves per frame (6.09 / 7.16).
+    // SSLAM_NFA_WAVES=n forces the workgroup form with n waves, SSLAM_NFA_FUSED=0 the launches, =2 the one-wave form (tests).
+    int nfaWaves = 0;
+    if (const char* e = getenv("SSLAM_NFA_WAVES")) nfaWaves = std::max(1, std::min(16, atoi(e)));
+    bool nfaFused = nfaWaves > 0 || (countWaves == 1 && evalWaves == 1);
+    if (nfaWaves == 0) nfaWaves = 1;
+    if (const char* e = getenv("SSLAM_NFA_FUSED")) { nfaFused = atoi(e) == 2 || (nfaFused && atoi(e) != 0); if (atoi(e) == 2) nfaWaves = 1; }
+    if (nfaFused && nfaWaves == 1) {
         sslam::ProfScope _ps(L->ctx, "k_nfa_all", st);
         hipLaunchKernelGGL(k_nfa_all, dim3(nframes), dim3(64), 0, st, ws, P, L->dLgam.as<double>());
+    } else if (nfaFused) {
+        const size_t nfaLds = sizeof(NfaLdsT<WG_CH>) * (size_t)nfaWaves;
+        sslam::ProfScope _ps(L->ctx, "k_nfa_all", st);
+        if (nfaWaves > 8) {
+            if (nfaLds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_nfa_all_wg<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nfaLds));
+            hipLaunchKernelGGL(k_nfa_all_wg<1024>, dim3(nframes), dim3(64 * nfaWaves), nfaLds, st, ws, P, L->dLgam.as<double>());
+        } else {
+            if (nfaLds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_nfa_all_wg<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nfaLds));
+            hipLaunchKernelGGL(k_nfa_all_wg<512>, dim3(nframes), dim3(64 * nfaWaves), nfaLds, st, ws, P, L->dLgam.as<double>());
+        }
     } else {
         for (int stage = 0; stage <= 4; ++stage) {
             { static const char* kCountNames[5] = {"k_nfa_count", "k_nfa_count/s1", "k_nfa_count/s2", "k_nfa_count/s3", "k_nfa_count/s4"};
@@ -440,7 +460,7 @@ extern "C" int sslam_lines_debug_cycles(sslam_lines* L, int frame, long long* ou
 
 // counters of the cluster form's helpers for frame `frame` of the last call (lsd_cluster.h, ClCtl::stat; filled by builds with -DSSLAM_CL_CYCLES)
 extern "C" int sslam_lines_debug_cluster(sslam_lines* L, int frame, long long* out8) {
-    if (!L || frame < 0 || frame >= 128 || !out8 || !L->dCl.p || !L->clFrame) return SSLAM_ERR_INVALID;
+    if (!L || frame < 0 || frame >= L->clSlots || !out8 || !L->dCl.p || !L->clFrame) return SSLAM_ERR_INVALID;
     SSLAM_HIP(hipSetDevice(L->ctx->device));
     SSLAM_HIP(hipDeviceSynchronize());
     ClCtl c;

@@ -551,14 +551,18 @@ __global__ __launch_bounds__(256) void k_selftest_align(unsigned long long seed,
 #define SSLAM_COUNT_MINWAVES 4
 #endif
 // LDS of one wave of the NFA stage: the counter's item batch + active list, or the evaluator's item list (never both at once)
-struct NfaCountLds {
+template <int CH>
+struct NfaCountLdsT {
     CntItem its[64];
 #ifdef SSLAM_NFA_INT
     int nestWin[CNT_NEST][6][4];                                     // nested stages: {lo0, hi0, lo1, hi1} per precision
 #endif
-    unsigned short act[EVAL_CH];
+    unsigned short act[CH];
 };
-union NfaLds { NfaCountLds c; unsigned short items[EVAL_CH * 5]; };      // items: (rect - chunk) << 3 | candidate
+template <int CH> union NfaLdsT { NfaCountLdsT<CH> c; unsigned short items[CH * 5]; };      // items: (rect - chunk) << 3 | candidate; CH = rectangles per chunk
+typedef NfaCountLdsT<EVAL_CH> NfaCountLds;
+typedef NfaLdsT<EVAL_CH> NfaLds;
+constexpr int WG_CH = 128;             // chunk of the workgroup-per-frame form (sixteen waves share a frame's few hundred rectangles)
 
 // the inner synchronisation of the per-wave stage bodies: only the wave's own LDS arrays are at stake.  A single-wave workgroup may use
 // the workgroup barrier; waves of a larger workgroup run the bodies with different trip counts and must not meet at one.
@@ -569,8 +573,8 @@ __device__ __forceinline__ void nfa_wave_sync() {
 }
 
 // aligned-point counts of the stage's candidates for the rectangles [part * per, ...) of one frame: the body of one wave
-template <bool WG1>
-__device__ __forceinline__ void nfa_count_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int part, int nparts, int lane, NfaCountLds& L) {
+template <bool WG1, int CH>
+__device__ __forceinline__ void nfa_count_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int part, int nparts, int lane, NfaCountLdsT<CH>& L) {
     CntItem* its = L.its;
 #ifdef SSLAM_NFA_INT
     int (*nestWin)[6][4] = L.nestWin;
@@ -587,8 +591,8 @@ __device__ __forceinline__ void nfa_count_body(uint8_t* __restrict__ base, const
     const bool nested = stage == 0 || stage == 4;
     const bool small = sw < 32768 && sh < 32768;
     const int rpb = nested ? CNT_NEST : 12;                        // rectangles per batch (stages 1-3: five lanes each)
-    for (int chunk = c0; chunk < c1; chunk += EVAL_CH) {
-        const int cend = min(chunk + EVAL_CH, c1);
+    for (int chunk = c0; chunk < c1; chunk += CH) {
+        const int cend = min(chunk + CH, c1);
         int nAct = 0;
         for (int cb = chunk; cb < cend; cb += 64) {               // rectangles still being refined
             const int c = cb + lane;
@@ -706,7 +710,7 @@ __device__ __forceinline__ void nfa_count_body(uint8_t* __restrict__ base, const
 __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
     __shared__ NfaCountLds L;
     const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y;
-    nfa_count_body<true>(ws + (size_t)b * P.frameBytes, P, stage, blockIdx.x, gridDim.x, threadIdx.x, L);
+    nfa_count_body<true, EVAL_CH>(ws + (size_t)b * P.frameBytes, P, stage, blockIdx.x, gridDim.x, threadIdx.x, L);
 }
 
 // stage -1: the initial evaluation (cnt[0]); stage 0: cnt[1..5]; stages 1-4: cnt[0..nc).
@@ -719,7 +723,7 @@ __device__ __forceinline__ int stage_ncand(const NfaState& s, int stage) {
     if (s.done) return 0;
     return stage == 0 ? 5 : stage == 4 ? (s.nc > 0 ? 5 : 0) : s.nc;
 }
-template <bool WG1>
+template <bool WG1, int CH>
 __device__ __forceinline__ void nfa_eval_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, const double* __restrict__ lgam, int part, int nparts, int lane,
                                                unsigned short* __restrict__ items) {
     Misc* misc = (Misc*)(base + P.offMisc);
@@ -733,8 +737,8 @@ __device__ __forceinline__ void nfa_eval_body(uint8_t* __restrict__ base, const 
 #ifdef SSLAM_LSD_STATS
     long long useful = 0, executed = 0, evals = 0;
 #endif
-    for (int chunk = c0; chunk < c1; chunk += EVAL_CH) {
-        const int cend = min(chunk + EVAL_CH, c1);
+    for (int chunk = c0; chunk < c1; chunk += CH) {
+        const int cend = min(chunk + CH, c1);
         int nItems = 0;
         for (int cb = chunk; cb < cend; cb += 64) {
             const int c = cb + lane;
@@ -803,7 +807,7 @@ __device__ __forceinline__ void nfa_eval_body(uint8_t* __restrict__ base, const 
 __global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPlan P, int stage, const double* __restrict__ lgam) {
     __shared__ unsigned short items[EVAL_CH * 5];
     const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y;
-    nfa_eval_body<true>(ws + (size_t)b * P.frameBytes, P, stage, lgam, blockIdx.x, gridDim.x, threadIdx.x, items);
+    nfa_eval_body<true, EVAL_CH>(ws + (size_t)b * P.frameBytes, P, stage, lgam, blockIdx.x, gridDim.x, threadIdx.x, items);
 }
 
 // rect_improve's acceptance, in candidate order, one lane per rectangle (the candidates of a stage do not depend on which of
@@ -860,8 +864,8 @@ __global__ __launch_bounds__(256) void k_nfa_finish(uint8_t* __restrict__ ws, Ls
 // chip) walk the frame's rectangles stage after stage with a workgroup barrier in between.  18 dependent launches became one: the line
 // stream queues once behind the point branch's grids instead of 18 times, and a frame no longer waits at every stage for the slowest
 // frame of the batch -- only the kernel's one tail is left.  Results are those of the separate launches (same bodies, same order).
-template <bool WG1>
-__device__ __forceinline__ void nfa_all_body(uint8_t* __restrict__ base, const LsdPlan& P, const double* __restrict__ lgam, int wave, int nwaves, int lane, NfaLds& L) {
+template <bool WG1, int CH>
+__device__ __forceinline__ void nfa_all_body(uint8_t* __restrict__ base, const LsdPlan& P, const double* __restrict__ lgam, int wave, int nwaves, int lane, NfaLdsT<CH>& L) {
     const int nthreads = nwaves * 64;
 #pragma unroll 1
     for (int it = -1; it <= 4; ++it) {
@@ -870,11 +874,11 @@ __device__ __forceinline__ void nfa_all_body(uint8_t* __restrict__ base, const L
 #define NFA_OPAQUE() asm volatile("" : "+s"(base), "+s"(lgam), "+v"(lane))
         NFA_OPAQUE();
         if (it != 0) {                                   // stage 0's counts came with the initial evaluation's (nested tolerances, one pass)
-            nfa_count_body<WG1>(base, P, it < 0 ? 0 : it, wave, nwaves, lane, L.c);
+            nfa_count_body<WG1, CH>(base, P, it < 0 ? 0 : it, wave, nwaves, lane, L.c);
             __syncthreads();
         }
         NFA_OPAQUE();
-        nfa_eval_body<WG1>(base, P, it, lgam, wave, nwaves, lane, L.items);
+        nfa_eval_body<WG1, CH>(base, P, it, lgam, wave, nwaves, lane, L.items);
         __syncthreads();
         NFA_OPAQUE();
         nfa_accept_body(base, P, it, wave * 64 + lane, nthreads);
@@ -890,5 +894,18 @@ __device__ __forceinline__ void nfa_all_body(uint8_t* __restrict__ base, const L
 __global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_all(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
     __shared__ NfaLds L;
     const int b = xcd_mix_frame(blockIdx.x, gridDim.x);
-    nfa_all_body<true>(ws + (size_t)b * P.frameBytes, P, lgam, 0, 1, threadIdx.x, L);
+    nfa_all_body<true, EVAL_CH>(ws + (size_t)b * P.frameBytes, P, lgam, 0, 1, threadIdx.x, L);
+}
+
+// The same for calls of fewer frames than the chip has wave slots (the one-frame-at-a-time mode of Frame::ExtractLSD above all): ONE workgroup
+// of up to sixteen waves per frame walks the stages with workgroup barriers in between; each wave owns a share of the frame's rectangles and its
+// own LDS arrays.  One launch and sixteen barriers instead of 18 dependent launches of 64 / 16 waves (0.62 ms of a 6 ms frame were launch
+// boundaries and tails); a single workgroup needs no inter-workgroup barrier, hence no agent-scope fences (~7 us each) and no co-residency
+// requirement.  Dynamic LDS: blockDim.x / 64 x sizeof(NfaLdsT<WG_CH>).
+template <int MAXT>      // 1024: sixteen waves at 128 VGPRs each (the evaluator spills a little); 512: eight waves, no spills
+__global__ __launch_bounds__(MAXT) void k_nfa_all_wg(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
+    extern __shared__ __align__(16) unsigned char nfaDyn[];
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    NfaLdsT<WG_CH>* L = (NfaLdsT<WG_CH>*)nfaDyn + wave;
+    nfa_all_body<false, WG_CH>(ws + (size_t)blockIdx.x * P.frameBytes, P, lgam, wave, nwaves, threadIdx.x & 63, *L);
 }

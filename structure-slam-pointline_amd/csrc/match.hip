@@ -98,7 +98,7 @@ extern "C" int sslam_orb_search_for_initialization_batch_dev(sslam_ctx* ctx,
     A.kp1 = d_kp1; A.d1 = d_desc1; A.n1 = d_n1; A.kp2 = d_kp2; A.d2 = d_desc2; A.n2 = d_n2;
     A.cap = cap; A.n1s = 0; A.n2s = 0; A.prevMatched = d_prev; A.m12 = d_m12; A.nmatches = d_nm;
     A.scratch = ctx->scratch[3].as<int>(); A.window = window; A.nnratio = nnratio; A.checkOri = checkOri;
-    A.minX = bounds[0]; A.maxX = bounds[1]; A.minY = bounds[2]; A.maxY = bounds[3];
+    A.minX = bounds[0]; A.maxX = bounds[1]; A.minY = bounds[2]; A.maxY = bounds[3]; A.ccap = 0;
     // a handful of pairs (the single call of Tracking::MonocularInitialization): the LDS-resident kernel, as long as a pair fits the CU's LDS
     const size_t ldsNeed = 64 + (size_t)cap * 15 * 4 + (size_t)cap * 2 * 4;      // per candidate 15 words (14 + the stamp of the speculative form), per F1 keypoint 2
     const char* sfiForm = getenv("SSLAM_SFI_FORM");      // test / experiment knob: "global", "lds" (one wave), default: sixteen speculative waves
@@ -108,8 +108,19 @@ extern "C" int sslam_orb_search_for_initialization_batch_dev(sslam_ctx* ctx,
         sslam::ProfScope _ps(ctx, "k_search_init", pick(ctx, stream));
         if (oneWave) hipLaunchKernelGGL(k_search_init_lds, dim3(npairs), dim3(64), ldsNeed, pick(ctx, stream), A);
         else hipLaunchKernelGGL(k_search_init_spec, dim3(npairs), dim3(SFI_WAVES * 64), ldsNeed, pick(ctx, stream), A);
-    } else
-    { sslam::ProfScope _ps(ctx, "k_search_init", pick(ctx, stream)); hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(64), 0, pick(ctx, stream), A); }
+    } else {
+        // the batch: one wave per pair with the pair's level-0 features in LDS (capacity 3/8 of the rows, at least 256: the level-0 quota of an
+        // 8-level pyramid is 21.7 % of nfeatures; a pair beyond it takes the global-memory body inside the same launch).  SSLAM_SFI_BATCH=global: the round 1-3 kernel.
+        const int ccap = std::min(cap, std::max(256, cap * 3 / 8));
+        const size_t ldsB = 64 + (size_t)ccap * 16 * 4;
+        const char* bf = getenv("SSLAM_SFI_BATCH");
+        sslam::ProfScope _ps(ctx, "k_search_init", pick(ctx, stream));
+        if (ldsB <= 64 * 1024 && !(bf && bf[0] == 'g')) {
+            A.ccap = ccap;
+            if (ldsB > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_search_init_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
+            hipLaunchKernelGGL(k_search_init_lds, dim3(npairs), dim3(64), ldsB, pick(ctx, stream), A);
+        } else hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(64), 0, pick(ctx, stream), A);
+    }
     SSLAM_HIP(hipGetLastError());
     return SSLAM_OK;
 }

@@ -16,10 +16,11 @@ struct SfiArgs {
     int* scratch;                  // per pair: matchedDist[cap], m21[cap], cand[cap], key[cap], bin[cap]
     int window; float nnratio; int checkOri;
     float minX, maxX, minY, maxY;
+    int ccap;                      // k_search_init_lds: LDS capacity in level-0 candidates / level-0 keypoints of F1 (0: the pair's own counts)
 };
 
-__global__ __launch_bounds__(64) void k_search_init(SfiArgs A) {
-    const int p = xcd_mix_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;      // one wave per frame pair: see xcd_mix_frame
+// the pair's state in global memory (what a pair falls back to when its level-0 features do not fit the LDS capacity of the batch launch)
+__device__ __forceinline__ void sfi_global_body(const SfiArgs& A, int p, int lane, int* __restrict__ hist) {
     const int n1 = A.n1 ? A.n1[p] : A.n1s, n2 = A.n2 ? A.n2[p] : A.n2s;
     const sslam_keypoint* kp1 = A.kp1 + (size_t)p * A.cap;
     const sslam_keypoint* kp2 = A.kp2 + (size_t)p * A.cap;
@@ -32,7 +33,6 @@ __global__ __launch_bounds__(64) void k_search_init(SfiArgs A) {
     int* cand = m21 + A.cap;       // compact list of F2 level-0, in-grid keypoints
     int* ckey = cand + A.cap;      // their GetFeaturesInArea order key
     int* binOf = ckey + A.cap;     // rotation bin of i1 (or -1)
-    __shared__ int hist[HISTO_LENGTH];
 
     const float invW = __fdiv_rn((float)GRID_COLS, __fsub_rn(A.maxX, A.minX));
     const float invH = __fdiv_rn((float)GRID_ROWS, __fsub_rn(A.maxY, A.minY));
@@ -129,6 +129,11 @@ __global__ __launch_bounds__(64) void k_search_init(SfiArgs A) {
     if (lane == 0) A.nmatches[p] = nmatches;
 }
 
+__global__ __launch_bounds__(64) void k_search_init(SfiArgs A) {
+    __shared__ int hist[HISTO_LENGTH];
+    sfi_global_body(A, xcd_mix_frame(blockIdx.x, gridDim.x), threadIdx.x, hist);      // one wave per frame pair: see xcd_mix_frame
+}
+
 
 // Low-latency form for the single call (Tracking::MonocularInitialization hands over ONE frame pair and waits): the same sequential i1
 // loop, but everything an iteration touches lives in LDS -- the level-0 keypoints of F1 as a compact list, and per candidate of F2 its
@@ -138,23 +143,28 @@ __global__ __launch_bounds__(64) void k_search_init(SfiArgs A) {
 // dynamic LDS: per candidate 14 words (x, y, key, index, matchedDist, owner, 8 descriptor words) + per F1 keypoint 2 words (level-0 list, bin)
 __global__ __launch_bounds__(64) void k_search_init_lds(SfiArgs A) {
     extern __shared__ __align__(16) unsigned sfi[];
-    const int p = blockIdx.x, lane = threadIdx.x;
+    const int p = A.ccap > 0 ? xcd_mix_frame(blockIdx.x, gridDim.x) : blockIdx.x, lane = threadIdx.x;
     const int n1 = A.n1 ? A.n1[p] : A.n1s, n2 = A.n2 ? A.n2[p] : A.n2s;
+    // Round 4: also the batch form.  Only LEVEL-0 features enter the search (a fifth of a frame's keypoints), so the arrays are sized by a
+    // capacity in level-0 features chosen by the host (ccap; 0 = the pair's own counts, the single call) -- ~25 KB for 1000-keypoint frames, six
+    // pairs per compute unit -- and a pair that exceeds it takes the global-memory body.  The batch kernel before gathered every candidate's
+    // position, key, descriptor and matched distance from global memory for every query: 2.45 MB of HBM traffic per pair for 72 KB of inputs.
+    const int cc = A.ccap > 0 ? A.ccap : n2, lc = A.ccap > 0 ? A.ccap : n1;
     const sslam_keypoint* kp1 = A.kp1 + (size_t)p * A.cap;
     const sslam_keypoint* kp2 = A.kp2 + (size_t)p * A.cap;
     const uint8_t* d1 = A.d1 + (size_t)p * A.cap * 32;
     const uint8_t* d2 = A.d2 + (size_t)p * A.cap * 32;
     float* pm = A.prevMatched + (size_t)p * A.cap * 2;
     int* m12 = A.m12 + (size_t)p * A.cap;
-    uint4* cdesc = (uint4*)sfi;                              // [2 * n2]
-    float* cxs = (float*)(cdesc + 2 * (size_t)n2);            // [n2]
-    float* cys = cxs + n2;
-    int* ckey = (int*)(cys + n2);
-    int* cj = ckey + n2;
-    int* md = cj + n2;                                       // matched distance per candidate slot
-    int* owner = md + n2;                                    // m21 per candidate slot
-    int* list1 = owner + n2;                                 // level-0 keypoints of F1, ascending  [n1]
-    int* binOf = list1 + n1;                                 // rotation bin per F1 keypoint, -1   [n1]
+    uint4* cdesc = (uint4*)sfi;                              // [2 * cc]
+    float* cxs = (float*)(cdesc + 2 * (size_t)cc);            // [cc]
+    float* cys = cxs + cc;
+    int* ckey = (int*)(cys + cc);
+    int* cj = ckey + cc;
+    int* md = cj + cc;                                       // matched distance per candidate slot
+    int* owner = md + cc;                                    // m21 per candidate slot
+    int* list1 = owner + cc;                                 // level-0 keypoints of F1, ascending  [lc]
+    int* binOf = list1 + lc;                                 // rotation bin per entry of list1, -1  [lc]
     __shared__ int hist[HISTO_LENGTH];
     const float invW = __fdiv_rn((float)GRID_COLS, __fsub_rn(A.maxX, A.minX));
     const float invH = __fdiv_rn((float)GRID_ROWS, __fsub_rn(A.maxY, A.minY));
@@ -163,9 +173,9 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SfiArgs A) {
     for (int i0 = 0; i0 < n1; i0 += 64) {
         const int i = i0 + lane;
         const bool l0 = i < n1 && kp1[i].octave == 0;
-        if (i < n1) { m12[i] = -1; binOf[i] = -1; }
+        if (i < n1) m12[i] = -1;
         const unsigned long long m = __ballot(l0);
-        if (l0) list1[nl + mbcnt(m)] = i;
+        if (l0) { const int o = nl + mbcnt(m); if (o < lc) { list1[o] = i; binOf[o] = -1; } }
         nl += __popcll(m);
     }
     int nc = 0;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SfiArgs A) {
             cell = px * GRID_ROWS + py; x = k.x; y = k.y;
         }
         const unsigned long long m = __ballot(ok);
-        if (ok) {
+        if (ok && nc + mbcnt(m) < cc) {
             const int o = nc + mbcnt(m);
             cxs[o] = x; cys[o] = y; ckey[o] = (cell << 19) | o; cj[o] = j; md[o] = 0x7FFFFFFF; owner[o] = -1;
             const uint4* tp = (const uint4*)(d2 + (size_t)j * 32);
@@ -189,6 +199,7 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SfiArgs A) {
         nc += __popcll(m);
     }
     __syncthreads();
+    if (nl > lc || nc > cc) { sfi_global_body(A, p, lane, hist); return; }      // (wave-uniform) more level-0 features than the launch planned for
     int nmatches = 0;
     const float r = (float)A.window;
     uint4 q0n = make_uint4(0, 0, 0, 0), q1n = q0n; float cxn = 0, cyn = 0;
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SfiArgs A) {
                 if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
                 int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
                 if (bin == HISTO_LENGTH) bin = 0;
-                if (lane == 0) { binOf[i1] = bin; hist[bin]++; }
+                if (lane == 0) { binOf[t] = bin; hist[bin]++; }
             }
             __syncthreads();
         }
@@ -242,11 +253,11 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SfiArgs A) {
         if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
         int removed = 0;
-        for (int i0 = 0; i0 < n1; i0 += 64) {
-            const int i = i0 + lane;
+        for (int t0 = 0; t0 < nl; t0 += 64) {
+            const int t = t0 + lane;
             bool rm = false;
-            if (i < n1) {
-                const int bn = binOf[i];
+            if (t < nl) {
+                const int bn = binOf[t], i = list1[t];
                 rm = bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3 && m12[i] >= 0;
                 if (rm) m12[i] = -1;
             }

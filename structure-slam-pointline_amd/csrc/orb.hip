@@ -226,7 +226,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                                                    unsigned* __restrict__ cand, int* __restrict__ cellCount,
                                                    int iniTh, int minTh, int tileP, int scP) {
     extern __shared__ __align__(16) uint8_t lds[];
-    const int cellId = blockIdx.x, b = blockIdx.y;
+    // Round 4: which cell a workgroup takes follows the dispatch order.  Workgroups are dealt round-robin over the eight XCDs, so with
+    // cellId = blockIdx.x horizontally adjacent cells -- which share their 6-pixel overlap and the 128-byte lines both tiles straddle -- were
+    // fetched through eight different L2s (4.34 MB fetched per frame for 0.95 MB of pyramid, PMC).  Now the workgroups of one XCD
+    // (blockIdx.x % 8) walk one contiguous eighth of the frame's cell list, in order; which eighth rotates with the frame so that
+    // every XCD sees every pyramid level (the levels differ in corner density).  gridDim.x = 8 * ceil(nCells / 8).
+    const int b = blockIdx.y, per = gridDim.x >> 3;
+    const int cellId = (((blockIdx.x & 7) + b) & 7) * per + (blockIdx.x >> 3);
+    if (cellId >= P.nCellsFrame) return;
     const int lane = threadIdx.x;
     const CellInfo ci = cells[cellId];
     const LevelInfo& L = P.L[ci.level];
@@ -1071,7 +1078,7 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
     if (P.nCellsFrame > 0) {
         int tileP = (P.maxCellW + 6 + 3 + 7) & ~3, scP = P.maxCellW + 2;
         size_t lds = (size_t)(P.maxCellH + 6) * tileP + (((size_t)(P.maxCellH + 2) * scP + 3) & ~(size_t)3) + 3 * (size_t)P.maxCellH * P.maxCellW + 32;
-        dim3 grd(P.nCellsFrame, nframes);
+        dim3 grd(8 * ((P.nCellsFrame + 7) / 8), nframes);
         { sslam::ProfScope _ps(o->ctx, "k_fast_cells", st); hipLaunchKernelGGL(k_fast_cells, grd, dim3(64), lds, st, pyr, P.pyrFrame, P, o->dCells.as<CellInfo>(), o->dCand.as<unsigned>(),
                            o->dCellCount.as<int>(), o->iniTh, o->minTh, tileP, scP); }
     }

@@ -27,8 +27,14 @@ assert PQ_DTYPE.itemsize == 44
 _lib = None
 
 
+SSLAM_ERR_INVALID, SSLAM_ERR_NO_DEVICE, SSLAM_ERR_CAPACITY, SSLAM_ERR_HIP, SSLAM_ERR_UNSUPPORTED = -1, -2, -3, -4, -5      # include/sslam_frontend.h:31-35
+
+
 class SslamError(RuntimeError):
-    pass
+    """raised for every non-zero status of the C ABI; `code` is the status (SSLAM_ERR_*)"""
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 def lib():
@@ -46,7 +52,7 @@ def lib():
 def _chk(rc):
     if rc != 0:
         L = lib()
-        raise SslamError("%s: %s" % (L.sslam_status_str(rc).decode(), L.sslam_last_error().decode()))
+        raise SslamError("%s: %s" % (L.sslam_status_str(rc).decode(), L.sslam_last_error().decode()), rc)
 
 
 def _p(a):

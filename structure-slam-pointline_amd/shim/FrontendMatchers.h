@@ -61,6 +61,9 @@ int SearchByProjection(int mode, const std::vector<cv::KeyPoint> &keysUn, const 
                        std::vector<int> &assigned, long frameId = -1);
 // frameId >= 0 (Frame::mnId, include/Frame.h:128): the frame's features stay on the device between calls (a small cache in the shim), so the
 // retry of TrackWithMotionModel (src/Tracking.cc:1243) and SearchLocalPoints (:1736) on the same frame upload nothing but their queries.
+// The cache keys on (mnId, keypoint count, a fingerprint of a few keypoints and descriptor rows): ids repeat after Tracking::Reset()
+// (src/Tracking.cc:2150).  InvalidateResidentFrames() drops every resident frame -- one line for Tracking::Reset.
+void InvalidateResidentFrames();
 template <class T> auto FrameId(const T &f, int) -> decltype((long)f.mnId) { return (long)f.mnId; }
 template <class T> long FrameId(const T &, ...) { return -1; }
 int SearchLinesByProjection(const std::vector<cv::line_descriptor::KeyLine> &keylinesUn, const cv::Mat &ldesc,

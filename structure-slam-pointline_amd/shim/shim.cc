@@ -135,24 +135,47 @@ static_assert(sizeof(ProjQuery) == sizeof(sslam_proj_query), "ProjQuery layout")
 // `mLastFrame = Frame(mCurrentFrame)` share the id and the features.  The last few frames stay on the device, so the second and later
 // matcher calls on a frame (Tracking.cc:1227 and its retry :1243, :1736) skip the upload of ~60 KB of features.
 namespace {
-struct ResidentFrame { long id = -1; int kind = 0, n = 0; sslam_frame* h = nullptr; unsigned long stamp = 0; };
+// The key is (mnId, kind, n) AND a fingerprint of the features themselves: Tracking::Reset() sets Frame::nNextId back to 0
+// (src/Tracking.cc:2150), so ids repeat after every reset -- a post-reset frame with the id and keypoint count of a cached pre-reset frame
+// must not be matched against the old image's features.  InvalidateResidentFrames() drops everything (call it from Tracking::Reset; the
+// fingerprint makes forgetting that harmless).
+struct ResidentFrame { long id = -1; int kind = 0, n = 0; unsigned long long fp = 0; sslam_frame* h = nullptr; unsigned long stamp = 0; };
 ResidentFrame g_resident[4];
 unsigned long g_residentClock = 0;
 std::mutex g_residentMu;
-sslam_frame* resident_frame(long id, int kind, const void* feats, const uint8_t* desc, int n, const float* uright, const float bounds[4]) {
-    std::lock_guard<std::mutex> lk(g_residentMu);
+unsigned long long fnv1a(unsigned long long h, const void* p, size_t n) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+unsigned long long frame_fingerprint(const std::vector<cv::KeyPoint>& k, const cv::Mat& desc) {
+    unsigned long long h = 1469598103934665603ull;
+    const int n = (int)k.size();
+    h = fnv1a(h, &n, sizeof(n));
+    const int picks[5] = {0, n / 4, n / 2, (3 * n) / 4, n - 1};
+    for (int i : picks) if (i >= 0 && i < n) { h = fnv1a(h, &k[i], sizeof(cv::KeyPoint)); if (i < desc.rows) h = fnv1a(h, desc.ptr(i), 32); }
+    return h;
+}
+// g_residentMu must be held by the caller, from the lookup to the end of the search that uses the handle (another thread may evict the slot)
+sslam_frame* resident_frame_locked(long id, int kind, unsigned long long fp, const std::vector<cv::KeyPoint>& k, const cv::Mat& desc, const float* uright, const float bounds[4]) {
+    const int n = (int)k.size();
     ResidentFrame* victim = &g_resident[0];
     for (auto& r : g_resident) {
-        if (r.h && r.id == id && r.kind == kind && r.n == n) { r.stamp = ++g_residentClock; return r.h; }
+        if (r.h && r.id == id && r.kind == kind && r.n == n && r.fp == fp) { r.stamp = ++g_residentClock; return r.h; }
         if (r.stamp < victim->stamp) victim = &r;
     }
     if (victim->h) { sslam_frame_destroy(victim->h); victim->h = nullptr; }
+    const std::vector<uint8_t> a = rows32(desc);          // built on the miss path only
     sslam_frame* h = nullptr;
-    check(sslam_frame_upload(G.get(), kind, feats, desc, n, uright, bounds, &h));
-    victim->id = id; victim->kind = kind; victim->n = n; victim->h = h; victim->stamp = ++g_residentClock;
+    check(sslam_frame_upload(G.get(), kind, k.data(), a.data(), n, uright, bounds, &h));
+    victim->id = id; victim->kind = kind; victim->n = n; victim->fp = fp; victim->h = h; victim->stamp = ++g_residentClock;
     return h;
 }
 }  // namespace
+void InvalidateResidentFrames() {
+    std::lock_guard<std::mutex> lk(g_residentMu);
+    for (auto& r : g_resident) { if (r.h) sslam_frame_destroy(r.h); r = ResidentFrame(); }
+}
 int SearchByProjection(int mode, const std::vector<cv::KeyPoint> &k, const cv::Mat &desc, const float bounds[4], const std::vector<float> *uRight,
                        const std::vector<unsigned char> &occupied, const std::vector<ProjQuery> &queries, const cv::Mat &qd, float nnratio,
                        int thDist, bool checkOri, std::vector<int> &assigned, long frameId) {
@@ -161,14 +184,9 @@ int SearchByProjection(int mode, const std::vector<cv::KeyPoint> &k, const cv::M
     std::vector<uint8_t> b = rows32(qd);
     int n = 0;
     if (frameId >= 0) {
-        sslam_frame* fr = nullptr;
-        {
-            std::vector<uint8_t> a;      // only built when the frame is not resident yet: resident_frame() uploads at most once per frame
-            bool have = false;
-            { std::lock_guard<std::mutex> lk(g_residentMu); for (auto& r : g_resident) have = have || (r.h && r.id == frameId && r.kind == 0 && r.n == (int)k.size()); }
-            if (!have) a = rows32(desc);
-            fr = resident_frame(frameId, 0, k.data(), a.data(), (int)k.size(), uRight ? uRight->data() : nullptr, bounds);
-        }
+        const unsigned long long fp = frame_fingerprint(k, desc);
+        std::lock_guard<std::mutex> lk(g_residentMu);      // lookup, upload and search under one lock: the handle cannot be evicted in between
+        sslam_frame* fr = resident_frame_locked(frameId, 0, fp, k, desc, uRight ? uRight->data() : nullptr, bounds);
         check(sslam_search_by_projection_frame(G.get(), fr, mode, occupied.empty() ? nullptr : occupied.data(), (const sslam_proj_query*)queries.data(), b.data(),
                                                (int)queries.size(), nnratio, thDist, checkOri ? 1 : 0, assigned.data(), &n));
         return n;

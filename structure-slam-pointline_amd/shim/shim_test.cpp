@@ -220,6 +220,25 @@ int main(int argc, char** argv) {
         sslam_shim::ORBVocabulary bad;
         if (bad.loadFromTextFile(std::string(argv[8]) + ".missing") || !bad.empty()) return 4;
     }
+    {   // Frame ids repeat after Tracking::Reset() (src/Tracking.cc:2150 sets Frame::nNextId = 0): a second frame with the id AND the keypoint count of
+        // a frame whose features are resident must be matched against ITS features, not the cached ones (the cache keys on a fingerprint as well)
+        const int n = (int)std::min(k1.size(), k2.size());
+        if (n > 50) {
+            std::vector<cv::KeyPoint> ka(k2.begin(), k2.begin() + n), kb(k1.begin(), k1.begin() + n);
+            cv::Mat da(n, 32, CV_8U), db(n, 32, CV_8U);
+            for (int i = 0; i < n; ++i) { memcpy(da.ptr(i), d2.ptr(i), 32); memcpy(db.ptr(i), d1.ptr(i), 32); }
+            std::vector<sslam_shim::ProjQuery> q; cv::Mat qd(std::min(n, 200), 32, CV_8U);
+            for (int i = 0; i < qd.rows; ++i) { sslam_shim::ProjQuery e = {ka[i].pt.x + 1.f, ka[i].pt.y - 1.f, 0.f, 0.f, 12.f, 0, 7, ka[i].angle, -1.f, 1, 1}; q.push_back(e); memcpy(qd.ptr(i), da.ptr(i), 32); }
+            const float bounds[4] = {0.f, (float)w, 0.f, (float)h};
+            std::vector<unsigned char> occ; std::vector<int> ra, rb, rb0, rb2;
+            sslam_shim::SearchByProjection(0, ka, da, bounds, nullptr, occ, q, qd, 0.9f, 100, true, ra, 4711);       // uploads "frame 4711"
+            sslam_shim::SearchByProjection(0, kb, db, bounds, nullptr, occ, q, qd, 0.9f, 100, true, rb, 4711);       // another image under the same id and count
+            sslam_shim::SearchByProjection(0, kb, db, bounds, nullptr, occ, q, qd, 0.9f, 100, true, rb0, -1);        // the same call without the cache
+            sslam_shim::InvalidateResidentFrames();
+            sslam_shim::SearchByProjection(0, kb, db, bounds, nullptr, occ, q, qd, 0.9f, 100, true, rb2, 4711);
+            if (rb != rb0 || rb2 != rb0 || ra == rb0) { std::fprintf(stderr, "shim_test: a reused frame id was served from the resident-frame cache\n"); return 5; }
+        }
+    }
     int meta[8] = {(int)k2.size(), (int)l2.size(), nm, nlm, emptyOk, ext->GetLevels(), bestIdx, nWords};
     dump(out + "_meta.bin", meta, 8);
     std::printf("shim_test: %zu keypoints, %zu lines, %d ORB matches, %d line matches\n", k2.size(), l2.size(), nm, nlm);

@@ -1,5 +1,9 @@
 import os, sys
 import pytest
+try:                      # torch first: it ships its own HIP runtime, and a process that initialised the system one first (through the library under
+    import torch          # test) finds no device from torch afterwards ("No HIP GPUs are available"); the harness modules import torch at their top too
+except Exception:         # pragma: no cover
+    torch = None
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 

@@ -203,3 +203,14 @@ def test_lsd_multiwave_batch(fe, ctx, oracle, monkeypatch):
             np.testing.assert_array_equal(ex.debug_segments(i), oraw, err_msg="frame %d" % i)
     finally:
         ex.close()
+
+
+@pytest.mark.parametrize("knob", [("SSLAM_NFA_FUSED", "0"), ("SSLAM_NFA_FUSED", "2"), ("SSLAM_NFA_WAVES", "16"), ("SSLAM_NFA_WAVES", "8"), ("SSLAM_NFA_WAVES", "3")])
+def test_nfa_stage_launch_forms(fe, ctx, oracle, knob, monkeypatch):
+    """The NFA stage (rect_improve: count -> evaluate -> accept, five refinement stages) has three launch forms: 18 launches (rounds 1-3), one wave per
+    frame in one launch (k_nfa_all: batches that fill the chip) and one workgroup of up to sixteen waves per frame in one launch (k_nfa_all_wg: single
+    frames and small batches; <= 8 waves take the 512-thread instantiation).  Each against the oracle on frames whose rectangle counts differ by 10x,
+    including one with more rectangles per wave than a chunk of the workgroup form holds."""
+    monkeypatch.setenv(*knob)
+    for img, cap in [(synth_frame(2000), 200), (synth_frame(1235, w=1280, h=960), 400), (noise_frame(3, w=320, h=240), 200), (synth_frame(91, w=333, h=251), 40)]:
+        _cmp_lines(fe, ctx, oracle, img, cap)

@@ -89,6 +89,56 @@ def test_search_for_initialization_contention(fe, ctx, oracle, form, seed, monke
     np.testing.assert_array_equal(pmo, opm)
 
 
+@pytest.mark.parametrize("form", ["lds", "global"])
+def test_search_for_initialization_batch_forms(fe, ctx, oracle, form, monkeypatch):
+    """sslam_orb_search_for_initialization_batch_dev, more than eight pairs per call: one wave per pair with the pair's level-0 features staged
+    in LDS (round 4; capacity 3/8 of the rows), pairs with more level-0 features than that falling back to the global-memory body inside the
+    same launch, and the global-memory kernel of rounds 1-3 (SSLAM_SFI_BATCH=global).  Every pair against the oracle."""
+    import ctypes as C, torch
+    if form == "global": monkeypatch.setenv("SSLAM_SFI_BATCH", "global")
+    rng = np.random.default_rng(99)
+    P, cap = 13, 700
+    kp1 = np.zeros((P, cap), fe.KP_DTYPE); kp2 = np.zeros((P, cap), fe.KP_DTYPE)
+    d1 = np.zeros((P, cap, 32), np.uint8); d2 = np.zeros((P, cap, 32), np.uint8)
+    n1 = np.zeros(P, np.int32); n2 = np.zeros(P, np.int32)
+    for p in range(P):
+        a, b = int(rng.integers(50, cap + 1)), int(rng.integers(50, cap + 1))
+        if p == 3: a = b = 0                                    # an empty pair
+        if p == 5: a = cap                                      # rows full
+        lvl0 = [0.2, 0.2, 0.2, 0.2, 0.9, 1.0, 0.2, 0.45, 0.2, 0.2, 1.0, 0.2, 0.05][p]      # pairs 4, 5, 7, 10: more level-0 features than the LDS capacity (262)
+        kp2[p, :b]["x"] = rng.uniform(5, 635, b); kp2[p, :b]["y"] = rng.uniform(5, 475, b); kp2[p, :b]["octave"] = (rng.random(b) >= lvl0).astype(np.int32) * rng.integers(1, 8, b)
+        kp2[p, :b]["angle"] = rng.uniform(0, 360, b); d2[p, :b] = _rand_desc(rng, b)
+        src = rng.integers(0, max(b, 1), a)
+        kp1[p, :a]["x"] = kp2[p, src]["x"] + rng.uniform(-4, 4, a) if b else 0; kp1[p, :a]["y"] = kp2[p, src]["y"] + rng.uniform(-4, 4, a) if b else 0
+        kp1[p, :a]["octave"] = (rng.random(a) >= lvl0).astype(np.int32) * rng.integers(1, 8, a)
+        kp1[p, :a]["angle"] = (kp2[p, src]["angle"] + rng.normal(0, 10, a)) % 360 if b else 0
+        if b:
+            d1[p, :a] = d2[p, src]
+            flips = rng.integers(0, 256, (a, 20)); on = rng.random((a, 20)) < 0.6
+            for i in range(a):
+                for bit in flips[i][on[i]]: d1[p, i, bit >> 3] ^= np.uint8(1 << (bit & 7))
+        n1[p], n2[p] = a, b
+    pm = np.stack([kp1["x"], kp1["y"]], axis=2).astype(np.float32)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    g = dict(kp1=t(kp1.view(np.uint8)), d1=t(d1), n1=t(n1), kp2=t(kp2.view(np.uint8)), d2=t(d2), n2=t(n2), pm=t(pm))
+    m12 = torch.full((P, cap), -7, dtype=torch.int32, device="cuda"); nm = torch.zeros(P, dtype=torch.int32, device="cuda")
+    _p = lambda x: C.c_void_p(x.data_ptr())
+    bounds = (C.c_float * 4)(0.0, 640.0, 0.0, 480.0)
+    rc = fe.lib().sslam_orb_search_for_initialization_batch_dev(ctx.h, _p(g["kp1"]), _p(g["d1"]), _p(g["n1"]), _p(g["kp2"]), _p(g["d2"]), _p(g["n2"]), cap, P, _p(g["pm"]), _p(m12), _p(nm),
+                                                                100, C.c_float(0.9), 1, bounds, C.c_void_p(0))
+    assert rc == 0, fe.lib().sslam_last_error()
+    ctx.synchronize()
+    m12 = m12.cpu().numpy(); nm = nm.cpu().numpy(); pmo = g["pm"].cpu().numpy()
+    total = 0
+    for p in range(P):
+        a, b = int(n1[p]), int(n2[p])
+        om12, opm, on = oracle.search_for_initialization(kp1[p, :a], d1[p, :a], kp2[p, :b], d2[p, :b], pm[p, :a], 100, 0.9, True)
+        assert nm[p] == on, (p, nm[p], on)
+        np.testing.assert_array_equal(m12[p, :a], om12, err_msg="pair %d" % p); np.testing.assert_array_equal(pmo[p, :a], opm, err_msg="pair %d" % p)
+        total += on
+    assert total > 300
+
+
 @pytest.mark.parametrize("n1,n2,ratio", [(40, 40, False), (200, 187, False), (400, 400, True), (1, 2, False), (5, 1, False), (0, 9, False)])
 def test_line_match(ctx, oracle, n1, n2, ratio):
     rng = np.random.default_rng(n1 * 31 + n2)
