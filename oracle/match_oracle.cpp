@@ -1,9 +1,13 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see cvleaf.h header).
-// PINNED (round 4, `make -C oracle/ref_pin pin-stub`, oracle/ref_pin/compare_slices.py): the reference's own bodies of DescriptorDistance,
-// ComputeThreeMaxima, SearchForInitialization, AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea / GetLinesInArea, lineDescriptorMAD and
-// LSDmatcher::SerachForInitialize -- cut by line range and compiled here -- return what this file's restatements return on the same arrays.
-// The projection / BoW / Fuse / Sim3 / triangulation restatements below are NOT pinned that way (their reference bodies need MapPoint /
-// KeyFrame / DBoW2), nor is cv::BFMatcher::knnMatch's tie-break (OpenCV leaf).
+// PINNED (round 4, `make -C oracle/ref_pin pin-stub`, oracle/ref_pin/compare_slices.py): the reference's own bodies -- cut by line range out of
+// src/ORBmatcher.cc, src/LSDmatcher.cpp, src/Frame.cc, src/ExtractLineSegment.cpp and compiled here against stand-in Frame / KeyFrame / MapPoint /
+// MapLine types (and the reference's own vendored DBoW2::FeatureVector) -- return what this file's restatements return on the same arrays:
+// DescriptorDistance, ComputeThreeMaxima, SearchForInitialization, AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea / GetLinesInArea,
+// lineDescriptorMAD, LSDmatcher::SerachForInitialize, ORBmatcher::SearchByProjection(F, MapPoints) and (Cur, Last, th, bMono),
+// LSDmatcher::SearchByProjection(F, MapLines) and (Cur, Last, th, bMono), ORBmatcher::SearchByBoW(KF, F) and (KF, KF), and the
+// orchestration of LineSegment::ExtractLineSegment.  NOT pinned that way: Fuse / SearchBySim3 / SearchForTriangulation / the relocalisation and
+// loop-closing projection overloads (restated below from the source, compared with the HIP library only), and the OpenCV leaves
+// (cv::BFMatcher::knnMatch's tie-break, cv::gemm's accumulation order in the pose algebra of the (Cur, Last) calls).
 //
 // CPU restatement of the reference's Hamming matchers on the hot path:
 //   ORBmatcher::DescriptorDistance      src/ORBmatcher.cc:1650-1666

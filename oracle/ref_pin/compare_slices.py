@@ -96,5 +96,184 @@ for name in ("synth1234", "synth2000", "big1235"):
         eq = nr == len(po) and np.array_equal(pr[:nr], po) and mad.value == omad and mad12.value == omad12
         note("LSDmatcher::SerachForInitialize %s %dx%d" % (name, n1, n2), eq, pairs=int(nr), nn_mad=mad.value, nn12_mad=mad12.value)
 
+# --- the tracking thread's projection matchers (src/ORBmatcher.cc:45-137, 1331-1473; src/LSDmatcher.cpp:22-141, 185-255) ---------------------
+# The reference bodies run on stand-in Frame / MapPoint / MapLine objects (stub_slam.h); the oracle's restatement takes the QUERIES the reference's
+# projection loops form, so they are formed here the way shim/ORBmatcher.h / LSDmatcher.h form them (float32, the reference's operation order).
+import importlib.util
+spec = importlib.util.spec_from_file_location("sslam_frontend_types", os.path.join(HERE, "..", "..", "structure-slam-pointline_amd", "frontend.py"))
+fe = importlib.util.module_from_spec(spec); spec.loader.exec_module(fe)      # dtypes only (PQ_DTYPE): nothing of the HIP library is loaded
+f32 = np.float32
+MP = np.dtype([("inView", "<i4"), ("bad", "<i4"), ("level", "<i4"), ("nObs", "<i4"), ("viewCos", "<f4"), ("projX", "<f4"), ("projY", "<f4"), ("projXR", "<f4")])
+ML = np.dtype([("inView", "<i4"), ("bad", "<i4"), ("level", "<i4"), ("nObs", "<i4"), ("viewCos", "<f4"), ("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4")])
+sc = [f32(1.0)]
+for _ in range(7): sc.append(f32(sc[-1] * f32(1.2)))
+scale8 = np.array(sc, np.float32)
+
+
+def decode(assigned, owner, state):
+    """oracle `assigned` (query index, -1 untouched, -2 matched then pruned) -> the reference side's encoding"""
+    return np.array([owner[a] if a >= 0 else -1 if a == -2 else (-2 if state[i] == 1 else -3 if state[i] == 2 else -1) for i, a in enumerate(assigned)], np.int32)
+
+
+for name in ("synth1234", "synth2000", "big1235"):
+    img, (kp1, d1), (kp2, d2) = frames[name]
+    h, w = img.shape; bounds = (0.0, float(w), 0.0, float(h)); bb = np.array(bounds, np.float32)
+    n1, n2 = len(kp1), len(kp2)
+    state2 = rng.choice([0, 0, 0, 1, 2], n2).astype(np.uint8)
+    for stereo in (False, True):
+        ur2 = np.where(rng.random(n2) < 0.5, kp2["x"] - rng.uniform(2, 40, n2), -1).astype(np.float32) if stereo else np.full(n2, -1, np.float32)
+        # -- SearchByProjection(F, vpMapPoints, th): Tracking::SearchLocalPoints (th = 1, 3 or 5)
+        for th in (1.0, 3.0, 5.0):
+            mp = np.zeros(n1, MP)
+            mp["inView"] = rng.random(n1) < 0.85; mp["bad"] = rng.random(n1) < 0.05; mp["level"] = kp1["octave"]; mp["nObs"] = rng.integers(0, 3, n1)
+            mp["viewCos"] = np.where(rng.random(n1) < 0.5, 0.9995, 0.97); mp["projX"] = kp1["x"] + rng.uniform(-3, 3, n1); mp["projY"] = kp1["y"] + rng.uniform(-3, 3, n1)
+            mp["projXR"] = mp["projX"] - rng.uniform(2, 40, n1)
+            out_r = np.zeros(n2, np.int32)
+            nr = R.ref_search_by_projection_mappoints(_p(kp2), _p(d2), n2, _p(bb), _p(scale8), _p(ur2), _p(state2), _p(mp), _p(d1), n1, C.c_float(th), C.c_float(0.8), _p(out_r))
+            q = np.zeros(n1, fe.PQ_DTYPE)
+            for i in range(n1):
+                r0 = f32(2.5) if mp["viewCos"][i] > f32(0.998) else f32(4.0)
+                if th != 1.0: r0 = f32(r0 * f32(th))
+                lv = int(mp["level"][i])
+                q[i] = (mp["projX"][i], mp["projY"][i], 0, 0, f32(r0 * sc[lv]), lv - 1, lv, 0.0, mp["projXR"][i], int(mp["inView"][i] and not mp["bad"][i]), int(mp["nObs"][i] > 0))
+            a, no = orc.search_by_projection(0, 0, kp2, d2, q, d1, occupied=(state2 == 1).astype(np.uint8), uright=ur2, nnratio=0.8, th_dist=100, check_orientation=False, bounds=bounds)[:2]
+            note("ORBmatcher::SearchByProjection(F, MapPoints) %s th=%g stereo=%d" % (name, th, stereo), nr == no and np.array_equal(out_r, decode(a, list(range(n1)), state2)), matches=int(nr))
+    # -- SearchByProjection(CurrentFrame, LastFrame, th, bMono): poses, intrinsics, world points behind the last frame's keypoints
+    cz, sz = f32(0.99995), f32(0.0099998)
+    TL = np.eye(4, dtype=np.float32)
+    for pose, (tz, mb) in enumerate([(-0.05, 0.01), (0.06, 0.01), (0.002, 0.05)]):       # forward / backward / neither (when not mono)
+        TC = np.array([[cz, -sz, 0, 0.012], [sz, cz, 0, -0.007], [0, 0, 1, tz], [0, 0, 0, 1]], np.float32)
+        cam = np.array([520.9 * w / 640, 521.0 * h / 480, 325.1 * w / 640, 249.7 * h / 480, 40.0, mb], np.float32)
+        fx, fy, cx, cy, mbf, mbv = (f32(v) for v in cam)
+        z = (2.0 + 0.35 * (np.arange(n1) % 7)).astype(np.float32)
+        wp = np.stack([(kp1["x"] - cx) / fx * z, (kp1["y"] - cy) / fy * z, np.where(np.arange(n1) % 61 == 0, -z, z)], 1).astype(np.float32)
+        has1 = (rng.random(n1) < 0.75).astype(np.uint8); out1 = (rng.random(n1) < 0.1).astype(np.uint8); nobs1 = rng.integers(0, 3, n1).astype(np.int32)
+
+        def rx_plus_t(T, x):
+            return [f32(f32(f32(f32(T[r, 0] * x[0]) + f32(T[r, 1] * x[1])) + f32(T[r, 2] * x[2])) + T[r, 3]) for r in range(3)]
+        twc = [f32(f32(f32(f32(-TC[0, r]) * TC[0, 3]) + f32(f32(-TC[1, r]) * TC[1, 3])) + f32(f32(-TC[2, r]) * TC[2, 3])) for r in range(3)]
+        tlc = rx_plus_t(TL, twc)
+        for bMono in (True, False):
+            fwd = bool(tlc[2] > mbv) and not bMono; bwd = bool(-tlc[2] > mbv) and not bMono
+            lev = lambda o: (o, -1) if fwd else (0, o) if bwd else (o - 1, o + 1)
+            ur2 = np.full(n2, -1, np.float32) if bMono else np.where(rng.random(n2) < 0.5, kp2["x"] - rng.uniform(2, 40, n2), -1).astype(np.float32)
+            th = 15.0 if bMono else 7.0
+            out_r = np.zeros(n2, np.int32)
+            nr = R.ref_track_points(_p(kp1), _p(d1), n1, _p(has1), _p(out1), _p(nobs1), _p(wp), _p(kp2), _p(d2), n2, _p(state2), _p(ur2), _p(bb), _p(scale8),
+                                    _p(cam), _p(TL), _p(TC), C.c_float(th), int(bMono), C.c_float(0.9), _p(out_r))
+            q = []; qd = []; owner = []
+            for i in range(n1):
+                if not has1[i] or out1[i]: continue
+                xc, yc, zc = rx_plus_t(TC, wp[i])
+                invzc = f32(1.0 / np.float64(zc))
+                if invzc < 0: continue
+                u = f32(f32(f32(fx * xc) * invzc) + cx); v = f32(f32(f32(fy * yc) * invzc) + cy)
+                if u < 0 or u > f32(w) or v < 0 or v > f32(h): continue
+                o = int(kp1["octave"][i]); lo, hi = lev(o)
+                q.append((u, v, 0, 0, f32(f32(th) * sc[o]), lo, hi, f32(kp1["angle"][i]), f32(u - f32(mbf * invzc)), 1, int(nobs1[i] > 0))); qd.append(d1[i]); owner.append(i)
+            a, no = orc.search_by_projection(0, 1, kp2, d2, np.array(q, fe.PQ_DTYPE), np.stack(qd), occupied=(state2 == 1).astype(np.uint8), uright=ur2, nnratio=0.9, th_dist=100,
+                                             check_orientation=True, bounds=bounds)[:2]
+            note("ORBmatcher::SearchByProjection(Cur, Last) %s pose=%d mono=%d" % (name, pose, bMono), nr == no and np.array_equal(out_r, decode(a, owner, state2)),
+                 matches=int(nr), queries=len(q), pruned=int((a == -2).sum()), fwd=fwd, bwd=bwd)
+            # -- the line twin (src/LSDmatcher.cpp:22-141)
+            kl1, ld1 = orc.lines_extract(warp_prev(img), 200)[:2]; kl2, ld2 = orc.lines_extract(img, 200)[:2]
+            nl1, nl2 = len(kl1), len(kl2)
+            zl = 2.5 + 0.4 * (np.arange(nl1) % 5)
+            wl = np.stack([(kl1["startPointX"] - cx) / fx * zl, (kl1["startPointY"] - cy) / fy * zl, np.where(np.arange(nl1) % 17 == 3, -zl, zl),
+                           (kl1["endPointX"] - cx) / fx * zl, (kl1["endPointY"] - cy) / fy * zl, zl], 1).astype(np.float64)
+            hasl = (rng.random(nl1) < 0.8).astype(np.uint8); badl = (rng.random(nl1) < 0.08).astype(np.uint8); outl = (rng.random(nl1) < 0.1).astype(np.uint8)
+            nobsl = rng.integers(0, 3, nl1).astype(np.int32); statel = rng.choice([0, 0, 1, 2], nl2).astype(np.uint8)
+            out_l = np.zeros(nl2, np.int32)
+            nrl = R.ref_track_lines(_p(kp1), n1, _p(kl1), _p(ld1), nl1, _p(hasl), _p(badl), _p(outl), _p(nobsl), _p(wl), _p(kl2), _p(ld2), nl2, _p(statel), _p(bb), _p(scale8),
+                                    _p(cam), _p(TL), _p(TC), C.c_float(th), int(bMono), C.c_float(0.6), _p(out_l))
+            q = []; qd = []; owner = []
+            for i in range(nl1):
+                if not hasl[i] or badl[i] or outl[i]: continue
+                s3 = rx_plus_t(TC, [f32(wl[i, k]) for k in range(3)]); e3 = rx_plus_t(TC, [f32(wl[i, 3 + k]) for k in range(3)])
+                if s3[2] < 0 or e3[2] < 0: continue
+                iz1 = f32(f32(1.0) / s3[2]); u1 = f32(f32(f32(fx * s3[0]) * iz1) + cx); v1 = f32(f32(f32(fy * s3[1]) * iz1) + cy)
+                if u1 < 0 or u1 > f32(w) or v1 < 0 or v1 > f32(h): continue
+                iz2 = f32(f32(1.0) / e3[2]); u2 = f32(f32(f32(fx * e3[0]) * iz2) + cx); v2 = f32(f32(f32(fy * e3[1]) * iz2) + cy)
+                if u2 < 0 or u2 > f32(w) or v2 < 0 or v2 > f32(h): continue
+                o = int(kp1["octave"][i]); lo, hi = lev(o)
+                q.append((u1, v1, u2, v2, f32(f32(th) * sc[o]), lo, hi, 0.0, 0.0, 1, int(nobsl[i] > 0))); qd.append(ld1[i]); owner.append(i)
+            if q:
+                a, nol = orc.search_by_projection(1, 0, kl2, ld2, np.array(q, fe.PQ_DTYPE), np.stack(qd), occupied=(statel == 1).astype(np.uint8), uright=None, nnratio=0.6, th_dist=100,
+                                                  check_orientation=False, bounds=bounds)[:2]
+                exp = decode(a, owner, statel)
+            else:
+                nol, exp = 0, decode(np.full(nl2, -1), owner, statel)
+            note("LSDmatcher::SearchByProjection(Cur, Last) %s pose=%d mono=%d" % (name, pose, bMono), nrl == nol and np.array_equal(out_l, exp), matches=int(nrl), queries=len(q))
+    # -- LSDmatcher::SearchByProjection(F, vpMapLines, th)
+    kl1, ld1 = orc.lines_extract(warp_prev(img), 200)[:2]; kl2, ld2 = orc.lines_extract(img, 200)[:2]
+    nl1, nl2 = len(kl1), len(kl2)
+    statel = rng.choice([0, 0, 1, 2], nl2).astype(np.uint8)
+    for th in (1.0, 3.0):
+        ml = np.zeros(nl1, ML)
+        ml["inView"] = rng.random(nl1) < 0.85; ml["bad"] = rng.random(nl1) < 0.05; ml["level"] = rng.integers(0, 3, nl1); ml["nObs"] = rng.integers(0, 3, nl1)
+        ml["viewCos"] = np.where(rng.random(nl1) < 0.5, 0.9995, 0.97)
+        ml["x1"] = kl1["startPointX"] + 2; ml["y1"] = kl1["startPointY"] - 1; ml["x2"] = kl1["endPointX"] + 2; ml["y2"] = kl1["endPointY"] - 1
+        out_l = np.zeros(nl2, np.int32)
+        nrl = R.ref_line_search_by_projection_maplines(_p(kl2), _p(ld2), nl2, _p(scale8), _p(statel), _p(ml), _p(ld1), nl1, C.c_float(th), C.c_float(0.6), _p(out_l))
+        q = np.zeros(nl1, fe.PQ_DTYPE)
+        for i in range(nl1):
+            r0 = f32(5.0) if ml["viewCos"][i] > f32(0.998) else f32(8.0)
+            if th != 1.0: r0 = f32(r0 * f32(th))
+            lv = int(ml["level"][i])
+            q[i] = (ml["x1"][i], ml["y1"][i], ml["x2"][i], ml["y2"][i], f32(r0 * sc[lv]), lv - 1, lv, 0.0, 0.0, int(ml["inView"][i] and not ml["bad"][i]), int(ml["nObs"][i] > 0))
+        a, nol = orc.search_by_projection(1, 0, kl2, ld2, q, ld1, occupied=(statel == 1).astype(np.uint8), uright=None, nnratio=0.6, th_dist=100, check_orientation=False, bounds=bounds)[:2]
+        note("LSDmatcher::SearchByProjection(F, MapLines) %s th=%g" % (name, th), nrl == nol and np.array_equal(out_l, decode(a, list(range(nl1)), statel)), matches=int(nrl))
+
+# --- SearchByBoW (src/ORBmatcher.cc:159-291, 525-658): the reference walks two DBoW2::FeatureVector maps (its own vendored class, compiled here);
+# the oracle takes the shared nodes as CSR lists, which is what the walk with its lower_bound jumps visits
+def shared_csr(nodeA, nodeB):
+    ptrA, ptrB, idxA, idxB = [0], [0], [], []
+    for nd in sorted(set(nodeA.tolist()) & set(nodeB.tolist())):
+        idxA += np.nonzero(nodeA == nd)[0].tolist(); idxB += np.nonzero(nodeB == nd)[0].tolist()
+        ptrA.append(len(idxA)); ptrB.append(len(idxB))
+    return np.array(ptrA, np.int32), np.array(ptrB, np.int32), np.array(idxA, np.int32), np.array(idxB, np.int32)
+
+
+for name in ("synth1234", "synth2000", "noise7"):
+    img, (kp1, d1), (kp2, d2) = frames[name]
+    n1, n2 = len(kp1), len(kp2)
+    # nodes: nearby keypoints share a node (a coarse position hash plays the vocabulary), plus nodes that exist on one side only
+    node1 = ((kp1["x"] // 80).astype(np.int32) * 16 + (kp1["y"] // 80).astype(np.int32)) * 3; node2 = ((kp2["x"] // 80).astype(np.int32) * 16 + (kp2["y"] // 80).astype(np.int32)) * 3
+    node1 = np.where(rng.random(n1) < 0.1, node1 + 1, node1).astype(np.int32); node2 = np.where(rng.random(n2) < 0.1, node2 + 2, node2).astype(np.int32)
+    valid1 = rng.choice([0, 1, 1, 1, 2], n1).astype(np.uint8); valid2 = rng.choice([0, 1, 1, 1, 2], n2).astype(np.uint8)
+    pk, pf, ik, if_ = shared_csr(node1, node2)
+    for ratio, ori in [(0.7, True), (0.9, False)]:
+        out_r = np.zeros(n2, np.int32)
+        nr = R.ref_search_by_bow(_p(kp1), _p(d1), n1, _p(node1), _p(valid1), _p(kp2), _p(d2), n2, _p(node2), C.c_float(ratio), int(ori), _p(out_r))
+        a, no = orc.search_by_bow(kp1, d1, (valid1 == 1).astype(np.uint8), kp2, d2, pk, pf, ik, if_, ratio, ori)
+        note("ORBmatcher::SearchByBoW(KF, F) %s r=%.1f ori=%d" % (name, ratio, ori), nr == no and np.array_equal(out_r, a), matches=int(nr), shared_nodes=len(pk) - 1)
+        m_r = np.zeros(n1, np.int32)
+        nr = R.ref_search_by_bow_keyframes(_p(kp1), _p(d1), n1, _p(node1), _p(valid1), _p(kp2), _p(d2), n2, _p(node2), _p(valid2), C.c_float(ratio), int(ori), _p(m_r))
+        m_o, no = orc.search_by_bow_keyframes(kp1, d1, (valid1 == 1).astype(np.uint8), kp2, d2, (valid2 == 1).astype(np.uint8), pk, pf, ik, if_, ratio, ori)
+        note("ORBmatcher::SearchByBoW(KF, KF) %s r=%.1f ori=%d" % (name, ratio, ori), nr == no and np.array_equal(m_r, m_o), matches=int(nr))
+
+# --- LineSegment::ExtractLineSegment (src/ExtractLineSegment.cpp:18-69) over stand-in LSDDetector / BinaryDescriptor classes that forward to the oracle's
+# LSD / LBD: the reference's own orchestration -- cap of 40, std::sort by response (UNSTABLE: decision D3 of the oracle is a stable sort), class ids,
+# Eigen cross product for the line equations.  Lines are compared as records; an order that differs only among equal responses is D3's error bar.
+from oracle_lib import KL_DTYPE
+d3 = {"fixtures": 0, "lines": 0, "fixtures_with_another_order": 0, "lines_at_another_rank": 0, "fixtures_with_another_set": 0}
+for name, img in [("synth1234", frames["synth1234"][0]), ("synth2000", frames["synth2000"][0]), ("big1235", frames["big1235"][0]), ("icl", np.load(os.path.join(HERE, "..", "..", "tests", "golden", "icl_input_gray.npz"))["gray"]),
+                  ("noise3", noise_frame(3, w=320, h=240)), ("synth91", synth_frame(91, w=333, h=251)), ("synth2001", synth_frame(2001)), ("synth2002", synth_frame(2002)), ("few", synth_frame(5, nshapes=3, nstrokes=2))]:
+    img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+    kl = np.zeros(64, KL_DTYPE); ld = np.zeros((64, 32), np.uint8); fn = np.zeros((64, 3), np.float64)
+    n = R.ref_extract_line_segment(_p(img), w, h, _p(kl), _p(ld), _p(fn), 64)
+    okl, old, ofn, _ = orc.lines_extract(img, 40)
+    kl, ld, fn = kl[:n], ld[:n], fn[:n]
+    same = n == len(okl) and np.array_equal(kl.view(np.uint8), okl.view(np.uint8)) and np.array_equal(ld, old) and np.array_equal(fn, ofn)
+    # up to the order among equal responses: compare as sets of (record without class_id, descriptor, equation)
+    key = lambda K, D, F: sorted((bytes(np.concatenate([K[i:i + 1].view(np.uint8)[:4], K[i:i + 1].view(np.uint8)[8:]])) + D[i].tobytes() + F[i].tobytes()) for i in range(len(K)))
+    same_set = n == len(okl) and key(kl, ld, fn) == key(okl, old, ofn)
+    moved = int(sum(1 for i in range(min(n, len(okl))) if kl[i:i + 1].view(np.uint8)[8:].tobytes() != okl[i:i + 1].view(np.uint8)[8:].tobytes()))
+    d3["fixtures"] += 1; d3["lines"] += int(n); d3["fixtures_with_another_order"] += int(not same and same_set); d3["lines_at_another_rank"] += 0 if same else moved
+    d3["fixtures_with_another_set"] += int(not same_set)
+    note("LineSegment::ExtractLineSegment %s" % name, same_set, lines=int(n), identical_order=bool(same), lines_at_another_rank=0 if same else moved)
+report["d3_error_bar"] = d3
+print("D3 (std::sort vs stable sort of the 40 strongest lines):", d3)
+
 json.dump(report, open(report_path, "w"), indent=1)
 print("reference slices == oracle on every case:", report["all_equal"])

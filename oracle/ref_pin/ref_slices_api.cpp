@@ -16,6 +16,23 @@ static void fill_frame(Frame& F, const cv::KeyPoint* kp, const uint8_t* desc, in
     F.AssignFeaturesToGrid();
 }
 
+// ---- the tracking thread's projection matchers (round 4): src/ORBmatcher.cc:45-137, 1331-1473; src/LSDmatcher.cpp:22-141, 185-255 ----
+// state[i] of a frame feature: 0 = holds nothing, 1 = holds a map point / line with observations, 2 = holds one without
+// (src/ORBmatcher.cc:89-91: only the first kind is skipped).  assigned[i]: >= 0 the map point / line matched to feature i, -1 NULL after the
+// call, -2 / -3 still the occupant it had before (with / without observations).
+struct MpIn { int inView, bad, level, nObs; float viewCos, projX, projY, projXR; };
+struct MlIn { int inView, bad, level, nObs; float viewCos, x1, y1, x2, y2; };
+static void set_frame_common(Frame& F, const cv::KeyPoint* kp, const uint8_t* desc, int n, const float* bounds, const float* scale8, const float* uright) {
+    fill_frame(F, kp, desc, n, bounds);
+    F.mvKeys.assign(kp, kp + n); F.mvScaleFactors.assign(scale8, scale8 + 8); F.mvuRight.assign(n, -1.f);
+    if (uright) F.mvuRight.assign(uright, uright + n);
+}
+template <class T> static void encode(const std::vector<T*>& now, const std::vector<T>& pool, const std::vector<T>& occ, int32_t* assigned) {
+    for (size_t i = 0; i < now.size(); ++i) {
+        const T* p = now[i];
+        assigned[i] = !p ? -1 : p == &occ[0] ? -2 : p == &occ[1] ? -3 : (int32_t)(p - pool.data());
+    }
+}
 extern "C" {
 int ref_descriptor_distance(const uint8_t* a, const uint8_t* b) {
     cv::Mat A(1, 32, CV_8UC1, (void*)a), B(1, 32, CV_8UC1, (void*)b);
@@ -59,5 +76,134 @@ int ref_line_search_for_initialize(const uint8_t* l1, int n1, const uint8_t* l2,
         B->lineDescriptorMAD(k, *nn_mad, *nn12_mad);
     }
     delete A; delete B; return n;
+}
+
+int ref_search_by_projection_mappoints(const cv::KeyPoint* kp, const uint8_t* desc, int n, const float* bounds, const float* scale8, const float* uright, const uint8_t* state,
+                                       const MpIn* mp, const uint8_t* mpDesc, int nmp, float th, float nnratio, int32_t* assigned) {
+    Frame* F = new Frame(); set_frame_common(*F, kp, desc, n, bounds, scale8, uright);
+    std::vector<StructureSLAM::MapPoint> pool(nmp), occ(2); occ[0].nObs = 1; occ[1].nObs = 0;
+    std::vector<StructureSLAM::MapPoint*> vp(nmp);
+    for (int i = 0; i < nmp; ++i) {
+        StructureSLAM::MapPoint& q = pool[i];
+        q.mbTrackInView = mp[i].inView != 0; q.bad = mp[i].bad != 0; q.mnTrackScaleLevel = mp[i].level; q.nObs = mp[i].nObs; q.mTrackViewCos = mp[i].viewCos;
+        q.mTrackProjX = mp[i].projX; q.mTrackProjY = mp[i].projY; q.mTrackProjXR = mp[i].projXR; q.desc = cv::Mat(1, 32, CV_8UC1, (void*)(mpDesc + (size_t)i * 32));
+        vp[i] = &q;
+    }
+    F->mvpMapPoints.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) if (state[i]) F->mvpMapPoints[i] = &occ[state[i] - 1];
+    StructureSLAM::ORBmatcher m(nnratio, true);
+    const int r = m.SearchByProjection(*F, vp, th);
+    encode(F->mvpMapPoints, pool, occ, assigned);
+    delete F; return r;
+}
+int ref_line_search_by_projection_maplines(const KeyLine* kl, const uint8_t* ldesc, int n, const float* scale8, const uint8_t* state,
+                                           const MlIn* ml, const uint8_t* mlDesc, int nml, float th, float nnratio, int32_t* assigned) {
+    Frame* F = new Frame(); F->NL = n; F->mvKeylinesUn.assign(kl, kl + n); F->mvScaleFactors.assign(scale8, scale8 + 8);
+    F->mLdesc.create(n, 32, CV_8UC1); if (n) std::memcpy(F->mLdesc.data, ldesc, (size_t)n * 32);
+    std::vector<StructureSLAM::MapLine> pool(nml), occ(2); occ[0].nObs = 1; occ[1].nObs = 0;
+    std::vector<StructureSLAM::MapLine*> vp(nml);
+    for (int i = 0; i < nml; ++i) {
+        StructureSLAM::MapLine& q = pool[i];
+        q.mbTrackInView = ml[i].inView != 0; q.bad = ml[i].bad != 0; q.mnTrackScaleLevel = ml[i].level; q.nObs = ml[i].nObs; q.mTrackViewCos = ml[i].viewCos;
+        q.mTrackProjX1 = ml[i].x1; q.mTrackProjY1 = ml[i].y1; q.mTrackProjX2 = ml[i].x2; q.mTrackProjY2 = ml[i].y2; q.desc = cv::Mat(1, 32, CV_8UC1, (void*)(mlDesc + (size_t)i * 32));
+        vp[i] = &q;
+    }
+    F->mvpMapLines.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) if (state[i]) F->mvpMapLines[i] = &occ[state[i] - 1];
+    StructureSLAM::LSDmatcher m(nnratio, true);
+    const int r = m.SearchByProjection(*F, vp, th);
+    encode(F->mvpMapLines, pool, occ, assigned);
+    delete F; return r;
+}
+// Tracking::TrackWithMotionModel's calls (src/Tracking.cc:1227, :1243): (CurrentFrame, LastFrame, th, bMono) for points and for lines.
+// cam = {fx, fy, cx, cy, mbf, mb}; TL / TC = LastFrame.mTcw / CurrentFrame.mTcw (4 x 4 float, row major); has1[i]: 0 no map point, 1 one, outlier1[i]: mvbOutlier
+int ref_track_points(const cv::KeyPoint* kp1, const uint8_t* d1, int n1, const uint8_t* has1, const uint8_t* outlier1, const int32_t* nObs1, const float* wp1,
+                     const cv::KeyPoint* kp2, const uint8_t* d2, int n2, const uint8_t* state2, const float* uright2, const float* bounds, const float* scale8,
+                     const float* cam, const float* TL, const float* TC, float th, int bMono, float nnratio, int32_t* assigned) {
+    Frame* Last = new Frame(); Frame* Cur = new Frame();
+    set_frame_common(*Cur, kp2, d2, n2, bounds, scale8, uright2); set_frame_common(*Last, kp1, d1, n1, bounds, scale8, nullptr);
+    Cur->fx = cam[0]; Cur->fy = cam[1]; Cur->cx = cam[2]; Cur->cy = cam[3]; Cur->mbf = cam[4]; Cur->mb = cam[5];
+    Cur->mTcw = cv::Mat(4, 4, CV_32F); Last->mTcw = cv::Mat(4, 4, CV_32F);
+    std::memcpy(Cur->mTcw.data, TC, 64); std::memcpy(Last->mTcw.data, TL, 64);
+    std::vector<StructureSLAM::MapPoint> pool(n1), occ(2); occ[0].nObs = 1; occ[1].nObs = 0;
+    Last->mvpMapPoints.assign(n1, nullptr); Last->mvbOutlier.assign(n1, false);
+    for (int i = 0; i < n1; ++i) {
+        pool[i].nObs = nObs1[i]; pool[i].desc = cv::Mat(1, 32, CV_8UC1, (void*)(d1 + (size_t)i * 32)); pool[i].worldPos = cv::Mat(3, 1, CV_32F, (void*)(wp1 + 3 * (size_t)i));
+        if (has1[i]) Last->mvpMapPoints[i] = &pool[i];
+        Last->mvbOutlier[i] = outlier1[i] != 0;
+    }
+    Cur->mvpMapPoints.assign(n2, nullptr);
+    for (int i = 0; i < n2; ++i) if (state2[i]) Cur->mvpMapPoints[i] = &occ[state2[i] - 1];
+    StructureSLAM::ORBmatcher m(nnratio, true);
+    const int r = m.SearchByProjection(*Cur, *Last, th, bMono != 0);
+    encode(Cur->mvpMapPoints, pool, occ, assigned);
+    delete Last; delete Cur; return r;
+}
+int ref_track_lines(const cv::KeyPoint* kp1, int n1kp, const KeyLine* kl1, const uint8_t* ld1, int nl1, const uint8_t* has1, const uint8_t* bad1, const uint8_t* outlier1, const int32_t* nObs1, const double* wl1,
+                    const KeyLine* kl2, const uint8_t* ld2, int nl2, const uint8_t* state2, const float* bounds, const float* scale8,
+                    const float* cam, const float* TL, const float* TC, float th, int bMono, float nnratio, int32_t* assigned) {
+    Frame* Last = new Frame(); Frame* Cur = new Frame();
+    Frame::mnMinX = bounds[0]; Frame::mnMaxX = bounds[1]; Frame::mnMinY = bounds[2]; Frame::mnMaxY = bounds[3];
+    Last->mvKeys.assign(kp1, kp1 + n1kp);          // LastFrame.mvKeys[i].octave with i a LINE index: the reference's own expression (src/LSDmatcher.cpp:80)
+    Last->NL = nl1; Cur->NL = nl2; Cur->mvKeylinesUn.assign(kl2, kl2 + nl2); Cur->mvScaleFactors.assign(scale8, scale8 + 8);
+    Cur->mLdesc.create(nl2, 32, CV_8UC1); if (nl2) std::memcpy(Cur->mLdesc.data, ld2, (size_t)nl2 * 32);
+    Cur->fx = cam[0]; Cur->fy = cam[1]; Cur->cx = cam[2]; Cur->cy = cam[3]; Cur->mbf = cam[4]; Cur->mb = cam[5];
+    Cur->mTcw = cv::Mat(4, 4, CV_32F); Last->mTcw = cv::Mat(4, 4, CV_32F);
+    std::memcpy(Cur->mTcw.data, TC, 64); std::memcpy(Last->mTcw.data, TL, 64);
+    std::vector<StructureSLAM::MapLine> pool(nl1), occ(2); occ[0].nObs = 1; occ[1].nObs = 0;
+    Last->mvpMapLines.assign(nl1, nullptr); Last->mvbLineOutlier.assign(nl1, false);
+    for (int i = 0; i < nl1; ++i) {
+        pool[i].nObs = nObs1[i]; pool[i].bad = bad1[i] != 0; pool[i].desc = cv::Mat(1, 32, CV_8UC1, (void*)(ld1 + (size_t)i * 32));
+        for (int k = 0; k < 6; ++k) pool[i].worldPos.v[k] = wl1[6 * (size_t)i + k];
+        if (has1[i]) Last->mvpMapLines[i] = &pool[i];
+        Last->mvbLineOutlier[i] = outlier1[i] != 0;
+    }
+    Cur->mvpMapLines.assign(nl2, nullptr);
+    for (int i = 0; i < nl2; ++i) if (state2[i]) Cur->mvpMapLines[i] = &occ[state2[i] - 1];
+    StructureSLAM::LSDmatcher m(nnratio, true);
+    const int r = m.SearchByProjection(*Cur, *Last, th, bMono != 0);
+    encode(Cur->mvpMapLines, pool, occ, assigned);
+    delete Last; delete Cur; return r;
+}
+
+// ---- SearchByBoW (src/ORBmatcher.cc:159-291 keyframe -> frame, :525-658 keyframe -> keyframe) over the reference's own DBoW2::FeatureVector ----
+// node1[i] / node2[i]: the vocabulary node of feature i (the FeatureVector groups features by node, in ascending feature order: FeatureVector::addFeature)
+static void fill_kf(StructureSLAM::KeyFrame& K, std::vector<StructureSLAM::MapPoint>& pool, const cv::KeyPoint* kp, const uint8_t* desc, int n, const int32_t* node, const uint8_t* valid) {
+    K.mvKeysUn.assign(kp, kp + n); K.mDescriptors.create(n, 32, CV_8UC1); if (n) std::memcpy(K.mDescriptors.data, desc, (size_t)n * 32);
+    pool.resize(n); K.mvpMapPoints.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) { K.mFeatVec.addFeature((unsigned)node[i], (unsigned)i); pool[i].bad = valid[i] == 2; if (valid[i]) K.mvpMapPoints[i] = &pool[i]; }      // valid: 0 none, 1 good, 2 bad
+}
+int ref_search_by_bow(const cv::KeyPoint* kpKF, const uint8_t* dKF, int nKF, const int32_t* nodeKF, const uint8_t* validKF,
+                      const cv::KeyPoint* kpF, const uint8_t* dF, int nF, const int32_t* nodeF, float nnratio, int checkOri, int32_t* assigned) {
+    StructureSLAM::KeyFrame K; std::vector<StructureSLAM::MapPoint> pool; fill_kf(K, pool, kpKF, dKF, nKF, nodeKF, validKF);
+    Frame* F = new Frame(); F->N = nF; F->mvKeys.assign(kpF, kpF + nF); F->mvKeysUn = F->mvKeys;
+    F->mDescriptors.create(nF, 32, CV_8UC1); if (nF) std::memcpy(F->mDescriptors.data, dF, (size_t)nF * 32);
+    for (int i = 0; i < nF; ++i) F->mFeatVec.addFeature((unsigned)nodeF[i], (unsigned)i);
+    std::vector<StructureSLAM::MapPoint*> m;
+    StructureSLAM::ORBmatcher matcher(nnratio, checkOri != 0);
+    const int r = matcher.SearchByBoW(&K, *F, m);
+    for (int i = 0; i < nF; ++i) assigned[i] = m[i] ? (int32_t)(m[i] - pool.data()) : -1;
+    delete F; return r;
+}
+int ref_search_by_bow_keyframes(const cv::KeyPoint* kp1, const uint8_t* d1, int n1, const int32_t* node1, const uint8_t* valid1,
+                                const cv::KeyPoint* kp2, const uint8_t* d2, int n2, const int32_t* node2, const uint8_t* valid2, float nnratio, int checkOri, int32_t* m12) {
+    StructureSLAM::KeyFrame K1, K2; std::vector<StructureSLAM::MapPoint> p1, p2; fill_kf(K1, p1, kp1, d1, n1, node1, valid1); fill_kf(K2, p2, kp2, d2, n2, node2, valid2);
+    std::vector<StructureSLAM::MapPoint*> m;
+    StructureSLAM::ORBmatcher matcher(nnratio, checkOri != 0);
+    const int r = matcher.SearchByBoW(&K1, &K2, m);
+    for (int i = 0; i < n1; ++i) m12[i] = m[i] ? (int32_t)(m[i] - p2.data()) : -1;
+    return r;
+}
+
+// ---- LineSegment::ExtractLineSegment (src/ExtractLineSegment.cpp:18-69): detect, keep the 40 strongest (std::sort by response), describe, line equations ----
+int ref_extract_line_segment(const uint8_t* gray, int w, int h, KeyLine* kl_out, uint8_t* ldesc_out, double* fn_out, int cap) {
+    cv::Mat img(h, w, CV_8UC1, (void*)gray);
+    std::vector<KeyLine> kl; cv::Mat ld; std::vector<Vector3d> fn;
+    StructureSLAM::LineSegment* seg = nullptr;                  // the reference calls it through a never-constructed object (include/Frame.h:125)
+    StructureSLAM::LineSegment dummy; seg = &dummy;
+    seg->ExtractLineSegment(img, kl, ld, fn);
+    const int n = std::min((int)kl.size(), cap);
+    for (int i = 0; i < n; ++i) { kl_out[i] = kl[i]; std::memcpy(ldesc_out + (size_t)i * 32, ld.ptr(i), 32); fn_out[3 * i] = fn[i](0); fn_out[3 * i + 1] = fn[i](1); fn_out[3 * i + 2] = fn[i](2); }
+    return (int)kl.size();
 }
 }

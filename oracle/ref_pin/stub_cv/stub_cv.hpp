@@ -208,6 +208,7 @@ public:
         return (cr.start == INT32_MIN) ? m : m.colRange(cr);
     }
     Mat clone() const { Mat m; copyTo(m); return m; }
+    Mat t() const;
     void copyTo(Mat& m) const {
         if (empty()) { m.release(); return; }
         m.create(rows, cols, type());
@@ -223,6 +224,41 @@ private:
     }
 };
 inline MatExpr::operator Mat() const { Mat m; m = *this; return m; }
+inline Mat mat_t(const Mat& a);
+inline Mat Mat::t() const { return mat_t(*this); }
+
+// --- the little matrix algebra the tracking matchers use on CV_32F poses (src/ORBmatcher.cc:1341-1349, 1364; src/LSDmatcher.cpp:25-45):
+// A * B, A + B, -A, A.t().  In OpenCV these are MatExpr nodes folded into cv::gemm -- an un-vendored leaf; the stand-in evaluates in
+// float32, row by row, ((a0 b0 + a1 b1) + a2 b2) (+ c): the operation order of shim/FrontendMatchers.h's stand-in path (RxPlusT).
+inline Mat mat_t(const Mat& a) { Mat r(a.cols, a.rows, CV_32F); for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) r.at<float>(j, i) = a.at<float>(i, j); return r; }
+inline Mat operator-(const Mat& a) { Mat r(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) r.at<float>(i, j) = -a.at<float>(i, j); return r; }
+inline Mat operator*(const Mat& a, const Mat& b) {
+    assert(a.type() == CV_32F && b.type() == CV_32F && a.cols == b.rows);
+    Mat r(a.rows, b.cols, CV_32F);
+    for (int i = 0; i < a.rows; ++i) for (int j = 0; j < b.cols; ++j) {
+        float acc = a.at<float>(i, 0) * b.at<float>(0, j);
+        for (int k = 1; k < a.cols; ++k) acc = acc + a.at<float>(i, k) * b.at<float>(k, j);
+        r.at<float>(i, j) = acc;
+    }
+    return r;
+}
+inline Mat operator+(const Mat& a, const Mat& b) {
+    assert(a.type() == CV_32F && b.type() == CV_32F && a.rows == b.rows && a.cols == b.cols);
+    Mat r(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) r.at<float>(i, j) = a.at<float>(i, j) + b.at<float>(i, j);
+    return r;
+}
+template <class T> class Mat_;
+template <class T> struct MatCommaInitializer_ {
+    Mat m; int idx;
+    template <class U> MatCommaInitializer_& operator,(U v) { m.at<T>(idx / m.cols, idx % m.cols) = (T)v; ++idx; return *this; }
+    operator Mat() const { return m; }
+};
+template <class T> class Mat_ : public Mat {
+public:
+    Mat_(int r, int c) : Mat(r, c, sizeof(T) == 4 ? CV_32F : CV_64F) {}
+    template <class U> MatCommaInitializer_<T> operator<<(U v) { MatCommaInitializer_<T> ci{*this, 0}; return (ci, v); }
+};
 
 // --- proxies ---------------------------------------------------------------------------------------------------------------------
 class _InputArray {

@@ -9,7 +9,9 @@
 #include <cstdint>
 #include <utility>
 #include <vector>
+#include <set>
 #include "../stub_cv/stub_cv.hpp"
+#include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"      // the reference's own vendored DBoW2 header, where it lies (-I$(REF)); FeatureVector.cpp is compiled beside the slices
 
 namespace cv {
 namespace line_descriptor {
@@ -19,6 +21,34 @@ struct KeyLine {            // opencv_contrib line_descriptor/descriptor.hpp: 68
     int numOfPixels;
 };
 static_assert(sizeof(KeyLine) == 68, "KeyLine is 68 bytes");
+}  // namespace line_descriptor
+
+// cv::Ptr, LSDDetector::createLSDDetector()->detect(img, keylines, scale, numOctaves), BinaryDescriptor::createBinaryDescriptor()->compute(img,
+// keylines, descriptors): the two opencv_contrib classes LineSegment::ExtractLineSegment drives (src/ExtractLineSegment.cpp:38-40, 53).  Leaves:
+// they forward to the oracle's restatements (oracle/lsd_oracle.cpp, lbd_oracle.cpp, UPSTREAM-RECALL) through liboracle.so.
+}  // namespace cv
+#include "../../lines_types.h"
+namespace cv {
+template <class T> struct Ptr { std::shared_ptr<T> p; T* operator->() const { return p.get(); } };
+namespace line_descriptor {
+static_assert(sizeof(KeyLine) == sizeof(orc::KeyLine), "KeyLine layouts");
+struct LSDDetector {
+    static Ptr<LSDDetector> createLSDDetector() { return Ptr<LSDDetector>{std::make_shared<LSDDetector>()}; }
+    void detect(const Mat& image, std::vector<KeyLine>& keylines, int scale, int numOctaves, const Mat& = Mat()) {
+        assert(scale == 1 && numOctaves == 1);      // what `int scale = 1.2` truncates to (include/ExtractLineSegment.h:62)
+        std::vector<orc::KeyLine> k; orc::lsd_detect_keylines(stubdetail::toImg(image), k, nullptr);
+        keylines.resize(k.size()); if (!k.empty()) std::memcpy(keylines.data(), k.data(), sizeof(KeyLine) * k.size());
+    }
+};
+struct BinaryDescriptor {
+    static Ptr<BinaryDescriptor> createBinaryDescriptor() { return Ptr<BinaryDescriptor>{std::make_shared<BinaryDescriptor>()}; }
+    void compute(const Mat& image, std::vector<KeyLine>& keylines, Mat& descriptors, bool = false) const {
+        std::vector<orc::KeyLine> k(keylines.size()); if (!k.empty()) std::memcpy(k.data(), keylines.data(), sizeof(KeyLine) * k.size());
+        std::vector<uint8_t> d; orc::lbd_compute(stubdetail::toImg(image), k, d, nullptr);
+        descriptors.create((int)k.size(), 32, CV_8UC1);
+        for (size_t i = 0; i < k.size(); ++i) std::memcpy(descriptors.ptr((int)i), &d[i * 32], 32);
+    }
+};
 }  // namespace line_descriptor
 
 // cv::BFMatcher(NORM_HAMMING, crossCheck=false).knnMatch(query, train, matches, k): UPSTREAM-RECALL (modules/features2d/src/matchers.cpp,
@@ -51,15 +81,58 @@ using namespace cv::line_descriptor;
 // include/auxiliar.h:47-74 (the comparators of lineDescriptorMAD / SerachForInitialize) is spliced in by the build right after this header.
 #define SSLAM_PIN_STUB_SLAM 1
 
+// auxiliar.h:42 `typedef Matrix<double,6,1> Vector6d;` (Eigen, un-vendored): the slices only read P(0) .. P(5)
+struct Vector6d { double v[6]; double operator()(int i) const { return v[i]; } };
+// Eigen::Vector3d as src/ExtractLineSegment.cpp:56-68 uses it (Eigen is not vendored either): `v << a, b, c`, cross, v / s, v(i); all in double
+namespace Eigen {
+struct Vector3d {
+    double v[3];
+    struct Comma { Vector3d* t; int i; Comma& operator,(double x) { t->v[i++] = x; return *this; } };
+    Comma operator<<(double x) { v[0] = x; return Comma{this, 1}; }
+    Vector3d& operator<<(const Vector3d& o) { *this = o; return *this; }
+    Vector3d cross(const Vector3d& o) const { Vector3d r; r.v[0] = v[1] * o.v[2] - v[2] * o.v[1]; r.v[1] = v[2] * o.v[0] - v[0] * o.v[2]; r.v[2] = v[0] * o.v[1] - v[1] * o.v[0]; return r; }
+    Vector3d operator/(double s) const { Vector3d r; r.v[0] = v[0] / s; r.v[1] = v[1] / s; r.v[2] = v[2] / s; return r; }
+    double operator()(int i) const { return v[i]; }
+};
+}
+using namespace Eigen;
+
 namespace StructureSLAM {
 #ifndef FRAME_GRID_ROWS
 #define FRAME_GRID_ROWS 48      // include/Frame.h:45-46 (the build greps the two defines and fails if they ever change)
 #define FRAME_GRID_COLS 64
 #endif
 
+// include/MapPoint.h / include/MapLine.h: what the tracking matchers read of a map point / map line (names and types as in the reference;
+// the tracking fields are filled by Frame::isInFrustum in the real system, by the test driver here)
+class MapPoint {
+public:
+    bool mbTrackInView = false; int mnTrackScaleLevel = 0; float mTrackViewCos = 0, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
+    bool isBad() { return bad; }
+    cv::Mat GetDescriptor() { return desc.clone(); }
+    cv::Mat GetWorldPos() { return worldPos.clone(); }
+    int Observations() { return nObs; }
+    bool bad = false; int nObs = 1; cv::Mat desc, worldPos;      // (stand-in state)
+};
+class MapLine {
+public:
+    bool mbTrackInView = false; int mnTrackScaleLevel = 0; float mTrackViewCos = 0, mTrackProjX1 = 0, mTrackProjY1 = 0, mTrackProjX2 = 0, mTrackProjY2 = 0;
+    bool isBad() { return bad; }
+    cv::Mat GetDescriptor() { return desc.clone(); }
+    Vector6d GetWorldPos() { return worldPos; }
+    int Observations() { return nObs; }
+    bool bad = false; int nObs = 1; cv::Mat desc; Vector6d worldPos;
+};
+
 class Frame {
 public:
     Frame() : N(0), NL(0) {}
+    DBoW2::FeatureVector mFeatVec;
+    // what the tracking matchers read besides the features (include/Frame.h:97-189)
+    cv::Mat mTcw; float mb = 0, mbf = 0, fx = 0, fy = 0, cx = 0, cy = 0;
+    std::vector<cv::KeyPoint> mvKeys; std::vector<float> mvuRight, mvScaleFactors;
+    std::vector<MapPoint*> mvpMapPoints; std::vector<bool> mvbOutlier;
+    std::vector<MapLine*> mvpMapLines; std::vector<bool> mvbLineOutlier;
     // src/Frame.cc:133-148, 462-472, 368-421, 423-460, 190-215 -- bodies from the reference
     void AssignFeaturesToGrid();
     bool PosInGrid(const cv::KeyPoint& kp, int& posX, int& posY);
@@ -76,19 +149,44 @@ public:
     static float mnMinX, mnMaxX, mnMinY, mnMaxY;
 };
 
+// include/KeyFrame.h: what SearchByBoW reads of a keyframe
+class KeyFrame {
+public:
+    std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+    DBoW2::FeatureVector mFeatVec; cv::Mat mDescriptors; std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<MapPoint*> mvpMapPoints;      // (stand-in state)
+};
+
 class ORBmatcher {
 public:
     ORBmatcher(float nnratio = 0.6, bool checkOri = true);
     static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);
     int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10);
+    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3);
+    int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
+    int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
+    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
+    float RadiusByViewingCos(const float& viewCos);
     static const int TH_LOW, TH_HIGH, HISTO_LENGTH;
     void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
     float mfNNratio; bool mbCheckOrientation;
 };
 
+class LineSegment {       // include/ExtractLineSegment.h:51-78
+public:
+    LineSegment();
+    void ExtractLineSegment(const Mat& img, vector<KeyLine>& keylines, Mat& ldesc, vector<Vector3d>& keylineFunctions, int scale = 1.2, int numOctaves = 1);
+};
+
 class LSDmatcher {
 public:
+    static const int TH_HIGH, TH_LOW;
+    LSDmatcher(float nnratio = 0.6, bool checkOri = true);
     static int DescriptorDistance(const Mat& a, const Mat& b);
     int SerachForInitialize(Frame& InitialFrame, Frame& CurrentFrame, vector<pair<int, int> >& LineMatches);
+    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
+    int SearchByProjection(Frame& F, const std::vector<MapLine*>& vpMapLines, const float th = 3);
+    float RadiusByViewingCos(const float& viewCos);
+    float mfNNratio; bool mbCheckOrientation;
 };
 }  // namespace StructureSLAM
