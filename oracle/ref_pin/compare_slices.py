@@ -275,5 +275,29 @@ for name, img in [("synth1234", frames["synth1234"][0]), ("synth2000", frames["s
 report["d3_error_bar"] = d3
 print("D3 (std::sort vs stable sort of the 40 strongest lines):", d3)
 
+# --- the keyframe-side line matchers (src/LSDmatcher.cpp:143-183, 286-362, 382-415 over KeyFrame::lineDescriptorMAD, src/KeyFrame.cc:820-845)
+for name in ("synth1234", "synth2000", "big1235"):
+    img = frames[name][0]
+    l1 = orc.lines_extract(warp_prev(img), 200)[1]; l2 = orc.lines_extract(img, 200)[1]
+    n1, n2 = len(l1), len(l2)
+    has1 = (rng.random(n1) < 0.6).astype(np.uint8); has2 = (rng.random(n2) < 0.6).astype(np.uint8)
+    pr, _, _ = orc.line_match(l1, l2, 0.5, True)          # ratio gate
+    p05, _, _ = orc.line_match(l1, l2, 0.5, False)        # 0.5 x MAD gate
+    p01, _, _ = orc.line_match(l1, l2, 0.1, False)        # 0.1 x MAD gate
+    for which, label in [(0, "SearchByProjection(KF, F)"), (1, "SearchByDescriptor(KF, F)")]:
+        out = np.full(n2, -9, np.int32); r = R.ref_line_keyframe_match(which, _p(l1), n1, _p(has1), _p(l2), n2, _p(has2), _p(out), n2)
+        e = np.full(n2, -1, np.int32); cnt = 0
+        for a, b in pr:
+            if has1[a]: e[b] = a; cnt += 1
+        note("LSDmatcher::%s %s" % (label, name), r == cnt and np.array_equal(out, e), matches=int(r))
+    out = np.full(n1, -9, np.int32); r = R.ref_line_keyframe_match(2, _p(l1), n1, _p(has1), _p(l2), n2, _p(has2), _p(out), n1)
+    e = np.full(n1, -1, np.int32); cnt = 0
+    for a, b in p05:
+        if has2[b]: e[a] = b; cnt += 1
+    note("LSDmatcher::SearchByDescriptor(KF, KF) %s" % name, r == cnt and np.array_equal(out, e), matches=int(r))
+    out = np.full(2 * n1 + 2, -9, np.int32); r = R.ref_line_keyframe_match(3, _p(l1), n1, _p(has1), _p(l2), n2, _p(has2), _p(out), 2 * n1 + 2)
+    e = np.array([p for p in p01 if not (has1[p[0]] or has2[p[1]])], np.int32).reshape(-1, 2)
+    note("LSDmatcher::SearchForTriangulation %s" % name, r == len(e) and np.array_equal(out[:2 * r].reshape(-1, 2), e), pairs=int(r))
+
 json.dump(report, open(report_path, "w"), indent=1)
 print("reference slices == oracle on every case:", report["all_equal"])

@@ -206,4 +206,30 @@ int ref_extract_line_segment(const uint8_t* gray, int w, int h, KeyLine* kl_out,
     for (int i = 0; i < n; ++i) { kl_out[i] = kl[i]; std::memcpy(ldesc_out + (size_t)i * 32, ld.ptr(i), 32); fn_out[3 * i] = fn[i](0); fn_out[3 * i + 1] = fn[i](1); fn_out[3 * i + 2] = fn[i](2); }
     return (int)kl.size();
 }
+
+// ---- the keyframe-side line matchers: knn-2 + ratio gate (src/LSDmatcher.cpp:143-183, 286-324), knn-2 + 0.5 MAD gate (:326-362), + 0.1 MAD gate (:382-415) ----
+// has1 / has2: the keyframe's line i holds a map line.  which: 0 SearchByProjection(KF, F), 1 SearchByDescriptor(KF, F), 2 SearchByDescriptor(KF, KF2), 3 SearchForTriangulation
+int ref_line_keyframe_match(int which, const uint8_t* l1, int n1, const uint8_t* has1, const uint8_t* l2, int n2, const uint8_t* has2, int32_t* out, int cap) {
+    StructureSLAM::KeyFrame K1, K2; Frame* F = new Frame();
+    std::vector<StructureSLAM::MapLine> p1(n1), p2(n2);
+    K1.mLineDescriptors.create(n1, 32, CV_8UC1); if (n1) std::memcpy(K1.mLineDescriptors.data, l1, (size_t)n1 * 32);
+    K2.mLineDescriptors.create(n2, 32, CV_8UC1); if (n2) std::memcpy(K2.mLineDescriptors.data, l2, (size_t)n2 * 32);
+    F->NL = n2; F->mLdesc = K2.mLineDescriptors;
+    K1.mvpMapLines.assign(n1, nullptr); K2.mvpMapLines.assign(n2, nullptr);
+    for (int i = 0; i < n1; ++i) if (has1[i]) K1.mvpMapLines[i] = &p1[i];
+    for (int i = 0; i < n2; ++i) if (has2[i]) K2.mvpMapLines[i] = &p2[i];
+    StructureSLAM::LSDmatcher m;
+    std::vector<StructureSLAM::MapLine*> res; int r = 0;
+    if (which == 3) {
+        std::vector<std::pair<size_t, size_t> > pairs;
+        r = m.SearchForTriangulation(&K1, &K2, pairs);
+        for (int i = 0; i < (int)pairs.size() && i < cap / 2; ++i) { out[2 * i] = (int32_t)pairs[i].first; out[2 * i + 1] = (int32_t)pairs[i].second; }
+        delete F; return (int)pairs.size() == r ? r : -1;
+    }
+    if (which == 0) r = m.SearchByProjection(&K1, *F, res);
+    else if (which == 1) r = m.SearchByDescriptor(&K1, *F, res);
+    else r = m.SearchByDescriptor(&K1, &K2, res);
+    for (int i = 0; i < (int)res.size() && i < cap; ++i) out[i] = !res[i] ? -1 : which == 2 ? (int32_t)(res[i] - p2.data()) : (int32_t)(res[i] - p1.data());
+    delete F; return r;
+}
 }

@@ -10,6 +10,7 @@
 #include <utility>
 #include <vector>
 #include <set>
+#include <iostream>
 #include "../stub_cv/stub_cv.hpp"
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"      // the reference's own vendored DBoW2 header, where it lies (-I$(REF)); FeatureVector.cpp is compiled beside the slices
 
@@ -153,6 +154,10 @@ public:
 class KeyFrame {
 public:
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+    std::vector<MapLine*> GetMapLineMatches() { return mvpMapLines; }
+    MapLine* GetMapLine(const size_t& idx) { return mvpMapLines[idx]; }
+    void lineDescriptorMAD(std::vector<std::vector<cv::DMatch> > line_matches, double& nn_mad, double& nn12_mad) const;      // src/KeyFrame.cc:820-845
+    cv::Mat mLineDescriptors; std::vector<MapLine*> mvpMapLines;
     DBoW2::FeatureVector mFeatVec; cv::Mat mDescriptors; std::vector<cv::KeyPoint> mvKeysUn;
     std::vector<MapPoint*> mvpMapPoints;      // (stand-in state)
 };
@@ -186,6 +191,10 @@ public:
     int SerachForInitialize(Frame& InitialFrame, Frame& CurrentFrame, vector<pair<int, int> >& LineMatches);
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
     int SearchByProjection(Frame& F, const std::vector<MapLine*>& vpMapLines, const float th = 3);
+    int SearchByProjection(KeyFrame* pKF, Frame& currentF, vector<MapLine*>& vpMapLineMatches);
+    int SearchByDescriptor(KeyFrame* pKF, Frame& currentF, std::vector<MapLine*>& vpMapLineMatches);
+    int SearchByDescriptor(KeyFrame* pKF, KeyFrame* pKF2, std::vector<MapLine*>& vpMapLineMatches);
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs);
     float RadiusByViewingCos(const float& viewCos);
     float mfNNratio; bool mbCheckOrientation;
 };
