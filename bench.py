@@ -498,8 +498,10 @@ def main():
             # same harness in a child process (this process holds no batch any more), its headline numbers appended to this line
             import subprocess
             try:
+                child_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                               "SSLAM_FORCE_COLLECTIVE", "TORCHELASTIC_RUN_ID")}      # a plain single-process run, whatever launched this one
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pcie"],
-                                   capture_output=True, text=True, timeout=900)
+                                   capture_output=True, text=True, timeout=900, env=child_env)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 c4 = json.loads(line[-1])
                 out["other_workloads"] = {"c4": {"workload": c4["config"]["workload"], "value": c4["value"], "unit": c4["unit"], "ms_per_step": c4["ms_per_step"], "steps": c4["steps"],

@@ -174,8 +174,14 @@ def test_sharded_batch_soft_statuses_from_a_non_root_member(fe, ctx, fake_rccl):
             rc_ref, ref = _raw_batch(fe, orb, lines, frames, cap, lcap)
             rc, got = _raw_sharded(fe, g, frames, 400, 80, cap, lcap)
             assert rc == rc_ref == want, (rc, rc_ref, want)
-            for a, b in zip(got, ref):
-                np.testing.assert_array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+            (kp, desc, nk, kl, ld, fn, nl), (rkp, rdesc, rnk, rkl, rld, rfn, rnl) = got, ref
+            np.testing.assert_array_equal(nk, rnk); np.testing.assert_array_equal(nl, rnl)      # counts are clamped to the capacities on both paths
+            assert want == 0 or nk.max() == cap or nl.max() == lcap
+            for i in range(n):                                                                  # rows up to min(count, capacity) are defined; what lies behind them is not
+                a, b = min(int(nk[i]), cap), min(int(nl[i]), lcap)
+                np.testing.assert_array_equal(kp[i, :a].view(np.uint8), rkp[i, :a].view(np.uint8)); np.testing.assert_array_equal(desc[i, :a], rdesc[i, :a])
+                np.testing.assert_array_equal(kl[i, :b].view(np.uint8), rkl[i, :b].view(np.uint8)); np.testing.assert_array_equal(ld[i, :b], rld[i, :b])
+                np.testing.assert_array_equal(fn[i, :b], rfn[i, :b])
     finally:
         g.close(); orb.close(); lines.close()
 

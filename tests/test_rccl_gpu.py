@@ -15,7 +15,7 @@ def test_bench_under_torchrun_with_rccl_gather():
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--no-other-workloads"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
