@@ -5,8 +5,9 @@
 // DescriptorDistance, ComputeThreeMaxima, SearchForInitialization, AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea / GetLinesInArea,
 // lineDescriptorMAD, LSDmatcher::SerachForInitialize, ORBmatcher::SearchByProjection(F, MapPoints) and (Cur, Last, th, bMono),
 // LSDmatcher::SearchByProjection(F, MapLines), (Cur, Last, th, bMono) and (KF, F), LSDmatcher::SearchByDescriptor (KF, F) and (KF, KF),
-// LSDmatcher::SearchForTriangulation over KeyFrame::lineDescriptorMAD, ORBmatcher::SearchByBoW(KF, F) and (KF, KF), and the
-// orchestration of LineSegment::ExtractLineSegment.  NOT pinned that way: Fuse / SearchBySim3 / ORBmatcher::SearchForTriangulation / the relocalisation and
+// LSDmatcher::SearchForTriangulation over KeyFrame::lineDescriptorMAD, ORBmatcher::SearchByBoW(KF, F) and (KF, KF),
+// ORBmatcher::SearchForTriangulation with CheckDistEpipolarLine, and the
+// orchestration of LineSegment::ExtractLineSegment.  NOT pinned that way: Fuse / SearchBySim3 / the relocalisation and
 // loop-closing projection overloads (restated below from the source, compared with the HIP library only), and the OpenCV leaves
 // (cv::BFMatcher::knnMatch's tie-break, cv::gemm's accumulation order in the pose algebra of the (Cur, Last) calls).
 //

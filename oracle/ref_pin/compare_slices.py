@@ -299,5 +299,32 @@ for name in ("synth1234", "synth2000", "big1235"):
     e = np.array([p for p in p01 if not (has1[p[0]] or has2[p[1]])], np.int32).reshape(-1, 2)
     note("LSDmatcher::SearchForTriangulation %s" % name, r == len(e) and np.array_equal(out[:2 * r].reshape(-1, 2), e), pairs=int(r))
 
+# --- ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:660-826) + CheckDistEpipolarLine (:140-157): the epipole comes out of the reference's own
+# pose algebra (C2 = R2w * Cw + t2w, float32 row order of the stand-in gemm); the oracle takes it as (ex, ey)
+for name in ("synth1234", "synth2000", "noise7"):
+    img, (kp1, d1), (kp2, d2) = frames[name]
+    n1, n2 = len(kp1), len(kp2); h, w = img.shape
+    node1 = ((kp1["x"] // 64).astype(np.int32) * 32 + (kp1["y"] // 64).astype(np.int32)); node2 = ((kp2["x"] // 64).astype(np.int32) * 32 + (kp2["y"] // 64).astype(np.int32))
+    node1 = np.where(rng.random(n1) < 0.08, node1 + 4000, node1).astype(np.int32)
+    a = np.deg2rad(1.5); cxh, cyh = (w - 1) / 2.0, (h - 1) / 2.0
+    Hm = np.array([[np.cos(a), np.sin(a), cxh - 3.0 - cxh * np.cos(a) - cyh * np.sin(a)], [-np.sin(a), np.cos(a), cyh + 2.0 + cxh * np.sin(a) - cyh * np.cos(a)], [0, 0, 1.0]])
+    for only_stereo, ori, C1 in [(False, True, (-4.0, 0.3, 0.9)), (True, True, (-4.0, 0.3, 0.9)), (False, False, (0.02, -0.01, 2.0))]:
+        T2 = np.array([[0.99995, -0.0099998, 0, 0.012], [0.0099998, 0.99995, 0, -0.007], [0, 0, 1, 0.3], [0, 0, 0, 1]], np.float32)
+        cam2 = np.array([520.9, 521.0, 325.1, 249.7], np.float32); C1a = np.array(C1, np.float32)
+        c2 = [f32(f32(f32(f32(T2[r, 0] * C1a[0]) + f32(T2[r, 1] * C1a[1])) + f32(T2[r, 2] * C1a[2])) + T2[r, 3]) for r in range(3)]
+        invz = f32(f32(1.0) / c2[2]); ex = f32(f32(f32(cam2[0] * c2[0]) * invz) + cam2[2]); ey = f32(f32(f32(cam2[1] * c2[1]) * invz) + cam2[3])
+        E = np.array([[0, -1.0, float(ey)], [1.0, 0, -float(ex)], [-float(ey), float(ex), 0]])
+        F12 = (E @ Hm).T; F12 = np.ascontiguousarray(F12 / np.abs(F12).max(), np.float32)      # (C order: the slice takes the raw buffer)
+        sg8 = (scale8 * scale8).astype(np.float32)
+        free1 = (rng.random(n1) < 0.9).astype(np.uint8); free2 = (rng.random(n2) < 0.9).astype(np.uint8)
+        pst = 0.7 if only_stereo else 0.3
+        ur1 = np.where(rng.random(n1) < pst, kp1["x"] - 5, -1).astype(np.float32); ur2 = np.where(rng.random(n2) < pst, kp2["x"] - 5, -1).astype(np.float32)
+        m_r = np.zeros(n1, np.int32)
+        nr = R.ref_search_for_triangulation(_p(kp1), _p(d1), n1, _p(node1), _p(free1), _p(ur1), _p(kp2), _p(d2), n2, _p(node2), _p(free2), _p(ur2), _p(F12), _p(T2), _p(C1a), _p(cam2),
+                                            _p(scale8), _p(sg8), int(only_stereo), int(ori), _p(m_r))
+        pk, pf, ik, if_ = shared_csr(node1, node2)
+        m_o, no = orc.search_for_triangulation(kp1, d1, ur1, free1, kp2, d2, ur2, free2, pk, pf, ik, if_, F12, float(ex), float(ey), scale8, sg8, only_stereo, ori)
+        note("ORBmatcher::SearchForTriangulation %s stereo=%d ori=%d" % (name, only_stereo, ori), nr == no and np.array_equal(m_r, m_o), pairs=int(nr), epipole=(round(float(ex), 1), round(float(ey), 1)))
+
 json.dump(report, open(report_path, "w"), indent=1)
 print("reference slices == oracle on every case:", report["all_equal"])

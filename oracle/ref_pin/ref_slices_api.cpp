@@ -232,4 +232,27 @@ int ref_line_keyframe_match(int which, const uint8_t* l1, int n1, const uint8_t*
     for (int i = 0; i < (int)res.size() && i < cap; ++i) out[i] = !res[i] ? -1 : which == 2 ? (int32_t)(res[i] - p2.data()) : (int32_t)(res[i] - p1.data());
     delete F; return r;
 }
+
+// ---- ORBmatcher::SearchForTriangulation + CheckDistEpipolarLine (src/ORBmatcher.cc:660-826, 140-157) ----
+// free1 / free2: the keypoint holds no map point yet.  T2 = pKF2's pose (4 x 4 float), C1 = pKF1's camera centre (3 floats), cam2 = {fx, fy, cx, cy}
+int ref_search_for_triangulation(const cv::KeyPoint* kp1, const uint8_t* d1, int n1, const int32_t* node1, const uint8_t* free1, const float* ur1,
+                                 const cv::KeyPoint* kp2, const uint8_t* d2, int n2, const int32_t* node2, const uint8_t* free2, const float* ur2,
+                                 const float* F12, const float* T2, const float* C1, const float* cam2, const float* scale8, const float* sigma8,
+                                 int onlyStereo, int checkOri, int32_t* m12) {
+    StructureSLAM::KeyFrame K1, K2; std::vector<StructureSLAM::MapPoint> p1, p2;
+    std::vector<uint8_t> v1(n1), v2(n2); for (int i = 0; i < n1; ++i) v1[i] = free1[i] ? 0 : 1; for (int i = 0; i < n2; ++i) v2[i] = free2[i] ? 0 : 1;
+    fill_kf(K1, p1, kp1, d1, n1, node1, v1.data()); fill_kf(K2, p2, kp2, d2, n2, node2, v2.data());
+    K1.N = n1; K2.N = n2; K1.mvuRight.assign(ur1, ur1 + n1); K2.mvuRight.assign(ur2, ur2 + n2);
+    K2.fx = cam2[0]; K2.fy = cam2[1]; K2.cx = cam2[2]; K2.cy = cam2[3];
+    K2.mvScaleFactors.assign(scale8, scale8 + 8); K2.mvLevelSigma2.assign(sigma8, sigma8 + 8);
+    K2.Tcw = cv::Mat(4, 4, CV_32F); std::memcpy(K2.Tcw.data, T2, 64);
+    K1.Ow = cv::Mat(3, 1, CV_32F); std::memcpy(K1.Ow.data, C1, 12);
+    cv::Mat F(3, 3, CV_32F); std::memcpy(F.data, F12, 36);
+    std::vector<std::pair<size_t, size_t> > pairs;
+    StructureSLAM::ORBmatcher m(0.6f, checkOri != 0);
+    const int r = m.SearchForTriangulation(&K1, &K2, F, pairs, onlyStereo != 0);
+    for (int i = 0; i < n1; ++i) m12[i] = -1;
+    for (auto& pr : pairs) m12[pr.first] = (int32_t)pr.second;
+    return (int)pairs.size() == r ? r : -1;
+}
 }

@@ -158,6 +158,14 @@ public:
     MapLine* GetMapLine(const size_t& idx) { return mvpMapLines[idx]; }
     void lineDescriptorMAD(std::vector<std::vector<cv::DMatch> > line_matches, double& nn_mad, double& nn12_mad) const;      // src/KeyFrame.cc:820-845
     cv::Mat mLineDescriptors; std::vector<MapLine*> mvpMapLines;
+    // what ORBmatcher::SearchForTriangulation / CheckDistEpipolarLine read (include/KeyFrame.h)
+    MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
+    cv::Mat GetCameraCenter() { return Ow.clone(); }
+    cv::Mat GetRotation() { return Tcw.rowRange(0, 3).colRange(0, 3).clone(); }
+    cv::Mat GetTranslation() { return Tcw.rowRange(0, 3).col(3).clone(); }
+    int N = 0; float fx = 0, fy = 0, cx = 0, cy = 0;
+    std::vector<float> mvuRight, mvScaleFactors, mvLevelSigma2;
+    cv::Mat Tcw, Ow;      // (stand-in state)
     DBoW2::FeatureVector mFeatVec; cv::Mat mDescriptors; std::vector<cv::KeyPoint> mvKeysUn;
     std::vector<MapPoint*> mvpMapPoints;      // (stand-in state)
 };
@@ -170,6 +178,8 @@ public:
     int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3);
     int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
     int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs, const bool bOnlyStereo);
+    bool CheckDistEpipolarLine(const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const cv::Mat& F12, const KeyFrame* pKF);
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
     float RadiusByViewingCos(const float& viewCos);
     static const int TH_LOW, TH_HIGH, HISTO_LENGTH;
