@@ -326,5 +326,57 @@ for name in ("synth1234", "synth2000", "noise7"):
         m_o, no = orc.search_for_triangulation(kp1, d1, ur1, free1, kp2, d2, ur2, free2, pk, pf, ik, if_, F12, float(ex), float(ey), scale8, sg8, only_stereo, ori)
         note("ORBmatcher::SearchForTriangulation %s stereo=%d ori=%d" % (name, only_stereo, ori), nr == no and np.array_equal(m_r, m_o), pairs=int(nr), epipole=(round(float(ex), 1), round(float(ey), 1)))
 
+# --- Frame::ComputeBoW (src/Frame.cc:474-481) over the reference's own vendored DBoW2, compiled unmodified (oracle/_ref/libref_dbow2.so): ORBVocabulary::
+# loadFromTextFile (TemplatedVocabulary.h:1338-1423: what System.cc:64-73 calls on ORBvoc.txt) + transform(features, BowVector&, FeatureVector&, levelsup)
+# (:1126-1208, tree descent :1216-1259, FORB::distance) against the oracle's restatement of the loader and the transform.  ORBvoc.txt itself is a git-LFS
+# pointer in the reference tree, so the vocabularies are synthetic trees written in its text format (ragged branches, stopped words, all weightings / scorings).
+import tempfile
+from synth import synthetic_vocab, write_vocab_text
+D2 = C.CDLL(os.path.join(ref_dir, "libref_dbow2.so"))
+kpv, dv = frames["synth1234"][2]
+d9 = {"files_with_trailing_newline": 0, "phantom_words": 0, "bow_entries_differing": 0, "bow_entries": 0}
+with tempfile.TemporaryDirectory() as td:
+    for vi, (k, Lv, weighting, scoring, levelsup, fmt) in enumerate([(10, 4, 0, 0, 4, "%r"), (9, 3, 1, 1, 2, "%.6g"), (9, 3, 2, 2, 0, "%.6g"), (10, 4, 3, 5, 6, "%r"), (5, 5, 0, 3, 3, "%r"), (10, 3, 0, 4, 1, "%r")]):
+        Lx, ptr, ch, nd, word, weight = synthetic_vocab(np.random.default_rng(100 + vi), k=k, L=Lv)
+        feat = np.ascontiguousarray(np.concatenate([dv, nd[np.random.default_rng(vi).integers(1, len(nd), 150)]]))
+        n = len(feat)
+        for nl in (False, True):
+            path = os.path.join(td, "voc%d_%d.txt" % (vi, nl))
+            write_vocab_text(path, k, Lx, ptr, ch, nd, weight, scoring=scoring, weighting=weighting, weight_fmt=fmt, trailing_newline=nl)
+            info = np.zeros(5, np.int32); bw = np.zeros(n, np.int32); bv = np.zeros(n, np.float64); fnn = np.zeros(n, np.int32); fpp = np.zeros(n + 1, np.int32); fff = np.zeros(n, np.int32)
+            nb = C.c_int32(); nf = C.c_int32()
+            rc = D2.ref_vocab_compute_bow(path.encode(), _p(feat), n, levelsup, _p(info), _p(bw), _p(bv), C.byref(nb), _p(fnn), _p(fpp), _p(fff), C.byref(nf))
+            ov = orc.vocab_load_text(path)
+            obw, obv, ofn, ofp, off = orc.compute_bow(ov["levels"], ov["child_ptr"], ov["children"], ov["node_desc"], ov["word_id"], ov["weight"], feat, levelsup, ov["weighting"], ov["scoring"])
+            if not nl:
+                # D10.  A word that sits SHALLOWER than level L - levelsup never reaches the line that stores its FeatureVector node (TemplatedVocabulary.h:1250-1251),
+                # and the caller's `NodeId nid;` is uninitialised (:1150): the reference files such a feature under whatever the previous feature left on the stack.
+                # The oracle (and the library) file it under the root, node 0.  Such features are compared on the BowVector only and counted.
+                cp, chd = ov["child_ptr"], ov["children"]; depth = np.zeros(len(cp) - 1, np.int32)
+                for nd_ in range(len(cp) - 1):
+                    for c_ in chd[cp[nd_]:cp[nd_ + 1]]: depth[c_] = depth[nd_] + 1          # (DBoW2 numbers children after their parents)
+                leaf_of_word = {int(wd): i_ for i_, wd in enumerate(ov["word_id"]) if cp[i_ + 1] == cp[i_] and i_ > 0}
+                fw, fwt, fnode = orc.bow_transform(ov["levels"], cp, chd, ov["node_desc"], ov["word_id"], ov["weight"], feat, levelsup)
+                undefined = set(i_ for i_ in range(n) if fwt[i_] > 0 and ov["levels"] - levelsup > 0 and depth[leaf_of_word[int(fw[i_])]] < ov["levels"] - levelsup)
+                def fv_pairs(nodes, ptr_, feats):
+                    return sorted((int(nodes[j]), int(f_)) for j in range(len(nodes)) for f_ in feats[ptr_[j]:ptr_[j + 1]] if int(f_) not in undefined)
+                ok = (rc == 0 and list(info) == [ov["k"], ov["levels"], ov["scoring"], ov["weighting"], ov["nwords"]] and nb.value == len(obw) and np.array_equal(bw[:nb.value], obw)
+                      and np.array_equal(bv[:nb.value].view(np.uint64), obv.view(np.uint64)) and fv_pairs(fnn[:nf.value], fpp, fff) == fv_pairs(ofn, ofp, off))
+                d9["features_on_words_above_the_node_level"] = d9.get("features_on_words_above_the_node_level", 0) + len(undefined)
+                note("DBoW2 loadFromTextFile + transform k=%d L=%d weighting=%d scoring=%d levelsup=%d" % (k, Lv, weighting, scoring, levelsup), ok, words=int(nb.value), nodes=int(nf.value),
+                     vocabulary_words=int(info[4]), features_with_undefined_node=len(undefined))
+            else:
+                # D9.  A file that ends with a newline (as ORBvoc.txt does) makes the reference's `while(!f.eof())` loop read one more, empty line: `ssnode >> pid` fails
+                # before storing, so the phantom node's parent and leaf flag are whatever the previous iteration left on the stack (TemplatedVocabulary.h:1381-1398, undefined
+                # behaviour), its descriptor is an unfilled 32-byte row.  The oracle (and the library) stop at the last real line.  Recorded, not asserted: the reference's
+                # answer here depends on its own stack and heap.
+                ref_set = dict(zip(bw[:nb.value].tolist(), bv[:nb.value].tolist())); orc_set = dict(zip(obw.tolist(), obv.tolist()))
+                d9["files_with_trailing_newline"] += 1; d9["phantom_words"] += int(info[4]) - int(ov["nwords"])
+                d9["bow_entries"] += len(orc_set); d9["bow_entries_differing"] += sum(1 for w_ in set(ref_set) | set(orc_set) if ref_set.get(w_) != orc_set.get(w_))
+    bad = os.path.join(td, "missing.txt")
+    note("DBoW2 loadFromTextFile on a missing file", D2.ref_vocab_compute_bow(bad.encode(), _p(feat), n, 2, _p(info), _p(bw), _p(bv), C.byref(nb), _p(fnn), _p(fpp), _p(fff), C.byref(nf)) == -1)
+report["d9_trailing_newline"] = d9
+print("D9 (vocabulary file with a trailing newline: the reference reads a phantom node, undefined behaviour):", d9)
+
 json.dump(report, open(report_path, "w"), indent=1)
 print("reference slices == oracle on every case:", report["all_equal"])

@@ -26,7 +26,11 @@
 #include <cassert>
 #include <cstdlib>
 #include <memory>
+#include <sstream>      // (the real opencv2/core/core.hpp pulls these in; the vendored DBoW2 relies on it)
+#include <iostream>
+#include <string>
 #include <vector>
+#include <string>
 #include <algorithm>
 #include "../../cvleaf.h"
 
@@ -288,6 +292,29 @@ enum { BORDER_CONSTANT = 0, BORDER_REPLICATE = 1, BORDER_REFLECT = 2, BORDER_WRA
        BORDER_DEFAULT = 4, BORDER_ISOLATED = 16 };
 enum { INTER_NEAREST = 0, INTER_LINEAR = 1, INTER_CUBIC = 2, INTER_AREA = 3 };
 enum { NORM_L2 = 4, NORM_HAMMING = 6 };
+
+// --- cv::FileStorage / cv::FileNode: the vendored DBoW2 (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1456-1640) has YAML save / load members that must
+// compile because they are virtual; the reference never calls them (the vocabulary comes from ORBvoc.txt through loadFromTextFile).  Inert stand-ins:
+// a storage never opens, so save(filename) / load(filename) throw as they do on a missing file.
+struct FileNode {
+    FileNode operator[](const char*) const { return FileNode(); }
+    FileNode operator[](const std::string&) const { return FileNode(); }
+    FileNode operator[](int) const { return FileNode(); }
+    size_t size() const { return 0; }
+    operator int() const { return 0; }
+    operator float() const { return 0.f; }
+    operator double() const { return 0.0; }
+    operator std::string() const { return std::string(); }
+};
+struct FileStorage {
+    enum { READ = 0, WRITE = 1 };
+    FileStorage() {}
+    FileStorage(const std::string&, int) {}
+    bool isOpened() const { return false; }
+    FileNode operator[](const char*) const { return FileNode(); }
+    FileNode operator[](const std::string&) const { return FileNode(); }
+};
+template <class T> static inline FileStorage& operator<<(FileStorage& fs, const T&) { return fs; }
 
 // --- leaves (UPSTREAM-RECALL, oracle/cvleaf.h) -------------------------------------------------------------------------------------
 static inline float fastAtan2(float y, float x) { return orc::fast_atan2(y, x); }
