@@ -66,3 +66,35 @@ def test_hip_matchers_equal_reference_slices(fe, ctx):
     pairs = gp[0]
     assert nr == len(pairs) > 20
     np.testing.assert_array_equal(pairs, pr[:nr])
+
+
+DBOW2 = os.path.join(REFDIR, "libref_dbow2.so")
+
+
+@pytest.mark.skipif(not os.path.exists(DBOW2), reason="oracle/_ref/libref_dbow2.so did not travel")
+@pytest.mark.parametrize("k,L,weighting,scoring,levelsup", [(10, 4, 0, 0, 4), (9, 3, 1, 1, 2), (5, 5, 2, 3, 3)])
+def test_hip_compute_bow_equals_vendored_dbow2(fe, ctx, oracle, tmp_path, k, L, weighting, scoring, levelsup):
+    """Frame::ComputeBoW: the HIP vocabulary (sslam_vocab_load_text + sslam_compute_bow) against the reference's own vendored DBoW2 compiled whole
+    (ORBVocabulary::loadFromTextFile + transform).  Files without a trailing newline and trees whose words are at least L - levelsup deep:
+    outside that the reference reads uninitialised locals."""
+    from synth import synthetic_vocab, write_vocab_text
+    D2 = C.CDLL(DBOW2)
+    rng = np.random.default_rng(7 * k + L)
+    Lx, ptr, ch, nd, word, weight = synthetic_vocab(rng, k=k, L=L)
+    path = tmp_path / "voc.txt"
+    write_vocab_text(path, k, Lx, ptr, ch, nd, weight, scoring=scoring, weighting=weighting, weight_fmt="%r", trailing_newline=False)
+    kp, d = oracle.orb_extract(synth_frame(1234), 1000)
+    feat = np.ascontiguousarray(np.concatenate([d, nd[rng.integers(1, len(nd), 100)]])); n = len(feat)
+    info = np.zeros(5, np.int32); bw = np.zeros(n, np.int32); bv = np.zeros(n, np.float64); fn = np.zeros(n, np.int32); fp = np.zeros(n + 1, np.int32); ff = np.zeros(n, np.int32)
+    nb = C.c_int32(); nf = C.c_int32()
+    assert D2.ref_vocab_compute_bow(str(path).encode(), _p(feat), n, levelsup, _p(info), _p(bw), _p(bv), C.byref(nb), _p(fn), _p(fp), _p(ff), C.byref(nf)) == 0
+    voc = fe.Vocabulary.from_text_file(ctx, path)
+    try:
+        vi = voc.info()
+        assert [vi["k"], vi["levels"], vi["scoring"], vi["weighting"], vi["nwords"]] == list(info)
+        bow, fv = voc.compute_bow(feat, levelsup)
+    finally:
+        voc.close()
+    assert list(bow.keys()) == bw[:nb.value].tolist() and np.array_equal(np.array(list(bow.values()), np.float64).view(np.uint64), bv[:nb.value].view(np.uint64)) and nb.value > 100
+    ref_fv = {int(fn[j]): ff[fp[j]:fp[j + 1]].tolist() for j in range(nf.value)}
+    assert {int(a): list(map(int, b)) for a, b in fv.items()} == ref_fv          # (every word of these trees is at least L - levelsup deep)
