@@ -326,6 +326,26 @@ for name in ("synth1234", "synth2000", "noise7"):
         m_o, no = orc.search_for_triangulation(kp1, d1, ur1, free1, kp2, d2, ur2, free2, pk, pf, ik, if_, F12, float(ex), float(ey), scale8, sg8, only_stereo, ori)
         note("ORBmatcher::SearchForTriangulation %s stereo=%d ori=%d" % (name, only_stereo, ori), nr == no and np.array_equal(m_r, m_o), pairs=int(nr), epipole=(round(float(ex), 1), round(float(ey), 1)))
 
+# --- MapPoint / MapLine::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312, src/MapLine.cpp:246-317): least median Hamming distance to the others
+ok_all = True; nsets = 0
+base = frames["synth2000"][2][1]
+for trial in range(400):
+    n = int(rng.integers(1, 40)) if trial % 7 else int(rng.integers(40, 120))
+    seed_row = base[int(rng.integers(0, len(base)))]
+    desc = np.tile(seed_row, (n, 1)).copy()
+    for i in range(n):                                           # observations of one point: near-duplicates (ties are the interesting case), a few outliers
+        for b_ in rng.integers(0, 256, int(rng.integers(0, 12)) if rng.random() < 0.85 else 90): desc[i, b_ >> 3] ^= np.uint8(1 << (b_ & 7))
+    if trial % 5 == 0: desc[1:] = desc[0]                          # all identical
+    bad = (rng.random(n) < 0.15).astype(np.uint8) if trial % 3 == 0 else np.zeros(n, np.uint8)
+    good = np.ascontiguousarray(desc[bad == 0])
+    want = int(orc.distinctive(good, np.array([0, len(good)], np.int32))[0]) if len(good) else -1
+    for lines in (0, 1):
+        got = R.ref_distinctive(lines, _p(np.ascontiguousarray(desc)), n, _p(bad))
+        # identical descriptors: the reference returns a CLONE, so any row that holds the chosen bytes is the same answer
+        same = got == want or (got >= 0 and want >= 0 and np.array_equal(good[got], good[want]))
+        ok_all &= bool(same); nsets += 1
+note("MapPoint / MapLine::ComputeDistinctiveDescriptors", ok_all, observation_sets=nsets)
+
 # --- Frame::ComputeBoW (src/Frame.cc:474-481) over the reference's own vendored DBoW2, compiled unmodified (oracle/_ref/libref_dbow2.so): ORBVocabulary::
 # loadFromTextFile (TemplatedVocabulary.h:1338-1423: what System.cc:64-73 calls on ORBvoc.txt) + transform(features, BowVector&, FeatureVector&, levelsup)
 # (:1126-1208, tree descent :1216-1259, FORB::distance) against the oracle's restatement of the loader and the transform.  ORBvoc.txt itself is a git-LFS

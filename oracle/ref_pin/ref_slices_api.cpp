@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  C entry points around the reference functions that `make -C oracle/ref_pin pin-stub` cuts out of
 // src/ORBmatcher.cc, src/LSDmatcher.cpp and src/Frame.cc (this file is appended to the generated oracle/_ref/ref_slices.cc; it holds no
 // reference code).  compare_stub.py calls them through ctypes next to the oracle's orc_* functions on the same arrays.
+std::mutex StructureSLAM::gStubMutex;
 namespace StructureSLAM {
 float Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv, Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
 }
@@ -254,5 +255,26 @@ int ref_search_for_triangulation(const cv::KeyPoint* kp1, const uint8_t* d1, int
     for (int i = 0; i < n1; ++i) m12[i] = -1;
     for (auto& pr : pairs) m12[pr.first] = (int32_t)pr.second;
     return (int)pairs.size() == r ? r : -1;
+}
+
+// ---- MapPoint / MapLine::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312, src/MapLine.cpp:246-317) ----
+// the observation set: rows of `desc`, one per keyframe; bad[i]: that keyframe isBad().  The reference walks a std::map keyed by KeyFrame*, i.e. in
+// ADDRESS order (which of several equally good descriptors wins depends on the allocator in the author's binary); the keyframes here are elements of one
+// array, so address order = row order.  Returns the row of the chosen descriptor among the rows of keyframes that are not bad, -1 when nothing was chosen.
+int ref_distinctive(int lines, const uint8_t* desc, int n, const uint8_t* bad) {
+    std::vector<StructureSLAM::KeyFrame> kfs(n);
+    std::map<StructureSLAM::KeyFrame*, size_t> obs;
+    for (int i = 0; i < n; ++i) {
+        cv::Mat& D = lines ? kfs[i].mLineDescriptors : kfs[i].mDescriptors;
+        D.create(3, 32, CV_8UC1); std::memset(D.data, 0xA5, 96); std::memcpy(D.ptr(1), desc + (size_t)i * 32, 32);      // the observed feature is row 1 of that keyframe
+        kfs[i].bad = bad && bad[i]; obs[&kfs[i]] = 1;
+    }
+    cv::Mat chosen;
+    if (lines) { StructureSLAM::MapLine m; m.mObservations = obs; m.ComputeDistinctiveDescriptors(); chosen = m.mLDescriptor; }
+    else { StructureSLAM::MapPoint m; m.mObservations = obs; m.ComputeDistinctiveDescriptors(); chosen = m.mDescriptor; }
+    if (chosen.empty()) return -1;
+    int row = 0;
+    for (int i = 0; i < n; ++i) { if (kfs[i].bad) continue; if (std::memcmp(chosen.data, desc + (size_t)i * 32, 32) == 0) return row; ++row; }
+    return -2;
 }
 }

@@ -252,6 +252,8 @@ inline Mat operator+(const Mat& a, const Mat& b) {
     for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) r.at<float>(i, j) = a.at<float>(i, j) + b.at<float>(i, j);
     return r;
 }
+// cv::norm(a, b, NORM_HAMMING) (src/MapLine.cpp:283): popcount of the xor, as a double (leaf)
+inline double norm(const Mat& a, const Mat& b, int normType);
 template <class T> class Mat_;
 template <class T> struct MatCommaInitializer_ {
     Mat m; int idx;
@@ -315,6 +317,13 @@ struct FileStorage {
     FileNode operator[](const std::string&) const { return FileNode(); }
 };
 template <class T> static inline FileStorage& operator<<(FileStorage& fs, const T&) { return fs; }
+
+inline double norm(const Mat& a, const Mat& b, int normType) {
+    assert(normType == NORM_HAMMING && a.type() == CV_8UC1 && a.rows == b.rows && a.cols == b.cols);
+    long d = 0;
+    for (int y = 0; y < a.rows; ++y) for (int x = 0; x < a.cols; ++x) d += __builtin_popcount((unsigned)(a.ptr(y)[x] ^ b.ptr(y)[x]));
+    return (double)d;
+}
 
 // --- leaves (UPSTREAM-RECALL, oracle/cvleaf.h) -------------------------------------------------------------------------------------
 static inline float fastAtan2(float y, float x) { return orc::fast_atan2(y, x); }

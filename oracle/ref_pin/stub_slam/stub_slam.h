@@ -10,6 +10,8 @@
 #include <utility>
 #include <vector>
 #include <set>
+#include <map>
+#include <mutex>
 #include <iostream>
 #include "../stub_cv/stub_cv.hpp"
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"      // the reference's own vendored DBoW2 header, where it lies (-I$(REF)); FeatureVector.cpp is compiled beside the slices
@@ -106,8 +108,13 @@ namespace StructureSLAM {
 
 // include/MapPoint.h / include/MapLine.h: what the tracking matchers read of a map point / map line (names and types as in the reference;
 // the tracking fields are filled by Frame::isInFrustum in the real system, by the test driver here)
+class KeyFrame;
+extern std::mutex gStubMutex;       // one mutex behind every stand-in's mMutexFeatures (the stand-ins stay movable)
 class MapPoint {
 public:
+    // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312) reads these
+    void ComputeDistinctiveDescriptors();
+    std::mutex& mMutexFeatures = gStubMutex; bool mbBad = false; std::map<KeyFrame*, size_t> mObservations; cv::Mat mDescriptor;
     bool mbTrackInView = false; int mnTrackScaleLevel = 0; float mTrackViewCos = 0, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
     bool isBad() { return bad; }
     cv::Mat GetDescriptor() { return desc.clone(); }
@@ -117,6 +124,8 @@ public:
 };
 class MapLine {
 public:
+    void ComputeDistinctiveDescriptors();      // src/MapLine.cpp:246-317
+    std::mutex& mMutexFeatures = gStubMutex; bool mbBad = false; std::map<KeyFrame*, size_t> mObservations; cv::Mat mLDescriptor;
     bool mbTrackInView = false; int mnTrackScaleLevel = 0; float mTrackViewCos = 0, mTrackProjX1 = 0, mTrackProjY1 = 0, mTrackProjX2 = 0, mTrackProjY2 = 0;
     bool isBad() { return bad; }
     cv::Mat GetDescriptor() { return desc.clone(); }
@@ -153,6 +162,7 @@ public:
 // include/KeyFrame.h: what SearchByBoW reads of a keyframe
 class KeyFrame {
 public:
+    bool isBad() { return bad; } bool bad = false;
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
     std::vector<MapLine*> GetMapLineMatches() { return mvpMapLines; }
     MapLine* GetMapLine(const size_t& idx) { return mvpMapLines[idx]; }

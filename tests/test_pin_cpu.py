@@ -22,11 +22,11 @@ def _check(rep):
     bad = {k: v for k, v in rep["slices"]["cases"].items() if not v["equal"]}
     assert not bad, bad
     assert rep["all_equal"]
-    assert len(rep["orb_extractor"]["fixtures"]) >= 16 and len(rep["slices"]["cases"]) >= 141
+    assert len(rep["orb_extractor"]["fixtures"]) >= 16 and len(rep["slices"]["cases"]) >= 143
     covered = " ".join(rep["slices"]["cases"])
     for fn in ("DescriptorDistance", "GetFeaturesInArea", "GetLinesInArea", "SearchForInitialization", "SerachForInitialize", "SearchByProjection(F, MapPoints)",
                "SearchByProjection(Cur, Last)", "SearchByProjection(F, MapLines)", "SearchByBoW(KF, F)", "SearchByBoW(KF, KF)", "ExtractLineSegment", "SearchByProjection(KF, F)", "SearchByDescriptor(KF, F)",
-               "SearchByDescriptor(KF, KF)", "LSDmatcher::SearchForTriangulation", "ORBmatcher::SearchForTriangulation", "DBoW2 loadFromTextFile + transform"):
+               "SearchByDescriptor(KF, KF)", "LSDmatcher::SearchForTriangulation", "ORBmatcher::SearchForTriangulation", "DBoW2 loadFromTextFile + transform", "ComputeDistinctiveDescriptors"):
         assert fn in covered, fn
     # the error bars of decisions D1 / D4 are part of the report (DESIGN.md section 2 quotes them)
     eb = rep["orb_extractor"]["error_bars"]
