@@ -79,6 +79,12 @@ int sslam_profile_drain(sslam_ctx* ctx, const char** names_out, double* ms_out, 
 int sslam_orb_create(sslam_ctx* ctx, int nfeatures, float scaleFactor, int nlevels,
                      int iniThFAST, int minThFAST, sslam_orb** out);
 int sslam_orb_destroy(sslam_orb* orb);
+/* Which 8-bit cv::GaussianBlur(7x7, sigma 2) the descriptors are computed on (src/ORBextractor.cc:1085-1086; the leaf is OpenCV's, and its
+ * arithmetic changed inside the 3.4 series): 0 (default) = the bit-exact fixed-point filter of OpenCV >= 3.4.1, 8.8 taps 18 34 48 56 48 34 18
+ * that sum to 256 (DESIGN.md decision D6); 1 = OpenCV 3.4.0 -- the version the reference's README names -- whose filter engine rounds every
+ * tap of the float kernel: 18 34 49 55 49 34 18 (sum 257, result saturated).  Keypoints are the same either way; 3.7 % of the descriptor bits
+ * differ between the two (oracle/ref_pin/pin_report_stub.json).  Takes effect with the next extraction. */
+int sslam_orb_set_blur_variant(sslam_orb* orb, int variant);
 
 /* GetLevels/GetScaleFactors/GetInverseScaleFactors/GetScaleSigmaSquares/
  * GetInverseScaleSigmaSquares, include/ORBextractor.h:63-83.  Each array has

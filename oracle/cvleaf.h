@@ -212,18 +212,31 @@ static inline std::vector<int> gauss_taps_q8(int n, double sigma) {
     return t;
 }
 
+// The ALTERNATIVE of decision D6 (selectable: orc_set_gauss_variant(1), sslam_orb_set_blur_variant(orb, 1)): OpenCV 3.4.0 -- the version the
+// reference's README.md:22 names -- has no bit-exact 8-bit Gaussian yet; its separable filter engine (filter.cpp, createSeparableLinearFilter,
+// bits = 8) takes the FLOAT kernel of getGaussianKernel(n, sigma, CV_32F), scales it by 256 and rounds EACH tap, so the taps need not sum to 256:
+// sigma 2, n 7 gives 18 34 49 55 49 34 18 (sum 257) against the error-diffused 18 34 48 56 48 34 18.  Same 16.16 accumulation and rounding, result
+// saturated to 255 (the sum can reach 257 / 256 of a flat area).  UPSTREAM-RECALL like the rest of this file.
+static inline std::vector<int> gauss_taps_340(int n, double sigma) {
+    std::vector<float> k(n); double sum = 0; const double s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; k[i] = (float)std::exp(s2 * x * x); sum += k[i]; }
+    sum = 1. / sum;
+    std::vector<int> t(n);
+    for (int i = 0; i < n; ++i) { k[i] = (float)(k[i] * sum); t[i] = cv_round(k[i] * 256.0); }
+    return t;
+}
+
 // cv::GaussianBlur(src8u, ksize n x n, sigma, BORDER_REFLECT_101), D6 variant:
 // horizontal 8.8 accumulate, vertical 16.16 accumulate, round-to-nearest.  A.6
-static inline Img8 gaussian_blur_8u(const Img8& s, int n, double sigma) {
-    std::vector<int> t = gauss_taps_q8(n, sigma);
-    const int r = n / 2;
-    std::vector<uint16_t> tmp((size_t)s.w * s.h);
+static inline Img8 gaussian_blur_8u_taps(const Img8& s, const std::vector<int>& t) {
+    const int n = (int)t.size(), r = n / 2;
+    std::vector<uint32_t> tmp((size_t)s.w * s.h);
     for (int y = 0; y < s.h; ++y) {
         const uint8_t* S = s.row(y);
         for (int x = 0; x < s.w; ++x) {
             uint32_t acc = 0;
             for (int k = -r; k <= r; ++k) acc += (uint32_t)S[reflect101(x + k, s.w)] * t[k + r];
-            tmp[(size_t)y * s.w + x] = (uint16_t)acc;      // <= 255*256
+            tmp[(size_t)y * s.w + x] = acc;      // <= 255 * sum(taps)
         }
     }
     Img8 o(s.w, s.h);
@@ -232,11 +245,14 @@ static inline Img8 gaussian_blur_8u(const Img8& s, int n, double sigma) {
         for (int x = 0; x < s.w; ++x) {
             uint32_t acc = 0;
             for (int k = -r; k <= r; ++k)
-                acc += (uint32_t)tmp[(size_t)reflect101(y + k, s.h) * s.w + x] * t[k + r];
-            D[x] = (uint8_t)((acc + (1u << 15)) >> 16);
+                acc += tmp[(size_t)reflect101(y + k, s.h) * s.w + x] * t[k + r];
+            D[x] = (uint8_t)std::min<uint32_t>((acc + (1u << 15)) >> 16, 255u);
         }
     }
     return o;
+}
+static inline Img8 gaussian_blur_8u(const Img8& s, int n, double sigma, int variant = 0) {
+    return gaussian_blur_8u_taps(s, variant == 1 ? gauss_taps_340(n, sigma) : gauss_taps_q8(n, sigma));
 }
 
 // ---- FAST-9/16 -----------------------------------------------------------

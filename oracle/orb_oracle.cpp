@@ -21,6 +21,8 @@
 
 namespace orc {
 
+static int g_gaussVariant = 0;      // decision D6 (0) or its OpenCV-3.4.0 alternative (1): cvleaf.h, orc_set_gauss_variant
+
 static const int kPattern[1024] = {
 #include "orb_pattern.inc"
 };
@@ -309,7 +311,7 @@ static void orb_extract(const OrbParams& P, const Img8& image, std::vector<KP>& 
     for (int level = 0; level < P.nlevels; ++level) {
         std::vector<KP>& keypoints = all[level];
         if (keypoints.empty()) continue;
-        Img8 working = gaussian_blur_8u(pyr[level].roi, 7, 2.0);     // clone + GaussianBlur(7x7, 2, 2, REFLECT_101), :1085-1086
+        Img8 working = gaussian_blur_8u(pyr[level].roi, 7, 2.0, g_gaussVariant);     // clone + GaussianBlur(7x7, 2, 2, REFLECT_101), :1085-1086
         for (size_t i = 0; i < keypoints.size(); ++i) orb_descriptor(keypoints[i], working, &desc[(size_t)(offset + i) * 32]);
         offset += (int)keypoints.size();
         if (level != 0) {
@@ -375,15 +377,16 @@ int orc_orb_candidates(const uint8_t* gray, int w, int h, int stride, int nfeatu
     return (int)c.size();
 }
 
+int orc_set_gauss_variant(int v) { const int old = g_gaussVariant; g_gaussVariant = v == 1 ? 1 : 0; return old; }
 int orc_blur7(const uint8_t* src, int w, int h, uint8_t* dst) {
     Img8 im(w, h); std::memcpy(im.d.data(), src, (size_t)w * h);
-    Img8 o = gaussian_blur_8u(im, 7, 2.0);
+    Img8 o = gaussian_blur_8u(im, 7, 2.0, g_gaussVariant);
     std::memcpy(dst, o.d.data(), (size_t)w * h);
     return 0;
 }
 
 int orc_gauss_taps(int n, double sigma, int* out) {
-    std::vector<int> t = gauss_taps_q8(n, sigma);
+    std::vector<int> t = g_gaussVariant == 1 ? gauss_taps_340(n, sigma) : gauss_taps_q8(n, sigma);
     for (int i = 0; i < n; ++i) out[i] = t[i];
     return 0;
 }

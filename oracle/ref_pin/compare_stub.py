@@ -9,6 +9,7 @@ Four builds of the same reference source are run:
   ref_orb_stub_fma      -O3 -march=native (GCC default: contraction on), monotonic  -> D4's error bar (FMA in x*b + y*a, src/ORBextractor.cc:118-120)
   ref_orb_stub_malloc   -ffp-contract=off, glibc malloc                             -> D1's error bar (sort by heap pointer, src/ORBextractor.cc:684)
   ref_orb_stub_asbuilt  -O3 -march=native, glibc malloc  = the reference's own CMake flags (CMakeLists.txt:10-11) -> both together
+  ref_orb_stub_gauss340 the pinned binary with the stub's GaussianBlur switched to OpenCV 3.4.0's rounded taps  -> D6's error bar (descriptor bits only)
 The report says, per fixture: equal or not for the pinned build; for the other three how many keypoints (as a set of (octave, x, y))
 and how many descriptor bits differ from the oracle.  Exit status 0 either way -- tests/test_pin_cpu.py turns the report into a verdict."""
 import glob, json, os, subprocess, sys
@@ -22,12 +23,14 @@ ref, fx, report_path = sys.argv[1], sys.argv[2], sys.argv[3]
 orc = oracle_lib.Oracle()
 # fixture name -> extractor parameters (nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST); default = Examples/ICL.yaml:41-54
 PARAMS = {"synth4lev15_700": (700, 1.5, 4, 20, 7), "synthth_1200": (1200, 1.2, 8, 35, 12)}
-VARIANTS = ["ref_orb_stub", "ref_orb_stub_fma", "ref_orb_stub_malloc", "ref_orb_stub_asbuilt"]
+VARIANTS = ["ref_orb_stub", "ref_orb_stub_fma", "ref_orb_stub_malloc", "ref_orb_stub_asbuilt", "ref_orb_stub_gauss340"]      # the last one: the pinned binary with SSLAM_STUB_GAUSS_340=1 (decision D6's alternative)
 
 
 def run(binary, pgm, params):
     out = os.path.join(fx, os.path.basename(pgm)[:-4] + "." + binary)
-    subprocess.run([os.path.join(ref, binary), pgm, out] + [repr(p) if isinstance(p, float) else str(p) for p in params], check=True, capture_output=True)
+    env = dict(os.environ); exe = binary
+    if binary == "ref_orb_stub_gauss340": env["SSLAM_STUB_GAUSS_340"] = "1"; exe = "ref_orb_stub"
+    subprocess.run([os.path.join(ref, exe), pgm, out] + [repr(p) if isinstance(p, float) else str(p) for p in params], check=True, capture_output=True, env=env)
     return np.fromfile(out + "_kp.bin", dtype=KP), np.fromfile(out + "_desc.bin", dtype=np.uint8).reshape(-1, 32), np.fromfile(out + "_tables.bin", dtype=np.float32)
 
 
@@ -67,6 +70,10 @@ for pgm in sorted(glob.glob(os.path.join(fx, "*.pgm"))):
             res["scale_tables_equal"] = bool(np.array_equal(tables[:params[2]].view(np.uint32), np.asarray(sc[0], np.float32).view(np.uint32)))
             report["all_equal"] &= res["scale_tables_equal"]
         else:
+            if v == "ref_orb_stub_gauss340":          # the alternative is selectable in the oracle and in the library: the reference compiled with it must equal the oracle's variant 1
+                orc.set_gauss_variant(1); okp1, odesc1 = orc.orb_extract(img, *params); orc.set_gauss_variant(0)
+                d["equals_oracle_variant_1"] = bool(kp.size == okp1.size and np.array_equal(kp.view(np.uint8), okp1.view(np.uint8)) and np.array_equal(desc, odesc1))
+                report["all_equal"] &= d["equals_oracle_variant_1"]
             res[v] = d
             e = report["error_bars"][v]
             e["keypoints_differing"] += d["only_in_reference"] + d["only_in_oracle"]; e["keypoints"] += d["keypoints_reference"]
@@ -74,8 +81,8 @@ for pgm in sorted(glob.glob(os.path.join(fx, "*.pgm"))):
     report["fixtures"][name] = res
 json.dump(report, open(report_path, "w"), indent=1)
 for n, r in report["fixtures"].items():
-    print("%-20s pinned kp %s desc %s (%d kp) | fma: %d kp / %d bits differ | malloc: %d kp differ | as built: %d kp / %d bits differ" % (
-        n, r["pinned"]["kp_equal"], r["pinned"]["desc_equal"], r["pinned"]["keypoints"],
+    print("%-20s pinned kp %s desc %s (%d kp) | gauss 3.4.0: %d bits differ | fma: %d kp / %d bits differ | malloc: %d kp differ | as built: %d kp / %d bits differ" % (
+        n, r["pinned"]["kp_equal"], r["pinned"]["desc_equal"], r["pinned"]["keypoints"], r["ref_orb_stub_gauss340"]["descriptor_bits_differing"],
         r["ref_orb_stub_fma"]["only_in_reference"] + r["ref_orb_stub_fma"]["only_in_oracle"], r["ref_orb_stub_fma"]["descriptor_bits_differing"],
         r["ref_orb_stub_malloc"]["only_in_reference"] + r["ref_orb_stub_malloc"]["only_in_oracle"],
         r["ref_orb_stub_asbuilt"]["only_in_reference"] + r["ref_orb_stub_asbuilt"]["only_in_oracle"], r["ref_orb_stub_asbuilt"]["descriptor_bits_differing"]))

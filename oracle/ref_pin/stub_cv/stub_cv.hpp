@@ -385,11 +385,13 @@ static inline void copyMakeBorder(InputArray src_, OutputArray dst_, int top, in
     for (int y = 0; y < bottom; ++y) std::memcpy(dst.ptr(top + sh + y), dst.ptr(top + orc::reflect101(sh + y, sh)), (size_t)dw);
 }
 
+// SSLAM_STUB_GAUSS_340=1 switches this leaf to decision D6's alternative (OpenCV 3.4.0's rounded taps, oracle/cvleaf.h gauss_taps_340)
 static inline void GaussianBlur(InputArray src_, OutputArray dst_, Size ksize, double sigmaX, double sigmaY = 0, int borderType = BORDER_DEFAULT) {
     Mat src = src_.getMat();
     assert(ksize.width == ksize.height && (sigmaY == 0 || sigmaY == sigmaX) && (borderType & ~BORDER_ISOLATED) == BORDER_REFLECT_101);
     assert(!src.isSubmatrix() || (borderType & BORDER_ISOLATED));   // a ROI would read its parent's pixels: the reference blurs a clone
-    orc::Img8 r = orc::gaussian_blur_8u(stubdetail::toImg(src), ksize.width, sigmaX);
+    static const bool v340 = std::getenv("SSLAM_STUB_GAUSS_340") != nullptr;
+    orc::Img8 r = orc::gaussian_blur_8u(stubdetail::toImg(src), ksize.width, sigmaX, v340 ? 1 : 0);
     dst_.create(src.rows, src.cols, src.type());
     Mat d = dst_.getMat();
     for (int y = 0; y < r.h; ++y) std::memcpy(d.ptr(y), r.row(y), (size_t)r.w);

@@ -47,6 +47,7 @@ struct LevelInfo {
 struct Plan {
     int nlevels;
     int nCellsFrame, candFrame, selFrame;
+    unsigned blurPack0, blurPack1;      // taps 0-3 and 4-6 of the 7x7 sigma-2 blur as bytes (q8)
     size_t pyrFrame;              // bytes
     int maxCellW, maxCellH, maxCellsLevel, maxNodeCap;
     LevelInfo L[MAX_LEVELS];
@@ -65,8 +66,7 @@ __constant__ int kUmax[16];
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 as_s16x2(unsigned v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ unsigned as_u32(s16x2 v) { return __builtin_bit_cast(unsigned, v); }
-__constant__ int kBlurTaps[7];
-__constant__ unsigned kBlurPack[2];      // taps 0-3 and 4-6 as bytes, for v_dot4_u32_u8
+// (the 7 blur taps travel in the Plan, packed as bytes for v_dot4_u32_u8: they belong to the extractor -- sslam_orb_set_blur_variant -- not to the module)
 __constant__ unsigned kDiscMask[31 * 8];  // byte masks of the r=15 disc: row v, dword m covers u = 4m-15 .. 4m-12
 
 // ------------------------------------------------------------------ level 0 copy
@@ -718,7 +718,10 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
     m10 = wave_sum(m10); m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // horizontal blur pass: all 43 rows, columns x-18..x+21 in groups of four outputs from three dwords
-    const unsigned T0 = kBlurPack[0], T1 = kBlurPack[1];
+    const unsigned T0 = P.blurPack0, T1 = P.blurPack1;
+    unsigned kBlurTaps[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) kBlurTaps[q] = ((q < 4 ? T0 : T1) >> (8 * (q & 3))) & 255u;
     for (int i = lane; i < PW * 10; i += 64) {
         const int r = i / 10, g4 = i - r * 10;
         const unsigned* p = (const unsigned*)(patch + r * PP) + g4;
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
             unsigned acc = 0;
 #pragma unroll
             for (int q = 0; q < 7; ++q) acc += (unsigned)h[q * 40] * (unsigned)kBlurTaps[q];
-            descOut[((size_t)b * cap + outIdx) * (TAPW * TAPW) + i] = (uint8_t)((acc + 32768u) >> 16);
+            descOut[((size_t)b * cap + outIdx) * (TAPW * TAPW) + i] = (uint8_t)min((acc + 32768u) >> 16, 255u);      // (saturation only bites with taps that sum to 257: blur variant 1)
         }
     }
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
             unsigned acc = 0;
 #pragma unroll
             for (int q = 0; q < 7; ++q) acc += (unsigned)h[q * 40] * (unsigned)kBlurTaps[q];
-            t[e] = (int)((acc + 32768u) >> 16);
+            t[e] = (int)min((acc + 32768u) >> 16, 255u);
         }
         nib |= (unsigned)(t[0] < t[1]) << k;
     }
@@ -828,10 +831,20 @@ struct sslam_orb {
     int lastFrames = 0;
     int lastN = -1;                 // keypoints of the last sslam_orb_extract (still resident in dKp/dDesc)
     bool constsUploaded = false;
+    int blurVariant = 0;            // sslam_orb_set_blur_variant
 };
 
 static inline int cvRoundF(float v) { return (int)lrintf(v); }
 
+// OpenCV 3.4.0's 8-bit Gaussian taps (decision D6's alternative, oracle/cvleaf.h gauss_taps_340): the float kernel times 256, every tap rounded
+static std::vector<int> blur_taps_340(int n, double sigma) {
+    std::vector<float> k(n); double sum = 0; const double s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; k[i] = (float)std::exp(s2 * x * x); sum += k[i]; }
+    sum = 1. / sum;
+    std::vector<int> t(n);
+    for (int i = 0; i < n; ++i) { k[i] = (float)(k[i] * sum); t[i] = (int)lrint((double)k[i] * 256.0); }
+    return t;
+}
 static std::vector<int> blur_taps_q8(int n, double sigma) {
     // bit-exact 8.8 Gaussian taps with error diffusion, sum == 256 (decision D6)
     std::vector<double> k(n);
@@ -1002,6 +1015,13 @@ extern "C" int sslam_orb_create(sslam_ctx* ctx, int nfeatures, float scaleFactor
     return SSLAM_OK;
 }
 
+extern "C" int sslam_orb_set_blur_variant(sslam_orb* o, int variant) {
+    if (!o || (variant != 0 && variant != 1)) { set_error("sslam_orb_set_blur_variant: invalid arguments"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::recursive_mutex> lk(o->ctx->mu);
+    o->blurVariant = variant;
+    return SSLAM_OK;
+}
+
 extern "C" int sslam_orb_destroy(sslam_orb* o) {
     if (!o) return SSLAM_OK;
     (void)hipSetDevice(o->ctx->device);
@@ -1045,14 +1065,14 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
         SSLAM_HIP(hipStreamSynchronize(st));
         if ((rc = build_plan(o, w, h))) return rc;
     }
-    if (!o->constsUploaded) {
-        std::vector<int> taps = blur_taps_q8(7, 2.0);
-        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kUmax), o->umax, sizeof(int) * 16));
-        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kBlurTaps), taps.data(), sizeof(int) * 7));
+    {   // the blur taps of this extractor (decision D6, or its OpenCV-3.4.0 alternative: sslam_orb_set_blur_variant)
+        const std::vector<int> taps = o->blurVariant == 1 ? blur_taps_340(7, 2.0) : blur_taps_q8(7, 2.0);
         for (int t : taps) if (t < 0 || t > 255) { set_error("blur taps do not fit a byte"); return SSLAM_ERR_UNSUPPORTED; }
-        const unsigned pack[2] = {(unsigned)taps[0] | ((unsigned)taps[1] << 8) | ((unsigned)taps[2] << 16) | ((unsigned)taps[3] << 24),
-                                  (unsigned)taps[4] | ((unsigned)taps[5] << 8) | ((unsigned)taps[6] << 16)};
-        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kBlurPack), pack, sizeof(pack)));
+        o->plan.blurPack0 = (unsigned)taps[0] | ((unsigned)taps[1] << 8) | ((unsigned)taps[2] << 16) | ((unsigned)taps[3] << 24);
+        o->plan.blurPack1 = (unsigned)taps[4] | ((unsigned)taps[5] << 8) | ((unsigned)taps[6] << 16);
+    }
+    if (!o->constsUploaded) {
+        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kUmax), o->umax, sizeof(int) * 16));
         unsigned mask[31 * 8];
         for (int r = 0; r < 31; ++r)
             for (int m = 0; m < 8; ++m) {

@@ -385,6 +385,10 @@ class OrbExtractor:
         _chk(lib().sslam_orb_create(ctx.h, int(nfeatures), C.c_float(scale_factor), int(nlevels), int(ini_th), int(min_th), C.byref(self.h)))
         self.cap = lib().sslam_orb_max_keypoints(self.h)
 
+    def set_blur_variant(self, variant):
+        """0: the bit-exact 8-bit GaussianBlur of OpenCV >= 3.4.1 (default, decision D6); 1: OpenCV 3.4.0's rounded taps (sslam_orb_set_blur_variant)"""
+        _chk(lib().sslam_orb_set_blur_variant(self.h, int(variant)))
+
     def scales(self):
         n = self.nlevels
         s = np.zeros(n, np.float32); i = np.zeros(n, np.float32); g = np.zeros(n, np.float32); ig = np.zeros(n, np.float32)

@@ -40,6 +40,9 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST), mHandle(nullptr)
 {
     check(sslam_orb_create(G.get(), nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, &mHandle));
+    // the class keeps the reference's constructor signature, so the one leaf whose arithmetic depends on the OpenCV release the system was built against
+    // is chosen by the environment: SSLAM_ORB_BLUR_VARIANT=1 = OpenCV 3.4.0's 8-bit GaussianBlur (include/sslam_frontend.h, sslam_orb_set_blur_variant)
+    if (const char* e = std::getenv("SSLAM_ORB_BLUR_VARIANT")) check(sslam_orb_set_blur_variant(mHandle, std::atoi(e)));
     mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
     check(sslam_orb_get_scales(mHandle, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(), nullptr));
     mvImagePyramid.resize(nlevels);

@@ -44,6 +44,10 @@ class Oracle:
         self.L.orc_fast_atan2.restype = C.c_float
         self.L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
 
+    def set_gauss_variant(self, v):
+        """0: decision D6 (bit-exact 8.8 taps that sum to 256); 1: OpenCV 3.4.0's rounded taps (sum 257).  Process-global; returns the previous value."""
+        return int(self.L.orc_set_gauss_variant(int(v)))
+
     def orb_params(self, nfeatures=1000, scale=1.2, nlevels=8):
         s = np.zeros(nlevels, np.float32); p = np.zeros(nlevels, np.int32); u = np.zeros(16, np.int32)
         self.L.orc_orb_params(nfeatures, C.c_float(scale), nlevels, _p(s), _p(p), _p(u))

@@ -64,6 +64,14 @@ def test_reflect101(oracle):
 def test_gauss_taps(oracle):
     assert list(oracle.gauss_taps(7, 2.0)) == [18, 34, 48, 56, 48, 34, 18]      # 8.8 fixed point, sum == 256 (decision D6)
     assert sum(oracle.gauss_taps(7, 0.75)) == 256 and sum(oracle.gauss_taps(5, 1.0)) == 256
+    # decision D6's selectable alternative: OpenCV 3.4.0 rounds every tap of the float kernel (sum 257) and saturates
+    try:
+        oracle.set_gauss_variant(1)
+        assert list(oracle.gauss_taps(7, 2.0)) == [18, 34, 49, 55, 49, 34, 18]
+        assert (oracle.blur7(np.full((40, 50), 255, np.uint8)) == 255).all() and (oracle.blur7(np.full((40, 50), 100, np.uint8)) == 101).all()      # 100 * 257^2 / 65536 = 100.78
+    finally:
+        assert oracle.set_gauss_variant(0) == 1
+    assert (oracle.blur7(np.full((40, 50), 100, np.uint8)) == 100).all()
 
 
 def test_blur_constant_and_impulse(oracle):

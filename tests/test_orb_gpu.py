@@ -54,3 +54,32 @@ def test_orb_wide(fe, ctx, oracle):
 
 def test_orb_1280(fe, ctx, oracle):
     _cmp_orb(fe, ctx, oracle, synth_frame(1235, w=1280, h=960), nfeat=2000)
+
+
+def test_orb_blur_variant_opencv_340(fe, ctx, oracle):
+    """Decision D6 has a selectable alternative: the 8-bit GaussianBlur of OpenCV 3.4.0 (every tap of the float kernel rounded: 18 34 49 55 49 34 18, sum 257,
+    saturated) instead of the bit-exact filter of >= 3.4.1.  Same keypoints, other descriptors; the library under variant 1 equals the oracle under variant 1
+    (which equals the reference compiled with that leaf: oracle/ref_pin), and switching back restores variant 0."""
+    for img, nfeat in ((synth_frame(1234), 1000), (synth_frame(1235, w=1280, h=960), 2000), (np.full((240, 320), 255, np.uint8), 300)):
+        ex = fe.OrbExtractor(ctx, nfeat)
+        try:
+            kp0, d0 = ex(img)
+            ex.set_blur_variant(1)
+            kp1, d1 = ex(img)
+            try:
+                oracle.set_gauss_variant(1)
+                okp1, od1 = oracle.orb_extract(img, nfeat)
+            finally:
+                oracle.set_gauss_variant(0)
+            np.testing.assert_array_equal(kp1.view(np.uint8), okp1.view(np.uint8)); np.testing.assert_array_equal(d1, od1)
+            np.testing.assert_array_equal(kp1.view(np.uint8), kp0.view(np.uint8))                    # the blur only feeds the descriptors
+            if len(kp0):
+                frac = np.unpackbits(d0 ^ d1).mean()
+                assert 0.01 < frac < 0.10, frac                                                       # ~3.7 % of the bits
+            ex.set_blur_variant(0)
+            kp2, d2 = ex(img)
+            np.testing.assert_array_equal(d2, d0)
+            with pytest.raises(fe.SslamError):
+                ex.set_blur_variant(2)
+        finally:
+            ex.close()
