@@ -342,6 +342,10 @@ int sslam_lines_destroy(sslam_lines* ln);
 int sslam_lines_extract(sslam_lines* ln, const uint8_t* gray, int w, int h, size_t stride,
                         sslam_keyline* kl_out, uint8_t* ldesc_out, double* linefn_out /*3 per line*/,
                         int cap, int* n_out);
+/* The line twin of sslam_orb_set_blur_variant: which 8-bit cv::GaussianBlur LBD's 5x5 sigma-1 pre-blur is (BinaryDescriptor::compute, called at
+ * src/ExtractLineSegment.cpp:53): 0 = OpenCV >= 3.4.1 (taps 14 62 104 62 14), 1 = OpenCV 3.4.0 (14 63 103 63 14).  LSD's own 7x7 sigma-0.75 pre-blur has the
+ * same taps (0 4 56 136 56 4 0) under both, so the segments do not depend on it; the LBD bytes do. */
+int sslam_lines_set_blur_variant(sslam_lines* ln, int variant);
 int sslam_lines_extract_batch_dev(sslam_lines* ln, const uint8_t* d_images, int w, int h,
                                   size_t pitch, size_t image_stride, int nframes,
                                   sslam_keyline* d_kl, uint8_t* d_ldesc, double* d_linefn,

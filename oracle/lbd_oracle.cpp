@@ -25,7 +25,7 @@ void lbd_compute(const Img8& image, const std::vector<KeyLine>& keylines, std::v
     if (float_desc) float_desc->assign((size_t)n * 72, 0.f);
     if (n == 0) return;
     // BinaryDescriptor::computeGaussianPyramid: 5x5 sigma 1 blur of the base image, then Sobel 3x3 -> s16
-    Img8 blurred = gaussian_blur_8u(image, 5, 1.0);
+    Img8 blurred = gaussian_blur_8u(image, 5, 1.0, g_gaussVariant);      // (variant 1: taps 14 63 103 63 14 instead of 14 62 104 62 14)
     std::vector<int16_t> dxImg, dyImg;
     sobel3_s16(blurred, dxImg, dyImg);
     // Gaussian weights (BinaryDescriptor ctor; integer divisions are the library's)

@@ -13,6 +13,7 @@ struct KeyLine {
 };
 static_assert(sizeof(KeyLine) == 68, "KeyLine layout");
 struct Img8;
+extern int g_gaussVariant;      // orb_oracle.cpp: which 8-bit GaussianBlur the path uses (decision D6 / its OpenCV-3.4.0 alternative)
 void lsd_detect_keylines(const Img8& image, std::vector<KeyLine>& keylines, std::vector<Seg4f>* raw);
 void lsd_debug_scaled(const Img8& image, Img8& scaled_out);
 void lbd_compute(const Img8& image, const std::vector<KeyLine>& keylines, std::vector<uint8_t>& desc, std::vector<float>* float_desc);

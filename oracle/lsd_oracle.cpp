@@ -356,7 +356,7 @@ struct Lsd {
         const double sigma = SIGMA_SCALE / SCALE;
         const double sprec = 3;
         const unsigned hk = (unsigned)(std::ceil(sigma * std::sqrt(2 * sprec * std::log(10.0))));
-        Img8 g = gaussian_blur_8u(image, 1 + 2 * hk, sigma);          // D6
+        Img8 g = gaussian_blur_8u(image, 1 + 2 * hk, sigma, g_gaussVariant);          // D6 (sigma 0.75, n 7: both variants give 0 4 56 136 56 4 0)
         scaled = resize_linear_exact_8u(g, SCALE, SCALE);            // D7
         w = scaled.w; h = scaled.h;
         ll_angle(rho);
@@ -441,7 +441,7 @@ void lsd_debug_scaled(const Img8& image, Img8& scaled_out) {
     Lsd lsd;
     const double sigma = lsd.SIGMA_SCALE / lsd.SCALE;
     const unsigned hk = (unsigned)(std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0))));
-    scaled_out = resize_linear_exact_8u(gaussian_blur_8u(image, 1 + 2 * hk, sigma), lsd.SCALE, lsd.SCALE);
+    scaled_out = resize_linear_exact_8u(gaussian_blur_8u(image, 1 + 2 * hk, sigma, g_gaussVariant), lsd.SCALE, lsd.SCALE);
 }
 
 }  // namespace orc

@@ -16,12 +16,13 @@
 // larger), so equal-size nodes are split latest-created first.
 #include "oracle.h"
 #include "cvleaf.h"
+#include "lines_types.h"
 #include <list>
 #include <utility>
 
 namespace orc {
 
-static int g_gaussVariant = 0;      // decision D6 (0) or its OpenCV-3.4.0 alternative (1): cvleaf.h, orc_set_gauss_variant
+int g_gaussVariant = 0;      // decision D6 (0) or its OpenCV-3.4.0 alternative (1) for EVERY 8-bit GaussianBlur of the path (ORB 7x7 sigma 2, LSD 7x7 sigma 0.75, LBD 5x5 sigma 1): cvleaf.h, orc_set_gauss_variant
 
 static const int kPattern[1024] = {
 #include "orb_pattern.inc"

@@ -547,6 +547,12 @@ extern "C" int sslam_frontend_batch_sharded(sslam_group* g, const sslam_frontend
             if (m.orb) { sslam_orb_destroy(m.orb); m.orb = nullptr; }
             int rc = sslam_orb_create(m.ctx, prm->nfeatures, prm->scale_factor, prm->nlevels, prm->ini_th_fast, prm->min_th_fast, &m.orb);
             if (rc == SSLAM_OK && lines) rc = sslam_lines_create(m.ctx, prm->max_lines, &m.lines);
+            // sslam_frontend_params has no field for it (its layout is part of the ABI): the members' extractors take the Gaussian variant from the environment,
+            // like the drop-in classes do (SSLAM_ORB_BLUR_VARIANT=1: OpenCV 3.4.0's rounded taps, include/sslam_frontend.h)
+            if (const char* e = getenv("SSLAM_ORB_BLUR_VARIANT")) {
+                if (rc == SSLAM_OK) rc = sslam_orb_set_blur_variant(m.orb, atoi(e));
+                if (rc == SSLAM_OK && m.lines) rc = sslam_lines_set_blur_variant(m.lines, atoi(e));
+            }
             if (rc != SSLAM_OK) { g->haveParams = false; return rc; }
         }
         g->params = *prm; g->haveParams = true;

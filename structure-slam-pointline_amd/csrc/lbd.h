@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ 
         unsigned d0, d1, d2;
         load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, d0, d1, d2);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) hb[r % 5][c] = hdot(d0, d1, d2, c + 1, T0, T1);      // columns x4+c-3 .. x4+c+1 (sums fit 16 bits: taps sum to 256)
+        for (int c = 0; c < 6; ++c) hb[r % 5][c] = hdot(d0, d1, d2, c + 1, T0, T1);      // columns x4+c-3 .. x4+c+1 (sums fit 16 bits: taps sum to 256 or 257)
         if (r >= 4) {
             const int q = r - 4;                           // blurred row y0 - 1 + q
 #pragma unroll
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ 
                 unsigned acc = 0;
 #pragma unroll
                 for (int k = 0; k < 5; ++k) acc += hb[(q + k) % 5][c] * taps[k];
-                bl[q % 3][c] = (int)(((acc + 32768u) >> 16) & 255u);
+                bl[q % 3][c] = (int)min((acc + 32768u) >> 16, 255u);      // (saturation only bites with taps that sum to 257: blur variant 1)
             }
             if (q >= 2) {
                 const int y = y0 + q - 2;

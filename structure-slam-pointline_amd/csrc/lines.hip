@@ -76,6 +76,7 @@ struct sslam_lines {
     DevBuf dImg, dKl, dDesc, dFn, dCounts;
     HostPinned hOut;
     bool constsUploaded = false;
+    int blurVariant = 0;            // sslam_lines_set_blur_variant
 };
 
 static std::vector<int> taps_q8(int n, double sigma) {
@@ -90,6 +91,16 @@ static std::vector<int> taps_q8(int n, double sigma) {
         err = adj - v; t[i] = t[n - 1 - i] = v; isum += v;
     }
     t[n / 2] = (int)(256 - 2 * isum);
+    return t;
+}
+
+// OpenCV 3.4.0's 8-bit Gaussian taps (decision D6's alternative, oracle/cvleaf.h gauss_taps_340): the float kernel times 256, every tap rounded
+static std::vector<int> taps_340(int n, double sigma) {
+    std::vector<float> k(n); double sum = 0; const double s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; k[i] = (float)std::exp(s2 * x * x); sum += k[i]; }
+    sum = 1. / sum;
+    std::vector<int> t(n);
+    for (int i = 0; i < n; ++i) { k[i] = (float)(k[i] * sum); t[i] = (int)lrint((double)k[i] * 256.0); }
     return t;
 }
 
@@ -114,7 +125,10 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     const double sigma = SIGMA_SCALE / SCALE;
     const unsigned hk = (unsigned)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
     if (hk != 3) { set_error("unexpected LSD kernel size"); return SSLAM_ERR_UNSUPPORTED; }
-    std::vector<int> t7 = taps_q8(7, sigma), t5 = taps_q8(5, 1.0);
+    // LSD's pre-blur (sigma 0.75: 0 4 56 136 56 4 0 under both variants) and LBD's (sigma 1: 14 62 104 62 14, or 14 63 103 63 14 under variant 1)
+    std::vector<int> t7 = L->blurVariant == 1 ? taps_340(7, sigma) : taps_q8(7, sigma), t5 = L->blurVariant == 1 ? taps_340(5, 1.0) : taps_q8(5, 1.0);
+    for (int t : t7) if (t < 0 || t > 255) { set_error("blur taps do not fit a byte"); return SSLAM_ERR_UNSUPPORTED; }
+    for (int t : t5) if (t < 0 || t > 255) { set_error("blur taps do not fit a byte"); return SSLAM_ERR_UNSUPPORTED; }
     for (int i = 0; i < 7; ++i) P.blurTaps[i] = t7[i];
     for (int i = 0; i < 5; ++i) P.blur5Taps[i] = t5[i];
     // INTER_LINEAR_EXACT tables (D7)
@@ -178,6 +192,13 @@ extern "C" int sslam_lines_create(sslam_ctx* ctx, int max_lines, sslam_lines** o
     sslam_lines* L = new sslam_lines();
     L->ctx = ctx; L->maxLines = max_lines;
     *out = L;
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_lines_set_blur_variant(sslam_lines* L, int variant) {
+    if (!L || (variant != 0 && variant != 1)) { set_error("sslam_lines_set_blur_variant: invalid arguments"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::recursive_mutex> lk(L->ctx->mu);
+    if (L->blurVariant != variant) { L->blurVariant = variant; L->planW = L->planH = 0; }      // the taps are part of the plan: rebuilt (and uploaded) by the next extraction
     return SSLAM_OK;
 }
 

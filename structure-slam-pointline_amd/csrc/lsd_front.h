@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, 
                 unsigned acc = 0;
 #pragma unroll
                 for (int k = 0; k < 7; ++k) acc += win[(r - 2 * R + k) % 7][j] * taps[k];
-                o[j] = (acc + 32768u) >> 16;
+                o[j] = min((acc + 32768u) >> 16, 255u);
             }
             uint8_t* dp = d + (size_t)y * dpitch + x4;
             if (x4 + 3 < w) *(unsigned*)dp = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);      // dpitch % 64 == 0, x4 % 4 == 0

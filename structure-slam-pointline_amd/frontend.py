@@ -457,6 +457,10 @@ class LineExtractor:
                                                  int(nframes), _p(d_kl), _p(d_ldesc), _p(d_linefn), _p(d_counts), int(cap),
                                                  C.c_void_p(stream or 0)))
 
+    def set_blur_variant(self, variant):
+        """0: OpenCV >= 3.4.1's bit-exact 8-bit GaussianBlur (default, decision D6); 1: OpenCV 3.4.0's rounded taps (sslam_lines_set_blur_variant)"""
+        _chk(lib().sslam_lines_set_blur_variant(self.h, int(variant)))
+
     def set_core_event(self, hip_event):
         """hipEvent_t handle (int) recorded right before the sequential LSD core of every following batch call; 0 / None clears it"""
         _chk(lib().sslam_lines_set_core_event(self.h, C.c_void_p(int(hip_event or 0))))

@@ -27,7 +27,10 @@ struct Global {
     sslam_lines* getLines() {
         sslam_ctx* c = get();
         std::lock_guard<std::mutex> lk(mu);
-        if (!lines && sslam_lines_create(c, maxLines, &lines) != SSLAM_OK) throw std::runtime_error(sslam_last_error());
+        if (!lines) {
+            if (sslam_lines_create(c, maxLines, &lines) != SSLAM_OK) throw std::runtime_error(sslam_last_error());
+            if (const char* e = std::getenv("SSLAM_ORB_BLUR_VARIANT")) if (sslam_lines_set_blur_variant(lines, std::atoi(e)) != SSLAM_OK) throw std::runtime_error(sslam_last_error());      // one knob for both extractors: the OpenCV release behind the reference build
+        }
         return lines;
     }
 } G;

@@ -214,3 +214,30 @@ def test_nfa_stage_launch_forms(fe, ctx, oracle, knob, monkeypatch):
     monkeypatch.setenv(*knob)
     for img, cap in [(synth_frame(2000), 200), (synth_frame(1235, w=1280, h=960), 400), (noise_frame(3, w=320, h=240), 200), (synth_frame(91, w=333, h=251), 40)]:
         _cmp_lines(fe, ctx, oracle, img, cap)
+
+
+def test_lines_blur_variant_opencv_340(fe, ctx, oracle):
+    """sslam_lines_set_blur_variant(1): LBD's 5x5 pre-blur with OpenCV 3.4.0's rounded taps (14 63 103 63 14).  LSD's own pre-blur has the same taps under both
+    variants, so the segments and keylines are unchanged; the LBD bytes follow the oracle's variant 1 and come back when the variant is switched back."""
+    for img, cap in ((synth_frame(2000), 200), (np.full((240, 320), 255, np.uint8), 40), (synth_frame(91, w=333, h=251), 40)):
+        ex = fe.LineExtractor(ctx, cap)
+        try:
+            kl0, ld0, fn0 = ex(img)
+            ex.set_blur_variant(1)
+            kl1, ld1, fn1 = ex(img)
+            try:
+                oracle.set_gauss_variant(1)
+                okl, old, ofn, oraw = oracle.lines_extract(img, cap)
+            finally:
+                oracle.set_gauss_variant(0)
+            np.testing.assert_array_equal(ex.debug_segments(0), oraw)
+            assert len(kl1) == len(okl) == len(kl0)
+            same = kl1["angle"].view(np.uint32) == okl["angle"].view(np.uint32)
+            np.testing.assert_array_equal(ld1[same], old[same]); np.testing.assert_array_equal(fn1, ofn)
+            if len(kl0) > 20:
+                assert (ld1 != ld0).any()
+            ex.set_blur_variant(0)
+            kl2, ld2, fn2 = ex(img)
+            np.testing.assert_array_equal(ld2, ld0)
+        finally:
+            ex.close()

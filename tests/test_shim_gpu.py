@@ -9,8 +9,19 @@ from synth import synth_frame, warp_prev, synthetic_vocab, write_vocab_text
 pytestmark = pytest.mark.gpu
 
 
-def test_cpp_shim_end_to_end(oracle):
+@pytest.mark.parametrize("blur_variant", [0, 1])
+def test_cpp_shim_end_to_end(oracle, blur_variant):
+    """blur_variant 1: the drop-in classes read SSLAM_ORB_BLUR_VARIANT in their constructors (OpenCV 3.4.0's 8-bit GaussianBlur for the rBRIEF and LBD
+    pre-blurs, include/sslam_frontend.h); everything downstream (matches, distinctive descriptor, BoW) is then compared with the oracle under the same variant."""
     exe = pkg.builder().build_shim(force=False, verbose=False)
+    prev_variant = oracle.set_gauss_variant(blur_variant)
+    try:
+        _shim_end_to_end(oracle, exe, blur_variant)
+    finally:
+        oracle.set_gauss_variant(prev_variant)
+
+
+def _shim_end_to_end(oracle, exe, blur_variant):
     cur = synth_frame(1234); prev = warp_prev(cur)
     with tempfile.TemporaryDirectory() as d:
         cur.tofile(os.path.join(d, "cur.raw")); prev.tofile(os.path.join(d, "prev.raw"))
@@ -19,7 +30,9 @@ def test_cpp_shim_end_to_end(oracle):
         L, ptr, ch, nd, word, weight = synthetic_vocab(rng, k=8, L=3)
         vpath = os.path.join(d, "voc.txt"); write_vocab_text(vpath, 8, L, ptr, ch, nd, weight, weight_fmt="%.6g")
         ov = oracle.vocab_load_text(vpath)
-        r = subprocess.run([exe, os.path.join(d, "cur.raw"), "640", "480", os.path.join(d, "prev.raw"), out, "1000", "40", vpath], capture_output=True, text=True, timeout=300)
+        env = dict(os.environ)
+        if blur_variant: env["SSLAM_ORB_BLUR_VARIANT"] = str(blur_variant)
+        r = subprocess.run([exe, os.path.join(d, "cur.raw"), "640", "480", os.path.join(d, "prev.raw"), out, "1000", "40", vpath], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         rd = lambda n, dt: np.fromfile(out + "_" + n + ".bin", dtype=dt)
         meta = rd("meta", np.int32)
