@@ -18,6 +18,8 @@
 #include "lines_types.h"
 
 namespace orc {
+int g_lsdSeedSort = 0;      // 0: decision D2 (stable: raster order inside a bin); 1: upstream's std::sort (error bar only)
+
 
 static const double NOTDEF = -1024.0;
 static const double M_3_2_PI = (3 * M_PI) / 2, M_2__PI = 2 * M_PI, DEG_TO_RADS = M_PI / 180;
@@ -94,6 +96,22 @@ struct Lsd {
             }
         }
         double bin_coef = (max_grad > 0) ? double(N_BINS - 1) / max_grad : 0;
+        order.clear();
+        if (g_lsdSeedSort == 1) {
+            // Decision D2's alternative, for its error bar only (orc_set_lsd_seed_sort(1)): upstream (UPSTREAM-RECALL, imgproc/src/lsd.cpp ll_angle) fills a vector of
+            // {point, bin} in raster order and calls std::sort with `a.norm > b.norm` -- an UNSTABLE introsort, so the order inside a bin is whatever libstdc++'s
+            // algorithm leaves (median-of-three quicksort to depth 2 lg n, insertion sort below 16 elements; unchanged since GCC 4).  The library cannot follow it:
+            // the permutation is the result of ~17 n dependent comparisons per frame.
+            struct NormPoint { int x, y, norm; };
+            std::vector<NormPoint> pts; pts.reserve((size_t)(w - 1) * (h - 1));
+            for (int y = 0; y < h - 1; ++y)
+                for (int x = 0; x < w - 1; ++x) {
+                    int i = int(modgrad[(size_t)y * w + x] * bin_coef);
+                    pts.push_back({x, y, i});
+                }
+            std::sort(pts.begin(), pts.end(), [](const NormPoint& a, const NormPoint& b) { return a.norm > b.norm; });
+            for (const NormPoint& q : pts) order.push_back(q.y * w + q.x);
+        } else {
         // counting sort, descending bin, raster order inside a bin (D2)
         std::vector<std::vector<int>> bins(N_BINS);
         for (int y = 0; y < h - 1; ++y)
@@ -103,8 +121,8 @@ struct Lsd {
                 if (i >= N_BINS) i = N_BINS - 1;
                 bins[i].push_back(y * w + x);
             }
-        order.clear();
         for (int b = N_BINS - 1; b >= 0; --b) order.insert(order.end(), bins[b].begin(), bins[b].end());
+        }
     }
 
     void region_grow(int sx, int sy, std::vector<RegionPoint>& reg, double& reg_angle, double prec) {
@@ -423,6 +441,7 @@ void lsd_detect_keylines(const Img8& image, std::vector<KeyLine>& keylines, std:
 }
 
 // test taps: the NFA of (n, k, p) for an image of w x h pixels, and cv::Sobel 3x3 as the LBD stage calls it
+extern "C" int orc_set_lsd_seed_sort(int v) { const int old = orc::g_lsdSeedSort; orc::g_lsdSeedSort = v == 1 ? 1 : 0; return old; }
 extern "C" double orc_lsd_nfa(int w, int h, int n, int k, double p) {
     Lsd lsd; lsd.w = w; lsd.h = h;
     lsd.LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);

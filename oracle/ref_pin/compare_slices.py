@@ -398,5 +398,19 @@ with tempfile.TemporaryDirectory() as td:
 report["d9_trailing_newline"] = d9
 print("D9 (vocabulary file with a trailing newline: the reference reads a phantom node, undefined behaviour):", d9)
 
+# --- D2 (LSD seed order inside a gradient bin): NOT a comparison with reference code -- both sides are the oracle's LSD (UPSTREAM-RECALL), once with the stable order the
+# oracle and the library define, once with upstream's std::sort as recalled.  Recorded as the size of what that decision can move.
+d2 = {"frames": 0, "segments": 0, "segments_in_one_set_only": 0}
+for img in [frames["synth1234"][0], frames["synth2000"][0], frames["big1235"][0], synth_frame(2001), synth_frame(2002), synth_frame(91, w=333, h=251),
+            np.load(os.path.join(HERE, "..", "..", "tests", "golden", "icl_input_gray.npz"))["gray"]]:
+    a = orc.lines_extract(img, 400)[3]
+    O.orc_set_lsd_seed_sort(1)
+    try: b = orc.lines_extract(img, 400)[3]
+    finally: O.orc_set_lsd_seed_sort(0)
+    sa = set(map(bytes, a.view(np.uint8).reshape(len(a), -1))); sb = set(map(bytes, b.view(np.uint8).reshape(len(b), -1)))
+    d2["frames"] += 1; d2["segments"] += len(sa); d2["segments_in_one_set_only"] += len(sa ^ sb)
+report["d2_error_bar_oracle_only"] = d2
+print("D2 (stable seed order vs upstream's std::sort, oracle against oracle):", d2)
+
 json.dump(report, open(report_path, "w"), indent=1)
 print("reference slices == oracle on every case:", report["all_equal"])
