@@ -1,0 +1,107 @@
+#!/bin/bash
+# The individual gpurun calls of round 4 besides the main recipe (tools/gpu_profile_r04.sh), as sections of one script:
+#     gpurun --timeout 2400 -- 'bash tools/gpu_r04_experiments.sh <section>'
+# Outputs land in gpurun_out/r04<section>/; the tables and logs that matter were copied to profiles/ (profiles/README.md, round 4).
+set -x
+R=$GRAFT_REPO_ROOT; cd $R
+case "$1" in
+a)
+# round 4, first GPU call: fused NFA launch + k_keylines LDS fix -- parity (fused form forced on the small test batches), then A/B bench lines
+O=$R/gpurun_out/r04a; mkdir -p $O
+SSLAM_NFA_FUSED=2 timeout 900 python -m pytest tests/test_lines_gpu.py tests/test_configs_gpu.py tests/test_batch_gpu.py tests/test_pin_gpu.py -x -q -m gpu > $O/pytest_fused.txt 2>&1; tail -5 $O/pytest_fused.txt
+timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_fused.json 2> $O/bench_fused.err; tail -c 300 $O/bench_fused.err
+SSLAM_NFA_FUSED=0 timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_unfused.json 2>/dev/null
+SSLAM_LIB=$R/structure-slam-pointline_amd/lib/variants/nfa4.so timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_fused_mw4.json 2>/dev/null
+timeout 600 python bench.py --no-overlap --no-cpu-baseline --no-extras > $O/bench_fused_one_stream.json 2>/dev/null
+SSLAM_LIB=$R/structure-slam-pointline_amd/lib/variants/nfa4.so timeout 600 python bench.py --no-overlap --no-cpu-baseline --no-extras > $O/bench_fused_mw4_one_stream.json 2>/dev/null
+python - <<'PY'
+import json
+for n in ('bench_fused','bench_unfused','bench_fused_mw4','bench_fused_one_stream','bench_fused_mw4_one_stream'):
+    try:
+        d=json.load(open('gpurun_out/r04a/%s.json'%n)); k=d['roofline']['kernels_ms_per_step']
+        print(n, round(d['value']), round(d['ms_per_step'],1), {a: round(b,1) for a,b in k.items() if b>0.5})
+    except Exception as e: print(n, 'failed', e)
+PY
+;;
+b)
+# round 4, call b: the in-process RCCL stand-in (N > 1 group paths), the stress / fuzz tests of the driver-run suite, bench line with other_workloads
+O=$R/gpurun_out/r04b; mkdir -p $O
+timeout 900 python -m pytest tests/test_group_gpu.py tests/test_pin_gpu.py -x -q -m gpu > $O/pytest_group.txt 2>&1; tail -15 $O/pytest_group.txt
+timeout 900 python -m pytest tests/test_stress_gpu.py -x -q -m gpu -s > $O/pytest_stress.txt 2>&1; tail -8 $O/pytest_stress.txt
+timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r04b/bench.json'))
+print(round(d['value']), d['ms_per_step'], d.get('latency',{}).get('lines_extract_hipEvent'), d.get('other_workloads'))
+print(d.get('cpu_baseline',{}).get('value'), d.get('cpu_baseline',{}).get('parity_vs_gpu'), d.get('pcie_inclusive',{}).get('pinned_frames_per_s'))
+PY
+;;
+c)
+# round 4, call c: stand-in RCCL tests (fixed), stress / fuzz tests, NFA launch forms, batch SearchForInitialization in LDS, single-frame latency A/B
+O=$R/gpurun_out/r04c; mkdir -p $O
+timeout 420 python -m pytest tests/test_group_gpu.py -x -q -m gpu > $O/pytest_group.txt 2>&1; tail -4 $O/pytest_group.txt
+timeout 600 python -m pytest tests/test_lines_gpu.py tests/test_match_gpu.py tests/test_shim_gpu.py tests/test_batch_gpu.py -x -q -m gpu > $O/pytest_a.txt 2>&1; tail -4 $O/pytest_a.txt
+timeout 400 python -m pytest tests/test_stress_gpu.py -x -q -m gpu -s > $O/pytest_stress.txt 2>&1; tail -4 $O/pytest_stress.txt
+for v in "def:" "old:SSLAM_NFA_FUSED=0" "old256:SSLAM_NFA_FUSED=0 SSLAM_COUNT_WAVES=256 SSLAM_EVAL_WAVES=64" "old128:SSLAM_NFA_FUSED=0 SSLAM_COUNT_WAVES=128 SSLAM_EVAL_WAVES=32" "wg8:SSLAM_NFA_WAVES=8"; do
+  n=${v%%:*}; e=${v#*:}
+  env $e timeout 200 python tools/latency_probe.py > $O/lat_$n.txt 2>&1; tail -1 $O/lat_$n.txt
+done
+timeout 300 python bench.py --no-cpu-baseline --no-extras --no-overlap > $O/bench_one_stream.json 2>/dev/null
+SSLAM_SFI_BATCH=global timeout 300 python bench.py --no-cpu-baseline --no-extras --no-overlap > $O/bench_one_stream_sfi_global.json 2>/dev/null
+timeout 300 python bench.py --no-cpu-baseline --no-extras > $O/bench_two_streams.json 2>/dev/null
+python - <<'PY'
+import json
+for n in ('bench_one_stream','bench_one_stream_sfi_global','bench_two_streams'):
+    try:
+        d=json.load(open('gpurun_out/r04c/%s.json'%n)); k=d['roofline']['kernels_ms_per_step']
+        print(n, round(d['value']), round(d['ms_per_step'],1), {a: round(b,1) for a,b in k.items() if b>0.5})
+    except Exception as e: print(n, 'failed', e)
+PY
+;;
+d)
+# round 4, call d: the sequential core at 7 / 8 waves per SIMD (72 / 64 VGPRs) against 6, at the bench's batch and at batches that fill the larger slot counts; group test re-run
+O=$R/gpurun_out/r04d; mkdir -p $O
+timeout 420 python -m pytest tests/test_group_gpu.py -x -q -m gpu > $O/pytest_group.txt 2>&1; tail -3 $O/pytest_group.txt
+V=$R/structure-slam-pointline_amd/lib/variants
+for v in "w6:" "w7:SSLAM_LIB=$V/core7.so" "w8:SSLAM_LIB=$V/core8.so"; do
+  n=${v%%:*}; e=${v#*:}
+  env $e timeout 300 python bench.py --no-cpu-baseline --no-extras > $O/bench_$n.json 2>/dev/null
+  env $e timeout 300 python bench.py --no-cpu-baseline --no-extras --no-overlap > $O/bench_${n}_one.json 2>/dev/null
+done
+SSLAM_LIB=$V/core7.so timeout 300 python bench.py --no-cpu-baseline --no-extras --batch 14336 > $O/bench_w7_B14336.json 2>/dev/null
+SSLAM_LIB=$V/core8.so timeout 300 python bench.py --no-cpu-baseline --no-extras --batch 16384 > $O/bench_w8_B16384.json 2>/dev/null
+SSLAM_LIB=$V/core7.so timeout 300 python -m pytest tests/test_lines_gpu.py tests/test_batch_gpu.py -x -q -m gpu > $O/pytest_w7.txt 2>&1; tail -2 $O/pytest_w7.txt
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob('gpurun_out/r04d/bench_*.json')):
+    try:
+        d=json.load(open(f)); k=d['roofline']['kernels_ms_per_step']
+        print(f.split('/')[-1], d['config']['batch_per_gpu'], round(d['value']), round(d['ms_per_step'],1), 'core', round(k.get('k_lsd_regions',0),1))
+    except Exception as e: print(f, 'failed', e)
+PY
+;;
+e)
+# round 4, call e: the whole GPU suite on the final tree (log kept in profiles/), smoke
+O=$R/gpurun_out/r04e; mkdir -p $O
+timeout 1500 python -m pytest tests -q -m gpu --durations=5 > $O/pytest_gpu.txt 2>&1; tail -12 $O/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
+;;
+f)
+# round 4, call f: the long randomised sweeps on the final kernels (logs -> profiles/r04_fuzz_*)
+O=$R/gpurun_out/r04f; mkdir -p $O
+timeout 900 python tools/fuzz_parity.py 1500 20260926 > $O/fuzz_parity_1500.txt 2>&1; tail -2 $O/fuzz_parity_1500.txt
+timeout 600 python tools/fuzz_matchers.py > $O/fuzz_matchers.txt 2>&1; tail -2 $O/fuzz_matchers.txt
+timeout 600 python tools/fuzz_reuse.py > $O/fuzz_reuse.txt 2>&1; tail -1 $O/fuzz_reuse.txt
+timeout 300 python tools/cl_stress.py 300 6 > $O/cl_stress.txt 2>&1; tail -1 $O/cl_stress.txt
+timeout 300 python tools/bench_matchers.py > $O/matchers.txt 2>&1; tail -14 $O/matchers.txt
+;;
+g)
+# round 4, call g: the Gaussian-variant tests + the suites their kernels touch
+O=$R/gpurun_out/r04g; mkdir -p $O
+timeout 900 python -m pytest tests/test_orb_gpu.py tests/test_lines_gpu.py tests/test_configs_gpu.py tests/test_batch_gpu.py tests/test_shim_gpu.py tests/test_pin_gpu.py tests/test_group_gpu.py -x -q -m gpu > $O/pytest.txt 2>&1; tail -5 $O/pytest.txt
+SSLAM_ORB_BLUR_VARIANT=1 timeout 300 python -m pytest tests/test_shim_gpu.py -x -q -m gpu -k end_to_end > $O/pytest_shim_v1.txt 2>&1; tail -3 $O/pytest_shim_v1.txt
+timeout 300 python bench.py --no-cpu-baseline --no-extras > $O/bench.json 2>/dev/null; python -c "
+import json; d=json.load(open('$O/bench.json')); print(round(d['value']), d['ms_per_step'])"
+;;
+*) echo "usage: $0 {a|b|c|d|e|f|g}"; exit 2 ;;
+esac
