@@ -18,6 +18,7 @@
 #include "lines_types.h"
 
 namespace orc {
+int g_lsdResize = 0;        // 0: decision D7 (INTER_LINEAR_EXACT); 1: INTER_LINEAR (error bar only)
 int g_lsdSeedSort = 0;      // 0: decision D2 (stable: raster order inside a bin); 1: upstream's std::sort (error bar only)
 
 
@@ -375,7 +376,8 @@ struct Lsd {
         const double sprec = 3;
         const unsigned hk = (unsigned)(std::ceil(sigma * std::sqrt(2 * sprec * std::log(10.0))));
         Img8 g = gaussian_blur_8u(image, 1 + 2 * hk, sigma, g_gaussVariant);          // D6 (sigma 0.75, n 7: both variants give 0 4 56 136 56 4 0)
-        scaled = resize_linear_exact_8u(g, SCALE, SCALE);            // D7
+        // D7; its alternative (orc_set_lsd_resize(1), error bar only): plain INTER_LINEAR, the 11-bit fixed-point resize of the ORB pyramid, with the same output size
+        scaled = g_lsdResize == 1 ? resize_linear_8u(g, cv_round(g.w * SCALE), cv_round(g.h * SCALE)) : resize_linear_exact_8u(g, SCALE, SCALE);
         w = scaled.w; h = scaled.h;
         ll_angle(rho);
         LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
@@ -441,6 +443,7 @@ void lsd_detect_keylines(const Img8& image, std::vector<KeyLine>& keylines, std:
 }
 
 // test taps: the NFA of (n, k, p) for an image of w x h pixels, and cv::Sobel 3x3 as the LBD stage calls it
+extern "C" int orc_set_lsd_resize(int v) { const int old = orc::g_lsdResize; orc::g_lsdResize = v == 1 ? 1 : 0; return old; }
 extern "C" int orc_set_lsd_seed_sort(int v) { const int old = orc::g_lsdSeedSort; orc::g_lsdSeedSort = v == 1 ? 1 : 0; return old; }
 extern "C" double orc_lsd_nfa(int w, int h, int n, int k, double p) {
     Lsd lsd; lsd.w = w; lsd.h = h;

@@ -400,15 +400,30 @@ print("D9 (vocabulary file with a trailing newline: the reference reads a phanto
 
 # --- D2 (LSD seed order inside a gradient bin): NOT a comparison with reference code -- both sides are the oracle's LSD (UPSTREAM-RECALL), once with the stable order the
 # oracle and the library define, once with upstream's std::sort as recalled.  Recorded as the size of what that decision can move.
-d2 = {"frames": 0, "segments": 0, "segments_in_one_set_only": 0}
+def unmatched(a, b, tol=1.0):
+    """segments of a without a counterpart in b whose two end points lie within tol pixels (either orientation)"""
+    if len(a) == 0: return 0
+    if len(b) == 0: return len(a)
+    A = a.view(np.float32).reshape(-1, 4).astype(np.float64); B = b.view(np.float32).reshape(-1, 4).astype(np.float64)
+    d1 = np.maximum(np.hypot(A[:, None, 0] - B[None, :, 0], A[:, None, 1] - B[None, :, 1]), np.hypot(A[:, None, 2] - B[None, :, 2], A[:, None, 3] - B[None, :, 3]))
+    d2_ = np.maximum(np.hypot(A[:, None, 0] - B[None, :, 2], A[:, None, 1] - B[None, :, 3]), np.hypot(A[:, None, 2] - B[None, :, 0], A[:, None, 3] - B[None, :, 1]))
+    return int((np.minimum(d1, d2_).min(axis=1) > tol).sum())
+
+
+d2 = {"frames": 0, "segments": 0, "segments_in_one_set_only": 0, "segments_moved_more_than_1px": 0}; d7 = {"frames": 0, "segments": 0, "segments_in_one_set_only": 0, "segments_moved_more_than_1px": 0}
 for img in [frames["synth1234"][0], frames["synth2000"][0], frames["big1235"][0], synth_frame(2001), synth_frame(2002), synth_frame(91, w=333, h=251),
             np.load(os.path.join(HERE, "..", "..", "tests", "golden", "icl_input_gray.npz"))["gray"]]:
     a = orc.lines_extract(img, 400)[3]
-    O.orc_set_lsd_seed_sort(1)
-    try: b = orc.lines_extract(img, 400)[3]
-    finally: O.orc_set_lsd_seed_sort(0)
-    sa = set(map(bytes, a.view(np.uint8).reshape(len(a), -1))); sb = set(map(bytes, b.view(np.uint8).reshape(len(b), -1)))
-    d2["frames"] += 1; d2["segments"] += len(sa); d2["segments_in_one_set_only"] += len(sa ^ sb)
+    sa = set(map(bytes, a.view(np.uint8).reshape(len(a), -1)))
+    for setter, acc in ((O.orc_set_lsd_seed_sort, d2), (O.orc_set_lsd_resize, d7)):
+        setter(1)
+        try: b = orc.lines_extract(img, 400)[3]
+        finally: setter(0)
+        sb = set(map(bytes, b.view(np.uint8).reshape(len(b), -1)))
+        acc["frames"] += 1; acc["segments"] += len(sa); acc["segments_in_one_set_only"] += len(sa ^ sb)
+        acc["segments_moved_more_than_1px"] += unmatched(a, b) + unmatched(b, a)
+report["d7_error_bar_oracle_only"] = d7
+print("D7 (INTER_LINEAR_EXACT vs INTER_LINEAR for LSD's 0.8x scale, oracle against oracle):", d7)
 report["d2_error_bar_oracle_only"] = d2
 print("D2 (stable seed order vs upstream's std::sort, oracle against oracle):", d2)
 
