@@ -77,6 +77,7 @@ struct sslam_lines {
     HostPinned hOut;
     bool constsUploaded = false;
     int blurVariant = 0;            // sslam_lines_set_blur_variant
+    int sMin = 0;                   // smallest |g|^2 of a defined pixel (k_grad_smin, with the gradient table)
 };
 
 static std::vector<int> taps_q8(int n, double sigma) {
@@ -116,7 +117,10 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.spitch = (P.sw + 63) & ~63;
     P.npx = P.sw * P.sh;
     if (P.sw > 65535 || P.sh > 65535) { set_error("image %dx%d too large", w, h); return SSLAM_ERR_UNSUPPORTED; }
-    P.nTiles = (P.npx + TILE_PX - 1) / TILE_PX;
+    P.nXB = (P.sw + 255) / 256;
+    P.tileRows = std::min(64, std::max(1, TILE_PX / P.sw));
+    P.nTiles = (P.sh + P.tileRows - 1) / P.tileRows;
+    if (P.tileRows * P.nXB > MAX_TSEG) { set_error("image %dx%d: too many segments per counting-sort tile", w, h); return SSLAM_ERR_UNSUPPORTED; }
     const double ANG_TH = 22.5, QUANT = 2.0, SIGMA_SCALE = 0.6;
     P.prec = kPI * ANG_TH / 180; P.p = ANG_TH / 180;
     P.rho = QUANT / std::sin(P.prec);
@@ -164,7 +168,9 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offCs = take(sizeof(float2) * (size_t)P.npx);
     P.offOrder = take(sizeof(unsigned) * (size_t)P.npx);
     P.offTileHist = take(sizeof(int) * (size_t)P.nTiles * N_BINS);
-    P.offReg = take(sizeof(unsigned) * (size_t)P.npx);
+    P.offReg = take(sizeof(unsigned) * std::max((size_t)P.npx, (size_t)P.sh * P.nXB * 256));      // region lists beyond QCAP; before the core: the segments' lists
+    P.offComp = P.offReg;
+    P.offSegCnt = take(sizeof(int) * (size_t)P.sh * P.nXB);
     P.offSeg = take(sizeof(float4) * MAX_SEG);
     P.offCand = take(sizeof(double) * 12 * MAX_SEG);      // candidate rectangles (RectD) awaiting the NFA stage, seed order
     P.offFlag = take(sizeof(int) * MAX_SEG);
@@ -173,11 +179,17 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offDxy = take(sizeof(unsigned) * (size_t)w * h);       // Sobel {dx, dy} of the sigma-1 blur, int16 pairs
     P.offKl = take(sizeof(sslam_keyline) * MAX_SEG);
     P.frameBytes = align_up(off, 4096);
-    if (!L->dGtab.p) {   // gradient -> {angle, cos, sin, |g|^2} table (rho depends only on LSD constants)
-        if ((rc = L->dGtab.ensure(sizeof(float4) * (size_t)GT * GT))) return rc;
+    if (!L->dGtab.p) {   // gradient -> {angle, cos, sin, |g|^2} table (rho depends only on LSD constants), and the smallest defined |g|^2 behind it
+        if ((rc = L->dGtab.ensure(sizeof(float4) * ((size_t)GT * GT + 1)))) return rc;
+        int* dSmin = (int*)(L->dGtab.as<float4>() + (size_t)GT * GT);
+        const int big = 0x7FFFFFFF;
+        SSLAM_HIP(hipMemcpy(dSmin, &big, sizeof(int), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_grad_table, dim3((GT * GT + 255) / 256), dim3(256), 0, L->ctx->stream, L->dGtab.as<float4>(), P.rho);
+        hipLaunchKernelGGL(k_grad_smin, dim3((2 * 510 * 510 + 256) / 256), dim3(256), 0, L->ctx->stream, dSmin, P.rho);
         SSLAM_HIP(hipStreamSynchronize(L->ctx->stream));
+        SSLAM_HIP(hipMemcpy(&L->sMin, dSmin, sizeof(int), hipMemcpyDeviceToHost));
     }
+    P.sMin = L->sMin;
     {   // log-gamma table for nfa(): arguments are integers in [1, npx+2]
         const int nl = P.npx + 4;
         if ((rc = L->dLgam.ensure(sizeof(double) * (2 * (size_t)nl + 48)))) return rc;

@@ -108,11 +108,23 @@ __global__ void k_grad_table(float4* __restrict__ tab, double rho) {
     tab[i] = make_float4(a, cs, sn, __int_as_float(s));
 }
 
-// One thread = four horizontally adjacent pixels: the 2x5 source bytes come from two dword + two byte loads, the four
-// table gathers are in flight together.  Outputs (16 B per pixel; 24 in rounds 1-2): the T plane (angle, NOTDEF), the Cs plane
-// (cos, sin) and the sort key S[i] = |g|^2 for DEFINED pixels and -1 otherwise (lsd_plan.h).
-// The 0.8x INTER_LINEAR_EXACT image (D7) is never stored: this kernel is bound by its writes, so the 2 x 5
-// scaled pixels a thread needs are recomputed here from the blurred source (four source rows as three aligned dwords each).
+// smallest |g|^2 of a DEFINED pixel: "sqrt(s / 4.0) > rho" is monotone in the integer s, so the table's test is "s >= sMin"
+__global__ void k_grad_smin(int* __restrict__ out, double rho) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s <= 2 * 510 * 510 && sqrt((double)s / 4.0) > rho) atomicMin(out, s);
+}
+
+// One thread = four horizontally adjacent pixels, one wave = 256 pixels of one row (a SEGMENT): the 2x5 source bytes come from two dword +
+// two byte loads.  Round 4 (second half): only 10-20 % of the pixels of a frame are DEFINED (|g|/2 > rho), and everything but the angle plane
+// is read for defined pixels only, so
+//   * T (angle, NOTDEF) is the one plane written densely (4 B per pixel);
+//   * the table gather, the Cs pair and the S value exist only for lanes that hold a defined pixel (undefined pixels keep whatever the
+//     workspace held: region growing tests T before it looks at Cs, region2rect reads S at region pixels);
+//   * the counting sort no longer streams a dense S plane twice: each wave appends its defined pixels, in raster order, to the segment's
+//     list (ballot-free: a DPP prefix sum of the lanes' counts) as |g|^2 << 8 | column-in-segment, and stores the segment's count.
+// 16 B written per pixel in round 3 (24 in rounds 1-2); now 4 B + ~24 B per defined pixel.
+// The 0.8x INTER_LINEAR_EXACT image (D7) is never stored: the 2 x 5 scaled pixels a thread needs are recomputed here from the blurred
+// source (four source rows as three aligned dwords each).
 __device__ __forceinline__ int scaled_px(unsigned e0, unsigned e1, unsigned cx, unsigned cy) {      // e = {p0, p1} bytes of the two source rows
     const unsigned r0 = (e0 & 255u) * (256u - cx) + ((e0 >> 8) & 255u) * cx, r1 = (e1 & 255u) * (256u - cx) + ((e1 >> 8) & 255u) * cx;
     return (int)((r0 * (256u - cy) + r1 * cy + 32768u) >> 16);
@@ -128,12 +140,12 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
     Misc* misc = (Misc*)(base + P.offMisc);
     const int lane = threadIdx.x, tyy = threadIdx.y;
     const int y = blockIdx.y * 4 + tyy, x4 = (blockIdx.x * 64 + lane) * 4;
-    __shared__ float4 stC[4][2 * 64];      // per wave: the {cos, sin} pairs of its 256 pixels, transposed for contiguous stores (below)
-    float4 rec[4];
+    if (y >= P.sh) return;                                  // the whole wave
+    float ang[4]; float2 cs[4]; int sv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rec[j] = make_float4(NOTDEF_F, 0.f, 0.f, 0.f);
-    int smax = 0;
-    if (y < P.sh && x4 < P.sw) {
+    for (int j = 0; j < 4; ++j) { ang[j] = NOTDEF_F; cs[j] = make_float2(0.f, 0.f); sv[j] = -1; }
+    unsigned flags = 0;                                     // bit j: pixel x4 + j is defined
+    if (x4 < P.sw) {
         const bool lastRow = y >= P.sh - 1;
         const int2 ty0 = ((const int2*)ty)[y], ty1 = ((const int2*)ty)[min(y + 1, P.sh - 1)];
         int2 txv[5];
@@ -161,49 +173,43 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
                 p1[j] = scaled_px(rw[2][sx] | ((unsigned)rw[2][sx1] << 8), rw[3][sx] | ((unsigned)rw[3][sx1] << 8), (unsigned)txv[j].y, (unsigned)ty1.y);
             }
         }
+        int gidx[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int DA = p1[j + 1] - p0[j], BC = p0[j + 1] - p1[j];
-            const int gx = DA + BC, gy = DA - BC;
-            const bool in = !lastRow && x4 + j < P.sw - 1;
-            if (in) rec[j] = gtab[(gy + 510) * GT + (gx + 510)];
+            const int gx = DA + BC, gy = DA - BC, s = gx * gx + gy * gy;
+            gidx[j] = (gy + 510) * GT + (gx + 510);
+            if (!lastRow && x4 + j < P.sw - 1 && s >= P.sMin) { flags |= 1u << j; sv[j] = s; }
         }
-        int sv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool def = rec[j].x != NOTDEF_F;
-            sv[j] = def ? __float_as_int(rec[j].w) : -1;
-            smax = max(smax, sv[j]);
-        }
+        for (int j = 0; j < 4; ++j)
+            if (flags & (1u << j)) { const float4 rec = gtab[gidx[j]]; ang[j] = rec.x; cs[j] = make_float2(rec.y, rec.z); }      // the four gathers are in flight together
         const size_t i = (size_t)y * P.sw + x4;
-        if ((P.sw & 3) == 0) *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
-        else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) S[i + j] = sv[j];
-        }
-    }
-    if (y < P.sh) {
-        const size_t i = (size_t)y * P.sw + x4;
-        if ((P.sw & 255) == 0) {
-            // T: one 16-byte store per lane, 1 KB contiguous per instruction.  Cs: a lane's four pairs are 32 bytes -- stored directly,
-            // each of the two store instructions would write 16 of every 32 bytes; through the wave's own 2 KB of LDS (in-order DS, no
-            // workgroup barrier) each instruction writes 1 KB contiguous
-            *(float4*)(T + i) = make_float4(rec[0].x, rec[1].x, rec[2].x, rec[3].x);
-            float4* t = stC[tyy];
-            t[lane] = make_float4(rec[0].y, rec[0].z, rec[1].y, rec[1].z);
-            t[64 + lane] = make_float4(rec[2].y, rec[2].z, rec[3].y, rec[3].z);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            float4* row = (float4*)(Cs + (size_t)y * P.sw + (size_t)blockIdx.x * 256);      // 128 float4 per wave: element e = pixels 2e, 2e + 1
-            row[lane] = t[(lane & 1) * 64 + (lane >> 1)];
-            row[64 + lane] = t[(lane & 1) * 64 + 32 + (lane >> 1)];
+        if ((P.sw & 3) == 0) {
+            *(float4*)(T + i) = make_float4(ang[0], ang[1], ang[2], ang[3]);
+            if (flags) {
+                *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
+                float4* c = (float4*)(Cs + i);
+                c[0] = make_float4(cs[0].x, cs[0].y, cs[1].x, cs[1].y);
+                c[1] = make_float4(cs[2].x, cs[2].y, cs[3].x, cs[3].y);
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) { T[i + j] = rec[j].x; Cs[i + j] = make_float2(rec[j].y, rec[j].z); }
+            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) {
+                T[i + j] = ang[j];
+                if (flags & (1u << j)) { S[i + j] = sv[j]; Cs[i + j] = cs[j]; }
+            }
         }
     }
-    smax = wave_max(smax);
+    // the segment's list of defined pixels, raster order = lane order, then column inside the lane
+    const int seg = y * P.nXB + blockIdx.x;
+    const int cnt = __popc(flags), incl = wave_incl_scan(cnt);
+    unsigned* dst = (unsigned*)(base + P.offComp) + ((size_t)seg << 8);
+    int pos = incl - cnt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (flags & (1u << j)) dst[pos++] = ((unsigned)sv[j] << 8) | (unsigned)(4 * lane + j);
+    if (lane == 63) ((int*)(base + P.offSegCnt))[seg] = incl;
+    const int smax = wave_max(max(max(sv[0], sv[1]), max(sv[2], sv[3])));
     if (lane == 0 && smax > 0) atomicMax(&misc->maxS, smax);
 }
 
@@ -215,25 +221,56 @@ __device__ __forceinline__ double lsd_bin_coef(int maxS) {
     return maxS > 0 ? (double)(N_BINS - 1) / sqrt((double)maxS / 4.0) : 0.0;
 }
 
-// stable counting sort of the DEFINED pixels by descending bin, raster order inside a bin (D2):
-// per-tile histograms -> scan -> stable scatter.
+// stable counting sort of the DEFINED pixels by descending bin, raster order inside a bin (D2): per-tile histograms -> scan -> stable
+// scatter.  A tile = P.tileRows whole rows = the consecutive segments [seg0, seg0 + nseg) of k_lsd_grad's lists; both kernels walk the
+// tile's entries as one flat sequence (exclusive prefix sums of the segment counts in LDS; a lane's segment cursor only moves forward).
+constexpr int MAX_TSEG = 256;           // segments per tile (lines_build_plan)
+__device__ __forceinline__ int tile_segments(const int* __restrict__ segCnt, int seg0, int nseg, int* __restrict__ pref, int lane) {
+    int carry = 0;
+    for (int s0 = 0; s0 < nseg; s0 += 64) {
+        const int s = s0 + lane;
+        const int c = s < nseg ? segCnt[seg0 + s] : 0;
+        const int incl = wave_incl_scan(c);
+        if (s < nseg) pref[s] = carry + incl - c;
+        carry += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (lane == 0) pref[nseg] = carry;
+    return carry;
+}
+
+// histogram pass: bins the entries once (the fp64 square root) and leaves bin << 8 | column in place of |g|^2 << 8 | column for the scatter pass
 __global__ __launch_bounds__(64) void k_lsd_hist(uint8_t* __restrict__ ws, LsdPlan P) {
     __shared__ int hist[N_BINS];
+    __shared__ int pref[MAX_TSEG + 1];
     const int tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
-    const int* S = (const int*)(base + P.offS);
     const Misc* misc = (const Misc*)(base + P.offMisc);
+    unsigned* comp = (unsigned*)(base + P.offComp);
     int* th = (int*)(base + P.offTileHist) + (size_t)tile * N_BINS;
     for (int i = lane; i < N_BINS; i += 64) hist[i] = 0;
+    const int r0 = tile * P.tileRows, r1 = min(P.sh, r0 + P.tileRows), seg0 = r0 * P.nXB, nseg = (r1 - r0) * P.nXB;
+    const int total = tile_segments((const int*)(base + P.offSegCnt), seg0, nseg, pref, lane);
     __syncthreads();
     const double bc = lsd_bin_coef(misc->maxS);
-    const int beg = tile * TILE_PX, end = min(beg + TILE_PX, P.npx);
-    for (int i0 = beg; i0 < end; i0 += 512) {            // eight coalesced loads in flight per lane (order is irrelevant here)
-        int v[8];
+    int sgi = 0;
+    for (int e0 = 0; e0 < total; e0 += 256) {            // four loads in flight per lane
+        unsigned* p[4]; unsigned ent[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const int i = i0 + k * 64 + lane; v[k] = i < end ? S[i] : -1; }
+        for (int k = 0; k < 4; ++k) {
+            const int e = e0 + k * 64 + lane;
+            p[k] = nullptr; ent[k] = 0;
+            if (e < total) {
+                while (e >= pref[sgi + 1]) ++sgi;
+                p[k] = comp + ((size_t)(seg0 + sgi) << 8) + (e - pref[sgi]);
+                ent[k] = *p[k];
+            }
+        }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (v[k] >= 0) atomicAdd(&hist[lsd_bin(v[k], bc)], 1);
+        for (int k = 0; k < 4; ++k) if (p[k]) {
+            const int bin = lsd_bin((int)(ent[k] >> 8), bc);
+            atomicAdd(&hist[bin], 1);
+            *p[k] = ((unsigned)bin << 8) | (ent[k] & 255u);
+        }
     }
     __syncthreads();
     for (int i = lane; i < N_BINS; i += 64) th[i] = hist[i];
@@ -265,49 +302,60 @@ __global__ __launch_bounds__(1024) void k_lsd_scan(uint8_t* __restrict__ ws, Lsd
     if (t == 1023) misc->nDefined = part[1023];
 }
 
-// One wave per tile walks its pixels in raster order, 64 at a time (four such groups are loaded ahead).  Inside a group
-// the rank of a pixel among the lanes of the same bin comes from ballots; the wave's LDS accesses execute in program order,
-// so the cursor read / write-back needs no barrier.
+// which lanes hold the same 10-bit key: one ballot per key bit, every lane keeps the lanes that agree with it on that bit (`own` is 0 or
+// -1: m ^ own is m or ~m) -- 60 lane-parallel instructions per 64 entries, where a leader loop runs once per DISTINCT key (round 3: ~10
+// dependent instructions for each of up to 64 bins)
+__device__ __forceinline__ unsigned long long same_key10(int key, unsigned long long valid) {
+    unsigned lo = (unsigned)valid, hi = (unsigned)(valid >> 32);
+#pragma unroll
+    for (int bit = 0; bit < 10; ++bit) {
+        const int own = -((key >> bit) & 1);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(own != 0);
+        lo &= ~((unsigned)m ^ (unsigned)own); hi &= ~((unsigned)(m >> 32) ^ (unsigned)own);
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// One wave per tile walks its entries in raster order, 64 at a time (four such groups are loaded ahead).  Inside a group the rank of an
+// entry among the lanes of the same bin comes from same_key10; the wave's LDS accesses execute in program order, so the cursor read /
+// write-back needs no barrier.
 __global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, LsdPlan P) {
     __shared__ int cursor[N_BINS];
+    __shared__ int pref[MAX_TSEG + 1];
+    __shared__ unsigned segXY[MAX_TSEG];      // first column | row << 16 of each segment of the tile
     const int tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
-    const int* S = (const int*)(base + P.offS);
-    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const unsigned* comp = (const unsigned*)(base + P.offComp);
     const int* th = (const int*)(base + P.offTileHist) + (size_t)tile * N_BINS;
     unsigned* order = (unsigned*)(base + P.offOrder);
     for (int i = lane; i < N_BINS; i += 64) cursor[i] = th[i];
+    const int r0 = tile * P.tileRows, r1 = min(P.sh, r0 + P.tileRows), seg0 = r0 * P.nXB, nseg = (r1 - r0) * P.nXB;
+    for (int s = lane; s < nseg; s += 64) { const int r = s / P.nXB; segXY[s] = (unsigned)((s - r * P.nXB) << 8) | ((unsigned)(r0 + r) << 16); }
+    const int total = tile_segments((const int*)(base + P.offSegCnt), seg0, nseg, pref, lane);
     __syncthreads();
-    const double bc = lsd_bin_coef(misc->maxS);
-    const int beg = tile * TILE_PX, end = min(beg + TILE_PX, P.npx);
-    const int y0 = beg / P.sw, x0 = beg - y0 * P.sw;
-    const float rsw = 1.0f / (float)P.sw;
-    for (int i0 = beg; i0 < end; i0 += 256) {
-        int v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const int i = i0 + k * 64 + lane; v[k] = i < end ? S[i] : -1; }
+    int sgi = 0;
+    for (int e0 = 0; e0 < total; e0 += 256) {
+        unsigned ent[4], xy[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bool def = v[k] >= 0;
-            const int bin = def ? lsd_bin(v[k], bc) : -1;
-            unsigned long long todo = __ballot(def);
-            int rank = 0, total = 0;
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int bsel = __builtin_amdgcn_readlane(bin, leader);
-                const unsigned long long m = __ballot(bin == bsel);
-                if (bin == bsel) { rank = mbcnt(m); total = __popcll(m); }
-                todo &= ~m;
+            const int e = e0 + k * 64 + lane;
+            ent[k] = 0; xy[k] = 0;
+            if (e < total) {
+                while (e >= pref[sgi + 1]) ++sgi;
+                ent[k] = comp[((size_t)(seg0 + sgi) << 8) + (e - pref[sgi])];
+                xy[k] = segXY[sgi];
             }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (e0 + k * 64 >= total) break;             // wave-uniform
+            const bool def = e0 + k * 64 + lane < total;
+            const int bin = (int)(ent[k] >> 8);
+            const unsigned long long peers = same_key10(bin, __ballot(def));
             if (def) {
-                const int pos = cursor[bin] + rank;
-                // x | y << 16 (the packing of the region lists): v = column of the tile's first pixel + offset < 2^24, so the float
-                // quotient is off by at most one
-                const int vo = x0 + (i0 - beg) + k * 64 + lane;
-                int qy = (int)((float)vo * rsw), rx = vo - qy * P.sw;
-                if (rx < 0) { --qy; rx += P.sw; } else if (rx >= P.sw) { ++qy; rx -= P.sw; }
-                order[pos] = (unsigned)rx | ((unsigned)(y0 + qy) << 16);
-                if (rank == total - 1) cursor[bin] = pos + 1;
+                const int rank = mbcnt(peers), pos = cursor[bin] + rank;
+                order[pos] = xy[k] + (ent[k] & 255u);      // x | y << 16 (the packing of the region lists)
+                if (rank == __popcll(peers) - 1) cursor[bin] = pos + 1;
             }
         }
     }

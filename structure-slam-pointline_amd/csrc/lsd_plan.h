@@ -13,13 +13,17 @@ constexpr float NOTDEF_F = -1024.0f;
 //            compare (bits >= 0), releasing a pixel clears the bit again, and the angle survives for the rectangle counter
 //            (|T|; NOTDEF becomes 1024, above every angle).
 //   Cs  8 B  {cosf, sinf} of the angle (decision D5); read with T by region growing for the accepted pixels' direction sums.
-//   S   4 B  gx^2 + gy^2 (-1: undefined): the counting sort streams it, region2rect gathers its weights from it.
-// 16 bytes per pixel written by k_lsd_grad instead of 24.  (A tiled form of T / Cs -- 8 x 4 and 4 x 4 pixels per 128-byte line -- was built
+//            Written for DEFINED pixels only (round 4): an undefined pixel's entry is whatever the workspace held and is never used.
+//   S   4 B  gx^2 + gy^2, defined pixels only: region2rect gathers its weights from it.
+// plus, per SEGMENT (256 pixels of one row = one wave of k_lsd_grad), the list of its defined pixels in raster order, |g|^2 << 8 | column
+// (k_lsd_hist turns it into bin << 8 | column): what the counting sort reads instead of a dense plane.  The lists share their memory with
+// the core's overflow region lists (offReg): they are dead when the core starts.
+// 16 bytes per pixel written by k_lsd_grad in round 3 (24 before), 4 B + ~24 B per defined pixel now.  (A tiled form of T / Cs -- 8 x 4 and 4 x 4 pixels per 128-byte line -- was built
 // and measured first: L1 misses of the sequential core -12 %, its time unchanged, the rectangle counter +40 % for the address
 // arithmetic; profiles/README.md, round 3.)
 constexpr unsigned USED_BIT = 0x80000000u;
 constexpr int N_BINS = 1024;
-constexpr int TILE_PX = 8192;           // raster tile of the counting sort
+constexpr int TILE_PX = 8192;           // raster tile of the counting sort (rounded down to whole rows: LsdPlan::tileRows)
 constexpr int MAX_SEG = 8192;           // segments per frame (LSD output capacity)
 constexpr int NUM_BANDS = 9, BAND_W = 7, LSP_H = 63;
 
@@ -27,10 +31,12 @@ struct LsdPlan {
     int w, h;                 // source image
     int sw, sh, spitch;       // scaled image (0.8x)
     int npx;                  // sw*sh
-    int nTiles;
+    int nTiles, tileRows;     // counting-sort tiles: tileRows whole rows each
+    int nXB;                  // segments per row = ceil(sw / 256)
+    int sMin;                 // smallest gx^2 + gy^2 of a defined pixel (k_grad_smin)
     size_t frameBytes;        // per-frame workspace
     int tW, cW;               // row pitch (elements) of the T and Cs planes (= sw)
-    size_t offBlur, offT, offS, offCs, offCand, offFlag, offNfa, offOrder, offTileHist, offReg, offSeg, offMisc, offDxy, offKl, offSortIdx;
+    size_t offBlur, offT, offS, offCs, offCand, offFlag, offNfa, offOrder, offTileHist, offReg, offSeg, offMisc, offDxy, offKl, offSortIdx, offSegCnt, offComp;
     int blurTaps[7];          // sigma 0.75, 7 taps (q8)
     int blur5Taps[5];         // sigma 1, 5 taps (q8)
     int tabX, tabY;           // offsets into the resize table (int: ofs, c1)

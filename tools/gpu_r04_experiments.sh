@@ -103,5 +103,20 @@ SSLAM_ORB_BLUR_VARIANT=1 timeout 300 python -m pytest tests/test_shim_gpu.py -x 
 timeout 300 python bench.py --no-cpu-baseline --no-extras > $O/bench.json 2>/dev/null; python -c "
 import json; d=json.load(open('$O/bench.json')); print(round(d['value']), d['ms_per_step'])"
 ;;
-*) echo "usage: $0 {a|b|c|d|e|f|g}"; exit 2 ;;
+h)
+# round 4, call h: the counting sort on per-segment lists of defined pixels (k_lsd_grad / k_lsd_hist / k_lsd_scatter): parity, then the two bench lines
+O=$R/gpurun_out/r04h; mkdir -p $O
+timeout 700 python -m pytest tests/test_lines_gpu.py tests/test_configs_gpu.py tests/test_batch_gpu.py tests/test_edge_gpu.py tests/test_pin_gpu.py -x -q -m gpu > $O/pytest_lines.txt 2>&1; tail -6 $O/pytest_lines.txt
+timeout 400 python bench.py --no-cpu-baseline --no-extras --no-other-workloads > $O/bench_two_streams.json 2> $O/bench.err; tail -c 300 $O/bench.err
+timeout 400 python bench.py --no-cpu-baseline --no-extras --no-other-workloads --no-overlap > $O/bench_one_stream.json 2>/dev/null
+python - <<'PY'
+import json
+for n in ('bench_two_streams','bench_one_stream'):
+    try:
+        d=json.load(open('gpurun_out/r04h/%s.json'%n)); k=d['roofline']['kernels_ms_per_step']
+        print(n, round(d['value']), round(d['ms_per_step'],1), {a: round(b,2) for a,b in k.items() if b>0.3})
+    except Exception as e: print(n, 'failed', e)
+PY
+;;
+*) echo "usage: $0 {a|b|c|d|e|f|g|h}"; exit 2 ;;
 esac
