@@ -65,6 +65,7 @@ struct sslam_ctx {
     hipStream_t stream = nullptr;
     std::recursive_mutex mu;       // every entry point serialises on the context (SURVEY §8b threading); recursive: the host forms call the *_batch_dev forms
     sslam::DevBuf scratch[8];      // matcher staging
+    sslam::DevBuf knnExpand;       // sslam_hamming_knn2_batch_dev: the train rows as int8 matrix-core operands (match_knn.h)
     sslam::DevBuf recordOffsets[4];   // sslam_pack_records_dev: per-frame offsets of the record stream, one buffer per stream that packs
     void* recordOffsetsStream[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned long recordOffsetsUse[4] = {0, 0, 0, 0}, recordOffsetsClock = 0;      // least-recently-used recycling of the four slots

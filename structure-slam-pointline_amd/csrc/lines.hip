@@ -264,11 +264,11 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     // LSD: blur(7, 0.75) -> 0.8x -> gradient
     { sslam::ProfScope _ps(L->ctx, "k_blur7", st); hipLaunchKernelGGL(k_blur7, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride,
                        ws + P.offBlur, bpitch, P.frameBytes, w, h, taps); }
-    { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st); hipLaunchKernelGGL(k_lsd_grad, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, nframes), dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>(), bpitch,
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st); hipLaunchKernelGGL(k_lsd_grad, dim3(P.nXB, (P.sh + 4 * GRAD_ROWS - 1) / (4 * GRAD_ROWS), nframes), dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>(), bpitch,
                                                                         L->dTabs.as<int>() + P.tabX, L->dTabs.as<int>() + P.tabY); }
-    { sslam::ProfScope _ps(L->ctx, "k_lsd_hist", st); hipLaunchKernelGGL(k_lsd_hist, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_hist", st); hipLaunchKernelGGL(k_lsd_hist, dim3(sort_grid(P.nTiles, nframes)), dim3(64), 0, st, ws, P, nframes); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scan", st); hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P); }
-    { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter, dim3(P.nTiles, nframes), dim3(64), 0, st, ws, P); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter, dim3(sort_grid(P.nTiles, nframes)), dim3(64), 0, st, ws, P, nframes); }
     {
         size_t lds = sizeof(unsigned) * (QCAP + 4);      // + the sink slot behind the queue (region_grow_w)
         if (const char* e = getenv("SSLAM_LSD_LDS_PAD")) lds = std::max(lds, (size_t)atoi(e));      // experiment knob: cap resident region workgroups per CU
@@ -331,8 +331,12 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             const size_t mwLds = lds + sizeof(unsigned) * ((size_t)nHelpers * ((size_t)MW_RING + MW_BM_WORDS) + specWords);
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_mw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mwLds));
             hipLaunchKernelGGL(k_lsd_regions_mw, dim3(nframes), dim3(64 * (1 + MW_HMAX)), mwLds, st, ws, P, nHelpers, specWords, specShift);
-        } else if (lone) hipLaunchKernelGGL(k_lsd_regions<true>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());      // lone waves: shortest chain
-        else hipLaunchKernelGGL(k_lsd_regions<false>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>());
+        } else if (lone) hipLaunchKernelGGL(k_lsd_regions<true>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);      // lone waves: shortest chain
+        else {
+            int grid = nframes;
+            if (const char* e = getenv("SSLAM_LSD_PERSIST")) { const int g = atoi(e) & ~7; if (g >= 8 && g < nframes) grid = g; }      // experiment knob: persistent workgroups
+            hipLaunchKernelGGL(k_lsd_regions<false>, dim3(grid), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
+        }
     }
     if (L->coreDone) SSLAM_HIP(hipEventRecord(L->coreDone, st));
     int evalWaves = nframes >= 1024 ? 1 : nframes >= 64 ? 4 : nframes >= 16 ? 16 : 32;      // waves per frame walking the NFA evaluations

@@ -129,6 +129,19 @@ __device__ __forceinline__ int scaled_px(unsigned e0, unsigned e1, unsigned cx, 
     const unsigned r0 = (e0 & 255u) * (256u - cx) + ((e0 >> 8) & 255u) * cx, r1 = (e1 & 255u) * (256u - cx) + ((e1 >> 8) & 255u) * cx;
     return (int)((r0 * (256u - cy) + r1 * cy + 32768u) >> 16);
 }
+#ifndef SSLAM_GRAD_ROWS
+#define SSLAM_GRAD_ROWS 8
+#endif
+#ifndef SSLAM_GRAD_WIDE
+#define SSLAM_GRAD_WIDE 0
+#endif
+#ifndef SSLAM_GRAD_WAVES
+#define SSLAM_GRAD_WAVES 0
+#endif
+constexpr int GRAD_ROWS = SSLAM_GRAD_ROWS;            // output rows a wave walks down: scaled row y + 1 of one step is scaled row y of the next
+#if SSLAM_GRAD_WAVES
+__attribute__((amdgpu_waves_per_eu(SSLAM_GRAD_WAVES, SSLAM_GRAD_WAVES)))
+#endif
 __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws, LsdPlan P, const float4* __restrict__ gtab, size_t bpitch,
                                                   const int* __restrict__ tx, const int* __restrict__ ty) {
     const int b = blockIdx.z;
@@ -138,58 +151,76 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
     float2* Cs = (float2*)(base + P.offCs);
     int* S = (int*)(base + P.offS);
     Misc* misc = (Misc*)(base + P.offMisc);
-    const int lane = threadIdx.x, tyy = threadIdx.y;
-    const int y = blockIdx.y * 4 + tyy, x4 = (blockIdx.x * 64 + lane) * 4;
-    if (y >= P.sh) return;                                  // the whole wave
-    float ang[4]; float2 cs[4]; int sv[4];
+    unsigned* comp = (unsigned*)(base + P.offComp);
+    int* segCnt = (int*)(base + P.offSegCnt);
+    const int lane = threadIdx.x;
+    const int yBeg = __builtin_amdgcn_readfirstlane((blockIdx.y * 4 + threadIdx.y) * GRAD_ROWS), yEnd = min(P.sh, yBeg + GRAD_ROWS);
+    if (yBeg >= P.sh) return;                               // the whole wave
+    const int x4 = (blockIdx.x * 64 + lane) * 4;
+    const bool inx = x4 < P.sw;                             // lanes beyond the row compute on clamped columns and store nothing
+    int ofs[5]; unsigned cx[5];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { ang[j] = NOTDEF_F; cs[j] = make_float2(0.f, 0.f); sv[j] = -1; }
-    unsigned flags = 0;                                     // bit j: pixel x4 + j is defined
-    if (x4 < P.sw) {
-        const bool lastRow = y >= P.sh - 1;
-        const int2 ty0 = ((const int2*)ty)[y], ty1 = ((const int2*)ty)[min(y + 1, P.sh - 1)];
-        int2 txv[5];
+    for (int j = 0; j < 5; ++j) { const int2 t = ((const int2*)tx)[min(x4 + j, P.sw - 1)]; ofs[j] = t.x; cx[j] = (unsigned)t.y; }
+    const int a = ofs[0] & ~3;
+    // bpitch % 64 == 0 and another buffer follows the last row: whole dwords are readable.  A 0.8x row needs at most 10 bytes from `a`.
+    const bool fast = __builtin_amdgcn_ballot_w64(ofs[4] - a <= 10) == ~0ull;
+    const int2* tyv = (const int2*)ty;
+    auto load_raw = [&](int yy, unsigned (&d)[2][3]) {
+        const int r = tyv[yy].x;
+        const unsigned* q0 = (const unsigned*)(src + (size_t)r * bpitch + a);
+        const unsigned* q1 = (const unsigned*)(src + (size_t)min(r + 1, P.h - 1) * bpitch + a);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) txv[j] = ((const int2*)tx)[min(x4 + j, P.sw - 1)];
-        const uint8_t* rw[4] = {src + (size_t)ty0.x * bpitch, src + (size_t)min(ty0.x + 1, P.h - 1) * bpitch,
-                                src + (size_t)ty1.x * bpitch, src + (size_t)min(ty1.x + 1, P.h - 1) * bpitch};
-        int p0[5], p1[5];
-        const int a = txv[0].x & ~3;
-        if (txv[4].x - a <= 10) {                       // bpitch % 64 == 0 and another buffer follows the last row: whole dwords are readable
-            unsigned d[4][3];
+        for (int k = 0; k < 3; ++k) { d[0][k] = q0[k]; d[1][k] = q1[k]; }
+    };
+    auto scale_fast = [&](int yy, const unsigned (&d)[2][3], int (&p)[5]) {
+        const unsigned cy = (unsigned)tyv[yy].y;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const unsigned* q = (const unsigned*)(rw[r] + a); d[r][0] = q[0]; d[r][1] = q[1]; d[r][2] = q[2]; }
+        for (int j = 0; j < 5; ++j) { const int o = ofs[j] - a; p[j] = scaled_px(pick2(d[0][0], d[0][1], d[0][2], o), pick2(d[1][0], d[1][1], d[1][2], o), cx[j], cy); }      // second tap has weight 0 at the last column
+    };
+    auto scale_slow = [&](int yy, int (&p)[5]) {
+        const int2 t = tyv[yy];
+        const uint8_t* r0 = src + (size_t)t.x * bpitch; const uint8_t* r1 = src + (size_t)min(t.x + 1, P.h - 1) * bpitch;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int o = txv[j].x - a;                                    // second tap has weight 0 at the last column
-                p0[j] = scaled_px(pick2(d[0][0], d[0][1], d[0][2], o), pick2(d[1][0], d[1][1], d[1][2], o), (unsigned)txv[j].y, (unsigned)ty0.y);
-                p1[j] = scaled_px(pick2(d[2][0], d[2][1], d[2][2], o), pick2(d[3][0], d[3][1], d[3][2], o), (unsigned)txv[j].y, (unsigned)ty1.y);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int sx = txv[j].x, sx1 = min(sx + 1, P.w - 1);
-                p0[j] = scaled_px(rw[0][sx] | ((unsigned)rw[0][sx1] << 8), rw[1][sx] | ((unsigned)rw[1][sx1] << 8), (unsigned)txv[j].y, (unsigned)ty0.y);
-                p1[j] = scaled_px(rw[2][sx] | ((unsigned)rw[2][sx1] << 8), rw[3][sx] | ((unsigned)rw[3][sx1] << 8), (unsigned)txv[j].y, (unsigned)ty1.y);
-            }
+        for (int j = 0; j < 5; ++j) {
+            const int sx = ofs[j], sx1 = min(sx + 1, P.w - 1);
+            p[j] = scaled_px(r0[sx] | ((unsigned)r0[sx1] << 8), r1[sx] | ((unsigned)r1[sx1] << 8), cx[j], (unsigned)t.y);
         }
-        int gidx[4];
+    };
+    int smax = 0;
+    auto process = [&](int y, const int (&p0)[5], const int (&p1)[5]) {      // p0 / p1: the scaled rows y and y + 1
+        float ang[4]; float2 cs[4]; int sv[4], gidx[4];
+        unsigned flags = 0;                                 // bit j: pixel x4 + j is defined
+        const bool lastRow = y >= P.sh - 1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            ang[j] = NOTDEF_F; cs[j] = make_float2(0.f, 0.f); sv[j] = -1;
             const int DA = p1[j + 1] - p0[j], BC = p0[j + 1] - p1[j];
             const int gx = DA + BC, gy = DA - BC, s = gx * gx + gy * gy;
             gidx[j] = (gy + 510) * GT + (gx + 510);
-            if (!lastRow && x4 + j < P.sw - 1 && s >= P.sMin) { flags |= 1u << j; sv[j] = s; }
+            if (inx && !lastRow && x4 + j < P.sw - 1 && s >= P.sMin) { flags |= 1u << j; sv[j] = s; }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (flags & (1u << j)) { const float4 rec = gtab[gidx[j]]; ang[j] = rec.x; cs[j] = make_float2(rec.y, rec.z); }      // the four gathers are in flight together
         const size_t i = (size_t)y * P.sw + x4;
         if ((P.sw & 3) == 0) {
-            *(float4*)(T + i) = make_float4(ang[0], ang[1], ang[2], ang[3]);
+            if (inx) *(float4*)(T + i) = make_float4(ang[0], ang[1], ang[2], ang[3]);
+#if SSLAM_GRAD_WIDE      // whole 64-byte blocks: S of a lane quad, Cs of a lane pair
+            const unsigned f2 = flags | (unsigned)__builtin_amdgcn_mov_dpp((int)flags, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+            const unsigned f4 = f2 | (unsigned)__builtin_amdgcn_mov_dpp((int)f2, 0x4E, 0xF, 0xF, true);             // quad_perm [2,3,0,1]
+            if (f4 && inx) *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
+            if (f2 && inx) {
+                float4* c = (float4*)(Cs + i);
+                c[0] = make_float4(cs[0].x, cs[0].y, cs[1].x, cs[1].y);
+                c[1] = make_float4(cs[2].x, cs[2].y, cs[3].x, cs[3].y);
+            }
+            if (false) {
+                float4* c = nullptr;
+#else
             if (flags) {
                 *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
                 float4* c = (float4*)(Cs + i);
+#endif
                 c[0] = make_float4(cs[0].x, cs[0].y, cs[1].x, cs[1].y);
                 c[1] = make_float4(cs[2].x, cs[2].y, cs[3].x, cs[3].y);
             }
@@ -200,16 +231,38 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
                 if (flags & (1u << j)) { S[i + j] = sv[j]; Cs[i + j] = cs[j]; }
             }
         }
-    }
-    // the segment's list of defined pixels, raster order = lane order, then column inside the lane
-    const int seg = y * P.nXB + blockIdx.x;
-    const int cnt = __popc(flags), incl = wave_incl_scan(cnt);
-    unsigned* dst = (unsigned*)(base + P.offComp) + ((size_t)seg << 8);
-    int pos = incl - cnt;
+        // the segment's list of defined pixels, raster order = lane order, then column inside the lane
+        const int seg = y * P.nXB + blockIdx.x;
+        const int cnt = __popc(flags), incl = wave_incl_scan(cnt);
+        unsigned* dst = comp + ((size_t)seg << 8);
+        int pos = incl - cnt;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (flags & (1u << j)) dst[pos++] = ((unsigned)sv[j] << 8) | (unsigned)(4 * lane + j);
-    if (lane == 63) ((int*)(base + P.offSegCnt))[seg] = incl;
-    const int smax = wave_max(max(max(sv[0], sv[1]), max(sv[2], sv[3])));
+        for (int j = 0; j < 4; ++j) if (flags & (1u << j)) dst[pos++] = ((unsigned)sv[j] << 8) | (unsigned)(4 * lane + j);
+        if (lane == 63) segCnt[seg] = incl;
+        smax = max(smax, max(max(sv[0], sv[1]), max(sv[2], sv[3])));
+    };
+    int pc[5], pn[5];
+    if (fast) {
+        unsigned d0[2][3], d1[2][3];
+        load_raw(yBeg, d0); load_raw(min(yBeg + 1, P.sh - 1), d1);
+        scale_fast(yBeg, d0, pc);
+        for (int y = yBeg; y < yEnd; ++y) {
+            scale_fast(min(y + 1, P.sh - 1), d1, pn);
+            load_raw(min(y + 2, P.sh - 1), d1);            // in flight while this row's gathers and stores are
+            process(y, pc, pn);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) pc[j] = pn[j];
+        }
+    } else {
+        scale_slow(yBeg, pc);
+        for (int y = yBeg; y < yEnd; ++y) {
+            scale_slow(min(y + 1, P.sh - 1), pn);
+            process(y, pc, pn);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) pc[j] = pn[j];
+        }
+    }
+    smax = wave_max(smax);
     if (lane == 0 && smax > 0) atomicMax(&misc->maxS, smax);
 }
 
@@ -238,11 +291,22 @@ __device__ __forceinline__ int tile_segments(const int* __restrict__ segCnt, int
     return carry;
 }
 
+// Which (tile, frame) a workgroup of the two tile kernels takes: workgroups are dealt round-robin over the eight XCDs, and every tile of a
+// frame goes to the SAME one -- the scatter's 4-byte stores of the tiles of a frame interleave in the frame's `order` array, and lines
+// that several L2s hold partially leave as partial writes.  Grid = 8 * ceil(nframes / 8) * nTiles workgroups (sort_grid).
+__device__ __forceinline__ bool sort_tile(int nTiles, int nframes, int& tile, int& b) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, q = k / nTiles;
+    tile = k - q * nTiles; b = q * 8 + xcd;
+    return b < nframes;
+}
+static inline unsigned sort_grid(int nTiles, int nframes) { return 8u * (unsigned)((nframes + 7) / 8) * (unsigned)nTiles; }
+
 // histogram pass: bins the entries once (the fp64 square root) and leaves bin << 8 | column in place of |g|^2 << 8 | column for the scatter pass
-__global__ __launch_bounds__(64) void k_lsd_hist(uint8_t* __restrict__ ws, LsdPlan P) {
+__global__ __launch_bounds__(64) void k_lsd_hist(uint8_t* __restrict__ ws, LsdPlan P, int nframes) {
     __shared__ int hist[N_BINS];
     __shared__ int pref[MAX_TSEG + 1];
-    const int tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    int tile, b; const int lane = threadIdx.x;
+    if (!sort_tile(P.nTiles, nframes, tile, b)) return;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     const Misc* misc = (const Misc*)(base + P.offMisc);
     unsigned* comp = (unsigned*)(base + P.offComp);
@@ -319,11 +383,12 @@ __device__ __forceinline__ unsigned long long same_key10(int key, unsigned long 
 // One wave per tile walks its entries in raster order, 64 at a time (four such groups are loaded ahead).  Inside a group the rank of an
 // entry among the lanes of the same bin comes from same_key10; the wave's LDS accesses execute in program order, so the cursor read /
 // write-back needs no barrier.
-__global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, LsdPlan P) {
+__global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, LsdPlan P, int nframes) {
     __shared__ int cursor[N_BINS];
     __shared__ int pref[MAX_TSEG + 1];
     __shared__ unsigned segXY[MAX_TSEG];      // first column | row << 16 of each segment of the tile
-    const int tile = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    int tile, b; const int lane = threadIdx.x;
+    if (!sort_tile(P.nTiles, nframes, tile, b)) return;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     const unsigned* comp = (const unsigned*)(base + P.offComp);
     const int* th = (const int*)(base + P.offTileHist) + (size_t)tile * N_BINS;

@@ -877,12 +877,16 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
 }
 
 template <bool LAT>
-__global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
+__global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam, int nframes) {
     extern __shared__ __align__(16) unsigned dynLds[];           // region queue (first QCAP points)
     __shared__ double red[3 * 64];                                 // addends of the ordered fp64 sums
     __shared__ float4 seedStash[64];                               // per seed candidate of the current chunk: angle, cos, sin, x | y << 16
-    __syncthreads();
-    lsd_regions_body<LAT, false>(ws, P, xcd_mix_frame(blockIdx.x, gridDim.x), dynLds, red, seedStash, MwShared{});
+    // gridDim.x == nframes: one frame per workgroup.  A smaller grid (SSLAM_LSD_PERSIST) makes the workgroups persistent: each walks its
+    // share of the frames, and the wave slots the grid does not fill stay free for the other branch's kernels for the whole launch
+    for (int i = blockIdx.x; i < nframes; i += gridDim.x) {
+        __syncthreads();
+        lsd_regions_body<LAT, false>(ws, P, xcd_mix_frame(i, nframes), dynLds, red, seedStash, MwShared{});
+    }
 }
 
 // ------------------------------------------------------------------ multi-wave form: the helper wave and the kernel

@@ -37,6 +37,18 @@ extern "C" int sslam_hamming_knn2_batch_dev(sslam_ctx* ctx, const uint8_t* d_q, 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
+    static const int form = [] { const char* e = getenv("SSLAM_KNN2_BATCH"); return !e ? 2 : !strcmp(e, "popc") ? 0 : !strcmp(e, "mfma1") ? 1 : 2; }();      // experiment knob: popc = the xor + popcount form, mfma1 = 32 queries per wave
+    const int tilesCap = (cap + 31) / 32;
+    if (tilesCap <= KNN_MFMA_MAX_TILES && form) {       // matrix-core form (match_knn.h): train rows expanded to +-64 bytes in operand order, then 32 / 64 queries per wave
+        int rc;
+        if ((rc = ctx->knnExpand.ensure((size_t)nframes * tilesCap * 8 * 1024))) return rc;
+        { sslam::ProfScope _ps(ctx, "k_knn2_expand", st); hipLaunchKernelGGL(k_knn2_expand, dim3(tilesCap, nframes), dim3(64), 0, st, d_t, d_nt, cap, tilesCap, ctx->knnExpand.as<uint8_t>()); }
+        const int qblocks = form == 2 ? (cap + 63) / 64 : tilesCap;
+        const dim3 grid(8u * (unsigned)((nframes + 7) / 8) * (unsigned)qblocks);
+        sslam::ProfScope _ps(ctx, "k_knn2_batch", st);
+        if (form == 2) hipLaunchKernelGGL(k_knn2_mfma<2>, grid, dim3(64), 0, st, d_q, d_nq, ctx->knnExpand.as<uint8_t>(), d_nt, cap, tilesCap, qblocks, nframes, d_idx, d_dist);
+        else hipLaunchKernelGGL(k_knn2_mfma<1>, grid, dim3(64), 0, st, d_q, d_nq, ctx->knnExpand.as<uint8_t>(), d_nt, cap, tilesCap, qblocks, nframes, d_idx, d_dist);
+    } else
     { sslam::ProfScope _ps(ctx, "k_knn2_batch", st); hipLaunchKernelGGL(k_knn2_batch, dim3((cap + 15) / 16, nframes), dim3(256), 0, st, d_q, d_nq, d_t, d_nt, cap, d_idx, d_dist); }
     SSLAM_HIP(hipGetLastError());
     return SSLAM_OK;

@@ -111,6 +111,139 @@ __global__ __launch_bounds__(256) void k_knn2_batch(const uint8_t* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- knn-2 of a batch on the matrix cores
+// The dense best / second-best search of a frame pair is 10^6 descriptor pairs; as xor + popcount it is 20 vector instructions per pair
+// and lane (k_knn2_batch: 0.43 M wave-instructions per frame, 6 % of a step that is bound by vector issue).  The same
+// distances as a product of +-64 matrices (int8): sum_k a_k b_k = 4096 (256 - 2 h), h the Hamming distance -- exact in the i32
+// accumulator of v_mfma_i32_32x32x32_i8.  One wave holds 32 (or 64) queries as the B operand (column j = lane & 31; 8 k-steps x 16 bytes
+// per lane, expanded once from the 256 bits) and streams the train rows through the A operand in tiles of 32; each lane then owns ONE
+// query and 16 train rows per tile (C/D layout: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)), so best and second-best are a per-lane
+// running max / min over keys -- a handful of vector instructions per pair instead of 20, and the multiply-adds run on an otherwise
+// idle unit.  The accumulator is started at 4096 * 256 + (31 - row-in-tile) (a constant vector), so that
+//     key = acc + 32 * (127 - tile) = 4096 (512 - 2 h) + 32 (127 - tile) + (31 - row-in-tile)              (one add)
+// orders by distance first and by train index second exactly like BFMatcher's (dist, index) comparison (A.10); a key is > 0, 0 = none.
+// 7 bits of tile: up to 4096 train rows per frame (sslam_hamming_knn2_batch_dev keeps the popcount form beyond).
+// The k index a byte of the A / B operands stands for is whatever the hardware assigns to (lane >> 5, byte): both operands are filled
+// by the same rule (descriptor bit 32 s + 16 (lane >> 5) + byte in k-step s), which is all a dot product needs.
+// k_knn2_expand writes the train side in operand order: frame f, tile T, k-step s = 64 lanes x 16 bytes, contiguous.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int KNN_MFMA_MAX_TILES = 128;
+__device__ __forceinline__ unsigned spread4(unsigned n) { return (n * 0x00204081u) & 0x01010101u; }      // bit i of a nibble -> byte i (0 / 1)
+__device__ __forceinline__ int pm64(unsigned nibble) { const unsigned m = spread4(nibble); return (int)((m << 7) ^ 0xC0C0C0C0u); }      // bit 1 -> +64 (0x40), bit 0 -> -64 (0xC0)
+
+__global__ __launch_bounds__(64) void k_knn2_expand(const uint8_t* __restrict__ t, const int* __restrict__ nt, int cap, int tilesCap, uint8_t* __restrict__ out) {
+    const int T = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    const int ntf = nt[f];
+    if (T * 32 >= ntf) return;                     // tiles past the frame's rows are never read
+    const int row = T * 32 + (lane & 31), h = lane >> 5;
+    uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
+    const bool valid = row < ntf;
+    if (valid) { const uint4* tp = (const uint4*)(t + ((size_t)f * cap + row) * 32); d0 = tp[0]; d1 = tp[1]; }
+    const unsigned w[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    v4i* o = (v4i*)(out + ((size_t)f * tilesCap + T) * 8 * 1024) + lane;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const unsigned bits = (w[s] >> (16 * h)) & 0xFFFFu;
+        v4i v;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[d] = valid ? pm64((bits >> (4 * d)) & 15u) : 0;      // (rows past the end: 0, and masked again below)
+        o[s * 64] = v;
+    }
+}
+
+// QS = query sets of 32 per wave: 2 halves the passes over the frame's train rows (the kernel's L2 traffic)
+template <int QS>
+__global__ __launch_bounds__(64) void k_knn2_mfma(const uint8_t* __restrict__ q, const int* __restrict__ nq, const uint8_t* __restrict__ texp,
+                                                  const int* __restrict__ nt, int cap, int tilesCap, int qblocks, int nframes,
+                                                  int* __restrict__ idx, int* __restrict__ dist) {
+    // every query block of a frame on the same XCD (workgroups are dealt round-robin over the eight): the frame's expanded train rows
+    // (256 KB) are fetched into one L2 instead of eight
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3, qf = kk / qblocks, qb = kk - qf * qblocks, f = qf * 8 + xcd;
+    if (f >= nframes) return;
+    const int nqf = nq[f], ntf = nt[f], lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int q0 = qb * 32 * QS;
+    if (q0 >= nqf) return;
+    v4i Bf[QS][8];
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+        const uint4* qp = (const uint4*)(q + ((size_t)f * cap + min(q0 + 32 * u + j, nqf - 1)) * 32);
+        const uint4 d0 = qp[0], d1 = qp[1];
+        const unsigned w[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const unsigned bits = (w[s] >> (16 * h)) & 0xFFFFu;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) Bf[u][s][d] = pm64((bits >> (4 * d)) & 15u);
+        }
+    }
+    v16i cin;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cin[r] = 4096 * 256 + 31 - ((r & 3) + 8 * (r >> 2));
+    unsigned b[QS], s2[QS];
+#pragma unroll
+    for (int u = 0; u < QS; ++u) { b[u] = 0; s2[u] = 0; }
+    const int ntiles = (ntf + 31) >> 5;
+    const v4i* A = (const v4i*)(texp + (size_t)f * tilesCap * 8 * 1024) + lane;
+    auto load_tile = [&](int T, v4i (&a)[8]) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) a[s] = A[((size_t)T * 8 + s) * 64];
+    };
+    auto do_tile = [&](int T, const v4i (&a)[8]) {
+        const unsigned tk = 32u * (unsigned)(KNN_MFMA_MAX_TILES - 1 - T);
+        const bool partial = T == ntiles - 1 && (ntf & 31);      // the last, partial tile: rows past the end are no candidates
+#pragma unroll
+        for (int u = 0; u < QS; ++u) {
+            v16i acc = cin;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], Bf[u][s], acc, 0, 0, 0);
+            if (partial) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = T * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const unsigned key = row < ntf ? (unsigned)acc[r] + tk : 0u;
+                    s2[u] = max(s2[u], min(b[u], key)); b[u] = max(b[u], key);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned key = (unsigned)acc[r] + tk;
+                    s2[u] = max(s2[u], min(b[u], key)); b[u] = max(b[u], key);
+                }
+            }
+        }
+    };
+    v4i a0[8], a1[8];
+    if (ntiles > 0) load_tile(0, a0);
+    for (int T = 0; T < ntiles; T += 2) {                   // two tiles per trip: the next tile's rows are in flight while this one is multiplied
+        if (T + 1 < ntiles) load_tile(T + 1, a1);
+        do_tile(T, a0);
+        if (T + 2 < ntiles) load_tile(T + 2, a0);
+        if (T + 1 < ntiles) do_tile(T + 1, a1);
+    }
+    // per lane: the best two of its 16 rows per tile.  To (512 - 2 h) << 16 | (0xFFFF - train index), then the two lanes of a query merge
+    auto canon = [&](unsigned key) -> unsigned {
+        if (key == 0u) return 0u;
+        const unsigned T = (unsigned)(KNN_MFMA_MAX_TILES - 1) - ((key >> 5) & 127u);
+        const unsigned ti = T * 32u + (31u - (key & 31u)) + 4u * (unsigned)h;
+        return ((key >> 12) << 16) | (0xFFFFu - ti);
+    };
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+        const unsigned cb = canon(b[u]), cs = canon(s2[u]);
+        const unsigned ob = (unsigned)__shfl_xor((int)cb, 32, 64), os = (unsigned)__shfl_xor((int)cs, 32, 64);
+        const unsigned best = max(cb, ob), second = max(min(cb, ob), max(cs, os));
+        const int qi = q0 + 32 * u + j;
+        if (h == 0 && qi < nqf) {
+            const size_t o = ((size_t)f * cap + qi) * 2;
+            idx[o] = best ? (int)(0xFFFFu - (best & 0xFFFFu)) : -1;
+            dist[o] = best ? (int)((512u - (best >> 16)) >> 1) : -1;
+            idx[o + 1] = second ? (int)(0xFFFFu - (second & 0xFFFFu)) : -1;
+            dist[o + 1] = second ? (int)((512u - (second >> 16)) >> 1) : -1;
+        }
+    }
+}
+
 __global__ void k_hamming_matrix(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt, unsigned short* __restrict__ D) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (j >= nt || i >= nq) return;

@@ -34,6 +34,42 @@ def test_knn2_ties_lowest_index(ctx, oracle):
     assert (idx == [[0, 1]] * 3).all() and (dist == 256).all()
 
 
+@pytest.mark.parametrize("cap", [1000, 96, 33])
+def test_knn2_batch_dev_matrix_core_form(fe, ctx, oracle, cap):
+    """sslam_hamming_knn2_batch_dev (the matrix-core form, match_knn.h): ragged row counts per frame (0, 1, 2, tile edges, the capacity),
+    heavy ties (duplicated and all-equal rows), rows past a frame's count filled with junk -- against the oracle's knn2, frame by frame."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(cap)
+    counts = [(0, 5), (5, 0), (1, 1), (3, 2), (31, 31), (32, 32), (33, 33), (64, 65), (cap, cap), (cap, 1), (7, cap), (min(cap, 40), min(cap, 95))]
+    counts = [(min(a, cap), min(b, cap)) for a, b in counts]
+    B = len(counts)
+    q = rng.integers(0, 256, size=(B, cap, 32), dtype=np.uint8); t = rng.integers(0, 256, size=(B, cap, 32), dtype=np.uint8)      # junk beyond the counts
+    for f, (a, b) in enumerate(counts):
+        if b:
+            t[f, :b] = _rand_desc(rng, b)
+            if f % 3 == 0: t[f, :b] = t[f, rng.integers(0, max(1, b // 4), size=b)]      # many duplicated train rows: ties resolved by index
+            if f % 4 == 1: t[f, :b] = 0
+            if a: q[f, :a] = _rand_desc(rng, a, flip_from=t[f, :b], flips=6)
+    dq = torch.from_numpy(q).cuda(); dt = torch.from_numpy(t).cuda()
+    nq = torch.tensor([a for a, _ in counts], dtype=torch.int32).cuda(); nt = torch.tensor([b for _, b in counts], dtype=torch.int32).cuda()
+    idx = torch.full((B, cap, 2), -7, dtype=torch.int32).cuda(); dist = torch.full((B, cap, 2), -7, dtype=torch.int32).cuda()
+    _p = lambda x: C.c_void_p(x.data_ptr())
+    rc = fe.lib().sslam_hamming_knn2_batch_dev(ctx.h, _p(dq), _p(nq), _p(dt), _p(nt), cap, B, _p(idx), _p(dist), None)
+    assert rc == 0, fe.lib().sslam_last_error()
+    torch.cuda.synchronize()
+    idx = idx.cpu().numpy(); dist = dist.cpu().numpy()
+    for f, (a, b) in enumerate(counts):
+        if a == 0: continue
+        if b == 0:
+            assert (idx[f, :a] == -1).all() and (dist[f, :a] == -1).all()
+            continue
+        oi, od = oracle.knn2(q[f, :a], t[f, :b])
+        np.testing.assert_array_equal(idx[f, :a], oi, err_msg="frame %d (%d x %d)" % (f, a, b))
+        np.testing.assert_array_equal(dist[f, :a], od, err_msg="frame %d (%d x %d)" % (f, a, b))
+        assert (idx[f, a:] == -7).all()          # rows past the frame's queries are not written
+
+
 def test_hamming_matrix(ctx, oracle):
     rng = np.random.default_rng(5)
     q = _rand_desc(rng, 300); t = _rand_desc(rng, 517)

@@ -118,5 +118,81 @@ for n in ('bench_two_streams','bench_one_stream'):
     except Exception as e: print(n, 'failed', e)
 PY
 ;;
-*) echo "usage: $0 {a|b|c|d|e|f|g|h}"; exit 2 ;;
+i)
+# round 4, call i: k_lsd_grad variants (tools/build_variant.sh NAME FLAGS): whole-block stores, occupancy, rows per wave -- one-stream per-kernel times
+O=$R/gpurun_out/r04i; mkdir -p $O
+for n in base gw g8w g6w gr4 gr16 gw8; do
+  L=$R/structure-slam-pointline_amd/lib/variants/$n.so; [ $n = base ] && L=$R/structure-slam-pointline_amd/lib/libsslam_frontend.so
+  [ -f $L ] || continue
+  SSLAM_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-extras --no-other-workloads --no-overlap --steps 3 --warmup 1 > $O/bench_$n.json 2>/dev/null
+  python - <<PY
+import json
+try:
+    d=json.load(open('$O/bench_$n.json')); k=d['roofline']['kernels_ms_per_step']
+    print('$n', round(d['value']), round(d['ms_per_step'],1), {a: round(k[a],2) for a in ('k_blur7','k_lsd_grad','k_lsd_hist','k_lsd_scan','k_lsd_scatter','k_lsd_regions')})
+except Exception as e: print('$n', 'failed', e)
+PY
+done 2>&1 | tee $O/summary.txt
+;;
+j)
+# round 4, call j: FETCH_SIZE / WRITE_SIZE of the kernels after the segment-list prologue (regenerates profiles/pmc_traffic.json's numbers)
+O=$R/gpurun_out/r04j; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+b=6144
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $O/pmc_c3_$c && timeout 600 rocprofv3 --pmc $c -d $O/pmc_c3_$c -- python $R/bench.py --workload c3 --batch $b --steps 1 --warmup 1 --no-overlap --no-cpu-baseline --no-extras --no-profile --no-other-workloads > $O/pmc_c3_$c.log 2>&1
+done
+cd $R
+python tools/rocpd_pmc_summary.py $O/pmc_c3_FETCH_SIZE $O/pmc_fetch_c3.txt > /dev/null
+python tools/rocpd_pmc_summary.py $O/pmc_c3_WRITE_SIZE $O/pmc_write_c3.txt > /dev/null
+python tools/make_pmc_traffic.py $O/pmc_c3_FETCH_SIZE $O/pmc_c3_WRITE_SIZE $b 3 2 $O/pmc_traffic_c3.json | head -60
+rm -rf $O/pmc_c3_FETCH_SIZE $O/pmc_c3_WRITE_SIZE
+;;
+k)
+# round 4, call k: the core capped at 5 / 4 waves per SIMD (LDS padding) so that point-branch waves find slots during its first round -- two-stream bench lines
+O=$R/gpurun_out/r04k; mkdir -p $O
+for pad in 0 8192 10240; do
+  SSLAM_LSD_LDS_PAD=$pad timeout 300 python bench.py --no-cpu-baseline --no-extras --no-other-workloads --steps 3 --warmup 1 > $O/bench_pad$pad.json 2>/dev/null
+  python - <<PY
+import json
+try:
+    d=json.load(open('$O/bench_pad$pad.json')); k=d['roofline']['kernels_ms_per_step']
+    print('pad $pad', round(d['value']), round(d['ms_per_step'],1), {a: round(b,1) for a,b in k.items() if b>3})
+except Exception as e: print('pad $pad', 'failed', e)
+PY
+done 2>&1 | tee $O/summary.txt
+;;
+l)
+# round 4, call l: persistent workgroups for the sequential core (SSLAM_LSD_PERSIST=G): G < wave slots leaves room for the point branch during the whole launch
+O=$R/gpurun_out/r04l; mkdir -p $O
+for g in ${GRIDS:-0 5120 4096 3072 2048}; do
+  SSLAM_LSD_PERSIST=$g timeout 300 python bench.py --no-cpu-baseline --no-extras --no-other-workloads --steps 3 --warmup 1 > $O/bench_g$g.json 2>/dev/null
+  python - <<PY
+import json
+try:
+    d=json.load(open('$O/bench_g$g.json')); k=d['roofline']['kernels_ms_per_step']
+    print('grid $g', round(d['value']), round(d['ms_per_step'],1), {a: round(b,1) for a,b in k.items() if b>3})
+except Exception as e: print('grid $g', 'failed', e)
+PY
+done 2>&1 | tee $O/summary.txt
+;;
+m)
+# round 4, call m: batch knn-2 on the matrix cores (k_knn2_expand + k_knn2_mfma) against the xor + popcount form: parity, then bench lines
+O=$R/gpurun_out/r04m; mkdir -p $O
+timeout 600 python -m pytest tests/test_match_gpu.py tests/test_batch_gpu.py -x -q -m gpu -k "knn2 or batch" > $O/pytest.txt 2>&1; tail -6 $O/pytest.txt
+SSLAM_KNN2_BATCH=mfma2 timeout 600 python -m pytest tests/test_match_gpu.py tests/test_batch_gpu.py -x -q -m gpu -k "knn2 or batch" > $O/pytest_mfma2.txt 2>&1; tail -6 $O/pytest_mfma2.txt
+for v in mfma mfma2 popc; do
+  for ov in "" "--no-overlap"; do
+    SSLAM_KNN2_BATCH=$v timeout 300 python bench.py --no-cpu-baseline --no-extras --no-other-workloads --steps 3 --warmup 1 $ov > $O/bench_$v$ov.json 2>/dev/null
+    python - <<PY
+import json
+try:
+    d=json.load(open('$O/bench_$v$ov.json')); k=d['roofline']['kernels_ms_per_step']
+    print('$v $ov', round(d['value']), round(d['ms_per_step'],1), {a: round(b,2) for a,b in k.items() if 'knn2' in a or b>20})
+except Exception as e: print('$v $ov', 'failed', e)
+PY
+  done
+done 2>&1 | tee $O/summary.txt
+;;
+*) echo "usage: $0 {a|b|c|d|e|f|g|h|i|j|k|l|m}"; exit 2 ;;
 esac
