@@ -361,6 +361,11 @@ int sslam_lines_batch_status_dev(sslam_lines* ln, int cap, int32_t* d_status4, v
  * and leaves issue slots free, the kernels in front of it are bandwidth-bound and do not: a second stream that waits for the event overlaps
  * the core instead of the prologue.  The event stays the caller's. */
 int sslam_lines_set_core_event(sslam_lines* ln, void* hip_event);
+/* The counterpart on the point side: `hip_event` (a hipEvent_t; NULL clears it) is WAITED for on the stream of every following
+ * sslam_orb_extract_batch_dev call after the pyramid kernels (level copy, resizes: bandwidth-bound like the line branch's prologue) and before
+ * the FAST / quadtree / descriptor kernels (vector-bound: the ones that should run under the sequential core).  With the core event here the
+ * point stream needs no wait of its own: the pyramid is built beside the line prologue, the rest starts with the core. */
+int sslam_orb_set_gate_event(sslam_orb* orb, void* hip_event);
 /* Two extractors that take turns (a batch processed as two half batches, each on its own streams): the sequential core wants every wave slot
  * of the chip, so two cores must not overlap -- but one half's kernels BEHIND its core (NFA stages, LBD: VALU-bound) overlap well with the
  * other half's kernels IN FRONT of its core (blur, gradient, counting sort: bandwidth-bound).  Every following sslam_lines_extract_batch_dev

@@ -261,6 +261,16 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     const size_t bpitch = ((size_t)w + 63) & ~(size_t)63;
     const int* taps = L->dTaps.as<int>();
     { sslam::ProfScope _ps(L->ctx, "k_zero_misc", st); hipLaunchKernelGGL(k_zero_misc, dim3(nframes), dim3(64), 0, st, ws, P); }
+    // LBD's gradient image (sigma-1 blur + Sobel of the SOURCE) does not depend on the segments; SSLAM_LBD_SOBEL=early launches it here, in
+    // the prologue (8 ms with the chip to itself instead of 35 ms under the point branch) -- measured: the step does not respond to where a
+    // kernel runs, only to how long the kernels take alone (194.1 vs 191.4 ms), so it stays behind the NFA stage
+    static const bool sobelEarly = [] { const char* e = getenv("SSLAM_LBD_SOBEL"); return e && !strcmp(e, "early"); }();
+    auto launch_blur_sobel = [&]() {
+        sslam::ProfScope _ps(L->ctx, "k_blur_sobel", st);
+        hipLaunchKernelGGL(k_blur_sobel, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride, w, h,
+                           (unsigned*)(ws + P.offDxy), P.frameBytes, taps + 8);
+    };
+    if (sobelEarly) launch_blur_sobel();
     // LSD: blur(7, 0.75) -> 0.8x -> gradient
     { sslam::ProfScope _ps(L->ctx, "k_blur7", st); hipLaunchKernelGGL(k_blur7, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride,
                        ws + P.offBlur, bpitch, P.frameBytes, w, h, taps); }
@@ -380,9 +390,8 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         { sslam::ProfScope _ps(L->ctx, "k_nfa_finish", st); hipLaunchKernelGGL(k_nfa_finish, dim3(4, nframes), dim3(256), 0, st, ws, P); }
     }
     { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
-    // LBD: blur(5, 1) + Sobel fused -> bands
-    { sslam::ProfScope _ps(L->ctx, "k_blur_sobel", st); hipLaunchKernelGGL(k_blur_sobel, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride, w, h,
-                       (unsigned*)(ws + P.offDxy), P.frameBytes, taps + 8); }
+    // LBD: blur(5, 1) + Sobel fused (SSLAM_LBD_SOBEL=early: in the prologue) -> bands
+    if (!sobelEarly) launch_blur_sobel();
     { sslam::ProfScope _ps(L->ctx, "k_lbd", st); hipLaunchKernelGGL(k_lbd, dim3(std::min(L->maxLines, cap), nframes), dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap); }
     SSLAM_HIP(hipGetLastError());
     L->lastFrames = nframes;

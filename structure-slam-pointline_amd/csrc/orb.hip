@@ -42,12 +42,15 @@ struct LevelInfo {
     float scale;                  // mvScaleFactor
     float size;                   // float(int(31*scale))
     int tabX, tabY;               // entry (int16x4) offsets into the resize tables
+    float rcpGroups;              // 1 / ((w + 3) / 4): k_resize's row index
 };
 
 struct Plan {
     int nlevels;
     int nCellsFrame, candFrame, selFrame;
     unsigned blurPack0, blurPack1;      // taps 0-3 and 4-6 of the 7x7 sigma-2 blur as bytes (q8)
+    const uint4* blurToep;              // the horizontal pass of k_describe as matrix-core operands (build_blur_toeplitz)
+    int blurTapSum;
     size_t pyrFrame;              // bytes
     int maxCellW, maxCellH, maxCellsLevel, maxNodeCap;
     LevelInfo L[MAX_LEVELS];
@@ -57,6 +60,7 @@ struct CellInfo {
     short level, x0, y0, x1, y1;  // detection rectangle [x0,x1) x [y0,y1) in level coordinates
     short pad;
     int candOff;                  // offset inside the frame's candidate array
+    unsigned magic, gmagic;       // 2^20 / cell width + 1 and 2^20 / (dword groups per row) + 1: k_fast_cells' exact divisions (a u32 division is ~35 instructions, per wave)
 };
 
 __device__ const signed char kPat[1024] = {
@@ -102,7 +106,10 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
     const int b = blockIdx.y;
     const int ngroups = (D.w + 3) >> 2;                 // flattened (row, 4-pixel group) index: full waves whatever the level width
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const int y = t / ngroups, x4 = (t - y * ngroups) * 4;
+    // t / ngroups without the ~35-instruction division: the quotient of the float product is off by at most one for t < 2^24
+    int y = (int)((float)t * D.rcpGroups);
+    { const int r = t - y * ngroups; y += r >= ngroups ? 1 : (r < 0 ? -1 : 0); }
+    const int x4 = (t - y * ngroups) * 4;
     if (y >= D.h) return;
     const short4 ty = tabs[D.tabY + y];
     const uint4 ta = *(const uint4*)(tabs + D.tabX + x4), tb = *(const uint4*)(tabs + D.tabX + x4 + 2);
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     }
     for (int i = lane; i < (((ch + 2) * scP + 3) >> 2); i += 64) ((unsigned*)sc)[i] = 0;
     __syncthreads();
-    const unsigned magic = (1u << 20) / (unsigned)cw + 1;      // floor(i/cw) == (i*magic)>>20 for i < 4400, cw <= 64
+    const unsigned magic = ci.magic;      // (1 << 20) / cw + 1: floor(i/cw) == (i*magic)>>20 for i < 4400, cw <= 64
     // pass A: necessary condition for a 9-arc at minTh, four pixels per lane on whole dwords.  Nine contiguous ring positions
     // always contain two ADJACENT compass points (ring 0/4/8/12 = S/E/N/W at distance 3), i.e. one vertical and one
     // horizontal one, and both must lie on the arc's side of the threshold:
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     {
         const int T0 = off + 3;                                    // tile column of pixel 0
         const int gmin = T0 >> 2, ng = ((T0 + cw - 1) >> 2) - gmin + 1;
-        const unsigned gmagic = (1u << 20) / (unsigned)ng + 1;     // ng <= 17, items < 4400
+        const unsigned gmagic = ci.gmagic;                          // (1 << 20) / ng + 1: ng <= 17, items < 4400
         const int nitems = ch * ng;
         const s16x2 th2 = {(short)minTh, (short)minTh};
         for (int it0 = 0; it0 < nitems; it0 += 64) {
@@ -649,6 +656,9 @@ constexpr int PP = 48;               // LDS pitch: 12 aligned dwords per row
 // TAP = true is the stage tap of the blur (a7, sslam_orb_debug_blur_patches): the same staging and the same two blur passes, but instead
 // of the 512 rBRIEF taps every position of the 37x37 window |dx|,|dy| <= 18 is evaluated and written to descOut (1369 bytes per keypoint).
 constexpr int TAPW = 37;
+#ifndef SSLAM_DESCRIBE_MFMA
+#define SSLAM_DESCRIBE_MFMA 1
+#endif
 template <bool TAP>
 __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr, size_t pyrFrame, Plan P,
                                                  const unsigned* __restrict__ sel, const int* __restrict__ selCount,
@@ -717,11 +727,57 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
     }
     m10 = wave_sum(m10); m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // horizontal blur pass: all 43 rows, columns x-18..x+21 in groups of four outputs from three dwords
+    // horizontal blur pass: all 43 rows, columns x-18..x+21
     const unsigned T0 = P.blurPack0, T1 = P.blurPack1;
     unsigned kBlurTaps[7];
 #pragma unroll
     for (int q = 0; q < 7; ++q) kBlurTaps[q] = ((q < 4 ? T0 : T1) >> (8 * (q & 3))) & 255u;
+#if SSLAM_DESCRIBE_MFMA
+    // ... as a product with the banded matrix of the taps on the matrix cores (v_mfma_i32_32x32x32_i8; the vector unit is what this step is short
+    // of): hb[r][c] = sum_k patch[r][k] * Toep[k][c], Toep[k][c] = tap[k - c - 2].  A = 32 patch rows, 16 bytes per lane straight
+    // from LDS (as signed bytes p - 128: the accumulator starts at 128 * sum(taps), every column of the band sums to that); B = the band, three
+    // 32 x 32 blocks precomputed on the host in operand order (the block k < 32, c >= 32 is zero); the k a byte stands for is the same in both
+    // operands by construction.  D: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    {
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        typedef int v16i __attribute__((ext_vector_type(16)));
+        const int j = lane & 31, h = lane >> 5;
+        const uint4 b0 = P.blurToep[lane], b1 = P.blurToep[64 + lane], b2 = P.blurToep[128 + lane];
+        const v4i B0 = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w}, B1 = {(int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w}, B2 = {(int)b2.x, (int)b2.y, (int)b2.z, (int)b2.w};
+        // the accumulators are sums of (p - 128) * tap: + 128 * sum(taps) per result.  Two results are packed per dword (v_perm of the low
+        // halves), then the bias goes on with a packed 16-bit add -- no carry between the halves, and every true sum fits 16 bits
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const unsigned biasU = (unsigned)(128 * P.blurTapSum) * 0x00010001u;
+        const u16x2 bias2 = __builtin_bit_cast(u16x2, biasU);
+        auto pack2 = [&](int a0, int a1) -> unsigned { return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, __builtin_amdgcn_perm((unsigned)a1, (unsigned)a0, 0x05040100u)) + bias2); };
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int rowA = min(32 * mt + j, PW - 1);
+            const uint4 a0 = *(const uint4*)(patch + rowA * PP + 16 * h), a1 = *(const uint4*)(patch + rowA * PP + 32 + 16 * h);
+            const v4i A0 = {(int)(a0.x ^ 0x80808080u), (int)(a0.y ^ 0x80808080u), (int)(a0.z ^ 0x80808080u), (int)(a0.w ^ 0x80808080u)};
+            const v4i A1 = {(int)(a1.x ^ 0x80808080u), (int)(a1.y ^ 0x80808080u), (int)(a1.z ^ 0x80808080u), (int)(a1.w ^ 0x80808080u)};
+            // transposed product (band^T x patch^T): the lane's 16 results of a block are output columns (r & 3) + 8 (r >> 2) + 4 h of ITS patch
+            // row -- four runs of four adjacent columns, one 8-byte LDS store each
+            const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (an inline constant as the C operand: no registers)
+            const int row = 32 * mt + j;
+            unsigned short* hr = hb + min(row, PW - 1) * 40 + 4 * h;
+            v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(B0, A0, zero, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(B1, A1, acc, 0, 0, 0);
+            if (row < PW) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 w2; w2.x = pack2(acc[4 * g], acc[4 * g + 1]); w2.y = pack2(acc[4 * g + 2], acc[4 * g + 3]);
+                    *(uint2*)(hr + 8 * g) = w2;
+                }
+            }
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(B2, A1, zero, 0, 0, 0);
+            if (row < PW) {
+                uint2 w2; w2.x = pack2(acc[0], acc[1]); w2.y = pack2(acc[2], acc[3]);
+                *(uint2*)(hr + 32) = w2;          // columns 32 + 4 h .. + 3 (the rest of the second block is past column 39)
+            }
+        }
+    }
+#else
     for (int i = lane; i < PW * 10; i += 64) {
         const int r = i / 10, g4 = i - r * 10;
         const unsigned* p = (const unsigned*)(patch + r * PP) + g4;
@@ -738,6 +794,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
         uint2 w2; w2.x = o0 | (o1 << 16); w2.y = o2 | (o3 << 16);
         *(uint2*)(hb + r * 40 + g4 * 4) = w2;
     }
+#endif
     __syncthreads();
     if (TAP) {
         for (int i = lane; i < TAPW * TAPW; i += 64) {
@@ -832,6 +889,8 @@ struct sslam_orb {
     int lastN = -1;                 // keypoints of the last sslam_orb_extract (still resident in dKp/dDesc)
     bool constsUploaded = false;
     int blurVariant = 0;            // sslam_orb_set_blur_variant
+    hipEvent_t gateEvent = nullptr;         // sslam_orb_set_gate_event
+    DevBuf dToep; int toepVariant = -1, toepSum = 0;      // the blur's band matrix as matrix-core operands, for the taps of blurVariant
 };
 
 static inline int cvRoundF(float v) { return (int)lrintf(v); }
@@ -872,6 +931,7 @@ static int build_plan(sslam_orb* o, int w, int h) {
         LevelInfo& L = P.L[l];
         float s = o->invScale[l];
         L.w = cvRoundF((float)w * s); L.h = cvRoundF((float)h * s);     // ComputePyramid :1112
+        L.rcpGroups = 1.0f / (float)((L.w + 3) >> 2);
         if (L.w < 1 || L.h < 1 || L.w > 4095 + MINB || L.h > 4095 + MINB) { set_error("image size %dx%d unsupported at level %d", w, h, l); return SSLAM_ERR_UNSUPPORTED; }
         L.pitch = (L.w + 63) & ~63;
         L.off = (unsigned)off;
@@ -908,6 +968,10 @@ static int build_plan(sslam_orb* o, int w, int h) {
                     int cw = c.x1 - c.x0, chh = c.y1 - c.y0;
                     candOff += ((cw + 1) / 2) * ((chh + 1) / 2);      // strict 3x3 NMS keeps <= 1 per 2x2
                     P.maxCellW = std::max(P.maxCellW, cw); P.maxCellH = std::max(P.maxCellH, chh);
+                    {   // as k_fast_cells lays the tile out: tile column of pixel 0 = off + 3, off = (x0 - 3) & 3
+                        const int T0 = ((c.x0 - 3) & 3) + 3, gmin = T0 >> 2, ng = ((T0 + cw - 1) >> 2) - gmin + 1;
+                        c.magic = (1u << 20) / (unsigned)cw + 1; c.gmagic = (1u << 20) / (unsigned)ng + 1;
+                    }
                     o->cells.push_back(c);
                 }
             }
@@ -1026,7 +1090,7 @@ extern "C" int sslam_orb_destroy(sslam_orb* o) {
     if (!o) return SSLAM_OK;
     (void)hipSetDevice(o->ctx->device);
     (void)hipStreamSynchronize(o->ctx->stream);
-    DevBuf* bufs[] = {&o->dCells, &o->dTabs, &o->dPyr, &o->dCellCount, &o->dCand, &o->dBufA, &o->dBufB, &o->dSel, &o->dSelCount, &o->dImg, &o->dKp, &o->dDesc, &o->dCounts};
+    DevBuf* bufs[] = {&o->dCells, &o->dTabs, &o->dPyr, &o->dCellCount, &o->dCand, &o->dBufA, &o->dBufB, &o->dSel, &o->dSelCount, &o->dImg, &o->dKp, &o->dDesc, &o->dCounts, &o->dToep};
     for (DevBuf* b : bufs) b->release();
     o->hImg.release(); o->hOut.release();
     delete o;
@@ -1042,6 +1106,13 @@ extern "C" int sslam_orb_get_scales(const sslam_orb* o, float* scale, float* inv
         if (inv_sigma2) inv_sigma2[i] = o->invSigma2[i];
         if (per_level) per_level[i] = o->perLevel[i];
     }
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_orb_set_gate_event(sslam_orb* o, void* hip_event) {
+    if (!o) { set_error("sslam_orb_set_gate_event: null handle"); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::recursive_mutex> lk(o->ctx->mu);
+    o->gateEvent = (hipEvent_t)hip_event;
     return SSLAM_OK;
 }
 
@@ -1070,6 +1141,24 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
         for (int t : taps) if (t < 0 || t > 255) { set_error("blur taps do not fit a byte"); return SSLAM_ERR_UNSUPPORTED; }
         o->plan.blurPack0 = (unsigned)taps[0] | ((unsigned)taps[1] << 8) | ((unsigned)taps[2] << 16) | ((unsigned)taps[3] << 24);
         o->plan.blurPack1 = (unsigned)taps[4] | ((unsigned)taps[5] << 8) | ((unsigned)taps[6] << 16);
+        if (o->toepVariant != o->blurVariant) {
+            // k_describe's horizontal pass as int8 matrix-core operands: blocks (k < 32, c < 32), (k >= 32, c < 32), (k >= 32, c >= 32) of
+            // Toep[k][c] = tap[k - c - 2] (k = LDS byte of the patch row, 48 of them; c = output column, 40 of them); lane l holds bytes
+            // e = 0..15 for k = 32 ks + 16 (l >> 5) + e, c = 32 nt + (l & 31)
+            std::vector<signed char> tb(3 * 64 * 16, 0);
+            const int blk[3][2] = {{0, 0}, {0, 1}, {1, 1}};      // (nt, ks)
+            int sum = 0;
+            for (int t : taps) { if (t > 127) { set_error("blur taps do not fit a signed byte"); return SSLAM_ERR_UNSUPPORTED; } sum += t; }
+            for (int f = 0; f < 3; ++f) for (int l = 0; l < 64; ++l) for (int e = 0; e < 16; ++e) {
+                const int k = 32 * blk[f][1] + 16 * (l >> 5) + e, c = 32 * blk[f][0] + (l & 31), q = k - c - 2;
+                if (q >= 0 && q <= 6 && c < 40 && k < 48) tb[((size_t)f * 64 + l) * 16 + e] = (signed char)taps[q];
+            }
+            if ((rc = o->dToep.ensure(tb.size()))) return rc;
+            SSLAM_HIP(hipStreamSynchronize(st));
+            SSLAM_HIP(hipMemcpy(o->dToep.p, tb.data(), tb.size(), hipMemcpyHostToDevice));
+            o->toepVariant = o->blurVariant; o->toepSum = sum;
+        }
+        o->plan.blurToep = o->dToep.as<uint4>(); o->plan.blurTapSum = o->toepSum;
     }
     if (!o->constsUploaded) {
         SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kUmax), o->umax, sizeof(int) * 16));
@@ -1095,6 +1184,7 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
         dim3 blk(256), grd((((P.L[l].w + 3) / 4) * P.L[l].h + 255) / 256, nframes);
         { sslam::ProfScope _ps(o->ctx, "k_resize", st); hipLaunchKernelGGL(k_resize, grd, blk, 0, st, pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short4>()); }
     }
+    if (o->gateEvent) SSLAM_HIP(hipStreamWaitEvent(st, o->gateEvent, 0));      // sslam_orb_set_gate_event: the pyramid is built ahead, the rest waits (e.g. for the line branch's sequential core)
     if (P.nCellsFrame > 0) {
         int tileP = (P.maxCellW + 6 + 3 + 7) & ~3, scP = P.maxCellW + 2;
         size_t lds = (size_t)(P.maxCellH + 6) * tileP + (((size_t)(P.maxCellH + 2) * scP + 3) & ~(size_t)3) + 3 * (size_t)P.maxCellH * P.maxCellW + 32;

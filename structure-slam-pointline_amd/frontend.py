@@ -389,6 +389,10 @@ class OrbExtractor:
         """0: the bit-exact 8-bit GaussianBlur of OpenCV >= 3.4.1 (default, decision D6); 1: OpenCV 3.4.0's rounded taps (sslam_orb_set_blur_variant)"""
         _chk(lib().sslam_orb_set_blur_variant(self.h, int(variant)))
 
+    def set_gate_event(self, hip_event):
+        """hipEvent_t handle (int) every following batch call waits for between its pyramid kernels and the rest; 0 / None clears it (sslam_orb_set_gate_event)"""
+        _chk(lib().sslam_orb_set_gate_event(self.h, C.c_void_p(int(hip_event or 0))))
+
     def scales(self):
         n = self.nlevels
         s = np.zeros(n, np.float32); i = np.zeros(n, np.float32); g = np.zeros(n, np.float32); ig = np.zeros(n, np.float32)

@@ -121,10 +121,14 @@ class FrontendBatch:
             # waits for it: it then runs under the core instead of competing with the prologue (SSLAM_POINTS_AT_CORE=0: both start together).
             import os
             self._core_event = None
-            if os.environ.get("SSLAM_POINTS_AT_CORE", "1") != "0":
+            mode = os.environ.get("SSLAM_POINTS_AT_CORE", "1")
+            self._gate_in_orb = mode == "pyr"      # "pyr": the pyramid is built beside the line prologue, FAST and what follows wait for the core (sslam_orb_set_gate_event)
+            if mode != "0":
                 ev = torch.cuda.Event(); ev.record(self._s2)          # (recording creates the hipEvent_t)
                 self._core_event = ev
                 self.lines.set_core_event(ev.cuda_event)
+                if self._gate_in_orb:
+                    self.orb.set_gate_event(ev.cuda_event)
         cur = torch.cuda.current_stream(self.dev)
         self._s1.wait_stream(cur); self._s2.wait_stream(cur)
         f = self.feat["cur"]
@@ -134,7 +138,7 @@ class FrontendBatch:
             if self.with_match:
                 self._match_lines()
         with torch.cuda.stream(self._s1):
-            if self._core_event is not None:      # the point branch starts when the sequential LSD core does (sslam_lines_set_core_event)
+            if self._core_event is not None and not self._gate_in_orb:      # the point branch starts when the sequential LSD core does (sslam_lines_set_core_event)
                 self._s1.wait_event(self._core_event)
             self.orb.extract_batch_dev(images, self.w, self.h, self.w, self.w * self.h, self.B, f["kp"], f["desc"], f["n"], self.cap, self._stream())
             if self.with_match:

@@ -194,5 +194,52 @@ PY
   done
 done 2>&1 | tee $O/summary.txt
 ;;
-*) echo "usage: $0 {a|b|c|d|e|f|g|h|i|j|k|l|m}"; exit 2 ;;
+n)
+# round 4, call n: the horizontal blur pass of k_describe on the matrix cores: ORB parity (both blur variants, the blur stage tap), bench lines
+O=$R/gpurun_out/r04n; mkdir -p $O
+timeout 600 python -m pytest tests/test_orb_gpu.py tests/test_batch_gpu.py tests/test_pin_gpu.py tests/test_configs_gpu.py -x -q -m gpu > $O/pytest.txt 2>&1; tail -6 $O/pytest.txt
+for v in mfma dnomfma; do
+ L=$R/structure-slam-pointline_amd/lib/libsslam_frontend.so; [ $v = dnomfma ] && L=$R/structure-slam-pointline_amd/lib/variants/dnomfma.so
+ for ov in "" "--no-overlap"; do
+  SSLAM_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-extras --no-other-workloads --steps 3 --warmup 1 $ov > $O/bench_$v$ov.json 2>/dev/null
+  python - <<PY
+import json
+try:
+    d=json.load(open('$O/bench_$v$ov.json')); k=d['roofline']['kernels_ms_per_step']
+    print('$v $ov', round(d['value']), round(d['ms_per_step'],1), {a: round(b,2) for a,b in k.items() if b>3})
+except Exception as e: print('$v $ov', 'failed', e)
+PY
+ done
+done 2>&1 | tee $O/summary.txt
+;;
+o)
+# round 4, call o: where k_blur_sobel runs (prologue / behind the NFA stage) x where the point branch waits for the core event (before the pyramid / behind it)
+O=$R/gpurun_out/r04o; mkdir -p $O
+for sob in early late; do for pc in 1 pyr; do
+  SSLAM_LBD_SOBEL=$sob SSLAM_POINTS_AT_CORE=$pc timeout 300 python bench.py --no-cpu-baseline --no-extras --no-other-workloads --steps 3 --warmup 1 > $O/bench_${sob}_$pc.json 2>/dev/null
+  python - <<PY
+import json
+try:
+    d=json.load(open('$O/bench_${sob}_$pc.json')); k=d['roofline']['kernels_ms_per_step']
+    print('sobel $sob points $pc', round(d['value']), round(d['ms_per_step'],1), {a: round(b,1) for a,b in k.items() if b>3})
+except Exception as e: print('sobel $sob points $pc', 'failed', e)
+PY
+done; done 2>&1 | tee $O/summary.txt
+;;
+p)
+# round 4, call p: divisions out of k_fast_cells / k_resize, packed fp32 sums in k_lbd: parity of both extractors, bench lines
+O=$R/gpurun_out/r04p; mkdir -p $O
+timeout 700 python -m pytest tests/test_orb_gpu.py tests/test_lines_gpu.py tests/test_batch_gpu.py tests/test_configs_gpu.py tests/test_edge_gpu.py -x -q -m gpu > $O/pytest.txt 2>&1; tail -6 $O/pytest.txt
+for ov in "" "--no-overlap"; do
+  timeout 300 python bench.py --no-cpu-baseline --no-extras --no-other-workloads --steps 3 --warmup 1 $ov > $O/bench$ov.json 2>/dev/null
+  python - <<PY
+import json
+try:
+    d=json.load(open('$O/bench$ov.json')); k=d['roofline']['kernels_ms_per_step']
+    print('$ov', round(d['value']), round(d['ms_per_step'],1), {a: round(b,2) for a,b in k.items() if b>3})
+except Exception as e: print('$ov', 'failed', e)
+PY
+done 2>&1 | tee $O/summary.txt
+;;
+*) echo "usage: $0 {a|b|c|d|e|f|g|h|i|j|k|l|m|n|o|p}"; exit 2 ;;
 esac
