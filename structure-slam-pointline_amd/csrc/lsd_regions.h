@@ -19,8 +19,15 @@ struct RegQ {
 struct Planes {
     float* T; const float2* Cs; const int* S; int tW, cW;
     __device__ __forceinline__ unsigned* Tb() const { return (unsigned*)T; }
-    __device__ __forceinline__ int ti(int x, int y) const { return tix(x, y, tW); }
-    __device__ __forceinline__ int ti(unsigned e) const { return tix((int)(e & 0xFFFF), (int)(e >> 16), tW); }
+    // element i of a plane through a 32-bit byte offset: the planes' base pointers are wave-uniform, so the load takes the scalar-base +
+    // 32-bit-offset form (global_load ... v_off, s[base]) instead of a 64-bit address computed per lane (a frame's planes are < 2^31 bytes)
+    __device__ __forceinline__ float ldT(int i) const { return *(const float*)((const char*)T + ((unsigned)i << 2)); }
+    __device__ __forceinline__ void stT(int i, float v) const { *(float*)((char*)T + ((unsigned)i << 2)) = v; }
+    __device__ __forceinline__ float2 ldCs(int i) const { return *(const float2*)((const char*)Cs + ((unsigned)i << 3)); }
+    // (coordinates and pitch are < 2^16: v_mad_u32_u24, one full-rate instruction; v_mul_lo_u32 is quarter rate)
+    __device__ __forceinline__ int ti(int x, int y) const { return (int)(__umul24((unsigned)y, (unsigned)tW) + (unsigned)x); }
+    __device__ __forceinline__ int ti(unsigned e) const { return (int)(__umul24(e >> 16, (unsigned)tW) + (e & 0xFFFFu)); }
+
 };
 __device__ __forceinline__ bool t_free(float t) { return __float_as_int(t) >= 0; }      // defined and not part of a region
 __device__ __forceinline__ float t_used(float t) { return __int_as_float(__float_as_int(t) | (int)USED_BIT); }
@@ -151,7 +158,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
     float sumdx = seedCos, sumdy = seedSin;
     if (lane == 0) {
         rq.set(0, (unsigned)seedX | ((unsigned)seedY << 16));
-        if (MARK) { const int bi = bm_bit<G>(seedX, seedY); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pl.T[pl.ti(seedX, seedY)] = t_used(seedDeg);
+        if (MARK) { const int bi = bm_bit<G>(seedX, seedY); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pl.stT(pl.ti(seedX, seedY), t_used(seedDeg));
     }
     const int g = lane >> 3, k8 = lane & 7;             // group (queue slot) and neighbour slot (centre skipped)
     const int k = k8 + (k8 >= 4 ? 1 : 0);                // row-major 3x3 position 0..8 without 4
@@ -184,8 +191,8 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
             xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
             const int cx = min(max(xx, 0), sw - 1), cy = min(max(yy, 0), sh - 1);
             nidx = pl.ti(cx, cy);
-            tv = pl.T[nidx];                             // sign bit set: NOTDEF or already USED
-            cs = pl.Cs[nidx];                            // (same row pitch: one index serves both planes)
+            tv = pl.ldT(nidx);                           // sign bit set: NOTDEF or already USED
+            cs = pl.ldCs(nidx);                            // (same row pitch: one index serves both planes)
             candM = __builtin_amdgcn_ballot_w64(t_free(tv)) & __builtin_amdgcn_ballot_w64((unsigned)xx < (unsigned)sw) &
                     __builtin_amdgcn_ballot_w64((unsigned)yy < (unsigned)sh) & (np == 8 ? ~0ull : ((1ull << (np * 8)) - 1));
             if (MARK) { const int bi = bm_bit<G>(xx, yy); candM &= ~__builtin_amdgcn_ballot_w64((bm_word<G>(bm, bi >> 5) >> (bi & 31)) & 1u); }      // taken by this wave itself
@@ -195,9 +202,9 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
                 const unsigned e = rq.get_n(i + g, n);
                 xx = (int)(e & 0xFFFF) + dx; yy = (int)(e >> 16) + dy;
                 if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
-                    nidx = pl.ti(xx, yy);
-                    tv = pl.T[nidx];
-                    cs = pl.Cs[nidx];
+                    nidx = pl.ti(xx, yy);      // y, pitch, x < 2^16: one full-rate instruction (v_mul_lo_u32 is quarter rate)
+                    tv = pl.ldT(nidx);
+                    cs = pl.ldCs(nidx);
                     cand = t_free(tv);
                 }
             }
@@ -223,7 +230,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
                 if (LAT) accMask |= 1ull << sel;               // lone wave: the used-map / queue stores follow the loop, all lanes at once
                 else if (lane == sel) {                        // LDS slot QCAP is a sink, so the common case has no branch around the store
                     const unsigned v = (unsigned)xx | ((unsigned)yy << 16);
-                    pl.T[nidx] = t_used(tv); rq.lds[min(n, QCAP)] = v;
+                    pl.stT(nidx, t_used(tv)); rq.lds[min(n, QCAP)] = v;
                     if (n >= QCAP) rq.glb[n] = v;
                 }
                 ++n;
@@ -273,7 +280,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
                 if (LAT) accMask |= 1ull << sel;
                 else if (lane == sel) {
                     const unsigned v = (unsigned)xx | ((unsigned)yy << 16);
-                    pl.T[nidx] = t_used(tv); rq.lds[min(n, QCAP)] = v;
+                    pl.stT(nidx, t_used(tv)); rq.lds[min(n, QCAP)] = v;
                     if (n >= QCAP) rq.glb[n] = v;
                 }
                 ++n;
@@ -292,7 +299,7 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
             }
         }
         if (LAT && accMask != 0 && ((accMask >> lane) & 1ull)) {
-            if (MARK) { const int bi = bm_bit<G>(xx, yy); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pl.T[nidx] = t_used(tv);
+            if (MARK) { const int bi = bm_bit<G>(xx, yy); atomicOr(&bm[bi >> 5], 1u << (bi & 31)); } else pl.stT(nidx, t_used(tv));
             rq.set(nBefore + mbcnt(accMask), (unsigned)xx | ((unsigned)yy << 16));
         }
         if (MARK == MARK_SPEC && __builtin_amdgcn_ballot_w64(((accMask >> lane) & 1ull) && (abs(xx - seedX) > G::REACH || abs(yy - seedY) > G::REACH))) return -n;      // leaves the torus
@@ -347,7 +354,7 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const int* __restri
         if (i < n) {
             const unsigned e = rq.get_n(i, n);
             const int px = e & 0xFFFF, py = e >> 16;
-            wgt = sqrt((double)S[py * sw + px] / 4.0);
+            wgt = sqrt((double)*(const int*)((const char*)S + ((__umul24((unsigned)py, (unsigned)sw) + (unsigned)px) << 2)) / 4.0);
             fx = (double)px * wgt; fy = (double)py * wgt;
             if (base == 0) { wgt0 = wgt; px0 = px; py0 = py; }
         }
@@ -365,7 +372,7 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const int* __restri
             if (base != 0) {
                 const unsigned e = rq.get_n(i, n);
                 px = e & 0xFFFF; py = e >> 16;
-                wgt = sqrt((double)S[py * sw + px] / 4.0);
+                wgt = sqrt((double)*(const int*)((const char*)S + ((__umul24((unsigned)py, (unsigned)sw) + (unsigned)px) << 2)) / 4.0);
             }
             const double ddx = (double)px - x, ddy = (double)py - y;
             a = ddy * ddy * wgt; b = ddx * ddx * wgt; c = ddx * ddy * wgt;
@@ -576,9 +583,9 @@ __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& r
         if (i < n) {
             const unsigned e = rq.get_n(i, n);
             const int px = e & 0xFFFF, py = e >> 16, id = pl.ti(px, py);
-            const float aOrig = fabsf(pl.T[id]);      // the angle whatever the used bit says (a helper's view may be racing the main wave's marks)
+            const float aOrig = fabsf(pl.ldT(id));      // the angle whatever the used bit says (a helper's view may be racing the main wave's marks)
             if (MARK) { const int bi = bm_bit<G>(px, py); atomicAnd(&sl->bm[bi >> 5], ~(1u << (bi & 31))); }
-            else pl.T[id] = aOrig;                  // NOTUSED again
+            else pl.stT(id, aOrig);                  // NOTUSED again
             if (dist_d(xc, yc, (double)px, (double)py) < rec.width) { in = true; ad = angle_diff_signed((double)aOrig * DEG2RAD, ang_c); }
         }
         // points outside the radius contribute an exact +0.0 (the sums start at +0 and can never be -0)
@@ -693,7 +700,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
         // One gather per chunk of 64 seed candidates: T is the candidate's level-line angle while it is unused.  What a region start
         // needs from its seed -- coordinates, the angle, cos and sin of it (two fp64 evaluations that the whole wave used to execute for ONE
         // seed, after a dependent load of the angle) -- is computed here for all 64 candidates at once and parked in LDS.
-        const float a0 = have ? pl.T[tiSeed] : NOTDEF_F;
+        const float a0 = have ? pl.ldT(tiSeed) : NOTDEF_F;
         unsigned long long unM = __ballot(t_free(a0));        // candidates of this chunk that are still unused (wave-uniform, kept up to date below)
         if (!unM) continue;
         // (multi-wave form: only the seeds the main wave grows itself need this -- evaluated at the first one of the chunk)
@@ -1000,7 +1007,7 @@ __device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 __builtin_amdgcn_s_sleep(8);
                 SSLAM_MW_T(6);
             }
-            const float a0 = have ? pl.T[tiSeed] : NOTDEF_F;
+            const float a0 = have ? pl.ldT(tiSeed) : NOTDEF_F;
             unsigned long long unM = __ballot(t_free(a0) && (pass > 0 || !mw.spec(cx, cy))) & ~haveRes;
             if (pass == 0) SSLAM_MW_WHY(0, __popcll(__ballot(t_free(a0) && mw.spec(cx, cy))));
             if (unM) {

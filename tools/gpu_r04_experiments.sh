@@ -241,5 +241,20 @@ except Exception as e: print('$ov', 'failed', e)
 PY
 done 2>&1 | tee $O/summary.txt
 ;;
-*) echo "usage: $0 {a|b|c|d|e|f|g|h|i|j|k|l|m|n|o|p}"; exit 2 ;;
+q)
+# round 4, call q: frames per step (rounds of the sequential core per launch): 12288 (two rounds of 6144 wave slots), 18432, 24576
+O=$R/gpurun_out/r04q; mkdir -p $O
+for b in ${BATCHES:-12288 18432 24576}; do
+  timeout 400 python bench.py --no-cpu-baseline --no-extras --no-other-workloads --steps 3 --warmup 1 --batch $b > $O/bench_b$b.json 2> $O/bench_b$b.err
+  python - <<PY
+import json
+try:
+    d=json.load(open('$O/bench_b$b.json')); k=d['roofline']['kernels_ms_per_step']
+    print('batch $b', round(d['value']), round(d['ms_per_step'],1), {a: round(v,1) for a,v in k.items() if v>8})
+except Exception as e: print('batch $b', 'failed', e, open('$O/bench_b$b.err').read()[-300:])
+PY
+done 2>&1 | tee $O/summary.txt
+rocm-smi --showmeminfo vram 2>/dev/null | tail -4
+;;
+*) echo "usage: $0 {a|b|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q}"; exit 2 ;;
 esac
