@@ -81,6 +81,7 @@ def alg_bytes_per_frame(w, h, nkp, nln):
         "k_blur_sobel": w * h + 4 * w * h,                  # fused LBD pre-blur + Sobel: source read, {dx,dy} s16 pair write
         "k_lbd": nln * 63 * 100 * 4 + nln * 100,            # band reads at a nominal 100-px line + descriptor
         "k_search_init": 2 * 32 * nkp + 8 * nkp, "k_knn2_batch": 2 * 32 * nkp + 16 * nkp,
+        "k_knn2_expand": 0,                                 # the train rows as int8 matrix-core operands: implementation traffic (8x the descriptors), not algorithmic bytes
         "k_line_match": 2 * 32 * nln + 16 * nln,
         "k_zero_misc": 0,
     }

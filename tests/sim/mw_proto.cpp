@@ -19,6 +19,7 @@
 // cluster form needs the monotonic map.
 //   usage: mw_proto <frame.raw> <w> <h> <helpers> <repeats> <chaos: yield once in N reads, 0 = never> [checks: 3 = both (default), 1 = only (b), 2 = only (c), 0 = none] [percentage of seeds the main thread does itself regardless] [mode: 0 multi-wave, 1 cluster] [stale: a cached line is refreshed once in N reads, 0 = views are always fresh]
 #include "../../oracle/lsd_oracle.cpp"
+namespace orc { int g_gaussVariant = 0; }      // (defined in orb_oracle.cpp, which this single-file build does not link)
 #include <atomic>
 #include <chrono>
 #include <cstdio>
