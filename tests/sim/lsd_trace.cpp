@@ -3,6 +3,7 @@
 // seeds grown, region sizes, accepts per staged queue point for staging widths 1/2/4/8, candidate rectangles, refine / radius reductions.
 // Built by tests/sim/lsd_pack_sim.py with g++; never linked into the library.
 #include "../../oracle/lsd_oracle.cpp"
+namespace orc { int g_gaussVariant = 0; }      // (defined in orb_oracle.cpp, which this single-file build does not link)
 
 namespace {
 struct Trace {

@@ -7,6 +7,7 @@
 // build: g++ -O2 -std=c++17 -ffp-contract=off -pthread -Ioracle tools/lsd_spec_proto.cpp -o /tmp/lsd_spec_proto
 // run:   /tmp/lsd_spec_proto <frame.raw 640x480> <threads> <repeats> [chaos: yield once in N pixel reads] [0 = no stamp validation] [1 = FIFO hand-out as in the draft kernel]
 #include "../oracle/lsd_oracle.cpp"
+namespace orc { int g_gaussVariant = 0; }      // (defined in orb_oracle.cpp, which this single-file build does not link)
 #include <atomic>
 #include <climits>
 #include <cstdio>

@@ -5,6 +5,7 @@
 // run:   python -c "import sys; sys.path.insert(0,'tests'); from synth import synth_frame; synth_frame(2000).tofile('/tmp/frame.raw')"
 //        /tmp/lsd_spec_sim <waves> <tile> 0 <commit cost> /tmp/frame.raw
 #include "../oracle/lsd_oracle.cpp"
+namespace orc { int g_gaussVariant = 0; }      // (defined in orb_oracle.cpp, which this single-file build does not link)
 #include <cstdio>
 #include <set>
 #include <random>
