@@ -219,21 +219,24 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
         for (int r = 0; r < lane; ++r) { sx0 = __fsub_rn(sx0, dL1); sy0 = __fadd_rn(sy0, dL0); }
         float sx = sx0, sy = sy0;
         float pL = 0, nL = 0, pO = 0, nO = 0;
-        for (int w0 = 0; w0 < lengthOfLSP; w0 += 8) {
+        // The walk's coordinates do not depend on what is gathered: the eight gathers of the NEXT group of steps are issued before the current
+        // group is consumed (two register sets, two groups per trip), so a wave waits for memory once per line, not once per eight steps
+        auto issue = [&](unsigned (&g)[8]) {
             // coordinates of eight consecutive steps (the float walk itself stays sequential), then the eight gathers together
-            int idx8[8];
+            unsigned off8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 int tc = (int)(short)(int)roundf(sx);
                 const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
                 tc = (int)(short)(int)roundf(sy);
                 const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
-                idx8[u] = yCor * realWidth + xCor;
+                off8[u] = (__umul24((unsigned)yCor, (unsigned)realWidth) + (unsigned)xCor) << 2;      // byte offset: both factors < 2^16 (v_mad_u32_u24 instead of a 64-bit multiply-add)
                 sx = __fadd_rn(sx, dL0); sy = __fadd_rn(sy, dL1);
             }
-            unsigned g[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) g[u] = dxyImg[idx8[u]];
+            for (int u = 0; u < 8; ++u) g[u] = *(const unsigned*)((const char*)dxyImg + off8[u]);      // wave-uniform base + 32-bit offset
+        };
+        auto consume = [&](const unsigned (&g)[8], int w0) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (w0 + u < lengthOfLSP) {
@@ -244,6 +247,14 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
                     if (gDO > 0) pO = __fadd_rn(pO, gDO); else nO = __fsub_rn(nO, gDO);
                 }
             }
+        };
+        unsigned gA[8], gB[8];
+        if (lengthOfLSP > 0) issue(gA);
+        for (int w0 = 0; w0 < lengthOfLSP; w0 += 16) {
+            if (w0 + 8 < lengthOfLSP) issue(gB);
+            consume(gA, w0);
+            if (w0 + 16 < lengthOfLSP) issue(gA);
+            if (w0 + 8 < lengthOfLSP) consume(gB, w0 + 8);
         }
         const float cg = kGaussG[lane];
         pL = __fmul_rn(cg, pL); nL = __fmul_rn(cg, nL); pO = __fmul_rn(cg, pO); nO = __fmul_rn(cg, nO);
