@@ -695,10 +695,16 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
         const int delta = (kx - PR) - ax - SH;                     // LDS byte b of a row = global byte ax + delta + b
         const uint8_t* src = img + (size_t)(ky - PR) * L.pitch + ax;
         const int rr = lane / 12, q = lane - rr * 12;
-        for (int r0 = 0; r0 < PW; r0 += 5) {
-            const int r = r0 + rr;
+        // all nine loads first (rows past the patch re-read its last row: no branch around a load, so none of them waits for the one before --
+        // as a loop of load / shift / store the kernel spent nine dependent memory round trips per keypoint here), then the shifts and LDS stores
+        unsigned gl[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gl[k] = ((const unsigned*)(src + (size_t)min(5 * k + rr, PW - 1) * L.pitch))[min(q, 11)];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int r = 5 * k + rr;
             const bool on = lane < 60 && r < PW;
-            const unsigned g = on ? ((const unsigned*)(src + (size_t)r * L.pitch))[q] : 0u;
+            const unsigned g = gl[k];
             const unsigned nxt = (unsigned)__builtin_amdgcn_mov_dpp((int)g, 0x130, 0xF, 0xF, false);      // wave_shl:1 = lane + 1
             const unsigned prv = (unsigned)__builtin_amdgcn_mov_dpp((int)g, 0x138, 0xF, 0xF, false);      // wave_shr:1 = lane - 1
             unsigned word;
