@@ -144,11 +144,20 @@ __global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ 
     const bool vec = ((w & 3) == 0) && ((dframeBytes & 15) == 0);
     unsigned hb[5][6];                                     // horizontally blurred rows, columns x4-1 .. x4+4
     int bl[3][6];                                          // blurred rows
+    constexpr int NR = STRIP + 2 * R;
+    const bool uni = row12_uniform(s, spitch, w);      // kernel-uniform: branch-free row loads, ROW_AHEAD_SOBEL rows in flight (lsd_front.h)
+    const int x4u = uni ? x4 : 0;                       // (otherwise the ring reads the first bytes of the rows, unused, and load_row12 does the work)
+    Row12 ring[ROW_AHEAD_SOBEL];
 #pragma unroll
-    for (int r = 0; r < STRIP + 2 * R; ++r) {
+    for (int k = 0; k < ROW_AHEAD_SOBEL; ++k) ring[k] = row12_issue(s, spitch, reflect_row(y0 - R + k, h, R), x4u, w);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
         if (r >= 2 * R && y0 + r - 2 * R >= h) break;
-        unsigned d0, d1, d2;
-        load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, d0, d1, d2);
+        Row12 cur = ring[r % ROW_AHEAD_SOBEL];
+        if (r + ROW_AHEAD_SOBEL < NR) ring[r % ROW_AHEAD_SOBEL] = row12_issue(s, spitch, reflect_row(y0 - R + r + ROW_AHEAD_SOBEL, h, R), x4u, w);
+        row12_fix(cur, x4u, w);
+        if (!uni) load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, cur.d0, cur.d1, cur.d2);
+        const unsigned d0 = cur.d0, d1 = cur.d1, d2 = cur.d2;
 #pragma unroll
         for (int c = 0; c < 6; ++c) hb[r % 5][c] = hdot(d0, d1, d2, c + 1, T0, T1);      // columns x4+c-3 .. x4+c+1 (sums fit 16 bits: taps sum to 256 or 257)
         if (r >= 4) {
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ 
             for (int c = 0; c < 6; ++c) {
                 unsigned acc = 0;
 #pragma unroll
-                for (int k = 0; k < 5; ++k) acc += hb[(q + k) % 5][c] * taps[k];
+                for (int k = 0; k < 5; ++k) acc = __umul24(hb[(q + k) % 5][c], taps[k]) + acc;      // 16-bit sums x 8-bit taps: v_mad_u32_u24 (a 32-bit multiply is quarter rate)
                 bl[q % 3][c] = (int)min((acc + 32768u) >> 16, 255u);      // (saturation only bites with taps that sum to 257: blur variant 1)
             }
             if (q >= 2) {

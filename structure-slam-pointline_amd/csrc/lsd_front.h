@@ -29,6 +29,25 @@ __device__ __forceinline__ void load_row12(const uint8_t* __restrict__ s, size_t
         d2 = px[8] | (px[9] << 8) | (px[10] << 16) | (px[11] << 24);
     }
 }
+// Branch-free form of load_row12 for images whose width is a multiple of four (>= 12) with dword-aligned base and pitch: every lane loads three
+// aligned dwords -- the lanes at the left / right image border re-read an in-range dword in place of the one outside and build the reflected
+// bytes (BORDER_REFLECT_101: columns -1, -2, -3 = 1, 2, 3; w, w + 1, w + 2 = w - 2, w - 3, w - 4) with one v_perm after the data arrived.  Without
+// a branch around the loads the rows of a strip can be requested ahead of the arithmetic (ROW_AHEAD_* rows requested ahead per lane, and the scheduler is free to hoist more): with the branch
+// every row waited for its own round trip, 38 of them per strip (round 4).
+struct Row12 { unsigned d0, d1, d2; };
+// rows requested ahead per lane, per kernel (measured, profiles/r04_kernel_variants.txt: more rows in flight cost registers, i.e. resident waves)
+constexpr int ROW_AHEAD_BLUR7 = 1, ROW_AHEAD_SOBEL = 2;
+__device__ __forceinline__ bool row12_uniform(const uint8_t* s, size_t spitch, int w) { return (w & 3) == 0 && w >= 12 && ((spitch | (size_t)(uintptr_t)s) & 3) == 0; }
+__device__ __forceinline__ Row12 row12_issue(const uint8_t* __restrict__ s, size_t spitch, int yy, int x4, int w) {
+    const unsigned* q = (const unsigned*)(s + (size_t)yy * spitch + x4);
+    Row12 r; r.d1 = q[0]; r.d0 = q[x4 < 4 ? 0 : -1]; r.d2 = q[x4 + 8 > w ? 0 : 1];
+    return r;
+}
+__device__ __forceinline__ void row12_fix(Row12& r, int x4, int w) {
+    const unsigned l = __builtin_amdgcn_perm(r.d2, r.d1, 0x01020304u);       // columns -4 .. -1 <- 4, 3, 2, 1
+    const unsigned rr = __builtin_amdgcn_perm(r.d1, r.d0, 0x03040506u);      // columns w .. w + 3 <- w - 2, w - 3, w - 4, w - 5
+    r.d0 = x4 < 4 ? l : r.d0; r.d2 = x4 + 8 > w ? rr : r.d2;
+}
 // sum over k of tap[k] * byte[s + k] of the 12 bytes d0:d1:d2, taps packed four to a dword (v_dot4_u32_u8); s = 1 .. 6,
 // the taps beyond the kernel length are 0 so the bytes they meet do not matter
 __device__ __forceinline__ unsigned hdot(unsigned d0, unsigned d1, unsigned d2, int s, unsigned T0, unsigned T1) {
@@ -59,11 +78,20 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, 
     const unsigned T0 = taps[0] | (taps[1] << 8) | (taps[2] << 16) | (taps[3] << 24), T1 = taps[4] | (taps[5] << 8) | (taps[6] << 16);   // q8 taps < 256
     const bool fast = x4 >= 4 && x4 + 8 <= w && ((spitch | (size_t)(uintptr_t)s) & 3) == 0;
     unsigned win[7][4];
+    constexpr int NR = STRIP + 2 * R;
+    const bool uni = row12_uniform(s, spitch, w);      // kernel-uniform: branch-free row loads, ROW_AHEAD_BLUR7 rows in flight (lsd_front.h)
+    const int x4u = uni ? x4 : 0;                       // (otherwise the ring reads the first bytes of the rows, unused, and load_row12 does the work)
+    Row12 ring[ROW_AHEAD_BLUR7];
 #pragma unroll
-    for (int r = 0; r < STRIP + 2 * R; ++r) {
+    for (int k = 0; k < ROW_AHEAD_BLUR7; ++k) ring[k] = row12_issue(s, spitch, reflect_row(y0 - R + k, h, R), x4u, w);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
         if (r >= 2 * R && y0 + r - 2 * R >= h) break;
-        unsigned d0, d1, d2;
-        load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, d0, d1, d2);
+        Row12 cur = ring[r % ROW_AHEAD_BLUR7];
+        if (r + ROW_AHEAD_BLUR7 < NR) ring[r % ROW_AHEAD_BLUR7] = row12_issue(s, spitch, reflect_row(y0 - R + r + ROW_AHEAD_BLUR7, h, R), x4u, w);
+        row12_fix(cur, x4u, w);
+        if (!uni) load_row12(s, spitch, reflect_row(y0 - R + r, h, R), x4, w, fast, cur.d0, cur.d1, cur.d2);
+        const unsigned d0 = cur.d0, d1 = cur.d1, d2 = cur.d2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) win[r % 7][j] = hdot(d0, d1, d2, j + 1, T0, T1);      // columns x4+j-3 .. x4+j+3
         if (r >= 2 * R) {
@@ -73,7 +101,7 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, 
             for (int j = 0; j < 4; ++j) {
                 unsigned acc = 0;
 #pragma unroll
-                for (int k = 0; k < 7; ++k) acc += win[(r - 2 * R + k) % 7][j] * taps[k];
+                for (int k = 0; k < 7; ++k) acc = __umul24(win[(r - 2 * R + k) % 7][j], taps[k]) + acc;      // 16-bit sums x 8-bit taps: v_mad_u32_u24 (a 32-bit multiply is quarter rate)
                 o[j] = min((acc + 32768u) >> 16, 255u);
             }
             uint8_t* dp = d + (size_t)y * dpitch + x4;
@@ -126,8 +154,9 @@ __global__ void k_grad_smin(int* __restrict__ out, double rho) {
 // The 0.8x INTER_LINEAR_EXACT image (D7) is never stored: the 2 x 5 scaled pixels a thread needs are recomputed here from the blurred
 // source (four source rows as three aligned dwords each).
 __device__ __forceinline__ int scaled_px(unsigned e0, unsigned e1, unsigned cx, unsigned cy) {      // e = {p0, p1} bytes of the two source rows
-    const unsigned r0 = (e0 & 255u) * (256u - cx) + ((e0 >> 8) & 255u) * cx, r1 = (e1 & 255u) * (256u - cx) + ((e1 >> 8) & 255u) * cx;
-    return (int)((r0 * (256u - cy) + r1 * cy + 32768u) >> 16);
+    // (every factor is below 2^17: v_mul_u32_u24 / v_mad_u32_u24, full rate; a 32-bit multiply is quarter rate)
+    const unsigned r0 = __umul24(e0 & 255u, 256u - cx) + __umul24((e0 >> 8) & 255u, cx), r1 = __umul24(e1 & 255u, 256u - cx) + __umul24((e1 >> 8) & 255u, cx);
+    return (int)((__umul24(r0, 256u - cy) + __umul24(r1, cy) + 32768u) >> 16);
 }
 #ifndef SSLAM_GRAD_ROWS
 #define SSLAM_GRAD_ROWS 8

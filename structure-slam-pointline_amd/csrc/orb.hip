@@ -808,7 +808,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
             const unsigned short* h = hb + (PR + yy - 3) * 40 + (18 + xx);
             unsigned acc = 0;
 #pragma unroll
-            for (int q = 0; q < 7; ++q) acc += (unsigned)h[q * 40] * (unsigned)kBlurTaps[q];
+            for (int q = 0; q < 7; ++q) acc = __umul24((unsigned)h[q * 40], kBlurTaps[q]) + acc;
             descOut[((size_t)b * cap + outIdx) * (TAPW * TAPW) + i] = (uint8_t)min((acc + 32768u) >> 16, 255u);      // (saturation only bites with taps that sum to 257: blur variant 1)
         }
     }
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
             const unsigned short* h = hb + (PR + yy - 3) * 40 + (18 + xx);
             unsigned acc = 0;
 #pragma unroll
-            for (int q = 0; q < 7; ++q) acc += (unsigned)h[q * 40] * (unsigned)kBlurTaps[q];
+            for (int q = 0; q < 7; ++q) acc = __umul24((unsigned)h[q * 40], kBlurTaps[q]) + acc;
             t[e] = (int)min((acc + 32768u) >> 16, 255u);
         }
         nib |= (unsigned)(t[0] < t[1]) << k;

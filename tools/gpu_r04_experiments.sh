@@ -256,5 +256,22 @@ PY
 done 2>&1 | tee $O/summary.txt
 rocm-smi --showmeminfo vram 2>/dev/null | tail -4
 ;;
-*) echo "usage: $0 {a|b|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q}"; exit 2 ;;
+r)
+# round 4, call r: k_blur7 / k_blur_sobel with branch-free row loads (ROW_AHEAD rows requested ahead) and 24-bit multiplies: parity, one-stream kernel times per variant
+O=$R/gpurun_out/r04r; mkdir -p $O
+timeout 600 python -m pytest tests/test_lines_gpu.py tests/test_orb_gpu.py tests/test_edge_gpu.py tests/test_configs_gpu.py -x -q -m gpu > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt
+for n in base ra1 ra2; do
+  L=$R/structure-slam-pointline_amd/lib/variants/$n.so; [ $n = base ] && L=$R/structure-slam-pointline_amd/lib/libsslam_frontend.so
+  [ -f $L ] || continue
+  SSLAM_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-extras --no-other-workloads --no-overlap --steps 3 --warmup 1 > $O/bench_$n.json 2>/dev/null
+  python - <<PY
+import json
+try:
+    d=json.load(open('$O/bench_$n.json')); k=d['roofline']['kernels_ms_per_step']
+    print('$n', round(d['value']), round(d['ms_per_step'],1), {a: round(k[a],2) for a in ('k_blur7','k_blur_sobel','k_lsd_grad','k_describe','k_lbd')})
+except Exception as e: print('$n', 'failed', e)
+PY
+done 2>&1 | tee $O/summary.txt
+;;
+*) echo "usage: $0 {a|b|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q|r}"; exit 2 ;;
 esac
