@@ -60,7 +60,7 @@ struct CellInfo {
     short level, x0, y0, x1, y1;  // detection rectangle [x0,x1) x [y0,y1) in level coordinates
     short pad;
     int candOff;                  // offset inside the frame's candidate array
-    unsigned magic, gmagic;       // 2^20 / cell width + 1 and 2^20 / (dword groups per row) + 1: k_fast_cells' exact divisions (a u32 division is ~35 instructions, per wave)
+    unsigned magic, gmagic;       // 2^19 / cell width + 1 and 2^19 / (dword groups per row) + 1: k_fast_cells' exact divisions as one 24-bit multiply and a shift (i < 4400 < 2^19 / 64; the product stays below 2^32)
 };
 
 __device__ const signed char kPat[1024] = {
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
     const int t = blockIdx.x * 256 + threadIdx.x;
     // t / ngroups without the ~35-instruction division: the quotient of the float product is off by at most one for t < 2^24
     int y = (int)((float)t * D.rcpGroups);
-    { const int r = t - y * ngroups; y += r >= ngroups ? 1 : (r < 0 ? -1 : 0); }
-    const int x4 = (t - y * ngroups) * 4;
+    { const int r = t - __mul24(y, ngroups); y += r >= ngroups ? 1 : (r < 0 ? -1 : 0); }
+    const int x4 = (t - __mul24(y, ngroups)) * 4;
     if (y >= D.h) return;
     const short4 ty = tabs[D.tabY + y];
     const uint4 ta = *(const uint4*)(tabs + D.tabX + x4), tb = *(const uint4*)(tabs + D.tabX + x4 + 2);
@@ -131,7 +131,6 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
         const unsigned* q0 = (const unsigned*)(g0 + a);
         const unsigned* q1 = (const unsigned*)(g1 + a);
         const unsigned u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
-        const int b0s = b0 << 16, b1s = b1 << 16;            // (b * x) >> 16 == mulhi(b << 16, x) for the 11-bit taps
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
             const int oA = sx[2 * pr] - a, oB = sx[2 * pr + 1] - a;
@@ -148,7 +147,7 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
                 const s16x2 p0 = as_s16x2(__builtin_amdgcn_perm(0u, r0, wsel)), p1 = as_s16x2(__builtin_amdgcn_perm(0u, r1, wsel));
                 const s16x2 cf = as_s16x2(__builtin_amdgcn_alignbit(tw[2 * i + 1], tw[2 * i], 16));      // (a0, a1)
                 const int h0 = __builtin_amdgcn_sdot2(p0, cf, 0, false), h1 = __builtin_amdgcn_sdot2(p1, cf, 0, false);
-                const int v = (__mulhi(b0s, h0 >> 4) + __mulhi(b1s, h1 >> 4) + 2) >> 2;
+                const int v = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;      // coefficients <= 2^11, row sums <= 2^15: v_mul_i32_i24 (v_mul_hi_i32 is quarter rate)
                 out |= (unsigned)(v & 255) << (8 * i);
             }
         }
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     }
     for (int i = lane; i < (((ch + 2) * scP + 3) >> 2); i += 64) ((unsigned*)sc)[i] = 0;
     __syncthreads();
-    const unsigned magic = ci.magic;      // (1 << 20) / cw + 1: floor(i/cw) == (i*magic)>>20 for i < 4400, cw <= 64
+    const unsigned magic = ci.magic;      // (1 << 19) / cw + 1: floor(i/cw) == (i*magic)>>19 for i < 4400, cw <= 64
     // pass A: necessary condition for a 9-arc at minTh, four pixels per lane on whole dwords.  Nine contiguous ring positions
     // always contain two ADJACENT compass points (ring 0/4/8/12 = S/E/N/W at distance 3), i.e. one vertical and one
     // horizontal one, and both must lie on the arc's side of the threshold:
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     {
         const int T0 = off + 3;                                    // tile column of pixel 0
         const int gmin = T0 >> 2, ng = ((T0 + cw - 1) >> 2) - gmin + 1;
-        const unsigned gmagic = ci.gmagic;                          // (1 << 20) / ng + 1: ng <= 17, items < 4400
+        const unsigned gmagic = ci.gmagic;                          // (1 << 19) / ng + 1: ng <= 17, items < 4400
         const int nitems = ch * ng;
         const s16x2 th2 = {(short)minTh, (short)minTh};
         for (int it0 = 0; it0 < nitems; it0 += 64) {
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
             unsigned flags = 0;
             int py = 0, g = 0;
             if (it < nitems) {
-                py = (int)(((unsigned long long)(unsigned)it * gmagic) >> 20);
+                py = (int)(__umul24((unsigned)it, gmagic) >> 19);
                 g = gmin + (it - py * ng);
                 const unsigned* rc = (const unsigned*)(tile + (py + 3) * tileP) + g;
                 const unsigned c1 = rc[0], c0 = rc[-1], c2 = rc[1];
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     __syncthreads();
     for (int j = lane; j < ncl; j += 64) {
         const int i = clist[j];
-        const int py = (int)(((unsigned long long)(unsigned)i * magic) >> 20), px = i - py * cw;
+        const int py = (int)(__umul24((unsigned)i, magic) >> 19), px = i - __mul24(py, cw);
         const int s = fast_score16(tile + (py + 3) * tileP + (off + px + 3), tileP, minTh);
         if (s) sc[(py + 1) * scP + (px + 1)] = (uint8_t)s;        // sc is pre-zeroed
     }
@@ -333,7 +332,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
         int cde = 0;
         if (j < ncl) {
             const int i = clist[j];
-            const int py = (int)(((unsigned long long)(unsigned)i * magic) >> 20), px = i - py * cw;
+            const int py = (int)(__umul24((unsigned)i, magic) >> 19), px = i - __mul24(py, cw);
             const uint8_t* c = sc + (py + 1) * scP + (px + 1);
             int s = c[0];
             if (s > 0 && s > c[-1] && s > c[1] && s > c[-scP - 1] && s > c[-scP] && s > c[-scP + 1] &&
@@ -354,7 +353,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
         unsigned long long m = __ballot(keep);
         if (keep) {
             const int i = clist[j];
-            const int py = (int)(((unsigned long long)(unsigned)i * magic) >> 20), px = i - py * cw;
+            const int py = (int)(__umul24((unsigned)i, magic) >> 19), px = i - __mul24(py, cw);
             int s = sc[(py + 1) * scP + (px + 1)];
             out[n + mbcnt(m)] = ((unsigned)s << 24) | ((unsigned)(ci.y0 + py - MINB) << 12) | (unsigned)(ci.x0 + px - MINB);
         }
@@ -976,7 +975,7 @@ static int build_plan(sslam_orb* o, int w, int h) {
                     P.maxCellW = std::max(P.maxCellW, cw); P.maxCellH = std::max(P.maxCellH, chh);
                     {   // as k_fast_cells lays the tile out: tile column of pixel 0 = off + 3, off = (x0 - 3) & 3
                         const int T0 = ((c.x0 - 3) & 3) + 3, gmin = T0 >> 2, ng = ((T0 + cw - 1) >> 2) - gmin + 1;
-                        c.magic = (1u << 20) / (unsigned)cw + 1; c.gmagic = (1u << 20) / (unsigned)ng + 1;
+                        c.magic = (1u << 19) / (unsigned)cw + 1; c.gmagic = (1u << 19) / (unsigned)ng + 1;
                     }
                     o->cells.push_back(c);
                 }
