@@ -20,6 +20,8 @@
 #include <cfloat>
 #include <algorithm>
 
+namespace sslam { int launch_nfa_stage(sslam_ctx* ctx, hipStream_t st, uint8_t* ws, const void* plan, size_t planBytes, const double* lgam, int nframes); }      // lines_nfa.hip
+
 using namespace sslam;
 
 namespace {
@@ -349,46 +351,8 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         }
     }
     if (L->coreDone) SSLAM_HIP(hipEventRecord(L->coreDone, st));
-    int evalWaves = nframes >= 1024 ? 1 : nframes >= 64 ? 4 : nframes >= 16 ? 16 : 32;      // waves per frame walking the NFA evaluations
-    int countWaves = nframes >= 2048 ? 1 : nframes >= 128 ? 8 : nframes >= 16 ? 64 : 128;   // waves per frame walking the rectangle counts (round 4: 128 / 32 for a handful of frames, 6.25 -> 6.09 ms per frame)
-    if (const char* e = getenv("SSLAM_COUNT_WAVES")) countWaves = std::max(1, atoi(e));
-    if (const char* e = getenv("SSLAM_EVAL_WAVES")) evalWaves = std::max(1, atoi(e));
-    // The whole NFA stage as ONE launch (lsd_nfa.h): one wave per frame when the frames themselves fill the chip (k_nfa_all, calls of >= 2048 frames).
-    // Below that the 18 launches stay: a single frame's stage is bound by the work of each wave, not by launch boundaries (kernel durations add up
-    // to the stage's 0.6 ms), and the one-workgroup form (k_nfa_all_wg, sixteen waves) has a quarter of the counting waves: measured 6.42 / 7.70 ms
-    // p50 / p90 per frame against 6.25 / 7.40 (eight waves: 6.66).  What helped instead: 128 counting and 32 evaluating waves per frame (6.09 / 7.16).
-    // SSLAM_NFA_WAVES=n forces the workgroup form with n waves, SSLAM_NFA_FUSED=0 the launches, =2 the one-wave form (tests).
-    int nfaWaves = 0;
-    if (const char* e = getenv("SSLAM_NFA_WAVES")) nfaWaves = std::max(1, std::min(16, atoi(e)));
-    bool nfaFused = nfaWaves > 0 || (countWaves == 1 && evalWaves == 1);
-    if (nfaWaves == 0) nfaWaves = 1;
-    if (const char* e = getenv("SSLAM_NFA_FUSED")) { nfaFused = atoi(e) == 2 || (nfaFused && atoi(e) != 0); if (atoi(e) == 2) nfaWaves = 1; }
-    if (nfaFused && nfaWaves == 1) {
-        sslam::ProfScope _ps(L->ctx, "k_nfa_all", st);
-        hipLaunchKernelGGL(k_nfa_all, dim3(nframes), dim3(64), 0, st, ws, P, L->dLgam.as<double>());
-    } else if (nfaFused) {
-        const size_t nfaLds = sizeof(NfaLdsT<WG_CH>) * (size_t)nfaWaves;
-        sslam::ProfScope _ps(L->ctx, "k_nfa_all", st);
-        if (nfaWaves > 8) {
-            if (nfaLds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_nfa_all_wg<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nfaLds));
-            hipLaunchKernelGGL(k_nfa_all_wg<1024>, dim3(nframes), dim3(64 * nfaWaves), nfaLds, st, ws, P, L->dLgam.as<double>());
-        } else {
-            if (nfaLds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_nfa_all_wg<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nfaLds));
-            hipLaunchKernelGGL(k_nfa_all_wg<512>, dim3(nframes), dim3(64 * nfaWaves), nfaLds, st, ws, P, L->dLgam.as<double>());
-        }
-    } else {
-        for (int stage = 0; stage <= 4; ++stage) {
-            { static const char* kCountNames[5] = {"k_nfa_count", "k_nfa_count/s1", "k_nfa_count/s2", "k_nfa_count/s3", "k_nfa_count/s4"};
-              sslam::ProfScope _ps(L->ctx, getenv("SSLAM_PROF_STAGES") ? kCountNames[stage] : "k_nfa_count", st); hipLaunchKernelGGL(k_nfa_count, dim3(countWaves, nframes), dim3(64), 0, st, ws, P, stage); }
-            if (stage == 0) {
-                { sslam::ProfScope _ps(L->ctx, "k_nfa_eval", st); hipLaunchKernelGGL(k_nfa_eval, dim3(evalWaves, nframes), dim3(64), 0, st, ws, P, -1, L->dLgam.as<double>()); }
-                { sslam::ProfScope _ps(L->ctx, "k_nfa_accept", st); hipLaunchKernelGGL(k_nfa_accept, dim3(4, nframes), dim3(256), 0, st, ws, P, -1); }
-            }
-            { sslam::ProfScope _ps(L->ctx, "k_nfa_eval", st); hipLaunchKernelGGL(k_nfa_eval, dim3(evalWaves, nframes), dim3(64), 0, st, ws, P, stage, L->dLgam.as<double>()); }
-            { sslam::ProfScope _ps(L->ctx, "k_nfa_accept", st); hipLaunchKernelGGL(k_nfa_accept, dim3(4, nframes), dim3(256), 0, st, ws, P, stage); }
-        }
-        { sslam::ProfScope _ps(L->ctx, "k_nfa_finish", st); hipLaunchKernelGGL(k_nfa_finish, dim3(4, nframes), dim3(256), 0, st, ws, P); }
-    }
+    // the NFA stage: its kernels and launch forms live in lines_nfa.hip, a translation unit of its own (compiled with -mllvm -disable-machine-licm)
+    { const int rc = sslam::launch_nfa_stage(L->ctx, st, ws, &P, sizeof(P), L->dLgam.as<double>(), nframes); if (rc) return rc; }
     { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
     // LBD: blur(5, 1) + Sobel fused (SSLAM_LBD_SOBEL=early: in the prologue) -> bands
     if (!sobelEarly) launch_blur_sobel();

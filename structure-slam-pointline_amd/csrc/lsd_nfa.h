@@ -493,6 +493,7 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
     for (int j = 0; j < MAXC; ++j) total[j] = wave_sum_dpp(total[j]);
 }
 
+#ifndef SSLAM_NFA_STAGE_ONLY      // (needs the gradient table of lsd_front.h: lines.hip only)
 // Self-test of lsd_align_win.h on the device (sslam_selftest_align_windows): one (theta, tolerance) case per block round -- theta anywhere
 // region2rect can put it ([0, 3pi)), negative, glued to the 0 / 2pi seams or to the pruning edges; tolerances pi/8 * 2^-h and arbitrary
 // ones below pi/2 -- whose windows are compared with the reference predicate (is_aligned_val, lsd_plan.h) on EVERY angle the gradient
@@ -544,6 +545,8 @@ __global__ __launch_bounds__(256) void k_selftest_align(unsigned long long seed,
     if (bad) atomicAdd(out, bad);
     atomicAdd(out + 1, tests);
 }
+
+#endif
 
 // stage 0 is merged with the initial evaluation: same rectangle, six precisions (p, p/2 .. p/32); stage 4 likewise has one
 // geometry and five precisions.  Stages 1-3 change the rectangle itself: up to five candidates per rectangle.
@@ -723,6 +726,16 @@ __device__ __forceinline__ int stage_ncand(const NfaState& s, int stage) {
     if (s.done) return 0;
     return stage == 0 ? 5 : stage == 4 ? (s.nc > 0 ? 5 : 0) : s.nc;
 }
+// log10 behind a call (SSLAM_NFA_LOG10_CALL): inlined into the fused kernel its polynomial constants are hoisted out of the evaluation loop into
+// registers the loop does not have, spilled, and reloaded from scratch one by one with a wait each (six dependent round trips per use)
+#ifndef SSLAM_NFA_LOG10_CALL
+#define SSLAM_NFA_LOG10_CALL 1
+#endif
+#if SSLAM_NFA_LOG10_CALL
+__device__ __noinline__ double nfa_log10(double x) { return log10(x); }
+#else
+__device__ __forceinline__ double nfa_log10(double x) { return log10(x); }
+#endif
 template <bool WG1, int CH>
 __device__ __forceinline__ void nfa_eval_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, const double* __restrict__ lgam, int part, int nparts, int lane,
                                                unsigned short* __restrict__ items) {
@@ -759,7 +772,7 @@ __device__ __forceinline__ void nfa_eval_body(uint8_t* __restrict__ base, const 
             const bool more = pos < nItems;
             if ((more && nIdle >= EVAL_REFILL) || am == 0) {
                 if (!active && pending) {                      // finish and publish what the idle lanes hold
-                    if (needLog) v = -log10(S.bin_tail) - P.logNT;
+                    if (needLog) v = -nfa_log10(S.bin_tail) - P.logNT;
                     st[myc].val[myj] = v;
                     pending = false;
                 }
