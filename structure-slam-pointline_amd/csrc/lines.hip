@@ -166,8 +166,13 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offBlur = take(bpitch * h);                         // sigma-0.75 blur of the source (LSD)
     P.tW = P.sw; P.cW = P.sw;
     P.offT = take(sizeof(float) * (size_t)P.npx);
+#if SSLAM_LSD_PACKED
+    P.offCs = take(16 * (size_t)P.npx);      // {cos, sin, |g|^2, -} records
+    P.offS = P.offCs + 8;
+#else
     P.offS = take(sizeof(int) * (size_t)P.npx);
     P.offCs = take(sizeof(float2) * (size_t)P.npx);
+#endif
     P.offOrder = take(sizeof(unsigned) * (size_t)P.npx);
     P.offTileHist = take(sizeof(int) * (size_t)P.nTiles * N_BINS);
     P.offReg = take(sizeof(unsigned) * std::max((size_t)P.npx, (size_t)P.sh * P.nXB * 256));      // region lists beyond QCAP; before the core: the segments' lists

@@ -161,9 +161,6 @@ __device__ __forceinline__ int scaled_px(unsigned e0, unsigned e1, unsigned cx, 
 #ifndef SSLAM_GRAD_ROWS
 #define SSLAM_GRAD_ROWS 8
 #endif
-#ifndef SSLAM_GRAD_WIDE
-#define SSLAM_GRAD_WIDE 0
-#endif
 #ifndef SSLAM_GRAD_WAVES
 #define SSLAM_GRAD_WAVES 0
 #endif
@@ -178,7 +175,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
     const uint8_t* src = base + P.offBlur;
     float* T = (float*)(base + P.offT);
     float2* Cs = (float2*)(base + P.offCs);
-    int* S = (int*)(base + P.offS);
+    int* S = (int*)(base + P.offS); (void)S;
     Misc* misc = (Misc*)(base + P.offMisc);
     unsigned* comp = (unsigned*)(base + P.offComp);
     int* segCnt = (int*)(base + P.offSegCnt);
@@ -232,24 +229,28 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
         for (int j = 0; j < 4; ++j)
             if (flags & (1u << j)) { const float4 rec = gtab[gidx[j]]; ang[j] = rec.x; cs[j] = make_float2(rec.y, rec.z); }      // the four gathers are in flight together
         const size_t i = (size_t)y * P.sw + x4;
+#if SSLAM_LSD_PACKED
+        // T densely; {cos, sin, |g|^2, -} records under the lanes that hold a defined pixel: the four records of a lane are 64 contiguous bytes
+        float4* rec = (float4*)((char*)Cs + (i << 4));
         if ((P.sw & 3) == 0) {
             if (inx) *(float4*)(T + i) = make_float4(ang[0], ang[1], ang[2], ang[3]);
-#if SSLAM_GRAD_WIDE      // whole 64-byte blocks: S of a lane quad, Cs of a lane pair
-            const unsigned f2 = flags | (unsigned)__builtin_amdgcn_mov_dpp((int)flags, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
-            const unsigned f4 = f2 | (unsigned)__builtin_amdgcn_mov_dpp((int)f2, 0x4E, 0xF, 0xF, true);             // quad_perm [2,3,0,1]
-            if (f4 && inx) *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
-            if (f2 && inx) {
-                float4* c = (float4*)(Cs + i);
-                c[0] = make_float4(cs[0].x, cs[0].y, cs[1].x, cs[1].y);
-                c[1] = make_float4(cs[2].x, cs[2].y, cs[3].x, cs[3].y);
+            if (flags) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rec[j] = make_float4(cs[j].x, cs[j].y, __int_as_float(sv[j]), 0.f);
             }
-            if (false) {
-                float4* c = nullptr;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) {
+                T[i + j] = ang[j];
+                if (flags & (1u << j)) rec[j] = make_float4(cs[j].x, cs[j].y, __int_as_float(sv[j]), 0.f);
+            }
+        }
 #else
+        if ((P.sw & 3) == 0) {
+            if (inx) *(float4*)(T + i) = make_float4(ang[0], ang[1], ang[2], ang[3]);
             if (flags) {
                 *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
                 float4* c = (float4*)(Cs + i);
-#endif
                 c[0] = make_float4(cs[0].x, cs[0].y, cs[1].x, cs[1].y);
                 c[1] = make_float4(cs[2].x, cs[2].y, cs[3].x, cs[3].y);
             }
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
                 if (flags & (1u << j)) { S[i + j] = sv[j]; Cs[i + j] = cs[j]; }
             }
         }
+#endif
         // the segment's list of defined pixels, raster order = lane order, then column inside the lane
         const int seg = y * P.nXB + blockIdx.x;
         const int cnt = __popc(flags), incl = wave_incl_scan(cnt);

@@ -21,6 +21,13 @@ constexpr float NOTDEF_F = -1024.0f;
 // 16 bytes per pixel written by k_lsd_grad in round 3 (24 before), 4 B + ~24 B per defined pixel now.  (A tiled form of T / Cs -- 8 x 4 and 4 x 4 pixels per 128-byte line -- was built
 // and measured first: L1 misses of the sequential core -12 %, its time unchanged, the rectangle counter +40 % for the address
 // arithmetic; profiles/README.md, round 3.)
+// SSLAM_LSD_PACKED=1 (experiment, round 4 §5g): Cs and S of a pixel in ONE 16-byte record {cos, sin, |g|^2, -} (offCs; offS = offCs + 8), so that the
+// four records of a lane of k_lsd_grad are one full 64-byte store where a 32-byte Cs store and a 16-byte S store are two partial ones.  Measured
+// SLOWER (k_lsd_grad 11.2 -> 13.0 ms: it is the bytes that count, 64 against 48 per lane, not the bursts), the core unchanged: off.
+#ifndef SSLAM_LSD_PACKED
+#define SSLAM_LSD_PACKED 0
+#endif
+constexpr int CS_SHIFT = SSLAM_LSD_PACKED ? 4 : 3, S_SHIFT = SSLAM_LSD_PACKED ? 4 : 2;      // log2 of the byte stride of the Cs / S entries
 constexpr unsigned USED_BIT = 0x80000000u;
 constexpr int N_BINS = 1024;
 constexpr int TILE_PX = 8192;           // raster tile of the counting sort (rounded down to whole rows: LsdPlan::tileRows)

@@ -23,7 +23,7 @@ struct Planes {
     // 32-bit-offset form (global_load ... v_off, s[base]) instead of a 64-bit address computed per lane (a frame's planes are < 2^31 bytes)
     __device__ __forceinline__ float ldT(int i) const { return *(const float*)((const char*)T + ((unsigned)i << 2)); }
     __device__ __forceinline__ void stT(int i, float v) const { *(float*)((char*)T + ((unsigned)i << 2)) = v; }
-    __device__ __forceinline__ float2 ldCs(int i) const { return *(const float2*)((const char*)Cs + ((unsigned)i << 3)); }
+    __device__ __forceinline__ float2 ldCs(int i) const { return *(const float2*)((const char*)Cs + ((unsigned)i << CS_SHIFT)); }
     // (coordinates and pitch are < 2^16: v_mad_u32_u24, one full-rate instruction; v_mul_lo_u32 is quarter rate)
     __device__ __forceinline__ int ti(int x, int y) const { return (int)(__umul24((unsigned)y, (unsigned)tW) + (unsigned)x); }
     __device__ __forceinline__ int ti(unsigned e) const { return (int)(__umul24(e >> 16, (unsigned)tW) + (e & 0xFFFFu)); }
@@ -354,7 +354,7 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const int* __restri
         if (i < n) {
             const unsigned e = rq.get_n(i, n);
             const int px = e & 0xFFFF, py = e >> 16;
-            wgt = sqrt((double)*(const int*)((const char*)S + ((__umul24((unsigned)py, (unsigned)sw) + (unsigned)px) << 2)) / 4.0);
+            wgt = sqrt((double)*(const int*)((const char*)S + ((__umul24((unsigned)py, (unsigned)sw) + (unsigned)px) << S_SHIFT)) / 4.0);
             fx = (double)px * wgt; fy = (double)py * wgt;
             if (base == 0) { wgt0 = wgt; px0 = px; py0 = py; }
         }
@@ -372,7 +372,7 @@ __device__ void region2rect_m(const RegQ& rq, int n, int sw, const int* __restri
             if (base != 0) {
                 const unsigned e = rq.get_n(i, n);
                 px = e & 0xFFFF; py = e >> 16;
-                wgt = sqrt((double)*(const int*)((const char*)S + ((__umul24((unsigned)py, (unsigned)sw) + (unsigned)px) << 2)) / 4.0);
+                wgt = sqrt((double)*(const int*)((const char*)S + ((__umul24((unsigned)py, (unsigned)sw) + (unsigned)px) << S_SHIFT)) / 4.0);
             }
             const double ddx = (double)px - x, ddy = (double)py - y;
             a = ddy * ddy * wgt; b = ddx * ddx * wgt; c = ddx * ddy * wgt;

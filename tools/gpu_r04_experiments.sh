@@ -294,5 +294,24 @@ PY
   SSLAM_LIB=$L timeout 200 python tools/latency_probe.py 2>&1 | tail -1 | cut -c1-200
 done 2>&1 | tee $O/summary.txt
 ;;
-*) echo "usage: $0 {a|b|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q|r|s}"; exit 2 ;;
+t)
+# round 4, call t: Cs and S of a pixel in one 16-byte record (SSLAM_LSD_PACKED, default) against the two planes (variant `unpacked`): parity, kernel times, latency
+O=$R/gpurun_out/r04t; mkdir -p $O
+timeout 600 python -m pytest tests/test_lines_gpu.py tests/test_configs_gpu.py tests/test_batch_gpu.py tests/test_edge_gpu.py -x -q -m gpu > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt
+for n in base unpacked; do
+  L=$R/structure-slam-pointline_amd/lib/variants/$n.so; [ $n = base ] && L=$R/structure-slam-pointline_amd/lib/libsslam_frontend.so
+  for ov in "--no-overlap" ""; do
+  SSLAM_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-extras --no-other-workloads $ov --steps 3 --warmup 1 > $O/bench_$n$ov.json 2>/dev/null
+  python - <<PY
+import json
+try:
+    d=json.load(open('$O/bench_$n$ov.json')); k=d['roofline']['kernels_ms_per_step']
+    print('$n $ov', round(d['value']), round(d['ms_per_step'],1), {a: round(v,2) for a,v in k.items() if a in ('k_lsd_regions','k_nfa_all','k_lsd_grad','k_lsd_hist','k_lsd_scatter')})
+except Exception as e: print('$n', 'failed', e)
+PY
+  done
+  SSLAM_LIB=$L timeout 200 python tools/latency_probe.py 2>&1 | tail -1 | cut -c1-200
+done 2>&1 | tee $O/summary.txt
+;;
+*) echo "usage: $0 {a|b|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q|r|s|t}"; exit 2 ;;
 esac
