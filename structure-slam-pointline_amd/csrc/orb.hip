@@ -280,10 +280,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
             int py = 0, g = 0;
             if (it < nitems) {
                 py = (int)(__umul24((unsigned)it, gmagic) >> 19);
-                g = gmin + (it - py * ng);
-                const unsigned* rc = (const unsigned*)(tile + (py + 3) * tileP) + g;
+                g = gmin + (it - __mul24(py, ng));
+                const int rowN = __mul24(py, tileP);               // (24-bit multiplies throughout: v_mul_lo_u32 is quarter rate)
+                const unsigned* rc = (const unsigned*)(tile + rowN + 3 * tileP) + g;
                 const unsigned c1 = rc[0], c0 = rc[-1], c2 = rc[1];
-                const unsigned n4 = ((const unsigned*)(tile + py * tileP))[g], s4 = ((const unsigned*)(tile + (py + 6) * tileP))[g];
+                const unsigned n4 = ((const unsigned*)(tile + rowN))[g], s4 = ((const unsigned*)(tile + rowN + 6 * tileP))[g];
                 const unsigned e4 = __builtin_amdgcn_alignbyte(c2, c1, 3), w4 = __builtin_amdgcn_alignbyte(c1, c0, 1);
                 unsigned res = 0;
 #pragma unroll
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
             const int cntf = __popc(flags);
             const int incl = wave_incl_scan(cntf);
             int pos = ncl + incl - cntf;
-            const int ibase = py * cw + 4 * g - T0;
+            const int ibase = __mul24(py, cw) + 4 * g - T0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (flags & (1u << k)) clist[pos++] = (unsigned short)(ibase + k);
             ncl += __builtin_amdgcn_readlane(incl, 63);
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     for (int j = lane; j < ncl; j += 64) {
         const int i = clist[j];
         const int py = (int)(__umul24((unsigned)i, magic) >> 19), px = i - __mul24(py, cw);
-        const int s = fast_score16(tile + (py + 3) * tileP + (off + px + 3), tileP, minTh);
-        if (s) sc[(py + 1) * scP + (px + 1)] = (uint8_t)s;        // sc is pre-zeroed
+        const int s = fast_score16(tile + __mul24(py + 3, tileP) + (off + px + 3), tileP, minTh);
+        if (s) sc[__mul24(py + 1, scP) + (px + 1)] = (uint8_t)s;        // sc is pre-zeroed
     }
     __syncthreads();
     // NMS + thresholds + emission only visit the compacted list (it is in raster order, and so is what it emits)
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
         if (j < ncl) {
             const int i = clist[j];
             const int py = (int)(__umul24((unsigned)i, magic) >> 19), px = i - __mul24(py, cw);
-            const uint8_t* c = sc + (py + 1) * scP + (px + 1);
+            const uint8_t* c = sc + __mul24(py + 1, scP) + (px + 1);
             int s = c[0];
             if (s > 0 && s > c[-1] && s > c[1] && s > c[-scP - 1] && s > c[-scP] && s > c[-scP + 1] &&
                 s > c[scP - 1] && s > c[scP] && s > c[scP + 1])
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
         if (keep) {
             const int i = clist[j];
             const int py = (int)(__umul24((unsigned)i, magic) >> 19), px = i - __mul24(py, cw);
-            int s = sc[(py + 1) * scP + (px + 1)];
+            int s = sc[__mul24(py + 1, scP) + (px + 1)];
             out[n + mbcnt(m)] = ((unsigned)s << 24) | ((unsigned)(ci.y0 + py - MINB) << 12) | (unsigned)(ci.x0 + px - MINB);
         }
         n += __popcll(m);
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
         // as a loop of load / shift / store the kernel spent nine dependent memory round trips per keypoint here), then the shifts and LDS stores
         unsigned gl[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) gl[k] = ((const unsigned*)(src + (size_t)min(5 * k + rr, PW - 1) * L.pitch))[min(q, 11)];
+        for (int k = 0; k < 9; ++k) gl[k] = *(const unsigned*)(src + (__umul24((unsigned)min(5 * k + rr, PW - 1), (unsigned)L.pitch) + 4u * (unsigned)min(q, 11)));      // 32-bit offset from the wave's base (a 64-bit row product is three quarter-rate multiplies)
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int r = 5 * k + rr;
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
     if (TAP) {
         for (int i = lane; i < TAPW * TAPW; i += 64) {
             const int yy = i / TAPW - 18, xx = i - (i / TAPW) * TAPW - 18;
-            const unsigned short* h = hb + (PR + yy - 3) * 40 + (18 + xx);
+            const unsigned short* h = hb + __mul24(PR + yy - 3, 40) + (18 + xx);
             unsigned acc = 0;
 #pragma unroll
             for (int q = 0; q < 7; ++q) acc = __umul24((unsigned)h[q * 40], kBlurTaps[q]) + acc;
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
             float px = (float)pp[0], py = (float)pp[1];
             int yy = cv_roundf(__fadd_rn(__fmul_rn(px, bsn), __fmul_rn(py, a)));
             int xx = cv_roundf(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, bsn)));
-            const unsigned short* h = hb + (PR + yy - 3) * 40 + (18 + xx);
+            const unsigned short* h = hb + __mul24(PR + yy - 3, 40) + (18 + xx);
             unsigned acc = 0;
 #pragma unroll
             for (int q = 0; q < 7; ++q) acc = __umul24((unsigned)h[q * 40], kBlurTaps[q]) + acc;
