@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_knn2_batch(const uint8_t* __restrict__ 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int KNN_MFMA_MAX_TILES = 128;
-__device__ __forceinline__ unsigned spread4(unsigned n) { return (n * 0x00204081u) & 0x01010101u; }      // bit i of a nibble -> byte i (0 / 1)
+__device__ __forceinline__ unsigned spread4(unsigned n) { return __umul24(n, 0x00204081u) & 0x01010101u; }      // bit i of a nibble -> byte i (0 / 1)
 __device__ __forceinline__ int pm64(unsigned nibble) { const unsigned m = spread4(nibble); return (int)((m << 7) ^ 0xC0C0C0C0u); }      // bit 1 -> +64 (0x40), bit 0 -> -64 (0xC0)
 
 __global__ __launch_bounds__(64) void k_knn2_expand(const uint8_t* __restrict__ t, const int* __restrict__ nt, int cap, int tilesCap, uint8_t* __restrict__ out) {
