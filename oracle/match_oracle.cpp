@@ -6,9 +6,11 @@
 // lineDescriptorMAD, LSDmatcher::SerachForInitialize, ORBmatcher::SearchByProjection(F, MapPoints) and (Cur, Last, th, bMono),
 // LSDmatcher::SearchByProjection(F, MapLines), (Cur, Last, th, bMono) and (KF, F), LSDmatcher::SearchByDescriptor (KF, F) and (KF, KF),
 // LSDmatcher::SearchForTriangulation over KeyFrame::lineDescriptorMAD, ORBmatcher::SearchByBoW(KF, F) and (KF, KF),
-// ORBmatcher::SearchForTriangulation with CheckDistEpipolarLine, MapPoint / MapLine::ComputeDistinctiveDescriptors, the vocabulary loader + transform below against the reference's own vendored
+// ORBmatcher::SearchForTriangulation with CheckDistEpipolarLine, ORBmatcher::Fuse(KF, MapPoints, th) (:828-978, over KeyFrame::GetFeaturesInArea / IsInImage and
+// MapPoint::PredictScale / Get*DistanceInvariance; fuse_search below on the windows the reference's own projection block forms),
+// MapPoint / MapLine::ComputeDistinctiveDescriptors, the vocabulary loader + transform below against the reference's own vendored
 // DBoW2 compiled whole (oracle/_ref/libref_dbow2.so; the two places where that code reads uninitialised locals are decisions D9 / D10), and the
-// orchestration of LineSegment::ExtractLineSegment.  NOT pinned that way: Fuse / SearchBySim3 / the relocalisation and
+// orchestration of LineSegment::ExtractLineSegment.  NOT pinned that way: Fuse(KF, Scw, ...) / the line Fuse overloads / SearchBySim3 / the relocalisation and
 // loop-closing projection overloads (restated below from the source, compared with the HIP library only), and the OpenCV leaves
 // (cv::BFMatcher::knnMatch's tie-break, cv::gemm's accumulation order in the pose algebra of the (Cur, Last) calls).
 //

@@ -326,6 +326,62 @@ for name in ("synth1234", "synth2000", "noise7"):
         m_o, no = orc.search_for_triangulation(kp1, d1, ur1, free1, kp2, d2, ur2, free2, pk, pf, ik, if_, F12, float(ex), float(ey), scale8, sg8, only_stereo, ori)
         note("ORBmatcher::SearchForTriangulation %s stereo=%d ori=%d" % (name, only_stereo, ori), nr == no and np.array_equal(m_r, m_o), pairs=int(nr), epipole=(round(float(ex), 1), round(float(ey), 1)))
 
+# --- ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th) (src/ORBmatcher.cc:828-978) over KeyFrame::GetFeaturesInArea / IsInImage (src/KeyFrame.cc:610-649,
+# 686-689) and MapPoint::PredictScale / Get*DistanceInvariance (src/MapPoint.cc:378-405): LocalMapping::SearchInNeighbors' call (th = 3).  The oracle restates the
+# search per map point (fuse_search: the window, the level gate, the chi-square gates, the best descriptor); the windows are the ones the reference's own
+# projection block forms (ref_fuse_queries, same stand-ins and leaves).  Compared: which keyframe feature every map point is fused to, and the count.
+FMP = np.dtype([("wp", "<f4", 3), ("nrm", "<f4", 3), ("minDist", "<f4"), ("maxDist", "<f4"), ("nObs", "<i4"), ("bad", "<i4"), ("inKF", "<i4")])
+FQ = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("level", "<i4"), ("valid", "<i4")])
+inv_sigma2 = np.array([f32(1.0) / (s_ * s_) for s_ in scale8], np.float32); log_sf = float(np.log(f32(1.2)))
+for name in ("synth1234", "synth2000", "big1235"):
+    img, (kp1, d1), (kp2, d2) = frames[name]
+    h, w = img.shape; bb = np.array((0.0, float(w), 0.0, float(h)), np.float32); n2 = len(kp2)
+    fx = fy = f32(0.9 * w); cxx, cyy = f32(w / 2 - 3.25), f32(h / 2 + 1.5)
+    for stereo, th, same in ((False, 3.0, False), (True, 3.0, False), (True, 5.0, False), (True, 3.0, True), (False, 4.0, True)):
+        skp, sd = (kp2, d2) if same else (kp1, d1)      # where the map points come from: this keyframe's own features (most of them fuse) or the other view's
+        ur2 = np.where(rng.random(n2) < 0.5, kp2["x"] - rng.uniform(2, 40, n2), -1).astype(np.float32) if stereo else np.full(n2, -1, np.float32)
+        cam = np.array([fx, fy, cxx, cyy, 40.0], np.float32)
+        # a pose (small rotation about y and x, a translation) and its camera centre Ow = -R^T t, all float32
+        ay, ax = 0.07, -0.04
+        Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]]); Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+        Rm = (Ry @ Rx).astype(np.float32); t = np.array([0.3, -0.2, 0.5], np.float32)
+        Tcw = np.eye(4, dtype=np.float32); Tcw[:3, :3] = Rm; Tcw[:3, 3] = t
+        Ow = (-(Rm.astype(np.float64).T @ t.astype(np.float64))).astype(np.float32)
+        # map points: features of the other view unprojected at random depths (so that they land near features of this keyframe), some pushed
+        # out of the image / behind the camera / out of their distance range / seen from the side
+        nmp = len(skp); depth = rng.uniform(2.0, 12.0, nmp)
+        uu = skp["x"].astype(np.float64) + rng.uniform(-4, 4, nmp); vv = skp["y"].astype(np.float64) + rng.uniform(-4, 4, nmp)
+        pc = np.stack([(uu - float(cxx)) / float(fx) * depth, (vv - float(cyy)) / float(fy) * depth, depth], 1)
+        kind = rng.choice(6, nmp, p=[0.7, 0.06, 0.06, 0.06, 0.06, 0.06])
+        pc[kind == 1, 2] *= -1                                        # behind the camera
+        pc[kind == 2, 0] += 3 * depth[kind == 2]                      # outside the image
+        pw = (Rm.astype(np.float64).T @ (pc - t.astype(np.float64)).T).T
+        mp = np.zeros(nmp, FMP); mp["wp"] = pw.astype(np.float32)
+        po = pw - Ow.astype(np.float64); dist = np.linalg.norm(po, axis=1)
+        nrm = po / dist[:, None]; nrm[kind == 3] = -nrm[kind == 3]    # seen from behind
+        side = kind == 4; nrm[side] = np.cross(nrm[side], [0.0, 1.0, 0.0]) * 0.9 + nrm[side] * 0.45      # a viewing angle around the 60-degree gate
+        mp["nrm"] = nrm.astype(np.float32)
+        lvl = skp["octave"].astype(np.int64) if same else rng.integers(0, 8, nmp); mp["maxDist"] = (dist * 1.2 ** lvl * rng.uniform(0.9, 1.3, nmp)).astype(np.float32)
+        mp["minDist"] = (mp["maxDist"] / f32(1.2 ** 7)).astype(np.float32)
+        far = kind == 5; mp["maxDist"][far] = (dist[far] * 0.5).astype(np.float32)          # outside the scale range
+        mp["nObs"] = rng.integers(0, 4, nmp); mp["bad"] = rng.random(nmp) < 0.04; mp["inKF"] = rng.random(nmp) < 0.04
+        mpd = sd.copy()
+        flip = rng.random(nmp) < 0.5
+        for i in np.nonzero(flip)[0]: mpd[i, rng.integers(0, 32, 6)] ^= rng.integers(1, 256, 6).astype(np.uint8)      # some descriptors drift past TH_LOW
+        state = rng.choice([0, 0, 1, 1, 2], n2).astype(np.uint8); sobs = rng.integers(0, 4, n2).astype(np.int32)
+        fused = np.zeros(nmp, np.int32); act = np.zeros(nmp, np.int32)
+        nr = R.ref_fuse(_p(kp2), _p(d2), n2, _p(bb), _p(scale8), _p(inv_sigma2), C.c_float(log_sf), _p(ur2), _p(state), _p(sobs), _p(cam), _p(Tcw), _p(Ow),
+                        _p(mp), _p(mpd), nmp, C.c_float(th), _p(fused), _p(act))
+        fq = np.zeros(nmp, FQ)
+        R.ref_fuse_queries(_p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Tcw), _p(Ow), _p(mp), nmp, C.c_float(th), _p(fq))
+        q = np.zeros(nmp, fe.PQ_DTYPE)
+        q["u"] = fq["u"]; q["v"] = fq["v"]; q["ur"] = fq["ur"]; q["radius"] = fq["radius"]; q["min_level"] = fq["level"] - 1; q["max_level"] = fq["level"]; q["valid"] = fq["valid"]
+        bi, bd = orc.fuse_search(0, 1, kp2, d2, q, mpd, uright=ur2, inv_level_sigma2=inv_sigma2, bounds=tuple(bb))
+        want = np.where((fq["valid"] == 1) & (bi >= 0) & (bd <= 50), bi, -1)
+        eq = nr == int((want >= 0).sum()) and np.array_equal(fused, want)
+        note("Fuse(KeyFrame, MapPoints) %s %s th=%g %s" % (name, "stereo" if stereo else "mono", th, "own features" if same else "other view"), eq, map_points=int(nmp), projected=int(fq["valid"].sum()), fused=int(nr),
+             added=int((act == 1).sum()), kf_point_kept=int((act == 2).sum()), kf_point_replaced=int((act == 3).sum()))
+
 # --- MapPoint / MapLine::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312, src/MapLine.cpp:246-317): least median Hamming distance to the others
 ok_all = True; nsets = 0
 base = frames["synth2000"][2][1]

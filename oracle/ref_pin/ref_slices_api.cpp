@@ -34,7 +34,107 @@ template <class T> static void encode(const std::vector<T*>& now, const std::vec
         assigned[i] = !p ? -1 : p == &occ[0] ? -2 : p == &occ[1] ? -3 : (int32_t)(p - pool.data());
     }
 }
+// ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th) (src/ORBmatcher.cc:828-977): what it does to the map is recorded per map point
+struct FuseMp { float wp[3], nrm[3]; float minDist, maxDist; int nObs, bad, inKF; };
+struct FuseLog { StructureSLAM::KeyFrame* kf = nullptr; StructureSLAM::MapPoint* pool = nullptr; int npool = 0; StructureSLAM::MapPoint* occ = nullptr; int nocc = 0;
+                 std::vector<int> idx, act; int cur = -1; };
+static FuseLog gFuse;
+// index of p in the harness's pool of map points, -1 for any other object (integer arithmetic: p may point into another array)
+static long fuse_pool_index(const StructureSLAM::MapPoint* p) {
+    const uintptr_t a = (uintptr_t)p, b = (uintptr_t)gFuse.pool, e = b + (uintptr_t)gFuse.npool * sizeof(StructureSLAM::MapPoint);
+    return gFuse.pool && a >= b && a < e ? (long)((a - b) / sizeof(StructureSLAM::MapPoint)) : -1;
+}
+namespace StructureSLAM {
+bool MapPoint::isBad() {                                      // Fuse asks every map point of its list first (:850): that is the point the loop is at
+    const long i = fuse_pool_index(this);
+    if (i >= 0) gFuse.cur = (int)i;
+    return bad;
+}
+MapPoint* KeyFrame::GetMapPoint(const size_t& idx) {          // Fuse: only behind "bestDist <= TH_LOW" (:950) -- the feature the current map point is fused to
+    lastQueried = (int)idx;
+    if (gFuse.kf == this && gFuse.cur >= 0) { gFuse.idx[gFuse.cur] = (int)idx; if (!gFuse.act[gFuse.cur]) gFuse.act[gFuse.cur] = 4; }      // 4: the slot holds a bad point (counted, nothing done)
+    return mvpMapPoints[idx];
+}
+void MapPoint::AddObservation(KeyFrame*, size_t idx) {      // "pMP->AddObservation(pKF, bestIdx)": a new measurement of pMP
+    const long i = fuse_pool_index(this);
+    if (i >= 0) { gFuse.idx[i] = (int)idx; gFuse.act[i] = 1; }
+}
+void MapPoint::Replace(MapPoint* pMP) {
+    const int at = gFuse.kf->lastQueried;                    // pKF->GetMapPoint(bestIdx) came right before
+    const long i = fuse_pool_index(this), j = fuse_pool_index(pMP);
+    if (i >= 0 && gFuse.cur == i) { gFuse.idx[i] = at; gFuse.act[i] = 2; }              // pMP->Replace(pMPinKF): the keyframe's point survives
+    else if (j >= 0) { gFuse.idx[j] = at; gFuse.act[j] = 3; gFuse.kf->mvpMapPoints[at] = pMP; }      // pMPinKF->Replace(pMP): the slot now holds pMP
+    bad = true;                                              // src/MapPoint.cc:196 mbBad = true
+}
+}
+static void fill_keyframe(StructureSLAM::KeyFrame& K, StructureSLAM::Frame& F, const cv::KeyPoint* kp, const uint8_t* desc, int n, const float* bounds, const float* scale8,
+                          const float* invSigma2_8, float logScaleFactor, const float* uright, const float* cam, const float* Tcw, const float* Ow) {
+    fill_frame(F, kp, desc, n, bounds);                      // Frame::AssignFeaturesToGrid (reference body); KeyFrame::KeyFrame copies the grid (src/KeyFrame.cc:45-50)
+    K.N = n; K.mvKeysUn.assign(kp, kp + n); K.mDescriptors = F.mDescriptors.clone();
+    K.mvuRight.assign(n, -1.f); if (uright) K.mvuRight.assign(uright, uright + n);
+    K.mvScaleFactors.assign(scale8, scale8 + 8); K.mvInvLevelSigma2.assign(invSigma2_8, invSigma2_8 + 8); K.mfLogScaleFactor = logScaleFactor; K.mnScaleLevels = 8;
+    K.fx = cam[0]; K.fy = cam[1]; K.cx = cam[2]; K.cy = cam[3]; K.mbf = cam[4];
+    K.mnMinX = (int)bounds[0]; K.mnMaxX = (int)bounds[1]; K.mnMinY = (int)bounds[2]; K.mnMaxY = (int)bounds[3];      // const int members initialised from Frame's floats (include/KeyFrame.h:221-228)
+    K.mfGridElementWidthInv = StructureSLAM::Frame::mfGridElementWidthInv; K.mfGridElementHeightInv = StructureSLAM::Frame::mfGridElementHeightInv;
+    K.mGrid.assign(FRAME_GRID_COLS, std::vector<std::vector<size_t> >(FRAME_GRID_ROWS));
+    for (int i = 0; i < FRAME_GRID_COLS; ++i) for (int j = 0; j < FRAME_GRID_ROWS; ++j) K.mGrid[i][j] = F.mGrid[i][j];
+    K.Tcw = cv::Mat(4, 4, CV_32F); std::memcpy(K.Tcw.data, Tcw, 64); K.Ow = cv::Mat(3, 1, CV_32F); std::memcpy(K.Ow.data, Ow, 12);
+}
+static void fill_fuse_point(StructureSLAM::MapPoint& q, const FuseMp& m, const uint8_t* d) {
+    q.worldPos = cv::Mat(3, 1, CV_32F); std::memcpy(q.worldPos.data, m.wp, 12); q.normal = cv::Mat(3, 1, CV_32F); std::memcpy(q.normal.data, m.nrm, 12);
+    q.mfMinDistance = m.minDist; q.mfMaxDistance = m.maxDist; q.nObs = m.nObs; q.bad = m.bad != 0; q.inKF = m.inKF != 0;
+    q.desc = cv::Mat(1, 32, CV_8UC1, (void*)d);
+}
 extern "C" {
+// state[i]: 0 the keyframe's slot i holds no map point, 1 a good one with stateObs[i] observations, 2 a bad one.  cam = {fx, fy, cx, cy, mbf}.
+// fusedIdx[k] / action[k] for map point k: the keyframe feature it was fused to (-1) and how (0 not, 1 new observation, 2 replaced BY the keyframe's point,
+// 3 it replaced the keyframe's point, 4 the slot holds a bad point: counted, nothing done); returns nFused
+int ref_fuse(const cv::KeyPoint* kp, const uint8_t* desc, int n, const float* bounds, const float* scale8, const float* invSigma2_8, float logScaleFactor, const float* uright,
+             const uint8_t* state, const int32_t* stateObs, const float* cam, const float* Tcw, const float* Ow, const FuseMp* mp, const uint8_t* mpDesc, int nmp, float th,
+             int32_t* fusedIdx, int32_t* action) {
+    StructureSLAM::Frame* F = new StructureSLAM::Frame(); StructureSLAM::KeyFrame K;
+    fill_keyframe(K, *F, kp, desc, n, bounds, scale8, invSigma2_8, logScaleFactor, uright, cam, Tcw, Ow);
+    std::vector<StructureSLAM::MapPoint> pool(nmp), occ(n);
+    std::vector<StructureSLAM::MapPoint*> vp(nmp);
+    for (int i = 0; i < nmp; ++i) { fill_fuse_point(pool[i], mp[i], mpDesc + (size_t)i * 32); vp[i] = &pool[i]; }
+    K.mvpMapPoints.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) if (state[i]) { occ[i].nObs = stateObs[i]; occ[i].bad = state[i] == 2; K.mvpMapPoints[i] = &occ[i]; }
+    gFuse.kf = &K; gFuse.pool = pool.data(); gFuse.npool = nmp; gFuse.occ = occ.data(); gFuse.nocc = n; gFuse.idx.assign(nmp, -1); gFuse.act.assign(nmp, 0);
+    StructureSLAM::ORBmatcher m(0.6f, true);
+    const int r = m.Fuse(&K, vp, th);
+    for (int i = 0; i < nmp; ++i) { fusedIdx[i] = gFuse.idx[i]; action[i] = gFuse.act[i]; }
+    gFuse = FuseLog(); delete F; return r;
+}
+// The window the reference's projection block (:853-894) forms for every map point, on the same stand-in objects and leaves: what a caller of
+// sslam_fuse_search / the oracle's fuse_search passes as its queries.  q[k] = {u, v, ur, radius, predicted level, valid}
+struct FuseQ { float u, v, ur, radius; int level, valid; };
+int ref_fuse_queries(const float* bounds, const float* scale8, float logScaleFactor, const float* cam, const float* Tcw, const float* Ow, const FuseMp* mp, int nmp, float th, FuseQ* q) {
+    StructureSLAM::KeyFrame K; K.mvScaleFactors.assign(scale8, scale8 + 8); K.mfLogScaleFactor = logScaleFactor; K.mnScaleLevels = 8;
+    K.mnMinX = (int)bounds[0]; K.mnMaxX = (int)bounds[1]; K.mnMinY = (int)bounds[2]; K.mnMaxY = (int)bounds[3];
+    K.Tcw = cv::Mat(4, 4, CV_32F); std::memcpy(K.Tcw.data, Tcw, 64); K.Ow = cv::Mat(3, 1, CV_32F); std::memcpy(K.Ow.data, Ow, 12);
+    const cv::Mat Rcw = K.GetRotation(), tcw = K.GetTranslation(), Owm = K.GetCameraCenter();
+    const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3], bf = cam[4];
+    uint8_t zero[32] = {0};
+    for (int i = 0; i < nmp; ++i) {
+        StructureSLAM::MapPoint P; fill_fuse_point(P, mp[i], zero);
+        FuseQ& Q = q[i]; Q = FuseQ();
+        if (P.isBad() || P.IsInKeyFrame(&K)) continue;
+        cv::Mat p3Dw = P.GetWorldPos(); cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0f) continue;
+        const float invz = 1 / p3Dc.at<float>(2); const float x = p3Dc.at<float>(0) * invz; const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx; const float v = fy * y + cy;
+        if (!K.IsInImage(u, v)) continue;
+        const float ur = u - bf * invz;
+        const float maxDistance = P.GetMaxDistanceInvariance(); const float minDistance = P.GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Owm; const float dist3D = cv::norm(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        cv::Mat Pn = P.GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) continue;
+        const int lvl = P.PredictScale(dist3D, &K);
+        Q.u = u; Q.v = v; Q.ur = ur; Q.radius = th * K.mvScaleFactors[lvl]; Q.level = lvl; Q.valid = 1;
+    }
+    return 0;
+}
 int ref_descriptor_distance(const uint8_t* a, const uint8_t* b) {
     cv::Mat A(1, 32, CV_8UC1, (void*)a), B(1, 32, CV_8UC1, (void*)b);
     int d = StructureSLAM::ORBmatcher::DescriptorDistance(A, B);

@@ -213,6 +213,7 @@ public:
     }
     Mat clone() const { Mat m; copyTo(m); return m; }
     Mat t() const;
+    double dot(const Mat& m) const;      // (leaf) CV_32F: products and sum in double, element order
     void copyTo(Mat& m) const {
         if (empty()) { m.release(); return; }
         m.create(rows, cols, type());
@@ -251,6 +252,26 @@ inline Mat operator+(const Mat& a, const Mat& b) {
     Mat r(a.rows, a.cols, CV_32F);
     for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) r.at<float>(i, j) = a.at<float>(i, j) + b.at<float>(i, j);
     return r;
+}
+inline Mat operator-(const Mat& a, const Mat& b) {
+    assert(a.type() == CV_32F && b.type() == CV_32F && a.rows == b.rows && a.cols == b.cols);
+    Mat r(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) r.at<float>(i, j) = a.at<float>(i, j) - b.at<float>(i, j);
+    return r;
+}
+// Mat::dot and cv::norm(m) (NORM_L2) on CV_32F vectors as ORBmatcher::Fuse uses them (src/ORBmatcher.cc:878, 888; un-vendored leaves, UPSTREAM-RECALL:
+// modules/core/src/matmul.cpp dotProd_32f / stat.cpp normL2_32f): every product and the running sum in double, element order
+inline double Mat::dot(const Mat& m) const {
+    assert(type() == CV_32F && m.type() == CV_32F && rows * cols == m.rows * m.cols);
+    double r = 0;
+    for (int i = 0; i < rows; ++i) for (int j = 0; j < cols; ++j) { const int k = i * cols + j; r += (double)at<float>(i, j) * (double)m.at<float>(k / m.cols, k % m.cols); }
+    return r;
+}
+inline double norm(const Mat& a) {
+    assert(a.type() == CV_32F);
+    double s = 0;
+    for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) s += (double)a.at<float>(i, j) * (double)a.at<float>(i, j);
+    return std::sqrt(s);
 }
 // cv::norm(a, b, NORM_HAMMING) (src/MapLine.cpp:283): popcount of the xor, as a double (leaf)
 inline double norm(const Mat& a, const Mat& b, int normType);

@@ -116,11 +116,19 @@ public:
     void ComputeDistinctiveDescriptors();
     std::mutex& mMutexFeatures = gStubMutex; bool mbBad = false; std::map<KeyFrame*, size_t> mObservations; cv::Mat mDescriptor;
     bool mbTrackInView = false; int mnTrackScaleLevel = 0; float mTrackViewCos = 0, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
-    bool isBad() { return bad; }
+    bool isBad();                                     // ref_slices_api.cpp (returns `bad`; the Fuse harness notes which map point the loop is at)
     cv::Mat GetDescriptor() { return desc.clone(); }
     cv::Mat GetWorldPos() { return worldPos.clone(); }
     int Observations() { return nObs; }
     bool bad = false; int nObs = 1; cv::Mat desc, worldPos;      // (stand-in state)
+    // what ORBmatcher::Fuse reads and does (include/MapPoint.h); PredictScale / Get*DistanceInvariance bodies from src/MapPoint.cc:378-405
+    std::mutex& mMutexPos = gStubMutex; float mfMinDistance = 0, mfMaxDistance = 0; cv::Mat normal;
+    bool IsInKeyFrame(KeyFrame*) { return inKF; } bool inKF = false;
+    cv::Mat GetNormal() { return normal.clone(); }
+    float GetMinDistanceInvariance(); float GetMaxDistanceInvariance();
+    int PredictScale(const float& currentDist, KeyFrame* pKF);
+    void Replace(MapPoint* pMP);                      // ref_slices_api.cpp: recorded, the keyframe's slot re-pointed as src/MapPoint.cc:180-230 does
+    void AddObservation(KeyFrame* pKF, size_t idx);   // recorded
 };
 class MapLine {
 public:
@@ -169,7 +177,8 @@ public:
     void lineDescriptorMAD(std::vector<std::vector<cv::DMatch> > line_matches, double& nn_mad, double& nn12_mad) const;      // src/KeyFrame.cc:820-845
     cv::Mat mLineDescriptors; std::vector<MapLine*> mvpMapLines;
     // what ORBmatcher::SearchForTriangulation / CheckDistEpipolarLine read (include/KeyFrame.h)
-    MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
+    MapPoint* GetMapPoint(const size_t& idx);         // ref_slices_api.cpp (returns mvpMapPoints[idx]; the Fuse harness notes the index)
+    int lastQueried = -1;
     cv::Mat GetCameraCenter() { return Ow.clone(); }
     cv::Mat GetRotation() { return Tcw.rowRange(0, 3).colRange(0, 3).clone(); }
     cv::Mat GetTranslation() { return Tcw.rowRange(0, 3).col(3).clone(); }
@@ -178,6 +187,14 @@ public:
     cv::Mat Tcw, Ow;      // (stand-in state)
     DBoW2::FeatureVector mFeatVec; cv::Mat mDescriptors; std::vector<cv::KeyPoint> mvKeysUn;
     std::vector<MapPoint*> mvpMapPoints;      // (stand-in state)
+    // what ORBmatcher::Fuse reads (include/KeyFrame.h:150-250); GetFeaturesInArea / IsInImage bodies from src/KeyFrame.cc:610-649, 686-689
+    float mbf = 0; int mnGridCols = FRAME_GRID_COLS, mnGridRows = FRAME_GRID_ROWS; float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+    int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;      // (int in the reference's KeyFrame, include/KeyFrame.h:225-228)
+    int mnScaleLevels = 8; float mfLogScaleFactor = 0; std::vector<float> mvInvLevelSigma2;
+    std::vector<std::vector<std::vector<size_t> > > mGrid;
+    std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r) const;
+    bool IsInImage(const float& x, const float& y) const;
+    void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
 };
 
 class ORBmatcher {
@@ -191,6 +208,7 @@ public:
     int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs, const bool bOnlyStereo);
     bool CheckDistEpipolarLine(const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const cv::Mat& F12, const KeyFrame* pKF);
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
+    int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0);
     float RadiusByViewingCos(const float& viewCos);
     static const int TH_LOW, TH_HIGH, HISTO_LENGTH;
     void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
