@@ -382,6 +382,92 @@ for name in ("synth1234", "synth2000", "big1235"):
         note("Fuse(KeyFrame, MapPoints) %s %s th=%g %s" % (name, "stereo" if stereo else "mono", th, "own features" if same else "other view"), eq, map_points=int(nmp), projected=int(fq["valid"].sum()), fused=int(nr),
              added=int((act == 1).sum()), kf_point_kept=int((act == 2).sum()), kf_point_replaced=int((act == 3).sum()))
 
+# --- ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1475-1602) over MapPoint::PredictScale(dist, Frame*)
+# (src/MapPoint.cc:407-422): Tracking::Relocalization's calls (th = 10 / ORBdist = 100, then 3 / 64).  The oracle's restatement takes the windows; they are the ones
+# the reference's own projection block forms (ref_reloc_queries).  Compared: CurrentFrame.mvpMapPoints after the call and the count.
+for name in ("synth1234", "synth2000", "big1235"):
+    img, (kp1, d1), (kp2, d2) = frames[name]
+    h, w = img.shape; bb = np.array((0.0, float(w), 0.0, float(h)), np.float32); n2 = len(kp2); nkf = len(kp1)
+    fx = fy = f32(0.9 * w); cxx, cyy = f32(w / 2 - 3.25), f32(h / 2 + 1.5); cam = np.array([fx, fy, cxx, cyy, 40.0], np.float32)
+    ay, ax = -0.05, 0.03
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]]); Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Rm = (Ry @ Rx).astype(np.float32); t = np.array([-0.2, 0.1, 0.4], np.float32)
+    Tcw = np.eye(4, dtype=np.float32); Tcw[:3, :3] = Rm; Tcw[:3, 3] = t
+    Ow = (-(Rm.astype(np.float64).T @ t.astype(np.float64)))
+    for th, orbdist, ori, same in ((10.0, 100, 1, False), (3.0, 64, 1, False), (10.0, 100, 0, False), (10.0, 100, 1, True), (3.0, 64, 1, True)):
+        # the keyframe: the other view's features, or (same) the current frame's own -- then most map points find their feature again
+        kkp, kd = (kp2, d2) if same else (kp1, d1); nkf = len(kkp)
+        depth = rng.uniform(2.0, 12.0, nkf)
+        uu = kkp["x"].astype(np.float64) + rng.uniform(-6, 6, nkf); vv = kkp["y"].astype(np.float64) + rng.uniform(-6, 6, nkf)
+        pc = np.stack([(uu - float(cxx)) / float(fx) * depth, (vv - float(cyy)) / float(fy) * depth, depth], 1)
+        kind = rng.choice(4, nkf, p=[0.85, 0.05, 0.05, 0.05])
+        pc[kind == 1, 0] += 3 * depth[kind == 1]                      # outside the image
+        pw = (Rm.astype(np.float64).T @ (pc - t.astype(np.float64)).T).T
+        mp = np.zeros(nkf, FMP); mp["wp"] = pw.astype(np.float32)
+        dist = np.linalg.norm(pw - Ow, axis=1)
+        lvl = kkp["octave"].astype(np.int64); mp["maxDist"] = (dist * 1.2 ** lvl * rng.uniform(0.9, 1.3, nkf)).astype(np.float32)
+        mp["minDist"] = (mp["maxDist"] / f32(1.2 ** 7)).astype(np.float32)
+        far = kind == 2; mp["maxDist"][far] = (dist[far] * 0.5).astype(np.float32)
+        mp["bad"] = kind == 3
+        present = rng.choice([0, 1, 1, 1, 1, 2], nkf).astype(np.uint8)
+        mpd = kd.copy()
+        for i in np.nonzero(rng.random(nkf) < 0.5)[0]: mpd[i, rng.integers(0, 32, 5)] ^= rng.integers(1, 256, 5).astype(np.uint8)
+        state = (rng.random(n2) < 0.3).astype(np.uint8)
+        out_r = np.zeros(n2, np.int32)
+        nr = R.ref_search_by_projection_reloc(_p(kp2), _p(d2), n2, _p(bb), _p(scale8), C.c_float(log_sf), _p(state), _p(cam), _p(Tcw), _p(kkp), _p(present), _p(mp), _p(mpd), nkf,
+                                              C.c_float(th), orbdist, ori, _p(out_r))
+        fq = np.zeros(nkf, FQ)
+        R.ref_reloc_queries(_p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Tcw), _p(present), _p(mp), nkf, C.c_float(th), _p(fq))
+        q = np.zeros(nkf, fe.PQ_DTYPE)
+        q["u"] = fq["u"]; q["v"] = fq["v"]; q["radius"] = fq["radius"]; q["max_level"] = fq["level"]; q["min_level"] = fq["level"] - 1; q["angle"] = kkp["angle"]; q["valid"] = fq["valid"]
+        a, no = orc.search_by_projection_reloc(kp2, d2, q, mpd, state, orb_dist=orbdist, check_orientation=bool(ori), bounds=tuple(bb))
+        want = np.array([x if x >= 0 else (-2 if state[i] else -1) for i, x in enumerate(a)], np.int32)      # (pruned by the rotation histogram: NULL again, i.e. -1)
+        eq = nr == no and np.array_equal(out_r, want)
+        note("SearchByProjection(Cur, KF, found) %s th=%g dist=%d ori=%d %s" % (name, th, orbdist, ori, "own features" if same else "other view"), eq,
+             keyframe_points=int((present == 1).sum()), projected=int(fq["valid"].sum()), matches=int(nr), pruned=int((a == -2).sum()))
+
+# --- ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:293-406): LoopClosing::ComputeSim3's call (th = 10).  Scw = s [R | t]:
+# the decomposition (scale from the first row, R = sR / s, t / s) is the reference's own, on the stand-in Mat algebra; the oracle takes the windows it leads to.
+for name in ("synth1234", "synth2000", "big1235"):
+    img, (kp1, d1), (kp2, d2) = frames[name]
+    h, w = img.shape; bb = np.array((0.0, float(w), 0.0, float(h)), np.float32); n2 = len(kp2)
+    fx = fy = f32(0.9 * w); cxx, cyy = f32(w / 2 - 3.25), f32(h / 2 + 1.5); cam = np.array([fx, fy, cxx, cyy, 40.0], np.float32)
+    ay, ax = 0.04, 0.06
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]]); Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Rm64 = Ry @ Rx; t64 = np.array([0.25, 0.15, -0.3])
+    for scale, th, same in ((1.0, 10, False), (1.37, 10, False), (0.81, 10, True), (1.37, 4, True)):
+        Scw = np.eye(4, dtype=np.float32); Scw[:3, :3] = (scale * Rm64).astype(np.float32); Scw[:3, 3] = (scale * t64).astype(np.float32)
+        Ow = -(Rm64.T @ t64)
+        skp, sd = (kp2, d2) if same else (kp1, d1); nmp = len(skp)
+        depth = rng.uniform(2.0, 12.0, nmp)
+        uu = skp["x"].astype(np.float64) + rng.uniform(-6, 6, nmp); vv = skp["y"].astype(np.float64) + rng.uniform(-6, 6, nmp)
+        pc = np.stack([(uu - float(cxx)) / float(fx) * depth, (vv - float(cyy)) / float(fy) * depth, depth], 1)
+        kind = rng.choice(5, nmp, p=[0.8, 0.05, 0.05, 0.05, 0.05])
+        pc[kind == 1, 2] *= -1; pc[kind == 2, 0] += 3 * depth[kind == 2]
+        pw = (Rm64.T @ (pc - t64).T).T
+        mp = np.zeros(nmp, FMP); mp["wp"] = pw.astype(np.float32)
+        po = pw - Ow; dist = np.linalg.norm(po, axis=1); nrm = po / dist[:, None]; nrm[kind == 3] = -nrm[kind == 3]; mp["nrm"] = nrm.astype(np.float32)
+        lvl = skp["octave"].astype(np.int64) if same else rng.integers(0, 8, nmp)
+        mp["maxDist"] = (dist * 1.2 ** lvl * rng.uniform(0.9, 1.3, nmp)).astype(np.float32); mp["minDist"] = (mp["maxDist"] / f32(1.2 ** 7)).astype(np.float32)
+        mp["bad"] = kind == 4
+        mpd = sd.copy()
+        for i in np.nonzero(rng.random(nmp) < 0.5)[0]: mpd[i, rng.integers(0, 32, 5)] ^= rng.integers(1, 256, 5).astype(np.uint8)
+        # vpMatched on entry: empty slots, slots holding some other point, slots holding one of the candidates (those candidates are "already found")
+        m_in = np.full(n2, -1, np.int32); r_ = rng.random(n2); m_in[r_ < 0.15] = -2
+        pick = np.nonzero((r_ >= 0.15) & (r_ < 0.25))[0]; m_in[pick] = rng.permutation(nmp)[:len(pick)]
+        found = np.zeros(nmp, np.uint8); found[m_in[m_in >= 0]] = 1
+        m_ref = m_in.copy()
+        nr = R.ref_search_by_projection_sim3(_p(kp2), _p(d2), n2, _p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Scw), _p(mp), _p(mpd), nmp, th, _p(m_ref))
+        fq = np.zeros(nmp, FQ)
+        R.ref_sim3_queries(_p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Scw), _p(found), _p(mp), nmp, th, _p(fq))
+        q = np.zeros(nmp, fe.PQ_DTYPE)
+        q["u"] = fq["u"]; q["v"] = fq["v"]; q["radius"] = fq["radius"]; q["max_level"] = fq["level"]; q["min_level"] = fq["level"] - 1; q["valid"] = fq["valid"]
+        a, no = orc.search_by_projection_sim3(0, kp2, d2, q, mpd, (m_in != -1).astype(np.uint8), bounds=tuple(bb))
+        want = np.where(a >= 0, a, m_in).astype(np.int32)
+        eq = nr == no and np.array_equal(m_ref, want)
+        note("SearchByProjection(KF, Scw, points) %s s=%g th=%d %s" % (name, scale, th, "own features" if same else "other view"), eq,
+             candidates=int(nmp), already_found=int(found.sum()), projected=int(fq["valid"].sum()), matches=int(nr))
+
 # --- MapPoint / MapLine::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312, src/MapLine.cpp:246-317): least median Hamming distance to the others
 ok_all = True; nsets = 0
 base = frames["synth2000"][2][1]

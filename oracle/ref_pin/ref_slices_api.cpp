@@ -135,6 +135,103 @@ int ref_fuse_queries(const float* bounds, const float* scale8, float logScaleFac
     }
     return 0;
 }
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1475-1602, Tracking::Relocalization's calls :1634, :1647).
+// kpKF[i]: pKF->mvKeysUn (the angle of the rotation histogram); mp[i]: the keyframe's map point i (present[i] 0: NULL, 1: a point, 2: a point in sAlreadyFound; mp[i].inKF unused);
+// stateCur[i2]: CurrentFrame.mvpMapPoints[i2] != NULL on entry.  assigned[i2]: the keyframe's map-point index matched to feature i2, -1 untouched, -2 occupied on entry,
+// -4 matched and removed by the rotation histogram (the reference sets NULL: told apart from "untouched" through the occupied-before / after pair)
+int ref_search_by_projection_reloc(const cv::KeyPoint* kp, const uint8_t* desc, int n, const float* bounds, const float* scale8, float logScaleFactor, const uint8_t* stateCur,
+                                   const float* cam, const float* Tcw, const cv::KeyPoint* kpKF, const uint8_t* present, const FuseMp* mp, const uint8_t* mpDesc, int nkf,
+                                   float th, int ORBdist, int checkOri, int32_t* assigned) {
+    StructureSLAM::Frame* F = new StructureSLAM::Frame(); set_frame_common(*F, kp, desc, n, bounds, scale8, nullptr);
+    F->fx = cam[0]; F->fy = cam[1]; F->cx = cam[2]; F->cy = cam[3]; F->mfLogScaleFactor = logScaleFactor; F->mnScaleLevels = 8;
+    F->mTcw = cv::Mat(4, 4, CV_32F); std::memcpy(F->mTcw.data, Tcw, 64);
+    StructureSLAM::KeyFrame K; K.N = nkf; K.mvKeysUn.assign(kpKF, kpKF + nkf);
+    std::vector<StructureSLAM::MapPoint> pool(nkf), occ(1);
+    std::set<StructureSLAM::MapPoint*> found;
+    K.mvpMapPoints.assign(nkf, nullptr);
+    for (int i = 0; i < nkf; ++i) if (present[i]) { fill_fuse_point(pool[i], mp[i], mpDesc + (size_t)i * 32); K.mvpMapPoints[i] = &pool[i]; if (present[i] == 2) found.insert(&pool[i]); }
+    F->mvpMapPoints.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) if (stateCur[i]) F->mvpMapPoints[i] = &occ[0];
+    StructureSLAM::ORBmatcher m(0.9f, checkOri != 0);
+    const int r = m.SearchByProjection(*F, &K, found, th, ORBdist);
+    for (int i = 0; i < n; ++i) {
+        const StructureSLAM::MapPoint* p = F->mvpMapPoints[i];
+        assigned[i] = !p ? -1 : p == &occ[0] ? -2 : (int32_t)(p - pool.data());
+    }
+    delete F; return r;
+}
+// the windows the reference's projection block (:1499-1530) forms: q[i] = {u, v, -, radius, predicted level, valid}
+int ref_reloc_queries(const float* bounds, const float* scale8, float logScaleFactor, const float* cam, const float* Tcw, const uint8_t* present, const FuseMp* mp, int nkf, float th, FuseQ* q) {
+    StructureSLAM::Frame F; F.mvScaleFactors.assign(scale8, scale8 + 8); F.mfLogScaleFactor = logScaleFactor; F.mnScaleLevels = 8;
+    F.fx = cam[0]; F.fy = cam[1]; F.cx = cam[2]; F.cy = cam[3];
+    StructureSLAM::Frame::mnMinX = bounds[0]; StructureSLAM::Frame::mnMaxX = bounds[1]; StructureSLAM::Frame::mnMinY = bounds[2]; StructureSLAM::Frame::mnMaxY = bounds[3];
+    F.mTcw = cv::Mat(4, 4, CV_32F); std::memcpy(F.mTcw.data, Tcw, 64);
+    const cv::Mat Rcw = F.mTcw.rowRange(0, 3).colRange(0, 3); const cv::Mat tcw = F.mTcw.rowRange(0, 3).col(3); const cv::Mat Ow = -Rcw.t() * tcw;
+    uint8_t zero[32] = {0};
+    for (int i = 0; i < nkf; ++i) {
+        FuseQ& Q = q[i]; Q = FuseQ();
+        if (present[i] != 1) continue;
+        StructureSLAM::MapPoint P; fill_fuse_point(P, mp[i], zero);
+        if (P.isBad()) continue;
+        cv::Mat x3Dw = P.GetWorldPos(); cv::Mat x3Dc = Rcw * x3Dw + tcw;
+        const float xc = x3Dc.at<float>(0); const float yc = x3Dc.at<float>(1); const float invzc = 1.0 / x3Dc.at<float>(2);
+        const float u = F.fx * xc * invzc + F.cx; const float v = F.fy * yc * invzc + F.cy;
+        if (u < StructureSLAM::Frame::mnMinX || u > StructureSLAM::Frame::mnMaxX) continue;
+        if (v < StructureSLAM::Frame::mnMinY || v > StructureSLAM::Frame::mnMaxY) continue;
+        cv::Mat PO = x3Dw - Ow; float dist3D = cv::norm(PO);
+        const float maxDistance = P.GetMaxDistanceInvariance(); const float minDistance = P.GetMinDistanceInvariance();
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int lvl = P.PredictScale(dist3D, &F);
+        Q.u = u; Q.v = v; Q.radius = th * F.mvScaleFactors[lvl]; Q.level = lvl; Q.valid = 1;
+    }
+    return 0;
+}
+// ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:293-406, LoopClosing::ComputeSim3 :449 with th = 10).
+// matched[idx] on entry AND exit: -1 NULL, -2 a map point that is not in vpPoints, k >= 0 vpPoints[k]
+int ref_search_by_projection_sim3(const cv::KeyPoint* kp, const uint8_t* desc, int n, const float* bounds, const float* scale8, float logScaleFactor, const float* cam,
+                                  const float* Scw, const FuseMp* mp, const uint8_t* mpDesc, int nmp, int th, int32_t* matched) {
+    StructureSLAM::Frame* F = new StructureSLAM::Frame(); StructureSLAM::KeyFrame K;
+    const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, O3[3] = {0, 0, 0}, one8[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    fill_keyframe(K, *F, kp, desc, n, bounds, scale8, one8, logScaleFactor, nullptr, cam, I4, O3);
+    std::vector<StructureSLAM::MapPoint> pool(nmp), other(1);
+    std::vector<StructureSLAM::MapPoint*> vp(nmp), vm(n, nullptr);
+    for (int i = 0; i < nmp; ++i) { fill_fuse_point(pool[i], mp[i], mpDesc + (size_t)i * 32); vp[i] = &pool[i]; }
+    for (int i = 0; i < n; ++i) vm[i] = matched[i] == -1 ? nullptr : matched[i] == -2 ? &other[0] : &pool[matched[i]];
+    cv::Mat S(4, 4, CV_32F); std::memcpy(S.data, Scw, 64);
+    StructureSLAM::ORBmatcher m(0.75f, true);
+    const int r = m.SearchByProjection(&K, S, vp, vm, th);
+    for (int i = 0; i < n; ++i) matched[i] = !vm[i] ? -1 : vm[i] == &other[0] ? -2 : (int32_t)(vm[i] - pool.data());
+    delete F; return r;
+}
+// the windows of its projection block (:296-360): q[k] = {u, v, -, radius, predicted level, valid}; found[k]: vpPoints[k] is in vpMatched on entry
+int ref_sim3_queries(const float* bounds, const float* scale8, float logScaleFactor, const float* cam, const float* Scw, const uint8_t* found, const FuseMp* mp, int nmp, int th, FuseQ* q) {
+    StructureSLAM::KeyFrame K; K.mvScaleFactors.assign(scale8, scale8 + 8); K.mfLogScaleFactor = logScaleFactor; K.mnScaleLevels = 8;
+    K.mnMinX = (int)bounds[0]; K.mnMaxX = (int)bounds[1]; K.mnMinY = (int)bounds[2]; K.mnMaxY = (int)bounds[3];
+    const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    cv::Mat S(4, 4, CV_32F); std::memcpy(S.data, Scw, 64);
+    cv::Mat sRcw = S.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw; cv::Mat tcw = S.rowRange(0, 3).col(3) / scw; cv::Mat Ow = -Rcw.t() * tcw;
+    uint8_t zero[32] = {0};
+    for (int i = 0; i < nmp; ++i) {
+        FuseQ& Q = q[i]; Q = FuseQ();
+        StructureSLAM::MapPoint P; fill_fuse_point(P, mp[i], zero);
+        if (P.isBad() || found[i]) continue;
+        cv::Mat p3Dw = P.GetWorldPos(); cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0) continue;
+        const float invz = 1 / p3Dc.at<float>(2); const float x = p3Dc.at<float>(0) * invz; const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx; const float v = fy * y + cy;
+        if (!K.IsInImage(u, v)) continue;
+        const float maxDistance = P.GetMaxDistanceInvariance(); const float minDistance = P.GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow; const float dist = cv::norm(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        cv::Mat Pn = P.GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist) continue;
+        const int lvl = P.PredictScale(dist, &K);
+        Q.u = u; Q.v = v; Q.radius = th * K.mvScaleFactors[lvl]; Q.level = lvl; Q.valid = 1;
+    }
+    return 0;
+}
 int ref_descriptor_distance(const uint8_t* a, const uint8_t* b) {
     cv::Mat A(1, 32, CV_8UC1, (void*)a), B(1, 32, CV_8UC1, (void*)b);
     int d = StructureSLAM::ORBmatcher::DescriptorDistance(A, B);

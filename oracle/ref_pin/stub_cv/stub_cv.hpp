@@ -259,6 +259,15 @@ inline Mat operator-(const Mat& a, const Mat& b) {
     for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) r.at<float>(i, j) = a.at<float>(i, j) - b.at<float>(i, j);
     return r;
 }
+// A / s on CV_32F (src/ORBmatcher.cc:304-305: the Sim3 decomposition): a MatExpr scaled by alpha = 1 / s in double, every element (float)(a * alpha) (leaf, UPSTREAM-RECALL:
+// modules/core/src/matop.cpp MatOp_AddEx::divide -> convertTo with a double alpha)
+inline Mat operator/(const Mat& a, double s) {
+    assert(a.type() == CV_32F);
+    const double alpha = 1.0 / s;
+    Mat r(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) r.at<float>(i, j) = (float)((double)a.at<float>(i, j) * alpha);
+    return r;
+}
 // Mat::dot and cv::norm(m) (NORM_L2) on CV_32F vectors as ORBmatcher::Fuse uses them (src/ORBmatcher.cc:878, 888; un-vendored leaves, UPSTREAM-RECALL:
 // modules/core/src/matmul.cpp dotProd_32f / stat.cpp normL2_32f): every product and the running sum in double, element order
 inline double Mat::dot(const Mat& m) const {

@@ -108,7 +108,7 @@ namespace StructureSLAM {
 
 // include/MapPoint.h / include/MapLine.h: what the tracking matchers read of a map point / map line (names and types as in the reference;
 // the tracking fields are filled by Frame::isInFrustum in the real system, by the test driver here)
-class KeyFrame;
+class KeyFrame; class Frame;
 extern std::mutex gStubMutex;       // one mutex behind every stand-in's mMutexFeatures (the stand-ins stay movable)
 class MapPoint {
 public:
@@ -127,6 +127,7 @@ public:
     cv::Mat GetNormal() { return normal.clone(); }
     float GetMinDistanceInvariance(); float GetMaxDistanceInvariance();
     int PredictScale(const float& currentDist, KeyFrame* pKF);
+    int PredictScale(const float& currentDist, Frame* pF);      // src/MapPoint.cc:407-422
     void Replace(MapPoint* pMP);                      // ref_slices_api.cpp: recorded, the keyframe's slot re-pointed as src/MapPoint.cc:180-230 does
     void AddObservation(KeyFrame* pKF, size_t idx);   // recorded
 };
@@ -147,7 +148,7 @@ public:
     Frame() : N(0), NL(0) {}
     DBoW2::FeatureVector mFeatVec;
     // what the tracking matchers read besides the features (include/Frame.h:97-189)
-    cv::Mat mTcw; float mb = 0, mbf = 0, fx = 0, fy = 0, cx = 0, cy = 0;
+    cv::Mat mTcw; float mb = 0, mbf = 0, fx = 0, fy = 0, cx = 0, cy = 0; int mnScaleLevels = 8; float mfLogScaleFactor = 0;      // (the last two: MapPoint::PredictScale(dist, Frame*))
     std::vector<cv::KeyPoint> mvKeys; std::vector<float> mvuRight, mvScaleFactors;
     std::vector<MapPoint*> mvpMapPoints; std::vector<bool> mvbOutlier;
     std::vector<MapLine*> mvpMapLines; std::vector<bool> mvbLineOutlier;
@@ -209,6 +210,8 @@ public:
     bool CheckDistEpipolarLine(const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const cv::Mat& F12, const KeyFrame* pKF);
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
     int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0);
+    int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist);      // relocalisation, :1475-1602
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th);      // loop closing, :293-406
     float RadiusByViewingCos(const float& viewCos);
     static const int TH_LOW, TH_HIGH, HISTO_LENGTH;
     void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
