@@ -459,7 +459,7 @@ for name in ("synth1234", "synth2000", "big1235"):
         m_ref = m_in.copy()
         nr = R.ref_search_by_projection_sim3(_p(kp2), _p(d2), n2, _p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Scw), _p(mp), _p(mpd), nmp, th, _p(m_ref))
         fq = np.zeros(nmp, FQ)
-        R.ref_sim3_queries(_p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Scw), _p(found), _p(mp), nmp, th, _p(fq))
+        R.ref_sim3_queries(_p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Scw), _p(found), _p(mp), nmp, C.c_float(th), 0, _p(fq))
         q = np.zeros(nmp, fe.PQ_DTYPE)
         q["u"] = fq["u"]; q["v"] = fq["v"]; q["radius"] = fq["radius"]; q["max_level"] = fq["level"]; q["min_level"] = fq["level"] - 1; q["valid"] = fq["valid"]
         a, no = orc.search_by_projection_sim3(0, kp2, d2, q, mpd, (m_in != -1).astype(np.uint8), bounds=tuple(bb))
@@ -467,6 +467,47 @@ for name in ("synth1234", "synth2000", "big1235"):
         eq = nr == no and np.array_equal(m_ref, want)
         note("SearchByProjection(KF, Scw, points) %s s=%g th=%d %s" % (name, scale, th, "own features" if same else "other view"), eq,
              candidates=int(nmp), already_found=int(found.sum()), projected=int(fq["valid"].sum()), matches=int(nr))
+
+# --- ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:980-1103): LoopClosing::SearchAndFuse's call (th = 4).  The oracle's
+# fuse_search without the chi-square gates, on the windows of the reference's own Sim3 projection block; candidates the keyframe already observes are skipped.
+for name in ("synth1234", "synth2000", "big1235"):
+    img, (kp1, d1), (kp2, d2) = frames[name]
+    h, w = img.shape; bb = np.array((0.0, float(w), 0.0, float(h)), np.float32); n2 = len(kp2)
+    fx = fy = f32(0.9 * w); cxx, cyy = f32(w / 2 - 3.25), f32(h / 2 + 1.5); cam = np.array([fx, fy, cxx, cyy, 40.0], np.float32)
+    ay, ax = -0.03, 0.05
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]]); Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Rm64 = Ry @ Rx; t64 = np.array([-0.15, 0.2, 0.35])
+    for scale, th, same in ((1.0, 4.0, False), (1.21, 4.0, True), (0.9, 6.0, True)):
+        Scw = np.eye(4, dtype=np.float32); Scw[:3, :3] = (scale * Rm64).astype(np.float32); Scw[:3, 3] = (scale * t64).astype(np.float32)
+        Ow = -(Rm64.T @ t64)
+        skp, sd = (kp2, d2) if same else (kp1, d1); nmp = len(skp)
+        depth = rng.uniform(2.0, 12.0, nmp)
+        uu = skp["x"].astype(np.float64) + rng.uniform(-3, 3, nmp); vv = skp["y"].astype(np.float64) + rng.uniform(-3, 3, nmp)
+        pc = np.stack([(uu - float(cxx)) / float(fx) * depth, (vv - float(cyy)) / float(fy) * depth, depth], 1)
+        kind = rng.choice(5, nmp, p=[0.8, 0.05, 0.05, 0.05, 0.05])
+        pc[kind == 1, 2] *= -1; pc[kind == 2, 0] += 3 * depth[kind == 2]
+        pw = (Rm64.T @ (pc - t64).T).T
+        mp = np.zeros(nmp, FMP); mp["wp"] = pw.astype(np.float32)
+        po = pw - Ow; dist = np.linalg.norm(po, axis=1); nrm = po / dist[:, None]; nrm[kind == 3] = -nrm[kind == 3]; mp["nrm"] = nrm.astype(np.float32)
+        lvl = skp["octave"].astype(np.int64) if same else rng.integers(0, 8, nmp)
+        mp["maxDist"] = (dist * 1.2 ** lvl * rng.uniform(0.9, 1.3, nmp)).astype(np.float32); mp["minDist"] = (mp["maxDist"] / f32(1.2 ** 7)).astype(np.float32)
+        mp["bad"] = kind == 4
+        mpd = sd.copy()
+        for i in np.nonzero(rng.random(nmp) < 0.5)[0]: mpd[i, rng.integers(0, 32, 5)] ^= rng.integers(1, 256, 5).astype(np.uint8)
+        state = rng.choice([0, 0, 1, 1, 2], n2).astype(np.uint8)
+        slot = np.full(nmp, -1, np.int32); own = rng.permutation(nmp)[:nmp // 12]; slot[own] = rng.permutation(n2)[:len(own)]      # candidates the keyframe already holds
+        found = ((slot >= 0) & (mp["bad"] == 0)).astype(np.uint8)                      # GetMapPoints(): good points only
+        fused = np.zeros(nmp, np.int32); act = np.zeros(nmp, np.int32)
+        nr = R.ref_fuse_sim3(_p(kp2), _p(d2), n2, _p(bb), _p(scale8), C.c_float(log_sf), _p(state), _p(slot), _p(cam), _p(Scw), _p(mp), _p(mpd), nmp, C.c_float(th), _p(fused), _p(act))
+        fq = np.zeros(nmp, FQ)
+        R.ref_sim3_queries(_p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Scw), _p(found), _p(mp), nmp, C.c_float(th), 1, _p(fq))
+        q = np.zeros(nmp, fe.PQ_DTYPE)
+        q["u"] = fq["u"]; q["v"] = fq["v"]; q["radius"] = fq["radius"]; q["min_level"] = fq["level"] - 1; q["max_level"] = fq["level"]; q["valid"] = fq["valid"]
+        bi, bd = orc.fuse_search(0, 0, kp2, d2, q, mpd, bounds=tuple(bb))
+        want = np.where((fq["valid"] == 1) & (bi >= 0) & (bd <= 50), bi, -1)
+        eq = nr == int((want >= 0).sum()) and np.array_equal(fused, want)
+        note("Fuse(KeyFrame, Scw, points) %s s=%g th=%g %s" % (name, scale, th, "own features" if same else "other view"), eq, candidates=int(nmp), already_in_keyframe=int(found.sum()),
+             projected=int(fq["valid"].sum()), fused=int(nr), added=int((act == 1).sum()), to_replace=int((act == 2).sum()))
 
 # --- MapPoint / MapLine::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312, src/MapLine.cpp:246-317): least median Hamming distance to the others
 ok_all = True; nsets = 0

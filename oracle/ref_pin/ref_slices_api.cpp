@@ -55,6 +55,11 @@ MapPoint* KeyFrame::GetMapPoint(const size_t& idx) {          // Fuse: only behi
     if (gFuse.kf == this && gFuse.cur >= 0) { gFuse.idx[gFuse.cur] = (int)idx; if (!gFuse.act[gFuse.cur]) gFuse.act[gFuse.cur] = 4; }      // 4: the slot holds a bad point (counted, nothing done)
     return mvpMapPoints[idx];
 }
+std::set<MapPoint*> KeyFrame::GetMapPoints() {              // src/KeyFrame.cc:300-313: every non-NULL, non-bad entry of mvpMapPoints
+    std::set<MapPoint*> s;
+    for (size_t i = 0; i < mvpMapPoints.size(); ++i) if (mvpMapPoints[i] && !mvpMapPoints[i]->bad) s.insert(mvpMapPoints[i]);
+    return s;
+}
 void MapPoint::AddObservation(KeyFrame*, size_t idx) {      // "pMP->AddObservation(pKF, bestIdx)": a new measurement of pMP
     const long i = fuse_pool_index(this);
     if (i >= 0) { gFuse.idx[i] = (int)idx; gFuse.act[i] = 1; }
@@ -204,7 +209,7 @@ int ref_search_by_projection_sim3(const cv::KeyPoint* kp, const uint8_t* desc, i
     delete F; return r;
 }
 // the windows of its projection block (:296-360): q[k] = {u, v, -, radius, predicted level, valid}; found[k]: vpPoints[k] is in vpMatched on entry
-int ref_sim3_queries(const float* bounds, const float* scale8, float logScaleFactor, const float* cam, const float* Scw, const uint8_t* found, const FuseMp* mp, int nmp, int th, FuseQ* q) {
+int ref_sim3_queries(const float* bounds, const float* scale8, float logScaleFactor, const float* cam, const float* Scw, const uint8_t* found, const FuseMp* mp, int nmp, float th, int fuseForm, FuseQ* q) {
     StructureSLAM::KeyFrame K; K.mvScaleFactors.assign(scale8, scale8 + 8); K.mfLogScaleFactor = logScaleFactor; K.mnScaleLevels = 8;
     K.mnMinX = (int)bounds[0]; K.mnMaxX = (int)bounds[1]; K.mnMinY = (int)bounds[2]; K.mnMaxY = (int)bounds[3];
     const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
@@ -219,7 +224,8 @@ int ref_sim3_queries(const float* bounds, const float* scale8, float logScaleFac
         if (P.isBad() || found[i]) continue;
         cv::Mat p3Dw = P.GetWorldPos(); cv::Mat p3Dc = Rcw * p3Dw + tcw;
         if (p3Dc.at<float>(2) < 0.0) continue;
-        const float invz = 1 / p3Dc.at<float>(2); const float x = p3Dc.at<float>(0) * invz; const float y = p3Dc.at<float>(1) * invz;
+        const float invz = fuseForm ? (float)(1.0 / p3Dc.at<float>(2)) : 1 / p3Dc.at<float>(2);      // (:1024 divides in double, :336 in float)
+        const float x = p3Dc.at<float>(0) * invz; const float y = p3Dc.at<float>(1) * invz;
         const float u = fx * x + cx; const float v = fy * y + cy;
         if (!K.IsInImage(u, v)) continue;
         const float maxDistance = P.GetMaxDistanceInvariance(); const float minDistance = P.GetMinDistanceInvariance();
@@ -231,6 +237,27 @@ int ref_sim3_queries(const float* bounds, const float* scale8, float logScaleFac
         Q.u = u; Q.v = v; Q.radius = th * K.mvScaleFactors[lvl]; Q.level = lvl; Q.valid = 1;
     }
     return 0;
+}
+// ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:980-1103; LoopClosing::SearchAndFuse :665 with th = 4).
+// state / stateObs as in ref_fuse; inKF[k]: vpPoints[k] is one of the keyframe's own map points (it sits in slot kfSlot[k]).
+// fusedIdx / action as in ref_fuse (2: vpReplacePoint[k] = the keyframe's point)
+int ref_fuse_sim3(const cv::KeyPoint* kp, const uint8_t* desc, int n, const float* bounds, const float* scale8, float logScaleFactor, const uint8_t* state, const int32_t* kfSlot,
+                  const float* cam, const float* Scw, const FuseMp* mp, const uint8_t* mpDesc, int nmp, float th, int32_t* fusedIdx, int32_t* action) {
+    StructureSLAM::Frame* F = new StructureSLAM::Frame(); StructureSLAM::KeyFrame K;
+    const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, O3[3] = {0, 0, 0}, one8[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    fill_keyframe(K, *F, kp, desc, n, bounds, scale8, one8, logScaleFactor, nullptr, cam, I4, O3);
+    std::vector<StructureSLAM::MapPoint> pool(nmp), occ(n);
+    std::vector<StructureSLAM::MapPoint*> vp(nmp), rep(nmp, nullptr);
+    for (int i = 0; i < nmp; ++i) { fill_fuse_point(pool[i], mp[i], mpDesc + (size_t)i * 32); vp[i] = &pool[i]; }
+    K.mvpMapPoints.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) if (state[i]) { occ[i].bad = state[i] == 2; K.mvpMapPoints[i] = &occ[i]; }
+    for (int k = 0; k < nmp; ++k) if (kfSlot[k] >= 0) K.mvpMapPoints[kfSlot[k]] = &pool[k];      // candidates the keyframe already observes
+    gFuse.kf = &K; gFuse.pool = pool.data(); gFuse.npool = nmp; gFuse.idx.assign(nmp, -1); gFuse.act.assign(nmp, 0);
+    cv::Mat S(4, 4, CV_32F); std::memcpy(S.data, Scw, 64);
+    StructureSLAM::ORBmatcher m(0.8f, true);
+    const int r = m.Fuse(&K, S, vp, th, rep);
+    for (int i = 0; i < nmp; ++i) { fusedIdx[i] = gFuse.idx[i]; action[i] = rep[i] ? 2 : gFuse.act[i]; }
+    gFuse = FuseLog(); delete F; return r;
 }
 int ref_descriptor_distance(const uint8_t* a, const uint8_t* b) {
     cv::Mat A(1, 32, CV_8UC1, (void*)a), B(1, 32, CV_8UC1, (void*)b);

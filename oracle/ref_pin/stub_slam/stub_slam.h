@@ -196,6 +196,7 @@ public:
     std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r) const;
     bool IsInImage(const float& x, const float& y) const;
     void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
+    std::set<MapPoint*> GetMapPoints();               // ref_slices_api.cpp: the good map points of the keyframe (src/KeyFrame.cc:300-313)
 };
 
 class ORBmatcher {
@@ -210,6 +211,7 @@ public:
     bool CheckDistEpipolarLine(const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const cv::Mat& F12, const KeyFrame* pKF);
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
     int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0);
+    int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint);      // loop closing, :980-1103
     int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist);      // relocalisation, :1475-1602
     int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th);      // loop closing, :293-406
     float RadiusByViewingCos(const float& viewCos);
