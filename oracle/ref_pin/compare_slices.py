@@ -509,6 +509,56 @@ for name in ("synth1234", "synth2000", "big1235"):
         note("Fuse(KeyFrame, Scw, points) %s s=%g th=%g %s" % (name, scale, th, "own features" if same else "other view"), eq, candidates=int(nmp), already_in_keyframe=int(found.sum()),
              projected=int(fq["valid"].sum()), fused=int(nr), added=int((act == 1).sum()), to_replace=int((act == 2).sum()))
 
+# --- ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1105-1329): LoopClosing::ComputeSim3's call (th = 7.5).  Both directions are the fuse_search of the oracle without the
+# chi-square gates and with TH_HIGH, on the windows of the reference's own two projection blocks; the agreement test is restated here in three lines.
+for name in ("synth1234", "synth2000", "big1235"):
+    img, (kp1, d1), (kp2, d2) = frames[name]
+    h, w = img.shape; bb = np.array((0.0, float(w), 0.0, float(h)), np.float32); n = len(kp2)
+    fx = fy = f32(0.9 * w); cxx, cyy = f32(w / 2 - 3.25), f32(h / 2 + 1.5); cam = np.array([fx, fy, cxx, cyy, 40.0], np.float32)
+    ay, ax = 0.05, -0.02
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]]); Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Rw = Ry @ Rx; tw = np.array([0.1, -0.25, 0.3])
+    T1w = np.eye(4, dtype=np.float32); T1w[:3, :3] = Rw.astype(np.float32); T1w[:3, 3] = tw.astype(np.float32); T2w = T1w.copy()      # both keyframes at one pose, the Sim3 slightly off identity
+    for s12, ang, th in ((1.0, 0.0, 7.5), (1.03, 0.004, 7.5), (0.97, -0.006, 4.0)):
+        Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]]); R12 = Rz.astype(np.float32); t12 = np.array([0.02, -0.01, 0.015 * (s12 != 1.0)], np.float32)
+
+        def points(kp):
+            m = len(kp); depth = rng.uniform(2.0, 12.0, m)
+            uu = kp["x"].astype(np.float64) + rng.uniform(-2, 2, m); vv = kp["y"].astype(np.float64) + rng.uniform(-2, 2, m)
+            pc = np.stack([(uu - float(cxx)) / float(fx) * depth, (vv - float(cyy)) / float(fy) * depth, depth], 1)
+            pw = (Rw.T @ (pc - tw).T).T
+            mp = np.zeros(m, FMP); mp["wp"] = pw.astype(np.float32)
+            lvl = kp["octave"].astype(np.int64)
+            mp["maxDist"] = (depth * np.sqrt(1 + ((uu - float(cxx)) / float(fx)) ** 2 + ((vv - float(cyy)) / float(fy)) ** 2) * 1.2 ** lvl * rng.uniform(0.9, 1.3, m)).astype(np.float32)
+            mp["minDist"] = (mp["maxDist"] / f32(1.2 ** 7)).astype(np.float32); mp["bad"] = rng.random(m) < 0.04
+            return mp
+        mp1, mp2 = points(kp2), points(kp2)
+        mpd1, mpd2 = d2.copy(), d2.copy()
+        for dd in (mpd1, mpd2):
+            for i in np.nonzero(rng.random(n) < 0.5)[0]: dd[i, rng.integers(0, 32, 6)] ^= rng.integers(1, 256, 6).astype(np.uint8)
+        present1 = (rng.random(n) < 0.85).astype(np.uint8); present2 = (rng.random(n) < 0.85).astype(np.uint8)
+        m_in = np.full(n, -1, np.int32); r_ = rng.random(n); m_in[r_ < 0.06] = -2
+        pick = np.nonzero((r_ >= 0.06) & (r_ < 0.16))[0]; m_in[pick] = rng.choice(np.nonzero(present2)[0], len(pick), replace=False)
+        m_ref = m_in.copy()
+        nr = R.ref_search_by_sim3(_p(kp2), _p(d2), n, _p(kp2), _p(d2), n, _p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(T1w), _p(T2w), C.c_float(s12), _p(R12), _p(t12),
+                                  _p(present1), _p(mp1), _p(mpd1), _p(present2), _p(mp2), _p(mpd2), C.c_float(th), _p(m_ref))
+        already1 = m_in != -1; already2 = np.zeros(n, bool); already2[m_in[m_in >= 0]] = True
+        vn = []
+        for direction, present, already, mp, mpd in ((0, present1, already1, mp1, mpd1), (1, present2, already2, mp2, mpd2)):
+            skip = ((present == 0) | already).astype(np.uint8); fq = np.zeros(n, FQ)
+            R.ref_sim3_pair_queries(direction, _p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(T1w), _p(T2w), C.c_float(s12), _p(R12), _p(t12), _p(skip), _p(mp), n, C.c_float(th), _p(fq))
+            q = np.zeros(n, fe.PQ_DTYPE)
+            q["u"] = fq["u"]; q["v"] = fq["v"]; q["radius"] = fq["radius"]; q["min_level"] = fq["level"] - 1; q["max_level"] = fq["level"]; q["valid"] = fq["valid"]
+            bi, bd = orc.fuse_search(0, 0, kp2, d2, q, mpd, bounds=tuple(bb))
+            vn.append(np.where((fq["valid"] == 1) & (bi >= 0) & (bd <= 100), bi, -1))
+        want = m_in.copy(); found = 0
+        for i1 in range(n):
+            i2 = vn[0][i1]
+            if i2 >= 0 and vn[1][i2] == i1: want[i1] = i2 if present2[i2] else -1; found += 1
+        eq = nr == found and np.array_equal(m_ref, want)
+        note("SearchBySim3 %s s12=%g rot=%g th=%g" % (name, s12, ang, th), eq, points1=int(present1.sum()), points2=int(present2.sum()), already_matched=int(already1.sum()),
+             one_way=int((vn[0] >= 0).sum()), other_way=int((vn[1] >= 0).sum()), agreed=int(found))
+
 # --- MapPoint / MapLine::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312, src/MapLine.cpp:246-317): least median Hamming distance to the others
 ok_all = True; nsets = 0
 base = frames["synth2000"][2][1]

@@ -259,6 +259,63 @@ int ref_fuse_sim3(const cv::KeyPoint* kp, const uint8_t* desc, int n, const floa
     for (int i = 0; i < nmp; ++i) { fusedIdx[i] = gFuse.idx[i]; action[i] = rep[i] ? 2 : gFuse.act[i]; }
     gFuse = FuseLog(); delete F; return r;
 }
+// ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (src/ORBmatcher.cc:1105-1329; LoopClosing::ComputeSim3 :416 with th = 7.5).
+// present1 / present2: the keyframes' map-point slots (0 NULL, 1 a point); m12[i1] on entry and exit: -1 NULL, -2 a map point pKF2 does not observe, k >= 0 pKF2's point of slot k
+int ref_search_by_sim3(const cv::KeyPoint* kp1, const uint8_t* d1, int n1, const cv::KeyPoint* kp2, const uint8_t* d2, int n2, const float* bounds, const float* scale8, float logScaleFactor,
+                       const float* cam, const float* T1w, const float* T2w, float s12, const float* R12, const float* t12, const uint8_t* present1, const FuseMp* mp1, const uint8_t* mpDesc1,
+                       const uint8_t* present2, const FuseMp* mp2, const uint8_t* mpDesc2, float th, int32_t* m12) {
+    const float O3[3] = {0, 0, 0}, one8[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    StructureSLAM::Frame* F1 = new StructureSLAM::Frame(); StructureSLAM::Frame* F2 = new StructureSLAM::Frame(); StructureSLAM::KeyFrame K1, K2;
+    fill_keyframe(K1, *F1, kp1, d1, n1, bounds, scale8, one8, logScaleFactor, nullptr, cam, T1w, O3);
+    fill_keyframe(K2, *F2, kp2, d2, n2, bounds, scale8, one8, logScaleFactor, nullptr, cam, T2w, O3);
+    std::vector<StructureSLAM::MapPoint> pool1(n1), pool2(n2), other(1);
+    K1.mvpMapPoints.assign(n1, nullptr); K2.mvpMapPoints.assign(n2, nullptr);
+    for (int i = 0; i < n1; ++i) if (present1[i]) { fill_fuse_point(pool1[i], mp1[i], mpDesc1 + (size_t)i * 32); K1.mvpMapPoints[i] = &pool1[i]; }
+    for (int i = 0; i < n2; ++i) if (present2[i]) { fill_fuse_point(pool2[i], mp2[i], mpDesc2 + (size_t)i * 32); pool2[i].idxInKF2 = i; K2.mvpMapPoints[i] = &pool2[i]; }
+    std::vector<StructureSLAM::MapPoint*> vm(n1, nullptr);
+    for (int i = 0; i < n1; ++i) vm[i] = m12[i] == -1 ? nullptr : m12[i] == -2 ? &other[0] : &pool2[m12[i]];
+    cv::Mat R(3, 3, CV_32F), t(3, 1, CV_32F); std::memcpy(R.data, R12, 36); std::memcpy(t.data, t12, 12);
+    StructureSLAM::ORBmatcher m(0.75f, true);
+    const int r = m.SearchBySim3(&K1, &K2, vm, s12, R, t, th);
+    for (int i = 0; i < n1; ++i) m12[i] = !vm[i] ? -1 : vm[i] == &other[0] ? -2 : (int32_t)(vm[i] - pool2.data());
+    delete F1; delete F2; return r;
+}
+// the windows of its two projection blocks: dir 0 = pKF1's points into pKF2 (:1152-1196: R1w, t1w then sR21, t21), dir 1 = pKF2's into pKF1 (:1232-1276: R2w, t2w then sR12, t12);
+// skip[i]: the slot is NULL or already matched
+int ref_sim3_pair_queries(int dir, const float* bounds, const float* scale8, float logScaleFactor, const float* cam, const float* T1w, const float* T2w, float s12, const float* R12v, const float* t12v,
+                          const uint8_t* skip, const FuseMp* mp, int nmp, float th, FuseQ* q) {
+    StructureSLAM::KeyFrame K1, K2;
+    for (StructureSLAM::KeyFrame* K : {&K1, &K2}) {
+        K->mvScaleFactors.assign(scale8, scale8 + 8); K->mfLogScaleFactor = logScaleFactor; K->mnScaleLevels = 8;
+        K->mnMinX = (int)bounds[0]; K->mnMaxX = (int)bounds[1]; K->mnMinY = (int)bounds[2]; K->mnMaxY = (int)bounds[3];
+    }
+    K1.Tcw = cv::Mat(4, 4, CV_32F); std::memcpy(K1.Tcw.data, T1w, 64); K2.Tcw = cv::Mat(4, 4, CV_32F); std::memcpy(K2.Tcw.data, T2w, 64);
+    const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    cv::Mat R1w = K1.GetRotation(), t1w = K1.GetTranslation(), R2w = K2.GetRotation(), t2w = K2.GetTranslation();
+    cv::Mat R12(3, 3, CV_32F), t12(3, 1, CV_32F); std::memcpy(R12.data, R12v, 36); std::memcpy(t12.data, t12v, 12);
+    cv::Mat sR12 = s12 * R12; cv::Mat sR21 = (1.0 / s12) * R12.t(); cv::Mat t21 = -sR21 * t12;
+    uint8_t zero[32] = {0};
+    for (int i = 0; i < nmp; ++i) {
+        FuseQ& Q = q[i]; Q = FuseQ();
+        if (skip[i]) continue;
+        StructureSLAM::MapPoint P; fill_fuse_point(P, mp[i], zero);
+        if (P.isBad()) continue;
+        cv::Mat p3Dw = P.GetWorldPos();
+        cv::Mat pa = dir == 0 ? cv::Mat(R1w * p3Dw + t1w) : cv::Mat(R2w * p3Dw + t2w);
+        cv::Mat pb = dir == 0 ? cv::Mat(sR21 * pa + t21) : cv::Mat(sR12 * pa + t12);
+        if (pb.at<float>(2) < 0.0) continue;
+        const float invz = 1.0 / pb.at<float>(2); const float x = pb.at<float>(0) * invz; const float y = pb.at<float>(1) * invz;
+        const float u = fx * x + cx; const float v = fy * y + cy;
+        StructureSLAM::KeyFrame* Kt = dir == 0 ? &K2 : &K1;
+        if (!Kt->IsInImage(u, v)) continue;
+        const float maxDistance = P.GetMaxDistanceInvariance(); const float minDistance = P.GetMinDistanceInvariance();
+        const float dist3D = cv::norm(pb);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int lvl = P.PredictScale(dist3D, Kt);
+        Q.u = u; Q.v = v; Q.radius = th * Kt->mvScaleFactors[lvl]; Q.level = lvl; Q.valid = 1;
+    }
+    return 0;
+}
 int ref_descriptor_distance(const uint8_t* a, const uint8_t* b) {
     cv::Mat A(1, 32, CV_8UC1, (void*)a), B(1, 32, CV_8UC1, (void*)b);
     int d = StructureSLAM::ORBmatcher::DescriptorDistance(A, B);

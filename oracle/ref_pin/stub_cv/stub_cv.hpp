@@ -268,6 +268,13 @@ inline Mat operator/(const Mat& a, double s) {
     for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) r.at<float>(i, j) = (float)((double)a.at<float>(i, j) * alpha);
     return r;
 }
+// s * A on CV_32F (src/ORBmatcher.cc:1123-1124: sR12 = s12 * R12, sR21 = (1.0 / s12) * R12.t()): a MatExpr with alpha = s in double, every element (float)(a * alpha) (leaf, as A / s above)
+inline Mat operator*(double s, const Mat& a) {
+    assert(a.type() == CV_32F);
+    Mat r(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; ++i) for (int j = 0; j < a.cols; ++j) r.at<float>(i, j) = (float)((double)a.at<float>(i, j) * s);
+    return r;
+}
 // Mat::dot and cv::norm(m) (NORM_L2) on CV_32F vectors as ORBmatcher::Fuse uses them (src/ORBmatcher.cc:878, 888; un-vendored leaves, UPSTREAM-RECALL:
 // modules/core/src/matmul.cpp dotProd_32f / stat.cpp normL2_32f): every product and the running sum in double, element order
 inline double Mat::dot(const Mat& m) const {

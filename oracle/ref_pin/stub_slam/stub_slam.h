@@ -128,6 +128,7 @@ public:
     float GetMinDistanceInvariance(); float GetMaxDistanceInvariance();
     int PredictScale(const float& currentDist, KeyFrame* pKF);
     int PredictScale(const float& currentDist, Frame* pF);      // src/MapPoint.cc:407-422
+    int GetIndexInKeyFrame(KeyFrame*) { return idxInKF2; } int idxInKF2 = -1;      // (SearchBySim3 asks for the index in pKF2 only)
     void Replace(MapPoint* pMP);                      // ref_slices_api.cpp: recorded, the keyframe's slot re-pointed as src/MapPoint.cc:180-230 does
     void AddObservation(KeyFrame* pKF, size_t idx);   // recorded
 };
@@ -212,6 +213,7 @@ public:
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
     int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0);
     int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint);      // loop closing, :980-1103
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th);      // :1105-1329
     int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist);      // relocalisation, :1475-1602
     int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th);      // loop closing, :293-406
     float RadiusByViewingCos(const float& viewCos);
