@@ -559,6 +559,52 @@ for name in ("synth1234", "synth2000", "big1235"):
         note("SearchBySim3 %s s12=%g rot=%g th=%g" % (name, s12, ang, th), eq, points1=int(present1.sum()), points2=int(present2.sum()), already_matched=int(already1.sum()),
              one_way=int((vn[0] >= 0).sum()), other_way=int((vn[1] >= 0).sum()), agreed=int(found))
 
+# --- LSDmatcher::Fuse(KeyFrame*, vector<MapLine*>, th) (src/LSDmatcher.cpp:417-548) over KeyFrame::GetLinesInArea (src/KeyFrame.cc:651-684) and MapLine::PredictScale /
+# Get*DistanceInvariance (src/MapLine.cpp:374-395): LocalMapping::SearchInNeighbors' line call.  Oracle: fuse_search, kind 1, on the windows of the reference's projection block.
+# (MapLine::PredictScale does not clamp its level, and the reference indexes mvScaleFactors with it: the cases keep every predicted level inside [0, 7].)
+FML = np.dtype([("wp", "<f8", 6), ("nrm", "<f8", 3), ("minDist", "<f4"), ("maxDist", "<f4"), ("nObs", "<i4"), ("bad", "<i4")])
+FQL = np.dtype([("u1", "<f4"), ("v1", "<f4"), ("u2", "<f4"), ("v2", "<f4"), ("radius", "<f4"), ("level", "<i4"), ("valid", "<i4")])
+for name in ("synth1234", "synth2000", "big1235"):
+    img = frames[name][0]; h, w = img.shape; bb = np.array((0.0, float(w), 0.0, float(h)), np.float32)
+    kl1, ld1 = orc.lines_extract(warp_prev(img), 200)[:2]; kl2, ld2 = orc.lines_extract(img, 200)[:2]
+    fx = fy = f32(0.9 * w); cxx, cyy = f32(w / 2 - 3.25), f32(h / 2 + 1.5); cam = np.array([fx, fy, cxx, cyy, 40.0], np.float32)
+    ay, ax = 0.03, -0.05
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]]); Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Rm = (Ry @ Rx).astype(np.float32); t = np.array([0.2, 0.1, 0.3], np.float32)
+    Tcw = np.eye(4, dtype=np.float32); Tcw[:3, :3] = Rm; Tcw[:3, 3] = t
+    Ow32 = (-(Rm.astype(np.float64).T @ t.astype(np.float64))).astype(np.float32)
+    R64 = Rm.astype(np.float64); t64 = t.astype(np.float64)
+    for th, same in ((3.0, False), (3.0, True), (6.0, True)):
+        skl, sld = (kl2, ld2) if same else (kl1, ld1); nml = len(skl); nl2 = len(kl2)
+        z = rng.uniform(2.0, 9.0, nml); dz = rng.uniform(-0.4, 0.4, nml)
+        def unproj(x, y, zz):
+            pc = np.stack([(x.astype(np.float64) + rng.uniform(-2, 2, nml) - float(cxx)) / float(fx) * zz, (y.astype(np.float64) + rng.uniform(-2, 2, nml) - float(cyy)) / float(fy) * zz, zz], 1)
+            return (R64.T @ (pc - t64).T).T
+        kind = rng.choice(5, nml, p=[0.8, 0.05, 0.05, 0.05, 0.05])
+        zs = z.copy(); zs[kind == 1] *= -1                                     # one end behind the camera
+        sp = unproj(skl["startPointX"], skl["startPointY"], zs); ep = unproj(skl["endPointX"], skl["endPointY"], z + dz)
+        sp[kind == 2, 0] += 40.0                                               # projects outside the image
+        ml = np.zeros(nml, FML); ml["wp"] = np.concatenate([sp, ep], 1).astype(np.float32).astype(np.float64)      # (Vector6d of values a float holds exactly)
+        mid = 0.5 * (sp + ep); om = mid - Ow32.astype(np.float64); dist = np.linalg.norm(om, axis=1); nrm = om / dist[:, None]; nrm[kind == 3] = -nrm[kind == 3]
+        ml["nrm"] = nrm.astype(np.float32).astype(np.float64)
+        lvl = rng.choice([0, 0, 0, 1, 1, 2, 4], nml); ml["maxDist"] = (dist * 1.2 ** lvl * rng.uniform(0.86, 0.99, nml)).astype(np.float32)      # ceil(log(max / dist) / log 1.2) = lvl
+        ml["minDist"] = (ml["maxDist"] / f32(1.2 ** 7)).astype(np.float32); ml["bad"] = kind == 4; ml["nObs"] = rng.integers(0, 4, nml)
+        mld = sld.copy()
+        for i in np.nonzero(rng.random(nml) < 0.4)[0]: mld[i, rng.integers(0, 32, 4)] ^= rng.integers(1, 256, 4).astype(np.uint8)
+        state = rng.choice([0, 0, 1, 1, 2], nl2).astype(np.uint8); sobs = rng.integers(0, 4, nl2).astype(np.int32)
+        fql = np.zeros(nml, FQL)
+        R.ref_line_fuse_queries(_p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Tcw), _p(Ow32), _p(ml), nml, C.c_float(th), _p(fql))
+        assert (fql["valid"] != 2).all(), "a predicted level outside [0, 7]: the reference would read out of bounds"
+        fused = np.zeros(nml, np.int32); act = np.zeros(nml, np.int32)
+        nr = R.ref_line_fuse(_p(kl2), _p(ld2), nl2, _p(bb), _p(scale8), C.c_float(log_sf), _p(state), _p(sobs), _p(cam), _p(Tcw), _p(Ow32), _p(ml), _p(mld), nml, C.c_float(th), _p(fused), _p(act))
+        q = np.zeros(nml, fe.PQ_DTYPE)
+        q["u"] = fql["u1"]; q["v"] = fql["v1"]; q["u2"] = fql["u2"]; q["v2"] = fql["v2"]; q["radius"] = fql["radius"]; q["min_level"] = fql["level"] - 1; q["max_level"] = fql["level"]; q["valid"] = fql["valid"]
+        bi, bd = orc.fuse_search(1, 0, kl2, ld2, q, mld, bounds=tuple(bb))
+        want = np.where((fql["valid"] == 1) & (bi >= 0) & (bd <= 50), bi, -1)
+        eq = nr == int((want >= 0).sum()) and np.array_equal(fused, want)
+        note("LSDmatcher::Fuse(KeyFrame, MapLines) %s th=%g %s" % (name, th, "own lines" if same else "other view"), eq, map_lines=int(nml), projected=int((fql["valid"] == 1).sum()),
+             fused=int(nr), added=int((act == 1).sum()), kf_line_kept=int((act == 2).sum()), kf_line_replaced=int((act == 3).sum()))
+
 # --- MapPoint / MapLine::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312, src/MapLine.cpp:246-317): least median Hamming distance to the others
 ok_all = True; nsets = 0
 base = frames["synth2000"][2][1]

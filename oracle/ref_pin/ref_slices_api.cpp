@@ -90,7 +90,91 @@ static void fill_fuse_point(StructureSLAM::MapPoint& q, const FuseMp& m, const u
     q.mfMinDistance = m.minDist; q.mfMaxDistance = m.maxDist; q.nObs = m.nObs; q.bad = m.bad != 0; q.inKF = m.inKF != 0;
     q.desc = cv::Mat(1, 32, CV_8UC1, (void*)d);
 }
+// LSDmatcher::Fuse(KeyFrame*, vector<MapLine*>, th) (src/LSDmatcher.cpp:417-548): the same bookkeeping for map lines
+struct FuseMl { double wp[6], nrm[3]; float minDist, maxDist; int nObs, bad; };
+struct FuseLogL { StructureSLAM::KeyFrame* kf = nullptr; StructureSLAM::MapLine* pool = nullptr; int npool = 0; std::vector<int> idx, act; int cur = -1; };
+static FuseLogL gFuseL;
+static long fuse_line_index(const StructureSLAM::MapLine* p) {
+    const uintptr_t a = (uintptr_t)p, b = (uintptr_t)gFuseL.pool, e = b + (uintptr_t)gFuseL.npool * sizeof(StructureSLAM::MapLine);
+    return gFuseL.pool && a >= b && a < e ? (long)((a - b) / sizeof(StructureSLAM::MapLine)) : -1;
+}
+namespace StructureSLAM {
+bool MapLine::isBad() { const long i = fuse_line_index(this); if (i >= 0) gFuseL.cur = (int)i; return bad; }
+MapLine* KeyFrame::GetMapLine(const size_t& idx) {
+    lastQueried = (int)idx;
+    if (gFuseL.kf == this && gFuseL.cur >= 0) { gFuseL.idx[gFuseL.cur] = (int)idx; if (!gFuseL.act[gFuseL.cur]) gFuseL.act[gFuseL.cur] = 4; }
+    return mvpMapLines[idx];
+}
+void MapLine::AddObservation(KeyFrame*, size_t idx) { const long i = fuse_line_index(this); if (i >= 0) { gFuseL.idx[i] = (int)idx; gFuseL.act[i] = 1; } }
+void MapLine::Replace(MapLine* pML) {
+    const int at = gFuseL.kf->lastQueried;
+    const long i = fuse_line_index(this), j = fuse_line_index(pML);
+    if (i >= 0 && gFuseL.cur == i) { gFuseL.idx[i] = at; gFuseL.act[i] = 2; }
+    else if (j >= 0) { gFuseL.idx[j] = at; gFuseL.act[j] = 3; gFuseL.kf->mvpMapLines[at] = pML; }
+    bad = true;
+}
+}
+static void fill_fuse_line(StructureSLAM::MapLine& q, const FuseMl& m, const uint8_t* d) {
+    for (int k = 0; k < 6; ++k) q.worldPos.v[k] = m.wp[k];
+    for (int k = 0; k < 3; ++k) q.normal.v[k] = m.nrm[k];
+    q.mfMinDistance = m.minDist; q.mfMaxDistance = m.maxDist; q.nObs = m.nObs; q.bad = m.bad != 0; q.desc = cv::Mat(1, 32, CV_8UC1, (void*)d);
+}
+static void fill_line_keyframe(StructureSLAM::KeyFrame& K, const KeyLine* kl, const uint8_t* ldesc, int n, const float* bounds, const float* scale8, float logScaleFactor, const float* cam,
+                               const float* Tcw, const float* Ow) {
+    K.mvKeyLines.assign(kl, kl + n); K.mLineDescriptors.create(n, 32, CV_8UC1); if (n) std::memcpy(K.mLineDescriptors.data, ldesc, (size_t)n * 32);
+    K.mvScaleFactors.assign(scale8, scale8 + 8); K.mfLogScaleFactor = logScaleFactor; K.mnScaleLevels = 8;
+    K.fx = cam[0]; K.fy = cam[1]; K.cx = cam[2]; K.cy = cam[3]; K.mbf = cam[4];
+    K.mnMinX = (int)bounds[0]; K.mnMaxX = (int)bounds[1]; K.mnMinY = (int)bounds[2]; K.mnMaxY = (int)bounds[3];
+    K.Tcw = cv::Mat(4, 4, CV_32F); std::memcpy(K.Tcw.data, Tcw, 64); K.Ow = cv::Mat(3, 1, CV_32F); std::memcpy(K.Ow.data, Ow, 12);
+}
 extern "C" {
+int ref_line_fuse(const KeyLine* kl, const uint8_t* ldesc, int n, const float* bounds, const float* scale8, float logScaleFactor, const uint8_t* state, const int32_t* stateObs,
+                  const float* cam, const float* Tcw, const float* Ow, const FuseMl* ml, const uint8_t* mlDesc, int nml, float th, int32_t* fusedIdx, int32_t* action) {
+    StructureSLAM::KeyFrame K; fill_line_keyframe(K, kl, ldesc, n, bounds, scale8, logScaleFactor, cam, Tcw, Ow);
+    std::vector<StructureSLAM::MapLine> pool(nml), occ(n);
+    std::vector<StructureSLAM::MapLine*> vp(nml);
+    for (int i = 0; i < nml; ++i) { fill_fuse_line(pool[i], ml[i], mlDesc + (size_t)i * 32); vp[i] = &pool[i]; }
+    K.mvpMapLines.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) if (state[i]) { occ[i].nObs = stateObs[i]; occ[i].bad = state[i] == 2; K.mvpMapLines[i] = &occ[i]; }
+    gFuseL.kf = &K; gFuseL.pool = pool.data(); gFuseL.npool = nml; gFuseL.idx.assign(nml, -1); gFuseL.act.assign(nml, 0);
+    StructureSLAM::LSDmatcher m(0.6f, true);
+    const int r = m.Fuse(&K, vp, th);
+    for (int i = 0; i < nml; ++i) { fusedIdx[i] = gFuseL.idx[i]; action[i] = gFuseL.act[i]; }
+    gFuseL = FuseLogL(); return r;
+}
+// the windows of its projection block (:437-497): q[k] = {u1, v1, u2, v2, radius, predicted level, valid}
+struct FuseQL { float u1, v1, u2, v2, radius; int level, valid; };
+int ref_line_fuse_queries(const float* bounds, const float* scale8, float logScaleFactor, const float* cam, const float* Tcw, const float* Owv, const FuseMl* ml, int nml, float th, FuseQL* q) {
+    StructureSLAM::KeyFrame K; fill_line_keyframe(K, nullptr, nullptr, 0, bounds, scale8, logScaleFactor, cam, Tcw, Owv);
+    cv::Mat Rcw = K.GetRotation(), tcw = K.GetTranslation(), Ow = K.GetCameraCenter();
+    const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    uint8_t zero[32] = {0};
+    for (int i = 0; i < nml; ++i) {
+        FuseQL& Q = q[i]; Q = FuseQL();
+        StructureSLAM::MapLine L; fill_fuse_line(L, ml[i], zero);
+        if (L.isBad()) continue;
+        Vector6d P = L.GetWorldPos();
+        cv::Mat SP = (Mat_<float>(3, 1) << P(0), P(1), P(2)); cv::Mat EP = (Mat_<float>(3, 1) << P(3), P(4), P(5));
+        const cv::Mat SPc = Rcw * SP + tcw; const cv::Mat EPc = Rcw * EP + tcw;
+        const float SPcX = SPc.at<float>(0), SPcY = SPc.at<float>(1), SPcZ = SPc.at<float>(2), EPcX = EPc.at<float>(0), EPcY = EPc.at<float>(1), EPcZ = EPc.at<float>(2);
+        if (SPcZ < 0.0f || EPcZ < 0.0f) continue;
+        const float invz1 = 1.0f / SPcZ; const float u1 = fx * SPcX * invz1 + cx; const float v1 = fy * SPcY * invz1 + cy;
+        if (u1 < K.mnMinX || u1 > K.mnMaxX) continue;
+        if (v1 < K.mnMinY || v1 > K.mnMaxY) continue;
+        const float invz2 = 1.0f / EPcZ; const float u2 = fx * EPcX * invz2 + cx; const float v2 = fy * EPcY * invz2 + cy;
+        if (u2 < K.mnMinX || u2 > K.mnMaxX) continue;
+        if (v2 < K.mnMinY || v2 > K.mnMaxY) continue;
+        const float maxDistance = L.GetMaxDistanceInvariance(); const float minDistance = L.GetMinDistanceInvariance();
+        const cv::Mat OM = 0.5 * (SP + EP) - Ow; const float dist = cv::norm(OM);
+        if (dist < minDistance || dist > maxDistance) continue;
+        Vector3d Pn = L.GetNormal(); cv::Mat pn = (Mat_<float>(3, 1) << Pn(0), Pn(1), Pn(2));
+        if (OM.dot(pn) < 0.5 * dist) continue;
+        const int lvl = L.PredictScale(dist, K.mfLogScaleFactor);
+        Q.u1 = u1; Q.v1 = v1; Q.u2 = u2; Q.v2 = v2; Q.level = lvl; Q.valid = lvl >= 0 && lvl < 8 ? 1 : 2;      // 2: the reference would index mvScaleFactors out of range (no clamp in MapLine::PredictScale)
+        if (Q.valid == 1) Q.radius = th * K.mvScaleFactors[lvl];
+    }
+    return 0;
+}
 // state[i]: 0 the keyframe's slot i holds no map point, 1 a good one with stateObs[i] observations, 2 a bad one.  cam = {fx, fy, cx, cy, mbf}.
 // fusedIdx[k] / action[k] for map point k: the keyframe feature it was fused to (-1) and how (0 not, 1 new observation, 2 replaced BY the keyframe's point,
 // 3 it replaced the keyframe's point, 4 the slot holds a bad point: counted, nothing done); returns nFused

@@ -137,11 +137,18 @@ public:
     void ComputeDistinctiveDescriptors();      // src/MapLine.cpp:246-317
     std::mutex& mMutexFeatures = gStubMutex; bool mbBad = false; std::map<KeyFrame*, size_t> mObservations; cv::Mat mLDescriptor;
     bool mbTrackInView = false; int mnTrackScaleLevel = 0; float mTrackViewCos = 0, mTrackProjX1 = 0, mTrackProjY1 = 0, mTrackProjX2 = 0, mTrackProjY2 = 0;
-    bool isBad() { return bad; }
+    bool isBad();                                     // ref_slices_api.cpp (as MapPoint::isBad)
     cv::Mat GetDescriptor() { return desc.clone(); }
     Vector6d GetWorldPos() { return worldPos; }
     int Observations() { return nObs; }
     bool bad = false; int nObs = 1; cv::Mat desc; Vector6d worldPos;
+    // what LSDmatcher::Fuse reads and does (include/MapLine.h); Get*DistanceInvariance / PredictScale bodies from src/MapLine.cpp:374-394
+    std::mutex& mMutexPos = gStubMutex; float mfMinDistance = 0, mfMaxDistance = 0; Eigen::Vector3d normal;
+    Eigen::Vector3d GetNormal() { return normal; }
+    float GetMinDistanceInvariance(); float GetMaxDistanceInvariance();
+    int PredictScale(const float& currentDist, const float& logScaleFactor);
+    void Replace(MapLine* pML);                       // ref_slices_api.cpp (recorded)
+    void AddObservation(KeyFrame* pKF, size_t idx);
 };
 
 class Frame {
@@ -175,7 +182,10 @@ public:
     bool isBad() { return bad; } bool bad = false;
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
     std::vector<MapLine*> GetMapLineMatches() { return mvpMapLines; }
-    MapLine* GetMapLine(const size_t& idx) { return mvpMapLines[idx]; }
+    MapLine* GetMapLine(const size_t& idx);           // ref_slices_api.cpp (as GetMapPoint)
+    void AddMapLine(MapLine* pML, const size_t& idx) { mvpMapLines[idx] = pML; }
+    std::vector<KeyLine> mvKeyLines;                  // (include/KeyFrame.h:201; mLineDescriptors is declared below)
+    std::vector<size_t> GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r, const int minLevel = -1, const int maxLevel = -1) const;      // src/KeyFrame.cc:651-684
     void lineDescriptorMAD(std::vector<std::vector<cv::DMatch> > line_matches, double& nn_mad, double& nn12_mad) const;      // src/KeyFrame.cc:820-845
     cv::Mat mLineDescriptors; std::vector<MapLine*> mvpMapLines;
     // what ORBmatcher::SearchForTriangulation / CheckDistEpipolarLine read (include/KeyFrame.h)
@@ -240,6 +250,7 @@ public:
     int SearchByDescriptor(KeyFrame* pKF, Frame& currentF, std::vector<MapLine*>& vpMapLineMatches);
     int SearchByDescriptor(KeyFrame* pKF, KeyFrame* pKF2, std::vector<MapLine*>& vpMapLineMatches);
     int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs);
+    int Fuse(KeyFrame* pKF, const std::vector<MapLine*>& vpMapLines, const float th = 3.0);      // src/LSDmatcher.cpp:417-548
     float RadiusByViewingCos(const float& viewCos);
     float mfNNratio; bool mbCheckOrientation;
 };
