@@ -605,6 +605,59 @@ for name in ("synth1234", "synth2000", "big1235"):
         note("LSDmatcher::Fuse(KeyFrame, MapLines) %s th=%g %s" % (name, th, "own lines" if same else "other view"), eq, map_lines=int(nml), projected=int((fql["valid"] == 1).sum()),
              fused=int(nr), added=int((act == 1).sum()), kf_line_kept=int((act == 2).sum()), kf_line_replaced=int((act == 3).sum()))
 
+# --- LSDmatcher::SearchByProjection(KeyFrame*, Scw, vpLines, vpMatched, th) (src/LSDmatcher.cpp:558-683) and LSDmatcher::Fuse(KeyFrame*, Scw, vpLines, th, vpReplaceLine)
+# (:931-1063): the loop-closing line calls.  Oracle: search_by_projection_sim3 / fuse_search, kind 1, on the windows of the reference's (common) Sim3 projection block.
+for name in ("synth1234", "synth2000", "big1235"):
+    img = frames[name][0]; h, w = img.shape; bb = np.array((0.0, float(w), 0.0, float(h)), np.float32)
+    kl1, ld1 = orc.lines_extract(warp_prev(img), 200)[:2]; kl2, ld2 = orc.lines_extract(img, 200)[:2]; nl2 = len(kl2)
+    fx = fy = f32(0.9 * w); cxx, cyy = f32(w / 2 - 3.25), f32(h / 2 + 1.5); cam = np.array([fx, fy, cxx, cyy, 40.0], np.float32)
+    ay, ax = -0.04, 0.02
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]]); Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    R64 = Ry @ Rx; t64 = np.array([0.1, -0.15, 0.25]); Ow64 = -(R64.T @ t64)
+    for scale, th, same in ((1.0, 10.0, False), (1.19, 10.0, True), (0.87, 4.0, True)):
+        Scw = np.eye(4, dtype=np.float32); Scw[:3, :3] = (scale * R64).astype(np.float32); Scw[:3, 3] = (scale * t64).astype(np.float32)
+        skl, sld = (kl2, ld2) if same else (kl1, ld1); nml = len(skl)
+        z = rng.uniform(2.0, 9.0, nml); dz = rng.uniform(-0.4, 0.4, nml)
+        def unproj(x, y, zz):
+            pc = np.stack([(x.astype(np.float64) + rng.uniform(-2, 2, nml) - float(cxx)) / float(fx) * zz, (y.astype(np.float64) + rng.uniform(-2, 2, nml) - float(cyy)) / float(fy) * zz, zz], 1)
+            return (R64.T @ (pc - t64).T).T
+        kind = rng.choice(5, nml, p=[0.8, 0.05, 0.05, 0.05, 0.05])
+        zs = z.copy(); zs[kind == 1] *= -1
+        sp = unproj(skl["startPointX"], skl["startPointY"], zs); ep = unproj(skl["endPointX"], skl["endPointY"], z + dz); sp[kind == 2, 0] += 40.0
+        ml = np.zeros(nml, FML); ml["wp"] = np.concatenate([sp, ep], 1).astype(np.float32).astype(np.float64)
+        om = 0.5 * (sp + ep) - Ow64; dist = np.linalg.norm(om, axis=1); nrm = om / dist[:, None]; nrm[kind == 3] = -nrm[kind == 3]; ml["nrm"] = nrm.astype(np.float32).astype(np.float64)
+        lvl = rng.choice([0, 0, 0, 1, 1, 2, 4], nml); ml["maxDist"] = (dist * 1.2 ** lvl * rng.uniform(0.86, 0.99, nml)).astype(np.float32)
+        ml["minDist"] = (ml["maxDist"] / f32(1.2 ** 7)).astype(np.float32); ml["bad"] = kind == 4
+        mld = sld.copy()
+        for i in np.nonzero(rng.random(nml) < 0.4)[0]: mld[i, rng.integers(0, 32, 4)] ^= rng.integers(1, 256, 4).astype(np.uint8)
+        # -- SearchByProjection(KF, Scw, lines, matched, th)
+        m_in = np.full(nl2, -1, np.int32); r_ = rng.random(nl2); m_in[r_ < 0.15] = -2
+        pick = np.nonzero((r_ >= 0.15) & (r_ < 0.25))[0]; m_in[pick] = rng.permutation(nml)[:len(pick)]
+        found = np.zeros(nml, np.uint8); found[m_in[m_in >= 0]] = 1
+        fql = np.zeros(nml, FQL)
+        R.ref_line_sim3_queries(_p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Scw), _p(found), _p(ml), nml, C.c_float(th), _p(fql))
+        assert (fql["valid"] != 2).all()
+        m_ref = m_in.copy()
+        nr = R.ref_line_search_by_projection_sim3(_p(kl2), _p(ld2), nl2, _p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Scw), _p(ml), _p(mld), nml, int(th), _p(m_ref))
+        q = np.zeros(nml, fe.PQ_DTYPE)
+        q["u"] = fql["u1"]; q["v"] = fql["v1"]; q["u2"] = fql["u2"]; q["v2"] = fql["v2"]; q["radius"] = fql["radius"]; q["min_level"] = fql["level"] - 1; q["max_level"] = fql["level"]; q["valid"] = fql["valid"]
+        a, no = orc.search_by_projection_sim3(1, kl2, ld2, q, mld, (m_in != -1).astype(np.uint8), bounds=tuple(bb))
+        want = np.where(a >= 0, a, m_in).astype(np.int32)
+        note("LSDmatcher::SearchByProjection(KF, Scw, lines) %s s=%g th=%g %s" % (name, scale, th, "own lines" if same else "other view"), nr == no and np.array_equal(m_ref, want),
+             candidates=int(nml), already_found=int(found.sum()), projected=int((fql["valid"] == 1).sum()), matches=int(nr))
+        # -- Fuse(KF, Scw, lines, th, replace)
+        state = rng.choice([0, 0, 1, 1, 2], nl2).astype(np.uint8)
+        slot = np.full(nml, -1, np.int32); own = rng.permutation(nml)[:nml // 10]; slot[own] = rng.permutation(nl2)[:len(own)]
+        inkf = ((slot >= 0) & (ml["bad"] == 0)).astype(np.uint8)
+        R.ref_line_sim3_queries(_p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(Scw), _p(inkf), _p(ml), nml, C.c_float(th), _p(fql))
+        fused = np.zeros(nml, np.int32); act = np.zeros(nml, np.int32)
+        nr = R.ref_line_fuse_sim3(_p(kl2), _p(ld2), nl2, _p(bb), _p(scale8), C.c_float(log_sf), _p(state), _p(slot), _p(cam), _p(Scw), _p(ml), _p(mld), nml, C.c_float(th), _p(fused), _p(act))
+        q["u"] = fql["u1"]; q["v"] = fql["v1"]; q["u2"] = fql["u2"]; q["v2"] = fql["v2"]; q["radius"] = fql["radius"]; q["min_level"] = fql["level"] - 1; q["max_level"] = fql["level"]; q["valid"] = fql["valid"]
+        bi, bd = orc.fuse_search(1, 0, kl2, ld2, q, mld, bounds=tuple(bb))
+        want = np.where((fql["valid"] == 1) & (bi >= 0) & (bd <= 50), bi, -1)
+        note("LSDmatcher::Fuse(KeyFrame, Scw, lines) %s s=%g th=%g %s" % (name, scale, th, "own lines" if same else "other view"), nr == int((want >= 0).sum()) and np.array_equal(fused, want),
+             candidates=int(nml), already_in_keyframe=int(inkf.sum()), projected=int((fql["valid"] == 1).sum()), fused=int(nr), added=int((act == 1).sum()), to_replace=int((act == 2).sum()))
+
 # --- MapPoint / MapLine::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312, src/MapLine.cpp:246-317): least median Hamming distance to the others
 ok_all = True; nsets = 0
 base = frames["synth2000"][2][1]

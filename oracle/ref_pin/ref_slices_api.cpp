@@ -105,6 +105,11 @@ MapLine* KeyFrame::GetMapLine(const size_t& idx) {
     if (gFuseL.kf == this && gFuseL.cur >= 0) { gFuseL.idx[gFuseL.cur] = (int)idx; if (!gFuseL.act[gFuseL.cur]) gFuseL.act[gFuseL.cur] = 4; }
     return mvpMapLines[idx];
 }
+std::set<MapLine*> KeyFrame::GetMapLines() {
+    std::set<MapLine*> s;
+    for (size_t i = 0; i < mvpMapLines.size(); ++i) if (mvpMapLines[i] && !mvpMapLines[i]->bad) s.insert(mvpMapLines[i]);
+    return s;
+}
 void MapLine::AddObservation(KeyFrame*, size_t idx) { const long i = fuse_line_index(this); if (i >= 0) { gFuseL.idx[i] = (int)idx; gFuseL.act[i] = 1; } }
 void MapLine::Replace(MapLine* pML) {
     const int at = gFuseL.kf->lastQueried;
@@ -171,6 +176,75 @@ int ref_line_fuse_queries(const float* bounds, const float* scale8, float logSca
         if (OM.dot(pn) < 0.5 * dist) continue;
         const int lvl = L.PredictScale(dist, K.mfLogScaleFactor);
         Q.u1 = u1; Q.v1 = v1; Q.u2 = u2; Q.v2 = v2; Q.level = lvl; Q.valid = lvl >= 0 && lvl < 8 ? 1 : 2;      // 2: the reference would index mvScaleFactors out of range (no clamp in MapLine::PredictScale)
+        if (Q.valid == 1) Q.radius = th * K.mvScaleFactors[lvl];
+    }
+    return 0;
+}
+// LSDmatcher::SearchByProjection(KeyFrame*, Scw, vpLines, vpMatched, th) (src/LSDmatcher.cpp:558-683); matched[idx] as in ref_search_by_projection_sim3
+int ref_line_search_by_projection_sim3(const KeyLine* kl, const uint8_t* ldesc, int n, const float* bounds, const float* scale8, float logScaleFactor, const float* cam, const float* Scw,
+                                       const FuseMl* ml, const uint8_t* mlDesc, int nml, int th, int32_t* matched) {
+    const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, O3[3] = {0, 0, 0};
+    StructureSLAM::KeyFrame K; fill_line_keyframe(K, kl, ldesc, n, bounds, scale8, logScaleFactor, cam, I4, O3);
+    std::vector<StructureSLAM::MapLine> pool(nml), other(1);
+    std::vector<StructureSLAM::MapLine*> vp(nml), vm(n, nullptr);
+    for (int i = 0; i < nml; ++i) { fill_fuse_line(pool[i], ml[i], mlDesc + (size_t)i * 32); vp[i] = &pool[i]; }
+    for (int i = 0; i < n; ++i) vm[i] = matched[i] == -1 ? nullptr : matched[i] == -2 ? &other[0] : &pool[matched[i]];
+    cv::Mat S(4, 4, CV_32F); std::memcpy(S.data, Scw, 64);
+    StructureSLAM::LSDmatcher m(0.75f, true);
+    const int r = m.SearchByProjection(&K, S, vp, vm, th);
+    for (int i = 0; i < n; ++i) matched[i] = !vm[i] ? -1 : vm[i] == &other[0] ? -2 : (int32_t)(vm[i] - pool.data());
+    return r;
+}
+// LSDmatcher::Fuse(KeyFrame*, Scw, vpLines, th, vpReplaceLine) (src/LSDmatcher.cpp:931-1063); state / kfSlot / outputs as in ref_fuse_sim3
+int ref_line_fuse_sim3(const KeyLine* kl, const uint8_t* ldesc, int n, const float* bounds, const float* scale8, float logScaleFactor, const uint8_t* state, const int32_t* kfSlot,
+                       const float* cam, const float* Scw, const FuseMl* ml, const uint8_t* mlDesc, int nml, float th, int32_t* fusedIdx, int32_t* action) {
+    const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, O3[3] = {0, 0, 0};
+    StructureSLAM::KeyFrame K; fill_line_keyframe(K, kl, ldesc, n, bounds, scale8, logScaleFactor, cam, I4, O3);
+    std::vector<StructureSLAM::MapLine> pool(nml), occ(n);
+    std::vector<StructureSLAM::MapLine*> vp(nml), rep(nml, nullptr);
+    for (int i = 0; i < nml; ++i) { fill_fuse_line(pool[i], ml[i], mlDesc + (size_t)i * 32); vp[i] = &pool[i]; }
+    K.mvpMapLines.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) if (state[i]) { occ[i].bad = state[i] == 2; K.mvpMapLines[i] = &occ[i]; }
+    for (int k = 0; k < nml; ++k) if (kfSlot[k] >= 0) K.mvpMapLines[kfSlot[k]] = &pool[k];
+    gFuseL.kf = &K; gFuseL.pool = pool.data(); gFuseL.npool = nml; gFuseL.idx.assign(nml, -1); gFuseL.act.assign(nml, 0);
+    cv::Mat S(4, 4, CV_32F); std::memcpy(S.data, Scw, 64);
+    StructureSLAM::LSDmatcher m(0.8f, true);
+    const int r = m.Fuse(&K, S, vp, th, rep);
+    for (int i = 0; i < nml; ++i) { fusedIdx[i] = gFuseL.idx[i]; action[i] = rep[i] ? 2 : gFuseL.act[i]; }
+    gFuseL = FuseLogL(); return r;
+}
+// the windows of their (common) projection block: the Sim3 decomposition, then as ref_line_fuse_queries; skip[k]: the candidate is already in the keyframe / in vpMatched
+int ref_line_sim3_queries(const float* bounds, const float* scale8, float logScaleFactor, const float* cam, const float* Scw, const uint8_t* skip, const FuseMl* ml, int nml, float th, FuseQL* q) {
+    const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, O3[3] = {0, 0, 0};
+    StructureSLAM::KeyFrame K; fill_line_keyframe(K, nullptr, nullptr, 0, bounds, scale8, logScaleFactor, cam, I4, O3);
+    const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    cv::Mat S(4, 4, CV_32F); std::memcpy(S.data, Scw, 64);
+    cv::Mat sRcw = S.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw; cv::Mat tcw = S.rowRange(0, 3).col(3) / scw; cv::Mat Ow = -Rcw.t() * tcw;
+    uint8_t zero[32] = {0};
+    for (int i = 0; i < nml; ++i) {
+        FuseQL& Q = q[i]; Q = FuseQL();
+        StructureSLAM::MapLine L; fill_fuse_line(L, ml[i], zero);
+        if (L.isBad() || skip[i]) continue;
+        Vector6d P = L.GetWorldPos();
+        cv::Mat SP = (Mat_<float>(3, 1) << P(0), P(1), P(2)); cv::Mat EP = (Mat_<float>(3, 1) << P(3), P(4), P(5));
+        const cv::Mat SPc = Rcw * SP + tcw; const cv::Mat EPc = Rcw * EP + tcw;
+        const float SPcX = SPc.at<float>(0), SPcY = SPc.at<float>(1), SPcZ = SPc.at<float>(2), EPcX = EPc.at<float>(0), EPcY = EPc.at<float>(1), EPcZ = EPc.at<float>(2);
+        if (SPcZ < 0.0f || EPcZ < 0.0f) continue;
+        const float invz1 = 1.0f / SPcZ; const float u1 = fx * SPcX * invz1 + cx; const float v1 = fy * SPcY * invz1 + cy;
+        if (u1 < K.mnMinX || u1 > K.mnMaxX) continue;
+        if (v1 < K.mnMinY || v1 > K.mnMaxY) continue;
+        const float invz2 = 1.0f / EPcZ; const float u2 = fx * EPcX * invz2 + cx; const float v2 = fy * EPcY * invz2 + cy;
+        if (u2 < K.mnMinX || u2 > K.mnMaxX) continue;
+        if (v2 < K.mnMinY || v2 > K.mnMaxY) continue;
+        const float maxDistance = L.GetMaxDistanceInvariance(); const float minDistance = L.GetMinDistanceInvariance();
+        const cv::Mat OM = 0.5 * (SP + EP) - Ow; const float dist = cv::norm(OM);
+        if (dist < minDistance || dist > maxDistance) continue;
+        Vector3d Pn = L.GetNormal(); cv::Mat pn = (Mat_<float>(3, 1) << Pn(0), Pn(1), Pn(2));
+        if (OM.dot(pn) < 0.5 * dist) continue;
+        const int lvl = L.PredictScale(dist, K.mfLogScaleFactor);
+        Q.u1 = u1; Q.v1 = v1; Q.u2 = u2; Q.v2 = v2; Q.level = lvl; Q.valid = lvl >= 0 && lvl < 8 ? 1 : 2;
         if (Q.valid == 1) Q.radius = th * K.mvScaleFactors[lvl];
     }
     return 0;

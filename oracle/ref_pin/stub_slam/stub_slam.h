@@ -184,6 +184,7 @@ public:
     std::vector<MapLine*> GetMapLineMatches() { return mvpMapLines; }
     MapLine* GetMapLine(const size_t& idx);           // ref_slices_api.cpp (as GetMapPoint)
     void AddMapLine(MapLine* pML, const size_t& idx) { mvpMapLines[idx] = pML; }
+    std::set<MapLine*> GetMapLines();                 // ref_slices_api.cpp: the good map lines of the keyframe (src/KeyFrame.cc:737-750)
     std::vector<KeyLine> mvKeyLines;                  // (include/KeyFrame.h:201; mLineDescriptors is declared below)
     std::vector<size_t> GetLinesInArea(const float& x1, const float& y1, const float& x2, const float& y2, const float& r, const int minLevel = -1, const int maxLevel = -1) const;      // src/KeyFrame.cc:651-684
     void lineDescriptorMAD(std::vector<std::vector<cv::DMatch> > line_matches, double& nn_mad, double& nn12_mad) const;      // src/KeyFrame.cc:820-845
@@ -251,6 +252,8 @@ public:
     int SearchByDescriptor(KeyFrame* pKF, KeyFrame* pKF2, std::vector<MapLine*>& vpMapLineMatches);
     int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs);
     int Fuse(KeyFrame* pKF, const std::vector<MapLine*>& vpMapLines, const float th = 3.0);      // src/LSDmatcher.cpp:417-548
+    int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapLine*>& vpLines, float th, std::vector<MapLine*>& vpReplaceLine);      // :931-1063
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapLine*>& vpLines, std::vector<MapLine*>& vpMatched, int th);      // :558-683
     float RadiusByViewingCos(const float& viewCos);
     float mfNNratio; bool mbCheckOrientation;
 };
