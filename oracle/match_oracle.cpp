@@ -6,13 +6,16 @@
 // lineDescriptorMAD, LSDmatcher::SerachForInitialize, ORBmatcher::SearchByProjection(F, MapPoints) and (Cur, Last, th, bMono),
 // LSDmatcher::SearchByProjection(F, MapLines), (Cur, Last, th, bMono) and (KF, F), LSDmatcher::SearchByDescriptor (KF, F) and (KF, KF),
 // LSDmatcher::SearchForTriangulation over KeyFrame::lineDescriptorMAD, ORBmatcher::SearchByBoW(KF, F) and (KF, KF),
-// ORBmatcher::SearchForTriangulation with CheckDistEpipolarLine, ORBmatcher::Fuse(KF, MapPoints, th) (:828-978, over KeyFrame::GetFeaturesInArea / IsInImage and
-// MapPoint::PredictScale / Get*DistanceInvariance; fuse_search below on the windows the reference's own projection block forms),
-// MapPoint / MapLine::ComputeDistinctiveDescriptors, the vocabulary loader + transform below against the reference's own vendored
-// DBoW2 compiled whole (oracle/_ref/libref_dbow2.so; the two places where that code reads uninitialised locals are decisions D9 / D10), and the
-// orchestration of LineSegment::ExtractLineSegment.  NOT pinned that way: Fuse(KF, Scw, ...) / the line Fuse overloads / SearchBySim3 / the relocalisation and
-// loop-closing projection overloads (restated below from the source, compared with the HIP library only), and the OpenCV leaves
-// (cv::BFMatcher::knnMatch's tie-break, cv::gemm's accumulation order in the pose algebra of the (Cur, Last) calls).
+// ORBmatcher::SearchForTriangulation with CheckDistEpipolarLine, MapPoint / MapLine::ComputeDistinctiveDescriptors, the vocabulary loader + transform below against the
+// reference's own vendored DBoW2 compiled whole (oracle/_ref/libref_dbow2.so; the two places where that code reads uninitialised locals are decisions D9 / D10), the
+// orchestration of LineSegment::ExtractLineSegment -- and, since the end of round 4, the mapping / relocalisation / loop-closing overloads as well: ORBmatcher::Fuse x2
+// (:828-978, :980-1103), SearchByProjection(Cur, KF, found, th, dist) (:1475-1602) and (KF, Scw, points, matched, th) (:293-406), SearchBySim3 (:1105-1329);
+// LSDmatcher::Fuse x2 (src/LSDmatcher.cpp:417-548, 931-1063), SearchByProjection(KF, Scw, lines, matched, th) (:558-683), SearchBySim3 (:685-929); over
+// KeyFrame::GetFeaturesInArea / GetLinesInArea / IsInImage and MapPoint / MapLine::PredictScale / Get*DistanceInvariance.  For those the restatements below
+// (fuse_search, search_by_projection_reloc / _sim3) take the search windows; the windows are the ones the reference's own projection blocks form on the same
+// stand-in objects (ref_*_queries in oracle/ref_pin/ref_slices_api.cpp).  Every public function of ORBmatcher and LSDmatcher is compared with its reference body.
+// NOT pinned: the OpenCV leaves (cv::BFMatcher::knnMatch's tie-break; cv::gemm's accumulation order, Mat::dot, cv::norm and the MatExpr scalings in the pose
+// algebra: the stand-ins of oracle/ref_pin/stub_cv state what they assume).
 //
 // CPU restatement of the reference's Hamming matchers on the hot path:
 //   ORBmatcher::DescriptorDistance      src/ORBmatcher.cc:1650-1666

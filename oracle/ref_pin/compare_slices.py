@@ -658,6 +658,56 @@ for name in ("synth1234", "synth2000", "big1235"):
         note("LSDmatcher::Fuse(KeyFrame, Scw, lines) %s s=%g th=%g %s" % (name, scale, th, "own lines" if same else "other view"), nr == int((want >= 0).sum()) and np.array_equal(fused, want),
              candidates=int(nml), already_in_keyframe=int(inkf.sum()), projected=int((fql["valid"] == 1).sum()), fused=int(nr), added=int((act == 1).sum()), to_replace=int((act == 2).sum()))
 
+# --- LSDmatcher::SearchBySim3 (src/LSDmatcher.cpp:685-929): both directions = fuse_search, kind 1, TH_HIGH, on the windows of the reference's two projection blocks; agreement restated here.
+for name in ("synth1234", "synth2000", "big1235"):
+    img = frames[name][0]; h, w = img.shape; bb = np.array((0.0, float(w), 0.0, float(h)), np.float32)
+    kl2, ld2 = orc.lines_extract(img, 200)[:2]; n = len(kl2)
+    fx = fy = f32(0.9 * w); cxx, cyy = f32(w / 2 - 3.25), f32(h / 2 + 1.5); cam = np.array([fx, fy, cxx, cyy, 40.0], np.float32)
+    ay, ax = 0.02, 0.04
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]]); Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Rw = Ry @ Rx; tw = np.array([-0.1, 0.2, 0.3])
+    T1w = np.eye(4, dtype=np.float32); T1w[:3, :3] = Rw.astype(np.float32); T1w[:3, 3] = tw.astype(np.float32); T2w = T1w.copy()
+    for s12, ang, th in ((1.0, 0.0, 7.5), (1.02, 0.003, 7.5), (0.98, -0.004, 4.0)):
+        Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]]); R12 = Rz.astype(np.float32); t12 = np.array([0.01, -0.02, 0.01 * (s12 != 1.0)], np.float32)
+
+        def lines3d():
+            z = rng.uniform(2.0, 9.0, n); dz = rng.uniform(-0.3, 0.3, n)
+            def unproj(x, y, zz):
+                pc = np.stack([(x.astype(np.float64) + rng.uniform(-1.5, 1.5, n) - float(cxx)) / float(fx) * zz, (y.astype(np.float64) + rng.uniform(-1.5, 1.5, n) - float(cyy)) / float(fy) * zz, zz], 1)
+                return pc, (Rw.T @ (pc - tw).T).T
+            pcs, sp = unproj(kl2["startPointX"], kl2["startPointY"], z); pce, ep = unproj(kl2["endPointX"], kl2["endPointY"], z + dz)
+            ml = np.zeros(n, FML); ml["wp"] = np.concatenate([sp, ep], 1).astype(np.float32).astype(np.float64)
+            dist = np.linalg.norm(0.5 * (pcs + pce), axis=1)
+            lvl = rng.choice([0, 0, 0, 1, 1, 2], n); ml["maxDist"] = (dist * 1.2 ** lvl * rng.uniform(0.88, 0.97, n)).astype(np.float32)
+            ml["minDist"] = (ml["maxDist"] / f32(1.2 ** 7)).astype(np.float32); ml["bad"] = rng.random(n) < 0.04
+            return ml
+        ml1, ml2 = lines3d(), lines3d()
+        mld1, mld2 = ld2.copy(), ld2.copy()
+        for dd in (mld1, mld2):
+            for i in np.nonzero(rng.random(n) < 0.4)[0]: dd[i, rng.integers(0, 32, 5)] ^= rng.integers(1, 256, 5).astype(np.uint8)
+        present1 = (rng.random(n) < 0.85).astype(np.uint8); present2 = (rng.random(n) < 0.85).astype(np.uint8)
+        m_in = np.full(n, -1, np.int32); r_ = rng.random(n); m_in[r_ < 0.06] = -2
+        pick = np.nonzero((r_ >= 0.06) & (r_ < 0.16))[0]; m_in[pick] = rng.choice(np.nonzero(present2)[0], len(pick), replace=False)
+        m_ref = m_in.copy()
+        nr = R.ref_line_search_by_sim3(_p(kl2), _p(ld2), n, _p(kl2), _p(ld2), n, _p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(T1w), _p(T2w), C.c_float(s12), _p(R12), _p(t12),
+                                       _p(present1), _p(ml1), _p(mld1), _p(present2), _p(ml2), _p(mld2), C.c_float(th), _p(m_ref))
+        already1 = m_in != -1; already2 = np.zeros(n, bool); already2[m_in[m_in >= 0]] = True
+        vn = []
+        for direction, present, already, ml, mld in ((0, present1, already1, ml1, mld1), (1, present2, already2, ml2, mld2)):
+            skip = ((present == 0) | already).astype(np.uint8); fql = np.zeros(n, FQL)
+            R.ref_line_sim3_pair_queries(direction, _p(bb), _p(scale8), C.c_float(log_sf), _p(cam), _p(T1w), _p(T2w), C.c_float(s12), _p(R12), _p(t12), _p(skip), _p(ml), n, C.c_float(th), _p(fql))
+            assert (fql["valid"] != 2).all()
+            q = np.zeros(n, fe.PQ_DTYPE)
+            q["u"] = fql["u1"]; q["v"] = fql["v1"]; q["u2"] = fql["u2"]; q["v2"] = fql["v2"]; q["radius"] = fql["radius"]; q["min_level"] = fql["level"] - 1; q["max_level"] = fql["level"]; q["valid"] = fql["valid"]
+            bi, bd = orc.fuse_search(1, 0, kl2, ld2, q, mld, bounds=tuple(bb))
+            vn.append(np.where((fql["valid"] == 1) & (bi >= 0) & (bd <= 100), bi, -1))
+        want = m_in.copy(); found = 0
+        for i1 in range(n):
+            i2 = vn[0][i1]
+            if i2 >= 0 and vn[1][i2] == i1: want[i1] = i2 if present2[i2] else -1; found += 1
+        note("LSDmatcher::SearchBySim3 %s s12=%g rot=%g th=%g" % (name, s12, ang, th), nr == found and np.array_equal(m_ref, want), lines1=int(present1.sum()), lines2=int(present2.sum()),
+             already_matched=int(already1.sum()), one_way=int((vn[0] >= 0).sum()), other_way=int((vn[1] >= 0).sum()), agreed=int(found))
+
 # --- MapPoint / MapLine::ComputeDistinctiveDescriptors (src/MapPoint.cc:247-312, src/MapLine.cpp:246-317): least median Hamming distance to the others
 ok_all = True; nsets = 0
 base = frames["synth2000"][2][1]

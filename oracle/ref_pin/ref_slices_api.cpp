@@ -249,6 +249,59 @@ int ref_line_sim3_queries(const float* bounds, const float* scale8, float logSca
     }
     return 0;
 }
+// LSDmatcher::SearchBySim3 (src/LSDmatcher.cpp:685-929); arguments as ref_search_by_sim3, with key lines and map lines
+int ref_line_search_by_sim3(const KeyLine* kl1, const uint8_t* ld1, int n1, const KeyLine* kl2, const uint8_t* ld2, int n2, const float* bounds, const float* scale8, float logScaleFactor,
+                            const float* cam, const float* T1w, const float* T2w, float s12, const float* R12, const float* t12, const uint8_t* present1, const FuseMl* ml1, const uint8_t* mlDesc1,
+                            const uint8_t* present2, const FuseMl* ml2, const uint8_t* mlDesc2, float th, int32_t* m12) {
+    const float O3[3] = {0, 0, 0};
+    StructureSLAM::KeyFrame K1, K2;
+    fill_line_keyframe(K1, kl1, ld1, n1, bounds, scale8, logScaleFactor, cam, T1w, O3); fill_line_keyframe(K2, kl2, ld2, n2, bounds, scale8, logScaleFactor, cam, T2w, O3);
+    std::vector<StructureSLAM::MapLine> pool1(n1), pool2(n2), other(1);
+    K1.mvpMapLines.assign(n1, nullptr); K2.mvpMapLines.assign(n2, nullptr);
+    for (int i = 0; i < n1; ++i) if (present1[i]) { fill_fuse_line(pool1[i], ml1[i], mlDesc1 + (size_t)i * 32); K1.mvpMapLines[i] = &pool1[i]; }
+    for (int i = 0; i < n2; ++i) if (present2[i]) { fill_fuse_line(pool2[i], ml2[i], mlDesc2 + (size_t)i * 32); pool2[i].idxInKF2 = i; K2.mvpMapLines[i] = &pool2[i]; }
+    std::vector<StructureSLAM::MapLine*> vm(n1, nullptr);
+    for (int i = 0; i < n1; ++i) vm[i] = m12[i] == -1 ? nullptr : m12[i] == -2 ? &other[0] : &pool2[m12[i]];
+    cv::Mat R(3, 3, CV_32F), t(3, 1, CV_32F); std::memcpy(R.data, R12, 36); std::memcpy(t.data, t12, 12);
+    StructureSLAM::LSDmatcher m(0.75f, true);
+    const int r = m.SearchBySim3(&K1, &K2, vm, s12, R, t, th);
+    for (int i = 0; i < n1; ++i) m12[i] = !vm[i] ? -1 : vm[i] == &other[0] ? -2 : (int32_t)(vm[i] - pool2.data());
+    return r;
+}
+int ref_line_sim3_pair_queries(int dir, const float* bounds, const float* scale8, float logScaleFactor, const float* cam, const float* T1w, const float* T2w, float s12, const float* R12v,
+                               const float* t12v, const uint8_t* skip, const FuseMl* ml, int nml, float th, FuseQL* q) {
+    const float O3[3] = {0, 0, 0};
+    StructureSLAM::KeyFrame K1, K2; fill_line_keyframe(K1, nullptr, nullptr, 0, bounds, scale8, logScaleFactor, cam, T1w, O3); fill_line_keyframe(K2, nullptr, nullptr, 0, bounds, scale8, logScaleFactor, cam, T2w, O3);
+    const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    cv::Mat R1w = K1.GetRotation(), t1w = K1.GetTranslation(), R2w = K2.GetRotation(), t2w = K2.GetTranslation();
+    cv::Mat R12(3, 3, CV_32F), t12(3, 1, CV_32F); std::memcpy(R12.data, R12v, 36); std::memcpy(t12.data, t12v, 12);
+    cv::Mat sR12 = s12 * R12; cv::Mat sR21 = (1.0 / s12) * R12.t(); cv::Mat t21 = -sR21 * t12;
+    uint8_t zero[32] = {0};
+    for (int i = 0; i < nml; ++i) {
+        FuseQL& Q = q[i]; Q = FuseQL();
+        if (skip[i]) continue;
+        StructureSLAM::MapLine L; fill_fuse_line(L, ml[i], zero);
+        if (L.isBad()) continue;
+        Vector6d P = L.GetWorldPos();
+        cv::Mat SP = (Mat_<float>(3, 1) << P(0), P(1), P(2)); cv::Mat EP = (Mat_<float>(3, 1) << P(3), P(4), P(5));
+        const cv::Mat SPa = dir == 0 ? cv::Mat(R1w * SP + t1w) : cv::Mat(R2w * SP + t2w); const cv::Mat SPb = dir == 0 ? cv::Mat(sR21 * SPa + t21) : cv::Mat(sR12 * SPa + t12);
+        const cv::Mat EPa = dir == 0 ? cv::Mat(R1w * EP + t1w) : cv::Mat(R2w * EP + t2w); const cv::Mat EPb = dir == 0 ? cv::Mat(sR21 * EPa + t21) : cv::Mat(sR12 * EPa + t12);
+        const float SPcX = SPb.at<float>(0), SPcY = SPb.at<float>(1), SPcZ = SPb.at<float>(2), EPcX = EPb.at<float>(0), EPcY = EPb.at<float>(1), EPcZ = EPb.at<float>(2);
+        if (SPcZ < 0.0f || EPcZ < 0.0f) continue;
+        StructureSLAM::KeyFrame* Kt = dir == 0 ? &K2 : &K1;
+        const float invz1 = 1.0f / SPcZ; const float u1 = fx * SPcX * invz1 + cx; const float v1 = fy * SPcY * invz1 + cy;
+        if (!Kt->IsInImage(u1, v1)) continue;
+        const float invz2 = 1.0f / EPcZ; const float u2 = fx * EPcX * invz2 + cx; const float v2 = fy * EPcY * invz2 + cy;
+        if (!Kt->IsInImage(u2, v2)) continue;
+        const float maxDistance = L.GetMaxDistanceInvariance(); const float minDistance = L.GetMinDistanceInvariance();
+        const float dist3D = cv::norm(0.5 * (SPb + EPb));
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int lvl = L.PredictScale(dist3D, Kt->mfLogScaleFactor);
+        Q.u1 = u1; Q.v1 = v1; Q.u2 = u2; Q.v2 = v2; Q.level = lvl; Q.valid = lvl >= 0 && lvl < 8 ? 1 : 2;
+        if (Q.valid == 1) Q.radius = th * Kt->mvScaleFactors[lvl];
+    }
+    return 0;
+}
 // state[i]: 0 the keyframe's slot i holds no map point, 1 a good one with stateObs[i] observations, 2 a bad one.  cam = {fx, fy, cx, cy, mbf}.
 // fusedIdx[k] / action[k] for map point k: the keyframe feature it was fused to (-1) and how (0 not, 1 new observation, 2 replaced BY the keyframe's point,
 // 3 it replaced the keyframe's point, 4 the slot holds a bad point: counted, nothing done); returns nFused

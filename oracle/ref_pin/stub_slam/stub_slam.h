@@ -148,6 +148,7 @@ public:
     float GetMinDistanceInvariance(); float GetMaxDistanceInvariance();
     int PredictScale(const float& currentDist, const float& logScaleFactor);
     void Replace(MapLine* pML);                       // ref_slices_api.cpp (recorded)
+    int GetIndexInKeyFrame(KeyFrame*) { return idxInKF2; } int idxInKF2 = -1;      // (SearchBySim3 asks for the index in pKF2 only)
     void AddObservation(KeyFrame* pKF, size_t idx);
 };
 
@@ -254,6 +255,7 @@ public:
     int Fuse(KeyFrame* pKF, const std::vector<MapLine*>& vpMapLines, const float th = 3.0);      // src/LSDmatcher.cpp:417-548
     int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapLine*>& vpLines, float th, std::vector<MapLine*>& vpReplaceLine);      // :931-1063
     int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapLine*>& vpLines, std::vector<MapLine*>& vpMatched, int th);      // :558-683
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapLine*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th);      // :685-929
     float RadiusByViewingCos(const float& viewCos);
     float mfNNratio; bool mbCheckOrientation;
 };

@@ -22,7 +22,7 @@ def _check(rep):
     bad = {k: v for k, v in rep["slices"]["cases"].items() if not v["equal"]}
     assert not bad, bad
     assert rep["all_equal"]
-    assert len(rep["orb_extractor"]["fixtures"]) >= 16 and len(rep["slices"]["cases"]) >= 230
+    assert len(rep["orb_extractor"]["fixtures"]) >= 16 and len(rep["slices"]["cases"]) >= 239
     covered = " ".join(rep["slices"]["cases"])
     for fn in ("DescriptorDistance", "GetFeaturesInArea", "GetLinesInArea", "SearchForInitialization", "SerachForInitialize", "SearchByProjection(F, MapPoints)",
                "SearchByProjection(Cur, Last)", "SearchByProjection(F, MapLines)", "SearchByBoW(KF, F)", "SearchByBoW(KF, KF)", "ExtractLineSegment", "SearchByProjection(KF, F)", "SearchByDescriptor(KF, F)",
