@@ -1,0 +1,79 @@
+"""Independent cross-checks of two of the oracle's OpenCV leaves (UPSTREAM-RECALL: restated from memory, no OpenCV in this image) against other people's code that
+happens to be installed -- not a pin (different libraries), but the parts whose definition leaves no freedom must agree exactly:
+
+* FAST-9/16: WHICH pixels pass the segment test at a threshold is the published definition (>= 9 contiguous ring pixels all brighter than p + t or all darker than
+  p - t); scikit-image's corner_fast (0.18, /opt/conda's python3.9 -- not importable from this interpreter, hence the subprocess) implements the same test on its own.
+  Compared: the corner set before non-maximum suppression.  cv::FAST's score and its NMS are NOT covered (scikit-image's response is a different quantity).
+* Sobel 3x3 with BORDER_REFLECT_101 (LBD's gradient): integer arithmetic, scipy.ndimage.sobel with mode="mirror"."""
+import os, subprocess, sys
+import numpy as np
+import pytest
+from synth import synth_frame, noise_frame
+
+CONDA_PY = "/opt/conda/bin/python3.9"
+SK_SCRIPT = """
+import sys, numpy as np
+from skimage.feature import corner_fast
+img = np.load(sys.argv[1]).astype(np.float64)          # integer-valued doubles and an integer threshold: every comparison is exact
+np.save(sys.argv[3], corner_fast(img, n=9, threshold=float(sys.argv[2])) > 0)
+"""
+
+
+def _have_skimage():
+    if not os.path.exists(CONDA_PY):
+        return False
+    return subprocess.run([CONDA_PY, "-c", "import skimage.feature"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
+
+
+@pytest.mark.skipif(not _have_skimage(), reason="no scikit-image interpreter at /opt/conda/bin/python3.9")
+@pytest.mark.parametrize("threshold", [20, 7])
+def test_fast_segment_test_equals_scikit_image(oracle, tmp_path, threshold):
+    script = tmp_path / "sk.py"; script.write_text(SK_SCRIPT)
+    for k, img in enumerate((synth_frame(1234), noise_frame(7)[:240, :320].copy(), np.full((64, 80), 127, np.uint8))):
+        score_map, _ = oracle.fast_image(img, threshold)
+        np.save(tmp_path / "img.npy", img)
+        subprocess.run([CONDA_PY, str(script), str(tmp_path / "img.npy"), str(threshold), str(tmp_path / "out.npy")], check=True, stderr=subprocess.DEVNULL)
+        theirs = np.load(tmp_path / "out.npy")
+        ours = score_map > 0
+        assert not ours[:3].any() and not ours[-3:].any() and not ours[:, :3].any() and not ours[:, -3:].any()          # cv::FAST skips the 3-pixel rim
+        inner = np.zeros_like(ours); inner[3:-3, 3:-3] = True
+        assert np.array_equal(ours & inner, theirs & inner), "image %d: %d corners differ" % (k, int(((ours != theirs) & inner).sum()))
+        if k < 2:
+            assert ours.sum() > 1000
+
+
+def test_sobel3_reflect101_equals_scipy(oracle):
+    import ctypes as C
+    from scipy import ndimage
+    from oracle_lib import _p
+    for img in (noise_frame(3)[:200, :300].copy(), synth_frame(77, w=331, h=113)):
+        h, w = img.shape
+        gx = np.zeros((h, w), np.int16); gy = np.zeros((h, w), np.int16)
+        oracle.L.orc_sobel3(_p(np.ascontiguousarray(img)), w, h, _p(gx), _p(gy))
+        i32 = img.astype(np.int32)
+        assert np.array_equal(gx, ndimage.sobel(i32, axis=1, mode="mirror")) and np.array_equal(gy, ndimage.sobel(i32, axis=0, mode="mirror"))
+
+
+def test_resize_blur_atan2_agree_with_float_references_to_within_a_grey_level(oracle):
+    """Not bit-level (OpenCV's 8-bit resize and blur are fixed-point, the references below are float64), but the sampling geometry, the border rule and the kernel are
+    what a whole grey level of disagreement would mean: cv::resize INTER_LINEAR samples at (x + 0.5) * scale - 0.5 (torch's align_corners=False), GaussianBlur
+    7x7 sigma 2 reflects without repeating the edge pixel (scipy's "mirror"), fastAtan2 is within 0.01 degrees of atan2."""
+    import ctypes as C
+    import torch
+    from scipy import ndimage
+    img = synth_frame(1234)
+    prev = img
+    for level in (1, 2, 3):
+        cur = oracle.pyramid_level(img, level)                      # level l is resized from level l - 1 (src/ORBextractor.cc:1118-1122)
+        ref = torch.nn.functional.interpolate(torch.from_numpy(prev.astype(np.float64))[None, None], size=cur.shape, mode="bilinear", align_corners=False)[0, 0].numpy()
+        assert np.abs(cur.astype(np.float64) - ref).max() < 1.0
+        prev = cur
+    x = np.arange(7) - 3.0; k = np.exp(-x * x / 8.0); k /= k.sum()
+    ref = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    assert np.abs(oracle.blur7(img).astype(np.float64) - ref).max() < 1.0
+    oracle.L.orc_fast_atan2.restype = C.c_float
+    rng = np.random.default_rng(1)
+    ys = (rng.normal(size=5000) * 100).astype(np.float32); xs = (rng.normal(size=5000) * 100).astype(np.float32)
+    a = np.array([oracle.L.orc_fast_atan2(C.c_float(float(y)), C.c_float(float(x))) for y, x in zip(ys, xs)])
+    d = np.abs(a - np.degrees(np.arctan2(ys.astype(np.float64), xs.astype(np.float64))) % 360); d = np.minimum(d, 360 - d)
+    assert d.max() < 0.01 and a.min() >= 0 and a.max() < 360
