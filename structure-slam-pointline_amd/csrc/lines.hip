@@ -20,6 +20,8 @@
 #include <cfloat>
 #include <algorithm>
 
+namespace sslam { int launch_nfa_stream(sslam_ctx* ctx, hipStream_t st, uint8_t* ws, const void* plan, size_t planBytes, const double* lgam, uint8_t* clArea, size_t clFrameBytes,
+                                        size_t stageOff, int nframes, int waves, long long spinTicks, const char* scope); }      // lines_nfa.hip
 namespace sslam { int launch_nfa_stage(sslam_ctx* ctx, hipStream_t st, uint8_t* ws, const void* plan, size_t planBytes, const double* lgam, int nframes); }      // lines_nfa.hip
 
 using namespace sslam;
@@ -80,6 +82,7 @@ struct sslam_lines {
     bool constsUploaded = false;
     int blurVariant = 0;            // sslam_lines_set_blur_variant
     int sMin = 0;                   // smallest |g|^2 of a defined pixel (k_grad_smin, with the gradient table)
+    hipStream_t nfaStream = nullptr; hipEvent_t nfaFork = nullptr, nfaJoin = nullptr;      // SSLAM_NFA_STREAM=1: the NFA stage next to the cluster form of the core
 };
 
 static std::vector<int> taps_q8(int n, double sigma) {
@@ -225,6 +228,7 @@ extern "C" int sslam_lines_destroy(sslam_lines* L) {
     if (!L) return SSLAM_OK;
     (void)hipSetDevice(L->ctx->device);
     (void)hipStreamSynchronize(L->ctx->stream);
+    if (L->nfaStream) { (void)hipStreamSynchronize(L->nfaStream); (void)hipStreamDestroy(L->nfaStream); (void)hipEventDestroy(L->nfaFork); (void)hipEventDestroy(L->nfaJoin); }
     DevBuf* bufs[] = {&L->dWs, &L->dCl, &L->dTabs, &L->dTaps, &L->dLgam, &L->dGtab, &L->dImg, &L->dKl, &L->dDesc, &L->dFn, &L->dCounts};
     for (DevBuf* b : bufs) b->release();
     L->hOut.release();
@@ -286,6 +290,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     { sslam::ProfScope _ps(L->ctx, "k_lsd_hist", st); hipLaunchKernelGGL(k_lsd_hist, dim3(sort_grid(P.nTiles, nframes)), dim3(64), 0, st, ws, P, nframes); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scan", st); hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter, dim3(sort_grid(P.nTiles, nframes)), dim3(64), 0, st, ws, P, nframes); }
+    bool nfaStreamed = false; size_t nfaStageOff = 0;
     {
         size_t lds = sizeof(unsigned) * (QCAP + 4);      // + the sink slot behind the queue (region_grow_w)
         if (const char* e = getenv("SSLAM_LSD_LDS_PAD")) lds = std::max(lds, (size_t)atoi(e));      // experiment knob: cap resident region workgroups per CU
@@ -336,13 +341,34 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             // per frame: the zeroed head, two result records per seed position, one 256 KB list arena per HELPER THAT EXISTS ((nWG - 1) x CL_HPW: 27 by default;
             // rounds 1-3 sized it for 64).  One slot per frame of the call: blocks with b >= nframes return at once, so the XCD-aligned grid needs no padding slots
             // (a single 640x480 frame held 8 slots of 30 MB before).
-            const size_t clFrame = align_up(zeroBytes + maxSubs * CL_RES * sizeof(ClRec) + 4 * (size_t)CL_ARENA * (size_t)std::max(1, (nWG - 1) * CL_HPW), 4096);
+            // SSLAM_NFA_STREAM=1 (experiment knob, off by default): the NFA stage runs NEXT TO the core on a second stream, on the rectangles the main wave
+            // has published so far (lsd_nfa.h, k_nfa_stream); =n > 1: n consumer waves per frame (default 16)
+            int nfaStreamWaves = 0;
+            if (const char* e = getenv("SSLAM_NFA_STREAM")) { nfaStreamWaves = atoi(e); if (nfaStreamWaves == 1) nfaStreamWaves = 16; nfaStreamWaves = std::max(0, std::min(64, nfaStreamWaves)); }
+            const size_t stageOff = zeroBytes + maxSubs * CL_RES * sizeof(ClRec) + 4 * (size_t)CL_ARENA * (size_t)std::max(1, (nWG - 1) * CL_HPW);      // (k_lsd_regions_cl_stream: cl.candStage)
+            const size_t clFrame = align_up(stageOff + (nfaStreamWaves ? sizeof(double) * 12 * (size_t)MAX_SEG : 0), 4096);
             L->clFrame = clFrame; L->clSlots = nframes;
             const size_t clSlots = (size_t)nframes;
             if (L->dCl.cap < clFrame * clSlots) { SSLAM_HIP(hipStreamSynchronize(st)); if ((rc = L->dCl.ensure(clFrame * clSlots))) return rc; }
             for (int f = 0; f < nframes; ++f) SSLAM_HIP(hipMemsetAsync(L->dCl.as<uint8_t>() + (size_t)f * clFrame, 0, zeroBytes, st));
             const size_t clLds = sizeof(unsigned) * std::max((size_t)QCAP + 4 + (bigFrame ? 0 : TorusFrame::WORDS) + CL_SCAN + CL_RING_WORDS, (size_t)CL_HPW * (CL_LIST + ClTorus::WORDS));      // the main wave's workgroup / a helper workgroup
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
+            if (nfaStreamWaves) {
+                if (!L->nfaStream) {
+                    SSLAM_HIP(hipStreamCreateWithFlags(&L->nfaStream, hipStreamNonBlocking));
+                    SSLAM_HIP(hipEventCreateWithFlags(&L->nfaFork, hipEventDisableTiming));
+                    SSLAM_HIP(hipEventCreateWithFlags(&L->nfaJoin, hipEventDisableTiming));
+                }
+                long long spinTicks = 20000000;      // 0.2 s of the 100 MHz clock: a consumer wave that has seen no progress for that long leaves its blocks to the launch behind the core
+                if (const char* e = getenv("SSLAM_NFA_STREAM_TICKS")) spinTicks = std::max(0ll, atoll(e));
+                SSLAM_HIP(hipEventRecord(L->nfaFork, st));      // (the prologue's planes and the zeroed slot heads are what the consumers need)
+                SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
+                hipLaunchKernelGGL(k_lsd_regions_cl_stream, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
+                SSLAM_HIP(hipStreamWaitEvent(L->nfaStream, L->nfaFork, 0));
+                if ((rc = sslam::launch_nfa_stream(L->ctx, L->nfaStream, ws, &P, sizeof(P), L->dLgam.as<double>(), L->dCl.as<uint8_t>(), clFrame, stageOff, nframes, nfaStreamWaves, spinTicks, nullptr))) return rc;
+                SSLAM_HIP(hipEventRecord(L->nfaJoin, L->nfaStream));
+                nfaStreamed = true; nfaStageOff = stageOff;
+            } else
             hipLaunchKernelGGL(k_lsd_regions_cl, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
         } else if (mw) {
             const size_t mwLds = lds + sizeof(unsigned) * ((size_t)nHelpers * ((size_t)MW_RING + MW_BM_WORDS) + specWords);
@@ -357,6 +383,11 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     }
     if (L->coreDone) SSLAM_HIP(hipEventRecord(L->coreDone, st));
     // the NFA stage: its kernels and launch forms live in lines_nfa.hip, a translation unit of its own (compiled with -mllvm -disable-machine-licm)
+    if (nfaStreamed) {      // what the concurrent consumers left (nothing, unless they gave up waiting): the same kernel behind both, everything published, no waiting
+        SSLAM_HIP(hipStreamWaitEvent(st, L->nfaJoin, 0));
+        const int rc2 = sslam::launch_nfa_stream(L->ctx, st, ws, &P, sizeof(P), L->dLgam.as<double>(), L->dCl.as<uint8_t>(), L->clFrame, nfaStageOff, nframes, 16, 0, "k_nfa_stream");
+        if (rc2) return rc2;
+    } else
     { const int rc = sslam::launch_nfa_stage(L->ctx, st, ws, &P, sizeof(P), L->dLgam.as<double>(), nframes); if (rc) return rc; }
     { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
     // LBD: blur(5, 1) + Sobel fused (SSLAM_LBD_SOBEL=early: in the prologue) -> bands

@@ -53,7 +53,8 @@ constexpr int CL_SPIN_LIMIT = 1 << 18;     // polls before the main wave stops w
 struct ClSub { int state, flag; };         // per sub-chunk, zeroed per launch; state: 0 free, 1 the main wave's, 2 + h helper h's; flag = doneLane (0..16) | nres << 8
 struct alignas(16) ClRec { MwRes m; unsigned pad[3]; };           // 32 bytes; records of sub-chunk sc: rec[sc * CL_RES ..)
 static_assert(sizeof(ClRec) == 32, "result record layout");
-struct ClCtl { int mainPos, finished, cursor, pad; long long stat[8]; };
+struct ClCtl { int mainPos, finished, cursor, pad; long long stat[8]; NfaStreamCtl ns; };      // ns: rectangles handed to a concurrent NFA stage (k_lsd_regions_cl_stream only; zero otherwise)
+static_assert(offsetof(ClCtl, ns) == NFA_STREAM_CTL_OFF && sizeof(ClCtl) <= 512, "control block layout (lsd_plan.h, the slot's zeroed head)");
 // The main wave's workgroup runs ONE more wave, the FEEDER: it walks the seed list a few chunks ahead of the main wave and stages in LDS what
 // the main wave would otherwise fetch from global memory with one dependent round trip after the other -- states and flags of the chunk's
 // sub-chunks, the result records, and for every result of up to CL_STG points its list and the map values of its points (LDS-DMA loads,
@@ -109,7 +110,9 @@ __device__ __forceinline__ bool cl_spec(const ClShared& cl, int x, int y) {
 #define CL_STAT(i, v)
 #endif
 // ------------------------------------------------------------------ the main wave
-template <class G>      // the main wave's private bitmap: TorusFrame (LDS) or TorusGlobal (larger frames)
+// STREAM (k_lsd_regions_cl_stream, SSLAM_NFA_STREAM=1): rectangle records go to the slot's staging array with L1-bypassing stores and a counter is published every
+// NFA_STREAM_BLOCK rectangles -- lsd_nfa.h's k_nfa_stream runs the NFA stage on them while this wave goes on.  Nothing else differs, and this wave never waits for it.
+template <class G, bool STREAM>      // G: the main wave's private bitmap: TorusFrame (LDS) or TorusGlobal (larger frames)
 __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsigned* __restrict__ qLds, unsigned* __restrict__ bmMain, unsigned* __restrict__ scanBuf,
                         double* __restrict__ red, float4* __restrict__ seedStash, const ClShared& cl, ClSlot* __restrict__ ring, ClLocal* __restrict__ loc) {
     const int lane = threadIdx.x & 63;
@@ -405,6 +408,20 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                 unM &= ~__ballot(usedNow);
             }
             if (!emit) continue;
+            if (STREAM) {
+                if (nSeg < MAX_SEG) {
+                    if (lane == 0) {
+                        unsigned long long* o = (unsigned long long*)(cl.arena + (size_t)CL_ARENA * (size_t)max(1, cl.nHelpers)) + (size_t)nSeg * 12;      // the staging array lies behind the list arenas (lines.hip: stageOff)
+                        const double v[12] = {rec.x1, rec.y1, rec.x2, rec.y2, rec.width, rec.x, rec.y, rec.theta, rec.dx, rec.dy, rec.prec, rec.p};
+#pragma unroll
+                        for (int q = 0; q < 12; ++q) __hip_atomic_store(o + q, (unsigned long long)__double_as_longlong(v[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (((nSeg + 1) & (NFA_STREAM_BLOCK - 1)) == 0) {      // a block is complete: records, s_waitcnt vmcnt(0), counter (MAX_SEG is a multiple of the block)
+                        cl_stores_done();
+                        if (lane == 0) g_st(&cl.ctl->ns.candReady, nSeg + 1);
+                    }
+                }
+            } else
             if (nSeg < MAX_SEG && lane == 0) {
                 double* o = candOut + (size_t)nSeg * 12;
                 o[0] = rec.x1; o[1] = rec.y1; o[2] = rec.x2; o[3] = rec.y2; o[4] = rec.width; o[5] = rec.x; o[6] = rec.y;
@@ -414,6 +431,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
         }
     }
     lds_st(&loc->finished, 1);
+    if (STREAM) { cl_stores_done(); if (lane == 0) g_st(&cl.ctl->ns.candFinal, 1 + min(nSeg, MAX_SEG)); }
     if (lane == 0) {
         g_st(&cl.ctl->finished, 1);
         misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
@@ -732,11 +750,60 @@ __global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl(uint8_t* __res
         ClSlot* ring = (ClSlot*)(dynLds + QCAP + 4 + bmWords + CL_SCAN);
         ClLocal* loc = (ClLocal*)(ring + CL_RING);
         if (wave == 0) {
-            if (bigFrame) cl_main<TorusGlobal>(ws, P, b, dynLds, cl.bigBm, dynLds + QCAP + 4, red[0], stashes[0], cl, ring, loc);
-            else cl_main<TorusFrame>(ws, P, b, dynLds, dynLds + QCAP + 4, dynLds + QCAP + 4 + TorusFrame::WORDS, red[0], stashes[0], cl, ring, loc);
+            if (bigFrame) cl_main<TorusGlobal, false>(ws, P, b, dynLds, cl.bigBm, dynLds + QCAP + 4, red[0], stashes[0], cl, ring, loc);
+            else cl_main<TorusFrame, false>(ws, P, b, dynLds, dynLds + QCAP + 4, dynLds + QCAP + 4 + TorusFrame::WORDS, red[0], stashes[0], cl, ring, loc);
         }
         else if (wave == 1 && !nofeed) cl_feeder(ws, P, b, cl, ring, loc);
         return;
     }
     else if (wave < CL_HPW) cl_helper((role - 1) * CL_HPW + wave, ws, P, b, cl, mine, mine + CL_LIST, stashes[wave], red[wave]);
 }
+
+// The same with the rectangles streamed to a concurrent NFA stage (SSLAM_NFA_STREAM=1, an experiment: cl_main<G, true>, lsd_nfa.h: k_nfa_stream).  A copy of the kernel above rather
+// than a shared body: wrapped into a common inline function the default kernel came out with other register assignments, and the default kernel is the measured one.
+__global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl_stream(uint8_t* __restrict__ ws, LsdPlan P, uint8_t* __restrict__ clArea, size_t clFrameBytes, int nframes, int nWG,
+                                                                        int specWords, int specShift, int window) {
+    extern __shared__ __align__(16) unsigned dynLds[];
+    __shared__ double red[CL_WAVES][3 * 64];
+    __shared__ float4 stashes[CL_WAVES][64];
+    // blocks with the same (blockIdx % 8) share an XCD; an XCD hosts frames xcd, xcd + 8, xcd + 16, ... (nWG workgroups each)
+    const int j = blockIdx.x >> 3, b = (blockIdx.x & 7) + 8 * (j / nWG), role = j % nWG, wave = threadIdx.x >> 6;
+    const bool nofeed = (window & (1 << 20)) != 0;      // (experiment knob: no feeder wave)
+    if (window >= 0) window &= (1 << 20) - 1;
+    if (b >= nframes) return;
+    uint8_t* area = clArea + (size_t)b * clFrameBytes;
+    ClShared cl;
+    cl.ctl = (ClCtl*)area;
+    const size_t maxSubs = ((size_t)P.npx + CL_SUB - 1) / CL_SUB;
+    cl.sub = (ClSub*)(area + 512);
+    cl.specMap = (unsigned*)(area + 512 + ((maxSubs * sizeof(ClSub) + 511) & ~(size_t)511));
+    cl.bigBm = cl.specMap + ((specWords + 127) & ~127);      // (zeroed with the shared map when the frame is too large for the LDS bitmap; empty otherwise)
+    cl.rec = (ClRec*)(cl.bigBm + ((P.sw > TorusFrame::XMASK + 1 || P.sh > TorusFrame::YMASK + 1) ? TorusGlobal::WORDS : 0));
+    cl.arena = (unsigned*)(cl.rec + maxSubs * CL_RES);
+    cl.specShift = specShift; cl.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
+    cl.nHelpers = (nWG - 1) * CL_HPW; cl.window = window;
+    unsigned* mine = dynLds + (size_t)wave * (CL_LIST + ClTorus::WORDS);      // (helper workgroups)
+    if (role != 0 && wave < CL_HPW) for (int i = threadIdx.x & 63; i < ClTorus::WORDS; i += 64) mine[CL_LIST + i] = 0u;
+    const bool bigFrame = P.sw > TorusFrame::XMASK + 1 || P.sh > TorusFrame::YMASK + 1;      // the main wave's bitmap lives in global memory (zeroed by the host)
+    const int bmWords = bigFrame ? 0 : TorusFrame::WORDS;
+    if (role == 0) {
+        for (int i = threadIdx.x; i < bmWords; i += blockDim.x) dynLds[QCAP + 4 + i] = 0u;
+        ClSlot* ring = (ClSlot*)(dynLds + QCAP + 4 + bmWords + CL_SCAN);
+        if (threadIdx.x < CL_RING) { ring[threadIdx.x].chunk = -1; ring[threadIdx.x].ready = 0; }
+        if (threadIdx.x == 0) { ClLocal* loc = (ClLocal*)(ring + CL_RING); loc->mainChunk = 0; loc->commitSeq = 0; loc->finished = 0; }
+    }
+    __syncthreads();
+    if (role == 0) {
+        // the main wave's workgroup: main wave + feeder.  No helpers here: their L1 invalidations cost the main wave 4 % (7.21 -> 6.89 ms)
+        ClSlot* ring = (ClSlot*)(dynLds + QCAP + 4 + bmWords + CL_SCAN);
+        ClLocal* loc = (ClLocal*)(ring + CL_RING);
+        if (wave == 0) {
+            if (bigFrame) cl_main<TorusGlobal, true>(ws, P, b, dynLds, cl.bigBm, dynLds + QCAP + 4, red[0], stashes[0], cl, ring, loc);
+            else cl_main<TorusFrame, true>(ws, P, b, dynLds, dynLds + QCAP + 4, dynLds + QCAP + 4 + TorusFrame::WORDS, red[0], stashes[0], cl, ring, loc);
+        }
+        else if (wave == 1 && !nofeed) cl_feeder(ws, P, b, cl, ring, loc);
+        return;
+    }
+    else if (wave < CL_HPW) cl_helper((role - 1) * CL_HPW + wave, ws, P, b, cl, mine, mine + CL_LIST, stashes[wave], red[wave]);
+}
+

@@ -576,21 +576,19 @@ __device__ __forceinline__ void nfa_wave_sync() {
 }
 
 // aligned-point counts of the stage's candidates for the rectangles [part * per, ...) of one frame: the body of one wave
+// (the bodies come as *_range over the rectangles [c0, c1) -- what the streaming form below hands out block by block -- and as *_body over a wave's share of the frame)
 template <bool WG1, int CH>
-__device__ __forceinline__ void nfa_count_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int part, int nparts, int lane, NfaCountLdsT<CH>& L) {
+__device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int c0, int c1, int lane, NfaCountLdsT<CH>& L) {
     CntItem* its = L.its;
 #ifdef SSLAM_NFA_INT
     int (*nestWin)[6][4] = L.nestWin;
 #endif
     unsigned short* act = L.act;
     Misc* misc = (Misc*)(base + P.offMisc);
-    const int nCand = misc->nCand;
     const unsigned* Tb = (const unsigned*)(base + P.offT);
     const double* rects = (const double*)(base + P.offCand);
     NfaState* st = (NfaState*)(base + P.offNfa);
     const int sw = P.sw, sh = P.sh, tW = P.tW;
-    const int per = (nCand + nparts - 1) / nparts;
-    const int c0 = part * per, c1 = min(c0 + per, nCand);
     const bool nested = stage == 0 || stage == 4;
     const bool small = sw < 32768 && sh < 32768;
     const int rpb = nested ? CNT_NEST : 12;                        // rectangles per batch (stages 1-3: five lanes each)
@@ -710,6 +708,14 @@ __device__ __forceinline__ void nfa_count_body(uint8_t* __restrict__ base, const
     }
 }
 
+template <bool WG1, int CH>
+__device__ __forceinline__ void nfa_count_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int part, int nparts, int lane, NfaCountLdsT<CH>& L) {
+    const int nCand = ((const Misc*)(base + P.offMisc))->nCand;
+    const int per = (nCand + nparts - 1) / nparts;
+    const int c0 = part * per, c1 = min(c0 + per, nCand);
+    nfa_count_range<WG1, CH>(base, P, stage, c0, c1, lane, L);
+}
+
 __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
     __shared__ NfaCountLds L;
     const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y;
@@ -737,16 +743,13 @@ __device__ __noinline__ double nfa_log10(double x) { return log10(x); }
 __device__ __forceinline__ double nfa_log10(double x) { return log10(x); }
 #endif
 template <bool WG1, int CH>
-__device__ __forceinline__ void nfa_eval_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, const double* __restrict__ lgam, int part, int nparts, int lane,
-                                               unsigned short* __restrict__ items) {
-    Misc* misc = (Misc*)(base + P.offMisc);
-    const int nCand = misc->nCand;
+__device__ __forceinline__ void nfa_eval_range(uint8_t* __restrict__ base, const LsdPlan& P, int stage, const double* __restrict__ lgam, int c0, int c1, int lane,
+                                                unsigned short* __restrict__ items) {
+    Misc* misc = (Misc*)(base + P.offMisc); (void)misc;
     const double* rects = (const double*)(base + P.offCand);
     NfaState* st = (NfaState*)(base + P.offNfa);
     const PLog* plog = (const PLog*)(lgam + P.npx + 4);
     const double* rcp = lgam + P.npx + 4 + 48;
-    const int per = (nCand + nparts - 1) / nparts;
-    const int c0 = part * per, c1 = min(c0 + per, nCand);
 #ifdef SSLAM_LSD_STATS
     long long useful = 0, executed = 0, evals = 0;
 #endif
@@ -817,6 +820,15 @@ __device__ __forceinline__ void nfa_eval_body(uint8_t* __restrict__ base, const 
 #endif
 }
 
+template <bool WG1, int CH>
+__device__ __forceinline__ void nfa_eval_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, const double* __restrict__ lgam, int part, int nparts, int lane,
+                                               unsigned short* __restrict__ items) {
+    const int nCand = ((const Misc*)(base + P.offMisc))->nCand;
+    const int per = (nCand + nparts - 1) / nparts;
+    const int c0 = part * per, c1 = min(c0 + per, nCand);
+    nfa_eval_range<WG1, CH>(base, P, stage, lgam, c0, c1, lane, items);
+}
+
 __global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPlan P, int stage, const double* __restrict__ lgam) {
     __shared__ unsigned short items[EVAL_CH * 5];
     const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y;
@@ -825,12 +837,10 @@ __global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPl
 
 // rect_improve's acceptance, in candidate order, one lane per rectangle (the candidates of a stage do not depend on which of
 // them is accepted, so they were all evaluated up front).
-__device__ __forceinline__ void nfa_accept_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int tid, int nthreads) {
-    const Misc* misc = (const Misc*)(base + P.offMisc);
-    const int nCand = misc->nCand;
+__device__ __forceinline__ void nfa_accept_range(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int c0, int c1, int tid, int nthreads) {
     double* rects = (double*)(base + P.offCand);
     NfaState* st = (NfaState*)(base + P.offNfa);
-    for (int c = tid; c < nCand; c += nthreads) {
+    for (int c = c0 + tid; c < c1; c += nthreads) {
         if (stage < 0) { const double v0 = st[c].val[0]; st[c].logNfa = v0; st[c].done = v0 > 0.0 ? 1 : 0; continue; }
         const int nc = stage_ncand(st[c], stage);
         if (st[c].done) continue;
@@ -846,18 +856,20 @@ __device__ __forceinline__ void nfa_accept_body(uint8_t* __restrict__ base, cons
     }
 }
 
+__device__ __forceinline__ void nfa_accept_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int tid, int nthreads) {
+    nfa_accept_range(base, P, stage, 0, ((const Misc*)(base + P.offMisc))->nCand, tid, nthreads);
+}
+
 __global__ __launch_bounds__(256) void k_nfa_accept(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
     nfa_accept_body(ws + (size_t)blockIdx.y * P.frameBytes, P, stage, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
-__device__ __forceinline__ void nfa_finish_body(uint8_t* __restrict__ base, const LsdPlan& P, int tid, int nthreads) {
-    const Misc* misc = (const Misc*)(base + P.offMisc);
-    const int nCand = misc->nCand;
+__device__ __forceinline__ void nfa_finish_range(uint8_t* __restrict__ base, const LsdPlan& P, int c0, int c1, int tid, int nthreads) {
     const double* rects = (const double*)(base + P.offCand);
     const NfaState* st = (const NfaState*)(base + P.offNfa);
     float4* seg = (float4*)(base + P.offSeg);
     int* flag = (int*)(base + P.offFlag);
-    for (int c = tid; c < nCand; c += nthreads) {
+    for (int c = c0 + tid; c < c1; c += nthreads) {
         const bool ok = st[c].logNfa > 0.0;
         flag[c] = ok ? 1 : 0;
         if (ok) {
@@ -866,6 +878,10 @@ __device__ __forceinline__ void nfa_finish_body(uint8_t* __restrict__ base, cons
             seg[c] = make_float4((float)((o[0] + 0.5) / SCALE), (float)((o[1] + 0.5) / SCALE), (float)((o[2] + 0.5) / SCALE), (float)((o[3] + 0.5) / SCALE));
         }
     }
+}
+
+__device__ __forceinline__ void nfa_finish_body(uint8_t* __restrict__ base, const LsdPlan& P, int tid, int nthreads) {
+    nfa_finish_range(base, P, 0, ((const Misc*)(base + P.offMisc))->nCand, tid, nthreads);
 }
 
 __global__ __launch_bounds__(256) void k_nfa_finish(uint8_t* __restrict__ ws, LsdPlan P) {
@@ -921,4 +937,72 @@ __global__ __launch_bounds__(MAXT) void k_nfa_all_wg(uint8_t* __restrict__ ws, L
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     NfaLdsT<WG_CH>* L = (NfaLdsT<WG_CH>*)nfaDyn + wave;
     nfa_all_body<false, WG_CH>(ws + (size_t)blockIdx.x * P.frameBytes, P, lgam, wave, nwaves, threadIdx.x & 63, *L);
+}
+
+// ------------------------------------------------------------------ streaming form (SSLAM_NFA_STREAM=1, single frames / small calls in the cluster form; off by default)
+// A single frame's NFA stage is 0.6 ms of launches behind a 5 ms core that produces its rectangles one after the other -- and no rectangle's verdict
+// feeds back into the core (a rejected rectangle's pixels stay USED).  So the stage can run WHILE the core runs: the cluster form's main wave writes its
+// rectangle records into a staging array of the frame's cluster slot with L1-bypassing stores and publishes a counter every NFA_STREAM_BLOCK rectangles
+// (lsd_cluster.h, cl_main<G, true>); waves of this kernel, launched on a second stream next to the core, claim complete blocks (CAS on a block cursor), copy
+// the block's records into the workspace and run the whole chain -- count / evaluate / accept for stages -1 .. 4, then the segment output -- on their block:
+// the chain of a rectangle depends on nothing but the rectangle.  What is left behind the core is the chain of the last block or two.
+//   * The main wave never waits for a consumer, and a consumer waits for nothing but the main wave's progress (bounded: `spinTicks` of the 100 MHz
+//     clock, then it leaves).  The SAME kernel is launched once more behind the core with spinTicks = 0: everything is published by then, its waves take
+//     whatever blocks are unclaimed (none, normally) and return.  So the result does not depend on the consumers having run at all.
+//   * Visibility: records and counters cross compute units and possibly XCDs -> agent-scope (sc1) stores by the main wave, records before
+//     s_waitcnt vmcnt(0) before the counter; agent-scope loads here, counter before records.  The block's working copy in the workspace, the NfaState and the
+//     outputs are private to the claiming wave until the kernel ends.
+//   * Results are those of the launches: same bodies (nfa_*_range), same order per rectangle.
+__device__ __forceinline__ int ns_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ns_ld64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_stream(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam, uint8_t* __restrict__ clArea,
+                                                                          size_t clFrameBytes, size_t stageOff, long long spinTicks) {
+    __shared__ NfaLds L;
+    const int f = blockIdx.y;
+    int lane = threadIdx.x;
+    uint8_t* base = ws + (size_t)f * P.frameBytes;
+    uint8_t* area = clArea + (size_t)f * clFrameBytes;
+    NfaStreamCtl* ns = (NfaStreamCtl*)(area + NFA_STREAM_CTL_OFF);
+    const unsigned long long* staged = (const unsigned long long*)(area + stageOff);
+    unsigned long long* rects = (unsigned long long*)(base + P.offCand);
+    long long t0 = (long long)wall_clock64();                                       // (of the last progress this wave saw)
+    for (;;) {
+        int c0 = -1, c1 = 0;
+        if (lane == 0) {
+            for (;;) {
+                const int fin = ns_ld(&ns->candFinal);                               // (read before candReady: a set flag makes the count final)
+                const int ready = fin ? fin - 1 : ns_ld(&ns->candReady);
+                const int cur = ns_ld(&ns->claim);
+                const int b0 = cur * NFA_STREAM_BLOCK;
+                if (b0 < ready) {                                                    // before `fin`, ready is a multiple of the block: only whole blocks are handed out
+                    if (atomicCAS(&ns->claim, cur, cur + 1) == cur) { c0 = b0; c1 = min(b0 + NFA_STREAM_BLOCK, ready); break; }
+                    continue;
+                }
+                if (fin) break;                                                      // everything is handed out
+                if ((long long)wall_clock64() - t0 >= spinTicks) { atomicAdd(&ns->expired, 1); break; }
+                __builtin_amdgcn_s_sleep(64);
+            }
+        }
+        c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);
+        if (c0 < 0) return;
+        for (int i = lane; i < (c1 - c0) * 12; i += 64) rects[(size_t)c0 * 12 + i] = ns_ld64(staged + (size_t)c0 * 12 + i);
+        __syncthreads();
+#pragma unroll 1
+        for (int it = -1; it <= 4; ++it) {
+#define NFA_OPAQUE() asm volatile("" : "+s"(base), "+s"(lgam), "+v"(lane))       // (as in nfa_all_body: nothing of a body's address arithmetic may be hoisted across the chain)
+            NFA_OPAQUE();
+            if (it != 0) { nfa_count_range<true, EVAL_CH>(base, P, it < 0 ? 0 : it, c0, c1, lane, L.c); __syncthreads(); }
+            NFA_OPAQUE();
+            nfa_eval_range<true, EVAL_CH>(base, P, it, lgam, c0, c1, lane, L.items);
+            __syncthreads();
+            NFA_OPAQUE();
+            nfa_accept_range(base, P, it, c0, c1, lane, 64);
+            __syncthreads();
+#undef NFA_OPAQUE
+        }
+        nfa_finish_range(base, P, c0, c1, lane, 64);
+        __syncthreads();
+        t0 = (long long)wall_clock64();
+    }
 }
