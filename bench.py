@@ -214,6 +214,38 @@ def latency_leg(fe, ctx, frames, with_lines, nframes=120):
     return out
 
 
+def nfa_stream_leg():
+    """Child process of the default run (`bench.py --nfa-stream-leg`, prints one JSON object): the one-frame-at-a-time line extraction of the latency leg's 64 frames
+    with the experiment SSLAM_NFA_STREAM=1 (the NFA stage next to the cluster form of the core: csrc/lsd_nfa.h k_nfa_stream; off by default) beside
+    the default path -- HIP events around sslam_lines_extract, and every frame's keylines / LBD bytes / line functions compared with the default path's."""
+    import numpy as np, torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pkg
+    torch.cuda.set_device(0)
+    fe = pkg.frontend(); ctx = fe.Context(0)
+    frames, _ = synth_frames(640, 480, 64, 0)
+    st = torch.cuda.ExternalStream(ctx.stream)
+    pct = lambda a: {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "max": float(a.max())}
+    res = {"unit": "ms", "frames": 128, "path": "sslam_lines_extract per frame (host image in, host results out), HIP events"}
+    outs = {}
+    for mode in ("default", "nfa_stream"):
+        os.environ.pop("SSLAM_NFA_STREAM", None)
+        if mode == "nfa_stream": os.environ["SSLAM_NFA_STREAM"] = "1"
+        lx = fe.LineExtractor(ctx, 200)
+        for f in frames[:4]: lx(f)
+        t = []; outs[mode] = []
+        for i in range(128):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st); r = lx(frames[i % 64]); e1.record(st); torch.cuda.synchronize()
+            t.append(e0.elapsed_time(e1))
+            if i < 64: outs[mode].append(tuple(np.ascontiguousarray(a).tobytes() for a in r))
+        lx.close()
+        res[mode] = pct(np.array(t))
+    os.environ.pop("SSLAM_NFA_STREAM", None)
+    res["frames_differing_from_default_path"] = int(sum(a != b for a, b in zip(outs["default"], outs["nfa_stream"])))
+    print(json.dumps(res))
+
+
 def pcie_leg(fe, ctx, frames, with_lines, n=18432, chunk=0, prev_frames=None):
     """sslam_frontend_batch: host images in, host records out (extract only: the API of SURVEY §8(b)).  n covers three chunks of the default
     size (6144 frames = every wave slot of the sequential LSD core), so that uploads, kernels and downloads of neighbouring chunks overlap;
@@ -267,8 +299,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the latency and PCIe-inclusive legs")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing (used for rocprofv3 runs)")
     ap.add_argument("--no-pcie", action="store_true", help="latency leg only (no PCIe-inclusive host-batch leg)")
+    ap.add_argument("--nfa-stream-leg", action="store_true", help="(child process of the default run) single-frame line extraction with SSLAM_NFA_STREAM=1 beside the default path")
     ap.add_argument("--no-other-workloads", action="store_true", help="the default run appends a short pass of BASELINE configs[3] (1280x960 / 2000 kp / 400 lines) as other_workloads.c4; this skips it")
     args = ap.parse_args()
+    if args.nfa_stream_leg:
+        nfa_stream_leg()
+        return
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver (already exported on the GPU boxes)
     import numpy as np
@@ -512,6 +548,13 @@ def main():
                                                  "latency": {k: c4.get("latency", {}).get(k) for k in ("orb_extract_hipEvent", "lines_extract_hipEvent", "frames_per_s_one_at_a_time")}}}
             except Exception as e:
                 out["other_workloads"] = {"c4": {"error": str(e)[:300]}}
+            try:      # an experiment that is off by default, in a child process of its own (a fault there cannot touch this line): the NFA stage next to the core, one frame at a time
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--nfa-stream-leg"], capture_output=True, text=True, timeout=240,
+                                   env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+                out["latency_experiment_nfa_stream"] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:
+                out["latency_experiment_nfa_stream"] = {"error": str(e)[:300]}
         print(json.dumps(out))
     if gather is not None:
         gather.wait()

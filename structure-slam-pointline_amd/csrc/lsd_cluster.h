@@ -110,8 +110,8 @@ __device__ __forceinline__ bool cl_spec(const ClShared& cl, int x, int y) {
 #define CL_STAT(i, v)
 #endif
 // ------------------------------------------------------------------ the main wave
-// STREAM (k_lsd_regions_cl_stream, SSLAM_NFA_STREAM=1): rectangle records go to the slot's staging array with L1-bypassing stores and a counter is published every
-// NFA_STREAM_BLOCK rectangles -- lsd_nfa.h's k_nfa_stream runs the NFA stage on them while this wave goes on.  Nothing else differs, and this wave never waits for it.
+// STREAM (k_lsd_regions_cl_stream, SSLAM_NFA_STREAM=1): rectangle records go to the slot's staging array with L1-bypassing stores and a counter of the complete ones is
+// published with every rectangle -- lsd_nfa.h's k_nfa_stream runs the NFA stage on them while this wave goes on.  Nothing else differs, and this wave never waits for it.
 template <class G, bool STREAM>      // G: the main wave's private bitmap: TorusFrame (LDS) or TorusGlobal (larger frames)
 __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsigned* __restrict__ qLds, unsigned* __restrict__ bmMain, unsigned* __restrict__ scanBuf,
                         double* __restrict__ red, float4* __restrict__ seedStash, const ClShared& cl, ClSlot* __restrict__ ring, ClLocal* __restrict__ loc) {
@@ -410,15 +410,15 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             if (!emit) continue;
             if (STREAM) {
                 if (nSeg < MAX_SEG) {
+                    // Publication lags by one record: the stores of record nSeg - 1 were issued a region ago, so the wait in front of the counter costs
+                    // nothing, and every rectangle but the frame's last is handed over as soon as the next one exists (the last one with candFinal).
+                    cl_stores_done();
                     if (lane == 0) {
+                        g_st(&cl.ctl->ns.candReady, nSeg);                 // records [0, nSeg) are complete
                         unsigned long long* o = (unsigned long long*)(cl.arena + (size_t)CL_ARENA * (size_t)max(1, cl.nHelpers)) + (size_t)nSeg * 12;      // the staging array lies behind the list arenas (lines.hip: stageOff)
                         const double v[12] = {rec.x1, rec.y1, rec.x2, rec.y2, rec.width, rec.x, rec.y, rec.theta, rec.dx, rec.dy, rec.prec, rec.p};
 #pragma unroll
                         for (int q = 0; q < 12; ++q) __hip_atomic_store(o + q, (unsigned long long)__double_as_longlong(v[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (((nSeg + 1) & (NFA_STREAM_BLOCK - 1)) == 0) {      // a block is complete: records, s_waitcnt vmcnt(0), counter (MAX_SEG is a multiple of the block)
-                        cl_stores_done();
-                        if (lane == 0) g_st(&cl.ctl->ns.candReady, nSeg + 1);
                     }
                 }
             } else

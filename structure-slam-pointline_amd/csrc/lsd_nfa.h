@@ -942,10 +942,10 @@ __global__ __launch_bounds__(MAXT) void k_nfa_all_wg(uint8_t* __restrict__ ws, L
 // ------------------------------------------------------------------ streaming form (SSLAM_NFA_STREAM=1, single frames / small calls in the cluster form; off by default)
 // A single frame's NFA stage is 0.6 ms of launches behind a 5 ms core that produces its rectangles one after the other -- and no rectangle's verdict
 // feeds back into the core (a rejected rectangle's pixels stay USED).  So the stage can run WHILE the core runs: the cluster form's main wave writes its
-// rectangle records into a staging array of the frame's cluster slot with L1-bypassing stores and publishes a counter every NFA_STREAM_BLOCK rectangles
-// (lsd_cluster.h, cl_main<G, true>); waves of this kernel, launched on a second stream next to the core, claim complete blocks (CAS on a block cursor), copy
-// the block's records into the workspace and run the whole chain -- count / evaluate / accept for stages -1 .. 4, then the segment output -- on their block:
-// the chain of a rectangle depends on nothing but the rectangle.  What is left behind the core is the chain of the last block or two.
+// rectangle records into a staging array of the frame's cluster slot with L1-bypassing stores and publishes the number of complete records with every rectangle
+// (lsd_cluster.h, cl_main<G, true>); waves of this kernel, launched on a second stream next to the core, claim 1 .. NFA_STREAM_BLOCK published rectangles (CAS on a
+// cursor), copy their records into the workspace and run the whole chain -- count / evaluate / accept for stages -1 .. 4, then the segment output -- on them:
+// the chain of a rectangle depends on nothing but the rectangle.  What is left behind the core is the chain of the last rectangle.
 //   * The main wave never waits for a consumer, and a consumer waits for nothing but the main wave's progress (bounded: `spinTicks` of the 100 MHz
 //     clock, then it leaves).  The SAME kernel is launched once more behind the core with spinTicks = 0: everything is published by then, its waves take
 //     whatever blocks are unclaimed (none, normally) and return.  So the result does not depend on the consumers having run at all.
@@ -957,7 +957,7 @@ __device__ __forceinline__ int ns_ld(const int* p) { return __hip_atomic_load(p,
 __device__ __forceinline__ unsigned long long ns_ld64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_stream(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam, uint8_t* __restrict__ clArea,
-                                                                          size_t clFrameBytes, size_t stageOff, long long spinTicks) {
+                                                                          size_t clFrameBytes, size_t stageOff, long long spinTicks, int takeMax) {
     __shared__ NfaLds L;
     const int f = blockIdx.y;
     int lane = threadIdx.x;
@@ -974,9 +974,11 @@ __global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_stream(uint8
                 const int fin = ns_ld(&ns->candFinal);                               // (read before candReady: a set flag makes the count final)
                 const int ready = fin ? fin - 1 : ns_ld(&ns->candReady);
                 const int cur = ns_ld(&ns->claim);
-                const int b0 = cur * NFA_STREAM_BLOCK;
-                if (b0 < ready) {                                                    // before `fin`, ready is a multiple of the block: only whole blocks are handed out
-                    if (atomicCAS(&ns->claim, cur, cur + 1) == cur) { c0 = b0; c1 = min(b0 + NFA_STREAM_BLOCK, ready); break; }
+                if (cur < ready) {
+                    // A quarter of what is waiting, 1 .. takeMax rectangles: while the core runs they arrive one at a time and each goes to a wave of its own at once (a
+                    // rectangle's chain is ~50 us of dependent steps; what is behind the core in the end is the chain of its last rectangle), a backlog goes out in larger pieces.
+                    const int take = min(takeMax, max(1, (ready - cur) >> 2));
+                    if (atomicCAS(&ns->claim, cur, cur + take) == cur) { c0 = cur; c1 = cur + take; break; }
                     continue;
                 }
                 if (fin) break;                                                      // everything is handed out

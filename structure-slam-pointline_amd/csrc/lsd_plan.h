@@ -64,12 +64,12 @@ struct Misc {                 // per-frame scalars
 // Streaming hand-over of candidate rectangles from the cluster form's main wave to the NFA stage (SSLAM_NFA_STREAM=1; lsd_cluster.h writes, lsd_nfa.h's
 // k_nfa_stream reads -- two translation units, hence here).  Lives in the zeroed head of a frame's cluster slot, behind ClCtl's counters.
 struct NfaStreamCtl {
-    int candReady;            // rectangles published so far, a multiple of NFA_STREAM_BLOCK (their records are complete in the slot's staging array)
+    int candReady;            // rectangles published so far (their records are complete in the slot's staging array)
     int candFinal;            // 0 while the main wave runs, then 1 + the frame's number of rectangles (everything is published)
-    int claim;                // blocks of NFA_STREAM_BLOCK rectangles handed out to consumer waves (CAS)
+    int claim;                // rectangles handed out to consumer waves so far (CAS; a claim takes 1 .. NFA_STREAM_BLOCK of them)
     int expired;              // consumer waves that stopped waiting (the launch behind the core takes what they left)
 };
-constexpr int NFA_STREAM_BLOCK = 8;        // rectangles per block: one wave evaluates 8 x 5 candidates in one pass of its 64 lanes
+constexpr int NFA_STREAM_BLOCK = 8;        // rectangles per claim at most: one wave evaluates 8 x 5 candidates in one pass of its 64 lanes
 constexpr int NFA_STREAM_CTL_OFF = 80;     // byte offset of NfaStreamCtl in the slot (lsd_cluster.h asserts it against ClCtl)
 
 // element index of pixel (x, y) in the T / Cs planes

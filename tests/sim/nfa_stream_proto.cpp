@@ -1,10 +1,10 @@
 // The hand-over of candidate rectangles from the cluster form's main wave to a concurrent NFA stage (csrc/lsd_cluster.h cl_main<G, true> ->
-// csrc/lsd_nfa.h k_nfa_stream; SSLAM_NFA_STREAM=1) as a CPU model with real threads: one producer writes records and publishes a counter every
-// BLOCK records and a final count; consumer threads claim whole blocks by CAS, copy and "evaluate" them, and may give up waiting; a second pass
+// csrc/lsd_nfa.h k_nfa_stream; SSLAM_NFA_STREAM=1) as a CPU model with real threads: one producer writes records, publishes the number of complete
+// records with every record (lagging by one) and a final count; consumer threads claim 1 .. BLOCK published records by CAS, copy and "evaluate" them, and may give up waiting; a second pass
 // behind the producer (the launch behind the core) takes what is unclaimed.  Checked per run: every record processed exactly once, by a thread
 // that saw its final contents, nothing beyond the final count touched.  Relaxed atomics + a release/acquire pair on the counters stand for the
 // kernel's sc1 accesses and its "records, s_waitcnt vmcnt(0), counter" order.
-// usage: nfa_stream_proto <runs> <max records> <consumers> <expire 0|1> [break]     (break = 1: publish the counter BEFORE the records -> must fail)
+// usage: nfa_stream_proto <runs> <max records> <consumers> <expire 0|1> [break]     (break = 1: the counter includes the record that is being written -> must fail)
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -29,10 +29,10 @@ static void consume(Ctl& c, unsigned long long salt, bool mayWait, int patience,
             const int fin = c.candFinal.load(std::memory_order_acquire);
             const int ready = fin ? fin - 1 : c.candReady.load(std::memory_order_acquire);
             const int cur = c.claim.load(std::memory_order_relaxed);
-            const int b0 = cur * BLOCK;
-            if (b0 < ready) {
+            if (cur < ready) {
+                const int take = std::min(BLOCK, std::max(1, (ready - cur) >> 2));
                 int expect = cur;
-                if (c.claim.compare_exchange_strong(expect, cur + 1)) { c0 = b0; c1 = std::min(b0 + BLOCK, ready); break; }
+                if (c.claim.compare_exchange_strong(expect, cur + take)) { c0 = cur; c1 = cur + take; break; }
                 continue;
             }
             if (fin) break;
@@ -64,10 +64,9 @@ int main(int argc, char** argv) {
         {   // the main wave
             std::minstd_rand rng(top());
             for (int i = 0; i < n; ++i) {
-                if (broken && ((i + 1) % BLOCK) == 0) c.candReady.store(i + 1, std::memory_order_release);
+                c.candReady.store(broken ? i + 1 : i, std::memory_order_release);      // the kernel publishes with a lag of one record: [0, i) are complete when record i is written
                 if (rng() % 8 == 0) std::this_thread::yield();
                 staged[i].store((unsigned long long)i ^ salt, std::memory_order_relaxed);
-                if (!broken && ((i + 1) % BLOCK) == 0) c.candReady.store(i + 1, std::memory_order_release);
                 if (rng() % 16 == 0) std::this_thread::sleep_for(std::chrono::microseconds(rng() % 30));
             }
             c.candFinal.store(1 + n, std::memory_order_release);
@@ -80,11 +79,11 @@ int main(int argc, char** argv) {
             for (auto& t : t2) t.join();
         }
         tailBlocks += c.claim.load() - claimedBefore; expiredTotal += c.expired.load();
-        bool ok = badValue.load() == 0 && c.claim.load() == (n + BLOCK - 1) / BLOCK;
+        bool ok = badValue.load() == 0 && c.claim.load() == n;
         for (int i = 0; i < n + 64 && ok; ++i) ok = processed[i].load() == (i < n ? 1 : 0);
         if (!ok) ++bad;
     }
-    printf("expired waits %lld, blocks left to the second pass %lld\n", expiredTotal, tailBlocks);
+    printf("expired waits %lld, records left to the second pass %lld\n", expiredTotal, tailBlocks);
     printf("bad runs: %d of %d\n", bad, runs);
     return 0;
 }
