@@ -21,7 +21,7 @@
 #include <algorithm>
 
 namespace sslam { int launch_nfa_stream(sslam_ctx* ctx, hipStream_t st, uint8_t* ws, const void* plan, size_t planBytes, const double* lgam, uint8_t* clArea, size_t clFrameBytes,
-                                        size_t stageOff, int nframes, int waves, long long spinTicks, size_t ldsPad, int takeMax, const char* scope); }      // lines_nfa.hip
+                                        size_t stageOff, int nframes, int waves, long long spinTicks, size_t ldsPad, int takeMax, int sleepReps, const char* scope); }      // lines_nfa.hip
 namespace sslam { int launch_nfa_stage(sslam_ctx* ctx, hipStream_t st, uint8_t* ws, const void* plan, size_t planBytes, const double* lgam, int nframes); }      // lines_nfa.hip
 
 using namespace sslam;
@@ -364,12 +364,14 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
                 size_t nfaLdsPad = 40 * 1024;        // (lines_nfa.hip: keeps the consumers off the main wave's and the helpers' compute units)
                 int nfaTakeMax = NFA_STREAM_BLOCK;   // rectangles per claim at most (lsd_nfa.h)
                 if (const char* e = getenv("SSLAM_NFA_STREAM_TAKE")) nfaTakeMax = atoi(e);
+                int nfaSleep = 1;                     // s_sleep(127) between two polls of a waiting consumer (lsd_nfa.h)
+                if (const char* e = getenv("SSLAM_NFA_STREAM_SLEEP")) nfaSleep = std::max(0, std::min(64, atoi(e)));
                 if (const char* e = getenv("SSLAM_NFA_STREAM_LDS")) nfaLdsPad = (size_t)std::max(0, std::min(48 * 1024, atoi(e)));
                 SSLAM_HIP(hipEventRecord(L->nfaFork, st));      // (the prologue's planes and the zeroed slot heads are what the consumers need)
                 SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
                 hipLaunchKernelGGL(k_lsd_regions_cl_stream, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
                 SSLAM_HIP(hipStreamWaitEvent(L->nfaStream, L->nfaFork, 0));
-                if ((rc = sslam::launch_nfa_stream(L->ctx, L->nfaStream, ws, &P, sizeof(P), L->dLgam.as<double>(), L->dCl.as<uint8_t>(), clFrame, stageOff, nframes, nfaStreamWaves, spinTicks, nfaLdsPad, nfaTakeMax, nullptr))) return rc;
+                if ((rc = sslam::launch_nfa_stream(L->ctx, L->nfaStream, ws, &P, sizeof(P), L->dLgam.as<double>(), L->dCl.as<uint8_t>(), clFrame, stageOff, nframes, nfaStreamWaves, spinTicks, nfaLdsPad, nfaTakeMax, nfaSleep, nullptr))) return rc;
                 SSLAM_HIP(hipEventRecord(L->nfaJoin, L->nfaStream));
                 nfaStreamed = true; nfaStageOff = stageOff;
             } else
@@ -389,7 +391,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     // the NFA stage: its kernels and launch forms live in lines_nfa.hip, a translation unit of its own (compiled with -mllvm -disable-machine-licm)
     if (nfaStreamed) {      // what the concurrent consumers left (nothing, unless they gave up waiting): the same kernel behind both, everything published, no waiting
         SSLAM_HIP(hipStreamWaitEvent(st, L->nfaJoin, 0));
-        const int rc2 = sslam::launch_nfa_stream(L->ctx, st, ws, &P, sizeof(P), L->dLgam.as<double>(), L->dCl.as<uint8_t>(), L->clFrame, nfaStageOff, nframes, 16, 0, 0, NFA_STREAM_BLOCK, "k_nfa_stream");
+        const int rc2 = sslam::launch_nfa_stream(L->ctx, st, ws, &P, sizeof(P), L->dLgam.as<double>(), L->dCl.as<uint8_t>(), L->clFrame, nfaStageOff, nframes, 16, 0, 0, NFA_STREAM_BLOCK, 1, "k_nfa_stream");
         if (rc2) return rc2;
     } else
     { const int rc = sslam::launch_nfa_stage(L->ctx, st, ws, &P, sizeof(P), L->dLgam.as<double>(), nframes); if (rc) return rc; }

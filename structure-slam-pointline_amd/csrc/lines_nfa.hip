@@ -77,13 +77,13 @@ int launch_nfa_stage(sslam_ctx* ctx, hipStream_t st, uint8_t* ws, const void* pl
 // ldsPad: dynamic LDS the kernel does not use -- next to the core it keeps the consumers off the compute units of the main wave and of the helpers (their workgroups hold
 // > 120 KB of the 160; a consumer that asks for 40 KB does not fit beside them: a wave sharing the main wave's SIMD would slow the one chain the frame waits for).
 int launch_nfa_stream(sslam_ctx* ctx, hipStream_t st, uint8_t* ws, const void* plan, size_t planBytes, const double* lgam, uint8_t* clArea, size_t clFrameBytes,
-                      size_t stageOff, int nframes, int waves, long long spinTicks, size_t ldsPad, int takeMax, const char* scope) {
+                      size_t stageOff, int nframes, int waves, long long spinTicks, size_t ldsPad, int takeMax, int sleepReps, const char* scope) {
     if (planBytes != sizeof(LsdPlan)) { set_error("launch_nfa_stream: plan layout mismatch between translation units"); return SSLAM_ERR_INVALID; }
     takeMax = std::max(1, std::min(NFA_STREAM_BLOCK, takeMax));
     if (waves < 1 || nframes < 1 || (stageOff & 7)) { set_error("launch_nfa_stream: invalid arguments"); return SSLAM_ERR_INVALID; }
     LsdPlan P; memcpy(&P, plan, sizeof(P));
-    if (scope) { sslam::ProfScope _ps(ctx, scope, st); hipLaunchKernelGGL(k_nfa_stream, dim3(waves, nframes), dim3(64), ldsPad, st, ws, P, lgam, clArea, clFrameBytes, stageOff, spinTicks, takeMax); }
-    else hipLaunchKernelGGL(k_nfa_stream, dim3(waves, nframes), dim3(64), ldsPad, st, ws, P, lgam, clArea, clFrameBytes, stageOff, spinTicks, takeMax);
+    if (scope) { sslam::ProfScope _ps(ctx, scope, st); hipLaunchKernelGGL(k_nfa_stream, dim3(waves, nframes), dim3(64), ldsPad, st, ws, P, lgam, clArea, clFrameBytes, stageOff, spinTicks, takeMax, sleepReps); }
+    else hipLaunchKernelGGL(k_nfa_stream, dim3(waves, nframes), dim3(64), ldsPad, st, ws, P, lgam, clArea, clFrameBytes, stageOff, spinTicks, takeMax, sleepReps);
     SSLAM_HIP(hipGetLastError());
     return SSLAM_OK;
 }

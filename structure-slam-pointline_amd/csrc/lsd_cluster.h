@@ -53,8 +53,9 @@ constexpr int CL_SPIN_LIMIT = 1 << 18;     // polls before the main wave stops w
 struct ClSub { int state, flag; };         // per sub-chunk, zeroed per launch; state: 0 free, 1 the main wave's, 2 + h helper h's; flag = doneLane (0..16) | nres << 8
 struct alignas(16) ClRec { MwRes m; unsigned pad[3]; };           // 32 bytes; records of sub-chunk sc: rec[sc * CL_RES ..)
 static_assert(sizeof(ClRec) == 32, "result record layout");
-struct ClCtl { int mainPos, finished, cursor, pad; long long stat[8]; NfaStreamCtl ns; };      // ns: rectangles handed to a concurrent NFA stage (k_lsd_regions_cl_stream only; zero otherwise)
-static_assert(offsetof(ClCtl, ns) == NFA_STREAM_CTL_OFF && sizeof(ClCtl) <= 512, "control block layout (lsd_plan.h, the slot's zeroed head)");
+struct ClCtl { int mainPos, finished, cursor, pad; long long stat[8]; };
+static_assert(sizeof(ClCtl) <= NFA_STREAM_CTL_OFF && NFA_STREAM_CTL_OFF + sizeof(NfaStreamCtl) <= 512, "control block layout (lsd_plan.h: the streaming hand-over has a line of its own in the slot's zeroed head)");
+__device__ __forceinline__ NfaStreamCtl* cl_ns(ClCtl* ctl) { return (NfaStreamCtl*)((uint8_t*)ctl + NFA_STREAM_CTL_OFF); }      // (k_lsd_regions_cl_stream only; zero otherwise)
 // The main wave's workgroup runs ONE more wave, the FEEDER: it walks the seed list a few chunks ahead of the main wave and stages in LDS what
 // the main wave would otherwise fetch from global memory with one dependent round trip after the other -- states and flags of the chunk's
 // sub-chunks, the result records, and for every result of up to CL_STG points its list and the map values of its points (LDS-DMA loads,
@@ -414,7 +415,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                     // nothing, and every rectangle but the frame's last is handed over as soon as the next one exists (the last one with candFinal).
                     cl_stores_done();
                     if (lane == 0) {
-                        g_st(&cl.ctl->ns.candReady, nSeg);                 // records [0, nSeg) are complete
+                        g_st(&cl_ns(cl.ctl)->candReady, nSeg);                 // records [0, nSeg) are complete
                         unsigned long long* o = (unsigned long long*)(cl.arena + (size_t)CL_ARENA * (size_t)max(1, cl.nHelpers)) + (size_t)nSeg * 12;      // the staging array lies behind the list arenas (lines.hip: stageOff)
                         const double v[12] = {rec.x1, rec.y1, rec.x2, rec.y2, rec.width, rec.x, rec.y, rec.theta, rec.dx, rec.dy, rec.prec, rec.p};
 #pragma unroll
@@ -431,7 +432,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
         }
     }
     lds_st(&loc->finished, 1);
-    if (STREAM) { cl_stores_done(); if (lane == 0) g_st(&cl.ctl->ns.candFinal, 1 + min(nSeg, MAX_SEG)); }
+    if (STREAM) { cl_stores_done(); if (lane == 0) g_st(&cl_ns(cl.ctl)->candFinal, 1 + min(nSeg, MAX_SEG)); }
     if (lane == 0) {
         g_st(&cl.ctl->finished, 1);
         misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;

@@ -957,7 +957,7 @@ __device__ __forceinline__ int ns_ld(const int* p) { return __hip_atomic_load(p,
 __device__ __forceinline__ unsigned long long ns_ld64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_stream(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam, uint8_t* __restrict__ clArea,
-                                                                          size_t clFrameBytes, size_t stageOff, long long spinTicks, int takeMax) {
+                                                                          size_t clFrameBytes, size_t stageOff, long long spinTicks, int takeMax, int sleepReps) {
     __shared__ NfaLds L;
     const int f = blockIdx.y;
     int lane = threadIdx.x;
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_stream(uint8
                 }
                 if (fin) break;                                                      // everything is handed out
                 if ((long long)wall_clock64() - t0 >= spinTicks) { atomicAdd(&ns->expired, 1); break; }
-                __builtin_amdgcn_s_sleep(64);
+                for (int q = 0; q < sleepReps; ++q) __builtin_amdgcn_s_sleep(127);      // ~3.4 us each: every poll is three loads that go past the caches
             }
         }
         c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);

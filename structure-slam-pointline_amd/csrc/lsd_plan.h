@@ -62,7 +62,7 @@ struct Misc {                 // per-frame scalars
 };
 
 // Streaming hand-over of candidate rectangles from the cluster form's main wave to the NFA stage (SSLAM_NFA_STREAM=1; lsd_cluster.h writes, lsd_nfa.h's
-// k_nfa_stream reads -- two translation units, hence here).  Lives in the zeroed head of a frame's cluster slot, behind ClCtl's counters.
+// k_nfa_stream reads -- two translation units, hence here).  Lives in the zeroed head of a frame's cluster slot, in a cache line of its own.
 struct NfaStreamCtl {
     int candReady;            // rectangles published so far (their records are complete in the slot's staging array)
     int candFinal;            // 0 while the main wave runs, then 1 + the frame's number of rectangles (everything is published)
@@ -70,7 +70,7 @@ struct NfaStreamCtl {
     int expired;              // consumer waves that stopped waiting (the launch behind the core takes what they left)
 };
 constexpr int NFA_STREAM_BLOCK = 8;        // rectangles per claim at most: one wave evaluates 8 x 5 candidates in one pass of its 64 lanes
-constexpr int NFA_STREAM_CTL_OFF = 80;     // byte offset of NfaStreamCtl in the slot (lsd_cluster.h asserts it against ClCtl)
+constexpr int NFA_STREAM_CTL_OFF = 256;    // byte offset of NfaStreamCtl in the slot's zeroed head (512 bytes): a 128-byte line of its own -- the consumers poll it, and the line of ClCtl's cursors is where the helpers claim
 
 // element index of pixel (x, y) in the T / Cs planes
 __device__ __forceinline__ int tix(int x, int y, int tW) { return y * tW + x; }

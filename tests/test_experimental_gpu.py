@@ -1,5 +1,5 @@
 """Experiments that are in the tree behind knobs (off by default) and have not run through the GPU suite yet (SSLAM_NFA_STREAM: only sslam_lines_extract on 640x480
-frames has, profiles/r04_nfa_stream_single_frame.txt): they stay out of the driver's `pytest -m gpu` run until they have.
+frames has, profiles/r04_nfa_stream_c_abi_runs.txt): they stay out of the driver's `pytest -m gpu` run until they have.
     SSLAM_TEST_EXPERIMENTAL=1 python -m pytest tests/test_experimental_gpu.py -m gpu -q        (under a `timeout`: the first item spins on device-side flags)"""
 import os, sys
 import numpy as np

@@ -3,7 +3,7 @@
 #     gpurun --timeout 1500 -- 'bash tools/gpu_r05_first.sh'
 # 1. the default path once (the refactor of the NFA bodies into *_range forms moved a handful of instructions in k_nfa_count / k_nfa_all; k_lsd_regions_cl is
 #    byte-identical to the round-4 build) -- the single-frame and line suites, then the latency leg as the baseline of this box;
-# 2. SSLAM_NFA_STREAM=1 (the NFA stage next to the cluster form of the core; 640x480 single frames measured in round 4: profiles/r04_nfa_stream_single_frame.txt): the experimental tests (spin on device flags -> tight timeout),
+# 2. SSLAM_NFA_STREAM=1 (the NFA stage next to the cluster form of the core; 640x480 single frames measured in round 4: profiles/r04_nfa_stream_c_abi_runs.txt): the experimental tests (spin on device flags -> tight timeout),
 #    then the latency leg with 16 / 8 / 32 consumer waves, with --check (24 frames against the oracle).
 # Outputs: gpurun_out/r05a/.
 set -x

@@ -10,19 +10,23 @@
 #include <time.h>
 #include "sslam_frontend.h"
 
-enum { W = 640, H = 480, CAP = 256, NF = 64 };
+enum { CAP = 512, MAXNF = 64 };
+static int W = 640, H = 480, NF = 64, MAXL = 200;      /* LAT_W / LAT_H / LAT_NF / LAT_LINES + LAT_FRAMES / LAT_EXPECTED: another frame set (tools/lat_check_prepare.py <w> <h> <n> <lines>) */
 typedef struct { int n; sslam_keyline kl[CAP]; unsigned char d[CAP * 32]; double fn[CAP * 3]; } Out;
 static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 static int cmp_d(const void* a, const void* b) { const double x = *(const double*)a, y = *(const double*)b; return x < y ? -1 : x > y; }
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 2;
-    static unsigned char img[NF][W * H];
-    static Out want[NF], got;
-    FILE* f = fopen("tools/lat_frames.raw", "rb");
-    if (!f || fread(img, 1, sizeof(img), f) != sizeof(img)) { fprintf(stderr, "tools/lat_frames.raw missing (tools/lat_check_prepare.py)\n"); return 2; }
+    if (getenv("LAT_W")) W = atoi(getenv("LAT_W")); if (getenv("LAT_H")) H = atoi(getenv("LAT_H")); if (getenv("LAT_NF")) NF = atoi(getenv("LAT_NF")); if (getenv("LAT_LINES")) MAXL = atoi(getenv("LAT_LINES"));
+    if (NF < 8 || NF > MAXNF || MAXL > CAP) return 2;
+    const size_t fsz = (size_t)W * H;
+    unsigned char* imgs = malloc(fsz * NF);
+    static Out want[MAXNF], got;
+    FILE* f = fopen(getenv("LAT_FRAMES") ? getenv("LAT_FRAMES") : "tools/lat_frames.raw", "rb");
+    if (!f || fread(imgs, 1, fsz * NF, f) != fsz * NF) { fprintf(stderr, "tools/lat_frames.raw missing (tools/lat_check_prepare.py)\n"); return 2; }
     fclose(f);
-    f = fopen("tools/lat_expected.bin", "rb");
+    f = fopen(getenv("LAT_EXPECTED") ? getenv("LAT_EXPECTED") : "tools/lat_expected.bin", "rb");
     if (!f) { fprintf(stderr, "tools/lat_expected.bin missing\n"); return 2; }
     for (int i = 0; i < NF; ++i) {
         int n = 0;
@@ -32,19 +36,19 @@ int main(int argc, char** argv) {
     }
     fclose(f);
     sslam_ctx* ctx = NULL; sslam_lines* L = NULL;
-    if (sslam_ctx_create(0, &ctx) || sslam_lines_create(ctx, 200, &L)) { fprintf(stderr, "create: %s\n", sslam_last_error()); return 2; }
+    if (sslam_ctx_create(0, &ctx) || sslam_lines_create(ctx, MAXL, &L)) { fprintf(stderr, "create: %s\n", sslam_last_error()); return 2; }
     int bad_total = 0;
     for (int a = 2; a < argc || a == 2; ++a) {
         char buf[512]; const char* names[16]; int nn = 0;
         snprintf(buf, sizeof(buf), "%s", a < argc ? argv[a] : "");
         for (char* tok = strtok(buf, ","); tok && nn < 16; tok = strtok(NULL, ",")) { char* eq = strchr(tok, '='); if (!eq) continue; *eq = 0; setenv(tok, eq + 1, 1); names[nn++] = tok; }
         int bad = 0, angle_only = 0;
-        for (int i = 0; i < 8; ++i) sslam_lines_extract(L, img[i], W, H, W, got.kl, got.d, got.fn, CAP, &got.n);      /* warm-up (first call plans the workspace) */
-        static double t[NF * 16];
+        for (int i = 0; i < 8; ++i) sslam_lines_extract(L, imgs + fsz * i, W, H, W, got.kl, got.d, got.fn, CAP, &got.n);      /* warm-up (first call plans the workspace) */
+        static double t[MAXNF * 16];
         int nt = 0;
         for (int r = 0; r < reps && r < 16; ++r) for (int i = 0; i < NF; ++i) {
             const double t0 = now_ms();
-            const int rc = sslam_lines_extract(L, img[i], W, H, W, got.kl, got.d, got.fn, CAP, &got.n);
+            const int rc = sslam_lines_extract(L, imgs + fsz * i, W, H, W, got.kl, got.d, got.fn, CAP, &got.n);
             t[nt++] = now_ms() - t0;
             if (rc) { fprintf(stderr, "extract: %d %s\n", rc, sslam_last_error()); return 2; }
             int ok = got.n == want[i].n && !memcmp(got.d, want[i].d, 32 * got.n) && !memcmp(got.fn, want[i].fn, 24 * got.n);
@@ -60,6 +64,17 @@ int main(int argc, char** argv) {
         printf("%-58s p50 %.3f  p90 %.3f  mean %.3f ms   vs oracle: %d of %d differ (%d in KeyLine.angle bits only)\n", a < argc && argv[a][0] ? argv[a] : "(default)", t[nt / 2], t[(nt * 9) / 10], sum / nt, bad, nt, angle_only);
         fflush(stdout);
         bad_total += bad;
+        if (getenv("LAT_PROFILE")) {      /* per launch scope: HIP events around each launch on the context's stream (sslam_profile_*), one more pass over the frames */
+            sslam_profile_enable(ctx, 1);
+            for (int i = 0; i < NF; ++i) sslam_lines_extract(L, imgs + fsz * i, W, H, W, got.kl, got.d, got.fn, CAP, &got.n);
+            const char* nm[64]; double ms[64]; int ln[64];
+            const int nk = sslam_profile_drain(ctx, nm, ms, ln, 64);
+            sslam_profile_enable(ctx, 0);
+            double tot = 0; for (int k = 0; k < nk && k < 64; ++k) tot += ms[k];
+            printf("    launch scopes, us per frame (sum %.0f):", tot * 1e3 / NF);
+            for (int k = 0; k < nk && k < 64; ++k) printf(" %s %.0f (%d)", nm[k], ms[k] * 1e3 / NF, ln[k] / NF);
+            printf("\n"); fflush(stdout);
+        }
         for (int k = 0; k < nn; ++k) unsetenv(names[k]);
         if (a >= argc) break;
     }
