@@ -77,3 +77,36 @@ def test_resize_blur_atan2_agree_with_float_references_to_within_a_grey_level(or
     a = np.array([oracle.L.orc_fast_atan2(C.c_float(float(y)), C.c_float(float(x))) for y, x in zip(ys, xs)])
     d = np.abs(a - np.degrees(np.arctan2(ys.astype(np.float64), xs.astype(np.float64))) % 360); d = np.minimum(d, 360 - d)
     assert d.max() < 0.01 and a.min() >= 0 and a.max() < 360
+
+
+def _ring(img):
+    """the 16 pixels of the radius-3 Bresenham circle around every interior pixel, in order"""
+    off = [(0, -3), (1, -3), (2, -2), (3, -1), (3, 0), (3, 1), (2, 2), (1, 3), (0, 3), (-1, 3), (-2, 2), (-3, 1), (-3, 0), (-3, -1), (-2, -2), (-1, -3)]
+    h, w = img.shape
+    c = img[3:h - 3, 3:w - 3].astype(np.int32)
+    return c, [img[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx].astype(np.int32) for dx, dy in off]
+
+
+@pytest.mark.parametrize("threshold", [20, 7])
+def test_fast_score_is_the_largest_threshold_that_keeps_the_corner(oracle, threshold):
+    """cv::FAST's response (cornerScore<16>) by its DEFINITION, not by its formula: the largest t for which the pixel still passes the segment test
+    (9 contiguous ring pixels all > p + t or all < p - t), found by trying every t.  The oracle computes it the way OpenCV does (maxima of arc minima)."""
+    for img in (synth_frame(1234)[100:340, 200:520].copy(), noise_frame(7)[:120, :160].copy()):
+        score_map, _ = oracle.fast_image(img, threshold)
+        c, ring = _ring(img)
+        best = np.full(c.shape, -1, np.int32)
+        for t in range(threshold, 256):
+            br = [r > c + t for r in ring]; dk = [r < c - t for r in ring]
+            ok = np.zeros(c.shape, bool)
+            for s in range(16):
+                b = br[s]; d = dk[s]
+                for k in range(1, 9):
+                    b = b & br[(s + k) & 15]; d = d & dk[(s + k) & 15]
+                ok |= b | d
+            if not ok.any():
+                break
+            best[ok] = t
+        want = np.where(best >= threshold, best, 0)
+        got = score_map[3:-3, 3:-3].astype(np.int32)
+        assert (want > 0).sum() > 300
+        assert np.array_equal(got, want), "%d pixels differ" % int((got != want).sum())

@@ -1,22 +1,28 @@
 #!/bin/bash
-# Round 5, first GPU call: the experiment that round 4 left in the tree behind a knob with only its single-frame path run on hardware, each step under its own timeout:
+# Round 5, first GPU call: decide whether SSLAM_NFA_STREAM (the NFA stage next to the cluster form of the core) becomes the default for calls of <= 64 frames.
+#     python tools/lat_check_prepare.py && python tools/mix_check_prepare.py      (CPU, once: inputs of the C harnesses; they travel with the snapshot)
+#     gcc ... tools/lat_check.c / mix_check.c / batch_check.c                     (command lines in the files' headers)
 #     gpurun --timeout 1500 -- 'bash tools/gpu_r05_first.sh'
-# 1. the default path once (the refactor of the NFA bodies into *_range forms moved a handful of instructions in k_nfa_count / k_nfa_all; k_lsd_regions_cl is
-#    byte-identical to the round-4 build) -- the single-frame and line suites, then the latency leg as the baseline of this box;
-# 2. SSLAM_NFA_STREAM=1 (the NFA stage next to the cluster form of the core; 640x480 single frames measured in round 4: profiles/r04_nfa_stream_c_abi_runs.txt): the experimental tests (spin on device flags -> tight timeout),
-#    then the latency leg with 16 / 8 / 32 consumer waves, with --check (24 frames against the oracle).
-# Outputs: gpurun_out/r05a/.
+# Round 4 measured it through the C ABI alone (profiles/r04_nfa_stream_c_abi_runs.txt: every output equal to the oracle, 5.85 / 7.00 -> 5.57 / 6.72 ms per frame, calls of
+# 2 .. 64 frames -10 .. -25 %) but had no GPU minutes left for the suite.  What decides: the WHOLE GPU suite with the knob exported (every cluster-form call of every
+# test then takes the streaming form), the experimental tests (consumer counts, patience settings), and the stress runs.  Each step under its own timeout; outputs in gpurun_out/r05a/.
 set -x
 R=$GRAFT_REPO_ROOT; cd $R
 O=$R/gpurun_out/r05a; mkdir -p $O
-timeout 600 python -m pytest tests/test_lines_gpu.py tests/test_configs_gpu.py -x -q -m gpu > $O/pytest_default.txt 2>&1; tail -3 $O/pytest_default.txt
-timeout 300 python tools/latency_probe.py --check > $O/latency_default.txt 2>&1; tail -2 $O/latency_default.txt
-SSLAM_TEST_EXPERIMENTAL=1 timeout 420 python -m pytest tests/test_experimental_gpu.py -x -q -m gpu > $O/pytest_nfa_stream.txt 2>&1; echo "rc=$?" >> $O/pytest_nfa_stream.txt; tail -5 $O/pytest_nfa_stream.txt
-if grep -q "rc=0" $O/pytest_nfa_stream.txt; then
-  for W in 1 8 32; do
-    SSLAM_NFA_STREAM=$W timeout 300 python tools/latency_probe.py --check > $O/latency_nfa_stream_$W.txt 2>&1; tail -2 $O/latency_nfa_stream_$W.txt
-  done
-  cd /tmp && export TMPDIR=/tmp
-  SSLAM_NFA_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_stream -- python $R/tools/latency_probe.py > $O/prof_stream.log 2>&1
-  cd $R; python tools/rocpd_summary.py $O/prof_stream $O/kernel_trace_nfa_stream.txt > /dev/null; rm -rf $O/prof_stream; head -12 $O/kernel_trace_nfa_stream.txt
-fi
+# 1. seconds: the C harnesses (no Python) -- default and streaming form, parity + latency on this box
+[ -x tools/mix_check ] && timeout 60 tools/mix_check 2 "" "SSLAM_NFA_STREAM=1" "SSLAM_NFA_STREAM=1,SSLAM_NFA_STREAM_TICKS=0" > $O/mix_check.txt 2>&1; tail -4 $O/mix_check.txt
+[ -x tools/lat_check ] && LAT_PROFILE=1 timeout 60 tools/lat_check 2 "" "SSLAM_NFA_STREAM=1" "SSLAM_NFA_STREAM=8" > $O/lat_check.txt 2>&1; cut -c1-200 $O/lat_check.txt
+[ -x tools/batch_check ] && timeout 60 tools/batch_check "" "SSLAM_NFA_STREAM=1" > $O/batch_check.txt 2>&1; tail -16 $O/batch_check.txt
+# 2. the experimental tests (they spin on device flags: tight timeout)
+SSLAM_TEST_EXPERIMENTAL=1 timeout 420 python -m pytest tests/test_experimental_gpu.py -x -q -m gpu > $O/pytest_experimental.txt 2>&1; echo "rc=$?" >> $O/pytest_experimental.txt; tail -4 $O/pytest_experimental.txt
+# 3. the whole suite with the knob exported, then without (the default path after the refactor of the NFA bodies into *_range forms)
+SSLAM_NFA_STREAM=1 timeout 600 python -m pytest tests -x -q -m gpu > $O/pytest_gpu_nfa_stream.txt 2>&1; echo "rc=$?" >> $O/pytest_gpu_nfa_stream.txt; tail -4 $O/pytest_gpu_nfa_stream.txt
+timeout 600 python -m pytest tests -x -q -m gpu > $O/pytest_gpu_default.txt 2>&1; echo "rc=$?" >> $O/pytest_gpu_default.txt; tail -4 $O/pytest_gpu_default.txt
+# 4. the bench line (its latency leg and the child-process comparison `latency_experiment_nfa_stream`)
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; python - <<'PY'
+import json
+try:
+    d = json.loads(open('gpurun_out/r05a/bench.json').read().strip().splitlines()[-1])
+    print(round(d['value']), d['latency']['lines_extract_hipEvent'], d.get('latency_experiment_nfa_stream'))
+except Exception as e: print('bench failed', e)
+PY
