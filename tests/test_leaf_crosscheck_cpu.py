@@ -110,3 +110,22 @@ def test_fast_score_is_the_largest_threshold_that_keeps_the_corner(oracle, thres
         got = score_map[3:-3, 3:-3].astype(np.int32)
         assert (want > 0).sum() > 300
         assert np.array_equal(got, want), "%d pixels differ" % int((got != want).sum())
+
+
+def test_fast_suppression_keeps_strict_3x3_maxima_of_the_response(oracle):
+    """cv::FAST(nonmaxSuppression = true) as recalled: a corner stays iff its response is strictly greater than the responses of its eight neighbours (a pixel that is no
+    corner has response 0).  A second statement of the same rule in numpy over the oracle's own response map -- it checks the oracle's code, not the recollection."""
+    for img, t in ((synth_frame(1234), 20), (noise_frame(7)[:240, :320].copy(), 7), (synth_frame(91, w=333, h=251), 7)):
+        sc, kps = oracle.fast_image(img, t)
+        s = sc.astype(np.int32); h, w = s.shape
+        nb = np.zeros_like(s)
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dy or dx:
+                    sh = np.zeros_like(s); sh[max(0, -dy):h - max(0, dy), max(0, -dx):w - max(0, dx)] = s[max(0, dy):h - max(0, -dy), max(0, dx):w - max(0, -dx)]
+                    nb = np.maximum(nb, sh)
+        keep = (s > 0) & (s > nb)
+        got = np.zeros_like(keep); got[kps[:, 1], kps[:, 0]] = True
+        assert np.array_equal(got, keep) and len(kps) == int(keep.sum()) > 100
+        assert np.array_equal(kps[:, 2], s[kps[:, 1], kps[:, 0]])                     # the keypoint's response is the map's
+        assert np.array_equal(np.lexsort((kps[:, 0], kps[:, 1])), np.arange(len(kps)))      # raster order
