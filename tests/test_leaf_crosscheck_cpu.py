@@ -129,3 +129,31 @@ def test_fast_suppression_keeps_strict_3x3_maxima_of_the_response(oracle):
         assert np.array_equal(got, keep) and len(kps) == int(keep.sum()) > 100
         assert np.array_equal(kps[:, 2], s[kps[:, 1], kps[:, 0]])                     # the keypoint's response is the map's
         assert np.array_equal(np.lexsort((kps[:, 0], kps[:, 1])), np.arange(len(kps)))      # raster order
+
+
+def test_lsd_nfa_is_the_binomial_tail_within_its_own_tolerance(oracle):
+    """LSD's nfa(n, k, p) = -log10(NT * P[Binomial(n, p) >= k]) with NT = (w h)^(5/2) * 11 (LSD_REFINE_ADV's eleven tolerances), computed by upstream with log-gamma
+    approximations and a tail sum that stops at 10 % relative error (so up to log10(1.1) = 0.041 off by design).  Against scipy's exact tail: 0.0014 at most over these
+    cases; its log-gamma (Lanczos below 15, Windschitl above) within 1e-12 of scipy's."""
+    import ctypes as C
+    from scipy import stats, special
+    L = oracle.L
+    L.orc_lsd_nfa.restype = C.c_double; L.orc_lsd_nfa.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
+    L.orc_log_gamma.restype = C.c_double; L.orc_log_gamma.argtypes = [C.c_double]
+    xs = np.concatenate([np.arange(1, 200), np.random.default_rng(0).integers(200, 400000, 500)]).astype(float)
+    lg = np.array([L.orc_log_gamma(x) for x in xs]); ref = special.gammaln(xs)
+    assert np.max(np.abs(lg - ref) / np.maximum(1, np.abs(ref))) < 1e-11
+    rng = np.random.default_rng(1); w, h = 512, 384
+    log_nt = 5 * (np.log10(w) + np.log10(h)) / 2 + np.log10(11.0)
+    worst = 0.0
+    for it in range(4000):
+        p = float(rng.choice([0.125, 0.0625, 0.03125, 0.015625, 1 / 128]))
+        n = int(rng.integers(1, 30000)) if it % 3 else int(rng.integers(1, 200))
+        lo = int(n * p * 0.5)
+        k = int(min(n, rng.integers(lo, lo + max(2, int(4 * np.sqrt(n * p * (1 - p)) + n * p)))))
+        got = L.orc_lsd_nfa(w, h, n, k, p)
+        want = -log_nt if k == 0 else -(stats.binom.logsf(k - 1, n, p) / np.log(10) + log_nt)
+        if np.isfinite(want):
+            worst = max(worst, abs(got - want))
+    assert worst < 0.0414, worst
+    assert worst < 0.005, worst            # what it actually achieves
