@@ -13,6 +13,12 @@ O=$R/gpurun_out/r05a; mkdir -p $O
 [ -x tools/mix_check ] && timeout 60 tools/mix_check 2 "" "SSLAM_NFA_STREAM=1" "SSLAM_NFA_STREAM=1,SSLAM_NFA_STREAM_TICKS=0" > $O/mix_check.txt 2>&1; tail -4 $O/mix_check.txt
 [ -x tools/lat_check ] && LAT_PROFILE=1 timeout 60 tools/lat_check 2 "" "SSLAM_NFA_STREAM=1" "SSLAM_NFA_STREAM=8" > $O/lat_check.txt 2>&1; cut -c1-200 $O/lat_check.txt
 [ -x tools/batch_check ] && timeout 60 tools/batch_check "" "SSLAM_NFA_STREAM=1" > $O/batch_check.txt 2>&1; tail -16 $O/batch_check.txt
+# 1b. the main wave's code is a roll of the register allocator's dice (the streaming kernel's core is 3 % slower than the default's, same source plus thirty
+#     instructions): other rolls of lines.hip, built on the CPU beforehand -- tools/build_variant.sh pm0 "-mllvm -enable-post-misched=0"; ... ilp "-mllvm -amdgpu-sched-strategy=max-ilp";
+#     ... il1 "-mllvm -inline-threshold=100000" -- each through the C harness (LD_PRELOAD replaces the library), default and streaming form; parity is checked in every run
+for V in pm0 ilp il1; do
+  [ -f structure-slam-pointline_amd/lib/variants/$V.so ] && LD_PRELOAD=$R/structure-slam-pointline_amd/lib/variants/$V.so LAT_PROFILE=1 timeout 60 tools/lat_check 2 "" "SSLAM_NFA_STREAM=1" > $O/lat_check_$V.txt 2>&1; cut -c1-200 $O/lat_check_$V.txt
+done
 # 2. the experimental tests (they spin on device flags: tight timeout)
 SSLAM_TEST_EXPERIMENTAL=1 timeout 420 python -m pytest tests/test_experimental_gpu.py -x -q -m gpu > $O/pytest_experimental.txt 2>&1; echo "rc=$?" >> $O/pytest_experimental.txt; tail -4 $O/pytest_experimental.txt
 # 3. the whole suite with the knob exported, then without (the default path after the refactor of the NFA bodies into *_range forms)
