@@ -368,8 +368,17 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
                 if (const char* e = getenv("SSLAM_NFA_STREAM_SLEEP")) nfaSleep = std::max(0, std::min(64, atoi(e)));
                 if (const char* e = getenv("SSLAM_NFA_STREAM_LDS")) nfaLdsPad = (size_t)std::max(0, std::min(48 * 1024, atoi(e)));
                 SSLAM_HIP(hipEventRecord(L->nfaFork, st));      // (the prologue's planes and the zeroed slot heads are what the consumers need)
+                // SSLAM_NFA_STREAM_EMIT=lds (not yet run on a GPU): the main wave hands its rectangles to a publisher wave of its workgroup through LDS instead of writing them
+                // to memory itself (lsd_cluster.h, STREAM == 2: its sc1 stores delayed its next loads by 0.6 us per rectangle)
+                const char* emitForm = getenv("SSLAM_NFA_STREAM_EMIT");
+                if (emitForm && emitForm[0] == 'l') {
+                    const size_t clLds2 = std::max(clLds, sizeof(unsigned) * ((size_t)QCAP + 4 + (bigFrame ? 0 : TorusFrame::WORDS) + CL_SCAN + CL_RING_WORDS) + 16 + sizeof(ClEmitRing));
+                    SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl_stream2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds2));
+                    hipLaunchKernelGGL(k_lsd_regions_cl_stream2, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds2, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
+                } else {
                 SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
                 hipLaunchKernelGGL(k_lsd_regions_cl_stream, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
+                }
                 SSLAM_HIP(hipStreamWaitEvent(L->nfaStream, L->nfaFork, 0));
                 if ((rc = sslam::launch_nfa_stream(L->ctx, L->nfaStream, ws, &P, sizeof(P), L->dLgam.as<double>(), L->dCl.as<uint8_t>(), clFrame, stageOff, nframes, nfaStreamWaves, spinTicks, nfaLdsPad, nfaTakeMax, nfaSleep, nullptr))) return rc;
                 SSLAM_HIP(hipEventRecord(L->nfaJoin, L->nfaStream));

@@ -17,7 +17,9 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SSLAM_TEST_EXP
 @pytest.mark.parametrize("knobs", [{"SSLAM_NFA_STREAM": "1"}, {"SSLAM_NFA_STREAM": "3"}, {"SSLAM_NFA_STREAM": "48"},
                                    {"SSLAM_NFA_STREAM": "1", "SSLAM_NFA_STREAM_TICKS": "0"},          # every consumer gives up at once: the launch behind the core does all of it
                                    {"SSLAM_NFA_STREAM": "1", "SSLAM_NFA_STREAM_TICKS": "20000"},      # 0.2 ms of patience: some of each
-                                   {"SSLAM_NFA_STREAM": "1", "SSLAM_CL_WINDOW": "-1"}])               # no helpers: a slow core, consumers mostly waiting
+                                   {"SSLAM_NFA_STREAM": "1", "SSLAM_CL_WINDOW": "-1"},                # no helpers: a slow core, consumers mostly waiting
+                                   {"SSLAM_NFA_STREAM": "1", "SSLAM_NFA_STREAM_EMIT": "lds"},         # hand-over through LDS and a publisher wave (never run on a GPU before round 5)
+                                   {"SSLAM_NFA_STREAM": "8", "SSLAM_NFA_STREAM_EMIT": "lds", "SSLAM_NFA_STREAM_TICKS": "20000"}])
 def test_nfa_stage_next_to_the_core(fe, ctx, oracle, knobs, monkeypatch):
     """SSLAM_NFA_STREAM: the NFA stage on a second stream, on the rectangles the cluster form's main wave has published so far (csrc/lsd_nfa.h k_nfa_stream;
     the protocol as a thread model: tests/test_nfa_stream_proto_cpu.py).  Frames with 10x different rectangle counts, one with none, one larger than the LDS bitmap."""

@@ -29,3 +29,13 @@ def test_every_rectangle_is_evaluated_exactly_once(proto, runs, max_records, con
 def test_counter_before_records_is_caught(proto):
     bad, out = _bad(proto, 300, 400, 8, 0, 1)
     assert bad > 0, out
+
+
+@pytest.mark.parametrize("runs,max_records,consumers,expire", [(300, 400, 8, 0), (100, 3000, 8, 1)])
+def test_hand_over_through_a_ring_and_a_publisher(proto, runs, max_records, consumers, expire):
+    """STREAM == 2 (SSLAM_NFA_STREAM_EMIT=lds): the main wave writes into a ring of 64 records in LDS, a publisher wave of its workgroup drains it into the staging array and
+    publishes the counters (csrc/lsd_cluster.h cl_publisher); more records than the ring holds, so it wraps and fills"""
+    bad, out = _bad(proto, runs, max_records, consumers, expire, 0, 1)
+    assert bad == 0, out
+    bad, out = _bad(proto, 300, 400, 8, 0, 1, 1)          # `produced` before the record: must be caught
+    assert bad > 0, out
