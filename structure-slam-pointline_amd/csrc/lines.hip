@@ -369,7 +369,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
                 if (const char* e = getenv("SSLAM_NFA_STREAM_LDS")) nfaLdsPad = (size_t)std::max(0, std::min(48 * 1024, atoi(e)));
                 SSLAM_HIP(hipEventRecord(L->nfaFork, st));      // (the prologue's planes and the zeroed slot heads are what the consumers need)
                 // SSLAM_NFA_STREAM_EMIT=lds (not yet run on a GPU): the main wave hands its rectangles to a publisher wave of its workgroup through LDS instead of writing them
-                // to memory itself (lsd_cluster.h, STREAM == 2: its sc1 stores delayed its next loads by 0.6 us per rectangle)
+                // to memory itself (lsd_cluster.h, STREAM == 2: one candidate for the streaming kernel's slower core is its sc1 stores delaying its next loads)
                 const char* emitForm = getenv("SSLAM_NFA_STREAM_EMIT");
                 if (emitForm && emitForm[0] == 'l') {
                     const size_t clLds2 = std::max(clLds, sizeof(unsigned) * ((size_t)QCAP + 4 + (bigFrame ? 0 : TorusFrame::WORDS) + CL_SCAN + CL_RING_WORDS) + 16 + sizeof(ClEmitRing));

@@ -112,10 +112,11 @@ __device__ __forceinline__ bool cl_spec(const ClShared& cl, int x, int y) {
 #endif
 // ------------------------------------------------------------------ the main wave
 // STREAM == 2 (k_lsd_regions_cl_stream2, SSLAM_NFA_STREAM_EMIT=lds; NOT yet run on a GPU): the main wave hands its rectangles over through LDS, wave 2 of its workgroup -- idle
-// otherwise -- writes them to the staging array and publishes the counters.  Why: measured with STREAM == 1 the core is 0.6 us slower PER RECTANGLE (190 us at 640 x 480, 340 at
-// 1280 x 960, consumers or not): vector memory operations of a wave complete in order, so the main wave's next load waits until its twelve sc1 stores have been acknowledged by
-// memory, not by the L2.  With the ring the main wave issues no global store for a rectangle at all (the default issues twelve plain ones).  DS operations of a wave execute in
-// order: record, then `produced`; the publisher reads `finished` (set behind the last record) before `produced`.
+// otherwise -- writes them to the staging array and publishes the counters.  Why: measured with STREAM == 1 the core is 190 us slower at 640 x 480 (439 rectangles) and 340 at
+// 1280 x 960 (1 862), consumers or not.  One candidate: vector memory operations of a wave complete in order, so the main wave's next load waits until its twelve sc1 stores have
+// been acknowledged by memory, not by the L2 (the other: the register assignment of another kernel).  With the ring the main wave issues no global store for a
+// rectangle at all (the default issues twelve plain ones).  DS operations of a wave execute in order: record, then `produced`; the publisher reads `finished` (set behind the
+// last record) before `produced`.
 constexpr int CL_EMIT_RING = 64;           // records; one every ~10 us against ~2 us per drain
 struct alignas(16) ClEmitRing { int produced, consumed, pad0, pad1; unsigned long long rec[CL_EMIT_RING][12]; };
 __device__ void cl_publisher(const ClShared& cl, ClLocal* __restrict__ loc) {

@@ -12,7 +12,7 @@ O=$R/gpurun_out/r05a; mkdir -p $O
 # 1. seconds: the C harnesses (no Python) -- default and streaming form, parity + latency on this box
 [ -x tools/mix_check ] && timeout 60 tools/mix_check 2 "" "SSLAM_NFA_STREAM=1" "SSLAM_NFA_STREAM=1,SSLAM_NFA_STREAM_TICKS=0" > $O/mix_check.txt 2>&1; tail -4 $O/mix_check.txt
 [ -x tools/lat_check ] && LAT_PROFILE=1 timeout 60 tools/lat_check 2 "" "SSLAM_NFA_STREAM=1" "SSLAM_NFA_STREAM=8" > $O/lat_check.txt 2>&1; cut -c1-200 $O/lat_check.txt
-# 1a. NEVER RUN ON A GPU BEFORE: the hand-over through LDS and a publisher wave (SSLAM_NFA_STREAM_EMIT=lds; the hypothesis: the main wave's sc1 stores cost it 0.6 us per rectangle) --
+# 1a. NEVER RUN ON A GPU BEFORE: the hand-over through LDS and a publisher wave (SSLAM_NFA_STREAM_EMIT=lds; one candidate for the streaming kernel's slower core: its next loads wait behind the sc1 stores) --
 #     own timeout, parity is checked in the run; compare the k_lsd_regions scope with the two lines above
 [ -x tools/lat_check ] && LAT_PROFILE=1 timeout 40 tools/lat_check 2 "SSLAM_NFA_STREAM=1,SSLAM_NFA_STREAM_EMIT=lds" "SSLAM_NFA_STREAM=8,SSLAM_NFA_STREAM_EMIT=lds" > $O/lat_check_lds.txt 2>&1; cut -c1-200 $O/lat_check_lds.txt
 [ -x tools/mix_check ] && timeout 40 tools/mix_check 2 "SSLAM_NFA_STREAM=1,SSLAM_NFA_STREAM_EMIT=lds" > $O/mix_check_lds.txt 2>&1; tail -2 $O/mix_check_lds.txt
