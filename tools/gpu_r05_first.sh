@@ -1,7 +1,6 @@
 #!/bin/bash
 # Round 5, first GPU call: decide whether SSLAM_NFA_STREAM (the NFA stage next to the cluster form of the core) becomes the default for calls of <= 64 frames.
-#     python tools/lat_check_prepare.py && python tools/mix_check_prepare.py      (CPU, once: inputs of the C harnesses; they travel with the snapshot)
-#     gcc ... tools/lat_check.c / mix_check.c / batch_check.c                     (command lines in the files' headers)
+#     bash tools/build_c_harnesses.sh                                            (CPU, once: the C harnesses and their inputs; they travel with the snapshot)
 #     gpurun --timeout 1500 -- 'bash tools/gpu_r05_first.sh'
 # Round 4 measured it through the C ABI alone (profiles/r04_nfa_stream_c_abi_runs.txt: every output equal to the oracle, 5.85 / 7.00 -> 5.57 / 6.72 ms per frame, calls of
 # 2 .. 64 frames -10 .. -25 %) but had no GPU minutes left for the suite.  What decides: the WHOLE GPU suite with the knob exported (every cluster-form call of every
