@@ -22,6 +22,9 @@ O=$R/gpurun_out/r05a; mkdir -p $O
 for V in pm0 ilp il1; do
   [ -f structure-slam-pointline_amd/lib/variants/$V.so ] && LD_PRELOAD=$R/structure-slam-pointline_amd/lib/variants/$V.so LAT_PROFILE=1 timeout 60 tools/lat_check 2 "" "SSLAM_NFA_STREAM=1" > $O/lat_check_$V.txt 2>&1; cut -c1-200 $O/lat_check_$V.txt
 done
+# 1c. NEVER RUN ON A GPU BEFORE: the bench's step through the C ABI alone (tools/step_check.c) -- if its frames/s and per-frame means agree with bench.py's line (68.3 k frames/s,
+#     1004.2 keypoints, 164.45 lines, 102.7 / 118.8 matches per frame on the round-4 build), kernel experiments on the headline metric cost ~20 s of GPU time from here on
+[ -x tools/step_check ] && STEP_PROFILE=1 timeout 120 tools/step_check 12288 5 2 > $O/step_check.txt 2>&1; cat $O/step_check.txt
 # 2. the experimental tests (they spin on device flags: tight timeout)
 SSLAM_TEST_EXPERIMENTAL=1 timeout 420 python -m pytest tests/test_experimental_gpu.py -x -q -m gpu > $O/pytest_experimental.txt 2>&1; echo "rc=$?" >> $O/pytest_experimental.txt; tail -4 $O/pytest_experimental.txt
 # 3. the whole suite with the knob exported, then without (the default path after the refactor of the NFA bodies into *_range forms)
