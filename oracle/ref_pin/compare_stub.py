@@ -4,11 +4,12 @@ of oracle/ref_pin/stub_cv (OpenCV leaves = oracle/cvleaf.h) -- against the CPU o
 
     compare_stub.py <ref_dir (oracle/_ref)> <fixtures dir> <report.json>
 
-Four builds of the same reference source are run:
-  ref_orb_stub          -O3 -march=native -ffp-contract=off, monotonic allocator   = the oracle's decisions D1 + D4: MUST equal the oracle
-  ref_orb_stub_fma      -O3 -march=native (GCC default: contraction on), monotonic  -> D4's error bar (FMA in x*b + y*a, src/ORBextractor.cc:118-120)
-  ref_orb_stub_malloc   -ffp-contract=off, glibc malloc                             -> D1's error bar (sort by heap pointer, src/ORBextractor.cc:684)
-  ref_orb_stub_asbuilt  -O3 -march=native, glibc malloc  = the reference's own CMake flags (CMakeLists.txt:10-11) -> both together
+Five builds of the same reference source are run:
+  ref_orb_stub          -O3 -march=native -ffp-contract=off, monotonic allocator, correctly rounded cosf / sinf   = the oracle's decisions D1 + D4 + D5: MUST equal the oracle
+  ref_orb_stub_fma      the same with GCC's default contraction                     -> D4's error bar (FMA in x*b + y*a, src/ORBextractor.cc:118-120)
+  ref_orb_stub_malloc   the same with glibc malloc                                  -> D1's error bar (sort by heap pointer, src/ORBextractor.cc:684)
+  ref_orb_stub_libm     the same with libm's own cosf / sinf                        -> D5's error bar (src/ORBextractor.cc:113; found by campaign_orb.py: one descriptor bit in 73 M)
+  ref_orb_stub_asbuilt  -O3 -march=native, glibc malloc, libm  = the reference's own CMake flags (CMakeLists.txt:10-11) -> all three together
   ref_orb_stub_gauss340 the pinned binary with the stub's GaussianBlur switched to OpenCV 3.4.0's rounded taps  -> D6's error bar (descriptor bits only)
 The report says, per fixture: equal or not for the pinned build; for the other three how many keypoints (as a set of (octave, x, y))
 and how many descriptor bits differ from the oracle.  Exit status 0 either way -- tests/test_pin_cpu.py turns the report into a verdict."""
@@ -23,7 +24,7 @@ ref, fx, report_path = sys.argv[1], sys.argv[2], sys.argv[3]
 orc = oracle_lib.Oracle()
 # fixture name -> extractor parameters (nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST); default = Examples/ICL.yaml:41-54
 PARAMS = {"synth4lev15_700": (700, 1.5, 4, 20, 7), "synthth_1200": (1200, 1.2, 8, 35, 12)}
-VARIANTS = ["ref_orb_stub", "ref_orb_stub_fma", "ref_orb_stub_malloc", "ref_orb_stub_asbuilt", "ref_orb_stub_gauss340"]      # the last one: the pinned binary with SSLAM_STUB_GAUSS_340=1 (decision D6's alternative)
+VARIANTS = ["ref_orb_stub", "ref_orb_stub_fma", "ref_orb_stub_malloc", "ref_orb_stub_libm", "ref_orb_stub_asbuilt", "ref_orb_stub_gauss340"]      # the last one: the pinned binary with SSLAM_STUB_GAUSS_340=1 (decision D6's alternative)
 
 
 def run(binary, pgm, params):
@@ -81,10 +82,10 @@ for pgm in sorted(glob.glob(os.path.join(fx, "*.pgm"))):
     report["fixtures"][name] = res
 json.dump(report, open(report_path, "w"), indent=1)
 for n, r in report["fixtures"].items():
-    print("%-20s pinned kp %s desc %s (%d kp) | gauss 3.4.0: %d bits differ | fma: %d kp / %d bits differ | malloc: %d kp differ | as built: %d kp / %d bits differ" % (
+    print("%-20s pinned kp %s desc %s (%d kp) | gauss 3.4.0: %d bits differ | fma: %d kp / %d bits differ | malloc: %d kp differ | libm cosf/sinf: %d bits differ | as built: %d kp / %d bits differ" % (
         n, r["pinned"]["kp_equal"], r["pinned"]["desc_equal"], r["pinned"]["keypoints"], r["ref_orb_stub_gauss340"]["descriptor_bits_differing"],
         r["ref_orb_stub_fma"]["only_in_reference"] + r["ref_orb_stub_fma"]["only_in_oracle"], r["ref_orb_stub_fma"]["descriptor_bits_differing"],
-        r["ref_orb_stub_malloc"]["only_in_reference"] + r["ref_orb_stub_malloc"]["only_in_oracle"],
+        r["ref_orb_stub_malloc"]["only_in_reference"] + r["ref_orb_stub_malloc"]["only_in_oracle"], r["ref_orb_stub_libm"]["descriptor_bits_differing"],
         r["ref_orb_stub_asbuilt"]["only_in_reference"] + r["ref_orb_stub_asbuilt"]["only_in_oracle"], r["ref_orb_stub_asbuilt"]["descriptor_bits_differing"]))
 print("reference ORBextractor.cc (stub cv) == oracle on every fixture:", report["all_equal"])
 print("error bars:", json.dumps(report["error_bars"]))

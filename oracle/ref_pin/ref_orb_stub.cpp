@@ -2,7 +2,7 @@
 // /root/reference/src/ORBextractor.cc compiled unmodified against oracle/ref_pin/stub_cv -- the way Frame::ExtractORB does
 // (src/Frame.cc:155-161) and dumps keypoints (28 B) and descriptor rows (32 B) for compare_stub.py.
 //   ref_orb_stub <image.pgm> <outprefix> <nfeatures> [scaleFactor=1.2 nlevels=8 iniThFAST=20 minThFAST=7]
-// -DPIN_BUMP_ALLOC replaces the global allocator with a monotonic arena, so that the heap addresses of the quadtree's list nodes
+// -DPIN_CR_TRIG: see below (decision D5).  -DPIN_BUMP_ALLOC replaces the global allocator with a monotonic arena, so that the heap addresses of the quadtree's list nodes
 // increase with creation order: src/ORBextractor.cc:684 sorts (size, ExtractorNode*) pairs, and decision D1 of the oracle
 // ("equal sizes: later-created node first") is exactly what that sort yields under such an allocator.  Without the flag the
 // nodes come from glibc malloc (recycled addresses) -- the difference between the two builds is D1's error bar.
@@ -15,6 +15,15 @@
 #include <vector>
 #include "ORBextractor.h"
 
+#ifdef PIN_CR_TRIG
+// Decision D5 of the oracle: cosf / sinf := the correctly rounded float of the real function.  src/ORBextractor.cc:113 calls cos(float) / sin(float), i.e. libm's cosf / sinf,
+// which are within an ulp but not correctly rounded (glibc here: 1.3 % of random angles differ in the last bit, and which of its ifunc variants runs depends on the CPU).
+// Defining the two symbols in the executable makes the reference's own code take the correctly rounded values; the build without this flag (ref_orb_stub_libm) is D5's error bar.
+#include <cmath>
+extern "C" float cosf(float x) noexcept { return (float)cos((double)x); }
+extern "C" float sinf(float x) noexcept { return (float)sin((double)x); }
+extern "C" void sincosf(float x, float* s, float* c) noexcept { *s = (float)sin((double)x); *c = (float)cos((double)x); }      // (GCC merges the pair of calls at src/ORBextractor.cc:113 into this one)
+#endif
 #ifdef PIN_BUMP_ALLOC
 #include <sys/mman.h>
 static char* g_arena = nullptr; static size_t g_off = 0; static const size_t kArena = (size_t)24 << 30;   // lazily committed

@@ -30,7 +30,7 @@ def _check(rep):
         assert fn in covered, fn
     # the error bars of decisions D1 / D4 are part of the report (DESIGN.md section 2 quotes them)
     eb = rep["orb_extractor"]["error_bars"]
-    assert set(eb) == {"ref_orb_stub_fma", "ref_orb_stub_malloc", "ref_orb_stub_asbuilt", "ref_orb_stub_gauss340"} and all(v["keypoints"] > 10000 for v in eb.values())
+    assert set(eb) == {"ref_orb_stub_fma", "ref_orb_stub_malloc", "ref_orb_stub_libm", "ref_orb_stub_asbuilt", "ref_orb_stub_gauss340"} and all(v["keypoints"] > 10000 for v in eb.values())
 
 
 def test_reference_compiled_here_equals_oracle():

@@ -1,5 +1,5 @@
 """GPU parity against the REFERENCE ITSELF (not only the restatement): oracle/_ref/ref_orb_stub is /root/reference/src/ORBextractor.cc compiled
-unmodified in the build container (oracle/ref_pin, stub cv:: layer over oracle/cvleaf.h, decisions D1 + D4 as the oracle defines them) and
+unmodified in the build container (oracle/ref_pin, stub cv:: layer over oracle/cvleaf.h, decisions D1 + D4 + D5 as the oracle defines them) and
 oracle/_ref/libref_slices.so holds the reference's own SearchForInitialization / GetFeaturesInArea / SerachForInitialize bodies; both are
 plain x86-64 binaries that travel with the snapshot.  Here the HIP library's outputs are compared with THEIR outputs, byte for byte.
 Skipped (not failed) when the binaries did not travel: tests/test_pin_cpu.py is what must pass in the build container."""
