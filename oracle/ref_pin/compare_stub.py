@@ -52,7 +52,10 @@ report = {"what": "reference src/ORBextractor.cc compiled unmodified against ora
           "fixtures": {}, "all_equal": True, "error_bars": {v: {"keypoints_differing": 0, "keypoints": 0, "descriptor_bits_differing": 0, "descriptor_bits_compared": 0} for v in VARIANTS[1:]}}
 for pgm in sorted(glob.glob(os.path.join(fx, "*.pgm"))):
     name = os.path.basename(pgm)[:-4]
-    params = PARAMS.get(name, (int(name.rsplit("_", 1)[1]), 1.2, 8, 20, 7))
+    if name.startswith("p") and name.count("_") == 5:      # campaign_orb.py --params: p<k>_<nfeatures>_<scaleFactor x 100>_<nlevels>_<iniThFAST>_<minThFAST>
+        f_ = name.split("_"); params = (int(f_[1]), int(f_[2]) / 100.0, int(f_[3]), int(f_[4]), int(f_[5]))
+    else:
+        params = PARAMS.get(name, (int(name.rsplit("_", 1)[1]), 1.2, 8, 20, 7))
     with open(pgm, "rb") as f:
         assert f.readline().strip() == b"P5"; w, h = map(int, f.readline().split()); f.readline()
         img = np.frombuffer(f.read(), np.uint8).reshape(h, w)
