@@ -194,7 +194,7 @@ def latency_leg(fe, ctx, frames, with_lines, nframes=120):
     if lx: lx.close()
     pct = lambda a: {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "max": float(a.max())}
     out = {"unit": "ms", "frames": nframes, "path": "sslam_orb_extract + sslam_lines_extract per frame (host image in, host results out)",
-           "lsd_core": "cluster form (one main wave + helper waves on several compute units; lsd_cluster.h)" if (W * 0.8 <= 2048 and H * 0.8 <= 1024 and os.environ.get("SSLAM_LSD_CLUSTER", "1") != "0" and os.environ.get("SSLAM_LSD_FLAVOUR", "c")[0] == "c") else "multi-wave (one main wave + helper waves per frame; lsd_regions.h)",
+           "lsd_core": "cluster form (one main wave + helper waves on several compute units; lsd_cluster.h), NFA stage next to it (k_nfa_stream)" if (W * 0.8 <= 2048 and H * 0.8 <= 1024 and os.environ.get("SSLAM_LSD_CLUSTER", "1") != "0" and os.environ.get("SSLAM_LSD_FLAVOUR", "c")[0] == "c") else "multi-wave (one main wave + helper waves per frame; lsd_regions.h)",
            "orb_extract_hipEvent": pct(orb), "lines_extract_hipEvent": pct(lin) if with_lines else None, "frame_hipEvent": pct(orb + lin), "frame_wall": pct(wall),
            "frames_per_s_one_at_a_time": float(1e3 / np.median(wall))}
     if with_lines and not os.environ.get("SSLAM_LSD_FLAVOUR"):
@@ -216,8 +216,8 @@ def latency_leg(fe, ctx, frames, with_lines, nframes=120):
 
 def nfa_stream_leg():
     """Child process of the default run (`bench.py --nfa-stream-leg`, prints one JSON object): the one-frame-at-a-time line extraction of the latency leg's 64 frames
-    with the experiment SSLAM_NFA_STREAM=1 (the NFA stage next to the cluster form of the core: csrc/lsd_nfa.h k_nfa_stream; off by default) beside
-    the default path -- HIP events around sslam_lines_extract, and every frame's keylines / LBD bytes / line functions compared with the default path's."""
+    on the default path (round 5: the NFA stage NEXT TO the cluster form of the core, csrc/lsd_nfa.h k_nfa_stream) and with SSLAM_NFA_STREAM=0 (the stage behind the core,
+    the round-4 default) -- HIP events around sslam_lines_extract, and every frame's keylines / LBD bytes / line functions compared between the two."""
     import numpy as np, torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pkg
@@ -228,9 +228,9 @@ def nfa_stream_leg():
     pct = lambda a: {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "max": float(a.max())}
     res = {"unit": "ms", "frames": 128, "path": "sslam_lines_extract per frame (host image in, host results out), HIP events"}
     outs = {}
-    for mode in ("default", "nfa_stream"):
+    for mode in ("default", "nfa_behind_core"):
         os.environ.pop("SSLAM_NFA_STREAM", None)
-        if mode == "nfa_stream": os.environ["SSLAM_NFA_STREAM"] = "1"
+        if mode == "nfa_behind_core": os.environ["SSLAM_NFA_STREAM"] = "0"
         lx = fe.LineExtractor(ctx, 200)
         for f in frames[:4]: lx(f)
         t = []; outs[mode] = []
@@ -242,7 +242,7 @@ def nfa_stream_leg():
         lx.close()
         res[mode] = pct(np.array(t))
     os.environ.pop("SSLAM_NFA_STREAM", None)
-    res["frames_differing_from_default_path"] = int(sum(a != b for a, b in zip(outs["default"], outs["nfa_stream"])))
+    res["frames_differing_from_default_path"] = int(sum(a != b for a, b in zip(outs["default"], outs["nfa_behind_core"])))
     print(json.dumps(res))
 
 
@@ -299,7 +299,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the latency and PCIe-inclusive legs")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing (used for rocprofv3 runs)")
     ap.add_argument("--no-pcie", action="store_true", help="latency leg only (no PCIe-inclusive host-batch leg)")
-    ap.add_argument("--nfa-stream-leg", action="store_true", help="(child process of the default run) single-frame line extraction with SSLAM_NFA_STREAM=1 beside the default path")
+    ap.add_argument("--nfa-stream-leg", action="store_true", help="(child process of the default run) single-frame line extraction with SSLAM_NFA_STREAM=0 (the NFA stage behind the core) beside the default path")
     ap.add_argument("--no-other-workloads", action="store_true", help="the default run appends a short pass of BASELINE configs[3] (1280x960 / 2000 kp / 400 lines) as other_workloads.c4; this skips it")
     args = ap.parse_args()
     if args.nfa_stream_leg:
@@ -548,13 +548,13 @@ def main():
                                                  "latency": {k: c4.get("latency", {}).get(k) for k in ("orb_extract_hipEvent", "lines_extract_hipEvent", "frames_per_s_one_at_a_time")}}}
             except Exception as e:
                 out["other_workloads"] = {"c4": {"error": str(e)[:300]}}
-            try:      # an experiment that is off by default, in a child process of its own (a fault there cannot touch this line): the NFA stage next to the core, one frame at a time
+            try:      # the alternative of the single-frame default, in a child process of its own (a fault there cannot touch this line): the NFA stage behind the core instead of next to it
                 import subprocess
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--nfa-stream-leg"], capture_output=True, text=True, timeout=240,
                                    env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
-                out["latency_experiment_nfa_stream"] = json.loads(r.stdout.strip().splitlines()[-1])
+                out["latency_nfa_behind_core"] = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as e:
-                out["latency_experiment_nfa_stream"] = {"error": str(e)[:300]}
+                out["latency_nfa_behind_core"] = {"error": str(e)[:300]}
         print(json.dumps(out))
     if gather is not None:
         gather.wait()

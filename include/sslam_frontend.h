@@ -142,7 +142,10 @@ int sslam_hamming_knn2(sslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* 
 int sslam_hamming_knn2_dev(sslam_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
                            int32_t* d_idx, int32_t* d_dist, void* stream);
 /* Batch form: frame f = rows [f*cap, f*cap+nq[f]) of d_q against rows [f*cap, f*cap+nt[f]) of d_t;
- * d_idx/d_dist are nframes*cap x 2. */
+ * d_idx/d_dist are nframes*cap x 2.  For cap <= 4096 the train rows are first expanded to matrix-core operands in a buffer the CONTEXT keeps
+ * (256 B per train row, nframes * cap rows, never shrunk: 3 GB for 12 288 frames of 1 000 rows).  Calls on different streams of one context are
+ * ordered on that buffer by an event (a later call's expansion waits for the earlier call's search), so they do not overlap; use one context per
+ * stream for concurrent searches. */
 int sslam_hamming_knn2_batch_dev(sslam_ctx* ctx, const uint8_t* d_q, const int32_t* d_nq, const uint8_t* d_t,
                                  const int32_t* d_nt, int cap, int nframes, int32_t* d_idx, int32_t* d_dist, void* stream);
 /* Dense nq x nt distance matrix (uint16), the input of the windowed Search* variants. */
@@ -346,6 +349,24 @@ int sslam_lines_extract(sslam_lines* ln, const uint8_t* gray, int w, int h, size
  * src/ExtractLineSegment.cpp:53): 0 = OpenCV >= 3.4.1 (taps 14 62 104 62 14), 1 = OpenCV 3.4.0 (14 63 103 63 14).  LSD's own 7x7 sigma-0.75 pre-blur has the
  * same taps (0 4 56 136 56 4 0) under both, so the segments do not depend on it; the LBD bytes do. */
 int sslam_lines_set_blur_variant(sslam_lines* ln, int variant);
+/* The other stated decisions of the line path that have a selectable alternative.  The arithmetic of LSD and LBD is OpenCV's (called at
+ * src/ExtractLineSegment.cpp:38-40,53); this image holds no OpenCV, so each of these is a choice between two restatements, with the size of what it moves
+ * measured in oracle/ref_pin/pin_report_stub.json.  variant is 0 (default) or 1; the next extraction takes it.
+ *   sslam_lines_set_nfa_variant    D11 -- the first term of LineSegmentDetectorImpl::nfa()'s log1term: 0 = log_gamma(n + 1), the binomial coefficient of von Gioi's
+ *                                  lsd.c; 1 = (double(n) + 1) without the log_gamma, as imgproc/src/lsd.cpp is recalled to read.  Under 1 nearly every rectangle passes
+ *                                  at its first rect_nfa: 2.0-2.7 x the segments.
+ *   sslam_lines_set_lbd_bit_order  D12 -- BinaryDescriptor::binaryConversion: 0 = comparison i sets bit i; 1 = comparison i sets 0x80 >> i.  Every byte is bit-reversed;
+ *                                  Hamming distances, hence every matcher result, are the same.
+ *   sslam_lines_set_resize_variant D7 -- LSD's 0.8x rescale: 0 = INTER_LINEAR_EXACT (8.8 coefficients, one rounding); 1 = INTER_LINEAR (11-bit coefficients, the two-stage
+ *                                  8u rounding of the ORB pyramid's resize).
+ *   sslam_lines_set_seed_order     D2 -- the order of LSD's seeds inside one of the 1024 gradient bins: 0 = raster order (a stable counting sort, on the device);
+ *                                  1 = whatever `std::sort` of this library's libstdc++ leaves, as upstream's ll_angle sorts: the bins are sorted ON THE HOST (one
+ *                                  download, one std::sort of every pixel and one upload per frame: ~15 ms per 640x480 frame -- a switch for comparing with a
+ *                                  maintainer's CPU build, not a production path). */
+int sslam_lines_set_nfa_variant(sslam_lines* ln, int variant);
+int sslam_lines_set_lbd_bit_order(sslam_lines* ln, int variant);
+int sslam_lines_set_resize_variant(sslam_lines* ln, int variant);
+int sslam_lines_set_seed_order(sslam_lines* ln, int variant);
 int sslam_lines_extract_batch_dev(sslam_lines* ln, const uint8_t* d_images, int w, int h,
                                   size_t pitch, size_t image_stride, int nframes,
                                   sslam_keyline* d_kl, uint8_t* d_ldesc, double* d_linefn,

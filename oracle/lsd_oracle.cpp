@@ -20,6 +20,9 @@
 namespace orc {
 int g_lsdResize = 0;        // 0: decision D7 (INTER_LINEAR_EXACT); 1: INTER_LINEAR (error bar only)
 int g_lsdSeedSort = 0;      // 0: decision D2 (stable: raster order inside a bin); 1: upstream's std::sort (error bar only)
+int g_lsdNfaVariant = 0;    // decision D11 -- 0: nfa()'s first term as von Gioi's lsd.c has it, log_gamma(n + 1) (the mathematical binomial coefficient);
+                            // 1: the term as two independent recollections of OpenCV's imgproc/src/lsd.cpp have it, (double(n) + 1) WITHOUT the log_gamma around it
+                            // (UPSTREAM-RECALL; the round-4 review's and the builder's).  orc_set_lsd_nfa_variant(); the library's switch is sslam_lines_set_nfa_variant().
 
 
 static const double NOTDEF = -1024.0;
@@ -240,7 +243,8 @@ struct Lsd {
         if (n == 0 || k == 0) return -LOG_NT;
         if (n == k) return -LOG_NT - double(n) * std::log10(p);
         double p_term = p / (1 - p);
-        double log1term = log_gamma(double(n) + 1) - log_gamma(double(k) + 1) - log_gamma(double(n - k) + 1)
+        const double first = g_lsdNfaVariant == 1 ? (double(n) + 1) : log_gamma(double(n) + 1);          // decision D11 (see g_lsdNfaVariant)
+        double log1term = first - log_gamma(double(k) + 1) - log_gamma(double(n - k) + 1)
                           + double(k) * std::log(p) + double(n - k) * std::log(1.0 - p);
         double term = std::exp(log1term);
         if (double_equal(term, 0)) {
@@ -444,6 +448,7 @@ void lsd_detect_keylines(const Img8& image, std::vector<KeyLine>& keylines, std:
 
 // test taps: the NFA of (n, k, p) for an image of w x h pixels, and cv::Sobel 3x3 as the LBD stage calls it
 extern "C" int orc_set_lsd_resize(int v) { const int old = orc::g_lsdResize; orc::g_lsdResize = v == 1 ? 1 : 0; return old; }
+extern "C" int orc_set_lsd_nfa_variant(int v) { const int old = orc::g_lsdNfaVariant; orc::g_lsdNfaVariant = v == 1 ? 1 : 0; return old; }
 extern "C" int orc_set_lsd_seed_sort(int v) { const int old = orc::g_lsdSeedSort; orc::g_lsdSeedSort = v == 1 ? 1 : 0; return old; }
 extern "C" double orc_lsd_nfa(int w, int h, int n, int k, double p) {
     Lsd lsd; lsd.w = w; lsd.h = h;

@@ -793,6 +793,13 @@ def unmatched(a, b, tol=1.0):
 
 
 d2 = {"frames": 0, "segments": 0, "segments_in_one_set_only": 0, "segments_moved_more_than_1px": 0}; d7 = {"frames": 0, "segments": 0, "segments_in_one_set_only": 0, "segments_moved_more_than_1px": 0}
+# D11 (nfa()'s first term: log_gamma(n + 1) | (double(n) + 1)) and D12 (LBD bit order: 1 << i | 0x80 >> i): the same kind of row -- oracle against oracle, the size of what the
+# decision moves.  Both alternatives are selectable in the library too (sslam_lines_set_nfa_variant / _lbd_bit_order; tests/test_variants_gpu.py compares library and oracle under each).
+d11 = {"frames": 0, "segments": 0, "segments_variant_1": 0, "segments_in_both": 0, "segments_in_one_set_only": 0, "segments_moved_more_than_1px": 0,
+       "keylines_after_cap_200": 0, "keylines_after_cap_200_variant_1": 0}
+d12 = {"frames": 0, "lines": 0, "lbd_bytes": 0, "lbd_bytes_differing": 0, "lbd_bytes_not_the_bit_reversal": 0, "hamming_distances_differing": 0, "line_matcher_results_differing": 0}
+_rev = np.array([int("{:08b}".format(i)[::-1], 2) for i in range(256)], np.uint8)
+_prev = None
 for img in [frames["synth1234"][0], frames["synth2000"][0], frames["big1235"][0], synth_frame(2001), synth_frame(2002), synth_frame(91, w=333, h=251),
             np.load(os.path.join(HERE, "..", "..", "tests", "golden", "icl_input_gray.npz"))["gray"]]:
     a = orc.lines_extract(img, 400)[3]
@@ -804,6 +811,29 @@ for img in [frames["synth1234"][0], frames["synth2000"][0], frames["big1235"][0]
         sb = set(map(bytes, b.view(np.uint8).reshape(len(b), -1)))
         acc["frames"] += 1; acc["segments"] += len(sa); acc["segments_in_one_set_only"] += len(sa ^ sb)
         acc["segments_moved_more_than_1px"] += unmatched(a, b) + unmatched(b, a)
+    # D11
+    O.orc_set_lsd_nfa_variant(1)
+    try: r1 = orc.lines_extract(img, 200)
+    finally: O.orc_set_lsd_nfa_variant(0)
+    r0 = orc.lines_extract(img, 200)
+    b = r1[3]; sb = set(map(bytes, b.view(np.uint8).reshape(len(b), -1)))
+    d11["frames"] += 1; d11["segments"] += len(sa); d11["segments_variant_1"] += len(sb); d11["segments_in_both"] += len(sa & sb); d11["segments_in_one_set_only"] += len(sa ^ sb)
+    d11["segments_moved_more_than_1px"] += unmatched(a, b) + unmatched(b, a); d11["keylines_after_cap_200"] += len(r0[0]); d11["keylines_after_cap_200_variant_1"] += len(r1[0])
+    # D12
+    O.orc_set_lbd_bit_order(1)
+    try: q1 = orc.lines_extract(img, 200)
+    finally: O.orc_set_lbd_bit_order(0)
+    d12["frames"] += 1; d12["lines"] += len(r0[0]); d12["lbd_bytes"] += r0[1].size; d12["lbd_bytes_differing"] += int((r0[1] != q1[1]).sum()); d12["lbd_bytes_not_the_bit_reversal"] += int((_rev[r0[1]] != q1[1]).sum())
+    if _prev is not None and len(_prev[0]) >= 2 and len(r0[1]) >= 2:
+        d12["hamming_distances_differing"] += int((orc.hamming_matrix(_prev[0], r0[1]) != orc.hamming_matrix(_prev[1], q1[1])).sum())
+        for gate, ratio in ((0.5, False), (0.1, False), (0.5, True)):
+            m0 = orc.line_match(_prev[0], r0[1], gate, ratio); m1 = orc.line_match(_prev[1], q1[1], gate, ratio)
+            d12["line_matcher_results_differing"] += int(not (np.array_equal(m0[0], m1[0]) and m0[1:] == m1[1:]))
+    _prev = (r0[1], q1[1])
+report["d11_nfa_variant_error_bar_oracle_only"] = d11
+print("D11 (nfa() first term log_gamma(n + 1) vs (n + 1), oracle against oracle):", d11)
+report["d12_lbd_bit_order_oracle_only"] = d12
+print("D12 (LBD bit order 1 << i vs 0x80 >> i, oracle against oracle):", d12)
 report["d7_error_bar_oracle_only"] = d7
 print("D7 (INTER_LINEAR_EXACT vs INTER_LINEAR for LSD's 0.8x scale, oracle against oracle):", d7)
 report["d2_error_bar_oracle_only"] = d2

@@ -66,6 +66,8 @@ struct sslam_ctx {
     std::recursive_mutex mu;       // every entry point serialises on the context (SURVEY §8b threading); recursive: the host forms call the *_batch_dev forms
     sslam::DevBuf scratch[8];      // matcher staging
     sslam::DevBuf knnExpand;       // sslam_hamming_knn2_batch_dev: the train rows as int8 matrix-core operands (match_knn.h)
+    hipEvent_t knnDone = nullptr;  // recorded behind the kernel that reads knnExpand: a call on ANOTHER stream waits for it before it overwrites the buffer
+    void* knnLastStream = nullptr;
     sslam::DevBuf recordOffsets[4];   // sslam_pack_records_dev: per-frame offsets of the record stream, one buffer per stream that packs
     void* recordOffsetsStream[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned long recordOffsetsUse[4] = {0, 0, 0, 0}, recordOffsetsClock = 0;      // least-recently-used recycling of the four slots

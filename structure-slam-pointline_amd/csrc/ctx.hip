@@ -76,6 +76,7 @@ extern "C" int sslam_ctx_destroy(sslam_ctx* c) {
     if (c->batchCache && c->batchCacheFree) { c->batchCacheFree(c->batchCache); c->batchCache = nullptr; }
     for (auto& b : c->scratch) b.release();
     c->knnExpand.release();
+    if (c->knnDone) (void)hipEventDestroy(c->knnDone);
     for (auto& b : c->recordOffsets) b.release();
     for (auto& b : c->pinned) b.release();
     (void)hipStreamDestroy(c->stream);

@@ -9,6 +9,7 @@
 // ~80 KB per 640x480 frame that is >4 M frames/s of ingest, two orders of magnitude above what eight GPUs extract; the exchange is
 // latency, not bandwidth.
 #include "common.h"
+#include <atomic>
 #include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
@@ -63,7 +64,7 @@ Rccl* rccl_real() {
     return R.h ? &R : nullptr;
 }
 
-// ------------------------------------------------------------------ SSLAM_GROUP_FAKE_RCCL=1: an in-process stand-in for the RCCL entry points
+// ------------------------------------------------------------------ sslam_testing_use_rccl_standin(1) (include/sslam_testing.h): an in-process stand-in for the RCCL entry points
 // N > 1 has never run on hardware here (one GPU per box), so the group code's multi-member paths -- a host thread per device, uneven tails,
 // the collective error agreement, grouped send / receive to the root -- had no execution at all.  With this table selected at group creation
 // the "devices" of a group are contexts (streams) of whatever GPUs are visible, dealt round-robin, and the collectives are host-mediated
@@ -89,8 +90,19 @@ std::vector<std::pair<NcclUid, FakeWorld*>> gFakeWorlds;      // worlds being as
 int gFakeIdCounter = 0;
 
 size_t fake_dtype_bytes(int dt) { return dt == kNcclUint64 ? 8 : 1; }
+int fake_flush_ops(std::vector<FakeOp>& ops);
 int fake_flush() {
     std::vector<FakeOp> ops; ops.swap(tFakeOps);
+    const int rc = fake_flush_ops(ops);
+    if (rc != 0)      // an error leaves nothing behind: the rank's own posted sends (device pointers that may die with the caller's buffers) are withdrawn, or a later receive could match them
+        for (FakeOp& o : ops) if (o.kind == 0 && o.id) {
+            std::lock_guard<std::mutex> lk(o.c->w->mu);
+            for (size_t i = 0; i < o.c->w->box.size(); ++i) if (o.c->w->box[i].id == o.id) { o.c->w->box.erase(o.c->w->box.begin() + i); break; }
+            o.c->w->cv.notify_all();
+        }
+    return rc;
+}
+int fake_flush_ops(std::vector<FakeOp>& ops) {
     // sends first: publish (the data must be final: drain the sender's stream), then receives (wait for the partner's publication, copy,
     // acknowledge), then wait until every own send was taken -- a rank that posts both directions in one group cannot block itself
     for (FakeOp& o : ops) if (o.kind == 0) {
@@ -192,14 +204,16 @@ Rccl* rccl_fake() {
     });
     return &F;
 }
-bool fake_rccl_requested() { const char* e = getenv("SSLAM_GROUP_FAKE_RCCL"); return e && atoi(e) != 0; }
+// selected by a TEST entry point only (sslam_testing_use_rccl_standin, include/sslam_testing.h) -- no environment variable changes which library a product group binds
+std::atomic<int> gStandinRequested{0};
+bool fake_rccl_requested() { return gStandinRequested.load() != 0; }
 // the table a NEW group binds (kept in the group: a process may hold real and stand-in groups side by side)
 Rccl* rccl() { return fake_rccl_requested() ? rccl_fake() : rccl_real(); }
-#define SSLAM_NCCL(expr)                                                                                              \
+#define SSLAM_NCCL(api, expr)                                                                                         \
     do {                                                                                                              \
         int _r = (expr);                                                                                              \
         if (_r != 0) {                                                                                                \
-            sslam::set_error("%s failed (rccl status %d)", #expr, _r);                                               \
+            sslam::set_error("%s failed: %s (rccl status %d)", #expr, (api) && (api)->GetErrorString ? (api)->GetErrorString(_r) : "rccl error", _r);      \
             return SSLAM_ERR_HIP;                                                                                     \
         }                                                                                                             \
     } while (0)
@@ -278,7 +292,7 @@ struct Member {       // one GPU of a single-process group
 struct sslam_group {
     int nranks = 1, rank = 0, device = 0;
     bool singleProcess = true;
-    Rccl* api = nullptr;                   // real RCCL, or the in-process stand-in (SSLAM_GROUP_FAKE_RCCL=1 when the group was created)
+    Rccl* api = nullptr;                   // real RCCL, or the in-process stand-in (sslam_testing_use_rccl_standin(1) when the group was created)
     std::vector<Member> mem;               // single-process: one per device; rank form: one
     sslam_frontend_params params{};
     bool haveParams = false;
@@ -375,6 +389,10 @@ static void member_release(Member& m) {
     m = Member();
 }
 
+// TEST entry point (include/sslam_testing.h): groups created while this is on bind the in-process stand-in above instead of librccl, and may hold more members than
+// GPUs are visible (dealt round-robin).  Returns the previous setting.
+extern "C" int sslam_testing_use_rccl_standin(int on) { return gStandinRequested.exchange(on ? 1 : 0); }
+
 extern "C" int sslam_group_create(int ngpu, sslam_group** out) {
     if (!out || ngpu <= 0 || ngpu > 64) { set_error("sslam_group_create: invalid arguments"); return SSLAM_ERR_INVALID; }
     int have = 0;
@@ -404,7 +422,7 @@ extern "C" int sslam_group_unique_id(uint8_t id_out[SSLAM_GROUP_ID_BYTES]) {
     if (!id_out) return SSLAM_ERR_INVALID;
     if (!rccl()) { set_error("sslam_group_unique_id: librccl.so.1 could not be loaded"); return SSLAM_ERR_UNSUPPORTED; }
     NcclUid u;
-    SSLAM_NCCL(rccl()->GetUniqueId(&u));
+    SSLAM_NCCL(rccl(), rccl()->GetUniqueId(&u));
     memcpy(id_out, u.internal, SSLAM_GROUP_ID_BYTES);
     return SSLAM_OK;
 }
@@ -461,7 +479,7 @@ extern "C" int sslam_group_gather_dev(sslam_group* g, const uint8_t* d_send, con
     hPair[1] = g->rank == 0 ? recv_capacity : 0;
     SSLAM_HIP(hipMemcpyAsync(dPair, d_send_bytes, 8, hipMemcpyDeviceToDevice, st));
     SSLAM_HIP(hipMemcpyAsync(dPair + 1, hPair + 1, 8, hipMemcpyHostToDevice, st));
-    SSLAM_NCCL(R->AllGather(dPair, dAll, 2, kNcclUint64, comm, st));
+    SSLAM_NCCL(R, R->AllGather(dPair, dAll, 2, kNcclUint64, comm, st));
     SSLAM_HIP(hipMemcpyAsync(hAll, dAll, 16 * (size_t)g->nranks, hipMemcpyDeviceToHost, st));
     SSLAM_HIP(hipStreamSynchronize(st));
     std::vector<uint64_t> hSv((size_t)g->nranks);
@@ -479,7 +497,7 @@ extern "C" int sslam_group_gather_dev(sslam_group* g, const uint8_t* d_send, con
     // 2. payload: one grouped send / receive per peer; the root's own stream is a device-to-device copy (or, for tests on one GPU, a
     //    self send/recv through RCCL with SSLAM_GROUP_SELF_SENDRECV=1)
     const bool selfRccl = getenv("SSLAM_GROUP_SELF_SENDRECV") != nullptr;
-    SSLAM_NCCL(R->GroupStart());
+    SSLAM_NCCL(R, R->GroupStart());
     int rcN = 0;
     if (g->rank == 0) {
         uint64_t off = 0;

@@ -334,6 +334,7 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
         unsigned r = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) if (f1[i] > f2[i]) r += 1u << i;
+        if (P.lbdBitOrder) r = __brev(r) >> 24;          // decision D12's alternative: comparison i -> 0x80 >> i
         descOut[((size_t)b * cap + li) * 32 + lane] = (uint8_t)r;
     }
 }

@@ -81,6 +81,8 @@ struct sslam_lines {
     HostPinned hOut;
     bool constsUploaded = false;
     int blurVariant = 0;            // sslam_lines_set_blur_variant
+    int nfaVariant = 0, lbdBitOrder = 0, lsdResize = 0;      // sslam_lines_set_nfa_variant / _lbd_bit_order / _resize_variant (decisions D11, D12, D7)
+    int seedOrder = 0;              // sslam_lines_set_seed_order (decision D2): 1 = the seeds are ordered by the host's std::sort
     int sMin = 0;                   // smallest |g|^2 of a defined pixel (k_grad_smin, with the gradient table)
     hipStream_t nfaStream = nullptr; hipEvent_t nfaFork = nullptr, nfaJoin = nullptr;      // SSLAM_NFA_STREAM=1: the NFA stage next to the cluster form of the core
 };
@@ -140,7 +142,7 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     for (int t : t5) if (t < 0 || t > 255) { set_error("blur taps do not fit a byte"); return SSLAM_ERR_UNSUPPORTED; }
     for (int i = 0; i < 7; ++i) P.blurTaps[i] = t7[i];
     for (int i = 0; i < 5; ++i) P.blur5Taps[i] = t5[i];
-    // INTER_LINEAR_EXACT tables (D7)
+    // INTER_LINEAR_EXACT tables (D7): {source offset, q8 coefficient of the second tap}
     std::vector<int> tabs;
     auto coeffs = [&](double inv_scale, int ssz, int dsz) {
         double scale = 1.0 / inv_scale;
@@ -152,8 +154,23 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
             tabs.push_back(ofs); tabs.push_back(c1);
         }
     };
-    P.tabX = 0; coeffs(SCALE, w, P.sw);
-    P.tabY = (int)tabs.size(); coeffs(SCALE, h, P.sh);
+    // D7's alternative (sslam_lines_set_resize_variant(1)): cv::resize(..., dsize, 0, 0, INTER_LINEAR) for 8u -- {source offset, a0 | a1 << 16} with the reference's own
+    // float arithmetic: fx = (float)((dx + 0.5) * scale - 0.5), sx = floor, fx -= sx, clamped at both ends, each coefficient cvRound(c * 2048) on its own
+    auto coeffs_linear = [&](int ssz, int dsz) {
+        const double scale = 1.0 / ((double)dsz / ssz);
+        for (int v = 0; v < dsz; ++v) {
+            float fv = (float)(((double)v + 0.5) * scale - 0.5);
+            int iv = (int)std::floor(fv);
+            fv -= (float)iv;
+            if (iv < 0) { fv = 0.f; iv = 0; }
+            if (iv >= ssz - 1) { fv = 0.f; iv = ssz - 1; }
+            const int a0 = (int)lrintf((1.f - fv) * 2048.f), a1 = (int)lrintf(fv * 2048.f);
+            tabs.push_back(iv); tabs.push_back(a0 | (a1 << 16));
+        }
+    };
+    P.nfaVariant = L->nfaVariant; P.lbdBitOrder = L->lbdBitOrder; P.lsdResize = L->lsdResize;
+    P.tabX = 0; if (P.lsdResize) coeffs_linear(w, P.sw); else coeffs(SCALE, w, P.sw);
+    P.tabY = (int)tabs.size(); if (P.lsdResize) coeffs_linear(h, P.sh); else coeffs(SCALE, h, P.sh);
     int rc;
     if ((rc = L->dTabs.ensure(tabs.size() * sizeof(int)))) return rc;
     SSLAM_HIP(hipMemcpy(L->dTabs.p, tabs.data(), tabs.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -169,13 +186,8 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offBlur = take(bpitch * h);                         // sigma-0.75 blur of the source (LSD)
     P.tW = P.sw; P.cW = P.sw;
     P.offT = take(sizeof(float) * (size_t)P.npx);
-#if SSLAM_LSD_PACKED
-    P.offCs = take(16 * (size_t)P.npx);      // {cos, sin, |g|^2, -} records
-    P.offS = P.offCs + 8;
-#else
     P.offS = take(sizeof(int) * (size_t)P.npx);
     P.offCs = take(sizeof(float2) * (size_t)P.npx);
-#endif
     P.offOrder = take(sizeof(unsigned) * (size_t)P.npx);
     P.offTileHist = take(sizeof(int) * (size_t)P.nTiles * N_BINS);
     P.offReg = take(sizeof(unsigned) * std::max((size_t)P.npx, (size_t)P.sh * P.nXB * 256));      // region lists beyond QCAP; before the core: the segments' lists
@@ -221,6 +233,51 @@ extern "C" int sslam_lines_set_blur_variant(sslam_lines* L, int variant) {
     if (!L || (variant != 0 && variant != 1)) { set_error("sslam_lines_set_blur_variant: invalid arguments"); return SSLAM_ERR_INVALID; }
     std::lock_guard<std::recursive_mutex> lk(L->ctx->mu);
     if (L->blurVariant != variant) { L->blurVariant = variant; L->planW = L->planH = 0; }      // the taps are part of the plan: rebuilt (and uploaded) by the next extraction
+    return SSLAM_OK;
+}
+
+// The other stated decisions of the line path that have a selectable alternative (include/sslam_frontend.h).  Each is part of the plan: the next
+// extraction rebuilds it.  which: 0 = nfa() first term (D11), 1 = LBD bit order (D12), 2 = the 0.8x rescale (D7).
+static int lines_set_variant(sslam_lines* L, int which, int variant, const char* name) {
+    if (!L || (variant != 0 && variant != 1)) { set_error("%s: invalid arguments", name); return SSLAM_ERR_INVALID; }
+    std::lock_guard<std::recursive_mutex> lk(L->ctx->mu);
+    int& field = which == 0 ? L->nfaVariant : which == 1 ? L->lbdBitOrder : which == 2 ? L->lsdResize : L->seedOrder;
+    if (field != variant) { field = variant; L->planW = L->planH = 0; }
+    return SSLAM_OK;
+}
+extern "C" int sslam_lines_set_nfa_variant(sslam_lines* L, int variant) { return lines_set_variant(L, 0, variant, "sslam_lines_set_nfa_variant"); }
+extern "C" int sslam_lines_set_lbd_bit_order(sslam_lines* L, int variant) { return lines_set_variant(L, 1, variant, "sslam_lines_set_lbd_bit_order"); }
+extern "C" int sslam_lines_set_resize_variant(sslam_lines* L, int variant) { return lines_set_variant(L, 2, variant, "sslam_lines_set_resize_variant"); }
+extern "C" int sslam_lines_set_seed_order(sslam_lines* L, int variant) { return lines_set_variant(L, 3, variant, "sslam_lines_set_seed_order"); }
+
+// Decision D2's alternative (sslam_lines_set_seed_order(1)): upstream's ll_angle (imgproc/src/lsd.cpp, UPSTREAM-RECALL) fills a vector of {point, bin} in raster order over
+// the (w - 1) x (h - 1) pixels that have a gradient and calls std::sort with `a.norm > b.norm` -- an unstable introsort, so the order inside a bin is whatever libstdc++'s
+// algorithm leaves.  That permutation is the result of ~17 n dependent comparisons: it is produced HERE, on the host, by the same std::sort over the keys the device computed
+// (k_lsd_grad<DENSE> left |g|^2 of every pixel in S), and uploaded as the frame's seed list in place of the device's counting sort.  Synchronous, ~15 ms per 640x480 frame.
+static int lines_host_seed_order(sslam_lines* L, uint8_t* ws, int nframes, hipStream_t st) {
+    const LsdPlan& P = L->plan;
+    struct NormPoint { int x, y, norm; };
+    std::vector<int> S((size_t)P.npx);
+    std::vector<NormPoint> pts;
+    std::vector<unsigned> order;
+    SSLAM_HIP(hipStreamSynchronize(st));
+    for (int b = 0; b < nframes; ++b) {
+        uint8_t* base = ws + (size_t)b * P.frameBytes;
+        Misc m;
+        SSLAM_HIP(hipMemcpy(&m, base + P.offMisc, sizeof(m), hipMemcpyDeviceToHost));
+        SSLAM_HIP(hipMemcpy(S.data(), base + P.offS, sizeof(int) * (size_t)P.npx, hipMemcpyDeviceToHost));
+        const double maxGrad = m.maxS > 0 ? std::sqrt((double)m.maxS / 4.0) : -1.0;
+        const double binCoef = maxGrad > 0 ? (double)(N_BINS - 1) / maxGrad : 0.0;
+        pts.clear(); pts.reserve((size_t)(P.sw - 1) * (P.sh - 1));
+        for (int y = 0; y < P.sh - 1; ++y)
+            for (int x = 0; x < P.sw - 1; ++x) pts.push_back({x, y, (int)(std::sqrt((double)S[(size_t)y * P.sw + x] / 4.0) * binCoef)});
+        std::sort(pts.begin(), pts.end(), [](const NormPoint& a, const NormPoint& c) { return a.norm > c.norm; });
+        order.clear();
+        for (const NormPoint& q : pts) if (S[(size_t)q.y * P.sw + q.x] >= P.sMin) order.push_back((unsigned)q.x | ((unsigned)q.y << 16));      // defined pixels only, as the device's list
+        m.nDefined = (int)order.size();
+        if (!order.empty()) SSLAM_HIP(hipMemcpy(base + P.offOrder, order.data(), sizeof(unsigned) * order.size(), hipMemcpyHostToDevice));
+        SSLAM_HIP(hipMemcpy(base + P.offMisc + offsetof(Misc, nDefined), &m.nDefined, sizeof(int), hipMemcpyHostToDevice));
+    }
     return SSLAM_OK;
 }
 
@@ -285,11 +342,21 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     // LSD: blur(7, 0.75) -> 0.8x -> gradient
     { sslam::ProfScope _ps(L->ctx, "k_blur7", st); hipLaunchKernelGGL(k_blur7, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride,
                        ws + P.offBlur, bpitch, P.frameBytes, w, h, taps); }
-    { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st); hipLaunchKernelGGL(k_lsd_grad, dim3(P.nXB, (P.sh + 4 * GRAD_ROWS - 1) / (4 * GRAD_ROWS), nframes), dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>(), bpitch,
-                                                                        L->dTabs.as<int>() + P.tabX, L->dTabs.as<int>() + P.tabY); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st);
+      const dim3 gg(P.nXB, (P.sh + 4 * GRAD_ROWS - 1) / (4 * GRAD_ROWS), nframes);
+      const int* tabX = L->dTabs.as<int>() + P.tabX; const int* tabY = L->dTabs.as<int>() + P.tabY;
+      switch ((P.lsdResize ? 1 : 0) | (L->seedOrder ? 2 : 0)) {
+          case 0: hipLaunchKernelGGL(k_lsd_grad<0>, gg, dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>(), bpitch, tabX, tabY); break;
+          case 1: hipLaunchKernelGGL(k_lsd_grad<1>, gg, dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>(), bpitch, tabX, tabY); break;
+          case 2: hipLaunchKernelGGL(k_lsd_grad<2>, gg, dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>(), bpitch, tabX, tabY); break;
+          default: hipLaunchKernelGGL(k_lsd_grad<3>, gg, dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>(), bpitch, tabX, tabY); break;
+      } }
+    if (L->seedOrder) { if ((rc = lines_host_seed_order(L, ws, nframes, st))) return rc; }
+    else {
     { sslam::ProfScope _ps(L->ctx, "k_lsd_hist", st); hipLaunchKernelGGL(k_lsd_hist, dim3(sort_grid(P.nTiles, nframes)), dim3(64), 0, st, ws, P, nframes); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scan", st); hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter, dim3(sort_grid(P.nTiles, nframes)), dim3(64), 0, st, ws, P, nframes); }
+    }
     bool nfaStreamed = false; size_t nfaStageOff = 0;
     {
         size_t lds = sizeof(unsigned) * (QCAP + 4);      // + the sink slot behind the queue (region_grow_w)
@@ -302,31 +369,17 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         if (L->coreEvent) SSLAM_HIP(hipEventRecord(L->coreEvent, st));
         sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st);
         bool lone = nframes < 1024;
-        // a frame that gets a CU to itself: one main wave + helper waves running flsd()'s per-seed body ahead of it (lsd_regions.h, multi-wave form).
-        // LDS: the kernel's static arrays + main queue, per helper its chunk slots and its private torus, and the shared map that steers the
-        // helpers' seed choice (per 2 x 2 cell by default; SSLAM_MW_SMAP: -1 none, 0 one bit per pixel, 1 / 2 coarser)
-        const size_t mwBase = lds + sizeof(MwSlot) * MW_HMAX * MW_NSLOT + 20 * 1024, perHelper = sizeof(unsigned) * ((size_t)MW_RING + MW_BM_WORDS);
-        int specShift = 1, specWords = 0, nHelpers = 0;
-        if (const char* e = getenv("SSLAM_MW_SMAP")) specShift = atoi(e);
-        for (; specShift <= 3; ++specShift) {
-            specWords = specShift < 0 ? 0 : (((P.sw + (1 << specShift) - 1) >> specShift) * ((P.sh + (1 << specShift) - 1) >> specShift) + 31) / 32;
-            const size_t fixed = mwBase + sizeof(unsigned) * specWords;
-            nHelpers = 160 * 1024 > fixed ? (int)std::min<size_t>(MW_HMAX, (160 * 1024 - fixed) / perHelper) : 0;
-            if (nHelpers >= std::min(MW_HMAX, 5) || specShift < 0) break;      // a coarser map rather than fewer helpers (large frames)
-        }
-        bool mw = nframes <= 256 && nHelpers >= 1;
-        if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) { lone = e[0] == 'l' || e[0] == 'm' || e[0] == 'c'; mw = (e[0] == 'm' || e[0] == 'c') && nHelpers >= 1; }      // experiment knob: "cl" / "mw" / "lat" / "thr"
-        if (const char* e = getenv("SSLAM_LSD_HELPERS")) nHelpers = std::max(1, std::min(nHelpers, atoi(e)));
+        if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) lone = e[0] == 'l' || e[0] == 'c';      // experiment knob: "cl" / "lat" / "thr"
         // Up to 64 frames (one to eight per XCD) whose frame-wide bitmap fits the main wave's LDS: the cluster form -- helper waves on several compute
-        // units, results through global memory, monotonic pixel map (lsd_cluster.h).  SSLAM_LSD_CLUSTER=0 (or SSLAM_LSD_FLAVOUR=mw) keeps the
-        // multi-wave form; SSLAM_CL_WGS = workgroups per frame (4 waves each), SSLAM_CL_WINDOW = how many sub-chunks of 16 seed positions the
+        // units, results through global memory, monotonic pixel map (lsd_cluster.h).  SSLAM_LSD_CLUSTER=0 (or SSLAM_LSD_FLAVOUR=lat) takes lone
+        // waves instead; SSLAM_CL_WGS = workgroups per frame (4 waves each), SSLAM_CL_WINDOW = how many sub-chunks of 16 seed positions the
         // helpers may run ahead, SSLAM_CL_SMAP = cell size (log2) of the shared map that steers their seed choice (-1: none).
         int CL_MAXFRAMES = 64;      // up to eight frames per XCD, four workgroups each.  Per call, cluster against multi-wave form (tools/small_batch_probe.py):
                                     // 1 frame 5.9 / 7.9 ms, 8: 8.5 / 11.2, 16: 9.0 / 11.9, 24: 9.4 / 12.6, 32: 10.3 / 13.1, 64: 13.5 / 15.7, 96: 21.6 / 15.9
         if (const char* e = getenv("SSLAM_CL_MAXFRAMES")) CL_MAXFRAMES = std::max(1, std::min(128, atoi(e)));      // experiment knob
         const bool bigFrame = P.sw > TorusFrame::XMASK + 1 || P.sh > TorusFrame::YMASK + 1;      // the main wave's bitmap in global memory instead of LDS
         bool cluster = nframes <= CL_MAXFRAMES && P.sw <= TorusGlobal::XMASK + 1 && P.sh <= TorusGlobal::YMASK + 1;
-        if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) cluster = cluster && e[0] == 'c';      // "cl" / "mw" / "lat" / "thr"
+        if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) cluster = cluster && e[0] == 'c';      // "cl" / "lat" / "thr"
         if (const char* e = getenv("SSLAM_LSD_CLUSTER")) cluster = cluster && atoi(e) != 0;
         if (cluster) {
             int nWG = 10, window = 0, clShift = 0;
@@ -341,9 +394,10 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             // per frame: the zeroed head, two result records per seed position, one 256 KB list arena per HELPER THAT EXISTS ((nWG - 1) x CL_HPW: 27 by default;
             // rounds 1-3 sized it for 64).  One slot per frame of the call: blocks with b >= nframes return at once, so the XCD-aligned grid needs no padding slots
             // (a single 640x480 frame held 8 slots of 30 MB before).
-            // SSLAM_NFA_STREAM=1 (experiment knob, off by default): the NFA stage runs NEXT TO the core on a second stream, on the rectangles the main wave
-            // has published so far (lsd_nfa.h, k_nfa_stream); =n > 1: n consumer waves per frame (default 16)
-            int nfaStreamWaves = 0;
+            // The NFA stage runs NEXT TO the core on a second stream, on the rectangles the main wave has published so far (lsd_nfa.h, k_nfa_stream) -- the default since round 5
+            // (whole GPU suite with the knob exported, single frames 6.02 / 7.18 -> 5.76 / 6.89 ms p50 / p90, calls of 2 .. 64 frames -8 .. -24 %: profiles/r05a_*).
+            // SSLAM_NFA_STREAM=0: the stage behind the core as one launch (the round-4 default); =n > 1: n consumer waves per frame (default 16)
+            int nfaStreamWaves = 16;
             if (const char* e = getenv("SSLAM_NFA_STREAM")) { nfaStreamWaves = atoi(e); if (nfaStreamWaves == 1) nfaStreamWaves = 16; nfaStreamWaves = std::max(0, std::min(64, nfaStreamWaves)); }
             const size_t stageOff = zeroBytes + maxSubs * CL_RES * sizeof(ClRec) + 4 * (size_t)CL_ARENA * (size_t)std::max(1, (nWG - 1) * CL_HPW);      // (k_lsd_regions_cl_stream: cl.candStage)
             const size_t clFrame = align_up(stageOff + (nfaStreamWaves ? sizeof(double) * 12 * (size_t)MAX_SEG : 0), 4096);
@@ -368,27 +422,14 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
                 if (const char* e = getenv("SSLAM_NFA_STREAM_SLEEP")) nfaSleep = std::max(0, std::min(64, atoi(e)));
                 if (const char* e = getenv("SSLAM_NFA_STREAM_LDS")) nfaLdsPad = (size_t)std::max(0, std::min(48 * 1024, atoi(e)));
                 SSLAM_HIP(hipEventRecord(L->nfaFork, st));      // (the prologue's planes and the zeroed slot heads are what the consumers need)
-                // SSLAM_NFA_STREAM_EMIT=lds (not yet run on a GPU): the main wave hands its rectangles to a publisher wave of its workgroup through LDS instead of writing them
-                // to memory itself (lsd_cluster.h, STREAM == 2: one candidate for the streaming kernel's slower core is its sc1 stores delaying its next loads)
-                const char* emitForm = getenv("SSLAM_NFA_STREAM_EMIT");
-                if (emitForm && emitForm[0] == 'l') {
-                    const size_t clLds2 = std::max(clLds, sizeof(unsigned) * ((size_t)QCAP + 4 + (bigFrame ? 0 : TorusFrame::WORDS) + CL_SCAN + CL_RING_WORDS) + 16 + sizeof(ClEmitRing));
-                    SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl_stream2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds2));
-                    hipLaunchKernelGGL(k_lsd_regions_cl_stream2, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds2, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
-                } else {
                 SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
                 hipLaunchKernelGGL(k_lsd_regions_cl_stream, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
-                }
                 SSLAM_HIP(hipStreamWaitEvent(L->nfaStream, L->nfaFork, 0));
                 if ((rc = sslam::launch_nfa_stream(L->ctx, L->nfaStream, ws, &P, sizeof(P), L->dLgam.as<double>(), L->dCl.as<uint8_t>(), clFrame, stageOff, nframes, nfaStreamWaves, spinTicks, nfaLdsPad, nfaTakeMax, nfaSleep, nullptr))) return rc;
                 SSLAM_HIP(hipEventRecord(L->nfaJoin, L->nfaStream));
                 nfaStreamed = true; nfaStageOff = stageOff;
             } else
             hipLaunchKernelGGL(k_lsd_regions_cl, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
-        } else if (mw) {
-            const size_t mwLds = lds + sizeof(unsigned) * ((size_t)nHelpers * ((size_t)MW_RING + MW_BM_WORDS) + specWords);
-            SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_mw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mwLds));
-            hipLaunchKernelGGL(k_lsd_regions_mw, dim3(nframes), dim3(64 * (1 + MW_HMAX)), mwLds, st, ws, P, nHelpers, specWords, specShift);
         } else if (lone) hipLaunchKernelGGL(k_lsd_regions<true>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);      // lone waves: shortest chain
         else {
             int grid = nframes;

@@ -34,27 +34,14 @@ int launch_nfa_stage(sslam_ctx* ctx, hipStream_t st, uint8_t* ws, const void* pl
     if (const char* e = getenv("SSLAM_EVAL_WAVES")) evalWaves = std::max(1, atoi(e));
     // The whole NFA stage as ONE launch (lsd_nfa.h): one wave per frame when the frames themselves fill the chip (k_nfa_all, calls of >= 2048 frames).
     // Below that the 18 launches stay: a single frame's stage is bound by the work of each wave, not by launch boundaries (kernel durations add up
-    // to the stage's 0.6 ms), and the one-workgroup form (k_nfa_all_wg, sixteen waves) has a quarter of the counting waves: measured 6.42 / 7.70 ms
-    // p50 / p90 per frame against 6.25 / 7.40 (eight waves: 6.66).  What helped instead: 128 counting and 32 evaluating waves per frame (6.09 / 7.16).
-    // SSLAM_NFA_WAVES=n forces the workgroup form with n waves, SSLAM_NFA_FUSED=0 the launches, =2 the one-wave form (tests).
-    int nfaWaves = 0;
-    if (const char* e = getenv("SSLAM_NFA_WAVES")) nfaWaves = std::max(1, std::min(16, atoi(e)));
-    bool nfaFused = nfaWaves > 0 || (countWaves == 1 && evalWaves == 1);
-    if (nfaWaves == 0) nfaWaves = 1;
-    if (const char* e = getenv("SSLAM_NFA_FUSED")) { nfaFused = atoi(e) == 2 || (nfaFused && atoi(e) != 0); if (atoi(e) == 2) nfaWaves = 1; }
-    if (nfaFused && nfaWaves == 1) {
+    // to the stage's 0.6 ms; a one-workgroup form with sixteen waves was measured at 6.42 / 7.70 ms p50 / p90 per frame against 6.25 / 7.40 and removed in round 5).
+    // What helped instead: 128 counting and 32 evaluating waves per frame (6.09 / 7.16).
+    // SSLAM_NFA_FUSED=0 forces the launches, =2 the one-wave form (tests).
+    bool nfaFused = countWaves == 1 && evalWaves == 1;
+    if (const char* e = getenv("SSLAM_NFA_FUSED")) nfaFused = atoi(e) == 2 || (nfaFused && atoi(e) != 0);
+    if (nfaFused) {
         sslam::ProfScope _ps(ctx, "k_nfa_all", st);
         hipLaunchKernelGGL(k_nfa_all, dim3(nframes), dim3(64), 0, st, ws, P, lgam);
-    } else if (nfaFused) {
-        const size_t nfaLds = sizeof(NfaLdsT<WG_CH>) * (size_t)nfaWaves;
-        sslam::ProfScope _ps(ctx, "k_nfa_all", st);
-        if (nfaWaves > 8) {
-            if (nfaLds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_nfa_all_wg<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nfaLds));
-            hipLaunchKernelGGL(k_nfa_all_wg<1024>, dim3(nframes), dim3(64 * nfaWaves), nfaLds, st, ws, P, lgam);
-        } else {
-            if (nfaLds > 48 * 1024) SSLAM_HIP(hipFuncSetAttribute((const void*)k_nfa_all_wg<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nfaLds));
-            hipLaunchKernelGGL(k_nfa_all_wg<512>, dim3(nframes), dim3(64 * nfaWaves), nfaLds, st, ws, P, lgam);
-        }
     } else {
         for (int stage = 0; stage <= 4; ++stage) {
             { static const char* kCountNames[5] = {"k_nfa_count", "k_nfa_count/s1", "k_nfa_count/s2", "k_nfa_count/s3", "k_nfa_count/s4"};

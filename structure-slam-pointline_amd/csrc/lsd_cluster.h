@@ -111,40 +111,6 @@ __device__ __forceinline__ bool cl_spec(const ClShared& cl, int x, int y) {
 #define CL_STAT(i, v)
 #endif
 // ------------------------------------------------------------------ the main wave
-// STREAM == 2 (k_lsd_regions_cl_stream2, SSLAM_NFA_STREAM_EMIT=lds; NOT yet run on a GPU): the main wave hands its rectangles over through LDS, wave 2 of its workgroup -- idle
-// otherwise -- writes them to the staging array and publishes the counters.  Why: measured with STREAM == 1 the core is 190 us slower at 640 x 480 (439 rectangles) and 340 at
-// 1280 x 960 (1 862), consumers or not.  One candidate: vector memory operations of a wave complete in order, so the main wave's next load waits until its twelve sc1 stores have
-// been acknowledged by memory, not by the L2 (the other: the register assignment of another kernel).  With the ring the main wave issues no global store for a
-// rectangle at all (the default issues twelve plain ones).  DS operations of a wave execute in order: record, then `produced`; the publisher reads `finished` (set behind the
-// last record) before `produced`.
-constexpr int CL_EMIT_RING = 64;           // records; one every ~10 us against ~2 us per drain
-struct alignas(16) ClEmitRing { int produced, consumed, pad0, pad1; unsigned long long rec[CL_EMIT_RING][12]; };
-__device__ void cl_publisher(const ClShared& cl, ClLocal* __restrict__ loc) {
-    const int lane = threadIdx.x & 63;
-    ClEmitRing* er = (ClEmitRing*)(loc + 1);
-    NfaStreamCtl* ns = cl_ns(cl.ctl);
-    unsigned long long* staged = (unsigned long long*)(cl.arena + (size_t)CL_ARENA * (size_t)max(1, cl.nHelpers));      // (lines.hip: stageOff)
-    const int rOf = lane / 12, qOf = lane - 12 * rOf;      // five records of twelve words per pass
-    int published = 0;
-    for (;;) {
-        const int fin = __builtin_amdgcn_readfirstlane(lds_ld(&loc->finished));
-        const int p = __builtin_amdgcn_readfirstlane(lds_ld(&er->produced));
-        if (p > published) {
-            const int n = min(p - published, 5);
-            if (rOf < n) {
-                const int r = published + rOf;
-                __hip_atomic_store(staged + (size_t)r * 12 + qOf, er->rec[r & (CL_EMIT_RING - 1)][qOf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            cl_stores_done();
-            published += n;
-            if (lane == 0) { g_st(&ns->candReady, published); __hip_atomic_store(&er->consumed, published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-            continue;
-        }
-        if (fin) break;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    if (lane == 0) g_st(&ns->candFinal, 1 + published);      // (every record is in memory: the wait above)
-}
 // STREAM (k_lsd_regions_cl_stream, SSLAM_NFA_STREAM=1): rectangle records go to the slot's staging array with L1-bypassing stores and a counter of the complete ones is
 // published with every rectangle -- lsd_nfa.h's k_nfa_stream runs the NFA stage on them while this wave goes on.  Nothing else differs, and this wave never waits for it.
 template <class G, int STREAM>      // G: the main wave's private bitmap: TorusFrame (LDS) or TorusGlobal (larger frames)
@@ -160,7 +126,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
     RegQ rq; rq.lds = qLds; rq.glb = (unsigned*)(base + P.offReg);
     const int nOrd = misc->nDefined;
     const double prec = P.prec;
-    int nSeg = 0, emitConsumed = 0; (void)emitConsumed;
+    int nSeg = 0;
     long long clTaken = 0, clOwn = 0, clBad = 0, clWait = 0, clOwnChunks = 0, clRefused = 0;
     long long cWait = 0, cTake = 0, cOwn = 0, cRect = 0, clOwnRefused = 0;
     const long long cStart = CL_CLK();
@@ -443,23 +409,6 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
                 unM &= ~__ballot(usedNow);
             }
             if (!emit) continue;
-            if (STREAM == 2) {
-                if (nSeg < MAX_SEG) {
-                    ClEmitRing* er = (ClEmitRing*)(loc + 1);
-                    while (nSeg - emitConsumed >= CL_EMIT_RING) {      // never in practice; the publisher is a wave of this workgroup, so it runs
-                        emitConsumed = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&er->consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        if (nSeg - emitConsumed >= CL_EMIT_RING) __builtin_amdgcn_s_sleep(2);
-                    }
-                    if (lane == 0) {
-                        unsigned long long* o = er->rec[nSeg & (CL_EMIT_RING - 1)];
-                        const double v[12] = {rec.x1, rec.y1, rec.x2, rec.y2, rec.width, rec.x, rec.y, rec.theta, rec.dx, rec.dy, rec.prec, rec.p};
-#pragma unroll
-                        for (int q = 0; q < 12; ++q) o[q] = (unsigned long long)__double_as_longlong(v[q]);
-                    }
-                    cl_compiler_fence();
-                    if (lane == 0) __hip_atomic_store(&er->produced, nSeg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            } else
             if (STREAM) {
                 if (nSeg < MAX_SEG) {
                     // Publication lags by one record: the stores of record nSeg - 1 were issued a region ago, so the wait in front of the counter costs
@@ -483,7 +432,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
         }
     }
     lds_st(&loc->finished, 1);
-    if (STREAM == 1) { cl_stores_done(); if (lane == 0) g_st(&cl_ns(cl.ctl)->candFinal, 1 + min(nSeg, MAX_SEG)); }      // (STREAM == 2: the publisher does, once loc->finished is set below)
+    if (STREAM) { cl_stores_done(); if (lane == 0) g_st(&cl_ns(cl.ctl)->candFinal, 1 + min(nSeg, MAX_SEG)); }
     if (lane == 0) {
         g_st(&cl.ctl->finished, 1);
         misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
@@ -859,50 +808,3 @@ __global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl_stream(uint8_t
     else if (wave < CL_HPW) cl_helper((role - 1) * CL_HPW + wave, ws, P, b, cl, mine, mine + CL_LIST, stashes[wave], red[wave]);
 }
 
-// The same with the hand-over through LDS and a publisher wave (cl_main<G, 2>, cl_publisher; SSLAM_NFA_STREAM_EMIT=lds).  Dynamic LDS: the main wave's layout + sizeof(ClEmitRing).
-__global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl_stream2(uint8_t* __restrict__ ws, LsdPlan P, uint8_t* __restrict__ clArea, size_t clFrameBytes, int nframes, int nWG,
-                                                                        int specWords, int specShift, int window) {
-    extern __shared__ __align__(16) unsigned dynLds[];
-    __shared__ double red[CL_WAVES][3 * 64];
-    __shared__ float4 stashes[CL_WAVES][64];
-    // blocks with the same (blockIdx % 8) share an XCD; an XCD hosts frames xcd, xcd + 8, xcd + 16, ... (nWG workgroups each)
-    const int j = blockIdx.x >> 3, b = (blockIdx.x & 7) + 8 * (j / nWG), role = j % nWG, wave = threadIdx.x >> 6;
-    const bool nofeed = (window & (1 << 20)) != 0;      // (experiment knob: no feeder wave)
-    if (window >= 0) window &= (1 << 20) - 1;
-    if (b >= nframes) return;
-    uint8_t* area = clArea + (size_t)b * clFrameBytes;
-    ClShared cl;
-    cl.ctl = (ClCtl*)area;
-    const size_t maxSubs = ((size_t)P.npx + CL_SUB - 1) / CL_SUB;
-    cl.sub = (ClSub*)(area + 512);
-    cl.specMap = (unsigned*)(area + 512 + ((maxSubs * sizeof(ClSub) + 511) & ~(size_t)511));
-    cl.bigBm = cl.specMap + ((specWords + 127) & ~127);      // (zeroed with the shared map when the frame is too large for the LDS bitmap; empty otherwise)
-    cl.rec = (ClRec*)(cl.bigBm + ((P.sw > TorusFrame::XMASK + 1 || P.sh > TorusFrame::YMASK + 1) ? TorusGlobal::WORDS : 0));
-    cl.arena = (unsigned*)(cl.rec + maxSubs * CL_RES);
-    cl.specShift = specShift; cl.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
-    cl.nHelpers = (nWG - 1) * CL_HPW; cl.window = window;
-    unsigned* mine = dynLds + (size_t)wave * (CL_LIST + ClTorus::WORDS);      // (helper workgroups)
-    if (role != 0 && wave < CL_HPW) for (int i = threadIdx.x & 63; i < ClTorus::WORDS; i += 64) mine[CL_LIST + i] = 0u;
-    const bool bigFrame = P.sw > TorusFrame::XMASK + 1 || P.sh > TorusFrame::YMASK + 1;      // the main wave's bitmap lives in global memory (zeroed by the host)
-    const int bmWords = bigFrame ? 0 : TorusFrame::WORDS;
-    if (role == 0) {
-        for (int i = threadIdx.x; i < bmWords; i += blockDim.x) dynLds[QCAP + 4 + i] = 0u;
-        ClSlot* ring = (ClSlot*)(dynLds + QCAP + 4 + bmWords + CL_SCAN);
-        if (threadIdx.x < CL_RING) { ring[threadIdx.x].chunk = -1; ring[threadIdx.x].ready = 0; }
-        if (threadIdx.x == 0) { ClLocal* loc = (ClLocal*)(ring + CL_RING); loc->mainChunk = 0; loc->commitSeq = 0; loc->finished = 0; ClEmitRing* er = (ClEmitRing*)(loc + 1); er->produced = 0; er->consumed = 0; }
-    }
-    __syncthreads();
-    if (role == 0) {
-        // the main wave's workgroup: main wave + feeder.  No helpers here: their L1 invalidations cost the main wave 4 % (7.21 -> 6.89 ms)
-        ClSlot* ring = (ClSlot*)(dynLds + QCAP + 4 + bmWords + CL_SCAN);
-        ClLocal* loc = (ClLocal*)(ring + CL_RING);
-        if (wave == 0) {
-            if (bigFrame) cl_main<TorusGlobal, 2>(ws, P, b, dynLds, cl.bigBm, dynLds + QCAP + 4, red[0], stashes[0], cl, ring, loc);
-            else cl_main<TorusFrame, 2>(ws, P, b, dynLds, dynLds + QCAP + 4, dynLds + QCAP + 4 + TorusFrame::WORDS, red[0], stashes[0], cl, ring, loc);
-        }
-        else if (wave == 1 && !nofeed) cl_feeder(ws, P, b, cl, ring, loc);
-        else if (wave == 2) cl_publisher(cl, loc);
-        return;
-    }
-    else if (wave < CL_HPW) cl_helper((role - 1) * CL_HPW + wave, ws, P, b, cl, mine, mine + CL_LIST, stashes[wave], red[wave]);
-}

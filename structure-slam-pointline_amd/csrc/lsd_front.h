@@ -153,7 +153,15 @@ __global__ void k_grad_smin(int* __restrict__ out, double rho) {
 // 16 B written per pixel in round 3 (24 in rounds 1-2); now 4 B + ~24 B per defined pixel.
 // The 0.8x INTER_LINEAR_EXACT image (D7) is never stored: the 2 x 5 scaled pixels a thread needs are recomputed here from the blurred
 // source (four source rows as three aligned dwords each).
+// LIN (decision D7's alternative, LsdPlan::lsdResize = 1): cv::resize(..., INTER_LINEAR) for 8u -- cx = a0 | a1 << 16, cy = b0 | b1 << 16 (the 11-bit coefficient PAIRS of the
+// reference's ialpha / ibeta: each is rounded on its own, they need not sum to 2048) and the 8u two-stage rounding of its vertical pass (oracle/cvleaf.h resize_linear_8u).
+template <bool LIN>
 __device__ __forceinline__ int scaled_px(unsigned e0, unsigned e1, unsigned cx, unsigned cy) {      // e = {p0, p1} bytes of the two source rows
+    if (LIN) {
+        const unsigned a0 = cx & 0xFFFFu, a1 = cx >> 16, b0 = cy & 0xFFFFu, b1 = cy >> 16;
+        const unsigned r0 = __umul24(e0 & 255u, a0) + __umul24((e0 >> 8) & 255u, a1), r1 = __umul24(e1 & 255u, a0) + __umul24((e1 >> 8) & 255u, a1);
+        return (int)(((__umul24(b0, r0 >> 4) >> 16) + (__umul24(b1, r1 >> 4) >> 16) + 2u) >> 2);
+    }
     // (every factor is below 2^17: v_mul_u32_u24 / v_mad_u32_u24, full rate; a 32-bit multiply is quarter rate)
     const unsigned r0 = __umul24(e0 & 255u, 256u - cx) + __umul24((e0 >> 8) & 255u, cx), r1 = __umul24(e1 & 255u, 256u - cx) + __umul24((e1 >> 8) & 255u, cx);
     return (int)((__umul24(r0, 256u - cy) + __umul24(r1, cy) + 32768u) >> 16);
@@ -168,8 +176,12 @@ constexpr int GRAD_ROWS = SSLAM_GRAD_ROWS;            // output rows a wave walk
 #if SSLAM_GRAD_WAVES
 __attribute__((amdgpu_waves_per_eu(SSLAM_GRAD_WAVES, SSLAM_GRAD_WAVES)))
 #endif
+// MODE bit 0 = LIN (D7's alternative, see scaled_px); bit 1 = DENSE (D2's alternative, sslam_lines_set_seed_order(1)): S holds |g|^2 of EVERY pixel, because upstream's
+// std::sort permutes the undefined pixels along with the defined ones and the host needs all the keys.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws, LsdPlan P, const float4* __restrict__ gtab, size_t bpitch,
                                                   const int* __restrict__ tx, const int* __restrict__ ty) {
+    constexpr bool LIN = (MODE & 1) != 0, DENSE = (MODE & 2) != 0;
     const int b = blockIdx.z;
     const uint8_t* base = ws + (size_t)b * P.frameBytes;
     const uint8_t* src = base + P.offBlur;
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
     auto scale_fast = [&](int yy, const unsigned (&d)[2][3], int (&p)[5]) {
         const unsigned cy = (unsigned)tyv[yy].y;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { const int o = ofs[j] - a; p[j] = scaled_px(pick2(d[0][0], d[0][1], d[0][2], o), pick2(d[1][0], d[1][1], d[1][2], o), cx[j], cy); }      // second tap has weight 0 at the last column
+        for (int j = 0; j < 5; ++j) { const int o = ofs[j] - a; p[j] = scaled_px<LIN>(pick2(d[0][0], d[0][1], d[0][2], o), pick2(d[1][0], d[1][1], d[1][2], o), cx[j], cy); }      // second tap has weight 0 at the last column
     };
     auto scale_slow = [&](int yy, int (&p)[5]) {
         const int2 t = tyv[yy];
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int sx = ofs[j], sx1 = min(sx + 1, P.w - 1);
-            p[j] = scaled_px(r0[sx] | ((unsigned)r0[sx1] << 8), r1[sx] | ((unsigned)r1[sx1] << 8), cx[j], (unsigned)t.y);
+            p[j] = scaled_px<LIN>(r0[sx] | ((unsigned)r0[sx1] << 8), r1[sx] | ((unsigned)r1[sx1] << 8), cx[j], (unsigned)t.y);
         }
     };
     int smax = 0;
@@ -224,32 +236,17 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
             const int gx = DA + BC, gy = DA - BC, s = gx * gx + gy * gy;
             gidx[j] = (gy + 510) * GT + (gx + 510);
             if (inx && !lastRow && x4 + j < P.sw - 1 && s >= P.sMin) { flags |= 1u << j; sv[j] = s; }
+            else if (DENSE) sv[j] = s;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (flags & (1u << j)) { const float4 rec = gtab[gidx[j]]; ang[j] = rec.x; cs[j] = make_float2(rec.y, rec.z); }      // the four gathers are in flight together
         const size_t i = (size_t)y * P.sw + x4;
-#if SSLAM_LSD_PACKED
-        // T densely; {cos, sin, |g|^2, -} records under the lanes that hold a defined pixel: the four records of a lane are 64 contiguous bytes
-        float4* rec = (float4*)((char*)Cs + (i << 4));
         if ((P.sw & 3) == 0) {
             if (inx) *(float4*)(T + i) = make_float4(ang[0], ang[1], ang[2], ang[3]);
+            if (DENSE && inx) *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
             if (flags) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rec[j] = make_float4(cs[j].x, cs[j].y, __int_as_float(sv[j]), 0.f);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) {
-                T[i + j] = ang[j];
-                if (flags & (1u << j)) rec[j] = make_float4(cs[j].x, cs[j].y, __int_as_float(sv[j]), 0.f);
-            }
-        }
-#else
-        if ((P.sw & 3) == 0) {
-            if (inx) *(float4*)(T + i) = make_float4(ang[0], ang[1], ang[2], ang[3]);
-            if (flags) {
-                *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
+                if (!DENSE) *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
                 float4* c = (float4*)(Cs + i);
                 c[0] = make_float4(cs[0].x, cs[0].y, cs[1].x, cs[1].y);
                 c[1] = make_float4(cs[2].x, cs[2].y, cs[3].x, cs[3].y);
@@ -258,10 +255,10 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (x4 + j < P.sw) {
                 T[i + j] = ang[j];
+                if (DENSE) S[i + j] = sv[j];
                 if (flags & (1u << j)) { S[i + j] = sv[j]; Cs[i + j] = cs[j]; }
             }
         }
-#endif
         // the segment's list of defined pixels, raster order = lane order, then column inside the lane
         const int seg = y * P.nXB + blockIdx.x;
         const int cnt = __popc(flags), incl = wave_incl_scan(cnt);
@@ -270,7 +267,8 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (flags & (1u << j)) dst[pos++] = ((unsigned)sv[j] << 8) | (unsigned)(4 * lane + j);
         if (lane == 63) segCnt[seg] = incl;
-        smax = max(smax, max(max(sv[0], sv[1]), max(sv[2], sv[3])));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (!DENSE || (flags & (1u << j))) smax = max(smax, sv[j]);
     };
     int pc[5], pn[5];
     if (fast) {

@@ -58,6 +58,7 @@ struct PLog { double lp, l1mp, l10p; };
 // split exponent + fp32 mantissa log is within 1e-7 absolute; the bands below are several times wider than that.
 __device__ __forceinline__ int tail_test_cheap(double term, double m, int q, double bin_tail, double logNT) {
     if (!(m > 0.0 && m < 0.15)) return -1;
+    if (!(term > 1e-280)) return -1;      // the guard bands below are relative: not near the denormals (decision D11's variant 1 reaches them)
     double B = 0.0;
     if (q >= 2) {
         double mq = 0.0;
@@ -127,15 +128,20 @@ __global__ void k_probe_gather16(const float4* __restrict__ buf, size_t nElem, i
 struct TailState { double term, bin_tail, p_term; int n, i; };           // i = next term index (k+1 .. n)
 
 // returns true when the tail loop has to run; otherwise v is the function value
-__device__ __forceinline__ bool nfa_setup(int n, int k, double p, double logNT, const double* __restrict__ lgam, const PLog* __restrict__ plog, TailState& S, double& v) {
+// variant (decision D11, LsdPlan::nfaVariant): 0 = the first term of log1term is log_gamma(n + 1) (the binomial coefficient, von Gioi's lsd.c); 1 = it is (double(n) + 1), as
+// OpenCV's lsd.cpp is recalled to have it.  Under 1 the term is smaller by e^(lgamma(n+1) - (n+1)): it is a denormal for n around 200-240 and an exact 0 beyond.
+__device__ __forceinline__ bool nfa_setup(int n, int k, double p, double logNT, int variant, const double* __restrict__ lgam, const PLog* __restrict__ plog, TailState& S, double& v) {
     if (n == 0 || k == 0) { v = -logNT; return false; }
     const int h = 1020 - ((__double2hiint(p) >> 20) & 0x7FF);        // p is an exact power of two
     const bool tab = h >= 0 && h < 16 && p == ldexp(0.125, -h);
     if (n == k) { v = -logNT - (double)n * (tab ? plog[h].l10p : log10(p)); return false; }
     const double p_term = p / (1 - p);
-    const double log1term = lgam[n + 1] - lgam[k + 1] - lgam[n - k + 1] + (double)k * (tab ? plog[h].lp : log(p)) + (double)(n - k) * (tab ? plog[h].l1mp : log(1.0 - p));
+    const double first = variant ? (double)(n + 1) : lgam[n + 1];
+    const double log1term = first - lgam[k + 1] - lgam[n - k + 1] + (double)k * (tab ? plog[h].lp : log(p)) + (double)(n - k) * (tab ? plog[h].l1mp : log(1.0 - p));
     const double term = exp(log1term);
-    if (term == 0.0) {      // double_equal(term, 0) holds only for an exact zero
+    // double_equal(term, 0): |term| / max(|term|, DBL_MIN) <= 100 * DBL_EPSILON -- an exact zero, or a denormal of at most 100 units (m * 2^-1074 / 2^-1022 = m * 2^-52 <= 100 * 2^-52).
+    // (Rounds 1-4 tested `term == 0.0`: the two differ for log1term in [-745.1, -739.9], which decision D11's variant 1 reaches on ordinary frames; found by tests/test_variants_cpu.py.)
+    if (term <= 0x1.9p-1068) {
         v = ((double)k > (double)n * p) ? -log1term / 2.30258509299404568402 - logNT : -logNT;
         return false;
     }
@@ -179,6 +185,70 @@ __device__ __forceinline__ bool tail_block(TailState& S, double logNT, const dou
     return done || S.i > n;
 }
 
+// ------------------------------------------------------------------ rect_improve as staged, fully parallel kernels
+// rect_improve (LSD_REFINE_ADV) evaluates the rectangle, then five refinement stages of up to five candidate rectangles
+// each; inside a stage the candidates do not depend on which of them is accepted.  Per stage two launches cover every
+// candidate of every frame: k_nfa_count (one wave per rectangle: aligned-point counts of the stage's candidates) and
+// k_nfa_eval (the binomial-tail NFAs of all candidates, lanes scheduled dynamically) + k_nfa_accept (the reference's sequential acceptance).
+struct NfaState { double logNfa; int done, nc; int cnt[6][2]; double val[6]; };      // per rectangle; cnt[k] = {total, aligned}, val[j] = NFA of candidate j
+
+#ifndef SSLAM_NFA_STAGE_ONLY      // (needs the gradient table of lsd_front.h: lines.hip only)
+// Self-test of lsd_align_win.h on the device (sslam_selftest_align_windows): one (theta, tolerance) case per block round -- theta anywhere
+// region2rect can put it ([0, 3pi)), negative, glued to the 0 / 2pi seams or to the pruning edges; tolerances pi/8 * 2^-h and arbitrary
+// ones below pi/2 -- whose windows are compared with the reference predicate (is_aligned_val, lsd_plan.h) on EVERY angle the gradient
+// table holds, on the +-3 neighbours of every end point and on random bit patterns.  out[0] = disagreements, out[1] = tests,
+// out[2] = cases with three non-empty windows (excluded by construction).
+__global__ __launch_bounds__(256) void k_selftest_align(unsigned long long seed, int rounds, unsigned long long* __restrict__ out) {
+    __shared__ int w[6];
+    __shared__ double tp[2];
+    unsigned long long bad = 0, tests = 0;
+    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x + 1) * 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (double)(x >> 11) * 0x1p-53; };
+    for (int rd = 0; rd < rounds; ++rd) {
+        if (threadIdx.x == 0) {
+            const int mode = (int)(rnd() * 8);
+            double theta = -kPI + rnd() * 4 * kPI;
+            if (mode == 0) theta = (rnd() - 0.5) * 0.9;
+            else if (mode == 1) theta = 2 * kPI + (rnd() - 0.5) * 0.9;
+            else if (mode == 2) theta = (double)fast_atan2_deg((float)((int)(rnd() * 1021) - 510), (float)((int)(rnd() * 1021) - 510) + 0.5f) * DEG2RAD;
+            else if (mode == 3) theta = -kPI + rnd() * 0.5;
+            double prec = kPI * (22.5 / 180.0);
+            const int h = (int)(rnd() * 7);
+            for (int i = 0; i < h; ++i) prec /= 2;
+            if (mode == 5) prec = rnd() * 1.5;
+            if (mode == 6) theta = prec * (rnd() < 0.5 ? 1 : -1) + (rnd() - 0.5) * 1e-9 + (rnd() < 0.5 ? 0 : 2 * kPI);
+            int n, lo[2], hi[2];
+            const bool ok = alnwin::windows(theta, prec, n, lo, hi);
+            w[0] = n; w[1] = lo[0]; w[2] = hi[0]; w[3] = lo[1]; w[4] = hi[1]; w[5] = ok ? 0 : 1;
+            tp[0] = theta; tp[1] = prec;
+        }
+        __syncthreads();
+        const double theta = tp[0], prec = tp[1];
+        const int n = w[0], lo0 = w[1], hi0 = w[2], lo1 = w[3], hi1 = w[4];
+        auto check = [&](int b) {
+            if (b < 0 || b > alnwin::BMAX) return;
+            const bool inw = (n > 0 && b >= lo0 && b <= hi0) || (n > 1 && b >= lo1 && b <= hi1);
+            ++tests;
+            if (is_aligned_val(__int_as_float(b), theta, prec) != inw) ++bad;
+        };
+        for (int i = threadIdx.x; i < GT * GT; i += blockDim.x) {
+            const int gy = i / GT - 510, gx = i - (i / GT) * GT - 510;
+            if (gx == 0 && gy == 0) continue;
+            check(__float_as_int(fast_atan2_deg((float)gx, (float)(-gy))));
+        }
+        if (threadIdx.x < 14) { const int d = (int)threadIdx.x % 7 - 3; check((threadIdx.x < 7 ? lo0 : hi0) + d); check((threadIdx.x < 7 ? lo1 : hi1) + d); }
+        for (int i = 0; i < 16; ++i) check((int)(rnd() * (alnwin::BMAX + 1.0)));
+        if (threadIdx.x == 0 && w[5]) atomicAdd(out + 2, 1ull);
+        __syncthreads();
+    }
+    if (bad) atomicAdd(out, bad);
+    atomicAdd(out + 1, tests);
+}
+
+#endif
+
+// Everything below is the stage itself: compiled by lines_nfa.hip only (round 4 compiled it into lines.hip as well -- a second k_nfa_all with 81 spilled VGPRs that nothing launched).
+#ifdef SSLAM_NFA_STAGE_ONLY
 enum { NFA_MAXROWS = 64 };
 struct NfaGeom { int mx, y0, y1, ly, ry, fl, sl, fr, sr; };
 
@@ -278,12 +348,6 @@ __device__ int nfa_max_width(const NfaGeom& g) {
     return best;
 }
 
-// ------------------------------------------------------------------ rect_improve as staged, fully parallel kernels
-// rect_improve (LSD_REFINE_ADV) evaluates the rectangle, then five refinement stages of up to five candidate rectangles
-// each; inside a stage the candidates do not depend on which of them is accepted.  Per stage two launches cover every
-// candidate of every frame: k_nfa_count (one wave per rectangle: aligned-point counts of the stage's candidates) and
-// k_nfa_eval (the binomial-tail NFAs of all candidates, lanes scheduled dynamically) + k_nfa_accept (the reference's sequential acceptance).
-struct NfaState { double logNfa; int done, nc; int cnt[6][2]; double val[6]; };      // per rectangle; cnt[k] = {total, aligned}, val[j] = NFA of candidate j
 
 // candidate j of stage `stage` (0..4) grown from the stage's starting rectangle exactly like rect_improve's loops;
 // false when iteration j is skipped (width floor) — then every later iteration is skipped too.
@@ -493,60 +557,6 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
     for (int j = 0; j < MAXC; ++j) total[j] = wave_sum_dpp(total[j]);
 }
 
-#ifndef SSLAM_NFA_STAGE_ONLY      // (needs the gradient table of lsd_front.h: lines.hip only)
-// Self-test of lsd_align_win.h on the device (sslam_selftest_align_windows): one (theta, tolerance) case per block round -- theta anywhere
-// region2rect can put it ([0, 3pi)), negative, glued to the 0 / 2pi seams or to the pruning edges; tolerances pi/8 * 2^-h and arbitrary
-// ones below pi/2 -- whose windows are compared with the reference predicate (is_aligned_val, lsd_plan.h) on EVERY angle the gradient
-// table holds, on the +-3 neighbours of every end point and on random bit patterns.  out[0] = disagreements, out[1] = tests,
-// out[2] = cases with three non-empty windows (excluded by construction).
-__global__ __launch_bounds__(256) void k_selftest_align(unsigned long long seed, int rounds, unsigned long long* __restrict__ out) {
-    __shared__ int w[6];
-    __shared__ double tp[2];
-    unsigned long long bad = 0, tests = 0;
-    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x + 1) * 0x9E3779B97F4A7C15ull;
-    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (double)(x >> 11) * 0x1p-53; };
-    for (int rd = 0; rd < rounds; ++rd) {
-        if (threadIdx.x == 0) {
-            const int mode = (int)(rnd() * 8);
-            double theta = -kPI + rnd() * 4 * kPI;
-            if (mode == 0) theta = (rnd() - 0.5) * 0.9;
-            else if (mode == 1) theta = 2 * kPI + (rnd() - 0.5) * 0.9;
-            else if (mode == 2) theta = (double)fast_atan2_deg((float)((int)(rnd() * 1021) - 510), (float)((int)(rnd() * 1021) - 510) + 0.5f) * DEG2RAD;
-            else if (mode == 3) theta = -kPI + rnd() * 0.5;
-            double prec = kPI * (22.5 / 180.0);
-            const int h = (int)(rnd() * 7);
-            for (int i = 0; i < h; ++i) prec /= 2;
-            if (mode == 5) prec = rnd() * 1.5;
-            if (mode == 6) theta = prec * (rnd() < 0.5 ? 1 : -1) + (rnd() - 0.5) * 1e-9 + (rnd() < 0.5 ? 0 : 2 * kPI);
-            int n, lo[2], hi[2];
-            const bool ok = alnwin::windows(theta, prec, n, lo, hi);
-            w[0] = n; w[1] = lo[0]; w[2] = hi[0]; w[3] = lo[1]; w[4] = hi[1]; w[5] = ok ? 0 : 1;
-            tp[0] = theta; tp[1] = prec;
-        }
-        __syncthreads();
-        const double theta = tp[0], prec = tp[1];
-        const int n = w[0], lo0 = w[1], hi0 = w[2], lo1 = w[3], hi1 = w[4];
-        auto check = [&](int b) {
-            if (b < 0 || b > alnwin::BMAX) return;
-            const bool inw = (n > 0 && b >= lo0 && b <= hi0) || (n > 1 && b >= lo1 && b <= hi1);
-            ++tests;
-            if (is_aligned_val(__int_as_float(b), theta, prec) != inw) ++bad;
-        };
-        for (int i = threadIdx.x; i < GT * GT; i += blockDim.x) {
-            const int gy = i / GT - 510, gx = i - (i / GT) * GT - 510;
-            if (gx == 0 && gy == 0) continue;
-            check(__float_as_int(fast_atan2_deg((float)gx, (float)(-gy))));
-        }
-        if (threadIdx.x < 14) { const int d = (int)threadIdx.x % 7 - 3; check((threadIdx.x < 7 ? lo0 : hi0) + d); check((threadIdx.x < 7 ? lo1 : hi1) + d); }
-        for (int i = 0; i < 16; ++i) check((int)(rnd() * (alnwin::BMAX + 1.0)));
-        if (threadIdx.x == 0 && w[5]) atomicAdd(out + 2, 1ull);
-        __syncthreads();
-    }
-    if (bad) atomicAdd(out, bad);
-    atomicAdd(out + 1, tests);
-}
-
-#endif
 
 // stage 0 is merged with the initial evaluation: same rectangle, six precisions (p, p/2 .. p/32); stage 4 likewise has one
 // geometry and five precisions.  Stages 1-3 change the rectangle itself: up to five candidates per rectangle.
@@ -565,19 +575,13 @@ struct NfaCountLdsT {
 template <int CH> union NfaLdsT { NfaCountLdsT<CH> c; unsigned short items[CH * 5]; };      // items: (rect - chunk) << 3 | candidate; CH = rectangles per chunk
 typedef NfaCountLdsT<EVAL_CH> NfaCountLds;
 typedef NfaLdsT<EVAL_CH> NfaLds;
-constexpr int WG_CH = 128;             // chunk of the workgroup-per-frame form (sixteen waves share a frame's few hundred rectangles)
 
-// the inner synchronisation of the per-wave stage bodies: only the wave's own LDS arrays are at stake.  A single-wave workgroup may use
-// the workgroup barrier; waves of a larger workgroup run the bodies with different trip counts and must not meet at one.
-template <bool WG1>
-__device__ __forceinline__ void nfa_wave_sync() {
-    if (WG1) __syncthreads();
-    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
-}
+// the inner synchronisation of the per-wave stage bodies: only the wave's own LDS arrays are at stake, and every kernel of this stage is a single-wave workgroup
+__device__ __forceinline__ void nfa_wave_sync() { __syncthreads(); }
 
 // aligned-point counts of the stage's candidates for the rectangles [part * per, ...) of one frame: the body of one wave
 // (the bodies come as *_range over the rectangles [c0, c1) -- what the streaming form below hands out block by block -- and as *_body over a wave's share of the frame)
-template <bool WG1, int CH>
+template <int CH>
 __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int c0, int c1, int lane, NfaCountLdsT<CH>& L) {
     CntItem* its = L.its;
 #ifdef SSLAM_NFA_INT
@@ -602,7 +606,7 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
             if (on) act[nAct + mbcnt(m)] = (unsigned short)(c - chunk);
             nAct += __popcll(m);
         }
-        nfa_wave_sync<WG1>();
+        nfa_wave_sync();
         for (int a0 = 0; a0 < nAct; a0 += rpb) {
             const int nr = min(rpb, nAct - a0);
             const int nIt = nested ? nr : nr * MAXC;
@@ -653,7 +657,7 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
                     else if (j == 0) st[c].nc = __popcll((vm >> lane) & 31ull);
                 }
             }
-            nfa_wave_sync<WG1>();
+            nfa_wave_sync();
             if (!nested) {
                 for (int ri = 0; ri < nr; ++ri) {
                     const CntItem* it5 = its + ri * MAXC;
@@ -703,23 +707,23 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
                     st[c].nc = K;
                 }
             }
-            nfa_wave_sync<WG1>();
+            nfa_wave_sync();
         }
     }
 }
 
-template <bool WG1, int CH>
+template <int CH>
 __device__ __forceinline__ void nfa_count_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int part, int nparts, int lane, NfaCountLdsT<CH>& L) {
     const int nCand = ((const Misc*)(base + P.offMisc))->nCand;
     const int per = (nCand + nparts - 1) / nparts;
     const int c0 = part * per, c1 = min(c0 + per, nCand);
-    nfa_count_range<WG1, CH>(base, P, stage, c0, c1, lane, L);
+    nfa_count_range<CH>(base, P, stage, c0, c1, lane, L);
 }
 
 __global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
     __shared__ NfaCountLds L;
     const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y;
-    nfa_count_body<true, EVAL_CH>(ws + (size_t)b * P.frameBytes, P, stage, blockIdx.x, gridDim.x, threadIdx.x, L);
+    nfa_count_body<EVAL_CH>(ws + (size_t)b * P.frameBytes, P, stage, blockIdx.x, gridDim.x, threadIdx.x, L);
 }
 
 // stage -1: the initial evaluation (cnt[0]); stage 0: cnt[1..5]; stages 1-4: cnt[0..nc).
@@ -742,7 +746,7 @@ __device__ __noinline__ double nfa_log10(double x) { return log10(x); }
 #else
 __device__ __forceinline__ double nfa_log10(double x) { return log10(x); }
 #endif
-template <bool WG1, int CH>
+template <int CH>
 __device__ __forceinline__ void nfa_eval_range(uint8_t* __restrict__ base, const LsdPlan& P, int stage, const double* __restrict__ lgam, int c0, int c1, int lane,
                                                 unsigned short* __restrict__ items) {
     Misc* misc = (Misc*)(base + P.offMisc); (void)misc;
@@ -764,7 +768,7 @@ __device__ __forceinline__ void nfa_eval_range(uint8_t* __restrict__ base, const
             for (int j = 0; j < cnt; ++j) items[ex + j] = (unsigned short)(((c - chunk) << 3) | j);
             nItems += __builtin_amdgcn_readlane(incl, 63);
         }
-        nfa_wave_sync<WG1>();
+        nfa_wave_sync();
         int pos = 0, myc = 0, myj = 0;
         bool active = false, pending = false, needLog = false;
         TailState S; S.term = 0; S.bin_tail = 1; S.p_term = 0; S.n = 0; S.i = 1;
@@ -790,7 +794,7 @@ __device__ __forceinline__ void nfa_eval_range(uint8_t* __restrict__ base, const
                             const int n = st[myc].cnt[myj + kofs][0], k = st[myc].cnt[myj + kofs][1];
                             double p = rects[(size_t)myc * 12 + 11];
                             if (stage == 0 || stage == 4) p = ldexp(p, -(myj + 1));       // stage_cand halves p once per step
-                            needLog = nfa_setup(n, k, p, P.logNT, lgam, plog, S, v);
+                            needLog = nfa_setup(n, k, p, P.logNT, P.nfaVariant, lgam, plog, S, v);
                             active = needLog; pending = true;
 #ifdef SSLAM_LSD_STATS
                             ++evals;
@@ -811,7 +815,7 @@ __device__ __forceinline__ void nfa_eval_range(uint8_t* __restrict__ base, const
             executed += 8;
 #endif
         }
-        nfa_wave_sync<WG1>();
+        nfa_wave_sync();
     }
 #ifdef SSLAM_LSD_STATS
     // cyc[5] = useful tail iterations (upper bound: whole blocks), cyc[6] = lane-iterations the wave executed, cyc[7] = evaluations
@@ -820,19 +824,19 @@ __device__ __forceinline__ void nfa_eval_range(uint8_t* __restrict__ base, const
 #endif
 }
 
-template <bool WG1, int CH>
+template <int CH>
 __device__ __forceinline__ void nfa_eval_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, const double* __restrict__ lgam, int part, int nparts, int lane,
                                                unsigned short* __restrict__ items) {
     const int nCand = ((const Misc*)(base + P.offMisc))->nCand;
     const int per = (nCand + nparts - 1) / nparts;
     const int c0 = part * per, c1 = min(c0 + per, nCand);
-    nfa_eval_range<WG1, CH>(base, P, stage, lgam, c0, c1, lane, items);
+    nfa_eval_range<CH>(base, P, stage, lgam, c0, c1, lane, items);
 }
 
 __global__ __launch_bounds__(64) void k_nfa_eval(uint8_t* __restrict__ ws, LsdPlan P, int stage, const double* __restrict__ lgam) {
     __shared__ unsigned short items[EVAL_CH * 5];
     const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y;
-    nfa_eval_body<true, EVAL_CH>(ws + (size_t)b * P.frameBytes, P, stage, lgam, blockIdx.x, gridDim.x, threadIdx.x, items);
+    nfa_eval_body<EVAL_CH>(ws + (size_t)b * P.frameBytes, P, stage, lgam, blockIdx.x, gridDim.x, threadIdx.x, items);
 }
 
 // rect_improve's acceptance, in candidate order, one lane per rectangle (the candidates of a stage do not depend on which of
@@ -893,7 +897,7 @@ __global__ __launch_bounds__(256) void k_nfa_finish(uint8_t* __restrict__ ws, Ls
 // chip) walk the frame's rectangles stage after stage with a workgroup barrier in between.  18 dependent launches became one: the line
 // stream queues once behind the point branch's grids instead of 18 times, and a frame no longer waits at every stage for the slowest
 // frame of the batch -- only the kernel's one tail is left.  Results are those of the separate launches (same bodies, same order).
-template <bool WG1, int CH>
+template <int CH>
 __device__ __forceinline__ void nfa_all_body(uint8_t* __restrict__ base, const LsdPlan& P, const double* __restrict__ lgam, int wave, int nwaves, int lane, NfaLdsT<CH>& L) {
     const int nthreads = nwaves * 64;
 #pragma unroll 1
@@ -903,11 +907,11 @@ __device__ __forceinline__ void nfa_all_body(uint8_t* __restrict__ base, const L
 #define NFA_OPAQUE() asm volatile("" : "+s"(base), "+s"(lgam), "+v"(lane))
         NFA_OPAQUE();
         if (it != 0) {                                   // stage 0's counts came with the initial evaluation's (nested tolerances, one pass)
-            nfa_count_body<WG1, CH>(base, P, it < 0 ? 0 : it, wave, nwaves, lane, L.c);
+            nfa_count_body<CH>(base, P, it < 0 ? 0 : it, wave, nwaves, lane, L.c);
             __syncthreads();
         }
         NFA_OPAQUE();
-        nfa_eval_body<WG1, CH>(base, P, it, lgam, wave, nwaves, lane, L.items);
+        nfa_eval_body<CH>(base, P, it, lgam, wave, nwaves, lane, L.items);
         __syncthreads();
         NFA_OPAQUE();
         nfa_accept_body(base, P, it, wave * 64 + lane, nthreads);
@@ -923,21 +927,9 @@ __device__ __forceinline__ void nfa_all_body(uint8_t* __restrict__ base, const L
 __global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_all(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
     __shared__ NfaLds L;
     const int b = xcd_mix_frame(blockIdx.x, gridDim.x);
-    nfa_all_body<true, EVAL_CH>(ws + (size_t)b * P.frameBytes, P, lgam, 0, 1, threadIdx.x, L);
+    nfa_all_body<EVAL_CH>(ws + (size_t)b * P.frameBytes, P, lgam, 0, 1, threadIdx.x, L);
 }
 
-// The same for calls of fewer frames than the chip has wave slots (the one-frame-at-a-time mode of Frame::ExtractLSD above all): ONE workgroup
-// of up to sixteen waves per frame walks the stages with workgroup barriers in between; each wave owns a share of the frame's rectangles and its
-// own LDS arrays.  One launch and sixteen barriers instead of 18 dependent launches of 64 / 16 waves (0.62 ms of a 6 ms frame were launch
-// boundaries and tails); a single workgroup needs no inter-workgroup barrier, hence no agent-scope fences (~7 us each) and no co-residency
-// requirement.  Dynamic LDS: blockDim.x / 64 x sizeof(NfaLdsT<WG_CH>).
-template <int MAXT>      // 1024: sixteen waves at 128 VGPRs each (the evaluator spills a little); 512: eight waves, no spills
-__global__ __launch_bounds__(MAXT) void k_nfa_all_wg(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
-    extern __shared__ __align__(16) unsigned char nfaDyn[];
-    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    NfaLdsT<WG_CH>* L = (NfaLdsT<WG_CH>*)nfaDyn + wave;
-    nfa_all_body<false, WG_CH>(ws + (size_t)blockIdx.x * P.frameBytes, P, lgam, wave, nwaves, threadIdx.x & 63, *L);
-}
 
 // ------------------------------------------------------------------ streaming form (SSLAM_NFA_STREAM=1, single frames / small calls in the cluster form; off by default)
 // A single frame's NFA stage is 0.6 ms of launches behind a 5 ms core that produces its rectangles one after the other -- and no rectangle's verdict
@@ -994,9 +986,9 @@ __global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_stream(uint8
         for (int it = -1; it <= 4; ++it) {
 #define NFA_OPAQUE() asm volatile("" : "+s"(base), "+s"(lgam), "+v"(lane))       // (as in nfa_all_body: nothing of a body's address arithmetic may be hoisted across the chain)
             NFA_OPAQUE();
-            if (it != 0) { nfa_count_range<true, EVAL_CH>(base, P, it < 0 ? 0 : it, c0, c1, lane, L.c); __syncthreads(); }
+            if (it != 0) { nfa_count_range<EVAL_CH>(base, P, it < 0 ? 0 : it, c0, c1, lane, L.c); __syncthreads(); }
             NFA_OPAQUE();
-            nfa_eval_range<true, EVAL_CH>(base, P, it, lgam, c0, c1, lane, L.items);
+            nfa_eval_range<EVAL_CH>(base, P, it, lgam, c0, c1, lane, L.items);
             __syncthreads();
             NFA_OPAQUE();
             nfa_accept_range(base, P, it, c0, c1, lane, 64);
@@ -1008,3 +1000,4 @@ __global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_stream(uint8
         t0 = (long long)wall_clock64();
     }
 }
+#endif      // SSLAM_NFA_STAGE_ONLY

@@ -21,13 +21,8 @@ constexpr float NOTDEF_F = -1024.0f;
 // 16 bytes per pixel written by k_lsd_grad in round 3 (24 before), 4 B + ~24 B per defined pixel now.  (A tiled form of T / Cs -- 8 x 4 and 4 x 4 pixels per 128-byte line -- was built
 // and measured first: L1 misses of the sequential core -12 %, its time unchanged, the rectangle counter +40 % for the address
 // arithmetic; profiles/README.md, round 3.)
-// SSLAM_LSD_PACKED=1 (experiment, round 4 §5g): Cs and S of a pixel in ONE 16-byte record {cos, sin, |g|^2, -} (offCs; offS = offCs + 8), so that the
-// four records of a lane of k_lsd_grad are one full 64-byte store where a 32-byte Cs store and a 16-byte S store are two partial ones.  Measured
-// SLOWER (k_lsd_grad 11.2 -> 13.0 ms: it is the bytes that count, 64 against 48 per lane, not the bursts), the core unchanged: off.
-#ifndef SSLAM_LSD_PACKED
-#define SSLAM_LSD_PACKED 0
-#endif
-constexpr int CS_SHIFT = SSLAM_LSD_PACKED ? 4 : 3, S_SHIFT = SSLAM_LSD_PACKED ? 4 : 2;      // log2 of the byte stride of the Cs / S entries
+// (A form with Cs and S of a pixel in ONE 16-byte record was measured in round 4: k_lsd_grad 11.2 -> 13.0 ms, the core unchanged -- it is the bytes that count, not the bursts.)
+constexpr int CS_SHIFT = 3, S_SHIFT = 2;      // log2 of the byte stride of the Cs / S entries
 constexpr unsigned USED_BIT = 0x80000000u;
 constexpr int N_BINS = 1024;
 constexpr int TILE_PX = 8192;           // raster tile of the counting sort (rounded down to whole rows: LsdPlan::tileRows)
@@ -49,6 +44,10 @@ struct LsdPlan {
     int tabX, tabY;           // offsets into the resize table (int: ofs, c1)
     double rho, prec, p, logNT;
     int minRegSize;
+    // stated decisions with a selectable alternative (sslam_lines_set_*): all 0 by default
+    int nfaVariant;           // D11: first term of nfa()'s log1term -- 0: log_gamma(n + 1); 1: (double(n) + 1)
+    int lbdBitOrder;          // D12: LBD byte packing -- 0: comparison i -> bit i; 1: comparison i -> bit 7 - i (0x80 >> i)
+    int lsdResize;            // D7: the 0.8x rescale -- 0: INTER_LINEAR_EXACT (q8 coefficients, one rounding); 1: INTER_LINEAR (11-bit coefficients, the two-stage 8u rounding)
 };
 
 struct Misc {                 // per-frame scalars

@@ -141,7 +141,7 @@ __global__ void k_selftest_region_div(unsigned long long seed, int iters, unsign
 #ifndef SSLAM_LSD_DRIFT
 #define SSLAM_LSD_DRIFT 1
 #endif
-// SPEC (multi-wave form, lsd_regions_mw.h): a helper wave grows a region AHEAD of the frame's main wave.  It never writes the pixel map: the
+// SPEC (helper waves of the cluster form, lsd_cluster.h): a helper wave grows a region AHEAD of the frame's main wave.  It never writes the pixel map: the
 // pixels it takes are marked in its own bitmap `bm` (LDS), and it gives up (returns -n) when the list would outgrow `capN` points.
 template <bool LAT, bool WIDE, int MARK = MARK_MAP, class G = TorusHelper>
 __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos, float seedSin, int sw, int sh, const Planes& pl, const RegQ& rq,
@@ -456,51 +456,10 @@ __device__ __forceinline__ double dist_d(double x1, double y1, double x2, double
     return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1));
 }
 
-// ------------------------------------------------------------------ multi-wave form (one frame at a time): shared state
-//   A frame that has a CU to itself -- the reference calls LineSegment::ExtractLineSegment once per frame,
-// src/Frame.cc:157-161 -- gets one MAIN wave, which replays flsd()'s seed loop in order exactly like the single-wave kernel, and up to MW_HMAX
-// HELPER waves that run the loop's per-seed body (region_grow, region2rect, refine with its re-growth and reduce_region_radius) AHEAD of it.
-// Only the main wave ever writes the pixel map.
-//   * helpers claim MW_SUB order positions at a time (CAS on MwCtl::cursor) and process the unused seeds of their claim, EACH SEED ON ITS
-//     OWN, on a READ-ONLY view of the pixel map; the pixels a region takes -- and releases again in refine() -- live in the helper's private
-//     bitmap.  Per seed they publish (MwRes + the helper's ring in LDS): list A = the region as first grown, list B = the region re-grown at
-//     refine's tolerance (if refine ran), list F = what reduce_region_radius left (if it ran), the rectangle, the bounding box of A and B
-//     and the release sequence number sampled before the first pixel was read;
-//   * the main wave, at a seed whose claim a helper owns, TAKES the helper's result (marks the last list USED, emits the rectangle) instead
-//     of running the body when the result is what the body would produce NOW:
-//       (b) every point of A and B is unused now (one parallel gather; region_grow's dependency chain is gone);
-//       (c) no pixel the helper can have seen as USED has been released since: pixels are released only by a refine() the main wave runs
-//           itself, each logs the bounding box of everything it touched with a new sequence number AFTER its last store, and a result whose
-//           box (grown by one pixel: the tested neighbourhood) meets a box logged after the result's sample is not taken.
-//     A pixel the helper saw unused and rejected by angle stays rejected whatever its state is now; a pixel it saw used and that is still
-//     used blocks growth the same way; accepted pixels are in A or B.  So (b) and (c) make the helper's lists, in their order, the lists the
-//     sequential body yields, and rectangle and refine outcome are functions of the lists.  Anything else: the main wave runs the body itself.
-//   * what published-but-not-yet-taken results would mark is recorded in a coarse shared map (2 x 2 pixel cells) that only steers the
-//     helpers' choice of seeds -- a seed inside somebody's speculative region will most likely be used by its turn -- and never enters a
-//     region's growth.
-// Stale or torn views only ever cost a fallback: the checks read the main wave's own stores.  Every wait of the main wave is bounded.
-#ifndef SSLAM_MW_HMAX
-#define SSLAM_MW_HMAX 6
-#endif
-constexpr int MW_HMAX = SSLAM_MW_HMAX;          // helper waves
-
-#ifndef SSLAM_MW_SUB
-#define SSLAM_MW_SUB 64
-#endif
-#ifndef SSLAM_MW_NSLOT
-#define SSLAM_MW_NSLOT 2
-#endif
-constexpr int MW_SUB = SSLAM_MW_SUB;          // order positions a helper claims at a time: 64 = the main wave's chunk (16 and 32 spread dense stretches of the
-                                    // seed list over several helpers -- half as many regions left to the main wave -- but the claims cost the helpers more than that returns: 9.1 / 8.6 / 8.4 ms)
-constexpr int MW_NSLOT = SSLAM_MW_NSLOT;         // claims a helper can have published and not yet passed by the main wave
-#ifndef SSLAM_MW_RING
-#define SSLAM_MW_RING 3072
-#endif
-constexpr int MW_RING = SSLAM_MW_RING;        // list words per helper, shared by its chunks (points of every list + 24 words per rectangle)
-constexpr int MW_RES = MW_SUB < 24 ? MW_SUB : 24;      // regions per claim
-constexpr int MW_WANT = QCAP / 2 + 24;      // ring space a helper waits for before it starts a region (while older chunks can still retire)
-constexpr int MW_EV = 16;           // refine events kept
-constexpr int MW_SPIN_LIMIT = 1 << 21;      // polls (tens of milliseconds) before the main wave stops waiting for a helper
+// ------------------------------------------------------------------ records shared with the cluster form (lsd_cluster.h)
+// (Rounds 2-4 also shipped a multi-wave form of this kernel -- one main wave + helper waves inside ONE workgroup, results through LDS: DESIGN history, section 5c.  The
+// cluster form superseded it for calls of up to 64 frames and the lone-wave flavour is as fast from 65 frames on, so it was removed in round 5; the record a helper
+// publishes per seed and the validation rules (b) / (c) live on in lsd_cluster.h.)
 // A published seed.  Lists in the helper's ring from `off`: A = the region as first grown (nA points); if refine() ran, B = the region
 // re-grown at the refined tolerance (nB), and if reduce_region_radius ran, F = what it left of B (nF).  The pixels that end up USED are the
 // last list's; A and B are what the helper accepted on the way, i.e. what must still be unused for the result to stand.
@@ -514,14 +473,6 @@ struct MwRes {                      // 20 bytes; lo = x0 | y0 << 16, hi = x1 | y
     __device__ __forceinline__ int nA() const { return w1 >> 16; }
     __device__ __forceinline__ int nB() const { return w2 & 0xFFFF; }
     __device__ __forceinline__ int nF() const { return w2 >> 16; }
-};
-struct MwSlot { int chunkPos, nres, doneLane, begin; MwRes res[MW_RES]; };      // begin: where the chunk's lists start in the helper's ring
-struct MwCtl { int cursor, finished, unmarkSeq, mainPos; int evLo[MW_EV], evHi[MW_EV]; unsigned long long helperIdle, helperBusy; int why[8]; unsigned long long hcyc[8], published;
-               int flPos[MW_HMAX]; float flX[MW_HMAX], flY[MW_HMAX], flCos[MW_HMAX], flSin[MW_HMAX], flAng[MW_HMAX]; };      // fl*: the seed each helper is growing right now
-struct MwShared {
-    MwCtl* ctl; MwSlot* slots; unsigned* arena; unsigned* specMap; int specW, specShift; int nHelpers;      // specShift: log2 of the shared map's cell edge, < 0: no map
-    __device__ __forceinline__ int cell(int x, int y) const { return (y >> specShift) * specW + (x >> specShift); }
-    __device__ __forceinline__ bool spec(int x, int y) const { if (specShift < 0) return false; const int c = cell(x, y); return (specMap[c >> 5] >> (c & 31)) & 1u; }
 };
 struct SpecLists { unsigned* bm; unsigned* free; int cap; int nB; bool reduced, gaveUp; };      // helper side of rect_refine
 __device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -663,9 +614,8 @@ __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& r
 #ifndef SSLAM_LSD_MINWAVES
 #define SSLAM_LSD_MINWAVES 6          // waves/SIMD the register allocator must leave room for (6 x 4 SIMDs = 24 frames per CU, LDS allows 32)
 #endif
-template <bool LAT, bool MW>
-__device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsigned* __restrict__ dynLds, double* __restrict__ red, float4* __restrict__ seedStash,
-                                                 const MwShared& mw) {
+template <bool LAT>
+__device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsigned* __restrict__ dynLds, double* __restrict__ red, float4* __restrict__ seedStash) {
     const int lane = threadIdx.x & 63;
     uint8_t* base = ws + (size_t)b * P.frameBytes;
     Planes pl; pl.T = (float*)(base + P.offT); pl.Cs = (const float2*)(base + P.offCs); pl.S = (const int*)(base + P.offS); pl.tW = P.tW; pl.cW = P.cW;
@@ -675,24 +625,11 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
     const int sw = P.sw, sh = P.sh;
     RegQ rq; rq.lds = dynLds; rq.glb = (unsigned*)(base + P.offReg);
     const int nOrd = misc->nDefined;
-    int unmarkSeq = 0;                                             // MW: refine events logged so far (the main wave is the only writer)
-    long long mwTaken = 0, mwOwn = 0, mwBadChunks = 0;             // MW statistics (Misc::cyc[5..7])
-#ifdef SSLAM_MW_STATS
-    long long mwCause[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mwBig = 0, mwTiny = 0;                // why the main wave grew a region itself (count | points << 32): tools/mw_debug.py
-#define SSLAM_MW_CAUSE(c) cause = (c)
-#else
-#define SSLAM_MW_CAUSE(c)
-#endif
     const double prec = P.prec;
     int nSeg = 0;
-    long long cyc0 = 0, cyc1 = 0, cyc2 = 0, cyc3 = 0, cycWait = 0, cycTake = 0, cycOwn = 0;
+    long long cyc0 = 0, cyc1 = 0, cyc2 = 0, cyc3 = 0;
     const long long tStart = SSLAM_CLK();
-#ifdef SSLAM_MW_STATS
-#define SSLAM_CLK2() __builtin_readcyclecounter()
-    const long long tStart2 = SSLAM_CLK2();
-#endif
     for (int pos0 = 0; pos0 < nOrd; pos0 += 64) {
-        if (MW) lds_st(&mw.ctl->mainPos, pos0);                   // every chunk below pos0 is finished: its helper may move on
         const int q = pos0 + lane;
         const bool have = q < nOrd;
         const unsigned idx = have ? order[q] : 0xFFFFFFFFu;
@@ -703,156 +640,44 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
         const float a0 = have ? pl.ldT(tiSeed) : NOTDEF_F;
         unsigned long long unM = __ballot(t_free(a0));        // candidates of this chunk that are still unused (wave-uniform, kept up to date below)
         if (!unM) continue;
-        // (multi-wave form: only the seeds the main wave grows itself need this -- evaluated at the first one of the chunk)
-        bool stashReady = false;
-        auto fill_stash = [&]() {
+        {
             const double ar = (double)a0 * DEG2RAD;
             seedStash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float((int)idx));
-            stashReady = true;
-        };
-        if (!MW) fill_stash();
-        // MW: whose positions are these?  Helpers claim MW_SUB positions at a time from the cursor; what is still unclaimed of this chunk (and
-        // everything the cursor skipped) becomes the main wave's own.
-        unsigned mineMask = 0;                                // bit j: positions [pos0 + j * MW_SUB, + MW_SUB) are the main wave's
-        int owner = -1, ownerSub = -1;
-        if (MW) for (;;) {
-            const int c = lds_ld(&mw.ctl->cursor);
-            if (c >= pos0 + 64) break;
-            const int cc = max(c, pos0);
-            if (lds_cas_uniform(&mw.ctl->cursor, c, cc + MW_SUB, lane) == c) mineMask |= 1u << ((cc - pos0) / MW_SUB);
         }
         while (unM) {
-            // (multi-wave form: the mask is wave-uniform by construction but carried through branches on LDS loads, which the compiler
-            // cannot prove uniform -- pinned to scalar registers, or the whole seed loop runs under exec-mask bookkeeping)
-            if (MW) unM = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unM >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)unM);
             const int first = __ffsll((long long)unM) - 1;
             unM &= unM - 1;                                   // the seed itself is consumed whatever happens
-            float4 sd = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!MW) sd = seedStash[first];                   // wave-uniform address: one broadcast read
+            const float4 sd = seedStash[first];               // wave-uniform address: one broadcast read
             double regAngle;
             long long t0 = SSLAM_CLK();
-            int n = -1;
-            bool took = false, tookEmit = false; RectD tookRec; const unsigned* smallList = rq.lds;
-            unsigned bxLo = 0u, bxHi = 0xFFFFFFFFu;              // box (packed x | y << 16 minima / maxima) of every pixel this seed's body touched
-#ifdef SSLAM_MW_STATS
-            int cause = 7;                                      // 7: the main wave's own chunk
-#endif
-            if (MW && first / MW_SUB != ownerSub) {
-                // the claimant publishes its slot right after the CAS.  Every wait of the main wave is bounded: if a helper ever failed to show
-                // up the main wave would go on alone (Misc::cyc[7] counts it; the tests require zero)
-                ownerSub = first / MW_SUB;
-                owner = ((mineMask >> ownerSub) & 1u) ? -1 : -2;
-                for (int spin = 0; owner == -2; ++spin) {
-                    for (int h = 0; h < mw.nHelpers * MW_NSLOT; ++h) if (lds_ld(&mw.slots[h].chunkPos) == pos0 + ownerSub * MW_SUB) owner = h;
-                    if (owner == -2) { if (spin > MW_SPIN_LIMIT) { owner = -1; ++mwBadChunks; } else __builtin_amdgcn_s_sleep(1); }
-                }
-            }
-            if (MW && owner >= 0) {
-                MwSlot* S = &mw.slots[owner];
-                int spin = 0;
-                while (lds_ld(&S->doneLane) <= first && spin <= MW_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); ++spin; }
-                if (spin > MW_SPIN_LIMIT) { owner = -1; ++mwBadChunks; }
-                const long long tw = SSLAM_CLK(); cycWait += tw - t0;
-                const int nres = owner >= 0 ? lds_ld(&S->nres) : 0;
-                // the helper's regions are in no particular order (it may have looked at the chunk more than once)
-                const unsigned long long hit = __ballot(lane < nres && S->res[min(lane, MW_RES - 1)].lane() == first);
-                SSLAM_MW_CAUSE(1);
-                if (hit) {
-                    const MwRes* r = &S->res[__ffsll((long long)hit) - 1];
-                    const int nA = r->nA(), nB = r->nB(), nF = r->nF(), flags = r->flags();
-                    const int startSeq = unmarkSeq - ((unmarkSeq - r->startSeq()) & 0xFFFF);      // the sample, 16 bits of it published
-                    const unsigned* lstA = mw.arena + (size_t)(owner / MW_NSLOT) * MW_RING + r->off();
-                    const unsigned* lstB = lstA + nA;
-                    const unsigned* lstF = (flags & MW_REDUCED) ? lstB + nB : (flags & MW_REFINED) ? lstB : lstA;
-                    bool ok = unmarkSeq - startSeq <= MW_EV;
-                    if (!ok) SSLAM_MW_CAUSE(4);
-                    for (int sq = startSeq + 1; ok && sq <= unmarkSeq; ++sq) {
-                        ok = !boxes_meet(r->lo, r->hi, (unsigned)mw.ctl->evLo[sq & (MW_EV - 1)], (unsigned)mw.ctl->evHi[sq & (MW_EV - 1)], 1);
-                        if (!ok) SSLAM_MW_CAUSE(4);
-                    }
-                    // everything the helper accepted on the way (A, and B when refine() ran) must be unused now
-                    // (a region of one point is its seed, which the main wave knows to be unused: no gather -- 45 % of the takes)
-                    float v0 = 0.f; int ti0 = 0;                 // first 64 points: value and element kept for the marking below
-                    for (int bs = 0; ok && nA + nB > 1 && bs < nA + nB; bs += 64) {
-                        const int i = bs + lane;
-                        bool usedNow = false;
-                        if (i < nA + nB) { const int ti = pl.ti(lstA[i]); const float v = pl.T[ti]; usedNow = !t_free(v); if (bs == 0) { v0 = v; ti0 = ti; } }
-                        ok = __ballot(usedNow) == 0;
-                        if (!ok) SSLAM_MW_CAUSE(3);
-                    }
-                    if (ok) {
-                        // mark list F used (the used bit joins the angle, so a mark needs the pixel's value): a one-point region is the seed,
-                        // whose value lane `first` read with the chunk; an unrefined region of up to 64 points is list A, just gathered
-                        if (nA + nB == 1) { if (lane == first) pl.T[tiSeed] = t_used(a0); }
-                        else if (!(flags & MW_REFINED) && nF <= 64) { if (lane < nF) pl.T[ti0] = t_used(v0); }
-                        else for (int i = lane; i < nF; i += 64) { unsigned* t = pl.Tb() + pl.ti(lstF[i]); *t |= USED_BIT; }
-                        took = true; n = nA; smallList = lstA; bxLo = r->lo; bxHi = r->hi;
-                        tookEmit = (flags & MW_EMIT) != 0;
-                        if (tookEmit) {
-                            const int* rw = (const int*)(lstB + nB + ((flags & MW_REDUCED) ? nF : 0));
-                            double* rd = (double*)&tookRec;
-#pragma unroll
-                            for (int j = 0; j < 12; ++j) rd[j] = __hiloint2double(rw[2 * j + 1], rw[2 * j]);
-                        }
-                        mwTaken += 1 + ((long long)n << 32);
-                    }
-                }
-                cycTake += SSLAM_CLK() - tw;
-            }
-            if (n < 0) {
-                const long long to = SSLAM_CLK();
-                if (MW) { if (!stashReady) fill_stash(); sd = seedStash[first]; }
-                const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
-                n = region_grow_m<LAT>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pl, rq, prec, regAngle, &misc->cyc[6]);
-                cycOwn += SSLAM_CLK() - to;
-                mwOwn += 1 + ((long long)n << 32);
-#ifdef SSLAM_MW_STATS
-                mwCause[cause] += 1 + ((long long)n << 32);
-                if (n >= 100) mwBig += 1ll << (cause == 1 ? 0 : cause == 3 ? 16 : cause == 4 ? 32 : 48);
-                if (n <= 2) mwTiny += 1 + ((long long)n << 32);
-#endif
-            }
+            const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
+            int n = region_grow_m<LAT>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pl, rq, prec, regAngle, &misc->cyc[6]);
             long long t1 = SSLAM_CLK(); cyc0 += t1 - t0;
             if (n < P.minRegSize) {
                 // too small: rejected, its pixels stay used.  Which candidates of this chunk did it take?  Compare them with the (few) points of
                 // the region instead of gathering 64 pixel records again.
                 for (int k = 1; k < n; ++k) {
-                    const unsigned e = smallList[k];          // minRegSize < QCAP
+                    const unsigned e = rq.lds[k];             // minRegSize < QCAP
                     unM &= ~__ballot(idx == e);
                 }
                 continue;
             }
             RectD rec;
-            bool emit = false;
-            long long t2 = t1;
-            if (took) { emit = tookEmit; rec = tookRec; }
-            else {
-                bool refined = false; unsigned evLo = 0xFFFFFFFFu, evHi = 0u;      // MW: everything refine() may have released lies inside this box
-                long long cycs[3] = {0, 0, 0};
-                const int nGrown = n;
-                emit = rect_refine<LAT, false, true>(P, sd, n, regAngle, rq, pl, red, rec, refined, evLo, evHi, cycs, nullptr, &misc->cyc[6]);
-                cyc1 += cycs[0]; t2 = t1 + cycs[0]; cyc3 += cycs[2];
-                if (!refined) { if (nGrown <= QCAP) list_bbox(rq.lds, nGrown, lane, evLo, evHi); else { evLo = 0u; evHi = 0xFFFFFFFFu; } }      // the list is the region as grown
-                bxLo = evLo; bxHi = evHi;
-                if (MW && refined) {                              // log the event once the last store of this refine has left
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    ++unmarkSeq;
-                    if (lane == 0) { mw.ctl->evLo[unmarkSeq & (MW_EV - 1)] = (int)evLo; mw.ctl->evHi[unmarkSeq & (MW_EV - 1)] = (int)evHi; }
-                    lds_st(&mw.ctl->unmarkSeq, unmarkSeq);
-                }
-            }
+            bool refined = false; unsigned evLo = 0xFFFFFFFFu, evHi = 0u;      // everything refine() may have released lies inside this box
+            long long cycs[3] = {0, 0, 0};
+            const int nGrown = n;
+            const bool emit = rect_refine<LAT, false, true>(P, sd, n, regAngle, rq, pl, red, rec, refined, evLo, evHi, cycs, nullptr, &misc->cyc[6]);
+            cyc1 += cycs[0]; const long long t2 = t1 + cycs[0]; cyc3 += cycs[2];
+            if (!refined) { if (nGrown <= QCAP) list_bbox(rq.lds, nGrown, lane, evLo, evHi); else { evLo = 0u; evHi = 0xFFFFFFFFu; } }      // the list is the region as grown
             // ---- hand the rectangle to the NFA stage (rect_improve reads only the static angle map and never touches
-            // `used`, so it is not part of the sequential dependency chain: k_lsd_nfa evaluates all candidates in parallel)
+            // `used`, so it is not part of the sequential dependency chain: k_nfa_all evaluates all candidates in parallel)
             long long t3 = SSLAM_CLK(); cyc2 += t3 - t2;
             // a region of this size -- kept or not, refine() may have released pixels again -- can have changed the candidates of the chunk that
             // lie inside the box of what it touched (everything it marked or released is inside; pixels of other regions are never released):
             // only those are gathered again.  (Rounds 1-2 gathered all 64: 27 k scattered lines per frame, a quarter of the core's L1 misses.)
             {
                 const int ix = (int)(idx & 0xFFFF), iy = (int)(idx >> 16);
-#ifdef SSLAM_LSD_NO_BOXFILTER      // A/B knob: the round-2 behaviour
-                bxLo = 0u; bxHi = 0xFFFFFFFFu;
-#endif
-                const bool chk = have && ((unM >> lane) & 1ull) && ix >= (int)(bxLo & 0xFFFF) && ix <= (int)(bxHi & 0xFFFF) && iy >= (int)(bxLo >> 16) && iy <= (int)(bxHi >> 16);
+                const bool chk = have && ((unM >> lane) & 1ull) && ix >= (int)(evLo & 0xFFFF) && ix <= (int)(evHi & 0xFFFF) && iy >= (int)(evLo >> 16) && iy <= (int)(evHi >> 16);
                 bool usedNow = false;
                 if (chk) usedNow = !t_free(pl.T[tiSeed]);
                 unM &= ~__ballot(usedNow);
@@ -866,20 +691,9 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
             ++nSeg;
         }
     }
-    if (MW) lds_st(&mw.ctl->finished, 1);
     if (lane == 0) {
         misc->nCand = min(nSeg, MAX_SEG); if (nSeg > MAX_SEG) misc->overflow = 1;
         misc->cyc[0] = cyc0; misc->cyc[1] = cyc1; misc->cyc[2] = cyc2; misc->cyc[3] = cyc3; misc->cyc[4] = SSLAM_CLK() - tStart;
-        if (MW) { misc->cyc[5] = mwTaken; misc->cyc[6] = mwOwn; misc->cyc[7] = mwBadChunks; }
-#ifdef SSLAM_LSD_CYCLES
-        if (MW) { misc->cyc[5] = cycWait; misc->cyc[6] = cycTake; misc->cyc[7] = cycOwn; }
-#endif
-#ifdef SSLAM_MW_HCYC
-        if (MW) { for (int c = 0; c < 8; ++c) misc->cyc[c] = (long long)mw.ctl->hcyc[c]; misc->cyc[7] = (long long)mw.ctl->published; }
-#elif defined(SSLAM_MW_STATS)
-        if (MW) { misc->cyc[0] = mwTaken; for (int c = 1; c < 8; ++c) misc->cyc[c] = mwCause[c]; misc->cyc[5] = (long long)mw.ctl->helperBusy; misc->cyc[6] = (long long)mw.ctl->helperIdle; misc->cyc[2] = SSLAM_CLK2() - tStart2; misc->cyc[7] = mwBig; misc->cyc[1] = mwCause[1] + mwCause[3] + mwCause[4];
-                  long long w0 = 0, w1 = 0; for (int c = 0; c < 4; ++c) { w0 |= (long long)(mw.ctl->why[c] & 0xFFFF) << (16 * c); w1 |= (long long)(mw.ctl->why[4 + c] & 0xFFFF) << (16 * c); } misc->cyc[3] = w0; misc->cyc[4] = w1; }
-#endif
     }
 }
 
@@ -892,254 +706,6 @@ __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t*
     // share of the frames, and the wave slots the grid does not fill stay free for the other branch's kernels for the whole launch
     for (int i = blockIdx.x; i < nframes; i += gridDim.x) {
         __syncthreads();
-        lsd_regions_body<LAT, false>(ws, P, xcd_mix_frame(i, nframes), dynLds, red, seedStash, MwShared{});
+        lsd_regions_body<LAT>(ws, P, xcd_mix_frame(i, nframes), dynLds, red, seedStash);
     }
-}
-
-// ------------------------------------------------------------------ multi-wave form: the helper wave and the kernel
-// One helper: claim a chunk, grow its unused seeds in order on the read-only view + own bitmap, publish, wait until the main wave has passed.
-__device__ void mw_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int b, const MwShared& mw, unsigned* __restrict__ bm, float4* __restrict__ stash, double* __restrict__ red) {
-    const int lane = threadIdx.x & 63;
-    uint8_t* base = ws + (size_t)b * P.frameBytes;
-    Planes pl; pl.T = (float*)(base + P.offT); pl.Cs = (const float2*)(base + P.offCs); pl.S = (const int*)(base + P.offS); pl.tW = P.tW; pl.cW = P.cW;
-    const unsigned* order = (const unsigned*)(base + P.offOrder);
-    const Misc* misc = (const Misc*)(base + P.offMisc);
-    const int sw = P.sw, sh = P.sh, nOrd = misc->nDefined;
-    MwCtl* ctl = mw.ctl;
-    MwSlot* slots = &mw.slots[h * MW_NSLOT];
-    unsigned* ring = mw.arena + (size_t)h * MW_RING;
-#ifdef SSLAM_MW_STATS
-#define SSLAM_MW_WHY(i, v) do { if (lane == 0) atomicAdd(&ctl->why[i], (v)); } while (0)
-#define SSLAM_MW_T(i) do { const long long tn_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&ctl->hcyc[i], (unsigned long long)(tn_ - tPrev)); tPrev = tn_; } while (0)
-    long long tPrev = __builtin_readcyclecounter();
-#else
-#define SSLAM_MW_WHY(i, v)
-#define SSLAM_MW_T(i)
-#endif
-    for (int i = lane; i < MW_BM_WORDS; i += 64) bm[i] = 0u;
-    // The lists of this helper's chunks live in ONE ring of MW_RING words, allocated front to back: the chunks the main wave has not passed
-    // occupy the band [tail, head).  reap() retires the chunks it has passed (their regions leave the shared map, the slot is free again)
-    // and returns the band's tail, or -1 when nothing is outstanding.
-    int head = 0;
-    const MwSlot* cur = nullptr;           // the slot being filled is never retired from inside its own loop
-    auto reap = [&]() -> int {
-        const int mp = lds_ld(&ctl->mainPos);
-        int tailChunk = 0x7FFFFFFF, tail = -1;
-        for (int j = 0; j < MW_NSLOT; ++j) {
-            MwSlot* T = &slots[j];
-            const int cp = T->chunkPos;
-            if (cp < 0) continue;
-            if (mp > cp && T != cur) {
-                if (mw.specShift >= 0)
-                    for (int kk = 0; kk < T->nres; ++kk) {
-                        const MwRes* r = &T->res[kk];
-                        const unsigned* lstF = ring + r->off() + ((r->flags() & MW_REDUCED) ? r->nA() + r->nB() : (r->flags() & MW_REFINED) ? r->nA() : 0);
-                        for (int i = lane; i < r->nF(); i += 64) { const unsigned e = lstF[i]; const int cl = mw.cell((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&mw.specMap[cl >> 5], ~(1u << (cl & 31))); }
-                    }
-                lds_st(&T->chunkPos, -1);
-            } else if (cp < tailChunk) { tailChunk = cp; tail = T->begin; }
-        }
-        return tail;
-    };
-    // words that can be written at `head` in one piece without touching the band (one word stays free so that head == tail means empty);
-    // moves head to the front of the ring when the piece there is the larger one
-    auto contiguous = [&](int tail) -> int {
-        if (tail < 0) { head = 0; return MW_RING; }
-        if (head < tail) return tail - head - 1;
-        int cap = MW_RING - head;
-        if (tail - 1 > cap) { head = 0; cap = tail - 1; }
-        return cap;
-    };
-    for (;;) {
-        // ---- a free slot
-        MwSlot* S = nullptr;
-        cur = nullptr;
-#ifdef SSLAM_MW_STATS
-        const long long tIdle0 = __builtin_readcyclecounter();
-#endif
-        for (;;) {
-            if (lds_ld(&ctl->finished)) return;
-            reap();
-            for (int j = 0; j < MW_NSLOT; ++j) if (slots[j].chunkPos < 0) S = &slots[j];
-            if (S) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-#ifdef SSLAM_MW_STATS
-        if (lane == 0) atomicAdd(&ctl->helperIdle, (unsigned long long)(__builtin_readcyclecounter() - tIdle0));
-#endif
-        SSLAM_MW_T(0);
-        // ---- claim the next chunk nobody has
-        int c;
-        for (;;) {
-            if (lds_ld(&ctl->finished)) return;
-            c = lds_ld(&ctl->cursor);
-            const int mp = lds_ld(&ctl->mainPos);
-            if (c >= nOrd) return;
-            if (c < mp) { lds_cas_uniform(&ctl->cursor, c, mp, lane); continue; }      // the main wave is already past it
-            if (lds_cas_uniform(&ctl->cursor, c, c + MW_SUB, lane) == c) break;
-        }
-#ifdef SSLAM_MW_STATS
-        const long long tClaim = __builtin_readcyclecounter();
-#endif
-        contiguous(reap());                                    // (resets head when nothing is outstanding)
-        if (lane == 0) { S->nres = 0; S->doneLane = 0; S->begin = head; }
-        lds_st(&S->chunkPos, c);
-        cur = S;
-        // ---- the chunk's seed candidates as this wave sees them now
-        const int q = c + lane, laneBase = c & 63;            // lanes are numbered as in the main wave's chunk of 64
-        const bool have = lane < MW_SUB && q < nOrd;
-        const unsigned idx = have ? order[q] : 0u;
-        const int cy = idx >> 16, cx = idx & 0xFFFF, tiSeed = pl.ti(idx);
-        // Pass 0 grows the seeds that are unused and outside every speculative region, in order.  While the main wave is still in front of
-        // the chunk and this helper has nowhere else to go (no free slot), it keeps looking again: whatever is unused by then and still has
-        // no region -- seeds the shared map had talked it out of, pixels a refine() released -- is grown as well, so that the main wave
-        // finds a region for (nearly) every seed instead of growing those itself.
-        unsigned long long haveRes = 0;      // seeds with a region, or that this helper gave up on
-        unsigned long long deferred = 0;     // seeds put off in pass 0 because an earlier seed of (most likely) the same edge is being grown elsewhere
-        int k = 0; bool room = true;
-        for (int pass = 0; room; ++pass) {
-            if (pass > 0) {
-                SSLAM_MW_T(7);
-                reap();
-                bool freeSlot = false;
-                for (int j = 0; j < MW_NSLOT; ++j) freeSlot |= slots[j].chunkPos < 0;
-                if ((freeSlot && !(pass == 1 && (deferred & ~haveRes))) || lds_ld(&ctl->mainPos) >= (c & ~63) || lds_ld(&ctl->finished)) break;
-                __builtin_amdgcn_s_sleep(8);
-                SSLAM_MW_T(6);
-            }
-            const float a0 = have ? pl.ldT(tiSeed) : NOTDEF_F;
-            unsigned long long unM = __ballot(t_free(a0) && (pass > 0 || !mw.spec(cx, cy))) & ~haveRes;
-            if (pass == 0) SSLAM_MW_WHY(0, __popcll(__ballot(t_free(a0) && mw.spec(cx, cy))));
-            if (unM) {
-                const double ar = (double)a0 * DEG2RAD;
-                stash[lane] = make_float4(a0, (float)cos(ar), (float)sin(ar), __int_as_float(cx | (cy << 16)));
-            }
-            SSLAM_MW_T(1);
-            while (unM) {
-                if (lds_ld(&ctl->mainPos) > c || lds_ld(&ctl->finished)) { SSLAM_MW_WHY(7, 1 + __popcll(unM)); room = false; break; }
-                const int first = __ffsll((long long)unM) - 1;
-                unM &= unM - 1;
-                const float4 sd = stash[first];
-                const int sxy = __float_as_int(sd.w), sx = sxy & 0xFFFF, sy = sxy >> 16;
-                const int startSeq = lds_ld(&ctl->unmarkSeq);      // sampled BEFORE the first pixel of this region is read
-                if (!t_free(pl.T[pl.ti(sx, sy)])) { SSLAM_MW_WHY(1, 1); continue; }           // taken since the chunk was scanned (a region in front of it, committed meanwhile)
-                if ((pass == 0 || ((deferred >> first) & 1ull)) && mw.spec(sx, sy)) { SSLAM_MW_WHY(2, 1); continue; }         // ... or about to be
-                // Consecutive positions of the top bins are pixels of the same long edges: helpers that start them together each grow the whole
-                // edge and only the earliest seed's region is ever taken.  So: if another helper is growing an EARLIER seed whose level line
-                // passes within 3 pixels of this seed at a similar angle, this seed is put off (pass 0) / waits for that region (later passes)
-                // and is looked at again once it is settled -- by then it is usually covered.  A guess about what to grow, nothing more.
-                {
-                    const int myP = c + first;
-                    auto blocked = [&]() -> bool {
-                        bool b = false;
-                        for (int j = 0; j < mw.nHelpers; ++j) {
-                            if (j == h || lds_ld(&ctl->flPos[j]) >= myP) continue;
-                            const float da = fabsf(sd.x - ctl->flAng[j]), dd = fminf(da, 360.f - da);
-                            const float perp = fabsf(((float)sx - ctl->flX[j]) * ctl->flSin[j] - ((float)sy - ctl->flY[j]) * ctl->flCos[j]);
-                            b |= dd < 22.5f && perp < 3.f;
-                        }
-                        return b;
-                    };
-                    if (blocked()) {
-                        if (pass == 0) { deferred |= 1ull << first; SSLAM_MW_WHY(3, 1); continue; }
-                        while (blocked() && lds_ld(&ctl->mainPos) < (c & ~63) && !lds_ld(&ctl->finished)) __builtin_amdgcn_s_sleep(8);
-                        if (!t_free(pl.T[pl.ti(sx, sy)]) || mw.spec(sx, sy)) continue;
-                    }
-                }
-                if (lane == 0) { ctl->flX[h] = (float)sx; ctl->flY[h] = (float)sy; ctl->flCos[h] = sd.y; ctl->flSin[h] = sd.z; ctl->flAng[h] = sd.x; }
-                lds_st(&ctl->flPos[h], c + first);
-                struct FlGuard { int* p; __device__ ~FlGuard() { lds_st(p, 0x7FFFFFFF); } } flGuard{&ctl->flPos[h]};      // cleared however the body is left
-                // room for a region of some size, or as much as there will ever be: older chunks of this helper still in the ring are
-                // retired as the main wave passes them -- waiting for that beats abandoning a seed (the main wave would grow it itself)
-                int tail = reap(), space = contiguous(tail);          // may move head
-                while (space < MW_WANT && tail >= 0 && tail != S->begin && !lds_ld(&ctl->finished) && lds_ld(&ctl->mainPos) < (c & ~63)) {      // (never once the main wave is AT this chunk: it may be waiting for us)
-                    __builtin_amdgcn_s_sleep(4);
-                    tail = reap(); space = contiguous(tail);
-                }
-                SSLAM_MW_T(2);
-                const int capN = min(QCAP, space - 24);
-                if (k >= MW_RES || capN <= 64) { SSLAM_MW_WHY(k >= MW_RES ? 3 : 4, 1 + __popcll(unM)); room = false; break; }      // no room left: the main wave grows the rest itself
-                RegQ rq; rq.lds = ring + head; rq.glb = nullptr;
-                double regAngle = 0;
-                int n = region_grow_w<true, false, true>(sx, sy, sd.x, sd.y, sd.z, sw, sh, pl, rq, P.prec, regAngle, nullptr, bm, capN);
-                if (n < 0) {                                        // too long for a helper: release its marks, the main wave grows this one
-                    for (int i = lane; i < -n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
-                    SSLAM_MW_WHY(5, 1); haveRes |= 1ull << first;
-                    continue;
-                }
-                SSLAM_MW_T(3);
-                // ---- the rest of flsd()'s per-seed body on the private marks: region2rect, refine()
-                const int nA = n;
-                unsigned* lstA = rq.lds;
-                SpecLists sl; sl.bm = bm; sl.free = lstA + nA; sl.cap = space - 24 - nA; sl.nB = 0; sl.reduced = false; sl.gaveUp = false;
-                bool emit = false, refined = false; unsigned dLo = 0, dHi = 0; long long cycs[3];
-                RectD rec;
-                if (n >= P.minRegSize) {
-                    emit = rect_refine<true, true, false>(P, sd, n, regAngle, rq, pl, red, rec, refined, dLo, dHi, cycs, &sl, nullptr);
-                    if (sl.gaveUp) { SSLAM_MW_WHY(6, 1); haveRes |= 1ull << first; continue; }      // its marks are released; the main wave handles this seed
-                }
-                SSLAM_MW_T(4);
-                // marks still set: the final list (rq.lds[0..n)).  They go -- the next region is grown on its own.
-                for (int i = lane; i < n; i += 64) { const unsigned e = rq.lds[i]; const int bi = mw_bit((int)(e & 0xFFFF), (int)(e >> 16)); atomicAnd(&bm[bi >> 5], ~(1u << (bi & 31))); }
-                const int nAB = nA + sl.nB;
-                int total = nAB + (sl.reduced ? n : 0);
-                if (emit) {                                         // the rectangle follows the lists
-                    if (lane == 0) {
-                        int* rw = (int*)(lstA + total); const double* rd = (const double*)&rec;
-#pragma unroll
-                        for (int j = 0; j < 12; ++j) { rw[2 * j] = __double2loint(rd[j]); rw[2 * j + 1] = __double2hiint(rd[j]); }
-                    }
-                    total += 24;
-                }
-                unsigned lo, hi;
-                list_bbox(lstA, nAB, lane, lo, hi);
-                if (lane == 0) {
-                    MwRes& r = S->res[k];
-                    const unsigned flags = (refined ? MW_REFINED : 0) | (sl.reduced ? MW_REDUCED : 0) | (emit ? MW_EMIT : 0);
-                    r.w0 = (unsigned)(laneBase + first) | (flags << 8) | ((unsigned)(startSeq & 0xFFFF) << 16);
-                    r.w1 = (unsigned)head | ((unsigned)nA << 16); r.w2 = (unsigned)sl.nB | ((unsigned)n << 16); r.lo = lo; r.hi = hi;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                ++k; head += total; haveRes |= 1ull << first;
-#ifdef SSLAM_MW_STATS
-                if (lane == 0) atomicAdd(&ctl->published, 1ull + ((unsigned long long)(nA + sl.nB) << 32));
-#endif
-                lds_st(&S->nres, k);
-                if (pass == 0) lds_st(&S->doneLane, laneBase + first + 1);
-                // what the region leaves USED enters the shared map that steers seed choice; candidates of this chunk inside it are dropped
-                for (int i = lane; i < n; i += 64) {
-                    if (mw.specShift < 0) break;
-                    const unsigned e = rq.lds[i]; const int cl = mw.cell((int)(e & 0xFFFF), (int)(e >> 16));
-                    atomicOr(&mw.specMap[cl >> 5], 1u << (cl & 31));
-                }
-                if (n > 1 && pass == 0) unM &= ~__ballot(have && mw.spec(cx, cy));
-                SSLAM_MW_T(5);
-            }
-            if (pass == 0) lds_st(&S->doneLane, 64);
-        }
-#ifdef SSLAM_MW_STATS
-        if (lane == 0) atomicAdd(&ctl->helperBusy, (unsigned long long)(__builtin_readcyclecounter() - tClaim));
-#endif
-    }
-}
-
-// dynamic LDS: [main queue QCAP + 4][rings nHelpers x MW_RING][bitmaps nHelpers x MW_BM_WORDS][shared coarse map specWords]
-__global__ __launch_bounds__(64 * (1 + MW_HMAX)) void k_lsd_regions_mw(uint8_t* __restrict__ ws, LsdPlan P, int nHelpers, int specWords, int specShift) {
-    extern __shared__ __align__(16) unsigned dynLds[];
-    __shared__ double red[3 * 64];
-    __shared__ float4 seedStash[64];
-    __shared__ float4 helperStash[MW_HMAX][64];
-    __shared__ double helperRed[MW_HMAX][3 * 64];
-    __shared__ MwCtl ctl;
-    __shared__ MwSlot slots[MW_HMAX * MW_NSLOT];
-    const int wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { ctl.cursor = 0; ctl.finished = 0; ctl.unmarkSeq = 0; ctl.mainPos = 0; ctl.helperIdle = 0; ctl.helperBusy = 0; for (int c = 0; c < 8; ++c) { ctl.why[c] = 0; ctl.hcyc[c] = 0; } ctl.published = 0; for (int c = 0; c < MW_HMAX; ++c) ctl.flPos[c] = 0x7FFFFFFF; }
-    if (threadIdx.x < MW_HMAX * MW_NSLOT) { slots[threadIdx.x].chunkPos = -1; slots[threadIdx.x].nres = 0; slots[threadIdx.x].doneLane = 0; slots[threadIdx.x].begin = 0; }
-    MwShared mw; mw.ctl = &ctl; mw.slots = slots; mw.arena = dynLds + QCAP + 4; mw.nHelpers = nHelpers;
-    mw.specMap = mw.arena + (size_t)nHelpers * (MW_RING + MW_BM_WORDS); mw.specShift = specShift; mw.specW = specShift >= 0 ? (P.sw + (1 << specShift) - 1) >> specShift : 0;
-    for (int i = threadIdx.x; i < specWords; i += blockDim.x) mw.specMap[i] = 0u;
-    __syncthreads();
-    const int b = blockIdx.x;
-    if (wave == 0) lsd_regions_body<true, true>(ws, P, b, dynLds, red, seedStash, mw);
-    else if (wave <= nHelpers) mw_helper(wave - 1, ws, P, b, mw, dynLds + QCAP + 4 + (size_t)nHelpers * MW_RING + (size_t)(wave - 1) * MW_BM_WORDS, helperStash[wave - 1], helperRed[wave - 1]);
 }

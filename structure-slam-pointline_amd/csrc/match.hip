@@ -37,10 +37,15 @@ extern "C" int sslam_hamming_knn2_batch_dev(sslam_ctx* ctx, const uint8_t* d_q, 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     SSLAM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
-    static const int form = [] { const char* e = getenv("SSLAM_KNN2_BATCH"); return !e ? 2 : !strcmp(e, "popc") ? 0 : !strcmp(e, "mfma1") ? 1 : 2; }();      // experiment knob: popc = the xor + popcount form, mfma1 = 32 queries per wave
+    const char* formEnv = getenv("SSLAM_KNN2_BATCH");      // experiment / test knob, read on every call: popc = the xor + popcount form (the only one beyond 4096 rows), mfma1 = 32 queries per wave
+    const int form = !formEnv ? 2 : !strcmp(formEnv, "popc") ? 0 : !strcmp(formEnv, "mfma1") ? 1 : 2;
     const int tilesCap = (cap + 31) / 32;
     if (tilesCap <= KNN_MFMA_MAX_TILES && form) {       // matrix-core form (match_knn.h): train rows expanded to +-64 bytes in operand order, then 32 / 64 queries per wave
         int rc;
+        // ONE expand buffer per context (256 B per train row: 3 GB at 12 288 frames of 1 000 rows, never shrunk; sslam_frontend_batch counts it in its chunk estimate).
+        // k_knn2_expand writes it and k_knn2_mfma reads it on the caller's stream: a call on another stream first waits for the event behind the previous reader.
+        if (ctx->knnDone && ctx->knnLastStream != (void*)st) SSLAM_HIP(hipStreamWaitEvent(st, ctx->knnDone, 0));
+        if (!ctx->knnDone) SSLAM_HIP(hipEventCreateWithFlags(&ctx->knnDone, hipEventDisableTiming));
         if ((rc = ctx->knnExpand.ensure((size_t)nframes * tilesCap * 8 * 1024))) return rc;
         { sslam::ProfScope _ps(ctx, "k_knn2_expand", st); hipLaunchKernelGGL(k_knn2_expand, dim3(tilesCap, nframes), dim3(64), 0, st, d_t, d_nt, cap, tilesCap, ctx->knnExpand.as<uint8_t>()); }
         const int qblocks = form == 2 ? (cap + 63) / 64 : tilesCap;
@@ -48,6 +53,7 @@ extern "C" int sslam_hamming_knn2_batch_dev(sslam_ctx* ctx, const uint8_t* d_q, 
         sslam::ProfScope _ps(ctx, "k_knn2_batch", st);
         if (form == 2) hipLaunchKernelGGL(k_knn2_mfma<2>, grid, dim3(64), 0, st, d_q, d_nq, ctx->knnExpand.as<uint8_t>(), d_nt, cap, tilesCap, qblocks, nframes, d_idx, d_dist);
         else hipLaunchKernelGGL(k_knn2_mfma<1>, grid, dim3(64), 0, st, d_q, d_nq, ctx->knnExpand.as<uint8_t>(), d_nt, cap, tilesCap, qblocks, nframes, d_idx, d_dist);
+        SSLAM_HIP(hipEventRecord(ctx->knnDone, st)); ctx->knnLastStream = (void*)st;
     } else
     { sslam::ProfScope _ps(ctx, "k_knn2_batch", st); hipLaunchKernelGGL(k_knn2_batch, dim3((cap + 15) / 16, nframes), dim3(256), 0, st, d_q, d_nq, d_t, d_nt, cap, d_idx, d_dist); }
     SSLAM_HIP(hipGetLastError());

@@ -465,6 +465,22 @@ class LineExtractor:
         """0: OpenCV >= 3.4.1's bit-exact 8-bit GaussianBlur (default, decision D6); 1: OpenCV 3.4.0's rounded taps (sslam_lines_set_blur_variant)"""
         _chk(lib().sslam_lines_set_blur_variant(self.h, int(variant)))
 
+    def set_nfa_variant(self, variant):
+        """decision D11: 0 = nfa()'s first term is log_gamma(n + 1) (default); 1 = (double(n) + 1) (sslam_lines_set_nfa_variant)"""
+        _chk(lib().sslam_lines_set_nfa_variant(self.h, int(variant)))
+
+    def set_lbd_bit_order(self, variant):
+        """decision D12: 0 = comparison i -> bit i (default); 1 = comparison i -> 0x80 >> i (sslam_lines_set_lbd_bit_order)"""
+        _chk(lib().sslam_lines_set_lbd_bit_order(self.h, int(variant)))
+
+    def set_resize_variant(self, variant):
+        """decision D7: 0 = INTER_LINEAR_EXACT for LSD's 0.8x rescale (default); 1 = INTER_LINEAR (sslam_lines_set_resize_variant)"""
+        _chk(lib().sslam_lines_set_resize_variant(self.h, int(variant)))
+
+    def set_seed_order(self, variant):
+        """decision D2: 0 = raster order inside a gradient bin (default, on the device); 1 = the host's std::sort (sslam_lines_set_seed_order)"""
+        _chk(lib().sslam_lines_set_seed_order(self.h, int(variant)))
+
     def set_core_event(self, hip_event):
         """hipEvent_t handle (int) recorded right before the sequential LSD core of every following batch call; 0 / None clears it"""
         _chk(lib().sslam_lines_set_core_event(self.h, C.c_void_p(int(hip_event or 0))))

@@ -154,12 +154,18 @@ unsigned long long fnv1a(unsigned long long h, const void* p, size_t n) {
     for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
     return h;
 }
-unsigned long long frame_fingerprint(const std::vector<cv::KeyPoint>& k, const cv::Mat& desc) {
+// every keypoint, every descriptor row, mvuRight and the image bounds: 60 KB of hashing per lookup is cheap next to the upload it saves, and a frame that
+// differs from the cached one ANYWHERE (stereo data, one row in the middle) must miss (round 4 hashed five sampled rows only)
+unsigned long long frame_fingerprint(const std::vector<cv::KeyPoint>& k, const cv::Mat& desc, const float* uright, const float bounds[4]) {
     unsigned long long h = 1469598103934665603ull;
     const int n = (int)k.size();
     h = fnv1a(h, &n, sizeof(n));
-    const int picks[5] = {0, n / 4, n / 2, (3 * n) / 4, n - 1};
-    for (int i : picks) if (i >= 0 && i < n) { h = fnv1a(h, &k[i], sizeof(cv::KeyPoint)); if (i < desc.rows) h = fnv1a(h, desc.ptr(i), 32); }
+    if (n) h = fnv1a(h, k.data(), sizeof(cv::KeyPoint) * (size_t)n);
+    for (int i = 0; i < n && i < desc.rows; ++i) h = fnv1a(h, desc.ptr(i), 32);
+    const int hasU = uright ? 1 : 0;
+    h = fnv1a(h, &hasU, sizeof(hasU));
+    if (uright && n) h = fnv1a(h, uright, sizeof(float) * (size_t)n);
+    h = fnv1a(h, bounds, 4 * sizeof(float));
     return h;
 }
 // g_residentMu must be held by the caller, from the lookup to the end of the search that uses the handle (another thread may evict the slot)
@@ -190,7 +196,7 @@ int SearchByProjection(int mode, const std::vector<cv::KeyPoint> &k, const cv::M
     std::vector<uint8_t> b = rows32(qd);
     int n = 0;
     if (frameId >= 0) {
-        const unsigned long long fp = frame_fingerprint(k, desc);
+        const unsigned long long fp = frame_fingerprint(k, desc, uRight ? uRight->data() : nullptr, bounds);
         std::lock_guard<std::mutex> lk(g_residentMu);      // lookup, upload and search under one lock: the handle cannot be evicted in between
         sslam_frame* fr = resident_frame_locked(frameId, 0, fp, k, desc, uRight ? uRight->data() : nullptr, bounds);
         check(sslam_search_by_projection_frame(G.get(), fr, mode, occupied.empty() ? nullptr : occupied.data(), (const sslam_proj_query*)queries.data(), b.data(),

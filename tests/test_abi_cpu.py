@@ -1,5 +1,5 @@
-"""CPU suite: the C-ABI library is built, loads, exports every symbol include/sslam_frontend.h
-declares, and refuses to run without a GPU (no CPU fallback)."""
+"""CPU suite: the C-ABI library is built, loads, exports every symbol include/*.h
+declare (sslam_frontend.h: the drop-in boundary; sslam_testing.h: test entry points), and refuses to run without a GPU (no CPU fallback)."""
 import ctypes, os, re
 import pytest
 import pkg
@@ -8,9 +8,12 @@ ROOT = pkg.ROOT
 
 
 def _declared_functions():
-    txt = open(os.path.join(ROOT, "include", "sslam_frontend.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(sslam_[a-z0-9_]+)\s*\(", txt)))
+    import glob
+    names = set()
+    for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(sslam_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -77,7 +80,7 @@ def test_documents_name_only_declared_entry_points():
     """every sslam_* name in the documents is declared in include/sslam_frontend.h (prefixes like `sslam_vocab_*` and the C++ shim namespace aside)"""
     import os, re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    declared = set(re.findall(r"\b(sslam_[a-z0-9_]+)\b", open(os.path.join(root, "include", "sslam_frontend.h")).read()))
+    declared = set(re.findall(r"\b(sslam_[a-z0-9_]+)\b", open(os.path.join(root, "include", "sslam_frontend.h")).read() + open(os.path.join(root, "include", "sslam_testing.h")).read()))
     for doc in ("INTEGRATION.md", "DESIGN.md", "README.md", os.path.join("profiles", "README.md"), os.path.join("tools", "README.md")):
         names = set(re.findall(r"\b(sslam_[a-z0-9_]+)\b", open(os.path.join(root, doc)).read()))
         unknown = sorted(n for n in names if n not in declared and not n.startswith("sslam_shim") and not n.endswith("_"))

@@ -106,15 +106,15 @@ def test_group_rank_form_world1(fe, ctx):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
-# N > 1 without an N-GPU box: SSLAM_GROUP_FAKE_RCCL=1 binds a new group to an in-process stand-in for the RCCL entry points (group.hip), the
+# N > 1 without an N-GPU box: sslam_testing_use_rccl_standin(1) (include/sslam_testing.h) binds a new group to an in-process stand-in for the RCCL entry points (group.hip), the
 # members of a group become contexts (streams) of the GPUs that are visible.  What runs is the group code itself -- one host thread per
 # member, the dealing of frames (uneven tails, members without frames), the collective decisions, grouped send / receive to the root,
 # reassembly by header.frame -- with real device buffers and real copies.  The xGMI run stays the driver's scaling run.
 @pytest.fixture
-def fake_rccl():
-    os.environ["SSLAM_GROUP_FAKE_RCCL"] = "1"
+def fake_rccl(fe):
+    fe.lib().sslam_testing_use_rccl_standin(1)
     yield
-    os.environ.pop("SSLAM_GROUP_FAKE_RCCL", None)
+    fe.lib().sslam_testing_use_rccl_standin(0)
     os.environ.pop("SSLAM_GROUP_SELF_SENDRECV", None)
 
 

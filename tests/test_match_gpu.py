@@ -70,6 +70,44 @@ def test_knn2_batch_dev_matrix_core_form(fe, ctx, oracle, cap):
         assert (idx[f, a:] == -7).all()          # rows past the frame's queries are not written
 
 
+@pytest.mark.parametrize("cap,knob", [(4200, None), (1000, "popc"), (96, "mfma1")])
+def test_knn2_batch_dev_other_forms(fe, ctx, oracle, cap, knob, monkeypatch):
+    """the xor + popcount form (the only one beyond 4096 rows per frame; SSLAM_KNN2_BATCH=popc forces it below) and the 32-queries-per-wave matrix-core form
+    (mfma1) against the oracle -- the knob is read on every call since round 5, so one process can compare the forms"""
+    import ctypes as C
+    import torch
+    if knob: monkeypatch.setenv("SSLAM_KNN2_BATCH", knob)
+    rng = np.random.default_rng(cap + 1)
+    counts = [(cap, cap), (37, cap), (cap, 2), (0, 9), (65, 64)]
+    B = len(counts)
+    q = rng.integers(0, 256, size=(B, cap, 32), dtype=np.uint8); t = rng.integers(0, 256, size=(B, cap, 32), dtype=np.uint8)
+    for f, (a, b) in enumerate(counts):
+        t[f, :b] = _rand_desc(rng, b)
+        if f == 0: t[f, :b] = t[f, rng.integers(0, max(1, b // 4), size=b)]
+        if a: q[f, :a] = _rand_desc(rng, a, flip_from=t[f, :b], flips=6)
+    dq = torch.from_numpy(q).cuda(); dt = torch.from_numpy(t).cuda()
+    nq = torch.tensor([a for a, _ in counts], dtype=torch.int32).cuda(); nt = torch.tensor([b for _, b in counts], dtype=torch.int32).cuda()
+    idx = torch.full((B, cap, 2), -7, dtype=torch.int32).cuda(); dist = torch.full((B, cap, 2), -7, dtype=torch.int32).cuda()
+    _p = lambda x: C.c_void_p(x.data_ptr())
+    # two calls on two streams of the one context: the second one's expansion must wait for the first one's search (the context's expand buffer)
+    s2 = torch.cuda.Stream()
+    idx2 = torch.full((B, cap, 2), -7, dtype=torch.int32).cuda(); dist2 = torch.full((B, cap, 2), -7, dtype=torch.int32).cuda()
+    torch.cuda.synchronize()
+    assert fe.lib().sslam_hamming_knn2_batch_dev(ctx.h, _p(dq), _p(nq), _p(dt), _p(nt), cap, B, _p(idx), _p(dist), None) == 0, fe.lib().sslam_last_error()
+    assert fe.lib().sslam_hamming_knn2_batch_dev(ctx.h, _p(dt), _p(nt), _p(dq), _p(nq), cap, B, _p(idx2), _p(dist2), C.c_void_p(s2.cuda_stream)) == 0, fe.lib().sslam_last_error()
+    ctx.synchronize(); torch.cuda.synchronize()
+    idx = idx.cpu().numpy(); dist = dist.cpu().numpy(); idx2 = idx2.cpu().numpy(); dist2 = dist2.cpu().numpy()
+    for f, (a, b) in enumerate(counts):
+        for (na, nb, qq, tt, ii, dd) in ((a, b, q, t, idx, dist), (b, a, t, q, idx2, dist2)):
+            if na == 0: continue
+            if nb == 0:
+                assert (ii[f, :na] == -1).all() and (dd[f, :na] == -1).all()
+                continue
+            oi, od = oracle.knn2(qq[f, :na], tt[f, :nb])
+            np.testing.assert_array_equal(ii[f, :na], oi, err_msg="frame %d (%d x %d)" % (f, na, nb))
+            np.testing.assert_array_equal(dd[f, :na], od, err_msg="frame %d (%d x %d)" % (f, na, nb))
+
+
 def test_hamming_matrix(ctx, oracle):
     rng = np.random.default_rng(5)
     q = _rand_desc(rng, 300); t = _rand_desc(rng, 517)

@@ -1,6 +1,6 @@
-"""Experiments that are in the tree behind knobs (off by default) and have not run through the GPU suite yet (SSLAM_NFA_STREAM: only sslam_lines_extract on 640x480
-frames has, profiles/r04_nfa_stream_c_abi_runs.txt): they stay out of the driver's `pytest -m gpu` run until they have.
-    SSLAM_TEST_EXPERIMENTAL=1 python -m pytest tests/test_experimental_gpu.py -m gpu -q        (under a `timeout`: the first item spins on device-side flags)"""
+"""The NFA stage next to the cluster form of the core (k_nfa_stream, the default for calls of up to 64 frames since round 5; SSLAM_NFA_STREAM=0 puts it back behind the
+core): consumer counts, patience settings, a core without helpers, small batches.  (Round 4 kept these behind SSLAM_TEST_EXPERIMENTAL; round 5's first GPU call ran them and the
+whole suite with the knob exported -- profiles/r05a_pytest_gpu_SSLAM_NFA_STREAM_1.txt -- before the default was flipped.)"""
 import os, sys
 import numpy as np
 import pytest
@@ -11,15 +11,13 @@ sys.path.insert(0, HERE)
 from synth import synth_frame, noise_frame
 from test_lines_gpu import _cmp_lines            # the suite's comparison of one extraction with the oracle (segments, keylines, LBD bytes)
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SSLAM_TEST_EXPERIMENTAL") != "1", reason="experiments not yet run on a GPU: SSLAM_TEST_EXPERIMENTAL=1")]
+pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("knobs", [{"SSLAM_NFA_STREAM": "1"}, {"SSLAM_NFA_STREAM": "3"}, {"SSLAM_NFA_STREAM": "48"},
+@pytest.mark.parametrize("knobs", [{"SSLAM_NFA_STREAM": "0"}, {"SSLAM_NFA_STREAM": "1"}, {"SSLAM_NFA_STREAM": "3"}, {"SSLAM_NFA_STREAM": "48"},
                                    {"SSLAM_NFA_STREAM": "1", "SSLAM_NFA_STREAM_TICKS": "0"},          # every consumer gives up at once: the launch behind the core does all of it
                                    {"SSLAM_NFA_STREAM": "1", "SSLAM_NFA_STREAM_TICKS": "20000"},      # 0.2 ms of patience: some of each
-                                   {"SSLAM_NFA_STREAM": "1", "SSLAM_CL_WINDOW": "-1"},                # no helpers: a slow core, consumers mostly waiting
-                                   {"SSLAM_NFA_STREAM": "1", "SSLAM_NFA_STREAM_EMIT": "lds"},         # hand-over through LDS and a publisher wave (never run on a GPU before round 5)
-                                   {"SSLAM_NFA_STREAM": "8", "SSLAM_NFA_STREAM_EMIT": "lds", "SSLAM_NFA_STREAM_TICKS": "20000"}])
+                                   {"SSLAM_NFA_STREAM": "1", "SSLAM_CL_WINDOW": "-1"}])               # no helpers: a slow core, consumers mostly waiting
 def test_nfa_stage_next_to_the_core(fe, ctx, oracle, knobs, monkeypatch):
     """SSLAM_NFA_STREAM: the NFA stage on a second stream, on the rectangles the cluster form's main wave has published so far (csrc/lsd_nfa.h k_nfa_stream;
     the protocol as a thread model: tests/test_nfa_stream_proto_cpu.py).  Frames with 10x different rectangle counts, one with none, one larger than the LDS bitmap."""

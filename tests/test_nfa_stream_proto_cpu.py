@@ -1,5 +1,4 @@
-"""The hand-over of candidate rectangles from the cluster form's main wave to a concurrent NFA stage (SSLAM_NFA_STREAM=1, an experiment that is off by
-default: csrc/lsd_cluster.h cl_main<G, true>, csrc/lsd_nfa.h k_nfa_stream) as a CPU model with real threads (tests/sim/nfa_stream_proto.cpp): every record is
+"""The hand-over of candidate rectangles from the cluster form's main wave to a concurrent NFA stage (the streaming NFA stage of calls of up to 64 frames: csrc/lsd_cluster.h cl_main<G, true>, csrc/lsd_nfa.h k_nfa_stream) as a CPU model with real threads (tests/sim/nfa_stream_proto.cpp): every record is
 processed exactly once, by a thread that saw its final contents -- with consumers that wait as long as it takes, with consumers that give up (the launch behind the
 core takes what they left), and NOT when the counter is published before the records (negative control: the test can see a broken protocol)."""
 import os, subprocess
@@ -27,15 +26,8 @@ def test_every_rectangle_is_evaluated_exactly_once(proto, runs, max_records, con
 
 
 def test_counter_before_records_is_caught(proto):
-    bad, out = _bad(proto, 300, 400, 8, 0, 1)
-    assert bad > 0, out
-
-
-@pytest.mark.parametrize("runs,max_records,consumers,expire", [(300, 400, 8, 0), (100, 3000, 8, 1)])
-def test_hand_over_through_a_ring_and_a_publisher(proto, runs, max_records, consumers, expire):
-    """STREAM == 2 (SSLAM_NFA_STREAM_EMIT=lds): the main wave writes into a ring of 64 records in LDS, a publisher wave of its workgroup drains it into the staging array and
-    publishes the counters (csrc/lsd_cluster.h cl_publisher); more records than the ring holds, so it wraps and fills"""
-    bad, out = _bad(proto, runs, max_records, consumers, expire, 0, 1)
-    assert bad == 0, out
-    bad, out = _bad(proto, 300, 400, 8, 0, 1, 1)          # `produced` before the record: must be caught
-    assert bad > 0, out
+    """negative control, deterministic: the faulty producer announces record n / 2 and holds it back until a consumer has read it (tests/sim/nfa_stream_proto.cpp),
+    so EVERY run with at least one record is bad -- not "some of 300" as in round 4, which failed 2 of 5 times on an 8-core box"""
+    runs = 40
+    bad, out = _bad(proto, runs, 400, 8, 0, 1)
+    assert bad >= runs - 1, out          # (run 0 has no record)

@@ -1,0 +1,102 @@
+"""GPU parity of the SELECTABLE decisions of the line path: the library under a variant equals the oracle under the same variant.
+
+The arithmetic of LSD / LBD is OpenCV's (called at reference src/ExtractLineSegment.cpp:38-40,53) and this image holds no OpenCV, so where two restatements of a leaf are
+plausible both exist, in the oracle (orc_set_*) AND in the library (sslam_lines_set_*), with the size of what each moves in oracle/ref_pin/pin_report_stub.json:
+  D11 nfa()'s first term   log_gamma(n + 1)  |  (double(n) + 1)
+  D12 LBD bit order        1 << i            |  0x80 >> i
+  D7  LSD's 0.8x rescale   INTER_LINEAR_EXACT|  INTER_LINEAR
+  D2  seed order in a bin  raster (stable)   |  the host's std::sort
+Same bar as tests/test_lines_gpu.py: segments, keylines, line equations bit-equal; KeyLine.angle within 1 ulp; LBD bytes equal wherever the angle is."""
+import numpy as np
+import pytest
+from synth import synth_frame, noise_frame
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {
+    "nfa": ("set_nfa_variant", "orc_set_lsd_nfa_variant"),
+    "lbd_bits": ("set_lbd_bit_order", "orc_set_lbd_bit_order"),
+    "resize": ("set_resize_variant", "orc_set_lsd_resize"),
+    "seed_order": ("set_seed_order", "orc_set_lsd_seed_sort"),
+}
+FRAMES = [(lambda: synth_frame(2000), 200), (lambda: synth_frame(1235, w=1280, h=960), 400), (lambda: noise_frame(3, w=320, h=240), 200),
+          (lambda: synth_frame(91, w=333, h=251), 40), (lambda: np.full((240, 320), 255, np.uint8), 40)]
+
+
+def _ulp_diff(a, b):
+    ai = a.view(np.int32).astype(np.int64); bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai); bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return np.abs(ai - bi)
+
+
+def _equal_to_oracle(ex, oracle, img, cap):
+    kl, ld, fn = ex(img)
+    okl, old, ofn, oraw = oracle.lines_extract(img, cap)
+    np.testing.assert_array_equal(ex.debug_segments(0), oraw, err_msg="LSD segments (before top-N)")
+    assert len(kl) == len(okl)
+    for f in kl.dtype.names:
+        if f == "angle": assert _ulp_diff(kl[f], okl[f]).max(initial=0) <= 1, "KeyLine.angle"
+        else: np.testing.assert_array_equal(kl[f], okl[f], err_msg=f)
+    same = kl["angle"].view(np.uint32) == okl["angle"].view(np.uint32)
+    np.testing.assert_array_equal(ld[same], old[same])
+    assert np.unpackbits(ld ^ old, axis=1).sum(axis=1).max(initial=0) <= 8
+    np.testing.assert_array_equal(fn, ofn)
+    return kl, ld, oraw
+
+
+@pytest.mark.parametrize("which", sorted(VARIANTS))
+def test_line_variant_equals_oracle_variant(fe, ctx, oracle, which):
+    lib_setter, orc_setter = VARIANTS[which]
+    moved = 0
+    for make, cap in FRAMES:
+        img = make()
+        ex = fe.LineExtractor(ctx, cap)
+        try:
+            kl0, ld0, raw0 = _equal_to_oracle(ex, oracle, img, cap)
+            getattr(ex, lib_setter)(1)
+            getattr(oracle.L, orc_setter)(1)
+            try: kl1, ld1, raw1 = _equal_to_oracle(ex, oracle, img, cap)
+            finally: getattr(oracle.L, orc_setter)(0)
+            if which == "lbd_bits":
+                rev = np.array([int("{:08b}".format(i)[::-1], 2) for i in range(256)], np.uint8)
+                np.testing.assert_array_equal(raw1, raw0); np.testing.assert_array_equal(ld1, rev[ld0])      # every byte bit-reversed, nothing else
+                moved += int((ld1 != ld0).sum())
+            else:
+                moved += int(raw1.shape != raw0.shape or (raw1 != raw0).any())
+            if which == "nfa" and len(raw0) > 20: assert len(raw1) > 1.3 * len(raw0), (len(raw0), len(raw1))        # nearly every rectangle passes under variant 1
+            getattr(ex, lib_setter)(0)
+            _, ld2, raw2 = _equal_to_oracle(ex, oracle, img, cap)
+            np.testing.assert_array_equal(raw2, raw0); np.testing.assert_array_equal(ld2, ld0)                # and back
+        finally:
+            ex.close()
+    assert moved > 0, "the variant moved nothing on any frame: the switch is not connected"
+
+
+def test_line_variants_combined_batch(fe, ctx, oracle):
+    """nfa + bit order + resize variants together, through the batch entry (frames resident on the device), 9 frames in one call"""
+    import torch
+    frames = [synth_frame(3000 + i) for i in range(9)]
+    ex = fe.LineExtractor(ctx, 200)
+    try:
+        ex.set_nfa_variant(1); ex.set_lbd_bit_order(1); ex.set_resize_variant(1)
+        for s in ("orc_set_lsd_nfa_variant", "orc_set_lbd_bit_order", "orc_set_lsd_resize"): getattr(oracle.L, s)(1)
+        try:
+            want = [oracle.lines_extract(f, 200) for f in frames]
+        finally:
+            for s in ("orc_set_lsd_nfa_variant", "orc_set_lbd_bit_order", "orc_set_lsd_resize"): getattr(oracle.L, s)(0)
+        dev = torch.from_numpy(np.stack(frames)).cuda()
+        n = len(frames)
+        d_kl = torch.zeros((n, 200, 68), dtype=torch.uint8, device="cuda"); d_ld = torch.zeros((n, 200, 32), dtype=torch.uint8, device="cuda")
+        d_fn = torch.zeros((n, 200, 3), dtype=torch.float64, device="cuda"); d_cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ex.extract_batch_dev(dev.data_ptr(), 640, 480, 640, 640 * 480, n, d_kl.data_ptr(), d_ld.data_ptr(), d_fn.data_ptr(), d_cnt.data_ptr(), 200)
+        torch.cuda.synchronize()
+        cnt = d_cnt.cpu().numpy()
+        for i, (okl, old, ofn, oraw) in enumerate(want):
+            assert cnt[i] == len(okl)
+            np.testing.assert_array_equal(ex.debug_segments(i), oraw)
+            kl = d_kl[i, :cnt[i]].cpu().numpy().reshape(-1).view(fe.KL_DTYPE)
+            same = kl["angle"].view(np.uint32) == okl["angle"].view(np.uint32)
+            np.testing.assert_array_equal(d_ld[i, :cnt[i]].cpu().numpy()[same], old[same])
+            np.testing.assert_array_equal(d_fn[i, :cnt[i]].cpu().numpy(), ofn)
+    finally:
+        ex.close()
