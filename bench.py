@@ -300,6 +300,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing (used for rocprofv3 runs)")
     ap.add_argument("--no-pcie", action="store_true", help="latency leg only (no PCIe-inclusive host-batch leg)")
     ap.add_argument("--nfa-stream-leg", action="store_true", help="(child process of the default run) single-frame line extraction with SSLAM_NFA_STREAM=0 (the NFA stage behind the core) beside the default path")
+    ap.add_argument("--lsd-nfa-variant", type=int, default=-1, help="decision D11 (sslam_lines_set_nfa_variant): 0 = log_gamma(n + 1), the default of rounds 1-4; 1 = (double(n) + 1), the default since round 5; -1: the library's default")
     ap.add_argument("--no-other-workloads", action="store_true", help="the default run appends a short pass of BASELINE configs[3] (1280x960 / 2000 kp / 400 lines) as other_workloads.c4; this skips it")
     args = ap.parse_args()
     if args.nfa_stream_leg:
@@ -352,6 +353,7 @@ def main():
         host_cur = torch.empty((B, H, W), dtype=torch.uint8, pin_memory=True); host_cur.copy_(cur)
 
     pipe = pipeline.FrontendBatch(fe, ctx, W, H, B, NFEAT, NLINES, dev, with_lines=with_lines, with_match=wl["match"])
+    if args.lsd_nfa_variant >= 0 and pipe.lines is not None: pipe.lines.set_nfa_variant(args.lsd_nfa_variant)
     pipe.extract(prev, "prev")      # previous-frame features: extracted once, resident (the stream's t-1 state)
     torch.cuda.synchronize()
 
@@ -480,6 +482,8 @@ def main():
                        "keypoints_per_frame": stat(counts), "lines_per_frame": stat(lcounts),
                        "mean_keypoints": float(counts.mean()), "mean_lines": float(lcounts.mean()),
                        "mean_orb_matches": float(nm.mean()), "mean_line_matches": float(nlp.mean()),
+                       "line_decisions": {"lsd_nfa_variant": (1 if args.lsd_nfa_variant < 0 else args.lsd_nfa_variant), "lbd_bit_order": 1, "lsd_resize": 0, "seed_order": 0,
+                                          "note": "include/sslam_frontend.h sslam_lines_set_*: D11 / D12 default to the OpenCV-as-recalled forms since round 5 (rounds 1-4: 0 / 0; other_workloads.c3_lsd_nfa_variant_0 is the step under the old D11)"},
                        "streams": "point branch and line branch on two HIP streams" if not args.no_overlap else "one stream",
                        "parallelism": ("frames sharded %d/GPU, RCCL gather (sslam_group_gather_dev) of compacted records to rank 0 per step" % B) if gather is not None else "single GPU",
                        "gather_check": gather_info["ok"] if gather_info else None, "gather": gather_info},
@@ -548,6 +552,17 @@ def main():
                                                  "latency": {k: c4.get("latency", {}).get(k) for k in ("orb_extract_hipEvent", "lines_extract_hipEvent", "frames_per_s_one_at_a_time")}}}
             except Exception as e:
                 out["other_workloads"] = {"c4": {"error": str(e)[:300]}}
+            try:      # trend continuity: the same step under decision D11's variant 0 (nfa()'s first term = log_gamma(n + 1): the default of rounds 1-4, whose bench lines r01-r04 are)
+                if args.lsd_nfa_variant < 0:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--no-other-workloads", "--lsd-nfa-variant", "0"],
+                                       capture_output=True, text=True, timeout=600, env=child_env)
+                    v0 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                    out["other_workloads"]["c3_lsd_nfa_variant_0"] = {
+                        "workload": "the headline step with sslam_lines_set_nfa_variant(0) -- log_gamma(n + 1), the default of rounds 1-4 (BENCH_r01..r04 were measured on it); the headline's default, variant 1, accepts 2.0-2.7 x the segments, so its NFA stage is shorter and its frames hold more lines",
+                        "value": v0["value"], "unit": v0["unit"], "ms_per_step": v0["ms_per_step"], "steps": v0["steps"], "mean_lines": v0["config"].get("mean_lines"), "mean_line_matches": v0["config"].get("mean_line_matches"),
+                        "kernels_ms_per_step": {k: v0.get("roofline", {}).get("kernels_ms_per_step", {}).get(k) for k in ("k_lsd_regions", "k_nfa_all", "k_lbd", "k_keylines", "k_line_match")}}
+            except Exception as e:
+                out.setdefault("other_workloads", {})["c3_lsd_nfa_variant_0"] = {"error": str(e)[:300]}
             try:      # the alternative of the single-frame default, in a child process of its own (a fault there cannot touch this line): the NFA stage behind the core instead of next to it
                 import subprocess
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--nfa-stream-leg"], capture_output=True, text=True, timeout=240,

@@ -351,15 +351,15 @@ int sslam_lines_extract(sslam_lines* ln, const uint8_t* gray, int w, int h, size
 int sslam_lines_set_blur_variant(sslam_lines* ln, int variant);
 /* The other stated decisions of the line path that have a selectable alternative.  The arithmetic of LSD and LBD is OpenCV's (called at
  * src/ExtractLineSegment.cpp:38-40,53); this image holds no OpenCV, so each of these is a choice between two restatements, with the size of what it moves
- * measured in oracle/ref_pin/pin_report_stub.json.  variant is 0 (default) or 1; the next extraction takes it.
- *   sslam_lines_set_nfa_variant    D11 -- the first term of LineSegmentDetectorImpl::nfa()'s log1term: 0 = log_gamma(n + 1), the binomial coefficient of von Gioi's
- *                                  lsd.c; 1 = (double(n) + 1) without the log_gamma, as imgproc/src/lsd.cpp is recalled to read.  Under 1 nearly every rectangle passes
- *                                  at its first rect_nfa: 2.0-2.7 x the segments.
- *   sslam_lines_set_lbd_bit_order  D12 -- BinaryDescriptor::binaryConversion: 0 = comparison i sets bit i; 1 = comparison i sets 0x80 >> i.  Every byte is bit-reversed;
- *                                  Hamming distances, hence every matcher result, are the same.
- *   sslam_lines_set_resize_variant D7 -- LSD's 0.8x rescale: 0 = INTER_LINEAR_EXACT (8.8 coefficients, one rounding); 1 = INTER_LINEAR (11-bit coefficients, the two-stage
- *                                  8u rounding of the ORB pyramid's resize).
- *   sslam_lines_set_seed_order     D2 -- the order of LSD's seeds inside one of the 1024 gradient bins: 0 = raster order (a stable counting sort, on the device);
+ * measured in oracle/ref_pin/pin_report_stub.json.  variant is 0 or 1; the next extraction takes it.
+ *   sslam_lines_set_nfa_variant    D11 -- the first term of LineSegmentDetectorImpl::nfa()'s log1term.  1 (DEFAULT since round 5) = `(double(n) + 1)` without the log_gamma,
+ *                                  as imgproc/src/lsd.cpp is recalled to read (two independent recollections); 0 = log_gamma(n + 1), the binomial coefficient of von Gioi's
+ *                                  lsd.c (the default of rounds 1-4).  Under 1 nearly every rectangle passes at its first rect_nfa: 2.0-2.7 x the segments of 0.
+ *   sslam_lines_set_lbd_bit_order  D12 -- BinaryDescriptor::binaryConversion.  1 (DEFAULT since round 5) = comparison i sets `0x80 >> i` (as recalled); 0 = comparison i
+ *                                  sets bit i (rounds 1-4).  Every byte is bit-reversed; Hamming distances, hence every matcher result, are the same.
+ *   sslam_lines_set_resize_variant D7 -- LSD's 0.8x rescale: 0 (default) = INTER_LINEAR_EXACT (8.8 coefficients, one rounding); 1 = INTER_LINEAR (11-bit coefficients,
+ *                                  the two-stage 8u rounding of the ORB pyramid's resize).
+ *   sslam_lines_set_seed_order     D2 -- the order of LSD's seeds inside one of the 1024 gradient bins: 0 (default) = raster order (a stable counting sort, on the device);
  *                                  1 = whatever `std::sort` of this library's libstdc++ leaves, as upstream's ll_angle sorts: the bins are sorted ON THE HOST (one
  *                                  download, one std::sort of every pixel and one upload per frame: ~15 ms per 640x480 frame -- a switch for comparing with a
  *                                  maintainer's CPU build, not a production path). */

@@ -12,7 +12,7 @@
 #include "lines_types.h"
 
 namespace orc {
-int g_lbdBitOrder = 0;      // decision D12 (see the pack step below); orc_set_lbd_bit_order(), library: sslam_lines_set_lbd_bit_order()
+int g_lbdBitOrder = 1;      // decision D12 (see the pack step below; 1 = the default since round 5); orc_set_lbd_bit_order(), library: sslam_lines_set_lbd_bit_order()
 
 static const int NUM_OF_BANDS = 9, WIDTH_OF_BAND = 7;
 
@@ -128,8 +128,9 @@ void lbd_compute(const Img8& image, const std::vector<KeyLine>& keylines, std::v
             const float* f1 = &desVec[8 * kCombinations[comb][0]];
             const float* f2 = &desVec[8 * kCombinations[comb][1]];
             uint8_t result = 0;
-            // decision D12 -- 0: bit i of the byte = comparison i (LSB first); 1: BinaryDescriptor::binaryConversion as two independent recollections have it,
-            // `result += 0x80 >> i` (MSB first; UPSTREAM-RECALL).  Hamming distances -- every matcher result -- are the same under both.
+            // decision D12 -- 1 (DEFAULT since round 5): BinaryDescriptor::binaryConversion as two independent recollections have it, `result += (uchar)(0x80 >> i)`
+            // (MSB first; UPSTREAM-RECALL); 0: bit i of the byte = comparison i (LSB first, the default of rounds 1-4).  Hamming distances -- every matcher result --
+            // are the same under both.
             for (int i = 0; i < 8; ++i) if (f1[i] > f2[i]) result += (uint8_t)(g_lbdBitOrder == 1 ? (0x80 >> i) : (1 << i));
             row[comb] = result;
         }

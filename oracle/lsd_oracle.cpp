@@ -20,9 +20,11 @@
 namespace orc {
 int g_lsdResize = 0;        // 0: decision D7 (INTER_LINEAR_EXACT); 1: INTER_LINEAR (error bar only)
 int g_lsdSeedSort = 0;      // 0: decision D2 (stable: raster order inside a bin); 1: upstream's std::sort (error bar only)
-int g_lsdNfaVariant = 0;    // decision D11 -- 0: nfa()'s first term as von Gioi's lsd.c has it, log_gamma(n + 1) (the mathematical binomial coefficient);
-                            // 1: the term as two independent recollections of OpenCV's imgproc/src/lsd.cpp have it, (double(n) + 1) WITHOUT the log_gamma around it
-                            // (UPSTREAM-RECALL; the round-4 review's and the builder's).  orc_set_lsd_nfa_variant(); the library's switch is sslam_lines_set_nfa_variant().
+int g_lsdNfaVariant = 1;    // decision D11 -- nfa()'s first term.  1 (DEFAULT since round 5): `(double(n) + 1)`, as imgproc/src/lsd.cpp is recalled to read by two independent
+                            // recollections (the round-4 review's and the builder's, the latter including the comment block above the line: "bincoef(n,k) = gamma(n+1) /
+                            // ( gamma(k+1) * gamma(n-k+1) ).  We use this to compute the first term.  Actually the log of it." followed by a first term WITHOUT the log_gamma);
+                            // 0: log_gamma(n + 1), the binomial coefficient of von Gioi's lsd.c (the default of rounds 1-4).  UPSTREAM-RECALL either way: orc_set_lsd_nfa_variant();
+                            // the library's switch is sslam_lines_set_nfa_variant().
 
 
 static const double NOTDEF = -1024.0;

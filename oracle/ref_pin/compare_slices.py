@@ -793,10 +793,10 @@ def unmatched(a, b, tol=1.0):
 
 
 d2 = {"frames": 0, "segments": 0, "segments_in_one_set_only": 0, "segments_moved_more_than_1px": 0}; d7 = {"frames": 0, "segments": 0, "segments_in_one_set_only": 0, "segments_moved_more_than_1px": 0}
-# D11 (nfa()'s first term: log_gamma(n + 1) | (double(n) + 1)) and D12 (LBD bit order: 1 << i | 0x80 >> i): the same kind of row -- oracle against oracle, the size of what the
+# D11 (nfa()'s first term: (double(n) + 1), the default | log_gamma(n + 1)) and D12 (LBD bit order: 0x80 >> i, the default | 1 << i): the same kind of row -- oracle against oracle, the size of what the
 # decision moves.  Both alternatives are selectable in the library too (sslam_lines_set_nfa_variant / _lbd_bit_order; tests/test_variants_gpu.py compares library and oracle under each).
-d11 = {"frames": 0, "segments": 0, "segments_variant_1": 0, "segments_in_both": 0, "segments_in_one_set_only": 0, "segments_moved_more_than_1px": 0,
-       "keylines_after_cap_200": 0, "keylines_after_cap_200_variant_1": 0}
+d11 = {"frames": 0, "segments": 0, "segments_variant_0": 0, "segments_in_both": 0, "segments_in_one_set_only": 0, "segments_moved_more_than_1px": 0,
+       "keylines_after_cap_200": 0, "keylines_after_cap_200_variant_0": 0}
 d12 = {"frames": 0, "lines": 0, "lbd_bytes": 0, "lbd_bytes_differing": 0, "lbd_bytes_not_the_bit_reversal": 0, "hamming_distances_differing": 0, "line_matcher_results_differing": 0}
 _rev = np.array([int("{:08b}".format(i)[::-1], 2) for i in range(256)], np.uint8)
 _prev = None
@@ -805,31 +805,31 @@ for img in [frames["synth1234"][0], frames["synth2000"][0], frames["big1235"][0]
     a = orc.lines_extract(img, 400)[3]
     sa = set(map(bytes, a.view(np.uint8).reshape(len(a), -1)))
     for setter, acc in ((O.orc_set_lsd_seed_sort, d2), (O.orc_set_lsd_resize, d7)):
-        setter(1)
+        old_ = setter(1)
         try: b = orc.lines_extract(img, 400)[3]
-        finally: setter(0)
+        finally: setter(old_)
         sb = set(map(bytes, b.view(np.uint8).reshape(len(b), -1)))
         acc["frames"] += 1; acc["segments"] += len(sa); acc["segments_in_one_set_only"] += len(sa ^ sb)
         acc["segments_moved_more_than_1px"] += unmatched(a, b) + unmatched(b, a)
-    # D11
-    O.orc_set_lsd_nfa_variant(1)
-    try: r1 = orc.lines_extract(img, 200)
-    finally: O.orc_set_lsd_nfa_variant(0)
-    r0 = orc.lines_extract(img, 200)
-    b = r1[3]; sb = set(map(bytes, b.view(np.uint8).reshape(len(b), -1)))
-    d11["frames"] += 1; d11["segments"] += len(sa); d11["segments_variant_1"] += len(sb); d11["segments_in_both"] += len(sa & sb); d11["segments_in_one_set_only"] += len(sa ^ sb)
-    d11["segments_moved_more_than_1px"] += unmatched(a, b) + unmatched(b, a); d11["keylines_after_cap_200"] += len(r0[0]); d11["keylines_after_cap_200_variant_1"] += len(r1[0])
-    # D12
-    O.orc_set_lbd_bit_order(1)
-    try: q1 = orc.lines_extract(img, 200)
-    finally: O.orc_set_lbd_bit_order(0)
-    d12["frames"] += 1; d12["lines"] += len(r0[0]); d12["lbd_bytes"] += r0[1].size; d12["lbd_bytes_differing"] += int((r0[1] != q1[1]).sum()); d12["lbd_bytes_not_the_bit_reversal"] += int((_rev[r0[1]] != q1[1]).sum())
-    if _prev is not None and len(_prev[0]) >= 2 and len(r0[1]) >= 2:
-        d12["hamming_distances_differing"] += int((orc.hamming_matrix(_prev[0], r0[1]) != orc.hamming_matrix(_prev[1], q1[1])).sum())
+    # D11: variant 0 (von Gioi's binomial coefficient) against the default, variant 1
+    old_ = O.orc_set_lsd_nfa_variant(0)
+    try: r0 = orc.lines_extract(img, 200); a0 = orc.lines_extract(img, 400)[3]
+    finally: O.orc_set_lsd_nfa_variant(old_)
+    r1 = orc.lines_extract(img, 200)
+    sa0 = set(map(bytes, a0.view(np.uint8).reshape(len(a0), -1)))
+    d11["frames"] += 1; d11["segments_variant_0"] += len(sa0); d11["segments"] += len(sa); d11["segments_in_both"] += len(sa & sa0); d11["segments_in_one_set_only"] += len(sa ^ sa0)
+    d11["segments_moved_more_than_1px"] += unmatched(a, a0) + unmatched(a0, a); d11["keylines_after_cap_200_variant_0"] += len(r0[0]); d11["keylines_after_cap_200"] += len(r1[0])
+    # D12: variant 0 (LSB first) against the default
+    old_ = O.orc_set_lbd_bit_order(0)
+    try: q0 = orc.lines_extract(img, 200)
+    finally: O.orc_set_lbd_bit_order(old_)
+    d12["frames"] += 1; d12["lines"] += len(r1[0]); d12["lbd_bytes"] += r1[1].size; d12["lbd_bytes_differing"] += int((r1[1] != q0[1]).sum()); d12["lbd_bytes_not_the_bit_reversal"] += int((_rev[r1[1]] != q0[1]).sum())
+    if _prev is not None and len(_prev[0]) >= 2 and len(r1[1]) >= 2:
+        d12["hamming_distances_differing"] += int((orc.hamming_matrix(_prev[0], r1[1]) != orc.hamming_matrix(_prev[1], q0[1])).sum())
         for gate, ratio in ((0.5, False), (0.1, False), (0.5, True)):
-            m0 = orc.line_match(_prev[0], r0[1], gate, ratio); m1 = orc.line_match(_prev[1], q1[1], gate, ratio)
+            m0 = orc.line_match(_prev[0], r1[1], gate, ratio); m1 = orc.line_match(_prev[1], q0[1], gate, ratio)
             d12["line_matcher_results_differing"] += int(not (np.array_equal(m0[0], m1[0]) and m0[1:] == m1[1:]))
-    _prev = (r0[1], q1[1])
+    _prev = (r1[1], q0[1])
 report["d11_nfa_variant_error_bar_oracle_only"] = d11
 print("D11 (nfa() first term log_gamma(n + 1) vs (n + 1), oracle against oracle):", d11)
 report["d12_lbd_bit_order_oracle_only"] = d12

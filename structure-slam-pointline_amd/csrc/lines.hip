@@ -81,7 +81,7 @@ struct sslam_lines {
     HostPinned hOut;
     bool constsUploaded = false;
     int blurVariant = 0;            // sslam_lines_set_blur_variant
-    int nfaVariant = 0, lbdBitOrder = 0, lsdResize = 0;      // sslam_lines_set_nfa_variant / _lbd_bit_order / _resize_variant (decisions D11, D12, D7)
+    int nfaVariant = 1, lbdBitOrder = 1, lsdResize = 0;      // sslam_lines_set_nfa_variant / _lbd_bit_order / _resize_variant (decisions D11, D12, D7): D11 and D12 default to the OpenCV-as-recalled forms since round 5
     int seedOrder = 0;              // sslam_lines_set_seed_order (decision D2): 1 = the seeds are ordered by the host's std::sort
     int sMin = 0;                   // smallest |g|^2 of a defined pixel (k_grad_smin, with the gradient table)
     hipStream_t nfaStream = nullptr; hipEvent_t nfaFork = nullptr, nfaJoin = nullptr;      // SSLAM_NFA_STREAM=1: the NFA stage next to the cluster form of the core

@@ -44,9 +44,9 @@ struct LsdPlan {
     int tabX, tabY;           // offsets into the resize table (int: ofs, c1)
     double rho, prec, p, logNT;
     int minRegSize;
-    // stated decisions with a selectable alternative (sslam_lines_set_*): all 0 by default
-    int nfaVariant;           // D11: first term of nfa()'s log1term -- 0: log_gamma(n + 1); 1: (double(n) + 1)
-    int lbdBitOrder;          // D12: LBD byte packing -- 0: comparison i -> bit i; 1: comparison i -> bit 7 - i (0x80 >> i)
+    // stated decisions with a selectable alternative (sslam_lines_set_*)
+    int nfaVariant;           // D11: first term of nfa()'s log1term -- 1 (default): (double(n) + 1); 0: log_gamma(n + 1)
+    int lbdBitOrder;          // D12: LBD byte packing -- 1 (default): comparison i -> bit 7 - i (0x80 >> i); 0: comparison i -> bit i
     int lsdResize;            // D7: the 0.8x rescale -- 0: INTER_LINEAR_EXACT (q8 coefficients, one rounding); 1: INTER_LINEAR (11-bit coefficients, the two-stage 8u rounding)
 };
 

@@ -466,11 +466,11 @@ class LineExtractor:
         _chk(lib().sslam_lines_set_blur_variant(self.h, int(variant)))
 
     def set_nfa_variant(self, variant):
-        """decision D11: 0 = nfa()'s first term is log_gamma(n + 1) (default); 1 = (double(n) + 1) (sslam_lines_set_nfa_variant)"""
+        """decision D11: 1 = nfa()'s first term is (double(n) + 1) (default since round 5, OpenCV as recalled); 0 = log_gamma(n + 1) (sslam_lines_set_nfa_variant)"""
         _chk(lib().sslam_lines_set_nfa_variant(self.h, int(variant)))
 
     def set_lbd_bit_order(self, variant):
-        """decision D12: 0 = comparison i -> bit i (default); 1 = comparison i -> 0x80 >> i (sslam_lines_set_lbd_bit_order)"""
+        """decision D12: 1 = comparison i -> 0x80 >> i (default since round 5, OpenCV as recalled); 0 = comparison i -> bit i (sslam_lines_set_lbd_bit_order)"""
         _chk(lib().sslam_lines_set_lbd_bit_order(self.h, int(variant)))
 
     def set_resize_variant(self, variant):

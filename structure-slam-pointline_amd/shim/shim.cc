@@ -29,6 +29,12 @@ struct Global {
         std::lock_guard<std::mutex> lk(mu);
         if (!lines) {
             if (sslam_lines_create(c, maxLines, &lines) != SSLAM_OK) throw std::runtime_error(sslam_last_error());
+            // the other leaves of the line path whose upstream form is a stated decision (include/sslam_frontend.h): one environment variable each, so
+            // that the day `make -C oracle/ref_pin pin` first runs against a real OpenCV no recompilation stands between a maintainer and the matching variant
+            struct { const char* env; int (*set)(sslam_lines*, int); } knobs[] = {
+                {"SSLAM_LSD_NFA_VARIANT", sslam_lines_set_nfa_variant}, {"SSLAM_LBD_BIT_ORDER", sslam_lines_set_lbd_bit_order},
+                {"SSLAM_LSD_RESIZE_VARIANT", sslam_lines_set_resize_variant}, {"SSLAM_LSD_SEED_ORDER", sslam_lines_set_seed_order}};
+            for (auto& k : knobs) if (const char* e = std::getenv(k.env)) if (k.set(lines, std::atoi(e)) != SSLAM_OK) throw std::runtime_error(sslam_last_error());
             if (const char* e = std::getenv("SSLAM_ORB_BLUR_VARIANT")) if (sslam_lines_set_blur_variant(lines, std::atoi(e)) != SSLAM_OK) throw std::runtime_error(sslam_last_error());      // one knob for both extractors: the OpenCV release behind the reference build
         }
         return lines;

@@ -273,7 +273,9 @@ def test_fast_and_orientation_against_scikit_image(oracle):
 def test_sobel_and_nfa_against_scipy(oracle):
     """two more leaves with an independent implementation at hand: cv::Sobel 3x3 / BORDER_REFLECT_101 (scipy.ndimage.correlate, mode
     'mirror', exact integers) and the LSD number of false alarms (exact binomial tail from scipy.stats; the restated algorithm truncates
-    the tail once the remainder is below 10 % of |NFA| x tail, so it may only err upwards and by a bounded amount)"""
+    the tail once the remainder is below 10 % of |NFA| x tail, so it may only err upwards and by a bounded amount).  The NFA half runs under decision D11's variant 0
+    (log_gamma(n + 1), von Gioi's mathematical form): that proves variant 0 IS the binomial tail -- it does not say which form OpenCV ships; variant 1, the default since
+    round 5, differs from it by exactly (lgamma(n + 1) - (n + 1)) / ln 10 in every value that passes through log1term (tests/test_variants_cpu.py)."""
     import ctypes as C
     from scipy import ndimage, stats
     img = synth_frame(5, w=200, h=120)
@@ -287,6 +289,7 @@ def test_sobel_and_nfa_against_scipy(oracle):
     log_nt = 5 * (np.log10(w) + np.log10(h)) / 2 + np.log10(11.0)
     rng = np.random.default_rng(3)
     checked = 0
+    old_variant = oracle.L.orc_set_lsd_nfa_variant(0)
     for _ in range(3000):
         n = int(rng.integers(2, 600)); p = float(rng.choice([0.125, 0.0625, 0.03125]))
         kk = int(rng.integers(max(1, int(n * p)), n + 1))
@@ -298,6 +301,7 @@ def test_sobel_and_nfa_against_scipy(oracle):
         slack = np.log10(1.0 + 0.1 * abs(got)) + lg
         assert -lg <= got - ref <= slack, (n, kk, p, got, ref)
         checked += 1
+    oracle.L.orc_set_lsd_nfa_variant(old_variant)
     assert checked > 2500
     assert oracle.L.orc_lsd_nfa(w, h, 0, 0, C.c_double(0.125)) == -log_nt                    # n == 0 or k == 0: -logNT
 

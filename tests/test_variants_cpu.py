@@ -54,34 +54,38 @@ def test_nfa_variant_is_the_first_term_only(orc):
         finally:
             L.orc_set_lsd_nfa_variant(old)
     # what the variant means for the detector: the rectangle of a small, poorly aligned region is meaningful under 1 and not under 0
-    v0 = L.orc_lsd_nfa(w, h, 60, 18, 0.125)
-    L.orc_set_lsd_nfa_variant(1)
-    try: v1 = L.orc_lsd_nfa(w, h, 60, 18, 0.125)
-    finally: L.orc_set_lsd_nfa_variant(0)
+    old = L.orc_set_lsd_nfa_variant(0)
+    try:
+        v0 = L.orc_lsd_nfa(w, h, 60, 18, 0.125)
+        L.orc_set_lsd_nfa_variant(1)
+        v1 = L.orc_lsd_nfa(w, h, 60, 18, 0.125)
+    finally: L.orc_set_lsd_nfa_variant(old)
+    assert old == 1, "variant 1 (OpenCV as recalled) is the default since round 5"
     assert v0 < 0 < v1 and v1 - v0 == pytest.approx((_lg(61.0, orc) - 61.0) / math.log(10.0), rel=1e-6)
 
 
 def test_nfa_variant_accepts_more_segments_and_keeps_the_candidates(orc):
     for img in (synth_frame(1234), synth_frame(91, w=333, h=251)):
-        a = orc.lines_extract(img, 400)[3]
-        orc.L.orc_set_lsd_nfa_variant(1)
-        try: b = orc.lines_extract(img, 400)[3]
-        finally: orc.L.orc_set_lsd_nfa_variant(0)
+        b = orc.lines_extract(img, 400)[3]                      # the default: variant 1
+        old = orc.L.orc_set_lsd_nfa_variant(0)
+        try: a = orc.lines_extract(img, 400)[3]
+        finally: orc.L.orc_set_lsd_nfa_variant(old)
         assert len(b) > 1.5 * len(a)
         sa = set(map(bytes, a.view(np.uint8).reshape(len(a), -1))); sb = set(map(bytes, b.view(np.uint8).reshape(len(b), -1)))
         assert len(sa & sb) > 0.8 * len(sa)          # a rectangle that passed at its first rect_nfa under 0 passes unchanged under 1
         c = orc.lines_extract(img, 400)[3]
-        np.testing.assert_array_equal(a, c)
+        np.testing.assert_array_equal(b, c)
 
 
 def test_lbd_bit_order_reverses_every_byte_and_no_distance(orc):
     rev = np.array([int("{:08b}".format(i)[::-1], 2) for i in range(256)], np.uint8)
     res = []
     for img in (synth_frame(2000), synth_frame(2001)):
-        kl0, ld0, fn0, raw0 = orc.lines_extract(img, 200)
-        orc.L.orc_set_lbd_bit_order(1)
-        try: kl1, ld1, fn1, raw1 = orc.lines_extract(img, 200)
-        finally: orc.L.orc_set_lbd_bit_order(0)
+        kl1, ld1, fn1, raw1 = orc.lines_extract(img, 200)      # the default: 0x80 >> i
+        old = orc.L.orc_set_lbd_bit_order(0)
+        try: kl0, ld0, fn0, raw0 = orc.lines_extract(img, 200)
+        finally: orc.L.orc_set_lbd_bit_order(old)
+        assert old == 1
         np.testing.assert_array_equal(kl0, kl1); np.testing.assert_array_equal(raw0, raw1); np.testing.assert_array_equal(fn0, fn1)
         np.testing.assert_array_equal(ld1, rev[ld0])
         assert (ld1 != ld0).mean() > 0.5

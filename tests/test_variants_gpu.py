@@ -2,10 +2,11 @@
 
 The arithmetic of LSD / LBD is OpenCV's (called at reference src/ExtractLineSegment.cpp:38-40,53) and this image holds no OpenCV, so where two restatements of a leaf are
 plausible both exist, in the oracle (orc_set_*) AND in the library (sslam_lines_set_*), with the size of what each moves in oracle/ref_pin/pin_report_stub.json:
-  D11 nfa()'s first term   log_gamma(n + 1)  |  (double(n) + 1)
-  D12 LBD bit order        1 << i            |  0x80 >> i
-  D7  LSD's 0.8x rescale   INTER_LINEAR_EXACT|  INTER_LINEAR
-  D2  seed order in a bin  raster (stable)   |  the host's std::sort
+                           default            |  alternative
+  D11 nfa()'s first term   (double(n) + 1)    |  log_gamma(n + 1)
+  D12 LBD bit order        0x80 >> i          |  1 << i
+  D7  LSD's 0.8x rescale   INTER_LINEAR_EXACT |  INTER_LINEAR
+  D2  seed order in a bin  raster (stable)    |  the host's std::sort
 Same bar as tests/test_lines_gpu.py: segments, keylines, line equations bit-equal; KeyLine.angle within 1 ulp; LBD bytes equal wherever the angle is."""
 import numpy as np
 import pytest
@@ -13,11 +14,11 @@ from synth import synth_frame, noise_frame
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = {
-    "nfa": ("set_nfa_variant", "orc_set_lsd_nfa_variant"),
-    "lbd_bits": ("set_lbd_bit_order", "orc_set_lbd_bit_order"),
-    "resize": ("set_resize_variant", "orc_set_lsd_resize"),
-    "seed_order": ("set_seed_order", "orc_set_lsd_seed_sort"),
+VARIANTS = {          # library setter, oracle setter, default value
+    "nfa": ("set_nfa_variant", "orc_set_lsd_nfa_variant", 1),
+    "lbd_bits": ("set_lbd_bit_order", "orc_set_lbd_bit_order", 1),
+    "resize": ("set_resize_variant", "orc_set_lsd_resize", 0),
+    "seed_order": ("set_seed_order", "orc_set_lsd_seed_sort", 0),
 }
 FRAMES = [(lambda: synth_frame(2000), 200), (lambda: synth_frame(1235, w=1280, h=960), 400), (lambda: noise_frame(3, w=320, h=240), 200),
           (lambda: synth_frame(91, w=333, h=251), 40), (lambda: np.full((240, 320), 255, np.uint8), 40)]
@@ -46,25 +47,26 @@ def _equal_to_oracle(ex, oracle, img, cap):
 
 @pytest.mark.parametrize("which", sorted(VARIANTS))
 def test_line_variant_equals_oracle_variant(fe, ctx, oracle, which):
-    lib_setter, orc_setter = VARIANTS[which]
+    lib_setter, orc_setter, dflt = VARIANTS[which]
+    alt = 1 - dflt
     moved = 0
     for make, cap in FRAMES:
         img = make()
         ex = fe.LineExtractor(ctx, cap)
         try:
-            kl0, ld0, raw0 = _equal_to_oracle(ex, oracle, img, cap)
-            getattr(ex, lib_setter)(1)
-            getattr(oracle.L, orc_setter)(1)
+            kl0, ld0, raw0 = _equal_to_oracle(ex, oracle, img, cap)                       # both on their defaults
+            getattr(ex, lib_setter)(alt)
+            assert getattr(oracle.L, orc_setter)(alt) == dflt, "oracle and library disagree on the default of " + which
             try: kl1, ld1, raw1 = _equal_to_oracle(ex, oracle, img, cap)
-            finally: getattr(oracle.L, orc_setter)(0)
+            finally: getattr(oracle.L, orc_setter)(dflt)
             if which == "lbd_bits":
                 rev = np.array([int("{:08b}".format(i)[::-1], 2) for i in range(256)], np.uint8)
                 np.testing.assert_array_equal(raw1, raw0); np.testing.assert_array_equal(ld1, rev[ld0])      # every byte bit-reversed, nothing else
                 moved += int((ld1 != ld0).sum())
             else:
                 moved += int(raw1.shape != raw0.shape or (raw1 != raw0).any())
-            if which == "nfa" and len(raw0) > 20: assert len(raw1) > 1.3 * len(raw0), (len(raw0), len(raw1))        # nearly every rectangle passes under variant 1
-            getattr(ex, lib_setter)(0)
+            if which == "nfa" and len(raw1) > 20: assert len(raw0) > 1.3 * len(raw1), (len(raw0), len(raw1))        # nearly every rectangle passes under variant 1 (the default)
+            getattr(ex, lib_setter)(dflt)
             _, ld2, raw2 = _equal_to_oracle(ex, oracle, img, cap)
             np.testing.assert_array_equal(raw2, raw0); np.testing.assert_array_equal(ld2, ld0)                # and back
         finally:
@@ -73,17 +75,17 @@ def test_line_variant_equals_oracle_variant(fe, ctx, oracle, which):
 
 
 def test_line_variants_combined_batch(fe, ctx, oracle):
-    """nfa + bit order + resize variants together, through the batch entry (frames resident on the device), 9 frames in one call"""
+    """the three alternatives that run on the device together (nfa 0, bit order 0, resize 1), through the batch entry (frames resident on the device), 9 frames in one call"""
     import torch
     frames = [synth_frame(3000 + i) for i in range(9)]
     ex = fe.LineExtractor(ctx, 200)
     try:
-        ex.set_nfa_variant(1); ex.set_lbd_bit_order(1); ex.set_resize_variant(1)
-        for s in ("orc_set_lsd_nfa_variant", "orc_set_lbd_bit_order", "orc_set_lsd_resize"): getattr(oracle.L, s)(1)
+        ex.set_nfa_variant(0); ex.set_lbd_bit_order(0); ex.set_resize_variant(1)
+        olds = [(s, getattr(oracle.L, s)(v)) for s, v in (("orc_set_lsd_nfa_variant", 0), ("orc_set_lbd_bit_order", 0), ("orc_set_lsd_resize", 1))]
         try:
             want = [oracle.lines_extract(f, 200) for f in frames]
         finally:
-            for s in ("orc_set_lsd_nfa_variant", "orc_set_lbd_bit_order", "orc_set_lsd_resize"): getattr(oracle.L, s)(0)
+            for s, v in olds: getattr(oracle.L, s)(v)
         dev = torch.from_numpy(np.stack(frames)).cuda()
         n = len(frames)
         d_kl = torch.zeros((n, 200, 68), dtype=torch.uint8, device="cuda"); d_ld = torch.zeros((n, 200, 32), dtype=torch.uint8, device="cuda")

@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
     HIPCHK(hipSetDevice(0));
     sslam_ctx* ctx = NULL; sslam_orb* orb = NULL; sslam_lines* ln = NULL;
     SCHK(sslam_ctx_create(0, &ctx)); SCHK(sslam_orb_create(ctx, 1000, 1.2f, 8, 20, 7, &orb)); SCHK(sslam_lines_create(ctx, LCAP, &ln));
+    if (getenv("STEP_NFA_VARIANT")) SCHK(sslam_lines_set_nfa_variant(ln, atoi(getenv("STEP_NFA_VARIANT"))));      /* decision D11's other form: timing only (the expected lines are the default's) */
     const int cap = sslam_orb_max_keypoints(orb);
     unsigned char *dCur, *dPrev;
     HIPCHK(hipMalloc((void**)&dCur, (size_t)B * fsz)); HIPCHK(hipMalloc((void**)&dPrev, (size_t)B * fsz));
