@@ -52,6 +52,10 @@ struct Plan {
     const uint4* blurToep;              // the horizontal pass of k_describe as matrix-core operands (build_blur_toeplitz)
     int blurTapSum;
     size_t pyrFrame;              // bytes
+    // Level 0 of the pyramid is the caller's image (src/ORBextractor.cc:1107-1132 copies it into a padded buffer; the padding is reflect-101 addressing here).  When base,
+    // pitch and frame stride are 4-byte aligned the consumers read it IN PLACE (img0 != nullptr: per call, set by sslam_orb_extract_batch_dev); otherwise k_copy_level0
+    // copies it into the frame's pyramid block first (rounds 1-4 always did: 0.6 MB per frame read and written for nothing).
+    const uint8_t* img0; size_t img0Stride; int img0Pitch;
     int maxCellW, maxCellH, maxCellsLevel, maxNodeCap;
     LevelInfo L[MAX_LEVELS];
 };
@@ -62,6 +66,13 @@ struct CellInfo {
     int candOff;                  // offset inside the frame's candidate array
     unsigned magic, gmagic;       // 2^19 / cell width + 1 and 2^19 / (dword groups per row) + 1: k_fast_cells' exact divisions as one 24-bit multiply and a shift (i < 4400 < 2^19 / 64; the product stays below 2^32)
 };
+
+// base pointer and row pitch of level `level` of frame b
+__device__ __forceinline__ const uint8_t* level_image(const Plan& P, const uint8_t* __restrict__ pyr, size_t pyrFrame, int b, int level, int& pitch) {
+    if (level == 0 && P.img0) { pitch = P.img0Pitch; return P.img0 + (size_t)b * P.img0Stride; }
+    pitch = P.L[level].pitch;
+    return pyr + (size_t)b * pyrFrame + P.L[level].off;
+}
 
 __device__ const signed char kPat[1024] = {
 #include "orb_pattern.inc"
@@ -101,8 +112,10 @@ __device__ __forceinline__ unsigned pick2(unsigned d0, unsigned d1, unsigned d2,
     const unsigned long long w12 = (unsigned long long)d1 | ((unsigned long long)d2 << 32);
     return (unsigned)((o < 4 ? w01 : w12) >> (8 * (o < 4 ? o : o - 4)));
 }
-__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_t pyrFrame, LevelInfo S, LevelInfo D,
-                                                const short4* __restrict__ tabs) {
+// src / srcStride / srcPitch: the source level (a level of the pyramid block, or the caller's image for level 1: Plan::img0); srcGuard: the source has no spare bytes
+// behind a row (the caller's image), so a group whose three dwords would reach past the pitch takes the byte path
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, size_t srcStride, int srcPitch, int srcGuard, uint8_t* __restrict__ pyr, size_t pyrFrame,
+                                                LevelInfo S, LevelInfo D, const short4* __restrict__ tabs) {
     const int b = blockIdx.y;
     const int ngroups = (D.w + 3) >> 2;                 // flattened (row, 4-pixel group) index: full waves whatever the level width
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -114,9 +127,9 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
     const short4 ty = tabs[D.tabY + y];
     const uint4 ta = *(const uint4*)(tabs + D.tabX + x4), tb = *(const uint4*)(tabs + D.tabX + x4 + 2);
     const int sy0 = min(max((int)ty.x, 0), S.h - 1), sy1 = min(max((int)ty.x + 1, 0), S.h - 1);
-    const uint8_t* sbase = pyr + (size_t)b * pyrFrame + S.off;
-    const uint8_t* g0 = sbase + (size_t)sy0 * S.pitch;
-    const uint8_t* g1 = sbase + (size_t)sy1 * S.pitch;
+    const uint8_t* sbase = src + (size_t)b * srcStride;
+    const uint8_t* g0 = sbase + (size_t)sy0 * srcPitch;
+    const uint8_t* g1 = sbase + (size_t)sy1 * srcPitch;
     const unsigned tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
     int sx[4];
 #pragma unroll
@@ -124,7 +137,7 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
     const int a = sx[0] & ~3;
     unsigned out = 0;
     const int b0 = ty.y, b1 = ty.z;
-    if (sx[3] - a <= 10 && sx[1] - sx[0] <= 2 && sx[3] - sx[2] <= 2) {      // pitch % 64 == 0 and the frame block has 16 spare bytes: the dwords are readable
+    if (sx[3] - a <= 10 && sx[1] - sx[0] <= 2 && sx[3] - sx[2] <= 2 && (!srcGuard || a + 12 <= srcPitch)) {      // pyramid levels: pitch % 64 == 0 and the frame block has 16 spare bytes, the dwords are readable; the caller's image: inside the row
         // Two outputs at a time: their four source bytes per row lie inside one 8-byte window of the three loaded dwords (window start =
         // dword 0 or 1), so ONE v_perm per row fetches [left_i, right_i, left_i+1, right_i+1]; a second v_perm widens a pair to 16-bit
         // lanes for v_dot2_i32_i16 with the (a0, a1) coefficient pair taken from the table words with one v_alignbit.
@@ -247,13 +260,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     uint8_t* tile = lds;                                       // (maxCellH+6) x tileP, tileP % 4 == 0
     uint8_t* sc = tile + (P.maxCellH + 6) * tileP;             // (maxCellH+2) x scP
     uint8_t* code = sc + (P.maxCellH + 2) * scP;               // maxCellH x maxCellW
-    const uint8_t* img = pyr + (size_t)b * pyrFrame + L.off;
-    // stage rows [y0-3, y1+3) from the 4-byte aligned column ax <= x0-3; cells are interior (x0 >= 19) and the
-    // row pitch is a multiple of 64, so the aligned dwords stay inside the row
+    int pitch;
+    const uint8_t* img = level_image(P, pyr, pyrFrame, b, ci.level, pitch);
+    // stage rows [y0-3, y1+3) from the 4-byte aligned column ax <= x0-3; cells are interior (x0 >= 19, x1 + 3 <= w - 13) and the
+    // row pitch is a multiple of 4, so the aligned dwords stay inside the row
     const int ax = (ci.x0 - 3) & ~3, off = (ci.x0 - 3) - ax;
     const int ndw = (off + cw + 6 + 3) >> 2, th = ch + 6;
     for (int ry = lane >> 4; ry < th; ry += 4) {
-        const uint8_t* srow = img + (size_t)(ci.y0 - 3 + ry) * L.pitch + ax;
+        const uint8_t* srow = img + (size_t)(ci.y0 - 3 + ry) * pitch + ax;
         for (int q = lane & 15; q < ndw; q += 16) ((unsigned*)(tile + ry * tileP))[q] = ((const unsigned*)srow)[q];
     }
     for (int i = lane; i < (((ch + 2) * scP + 3) >> 2); i += 64) ((unsigned*)sc)[i] = 0;
@@ -682,7 +696,8 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
     if (outIdx >= cap) return;
     const unsigned pk = sel[(size_t)b * P.selFrame + slot];
     const int kx = (int)(pk & 0xFFF) + MINB, ky = (int)((pk >> 12) & 0xFFF) + MINB, score = pk >> 24;
-    const uint8_t* img = pyr + (size_t)b * pyrFrame + L.off;
+    int pitch;
+    const uint8_t* img = level_image(P, pyr, pyrFrame, b, level, pitch);
     // stage the 43x43 patch so that patch column c sits at LDS byte c + 2 of its row: the disc of IC_Angle (columns 6..36)
     // and the four-output groups of the horizontal blur then start on dword boundaries and can be consumed as whole dwords
     // (v_dot4_u32_u8 does four multiply-adds per instruction).  Interior keypoints (almost all): 12 aligned global dwords per
@@ -690,16 +705,16 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
     // never straddles the wave.  Keypoints within 21 px of the level border: byte loads with reflect-101.
     constexpr int SH = 2;
     const int ax = (kx - PR) & ~3;
-    const bool interior = kx - PR >= 0 && ky - PR >= 0 && ky + PR < L.h && kx + PR < L.w && ax + 48 <= L.pitch;
+    const bool interior = kx - PR >= 0 && ky - PR >= 0 && ky + PR < L.h && kx + PR < L.w && ax + 48 <= pitch;
     if (interior) {
         const int delta = (kx - PR) - ax - SH;                     // LDS byte b of a row = global byte ax + delta + b
-        const uint8_t* src = img + (size_t)(ky - PR) * L.pitch + ax;
+        const uint8_t* src = img + (size_t)(ky - PR) * pitch + ax;
         const int rr = lane / 12, q = lane - rr * 12;
         // all nine loads first (rows past the patch re-read its last row: no branch around a load, so none of them waits for the one before --
         // as a loop of load / shift / store the kernel spent nine dependent memory round trips per keypoint here), then the shifts and LDS stores
         unsigned gl[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) gl[k] = *(const unsigned*)(src + (__umul24((unsigned)min(5 * k + rr, PW - 1), (unsigned)L.pitch) + 4u * (unsigned)min(q, 11)));      // 32-bit offset from the wave's base (a 64-bit row product is three quarter-rate multiplies)
+        for (int k = 0; k < 9; ++k) gl[k] = *(const unsigned*)(src + (__umul24((unsigned)min(5 * k + rr, PW - 1), (unsigned)pitch) + 4u * (unsigned)min(q, 11)));      // 32-bit offset from the wave's base (a 64-bit row product is three quarter-rate multiplies)
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int r = 5 * k + rr;
@@ -716,7 +731,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
         for (int i = lane; i < PW * PW; i += 64) {
             int r = i / PW, c = i - r * PW;
             int yy = reflect101(ky - PR + r, L.h), xx = reflect101(kx - PR + c, L.w);
-            patch[r * PP + SH + c] = img[(size_t)yy * L.pitch + xx];
+            patch[r * PP + SH + c] = img[(size_t)yy * pitch + xx];
         }
     }
     __syncthreads();
@@ -885,6 +900,7 @@ struct sslam_orb {
     int umax[16];
     int planW = 0, planH = 0;
     Plan plan;
+    const uint8_t* lastImg0 = nullptr; size_t lastImg0Pitch = 0, lastImg0Stride = 0; bool lastInPlace = false;      // the image of the last call (debug taps of level 0)
     std::vector<CellInfo> cells;
     std::vector<short> tabs;
     DevBuf dCells, dTabs, dPyr, dCellCount, dCand, dBufA, dBufB, dSel, dSelCount;
@@ -1180,15 +1196,22 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
     }
     if (nframes > o->wsFrames) { SSLAM_HIP(hipStreamSynchronize(st)); }
     if ((rc = ensure_workspace(o, nframes))) return rc;
-    const Plan& P = o->plan;
+    Plan P = o->plan;
     uint8_t* pyr = o->dPyr.as<uint8_t>();
-    {
+    // level 0 in place when the caller's layout allows aligned dword loads (see Plan::img0); SSLAM_ORB_COPY_LEVEL0=1 forces the copy (A/B knob)
+    const bool inPlace = ((uintptr_t)d_images & 3) == 0 && (pitch & 3) == 0 && (image_stride & 3) == 0 && pitch <= 0x7FFFFFFF && !getenv("SSLAM_ORB_COPY_LEVEL0");
+    P.img0 = inPlace ? d_images : nullptr; P.img0Stride = image_stride; P.img0Pitch = (int)pitch;
+    o->lastImg0 = d_images; o->lastImg0Pitch = pitch; o->lastImg0Stride = image_stride; o->lastInPlace = inPlace;
+    if (!inPlace) {
         dim3 blk(64), grd((w + 64 * 16 - 1) / (64 * 16), h, nframes);
         { sslam::ProfScope _ps(o->ctx, "k_copy_level0", st); hipLaunchKernelGGL(k_copy_level0, grd, blk, 0, st, d_images, pitch, image_stride, pyr, P.pyrFrame, w, h, P.L[0].pitch); }
     }
     for (int l = 1; l < P.nlevels; ++l) {
         dim3 blk(256), grd((((P.L[l].w + 3) / 4) * P.L[l].h + 255) / 256, nframes);
-        { sslam::ProfScope _ps(o->ctx, "k_resize", st); hipLaunchKernelGGL(k_resize, grd, blk, 0, st, pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short4>()); }
+        const bool fromImage = l == 1 && inPlace;
+        { sslam::ProfScope _ps(o->ctx, "k_resize", st);
+          hipLaunchKernelGGL(k_resize, grd, blk, 0, st, fromImage ? d_images : pyr + P.L[l - 1].off, fromImage ? image_stride : P.pyrFrame, fromImage ? (int)pitch : P.L[l - 1].pitch, fromImage ? 1 : 0,
+                             pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short4>()); }
     }
     if (o->gateEvent) SSLAM_HIP(hipStreamWaitEvent(st, o->gateEvent, 0));      // sslam_orb_set_gate_event: the pyramid is built ahead, the rest waits (e.g. for the line branch's sequential core)
     if (P.nCellsFrame > 0) {
@@ -1281,7 +1304,9 @@ extern "C" int sslam_orb_debug_level(sslam_orb* o, int frame, int level, uint8_t
     const LevelInfo& L = o->plan.L[level];
     if (w) *w = L.w;
     if (h) *h = L.h;
-    if (out) SSLAM_HIP(hipMemcpy2D(out, L.w, o->dPyr.as<uint8_t>() + (size_t)frame * o->plan.pyrFrame + L.off, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    // level 0 is the image of the last call itself (read in place when its layout allowed it: Plan::img0) -- the caller's buffer must still be alive
+    if (out && level == 0 && o->lastInPlace) SSLAM_HIP(hipMemcpy2D(out, L.w, o->lastImg0 + (size_t)frame * o->lastImg0Stride, o->lastImg0Pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    else if (out) SSLAM_HIP(hipMemcpy2D(out, L.w, o->dPyr.as<uint8_t>() + (size_t)frame * o->plan.pyrFrame + L.off, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
     return SSLAM_OK;
 }
 
@@ -1318,7 +1343,8 @@ extern "C" int sslam_orb_debug_blur_patches(sslam_orb* o, int frame, sslam_keypo
     SSLAM_HIP(hipSetDevice(o->ctx->device));
     hipStream_t st = o->ctx->stream;
     SSLAM_HIP(hipStreamSynchronize(st));
-    const Plan& P = o->plan;
+    Plan P = o->plan;
+    if (o->lastInPlace) { P.img0 = o->lastImg0 + (size_t)frame * o->lastImg0Stride; P.img0Stride = 0; P.img0Pitch = (int)o->lastImg0Pitch; }      // (the kernel below runs as frame 0)
     const int icap = sslam_orb_max_keypoints(o);
     DevBuf dk, dp, dc;
     int rc;
