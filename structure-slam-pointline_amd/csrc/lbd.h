@@ -235,10 +235,12 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
             unsigned off8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                int tc = (int)(short)(int)roundf(sx);
-                const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
-                tc = (int)(short)(int)roundf(sy);
-                const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
+                // (int)roundf(x) without the seven-instruction round-half-away sequence: 2x is exact, t = trunc(2x), and round-half-away(x) = sign(x) * ((|t| + 1) >> 1)
+                // = (t + 1) >> 1 for t >= 0 and t >> 1 (= floor(t / 2) = -ceil(|t| / 2)) for t < 0, i.e. (t + 1 + (t >> 31)) >> 1 -- every |x| < 2^30.  The reference's
+                // (short) cast and its clamp "tc < 0 ? 0 : tc > W ? W : tc" are a sign extension and a median of three.
+                auto rnd = [](float x) -> int { const int t = (int)__fadd_rn(x, x); return (t + 1 + (t >> 31)) >> 1; };
+                const int xCor = min(max((int)(short)rnd(sx), 0), imageWidth);
+                const int yCor = min(max((int)(short)rnd(sy), 0), imageHeight);
                 off8[u] = (__umul24((unsigned)yCor, (unsigned)realWidth) + (unsigned)xCor) << 2;      // byte offset: both factors < 2^16 (v_mad_u32_u24 instead of a 64-bit multiply-add)
                 sx = __fadd_rn(sx, dL0); sy = __fadd_rn(sy, dL1);
             }
@@ -252,8 +254,10 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
                     const float dx = (float)(short)(g[u] & 0xFFFFu), dy = (float)(short)(g[u] >> 16);
                     const float gDL = __fadd_rn(__fmul_rn(dx, dL0), __fmul_rn(dy, dL1));
                     const float gDO = __fadd_rn(__fmul_rn(dx, dO0), __fmul_rn(dy, dO1));
-                    if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
-                    if (gDO > 0) pO = __fadd_rn(pO, gDO); else nO = __fsub_rn(nO, gDO);
+                    // "if (g > 0) p += g; else n -= g" without the branch: the side that is not taken adds / subtracts a zero, which leaves a sum that started at +0 and only
+                    // ever took non-negative addends unchanged bit for bit (x + (+-0) == x; +0 + (+-0) == +0 under round-to-nearest)
+                    pL = __fadd_rn(pL, fmaxf(gDL, 0.f)); nL = __fsub_rn(nL, fminf(gDL, 0.f));
+                    pO = __fadd_rn(pO, fmaxf(gDO, 0.f)); nO = __fsub_rn(nO, fminf(gDO, 0.f));
                 }
             }
         };

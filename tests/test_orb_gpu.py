@@ -83,3 +83,12 @@ def test_orb_blur_variant_opencv_340(fe, ctx, oracle):
                 ex.set_blur_variant(2)
         finally:
             ex.close()
+
+
+@pytest.mark.parametrize("scale,nlevels", [(1.1, 8), (1.5, 5), (2.0, 4), (2.6, 3), (3.4, 3)])
+def test_orb_scale_factors(fe, ctx, oracle, scale, nlevels):
+    """k_resize's group records (round 5: offsets, v_perm selectors and coefficient pairs per four outputs, built on the host) over the scale factors the constructor accepts:
+    1.1 (windows overlap almost completely), 2.0 (the exact 2x decimation: INTER_LINEAR == INTER_AREA there, tests/test_variants_cpu.py), 2.6 (a pair's taps still inside its
+    8-byte window) and 3.4 (they are not: the byte path).  Every level's bytes, the candidates and the keypoints against the oracle; odd and even sizes."""
+    for img in (synth_frame(77, w=640, h=480), synth_frame(78, w=333, h=251)):
+        _cmp_orb(fe, ctx, oracle, img, 800, nlevels, scale)
