@@ -43,18 +43,16 @@ int launch_nfa_stage(sslam_ctx* ctx, hipStream_t st, uint8_t* ws, const void* pl
         sslam::ProfScope _ps(ctx, "k_nfa_all", st);
         hipLaunchKernelGGL(k_nfa_all, dim3(nframes), dim3(64), 0, st, ws, P, lgam);
     } else {
-        const bool twoPass = nfa_two_pass(P);      // (lsd_nfa.h: the initial evaluation's count on its own, then stage 0 for what it did not accept)
-        static const char* kCountNames[5] = {"k_nfa_count", "k_nfa_count/s1", "k_nfa_count/s2", "k_nfa_count/s3", "k_nfa_count/s4"};
-        auto count = [&](int stage, int all) {
-            sslam::ProfScope _ps(ctx, getenv("SSLAM_PROF_STAGES") ? kCountNames[std::max(stage, 0)] : "k_nfa_count", st);
-            hipLaunchKernelGGL(k_nfa_count, dim3(countWaves, nframes), dim3(64), 0, st, ws, P, stage, all);
-        };
-        auto eval = [&](int stage) { sslam::ProfScope _ps(ctx, "k_nfa_eval", st); hipLaunchKernelGGL(k_nfa_eval, dim3(evalWaves, nframes), dim3(64), 0, st, ws, P, stage, lgam); };
-        auto accept = [&](int stage) { sslam::ProfScope _ps(ctx, "k_nfa_accept", st); hipLaunchKernelGGL(k_nfa_accept, dim3(4, nframes), dim3(256), 0, st, ws, P, stage); };
-        count(twoPass ? -1 : 0, 1); eval(-1); accept(-1);
-        if (twoPass) count(0, 0);
-        eval(0); accept(0);
-        for (int stage = 1; stage <= 4; ++stage) { count(stage, 0); eval(stage); accept(stage); }
+        for (int stage = 0; stage <= 4; ++stage) {
+            { static const char* kCountNames[5] = {"k_nfa_count", "k_nfa_count/s1", "k_nfa_count/s2", "k_nfa_count/s3", "k_nfa_count/s4"};
+              sslam::ProfScope _ps(ctx, getenv("SSLAM_PROF_STAGES") ? kCountNames[stage] : "k_nfa_count", st); hipLaunchKernelGGL(k_nfa_count, dim3(countWaves, nframes), dim3(64), 0, st, ws, P, stage); }
+            if (stage == 0) {
+                { sslam::ProfScope _ps(ctx, "k_nfa_eval", st); hipLaunchKernelGGL(k_nfa_eval, dim3(evalWaves, nframes), dim3(64), 0, st, ws, P, -1, lgam); }
+                { sslam::ProfScope _ps(ctx, "k_nfa_accept", st); hipLaunchKernelGGL(k_nfa_accept, dim3(4, nframes), dim3(256), 0, st, ws, P, -1); }
+            }
+            { sslam::ProfScope _ps(ctx, "k_nfa_eval", st); hipLaunchKernelGGL(k_nfa_eval, dim3(evalWaves, nframes), dim3(64), 0, st, ws, P, stage, lgam); }
+            { sslam::ProfScope _ps(ctx, "k_nfa_accept", st); hipLaunchKernelGGL(k_nfa_accept, dim3(4, nframes), dim3(256), 0, st, ws, P, stage); }
+        }
         { sslam::ProfScope _ps(ctx, "k_nfa_finish", st); hipLaunchKernelGGL(k_nfa_finish, dim3(4, nframes), dim3(256), 0, st, ws, P); }
     }
     SSLAM_HIP(hipGetLastError());

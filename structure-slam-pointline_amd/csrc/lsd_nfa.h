@@ -431,11 +431,9 @@ __device__ __forceinline__ unsigned t_abs_u(unsigned v) { asm volatile("" : "+v"
 // aligned-point counts of one rectangle for six nested tolerances; total = pixels visited.  win: [k] {lo, hi} of ONE window per tolerance
 // (an item whose angles straddle the 0 / 360 seam has a second window: the caller runs a second pass for it -- the windows are disjoint,
 // so the counts add -- instead of every pixel step carrying a second set of compares).
-// K = the number of nested tolerances counted in the one pass over the rectangle's pixels: 6 (stage 0 merged with the initial evaluation), 5 of them used in stage 4, and 1
-// for the initial evaluation on its own (round 5: under decision D11's default nearly every rectangle is accepted there, and the other five votes per pixel were wasted)
-template <int K = 6>
 __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const int* __restrict__ win, const unsigned* __restrict__ Tb, int tW, int sw, bool small,
                                            int lane, int& totalOut, int (&alg)[6], double theta = 0, const double* precs = nullptr) {
+    constexpr int K = 6;
     const int nrows = g.y1 - g.y0 + 1;
     const int rowsPer = 64 >> lg, r = lane >> lg, sub = lane & ((1 << lg) - 1);
     int total = 0;
@@ -583,16 +581,8 @@ __device__ __forceinline__ void nfa_wave_sync() { __syncthreads(); }
 
 // aligned-point counts of the stage's candidates for the rectangles [part * per, ...) of one frame: the body of one wave
 // (the bodies come as *_range over the rectangles [c0, c1) -- what the streaming form below hands out block by block -- and as *_body over a wave's share of the frame)
-// stage -1 .. 4.  Stage -1 = the initial evaluation's count on its own (one tolerance); stage 0 = the six nested tolerances of the initial evaluation and rect_improve's first
-// step in one pass.  `all`: every rectangle of the range (the first count of a chain: the `done` flags are the previous call's); otherwise the ones still being refined.
-// Two chains give the same counts: {0(all), 1, 2, 3, 4} (rounds 1-4) and {-1(all), 0, 1, 2, 3, 4} (nfa_two_pass(): the initial evaluation accepts most rectangles).
-#ifdef SSLAM_NFA_ONE_PASS      // A/B knob (tools/build_variant.sh): the rounds 1-4 chain whatever the variant
-__host__ __device__ __forceinline__ bool nfa_two_pass(const LsdPlan& P) { return false; }
-#else
-__host__ __device__ __forceinline__ bool nfa_two_pass(const LsdPlan& P) { return P.nfaVariant != 0; }
-#endif
 template <int CH>
-__device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, const LsdPlan& P, int stage, bool all, int c0, int c1, int lane, NfaCountLdsT<CH>& L) {
+__device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int c0, int c1, int lane, NfaCountLdsT<CH>& L) {
     CntItem* its = L.its;
 #ifdef SSLAM_NFA_INT
     int (*nestWin)[6][4] = L.nestWin;
@@ -603,7 +593,7 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
     const double* rects = (const double*)(base + P.offCand);
     NfaState* st = (NfaState*)(base + P.offNfa);
     const int sw = P.sw, sh = P.sh, tW = P.tW;
-    const bool nested = stage <= 0 || stage == 4;
+    const bool nested = stage == 0 || stage == 4;
     const bool small = sw < 32768 && sh < 32768;
     const int rpb = nested ? CNT_NEST : 12;                        // rectangles per batch (stages 1-3: five lanes each)
     for (int chunk = c0; chunk < c1; chunk += CH) {
@@ -611,7 +601,7 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
         int nAct = 0;
         for (int cb = chunk; cb < cend; cb += 64) {               // rectangles still being refined
             const int c = cb + lane;
-            const bool on = c < cend && (all || !st[c].done);
+            const bool on = c < cend && (stage == 0 || !st[c].done);
             const unsigned long long m = __ballot(on);
             if (on) act[nAct + mbcnt(m)] = (unsigned short)(c - chunk);
             nAct += __popcll(m);
@@ -627,7 +617,7 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
                 if (lane < nIt) {
                     c = chunk + act[a0 + ri];
                     RectD rec, r; load_rect(rects + (size_t)c * 12, rec);
-                    if (nested) { r = rec; valid = stage <= 0 || (rec.width - 0.5) >= 0.5; }
+                    if (nested) { r = rec; valid = stage == 0 || (rec.width - 0.5) >= 0.5; }
                     else valid = stage_cand(rec, stage, j, r);
                     CntItem& I = its[lane];
                     I.c = c; I.j = valid ? j : -1;
@@ -642,11 +632,11 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
 #ifdef SSLAM_NFA_INT
                         // aligned-angle windows (lsd_align_win.h): six tolerances around one theta in the nested stages (stage 4 uses five of
                         // them), one for the first candidate of a rectangle in stages 1-3 (its candidates share theta and the tolerance)
-                        const int nK = nested ? (stage < 0 ? 1 : 6) : j == 0 ? 1 : 0;
+                        const int nK = nested ? 6 : j == 0 ? 1 : 0;
                         int nw = 0;
 #pragma unroll 1
                         for (int k = 0; k < nK; ++k) {
-                            const double pk = !nested ? r.prec : stage <= 0 ? (k == 0 ? r.prec : ldexp(r.p, -k) * kPI) : ldexp(r.p, -(k + 1)) * kPI;
+                            const double pk = !nested ? r.prec : stage == 0 ? (k == 0 ? r.prec : ldexp(r.p, -k) * kPI) : ldexp(r.p, -(k + 1)) * kPI;
                             const alnwin::Win w = alnwin::windows(r.theta, pk);
                             winOk &= w.ok != 0;
                             // (which window lands in which slot may differ between tolerances: the counter adds both slots, empty ones count nothing)
@@ -704,16 +694,14 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
 #endif
 #ifndef SSLAM_NFA_INT
                 double precs[6];
-                for (int k = 0; k < 6; ++k) precs[k] = stage <= 0 ? (k == 0 ? its[it].prec : ldexp(its[it].p, -k) * kPI) : ldexp(its[it].p, -(k + 1)) * kPI;
-                if (stage < 0) count_item<1>(g, lg, win, Tb, tW, sw, small, lane, total, alg, its[it].theta, precs);
-                else count_item<6>(g, lg, win, Tb, tW, sw, small, lane, total, alg, its[it].theta, precs);
-                (void)nWin; (void)tot2;
+                for (int k = 0; k < 6; ++k) precs[k] = stage == 0 ? (k == 0 ? its[it].prec : ldexp(its[it].p, -k) * kPI) : ldexp(its[it].p, -(k + 1)) * kPI;
+                count_item(g, lg, win, Tb, tW, sw, small, lane, total, alg, its[it].theta, precs); (void)nWin; (void)tot2;
 #else
-                if (stage < 0) { count_item<1>(g, lg, win, Tb, tW, sw, small, lane, total, alg); if (nWin > 1) count_item<1>(g, lg, win + 2, Tb, tW, sw, small, lane, tot2, alg); }
-                else { count_item<6>(g, lg, win, Tb, tW, sw, small, lane, total, alg); if (nWin > 1) count_item<6>(g, lg, win + 2, Tb, tW, sw, small, lane, tot2, alg); }      // the 0 / 360 seam: second windows, disjoint from the first
+                count_item(g, lg, win, Tb, tW, sw, small, lane, total, alg);
+                if (nWin > 1) count_item(g, lg, win + 2, Tb, tW, sw, small, lane, tot2, alg);      // the 0 / 360 seam: second windows, disjoint from the first
 #endif
                 if (lane == 0) {
-                    const int K = stage < 0 ? 1 : stage == 0 ? 6 : 5;
+                    const int K = stage == 0 ? 6 : 5;
 #pragma unroll
                     for (int k = 0; k < 6; ++k) if (k < K) { st[c].cnt[k][0] = total; st[c].cnt[k][1] = alg[k]; }
                     st[c].nc = K;
@@ -725,17 +713,17 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
 }
 
 template <int CH>
-__device__ __forceinline__ void nfa_count_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, bool all, int part, int nparts, int lane, NfaCountLdsT<CH>& L) {
+__device__ __forceinline__ void nfa_count_body(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int part, int nparts, int lane, NfaCountLdsT<CH>& L) {
     const int nCand = ((const Misc*)(base + P.offMisc))->nCand;
     const int per = (nCand + nparts - 1) / nparts;
     const int c0 = part * per, c1 = min(c0 + per, nCand);
-    nfa_count_range<CH>(base, P, stage, all, c0, c1, lane, L);
+    nfa_count_range<CH>(base, P, stage, c0, c1, lane, L);
 }
 
-__global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage, int all) {
+__global__ __launch_bounds__(64, SSLAM_COUNT_MINWAVES) void k_nfa_count(uint8_t* __restrict__ ws, LsdPlan P, int stage) {
     __shared__ NfaCountLds L;
     const int b = gridDim.x == 1 ? xcd_mix_frame(blockIdx.y, gridDim.y) : blockIdx.y;
-    nfa_count_body<EVAL_CH>(ws + (size_t)b * P.frameBytes, P, stage, all != 0, blockIdx.x, gridDim.x, threadIdx.x, L);
+    nfa_count_body<EVAL_CH>(ws + (size_t)b * P.frameBytes, P, stage, blockIdx.x, gridDim.x, threadIdx.x, L);
 }
 
 // stage -1: the initial evaluation (cnt[0]); stage 0: cnt[1..5]; stages 1-4: cnt[0..nc).
@@ -918,10 +906,8 @@ __device__ __forceinline__ void nfa_all_body(uint8_t* __restrict__ base, const L
         // this loop the bodies' address arithmetic was live across all of them (131 spilled SGPRs, 14 spilled VGPRs, 60 bytes of scratch).
 #define NFA_OPAQUE() asm volatile("" : "+s"(base), "+s"(lgam), "+v"(lane))
         NFA_OPAQUE();
-        // the initial evaluation's count: on its own (stage -1, then stage 0 for what it did not accept) or with stage 0's (nested tolerances, one pass) -- nfa_two_pass()
-        const bool twoPass = nfa_two_pass(P);
-        if (it != 0 || twoPass) {
-            nfa_count_body<CH>(base, P, it < 0 ? (twoPass ? -1 : 0) : it, it < 0, wave, nwaves, lane, L.c);
+        if (it != 0) {                                   // stage 0's counts came with the initial evaluation's (nested tolerances, one pass)
+            nfa_count_body<CH>(base, P, it < 0 ? 0 : it, wave, nwaves, lane, L.c);
             __syncthreads();
         }
         NFA_OPAQUE();
@@ -1000,8 +986,7 @@ __global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_stream(uint8
         for (int it = -1; it <= 4; ++it) {
 #define NFA_OPAQUE() asm volatile("" : "+s"(base), "+s"(lgam), "+v"(lane))       // (as in nfa_all_body: nothing of a body's address arithmetic may be hoisted across the chain)
             NFA_OPAQUE();
-            const bool twoPass = nfa_two_pass(P);
-            if (it != 0 || twoPass) { nfa_count_range<EVAL_CH>(base, P, it < 0 ? (twoPass ? -1 : 0) : it, it < 0, c0, c1, lane, L.c); __syncthreads(); }
+            if (it != 0) { nfa_count_range<EVAL_CH>(base, P, it < 0 ? 0 : it, c0, c1, lane, L.c); __syncthreads(); }
             NFA_OPAQUE();
             nfa_eval_range<EVAL_CH>(base, P, it, lgam, c0, c1, lane, L.items);
             __syncthreads();

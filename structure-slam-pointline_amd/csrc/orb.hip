@@ -41,7 +41,7 @@ struct LevelInfo {
     int W, H;                     // maxBorder-minBorder extents
     float scale;                  // mvScaleFactor
     float size;                   // float(int(31*scale))
-    int tabX, tabY, tabG;         // entry (int16x4) offsets into the resize tables: per output column, per output row, per group of four columns (four entries each)
+    int tabX, tabY;               // entry (int16x4) offsets into the resize tables
     float rcpGroups;              // 1 / ((w + 3) / 4): k_resize's row index
 };
 
@@ -103,18 +103,18 @@ __global__ void k_copy_level0(const uint8_t* __restrict__ in, size_t pitch, size
 
 // ------------------------------------------------------------------ bilinear /1.2
 // cv::resize(INTER_LINEAR) for CV_8UC1: 11-bit fixed-point taps.
-// Tables (host, build_plan): tabY entries {src row, b0, b1, 0} as int16x4; per GROUP of four horizontally adjacent outputs one 32-byte record (tabG, round 5):
-//   aLo, aHi    byte offsets (multiples of 4) of two 8-byte source windows: outputs 0,1 read theirs from [aLo, aLo + 8), outputs 2,3 from [aHi, aHi + 8)
-//               (aHi < 0: the taps of a pair span more than a window -- scale factors above ~3 -- and the group takes the byte path over tabX)
-//   sel01/sel23 v_perm selectors that fetch [left_i, right_i, left_i+1, right_i+1] of a pair from its window in ONE instruction per source row
-//   cf[4]       the (a0, a1) coefficient pairs as the two 16-bit lanes v_dot2_i32_i16 takes
-// One thread = one group: two 16-byte table loads, four 8-byte source loads (32-bit offsets from the wave-uniform frame base), 2 x 2 v_perm, and per output
-// 2 v_perm (widening) + 2 v_dot2 + the 8u two-stage rounding; one dword store.  Rounds 1-4 decoded offsets and selectors from per-output entries in the kernel:
-// 0.33 M vector instructions per frame for 0.64 M output pixels, a third of them table decoding.
-struct ResizeGroup { int aLo, aHi; unsigned sel01, sel23; unsigned cf[4]; };
-static_assert(sizeof(ResizeGroup) == 32, "one group = two 16-byte loads");
+// tabX/tabY entries: {src offset, coef0, coef1, 0} as int16x4 (tabX padded to a multiple of 4 entries).
+// One thread = 4 horizontally adjacent output pixels: two 16-byte table loads, then the two source rows as three aligned
+// dwords each (sub-dword global loads cost the texture path four times a dword load), bytes picked with 64-bit shifts,
+// one dword store.  A group whose taps span more than the 12 loaded bytes (scale factors above ~2) takes byte loads.
+__device__ __forceinline__ unsigned pick2(unsigned d0, unsigned d1, unsigned d2, int o) {      // bytes o, o+1 of d0:d1:d2 (o <= 10)
+    const unsigned long long w01 = (unsigned long long)d0 | ((unsigned long long)d1 << 32);
+    const unsigned long long w12 = (unsigned long long)d1 | ((unsigned long long)d2 << 32);
+    return (unsigned)((o < 4 ? w01 : w12) >> (8 * (o < 4 ? o : o - 4)));
+}
 // src / srcStride / srcPitch: the source level (a level of the pyramid block, or the caller's image for level 1: Plan::img0); srcGuard: the source has no spare bytes
-// behind a row (the caller's image), so a group whose windows would reach past the pitch takes the byte path
+// behind its LAST row (the caller's image: behind any other row lies the next one), so a group of the last source row whose three dwords would reach past the pitch takes
+// the byte path.  (Guarding every row put one byte-path lane into almost every wave: 8.9 -> 9.6 ms per 12 288 frames, GPU call B.)
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, size_t srcStride, int srcPitch, int srcGuard, uint8_t* __restrict__ pyr, size_t pyrFrame,
                                                 LevelInfo S, LevelInfo D, const short4* __restrict__ tabs) {
     const int b = blockIdx.y;
@@ -123,46 +123,61 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     // t / ngroups without the ~35-instruction division: the quotient of the float product is off by at most one for t < 2^24
     int y = (int)((float)t * D.rcpGroups);
     { const int r = t - __mul24(y, ngroups); y += r >= ngroups ? 1 : (r < 0 ? -1 : 0); }
-    const int g = t - __mul24(y, ngroups), x4 = g * 4;
+    const int x4 = (t - __mul24(y, ngroups)) * 4;
     if (y >= D.h) return;
     const short4 ty = tabs[D.tabY + y];
-    const uint4* G = (const uint4*)(tabs + D.tabG) + 2 * g;
-    const uint4 g0 = G[0], g1 = G[1];
+    const uint4 ta = *(const uint4*)(tabs + D.tabX + x4), tb = *(const uint4*)(tabs + D.tabX + x4 + 2);
     const int sy0 = min(max((int)ty.x, 0), S.h - 1), sy1 = min(max((int)ty.x + 1, 0), S.h - 1);
     const uint8_t* sbase = src + (size_t)b * srcStride;
-    const unsigned off0 = __umul24((unsigned)sy0, (unsigned)srcPitch), off1 = __umul24((unsigned)sy1, (unsigned)srcPitch);      // rows and pitch < 2^16
-    const int aLo = (int)g0.x, aHi = (int)g0.y;
-    const int b0 = ty.y, b1 = ty.z;
+    const uint8_t* g0 = sbase + (size_t)sy0 * srcPitch;
+    const uint8_t* g1 = sbase + (size_t)sy1 * srcPitch;
+    const unsigned tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+    int sx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sx[i] = (short)(tw[2 * i] & 0xFFFF);
+    const int a = sx[0] & ~3;
     unsigned out = 0;
-    if (aHi >= 0 && (!srcGuard || aHi + 8 <= srcPitch)) {      // pyramid levels: pitch % 64 == 0 and the frame block has 16 spare bytes, the windows are readable; the caller's image: inside the row
-        const unsigned* p00 = (const unsigned*)(sbase + (off0 + (unsigned)aLo)); const unsigned* p01 = (const unsigned*)(sbase + (off0 + (unsigned)aHi));
-        const unsigned* p10 = (const unsigned*)(sbase + (off1 + (unsigned)aLo)); const unsigned* p11 = (const unsigned*)(sbase + (off1 + (unsigned)aHi));
-        const unsigned u0 = p00[0], u1 = p00[1], u2 = p01[0], u3 = p01[1], v0 = p10[0], v1 = p10[1], v2 = p11[0], v3 = p11[1];
-        const unsigned cf[4] = {g1.x, g1.y, g1.z, g1.w};
+    const int b0 = ty.y, b1 = ty.z;
+    if (sx[3] - a <= 10 && sx[1] - sx[0] <= 2 && sx[3] - sx[2] <= 2 && !(srcGuard && a + 12 > srcPitch && sy1 >= S.h - 1)) {      // pyramid levels: pitch % 64 == 0 and the frame block has 16 spare bytes, the dwords are readable; the caller's image: inside the row
+        // Two outputs at a time: their four source bytes per row lie inside one 8-byte window of the three loaded dwords (window start =
+        // dword 0 or 1), so ONE v_perm per row fetches [left_i, right_i, left_i+1, right_i+1]; a second v_perm widens a pair to 16-bit
+        // lanes for v_dot2_i32_i16 with the (a0, a1) coefficient pair taken from the table words with one v_alignbit.
+        const unsigned* q0 = (const unsigned*)(g0 + a);
+        const unsigned* q1 = (const unsigned*)(g1 + a);
+        const unsigned u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-            const unsigned sel = pr == 0 ? g0.z : g0.w;
-            const unsigned r0 = pr == 0 ? __builtin_amdgcn_perm(u1, u0, sel) : __builtin_amdgcn_perm(u3, u2, sel);      // [left_i, right_i, left_i+1, right_i+1] of the upper row
-            const unsigned r1 = pr == 0 ? __builtin_amdgcn_perm(v1, v0, sel) : __builtin_amdgcn_perm(v3, v2, sel);      // ... of the lower row
+            const int oA = sx[2 * pr] - a, oB = sx[2 * pr + 1] - a;
+            const bool hi = oA >= 4;
+            const int base = hi ? 4 : 0;
+            const unsigned w = (unsigned)(oA - base) | ((unsigned)(oB - base) << 16);
+            const unsigned sel = w * 0x0101u + 0x01000100u;                                  // bytes q, q+1 for both outputs
+            const unsigned r0 = __builtin_amdgcn_perm(hi ? u2 : u1, hi ? u1 : u0, sel);
+            const unsigned r1 = __builtin_amdgcn_perm(hi ? v2 : v1, hi ? v1 : v0, sel);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int i = 2 * pr + e;
                 const unsigned wsel = e == 0 ? 0x0c010c00u : 0x0c030c02u;                    // (byte, 0, byte + 1, 0): two zero-extended 16-bit lanes
-                const s16x2 q0 = as_s16x2(__builtin_amdgcn_perm(0u, r0, wsel)), q1 = as_s16x2(__builtin_amdgcn_perm(0u, r1, wsel));
-                const s16x2 c = as_s16x2(cf[i]);                                              // (a0, a1)
-                const int h0 = __builtin_amdgcn_sdot2(q0, c, 0, false), h1 = __builtin_amdgcn_sdot2(q1, c, 0, false);
+                const s16x2 p0 = as_s16x2(__builtin_amdgcn_perm(0u, r0, wsel)), p1 = as_s16x2(__builtin_amdgcn_perm(0u, r1, wsel));
+                const s16x2 cf = as_s16x2(__builtin_amdgcn_alignbit(tw[2 * i + 1], tw[2 * i], 16));      // (a0, a1)
+                const int h0 = __builtin_amdgcn_sdot2(p0, cf, 0, false), h1 = __builtin_amdgcn_sdot2(p1, cf, 0, false);
                 const int v = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;      // coefficients <= 2^11, row sums <= 2^15: v_mul_i32_i24 (v_mul_hi_i32 is quarter rate)
                 out |= (unsigned)(v & 255) << (8 * i);
             }
         }
     } else {
-        const uint8_t* r0p = sbase + off0; const uint8_t* r1p = sbase + off1;
+        int p00[4], p01[4], p10[4], p11[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const short4 tx = tabs[D.tabX + x4 + i];
-            const int sx = tx.x, sx1 = min(sx + 1, S.w - 1), a0 = tx.y, a1 = tx.z;
-            const int h0 = r0p[sx] * a0 + r0p[sx1] * a1, h1 = r1p[sx] * a0 + r1p[sx1] * a1;
-            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            const int sx1 = min(sx[i] + 1, S.w - 1);
+            p00[i] = g0[sx[i]]; p01[i] = g0[sx1]; p10[i] = g1[sx[i]]; p11[i] = g1[sx1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a0 = (short)(tw[2 * i] >> 16), a1 = (short)(tw[2 * i + 1] & 0xFFFF);
+            const int r0 = p00[i] * a0 + p01[i] * a1;
+            const int r1 = p10[i] * a0 + p11[i] * a1;
+            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
             out |= (unsigned)(v & 255) << (8 * i);
         }
     }
@@ -1028,24 +1043,7 @@ static int build_plan(sslam_orb* o, int w, int h) {
                 o->tabs.push_back((short)cvRoundF(fy * 2048));
                 o->tabs.push_back(0);
             }
-            while ((o->tabs.size() / 4) % 4) o->tabs.insert(o->tabs.end(), 4, (short)0);      // keep every table 32-byte aligned
-            // the group records of k_resize (ResizeGroup): built from the per-column entries just written
-            L.tabG = (int)o->tabs.size() / 4;
-            for (int x4 = 0; x4 < ((L.w + 3) & ~3); x4 += 4) {
-                const short* e = o->tabs.data() + ((size_t)L.tabX + x4) * 4;      // {sx, a0, a1, 0} x 4
-                const int sx[4] = {e[0], e[4], e[8], e[12]};
-                ResizeGroup G;
-                G.aLo = sx[0] & ~3; G.aHi = sx[2] & ~3;
-                const int oA = sx[0] - G.aLo, oB = sx[1] - G.aLo, oC = sx[2] - G.aHi, oD = sx[3] - G.aHi;
-                if (oB + 1 > 7 || oD + 1 > 7 || oB < 0 || oD < 0) { G.aHi = -1; G.sel01 = G.sel23 = 0; }
-                else {
-                    G.sel01 = (unsigned)oA | ((unsigned)(oA + 1) << 8) | ((unsigned)oB << 16) | ((unsigned)(oB + 1) << 24);
-                    G.sel23 = (unsigned)oC | ((unsigned)(oC + 1) << 8) | ((unsigned)oD << 16) | ((unsigned)(oD + 1) << 24);
-                }
-                for (int i = 0; i < 4; ++i) G.cf[i] = (unsigned)(unsigned short)e[4 * i + 1] | ((unsigned)(unsigned short)e[4 * i + 2] << 16);
-                const short* gs = (const short*)&G;
-                o->tabs.insert(o->tabs.end(), gs, gs + 16);
-            }
+            while ((o->tabs.size() / 4) % 4) o->tabs.insert(o->tabs.end(), 4, (short)0);      // keep every tabX 32-byte aligned
         }
     }
     P.pyrFrame = (off + 16 + 255) & ~(size_t)255;      // 16 spare bytes: k_resize reads whole dwords past a row's last pixel

@@ -83,5 +83,5 @@ def test_documents_name_only_declared_entry_points():
     declared = set(re.findall(r"\b(sslam_[a-z0-9_]+)\b", open(os.path.join(root, "include", "sslam_frontend.h")).read() + open(os.path.join(root, "include", "sslam_testing.h")).read()))
     for doc in ("INTEGRATION.md", "DESIGN.md", "README.md", os.path.join("profiles", "README.md"), os.path.join("tools", "README.md")):
         names = set(re.findall(r"\b(sslam_[a-z0-9_]+)\b", open(os.path.join(root, doc)).read()))
-        unknown = sorted(n for n in names if n not in declared and not n.startswith("sslam_shim") and not n.endswith("_"))
+        unknown = sorted(n for n in names if n not in declared and not n.startswith("sslam_shim") and not n.endswith("_") and n not in ("sslam_frontend", "sslam_testing"))      # (the two header names)
         assert not unknown, (doc, unknown)
