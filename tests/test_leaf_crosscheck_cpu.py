@@ -134,7 +134,8 @@ def test_fast_suppression_keeps_strict_3x3_maxima_of_the_response(oracle):
 def test_lsd_nfa_is_the_binomial_tail_within_its_own_tolerance(oracle):
     """LSD's nfa(n, k, p) = -log10(NT * P[Binomial(n, p) >= k]) with NT = (w h)^(5/2) * 11 (LSD_REFINE_ADV's eleven tolerances), computed by upstream with log-gamma
     approximations and a tail sum that stops at 10 % relative error (so up to log10(1.1) = 0.041 off by design).  Against scipy's exact tail: 0.0014 at most over these
-    cases; its log-gamma (Lanczos below 15, Windschitl above) within 1e-12 of scipy's."""
+    cases; its log-gamma (Lanczos below 15, Windschitl above) within 1e-12 of scipy's.  This is decision D11's variant 0 (log_gamma(n + 1): the mathematical form);
+    the default since round 5, variant 1, is what OpenCV's source is recalled to compute instead and is NOT the binomial tail (tests/test_variants_cpu.py)."""
     import ctypes as C
     from scipy import stats, special
     L = oracle.L
@@ -146,6 +147,7 @@ def test_lsd_nfa_is_the_binomial_tail_within_its_own_tolerance(oracle):
     rng = np.random.default_rng(1); w, h = 512, 384
     log_nt = 5 * (np.log10(w) + np.log10(h)) / 2 + np.log10(11.0)
     worst = 0.0
+    old_variant = L.orc_set_lsd_nfa_variant(0)
     for it in range(4000):
         p = float(rng.choice([0.125, 0.0625, 0.03125, 0.015625, 1 / 128]))
         n = int(rng.integers(1, 30000)) if it % 3 else int(rng.integers(1, 200))
@@ -155,5 +157,6 @@ def test_lsd_nfa_is_the_binomial_tail_within_its_own_tolerance(oracle):
         want = -log_nt if k == 0 else -(stats.binom.logsf(k - 1, n, p) / np.log(10) + log_nt)
         if np.isfinite(want):
             worst = max(worst, abs(got - want))
+    L.orc_set_lsd_nfa_variant(old_variant)
     assert worst < 0.0414, worst
     assert worst < 0.005, worst            # what it actually achieves

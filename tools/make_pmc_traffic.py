@@ -14,7 +14,7 @@ FETCH_CORRECTION = 2.0      # gfx950 tallies 128-byte read requests at 64 B (MI3
 
 def lsd_core(batch):
     """which launch form of the sequential LSD core a batch of this size runs (lines.hip: sslam_lines_extract_batch_dev)"""
-    return "k_lsd_regions_mw" if batch <= 256 else "k_lsd_regions<true>" if batch < 1024 else "k_lsd_regions<false>"
+    return "k_lsd_regions_cl" if batch <= 64 else "k_lsd_regions<true>" if batch < 1024 else "k_lsd_regions<false>"
 
 ONCE = {"k_grad_table", "k_lgamma_table", "k_probe_stream16", "k_probe_gather16"}
 
