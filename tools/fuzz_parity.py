@@ -1,5 +1,6 @@
 """Randomised GPU-vs-oracle parity sweep (run through gpurun): random sizes, shape densities, noise levels and extractor
-parameters; every ORB keypoint / descriptor, LSD segment, KeyLine field, LBD byte, line equation and knn-2 result is compared
+parameters -- and, since round 5, random settings of the line path's selectable decisions (D11 nfa variant, D12 LBD bit order, D7 resize variant, D2 seed order) on both
+sides; every ORB keypoint / descriptor, LSD segment, KeyLine field, LBD byte, line equation and knn-2 result is compared
 with the CPU oracle exactly as tests/ does.  usage: python tools/fuzz_parity.py [n_frames] [seed]"""
 import sys, time; sys.path.insert(0, 'tests')
 import numpy as np
@@ -13,10 +14,12 @@ def cases(n, rng):
         kind = rng.random()
         if kind < 0.1: img = noise_frame(seed, w, h)
         else: img = synth_frame(seed, w, h, nshapes=int(rng.integers(2, 120)), nstrokes=int(rng.integers(0, 80)), noise=float(rng.choice([0.0, 1.0, 2.0, 4.0, 8.0])))
-        nfeat = int(rng.choice([300, 1000, 2000])); nlev = int(rng.choice([4, 8])); sf = float(rng.choice([1.2, 1.2, 1.5]))
+        nfeat = int(rng.choice([300, 1000, 2000])); nlev = int(rng.choice([4, 8])); sf = float(rng.choice([1.2, 1.2, 1.5, 1.1, 2.0]))
         ini, mn = (20, 7) if rng.random() < 0.8 else (int(rng.integers(10, 40)), int(rng.integers(3, 10)))
         cap = int(rng.choice([40, 200, 400]))
-        yield it, img, nfeat, nlev, sf, ini, mn, cap
+        # the line path's decisions: mostly the defaults (1, 1, 0, 0), each alternative now and then; the host-sorted seed order rarely (15 ms per frame)
+        dec = (int(rng.random() < 0.75), int(rng.random() < 0.75), int(rng.random() < 0.2), int(rng.random() < 0.06))
+        yield it, img, nfeat, nlev, sf, ini, mn, cap, dec
 
 
 def main():
@@ -27,16 +30,23 @@ def main():
     fe = pkg.frontend(); ctx = fe.Context(0); orc = oracle_lib.Oracle()
     bad = []; stats = dict(frames=0, kp=0, lines=0, lbd_bits=0, angle_ulp=0)
     t0 = time.time()
-    for it, img, nfeat, nlev, sf, ini, mn, cap in cases(n_frames, rng):
+    SETTERS = (("set_nfa_variant", "orc_set_lsd_nfa_variant"), ("set_lbd_bit_order", "orc_set_lbd_bit_order"), ("set_resize_variant", "orc_set_lsd_resize"), ("set_seed_order", "orc_set_lsd_seed_sort"))
+    ndec = np.zeros((4, 2), int)
+    for it, img, nfeat, nlev, sf, ini, mn, cap, dec in cases(n_frames, rng):
         h, w = img.shape
-        tag = "it %d %dx%d nfeat %d lev %d sf %.1f th %d/%d cap %d" % (it, w, h, nfeat, nlev, sf, ini, mn, cap)
+        tag = "it %d %dx%d nfeat %d lev %d sf %.1f th %d/%d cap %d decisions %s" % (it, w, h, nfeat, nlev, sf, ini, mn, cap, dec)
+        for k, v in enumerate(dec): ndec[k, v] += 1
         try:
             ox = fe.OrbExtractor(ctx, nfeat, sf, nlev, ini, mn)
             kp, d = ox(img); okp, od = orc.orb_extract(img, nfeat, sf, nlev, ini, mn); ox.close()
             if len(kp) != len(okp) or not np.array_equal(kp.view(np.uint8), okp.view(np.uint8)) or not np.array_equal(d, od): bad.append("ORB " + tag)
             lx = fe.LineExtractor(ctx, cap)
+            for (ls, os_), v in zip(SETTERS, dec): getattr(lx, ls)(v)
             kl, ld, fn = lx(img); raw = lx.debug_segments(0); lx.close()
-            okl, old, ofn, oraw = orc.lines_extract(img, cap)
+            olds = [getattr(orc.L, os_)(v) for (ls, os_), v in zip(SETTERS, dec)]
+            try: okl, old, ofn, oraw = orc.lines_extract(img, cap)
+            finally:
+                for (ls, os_), v in zip(SETTERS, olds): getattr(orc.L, os_)(v)
             if raw.shape != oraw.shape or not np.array_equal(raw, oraw): bad.append("LSD segments " + tag)
             elif len(kl) != len(okl): bad.append("KeyLine count " + tag)
             else:
@@ -58,6 +68,7 @@ def main():
             bad.append("EXC %r %s" % (e, tag))
     print("fuzz_parity: %d frames, %d keypoints, %d lines compared in %.1f s; max KeyLine.angle diff %d ulp; LBD bits differing %d; %d mismatches"
           % (stats["frames"], stats["kp"], stats["lines"], time.time() - t0, stats["angle_ulp"], stats["lbd_bits"], len(bad)))
+    print("line decisions drawn (value 0 / value 1): nfa %d / %d, LBD bit order %d / %d, resize %d / %d, seed order %d / %d" % tuple(ndec.reshape(-1)))
     for b in bad[:40]: print("  MISMATCH", b)
     sys.exit(1 if bad else 0)
 

@@ -40,6 +40,8 @@ STEP_PROFILE=1 timeout 100 tools/step_check 12288 5 2 > $O/step_two_streams.txt 
 LAT_PROFILE=1 timeout 80 tools/lat_check 2 "" "SSLAM_NFA_STREAM=0" > $O/lat_check.txt 2>&1; LAT_W=1280 LAT_H=960 LAT_NF=8 LAT_LINES=400 LAT_FRAMES=tools/lat_frames_1280x960.raw LAT_EXPECTED=tools/lat_expected_1280x960.bin LAT_PROFILE=1 timeout 80 tools/lat_check 2 "" > $O/lat_check_1280.txt 2>&1
 timeout 900 python -m pytest tests -q -m gpu --durations=8 > $O/pytest_gpu.txt 2>&1; echo "rc=$?" >> $O/pytest_gpu.txt; tail -14 $O/pytest_gpu.txt
 timeout 900 python bench.py > $O/bench_r05.json 2> $O/bench_r05.err; tail -c 300 $O/bench_r05.err
+timeout 400 python tools/fuzz_parity.py 900 20260928 > $O/fuzz_parity.txt 2>&1; tail -4 $O/fuzz_parity.txt
+timeout 300 python tools/fuzz_matchers.py 1200 > $O/fuzz_matchers.txt 2>&1; tail -3 $O/fuzz_matchers.txt
 python - <<'PY'
 import json
 try:
