@@ -231,7 +231,9 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
         // The walk's coordinates do not depend on what is gathered: the eight gathers of the NEXT group of steps are issued before the current
         // group is consumed (two register sets, two groups per trip), so a wave waits for memory once per line, not once per eight steps
         auto issue = [&](unsigned (&g)[8]) {
-            // coordinates of eight consecutive steps (the float walk itself stays sequential), then the eight gathers together
+            // coordinates of eight consecutive steps (the float walk itself stays sequential), then the eight gathers together.  (The last group of a line runs up to seven
+            // steps past its end: loaded, never consumed -- the clamp keeps them addressable.  A clamp-free walk for support regions inside the image was measured in round 5,
+            // GPU calls G-I: no gain, and its first form faulted on exactly those steps; removed.)
             unsigned off8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {

@@ -84,7 +84,7 @@ struct sslam_lines {
     int nfaVariant = 1, lbdBitOrder = 1, lsdResize = 0;      // sslam_lines_set_nfa_variant / _lbd_bit_order / _resize_variant (decisions D11, D12, D7): D11 and D12 default to the OpenCV-as-recalled forms since round 5
     int seedOrder = 0;              // sslam_lines_set_seed_order (decision D2): 1 = the seeds are ordered by the host's std::sort
     int sMin = 0;                   // smallest |g|^2 of a defined pixel (k_grad_smin, with the gradient table)
-    hipStream_t nfaStream = nullptr; hipEvent_t nfaFork = nullptr, nfaJoin = nullptr;      // SSLAM_NFA_STREAM=1: the NFA stage next to the cluster form of the core
+    hipStream_t nfaStream = nullptr; hipEvent_t nfaFork = nullptr, nfaJoin = nullptr;      // the NFA stage next to the cluster form of the core (calls of up to 64 frames)
 };
 
 static std::vector<int> taps_q8(int n, double sigma) {
@@ -333,12 +333,14 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     // the prologue (8 ms with the chip to itself instead of 35 ms under the point branch) -- measured: the step does not respond to where a
     // kernel runs, only to how long the kernels take alone (194.1 vs 191.4 ms), so it stays behind the NFA stage
     static const bool sobelEarly = [] { const char* e = getenv("SSLAM_LBD_SOBEL"); return e && !strcmp(e, "early"); }();
-    auto launch_blur_sobel = [&]() {
-        sslam::ProfScope _ps(L->ctx, "k_blur_sobel", st);
-        hipLaunchKernelGGL(k_blur_sobel, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride, w, h,
+    bool sobelDone = false;
+    auto launch_blur_sobel = [&](hipStream_t s) {
+        sslam::ProfScope _ps(L->ctx, "k_blur_sobel", s);
+        hipLaunchKernelGGL(k_blur_sobel, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, s, d_images, pitch, image_stride, w, h,
                            (unsigned*)(ws + P.offDxy), P.frameBytes, taps + 8);
+        sobelDone = true;
     };
-    if (sobelEarly) launch_blur_sobel();
+    if (sobelEarly) launch_blur_sobel(st);
     // LSD: blur(7, 0.75) -> 0.8x -> gradient
     { sslam::ProfScope _ps(L->ctx, "k_blur7", st); hipLaunchKernelGGL(k_blur7, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride,
                        ws + P.offBlur, bpitch, P.frameBytes, w, h, taps); }
@@ -374,7 +376,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         // units, results through global memory, monotonic pixel map (lsd_cluster.h).  SSLAM_LSD_CLUSTER=0 (or SSLAM_LSD_FLAVOUR=lat) takes lone
         // waves instead; SSLAM_CL_WGS = workgroups per frame (4 waves each), SSLAM_CL_WINDOW = how many sub-chunks of 16 seed positions the
         // helpers may run ahead, SSLAM_CL_SMAP = cell size (log2) of the shared map that steers their seed choice (-1: none).
-        int CL_MAXFRAMES = 64;      // up to eight frames per XCD, four workgroups each.  Per call, cluster against multi-wave form (tools/small_batch_probe.py):
+        int CL_MAXFRAMES = 64;      // up to eight frames per XCD, four workgroups each.  Per call, cluster form against the multi-wave form of rounds 2-4 (tools/small_batch_probe.py, round 3):
                                     // 1 frame 5.9 / 7.9 ms, 8: 8.5 / 11.2, 16: 9.0 / 11.9, 24: 9.4 / 12.6, 32: 10.3 / 13.1, 64: 13.5 / 15.7, 96: 21.6 / 15.9
         if (const char* e = getenv("SSLAM_CL_MAXFRAMES")) CL_MAXFRAMES = std::max(1, std::min(128, atoi(e)));      // experiment knob
         const bool bigFrame = P.sw > TorusFrame::XMASK + 1 || P.sh > TorusFrame::YMASK + 1;      // the main wave's bitmap in global memory instead of LDS
@@ -425,6 +427,9 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
                 SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
                 hipLaunchKernelGGL(k_lsd_regions_cl_stream, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
                 SSLAM_HIP(hipStreamWaitEvent(L->nfaStream, L->nfaFork, 0));
+                // LBD's gradient image depends on the source alone: on the second stream it runs under the core instead of behind the NFA stage (28 us of a single frame's
+                // 5.4 ms; the join below orders it before k_lbd)
+                if (!sobelDone && !getenv("SSLAM_LBD_SOBEL_MAIN")) launch_blur_sobel(L->nfaStream);      // (the knob: A/B, GPU call I -- 5.43 -> 5.38 ms p50)
                 if ((rc = sslam::launch_nfa_stream(L->ctx, L->nfaStream, ws, &P, sizeof(P), L->dLgam.as<double>(), L->dCl.as<uint8_t>(), clFrame, stageOff, nframes, nfaStreamWaves, spinTicks, nfaLdsPad, nfaTakeMax, nfaSleep, nullptr))) return rc;
                 SSLAM_HIP(hipEventRecord(L->nfaJoin, L->nfaStream));
                 nfaStreamed = true; nfaStageOff = stageOff;
@@ -447,7 +452,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     { const int rc = sslam::launch_nfa_stage(L->ctx, st, ws, &P, sizeof(P), L->dLgam.as<double>(), nframes); if (rc) return rc; }
     { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
     // LBD: blur(5, 1) + Sobel fused (SSLAM_LBD_SOBEL=early: in the prologue) -> bands
-    if (!sobelEarly) launch_blur_sobel();
+    if (!sobelDone) launch_blur_sobel(st);
     { sslam::ProfScope _ps(L->ctx, "k_lbd", st); hipLaunchKernelGGL(k_lbd, dim3(std::min(L->maxLines, cap), nframes), dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap); }
     SSLAM_HIP(hipGetLastError());
     L->lastFrames = nframes;

@@ -1,14 +1,12 @@
 // LSD sequential core, CLUSTER form: up to 64 frames per call, each with helper waves on SEVERAL compute units.  Part of lines.hip (included
-// after lsd_regions.h, same anonymous namespace).  Not a standalone header.  DESIGN.md 5e has the measurements.
+// after lsd_regions.h, same anonymous namespace).  Not a standalone header.  docs/history/DESIGN_rounds_1-4.md 5e has the measurements.
 //
-// The multi-wave form (lsd_regions.h) keeps everything in one workgroup's LDS and is bound by what six helper waves next to
-// the main wave can grow (they are busy 99 % of the frame; the main wave waits for them a quarter of its time and grows what they could
-// not provide -- results full, ring full, reach of the 256 x 256 torus -- itself).  This form takes the helpers out of the main wave's
-// workgroup: a frame owns nWG workgroups of one XCD (blockIdx % 8 == frame % 8: the observed dispatch rule, those share an L2; nothing
+// Its predecessor, the multi-wave form of rounds 2-4 (history 5c; removed in round 5), kept everything in one workgroup's LDS and was bound by what six helper
+// waves next to the main wave could grow.  This form takes the helpers out of the main wave's workgroup: a frame owns nWG workgroups of one XCD (blockIdx % 8 == frame % 8: the observed dispatch rule, those share an L2; nothing
 // below depends on it for correctness).  Workgroup 0 of a frame runs the MAIN wave and a FEEDER wave, the others three HELPER waves each.
 // Shared state lives in global memory.
 //
-// Protocol (what is different from the multi-wave form):
+// Protocol (what is different from that multi-wave form, whose records and validation rule (b) it keeps: lsd_regions.h):
 //   * THE PIXEL MAP IS MONOTONIC.  The main wave never releases a pixel in it: a seed it has to grow itself is grown on a private bitmap
 //     that covers the whole frame (MARK_PRIV), refine() / reduce_region_radius release and re-mark there, and only the pixels that end up
 //     USED are committed to the map.  A taken result commits its last list, as before.
@@ -111,7 +109,7 @@ __device__ __forceinline__ bool cl_spec(const ClShared& cl, int x, int y) {
 #define CL_STAT(i, v)
 #endif
 // ------------------------------------------------------------------ the main wave
-// STREAM (k_lsd_regions_cl_stream, SSLAM_NFA_STREAM=1): rectangle records go to the slot's staging array with L1-bypassing stores and a counter of the complete ones is
+// STREAM (k_lsd_regions_cl_stream: the default since round 5, SSLAM_NFA_STREAM=0 takes k_lsd_regions_cl): rectangle records go to the slot's staging array with L1-bypassing stores and a counter of the complete ones is
 // published with every rectangle -- lsd_nfa.h's k_nfa_stream runs the NFA stage on them while this wave goes on.  Nothing else differs, and this wave never waits for it.
 template <class G, int STREAM>      // G: the main wave's private bitmap: TorusFrame (LDS) or TorusGlobal (larger frames)
 __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsigned* __restrict__ qLds, unsigned* __restrict__ bmMain, unsigned* __restrict__ scanBuf,
@@ -760,7 +758,7 @@ __global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl(uint8_t* __res
     else if (wave < CL_HPW) cl_helper((role - 1) * CL_HPW + wave, ws, P, b, cl, mine, mine + CL_LIST, stashes[wave], red[wave]);
 }
 
-// The same with the rectangles streamed to a concurrent NFA stage (SSLAM_NFA_STREAM=1, an experiment: cl_main<G, true>, lsd_nfa.h: k_nfa_stream).  A copy of the kernel above rather
+// The same with the rectangles streamed to a concurrent NFA stage (the default since round 5: cl_main<G, true>, lsd_nfa.h: k_nfa_stream).  A copy of the kernel above rather
 // than a shared body: wrapped into a common inline function the default kernel came out with other register assignments, and the default kernel is the measured one.
 __global__ __launch_bounds__(64 * CL_WAVES) void k_lsd_regions_cl_stream(uint8_t* __restrict__ ws, LsdPlan P, uint8_t* __restrict__ clArea, size_t clFrameBytes, int nframes, int nWG,
                                                                         int specWords, int specShift, int window) {

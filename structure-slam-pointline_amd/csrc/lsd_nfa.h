@@ -931,7 +931,7 @@ __global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_all(uint8_t*
 }
 
 
-// ------------------------------------------------------------------ streaming form (SSLAM_NFA_STREAM=1, single frames / small calls in the cluster form; off by default)
+// ------------------------------------------------------------------ streaming form (single frames / calls of up to 64 frames in the cluster form; the default since round 5, SSLAM_NFA_STREAM=0 turns it off)
 // A single frame's NFA stage is 0.6 ms of launches behind a 5 ms core that produces its rectangles one after the other -- and no rectangle's verdict
 // feeds back into the core (a rejected rectangle's pixels stay USED).  So the stage can run WHILE the core runs: the cluster form's main wave writes its
 // rectangle records into a staging array of the frame's cluster slot with L1-bypassing stores and publishes the number of complete records with every rectangle

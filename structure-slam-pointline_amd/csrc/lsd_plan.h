@@ -60,7 +60,7 @@ struct Misc {                 // per-frame scalars
     long long cyc[8];         // master-wave cycle breakdown (debug): grow, rect, refine, nfa count, nfa math, seed scan
 };
 
-// Streaming hand-over of candidate rectangles from the cluster form's main wave to the NFA stage (SSLAM_NFA_STREAM=1; lsd_cluster.h writes, lsd_nfa.h's
+// Streaming hand-over of candidate rectangles from the cluster form's main wave to the NFA stage (the default for calls of up to 64 frames; lsd_cluster.h writes, lsd_nfa.h's
 // k_nfa_stream reads -- two translation units, hence here).  Lives in the zeroed head of a frame's cluster slot, in a cache line of its own.
 struct NfaStreamCtl {
     int candReady;            // rectangles published so far (their records are complete in the slot's staging array)

@@ -31,12 +31,12 @@ struct Planes {
 };
 __device__ __forceinline__ bool t_free(float t) { return __float_as_int(t) >= 0; }      // defined and not part of a region
 __device__ __forceinline__ float t_used(float t) { return __int_as_float(__float_as_int(t) | (int)USED_BIT); }
-// multi-wave form (below): a helper's private marks: a 256 x 256 bit TORUS (8 KB of LDS whatever the frame size).  A region that stays within +-126 pixels of its seed
+// helper waves (cluster form, lsd_cluster.h): a helper's private marks: a bit TORUS in LDS whatever the frame size (256 x 256 bits = 8 KB here; TorusWide for three helpers per workgroup).  A region that stays within +-126 pixels of its seed
 // (tested neighbours: +-127) cannot alias on it; a helper abandons a region that reaches further and the main wave grows that one itself.
 constexpr int MW_BM_WORDS = 256 * 256 / 32, MW_REACH = 126;
 __device__ __forceinline__ int mw_bit(int x, int y) { return ((y & 255) << 8) | (x & 255); }
 // Where a growing region's marks live (template argument of region_grow_w / rect_refine / remove_far_points_lds):
-//   MARK_MAP   the pixel map itself (single-wave kernel, main wave of the multi-wave form);
+//   MARK_MAP   the pixel map itself (single-wave kernel);
 //   MARK_SPEC  a helper's private bitmap: lists A / B / F are all kept for the later validation, growth gives up beyond capN points or
 //              outside the bitmap's reach;
 //   MARK_PRIV  a private bitmap that covers the whole frame (main wave of the cluster form): lists are handled as with MARK_MAP, the pixel
@@ -517,7 +517,7 @@ __device__ __forceinline__ bool boxes_meet(unsigned lo, unsigned hi, unsigned el
 
 // region2rect + refine() (LSD_REFINE_STD) of one grown region: returns whether a rectangle goes to the NFA stage.  n / rq hold the region on
 // entry and what is left USED on exit.  Main-wave form: releases and re-marks pixels in the pixel map (WANTBOX: the box of everything touched,
-// for the multi-wave event log).  SPEC form (helper wave): marks live in the private bitmap, the re-grown list goes BEHIND the first one in the
+// of the re-gather of the chunk's remaining candidates).  SPEC form (helper wave): marks live in the private bitmap, the re-grown list goes BEHIND the first one in the
 // arena and reduce_region_radius works on a copy, so that everything the helper ever accepted can be validated later.
 template <bool LAT, int MARK, bool WANTBOX, class G = TorusHelper>
 __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& regAngle, RegQ& rq, const Planes& pl, double* __restrict__ red,

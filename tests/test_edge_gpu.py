@@ -119,10 +119,10 @@ def test_randomised_parity_sweep(fe, ctx, oracle):
     dropped on wide images, a 1-ulp native sqrt in LBD, device-evaluated log-gamma tables in the NFA.)"""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
-    from fuzz_parity import cases
+    from fuzz_parity import cases, lines_both
     rng = np.random.default_rng(777)
     n = 0
-    for it, img, nfeat, nlev, sf, ini, mn, cap in cases(80, rng):
+    for it, img, nfeat, nlev, sf, ini, mn, cap, dec in cases(80, rng):
         if it % 2 and it != 75:          # every other case, plus the frame whose NFA hinged on the last bit of log-gamma
             continue
         ox = fe.OrbExtractor(ctx, nfeat, sf, nlev, ini, mn)
@@ -130,9 +130,8 @@ def test_randomised_parity_sweep(fe, ctx, oracle):
         assert len(kp) == len(okp), (it, img.shape)
         np.testing.assert_array_equal(kp.view(np.uint8), okp.view(np.uint8)); np.testing.assert_array_equal(d, od)
         lx = fe.LineExtractor(ctx, cap)
-        kl, ld, fn = lx(img); raw = lx.debug_segments(0); lx.close()
-        okl, old, ofn, oraw = oracle.lines_extract(img, cap)
-        np.testing.assert_array_equal(raw, oraw, err_msg="LSD segments, case %d %s" % (it, img.shape))
+        (kl, ld, fn, raw), (okl, old, ofn, oraw) = lines_both(lx, oracle, img, cap, dec); lx.close()      # (round 5: under the case's draw of the line path's decisions)
+        np.testing.assert_array_equal(raw, oraw, err_msg="LSD segments, case %d %s decisions %s" % (it, img.shape, dec))
         for f in kl.dtype.names:
             if f != "angle":
                 np.testing.assert_array_equal(kl[f], okl[f], err_msg=f)

@@ -51,19 +51,18 @@ def test_cluster_form_stress_time_boxed(fe, ctx, oracle):
 
 
 def test_fuzz_parity_150(fe, ctx, oracle):
-    from fuzz_parity import cases
+    from fuzz_parity import cases, lines_both
     from test_lines_gpu import _ulp_diff
     rng = np.random.default_rng(20260926)
     bad = []; nkp = nl = 0
-    for it, img, nfeat, nlev, sf, ini, mn, cap in cases(150, rng):
+    for it, img, nfeat, nlev, sf, ini, mn, cap, dec in cases(150, rng):
         tag = "case %d %dx%d nfeat %d lev %d sf %.1f th %d/%d cap %d" % (it, img.shape[1], img.shape[0], nfeat, nlev, sf, ini, mn, cap)
         ox = fe.OrbExtractor(ctx, nfeat, sf, nlev, ini, mn)
         kp, d = ox(img); ox.close()
         okp, od = oracle.orb_extract(img, nfeat, sf, nlev, ini, mn)
         if len(kp) != len(okp) or not np.array_equal(kp.view(np.uint8), okp.view(np.uint8)) or not np.array_equal(d, od): bad.append("ORB " + tag)
         lx = fe.LineExtractor(ctx, cap)
-        kl, ld, fn = lx(img); raw = lx.debug_segments(0); lx.close()
-        okl, old, ofn, oraw = oracle.lines_extract(img, cap)
+        (kl, ld, fn, raw), (okl, old, ofn, oraw) = lines_both(lx, oracle, img, cap, dec); lx.close()
         if raw.shape != oraw.shape or not np.array_equal(raw, oraw): bad.append("LSD segments " + tag)
         elif len(kl) != len(okl): bad.append("KeyLine count " + tag)
         else:
