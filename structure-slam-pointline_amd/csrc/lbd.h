@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void k_blur_sobel(const uint8_t* __restrict__ 
 // fold rows into bands (again in row order), and the 72-float vector is normalised,
 // clipped and binarised by lane 0..31.
 __constant__ float kGaussL[21];
+__constant__ float kGaussL2[21];      // kGaussL[j] * kGaussL[j], rounded once (the reference's c * c * x is (c * c) * x)
 __constant__ float kGaussG[63];
 __constant__ signed char kComb[64];
 
@@ -225,7 +226,9 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
         // row start: sCor0 after `lane` steps of (sCorX0 -= dL1, sCorY0 += dL0), sequential float ops
         float sx0 = __fadd_rn(__fadd_rn(__fmul_rn(-dL0, (float)halfWidth), __fmul_rn(dL1, (float)halfHeight)), midX);
         float sy0 = __fadd_rn(__fsub_rn(__fmul_rn(-dL1, (float)halfWidth), __fmul_rn(dL0, (float)halfHeight)), midY);
-        for (int r = 0; r < lane; ++r) { sx0 = __fsub_rn(sx0, dL1); sy0 = __fadd_rn(sy0, dL0); }
+        float ndL1 = -dL1;                              // x - y == x + (-y) bit for bit: both coordinates step by an addition, one packed instruction
+        asm volatile("" : "+v"(ndL1));                  // (opaque, or the compiler turns it back into a subtraction and issues a packed add AND a packed subtract per step)
+        for (int r = 0; r < lane; ++r) { sx0 = __fadd_rn(sx0, ndL1); sy0 = __fadd_rn(sy0, dL0); }
         float sx = sx0, sy = sy0;
         float pL = 0, nL = 0, pO = 0, nO = 0;
         // The walk's coordinates do not depend on what is gathered: the eight gathers of the NEXT group of steps are issued before the current
@@ -240,7 +243,9 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
                 // (int)roundf(x) without the seven-instruction round-half-away sequence: 2x is exact, t = trunc(2x), and round-half-away(x) = sign(x) * ((|t| + 1) >> 1)
                 // = (t + 1) >> 1 for t >= 0 and t >> 1 (= floor(t / 2) = -ceil(|t| / 2)) for t < 0, i.e. (t + 1 + (t >> 31)) >> 1 -- every |x| < 2^30.  The reference's
                 // (short) cast and its clamp "tc < 0 ? 0 : tc > W ? W : tc" are a sign extension and a median of three.
-                auto rnd = [](float x) -> int { const int t = (int)__fadd_rn(x, x); return (t + 1 + (t >> 31)) >> 1; };
+                // Round 5: the sign term is dropped -- for t < 0 both (t + 1 + (t >> 31)) >> 1 and (t + 1) >> 1 are <= 0 (t = -1: 0 and 0; t <= -2: both negative), and the
+                // clamp below turns every value <= 0 into 0; for t >= 0 the term is 0.
+                auto rnd = [](float x) -> int { const int t = (int)__fadd_rn(x, x); return (t + 1) >> 1; };
                 const int xCor = min(max((int)(short)rnd(sx), 0), imageWidth);
                 const int yCor = min(max((int)(short)rnd(sy), 0), imageHeight);
                 off8[u] = (__umul24((unsigned)yCor, (unsigned)realWidth) + (unsigned)xCor) << 2;      // byte offset: both factors < 2^16 (v_mad_u32_u24 instead of a 64-bit multiply-add)
@@ -277,23 +282,29 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
         rows[4][lane] = pO; rows[5][lane] = nO; rows[6][lane] = __fmul_rn(pO, pO); rows[7][lane] = __fmul_rn(nO, nO);
     }
     __syncthreads();
-    // band sums: lane -> (quantity q = lane/9, band = lane%9); rows visited in increasing hID so the
-    // accumulation order equals the reference's (own band, band above, band below contributions interleave by row)
-    for (int t = lane; t < 8 * NUM_BANDS; t += 64) {
-        const int q = t / NUM_BANDS, bd = t - q * NUM_BANDS;
-        const bool sq = (q == 2 || q == 3 || q == 6 || q == 7);
-        float acc = 0;
-        const int h0 = max(0, (bd - 1) * BAND_W), h1 = min(LSP_H, (bd + 2) * BAND_W);
-        for (int hID = h0; hID < h1; ++hID) {
-            const int own = hID / BAND_W, m = hID - own * BAND_W;
-            float c;
-            if (own == bd) c = kGaussL[m + BAND_W];
-            else if (own == bd + 1) c = kGaussL[m + 2 * BAND_W];     // row of the band below contributes "upward"
-            else c = kGaussL[m];                                       // row of the band above contributes "downward"
-            const float v = rows[q][hID];
-            acc = sq ? __fadd_rn(acc, __fmul_rn(__fmul_rn(c, c), v)) : __fadd_rn(acc, __fmul_rn(c, v));
+    // band sums: lane -> (pair p = lane / 9 of {pgdL, ngdL, pgdO, ngdO}, band = lane % 9), each lane folding the mean AND the squared quantity; rows visited in increasing
+    // hID so the accumulation order equals the reference's (a row adds to its own band and to the bands above and below, one accumulator per band).  Row hID of the three
+    // bands around `bd` carries gaussCoefL[hID - 7 * (bd - 1)] (entries 0..6: the band above contributes "downward", 7..13: own band, 14..20: the band below "upward"), so
+    // the 21 steps are the same for every lane: scalar coefficients, LDS reads at constant offsets, no division by the band width and no table gather (round 5: the
+    // previous loop spent ~1 000 of a line's ~3 900 vector instructions here).
+    if (lane < 4 * NUM_BANDS) {
+        const int p = lane / NUM_BANDS, bd = lane - p * NUM_BANDS;
+        const int q = (p & 1) + 4 * (p >> 1);               // rows[] of the mean quantity (0, 1, 4, 5); its square is rows[q + 2]
+        const float* rf = &rows[0][0];
+        const int r0 = q * 64 + (bd - 1) * BAND_W;          // row hID = (bd - 1) * 7 + j of quantity q
+        float acc = 0, acc2 = 0;
+        auto fold = [&](int j) { const float v = rf[r0 + j], v2 = rf[r0 + j + 2 * 64]; acc = __fadd_rn(acc, __fmul_rn(kGaussL[j], v)); acc2 = __fadd_rn(acc2, __fmul_rn(kGaussL2[j], v2)); };
+        if (bd > 0) {
+#pragma unroll
+            for (int j = 0; j < BAND_W; ++j) fold(j);
         }
-        band[q][bd] = acc;
+#pragma unroll
+        for (int j = BAND_W; j < 2 * BAND_W; ++j) fold(j);
+        if (bd < NUM_BANDS - 1) {
+#pragma unroll
+            for (int j = 2 * BAND_W; j < 3 * BAND_W; ++j) fold(j);
+        }
+        band[q][bd] = acc; band[q + 2][bd] = acc2;
     }
     __syncthreads();
     // sqrtf, not __fsqrt_rn: HIP maps the latter to the native (1-ulp) v_sqrt_f32, the former is correctly rounded

@@ -314,7 +314,10 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         }
         static const signed char comb[64] = {0, 1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 1, 2, 1, 3, 1, 4, 1, 5, 1, 6, 2, 3, 2, 4, 2, 5, 2, 6, 2, 7,
                                              2, 8, 3, 4, 3, 5, 3, 6, 3, 7, 3, 8, 4, 5, 4, 6, 4, 7, 4, 8, 5, 6, 5, 7, 5, 8, 6, 7, 6, 8, 7, 8};
+        float gl2[21];
+        for (int i = 0; i < 21; ++i) { volatile float c = gl[i]; gl2[i] = c * c; }      // one fp32 rounding, as the device's __fmul_rn(c, c)
         SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kGaussL), gl, sizeof(gl)));
+        SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kGaussL2), gl2, sizeof(gl2)));
         SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kGaussG), gg, sizeof(gg)));
         SSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kComb), comb, sizeof(comb)));
         L->constsUploaded = true;
