@@ -221,6 +221,8 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
     const float midY = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveY, kl.ePointInOctaveY));
     const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);      // D5
     const float dO0 = -dL1, dO1 = dL0;
+    // (A pitch of the gradient plane with an odd number of 64-byte lines per row -- k_lbd spends 37 % of the vector L1's cycles in tag-conflict stalls when 63 lanes read one
+    // column of 63 rows 40 lines apart -- was measured in round 5, GPU call M: conflicts 37 -> 30 %, k_lbd 10.3 -> 10.0 ms, k_blur_sobel 6.2 -> 6.9 ms.  Not kept.)
     const int realWidth = P.w, imageWidth = P.w - 1, imageHeight = P.h - 1;
     if (lane < LSP_H) {
         // row start: sCor0 after `lane` steps of (sCorX0 -= dL1, sCorY0 += dL0), sequential float ops

@@ -427,6 +427,10 @@ __device__ __forceinline__ unsigned t_raw(const unsigned* __restrict__ Tb, int y
 // the point of use: without it the compiler sinks the mask back into the conditional load
 __device__ __forceinline__ unsigned t_abs_u(unsigned v) { asm volatile("" : "+v"(v)); return v & 0x7FFFFFFFu; }
 #define T_ABS(v) ((int)t_abs_u(v))
+#ifndef SSLAM_NFA_X4
+#define SSLAM_NFA_X4 1
+#endif
+struct __attribute__((packed, aligned(4))) T4 { unsigned v[4]; };      // four pixels of a row of T from any dword
 
 // aligned-point counts of one rectangle for six nested tolerances; total = pixels visited.  win: [k] {lo, hi} of ONE window per tolerance
 // (an item whose angles straddle the 0 / 360 seam has a second window: the caller runs a second pass for it -- the windows are disjoint,
@@ -454,6 +458,21 @@ __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const int* 
         const int yb = tix(0, max(y, 0), tW);
         for (int c0 = 0; vote(c0 < mine) != 0; c0 += 12) {
             unsigned a[12];
+#if SSLAM_NFA_X4
+            // a lane's run as three 16-byte loads (dword-aligned: the hardware takes them) instead of twelve dword loads: every lane of a gather is on a row of its own, so
+            // the address unit spends its cycles per INSTRUCTION and lane, not per byte.  A load may run up to three pixels past the lane's run -- into the neighbour's run, the
+            // rest of the row or the plane behind T, all inside the frame's workspace --; those slots are masked where the votes are taken (`valid`), not here (a select on the
+            // loaded value would make every load a round trip of its own, see t_raw).
+#pragma unroll
+            for (int gq = 0; gq < 3; ++gq) {
+                if (gq == 0 || vote(c0 + 4 * gq < mine)) {
+                    T4 t = {{PIX_NONE, PIX_NONE, PIX_NONE, PIX_NONE}};
+                    if (c0 + 4 * gq < mine) t = *(const T4*)(Tb + yb + xs + c0 + 4 * gq);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[4 * gq + q] = t.v[q];
+                }
+            }
+#else
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
             if (vote(c0 + 4 < mine)) {
@@ -464,19 +483,21 @@ __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const int* 
 #pragma unroll
                 for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
             }
+#endif
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
-                if (!vote(c0 + q < mine)) break;
+                const unsigned long long valid = vote(c0 + q < mine);
+                if (!valid) break;
 #ifndef SSLAM_NFA_INT
                 const float af = __uint_as_float(t_abs_u(a[q]));
                 const double dd = align_dist_min(af, theta);
-                const unsigned long long def = vote(af < 1000.f);       // NOTDEF is 1024 here, lanes without a pixel hold a NaN pattern
+                const unsigned long long def = vote(af < 1000.f) & valid;       // NOTDEF is 1024 here, lanes without a pixel hold a NaN pattern (or, with 16-byte loads, somebody else's pixel)
 #pragma unroll
                 for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(dd <= precs[k]) & def);
 #else
                 const int ab = T_ABS(a[q]);
 #pragma unroll
-                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(ab >= lo[k]) & ~vote(ab > hi[k]));      // lanes without a pixel: above every hi
+                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(ab >= lo[k]) & ~vote(ab > hi[k]) & valid);      // lanes without a pixel: above every hi
 #endif
             }
         }
