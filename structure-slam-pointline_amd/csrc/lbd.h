@@ -223,6 +223,10 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
     const float dO0 = -dL1, dO1 = dL0;
     // (A pitch of the gradient plane with an odd number of 64-byte lines per row -- k_lbd spends 37 % of the vector L1's cycles in tag-conflict stalls when 63 lanes read one
     // column of 63 rows 40 lines apart -- was measured in round 5, GPU call M: conflicts 37 -> 30 %, k_lbd 10.3 -> 10.0 ms, k_blur_sobel 6.2 -> 6.9 ms.  Not kept.)
+    // What bounds this kernel is the vector L1, not the vector pipes (round 5, profiles/r05l_tcp_counters.txt): a gather touches 38 different 64-byte lines on average (63 for a
+    // horizontal line: one column of 63 rows), ~500 k line accesses per frame = more than one per L1 per cycle of the kernel, 37 % of the L1's cycles in tag-conflict stalls.
+    // Measured and not kept: a plane pitch with an odd number of lines per row (conflicts 37 -> 30 %, k_lbd 10.3 -> 10.0 ms, but k_blur_sobel 6.2 -> 6.9 ms); the per-line set-up
+    // (fp64 cos / sin, the region's corner: 260 vector instructions per line) moved into k_keylines and read back with scalar loads: 10.3 -> 11.1 ms.
     const int realWidth = P.w, imageWidth = P.w - 1, imageHeight = P.h - 1;
     if (lane < LSP_H) {
         // row start: sCor0 after `lane` steps of (sCorX0 -= dL1, sCorY0 += dL0), sequential float ops
