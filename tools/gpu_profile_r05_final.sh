@@ -42,6 +42,7 @@ timeout 900 python -m pytest tests -q -m gpu --durations=8 > $O/pytest_gpu.txt 2
 timeout 900 python bench.py > $O/bench_r05.json 2> $O/bench_r05.err; tail -c 300 $O/bench_r05.err
 timeout 400 python tools/fuzz_parity.py 900 20260928 > $O/fuzz_parity.txt 2>&1; tail -4 $O/fuzz_parity.txt
 timeout 300 python tools/fuzz_matchers.py 1200 > $O/fuzz_matchers.txt 2>&1; tail -3 $O/fuzz_matchers.txt
+timeout 300 python tools/fuzz_parity.py 500 20260930 > $O/fuzz_parity_b.txt 2>&1; tail -4 $O/fuzz_parity_b.txt      # (a second seed, added for the last run of the round)
 python - <<'PY'
 import json
 try:
