@@ -334,7 +334,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     { sslam::ProfScope _ps(L->ctx, "k_zero_misc", st); hipLaunchKernelGGL(k_zero_misc, dim3(nframes), dim3(64), 0, st, ws, P); }
     // LBD's gradient image (sigma-1 blur + Sobel of the SOURCE) does not depend on the segments; SSLAM_LBD_SOBEL=early launches it here, in
     // the prologue (8 ms with the chip to itself instead of 35 ms under the point branch) -- measured: the step does not respond to where a
-    // kernel runs, only to how long the kernels take alone (194.1 vs 191.4 ms), so it stays behind the NFA stage
+    // kernel runs, only to how long the kernels take alone (194.1 vs 191.4 ms; docs/history/DESIGN_rounds_1-4.md 5g), so it stays behind the NFA stage
     static const bool sobelEarly = [] { const char* e = getenv("SSLAM_LBD_SOBEL"); return e && !strcmp(e, "early"); }();
     bool sobelDone = false;
     auto launch_blur_sobel = [&](hipStream_t s) {

@@ -4,7 +4,7 @@
 // not have at four waves per SIMD, spills them, and reloads them from scratch one at a time with a wait each -- 208 bytes of scratch and 213
 // scratch loads in k_nfa_all.  Without it the constants are rematerialised where they are used: 16 bytes of scratch, 28.4 -> 26.8 ms per
 // 12 288 frames.  The sequential core in lines.hip is the other way round (78.9 -> 79.4 ms without the hoisting), hence two units
-// (DESIGN.md §5g).  The kernels are launched from here; lines.hip calls sslam::launch_nfa_stage.
+// (docs/history/DESIGN_rounds_1-4.md 5g).  The kernels are launched from here; lines.hip calls sslam::launch_nfa_stage.
 #include "common.h"
 #include <cmath>
 #include <cstdlib>

@@ -33,7 +33,7 @@ __device__ __forceinline__ void load_row12(const uint8_t* __restrict__ s, size_t
 // aligned dwords -- the lanes at the left / right image border re-read an in-range dword in place of the one outside and build the reflected
 // bytes (BORDER_REFLECT_101: columns -1, -2, -3 = 1, 2, 3; w, w + 1, w + 2 = w - 2, w - 3, w - 4) with one v_perm after the data arrived.  Without
 // a branch around the loads the rows of a strip can be requested ahead of the arithmetic (ROW_AHEAD_* rows requested ahead per lane, and the scheduler is free to hoist more): with the branch
-// every row waited for its own round trip, 38 of them per strip (round 4).
+// every row waited for its own round trip, 38 of them per strip (round 4, docs/history/DESIGN_rounds_1-4.md 5g).
 struct Row12 { unsigned d0, d1, d2; };
 // rows requested ahead per lane, per kernel (measured, profiles/r04_kernel_variants.txt: more rows in flight cost registers, i.e. resident waves)
 constexpr int ROW_AHEAD_BLUR7 = 1, ROW_AHEAD_SOBEL = 2;

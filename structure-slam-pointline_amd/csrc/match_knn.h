@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_knn2_batch(const uint8_t* __restrict__ 
 
 // ---------------------------------------------------------------- knn-2 of a batch on the matrix cores
 // The dense best / second-best search of a frame pair is 10^6 descriptor pairs; as xor + popcount it is 20 vector instructions per pair
-// and lane (k_knn2_batch: 0.43 M wave-instructions per frame, 6 % of a step that is bound by vector issue).  The same
+// and lane (k_knn2_batch: 0.43 M wave-instructions per frame, 6 % of a step that is bound by vector issue, docs/history/DESIGN_rounds_1-4.md 5f).  The same
 // distances as a product of +-64 matrices (int8): sum_k a_k b_k = 4096 (256 - 2 h), h the Hamming distance -- exact in the i32
 // accumulator of v_mfma_i32_32x32x32_i8.  One wave holds 32 (or 64) queries as the B operand (column j = lane & 31; 8 k-steps x 16 bytes
 // per lane, expanded once from the 256 bits) and streams the train rows through the A operand in tiles of 32; each lane then owns ONE

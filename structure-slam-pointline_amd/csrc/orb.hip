@@ -758,7 +758,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
     for (int q = 0; q < 7; ++q) kBlurTaps[q] = ((q < 4 ? T0 : T1) >> (8 * (q & 3))) & 255u;
 #if SSLAM_DESCRIBE_MFMA
     // ... as a product with the banded matrix of the taps on the matrix cores (v_mfma_i32_32x32x32_i8; the vector unit is what this step is short
-    // of): hb[r][c] = sum_k patch[r][k] * Toep[k][c], Toep[k][c] = tap[k - c - 2].  A = 32 patch rows, 16 bytes per lane straight
+    // of, docs/history/DESIGN_rounds_1-4.md 5f): hb[r][c] = sum_k patch[r][k] * Toep[k][c], Toep[k][c] = tap[k - c - 2].  A = 32 patch rows, 16 bytes per lane straight
     // from LDS (as signed bytes p - 128: the accumulator starts at 128 * sum(taps), every column of the band sums to that); B = the band, three
     // 32 x 32 blocks precomputed on the host in operand order (the block k < 32, c >= 32 is zero); the k a byte stands for is the same in both
     // operands by construction.  D: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).

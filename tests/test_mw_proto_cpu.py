@@ -1,4 +1,5 @@
-"""The protocol of the multi-wave LSD core (csrc/lsd_regions.h) as a CPU model with real threads and real races
+"""The helper-wave protocol of the LSD core -- the cluster form of csrc/lsd_cluster.h (mode 1 of the model: monotonic map, check (b) alone) and the multi-wave form it came
+from (rounds 2-4, removed in round 5: checks (b) and (c); docs/history/DESIGN_rounds_1-4.md 5c, 5e) -- as a CPU model with real threads and real races
 (tests/sim/mw_proto.cpp, on top of the oracle's LSD): one main thread replaying flsd() in order as the only writer of the used-map, helper
 threads running the per-seed body ahead on a read-only view + private marks, results taken after the two checks the kernel makes -- (b) every
 accepted point still unused, (c) no refine released pixels near the result since its sample.  Compared with the sequential run seed by seed
