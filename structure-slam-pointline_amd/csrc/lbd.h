@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
     // hID so the accumulation order equals the reference's (a row adds to its own band and to the bands above and below, one accumulator per band).  Row hID of the three
     // bands around `bd` carries gaussCoefL[hID - 7 * (bd - 1)] (entries 0..6: the band above contributes "downward", 7..13: own band, 14..20: the band below "upward"), so
     // the 21 steps are the same for every lane: scalar coefficients, LDS reads at constant offsets, no division by the band width and no table gather (round 5: the
-    // previous loop spent ~1 000 of a line's ~3 900 vector instructions here).
+    // previous loop spent ~1 000 of a line's ~3 200 vector instructions here: 634 k -> 415 k per frame of 200 lines, profiles/r05_pmc_sq_table.txt).
     if (lane < 4 * NUM_BANDS) {
         const int p = lane / NUM_BANDS, bd = lane - p * NUM_BANDS;
         const int q = (p & 1) + 4 * (p >> 1);               // rows[] of the mean quantity (0, 1, 4, 5); its square is rows[q + 2]
