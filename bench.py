@@ -87,6 +87,66 @@ def alg_bytes_per_frame(w, h, nkp, nln):
     }
 
 
+SIMDS, VALU_CYCLES, CLOCK_HZ = 1024, 4, 2.4e9      # MI355X: 256 CUs x 4 SIMDs, one VALU wave-instruction per SIMD per 4 cycles, 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
+CORE_STAGINGS_PER_FRAME = 13054                     # dependent gather round trips of the sequential core per frame (profiles/r05_core_phase_table_B12288.txt)
+CORE_RESIDENT_WAVES = 6144                          # 6 waves x 1 024 SIMDs
+
+
+def other_walls(kernel, avg_launch_ms, B, ms_per_step, workload, hbm_frac):
+    """The walls other than HBM bytes that this path can stand against, for the dominant kernel and for the whole step:
+      issue          VALU wave-instructions (profiles/sq_instr.json: rocprofv3 --pmc SQ_INSTS_VALU per kernel, per frame) x frames x 4 cycles / (1 024 SIMDs x clock):
+                     the time the vector pipes need if they never idle
+      random_sector  tools/gather_probe run NOW on this GPU: random 64-B sectors per second with many loads in flight (the fabric's request rate) and as a dependent
+                     chain at the core's residency (the round trip one staging of region growing waits for); against the kernel's counted L2 read requests and its
+                     dependent stagings
+    `bound` = the wall the dominant kernel is closest to.  Counter-derived inputs come from committed profiles (counters need their own rocprofv3 passes)."""
+    import subprocess
+    issue = None; rs = None
+    fr = {"hbm": hbm_frac}
+    sq = None
+    if workload == "c3":
+        try: sq = json.load(open(os.path.join(ROOT, "profiles", "sq_instr.json")))
+        except Exception: sq = None
+    if sq:
+        k = sq["kernels"].get(kernel, {})
+        fl = lambda v: v * B * VALU_CYCLES / (SIMDS * CLOCK_HZ) * 1e3
+        issue = {"unit": "ms", "clock_ghz": CLOCK_HZ / 1e9, "source": "profiles/sq_instr.json: " + sq.get("source", ""),
+                 "kernel": {"valu_wave_instructions_per_frame": k.get("valu_per_frame"), "salu_wave_instructions_per_frame": k.get("salu_per_frame"),
+                            "floor_ms_per_launch": fl(k.get("valu_per_frame", 0.0)), "frac": fl(k.get("valu_per_frame", 0.0)) / avg_launch_ms if avg_launch_ms > 0 else None},
+                 "step": {"valu_wave_instructions_per_frame": sq["valu_per_frame_total"], "floor_ms_per_step": fl(sq["valu_per_frame_total"]), "ms_per_step": ms_per_step,
+                          "frac": fl(sq["valu_per_frame_total"]) / ms_per_step if ms_per_step > 0 else None}}
+        fr["valu_issue"] = issue["kernel"]["frac"] or 0.0
+    probe = None; probe_src = None
+    exe = os.path.join(ROOT, "tools", "gather_probe")
+    if os.path.exists(exe):
+        try:
+            r = subprocess.run([exe, "16", "6"], capture_output=True, text=True, timeout=120)
+            probe = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]); probe_src = "tools/gather_probe run after the timed region on this GPU"
+        except Exception:
+            probe = None
+    if probe is None:
+        try: probe = json.load(open(os.path.join(ROOT, "profiles", "random_sector.json"))); probe_src = "profiles/random_sector.json (tools/gather_probe on another box: the binary is not built here)"
+        except Exception: probe = None
+    if probe:
+        rs = {"probe": probe, "probe_source": probe_src}
+        k = (sq or {}).get("kernels", {}).get(kernel, {})
+        if k.get("l2_reads_per_frame") and avg_launch_ms > 0:
+            rate = k["l2_reads_per_frame"] * B / (avg_launch_ms * 1e-3) / 1e9
+            rs["kernel_l2_read_requests_per_frame"] = k["l2_reads_per_frame"]; rs["kernel_gsectors_per_s"] = rate
+            rs["frac_of_request_rate"] = rate / probe["independent"]["gsectors_per_s"]
+            fr["random_sector_rate"] = rs["frac_of_request_rate"]
+        if kernel.startswith("k_lsd_regions") and avg_launch_ms > 0:
+            rounds = max(1.0, B / CORE_RESIDENT_WAVES)
+            floor = rounds * CORE_STAGINGS_PER_FRAME * probe["dependent"]["round_trip_us"] * 1e-3
+            rs["dependent_chain"] = {"stagings_per_frame": CORE_STAGINGS_PER_FRAME, "round_trip_us": probe["dependent"]["round_trip_us"], "frames_per_wave_slot": rounds,
+                                     "floor_ms_per_launch": floor, "frac": floor / avg_launch_ms,
+                                     "note": "every staging of region growing is one dependent gather: a wave cannot issue the next before this one answered; 6 144 waves are resident, so a launch is `frames_per_wave_slot` frames deep"}
+            fr["dependent_gather_latency"] = rs["dependent_chain"]["frac"]
+    bound = max(fr.items(), key=lambda kv: kv[1])[0]
+    note = "fractions of each wall for %s: %s; achieved / peak / frac above stay the HBM figures of the contract (algorithmic bytes over 8 TB/s)" % (kernel, ", ".join("%s %.3f" % kv for kv in sorted(fr.items(), key=lambda kv: -kv[1])))
+    return {"bound": bound, "note": note, "issue": issue, "random_sector": rs}
+
+
 def synth_frames(w, h, U, rank):
     """U distinct seeded scenes per rank (+ their warped previous frames): object count and noise vary from frame to frame, so the LSD core's
     content-dependent work varies too.  Cached in /tmp (generation costs ~0.2 s per 640x480 frame)."""
@@ -118,27 +178,43 @@ def cpu_baseline(frames_cur, frames_prev, budget_s=12.0, max_frames=600, with_li
     orc = oracle_lib.Oracle(native=True)
     pk, pd = orc.orb_extract(frames_prev[0], NFEAT)      # prime "previous" features outside the timed loop
     pl = orc.lines_extract(frames_prev[0], NLINES) if with_lines else None
-    t0 = time.perf_counter()
-    n = 0
     ref = []        # the oracle's outputs for the first distinct frames: compared with the GPU batch after the timing
-    while n < max_frames and (time.perf_counter() - t0) < budget_s:
-        cur = frames_cur[n % len(frames_cur)]
+
+    def one_frame(i):
+        cur = frames_cur[i % len(frames_cur)]
         kp, d = orc.orb_extract(cur, NFEAT)
+        kl = ld = None
         if with_lines:
             kl, ld, fn, raw = orc.lines_extract(cur, NLINES)
-        if n < min(nref, len(frames_cur)):
-            ref.append((kp, d, kl if with_lines else None, ld if with_lines else None))
         if with_match:
             pm = np.stack([pk["x"], pk["y"]], axis=1).astype(np.float32)
             orc.search_for_initialization(pk, pd, kp, d, pm, 100, 0.9, True, (0.0, float(W), 0.0, float(H)))
             orc.knn2(pd, d)
             if with_lines:
                 orc.line_match(pl[1], ld, 0.5, False)
+        return kp, d, kl, ld
+
+    # SURVEY.md §8(d)'s protocol: 5 warm-up frames, then per-frame times of >= 50 frames (bounded by the budget), median + p10 / p90 beside the mean rate
+    WARM = 5
+    for i in range(WARM):
+        r = one_frame(i)
+        if i < min(nref, len(frames_cur)): ref.append(r)
+    per = []
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_frames and ((time.perf_counter() - t0) < budget_s or n < 50):
+        ta = time.perf_counter()
+        r = one_frame(WARM + n)
+        per.append(time.perf_counter() - ta)
+        if WARM + n < min(nref, len(frames_cur)): ref.append(r)
         n += 1
     dt = time.perf_counter() - t0
+    per = np.array(per) * 1e3
     out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "ms_per_frame": {"median": float(np.median(per)), "p10": float(np.percentile(per, 10)), "p90": float(np.percentile(per, 90)), "mean": float(per.mean())},
+           "frames_per_s_median": float(1e3 / np.median(per)), "frames": n, "warmup_frames": WARM,
            "flags": "-O3 -march=native -ffp-contract=off, built on this host" if orc.native else "-O3 generic x86-64 (the native build failed on this host)",
-           "sample": "%d frames of the same %dx%d workload (ORB %d%s%s), %.1f s, single thread" % (n, W, H, NFEAT, " + LSD/LBD %d" % NLINES if with_lines else "", " + SearchForInitialization + dense knn-2 + line match" if with_match else "", dt),
+           "sample": "%d frames (after %d warm-up frames) of the same %dx%d workload (ORB %d%s%s), %.1f s, single thread; value = frames / total time, ms_per_frame = per-frame median / p10 / p90 (SURVEY.md 8(d))" % (n, WARM, W, H, NFEAT, " + LSD/LBD %d" % NLINES if with_lines else "", " + SearchForInitialization + dense knn-2 + line match" if with_match else "", dt),
            "note": "the workload's dense 1000x1000 knn-2 (SURVEY.md §8(d) config 3) is part of both sides; the reference itself only runs the windowed search per frame"}
     # the same oracle as N independent single-threaded processes, one pinned per host core (informational; `value` stays the
     # single-thread figure, the reference's front-end being single-threaded).  A separate interpreter without torch; any failure just omits it.
@@ -194,7 +270,7 @@ def latency_leg(fe, ctx, frames, with_lines, nframes=120):
     if lx: lx.close()
     pct = lambda a: {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "max": float(a.max())}
     out = {"unit": "ms", "frames": nframes, "path": "sslam_orb_extract + sslam_lines_extract per frame (host image in, host results out)",
-           "lsd_core": "cluster form (one main wave + helper waves on several compute units; lsd_cluster.h), NFA stage next to it (k_nfa_stream)" if (W * 0.8 <= 2048 and H * 0.8 <= 1024 and os.environ.get("SSLAM_LSD_CLUSTER", "1") != "0" and os.environ.get("SSLAM_LSD_FLAVOUR", "c")[0] == "c") else "multi-wave (one main wave + helper waves per frame; lsd_regions.h)",
+           "lsd_core": "cluster form (one main wave + helper waves on several compute units; lsd_cluster.h), NFA stage next to it (k_nfa_stream)" if (W * 0.8 <= 2048 and H * 0.8 <= 1024 and os.environ.get("SSLAM_LSD_CLUSTER", "1") != "0" and os.environ.get("SSLAM_LSD_FLAVOUR", "c")[0] == "c") else "lone wave per frame (lsd_regions.h, k_lsd_regions<true>)",
            "orb_extract_hipEvent": pct(orb), "lines_extract_hipEvent": pct(lin) if with_lines else None, "frame_hipEvent": pct(orb + lin), "frame_wall": pct(wall),
            "frames_per_s_one_at_a_time": float(1e3 / np.median(wall))}
     if with_lines and not os.environ.get("SSLAM_LSD_FLAVOUR"):
@@ -286,6 +362,31 @@ def pcie_leg(fe, ctx, frames, with_lines, n=18432, chunk=0, prev_frames=None):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, one per GPU, under torch.distributed.run on 127.0.0.1 (what the driver's own command
+    line does), hand their output through -- rank 0 prints the ONE JSON line -- and return the launcher's exit code: non-zero only when a rank really failed."""
+    import subprocess, socket, ctypes
+    n = args.gpus
+    try:      # a clear message instead of N tracebacks when the node has fewer GPUs than asked for
+        hip = ctypes.CDLL("libamdhip64.so"); cnt = ctypes.c_int(0)
+        if hip.hipGetDeviceCount(ctypes.byref(cnt)) != 0: cnt.value = 0
+        if cnt.value < n:
+            print("bench.py: --gpus %d but %d GPU(s) visible%s" % (n, cnt.value, "; this framework has no CPU fallback" if cnt.value == 0 else ""), file=sys.stderr)
+            return 2
+    except OSError:
+        pass
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    argv = [a for a in sys.argv[1:] if a != "--self-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SSLAM_BENCH_SELF_LAUNCHED"] = "1"
+    if n == 1:
+        env.setdefault("SSLAM_FORCE_COLLECTIVE", "1")      # one rank: the exchange step still runs through RCCL (ncclSend / ncclRecv to itself)
+    print("bench.py: launching %d rank(s): %s" % (n, " ".join(cmd)), file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,11 +402,14 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="latency leg only (no PCIe-inclusive host-batch leg)")
     ap.add_argument("--nfa-stream-leg", action="store_true", help="(child process of the default run) single-frame line extraction with SSLAM_NFA_STREAM=0 (the NFA stage behind the core) beside the default path")
     ap.add_argument("--lsd-nfa-variant", type=int, default=-1, help="decision D11 (sslam_lines_set_nfa_variant): 0 = log_gamma(n + 1), the default of rounds 1-4; 1 = (double(n) + 1), the default since round 5; -1: the library's default")
+    ap.add_argument("--self-launch", action="store_true", help="start the ranks from this process even for --gpus 1 (what --gpus N > 1 does by itself when no launcher set RANK): the N = 1 test of the multi-rank path, RCCL exchange included")
     ap.add_argument("--no-other-workloads", action="store_true", help="the default run appends a short pass of BASELINE configs[3] (1280x960 / 2000 kp / 400 lines) as other_workloads.c4; this skips it")
     args = ap.parse_args()
     if args.nfa_stream_leg:
         nfa_stream_leg()
         return
+    if "RANK" not in os.environ and (args.gpus > 1 or args.self_launch):
+        sys.exit(self_launch(args))
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver (already exported on the GPU boxes)
     import numpy as np
@@ -320,7 +424,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" % (args.gpus, args.gpus), file=sys.stderr)
+        print("bench.py: --gpus %d under a launcher that set WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; this framework has no CPU fallback", file=sys.stderr)
@@ -462,7 +566,8 @@ def main():
             if with_lines:
                 nl_own = c["nl"].cpu().numpy()
                 ok = ok and bool((rnl[0::world] == nl_own).all()) and bool(np.array_equal(rfn[0::world][-1, :nl_own[-1]], c["linefn"][-1, :nl_own[-1]].cpu().numpy()))
-            gather_info = {"ok": bool(ok), "impl": gather_impl, "records": int(nrec), "bytes_per_rank": sizes, "bytes_per_frame": float(sum(sizes)) / max(nrec, 1),
+            gather_info = {"ok": bool(ok), "impl": gather_impl, "rccl_ranks": int(group.size) if group is not None else int(dist.get_world_size()), "self_launched": os.environ.get("SSLAM_BENCH_SELF_LAUNCHED") == "1",
+                           "records": int(nrec), "bytes_per_rank": sizes, "bytes_per_frame": float(sum(sizes)) / max(nrec, 1),
                            "per_rank": per_rank, "note": "gather_wait_ms_per_step = time the pipeline waited for the previous step's exchange (0: hidden behind the kernels)"}
         except Exception as e:
             gather_info = {"ok": False, "impl": gather_impl, "error": str(e)[:200], "per_rank": per_rank}
@@ -499,7 +604,7 @@ def main():
             try:      # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs cannot share a process with this timing run), scaled to this batch
                 pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_c4.json" if args.workload == "c4" else "pmc_traffic.json")))
                 pt = pj["kernels"][name]      # fetch side x2: gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, calibrated in profiles/)
-                core_now = "k_lsd_regions_mw" if B <= 256 else "k_lsd_regions<true>" if B < 1024 else "k_lsd_regions<false>"
+                core_now = "k_lsd_regions_cl" if B <= 64 else "k_lsd_regions<true>" if B < 1024 else "k_lsd_regions<false>"      # lines.hip's dispatch rule: cluster form, lone waves, throughput form
                 if "fetch_correction" not in pj or pj.get("lsd_core") != core_now:
                     # the counted kernel must be the instantiation this run times, and the gfx950 fetch correction must be on record in the file
                     traffic_src = "refused: the PMC file counted %s at batch %s (fetch_correction %s), this run times %s" % (pj.get("lsd_core"), pj.get("batch"), pj.get("fetch_correction"), core_now)
@@ -510,7 +615,9 @@ def main():
                 pass
             sv = survey_bytes_per_frame(W, H, NFEAT, NLINES if with_lines else 0)
             per_gpu_fps = fps / world
-            out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            walls = other_walls(name, ms / launches, B, dt / args.steps * 1e3, args.workload, ach / HBM_PEAK_GBS)
+            out["roofline"] = {"kernel": name, "bound": walls["bound"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "bound_note": walls["note"], "issue": walls["issue"], "random_sector": walls["random_sector"],
                                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": ms / launches, "launches": launches,
                                "alg_bytes_per_launch": bytes_per_launch,
                                "isolated": ({"avg_launch_ms": prof_iso[name][0] / prof_iso[name][1], "frac": bytes_per_launch / (prof_iso[name][0] / prof_iso[name][1] * 1e-3) / 1e9 / HBM_PEAK_GBS,

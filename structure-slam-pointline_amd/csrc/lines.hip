@@ -39,7 +39,7 @@ namespace {
 __global__ void k_zero_misc(uint8_t* ws, LsdPlan P) {
     Misc* m = (Misc*)(ws + (size_t)blockIdx.x * P.frameBytes + P.offMisc);
     if (threadIdx.x == 0) {
-        m->maxS = 0; m->nDefined = 0; m->nSeg = 0; m->nCand = 0; m->nKl = 0; m->overflow = 0;
+        m->maxS = 0; m->nDefined = 0; m->nSeg = 0; m->nCand = 0; m->nKl = 0; m->overflow = 0; m->claim = 0;
 #if defined(SSLAM_LSD_DRIFT_VERIFY) || defined(SSLAM_LSD_CYCLES)
         m->cyc[5] = 0; m->cyc[6] = 0; m->cyc[7] = 0;      // shortcut decisions that disagree with the exact test; (shortcuts << 32) + decisions
 #endif

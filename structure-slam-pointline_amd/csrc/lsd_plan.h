@@ -57,6 +57,8 @@ struct Misc {                 // per-frame scalars
     int nCand;                // rectangles handed from the sequential core to the NFA stage
     int nKl;
     int overflow;
+    int claim;                // frame 0 only: frames handed out so far to the persistent workgroups of the sequential core (k_lsd_regions)
+    int pad_;
     long long cyc[8];         // master-wave cycle breakdown (debug): grow, rect, refine, nfa count, nfa math, seed scan
 };
 

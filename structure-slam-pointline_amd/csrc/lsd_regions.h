@@ -708,14 +708,22 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
 }
 
 template <bool LAT>
+#ifdef SSLAM_LSD_NUM_VGPR
+__attribute__((amdgpu_num_vgpr(SSLAM_LSD_NUM_VGPR)))
+#endif
 __global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam, int nframes) {
     extern __shared__ __align__(16) unsigned dynLds[];           // region queue (first QCAP points)
     __shared__ double red[3 * 64];                                 // addends of the ordered fp64 sums
     __shared__ float4 seedStash[64];                               // per seed candidate of the current chunk: angle, cos, sin, x | y << 16
-    // gridDim.x == nframes: one frame per workgroup.  A smaller grid (SSLAM_LSD_PERSIST) makes the workgroups persistent: each walks its
-    // share of the frames, and the wave slots the grid does not fill stay free for the other branch's kernels for the whole launch
-    for (int i = blockIdx.x; i < nframes; i += gridDim.x) {
-        __syncthreads();
+    // gridDim.x == nframes: one frame per workgroup.  A smaller grid makes the workgroups persistent: each takes the next unclaimed frame when it
+    // has finished one (Misc::claim of frame 0, zeroed by k_zero_misc), and the wave slots the grid does not fill stay free for the other
+    // branch's kernels for the whole launch (lines.hip: the resident-wave budget of the core)
+    int* claim = &((Misc*)(ws + P.offMisc))->claim;
+    for (int i = blockIdx.x; i < nframes;) {
         lsd_regions_body<LAT>(ws, P, xcd_mix_frame(i, nframes), dynLds, red, seedStash);
+        if (gridDim.x >= (unsigned)nframes) break;
+        int nxt = 0;
+        if (threadIdx.x == 0) nxt = atomicAdd(claim, 1);
+        i = (int)gridDim.x + __builtin_amdgcn_readfirstlane(nxt);
     }
 }

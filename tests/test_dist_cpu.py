@@ -117,3 +117,13 @@ def test_sharded_batch_bookkeeping_without_devices():
                 per = [sum(L.sslam_shard_chunk_count(n, G, ck, d) for ck in range(K)) for d in range(G)]
                 assert max(per) - min(per) == 1 and sum(per) == n
     assert L.sslam_shard_frame(10, 2, 0, 2, 0) == -1 and L.sslam_shard_frame(10, 2, 5, 0, 0) == -1 and L.sslam_shard_layout(-1, 2, None, None) != 0
+
+
+def test_bench_gpus_n_launches_itself_or_refuses_in_one_line():
+    """`python bench.py --gpus N` outside a launcher starts its own ranks (bench.py self_launch); with fewer GPUs than ranks -- none here -- it says so in one line and
+    exits non-zero before any rank is started (the round-5 behaviour was "needs torch.distributed.run", exit 2, on every node)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["HIP_VISIBLE_DEVICES"] = ""      # whatever this host has: none visible to the count
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "--gpus 8 but 0 GPU(s) visible" in r.stderr and "Traceback" not in r.stderr

@@ -25,6 +25,27 @@ def test_bench_under_torchrun_with_rccl_gather():
     assert out["config"]["gather_check"] is True          # rank 0 compared what RCCL delivered with its own packed records
 
 
+@pytest.mark.timeout(600)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it must start its N ranks itself (what the driver's first 8-GPU run will type).  One GPU here: the same code path
+    with N = 1 forced through it (--self-launch): torch.distributed.run on 127.0.0.1, one rank, the RCCL exchange inside every step, ONE JSON line from rank 0 that
+    carries n_gpus, the per-rank wall times, gather_check and the communicator's rank count, exit code 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SSLAM_FORCE_COLLECTIVE")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--self-launch", "--steps", "2", "--warmup", "1", "--batch", "64", "--no-cpu-baseline", "--no-other-workloads"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
+    g = out["config"]["gather"]
+    assert out["config"]["gather_check"] is True and g["self_launched"] is True and g["rccl_ranks"] == 1
+    assert len(g["per_rank"]) == 1 and g["per_rank"][0]["wall_s"] > 0
+    # more ranks than GPUs: a one-line refusal and a non-zero exit code, not N tracebacks
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+
+
 _RANK_SCRIPT = r"""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.join(sys.argv[1], "tests"))

@@ -10,8 +10,9 @@ L=(-Iinclude -Lstructure-slam-pointline_amd/lib -lsslam_frontend '-Wl,-rpath,$OR
 for t in lat_check mix_check nfa_stream_check; do gcc -O2 -Wall -Wno-misleading-indentation tools/$t.c "${L[@]}" -o tools/$t; done
 gcc -O2 -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tools/batch_check.c "${L[@]}" -L/opt/rocm/lib -lamdhip64 -lpthread -Wl,-rpath,/opt/rocm/lib -o tools/batch_check
 gcc -O2 -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tools/step_check.c "${L[@]}" -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -o tools/step_check
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/gather_probe.hip -o tools/gather_probe
 [ -f tools/step_frames.raw ] && [ -f tools/step_expected_orb.bin ] || python tools/step_check_prepare.py
 [ -f tools/lat_frames.raw ] && [ -f tools/lat_expected.bin ] || python tools/lat_check_prepare.py
 [ -f tools/lat_frames_1280x960.raw ] || python tools/lat_check_prepare.py 1280 960 8 400
 [ -f tools/mix_frames.bin ] || python tools/mix_check_prepare.py > /dev/null
-ls -la tools/lat_check tools/mix_check tools/batch_check tools/nfa_stream_check tools/step_check tools/*.raw tools/*.bin
+ls -la tools/lat_check tools/mix_check tools/batch_check tools/nfa_stream_check tools/step_check tools/gather_probe tools/*.raw tools/*.bin

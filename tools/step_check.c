@@ -51,7 +51,9 @@ int main(int argc, char** argv) {
     HIPCHK(hipMalloc((void**)&knnIdx, (size_t)B * cap * 8)); HIPCHK(hipMalloc((void**)&knnDist, (size_t)B * cap * 8));
     HIPCHK(hipMalloc((void**)&lpairs, (size_t)B * LCAP * 8)); HIPCHK(hipMalloc((void**)&nlpairs, B * 4));
     hipStream_t s1, s2; hipEvent_t core, e1, e2;
-    HIPCHK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    /* STEP_POINT_PRIO / STEP_LINE_PRIO: HIP stream priorities of the point / line branch (0 = default, -1 = high, 1 = low) */
+    HIPCHK(hipStreamCreateWithPriority(&s1, hipStreamNonBlocking, getenv("STEP_POINT_PRIO") ? atoi(getenv("STEP_POINT_PRIO")) : 0));
+    HIPCHK(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, getenv("STEP_LINE_PRIO") ? atoi(getenv("STEP_LINE_PRIO")) : 0));
     HIPCHK(hipEventCreateWithFlags(&core, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
     const float bounds[4] = {0.f, (float)W, 0.f, (float)H};
     Feat *P = &ft[1], *C = &ft[0];
@@ -60,14 +62,17 @@ int main(int argc, char** argv) {
     SCHK(sslam_lines_extract_batch_dev(ln, dPrev, W, H, W, fsz, B, P->kl, P->ldesc, P->fn, P->nl, LCAP, s1));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy2D(pm0, 8, P->kp, sizeof(sslam_keypoint), 8, (size_t)B * cap, hipMemcpyDeviceToDevice));      /* vbPrevMatched starts at F1's keypoint positions (Tracking.cc:340-342); a pristine copy, restored every step */
-    if (!one) { HIPCHK(hipEventRecord(core, s2)); SCHK(sslam_lines_set_core_event(ln, core)); }
+    /* STEP_GATE: when the point branch starts -- "core" (default): with the sequential LSD core; "pyr": the pyramid at once (beside the line prologue), FAST and what follows
+     * with the core (sslam_orb_set_gate_event); "none": everything at once */
+    const char* gate = getenv("STEP_GATE") ? getenv("STEP_GATE") : "core";
+    if (!one) { HIPCHK(hipEventRecord(core, s2)); SCHK(sslam_lines_set_core_event(ln, core)); if (!strcmp(gate, "pyr")) SCHK(sslam_orb_set_gate_event(orb, core)); }
     double t0 = 0;
     for (int it = 0; it < warm + steps; ++it) {
         if (it == warm) { HIPCHK(hipDeviceSynchronize()); if (getenv("STEP_PROFILE")) sslam_profile_enable(ctx, 1); t0 = now_ms(); }
         hipStream_t sl = one ? s1 : s2;
         SCHK(sslam_lines_extract_batch_dev(ln, dCur, W, H, W, fsz, B, C->kl, C->ldesc, C->fn, C->nl, LCAP, sl));
         SCHK(sslam_line_match_batch_dev(ctx, P->ldesc, P->nl, C->ldesc, C->nl, LCAP, B, 0.5, 0, lpairs, nlpairs, sl));
-        if (!one) HIPCHK(hipStreamWaitEvent(s1, core, 0));      /* the point branch starts when the sequential LSD core does */
+        if (!one && !strcmp(gate, "core")) HIPCHK(hipStreamWaitEvent(s1, core, 0));      /* the point branch starts when the sequential LSD core does */
         SCHK(sslam_orb_extract_batch_dev(orb, dCur, W, H, W, fsz, B, C->kp, C->desc, C->n, cap, s1));
         HIPCHK(hipMemcpyAsync(pm, pm0, (size_t)B * cap * 8, hipMemcpyDeviceToDevice, s1));      /* (pipeline.py copies the positions out of the keypoint records here: the same bytes) */
         SCHK(sslam_orb_search_for_initialization_batch_dev(ctx, P->kp, P->desc, P->n, C->kp, C->desc, C->n, cap, B, pm, m12, nmatch, 100, 0.9f, 1, bounds, s1));
