@@ -137,8 +137,9 @@ def other_walls(kernel, avg_launch_ms, B, ms_per_step, workload, hbm_frac):
             fr["random_sector_rate"] = rs["frac_of_request_rate"]
         if kernel.startswith("k_lsd_regions") and avg_launch_ms > 0:
             rounds = max(1.0, B / CORE_RESIDENT_WAVES)
-            floor = rounds * CORE_STAGINGS_PER_FRAME * probe["dependent"]["round_trip_us"] * 1e-3
-            rs["dependent_chain"] = {"stagings_per_frame": CORE_STAGINGS_PER_FRAME, "round_trip_us": probe["dependent"]["round_trip_us"], "frames_per_wave_slot": rounds,
+            rt = probe.get("unloaded", probe["dependent"])["round_trip_us"]      # the round trip when nothing queues: a lower bound on what a staging waits
+            floor = rounds * CORE_STAGINGS_PER_FRAME * rt * 1e-3
+            rs["dependent_chain"] = {"stagings_per_frame": CORE_STAGINGS_PER_FRAME, "round_trip_us": rt, "frames_per_wave_slot": rounds,
                                      "floor_ms_per_launch": floor, "frac": floor / avg_launch_ms,
                                      "note": "every staging of region growing is one dependent gather: a wave cannot issue the next before this one answered; 6 144 waves are resident, so a launch is `frames_per_wave_slot` frames deep"}
             fr["dependent_gather_latency"] = rs["dependent_chain"]["frac"]

@@ -507,46 +507,14 @@ int sslam_shard_layout(int n, int ngpu, int* chunk_slots_out, int* nchunks_out);
 int sslam_shard_frame(int n, int ngpu, int chunk, int gpu, int slot);
 int sslam_shard_chunk_count(int n, int ngpu, int chunk, int gpu);
 
-/* Self-test of the table-based exact integer division of the NFA binomial tail against the hardware IEEE division:
- * `pairs` random quotients a/b with 1 <= a,b < n; *mismatches_out must come back 0. */
-int sslam_selftest_exact_div(sslam_ctx* ctx, int n, long long pairs, long long* mismatches_out);
-/* The log-gamma / log(p) / reciprocal tables of the NFA stage as the library evaluates them on the host with the reference's own libm
- * expressions (opencv lsd.cpp log_gamma_windschitl / log_gamma_lanczos, reached from src/ExtractLineSegment.cpp:38-40): out[2n + 48].
- * Host-only; lets a test pin the table bits (a libm that rounds differently would otherwise go unnoticed until a rectangle flips). */
-int sslam_debug_nfa_tables(int n, double* out);
-/* Self-test of the guarded fp32 early-exit test used in the NFA tail loop (the reference's `err < tolerance * ...` test,
- * opencv lsd.cpp nfa(), reached from src/ExtractLineSegment.cpp:38-43): random inputs, half on the decision boundary.
- * disagree_out must be 0; ambiguous_out = cases that fall back to the fp64 expression. */
-int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long long* disagree_out, long long* ambiguous_out);
-/* The region-growing core replaces the IEEE division inside cv::fastAtan2 by the hardware's refinement sequence without its
- * scaling / special-case steps (identity on the value range of a region's direction sums) and the quadrant compares by sign-bit
- * arithmetic: `samples` random and adversarial sums, bit-compared with the `/` operator and the straight form.
- * mismatches_out[0] = divisions that differ, mismatches_out[1] = angles that differ. */
-int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long long mismatches_out[2]);
-
-/* The rectangle counter tests a pixel's level-line angle against (theta, tolerance) with integer compares: the set the reference's
- * isAligned accepts (opencv lsd.cpp, restated at oracle/lsd_oracle.cpp:68-76; reached from src/ExtractLineSegment.cpp:38-40) is at most
- * two intervals of fp32 bit patterns whose end points are found with the fp64 expression itself (csrc/lsd_align_win.h).  `cases` random and
- * adversarial (theta, tolerance) pairs, each compared with the reference predicate on every angle the gradient table can hold, the
- * neighbours of every end point and random patterns.  out3 = {disagreements (must be 0), tests, cases with three windows (must be 0)}. */
-int sslam_selftest_align_windows(sslam_ctx* ctx, int cases, long long out3[3]);
-/* Profiling aid (no reference counterpart): the chip's issue rate for one kind of vector instruction (0: v_add_u32, 1: v_fma_f32,
- * 2: v_add_f64, 3: v_bcnt_u32_b32), 16 independent instructions per lane and round with 8 waves per SIMD resident: wave-instructions per
- * second in units of 1e9.  What the SQ utilisation figures of profiles/README.md are priced against. */
-int sslam_selftest_valu_rate(sslam_ctx* ctx, int kind, double* ginst_per_s_out);
-/* Profiling aid (no reference counterpart): reads a known number of bytes in one of the library's two dominant access
- * patterns (mode 0: 16 B/lane coalesced stream, mode 1: scattered 16-B gathers) so that rocprofv3's FETCH_SIZE can be
- * calibrated on this device (tools/fetch_probe.py, profiles/README.md). */
-int sslam_selftest_fetch_probe(sslam_ctx* ctx, size_t bytes, int mode, long long* bytes_requested_out);
+/* ---- Stage taps (diagnostics).  They read back intermediate results of the LAST extraction of a handle so that a maintainer who pins this
+ * library against the reference built with OpenCV 3.4 can compare stage by stage (pyramid level bytes, FAST candidates, blurred patches: sslam_orb_debug_*, declared with
+ * the extractor above; LSD segments before the top-N cut: below).  Synchronous; nothing on the product path calls them. */
 /* Stage tap: all LSD segments (x1,y1,x2,y2 float) of frame `frame` of the last batch, before top-N. */
 int sslam_lines_debug_segments(sslam_lines* ln, int frame, float* seg_out, int cap, int* n_out);
 /* Stage clocks of the sequential LSD core for frame `frame` of the last call (grow, rect, refine, radius reduction, total, ...): zeros unless
  * the library was built with -DSSLAM_LSD_CYCLES (tools/lsd_cycles.py). */
 int sslam_lines_debug_cycles(sslam_lines* ln, int frame, long long* out8);
-/* counters of the cluster form of the sequential core (one frame at a time, helper waves on several compute units) for frame `frame` of
- * the last call; meaningful in builds with -DSSLAM_CL_CYCLES only (tools/cl_probe.py). */
-int sslam_lines_debug_cluster(sslam_lines* ln, int frame, long long* out8);
-
 #ifdef __cplusplus
 }
 #endif

@@ -31,28 +31,49 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# libsslam_frontend_testing.so = the same sources with -DSSLAM_TESTING: the product's entry points plus the self-tests, probes and the RCCL stand-in declared in
+# include/sslam_testing.h.  Only these units hold SSLAM_TESTING code and are compiled a second time; the other objects are shared.
+TEST_LIB = os.path.join(LIBDIR, "libsslam_frontend_testing.so")
+TESTING_UNITS = ("lines.hip", "group.hip")
+
+
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    if not force and not needs_build():
+    if not force and not needs_build() and os.path.exists(TEST_LIB) and os.path.getmtime(TEST_LIB) >= os.path.getmtime(LIB):
         return LIB
-    objs = []
+    objs, tobjs = [], []
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    procs = []
+    jobs = []
     for s in sources():
-        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        base = os.path.basename(s)
+        o = os.path.join(objdir, base + ".o")
         objs.append(o)
-        cmd = [HIPCC] + FLAGS + UNIT_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
+        jobs.append([HIPCC] + FLAGS + UNIT_FLAGS.get(base, []) + ["-c", s, "-o", o])
+        if base in TESTING_UNITS:
+            t = os.path.join(objdir, base + ".testing.o")
+            tobjs.append(t)
+            jobs.append([HIPCC] + FLAGS + UNIT_FLAGS.get(base, []) + ["-DSSLAM_TESTING", "-c", s, "-o", t])
+        else:
+            tobjs.append(o)
+    ncpu = max(1, min(len(jobs), (os.cpu_count() or 4)))
+    running = []
+    for cmd in jobs:
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
+        running.append((cmd, subprocess.Popen(cmd)))
+        while len([1 for _, p in running if p.poll() is None]) >= ncpu:
+            for _, p in running:
+                if p.poll() is None:
+                    p.wait(); break
+    for cmd, p in running:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    for lib, oo in ((LIB, objs), (TEST_LIB, tobjs)):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + oo
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 

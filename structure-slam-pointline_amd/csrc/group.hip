@@ -64,6 +64,7 @@ Rccl* rccl_real() {
     return R.h ? &R : nullptr;
 }
 
+#ifdef SSLAM_TESTING      // libsslam_frontend_testing.so only
 // ------------------------------------------------------------------ sslam_testing_use_rccl_standin(1) (include/sslam_testing.h): an in-process stand-in for the RCCL entry points
 // N > 1 has never run on hardware here (one GPU per box), so the group code's multi-member paths -- a host thread per device, uneven tails,
 // the collective error agreement, grouped send / receive to the root -- had no execution at all.  With this table selected at group creation
@@ -207,6 +208,10 @@ Rccl* rccl_fake() {
 // selected by a TEST entry point only (sslam_testing_use_rccl_standin, include/sslam_testing.h) -- no environment variable changes which library a product group binds
 std::atomic<int> gStandinRequested{0};
 bool fake_rccl_requested() { return gStandinRequested.load() != 0; }
+#else       // the product library holds no stand-in: a group binds librccl or fails
+bool fake_rccl_requested() { return false; }
+Rccl* rccl_fake() { return nullptr; }
+#endif      // SSLAM_TESTING
 // the table a NEW group binds (kept in the group: a process may hold real and stand-in groups side by side)
 Rccl* rccl() { return fake_rccl_requested() ? rccl_fake() : rccl_real(); }
 #define SSLAM_NCCL(api, expr)                                                                                         \
@@ -391,7 +396,9 @@ static void member_release(Member& m) {
 
 // TEST entry point (include/sslam_testing.h): groups created while this is on bind the in-process stand-in above instead of librccl, and may hold more members than
 // GPUs are visible (dealt round-robin).  Returns the previous setting.
+#ifdef SSLAM_TESTING
 extern "C" int sslam_testing_use_rccl_standin(int on) { return gStandinRequested.exchange(on ? 1 : 0); }
+#endif
 
 extern "C" int sslam_group_create(int ngpu, sslam_group** out) {
     if (!out || ngpu <= 0 || ngpu > 64) { set_error("sslam_group_create: invalid arguments"); return SSLAM_ERR_INVALID; }

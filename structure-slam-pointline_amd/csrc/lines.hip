@@ -29,7 +29,6 @@ using namespace sslam;
 namespace {
 
 #include "lsd_plan.h"
-#include "lsd_align_win.h"
 #include "lsd_front.h"
 #include "lsd_regions.h"
 #include "lsd_cluster.h"
@@ -344,6 +343,21 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         sobelDone = true;
     };
     if (sobelEarly) launch_blur_sobel(st);
+    // Work forked onto the side stream (L->nfaStream) is joined into `st` on EVERY way out of this function -- also the early error returns: the caller may reuse or
+    // free the workspace as soon as `st` is idle, and the side stream's kernels write into it
+    struct SideJoin {
+        sslam_lines* L; hipStream_t st; bool forked = false, joined = false;
+        void join() { if (forked && !joined) { (void)hipEventRecord(L->nfaJoin, L->nfaStream); (void)hipStreamWaitEvent(st, L->nfaJoin, 0); joined = true; } }
+        ~SideJoin() { join(); }
+    } side{L, st};
+    auto side_stream_ready = [&]() -> int {
+        if (!L->nfaStream) {
+            SSLAM_HIP(hipStreamCreateWithFlags(&L->nfaStream, hipStreamNonBlocking));
+            SSLAM_HIP(hipEventCreateWithFlags(&L->nfaFork, hipEventDisableTiming));
+            SSLAM_HIP(hipEventCreateWithFlags(&L->nfaJoin, hipEventDisableTiming));
+        }
+        return SSLAM_OK;
+    };
     // LSD: blur(7, 0.75) -> 0.8x -> gradient
     { sslam::ProfScope _ps(L->ctx, "k_blur7", st); hipLaunchKernelGGL(k_blur7, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride,
                        ws + P.offBlur, bpitch, P.frameBytes, w, h, taps); }
@@ -367,8 +381,9 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         size_t lds = sizeof(unsigned) * (QCAP + 4);      // + the sink slot behind the queue (region_grow_w)
         if (const char* e = getenv("SSLAM_LSD_LDS_PAD")) lds = std::max(lds, (size_t)atoi(e));      // experiment knob: cap resident region workgroups per CU
         if (lds > 48 * 1024) {
-            SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         if (L->coreWait) SSLAM_HIP(hipStreamWaitEvent(st, L->coreWait, 0));      // (sslam_lines_set_core_gate: another extractor's core has the wave slots until then)
         if (L->coreEvent) SSLAM_HIP(hipEventRecord(L->coreEvent, st));
@@ -413,11 +428,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             const size_t clLds = sizeof(unsigned) * std::max((size_t)QCAP + 4 + (bigFrame ? 0 : TorusFrame::WORDS) + CL_SCAN + CL_RING_WORDS, (size_t)CL_HPW * (CL_LIST + ClTorus::WORDS));      // the main wave's workgroup / a helper workgroup
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
             if (nfaStreamWaves) {
-                if (!L->nfaStream) {
-                    SSLAM_HIP(hipStreamCreateWithFlags(&L->nfaStream, hipStreamNonBlocking));
-                    SSLAM_HIP(hipEventCreateWithFlags(&L->nfaFork, hipEventDisableTiming));
-                    SSLAM_HIP(hipEventCreateWithFlags(&L->nfaJoin, hipEventDisableTiming));
-                }
+                if ((rc = side_stream_ready())) return rc;
                 long long spinTicks = 20000000;      // 0.2 s of the 100 MHz clock: a consumer wave that has seen no progress for that long leaves its blocks to the launch behind the core
                 if (const char* e = getenv("SSLAM_NFA_STREAM_TICKS")) spinTicks = std::max(0ll, atoll(e));
                 size_t nfaLdsPad = 40 * 1024;        // (lines_nfa.hip: keeps the consumers off the main wave's and the helpers' compute units)
@@ -430,25 +441,41 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
                 SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
                 hipLaunchKernelGGL(k_lsd_regions_cl_stream, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
                 SSLAM_HIP(hipStreamWaitEvent(L->nfaStream, L->nfaFork, 0));
+                side.forked = true;
                 // LBD's gradient image depends on the source alone: on the second stream it runs under the core instead of behind the NFA stage (28 us of a single frame's
                 // 5.4 ms; the join below orders it before k_lbd)
                 if (!sobelDone && !getenv("SSLAM_LBD_SOBEL_MAIN")) launch_blur_sobel(L->nfaStream);      // (the knob: A/B, GPU call I -- 5.43 -> 5.38 ms p50)
                 if ((rc = sslam::launch_nfa_stream(L->ctx, L->nfaStream, ws, &P, sizeof(P), L->dLgam.as<double>(), L->dCl.as<uint8_t>(), clFrame, stageOff, nframes, nfaStreamWaves, spinTicks, nfaLdsPad, nfaTakeMax, nfaSleep, nullptr))) return rc;
-                SSLAM_HIP(hipEventRecord(L->nfaJoin, L->nfaStream));
                 nfaStreamed = true; nfaStageOff = stageOff;
             } else
             hipLaunchKernelGGL(k_lsd_regions_cl, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
-        } else if (lone) hipLaunchKernelGGL(k_lsd_regions<true>, dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);      // lone waves: shortest chain
+        } else if (lone) hipLaunchKernelGGL((k_lsd_regions<true, 6>), dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);      // lone waves: shortest chain
         else {
-            int grid = nframes;
-            if (const char* e = getenv("SSLAM_LSD_PERSIST")) { const int g = atoi(e) & ~7; if (g >= 8 && g < nframes) grid = g; }      // experiment knob: persistent workgroups
-            hipLaunchKernelGGL(k_lsd_regions<false>, dim3(grid), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
+            // A caller that announced a branch running beside the core (sslam_lines_set_core_event: the bench step's point branch waits for that event) gets the GUEST form
+            // (lsd_regions.h): 16 persistent workgroups per compute unit of the four-wave instantiation, a third of the registers free for the other branch's waves -- and
+            // LBD's gradient image, which needs the source alone, as one more guest under the core on the side stream instead of 6 ms of the tail.
+            // SSLAM_LSD_GUEST=0 / 1 overrides (A/B), SSLAM_LSD_PERSIST=g sets the grid.
+            int grid = 16 * L->ctx->num_cus;
+            bool guest = L->coreEvent != nullptr;
+            if (const char* e = getenv("SSLAM_LSD_GUEST")) guest = atoi(e) != 0;
+            if (const char* e = getenv("SSLAM_LSD_PERSIST")) { const int g = atoi(e) & ~7; if (g >= 8) grid = g; }
+            guest = guest && grid < nframes;
+            if (guest) {
+                if (!sobelDone && !getenv("SSLAM_LBD_SOBEL_MAIN")) {
+                    if ((rc = side_stream_ready())) return rc;
+                    SSLAM_HIP(hipEventRecord(L->nfaFork, st));
+                    SSLAM_HIP(hipStreamWaitEvent(L->nfaStream, L->nfaFork, 0));
+                    side.forked = true;
+                }
+                hipLaunchKernelGGL((k_lsd_regions<false, 4>), dim3(grid), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
+                if (side.forked) launch_blur_sobel(L->nfaStream);
+            } else hipLaunchKernelGGL((k_lsd_regions<false, 6>), dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
         }
     }
     if (L->coreDone) SSLAM_HIP(hipEventRecord(L->coreDone, st));
     // the NFA stage: its kernels and launch forms live in lines_nfa.hip, a translation unit of its own (compiled with -mllvm -disable-machine-licm)
     if (nfaStreamed) {      // what the concurrent consumers left (nothing, unless they gave up waiting): the same kernel behind both, everything published, no waiting
-        SSLAM_HIP(hipStreamWaitEvent(st, L->nfaJoin, 0));
+        side.join();
         const int rc2 = sslam::launch_nfa_stream(L->ctx, st, ws, &P, sizeof(P), L->dLgam.as<double>(), L->dCl.as<uint8_t>(), L->clFrame, nfaStageOff, nframes, 16, 0, 0, NFA_STREAM_BLOCK, 1, "k_nfa_stream");
         if (rc2) return rc2;
     } else
@@ -456,6 +483,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     { sslam::ProfScope _ps(L->ctx, "k_keylines", st); hipLaunchKernelGGL(k_keylines, dim3(nframes), dim3(256), 0, st, ws, P, L->maxLines, d_kl, d_linefn, d_counts, cap); }
     // LBD: blur(5, 1) + Sobel fused (SSLAM_LBD_SOBEL=early: in the prologue) -> bands
     if (!sobelDone) launch_blur_sobel(st);
+    side.join();
     { sslam::ProfScope _ps(L->ctx, "k_lbd", st); hipLaunchKernelGGL(k_lbd, dim3(std::min(L->maxLines, cap), nframes), dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap); }
     SSLAM_HIP(hipGetLastError());
     L->lastFrames = nframes;
@@ -568,6 +596,7 @@ extern "C" int sslam_lines_debug_cycles(sslam_lines* L, int frame, long long* ou
     return SSLAM_OK;
 }
 
+#ifdef SSLAM_TESTING      // everything from here to the matching #endif exists in libsslam_frontend_testing.so only (include/sslam_testing.h)
 // counters of the cluster form's helpers for frame `frame` of the last call (lsd_cluster.h, ClCtl::stat; filled by builds with -DSSLAM_CL_CYCLES)
 extern "C" int sslam_lines_debug_cluster(sslam_lines* L, int frame, long long* out8) {
     if (!L || frame < 0 || frame >= L->clSlots || !out8 || !L->dCl.p || !L->clFrame) return SSLAM_ERR_INVALID;
@@ -642,22 +671,6 @@ extern "C" int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long
     return SSLAM_OK;
 }
 
-extern "C" int sslam_selftest_align_windows(sslam_ctx* ctx, int cases, long long out3[3]) {
-    if (!ctx || cases <= 0 || !out3) return SSLAM_ERR_INVALID;
-    SSLAM_HIP(hipSetDevice(ctx->device));
-    ScopedDev dMem;
-    SSLAM_HIP(hipMalloc(&dMem.p, 3 * sizeof(unsigned long long)));
-    unsigned long long* d = (unsigned long long*)dMem.p;
-    SSLAM_HIP(hipMemset(d, 0, 3 * sizeof(unsigned long long)));
-    const int blocks = 512, rounds = (cases + blocks - 1) / blocks;
-    hipLaunchKernelGGL(k_selftest_align, dim3(blocks), dim3(256), 0, ctx->stream, 0xA11D0C5ull, rounds, d);
-    unsigned long long h[3] = {0, 0, 0};
-    SSLAM_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    SSLAM_HIP(hipStreamSynchronize(ctx->stream));
-    out3[0] = (long long)h[0]; out3[1] = (long long)h[1]; out3[2] = (long long)h[2];
-    return SSLAM_OK;
-}
-
 // Issue-rate probe (profiles/README.md, round 3): every lane runs `iters` rounds of 16 independent VALU instructions of one kind
 // (0: v_add_u32, 1: v_fma_f32, 2: v_add_f64, 3: v_bcnt_u32_b32) with 8 waves per SIMD resident, so that the rate is the pipe's, not a
 // dependency chain's.  *ginst_per_s_out = wave-instructions per second over the whole chip (divide by SIMDs x clock for cycles per instruction).
@@ -729,6 +742,8 @@ extern "C" int sslam_selftest_fetch_probe(sslam_ctx* ctx, size_t bytes, int mode
     return SSLAM_OK;
 }
 
+#endif      // SSLAM_TESTING
+
 // Device-resident frame handle of the last sslam_lines_extract call (keylines + LBD descriptors), see sslam_frame_from_orb.
 int sslam_frame_from_device(sslam_ctx* ctx, int kind, const void* d_feats, const uint8_t* d_desc, int n, const float bounds[4], sslam_frame** out);
 extern "C" int sslam_frame_from_lines(sslam_lines* L, const float bounds[4], sslam_frame** out) {
@@ -769,6 +784,7 @@ extern "C" int sslam_lines_debug_lbd_floats(sslam_lines* L, int frame, float* ou
 
 extern "C" sslam_ctx* sslam_lines_context(sslam_lines* L) { return L ? L->ctx : nullptr; }
 
+#ifdef SSLAM_TESTING
 // The host-evaluated nfa() tables exactly as upload_nfa_tables() sends them to the device (decision D8): lgam[0..n), then 16 x {log p,
 // log(1-p), log10 p}, then 1/j.  Pure host code (no GPU needed): tests/test_oracle_cpu.py pins the bits against committed goldens, so a
 // host libm that rounds log / sinh / pow differently is noticed before it can flip a borderline rectangle.
@@ -779,3 +795,4 @@ extern "C" int sslam_debug_nfa_tables(int n, double* out) {
     for (int j = 0; j < n; ++j) out[(size_t)n + 48 + j] = j >= 1 ? 1.0 / (double)j : 0.0;
     return SSLAM_OK;
 }
+#endif      // SSLAM_TESTING

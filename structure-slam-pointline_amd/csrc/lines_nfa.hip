@@ -18,7 +18,6 @@ namespace {
 
 #define SSLAM_NFA_STAGE_ONLY 1
 #include "lsd_plan.h"
-#include "lsd_align_win.h"
 #include "lsd_nfa.h"
 
 }  // namespace

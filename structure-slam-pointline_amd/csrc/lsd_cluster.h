@@ -87,11 +87,7 @@ struct ClShared {
 __device__ __forceinline__ int g_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned g_ldu(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void g_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#ifdef SSLAM_CL_PLAIN_STORES      // measurement knob: result stores stay in the XCD's L2 (only correct while helpers and main wave share an XCD)
-__device__ __forceinline__ void g_stu(unsigned* p, unsigned v) { *(volatile unsigned*)p = v; }
-#else
 __device__ __forceinline__ void g_stu(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#endif
 __device__ __forceinline__ void cl_compiler_fence() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ void cl_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ bool cl_spec(const ClShared& cl, int x, int y) {
@@ -156,11 +152,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             if (pos0 + 64 * CL_GROUP < nOrd) load_group(pos0 + 64 * CL_GROUP);
         }
         if (lane == 0) g_st(&cl.ctl->mainPos, pos0);
-#if defined(SSLAM_CL_RELAXED_SEQ)
-        __hip_atomic_store(&loc->mainChunk, pos0 >> 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
         lds_st(&loc->mainChunk, pos0 >> 6);
-#endif
         const unsigned idx = scanIdx[64 * gj + lane];
         const bool have = idx != 0xFFFFFFFFu;
         const int tiSeed = have ? pl.ti(idx) : 0;
@@ -386,11 +378,7 @@ __device__ void cl_main(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsig
             accCurAny = accNextAny = true;
             ++commitSeq;                                  // (after the commit's stores were issued: the feeder reads the counter before it gathers)
             if (lane == (commitSeq & 63)) { logLo = bxLo; logHi = bxHi; logSeq = commitSeq; }
-#if defined(SSLAM_CL_RELAXED_SEQ)      // measurement knob: how much the release (a wait for the commit's stores) costs
-            __hip_atomic_store(&loc->commitSeq, commitSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
             lds_st(&loc->commitSeq, commitSeq);
-#endif
             if (tooSmall) {
                 // too small: rejected, its pixels stay used.  Which candidates of this chunk did it take?
                 for (int k = 1; k < n; ++k) {
@@ -601,11 +589,7 @@ __device__ void cl_helper(int h, uint8_t* __restrict__ ws, const LsdPlan& P, int
                 reap();
                 const int mp = g_ld(&ctl->mainPos);
                 if (mp >= c * 64 || g_ld(&ctl->finished)) break;
-#ifdef SSLAM_CL_EAGER_SECOND_LOOK
-                if (pass > 1 && g_ld(&ctl->cursor) <= (mp >> 6) * CL_NSUB + cl.window && fHead - fTail < CL_FIFO - 1) break;
-#else
                 if (g_ld(&ctl->cursor) <= (mp >> 6) * CL_NSUB + cl.window && fHead - fTail < CL_FIFO - 1) break;
-#endif
                 __builtin_amdgcn_s_sleep(8);
                 asm volatile("buffer_inv sc1" ::: "memory");
                 // Re-validation: a published result that a commit has overtaken since (one of its points is used now) would be refused by

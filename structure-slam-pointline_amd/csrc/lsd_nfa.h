@@ -34,6 +34,7 @@ __device__ __forceinline__ double exact_div(double a, double b, double y) {
     const double r = fma(-b, q0, a);
     return fma(r, y, q0);
 }
+#if defined(SSLAM_TESTING) && !defined(SSLAM_NFA_STAGE_ONLY)
 __global__ void k_selftest_div(const double* __restrict__ rcp, int n, unsigned long long seed, int iters, unsigned long long* __restrict__ bad) {
     unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
     unsigned long long nb = 0;
@@ -46,6 +47,7 @@ __global__ void k_selftest_div(const double* __restrict__ rcp, int n, unsigned l
     }
     if (nb) atomicAdd(bad, nb);
 }
+#endif
 // plog[h] = {log(p), log(1-p), log10(p)} for p = 0.125 * 2^-h: every precision rect_improve can reach
 struct PLog { double lp, l1mp, l10p; };
 
@@ -79,6 +81,7 @@ __device__ __forceinline__ int tail_test_cheap(double term, double m, int q, dou
     return -1;
 }
 
+#if defined(SSLAM_TESTING) && !defined(SSLAM_NFA_STAGE_ONLY)
 // Self-test of tail_test_cheap (sslam_selftest_tail_test): random (term, m, q, bin_tail), half of them steered onto the
 // decision boundary err ~ rhs, counted as disagreeing when the cheap verdict differs from the fp64 expression.
 __global__ void k_selftest_tail(unsigned long long seed, int iters, double logNT, unsigned long long* __restrict__ out) {
@@ -123,6 +126,7 @@ __global__ void k_probe_gather16(const float4* __restrict__ buf, size_t nElem, i
     }
     if (acc == 12345.678f) *sink = acc;
 }
+#endif
 // LineSegmentDetectorImpl::nfa() split for lane-dynamic scheduling: nfa_setup() covers everything before the binomial-tail
 // loop, tail_block() advances the loop by up to eight terms, and the caller finishes with -log10(bin_tail) - logNT.
 struct TailState { double term, bin_tail, p_term; int n, i; };           // i = next term index (k+1 .. n)
@@ -192,60 +196,6 @@ __device__ __forceinline__ bool tail_block(TailState& S, double logNT, const dou
 // k_nfa_eval (the binomial-tail NFAs of all candidates, lanes scheduled dynamically) + k_nfa_accept (the reference's sequential acceptance).
 struct NfaState { double logNfa; int done, nc; int cnt[6][2]; double val[6]; };      // per rectangle; cnt[k] = {total, aligned}, val[j] = NFA of candidate j
 
-#ifndef SSLAM_NFA_STAGE_ONLY      // (needs the gradient table of lsd_front.h: lines.hip only)
-// Self-test of lsd_align_win.h on the device (sslam_selftest_align_windows): one (theta, tolerance) case per block round -- theta anywhere
-// region2rect can put it ([0, 3pi)), negative, glued to the 0 / 2pi seams or to the pruning edges; tolerances pi/8 * 2^-h and arbitrary
-// ones below pi/2 -- whose windows are compared with the reference predicate (is_aligned_val, lsd_plan.h) on EVERY angle the gradient
-// table holds, on the +-3 neighbours of every end point and on random bit patterns.  out[0] = disagreements, out[1] = tests,
-// out[2] = cases with three non-empty windows (excluded by construction).
-__global__ __launch_bounds__(256) void k_selftest_align(unsigned long long seed, int rounds, unsigned long long* __restrict__ out) {
-    __shared__ int w[6];
-    __shared__ double tp[2];
-    unsigned long long bad = 0, tests = 0;
-    unsigned long long x = seed + (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x + 1) * 0x9E3779B97F4A7C15ull;
-    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (double)(x >> 11) * 0x1p-53; };
-    for (int rd = 0; rd < rounds; ++rd) {
-        if (threadIdx.x == 0) {
-            const int mode = (int)(rnd() * 8);
-            double theta = -kPI + rnd() * 4 * kPI;
-            if (mode == 0) theta = (rnd() - 0.5) * 0.9;
-            else if (mode == 1) theta = 2 * kPI + (rnd() - 0.5) * 0.9;
-            else if (mode == 2) theta = (double)fast_atan2_deg((float)((int)(rnd() * 1021) - 510), (float)((int)(rnd() * 1021) - 510) + 0.5f) * DEG2RAD;
-            else if (mode == 3) theta = -kPI + rnd() * 0.5;
-            double prec = kPI * (22.5 / 180.0);
-            const int h = (int)(rnd() * 7);
-            for (int i = 0; i < h; ++i) prec /= 2;
-            if (mode == 5) prec = rnd() * 1.5;
-            if (mode == 6) theta = prec * (rnd() < 0.5 ? 1 : -1) + (rnd() - 0.5) * 1e-9 + (rnd() < 0.5 ? 0 : 2 * kPI);
-            int n, lo[2], hi[2];
-            const bool ok = alnwin::windows(theta, prec, n, lo, hi);
-            w[0] = n; w[1] = lo[0]; w[2] = hi[0]; w[3] = lo[1]; w[4] = hi[1]; w[5] = ok ? 0 : 1;
-            tp[0] = theta; tp[1] = prec;
-        }
-        __syncthreads();
-        const double theta = tp[0], prec = tp[1];
-        const int n = w[0], lo0 = w[1], hi0 = w[2], lo1 = w[3], hi1 = w[4];
-        auto check = [&](int b) {
-            if (b < 0 || b > alnwin::BMAX) return;
-            const bool inw = (n > 0 && b >= lo0 && b <= hi0) || (n > 1 && b >= lo1 && b <= hi1);
-            ++tests;
-            if (is_aligned_val(__int_as_float(b), theta, prec) != inw) ++bad;
-        };
-        for (int i = threadIdx.x; i < GT * GT; i += blockDim.x) {
-            const int gy = i / GT - 510, gx = i - (i / GT) * GT - 510;
-            if (gx == 0 && gy == 0) continue;
-            check(__float_as_int(fast_atan2_deg((float)gx, (float)(-gy))));
-        }
-        if (threadIdx.x < 14) { const int d = (int)threadIdx.x % 7 - 3; check((threadIdx.x < 7 ? lo0 : hi0) + d); check((threadIdx.x < 7 ? lo1 : hi1) + d); }
-        for (int i = 0; i < 16; ++i) check((int)(rnd() * (alnwin::BMAX + 1.0)));
-        if (threadIdx.x == 0 && w[5]) atomicAdd(out + 2, 1ull);
-        __syncthreads();
-    }
-    if (bad) atomicAdd(out, bad);
-    atomicAdd(out + 1, tests);
-}
-
-#endif
 
 // Everything below is the stage itself: compiled by lines_nfa.hip only (round 4 compiled it into lines.hip as well -- a second k_nfa_all with 81 spilled VGPRs that nothing launched).
 #ifdef SSLAM_NFA_STAGE_ONLY
@@ -388,33 +338,19 @@ __device__ __forceinline__ unsigned long long vote(bool p) { return __builtin_am
 //
 // Round 3: the pixels a candidate covers are no longer counted by votes -- that total is the sum of its row widths, accumulated by the
 // first lane of every row -- and the angle plane is T (|T|: the used bit is the sign; NOTDEF becomes 1024).
-// The alignment test has an INTEGER form as well (-DSSLAM_NFA_INT): theta and the tolerance are fixed per item and isAligned is monotone
-// in the stored fp32 angle, so the aligned set is at most two intervals of angle bit patterns (lsd_align_win.h: end points found with the
-// fp64 expression itself in the lane-parallel setup; "in [lo, hi]" = two integer compares, a second pass for the rare second window).
-// It is exact (CPU test over every table angle, sslam_selftest_align_windows, the whole GPU suite and the fuzz sweeps ran with it) and it
-// removes the eight fp64 instructions per pixel slot -- and the kernel does not get faster: 21.2 ms per 12 288 frames against 20.3 ms with
-// the fp64 predicate on the same planes (19.9 ms in round 2).  The counter is bound by its row-range bookkeeping and its dependent
-// loads, not by the predicate; the fp64 form stays the default.  (What DID cost 33 %: masking the used bit inside the conditional load,
-// which made the compiler wait for every load before issuing the next -- see t_raw.)
+// (An integer form of the alignment test -- at most two windows of fp32 angle bit patterns per (theta, tolerance) -- was exact and 4 % slower: the counter is bound by
+// its row-range bookkeeping and its dependent loads, not by the predicate.  Removed in round 6; docs/history has the measurement.)
 constexpr int EVAL_CH = 1024;          // rectangles per item-list chunk (k_nfa_count, k_nfa_eval)
 constexpr int EVAL_REFILL = 16;
-#ifdef SSLAM_NFA_INT
-constexpr int CNT_NEST = 32;           // items per batch in the nested stages (their windows need 6 x 2 intervals each)
-#else
 constexpr int CNT_NEST = 64;
-#endif
 constexpr unsigned PIX_NONE = 0x7FFFFFFFu;      // what a lane without a pixel holds: above every interval
-struct CntItem { NfaGeom g; int c, j, lg, nWin; int lo[2], hi[2];      // lg: log2 of the lanes sharing a row; [lo, hi]: aligned angle bit patterns
-#ifndef SSLAM_NFA_INT               // default: the per-pixel fp64 predicate (-DSSLAM_NFA_INT: the integer windows of lsd_align_win.h -- exact, measured 4 % slower)
+struct CntItem { NfaGeom g; int c, j, lg;      // lg: log2 of the lanes sharing a row
                  double theta, prec, p;
-#endif
 };
-#ifndef SSLAM_NFA_INT
 __device__ __forceinline__ double align_dist_min(float aDeg, double theta) {
     const double n_theta = fabs(theta - (double)aDeg * DEG2RAD);
     return fmin(n_theta, fabs(n_theta - M_2PI_));
 }
-#endif
 
 // Pixel walk shared by the two counters below.  A row is shared by 2^lg lanes (lg picked per rectangle from its widest
 // row: tall thin rectangles put 32 rows in flight, flat ones spread one row over the whole wave); each lane owns a
@@ -427,25 +363,15 @@ __device__ __forceinline__ unsigned t_raw(const unsigned* __restrict__ Tb, int y
 // the point of use: without it the compiler sinks the mask back into the conditional load
 __device__ __forceinline__ unsigned t_abs_u(unsigned v) { asm volatile("" : "+v"(v)); return v & 0x7FFFFFFFu; }
 #define T_ABS(v) ((int)t_abs_u(v))
-#ifndef SSLAM_NFA_X4
-#define SSLAM_NFA_X4 1
-#endif
 struct __attribute__((packed, aligned(4))) T4 { unsigned v[4]; };      // four pixels of a row of T from any dword
 
-// aligned-point counts of one rectangle for six nested tolerances; total = pixels visited.  win: [k] {lo, hi} of ONE window per tolerance
-// (an item whose angles straddle the 0 / 360 seam has a second window: the caller runs a second pass for it -- the windows are disjoint,
-// so the counts add -- instead of every pixel step carrying a second set of compares).
-__device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const int* __restrict__ win, const unsigned* __restrict__ Tb, int tW, int sw, bool small,
+// aligned-point counts of one rectangle for six nested tolerances (precs[k], around theta); total = pixels visited.
+__device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const unsigned* __restrict__ Tb, int tW, int sw, bool small,
                                            int lane, int& totalOut, int (&alg)[6], double theta = 0, const double* precs = nullptr) {
     constexpr int K = 6;
     const int nrows = g.y1 - g.y0 + 1;
     const int rowsPer = 64 >> lg, r = lane >> lg, sub = lane & ((1 << lg) - 1);
     int total = 0;
-#ifdef SSLAM_NFA_INT
-    int lo[K], hi[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) { lo[k] = win[k * 4]; hi[k] = win[k * 4 + 1]; }
-#endif
     for (int t0 = 0; t0 < nrows; t0 += rowsPer) {
         const int t = t0 + r;
         int xa = 0, xb = -1; const int y = g.y0 + t;
@@ -458,7 +384,6 @@ __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const int* 
         const int yb = tix(0, max(y, 0), tW);
         for (int c0 = 0; vote(c0 < mine) != 0; c0 += 12) {
             unsigned a[12];
-#if SSLAM_NFA_X4
             // a lane's run as three 16-byte loads (dword-aligned: the hardware takes them) instead of twelve dword loads: every lane of a gather is on a row of its own, so
             // the address unit spends its cycles per INSTRUCTION and lane, not per byte.  A load may run up to three pixels past the lane's run -- into the neighbour's run, the
             // rest of the row or the plane behind T, all inside the frame's workspace --; those slots are masked where the votes are taken (`valid`), not here (a select on the
@@ -472,33 +397,15 @@ __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const int* 
                     for (int q = 0; q < 4; ++q) a[4 * gq + q] = t.v[q];
                 }
             }
-#else
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
-            if (vote(c0 + 4 < mine)) {
-#pragma unroll
-                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
-            }
-            if (vote(c0 + 8 < mine)) {
-#pragma unroll
-                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
-            }
-#endif
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 const unsigned long long valid = vote(c0 + q < mine);
                 if (!valid) break;
-#ifndef SSLAM_NFA_INT
                 const float af = __uint_as_float(t_abs_u(a[q]));
                 const double dd = align_dist_min(af, theta);
                 const unsigned long long def = vote(af < 1000.f) & valid;       // NOTDEF is 1024 here, lanes without a pixel hold a NaN pattern (or, with 16-byte loads, somebody else's pixel)
 #pragma unroll
                 for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(dd <= precs[k]) & def);
-#else
-                const int ab = T_ABS(a[q]);
-#pragma unroll
-                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(ab >= lo[k]) & ~vote(ab > hi[k]) & valid);      // lanes without a pixel: above every hi
-#endif
             }
         }
     }
@@ -512,12 +419,9 @@ __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const int* 
 // Stages 1-3: the (up to five) candidates of a rectangle differ by half-pixel width / offset steps and share theta and the
 // tolerance, so they are counted in ONE pass over the union of their rows: the angle test runs once per pixel, membership in
 // candidate j is two integer compares against that candidate's own row range (rect_nfa's edge stepping, per candidate).
-// [lo, hi]: one window of aligned angle patterns (second pass for a second window, as above; totals from the first pass).
-__device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int nc, int lg, int lo, int hi, const unsigned* __restrict__ Tb, int tW, int sw, bool small, int lane,
+__device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int nc, int lg, const unsigned* __restrict__ Tb, int tW, int sw, bool small, int lane,
                                             int (&total)[MAXC], int (&alg)[MAXC]) {
-#ifndef SSLAM_NFA_INT
     const double theta = it5[0].theta, prec = it5[0].prec;
-#endif
     NfaGeom g[MAXC];
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) g[j] = it5[j < nc ? j : 0].g;
@@ -563,13 +467,8 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 if (!vote(c0 + q < mine)) break;
-#ifndef SSLAM_NFA_INT
                 const float af = __uint_as_float(t_abs_u(a[q]));
                 const unsigned long long al = vote(align_dist_min(af, theta) <= prec) & vote(af < 1000.f);
-#else
-                const int ab = T_ABS(a[q]);
-                const unsigned long long al = vote(ab >= lo) & ~vote(ab > hi);       // lanes without a pixel hold PIX_NONE: above every hi
-#endif
                 const int x = xs + c0 + q;
 #pragma unroll
                 for (int j = 0; j < MAXC; ++j) {
@@ -592,9 +491,6 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
 template <int CH>
 struct NfaCountLdsT {
     CntItem its[64];
-#ifdef SSLAM_NFA_INT
-    int nestWin[CNT_NEST][6][4];                                     // nested stages: {lo0, hi0, lo1, hi1} per precision
-#endif
     unsigned short act[CH];
 };
 template <int CH> union NfaLdsT { NfaCountLdsT<CH> c; unsigned short items[CH * 5]; };      // items: (rect - chunk) << 3 | candidate; CH = rectangles per chunk
@@ -609,9 +505,6 @@ __device__ __forceinline__ void nfa_wave_sync() { __syncthreads(); }
 template <int CH>
 __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, const LsdPlan& P, int stage, int c0, int c1, int lane, NfaCountLdsT<CH>& L) {
     CntItem* its = L.its;
-#ifdef SSLAM_NFA_INT
-    int (*nestWin)[6][4] = L.nestWin;
-#endif
     unsigned short* act = L.act;
     Misc* misc = (Misc*)(base + P.offMisc);
     const unsigned* Tb = (const unsigned*)(base + P.offT);
@@ -637,7 +530,7 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
             const int nIt = nested ? nr : nr * MAXC;
             {
                 const int ri = nested ? lane : lane / MAXC, j = nested ? 0 : lane - ri * MAXC;
-                bool valid = false, winOk = true;
+                bool valid = false;
                 int c = 0;
                 if (lane < nIt) {
                     c = chunk + act[a0 + ri];
@@ -651,31 +544,9 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
                         const int need = (nfa_max_width(I.g) + (nested ? 0 : 3) + 11) / 12;       // lanes per row so that a run is <= 12 pixels
                         int lg = 1; while ((1 << lg) < need && lg < 6) ++lg;
                         I.lg = lg;
-#ifndef SSLAM_NFA_INT
                         I.theta = r.theta; I.prec = r.prec; I.p = r.p;
-#endif
-#ifdef SSLAM_NFA_INT
-                        // aligned-angle windows (lsd_align_win.h): six tolerances around one theta in the nested stages (stage 4 uses five of
-                        // them), one for the first candidate of a rectangle in stages 1-3 (its candidates share theta and the tolerance)
-                        const int nK = nested ? 6 : j == 0 ? 1 : 0;
-                        int nw = 0;
-#pragma unroll 1
-                        for (int k = 0; k < nK; ++k) {
-                            const double pk = !nested ? r.prec : stage == 0 ? (k == 0 ? r.prec : ldexp(r.p, -k) * kPI) : ldexp(r.p, -(k + 1)) * kPI;
-                            const alnwin::Win w = alnwin::windows(r.theta, pk);
-                            winOk &= w.ok != 0;
-                            // (which window lands in which slot may differ between tolerances: the counter adds both slots, empty ones count nothing)
-                            if (nested) { nestWin[lane][k][0] = w.lo0; nestWin[lane][k][1] = w.hi0; nestWin[lane][k][2] = w.lo1; nestWin[lane][k][3] = w.hi1; }
-                            else { I.lo[0] = w.lo0; I.hi[0] = w.hi0; I.lo[1] = w.lo1; I.hi[1] = w.hi1; }
-                            nw = max(nw, w.n);
-                        }
-                        I.nWin = nw;
-#else
-                        I.nWin = 1;
-#endif
                     }
                 }
-                if (__ballot(!winOk) && lane == 0) misc->overflow = 1;      // three non-empty windows: excluded by construction (lsd_align_win.h); never count wrong silently
                 const unsigned long long vm = __ballot(valid);
                 if (lane < nIt) {
                     if (nested) { if (!valid) st[c].nc = 0; }
@@ -693,10 +564,7 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
                     int total[MAXC], alg[MAXC], tot2[MAXC];
 #pragma unroll
                     for (int j = 0; j < MAXC; ++j) alg[j] = 0;
-                    count_rect5(it5, nc, it5[0].lg, it5[0].lo[0], it5[0].hi[0], Tb, tW, sw, small, lane, total, alg);
-#ifdef SSLAM_NFA_INT
-                    if (it5[0].nWin > 1) count_rect5(it5, nc, it5[0].lg, it5[0].lo[1], it5[0].hi[1], Tb, tW, sw, small, lane, tot2, alg);      // the 0 / 360 seam: a second, disjoint window
-#endif
+                    count_rect5(it5, nc, it5[0].lg, Tb, tW, sw, small, lane, total, alg);
                     const int c = it5[0].c;
                     if (lane < nc) {
                         const int tj = lane == 0 ? total[0] : lane == 1 ? total[1] : lane == 2 ? total[2] : lane == 3 ? total[3] : total[4];
@@ -711,20 +579,10 @@ __device__ __forceinline__ void nfa_count_range(uint8_t* __restrict__ base, cons
                 const NfaGeom g = its[it].g;
                 const int c = its[it].c;
                 int total, tot2, alg[6] = {0, 0, 0, 0, 0, 0};
-                const int lg = its[it].lg, nWin = its[it].nWin;
-#ifdef SSLAM_NFA_INT
-                const int* win = &nestWin[it][0][0];
-#else
-                const int* win = nullptr;
-#endif
-#ifndef SSLAM_NFA_INT
+                const int lg = its[it].lg;
                 double precs[6];
                 for (int k = 0; k < 6; ++k) precs[k] = stage == 0 ? (k == 0 ? its[it].prec : ldexp(its[it].p, -k) * kPI) : ldexp(its[it].p, -(k + 1)) * kPI;
-                count_item(g, lg, win, Tb, tW, sw, small, lane, total, alg, its[it].theta, precs); (void)nWin; (void)tot2;
-#else
-                count_item(g, lg, win, Tb, tW, sw, small, lane, total, alg);
-                if (nWin > 1) count_item(g, lg, win + 2, Tb, tW, sw, small, lane, tot2, alg);      // the 0 / 360 seam: second windows, disjoint from the first
-#endif
+                count_item(g, lg, Tb, tW, sw, small, lane, total, alg, its[it].theta, precs); (void)tot2;
                 if (lane == 0) {
                     const int K = stage == 0 ? 6 : 5;
 #pragma unroll
@@ -763,14 +621,7 @@ __device__ __forceinline__ int stage_ncand(const NfaState& s, int stage) {
 }
 // log10 behind a call (SSLAM_NFA_LOG10_CALL): inlined into the fused kernel its polynomial constants are hoisted out of the evaluation loop into
 // registers the loop does not have, spilled, and reloaded from scratch one by one with a wait each (six dependent round trips per use)
-#ifndef SSLAM_NFA_LOG10_CALL
-#define SSLAM_NFA_LOG10_CALL 1
-#endif
-#if SSLAM_NFA_LOG10_CALL
 __device__ __noinline__ double nfa_log10(double x) { return log10(x); }
-#else
-__device__ __forceinline__ double nfa_log10(double x) { return log10(x); }
-#endif
 template <int CH>
 __device__ __forceinline__ void nfa_eval_range(uint8_t* __restrict__ base, const LsdPlan& P, int stage, const double* __restrict__ lgam, int c0, int c1, int lane,
                                                 unsigned short* __restrict__ items) {

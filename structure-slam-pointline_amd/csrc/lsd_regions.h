@@ -92,6 +92,7 @@ __device__ __forceinline__ float fast_atan2_deg_unit(float y, float x) {
     return a;
 }
 
+#ifdef SSLAM_TESTING
 // selftest: the trimmed division and the branch-free atan2 against the `/` operator and fast_atan2_deg on direction sums of every magnitude
 // a region can produce (components from 6e-17 -- cos of 90.0 degrees in float -- up to 2^20 pixels, exact zeros, equal components)
 __global__ void k_selftest_region_div(unsigned long long seed, int iters, unsigned long long* __restrict__ out) {
@@ -115,6 +116,7 @@ __global__ void k_selftest_region_div(unsigned long long seed, int iters, unsign
     if (bad) atomicAdd(out, bad);
     if (bad2) atomicAdd(out + 1, bad2);
 }
+#endif
 
 // LineSegmentDetectorImpl::region_grow by one wave.  Eight queue entries are staged at a time (8
 // lanes each: the 3x3 neighbourhood in row-major order without its centre), so one global-load round
@@ -140,9 +142,6 @@ __global__ void k_selftest_region_div(unsigned long long seed, int iters, unsign
 // and counts disagreements in Misc::cyc[6] (cyc[7] = shortcuts << 32 | decisions; tools/lsd_drift_verify.py).
 #ifndef SSLAM_LSD_DRIFT
 #define SSLAM_LSD_DRIFT 1
-#endif
-#ifndef SSLAM_LSD_EARLY_DC
-#define SSLAM_LSD_EARLY_DC 1
 #endif
 // SPEC (helper waves of the cluster form, lsd_cluster.h): a helper wave grows a region AHEAD of the frame's main wave.  It never writes the pixel map: the
 // pixels it takes are marked in its own bitmap `bm` (LDS), and it gives up (returns -n) when the list would outgrow `capN` points.
@@ -287,17 +286,11 @@ __device__ int region_grow_w(int seedX, int seedY, float seedDeg, float seedCos,
                     if (n >= QCAP) rq.glb[n] = v;
                 }
                 ++n;
-#if SSLAM_LSD_EARLY_DC          // round 5: the three broadcasts of the accepted lane issued together -- one LDS round trip per accepted pixel instead of two (78.8 -> 77.8 ms per 12 288 frames)
                 const float dcsEarly = __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(dc), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(dc)));
-#endif
                 sumdx = __fadd_rn(sumdx, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(cs.x), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(cs.x))));
                 sumdy = __fadd_rn(sumdy, __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(cs.y), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(cs.y))));
                 {   // the sums turned by at most K (dc(sel) + eps + E) / max(|S'x|, |S'y|) + ADD degrees (eps + E = band - slack + E)
-#if SSLAM_LSD_EARLY_DC
                     const float dcs = dcsEarly;
-#else
-                    const float dcs = __int_as_float(RL ? __builtin_amdgcn_readlane(__float_as_int(dc), sel) : __builtin_amdgcn_ds_bpermute(sel << 2, __float_as_int(dc)));
-#endif
                     const float M = fmaxf(fabsf(sumdx), fabsf(sumdy));
                     const float aK = __builtin_fmaf(__fadd_rn(dcs, band), DRIFT_K, (DRIFT_E - DRIFT_SLACK) * DRIFT_K);
                     const float r = M < minM ? 1.0e9f : __builtin_amdgcn_rcpf(M);
@@ -621,9 +614,6 @@ __device__ bool rect_refine(const LsdPlan& P, const float4 sd, int& n, double& r
 }
 
 // One persistent single-wave workgroup per frame: the flsd() main loop replayed in order.
-#ifndef SSLAM_LSD_MINWAVES
-#define SSLAM_LSD_MINWAVES 6          // waves/SIMD the register allocator must leave room for (6 x 4 SIMDs = 24 frames per CU, LDS allows 32)
-#endif
 template <bool LAT>
 __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const LsdPlan& P, int b, unsigned* __restrict__ dynLds, double* __restrict__ red, float4* __restrict__ seedStash) {
     const int lane = threadIdx.x & 63;
@@ -707,17 +697,19 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
     }
 }
 
-template <bool LAT>
-#ifdef SSLAM_LSD_NUM_VGPR
-__attribute__((amdgpu_num_vgpr(SSLAM_LSD_NUM_VGPR)))
-#endif
-__global__ __launch_bounds__(64, SSLAM_LSD_MINWAVES) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam, int nframes) {
+// MW = waves per SIMD the register allocator leaves room for:
+//   6  (80 VGPRs, 11 dwords spilled): every wave slot the register file has -- the fastest form when the core has the chip to itself (77.8 ms per 12 288 frames; 5 and 4: 86 / 85)
+//   4  (97 VGPRs, nothing spilled), launched as a PERSISTENT grid of 16 workgroups per compute unit that claim frames dynamically: a third of every SIMD's registers
+//      stays free, so the kernels of another branch (the point branch of the bench step) are co-resident from the first millisecond instead of waiting for core waves to
+//      retire -- lines.hip picks it when the caller announced such a branch (sslam_lines_set_core_event); profiles/r06c_*: 160.5 ms per step against 167.5
+template <bool LAT, int MW>
+__global__ __launch_bounds__(64, MW) void k_lsd_regions(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam, int nframes) {
     extern __shared__ __align__(16) unsigned dynLds[];           // region queue (first QCAP points)
     __shared__ double red[3 * 64];                                 // addends of the ordered fp64 sums
     __shared__ float4 seedStash[64];                               // per seed candidate of the current chunk: angle, cos, sin, x | y << 16
     // gridDim.x == nframes: one frame per workgroup.  A smaller grid makes the workgroups persistent: each takes the next unclaimed frame when it
     // has finished one (Misc::claim of frame 0, zeroed by k_zero_misc), and the wave slots the grid does not fill stay free for the other
-    // branch's kernels for the whole launch (lines.hip: the resident-wave budget of the core)
+    // branch's kernels for the whole launch
     int* claim = &((Misc*)(ws + P.offMisc))->claim;
     for (int i = blockIdx.x; i < nframes;) {
         lsd_regions_body<LAT>(ws, P, xcd_mix_frame(i, nframes), dynLds, red, seedStash);

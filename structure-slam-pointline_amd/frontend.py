@@ -49,6 +49,37 @@ def lib():
     return _lib
 
 
+TESTING_LIB_PATH = os.path.join(HERE, "lib", "libsslam_frontend_testing.so")
+_testing = None
+
+
+def testing_lib():
+    """libsslam_frontend_testing.so: the product's sources compiled with -DSSLAM_TESTING -- every product entry point plus the self-tests, probes and the RCCL stand-in of
+    include/sslam_testing.h.  The self-tests take a context handle; a handle made by the product library is fine (same structs, same HIP runtime)."""
+    global _testing
+    if _testing is None:
+        if not os.path.exists(TESTING_LIB_PATH):
+            raise SslamError("testing library %s not built (run __graft_entry__.build())" % TESTING_LIB_PATH)
+        _testing = C.CDLL(TESTING_LIB_PATH)
+        _testing.sslam_status_str.restype = C.c_char_p
+        _testing.sslam_last_error.restype = C.c_char_p
+        _testing.sslam_ctx_stream.restype = C.c_void_p
+    return _testing
+
+
+class use_testing_library:
+    """with fe.use_testing_library(): every call of this binding goes to the testing library (what the group tests need: the stand-in for RCCL is bound when a group is
+    CREATED, so the groups, contexts and extractors of such a test all live in that library).  Objects made inside must be closed inside."""
+    def __enter__(self):
+        global _lib
+        lib(); self.prev = _lib; _lib = testing_lib()
+        return _lib
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self.prev
+
+
 def _chk(rc):
     if rc != 0:
         L = lib()

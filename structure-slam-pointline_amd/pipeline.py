@@ -116,13 +116,15 @@ class FrontendBatch:
             return
         self._streams()
         if not hasattr(self, "_core_event"):
-            # The kernels in front of the sequential core (blur, gradient, counting sort: ~33 ms of 12 288 frames) are bandwidth-bound; the core
-            # itself is latency-bound and leaves issue slots free.  The library records this event right before the core, and the point branch
-            # waits for it: it then runs under the core instead of competing with the prologue (SSLAM_POINTS_AT_CORE=0: both start together).
+            # The kernels in front of the sequential core (blur, gradient, counting sort: ~22 ms of 12 288 frames) are bandwidth-bound; the core itself is latency-bound
+            # and leaves issue slots free.  The library records this event right before the core.  Default ("pyr", round 6): the pyramid is built at once, beside the
+            # line prologue, and FAST .. matching wait for the event (sslam_orb_set_gate_event) -- announced this way, the library launches the core in its guest form
+            # (a third of the registers free: csrc/lsd_regions.h), so FAST starts with the core instead of behind its first 6 144 waves (profiles/r06a_timeline_*).
+            # SSLAM_POINTS_AT_CORE=1: the whole point branch waits for the event (rounds 3-5); =0: both branches start together.
             import os
             self._core_event = None
-            mode = os.environ.get("SSLAM_POINTS_AT_CORE", "1")
-            self._gate_in_orb = mode == "pyr"      # "pyr": the pyramid is built beside the line prologue, FAST and what follows wait for the core (sslam_orb_set_gate_event)
+            mode = os.environ.get("SSLAM_POINTS_AT_CORE", "pyr")
+            self._gate_in_orb = mode == "pyr"
             if mode != "0":
                 ev = torch.cuda.Event(); ev.record(self._s2)          # (recording creates the hipEvent_t)
                 self._core_event = ev

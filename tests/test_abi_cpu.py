@@ -7,22 +7,27 @@ import pkg
 ROOT = pkg.ROOT
 
 
-def _declared_functions():
-    import glob
-    names = set()
-    for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
-        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
-        names |= set(re.findall(r"\b(sslam_[a-z0-9_]+)\s*\(", txt))
-    return sorted(names)
+def _declared_functions(header):
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", header)).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(sslam_[a-z0-9_]+)\s*\(", txt)))
 
 
-def test_library_exports_every_declared_symbol():
+def _exported(lib_path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib_path], text=True)
+    return sorted(l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("sslam_"))
+
+
+def test_library_exports_exactly_the_declared_symbols():
+    """libsslam_frontend.so exports the entry points of include/sslam_frontend.h and nothing else (no self-tests, probes or stand-ins: those live in
+    libsslam_frontend_testing.so = the same sources with -DSSLAM_TESTING, which exports the boundary plus include/sslam_testing.h)."""
     lib_path = pkg.builder().build(force=False, verbose=False)
+    boundary = _declared_functions("sslam_frontend.h")
+    testing = _declared_functions("sslam_testing.h")
+    assert len(boundary) >= 80 and len(testing) >= 8 and not set(boundary) & set(testing)
+    assert _exported(lib_path) == boundary
+    assert _exported(pkg.builder().TEST_LIB) == sorted(boundary + testing)
     L = ctypes.CDLL(lib_path)
-    names = _declared_functions()
-    assert len(names) >= 25
-    missing = [n for n in names if not hasattr(L, n)]
-    assert not missing, missing
     assert L.sslam_abi_version() == 1
 
 

@@ -112,9 +112,11 @@ def test_group_rank_form_world1(fe, ctx):
 # reassembly by header.frame -- with real device buffers and real copies.  The xGMI run stays the driver's scaling run.
 @pytest.fixture
 def fake_rccl(fe):
-    fe.lib().sslam_testing_use_rccl_standin(1)
-    yield
-    fe.lib().sslam_testing_use_rccl_standin(0)
+    # the stand-in exists in libsslam_frontend_testing.so only (the product's sources + -DSSLAM_TESTING): for the duration of the test the binding calls that library
+    with fe.use_testing_library() as L:
+        L.sslam_testing_use_rccl_standin(1)
+        yield
+        L.sslam_testing_use_rccl_standin(0)
     os.environ.pop("SSLAM_GROUP_SELF_SENDRECV", None)
 
 

@@ -77,7 +77,7 @@ def test_exact_division_selftest(fe, ctx):
     """the NFA tail divides small integers through a reciprocal table + two FMAs; it must equal the IEEE division bit for bit"""
     import ctypes as C
     bad = C.c_longlong(-1)
-    rc = fe.lib().sslam_selftest_exact_div(ctx.h, 1024 * 768 + 4, C.c_longlong(2_000_000_000), C.byref(bad))
+    rc = fe.testing_lib().sslam_selftest_exact_div(ctx.h, 1024 * 768 + 4, C.c_longlong(2_000_000_000), C.byref(bad))
     assert rc == 0 and bad.value == 0, bad.value
 
 
@@ -87,7 +87,7 @@ def test_tail_test_selftest(fe, ctx):
     import ctypes as C
     bad, amb = C.c_longlong(-1), C.c_longlong(-1)
     n = 500_000_000
-    rc = fe.lib().sslam_selftest_tail_test(ctx.h, C.c_longlong(n), C.byref(bad), C.byref(amb))
+    rc = fe.testing_lib().sslam_selftest_tail_test(ctx.h, C.c_longlong(n), C.byref(bad), C.byref(amb))
     assert rc == 0 and bad.value == 0, (bad.value, amb.value)
     assert 0 < amb.value < 0.2 * n, amb.value        # half of the samples sit within 1e-3 of the boundary
 
@@ -96,17 +96,8 @@ def test_region_division_selftest(fe, ctx):
     """the accept chain's division / atan2 shortcuts must equal the plain forms bit for bit over every magnitude a region can produce"""
     import ctypes as C
     bad = (C.c_longlong * 2)(-1, -1)
-    rc = fe.lib().sslam_selftest_region_div(ctx.h, C.c_longlong(2_000_000_000), bad)
+    rc = fe.testing_lib().sslam_selftest_region_div(ctx.h, C.c_longlong(2_000_000_000), bad)
     assert rc == 0 and bad[0] == 0 and bad[1] == 0, (bad[0], bad[1])
-
-
-def test_align_windows_selftest(fe, ctx):
-    """k_nfa_count's integer form of isAligned: the windows of (theta, tolerance) must be exactly the set the reference predicate accepts,
-    on every angle the gradient table can hold (1021^2 gradients per case), end-point neighbours and random patterns"""
-    import ctypes as C
-    out = (C.c_longlong * 3)(-1, -1, -1)
-    rc = fe.lib().sslam_selftest_align_windows(ctx.h, 4096, out)
-    assert rc == 0 and out[0] == 0 and out[2] == 0 and out[1] > 4_000_000_000, (out[0], out[1], out[2])
 
 
 def test_lines_huge_regions(fe, ctx, oracle):

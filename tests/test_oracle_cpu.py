@@ -359,7 +359,8 @@ def test_nfa_tables_are_pinned(oracle):
     import ctypes as C
     import pkg
     g = np.load(os.path.join(GOLD, "nfa_tables.npz"))
-    L = C.CDLL(pkg.builder().build(force=False, verbose=False))
+    pkg.builder().build(force=False, verbose=False)
+    L = C.CDLL(pkg.builder().TEST_LIB)      # (a test entry point: include/sslam_testing.h; the table code itself is the product's)
     n = int(g["j"].max()) + 4
     tab = np.zeros(2 * n + 48)
     assert L.sslam_debug_nfa_tables(n, C.c_void_p(tab.ctypes.data)) == 0

@@ -17,7 +17,7 @@ for i, f in enumerate(cur[:n]):
     out = (C.c_longlong * 8)(); fe.lib().sslam_lines_debug_cycles(lx.h, 0, out); o = [int(x) for x in out]
     cyc += np.array(o[:5], float)
     if "--cycles" in sys.argv:
-        o2 = (C.c_longlong * 8)(); fe.lib().sslam_lines_debug_cluster(lx.h, 0, o2); hst += np.array([int(x) for x in o2], np.int64)
+        o2 = (C.c_longlong * 8)(); fe.testing_lib().sslam_lines_debug_cluster(lx.h, 0, o2); hst += np.array([int(x) for x in o2], np.int64)
     stg += np.array([o[3] & 0xFFFFFFFF, o[3] >> 32, o[4] & 0xFFFFFFFF, o[4] >> 32], float)
     acc += np.array([o[5] & 0xFFFFFFFF, o[5] >> 32, o[6] & 0xFFFFFFFF, o[6] >> 32, o[2], o[1], o[0], o[7]], float)
     if orc is not None:

@@ -6,5 +6,5 @@ import pkg
 fe = pkg.frontend(); ctx = fe.Context(0)
 for mode in (0, 1):
     req = C.c_longlong(0)
-    rc = fe.lib().sslam_selftest_fetch_probe(ctx.h, C.c_size_t(4 << 30), mode, C.byref(req))
+    rc = fe.testing_lib().sslam_selftest_fetch_probe(ctx.h, C.c_size_t(4 << 30), mode, C.byref(req))
     print("mode", mode, "rc", rc, "bytes requested", req.value)

@@ -4,6 +4,7 @@
 //                planes of the 6 144 resident frames of the bench step), 8 waves per SIMD: the fabric's request rate
 //   dependent    one load per lane and round whose address depends on the value loaded before (the buffer holds a random permutation step), W waves
 //                per SIMD (default 6 = the core's residency): what a chain of dependent stagings can reach, and the round-trip time behind it
+//   unloaded     the same chain with one wave per compute unit: the round trip of a dependent gather when nothing queues
 // Prints one JSON object.  Built by tools/build_c_harnesses.sh (hipcc --offload-arch=gfx950); bench.py runs it for roofline.random_sector.
 //     tools/gather_probe [GiB=16] [waves_dependent=6]
 #include <hip/hip_runtime.h>
@@ -76,8 +77,17 @@ int main(int argc, char** argv) {
     }
     float msD = 0; CHK(hipEventElapsedTime(&msD, e0, e1));
     const double sectD = (double)blocksD * 64 * itersD / (msD * 1e-3);
+    // unloaded round trip: one wave per compute unit (16 K requests in flight on the whole chip: far below the fabric's rate), the same dependent chain
+    for (int rep = 0; rep < 2; ++rep) {
+        CHK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_gather_dep, dim3(cus), dim3(64), 0, 0, buf, nSect, itersD, sink);
+        CHK(hipEventRecord(e1, 0)); CHK(hipDeviceSynchronize());
+    }
+    float msU = 0; CHK(hipEventElapsedTime(&msU, e0, e1));
     printf("{\"buffer_gib\": %.2f, \"compute_units\": %d, \"independent\": {\"loads_in_flight_per_lane\": 8, \"waves_per_simd\": 8, \"gsectors_per_s\": %.2f, \"gb_per_s_at_64B\": %.1f, \"ms\": %.3f}, "
-           "\"dependent\": {\"waves_per_simd\": %d, \"gsectors_per_s\": %.2f, \"gb_per_s_at_64B\": %.1f, \"round_trip_us\": %.3f, \"ms\": %.3f}}\n",
-           nSect * 64.0 / (1ull << 30), cus, sectI / 1e9, sectI * 64 / 1e9, ms, wavesDep, sectD / 1e9, sectD * 64 / 1e9, msD * 1e3 / itersD, msD);
+           "\"dependent\": {\"waves_per_simd\": %d, \"gsectors_per_s\": %.2f, \"gb_per_s_at_64B\": %.1f, \"round_trip_us\": %.3f, \"ms\": %.3f}, "
+           "\"unloaded\": {\"waves\": %d, \"round_trip_us\": %.3f, \"gsectors_per_s\": %.2f}}\n",
+           nSect * 64.0 / (1ull << 30), cus, sectI / 1e9, sectI * 64 / 1e9, ms, wavesDep, sectD / 1e9, sectD * 64 / 1e9, msD * 1e3 / itersD, msD,
+           cus, msU * 1e3 / itersD, (double)cus * 64 * itersD / (msU * 1e-3) / 1e9);
     return 0;
 }
