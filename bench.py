@@ -136,7 +136,8 @@ def other_walls(kernel, avg_launch_ms, B, ms_per_step, workload, hbm_frac):
             rs["frac_of_request_rate"] = rate / probe["independent"]["gsectors_per_s"]
             fr["random_sector_rate"] = rs["frac_of_request_rate"]
         if kernel.startswith("k_lsd_regions") and avg_launch_ms > 0:
-            rounds = max(1.0, B / CORE_RESIDENT_WAVES)
+            resident = 4096 if B > 4096 else CORE_RESIDENT_WAVES      # the guest form of the two-stream step: 16 persistent workgroups per compute unit
+            rounds = max(1.0, B / resident)
             rt = probe.get("unloaded", probe["dependent"])["round_trip_us"]      # the round trip when nothing queues: a lower bound on what a staging waits
             floor = rounds * CORE_STAGINGS_PER_FRAME * rt * 1e-3
             rs["dependent_chain"] = {"stagings_per_frame": CORE_STAGINGS_PER_FRAME, "round_trip_us": rt, "frames_per_wave_slot": rounds,

@@ -8,8 +8,10 @@
 //   * the point branch and the line branch of a chunk run on two HIP streams, the point branch released by the event the library records
 //     right before the sequential core (sslam_lines_set_core_event) -- the alignment pipeline.py uses for resident batches, now inside the
 //     library;
-//   * pageable caller memory is staged through pinned buffers by a few host threads (one memcpy thread moves ~10 GB/s: 32 k frames/s of
-//     307 KB frames at best); the buffers, streams and events live in a per-context cache instead of being allocated per call;
+//   * pageable caller memory goes through a pinned bounce ring (two chunk-sized buffers each way) fed by a pool of host copy threads that lives in the per-context
+//     cache: chunk k is staged WHILE chunk k-2's results are copied out (two task groups on the same pool), both while the GPU works on chunk k-1.  Rounds 3-5 ran the two
+//     copies one after the other on the calling thread with at most 8 helpers (2.6 GB of memcpy per 6 144-frame chunk against 85-95 ms of GPU time per chunk: the
+//     host was the bottleneck, 43.8 k frames/s against 63.4 k from pinned memory);
 //   * uploads, kernels and downloads of neighbouring chunks overlap as before (two slots);
 //   * sslam_frontend_batch_match adds the match stage of BASELINE configs[2] ("extract + Hamming match vs previous frame"): frame i is
 //     matched against frame i-1 of the call -- ORBmatcher::SearchForInitialization, the dense Hamming 2-NN and the LSD line matcher, the
@@ -17,7 +19,11 @@
 //     of the chunk before it), so "previous" and "current" are the same arrays one frame apart and the *_batch_dev matchers run unchanged.
 #include "common.h"
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 using namespace sslam;
@@ -25,6 +31,8 @@ using namespace sslam;
 extern "C" int sslam_orb_batch_status_dev(sslam_orb* orb, int cap, int32_t* d_status4, void* stream);
 extern "C" int sslam_lines_batch_status_dev(sslam_lines* lines, int cap, int32_t* d_status4, void* stream);
 extern "C" int sslam_lines_set_core_event(sslam_lines* lines, void* hip_event);
+extern "C" int sslam_lines_core_guest_form(sslam_lines* lines, int nframes);
+extern "C" int sslam_orb_set_gate_event(sslam_orb* orb, void* hip_event);
 
 // vbPrevMatched of SearchForInitialization starts at F1's keypoint positions (src/Tracking.cc:340-342): the first two floats of each record
 __global__ __launch_bounds__(256) void k_prev_matched_init(const sslam_keypoint* __restrict__ kp, size_t rows, float2* __restrict__ pm) {
@@ -33,6 +41,48 @@ __global__ __launch_bounds__(256) void k_prev_matched_init(const sslam_keypoint*
 }
 
 namespace {
+int copy_threads() {
+    static const int n = [] {
+        if (const char* e = getenv("SSLAM_BATCH_THREADS")) return std::max(1, atoi(e));
+        const unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(24u, hc ? hc / 2 : 4u));      // one memcpy thread moves ~10 GB/s; a chunk wants ~25 GB/s each way to stay ahead of the GPU
+    }();
+    return n;
+}
+// The host copy threads of the pageable path.  A TaskGroup is one parallel copy (the staging of a chunk, or the copy-out of a chunk's results); several groups may be in
+// flight on the pool at once, and the caller waits for the group it needs.
+struct TaskGroup {
+    std::mutex m; std::condition_variable cv; int left = 0;
+    void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return left == 0; }); }
+};
+struct CopyPool {
+    std::vector<std::thread> th;
+    std::mutex m; std::condition_variable cv;
+    std::deque<std::pair<TaskGroup*, std::function<void()>>> q;
+    bool stop = false;
+    explicit CopyPool(int n) {
+        for (int i = 0; i < n; ++i) th.emplace_back([this] {
+            for (;;) {
+                std::pair<TaskGroup*, std::function<void()>> job;
+                { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return stop || !q.empty(); }); if (q.empty()) return; job = std::move(q.front()); q.pop_front(); }
+                job.second();
+                { std::lock_guard<std::mutex> lk(job.first->m); if (--job.first->left == 0) job.first->cv.notify_all(); }
+            }
+        });
+    }
+    ~CopyPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+    // f(a, b) over [0, items) in pieces, asynchronously: g.wait() returns when all of them ran
+    template <class F>
+    void parallel_for(TaskGroup& g, int items, F f) {
+        if (items <= 0) return;
+        const int pieces = std::max(1, std::min(items, (int)th.size() * 2)), per = (items + pieces - 1) / pieces;
+        int npieces = 0;
+        for (int a = 0; a < items; a += per) ++npieces;
+        { std::lock_guard<std::mutex> lk(g.m); g.left += npieces; }
+        { std::lock_guard<std::mutex> lk(m); for (int a = 0; a < items; a += per) { const int b = std::min(items, a + per); q.emplace_back(&g, [=] { f(a, b); }); } }
+        cv.notify_all();
+    }
+};
 struct Slot {
     DevBuf dIn, dKp, dDesc, dN, dKl, dLd, dFn, dNl, dStatus;
     DevBuf dPm, dM12, dNm, dKnnI, dKnnD, dLp, dNlp;      // match stage: vbPrevMatched, vnMatches12, counts, 2-NN, line pairs
@@ -49,7 +99,9 @@ struct BatchCache {
     Slot slot[2];
     hipStream_t cp = nullptr, cpOut = nullptr, stLines = nullptr;
     hipEvent_t evCore = nullptr;
+    CopyPool* pool = nullptr;
     ~BatchCache() {
+        delete pool;
         for (auto& s : slot) s.release();
         for (hipStream_t* st : {&cp, &cpOut, &stLines}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
         if (evCore) (void)hipEventDestroy(evCore);
@@ -57,25 +109,6 @@ struct BatchCache {
 };
 void free_batch_cache(void* p) { delete (BatchCache*)p; }
 
-// n bytes (or `rows` strided rows) copied by up to `threads` host threads: a single memcpy stream is the bottleneck of the pageable path
-template <class F>
-void parallel_for(int items, int threads, F f) {
-    threads = std::max(1, std::min(threads, items));
-    if (threads == 1) { f(0, items); return; }
-    std::vector<std::thread> th;
-    const int per = (items + threads - 1) / threads;
-    for (int t = 1; t < threads; ++t) { const int a = t * per, b = std::min(items, a + per); if (a < b) th.emplace_back([=] { f(a, b); }); }
-    f(0, std::min(items, per));
-    for (auto& t : th) t.join();
-}
-int copy_threads() {
-    static const int n = [] {
-        if (const char* e = getenv("SSLAM_BATCH_THREADS")) return std::max(1, atoi(e));
-        const unsigned hc = std::thread::hardware_concurrency();
-        return (int)std::max(1u, std::min(8u, hc ? hc / 2 : 4u));
-    }();
-    return n;
-}
 }  // namespace
 
 namespace {
@@ -149,10 +182,15 @@ int batch_impl(const char* fn, sslam_orb* orb, sslam_lines* lines, const uint8_t
             if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { set_error("%s: hipEventCreate failed", fn); return SSLAM_ERR_HIP; }
         if (n <= C) break;                 // one chunk: the second slot is never used
     }
-    const int T = copy_threads();
+    if (!B.pool && !(inDirect && outDirect)) B.pool = new CopyPool(copy_threads());
+    CopyPool* pool = B.pool;
+    TaskGroup gStage, gDrain[2];                       // the staging of the chunk being submitted; the copy-out of each slot's finished chunk
     int firstStatus = SSLAM_OK;                        // a truncated / unsupported frame does not stop the batch; it is reported at the end
-    // results of a finished chunk: pinned staging -> the caller's arrays
-    auto drain = [&](Slot& s) -> int {
+    // results of a finished chunk: pinned staging -> the caller's arrays.  drain() waits for the chunk's D2H, reads its status words and hands the copy to the pool
+    // (task group gDrain[slot]); drained() waits for that copy -- it must have finished before the slot's staging buffer receives another chunk's results.
+    auto drained = [&](int si) { gDrain[si].wait(); };
+    auto drain = [&](int si) -> int {
+        Slot& s = slot[si];
         if (s.count == 0) return SSLAM_OK;
         if (hipEventSynchronize(s.evOut) != hipSuccess) { set_error("%s: D2H failed", fn); return SSLAM_ERR_HIP; }
         // per-chunk status words (sslam_orb_batch_status_dev / sslam_lines_batch_status_dev): the conditions the single-frame calls report
@@ -165,7 +203,7 @@ int batch_impl(const char* fn, sslam_orb* orb, sslam_lines* lines, const uint8_t
         if (outDirect) { s.count = 0; return SSLAM_OK; }
         const uint8_t* H = s.hOut.as<uint8_t>();
         const size_t f0 = (size_t)s.first;
-        parallel_for(s.count, T, [&](int a, int b) {      // frames [a, b) of the chunk
+        pool->parallel_for(gDrain[si], s.count, [=](int a, int b) {      // frames [a, b) of the chunk
             const size_t c = (size_t)(b - a), g = f0 + a;
             std::memcpy(kp_out + g * cap, H + oKp + sizeof(sslam_keypoint) * (size_t)a * cap, sizeof(sslam_keypoint) * c * cap);
             std::memcpy(desc_out + 32 * g * cap, H + oDesc + 32 * (size_t)a * cap, 32 * c * cap);
@@ -191,12 +229,12 @@ int batch_impl(const char* fn, sslam_orb* orb, sslam_lines* lines, const uint8_t
     int k = 0;
     for (int f0 = 0; f0 < n && rc == SSLAM_OK; f0 += C, ++k) {
         Slot& s = slot[k & 1];
-        if ((rc = drain(s))) break;                                         // the slot's previous chunk (k-2) has to be out before it is reused
         const int c = std::min(C, n - f0);
         const uint8_t* hin = images + (size_t)f0 * fpx;
-        if (!inDirect) {
+        if (!inDirect) {      // this chunk's frames -> the slot's pinned input buffer (its previous upload, chunk k-2, finished long ago: the kernels of k-2 ran behind it and its results are in)
             uint8_t* stage = s.hIn.as<uint8_t>();
-            parallel_for(c, T, [&](int a, int b) {                          // tight rows in the staging buffer
+            if (s.count && hipEventSynchronize(s.evIn) != hipSuccess) { set_error("%s: H2D failed", fn); rc = SSLAM_ERR_HIP; break; }
+            pool->parallel_for(gStage, c, [=](int a, int b) {               // tight rows in the staging buffer
                 for (int i = a; i < b; ++i) {
                     const uint8_t* src = images + (size_t)(f0 + i) * image_stride;
                     if (stride == (size_t)w) std::memcpy(stage + i * fpx, src, fpx);
@@ -205,6 +243,8 @@ int batch_impl(const char* fn, sslam_orb* orb, sslam_lines* lines, const uint8_t
             });
             hin = stage;
         }
+        if ((rc = drain(k & 1))) { gStage.wait(); break; }                 // the slot's previous chunk (k-2): its copy-out runs on the pool beside the staging above
+        gStage.wait();
         hipStream_t stLn = twoStreams ? stL : stP;
         if (hipMemcpyAsync(s.dIn.p, hin, fpx * c, hipMemcpyHostToDevice, cp) != hipSuccess || hipEventRecord(s.evIn, cp) != hipSuccess ||
             hipStreamWaitEvent(stP, s.evIn, 0) != hipSuccess || (twoStreams && hipStreamWaitEvent(stL, s.evIn, 0) != hipSuccess)) { set_error("%s: H2D failed", fn); rc = SSLAM_ERR_HIP; break; }
@@ -232,7 +272,10 @@ int batch_impl(const char* fn, sslam_orb* orb, sslam_lines* lines, const uint8_t
         if (lines && (rc = sslam_lines_batch_status_dev(lines, lcap, s.dStatus.as<int32_t>() + 4, stLn))) break;
         if (lmatch && (rc = sslam_line_match_batch_dev(ctx, s.dLd.as<uint8_t>(), s.dNl.as<int32_t>(), dLd, dNl, lcap, c, M->line_gate_scale, M->line_ratio_mode,
                                                        s.dLp.as<int32_t>(), s.dNlp.as<int32_t>(), stLn))) break;
-        if (twoStreams && (hipEventRecord(s.evLines, stL) != hipSuccess || hipStreamWaitEvent(stP, B.evCore, 0) != hipSuccess)) { set_error("%s: event failed", fn); rc = SSLAM_ERR_HIP; break; }
+        // guest form of the core (chunks above 16 workgroups per CU): the pyramid goes ahead, FAST .. matching wait for the core event inside the ORB call; otherwise the whole point branch waits
+        const bool guestForm = twoStreams && sslam_lines_core_guest_form(lines, c) != 0;
+        (void)sslam_orb_set_gate_event(orb, guestForm ? (void*)B.evCore : nullptr);
+        if (twoStreams && (hipEventRecord(s.evLines, stL) != hipSuccess || (!guestForm && hipStreamWaitEvent(stP, B.evCore, 0) != hipSuccess))) { set_error("%s: event failed", fn); rc = SSLAM_ERR_HIP; break; }
         if ((rc = sslam_orb_extract_batch_dev(orb, s.dIn.as<uint8_t>(), w, h, (size_t)w, fpx, c, dKp, dDesc, dN, cap, stP))) break;
         if ((rc = sslam_orb_batch_status_dev(orb, cap, s.dStatus.as<int32_t>(), stP))) break;
         if (M) {      // previous frame = F1 (query), current frame = F2 (train), as Tracking::MonocularInitialization calls it (src/Tracking.cc:330-345)
@@ -245,7 +288,8 @@ int batch_impl(const char* fn, sslam_orb* orb, sslam_lines* lines, const uint8_t
         }
         if (hipEventRecord(s.evPoint, stP) != hipSuccess || hipStreamWaitEvent(cpOut, s.evPoint, 0) != hipSuccess ||
             (twoStreams && hipStreamWaitEvent(cpOut, s.evLines, 0) != hipSuccess)) { set_error("%s: event failed", fn); rc = SSLAM_ERR_HIP; break; }
-        // the next chunk's upload into the OTHER slot may start at once; this slot's input is overwritten only two chunks later, after drain()
+        // the next chunk's upload into the OTHER slot may start at once; this slot's input is overwritten only two chunks later
+        drained(k & 1);                                                     // (the slot's result staging is about to be named as a D2H target again)
         uint8_t* H = outDirect ? nullptr : s.hOut.as<uint8_t>();
         const size_t g = (size_t)f0;
         bool ok = true;
@@ -271,10 +315,12 @@ int batch_impl(const char* fn, sslam_orb* orb, sslam_lines* lines, const uint8_t
         if (!ok || hipEventRecord(s.evOut, cpOut) != hipSuccess) { set_error("%s: D2H failed", fn); rc = SSLAM_ERR_HIP; break; }
         s.first = f0; s.count = c;
     }
-    if (rc == SSLAM_OK) rc = drain(slot[k & 1]);          // older chunk first
-    if (rc == SSLAM_OK) rc = drain(slot[(k + 1) & 1]);
+    if (rc == SSLAM_OK) rc = drain(k & 1);          // older chunk first
+    if (rc == SSLAM_OK) rc = drain((k + 1) & 1);
+    gStage.wait(); drained(0); drained(1);           // (also on the error paths: no task may outlive the caller's buffers)
     (void)hipStreamSynchronize(cp); (void)hipStreamSynchronize(cpOut); (void)hipStreamSynchronize(stL); (void)hipStreamSynchronize(stP);
     if (lines) (void)sslam_lines_set_core_event(lines, nullptr);
+    (void)sslam_orb_set_gate_event(orb, nullptr);
     for (int i = 0; i < 2; ++i) slot[i].count = 0;
     return rc != SSLAM_OK ? rc : firstStatus;
 }

@@ -280,6 +280,21 @@ static int lines_host_seed_order(sslam_lines* L, uint8_t* ws, int nframes, hipSt
     return SSLAM_OK;
 }
 
+// Whether a batch of `nframes` runs the sequential core in its guest form (lsd_regions.h): a co-running branch was announced (sslam_lines_set_core_event) and the batch is
+// larger than the persistent grid of 16 workgroups per compute unit -- a smaller batch leaves wave slots free anyway.
+static bool lines_guest_form(const sslam_lines* L, int nframes, int* grid_out) {
+    int grid = 16 * L->ctx->num_cus;
+    bool guest = L->coreEvent != nullptr;
+    if (const char* e = getenv("SSLAM_LSD_GUEST")) guest = atoi(e) != 0;
+    if (const char* e = getenv("SSLAM_LSD_PERSIST")) { const int g = atoi(e) & ~7; if (g >= 8) grid = g; }
+    if (grid_out) *grid_out = grid;
+    return guest && nframes >= 1024 && grid < nframes;
+}
+extern "C" int sslam_lines_core_guest_form(sslam_lines* L, int nframes) {
+    if (!L || nframes <= 0) return 0;
+    return lines_guest_form(L, nframes, nullptr) ? 1 : 0;
+}
+
 extern "C" int sslam_lines_destroy(sslam_lines* L) {
     if (!L) return SSLAM_OK;
     (void)hipSetDevice(L->ctx->device);
@@ -452,27 +467,24 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         } else if (lone) hipLaunchKernelGGL((k_lsd_regions<true, 6>), dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);      // lone waves: shortest chain
         else {
             // A caller that announced a branch running beside the core (sslam_lines_set_core_event: the bench step's point branch waits for that event) gets the GUEST form
-            // (lsd_regions.h): 16 persistent workgroups per compute unit of the four-wave instantiation, a third of the registers free for the other branch's waves -- and
-            // LBD's gradient image, which needs the source alone, as one more guest under the core on the side stream instead of 6 ms of the tail.
-            // SSLAM_LSD_GUEST=0 / 1 overrides (A/B), SSLAM_LSD_PERSIST=g sets the grid.
-            int grid = 16 * L->ctx->num_cus;
-            bool guest = L->coreEvent != nullptr;
-            if (const char* e = getenv("SSLAM_LSD_GUEST")) guest = atoi(e) != 0;
-            if (const char* e = getenv("SSLAM_LSD_PERSIST")) { const int g = atoi(e) & ~7; if (g >= 8) grid = g; }
-            guest = guest && grid < nframes;
-            if (guest) {
-                if (!sobelDone && !getenv("SSLAM_LBD_SOBEL_MAIN")) {
-                    if ((rc = side_stream_ready())) return rc;
-                    SSLAM_HIP(hipEventRecord(L->nfaFork, st));
-                    SSLAM_HIP(hipStreamWaitEvent(L->nfaStream, L->nfaFork, 0));
-                    side.forked = true;
-                }
-                hipLaunchKernelGGL((k_lsd_regions<false, 4>), dim3(grid), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
-                if (side.forked) launch_blur_sobel(L->nfaStream);
-            } else hipLaunchKernelGGL((k_lsd_regions<false, 6>), dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
+            // (lsd_regions.h): 16 persistent workgroups per compute unit of the four-wave instantiation, a third of the registers free for the other branch's waves.
+            // SSLAM_LSD_GUEST=0 / 1 overrides (A/B), SSLAM_LSD_PERSIST=g sets the grid.  (LBD's blur + Sobel as one more guest under the core, on the side stream, was
+            // measured too: its 126-VGPR waves take the slots FAST needs -- 167.7 ms per step against 160.8 with the kernel in the tail; profiles/r06d_*.)
+            int grid = 0;
+            if (lines_guest_form(L, nframes, &grid)) hipLaunchKernelGGL((k_lsd_regions<false, 4>), dim3(grid), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
+            else hipLaunchKernelGGL((k_lsd_regions<false, 6>), dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
         }
     }
     if (L->coreDone) SSLAM_HIP(hipEventRecord(L->coreDone, st));
+    // LBD's gradient image needs the source alone and is bandwidth-bound; the NFA stage behind the core is latency-bound (a third of the vector pipes busy): on the side
+    // stream the one runs beside the other instead of behind it (SSLAM_LBD_SOBEL_MAIN=1: behind, A/B)
+    if (!sobelDone && !side.forked && nframes >= 1024 && !getenv("SSLAM_LBD_SOBEL_MAIN")) {
+        if ((rc = side_stream_ready())) return rc;
+        SSLAM_HIP(hipEventRecord(L->nfaFork, st));
+        SSLAM_HIP(hipStreamWaitEvent(L->nfaStream, L->nfaFork, 0));
+        side.forked = true;
+        launch_blur_sobel(L->nfaStream);
+    }
     // the NFA stage: its kernels and launch forms live in lines_nfa.hip, a translation unit of its own (compiled with -mllvm -disable-machine-licm)
     if (nfaStreamed) {      // what the concurrent consumers left (nothing, unless they gave up waiting): the same kernel behind both, everything published, no waiting
         side.join();

@@ -25,7 +25,10 @@ constexpr float NOTDEF_F = -1024.0f;
 constexpr int CS_SHIFT = 3, S_SHIFT = 2;      // log2 of the byte stride of the Cs / S entries
 constexpr unsigned USED_BIT = 0x80000000u;
 constexpr int N_BINS = 1024;
-constexpr int TILE_PX = 8192;           // raster tile of the counting sort (rounded down to whole rows: LsdPlan::tileRows)
+#ifndef SSLAM_TILE_PX
+#define SSLAM_TILE_PX 8192
+#endif
+constexpr int TILE_PX = SSLAM_TILE_PX;          // raster tile of the counting sort (rounded down to whole rows: LsdPlan::tileRows)
 constexpr int MAX_SEG = 8192;           // segments per frame (LSD output capacity)
 constexpr int NUM_BANDS = 9, BAND_W = 7, LSP_H = 63;
 

@@ -117,20 +117,24 @@ class FrontendBatch:
         self._streams()
         if not hasattr(self, "_core_event"):
             # The kernels in front of the sequential core (blur, gradient, counting sort: ~22 ms of 12 288 frames) are bandwidth-bound; the core itself is latency-bound
-            # and leaves issue slots free.  The library records this event right before the core.  Default ("pyr", round 6): the pyramid is built at once, beside the
+            # and leaves issue slots free.  The library records this event right before the core.  Default (round 6, where the library takes the guest form): the pyramid is built at once, beside the
             # line prologue, and FAST .. matching wait for the event (sslam_orb_set_gate_event) -- announced this way, the library launches the core in its guest form
             # (a third of the registers free: csrc/lsd_regions.h), so FAST starts with the core instead of behind its first 6 144 waves (profiles/r06a_timeline_*).
             # SSLAM_POINTS_AT_CORE=1: the whole point branch waits for the event (rounds 3-5); =0: both branches start together.
             import os
             self._core_event = None
-            mode = os.environ.get("SSLAM_POINTS_AT_CORE", "pyr")
-            self._gate_in_orb = mode == "pyr"
+            mode = os.environ.get("SSLAM_POINTS_AT_CORE", "auto")
             if mode != "0":
                 ev = torch.cuda.Event(); ev.record(self._s2)          # (recording creates the hipEvent_t)
                 self._core_event = ev
                 self.lines.set_core_event(ev.cuda_event)
+                if mode == "auto":      # the pyramid goes ahead of the event where the core runs in its guest form (batches above 16 workgroups per CU); smaller batches: measured better with the whole branch behind it
+                    mode = "pyr" if self.fe.lib().sslam_lines_core_guest_form(self.lines.h, self.B) else "1"
+                self._gate_in_orb = mode == "pyr"
                 if self._gate_in_orb:
                     self.orb.set_gate_event(ev.cuda_event)
+            else:
+                self._gate_in_orb = False
         cur = torch.cuda.current_stream(self.dev)
         self._s1.wait_stream(cur); self._s2.wait_stream(cur)
         f = self.feat["cur"]

@@ -64,8 +64,12 @@ int main(int argc, char** argv) {
     HIPCHK(hipMemcpy2D(pm0, 8, P->kp, sizeof(sslam_keypoint), 8, (size_t)B * cap, hipMemcpyDeviceToDevice));      /* vbPrevMatched starts at F1's keypoint positions (Tracking.cc:340-342); a pristine copy, restored every step */
     /* STEP_GATE: when the point branch starts -- "pyr" (default, as pipeline.py): the pyramid at once (beside the line prologue), FAST and what follows with the sequential LSD
      * core (sslam_orb_set_gate_event); "core": all of it with the core (rounds 3-5); "none": everything at once */
-    const char* gate = getenv("STEP_GATE") ? getenv("STEP_GATE") : "pyr";
-    if (!one && strcmp(gate, "none")) { HIPCHK(hipEventRecord(core, s2)); SCHK(sslam_lines_set_core_event(ln, core)); if (!strcmp(gate, "pyr")) SCHK(sslam_orb_set_gate_event(orb, core)); }
+    const char* gate = getenv("STEP_GATE") ? getenv("STEP_GATE") : "auto";
+    if (!one && strcmp(gate, "none")) {
+        HIPCHK(hipEventRecord(core, s2)); SCHK(sslam_lines_set_core_event(ln, core));
+        if (!strcmp(gate, "auto")) gate = sslam_lines_core_guest_form(ln, B) ? "pyr" : "core";      /* as pipeline.py */
+        if (!strcmp(gate, "pyr")) SCHK(sslam_orb_set_gate_event(orb, core));
+    }
     double t0 = 0;
     for (int it = 0; it < warm + steps; ++it) {
         if (it == warm) { HIPCHK(hipDeviceSynchronize()); if (getenv("STEP_PROFILE")) sslam_profile_enable(ctx, 1); t0 = now_ms(); }
