@@ -45,7 +45,7 @@ int copy_threads() {
     static const int n = [] {
         if (const char* e = getenv("SSLAM_BATCH_THREADS")) return std::max(1, atoi(e));
         const unsigned hc = std::thread::hardware_concurrency();
-        return (int)std::max(1u, std::min(24u, hc ? hc / 2 : 4u));      // one memcpy thread moves ~10 GB/s; a chunk wants ~25 GB/s each way to stay ahead of the GPU
+        return (int)std::max(1u, std::min(12u, hc ? hc / 2 : 4u));      // measured with 8, 16, 24 and 48 threads on a 256-thread host: 61.1 / 59.7 / 57.2 / 60.8 k frames per second (profiles/r06e_*) -- what counts is that staging and copy-out run side by side, not the thread count
     }();
     return n;
 }
