@@ -477,8 +477,10 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     }
     if (L->coreDone) SSLAM_HIP(hipEventRecord(L->coreDone, st));
     // LBD's gradient image needs the source alone and is bandwidth-bound; the NFA stage behind the core is latency-bound (a third of the vector pipes busy): on the side
-    // stream the one runs beside the other instead of behind it (SSLAM_LBD_SOBEL_MAIN=1: behind, A/B)
-    if (!sobelDone && !side.forked && nframes >= 1024 && !getenv("SSLAM_LBD_SOBEL_MAIN")) {
+    // stream the one runs beside the other instead of behind it -- for a caller WITHOUT a branch of its own beside this one (no core event): 187.5 against 190.1 ms per
+    // one-stream step.  With the point branch still running there (two-stream step) the pair costs 3.5 ms instead (164.1 against 160.2: k_blur_sobel and k_nfa_all are 56 KB
+    // and 54 KB of code, together more than the 64 KB instruction cache two compute units share, beside a third kernel); profiles/r06f_*.  SSLAM_LBD_SOBEL_MAIN=1: always behind.
+    if (!sobelDone && !side.forked && nframes >= 1024 && !L->coreEvent && !getenv("SSLAM_LBD_SOBEL_MAIN")) {
         if ((rc = side_stream_ready())) return rc;
         SSLAM_HIP(hipEventRecord(L->nfaFork, st));
         SSLAM_HIP(hipStreamWaitEvent(L->nfaStream, L->nfaFork, 0));

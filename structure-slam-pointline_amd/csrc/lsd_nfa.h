@@ -454,21 +454,23 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
         const int yb = tix(0, max(y, 0), tW);
         for (int c0 = 0; vote(c0 < mine) != 0; c0 += 12) {
             unsigned a[12];
+            // three 16-byte loads per run, as in count_item (round 6: this counter still issued twelve dword loads per run -- it is where the time of the refinement stages
+            // goes, i.e. most of the stage under decision D11 = 0); slots past the lane's run hold a neighbour's pixel and are masked at the vote (`valid`)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
-            if (vote(c0 + 4 < mine)) {
+            for (int gq = 0; gq < 3; ++gq) {
+                if (gq == 0 || vote(c0 + 4 * gq < mine)) {
+                    T4 t = {{PIX_NONE, PIX_NONE, PIX_NONE, PIX_NONE}};
+                    if (c0 + 4 * gq < mine) t = *(const T4*)(Tb + yb + xs + c0 + 4 * gq);
 #pragma unroll
-                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
-            }
-            if (vote(c0 + 8 < mine)) {
-#pragma unroll
-                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
+                    for (int q = 0; q < 4; ++q) a[4 * gq + q] = t.v[q];
+                }
             }
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
-                if (!vote(c0 + q < mine)) break;
+                const unsigned long long valid = vote(c0 + q < mine);
+                if (!valid) break;
                 const float af = __uint_as_float(t_abs_u(a[q]));
-                const unsigned long long al = vote(align_dist_min(af, theta) <= prec) & vote(af < 1000.f);
+                const unsigned long long al = vote(align_dist_min(af, theta) <= prec) & vote(af < 1000.f) & valid;
                 const int x = xs + c0 + q;
 #pragma unroll
                 for (int j = 0; j < MAXC; ++j) {

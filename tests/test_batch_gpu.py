@@ -119,18 +119,26 @@ def test_batch_of_19_distinct_frames(fe, ctx, oracle):
     pipe.close()
 
 
-def test_batch_of_2176_frames_throughput_kernels(fe, ctx, oracle):
-    """from 1024 frames on the LSD core runs its six-waves-per-SIMD flavour (k_lsd_regions<false>) and the NFA stages one wave per frame
+@pytest.mark.parametrize("form", ["one_stream", "guest"])
+def test_batch_of_2176_frames_throughput_kernels(fe, ctx, oracle, form, monkeypatch):
+    """from 1024 frames on the LSD core runs its six-waves-per-SIMD flavour (k_lsd_regions<false, 6>) and the NFA stages one wave per frame
     (from 2048 on also the rectangle counter): the kernels the benchmark times.  2176 = 17 * 128 small frames, 17 distinct ones tiled, so
     every distinct frame lands on many different workgroups / XCDs; a sample of slots is compared with the oracle and all copies of a
-    frame must agree with each other byte for byte."""
+    frame must agree with each other byte for byte.
+    form "guest" (round 6): the two-stream step with a core event announced and a persistent grid of 136 workgroups (SSLAM_LSD_PERSIST; the library's own grid, 16 per
+    compute unit, would be larger than this batch) -- k_lsd_regions<false, 4> claiming its 2 176 frames dynamically, the pyramid built ahead of the event, FAST .. gated on it."""
     pipeline = pkg._load("sslam_pipeline", os.path.join(pkg.PKG_DIR, "pipeline.py"))
     w, h, U, REP = 192, 144, 17, 128
     B = U * REP
     frames = [synth_frame(5000 + i, w, h, nshapes=8 + 3 * i, nstrokes=2 * i, noise=float(i % 3)) for i in range(U)]
+    if form == "guest": monkeypatch.setenv("SSLAM_LSD_PERSIST", "136")
     pipe = pipeline.FrontendBatch(fe, ctx, w, h, B, 300, 60, "cuda:0", with_match=False)
     imgs = torch.from_numpy(np.stack(frames)).cuda().repeat(REP, 1, 1).contiguous()          # slot s holds frame s % 17
-    pipe.step(imgs)
+    if form == "guest":
+        for _ in range(2): pipe.step(imgs, overlap=True)      # twice: the frame counter of the persistent grid is reset per launch
+        assert fe.lib().sslam_lines_core_guest_form(pipe.lines.h, B) == 1 and pipe._gate_in_orb
+    else:
+        pipe.step(imgs)
     torch.cuda.synchronize()
     c = pipe.feat["cur"]
     n = c["n"].cpu().numpy(); nl = c["nl"].cpu().numpy()

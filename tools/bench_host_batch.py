@@ -9,8 +9,13 @@ chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 if len(sys.argv) > 3 and sys.argv[3] == "1": os.environ["SSLAM_BATCH_ONE_STREAM"] = "1"
 fe = pkg.frontend(); ctx = fe.Context(0)
 orb = fe.OrbExtractor(ctx, 1000); lines = fe.LineExtractor(ctx, 200)
-u = np.stack([synth_frame(2000 + i) for i in range(8)])
-frames = np.ascontiguousarray(np.tile(u, (n // 8, 1, 1)))
+if os.environ.get("HOST_BATCH_BENCH_FRAMES"):      # the bench's own sequence: 64 scenes of varied density, previous / current frame alternating (bench.py pcie_leg)
+    sys.path.insert(0, '.'); import bench
+    cur, prev = bench.synth_frames(640, 480, 64, 0)
+    u = np.stack([(prev if i % 2 == 0 else cur)[(i // 2) % 64] for i in range(256)])
+else:
+    u = np.stack([synth_frame(2000 + i) for i in range(8)])
+frames = np.ascontiguousarray(np.tile(u, ((n + len(u) - 1) // len(u), 1, 1))[:n])
 pin = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True); pin.numpy()[:] = frames
 outs = {False: fe.frontend_batch_alloc(n, orb.cap, 200, pinned=False), True: fe.frontend_batch_alloc(n, orb.cap, 200, pinned=True)}
 fe.frontend_batch_raw(orb, lines, frames[:min(n, 6144)], tuple(a[:min(n, 6144)] for a in outs[False]), chunk=chunk)                # warm-up: allocations, first-touch
