@@ -281,14 +281,16 @@ static int lines_host_seed_order(sslam_lines* L, uint8_t* ws, int nframes, hipSt
 }
 
 // Whether a batch of `nframes` runs the sequential core in its guest form (lsd_regions.h): a co-running branch was announced (sslam_lines_set_core_event) and the batch is
-// larger than the persistent grid of 16 workgroups per compute unit -- a smaller batch leaves wave slots free anyway.
+// at least two rounds of the persistent grid of 16 workgroups per compute unit.
 static bool lines_guest_form(const sslam_lines* L, int nframes, int* grid_out) {
     int grid = 16 * L->ctx->num_cus;
     bool guest = L->coreEvent != nullptr;
     if (const char* e = getenv("SSLAM_LSD_GUEST")) guest = atoi(e) != 0;
     if (const char* e = getenv("SSLAM_LSD_PERSIST")) { const int g = atoi(e) & ~7; if (g >= 8) grid = g; }
     if (grid_out) *grid_out = grid;
-    return guest && nframes >= 1024 && grid < nframes;
+    // at least two full rounds of the persistent grid: a batch of 1.5 grids (sslam_frontend_batch's chunks of 6 144 frames) would run half of the slots twice and the
+    // other half once -- measured on the bench's frame sequence, 24 576 frames through host memory: 61.1 k frames/s in this form against 66.0 k in the other (profiles/r06g_*)
+    return guest && nframes >= 1024 && 2 * grid <= nframes;
 }
 extern "C" int sslam_lines_core_guest_form(sslam_lines* L, int nframes) {
     if (!L || nframes <= 0) return 0;

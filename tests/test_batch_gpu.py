@@ -131,7 +131,7 @@ def test_batch_of_2176_frames_throughput_kernels(fe, ctx, oracle, form, monkeypa
     w, h, U, REP = 192, 144, 17, 128
     B = U * REP
     frames = [synth_frame(5000 + i, w, h, nshapes=8 + 3 * i, nstrokes=2 * i, noise=float(i % 3)) for i in range(U)]
-    if form == "guest": monkeypatch.setenv("SSLAM_LSD_PERSIST", "136")
+    if form == "guest": monkeypatch.setenv("SSLAM_LSD_PERSIST", "136")      # (& ~7 = 136 workgroups: 16 rounds of this batch)
     pipe = pipeline.FrontendBatch(fe, ctx, w, h, B, 300, 60, "cuda:0", with_match=False)
     imgs = torch.from_numpy(np.stack(frames)).cuda().repeat(REP, 1, 1).contiguous()          # slot s holds frame s % 17
     if form == "guest":
