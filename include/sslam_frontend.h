@@ -105,7 +105,11 @@ int sslam_orb_extract(sslam_orb* orb, const uint8_t* gray, int w, int h, size_t 
 
 /* Batch-of-frames mode (north_star): nframes independent images of identical size
  * resident in HBM.  d_images + i*image_stride is frame i (row pitch `pitch`).
- * d_kp[nframes*cap], d_desc[nframes*cap*32], d_counts[nframes] are device buffers. */
+ * d_kp[nframes*cap], d_desc[nframes*cap*32], d_counts[nframes] are device buffers.
+ * Level 0 of the pyramid is READ IN PLACE from d_images when base, pitch and image_stride are multiples of 4 and the frames are whole blocks
+ * (pitch == w, or image_stride >= pitch * h): the kernels load aligned dwords and may touch the padding bytes [w, pitch) of a row, so with
+ * padded rows every frame -- the last one included -- must be readable for pitch * h bytes.  Any other layout is copied first (one more pass).
+ * The images must stay valid until the call's work on `stream` has finished (as for any asynchronous launch). */
 int sslam_orb_extract_batch_dev(sslam_orb* orb, const uint8_t* d_images, int w, int h,
                                 size_t pitch, size_t image_stride, int nframes,
                                 sslam_keypoint* d_kp, uint8_t* d_desc, int32_t* d_counts,
@@ -122,7 +126,9 @@ int sslam_orb_batch_status_dev(sslam_orb* orb, int cap, int32_t* d_status4, void
 /* Stage taps for stage-by-stage parity tests (not used by the drop-in shim):
  * copy pyramid level `level` of frame `frame` of the LAST batch to host (unpadded,
  * contiguous w*h), and the FAST candidate list (x,y,score triplets relative to
- * minBorder, reference src/ORBextractor.cc:820-825) of that level. */
+ * minBorder, reference src/ORBextractor.cc:820-825) of that level.
+ * Level 0 (and the blurred patches of level-0 keypoints) of a batch that was read in place come from the CALLER's image buffer of that
+ * batch: it must still be alive when a tap is called (sslam_orb_extract keeps its own copy; a freed device buffer is the caller's error). */
 int sslam_orb_debug_level(sslam_orb* orb, int frame, int level, uint8_t* out, int* w, int* h);
 int sslam_orb_debug_candidates(sslam_orb* orb, int frame, int level, int32_t* xys_out, int cap, int* n_out);
 /* Stage tap of GaussianBlur(7x7, sigma 2) on the level clones (src/ORBextractor.cc:1085-1086): the blurred levels are never stored

@@ -446,7 +446,8 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clLds));
             if (nfaStreamWaves) {
                 if ((rc = side_stream_ready())) return rc;
-                long long spinTicks = 20000000;      // 0.2 s of the 100 MHz clock: a consumer wave that has seen no progress for that long leaves its blocks to the launch behind the core
+                long long spinTicks = 5000000;       // 50 ms of the 100 MHz clock (ten single-frame cores): a consumer wave that has seen no progress for that long leaves its blocks to the launch behind the core
+                                                      // (0.2 s in round 5: on a GPU shared with another process the consumers can be resident before the producer, and the wait was the spike)
                 if (const char* e = getenv("SSLAM_NFA_STREAM_TICKS")) spinTicks = std::max(0ll, atoll(e));
                 size_t nfaLdsPad = 40 * 1024;        // (lines_nfa.hip: keeps the consumers off the main wave's and the helpers' compute units)
                 int nfaTakeMax = NFA_STREAM_BLOCK;   // rectangles per claim at most (lsd_nfa.h)

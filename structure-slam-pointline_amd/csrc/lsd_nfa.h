@@ -455,19 +455,7 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
         for (int c0 = 0; vote(c0 < mine) != 0; c0 += 12) {
             unsigned a[12];
             // three 16-byte loads per run, as in count_item (round 6: this counter still issued twelve dword loads per run -- it is where the time of the refinement stages
-            // goes, i.e. most of the stage under decision D11 = 0); slots past the lane's run hold a neighbour's pixel and are masked at the vote (`valid`)
-#ifdef SSLAM_RECT5_DWORD_LOADS      // (A/B of GPU call H: the twelve dword loads of rounds 3-5)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
-            if (vote(c0 + 4 < mine)) {
-#pragma unroll
-                for (int q = 4; q < 8; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
-            }
-            if (vote(c0 + 8 < mine)) {
-#pragma unroll
-                for (int q = 8; q < 12; ++q) a[q] = c0 + q < mine ? t_raw(Tb, yb, xs + c0 + q) : PIX_NONE;
-            }
-#else
+            // goes, i.e. most of the stage under decision D11 = 0: 26.6 -> 26.4 ms there, 12.2 -> 12.0 under D11 = 1, GPU call H); slots past the lane's run hold a neighbour's pixel and are masked at the vote (`valid`)
 #pragma unroll
             for (int gq = 0; gq < 3; ++gq) {
                 if (gq == 0 || vote(c0 + 4 * gq < mine)) {
@@ -477,7 +465,6 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
                     for (int q = 0; q < 4; ++q) a[4 * gq + q] = t.v[q];
                 }
             }
-#endif
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 const unsigned long long valid = vote(c0 + q < mine);

@@ -1202,7 +1202,10 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
     Plan P = o->plan;
     uint8_t* pyr = o->dPyr.as<uint8_t>();
     // level 0 in place when the caller's layout allows aligned dword loads (see Plan::img0); SSLAM_ORB_COPY_LEVEL0=1 forces the copy (A/B knob)
-    const bool inPlace = ((uintptr_t)d_images & 3) == 0 && (pitch & 3) == 0 && (image_stride & 3) == 0 && pitch <= 0x7FFFFFFF && !getenv("SSLAM_ORB_COPY_LEVEL0");
+    // The aligned dword reads of the kernels may touch the padding bytes [w, pitch) of a row: with padded rows the frames must therefore be whole pitch x h blocks
+    // (image_stride >= pitch * h; include/sslam_frontend.h states it, and that the LAST frame's buffer must hold pitch * h bytes) -- a layout that does not say so is copied.
+    const bool inPlace = ((uintptr_t)d_images & 3) == 0 && (pitch & 3) == 0 && (image_stride & 3) == 0 && pitch <= 0x7FFFFFFF &&
+                         (pitch == (size_t)w || image_stride >= pitch * (size_t)h) && !getenv("SSLAM_ORB_COPY_LEVEL0");
     P.img0 = inPlace ? d_images : nullptr; P.img0Stride = image_stride; P.img0Pitch = (int)pitch;
     o->lastImg0 = d_images; o->lastImg0Pitch = pitch; o->lastImg0Stride = image_stride; o->lastInPlace = inPlace;
     if (!inPlace) {

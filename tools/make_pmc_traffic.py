@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; rocpd .db directories).
 
-    tools/make_pmc_traffic.py <fetch_dir> <write_dir> <batch> <extract_passes> <match_passes> <out.json>
+    tools/make_pmc_traffic.py <fetch_dir> <write_dir> <batch> <extract_passes> <match_passes> <out.json> [two_streams 0/1]
 
 The PMC runs call bench.py with a small batch; every extraction kernel runs `extract_passes` times over `batch` frames
 (previous-frame priming + warm-up + timed steps), every matching kernel `match_passes` times.  Values are the raw counter
@@ -12,9 +12,12 @@ MATCH = {"k_knn2_batch", "k_search_init", "k_line_match"}
 FETCH_CORRECTION = 2.0      # gfx950 tallies 128-byte read requests at 64 B (MI355X_MICROARCH.md, HBM section; calibrated in profiles/README.md on this library's own access patterns)
 
 
-def lsd_core(batch):
-    """which launch form of the sequential LSD core a batch of this size runs (lines.hip: sslam_lines_extract_batch_dev)"""
-    return "k_lsd_regions_cl" if batch <= 64 else "k_lsd_regions<true>" if batch < 1024 else "k_lsd_regions<false>"
+def lsd_core(batch, two_streams=False):
+    """which launch form of the sequential LSD core a batch of this size runs (lines.hip: sslam_lines_extract_batch_dev; the guest form needs a core event -- the
+    two-stream step -- and two rounds of its grid of 16 workgroups per compute unit)"""
+    if batch <= 64: return "k_lsd_regions_cl"
+    if batch < 1024: return "k_lsd_regions<true, 6>"
+    return "k_lsd_regions<false, 4>" if two_streams and batch >= 8192 else "k_lsd_regions<false, 6>"
 
 ONCE = {"k_grad_table", "k_lgamma_table", "k_probe_stream16", "k_probe_gather16"}
 
@@ -30,6 +33,7 @@ def totals(path):
 
 def main():
     fdir, wdir, B, ep, mp, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    two = len(sys.argv) > 7 and sys.argv[7] == "1"
     f, w = totals(fdir), totals(wdir)
     ker = {}
     for k in sorted(set(f) | set(w)):
@@ -37,9 +41,9 @@ def main():
             continue
         frames = B * (mp if k in MATCH else ep)
         ker[k] = {"fetch_bytes_per_frame": f.get(k, 0.0) * 1024.0 / frames, "write_bytes_per_frame": w.get(k, 0.0) * 1024.0 / frames}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --batch %d (%d extraction passes, %d matching passes); raw counter values, "
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, the step at batch %d (%d extraction passes, %d matching passes); raw counter values, "
                          "multi-launch kernels summed; see profiles/README.md for the gfx950 calibration" % (B, ep, mp),
-               "batch": B, "lsd_core": lsd_core(B), "fetch_correction": FETCH_CORRECTION,
+               "batch": B, "lsd_core": lsd_core(B, two), "fetch_correction": FETCH_CORRECTION,
                "fetch_correction_note": "multiply fetch_bytes_per_frame by this before comparing with a byte count (write side raw)",
                "kernels": ker}, open(out, 'w'), indent=1)
     for k, v in sorted(ker.items(), key=lambda kv: -(kv[1]["fetch_bytes_per_frame"] + kv[1]["write_bytes_per_frame"])):
