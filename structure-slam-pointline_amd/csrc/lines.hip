@@ -401,11 +401,13 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SSLAM_HIP(hipFuncSetAttribute((const void*)k_lsd_regions<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         if (L->coreWait) SSLAM_HIP(hipStreamWaitEvent(st, L->coreWait, 0));      // (sslam_lines_set_core_gate: another extractor's core has the wave slots until then)
         if (L->coreEvent) SSLAM_HIP(hipEventRecord(L->coreEvent, st));
         sslam::ProfScope _ps(L->ctx, "k_lsd_regions", st);
         bool lone = nframes < 1024;
+        const bool spillFree = !(getenv("SSLAM_LSD_SPILLFREE") && atoi(getenv("SSLAM_LSD_SPILLFREE")) == 0);
         if (const char* e = getenv("SSLAM_LSD_FLAVOUR")) lone = e[0] == 'l' || e[0] == 'c';      // experiment knob: "cl" / "lat" / "thr"
         // Up to 64 frames (one to eight per XCD) whose frame-wide bitmap fits the main wave's LDS: the cluster form -- helper waves on several compute
         // units, results through global memory, monotonic pixel map (lsd_cluster.h).  SSLAM_LSD_CLUSTER=0 (or SSLAM_LSD_FLAVOUR=lat) takes lone
@@ -467,14 +469,18 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
                 nfaStreamed = true; nfaStageOff = stageOff;
             } else
             hipLaunchKernelGGL(k_lsd_regions_cl, dim3(8 * nWG * ((nframes + 7) / 8)), dim3(64 * CL_WAVES), clLds, st, ws, P, L->dCl.as<uint8_t>(), clFrame, nframes, nWG, clSpecWords, clShift, window);
-        } else if (lone) hipLaunchKernelGGL((k_lsd_regions<true, 6>), dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);      // lone waves: shortest chain
-        else {
+        } else if (lone) {      // lone waves: shortest chain.  At most one wave per SIMD is resident, so the instantiation that spills nothing costs no occupancy (SSLAM_LSD_SPILLFREE=0: the six-wave one, A/B)
+            if (spillFree) hipLaunchKernelGGL((k_lsd_regions<true, 4>), dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
+            else hipLaunchKernelGGL((k_lsd_regions<true, 6>), dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
+        } else {
             // A caller that announced a branch running beside the core (sslam_lines_set_core_event: the bench step's point branch waits for that event) gets the GUEST form
             // (lsd_regions.h): 16 persistent workgroups per compute unit of the four-wave instantiation, a third of the registers free for the other branch's waves.
             // SSLAM_LSD_GUEST=0 / 1 overrides (A/B), SSLAM_LSD_PERSIST=g sets the grid.  (LBD's blur + Sobel as one more guest under the core, on the side stream, was
             // measured too: its 126-VGPR waves take the slots FAST needs -- 167.7 ms per step against 160.8 with the kernel in the tail; profiles/r06d_*.)
             int grid = 0;
             if (lines_guest_form(L, nframes, &grid)) hipLaunchKernelGGL((k_lsd_regions<false, 4>), dim3(grid), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
+            else if (spillFree && nframes <= 16 * L->ctx->num_cus)      // up to four waves per SIMD anyway (BASELINE configs[3]: 3 072 frames): the spill-free instantiation, one workgroup per frame
+                hipLaunchKernelGGL((k_lsd_regions<false, 4>), dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
             else hipLaunchKernelGGL((k_lsd_regions<false, 6>), dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
         }
     }

@@ -7,7 +7,7 @@ import numpy as np, torch, pkg, bench
 torch.cuda.set_device(0)
 fe = pkg.frontend(); ctx = fe.Context(0)
 cur, prev = bench.synth_frames(640, 480, 64, 0)
-for nf in (1, 2, 4, 8, 16, 32, 64, 96):
+for nf in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 16, 32, 64, 96]):      # frames per call (arguments: other sizes, e.g. 128 512 1024 3072)
     ex = fe.LineExtractor(ctx, 200)
     cap = 256
     d_kl = torch.zeros(nf * cap * 68, dtype=torch.uint8, device="cuda"); d_ld = torch.zeros(nf * cap * 32, dtype=torch.uint8, device="cuda")
