@@ -41,6 +41,11 @@ def test_bench_launches_its_own_ranks():
     g = out["config"]["gather"]
     assert out["config"]["gather_check"] is True and g["self_launched"] is True and g["rccl_ranks"] == 1
     assert len(g["per_rank"]) == 1 and g["per_rank"][0]["wall_s"] > 0
+    # BASELINE configs[4] (8 frames dealt over the GPUs, H2D + extract + match + RCCL gather inside the step) through the same launch path
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--self-launch", "--workload", "c5", "--steps", "3", "--warmup", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    c5 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert c5["n_gpus"] == 1 and c5["scaling"] == "strong" and c5["config"]["global_batch"] == 8 and c5["config"]["gather_check"] is True
     # more ranks than GPUs: a one-line refusal and a non-zero exit code, not N tracebacks
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "GPU(s) visible" in r.stderr

@@ -16,8 +16,9 @@ def lsd_core(batch, two_streams=False):
     """which launch form of the sequential LSD core a batch of this size runs (lines.hip: sslam_lines_extract_batch_dev; the guest form needs a core event -- the
     two-stream step -- and two rounds of its grid of 16 workgroups per compute unit)"""
     if batch <= 64: return "k_lsd_regions_cl"
-    if batch < 1024: return "k_lsd_regions<true, 6>"
-    return "k_lsd_regions<false, 4>" if two_streams and batch >= 8192 else "k_lsd_regions<false, 6>"
+    if batch < 1024: return "k_lsd_regions<true, 4>"
+    if batch <= 4096: return "k_lsd_regions<false, 4>, one workgroup per frame"
+    return "k_lsd_regions<false, 4>, guest form (persistent grid)" if two_streams and batch >= 8192 else "k_lsd_regions<false, 6>"
 
 ONCE = {"k_grad_table", "k_lgamma_table", "k_probe_stream16", "k_probe_gather16"}
 
