@@ -83,6 +83,7 @@ struct sslam_lines {
     int nfaVariant = 1, lbdBitOrder = 1, lsdResize = 0;      // sslam_lines_set_nfa_variant / _lbd_bit_order / _resize_variant (decisions D11, D12, D7): D11 and D12 default to the OpenCV-as-recalled forms since round 5
     int seedOrder = 0;              // sslam_lines_set_seed_order (decision D2): 1 = the seeds are ordered by the host's std::sort
     int sMin = 0;                   // smallest |g|^2 of a defined pixel (k_grad_smin, with the gradient table)
+    bool fusedGeometry = false;     // lines_build_plan: the plan admits k_lsd_grad_fused
     hipStream_t nfaStream = nullptr; hipEvent_t nfaFork = nullptr, nfaJoin = nullptr;      // the NFA stage next to the cluster form of the core (calls of up to 64 frames)
 };
 
@@ -215,6 +216,13 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
         const int nl = P.npx + 4;
         if ((rc = L->dLgam.ensure(sizeof(double) * (2 * (size_t)nl + 48)))) return rc;
         if ((rc = upload_nfa_tables(L->dLgam.as<double>(), nl, L->ctx->stream))) return rc;
+    }
+    // the fused blur + gradient kernel (lsd_front.h k_lsd_grad_fused) covers the 5-to-4 geometry with the plain table pattern and a five-tap blur; anything else keeps k_blur7 + k_lsd_grad
+    {
+        bool ok = (w % 4) == 0 && (P.sw % 4) == 0 && (P.sh % 4) == 0 && w == 5 * (P.sw / 4) && h == 5 * (P.sh / 4) && w >= 20 && h >= 10 && t7[0] == 0 && t7[6] == 0;
+        for (int x = 0; ok && x < P.sw; ++x) ok = tabs[(size_t)P.tabX + 2 * x] == 5 * (x >> 2) + (x & 3);
+        for (int y = 0; ok && y < P.sh; ++y) ok = tabs[(size_t)P.tabY + 2 * y] == 5 * (y >> 2) + (y & 3);
+        L->fusedGeometry = ok;
     }
     L->planW = w; L->planH = h; L->wsFrames = 0;
     return SSLAM_OK;
@@ -375,7 +383,20 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
         }
         return SSLAM_OK;
     };
-    // LSD: blur(7, 0.75) -> 0.8x -> gradient
+    // LSD: blur(7, 0.75) -> 0.8x -> gradient; one kernel where the geometry allows (SSLAM_LSD_FUSED=0: always two, A/B)
+    const bool fused = L->fusedGeometry && GRAD_ROWS == 8 && ((uintptr_t)d_images & 3) == 0 && (pitch & 3) == 0 && (image_stride & 3) == 0 && pitch <= 0x7FFFFFFF &&
+                       !(getenv("SSLAM_LSD_FUSED") && atoi(getenv("SSLAM_LSD_FUSED")) == 0);
+    if (fused) {
+      sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st);
+      const dim3 gg(P.nXB, (P.sh + 31) / 32, nframes);
+      const int* tabX = L->dTabs.as<int>() + P.tabX; const int* tabY = L->dTabs.as<int>() + P.tabY;
+      switch ((P.lsdResize ? 1 : 0) | (L->seedOrder ? 2 : 0)) {
+          case 0: hipLaunchKernelGGL(k_lsd_grad_fused<0>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps); break;
+          case 1: hipLaunchKernelGGL(k_lsd_grad_fused<1>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps); break;
+          case 2: hipLaunchKernelGGL(k_lsd_grad_fused<2>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps); break;
+          default: hipLaunchKernelGGL(k_lsd_grad_fused<3>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps); break;
+      }
+    } else {
     { sslam::ProfScope _ps(L->ctx, "k_blur7", st); hipLaunchKernelGGL(k_blur7, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride,
                        ws + P.offBlur, bpitch, P.frameBytes, w, h, taps); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st);
@@ -387,6 +408,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
           case 2: hipLaunchKernelGGL(k_lsd_grad<2>, gg, dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>(), bpitch, tabX, tabY); break;
           default: hipLaunchKernelGGL(k_lsd_grad<3>, gg, dim3(64, 4), 0, st, ws, P, L->dGtab.as<float4>(), bpitch, tabX, tabY); break;
       } }
+    }
     if (L->seedOrder) { if ((rc = lines_host_seed_order(L, ws, nframes, st))) return rc; }
     else {
     { sslam::ProfScope _ps(L->ctx, "k_lsd_hist", st); hipLaunchKernelGGL(k_lsd_hist, dim3(sort_grid(P.nTiles, nframes)), dim3(64), 0, st, ws, P, nframes); }

@@ -295,6 +295,179 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
     if (lane == 0 && smax > 0) atomicMax(&misc->maxS, smax);
 }
 
+
+// ------------------------------------------------------------------ round 6: the pre-blur INSIDE the gradient kernel
+// k_blur7 + k_lsd_grad as one kernel for the geometry the bench and the reference's camera have: w = 5m, sw = 4m, h = 5n, sh = 4n (640x480, 1280x960, 320x240 ...), the
+// blur's outer taps zero (0 4 56 136 56 4 0 under both D6 variants) and resize tables of the plain 4-to-5 pattern (lines_build_plan checks all of it on the host; anything
+// else keeps the two kernels).  The 8-bit Gaussian is exact integer arithmetic with ONE rounding at the end -- blurred = min((sum_k sum_l t[k] t[l] raw[r+k][c+l] + 32768)
+// >> 16, 255) -- so its 5 x 5 sum can be evaluated wherever it is needed.  A lane (four output pixels of one row) needs the blurred columns c0 .. c0 + 6, c0 = 5 x4 / 4, of
+// the blurred rows 10 q .. 10 q + 11 for its strip of eight output rows (q = strip index): sixteen raw rows 10 q - 2 .. 10 q + 13, each read as one 16-byte window, their
+// horizontal 5-tap sums H (<= 65 280: two per dword) kept in a ring of five rows, a blurred row finished whenever its fifth H row arrives, a scaled row whenever its two
+// blurred rows exist.  What the fusion removes: k_blur7's launch, the blurred image's write and its 2.5-fold re-read, and -- in the two-stream step -- the kernel the pyramid's
+// k_resize launches stretched most (3.5 -> 9.0 ms).
+// BORDER_REFLECT_101: rows through reflect_row; columns only touch the row's first lane (c0 = 0: raw columns -2, -1 = 2, 1) and its last one (c0 = w - 5: columns w .. w + 3
+// = w - 2 .. w - 5), each fixed with one v_perm on in-range dwords.
+struct Raw16 { unsigned v[4]; };
+template <int MODE>
+__global__ __launch_bounds__(256) void k_lsd_grad_fused(const uint8_t* __restrict__ img, size_t ipitch, size_t iframe, const uint8_t* __restrict__ ws, LsdPlan P,
+                                                        const float4* __restrict__ gtab, const int* __restrict__ tx, const int* __restrict__ ty, const int* __restrict__ tapsArr) {
+    constexpr bool LIN = (MODE & 1) != 0, DENSE = (MODE & 2) != 0;
+    const int b = blockIdx.z;
+    const uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const uint8_t* src = img + (size_t)b * iframe;
+    float* T = (float*)(base + P.offT);
+    float2* Cs = (float2*)(base + P.offCs);
+    int* S = (int*)(base + P.offS); (void)S;
+    Misc* misc = (Misc*)(base + P.offMisc);
+    unsigned* comp = (unsigned*)(base + P.offComp);
+    int* segCnt = (int*)(base + P.offSegCnt);
+    const int lane = threadIdx.x;
+    const int strip = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);      // eight output rows, ten blurred rows
+    const int yBeg = strip * 8, yEnd = min(P.sh, yBeg + 8);
+    if (yBeg >= P.sh) return;                               // the whole wave
+    const int x4 = (blockIdx.x * 64 + lane) * 4;
+    const bool inx = x4 < P.sw;                             // lanes beyond the row compute on the row's last group and store nothing
+    const int x4c = min(x4, P.sw - 4);
+    const int c0 = (x4c >> 2) * 5;                          // first source column of the group (the tables were checked against this pattern)
+    unsigned cx[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) cx[j] = (unsigned)((const int2*)tx)[min(x4c + j, P.sw - 1)].y;
+    const int2* tyv = (const int2*)ty;
+    // the 16-byte window of a raw row: columns a .. a + 15, a = (c0 - 2) & ~3, needed bytes o0 .. o0 + 10 (o0 = (c0 - 2) & 3).  First lane of a row: a = -4, the window is
+    // read from column 0 and shifted by one dword, its first dword built from the reflection; last lane (a = w - 8): the third dword is the reflection, the fourth is not needed.
+    const int a = (c0 - 2) & ~3;
+    const unsigned o0 = (unsigned)(c0 - 2) & 3u;
+    const bool isLeft = a < 0, isRight = a + 8 >= P.w;
+    const int aLoad = isLeft ? 0 : a;
+    const unsigned t1 = (unsigned)tapsArr[1], t2 = (unsigned)tapsArr[2], t3 = (unsigned)tapsArr[3], t4 = (unsigned)tapsArr[4], t5 = (unsigned)tapsArr[5];
+    const unsigned TA = t1 | (t2 << 8) | (t3 << 16) | (t4 << 24);      // taps of bytes i .. i + 3; byte i + 4 takes t5
+    unsigned Hring[5][4];                                   // packed pairs: H[2j] | H[2j + 1] << 16, columns c0 .. c0 + 7 (the eighth is never used)
+    // (columns up to w - 1 only: what lies behind a row is the next row, or -- for the last row of the last frame -- nothing.  The third and fourth dword of the lanes at
+    // the row's end are re-read from the row's last dword: the last lane rebuilds its third from the reflection, nobody needs the others)
+    const int off2 = min(aLoad + 8, P.w - 4), off3 = min(aLoad + 12, P.w - 4);
+    auto raw_row = [&](int n) -> Raw16 {                    // raw row 10 strip - 2 + n of this frame
+        const int rr = reflect_row(10 * strip - 2 + n, P.h, 2);
+        const uint8_t* row = src + (size_t)rr * ipitch;
+        Raw16 r;
+        const uint2 lo = *(const uint2*)(row + aLoad);      // (4-byte aligned: the hardware takes it)
+        r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = *(const unsigned*)(row + off2); r.v[3] = *(const unsigned*)(row + off3);
+        return r;
+    };
+    auto hrow = [&](const Raw16& r, unsigned (&Hp)[4]) {
+        unsigned L0 = r.v[0], L1 = r.v[1], L2 = r.v[2], L3 = r.v[3];
+        if (isLeft) {       // loaded columns 0 .. 15 are L1 .. L3 (+ one more); L0 = columns -4 .. -1 = 4, 3, 2, 1
+            L3 = L2; L2 = L1; L1 = L0;
+            L0 = __builtin_amdgcn_perm(L2, L1, 0x01020304u);
+        }
+        if (isRight) L2 = __builtin_amdgcn_perm(L1, L0, 0x03040506u);      // columns w .. w + 3 = w - 2, w - 3, w - 4, w - 5 (L0:L1 = columns w - 8 .. w - 1)
+        // e = bytes o0 .. o0 + 11 of the window = raw columns c0 - 2 .. c0 + 9
+        const unsigned e0 = __builtin_amdgcn_alignbyte(L1, L0, o0), e1 = __builtin_amdgcn_alignbyte(L2, L1, o0), e2 = __builtin_amdgcn_alignbyte(L3, L2, o0);
+        unsigned H[8];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {                       // H[i] = sum over l of t[l + 1] * e.byte[i + l], l = 0 .. 4
+            const int q = i >> 2, sft = i & 3;
+            const unsigned lo = q == 0 ? (sft ? __builtin_amdgcn_alignbyte(e1, e0, (unsigned)sft) : e0) : (sft ? __builtin_amdgcn_alignbyte(e2, e1, (unsigned)sft) : e1);
+            const int i4 = i + 4, q4 = i4 >> 2, s4 = i4 & 3;
+            const unsigned b4 = ((q4 == 1 ? e1 : e2) >> (8 * s4)) & 255u;
+            H[i] = __builtin_amdgcn_udot4(lo, TA, __umul24(b4, t5), false);
+        }
+        H[7] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Hp[j] = H[2 * j] | (H[2 * j + 1] << 16);
+    };
+    auto blur_row = [&](int top, int (&B)[7]) {             // the blurred row whose five H rows start at ring slot `top`
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            unsigned acc = 32768u;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const unsigned hp = Hring[(top + k) % 5][i >> 1];
+                const unsigned tk = k == 0 ? t1 : k == 1 ? t2 : k == 2 ? t3 : k == 3 ? t4 : t5;
+                acc += __umul24((i & 1) ? (hp >> 16) : (hp & 0xFFFFu), tk);
+            }
+            B[i] = (int)min(acc >> 16, 255u);
+        }
+    };
+    auto scale_row = [&](int yy, const int (&B0)[7], const int (&B1)[7], int (&p)[5]) {      // scaled row yy from its two blurred rows
+        const unsigned cy = (unsigned)tyv[yy].y;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = j < 4 ? j : 5;                    // source columns c0 + {0, 1, 2, 3, 5}
+            p[j] = scaled_px<LIN>((unsigned)B0[i] | ((unsigned)B0[i + 1] << 8), (unsigned)B1[i] | ((unsigned)B1[i + 1] << 8), cx[j], cy);
+        }
+        if (x4c + 4 > P.sw - 1) p[4] = p[3];                // the row's last group: column sw is clamped to sw - 1 (the table lookup above used its entry for both)
+    };
+    int smax = 0;
+    auto process = [&](int y, const int (&p0)[5], const int (&p1)[5]) {      // p0 / p1: the scaled rows y and y + 1 (k_lsd_grad's, unchanged)
+        float ang[4]; float2 cs[4]; int sv[4], gidx[4];
+        unsigned flags = 0;
+        const bool lastRow = y >= P.sh - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ang[j] = NOTDEF_F; cs[j] = make_float2(0.f, 0.f); sv[j] = -1;
+            const int DA = p1[j + 1] - p0[j], BC = p0[j + 1] - p1[j];
+            const int gx = DA + BC, gy = DA - BC, s = gx * gx + gy * gy;
+            gidx[j] = (gy + 510) * GT + (gx + 510);
+            if (inx && !lastRow && x4 + j < P.sw - 1 && s >= P.sMin) { flags |= 1u << j; sv[j] = s; }
+            else if (DENSE) sv[j] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (flags & (1u << j)) { const float4 rec = gtab[gidx[j]]; ang[j] = rec.x; cs[j] = make_float2(rec.y, rec.z); }
+        const size_t i = (size_t)y * P.sw + x4;
+        if (inx) *(float4*)(T + i) = make_float4(ang[0], ang[1], ang[2], ang[3]);      // (sw % 4 == 0 on this path)
+        if (DENSE && inx) *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
+        if (flags) {
+            if (!DENSE) *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
+            float4* c = (float4*)(Cs + i);
+            c[0] = make_float4(cs[0].x, cs[0].y, cs[1].x, cs[1].y);
+            c[1] = make_float4(cs[2].x, cs[2].y, cs[3].x, cs[3].y);
+        }
+        const int seg = y * P.nXB + blockIdx.x;
+        const int cnt = __popc(flags), incl = wave_incl_scan(cnt);
+        unsigned* dst = comp + ((size_t)seg << 8);
+        int pos = incl - cnt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (flags & (1u << j)) dst[pos++] = ((unsigned)sv[j] << 8) | (unsigned)(4 * lane + j);
+        if (lane == 63) segCnt[seg] = incl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (!DENSE || (flags & (1u << j))) smax = max(smax, sv[j]);
+    };
+    // Straight-line schedule over the sixteen raw rows n = 0 .. 15 (two loads ahead): blurred row bi = n - 4 is complete with raw row n; scaled row yBeg + i needs the
+    // blurred rows {0,1}, {1,2}, {2,3}, {3,4}, {5,6}, {6,7}, {7,8}, {8,9}, {10,11} for i = 0 .. 8; output row yBeg + i needs the scaled rows i and i + 1.
+    int Bprev[7], Bcur[7], pc[5], pn[5];
+    Raw16 ahead0 = raw_row(0), ahead1 = raw_row(1);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        const Raw16 cur = ahead0;
+        ahead0 = ahead1;
+        if (n + 2 < 16) ahead1 = raw_row(n + 2);
+        hrow(cur, Hring[n % 5]);
+        if (n < 4) continue;
+        const int bi = n - 4;                               // blurred row 10 strip + bi; its H rows are ring slots (n - 4) % 5 .. n % 5
+        blur_row((n + 1) % 5, Bcur);
+        const int sIdx = bi == 1 ? 0 : bi == 2 ? 1 : bi == 3 ? 2 : bi == 4 ? 3 : bi == 6 ? 4 : bi == 7 ? 5 : bi == 8 ? 6 : bi == 9 ? 7 : bi == 11 ? 8 : -1;      // the scaled row this blurred row completes
+        if (sIdx >= 0) {
+            const int yy = min(yBeg + sIdx, P.sh - 1);
+            if (sIdx == 0) scale_row(yy, Bprev, Bcur, pc);
+            else {
+                if (yBeg + sIdx > P.sh - 1) {               // below the image: the gradient's "next row" is the last row itself (k_lsd_grad: min(y + 1, sh - 1))
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) pn[j] = pc[j];
+                } else scale_row(yy, Bprev, Bcur, pn);
+                const int y = yBeg + sIdx - 1;
+                if (y < yEnd) process(y, pc, pn);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) pc[j] = pn[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) Bprev[i] = Bcur[i];
+    }
+    smax = wave_max(smax);
+    if (lane == 0 && smax > 0) atomicMax(&misc->maxS, smax);
+}
+
 __device__ __forceinline__ int lsd_bin(int s, double binCoef) {
     int i = (int)(sqrt((double)s / 4.0) * binCoef);
     return min(max(i, 0), N_BINS - 1);
