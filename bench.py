@@ -70,8 +70,8 @@ def alg_bytes_per_frame(w, h, nkp, nln):
         "k_fast_cells": sP,                                 # FAST read of every level
         "k_octree": 0,                                      # candidate lists only (latency-bound, no image traffic)
         "k_describe": 2 * sP + nkp * (2 * 961 + 32 + 28),   # blur r/w folded into the per-keypoint patch stage + patch reads + outputs
-        "k_blur7": 2 * w * h,                               # LSD pre-blur r/w
-        "k_lsd_grad": (w * h + s08) + s08 + 8 * s08,        # 0.8x resample (fused: blurred read, scaled image) + gradient read, fp32 angle + int magnitude write
+        "k_blur7": 0,                                       # LSD pre-blur: evaluated inside the gradient kernel since round 6 (k_lsd_grad_fused; 2 * w * h as a kernel of its own before, and for geometries off the fused path)
+        "k_lsd_grad": (w * h + s08) + s08 + 8 * s08,        # source read + 0.8x resample (never stored) + gradient read, fp32 angle + int magnitude write
         "k_lsd_hist": 8 * s08, "k_lsd_scan": 0, "k_lsd_scatter": 4 * s08,    # ordered-list build
         "k_lsd_regions": 5 * s08,                           # region-grow reads (angle + magnitude + used)
         "k_nfa_count": 2 * nln * 100 * 6 * 4,               # angle-map rows under ~2 nln candidate rectangles of a nominal 100 x 6 pixels, 4 B each
