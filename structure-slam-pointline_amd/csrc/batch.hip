@@ -132,7 +132,7 @@ int batch_impl(const char* fn, sslam_orb* orb, sslam_lines* lines, const uint8_t
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
             // per frame: the ORB workspace (pyramid + three candidate planes ~ 4.2 B per pixel), the LSD / LBD workspace (0.64 x 28 B of planes, order list and
             // region spill per pixel, 4 B of Sobel pairs, ~1.4 MB of rectangle / NFA records), the two slots of inputs and outputs
-            const size_t perFrame = 6 * fpx + (lines ? 22 * fpx + 1500000 : 0) + 2 * fpx + (size_t)cap * (60 * 3 + (M ? 12 + 20 + (knn ? 32 + 256 : 0) : 0)) + (lines ? (size_t)lcap * 124 * 3 : 0) + 65536;
+            const size_t perFrame = 6 * fpx + (lines ? 25 * fpx + 1500000 : 0) + 2 * fpx + (size_t)cap * (60 * 3 + (M ? 12 + 20 + (knn ? 32 + 256 : 0) : 0)) + (lines ? (size_t)lcap * 124 * 3 : 0) + 65536;
             const size_t fit = freeB / 3 / std::max<size_t>(perFrame, 1);
             if ((size_t)C > fit) C = (int)std::max<size_t>(fit, 1);      // little free memory (another process on the GPU, very large frames): smaller chunks, down to one frame; only then can an allocation fail
         }

@@ -261,9 +261,12 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
             for (int u = 0; u < 8; ++u) g[u] = *(const unsigned*)((const char*)dxyImg + off8[u]);      // wave-uniform base + 32-bit offset
         };
         auto consume = [&](const unsigned (&g)[8], int w0) {
+            // a group that lies wholly inside the line (all but the last one) takes the straight-line form: the per-step test is wave-uniform but a branch per step
+            // keeps the scheduler from interleaving the steps' independent multiplications
+            const bool whole = w0 + 8 <= lengthOfLSP;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (w0 + u < lengthOfLSP) {
+                if (whole || w0 + u < lengthOfLSP) {
                     const float dx = (float)(short)(g[u] & 0xFFFFu), dy = (float)(short)(g[u] >> 16);
                     const float gDL = __fadd_rn(__fmul_rn(dx, dL0), __fmul_rn(dy, dL1));
                     const float gDO = __fadd_rn(__fmul_rn(dx, dO0), __fmul_rn(dy, dO1));

@@ -193,6 +193,7 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offReg = take(sizeof(unsigned) * std::max((size_t)P.npx, (size_t)P.sh * P.nXB * 256));      // region lists beyond QCAP; before the core: the segments' lists
     P.offComp = P.offReg;
     P.offSegCnt = take(sizeof(int) * (size_t)P.sh * P.nXB);
+    P.offSorted = take(sizeof(unsigned) * (size_t)P.sh * P.nXB * 256);      // the segments' lists again, every tile's entries sorted by bin (k_lsd_hist_sort -> k_lsd_scatter_runs)
     P.offSeg = take(sizeof(float4) * MAX_SEG);
     P.offCand = take(sizeof(double) * 12 * MAX_SEG);      // candidate rectangles (RectD) awaiting the NFA stage, seed order
     P.offFlag = take(sizeof(int) * MAX_SEG);
@@ -411,9 +412,17 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     }
     if (L->seedOrder) { if ((rc = lines_host_seed_order(L, ws, nframes, st))) return rc; }
     else {
+    // tile-sorted runs (lsd_front.h) where a sorted entry's packing fits (scaled image up to 2048 x 2048); SSLAM_LSD_SORT_RUNS=0: the round-1-5 kernels (A/B)
+    const bool runs = P.sw <= (1 << SORT_XY_BITS) && P.sh <= (1 << SORT_XY_BITS) && !(getenv("SSLAM_LSD_SORT_RUNS") && atoi(getenv("SSLAM_LSD_SORT_RUNS")) == 0);
+    if (runs) {
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_hist", st); hipLaunchKernelGGL(k_lsd_hist_sort, dim3(sort_grid(P.nTiles, nframes)), dim3(64), 0, st, ws, P, nframes); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_scan", st); hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P); }
+    { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter_runs, dim3(sort_grid(P.nTiles, nframes)), dim3(64), 0, st, ws, P, nframes); }
+    } else {
     { sslam::ProfScope _ps(L->ctx, "k_lsd_hist", st); hipLaunchKernelGGL(k_lsd_hist, dim3(sort_grid(P.nTiles, nframes)), dim3(64), 0, st, ws, P, nframes); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scan", st); hipLaunchKernelGGL(k_lsd_scan, dim3(nframes), dim3(1024), 0, st, ws, P); }
     { sslam::ProfScope _ps(L->ctx, "k_lsd_scatter", st); hipLaunchKernelGGL(k_lsd_scatter, dim3(sort_grid(P.nTiles, nframes)), dim3(64), 0, st, ws, P, nframes); }
+    }
     }
     bool nfaStreamed = false; size_t nfaStageOff = 0;
     {

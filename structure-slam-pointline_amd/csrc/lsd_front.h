@@ -627,3 +627,125 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, Ls
         }
     }
 }
+
+// ------------------------------------------------------------------ round 6: the counting sort with tile-sorted runs
+// k_lsd_scatter issues one 4-byte store per defined pixel to wherever that pixel's bin lives in the frame's seed list: 369 M scattered stores per step of 12 288 frames, and
+// the kernel runs at the rate the chip answers random sectors (tools/gather_probe), 6.6 x write amplification included.  But a tile's ~1 200 entries fall into only ~300 of the
+// 1 024 bins, most of them in the few populous low-gradient bins: sorted by bin INSIDE the tile (stable), same-bin entries are neighbours, their positions in the frame's list are
+// consecutive, and neighbouring lanes store to neighbouring dwords -- 3.5 x fewer requests on the bench's frames.  The tile-local sort is a second pass of the histogram kernel
+// (it has the tile's histogram in LDS anyway): its scattered stores stay inside the tile's own 5 KB window, which the L2 absorbs.  A sorted entry is bin << 22 | y << 11 | x
+// (scaled images up to 2048 x 2048; larger ones keep k_lsd_hist + k_lsd_scatter).
+constexpr int SORT_XY_BITS = 11;
+__global__ __launch_bounds__(64) void k_lsd_hist_sort(uint8_t* __restrict__ ws, LsdPlan P, int nframes) {
+    __shared__ int hist[N_BINS];              // the tile's histogram, then its exclusive positions (descending bins) as the local cursors
+    __shared__ int pref[MAX_TSEG + 1];
+    __shared__ unsigned segXY[MAX_TSEG];      // first column | row << SORT_XY_BITS of each segment of the tile
+    int tile, b; const int lane = threadIdx.x;
+    if (!sort_tile(P.nTiles, nframes, tile, b)) return;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const Misc* misc = (const Misc*)(base + P.offMisc);
+    const unsigned* comp = (const unsigned*)(base + P.offComp);
+    unsigned* sorted = (unsigned*)(base + P.offSorted);
+    int* th = (int*)(base + P.offTileHist) + (size_t)tile * N_BINS;
+    for (int i = lane; i < N_BINS; i += 64) hist[i] = 0;
+    const int r0 = tile * P.tileRows, r1 = min(P.sh, r0 + P.tileRows), seg0 = r0 * P.nXB, nseg = (r1 - r0) * P.nXB;
+    for (int sgm = lane; sgm < nseg; sgm += 64) { const int r = sgm / P.nXB; segXY[sgm] = (unsigned)((sgm - r * P.nXB) << 8) | ((unsigned)(r0 + r) << SORT_XY_BITS); }
+    const int total = tile_segments((const int*)(base + P.offSegCnt), seg0, nseg, pref, lane);
+    __syncthreads();
+    const double bc = lsd_bin_coef(misc->maxS);
+    int sgi = 0;
+    for (int e0 = 0; e0 < total; e0 += 256) {            // pass 1: bin every entry and count (the entries stay as they are: pass 2 bins them again instead of reading back what this pass would have stored)
+        unsigned ent[4]; bool have[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = e0 + k * 64 + lane;
+            have[k] = e < total; ent[k] = 0;
+            if (have[k]) {
+                while (e >= pref[sgi + 1]) ++sgi;
+                ent[k] = comp[((size_t)(seg0 + sgi) << 8) + (e - pref[sgi])];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (have[k]) atomicAdd(&hist[lsd_bin((int)(ent[k] >> 8), bc)], 1);
+    }
+    __syncthreads();
+    // the tile's histogram goes to the scan kernel; locally it becomes exclusive positions in DESCENDING bin order (the frame list's order): lane l owns bins 1023 - 16 l .. 1008 - 16 l
+    {
+        int c[16], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { c[j] = hist[N_BINS - 1 - (16 * lane + j)]; sum += c[j]; }
+        for (int i = lane; i < N_BINS; i += 64) th[i] = hist[i];
+        int run = wave_incl_scan(sum) - sum;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { hist[N_BINS - 1 - (16 * lane + j)] = run; run += c[j]; }
+    }
+    __syncthreads();
+    unsigned* out = sorted + ((size_t)seg0 << 8);        // the tile's block: as many slots as its segments have (>= total)
+    sgi = 0;
+    for (int e0 = 0; e0 < total; e0 += 256) {            // pass 2: the tile's entries in raster order to their places in the tile-sorted block
+        unsigned ent[4], xy[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = e0 + k * 64 + lane;
+            ent[k] = 0; xy[k] = 0;
+            if (e < total) {
+                while (e >= pref[sgi + 1]) ++sgi;
+                ent[k] = comp[((size_t)(seg0 + sgi) << 8) + (e - pref[sgi])];
+                xy[k] = segXY[sgi];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (e0 + k * 64 >= total) break;             // wave-uniform
+            const bool def = e0 + k * 64 + lane < total;
+            const int bin = lsd_bin((int)(ent[k] >> 8), bc);
+            const unsigned long long peers = same_key10(bin, __ballot(def));
+            if (def) {
+                const int rank = mbcnt(peers), pos = hist[bin] + rank;
+                out[pos] = ((unsigned)bin << (2 * SORT_XY_BITS)) | (xy[k] + (ent[k] & 255u));
+                if (rank == __popcll(peers) - 1) hist[bin] = pos + 1;
+            }
+        }
+    }
+}
+
+// The scatter over tile-sorted runs: lanes of one run hold one bin, their rank is their distance from the run's first lane, and they store to consecutive dwords.
+__global__ __launch_bounds__(64) void k_lsd_scatter_runs(uint8_t* __restrict__ ws, LsdPlan P, int nframes) {
+    __shared__ int cursor[N_BINS];
+    int tile, b; const int lane = threadIdx.x;
+    if (!sort_tile(P.nTiles, nframes, tile, b)) return;
+    uint8_t* base = ws + (size_t)b * P.frameBytes;
+    const int* th = (const int*)(base + P.offTileHist) + (size_t)tile * N_BINS;
+    unsigned* order = (unsigned*)(base + P.offOrder);
+    for (int i = lane; i < N_BINS; i += 64) cursor[i] = th[i];
+    const int r0 = tile * P.tileRows, r1 = min(P.sh, r0 + P.tileRows), seg0 = r0 * P.nXB, nseg = (r1 - r0) * P.nXB;
+    const int* segCnt = (const int*)(base + P.offSegCnt) + seg0;
+    int total = 0;
+    for (int sgm = lane; sgm < nseg; sgm += 64) total += segCnt[sgm];
+    total = wave_sum(total);
+    const unsigned* in = (const unsigned*)(base + P.offSorted) + ((size_t)seg0 << 8);
+    __syncthreads();
+    constexpr unsigned XYM = (1u << SORT_XY_BITS) - 1;
+    for (int e0 = 0; e0 < total; e0 += 256) {
+        unsigned v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int e = e0 + k * 64 + lane; v[k] = e < total ? in[e] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (e0 + k * 64 >= total) break;             // wave-uniform
+            const bool def = e0 + k * 64 + lane < total;
+            const int bin = (int)(v[k] >> (2 * SORT_XY_BITS));
+            const int prevBin = __builtin_amdgcn_update_dpp(-1, bin, 0x138, 0xF, 0xF, false);      // wave_shr:1 -- lane 0 keeps -1: it always starts a run
+            const int nextBin = __builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, bin);
+            const unsigned long long heads = __ballot(def && (lane == 0 || bin != prevBin));
+            const unsigned long long below = heads & (~0ull >> (63 - lane));                      // run starts at or below this lane
+            const int start = 63 - __clzll((long long)below);
+            if (def) {
+                const int rank = lane - start, pos = cursor[bin] + rank;
+                order[pos] = (v[k] & XYM) | (((v[k] >> SORT_XY_BITS) & XYM) << 16);                 // x | y << 16 (the packing of the region lists)
+                const bool last = lane == 63 || nextBin != bin || e0 + k * 64 + lane + 1 >= total;
+                if (last) cursor[bin] = pos + 1;
+            }
+        }
+    }
+}
