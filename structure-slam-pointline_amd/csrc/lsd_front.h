@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad_fused(const uint8_t* __restric
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (flags & (1u << j)) { const float4 rec = gtab[gidx[j]]; ang[j] = rec.x; cs[j] = make_float2(rec.y, rec.z); }
+            if (flags & (1u << j)) { const float4 rec = gtab[gidx[j]]; ang[j] = rec.x; cs[j] = make_float2(rec.y, rec.z); }      // (the four gathers are in flight together; all of them cost 0.7 of the kernel's 11 ms: call P)
         const size_t i = (size_t)y * P.sw + x4;
         if (inx) *(float4*)(T + i) = make_float4(ang[0], ang[1], ang[2], ang[3]);      // (sw % 4 == 0 on this path)
         if (DENSE && inx) *(int4*)(S + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
@@ -433,15 +433,17 @@ __global__ __launch_bounds__(256) void k_lsd_grad_fused(const uint8_t* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (!DENSE || (flags & (1u << j))) smax = max(smax, sv[j]);
     };
-    // Straight-line schedule over the sixteen raw rows n = 0 .. 15 (two loads ahead): blurred row bi = n - 4 is complete with raw row n; scaled row yBeg + i needs the
+    // Straight-line schedule over the sixteen raw rows n = 0 .. 15 (AH loads ahead): blurred row bi = n - 4 is complete with raw row n; scaled row yBeg + i needs the
     // blurred rows {0,1}, {1,2}, {2,3}, {3,4}, {5,6}, {6,7}, {7,8}, {8,9}, {10,11} for i = 0 .. 8; output row yBeg + i needs the scaled rows i and i + 1.
     int Bprev[7], Bcur[7], pc[5], pn[5];
-    Raw16 ahead0 = raw_row(0), ahead1 = raw_row(1);
+    constexpr int AH = 2;                                   // raw rows requested ahead of the one being consumed (3, 4 and 6 measured: 10.9 against 11.1 ms, call Q -- the loads are not what it waits for)
+    Raw16 ring[AH];
+#pragma unroll
+    for (int k = 0; k < AH; ++k) ring[k] = raw_row(k);
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
-        const Raw16 cur = ahead0;
-        ahead0 = ahead1;
-        if (n + 2 < 16) ahead1 = raw_row(n + 2);
+        const Raw16 cur = ring[n % AH];
+        if (n + AH < 16) ring[n % AH] = raw_row(n + AH);
         hrow(cur, Hring[n % 5]);
         if (n < 4) continue;
         const int bi = n - 4;                               // blurred row 10 strip + bi; its H rows are ring slots (n - 4) % 5 .. n % 5
