@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
 // horizontal 5-tap sums H (<= 65 280: two per dword) kept in a ring of five rows, a blurred row finished whenever its fifth H row arrives, a scaled row whenever its two
 // blurred rows exist.  What the fusion removes: k_blur7's launch, the blurred image's write and its 2.5-fold re-read, and -- in the two-stream step -- the kernel the pyramid's
 // k_resize launches stretched most (3.5 -> 9.0 ms).
+// What bounds it at 11 ms (timing builds, call S): its stores -- 8.2 ms without the dense T plane, 8.2 ms without the sparse Cs / S planes; the table gathers cost 0.7 ms, more raw rows in flight nothing.
 // BORDER_REFLECT_101: rows through reflect_row; columns only touch the row's first lane (c0 = 0: raw columns -2, -1 = 2, 1) and its last one (c0 = w - 5: columns w .. w + 3
 // = w - 2 .. w - 5), each fixed with one v_perm on in-range dwords.
 struct Raw16 { unsigned v[4]; };
