@@ -106,6 +106,16 @@ def test_lines_huge_regions(fe, ctx, oracle):
     assert n >= 1
 
 
+@pytest.mark.parametrize("knobs", [{"SSLAM_LSD_FUSED": "0"}, {"SSLAM_LSD_SORT_RUNS": "0"}, {"SSLAM_LSD_FUSED": "0", "SSLAM_LSD_SORT_RUNS": "0"}, {"SSLAM_LSD_SPILLFREE": "0"}])
+def test_line_prologue_forms(fe, ctx, oracle, knobs, monkeypatch):
+    """Round 6 gave the line prologue new kernels that cover the common geometries only: the pre-blur evaluated inside the gradient kernel (k_lsd_grad_fused: w = 5m, sw = 4m,
+    h = 5n, sh = 4n) and the counting sort on tile-sorted runs (k_lsd_hist_sort + k_lsd_scatter_runs: scaled images up to 2048 x 2048); the round-1-5 kernels remain behind them.
+    Each older form (and the six-wave instantiation of the core for small calls) is forced here over frames of both kinds of geometry and compared with the oracle, as the default is everywhere else."""
+    for k, v in knobs.items(): monkeypatch.setenv(k, v)
+    for img, cap in [(synth_frame(2000), 200), (synth_frame(1235, w=1280, h=960), 400), (noise_frame(3, w=320, h=240), 200), (synth_frame(91, w=333, h=251), 200)]:
+        _cmp_lines(fe, ctx, oracle, img, cap)
+
+
 @pytest.mark.parametrize("flavour", ["cl", "lat", "thr"])
 def test_lsd_core_flavours(fe, ctx, oracle, flavour, monkeypatch):
     """The sequential core has three launch forms (lsd_regions.h, lsd_cluster.h): cluster (main wave + helper waves on several compute units,
