@@ -128,7 +128,7 @@ def test_batch_of_2176_frames_throughput_kernels(fe, ctx, oracle, form, monkeypa
     form "guest" (round 6): the two-stream step with a core event announced and a persistent grid of 136 workgroups (SSLAM_LSD_PERSIST; the library's own grid, 16 per
     compute unit, would be larger than this batch) -- k_lsd_regions<false, 4> claiming its 2 176 frames dynamically, the pyramid built ahead of the event, FAST .. gated on it."""
     pipeline = pkg._load("sslam_pipeline", os.path.join(pkg.PKG_DIR, "pipeline.py"))
-    w, h, U, REP = 192, 144, 17, 128
+    w, h, U, REP = (240, 180, 17, 128) if form == "guest" else (192, 144, 17, 128)      # 240 x 180 is a 5-to-4 geometry (fused gradient kernel), 192 x 144 is not (k_blur7 + k_lsd_grad)
     B = U * REP
     frames = [synth_frame(5000 + i, w, h, nshapes=8 + 3 * i, nstrokes=2 * i, noise=float(i % 3)) for i in range(U)]
     if form == "guest": monkeypatch.setenv("SSLAM_LSD_PERSIST", "136")      # (& ~7 = 136 workgroups: 16 rounds of this batch)
