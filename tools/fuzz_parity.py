@@ -10,6 +10,7 @@ from synth import synth_frame, noise_frame
 def cases(n, rng):
     for it in range(n):
         w = int(rng.integers(96, 900)); h = int(rng.integers(80, 700))
+        if it % 3 == 0: w, h = (w // 20) * 20, (h // 5) * 5      # every third case a 5-to-4 geometry (w = 5m, 4 | m): the fused gradient kernel of round 6; the others take k_blur7 + k_lsd_grad
         seed = int(rng.integers(0, 1 << 30))
         kind = rng.random()
         if kind < 0.1: img = noise_frame(seed, w, h)
