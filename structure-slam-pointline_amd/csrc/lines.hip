@@ -389,13 +389,13 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
                        !(getenv("SSLAM_LSD_FUSED") && atoi(getenv("SSLAM_LSD_FUSED")) == 0);
     if (fused) {
       sslam::ProfScope _ps(L->ctx, "k_lsd_grad", st);
-      const dim3 gg(P.nXB, (P.sh + 31) / 32, nframes);
+      const dim3 gg(P.nXB, (P.sh + 31) / 32, nframes);      // (frame-walking workgroups -- a grid of 1 024 / 2 048 -- were measured for this kernel too, call U: 171 / 175 ms per step against 158; the kernel keeps its frame loop, the grid covers the batch)
       const int* tabX = L->dTabs.as<int>() + P.tabX; const int* tabY = L->dTabs.as<int>() + P.tabY;
       switch ((P.lsdResize ? 1 : 0) | (L->seedOrder ? 2 : 0)) {
-          case 0: hipLaunchKernelGGL(k_lsd_grad_fused<0>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps); break;
-          case 1: hipLaunchKernelGGL(k_lsd_grad_fused<1>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps); break;
-          case 2: hipLaunchKernelGGL(k_lsd_grad_fused<2>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps); break;
-          default: hipLaunchKernelGGL(k_lsd_grad_fused<3>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps); break;
+          case 0: hipLaunchKernelGGL(k_lsd_grad_fused<0>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps, nframes); break;
+          case 1: hipLaunchKernelGGL(k_lsd_grad_fused<1>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps, nframes); break;
+          case 2: hipLaunchKernelGGL(k_lsd_grad_fused<2>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps, nframes); break;
+          default: hipLaunchKernelGGL(k_lsd_grad_fused<3>, gg, dim3(64, 4), 0, st, d_images, pitch, image_stride, ws, P, L->dGtab.as<float4>(), tabX, tabY, taps, nframes); break;
       }
     } else {
     { sslam::ProfScope _ps(L->ctx, "k_blur7", st); hipLaunchKernelGGL(k_blur7, dim3((((w + 3) / 4) * ((h + STRIP - 1) / STRIP) + 255) / 256, nframes), dim3(256), 0, st, d_images, pitch, image_stride,

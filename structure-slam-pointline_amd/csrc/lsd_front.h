@@ -311,9 +311,11 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ ws
 struct Raw16 { unsigned v[4]; };
 template <int MODE>
 __global__ __launch_bounds__(256) void k_lsd_grad_fused(const uint8_t* __restrict__ img, size_t ipitch, size_t iframe, const uint8_t* __restrict__ ws, LsdPlan P,
-                                                        const float4* __restrict__ gtab, const int* __restrict__ tx, const int* __restrict__ ty, const int* __restrict__ tapsArr) {
+                                                        const float4* __restrict__ gtab, const int* __restrict__ tx, const int* __restrict__ ty, const int* __restrict__ tapsArr, int nframes) {
     constexpr bool LIN = (MODE & 1) != 0, DENSE = (MODE & 2) != 0;
-    const int b = blockIdx.z;
+    // gridDim.z may be smaller than the batch: the workgroups then walk the frames with that stride (lines.hip: a grid the chip holds at once, so that another stream's
+    // kernels are dispatched beside this one and not behind its last workgroup)
+    for (int b = blockIdx.z; b < nframes; b += gridDim.z) {
     const uint8_t* base = ws + (size_t)b * P.frameBytes;
     const uint8_t* src = img + (size_t)b * iframe;
     float* T = (float*)(base + P.offT);
@@ -469,6 +471,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad_fused(const uint8_t* __restric
     }
     smax = wave_max(smax);
     if (lane == 0 && smax > 0) atomicMax(&misc->maxS, smax);
+    }
 }
 
 __device__ __forceinline__ int lsd_bin(int s, double binCoef) {

@@ -116,15 +116,15 @@ __device__ __forceinline__ unsigned pick2(unsigned d0, unsigned d1, unsigned d2,
 // behind its LAST row (the caller's image: behind any other row lies the next one), so a group of the last source row whose three dwords would reach past the pitch takes
 // the byte path.  (Guarding every row put one byte-path lane into almost every wave: 8.9 -> 9.6 ms per 12 288 frames, GPU call B.)
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, size_t srcStride, int srcPitch, int srcGuard, uint8_t* __restrict__ pyr, size_t pyrFrame,
-                                                LevelInfo S, LevelInfo D, const short4* __restrict__ tabs) {
-    const int b = blockIdx.y;
+                                                LevelInfo S, LevelInfo D, const short4* __restrict__ tabs, int nframes) {
+    for (int b = blockIdx.y; b < nframes; b += gridDim.y) {      // gridDim.y may be smaller than the batch: the workgroups walk the frames, and what follows up to the loads is loop-invariant (the compiler hoists it)
     const int ngroups = (D.w + 3) >> 2;                 // flattened (row, 4-pixel group) index: full waves whatever the level width
     const int t = blockIdx.x * 256 + threadIdx.x;
     // t / ngroups without the ~35-instruction division: the quotient of the float product is off by at most one for t < 2^24
     int y = (int)((float)t * D.rcpGroups);
     { const int r = t - __mul24(y, ngroups); y += r >= ngroups ? 1 : (r < 0 ? -1 : 0); }
     const int x4 = (t - __mul24(y, ngroups)) * 4;
-    if (y >= D.h) return;
+    if (y >= D.h) return;                               // (the same for every frame)
     const short4 ty = tabs[D.tabY + y];
     const uint4 ta = *(const uint4*)(tabs + D.tabX + x4), tb = *(const uint4*)(tabs + D.tabX + x4 + 2);
     const int sy0 = min(max((int)ty.x, 0), S.h - 1), sy1 = min(max((int)ty.x + 1, 0), S.h - 1);
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         }
     }
     *(unsigned*)(pyr + (size_t)b * pyrFrame + D.off + (size_t)y * D.pitch + x4) = out;   // pitch%64==0, pad columns are scratch
+    }
 }
 
 // ------------------------------------------------------------------ FAST per cell
@@ -1213,11 +1214,19 @@ extern "C" int sslam_orb_extract_batch_dev(sslam_orb* o, const uint8_t* d_images
         { sslam::ProfScope _ps(o->ctx, "k_copy_level0", st); hipLaunchKernelGGL(k_copy_level0, grd, blk, 0, st, d_images, pitch, image_stride, pyr, P.pyrFrame, w, h, P.L[0].pitch); }
     }
     for (int l = 1; l < P.nlevels; ++l) {
-        dim3 blk(256), grd((((P.L[l].w + 3) / 4) * P.L[l].h + 255) / 256, nframes);
+        const unsigned gx = (unsigned)((((P.L[l].w + 3) / 4) * P.L[l].h + 255) / 256);
+        // Workgroups WALK THE FRAMES (round 6): everything a thread derives from its four output columns and its row -- three table entries, the source window, the byte
+        // selectors and coefficient pairs -- is the same for every frame of the batch, so a grid of ~32 workgroups per compute unit whose workgroups step through the frames
+        // computes it once: 9.0 -> 6.0 ms for the seven launches alone (10.2 -> 6.0 in the harness of call V), the two-stream step 158.3 -> 153.7 ms.
+        // SSLAM_RESIZE_GRID_WGS=n: about n workgroups per launch (0: one per frame and tile, the form of rounds 1-5).
+        int wantWgs = 32 * o->ctx->num_cus;
+        if (const char* e = getenv("SSLAM_RESIZE_GRID_WGS")) wantWgs = atoi(e);
+        const int gy = wantWgs > 0 ? std::max(1, std::min(nframes, wantWgs / (int)std::max(gx, 1u))) : nframes;
+        dim3 blk(256), grd(gx, gy);
         const bool fromImage = l == 1 && inPlace;
         { sslam::ProfScope _ps(o->ctx, "k_resize", st);
           hipLaunchKernelGGL(k_resize, grd, blk, 0, st, fromImage ? d_images : pyr + P.L[l - 1].off, fromImage ? image_stride : P.pyrFrame, fromImage ? (int)pitch : P.L[l - 1].pitch, fromImage ? 1 : 0,
-                             pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short4>()); }
+                             pyr, P.pyrFrame, P.L[l - 1], P.L[l], o->dTabs.as<short4>(), nframes); }
     }
     if (o->gateEvent) SSLAM_HIP(hipStreamWaitEvent(st, o->gateEvent, 0));      // sslam_orb_set_gate_event: the pyramid is built ahead, the rest waits (e.g. for the line branch's sequential core)
     if (P.nCellsFrame > 0) {
