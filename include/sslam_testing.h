@@ -32,6 +32,11 @@ int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long long* disag
  * mismatches_out[0] = divisions that differ, mismatches_out[1] = angles that differ. */
 int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long long mismatches_out[2]);
 
+/* k_lbd's walk rounds a coordinate with ONE conversion (v_cvt_rpi_i32_f32 = floor(x + 0.5)) where BinaryDescriptor::computeLBD has (short)round(x) under a clamp to the image
+ * (OpenCV line_descriptor binary_descriptor.cpp, reached from src/ExtractLineSegment.cpp:53): every float bit pattern of the coordinate range, against the previous
+ * instruction sequence under the clamps (mismatches_out[0]) and against roundf for x >= 0 (mismatches_out[1]).  Both must be 0. */
+int sslam_selftest_lbd_round(sslam_ctx* ctx, long long mismatches_out[2]);
+
 /* Profiling aid (no reference counterpart): the chip's issue rate for one kind of vector instruction (0: v_add_u32, 1: v_fma_f32,
  * 2: v_add_f64, 3: v_bcnt_u32_b32), 16 independent instructions per lane and round with 8 waves per SIMD resident: wave-instructions per
  * second in units of 1e9.  What the SQ utilisation figures of profiles/README.md are priced against. */

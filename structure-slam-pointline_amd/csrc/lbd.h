@@ -205,9 +205,69 @@ __constant__ float kGaussL2[21];      // kGaussL[j] * kGaussL[j], rounded once (
 __constant__ float kGaussG[63];
 __constant__ signed char kComb[64];
 
+// Round 6, the walk's instruction count (25 vector instructions per step and row before; no gain while the vector L1 was the limit, see k_lbd):
+//   * (int)roundf(x) clamped to [0, W] is ONE conversion + ONE median: v_cvt_rpi_i32_f32 is floor(x + 0.5) evaluated exactly -- for x >= 0 that IS round-half-away, for x < 0
+//     both are <= 0 and the clamp makes them 0 -- (sslam_selftest_lbd_round compares it with the previous form on every float of the coordinate range).  The reference's
+//     (short) cast is the identity while |x| < 32 768, i.e. for images of up to 16 384 pixels a side (a walk stays within half a line length + 32 of the image); larger
+//     images take the previous form (RPI = false).
+//   * (gDL, gDO) = (dx dL0 + dy dL1, dy dL0 - dx dL1) as two packed multiplies whose operand halves are picked by op_sel and ONE packed add with a negated upper half;
+//     min(g, 0) = g - max(g, 0) (exact: g - g = +0, g - 0 = g; a zero of either sign leaves the sums, which never leave +0 .. +inf, unchanged): 10 instructions per step
+//     instead of 12, 7 instead of 13 for the coordinates.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int cvt_rpi(float x) { int r; asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+// (a.x * b.x, a.y * b.x) and (a.y * b.y, a.x * b.y)
+__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_mul_hi_swapped(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// (a.x + b.x, a.y - b.y)
+__device__ __forceinline__ f32x2 pk_add_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// max(x, 0) and the clamp to [0, hi] as the one instruction each is (behind an asm result the compiler canonicalises before fmaxf -- a v_max x, x per operand --, and it
+// cannot prove 0 <= hi for a run-time hi, so min(max()) stays two instructions)
+__device__ __forceinline__ float max0(float x) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ int med3_0(int x, int hi) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi)); return r; }
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+#ifdef SSLAM_TESTING
+// sslam_selftest_lbd_round: every float bit pattern with |x| < 24 608 (= 16 384 + 8 192 + 32: what a walk can reach on the largest image the RPI form is used for), the
+// conversion form against the previous one under the clamps [0, W] for three W, and against roundf itself for x >= 0.  Both counters must come back 0.
+__global__ __launch_bounds__(256) void k_selftest_lbd_round(unsigned long long* __restrict__ bad) {
+    unsigned long long nb0 = 0, nb1 = 0;
+    const unsigned base = (blockIdx.x * 256u + threadIdx.x) << 8;
+    for (unsigned i = 0; i < 256u; ++i) {
+        const float x = __uint_as_float(base + i);
+        if (!(fabsf(x) < 24608.f)) continue;
+        const int t = (int)__fadd_rn(x, x);
+        const int o = (int)(short)((t + 1) >> 1), n = cvt_rpi(x);
+        const int Ws[3] = {0, 639, 16383};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) nb0 += (min(max(o, 0), Ws[k]) != min(max(n, 0), Ws[k])) ? 1 : 0;
+        if (x >= 0.f) nb1 += (n != (int)roundf(x)) ? 1 : 0;
+    }
+    if (nb0) atomicAdd(bad, nb0);
+    if (nb1) atomicAdd(bad + 1, nb1);
+}
+#endif
+// The walk runs in blocks of LBD_TB steps with the gathers TRANSPOSED through LDS (round 6).  With a lane per row, one gather instruction read one step of all 63 rows: for a
+// horizontal line that is one column of 63 image rows = 63 different 64-byte lines, 38 on average over the bench's lines -- and the kernel ran at the vector L1's one line
+// per cycle (~500 k line accesses per frame, 37 % of the L1's cycles in tag-conflict stalls: profiles/r05l_tcp_counters.txt), not at the vector pipes' rate (a third fewer
+// instructions per step changed nothing: 10.2 -> 10.1 ms, GPU call W).  Here every lane still walks ITS row (the coordinates are sequential float additions, as the reference
+// has them) but only writes the byte offsets of a block into LDS; the gathers then run over the block in a lane mapping chosen per line -- 2^lgS consecutive steps of
+// 64 >> lgS rows per instruction, lgS minimising the image rows an instruction touches (8 steps x 8 rows for a horizontal line: 8 .. 16 lines instead of 63; one step x 64 rows
+// for a vertical one, as before) --, park their dwords in LDS, and every lane reads its row's values back in step order for the sums, whose order is unchanged.  One wave: its
+// LDS operations execute in program order, so the phases need no barrier, and the next block's gathers are in flight while a block is summed.
+// Measured per 12 288 frames (GPU calls X, Y): a gather per step 9.9 - 10.2 ms; blocks of 4 / 8 / 16 steps 10.1 / 8.6 / 9.9 ms (16: 9 KB of LDS, four waves per SIMD).
+// Measured earlier and not kept: a plane pitch with an odd number of lines per row (10.3 -> 10.0 ms, but k_blur_sobel 6.2 -> 6.9); the per-line set-up (fp64 cos / sin, the
+// region's corner: 260 vector instructions per line) moved into k_keylines and read back with scalar loads (10.3 -> 11.1 ms); a clamp-free walk for support regions inside
+// the image (no gain, and its first form faulted on the steps past a line's end).
+constexpr int LBD_TB = 8;
+template <bool RPI>
 __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdPlan P, const sslam_keyline* __restrict__ kls,
                                             const int* __restrict__ counts, uint8_t* __restrict__ descOut, int cap) {
-    __shared__ float rows[8][64];       // pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 per row
+    constexpr int TB = LBD_TB, TN = TB, TP = TB + 1;            // TP: LDS pitch of a row's block (odd: lanes a row apart fall into different banks)
+    __shared__ unsigned tbuf[2][64 * TP];                       // [0]: byte offsets (row, step); [1]: gathered dwords
+    float (*rows)[64] = (float (*)[64])&tbuf[0][0];             // after the walk: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 per row (8 x 64 floats <= 2 x 64 x TP)
+    static_assert(8 * 64 <= 2 * 64 * TP, "rows[][] lies over the walk's two block arrays");
     __shared__ float band[8][NUM_BANDS];
     __shared__ float des[72];
     const int li = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
@@ -221,71 +281,108 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
     const float midY = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveY, kl.ePointInOctaveY));
     const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);      // D5
     const float dO0 = -dL1, dO1 = dL0;
-    // (A pitch of the gradient plane with an odd number of 64-byte lines per row -- k_lbd spends 37 % of the vector L1's cycles in tag-conflict stalls when 63 lanes read one
-    // column of 63 rows 40 lines apart -- was measured in round 5, GPU call M: conflicts 37 -> 30 %, k_lbd 10.3 -> 10.0 ms, k_blur_sobel 6.2 -> 6.9 ms.  Not kept.)
-    // What bounds this kernel is the vector L1, not the vector pipes (round 5, profiles/r05l_tcp_counters.txt): a gather touches 38 different 64-byte lines on average (63 for a
-    // horizontal line: one column of 63 rows), ~500 k line accesses per frame = more than one per L1 per cycle of the kernel, 37 % of the L1's cycles in tag-conflict stalls.
-    // Measured and not kept: a plane pitch with an odd number of lines per row (conflicts 37 -> 30 %, k_lbd 10.3 -> 10.0 ms, but k_blur_sobel 6.2 -> 6.9 ms); the per-line set-up
-    // (fp64 cos / sin, the region's corner: 260 vector instructions per line) moved into k_keylines and read back with scalar loads: 10.3 -> 11.1 ms.
     const int realWidth = P.w, imageWidth = P.w - 1, imageHeight = P.h - 1;
-    if (lane < LSP_H) {
-        // row start: sCor0 after `lane` steps of (sCorX0 -= dL1, sCorY0 += dL0), sequential float ops
+    {
+        const int rl = min(lane, LSP_H - 1);                // (lane 63 walks row 62 once more: the transposed gathers want 64 rows of valid offsets; its sums are never read)
         float sx0 = __fadd_rn(__fadd_rn(__fmul_rn(-dL0, (float)halfWidth), __fmul_rn(dL1, (float)halfHeight)), midX);
         float sy0 = __fadd_rn(__fsub_rn(__fmul_rn(-dL1, (float)halfWidth), __fmul_rn(dL0, (float)halfHeight)), midY);
-        float ndL1 = -dL1;                              // x - y == x + (-y) bit for bit: both coordinates step by an addition, one packed instruction
-        asm volatile("" : "+v"(ndL1));                  // (opaque, or the compiler turns it back into a subtraction and issues a packed add AND a packed subtract per step)
-        for (int r = 0; r < lane; ++r) { sx0 = __fadd_rn(sx0, ndL1); sy0 = __fadd_rn(sy0, dL0); }
+        // row start: sCor0 after `lane` steps of (sCorX0 -= dL1, sCorY0 += dL0), sequential float operations; x - y == x + (-y) bit for bit
+        float ndL1 = -dL1;
+        asm volatile("" : "+v"(ndL1));                      // (opaque, or the compiler turns the addition back into a subtraction)
+        {
+            f32x2 s0 = {sx0, sy0}; const f32x2 dRow = {ndL1, dL0};
+            for (int r = 0; r < rl; ++r) s0 = pk_add(s0, dRow);      // (both coordinates step by an addition: one packed instruction per row)
+            sx0 = s0.x; sy0 = s0.y;
+        }
         float sx = sx0, sy = sy0;
         float pL = 0, nL = 0, pO = 0, nO = 0;
-        // The walk's coordinates do not depend on what is gathered: the eight gathers of the NEXT group of steps are issued before the current
-        // group is consumed (two register sets, two groups per trip), so a wave waits for memory once per line, not once per eight steps
-        auto issue = [&](unsigned (&g)[8]) {
-            // coordinates of eight consecutive steps (the float walk itself stays sequential), then the eight gathers together.  (The last group of a line runs up to seven
-            // steps past its end: loaded, never consumed -- the clamp keeps them addressable.  A clamp-free walk for support regions inside the image was measured in round 5,
-            // GPU calls G-I: no gain, and its first form faulted on exactly those steps; removed.)
-            unsigned off8[8];
+        f32x2 accP = {0.f, 0.f}, accN = {0.f, 0.f};
+        const f32x2 dLv = {dL0, dL1};
+        // steps per gather instruction: 2^lgS (<= TB), rows: 64 >> lgS; an instruction touches about 2^lgS |dL1| + (64 >> lgS) |dL0| image rows
+        int lgS = 0;
+        {
+            float best = 3.0e38f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                // (int)roundf(x) without the seven-instruction round-half-away sequence: 2x is exact, t = trunc(2x), and round-half-away(x) = sign(x) * ((|t| + 1) >> 1)
-                // = (t + 1) >> 1 for t >= 0 and t >> 1 (= floor(t / 2) = -ceil(|t| / 2)) for t < 0, i.e. (t + 1 + (t >> 31)) >> 1 -- every |x| < 2^30.  The reference's
-                // (short) cast and its clamp "tc < 0 ? 0 : tc > W ? W : tc" are a sign extension and a median of three.
-                // Round 5: the sign term is dropped -- for t < 0 both (t + 1 + (t >> 31)) >> 1 and (t + 1) >> 1 are <= 0 (t = -1: 0 and 0; t <= -2: both negative), and the
-                // clamp below turns every value <= 0 into 0; for t >= 0 the term is 0.
+            for (int c = 0; (1 << c) <= TB; ++c) {
+                const float cost = __fadd_rn(__fmul_rn((float)(1 << c), fabsf(dL1)), __fmul_rn((float)(64 >> c), fabsf(dL0)));
+                if (cost < best) { best = cost; lgS = c; }
+            }
+        }
+        lgS = __builtin_amdgcn_readfirstlane(lgS);
+        const int S = 1 << lgS, R = 64 >> lgS;
+        const unsigned laneIdx = (unsigned)(((lane >> lgS) * TP + (lane & (S - 1))) * 4);       // byte address of this lane's element of instruction 0 inside a block array
+        // instruction k of a block (TB of them): row group k & (S - 1) (rows from (k & (S - 1)) * R), step group k >> lgS (steps from (k >> lgS) * S)
+        unsigned ko[TN];                                    // (wave-uniform: scalar registers, computed once per line)
+#pragma unroll
+        for (int k = 0; k < TN; ++k) ko[k] = (unsigned)__builtin_amdgcn_readfirstlane((((k & (S - 1)) * R) * TP + ((k >> lgS) << lgS)) * 4);
+        auto kofs = [&](int k) -> unsigned { return ko[k]; };
+        // one wave: its LDS operations execute in program order, so the phases need no barrier (and no wait for the gathers in flight, which __syncthreads would bring) --
+        // only that the compiler keeps the order
+        auto lds_order = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+        char* offB = (char*)&tbuf[0][0]; char* valB = (char*)&tbuf[1][0];
+        unsigned g[TN];
+        auto offsets = [&]() {                              // the next TB steps of my row -> tbuf[0][lane][0 .. TB)
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                // RPI = false, (int)roundf(x) without the seven-instruction round-half-away sequence: 2x is exact, t = trunc(2x), and round-half-away(x) = (t + 1) >> 1 for
+                // t >= 0; for t < 0 both that and the exact form are <= 0 and the clamp below makes them 0.  The reference's (short) cast and its clamp
+                // "tc < 0 ? 0 : tc > W ? W : tc" are a sign extension and a median of three.
                 auto rnd = [](float x) -> int { const int t = (int)__fadd_rn(x, x); return (t + 1) >> 1; };
-                const int xCor = min(max((int)(short)rnd(sx), 0), imageWidth);
-                const int yCor = min(max((int)(short)rnd(sy), 0), imageHeight);
-                off8[u] = (__umul24((unsigned)yCor, (unsigned)realWidth) + (unsigned)xCor) << 2;      // byte offset: both factors < 2^16 (v_mad_u32_u24 instead of a 64-bit multiply-add)
+                const int xCor = RPI ? med3_0(cvt_rpi(sx), imageWidth) : min(max((int)(short)rnd(sx), 0), imageWidth);
+                const int yCor = RPI ? med3_0(cvt_rpi(sy), imageHeight) : min(max((int)(short)rnd(sy), 0), imageHeight);
+                tbuf[0][lane * TP + u] = (__umul24((unsigned)yCor, (unsigned)realWidth) + (unsigned)xCor) << 2;
                 sx = __fadd_rn(sx, dL0); sy = __fadd_rn(sy, dL1);
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) g[u] = *(const unsigned*)((const char*)dxyImg + off8[u]);      // wave-uniform base + 32-bit offset
         };
-        auto consume = [&](const unsigned (&g)[8], int w0) {
-            // a group that lies wholly inside the line (all but the last one) takes the straight-line form: the per-step test is wave-uniform but a branch per step
-            // keeps the scheduler from interleaving the steps' independent multiplications
-            const bool whole = w0 + 8 <= lengthOfLSP;
+        auto issue = [&]() {                                // the block's TB gathers in the transposed mapping (steps past the line's end: loaded, never consumed; the clamp keeps them addressable)
+            unsigned o[TN];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int k = 0; k < TB; ++k) o[k] = *(const unsigned*)(offB + laneIdx + kofs(k));
+#pragma unroll
+            for (int k = 0; k < TB; ++k) g[k] = *(const unsigned*)((const char*)dxyImg + o[k]);
+        };
+        auto park = [&]() {
+#pragma unroll
+            for (int k = 0; k < TB; ++k) *(unsigned*)(valB + laneIdx + kofs(k)) = g[k];
+        };
+        auto consume = [&](int w0) {
+            unsigned v[TN];
+#pragma unroll
+            for (int u = 0; u < TB; ++u) v[u] = tbuf[1][lane * TP + u];
+            const bool whole = w0 + TB <= lengthOfLSP;
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
                 if (whole || w0 + u < lengthOfLSP) {
-                    const float dx = (float)(short)(g[u] & 0xFFFFu), dy = (float)(short)(g[u] >> 16);
-                    const float gDL = __fadd_rn(__fmul_rn(dx, dL0), __fmul_rn(dy, dL1));
-                    const float gDO = __fadd_rn(__fmul_rn(dx, dO0), __fmul_rn(dy, dO1));
+                    const float dx = (float)(short)(v[u] & 0xFFFFu), dy = (float)(short)(v[u] >> 16);
                     // "if (g > 0) p += g; else n -= g" without the branch: the side that is not taken adds / subtracts a zero, which leaves a sum that started at +0 and only
                     // ever took non-negative addends unchanged bit for bit (x + (+-0) == x; +0 + (+-0) == +0 under round-to-nearest)
-                    pL = __fadd_rn(pL, fmaxf(gDL, 0.f)); nL = __fsub_rn(nL, fminf(gDL, 0.f));
-                    pO = __fadd_rn(pO, fmaxf(gDO, 0.f)); nO = __fsub_rn(nO, fminf(gDO, 0.f));
+                    if (RPI) {
+                        const f32x2 d = {dx, dy};
+                        const f32x2 G = pk_add_sub(pk_mul_lo(d, dLv), pk_mul_hi_swapped(d, dLv));      // (gDL, gDO)
+                        const f32x2 M = {max0(G.x), max0(G.y)};
+                        accP = pk_add(accP, M); accN = pk_sub(accN, pk_sub(G, M));
+                    } else {
+                        const float gDL = __fadd_rn(__fmul_rn(dx, dL0), __fmul_rn(dy, dL1));
+                        const float gDO = __fadd_rn(__fmul_rn(dx, dO0), __fmul_rn(dy, dO1));
+                        pL = __fadd_rn(pL, fmaxf(gDL, 0.f)); nL = __fsub_rn(nL, fminf(gDL, 0.f));
+                        pO = __fadd_rn(pO, fmaxf(gDO, 0.f)); nO = __fsub_rn(nO, fminf(gDO, 0.f));
+                    }
                 }
             }
         };
-        unsigned gA[8], gB[8];
-        if (lengthOfLSP > 0) issue(gA);
-        for (int w0 = 0; w0 < lengthOfLSP; w0 += 16) {
-            if (w0 + 8 < lengthOfLSP) issue(gB);
-            consume(gA, w0);
-            if (w0 + 16 < lengthOfLSP) issue(gA);
-            if (w0 + 8 < lengthOfLSP) consume(gB, w0 + 8);
+        if (lengthOfLSP > 0) { offsets(); lds_order(); issue(); }
+        for (int w0 = 0; w0 < lengthOfLSP; w0 += TB) {
+            const bool more = w0 + TB < lengthOfLSP;
+            lds_order();                                    // (the previous block's reads of tbuf[1], this block's reads of tbuf[0]: before they are overwritten)
+            if (more) offsets();
+            park();
+            lds_order();
+            if (more) issue();
+            consume(w0);
         }
-        const float cg = kGaussG[lane];
+        __syncthreads();                                    // rows[][] lies over tbuf
+        if (RPI) { pL = accP.x; pO = accP.y; nL = accN.x; nO = accN.y; }
+        const float cg = kGaussG[rl];
         pL = __fmul_rn(cg, pL); nL = __fmul_rn(cg, nL); pO = __fmul_rn(cg, pO); nO = __fmul_rn(cg, nO);
         rows[0][lane] = pL; rows[1][lane] = nL; rows[2][lane] = __fmul_rn(pL, pL); rows[3][lane] = __fmul_rn(nL, nL);
         rows[4][lane] = pO; rows[5][lane] = nO; rows[6][lane] = __fmul_rn(pO, pO); rows[7][lane] = __fmul_rn(nO, nO);
@@ -329,12 +426,15 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
     __syncthreads();
     // normalise means / stds separately, clip at 0.4, renormalise: sequential sums (every lane redundantly)
     float tempM = 0, tempS = 0;
-    for (int bd = 0; bd < NUM_BANDS; ++bd) {
-        const float* d = des + bd * 8;
-        tempM = __fadd_rn(tempM, __fmul_rn(d[0], d[0])); tempM = __fadd_rn(tempM, __fmul_rn(d[1], d[1]));
-        tempM = __fadd_rn(tempM, __fmul_rn(d[2], d[2])); tempM = __fadd_rn(tempM, __fmul_rn(d[3], d[3]));
-        tempS = __fadd_rn(tempS, __fmul_rn(d[4], d[4])); tempS = __fadd_rn(tempS, __fmul_rn(d[5], d[5]));
-        tempS = __fadd_rn(tempS, __fmul_rn(d[6], d[6])); tempS = __fadd_rn(tempS, __fmul_rn(d[7], d[7]));
+    {   // the two sums advance in lockstep (means d[0..3], deviations d[4..7] of a band): one packed multiply and one packed add per pair (d[i], d[i + 4]), each sum in its own order
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int bd = 0; bd < NUM_BANDS; ++bd) {
+            const float* d = des + bd * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const f32x2 v = {d[i], d[i + 4]}; acc = pk_add(acc, pk_mul(v, v)); }
+        }
+        tempM = acc.x; tempS = acc.y;
     }
     tempM = __fdiv_rn(1.f, sqrtf(tempM)); tempS = __fdiv_rn(1.f, sqrtf(tempS));
     __syncthreads();
@@ -346,7 +446,11 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
     }
     __syncthreads();
     float temp = 0;
-    for (int i = 0; i < 72; ++i) temp = __fadd_rn(temp, __fmul_rn(des[i], des[i]));
+#pragma unroll
+    for (int i = 0; i < 72; i += 2) {       // squares two at a time (packed), the sum in index order
+        const f32x2 v = {des[i], des[i + 1]}; const f32x2 q = pk_mul(v, v);
+        temp = __fadd_rn(temp, q.x); temp = __fadd_rn(temp, q.y);
+    }
     temp = __fdiv_rn(1.f, sqrtf(temp));
     __syncthreads();
     for (int i = lane; i < 72; i += 64) des[i] = __fmul_rn(des[i], temp);

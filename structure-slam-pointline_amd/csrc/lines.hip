@@ -538,7 +538,14 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
     // LBD: blur(5, 1) + Sobel fused (SSLAM_LBD_SOBEL=early: in the prologue) -> bands
     if (!sobelDone) launch_blur_sobel(st);
     side.join();
-    { sslam::ProfScope _ps(L->ctx, "k_lbd", st); hipLaunchKernelGGL(k_lbd, dim3(std::min(L->maxLines, cap), nframes), dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap); }
+    {   // the walk's conversion form (lbd.h): images of up to 16 384 pixels a side; SSLAM_LBD_RPI=0 forces the previous form (A/B, tests)
+        const bool rpiOff = getenv("SSLAM_LBD_RPI") && atoi(getenv("SSLAM_LBD_RPI")) == 0;
+        const bool rpi = !rpiOff && P.w <= 16384 && P.h <= 16384;
+        sslam::ProfScope _ps(L->ctx, "k_lbd", st);
+        const dim3 grd(std::min(L->maxLines, cap), nframes);
+        if (rpi) hipLaunchKernelGGL(k_lbd<true>, grd, dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap);
+        else hipLaunchKernelGGL(k_lbd<false>, grd, dim3(64), 0, st, ws, P, d_kl, d_counts, d_ldesc, cap);
+    }
     SSLAM_HIP(hipGetLastError());
     L->lastFrames = nframes;
     return SSLAM_OK;
@@ -722,6 +729,21 @@ extern "C" int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long
     SSLAM_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     SSLAM_HIP(hipStreamSynchronize(ctx->stream));
     mismatches_out[0] = (long long)h[0]; mismatches_out[1] = (long long)h[1];      // division, atan2
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_selftest_lbd_round(sslam_ctx* ctx, long long* mismatches_out) {
+    if (!ctx || !mismatches_out) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    ScopedDev dMem;
+    SSLAM_HIP(hipMalloc(&dMem.p, 2 * sizeof(unsigned long long)));
+    unsigned long long* d = (unsigned long long*)dMem.p;
+    SSLAM_HIP(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_selftest_lbd_round, dim3(65536), dim3(256), 0, ctx->stream, d);      // 2^32 bit patterns, 256 per thread
+    unsigned long long h[2] = {0, 0};
+    SSLAM_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SSLAM_HIP(hipStreamSynchronize(ctx->stream));
+    mismatches_out[0] = (long long)h[0]; mismatches_out[1] = (long long)h[1];      // against the previous form under the clamps, against roundf for x >= 0
     return SSLAM_OK;
 }
 

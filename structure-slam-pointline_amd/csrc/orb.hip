@@ -301,22 +301,22 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                 const unsigned* rc = (const unsigned*)(tile + rowN + 3 * tileP) + g;
                 const unsigned c1 = rc[0], c0 = rc[-1], c2 = rc[1];
                 const unsigned n4 = ((const unsigned*)(tile + rowN))[g], s4 = ((const unsigned*)(tile + rowN + 6 * tileP))[g];
-                const unsigned e4 = __builtin_amdgcn_alignbyte(c2, c1, 3), w4 = __builtin_amdgcn_alignbyte(c1, c0, 1);
                 unsigned res = 0;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {                      // h = 0: bytes 0,2   h = 1: bytes 1,3
-                    // bytes h and h + 2 of a dword as two zero-extended 16-bit lanes: one v_perm each
+                    // bytes h and h + 2 of a dword as two zero-extended 16-bit lanes: one v_perm each; the east / west neighbours (three bytes to the right / left) come
+                    // straight out of the dword pairs (c2:c1 bytes 3 + h, 5 + h; c1:c0 bytes 1 + h, 3 + h) -- no v_alignbyte in between
                     const unsigned wsel = h == 0 ? 0x0c020c00u : 0x0c030c01u;
                     const s16x2 v = as_s16x2(__builtin_amdgcn_perm(0u, c1, wsel));
                     const s16x2 rn = as_s16x2(__builtin_amdgcn_perm(0u, n4, wsel)), rs = as_s16x2(__builtin_amdgcn_perm(0u, s4, wsel));
-                    const s16x2 re = as_s16x2(__builtin_amdgcn_perm(0u, e4, wsel)), rw = as_s16x2(__builtin_amdgcn_perm(0u, w4, wsel));
-                    // (N or S brighter than v + t) == max(N, S) > v + t, (N or S darker) == min(N, S) < v - t: packed max / min, then one
-                    // packed subtraction per test whose sign bit is the answer
+                    const s16x2 re = as_s16x2(__builtin_amdgcn_perm(c2, c1, h == 0 ? 0x0c050c03u : 0x0c060c04u)), rw = as_s16x2(__builtin_amdgcn_perm(c1, c0, h == 0 ? 0x0c030c01u : 0x0c040c02u));
+                    // (N or S brighter than v + t) and (E or W brighter) == min(max(N, S), max(E, W)) > v + t; darker: max(min(N, S), min(E, W)) < v - t: packed max / min,
+                    // then one packed subtraction per polarity whose sign bit is the answer
                     const s16x2 vp = v + th2, vm = v - th2;
                     const s16x2 mxV = __builtin_elementwise_max(rn, rs), mnV = __builtin_elementwise_min(rn, rs);
                     const s16x2 mxH = __builtin_elementwise_max(re, rw), mnH = __builtin_elementwise_min(re, rw);
-                    const unsigned bright = as_u32(vp - mxV) & as_u32(vp - mxH);      // sign set <=> max > v + t on both axes
-                    const unsigned dark = as_u32(mnV - vm) & as_u32(mnH - vm);        // sign set <=> min < v - t on both axes
+                    const unsigned bright = as_u32(vp - __builtin_elementwise_min(mxV, mxH));      // sign set <=> max > v + t on both axes
+                    const unsigned dark = as_u32(__builtin_elementwise_max(mnV, mnH) - vm);        // sign set <=> min < v - t on both axes
                     const unsigned m = (bright | dark) & 0x80008000u;
                     res |= m >> (15 - h);                          // bit 0+h from byte h, bit 16+h from byte 2+h
                 }

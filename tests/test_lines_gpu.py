@@ -92,6 +92,15 @@ def test_tail_test_selftest(fe, ctx):
     assert 0 < amb.value < 0.2 * n, amb.value        # half of the samples sit within 1e-3 of the boundary
 
 
+def test_lbd_rounding_selftest(fe, ctx):
+    """k_lbd<true> rounds a walk coordinate with v_cvt_rpi_i32_f32 + a median where the reference has (short)round(x) under a clamp: every float bit pattern of the coordinate
+    range, against the previous sequence under the clamps and against roundf for x >= 0 (lbd.h, k_selftest_lbd_round)"""
+    import ctypes as C
+    bad = (C.c_longlong * 2)(-1, -1)
+    rc = fe.testing_lib().sslam_selftest_lbd_round(ctx.h, bad)
+    assert rc == 0 and bad[0] == 0 and bad[1] == 0, (rc, bad[0], bad[1])
+
+
 def test_region_division_selftest(fe, ctx):
     """the accept chain's division / atan2 shortcuts must equal the plain forms bit for bit over every magnitude a region can produce"""
     import ctypes as C
@@ -106,10 +115,11 @@ def test_lines_huge_regions(fe, ctx, oracle):
     assert n >= 1
 
 
-@pytest.mark.parametrize("knobs", [{"SSLAM_LSD_FUSED": "0"}, {"SSLAM_LSD_SORT_RUNS": "0"}, {"SSLAM_LSD_FUSED": "0", "SSLAM_LSD_SORT_RUNS": "0"}, {"SSLAM_LSD_SPILLFREE": "0"}])
+@pytest.mark.parametrize("knobs", [{"SSLAM_LSD_FUSED": "0"}, {"SSLAM_LSD_SORT_RUNS": "0"}, {"SSLAM_LSD_FUSED": "0", "SSLAM_LSD_SORT_RUNS": "0"}, {"SSLAM_LSD_SPILLFREE": "0"}, {"SSLAM_LBD_RPI": "0"}])
 def test_line_prologue_forms(fe, ctx, oracle, knobs, monkeypatch):
     """Round 6 gave the line prologue new kernels that cover the common geometries only: the pre-blur evaluated inside the gradient kernel (k_lsd_grad_fused: w = 5m, sw = 4m,
     h = 5n, sh = 4n) and the counting sort on tile-sorted runs (k_lsd_hist_sort + k_lsd_scatter_runs: scaled images up to 2048 x 2048); the round-1-5 kernels remain behind them.
+    LBD's walk rounds its coordinates with one conversion instruction on images of up to 16 384 pixels a side (k_lbd<true>); the previous instruction sequence remains for larger ones.
     Each older form (and the six-wave instantiation of the core for small calls) is forced here over frames of both kinds of geometry and compared with the oracle, as the default is everywhere else."""
     for k, v in knobs.items(): monkeypatch.setenv(k, v)
     for img, cap in [(synth_frame(2000), 200), (synth_frame(1235, w=1280, h=960), 400), (noise_frame(3, w=320, h=240), 200), (synth_frame(91, w=333, h=251), 200)]:
