@@ -40,7 +40,7 @@ int launch_nfa_stage(sslam_ctx* ctx, hipStream_t st, uint8_t* ws, const void* pl
     if (const char* e = getenv("SSLAM_NFA_FUSED")) nfaFused = atoi(e) == 2 || (nfaFused && atoi(e) != 0);
     if (nfaFused) {
         sslam::ProfScope _ps(ctx, "k_nfa_all", st);
-        hipLaunchKernelGGL(k_nfa_all, dim3(nframes), dim3(64), 0, st, ws, P, lgam);
+        hipLaunchKernelGGL(k_nfa_all<768>, dim3(nframes), dim3(64), 0, st, ws, P, lgam);
     } else {
         for (int stage = 0; stage <= 4; ++stage) {
             { static const char* kCountNames[5] = {"k_nfa_count", "k_nfa_count/s1", "k_nfa_count/s2", "k_nfa_count/s3", "k_nfa_count/s4"};

@@ -154,19 +154,20 @@ __device__ __forceinline__ bool nfa_setup(int n, int k, double p, double logNT, 
 }
 
 // up to eight terms of the tail loop; true when the loop is over (early exit or i > n)
+constexpr int TBK = 8;      // terms per block (four: 20 fewer registers in the evaluator, 27.5 -> 31.3 ms under D11 = 0, GPU call AB)
 __device__ __forceinline__ bool tail_block(TailState& S, double logNT, const double* __restrict__ rcp) {
     const double tolerance = 0.1;
     const int n = S.n, i0 = S.i;
     double term = S.term, bin_tail = S.bin_tail;
-    double mt[8];
+    double mt[TBK];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {           // independent divisions: issue back to back
+    for (int j = 0; j < TBK; ++j) {           // independent divisions: issue back to back
         const int i = min(i0 + j, n);
         mt[j] = exact_div((double)(n - i + 1), (double)i, rcp[i]) * S.p_term;
     }
     bool done = false;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < TBK; ++j) {
         const int i = i0 + j;
         if (i <= n && !done) {
             term *= mt[j];
@@ -185,7 +186,7 @@ __device__ __forceinline__ bool tail_block(TailState& S, double logNT, const dou
             }
         }
     }
-    S.term = term; S.bin_tail = bin_tail; S.i = i0 + 8;
+    S.term = term; S.bin_tail = bin_tail; S.i = i0 + TBK;
     return done || S.i > n;
 }
 
@@ -352,6 +353,19 @@ __device__ __forceinline__ double align_dist_min(float aDeg, double theta) {
     return fmin(n_theta, fabs(n_theta - M_2PI_));
 }
 
+// A rectangle's geometry is the same for every lane of the wave that counts it, but it comes out of LDS, i.e. in vector registers: handed to the scalar file explicitly
+// (nine registers per candidate, forty-five in count_rect5), the row-range arithmetic takes them as scalar operands
+__device__ __forceinline__ NfaGeom geom_uniform(const NfaGeom& g) {
+    NfaGeom u;
+    u.mx = __builtin_amdgcn_readfirstlane(g.mx); u.y0 = __builtin_amdgcn_readfirstlane(g.y0); u.y1 = __builtin_amdgcn_readfirstlane(g.y1);
+    u.ly = __builtin_amdgcn_readfirstlane(g.ly); u.ry = __builtin_amdgcn_readfirstlane(g.ry); u.fl = __builtin_amdgcn_readfirstlane(g.fl);
+    u.sl = __builtin_amdgcn_readfirstlane(g.sl); u.fr = __builtin_amdgcn_readfirstlane(g.fr); u.sr = __builtin_amdgcn_readfirstlane(g.sr);
+    return u;
+}
+__device__ __forceinline__ double uniform_f64(double x) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
 // Pixel walk shared by the two counters below.  A row is shared by 2^lg lanes (lg picked per rectangle from its widest
 // row: tall thin rectangles put 32 rows in flight, flat ones spread one row over the whole wave); each lane owns a
 // contiguous run of the row and the wave steps through the runs twelve pixels at a time.
@@ -366,9 +380,10 @@ __device__ __forceinline__ unsigned t_abs_u(unsigned v) { asm volatile("" : "+v"
 struct __attribute__((packed, aligned(4))) T4 { unsigned v[4]; };      // four pixels of a row of T from any dword
 
 // aligned-point counts of one rectangle for six nested tolerances (precs[k], around theta); total = pixels visited.
-__device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const unsigned* __restrict__ Tb, int tW, int sw, bool small,
+__device__ __forceinline__ void count_item(const NfaGeom& gIn, int lg, const unsigned* __restrict__ Tb, int tW, int sw, bool small,
                                            int lane, int& totalOut, int (&alg)[6], double theta = 0, const double* precs = nullptr) {
     constexpr int K = 6;
+    const NfaGeom g = geom_uniform(gIn);
     const int nrows = g.y1 - g.y0 + 1;
     const int rowsPer = 64 >> lg, r = lane >> lg, sub = lane & ((1 << lg) - 1);
     int total = 0;
@@ -421,10 +436,10 @@ __device__ __forceinline__ void count_item(const NfaGeom& g, int lg, const unsig
 // candidate j is two integer compares against that candidate's own row range (rect_nfa's edge stepping, per candidate).
 __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int nc, int lg, const unsigned* __restrict__ Tb, int tW, int sw, bool small, int lane,
                                             int (&total)[MAXC], int (&alg)[MAXC]) {
-    const double theta = it5[0].theta, prec = it5[0].prec;
+    const double theta = uniform_f64(it5[0].theta), prec = uniform_f64(it5[0].prec);
     NfaGeom g[MAXC];
 #pragma unroll
-    for (int j = 0; j < MAXC; ++j) g[j] = it5[j < nc ? j : 0].g;
+    for (int j = 0; j < MAXC; ++j) g[j] = geom_uniform(it5[j < nc ? j : 0].g);
     int y0u = g[0].y0, y1u = g[0].y1;
 #pragma unroll
     for (int j = 1; j < MAXC; ++j) if (j < nc) { y0u = min(y0u, g[j].y0); y1u = max(y1u, g[j].y1); }
@@ -802,10 +817,14 @@ __device__ __forceinline__ void nfa_all_body(uint8_t* __restrict__ base, const L
 #ifndef SSLAM_NFA_ALL_MINWAVES
 #define SSLAM_NFA_ALL_MINWAVES 4
 #endif
+// CH: rectangles per item-list chunk = the kernel's LDS (10 bytes per rectangle): 768 -> 7.5 KB, twenty workgroups = five waves per SIMD on a compute unit's 160 KB, which the
+// 92 vector registers of the kernel allow since the rectangles' geometry moved to scalar registers (geom_uniform: 128 registers and 16 bytes of scratch before).
+// Per 12 288 frames (GPU calls AA, AB): 13.4 -> 12.5 ms (D11 = 1), 29.6 -> 27.5 (D11 = 0); six waves (80 registers, 32 - 48 bytes of scratch, chunks of 640) 12.6 / 27.8: no further gain
+template <int CH>
 __global__ __launch_bounds__(64, SSLAM_NFA_ALL_MINWAVES) void k_nfa_all(uint8_t* __restrict__ ws, LsdPlan P, const double* __restrict__ lgam) {
-    __shared__ NfaLds L;
+    __shared__ NfaLdsT<CH> L;
     const int b = xcd_mix_frame(blockIdx.x, gridDim.x);
-    nfa_all_body<EVAL_CH>(ws + (size_t)b * P.frameBytes, P, lgam, 0, 1, threadIdx.x, L);
+    nfa_all_body<CH>(ws + (size_t)b * P.frameBytes, P, lgam, 0, 1, threadIdx.x, L);
 }
 
 
