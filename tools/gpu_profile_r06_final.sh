@@ -6,7 +6,7 @@
 # the fuzzers.  Every step under its own timeout.
 #     bash tools/build_c_harnesses.sh && gpurun --timeout 2400 -- 'bash tools/gpu_profile_r06_final.sh'
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06z; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 b=12288
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -56,7 +56,7 @@ timeout 300 python tools/fuzz_matchers.py 1200 > $O/fuzz_matchers.txt 2>&1; tail
 python - <<'PY'
 import json
 try:
-    d = json.loads(open('gpurun_out/r06z/bench_r06.json').read().strip().splitlines()[-1])
+    d = json.loads(open('gpurun_out/r06final/bench_r06.json').read().strip().splitlines()[-1])
     print(round(d['value']), d['ms_per_step'], d['roofline']['bound'], d['roofline']['frac'], d['roofline']['traffic'], d['latency']['lines_extract_hipEvent'])
     print(d['roofline']['bound_note']); print({k: v for k, v in d['pcie_inclusive'].items() if 'per_s' in k}); print({k: (v.get('value'), v.get('ms_per_step')) for k, v in d.get('other_workloads', {}).items()})
     print(d['cpu_baseline']['value'], d['cpu_baseline']['ms_per_frame'], d['cpu_baseline']['parity_vs_gpu']); print(d.get('latency_nfa_behind_core'))
