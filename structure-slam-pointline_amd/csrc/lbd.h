@@ -109,6 +109,9 @@ __global__ __launch_bounds__(256) void k_keylines(uint8_t* __restrict__ ws, LsdP
         sslam_keyline k = klw[src];
         if (doSort) k.class_id = i;
         klOut[(size_t)b * cap + i] = k;
+        // the line's direction for k_lbd (D5: cos / sin in double, rounded to float), once per line by ONE lane here instead of by all 64 lanes of the line's wave there:
+        // 200 of a line's ~2 100 vector instructions (the same expressions, the same bits)
+        ((float2*)(base + P.offLbdDir))[i] = make_float2((float)cos((double)k.angle), (float)sin((double)k.angle));
         // line equation sp x ep, normalised by its first two components (ExtractLineSegment :56-68), fp64
         const double sx = k.startPointX, sy = k.startPointY, ex = k.endPointX, ey = k.endPointY;
         const double l0 = __dsub_rn(sy, ey), l1 = __dsub_rn(ex, sx), l2 = __dsub_rn(__dmul_rn(sx, ey), __dmul_rn(sy, ex));
@@ -279,7 +282,8 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
     const int halfWidth = (lengthOfLSP - 1) / 2, halfHeight = (LSP_H - 1) / 2;
     const float midX = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveX, kl.ePointInOctaveX));
     const float midY = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveY, kl.ePointInOctaveY));
-    const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);      // D5
+    const float2 dLs = ((const float2*)(base + P.offLbdDir))[li];      // (float)cos((double)kl.angle), (float)sin(..): D5, evaluated by k_keylines; a scalar load
+    const float dL0 = dLs.x, dL1 = dLs.y;
     const float dO0 = -dL1, dO1 = dL0;
     const int realWidth = P.w, imageWidth = P.w - 1, imageHeight = P.h - 1;
     {

@@ -201,6 +201,7 @@ static int lines_build_plan(sslam_lines* L, int w, int h) {
     P.offMisc = take(sizeof(Misc));
     P.offDxy = take(sizeof(unsigned) * (size_t)w * h);       // Sobel {dx, dy} of the sigma-1 blur, int16 pairs
     P.offKl = take(sizeof(sslam_keyline) * MAX_SEG);
+    P.offLbdDir = take(sizeof(float2) * MAX_SEG);            // (cos, sin) of every output line's direction: k_keylines -> k_lbd
     P.frameBytes = align_up(off, 4096);
     if (!L->dGtab.p) {   // gradient -> {angle, cos, sin, |g|^2} table (rho depends only on LSD constants), and the smallest defined |g|^2 behind it
         if ((rc = L->dGtab.ensure(sizeof(float4) * ((size_t)GT * GT + 1)))) return rc;

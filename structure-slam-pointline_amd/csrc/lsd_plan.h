@@ -41,7 +41,7 @@ struct LsdPlan {
     int sMin;                 // smallest gx^2 + gy^2 of a defined pixel (k_grad_smin)
     size_t frameBytes;        // per-frame workspace
     int tW, cW;               // row pitch (elements) of the T and Cs planes (= sw)
-    size_t offBlur, offT, offS, offCs, offCand, offFlag, offNfa, offOrder, offTileHist, offReg, offSeg, offMisc, offDxy, offKl, offSortIdx, offSegCnt, offComp, offSorted;
+    size_t offBlur, offT, offS, offCs, offCand, offFlag, offNfa, offOrder, offTileHist, offReg, offSeg, offMisc, offDxy, offKl, offSortIdx, offSegCnt, offComp, offSorted, offLbdDir;
     int blurTaps[7];          // sigma 0.75, 7 taps (q8)
     int blur5Taps[5];         // sigma 1, 5 taps (q8)
     int tabX, tabY;           // offsets into the resize table (int: ofs, c1)
