@@ -257,20 +257,22 @@ __global__ __launch_bounds__(256) void k_selftest_lbd_round(unsigned long long* 
 // instructions per step changed nothing: 10.2 -> 10.1 ms, GPU call W).  Here every lane still walks ITS row (the coordinates are sequential float additions, as the reference
 // has them) but only writes the byte offsets of a block into LDS; the gathers then run over the block in a lane mapping chosen per line -- 2^lgS consecutive steps of
 // 64 >> lgS rows per instruction, lgS minimising the image rows an instruction touches (8 steps x 8 rows for a horizontal line: 8 .. 16 lines instead of 63; one step x 64 rows
-// for a vertical one, as before) --, park their dwords in LDS, and every lane reads its row's values back in step order for the sums, whose order is unchanged.  One wave: its
-// LDS operations execute in program order, so the phases need no barrier, and the next block's gathers are in flight while a block is summed.
-// Measured per 12 288 frames (GPU calls X, Y): a gather per step 9.9 - 10.2 ms; blocks of 4 / 8 / 16 steps 10.1 / 8.6 / 9.9 ms (16: 9 KB of LDS, four waves per SIMD).
+// for a vertical one, as before) --, park their dwords in LDS IN THE PLACE of the offsets, and every lane reads its row's values back in step order for the sums, whose order is
+// unchanged.  One wave: its LDS operations execute in program order, so the phases need no barrier; nothing is in flight across blocks (eight waves per SIMD cover a block's round trip:
+// a form with two arrays and the next block's gathers issued ahead measured the same, 8.5 - 8.7 ms).
+// Measured per 12 288 frames (GPU calls X, Y, AF): a gather per step 9.9 - 10.2 ms; blocks of 4 / 8 / 16 steps 10.1 / 8.5 / 8.7 - 9.9 ms.  The vector L1 still sets the pace:
+// 328 k line accesses per frame (503 k before: ~23 per gather instruction at the bench's line lengths and angles), 7.5 of the 8.5 ms at a line per cycle and compute unit.
 // Measured earlier and not kept: a plane pitch with an odd number of lines per row (10.3 -> 10.0 ms, but k_blur_sobel 6.2 -> 6.9); the per-line set-up (fp64 cos / sin, the
-// region's corner: 260 vector instructions per line) moved into k_keylines and read back with scalar loads (10.3 -> 11.1 ms); a clamp-free walk for support regions inside
+// region's corner: 260 vector instructions per line) moved into k_keylines and read back with scalar loads (10.3 -> 11.1 ms in round 5; the cos / sin alone moved there in round 6: no loss, kept); a clamp-free walk for support regions inside
 // the image (no gain, and its first form faulted on the steps past a line's end).
 constexpr int LBD_TB = 8;
 template <bool RPI>
 __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdPlan P, const sslam_keyline* __restrict__ kls,
                                             const int* __restrict__ counts, uint8_t* __restrict__ descOut, int cap) {
     constexpr int TB = LBD_TB, TN = TB, TP = TB + 1;            // TP: LDS pitch of a row's block (odd: lanes a row apart fall into different banks)
-    __shared__ unsigned tbuf[2][64 * TP];                       // [0]: byte offsets (row, step); [1]: gathered dwords
-    float (*rows)[64] = (float (*)[64])&tbuf[0][0];             // after the walk: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 per row (8 x 64 floats <= 2 x 64 x TP)
-    static_assert(8 * 64 <= 2 * 64 * TP, "rows[][] lies over the walk's two block arrays");
+    __shared__ unsigned tbuf[64 * TP];                          // a block's byte offsets (row, step), then its gathered dwords in their place
+    float (*rows)[64] = (float (*)[64])&tbuf[0];                // after the walk: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 per row
+    static_assert(8 * 64 <= 64 * TP, "rows[][] lies over the walk's block array");
     __shared__ float band[8][NUM_BANDS];
     __shared__ float des[72];
     const int li = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
         // one wave: its LDS operations execute in program order, so the phases need no barrier (and no wait for the gathers in flight, which __syncthreads would bring) --
         // only that the compiler keeps the order
         auto lds_order = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-        char* offB = (char*)&tbuf[0][0]; char* valB = (char*)&tbuf[1][0];
+        char* offB = (char*)&tbuf[0]; char* valB = offB;
         unsigned g[TN];
         auto offsets = [&]() {                              // the next TB steps of my row -> tbuf[0][lane][0 .. TB)
 #pragma unroll
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
                 auto rnd = [](float x) -> int { const int t = (int)__fadd_rn(x, x); return (t + 1) >> 1; };
                 const int xCor = RPI ? med3_0(cvt_rpi(sx), imageWidth) : min(max((int)(short)rnd(sx), 0), imageWidth);
                 const int yCor = RPI ? med3_0(cvt_rpi(sy), imageHeight) : min(max((int)(short)rnd(sy), 0), imageHeight);
-                tbuf[0][lane * TP + u] = (__umul24((unsigned)yCor, (unsigned)realWidth) + (unsigned)xCor) << 2;
+                tbuf[lane * TP + u] = (__umul24((unsigned)yCor, (unsigned)realWidth) + (unsigned)xCor) << 2;
                 sx = __fadd_rn(sx, dL0); sy = __fadd_rn(sy, dL1);
             }
         };
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
         auto consume = [&](int w0) {
             unsigned v[TN];
 #pragma unroll
-            for (int u = 0; u < TB; ++u) v[u] = tbuf[1][lane * TP + u];
+            for (int u = 0; u < TB; ++u) v[u] = tbuf[lane * TP + u];
             const bool whole = w0 + TB <= lengthOfLSP;
 #pragma unroll
             for (int u = 0; u < TB; ++u) {
@@ -374,14 +376,14 @@ __global__ __launch_bounds__(64) void k_lbd(const uint8_t* __restrict__ ws, LsdP
                 }
             }
         };
-        if (lengthOfLSP > 0) { offsets(); lds_order(); issue(); }
         for (int w0 = 0; w0 < lengthOfLSP; w0 += TB) {
-            const bool more = w0 + TB < lengthOfLSP;
-            lds_order();                                    // (the previous block's reads of tbuf[1], this block's reads of tbuf[0]: before they are overwritten)
-            if (more) offsets();
-            park();
+            lds_order();                                    // (the previous block's values are read: before they are overwritten)
+            offsets();
             lds_order();
-            if (more) issue();
+            issue();                                        // (all offsets are in registers before ...)
+            lds_order();
+            park();                                         // (... the values take their place)
+            lds_order();
             consume(w0);
         }
         __syncthreads();                                    // rows[][] lies over tbuf
