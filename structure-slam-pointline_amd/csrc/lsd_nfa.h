@@ -414,13 +414,16 @@ __device__ __forceinline__ void count_item(const NfaGeom& gIn, int lg, const uns
             }
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
-                const unsigned long long valid = vote(c0 + q < mine);
-                if (!valid) break;
+                const bool mineq = c0 + q < mine;
+                if (!vote(mineq)) break;
                 const float af = __uint_as_float(t_abs_u(a[q]));
-                const double dd = align_dist_min(af, theta);
-                const unsigned long long def = vote(af < 1000.f) & valid;       // NOTDEF is 1024 here, lanes without a pixel hold a NaN pattern (or, with 16-byte loads, somebody else's pixel)
+                // a slot that holds no pixel of this lane's run (NOTDEF is 1024 here; past the run: PIX_NONE or, with 16-byte loads, somebody else's pixel) gets the distance
+                // +inf ONCE -- one select on the upper half -- instead of a mask that every one of the six votes below is and-ed with: 13 + 27 -> 14 + 15 vector + scalar
+                // instructions per slot (round 6: the stage's time is the SUM of the two, 299 k + 239 k per frame x 4 cycles = its 12.5 ms)
+                const double d0 = align_dist_min(af, theta);
+                const double dd = __hiloint2double((mineq && af < 1000.f) ? __double2hiint(d0) : 0x7FF00000, __double2loint(d0));
 #pragma unroll
-                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(dd <= precs[k]) & def);
+                for (int k = 0; k < K; ++k) alg[k] += __popcll(vote(dd <= precs[k]));
             }
         }
     }
@@ -452,6 +455,7 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
         const int y = y0u + t;
         int xaj[MAXC], xbj[MAXC];
         int xa = 0x7fffffff, xb = -1;
+        unsigned wj[MAXC];                                              // xbj - xaj of a candidate's row; an empty row: xaj far to the right of every pixel, width 0
 #pragma unroll
         for (int j = 0; j < MAXC; ++j) {
             xaj[j] = 1; xbj[j] = 0;
@@ -461,6 +465,9 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
                 else { xaj[j] = 1; xbj[j] = 0; }
             }
             total[j] += sub == 0 ? xbj[j] - xaj[j] + 1 : 0;             // the candidate's pixels in this row (0 for an empty row: xaj = 1, xbj = 0)
+            const bool emptyRow = xbj[j] < xaj[j];
+            wj[j] = emptyRow ? 0u : (unsigned)(xbj[j] - xaj[j]);
+            if (emptyRow) xaj[j] = 0x40000000;
         }
         const int width = xb >= xa ? xb - xa + 1 : 0;
         const int share = (width + (1 << lg) - 1) >> lg;
@@ -482,14 +489,16 @@ __device__ __forceinline__ void count_rect5(const CntItem* __restrict__ it5, int
             }
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
-                const unsigned long long valid = vote(c0 + q < mine);
-                if (!valid) break;
+                const bool mineq = c0 + q < mine;
+                if (!vote(mineq)) break;
                 const float af = __uint_as_float(t_abs_u(a[q]));
-                const unsigned long long al = vote(align_dist_min(af, theta) <= prec) & vote(af < 1000.f) & valid;
-                const int x = xs + c0 + q;
+                // "aligned, defined, mine" moves the pixel's column to where no candidate's row reaches (one select) instead of masking each candidate's two votes; membership
+                // in candidate j's row [xaj, xbj] is ONE unsigned compare of x - xaj with the row's width
+                const bool al = mineq && af < 1000.f && align_dist_min(af, theta) <= prec;
+                const unsigned x = al ? (unsigned)(xs + c0 + q) : 0x80000000u;
 #pragma unroll
                 for (int j = 0; j < MAXC; ++j) {
-                    if (j < nc) alg[j] += __popcll(vote(x >= xaj[j]) & vote(x <= xbj[j]) & al);
+                    if (j < nc) alg[j] += __popcll(vote(x - (unsigned)xaj[j] <= wj[j]));
                 }
             }
         }
