@@ -32,6 +32,9 @@ int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long long* disag
  * mismatches_out[0] = divisions that differ, mismatches_out[1] = angles that differ. */
 int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long long mismatches_out[2]);
 
+/* k_lsd_hist_sort bins a pixel's |g|^2 (LSD's 1 024 gradient bins, opencv lsd.cpp ll_angle, reached from src/ExtractLineSegment.cpp:38-40) in fp32 where fp32 decides and with
+ * the reference's fp64 expression otherwise: every s in [0, max_s] (max_s = the frame's largest |g|^2, < 2^24) against the fp64 expression; *mismatches_out must be 0. */
+int sslam_selftest_lsd_bin(sslam_ctx* ctx, int max_s, long long* mismatches_out);
 /* k_lbd's walk rounds a coordinate with ONE conversion (v_cvt_rpi_i32_f32 = floor(x + 0.5)) where BinaryDescriptor::computeLBD has (short)round(x) under a clamp to the image
  * (OpenCV line_descriptor binary_descriptor.cpp, reached from src/ExtractLineSegment.cpp:53): every float bit pattern of the coordinate range, against the previous
  * instruction sequence under the clamps (mismatches_out[0]) and against roundf for x >= 0 (mismatches_out[1]).  Both must be 0. */

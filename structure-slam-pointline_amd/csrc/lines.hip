@@ -733,6 +733,21 @@ extern "C" int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long
     return SSLAM_OK;
 }
 
+extern "C" int sslam_selftest_lsd_bin(sslam_ctx* ctx, int max_s, long long* mismatches_out) {
+    if (!ctx || max_s < 0 || max_s >= (1 << 24) || !mismatches_out) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    ScopedDev dMem;
+    SSLAM_HIP(hipMalloc(&dMem.p, sizeof(unsigned long long)));
+    unsigned long long* d = (unsigned long long*)dMem.p;
+    SSLAM_HIP(hipMemset(d, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_selftest_lsd_bin, dim3(2048), dim3(256), 0, ctx->stream, max_s, d);
+    unsigned long long h = 0;
+    SSLAM_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SSLAM_HIP(hipStreamSynchronize(ctx->stream));
+    *mismatches_out = (long long)h;
+    return SSLAM_OK;
+}
+
 extern "C" int sslam_selftest_lbd_round(sslam_ctx* ctx, long long* mismatches_out) {
     if (!ctx || !mismatches_out) return SSLAM_ERR_INVALID;
     SSLAM_HIP(hipSetDevice(ctx->device));

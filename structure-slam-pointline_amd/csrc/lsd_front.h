@@ -481,6 +481,33 @@ __device__ __forceinline__ int lsd_bin(int s, double binCoef) {
 __device__ __forceinline__ double lsd_bin_coef(int maxS) {
     return maxS > 0 ? (double)(N_BINS - 1) / sqrt((double)maxS / 4.0) : 0.0;
 }
+// lsd_bin for a whole wave without the fp64 square root where fp32 decides: y = sqrt32(s) * (float)(binCoef / 2) is within 2.5e-4 of sqrt(s / 4) * binCoef (s < 2^24 is exact
+// in fp32; v_sqrt_f32 1 ulp, the coefficient's conversion and the product half an ulp each: 2.4e-7 relative of at most 1 023), the fp64 expression within 1e-9 of it -- so
+// floor(y) IS the bin unless y lies within 1e-3 of an integer (or at the clamp), and only then (about one slot in 500, one group of 64 in eight) the wave takes the exact
+// expression for the lanes concerned.  `have`: the lane holds an entry.  ~10 instead of ~30 vector instructions per entry and pass (k_lsd_hist_sort bins every entry twice).
+__device__ __forceinline__ int lsd_bin_wave(int s, bool have, double binCoef, float coef32) {
+    const float y = __builtin_amdgcn_sqrtf((float)s) * coef32;
+    const float fl = floorf(y), fr = y - fl;
+    int i = (int)fl;
+    const bool amb = have && !(fr >= 1e-3f && fr <= 0.999f && y < (float)(N_BINS - 2));
+    if (__builtin_amdgcn_ballot_w64(amb)) { if (amb) i = lsd_bin(s, binCoef); }
+    return i;
+}
+
+#ifdef SSLAM_TESTING
+// sslam_selftest_lsd_bin: lsd_bin_wave against lsd_bin for EVERY s in [0, maxS] (what a frame whose largest |g|^2 is maxS can hold)
+__global__ __launch_bounds__(256) void k_selftest_lsd_bin(int maxS, unsigned long long* __restrict__ bad) {
+    const double bc = lsd_bin_coef(maxS); const float bc32 = (float)(bc * 0.5);
+    unsigned long long nb = 0;
+    for (long long s0 = (long long)blockIdx.x * 256; s0 <= maxS; s0 += (long long)gridDim.x * 256) {
+        const long long s = s0 + threadIdx.x;
+        const bool have = s <= maxS;
+        const int a = lsd_bin_wave(have ? (int)s : 0, have, bc, bc32);
+        if (have && a != lsd_bin((int)s, bc)) ++nb;
+    }
+    if (nb) atomicAdd(bad, nb);
+}
+#endif
 
 // stable counting sort of the DEFINED pixels by descending bin, raster order inside a bin (D2): per-tile histograms -> scan -> stable
 // scatter.  A tile = P.tileRows whole rows = the consecutive segments [seg0, seg0 + nseg) of k_lsd_grad's lists; both kernels walk the
@@ -659,6 +686,7 @@ __global__ __launch_bounds__(64) void k_lsd_hist_sort(uint8_t* __restrict__ ws, 
     const int total = tile_segments((const int*)(base + P.offSegCnt), seg0, nseg, pref, lane);
     __syncthreads();
     const double bc = lsd_bin_coef(misc->maxS);
+    const float bc32 = (float)(bc * 0.5);
     int sgi = 0;
     for (int e0 = 0; e0 < total; e0 += 256) {            // pass 1: bin every entry and count (the entries stay as they are: pass 2 bins them again instead of reading back what this pass would have stored)
         unsigned ent[4]; bool have[4];
@@ -672,7 +700,11 @@ __global__ __launch_bounds__(64) void k_lsd_hist_sort(uint8_t* __restrict__ ws, 
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (have[k]) atomicAdd(&hist[lsd_bin((int)(ent[k] >> 8), bc)], 1);
+        for (int k = 0; k < 4; ++k) {
+            if (e0 + k * 64 >= total) break;             // wave-uniform
+            const int bin = lsd_bin_wave((int)(ent[k] >> 8), have[k], bc, bc32);
+            if (have[k]) atomicAdd(&hist[bin], 1);
+        }
     }
     __syncthreads();
     // the tile's histogram goes to the scan kernel; locally it becomes exclusive positions in DESCENDING bin order (the frame list's order): lane l owns bins 1023 - 16 l .. 1008 - 16 l
@@ -704,7 +736,7 @@ __global__ __launch_bounds__(64) void k_lsd_hist_sort(uint8_t* __restrict__ ws, 
         for (int k = 0; k < 4; ++k) {
             if (e0 + k * 64 >= total) break;             // wave-uniform
             const bool def = e0 + k * 64 + lane < total;
-            const int bin = lsd_bin((int)(ent[k] >> 8), bc);
+            const int bin = lsd_bin_wave((int)(ent[k] >> 8), def, bc, bc32);
             const unsigned long long peers = same_key10(bin, __ballot(def));
             if (def) {
                 const int rank = mbcnt(peers), pos = hist[bin] + rank;

@@ -92,6 +92,15 @@ def test_tail_test_selftest(fe, ctx):
     assert 0 < amb.value < 0.2 * n, amb.value        # half of the samples sit within 1e-3 of the boundary
 
 
+def test_lsd_bin_selftest(fe, ctx):
+    """k_lsd_hist_sort's fp32-guarded gradient bin against the fp64 expression for every |g|^2 of frames with several maxima (lsd_front.h, lsd_bin_wave)"""
+    import ctypes as C
+    for max_s in (0, 1, 7, 1023, 4096, 65025, 130050, 520200, 1040400, 2080800, 16777215):
+        bad = C.c_longlong(-1)
+        rc = fe.testing_lib().sslam_selftest_lsd_bin(ctx.h, max_s, C.byref(bad))
+        assert rc == 0 and bad.value == 0, (max_s, rc, bad.value)
+
+
 def test_lbd_rounding_selftest(fe, ctx):
     """k_lbd<true> rounds a walk coordinate with v_cvt_rpi_i32_f32 + a median where the reference has (short)round(x) under a clamp: every float bit pattern of the coordinate
     range, against the previous sequence under the clamps and against roundf for x >= 0 (lbd.h, k_selftest_lbd_round)"""
