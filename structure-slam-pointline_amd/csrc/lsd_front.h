@@ -669,6 +669,7 @@ __global__ __launch_bounds__(64) void k_lsd_scatter(uint8_t* __restrict__ ws, Ls
 // (it has the tile's histogram in LDS anyway): its scattered stores stay inside the tile's own 5 KB window, which the L2 absorbs.  A sorted entry is bin << 22 | y << 11 | x
 // (scaled images up to 2048 x 2048; larger ones keep k_lsd_hist + k_lsd_scatter).
 constexpr int SORT_XY_BITS = 11;
+constexpr int HSD = 12;      // groups of 64 entries loaded ahead per lane in both passes (2 / 4 / 8 / 12 / 16: 3.9 / 3.5 / 3.2 / 3.1 / 3.1 ms per 12 288 frames, GPU call AL: the wave waits for its loads)
 __global__ __launch_bounds__(64) void k_lsd_hist_sort(uint8_t* __restrict__ ws, LsdPlan P, int nframes) {
     __shared__ int hist[N_BINS];              // the tile's histogram, then its exclusive positions (descending bins) as the local cursors
     __shared__ int pref[MAX_TSEG + 1];
@@ -688,10 +689,10 @@ __global__ __launch_bounds__(64) void k_lsd_hist_sort(uint8_t* __restrict__ ws, 
     const double bc = lsd_bin_coef(misc->maxS);
     const float bc32 = (float)(bc * 0.5);
     int sgi = 0;
-    for (int e0 = 0; e0 < total; e0 += 256) {            // pass 1: bin every entry and count (the entries stay as they are: pass 2 bins them again instead of reading back what this pass would have stored)
-        unsigned ent[4]; bool have[4];
+    for (int e0 = 0; e0 < total; e0 += 64 * HSD) {            // pass 1: bin every entry and count (the entries stay as they are: pass 2 bins them again instead of reading back what this pass would have stored)
+        unsigned ent[HSD]; bool have[HSD];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < HSD; ++k) {
             const int e = e0 + k * 64 + lane;
             have[k] = e < total; ent[k] = 0;
             if (have[k]) {
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(64) void k_lsd_hist_sort(uint8_t* __restrict__ ws, 
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < HSD; ++k) {
             if (e0 + k * 64 >= total) break;             // wave-uniform
             const int bin = lsd_bin_wave((int)(ent[k] >> 8), have[k], bc, bc32);
             if (have[k]) atomicAdd(&hist[bin], 1);
@@ -720,10 +721,10 @@ __global__ __launch_bounds__(64) void k_lsd_hist_sort(uint8_t* __restrict__ ws, 
     __syncthreads();
     unsigned* out = sorted + ((size_t)seg0 << 8);        // the tile's block: as many slots as its segments have (>= total)
     sgi = 0;
-    for (int e0 = 0; e0 < total; e0 += 256) {            // pass 2: the tile's entries in raster order to their places in the tile-sorted block
-        unsigned ent[4], xy[4];
+    for (int e0 = 0; e0 < total; e0 += 64 * HSD) {            // pass 2: the tile's entries in raster order to their places in the tile-sorted block
+        unsigned ent[HSD], xy[HSD];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < HSD; ++k) {
             const int e = e0 + k * 64 + lane;
             ent[k] = 0; xy[k] = 0;
             if (e < total) {
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(64) void k_lsd_hist_sort(uint8_t* __restrict__ ws, 
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < HSD; ++k) {
             if (e0 + k * 64 >= total) break;             // wave-uniform
             const bool def = e0 + k * 64 + lane < total;
             const int bin = lsd_bin_wave((int)(ent[k] >> 8), def, bc, bc32);
@@ -748,6 +749,7 @@ __global__ __launch_bounds__(64) void k_lsd_hist_sort(uint8_t* __restrict__ ws, 
 }
 
 // The scatter over tile-sorted runs: lanes of one run hold one bin, their rank is their distance from the run's first lane, and they store to consecutive dwords.
+constexpr int SRD = 4;       // (8 / 16 groups ahead: no change, 1.9 ms)
 __global__ __launch_bounds__(64) void k_lsd_scatter_runs(uint8_t* __restrict__ ws, LsdPlan P, int nframes) {
     __shared__ int cursor[N_BINS];
     int tile, b; const int lane = threadIdx.x;
@@ -764,12 +766,12 @@ __global__ __launch_bounds__(64) void k_lsd_scatter_runs(uint8_t* __restrict__ w
     const unsigned* in = (const unsigned*)(base + P.offSorted) + ((size_t)seg0 << 8);
     __syncthreads();
     constexpr unsigned XYM = (1u << SORT_XY_BITS) - 1;
-    for (int e0 = 0; e0 < total; e0 += 256) {
-        unsigned v[4];
+    for (int e0 = 0; e0 < total; e0 += 64 * SRD) {
+        unsigned v[SRD];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const int e = e0 + k * 64 + lane; v[k] = e < total ? in[e] : 0xFFFFFFFFu; }
+        for (int k = 0; k < SRD; ++k) { const int e = e0 + k * 64 + lane; v[k] = e < total ? in[e] : 0xFFFFFFFFu; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SRD; ++k) {
             if (e0 + k * 64 >= total) break;             // wave-uniform
             const bool def = e0 + k * 64 + lane < total;
             const int bin = (int)(v[k] >> (2 * SORT_XY_BITS));
