@@ -388,7 +388,7 @@ int sslam_lines_batch_status_dev(sslam_lines* ln, int cap, int32_t* d_status4, v
  * and leaves issue slots free, the kernels in front of it are bandwidth-bound and do not: a second stream that waits for the event overlaps
  * the core instead of the prologue.  The event stays the caller's. */
 int sslam_lines_set_core_event(sslam_lines* ln, void* hip_event);
-/* With a core event set, a batch of at least 32 frames per compute unit (two rounds of 16 workgroups per CU) runs the sequential core in its GUEST form: a persistent grid of four-wave workgroups that
+/* With a core event set, a batch of at least 32 frames per compute unit (two rounds of 16 workgroups per CU; 18 per CU from 36 frames per compute unit on) runs the sequential core in its GUEST form: a persistent grid of four-wave workgroups that
  * claim frames dynamically and leave a third of every SIMD's registers to the caller's second stream.  Returns 1 when a call of `nframes` frames
  * would take that form, 0 otherwise.  A caller in the guest form gets the most from building the ORB pyramid BEFORE the event (sslam_orb_set_gate_event: FAST and
  * what follows wait for it) -- in the other form from making its whole second branch wait for the event (bench.py / pipeline.py / sslam_frontend_batch do exactly that). */

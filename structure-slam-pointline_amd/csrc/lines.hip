@@ -291,9 +291,12 @@ static int lines_host_seed_order(sslam_lines* L, uint8_t* ws, int nframes, hipSt
 }
 
 // Whether a batch of `nframes` runs the sequential core in its guest form (lsd_regions.h): a co-running branch was announced (sslam_lines_set_core_event) and the batch is
-// at least two rounds of the persistent grid of 16 workgroups per compute unit.
+// at least two rounds of the persistent grid of 18 (16 for smaller batches) workgroups per compute unit.  18: two SIMDs of a compute unit hold five core waves and keep 32
+// registers free, two hold four and keep 128 -- since k_fast_cells needs 29 registers (round 6, call AQ) its waves fit into either, and the core's fifth wave on half of the
+// SIMDs pays: 151.3 -> 149.3 ms per step (with the 51-register FAST: 153.2).  17 / 19 / 20 per compute unit: 150.8 / 149.4 / 150.0.
 static bool lines_guest_form(const sslam_lines* L, int nframes, int* grid_out) {
-    int grid = 16 * L->ctx->num_cus;
+    int grid = 18 * L->ctx->num_cus;
+    if (2 * grid > nframes) grid = 16 * L->ctx->num_cus;
     bool guest = L->coreEvent != nullptr;
     if (const char* e = getenv("SSLAM_LSD_GUEST")) guest = atoi(e) != 0;
     if (const char* e = getenv("SSLAM_LSD_PERSIST")) { const int g = atoi(e) & ~7; if (g >= 8) grid = g; }
@@ -506,7 +509,7 @@ extern "C" int sslam_lines_extract_batch_dev(sslam_lines* L, const uint8_t* d_im
             else hipLaunchKernelGGL((k_lsd_regions<true, 6>), dim3(nframes), dim3(64), lds, st, ws, P, L->dLgam.as<double>(), nframes);
         } else {
             // A caller that announced a branch running beside the core (sslam_lines_set_core_event: the bench step's point branch waits for that event) gets the GUEST form
-            // (lsd_regions.h): 16 persistent workgroups per compute unit of the four-wave instantiation, a third of the registers free for the other branch's waves.
+            // (lsd_regions.h): 16 - 18 persistent workgroups per compute unit of the four-wave instantiation, a third of the registers free for the other branch's waves.
             // SSLAM_LSD_GUEST=0 / 1 overrides (A/B), SSLAM_LSD_PERSIST=g sets the grid.  (LBD's blur + Sobel as one more guest under the core, on the side stream, was
             // measured too: its 126-VGPR waves take the slots FAST needs -- 167.7 ms per step against 160.8 with the kernel in the tail; profiles/r06d_*.)
             int grid = 0;

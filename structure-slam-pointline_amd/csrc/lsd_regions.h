@@ -699,7 +699,7 @@ __device__ __forceinline__ void lsd_regions_body(uint8_t* __restrict__ ws, const
 
 // MW = waves per SIMD the register allocator leaves room for:
 //   6  (80 VGPRs, 11 dwords spilled): every wave slot the register file has -- the fastest form when the core has the chip to itself (77.8 ms per 12 288 frames; 5 and 4: 86 / 85)
-//   4  (97 VGPRs, nothing spilled), launched as a PERSISTENT grid of 16 workgroups per compute unit that claim frames dynamically: a third of every SIMD's registers
+//   4  (97 VGPRs, nothing spilled), launched as a PERSISTENT grid of 16 - 18 workgroups per compute unit (lines.hip, lines_guest_form) that claim frames dynamically: a third of every SIMD's registers
 //      stays free, so the kernels of another branch (the point branch of the bench step) are co-resident from the first millisecond instead of waiting for core waves to
 //      retire -- lines.hip picks it when the caller announced such a branch (sslam_lines_set_core_event); profiles/r06c_*: 160.5 ms per step against 167.5
 template <bool LAT, int MW>

@@ -208,31 +208,37 @@ __device__ __forceinline__ int fast_score16(const uint8_t* c, int tp, int minTh)
     // have to share two ring positions, so at most one polarity can reach a score >= minTh >= 1: the lane picks the polarity its pair
     // test left open (d = v - r for a darker ring, r - v for a brighter one) and runs ONE max-of-arc-minimum network instead of the two
     // of cv::cornerScore; the rare pixel that passed both pair tests runs the network a second time with the other sign.
-    int best = 0;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        const bool on = pass == 0 ? true : (cb && cd);
-        if (__builtin_amdgcn_ballot_w64(on) == 0) break;
-        const bool dark = pass == 0 ? cd : false;               // pass 0: darker ring if that test passed, else brighter; pass 1: the brighter one
-        // d = signed contrast in the chosen polarity; the minimum over a 9-arc is a min3 of three min3's (v_min3_i32), the maximum over the
-        // sixteen arcs a max3 tree: 40 instructions instead of the 80 of a doubling network
-        // brighter ring: d = r - v.  Darker ring: ~(r - v) = (v - r) - 1 -- a bitwise NOT reverses the order like a negation does, costs one
-        // xor per element instead of a negate + select, and the constant 1 comes back after the network
-        const int sg = dark ? -1 : 0;
-        int d[16];
+    // d = signed contrast in the chosen polarity; the minimum over a 9-arc is a min3 of three min3's (v_min3_i32), the maximum over the sixteen arcs a max3 tree.
+    // brighter ring: d = r - v.  Darker ring: ~(r - v) = (v - r) - 1 -- a bitwise NOT reverses the order like a negation does, costs one xor per element instead of a
+    // negate + select, and the constant 1 comes back after the network.  The network works IN PLACE: m3[k] = min(d[k], d[k+1], d[k+2]) overwrites d[k] (d[0], d[1] kept
+    // for the wrap-around), m9[k] = min(m3[k], m3[k+3], m3[k+6]) goes straight into the running maximum -- sixteen live values instead of forty-eight; and the ring itself
+    // dies with the first evaluation (the rare second one reads it again): once the staging loop no longer set the kernel's register count the network did, and that count
+    // decides how many of the kernel's waves fit beside the sequential LSD core in its guest form.
+    auto network = [&](int (&d)[16], int sg) -> int {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = (r[k] - v) ^ sg;
-        int m3[16];
+        for (int k = 0; k < 16; ++k) d[k] = (d[k] - v) ^ sg;
+        const int d0 = d[0], d1 = d[1];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) m3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-        int m9[16];
+        for (int k = 0; k < 14; ++k) d[k] = min(min(d[k], d[k + 1]), d[k + 2]);
+        d[14] = min(min(d[14], d[15]), d0);
+        d[15] = min(min(d[15], d0), d1);
+        int A = min(min(d[0], d[3]), d[6]);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) m9[k] = min(min(m3[k], m3[(k + 3) & 15]), m3[(k + 6) & 15]);
-        int A = max(max(m9[0], m9[1]), m9[2]);
-#pragma unroll
-        for (int k = 3; k < 15; k += 2) A = max(max(A, m9[k]), m9[k + 1]);
-        A = max(A, m9[15]);
-        if (on) best = max(best, A - sg);      // + 1 for the darker polarity (see above)
+        for (int k = 1; k < 16; ++k) A = max(A, min(min(d[k], d[(k + 3) & 15]), d[(k + 6) & 15]));
+        return A - sg;                                       // + 1 for the darker polarity (see above)
+    };
+    int best = max(0, network(r, cd ? -1 : 0));             // the darker ring if that test passed, else the brighter one
+    const bool both = cb && cd;
+    if (__builtin_amdgcn_ballot_w64(both)) {                // rare: the brighter ring as well
+        const uint8_t* c2 = c;
+        asm volatile("" : "+v"(c2));                        // (read again: the first evaluation consumed the ring in place)
+        int q[16];
+        q[0] = c2[3 * tp];      q[1] = c2[3 * tp + 1];   q[2] = c2[2 * tp + 2];   q[3] = c2[tp + 3];
+        q[4] = c2[3];           q[5] = c2[-tp + 3];      q[6] = c2[-2 * tp + 2];  q[7] = c2[-3 * tp + 1];
+        q[8] = c2[-3 * tp];     q[9] = c2[-3 * tp - 1];  q[10] = c2[-2 * tp - 2]; q[11] = c2[-tp - 3];
+        q[12] = c2[-3];         q[13] = c2[tp - 3];      q[14] = c2[2 * tp - 2];  q[15] = c2[3 * tp - 1];
+        const int b2 = network(q, 0);
+        if (both) best = max(best, b2);
     }
     int s = best - 1;
     return s >= minTh ? s : 0;
@@ -268,9 +274,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     // row pitch is a multiple of 4, so the aligned dwords stay inside the row
     const int ax = (ci.x0 - 3) & ~3, off = (ci.x0 - 3) - ax;
     const int ndw = (off + cw + 6 + 3) >> 2, th = ch + 6;
-    for (int ry = lane >> 4; ry < th; ry += 4) {
-        const uint8_t* srow = img + (size_t)(ci.y0 - 3 + ry) * pitch + ax;
-        for (int q = lane & 15; q < ndw; q += 16) ((unsigned*)(tile + ry * tileP))[q] = ((const unsigned*)srow)[q];
+    {   // buffer loads: the tile's first byte in a scalar resource descriptor, ONE 32-bit offset register per load (the loop's sixteen loads in flight with 64-bit addresses
+        // set the kernel's register count: 51 -> how many of its waves fit beside the sequential LSD core in its guest form)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (size_t)(ci.y0 - 3) * pitch + ax), 0, 0x7FFFFFFF, 0x00020000);
+        const int q0 = lane & 15;
+        for (int ry = lane >> 4; ry < th; ry += 4) {
+            const int rowOff = __mul24(ry, pitch);
+            for (int q = q0; q < ndw; q += 16) ((unsigned*)(tile + ry * tileP))[q] = __builtin_amdgcn_raw_buffer_load_b32(rs, rowOff + 4 * q, 0, 0);
+        }
     }
     for (int i = lane; i < (((ch + 2) * scP + 3) >> 2); i += 64) ((unsigned*)sc)[i] = 0;
     __syncthreads();
