@@ -32,6 +32,9 @@ int sslam_selftest_tail_test(sslam_ctx* ctx, long long samples, long long* disag
  * mismatches_out[0] = divisions that differ, mismatches_out[1] = angles that differ. */
 int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long long mismatches_out[2]);
 
+/* k_describe steers the rBRIEF pattern with (float)cos / (float)sin of the keypoint angle evaluated in double (src/ORBextractor.cc:108-147 computeOrbDescriptor) through a
+ * reduction of its own for [0, 6.5] instead of the library's sincos: every float of the range, both results after the rounding to float; *mismatches_out must be 0. */
+int sslam_selftest_sincos(sslam_ctx* ctx, long long* mismatches_out);
 /* k_lsd_hist_sort bins a pixel's |g|^2 (LSD's 1 024 gradient bins, opencv lsd.cpp ll_angle, reached from src/ExtractLineSegment.cpp:38-40) in fp32 where fp32 decides and with
  * the reference's fp64 expression otherwise: every s in [0, max_s] (max_s = the frame's largest |g|^2, < 2^24) against the fp64 expression; *mismatches_out must be 0. */
 int sslam_selftest_lsd_bin(sslam_ctx* ctx, int max_s, long long* mismatches_out);

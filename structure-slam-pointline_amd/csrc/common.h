@@ -245,5 +245,40 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // cvRound(float): round half to even
 __device__ __forceinline__ int cv_roundf(float v) { return __float2int_rn(v); }
 
+// sin and cos of x in [0, 6.5] in double, for k_describe's steering angle (a float: the keypoint's angle in degrees times pi / 180).  The library's sincos carries the argument
+// reduction for every magnitude and cost ~150 of the kernel's ~700 vector instructions per keypoint (all 64 lanes of the keypoint's wave evaluate the same value) and its
+// highest register count; here: quadrant by one multiply (k = 0 .. 4), two-term Cody-Waite reduction (k * pi/2 is exact inside the FMA: k has three bits, the head 53), the fdlibm
+// kernels on [-pi/4, pi/4].  sslam_selftest_sincos compares (float)sin, (float)cos with the library's for EVERY float in the range: what k_describe consumes is identical.
+__device__ __forceinline__ void sincos_0_2pi(double x, double& sn, double& cs) {
+    const int k = (int)__builtin_fma(x, 0.63661977236758134308, 0.5);                  // round(x * 2 / pi): x >= 0
+    const double kd = (double)k;
+    double r = __builtin_fma(-kd, 1.57079632679489655800e+00, x);                       // pi/2 head
+    r = __builtin_fma(-kd, 6.12323399573676603587e-17, r);                              // pi/2 tail
+    const double z = r * r;
+    // __kernel_sin(r, 0)
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double sr = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double s = r + (z * r) * (S1 + z * sr);
+    // __kernel_cos(r, 0)
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double cr = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double ar = fabs(r);
+    double c;
+    if (ar < 0.3) c = 1.0 - (0.5 * z - z * cr);
+    else {
+        const double qx = ar > 0.78125 ? 0.28125 : __hiloint2double(__double2hiint(ar) - 0x00200000, 0);      // |r| / 4, truncated
+        const double hz = 0.5 * z - qx, a = 1.0 - qx;
+        c = a - (hz - z * cr);
+    }
+    switch (k & 3) {
+        case 0: sn = s; cs = c; break;
+        case 1: sn = c; cs = -s; break;
+        case 2: sn = -s; cs = -c; break;
+        default: sn = -c; cs = s; break;
+    }
+}
+
 }  // namespace sslam
 #endif

@@ -736,6 +736,38 @@ extern "C" int sslam_selftest_region_div(sslam_ctx* ctx, long long samples, long
     return SSLAM_OK;
 }
 
+// sslam_selftest_sincos: sincos_0_2pi (common.h) against the library's sincos after the rounding to float, for every float in [0, 6.5]
+namespace {
+__global__ __launch_bounds__(256) void k_selftest_sincos(unsigned long long* __restrict__ bad) {
+    unsigned long long nb = 0;
+    const unsigned base = (blockIdx.x * 256u + threadIdx.x) << 6;
+    for (unsigned i = 0; i < 64u; ++i) {
+        const unsigned bits = base + i;
+        if (bits > 0x40D00000u) break;                  // 6.5f
+        const float x = __uint_as_float(bits);
+        double s0, c0, s1, c1;
+        sincos((double)x, &s0, &c0); sslam::sincos_0_2pi((double)x, s1, c1);
+        if (__float_as_uint((float)s0) != __float_as_uint((float)s1) || __float_as_uint((float)c0) != __float_as_uint((float)c1)) ++nb;
+    }
+    if (nb) atomicAdd(bad, nb);
+}
+}
+extern "C" int sslam_selftest_sincos(sslam_ctx* ctx, long long* mismatches_out) {
+    if (!ctx || !mismatches_out) return SSLAM_ERR_INVALID;
+    SSLAM_HIP(hipSetDevice(ctx->device));
+    ScopedDev dMem;
+    SSLAM_HIP(hipMalloc(&dMem.p, sizeof(unsigned long long)));
+    unsigned long long* d = (unsigned long long*)dMem.p;
+    SSLAM_HIP(hipMemset(d, 0, sizeof(unsigned long long)));
+    const unsigned nthreads = (0x40D00000u >> 6) + 1;
+    hipLaunchKernelGGL(k_selftest_sincos, dim3((nthreads + 255) / 256), dim3(256), 0, ctx->stream, d);
+    unsigned long long h = 0;
+    SSLAM_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SSLAM_HIP(hipStreamSynchronize(ctx->stream));
+    *mismatches_out = (long long)h;
+    return SSLAM_OK;
+}
+
 extern "C" int sslam_selftest_lsd_bin(sslam_ctx* ctx, int max_s, long long* mismatches_out) {
     if (!ctx || max_s < 0 || max_s >= (1 << 24) || !mismatches_out) return SSLAM_ERR_INVALID;
     SSLAM_HIP(hipSetDevice(ctx->device));

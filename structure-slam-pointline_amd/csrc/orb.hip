@@ -845,7 +845,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ pyr
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
     double snD, csD;
-    sincos((double)ang, &snD, &csD);                                           // D5: one argument reduction for both
+    sincos_0_2pi((double)ang, snD, csD);                                       // D5 (common.h: identical to the library's after the rounding to float, for every float argument)
     const float a = (float)csD, bsn = (float)snD;
     unsigned nib = 0;
 #pragma unroll

@@ -92,3 +92,11 @@ def test_orb_scale_factors(fe, ctx, oracle, scale, nlevels):
     8-byte window) and 3.4 (they are not: the byte path).  Every level's bytes, the candidates and the keypoints against the oracle; odd and even sizes."""
     for img in (synth_frame(77, w=640, h=480), synth_frame(78, w=333, h=251)):
         _cmp_orb(fe, ctx, oracle, img, 800, nlevels, scale)
+
+
+def test_sincos_selftest(fe, ctx):
+    """k_describe's own double sin / cos on [0, 6.5] (common.h, sincos_0_2pi) against the library's sincos after the rounding to float, for every float of the range"""
+    import ctypes as C
+    bad = C.c_longlong(-1)
+    rc = fe.testing_lib().sslam_selftest_sincos(ctx.h, C.byref(bad))
+    assert rc == 0 and bad.value == 0, (rc, bad.value)
